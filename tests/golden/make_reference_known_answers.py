@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Known answers held by the reference's own gtest suites for the simulation path.
+
+Each entry is DATA (inputs + expected outputs) transcribed from the cited test of
+/root/reference (schmeing/ReSeq v1.1); `reference-test.fa` next to this file is the
+data file those tests read (reference/test/reference-test.fa).  Running this script
+rewrites reference_known_answers.json; tests/test_oracle_pinning.py checks the
+oracle against it.
+"""
+import json
+import math
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+ka = {}
+
+# reseq/SurroundingTest.cpp:42-120  (Forward/Reverse surroundings of test/reference-test.fa)
+ka["surrounding_forward"] = [     # [seq, pos, [block0, block1, block2]]
+    [0, 0, [83, 163795, 909796]],
+    [0, 1, [332, 655183, 493456]],
+    [0, 2, [1330, 523581, 925249]],
+    [0, 15, [1003384, 495722, 275383]],
+    [0, 497, [1015809, 313855, 325511]],
+    [0, 498, [917509, 206845, 253470]],
+    [0, 499, [524308, 827380, 1013881]],
+    [1, 17, [500825, 144533, 54422]],
+]
+# SurroundingTest.cpp:69-97: Forward(pos0) followed by UpdateForward(new positions) -> expected after each update
+ka["surrounding_update_forward"] = [   # [seq, set_pos, [update positions], [expected per update]]
+    [0, 0, [1, 2], [[332, 655183, 493456], [1330, 523581, 925249]]],
+    [0, 14, [15], [[1003384, 495722, 275383]]],
+    [0, 496, [497, 498, 499], [[1015809, 313855, 325511], [917509, 206845, 253470], [524308, 827380, 1013881]]],
+    [1, 16, [17], [[500825, 144533, 54422]]],
+]
+# SurroundingTest.cpp:99-148
+ka["surrounding_reverse"] = [
+    [0, 0, [57353, 846847, 855350]],
+    [0, 1, [538626, 473855, 1000269]],
+    [0, 2, [134656, 642751, 1036499]],
+    [0, 15, [613348, 739384, 10042]],
+    [0, 497, [524915, 720884, 216468]],
+    [0, 498, [917660, 966653, 54117]],
+    [0, 499, [229415, 241663, 275673]],
+    [1, 17, [960397, 945044, 626906]],
+]
+# SurroundingTest.cpp:150-198 (UpdateReverse parts only; RollBackReverse is not on the simulation path)
+ka["surrounding_update_reverse"] = [
+    [0, 0, [1, 2], [[538626, 473855, 1000269], [134656, 642751, 1036499]]],
+    [0, 14, [15], [[613348, 739384, 10042]]],
+    [0, 496, [497, 498, 499], [[524915, 720884, 216468], [917660, 966653, 54117], [229415, 241663, 275673]]],
+]
+
+# SurroundingTest.cpp:541-568 TestCombiningBias
+sep = [0.0] * 120
+for block in (0, 40, 80):
+    sep[block + 0] = 0.9
+    for i in (5, 10, 15, 19, 22, 25, 28, 35, 36):
+        sep[block + i] = 1.0
+    sep[block + 21] = 0.8
+ka["combine_positions"] = {"separated": sep, "expect": [[114252, 9.9], [113996, 9.7]]}   # same for all three blocks
+
+# SurroundingTest.cpp:570-640 TestSeparatingBias
+comb = [
+    [0, 954112, 1500], [0, 771557, 192], [0, 756483, 3200], [0, 594450, 2000], [0, 258785, 192],
+    [1, 8941, 1500], [1, 756483, 192], [1, 787452, 6400], [1, 196668, 2000], [1, 461635, 192],
+    [2, 930377, 1500], [2, 787452, 192], [2, 1017802, 3200], [2, 297745, 2000], [2, 4080, 192],
+    [0, 649012, 1500], [0, 787452, 192], [0, 377552, 3200], [0, 766430, 2000], [0, 983295, 192],
+    [1, 542591, 1500], [1, 258513, 192], [1, 802803, 2000], [1, 254450, 192],
+    [2, 1044692, 1500], [2, 674497, 192], [2, 258513, 3200], [2, 505785, 2000], [2, 739075, 192],
+]
+norm = (1 << 20) // 4
+exp = {}
+mean = (192 + 3200 + 192 + 3200 + 2000 + 1500 + 2000 + 1500 + 192 + 192) / 4.0
+exp[0] = (192 - mean) / norm
+exp[1] = (3200 - mean) / norm
+exp[2] = (192 + 3200 + 2000 + 1500 + 2000 - mean) / norm
+exp[3] = (1500 + 192 + 192 - mean) / norm
+mean = (1500 + 1500 + 192 + 3200 + 192 + 192 + 2000 + 2000 + 3200 + 192) / 4.0
+exp[36] = (1500 + 1500 + 192 + 3200 - mean) / norm
+exp[37] = (192 + 192 - mean) / norm
+exp[38] = (2000 + 2000 - mean) / norm
+exp[39] = (3200 + 192 - mean) / norm
+mean = (1500 + 2000 + 192 + 192 + 192 + 192 + 1500 + 2 * 3200 + 2000) / 4.0
+exp[40] = (1500 + 2000 + 192 + 192 - mean) / norm
+exp[41] = (192 - mean) / norm
+exp[42] = (192 + 1500 - mean) / norm
+exp[43] = (2 * 3200 + 2000 - mean) / norm
+mean = (2 * 3200 + 2000 + 1500 + 192 + 192 + 192 + 192 + 1500 + 2000) / 4.0
+exp[76] = (2 * 3200 + 2000 - mean) / norm
+exp[77] = (1500 + 192 - mean) / norm
+exp[78] = (192 - mean) / norm
+exp[79] = (192 + 192 + 1500 + 2000 - mean) / norm
+mean = (192 + 3200 + 2000 + 2000 + 192 + 192 + 1500 + 192 + 3200 + 1500) / 4.0
+exp[80] = (192 + 3200 - mean) / norm
+exp[81] = (2000 + 2000 - mean) / norm
+exp[82] = (192 + 192 - mean) / norm
+exp[83] = (1500 + 192 + 3200 + 1500 - mean) / norm
+mean = (192 + 192 + 1500 + 1500 + 2000 + 192 + 3200 + 2000 + 3200 + 192) / 4.0
+exp[116] = (192 + 192 + 1500 - mean) / norm
+exp[117] = (1500 + 2000 + 192 + 3200 + 2000 - mean) / norm
+exp[118] = (3200 - mean) / norm
+exp[119] = (192 - mean) / norm
+ka["separate_positions"] = {"combined": comb, "expect": [[k, v] for k, v in sorted(exp.items())]}
+
+# FragmentDistributionStatsTest.cpp:783-795  DrawNumberNonZeroStrands(num_possible_alleles, zero_probability, u)
+ka["draw_number_non_zero_strands"] = [
+    [1, 0.75, 0.5624, 0], [1, 0.75, 0.5626, 1], [1, 0.75, 0.9374, 1], [1, 0.75, 0.9376, 2], [1, 0.75, 1.0 - 1e-15, 2],
+    [2, 0.75, 0.31640, 0], [2, 0.75, 0.31641, 1], [2, 0.75, 0.99609, 3], [2, 0.75, 0.99610, 4], [2, 0.75, 1.0 - 1e-15, 4],
+]
+
+# FragmentDistributionStatsTest.cpp:797-849 + :208-228 CheckDrawnCounts
+ka["fragment_counts"] = {
+    "ref_seq_bias": 0.5, "insert_length": 367, "insert_length_bias": 0.5, "gc": 43,
+    "start_sur": [873425, 34, 7467], "end_sur": [364, 856687, 34562],
+    "sur_fill": -1000.0,
+    "sur_entries": [[0, 873425, -0.3], [1, 34, -0.7], [2, 7467, -math.log(3) + 1.0],
+                    [0, 364, -math.log(3) + 1.0], [1, 856687, -0.7], [2, 34562, -0.3]],
+    "bias_normalization": 0.2, "other_bias_negation": 2.0 * 2.0 * 2.0 * 2.0 * 5.0, "delta": 0.000001,
+    "cases": [   # dispersion parameters, bias, CDF gates (R ppois / pnbinom)
+        [[0.0, 1e-100], 1.0, [0.3678794, 0.7357589, 0.9196986, 0.9810118, 0.9963402, 0.9994058]],
+        [[0.0, 1e-100], 0.5, [0.6065307, 0.9097960, 0.9856123, 0.9982484, 0.9998279, 0.9999858]],
+        [[0.0, 1e-100], 0.1, [0.9048374, 0.9953212, 0.9998453, 0.9999962]],
+        [[0.0, 5.0], 1.0, [0.6988271, 0.8152983, 0.8735339, 0.9091223, 0.9328479, 0.9494559]],
+        [[0.0, 5.0], 0.5, [0.7783705, 0.8895663, 0.9372217, 0.9621840, 0.9764482, 0.9850067]],
+        [[0.0, 5.0], 0.1, [0.9221079, 0.9835818, 0.9958765, 0.9988819, 0.9996834, 0.9999078]],
+        [[5000.0, 10000.0], 1.0, [0.9993591, 0.9994258, 0.9994591, 0.9994813, 0.9994979, 0.9995113]],
+        [[5000.0, 10000.0], 0.5, [0.9995396, 0.9995896, 0.9996145, 0.9996312, 0.9996437, 0.9996537]],
+        [[5000.0, 10000.0], 0.1, [0.9998550, 0.9998717, 0.9998800, 0.9998856, 0.9998897, 0.9998931]],
+    ],
+}
+# SURVEY.md section 8(c) probe values of the reference binary (NegativeBinomial, Binomial, GetDispersion)
+ka["survey_probe"] = {"negative_binomial": [0.3, 2.5, 0.9, 3], "binomial": [4, 0.25, 0.8, 2],
+                      "get_dispersion": [1.7, 0.1, 0.2, 3.8636363636363629]}
+
+# SimulatorTest.cpp:63-85 TestCoverageConversion
+ka["coverage_conversion"] = {
+    "rl_by_fl": [[1, 200, 150, 10], [0, 150, 150, 10], [1, 100, 150, 5], [1, 50, 150, 10], [0, 0, 150, 10]],   # seg, frag_len, read_len, count
+    "non_mapped": [[1, 50, 150, 5]],
+    "adapter_part": 3000.0 / (45 * 150),
+    "coverage": 100.0, "total_ref_size": 50000, "average_read_length": 150.0, "total_pairs": 30000,
+}
+# SimulatorTest.cpp:87-114 TestSelectAllele: repeated SelectAllele(..., possible_strands, 0.5)
+ka["select_allele"] = [[2, 0.5, [1, 0]], [4, 0.5, [2, 1, 3, 0]]]
+
+# utilitiesTest.cpp:30-60,96-110 DominantBase on "CAGATTTTGGAANAGTNN" and its reverse complement
+ka["dominant_base"] = {
+    "seq": "CAGATTTTGGAANAGTNN",
+    "set_0_1_2": [1, 1, 0],
+    "set_from_3": [2, 0, 0, 3, 3, 3, 3, 3, 2, 0, 0, 0, 0, 0, 3],
+    "revcomp_set_0_1_2": [0, 0, 0],
+    "revcomp_set_from_3": [0, 1, 3, 3, 3, 3, 3, 1, 1, 0, 0, 0, 0, 0, 3],
+}
+# utilitiesTest.cpp:152-160,185-192
+ka["divide"] = [[0, 2, 0], [17438564308265206, 17438564308265206, 1], [73500, 7000, 11], [73400, 7000, 10]]
+ka["percent"] = [[0, 2, 0], [17438564308265206, 17438564308265206, 100], [735, 7000, 11], [734, 7000, 10]]
+ka["safe_percent_zero_den"] = [734, 0, 50]
+
+# ReferenceTest.cpp:275-284 (sequence lengths, ReferenceSequence forward / reversed, no variants)
+ka["reference_sequence"] = {"lengths": [500, 501],
+                            "cases": [[0, 0, 10, False, "AGCTTTTCAT"], [0, 500, 10, True, "ATGGTTTTTT"]]}
+# ReferenceTest.cpp:339-345
+ka["gc_content"] = [[0, 0, 7, 2, 29], [1, 22, 27, 4, 80]]      # seq, start, end, absolute, percent
+# ReferenceTest.cpp:367-443 TestSumBias: gc_bias by percent, surrounding bias entries (everything else -1000)
+ka["sum_bias"] = {
+    "seq": 0, "fragment_length": 10, "general_bias": 0.5,
+    "gc_bias": [[30, 0.1], [40, 0.3], [0, 1.0], [90, 0.2]],
+    "sur_fill": -1000.0,
+    "sur_entries": [
+        [0, 591524, 0.0], [0, 954112, 0.0], [0, 771557, 0.0], [0, 756483, 0.0], [0, 594450, -1.0], [0, 332464, 0.0], [0, 258785, 0.5],
+        [1, 211831, 0.0], [1, 8941, 0.0], [1, 756483, 0.0], [1, 787452, 0.5], [1, 196668, 0.0], [1, 440745, 0.0], [1, 461635, 0.0],
+        [2, 768572, 0.0], [2, 930377, 0.0], [2, 787452, 0.5], [2, 1017802, 0.0], [2, 297745, 0.0], [2, 924081, 0.0], [2, 4080, -0.5],
+        [0, 800017, 0.0], [0, 649012, 0.0], [0, 787452, 0.5], [0, 377552, 0.0], [0, 766430, 0.0], [0, 727476, 0.0], [0, 983295, 0.0],
+        [1, 139571, 0.0], [1, 542591, 0.0], [1, 258513, 0.0], [1, 802803, 0.0], [1, 612630, 0.0], [1, 254450, 0.0],
+        [2, 939769, 0.0], [2, 1044692, 0.0], [2, 674497, -0.5], [2, 258513, 0.0], [2, 505785, 0.0], [2, 989114, 0.0], [2, 739075, 0.5],
+    ],
+    "twice_sum": 2.9367, "twice_sum_tol": 0.0001, "max_bias": 0.774915, "max_bias_tol": 0.00001,
+}
+
+with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
+    json.dump(ka, f, indent=1)
+print("wrote", len(ka), "groups")

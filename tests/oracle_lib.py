@@ -1,0 +1,274 @@
+"""ctypes access to oracle/liboracle.so -- the CPU checker (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+
+
+class Fragment(C.Structure):
+    _fields_ = [("seq", C.c_uint32), ("start", C.c_uint32), ("len", C.c_uint32), ("dup", C.c_uint16),
+                ("strand", C.c_uint8), ("pad", C.c_uint8), ("block", C.c_uint32), ("number", C.c_uint32)]
+
+
+FRAGMENT_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("dup", "<u2"), ("strand", "u1"),
+                           ("pad", "u1"), ("block", "<u4"), ("number", "<u4")])
+
+
+class Read(C.Structure):
+    _fields_ = [("read_len", C.c_uint16), ("num_errors", C.c_uint16), ("seq", C.c_uint8 * 1024),
+                ("qual", C.c_uint8 * 1024), ("cigar", C.c_char * 4096)]
+
+
+class Text(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t)]
+
+
+class PhiloxOut(C.Structure):
+    _fields_ = [("w", C.c_uint32 * 4)]
+
+
+class Table(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("nm", C.c_uint32), ("par0", u32p), ("from_", C.c_uint32 * 4),
+                ("to", C.c_uint32 * 4), ("dim2", f64p * 4)]
+
+
+class DomBase(C.Structure):
+    _fields_ = [("dom_base", C.c_uint8), ("content", C.c_uint16 * 5)]
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    sig = {
+        "orc_philox4x32_10": (PhiloxOut, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "orc_u32": (C.c_double, [C.c_uint32]),
+        "orc_u53": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "orc_draw": (C.c_uint32, [C.POINTER(Table), u32p, C.c_double, f64p]),
+        "orc_max_value": (C.c_uint32, [C.POINTER(Table)]),
+        "orc_most_likely": (C.c_uint32, [C.POINTER(Table)]),
+        "orc_profile_load": (C.c_void_p, [C.c_char_p]),
+        "orc_profile_free": (None, [C.c_void_p]),
+        "orc_profile_change_error_rate": (None, [C.c_void_p, C.c_double]),
+        "orc_profile_remove_substitution_errors": (None, [C.c_void_p]),
+        "orc_profile_remove_indel_errors": (None, [C.c_void_p]),
+        "orc_profile_table": (C.POINTER(Table), [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "orc_divide_u32": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "orc_percent_u16": (C.c_uint8, [C.c_uint16, C.c_uint16]),
+        "orc_percent_u32": (C.c_uint8, [C.c_uint32, C.c_uint32]),
+        "orc_percent_u64": (C.c_uint8, [C.c_uint64, C.c_uint64]),
+        "orc_safe_percent_u16": (C.c_uint8, [C.c_uint16, C.c_uint16]),
+        "orc_transform_distance": (C.c_uint32, [C.c_uint32]),
+        "orc_inv_logit2": (C.c_double, [C.c_double]),
+        "orc_dombase_clear": (None, [C.POINTER(DomBase)]),
+        "orc_dombase_set": (None, [C.POINTER(DomBase), u8p, C.c_uint32, C.c_uint32]),
+        "orc_dombase_update": (None, [C.POINTER(DomBase), C.c_uint8, u8p, C.c_uint32, C.c_uint32]),
+        "orc_surrounding_forward": (None, [u8p, C.c_uint32, C.c_uint32, i32p]),
+        "orc_surrounding_reverse": (None, [u8p, C.c_uint32, C.c_uint32, i32p]),
+        "orc_surrounding_update_forward": (None, [u8p, C.c_uint32, C.c_uint32, i32p]),
+        "orc_surrounding_update_reverse": (None, [u8p, C.c_uint32, C.c_uint32, i32p]),
+        "orc_combine_positions": (None, [f64p, f64p]),
+        "orc_separate_positions": (None, [f64p, f64p]),
+        "orc_surrounding_bias": (C.c_double, [f64p, i32p]),
+        "orc_get_dispersion": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+        "orc_binomial": (C.c_uint16, [C.c_uint16, C.c_double, C.c_double]),
+        "orc_negative_binomial": (C.c_uint16, [C.c_double, C.c_double, C.c_double]),
+        "orc_calculate_non_zero_threshold": (C.c_double, [f64p, C.c_double, C.c_double, C.c_uint16]),
+        "orc_fragment_counts_core": (C.c_uint16, [f64p, f64p, C.c_double, C.c_double, C.c_double, C.c_double, i32p, i32p,
+                                                  C.c_double, C.c_uint16]),
+        "orc_sum_bias": (C.c_double, [f64p, C.c_uint32, C.c_uint32, f64p, u8p, C.c_uint32, C.c_uint32, C.c_double, f64p]),
+        "orc_select_allele": (None, [u16p, u32p, u8p, C.c_uint16, C.c_double]),
+        "orc_reference_new": (C.c_void_p, [C.c_uint32]),
+        "orc_reference_set": (None, [C.c_void_p, C.c_uint32, C.c_char_p, u8p, C.c_uint32]),
+        "orc_reference_free": (None, [C.c_void_p]),
+        "orc_reference_replace_n": (None, [C.c_void_p, C.c_uint64]),
+        "orc_sim_new": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_char_p]),
+        "orc_sim_free": (None, [C.c_void_p]),
+        "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),
+        "orc_coverage_prop_lost_from_adapters": (C.c_double, [C.c_void_p]),
+        "orc_coverage_to_number_pairs": (C.c_uint64, [C.c_double, C.c_uint64, C.c_double, C.c_double]),
+        "orc_number_pairs_to_coverage": (C.c_double, [C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
+        "orc_sieve_blocks": (C.c_uint64, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(Fragment))]),
+        "orc_create_reads": (C.c_int, [C.c_void_p, C.POINTER(Fragment), C.c_uint64, C.POINTER(Text), C.POINTER(Text)]),
+        "orc_simulate_adapter_only_pairs": (C.c_int, [C.c_void_p, C.POINTER(Text), C.POINTER(Text)]),
+        "orc_text_free": (None, [C.POINTER(Text)]),
+        "orc_error_model_only": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u8p, u8p, u32p, u8p,
+                                           u8p, C.POINTER(Read), u16p]),
+        "orc_systematic_errors": (None, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_int,
+                                         C.c_uint16, u8p, u8p, u8p]),
+        "orc_sim_bias_normalization": (C.c_double, [C.c_void_p]),
+        "orc_sim_n_groups": (C.c_uint32, [C.c_void_p]),
+        "orc_sim_insert_to": (C.c_uint32, [C.c_void_p]),
+        "orc_sim_total_pairs": (C.c_uint64, [C.c_void_p]),
+        "orc_sim_adapter_only_pairs": (C.c_uint64, [C.c_void_p]),
+        "orc_sim_total_blocks": (C.c_uint32, [C.c_void_p]),
+        "orc_sim_gc_range": (C.c_uint16, [C.c_void_p]),
+        "orc_sim_thresholds": (f64p, [C.c_void_p]),
+        "orc_sim_norm_by_len": (f64p, [C.c_void_p]),
+        "orc_sim_coverage_groups": (u32p, [C.c_void_p]),
+        "orc_sim_sys_dom": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
+        "orc_sim_sys_rate": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
+        "orc_sim_adapter_dom": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
+        "orc_sim_adapter_rate": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
+        "free": (None, [C.c_void_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+# ------------------------------------------------------------------ high level
+class Profile:
+    def __init__(self, path):
+        self.h = lib().orc_profile_load(str(path).encode())
+        if not self.h:
+            raise RuntimeError(f"oracle could not load {path}")
+
+    def table(self, family, a=0, b=0, c=0, d=0):
+        fam = {"quality": 0, "seq_quality": 1, "base_call": 2, "dom_error": 3, "error_rate": 4, "indels": 5}[family]
+        return lib().orc_profile_table(self.h, fam, a, b, c, d)
+
+    def close(self):
+        if self.h:
+            lib().orc_profile_free(self.h)
+            self.h = None
+
+
+class Reference:
+    def __init__(self, seqs):
+        L = lib()
+        self.seqs = [(n, np.ascontiguousarray(c, dtype=np.uint8)) for n, c in seqs]
+        self.h = L.orc_reference_new(len(self.seqs))
+        for i, (name, codes) in enumerate(self.seqs):
+            L.orc_reference_set(self.h, i, name.encode(), _ptr(codes, u8p), len(codes))
+
+    def close(self):
+        if self.h:
+            lib().orc_reference_free(self.h)
+            self.h = None
+
+
+def _take_text(t):
+    out = C.string_at(t.data, t.len) if t.len else b""
+    lib().orc_text_free(C.byref(t))
+    return out
+
+
+class Sim:
+    def __init__(self, profile, reference, seed, num_pairs=0, coverage=0.0, base_identifier=b""):
+        self.profile, self.reference = profile, reference
+        self.h = lib().orc_sim_new(profile.h, reference.h if reference else None, seed, num_pairs, coverage, base_identifier)
+
+    # pre-pass results
+    def thresholds(self):
+        L = lib()
+        n = L.orc_sim_n_groups(self.h) * L.orc_sim_insert_to(self.h) * 2
+        return np.ctypeslib.as_array(L.orc_sim_thresholds(self.h), shape=(n,)).reshape(L.orc_sim_n_groups(self.h), -1, 2).copy()
+
+    def norm_by_len(self):
+        L = lib()
+        return np.ctypeslib.as_array(L.orc_sim_norm_by_len(self.h), shape=(L.orc_sim_insert_to(self.h),)).copy()
+
+    def bias_normalization(self):
+        return lib().orc_sim_bias_normalization(self.h)
+
+    def set_normalization(self, bias_normalization, thresholds):
+        t = np.ascontiguousarray(thresholds, dtype=np.float64)
+        lib().orc_sim_set_normalization(self.h, bias_normalization, _ptr(t, f64p))
+
+    def sys_errors(self, strand, seq):
+        L = lib()
+        n = len(self.reference.seqs[seq][1])
+        dom = np.ctypeslib.as_array(L.orc_sim_sys_dom(self.h, strand, seq), shape=(n,)).copy()
+        rate = np.ctypeslib.as_array(L.orc_sim_sys_rate(self.h, strand, seq), shape=(n,)).copy()
+        return dom, rate
+
+    def adapter_sys_errors(self, seg, adapter, n):
+        L = lib()
+        p = L.orc_sim_adapter_dom(self.h, seg, adapter)
+        if not p:
+            return None
+        return (np.ctypeslib.as_array(p, shape=(n,)).copy(),
+                np.ctypeslib.as_array(L.orc_sim_adapter_rate(self.h, seg, adapter), shape=(n,)).copy())
+
+    def total_pairs(self):
+        return lib().orc_sim_total_pairs(self.h)
+
+    def adapter_only_pairs(self):
+        return lib().orc_sim_adapter_only_pairs(self.h)
+
+    def total_blocks(self):
+        return lib().orc_sim_total_blocks(self.h)
+
+    def sieve(self, block_lo, block_hi):
+        L = lib()
+        out = C.POINTER(Fragment)()
+        n = L.orc_sieve_blocks(self.h, block_lo, block_hi, C.byref(out))
+        arr = np.frombuffer(C.string_at(out, n * C.sizeof(Fragment)), dtype=FRAGMENT_DTYPE).copy() if n else np.zeros(0, FRAGMENT_DTYPE)
+        L.free(out)
+        return arr
+
+    def create_reads(self, frags):
+        L = lib()
+        frags = np.ascontiguousarray(frags, dtype=FRAGMENT_DTYPE)
+        r1, r2 = Text(), Text()
+        L.orc_create_reads(self.h, frags.ctypes.data_as(C.POINTER(Fragment)), len(frags), C.byref(r1), C.byref(r2))
+        return _take_text(r1), _take_text(r2)
+
+    def adapter_only(self):
+        r1, r2 = Text(), Text()
+        lib().orc_simulate_adapter_only_pairs(self.h, C.byref(r1), C.byref(r2))
+        return _take_text(r1), _take_text(r2)
+
+    def close(self):
+        if self.h:
+            lib().orc_sim_free(self.h)
+            self.h = None
+
+
+def error_model_only(profile, seed, rec, first_index=0):
+    """rec: dict from synth.make_error_model_input.  Returns list of (seq codes, qual bytes, cigar, nerr, tile)."""
+    L = lib()
+    n, rl = rec["seqs"].shape
+    out = (Read * n)()
+    tiles = np.zeros(n, np.uint16)
+    seqs = np.ascontiguousarray(rec["seqs"], np.uint8)
+    seg = np.ascontiguousarray(rec["seg"], np.uint8)
+    fl = np.ascontiguousarray(rec["frag_len"], np.uint32)
+    dom = np.ascontiguousarray(rec["dom"], np.uint8)
+    rate = np.ascontiguousarray(rec["rate"], np.uint8)
+    L.orc_error_model_only(profile.h, seed, first_index, n, rl, _ptr(seqs, u8p), _ptr(seg, u8p), _ptr(fl, u32p), _ptr(dom, u8p),
+                           _ptr(rate, u8p), out, _ptr(tiles, u16p))
+    res = []
+    for i in range(n):
+        r = out[i]
+        res.append((bytes(r.seq[:r.read_len]), bytes(r.qual[:r.read_len]), r.cigar.decode(), int(r.num_errors), int(tiles[i])))
+    return res

@@ -1,0 +1,246 @@
+"""Pins the CPU oracle to every known answer the reference's own tests hold for the
+simulation path (tests/golden/reference_known_answers.json)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN, read_fasta
+
+KA = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))
+REF = read_fasta(os.path.join(GOLDEN, "reference-test.fa"))
+
+
+def _sur(fn, seq, pos, sur=None):
+    codes = REF[seq][1]
+    s = np.zeros(3, np.int32) if sur is None else sur
+    fn(O._ptr(codes, O.u8p), len(codes), pos, O._ptr(s, O.i32p))
+    return s
+
+
+def test_reference_fixture_shape():
+    assert [len(c) for _, c in REF] == KA["reference_sequence"]["lengths"]
+    assert REF[0][0].startswith("NC_000913.3_1-500")
+
+
+def test_surrounding_forward_and_reverse():
+    L = O.lib()
+    for seq, pos, exp in KA["surrounding_forward"]:
+        assert _sur(L.orc_surrounding_forward, seq, pos).tolist() == exp
+    for seq, pos, exp in KA["surrounding_reverse"]:
+        assert _sur(L.orc_surrounding_reverse, seq, pos).tolist() == exp
+
+
+def test_surrounding_rolling_updates():
+    L = O.lib()
+    for seq, pos0, ups, exps in KA["surrounding_update_forward"]:
+        s = _sur(L.orc_surrounding_forward, seq, pos0)
+        for p, e in zip(ups, exps):
+            assert _sur(L.orc_surrounding_update_forward, seq, p, s).tolist() == e
+    for seq, pos0, ups, exps in KA["surrounding_update_reverse"]:
+        s = _sur(L.orc_surrounding_reverse, seq, pos0)
+        for p, e in zip(ups, exps):
+            assert _sur(L.orc_surrounding_update_reverse, seq, p, s).tolist() == e
+
+
+def test_rolling_equals_direct_everywhere():
+    L = O.lib()
+    for seq in range(2):
+        f = _sur(L.orc_surrounding_forward, seq, 0)
+        r = _sur(L.orc_surrounding_reverse, seq, 0)
+        for pos in range(1, len(REF[seq][1])):
+            _sur(L.orc_surrounding_update_forward, seq, pos, f)
+            _sur(L.orc_surrounding_update_reverse, seq, pos, r)
+            assert f.tolist() == _sur(L.orc_surrounding_forward, seq, pos).tolist()
+            assert r.tolist() == _sur(L.orc_surrounding_reverse, seq, pos).tolist()
+
+
+def test_combine_positions():
+    L = O.lib()
+    sep = np.asarray(KA["combine_positions"]["separated"], np.float64)
+    bias = np.zeros(3 << 20, np.float64)
+    L.orc_combine_positions(O._ptr(sep, O.f64p), O._ptr(bias, O.f64p))
+    for block in range(3):
+        for code, val in KA["combine_positions"]["expect"]:
+            assert bias[(block << 20) + code] == pytest.approx(val, rel=4e-16)        # EXPECT_DOUBLE_EQ
+    # the numpy generator used for synthetic profiles builds the same table
+    from reseq_amd.synth import combine_positions
+    np.testing.assert_allclose(combine_positions(sep).ravel(), bias, rtol=0, atol=1e-12)
+
+
+def test_separate_positions():
+    L = O.lib()
+    bias = np.zeros(3 << 20, np.float64)
+    for block, code, val in KA["separate_positions"]["combined"]:
+        bias[(block << 20) + code] = val
+    sep = np.zeros(120, np.float64)
+    L.orc_separate_positions(O._ptr(bias, O.f64p), O._ptr(sep, O.f64p))
+    for idx, val in KA["separate_positions"]["expect"]:
+        assert sep[idx] == pytest.approx(val, rel=1e-12)
+
+
+def test_reference_sequence_and_gc():
+    # Reference.cpp:483-496 as CreateReads uses it (forward infix / reverse complement of the infix before `start`)
+    for seq, start, n, rev, exp in KA["reference_sequence"]["cases"]:
+        codes = REF[seq][1]
+        got = (3 - codes[start - n:start][::-1]) if rev else codes[start:start + n]
+        assert "".join("ACGT"[c] for c in got) == exp
+    L = O.lib()
+    for seq, a, b, gc_abs, gc_perc in KA["gc_content"]:
+        codes = REF[seq][1]
+        gc = int(np.isin(codes[a:b], (1, 2)).sum())
+        assert gc == gc_abs
+        assert L.orc_percent_u32(gc, b - a) == gc_perc
+
+
+def test_sum_bias():
+    L = O.lib()
+    sb = KA["sum_bias"]
+    sur = np.full(3 << 20, sb["sur_fill"], np.float64)
+    for block, code, val in sb["sur_entries"]:
+        sur[(block << 20) + code] = val
+    gcb = np.zeros(101, np.float64)
+    for perc, val in sb["gc_bias"]:
+        gcb[perc] = val
+    codes = REF[sb["seq"]][1]
+    mx = C.c_double(0.0)
+    tot = L.orc_sum_bias(O._ptr(gcb, O.f64p), 0, 101, O._ptr(sur, O.f64p), O._ptr(codes, O.u8p), len(codes), sb["fragment_length"],
+                         sb["general_bias"], C.byref(mx))
+    assert abs(2 * tot - sb["twice_sum"]) < sb["twice_sum_tol"]
+    assert abs(mx.value - sb["max_bias"]) < sb["max_bias_tol"]
+
+
+def test_draw_number_non_zero_strands():
+    L = O.lib()
+    for alleles, zero_p, u, exp in KA["draw_number_non_zero_strands"]:
+        assert L.orc_binomial(2 * alleles, 1 - zero_p, u) == exp          # FragmentDistributionStats.cpp:3598
+
+
+def test_fragment_counts_gates():
+    L = O.lib()
+    fc = KA["fragment_counts"]
+    sur = np.full(3 << 20, fc["sur_fill"], np.float64)
+    for block, code, val in fc["sur_entries"]:
+        sur[(block << 20) + code] = val
+    s0 = np.asarray(fc["start_sur"], np.int32)
+    s1 = np.asarray(fc["end_sur"], np.int32)
+    norm, neg, delta = fc["bias_normalization"], fc["other_bias_negation"], fc["delta"]
+
+    def counts(disp, gc_bias, bias_norm, u):
+        d = np.asarray(disp, np.float64)
+        return L.orc_fragment_counts_core(O._ptr(sur, O.f64p), O._ptr(d, O.f64p), bias_norm, fc["ref_seq_bias"],
+                                          fc["insert_length_bias"], gc_bias, O._ptr(s0, O.i32p), O._ptr(s1, O.i32p), u, 1)
+
+    for disp, bias, gates in fc["cases"]:
+        gcb = bias * neg
+        for i, g in enumerate(gates):
+            assert counts(disp, gcb, norm, g - delta) == i
+            assert counts(disp, gcb, norm, g + delta) == i + 1
+        d = np.asarray(disp, np.float64)
+        thr = L.orc_calculate_non_zero_threshold(O._ptr(d, O.f64p), norm, gcb / neg / norm, 1)
+        assert abs(thr - gates[0]) < delta
+        assert counts(disp, gcb, norm - delta, thr) == 0
+        assert counts(disp, gcb, 1e-10, thr) == 0
+
+
+def test_survey_probe_values():
+    L = O.lib()
+    p, r, u, exp = KA["survey_probe"]["negative_binomial"]
+    assert L.orc_negative_binomial(p, r, u) == exp
+    n, p, u, exp = KA["survey_probe"]["binomial"]
+    assert L.orc_binomial(n, p, u) == exp
+    b, a1, b1, exp = KA["survey_probe"]["get_dispersion"]
+    assert L.orc_get_dispersion(b, a1, b1) == exp
+
+
+def test_select_allele_order():
+    L = O.lib()
+    for strands, u, exp in KA["select_allele"]:
+        chosen = np.zeros(strands, np.uint16)
+        n = C.c_uint32(0)
+        rev = np.ones(strands, np.uint8)
+        while n.value < strands:
+            L.orc_select_allele(O._ptr(chosen, O.u16p), C.byref(n), O._ptr(rev, O.u8p), strands, u)
+        assert chosen.tolist() == exp
+
+
+def test_coverage_conversion(tiny_profile_arrays, workdir):
+    from reseq_amd import synth
+    cc = KA["coverage_conversion"]
+    arrays = dict(tiny_profile_arrays)
+    nm = {(s, f, r): c for s, f, r, c in cc["non_mapped"]}
+    for seg in range(2):
+        rows = sorted((f, r, c) for s, f, r, c in cc["rl_by_fl"] if s == seg)
+        lo, hi = rows[0][0], rows[-1][0]
+        ptr, frm, vals, nmv = [0], [], [], []
+        for fl in range(lo, hi + 1):
+            hit = [(r, c) for f, r, c in rows if f == fl]
+            frm.append(hit[0][0] if hit else 0)
+            for r, c in hit:
+                vals.append(c)
+                nmv.append(nm.get((seg, fl, r), 0))
+            ptr.append(len(vals))
+        arrays[f"rl_by_fl.{seg}.from"] = np.asarray([lo], np.uint64)
+        arrays[f"rl_by_fl.{seg}.row_ptr"] = np.asarray(ptr, np.uint32)
+        arrays[f"rl_by_fl.{seg}.row_from"] = np.asarray(frm, np.uint32)
+        arrays[f"rl_by_fl.{seg}.values"] = np.asarray(vals, np.uint64)
+        arrays[f"rl_by_fl_nonmapped.{seg}.values"] = np.asarray(nmv, np.uint64)
+    path = workdir / "covconv.rsqp"
+    synth.write_profile(path, arrays)
+    prof = O.Profile(path)
+    L = O.lib()
+    part = L.orc_coverage_prop_lost_from_adapters(prof.h)
+    assert part == pytest.approx(cc["adapter_part"], rel=4e-16)
+    pairs = L.orc_coverage_to_number_pairs(cc["coverage"], cc["total_ref_size"], cc["average_read_length"], part)
+    assert pairs == cc["total_pairs"]
+    assert abs(L.orc_number_pairs_to_coverage(pairs, cc["total_ref_size"], cc["average_read_length"], part) - cc["coverage"]) < 0.01
+    prof.close()
+
+
+def _codes(s):
+    return np.asarray(["ACGTN".index(c) for c in s], np.uint8)
+
+
+def test_dominant_base():
+    L = O.lib()
+    db = KA["dominant_base"]
+    seq = _codes(db["seq"])
+    rc = np.where(seq[::-1] < 4, 3 - seq[::-1], 4).astype(np.uint8)
+    for codes, first, rest in ((seq, db["set_0_1_2"], db["set_from_3"]), (rc, db["revcomp_set_0_1_2"], db["revcomp_set_from_3"])):
+        expected = first + rest
+        rolling = O.DomBase()
+        for pos in range(len(codes)):
+            d = O.DomBase()
+            L.orc_dombase_set(C.byref(d), O._ptr(codes, O.u8p), len(codes), pos)
+            assert d.dom_base == expected[pos], pos
+            if pos == 0:
+                L.orc_dombase_set(C.byref(rolling), O._ptr(codes, O.u8p), len(codes), 0)
+            else:
+                L.orc_dombase_update(C.byref(rolling), int(codes[pos - 1]), O._ptr(codes, O.u8p), len(codes), pos - 1)
+            assert rolling.dom_base == expected[pos], pos
+
+
+def test_divide_and_percent():
+    L = O.lib()
+    for nom, den, exp in KA["divide"]:
+        if nom < 2 ** 32:
+            assert L.orc_divide_u32(nom, den) == exp
+    for nom, den, exp in KA["percent"]:
+        assert L.orc_percent_u64(nom, den) == exp
+        if nom < 600:
+            assert L.orc_percent_u16(nom, den) == exp
+    nom, den, exp = KA["safe_percent_zero_den"]
+    assert L.orc_safe_percent_u16(nom, den) == exp
+    # Percent casts nom*100 back to the type of nom: uint16 numerators wrap above 655
+    assert L.orc_percent_u16(700, 1000) == ((700 * 100) % 65536 + 500) // 1000
+
+
+def test_philox_known_answer():
+    # Random123 kat_vectors: philox4x32 10 rounds, counter ffffffff x4, key ffffffff x2
+    out = O.lib().orc_philox4x32_10(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [hex(w) for w in out.w] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    out = O.lib().orc_philox4x32_10(0, 0, 0, 0, 0)
+    assert [hex(w) for w in out.w] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
