@@ -1,0 +1,138 @@
+/*
+ * reseq_amd.h -- C ABI of libreseq_amd.so: the MI355X (gfx950) implementation of ReSeq's read-simulation
+ * hot path.  Plain pointers and sizes only; every entry point returns 0 on success or a negative RSQ_E* code
+ * (message via rsq_last_error()).  All functions are thread-compatible: one rsq_sim per GPU per thread.
+ *
+ * The reference (schmeing/ReSeq v1.1) has no plugin/FFI boundary: `main` calls three C++ methods of
+ * reseq::Simulator by value-typed references (reseq/Simulator.h:456-458).  Each entry point below names the
+ * reference interface it stands in for; INTEGRATION.md shows the binding a ReSeq maintainer would add.
+ *
+ * Pointers named *_dev are DEVICE pointers on the GPU the rsq_sim was created for; everything else is host
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef RESEQ_AMD_H
+#define RESEQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsq_profile rsq_profile;      /* DataStats + ProbabilityEstimates, simulation subset */
+typedef struct rsq_ref rsq_ref;              /* reseq::Reference */
+typedef struct rsq_sim rsq_sim;              /* reseq::Simulator bound to one GPU */
+
+enum {
+    RSQ_OK = 0,
+    RSQ_EINVAL = -1,      /* bad argument / inconsistent input */
+    RSQ_EIO = -2,         /* file could not be read / parsed */
+    RSQ_ENODEV = -3,      /* no usable HIP device: there is NO CPU fallback */
+    RSQ_EHIP = -4,        /* a HIP call failed */
+    RSQ_ENOSPC = -5,      /* caller's output buffer too small; required sizes are still reported */
+    RSQ_ESTATE = -6       /* call order violated (e.g. simulate before prepare) */
+};
+
+const char *rsq_last_error(void);
+const char *rsq_version(void);
+/* number of visible HIP devices, or RSQ_ENODEV */
+int rsq_device_count(void);
+
+/* ---- profile: stands in for DataStats::Load + PrepareProcessing (reseq/DataStats.cpp:1280-1340) and
+ *      ProbabilityEstimates::Load + PrepareResult (reseq/ProbabilityEstimates.cpp:961-1065).
+ *      `path` is an RSQP container (reseq_amd/container.py documents the layout). */
+int rsq_profile_load(const char *path, rsq_profile **out);
+void rsq_profile_free(rsq_profile *p);
+/* ProbabilityEstimates::ChangeErrorRate / RemoveSubstitutionErrors / RemoveInDelErrors
+ * (reseq/ProbabilityEstimates.h:1516-1549; CLI --errorMutliplier, --noSubstitutionErrors, --noInDelErrors) */
+int rsq_profile_change_error_rate(rsq_profile *p, double error_multiplier);
+int rsq_profile_remove_substitution_errors(rsq_profile *p);
+int rsq_profile_remove_indel_errors(rsq_profile *p);
+/* small getters the callers need to size buffers */
+int rsq_profile_max_read_length(const rsq_profile *p, uint32_t *out);
+int rsq_profile_num_tiles(const rsq_profile *p, uint32_t *out);
+
+/* ---- reference: Reference::ReadFasta (reseq/Reference.cpp:758) and Reference::ReplaceN (:813) */
+int rsq_ref_load_fasta(const char *path, rsq_ref **out);
+int rsq_ref_replace_n(rsq_ref *r, uint64_t seed);
+void rsq_ref_free(rsq_ref *r);
+int rsq_ref_num_sequences(const rsq_ref *r, uint32_t *out);
+int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out);
+/* copies the base codes (A=0,C=1,G=2,T=3,N=4) of one sequence into out[len] */
+int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len);
+
+/* ---- simulator.  rsq_sim_create packs the profile tables and the 2-bit reference into HBM of `device`
+ *      (`ref` may be NULL for the error-model-only mode).  The profile and reference may be freed afterwards. */
+int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim **out);
+void rsq_sim_free(rsq_sim *s);
+
+/* Everything Simulator::Simulate does before "Starting read generation" (reseq/Simulator.cpp:2687-2826):
+ * number of pairs (num_read_pairs, or coverage, or the profile's corrected coverage when both are 0), adapter-only
+ * share, CalculateBiasNormalization, systematic errors of adapters and of both strands of every sequence.
+ * With ref == NULL only the adapter part runs (Simulator::SimulateErrorModelOnly, :2951-2977).
+ * ref_bias_mode: 0 = keep (falls back to 1 when the counts differ), 1 = no bias (FragmentDistributionStats.cpp:3352). */
+int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier, void *stream);
+
+typedef struct {
+    uint64_t total_pairs;           /* total_pairs_ after removing the adapter-only pairs */
+    uint64_t adapter_only_pairs;    /* num_adapter_only_pairs_ */
+    uint32_t total_blocks;          /* forward blocks of 1000 start positions; ids run 1..total_blocks */
+    uint32_t n_coverage_groups;
+    uint32_t insert_to;             /* InsertLengths().to() */
+    uint32_t sys_chain_passes;      /* passes the speculative systematic-error chains needed */
+    double bias_normalization;
+} rsq_sim_info;
+int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out);
+
+/* pre-pass results, for inspection and stage-wise parity tests */
+int rsq_sim_get_thresholds(const rsq_sim *s, double *out, size_t n);           /* [groups][insert_to][2] */
+int rsq_sim_get_norm_by_len(const rsq_sim *s, double *out, size_t n);          /* [insert_to] */
+int rsq_sim_set_normalization(rsq_sim *s, double bias_normalization, const double *thresholds, size_t n);
+int rsq_sim_get_sys_errors(const rsq_sim *s, int reverse_strand, uint32_t seq, uint8_t *dom_out, uint8_t *rate_out, uint32_t len);
+int rsq_sim_get_adapter_sys_errors(const rsq_sim *s, int template_segment, uint32_t adapter, uint8_t *dom_out, uint8_t *rate_out, uint32_t len);
+
+/* One simulated fragment = one read pair (SimulateFromGivenBlock, reseq/Simulator.cpp:2249-2357). */
+typedef struct {
+    uint32_t seq, start, len;
+    uint16_t dup;
+    uint8_t strand, pad;
+    uint32_t block, number;
+} rsq_fragment;
+
+/* The hot path: Simulator::SimulationThread over blocks [block_lo, block_hi) (reseq/Simulator.cpp:2384-2401):
+ * coverage sieve, CreateReads, FASTQ text of both mates.  r1_dev / r2_dev receive the two FASTQ streams in
+ * identical record order ((block, start, length, strand choice, duplicate) order).  On RSQ_ENOSPC the required
+ * byte counts are returned in *r1_len / *r2_len and nothing is written.  frags_dev (optional, capacity
+ * frags_cap records) receives the fragment list. */
+int rsq_sim_pairs(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,
+                  uint64_t *n_pairs, rsq_fragment *frags_dev, size_t frags_cap, void *stream);
+/* Simulator::SimulateAdapterOnlyPairs (reseq/Simulator.cpp:2359-2382): pairs [first, first+n) of the adapter-only share */
+int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,
+                               void *stream);
+
+/* Simulator::ApplyErrorsAndQualityToFastaInput with the FASTA header already parsed (reseq/Simulator.cpp:2403-2512):
+ * n records of `read_len` template bases each.  Inputs (device): seqs[n][read_len] base codes 0..3, seg[n] template
+ * segment 0/1, frag_len[n], dom[n][read_len] dominant-error base codes 0..4, rate[n][read_len] error percent.
+ * Outputs (device): seq_out/qual_out [n][out_stride] (base codes / phred+offset characters), read_len_out[n],
+ * num_errors_out[n], tile_out[n], cigar_out[n][cigar_stride] NUL-terminated.  first_index is the index of the
+ * first record in the input file (it selects the records' random streams). */
+int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev,
+                        const uint32_t *frag_len_dev, const uint8_t *dom_dev, const uint8_t *rate_dev, uint8_t *seq_out_dev, uint8_t *qual_out_dev,
+                        uint32_t out_stride, uint16_t *read_len_out_dev, uint16_t *num_errors_out_dev, uint16_t *tile_out_dev, char *cigar_out_dev,
+                        uint32_t cigar_stride, void *stream);
+
+/* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded on the call's stream
+ * around each kernel.  names: "sieve_count", "sieve_emit", "fill_reads", "format_sizes", "format_write", "scan". */
+int rsq_sim_last_kernel_ms(const rsq_sim *s, const char *kernel, double *ms);
+
+/* ---- device memory helpers so that callers without a HIP binding (ctypes tests, the CLI) can stage buffers */
+int rsq_dev_alloc(int device, size_t bytes, void **out_dev);
+int rsq_dev_free(int device, void *dev);
+int rsq_dev_upload(int device, void *dst_dev, const void *src, size_t bytes);
+int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

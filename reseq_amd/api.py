@@ -1,0 +1,305 @@
+"""ctypes binding of libreseq_amd.so (C ABI: include/reseq_amd.h).
+
+There is no CPU fallback: importing this module without the built library, or
+creating a Simulator without a visible MI355X, raises.  The class names follow
+the reference's objects for this path (reseq::DataStats/ProbabilityEstimates ->
+Profile, reseq::Reference -> Reference, reseq::Simulator -> Simulator).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreseq_amd.so")
+
+RSQ_OK, RSQ_EINVAL, RSQ_EIO, RSQ_ENODEV, RSQ_EHIP, RSQ_ENOSPC, RSQ_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+FRAGMENT_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("dup", "<u2"), ("strand", "u1"),
+                           ("pad", "u1"), ("block", "<u4"), ("number", "<u4")])
+
+
+class SimInfo(C.Structure):
+    _fields_ = [("total_pairs", C.c_uint64), ("adapter_only_pairs", C.c_uint64), ("total_blocks", C.c_uint32),
+                ("n_coverage_groups", C.c_uint32), ("insert_to", C.c_uint32), ("sys_chain_passes", C.c_uint32),
+                ("bias_normalization", C.c_double)]
+
+
+class RsqError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rsq error {code}: {message}")
+        self.code = code
+
+
+# every symbol include/reseq_amd.h declares: name -> (restype, argtypes)
+_vp, _u64, _u32, _sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+_psz = C.POINTER(C.c_size_t)
+SYMBOLS = {
+    "rsq_last_error": (C.c_char_p, []),
+    "rsq_version": (C.c_char_p, []),
+    "rsq_device_count": (C.c_int, []),
+    "rsq_profile_load": (C.c_int, [C.c_char_p, _pp]),
+    "rsq_profile_free": (None, [_vp]),
+    "rsq_profile_change_error_rate": (C.c_int, [_vp, C.c_double]),
+    "rsq_profile_remove_substitution_errors": (C.c_int, [_vp]),
+    "rsq_profile_remove_indel_errors": (C.c_int, [_vp]),
+    "rsq_profile_max_read_length": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_profile_num_tiles": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_ref_load_fasta": (C.c_int, [C.c_char_p, _pp]),
+    "rsq_ref_replace_n": (C.c_int, [_vp, _u64]),
+    "rsq_ref_free": (None, [_vp]),
+    "rsq_ref_num_sequences": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_ref_sequence_length": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    "rsq_ref_get_codes": (C.c_int, [_vp, _u32, _vp, _u32]),
+    "rsq_sim_create": (C.c_int, [_vp, _vp, C.c_int, _pp]),
+    "rsq_sim_free": (None, [_vp]),
+    "rsq_sim_prepare": (C.c_int, [_vp, _u64, _u64, C.c_double, C.c_int, C.c_char_p, _vp]),
+    "rsq_sim_get_info": (C.c_int, [_vp, C.POINTER(SimInfo)]),
+    "rsq_sim_get_thresholds": (C.c_int, [_vp, _vp, _sz]),
+    "rsq_sim_get_norm_by_len": (C.c_int, [_vp, _vp, _sz]),
+    "rsq_sim_set_normalization": (C.c_int, [_vp, C.c_double, _vp, _sz]),
+    "rsq_sim_get_sys_errors": (C.c_int, [_vp, C.c_int, _u32, _vp, _vp, _u32]),
+    "rsq_sim_get_adapter_sys_errors": (C.c_int, [_vp, C.c_int, _u32, _vp, _vp, _u32]),
+    "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
+    "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
+    "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "rsq_sim_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
+    "rsq_dev_alloc": (C.c_int, [C.c_int, _sz, _pp]),
+    "rsq_dev_free": (C.c_int, [C.c_int, _vp]),
+    "rsq_dev_upload": (C.c_int, [C.c_int, _vp, _vp, _sz]),
+    "rsq_dev_download": (C.c_int, [C.c_int, _vp, _vp, _sz]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libreseq_amd.so; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C reseq_amd/csrc); reseq_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != RSQ_OK:
+        raise RsqError(rc, lib().rsq_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = lib().rsq_device_count()
+    if n < 0:
+        raise RsqError(n, lib().rsq_last_error().decode())
+    return n
+
+
+class Profile:
+    """DataStats::Load + ProbabilityEstimates::Load/PrepareResult on an RSQP container."""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        _check(lib().rsq_profile_load(os.fsencode(path), C.byref(self.h)))
+
+    def change_error_rate(self, multiplier):
+        _check(lib().rsq_profile_change_error_rate(self.h, multiplier))
+
+    def remove_substitution_errors(self):
+        _check(lib().rsq_profile_remove_substitution_errors(self.h))
+
+    def remove_indel_errors(self):
+        _check(lib().rsq_profile_remove_indel_errors(self.h))
+
+    def max_read_length(self):
+        v = C.c_uint32()
+        _check(lib().rsq_profile_max_read_length(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            lib().rsq_profile_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Reference:
+    """Reference::ReadFasta (+ ReplaceN)."""
+
+    def __init__(self, fasta_path, replace_n_seed=None):
+        self.h = C.c_void_p()
+        _check(lib().rsq_ref_load_fasta(os.fsencode(fasta_path), C.byref(self.h)))
+        if replace_n_seed is not None:
+            _check(lib().rsq_ref_replace_n(self.h, replace_n_seed))
+
+    def num_sequences(self):
+        v = C.c_uint32()
+        _check(lib().rsq_ref_num_sequences(self.h, C.byref(v)))
+        return v.value
+
+    def sequence_length(self, i):
+        v = C.c_uint32()
+        _check(lib().rsq_ref_sequence_length(self.h, i, C.byref(v)))
+        return v.value
+
+    def codes(self, i):
+        out = np.zeros(self.sequence_length(i), np.uint8)
+        _check(lib().rsq_ref_get_codes(self.h, i, out.ctypes.data, len(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().rsq_ref_free(self.h)
+            self.h = C.c_void_p()
+
+
+class DeviceArray:
+    """A device allocation made through the C ABI (tests and the bench stage their buffers with it)."""
+
+    def __init__(self, device, nbytes):
+        self.device, self.nbytes = device, int(nbytes)
+        self.ptr = C.c_void_p()
+        _check(lib().rsq_dev_alloc(device, self.nbytes, C.byref(self.ptr)))
+
+    @classmethod
+    def from_numpy(cls, device, a):
+        a = np.ascontiguousarray(a)
+        d = cls(device, max(a.nbytes, 8))
+        _check(lib().rsq_dev_upload(device, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def to_numpy(self, dtype, count):
+        out = np.zeros(count, dtype)
+        if out.nbytes:
+            _check(lib().rsq_dev_download(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().rsq_dev_free(self.device, self.ptr)
+            self.ptr = C.c_void_p()
+
+
+class Simulator:
+    """reseq::Simulator bound to one GPU (Simulator.h:453-459)."""
+
+    def __init__(self, profile, reference=None, device=0):
+        self.device = device
+        self.h = C.c_void_p()
+        _check(lib().rsq_sim_create(profile.h, reference.h if reference is not None else None, device, C.byref(self.h)))
+
+    def prepare(self, seed, num_read_pairs=0, coverage=0.0, ref_bias_mode=0, record_base_identifier="", stream=None):
+        _check(lib().rsq_sim_prepare(self.h, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier.encode(), stream))
+        return self.info()
+
+    def info(self):
+        i = SimInfo()
+        _check(lib().rsq_sim_get_info(self.h, C.byref(i)))
+        return i
+
+    def thresholds(self):
+        i = self.info()
+        out = np.zeros((i.n_coverage_groups, i.insert_to, 2), np.float64)
+        _check(lib().rsq_sim_get_thresholds(self.h, out.ctypes.data, out.size))
+        return out
+
+    def norm_by_len(self):
+        out = np.zeros(self.info().insert_to, np.float64)
+        _check(lib().rsq_sim_get_norm_by_len(self.h, out.ctypes.data, out.size))
+        return out
+
+    def set_normalization(self, bias_normalization, thresholds):
+        t = np.ascontiguousarray(thresholds, np.float64)
+        _check(lib().rsq_sim_set_normalization(self.h, bias_normalization, t.ctypes.data, t.size))
+
+    def sys_errors(self, reverse, seq, length):
+        dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
+        _check(lib().rsq_sim_get_sys_errors(self.h, int(reverse), seq, dom.ctypes.data, rate.ctypes.data, length))
+        return dom, rate
+
+    def adapter_sys_errors(self, seg, adapter, length):
+        dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
+        _check(lib().rsq_sim_get_adapter_sys_errors(self.h, seg, adapter, dom.ctypes.data, rate.ctypes.data, length))
+        return dom, rate
+
+    def pairs_device(self, block_lo, block_hi, r1, r2, frags=None, stream=None):
+        """Run the hot path into caller-owned DeviceArrays.  Returns (n_pairs, len1, len2, rc)."""
+        l1, l2, n = C.c_size_t(), C.c_size_t(), C.c_uint64()
+        rc = lib().rsq_sim_pairs(self.h, block_lo, block_hi, r1.ptr if r1 else None, r1.nbytes if r1 else 0, C.byref(l1), r2.ptr if r2 else None,
+                                 r2.nbytes if r2 else 0, C.byref(l2), C.byref(n), frags.ptr if frags else None,
+                                 frags.nbytes // FRAGMENT_DTYPE.itemsize if frags else 0, stream)
+        return n.value, l1.value, l2.value, rc
+
+    def pairs(self, block_lo, block_hi, stream=None):
+        """Convenience for tests: sizes the buffers with a first call, returns (fragments, fastq1 bytes, fastq2 bytes)."""
+        n, l1, l2, rc = self.pairs_device(block_lo, block_hi, None, None, None, stream)
+        if rc == RSQ_OK and n == 0:
+            return np.zeros(0, FRAGMENT_DTYPE), b"", b""
+        if rc != RSQ_ENOSPC:
+            _check(rc)
+        r1, r2 = DeviceArray(self.device, l1 + 64), DeviceArray(self.device, l2 + 64)
+        fr = DeviceArray(self.device, (n + 1) * FRAGMENT_DTYPE.itemsize)
+        try:
+            n2, l1b, l2b, rc = self.pairs_device(block_lo, block_hi, r1, r2, fr, stream)
+            _check(rc)
+            assert (n2, l1b, l2b) == (n, l1, l2)
+            return fr.to_numpy(FRAGMENT_DTYPE, n), r1.to_numpy(np.uint8, l1).tobytes(), r2.to_numpy(np.uint8, l2).tobytes()
+        finally:
+            for d in (r1, r2, fr):
+                d.free()
+
+    def adapter_only_pairs(self, first, n, stream=None):
+        l1, l2 = C.c_size_t(), C.c_size_t()
+        rc = lib().rsq_sim_adapter_only_pairs(self.h, first, n, None, 0, C.byref(l1), None, 0, C.byref(l2), stream)
+        if rc == RSQ_OK:
+            return b"", b""
+        if rc != RSQ_ENOSPC:
+            _check(rc)
+        r1, r2 = DeviceArray(self.device, l1.value + 64), DeviceArray(self.device, l2.value + 64)
+        try:
+            _check(lib().rsq_sim_adapter_only_pairs(self.h, first, n, r1.ptr, r1.nbytes, C.byref(l1), r2.ptr, r2.nbytes, C.byref(l2), stream))
+            return r1.to_numpy(np.uint8, l1.value).tobytes(), r2.to_numpy(np.uint8, l2.value).tobytes()
+        finally:
+            r1.free()
+            r2.free()
+
+    def error_model(self, rec, first_index=0, out_stride=None, cigar_stride=256, stream=None):
+        """Simulator::SimulateErrorModelOnly on arrays (rec as made by synth.make_error_model_input).
+        Returns list of (seq codes bytes, qual bytes, cigar str, num_errors, tile id)."""
+        n, rl = rec["seqs"].shape
+        out_stride = out_stride or 1024
+        dev = self.device
+        ins = [DeviceArray.from_numpy(dev, np.ascontiguousarray(rec[k], dt)) for k, dt in
+               (("seqs", np.uint8), ("seg", np.uint8), ("frag_len", np.uint32), ("dom", np.uint8), ("rate", np.uint8))]
+        outs = [DeviceArray(dev, n * out_stride), DeviceArray(dev, n * out_stride), DeviceArray(dev, n * 2), DeviceArray(dev, n * 2),
+                DeviceArray(dev, n * 2), DeviceArray(dev, n * cigar_stride)]
+        try:
+            _check(lib().rsq_sim_error_model(self.h, first_index, n, rl, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, outs[0].ptr, outs[1].ptr,
+                                             out_stride, outs[2].ptr, outs[3].ptr, outs[4].ptr, outs[5].ptr, cigar_stride, stream))
+            seq = outs[0].to_numpy(np.uint8, n * out_stride).reshape(n, out_stride)
+            qual = outs[1].to_numpy(np.uint8, n * out_stride).reshape(n, out_stride)
+            rlen = outs[2].to_numpy(np.uint16, n)
+            nerr = outs[3].to_numpy(np.uint16, n)
+            tile = outs[4].to_numpy(np.uint16, n)
+            cig = outs[5].to_numpy(np.uint8, n * cigar_stride).reshape(n, cigar_stride)
+            return [(seq[i, :rlen[i]].tobytes(), qual[i, :rlen[i]].tobytes(), cig[i].tobytes().split(b"\0")[0].decode(), int(nerr[i]), int(tile[i]))
+                    for i in range(n)]
+        finally:
+            for d in ins + outs:
+                d.free()
+
+    def last_kernel_ms(self, name):
+        v = C.c_double()
+        _check(lib().rsq_sim_last_kernel_ms(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            lib().rsq_sim_free(self.h)
+            self.h = C.c_void_p()

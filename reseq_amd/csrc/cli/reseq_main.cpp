@@ -1,0 +1,479 @@
+// reseq_main.cpp -- `reseq` command line for the simulation stage, on top of the C ABI (include/reseq_amd.h).
+//
+// Keeps the reference's modes and flags for this path (reseq/main.cpp:434-438 general, :710-753 illuminaPE,
+// :1009-1021 seqToIllumina): `reseq illuminaPE` simulates paired reads from a fitted profile, `reseq seqToIllumina`
+// (alias `replaceQuals`) applies the error and quality model to given sequences.  Profile creation (BAM statistics,
+// bias fit, IPF) is not part of this build: the flags are recognised and rejected with a clear message.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <random>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../../include/reseq_amd.h"
+
+namespace {
+
+int g_verbosity = 4;
+#define INFO(msg)                                                \
+    do {                                                         \
+        if (g_verbosity >= 3) std::cerr << "[INFO] " << msg << std::endl; \
+    } while (0)
+#define ERR(msg)                                                 \
+    do {                                                         \
+        if (g_verbosity >= 1) std::cerr << "[ERROR] " << msg << std::endl; \
+    } while (0)
+
+struct Args {
+    std::map<std::string, std::string> val;
+    std::set<std::string> flag;
+    bool has(const std::string &k) const { return val.count(k) || flag.count(k); }
+    std::string get(const std::string &k, const std::string &def = "") const {
+        auto it = val.find(k);
+        return it == val.end() ? def : it->second;
+    }
+};
+
+const std::map<std::string, std::string> kShort = {{"-j", "threads"}, {"-h", "help"}, {"-b", "bamIn"}, {"-r", "refIn"}, {"-s", "statsIn"}, {"-S", "statsOut"},
+                                                   {"-v", "vcfIn"},   {"-p", "probabilitiesIn"}, {"-P", "probabilitiesOut"}, {"-1", "firstReadsOut"},
+                                                   {"-2", "secondReadsOut"}, {"-c", "coverage"}, {"-R", "refSim"}, {"-V", "vcfSim"}, {"-i", "input"}, {"-o", "output"}};
+const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors"};
+
+bool parse(int argc, char **argv, int first, Args &a) {
+    for (int i = first; i < argc; ++i) {
+        std::string k = argv[i];
+        if (k.rfind("--", 0) == 0) k = k.substr(2);
+        else if (kShort.count(k)) k = kShort.at(k);
+        else {
+            ERR("unrecognised argument '" << argv[i] << "'");
+            return false;
+        }
+        std::string v;
+        size_t eq = k.find('=');
+        if (eq != std::string::npos) {
+            v = k.substr(eq + 1);
+            k = k.substr(0, eq);
+        }
+        if (kFlags.count(k)) {
+            a.flag.insert(k);
+            continue;
+        }
+        if (eq == std::string::npos) {
+            if (i + 1 >= argc) {
+                ERR("option '" << argv[i] << "' needs a value");
+                return false;
+            }
+            v = argv[++i];
+        }
+        a.val[k] = v;
+    }
+    return true;
+}
+
+bool check(int rc, const char *what) {
+    if (rc == RSQ_OK) return true;
+    ERR(what << ": " << rsq_last_error());
+    return false;
+}
+
+uint64_t get_seed(const Args &a) {                      // main.cpp:340: random seed if none is given
+    if (a.has("seed")) return strtoull(a.get("seed").c_str(), nullptr, 10);
+    std::random_device rd;
+    uint64_t s = ((uint64_t)rd() << 32) | rd();
+    INFO("Using random seed " << s);
+    return s;
+}
+
+bool load_profile(const Args &a, rsq_profile **p) {
+    for (const char *k : {"bamIn", "adapterFile", "adapterMatrix", "statsOut", "vcfIn", "statsOnly", "noBias", "tiles", "probabilitiesOut", "stopAfterEstimation"})
+        if (a.has(k)) {
+            ERR("--" << k << ": profile creation (statistics, bias fit, IPF) is not supported in this build; create the profile with the reference tool and pass it with -s");
+            return false;
+        }
+    if (!a.has("statsIn")) {
+        ERR("statsIn option mandatory.");
+        return false;
+    }
+    if (a.has("ipfIterations") && a.get("ipfIterations") != "0") INFO("--ipfIterations is ignored: the profile holds the prepared result tables");
+    INFO("Reading profile from " << a.get("statsIn"));
+    if (!check(rsq_profile_load(a.get("statsIn").c_str(), p), "Could not load profile")) return false;
+    const double mult = a.has("errorMutliplier") ? atof(a.get("errorMutliplier").c_str()) : 1.0;
+    if (a.has("noInDelErrors") && !check(rsq_profile_remove_indel_errors(*p), "noInDelErrors")) return false;          // main.cpp:964-982
+    if (a.has("noSubstitutionErrors")) {
+        if (mult != 1.0) {
+            ERR("noSubstitutionErrors and errorMutliplier cannot be combined.");
+            return false;
+        }
+        if (!check(rsq_profile_remove_substitution_errors(*p), "noSubstitutionErrors")) return false;
+    } else if (mult != 1.0 && !check(rsq_profile_change_error_rate(*p, mult), "errorMutliplier")) return false;
+    return true;
+}
+
+struct DevBuffer {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) rsq_dev_free(0, p);
+        p = nullptr;
+        cap = 0;
+        if (!check(rsq_dev_alloc(0, n, &p), "device allocation")) return false;
+        cap = n;
+        return true;
+    }
+    ~DevBuffer() {
+        if (p) rsq_dev_free(0, p);
+    }
+};
+
+bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<char> &h, std::ofstream &f1, std::ofstream &f2) {
+    h.resize(std::max(l1, l2) + 1);
+    if (!check(rsq_dev_download(0, h.data(), d1.p, l1), "download")) return false;
+    f1.write(h.data(), (std::streamsize)l1);
+    if (!check(rsq_dev_download(0, h.data(), d2.p, l2), "download")) return false;
+    f2.write(h.data(), (std::streamsize)l2);
+    return f1.good() && f2.good();
+}
+
+int illumina_pe(const Args &a) {
+    for (const char *k : {"vcfSim", "methylation", "readSysError", "writeSysError", "refBiasFile"})
+        if (a.has(k) && !a.get(k).empty()) {
+            ERR("--" << k << " is not supported yet in this build");
+            return 1;
+        }
+    int ref_bias_mode = 0;
+    if (a.has("refBias")) {
+        const std::string m = a.get("refBias");
+        if (m == "keep") ref_bias_mode = 0;
+        else if (m == "no") ref_bias_mode = 1;
+        else {
+            ERR("refBias '" << m << "' is not supported in this build (keep/no)");
+            return 1;
+        }
+    }
+    const std::string ref_path = a.has("refSim") ? a.get("refSim") : a.get("refIn");
+    if (ref_path.empty()) {
+        ERR("refIn or refSim option mandatory.");
+        return 1;
+    }
+    const std::string out1 = a.get("firstReadsOut", "reseq-R1.fq"), out2 = a.get("secondReadsOut", "reseq-R2.fq");      // main.cpp:404,412
+    rsq_profile *prof = nullptr;
+    rsq_ref *ref = nullptr;
+    rsq_sim *sim = nullptr;
+    bool ok = load_profile(a, &prof);
+    const uint64_t seed = ok ? get_seed(a) : 0;
+    if (ok) {
+        INFO("Reading reference from " << ref_path);
+        ok = check(rsq_ref_load_fasta(ref_path.c_str(), &ref), "Could not load reference") && check(rsq_ref_replace_n(ref, seed), "ReplaceN");
+    }
+    ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
+    if (ok) {
+        INFO("Preparing for simulation");
+        ok = check(rsq_sim_prepare(sim, seed, strtoull(a.get("numReads", "0").c_str(), nullptr, 10), atof(a.get("coverage", "0").c_str()), ref_bias_mode,
+                                   a.get("recordBaseIdentifier", "ReseqRead").c_str(), nullptr),
+                   "Preparation failed");
+    }
+    std::ofstream f1, f2;
+    if (ok) {
+        f1.open(out1, std::ios::binary);
+        f2.open(out2, std::ios::binary);
+        if (!f1 || !f2) {
+            ERR("Could not open '" << (f1 ? out2 : out1) << "' for writing.");
+            ok = false;
+        }
+    }
+    if (ok) {
+        rsq_sim_info info;
+        rsq_sim_get_info(sim, &info);
+        INFO("Aiming for " << info.total_pairs + info.adapter_only_pairs << " read pairs");
+        INFO("Starting read generation");
+        DevBuffer d1, d2;
+        std::vector<char> host;
+        uint64_t written = 0;
+        const uint32_t step = 2000;                          // 2 Mb of start positions per call
+        for (uint32_t lo = 1; ok && lo <= info.total_blocks; lo += step) {
+            const uint32_t hi = std::min(info.total_blocks + 1, lo + step);
+            size_t l1 = 0, l2 = 0;
+            uint64_t n = 0;
+            int rc = rsq_sim_pairs(sim, lo, hi, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, &n, nullptr, 0, nullptr);
+            if (rc == RSQ_ENOSPC) {
+                ok = d1.ensure(l1 + l1 / 8 + 4096) && d2.ensure(l2 + l2 / 8 + 4096);
+                if (ok) rc = rsq_sim_pairs(sim, lo, hi, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, &n, nullptr, 0, nullptr);
+            }
+            ok = ok && check(rc, "Simulation failed") && (n == 0 || flush_pair(d1, l1, d2, l2, host, f1, f2));
+            written += n;
+            if (ok && n) INFO("Generated " << written << " read pairs (" << (info.total_pairs ? (written * 100 + info.total_pairs / 2) / info.total_pairs : 0) << "%).");
+        }
+        for (uint64_t first = 0; ok && first < info.adapter_only_pairs; first += 100000) {       // Simulator.cpp:2359-2382
+            const uint64_t n = std::min<uint64_t>(100000, info.adapter_only_pairs - first);
+            size_t l1 = 0, l2 = 0;
+            int rc = rsq_sim_adapter_only_pairs(sim, first, n, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, nullptr);
+            if (rc == RSQ_ENOSPC) {
+                ok = d1.ensure(l1 + 4096) && d2.ensure(l2 + 4096);
+                if (ok) rc = rsq_sim_adapter_only_pairs(sim, first, n, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, nullptr);
+            }
+            ok = ok && check(rc, "Simulation of adapter-only pairs failed") && flush_pair(d1, l1, d2, l2, host, f1, f2);
+        }
+    }
+    f1.close();
+    f2.close();
+    rsq_sim_free(sim);
+    rsq_ref_free(ref);
+    rsq_profile_free(prof);
+    if (!ok) {                                               // Simulator.cpp:2888-2892: do not leave partial output behind
+        ERR("An error occurred in the process: Terminating simulation");
+        remove(out1.c_str());
+        remove(out2.c_str());
+        return 1;
+    }
+    INFO("Simulation finished succesfully");
+    return 0;
+}
+
+// one FASTA record of seqToIllumina's input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
+struct Record {
+    std::string id, seq, dom, rate;
+    uint8_t seg = 0;
+    uint32_t frag_len = 0;
+};
+
+bool parse_record(const std::string &header, const std::string &seq, Record &r) {
+    const size_t L = seq.size();
+    if (header.size() <= 2 * L + 2) {
+        ERR("Read description is too short to contain systematic error information and a sequence id: " << header);
+        return false;
+    }
+    size_t end = header.size() - 2 * L - 3;
+    if (header[end + 1] != ';' || header[end + 2 + L] != ';') {
+        ERR("The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " << header);
+        return false;
+    }
+    r.dom = header.substr(end + 2, L);
+    r.rate = header.substr(header.size() - L);
+    while (end && header[end] != ' ') --end;
+    if (!end) {
+        ERR("No sequence id found that is separated by a space from the ReSeq information: " << header);
+        return false;
+    }
+    r.id = header.substr(0, end);
+    if (header[end + 1] == '1') r.seg = 0;
+    else if (header[end + 1] == '2') r.seg = 1;
+    else {
+        ERR("Template segment is " << header[end + 1] << " not 1 or 2: " << header);
+        return false;
+    }
+    if (header[end + 2] != ';') {
+        ERR("The template segment and fragment length are not separated by a semicolon: " << header);
+        return false;
+    }
+    const std::string fl = header.substr(end + 3, header.size() - 2 * L - 2 - (end + 3));
+    char *stop = nullptr;
+    r.frag_len = (uint32_t)strtoul(fl.c_str(), &stop, 10);
+    if (fl.empty() || *stop) {
+        ERR("Fragment length '" << fl << "' is not a pure integer: " << header);
+        return false;
+    }
+    r.seq = seq;
+    return true;
+}
+
+int code_of(char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+bool run_batch(rsq_sim *sim, uint64_t first_index, const std::vector<Record> &recs, uint32_t max_read, uint8_t phred_unused, std::ostream &out) {
+    (void)phred_unused;
+    const size_t n = recs.size(), L = recs[0].seq.size();
+    std::vector<uint8_t> seqs(n * L), seg(n), dom(n * L), rate(n * L);
+    std::vector<uint32_t> fl(n);
+    for (size_t i = 0; i < n; ++i) {
+        seg[i] = recs[i].seg;
+        fl[i] = recs[i].frag_len;
+        for (size_t k = 0; k < L; ++k) {
+            const int b = code_of(recs[i].seq[k]);
+            if (b > 3) {
+                ERR("input sequences must not contain N: " << recs[i].id);
+                return false;
+            }
+            seqs[i * L + k] = (uint8_t)b;
+            dom[i * L + k] = (uint8_t)code_of(recs[i].dom[k]);
+            int r = (uint8_t)recs[i].rate[k] - 33;                     // Simulator.cpp:2439-2442
+            if (r > 86) r += r - 86;
+            rate[i * L + k] = (uint8_t)r;
+        }
+    }
+    const uint32_t stride = (max_read + 7u) & ~7u, cstride = 64 + 8 * max_read;
+    void *d[11] = {nullptr};
+    const size_t bytes[11] = {n * L, n, n * 4, n * L, n * L, n * stride, n * stride, n * 2, n * 2, n * 2, n * cstride};
+    bool ok = true;
+    for (int i = 0; ok && i < 11; ++i) ok = check(rsq_dev_alloc(0, bytes[i], &d[i]), "device allocation");
+    const void *src[5] = {seqs.data(), seg.data(), fl.data(), dom.data(), rate.data()};
+    for (int i = 0; ok && i < 5; ++i) ok = check(rsq_dev_upload(0, d[i], src[i], bytes[i]), "upload");
+    ok = ok && check(rsq_sim_error_model(sim, first_index, n, (uint32_t)L, (uint8_t *)d[0], (uint8_t *)d[1], (uint32_t *)d[2], (uint8_t *)d[3], (uint8_t *)d[4],
+                                         (uint8_t *)d[5], (uint8_t *)d[6], stride, (uint16_t *)d[7], (uint16_t *)d[8], (uint16_t *)d[9], (char *)d[10], cstride, nullptr),
+                     "Simulation failed");
+    std::vector<uint8_t> oseq(n * stride), oqual(n * stride);
+    std::vector<uint16_t> rlen(n), nerr(n);
+    std::vector<char> cig(n * cstride);
+    ok = ok && check(rsq_dev_download(0, oseq.data(), d[5], oseq.size()), "download") && check(rsq_dev_download(0, oqual.data(), d[6], oqual.size()), "download") &&
+         check(rsq_dev_download(0, rlen.data(), d[7], n * 2), "download") && check(rsq_dev_download(0, nerr.data(), d[8], n * 2), "download") &&
+         check(rsq_dev_download(0, cig.data(), d[10], cig.size()), "download");
+    for (int i = 0; i < 11; ++i)
+        if (d[i]) rsq_dev_free(0, d[i]);
+    if (!ok) return false;
+    std::string buf;
+    for (size_t i = 0; i < n; ++i) {                                   // Simulator.cpp:2497-2504: id + " {CIGAR} E{n}"
+        buf += '@';
+        buf += recs[i].id;
+        buf += ' ';
+        buf += &cig[i * cstride];
+        buf += " E";
+        buf += std::to_string(nerr[i]);
+        buf += '\n';
+        for (uint16_t k = 0; k < rlen[i]; ++k) buf += "ACGTN"[oseq[i * stride + k]];
+        buf += "\n+\n";
+        buf.append((const char *)&oqual[i * stride], rlen[i]);
+        buf += '\n';
+    }
+    out << buf;
+    return out.good();
+}
+
+int seq_to_illumina(const Args &a) {
+    rsq_profile *prof = nullptr;
+    rsq_sim *sim = nullptr;
+    bool ok = load_profile(a, &prof);
+    const uint64_t seed = ok ? get_seed(a) : 0;
+    ok = ok && check(rsq_sim_create(prof, nullptr, 0, &sim), "Could not set up the simulator") &&
+         check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
+    uint32_t max_read = 0;
+    if (ok) rsq_profile_max_read_length(prof, &max_read);
+    std::ifstream fin;
+    std::ofstream fout;
+    std::istream *in = &std::cin;
+    std::ostream *out = &std::cout;
+    if (ok && a.has("input")) {
+        fin.open(a.get("input"));
+        if (!fin) {
+            ERR("Could not open '" << a.get("input") << "' for reading.");
+            ok = false;
+        }
+        in = &fin;
+    }
+    if (ok && a.has("output")) {
+        fout.open(a.get("output"), std::ios::binary);
+        if (!fout) {
+            ERR("Could not open '" << a.get("output") << "' for writing.");
+            ok = false;
+        }
+        out = &fout;
+    }
+    if (ok) {
+        INFO("Starting read generation");
+        std::vector<Record> batch;
+        std::string line, header, seq;
+        uint64_t index = 0, first_index = 0, written = 0;
+        bool any = false;
+        auto flush = [&]() {
+            if (batch.empty()) return true;
+            const bool r = run_batch(sim, first_index, batch, max_read, 0, *out);
+            written += batch.size();
+            first_index += batch.size();
+            batch.clear();
+            if (r) INFO("Generated " << written << " reads.");
+            return r;
+        };
+        auto finish_record = [&]() {
+            if (header.empty()) return true;
+            Record r;
+            if (!parse_record(header, seq, r)) return false;
+            if (!batch.empty() && (batch[0].seq.size() != r.seq.size() || batch.size() >= 100000))       // one template length per launch
+                if (!flush()) return false;
+            batch.push_back(r);
+            ++index;
+            any = true;
+            return true;
+        };
+        while (ok && std::getline(*in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty() && line[0] == '>') {
+                ok = finish_record();
+                header = line.substr(1);
+                seq.clear();
+            } else seq += line;
+        }
+        ok = ok && finish_record() && flush();
+        if (ok && !any) {
+            ERR(a.get("input", "stdin") << " does not contain any sequences.");
+            ok = false;
+        }
+    }
+    fout.close();
+    rsq_sim_free(sim);
+    rsq_profile_free(prof);
+    if (!ok) {
+        ERR("An error occurred in the process: Terminating simulation");
+        if (a.has("output")) remove(a.get("output").c_str());
+        return 1;
+    }
+    INFO("Simulation finished succesfully");
+    return 0;
+}
+
+const char *kUsage =
+    "\nProgram: reseq (REal SEQuence replicator) -- MI355X simulation stage\n"
+    "Usage:  reseq <command> [options]\n"
+    "Commands:\n"
+    "  illuminaPE\t\tsimulates illumina paired-end data from a fitted profile (-s) and a reference (-R)\n"
+    "  seqToIllumina\t\tapplies illumina quality and error model to input sequences (alias: replaceQuals)\n"
+    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h\n";
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::string command;
+    int cmd_at = 0;
+    for (int i = 1; i < argc; ++i)
+        if (argv[i][0] != '-') {
+            command = argv[i];
+            cmd_at = i;
+            break;
+        } else if (!strcmp(argv[i], "-j") || !strcmp(argv[i], "--threads") || !strcmp(argv[i], "--verbosity")) ++i;
+    // general options may stand before or after the command
+    std::vector<char *> rest{argv[0]};
+    for (int i = 1; i < argc; ++i)
+        if (i != cmd_at) rest.push_back(argv[i]);
+    Args a;
+    if (!parse((int)rest.size(), rest.data(), 1, a)) return 1;
+    if (a.has("verbosity")) g_verbosity = atoi(a.get("verbosity").c_str());
+    if (a.has("version")) {
+        std::cerr << rsq_version() << " (stands in for ReSeq version 1.1 simulation stage)" << std::endl;
+        return 0;
+    }
+    if (command.empty() || a.has("help")) {
+        std::cerr << kUsage << std::endl;
+        return command.empty() && !a.has("help") ? 1 : 0;
+    }
+    if (command == "illuminaPE") return illumina_pe(a);
+    if (command == "seqToIllumina" || command == "replaceQuals") return seq_to_illumina(a);
+    if (command == "queryProfile" || command == "replaceN" || command == "test") {
+        ERR("command '" << command << "' is not part of this build (simulation stage only)");
+        return 1;
+    }
+    ERR("unknown command '" << command << "'");
+    std::cerr << kUsage << std::endl;
+    return 1;
+}

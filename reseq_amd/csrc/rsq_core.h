@@ -1,0 +1,427 @@
+// rsq_core.h -- the per-lane simulation arithmetic: Philox4x32-10 streams, LogArrayResult draws, 2-bit
+// reference access, Surrounding k-mers, fragment-count draws and the FillRead state machine.
+//
+// Design (DESIGN.md "Kernels"): ONE LANE PER READ.  Every draw is the reference's sequential double
+// precision recipe (ProbabilityEstimates.h:481-508) executed by a single lane, so sums and products are
+// formed in exactly the reference's order and results are bit-identical to the CPU oracle by construction;
+// a wave advances 64 independent reads per instruction instead of spending 64 lanes on one K<=41 draw.
+// Build with -ffp-contract=off: an FMA would change the rounding of `sum += a*b*c*d`.
+//
+// The functions are __host__ __device__ so that tests/hostemu can run the very same state machine on the
+// CPU against the oracle without a GPU.  The shipped library only ever calls them from kernels.
+#pragma once
+#include <math.h>
+
+#include "rsq_types.h"
+
+namespace rsq {
+
+// ------------------------------------------------------------------------------------------- Philox
+struct Words {
+    uint32_t w0, w1, w2, w3;
+};
+
+RSQ_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// Philox4x32-10 (Salmon et al., SC11); key = seed, counter = (c0,c1,c2,c3).
+RSQ_HD Words philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Words{c0, c1, c2, c3};
+}
+
+RSQ_HD double u32_to_unit(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+RSQ_HD double u53_to_unit(uint32_t hi, uint32_t lo) {
+    uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Identity of one read's random stream: counter words c0..c2 and the tag/segment bits of c3.
+struct Stream {
+    uint64_t seed;
+    uint32_t c0, c1, c2, c3base;
+    RSQ_HD Words step(uint32_t s) const { return philox(seed, c0, c1, c2, c3base | s); }
+};
+RSQ_HD uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel) { return (dom << 28) | (strand << 27) | (segsel << 25); }
+
+// ------------------------------------------------------------------------- integer helpers (utilities.hpp)
+RSQ_HD bool is_gc(uint32_t b) { return b == 1 || b == 2; }
+RSQ_HD uint32_t divide_u32(uint32_t nom, uint32_t den) { return (nom + den / 2u) / den; }          // :450-452
+RSQ_HD uint32_t percent_u16(uint32_t nom, uint32_t den) {                                            // :552-554, T = uint16_t
+    uint32_t n100 = (nom * 100u) & 0xFFFFu;
+    return (((n100 + den / 2u) / den) & 0xFFFFu) & 0xFFu;
+}
+RSQ_HD uint32_t percent_u32(uint32_t nom, uint32_t den) { return ((nom * 100u + den / 2u) / den) & 0xFFu; }
+RSQ_HD uint32_t safe_percent_u16(uint32_t nom, uint32_t den) { return den ? percent_u16(nom, den) : 50u; }  // :566-573
+RSQ_HD uint32_t transform_distance(uint32_t d) { return (d + 9u) / 10u; }                           // :593-595
+
+// first cumulative probability strictly above u (inverse CDF of the reference's std::discrete_distribution draws)
+RSQ_HD uint32_t discrete_draw(const double *cp, uint32_t n, double u) {
+    if (n < 2) return 0;
+    uint32_t i = 0;
+    while (i + 1 < n && !(cp[i] > u)) ++i;
+    return i;
+}
+
+// --------------------------------------------------------------------------- LogArrayResult<N>::Draw
+// ProbabilityEstimates.h:359-380 (Likelihood, AdjustIndeces) and :481-508 (Draw).  Two passes over the K
+// outcome columns: pass 1 forms prob_sum in ascending order, pass 2 re-forms the same products from the
+// top until the running sum exceeds u*prob_sum.  Nothing is kept between the passes, so K is unbounded and
+// the lane needs no per-outcome registers.
+template <int NM>
+RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, const uint8_t *__restrict__ par0, const uint32_t (&idx)[NM], double u,
+                     double &prob_sum) {
+    prob_sum = 0.0;
+    const uint32_t K = t.k;
+    if (!K) return 0;
+    const double *m[NM];
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+        uint32_t r = idx[n] < t.from[n] ? 0u : (idx[n] - t.from[n] >= t.rows[n] ? t.rows[n] - 1u : idx[n] - t.from[n]);
+        m[n] = pool + t.off[n] + (size_t)r * K;
+    }
+    double s = 0.0;
+    for (uint32_t k = 0; k < K; ++k) {
+        double p = m[0][k];
+#pragma unroll
+        for (int n = 1; n < NM; ++n) p *= m[n][k];
+        s += p;
+    }
+    prob_sum = s;
+    const double r = u * s;
+    double sum = 0.0;
+    uint32_t k = K;
+    while (sum <= r && --k) {
+        double p = m[0][k];
+#pragma unroll
+        for (int n = 1; n < NM; ++n) p *= m[n][k];
+        sum += p;
+    }
+    return par0[t.par0_off + k];
+}
+
+// ------------------------------------------------------------------------------- 2-bit reference access
+RSQ_HD uint32_t ref_base(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t pos) {
+    return (uint32_t)(words[word_off + (pos >> 5)] >> ((pos & 31u) * 2u)) & 3u;
+}
+// number of G/C in [a,b): a base is G/C iff its two bits differ
+RSQ_HD uint32_t ref_gc_count(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t a, uint32_t b) {
+    uint32_t gc = 0;
+    const uint64_t kLow = 0x5555555555555555ull;
+    for (uint32_t w = a >> 5; w <= ((b - 1) >> 5) && a < b; ++w) {
+        uint64_t x = words[word_off + w];
+        uint64_t g = (x ^ (x >> 1)) & kLow;
+        uint32_t lo = w == (a >> 5) ? (a & 31u) : 0u;
+        uint32_t hi = w == ((b - 1) >> 5) ? ((b - 1) & 31u) + 1u : 32u;
+        if (lo) g &= ~0ull << (2u * lo);
+        if (hi < 32u) g &= (1ull << (2u * hi)) - 1ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+        gc += (uint32_t)__popcll(g);
+#else
+        gc += (uint32_t)__builtin_popcountll(g);
+#endif
+    }
+    return gc;
+}
+
+// ----------------------------------------------------------------------------------------- Surrounding
+// SurroundingBase.hpp:64-81,196-202: block b of the start surrounding is the 10-mer ref[pos-10+10b ..), wrapping
+// around the sequence ends; the end surrounding is taken on the reverse complement at position L-1-pos.
+RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
+    uint64_t p = (uint64_t)pos + L - kSurStart;
+#pragma unroll
+    for (uint32_t b = 0; b < kSurBlocks; ++b) {
+        uint32_t v = 0;
+        for (uint32_t i = 0; i < kSurRange; ++i) v = (v << 2) + ref_base(words, word_off, (uint32_t)((p + b * kSurRange + i) % L));
+        sur[b] = v;
+    }
+}
+RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
+    uint64_t p = (uint64_t)(L - pos - 1) + L - kSurStart;
+#pragma unroll
+    for (uint32_t b = 0; b < kSurBlocks; ++b) {
+        uint32_t v = 0;
+        for (uint32_t i = 0; i < kSurRange; ++i) v = (v << 2) + (3u - ref_base(words, word_off, L - 1u - (uint32_t)((p + b * kSurRange + i) % L)));
+        sur[b] = v;
+    }
+}
+// Surrounding.h:114-120 (blocks summed last to first) and utilities.hpp:505 InvLogit2
+RSQ_HD double surrounding_bias(const double *__restrict__ sur_bias, const uint32_t (&sur)[3]) {
+    double bias = 0.0;
+    for (int b = (int)kSurBlocks; b--;) bias += sur_bias[(size_t)b * kSurSize + sur[b]];
+    return 2 / (1 + exp(-bias));
+}
+
+// ---------------------------------------------------------------------------- fragment-count arithmetic
+RSQ_HD double get_dispersion(double bias, double a, double b) {        // FragmentDistributionStats.cpp:900-907
+    double r = bias / (a + b * bias);
+    if (r > bias * 1e10) r = bias * 1e10;
+    return r;
+}
+RSQ_HD uint32_t binomial(uint32_t n, double p, double probability_chosen) {     // :3584-3596
+    double probability_count = pow(1 - p, (double)n), probability_left = probability_chosen - probability_count;
+    uint32_t count = 0;
+    while (0.0 < probability_left && count < n) {
+        ++count;
+        probability_count *= (double)(n + 1 - count) / count * p / (1 - p);
+        probability_left -= probability_count;
+    }
+    return count;
+}
+RSQ_HD uint32_t negative_binomial(double p, double r, double probability_chosen) {   // :3602-3613 (uintDupCount wraps at 2^16)
+    double probability_count = pow(1 - p, r), probability_left = probability_chosen - probability_count;
+    uint32_t count = 0;
+    while (0.0 < probability_left) {
+        count = (count + 1u) & 0xFFFFu;
+        probability_count *= p * ((r - 1) / count + 1);
+        probability_left -= probability_count;
+    }
+    return count;
+}
+// :3615-3627 GetFragmentCounts with Reference::Bias (Reference.h:167-169,283-285)
+RSQ_HD uint32_t fragment_counts(const DevSim &S, uint32_t seq, uint32_t fragment_length, uint32_t gc, const uint32_t (&sur_start)[3],
+                                const uint32_t (&sur_end)[3], double probability_chosen) {
+    double general = S.ref_seq_bias[seq] * S.insert_lengths_bias[fragment_length];
+    double bias = general * S.gc_bias[gc] * surrounding_bias(S.sur_bias, sur_start) * surrounding_bias(S.sur_bias, sur_end);
+    if (0.0 < bias) {
+        double mean = bias * S.bias_normalization;
+        double dispersion = get_dispersion(mean, S.dispersion[0], S.dispersion[1]) / 1;
+        mean /= 1;
+        return negative_binomial(mean / (mean + dispersion), dispersion, probability_chosen);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- FillRead state machine
+// Simulator.cpp:454-594 (FillRead), :294-452 (FillReadPart), :240-292 (GetSysErrorFromBlock, no variants),
+// Simulator.h:185-198 (ReadLength).
+//
+// Src: org_len(), base(k) in 0..3, sys(k) = dom | rate<<8 of the k-th template base.
+// Out: put(read_pos, base_code, qual_char), op(iteration, code) with code 0 = template base, 1 = deletion, 2 = insertion.
+// Random stream steps: 0 = {read length, adapter (adapter-only read), sequence quality, adapter start cut},
+// 1 = {poly-A tail length, adapter}, 2+t = t-th state-machine iteration {indel, quality, base call, overrun base}.
+
+RSQ_HD uint32_t digits10(uint32_t v) { return v < 10 ? 1u : v < 100 ? 2u : v < 1000 ? 3u : v < 10000 ? 4u : 5u; }
+
+struct CigarRun {                      // the RLE bookkeeping of FillReadPart (Simulator.cpp:311-312,358-368,398-408,428-438,447-449)
+    char element;
+    uint32_t length;
+    uint32_t chars;                    // characters of the CIGAR string so far
+    RSQ_HD void flush() { chars += digits10(length) + 1u; }
+};
+
+struct FillState {                     // Simulator.h:215-240 ReadFillParameter
+    uint32_t read_length, read_pos;
+    uint32_t previous_indel_type, indel_pos, base_call, gc_seq;
+    uint32_t seq_qual, qual, error_rate, num_errors;
+    uint32_t last_written_qual;        // at(sim_read.qual_, read_pos-1) - offset
+    uint32_t iteration;
+};
+
+template <class Src, class Out>
+RSQ_HD void fill_read_part(const DevSim &S, const Stream &st, uint32_t seg, uint32_t tile_id, const Src &src, uint32_t org_len, uint32_t org_pos, char base_element,
+                           FillState &par, CigarRun &cg, Out &out) {
+    // Without variants the block walk of GetSysErrorFromBlock advances in step with org_pos (one systematic
+    // error per consumed template base), so src.sys() is indexed by org_pos for templates and adapters alike.
+    cg.element = base_element;
+    cg.length = 0;
+    const uint32_t tbase = (seg * S.n_tiles + tile_id) * 4u;
+    while (par.read_pos < par.read_length && org_pos < org_len) {
+        const uint32_t it = par.iteration++;
+        const Words w = st.step(2u + it);
+        double prob_sum;
+        const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
+        uint32_t indel = draw<3>(S.indels[par.previous_indel_type * 6u + par.base_call], S.pool, S.par0, idx_i, u32_to_unit(w.w0), prob_sum);
+        if (0.0 == prob_sum) indel = 0;
+        const uint32_t org_base = src.base(org_pos);
+        const DevTable &qt = S.quality[tbase + org_base];
+        if (0 == indel) {
+            const uint32_t se = src.sys(org_pos);
+            const uint32_t dom_error = se & 0xFFu;
+            par.error_rate = se >> 8;
+            const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+            uint32_t q = draw<4>(qt, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
+            if (0.0 == prob_sum) q = par.read_pos ? par.last_written_qual : qt.max_value;
+            par.qual = q;
+            const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
+            uint32_t call = draw<4>(S.base_call[(tbase + org_base) * 5u + dom_error], S.pool, S.par0, idx_b, u32_to_unit(w.w2), prob_sum);
+            if (0.0 == prob_sum) call = org_base;
+            par.base_call = call;
+            out.put(par.read_pos, call, q + S.phred_offset);
+            par.last_written_qual = q;
+            out.op(it, 0u);
+            if (base_element == cg.element) ++cg.length;
+            else {
+                cg.flush();
+                cg.element = base_element;
+                cg.length = 1;
+                par.indel_pos = 0;
+                par.previous_indel_type = 0;
+            }
+            if (call != org_base) ++par.num_errors;
+            ++par.read_pos;
+            ++org_pos;
+        } else if (1 == indel) {                                   // ErrorStats::kDeletion
+            par.error_rate = src.sys(org_pos) >> 8;
+            out.op(it, 1u);
+            if ('D' == cg.element) {
+                ++cg.length;
+                ++par.indel_pos;
+            } else {
+                cg.flush();
+                cg.element = 'D';
+                cg.length = 1;
+                par.indel_pos = 1;
+                par.previous_indel_type = 1;
+            }
+            ++par.num_errors;
+            ++org_pos;
+        } else {                                                   // insertion of base indel-2
+            const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+            uint32_t q = draw<4>(qt, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
+            if (0.0 == prob_sum) q = par.qual;
+            out.put(par.read_pos, indel - 2u, q + S.phred_offset);
+            par.last_written_qual = q;
+            out.op(it, 2u);
+            if ('I' == cg.element) {
+                ++cg.length;
+                ++par.indel_pos;
+            } else {
+                cg.flush();
+                cg.element = 'I';
+                cg.length = 1;
+                par.indel_pos = 1;
+                par.previous_indel_type = 0;
+            }
+            ++par.num_errors;
+            ++par.read_pos;
+        }
+    }
+    if (cg.length) cg.flush();
+}
+
+RSQ_HD uint32_t draw_read_length(const DevSim &S, uint32_t seg, uint32_t fragment_length, double u) {   // Simulator.h:185-198
+    const DevReadLengths &rl = S.read_lengths[seg];
+    if (rl.fixed) return rl.fixed;
+    const double random_value = u * (double)S.insert_lengths[fragment_length];
+    double counter = 0.0;
+    const uint32_t row = fragment_length - rl.row_first;
+    const uint32_t from = rl.row_from[row] & 0xFFFFu;
+    uint32_t read_len = (from + (rl.row_ptr[row + 1] - rl.row_ptr[row])) & 0xFFFFu;
+    while (counter <= random_value) {
+        const bool more = read_len > from;
+        read_len = (read_len - 1u) & 0xFFFFu;                      // uintReadLen post-decrement (wraps like the reference)
+        if (!more) break;
+        counter += (double)rl.values[rl.row_ptr[row] + (read_len - from)];
+    }
+    return read_len;
+}
+
+struct AdapterSrc {                    // the adapter as template of FillReadPart(..., 'S', NULL, ...)
+    const uint8_t *seq;
+    const uint16_t *sys_;
+    RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
+    RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+};
+
+template <class Src, class Out>
+RSQ_HD void fill_read(const DevSim &S, const Stream &st, uint32_t seg, uint32_t tile_id, uint32_t fragment_length, const Src &src, Out &out, ReadMeta &meta) {
+    FillState par;
+    par.read_pos = 0;
+    par.previous_indel_type = 0;
+    par.indel_pos = 0;
+    par.base_call = 5;
+    par.gc_seq = 0;
+    par.qual = 1;
+    par.error_rate = 0;
+    par.num_errors = 0;
+    par.last_written_qual = 0;
+    par.iteration = 0;
+    const Words h0 = st.step(0);
+    par.read_length = draw_read_length(S, seg, fragment_length, u32_to_unit(h0.w0));
+    const DevAdapters &ad = S.adapters[seg];
+    const uint32_t org_len = src.org_len();
+    uint32_t adapter_id = 0;
+    const uint32_t seq_length = par.read_length < org_len ? par.read_length : org_len;
+    uint32_t mean_error_rate = 0;
+    if (seq_length) {                                              // Simulator.cpp:480-504
+        for (uint32_t k = 0; k < seq_length; ++k) {
+            if (is_gc(src.base(k))) ++par.gc_seq;
+            mean_error_rate += src.sys(k) >> 8;
+        }
+        par.gc_seq = percent_u16(par.gc_seq, seq_length);
+        mean_error_rate = divide_u32(mean_error_rate, seq_length);
+    } else {                                                       // adapter-only read :505-522
+        adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h0.w1));
+        const uint32_t a0 = ad.seq_ptr[adapter_id], alen = ad.seq_ptr[adapter_id + 1] - a0;
+        for (uint32_t k = 0; k < alen; ++k) {
+            if (is_gc(ad.seqs[a0 + k])) ++par.gc_seq;
+            mean_error_rate += ad.sys[a0 + k] >> 8;
+        }
+        par.gc_seq = percent_u16(par.gc_seq, alen & 0xFFFFu);
+        mean_error_rate = divide_u32(mean_error_rate, alen);
+    }
+    double prob_sum;
+    const DevTable &sqt = S.seq_quality[seg * S.n_tiles + tile_id];
+    const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
+    par.seq_qual = draw<3>(sqt, S.pool, S.par0, idx_sq, u32_to_unit(h0.w2), prob_sum);
+    if (0.0 == prob_sum) par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;       // MostLikely(), ProbabilityEstimates.h:519-526
+
+    CigarRun cg{'M', 0, 0};
+    fill_read_part(S, st, seg, tile_id, src, org_len, 0u, 'M', par, cg, out);
+    const uint32_t iter_m = par.iteration;
+    uint32_t hard_clip = 0;
+    if (par.read_pos < par.read_length) {                           // :537-589
+        const Words h1 = st.step(1);
+        if (0 == adapter_id) adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h1.w1));
+        uint32_t adapter_pos = 0;
+        if (0 == par.read_pos)
+            adapter_pos = discrete_draw(ad.cut_cp + ad.cut_ptr[adapter_id], ad.cut_ptr[adapter_id + 1] - ad.cut_ptr[adapter_id], u32_to_unit(h0.w3)) +
+                          ad.cut_from[adapter_id];
+        const uint32_t a0 = ad.seq_ptr[adapter_id];
+        AdapterSrc asrc{ad.seqs + a0, ad.sys + a0};
+        fill_read_part(S, st, seg, tile_id, asrc, ad.seq_ptr[adapter_id + 1] - a0, adapter_pos, 'S', par, cg, out);
+        if (par.read_pos < par.read_length) {
+            hard_clip = par.read_length - par.read_pos;
+            cg.chars += digits10(hard_clip) + 1u;
+            const DevTable &q0 = S.quality[(seg * S.n_tiles + tile_id) * 4u];
+            const uint32_t tail_length = discrete_draw(S.polya_cp, S.polya_n, u32_to_unit(h1.w0)) + S.polya_from;
+            for (uint32_t pos_tail = 0; par.read_pos < par.read_length; ++pos_tail) {
+                const Words w = st.step(2u + par.iteration++);
+                const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+                uint32_t q = draw<4>(q0, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
+                if (0.0 == prob_sum && par.read_pos) q = par.last_written_qual;   // at(qual_, read_pos-1) - offset
+                par.qual = q;
+                const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
+                out.put(par.read_pos, b, q + S.phred_offset);
+                par.last_written_qual = q;
+                ++par.read_pos;
+            }
+        }
+    }
+    meta.read_len = (uint16_t)par.read_length;
+    meta.num_errors = (uint16_t)par.num_errors;
+    meta.n_iter_m = (uint16_t)iter_m;
+    meta.n_iter_s = (uint16_t)(par.iteration - iter_m - hard_clip);   // every tail iteration emits exactly one base
+    meta.hard_clip = (uint16_t)hard_clip;
+    meta.tile_id = (uint16_t)tile_id;
+    meta.cigar_chars = cg.chars;
+}
+
+}  // namespace rsq

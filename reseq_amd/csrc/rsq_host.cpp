@@ -1,0 +1,268 @@
+// rsq_host.cpp -- RSQP container reader, profile loading and post-load edits, FASTA reader.
+#include "rsq_host.h"
+
+#include <string.h>
+
+#include <fstream>
+
+#include "rsq_core.h"
+
+namespace rsq {
+
+// ---------------------------------------------------------------------------------------------- container
+static size_t pad8(size_t n) { return (8 - (n & 7)) & 7; }
+
+Container::Container(const std::string &path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw Error("cannot open profile '" + path + "'");
+    std::streamsize sz = f.tellg();
+    f.seekg(0);
+    buf_.resize((size_t)sz);
+    if (!f.read(reinterpret_cast<char *>(buf_.data()), sz)) throw Error("cannot read profile '" + path + "'");
+    if (buf_.size() < 16 || memcmp(buf_.data(), "RSQPROF1", 8) != 0) throw Error("'" + path + "' is not an RSQP profile container");
+    uint32_t version, n;
+    memcpy(&version, &buf_[8], 4);
+    memcpy(&n, &buf_[12], 4);
+    if (version != 1) throw Error("unsupported RSQP version");
+    static const size_t kSize[7] = {1, 2, 4, 8, 4, 8, 8};
+    size_t pos = 16;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pos + 4 > buf_.size()) throw Error("truncated RSQP container");
+        uint16_t ln;
+        memcpy(&ln, &buf_[pos], 2);
+        std::string name(reinterpret_cast<const char *>(&buf_[pos + 2]), ln);
+        Array a;
+        a.dtype = buf_[pos + 2 + ln];
+        int ndim = buf_[pos + 3 + ln];
+        if (a.dtype > 6 || ndim > 4) throw Error("corrupt RSQP container");
+        size_t head = (size_t)ln + 4;
+        pos += head + pad8(head);
+        a.count = 1;
+        for (int d = 0; d < ndim; ++d) {
+            uint64_t dim;
+            memcpy(&dim, &buf_[pos], 8);
+            a.dims.push_back(dim);
+            a.count *= dim;
+            pos += 8;
+        }
+        size_t nbytes = a.count * kSize[a.dtype];
+        if (pos + nbytes > buf_.size()) throw Error("truncated RSQP container");
+        a.data = &buf_[pos];
+        pos += nbytes + pad8(nbytes);
+        arrays_[name] = a;
+    }
+}
+
+const Array &Container::get(const std::string &name) const {
+    auto it = arrays_.find(name);
+    if (it == arrays_.end()) throw Error("profile misses array '" + name + "'");
+    return it->second;
+}
+
+// ------------------------------------------------------------------------------------------------ profile
+std::vector<double> discrete_cp(const uint64_t *w, size_t n) {
+    std::vector<double> cp(n ? n : 1, 1.0);
+    if (n < 2) return cp;
+    double sum = 0.0;
+    for (size_t i = 0; i < n; ++i) sum += (double)w[i];
+    double acc = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        acc += (double)w[i] / sum;
+        cp[i] = acc;
+    }
+    cp[n - 1] = 1.0;
+    return cp;
+}
+
+void HostTable::modify_par0(uint32_t par0_index, double multiplier) {
+    size_t col = 0;
+    while (col < par0.size() && par0[col] != par0_index) ++col;
+    if (col >= par0.size()) return;
+    for (size_t i = col; i < dim2[0].size(); i += par0.size()) dim2[0][i] *= multiplier;
+}
+
+void HostTable::set_par0(uint32_t par0_index) {
+    par0.assign(1, par0_index);
+    for (uint32_t n = 0; n < nm; ++n) dim2[n].assign(to[n] - from[n], 1.0);
+}
+
+template <class T>
+static Vect<T> load_vect(const Container &c, const std::string &name, int dtype) {
+    Vect<T> v;
+    v.v = c.vec<T>(name, dtype);
+    v.from = c.scalar<uint64_t>(name + ".from", 3);
+    return v;
+}
+
+static HostTable load_table(const Container &c, const std::string &prefix, uint32_t nm) {
+    HostTable t;
+    t.nm = nm;
+    t.par0 = c.vec<uint32_t>("tab." + prefix + ".par0", 2);
+    std::vector<uint32_t> lim = c.vec<uint32_t>("tab." + prefix + ".limits", 2);
+    std::vector<double> d = c.vec<double>("tab." + prefix + ".dim2", 6);
+    if (lim.size() != 2 * (size_t)nm) throw Error("table '" + prefix + "': wrong number of limits");
+    size_t pos = 0;
+    for (uint32_t n = 0; n < nm; ++n) {
+        t.from[n] = lim[2 * n];
+        t.to[n] = lim[2 * n + 1];
+        if (t.to[n] < t.from[n]) throw Error("table '" + prefix + "': inverted limits");
+        size_t cnt = t.par0.empty() ? 0 : (size_t)(t.to[n] - t.from[n]) * t.par0.size();
+        if (pos + cnt > d.size()) throw Error("table '" + prefix + "': dim2 too short");
+        t.dim2[n].assign(d.begin() + pos, d.begin() + pos + cnt);
+        pos += cnt;
+    }
+    for (uint32_t v : t.par0)
+        if (v > 255) throw Error("table '" + prefix + "': outcome value above 255");
+    return t;
+}
+
+Profile Profile::load(const std::string &path) {
+    Container c(path);
+    Profile p;
+    p.phred_offset = c.scalar<uint8_t>("phred_quality_offset", 0);
+    p.corrected_coverage = c.scalar<double>("corrected_coverage", 6);
+    p.max_len_deletion = c.scalar<uint16_t>("errors.max_len_deletion", 1);
+    p.reset_distance = c.scalar<uint32_t>("coverage.reset_distance", 2);
+    for (int seg = 0; seg < 2; ++seg) {
+        const std::string s = std::to_string(seg);
+        p.read_lengths[seg] = load_vect<uint64_t>(c, "read_lengths." + s, 3);
+        for (uint64_t x : p.read_lengths[seg].v) p.total_number_reads += x;       // DataStats.cpp:698-700
+        HostRlByFl &r = p.rl_by_fl[seg];
+        r.from = c.scalar<uint64_t>("rl_by_fl." + s + ".from", 3);
+        r.row_ptr = c.vec<uint32_t>("rl_by_fl." + s + ".row_ptr", 2);
+        r.row_from = c.vec<uint32_t>("rl_by_fl." + s + ".row_from", 2);
+        r.values = c.vec<uint64_t>("rl_by_fl." + s + ".values", 3);
+        if (c.has("rl_by_fl_nonmapped." + s + ".values")) r.non_mapped = c.vec<uint64_t>("rl_by_fl_nonmapped." + s + ".values", 3);
+        else r.non_mapped.assign(r.values.size(), 0);
+        HostAdapters &a = p.adapters[seg];
+        a.seqs = c.vec<uint8_t>("adapters." + s + ".seqs", 0);
+        a.seq_ptr = c.vec<uint32_t>("adapters." + s + ".seq_ptr", 2);
+        a.counts = c.vec<uint64_t>("adapters." + s + ".counts", 3);
+        a.significant = c.vec<uint64_t>("adapters." + s + ".significant_counts", 3);
+        a.cut_ptr = c.vec<uint32_t>("adapters." + s + ".start_cut_ptr", 2);
+        a.cut_from = c.vec<uint32_t>("adapters." + s + ".start_cut_from", 2);
+        a.cut = c.vec<uint64_t>("adapters." + s + ".start_cut", 3);
+        if (a.seq_ptr.empty() || a.counts.size() != a.n() || a.significant.size() != a.n() || a.cut_ptr.size() != a.seq_ptr.size())
+            throw Error("inconsistent adapter arrays");
+        for (uint8_t b : a.seqs)
+            if (b > 3) throw Error("adapter sequences must not contain N");
+    }
+    p.tiles = c.vec<uint16_t>("tiles.tiles", 1);
+    p.tile_abundance = c.vec<uint64_t>("tiles.abundance", 3);
+    if (p.tiles.empty() || p.tiles.size() != p.tile_abundance.size()) throw Error("inconsistent tile arrays");
+    p.polya = load_vect<uint64_t>(c, "adapters.polya_tail_length", 3);
+    std::vector<uint64_t> ob = c.vec<uint64_t>("adapters.overrun_bases", 3);
+    for (int i = 0; i < 5; ++i) p.overrun_bases[i] = ob.at(i);
+    p.insert_lengths = load_vect<uint64_t>(c, "frag.insert_lengths", 3);
+    p.insert_lengths_bias = load_vect<double>(c, "frag.insert_lengths_bias", 6);
+    p.gc_bias = load_vect<double>(c, "frag.gc_bias", 6);
+    p.sur_bias = c.vec<double>("frag.sur_bias", 6);
+    if (p.sur_bias.size() != (size_t)kSurBlocks * kSurSize) throw Error("frag.sur_bias must hold 3 x 4^10 values");
+    std::vector<double> disp = c.vec<double>("frag.dispersion_parameters", 6);
+    p.dispersion[0] = disp.at(0);
+    p.dispersion[1] = disp.at(1);
+    p.ref_seq_bias = c.vec<double>("frag.ref_seq_bias", 6);
+
+    const uint32_t nt = p.n_tiles();
+    for (uint32_t seg = 0; seg < 2; ++seg)
+        for (uint32_t tile = 0; tile < nt; ++tile) {
+            const std::string st = std::to_string(seg) + "." + std::to_string(tile);
+            p.seq_quality.push_back(load_table(c, "seq_quality." + st, 3));
+            for (uint32_t base = 0; base < 4; ++base) {
+                p.quality.push_back(load_table(c, "quality." + st + "." + std::to_string(base), 4));
+                for (uint32_t dom = 0; dom < 5; ++dom) p.base_call.push_back(load_table(c, "base_call." + st + "." + std::to_string(base) + "." + std::to_string(dom), 4));
+            }
+        }
+    for (uint32_t base = 0; base < 4; ++base)
+        for (uint32_t x = 0; x < 5; ++x)
+            for (uint32_t y = 0; y < 5; ++y)
+                p.dom_error.push_back(load_table(c, "dom_error." + std::to_string(base) + "." + std::to_string(x) + "." + std::to_string(y), 3));
+    for (uint32_t base = 0; base < 4; ++base)
+        for (uint32_t x = 0; x < 5; ++x) p.error_rate.push_back(load_table(c, "error_rate." + std::to_string(base) + "." + std::to_string(x), 3));
+    for (uint32_t type = 0; type < 2; ++type)
+        for (uint32_t call = 0; call < 6; ++call) p.indels.push_back(load_table(c, "indels." + std::to_string(type) + "." + std::to_string(call), 3));
+    return p;
+}
+
+void Profile::change_error_rate(double multiplier) {
+    for (size_t i = 0; i < base_call.size(); ++i) base_call[i].modify_par0((uint32_t)((i / 5) % 4), 1.0 / multiplier);
+}
+void Profile::remove_substitution_errors() {
+    for (size_t i = 0; i < base_call.size(); ++i) base_call[i].set_par0((uint32_t)((i / 5) % 4));
+}
+void Profile::remove_indel_errors() {
+    for (HostTable &t : indels) t.set_par0(0);
+}
+
+// ---------------------------------------------------------------------------------------------- reference
+Reference Reference::read_fasta(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error("Could not open " + path + " for reading.");
+    uint8_t lut[256];
+    memset(lut, 4, sizeof lut);                // every IUPAC code that is not ACGT becomes N (IupacString -> Dna5String)
+    const char *acgt = "ACGT";
+    for (int i = 0; i < 4; ++i) {
+        lut[(uint8_t)acgt[i]] = (uint8_t)i;
+        lut[(uint8_t)(acgt[i] + 32)] = (uint8_t)i;
+    }
+    lut[(uint8_t)'U'] = lut[(uint8_t)'u'] = 3;
+    Reference r;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            r.names.push_back(line.substr(1));
+            r.codes.emplace_back();
+        } else {
+            if (r.codes.empty()) throw Error(path + " does not start with a FASTA header");
+            std::vector<uint8_t> &c = r.codes.back();
+            for (char ch : line)
+                if (ch != ' ' && ch != '\t') c.push_back(lut[(uint8_t)ch]);
+        }
+    }
+    if (r.codes.empty()) throw Error(path + " does not contain any reference sequences.");
+    for (const auto &c : r.codes)
+        if (c.size() > 0xFFFFFFFFull) throw Error("reference sequence longer than 2^32-1 bases");
+    return r;
+}
+
+bool Reference::has_n() const {
+    for (const auto &c : codes)
+        for (uint8_t b : c)
+            if (b > 3) return true;
+    return false;
+}
+
+uint64_t Reference::total_size() const {
+    uint64_t s = 0;
+    for (const auto &c : codes) s += c.size();
+    return s;
+}
+
+std::string Reference::first_part(size_t i) const {
+    const std::string &n = names.at(i);
+    return n.substr(0, n.find(' '));
+}
+
+// Reference.cpp:813-: N's are replaced so that every simulation from a position sees the same base.  The random
+// source is Philox keyed by (seed, sequence, position) instead of one mt19937_64 stream.  Stretches of at least
+// kMinNToReplaceNWithRepeat (100) N, which the reference fills with a 4-base repeat, are rejected for now.
+void Reference::replace_n(uint64_t seed) {
+    for (size_t s = 0; s < codes.size(); ++s) {
+        std::vector<uint8_t> &c = codes[s];
+        for (size_t start = 0; start < c.size();) {
+            if (c[start] <= 3) {
+                ++start;
+                continue;
+            }
+            size_t end = start;
+            while (++end < c.size() && c[end] > 3) {}
+            if (end - start >= 100) throw Error("reference contains a stretch of >= 100 N; run `reseq replaceN` of the reference tool first");
+            for (size_t pos = start; pos < end; ++pos) c[pos] = (uint8_t)(philox(seed, (uint32_t)pos, (uint32_t)s, 0, kDomReplaceN << 28).w0 & 3u);
+            start = end;
+        }
+    }
+}
+
+}  // namespace rsq

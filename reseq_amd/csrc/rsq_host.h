@@ -1,0 +1,121 @@
+// rsq_host.h -- host-side objects: RSQP container, profile (DataStats + ProbabilityEstimates subset the
+// simulation consumes, SURVEY.md section 8(a) row "in"), reference sequences.  No device code here.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace rsq {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------------------------------------- container
+struct Array {
+    int dtype = 0;   // 0 u8, 1 u16, 2 u32, 3 u64, 4 i32, 5 i64, 6 f64
+    std::vector<uint64_t> dims;
+    uint64_t count = 0;
+    const uint8_t *data = nullptr;
+};
+
+class Container {
+   public:
+    explicit Container(const std::string &path);
+    const Array &get(const std::string &name) const;
+    bool has(const std::string &name) const { return arrays_.count(name) != 0; }
+    template <class T>
+    std::vector<T> vec(const std::string &name, int dtype) const {
+        const Array &a = get(name);
+        if (a.dtype != dtype) throw Error("profile array '" + name + "' has the wrong type");
+        const T *p = reinterpret_cast<const T *>(a.data);
+        return std::vector<T>(p, p + a.count);
+    }
+    template <class T>
+    T scalar(const std::string &name, int dtype) const {
+        return vec<T>(name, dtype).at(0);
+    }
+
+   private:
+    std::vector<uint8_t> buf_;
+    std::map<std::string, Array> arrays_;
+};
+
+// ------------------------------------------------------------------------------------------------ profile
+template <class T>
+struct Vect {                       // reseq::Vect<T> (Vect.hpp): values with an offset; operator[] is 0 outside
+    uint64_t from = 0;
+    std::vector<T> v;
+    uint64_t to() const { return from + v.size(); }
+    T operator[](uint64_t i) const { return (i < from || i >= to()) ? T(0) : v[i - from]; }
+};
+
+struct HostTable {                  // LogArrayResult<N> (ProbabilityEstimates.h:351-357)
+    uint32_t nm = 0;
+    std::vector<uint32_t> par0;
+    uint32_t from[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0};
+    std::vector<double> dim2[4];
+    void modify_par0(uint32_t par0_index, double multiplier);   // ProbabilityEstimates.h:532-545
+    void set_par0(uint32_t par0_index);                          // ProbabilityEstimates.h:547-556
+};
+
+struct HostAdapters {               // AdapterStats getters (AdapterStats.h:101-107)
+    std::vector<uint8_t> seqs;
+    std::vector<uint32_t> seq_ptr;
+    std::vector<uint64_t> counts, significant;
+    std::vector<uint32_t> cut_ptr, cut_from;
+    std::vector<uint64_t> cut;
+    uint32_t n() const { return (uint32_t)seq_ptr.size() - 1; }
+};
+
+struct HostRlByFl {                 // ReadLengthsByFragmentLength (DataStats.h:198) as CSR over fragment lengths
+    uint64_t from = 0;
+    std::vector<uint32_t> row_ptr, row_from;
+    std::vector<uint64_t> values, non_mapped;
+};
+
+struct Profile {
+    uint8_t phred_offset = 33;
+    double corrected_coverage = 0;
+    uint16_t max_len_deletion = 0;
+    uint32_t reset_distance = 0;
+    Vect<uint64_t> read_lengths[2];
+    HostRlByFl rl_by_fl[2];
+    uint64_t total_number_reads = 0;
+    std::vector<uint16_t> tiles;
+    std::vector<uint64_t> tile_abundance;
+    HostAdapters adapters[2];
+    Vect<uint64_t> polya;
+    uint64_t overrun_bases[5] = {0, 0, 0, 0, 0};
+    Vect<uint64_t> insert_lengths;
+    Vect<double> insert_lengths_bias, gc_bias;
+    std::vector<double> sur_bias;       // [3][1<<20]
+    double dispersion[2] = {0, 0};
+    std::vector<double> ref_seq_bias;
+    std::vector<HostTable> quality, seq_quality, base_call, dom_error, error_rate, indels;
+    uint32_t n_tiles() const { return (uint32_t)tiles.size(); }
+
+    static Profile load(const std::string &path);
+    void change_error_rate(double multiplier);          // ProbabilityEstimates.h:1516-1527
+    void remove_substitution_errors();                  // :1529-1540
+    void remove_indel_errors();                         // :1542-1549
+};
+
+// cumulative probabilities of a std::discrete_distribution over `w` (libstdc++ param_type::_M_initialize)
+std::vector<double> discrete_cp(const uint64_t *w, size_t n);
+
+// ---------------------------------------------------------------------------------------------- reference
+struct Reference {
+    std::vector<std::string> names;          // full id lines (Reference::ReferenceId)
+    std::vector<std::vector<uint8_t>> codes; // A=0,C=1,G=2,T=3,N=4 (Dna5)
+    static Reference read_fasta(const std::string &path);   // Reference.cpp:758 ReadFasta
+    void replace_n(uint64_t seed);                          // Reference.cpp:813 ReplaceN
+    bool has_n() const;
+    uint64_t total_size() const;
+    std::string first_part(size_t i) const;                 // Reference.cpp:476-480 ReferenceIdFirstPart
+};
+
+}  // namespace rsq

@@ -1,0 +1,502 @@
+// rsq_pack.h -- host-side logic of the simulator that does not depend on where the packed arrays live:
+// packing the profile tables and the 2-bit reference, the number of pairs / block numbering, the chain list of
+// the systematic-error pre-pass and the spline / threshold arithmetic of the bias normalisation.
+// The shipped library uploads through hipMalloc (rsq_sim.hip); tests/hostemu keeps the arrays in host memory so
+// that the per-lane functions of rsq_core.h / rsq_kernels.h can be checked against the oracle without a GPU.
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "rsq_host.h"
+#include "rsq_kernels.h"
+
+namespace rsq {
+
+struct Uploader {                                   // copies a host array to wherever the kernels will read it
+    virtual void *put_bytes(const void *data, size_t bytes) = 0;
+    virtual ~Uploader() {}
+    template <class T>
+    T *put(const std::vector<T> &v) {
+        static const T kZero{};
+        return static_cast<T *>(put_bytes(v.empty() ? &kZero : v.data(), (v.empty() ? 1 : v.size()) * sizeof(T)));
+    }
+};
+
+struct SimState {
+    Profile prof;
+    bool has_ref = false;
+    std::vector<std::string> ref_first_names;
+    std::vector<uint32_t> seq_len;
+    std::vector<uint64_t> seq_word_off, seq_base_off;
+    uint64_t total_ref_size = 0;
+    std::vector<std::vector<uint8_t>> ref_codes;     // host copy: DominantBase carry-over between chains
+    DevSim dev{};
+    NameTable names{};
+    uint16_t *sys_fwd = nullptr, *sys_rev = nullptr, *adapter_sys[2] = {nullptr, nullptr};   // written by the chain pre-pass
+    uint32_t rmax = 0, read_stride = 0, ops_stride = 0, max_adapter = 0;
+    // prepare() results
+    bool prepared = false;
+    uint64_t seed = 0, total_pairs = 0, adapter_only_pairs = 0;
+    uint32_t n_groups = 0, passes = 0, total_blocks = 0;
+    std::vector<uint32_t> coverage_groups, first_block, n_blocks, block_seq;
+    std::vector<double> thresholds, norm_by_len, ref_seq_bias;
+    double bias_normalization = 0;
+};
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// --------------------------------------------------------------------------------------- packing (create)
+inline void pack_tables(SimState &s, Uploader &up) {
+    const Profile &p = s.prof;
+    std::vector<double> pool;
+    std::vector<uint8_t> par0;
+    auto pack = [&](const std::vector<HostTable> &tabs) {
+        std::vector<DevTable> out(tabs.size());
+        for (size_t i = 0; i < tabs.size(); ++i) {
+            const HostTable &t = tabs[i];
+            DevTable d{};
+            d.k = (uint32_t)t.par0.size();
+            d.par0_off = (uint32_t)par0.size();
+            for (uint32_t v : t.par0) {
+                par0.push_back((uint8_t)v);
+                d.max_value = std::max(d.max_value, v);
+            }
+            for (uint32_t n = 0; n < t.nm; ++n) {
+                d.from[n] = t.from[n];
+                d.rows[n] = t.to[n] - t.from[n];
+                if (pool.size() + t.dim2[n].size() > 0xFFFFFFFFull) throw Error("probability tables exceed 2^32 entries");
+                d.off[n] = (uint32_t)pool.size();
+                pool.insert(pool.end(), t.dim2[n].begin(), t.dim2[n].end());
+            }
+            out[i] = d;
+        }
+        return up.put(out);
+    };
+    s.dev.quality = pack(p.quality);
+    s.dev.seq_quality = pack(p.seq_quality);
+    s.dev.base_call = pack(p.base_call);
+    s.dev.dom_error = pack(p.dom_error);
+    s.dev.error_rate = pack(p.error_rate);
+    s.dev.indels = pack(p.indels);
+    par0.push_back(0);
+    pool.push_back(0.0);
+    s.dev.pool = up.put(pool);
+    s.dev.par0 = up.put(par0);
+}
+
+inline void pack_profile(SimState &s, Uploader &up) {
+    const Profile &p = s.prof;
+    DevSim &d = s.dev;
+    d.n_tiles = p.n_tiles();
+    d.phred_offset = p.phred_offset;
+    d.max_len_deletion = p.max_len_deletion;
+    d.reset_distance = p.reset_distance;
+    d.tile_cp = up.put(discrete_cp(p.tile_abundance.data(), p.tile_abundance.size()));
+    d.tiles = up.put(p.tiles);
+    s.rmax = 0;
+    uint32_t max_adapter = 0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const HostAdapters &a = p.adapters[seg];
+        DevAdapters &da = d.adapters[seg];
+        da.n = a.n();
+        da.seqs = up.put(a.seqs);
+        da.seq_ptr = up.put(a.seq_ptr);
+        da.adapter_cp = up.put(discrete_cp(a.significant.data(), a.significant.size()));
+        std::vector<double> cut_cp;
+        for (uint32_t i = 0; i < a.n(); ++i) {
+            std::vector<double> cp = discrete_cp(a.cut.data() + a.cut_ptr[i], a.cut_ptr[i + 1] - a.cut_ptr[i]);
+            cp.resize(a.cut_ptr[i + 1] - a.cut_ptr[i]);
+            cut_cp.insert(cut_cp.end(), cp.begin(), cp.end());
+            max_adapter = std::max(max_adapter, a.seq_ptr[i + 1] - a.seq_ptr[i]);
+        }
+        cut_cp.push_back(1.0);
+        da.cut_cp = up.put(cut_cp);
+        da.cut_ptr = up.put(a.cut_ptr);
+        da.cut_from = up.put(a.cut_from);
+        s.adapter_sys[seg] = up.put(std::vector<uint16_t>(a.seqs.size() + 1, 0));
+        da.sys = s.adapter_sys[seg];
+
+        const Vect<uint64_t> &rl = p.read_lengths[seg];
+        DevReadLengths &dr = d.read_lengths[seg];
+        if (rl.v.empty()) throw Error("profile has no read lengths");
+        dr.fixed = rl.v.size() == 1 ? (uint32_t)rl.from : 0u;
+        dr.to = (uint32_t)rl.to();
+        dr.row_first = (uint32_t)p.rl_by_fl[seg].from;
+        dr.rows = (uint32_t)p.rl_by_fl[seg].row_ptr.size() - 1;
+        dr.row_ptr = up.put(p.rl_by_fl[seg].row_ptr);
+        dr.row_from = up.put(p.rl_by_fl[seg].row_from);
+        dr.values = up.put(p.rl_by_fl[seg].values);
+        s.rmax = std::max(s.rmax, dr.to - 1);
+    }
+    d.polya_cp = up.put(discrete_cp(p.polya.v.data(), p.polya.v.size()));
+    d.polya_n = (uint32_t)p.polya.v.size();
+    d.polya_from = (uint32_t)p.polya.from;
+    std::vector<double> ocp = discrete_cp(p.overrun_bases, 4);           // Simulator.h:168: the N is dropped
+    for (int i = 0; i < 4; ++i) d.overrun_cp[i] = ocp[i];
+    d.insert_from = (uint32_t)std::max<uint64_t>(1, p.insert_lengths.from);       // Simulator.cpp:2300
+    d.insert_to = (uint32_t)p.insert_lengths.to();
+    std::vector<uint64_t> il(d.insert_to + 1, 0);
+    std::vector<double> ilb(d.insert_to + 1, 0.0), gcb(101, 0.0);
+    for (uint32_t i = 0; i < d.insert_to; ++i) {
+        il[i] = p.insert_lengths[i];
+        ilb[i] = p.insert_lengths_bias[i];
+    }
+    for (uint32_t i = 0; i < 101; ++i) gcb[i] = p.gc_bias[i];
+    d.insert_lengths = up.put(il);
+    d.insert_lengths_bias = up.put(ilb);
+    d.gc_bias = up.put(gcb);
+    d.sur_bias = up.put(p.sur_bias);
+    d.dispersion[0] = p.dispersion[0];
+    d.dispersion[1] = p.dispersion[1];
+
+    s.max_adapter = max_adapter;
+    s.read_stride = (s.rmax + 3u) & ~3u;
+    const uint32_t max_iter = 2u * s.rmax + p.max_len_deletion + max_adapter + 4u;
+    s.ops_stride = (max_iter + 15u) / 16u;
+}
+
+inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
+    DevSim &d = s.dev;
+    d.n_seqs = (uint32_t)r.codes.size();
+    s.has_ref = true;
+    uint64_t words = 0, bases = 0;
+    s.seq_len.clear();
+    s.seq_word_off.clear();
+    s.seq_base_off.clear();
+    s.ref_first_names.clear();
+    for (size_t i = 0; i < r.codes.size(); ++i) {
+        s.seq_len.push_back((uint32_t)r.codes[i].size());
+        s.seq_word_off.push_back(words);
+        s.seq_base_off.push_back(bases);
+        words += (r.codes[i].size() + 31) / 32 + 1;        // one spare word per sequence
+        bases += r.codes[i].size();
+        s.ref_first_names.push_back(r.first_part(i));
+    }
+    s.total_ref_size = bases;
+    std::vector<uint64_t> packed(words + 1, 0);
+    for (size_t i = 0; i < r.codes.size(); ++i) {
+        const std::vector<uint8_t> &c = r.codes[i];
+        uint64_t *w = &packed[s.seq_word_off[i]];
+        for (size_t pos = 0; pos < c.size(); ++pos) {
+            if (c[pos] > 3) throw Error("reference still contains N: call rsq_ref_replace_n first");
+            w[pos >> 5] |= (uint64_t)c[pos] << ((pos & 31) * 2);
+        }
+    }
+    s.ref_codes = r.codes;
+    d.ref_words = up.put(packed);
+    d.seq_word_off = up.put(s.seq_word_off);
+    d.seq_len = up.put(s.seq_len);
+    d.seq_base_off = up.put(s.seq_base_off);
+    s.sys_fwd = up.put(std::vector<uint16_t>(bases + 8, 0));
+    s.sys_rev = up.put(std::vector<uint16_t>(bases + 8, 0));
+    d.sys_fwd = s.sys_fwd;
+    d.sys_rev = s.sys_rev;
+    std::string names;
+    std::vector<uint32_t> ptr{0};
+    for (const std::string &n : s.ref_first_names) {
+        names += n;
+        ptr.push_back((uint32_t)names.size());
+    }
+    names.push_back(' ');
+    s.names.names = up.put(std::vector<char>(names.begin(), names.end()));
+    s.names.name_ptr = up.put(ptr);
+}
+
+// utilities.hpp:238-262 on the host, only to carry DominantBase::dom_base_ from the end of one chain to the start of
+// the next (Clear() does not reset it: Simulator.cpp:723-732, utilities.hpp:279-281).
+template <class Acc>
+inline uint32_t dom_base_after_chain(const Acc &acc, uint32_t len, uint32_t previous) {
+    if (!len) return previous;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    for (uint32_t p = len > 5 ? len - 5 : 0; p < len; ++p) ++cnt[acc(p)];
+    return find_dominant(acc, cnt, len);
+}
+
+// ------------------------------------------------------------------------------- bias normalisation (a14)
+// FragmentDistributionStats.cpp:1656-1705 GetSamplePositions
+inline std::vector<uint32_t> sample_positions(const Vect<uint64_t> &il) {
+    const uint32_t kDist = 20;                                    // FragmentDistributionStats.h:235
+    const uint32_t to = (uint32_t)il.to();
+    uint32_t first_sample = (uint32_t)std::max<uint64_t>(1, il.from);
+    while (first_sample < to && 0 == il[first_sample]) ++first_sample;
+    uint32_t num_samples = 0, hit_zero = 0;
+    for (uint32_t len = first_sample; len < to; len += kDist) {
+        if (hit_zero) {
+            if (il[len] >= 10) {
+                num_samples += (len - hit_zero) / kDist + 1;
+                hit_zero = 0;
+            }
+        } else if (il[len] > 0) ++num_samples;
+        else hit_zero = len;
+    }
+    if (2 > num_samples) throw Error("Sampling insert lengths did not find at least two usable lengths.");
+    std::vector<uint32_t> sp(num_samples);
+    sp[0] = first_sample;
+    uint32_t found_zeros = 0;
+    for (uint32_t k = 1; k < num_samples - found_zeros; ++k) {
+        sp[k] = sp[k - 1] + kDist;
+        while (0 == il[sp[k]]) {
+            ++found_zeros;
+            sp[k] += kDist;
+        }
+    }
+    sp.resize(num_samples - found_zeros);
+    return sp;
+}
+
+// Natural cubic spline through log(norm/len_bias) at the sampled lengths, evaluated for every length
+// (FragmentDistributionStats.cpp:418-467 PrepareSplines, :485-496, :1539-1567 FillInWithFittedRatios, :1729-1740).
+inline void interpolate_normalization(const Vect<double> &len_bias, const std::vector<uint32_t> &x, std::vector<double> &norm) {
+    const size_t n = x.size(), nh = n - 1;
+    std::vector<double> pars(n + 1, 1.0);
+    for (size_t k = 0; k < n; ++k) {
+        const double v = norm[x[k]] / len_bias[x[k]];
+        pars[k + 1] = v > 0.0 ? log(v) : log(1e-10);
+    }
+    std::vector<double> h(nh), mu(nh, 0.0), l(n, 0.0);
+    std::vector<std::vector<double>> beta(nh, std::vector<double>(n, 0.0)), z(n, std::vector<double>(n, 0.0)), c(n, std::vector<double>(n, 0.0)),
+        b(nh, std::vector<double>(n, 0.0)), d(nh, std::vector<double>(n, 0.0));
+    for (size_t i = 0; i < nh; ++i) h[i] = (double)(x[i + 1] - x[i]);
+    for (size_t k = 1; k < nh; ++k) {
+        beta[k][k + 1] = 3 / h[k];
+        beta[k][k] = -3 / h[k] - 3 / h[k - 1];
+        beta[k][k - 1] = 3 / h[k - 1];
+    }
+    for (size_t k = 1; k < nh; ++k) {
+        l[k] = 2 * (double)(x[k + 1] - x[k - 1]) - h[k - 1] * mu[k - 1];
+        mu[k] = h[k] / l[k];
+        for (size_t ai = 0; ai < n; ++ai) z[k][ai] = (beta[k][ai] - h[k - 1] * z[k - 1][ai]) / l[k];
+    }
+    l[n - 1] = 1.0;
+    for (size_t i = nh; i--;) {
+        for (size_t ai = 0; ai < n; ++ai) {
+            c[i][ai] = z[i][ai] - mu[i] * c[i + 1][ai];
+            b[i][ai] = -h[i] * (c[i + 1][ai] + 2 * c[i][ai]) / 3;
+            d[i][ai] = (c[i + 1][ai] - c[i][ai]) / 3 / h[i];
+        }
+        b[i][i + 1] += 1 / h[i];
+        b[i][i] -= 1 / h[i];
+    }
+    for (uint32_t len = 1; len < x[0]; ++len) norm[len] = 0.0;
+    double ca = 0, cb = 0, cc = 0, cd = 0;
+    size_t k = 0;
+    for (; k < n - 1; ++k) {
+        ca = pars[k + 1];
+        cb = cc = cd = 0.0;
+        for (size_t ai = 1; ai < n + 1; ++ai) {
+            cb += pars[ai] * b[k][ai - 1];
+            cc += pars[ai] * c[k][ai - 1];
+            cd += pars[ai] * d[k][ai - 1];
+        }
+        norm[x[k]] = len_bias[x[k]] * exp(ca);
+        for (uint32_t len = x[k] + 1; len < x[k + 1]; ++len) {
+            const uint32_t cur = len - x[k];
+            norm[len] = len_bias[len] * exp(ca + cb * cur + cc * cur * cur + cd * cur * cur * cur);
+        }
+    }
+    norm[x[k]] = len_bias[x[k]] * exp(pars[k + 1]);
+    const uint32_t cur = x[k] - x[k - 1];
+    const double slope = cb + cc * cur;
+    for (uint32_t len = x[k] + 1; len < norm.size(); ++len) norm[len] = len_bias[len] * exp(pars[k + 1] + (len - x[k]) * slope);
+}
+
+inline double threshold0(const double disp[2], double norm, double max_bias) {      // FragmentDistributionStats.cpp:2969-2976, one allele
+    double max_mean = norm * max_bias;
+    double max_dispersion = get_dispersion(max_mean, disp[0], disp[1]) / 1;
+    max_mean /= 1;
+    return pow(max_dispersion / (max_dispersion + max_mean), max_dispersion);
+}
+
+// Simulator.cpp:61-78
+inline double coverage_prop_lost_from_adapters(const Profile &p) {
+    uint64_t adapter_bases = 0, total_bases = 0;
+    for (int seg = 2; seg--;) {
+        const HostRlByFl &r = p.rl_by_fl[seg];
+        for (size_t row = 0; row + 1 < r.row_ptr.size(); ++row) {
+            const uint64_t frag_len = r.from + row;
+            for (uint32_t j = r.row_ptr[row]; j < r.row_ptr[row + 1]; ++j) {
+                const uint64_t read_len = r.row_from[row] + (j - r.row_ptr[row]);
+                total_bases += r.values[j] * read_len;
+                if (frag_len < read_len) {
+                    adapter_bases += (r.values[j] - r.non_mapped[j]) * (read_len - frag_len);
+                    adapter_bases += r.non_mapped[j] * read_len;
+                }
+            }
+        }
+    }
+    return (double)adapter_bases / total_bases;
+}
+
+
+// --------------------------------------------------------------------------------- prepare: pairs and blocks
+// Simulator.cpp:2705-2743 (number of pairs, adapter-only share), :2782 (sys_gc_range_), UpdateRefSeqBias kKeep/kNo
+// (FragmentDistributionStats.cpp:3352-3364) and the block numbering of CreateUnit/CreateBlock (:911-924,1149-1225).
+inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
+    const Profile &p = s.prof;
+    s.seed = seed;
+    s.dev.seed = seed;
+    std::string base = (base_identifier && base_identifier[0]) ? base_identifier : "ReseqRead";       // Simulator.cpp:2705-2710
+    if (base.size() > sizeof(s.names.base_identifier)) throw Error("record base identifier longer than 64 characters");
+    memcpy(s.names.base_identifier, base.data(), base.size());
+    s.names.base_len = (uint32_t)base.size();
+
+    uint64_t reads = 0, sum_read_length = 0;                                         // :2713-2721
+    for (int seg = 2; seg--;)
+        for (uint64_t len = p.read_lengths[seg].from; len < p.read_lengths[seg].to(); ++len) {
+            reads += p.read_lengths[seg][len];
+            sum_read_length += p.read_lengths[seg][len] * len;
+        }
+    if (!reads) throw Error("profile has no reads");
+    const double average_read_length = (double)sum_read_length / reads;
+    s.dev.sys_gc_range = (uint16_t)(((sum_read_length + reads / 2) / reads) / 2);      // :2782
+    if (!s.has_ref) return;
+
+    if (num_read_pairs) s.total_pairs = num_read_pairs;                              // :2726-2736
+    else {
+        const double adapter_part = coverage_prop_lost_from_adapters(p);
+        if (0.0 == coverage) coverage = p.corrected_coverage;
+        s.total_pairs = (uint64_t)round(coverage * s.total_ref_size / average_read_length / 2 / (1 - adapter_part));
+    }
+    s.adapter_only_pairs = (uint64_t)round((double)s.total_pairs * p.insert_lengths[0] / (p.total_number_reads / 2));    // :2739
+    s.total_pairs -= s.adapter_only_pairs;
+
+    const uint32_t n_seqs = s.dev.n_seqs;
+    s.ref_seq_bias.assign(n_seqs, 1.0);
+    if (ref_bias_mode == 0 && p.ref_seq_bias.size() == n_seqs) s.ref_seq_bias = p.ref_seq_bias;
+
+    s.first_block.assign(n_seqs, 0);
+    s.n_blocks.assign(n_seqs, 0);
+    s.block_seq.assign(1, 0);
+    uint32_t next_block = 1;
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        if (s.seq_len[i] < s.dev.insert_to) continue;                                // :1159,1186
+        s.first_block[i] = next_block;
+        s.n_blocks[i] = (s.seq_len[i] + kBlockSize - 1) / kBlockSize;
+        for (uint32_t b = 0; b < s.n_blocks[i]; ++b) s.block_seq.push_back(i);
+        next_block += s.n_blocks[i];
+    }
+    s.total_blocks = next_block - 1;
+    if (!s.total_blocks) throw Error("All reference sequences are too short for simulating. They should have at least " + std::to_string(s.dev.insert_to) + " bases");
+    s.block_seq.push_back(0);
+    s.dev.block_seq = up.put(s.block_seq);
+    s.dev.first_block = up.put(s.first_block);
+    s.dev.total_blocks = s.total_blocks;
+}
+
+// ------------------------------------------------------------------------------- chains of the a13 pre-pass
+constexpr uint32_t kChainChunk = 256;
+inline void build_chains(const SimState &s, bool with_reference, std::vector<Chain> &chains, std::vector<uint32_t> &chunk_chain) {
+    uint32_t dom_state = 0;                                       // DominantBase(): dom_base_(0)
+    auto add = [&](Chain c) {
+        c.first_chunk = (uint32_t)chunk_chain.size();
+        c.initial_dom = dom_state;
+        for (uint32_t k = 0; k < cdiv(c.len, kChainChunk); ++k) chunk_chain.push_back((uint32_t)chains.size());
+        chains.push_back(c);
+    };
+    const Profile &p = s.prof;
+    for (int seg = 2; seg--;) {                                   // Simulator.cpp:2784-2797 adapters, segment 1 first, ids descending
+        const HostAdapters &a = p.adapters[seg];
+        for (uint32_t i = a.n(); i--;) {
+            if (!a.counts[i]) continue;
+            const uint32_t len = a.seq_ptr[i + 1] - a.seq_ptr[i];
+            add(Chain{2u, i, (uint32_t)seg, len, i, 2u + (uint32_t)seg, 0, 0, s.adapter_sys[seg] + a.seq_ptr[i]});
+            const uint8_t *codes = a.seqs.data() + a.seq_ptr[i];
+            dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, len, dom_state);
+        }
+    }
+    if (with_reference)
+        for (uint32_t i = 0; i < s.dev.n_seqs; ++i) {
+            if (!s.n_blocks[i]) continue;                           // no unit for sequences shorter than the longest insert
+            const uint32_t L = s.seq_len[i];
+            const std::vector<uint8_t> &codes = s.ref_codes[i];
+            for (uint32_t strand = 2; strand--;) {                  // CreateUnit: whole reverse strand first, then the forward blocks
+                add(Chain{strand, i, 0u, L, i, strand, 0, 0, (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[i]});
+                if (strand) dom_state = dom_base_after_chain([&](uint32_t pos) { return 3u - codes[L - 1 - pos]; }, L, dom_state);
+                else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
+            }
+        }
+}
+
+// ------------------------------------------------- bias normalisation: parameter list and the arithmetic after SumBias
+// FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization, split around the SumBias scan.
+struct BiasPlan {
+    std::vector<uint32_t> sample;           // insert_length_spline.sample_positions_
+    std::vector<BiasParam> params;          // FillParamsSimulation order (:2185-2200)
+    uint32_t max_starts = 0;
+};
+
+inline BiasPlan plan_bias_normalization(SimState &s, Uploader &up) {
+    const Profile &p = s.prof;
+    const uint32_t n_seqs = s.dev.n_seqs;
+    BiasPlan plan;
+    plan.sample = sample_positions(p.insert_lengths);
+    std::vector<std::pair<double, uint32_t>> sorted;                                 // :2909-2932 SplitCoverageGroups
+    for (uint32_t i = n_seqs; i--;) sorted.emplace_back(s.ref_seq_bias[i], i);
+    std::sort(sorted.begin(), sorted.end());
+    s.coverage_groups.assign(n_seqs, 0);
+    double group_start = sorted.front().first;
+    uint32_t group = 0;
+    for (const auto &b : sorted) {
+        if (b.first > 2 * group_start) {
+            group_start = b.first;
+            ++group;
+        }
+        s.coverage_groups[b.second] = group;
+    }
+    s.n_groups = group + 1;
+    s.dev.coverage_group = up.put(s.coverage_groups);
+    s.dev.ref_seq_bias = up.put(s.ref_seq_bias);
+    for (uint32_t ref_id = n_seqs; ref_id--;) {
+        if (0.0 == s.ref_seq_bias[ref_id]) continue;
+        for (uint32_t fl : plan.sample)
+            if (fl <= s.seq_len[ref_id]) {
+                plan.params.push_back(BiasParam{ref_id, fl, s.ref_seq_bias[ref_id] * p.insert_lengths_bias[fl]});
+                plan.max_starts = std::max(plan.max_starts, s.seq_len[ref_id] - fl + 1);
+            }
+    }
+    return plan;
+}
+
+// sums[i], maxes[i]: SumBias total and maximum of plan.params[i]
+inline void finish_bias_normalization(SimState &s, const BiasPlan &plan, const std::vector<double> &sums, const std::vector<double> &maxes) {
+    const Profile &p = s.prof;
+    const uint32_t to = s.dev.insert_to;
+    const std::vector<uint32_t> &sp = plan.sample;
+    std::vector<double> norm(to, 0.0), max_bias((size_t)s.n_groups * to, 0.0);
+    for (size_t i = 0; i < plan.params.size(); ++i) {
+        norm[plan.params[i].len] += sums[i];
+        double &m = max_bias[(size_t)s.coverage_groups[plan.params[i].seq] * to + plan.params[i].len];
+        m = std::max(m, maxes[i]);
+    }
+    interpolate_normalization(p.insert_lengths_bias, sp, norm);
+    for (uint32_t g = 0; g < s.n_groups; ++g) {                                       // :3540-3559
+        double *grp = &max_bias[(size_t)g * to];
+        double max_ratio = 0.0;
+        for (uint32_t fl : sp) max_ratio = std::max(max_ratio, grp[fl] / p.insert_lengths_bias[fl]);
+        for (size_t k = 1; k < sp.size(); ++k)
+            for (uint32_t fl = sp[k - 1] + 1; fl < sp[k]; ++fl) grp[fl] = max_ratio * p.insert_lengths_bias[fl];
+        for (uint32_t fl = sp.back() + 1; fl < to; ++fl) grp[fl] = max_ratio * p.insert_lengths_bias[fl];
+    }
+    double normalization = 0.0;
+    for (double v : norm) normalization += v;
+    s.bias_normalization = s.total_pairs / (normalization * 2);                       // :3566
+    s.thresholds.assign((size_t)s.n_groups * to * 2, 1.0);
+    for (size_t i = 0; i < (size_t)s.n_groups * to; ++i)
+        if (0.0 != max_bias[i]) {
+            s.thresholds[2 * i] = threshold0(p.dispersion, s.bias_normalization, max_bias[i]);
+            s.thresholds[2 * i + 1] = pow(s.thresholds[2 * i], 2 * 1);
+        }
+    s.norm_by_len = norm;
+    if (0.0 == s.bias_normalization) throw Error("bias normalisation is zero");
+}
+
+inline void upload_normalization(SimState &s, Uploader &up) {
+    s.dev.thresholds = up.put(s.thresholds);
+    s.dev.bias_normalization = s.bias_normalization;
+}
+
+}  // namespace rsq

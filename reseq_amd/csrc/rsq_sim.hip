@@ -1,0 +1,593 @@
+// rsq_sim.hip -- the simulator object behind the C ABI (include/reseq_amd.h): packs profile + reference into
+// HBM, runs the pre-passes and drives the kernels of rsq_kernels.h.  Compiled for gfx950 only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/reseq_amd.h"
+#include "rsq_pack.h"
+
+namespace rsq {
+
+static thread_local std::string g_last_error;
+
+struct HipError : Error {
+    using Error::Error;
+};
+#define HIP_CHECK(expr)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ device memory
+class DevBuf {
+   public:
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    ~DevBuf() { if (p_) (void)hipFree(p_); }
+    void reserve(size_t bytes) {                   // grow-only
+        if (bytes <= bytes_) return;
+        if (p_) HIP_CHECK(hipFree(p_));
+        p_ = nullptr;
+        bytes_ = 0;
+        HIP_CHECK(hipMalloc(&p_, bytes ? bytes : 8));
+        bytes_ = bytes;
+    }
+    template <class T>
+    void upload(const std::vector<T> &v) {
+        reserve(v.size() * sizeof(T) + 8);
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p_, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p_); }
+    size_t bytes() const { return bytes_; }
+
+   private:
+    void *p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+struct Timer {                                     // HIP events on the stream the kernels are launched on
+    hipEvent_t a = nullptr, b = nullptr;
+    bool used = false;
+    void start(hipStream_t st) {
+        if (!a) {
+            HIP_CHECK(hipEventCreate(&a));
+            HIP_CHECK(hipEventCreate(&b));
+        }
+        HIP_CHECK(hipEventRecord(a, st));
+    }
+    void stop(hipStream_t st) {
+        HIP_CHECK(hipEventRecord(b, st));
+        used = true;
+    }
+    double ms() const {
+        if (!used) return 0.0;
+        float t = 0;
+        if (hipEventElapsedTime(&t, a, b) != hipSuccess) return 0.0;
+        return t;
+    }
+};
+
+}  // namespace rsq
+
+using namespace rsq;
+
+struct rsq_profile {
+    Profile p;
+};
+struct rsq_ref {
+    Reference r;
+};
+
+// arrays packed by rsq_pack.h go to HBM; they live as long as the simulator
+struct DeviceUploader : Uploader {
+    std::vector<std::unique_ptr<DevBuf>> owned;
+    void *put_bytes(const void *data, size_t bytes) override {
+        owned.emplace_back(new DevBuf());
+        owned.back()->reserve(bytes + 8);
+        HIP_CHECK(hipMemcpy(owned.back()->as<void>(), data, bytes, hipMemcpyHostToDevice));
+        return owned.back()->as<void>();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ rsq_sim
+struct rsq_sim : SimState {
+    int device = 0;
+    DeviceUploader up;
+    // workspace of the hot path (grow-only)
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2;
+    std::map<std::string, Timer> timers;
+};
+
+namespace rsq {
+
+// --------------------------------------------------------------------------------- systematic errors (a13)
+static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, bool with_reference) {
+    std::vector<Chain> chains;
+    std::vector<uint32_t> chunk_chain;
+    build_chains(s, with_reference, chains, chunk_chain);
+    const uint32_t n_chunks = (uint32_t)chunk_chain.size();
+    if (!n_chunks) return 0;
+    DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
+    d_chains.upload(chains);
+    d_chunk_chain.upload(chunk_chain);
+    d_used.reserve(n_chunks * 4);
+    d_out[0].reserve(n_chunks * 4);
+    d_out[1].reserve(n_chunks * 4);
+    d_changed.reserve(8);
+    uint32_t pass = 0;
+    for (;; ++pass) {
+        HIP_CHECK(hipMemsetAsync(d_changed.as<uint32_t>(), 0, 4, st));
+        hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_chunks, 64)), dim3(64), 0, st, s.dev, d_chains.as<Chain>(), d_chunk_chain.as<uint32_t>(), n_chunks, kChainChunk,
+                           d_used.as<uint32_t>(), d_out[(pass + 1) & 1].as<uint32_t>(), d_out[pass & 1].as<uint32_t>(), d_changed.as<uint32_t>(), (int)pass);
+        HIP_CHECK(hipGetLastError());
+        uint32_t changed = 0;
+        HIP_CHECK(hipMemcpyAsync(&changed, d_changed.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (pass > 0 && !changed) break;
+        if (pass > n_chunks + 2) throw Error("systematic-error chains did not converge");
+    }
+    return pass + 1;
+}
+
+// ------------------------------------------------------------------------------- bias normalisation (a14)
+// FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization; the SumBias scans (Reference.cpp:622-659) run on
+// the GPU, one launch for all (sequence, sampled length) pairs; partial sums are combined in a fixed order.
+static void bias_normalization(rsq_sim &s, hipStream_t st) {
+    const BiasPlan plan = plan_bias_normalization(s, s.up);
+    std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
+    if (!plan.params.empty()) {
+        const uint32_t gx = cdiv(plan.max_starts, kBiasBlock * kBiasRun);
+        DevBuf d_params, d_sum, d_max;
+        d_params.upload(plan.params);
+        d_sum.reserve((size_t)gx * plan.params.size() * 8);
+        d_max.reserve((size_t)gx * plan.params.size() * 8);
+        hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_sum.as<double>(), d_max.as<double>());
+        HIP_CHECK(hipGetLastError());
+        std::vector<double> h_sum((size_t)gx * plan.params.size()), h_max(h_sum.size());
+        HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < plan.params.size(); ++i)
+            for (uint32_t b = 0; b < gx; ++b) {
+                sums[i] += h_sum[i * gx + b];
+                maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
+            }
+    }
+    finish_bias_normalization(s, plan, sums, maxes);
+}
+
+static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
+    HIP_CHECK(hipSetDevice(s.device));
+    plan_simulation(s, s.up, seed, num_read_pairs, coverage, ref_bias_mode, base_identifier);
+    if (s.has_ref) {
+        bias_normalization(s, st);
+        upload_normalization(s, s.up);
+    }
+    s.passes = run_sys_chains(s, st, s.has_ref);
+    s.prepared = true;
+}
+
+// --------------------------------------------------------------------------------------------- hot path
+static void exclusive_scan(rsq_sim &s, const uint32_t *in, uint64_t n, uint64_t *out, hipStream_t st) {
+    const uint32_t tiles = cdiv(n, kScanTile);
+    s.tile_sums.reserve((size_t)(tiles + 1) * 8);
+    s.scan_total.reserve(8);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(64), 0, st, s.tile_sums.as<uint64_t>(), tiles, s.scan_total.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>(), s.scan_total.as<uint64_t>(), out);
+    HIP_CHECK(hipGetLastError());
+}
+
+static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
+    s.raw_seq.reserve(n_reads * s.read_stride + 16);
+    s.raw_qual.reserve(n_reads * s.read_stride + 16);
+    s.raw_ops.reserve(n_reads * s.ops_stride * 4 + 16);
+    s.raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
+    return RawLayout{s.raw_seq.as<uint8_t>(), s.raw_qual.as<uint8_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), s.read_stride, s.ops_stride};
+}
+
+// reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
+static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap,
+                          size_t *r2_len, hipStream_t st) {
+    *r1_len = *r2_len = 0;
+    if (!n_pairs) return RSQ_OK;
+    RawLayout raw = raw_layout(s, 2 * n_pairs);
+    const dim3 grid(cdiv(n_pairs, 64), 2), block(64);
+    s.timers["fill_reads"].start(st);
+    hipLaunchKernelGGL(k_fill_reads, grid, block, 0, st, s.dev, frags, n_pairs, adapter_first, raw);
+    s.timers["fill_reads"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    s.sizes.reserve(2 * n_pairs * 4 + 16);
+    s.off_r1.reserve((n_pairs + 1) * 8);
+    s.off_r2.reserve((n_pairs + 1) * 8);
+    s.timers["format_sizes"].start(st);
+    hipLaunchKernelGGL(k_format, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(), (const uint64_t *)nullptr,
+                       (const uint64_t *)nullptr, (char *)nullptr, (char *)nullptr);
+    s.timers["format_sizes"].stop(st);
+    s.timers["scan"].start(st);
+    exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
+    exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
+    s.timers["scan"].stop(st);
+    uint64_t tot[2];
+    HIP_CHECK(hipMemcpyAsync(&tot[0], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&tot[1], s.off_r2.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    *r1_len = tot[0];
+    *r2_len = tot[1];
+    if (tot[0] > r1_cap || tot[1] > r2_cap || !r1 || !r2) {
+        g_last_error = "output buffers too small: need " + std::to_string(tot[0]) + " and " + std::to_string(tot[1]) + " bytes";
+        return RSQ_ENOSPC;
+    }
+    s.timers["format_write"].start(st);
+    hipLaunchKernelGGL(k_format, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, (uint32_t *)nullptr, s.off_r1.as<uint64_t>(),
+                       s.off_r2.as<uint64_t>(), r1, r2);
+    s.timers["format_write"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));
+    return RSQ_OK;
+}
+
+static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, uint64_t *n_pairs,
+                     rsq_fragment *frags_out, size_t frags_cap, hipStream_t st) {
+    if (!s.prepared || !s.has_ref) {
+        g_last_error = "rsq_sim_prepare with a reference must run before rsq_sim_pairs";
+        return RSQ_ESTATE;
+    }
+    if (block_lo < 1 || block_hi > s.total_blocks + 1 || block_lo > block_hi) {
+        g_last_error = "block range outside [1, total_blocks]";
+        return RSQ_EINVAL;
+    }
+    HIP_CHECK(hipSetDevice(s.device));
+    *n_pairs = 0;
+    *r1_len = *r2_len = 0;
+    const uint64_t n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
+    if (!n_slots) return RSQ_OK;
+    s.counts.reserve(n_slots * 4 + 16);
+    s.offsets.reserve((n_slots + 1) * 8);
+    const dim3 sgrid(cdiv(n_slots, 4)), sblock(256);
+    s.timers["sieve_count"].start(st);
+    hipLaunchKernelGGL(k_sieve<false>, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr, (Fragment *)nullptr);
+    s.timers["sieve_count"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    *n_pairs = total;
+    if (!total) return RSQ_OK;
+    s.frags.reserve(total * sizeof(Fragment) + 16);
+    s.timers["sieve_emit"].start(st);
+    hipLaunchKernelGGL(k_sieve<true>, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(), s.frags.as<Fragment>());
+    s.timers["sieve_emit"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    if (frags_out) {
+        if (frags_cap < total) {
+            g_last_error = "fragment buffer too small: need " + std::to_string(total) + " records";
+            return RSQ_ENOSPC;
+        }
+        static_assert(sizeof(rsq_fragment) == sizeof(Fragment), "ABI fragment layout");
+        HIP_CHECK(hipMemcpyAsync(frags_out, s.frags.as<Fragment>(), total * sizeof(Fragment), hipMemcpyDeviceToDevice, st));
+    }
+    return reads_and_text(s, s.frags.as<Fragment>(), total, 0, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st);
+}
+
+// CIGAR strings and per-read scalars of the error-model-only mode
+__global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *num_errors_out,
+                                  uint16_t *tile_out, char *cigar_out, uint32_t cigar_stride, uint32_t *overflow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ReadMeta m = raw.meta[i];
+    read_len_out[i] = m.read_len;
+    num_errors_out[i] = m.num_errors;
+    tile_out[i] = m.tile_id;
+    const uint32_t nb = m.read_len < out_stride ? m.read_len : out_stride;
+    for (uint32_t k = 0; k < nb; ++k) {
+        seq_out[i * out_stride + k] = raw.seq[i * raw.read_stride + k];
+        qual_out[i * out_stride + k] = raw.qual[i * raw.read_stride + k];
+    }
+    if (m.cigar_chars + 1u > cigar_stride || m.read_len > out_stride) {
+        *overflow = 1;
+        cigar_out[i * cigar_stride] = 0;
+        return;
+    }
+    TextSink t{cigar_out + i * cigar_stride, 0};
+    cigar_replay(raw.ops + i * raw.ops_stride, m, t);
+    t.ch(0);
+}
+
+}  // namespace rsq
+
+// ================================================================================================= C ABI
+template <class F>
+static int guard(F &&f) {
+    try {
+        return f();
+    } catch (const HipError &e) {
+        g_last_error = e.what();
+        return RSQ_EHIP;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        return RSQ_EINVAL;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EINVAL;
+    }
+}
+#define REQUIRE(cond, msg)          \
+    do {                            \
+        if (!(cond)) {              \
+            g_last_error = msg;     \
+            return RSQ_EINVAL;      \
+        }                           \
+    } while (0)
+
+extern "C" {
+
+const char *rsq_last_error(void) { return g_last_error.c_str(); }
+const char *rsq_version(void) { return "reseq_amd 0.1 (gfx950)"; }
+
+int rsq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_last_error = "no HIP device visible; this library has no CPU fallback";
+        return RSQ_ENODEV;
+    }
+    return n;
+}
+
+int rsq_profile_load(const char *path, rsq_profile **out) {
+    REQUIRE(path && out, "null argument");
+    try {
+        *out = new rsq_profile{Profile::load(path)};
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
+void rsq_profile_free(rsq_profile *p) { delete p; }
+int rsq_profile_change_error_rate(rsq_profile *p, double m) {
+    REQUIRE(p && m > 0.0, "bad error multiplier");
+    p->p.change_error_rate(m);
+    return RSQ_OK;
+}
+int rsq_profile_remove_substitution_errors(rsq_profile *p) {
+    REQUIRE(p, "null profile");
+    p->p.remove_substitution_errors();
+    return RSQ_OK;
+}
+int rsq_profile_remove_indel_errors(rsq_profile *p) {
+    REQUIRE(p, "null profile");
+    p->p.remove_indel_errors();
+    return RSQ_OK;
+}
+int rsq_profile_max_read_length(const rsq_profile *p, uint32_t *out) {
+    REQUIRE(p && out, "null argument");
+    *out = (uint32_t)std::max(p->p.read_lengths[0].to(), p->p.read_lengths[1].to()) - 1;
+    return RSQ_OK;
+}
+int rsq_profile_num_tiles(const rsq_profile *p, uint32_t *out) {
+    REQUIRE(p && out, "null argument");
+    *out = p->p.n_tiles();
+    return RSQ_OK;
+}
+
+int rsq_ref_load_fasta(const char *path, rsq_ref **out) {
+    REQUIRE(path && out, "null argument");
+    try {
+        *out = new rsq_ref{Reference::read_fasta(path)};
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
+int rsq_ref_replace_n(rsq_ref *r, uint64_t seed) {
+    REQUIRE(r, "null reference");
+    return guard([&] {
+        r->r.replace_n(seed);
+        return RSQ_OK;
+    });
+}
+void rsq_ref_free(rsq_ref *r) { delete r; }
+int rsq_ref_num_sequences(const rsq_ref *r, uint32_t *out) {
+    REQUIRE(r && out, "null argument");
+    *out = (uint32_t)r->r.codes.size();
+    return RSQ_OK;
+}
+int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out) {
+    REQUIRE(r && out && seq < r->r.codes.size(), "bad sequence id");
+    *out = (uint32_t)r->r.codes[seq].size();
+    return RSQ_OK;
+}
+int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len) {
+    REQUIRE(r && out && seq < r->r.codes.size() && len == r->r.codes[seq].size(), "bad sequence id or length");
+    memcpy(out, r->r.codes[seq].data(), len);
+    return RSQ_OK;
+}
+
+int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim **out) {
+    REQUIRE(p && out, "null argument");
+    int n = rsq_device_count();
+    if (n < 0) return n;
+    REQUIRE(device >= 0 && device < n, "device index out of range");
+    std::unique_ptr<rsq_sim> s(new rsq_sim());
+    int rc = guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        s->device = device;
+        s->prof = p->p;
+        pack_tables(*s, s->up);
+        pack_profile(*s, s->up);
+        if (ref) pack_reference(*s, s->up, ref->r);
+        return RSQ_OK;
+    });
+    if (rc == RSQ_OK) *out = s.release();
+    return rc;
+}
+void rsq_sim_free(rsq_sim *s) {
+    if (s) (void)hipSetDevice(s->device);
+    delete s;
+}
+
+int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier, void *stream) {
+    REQUIRE(s, "null simulator");
+    return guard([&] {
+        prepare(*s, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier, (hipStream_t)stream);
+        return RSQ_OK;
+    });
+}
+
+int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out) {
+    REQUIRE(s && out && s->prepared, "simulator not prepared");
+    out->total_pairs = s->total_pairs;
+    out->adapter_only_pairs = s->adapter_only_pairs;
+    out->total_blocks = s->total_blocks;
+    out->n_coverage_groups = s->n_groups;
+    out->insert_to = s->dev.insert_to;
+    out->sys_chain_passes = s->passes;
+    out->bias_normalization = s->bias_normalization;
+    return RSQ_OK;
+}
+int rsq_sim_get_thresholds(const rsq_sim *s, double *out, size_t n) {
+    REQUIRE(s && out && s->prepared && n == s->thresholds.size(), "bad threshold buffer size");
+    memcpy(out, s->thresholds.data(), n * 8);
+    return RSQ_OK;
+}
+int rsq_sim_get_norm_by_len(const rsq_sim *s, double *out, size_t n) {
+    REQUIRE(s && out && s->prepared && n == s->norm_by_len.size(), "bad buffer size");
+    memcpy(out, s->norm_by_len.data(), n * 8);
+    return RSQ_OK;
+}
+int rsq_sim_set_normalization(rsq_sim *s, double bias_normalization, const double *thresholds, size_t n) {
+    REQUIRE(s && thresholds && s->prepared && n == s->thresholds.size(), "bad threshold buffer size");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        s->bias_normalization = bias_normalization;
+        s->thresholds.assign(thresholds, thresholds + n);
+        upload_normalization(*s, s->up);
+        return RSQ_OK;
+    });
+}
+static int download_sys(const rsq_sim *s, const uint16_t *src, uint8_t *dom_out, uint8_t *rate_out, uint32_t len) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        std::vector<uint16_t> tmp(len);
+        HIP_CHECK(hipMemcpy(tmp.data(), src, (size_t)len * 2, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < len; ++i) {
+            dom_out[i] = (uint8_t)(tmp[i] & 0xFF);
+            rate_out[i] = (uint8_t)(tmp[i] >> 8);
+        }
+        return RSQ_OK;
+    });
+}
+int rsq_sim_get_sys_errors(const rsq_sim *s, int reverse_strand, uint32_t seq, uint8_t *dom_out, uint8_t *rate_out, uint32_t len) {
+    REQUIRE(s && s->prepared && s->has_ref && seq < s->dev.n_seqs && len == s->seq_len[seq] && dom_out && rate_out, "bad arguments");
+    REQUIRE(s->n_blocks[seq], "sequence is shorter than the longest insert length and is not simulated");
+    return download_sys(s, (reverse_strand ? s->sys_rev : s->sys_fwd) + s->seq_base_off[seq], dom_out, rate_out, len);
+}
+int rsq_sim_get_adapter_sys_errors(const rsq_sim *s, int seg, uint32_t adapter, uint8_t *dom_out, uint8_t *rate_out, uint32_t len) {
+    REQUIRE(s && s->prepared && (seg == 0 || seg == 1) && adapter < s->prof.adapters[seg].n() && dom_out && rate_out, "bad arguments");
+    const HostAdapters &a = s->prof.adapters[seg];
+    REQUIRE(len == a.seq_ptr[adapter + 1] - a.seq_ptr[adapter], "bad adapter length");
+    return download_sys(s, s->adapter_sys[seg] + a.seq_ptr[adapter], dom_out, rate_out, len);
+}
+
+int rsq_sim_pairs(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,
+                  uint64_t *n_pairs, rsq_fragment *frags_dev, size_t frags_cap, void *stream) {
+    REQUIRE(s && r1_len && r2_len && n_pairs, "null argument");
+    return guard([&] { return sim_pairs(*s, block_lo, block_hi, r1_dev, r1_cap, r1_len, r2_dev, r2_cap, r2_len, n_pairs, frags_dev, frags_cap, (hipStream_t)stream); });
+}
+
+int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,
+                               void *stream) {
+    REQUIRE(s && r1_len && r2_len && s->prepared, "simulator not prepared");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        return reads_and_text(*s, nullptr, n, first, r1_dev, r1_cap, r1_len, r2_dev, r2_cap, r2_len, (hipStream_t)stream);
+    });
+}
+
+int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
+                        const uint8_t *dom_dev, const uint8_t *rate_dev, uint8_t *seq_out_dev, uint8_t *qual_out_dev, uint32_t out_stride, uint16_t *read_len_out_dev,
+                        uint16_t *num_errors_out_dev, uint16_t *tile_out_dev, char *cigar_out_dev, uint32_t cigar_stride, void *stream) {
+    REQUIRE(s && s->prepared, "simulator not prepared");
+    REQUIRE(seqs_dev && seg_dev && frag_len_dev && dom_dev && rate_dev && seq_out_dev && qual_out_dev && read_len_out_dev && num_errors_out_dev && tile_out_dev && cigar_out_dev,
+            "null device pointer");
+    if (!n) return RSQ_OK;
+    return guard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        HIP_CHECK(hipSetDevice(s->device));
+        // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
+        const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
+        if (need_ops > s->ops_stride) s->ops_stride = need_ops;
+        RawLayout raw = raw_layout(*s, n);
+        s->timers["fill_reads"].start(st);
+        hipLaunchKernelGGL(k_error_model, dim3(cdiv(n, 64)), dim3(64), 0, st, s->dev, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, raw);
+        s->timers["fill_reads"].stop(st);
+        HIP_CHECK(hipGetLastError());
+        s->scan_total.reserve(8);
+        HIP_CHECK(hipMemsetAsync(s->scan_total.as<uint32_t>(), 0, 4, st));
+        hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,
+                           tile_out_dev, cigar_out_dev, cigar_stride, s->scan_total.as<uint32_t>());
+        HIP_CHECK(hipGetLastError());
+        uint32_t overflow = 0;
+        HIP_CHECK(hipMemcpyAsync(&overflow, s->scan_total.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (overflow) {
+            g_last_error = "out_stride or cigar_stride too small for at least one record";
+            return (int)RSQ_ENOSPC;
+        }
+        return (int)RSQ_OK;
+    });
+}
+
+int rsq_sim_last_kernel_ms(const rsq_sim *s, const char *kernel, double *ms) {
+    REQUIRE(s && kernel && ms, "null argument");
+    auto it = s->timers.find(kernel);
+    REQUIRE(it != s->timers.end(), "unknown kernel name or kernel not launched yet");
+    *ms = it->second.ms();
+    return RSQ_OK;
+}
+
+int rsq_dev_alloc(int device, size_t bytes, void **out_dev) {
+    REQUIRE(out_dev, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipMalloc(out_dev, bytes ? bytes : 8));
+        return RSQ_OK;
+    });
+}
+int rsq_dev_free(int device, void *dev) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipFree(dev));
+        return RSQ_OK;
+    });
+}
+int rsq_dev_upload(int device, void *dst_dev, const void *src, size_t bytes) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice));
+        return RSQ_OK;
+    });
+}
+int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
+        return RSQ_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// rsq_types.h -- plain-data views shared by host code and HIP kernels.
+//
+// Everything a kernel reads after rsq_sim_create()/rsq_sim_prepare() sits in HBM and is described by
+// the DevSim struct below (passed to kernels by value).  Naming follows the reference
+// (schmeing/ReSeq): tables are LogArrayResult<N> (ProbabilityEstimates.h:351-557), "sys errors" are
+// SimBlock::sys_errors_ (Simulator.h:115), thresholds are non_zero_thresholds_ (Simulator.h:298).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RSQ_HD __host__ __device__ __forceinline__
+#else
+#define RSQ_HD inline
+#endif
+
+namespace rsq {
+
+constexpr uint32_t kBlockSize = 1000;          // Simulator.h:254 kBlockSize
+constexpr uint32_t kSurBlocks = 3;             // Surrounding.h:17
+constexpr uint32_t kSurRange = 10;
+constexpr uint32_t kSurStart = 10;
+constexpr uint32_t kSurSize = 1u << 20;
+constexpr uint32_t kSqFragmentLengthBinSize = 10;   // QualityStats.h:15
+
+// Counter domains of the Philox streams (DESIGN.md "Random streams"); tag = c3 >> 28.
+enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5 };
+
+// One LogArrayResult<N>: K outcome columns, NM = N-1 conditioning margins.
+// margin n: rows[n] x K doubles at pool[off[n]], row r = clamp(value - from[n]).
+struct DevTable {
+    uint32_t k;            // par0_indeces_.size(); 0 = empty table (Draw returns prob_sum 0)
+    uint32_t par0_off;     // into the u8 outcome-value pool
+    uint32_t from[4];      // limits_[n].first
+    uint32_t rows[4];      // limits_[n].second - limits_[n].first
+    uint32_t off[4];       // into the double pool
+    uint32_t max_value;    // MaxValue()  (ProbabilityEstimates.h:510-517)
+    uint32_t pad;
+};
+
+// Fragment produced by the coverage sieve: one simulated read pair (Simulator.cpp:2249-2357 -> CreateReads).
+struct Fragment {
+    uint32_t seq;          // reference sequence id
+    uint32_t start;        // forward start position
+    uint32_t len;          // fragment length (0 = adapter-only pair)
+    uint16_t dup;          // duplicate index at this (start,len,strand) site
+    uint8_t strand;
+    uint8_t pad;
+    uint32_t block;        // block number printed in the read id
+    uint32_t number;       // read_number within the block (1-based)
+};
+
+// Per-read result meta data written by the read kernel (sequence, qualities and CIGAR ops are separate arrays).
+struct ReadMeta {
+    uint16_t read_len;
+    uint16_t num_errors;
+    uint16_t n_iter_m;     // state-machine iterations spent in the template ('M') part
+    uint16_t n_iter_s;     // iterations spent in the adapter ('S') part
+    uint16_t hard_clip;    // length of the 'H' element (poly-A tail + overrun bases)
+    uint16_t tile_id;
+    uint32_t cigar_chars;  // length of the CIGAR string
+};
+
+struct DevAdapters {
+    uint32_t n;
+    const uint8_t *seqs;          // base codes, concatenated
+    const uint32_t *seq_ptr;      // [n+1]
+    const uint16_t *sys;          // dom | rate<<8 per adapter base (adapter_sys_error_, Simulator.h:294)
+    const double *adapter_cp;     // cumulative probabilities over SignificantCounts
+    const double *cut_cp;         // concatenated per adapter
+    const uint32_t *cut_ptr;      // [n+1]
+    const uint32_t *cut_from;     // [n]
+};
+
+struct DevReadLengths {
+    uint32_t fixed;               // ReadLengths(seg).size() == 1 -> from(); else 0
+    uint32_t to;                  // ReadLengths(seg).to()
+    uint32_t row_first;           // first fragment length with a row
+    uint32_t rows;
+    const uint32_t *row_ptr;      // CSR over fragment lengths
+    const uint32_t *row_from;
+    const uint64_t *values;
+};
+
+struct DevSim {
+    uint64_t seed;
+    // ---- tables
+    const double *pool;
+    const uint8_t *par0;
+    const DevTable *quality;       // [2][n_tiles][4]
+    const DevTable *seq_quality;   // [2][n_tiles]
+    const DevTable *base_call;     // [2][n_tiles][4][5]
+    const DevTable *dom_error;     // [4][5][5]
+    const DevTable *error_rate;    // [4][5]
+    const DevTable *indels;        // [2][6]
+    uint32_t n_tiles;
+    uint8_t phred_offset;
+    uint16_t max_len_deletion;
+    uint32_t reset_distance;
+    uint16_t sys_gc_range;
+    // ---- static categorical draws (GeneralRandomDistributions, Simulator.h:146-213)
+    const double *tile_cp;
+    const uint16_t *tiles;
+    DevAdapters adapters[2];
+    DevReadLengths read_lengths[2];
+    const double *polya_cp;
+    uint32_t polya_n, polya_from;
+    double overrun_cp[4];
+    const uint64_t *insert_lengths;  // dense from 0 .. insert_to
+    // ---- reference: 2 bit per base, 32 bases per uint64_t word, every sequence starts on a word
+    uint32_t n_seqs;
+    const uint64_t *ref_words;
+    const uint64_t *seq_word_off;    // [n_seqs]
+    const uint32_t *seq_len;         // [n_seqs]
+    const uint64_t *seq_base_off;    // [n_seqs] offset of the sequence in the systematic-error tracks
+    const uint16_t *sys_fwd;         // dom | rate<<8 per forward position
+    const uint16_t *sys_rev;         // same for the reverse-complement strand, index = L-1-forward position
+    // ---- coverage model
+    uint32_t insert_from;            // max(1, InsertLengths().from())
+    uint32_t insert_to;              // InsertLengths().to()
+    const double *thresholds;        // [n_groups][insert_to][2]
+    const uint32_t *coverage_group;  // [n_seqs]
+    const double *ref_seq_bias;      // [n_seqs]
+    const double *insert_lengths_bias; // dense [insert_to]
+    const double *gc_bias;           // dense [101]
+    const double *sur_bias;          // [3][1<<20]
+    double dispersion[2];
+    double bias_normalization;
+    // ---- blocks
+    uint32_t total_blocks;
+    const uint32_t *block_seq;       // [total_blocks+1] sequence of block id b (index b, 1-based)
+    const uint32_t *first_block;     // [n_seqs]
+};
+
+}  // namespace rsq

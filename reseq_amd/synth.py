@@ -244,7 +244,7 @@ TINY = dict(
     ins_from=12, ins_to=90, ins_mu=45.0, ins_sigma=0.3, ins_total=200_000,
     adapter_only=150,
     tiles=[1101, 1102, 2308], tile_abundance=[5, 3, 2],
-    n_adapters=3, adapter_len=22,
+    n_adapters=3, adapter_len=9,
     sq_gc_from=10, sq_gc_to=91, sq_err_to=20, bc_nerr_to=8, indel_pos_to=4,
     err_scale=1.5, del_rate=1.5e-2, ins_rate=1.2e-2, sys_rate=0.15, err_rate_to=101,
     reset_distance=30, max_len_deletion=3,

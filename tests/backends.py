@@ -1,0 +1,209 @@
+"""Two drivers with one interface for the parity tests:
+
+EmuBackend   tests/hostemu/libhostemu.so -- the kernels' per-lane functions looped on the CPU (TEST-ONLY artefact,
+             lets `-m "not gpu"` check state machine / packing / counters against the oracle in this container);
+GpuBackend   reseq_amd.api -> libreseq_amd.so through the C ABI (the product; `-m gpu`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from reseq_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "hostemu")
+FRAGMENT_DTYPE = api.FRAGMENT_DTYPE
+
+
+class EmuInfo(C.Structure):
+    _fields_ = [("total_pairs", C.c_uint64), ("adapter_only_pairs", C.c_uint64), ("total_blocks", C.c_uint32), ("n_groups", C.c_uint32),
+                ("insert_to", C.c_uint32), ("passes", C.c_uint32), ("n_seqs", C.c_uint32), ("rmax", C.c_uint32), ("bias_normalization", C.c_double)]
+
+
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        subprocess.run(["make", "-C", EMU_DIR, "-s"], check=True)
+        L = C.CDLL(os.path.join(EMU_DIR, "libhostemu.so"))
+        L.emu_last_error.restype = C.c_char_p
+        L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.emu_free.argtypes = [C.c_void_p]
+        L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+        L.emu_prepare.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
+        L.emu_get_info.argtypes = [C.c_void_p, C.POINTER(EmuInfo)]
+        L.emu_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_get_norm_by_len.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_set_normalization.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
+        L.emu_get_sys.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.emu_get_adapter_sys.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.emu_get_codes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_sieve.restype = C.c_int64
+        L.emu_sieve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.emu_pairs_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
+        L.emu_error_model.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
+        L.emu_draw.restype = C.c_uint32
+        L.emu_draw.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+        L.emu_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        _emu = L
+    return _emu
+
+
+def _ok(rc):
+    if rc != 0:
+        raise RuntimeError(emu_lib().emu_last_error().decode())
+
+
+class EmuBackend:
+    name = "hostemu"
+
+    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None):
+        self.L = emu_lib()
+        self.h = C.c_void_p()
+        _ok(self.L.emu_create(str(profile_path).encode(), (str(fasta_path) if fasta_path else "").encode(), replace_n_seed, C.byref(self.h)))
+        if edits:
+            _ok(self.L.emu_edit_profile(self.h, edits.get("error_multiplier", 1.0), int(edits.get("no_substitutions", False)), int(edits.get("no_indels", False))))
+        self.seq_lens = None
+
+    def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+        _ok(self.L.emu_prepare(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))
+        return self.info()
+
+    def info(self):
+        i = EmuInfo()
+        self.L.emu_get_info(self.h, C.byref(i))
+        return dict(total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, total_blocks=i.total_blocks, n_groups=i.n_groups, insert_to=i.insert_to,
+                    passes=i.passes, bias_normalization=i.bias_normalization)
+
+    def thresholds(self):
+        i = self.info()
+        out = np.zeros((i["n_groups"], i["insert_to"], 2))
+        self.L.emu_get_thresholds(self.h, out.ctypes.data)
+        return out
+
+    def norm_by_len(self):
+        out = np.zeros(self.info()["insert_to"])
+        self.L.emu_get_norm_by_len(self.h, out.ctypes.data)
+        return out
+
+    def set_normalization(self, bias_normalization, thresholds):
+        t = np.ascontiguousarray(thresholds, np.float64)
+        _ok(self.L.emu_set_normalization(self.h, bias_normalization, t.ctypes.data, t.size))
+
+    def sys_errors(self, reverse, seq, length):
+        dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
+        self.L.emu_get_sys(self.h, int(reverse), seq, dom.ctypes.data, rate.ctypes.data)
+        return dom, rate
+
+    def adapter_sys_errors(self, seg, adapter, length):
+        dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
+        self.L.emu_get_adapter_sys(self.h, seg, adapter, dom.ctypes.data, rate.ctypes.data)
+        return dom, rate
+
+    def codes(self, seq, length):
+        out = np.zeros(length, np.uint8)
+        self.L.emu_get_codes(self.h, seq, out.ctypes.data)
+        return out
+
+    def _text(self, frags, n, first):
+        cap = max(4096, int(n) * 4096)
+        b1, b2 = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        l1, l2 = C.c_size_t(), C.c_size_t()
+        _ok(self.L.emu_pairs_text(self.h, frags.ctypes.data if frags is not None else None, n, first, b1, cap, C.byref(l1), b2, cap, C.byref(l2)))
+        return b1.raw[:l1.value], b2.raw[:l2.value]
+
+    def pairs(self, block_lo, block_hi):
+        n = self.L.emu_sieve(self.h, block_lo, block_hi, None, 0)
+        frags = np.zeros(max(n, 1), FRAGMENT_DTYPE)
+        self.L.emu_sieve(self.h, block_lo, block_hi, frags.ctypes.data, n)
+        frags = frags[:n]
+        r1, r2 = self._text(frags, n, 0) if n else (b"", b"")
+        return frags, r1, r2
+
+    def adapter_only_pairs(self, first, n):
+        return self._text(None, n, first) if n else (b"", b"")
+
+    def error_model(self, rec, first_index=0, out_stride=1024, cigar_stride=256):
+        n, rl = rec["seqs"].shape
+        a = [np.ascontiguousarray(rec[k], dt) for k, dt in (("seqs", np.uint8), ("seg", np.uint8), ("frag_len", np.uint32), ("dom", np.uint8), ("rate", np.uint8))]
+        seq, qual = np.zeros((n, out_stride), np.uint8), np.zeros((n, out_stride), np.uint8)
+        rlen, nerr, tile = np.zeros(n, np.uint16), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        cig = np.zeros((n, cigar_stride), np.uint8)
+        _ok(self.L.emu_error_model(self.h, first_index, n, rl, *[x.ctypes.data for x in a], seq.ctypes.data, qual.ctypes.data, out_stride, rlen.ctypes.data,
+                                   nerr.ctypes.data, tile.ctypes.data, cig.ctypes.data, cigar_stride))
+        return [(seq[i, :rlen[i]].tobytes(), qual[i, :rlen[i]].tobytes(), cig[i].tobytes().split(b"\0")[0].decode(), int(nerr[i]), int(tile[i])) for i in range(n)]
+
+    def draw(self, family, index, idx, u):
+        fam = {"quality": 0, "seq_quality": 1, "base_call": 2, "dom_error": 3, "error_rate": 4, "indels": 5}[family]
+        ii = np.asarray(list(idx) + [0] * (4 - len(idx)), np.uint32)
+        ps = C.c_double()
+        v = self.L.emu_draw(self.h, fam, index, ii.ctypes.data, u, C.byref(ps))
+        return v, ps.value
+
+    def close(self):
+        if self.h:
+            self.L.emu_free(self.h)
+            self.h = C.c_void_p()
+
+
+class GpuBackend:
+    name = "gpu"
+
+    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None, device=0):
+        self.prof = api.Profile(profile_path)
+        if edits:
+            if edits.get("error_multiplier", 1.0) != 1.0:
+                self.prof.change_error_rate(edits["error_multiplier"])
+            if edits.get("no_substitutions"):
+                self.prof.remove_substitution_errors()
+            if edits.get("no_indels"):
+                self.prof.remove_indel_errors()
+        self.ref = api.Reference(fasta_path, replace_n_seed) if fasta_path else None
+        self.sim = api.Simulator(self.prof, self.ref, device)
+
+    def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+        self.sim.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        return self.info()
+
+    def info(self):
+        i = self.sim.info()
+        return dict(total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, total_blocks=i.total_blocks, n_groups=i.n_coverage_groups,
+                    insert_to=i.insert_to, passes=i.sys_chain_passes, bias_normalization=i.bias_normalization)
+
+    def thresholds(self):
+        return self.sim.thresholds()
+
+    def norm_by_len(self):
+        return self.sim.norm_by_len()
+
+    def set_normalization(self, bias_normalization, thresholds):
+        self.sim.set_normalization(bias_normalization, thresholds)
+
+    def sys_errors(self, reverse, seq, length):
+        return self.sim.sys_errors(reverse, seq, length)
+
+    def adapter_sys_errors(self, seg, adapter, length):
+        return self.sim.adapter_sys_errors(seg, adapter, length)
+
+    def codes(self, seq, length):
+        return self.ref.codes(seq)
+
+    def pairs(self, block_lo, block_hi):
+        return self.sim.pairs(block_lo, block_hi)
+
+    def adapter_only_pairs(self, first, n):
+        return self.sim.adapter_only_pairs(first, n)
+
+    def error_model(self, rec, first_index=0, out_stride=1024, cigar_stride=256):
+        return self.sim.error_model(rec, first_index, out_stride, cigar_stride)
+
+    def close(self):
+        self.sim.close()
+        if self.ref:
+            self.ref.close()
+        self.prof.close()

@@ -1,0 +1,339 @@
+// hostemu.cpp -- TEST-ONLY CPU emulation of the kernels' per-lane functions.
+//
+// The shipped library (reseq_amd/libreseq_amd.so) has no CPU path.  This file builds a separate test artefact
+// (tests/hostemu/libhostemu.so, g++) that instantiates the very same __host__ __device__ functions the HIP
+// kernels call (rsq_core.h, rsq_kernels.h) and the same packing code (rsq_pack.h) with the arrays kept in host
+// memory, and walks them with plain loops in place of the grid.  `pytest -m "not gpu"` compares it with the
+// oracle so that state-machine, packing and counter-layout mistakes are caught in a container without a GPU.
+// Nothing in reseq_amd/ links to or loads this file.
+#include <stdlib.h>
+
+#include <memory>
+
+#include "../../reseq_amd/csrc/rsq_pack.h"
+
+using namespace rsq;
+
+namespace {
+
+struct HostUploader : Uploader {
+    std::vector<void *> owned;
+    void *put_bytes(const void *data, size_t bytes) override {
+        void *p = malloc(bytes + 8);
+        memcpy(p, data, bytes);
+        owned.push_back(p);
+        return p;
+    }
+    ~HostUploader() override {
+        for (void *p : owned) free(p);
+    }
+};
+
+struct Emu : SimState {
+    HostUploader up;
+};
+
+thread_local std::string g_err;
+
+template <class F>
+int guard(F &&f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// the reduction order of k_sum_bias: lanes own runs of kBiasRun starts, a block tree-reduces kBiasBlock lanes,
+// the host adds the block partials in order
+void sum_bias_like_kernel(const Emu &s, const BiasParam &p, double &sum_out, double &max_out) {
+    const uint32_t L = s.seq_len[p.seq];
+    const uint64_t wo = s.seq_word_off[p.seq];
+    const uint32_t n_starts = L - p.len + 1;
+    const uint32_t blocks = cdiv(n_starts, kBiasBlock * kBiasRun);
+    sum_out = 0.0;
+    max_out = 0.0;
+    for (uint32_t b = 0; b < blocks; ++b) {
+        double ls[kBiasBlock], lm[kBiasBlock];
+        for (uint32_t t = 0; t < kBiasBlock; ++t) {
+            const uint32_t first = (b * kBiasBlock + t) * kBiasRun;
+            double sum = 0.0, mx = 0.0;
+            if (first < n_starts) {
+                const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
+                uint32_t gc = ref_gc_count(s.dev.ref_words, wo, first, first + p.len);
+                for (uint32_t start = first; start < last; ++start) {
+                    const double bias = site_bias(s.dev, wo, L, start, p.len, gc, p.general_bias);
+                    sum += bias;
+                    mx = bias > mx ? bias : mx;
+                    if (start + 1 < last) gc = gc + is_gc(ref_base(s.dev.ref_words, wo, start + p.len)) - is_gc(ref_base(s.dev.ref_words, wo, start));
+                }
+            }
+            ls[t] = sum;
+            lm[t] = mx;
+        }
+        for (uint32_t d = kBiasBlock / 2; d > 0; d >>= 1)
+            for (uint32_t t = 0; t < d; ++t) {
+                ls[t] += ls[t + d];
+                lm[t] = lm[t + d] > lm[t] ? lm[t + d] : lm[t];
+            }
+        sum_out += ls[0];
+        max_out = std::max(max_out, lm[0]);
+    }
+}
+
+uint32_t run_chains(Emu &s, bool with_reference) {
+    std::vector<Chain> chains;
+    std::vector<uint32_t> chunk_chain;
+    build_chains(s, with_reference, chains, chunk_chain);
+    const uint32_t n = (uint32_t)chunk_chain.size();
+    if (!n) return 0;
+    std::vector<uint32_t> used(n, 0), out[2] = {std::vector<uint32_t>(n, 0), std::vector<uint32_t>(n, 0)};
+    uint32_t pass = 0;
+    for (;; ++pass) {                                      // same pass structure as k_sys_chain + run_sys_chains
+        bool changed = false;
+        const std::vector<uint32_t> &prev = out[(pass + 1) & 1];
+        std::vector<uint32_t> &cur = out[pass & 1];
+        for (uint32_t c = 0; c < n; ++c) {
+            const Chain &ch = chains[chunk_chain[c]];
+            const uint32_t local = c - ch.first_chunk;
+            uint32_t want = 0;
+            if (pass > 0) {
+                if (local == 0) {
+                    cur[c] = prev[c];
+                    continue;
+                }
+                want = prev[c - 1];
+                if (want == used[c]) {
+                    cur[c] = prev[c];
+                    continue;
+                }
+                changed = true;
+            }
+            used[c] = want;
+            ChainAcc acc{s.dev.ref_words, ch.kind, ch.len, ch.kind < 2 ? s.seq_word_off[ch.id] : 0,
+                         ch.kind == 2 ? s.dev.adapters[ch.seg].seqs + s.dev.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
+            uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
+            const uint32_t lo = local * kChainChunk, hi = std::min(lo + kChainChunk, ch.len);
+            sys_chain_chunk(s.dev, acc, ch.c1, ch.c2, lo, hi, ch.initial_dom, dist, start_rate, ch.out);
+            cur[c] = dist | (start_rate << 24);
+        }
+        if (pass > 0 && !changed) break;
+    }
+    return pass + 1;
+}
+
+struct Raw {
+    std::vector<uint8_t> seq, qual;
+    std::vector<uint32_t> ops;
+    ReadOut out(const Emu &s) {
+        seq.assign(s.read_stride + 8, 0);
+        qual.assign(s.read_stride + 8, 0);
+        ops.assign(s.ops_stride + 64, 0);
+        return ReadOut{seq.data(), qual.data(), ops.data(), 0u, 0u};
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *emu_last_error() { return g_err.c_str(); }
+
+int emu_create(const char *profile_path, const char *fasta_path, uint64_t replace_n_seed, void **out) {
+    return guard([&] {
+        std::unique_ptr<Emu> s(new Emu());
+        s->prof = Profile::load(profile_path);
+        pack_tables(*s, s->up);
+        pack_profile(*s, s->up);
+        if (fasta_path && fasta_path[0]) {
+            Reference r = Reference::read_fasta(fasta_path);
+            r.replace_n(replace_n_seed);
+            pack_reference(*s, s->up, r);
+        }
+        *out = s.release();
+    });
+}
+void emu_free(void *h) { delete static_cast<Emu *>(h); }
+
+int emu_edit_profile(void *h, double error_multiplier, int no_substitutions, int no_indels) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        if (error_multiplier != 1.0) s.prof.change_error_rate(error_multiplier);
+        if (no_substitutions) s.prof.remove_substitution_errors();
+        if (no_indels) s.prof.remove_indel_errors();
+        pack_tables(s, s.up);                               // repack the edited tables
+    });
+}
+
+int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        plan_simulation(s, s.up, seed, num_pairs, coverage, ref_bias_mode, base_identifier);
+        if (s.has_ref) {
+            const BiasPlan plan = plan_bias_normalization(s, s.up);
+            std::vector<double> sums(plan.params.size()), maxes(plan.params.size());
+            for (size_t i = 0; i < plan.params.size(); ++i) sum_bias_like_kernel(s, plan.params[i], sums[i], maxes[i]);
+            finish_bias_normalization(s, plan, sums, maxes);
+            upload_normalization(s, s.up);
+        }
+        s.passes = run_chains(s, s.has_ref);
+        s.prepared = true;
+    });
+}
+
+struct emu_info {
+    uint64_t total_pairs, adapter_only_pairs;
+    uint32_t total_blocks, n_groups, insert_to, passes, n_seqs, rmax;
+    double bias_normalization;
+};
+void emu_get_info(void *h, emu_info *o) {
+    Emu &s = *static_cast<Emu *>(h);
+    *o = emu_info{s.total_pairs, s.adapter_only_pairs, s.total_blocks, s.n_groups, s.dev.insert_to, s.passes, s.dev.n_seqs, s.rmax, s.bias_normalization};
+}
+void emu_get_thresholds(void *h, double *out) {
+    Emu &s = *static_cast<Emu *>(h);
+    memcpy(out, s.thresholds.data(), s.thresholds.size() * 8);
+}
+void emu_get_norm_by_len(void *h, double *out) {
+    Emu &s = *static_cast<Emu *>(h);
+    memcpy(out, s.norm_by_len.data(), s.norm_by_len.size() * 8);
+}
+int emu_set_normalization(void *h, double bias_normalization, const double *thr, size_t n) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        if (n != s.thresholds.size()) throw Error("bad threshold count");
+        s.bias_normalization = bias_normalization;
+        s.thresholds.assign(thr, thr + n);
+        upload_normalization(s, s.up);
+    });
+}
+void emu_get_sys(void *h, int reverse, uint32_t seq, uint8_t *dom, uint8_t *rate) {
+    Emu &s = *static_cast<Emu *>(h);
+    const uint16_t *src = (reverse ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq];
+    for (uint32_t i = 0; i < s.seq_len[seq]; ++i) {
+        dom[i] = (uint8_t)(src[i] & 0xFF);
+        rate[i] = (uint8_t)(src[i] >> 8);
+    }
+}
+void emu_get_adapter_sys(void *h, int seg, uint32_t id, uint8_t *dom, uint8_t *rate) {
+    Emu &s = *static_cast<Emu *>(h);
+    const HostAdapters &a = s.prof.adapters[seg];
+    for (uint32_t i = 0; i < a.seq_ptr[id + 1] - a.seq_ptr[id]; ++i) {
+        dom[i] = (uint8_t)(s.adapter_sys[seg][a.seq_ptr[id] + i] & 0xFF);
+        rate[i] = (uint8_t)(s.adapter_sys[seg][a.seq_ptr[id] + i] >> 8);
+    }
+}
+void emu_get_codes(void *h, uint32_t seq, uint8_t *out) {            // unpacks the 2-bit reference again
+    Emu &s = *static_cast<Emu *>(h);
+    for (uint32_t i = 0; i < s.seq_len[seq]; ++i) out[i] = (uint8_t)ref_base(s.dev.ref_words, s.seq_word_off[seq], i);
+}
+
+// the walk of k_sieve<COUNT> + scan + k_sieve<EMIT> with a plain loop over slots and lengths
+int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, uint64_t cap) {
+    Emu &s = *static_cast<Emu *>(h);
+    const DevSim &S = s.dev;
+    uint64_t n = 0;
+    for (uint32_t block_id = block_lo; block_id < block_hi; ++block_id) {
+        uint32_t number = 0;
+        for (uint32_t off = 0; off < kBlockSize; ++off) {
+            SieveSite site;
+            site.seq = S.block_seq[block_id];
+            site.L = S.seq_len[site.seq];
+            site.start = (block_id - S.first_block[site.seq]) * kBlockSize + off;
+            if (site.start >= site.L) break;
+            site.word_off = S.seq_word_off[site.seq];
+            site.thr = S.thresholds + (size_t)S.coverage_group[site.seq] * S.insert_to * 2u;
+            site.have_start = false;
+            for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
+                uint32_t cnt[2], strand_of[2];
+                if (!sieve_cell(S, site, len, cnt, strand_of)) continue;
+                for (uint32_t j = 0; j < 2; ++j)
+                    for (uint32_t dup = 0; dup < cnt[j]; ++dup) {
+                        if (n < cap) out[n] = make_fragment(site, len, dup, strand_of[j], block_id, number + 1);
+                        ++number;
+                        ++n;
+                    }
+            }
+        }
+    }
+    return (int64_t)n;
+}
+
+// k_fill_reads + k_format for fragments (frags != NULL) or adapter-only pairs; returns bytes written per file
+int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t cap1, size_t *len1, char *r2, size_t cap2, size_t *len2) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        size_t pos[2] = {0, 0};
+        char *dst[2] = {r1, r2};
+        size_t cap[2] = {cap1, cap2};
+        Raw raw;
+        for (uint64_t pair = 0; pair < n_pairs; ++pair)
+            for (uint32_t seg = 0; seg < 2; ++seg) {
+                ReadOut out = raw.out(s);
+                ReadMeta meta;
+                if (frags) fill_fragment_read(s.dev, frags[pair], seg, out, meta);
+                else fill_adapter_only_read(s.dev, adapter_first + pair, seg, out, meta);
+                out.finish();
+                const uint32_t need = format_record(s.dev, s.names, frags ? &frags[pair] : nullptr, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(),
+                                                    raw.ops.data(), nullptr);
+                if (pos[seg] + need > cap[seg]) throw Error("text buffer too small");
+                format_record(s.dev, s.names, frags ? &frags[pair] : nullptr, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(), raw.ops.data(), dst[seg] + pos[seg]);
+                pos[seg] += need;
+            }
+        *len1 = pos[0];
+        *len2 = pos[1];
+    });
+}
+
+// k_error_model + k_error_model_out
+int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs, const uint8_t *segs, const uint32_t *frag_len, const uint8_t *dom,
+                    const uint8_t *rate, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *nerr_out, uint16_t *tile_out,
+                    char *cigar_out, uint32_t cigar_stride) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        s.ops_stride = std::max(s.ops_stride, (s.rmax + read_len + s.max_adapter + 4u + 15u) / 16u);
+        Raw raw;
+        for (uint64_t i = 0; i < n; ++i) {
+            ReadOut out = raw.out(s);
+            ReadMeta m;
+            RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
+            fill_record_read(s.dev, first_index + i, segs[i], frag_len[i], src, out, m);
+            out.finish();
+            read_len_out[i] = m.read_len;
+            nerr_out[i] = m.num_errors;
+            tile_out[i] = m.tile_id;
+            if (m.read_len > out_stride || m.cigar_chars + 1 > cigar_stride) throw Error("output stride too small");
+            memcpy(seq_out + i * out_stride, raw.seq.data(), m.read_len);
+            memcpy(qual_out + i * out_stride, raw.qual.data(), m.read_len);
+            TextSink t{cigar_out + i * cigar_stride, 0};
+            cigar_replay(raw.ops.data(), m, t);
+            if (t.n != m.cigar_chars) throw Error("cigar_chars disagrees with the replayed CIGAR");
+            t.ch(0);
+        }
+    });
+}
+
+// single draws, for direct comparison with the oracle's Draw
+uint32_t emu_draw(void *h, int family, uint32_t index, const uint32_t *idx, double u, double *prob_sum) {
+    Emu &s = *static_cast<Emu *>(h);
+    const DevSim &S = s.dev;
+    if (family == 0 || family == 2) {
+        const uint32_t i4[4] = {idx[0], idx[1], idx[2], idx[3]};
+        return draw<4>((family == 0 ? S.quality : S.base_call)[index], S.pool, S.par0, i4, u, *prob_sum);
+    }
+    const uint32_t i3[3] = {idx[0], idx[1], idx[2]};
+    const DevTable *t = family == 1 ? S.seq_quality : family == 3 ? S.dom_error : family == 4 ? S.error_rate : S.indels;
+    return draw<3>(t[index], S.pool, S.par0, i3, u, *prob_sum);
+}
+
+void emu_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
+    const Words w = philox(seed, c0, c1, c2, c3);
+    out[0] = w.w0;
+    out[1] = w.w1;
+    out[2] = w.w2;
+    out[3] = w.w3;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+"""Parity cases shared by the CPU emulation run (`-m "not gpu"`) and the GPU run (`-m gpu`).
+
+Every case builds the same inputs for the oracle (oracle/liboracle.so) and for a backend (tests/backends.py) and
+compares: bit-exact for bytes / integers / indices (systematic-error tracks, fragment lists, FASTQ text, CIGARs),
+relative 1e-11 for the double-precision bias-normalisation results whose summation order differs (tree reduction
+on the device, sequential in the reference).
+"""
+import numpy as np
+
+import oracle_lib as O
+from reseq_amd import synth
+
+NORM_RTOL = 1e-11      # a14: device tree-reduction vs sequential sum of ~1e6 positive doubles
+
+
+def make_inputs(workdir, tag, cfg, ref_lengths, prof_seed=5, ref_seed=1, gc=0.5):
+    ppath = workdir / f"{tag}.rsqp"
+    fpath = workdir / f"{tag}.fa"
+    if not ppath.exists():
+        synth.write_profile(ppath, synth.make_profile(cfg, seed=prof_seed, n_ref_seqs=len(ref_lengths)))
+    seqs = synth.make_reference(ref_seed, ref_lengths, gc=gc)
+    if not fpath.exists():
+        synth.write_fasta(fpath, seqs)
+    return str(ppath), str(fpath), seqs
+
+
+class Pair:
+    """oracle + backend on the same inputs"""
+
+    def __init__(self, backend_cls, workdir, tag, cfg, ref_lengths, seed, num_pairs=0, coverage=0.0, base_identifier="", edits=None, **kw):
+        self.ppath, self.fpath, self.seqs = make_inputs(workdir, tag, cfg, ref_lengths, **kw)
+        self.oprof = O.Profile(self.ppath)
+        if edits:
+            L = O.lib()
+            if edits.get("error_multiplier", 1.0) != 1.0:
+                L.orc_profile_change_error_rate(self.oprof.h, edits["error_multiplier"])
+            if edits.get("no_substitutions"):
+                L.orc_profile_remove_substitution_errors(self.oprof.h)
+            if edits.get("no_indels"):
+                L.orc_profile_remove_indel_errors(self.oprof.h)
+        self.oref = O.Reference(self.seqs)
+        self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode())
+        self.b = backend_cls(self.ppath, self.fpath, 0, edits)
+        self.info = self.b.prepare(seed, num_pairs, coverage, 0, base_identifier)
+
+    def align_normalization(self):
+        """stage-wise parity: give the backend the oracle's thresholds so that the sieve sees identical doubles"""
+        self.b.set_normalization(self.osim.bias_normalization(), self.osim.thresholds())
+
+    def close(self):
+        self.b.close()
+        self.osim.close()
+        self.oref.close()
+        self.oprof.close()
+
+
+def case_reference_packing(backend_cls, workdir):
+    ppath, fpath, seqs = make_inputs(workdir, "pack", synth.TINY, [777, 33, 1025, 64])
+    b = backend_cls(ppath, fpath)
+    for i, (_, codes) in enumerate(seqs):
+        assert np.array_equal(b.codes(i, len(codes)), codes)
+    b.close()
+
+
+def case_prepass(backend_cls, workdir):
+    # three sequences, the middle one shorter than the longest insert (no unit: Simulator.cpp:1159)
+    p = Pair(backend_cls, workdir, "prepass", synth.TINY, [4100, 70, 2999], seed=11, num_pairs=4000)
+    try:
+        assert p.info["total_pairs"] == p.osim.total_pairs()
+        assert p.info["adapter_only_pairs"] == p.osim.adapter_only_pairs()
+        assert p.info["total_blocks"] == p.osim.total_blocks() == 5 + 3
+        np.testing.assert_allclose(p.b.norm_by_len(), p.osim.norm_by_len(), rtol=NORM_RTOL, atol=0)
+        np.testing.assert_allclose(p.b.thresholds(), p.osim.thresholds(), rtol=NORM_RTOL, atol=0)
+        assert abs(p.info["bias_normalization"] / p.osim.bias_normalization() - 1) < NORM_RTOL
+        for seq in (0, 2):
+            n = len(p.seqs[seq][1])
+            for strand in (0, 1):
+                od, orate = p.osim.sys_errors(strand, seq)
+                bd, brate = p.b.sys_errors(strand, seq, n)
+                assert np.array_equal(od, bd) and np.array_equal(orate, brate), (seq, strand)
+        arr = synth.make_profile(synth.TINY, seed=5)
+        for seg in (0, 1):
+            ptr = arr[f"adapters.{seg}.seq_ptr"]
+            for a in range(len(ptr) - 1):
+                n = int(ptr[a + 1] - ptr[a])
+                o = p.osim.adapter_sys_errors(seg, a, n)
+                bd, brate = p.b.adapter_sys_errors(seg, a, n)
+                assert np.array_equal(o[0], bd) and np.array_equal(o[1], brate), (seg, a)
+        assert p.info["passes"] >= 2
+    finally:
+        p.close()
+
+
+def _compare_blocks(p, lo, hi):
+    ofr = p.osim.sieve(lo, hi)
+    o1, o2 = p.osim.create_reads(ofr)
+    bfr, b1, b2 = p.b.pairs(lo, hi)
+    assert len(ofr) == len(bfr)
+    assert ofr.tobytes() == bfr.tobytes()          # start positions, lengths, strands, duplicates, ids: bit-identical
+    assert o1 == b1
+    assert o2 == b2
+    return len(ofr), o1
+
+
+def case_sieve_and_reads_tiny(backend_cls, workdir):
+    p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=7, num_pairs=3000)
+    try:
+        p.align_normalization()
+        tb = p.info["total_blocks"]
+        n_all, text = _compare_blocks(p, 1, tb + 1)
+        assert 2000 < n_all < 4000
+        # batching by block range does not change anything
+        n_a, _ = _compare_blocks(p, 1, 4)
+        n_b, _ = _compare_blocks(p, 4, tb + 1)
+        assert n_a + n_b == n_all
+        assert _compare_blocks(p, 3, 3)[0] == 0               # empty range
+        # the profile exercises indels, adapters, several tiles and variable read lengths
+        assert b"D" in text and b"I" in text and b"S" in text and b"H" in text
+        assert b":1102:" in text and b":2308:" in text
+        lens = {len(l) for l in text.split(b"\n")[1::4]}
+        assert len(lens) > 1
+    finally:
+        p.close()
+
+
+def case_sieve_own_thresholds(backend_cls, workdir):
+    """the other direction: the oracle takes the backend's own pre-pass results (tree-reduced sums)"""
+    p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=21, num_pairs=2500, base_identifier="Sim")
+    try:
+        p.osim.set_normalization(p.info["bias_normalization"], p.b.thresholds())
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert n > 1500 and text.startswith(b"@Sim1_1:")
+    finally:
+        p.close()
+
+
+def case_adapter_only(backend_cls, workdir):
+    p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=3, num_pairs=30000)
+    try:
+        n = p.info["adapter_only_pairs"]
+        assert n == p.osim.adapter_only_pairs() and n > 10
+        o1, o2 = p.osim.adapter_only()
+        b1, b2 = p.b.adapter_only_pairs(0, n)
+        assert o1 == b1 and o2 == b2
+        # split in two calls
+        c1, c2 = p.b.adapter_only_pairs(0, 5)
+        d1, d2 = p.b.adapter_only_pairs(5, n - 5)
+        assert c1 + d1 == o1 and c2 + d2 == o2
+    finally:
+        p.close()
+
+
+def case_p0_reads(backend_cls, workdir):
+    """HiSeq-shaped profile (K = 40 qualities, 2x150): a 30 kb reference, about 1500 pairs"""
+    p = Pair(backend_cls, workdir, "p0_small", synth.P0, [30000], seed=11, num_pairs=1500, prof_seed=103741084, ref_seed=2)
+    try:
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert 1000 < n < 2000
+        recs = text.split(b"\n")
+        assert all(len(s) == 150 for s in recs[1::4])
+    finally:
+        p.close()
+
+
+def case_profile_edits(backend_cls, workdir):
+    for edits in ({"error_multiplier": 3.0}, {"no_substitutions": True}, {"no_indels": True}, {"no_substitutions": True, "no_indels": True}):
+        p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=5, num_pairs=800, edits=edits)
+        try:
+            p.align_normalization()
+            n, text = _compare_blocks(p, 1, 4)
+            assert n > 100
+            if edits.get("no_indels"):
+                assert all(b"D" not in l.split(b" ")[1] and b"I" not in l.split(b" ")[1] for l in text.split(b"\n")[0::4] if l)
+            if edits.get("no_substitutions") and edits.get("no_indels"):
+                assert all(l.endswith(b" E0") for l in text.split(b"\n")[0::4] if l)
+        finally:
+            p.close()
+
+
+def _error_model(backend_cls, workdir, tag, cfg, n, read_len, seed, prof_seed, zero_frac):
+    ppath, _, _ = make_inputs(workdir, tag, cfg, [100], prof_seed=prof_seed)
+    arrays = synth.make_profile(cfg, seed=prof_seed)
+    rec = synth.make_error_model_input(9, n, read_len, arrays, zero_frac=zero_frac)
+    oprof = O.Profile(ppath)
+    exp = O.error_model_only(oprof, seed, rec, first_index=17)
+    b = backend_cls(ppath, None)
+    b.prepare(seed)
+    got = b.error_model(rec, first_index=17)
+    assert len(got) == len(exp) == n
+    for i, (e, g) in enumerate(zip(exp, got)):
+        assert e == g, i
+    b.close()
+    oprof.close()
+    return exp
+
+
+def case_error_model_tiny(backend_cls, workdir):
+    exp = _error_model(backend_cls, workdir, "em_tiny", synth.TINY, 400, 30, seed=13, prof_seed=5, zero_frac=0.7)
+    assert len({e[4] for e in exp}) == 3                      # all three tiles drawn
+    assert any("D" in e[2] for e in exp) and any("I" in e[2] for e in exp)
+
+
+def case_error_model_long_templates(backend_cls, workdir):
+    # templates longer than the profile's read length (the tail of the template is never reached)
+    _error_model(backend_cls, workdir, "em_tiny", synth.TINY, 64, 75, seed=2, prof_seed=5, zero_frac=0.5)
+
+
+def case_error_model_p0(backend_cls, workdir):
+    exp = _error_model(backend_cls, workdir, "em_p0", synth.P0, 300, 150, seed=99, prof_seed=103741084, zero_frac=0.97)
+    assert all(len(e[0]) == 150 for e in exp)

@@ -1,0 +1,89 @@
+"""The C-ABI library loads, exports every symbol include/reseq_amd.h declares, its host-only entry points work
+without a GPU, and the simulation entry points fail loudly (no CPU fallback) when no device is visible."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, read_fasta
+from reseq_amd import api
+
+HEADER = os.path.join(ROOT, "include", "reseq_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(api.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(api.SYMBOLS) == names                     # the Python binding covers the whole header
+
+
+def test_version_and_error_strings():
+    L = api.lib()
+    assert b"gfx950" in L.rsq_version()
+    h = C.c_void_p()
+    assert L.rsq_profile_load(b"/nonexistent/profile.rsqp", C.byref(h)) == api.RSQ_EIO
+    assert b"cannot open" in L.rsq_last_error()
+
+
+def test_reference_loading_matches_the_reference_tests_fixture():
+    ref = api.Reference(os.path.join(GOLDEN, "reference-test.fa"))
+    exp = read_fasta(os.path.join(GOLDEN, "reference-test.fa"))
+    assert ref.num_sequences() == 2
+    assert [ref.sequence_length(i) for i in range(2)] == [500, 501]        # ReferenceTest.cpp:275-276
+    for i in range(2):
+        assert np.array_equal(ref.codes(i), exp[i][1])
+    ref.close()
+
+
+def test_replace_n_is_seeded_and_complete(workdir):
+    path = workdir / "withn.fa"
+    path.write_text(">a\nACGTNNNNACGTRYKM\nnnAC\n>b\nNNNN\n")
+    r1, r2, r3 = (api.Reference(path, s) for s in (5, 5, 6))
+    a, b, c = r1.codes(0), r2.codes(0), r3.codes(0)
+    assert a.max() <= 3 and np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a[:4].tolist() == [0, 1, 2, 3] and a[8:12].tolist() == [0, 1, 2, 3]
+    raw = api.Reference(path).codes(0)
+    assert (raw == 4).sum() == 10                               # IUPAC codes other than ACGT load as N
+    for r in (r1, r2, r3):
+        r.close()
+
+
+def test_profile_loading_and_edits(tiny_profile_path):
+    p = api.Profile(tiny_profile_path)
+    assert p.max_read_length() == 30
+    p.change_error_rate(2.0)
+    p.remove_substitution_errors()
+    p.remove_indel_errors()
+    with pytest.raises(api.RsqError):
+        p.change_error_rate(0.0)
+    p.close()
+
+
+def test_truncated_profile_is_rejected(tiny_profile_path, workdir):
+    data = open(tiny_profile_path, "rb").read()
+    bad = workdir / "truncated.rsqp"
+    bad.write_bytes(data[: len(data) // 2])
+    with pytest.raises(api.RsqError) as e:
+        api.Profile(bad)
+    assert e.value.code == api.RSQ_EIO
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback_without_a_gpu(tiny_profile_path):
+    p = api.Profile(tiny_profile_path)
+    with pytest.raises(api.RsqError) as e:
+        api.Simulator(p, None, 0)
+    assert e.value.code == api.RSQ_ENODEV
+    assert "no CPU fallback" in str(e.value)
+    p.close()

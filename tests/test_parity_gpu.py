@@ -1,0 +1,53 @@
+"""GPU parity: the product (libreseq_amd.so through the C ABI, reseq_amd.api) against the CPU oracle on the same
+seeded inputs.  Same cases as tests/test_parity_hostemu.py (tests/parity_cases.py)."""
+import pytest
+
+import parity_cases as P
+from backends import GpuBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_visible():
+    from reseq_amd import api
+    assert api.device_count() >= 1
+
+
+def test_reference_packing(workdir):
+    P.case_reference_packing(GpuBackend, workdir)
+
+
+def test_prepass(workdir):
+    P.case_prepass(GpuBackend, workdir)
+
+
+def test_sieve_and_reads_tiny(workdir):
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+
+
+def test_sieve_own_thresholds(workdir):
+    P.case_sieve_own_thresholds(GpuBackend, workdir)
+
+
+def test_adapter_only(workdir):
+    P.case_adapter_only(GpuBackend, workdir)
+
+
+def test_p0_reads(workdir):
+    P.case_p0_reads(GpuBackend, workdir)
+
+
+def test_profile_edits(workdir):
+    P.case_profile_edits(GpuBackend, workdir)
+
+
+def test_error_model_tiny(workdir):
+    P.case_error_model_tiny(GpuBackend, workdir)
+
+
+def test_error_model_long_templates(workdir):
+    P.case_error_model_long_templates(GpuBackend, workdir)
+
+
+def test_error_model_p0(workdir):
+    P.case_error_model_p0(GpuBackend, workdir)

@@ -1,0 +1,91 @@
+"""CPU checks of the kernels' logic: the per-lane __host__ __device__ functions of reseq_amd/csrc (state
+machine, draws, packing, Philox counter layout, chunked systematic-error chains, sieve cells, FASTQ formatting)
+looped on the host by tests/hostemu and compared with the oracle.  The GPU run of the same cases through the
+C ABI is tests/test_parity_gpu.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_cases as P
+from backends import EmuBackend, emu_lib
+
+
+def test_philox_matches_oracle():
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        seed = int(rng.integers(0, 2 ** 63))
+        c = [int(x) for x in rng.integers(0, 2 ** 32, size=4)]
+        out = np.zeros(4, np.uint32)
+        emu_lib().emu_philox(seed, *c, out.ctypes.data)
+        assert out.tolist() == list(O.lib().orc_philox4x32_10(seed, *c).w)
+
+
+def test_single_draws_match_oracle(p0_profile_path, tiny_profile_path):
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    for path in (tiny_profile_path, p0_profile_path):
+        oprof = O.Profile(path)
+        b = EmuBackend(path)
+        fams = [("quality", 4, lambda: (int(rng.integers(0, 2)), 0, int(rng.integers(0, 4)), 0)),
+                ("seq_quality", 3, lambda: (int(rng.integers(0, 2)), 0, 0, 0)),
+                ("base_call", 4, lambda: (int(rng.integers(0, 2)), 0, int(rng.integers(0, 4)), int(rng.integers(0, 5)))),
+                ("dom_error", 3, lambda: (int(rng.integers(0, 4)), int(rng.integers(0, 5)), int(rng.integers(0, 5)), 0)),
+                ("error_rate", 3, lambda: (int(rng.integers(0, 4)), int(rng.integers(0, 5)), 0, 0)),
+                ("indels", 3, lambda: (int(rng.integers(0, 2)), int(rng.integers(0, 6)), 0, 0))]
+        nt = 3 if path == tiny_profile_path else 1
+        for fam, nm, pick in fams:
+            for _ in range(300):
+                a, bb, c, d = pick()
+                if fam in ("quality", "seq_quality", "base_call"):
+                    bb = int(rng.integers(0, nt))
+                flat = {"quality": (a * nt + bb) * 4 + c, "seq_quality": a * nt + bb, "base_call": ((a * nt + bb) * 4 + c) * 5 + d,
+                        "dom_error": (a * 5 + bb) * 5 + c, "error_rate": a * 5 + bb, "indels": a * 6 + bb}[fam]
+                idx = [int(x) for x in rng.integers(0, 200, size=nm)]       # far outside the limits too: clamping
+                u = float(rng.random()) if rng.random() < 0.9 else float(rng.choice([0.0, 1.0 - 2 ** -32]))
+                ps = C.c_double()
+                ii = np.asarray(idx, np.uint32)
+                exp = O.lib().orc_draw(oprof.table(fam, a, bb, c, d), O._ptr(ii, O.u32p), u, C.byref(ps))
+                got, gps = b.draw(fam, flat, idx, u)
+                assert (got, gps) == (exp, ps.value), (fam, a, bb, c, d, idx, u)
+        b.close()
+        oprof.close()
+
+
+def test_reference_packing(workdir):
+    P.case_reference_packing(EmuBackend, workdir)
+
+
+def test_prepass(workdir):
+    P.case_prepass(EmuBackend, workdir)
+
+
+def test_sieve_and_reads_tiny(workdir):
+    P.case_sieve_and_reads_tiny(EmuBackend, workdir)
+
+
+def test_sieve_own_thresholds(workdir):
+    P.case_sieve_own_thresholds(EmuBackend, workdir)
+
+
+def test_adapter_only(workdir):
+    P.case_adapter_only(EmuBackend, workdir)
+
+
+def test_p0_reads(workdir):
+    P.case_p0_reads(EmuBackend, workdir)
+
+
+def test_profile_edits(workdir):
+    P.case_profile_edits(EmuBackend, workdir)
+
+
+def test_error_model_tiny(workdir):
+    P.case_error_model_tiny(EmuBackend, workdir)
+
+
+def test_error_model_long_templates(workdir):
+    P.case_error_model_long_templates(EmuBackend, workdir)
+
+
+def test_error_model_p0(workdir):
+    P.case_error_model_p0(EmuBackend, workdir)
