@@ -135,7 +135,7 @@ def main():
         fill_ms += f
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve_count", "sieve_emit", "fill_reads", "format_sizes", "format_write", "scan")}
+    kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_emit", "fill_reads", "format_write", "scan")}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")

@@ -512,21 +512,22 @@ uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi
                 orc_surrounding_update_forward(codes, L, start, sur_start);
                 uint32_t last_gc = 0, last_gc_end = start;                                                  /* :1696-1697 */
                 for (uint32_t len = frag_len_start; len < to; ++len) {
-                    orc_philox_out w = orc_philox4x32_10(s->seed, start, seq, len, (uint32_t)ORC_DOM_SIEVE << 28);
-                    double probability_chosen = orc_u53(w.w[0], w.w[1]);
+                    /* one Philox block serves the two cells (start, 2q) and (start, 2q+1): DESIGN.md "Random streams" */
+                    orc_philox_out w = orc_philox4x32_10(s->seed, start, seq, len >> 1, (uint32_t)ORC_DOM_SIEVE << 28);
+                    double probability_chosen = (len & 1u) ? orc_u53(w.w[2], w.w[3]) : orc_u53(w.w[0], w.w[1]);
                     if (!(probability_chosen >= thr[2 * len + 1])) continue;                               /* Simulator.h:418-420 */
                     uint16_t non_zero_strands = orc_binomial(2, 1 - thr[2 * len], probability_chosen);     /* :2307, FDS.cpp:3598 */
                     if (!non_zero_strands) continue;
+                    orc_philox_out w2 = orc_philox4x32_10(s->seed, start, seq, len, ((uint32_t)ORC_DOM_SIEVE << 28) | 1u);
                     uint16_t chosen[2];
                     uint32_t n_chosen = 0;
                     uint8_t reverse_selection[2] = {1, 1};
-                    if (non_zero_strands <= 1) orc_select_allele(chosen, &n_chosen, reverse_selection, 2, orc_u32(w.w[2]));   /* :1387-1391 */
+                    if (non_zero_strands <= 1) orc_select_allele(chosen, &n_chosen, reverse_selection, 2, orc_u32(w2.w[2]));  /* :1387-1391 */
                     else {                                                                                  /* :1392-1396: complement of nothing */
                         chosen[0] = 0;
                         chosen[1] = 1;
                         n_chosen = 2;
                     }
-                    orc_philox_out w2 = orc_philox4x32_10(s->seed, start, seq, len, ((uint32_t)ORC_DOM_SIEVE << 28) | 1u);
                     for (uint32_t j = 0; j < n_chosen; ++j) {
                         uint8_t strand = chosen[j] % 2;
                         uint32_t end = start + len;

@@ -21,21 +21,14 @@ struct Words {
     uint32_t w0, w1, w2, w3;
 };
 
-RSQ_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
 
 // Philox4x32-10 (Salmon et al., SC11); key = seed, counter = (c0,c1,c2,c3).
 RSQ_HD Words philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;      // one v_mad_u64_u32 each
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -80,41 +73,101 @@ RSQ_HD uint32_t discrete_draw(const double *cp, uint32_t n, double u) {
 }
 
 // --------------------------------------------------------------------------- LogArrayResult<N>::Draw
-// ProbabilityEstimates.h:359-380 (Likelihood, AdjustIndeces) and :481-508 (Draw).  Two passes over the K
-// outcome columns: pass 1 forms prob_sum in ascending order, pass 2 re-forms the same products from the
-// top until the running sum exceeds u*prob_sum.  Nothing is kept between the passes, so K is unbounded and
-// the lane needs no per-outcome registers.
-template <int NM>
-RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, const uint8_t *__restrict__ par0, const uint32_t (&idx)[NM], double u,
-                     double &prob_sum) {
-    prob_sum = 0.0;
-    const uint32_t K = t.k;
-    if (!K) return 0;
-    const double *m[NM];
-#pragma unroll
-    for (int n = 0; n < NM; ++n) {
-        uint32_t r = idx[n] < t.from[n] ? 0u : (idx[n] - t.from[n] >= t.rows[n] ? t.rows[n] - 1u : idx[n] - t.from[n]);
-        m[n] = pool + t.off[n] + (size_t)r * K;
-    }
+// ProbabilityEstimates.h:359-380 (Likelihood, AdjustIndeces) and :481-508 (Draw).  Two passes over the K outcome
+// columns: pass 1 forms prob_sum in ascending order, pass 2 re-forms the same products from the top until the running
+// sum exceeds u*prob_sum.  Nothing is kept between the passes, so K is unbounded and the lane needs no per-outcome
+// registers.  Rows have an even stride (zero pad column), so both passes read two columns per 16-byte load; the pad
+// column adds +0.0 to prob_sum in pass 1 (exact) and is skipped in pass 2.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQ_LDS __attribute__((address_space(3)))
+#else
+#define RSQ_LDS
+#endif
+
+struct alignas(16) Pair {
+    double x, y;
+};
+
+struct GlobalRow {                     // a margin row in HBM (read through L1/L2)
+    const double *p;
+    RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const Pair *>(p + 2u * j); }
+};
+struct LdsRow {                        // a margin row staged in the workgroup's LDS image
+    const RSQ_LDS double *p;
+    RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const RSQ_LDS Pair *>(p + 2u * j); }
+};
+
+template <class R>
+RSQ_HD void mul_into(Pair &a, const R &r, uint32_t j) {
+    const Pair b = r.pair(j);
+    a.x *= b.x;
+    a.y *= b.y;
+}
+template <class R0, class... Rs>
+RSQ_HD Pair prod_pair(uint32_t j, const R0 &r0, const Rs &...rs) {      // ((r0*r1)*r2)*r3, the order of Likelihood()
+    Pair a = r0.pair(j);
+    (mul_into(a, rs, j), ...);
+    return a;
+}
+
+// returns the outcome COLUMN (index into par0); prob_sum as in the reference
+template <class... Rs>
+RSQ_HD uint32_t draw_rows(uint32_t K, double u, double &prob_sum, const Rs &...rs) {
     double s = 0.0;
-    for (uint32_t k = 0; k < K; ++k) {
-        double p = m[0][k];
-#pragma unroll
-        for (int n = 1; n < NM; ++n) p *= m[n][k];
-        s += p;
+    const uint32_t np = (K + 1u) >> 1;
+    for (uint32_t j = 0; j < np; ++j) {
+        const Pair p = prod_pair(j, rs...);
+        s += p.x;
+        s += p.y;
     }
     prob_sum = s;
     const double r = u * s;
     double sum = 0.0;
-    uint32_t k = K;
-    while (sum <= r && --k) {
-        double p = m[0][k];
-#pragma unroll
-        for (int n = 1; n < NM; ++n) p *= m[n][k];
-        sum += p;
+    for (uint32_t j = np; j--;) {                 // while(sum <= r && --k) sum += prob[k], two columns per step
+        const Pair p = prod_pair(j, rs...);
+        const uint32_t hi = 2u * j + 1u;
+        if (hi < K) {
+            sum += p.y;
+            if (!(sum <= r)) return hi;
+        }
+        if (j == 0) return 0;                     // column 0 is never added
+        sum += p.x;
+        if (!(sum <= r)) return 2u * j;
     }
-    return par0[t.par0_off + k];
+    return 0;
 }
+
+RSQ_HD uint32_t clamp_row(const DevTable &t, int n, uint32_t v) {      // AdjustIndeces (:368-380)
+    return v < t.from[n] ? 0u : (v - t.from[n] >= t.rows[n] ? t.rows[n] - 1u : v - t.from[n]);
+}
+
+// generic draw with every margin in HBM; returns the outcome VALUE
+template <int NM>
+RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, const uint8_t *__restrict__ par0, const uint32_t (&idx)[NM], double u,
+                     double &prob_sum) {
+    prob_sum = 0.0;
+    if (!t.k) return 0;
+    const uint32_t kp = row_stride(t.k);
+    GlobalRow m[NM];
+#pragma unroll
+    for (int n = 0; n < NM; ++n) m[n].p = pool + t.off[n] + (size_t)clamp_row(t, n, idx[n]) * kp;
+    uint32_t col;
+    if constexpr (NM == 3) col = draw_rows(t.k, u, prob_sum, m[0], m[1], m[2]);
+    else col = draw_rows(t.k, u, prob_sum, m[0], m[1], m[2], m[3]);
+    return par0[t.par0_off + col];
+}
+
+// How FillRead reaches its tables.  GlobalTables reads descriptors and rows from HBM; the read kernel uses LdsTables
+// (rsq_kernels.h) which serves descriptors and the per-lane-varying margins from LDS.
+struct GlobalTables {
+    const DevSim &S;
+    RSQ_HD const DevTable &quality(uint32_t i) const { return S.quality[i]; }
+    RSQ_HD const DevTable &seq_quality(uint32_t i) const { return S.seq_quality[i]; }
+    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const { return draw<4>(S.quality[i], S.pool, S.par0, idx, u, ps); }
+    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const { return draw<4>(S.base_call[i], S.pool, S.par0, idx, u, ps); }
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(S.indels[i], S.pool, S.par0, idx, u, ps); }
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(S.seq_quality[i], S.pool, S.par0, idx, u, ps); }
+};
 
 // ------------------------------------------------------------------------------- 2-bit reference access
 RSQ_HD uint32_t ref_base(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t pos) {
@@ -144,20 +197,30 @@ RSQ_HD uint32_t ref_gc_count(const uint64_t *__restrict__ words, uint64_t word_o
 // SurroundingBase.hpp:64-81,196-202: block b of the start surrounding is the 10-mer ref[pos-10+10b ..), wrapping
 // around the sequence ends; the end surrounding is taken on the reverse complement at position L-1-pos.
 RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
-    uint64_t p = (uint64_t)pos + L - kSurStart;
+    uint64_t p = (uint64_t)pos + L - kSurStart;                    // < 2L: one conditional subtraction replaces the reference's % length
+    if (p >= L) p -= L;
 #pragma unroll
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
-        for (uint32_t i = 0; i < kSurRange; ++i) v = (v << 2) + ref_base(words, word_off, (uint32_t)((p + b * kSurRange + i) % L));
+        for (uint32_t i = 0; i < kSurRange; ++i) {
+            v = (v << 2) + ref_base(words, word_off, (uint32_t)p);
+            if (++p == L) p = 0;
+        }
         sur[b] = v;
     }
 }
 RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
-    uint64_t p = (uint64_t)(L - pos - 1) + L - kSurStart;
+    // position q of the reverse complement is the complement of forward position L-1-q; q starts at (L-pos-1) + L - 10 (mod L)
+    uint64_t q = (uint64_t)(L - pos - 1) + L - kSurStart;
+    if (q >= L) q -= L;
+    uint32_t f = L - 1u - (uint32_t)q;                             // forward position, walks downwards with wrap-around
 #pragma unroll
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
-        for (uint32_t i = 0; i < kSurRange; ++i) v = (v << 2) + (3u - ref_base(words, word_off, L - 1u - (uint32_t)((p + b * kSurRange + i) % L)));
+        for (uint32_t i = 0; i < kSurRange; ++i) {
+            v = (v << 2) + (3u - ref_base(words, word_off, f));
+            f = f ? f - 1u : L - 1u;
+        }
         sur[b] = v;
     }
 }
@@ -234,9 +297,9 @@ struct FillState {                     // Simulator.h:215-240 ReadFillParameter
     uint32_t iteration;
 };
 
-template <class Src, class Out>
-RSQ_HD void fill_read_part(const DevSim &S, const Stream &st, uint32_t seg, uint32_t tile_id, const Src &src, uint32_t org_len, uint32_t org_pos, char base_element,
-                           FillState &par, CigarRun &cg, Out &out) {
+template <class Tab, class Src, class Out>
+RSQ_HD void fill_read_part(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg, uint32_t tile_id, const Src &src, uint32_t org_len, uint32_t org_pos,
+                           char base_element, FillState &par, CigarRun &cg, Out &out) {
     // Without variants the block walk of GetSysErrorFromBlock advances in step with org_pos (one systematic
     // error per consumed template base), so src.sys() is indexed by org_pos for templates and adapters alike.
     cg.element = base_element;
@@ -247,20 +310,20 @@ RSQ_HD void fill_read_part(const DevSim &S, const Stream &st, uint32_t seg, uint
         const Words w = st.step(2u + it);
         double prob_sum;
         const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
-        uint32_t indel = draw<3>(S.indels[par.previous_indel_type * 6u + par.base_call], S.pool, S.par0, idx_i, u32_to_unit(w.w0), prob_sum);
+        uint32_t indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, u32_to_unit(w.w0), prob_sum);
         if (0.0 == prob_sum) indel = 0;
         const uint32_t org_base = src.base(org_pos);
-        const DevTable &qt = S.quality[tbase + org_base];
+        const uint32_t qi = tbase + org_base;
         if (0 == indel) {
             const uint32_t se = src.sys(org_pos);
             const uint32_t dom_error = se & 0xFFu;
             par.error_rate = se >> 8;
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-            uint32_t q = draw<4>(qt, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
-            if (0.0 == prob_sum) q = par.read_pos ? par.last_written_qual : qt.max_value;
+            uint32_t q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
+            if (0.0 == prob_sum) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;
             par.qual = q;
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
-            uint32_t call = draw<4>(S.base_call[(tbase + org_base) * 5u + dom_error], S.pool, S.par0, idx_b, u32_to_unit(w.w2), prob_sum);
+            uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, u32_to_unit(w.w2), prob_sum);
             if (0.0 == prob_sum) call = org_base;
             par.base_call = call;
             out.put(par.read_pos, call, q + S.phred_offset);
@@ -294,7 +357,7 @@ RSQ_HD void fill_read_part(const DevSim &S, const Stream &st, uint32_t seg, uint
             ++org_pos;
         } else {                                                   // insertion of base indel-2
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-            uint32_t q = draw<4>(qt, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
+            uint32_t q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
             if (0.0 == prob_sum) q = par.qual;
             out.put(par.read_pos, indel - 2u, q + S.phred_offset);
             par.last_written_qual = q;
@@ -340,8 +403,9 @@ struct AdapterSrc {                    // the adapter as template of FillReadPar
     RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
 };
 
-template <class Src, class Out>
-RSQ_HD void fill_read(const DevSim &S, const Stream &st, uint32_t seg, uint32_t tile_id, uint32_t fragment_length, const Src &src, Out &out, ReadMeta &meta) {
+template <class Tab, class Src, class Out>
+RSQ_HD void fill_read(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg, uint32_t tile_id, uint32_t fragment_length, const Src &src, Out &out,
+                      ReadMeta &meta) {
     FillState par;
     par.read_pos = 0;
     par.previous_indel_type = 0;
@@ -378,13 +442,16 @@ RSQ_HD void fill_read(const DevSim &S, const Stream &st, uint32_t seg, uint32_t 
         mean_error_rate = divide_u32(mean_error_rate, alen);
     }
     double prob_sum;
-    const DevTable &sqt = S.seq_quality[seg * S.n_tiles + tile_id];
+    const uint32_t sqi = seg * S.n_tiles + tile_id;
     const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
-    par.seq_qual = draw<3>(sqt, S.pool, S.par0, idx_sq, u32_to_unit(h0.w2), prob_sum);
-    if (0.0 == prob_sum) par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;       // MostLikely(), ProbabilityEstimates.h:519-526
+    par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, u32_to_unit(h0.w2), prob_sum);
+    if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
+        const DevTable &sqt = tab.seq_quality(sqi);
+        par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
+    }
 
     CigarRun cg{'M', 0, 0};
-    fill_read_part(S, st, seg, tile_id, src, org_len, 0u, 'M', par, cg, out);
+    fill_read_part(S, tab, st, seg, tile_id, src, org_len, 0u, 'M', par, cg, out);
     const uint32_t iter_m = par.iteration;
     uint32_t hard_clip = 0;
     if (par.read_pos < par.read_length) {                           // :537-589
@@ -396,16 +463,16 @@ RSQ_HD void fill_read(const DevSim &S, const Stream &st, uint32_t seg, uint32_t 
                           ad.cut_from[adapter_id];
         const uint32_t a0 = ad.seq_ptr[adapter_id];
         AdapterSrc asrc{ad.seqs + a0, ad.sys + a0};
-        fill_read_part(S, st, seg, tile_id, asrc, ad.seq_ptr[adapter_id + 1] - a0, adapter_pos, 'S', par, cg, out);
+        fill_read_part(S, tab, st, seg, tile_id, asrc, ad.seq_ptr[adapter_id + 1] - a0, adapter_pos, 'S', par, cg, out);
         if (par.read_pos < par.read_length) {
             hard_clip = par.read_length - par.read_pos;
             cg.chars += digits10(hard_clip) + 1u;
-            const DevTable &q0 = S.quality[(seg * S.n_tiles + tile_id) * 4u];
+            const uint32_t q0 = (seg * S.n_tiles + tile_id) * 4u;
             const uint32_t tail_length = discrete_draw(S.polya_cp, S.polya_n, u32_to_unit(h1.w0)) + S.polya_from;
             for (uint32_t pos_tail = 0; par.read_pos < par.read_length; ++pos_tail) {
                 const Words w = st.step(2u + par.iteration++);
                 const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-                uint32_t q = draw<4>(q0, S.pool, S.par0, idx_q, u32_to_unit(w.w1), prob_sum);
+                uint32_t q = tab.draw_quality(q0, idx_q, u32_to_unit(w.w1), prob_sum);
                 if (0.0 == prob_sum && par.read_pos) q = par.last_written_qual;   // at(qual_, read_pos-1) - offset
                 par.qual = q;
                 const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));

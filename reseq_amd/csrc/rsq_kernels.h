@@ -190,19 +190,22 @@ struct SieveSite {
     bool have_start;
 };
 
-RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, uint32_t (&cnt)[2], uint32_t (&strand_of)[2]) {
+// Philox block shared by the two cells (start, 2q) and (start, 2q+1)
+RSQ_HD Words sieve_pair_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site.seq, q, kDomSieve << 28); }
+RSQ_HD double sieve_cell_uniform(const Words &w, uint32_t len) { return (len & 1u) ? u53_to_unit(w.w2, w.w3) : u53_to_unit(w.w0, w.w1); }
+
+RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, double probability_chosen, uint32_t (&cnt)[2], uint32_t (&strand_of)[2]) {
     cnt[0] = cnt[1] = 0;
     strand_of[0] = strand_of[1] = 0;
-    const Words w = philox(S.seed, site.start, site.seq, len, kDomSieve << 28);
-    const double probability_chosen = u53_to_unit(w.w0, w.w1);
     const double thr0 = site.thr[2u * len], thr1 = site.thr[2u * len + 1u];
     if (!(probability_chosen >= thr1)) return 0;                                    // Simulator.h:418-420
     const uint32_t non_zero_strands = binomial(2u, 1 - thr0, probability_chosen);   // Simulator.cpp:2307
     const uint32_t end = site.start + len;
     if (!non_zero_strands || !(end < site.L)) return 0;                             // :2308,:2318
+    const Words w2 = philox(S.seed, site.start, site.seq, len, (kDomSieve << 28) | 1u);
     uint32_t n_chosen;
     if (non_zero_strands <= 1u) {                                                   // :1387-1391 DrawNAlleles(1) -> SelectAllele
-        strand_of[0] = (uint32_t)(u32_to_unit(w.w2) * 2.0) & 1u;
+        strand_of[0] = (uint32_t)(u32_to_unit(w2.w2) * 2.0) & 1u;
         n_chosen = 1;
     } else {                                                                        // :1392-1396 complement of the empty draw
         strand_of[0] = 0;
@@ -216,7 +219,6 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, uint3
     uint32_t sur_end[3];
     surrounding_reverse(S.ref_words, site.word_off, site.L, end - 1u, sur_end);     // :1820-1832
     const uint32_t gc = percent_u32(ref_gc_count(S.ref_words, site.word_off, site.start, end), len);   // :1858-1873
-    const Words w2 = philox(S.seed, site.start, site.seq, len, (kDomSieve << 28) | 1u);
     uint32_t n_here = 0;
     for (uint32_t j = 0; j < n_chosen; ++j) {
         const double u = j ? u53_to_unit(w2.w2, w2.w3) : u53_to_unit(w2.w0, w2.w1);
@@ -226,6 +228,14 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, uint3
     }
     return n_here;
 }
+
+// a cell with fragments, recorded by the sieve pass and expanded into Fragment records after the scan
+struct SieveHit {
+    uint32_t slot;         // start position slot of the batch
+    uint32_t intra;        // pairs of the same start position that come before this cell
+    uint16_t len, cnt0, cnt1;
+    uint8_t strand0, strand1;
+};
 
 RSQ_HD Fragment make_fragment(const SieveSite &site, uint32_t len, uint32_t dup, uint32_t strand, uint32_t block_id, uint32_t number) {
     Fragment f;
@@ -240,58 +250,131 @@ RSQ_HD Fragment make_fragment(const SieveSite &site, uint32_t len, uint32_t dup,
     return f;
 }
 
-#if defined(__HIPCC__)
-// One wave per start position; lane l tests fragment lengths insert_from + l, + 64, ...  A cell that passes the
-// zero threshold (rare) is finished by its own lane.  COUNT pass: counts[slot] = pairs starting at this position.
-// EMIT pass: the same walk again, writing Fragment records at offsets[slot] in (length, chosen strand order,
-// duplicate) order -- the order of the reference's loops.
-template <bool EMIT>
-__global__ void __launch_bounds__(256) k_sieve(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t *counts, const uint64_t *offsets, Fragment *frags) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (slot >= n_slots) return;
-    const uint32_t block_id = block_lo + slot / kBlockSize;
-    SieveSite site;
+RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_block, SieveSite &site) {
     site.seq = S.block_seq[block_id];
     site.L = S.seq_len[site.seq];
-    site.start = (block_id - S.first_block[site.seq]) * kBlockSize + slot % kBlockSize;
-    if (site.start >= site.L) {
-        if (!EMIT && lane == 0) counts[slot] = 0;
-        return;
-    }
+    site.start = (block_id - S.first_block[site.seq]) * kBlockSize + offset_in_block;
     site.word_off = S.seq_word_off[site.seq];
     site.thr = S.thresholds + (size_t)S.coverage_group[site.seq] * S.insert_to * 2u;
     site.have_start = false;
-    uint32_t total = 0;                                            // COUNT: pairs of this lane; EMIT: pairs of all earlier iterations
-    uint64_t out_base = 0;
-    uint32_t number_base = 0;
-    if (EMIT) {
-        out_base = offsets[slot];
-        number_base = (uint32_t)(out_base - offsets[slot - slot % kBlockSize]);
-    }
-    for (uint32_t len0 = S.insert_from; len0 < S.insert_to; len0 += 64u) {
-        const uint32_t len = len0 + lane;
-        uint32_t n_here = 0, cnt[2] = {0, 0}, strand_of[2] = {0, 0};
-        if (len < S.insert_to) n_here = sieve_cell(S, site, len, cnt, strand_of);
-        if (!EMIT) {
-            total += n_here;
-        } else {
-            uint32_t incl = n_here;                                 // inclusive prefix over the wave: lanes hold ascending lengths
+}
+
+#if defined(__HIPCC__)
+// The sieve in two dense phases per wave.  A wave owns kSieveSlotsPerWave consecutive start positions.
+//   screen:  for each of its positions, lanes test the fragment lengths two per Philox block (lane l: lengths 2(q0+l),
+//            2(q0+l)+1, then q0 += 64) against the zero threshold; the rare cells that pass (about 0.2 %) are appended, in
+//            (position, length) order, to the wave's candidate queue in LDS;
+//   finish:  one lane per queued cell runs the expensive part (strand choice, GC percent, surroundings, negative binomial
+//            count) -- full lanes instead of the one or two that a fused loop would keep busy.
+// counts[slot] = pairs starting at the position.  Every cell with fragments is appended to `hits` together with the number
+// of pairs that precede it at the same start, so that k_sieve_emit can place its fragments in (length, chosen strand order,
+// duplicate) order -- the order of the reference's loops -- once the exclusive scan of counts is known.
+constexpr uint32_t kSieveSlotsPerWave = 16;
+constexpr uint32_t kSieveWaves = 4;
+constexpr uint32_t kSieveQueue = 512;                  // candidate capacity per wave; flushed when fewer than 128 slots are left
+
+__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t *counts, SieveHit *hits, uint32_t hit_cap,
+                                                           uint32_t *hit_count) {
+    __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
+    __shared__ uint32_t s_total[kSieveWaves][kSieveSlotsPerWave];  // pairs found so far per position
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slot0 = (blockIdx.x * kSieveWaves + wave) * kSieveSlotsPerWave;
+    if (slot0 >= n_slots) return;
+    uint32_t *queue = s_queue[wave], *totals = s_total[wave];
+    if (lane < kSieveSlotsPerWave) totals[lane] = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_queued = 0;
+
+    auto finish = [&]() {                                           // wave-uniform: all lanes call it together
+        for (uint32_t base = 0; base < n_queued; base += 64u) {
+            const bool active = base + lane < n_queued;
+            uint32_t key = 0xFFFFu, len = 0, n_here = 0, cnt[2] = {0, 0}, strand_of[2] = {0, 0};
+            if (active) {
+                const uint32_t e = queue[base + lane];
+                key = e >> 16;
+                len = e & 0xFFFFu;
+                SieveSite site;
+                const uint32_t slot = slot0 + key;
+                init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
+                n_here = sieve_cell(S, site, len, sieve_cell_uniform(sieve_pair_words(S, site, len >> 1), len), cnt, strand_of);
+            }
+            // exclusive prefix of n_here among the earlier queued cells of the same position (keys are non-decreasing)
+            uint32_t incl = n_here;
             for (uint32_t d = 1; d < 64u; d <<= 1) {
                 const uint32_t v = __shfl_up(incl, d, 64);
                 if (lane >= d) incl += v;
             }
-            const uint32_t wave_total = __shfl(incl, 63, 64);
-            uint32_t k = total + incl - n_here;
-            for (uint32_t j = 0; j < 2u; ++j)
-                for (uint32_t dup = 0; dup < cnt[j]; ++dup, ++k) frags[out_base + k] = make_fragment(site, len, dup, strand_of[j], block_id, number_base + k + 1u);
-            total += wave_total;
+            const uint32_t prev_key = __shfl_up(key, 1, 64);
+            const uint64_t heads = __ballot(lane == 0 || key != prev_key);
+            const uint32_t first = 63u - (uint32_t)__clzll(heads & (lt_mask | (1ull << lane)));
+            const uint32_t first_incl = __shfl(incl, first, 64), first_n = __shfl(n_here, first, 64);
+            const uint32_t before_in_batch = (incl - n_here) - (first_incl - first_n);
+            const uint32_t next_key = __shfl_down(key, 1, 64);
+            const uint32_t old_total = active ? totals[key] : 0u;
+            if (n_here) {
+                const uint32_t at = atomicAdd(hit_count, 1u);
+                if (at < hit_cap) {
+                    SieveHit h;
+                    h.slot = slot0 + key;
+                    h.intra = old_total + before_in_batch;
+                    h.len = (uint16_t)len;
+                    h.cnt0 = (uint16_t)cnt[0];
+                    h.cnt1 = (uint16_t)cnt[1];
+                    h.strand0 = (uint8_t)strand_of[0];
+                    h.strand1 = (uint8_t)strand_of[1];
+                    hits[at] = h;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (active && (lane == 63u || next_key != key)) totals[key] = old_total + before_in_batch + n_here;      // last cell of the position in this batch
+            __builtin_amdgcn_wave_barrier();
+        }
+        n_queued = 0;
+    };
+
+    for (uint32_t k = 0; k < kSieveSlotsPerWave; ++k) {
+        const uint32_t slot = slot0 + k;
+        if (slot >= n_slots) break;
+        SieveSite site;
+        init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
+        if (site.start >= site.L) continue;
+        for (uint32_t q0 = S.insert_from >> 1; 2u * q0 < S.insert_to; q0 += 64u) {
+            const uint32_t q = q0 + lane;
+            bool cand[2] = {false, false};
+            if (2u * q < S.insert_to) {
+                const Words w = sieve_pair_words(S, site, q);
+                for (uint32_t e = 0; e < 2u; ++e) {
+                    const uint32_t len = 2u * q + e;
+                    if (len >= S.insert_from && len < S.insert_to) cand[e] = sieve_cell_uniform(w, len) >= site.thr[2u * len + 1u];     // Simulator.h:418-420
+                }
+            }
+            const uint64_t m0 = __ballot(cand[0]), m1 = __ballot(cand[1]);
+            if (m0 | m1) {
+                const uint32_t at = n_queued + (uint32_t)__popcll(m0 & lt_mask) + (uint32_t)__popcll(m1 & lt_mask);
+                if (cand[0]) queue[at] = (k << 16) | (2u * q);
+                if (cand[1]) queue[at + (cand[0] ? 1u : 0u)] = (k << 16) | (2u * q + 1u);
+                n_queued += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+                if (n_queued > kSieveQueue - 128u) finish();        // an iteration adds at most 128 cells
+            }
         }
     }
-    if (!EMIT) {
-        for (uint32_t d = 32; d > 0; d >>= 1) total += __shfl_down(total, d, 64);
-        if (lane == 0) counts[slot] = total;
-    }
+    finish();
+    if (lane < kSieveSlotsPerWave && slot0 + lane < n_slots) counts[slot0 + lane] = totals[lane];
+}
+
+// one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at offsets[slot] + intra
+__global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, const SieveHit *hits, uint32_t n_hits, const uint64_t *offsets, Fragment *frags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hits) return;
+    const SieveHit h = hits[i];
+    const uint32_t block_id = block_lo + h.slot / kBlockSize;
+    SieveSite site;
+    init_site(S, block_id, h.slot % kBlockSize, site);
+    const uint64_t base = offsets[h.slot];
+    const uint32_t number_base = (uint32_t)(base - offsets[h.slot - h.slot % kBlockSize]);
+    uint32_t k = h.intra;
+    for (uint32_t dup = 0; dup < h.cnt0; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand0, block_id, number_base + k + 1u);
+    for (uint32_t dup = 0; dup < h.cnt1; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand1, block_id, number_base + k + 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -351,16 +434,143 @@ __global__ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *til
 
 #endif  // __HIPCC__
 
+// ---------------------------------------------------------------------------------------------- FASTQ text
+// Replays the CIGAR bookkeeping of FillReadPart over the stored 2-bit ops (see fill_read_part in rsq_core.h).
+template <class Sink>
+RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
+    uint32_t it = 0;
+    for (int part = 0; part < 2; ++part) {
+        const char base = part ? 'S' : 'M';
+        const uint32_t n = part ? m.n_iter_s : m.n_iter_m;
+        char element = base;
+        uint32_t length = 0;
+        for (uint32_t i = 0; i < n; ++i, ++it) {
+            const uint32_t code = (ops[it >> 4] >> ((it & 15u) * 2u)) & 3u;
+            const char want = code == 0 ? base : (code == 1 ? 'D' : 'I');
+            if (want == element) ++length;
+            else {
+                sink.element(element, length);
+                element = want;
+                length = 1;
+            }
+        }
+        if (length) sink.element(element, length);
+    }
+    if (m.hard_clip) sink.element('H', m.hard_clip);
+}
+
+template <class P>
+struct TextSinkT {                       // appends characters at p (no null check: LDS offset 0 is a valid destination)
+    P p;
+    uint32_t n;
+    RSQ_HD void ch(char c) {
+        p[n] = c;
+        ++n;
+    }
+    RSQ_HD void str(const char *s, uint32_t len) {
+        for (uint32_t i = 0; i < len; ++i) ch(s[i]);
+    }
+    RSQ_HD void num(uint64_t v) {
+        char tmp[20];
+        int k = 0;
+        do {
+            tmp[k++] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        while (k) ch(tmp[--k]);
+    }
+    RSQ_HD void element(char op, uint32_t count) {
+        num(count);
+        ch(op);
+    }
+};
+using TextSink = TextSinkT<char *>;
+
+RSQ_HD uint32_t digits_u64(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10) {
+        v /= 10;
+        ++n;
+    }
+    return n;
+}
+
+
+// One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632.
+template <class P>
+RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint8_t *seq,
+                              const uint8_t *qual, const uint32_t *ops, P dst) {
+    TextSinkT<P> t{dst, 0};
+    t.ch('@');
+    t.str(names.base_identifier, names.base_len);
+    if (f) {
+        const uint32_t end = f->start + f->len;
+        t.num(f->block);
+        t.ch('_');
+        t.num(f->number);
+        t.ch(':');
+        t.num(f->strand ? end : f->start + 1u);
+        t.ch(':');
+        t.str(names.names + names.name_ptr[f->seq], names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]);
+        t.ch(':');
+        t.num(f->strand ? f->start + 1u : end);
+    } else {
+        t.ch('0');
+        t.ch('_');
+        t.num(adapter_only_number);
+        t.str(":0:Adapter:0", 12);
+    }
+    t.ch(':');
+    t.num(S.tiles[m.tile_id]);
+    t.str(":1337:1337 ", 11);
+    cigar_replay(ops, m, t);
+    t.str(" E", 2);
+    t.num(m.num_errors);
+    t.ch('\n');
+    const uint32_t *seq4 = reinterpret_cast<const uint32_t *>(seq), *qual4 = reinterpret_cast<const uint32_t *>(qual);   // rows are 4-byte aligned
+    for (uint32_t i = 0; i < m.read_len; i += 4u) {
+        const uint32_t w = seq4[i >> 2];
+        for (uint32_t k = 0; k < 4u && i + k < m.read_len; ++k) t.ch("ACGTN"[(w >> (8u * k)) & 0xFFu]);
+    }
+    t.str("\n+\n", 3);
+    for (uint32_t i = 0; i < m.read_len; i += 4u) {
+        const uint32_t w = qual4[i >> 2];
+        for (uint32_t k = 0; k < 4u && i + k < m.read_len; ++k) t.ch((char)((w >> (8u * k)) & 0xFFu));
+    }
+    t.ch('\n');
+    return t.n;
+}
+
+// length of that record without producing it (the read kernel writes it next to the read)
+RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m) {
+    uint32_t n = 1u + names.base_len;
+    if (f) {
+        const uint32_t end = f->start + f->len;
+        n += digits_u64(f->block) + 1u + digits_u64(f->number) + 1u + digits_u64(f->strand ? end : f->start + 1u) + 1u +
+             (names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]) + 1u + digits_u64(f->strand ? f->start + 1u : end);
+    } else n += 2u + digits_u64(adapter_only_number) + 12u;
+    n += 1u + digits_u64(S.tiles[m.tile_id]) + 11u + m.cigar_chars + 2u + digits_u64(m.num_errors) + 1u;
+    return n + 2u * m.read_len + 4u;
+}
+
 // ------------------------------------------------------------------------------------------------- reads
-struct ReadOut {                        // destination of one lane's read
+struct ReadOut {                        // destination of one lane's read; bases and qualities leave in 4-byte stores
     uint8_t *seq, *qual;
     uint32_t *ops;
-    uint32_t cur_word, cur_index;
-    RSQ_HD void put(uint32_t pos, uint32_t base, uint32_t qual_char) {
-        seq[pos] = (uint8_t)base;
-        qual[pos] = (uint8_t)qual_char;
+    uint32_t cur_word, cur_index;       // CIGAR ops: 2 bits per iteration, 16 per word
+    uint32_t seq_word, qual_word, n_put;
+    RSQ_HD void put(uint32_t pos, uint32_t base, uint32_t qual_char) {      // pos runs 0,1,2,... (read_pos)
+        const uint32_t sh = (pos & 3u) * 8u;
+        seq_word |= base << sh;
+        qual_word |= qual_char << sh;
+        n_put = pos + 1u;
+        if ((pos & 3u) == 3u) {
+            *reinterpret_cast<uint32_t *>(seq + (pos & ~3u)) = seq_word;
+            *reinterpret_cast<uint32_t *>(qual + (pos & ~3u)) = qual_word;
+            seq_word = qual_word = 0;
+        }
     }
-    RSQ_HD void op(uint32_t it, uint32_t code) {                    // 2 bits per iteration, 16 per word
+    RSQ_HD void op(uint32_t it, uint32_t code) {
         const uint32_t wi = it >> 4;
         if (wi != cur_index) {
             ops[cur_index] = cur_word;
@@ -369,8 +579,15 @@ struct ReadOut {                        // destination of one lane's read
         }
         cur_word |= code << ((it & 15u) * 2u);
     }
-    RSQ_HD void finish() { ops[cur_index] = cur_word; }
+    RSQ_HD void finish() {
+        ops[cur_index] = cur_word;
+        if (n_put & 3u) {                                           // read_stride is a multiple of 4
+            *reinterpret_cast<uint32_t *>(seq + (n_put & ~3u)) = seq_word;
+            *reinterpret_cast<uint32_t *>(qual + (n_put & ~3u)) = qual_word;
+        }
+    }
 };
+RSQ_HD ReadOut make_read_out(uint8_t *seq, uint8_t *qual, uint32_t *ops) { return ReadOut{seq, qual, ops, 0u, 0u, 0u, 0u, 0u}; }
 
 struct RawLayout {                      // per-read arrays of the read kernel, read index = segment * n_pairs + pair
     uint8_t *seq, *qual;
@@ -405,8 +622,104 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- LDS staging
+// The rows a lane needs differ from lane to lane exactly where the conditioning value is per-read state: the quality
+// margins over sequence quality (0) and previous quality (1) and the base-call margin over the quality (0).  Those,
+// and the 64-byte table descriptors, are served from an LDS image built once per workgroup; the margins over read
+// position / error rate / error count are (nearly) the same row for every lane of a wave and stay in HBM (L1 hits).
+// Image layout (doubles): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (8 doubles each), then the
+// staged rows at DevTable::lds_off.  A workgroup serves ONE template segment.
+RSQ_HD uint32_t lds_desc_count(uint32_t n_tiles) { return 25u * n_tiles + 12u; }
+
+template <bool QL, bool BL>
+struct LdsTables {
+    const DevSim &S;
+    const RSQ_LDS double *img;
+    uint32_t seg;
+    RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
+    RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
+    RSQ_HD DevTable base_call(uint32_t i) const { return desc(4u * S.n_tiles + i - seg * 20u * S.n_tiles); }
+    RSQ_HD DevTable indel(uint32_t i) const { return desc(24u * S.n_tiles + i); }
+    RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.n_tiles + 12u + i - seg * S.n_tiles); }
+
+    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
+        const DevTable t = quality(i);
+        ps = 0.0;
+        if (!t.k) return 0;
+        const uint32_t kp = row_stride(t.k);
+        const GlobalRow m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp}, m3{S.pool + t.off[3] + clamp_row(t, 3, idx[3]) * kp};
+        uint32_t col;
+        if constexpr (QL) {
+            const LdsRow m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * kp};
+            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
+        } else {
+            const GlobalRow m0{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp}, m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp};
+            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
+        }
+        return S.par0[t.par0_off + col];
+    }
+    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
+        const DevTable t = base_call(i);
+        ps = 0.0;
+        if (!t.k) return 0;
+        const uint32_t kp = row_stride(t.k);
+        const GlobalRow m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp}, m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp},
+            m3{S.pool + t.off[3] + clamp_row(t, 3, idx[3]) * kp};
+        uint32_t col;
+        if constexpr (BL) {
+            const LdsRow m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp};
+            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
+        } else {
+            const GlobalRow m0{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp};
+            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
+        }
+        return S.par0[t.par0_off + col];
+    }
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
+        const DevTable t = indel(i);
+        return draw<3>(t, S.pool, S.par0, idx, u, ps);
+    }
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
+        const DevTable t = seq_quality(i);
+        return draw<3>(t, S.pool, S.par0, idx, u, ps);
+    }
+};
+
+// Builds the LDS image of segment `seg`; tid/nthreads describe the calling thread (the host emulation calls it with 0/1).
+// The caller must synchronise the workgroup between the two phases and after phase 1.
+RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
+    const uint32_t T = S.n_tiles;
+    RSQ_LDS uint32_t *dst = reinterpret_cast<RSQ_LDS uint32_t *>(img);
+    const uint32_t wq = 4u * T * 16u, wb = 20u * T * 16u, wi = 12u * 16u, ws = T * 16u;      // 16 words per descriptor
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(S.quality + seg * 4u * T), *b = reinterpret_cast<const uint32_t *>(S.base_call + seg * 20u * T),
+                   *in = reinterpret_cast<const uint32_t *>(S.indels), *sq = reinterpret_cast<const uint32_t *>(S.seq_quality + seg * T);
+    for (uint32_t i = tid; i < wq; i += nthreads) dst[i] = q[i];
+    for (uint32_t i = tid; i < wb; i += nthreads) dst[wq + i] = b[i];
+    for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
+    for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i];
+}
+RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS double *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
+    const uint32_t T = S.n_tiles;
+    const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
+    if (S.lds.stage_quality)
+        for (uint32_t t = 0; t < 4u * T; ++t) {
+            const DevTable tb = d[t];
+            if (!tb.k || tb.lds_off == kNoLds) continue;
+            const uint32_t n = (tb.rows[0] + tb.rows[1]) * row_stride(tb.k);
+            for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
+        }
+    if (S.lds.stage_base_call)
+        for (uint32_t t = 0; t < 20u * T; ++t) {
+            const DevTable tb = d[4u * T + t];
+            if (!tb.k || tb.lds_off == kNoLds) continue;
+            const uint32_t n = tb.rows[0] * row_stride(tb.k);
+            for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
+        }
+}
+
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
-RSQ_HD void fill_fragment_read(const DevSim &S, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
+template <class Tab>
+RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
     const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2));
     const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)};
@@ -419,13 +732,14 @@ RSQ_HD void fill_fragment_read(const DevSim &S, const Fragment &f, uint32_t seg,
     src.reverse = seg != f.strand;                                              // block.at(strand) = start_block (:680-684)
     src.first = src.reverse ? end : f.start;
     src.sys_ = src.reverse ? S.sys_rev + S.seq_base_off[f.seq] + (L - end) : S.sys_fwd + S.seq_base_off[f.seq] + f.start;
-    fill_read(S, st, seg, tile, f.len, src, out, meta);
+    fill_read(S, tab, st, seg, tile, f.len, src, out, meta);
 }
 // one mate of adapter-only pair i (Simulator.cpp:2359-2382)
-RSQ_HD void fill_adapter_only_read(const DevSim &S, uint64_t i, uint32_t seg, ReadOut &out, ReadMeta &meta) {
+template <class Tab>
+RSQ_HD void fill_adapter_only_read(const DevSim &S, const Tab &tab, uint64_t i, uint32_t seg, ReadOut &out, ReadMeta &meta) {
     const uint32_t tile = draw_tile(S, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, 2));
     const Stream st{S.seed, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, seg)};
-    fill_read(S, st, seg, tile, 0u, EmptySrc{}, out, meta);
+    fill_read(S, tab, st, seg, tile, 0u, EmptySrc{}, out, meta);
 }
 
 // seqToIllumina records (Simulator.cpp:2403-2512): templates and systematic errors come from arrays
@@ -437,25 +751,58 @@ struct RecordSrc {
     RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
     RSQ_HD uint32_t sys(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
 };
-RSQ_HD void fill_record_read(const DevSim &S, uint64_t idx, uint32_t seg, uint32_t frag_len, const RecordSrc &src, ReadOut &out, ReadMeta &meta) {
+template <class Tab>
+RSQ_HD void fill_record_read(const DevSim &S, const Tab &tab, uint64_t idx, uint32_t seg, uint32_t frag_len, const RecordSrc &src, ReadOut &out, ReadMeta &meta) {
     const uint32_t tile = draw_tile(S, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, 2));
     const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-    fill_read(S, st, seg, tile, frag_len, src, out, meta);
+    fill_read(S, tab, st, seg, tile, frag_len, src, out, meta);
 }
 
 #if defined(__HIPCC__)
-// grid.y = template segment
-__global__ void __launch_bounds__(64) k_fill_reads(DevSim S, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw) {
-    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= n_pairs) return;
-    const uint32_t seg = blockIdx.y;
-    const uint64_t r = (uint64_t)seg * n_pairs + pair;
-    ReadOut out{raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride, raw.ops + r * raw.ops_stride, 0u, 0u};
-    ReadMeta meta;
-    if (frags) fill_fragment_read(S, frags[pair], seg, out, meta);
-    else fill_adapter_only_read(S, adapter_only_first + pair, seg, out, meta);
-    out.finish();
-    raw.meta[r] = meta;
+// One lane per read, persistent waves.  A workgroup serves one template segment (blockIdx.x & 1), builds its LDS image
+// once, then every wave pulls chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail).
+// MODE 0: every table access goes to HBM (profiles whose tables do not fit the plan); 1: descriptors in LDS;
+// 2: + quality margins 0,1; 3: + base-call margin 0.
+constexpr uint32_t kFillBlock = 1024;
+template <int MODE>
+__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
+                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
+    extern __shared__ __attribute__((aligned(16))) double lds_image[];
+    const uint32_t seg = blockIdx.x & 1u;
+    RSQ_LDS double *img = (RSQ_LDS double *)lds_image;
+    if (MODE > 0) {
+        lds_stage_descriptors(S, img, seg, threadIdx.x, blockDim.x);
+        __syncthreads();
+        if (MODE > 1) lds_stage_rows(S, img, seg, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
+        chunk = __shfl(chunk, 0, 64);
+        const uint64_t first = (uint64_t)chunk * 64u;
+        if (first >= n_pairs) break;
+        const uint64_t pair = first + lane;
+        if (pair >= n_pairs) continue;
+        const uint64_t r = (uint64_t)seg * n_pairs + pair;
+        ReadOut out = make_read_out(raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride, raw.ops + r * raw.ops_stride);
+        ReadMeta meta;
+        Fragment f;
+        if (frags) f = frags[pair];
+        if (MODE == 0) {
+            const GlobalTables tab{S};
+            if (frags) fill_fragment_read(S, tab, f, seg, out, meta);
+            else fill_adapter_only_read(S, tab, adapter_only_first + pair, seg, out, meta);
+        } else {
+            const LdsTables<(MODE > 1), (MODE > 2)> tab{S, img, seg};
+            if (frags) fill_fragment_read(S, tab, f, seg, out, meta);
+            else fill_adapter_only_read(S, tab, adapter_only_first + pair, seg, out, meta);
+        }
+        out.finish();
+        raw.meta[r] = meta;
+        sizes[r] = record_size(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, meta);       // bytes of its FASTQ record
+    }
 }
 
 __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs, const uint8_t *segs,
@@ -463,127 +810,65 @@ __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_ind
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
-    ReadOut out{raw.seq + i * raw.read_stride, raw.qual + i * raw.read_stride, raw.ops + i * raw.ops_stride, 0u, 0u};
+    ReadOut out = make_read_out(raw.seq + i * raw.read_stride, raw.qual + i * raw.read_stride, raw.ops + i * raw.ops_stride);
     ReadMeta meta;
-    fill_record_read(S, first_index + i, segs[i], frag_len[i], src, out, meta);
+    const GlobalTables tab{S};
+    fill_record_read(S, tab, first_index + i, segs[i], frag_len[i], src, out, meta);
     out.finish();
     raw.meta[i] = meta;
 }
 
 #endif  // __HIPCC__
 
-// ---------------------------------------------------------------------------------------------- FASTQ text
-// Replays the CIGAR bookkeeping of FillReadPart over the stored 2-bit ops (see fill_read_part in rsq_core.h).
-template <class Sink>
-RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
-    uint32_t it = 0;
-    for (int part = 0; part < 2; ++part) {
-        const char base = part ? 'S' : 'M';
-        const uint32_t n = part ? m.n_iter_s : m.n_iter_m;
-        char element = base;
-        uint32_t length = 0;
-        for (uint32_t i = 0; i < n; ++i, ++it) {
-            const uint32_t code = (ops[it >> 4] >> ((it & 15u) * 2u)) & 3u;
-            const char want = code == 0 ? base : (code == 1 ? 'D' : 'I');
-            if (want == element) ++length;
-            else {
-                sink.element(element, length);
-                element = want;
-                length = 1;
-            }
-        }
-        if (length) sink.element(element, length);
-    }
-    if (m.hard_clip) sink.element('H', m.hard_clip);
-}
-
-struct TextSink {                        // writes when p != nullptr, always counts
-    char *p;
-    uint32_t n;
-    RSQ_HD void ch(char c) {
-        if (p) p[n] = c;
-        ++n;
-    }
-    RSQ_HD void str(const char *s, uint32_t len) {
-        for (uint32_t i = 0; i < len; ++i) ch(s[i]);
-    }
-    RSQ_HD void num(uint64_t v) {
-        char tmp[20];
-        int k = 0;
-        do {
-            tmp[k++] = (char)('0' + v % 10);
-            v /= 10;
-        } while (v);
-        while (k) ch(tmp[--k]);
-    }
-    RSQ_HD void element(char op, uint32_t count) {
-        num(count);
-        ch(op);
-    }
-};
-
-struct NameTable {                       // first parts of the reference ids + the record base identifier
-    const char *names;
-    const uint32_t *name_ptr;
-    char base_identifier[64];
-    uint32_t base_len;
-};
-
-// One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632; dst == nullptr only measures.
-RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint8_t *seq,
-                              const uint8_t *qual, const uint32_t *ops, char *dst) {
-    TextSink t{dst, 0};
-    t.ch('@');
-    t.str(names.base_identifier, names.base_len);
-    if (f) {
-        const uint32_t end = f->start + f->len;
-        t.num(f->block);
-        t.ch('_');
-        t.num(f->number);
-        t.ch(':');
-        t.num(f->strand ? end : f->start + 1u);
-        t.ch(':');
-        t.str(names.names + names.name_ptr[f->seq], names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]);
-        t.ch(':');
-        t.num(f->strand ? f->start + 1u : end);
-    } else {
-        t.ch('0');
-        t.ch('_');
-        t.num(adapter_only_number);
-        t.str(":0:Adapter:0", 12);
-    }
-    t.ch(':');
-    t.num(S.tiles[m.tile_id]);
-    t.str(":1337:1337 ", 11);
-    cigar_replay(ops, m, t);
-    t.str(" E", 2);
-    t.num(m.num_errors);
-    t.ch('\n');
-    const char *kBases = "ACGTN";
-    for (uint32_t i = 0; i < m.read_len; ++i) t.ch(kBases[seq[i]]);
-    t.str("\n+\n", 3);
-    for (uint32_t i = 0; i < m.read_len; ++i) t.ch((char)qual[i]);
-    t.ch('\n');
-    return t.n;
-}
-
 #if defined(__HIPCC__)
-// sizes pass (dst == nullptr) and write pass; grid.y = template segment, which is also the output file
-__global__ void __launch_bounds__(64) k_format(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw, uint32_t *sizes,
-                         const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1) {
-    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= n_pairs) return;
-    const uint32_t seg = blockIdx.y;
-    const uint64_t r = (uint64_t)seg * n_pairs + pair;
-    const ReadMeta m = raw.meta[r];
+// FASTQ text: one wave per 64 consecutive records of one file (grid.y = template segment = output file).  The 64 records
+// occupy one contiguous byte range of the output, so every lane formats its record into an LDS image of that range (laid out
+// with the same alignment modulo 16 as the destination) and the wave then copies the image out with aligned 16-byte stores.
+constexpr uint32_t kFormatLdsBytes = 40u * 1024u;
+__global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
+                                                    const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1) {
+    __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
+    const uint32_t lane = threadIdx.x, seg = blockIdx.y;
+    const uint64_t first = (uint64_t)blockIdx.x * 64u;
+    if (first >= n_pairs) return;
+    const uint64_t *offsets = seg ? offsets1 : offsets0;
+    char *dst = seg ? dst1 : dst0;
+    const uint64_t last = first + 64u < n_pairs ? first + 64u : n_pairs;
+    const uint64_t g_begin = offsets[first], g_end = offsets[last];
+    const uint64_t a_begin = (uint64_t)(uintptr_t)(dst + g_begin);                 // absolute byte address of the range
+    const uint32_t skew = (uint32_t)(a_begin & 15u), bytes = (uint32_t)(g_end - g_begin);
+    const uint64_t pair = first + lane;
+    const bool active = pair < last;
+    const bool through_lds = skew + bytes <= kFormatLdsBytes;                      // wave-uniform
+    ReadMeta m;
     Fragment f;
-    if (frags) f = frags[pair];
-    char *dst = nullptr;
-    if (!sizes) dst = (seg ? dst1 + offsets1[pair] : dst0 + offsets0[pair]);
-    const uint32_t n = format_record(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, m, raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride,
-                                     raw.ops + r * raw.ops_stride, dst);
-    if (sizes) sizes[r] = n;
+    uint64_t r = 0;
+    if (active) {
+        r = (uint64_t)seg * n_pairs + pair;
+        m = raw.meta[r];
+        if (frags) f = frags[pair];
+    }
+    if (!through_lds) {                                                            // oversized ids: write straight to HBM
+        if (active)
+            format_record(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, m, raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride,
+                          raw.ops + r * raw.ops_stride, dst + offsets[pair]);
+        return;
+    }
+    if (active)
+        format_record(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, m, raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride,
+                      raw.ops + r * raw.ops_stride, (RSQ_LDS char *)s_text + skew + (uint32_t)(offsets[pair] - g_begin));
+    __syncthreads();
+    const uint32_t lo = skew, hi = skew + bytes;                                   // LDS byte range holding text
+    char *g_chunk0 = dst + g_begin - skew;                                         // 16-byte aligned
+    for (uint32_t c = lane * 16u; c < hi; c += 64u * 16u) {
+        if (c >= lo && c + 16u <= hi) {
+            *reinterpret_cast<uint4 *>(g_chunk0 + c) = *reinterpret_cast<const uint4 *>(s_text + c);
+        } else {
+            for (uint32_t b = c < lo ? lo : c; b < c + 16u && b < hi; ++b) g_chunk0[b] = s_text[b];
+        }
+    }
 }
+
 #endif
 
 }  // namespace rsq

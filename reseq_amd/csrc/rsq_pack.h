@@ -50,6 +50,9 @@ struct SimState {
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // --------------------------------------------------------------------------------------- packing (create)
+// LDS budget of one k_fill_reads workgroup (MI355X: 160 KiB per CU, one workgroup per CU)
+constexpr uint32_t kLdsBudgetBytes = 160u * 1024u;
+
 inline void pack_tables(SimState &s, Uploader &up) {
     const Profile &p = s.prof;
     std::vector<double> pool;
@@ -61,28 +64,78 @@ inline void pack_tables(SimState &s, Uploader &up) {
             DevTable d{};
             d.k = (uint32_t)t.par0.size();
             d.par0_off = (uint32_t)par0.size();
+            d.lds_off = kNoLds;
             for (uint32_t v : t.par0) {
                 par0.push_back((uint8_t)v);
                 d.max_value = std::max(d.max_value, v);
             }
+            const uint32_t kp = row_stride(d.k);                       // even stride: zero pad column when K is odd
             for (uint32_t n = 0; n < t.nm; ++n) {
                 d.from[n] = t.from[n];
                 d.rows[n] = t.to[n] - t.from[n];
-                if (pool.size() + t.dim2[n].size() > 0xFFFFFFFFull) throw Error("probability tables exceed 2^32 entries");
+                const size_t rows = d.k ? d.rows[n] : 0;
+                if (pool.size() + rows * kp > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
                 d.off[n] = (uint32_t)pool.size();
-                pool.insert(pool.end(), t.dim2[n].begin(), t.dim2[n].end());
+                for (size_t r = 0; r < rows; ++r) {
+                    pool.insert(pool.end(), t.dim2[n].begin() + r * d.k, t.dim2[n].begin() + (r + 1) * d.k);
+                    if (kp != d.k) pool.push_back(0.0);
+                }
             }
             out[i] = d;
         }
-        return up.put(out);
+        return out;
     };
-    s.dev.quality = pack(p.quality);
-    s.dev.seq_quality = pack(p.seq_quality);
-    s.dev.base_call = pack(p.base_call);
-    s.dev.dom_error = pack(p.dom_error);
-    s.dev.error_rate = pack(p.error_rate);
-    s.dev.indels = pack(p.indels);
+    std::vector<DevTable> quality = pack(p.quality), seq_quality = pack(p.seq_quality), base_call = pack(p.base_call), dom_error = pack(p.dom_error),
+                          error_rate = pack(p.error_rate), indels = pack(p.indels);
+
+    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): per template segment, descriptors first, then margins 0+1
+    // of the quality tables, then margin 0 of the base-call tables -- as much as fits the budget.
+    const uint32_t T = p.n_tiles();
+    LdsPlan plan{};
+    plan.desc_doubles = lds_desc_count(T) * (uint32_t)(sizeof(DevTable) / sizeof(double));
+    auto rows_q = [&](const DevTable &d) { return d.k ? (d.rows[0] + d.rows[1]) * row_stride(d.k) : 0u; };
+    auto rows_b = [&](const DevTable &d) { return d.k ? d.rows[0] * row_stride(d.k) : 0u; };
+    uint64_t need_q = 0, need_b = 0;
+    for (uint32_t seg = 0; seg < 2; ++seg) {
+        uint64_t q = 0, b = 0;
+        for (uint32_t i = 0; i < 4 * T; ++i) q += rows_q(quality[seg * 4 * T + i]);
+        for (uint32_t i = 0; i < 20 * T; ++i) b += rows_b(base_call[seg * 20 * T + i]);
+        need_q = std::max(need_q, q);
+        need_b = std::max(need_b, b);
+    }
+    const uint64_t budget = kLdsBudgetBytes / sizeof(double);
+    plan.stage_desc = plan.desc_doubles <= budget / 4 ? 1u : 0u;
+    plan.stage_quality = plan.stage_desc && plan.desc_doubles + need_q <= budget ? 1u : 0u;
+    plan.stage_base_call = plan.stage_quality && plan.desc_doubles + need_q + need_b <= budget ? 1u : 0u;
+    plan.total_doubles = plan.stage_desc ? plan.desc_doubles : 0u;
+    if (plan.stage_quality) {
+        for (uint32_t seg = 0; seg < 2; ++seg) {
+            uint32_t at = plan.desc_doubles;
+            for (uint32_t i = 0; i < 4 * T; ++i) {
+                DevTable &d = quality[seg * 4 * T + i];
+                if (!d.k) continue;
+                d.lds_off = at;
+                at += rows_q(d);
+            }
+            if (plan.stage_base_call)
+                for (uint32_t i = 0; i < 20 * T; ++i) {
+                    DevTable &d = base_call[seg * 20 * T + i];
+                    if (!d.k) continue;
+                    d.lds_off = at;
+                    at += rows_b(d);
+                }
+            plan.total_doubles = std::max(plan.total_doubles, at);
+        }
+    }
+    s.dev.lds = plan;
+    s.dev.quality = up.put(quality);
+    s.dev.seq_quality = up.put(seq_quality);
+    s.dev.base_call = up.put(base_call);
+    s.dev.dom_error = up.put(dom_error);
+    s.dev.error_rate = up.put(error_rate);
+    s.dev.indels = up.put(indels);
     par0.push_back(0);
+    pool.push_back(0.0);
     pool.push_back(0.0);
     s.dev.pool = up.put(pool);
     s.dev.par0 = up.put(par0);

@@ -105,8 +105,10 @@ struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
     // workspace of the hot path (grow-only)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2;
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count;
     std::map<std::string, Timer> timers;
+    uint32_t n_cu = 256;
+    int force_fill_mode = -1;      // RSQ_FILL_MODE=0..3 caps the LDS staging mode (tests run every mode)
 };
 
 namespace rsq {
@@ -197,6 +199,36 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     return RawLayout{s.raw_seq.as<uint8_t>(), s.raw_qual.as<uint8_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), s.read_stride, s.ops_stride};
 }
 
+// k_fill_reads: persistent waves, one workgroup per CU slot; MODE chosen by the LDS plan of pack_tables
+template <int MODE>
+static void launch_fill_mode(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+    const size_t lds_bytes = MODE > 0 ? (size_t)s.dev.lds.total_doubles * sizeof(double) : 0;
+    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // workgroups resident per CU: limited by the LDS image (160 KiB) and by 2048 threads
+    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;
+    const uint64_t chunks = (n_pairs + 63) / 64;
+    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(chunks, kFillBlock / 64)));
+    blocks = (blocks + 1u) & ~1u;                                   // segments alternate over blockIdx.x
+    s.fill_counters.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
+    s.timers["fill_reads"].start(st);
+    hipLaunchKernelGGL(k_fill_reads<MODE>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
+                       s.fill_counters.as<uint32_t>());
+    s.timers["fill_reads"].stop(st);
+    HIP_CHECK(hipGetLastError());
+}
+static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+    const LdsPlan &pl = s.dev.lds;
+    const int mode = s.force_fill_mode >= 0 ? std::min(s.force_fill_mode, (int)(pl.stage_desc + pl.stage_quality + pl.stage_base_call))
+                                            : (int)(pl.stage_desc + pl.stage_quality + pl.stage_base_call);
+    switch (mode) {
+    case 0: launch_fill_mode<0>(s, frags, n_pairs, adapter_first, raw, st); break;
+    case 1: launch_fill_mode<1>(s, frags, n_pairs, adapter_first, raw, st); break;
+    case 2: launch_fill_mode<2>(s, frags, n_pairs, adapter_first, raw, st); break;
+    default: launch_fill_mode<3>(s, frags, n_pairs, adapter_first, raw, st); break;
+    }
+}
+
 // reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
 static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap,
                           size_t *r2_len, hipStream_t st) {
@@ -204,17 +236,10 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     if (!n_pairs) return RSQ_OK;
     RawLayout raw = raw_layout(s, 2 * n_pairs);
     const dim3 grid(cdiv(n_pairs, 64), 2), block(64);
-    s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL(k_fill_reads, grid, block, 0, st, s.dev, frags, n_pairs, adapter_first, raw);
-    s.timers["fill_reads"].stop(st);
-    HIP_CHECK(hipGetLastError());
     s.sizes.reserve(2 * n_pairs * 4 + 16);
     s.off_r1.reserve((n_pairs + 1) * 8);
     s.off_r2.reserve((n_pairs + 1) * 8);
-    s.timers["format_sizes"].start(st);
-    hipLaunchKernelGGL(k_format, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(), (const uint64_t *)nullptr,
-                       (const uint64_t *)nullptr, (char *)nullptr, (char *)nullptr);
-    s.timers["format_sizes"].stop(st);
+    launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st);
     s.timers["scan"].start(st);
     exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
     exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
@@ -230,8 +255,7 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
         return RSQ_ENOSPC;
     }
     s.timers["format_write"].start(st);
-    hipLaunchKernelGGL(k_format, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, (uint32_t *)nullptr, s.off_r1.as<uint64_t>(),
-                       s.off_r2.as<uint64_t>(), r1, r2);
+    hipLaunchKernelGGL(k_format_write, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(st));
@@ -255,20 +279,34 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     if (!n_slots) return RSQ_OK;
     s.counts.reserve(n_slots * 4 + 16);
     s.offsets.reserve((n_slots + 1) * 8);
-    const dim3 sgrid(cdiv(n_slots, 4)), sblock(256);
-    s.timers["sieve_count"].start(st);
-    hipLaunchKernelGGL(k_sieve<false>, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr, (Fragment *)nullptr);
-    s.timers["sieve_count"].stop(st);
-    HIP_CHECK(hipGetLastError());
-    exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
+    s.hit_count.reserve(8);
+    // capacity of the hit list: cells with fragments <= pairs; start from the expected share of this block range
+    uint64_t hit_cap = std::max<uint64_t>(s.hits.bytes() / sizeof(SieveHit),
+                                          (uint64_t)((double)s.total_pairs * (double)(block_hi - block_lo) / (double)s.total_blocks * 1.25) + 65536);
     uint64_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    uint32_t n_hits = 0;
+    const dim3 sgrid(cdiv(n_slots, kSieveWaves * kSieveSlotsPerWave)), sblock(64 * kSieveWaves);
+    for (int attempt = 0;; ++attempt) {
+        s.hits.reserve(hit_cap * sizeof(SieveHit));
+        HIP_CHECK(hipMemsetAsync(s.hit_count.as<uint32_t>(), 0, 4, st));
+        s.timers["sieve"].start(st);
+        hipLaunchKernelGGL(k_sieve, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap,
+                           s.hit_count.as<uint32_t>());
+        s.timers["sieve"].stop(st);
+        HIP_CHECK(hipGetLastError());
+        exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
+        HIP_CHECK(hipMemcpyAsync(&total, s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&n_hits, s.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (n_hits <= hit_cap) break;
+        if (attempt) throw Error("sieve hit list overflowed twice");
+        hit_cap = (uint64_t)n_hits + 65536;                         // every cell was counted: the exact size is known now
+    }
     *n_pairs = total;
     if (!total) return RSQ_OK;
     s.frags.reserve(total * sizeof(Fragment) + 16);
     s.timers["sieve_emit"].start(st);
-    hipLaunchKernelGGL(k_sieve<true>, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(), s.frags.as<Fragment>());
+    hipLaunchKernelGGL(k_sieve_emit, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(), s.frags.as<Fragment>());
     s.timers["sieve_emit"].stop(st);
     HIP_CHECK(hipGetLastError());
     if (frags_out) {
@@ -426,6 +464,10 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     int rc = guard([&] {
         HIP_CHECK(hipSetDevice(device));
         s->device = device;
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        s->n_cu = (uint32_t)prop.multiProcessorCount;
+        if (const char *m = getenv("RSQ_FILL_MODE")) s->force_fill_mode = atoi(m);
         s->prof = p->p;
         pack_tables(*s, s->up);
         pack_profile(*s, s->up);

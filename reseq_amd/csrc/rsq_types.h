@@ -27,15 +27,29 @@ constexpr uint32_t kSqFragmentLengthBinSize = 10;   // QualityStats.h:15
 enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5 };
 
 // One LogArrayResult<N>: K outcome columns, NM = N-1 conditioning margins.
-// margin n: rows[n] x K doubles at pool[off[n]], row r = clamp(value - from[n]).
+// margin n: rows[n] rows of stride kp = (K+1)&~1 doubles at pool[off[n]] (a zero pad column when K is odd, so that
+// rows are 16-byte aligned and can be read two columns at a time); row r = clamp(value - from[n]).
+// The margins of one table are contiguous in the pool: off[n+1] = off[n] + rows[n]*kp.
 struct DevTable {
     uint32_t k;            // par0_indeces_.size(); 0 = empty table (Draw returns prob_sum 0)
     uint32_t par0_off;     // into the u8 outcome-value pool
     uint32_t from[4];      // limits_[n].first
     uint32_t rows[4];      // limits_[n].second - limits_[n].first
-    uint32_t off[4];       // into the double pool
+    uint32_t off[4];       // into the double pool (even: 16-byte aligned)
     uint32_t max_value;    // MaxValue()  (ProbabilityEstimates.h:510-517)
-    uint32_t pad;
+    uint32_t lds_off;      // offset (doubles) of margin 0 in the workgroup's LDS image, kNoLds if the table is not staged
+};
+constexpr uint32_t kNoLds = 0xFFFFFFFFu;
+RSQ_HD uint32_t row_stride(uint32_t k) { return (k + 1u) & ~1u; }
+
+// LDS image of k_fill_reads, one per template segment (DESIGN.md "LDS staging"): the table descriptors of the segment,
+// then margins 0+1 of its quality tables, then margin 0 of its base-call tables.
+struct LdsPlan {
+    uint32_t stage_quality;      // 1: quality margins 0 and 1 are in LDS
+    uint32_t stage_base_call;    // 1: base-call margin 0 is in LDS
+    uint32_t stage_desc;         // 1: descriptors are in LDS
+    uint32_t desc_doubles;       // size of the descriptor area (in doubles)
+    uint32_t total_doubles;      // size of the whole image
 };
 
 // Fragment produced by the coverage sieve: one simulated read pair (Simulator.cpp:2249-2357 -> CreateReads).
@@ -93,6 +107,7 @@ struct DevSim {
     const DevTable *dom_error;     // [4][5][5]
     const DevTable *error_rate;    // [4][5]
     const DevTable *indels;        // [2][6]
+    LdsPlan lds;
     uint32_t n_tiles;
     uint8_t phred_offset;
     uint16_t max_len_deletion;
@@ -130,6 +145,13 @@ struct DevSim {
     uint32_t total_blocks;
     const uint32_t *block_seq;       // [total_blocks+1] sequence of block id b (index b, 1-based)
     const uint32_t *first_block;     // [n_seqs]
+};
+
+struct NameTable {                       // first parts of the reference ids + the record base identifier
+    const char *names;
+    const uint32_t *name_ptr;
+    char base_identifier[64];
+    uint32_t base_len;
 };
 
 }  // namespace rsq

@@ -34,6 +34,7 @@ def emu_lib():
         L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+        L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
         L.emu_prepare.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
         L.emu_get_info.argtypes = [C.c_void_p, C.POINTER(EmuInfo)]
         L.emu_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
@@ -62,13 +63,15 @@ def _ok(rc):
 class EmuBackend:
     name = "hostemu"
 
+    fill_mode = -1          # class attribute: tests subclass to cap the LDS staging mode
+
     def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None):
         self.L = emu_lib()
         self.h = C.c_void_p()
         _ok(self.L.emu_create(str(profile_path).encode(), (str(fasta_path) if fasta_path else "").encode(), replace_n_seed, C.byref(self.h)))
         if edits:
             _ok(self.L.emu_edit_profile(self.h, edits.get("error_multiplier", 1.0), int(edits.get("no_substitutions", False)), int(edits.get("no_indels", False))))
-        self.seq_lens = None
+        self.L.emu_set_fill_mode(self.h, self.fill_mode)
 
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
         _ok(self.L.emu_prepare(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))

@@ -31,7 +31,31 @@ struct HostUploader : Uploader {
 
 struct Emu : SimState {
     HostUploader up;
+    int fill_mode = -1;                         // -1: highest mode the LDS plan allows (as the product does); 0..3 caps it
+    std::vector<double> lds[2];                 // host stand-in for the LDS image of each template segment
+    int mode() const {
+        const int plan = (int)(dev.lds.stage_desc + dev.lds.stage_quality + dev.lds.stage_base_call);
+        return fill_mode >= 0 ? std::min(fill_mode, plan) : plan;
+    }
+    void build_lds() {                          // what a workgroup of k_fill_reads does before its first read
+        for (uint32_t seg = 0; seg < 2; ++seg) {
+            lds[seg].assign(dev.lds.total_doubles + 16, 0.0);
+            if (mode() > 0) lds_stage_descriptors(dev, lds[seg].data(), seg, 0, 1);
+            if (mode() > 1) lds_stage_rows(dev, lds[seg].data(), seg, 0, 1);
+        }
+    }
 };
+
+// dispatch on the staging mode exactly like k_fill_reads<MODE>
+template <class F>
+void with_tables(Emu &s, uint32_t seg, F &&f) {
+    switch (s.mode()) {
+    case 0: f(GlobalTables{s.dev}); break;
+    case 1: f(LdsTables<false, false>{s.dev, s.lds[seg].data(), seg}); break;
+    case 2: f(LdsTables<true, false>{s.dev, s.lds[seg].data(), seg}); break;
+    default: f(LdsTables<true, true>{s.dev, s.lds[seg].data(), seg}); break;
+    }
+}
 
 thread_local std::string g_err;
 
@@ -131,7 +155,7 @@ struct Raw {
         seq.assign(s.read_stride + 8, 0);
         qual.assign(s.read_stride + 8, 0);
         ops.assign(s.ops_stride + 64, 0);
-        return ReadOut{seq.data(), qual.data(), ops.data(), 0u, 0u};
+        return make_read_out(seq.data(), qual.data(), ops.data());
     }
 };
 
@@ -167,6 +191,8 @@ int emu_edit_profile(void *h, double error_multiplier, int no_substitutions, int
     });
 }
 
+void emu_set_fill_mode(void *h, int mode) { static_cast<Emu *>(h)->fill_mode = mode; }
+
 int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
     Emu &s = *static_cast<Emu *>(h);
     return guard([&] {
@@ -179,6 +205,7 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
             upload_normalization(s, s.up);
         }
         s.passes = run_chains(s, s.has_ref);
+        s.build_lds();
         s.prepared = true;
     });
 }
@@ -239,16 +266,12 @@ int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, 
         uint32_t number = 0;
         for (uint32_t off = 0; off < kBlockSize; ++off) {
             SieveSite site;
-            site.seq = S.block_seq[block_id];
-            site.L = S.seq_len[site.seq];
-            site.start = (block_id - S.first_block[site.seq]) * kBlockSize + off;
+            init_site(S, block_id, off, site);
             if (site.start >= site.L) break;
-            site.word_off = S.seq_word_off[site.seq];
-            site.thr = S.thresholds + (size_t)S.coverage_group[site.seq] * S.insert_to * 2u;
-            site.have_start = false;
             for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
                 uint32_t cnt[2], strand_of[2];
-                if (!sieve_cell(S, site, len, cnt, strand_of)) continue;
+                const Words w = sieve_pair_words(S, site, len >> 1);
+                if (!sieve_cell(S, site, len, sieve_cell_uniform(w, len), cnt, strand_of)) continue;
                 for (uint32_t j = 0; j < 2; ++j)
                     for (uint32_t dup = 0; dup < cnt[j]; ++dup) {
                         if (n < cap) out[n] = make_fragment(site, len, dup, strand_of[j], block_id, number + 1);
@@ -273,13 +296,16 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
             for (uint32_t seg = 0; seg < 2; ++seg) {
                 ReadOut out = raw.out(s);
                 ReadMeta meta;
-                if (frags) fill_fragment_read(s.dev, frags[pair], seg, out, meta);
-                else fill_adapter_only_read(s.dev, adapter_first + pair, seg, out, meta);
+                with_tables(s, seg, [&](const auto &tab) {
+                    if (frags) fill_fragment_read(s.dev, tab, frags[pair], seg, out, meta);
+                    else fill_adapter_only_read(s.dev, tab, adapter_first + pair, seg, out, meta);
+                });
                 out.finish();
-                const uint32_t need = format_record(s.dev, s.names, frags ? &frags[pair] : nullptr, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(),
-                                                    raw.ops.data(), nullptr);
+                const Fragment *fp = frags ? &frags[pair] : nullptr;
+                const uint32_t need = record_size(s.dev, s.names, fp, adapter_first + pair + 1, meta);      // what k_fill_reads stores in sizes[]
                 if (pos[seg] + need > cap[seg]) throw Error("text buffer too small");
-                format_record(s.dev, s.names, frags ? &frags[pair] : nullptr, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(), raw.ops.data(), dst[seg] + pos[seg]);
+                const uint32_t wrote = format_record(s.dev, s.names, fp, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(), raw.ops.data(), dst[seg] + pos[seg]);
+                if (wrote != need) throw Error("record_size disagrees with format_record");
                 pos[seg] += need;
             }
         *len1 = pos[0];
@@ -299,7 +325,7 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
             ReadOut out = raw.out(s);
             ReadMeta m;
             RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
-            fill_record_read(s.dev, first_index + i, segs[i], frag_len[i], src, out, m);
+            fill_record_read(s.dev, GlobalTables{s.dev}, first_index + i, segs[i], frag_len[i], src, out, m);
             out.finish();
             read_len_out[i] = m.read_len;
             nerr_out[i] = m.num_errors;

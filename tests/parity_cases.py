@@ -134,6 +134,18 @@ def case_sieve_own_thresholds(backend_cls, workdir):
         p.close()
 
 
+def case_dense_coverage(backend_cls, workdir):
+    """very high coverage: a quarter of all (start, length) cells carry fragments, duplicates are common and the sieve's
+    candidate queue has to be flushed in the middle of a wave's positions"""
+    p = Pair(backend_cls, workdir, "tiny_dense", synth.TINY, [3000], seed=17, num_pairs=60000)
+    try:
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert 50000 < n < 70000
+    finally:
+        p.close()
+
+
 def case_adapter_only(backend_cls, workdir):
     p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=3, num_pairs=30000)
     try:

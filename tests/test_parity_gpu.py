@@ -29,6 +29,10 @@ def test_sieve_own_thresholds(workdir):
     P.case_sieve_own_thresholds(GpuBackend, workdir)
 
 
+def test_dense_coverage(workdir):
+    P.case_dense_coverage(GpuBackend, workdir)
+
+
 def test_adapter_only(workdir):
     P.case_adapter_only(GpuBackend, workdir)
 
@@ -51,3 +55,11 @@ def test_error_model_long_templates(workdir):
 
 def test_error_model_p0(workdir):
     P.case_error_model_p0(GpuBackend, workdir)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_lds_staging_mode(workdir, mode, monkeypatch):
+    """k_fill_reads<MODE>: tables from HBM only / descriptors in LDS / + quality margins (mode 3 is the default above)"""
+    monkeypatch.setenv("RSQ_FILL_MODE", str(mode))
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+    P.case_p0_reads(GpuBackend, workdir)

@@ -67,6 +67,10 @@ def test_sieve_own_thresholds(workdir):
     P.case_sieve_own_thresholds(EmuBackend, workdir)
 
 
+def test_dense_coverage(workdir):
+    P.case_dense_coverage(EmuBackend, workdir)
+
+
 def test_adapter_only(workdir):
     P.case_adapter_only(EmuBackend, workdir)
 
@@ -89,3 +93,12 @@ def test_error_model_long_templates(workdir):
 
 def test_error_model_p0(workdir):
     P.case_error_model_p0(EmuBackend, workdir)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_lds_staging_mode(workdir, mode):
+    """k_fill_reads<MODE>: tables from HBM only / descriptors in LDS / + quality margins (3 = everything is the default above)"""
+    class Capped(EmuBackend):
+        fill_mode = mode
+    P.case_sieve_and_reads_tiny(Capped, workdir)
+    P.case_p0_reads(Capped, workdir)
