@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreseq_amd.so")
+LIB_PATH = os.environ.get("RSQ_LIB", os.path.join(_HERE, "libreseq_amd.so"))      # RSQ_LIB: experiment builds of the same library
 
 RSQ_OK, RSQ_EINVAL, RSQ_EIO, RSQ_ENODEV, RSQ_EHIP, RSQ_ENOSPC, RSQ_ESTATE = 0, -1, -2, -3, -4, -5, -6
 

@@ -96,45 +96,105 @@ struct LdsRow {                        // a margin row staged in the workgroup's
     const RSQ_LDS double *p;
     RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const RSQ_LDS Pair *>(p + 2u * j); }
 };
+// A row that most lanes of the wave find in LDS while the others read it from HBM.  `any_global` is wave-uniform: a wave
+// whose lanes all use LDS issues no vector-memory instruction (a load with few active lanes costs as much as a full one).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQ_ANY(x) (__any(x) != 0)
+#else
+#define RSQ_ANY(x) (x)
+#endif
+struct HybridRow {
+    LdsRow l;
+    GlobalRow g;
+    bool use_lds, any_global;
+};
+RSQ_HD HybridRow hybrid_row(const RSQ_LDS double *l, const double *g, bool use_lds) { return HybridRow{LdsRow{l}, GlobalRow{g}, use_lds, RSQ_ANY(!use_lds)}; }
 
-template <class R>
-RSQ_HD void mul_into(Pair &a, const R &r, uint32_t j) {
-    const Pair b = r.pair(j);
-    a.x *= b.x;
-    a.y *= b.y;
+// Both passes work on CHUNKS of U column pairs: all row loads of a chunk are issued before the first product is formed
+// (the loops are latency-bound otherwise).  Rows are zero-padded to whole chunks (row_stride), so no chunk needs a
+// validity mask: a pad column contributes the product +0.0, which changes neither sum.  The last chunk of pass 1 is the
+// first chunk of pass 2 and stays in registers.
+template <int U, class R>
+RSQ_HD void load_chunk(Pair (&v)[U], const R &r, uint32_t base) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) v[i] = r.pair(base + (uint32_t)i);
 }
-template <class R0, class... Rs>
-RSQ_HD Pair prod_pair(uint32_t j, const R0 &r0, const Rs &...rs) {      // ((r0*r1)*r2)*r3, the order of Likelihood()
-    Pair a = r0.pair(j);
-    (mul_into(a, rs, j), ...);
-    return a;
+template <int U>
+RSQ_HD void load_chunk(Pair (&v)[U], const HybridRow &r, uint32_t base) {
+    if (r.use_lds) load_chunk<U>(v, r.l, base);
+    if (r.any_global) {
+        if (!r.use_lds) load_chunk<U>(v, r.g, base);
+    }
+}
+template <int U>
+RSQ_HD void mul_chunk(Pair (&a)[U], const Pair (&b)[U]) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        a[i].x *= b[i].x;
+        a[i].y *= b[i].y;
+    }
+}
+// products ((r0*r1)*r2)*r3 -- the order of Likelihood() -- of the pairs base .. base+U-1
+template <int U, class R0, class R1, class R2>
+RSQ_HD void prod_chunk(Pair (&p)[U], uint32_t base, const R0 &r0, const R1 &r1, const R2 &r2) {
+    Pair b[U], c[U];
+    load_chunk<U>(p, r0, base);
+    load_chunk<U>(b, r1, base);
+    load_chunk<U>(c, r2, base);
+    mul_chunk<U>(p, b);
+    mul_chunk<U>(p, c);
+}
+template <int U, class R0, class R1, class R2, class R3>
+RSQ_HD void prod_chunk(Pair (&p)[U], uint32_t base, const R0 &r0, const R1 &r1, const R2 &r2, const R3 &r3) {
+    Pair b[U], c[U], d[U];
+    load_chunk<U>(p, r0, base);
+    load_chunk<U>(b, r1, base);
+    load_chunk<U>(c, r2, base);
+    load_chunk<U>(d, r3, base);
+    mul_chunk<U>(p, b);
+    mul_chunk<U>(p, c);
+    mul_chunk<U>(p, d);
 }
 
-// returns the outcome COLUMN (index into par0); prob_sum as in the reference
-template <class... Rs>
+// LogArrayResult::Draw (ProbabilityEstimates.h:528-560).  Returns the outcome COLUMN (index into par0); prob_sum as in
+// the reference.  Pass 2 is the reference's `while(sum <= r && --k) sum += prob[k]`: the products are non-negative, so the
+// running sum never decreases and the columns with sum > r are the lowest ones of the scan; counting them per chunk gives
+// the column the reference stops at without a branch per column (column 0 may be counted: the result is 0 either way).
+template <int U, class... Rs>
 RSQ_HD uint32_t draw_rows(uint32_t K, double u, double &prob_sum, const Rs &...rs) {
+    const uint32_t nc = chunks_of(K, U);
+    Pair p[U];
     double s = 0.0;
-    const uint32_t np = (K + 1u) >> 1;
-    for (uint32_t j = 0; j < np; ++j) {
-        const Pair p = prod_pair(j, rs...);
-        s += p.x;
-        s += p.y;
+    for (uint32_t c = 0; c < nc; ++c) {            // pass 1: prob_sum, ascending columns
+        prod_chunk<U>(p, c * U, rs...);
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            s += p[i].x;
+            s += p[i].y;
+        }
     }
     prob_sum = s;
     const double r = u * s;
     double sum = 0.0;
-    for (uint32_t j = np; j--;) {                 // while(sum <= r && --k) sum += prob[k], two columns per step
-        const Pair p = prod_pair(j, rs...);
-        const uint32_t hi = 2u * j + 1u;
-        if (hi < K) {
-            sum += p.y;
-            if (!(sum <= r)) return hi;
+    for (uint32_t c = nc; c--;) {                  // pass 2, descending columns; p holds the top chunk already
+        if (c != nc - 1u) prod_chunk<U>(p, c * U, rs...);
+        uint32_t above = 0;
+#pragma unroll
+        for (int i = U; i--;) {
+            sum += p[i].y;
+            above += !(sum <= r) ? 1u : 0u;
+            sum += p[i].x;
+            above += !(sum <= r) ? 1u : 0u;
         }
-        if (j == 0) return 0;                     // column 0 is never added
-        sum += p.x;
-        if (!(sum <= r)) return 2u * j;
+        if (above) return 2u * U * c + above - 1u;
     }
     return 0;
+}
+
+// the chunk size is a function of K alone (row_stride pads for it); wave-divergent only when lanes use tables of both classes
+template <class... Rs>
+RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &...rs) {
+    return K <= 2u * kChunkSmall ? draw_rows<(int)kChunkSmall>(K, u, prob_sum, rs...) : draw_rows<(int)kChunkLarge>(K, u, prob_sum, rs...);
 }
 
 RSQ_HD uint32_t clamp_row(const DevTable &t, int n, uint32_t v) {      // AdjustIndeces (:368-380)
@@ -152,8 +212,8 @@ RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, const u
 #pragma unroll
     for (int n = 0; n < NM; ++n) m[n].p = pool + t.off[n] + (size_t)clamp_row(t, n, idx[n]) * kp;
     uint32_t col;
-    if constexpr (NM == 3) col = draw_rows(t.k, u, prob_sum, m[0], m[1], m[2]);
-    else col = draw_rows(t.k, u, prob_sum, m[0], m[1], m[2], m[3]);
+    if constexpr (NM == 3) col = draw_rows_k(t.k, u, prob_sum, m[0], m[1], m[2]);
+    else col = draw_rows_k(t.k, u, prob_sum, m[0], m[1], m[2], m[3]);
     return par0[t.par0_off + col];
 }
 
@@ -297,15 +357,102 @@ struct FillState {                     // Simulator.h:215-240 ReadFillParameter
     uint32_t iteration;
 };
 
-template <class Tab, class Src, class Out>
-RSQ_HD void fill_read_part(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg, uint32_t tile_id, const Src &src, uint32_t org_len, uint32_t org_pos,
-                           char base_element, FillState &par, CigarRun &cg, Out &out) {
-    // Without variants the block walk of GetSysErrorFromBlock advances in step with org_pos (one systematic
-    // error per consumed template base), so src.sys() is indexed by org_pos for templates and adapters alike.
-    cg.element = base_element;
-    cg.length = 0;
-    const uint32_t tbase = (seg * S.n_tiles + tile_id) * 4u;
-    while (par.read_pos < par.read_length && org_pos < org_len) {
+RSQ_HD uint32_t draw_read_length(const DevSim &S, uint32_t seg, uint32_t fragment_length, double u) {   // Simulator.h:185-198
+    const DevReadLengths &rl = S.read_lengths[seg];
+    if (rl.fixed) return rl.fixed;
+    const double random_value = u * (double)S.insert_lengths[fragment_length];
+    double counter = 0.0;
+    const uint32_t row = fragment_length - rl.row_first;
+    const uint32_t from = rl.row_from[row] & 0xFFFFu;
+    uint32_t read_len = (from + (rl.row_ptr[row + 1] - rl.row_ptr[row])) & 0xFFFFu;
+    while (counter <= random_value) {
+        const bool more = read_len > from;
+        read_len = (read_len - 1u) & 0xFFFFu;                      // uintReadLen post-decrement (wraps like the reference)
+        if (!more) break;
+        counter += (double)rl.values[rl.row_ptr[row] + (read_len - from)];
+    }
+    return read_len;
+}
+
+struct AdapterSrc {                    // the adapter as template of FillReadPart(..., 'S', NULL, ...)
+    const uint8_t *seq;
+    const uint16_t *sys_;
+    RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
+    RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+};
+
+// FillRead as an explicit state machine: init() does everything before the first per-base iteration (Simulator.cpp:468-531),
+// every step() executes exactly ONE iteration of FillReadPart's loop (template part 'M', then adapter part 'S', :294-452) or
+// of the poly-A / overrun tail (:556-588) and consumes Philox step 2+t; finalize() fills the ReadMeta.  A kernel drives all
+// lanes of a wave through step() in one uniform loop, which is what allows wave-cooperative work between iterations.
+struct ReadMachine {
+    enum : uint32_t { kTemplate = 0, kAdapter = 1, kTail = 2, kDone = 3 };
+    FillState par;
+    CigarRun cg;
+    uint32_t phase, seg, tile_id, tbase;
+    uint32_t org_pos, org_len;         // position in / length of the current part's template
+    uint32_t adapter_id, adapter_a0;
+    uint32_t iter_m, hard_clip, tail_length, pos_tail;
+    uint32_t start_cut_word;           // h0.w3, needed only if the read starts inside the adapter
+
+    template <class Tab, class Src>
+    RSQ_HD void init(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg_, uint32_t tile, uint32_t fragment_length, const Src &src) {
+        seg = seg_;
+        tile_id = tile;
+        tbase = (seg * S.n_tiles + tile_id) * 4u;
+        par.read_pos = 0;
+        par.previous_indel_type = 0;
+        par.indel_pos = 0;
+        par.base_call = 5;
+        par.gc_seq = 0;
+        par.qual = 1;
+        par.error_rate = 0;
+        par.num_errors = 0;
+        par.last_written_qual = 0;
+        par.iteration = 0;
+        const Words h0 = st.step(0);
+        start_cut_word = h0.w3;
+        par.read_length = draw_read_length(S, seg, fragment_length, u32_to_unit(h0.w0));
+        const DevAdapters &ad = S.adapters[seg];
+        org_len = src.org_len();
+        org_pos = 0;
+        adapter_id = 0;
+        adapter_a0 = 0;
+        iter_m = hard_clip = tail_length = pos_tail = 0;
+        const uint32_t seq_length = par.read_length < org_len ? par.read_length : org_len;
+        uint32_t mean_error_rate = 0;
+        if (seq_length) {                                              // Simulator.cpp:480-504
+            for (uint32_t k = 0; k < seq_length; ++k) {
+                if (is_gc(src.base(k))) ++par.gc_seq;
+                mean_error_rate += src.sys(k) >> 8;
+            }
+            par.gc_seq = percent_u16(par.gc_seq, seq_length);
+            mean_error_rate = divide_u32(mean_error_rate, seq_length);
+        } else {                                                       // adapter-only read :505-522
+            adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h0.w1));
+            const uint32_t a0 = ad.seq_ptr[adapter_id], alen = ad.seq_ptr[adapter_id + 1] - a0;
+            for (uint32_t k = 0; k < alen; ++k) {
+                if (is_gc(ad.seqs[a0 + k])) ++par.gc_seq;
+                mean_error_rate += ad.sys[a0 + k] >> 8;
+            }
+            par.gc_seq = percent_u16(par.gc_seq, alen & 0xFFFFu);
+            mean_error_rate = divide_u32(mean_error_rate, alen);
+        }
+        double prob_sum;
+        const uint32_t sqi = seg * S.n_tiles + tile_id;
+        const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
+        par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, u32_to_unit(h0.w2), prob_sum);
+        if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
+            const DevTable sqt = tab.seq_quality(sqi);
+            par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
+        }
+        cg = CigarRun{'M', 0, 0};
+        phase = kTemplate;
+    }
+
+    // one iteration of FillReadPart's loop body (Simulator.cpp:322-444) on template `src`
+    template <class Tab, class Src, class Out>
+    RSQ_HD void iterate(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, char base_element, Out &out) {
         const uint32_t it = par.iteration++;
         const Words w = st.step(2u + it);
         double prob_sum;
@@ -315,6 +462,7 @@ RSQ_HD void fill_read_part(const DevSim &S, const Tab &tab, const Stream &st, ui
         const uint32_t org_base = src.base(org_pos);
         const uint32_t qi = tbase + org_base;
         if (0 == indel) {
+            // without variants the block walk of GetSysErrorFromBlock advances in step with org_pos (:286-291)
             const uint32_t se = src.sys(org_pos);
             const uint32_t dom_error = se & 0xFFu;
             par.error_rate = se >> 8;
@@ -376,119 +524,90 @@ RSQ_HD void fill_read_part(const DevSim &S, const Tab &tab, const Stream &st, ui
             ++par.read_pos;
         }
     }
-    if (cg.length) cg.flush();
-}
 
-RSQ_HD uint32_t draw_read_length(const DevSim &S, uint32_t seg, uint32_t fragment_length, double u) {   // Simulator.h:185-198
-    const DevReadLengths &rl = S.read_lengths[seg];
-    if (rl.fixed) return rl.fixed;
-    const double random_value = u * (double)S.insert_lengths[fragment_length];
-    double counter = 0.0;
-    const uint32_t row = fragment_length - rl.row_first;
-    const uint32_t from = rl.row_from[row] & 0xFFFFu;
-    uint32_t read_len = (from + (rl.row_ptr[row + 1] - rl.row_ptr[row])) & 0xFFFFu;
-    while (counter <= random_value) {
-        const bool more = read_len > from;
-        read_len = (read_len - 1u) & 0xFFFFu;                      // uintReadLen post-decrement (wraps like the reference)
-        if (!more) break;
-        counter += (double)rl.values[rl.row_ptr[row] + (read_len - from)];
+    // returns false once the read is complete
+    template <class Tab, class Src, class Out>
+    RSQ_HD bool step(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
+        for (;;) {
+            if (phase == kTemplate) {
+                if (par.read_pos < par.read_length && org_pos < org_len) {
+                    iterate(S, tab, st, src, 'M', out);
+                    return true;
+                }
+                if (cg.length) cg.flush();                          // Simulator.cpp:447-449
+                iter_m = par.iteration;
+                if (!(par.read_pos < par.read_length)) {
+                    phase = kDone;
+                    return false;
+                }
+                const DevAdapters &ad = S.adapters[seg];            // :537-553 the fragment ended before the read did
+                const Words h1 = st.step(1);
+                if (0 == adapter_id) adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h1.w1));
+                uint32_t adapter_pos = 0;
+                if (0 == par.read_pos)
+                    adapter_pos = discrete_draw(ad.cut_cp + ad.cut_ptr[adapter_id], ad.cut_ptr[adapter_id + 1] - ad.cut_ptr[adapter_id], u32_to_unit(start_cut_word)) +
+                                  ad.cut_from[adapter_id];
+                adapter_a0 = ad.seq_ptr[adapter_id];
+                org_len = ad.seq_ptr[adapter_id + 1] - adapter_a0;
+                org_pos = adapter_pos;
+                tail_length = discrete_draw(S.polya_cp, S.polya_n, u32_to_unit(h1.w0)) + S.polya_from;      // used only if a tail follows
+                cg.element = 'S';
+                cg.length = 0;
+                phase = kAdapter;
+            } else if (phase == kAdapter) {
+                if (par.read_pos < par.read_length && org_pos < org_len) {
+                    const DevAdapters &ad = S.adapters[seg];
+                    iterate(S, tab, st, AdapterSrc{ad.seqs + adapter_a0, ad.sys + adapter_a0}, 'S', out);
+                    return true;
+                }
+                if (cg.length) cg.flush();
+                if (!(par.read_pos < par.read_length)) {
+                    phase = kDone;
+                    return false;
+                }
+                hard_clip = par.read_length - par.read_pos;         // :556-558
+                cg.chars += digits10(hard_clip) + 1u;
+                pos_tail = 0;
+                phase = kTail;
+            } else if (phase == kTail) {
+                if (!(par.read_pos < par.read_length)) {
+                    phase = kDone;
+                    return false;
+                }
+                const Words w = st.step(2u + par.iteration++);       // :564-587 poly-A tail, then random overrun bases
+                double prob_sum;
+                const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+                uint32_t q = tab.draw_quality((seg * S.n_tiles + tile_id) * 4u, idx_q, u32_to_unit(w.w1), prob_sum);
+                if (0.0 == prob_sum && par.read_pos) q = par.last_written_qual;   // at(qual_, read_pos-1) - offset
+                par.qual = q;
+                const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
+                ++pos_tail;
+                out.put(par.read_pos, b, q + S.phred_offset);
+                par.last_written_qual = q;
+                ++par.read_pos;
+                return true;
+            } else return false;
+        }
     }
-    return read_len;
-}
 
-struct AdapterSrc {                    // the adapter as template of FillReadPart(..., 'S', NULL, ...)
-    const uint8_t *seq;
-    const uint16_t *sys_;
-    RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
-    RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+    RSQ_HD void finalize(ReadMeta &meta) const {
+        meta.read_len = (uint16_t)par.read_length;
+        meta.num_errors = (uint16_t)par.num_errors;
+        meta.n_iter_m = (uint16_t)iter_m;
+        meta.n_iter_s = (uint16_t)(par.iteration - iter_m - hard_clip);   // every tail iteration emits exactly one base
+        meta.hard_clip = (uint16_t)hard_clip;
+        meta.tile_id = (uint16_t)tile_id;
+        meta.cigar_chars = cg.chars;
+    }
 };
 
 template <class Tab, class Src, class Out>
 RSQ_HD void fill_read(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg, uint32_t tile_id, uint32_t fragment_length, const Src &src, Out &out,
                       ReadMeta &meta) {
-    FillState par;
-    par.read_pos = 0;
-    par.previous_indel_type = 0;
-    par.indel_pos = 0;
-    par.base_call = 5;
-    par.gc_seq = 0;
-    par.qual = 1;
-    par.error_rate = 0;
-    par.num_errors = 0;
-    par.last_written_qual = 0;
-    par.iteration = 0;
-    const Words h0 = st.step(0);
-    par.read_length = draw_read_length(S, seg, fragment_length, u32_to_unit(h0.w0));
-    const DevAdapters &ad = S.adapters[seg];
-    const uint32_t org_len = src.org_len();
-    uint32_t adapter_id = 0;
-    const uint32_t seq_length = par.read_length < org_len ? par.read_length : org_len;
-    uint32_t mean_error_rate = 0;
-    if (seq_length) {                                              // Simulator.cpp:480-504
-        for (uint32_t k = 0; k < seq_length; ++k) {
-            if (is_gc(src.base(k))) ++par.gc_seq;
-            mean_error_rate += src.sys(k) >> 8;
-        }
-        par.gc_seq = percent_u16(par.gc_seq, seq_length);
-        mean_error_rate = divide_u32(mean_error_rate, seq_length);
-    } else {                                                       // adapter-only read :505-522
-        adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h0.w1));
-        const uint32_t a0 = ad.seq_ptr[adapter_id], alen = ad.seq_ptr[adapter_id + 1] - a0;
-        for (uint32_t k = 0; k < alen; ++k) {
-            if (is_gc(ad.seqs[a0 + k])) ++par.gc_seq;
-            mean_error_rate += ad.sys[a0 + k] >> 8;
-        }
-        par.gc_seq = percent_u16(par.gc_seq, alen & 0xFFFFu);
-        mean_error_rate = divide_u32(mean_error_rate, alen);
-    }
-    double prob_sum;
-    const uint32_t sqi = seg * S.n_tiles + tile_id;
-    const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
-    par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, u32_to_unit(h0.w2), prob_sum);
-    if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
-        const DevTable &sqt = tab.seq_quality(sqi);
-        par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
-    }
-
-    CigarRun cg{'M', 0, 0};
-    fill_read_part(S, tab, st, seg, tile_id, src, org_len, 0u, 'M', par, cg, out);
-    const uint32_t iter_m = par.iteration;
-    uint32_t hard_clip = 0;
-    if (par.read_pos < par.read_length) {                           // :537-589
-        const Words h1 = st.step(1);
-        if (0 == adapter_id) adapter_id = discrete_draw(ad.adapter_cp, ad.n, u32_to_unit(h1.w1));
-        uint32_t adapter_pos = 0;
-        if (0 == par.read_pos)
-            adapter_pos = discrete_draw(ad.cut_cp + ad.cut_ptr[adapter_id], ad.cut_ptr[adapter_id + 1] - ad.cut_ptr[adapter_id], u32_to_unit(h0.w3)) +
-                          ad.cut_from[adapter_id];
-        const uint32_t a0 = ad.seq_ptr[adapter_id];
-        AdapterSrc asrc{ad.seqs + a0, ad.sys + a0};
-        fill_read_part(S, tab, st, seg, tile_id, asrc, ad.seq_ptr[adapter_id + 1] - a0, adapter_pos, 'S', par, cg, out);
-        if (par.read_pos < par.read_length) {
-            hard_clip = par.read_length - par.read_pos;
-            cg.chars += digits10(hard_clip) + 1u;
-            const uint32_t q0 = (seg * S.n_tiles + tile_id) * 4u;
-            const uint32_t tail_length = discrete_draw(S.polya_cp, S.polya_n, u32_to_unit(h1.w0)) + S.polya_from;
-            for (uint32_t pos_tail = 0; par.read_pos < par.read_length; ++pos_tail) {
-                const Words w = st.step(2u + par.iteration++);
-                const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-                uint32_t q = tab.draw_quality(q0, idx_q, u32_to_unit(w.w1), prob_sum);
-                if (0.0 == prob_sum && par.read_pos) q = par.last_written_qual;   // at(qual_, read_pos-1) - offset
-                par.qual = q;
-                const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
-                out.put(par.read_pos, b, q + S.phred_offset);
-                par.last_written_qual = q;
-                ++par.read_pos;
-            }
-        }
-    }
-    meta.read_len = (uint16_t)par.read_length;
-    meta.num_errors = (uint16_t)par.num_errors;
-    meta.n_iter_m = (uint16_t)iter_m;
-    meta.n_iter_s = (uint16_t)(par.iteration - iter_m - hard_clip);   // every tail iteration emits exactly one base
-    meta.hard_clip = (uint16_t)hard_clip;
-    meta.tile_id = (uint16_t)tile_id;
-    meta.cigar_chars = cg.chars;
+    ReadMachine m;
+    m.init(S, tab, st, seg, tile_id, fragment_length, src);
+    while (m.step(S, tab, st, src, out)) {}
+    m.finalize(meta);
 }
 
 }  // namespace rsq

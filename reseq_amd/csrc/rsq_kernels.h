@@ -623,18 +623,24 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
 }
 
 // ------------------------------------------------------------------------------------------- LDS staging
-// The rows a lane needs differ from lane to lane exactly where the conditioning value is per-read state: the quality
-// margins over sequence quality (0) and previous quality (1) and the base-call margin over the quality (0).  Those,
-// and the 64-byte table descriptors, are served from an LDS image built once per workgroup; the margins over read
-// position / error rate / error count are (nearly) the same row for every lane of a wave and stay in HBM (L1 hits).
-// Image layout (doubles): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (8 doubles each), then the
-// staged rows at DevTable::lds_off.  A workgroup serves ONE template segment.
+// A lane reads about 2 KB of table rows per base.  Measured on gfx950 (exp/ta_bench.hip): a wave-level global_load_dwordx4
+// costs the CU's vector-memory path >= 23 cycles (64 lanes x 16 B returned at 64 B/clk) however few lanes are active, and
+// about 2.3 cycles per distinct cache line touched; a ds_read_b128 costs 8.  The read kernel is bound by that path and by
+// the chain of dependent round trips, so the rows whose lines scatter most live in LDS (LdsPlan in rsq_types.h):
+//  * rows that differ from lane to lane because the conditioning value is per-read state -- quality margins over sequence
+//    quality (0) and previous quality (1), base-call margin over the quality (0);
+//  * the first rows of the error-rate margins (88 % of all positions have rate 0).  A lane whose rate is not staged reads
+//    its own row from HBM (HybridRow, rsq_core.h).
+// The rows over the read position stay in HBM: the lanes of a wave share them (4 cache lines per load), and staging them
+// per wave and step was measured slower (performance log).
+// Image layout (doubles): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (8 doubles each), staged
+// margins at DevTable::lds_off, error-rate rows at q3_off / b3_off.
 RSQ_HD uint32_t lds_desc_count(uint32_t n_tiles) { return 25u * n_tiles + 12u; }
 
-template <bool QL, bool BL>
+template <bool QL, bool BL, bool RT>
 struct LdsTables {
     const DevSim &S;
-    const RSQ_LDS double *img;
+    const RSQ_LDS double *img;         // image of the workgroup
     uint32_t seg;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
@@ -642,51 +648,60 @@ struct LdsTables {
     RSQ_HD DevTable indel(uint32_t i) const { return desc(24u * S.n_tiles + i); }
     RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.n_tiles + 12u + i - seg * S.n_tiles); }
 
+    template <class R0, class R1, class R2, class R3>
+    RSQ_HD uint32_t rows4(const DevTable &t, double u, double &ps, const R0 &r0, const R1 &r1, const R2 &r2, const R3 &r3) const {
+        return S.par0[t.par0_off + draw_rows_k(t.k, u, ps, r0, r1, r2, r3)];
+    }
+    // margins 2 (position) and 3 (error rate) of a quality draw
+    template <class R0, class R1>
+    RSQ_HD uint32_t quality_tail(const DevTable &t, uint32_t local, const uint32_t (&idx)[4], double u, double &ps, const R0 &m0, const R1 &m1) const {
+        const uint32_t kp = row_stride(t.k), r3 = clamp_row(t, 3, idx[3]);
+        const double *g2 = S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp, *g3 = S.pool + t.off[3] + r3 * kp;
+        const uint32_t nr = S.lds.rate_rows_q;
+        const RSQ_LDS double *l3 = img + S.lds.q3_off + (local * nr + (r3 < nr ? r3 : 0u)) * S.lds.slot_q;
+        if constexpr (RT) return rows4(t, u, ps, m0, m1, GlobalRow{g2}, hybrid_row(l3, g3, r3 < nr));
+        else return rows4(t, u, ps, m0, m1, GlobalRow{g2}, GlobalRow{g3});
+    }
     RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
-        const DevTable t = quality(i);
+        const uint32_t local = i - seg * 4u * S.n_tiles;
+        const DevTable t = desc(local);
         ps = 0.0;
         if (!t.k) return 0;
         const uint32_t kp = row_stride(t.k);
-        const GlobalRow m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp}, m3{S.pool + t.off[3] + clamp_row(t, 3, idx[3]) * kp};
-        uint32_t col;
-        if constexpr (QL) {
-            const LdsRow m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * kp};
-            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
-        } else {
-            const GlobalRow m0{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp}, m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp};
-            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
-        }
-        return S.par0[t.par0_off + col];
+        if constexpr (QL)
+            return quality_tail(t, local, idx, u, ps, LdsRow{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp},
+                                LdsRow{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * kp});
+        else
+            return quality_tail(t, local, idx, u, ps, GlobalRow{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp},
+                                GlobalRow{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp});
+    }
+    template <class R0>
+    RSQ_HD uint32_t base_call_tail(const DevTable &t, uint32_t local, const uint32_t (&idx)[4], double u, double &ps, const R0 &m0) const {
+        const uint32_t kp = row_stride(t.k), r3 = clamp_row(t, 3, idx[3]);
+        const GlobalRow m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp}, m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp};
+        const double *g3 = S.pool + t.off[3] + r3 * kp;
+        if constexpr (RT) {
+            const uint32_t nr = S.lds.rate_rows_b;
+            return rows4(t, u, ps, m0, m1, m2, hybrid_row(img + S.lds.b3_off + (local * nr + (r3 < nr ? r3 : 0u)) * S.lds.slot_b, g3, r3 < nr));
+        } else return rows4(t, u, ps, m0, m1, m2, GlobalRow{g3});
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
-        const DevTable t = base_call(i);
+        const uint32_t local = i - seg * 20u * S.n_tiles;
+        const DevTable t = desc(4u * S.n_tiles + local);
         ps = 0.0;
         if (!t.k) return 0;
         const uint32_t kp = row_stride(t.k);
-        const GlobalRow m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp}, m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp},
-            m3{S.pool + t.off[3] + clamp_row(t, 3, idx[3]) * kp};
-        uint32_t col;
-        if constexpr (BL) {
-            const LdsRow m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp};
-            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
-        } else {
-            const GlobalRow m0{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp};
-            col = draw_rows(t.k, u, ps, m0, m1, m2, m3);
-        }
-        return S.par0[t.par0_off + col];
+        if constexpr (BL) return base_call_tail(t, local, idx, u, ps, LdsRow{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp});
+        else return base_call_tail(t, local, idx, u, ps, GlobalRow{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp});
     }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
-        const DevTable t = indel(i);
-        return draw<3>(t, S.pool, S.par0, idx, u, ps);
-    }
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(indel(i), S.pool, S.par0, idx, u, ps); }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
-        const DevTable t = seq_quality(i);
-        return draw<3>(t, S.pool, S.par0, idx, u, ps);
+        return draw<3>(seq_quality(i), S.pool, S.par0, idx, u, ps);
     }
 };
 
-// Builds the LDS image of segment `seg`; tid/nthreads describe the calling thread (the host emulation calls it with 0/1).
-// The caller must synchronise the workgroup between the two phases and after phase 1.
+// Builds the static LDS image of segment `seg`; tid/nthreads describe the calling thread (the host emulation calls it with
+// 0/1).  The caller synchronises the workgroup between the two phases and after the second.
 RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
     const uint32_t T = S.n_tiles;
     RSQ_LDS uint32_t *dst = reinterpret_cast<RSQ_LDS uint32_t *>(img);
@@ -698,41 +713,58 @@ RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t
     for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
     for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i];
 }
-RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS double *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
+// rows 0..n_rows-1 of margin 3 of `n_tables` tables starting at descriptor `first`, one slot per row
+RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS double *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,
+                                uint32_t nthreads) {
+    const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
+    for (uint32_t i = tid; i < n_tables * n_rows * slot; i += nthreads) {
+        const DevTable tb = d[first + i / (n_rows * slot)];
+        const uint32_t row = (i / slot) % n_rows, c = i % slot, kp = tb.k ? row_stride(tb.k) : 0u;
+        img[dst_off + i] = (row < tb.rows[3] && c < kp) ? S.pool[tb.off[3] + row * kp + c] : 0.0;
+    }
+}
+RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS double *img, uint32_t mask, uint32_t tid, uint32_t nthreads) {
     const uint32_t T = S.n_tiles;
     const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
-    if (S.lds.stage_quality)
+    if (mask & kLdsQuality)
         for (uint32_t t = 0; t < 4u * T; ++t) {
             const DevTable tb = d[t];
             if (!tb.k || tb.lds_off == kNoLds) continue;
             const uint32_t n = (tb.rows[0] + tb.rows[1]) * row_stride(tb.k);
             for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
         }
-    if (S.lds.stage_base_call)
+    if (mask & kLdsBaseCall)
         for (uint32_t t = 0; t < 20u * T; ++t) {
             const DevTable tb = d[4u * T + t];
             if (!tb.k || tb.lds_off == kNoLds) continue;
             const uint32_t n = tb.rows[0] * row_stride(tb.k);
             for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
         }
+    if (mask & kLdsRate) {
+        lds_stage_rate_rows(S, img, 0u, 4u * T, S.lds.rate_rows_q, S.lds.slot_q, S.lds.q3_off, tid, nthreads);
+        lds_stage_rate_rows(S, img, 4u * T, 20u * T, S.lds.rate_rows_b, S.lds.slot_b, S.lds.b3_off, tid, nthreads);
+    }
 }
-
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
-template <class Tab>
-RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
-    const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
-    const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2));
-    const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)};
+// template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
+RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg) {
     const uint32_t L = S.seq_len[f.seq], end = f.start + f.len;
     const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion;           // Simulator.cpp:1918-1921
     FragmentSrc src;
     src.words = S.ref_words;
     src.word_off = S.seq_word_off[f.seq];
     src.len = f.len < want ? f.len : want;
-    src.reverse = seg != f.strand;                                              // block.at(strand) = start_block (:680-684)
+    src.reverse = seg != f.strand;                                              // block.at(strand) = start_block
     src.first = src.reverse ? end : f.start;
     src.sys_ = src.reverse ? S.sys_rev + S.seq_base_off[f.seq] + (L - end) : S.sys_fwd + S.seq_base_off[f.seq] + f.start;
-    fill_read(S, tab, st, seg, tile, f.len, src, out, meta);
+    return src;
+}
+template <class Tab>
+RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
+    const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
+    const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2));
+    const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)};
+    fill_read(S, tab, st, seg, tile, f.len, fragment_src(S, f, seg), out, meta);
 }
 // one mate of adapter-only pair i (Simulator.cpp:2359-2382)
 template <class Tab>
@@ -758,22 +790,26 @@ RSQ_HD void fill_record_read(const DevSim &S, const Tab &tab, uint64_t idx, uint
     fill_read(S, tab, st, seg, tile, frag_len, src, out, meta);
 }
 
+#ifndef RSQ_FILL_BLOCK
+#define RSQ_FILL_BLOCK 768
+#endif
+constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
+
 #if defined(__HIPCC__)
-// One lane per read, persistent waves.  A workgroup serves one template segment (blockIdx.x & 1), builds its LDS image
-// once, then every wave pulls chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail).
-// MODE 0: every table access goes to HBM (profiles whose tables do not fit the plan); 1: descriptors in LDS;
-// 2: + quality margins 0,1; 3: + base-call margin 0.
-constexpr uint32_t kFillBlock = 1024;
-template <int MODE>
+// One lane per read, persistent waves.  A workgroup serves one template segment (blockIdx.x & 1), builds its static LDS
+// image once, then every wave pulls chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail).
+// All lanes of a wave walk their reads' state machines in one uniform loop.  MASK = kLds* bits (0: every table access
+// goes to HBM).
+template <uint32_t MASK>
 __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
     extern __shared__ __attribute__((aligned(16))) double lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
     RSQ_LDS double *img = (RSQ_LDS double *)lds_image;
-    if (MODE > 0) {
+    if (MASK) {
         lds_stage_descriptors(S, img, seg, threadIdx.x, blockDim.x);
         __syncthreads();
-        if (MODE > 1) lds_stage_rows(S, img, seg, threadIdx.x, blockDim.x);
+        lds_stage_rows(S, img, MASK, threadIdx.x, blockDim.x);
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -784,24 +820,40 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         const uint64_t first = (uint64_t)chunk * 64u;
         if (first >= n_pairs) break;
         const uint64_t pair = first + lane;
-        if (pair >= n_pairs) continue;
-        const uint64_t r = (uint64_t)seg * n_pairs + pair;
+        const bool active = pair < n_pairs;
+        const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : first);
         ReadOut out = make_read_out(raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride, raw.ops + r * raw.ops_stride);
+        Fragment f{};
+        if (active && frags) f = frags[pair];
+        // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
+        const bool from_fragment = frags != nullptr;
+        const uint64_t ao = adapter_only_first + pair;
+        const uint32_t c0 = from_fragment ? f.start : (uint32_t)ao, c1 = from_fragment ? f.seq : 0xFFFFFFFFu,
+                       c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
+        const uint32_t strand = from_fragment ? f.strand : 0u;
+        const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg)};
+        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd};      // len 0 = empty template
+        ReadMachine m;
         ReadMeta meta;
-        Fragment f;
-        if (frags) f = frags[pair];
-        if (MODE == 0) {
+        if constexpr (MASK == 0) {
             const GlobalTables tab{S};
-            if (frags) fill_fragment_read(S, tab, f, seg, out, meta);
-            else fill_adapter_only_read(S, tab, adapter_only_first + pair, seg, out, meta);
+            if (active) {
+                m.init(S, tab, st, seg, draw_tile(S, c0, c1, c2, pair_c3(kDomPair, strand, 2)), f.len, src);
+                while (m.step(S, tab, st, src, out)) {}
+            }
         } else {
-            const LdsTables<(MODE > 1), (MODE > 2)> tab{S, img, seg};
-            if (frags) fill_fragment_read(S, tab, f, seg, out, meta);
-            else fill_adapter_only_read(S, tab, adapter_only_first + pair, seg, out, meta);
+            LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{S, img, seg};
+            bool running = active;
+            if (active) m.init(S, tab, st, seg, draw_tile(S, c0, c1, c2, pair_c3(kDomPair, strand, 2)), f.len, src);
+            while (__any(running))
+                if (running) running = m.step(S, tab, st, src, out);
         }
-        out.finish();
-        raw.meta[r] = meta;
-        sizes[r] = record_size(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, meta);       // bytes of its FASTQ record
+        if (active) {
+            m.finalize(meta);
+            out.finish();
+            raw.meta[r] = meta;
+            sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta);       // bytes of its FASTQ record
+        }
     }
 }
 
@@ -826,13 +878,14 @@ __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_ind
 // with the same alignment modulo 16 as the destination) and the wave then copies the image out with aligned 16-byte stores.
 constexpr uint32_t kFormatLdsBytes = 40u * 1024u;
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
-                                                    const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1) {
+                                                    const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1) {
     __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
     const uint32_t lane = threadIdx.x, seg = blockIdx.y;
     const uint64_t first = (uint64_t)blockIdx.x * 64u;
     if (first >= n_pairs) return;
     const uint64_t *offsets = seg ? offsets1 : offsets0;
     char *dst = seg ? dst1 : dst0;
+    if (offsets[n_pairs] > (seg ? cap1 : cap0)) return;                            // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
     const uint64_t last = first + 64u < n_pairs ? first + 64u : n_pairs;
     const uint64_t g_begin = offsets[first], g_end = offsets[last];
     const uint64_t a_begin = (uint64_t)(uintptr_t)(dst + g_begin);                 // absolute byte address of the range

@@ -5,6 +5,7 @@
 // that the per-lane functions of rsq_core.h / rsq_kernels.h can be checked against the oracle without a GPU.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -52,6 +53,7 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 // --------------------------------------------------------------------------------------- packing (create)
 // LDS budget of one k_fill_reads workgroup (MI355X: 160 KiB per CU, one workgroup per CU)
 constexpr uint32_t kLdsBudgetBytes = 160u * 1024u;
+constexpr uint32_t kLdsRateRows = 8;          // rows of the error-rate margins staged in LDS (97 % of all positions have rate 0)
 
 inline void pack_tables(SimState &s, Uploader &up) {
     const Profile &p = s.prof;
@@ -78,7 +80,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
                 d.off[n] = (uint32_t)pool.size();
                 for (size_t r = 0; r < rows; ++r) {
                     pool.insert(pool.end(), t.dim2[n].begin() + r * d.k, t.dim2[n].begin() + (r + 1) * d.k);
-                    if (kp != d.k) pool.push_back(0.0);
+                    pool.insert(pool.end(), kp - d.k, 0.0);
                 }
             }
             out[i] = d;
@@ -88,8 +90,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     std::vector<DevTable> quality = pack(p.quality), seq_quality = pack(p.seq_quality), base_call = pack(p.base_call), dom_error = pack(p.dom_error),
                           error_rate = pack(p.error_rate), indels = pack(p.indels);
 
-    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): per template segment, descriptors first, then margins 0+1
-    // of the quality tables, then margin 0 of the base-call tables -- as much as fits the budget.
+    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): as much as fits 160 KiB, most valuable first.
     const uint32_t T = p.n_tiles();
     LdsPlan plan{};
     plan.desc_doubles = lds_desc_count(T) * (uint32_t)(sizeof(DevTable) / sizeof(double));
@@ -103,12 +104,42 @@ inline void pack_tables(SimState &s, Uploader &up) {
         need_q = std::max(need_q, q);
         need_b = std::max(need_b, b);
     }
+    uint32_t max_rate_q = 0, max_rate_b = 0;
+    for (const DevTable &d : quality) {
+        plan.slot_q = std::max(plan.slot_q, d.k ? row_stride(d.k) : 0u);
+        if (d.k) max_rate_q = std::max(max_rate_q, d.rows[3]);
+    }
+    for (const DevTable &d : base_call) {
+        plan.slot_b = std::max(plan.slot_b, d.k ? row_stride(d.k) : 0u);
+        if (d.k) max_rate_b = std::max(max_rate_b, d.rows[3]);
+    }
     const uint64_t budget = kLdsBudgetBytes / sizeof(double);
-    plan.stage_desc = plan.desc_doubles <= budget / 4 ? 1u : 0u;
-    plan.stage_quality = plan.stage_desc && plan.desc_doubles + need_q <= budget ? 1u : 0u;
-    plan.stage_base_call = plan.stage_quality && plan.desc_doubles + need_q + need_b <= budget ? 1u : 0u;
-    plan.total_doubles = plan.stage_desc ? plan.desc_doubles : 0u;
-    if (plan.stage_quality) {
+    auto need_rate = [&](uint32_t rows) {
+        return (uint64_t)4 * T * std::max(1u, std::min(rows, max_rate_q)) * plan.slot_q + (uint64_t)20 * T * std::max(1u, std::min(rows, max_rate_b)) * plan.slot_b;
+    };
+    uint32_t allow = ~0u, rate_rows = kLdsRateRows;
+    if (const char *e = getenv("RSQ_FILL_MODE")) allow = (uint32_t)atoi(e);                       // tuning overrides: never stage these,
+    if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
+    uint64_t used = plan.desc_doubles;
+    if (used <= budget / 4 && (allow & kLdsDesc)) plan.mask |= kLdsDesc;
+    if ((plan.mask & kLdsDesc) && (allow & kLdsQuality) && used + need_q <= budget) {
+        plan.mask |= kLdsQuality;
+        used += need_q;
+        const bool want_rate = (allow & kLdsRate) && used + need_rate(1) <= budget;
+        if ((allow & kLdsBaseCall) && used + need_b + (want_rate ? need_rate(1) : 0) <= budget) {
+            plan.mask |= kLdsBaseCall;
+            used += need_b;
+        }
+        if (want_rate) {
+            while (rate_rows > 1 && used + need_rate(rate_rows) > budget) --rate_rows;
+            plan.mask |= kLdsRate;
+            plan.rate_rows_q = std::max(1u, std::min(rate_rows, max_rate_q));
+            plan.rate_rows_b = std::max(1u, std::min(rate_rows, max_rate_b));
+            used += need_rate(rate_rows);
+        }
+    }
+    if (plan.mask & kLdsQuality) {
+        uint32_t end = plan.desc_doubles;
         for (uint32_t seg = 0; seg < 2; ++seg) {
             uint32_t at = plan.desc_doubles;
             for (uint32_t i = 0; i < 4 * T; ++i) {
@@ -117,16 +148,19 @@ inline void pack_tables(SimState &s, Uploader &up) {
                 d.lds_off = at;
                 at += rows_q(d);
             }
-            if (plan.stage_base_call)
+            if (plan.mask & kLdsBaseCall)
                 for (uint32_t i = 0; i < 20 * T; ++i) {
                     DevTable &d = base_call[seg * 20 * T + i];
                     if (!d.k) continue;
                     d.lds_off = at;
                     at += rows_b(d);
                 }
-            plan.total_doubles = std::max(plan.total_doubles, at);
+            end = std::max(end, at);
         }
-    }
+        plan.q3_off = end;
+        plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
+        plan.total_doubles = (plan.mask & kLdsRate) ? plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b : end;
+    } else plan.total_doubles = (plan.mask & kLdsDesc) ? plan.desc_doubles : 0u;
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);
@@ -139,6 +173,21 @@ inline void pack_tables(SimState &s, Uploader &up) {
     pool.push_back(0.0);
     s.dev.pool = up.put(pool);
     s.dev.par0 = up.put(par0);
+}
+
+// the staging combinations k_fill_reads is instantiated for: a forced mode (RSQ_FILL_MODE, tests) is cut down to the nearest one
+constexpr uint32_t kFillMasks[] = {0u,
+                                   kLdsDesc,
+                                   kLdsDesc | kLdsQuality,
+                                   kLdsDesc | kLdsQuality | kLdsBaseCall,
+                                   kLdsDesc | kLdsQuality | kLdsRate,
+                                   kLdsDesc | kLdsQuality | kLdsRate | kLdsBaseCall};
+inline uint32_t effective_fill_mask(uint32_t plan_mask, int forced) {
+    uint32_t m = plan_mask;
+    if (forced >= 0) m &= (uint32_t)forced;
+    if (!(m & kLdsDesc)) return 0;
+    if (!(m & kLdsQuality)) return kLdsDesc;
+    return m & (kLdsDesc | kLdsQuality | kLdsBaseCall | kLdsRate);
 }
 
 inline void pack_profile(SimState &s, Uploader &up) {

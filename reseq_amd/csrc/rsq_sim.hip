@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/reseq_amd.h"
@@ -108,7 +109,8 @@ struct rsq_sim : SimState {
     DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
-    int force_fill_mode = -1;      // RSQ_FILL_MODE=0..3 caps the LDS staging mode (tests run every mode)
+    uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
+    int force_fill_mode = -1;      // RSQ_FILL_MODE=<mask of kLds* bits> restricts the LDS staging (tests run every variant)
 };
 
 namespace rsq {
@@ -199,34 +201,34 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     return RawLayout{s.raw_seq.as<uint8_t>(), s.raw_qual.as<uint8_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), s.read_stride, s.ops_stride};
 }
 
-// k_fill_reads: persistent waves, one workgroup per CU slot; MODE chosen by the LDS plan of pack_tables
-template <int MODE>
-static void launch_fill_mode(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
-    const size_t lds_bytes = MODE > 0 ? (size_t)s.dev.lds.total_doubles * sizeof(double) : 0;
-    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    // workgroups resident per CU: limited by the LDS image (160 KiB) and by 2048 threads
-    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;
+// k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
+template <uint32_t MASK>
+static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+    const LdsPlan &pl = s.dev.lds;
+    const size_t lds_bytes = MASK ? (size_t)pl.total_doubles * sizeof(double) : 0;
+    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
     const uint64_t chunks = (n_pairs + 63) / 64;
     uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(chunks, kFillBlock / 64)));
     blocks = (blocks + 1u) & ~1u;                                   // segments alternate over blockIdx.x
     s.fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL(k_fill_reads<MODE>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
+    hipLaunchKernelGGL(k_fill_reads<MASK>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
                        s.fill_counters.as<uint32_t>());
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
+template <size_t... I>
+static void launch_fill_dispatch(uint32_t mask, rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
+                                 std::index_sequence<I...>) {
+    bool done = false;
+    ((mask == kFillMasks[I] ? (launch_fill_mask<kFillMasks[I]>(s, frags, n_pairs, adapter_first, raw, st), done = true) : false), ...);
+    if (!done) throw Error("no k_fill_reads instantiation for staging mask " + std::to_string(mask));
+}
 static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
-    const LdsPlan &pl = s.dev.lds;
-    const int mode = s.force_fill_mode >= 0 ? std::min(s.force_fill_mode, (int)(pl.stage_desc + pl.stage_quality + pl.stage_base_call))
-                                            : (int)(pl.stage_desc + pl.stage_quality + pl.stage_base_call);
-    switch (mode) {
-    case 0: launch_fill_mode<0>(s, frags, n_pairs, adapter_first, raw, st); break;
-    case 1: launch_fill_mode<1>(s, frags, n_pairs, adapter_first, raw, st); break;
-    case 2: launch_fill_mode<2>(s, frags, n_pairs, adapter_first, raw, st); break;
-    default: launch_fill_mode<3>(s, frags, n_pairs, adapter_first, raw, st); break;
-    }
+    launch_fill_dispatch(effective_fill_mask(s.dev.lds.mask, s.force_fill_mode), s, frags, n_pairs, adapter_first, raw, st,
+                         std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
 }
 
 // reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
@@ -244,21 +246,21 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
     exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
     s.timers["scan"].stop(st);
-    uint64_t tot[2];
-    HIP_CHECK(hipMemcpyAsync(&tot[0], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&tot[1], s.off_r2.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    *r1_len = tot[0];
-    *r2_len = tot[1];
-    if (tot[0] > r1_cap || tot[1] > r2_cap || !r1 || !r2) {
-        g_last_error = "output buffers too small: need " + std::to_string(tot[0]) + " and " + std::to_string(tot[1]) + " bytes";
-        return RSQ_ENOSPC;
-    }
+    // the kernel itself refuses to write past the caller's capacity; the host learns the sizes with the final synchronisation
     s.timers["format_write"].start(st);
-    hipLaunchKernelGGL(k_format_write, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2);
+    hipLaunchKernelGGL(k_format_write, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
+                       (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0));
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&s.mailbox[3], s.off_r2.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    *r1_len = s.mailbox[2];
+    *r2_len = s.mailbox[3];
+    if (*r1_len > r1_cap || *r2_len > r2_cap || !r1 || !r2) {
+        g_last_error = "output buffers too small: need " + std::to_string(*r1_len) + " and " + std::to_string(*r2_len) + " bytes";
+        return RSQ_ENOSPC;
+    }
     return RSQ_OK;
 }
 
@@ -295,9 +297,12 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
         exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
-        HIP_CHECK(hipMemcpyAsync(&total, s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(&n_hits, s.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        s.mailbox[1] = 0;
+        HIP_CHECK(hipMemcpyAsync(&s.mailbox[0], s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&s.mailbox[1], s.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        total = s.mailbox[0];
+        n_hits = (uint32_t)s.mailbox[1];
         if (n_hits <= hit_cap) break;
         if (attempt) throw Error("sieve hit list overflowed twice");
         hit_cap = (uint64_t)n_hits + 65536;                         // every cell was counted: the exact size is known now
@@ -467,6 +472,7 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 8 * sizeof(uint64_t), hipHostMallocDefault));
         if (const char *m = getenv("RSQ_FILL_MODE")) s->force_fill_mode = atoi(m);
         s->prof = p->p;
         pack_tables(*s, s->up);
@@ -478,7 +484,10 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     return rc;
 }
 void rsq_sim_free(rsq_sim *s) {
-    if (s) (void)hipSetDevice(s->device);
+    if (s) {
+        (void)hipSetDevice(s->device);
+        if (s->mailbox) (void)hipHostFree(s->mailbox);
+    }
     delete s;
 }
 

@@ -27,8 +27,8 @@ constexpr uint32_t kSqFragmentLengthBinSize = 10;   // QualityStats.h:15
 enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5 };
 
 // One LogArrayResult<N>: K outcome columns, NM = N-1 conditioning margins.
-// margin n: rows[n] rows of stride kp = (K+1)&~1 doubles at pool[off[n]] (a zero pad column when K is odd, so that
-// rows are 16-byte aligned and can be read two columns at a time); row r = clamp(value - from[n]).
+// margin n: rows[n] rows of stride kp = row_stride(K) doubles at pool[off[n]] (zero pad columns up to whole
+// chunks of column pairs); row r = clamp(value - from[n]).
 // The margins of one table are contiguous in the pool: off[n+1] = off[n] + rows[n]*kp.
 struct DevTable {
     uint32_t k;            // par0_indeces_.size(); 0 = empty table (Draw returns prob_sum 0)
@@ -40,16 +40,29 @@ struct DevTable {
     uint32_t lds_off;      // offset (doubles) of margin 0 in the workgroup's LDS image, kNoLds if the table is not staged
 };
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
-RSQ_HD uint32_t row_stride(uint32_t k) { return (k + 1u) & ~1u; }
+// A draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
+constexpr uint32_t kChunkSmall = 3, kChunkLarge = 4;
+RSQ_HD uint32_t chunk_pairs(uint32_t k) { return k <= 2u * kChunkSmall ? kChunkSmall : kChunkLarge; }
+RSQ_HD uint32_t chunks_of(uint32_t k, uint32_t u) { return (k + 2u * u - 1u) / (2u * u); }
+// Row stride in doubles: whole chunks (zero pad columns, so that the draw needs no masks), even (16-byte rows) and
+// == 2 (mod 4): 2*stride dwords == 4 (mod 8), so that the rows different lanes read in one ds_read_b128 spread over all
+// LDS bank groups.
+RSQ_HD uint32_t row_stride(uint32_t k) {
+    const uint32_t u = chunk_pairs(k), kp = chunks_of(k, u) * 2u * u;
+    return (kp & 2u) ? kp : kp + 2u;
+}
 
-// LDS image of k_fill_reads, one per template segment (DESIGN.md "LDS staging"): the table descriptors of the segment,
-// then margins 0+1 of its quality tables, then margin 0 of its base-call tables.
+// LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup: the table
+// descriptors of the segment, margins 0+1 of its quality tables, margin 0 of its base-call tables, the first rows of the
+// error-rate margins (quality margin 3, base-call margin 3).
+enum : uint32_t { kLdsDesc = 1, kLdsQuality = 2, kLdsBaseCall = 4, kLdsRate = 16 };
 struct LdsPlan {
-    uint32_t stage_quality;      // 1: quality margins 0 and 1 are in LDS
-    uint32_t stage_base_call;    // 1: base-call margin 0 is in LDS
-    uint32_t stage_desc;         // 1: descriptors are in LDS
+    uint32_t mask;               // kLds* bits of what the plan stages
     uint32_t desc_doubles;       // size of the descriptor area (in doubles)
-    uint32_t total_doubles;      // size of the whole image
+    uint32_t slot_q, slot_b;     // row slot (doubles) per quality / base-call table = max row stride of the family
+    uint32_t rate_rows_q, rate_rows_b;   // kLdsRate: rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
+    uint32_t q3_off, b3_off;     // [4T][rate_rows_q] quality slots, [20T][rate_rows_b] base-call slots
+    uint32_t total_doubles;      // size of the image
 };
 
 // Fragment produced by the coverage sieve: one simulated read pair (Simulator.cpp:2249-2357 -> CreateReads).

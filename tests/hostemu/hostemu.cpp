@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <memory>
+#include <utility>
 
 #include "../../reseq_amd/csrc/rsq_pack.h"
 
@@ -31,30 +32,38 @@ struct HostUploader : Uploader {
 
 struct Emu : SimState {
     HostUploader up;
-    int fill_mode = -1;                         // -1: highest mode the LDS plan allows (as the product does); 0..3 caps it
-    std::vector<double> lds[2];                 // host stand-in for the LDS image of each template segment
-    int mode() const {
-        const int plan = (int)(dev.lds.stage_desc + dev.lds.stage_quality + dev.lds.stage_base_call);
-        return fill_mode >= 0 ? std::min(fill_mode, plan) : plan;
-    }
+    int fill_mode = -1;                         // -1: everything the LDS plan allows (as the product does); else a mask of kLds* bits
+    std::vector<double> lds[2];                 // host stand-in for the LDS image of each template segment (+ one wave area)
+    uint32_t mask() const { return effective_fill_mask(dev.lds.mask, fill_mode); }
     void build_lds() {                          // what a workgroup of k_fill_reads does before its first read
         for (uint32_t seg = 0; seg < 2; ++seg) {
             lds[seg].assign(dev.lds.total_doubles + 16, 0.0);
-            if (mode() > 0) lds_stage_descriptors(dev, lds[seg].data(), seg, 0, 1);
-            if (mode() > 1) lds_stage_rows(dev, lds[seg].data(), seg, 0, 1);
+            if (mask()) {
+                lds_stage_descriptors(dev, lds[seg].data(), seg, 0, 1);
+                lds_stage_rows(dev, lds[seg].data(), mask(), 0, 1);
+            }
         }
     }
 };
 
-// dispatch on the staging mode exactly like k_fill_reads<MODE>
-template <class F>
-void with_tables(Emu &s, uint32_t seg, F &&f) {
-    switch (s.mode()) {
-    case 0: f(GlobalTables{s.dev}); break;
-    case 1: f(LdsTables<false, false>{s.dev, s.lds[seg].data(), seg}); break;
-    case 2: f(LdsTables<true, false>{s.dev, s.lds[seg].data(), seg}); break;
-    default: f(LdsTables<true, true>{s.dev, s.lds[seg].data(), seg}); break;
-    }
+// one read through the state machine the way a lane of k_fill_reads<MASK> runs it
+template <uint32_t MASK, class Src>
+void run_lds(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta) {
+    LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{s.dev, s.lds[seg].data(), seg};
+    fill_read(s.dev, tab, st, seg, tile, frag_len, src, out, meta);
+}
+template <class Src, size_t... I>
+void run_read_dispatch(uint32_t mask, Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta,
+                       std::index_sequence<I...>) {
+    bool done = false;
+    ((mask == kFillMasks[I] ? (run_lds<kFillMasks[I]>(s, seg, st, tile, frag_len, src, out, meta), done = true) : false), ...);
+    if (!done) throw Error("no staging combination " + std::to_string(mask));
+}
+template <class Src>
+void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta) {
+    const uint32_t mask = s.mask();
+    if (!mask) fill_read(s.dev, GlobalTables{s.dev}, st, seg, tile, frag_len, src, out, meta);
+    else run_read_dispatch(mask, s, seg, st, tile, frag_len, src, out, meta, std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
 }
 
 thread_local std::string g_err;
@@ -296,10 +305,16 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
             for (uint32_t seg = 0; seg < 2; ++seg) {
                 ReadOut out = raw.out(s);
                 ReadMeta meta;
-                with_tables(s, seg, [&](const auto &tab) {
-                    if (frags) fill_fragment_read(s.dev, tab, frags[pair], seg, out, meta);
-                    else fill_adapter_only_read(s.dev, tab, adapter_first + pair, seg, out, meta);
-                });
+                if (frags) {
+                    const Fragment &f = frags[pair];
+                    const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
+                    run_read(s, seg, Stream{s.dev.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)}, draw_tile(s.dev, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2)),
+                             f.len, fragment_src(s.dev, f, seg), out, meta);
+                } else {
+                    const uint64_t i = adapter_first + pair;
+                    run_read(s, seg, Stream{s.dev.seed, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, seg)},
+                             draw_tile(s.dev, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, 2)), 0u, EmptySrc{}, out, meta);
+                }
                 out.finish();
                 const Fragment *fp = frags ? &frags[pair] : nullptr;
                 const uint32_t need = record_size(s.dev, s.names, fp, adapter_first + pair + 1, meta);      // what k_fill_reads stores in sizes[]

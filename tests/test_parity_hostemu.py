@@ -95,10 +95,18 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(EmuBackend, workdir)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 3, 7, 19])
 def test_every_lds_staging_mode(workdir, mode):
-    """k_fill_reads<MODE>: tables from HBM only / descriptors in LDS / + quality margins (3 = everything is the default above)"""
+    """k_fill_reads<MASK>: tables from HBM only (0), descriptors in LDS (1), + quality margins (3), + base-call margin (7),
+    quality margins + error-rate rows (19); everything the plan allows (23) is the default of the tests above"""
     class Capped(EmuBackend):
         fill_mode = mode
     P.case_sieve_and_reads_tiny(Capped, workdir)
     P.case_p0_reads(Capped, workdir)
+
+
+def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
+    """only row 0 of the error-rate margins staged: every position with a systematic error rate takes the HBM branch"""
+    monkeypatch.setenv("RSQ_RATE_ROWS", "1")
+    P.case_sieve_and_reads_tiny(EmuBackend, workdir)
+    P.case_p0_reads(EmuBackend, workdir)
