@@ -445,6 +445,12 @@ RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
         char element = base;
         uint32_t length = 0;
         for (uint32_t i = 0; i < n; ++i, ++it) {
+            if (!(it & 15u) && i + 16u <= n && element == base && !ops[it >> 4]) {      // 16 plain iterations at once
+                length += 16u;
+                i += 15u;
+                it += 15u;
+                continue;
+            }
             const uint32_t code = (ops[it >> 4] >> ((it & 15u) * 2u)) & 3u;
             const char want = code == 0 ? base : (code == 1 ? 'D' : 'I');
             if (want == element) ++length;
@@ -459,34 +465,106 @@ RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
     if (m.hard_clip) sink.element('H', m.hard_clip);
 }
 
-template <class P>
-struct TextSinkT {                       // appends characters at p (no null check: LDS offset 0 is a valid destination)
-    P p;
-    uint32_t n;
-    RSQ_HD void ch(char c) {
-        p[n] = c;
-        ++n;
-    }
+template <class Derived>
+struct TextOps {                        // what a record is made of, on top of Derived::ch
+    RSQ_HD Derived &self() { return *static_cast<Derived *>(this); }
     RSQ_HD void str(const char *s, uint32_t len) {
-        for (uint32_t i = 0; i < len; ++i) ch(s[i]);
+        for (uint32_t i = 0; i < len; ++i) self().ch(s[i]);
+    }
+    RSQ_HD void num(uint32_t v) {              // 32-bit: division by 10 is a multiply and a shift
+        char tmp[10];
+        int k = 0;
+        do {
+            tmp[k++] = (char)('0' + v % 10u);
+            v /= 10u;
+        } while (v);
+        while (k) self().ch(tmp[--k]);
     }
     RSQ_HD void num(uint64_t v) {
+        if (v <= 0xFFFFFFFFull) return num((uint32_t)v);
         char tmp[20];
         int k = 0;
         do {
             tmp[k++] = (char)('0' + v % 10);
             v /= 10;
         } while (v);
-        while (k) ch(tmp[--k]);
+        while (k) self().ch(tmp[--k]);
     }
     RSQ_HD void element(char op, uint32_t count) {
         num(count);
-        ch(op);
+        self().ch(op);
+    }
+};
+template <class P>
+struct TextSinkT : TextOps<TextSinkT<P>> {      // appends characters at p (no null check: LDS offset 0 is a valid destination)
+    P p;
+    uint32_t n;
+    RSQ_HD TextSinkT(P dst, uint32_t at) : p(dst), n(at) {}
+    RSQ_HD void ch(char c) {
+        p[n] = c;
+        ++n;
     }
 };
 using TextSink = TextSinkT<char *>;
 
+// The same stream written with aligned 4-byte stores: bytes collect in a register and leave a word at a time; only the
+// bytes before the first and after the last aligned word of the destination are stored singly (neighbouring records of
+// other lanes share those words).
+template <class P>
+struct WordPtr {
+    using type = uint32_t *;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+struct WordPtr<RSQ_LDS char *> {
+    using type = RSQ_LDS uint32_t *;
+};
+#endif
+template <class P>
+struct WordSinkT : TextOps<WordSinkT<P>> {
+    P p;                 // next destination byte not yet stored
+    uint64_t acc;        // pending bytes, first in the low byte
+    uint32_t pending, lead, n;
+    RSQ_HD explicit WordSinkT(P dst) : p(dst), acc(0), pending(0), lead((4u - ((uint32_t)(uintptr_t)dst & 3u)) & 3u), n(0) {}
+    RSQ_HD void push(uint32_t bytes, uint32_t count) {       // count <= 4 bytes, first in the low byte, the rest zero
+        acc |= (uint64_t)bytes << (8u * pending);
+        pending += count;
+        n += count;
+        while (lead && pending) {
+            *p = (char)(acc & 0xFFu);
+            p += 1;
+            acc >>= 8;
+            --pending;
+            --lead;
+        }
+        if (!lead && pending >= 4u) {
+            *reinterpret_cast<typename WordPtr<P>::type>(p) = (uint32_t)acc;
+            p += 4;
+            acc >>= 32;
+            pending -= 4u;
+        }
+    }
+    RSQ_HD void ch(char c) { push((uint8_t)c, 1u); }
+    RSQ_HD void finish() {
+        while (pending) {
+            *p = (char)(acc & 0xFFu);
+            p += 1;
+            acc >>= 8;
+            --pending;
+        }
+    }
+};
+
+RSQ_HD uint32_t digits_u32(uint32_t v) {
+    uint32_t n = 1;
+    while (v >= 10u) {
+        v /= 10u;
+        ++n;
+    }
+    return n;
+}
 RSQ_HD uint32_t digits_u64(uint64_t v) {
+    if (v <= 0xFFFFFFFFull) return digits_u32((uint32_t)v);
     uint32_t n = 1;
     while (v >= 10) {
         v /= 10;
@@ -496,11 +574,9 @@ RSQ_HD uint32_t digits_u64(uint64_t v) {
 }
 
 
-// One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632.
-template <class P>
-RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint8_t *seq,
-                              const uint8_t *qual, const uint32_t *ops, P dst) {
-    TextSinkT<P> t{dst, 0};
+// One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632: the id line ...
+template <class Sink>
+RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint32_t *ops, Sink &t) {
     t.ch('@');
     t.str(names.base_identifier, names.base_len);
     if (f) {
@@ -521,23 +597,56 @@ RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fra
         t.str(":0:Adapter:0", 12);
     }
     t.ch(':');
-    t.num(S.tiles[m.tile_id]);
+    t.num((uint32_t)S.tiles[m.tile_id]);
     t.str(":1337:1337 ", 11);
     cigar_replay(ops, m, t);
     t.str(" E", 2);
-    t.num(m.num_errors);
+    t.num((uint32_t)m.num_errors);
     t.ch('\n');
-    const uint32_t *seq4 = reinterpret_cast<const uint32_t *>(seq), *qual4 = reinterpret_cast<const uint32_t *>(qual);   // rows are 4-byte aligned
-    for (uint32_t i = 0; i < m.read_len; i += 4u) {
-        const uint32_t w = seq4[i >> 2];
-        for (uint32_t k = 0; k < 4u && i + k < m.read_len; ++k) t.ch("ACGTN"[(w >> (8u * k)) & 0xFFu]);
+}
+// ... and one of its two data lines: the bases ("SEQ\n+\n", is_qual false) or the qualities ("QUAL\n").  The read kernel
+// leaves both as bytes in 16-byte aligned rows; four base codes become four letters with one byte permute.
+struct alignas(16) Words16 {
+    uint32_t w0, w1, w2, w3;
+};
+RSQ_HD uint32_t base_letters(uint32_t codes) {                       // bytes 0..3 -> "ACGT", 4 -> 'N'
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x54474341u, codes);   // selector 0-3: bytes of "ACGT", 4-7: 'N'
+#else
+    uint32_t out = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t b = (codes >> (8u * k)) & 0xFFu;
+        out |= (uint32_t)("ACGTN"[b < 4u ? b : 4u]) << (8u * k);
     }
-    t.str("\n+\n", 3);
-    for (uint32_t i = 0; i < m.read_len; i += 4u) {
-        const uint32_t w = qual4[i >> 2];
-        for (uint32_t k = 0; k < 4u && i + k < m.read_len; ++k) t.ch((char)((w >> (8u * k)) & 0xFFu));
+    return out;
+#endif
+}
+template <class Sink>
+RSQ_HD void format_line(const uint8_t *row, uint32_t read_len, bool is_qual, Sink &t) {
+    const Words16 *row16 = reinterpret_cast<const Words16 *>(row);
+    for (uint32_t i = 0; i < read_len; i += 16u) {
+        const Words16 v = row16[i >> 4];
+        const uint32_t w[4] = {v.w0, v.w1, v.w2, v.w3};
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t at = i + 4u * k;
+            if (at >= read_len) break;
+            const uint32_t left = read_len - at, text = is_qual ? w[k] : base_letters(w[k]);
+            if (left >= 4u) t.push(text, 4u);
+            else t.push(text & ((1u << (8u * left)) - 1u), left);
+        }
     }
-    t.ch('\n');
+    if (is_qual) t.push('\n', 1u);
+    else t.push('\n' | ('+' << 8) | ('\n' << 16), 3u);
+}
+template <class P>
+RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint8_t *seq,
+                              const uint8_t *qual, const uint32_t *ops, P dst) {
+    WordSinkT<P> t(dst);
+    format_header(S, names, f, adapter_only_number, m, ops, t);
+    format_line(seq, m.read_len, false, t);
+    format_line(qual, m.read_len, true, t);
+    t.finish();
     return t.n;
 }
 
@@ -873,24 +982,27 @@ __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_ind
 #endif  // __HIPCC__
 
 #if defined(__HIPCC__)
-// FASTQ text: one wave per 64 consecutive records of one file (grid.y = template segment = output file).  The 64 records
-// occupy one contiguous byte range of the output, so every lane formats its record into an LDS image of that range (laid out
-// with the same alignment modulo 16 as the destination) and the wave then copies the image out with aligned 16-byte stores.
-constexpr uint32_t kFormatLdsBytes = 40u * 1024u;
+// FASTQ text: one wave per 32 consecutive records of one file (grid.y = template segment = output file).  The records
+// occupy one contiguous byte range of the output, so the wave formats them into an LDS image of that range (laid out with
+// the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Lanes 0-31
+// write the id line and the bases of their record, lanes 32-63 the qualities of the same record; 16 KiB of LDS per wave
+// keep ten waves resident per CU (the kernel is latency-bound: byte stores into LDS).
+constexpr uint32_t kFormatRecords = 32u, kFormatLdsBytes = 16u * 1024u;
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
                                                     const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1) {
     __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
-    const uint32_t lane = threadIdx.x, seg = blockIdx.y;
-    const uint64_t first = (uint64_t)blockIdx.x * 64u;
+    const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u);
+    const bool qual_half = lane >= kFormatRecords;
+    const uint64_t first = (uint64_t)blockIdx.x * kFormatRecords;
     if (first >= n_pairs) return;
     const uint64_t *offsets = seg ? offsets1 : offsets0;
     char *dst = seg ? dst1 : dst0;
     if (offsets[n_pairs] > (seg ? cap1 : cap0)) return;                            // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
-    const uint64_t last = first + 64u < n_pairs ? first + 64u : n_pairs;
+    const uint64_t last = first + kFormatRecords < n_pairs ? first + kFormatRecords : n_pairs;
     const uint64_t g_begin = offsets[first], g_end = offsets[last];
     const uint64_t a_begin = (uint64_t)(uintptr_t)(dst + g_begin);                 // absolute byte address of the range
     const uint32_t skew = (uint32_t)(a_begin & 15u), bytes = (uint32_t)(g_end - g_begin);
-    const uint64_t pair = first + lane;
+    const uint64_t pair = first + rec;
     const bool active = pair < last;
     const bool through_lds = skew + bytes <= kFormatLdsBytes;                      // wave-uniform
     ReadMeta m;
@@ -901,15 +1013,22 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         m = raw.meta[r];
         if (frags) f = frags[pair];
     }
+    const uint8_t *seq = raw.seq + r * raw.read_stride, *qual = raw.qual + r * raw.read_stride;
+    const uint32_t *ops = raw.ops + r * raw.ops_stride;
+    const Fragment *fp = frags ? &f : nullptr;
+    const uint64_t ao_number = adapter_only_first + pair + 1u;
     if (!through_lds) {                                                            // oversized ids: write straight to HBM
-        if (active)
-            format_record(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, m, raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride,
-                          raw.ops + r * raw.ops_stride, dst + offsets[pair]);
+        if (active && !qual_half) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair]);
         return;
     }
-    if (active)
-        format_record(S, names, frags ? &f : nullptr, adapter_only_first + pair + 1u, m, raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride,
-                      raw.ops + r * raw.ops_stride, (RSQ_LDS char *)s_text + skew + (uint32_t)(offsets[pair] - g_begin));
+    if (active) {
+        RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + skew + (uint32_t)(offsets[pair] - g_begin);
+        const uint32_t header = (uint32_t)(offsets[pair + 1u] - offsets[pair]) - 2u * m.read_len - 4u;
+        WordSinkT<RSQ_LDS char *> t(rec_text + (qual_half ? header + m.read_len + 3u : 0u));
+        if (!qual_half) format_header(S, names, fp, ao_number, m, ops, t);
+        format_line(qual_half ? qual : seq, m.read_len, qual_half, t);
+        t.finish();
+    }
     __syncthreads();
     const uint32_t lo = skew, hi = skew + bytes;                                   // LDS byte range holding text
     char *g_chunk0 = dst + g_begin - skew;                                         // 16-byte aligned

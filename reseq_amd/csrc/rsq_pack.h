@@ -256,7 +256,7 @@ inline void pack_profile(SimState &s, Uploader &up) {
     d.dispersion[1] = p.dispersion[1];
 
     s.max_adapter = max_adapter;
-    s.read_stride = (s.rmax + 3u) & ~3u;
+    s.read_stride = (s.rmax + 15u) & ~15u;        // 16-byte rows: k_format_write reads them with 16-byte loads
     const uint32_t max_iter = 2u * s.rmax + p.max_len_deletion + max_adapter + 4u;
     s.ops_stride = (max_iter + 15u) / 16u;
 }

@@ -237,7 +237,7 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     *r1_len = *r2_len = 0;
     if (!n_pairs) return RSQ_OK;
     RawLayout raw = raw_layout(s, 2 * n_pairs);
-    const dim3 grid(cdiv(n_pairs, 64), 2), block(64);
+    const dim3 grid(cdiv(n_pairs, kFormatRecords), 2), block(64);
     s.sizes.reserve(2 * n_pairs * 4 + 16);
     s.off_r1.reserve((n_pairs + 1) * 8);
     s.off_r2.reserve((n_pairs + 1) * 8);

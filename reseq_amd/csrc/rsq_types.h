@@ -41,7 +41,10 @@ struct DevTable {
 };
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 // A draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
-constexpr uint32_t kChunkSmall = 3, kChunkLarge = 4;
+#ifndef RSQ_CHUNK_LARGE
+#define RSQ_CHUNK_LARGE 4
+#endif
+constexpr uint32_t kChunkSmall = 3, kChunkLarge = RSQ_CHUNK_LARGE;
 RSQ_HD uint32_t chunk_pairs(uint32_t k) { return k <= 2u * kChunkSmall ? kChunkSmall : kChunkLarge; }
 RSQ_HD uint32_t chunks_of(uint32_t k, uint32_t u) { return (k + 2u * u - 1u) / (2u * u); }
 // Row stride in doubles: whole chunks (zero pad columns, so that the draw needs no masks), even (16-byte rows) and
