@@ -512,9 +512,9 @@ uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi
                 orc_surrounding_update_forward(codes, L, start, sur_start);
                 uint32_t last_gc = 0, last_gc_end = start;                                                  /* :1696-1697 */
                 for (uint32_t len = frag_len_start; len < to; ++len) {
-                    /* one Philox block serves the two cells (start, 2q) and (start, 2q+1): DESIGN.md "Random streams" */
-                    orc_philox_out w = orc_philox4x32_10(s->seed, start, seq, len >> 1, (uint32_t)ORC_DOM_SIEVE << 28);
-                    double probability_chosen = (len & 1u) ? orc_u53(w.w[2], w.w[3]) : orc_u53(w.w[0], w.w[1]);
+                    /* one Philox block serves the four cells (start, 4q .. 4q+3), one 32-bit uniform each: DESIGN.md "Random streams" */
+                    orc_philox_out w = orc_philox4x32_10(s->seed, start, seq, len >> 2, (uint32_t)ORC_DOM_SIEVE << 28);
+                    double probability_chosen = orc_u32(w.w[len & 3u]);
                     if (!(probability_chosen >= thr[2 * len + 1])) continue;                               /* Simulator.h:418-420 */
                     uint16_t non_zero_strands = orc_binomial(2, 1 - thr[2 * len], probability_chosen);     /* :2307, FDS.cpp:3598 */
                     if (!non_zero_strands) continue;

@@ -190,9 +190,12 @@ struct SieveSite {
     bool have_start;
 };
 
-// Philox block shared by the two cells (start, 2q) and (start, 2q+1)
-RSQ_HD Words sieve_pair_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site.seq, q, kDomSieve << 28); }
-RSQ_HD double sieve_cell_uniform(const Words &w, uint32_t len) { return (len & 1u) ? u53_to_unit(w.w2, w.w3) : u53_to_unit(w.w0, w.w1); }
+// Philox block shared by the four cells (start, 4q .. 4q+3): one 32-bit uniform each
+RSQ_HD Words sieve_quad_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site.seq, q, kDomSieve << 28); }
+RSQ_HD double sieve_cell_uniform(const Words &w, uint32_t len) {
+    const uint32_t k = len & 3u;
+    return u32_to_unit(k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)));
+}
 
 RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, double probability_chosen, uint32_t (&cnt)[2], uint32_t (&strand_of)[2]) {
     cnt[0] = cnt[1] = 0;
@@ -260,21 +263,54 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
 }
 
 #if defined(__HIPCC__)
-// The sieve in two dense phases per wave.  A wave owns kSieveSlotsPerWave consecutive start positions.
-//   screen:  for each of its positions, lanes test the fragment lengths two per Philox block (lane l: lengths 2(q0+l),
-//            2(q0+l)+1, then q0 += 64) against the zero threshold; the rare cells that pass (about 0.2 %) are appended, in
-//            (position, length) order, to the wave's candidate queue in LDS;
-//   finish:  one lane per queued cell runs the expensive part (strand choice, GC percent, surroundings, negative binomial
-//            count) -- full lanes instead of the one or two that a fused loop would keep busy.
+// The sieve in two kernels.
+//   k_sieve_screen: one lane per (start position, 32 fragment lengths): eight Philox blocks, 32 comparisons against the zero
+//            threshold, one bitmap word.  About 0.2 % of the cells pass.  Few registers, full occupancy: the kernel is a
+//            chain of dependent 32-bit multiplies and needs many waves per SIMD to keep the multiplier busy.
+//   k_sieve_finish: a wave owns kSieveSlotsPerWave consecutive start positions, turns their bitmap rows into a candidate
+//            queue in LDS, in (position, length) order, and runs the expensive part (strand choice, GC percent, surroundings,
+//            negative binomial count) one lane per queued cell -- full lanes instead of the one or two that a fused loop
+//            would keep busy.
 // counts[slot] = pairs starting at the position.  Every cell with fragments is appended to `hits` together with the number
 // of pairs that precede it at the same start, so that k_sieve_emit can place its fragments in (length, chosen strand order,
 // duplicate) order -- the order of the reference's loops -- once the exclusive scan of counts is known.
-constexpr uint32_t kSieveSlotsPerWave = 16;
+#ifndef RSQ_SIEVE_SLOTS
+#define RSQ_SIEVE_SLOTS 32
+#endif
+constexpr uint32_t kSieveSlotsPerWave = RSQ_SIEVE_SLOTS;
 constexpr uint32_t kSieveWaves = 4;
-constexpr uint32_t kSieveQueue = 512;                  // candidate capacity per wave; flushed when fewer than 128 slots are left
+constexpr uint32_t kSieveQueue = 2048;                 // candidate capacity per wave = the most one pass over 64 bitmap words can add
+constexpr uint32_t kScreenBlock = 256;
+constexpr uint32_t kSieveLoads = 8;                   // bitmap words a lane of k_sieve_finish has in flight
 
-__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t *counts, SieveHit *hits, uint32_t hit_cap,
-                                                           uint32_t *hit_count) {
+RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 31u) >> 5; }
+
+__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
+    const uint64_t t = (uint64_t)blockIdx.x * kScreenBlock + threadIdx.x;
+    const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
+    if (slot >= n_slots) return;
+    SieveSite site;
+    init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
+    uint32_t bits = 0;
+    if (site.start < site.L) {
+#pragma unroll 2
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t len0 = 32u * wi + 4u * j;
+            if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
+            const Words w = sieve_quad_words(S, site, len0 >> 2);
+            const uint32_t word[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; ++e) {
+                const uint32_t len = len0 + e;
+                if (len >= S.insert_from && len < S.insert_to && u32_to_unit(word[e]) >= site.thr[2u * len + 1u]) bits |= 1u << (4u * j + e);     // Simulator.h:418-420
+            }
+        }
+    }
+    bitmap[t] = bits;
+}
+
+__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, const uint32_t *bitmap,
+                                                                  uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
     __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
     __shared__ uint32_t s_total[kSieveWaves][kSieveSlotsPerWave];  // pairs found so far per position
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -296,7 +332,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve(DevSim S, uint32_t b
                 SieveSite site;
                 const uint32_t slot = slot0 + key;
                 init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
-                n_here = sieve_cell(S, site, len, sieve_cell_uniform(sieve_pair_words(S, site, len >> 1), len), cnt, strand_of);
+                n_here = sieve_cell(S, site, len, sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len), cnt, strand_of);
             }
             // exclusive prefix of n_here among the earlier queued cells of the same position (keys are non-decreasing)
             uint32_t incl = n_here;
@@ -332,30 +368,38 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve(DevSim S, uint32_t b
         n_queued = 0;
     };
 
-    for (uint32_t k = 0; k < kSieveSlotsPerWave; ++k) {
-        const uint32_t slot = slot0 + k;
-        if (slot >= n_slots) break;
-        SieveSite site;
-        init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
-        if (site.start >= site.L) continue;
-        for (uint32_t q0 = S.insert_from >> 1; 2u * q0 < S.insert_to; q0 += 64u) {
-            const uint32_t q = q0 + lane;
-            bool cand[2] = {false, false};
-            if (2u * q < S.insert_to) {
-                const Words w = sieve_pair_words(S, site, q);
-                for (uint32_t e = 0; e < 2u; ++e) {
-                    const uint32_t len = 2u * q + e;
-                    if (len >= S.insert_from && len < S.insert_to) cand[e] = sieve_cell_uniform(w, len) >= site.thr[2u * len + 1u];     // Simulator.h:418-420
-                }
+    // the wave's bitmap rows are one contiguous run of words in (position, length) order; kSieveLoads independent loads per lane
+    // are in flight at a time (the kernel runs one wave per SIMD: a dependent load per pass would cost a round trip each)
+    const uint32_t my_slots = n_slots - slot0 < kSieveSlotsPerWave ? n_slots - slot0 : kSieveSlotsPerWave;
+    const uint32_t n_words = my_slots * words_per_slot;
+    const uint32_t *row = bitmap + (uint64_t)slot0 * words_per_slot;
+    for (uint32_t i0 = 0; i0 < n_words; i0 += 64u * kSieveLoads) {
+        uint32_t bits_of[kSieveLoads];
+#pragma unroll
+        for (uint32_t u = 0; u < kSieveLoads; ++u) {
+            const uint32_t idx = i0 + 64u * u + lane;
+            bits_of[u] = idx < n_words ? row[idx] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kSieveLoads; ++u) {
+            uint32_t bits = bits_of[u];
+            if (!__any(bits != 0u)) continue;
+            const uint32_t idx = i0 + 64u * u + lane, k = idx / words_per_slot, wi = idx - k * words_per_slot;
+            const uint32_t mine = (uint32_t)__popc(bits);
+            uint32_t incl = mine;                                   // candidates of the lanes up to and including this one
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
             }
-            const uint64_t m0 = __ballot(cand[0]), m1 = __ballot(cand[1]);
-            if (m0 | m1) {
-                const uint32_t at = n_queued + (uint32_t)__popcll(m0 & lt_mask) + (uint32_t)__popcll(m1 & lt_mask);
-                if (cand[0]) queue[at] = (k << 16) | (2u * q);
-                if (cand[1]) queue[at + (cand[0] ? 1u : 0u)] = (k << 16) | (2u * q + 1u);
-                n_queued += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
-                if (n_queued > kSieveQueue - 128u) finish();        // an iteration adds at most 128 cells
+            const uint32_t added = __shfl(incl, 63, 64);
+            if (n_queued + added > kSieveQueue) finish();           // one pass adds at most 64*32 = kSieveQueue cells
+            uint32_t at = n_queued + incl - mine;
+            while (bits) {
+                const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+                queue[at++] = (k << 16) | (32u * wi + b);
+                bits &= bits - 1u;
             }
+            n_queued += added;
         }
     }
     finish();

@@ -106,7 +106,7 @@ struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
     // workspace of the hot path (grow-only)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count;
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -282,6 +282,8 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     s.counts.reserve(n_slots * 4 + 16);
     s.offsets.reserve((n_slots + 1) * 8);
     s.hit_count.reserve(8);
+    const uint32_t words_per_slot = sieve_words_per_slot(s.dev.insert_to);
+    s.sieve_bitmap.reserve(n_slots * words_per_slot * 4 + 16);
     // capacity of the hit list: cells with fragments <= pairs; start from the expected share of this block range
     uint64_t hit_cap = std::max<uint64_t>(s.hits.bytes() / sizeof(SieveHit),
                                           (uint64_t)((double)s.total_pairs * (double)(block_hi - block_lo) / (double)s.total_blocks * 1.25) + 65536);
@@ -292,8 +294,14 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         s.hits.reserve(hit_cap * sizeof(SieveHit));
         HIP_CHECK(hipMemsetAsync(s.hit_count.as<uint32_t>(), 0, 4, st));
         s.timers["sieve"].start(st);
-        hipLaunchKernelGGL(k_sieve, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap,
-                           s.hit_count.as<uint32_t>());
+        if (!attempt) {
+            s.timers["sieve_screen"].start(st);
+            hipLaunchKernelGGL(k_sieve_screen, dim3(cdiv(n_slots * words_per_slot, kScreenBlock)), dim3(kScreenBlock), 0, st, s.dev, block_lo, (uint32_t)n_slots,
+                               words_per_slot, s.sieve_bitmap.as<uint32_t>());
+            s.timers["sieve_screen"].stop(st);
+        }
+        hipLaunchKernelGGL(k_sieve_finish, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
+                           s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
         exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);

@@ -279,7 +279,7 @@ int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, 
             if (site.start >= site.L) break;
             for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
                 uint32_t cnt[2], strand_of[2];
-                const Words w = sieve_pair_words(S, site, len >> 1);
+                const Words w = sieve_quad_words(S, site, len >> 2);
                 if (!sieve_cell(S, site, len, sieve_cell_uniform(w, len), cnt, strand_of)) continue;
                 for (uint32_t j = 0; j < 2; ++j)
                     for (uint32_t dup = 0; dup < cnt[j]; ++dup) {
