@@ -392,7 +392,7 @@ struct ReadMachine {
     uint32_t phase, seg, tile_id, tbase;
     uint32_t org_pos, org_len;         // position in / length of the current part's template
     uint32_t adapter_id, adapter_a0;
-    uint32_t iter_m, hard_clip, tail_length, pos_tail;
+    uint32_t iter_m, hard_clip, tail_length, pos_tail, n_indels;
     uint32_t start_cut_word;           // h0.w3, needed only if the read starts inside the adapter
 
     template <class Tab, class Src>
@@ -418,7 +418,7 @@ struct ReadMachine {
         org_pos = 0;
         adapter_id = 0;
         adapter_a0 = 0;
-        iter_m = hard_clip = tail_length = pos_tail = 0;
+        iter_m = hard_clip = tail_length = pos_tail = n_indels = 0;
         const uint32_t seq_length = par.read_length < org_len ? par.read_length : org_len;
         uint32_t mean_error_rate = 0;
         if (seq_length) {                                              // Simulator.cpp:480-504
@@ -491,6 +491,7 @@ struct ReadMachine {
         } else if (1 == indel) {                                   // ErrorStats::kDeletion
             par.error_rate = src.sys(org_pos) >> 8;
             out.op(it, 1u);
+            ++n_indels;
             if ('D' == cg.element) {
                 ++cg.length;
                 ++par.indel_pos;
@@ -510,6 +511,7 @@ struct ReadMachine {
             out.put(par.read_pos, indel - 2u, q + S.phred_offset);
             par.last_written_qual = q;
             out.op(it, 2u);
+            ++n_indels;
             if ('I' == cg.element) {
                 ++cg.length;
                 ++par.indel_pos;
@@ -597,7 +599,8 @@ struct ReadMachine {
         meta.n_iter_s = (uint16_t)(par.iteration - iter_m - hard_clip);   // every tail iteration emits exactly one base
         meta.hard_clip = (uint16_t)hard_clip;
         meta.tile_id = (uint16_t)tile_id;
-        meta.cigar_chars = cg.chars;
+        meta.cigar_chars = (uint16_t)cg.chars;
+        meta.plain = n_indels ? 0u : 1u;
     }
 };
 

@@ -479,9 +479,23 @@ __global__ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *til
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------- FASTQ text
+// The read kernel's per-read word arrays are stored word-major: word w of read r lives at p[w * pitch + r], so the 64 lanes
+// of a wave (64 consecutive reads at the same position) store, and later load, 256 contiguous bytes.  pitch 1 = one read alone.
+struct WordColumn {
+    uint32_t *p;            // word 0 of this read
+    uint64_t pitch;         // reads per word row
+    RSQ_HD uint32_t &at(uint32_t w) const { return p[(uint64_t)w * pitch]; }
+};
+
 // Replays the CIGAR bookkeeping of FillReadPart over the stored 2-bit ops (see fill_read_part in rsq_core.h).
 template <class Sink>
-RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
+RSQ_HD void cigar_replay(const WordColumn &ops, const ReadMeta &m, Sink &sink) {
+    if (m.plain) {                                                  // the common read: no need to touch the ops
+        if (m.n_iter_m) sink.element('M', m.n_iter_m);
+        if (m.n_iter_s) sink.element('S', m.n_iter_s);
+        if (m.hard_clip) sink.element('H', m.hard_clip);
+        return;
+    }
     uint32_t it = 0;
     for (int part = 0; part < 2; ++part) {
         const char base = part ? 'S' : 'M';
@@ -489,13 +503,13 @@ RSQ_HD void cigar_replay(const uint32_t *ops, const ReadMeta &m, Sink &sink) {
         char element = base;
         uint32_t length = 0;
         for (uint32_t i = 0; i < n; ++i, ++it) {
-            if (!(it & 15u) && i + 16u <= n && element == base && !ops[it >> 4]) {      // 16 plain iterations at once
+            if (!(it & 15u) && i + 16u <= n && element == base && !ops.at(it >> 4)) {      // 16 plain iterations at once
                 length += 16u;
                 i += 15u;
                 it += 15u;
                 continue;
             }
-            const uint32_t code = (ops[it >> 4] >> ((it & 15u) * 2u)) & 3u;
+            const uint32_t code = (ops.at(it >> 4) >> ((it & 15u) * 2u)) & 3u;
             const char want = code == 0 ? base : (code == 1 ? 'D' : 'I');
             if (want == element) ++length;
             else {
@@ -620,7 +634,7 @@ RSQ_HD uint32_t digits_u64(uint64_t v) {
 
 // One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632: the id line ...
 template <class Sink>
-RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint32_t *ops, Sink &t) {
+RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t) {
     t.ch('@');
     t.str(names.base_identifier, names.base_len);
     if (f) {
@@ -650,9 +664,6 @@ RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragmen
 }
 // ... and one of its two data lines: the bases ("SEQ\n+\n", is_qual false) or the qualities ("QUAL\n").  The read kernel
 // leaves both as bytes in 16-byte aligned rows; four base codes become four letters with one byte permute.
-struct alignas(16) Words16 {
-    uint32_t w0, w1, w2, w3;
-};
 RSQ_HD uint32_t base_letters(uint32_t codes) {                       // bytes 0..3 -> "ACGT", 4 -> 'N'
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x54474341u, codes);   // selector 0-3: bytes of "ACGT", 4-7: 'N'
@@ -665,27 +676,36 @@ RSQ_HD uint32_t base_letters(uint32_t codes) {                       // bytes 0.
     return out;
 #endif
 }
+// words [first_word, first_word + n_words) of the line, then (with_end) the line end
 template <class Sink>
-RSQ_HD void format_line(const uint8_t *row, uint32_t read_len, bool is_qual, Sink &t) {
-    const Words16 *row16 = reinterpret_cast<const Words16 *>(row);
-    for (uint32_t i = 0; i < read_len; i += 16u) {
-        const Words16 v = row16[i >> 4];
-        const uint32_t w[4] = {v.w0, v.w1, v.w2, v.w3};
+RSQ_HD void format_line_part(const WordColumn &row, uint32_t read_len, bool is_qual, uint32_t first_word, uint32_t n_words, bool with_end, Sink &t) {
+    const uint32_t all_words = (read_len + 3u) >> 2, end_word = first_word + n_words < all_words ? first_word + n_words : all_words;
+    constexpr uint32_t kAhead = 10u;                                 // loads in flight
+    for (uint32_t i = first_word; i < end_word; i += kAhead) {
+        uint32_t w[kAhead];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t at = i + 4u * k;
-            if (at >= read_len) break;
+        for (uint32_t k = 0; k < kAhead; ++k) w[k] = i + k < end_word ? row.at(i + k) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; ++k) {
+            const uint32_t at = 4u * (i + k);
+            if (i + k >= end_word) break;
             const uint32_t left = read_len - at, text = is_qual ? w[k] : base_letters(w[k]);
             if (left >= 4u) t.push(text, 4u);
             else t.push(text & ((1u << (8u * left)) - 1u), left);
         }
     }
-    if (is_qual) t.push('\n', 1u);
-    else t.push('\n' | ('+' << 8) | ('\n' << 16), 3u);
+    if (with_end) {
+        if (is_qual) t.push('\n', 1u);
+        else t.push('\n' | ('+' << 8) | ('\n' << 16), 3u);
+    }
+}
+template <class Sink>
+RSQ_HD void format_line(const WordColumn &row, uint32_t read_len, bool is_qual, Sink &t) {
+    format_line_part(row, read_len, is_qual, 0u, (read_len + 3u) >> 2, true, t);
 }
 template <class P>
-RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const uint8_t *seq,
-                              const uint8_t *qual, const uint32_t *ops, P dst) {
+RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &seq,
+                              const WordColumn &qual, const WordColumn &ops, P dst) {
     WordSinkT<P> t(dst);
     format_header(S, names, f, adapter_only_number, m, ops, t);
     format_line(seq, m.read_len, false, t);
@@ -708,8 +728,7 @@ RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragm
 
 // ------------------------------------------------------------------------------------------------- reads
 struct ReadOut {                        // destination of one lane's read; bases and qualities leave in 4-byte stores
-    uint8_t *seq, *qual;
-    uint32_t *ops;
+    WordColumn seq, qual, ops;
     uint32_t cur_word, cur_index;       // CIGAR ops: 2 bits per iteration, 16 per word
     uint32_t seq_word, qual_word, n_put;
     RSQ_HD void put(uint32_t pos, uint32_t base, uint32_t qual_char) {      // pos runs 0,1,2,... (read_pos)
@@ -718,36 +737,39 @@ struct ReadOut {                        // destination of one lane's read; bases
         qual_word |= qual_char << sh;
         n_put = pos + 1u;
         if ((pos & 3u) == 3u) {
-            *reinterpret_cast<uint32_t *>(seq + (pos & ~3u)) = seq_word;
-            *reinterpret_cast<uint32_t *>(qual + (pos & ~3u)) = qual_word;
+            seq.at(pos >> 2) = seq_word;
+            qual.at(pos >> 2) = qual_word;
             seq_word = qual_word = 0;
         }
     }
     RSQ_HD void op(uint32_t it, uint32_t code) {
         const uint32_t wi = it >> 4;
         if (wi != cur_index) {
-            ops[cur_index] = cur_word;
+            ops.at(cur_index) = cur_word;
             cur_word = 0;
             cur_index = wi;
         }
         cur_word |= code << ((it & 15u) * 2u);
     }
     RSQ_HD void finish() {
-        ops[cur_index] = cur_word;
-        if (n_put & 3u) {                                           // read_stride is a multiple of 4
-            *reinterpret_cast<uint32_t *>(seq + (n_put & ~3u)) = seq_word;
-            *reinterpret_cast<uint32_t *>(qual + (n_put & ~3u)) = qual_word;
+        ops.at(cur_index) = cur_word;
+        if (n_put & 3u) {
+            seq.at(n_put >> 2) = seq_word;
+            qual.at(n_put >> 2) = qual_word;
         }
     }
 };
-RSQ_HD ReadOut make_read_out(uint8_t *seq, uint8_t *qual, uint32_t *ops) { return ReadOut{seq, qual, ops, 0u, 0u, 0u, 0u, 0u}; }
+RSQ_HD ReadOut make_read_out(const WordColumn &seq, const WordColumn &qual, const WordColumn &ops) { return ReadOut{seq, qual, ops, 0u, 0u, 0u, 0u, 0u}; }
 
-struct RawLayout {                      // per-read arrays of the read kernel, read index = segment * n_pairs + pair
-    uint8_t *seq, *qual;
-    uint32_t *ops;
+struct RawLayout {                      // word-major arrays of the read kernel, read index = segment * n_pairs + pair
+    uint32_t *seq, *qual;               // [read_words][pitch]: 4 bases / 4 quality characters per word
+    uint32_t *ops;                      // [ops_words][pitch]: 16 two-bit CIGAR ops per word
     ReadMeta *meta;
-    uint32_t read_stride;               // bytes per read in seq / qual
-    uint32_t ops_stride;                // words per read in ops
+    uint64_t pitch;                     // reads per word row (>= number of reads)
+    RSQ_HD WordColumn seq_of(uint64_t r) const { return WordColumn{seq + r, pitch}; }
+    RSQ_HD WordColumn qual_of(uint64_t r) const { return WordColumn{qual + r, pitch}; }
+    RSQ_HD WordColumn ops_of(uint64_t r) const { return WordColumn{ops + r, pitch}; }
+    RSQ_HD ReadOut out_of(uint64_t r) const { return make_read_out(seq_of(r), qual_of(r), ops_of(r)); }
 };
 
 struct FragmentSrc {                    // template of one mate cut from the 2-bit reference (Reference.cpp:483-496)
@@ -975,7 +997,7 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         const uint64_t pair = first + lane;
         const bool active = pair < n_pairs;
         const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : first);
-        ReadOut out = make_read_out(raw.seq + r * raw.read_stride, raw.qual + r * raw.read_stride, raw.ops + r * raw.ops_stride);
+        ReadOut out = raw.out_of(r);
         Fragment f{};
         if (active && frags) f = frags[pair];
         // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
@@ -1015,7 +1037,7 @@ __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_ind
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
-    ReadOut out = make_read_out(raw.seq + i * raw.read_stride, raw.qual + i * raw.read_stride, raw.ops + i * raw.ops_stride);
+    ReadOut out = raw.out_of(i);
     ReadMeta meta;
     const GlobalTables tab{S};
     fill_record_read(S, tab, first_index + i, segs[i], frag_len[i], src, out, meta);
@@ -1026,17 +1048,18 @@ __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_ind
 #endif  // __HIPCC__
 
 #if defined(__HIPCC__)
-// FASTQ text: one wave per 32 consecutive records of one file (grid.y = template segment = output file).  The records
+// FASTQ text: one wave per 16 consecutive records of one file (grid.y = template segment = output file).  The records
 // occupy one contiguous byte range of the output, so the wave formats them into an LDS image of that range (laid out with
-// the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Lanes 0-31
-// write the id line and the bases of their record, lanes 32-63 the qualities of the same record; 16 KiB of LDS per wave
-// keep ten waves resident per CU (the kernel is latency-bound: byte stores into LDS).
-constexpr uint32_t kFormatRecords = 32u, kFormatLdsBytes = 16u * 1024u;
+// the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Four lanes
+// share a record: lanes 0-15 write the id line and the first half of the bases, lanes 16-31 the second half, lanes 32-47 and
+// 48-63 the two halves of the qualities.  The kernel is latency-bound (dependent byte pushes, four load round trips), so
+// short per-lane work and 8 KiB of LDS per wave (twenty waves per CU) matter more than instruction count.
+constexpr uint32_t kFormatRecords = 16u, kFormatLdsBytes = 8u * 1024u;
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
                                                     const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1) {
     __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
-    const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u);
-    const bool qual_half = lane >= kFormatRecords;
+    const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords;
+    const bool is_qual = part >= 2u, second_half = (part & 1u) != 0u;
     const uint64_t first = (uint64_t)blockIdx.x * kFormatRecords;
     if (first >= n_pairs) return;
     const uint64_t *offsets = seg ? offsets1 : offsets0;
@@ -1057,20 +1080,22 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         m = raw.meta[r];
         if (frags) f = frags[pair];
     }
-    const uint8_t *seq = raw.seq + r * raw.read_stride, *qual = raw.qual + r * raw.read_stride;
-    const uint32_t *ops = raw.ops + r * raw.ops_stride;
+    const WordColumn seq = raw.seq_of(r), qual = raw.qual_of(r), ops = raw.ops_of(r);
     const Fragment *fp = frags ? &f : nullptr;
     const uint64_t ao_number = adapter_only_first + pair + 1u;
     if (!through_lds) {                                                            // oversized ids: write straight to HBM
-        if (active && !qual_half) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair]);
+        if (active && part == 0u) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair]);
         return;
     }
     if (active) {
         RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + skew + (uint32_t)(offsets[pair] - g_begin);
         const uint32_t header = (uint32_t)(offsets[pair + 1u] - offsets[pair]) - 2u * m.read_len - 4u;
-        WordSinkT<RSQ_LDS char *> t(rec_text + (qual_half ? header + m.read_len + 3u : 0u));
-        if (!qual_half) format_header(S, names, fp, ao_number, m, ops, t);
-        format_line(qual_half ? qual : seq, m.read_len, qual_half, t);
+        const uint32_t all_words = (m.read_len + 3u) >> 2, half = (all_words + 1u) >> 1;      // the first half ends on a word boundary
+        const uint32_t first_word = second_half ? half : 0u, line_at = header + (is_qual ? m.read_len + 3u : 0u);
+        const uint32_t part_at = part == 0u ? 0u : line_at + (4u * first_word < m.read_len ? 4u * first_word : m.read_len);
+        WordSinkT<RSQ_LDS char *> t(rec_text + part_at);
+        if (part == 0u) format_header(S, names, fp, ao_number, m, ops, t);
+        format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, second_half ? all_words - half : half, second_half, t);
         t.finish();
     }
     __syncthreads();

@@ -194,11 +194,12 @@ static void exclusive_scan(rsq_sim &s, const uint32_t *in, uint64_t n, uint64_t 
 }
 
 static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
-    s.raw_seq.reserve(n_reads * s.read_stride + 16);
-    s.raw_qual.reserve(n_reads * s.read_stride + 16);
-    s.raw_ops.reserve(n_reads * s.ops_stride * 4 + 16);
+    const uint64_t pitch = (n_reads + 63u) & ~(uint64_t)63u;            // word rows start on 256-byte boundaries
+    s.raw_seq.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
+    s.raw_qual.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
+    s.raw_ops.reserve((uint64_t)s.ops_stride * pitch * 4 + 16);
     s.raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
-    return RawLayout{s.raw_seq.as<uint8_t>(), s.raw_qual.as<uint8_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), s.read_stride, s.ops_stride};
+    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch};
 }
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
@@ -344,8 +345,8 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
     tile_out[i] = m.tile_id;
     const uint32_t nb = m.read_len < out_stride ? m.read_len : out_stride;
     for (uint32_t k = 0; k < nb; ++k) {
-        seq_out[i * out_stride + k] = raw.seq[i * raw.read_stride + k];
-        qual_out[i * out_stride + k] = raw.qual[i * raw.read_stride + k];
+        seq_out[i * out_stride + k] = (uint8_t)(raw.seq_of(i).at(k >> 2) >> (8u * (k & 3u)));
+        qual_out[i * out_stride + k] = (uint8_t)(raw.qual_of(i).at(k >> 2) >> (8u * (k & 3u)));
     }
     if (m.cigar_chars + 1u > cigar_stride || m.read_len > out_stride) {
         *overflow = 1;
@@ -353,7 +354,7 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
         return;
     }
     TextSink t{cigar_out + i * cigar_stride, 0};
-    cigar_replay(raw.ops + i * raw.ops_stride, m, t);
+    cigar_replay(raw.ops_of(i), m, t);
     t.ch(0);
 }
 

@@ -88,7 +88,8 @@ struct ReadMeta {
     uint16_t n_iter_s;     // iterations spent in the adapter ('S') part
     uint16_t hard_clip;    // length of the 'H' element (poly-A tail + overrun bases)
     uint16_t tile_id;
-    uint32_t cigar_chars;  // length of the CIGAR string
+    uint16_t cigar_chars;  // length of the CIGAR string
+    uint16_t plain;        // 1: no insertion or deletion anywhere, the CIGAR follows from the counts above without the stored ops
 };
 
 struct DevAdapters {

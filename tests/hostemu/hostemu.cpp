@@ -157,14 +157,16 @@ uint32_t run_chains(Emu &s, bool with_reference) {
     return pass + 1;
 }
 
-struct Raw {
-    std::vector<uint8_t> seq, qual;
-    std::vector<uint32_t> ops;
+struct Raw {                              // one read alone: word columns of pitch 1
+    std::vector<uint32_t> seq, qual, ops;
+    WordColumn seq_col() { return WordColumn{seq.data(), 1}; }
+    WordColumn qual_col() { return WordColumn{qual.data(), 1}; }
+    WordColumn ops_col() { return WordColumn{ops.data(), 1}; }
     ReadOut out(const Emu &s) {
-        seq.assign(s.read_stride + 8, 0);
-        qual.assign(s.read_stride + 8, 0);
+        seq.assign(s.read_stride / 4 + 2, 0);
+        qual.assign(s.read_stride / 4 + 2, 0);
         ops.assign(s.ops_stride + 64, 0);
-        return make_read_out(seq.data(), qual.data(), ops.data());
+        return make_read_out(seq_col(), qual_col(), ops_col());
     }
 };
 
@@ -319,7 +321,7 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 const Fragment *fp = frags ? &frags[pair] : nullptr;
                 const uint32_t need = record_size(s.dev, s.names, fp, adapter_first + pair + 1, meta);      // what k_fill_reads stores in sizes[]
                 if (pos[seg] + need > cap[seg]) throw Error("text buffer too small");
-                const uint32_t wrote = format_record(s.dev, s.names, fp, adapter_first + pair + 1, meta, raw.seq.data(), raw.qual.data(), raw.ops.data(), dst[seg] + pos[seg]);
+                const uint32_t wrote = format_record(s.dev, s.names, fp, adapter_first + pair + 1, meta, raw.seq_col(), raw.qual_col(), raw.ops_col(), dst[seg] + pos[seg]);
                 if (wrote != need) throw Error("record_size disagrees with format_record");
                 pos[seg] += need;
             }
@@ -349,7 +351,7 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
             memcpy(seq_out + i * out_stride, raw.seq.data(), m.read_len);
             memcpy(qual_out + i * out_stride, raw.qual.data(), m.read_len);
             TextSink t{cigar_out + i * cigar_stride, 0};
-            cigar_replay(raw.ops.data(), m, t);
+            cigar_replay(raw.ops_col(), m, t);
             if (t.n != m.cigar_chars) throw Error("cigar_chars disagrees with the replayed CIGAR");
             t.ch(0);
         }
