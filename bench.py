@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from reseq_amd import api, synth  # noqa: E402
+from reseq_amd import api, sharding, synth  # noqa: E402
 
 GENOME = 4_641_652
 PAIRS = 10_000_000
@@ -54,6 +54,21 @@ def cpu_baseline(profile_path, seqs, seed, sample_bp=100_000):
     ref.close()
     prof.close()
     return out
+
+
+def measured_traffic():
+    """HBM bytes per k_fill_reads launch from the PMC passes of profiles/collect.sh (FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md, plus WRITE_SIZE): counters cannot be read from inside an un-profiled run, so the
+    figure of the newest committed collection is reported together with its file name."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def main():
@@ -135,22 +150,15 @@ def main():
         fill_ms += f
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_emit", "fill_reads", "format_write", "scan")}
+    kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([pairs, nbytes], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_pairs, total_bytes = float(c[0].item()), float(c[1].item())
-    else:
-        total_pairs, total_bytes = float(pairs), float(nbytes)
+    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
 
     if rank == 0:
         launches = args.steps * len(batches)
         avg_fill_s = fill_ms / 1e3 / launches
         achieved = A_PAIR * (pairs / launches) / avg_fill_s / 1e9          # GB/s of algorithmic traffic in the dominant kernel
+        traffic, traffic_source = measured_traffic()
         out = {
             "metric": "simulated read-pairs/sec (2x150 bp)", "value": total_pairs / elapsed, "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -160,7 +168,7 @@ def main():
                        "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps, "batch_blocks": args.batch_blocks,
                        "sharding": "one reference shard per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches, "avg_launch_ms": avg_fill_s * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": A_PAIR * (pairs / launches), "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches, "avg_launch_ms": avg_fill_s * 1e3,
                          "note": "table-lookup + RNG bound, not HBM bound: 1.4 KB of algorithmic HBM traffic per pair (DESIGN.md)"},
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,

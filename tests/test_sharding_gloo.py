@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two processes over gloo, each simulating its block range with the host emulation of the
+kernels; the concatenated shards must equal the single-rank output byte for byte, and the job totals must add up."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+from reseq_amd import sharding
+
+HERE = pathlib.Path(__file__).resolve().parent
+
+
+def test_partition_covers_every_block_once():
+    for total, world in ((1, 1), (7, 2), (8, 3), (5, 8), (1000, 8)):
+        parts = sharding.partition_blocks(total, world)
+        assert len(parts) == world and parts[0][0] == 1 and parts[-1][1] == total + 1
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert all(lo <= hi for lo, hi in parts)
+    # balanced by weight: the heavy first block gets a rank of its own
+    assert sharding.partition_blocks(4, 2, [10, 1, 1, 1])[0] == (1, 2)
+    assert sharding.batches(3, 10, 4) == [(3, 7), (7, 10)]
+
+
+WORKER = r"""
+import os, sys, pathlib, time
+sys.path.insert(0, os.environ["RSQ_TESTS"]); sys.path.insert(0, os.environ["RSQ_ROOT"])
+import torch, torch.distributed as dist
+import parity_cases as P
+from backends import EmuBackend
+from reseq_amd import sharding, synth
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["RSQ_PORT"], rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+work = pathlib.Path(os.environ["RSQ_WORK"]) / f"rank{rank}"
+work.mkdir(parents=True, exist_ok=True)
+p = P.Pair(EmuBackend, work, "shard", synth.TINY, [5000, 80, 3210], seed=7, num_pairs=3000)
+p.align_normalization()
+tb = p.info["total_blocks"]
+def pairs_fn(lo, hi):
+    fr, a, b = p.b.pairs(lo, hi)
+    return len(fr), a, b
+t0 = time.perf_counter()
+mine = sharding.partition_blocks(tb, world)[rank]
+n, r1, r2 = sharding.simulate_shard(pairs_fn, mine, batch_blocks=2)
+tot_pairs, tot_bytes, max_t = sharding.job_totals(dist, "cpu", n, len(r1) + len(r2), time.perf_counter() - t0)
+shards = [None] * world
+dist.all_gather_object(shards, (n, r1, r2))
+if rank == 0:
+    n_all, w1, w2 = sharding.simulate_shard(pairs_fn, (1, tb + 1), batch_blocks=tb)
+    assert sum(s[0] for s in shards) == n_all == int(tot_pairs), (n_all, tot_pairs)
+    assert b"".join(s[1] for s in shards) == w1
+    assert b"".join(s[2] for s in shards) == w2
+    assert int(tot_bytes) == len(w1) + len(w2) and max_t > 0
+    assert all(s[0] > 0 for s in shards), "both ranks must have work in this case"
+    o1, o2 = p.osim.create_reads(p.osim.sieve(1, tb + 1))          # and the whole equals the oracle
+    assert o1 == w1 and o2 == w2
+    print("SHARDING_OK", n_all)
+p.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_over_gloo_reproduce_the_single_rank_output(workdir):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RSQ_TESTS=str(HERE), RSQ_ROOT=str(HERE.parent), RSQ_WORK=str(workdir), RSQ_PORT=str(port), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=550) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-3000:]
+    assert b"SHARDING_OK" in outs[0][0]
