@@ -71,8 +71,13 @@ void rsq_sim_free(rsq_sim *s);
  * number of pairs (num_read_pairs, or coverage, or the profile's corrected coverage when both are 0), adapter-only
  * share, CalculateBiasNormalization, systematic errors of adapters and of both strands of every sequence.
  * With ref == NULL only the adapter part runs (Simulator::SimulateErrorModelOnly, :2951-2977).
- * ref_bias_mode: 0 = keep (falls back to 1 when the counts differ), 1 = no bias (FragmentDistributionStats.cpp:3352). */
+ * ref_bias_mode = RefSeqBiasSimulation (FragmentDistributionStats.cpp:3352-3500): 0 keep (falls back to 1 when the counts differ),
+ * 1 no bias, 2 draw with replacement from the stored biases, 3 read the file given to rsq_sim_set_ref_bias_file. */
 int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier, void *stream);
+
+/* --refBiasFile: lines "identifier bias" (UpdateRefSeqBias kFile, FragmentDistributionStats.cpp:3386-3495); call before rsq_sim_prepare */
+int rsq_sim_set_ref_bias_file(rsq_sim *s, const char *path);
+int rsq_sim_get_ref_seq_bias(const rsq_sim *s, double *out, size_t n);          /* [n_sequences], after prepare */
 
 typedef struct {
     uint64_t total_pairs;           /* total_pairs_ after removing the adapter-only pairs */
@@ -91,6 +96,14 @@ int rsq_sim_get_norm_by_len(const rsq_sim *s, double *out, size_t n);          /
 int rsq_sim_set_normalization(rsq_sim *s, double bias_normalization, const double *thresholds, size_t n);
 int rsq_sim_get_sys_errors(const rsq_sim *s, int reverse_strand, uint32_t seq, uint8_t *dom_out, uint8_t *rate_out, uint32_t len);
 int rsq_sim_get_adapter_sys_errors(const rsq_sim *s, int template_segment, uint32_t adapter, uint8_t *dom_out, uint8_t *rate_out, uint32_t len);
+
+/* Simulator::CreateSystematicErrorProfile (--writeSysError, reseq/Simulator.cpp:2597-2653): draws both strands of every sequence and
+ * writes them as FASTQ (two records per sequence, "<id> reverse" first; seq = dominant error, qual = error percent, :2562-2588).
+ * Needs no rsq_sim_prepare and invalidates an earlier one. */
+int rsq_sim_create_sys_error_profile(rsq_sim *s, uint64_t seed, const char *path, void *stream);
+/* --readSysError (LoadSysErrorRecord reseq/Simulator.cpp:750-769, ReadSystematicErrors Simulator.h:326-335): after rsq_sim_prepare,
+ * replaces the drawn tracks of the reference strands by the file's; RSQ_EINVAL with the reference's message on a length mismatch. */
+int rsq_sim_read_sys_errors(rsq_sim *s, const char *path);
 
 /* One simulated fragment = one read pair (SimulateFromGivenBlock, reseq/Simulator.cpp:2249-2357). */
 typedef struct {

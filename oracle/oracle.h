@@ -200,6 +200,7 @@ typedef struct {
     uint32_t *len;
     uint8_t **codes;          /* A=0,C=1,G=2,T=3 (N=4 only before replace_n) */
     char **first_name;        /* ReferenceIdFirstPart (Reference.cpp:476-480) */
+    char **full_name;         /* ReferenceId */
 } orc_reference;
 
 orc_reference *orc_reference_new(uint32_t n_seqs);
@@ -249,7 +250,17 @@ typedef struct orc_sim {
 /* Simulator.cpp:2655-2898 up to "Starting read generation": pairs, thresholds, sys errors */
 orc_sim *orc_sim_new(const orc_profile *p, const orc_reference *r, uint64_t seed, uint64_t num_read_pairs, double coverage,
                      const char *record_base_identifier);
+/* the same with RefSeqBiasSimulation: 0 keep, 1 no, 2 draw, 3 file (FragmentDistributionStats.cpp:3352-3500); NULL + message in
+ * err on a bias-file error */
+orc_sim *orc_sim_new_bias(const orc_profile *p, const orc_reference *r, uint64_t seed, uint64_t num_read_pairs, double coverage,
+                          const char *record_base_identifier, int ref_bias_mode, const char *ref_bias_file, char *err, size_t err_cap);
+const double *orc_sim_ref_seq_bias(const orc_sim *s);
 void orc_sim_free(orc_sim *s);
+
+/* Simulator::CreateSystematicErrorProfile + WriteOutSystematicErrorProfile (Simulator.cpp:2562-2653): FASTQ text, two records per
+ * sequence ("<id> reverse" first).  sys_gc_range_ has the value Simulate() would set (the reference leaves it uninitialised here). */
+uint8_t orc_compress_sys_error_rate(uint8_t percent);              /* Simulator.cpp:2569-2574 */
+uint8_t orc_expand_sys_error_rate(uint8_t stored);                 /* Simulator.h:329-332 */
 /* replace the pre-pass results by externally supplied ones (stage-wise parity tests) */
 void orc_sim_set_normalization(orc_sim *s, double bias_normalization, const double *thresholds /*[n_groups][insert_to][2]*/);
 
@@ -288,6 +299,9 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
 /* Simulator.cpp:2359-2382 */
 int orc_simulate_adapter_only_pairs(const orc_sim *s, orc_text *r1, orc_text *r2);
 void orc_text_free(orc_text *t);
+int orc_create_sys_error_profile(const orc_profile *p, const orc_reference *r, uint64_t seed, orc_text *out);
+/* --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335); 0 or -1 with a message */
+int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err, size_t err_cap);
 
 /* Simulator.cpp:2403-2512 with the header already parsed: records as arrays. */
 int orc_error_model_only(const orc_profile *p, uint64_t seed, uint64_t first_index, uint64_t n, uint32_t read_len,

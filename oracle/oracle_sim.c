@@ -6,6 +6,8 @@
  * Variants, methylation and exclusion regions are not restated (SURVEY.md
  * section 8 rows a16/a17 are "next").
  */
+#define _POSIX_C_SOURCE 200809L      /* getline, ssize_t */
+#include <sys/types.h>
 #include "oracle.h"
 
 #include <math.h>
@@ -43,6 +45,7 @@ orc_reference *orc_reference_new(uint32_t n_seqs) {
     r->len = calloc(n_seqs ? n_seqs : 1, sizeof(uint32_t));
     r->codes = calloc(n_seqs ? n_seqs : 1, sizeof(uint8_t *));
     r->first_name = calloc(n_seqs ? n_seqs : 1, sizeof(char *));
+    r->full_name = calloc(n_seqs ? n_seqs : 1, sizeof(char *));
     return r;
 }
 void orc_reference_set(orc_reference *r, uint32_t i, const char *name, const uint8_t *codes, uint32_t len) {
@@ -54,15 +57,19 @@ void orc_reference_set(orc_reference *r, uint32_t i, const char *name, const uin
     r->first_name[i] = malloc(n + 1);
     memcpy(r->first_name[i], name, n);
     r->first_name[i][n] = 0;
+    r->full_name[i] = malloc(strlen(name) + 1);
+    strcpy(r->full_name[i], name);
 }
 void orc_reference_free(orc_reference *r) {
     if (!r) return;
     for (uint32_t i = 0; i < r->n_seqs; ++i) {
         free(r->codes[i]);
         free(r->first_name[i]);
+        free(r->full_name[i]);
     }
     free(r->codes);
     free(r->first_name);
+    free(r->full_name);
     free(r->len);
     free(r);
 }
@@ -386,8 +393,15 @@ static void adapter_sys_errors(orc_sim *s, uint8_t *dom_state) {
     }
 }
 
+static int read_ref_bias_file(const char *path, const orc_reference *r, double *bias, char *err, size_t err_cap);
+
 orc_sim *orc_sim_new(const orc_profile *p, const orc_reference *r, uint64_t seed, uint64_t num_read_pairs, double coverage,
                      const char *record_base_identifier) {
+    return orc_sim_new_bias(p, r, seed, num_read_pairs, coverage, record_base_identifier, 0, NULL, NULL, 0);
+}
+
+orc_sim *orc_sim_new_bias(const orc_profile *p, const orc_reference *r, uint64_t seed, uint64_t num_read_pairs, double coverage,
+                          const char *record_base_identifier, int ref_bias_mode, const char *ref_bias_file, char *err, size_t err_cap) {
     orc_sim *s = calloc(1, sizeof *s);
     s->p = p;
     s->r = r;
@@ -422,9 +436,24 @@ orc_sim *orc_sim_new(const orc_profile *p, const orc_reference *r, uint64_t seed
         (uint64_t)round((double)s->total_pairs * vect_u64_at(&p->insert_lengths, 0) / (p->total_number_reads / 2));   /* :2739 */
     s->total_pairs -= s->num_adapter_only_pairs;
 
-    /* UpdateRefSeqBias kKeep/kNo (FragmentDistributionStats.cpp:3352-3364) */
-    s->ref_seq_bias = calloc(r->n_seqs, sizeof(double));
-    for (uint32_t i = 0; i < r->n_seqs; ++i) s->ref_seq_bias[i] = (p->n_ref_bias == r->n_seqs) ? p->ref_seq_bias[i] : 1.0;
+    /* UpdateRefSeqBias (FragmentDistributionStats.cpp:3352-3500) */
+    s->ref_seq_bias = calloc(r->n_seqs ? r->n_seqs : 1, sizeof(double));
+    for (uint32_t i = 0; i < r->n_seqs; ++i) s->ref_seq_bias[i] = 1.0;                       /* kNo, and kKeep's fallback */
+    if (0 == ref_bias_mode) {                                                                  /* kKeep :3354-3360 */
+        if (p->n_ref_bias == r->n_seqs)
+            for (uint32_t i = 0; i < r->n_seqs; ++i) s->ref_seq_bias[i] = p->ref_seq_bias[i];
+    } else if (2 == ref_bias_mode) {                                                           /* kDraw :3365-3384, with replacement; Philox domain 6 */
+        for (uint32_t i = 0; i < r->n_seqs; ++i) {
+            uint32_t k = (uint32_t)(orc_u32(orc_philox4x32_10(seed, i, 0, 0, 6u << 28).w[0]) * (double)p->n_ref_bias);
+            s->ref_seq_bias[i] = p->ref_seq_bias[k < p->n_ref_bias ? k : p->n_ref_bias - 1];
+        }
+    } else if (3 == ref_bias_mode) {                                                           /* kFile :3386-3495 */
+        if (read_ref_bias_file(ref_bias_file, r, s->ref_seq_bias, err, err_cap)) {
+            free(s->ref_seq_bias);
+            free(s);
+            return NULL;
+        }
+    }
 
     s->insert_to = (uint32_t)(p->insert_lengths.from + p->insert_lengths.size);
     s->coverage_groups = calloc(r->n_seqs, sizeof(uint32_t));
@@ -898,4 +927,168 @@ const orc_table *orc_profile_table(const orc_profile *p, int family, uint32_t a,
     case 4: return &p->error_rate[a][b];
     default: return &p->indels[a][b];
     }
+}
+
+const double *orc_sim_ref_seq_bias(const orc_sim *s) { return s->ref_seq_bias; }
+
+/* UpdateRefSeqBias kFile (FragmentDistributionStats.cpp:3386-3495): one line per sequence "[>]identifier[ description]<sep>bias", the
+ * bias is what follows the last blank or tab, the identifier ends at the first blank (or at that separator); at most one empty line,
+ * at the end; every sequence of the reference must be found. */
+static int read_ref_bias_file(const char *path, const orc_reference *r, double *bias, char *err, size_t err_cap) {
+    FILE *f = path ? fopen(path, "rb") : NULL;
+    if (!f) {
+        if (err) snprintf(err, err_cap, "Unable to open reference bias file %s", path ? path : "(null)");
+        return -1;
+    }
+    uint8_t *found = calloc(r->n_seqs ? r->n_seqs : 1, 1);
+    for (uint32_t i = 0; i < r->n_seqs; ++i) bias[i] = 0.0;
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t n;
+    uint32_t nline = 0, errors = 0;
+    int empty_line = 0;
+    while ((n = getline(&line, &cap, f)) >= 0) {
+        if (n && line[n - 1] == '\n') line[--n] = 0;
+        if (empty_line) {
+            ++errors;
+            continue;
+        }
+        ++nline;
+        if (0 == n) {
+            empty_line = 1;
+            continue;
+        }
+        ssize_t sep = -1;
+        for (ssize_t k = n; k--;)
+            if (line[k] == ' ' || line[k] == '\t') {
+                sep = k;
+                break;
+            }
+        if (sep < 0) {
+            ++errors;
+            continue;
+        }
+        char *end = NULL;
+        double b = strtod(line + sep + 1, &end);
+        if (end == line + sep + 1) {                                  /* stod throws: counted, bias 0 */
+            ++errors;
+            b = 0.0;
+        }
+        if (0.0 > b) ++errors;
+        ssize_t id_len = -1;
+        for (ssize_t k = 0; k < n; ++k)
+            if (line[k] == ' ') {
+                id_len = k;
+                break;
+            }
+        if (id_len < 0) id_len = sep;
+        ssize_t id_start = 0;
+        if ('>' == line[0]) {
+            ++id_start;
+            --id_len;
+        }
+        for (uint32_t i = 0; i < r->n_seqs; ++i)                        /* unordered_map::emplace keeps the first of equal ids */
+            if (strlen(r->first_name[i]) == (size_t)id_len && 0 == strncmp(r->first_name[i], line + id_start, (size_t)id_len)) {
+                bias[i] = b;
+                found[i] = 1;
+                break;
+            }
+    }
+    free(line);
+    fclose(f);
+    for (uint32_t i = 0; i < r->n_seqs; ++i)
+        if (!found[i]) ++errors;
+    free(found);
+    if (errors) {
+        if (err) snprintf(err, err_cap, "reference bias file %s: %u errors", path, errors);
+        return -1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------ systematic-error profile */
+uint8_t orc_compress_sys_error_rate(uint8_t q_perc) {                /* Simulator.cpp:2569-2574 */
+    if (86 < q_perc) q_perc -= (q_perc - 85) / 2;
+    return q_perc;
+}
+uint8_t orc_expand_sys_error_rate(uint8_t error_rate) {               /* Simulator.h:329-332 */
+    if (86 < error_rate) error_rate += error_rate - 86;
+    return error_rate;
+}
+
+int orc_create_sys_error_profile(const orc_profile *p, const orc_reference *r, uint64_t seed, orc_text *out) {
+    static const char kBases[] = "ACGTN";
+    uint64_t reads = 0, sum_read_length = 0;                           /* sys_gc_range_ as Simulate sets it (Simulator.cpp:2713-2721,2782) */
+    for (int seg = 2; seg--;)
+        for (uint64_t len = p->read_lengths[seg].from; len < p->read_lengths[seg].from + p->read_lengths[seg].size; ++len) {
+            reads += vect_u64_at(&p->read_lengths[seg], len);
+            sum_read_length += vect_u64_at(&p->read_lengths[seg], len) * len;
+        }
+    if (!reads) return -1;
+    uint16_t gc_range = (uint16_t)(((sum_read_length + reads / 2) / reads) / 2);
+    uint8_t dom_state = 0;                                              /* a fresh Simulator: DominantBase() */
+    for (uint32_t i = 0; i < r->n_seqs; ++i) {                          /* :2628-2646 every sequence, reverse strand first */
+        uint32_t L = r->len[i];
+        uint8_t *dom = malloc(L ? L : 1), *rate = malloc(L ? L : 1);
+        for (int strand = 2; strand--;) {
+            orc_systematic_errors(p, seed, i, (uint32_t)strand, r->codes[i], L, strand, gc_range, &dom_state, dom, rate);
+            const char *label = strand ? " reverse" : " forward";
+            size_t idl = strlen(r->full_name[i]) + strlen(label);
+            text_reserve(out, idl + 2u * (size_t)L + 8);
+            out->data[out->len++] = '@';
+            memcpy(out->data + out->len, r->full_name[i], strlen(r->full_name[i]));
+            memcpy(out->data + out->len + strlen(r->full_name[i]), label, strlen(label));
+            out->len += idl;
+            out->data[out->len++] = '\n';
+            for (uint32_t k = 0; k < L; ++k) out->data[out->len++] = kBases[dom[k] < 4 ? dom[k] : 4];
+            out->data[out->len++] = '\n';
+            out->data[out->len++] = '+';
+            out->data[out->len++] = '\n';
+            for (uint32_t k = 0; k < L; ++k) out->data[out->len++] = (char)(orc_compress_sys_error_rate(rate[k]) + 33);
+            out->data[out->len++] = '\n';
+            out->data[out->len] = 0;
+        }
+        free(dom);
+        free(rate);
+    }
+    return 0;
+}
+
+int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err, size_t err_cap) {
+    const orc_reference *r = s->r;
+    size_t pos = 0;
+    for (uint32_t i = 0; i < r->n_seqs; ++i) {
+        if (!s->n_blocks[i]) continue;                                   /* no unit, no LoadSysErrorRecord: the file's records are NOT skipped */
+        for (int strand = 2; strand--;) {                                /* CreateUnit loads the reverse record, the forward one follows */
+            const char *line[4];
+            size_t line_len[4];
+            for (int k = 0; k < 4; ++k) {
+                if (pos >= len) {
+                    if (err) snprintf(err, err_cap, "Could not read systematic error profile for reference sequence '%s': end of file", r->first_name[i]);
+                    return -1;
+                }
+                const char *e = memchr(text + pos, '\n', len - pos);
+                size_t l = e ? (size_t)(e - (text + pos)) : len - pos;
+                line[k] = text + pos;
+                line_len[k] = l;
+                pos += l + 1;
+            }
+            if (line[0][0] != '@' || line[2][0] != '+' || line_len[1] != line_len[3]) {
+                if (err) snprintf(err, err_cap, "systematic error profile: malformed FASTQ record");
+                return -1;
+            }
+            if (line_len[1] != r->len[i]) {                              /* Simulator.cpp:762-766 */
+                if (err)
+                    snprintf(err, err_cap, "Systematic error profile '%.*s' (length %zu) does not match reference sequence '%s' (length %u). Wrong file or order incorrect?",
+                             (int)(line_len[0] - 1), line[0] + 1, line_len[1], r->first_name[i], r->len[i]);
+                return -1;
+            }
+            for (uint32_t k = 0; k < r->len[i]; ++k) {                   /* ReadSystematicErrors */
+                char c = line[1][k];
+                s->sys_dom[strand][i][k] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+                s->sys_rate[strand][i][k] = orc_expand_sys_error_rate((uint8_t)(line[3][k] - 33));
+            }
+        }
+    }
+    return 0;
 }

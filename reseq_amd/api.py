@@ -61,6 +61,10 @@ SYMBOLS = {
     "rsq_sim_set_normalization": (C.c_int, [_vp, C.c_double, _vp, _sz]),
     "rsq_sim_get_sys_errors": (C.c_int, [_vp, C.c_int, _u32, _vp, _vp, _u32]),
     "rsq_sim_get_adapter_sys_errors": (C.c_int, [_vp, C.c_int, _u32, _vp, _vp, _u32]),
+    "rsq_sim_create_sys_error_profile": (C.c_int, [_vp, _u64, C.c_char_p, _vp]),
+    "rsq_sim_read_sys_errors": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_set_ref_bias_file": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_get_ref_seq_bias": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
@@ -227,6 +231,22 @@ class Simulator:
         dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
         _check(lib().rsq_sim_get_adapter_sys_errors(self.h, seg, adapter, dom.ctypes.data, rate.ctypes.data, length))
         return dom, rate
+
+    def create_sys_error_profile(self, seed, path, stream=None):
+        """Simulator::CreateSystematicErrorProfile (--writeSysError)"""
+        _check(lib().rsq_sim_create_sys_error_profile(self.h, seed, str(path).encode(), stream))
+
+    def read_sys_errors(self, path):
+        """--readSysError: after prepare()"""
+        _check(lib().rsq_sim_read_sys_errors(self.h, str(path).encode()))
+
+    def set_ref_bias_file(self, path):
+        _check(lib().rsq_sim_set_ref_bias_file(self.h, str(path).encode()))
+
+    def ref_seq_bias(self, n_sequences):
+        out = np.zeros(n_sequences, np.float64)
+        _check(lib().rsq_sim_get_ref_seq_bias(self.h, out.ctypes.data, out.size))
+        return out
 
     def pairs_device(self, block_lo, block_hi, r1, r2, frags=None, stream=None):
         """Run the hot path into caller-owned DeviceArrays.  Returns (n_pairs, len1, len2, rc)."""

@@ -93,7 +93,7 @@ uint64_t get_seed(const Args &a) {                      // main.cpp:340: random 
 
 bool load_profile(const Args &a, rsq_profile **p) {
     for (const char *k : {"bamIn", "adapterFile", "adapterMatrix", "statsOut", "vcfIn", "statsOnly", "noBias", "tiles", "probabilitiesOut", "stopAfterEstimation"})
-        if (a.has(k)) {
+        if (a.has(k) && !(std::string(k) == "stopAfterEstimation" && a.has("writeSysError"))) {       // main.cpp:845: the profile alone may be asked for
             ERR("--" << k << ": profile creation (statistics, bias fit, IPF) is not supported in this build; create the profile with the reference tool and pass it with -s");
             return false;
         }
@@ -143,20 +143,38 @@ bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<
 }
 
 int illumina_pe(const Args &a) {
-    for (const char *k : {"vcfSim", "methylation", "readSysError", "writeSysError", "refBiasFile"})
+    for (const char *k : {"vcfSim", "methylation"})
         if (a.has(k) && !a.get(k).empty()) {
             ERR("--" << k << " is not supported yet in this build");
             return 1;
         }
+    // main.cpp:862-908: --refBias keep|no|draw|file, --refBiasFile implies file; keep is the default
     int ref_bias_mode = 0;
+    const std::string ref_bias_file = a.get("refBiasFile", "");
     if (a.has("refBias")) {
         const std::string m = a.get("refBias");
         if (m == "keep") ref_bias_mode = 0;
         else if (m == "no") ref_bias_mode = 1;
+        else if (m == "draw") ref_bias_mode = 2;
+        else if (m == "file") ref_bias_mode = 3;
         else {
-            ERR("refBias '" << m << "' is not supported in this build (keep/no)");
+            ERR("Unknown option for refSeqBias: " << m);
             return 1;
         }
+        if ((ref_bias_mode == 3) != !ref_bias_file.empty()) {
+            ERR((ref_bias_mode == 3 ? "refBiasFile option mandatory if refBias is set to 'file'." : "refBiasFile option only allowed if refBias is set to 'file'."));
+            return 1;
+        }
+    } else if (!ref_bias_file.empty()) {
+        INFO("Reading reference sequence biases from file.");
+        ref_bias_mode = 3;
+    }
+    // main.cpp:351-397 WriteSysError: the two options exclude each other; a written profile is the one the simulation then reads
+    const std::string sys_write = a.get("writeSysError", "");
+    std::string sys_read = a.get("readSysError", "");
+    if (!sys_write.empty() && !sys_read.empty()) {
+        ERR("writeSysError and readSysError option are mutually exclusive. Specify the one or the other.");
+        return 1;
     }
     const std::string ref_path = a.has("refSim") ? a.get("refSim") : a.get("refIn");
     if (ref_path.empty()) {
@@ -174,12 +192,26 @@ int illumina_pe(const Args &a) {
         ok = check(rsq_ref_load_fasta(ref_path.c_str(), &ref), "Could not load reference") && check(rsq_ref_replace_n(ref, seed), "ReplaceN");
     }
     ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
+    if (ok && !sys_write.empty()) {
+        INFO("Writing systematic error profile to " << sys_write);
+        ok = check(rsq_sim_create_sys_error_profile(sim, seed, sys_write.c_str(), nullptr), "Could not write systematic error profile");
+        if (!ok) remove(sys_write.c_str());                  // main.cpp:392
+        sys_read = sys_write;
+    }
+    if (ok && a.has("stopAfterEstimation")) {                 // main.cpp:845: with writeSysError the profile is all that was asked for
+        rsq_sim_free(sim);
+        rsq_ref_free(ref);
+        rsq_profile_free(prof);
+        return 0;
+    }
+    if (ok && ref_bias_mode == 3) ok = check(rsq_sim_set_ref_bias_file(sim, ref_bias_file.c_str()), "refBiasFile");
     if (ok) {
         INFO("Preparing for simulation");
         ok = check(rsq_sim_prepare(sim, seed, strtoull(a.get("numReads", "0").c_str(), nullptr, 10), atof(a.get("coverage", "0").c_str()), ref_bias_mode,
                                    a.get("recordBaseIdentifier", "ReseqRead").c_str(), nullptr),
                    "Preparation failed");
     }
+    if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
     std::ofstream f1, f2;
     if (ok) {
         f1.open(out1, std::ios::binary);

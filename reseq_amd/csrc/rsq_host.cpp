@@ -1,4 +1,5 @@
 // rsq_host.cpp -- RSQP container reader, profile loading and post-load edits, FASTA reader.
+#include <stdio.h>
 #include "rsq_host.h"
 
 #include <string.h>
@@ -263,6 +264,136 @@ void Reference::replace_n(uint64_t seed) {
             start = end;
         }
     }
+}
+
+// ------------------------------------------------------------------- systematic-error profile (FASTQ) and ref-bias file
+uint8_t compress_sys_error_rate(uint8_t q) {                     // Simulator.cpp:2569-2574
+    if (86 < q) q = (uint8_t)(q - (q - 85) / 2);
+    return q;
+}
+uint8_t expand_sys_error_rate(uint8_t r) {                       // Simulator.h:329-332
+    if (86 < r) r = (uint8_t)(r + (r - 86));
+    return r;
+}
+std::string sys_error_fastq_record(const std::string &id, const uint8_t *dom, const uint8_t *rate, size_t n) {
+    std::string out;
+    out.reserve(id.size() + 2 * n + 8);
+    out += '@';
+    out += id;
+    out += '\n';
+    for (size_t i = 0; i < n; ++i) out += "ACGTN"[dom[i] < 4 ? dom[i] : 4];
+    out += "\n+\n";
+    for (size_t i = 0; i < n; ++i) out += (char)(compress_sys_error_rate(rate[i]) + 33);
+    out += '\n';
+    return out;
+}
+std::vector<SysErrorRecord> parse_sys_error_fastq(const std::string &text) {
+    std::vector<SysErrorRecord> recs;
+    size_t pos = 0;
+    auto line = [&](std::string &l) {
+        if (pos >= text.size()) return false;
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        l.assign(text, pos, e - pos);
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        pos = e + 1;
+        return true;
+    };
+    std::string id, seq, plus, qual;
+    while (line(id)) {
+        if (id.empty()) continue;
+        if (id[0] != '@' || !line(seq) || !line(plus) || plus.empty() || plus[0] != '+' || !line(qual))
+            throw Error("systematic error profile: malformed FASTQ record " + std::to_string(recs.size()));
+        if (seq.size() != qual.size()) throw Error("systematic error profile '" + id.substr(1) + "': sequence and quality lengths differ");
+        SysErrorRecord r;
+        r.id = id.substr(1);
+        r.dom.resize(seq.size());
+        r.rate.resize(seq.size());
+        for (size_t i = 0; i < seq.size(); ++i) {
+            switch (seq[i]) {
+                case 'A': case 'a': r.dom[i] = 0; break;
+                case 'C': case 'c': r.dom[i] = 1; break;
+                case 'G': case 'g': r.dom[i] = 2; break;
+                case 'T': case 't': r.dom[i] = 3; break;
+                default: r.dom[i] = 4;
+            }
+            r.rate[i] = expand_sys_error_rate((uint8_t)(qual[i] - 33));
+        }
+        recs.push_back(std::move(r));
+    }
+    return recs;
+}
+std::string read_text_file(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw Error("Could not open '" + path + "' for reading.");
+    std::string text;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    return text;
+}
+void write_text_file(const std::string &path, const std::string &text) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw Error("Could not open '" + path + "' for writing.");
+    const size_t n = fwrite(text.data(), 1, text.size(), f);
+    if (fclose(f) != 0 || n != text.size()) throw Error("Could not write '" + path + "'.");
+}
+
+std::vector<double> read_ref_bias_file(const std::string &path, const std::vector<std::string> &first_names) {
+    const std::string text = read_text_file(path);                      // "Unable to open reference bias file" otherwise
+    std::map<std::string, uint32_t> ids;
+    for (uint32_t i = 0; i < first_names.size(); ++i) ids.emplace(first_names[i], i);      // emplace keeps the first of duplicates, like the reference
+    std::vector<double> bias(first_names.size(), 0.0);
+    std::vector<bool> found(first_names.size(), false);
+    std::string errors;
+    uint32_t nline = 0;
+    bool empty_line = false;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(pos, e - pos);
+        pos = e + 1;
+        if (empty_line) {
+            errors += "Line " + std::to_string(nline) + " is empty. ";
+            continue;
+        }
+        ++nline;
+        if (line.empty()) {
+            empty_line = true;
+            continue;
+        }
+        const size_t sep = line.find_last_of(" \t");
+        if (sep == std::string::npos) {
+            errors += "Line " + std::to_string(nline) + " does not have a field separator. ";
+            continue;
+        }
+        double b = 0.0;
+        try {
+            b = std::stod(line.substr(sep + 1));
+        } catch (const std::exception &) {
+            errors += "Could not convert bias in line " + std::to_string(nline) + " into double. ";
+            b = 0.0;
+        }
+        if (0.0 > b) errors += "Bias in line " + std::to_string(nline) + " is negative. ";
+        size_t id_len = line.find(' ');
+        if (id_len == std::string::npos) id_len = sep;
+        size_t id_start = 0;
+        if ('>' == line[0]) {
+            ++id_start;
+            --id_len;
+        }
+        auto it = ids.find(line.substr(id_start, id_len));
+        if (it != ids.end()) {
+            bias[it->second] = b;
+            found[it->second] = true;
+        }
+    }
+    for (uint32_t i = 0; i < first_names.size(); ++i)
+        if (!found[i]) errors += "Could not find bias for reference sequence " + first_names[i] + ". ";
+    if (!errors.empty()) throw Error("reference bias file " + path + ": " + errors);
+    return bias;
 }
 
 }  // namespace rsq

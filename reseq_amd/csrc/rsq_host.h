@@ -118,4 +118,23 @@ struct Reference {
     std::string first_part(size_t i) const;                 // Reference.cpp:476-480 ReferenceIdFirstPart
 };
 
+// ------------------------------------------------------------------- systematic-error profile (FASTQ) and ref-bias file
+// Simulator::WriteOutSystematicErrorProfile (Simulator.cpp:2562-2588) / ReadSystematicErrors (Simulator.h:326-335):
+// one FASTQ record per strand, seq = dominant error (ACGTN), qual = error percent + 33 where percents above 86 are halved
+// into the 94 printable values (odd values join the even one before them, so the round trip is lossy there).
+uint8_t compress_sys_error_rate(uint8_t percent);
+uint8_t expand_sys_error_rate(uint8_t stored);
+std::string sys_error_fastq_record(const std::string &id, const uint8_t *dom, const uint8_t *rate, size_t n);
+struct SysErrorRecord {
+    std::string id;
+    std::vector<uint8_t> dom, rate;      // base codes 0..4, percents (expanded)
+};
+std::vector<SysErrorRecord> parse_sys_error_fastq(const std::string &text);
+std::string read_text_file(const std::string &path);
+void write_text_file(const std::string &path, const std::string &text);
+
+// FragmentDistributionStats::UpdateRefSeqBias kFile (FragmentDistributionStats.cpp:3386-3495): lines "identifier bias";
+// `first_names` are the reference ids up to the first space.  Throws with the reference's messages joined.
+std::vector<double> read_ref_bias_file(const std::string &path, const std::vector<std::string> &first_names);
+
 }  // namespace rsq

@@ -19,6 +19,7 @@ namespace rsq {
 
 struct Uploader {                                   // copies a host array to wherever the kernels will read it
     virtual void *put_bytes(const void *data, size_t bytes) = 0;
+    virtual void write_bytes(void *dst, const void *src, size_t bytes) = 0;      // overwrite part of an array put earlier
     virtual ~Uploader() {}
     template <class T>
     T *put(const std::vector<T> &v) {
@@ -30,7 +31,7 @@ struct Uploader {                                   // copies a host array to wh
 struct SimState {
     Profile prof;
     bool has_ref = false;
-    std::vector<std::string> ref_first_names;
+    std::vector<std::string> ref_first_names, ref_ids;   // ReferenceIdFirstPart / ReferenceId
     std::vector<uint32_t> seq_len;
     std::vector<uint64_t> seq_word_off, seq_base_off;
     uint64_t total_ref_size = 0;
@@ -45,6 +46,7 @@ struct SimState {
     uint32_t n_groups = 0, passes = 0, total_blocks = 0;
     std::vector<uint32_t> coverage_groups, first_block, n_blocks, block_seq;
     std::vector<double> thresholds, norm_by_len, ref_seq_bias;
+    std::string ref_bias_file;                       // --refBiasFile, consumed by plan_simulation when ref_bias_mode is kRefBiasFile
     double bias_normalization = 0;
 };
 
@@ -270,6 +272,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
     s.seq_word_off.clear();
     s.seq_base_off.clear();
     s.ref_first_names.clear();
+    s.ref_ids.clear();
     for (size_t i = 0; i < r.codes.size(); ++i) {
         s.seq_len.push_back((uint32_t)r.codes[i].size());
         s.seq_word_off.push_back(words);
@@ -277,6 +280,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
         words += (r.codes[i].size() + 31) / 32 + 1;        // one spare word per sequence
         bases += r.codes[i].size();
         s.ref_first_names.push_back(r.first_part(i));
+        s.ref_ids.push_back(r.names[i]);
     }
     s.total_ref_size = bases;
     std::vector<uint64_t> packed(words + 1, 0);
@@ -437,6 +441,22 @@ inline double coverage_prop_lost_from_adapters(const Profile &p) {
 // --------------------------------------------------------------------------------- prepare: pairs and blocks
 // Simulator.cpp:2705-2743 (number of pairs, adapter-only share), :2782 (sys_gc_range_), UpdateRefSeqBias kKeep/kNo
 // (FragmentDistributionStats.cpp:3352-3364) and the block numbering of CreateUnit/CreateBlock (:911-924,1149-1225).
+enum : int { kRefBiasKeep = 0, kRefBiasNo = 1, kRefBiasDraw = 2, kRefBiasFile = 3 };      // RefSeqBiasSimulation (FragmentDistributionStats.h)
+
+// sys_gc_range_ = Divide(sum_read_length, reads) / 2 (Simulator.cpp:2782,2962); returns the average read length
+inline double set_sys_gc_range(SimState &s) {
+    const Profile &p = s.prof;
+    uint64_t reads = 0, sum_read_length = 0;                                         // :2713-2721
+    for (int seg = 2; seg--;)
+        for (uint64_t len = p.read_lengths[seg].from; len < p.read_lengths[seg].to(); ++len) {
+            reads += p.read_lengths[seg][len];
+            sum_read_length += p.read_lengths[seg][len] * len;
+        }
+    if (!reads) throw Error("profile has no reads");
+    s.dev.sys_gc_range = (uint16_t)(((sum_read_length + reads / 2) / reads) / 2);
+    return (double)sum_read_length / reads;
+}
+
 inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
     const Profile &p = s.prof;
     s.seed = seed;
@@ -446,15 +466,7 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
     memcpy(s.names.base_identifier, base.data(), base.size());
     s.names.base_len = (uint32_t)base.size();
 
-    uint64_t reads = 0, sum_read_length = 0;                                         // :2713-2721
-    for (int seg = 2; seg--;)
-        for (uint64_t len = p.read_lengths[seg].from; len < p.read_lengths[seg].to(); ++len) {
-            reads += p.read_lengths[seg][len];
-            sum_read_length += p.read_lengths[seg][len] * len;
-        }
-    if (!reads) throw Error("profile has no reads");
-    const double average_read_length = (double)sum_read_length / reads;
-    s.dev.sys_gc_range = (uint16_t)(((sum_read_length + reads / 2) / reads) / 2);      // :2782
+    const double average_read_length = set_sys_gc_range(s);
     if (!s.has_ref) return;
 
     if (num_read_pairs) s.total_pairs = num_read_pairs;                              // :2726-2736
@@ -467,8 +479,22 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
     s.total_pairs -= s.adapter_only_pairs;
 
     const uint32_t n_seqs = s.dev.n_seqs;
-    s.ref_seq_bias.assign(n_seqs, 1.0);
-    if (ref_bias_mode == 0 && p.ref_seq_bias.size() == n_seqs) s.ref_seq_bias = p.ref_seq_bias;
+    s.ref_seq_bias.assign(n_seqs, 1.0);                                                // UpdateRefSeqBias (FragmentDistributionStats.cpp:3352-3500)
+    switch (ref_bias_mode) {
+        case kRefBiasKeep:                                                             // falls back to kNo when the counts differ
+            if (p.ref_seq_bias.size() == n_seqs) s.ref_seq_bias = p.ref_seq_bias;
+            break;
+        case kRefBiasNo: break;
+        case kRefBiasDraw:                                                             // with replacement from the stored biases
+            if (p.ref_seq_bias.empty()) throw Error("refBias draw: the profile stores no reference sequence biases");
+            for (uint32_t i = 0; i < n_seqs; ++i) {
+                const uint32_t k = (uint32_t)(u32_to_unit(philox(seed, i, 0u, 0u, kDomRefBias << 28).w0) * (double)p.ref_seq_bias.size());
+                s.ref_seq_bias[i] = p.ref_seq_bias[k < p.ref_seq_bias.size() ? k : p.ref_seq_bias.size() - 1];
+            }
+            break;
+        case kRefBiasFile: s.ref_seq_bias = read_ref_bias_file(s.ref_bias_file, s.ref_first_names); break;
+        default: throw Error("Unknown option chosen for reference sequence bias");
+    }
 
     s.first_block.assign(n_seqs, 0);
     s.n_blocks.assign(n_seqs, 0);
@@ -491,7 +517,10 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
 
 // ------------------------------------------------------------------------------- chains of the a13 pre-pass
 constexpr uint32_t kChainChunk = 256;
-inline void build_chains(const SimState &s, bool with_reference, std::vector<Chain> &chains, std::vector<uint32_t> &chunk_chain) {
+// kChainsAdapters: SimulateErrorModelOnly (Simulator.cpp:2951-2977); kChainsSimulation: Simulate (adapters, then every sequence that
+// gets a unit); kChainsProfile: CreateSystematicErrorProfile (:2597-2653), every sequence and no adapters, from a fresh Simulator.
+enum ChainSet : int { kChainsAdapters = 0, kChainsSimulation = 1, kChainsProfile = 2 };
+inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &chains, std::vector<uint32_t> &chunk_chain) {
     uint32_t dom_state = 0;                                       // DominantBase(): dom_base_(0)
     auto add = [&](Chain c) {
         c.first_chunk = (uint32_t)chunk_chain.size();
@@ -500,7 +529,7 @@ inline void build_chains(const SimState &s, bool with_reference, std::vector<Cha
         chains.push_back(c);
     };
     const Profile &p = s.prof;
-    for (int seg = 2; seg--;) {                                   // Simulator.cpp:2784-2797 adapters, segment 1 first, ids descending
+    for (int seg = 2; set != kChainsProfile && seg--;) {           // Simulator.cpp:2784-2797 adapters, segment 1 first, ids descending
         const HostAdapters &a = p.adapters[seg];
         for (uint32_t i = a.n(); i--;) {
             if (!a.counts[i]) continue;
@@ -510,9 +539,9 @@ inline void build_chains(const SimState &s, bool with_reference, std::vector<Cha
             dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, len, dom_state);
         }
     }
-    if (with_reference)
+    if (set != kChainsAdapters)
         for (uint32_t i = 0; i < s.dev.n_seqs; ++i) {
-            if (!s.n_blocks[i]) continue;                           // no unit for sequences shorter than the longest insert
+            if (set == kChainsSimulation && !s.n_blocks[i]) continue;      // no unit for sequences shorter than the longest insert
             const uint32_t L = s.seq_len[i];
             const std::vector<uint8_t> &codes = s.ref_codes[i];
             for (uint32_t strand = 2; strand--;) {                  // CreateUnit: whole reverse strand first, then the forward blocks
@@ -521,6 +550,26 @@ inline void build_chains(const SimState &s, bool with_reference, std::vector<Cha
                 else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
             }
         }
+}
+
+// --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335).  Units consume the
+// records in file order, two per unit (reverse strand first); sequences without a unit consume none, exactly like the reference
+// (so a file written for a reference with too-short sequences is rejected with the length message).
+inline void apply_sys_error_records(SimState &s, Uploader &up, const std::vector<SysErrorRecord> &recs) {
+    size_t next = 0;
+    for (uint32_t i = 0; i < s.dev.n_seqs; ++i) {
+        if (!s.n_blocks[i]) continue;
+        for (uint32_t strand = 2; strand--;) {
+            if (next >= recs.size()) throw Error("Could not read systematic error profile for reference sequence '" + s.ref_first_names[i] + "': end of file");
+            const SysErrorRecord &r = recs[next++];
+            if (r.dom.size() != s.seq_len[i])
+                throw Error("Systematic error profile '" + r.id + "' (length " + std::to_string(r.dom.size()) + ") does not match reference sequence '" +
+                            s.ref_first_names[i] + "' (length " + std::to_string(s.seq_len[i]) + "). Wrong file or order incorrect?");
+            std::vector<uint16_t> track(r.dom.size());
+            for (size_t k = 0; k < track.size(); ++k) track[k] = (uint16_t)(r.dom[k] | ((uint16_t)r.rate[k] << 8));
+            up.write_bytes((strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[i], track.data(), track.size() * sizeof(uint16_t));
+        }
+    }
 }
 
 // ------------------------------------------------- bias normalisation: parameter list and the arithmetic after SumBias

@@ -99,6 +99,7 @@ struct DeviceUploader : Uploader {
         HIP_CHECK(hipMemcpy(owned.back()->as<void>(), data, bytes, hipMemcpyHostToDevice));
         return owned.back()->as<void>();
     }
+    void write_bytes(void *dst, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
 };
 
 // ------------------------------------------------------------------------------------------------ rsq_sim
@@ -116,10 +117,10 @@ struct rsq_sim : SimState {
 namespace rsq {
 
 // --------------------------------------------------------------------------------- systematic errors (a13)
-static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, bool with_reference) {
+static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set) {
     std::vector<Chain> chains;
     std::vector<uint32_t> chunk_chain;
-    build_chains(s, with_reference, chains, chunk_chain);
+    build_chains(s, set, chains, chunk_chain);
     const uint32_t n_chunks = (uint32_t)chunk_chain.size();
     if (!n_chunks) return 0;
     DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
@@ -178,8 +179,36 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
         bias_normalization(s, st);
         upload_normalization(s, s.up);
     }
-    s.passes = run_sys_chains(s, st, s.has_ref);
+    s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);
     s.prepared = true;
+}
+
+// Simulator::CreateSystematicErrorProfile (Simulator.cpp:2597-2653): both strands of every sequence, reverse first, as FASTQ.
+// The reference reads sys_gc_range_ uninitialised in this mode (it is only set in Simulate, :2782); here it has that value.
+static void create_sys_error_profile(rsq_sim &s, uint64_t seed, const char *path, hipStream_t st) {
+    if (!s.has_ref) throw Error("a reference is needed to draw a systematic error profile");
+    HIP_CHECK(hipSetDevice(s.device));
+    s.dev.seed = seed;
+    set_sys_gc_range(s);
+    run_sys_chains(s, st, kChainsProfile);
+    s.prepared = false;                                             // the simulation tracks were overwritten: prepare again before simulating
+    std::string text;
+    std::vector<uint16_t> track;
+    std::vector<uint8_t> dom, rate;
+    for (uint32_t i = 0; i < s.dev.n_seqs; ++i)
+        for (uint32_t strand = 2; strand--;) {
+            const uint32_t L = s.seq_len[i];
+            track.resize(L);
+            dom.resize(L);
+            rate.resize(L);
+            HIP_CHECK(hipMemcpy(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[i], (size_t)L * 2, hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < L; ++k) {
+                dom[k] = (uint8_t)(track[k] & 0xFF);
+                rate[k] = (uint8_t)(track[k] >> 8);
+            }
+            text += sys_error_fastq_record(s.ref_ids[i] + (strand ? " reverse" : " forward"), dom.data(), rate.data(), L);
+        }
+    write_text_file(path, text);
 }
 
 // --------------------------------------------------------------------------------------------- hot path
@@ -555,6 +584,31 @@ int rsq_sim_get_sys_errors(const rsq_sim *s, int reverse_strand, uint32_t seq, u
     REQUIRE(s && s->prepared && s->has_ref && seq < s->dev.n_seqs && len == s->seq_len[seq] && dom_out && rate_out, "bad arguments");
     REQUIRE(s->n_blocks[seq], "sequence is shorter than the longest insert length and is not simulated");
     return download_sys(s, (reverse_strand ? s->sys_rev : s->sys_fwd) + s->seq_base_off[seq], dom_out, rate_out, len);
+}
+int rsq_sim_create_sys_error_profile(rsq_sim *s, uint64_t seed, const char *path, void *stream) {
+    REQUIRE(s && path, "null argument");
+    return guard([&] {
+        create_sys_error_profile(*s, seed, path, (hipStream_t)stream);
+        return RSQ_OK;
+    });
+}
+int rsq_sim_read_sys_errors(rsq_sim *s, const char *path) {
+    REQUIRE(s && path && s->prepared && s->has_ref, "rsq_sim_prepare with a reference must run before rsq_sim_read_sys_errors");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        apply_sys_error_records(*s, s->up, parse_sys_error_fastq(read_text_file(path)));
+        return RSQ_OK;
+    });
+}
+int rsq_sim_set_ref_bias_file(rsq_sim *s, const char *path) {
+    REQUIRE(s && path, "null argument");
+    s->ref_bias_file = path;
+    return RSQ_OK;
+}
+int rsq_sim_get_ref_seq_bias(const rsq_sim *s, double *out, size_t n) {
+    REQUIRE(s && out && s->prepared && n == s->ref_seq_bias.size(), "bad arguments");
+    memcpy(out, s->ref_seq_bias.data(), n * sizeof(double));
+    return RSQ_OK;
 }
 int rsq_sim_get_adapter_sys_errors(const rsq_sim *s, int seg, uint32_t adapter, uint8_t *dom_out, uint8_t *rate_out, uint32_t len) {
     REQUIRE(s && s->prepared && (seg == 0 || seg == 1) && adapter < s->prof.adapters[seg].n() && dom_out && rate_out, "bad arguments");

@@ -24,7 +24,7 @@ constexpr uint32_t kSurSize = 1u << 20;
 constexpr uint32_t kSqFragmentLengthBinSize = 10;   // QualityStats.h:15
 
 // Counter domains of the Philox streams (DESIGN.md "Random streams"); tag = c3 >> 28.
-enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5 };
+enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5, kDomRefBias = 6 };
 
 // One LogArrayResult<N>: K outcome columns, NM = N-1 conditioning margins.
 // margin n: rows[n] rows of stride kp = row_stride(K) doubles at pool[off[n]] (zero pad columns up to whole

@@ -42,6 +42,10 @@ def emu_lib():
         L.emu_set_normalization.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
         L.emu_get_sys.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.emu_get_adapter_sys.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.emu_create_sys_error_profile.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
+        L.emu_read_sys_errors.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_set_ref_bias_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_get_ref_seq_bias.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_get_codes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_sieve.restype = C.c_int64
         L.emu_sieve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
@@ -111,6 +115,20 @@ class EmuBackend:
     def codes(self, seq, length):
         out = np.zeros(length, np.uint8)
         self.L.emu_get_codes(self.h, seq, out.ctypes.data)
+        return out
+
+    def create_sys_error_profile(self, seed, path):
+        _ok(self.L.emu_create_sys_error_profile(self.h, seed, str(path).encode()))
+
+    def read_sys_errors(self, path):
+        _ok(self.L.emu_read_sys_errors(self.h, str(path).encode()))
+
+    def set_ref_bias_file(self, path):
+        _ok(self.L.emu_set_ref_bias_file(self.h, str(path).encode()))
+
+    def ref_seq_bias(self, n_sequences):
+        out = np.zeros(n_sequences, np.float64)
+        self.L.emu_get_ref_seq_bias(self.h, out.ctypes.data)
         return out
 
     def _text(self, frags, n, first):
@@ -195,6 +213,18 @@ class GpuBackend:
 
     def codes(self, seq, length):
         return self.ref.codes(seq)
+
+    def create_sys_error_profile(self, seed, path):
+        self.sim.create_sys_error_profile(seed, path)
+
+    def read_sys_errors(self, path):
+        self.sim.read_sys_errors(path)
+
+    def set_ref_bias_file(self, path):
+        self.sim.set_ref_bias_file(path)
+
+    def ref_seq_bias(self, n_sequences):
+        return self.sim.ref_seq_bias(n_sequences)
 
     def pairs(self, block_lo, block_hi):
         return self.sim.pairs(block_lo, block_hi)

@@ -25,6 +25,7 @@ struct HostUploader : Uploader {
         owned.push_back(p);
         return p;
     }
+    void write_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
     ~HostUploader() override {
         for (void *p : owned) free(p);
     }
@@ -116,10 +117,10 @@ void sum_bias_like_kernel(const Emu &s, const BiasParam &p, double &sum_out, dou
     }
 }
 
-uint32_t run_chains(Emu &s, bool with_reference) {
+uint32_t run_chains(Emu &s, ChainSet set) {
     std::vector<Chain> chains;
     std::vector<uint32_t> chunk_chain;
-    build_chains(s, with_reference, chains, chunk_chain);
+    build_chains(s, set, chains, chunk_chain);
     const uint32_t n = (uint32_t)chunk_chain.size();
     if (!n) return 0;
     std::vector<uint32_t> used(n, 0), out[2] = {std::vector<uint32_t>(n, 0), std::vector<uint32_t>(n, 0)};
@@ -215,7 +216,7 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
             finish_bias_normalization(s, plan, sums, maxes);
             upload_normalization(s, s.up);
         }
-        s.passes = run_chains(s, s.has_ref);
+        s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters);
         s.build_lds();
         s.prepared = true;
     });
@@ -247,6 +248,49 @@ int emu_set_normalization(void *h, double bias_normalization, const double *thr,
         upload_normalization(s, s.up);
     });
 }
+// the host mirror of rsq_sim_create_sys_error_profile / rsq_sim_read_sys_errors / rsq_sim_set_ref_bias_file (rsq_sim.hip)
+int emu_create_sys_error_profile(void *h, uint64_t seed, const char *path) {
+    return guard([&] {
+        Emu &s = *static_cast<Emu *>(h);
+        s.dev.seed = seed;
+        set_sys_gc_range(s);
+        run_chains(s, kChainsProfile);
+        s.prepared = false;
+        std::string text;
+        std::vector<uint8_t> dom, rate;
+        for (uint32_t i = 0; i < s.dev.n_seqs; ++i)
+            for (uint32_t strand = 2; strand--;) {
+                const uint32_t L = s.seq_len[i];
+                const uint16_t *track = (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[i];
+                dom.resize(L);
+                rate.resize(L);
+                for (uint32_t k = 0; k < L; ++k) {
+                    dom[k] = (uint8_t)(track[k] & 0xFF);
+                    rate[k] = (uint8_t)(track[k] >> 8);
+                }
+                text += sys_error_fastq_record(s.ref_ids[i] + (strand ? " reverse" : " forward"), dom.data(), rate.data(), L);
+            }
+        write_text_file(path, text);
+        return 0;
+    });
+}
+int emu_read_sys_errors(void *h, const char *path) {
+    return guard([&] {
+        Emu &s = *static_cast<Emu *>(h);
+        if (!s.prepared || !s.has_ref) throw Error("prepare first");
+        apply_sys_error_records(s, s.up, parse_sys_error_fastq(read_text_file(path)));
+        return 0;
+    });
+}
+int emu_set_ref_bias_file(void *h, const char *path) {
+    static_cast<Emu *>(h)->ref_bias_file = path;
+    return 0;
+}
+void emu_get_ref_seq_bias(void *h, double *out) {
+    const Emu &s = *static_cast<Emu *>(h);
+    memcpy(out, s.ref_seq_bias.data(), s.ref_seq_bias.size() * sizeof(double));
+}
+
 void emu_get_sys(void *h, int reverse, uint32_t seq, uint8_t *dom, uint8_t *rate) {
     Emu &s = *static_cast<Emu *>(h);
     const uint16_t *src = (reverse ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq];

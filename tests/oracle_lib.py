@@ -108,6 +108,12 @@ def lib():
         "orc_reference_free": (None, [C.c_void_p]),
         "orc_reference_replace_n": (None, [C.c_void_p, C.c_uint64]),
         "orc_sim_new": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_char_p]),
+        "orc_sim_new_bias": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
+        "orc_sim_ref_seq_bias": (f64p, [C.c_void_p]),
+        "orc_compress_sys_error_rate": (C.c_uint8, [C.c_uint8]),
+        "orc_expand_sys_error_rate": (C.c_uint8, [C.c_uint8]),
+        "orc_create_sys_error_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Text)]),
+        "orc_sim_load_sys_errors": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "orc_sim_free": (None, [C.c_void_p]),
         "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),
         "orc_coverage_prop_lost_from_adapters": (C.c_double, [C.c_void_p]),
@@ -182,10 +188,30 @@ def _take_text(t):
     return out
 
 
+def create_sys_error_profile(profile, reference, seed):
+    """FASTQ text of Simulator::CreateSystematicErrorProfile"""
+    t = Text()
+    if lib().orc_create_sys_error_profile(profile.h, reference.h, seed, C.byref(t)):
+        raise RuntimeError("orc_create_sys_error_profile failed")
+    return _take_text(t)
+
+
 class Sim:
-    def __init__(self, profile, reference, seed, num_pairs=0, coverage=0.0, base_identifier=b""):
+    def __init__(self, profile, reference, seed, num_pairs=0, coverage=0.0, base_identifier=b"", ref_bias_mode=0, ref_bias_file=None):
         self.profile, self.reference = profile, reference
-        self.h = lib().orc_sim_new(profile.h, reference.h if reference else None, seed, num_pairs, coverage, base_identifier)
+        err = C.create_string_buffer(1024)
+        self.h = lib().orc_sim_new_bias(profile.h, reference.h if reference else None, seed, num_pairs, coverage, base_identifier, ref_bias_mode,
+                                        str(ref_bias_file).encode() if ref_bias_file else None, err, len(err))
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def ref_seq_bias(self):
+        return np.ctypeslib.as_array(lib().orc_sim_ref_seq_bias(self.h), shape=(len(self.reference.seqs),)).copy()
+
+    def load_sys_errors(self, text):
+        err = C.create_string_buffer(1024)
+        if lib().orc_sim_load_sys_errors(self.h, text, len(text), err, len(err)):
+            raise RuntimeError(err.value.decode())
 
     # pre-pass results
     def thresholds(self):

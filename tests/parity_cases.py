@@ -27,7 +27,8 @@ def make_inputs(workdir, tag, cfg, ref_lengths, prof_seed=5, ref_seed=1, gc=0.5)
 class Pair:
     """oracle + backend on the same inputs"""
 
-    def __init__(self, backend_cls, workdir, tag, cfg, ref_lengths, seed, num_pairs=0, coverage=0.0, base_identifier="", edits=None, **kw):
+    def __init__(self, backend_cls, workdir, tag, cfg, ref_lengths, seed, num_pairs=0, coverage=0.0, base_identifier="", edits=None, ref_bias_mode=0,
+                 ref_bias_file=None, **kw):
         self.ppath, self.fpath, self.seqs = make_inputs(workdir, tag, cfg, ref_lengths, **kw)
         self.oprof = O.Profile(self.ppath)
         if edits:
@@ -39,9 +40,11 @@ class Pair:
             if edits.get("no_indels"):
                 L.orc_profile_remove_indel_errors(self.oprof.h)
         self.oref = O.Reference(self.seqs)
-        self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode())
+        self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode(), ref_bias_mode, ref_bias_file)
         self.b = backend_cls(self.ppath, self.fpath, 0, edits)
-        self.info = self.b.prepare(seed, num_pairs, coverage, 0, base_identifier)
+        if ref_bias_file:
+            self.b.set_ref_bias_file(ref_bias_file)
+        self.info = self.b.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
 
     def align_normalization(self):
         """stage-wise parity: give the backend the oracle's thresholds so that the sieve sees identical doubles"""
@@ -221,3 +224,76 @@ def case_error_model_long_templates(backend_cls, workdir):
 def case_error_model_p0(backend_cls, workdir):
     exp = _error_model(backend_cls, workdir, "em_p0", synth.P0, 300, 150, seed=99, prof_seed=103741084, zero_frac=0.97)
     assert all(len(e[0]) == 150 for e in exp)
+
+
+def case_sys_error_profile_round_trip(backend_cls, workdir):
+    """--writeSysError / --readSysError (Simulator.cpp:2562-2653, Simulator.h:326-335): the profile text equals the oracle's, and a
+    simulation that reads it back produces the oracle's reads from the same file"""
+    p = Pair(backend_cls, workdir, "sysprof", synth.TINY, [4100, 2999], seed=19, num_pairs=2500)
+    try:
+        path = workdir / f"sysprof_{backend_cls.name}.fq"
+        p.b.create_sys_error_profile(31, path)
+        text = path.read_bytes()
+        assert text == O.create_sys_error_profile(p.oprof, p.oref, 31)
+        recs = text.split(b"\n")
+        assert recs[0].endswith(b" reverse") and recs[4].endswith(b" forward") and len(recs) == 4 * 4 + 1
+        assert set(recs[1]) <= set(b"ACGTN") and len(recs[1]) == len(recs[3]) == 4100
+        # drawn with another seed than the simulation: reading it back must change the tracks, identically on both sides
+        p.info = p.b.prepare(19, 2500)
+        before = p.b.sys_errors(0, 0, 4100)
+        p.b.read_sys_errors(path)
+        p.osim.load_sys_errors(text)
+        for seq, n in ((0, 4100), (1, 2999)):
+            for strand in (0, 1):
+                od, orate = p.osim.sys_errors(strand, seq)
+                bd, brate = p.b.sys_errors(strand, seq, n)
+                assert np.array_equal(od, bd) and np.array_equal(orate, brate)
+        assert not np.array_equal(before[1], p.b.sys_errors(0, 0, 4100)[1])
+        p.align_normalization()
+        assert _compare_blocks(p, 1, p.info["total_blocks"] + 1)[0] > 1500
+    finally:
+        p.close()
+
+
+def case_sys_error_profile_rejects_wrong_reference(backend_cls, workdir):
+    """LoadSysErrorRecord's length check (Simulator.cpp:762-766); a sequence without a unit consumes no record, so a profile
+    written for a reference with a too-short sequence in front is rejected, as in the reference"""
+    import pytest
+    p = Pair(backend_cls, workdir, "sysprof_bad", synth.TINY, [80, 4100], seed=19, num_pairs=500)
+    try:
+        path = workdir / f"sysprof_bad_{backend_cls.name}.fq"
+        p.b.create_sys_error_profile(31, path)
+        p.b.prepare(19, 500)
+        with pytest.raises(Exception, match="does not match reference sequence"):
+            p.b.read_sys_errors(path)
+        with pytest.raises(RuntimeError, match="does not match reference sequence"):
+            p.osim.load_sys_errors(path.read_bytes())
+    finally:
+        p.close()
+
+
+def case_ref_bias_modes(backend_cls, workdir):
+    """--refBias no|draw|file (UpdateRefSeqBias, FragmentDistributionStats.cpp:3352-3500)"""
+    lengths = [3000, 2600, 2800]
+    bias_file = workdir / "bias.tsv"
+    ppath, fpath, seqs = make_inputs(workdir, "refbias", synth.TINY, lengths)
+    names = [n.split(" ")[0] for n, _ in seqs]
+    bias_file.write_text(f">{names[1]} some description\t0.5\n{names[0]}\t2.25\n{names[2]} 1.0\n\n")
+    for mode, kw in ((1, {}), (2, {}), (3, {"ref_bias_file": bias_file})):
+        p = Pair(backend_cls, workdir, "refbias", synth.TINY, lengths, seed=23, num_pairs=1500, ref_bias_mode=mode, **kw)
+        try:
+            ob, bb = p.osim.ref_seq_bias(), p.b.ref_seq_bias(3)
+            assert np.array_equal(ob, bb), (mode, ob, bb)
+            if mode == 1:
+                assert list(bb) == [1.0, 1.0, 1.0]
+            if mode == 3:
+                assert list(bb) == [2.25, 0.5, 1.0]
+            assert abs(p.info["bias_normalization"] / p.osim.bias_normalization() - 1) < NORM_RTOL
+            p.align_normalization()
+            assert _compare_blocks(p, 1, p.info["total_blocks"] + 1)[0] > 800
+        finally:
+            p.close()
+    import pytest
+    bias_file.write_text(f"{names[0]}\t2.25\n")
+    with pytest.raises(Exception, match="[Cc]ould not find bias|errors"):
+        Pair(backend_cls, workdir, "refbias", synth.TINY, lengths, seed=23, num_pairs=1500, ref_bias_mode=3, ref_bias_file=bias_file)

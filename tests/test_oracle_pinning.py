@@ -244,3 +244,17 @@ def test_philox_known_answer():
     assert [hex(w) for w in out.w] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
     out = O.lib().orc_philox4x32_10(0, 0, 0, 0, 0)
     assert [hex(w) for w in out.w] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+
+
+def test_sys_error_rate_compression_formulas():
+    """WriteOutSystematicErrorProfile (Simulator.cpp:2569-2574): q -= (q-85)/2 above 86; ReadSystematicErrors (Simulator.h:329-332):
+    r += r-86 above 86.  Values transcribed from the two formulas; even percents survive the round trip, odd ones above 86 drop to
+    the even value before them, and the largest stored value, 93 (+33 = '~'), is percent 100."""
+    L = O.lib()
+    for q, stored in ((0, 0), (47, 47), (86, 86), (87, 86), (88, 87), (89, 87), (90, 88), (99, 92), (100, 93)):
+        assert L.orc_compress_sys_error_rate(q) == stored
+    for stored, q in ((0, 0), (86, 86), (87, 88), (88, 90), (92, 98), (93, 100)):
+        assert L.orc_expand_sys_error_rate(stored) == q
+    for q in range(101):
+        back = L.orc_expand_sys_error_rate(L.orc_compress_sys_error_rate(q))
+        assert back == (q if q <= 86 or q % 2 == 0 else q - 1)

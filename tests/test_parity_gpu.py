@@ -72,3 +72,35 @@ def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
     monkeypatch.setenv("RSQ_RATE_ROWS", "1")
     P.case_sieve_and_reads_tiny(GpuBackend, workdir)
     P.case_p0_reads(GpuBackend, workdir)
+
+
+def test_sys_error_profile_round_trip(workdir):
+    P.case_sys_error_profile_round_trip(GpuBackend, workdir)
+
+
+def test_sys_error_profile_rejects_wrong_reference(workdir):
+    P.case_sys_error_profile_rejects_wrong_reference(GpuBackend, workdir)
+
+
+def test_ref_bias_modes(workdir):
+    P.case_ref_bias_modes(GpuBackend, workdir)
+
+
+def test_cli_write_then_read_sys_error_profile(workdir):
+    """reseq illuminaPE --writeSysError f simulates from the profile it just wrote (main.cpp:389), so a second run with
+    --readSysError f and the same seed must produce the same FASTQ files; --refBias no is accepted"""
+    import os
+    import subprocess
+    from reseq_amd import synth
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reseq_amd", "reseq")
+    ppath, fpath, _ = P.make_inputs(workdir, "cli_sys", synth.TINY, [4100, 2999])
+    prof = workdir / "cli_sys.fq"
+    common = [exe, "illuminaPE", "-R", fpath, "-s", ppath, "--numReads", "1500", "--seed", "5", "--refBias", "no"]
+    a1, a2, b1, b2 = (str(workdir / n) for n in ("a1.fq", "a2.fq", "b1.fq", "b2.fq"))
+    subprocess.run(common + ["-1", a1, "-2", a2, "--writeSysError", str(prof)], check=True, capture_output=True)
+    subprocess.run(common + ["-1", b1, "-2", b2, "--readSysError", str(prof)], check=True, capture_output=True)
+    assert open(a1, "rb").read() == open(b1, "rb").read() and open(a2, "rb").read() == open(b2, "rb").read()
+    assert open(a1, "rb").read().count(b"\n") >= 4 * 1000
+    assert prof.read_bytes().count(b"\n") == 16
+    r = subprocess.run(common + ["-1", a1, "-2", a2, "--writeSysError", str(prof), "--readSysError", str(prof)], capture_output=True)
+    assert r.returncode != 0 and b"mutually exclusive" in r.stderr

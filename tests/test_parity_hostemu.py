@@ -110,3 +110,15 @@ def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
     monkeypatch.setenv("RSQ_RATE_ROWS", "1")
     P.case_sieve_and_reads_tiny(EmuBackend, workdir)
     P.case_p0_reads(EmuBackend, workdir)
+
+
+def test_sys_error_profile_round_trip(workdir):
+    P.case_sys_error_profile_round_trip(EmuBackend, workdir)
+
+
+def test_sys_error_profile_rejects_wrong_reference(workdir):
+    P.case_sys_error_profile_rejects_wrong_reference(EmuBackend, workdir)
+
+
+def test_ref_bias_modes(workdir):
+    P.case_ref_bias_modes(EmuBackend, workdir)
