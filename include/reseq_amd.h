@@ -75,6 +75,12 @@ void rsq_sim_free(rsq_sim *s);
  * 1 no bias, 2 draw with replacement from the stored biases, 3 read the file given to rsq_sim_set_ref_bias_file. */
 int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier, void *stream);
 
+/* --methylation: Reference::PrepareMethylationFile + ReadMethylation (reseq/Reference.cpp:1132-1310) for a reference without variants:
+ * extended BED "sequence start end methylation" in reference order.  Afterwards rsq_sim_pairs applies Simulator::CTConversion
+ * (reseq/Simulator.cpp:1925-2002,2219-2247) to the templates of every fragment: inside the listed regions each C becomes T with
+ * probability 1 - methylation, drawn once per (start, length, strand) site so that duplicates share the conversion. */
+int rsq_sim_read_methylation(rsq_sim *s, const char *path);
+
 /* --refBiasFile: lines "identifier bias" (UpdateRefSeqBias kFile, FragmentDistributionStats.cpp:3386-3495); call before rsq_sim_prepare */
 int rsq_sim_set_ref_bias_file(rsq_sim *s, const char *path);
 int rsq_sim_get_ref_seq_bias(const rsq_sim *s, double *out, size_t n);          /* [n_sequences], after prepare */

@@ -245,6 +245,10 @@ typedef struct orc_sim {
     uint32_t *n_blocks;
     uint32_t total_blocks;
     char base_identifier[64];
+    /* unmethylated regions per sequence (NULL without --methylation): [first, second) and the C->T probability */
+    uint32_t *meth_n;
+    uint32_t **meth_first, **meth_second;
+    double **meth_rate;
 } orc_sim;
 
 /* Simulator.cpp:2655-2898 up to "Starting read generation": pairs, thresholds, sys errors */
@@ -299,6 +303,9 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
 /* Simulator.cpp:2359-2382 */
 int orc_simulate_adapter_only_pairs(const orc_sim *s, orc_text *r1, orc_text *r2);
 void orc_text_free(orc_text *t);
+/* --methylation without variants: Reference::PrepareMethylationFile/ReadMethylation (Reference.cpp:1132-1310) and
+ * Simulator::CTConversion (Simulator.cpp:1925-2002,2219-2247).  0, or -1 with the reference's message. */
+int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap);
 int orc_create_sys_error_profile(const orc_profile *p, const orc_reference *r, uint64_t seed, orc_text *out);
 /* --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335); 0 or -1 with a message */
 int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err, size_t err_cap);

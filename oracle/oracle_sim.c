@@ -492,6 +492,17 @@ void orc_sim_set_normalization(orc_sim *s, double bias_normalization, const doub
 
 void orc_sim_free(orc_sim *s) {
     if (!s) return;
+    if (s->meth_n) {
+        for (uint32_t i = 0; i < s->r->n_seqs; ++i) {
+            free(s->meth_first[i]);
+            free(s->meth_second[i]);
+            free(s->meth_rate[i]);
+        }
+        free(s->meth_n);
+        free(s->meth_first);
+        free(s->meth_second);
+        free(s->meth_rate);
+    }
     for (int seg = 0; seg < 2; ++seg) {
         if (s->adapter_dom[seg])
             for (uint32_t i = 0; i < s->p->adapters[seg].n; ++i) {
@@ -816,6 +827,67 @@ static uint16_t draw_tile(const orc_profile *p, uint64_t seed, uint32_t c0, uint
 
 static uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel) { return (dom << 28) | (strand << 27) | (segsel << 25); }
 
+/* cur_methylation_start of SimulateFromGivenBlock for a start position (Simulator.cpp:2273,2293-2297; CreateBlock :1214-1219 and the
+ * per-position increment keep it at the first region that ends after the position) */
+static uint32_t methylation_start(const orc_sim *s, uint32_t seq, uint32_t pos) {
+    uint32_t i = 0;
+    while (i < s->meth_n[seq] && s->meth_second[seq][i] <= pos) ++i;
+    return i;
+}
+
+/* Simulator::CTConversion without variants (Simulator.cpp:1925-2002), variable widths as there (read_pos is a uint16_t).  Where the
+ * reference would evaluate regions.at(-1) (a reverse template that begins before the first region) nothing is converted.  The
+ * uniform of template position k: word k&3 of Philox block (start, seq, length, 7<<28 | reversed<<27 | k>>2). */
+static void ct_conversion(const orc_sim *s, uint8_t *read, uint32_t length, uint32_t seq_id, uint32_t start_pos, uint32_t cur_methylation_start, int reversed,
+                          uint32_t site_start, uint32_t site_len) {
+    const uint32_t *first = s->meth_first[seq_id], *second = s->meth_second[seq_id];
+    const double *conversion_rate = s->meth_rate[seq_id];
+    int32_t n = (int32_t)s->meth_n[seq_id], cur_meth = (int32_t)cur_methylation_start;
+    uint16_t read_pos = 0;
+    uint32_t ref_pos = start_pos;
+#define CONVERT()                                                                                                                              \
+    if (1 == read[read_pos]) {                                                                                                                 \
+        orc_philox_out w = orc_philox4x32_10(s->seed, site_start, seq_id, site_len, (7u << 28) | ((uint32_t)reversed << 27) | (read_pos >> 2)); \
+        if (orc_u32(w.w[read_pos & 3]) < conversion_rate[cur_meth]) read[read_pos] = 3;                                                        \
+    }
+    if (reversed) {
+        while (cur_meth < n && first[cur_meth] <= ref_pos) ++cur_meth;
+        --cur_meth;
+        if (cur_meth > 0 && second[cur_meth] <= ref_pos) {
+            read_pos = (uint16_t)(read_pos + (ref_pos - (second[cur_meth] - 1)));
+            ref_pos = second[cur_meth] - 1;
+        }
+        while (cur_meth > 0 && read_pos < length) {
+            while (ref_pos >= first[cur_meth] && read_pos < length) {
+                CONVERT();
+                --ref_pos;
+                ++read_pos;
+            }
+            if (--cur_meth > 0 && second[cur_meth] <= ref_pos) {
+                read_pos = (uint16_t)(read_pos + (ref_pos - (second[cur_meth] - 1)));
+                ref_pos = second[cur_meth] - 1;
+            }
+        }
+    } else {
+        if (cur_meth < n && first[cur_meth] > ref_pos) {
+            read_pos = (uint16_t)(read_pos + (first[cur_meth] - ref_pos));
+            ref_pos = first[cur_meth];
+        }
+        while (cur_meth < n && read_pos < length) {
+            while (ref_pos < second[cur_meth] && read_pos < length) {
+                CONVERT();
+                ++ref_pos;
+                ++read_pos;
+            }
+            if (++cur_meth < n) {
+                read_pos = (uint16_t)(read_pos + (first[cur_meth] - ref_pos));
+                ref_pos = first[cur_meth];
+            }
+        }
+    }
+#undef CONVERT
+}
+
 /* Simulator.cpp:634-721 + :596-632 + Reference.cpp:483-496 (GetOrgSeq :1916-1922) */
 int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, orc_text *r1, orc_text *r2) {
     const orc_profile *p = s->p;
@@ -836,6 +908,11 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
             if (!which) memcpy(tmpl[sg], codes + start, tl);
             else
                 for (uint32_t k = 0; k < tl; ++k) tmpl[sg][k] = (uint8_t)(3 - codes[end - 1 - k]);
+        }
+        if (s->meth_n) {                                            /* CTConversion (Simulator.cpp:2219-2247): forward template, then reverse */
+            uint32_t cur_methylation_start = methylation_start(s, f->seq, start);
+            ct_conversion(s, tmpl[strand], tlen[strand], f->seq, start, cur_methylation_start, 0, start, f->len);
+            ct_conversion(s, tmpl[!strand], tlen[!strand], f->seq, end, cur_methylation_start, 1, start, f->len);
         }
         uint32_t c2 = f->len | ((uint32_t)f->dup << 16);
         uint16_t tile_id = draw_tile(p, s->seed, start, f->seq, c2, pair_c3(ORC_DOM_PAIR, strand, 2));
@@ -1091,4 +1168,102 @@ int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err,
         }
     }
     return 0;
+}
+
+/* Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310), NumAlleles() == 1 */
+int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap) {
+#define FAIL(...)                                      \
+    do {                                               \
+        if (err) snprintf(err, err_cap, __VA_ARGS__);  \
+        free(line);                                    \
+        if (f) fclose(f);                              \
+        return -1;                                     \
+    } while (0)
+    const orc_reference *r = s->r;
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t len;
+    FILE *f = fopen(path, "rb");
+    if (!f) FAIL("Unable to open methylation file %s", path);
+    int have = 0;
+    while ((len = getline(&line, &cap, f)) >= 0) {                     /* :1139-1150 skip empty and track lines */
+        if (len && line[len - 1] == '\n') line[--len] = 0;
+        if (len && strncmp(line, "track", 5)) {
+            have = 1;
+            break;
+        }
+    }
+    if (!have) FAIL("Methylation file is empty or only contains track lines: %s", path);
+    s->meth_n = calloc(r->n_seqs, sizeof(uint32_t));
+    s->meth_first = calloc(r->n_seqs, sizeof(uint32_t *));
+    s->meth_second = calloc(r->n_seqs, sizeof(uint32_t *));
+    s->meth_rate = calloc(r->n_seqs, sizeof(double *));
+    char cur_seq[1024];
+    size_t sl = strcspn(line, " \t");
+    snprintf(cur_seq, sizeof cur_seq, "%.*s", (int)sl, line);
+    int eof = 0;
+    for (uint32_t i = 0; i < r->n_seqs && !eof; ++i) {
+        if (strcmp(r->first_name[i], cur_seq)) continue;                /* no entries for this sequence */
+        uint32_t n = 0, room = 0;
+        for (;;) {
+            char *q = line + strlen(cur_seq);
+            q += strspn(q, " \t");
+            char *e;
+            long long v = strtoll(q, &e, 10);
+            if (e == q) FAIL("Could not convert second field to int for line:\n%s", line);
+            if (!n) {
+                if (v < 0) FAIL("Second field is negative in line:\n%s", line);
+            } else if (v < (long long)s->meth_second[i][n - 1]) FAIL("Region is overlapping with previous region[%u - %u] in line:\n%s", s->meth_first[i][n - 1], s->meth_second[i][n - 1], line);
+            if (v >= (long long)r->len[i]) FAIL("Second field is larger than sequence length:\n%s", line);
+            uint32_t region_start = (uint32_t)v;
+            q = e + strspn(e, " \t");
+            v = strtoll(q, &e, 10);
+            if (e == q) FAIL("Could not convert third field to int for line:\n%s", line);
+            if (v <= (long long)region_start) FAIL("Third field is smaller than second field in line:\n%s", line);
+            if (v > (long long)r->len[i]) FAIL("Third field is larger than sequence length:\n%s", line);
+            if (n == room) {
+                room = room ? 2 * room : 16;
+                s->meth_first[i] = realloc(s->meth_first[i], room * sizeof(uint32_t));
+                s->meth_second[i] = realloc(s->meth_second[i], room * sizeof(uint32_t));
+                s->meth_rate[i] = realloc(s->meth_rate[i], room * sizeof(double));
+            }
+            s->meth_first[i][n] = region_start;
+            s->meth_second[i][n] = (uint32_t)v;
+            uint32_t allele = 0;
+            q = e + strspn(e, " \t");
+            while (*q) {
+                if (allele >= 1) FAIL("More alleles specified than in variant file [1] in line:\n%s", line);
+                double d = strtod(q, &e);
+                if (e == q) FAIL("Could not convert field %u to double for line:\n%s", 4 + allele, line);
+                if (0.0 > d || d > 1.0) FAIL("Field %u is not between 0 and 1:\n%s", 4 + allele, line);
+                s->meth_rate[i][n] = 1.0 - d;
+                ++allele;
+                q = e + strspn(e, " \t");
+            }
+            if (1 != allele) FAIL("%u alleles specified (must be either 1 or same as in variant file[1]) in line:\n%s", allele, line);
+            ++n;
+            s->meth_n[i] = n;
+            int got = 0;
+            while ((len = getline(&line, &cap, f)) >= 0) {              /* ignore all empty lines */
+                if (len && line[len - 1] == '\n') line[--len] = 0;
+                if (len) {
+                    got = 1;
+                    break;
+                }
+            }
+            if (!got) {
+                eof = 1;
+                break;
+            }
+            sl = strcspn(line, " \t");
+            if (sl != strlen(cur_seq) || strncmp(line, cur_seq, sl)) {      /* a new reference sequence */
+                snprintf(cur_seq, sizeof cur_seq, "%.*s", (int)sl, line);
+                break;
+            }
+        }
+    }
+    free(line);
+    fclose(f);
+    return 0;
+#undef FAIL
 }

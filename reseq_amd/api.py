@@ -64,6 +64,7 @@ SYMBOLS = {
     "rsq_sim_create_sys_error_profile": (C.c_int, [_vp, _u64, C.c_char_p, _vp]),
     "rsq_sim_read_sys_errors": (C.c_int, [_vp, C.c_char_p]),
     "rsq_sim_set_ref_bias_file": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_read_methylation": (C.c_int, [_vp, C.c_char_p]),
     "rsq_sim_get_ref_seq_bias": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
@@ -239,6 +240,10 @@ class Simulator:
     def read_sys_errors(self, path):
         """--readSysError: after prepare()"""
         _check(lib().rsq_sim_read_sys_errors(self.h, str(path).encode()))
+
+    def read_methylation(self, path):
+        """--methylation: extended BED, bisulfite conversion of the templates (Simulator::CTConversion)"""
+        _check(lib().rsq_sim_read_methylation(self.h, str(path).encode()))
 
     def set_ref_bias_file(self, path):
         _check(lib().rsq_sim_set_ref_bias_file(self.h, str(path).encode()))

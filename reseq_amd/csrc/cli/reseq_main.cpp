@@ -143,11 +143,10 @@ bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<
 }
 
 int illumina_pe(const Args &a) {
-    for (const char *k : {"vcfSim", "methylation"})
-        if (a.has(k) && !a.get(k).empty()) {
-            ERR("--" << k << " is not supported yet in this build");
-            return 1;
-        }
+    if (a.has("vcfSim") && !a.get("vcfSim").empty()) {
+        ERR("--vcfSim is not supported yet in this build (variants; methylation is supported for a reference without variants)");
+        return 1;
+    }
     // main.cpp:862-908: --refBias keep|no|draw|file, --refBiasFile implies file; keep is the default
     int ref_bias_mode = 0;
     const std::string ref_bias_file = a.get("refBiasFile", "");
@@ -205,6 +204,10 @@ int illumina_pe(const Args &a) {
         return 0;
     }
     if (ok && ref_bias_mode == 3) ok = check(rsq_sim_set_ref_bias_file(sim, ref_bias_file.c_str()), "refBiasFile");
+    if (ok && !a.get("methylation", "").empty()) {            // Simulator.cpp:2770-2780 PrepareMethylationFile
+        INFO("Reading methylation from file: " << a.get("methylation"));
+        ok = check(rsq_sim_read_methylation(sim, a.get("methylation").c_str()), "Could not read methylation file");
+    }
     if (ok) {
         INFO("Preparing for simulation");
         ok = check(rsq_sim_prepare(sim, seed, strtoull(a.get("numReads", "0").c_str(), nullptr, 10), atof(a.get("coverage", "0").c_str()), ref_bias_mode,

@@ -396,4 +396,81 @@ std::vector<double> read_ref_bias_file(const std::string &path, const std::vecto
     return bias;
 }
 
+// -------------------------------------------------------------------------------------------- methylation (BED)
+Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len) {
+    std::ifstream f(path);
+    if (!f.is_open()) throw Error("Unable to open methylation file " + path);
+    std::string line;
+    if (!std::getline(f, line)) throw Error("Methylation file is empty: " + path);
+    while ((line.empty() || !line.compare(0, 5, "track")) && std::getline(f, line)) {}       // Reference.cpp:1150 ignore track lines
+    if (f.fail()) throw Error("Methylation file only contains track lines: " + path);
+    std::string cur_seq = line.substr(0, line.find_first_of(" \t"));
+    const size_t n = first_names.size();
+    Methylation m;
+    m.first.resize(n);
+    m.second.resize(n);
+    m.rate.resize(n);
+    bool file_done = false;
+    for (size_t i = 0; i < n && !file_done; ++i) {
+        if (first_names[i] != cur_seq) continue;                                              // no entries for this sequence
+        while (!f.fail()) {
+            size_t a = line.find_first_not_of(" \t", cur_seq.size() + 1), b = line.find_first_of(" \t", a);
+            long long v;
+            try {
+                v = std::stoll(line.substr(a, b));
+            } catch (const std::exception &) {
+                throw Error("Could not convert second field to int for line:\n" + line);
+            }
+            if (m.first[i].empty()) {
+                if (v < 0) throw Error("Second field is negative in line:\n" + line);
+            } else if (v < (long long)m.second[i].back()) {
+                throw Error("Region is overlapping with previous region[" + std::to_string(m.first[i].back()) + " - " + std::to_string(m.second[i].back()) + "] in line:\n" + line);
+            }
+            if (v >= (long long)seq_len[i]) throw Error("Second field is larger than sequence length:\n" + line);
+            const uint32_t region_start = (uint32_t)v;
+            a = line.find_first_not_of(" \t", b);
+            b = line.find_first_of(" \t", a);
+            try {
+                v = std::stoll(line.substr(a, b));
+            } catch (const std::exception &) {
+                throw Error("Could not convert third field to int for line:\n" + line);
+            }
+            if (v <= (long long)region_start) throw Error("Third field is smaller than second field in line:\n" + line);
+            if (v > (long long)seq_len[i]) throw Error("Third field is larger than sequence length:\n" + line);
+            m.first[i].push_back(region_start);
+            m.second[i].push_back((uint32_t)v);
+            uint32_t allele = 0;
+            a = line.find_first_not_of(" \t", b);
+            while (a < line.size()) {
+                if (allele >= 1) throw Error("More alleles specified than in variant file [1] in line:\n" + line);
+                b = line.find_first_of(" \t", a);
+                double d;
+                try {
+                    d = std::stod(line.substr(a, b));
+                } catch (const std::exception &) {
+                    throw Error("Could not convert field " + std::to_string(4 + allele) + " to double for line:\n" + line);
+                }
+                if (0.0 > d || d > 1.0) throw Error("Field " + std::to_string(4 + allele) + " is not between 0 and 1:\n" + line);
+                m.rate[i].push_back(1.0 - d);                                                  // the probability of a C->T conversion
+                ++allele;
+                a = line.find_first_not_of(" \t", b);
+            }
+            if (1 != allele) throw Error(std::to_string(allele) + " alleles specified (must be either 1 or same as in variant file[1]) in line:\n" + line);
+            while (std::getline(f, line) && line.empty()) {}                                   // ignore all empty lines
+            if (!f.fail()) {
+                const size_t sp = line.find_first_of(" \t");
+                if (line.compare(0, sp, cur_seq)) {                                            // a new reference sequence
+                    cur_seq = line.substr(0, sp);
+                    break;
+                }
+            }
+        }
+        if (f.fail()) {
+            if (!f.eof()) throw Error("Could not read methylation file for reference sequence: " + first_names[i]);
+            file_done = true;
+        }
+    }
+    return m;
+}
+
 }  // namespace rsq

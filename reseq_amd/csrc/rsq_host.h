@@ -137,4 +137,13 @@ void write_text_file(const std::string &path, const std::string &text);
 // `first_names` are the reference ids up to the first space.  Throws with the reference's messages joined.
 std::vector<double> read_ref_bias_file(const std::string &path, const std::vector<std::string> &first_names);
 
+// Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310) for a reference without variants (one allele):
+// extended BED "sequence start end methylation"; per sequence the unmethylated regions [first, second) and the C->T
+// conversion probability 1 - methylation.  File order must follow the reference; throws with the reference's messages.
+struct Methylation {
+    std::vector<std::vector<uint32_t>> first, second;
+    std::vector<std::vector<double>> rate;
+};
+Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len);
+
 }  // namespace rsq

@@ -766,6 +766,8 @@ struct RawLayout {                      // word-major arrays of the read kernel,
     uint32_t *ops;                      // [ops_words][pitch]: 16 two-bit CIGAR ops per word
     ReadMeta *meta;
     uint64_t pitch;                     // reads per word row (>= number of reads)
+    uint64_t *templates;                // --methylation: [reads][template_words] converted templates, else nullptr
+    uint32_t template_words;
     RSQ_HD WordColumn seq_of(uint64_t r) const { return WordColumn{seq + r, pitch}; }
     RSQ_HD WordColumn qual_of(uint64_t r) const { return WordColumn{qual + r, pitch}; }
     RSQ_HD WordColumn ops_of(uint64_t r) const { return WordColumn{ops + r, pitch}; }
@@ -779,12 +781,97 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
     uint32_t len;
     bool reverse;
     const uint16_t *sys_;               // systematic errors at the first template base
+    const uint64_t *converted;          // --methylation: the template after CTConversion, 2 bits per base in read orientation; else nullptr
     RSQ_HD uint32_t org_len() const { return len; }
-    RSQ_HD uint32_t base(uint32_t k) const {
-        return reverse ? 3u - ref_base(words, word_off, first - 1u - k) : ref_base(words, word_off, first + k);
-    }
+    RSQ_HD uint32_t ref(uint32_t k) const { return reverse ? 3u - ref_base(words, word_off, first - 1u - k) : ref_base(words, word_off, first + k); }
+    RSQ_HD uint32_t base(uint32_t k) const { return converted ? (uint32_t)(converted[k >> 5] >> ((k & 31u) * 2u)) & 3u : ref(k); }
     RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
 };
+
+// ------------------------------------------------------------------------------------- bisulfite conversion (a16)
+// Simulator::CTConversion without variants (Simulator.cpp:1925-2002), once per (start, length, strand) site and mate, so
+// that all duplicates of a site share the converted template.  Restated with the reference's variable widths: read_pos is
+// a uintReadLen (uint16_t) and wraps when the next region is more than 65535 bases away, and the reverse walk stops at
+// region index 0 (`while(cur_meth && ...)`), exactly as written there.  The uniform of template position k is word k&3 of
+// Philox block (start, sequence, length, 7<<28 | reversed<<27 | k>>2).
+struct MethView {
+    const uint32_t *first, *second;
+    const double *rate;
+    uint32_t n;
+};
+RSQ_HD MethView meth_view(const DevSim &S, uint32_t seq) {
+    const uint32_t off = S.meth_ptr[seq];
+    return MethView{S.meth_first + off, S.meth_second + off, S.meth_rate + off, S.meth_ptr[seq + 1] - off};
+}
+// cur_methylation_start of SimulateFromGivenBlock (:2273,:2293-2297, CreateBlock :1214-1219): the first region that ends after pos
+RSQ_HD uint32_t meth_start_index(const MethView &m, uint32_t pos) {
+    uint32_t lo = 0, hi = m.n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (m.second[mid] <= pos) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+constexpr uint32_t kTemplateWordsMax = 64;      // 2048 template bases
+struct MethDraws {                      // lazily evaluated Philox blocks of one template
+    uint64_t seed;
+    uint32_t c0, c1, c2, c3base, have;
+    Words w;
+    RSQ_HD double uniform(uint32_t k) {
+        if (have != (k >> 2)) {
+            w = philox(seed, c0, c1, c2, c3base | (k >> 2));
+            have = k >> 2;
+        }
+        const uint32_t j = k & 3u;
+        return u32_to_unit(j == 0u ? w.w0 : (j == 1u ? w.w1 : (j == 2u ? w.w2 : w.w3)));
+    }
+};
+RSQ_HD void ct_convert_base(uint64_t *tmpl, uint32_t k, double rate, MethDraws &d) {
+    const uint32_t sh = (k & 31u) * 2u;
+    if (((tmpl[k >> 5] >> sh) & 3u) == 1u && d.uniform(k) < rate) tmpl[k >> 5] |= (uint64_t)3u << sh;      // C (1) -> T (3)
+}
+RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, uint32_t start_pos, uint32_t cur_methylation_start, bool reversed, MethDraws &d) {
+    int32_t cur_meth = (int32_t)cur_methylation_start;
+    uint16_t read_pos = 0;
+    uint32_t ref_pos = start_pos;
+    const int32_t n = (int32_t)m.n;
+    if (reversed) {
+        while (cur_meth < n && m.first[cur_meth] <= ref_pos) ++cur_meth;       // bring cur_meth to the last region in reach
+        --cur_meth;
+        if (cur_meth > 0 && m.second[cur_meth] <= ref_pos) {                     // `if( cur_meth && ...)`: -1 would index out of range in the reference
+            read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
+            ref_pos = m.second[cur_meth] - 1u;
+        }
+        while (cur_meth > 0 && read_pos < length) {
+            while (ref_pos >= m.first[cur_meth] && read_pos < length) {
+                ct_convert_base(tmpl, read_pos, m.rate[cur_meth], d);
+                --ref_pos;
+                ++read_pos;
+            }
+            if (--cur_meth > 0 && m.second[cur_meth] <= ref_pos) {
+                read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
+                ref_pos = m.second[cur_meth] - 1u;
+            }
+        }
+    } else {
+        if (cur_meth < n && m.first[cur_meth] > ref_pos) {
+            read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
+            ref_pos = m.first[cur_meth];
+        }
+        while (cur_meth < n && read_pos < length) {
+            while (ref_pos < m.second[cur_meth] && read_pos < length) {
+                ct_convert_base(tmpl, read_pos, m.rate[cur_meth], d);
+                ++ref_pos;
+                ++read_pos;
+            }
+            if (++cur_meth < n) {
+                read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
+                ref_pos = m.first[cur_meth];
+            }
+        }
+    }
+}
 
 struct EmptySrc {                       // adapter-only pair: org_seq_ = "" (Simulator.cpp:2369-2371)
     RSQ_HD uint32_t org_len() const { return 0; }
@@ -932,8 +1019,20 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
     src.reverse = seg != f.strand;                                              // block.at(strand) = start_block
     src.first = src.reverse ? end : f.start;
     src.sys_ = src.reverse ? S.sys_rev + S.seq_base_off[f.seq] + (L - end) : S.sys_fwd + S.seq_base_off[f.seq] + f.start;
+    src.converted = nullptr;
     return src;
 }
+// The converted template of mate `seg` of fragment f (CTConversion's dispatcher, Simulator.cpp:2219-2247): the forward mate is
+// converted from the start position on, the reverse mate from the end position on (`reversed`).
+RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, uint64_t *tmpl, uint32_t template_words) {
+    const FragmentSrc src = fragment_src(S, f, seg);
+    for (uint32_t w = 0; w < template_words; ++w) tmpl[w] = 0;
+    for (uint32_t k = 0; k < src.len; ++k) tmpl[k >> 5] |= (uint64_t)src.ref(k) << ((k & 31u) * 2u);
+    const MethView m = meth_view(S, f.seq);
+    MethDraws d{S.seed, f.start, f.seq, f.len, (kDomMethylation << 28) | ((src.reverse ? 1u : 0u) << 27), 0xFFFFFFFFu, Words{0, 0, 0, 0}};
+    ct_conversion(tmpl, src.len, m, src.first, meth_start_index(m, f.start), src.reverse, d);
+}
+
 template <class Tab>
 RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
@@ -1007,7 +1106,8 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
                        c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
         const uint32_t strand = from_fragment ? f.strand : 0u;
         const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg)};
-        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd};      // len 0 = empty template
+        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr};      // len 0 = empty template
+        if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
         ReadMachine m;
         ReadMeta meta;
         if constexpr (MASK == 0) {
@@ -1030,6 +1130,14 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
             sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta);       // bytes of its FASTQ record
         }
     }
+}
+
+// --methylation: one lane per read writes its converted template before the read kernel runs
+__global__ void __launch_bounds__(256) k_methylation_templates(DevSim S, const Fragment *frags, uint64_t n_pairs, RawLayout raw) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2u * n_pairs) return;
+    const uint32_t seg = r >= n_pairs ? 1u : 0u;
+    convert_template(S, frags[r - seg * n_pairs], seg, raw.templates + r * raw.template_words, raw.template_words);
 }
 
 __global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs, const uint8_t *segs,

@@ -39,7 +39,7 @@ struct SimState {
     DevSim dev{};
     NameTable names{};
     uint16_t *sys_fwd = nullptr, *sys_rev = nullptr, *adapter_sys[2] = {nullptr, nullptr};   // written by the chain pre-pass
-    uint32_t rmax = 0, read_stride = 0, ops_stride = 0, max_adapter = 0;
+    uint32_t rmax = 0, read_stride = 0, ops_stride = 0, max_adapter = 0, template_words = 0;
     // prepare() results
     bool prepared = false;
     uint64_t seed = 0, total_pairs = 0, adapter_only_pairs = 0;
@@ -550,6 +550,24 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
                 else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
             }
         }
+}
+
+// --methylation (Reference::PrepareMethylationFile / ReadMethylation, Simulator.cpp:2770-2780): regions as CSR on the device
+inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
+    std::vector<uint32_t> ptr{0}, first, second;
+    std::vector<double> rate;
+    for (size_t i = 0; i < m.first.size(); ++i) {
+        first.insert(first.end(), m.first[i].begin(), m.first[i].end());
+        second.insert(second.end(), m.second[i].begin(), m.second[i].end());
+        rate.insert(rate.end(), m.rate[i].begin(), m.rate[i].end());
+        ptr.push_back((uint32_t)first.size());
+    }
+    s.dev.meth_ptr = up.put(ptr);
+    s.dev.meth_first = up.put(first);
+    s.dev.meth_second = up.put(second);
+    s.dev.meth_rate = up.put(rate);
+    s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;          // GetOrgSeq: at most Rmax + MaxLenDeletion bases
+    if (s.template_words > kTemplateWordsMax) throw Error("templates longer than 2048 bases are not supported with --methylation");
 }
 
 // --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335).  Units consume the

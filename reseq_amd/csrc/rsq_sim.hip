@@ -107,7 +107,7 @@ struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
     // workspace of the hot path (grow-only)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap;
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -228,7 +228,7 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     s.raw_qual.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
     s.raw_ops.reserve((uint64_t)s.ops_stride * pitch * 4 + 16);
     s.raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
-    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch};
+    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0};
 }
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
@@ -271,6 +271,13 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     s.sizes.reserve(2 * n_pairs * 4 + 16);
     s.off_r1.reserve((n_pairs + 1) * 8);
     s.off_r2.reserve((n_pairs + 1) * 8);
+    if (frags && s.dev.meth_ptr) {                                   // --methylation: CTConversion of both mates' templates first
+        s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
+        raw.templates = s.templates.as<uint64_t>();
+        raw.template_words = s.template_words;
+        hipLaunchKernelGGL(k_methylation_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, n_pairs, raw);
+        HIP_CHECK(hipGetLastError());
+    }
     launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st);
     s.timers["scan"].start(st);
     exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
@@ -597,6 +604,14 @@ int rsq_sim_read_sys_errors(rsq_sim *s, const char *path) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         apply_sys_error_records(*s, s->up, parse_sys_error_fastq(read_text_file(path)));
+        return RSQ_OK;
+    });
+}
+int rsq_sim_read_methylation(rsq_sim *s, const char *path) {
+    REQUIRE(s && path && s->has_ref, "a simulator with a reference is needed");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        pack_methylation(*s, s->up, read_methylation_file(path, s->ref_first_names, s->seq_len));
         return RSQ_OK;
     });
 }

@@ -24,7 +24,7 @@ constexpr uint32_t kSurSize = 1u << 20;
 constexpr uint32_t kSqFragmentLengthBinSize = 10;   // QualityStats.h:15
 
 // Counter domains of the Philox streams (DESIGN.md "Random streams"); tag = c3 >> 28.
-enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5, kDomRefBias = 6 };
+enum : uint32_t { kDomSieve = 1, kDomPair = 2, kDomSysErr = 3, kDomErrModel = 4, kDomReplaceN = 5, kDomRefBias = 6, kDomMethylation = 7 };
 
 // One LogArrayResult<N>: K outcome columns, NM = N-1 conditioning margins.
 // margin n: rows[n] rows of stride kp = row_stride(K) doubles at pool[off[n]] (zero pad columns up to whole
@@ -162,6 +162,10 @@ struct DevSim {
     uint32_t total_blocks;
     const uint32_t *block_seq;       // [total_blocks+1] sequence of block id b (index b, 1-based)
     const uint32_t *first_block;     // [n_seqs]
+    // bisulfite conversion (--methylation): unmethylated regions [first, second) of every sequence as CSR, C->T probability each
+    const uint32_t *meth_ptr;        // [n_seqs + 1], nullptr without a methylation file
+    const uint32_t *meth_first, *meth_second;
+    const double *meth_rate;
 };
 
 struct NameTable {                       // first parts of the reference ids + the record base identifier

@@ -45,6 +45,7 @@ def emu_lib():
         L.emu_create_sys_error_profile.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
         L.emu_read_sys_errors.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_set_ref_bias_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_read_methylation.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_get_ref_seq_bias.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_get_codes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_sieve.restype = C.c_int64
@@ -125,6 +126,9 @@ class EmuBackend:
 
     def set_ref_bias_file(self, path):
         _ok(self.L.emu_set_ref_bias_file(self.h, str(path).encode()))
+
+    def read_methylation(self, path):
+        _ok(self.L.emu_read_methylation(self.h, str(path).encode()))
 
     def ref_seq_bias(self, n_sequences):
         out = np.zeros(n_sequences, np.float64)
@@ -222,6 +226,9 @@ class GpuBackend:
 
     def set_ref_bias_file(self, path):
         self.sim.set_ref_bias_file(path)
+
+    def read_methylation(self, path):
+        self.sim.read_methylation(path)
 
     def ref_seq_bias(self, n_sequences):
         return self.sim.ref_seq_bias(n_sequences)

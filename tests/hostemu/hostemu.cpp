@@ -282,6 +282,13 @@ int emu_read_sys_errors(void *h, const char *path) {
         return 0;
     });
 }
+int emu_read_methylation(void *h, const char *path) {
+    return guard([&] {
+        Emu &s = *static_cast<Emu *>(h);
+        pack_methylation(s, s.up, read_methylation_file(path, s.ref_first_names, s.seq_len));
+        return 0;
+    });
+}
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;
@@ -354,8 +361,14 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 if (frags) {
                     const Fragment &f = frags[pair];
                     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
+                    FragmentSrc src = fragment_src(s.dev, f, seg);
+                    uint64_t tmpl[kTemplateWordsMax];
+                    if (s.dev.meth_ptr) {                       // what k_methylation_templates does for this read
+                        convert_template(s.dev, f, seg, tmpl, s.template_words);
+                        src.converted = tmpl;
+                    }
                     run_read(s, seg, Stream{s.dev.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)}, draw_tile(s.dev, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2)),
-                             f.len, fragment_src(s.dev, f, seg), out, meta);
+                             f.len, src, out, meta);
                 } else {
                     const uint64_t i = adapter_first + pair;
                     run_read(s, seg, Stream{s.dev.seed, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, seg)},

@@ -113,6 +113,7 @@ def lib():
         "orc_compress_sys_error_rate": (C.c_uint8, [C.c_uint8]),
         "orc_expand_sys_error_rate": (C.c_uint8, [C.c_uint8]),
         "orc_create_sys_error_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Text)]),
+        "orc_sim_read_methylation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
         "orc_sim_load_sys_errors": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "orc_sim_free": (None, [C.c_void_p]),
         "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),
@@ -207,6 +208,11 @@ class Sim:
 
     def ref_seq_bias(self):
         return np.ctypeslib.as_array(lib().orc_sim_ref_seq_bias(self.h), shape=(len(self.reference.seqs),)).copy()
+
+    def read_methylation(self, path):
+        err = C.create_string_buffer(2048)
+        if lib().orc_sim_read_methylation(self.h, str(path).encode(), err, len(err)):
+            raise RuntimeError(err.value.decode())
 
     def load_sys_errors(self, text):
         err = C.create_string_buffer(1024)

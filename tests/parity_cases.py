@@ -297,3 +297,51 @@ def case_ref_bias_modes(backend_cls, workdir):
     bias_file.write_text(f"{names[0]}\t2.25\n")
     with pytest.raises(Exception, match="[Cc]ould not find bias|errors"):
         Pair(backend_cls, workdir, "refbias", synth.TINY, lengths, seed=23, num_pairs=1500, ref_bias_mode=3, ref_bias_file=bias_file)
+
+
+def case_methylation(backend_cls, workdir):
+    """--methylation without variants (CTConversion, Simulator.cpp:1925-2002,2219-2247; ReadMethylation, Reference.cpp:1177-1310):
+    C->T inside the listed regions with probability 1 - methylation, shared by the duplicates of a site; the reverse walk never
+    reaches region 0 and read_pos is 16 bits wide, both as in the reference"""
+    lengths = [70000, 90, 4000]
+    p = Pair(backend_cls, workdir, "meth", synth.TINY, lengths, seed=29, num_pairs=60000)
+    try:
+        names = [n.split(" ")[0] for n, _ in p.seqs]
+        bed = workdir / "meth.bed"
+        bed.write_text("track name=test\n\n"
+                       f"{names[0]}\t0\t400\t0.0\n{names[0]}\t420\t421\t0.5\n{names[0]} 900 1500 0.25\n\n{names[0]}\t66500\t69000\t0.0\n"
+                       f"{names[2]}\t100\t3900\t1.0\n")
+        p.b.read_methylation(bed)
+        p.osim.read_methylation(bed)
+        p.align_normalization()
+        tb = p.info["total_blocks"]
+        n_a, text_a = _compare_blocks(p, 1, 3)                 # regions 0..2: fully unmethylated start, a single base, a quarter methylated
+        n_b, _ = _compare_blocks(p, 66, 71)                    # 65 kb after the previous region: read_pos wraps in the forward walk
+        n_c, text_c = _compare_blocks(p, 71, tb + 1)           # sequence 2: methylation 1.0, nothing converts
+        assert n_a > 500 and n_b > 500 and n_c > 500
+        # forward-strand first mates that start inside [0, 400) are fully converted there: no C survives in the template part
+        plain = Pair(backend_cls, workdir, "meth", synth.TINY, lengths, seed=29, num_pairs=60000)
+        try:
+            plain.align_normalization()
+            _, text_plain_a = _compare_blocks(plain, 1, 3)
+            _, text_plain_c = _compare_blocks(plain, 71, tb + 1)
+        finally:
+            plain.close()
+        assert text_c == text_plain_c                          # methylation 1.0 == no file
+        assert text_a != text_plain_a and text_a.count(b"C") < text_plain_a.count(b"C")
+        assert len(text_a.split(b"\n")) == len(text_plain_a.split(b"\n"))
+    finally:
+        p.close()
+    import pytest
+    for bad, msg in ((f"{names[0]}\t10\t5\t0.5\n", "Third field is smaller"), (f"{names[0]}\t10\t20\t0.5\n{names[0]}\t15\t30\t0.5\n", "overlapping"),
+                     (f"{names[0]}\t10\t20\t1.5\n", "not between 0 and 1"), (f"{names[0]}\t10\t20\n", "alleles specified"),
+                     (f"{names[0]}\t10\t70001\t0.5\n", "larger than sequence length")):
+        bed.write_text(bad)
+        q = Pair(backend_cls, workdir, "meth", synth.TINY, lengths, seed=29, num_pairs=100)
+        try:
+            with pytest.raises(Exception, match=msg):
+                q.b.read_methylation(bed)
+            with pytest.raises(RuntimeError, match=msg):
+                q.osim.read_methylation(bed)
+        finally:
+            q.close()

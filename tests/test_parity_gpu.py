@@ -104,3 +104,7 @@ def test_cli_write_then_read_sys_error_profile(workdir):
     assert prof.read_bytes().count(b"\n") == 16
     r = subprocess.run(common + ["-1", a1, "-2", a2, "--writeSysError", str(prof), "--readSysError", str(prof)], capture_output=True)
     assert r.returncode != 0 and b"mutually exclusive" in r.stderr
+
+
+def test_methylation(workdir):
+    P.case_methylation(GpuBackend, workdir)

@@ -122,3 +122,7 @@ def test_sys_error_profile_rejects_wrong_reference(workdir):
 
 def test_ref_bias_modes(workdir):
     P.case_ref_bias_modes(EmuBackend, workdir)
+
+
+def test_methylation(workdir):
+    P.case_methylation(EmuBackend, workdir)
