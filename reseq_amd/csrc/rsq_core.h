@@ -253,12 +253,51 @@ RSQ_HD uint32_t ref_gc_count(const uint64_t *__restrict__ words, uint64_t word_o
     return gc;
 }
 
+// the same count from the per-word running totals built by pack_reference (gc_prefix[w] = G/C in words [0, w) of the sequence):
+// four independent loads instead of a loop over up to 32 words
+RSQ_HD uint32_t gc_low(uint64_t x, uint32_t n_bases) {            // G/C among the lowest n_bases (< 32) bases of a word
+    const uint64_t g = (x ^ (x >> 1)) & 0x5555555555555555ull & ((1ull << (2u * n_bases)) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(g);
+#else
+    return (uint32_t)__builtin_popcountll(g);
+#endif
+}
+RSQ_HD uint32_t ref_gc_count_prefix(const uint64_t *__restrict__ words, const uint32_t *__restrict__ gc_prefix, uint64_t word_off, uint32_t a, uint32_t b) {
+    const uint32_t wa = a >> 5, wb = b >> 5;
+    return gc_prefix[word_off + wb] - gc_prefix[word_off + wa] + gc_low(words[word_off + wb], b & 31u) - gc_low(words[word_off + wa], a & 31u);
+}
+
 // ----------------------------------------------------------------------------------------- Surrounding
 // SurroundingBase.hpp:64-81,196-202: block b of the start surrounding is the 10-mer ref[pos-10+10b ..), wrapping
 // around the sequence ends; the end surrounding is taken on the reverse complement at position L-1-pos.
+// 60 bits = 30 bases starting at base p of the sequence (p + 30 <= L): at most two words
+RSQ_HD uint64_t ref_bits60(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t p) {
+    const uint64_t *w = words + word_off + (p >> 5);
+    const uint32_t off = (p & 31u) * 2u;
+    uint64_t x = w[0] >> off;
+    if (off > 4u) x |= w[1] << (64u - off);                       // the sequence's spare word makes w[1] readable
+    return x & ((1ull << 60) - 1ull);
+}
+// ten bases packed first-base-lowest -> the reference's code with the first base most significant
+RSQ_HD uint32_t reverse_ten_bases(uint32_t g) {
+    uint32_t r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r = __brev(g) >> 12;
+#else
+    for (uint32_t i = 0; i < 20u; ++i) r |= ((g >> i) & 1u) << (19u - i);
+#endif
+    return ((r & 0x55555u) << 1) | ((r >> 1) & 0x55555u);         // the two bits of every base back in order
+}
 RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
     uint64_t p = (uint64_t)pos + L - kSurStart;                    // < 2L: one conditional subtraction replaces the reference's % length
     if (p >= L) p -= L;
+    if (p + kSurBlocks * kSurRange <= L) {                         // no wrap-around: two loads instead of thirty
+        const uint64_t x = ref_bits60(words, word_off, (uint32_t)p);
+#pragma unroll
+        for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = reverse_ten_bases((uint32_t)(x >> (20u * b)) & 0xFFFFFu);
+        return;
+    }
 #pragma unroll
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
@@ -274,6 +313,12 @@ RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t wor
     uint64_t q = (uint64_t)(L - pos - 1) + L - kSurStart;
     if (q >= L) q -= L;
     uint32_t f = L - 1u - (uint32_t)q;                             // forward position, walks downwards with wrap-around
+    if (f + 1u >= kSurBlocks * kSurRange) {                        // no wrap-around: block b is the complement of forward bases f-10b-9 .. f-10b
+        const uint64_t x = ref_bits60(words, word_off, f + 1u - kSurBlocks * kSurRange);
+#pragma unroll
+        for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = ~(uint32_t)(x >> (20u * (kSurBlocks - 1u - b))) & 0xFFFFFu;
+        return;
+    }
 #pragma unroll
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;

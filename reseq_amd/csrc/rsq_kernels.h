@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *par
     double sum = 0.0, mx = 0.0;
     if (first < n_starts) {
         const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
-        uint32_t gc = ref_gc_count(S.ref_words, wo, first, first + p.len);
+        uint32_t gc = ref_gc_count_prefix(S.ref_words, S.gc_prefix, wo, first, first + p.len);
         for (uint32_t start = first; start < last; ++start) {
             const double bias = site_bias(S, wo, L, start, p.len, gc, p.general_bias);
             sum += bias;
@@ -221,7 +221,7 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, doubl
     }
     uint32_t sur_end[3];
     surrounding_reverse(S.ref_words, site.word_off, site.L, end - 1u, sur_end);     // :1820-1832
-    const uint32_t gc = percent_u32(ref_gc_count(S.ref_words, site.word_off, site.start, end), len);   // :1858-1873
+    const uint32_t gc = percent_u32(ref_gc_count_prefix(S.ref_words, S.gc_prefix, site.word_off, site.start, end), len);   // :1858-1873
     uint32_t n_here = 0;
     for (uint32_t j = 0; j < n_chosen; ++j) {
         const double u = j ? u53_to_unit(w2.w2, w2.w3) : u53_to_unit(w2.w0, w2.w1);

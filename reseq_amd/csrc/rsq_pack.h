@@ -292,8 +292,21 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
             w[pos >> 5] |= (uint64_t)c[pos] << ((pos & 31) * 2);
         }
     }
+    std::vector<uint32_t> gc_prefix(words + 1, 0);                 // running G/C totals per word, restarting with every sequence
+    for (size_t i = 0; i < r.codes.size(); ++i) {
+        const size_t n_words = (r.codes[i].size() + 31) / 32;
+        uint32_t total = 0;
+        for (size_t w = 0; w <= n_words; ++w) {                    // the spare word holds the sequence total
+            gc_prefix[s.seq_word_off[i] + w] = total;
+            if (w < n_words) {
+                const uint64_t x = packed[s.seq_word_off[i] + w];
+                total += (uint32_t)__builtin_popcountll((x ^ (x >> 1)) & 0x5555555555555555ull);
+            }
+        }
+    }
     s.ref_codes = r.codes;
     d.ref_words = up.put(packed);
+    d.gc_prefix = up.put(gc_prefix);
     d.seq_word_off = up.put(s.seq_word_off);
     d.seq_len = up.put(s.seq_len);
     d.seq_base_off = up.put(s.seq_base_off);

@@ -142,6 +142,7 @@ struct DevSim {
     // ---- reference: 2 bit per base, 32 bases per uint64_t word, every sequence starts on a word
     uint32_t n_seqs;
     const uint64_t *ref_words;
+    const uint32_t *gc_prefix;       // per reference word: G/C bases in the sequence's earlier words (indexed like ref_words)
     const uint64_t *seq_word_off;    // [n_seqs]
     const uint32_t *seq_len;         // [n_seqs]
     const uint64_t *seq_base_off;    // [n_seqs] offset of the sequence in the systematic-error tracks

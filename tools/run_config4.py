@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3] restated on ONE GPU: a Drosophila-sized 143.7 Mb reference in 7
+sequences plus 1000 short scaffolds (shorter than the longest insert, so without units), profile P0, coverage 30
+(about 14.4 M pairs).  Prints one JSON line: sizes, pre-pass and generation times, checksums.  Not a bench line: a full-size
+run of the path that checks that nothing overflows and that batching does not change the output."""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from reseq_amd import api, synth  # noqa: E402
+
+BIG = [32_079_331, 28_110_227, 25_286_936, 23_542_271, 23_513_712, 7_350_000 + 3_667_352 - 1_000 * 600, 1_348_131]     # 143.7 Mb with the scaffolds
+tmp = tempfile.mkdtemp(prefix="rsq_c4_")
+ppath, fpath = os.path.join(tmp, "p0.rsqp"), os.path.join(tmp, "ref.fa")
+synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
+lengths = BIG + [600] * 1000
+t0 = time.perf_counter()
+synth.write_fasta(fpath, synth.make_reference(5, lengths, gc=0.42))
+t_make = time.perf_counter() - t0
+prof, ref = api.Profile(ppath), api.Reference(fpath, 7)
+sim = api.Simulator(prof, ref, 0)
+t0 = time.perf_counter()
+info = sim.prepare(7, 0, 30.0)
+t_prep = time.perf_counter() - t0
+nb = info.total_blocks
+r1 = r2 = None
+out = {}
+for name, batch in (("batch_4000", 4000), ("batch_1777", 1777)):
+    h1, h2, n, nbytes = hashlib.sha256(), hashlib.sha256(), 0, 0
+    t0 = time.perf_counter()
+    t_gpu = 0.0
+    for lo in range(1, nb + 1, batch):
+        hi = min(nb + 1, lo + batch)
+        if r1 is None:
+            _, l1, l2, _ = sim.pairs_device(lo, hi, None, None)
+            r1, r2 = api.DeviceArray(0, int(l1 * 1.3) + 4096), api.DeviceArray(0, int(l2 * 1.3) + 4096)
+        t1 = time.perf_counter()
+        k, l1, l2, rc = sim.pairs_device(lo, hi, r1, r2)
+        t_gpu += time.perf_counter() - t1
+        if rc != api.RSQ_OK:
+            raise SystemExit(f"rc {rc}: {api.lib().rsq_last_error().decode()}")
+        n += k
+        nbytes += l1 + l2
+        h1.update(r1.to_numpy(np.uint8, l1).tobytes())
+        h2.update(r2.to_numpy(np.uint8, l2).tobytes())
+    out[name] = {"pairs": n, "fastq_bytes": nbytes, "sha256_r1": h1.hexdigest(), "sha256_r2": h2.hexdigest(), "gpu_s": t_gpu, "wall_s_with_download_and_hash": time.perf_counter() - t0}
+same = out["batch_4000"]["sha256_r1"] == out["batch_1777"]["sha256_r1"] and out["batch_4000"]["sha256_r2"] == out["batch_1777"]["sha256_r2"]
+print(json.dumps({"config": "configs[3] Drosophila-sized, 1 GPU", "reference_bp": int(sum(lengths)), "sequences": len(lengths), "total_blocks": nb,
+                  "pairs_requested_from_coverage_30": info.total_pairs, "adapter_only_pairs": info.adapter_only_pairs, "prepare_s": t_prep,
+                  "sys_chain_passes": info.sys_chain_passes, "runs": out, "batching_invariant": same,
+                  "pairs_per_s_gpu": out["batch_4000"]["pairs"] / out["batch_4000"]["gpu_s"]}))
+sys.exit(0 if same else 1)
