@@ -1057,13 +1057,6 @@ struct RecordSrc {
     RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
     RSQ_HD uint32_t sys(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
 };
-template <class Tab>
-RSQ_HD void fill_record_read(const DevSim &S, const Tab &tab, uint64_t idx, uint32_t seg, uint32_t frag_len, const RecordSrc &src, ReadOut &out, ReadMeta &meta) {
-    const uint32_t tile = draw_tile(S, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, 2));
-    const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-    fill_read(S, tab, st, seg, tile, frag_len, src, out, meta);
-}
-
 #ifndef RSQ_FILL_BLOCK
 #define RSQ_FILL_BLOCK 768
 #endif
@@ -1074,11 +1067,9 @@ constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
 // image once, then every wave pulls chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail).
 // All lanes of a wave walk their reads' state machines in one uniform loop.  MASK = kLds* bits (0: every table access
 // goes to HBM).
+// the LDS image of the workgroup's template segment (all waves call it; returns after the final barrier)
 template <uint32_t MASK>
-__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
-                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
-    extern __shared__ __attribute__((aligned(16))) double lds_image[];
-    const uint32_t seg = blockIdx.x & 1u;
+__device__ RSQ_LDS double *fill_stage_image(const DevSim &S, double *lds_image, uint32_t seg) {
     RSQ_LDS double *img = (RSQ_LDS double *)lds_image;
     if (MASK) {
         lds_stage_descriptors(S, img, seg, threadIdx.x, blockDim.x);
@@ -1086,6 +1077,38 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         lds_stage_rows(S, img, MASK, threadIdx.x, blockDim.x);
         __syncthreads();
     }
+    return img;
+}
+// 64 reads of one wave through the state machine: one uniform step loop
+template <uint32_t MASK, class Src>
+__device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
+                                const Src &src, ReadOut &out, ReadMeta &meta) {
+    ReadMachine m;
+    if constexpr (MASK == 0) {
+        const GlobalTables tab{S};
+        if (active) {
+            m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
+            while (m.step(S, tab, st, src, out)) {}
+        }
+    } else {
+        LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{S, img, seg};
+        bool running = active;
+        if (active) m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
+        while (__any(running))
+            if (running) running = m.step(S, tab, st, src, out);
+    }
+    if (active) {
+        m.finalize(meta);
+        out.finish();
+    }
+}
+
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
+                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
+    extern __shared__ __attribute__((aligned(16))) double lds_image[];
+    const uint32_t seg = blockIdx.x & 1u;
+    const RSQ_LDS double *img = fill_stage_image<MASK>(S, lds_image, seg);
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
         uint32_t chunk = 0;
@@ -1108,28 +1131,66 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg)};
         FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr};      // len 0 = empty template
         if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
-        ReadMachine m;
         ReadMeta meta;
-        if constexpr (MASK == 0) {
-            const GlobalTables tab{S};
-            if (active) {
-                m.init(S, tab, st, seg, draw_tile(S, c0, c1, c2, pair_c3(kDomPair, strand, 2)), f.len, src);
-                while (m.step(S, tab, st, src, out)) {}
-            }
-        } else {
-            LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{S, img, seg};
-            bool running = active;
-            if (active) m.init(S, tab, st, seg, draw_tile(S, c0, c1, c2, pair_c3(kDomPair, strand, 2)), f.len, src);
-            while (__any(running))
-                if (running) running = m.step(S, tab, st, src, out);
-        }
+        fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
         if (active) {
-            m.finalize(meta);
-            out.finish();
             raw.meta[r] = meta;
             sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta);       // bytes of its FASTQ record
         }
     }
+}
+
+// seqToIllumina (ApplyErrorsAndQualityToFastaInput, Simulator.cpp:2403-2512) through the same workgroups: the records were
+// partitioned by template segment (rec_index: segment-0 records first; rec_count[2] on the device), a workgroup serves one
+// segment and its waves pull chunks of 64 records.
+struct RecordJob {
+    uint64_t first_index;
+    uint32_t read_len;
+    const uint8_t *seqs, *dom, *rate;
+    const uint32_t *frag_len;
+    const uint32_t *rec_index, *rec_count;
+};
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters) {
+    extern __shared__ __attribute__((aligned(16))) double lds_image[];
+    const uint32_t seg = blockIdx.x & 1u;
+    const RSQ_LDS double *img = fill_stage_image<MASK>(S, lds_image, seg);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_mine = job.rec_count[seg];
+    const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
+        chunk = __shfl(chunk, 0, 64);
+        const uint32_t first = chunk * 64u;
+        if (first >= n_mine) break;
+        const bool active = first + lane < n_mine;
+        const uint64_t i = index[active ? first + lane : first];
+        const uint64_t idx = job.first_index + i;
+        const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
+        const RecordSrc src{job.seqs + i * job.read_len, job.dom + i * job.read_len, job.rate + i * job.read_len, job.read_len};
+        ReadOut out = raw.out_of(i);
+        ReadMeta meta;
+        fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomErrModel, 0, 2), job.frag_len[i], src, out, meta);
+        if (active) raw.meta[i] = meta;
+    }
+}
+// the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known
+__global__ void k_record_flags(const uint8_t *segs, uint64_t n, uint32_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = segs[i] ? 1u : 0u;
+}
+__global__ void k_record_partition(const uint8_t *segs, uint64_t n, const uint64_t *ones_before, uint32_t *rec_index, uint32_t *rec_count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n1 = (uint32_t)ones_before[n], n0 = (uint32_t)n - n1;
+    if (i == 0) {
+        rec_count[0] = n0;
+        rec_count[1] = n1;
+    }
+    if (i >= n) return;
+    const uint32_t before = (uint32_t)ones_before[i];
+    if (segs[i]) rec_index[n0 + before] = (uint32_t)i;
+    else rec_index[(uint32_t)i - before] = (uint32_t)i;
 }
 
 // --methylation: one lane per read writes its converted template before the read kernel runs
@@ -1138,19 +1199,6 @@ __global__ void __launch_bounds__(256) k_methylation_templates(DevSim S, const F
     if (r >= 2u * n_pairs) return;
     const uint32_t seg = r >= n_pairs ? 1u : 0u;
     convert_template(S, frags[r - seg * n_pairs], seg, raw.templates + r * raw.template_words, raw.template_words);
-}
-
-__global__ void __launch_bounds__(64) k_error_model(DevSim S, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs, const uint8_t *segs,
-                                                   const uint32_t *frag_len, const uint8_t *dom, const uint8_t *rate, RawLayout raw) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
-    ReadOut out = raw.out_of(i);
-    ReadMeta meta;
-    const GlobalTables tab{S};
-    fill_record_read(S, tab, first_index + i, segs[i], frag_len[i], src, out, meta);
-    out.finish();
-    raw.meta[i] = meta;
 }
 
 #endif  // __HIPCC__

@@ -107,7 +107,7 @@ struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
     // workspace of the hot path (grow-only)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates;
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates, rec_flags, rec_index, rec_count;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -249,6 +249,26 @@ static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
+template <uint32_t MASK>
+static void launch_records_mask(rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st) {
+    const size_t lds_bytes = MASK ? (size_t)s.dev.lds.total_doubles * sizeof(double) : 0;
+    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_records<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;
+    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(cdiv(n, 64), kFillBlock / 64)));
+    blocks = (blocks + 1u) & ~1u;
+    s.fill_counters.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
+    s.timers["fill_reads"].start(st);
+    hipLaunchKernelGGL(k_fill_records<MASK>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.fill_counters.as<uint32_t>());
+    s.timers["fill_reads"].stop(st);
+    HIP_CHECK(hipGetLastError());
+}
+template <size_t... I>
+static void launch_records_dispatch(uint32_t mask, rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st, std::index_sequence<I...>) {
+    bool done = false;
+    ((mask == kFillMasks[I] ? (launch_records_mask<kFillMasks[I]>(s, job, n, raw, st), done = true) : false), ...);
+    if (!done) throw Error("no k_fill_records instantiation for staging mask " + std::to_string(mask));
+}
 template <size_t... I>
 static void launch_fill_dispatch(uint32_t mask, rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
                                  std::index_sequence<I...>) {
@@ -380,10 +400,18 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
     num_errors_out[i] = m.num_errors;
     tile_out[i] = m.tile_id;
     const uint32_t nb = m.read_len < out_stride ? m.read_len : out_stride;
-    for (uint32_t k = 0; k < nb; ++k) {
-        seq_out[i * out_stride + k] = (uint8_t)(raw.seq_of(i).at(k >> 2) >> (8u * (k & 3u)));
-        qual_out[i * out_stride + k] = (uint8_t)(raw.qual_of(i).at(k >> 2) >> (8u * (k & 3u)));
-    }
+    const WordColumn seq = raw.seq_of(i), qual = raw.qual_of(i);
+    if (!((out_stride | (uint32_t)(uintptr_t)seq_out | (uint32_t)(uintptr_t)qual_out) & 3u)) {      // word-aligned rows: copy words
+        uint32_t *so = reinterpret_cast<uint32_t *>(seq_out + i * out_stride), *qo = reinterpret_cast<uint32_t *>(qual_out + i * out_stride);
+        for (uint32_t w = 0; 4u * w < nb; ++w) {                   // bytes past read_len inside the last word are zero in the raw arrays
+            so[w] = seq.at(w);
+            qo[w] = qual.at(w);
+        }
+    } else
+        for (uint32_t k = 0; k < nb; ++k) {
+            seq_out[i * out_stride + k] = (uint8_t)(seq.at(k >> 2) >> (8u * (k & 3u)));
+            qual_out[i * out_stride + k] = (uint8_t)(qual.at(k >> 2) >> (8u * (k & 3u)));
+        }
     if (m.cigar_chars + 1u > cigar_stride || m.read_len > out_stride) {
         *overflow = 1;
         cigar_out[i * cigar_stride] = 0;
@@ -660,11 +688,21 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
         // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
         const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
         if (need_ops > s->ops_stride) s->ops_stride = need_ops;
+        if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
         RawLayout raw = raw_layout(*s, n);
-        s->timers["fill_reads"].start(st);
-        hipLaunchKernelGGL(k_error_model, dim3(cdiv(n, 64)), dim3(64), 0, st, s->dev, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, raw);
-        s->timers["fill_reads"].stop(st);
+        // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS
+        s->rec_flags.reserve(n * 4 + 16);
+        s->rec_index.reserve(n * 4 + 16);
+        s->rec_count.reserve(8);
+        s->offsets.reserve((n + 1) * 8);
+        const dim3 rgrid(cdiv(n, 256)), rblock(256);
+        hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
+        exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
+        hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
+        const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>()};
+        launch_records_dispatch(effective_fill_mask(s->dev.lds.mask, s->force_fill_mode), *s, job, n, raw, st,
+                                std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
         s->scan_total.reserve(8);
         HIP_CHECK(hipMemsetAsync(s->scan_total.as<uint32_t>(), 0, 4, st));
         hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,

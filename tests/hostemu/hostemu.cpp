@@ -387,7 +387,7 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
     });
 }
 
-// k_error_model + k_error_model_out
+// k_fill_records + k_error_model_out
 int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs, const uint8_t *segs, const uint32_t *frag_len, const uint8_t *dom,
                     const uint8_t *rate, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *nerr_out, uint16_t *tile_out,
                     char *cigar_out, uint32_t cigar_stride) {
@@ -399,7 +399,10 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
             ReadOut out = raw.out(s);
             ReadMeta m;
             RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
-            fill_record_read(s.dev, GlobalTables{s.dev}, first_index + i, segs[i], frag_len[i], src, out, m);
+            const uint64_t idx = first_index + i;              // as a lane of k_fill_records<MASK> runs it
+            const uint32_t seg = segs[i];
+            run_read(s, seg, Stream{s.dev.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)},
+                     draw_tile(s.dev, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, 2)), frag_len[i], src, out, m);
             out.finish();
             read_len_out[i] = m.read_len;
             nerr_out[i] = m.num_errors;
