@@ -73,12 +73,52 @@ void orc_reference_free(orc_reference *r) {
     free(r->len);
     free(r);
 }
-/* Reference.cpp:813-: every N becomes a uniform base.  (The reference fills stretches of >= kMinNToReplaceNWithRepeat
- * N with a drawn short repeat; that branch is not restated -- such references are rejected by the product.) */
+/* Reference::ReplaceN (Reference.cpp:813-886): short stretches of N become uniform bases, stretches of kMinNToReplaceNWithRepeat
+ * (100) or more a four-base repeat built from the flanks.  The draw for position p is Philox(seed; p, sequence, 0, 5<<28).w0 & 3
+ * (the reference consumes one mt19937_64 stream in order). */
 void orc_reference_replace_n(orc_reference *r, uint64_t seed) {
-    for (uint32_t s = 0; s < r->n_seqs; ++s)
-        for (uint32_t pos = 0; pos < r->len[s]; ++pos)
-            if (r->codes[s][pos] > 3) r->codes[s][pos] = (uint8_t)(orc_philox4x32_10(seed, pos, s, 0, (uint32_t)ORC_DOM_REPLACEN << 28).w[0] & 3u);
+#define DRAW(pos) ((uint8_t)(orc_philox4x32_10(seed, (uint32_t)(pos), s, 0, (uint32_t)ORC_DOM_REPLACEN << 28).w[0] & 3u))
+    for (uint32_t s = 0; s < r->n_seqs; ++s) {
+        uint8_t *seq = r->codes[s];
+        uint32_t len = r->len[s];
+        for (uint32_t start = 0; start < len;) {
+            if (seq[start] <= 3) {
+                ++start;
+                continue;
+            }
+            uint32_t end = start;                                       /* :822-823 */
+            while (++end < len && seq[end] > 3) {}
+            if (end - start < 100) {                                    /* :826-831 */
+                for (uint32_t pos = start; pos < end; ++pos) seq[pos] = DRAW(pos);
+            } else {
+                uint8_t short_repeat[4];
+                if (2 > start) {
+                    if (end + 4 > len) {                                /* :838-842 */
+                        for (uint32_t k = 0; k < 4; ++k) short_repeat[k] = DRAW(start + k);
+                    } else {                                            /* :845-852 */
+                        for (uint32_t k = 0; k < 4; ++k) short_repeat[k] = seq[end + k];
+                        for (uint32_t pos = 4; --pos;)
+                            if (short_repeat[pos] > 3) short_repeat[pos] = DRAW(end + pos);
+                    }
+                } else if (end + 2 > len) {
+                    if (4 > start) {                                    /* :857-861 */
+                        for (uint32_t k = 0; k < 4; ++k) short_repeat[k] = DRAW(start + k);
+                    } else {                                            /* :864-865 */
+                        for (uint32_t k = 0; k < 4; ++k) short_repeat[k] = seq[start - 4 + k];
+                    }
+                } else {                                                /* :869-876 */
+                    short_repeat[0] = seq[end];
+                    short_repeat[1] = seq[end + 1];
+                    short_repeat[2] = seq[start - 2];
+                    short_repeat[3] = seq[start - 1];
+                    if (short_repeat[1] > 3) short_repeat[1] = DRAW(end + 1);
+                }
+                for (uint32_t pos = start; pos < end; ++pos) seq[pos] = short_repeat[(pos - start) % 4];   /* :880-882 */
+            }
+            start = end;
+        }
+    }
+#undef DRAW
 }
 
 /* --------------------------------------------------------- systematic errors */

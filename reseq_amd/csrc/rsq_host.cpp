@@ -249,9 +249,14 @@ std::string Reference::first_part(size_t i) const {
 // Reference.cpp:813-: N's are replaced so that every simulation from a position sees the same base.  The random
 // source is Philox keyed by (seed, sequence, position) instead of one mt19937_64 stream.  Stretches of at least
 // kMinNToReplaceNWithRepeat (100) N, which the reference fills with a 4-base repeat, are rejected for now.
+// Reference.cpp:813-886.  Stretches of fewer than kMinNToReplaceNWithRepeat (100) N become uniform bases; longer stretches are filled
+// with a four-base repeat taken from the flanks (two bases after and two before the stretch; four after it at the sequence start,
+// four before it at the end; drawn when the stretch is the whole sequence).  The draw of position p is Philox word w0 & 3 of
+// counter (p, sequence, 0, 5<<28), also when p lies in a flank that is itself N.
 void Reference::replace_n(uint64_t seed) {
     for (size_t s = 0; s < codes.size(); ++s) {
         std::vector<uint8_t> &c = codes[s];
+        auto draw = [&](size_t pos) { return (uint8_t)(philox(seed, (uint32_t)pos, (uint32_t)s, 0, kDomReplaceN << 28).w0 & 3u); };
         for (size_t start = 0; start < c.size();) {
             if (c[start] <= 3) {
                 ++start;
@@ -259,8 +264,33 @@ void Reference::replace_n(uint64_t seed) {
             }
             size_t end = start;
             while (++end < c.size() && c[end] > 3) {}
-            if (end - start >= 100) throw Error("reference contains a stretch of >= 100 N; run `reseq replaceN` of the reference tool first");
-            for (size_t pos = start; pos < end; ++pos) c[pos] = (uint8_t)(philox(seed, (uint32_t)pos, (uint32_t)s, 0, kDomReplaceN << 28).w0 & 3u);
+            if (end - start < 100) {
+                for (size_t pos = start; pos < end; ++pos) c[pos] = draw(pos);
+            } else {
+                uint8_t rep[4];
+                if (2 > start) {
+                    if (end + 4 > c.size()) {
+                        for (size_t k = 0; k < 4; ++k) rep[k] = draw(start + k);                 // the stretch is the complete sequence
+                    } else {
+                        for (size_t k = 0; k < 4; ++k) rep[k] = c[end + k];                       // N's at the start of the sequence
+                        for (size_t k = 4; --k;)
+                            if (rep[k] > 3) rep[k] = draw(end + k);
+                    }
+                } else if (end + 2 > c.size()) {
+                    if (4 > start) {
+                        for (size_t k = 0; k < 4; ++k) rep[k] = draw(start + k);
+                    } else {
+                        for (size_t k = 0; k < 4; ++k) rep[k] = c[start - 4 + k];                 // N's at the end of the sequence
+                    }
+                } else {                                                                        // N's in the middle
+                    rep[0] = c[end];
+                    rep[1] = c[end + 1];
+                    rep[2] = c[start - 2];
+                    rep[3] = c[start - 1];
+                    if (rep[1] > 3) rep[1] = draw(end + 1);
+                }
+                for (size_t pos = start; pos < end; ++pos) c[pos] = rep[(pos - start) % 4];
+            }
             start = end;
         }
     }

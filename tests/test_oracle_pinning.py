@@ -258,3 +258,42 @@ def test_sys_error_rate_compression_formulas():
     for q in range(101):
         back = L.orc_expand_sys_error_rate(L.orc_compress_sys_error_rate(q))
         assert back == (q if q <= 86 or q % 2 == 0 else q - 1)
+
+
+def test_replace_n_repeat_fill_matches_the_product_host_code(workdir):
+    """Reference::ReplaceN (Reference.cpp:813-886): every branch of the long-stretch repeat fill -- middle of a sequence (two bases
+    after, two before), start, end, complete sequence, and an N inside the flank -- gives the same bases in the oracle and in the
+    product's host code (rsq_ref_replace_n needs no GPU); the middle case is checked against the rule itself"""
+    from reseq_amd import api, synth
+    rng = np.random.default_rng(3)
+    def acgt(n):
+        return rng.integers(0, 4, n).astype(np.uint8)
+    n = lambda k: np.full(k, 4, np.uint8)
+    seqs = [("mid", np.concatenate([acgt(50), n(130), acgt(40), n(99), acgt(7)])),
+            ("start", np.concatenate([n(101), acgt(30)])),
+            ("start1", np.concatenate([acgt(1), n(100), acgt(1), n(2), acgt(20)])),        # N inside the four bases after the stretch
+            ("end", np.concatenate([acgt(30), n(140)])),
+            ("end_short", np.concatenate([acgt(3), n(100), acgt(1)])),
+            ("all", n(120)),
+            ("mid_n_flank", np.concatenate([acgt(10), n(100), acgt(1), n(3), acgt(10)]))]
+    path = workdir / "long_n.fa"
+    synth.write_fasta(path, seqs)
+    ref = api.Reference(str(path), 77)
+    oref = O.Reference(seqs)
+    O.lib().orc_reference_replace_n(oref.h, 77)
+    for i, (name, codes) in enumerate(seqs):
+        got = ref.codes(i)
+        exp = np.ctypeslib.as_array(C.cast(oref_codes(oref, i), O.u8p), shape=(len(codes),))
+        assert got.max() <= 3 and np.array_equal(got, exp), name
+    mid = ref.codes(0)
+    rep = [mid[180], mid[181], mid[48], mid[49]]
+    assert mid[50:180].tolist() == [rep[k % 4] for k in range(130)]
+    assert not np.array_equal(mid[220:319], np.resize(mid[220:224], 99))                   # 99 N: drawn, no repeat
+    ref.close()
+    oref.close()
+
+
+def oref_codes(oref, i):
+    class _R(C.Structure):
+        _fields_ = [("n_seqs", C.c_uint32), ("len", O.u32p), ("codes", C.POINTER(O.u8p))]
+    return C.cast(oref.h, C.POINTER(_R)).contents.codes[i]
