@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
 
 #include <fstream>
 #include <iostream>
@@ -116,6 +119,56 @@ bool load_profile(const Args &a, rsq_profile **p) {
     return true;
 }
 
+// FASTQ / FASTA text files: gzip when the name ends in .gz (SeqAn's SeqFileOut / SeqFileIn pick the format the same way)
+struct TextOut {
+    FILE *plain = nullptr;
+    gzFile gz = nullptr;
+    bool failed = false;
+    bool open(const std::string &path) {
+        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) gz = gzopen(path.c_str(), "wb");
+        else plain = fopen(path.c_str(), "wb");
+        return plain || gz;
+    }
+    void write(const char *data, size_t n) {
+        if (gz) {
+            for (size_t done = 0; done < n && !failed;) {
+                const unsigned chunk = (unsigned)std::min<size_t>(n - done, 1u << 30);
+                failed = gzwrite(gz, data + done, chunk) != (int)chunk;
+                done += chunk;
+            }
+        } else if (plain) failed = failed || fwrite(data, 1, n, plain) != n;
+        else fwrite(data, 1, n, stdout);
+    }
+    bool good() const { return !failed; }
+    void close() {
+        if (gz) failed = (gzclose(gz) != Z_OK) || failed;
+        if (plain) failed = (fclose(plain) != 0) || failed;
+        gz = nullptr;
+        plain = nullptr;
+    }
+};
+struct TextIn {                       // lines of a plain or gzip file, or of stdin
+    gzFile gz = nullptr;
+    std::vector<char> buf = std::vector<char>(1 << 16);
+    bool open(const std::string &path) { return (gz = gzopen(path.c_str(), "rb")) != nullptr; }
+    bool getline(std::string &line) {
+        if (!gz) return (bool)std::getline(std::cin, line);
+        line.clear();
+        while (gzgets(gz, buf.data(), (int)buf.size())) {
+            line += buf.data();
+            if (!line.empty() && line.back() == '\n') {
+                line.pop_back();
+                return true;
+            }
+        }
+        return !line.empty();
+    }
+    void close() {
+        if (gz) gzclose(gz);
+        gz = nullptr;
+    }
+};
+
 struct DevBuffer {
     void *p = nullptr;
     size_t cap = 0;
@@ -133,12 +186,12 @@ struct DevBuffer {
     }
 };
 
-bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<char> &h, std::ofstream &f1, std::ofstream &f2) {
+bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<char> &h, TextOut &f1, TextOut &f2) {
     h.resize(std::max(l1, l2) + 1);
     if (!check(rsq_dev_download(0, h.data(), d1.p, l1), "download")) return false;
-    f1.write(h.data(), (std::streamsize)l1);
+    f1.write(h.data(), l1);
     if (!check(rsq_dev_download(0, h.data(), d2.p, l2), "download")) return false;
-    f2.write(h.data(), (std::streamsize)l2);
+    f2.write(h.data(), l2);
     return f1.good() && f2.good();
 }
 
@@ -215,12 +268,11 @@ int illumina_pe(const Args &a) {
                    "Preparation failed");
     }
     if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
-    std::ofstream f1, f2;
+    TextOut f1, f2;
     if (ok) {
-        f1.open(out1, std::ios::binary);
-        f2.open(out2, std::ios::binary);
-        if (!f1 || !f2) {
-            ERR("Could not open '" << (f1 ? out2 : out1) << "' for writing.");
+        const bool o1 = f1.open(out1), o2 = f2.open(out2);
+        if (!o1 || !o2) {
+            ERR("Could not open '" << (o1 ? out2 : out1) << "' for writing.");
             ok = false;
         }
     }
@@ -259,6 +311,7 @@ int illumina_pe(const Args &a) {
     }
     f1.close();
     f2.close();
+    ok = ok && f1.good() && f2.good();
     rsq_sim_free(sim);
     rsq_ref_free(ref);
     rsq_profile_free(prof);
@@ -329,7 +382,7 @@ int code_of(char c) {
     }
 }
 
-bool run_batch(rsq_sim *sim, uint64_t first_index, const std::vector<Record> &recs, uint32_t max_read, uint8_t phred_unused, std::ostream &out) {
+bool run_batch(rsq_sim *sim, uint64_t first_index, const std::vector<Record> &recs, uint32_t max_read, uint8_t phred_unused, TextOut &out) {
     (void)phred_unused;
     const size_t n = recs.size(), L = recs[0].seq.size();
     std::vector<uint8_t> seqs(n * L), seg(n), dom(n * L), rate(n * L);
@@ -383,7 +436,7 @@ bool run_batch(rsq_sim *sim, uint64_t first_index, const std::vector<Record> &re
         buf.append((const char *)&oqual[i * stride], rlen[i]);
         buf += '\n';
     }
-    out << buf;
+    out.write(buf.data(), buf.size());
     return out.good();
 }
 
@@ -396,25 +449,15 @@ int seq_to_illumina(const Args &a) {
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
     uint32_t max_read = 0;
     if (ok) rsq_profile_max_read_length(prof, &max_read);
-    std::ifstream fin;
-    std::ofstream fout;
-    std::istream *in = &std::cin;
-    std::ostream *out = &std::cout;
-    if (ok && a.has("input")) {
-        fin.open(a.get("input"));
-        if (!fin) {
-            ERR("Could not open '" << a.get("input") << "' for reading.");
-            ok = false;
-        }
-        in = &fin;
+    TextIn fin;                                              // stdin / stdout without -i / -o (main.cpp:1009-1021)
+    TextOut fout;
+    if (ok && a.has("input") && !fin.open(a.get("input"))) {
+        ERR("Could not open '" << a.get("input") << "' for reading.");
+        ok = false;
     }
-    if (ok && a.has("output")) {
-        fout.open(a.get("output"), std::ios::binary);
-        if (!fout) {
-            ERR("Could not open '" << a.get("output") << "' for writing.");
-            ok = false;
-        }
-        out = &fout;
+    if (ok && a.has("output") && !fout.open(a.get("output"))) {
+        ERR("Could not open '" << a.get("output") << "' for writing.");
+        ok = false;
     }
     if (ok) {
         INFO("Starting read generation");
@@ -424,7 +467,7 @@ int seq_to_illumina(const Args &a) {
         bool any = false;
         auto flush = [&]() {
             if (batch.empty()) return true;
-            const bool r = run_batch(sim, first_index, batch, max_read, 0, *out);
+            const bool r = run_batch(sim, first_index, batch, max_read, 0, fout);
             written += batch.size();
             first_index += batch.size();
             batch.clear();
@@ -442,7 +485,7 @@ int seq_to_illumina(const Args &a) {
             any = true;
             return true;
         };
-        while (ok && std::getline(*in, line)) {
+        while (ok && fin.getline(line)) {
             if (!line.empty() && line.back() == '\r') line.pop_back();
             if (!line.empty() && line[0] == '>') {
                 ok = finish_record();
@@ -456,7 +499,9 @@ int seq_to_illumina(const Args &a) {
             ok = false;
         }
     }
+    fin.close();
     fout.close();
+    ok = ok && fout.good();
     rsq_sim_free(sim);
     rsq_profile_free(prof);
     if (!ok) {

@@ -3,6 +3,9 @@
 #include "rsq_host.h"
 
 #include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
 
 #include <fstream>
 
@@ -196,9 +199,42 @@ void Profile::remove_indel_errors() {
 }
 
 // ---------------------------------------------------------------------------------------------- reference
+namespace {
+// plain or gzip-compressed text (zlib reads both through the same calls; SeqAn picks the format the same way)
+struct GzLines {
+    gzFile f;
+    std::vector<char> buf;
+    size_t at = 0, have = 0;
+    explicit GzLines(const std::string &path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) {
+        if (!f) throw Error("Could not open " + path + " for reading.");
+        gzbuffer(f, 1 << 20);
+    }
+    ~GzLines() { gzclose(f); }
+    bool getline(std::string &line) {
+        line.clear();
+        for (;;) {
+            if (at == have) {
+                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                if (n < 0) throw Error("read error in a compressed input file");
+                if (n == 0) return !line.empty();
+                at = 0;
+                have = (size_t)n;
+            }
+            const char *p = buf.data() + at, *e = (const char *)memchr(p, '\n', have - at);
+            if (e) {
+                line.append(p, (size_t)(e - p));
+                at += (size_t)(e - p) + 1;
+                return true;
+            }
+            line.append(p, have - at);
+            at = have;
+        }
+    }
+};
+}  // namespace
+
 Reference Reference::read_fasta(const std::string &path) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw Error("Could not open " + path + " for reading.");
+    GzLines f(path);
     uint8_t lut[256];
     memset(lut, 4, sizeof lut);                // every IUPAC code that is not ACGT becomes N (IupacString -> Dna5String)
     const char *acgt = "ACGT";
@@ -209,7 +245,7 @@ Reference Reference::read_fasta(const std::string &path) {
     lut[(uint8_t)'U'] = lut[(uint8_t)'u'] = 3;
     Reference r;
     std::string line;
-    while (std::getline(f, line)) {
+    while (f.getline(line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (line.empty()) continue;
         if (line[0] == '>') {
@@ -353,17 +389,34 @@ std::vector<SysErrorRecord> parse_sys_error_fastq(const std::string &text) {
     }
     return recs;
 }
-std::string read_text_file(const std::string &path) {
-    FILE *f = fopen(path.c_str(), "rb");
+static bool ends_with_gz(const std::string &path) { return path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
+std::string read_text_file(const std::string &path) {                       // plain or gzip
+    gzFile f = gzopen(path.c_str(), "rb");
     if (!f) throw Error("Could not open '" + path + "' for reading.");
     std::string text;
-    char buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
-    fclose(f);
+    std::vector<char> buf(1 << 20);
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) text.append(buf.data(), (size_t)n);
+    gzclose(f);
+    if (n < 0) throw Error("Could not read '" + path + "'.");
     return text;
 }
-void write_text_file(const std::string &path, const std::string &text) {
+void write_text_file(const std::string &path, const std::string &text) {   // gzip when the name ends in .gz, like SeqAn's SeqFileOut
+    if (ends_with_gz(path)) {
+        gzFile f = gzopen(path.c_str(), "wb");
+        if (!f) throw Error("Could not open '" + path + "' for writing.");
+        size_t done = 0;
+        while (done < text.size()) {
+            const unsigned chunk = (unsigned)std::min<size_t>(text.size() - done, 1u << 30);
+            if (gzwrite(f, text.data() + done, chunk) != (int)chunk) {
+                gzclose(f);
+                throw Error("Could not write '" + path + "'.");
+            }
+            done += chunk;
+        }
+        if (gzclose(f) != Z_OK) throw Error("Could not write '" + path + "'.");
+        return;
+    }
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) throw Error("Could not open '" + path + "' for writing.");
     const size_t n = fwrite(text.data(), 1, text.size(), f);

@@ -87,3 +87,18 @@ def test_no_cpu_fallback_without_a_gpu(tiny_profile_path):
     assert e.value.code == api.RSQ_ENODEV
     assert "no CPU fallback" in str(e.value)
     p.close()
+
+
+def test_gzip_fasta_loads_like_plain(workdir):
+    """SeqAn opens .gz references transparently (SURVEY.md section 8(b) inputs); so does rsq_ref_load_fasta"""
+    import gzip
+    plain = os.path.join(GOLDEN, "reference-test.fa")
+    packed = workdir / "reference-test.fa.gz"
+    with open(plain, "rb") as f, gzip.open(packed, "wb") as g:
+        g.write(f.read())
+    a, b = api.Reference(plain), api.Reference(str(packed))
+    assert a.num_sequences() == b.num_sequences() == 2
+    for i in range(2):
+        assert np.array_equal(a.codes(i), b.codes(i))
+    a.close()
+    b.close()

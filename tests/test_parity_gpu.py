@@ -108,3 +108,22 @@ def test_cli_write_then_read_sys_error_profile(workdir):
 
 def test_methylation(workdir):
     P.case_methylation(GpuBackend, workdir)
+
+
+def test_cli_gzip_output_and_input(workdir):
+    """-1/-2 ending in .gz are written gzip-compressed and hold the same text; a .gz reference and a .gz sys-error profile are read"""
+    import gzip
+    import os
+    import subprocess
+    from reseq_amd import synth
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reseq_amd", "reseq")
+    ppath, fpath, _ = P.make_inputs(workdir, "cli_gz", synth.TINY, [4100, 2999])
+    fgz = str(workdir / "cli_gz.fa.gz")
+    with open(fpath, "rb") as f, gzip.open(fgz, "wb") as g:
+        g.write(f.read())
+    prof = str(workdir / "cli_gz_sys.fq.gz")
+    a1, a2, b1, b2 = (str(workdir / n) for n in ("g1.fq", "g2.fq", "g1.fq.gz", "g2.fq.gz"))
+    subprocess.run([exe, "illuminaPE", "-R", fpath, "-s", ppath, "--numReads", "1200", "--seed", "9", "-1", a1, "-2", a2, "--writeSysError", prof], check=True, capture_output=True)
+    subprocess.run([exe, "illuminaPE", "-R", fgz, "-s", ppath, "--numReads", "1200", "--seed", "9", "-1", b1, "-2", b2, "--readSysError", prof], check=True, capture_output=True)
+    assert gzip.open(b1, "rb").read() == open(a1, "rb").read() and gzip.open(b2, "rb").read() == open(a2, "rb").read()
+    assert open(b1, "rb").read()[:2] == b"\x1f\x8b" and gzip.open(prof, "rb").read().count(b"\n") == 16
