@@ -59,6 +59,9 @@ int rsq_ref_replace_n(rsq_ref *r, uint64_t seed);
 void rsq_ref_free(rsq_ref *r);
 int rsq_ref_num_sequences(const rsq_ref *r, uint32_t *out);
 int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out);
+/* Reference::WriteFasta (reseq/Reference.cpp:896-916; `reseq replaceN` writes the reference after ReplaceN): FASTA, gzip when the
+ * name ends in .gz */
+int rsq_ref_write_fasta(const rsq_ref *r, const char *path);
 /* copies the base codes (A=0,C=1,G=2,T=3,N=4) of one sequence into out[len] */
 int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len);
 

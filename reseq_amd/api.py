@@ -51,6 +51,7 @@ SYMBOLS = {
     "rsq_ref_free": (None, [_vp]),
     "rsq_ref_num_sequences": (C.c_int, [_vp, C.POINTER(_u32)]),
     "rsq_ref_sequence_length": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    "rsq_ref_write_fasta": (C.c_int, [_vp, C.c_char_p]),
     "rsq_ref_get_codes": (C.c_int, [_vp, _u32, _vp, _u32]),
     "rsq_sim_create": (C.c_int, [_vp, _vp, C.c_int, _pp]),
     "rsq_sim_free": (None, [_vp]),
@@ -152,6 +153,9 @@ class Reference:
         v = C.c_uint32()
         _check(lib().rsq_ref_sequence_length(self.h, i, C.byref(v)))
         return v.value
+
+    def write_fasta(self, path):
+        _check(lib().rsq_ref_write_fasta(self.h, str(path).encode()))
 
     def codes(self, i):
         out = np.zeros(self.sequence_length(i), np.uint8)

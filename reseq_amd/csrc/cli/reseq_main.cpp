@@ -523,6 +523,26 @@ const char *kUsage =
 
 }  // namespace
 
+// reseq replaceN -r <refIn.fa> -R <refSim.fa> [--seed] (main.cpp:611-692)
+int replace_n(const Args &a) {
+    if (!a.has("refIn")) {
+        ERR("refIn option is mandatory.");
+        return 1;
+    }
+    if (!a.has("refSim")) {
+        ERR("refSim option is mandatory.");
+        return 1;
+    }
+    INFO("Reading reference from " << a.get("refIn"));
+    INFO("Writing reference without N to " << a.get("refSim"));
+    rsq_ref *ref = nullptr;
+    bool ok = check(rsq_ref_load_fasta(a.get("refIn").c_str(), &ref), "Could not load reference");
+    ok = ok && check(rsq_ref_replace_n(ref, get_seed(a)), "ReplaceN") && check(rsq_ref_write_fasta(ref, a.get("refSim").c_str()), "Could not write reference");
+    rsq_ref_free(ref);
+    if (ok) INFO("Finished replacing N's.");
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
     std::string command;
     int cmd_at = 0;
@@ -549,7 +569,8 @@ int main(int argc, char **argv) {
     }
     if (command == "illuminaPE") return illumina_pe(a);
     if (command == "seqToIllumina" || command == "replaceQuals") return seq_to_illumina(a);
-    if (command == "queryProfile" || command == "replaceN" || command == "test") {
+    if (command == "replaceN") return replace_n(a);
+    if (command == "queryProfile" || command == "test") {
         ERR("command '" << command << "' is not part of this build (simulation stage only)");
         return 1;
     }

@@ -527,6 +527,27 @@ int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out) {
     *out = (uint32_t)r->r.codes[seq].size();
     return RSQ_OK;
 }
+int rsq_ref_write_fasta(const rsq_ref *r, const char *path) {
+    REQUIRE(r && path, "null argument");
+    try {
+        std::string text;
+        for (size_t i = 0; i < r->r.codes.size(); ++i) {
+            text += '>';
+            text += r->r.names[i];
+            text += '\n';
+            const std::vector<uint8_t> &c = r->r.codes[i];
+            for (size_t k = 0; k < c.size(); k += 70) {               // SeqAn's default FASTA line length
+                for (size_t j = k; j < std::min(c.size(), k + 70); ++j) text += "ACGTN"[c[j] < 4 ? c[j] : 4];
+                text += '\n';
+            }
+        }
+        write_text_file(path, text);
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
 int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len) {
     REQUIRE(r && out && seq < r->r.codes.size() && len == r->r.codes[seq].size(), "bad sequence id or length");
     memcpy(out, r->r.codes[seq].data(), len);

@@ -102,3 +102,25 @@ def test_gzip_fasta_loads_like_plain(workdir):
         assert np.array_equal(a.codes(i), b.codes(i))
     a.close()
     b.close()
+
+
+def test_replace_n_cli_mode_and_write_fasta(workdir):
+    """`reseq replaceN -r in -R out --seed s` (main.cpp:611-692): ReadFasta, ReplaceN, WriteFasta -- host code only, no GPU needed"""
+    import subprocess
+    src = workdir / "n_in.fa"
+    src.write_text(">chr1 some description\nACGTNNNNACGT" + "N" * 120 + "GGCC\n>chr2\nNNAC\n")
+    out = workdir / "n_out.fa.gz"
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reseq_amd", "reseq")
+    subprocess.run([exe, "replaceN", "-r", str(src), "-R", str(out), "--seed", "4"], check=True, capture_output=True)
+    a = api.Reference(str(src), 4)
+    b = api.Reference(str(out))
+    assert b.num_sequences() == 2
+    for i in range(2):
+        assert np.array_equal(a.codes(i), b.codes(i)) and b.codes(i).max() <= 3
+    again = workdir / "n_again.fa"
+    b.write_fasta(again)
+    lines = again.read_text().split("\n")
+    assert lines[0] == ">chr1 some description" and len(lines[1]) == 70 and lines[1].startswith("ACGT")
+    assert subprocess.run([exe, "replaceN", "-r", str(src)], capture_output=True).returncode == 1
+    a.close()
+    b.close()
