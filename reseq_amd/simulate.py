@@ -1,0 +1,153 @@
+"""Multi-GPU `illuminaPE` simulation: one process per GPU, launched as
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m reseq_amd.simulate \\
+        -R ref.fa -s profile.rsqp -1 r1.fq -2 r2.fq --numReads 100000000 --seed 11
+
+Every rank packs the replicated tables and runs the pre-passes itself (they are a second of work; no collective), takes a
+contiguous range of 1000-position blocks balanced by expected pairs (`sharding.partition_blocks`), writes its FASTQ shard, and
+rank 0 concatenates the shards in rank order and appends the adapter-only pairs.  The result is byte for byte the output of a
+single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
+(seed, sequence, start, length), not by rank (Simulator.cpp:2384-2401 distributes blocks over threads the same way).
+torch.distributed (RCCL) carries two barriers and the job totals.
+"""
+import argparse
+import os
+import shutil
+import sys
+import time
+
+from . import sharding
+
+
+class GpuBackend:
+    """reseq_amd.api.Simulator with reusable device buffers (the product path)."""
+
+    def __init__(self, profile_path, fasta_path, device, replace_n_seed):
+        from . import api
+        self.api = api
+        self.prof = api.Profile(profile_path)
+        self.ref = api.Reference(fasta_path, replace_n_seed)
+        self.sim = api.Simulator(self.prof, self.ref, device)
+        self.device = device
+        self.r1 = self.r2 = None
+        self.seq_len = [self.ref.sequence_length(i) for i in range(self.ref.num_sequences())]
+
+    def prepare(self, seed, num_pairs, coverage, ref_bias_mode, base_identifier):
+        i = self.sim.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        return dict(total_blocks=i.total_blocks, total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, insert_to=i.insert_to)
+
+    def ref_seq_bias(self):
+        return self.sim.ref_seq_bias(len(self.seq_len))
+
+    def pairs(self, lo, hi):
+        import numpy as np
+        api = self.api
+        for _ in range(2):
+            n, l1, l2, rc = self.sim.pairs_device(lo, hi, self.r1, self.r2)
+            if rc == api.RSQ_OK:
+                return n, self.r1.to_numpy(np.uint8, l1).tobytes() if n else b"", self.r2.to_numpy(np.uint8, l2).tobytes() if n else b""
+            if rc != api.RSQ_ENOSPC:
+                raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+            for d in (self.r1, self.r2):
+                if d is not None:
+                    d.free()
+            self.r1, self.r2 = api.DeviceArray(self.device, l1 + l1 // 8 + 4096), api.DeviceArray(self.device, l2 + l2 // 8 + 4096)
+        raise RuntimeError("rsq_sim_pairs kept asking for larger buffers")
+
+    def adapter_only_pairs(self, first, n):
+        return self.sim.adapter_only_pairs(first, n)
+
+    def close(self):
+        for d in (self.r1, self.r2):
+            if d is not None:
+                d.free()
+        self.sim.close()
+        self.ref.close()
+        self.prof.close()
+
+
+def block_weights(seq_len, insert_to, ref_seq_bias):
+    """Expected pairs per block up to a constant: the sequence's reference bias (blocks of a sequence share it); sequences
+    shorter than the longest insert have no blocks (Simulator.cpp:1159)."""
+    w = []
+    for length, bias in zip(seq_len, ref_seq_bias):
+        if length >= insert_to:
+            w += [float(bias)] * ((length + 999) // 1000)
+    return w
+
+
+def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=2000, device="cpu"):
+    """One rank's share.  `backend` offers prepare / ref_seq_bias / seq_len / pairs / adapter_only_pairs.  Returns (pairs of the whole
+    job, seconds of the slowest rank)."""
+    info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+    weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
+    assert len(weights) == info["total_blocks"]
+    mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
+    t0 = time.perf_counter()
+    n_mine = n_bytes = 0
+    shard1, shard2 = f"{out1}.rank{rank}", f"{out2}.rank{rank}"
+    with open(shard1, "wb") as f1, open(shard2, "wb") as f2:
+        for lo, hi in sharding.batches(mine[0], mine[1], batch_blocks):
+            n, a, b = backend.pairs(lo, hi)
+            n_mine += n
+            n_bytes += len(a) + len(b)
+            f1.write(a)
+            f2.write(b)
+    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, n_bytes, time.perf_counter() - t0)
+    if dist is not None:
+        dist.barrier()                                               # every shard is on disk
+    if rank == 0:
+        with open(out1, "wb") as f1, open(out2, "wb") as f2:
+            for r in range(world):
+                for dst, shard in ((f1, f"{out1}.rank{r}"), (f2, f"{out2}.rank{r}")):
+                    with open(shard, "rb") as src:
+                        shutil.copyfileobj(src, dst, 1 << 24)
+                    os.remove(shard)
+            for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does
+                a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
+                f1.write(a)
+                f2.write(b)
+    if dist is not None:
+        dist.barrier()
+    return int(total_pairs) + info["adapter_only_pairs"], elapsed
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("-R", "--refSim", "-r", "--refIn", dest="ref", required=True)
+    ap.add_argument("-s", "--statsIn", dest="profile", required=True)
+    ap.add_argument("-1", "--firstReadsOut", dest="out1", default="reseq-R1.fq")
+    ap.add_argument("-2", "--secondReadsOut", dest="out2", default="reseq-R2.fq")
+    ap.add_argument("--numReads", type=int, default=0)
+    ap.add_argument("-c", "--coverage", type=float, default=0.0)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
+    ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
+    ap.add_argument("--batchBlocks", type=int, default=2000)
+    a = ap.parse_args(argv)
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")
+    if dist is not None:                                             # one seed for the whole job
+        t = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.broadcast(t, 0)
+        seed = int(t.item())
+    backend = GpuBackend(a.profile, a.ref, local_rank, seed)
+    try:
+        pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
+                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}")
+        if rank == 0:
+            print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
+    finally:
+        backend.close()
+        if dist is not None:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,3 +127,22 @@ def test_cli_gzip_output_and_input(workdir):
     subprocess.run([exe, "illuminaPE", "-R", fgz, "-s", ppath, "--numReads", "1200", "--seed", "9", "-1", b1, "-2", b2, "--readSysError", prof], check=True, capture_output=True)
     assert gzip.open(b1, "rb").read() == open(a1, "rb").read() and gzip.open(b2, "rb").read() == open(a2, "rb").read()
     assert open(b1, "rb").read()[:2] == b"\x1f\x8b" and gzip.open(prof, "rb").read().count(b"\n") == 16
+
+
+def test_simulate_module_equals_cli(workdir):
+    """python -m reseq_amd.simulate (the multi-GPU launcher, here with one rank) writes the files of reseq illuminaPE"""
+    import os
+    import subprocess
+    import sys
+    from reseq_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reseq_amd", "reseq")
+    ppath, fpath, _ = P.make_inputs(workdir, "cli_sim", synth.TINY, [5000, 80, 3210])
+    a1, a2, b1, b2 = (str(workdir / n) for n in ("s1.fq", "s2.fq", "t1.fq", "t2.fq"))
+    args = ["-R", fpath, "-s", ppath, "--numReads", "30000", "--seed", "13", "--refBias", "no"]
+    subprocess.run([exe, "illuminaPE"] + args + ["-1", a1, "-2", a2], check=True, capture_output=True)
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", b1, "-2", b2, "--batchBlocks", "3"], check=True, capture_output=True, env=env, cwd=root)
+    assert open(a1, "rb").read() == open(b1, "rb").read() and open(a2, "rb").read() == open(b2, "rb").read()
+    assert b":0:Adapter:0:" in open(a1, "rb").read()

@@ -23,6 +23,68 @@ def test_partition_covers_every_block_once():
     assert sharding.batches(3, 10, 4) == [(3, 7), (7, 10)]
 
 
+SIMULATE_WORKER = r"""
+import os, sys, pathlib
+sys.path.insert(0, os.environ["RSQ_TESTS"]); sys.path.insert(0, os.environ["RSQ_ROOT"])
+import torch.distributed as dist
+import parity_cases as P
+from backends import EmuBackend
+from reseq_amd import simulate, synth
+
+class Emu:                      # the host emulation behind the interface simulate.run_rank drives (the GPU run uses simulate.GpuBackend)
+    def __init__(self, ppath, fpath, seqs):
+        self.b = EmuBackend(ppath, fpath, 0)
+        self.seq_len = [len(c) for _, c in seqs]
+    def prepare(self, *a):
+        i = self.b.prepare(*a)
+        self.n_seqs = len(self.seq_len)
+        return i
+    def ref_seq_bias(self):
+        return self.b.ref_seq_bias(self.n_seqs)
+    def pairs(self, lo, hi):
+        fr, a, b = self.b.pairs(lo, hi)
+        return len(fr), a, b
+    def adapter_only_pairs(self, first, n):
+        return self.b.adapter_only_pairs(first, n)
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["RSQ_PORT"], rank=rank, world_size=world)
+work = pathlib.Path(os.environ["RSQ_WORK"])
+(work / f"sim{rank}").mkdir(parents=True, exist_ok=True)
+ppath, fpath, seqs = P.make_inputs(work / f"sim{rank}", "simjob", synth.TINY, [5000, 80, 3210])
+tag = os.environ["RSQ_TAG"]
+pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3)
+if rank == 0:
+    print("PAIRS", pairs)
+if world > 1:
+    dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+def test_simulate_module_two_ranks_equal_one_rank(workdir):
+    """reseq_amd.simulate.run_rank over gloo with two ranks writes the same two FASTQ files (adapter-only pairs included) as one rank"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, RSQ_TESTS=str(HERE), RSQ_ROOT=str(HERE.parent), RSQ_WORK=str(workdir), RSQ_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK="0", WORLD_SIZE="1", RSQ_TAG="one"), capture_output=True, timeout=800)
+    assert one.returncode == 0, one.stderr.decode()[-3000:]
+    procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="two"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = [p.communicate(timeout=800) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-3000:]
+    pairs_line = lambda out: [l for l in out.split(b"\n") if l.startswith(b"PAIRS")]          # gloo prints connection notes on stdout
+    assert pairs_line(one.stdout) == pairs_line(outs[0][0]) and len(pairs_line(one.stdout)) == 1
+    for k in (1, 2):
+        a, b = (workdir / f"one_{k}.fq").read_bytes(), (workdir / f"two_{k}.fq").read_bytes()
+        assert a == b and a.count(b"\n") % 4 == 0 and b":0:Adapter:0:" in a
+    assert not list(workdir.glob("*.rank*"))
+
+
 WORKER = r"""
 import os, sys, pathlib, time
 sys.path.insert(0, os.environ["RSQ_TESTS"]); sys.path.insert(0, os.environ["RSQ_ROOT"])
