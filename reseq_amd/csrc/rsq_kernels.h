@@ -267,17 +267,14 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
 //   k_sieve_screen: one lane per (start position, 32 fragment lengths): eight Philox blocks, 32 comparisons against the zero
 //            threshold, one bitmap word.  About 0.2 % of the cells pass.  Few registers, full occupancy: the kernel is a
 //            chain of dependent 32-bit multiplies and needs many waves per SIMD to keep the multiplier busy.
-//   k_sieve_finish: a wave owns kSieveSlotsPerWave consecutive start positions, turns their bitmap rows into a candidate
+//   k_sieve_finish: a wave owns slots_per_wave consecutive start positions (enough for about 64 candidates), turns their bitmap rows into a candidate
 //            queue in LDS, in (position, length) order, and runs the expensive part (strand choice, GC percent, surroundings,
 //            negative binomial count) one lane per queued cell -- full lanes instead of the one or two that a fused loop
 //            would keep busy.
 // counts[slot] = pairs starting at the position.  Every cell with fragments is appended to `hits` together with the number
 // of pairs that precede it at the same start, so that k_sieve_emit can place its fragments in (length, chosen strand order,
 // duplicate) order -- the order of the reference's loops -- once the exclusive scan of counts is known.
-#ifndef RSQ_SIEVE_SLOTS
-#define RSQ_SIEVE_SLOTS 32
-#endif
-constexpr uint32_t kSieveSlotsPerWave = RSQ_SIEVE_SLOTS;
+constexpr uint32_t kSieveSlotsMin = 32, kSieveSlotsMax = 1024;  // start positions per wave of k_sieve_finish, chosen from the pair density
 constexpr uint32_t kSieveWaves = 4;
 constexpr uint32_t kSieveQueue = 2048;                 // candidate capacity per wave = the most one pass over 64 bitmap words can add
 constexpr uint32_t kScreenBlock = 256;
@@ -285,10 +282,25 @@ constexpr uint32_t kSieveLoads = 8;                   // bitmap words a lane of 
 
 RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 31u) >> 5; }
 
+// thr1 of one coverage group in LDS, skewed by two doubles per 32 lengths: the lanes of a wave read lengths 32 apart, and the
+// skew spreads their 16-byte reads over all banks (from HBM each of those reads would touch its own cache line)
+RSQ_HD uint32_t thr_lds_index(uint32_t len) { return len + 2u * (len >> 5); }
+RSQ_HD uint32_t thr_lds_doubles(uint32_t insert_to) { return thr_lds_index(insert_to) + 4u; }
+
 __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
-    const uint64_t t = (uint64_t)blockIdx.x * kScreenBlock + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double s_thr1[];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kScreenBlock, t = t0 + threadIdx.x, n_tasks = (uint64_t)n_slots * words_per_slot;
+    // the block's positions lie in one sequence almost always: then its thresholds come from LDS
+    const uint32_t slot_first = (uint32_t)(t0 / words_per_slot), slot_last = (uint32_t)((t0 + kScreenBlock - 1 < n_tasks ? t0 + kScreenBlock - 1 : n_tasks - 1) / words_per_slot);
+    const uint32_t seq_first = S.block_seq[block_lo + slot_first / kBlockSize], seq_last = S.block_seq[block_lo + slot_last / kBlockSize];
+    const bool staged = seq_first == seq_last;                     // block-uniform
+    if (staged) {
+        const double *thr = S.thresholds + (size_t)S.coverage_group[seq_first] * S.insert_to * 2u;
+        for (uint32_t len = threadIdx.x; len < S.insert_to; len += kScreenBlock) s_thr1[thr_lds_index(len)] = thr[2u * len + 1u];
+        __syncthreads();
+    }
+    if (t >= n_tasks) return;
     const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
-    if (slot >= n_slots) return;
     SieveSite site;
     init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
     uint32_t bits = 0;
@@ -302,22 +314,25 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
 #pragma unroll
             for (uint32_t e = 0; e < 4u; ++e) {
                 const uint32_t len = len0 + e;
-                if (len >= S.insert_from && len < S.insert_to && u32_to_unit(word[e]) >= site.thr[2u * len + 1u]) bits |= 1u << (4u * j + e);     // Simulator.h:418-420
+                if (len >= S.insert_from && len < S.insert_to) {
+                    const double thr1 = staged ? s_thr1[thr_lds_index(len)] : site.thr[2u * len + 1u];
+                    if (u32_to_unit(word[e]) >= thr1) bits |= 1u << (4u * j + e);                     // Simulator.h:418-420
+                }
             }
         }
     }
     bitmap[t] = bits;
 }
 
-__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, const uint32_t *bitmap,
-                                                                  uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
+__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
+                                                                  const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
     __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
-    __shared__ uint32_t s_total[kSieveWaves][kSieveSlotsPerWave];  // pairs found so far per position
+    extern __shared__ uint32_t s_total[];                          // [kSieveWaves][slots_per_wave] pairs found so far per position
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t slot0 = (blockIdx.x * kSieveWaves + wave) * kSieveSlotsPerWave;
+    const uint32_t slot0 = (blockIdx.x * kSieveWaves + wave) * slots_per_wave;
     if (slot0 >= n_slots) return;
-    uint32_t *queue = s_queue[wave], *totals = s_total[wave];
-    if (lane < kSieveSlotsPerWave) totals[lane] = 0;
+    uint32_t *queue = s_queue[wave], *totals = s_total + wave * slots_per_wave;
+    for (uint32_t k = lane; k < slots_per_wave; k += 64u) totals[k] = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t n_queued = 0;
 
@@ -370,7 +385,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
 
     // the wave's bitmap rows are one contiguous run of words in (position, length) order; kSieveLoads independent loads per lane
     // are in flight at a time (the kernel runs one wave per SIMD: a dependent load per pass would cost a round trip each)
-    const uint32_t my_slots = n_slots - slot0 < kSieveSlotsPerWave ? n_slots - slot0 : kSieveSlotsPerWave;
+    const uint32_t my_slots = n_slots - slot0 < slots_per_wave ? n_slots - slot0 : slots_per_wave;
     const uint32_t n_words = my_slots * words_per_slot;
     const uint32_t *row = bitmap + (uint64_t)slot0 * words_per_slot;
     for (uint32_t i0 = 0; i0 < n_words; i0 += 64u * kSieveLoads) {
@@ -403,7 +418,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
         }
     }
     finish();
-    if (lane < kSieveSlotsPerWave && slot0 + lane < n_slots) counts[slot0 + lane] = totals[lane];
+    for (uint32_t k = lane; k < my_slots; k += 64u) counts[slot0 + k] = totals[k];
 }
 
 // one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at offsets[slot] + intra

@@ -346,18 +346,23 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
                                           (uint64_t)((double)s.total_pairs * (double)(block_hi - block_lo) / (double)s.total_blocks * 1.25) + 65536);
     uint64_t total = 0;
     uint32_t n_hits = 0;
-    const dim3 sgrid(cdiv(n_slots, kSieveWaves * kSieveSlotsPerWave)), sblock(64 * kSieveWaves);
+    // positions per wave of the finish kernel: about 64 cells with fragments, so that one pass fills the lanes
+    const double pairs_per_position = (double)s.total_pairs / std::max<double>(1.0, (double)s.total_blocks * kBlockSize);
+    uint32_t slots_per_wave = kSieveSlotsMin;
+    while (slots_per_wave < kSieveSlotsMax && slots_per_wave * pairs_per_position < 48.0) slots_per_wave *= 2;
+    const dim3 sgrid(cdiv(n_slots, kSieveWaves * slots_per_wave)), sblock(64 * kSieveWaves);
     for (int attempt = 0;; ++attempt) {
         s.hits.reserve(hit_cap * sizeof(SieveHit));
         HIP_CHECK(hipMemsetAsync(s.hit_count.as<uint32_t>(), 0, 4, st));
         s.timers["sieve"].start(st);
         if (!attempt) {
             s.timers["sieve_screen"].start(st);
-            hipLaunchKernelGGL(k_sieve_screen, dim3(cdiv(n_slots * words_per_slot, kScreenBlock)), dim3(kScreenBlock), 0, st, s.dev, block_lo, (uint32_t)n_slots,
-                               words_per_slot, s.sieve_bitmap.as<uint32_t>());
+            hipLaunchKernelGGL(k_sieve_screen, dim3(cdiv(n_slots * words_per_slot, kScreenBlock)), dim3(kScreenBlock), thr_lds_doubles(s.dev.insert_to) * sizeof(double), st,
+                               s.dev, block_lo, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
             s.timers["sieve_screen"].stop(st);
         }
-        hipLaunchKernelGGL(k_sieve_finish, sgrid, sblock, 0, st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
+        hipLaunchKernelGGL(k_sieve_finish, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot, slots_per_wave,
+                           s.sieve_bitmap.as<uint32_t>(),
                            s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
