@@ -142,20 +142,38 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
 
 // ------------------------------------------------------------------------------------ bias normalisation
 
-__global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *params, double *partial_sum, double *partial_max) {
+// The surrounding factors of Reference::Bias depend on one position each (the start, or the end, of the fragment) and are shared by
+// every sampled fragment length: computed once per position (3 table lookups in the 24 MB sur_bias table and an exp each), they turn
+// k_sum_bias from a random-access kernel into a streaming one.  Same function, same values, same product order.
+__global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, double *start_bias, double *end_bias) {
+    const uint32_t seq = blockIdx.y, L = S.seq_len[seq];
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= L) return;
+    const uint64_t wo = S.seq_word_off[seq], at = S.seq_base_off[seq] + pos;
+    uint32_t sur[3];
+    surrounding_forward(S.ref_words, wo, L, pos, sur);
+    start_bias[at] = surrounding_bias(S.sur_bias, sur);
+    surrounding_reverse(S.ref_words, wo, L, pos, sur);
+    end_bias[at] = surrounding_bias(S.sur_bias, sur);
+}
+
+__global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *params, const double *start_bias, const double *end_bias, double *partial_sum,
+                                                 double *partial_max) {
     __shared__ double s_sum[kBiasBlock];
     __shared__ double s_max[kBiasBlock];
     const BiasParam p = params[blockIdx.y];
     const uint32_t L = S.seq_len[p.seq];
     const uint64_t wo = S.seq_word_off[p.seq];
     const uint32_t n_starts = L - p.len + 1;                       // start positions 0 .. L-len (Reference.cpp:645)
+    const uint64_t bo = S.seq_base_off[p.seq];
     const uint32_t first = (blockIdx.x * kBiasBlock + threadIdx.x) * kBiasRun;
     double sum = 0.0, mx = 0.0;
     if (first < n_starts) {
         const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
         uint32_t gc = ref_gc_count_prefix(S.ref_words, S.gc_prefix, wo, first, first + p.len);
         for (uint32_t start = first; start < last; ++start) {
-            const double bias = site_bias(S, wo, L, start, p.len, gc, p.general_bias);
+            const double bias = start_bias ? p.general_bias * S.gc_bias[percent_u32(gc, p.len)] * start_bias[bo + start] * end_bias[bo + start + p.len - 1u]
+                                           : site_bias(S, wo, L, start, p.len, gc, p.general_bias);
             sum += bias;
             mx = bias > mx ? bias : mx;
             if (start + 1 < last) gc = gc + is_gc(ref_base(S.ref_words, wo, start + p.len)) - is_gc(ref_base(S.ref_words, wo, start));

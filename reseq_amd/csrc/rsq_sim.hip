@@ -148,16 +148,29 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set) {
 // ------------------------------------------------------------------------------- bias normalisation (a14)
 // FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization; the SumBias scans (Reference.cpp:622-659) run on
 // the GPU, one launch for all (sequence, sampled length) pairs; partial sums are combined in a fixed order.
+constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
 static void bias_normalization(rsq_sim &s, hipStream_t st) {
     const BiasPlan plan = plan_bias_normalization(s, s.up);
     std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
     if (!plan.params.empty()) {
         const uint32_t gx = cdiv(plan.max_starts, kBiasBlock * kBiasRun);
-        DevBuf d_params, d_sum, d_max;
+        DevBuf d_params, d_sum, d_max, d_start_bias, d_end_bias;
         d_params.upload(plan.params);
+        double *start_bias = nullptr, *end_bias = nullptr;
+        if (s.total_ref_size * 16 <= kSurroundingTrackBytesMax) {      // 16 bytes per base: 50 GB for a human genome, of 288 GB
+            d_start_bias.reserve(s.total_ref_size * 8 + 16);
+            d_end_bias.reserve(s.total_ref_size * 8 + 16);
+            start_bias = d_start_bias.as<double>();
+            end_bias = d_end_bias.as<double>();
+            uint32_t longest = 0;
+            for (uint32_t L : s.seq_len) longest = std::max(longest, L);
+            hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias);
+            HIP_CHECK(hipGetLastError());
+        }
         d_sum.reserve((size_t)gx * plan.params.size() * 8);
         d_max.reserve((size_t)gx * plan.params.size() * 8);
-        hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_sum.as<double>(), d_max.as<double>());
+        hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), start_bias, end_bias, d_sum.as<double>(),
+                           d_max.as<double>());
         HIP_CHECK(hipGetLastError());
         std::vector<double> h_sum((size_t)gx * plan.params.size()), h_max(h_sum.size());
         HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
