@@ -32,7 +32,7 @@ A_PAIR = 1436                 # algorithmic HBM bytes per 2x150 pair (SURVEY.md 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(profile_path, seqs, seed, sample_bp=100_000):
+def cpu_baseline(profile_path, seqs, seed, sample_bp=150_000):
     """The CPU oracle (a port, 1 thread) on a bounded sample of the same workload: the first `sample_bp` bases of the
     reference at the same pair density.  Times sieve + CreateReads only (pre-passes excluded, like the GPU figure)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=PAIRS)
     ap.add_argument("--genome", type=int, default=GENOME)
-    ap.add_argument("--batch-blocks", type=int, default=400)
+    ap.add_argument("--batch-blocks", type=int, default=1200)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--gc", type=float, default=0.508, help="G+C fraction of the synthetic reference (E. coli: 0.508)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,7 +98,7 @@ def main():
     ppath = os.path.join(tmp, "p0.rsqp")
     fpath = os.path.join(tmp, "ref.fa")
     synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
-    seqs = synth.make_reference(2 + rank, [args.genome], gc=0.508, names=[f"synthEcoli{rank} len={args.genome}"])
+    seqs = synth.make_reference(2 + rank, [args.genome], gc=args.gc, names=[f"synthEcoli{rank} len={args.genome}"])
     synth.write_fasta(fpath, seqs)
 
     prof = api.Profile(ppath)

@@ -349,6 +349,10 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     *r1_len = *r2_len = 0;
     const uint64_t n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
     if (!n_slots) return RSQ_OK;
+    if (n_slots * sieve_words_per_slot(s.dev.insert_to) >= (1ull << 32)) {       // slot and bitmap indices are 32 bits wide inside one call
+        g_last_error = "block range too large for one call: at most " + std::to_string(((1ull << 32) / sieve_words_per_slot(s.dev.insert_to)) / kBlockSize - 1) + " blocks";
+        return RSQ_EINVAL;
+    }
     s.counts.reserve(n_slots * 4 + 16);
     s.offsets.reserve((n_slots + 1) * 8);
     s.hit_count.reserve(8);

@@ -76,13 +76,15 @@ def block_weights(seq_len, insert_to, ref_seq_bias):
     return w
 
 
-def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=2000, device="cpu"):
+def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu"):
     """One rank's share.  `backend` offers prepare / ref_seq_bias / seq_len / pairs / adapter_only_pairs.  Returns (pairs of the whole
     job, seconds of the slowest rank)."""
     info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
     weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
     assert len(weights) == info["total_blocks"]
     mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
+    if not batch_blocks:                                             # about 4 M pairs per call (large launches), at least 2000 blocks
+        batch_blocks = int(min(100000, max(2000, 4e6 * info["total_blocks"] / max(1, info["total_pairs"]))))
     t0 = time.perf_counter()
     n_mine = n_bytes = 0
     shard1, shard2 = f"{out1}.rank{rank}", f"{out2}.rank{rank}"
@@ -123,7 +125,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
-    ap.add_argument("--batchBlocks", type=int, default=2000)
+    ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 4 M pairs)")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch
