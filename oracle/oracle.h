@@ -306,6 +306,8 @@ void orc_text_free(orc_text *t);
 /* --methylation without variants: Reference::PrepareMethylationFile/ReadMethylation (Reference.cpp:1132-1310) and
  * Simulator::CTConversion (Simulator.cpp:1925-2002,2219-2247).  0, or -1 with the reference's message. */
 int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap);
+int orc_parse_methylation(const char *path, const orc_reference *r, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out, uint32_t *second_out,
+                          double *rate_out, uint32_t cap, char *err, size_t err_cap);
 int orc_create_sys_error_profile(const orc_profile *p, const orc_reference *r, uint64_t seed, orc_text *out);
 /* --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335); 0 or -1 with a message */
 int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err, size_t err_cap);

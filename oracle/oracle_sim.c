@@ -1210,19 +1210,45 @@ int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err,
     return 0;
 }
 
-/* Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310), NumAlleles() == 1 */
-int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap) {
+/* Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310).  first/second: [seq][region]; rate: [seq][allele
+ * column][region] with n_cols[seq] columns (1 or num_alleles_ref).  0, or -1 with the reference's message. */
+typedef struct {
+    uint32_t *n, *n_cols;
+    uint32_t **first, **second;
+    double ***rate;
+} orc_methylation;
+
+static void methylation_free(orc_methylation *m, uint32_t n_seqs) {
+    if (!m->n) return;
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        free(m->first[i]);
+        free(m->second[i]);
+        if (m->rate[i]) {
+            for (uint32_t a = 0; a < m->n_cols[i]; ++a) free(m->rate[i][a]);
+            free(m->rate[i]);
+        }
+    }
+    free(m->n);
+    free(m->n_cols);
+    free(m->first);
+    free(m->second);
+    free(m->rate);
+    memset(m, 0, sizeof *m);
+}
+
+static int parse_methylation(const char *path, const orc_reference *r, uint32_t num_alleles_ref, orc_methylation *m, char *err, size_t err_cap) {
 #define FAIL(...)                                      \
     do {                                               \
         if (err) snprintf(err, err_cap, __VA_ARGS__);  \
         free(line);                                    \
         if (f) fclose(f);                              \
+        methylation_free(m, r->n_seqs);                \
         return -1;                                     \
     } while (0)
-    const orc_reference *r = s->r;
     char *line = NULL;
     size_t cap = 0;
     ssize_t len;
+    memset(m, 0, sizeof *m);
     FILE *f = fopen(path, "rb");
     if (!f) FAIL("Unable to open methylation file %s", path);
     int have = 0;
@@ -1234,17 +1260,20 @@ int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err
         }
     }
     if (!have) FAIL("Methylation file is empty or only contains track lines: %s", path);
-    s->meth_n = calloc(r->n_seqs, sizeof(uint32_t));
-    s->meth_first = calloc(r->n_seqs, sizeof(uint32_t *));
-    s->meth_second = calloc(r->n_seqs, sizeof(uint32_t *));
-    s->meth_rate = calloc(r->n_seqs, sizeof(double *));
+    m->n = calloc(r->n_seqs, sizeof(uint32_t));
+    m->n_cols = calloc(r->n_seqs, sizeof(uint32_t));
+    m->first = calloc(r->n_seqs, sizeof(uint32_t *));
+    m->second = calloc(r->n_seqs, sizeof(uint32_t *));
+    m->rate = calloc(r->n_seqs, sizeof(double **));
     char cur_seq[1024];
     size_t sl = strcspn(line, " \t");
     snprintf(cur_seq, sizeof cur_seq, "%.*s", (int)sl, line);
     int eof = 0;
     for (uint32_t i = 0; i < r->n_seqs && !eof; ++i) {
         if (strcmp(r->first_name[i], cur_seq)) continue;                /* no entries for this sequence */
-        uint32_t n = 0, room = 0;
+        uint32_t n = 0, room = 0, num_alleles = num_alleles_ref;        /* :1184-1185 */
+        m->n_cols[i] = num_alleles_ref;
+        m->rate[i] = calloc(num_alleles_ref, sizeof(double *));
         for (;;) {
             char *q = line + strlen(cur_seq);
             q += strspn(q, " \t");
@@ -1253,7 +1282,7 @@ int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err
             if (e == q) FAIL("Could not convert second field to int for line:\n%s", line);
             if (!n) {
                 if (v < 0) FAIL("Second field is negative in line:\n%s", line);
-            } else if (v < (long long)s->meth_second[i][n - 1]) FAIL("Region is overlapping with previous region[%u - %u] in line:\n%s", s->meth_first[i][n - 1], s->meth_second[i][n - 1], line);
+            } else if (v < (long long)m->second[i][n - 1]) FAIL("Region is overlapping with previous region[%u - %u] in line:\n%s", m->first[i][n - 1], m->second[i][n - 1], line);
             if (v >= (long long)r->len[i]) FAIL("Second field is larger than sequence length:\n%s", line);
             uint32_t region_start = (uint32_t)v;
             q = e + strspn(e, " \t");
@@ -1263,26 +1292,33 @@ int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err
             if (v > (long long)r->len[i]) FAIL("Third field is larger than sequence length:\n%s", line);
             if (n == room) {
                 room = room ? 2 * room : 16;
-                s->meth_first[i] = realloc(s->meth_first[i], room * sizeof(uint32_t));
-                s->meth_second[i] = realloc(s->meth_second[i], room * sizeof(uint32_t));
-                s->meth_rate[i] = realloc(s->meth_rate[i], room * sizeof(double));
+                m->first[i] = realloc(m->first[i], room * sizeof(uint32_t));
+                m->second[i] = realloc(m->second[i], room * sizeof(uint32_t));
+                for (uint32_t a = 0; a < m->n_cols[i]; ++a) m->rate[i][a] = realloc(m->rate[i][a], room * sizeof(double));
             }
-            s->meth_first[i][n] = region_start;
-            s->meth_second[i][n] = (uint32_t)v;
+            m->first[i][n] = region_start;
+            m->second[i][n] = (uint32_t)v;
             uint32_t allele = 0;
             q = e + strspn(e, " \t");
             while (*q) {
-                if (allele >= 1) FAIL("More alleles specified than in variant file [1] in line:\n%s", line);
+                if (allele >= num_alleles) {
+                    if (allele >= num_alleles_ref) FAIL("More alleles specified than in variant file [%u] in line:\n%s", num_alleles_ref, line);
+                    FAIL("More alleles specified than in last line [%u] in line:\n%s", num_alleles, line);
+                }
                 double d = strtod(q, &e);
                 if (e == q) FAIL("Could not convert field %u to double for line:\n%s", 4 + allele, line);
                 if (0.0 > d || d > 1.0) FAIL("Field %u is not between 0 and 1:\n%s", 4 + allele, line);
-                s->meth_rate[i][n] = 1.0 - d;
-                ++allele;
+                m->rate[i][allele++][n] = 1.0 - d;                      /* the probability of a C->T conversion */
                 q = e + strspn(e, " \t");
             }
-            if (1 != allele) FAIL("%u alleles specified (must be either 1 or same as in variant file[1]) in line:\n%s", allele, line);
+            if (0 == n && allele >= 1) {                                /* first entry: one column or one per allele (:1263-1272) */
+                if (1 != allele && num_alleles_ref != allele) FAIL("%u alleles specified (must be either 1 or same as in variant file[%u]) in line:\n%s", allele, num_alleles_ref, line);
+                num_alleles = allele;
+                for (uint32_t a = allele; a < m->n_cols[i]; ++a) free(m->rate[i][a]);
+                m->n_cols[i] = allele;
+            } else if (num_alleles != allele) FAIL("%u alleles specified (must be either identical in all lines of a sequence [%u]) in line:\n%s", allele, num_alleles, line);
             ++n;
-            s->meth_n[i] = n;
+            m->n[i] = n;
             int got = 0;
             while ((len = getline(&line, &cap, f)) >= 0) {              /* ignore all empty lines */
                 if (len && line[len - 1] == '\n') line[--len] = 0;
@@ -1306,4 +1342,40 @@ int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err
     fclose(f);
     return 0;
 #undef FAIL
+}
+
+int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap) {
+    orc_methylation m;
+    if (parse_methylation(path, s->r, 1, &m, err, err_cap)) return -1;
+    const uint32_t n_seqs = s->r->n_seqs;
+    s->meth_n = m.n;
+    s->meth_first = m.first;
+    s->meth_second = m.second;
+    s->meth_rate = calloc(n_seqs, sizeof(double *));
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        s->meth_rate[i] = m.rate[i] ? m.rate[i][0] : NULL;                /* the only allele */
+        free(m.rate[i]);
+    }
+    free(m.rate);
+    free(m.n_cols);
+    return 0;
+}
+
+/* parse only, for pinning against ReferenceTest::TestMethylationLoading: rate_out is [sum of regions][num_alleles] where a sequence
+ * with a single column repeats it for every allele (Reference::Unmethylation, Reference.h:390-397) */
+int orc_parse_methylation(const char *path, const orc_reference *r, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out, uint32_t *second_out,
+                          double *rate_out, uint32_t cap, char *err, size_t err_cap) {
+    orc_methylation m;
+    if (parse_methylation(path, r, num_alleles, &m, err, err_cap)) return -1;
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < r->n_seqs; ++i) {
+        n_regions[i] = m.n[i];
+        for (uint32_t k = 0; k < m.n[i] && at < cap; ++k, ++at) {
+            first_out[at] = m.first[i][k];
+            second_out[at] = m.second[i][k];
+            for (uint32_t a = 0; a < num_alleles; ++a) rate_out[(size_t)at * num_alleles + a] = m.rate[i][1 < m.n_cols[i] ? a : 0][k];
+        }
+    }
+    methylation_free(&m, r->n_seqs);
+    return 0;
 }

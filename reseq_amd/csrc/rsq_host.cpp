@@ -480,7 +480,7 @@ std::vector<double> read_ref_bias_file(const std::string &path, const std::vecto
 }
 
 // -------------------------------------------------------------------------------------------- methylation (BED)
-Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len) {
+Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len, uint32_t num_alleles_ref) {
     std::ifstream f(path);
     if (!f.is_open()) throw Error("Unable to open methylation file " + path);
     std::string line;
@@ -496,6 +496,8 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
     bool file_done = false;
     for (size_t i = 0; i < n && !file_done; ++i) {
         if (first_names[i] != cur_seq) continue;                                              // no entries for this sequence
+        m.rate[i].resize(num_alleles_ref);
+        uint32_t num_alleles = num_alleles_ref;
         while (!f.fail()) {
             size_t a = line.find_first_not_of(" \t", cur_seq.size() + 1), b = line.find_first_of(" \t", a);
             long long v;
@@ -525,7 +527,9 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
             uint32_t allele = 0;
             a = line.find_first_not_of(" \t", b);
             while (a < line.size()) {
-                if (allele >= 1) throw Error("More alleles specified than in variant file [1] in line:\n" + line);
+                if (allele >= num_alleles)
+                    throw Error(allele >= num_alleles_ref ? "More alleles specified than in variant file [" + std::to_string(num_alleles_ref) + "] in line:\n" + line
+                                                          : "More alleles specified than in last line [" + std::to_string(num_alleles) + "] in line:\n" + line);
                 b = line.find_first_of(" \t", a);
                 double d;
                 try {
@@ -534,11 +538,17 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
                     throw Error("Could not convert field " + std::to_string(4 + allele) + " to double for line:\n" + line);
                 }
                 if (0.0 > d || d > 1.0) throw Error("Field " + std::to_string(4 + allele) + " is not between 0 and 1:\n" + line);
-                m.rate[i].push_back(1.0 - d);                                                  // the probability of a C->T conversion
-                ++allele;
+                m.rate[i][allele++].push_back(1.0 - d);                                        // the probability of a C->T conversion
                 a = line.find_first_not_of(" \t", b);
             }
-            if (1 != allele) throw Error(std::to_string(allele) + " alleles specified (must be either 1 or same as in variant file[1]) in line:\n" + line);
+            if (1 == m.rate[i][0].size()) {                                                    // first entry of this sequence
+                if (1 != allele && num_alleles_ref != allele)
+                    throw Error(std::to_string(allele) + " alleles specified (must be either 1 or same as in variant file[" + std::to_string(num_alleles_ref) + "]) in line:\n" + line);
+                num_alleles = allele;
+                m.rate[i].resize(allele);
+            } else if (num_alleles != allele) {
+                throw Error(std::to_string(allele) + " alleles specified (must be either identical in all lines of a sequence [" + std::to_string(num_alleles) + "]) in line:\n" + line);
+            }
             while (std::getline(f, line) && line.empty()) {}                                   // ignore all empty lines
             if (!f.fail()) {
                 const size_t sp = line.find_first_of(" \t");

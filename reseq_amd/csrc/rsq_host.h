@@ -137,13 +137,14 @@ void write_text_file(const std::string &path, const std::string &text);
 // `first_names` are the reference ids up to the first space.  Throws with the reference's messages joined.
 std::vector<double> read_ref_bias_file(const std::string &path, const std::vector<std::string> &first_names);
 
-// Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310) for a reference without variants (one allele):
-// extended BED "sequence start end methylation"; per sequence the unmethylated regions [first, second) and the C->T
-// conversion probability 1 - methylation.  File order must follow the reference; throws with the reference's messages.
+// Reference::PrepareMethylationFile + ReadMethylation (Reference.cpp:1132-1310): extended BED "sequence start end methylation
+// [methylation of allele 1 ...]"; per sequence the unmethylated regions [first, second) and, per allele column, the C->T conversion
+// probability 1 - methylation (one column serves every allele).  File order must follow the reference; throws with the reference's
+// messages.  The simulation without variants has one allele.
 struct Methylation {
     std::vector<std::vector<uint32_t>> first, second;
-    std::vector<std::vector<double>> rate;
+    std::vector<std::vector<std::vector<double>>> rate;      // [sequence][allele column][region]
 };
-Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len);
+Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len, uint32_t num_alleles = 1);
 
 }  // namespace rsq

@@ -572,7 +572,7 @@ inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
     for (size_t i = 0; i < m.first.size(); ++i) {
         first.insert(first.end(), m.first[i].begin(), m.first[i].end());
         second.insert(second.end(), m.second[i].begin(), m.second[i].end());
-        rate.insert(rate.end(), m.rate[i].begin(), m.rate[i].end());
+        if (!m.rate[i].empty()) rate.insert(rate.end(), m.rate[i][0].begin(), m.rate[i][0].end());      // one allele without variants
         ptr.push_back((uint32_t)first.size());
     }
     s.dev.meth_ptr = up.put(ptr);

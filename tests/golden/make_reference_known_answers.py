@@ -177,6 +177,23 @@ ka["sum_bias"] = {
     "twice_sum": 2.9367, "twice_sum_tol": 0.0001, "max_bias": 0.774915, "max_bias_tol": 0.00001,
 }
 
+# ReferenceTest.cpp:526-593 TestReplaceN on test/reference-test.fa: stretches of 100 N get the four-base repeat of their flanks
+# (two bases after, two before), the 50-N stretch and the single N are drawn
+ka["replace_n"] = {
+    "set_n": [[0, 50, 150], [1, 350, 450], [1, 54, 104], [0, 253, 254], [0, 256, 257], [0, 263, 264]],      # [seq, from, to)
+    "n_in_reference": 253,
+    "expected": [[0, 50, 2], [0, 51, 1], [0, 52, 0], [0, 53, 0], [0, 54, 2], [0, 55, 1], [0, 56, 0], [0, 57, 0], [0, 146, 2], [0, 147, 1], [0, 148, 0], [0, 149, 0],
+                 [1, 350, 1], [1, 351, 0], [1, 352, 1], [1, 353, 2], [1, 354, 1], [1, 355, 0], [1, 356, 1], [1, 357, 2], [1, 446, 1], [1, 447, 0], [1, 448, 1], [1, 449, 2]],
+}
+# ReferenceTest.cpp:707-768 TestMethylationLoading on test/drosophila-methylation.bed (copied next to this file), two alleles:
+# the sequence at index 2 is NW_007931112.1, the one at index 9 NW_007931119.1; every other sequence has no entries
+ka["methylation_loading"] = {
+    "num_alleles": 2, "sequence_index": {"NW_007931112.1": 2, "NW_007931119.1": 9}, "n_sequences": 21,
+    "regions": {"2": [[0, 100], [100, 101], [34520, 34521]], "9": [[5000, 35000]]},
+    "unmethylation": {"2": [[0.75, 0.7, 0.6], [0.74, 0.69, 0.59]], "9": [[0.9], [0.9]]},      # [allele][region]; a single column serves every allele
+    "empty": [1, 10, 20],
+}
+
 with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
     json.dump(ka, f, indent=1)
 print("wrote", len(ka), "groups")

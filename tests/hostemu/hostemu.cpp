@@ -289,6 +289,33 @@ int emu_read_methylation(void *h, const char *path) {
         return 0;
     });
 }
+// the product's BED parser alone (rsq_host.cpp read_methylation_file), for pinning against the reference's own loading test:
+// rate_out is [sum of regions][num_alleles]; a sequence with one column repeats it for every allele (Reference.h:390-397)
+int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t *lens, uint32_t n_seqs, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out,
+                          uint32_t *second_out, double *rate_out, uint32_t cap) {
+    return guard([&] {
+        std::vector<std::string> names;
+        std::string cur;
+        for (const char *c = names_nl; *c; ++c) {
+            if (*c == '\n') {
+                names.push_back(cur);
+                cur.clear();
+            } else cur += *c;
+        }
+        if (names.size() != n_seqs) throw Error("one name per sequence");
+        const Methylation m = read_methylation_file(path, names, std::vector<uint32_t>(lens, lens + n_seqs), num_alleles);
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < n_seqs; ++i) {
+            n_regions[i] = (uint32_t)m.first[i].size();
+            for (size_t k = 0; k < m.first[i].size() && at < cap; ++k, ++at) {
+                first_out[at] = m.first[i][k];
+                second_out[at] = m.second[i][k];
+                for (uint32_t a = 0; a < num_alleles; ++a) rate_out[(size_t)at * num_alleles + a] = m.rate[i][1 < m.rate[i].size() ? a : 0][k];
+            }
+        }
+        return 0;
+    });
+}
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;

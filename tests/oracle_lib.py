@@ -114,6 +114,7 @@ def lib():
         "orc_expand_sys_error_rate": (C.c_uint8, [C.c_uint8]),
         "orc_create_sys_error_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Text)]),
         "orc_sim_read_methylation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+        "orc_parse_methylation": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, f64p, C.c_uint32, C.c_char_p, C.c_size_t]),
         "orc_sim_load_sys_errors": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "orc_sim_free": (None, [C.c_void_p]),
         "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),

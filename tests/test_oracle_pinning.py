@@ -297,3 +297,72 @@ def oref_codes(oref, i):
     class _R(C.Structure):
         _fields_ = [("n_seqs", C.c_uint32), ("len", O.u32p), ("codes", C.POINTER(O.u8p))]
     return C.cast(oref.h, C.POINTER(_R)).contents.codes[i]
+
+
+def test_replace_n_known_answers_of_the_reference_test():
+    """ReferenceTest::TestReplaceN (ReferenceTest.cpp:526-593): the repeat fill of the two 100-N stretches is deterministic (flank
+    bases of reference-test.fa), so the expected bases hold for the oracle and for the product's host code with any seed"""
+    from reseq_amd import api
+    g = KA["replace_n"]
+    seqs = [(n, c.copy()) for n, c in read_fasta(os.path.join(GOLDEN, "reference-test.fa"))]
+    for seq, lo, hi in g["set_n"]:
+        seqs[seq][1][lo:hi] = 4
+    assert sum(int((c == 4).sum()) for _, c in seqs) == g["n_in_reference"]
+    oref = O.Reference(seqs)
+    O.lib().orc_reference_replace_n(oref.h, 317)
+    import tempfile
+    from reseq_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "withn.fa")
+        synth.write_fasta(path, seqs)
+        pref = api.Reference(path, 317)
+        product = [pref.codes(i) for i in range(2)]
+        pref.close()
+    oracle = [np.ctypeslib.as_array(C.cast(oref_codes(oref, i), O.u8p), shape=(len(seqs[i][1]),)).copy() for i in range(2)]
+    for got in (oracle, product):
+        assert all(c.max() <= 3 for c in got)
+        for seq, pos, base in g["expected"]:
+            assert got[seq][pos] == base, (seq, pos)
+    assert all(np.array_equal(a, b) for a, b in zip(oracle, product))
+    oref.close()
+
+
+def test_methylation_loading_known_answers_of_the_reference_test(workdir):
+    """ReferenceTest::TestMethylationLoading (ReferenceTest.cpp:707-768) on test/drosophila-methylation.bed with two alleles, for
+    the oracle's and the product's BED parser (the latter through the test-only host library, no GPU needed)"""
+    from backends import emu_lib
+    g = KA["methylation_loading"]
+    n = g["n_sequences"]
+    names = [f"other{i}.1" for i in range(n)]
+    for name, idx in g["sequence_index"].items():
+        names[idx] = name
+    lens = np.full(n, 40000, np.uint32)
+    bed = os.path.join(GOLDEN, "drosophila-methylation.bed")
+    A = g["num_alleles"]
+
+    def check(n_regions, first, second, rate):
+        at = 0
+        for i in range(n):
+            exp = g["regions"].get(str(i), [])
+            assert n_regions[i] == len(exp), i
+            for k, (a, b) in enumerate(exp):
+                assert (first[at], second[at]) == (a, b)
+                for allele in range(A):
+                    assert abs(rate[at * A + allele] - g["unmethylation"][str(i)][allele][k]) < 1e-15      # EXPECT_DOUBLE_EQ
+                at += 1
+        for i in g["empty"]:
+            assert n_regions[i] == 0
+
+    seqs = [(nm, np.zeros(int(l), np.uint8)) for nm, l in zip(names, lens)]
+    oref = O.Reference(seqs)
+    nr, f, s2, r = np.zeros(n, np.uint32), np.zeros(16, np.uint32), np.zeros(16, np.uint32), np.zeros(16 * A)
+    err = C.create_string_buffer(1024)
+    assert O.lib().orc_parse_methylation(bed.encode(), oref.h, A, O._ptr(nr, O.u32p), O._ptr(f, O.u32p), O._ptr(s2, O.u32p), O._ptr(r, O.f64p), 16, err, len(err)) == 0, err.value
+    check(nr, f, s2, r)
+    oref.close()
+    L = emu_lib()
+    L.emu_parse_methylation.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
+    nr2, f2, s3, r2 = np.zeros(n, np.uint32), np.zeros(16, np.uint32), np.zeros(16, np.uint32), np.zeros(16 * A)
+    rc = L.emu_parse_methylation(bed.encode(), ("\n".join(names) + "\n").encode(), lens.ctypes.data, n, A, nr2.ctypes.data, f2.ctypes.data, s3.ctypes.data, r2.ctypes.data, 16)
+    assert rc == 0, L.emu_last_error()
+    check(nr2, f2, s3, r2)
