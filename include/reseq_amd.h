@@ -62,6 +62,14 @@ int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out);
 /* Reference::WriteFasta (reseq/Reference.cpp:896-916; `reseq replaceN` writes the reference after ReplaceN): FASTA, gzip when the
  * name ends in .gz */
 int rsq_ref_write_fasta(const rsq_ref *r, const char *path);
+/* Reference::PrepareVariantFile + ReadFirstVariants / ReadVariants (reseq/Reference.cpp:126-420,1003-1077): loads a VCF, split into
+ * single-position variants per sequence (Reference::Variant, Reference.h:24-62).  LOADING ONLY in this build: rsq_sim_create refuses a
+ * reference that carries variants (the per-allele simulation of SURVEY.md section 8 row a17 is not built yet). */
+int rsq_ref_read_variants(rsq_ref *r, const char *path);
+int rsq_ref_num_alleles(const rsq_ref *r, uint32_t *out);
+int rsq_ref_num_variants(const rsq_ref *r, uint32_t seq, uint32_t *out);
+/* variant `index` of sequence `seq`: position, its bases as letters (NUL-terminated, "" = deletion), the 128 allele bits */
+int rsq_ref_get_variant(const rsq_ref *r, uint32_t seq, uint32_t index, uint32_t *position, char *var_seq, size_t var_seq_cap, uint64_t allele_bits[2]);
 /* copies the base codes (A=0,C=1,G=2,T=3,N=4) of one sequence into out[len] */
 int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len);
 

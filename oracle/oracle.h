@@ -303,6 +303,26 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
 /* Simulator.cpp:2359-2382 */
 int orc_simulate_adapter_only_pairs(const orc_sim *s, orc_text *r1, orc_text *r2);
 void orc_text_free(orc_text *t);
+/* Reference::Variant, InsertVariant, ReadFirstVariants / ReadVariants (Reference.h:24-62,115-139; Reference.cpp:126-420,1046-1077).
+ * Loading only. */
+typedef struct {
+    uint32_t position;
+    uint32_t len;
+    uint8_t *var_seq;         /* base codes */
+    uint64_t allele[2];
+} orc_variant;
+typedef struct {
+    uint32_t num_alleles, n_seqs;
+    uint32_t *n;              /* variants per sequence */
+    orc_variant **v;
+} orc_variants;
+int orc_variant_in_allele(const orc_variant *v, uint32_t allele);
+uint32_t orc_variant_first_allele(const orc_variant *v);
+void orc_insert_variant(orc_variants *vs, uint32_t seq, uint32_t position, const uint8_t *var_seq, uint32_t len, const uint64_t allele[2]);
+orc_variants *orc_variants_new(uint32_t n_seqs);
+orc_variants *orc_read_variants(const char *path, const orc_reference *r, char *err, size_t err_cap);
+void orc_variants_free(orc_variants *vs);
+
 /* --methylation without variants: Reference::PrepareMethylationFile/ReadMethylation (Reference.cpp:1132-1310) and
  * Simulator::CTConversion (Simulator.cpp:1925-2002,2219-2247).  0, or -1 with the reference's message. */
 int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap);

@@ -1379,3 +1379,258 @@ int orc_parse_methylation(const char *path, const orc_reference *r, uint32_t num
     methylation_free(&m, r->n_seqs);
     return 0;
 }
+
+/* ------------------------------------------------------------------ variants */
+int orc_variant_in_allele(const orc_variant *v, uint32_t allele) { return (int)((v->allele[allele / 64] >> (allele % 64)) & 1); }   /* Reference.h:38-40 */
+uint32_t orc_variant_first_allele(const orc_variant *v) {                /* Reference.h:42-58 */
+    uint32_t first = 0;
+    for (int b = 0; b < 2; ++b) {
+        if (v->allele[b]) {
+            while (!orc_variant_in_allele(v, first)) ++first;
+            return first;
+        }
+        first += 64;
+    }
+    return 0;
+}
+orc_variants *orc_variants_new(uint32_t n_seqs) {
+    orc_variants *vs = calloc(1, sizeof *vs);
+    vs->num_alleles = 1;
+    vs->n_seqs = n_seqs;
+    vs->n = calloc(n_seqs ? n_seqs : 1, sizeof(uint32_t));
+    vs->v = calloc(n_seqs ? n_seqs : 1, sizeof(orc_variant *));
+    return vs;
+}
+void orc_variants_free(orc_variants *vs) {
+    if (!vs) return;
+    for (uint32_t s = 0; s < vs->n_seqs; ++s) {
+        for (uint32_t i = 0; i < vs->n[s]; ++i) free(vs->v[s][i].var_seq);
+        free(vs->v[s]);
+    }
+    free(vs->n);
+    free(vs->v);
+    free(vs);
+}
+/* Reference::InsertVariant (Reference.h:115-139): at one position deletion, substitution, insertions by length */
+void orc_insert_variant(orc_variants *vs, uint32_t seq, uint32_t position, const uint8_t *var_seq, uint32_t len, const uint64_t allele[2]) {
+    orc_variant *list = vs->v[seq];
+    uint32_t n = vs->n[seq], insert_at = n, var = n;
+    while (0 < var && list[--var].position == position) {
+        if (list[var].len == len && 0 == memcmp(list[var].var_seq, var_seq, len)) {      /* already in: only adjust the alleles */
+            list[var].allele[0] |= allele[0];
+            list[var].allele[1] |= allele[1];
+            return;
+        } else if (list[var].len > len) --insert_at;
+    }
+    list = realloc(list, (n + 1) * sizeof *list);
+    memmove(list + insert_at + 1, list + insert_at, (n - insert_at) * sizeof *list);
+    list[insert_at].position = position;
+    list[insert_at].len = len;
+    list[insert_at].var_seq = malloc(len ? len : 1);
+    memcpy(list[insert_at].var_seq, var_seq, len);
+    list[insert_at].allele[0] = allele[0];
+    list[insert_at].allele[1] = allele[1];
+    vs->v[seq] = list;
+    vs->n[seq] = n + 1;
+}
+
+static uint8_t dna5_code(char c) { return c == 'A' || c == 'a' ? 0 : c == 'C' || c == 'c' ? 1 : c == 'G' || c == 'g' ? 2 : c == 'T' || c == 't' ? 3 : 4; }
+static uint32_t split_tabs(char *line, char **field, uint32_t max_fields) {
+    uint32_t n = 0;
+    field[n++] = line;
+    for (char *c = line; *c && n < max_fields; ++c)
+        if (*c == '\t') {
+            *c = 0;
+            field[n++] = c + 1;
+        }
+    return n;
+}
+
+/* PrepareVariantFile (CheckVcf), ReadFirstVariants, ReadVariants over the whole file; NULL + first messages on any error */
+orc_variants *orc_read_variants(const char *path, const orc_reference *r, char *err, size_t err_cap) {
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        if (err) snprintf(err, err_cap, "Could not open vcf file '%s'.", path);
+        return NULL;
+    }
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t len;
+    char **contigs = NULL;
+    uint32_t n_contigs = 0, errors = 0;
+    int have_record = 0;
+    size_t err_at = 0;
+    if (err && err_cap) err[0] = 0;
+#define ERROR(...)                                                                              \
+    do {                                                                                        \
+        if (errors++ < 20 && err && err_at < err_cap) err_at += (size_t)snprintf(err + err_at, err_cap - err_at, __VA_ARGS__); \
+    } while (0)
+    while ((len = getline(&line, &cap, f)) >= 0) {
+        while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+        if (0 == strncmp(line, "##", 2)) {
+            if (0 == strncmp(line, "##contig=<ID=", 13)) {
+                size_t e = strcspn(line + 13, ",>");
+                contigs = realloc(contigs, (n_contigs + 1) * sizeof *contigs);
+                contigs[n_contigs] = malloc(e + 1);
+                memcpy(contigs[n_contigs], line + 13, e);
+                contigs[n_contigs++][e] = 0;
+            }
+            continue;
+        }
+        if (!len || line[0] == '#') continue;
+        have_record = 1;
+        break;
+    }
+    if (n_contigs != r->n_seqs) ERROR("Number of contigs does not match between reference(%u) and variant(%u) file. ", r->n_seqs, n_contigs);      /* CheckVcf :80-97 */
+    for (uint32_t c = 0; c < (n_contigs < r->n_seqs ? n_contigs : r->n_seqs); ++c)
+        if (strcmp(contigs[c], r->first_name[c])) ERROR("Contigs at position %u do not match between reference(%s) and variant(%s) file. ", c, r->first_name[c], contigs[c]);
+    if (!errors && !have_record) ERROR("Vcf file '%s' has no records. ", path);
+    orc_variants *vs = NULL;
+    if (!errors) {
+        vs = orc_variants_new(r->n_seqs);
+        char *rec[4096];
+        uint32_t nf = split_tabs(line, rec, 4096);
+        if (nf < 10) ERROR("Could not read first vcf record. ");
+        else {
+            uint32_t A = 0;                                            /* ReadFirstVariants :1046-1058 */
+            for (uint32_t g = 9; g < nf; ++g) {
+                for (const char *c = rec[g]; *c && *c != ':'; ++c)
+                    if (*c == '|' || *c == '/') ++A;
+                ++A;
+            }
+            vs->num_alleles = A;
+            if (A > 128) ERROR("Currently only 128 alleles are supported, but file has %u. ", A);
+            uint32_t *allele = calloc(A ? A : 1, sizeof *allele);
+            uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0;
+            while (!errors || errors < 20) {
+                uint32_t rid = 0;
+                while (rid < n_contigs && strcmp(contigs[rid], rec[0])) ++rid;
+                uint32_t begin_pos = (uint32_t)(atoll(rec[1]) - 1);
+                int skip = 0;
+                if (rid < read_for) {                                  /* :393-414 */
+                    ERROR("Variant file is not properly position sorted. Found sequence id %u after id %u ", rid, read_for);
+                    skip = 1;
+                } else if (rid == read_for && old_ref_id != 0xFFFFFFFFu && begin_pos < start_pos) {
+                    ERROR("Variant file is not properly position sorted. Found in sequence id %u position %u after position %u ", rid, begin_pos, start_pos);
+                    skip = 1;
+                } else read_for = rid;
+                if (!skip) {
+                    if (rid >= r->n_seqs) ERROR("Variant starting in reference sequence %u does not belong to an existing reference sequence. ", rid);       /* :149 */
+                    else if (begin_pos >= r->len[rid]) ERROR("Variant starting in reference sequence %u at position %u starts after the end of the reference sequence. ", rid, begin_pos);
+                    else {
+                        start_pos = begin_pos;
+                        if (old_ref_id == rid) {
+                            if (start_pos < end_pos) ERROR("Variant starting in reference sequence %u at position %u overlaps with a previous variant. ", rid, start_pos);
+                        } else old_ref_id = rid;
+                        const char *ref = rec[3], *alt = rec[4];
+                        uint32_t ref_len = (uint32_t)strlen(ref), alt_total = (uint32_t)strlen(alt);
+                        end_pos = start_pos + ref_len;
+                        int ref_n = 0, differs = end_pos > r->len[rid];
+                        for (uint32_t k = 0; k < ref_len; ++k) {
+                            if (dna5_code(ref[k]) > 3) ref_n = 1;
+                            else if (!differs && dna5_code(ref[k]) != r->codes[rid][start_pos + k]) differs = 1;
+                        }
+                        if (ref_n) ERROR("Variant starting in reference sequence %u at position %u has an reference column containing ambiguous bases (e.g. N). ", rid, start_pos);
+                        else if (differs) ERROR("The specified reference in vcf file '%s' is not identical with the specified reference sequence %u at position %u. ", ref, rid, start_pos);
+                        int ok = 1;                                    /* genotypes :196-262 */
+                        uint32_t cur_allele = 0;
+                        for (uint32_t g = 9; g < nf && ok; ++g) {
+                            if (cur_allele >= A) {
+                                ERROR("Found to many alleles in genotype definition ");
+                                ok = 0;
+                                break;
+                            }
+                            uint32_t chosen_var = 0;
+                            int column_ok = 1;
+                            for (const char *c = rec[g]; *c && *c != ':'; ++c) {
+                                if (*c == '|' || *c == '/') {
+                                    if (cur_allele < A) allele[cur_allele] = chosen_var;
+                                    ++cur_allele;
+                                    chosen_var = 0;
+                                } else if ('0' <= *c && *c <= '9') chosen_var = chosen_var * 10 + (uint32_t)(*c - 48);
+                                else {
+                                    ERROR("Unallowed character '%c' in genotype definition '%s' ", *c, rec[g]);
+                                    column_ok = 0;
+                                }
+                            }
+                            if (cur_allele >= A) {
+                                ERROR("Found to many alleles in genotype definition ");
+                                ok = 0;
+                                break;
+                            }
+                            allele[cur_allele++] = column_ok ? chosen_var : 0;
+                            ok = ok && column_ok;
+                        }
+                        if (ok && cur_allele < A) {
+                            ERROR("Could not find enough alleles in genotype definition ");
+                            ok = 0;
+                        }
+                        if (ok) {                                      /* :270-370 */
+                            uint32_t alt_start_pos[4096], n_alt_total = 0, chosen_var = 1;
+                            uint64_t gt_has_var[4096][2];
+                            alt_start_pos[0] = 0;
+                            for (uint32_t pos = 0; pos <= alt_total && n_alt_total < 4095; ++pos) {
+                                int last = pos == alt_total;
+                                if (!last && alt[pos] != ',') continue;
+                                alt_start_pos[n_alt_total + 1] = pos + 1;
+                                uint64_t bits[2] = {0, 0};
+                                for (uint32_t a = A; a--;) {           /* backwards: allele 0 is the rightmost bit */
+                                    bits[a / 64] <<= 1;
+                                    if (allele[a] == chosen_var) ++bits[a / 64];
+                                    else if (last && allele[a] > chosen_var) ERROR("Variant number %u does not exist for sequence id %u and position %u ", allele[a], rid, begin_pos);
+                                }
+                                gt_has_var[n_alt_total][0] = bits[0];
+                                gt_has_var[n_alt_total][1] = bits[1];
+                                ++n_alt_total;
+                                ++chosen_var;
+                            }
+                            for (uint32_t pos = 0; pos < ref_len; ++pos)
+                                for (uint32_t n_alt = 0; n_alt < n_alt_total; ++n_alt) {
+                                    if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
+                                    uint32_t alt_len = alt_start_pos[n_alt + 1] - 1 - alt_start_pos[n_alt];
+                                    uint8_t inserted[65536];
+                                    uint32_t ilen = 0;
+                                    if (pos + 1 == ref_len && pos + 1 < alt_len) {                     /* insertion */
+                                        for (uint32_t k = alt_start_pos[n_alt] + pos; k < alt_start_pos[n_alt + 1] - 1 && ilen < sizeof inserted; ++k) inserted[ilen++] = dna5_code(alt[k]);
+                                    } else if (pos < alt_len) {                                        /* base mutation */
+                                        uint8_t b = dna5_code(alt[alt_start_pos[n_alt] + pos]);
+                                        if (dna5_code(ref[pos]) == b) continue;
+                                        inserted[ilen++] = b;
+                                    }                                                                  /* else deletion */
+                                    int has_n = 0;
+                                    for (uint32_t k = 0; k < ilen; ++k) has_n |= inserted[k] > 3;
+                                    if (has_n) ERROR("Variant starting in reference sequence %u at position %u has an alternative column containing ambiguous bases (e.g. N). ", rid, start_pos);
+                                    else orc_insert_variant(vs, rid, start_pos + pos, inserted, ilen, gt_has_var[n_alt]);
+                                }
+                        }
+                    }
+                }
+                int got = 0;
+                while ((len = getline(&line, &cap, f)) >= 0) {
+                    while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+                    if (len) {
+                        got = 1;
+                        break;
+                    }
+                }
+                if (!got) break;
+                nf = split_tabs(line, rec, 4096);
+                if (nf < 10) {
+                    ERROR("Could not read vcf record. ");
+                    break;
+                }
+            }
+            free(allele);
+        }
+    }
+#undef ERROR
+    free(line);
+    fclose(f);
+    for (uint32_t c = 0; c < n_contigs; ++c) free(contigs[c]);
+    free(contigs);
+    if (errors) {
+        orc_variants_free(vs);
+        return NULL;
+    }
+    return vs;
+}

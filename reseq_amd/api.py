@@ -52,6 +52,10 @@ SYMBOLS = {
     "rsq_ref_num_sequences": (C.c_int, [_vp, C.POINTER(_u32)]),
     "rsq_ref_sequence_length": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
     "rsq_ref_write_fasta": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_ref_read_variants": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_ref_num_alleles": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_ref_num_variants": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    "rsq_ref_get_variant": (C.c_int, [_vp, _u32, _u32, C.POINTER(_u32), C.c_char_p, _sz, C.POINTER(_u64)]),
     "rsq_ref_get_codes": (C.c_int, [_vp, _u32, _vp, _u32]),
     "rsq_sim_create": (C.c_int, [_vp, _vp, C.c_int, _pp]),
     "rsq_sim_free": (None, [_vp]),
@@ -153,6 +157,24 @@ class Reference:
         v = C.c_uint32()
         _check(lib().rsq_ref_sequence_length(self.h, i, C.byref(v)))
         return v.value
+
+    def read_variants(self, path):
+        """Reference::PrepareVariantFile + ReadFirstVariants: returns the number of alleles"""
+        _check(lib().rsq_ref_read_variants(self.h, str(path).encode()))
+        n = _u32()
+        _check(lib().rsq_ref_num_alleles(self.h, C.byref(n)))
+        return n.value
+
+    def variants(self, seq):
+        """[(position, bases, allele bits as int)] of one sequence"""
+        n = _u32()
+        _check(lib().rsq_ref_num_variants(self.h, seq, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            pos, buf, bits = _u32(), C.create_string_buffer(1 << 16), (_u64 * 2)()
+            _check(lib().rsq_ref_get_variant(self.h, seq, i, C.byref(pos), buf, len(buf), bits))
+            out.append((pos.value, buf.value.decode(), bits[0] | (bits[1] << 64)))
+        return out
 
     def write_fasta(self, path):
         _check(lib().rsq_ref_write_fasta(self.h, str(path).encode()))

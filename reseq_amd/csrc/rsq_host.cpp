@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 
 #include <fstream>
 
@@ -564,6 +565,248 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
         }
     }
     return m;
+}
+
+// ---------------------------------------------------------------------------------------------- variants (VCF)
+uint32_t Variant::first_allele() const {                              // Reference.h:42-58
+    uint32_t first = 0;
+    for (uint64_t block : allele) {
+        if (block) {
+            while (!in_allele(first)) ++first;
+            return first;
+        }
+        first += 64;
+    }
+    return 0;                                                         // "Variant belonging to no allele"
+}
+
+void insert_variant(std::vector<Variant> &variants, uint32_t position, const std::vector<uint8_t> &var_seq, const uint64_t (&allele)[2]) {      // Reference.h:115-139
+    Variant v;
+    v.position = position;
+    v.var_seq = var_seq;
+    v.allele[0] = allele[0];
+    v.allele[1] = allele[1];
+    if (variants.empty()) {
+        variants.push_back(v);
+        return;
+    }
+    size_t insert_at = variants.size();                               // at one position: deletion / substitution / insertions by length
+    size_t var = variants.size();
+    while (0 < var && variants[--var].position == position) {
+        if (variants[var].var_seq == var_seq) {                       // already in: only adjust the alleles
+            variants[var].allele[0] |= allele[0];
+            variants[var].allele[1] |= allele[1];
+            return;
+        } else if (variants[var].var_seq.size() > var_seq.size()) --insert_at;
+    }
+    variants.insert(variants.begin() + (ptrdiff_t)insert_at, v);
+}
+
+namespace {
+std::vector<std::string> split_tabs(const std::string &line) {
+    std::vector<std::string> f;
+    size_t at = 0;
+    for (;;) {
+        const size_t e = line.find('\t', at);
+        if (e == std::string::npos) {
+            f.push_back(line.substr(at));
+            return f;
+        }
+        f.push_back(line.substr(at, e - at));
+        at = e + 1;
+    }
+}
+uint8_t dna5_code(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+}  // namespace
+
+Variants read_variants(const std::string &path, const std::vector<std::string> &first_names, const std::vector<std::vector<uint8_t>> &codes) {
+    GzLines f(path);
+    std::string line;
+    std::vector<std::string> contigs;
+    bool have_record = false;
+    while (f.getline(line)) {                                         // readHeader: ## lines, then the #CHROM line
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.compare(0, 2, "##") == 0) {
+            if (line.compare(0, 13, "##contig=<ID=") == 0) {
+                const size_t e = line.find_first_of(",>", 13);
+                contigs.push_back(line.substr(13, e == std::string::npos ? std::string::npos : e - 13));
+            }
+            continue;
+        }
+        if (!line.empty() && line[0] == '#') continue;
+        if (line.empty()) continue;
+        have_record = true;
+        break;
+    }
+    // CheckVcf (Reference.cpp:80-97)
+    std::string errors;
+    uint32_t n_errors = 0;
+    auto error = [&](const std::string &msg) {
+        if (n_errors++ < 20) errors += msg + " ";
+    };
+    if (contigs.size() != first_names.size())
+        error("Number of contigs does not match between reference(" + std::to_string(first_names.size()) + ") and variant(" + std::to_string(contigs.size()) + ") file.");
+    for (size_t c = 0; c < std::min(contigs.size(), first_names.size()); ++c)
+        if (contigs[c] != first_names[c]) error("Contigs at position " + std::to_string(c) + " do not match between reference(" + first_names[c] + ") and variant(" + contigs[c] + ") file.");
+    if (n_errors) throw Error(errors);
+    if (!have_record) throw Error("Vcf file '" + path + "' has no records.");
+
+    Variants out;
+    out.by_seq.resize(first_names.size());
+    std::vector<std::string> rec = split_tabs(line);
+    if (rec.size() < 10) throw Error("Could not read first vcf record: fewer than 10 columns");
+    out.num_alleles = 0;                                              // ReadFirstVariants (:1046-1058)
+    for (size_t g = 9; g < rec.size(); ++g) {
+        for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos)
+            if ('|' == rec[g][pos] || '/' == rec[g][pos]) ++out.num_alleles;
+        ++out.num_alleles;
+    }
+    if (out.num_alleles > Variant::kMaxAlleles) throw Error("Currently only 128 alleles are supported, but file has " + std::to_string(out.num_alleles) + ".");
+
+    // ReadVariants (:126-420) over the whole file
+    const uint32_t A = out.num_alleles;
+    std::vector<uint32_t> allele(A);
+    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0;
+    for (;;) {
+        uint32_t rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());      // unknown names get a new id
+        const long long pos1 = atoll(rec[1].c_str());
+        const uint32_t begin_pos = (uint32_t)(pos1 - 1);
+        bool skip_rest = false;
+        if (rid < read_for) {                                         // :393-401 (checked when the record is read)
+            error("Variant file is not properly position sorted. Found sequence id " + std::to_string(rid) + " after id " + std::to_string(read_for));
+            skip_rest = true;
+        } else if (rid == read_for && old_ref_id != 0xFFFFFFFFu && begin_pos < start_pos) {
+            error("Variant file is not properly position sorted. Found in sequence id " + std::to_string(rid) + " position " + std::to_string(begin_pos) + " after position " +
+                  std::to_string(start_pos));
+            skip_rest = true;
+        } else read_for = rid;
+        if (!skip_rest) {
+            if (rid >= first_names.size()) {
+                error("Variant starting in reference sequence " + std::to_string(rid) + " does not belong to an existing reference sequence.");
+            } else if (begin_pos >= codes[rid].size()) {
+                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(begin_pos) + " starts after the end of the reference sequence.");
+            } else {
+                start_pos = begin_pos;
+                if (old_ref_id == rid) {
+                    if (start_pos < end_pos) error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " overlaps with a previous variant.");
+                } else old_ref_id = rid;
+                const std::string &ref = rec[3], &alt = rec[4];
+                end_pos = start_pos + (uint32_t)ref.size();
+                std::vector<uint8_t> vcf_ref(ref.size());
+                bool ref_n = false;
+                for (size_t k = 0; k < ref.size(); ++k) ref_n |= (vcf_ref[k] = dna5_code(ref[k])) > 3;
+                if (ref_n)
+                    error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an reference column containing ambiguous bases (e.g. N).");
+                else if (end_pos > codes[rid].size() || !std::equal(vcf_ref.begin(), vcf_ref.end(), codes[rid].begin() + start_pos))
+                    error("The specified reference in vcf file '" + ref + "' is not identical with the specified reference sequence " + std::to_string(rid) + " at position " +
+                          std::to_string(start_pos) + ".");
+                // genotypes (:196-262)
+                bool ok = true;
+                uint32_t cur_allele = 0;
+                for (size_t g = 9; g < rec.size() && ok; ++g) {
+                    if (cur_allele >= A) {
+                        error("Found to many alleles in genotype definition");
+                        ok = false;
+                        break;
+                    }
+                    uint32_t chosen = 0;
+                    bool column_ok = true;
+                    for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos) {
+                        const char c = rec[g][pos];
+                        if ('|' == c || '/' == c) {
+                            if (cur_allele < A) allele[cur_allele] = chosen;
+                            ++cur_allele;
+                            chosen = 0;
+                        } else if ('0' <= c && '9' >= c) chosen = chosen * 10 + (uint32_t)(c - '0');
+                        else {
+                            error(std::string("Unallowed character '") + c + "' in genotype definition '" + rec[g] + "'");
+                            column_ok = false;
+                        }
+                    }
+                    if (cur_allele >= A) {                               // the reference would index past `allele` here
+                        error("Found to many alleles in genotype definition");
+                        ok = false;
+                        break;
+                    }
+                    allele[cur_allele++] = column_ok ? chosen : 0;
+                    ok = ok && column_ok;
+                }
+                if (ok && cur_allele < A) {
+                    error("Could not find enough alleles in genotype definition");
+                    ok = false;
+                }
+                if (ok) {                                             // :270-370 alternatives, one bit per allele that carries them
+                    std::vector<size_t> alt_start{0};
+                    std::vector<std::array<uint64_t, 2>> gt_has_var;
+                    uint32_t chosen_var = 1;
+                    auto carriers = [&](bool last) {
+                        std::array<uint64_t, 2> bits{0, 0};
+                        for (uint32_t a = A; a--;) {
+                            bits[a / 64] <<= 1;
+                            if (allele[a] == chosen_var) ++bits[a / 64];
+                            else if (last && allele[a] > chosen_var)
+                                error("Variant number " + std::to_string(allele[a]) + " does not exist for sequence id " + std::to_string(rid) + " and position " + std::to_string(begin_pos));
+                        }
+                        gt_has_var.push_back(bits);
+                        ++chosen_var;
+                    };
+                    for (size_t pos = 0; pos < alt.size(); ++pos)
+                        if (',' == alt[pos]) {
+                            alt_start.push_back(pos + 1);
+                            carriers(false);
+                        }
+                    alt_start.push_back(alt.size() + 1);
+                    carriers(true);
+                    for (size_t pos = 0; pos < vcf_ref.size(); ++pos)
+                        for (size_t n_alt = 0; n_alt < gt_has_var.size(); ++n_alt) {
+                            if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
+                            const size_t alt_len = alt_start[n_alt + 1] - 1 - alt_start[n_alt];
+                            std::vector<uint8_t> inserted;
+                            if (pos + 1 == vcf_ref.size() && pos + 1 < alt_len) {                         // insertion
+                                for (size_t k = alt_start[n_alt] + pos; k < alt_start[n_alt + 1] - 1; ++k) inserted.push_back(dna5_code(alt[k]));
+                            } else if (pos < alt_len) {                                                    // base mutation
+                                const uint8_t b = dna5_code(alt[alt_start[n_alt] + pos]);
+                                if (vcf_ref[pos] == b) continue;
+                                inserted.push_back(b);
+                            }                                                                              // else: deletion, ""
+                            bool has_n = false;
+                            for (uint8_t b : inserted) has_n |= b > 3;
+                            if (has_n) {
+                                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an alternative column containing ambiguous bases (e.g. N).");
+                            } else {
+                                const uint64_t bits[2] = {gt_has_var[n_alt][0], gt_has_var[n_alt][1]};
+                                insert_variant(out.by_seq[rid], start_pos + (uint32_t)pos, inserted, bits);
+                            }
+                        }
+                }
+            }
+        }
+        if (n_errors >= 20) break;                                    // kMaxErrorsShownPerFile
+        bool got = false;
+        while (f.getline(line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty()) {
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+        rec = split_tabs(line);
+        if (rec.size() < 10) {
+            error("Could not read vcf record: fewer than 10 columns");
+            break;
+        }
+    }
+    if (n_errors) throw Error(errors);
+    return out;
 }
 
 }  // namespace rsq

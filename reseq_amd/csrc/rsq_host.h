@@ -147,4 +147,25 @@ struct Methylation {
 };
 Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len, uint32_t num_alleles = 1);
 
+// ---------------------------------------------------------------------------------------------- variants (VCF)
+// Reference::Variant (Reference.h:24-62), InsertVariant (:115-139), PrepareVariantFile / ReadFirstVariants / ReadVariants
+// (Reference.cpp:126-420, 1003-1077): every VCF record is split into single-reference-position variants (substitution, deletion "",
+// insertion = the base at the position followed by the inserted bases), kept per sequence sorted by position and, at one position,
+// by length; one bit per allele (up to 128) says which alleles carry it.  Loading only: the simulation with variants (SURVEY.md
+// section 8 row a17) is not built yet.
+struct Variant {
+    static constexpr uint32_t kMaxAlleles = 128;
+    uint32_t position = 0;
+    std::vector<uint8_t> var_seq;          // base codes 0..3
+    uint64_t allele[2] = {0, 0};
+    bool in_allele(uint32_t a) const { return (allele[a / 64] >> (a % 64)) & 1; }
+    uint32_t first_allele() const;         // Reference.h:42-58
+};
+struct Variants {
+    uint32_t num_alleles = 1;
+    std::vector<std::vector<Variant>> by_seq;
+};
+void insert_variant(std::vector<Variant> &variants, uint32_t position, const std::vector<uint8_t> &var_seq, const uint64_t (&allele)[2]);
+Variants read_variants(const std::string &path, const std::vector<std::string> &first_names, const std::vector<std::vector<uint8_t>> &codes);
+
 }  // namespace rsq

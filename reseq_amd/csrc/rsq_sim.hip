@@ -88,6 +88,8 @@ struct rsq_profile {
 };
 struct rsq_ref {
     Reference r;
+    Variants variants;
+    bool has_variants = false;
 };
 
 // arrays packed by rsq_pack.h go to HBM; they live as long as the simulator
@@ -549,6 +551,40 @@ int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out) {
     *out = (uint32_t)r->r.codes[seq].size();
     return RSQ_OK;
 }
+int rsq_ref_read_variants(rsq_ref *r, const char *path) {
+    REQUIRE(r && path, "null argument");
+    try {
+        std::vector<std::string> first;
+        for (size_t i = 0; i < r->r.codes.size(); ++i) first.push_back(r->r.first_part(i));
+        r->variants = read_variants(path, first, r->r.codes);
+        r->has_variants = true;
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
+int rsq_ref_num_alleles(const rsq_ref *r, uint32_t *out) {
+    REQUIRE(r && out, "null argument");
+    *out = r->variants.num_alleles;
+    return RSQ_OK;
+}
+int rsq_ref_num_variants(const rsq_ref *r, uint32_t seq, uint32_t *out) {
+    REQUIRE(r && out && r->has_variants && seq < r->variants.by_seq.size(), "no variants loaded or bad sequence id");
+    *out = (uint32_t)r->variants.by_seq[seq].size();
+    return RSQ_OK;
+}
+int rsq_ref_get_variant(const rsq_ref *r, uint32_t seq, uint32_t index, uint32_t *position, char *var_seq, size_t var_seq_cap, uint64_t allele_bits[2]) {
+    REQUIRE(r && position && var_seq && allele_bits && r->has_variants && seq < r->variants.by_seq.size() && index < r->variants.by_seq[seq].size(), "bad variant index");
+    const Variant &v = r->variants.by_seq[seq][index];
+    REQUIRE(v.var_seq.size() + 1 <= var_seq_cap, "var_seq buffer too small");
+    *position = v.position;
+    for (size_t k = 0; k < v.var_seq.size(); ++k) var_seq[k] = "ACGTN"[v.var_seq[k]];
+    var_seq[v.var_seq.size()] = 0;
+    allele_bits[0] = v.allele[0];
+    allele_bits[1] = v.allele[1];
+    return RSQ_OK;
+}
 int rsq_ref_write_fasta(const rsq_ref *r, const char *path) {
     REQUIRE(r && path, "null argument");
     try {
@@ -581,6 +617,7 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     int n = rsq_device_count();
     if (n < 0) return n;
     REQUIRE(device >= 0 && device < n, "device index out of range");
+    REQUIRE(!(ref && ref->has_variants), "the reference carries variants: the per-allele simulation (--vcfSim) is not built yet");
     std::unique_ptr<rsq_sim> s(new rsq_sim());
     int rc = guard([&] {
         HIP_CHECK(hipSetDevice(device));

@@ -194,6 +194,28 @@ ka["methylation_loading"] = {
     "empty": [1, 10, 20],
 }
 
+# ReferenceTest.cpp:30-84 TestVariantClass: allele bit blocks -> InAllele of alleles (0, 1, 2, 64), FirstAllele
+ka["variant_class"] = [   # [allele_[0], allele_[1], {allele: InAllele}, FirstAllele]
+    [7, 0, {"0": True, "1": True, "2": True}, 0], [6, 0, {"0": False, "1": True, "2": True}, 1], [5, 0, {"0": True, "1": False, "2": True}, 0],
+    [4, 0, {"0": False, "1": False, "2": True}, 2], [3, 0, {"0": True, "1": True, "2": False}, 0], [2, 0, {"0": False, "1": True, "2": False}, 1],
+    [1, 0, {"0": True, "1": False, "2": False}, 0], [1, 1, {"0": True, "1": False, "2": False, "64": True}, 0], [0, 1, {"0": False, "64": True}, 64],
+]
+# ReferenceTest.cpp:86-136 TestInsertVariant: calls (position, var_seq, allele_[0]) in order -> resulting list
+ka["insert_variant"] = {
+    "calls": [[0, "A", 1], [1, "A", 2], [1, "ACT", 1], [1, "C", 4], [1, "", 8], [1, "C", 16], [1, "", 32], [1, "ACT", 64], [1, "TG", 128]],
+    "expected": [[0, "A", 1], [1, "", 40], [1, "A", 2], [1, "C", 20], [1, "TG", 128], [1, "ACT", 65]],
+}
+# ReferenceTest.cpp:138-239 TestVariationLoading on test/test-var.vcf (copied next to this file; E. coli NC_000913.3, 4 641 652 bases):
+# two alleles, 13 single-position variants [position, var_seq, InAllele(0), InAllele(1)].  ref_alleles are the VCF's own REF columns
+# (0-based position, bases): the reference sequence has to carry them for the consistency check of ReadVariants (Reference.cpp:188).
+ka["variation_loading"] = {
+    "contig": "NC_000913.3", "length": 4641652, "num_alleles": 2,
+    "ref_alleles": [[0, "AGCTTTTCA"], [16, "T"], [20, "A"], [11368, "CTA"], [953165, "A"], [3192437, "TT"], [3424235, "T"], [3424236, "C"]],
+    "variants": [[2, "T", False, True], [3, "A", False, True], [4, "A", False, True], [5, "G", False, True], [7, "A", False, True], [8, "TTTTTCAGCTTTTCA", False, True],
+                 [11368, "T", False, True], [11370, "T", False, True], [953165, "G", False, True], [3192437, "G", False, True], [3192438, "", False, True],
+                 [3424235, "C", True, True], [3424236, "A", True, True]],
+}
+
 with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
     json.dump(ka, f, indent=1)
 print("wrote", len(ka), "groups")

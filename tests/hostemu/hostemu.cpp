@@ -316,6 +316,27 @@ int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t
         return 0;
     });
 }
+// the product's InsertVariant alone (rsq_host.cpp), for ReferenceTest::TestInsertVariant: calls in, list out (positions, lengths, letters, bits)
+int emu_insert_variants_test(uint32_t n_calls, const uint32_t *positions, const char *const *var_seqs, const uint64_t *allele0, uint32_t *n_out, uint32_t *pos_out,
+                             char *seq_out /* n x 16 */, uint64_t *allele0_out) {
+    return guard([&] {
+        std::vector<Variant> list;
+        for (uint32_t i = 0; i < n_calls; ++i) {
+            std::vector<uint8_t> codes;
+            for (const char *c = var_seqs[i]; *c; ++c) codes.push_back((uint8_t)(strchr("ACGT", *c) - "ACGT"));
+            const uint64_t bits[2] = {allele0[i], 0};
+            insert_variant(list, positions[i], codes, bits);
+        }
+        *n_out = (uint32_t)list.size();
+        for (size_t i = 0; i < list.size(); ++i) {
+            pos_out[i] = list[i].position;
+            allele0_out[i] = list[i].allele[0];
+            for (size_t k = 0; k < list[i].var_seq.size(); ++k) seq_out[i * 16 + k] = "ACGT"[list[i].var_seq[k]];
+            seq_out[i * 16 + list[i].var_seq.size()] = 0;
+        }
+        return 0;
+    });
+}
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;

@@ -25,6 +25,14 @@ FRAGMENT_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("d
                            ("pad", "u1"), ("block", "<u4"), ("number", "<u4")])
 
 
+class OrcVariant(C.Structure):
+    _fields_ = [("position", C.c_uint32), ("len", C.c_uint32), ("var_seq", u8p), ("allele", C.c_uint64 * 2)]
+
+
+class OrcVariants(C.Structure):
+    _fields_ = [("num_alleles", C.c_uint32), ("n_seqs", C.c_uint32), ("n", u32p), ("v", C.POINTER(C.POINTER(OrcVariant)))]
+
+
 class Read(C.Structure):
     _fields_ = [("read_len", C.c_uint16), ("num_errors", C.c_uint16), ("seq", C.c_uint8 * 1024),
                 ("qual", C.c_uint8 * 1024), ("cigar", C.c_char * 4096)]
@@ -115,6 +123,12 @@ def lib():
         "orc_create_sys_error_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Text)]),
         "orc_sim_read_methylation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
         "orc_parse_methylation": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, u32p, u32p, u32p, f64p, C.c_uint32, C.c_char_p, C.c_size_t]),
+        "orc_variant_in_allele": (C.c_int, [C.POINTER(OrcVariant), C.c_uint32]),
+        "orc_variant_first_allele": (C.c_uint32, [C.POINTER(OrcVariant)]),
+        "orc_insert_variant": (None, [C.POINTER(OrcVariants), C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "orc_variants_new": (C.POINTER(OrcVariants), [C.c_uint32]),
+        "orc_read_variants": (C.POINTER(OrcVariants), [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]),
+        "orc_variants_free": (None, [C.POINTER(OrcVariants)]),
         "orc_sim_load_sys_errors": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "orc_sim_free": (None, [C.c_void_p]),
         "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),
@@ -187,6 +201,15 @@ class Reference:
 def _take_text(t):
     out = C.string_at(t.data, t.len) if t.len else b""
     lib().orc_text_free(C.byref(t))
+    return out
+
+
+def variant_list(vs, seq):
+    """[(position, letters, allele bits as int)] of one sequence of an OrcVariants"""
+    out = []
+    for i in range(vs.contents.n[seq]):
+        v = vs.contents.v[seq][i]
+        out.append((v.position, "".join("ACGT"[v.var_seq[k]] for k in range(v.len)), v.allele[0] | (v.allele[1] << 64)))
     return out
 
 

@@ -366,3 +366,71 @@ def test_methylation_loading_known_answers_of_the_reference_test(workdir):
     rc = L.emu_parse_methylation(bed.encode(), ("\n".join(names) + "\n").encode(), lens.ctypes.data, n, A, nr2.ctypes.data, f2.ctypes.data, s3.ctypes.data, r2.ctypes.data, 16)
     assert rc == 0, L.emu_last_error()
     check(nr2, f2, s3, r2)
+
+
+def test_variant_class_known_answers():
+    """ReferenceTest::TestVariantClass (ReferenceTest.cpp:30-84)"""
+    for a0, a1, in_allele, first in KA["variant_class"]:
+        v = O.OrcVariant(0, 0, None, (C.c_uint64 * 2)(a0, a1))
+        for allele, exp in in_allele.items():
+            assert bool(O.lib().orc_variant_in_allele(C.byref(v), int(allele))) == exp
+        assert O.lib().orc_variant_first_allele(C.byref(v)) == first
+
+
+def test_insert_variant_known_answers():
+    """ReferenceTest::TestInsertVariant (ReferenceTest.cpp:86-136) for the oracle's and the product's InsertVariant"""
+    from backends import emu_lib
+    g = KA["insert_variant"]
+    vs = O.lib().orc_variants_new(1)
+    for pos, seq, bits in g["calls"]:
+        codes = np.array(["ACGT".index(c) for c in seq], np.uint8)
+        O.lib().orc_insert_variant(vs, 0, pos, O._ptr(codes, O.u8p) if len(codes) else None, len(codes), (C.c_uint64 * 2)(bits, 0))
+    assert O.variant_list(vs, 0) == [tuple(e) for e in g["expected"]]
+    O.lib().orc_variants_free(vs)
+    L = emu_lib()
+    n = len(g["calls"])
+    pos = np.array([c[0] for c in g["calls"]], np.uint32)
+    bits = np.array([c[2] for c in g["calls"]], np.uint64)
+    seqs = (C.c_char_p * n)(*[c[1].encode() for c in g["calls"]])
+    n_out, pos_out, seq_out, bits_out = C.c_uint32(), np.zeros(n, np.uint32), C.create_string_buffer(16 * n), np.zeros(n, np.uint64)
+    L.emu_insert_variants_test.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_char_p, C.c_void_p]
+    assert L.emu_insert_variants_test(n, pos.ctypes.data, seqs, bits.ctypes.data, C.byref(n_out), pos_out.ctypes.data, seq_out, bits_out.ctypes.data) == 0
+    got = [(int(pos_out[i]), seq_out.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), int(bits_out[i])) for i in range(n_out.value)]
+    assert got == [tuple(e) for e in g["expected"]]
+
+
+def test_variation_loading_known_answers(workdir):
+    """ReferenceTest::TestVariationLoading (ReferenceTest.cpp:138-239) on test/test-var.vcf: the 13 single-position variants, for the
+    oracle's loader and for the product's (rsq_ref_read_variants, host code, no GPU).  The E. coli FASTA the reference test reads is not
+    part of the repository; a sequence of the right name and length carrying the VCF's REF alleles stands in (ReadVariants checks them)."""
+    from reseq_amd import api, synth
+    g = KA["variation_loading"]
+    codes = np.random.default_rng(5).integers(0, 4, g["length"]).astype(np.uint8)
+    for pos, bases in g["ref_alleles"]:
+        codes[pos:pos + len(bases)] = ["ACGT".index(c) for c in bases]
+    seqs = [(g["contig"] + " Escherichia coli str. K-12 substr. MG1655, complete genome", codes)]
+    vcf = os.path.join(GOLDEN, "test-var.vcf")
+    exp = [(p, s, (1 if a0 else 0) | (2 if a1 else 0)) for p, s, a0, a1 in g["variants"]]
+    oref = O.Reference(seqs)
+    err = C.create_string_buffer(4096)
+    vs = O.lib().orc_read_variants(vcf.encode(), oref.h, err, len(err))
+    assert vs, err.value
+    assert vs.contents.num_alleles == g["num_alleles"] and O.variant_list(vs, 0) == exp
+    O.lib().orc_variants_free(vs)
+    fa = workdir / "ecoli_standin.fa"
+    synth.write_fasta(fa, seqs)
+    ref = api.Reference(str(fa))
+    assert ref.read_variants(vcf) == g["num_alleles"]
+    assert ref.variants(0) == exp
+    ref.close()
+    # a reference that does not carry the REF alleles is rejected by both
+    codes[11368] = (codes[11368] + 1) % 4
+    oref2 = O.Reference([(seqs[0][0], codes)])
+    assert not O.lib().orc_read_variants(vcf.encode(), oref2.h, err, len(err)) and b"not identical" in err.value
+    synth.write_fasta(fa, [(seqs[0][0], codes)])
+    ref = api.Reference(str(fa))
+    with pytest.raises(api.RsqError, match="not identical"):
+        ref.read_variants(vcf)
+    ref.close()
+    oref.close()
+    oref2.close()
