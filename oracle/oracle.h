@@ -176,6 +176,12 @@ void orc_surrounding_forward(const uint8_t *seq, uint32_t len, uint32_t pos, int
 void orc_surrounding_reverse(const uint8_t *seq, uint32_t len, uint32_t pos, int32_t sur[3]);
 void orc_surrounding_update_forward(const uint8_t *seq, uint32_t len, uint32_t new_pos, int32_t sur[3]);
 void orc_surrounding_update_reverse(const uint8_t *seq, uint32_t len, uint32_t new_pos, int32_t sur[3]);
+/* Surrounding.cpp:22-192: edits of the three 20-bit blocks for a variant inside the window (pos 0..29, base codes 0..3) */
+void orc_sur_change_base(int32_t sur[3], uint32_t pos, uint8_t new_base);
+void orc_sur_delete_shift_right(int32_t sur[3], uint32_t pos, uint8_t new_end_base);
+void orc_sur_delete_shift_left(int32_t sur[3], uint32_t pos, uint8_t new_end_base);
+void orc_sur_insert_shift_right(int32_t sur[3], uint32_t pos, const uint8_t *new_bases, uint32_t n);
+void orc_sur_insert_shift_left(int32_t sur[3], uint32_t pos, const uint8_t *new_bases, uint32_t n);
 /* Surrounding.cpp:194-260 */
 void orc_combine_positions(const double *separated /*120*/, double *bias /*3<<20*/);
 void orc_separate_positions(const double *bias, double *separated);

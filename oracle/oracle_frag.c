@@ -186,3 +186,120 @@ void orc_select_allele(uint16_t *chosen, uint32_t *n_chosen, uint8_t *reverse_se
     chosen[(*n_chosen)++] = chosen_id;
     reverse_selection[chosen_id] = 0;
 }
+
+/* ------------------------------------------------- Surrounding edits (variants) */
+#define SUR_LENGTH 30
+#define SUR_ISIZE (1 << 20)
+void orc_sur_change_base(int32_t sur[3], uint32_t pos, uint8_t new_base) {               /* Surrounding.cpp:22-26 */
+    int bit_in_block = 2 * (SUR_RANGE - (pos % SUR_RANGE) - 1);
+    sur[pos / SUR_RANGE] = (sur[pos / SUR_RANGE] & ~(3 << bit_in_block)) + ((int32_t)new_base << bit_in_block);
+}
+void orc_sur_delete_shift_right(int32_t sur[3], uint32_t pos, uint8_t new_end_base) {    /* :28-43 */
+    int32_t new_base = new_end_base;
+    int del_block = (int)(pos / SUR_RANGE);
+    for (int block = SUR_BLOCKS; --block > del_block;) {                                  /* add the base at the end, shift towards the deletion */
+        sur[block] = (sur[block] << 2) + new_base;
+        new_base = sur[block] / SUR_ISIZE;
+        sur[block] = sur[block] % SUR_ISIZE;
+    }
+    int bit_in_block = 2 * (SUR_RANGE - (pos % SUR_RANGE) - 1);
+    new_base += (sur[del_block] % (1 << bit_in_block)) << 2;
+    sur[del_block] = (sur[del_block] >> (bit_in_block + 2) << (bit_in_block + 2)) + new_base;
+}
+void orc_sur_delete_shift_left(int32_t sur[3], uint32_t pos, uint8_t new_end_base) {     /* :45-60 */
+    int32_t new_base = new_end_base;
+    int del_block = (int)(pos / SUR_RANGE);
+    for (int block = 0; block < del_block; ++block) {
+        sur[block] += new_base * SUR_ISIZE;
+        new_base = sur[block] % 4;
+        sur[block] = sur[block] >> 2;
+    }
+    int bit_in_block = 2 * (SUR_RANGE - (pos % SUR_RANGE) - 1);
+    sur[del_block] += new_base * SUR_ISIZE;
+    sur[del_block] = (sur[del_block] >> (bit_in_block + 2) << bit_in_block) + sur[del_block] % (1 << bit_in_block);
+}
+static int imin(int a, int b) { return a < b ? a : b; }
+void orc_sur_insert_shift_right(int32_t sur[3], uint32_t pos, const uint8_t *new_bases, uint32_t n) {       /* :62-125 */
+    int block = (int)(pos / SUR_RANGE);
+    int bases_to_insert = imin((int)n, SUR_LENGTH - (int)pos);
+    int shift_blocks = bases_to_insert / SUR_RANGE, shift_bases = bases_to_insert % SUR_RANGE;
+    for (int cur_block = SUR_BLOCKS - shift_blocks; cur_block-- > block + 1;) {
+        sur[cur_block] >>= 2 * shift_bases;
+        sur[cur_block] += sur[cur_block - 1] % (1 << 2 * shift_bases) * (1 << 2 * (SUR_RANGE - shift_bases));
+    }
+    int inv_pos_in_block = SUR_RANGE - (int)(pos % SUR_RANGE);
+    int32_t tmp_sur = sur[block] % (1 << 2 * inv_pos_in_block);
+    sur[block] >>= 2 * inv_pos_in_block;
+    tmp_sur >>= 2 * shift_bases;
+    if (0 < shift_blocks && SUR_BLOCKS > block + shift_blocks) {
+        for (int cur_block = SUR_BLOCKS; cur_block-- > block + shift_blocks + 1;) sur[cur_block] = sur[cur_block - shift_blocks];
+        sur[block + shift_blocks] = tmp_sur;
+    }
+    int ins_pos = 0;
+    int into_this_block = imin(bases_to_insert, inv_pos_in_block);
+    bases_to_insert -= into_this_block;
+    for (; into_this_block--;) {
+        sur[block] <<= 2;
+        sur[block] += new_bases[ins_pos++];
+    }
+    if (0 == shift_blocks && inv_pos_in_block > shift_bases) {
+        sur[block] <<= 2 * (inv_pos_in_block - shift_bases);
+        sur[block] += tmp_sur;
+    } else {
+        while (0 < bases_to_insert) {
+            into_this_block = imin(bases_to_insert, SUR_RANGE);
+            bases_to_insert -= into_this_block;
+            tmp_sur = sur[++block] % (1 << 2 * (SUR_RANGE - into_this_block));
+            sur[block] = 0;
+            for (int i = into_this_block; i--;) {
+                sur[block] <<= 2;
+                sur[block] += new_bases[ins_pos++];
+            }
+            sur[block] <<= 2 * (SUR_RANGE - into_this_block);
+            sur[block] += tmp_sur;
+        }
+    }
+}
+void orc_sur_insert_shift_left(int32_t sur[3], uint32_t pos, const uint8_t *new_bases, uint32_t n) {        /* :127-192 */
+    int block = (int)(pos / SUR_RANGE);
+    int bases_to_insert = imin((int)n, (int)pos + 1);
+    int shift_blocks = bases_to_insert / SUR_RANGE, shift_bases = bases_to_insert % SUR_RANGE;
+    for (int cur_block = shift_blocks; cur_block < block; ++cur_block) {
+        sur[cur_block] %= 1 << 2 * (SUR_RANGE - shift_bases);
+        sur[cur_block] <<= 2 * shift_bases;
+        sur[cur_block] += sur[cur_block + 1] >> 2 * (SUR_RANGE - shift_bases);
+    }
+    int pos_in_block = (int)(pos % SUR_RANGE) + 1;
+    int32_t tmp_sur = sur[block] % (1 << 2 * (SUR_RANGE - pos_in_block));
+    if (pos_in_block > shift_bases) {
+        sur[block] >>= 2 * (SUR_RANGE - pos_in_block);
+        sur[block] %= 1 << 2 * (pos_in_block - shift_bases);
+    } else sur[block] = 0;
+    if (0 < shift_blocks) {
+        if (block >= shift_blocks) {
+            for (int cur_block = 0; cur_block + shift_blocks < block; ++cur_block) sur[cur_block] = sur[cur_block + shift_blocks];
+            sur[block - shift_blocks] = sur[block] << 2 * (SUR_RANGE - (pos_in_block - shift_bases));
+        }
+        sur[block] = 0;
+    }
+    int into_this_block = imin(bases_to_insert, pos_in_block);
+    int ins_pos_to = (int)n;
+    for (int ins_pos = ins_pos_to - into_this_block; ins_pos < ins_pos_to; ++ins_pos) {
+        sur[block] <<= 2;
+        sur[block] += new_bases[ins_pos];
+    }
+    bases_to_insert -= into_this_block;
+    ins_pos_to -= into_this_block;
+    sur[block] <<= 2 * (SUR_RANGE - pos_in_block);
+    sur[block] += tmp_sur;
+    while (0 < bases_to_insert) {
+        into_this_block = imin(bases_to_insert, SUR_RANGE);
+        sur[--block] >>= 2 * into_this_block;
+        for (int ins_pos = ins_pos_to - into_this_block; ins_pos < ins_pos_to; ++ins_pos) {
+            sur[block] <<= 2;
+            sur[block] += new_bases[ins_pos];
+        }
+        bases_to_insert -= into_this_block;
+        ins_pos_to -= into_this_block;
+    }
+}

@@ -337,6 +337,17 @@ int emu_insert_variants_test(uint32_t n_calls, const uint32_t *positions, const 
         return 0;
     });
 }
+// the product's Surrounding edits (rsq_core.h): op 0 change, 1 delete/shift right, 2 delete/shift left, 3 insert/shift right, 4 insert/shift left
+void emu_sur_edit(uint32_t *sur, int op, uint32_t pos, const uint8_t *bases, uint32_t n) {
+    uint32_t (&s)[3] = *reinterpret_cast<uint32_t (*)[3]>(sur);
+    switch (op) {
+        case 0: sur_change_base(s, pos, bases[0]); break;
+        case 1: sur_delete_shift_right(s, pos, bases[0]); break;
+        case 2: sur_delete_shift_left(s, pos, bases[0]); break;
+        case 3: sur_insert_shift_right(s, pos, bases, n); break;
+        default: sur_insert_shift_left(s, pos, bases, n); break;
+    }
+}
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;
@@ -455,7 +466,7 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
             read_len_out[i] = m.read_len;
             nerr_out[i] = m.num_errors;
             tile_out[i] = m.tile_id;
-            if (m.read_len > out_stride || m.cigar_chars + 1 > cigar_stride) throw Error("output stride too small");
+            if (m.read_len > out_stride || m.cigar_chars + 1u > cigar_stride) throw Error("output stride too small");
             memcpy(seq_out + i * out_stride, raw.seq.data(), m.read_len);
             memcpy(qual_out + i * out_stride, raw.qual.data(), m.read_len);
             TextSink t{cigar_out + i * cigar_stride, 0};

@@ -129,6 +129,11 @@ def lib():
         "orc_variants_new": (C.POINTER(OrcVariants), [C.c_uint32]),
         "orc_read_variants": (C.POINTER(OrcVariants), [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]),
         "orc_variants_free": (None, [C.POINTER(OrcVariants)]),
+        "orc_sur_change_base": (None, [i32p, C.c_uint32, C.c_uint8]),
+        "orc_sur_delete_shift_right": (None, [i32p, C.c_uint32, C.c_uint8]),
+        "orc_sur_delete_shift_left": (None, [i32p, C.c_uint32, C.c_uint8]),
+        "orc_sur_insert_shift_right": (None, [i32p, C.c_uint32, u8p, C.c_uint32]),
+        "orc_sur_insert_shift_left": (None, [i32p, C.c_uint32, u8p, C.c_uint32]),
         "orc_sim_load_sys_errors": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "orc_sim_free": (None, [C.c_void_p]),
         "orc_sim_set_normalization": (None, [C.c_void_p, C.c_double, f64p]),

@@ -434,3 +434,128 @@ def test_variation_loading_known_answers(workdir):
     ref.close()
     oref.close()
     oref2.close()
+
+
+class _SurOps:
+    """the five Surrounding edits of the oracle (int32 blocks) or of the product's rsq_core.h through the test-only host library"""
+
+    def __init__(self, product):
+        self.product = product
+        if product:
+            from backends import emu_lib
+            self.L = emu_lib()
+            self.L.emu_sur_edit.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32]
+            self.L.emu_sur_edit.restype = None
+
+    def apply(self, sur, op, pos, bases):
+        b = np.asarray(bases, np.uint8)
+        if self.product:
+            s = np.asarray(sur, np.uint32).copy()
+            self.L.emu_sur_edit(s.ctypes.data, op, pos, b.ctypes.data, len(b))
+            return [int(x) for x in s]
+        s = np.asarray(sur, np.int32).copy()
+        L = O.lib()
+        if op == 0:
+            L.orc_sur_change_base(O._ptr(s, O.i32p), pos, int(b[0]))
+        elif op == 1:
+            L.orc_sur_delete_shift_right(O._ptr(s, O.i32p), pos, int(b[0]))
+        elif op == 2:
+            L.orc_sur_delete_shift_left(O._ptr(s, O.i32p), pos, int(b[0]))
+        elif op == 3:
+            L.orc_sur_insert_shift_right(O._ptr(s, O.i32p), pos, O._ptr(b, O.u8p), len(b))
+        else:
+            L.orc_sur_insert_shift_left(O._ptr(s, O.i32p), pos, O._ptr(b, O.u8p), len(b))
+        return [int(x) for x in s]
+
+
+def _fwd(codes, pos):
+    s = np.zeros(3, np.int32)
+    c = np.ascontiguousarray(codes, np.uint8)
+    O.lib().orc_surrounding_forward(O._ptr(c, O.u8p), len(c), pos, O._ptr(s, O.i32p))
+    return [int(x) for x in s]
+
+
+@pytest.mark.parametrize("product", [False, True])
+def test_surrounding_modifiers_like_the_reference_test(product):
+    """SurroundingTest::TestModifiers (SurroundingTest.cpp:307-410): an edited surrounding equals the surrounding of the edited sequence.
+    The reference test reads positions 994..1024 of the E. coli genome; the same statements are made here around position 104 of
+    test/reference-test.fa (window position p <-> sequence position 94 + p)."""
+    ops = _SurOps(product)
+    ref = REF[0][1]
+    C0 = 104                                       # the reference test's 1004
+    base = _fwd(ref, C0)
+    for sur_pos in (10, 9):                        # ChangeSurroundingBase
+        for new in range(4):
+            edited = ref.copy()
+            edited[C0 - 10 + sur_pos] = new
+            assert ops.apply(base, 0, sur_pos, [new]) == _fwd(edited, C0)
+    for sur_pos in (10, 14, 21):                   # DeleteSurroundingBaseShiftingOnRightSide: the base after the window moves in
+        edited = np.concatenate([ref[:C0 - 10 + sur_pos], ref[C0 - 10 + sur_pos + 1:]])
+        assert ops.apply(base, 1, sur_pos, [ref[C0 + 20]]) == _fwd(edited, C0)
+    for sur_pos in (9, 6):                         # DeleteSurroundingBaseShiftingOnLeftSide: the base before the window moves in
+        edited = np.concatenate([ref[:C0 - 10 + sur_pos], ref[C0 - 10 + sur_pos + 1:]])
+        assert ops.apply(base, 2, sur_pos, [ref[C0 - 11]]) == _fwd(edited, C0 - 1)
+    acgt = [0, 1, 2, 3]
+    for ins_pos in (9, 10, 18, 19, 28):            # InsertSurroundingBasesShiftingOnRightSide
+        for ins in (acgt[:2], acgt, acgt * 3):
+            edited = np.concatenate([ref[:C0 - 10 + ins_pos], np.asarray(ins, np.uint8), ref[C0 - 10 + ins_pos:]])
+            assert ops.apply(base, 3, ins_pos, ins) == _fwd(edited, C0), (ins_pos, ins)
+    for ins_pos in (20, 19, 10, 9, 5, 0):          # InsertSurroundingBasesShiftingOnLeftSide (inserted after window position ins_pos)
+        for ins in (acgt, acgt * 3):
+            edited = np.concatenate([ref[:C0 - 9 + ins_pos], np.asarray(ins, np.uint8), ref[C0 - 9 + ins_pos:]])
+            assert ops.apply(base, 4, ins_pos, ins) == _fwd(edited, C0 + len(ins)), (ins_pos, ins)
+
+
+@pytest.mark.parametrize("product", [False, True])
+def test_surrounding_modifiers_extreme_cases(product):
+    """SurroundingTest::TestModifiersExtremCases (SurroundingTest.cpp:412-540), statement by statement"""
+    ops = _SurOps(product)
+    size, rng, nblocks, length = 1 << 20, 10, 3, 30
+    full_t, full_a, start_a, end_a = size - 1, 0, (size >> 2) - 1, size - 1 - 3
+    sur = [full_t] * 3
+    for block in reversed(range(nblocks)):
+        sur = ops.apply(sur, 0, block * rng, [0])
+        assert sur[block] == start_a
+        sur = ops.apply(sur, 0, block * rng, [3])
+        assert sur[block] == full_t
+        sur = ops.apply(sur, 0, (block + 1) * rng - 1, [0])
+        assert sur[block] == end_a
+        sur = ops.apply(sur, 0, (block + 1) * rng - 1, [3])
+        assert sur[block] == full_t
+    all_t, all_a = [3] * length, [0] * length
+    for block in reversed(range(nblocks)):         # right-shifting pair
+        for pos in (block * rng, (block + 1) * rng - 1):
+            sur = ops.apply(sur, 1, pos, [0])
+            assert sur == [full_t, full_t, end_a]
+            sur = ops.apply(sur, 3, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 1, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 3, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 3, pos, all_t)
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 3, pos, all_a)
+            for comp in range(nblocks):
+                exp = full_t if comp < block else (full_a if comp > block else (full_a if block * rng == pos else end_a))
+                assert sur[comp] == exp, (block, comp, pos)
+            sur = ops.apply(sur, 3, pos, all_t)
+            assert sur == [full_t] * 3
+    for block in reversed(range(nblocks)):         # left-shifting pair
+        for pos in (block * rng, (block + 1) * rng - 1):
+            sur = ops.apply(sur, 2, pos, [0])
+            assert sur == [start_a, full_t, full_t]
+            sur = ops.apply(sur, 4, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 2, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 4, pos, [3])
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 4, pos, all_t)
+            assert sur == [full_t] * 3
+            sur = ops.apply(sur, 4, pos, all_a)
+            for comp in range(nblocks):
+                exp = full_a if comp < block else (full_t if comp > block else (start_a if block * rng == pos else full_a))
+                assert sur[comp] == exp, (block, comp, pos)
+            sur = ops.apply(sur, 4, pos, all_t)
+            assert sur == [full_t] * 3
