@@ -174,7 +174,7 @@ def main():
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                    # the oracle, on rank 0 of a single-GPU run only
             out["cpu_baseline"] = cpu_baseline(ppath, seqs, args.seed)
         print(json.dumps(out))
     if dist is not None:
