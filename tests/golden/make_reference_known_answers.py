@@ -216,6 +216,41 @@ ka["variation_loading"] = {
                  [3424235, "C", True, True], [3424236, "A", True, True]],
 }
 
+# SimulatorTest.cpp:116-364 TestVariationInSimulateFromGivenBlock: the per-allele modifiers while SimulateFromGivenBlock walks start
+# positions 1003..1011 of E. coli (bases 1001-1020: GTTGCGAGATTTGGACGGAC, quoted in the test) with six variants on allele 1.
+# inner: arguments of TestVariationInInnerLoopOfSimulateFromGivenBlock (from, to, valid alleles, then per allele the expected
+# unhandled_variant_id / unhandled_bases_in_variant / gc_mod / end_pos_shift per fragment length, modified start positions, which
+# sequence the results are compared with: "ref", "alt" (the sequence with the variants applied) or null); after: first_variant_id_ and
+# start_variant_pos_ after CheckForInsertedBasesToStartFrom.
+ka["variation_in_simulate_from_given_block"] = {
+    "bases_1000_1019": "GTTGCGAGATTTGGACGGAC",
+    "variants": [[455, "", 2], [1002, "TAC", 2], [1004, "TGA", 2], [1008, "", 2], [1011, "C", 2], [1012, "", 2]],
+    "steps": [
+        {"start": 1003, "set_first_variant": 2, "forward_surrounding_start": True, "alt_start_surrounding_at": 1004,
+         "inner": [1, 13, 2, [[2, 3, 3, 3, 3, 4, 4, 4, 5, 6, 6, 6], [2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 6, 6]], [[0] * 12, [0, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]],
+                   [[0] * 12, [0, -1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0]], [[0] * 12, [0, 0, -1, -2, -2, -2, -2, -1, -1, -1, 0, 0]], [1003, 1004], ["ref", "alt"]],
+         "after": [2, 0]},
+        {"start": 1004, "forward_surrounding_start": True, "alt_start_surrounding_at": 1005,
+         "inner": [1, 12, 2, [[3, 3, 3, 3, 4, 4, 4, 5, 6, 6, 6], [2, 2, 3, 3, 3, 3, 4, 4, 5, 6, 6]], [[0] * 11, [2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]],
+                   [[0] * 11, [-1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0]], [[0] * 11, [0, -1, -2, -2, -2, -2, -1, -1, -1, 0, 0]], [1004, 1005], ["ref", "alt"]],
+         "after": [2, 1]},
+        {"start": 1004, "forward_surrounding_start": False, "alt_start_surrounding_at": 1006,
+         "inner": [1, 11, 1, [[], [3, 3, 3, 3, 3, 4, 4, 5, 6, 6]], [[], [0] * 10], [[], [0, 0, 0, 0, 0, 0, 0, 1, 0, 0]], [[], [0, -1, -1, -1, -1, 0, 0, 0, 1, 1]],
+                   [0, 1006], [None, "alt"]],
+         "after": [2, 2]},
+        {"start": 1004, "forward_surrounding_start": False, "alt_start_surrounding_at": 1007,
+         "inner": [1, 10, 1, [[], [3, 3, 3, 3, 4, 4, 5, 6, 6]], [[], [0] * 9], [[], [-1, -1, -1, -1, -1, -1, 0, -1, -1]], [[], [0, 0, 0, 0, 1, 1, 1, 2, 2]],
+                   [0, 1007], [None, "alt"]],
+         "after": [3, 0]},
+        {"start": 1008, "forward_surrounding_start": True, "alt_start_surrounding_at": None,
+         "inner": [1, 8, 1, [[4, 4, 4, 5, 6, 6, 6], []], [[0] * 7, []], [[0] * 7, []], [[0] * 7, []], [1008, 0], ["ref", None]],
+         "after": [4, 0]},
+        {"start": 1011, "forward_surrounding_start": True, "alt_start_surrounding_at": 1013,
+         "inner": [1, 5, 2, [[5, 6, 6, 6], [5, 6, 6, 6]], [[0] * 4, [0] * 4], [[0] * 4, [1, 0, 0, 0]], [[0] * 4, [0, 1, 1, 1]], [1011, 1013], ["ref", "alt"]],
+         "after": [5, 0]},
+    ],
+}
+
 with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
     json.dump(ka, f, indent=1)
 print("wrote", len(ka), "groups")

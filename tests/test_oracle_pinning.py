@@ -559,3 +559,68 @@ def test_surrounding_modifiers_extreme_cases(product):
                 assert sur[comp] == exp, (block, comp, pos)
             sur = ops.apply(sur, 4, pos, all_t)
             assert sur == [full_t] * 3
+
+
+def test_variant_bias_modifiers_like_the_reference_test():
+    """SimulatorTest::TestVariationInSimulateFromGivenBlock (SimulatorTest.cpp:116-364) for rsq_variants.h (host code of the product,
+    driven through the test-only host library): per start position and fragment length the per-allele unhandled variant, unhandled bases,
+    GC modification and end-position shift the reference test lists, and its comparisons of start / end surroundings, GC percent and both
+    templates with the sequence that has the variants applied.  The E. coli genome is replaced by 2000 seeded bases that carry the 20
+    bases the test quotes at 1000..1019 (everything the expected numbers depend on lies there)."""
+    from backends import emu_lib
+    g = KA["variation_in_simulate_from_given_block"]
+    L = emu_lib()
+    ref = np.random.default_rng(11).integers(0, 4, 2000).astype(np.uint8)
+    ref[1000:1020] = ["ACGT".index(c) for c in g["bases_1000_1019"]]
+    enc = lambda s: np.array(["ACGT".index(c) for c in s], np.uint8)
+    alt = np.concatenate([ref[:455], ref[456:1003], enc("AC"), ref[1003:1004], enc("TGA"), ref[1005:1008], ref[1009:1012]])      # SimulatorTest.cpp:210-219
+    alt[1013] = 1
+    alt = np.concatenate([alt, ref[1013:2000]])
+    n = len(g["variants"])
+    pos = np.array([v[0] for v in g["variants"]], np.uint32)
+    bits = np.array([v[2] for v in g["variants"]], np.uint64)
+    seqs = (C.c_char_p * n)(*[v[1].encode() for v in g["variants"]])
+    L.emu_var_new.restype = C.c_void_p
+    L.emu_var_new.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p]
+    L.emu_var_free.argtypes = [C.c_void_p]
+    L.emu_var_set_first_variant.argtypes = [C.c_void_p, C.c_int32]
+    L.emu_var_get_start.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    L.emu_var_prepare_start.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emu_var_inner_loop.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.emu_var_check_inserted.argtypes = [C.c_void_p, C.c_uint32]
+    h = L.emu_var_new(ref.ctypes.data, len(ref), alt.ctypes.data, len(alt), n, pos.ctypes.data, seqs, bits.ctypes.data)
+    try:
+        for step in g["steps"]:
+            start = step["start"]
+            if "set_first_variant" in step:
+                L.emu_var_set_first_variant(h, step["set_first_variant"])
+            sur, ref_sur, comp_sur = np.zeros(6, np.uint32), np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+            comp_at = step["alt_start_surrounding_at"]
+            assert L.emu_var_prepare_start(h, start, 1, comp_at if comp_at is not None else start, sur.ctypes.data, ref_sur.ctypes.data, comp_sur.ctypes.data) == 0, L.emu_last_error()
+            if step["forward_surrounding_start"]:
+                assert sur[:3].tolist() == ref_sur.tolist(), step                        # allele 0 keeps the reference surrounding
+            if comp_at is not None:
+                assert sur[3:].tolist() == comp_sur.tolist(), step                       # allele 1: the surrounding of the edited sequence
+            fr, to, valid, uvid, ubases, gcmod, eshift, mod_start, comp = step["inner"]
+            log = np.full((2, to - fr, 4), 99999, np.int32)
+            ms = np.array(mod_start, np.uint32)
+            use = np.array([{"ref": 0, "alt": 1, None: -1}[c] for c in comp], np.int32)
+            n_possible = C.c_uint32()
+            tests = L.emu_var_inner_loop(h, start, fr, to, ms.ctypes.data, use.ctypes.data, log.ctypes.data, C.byref(n_possible))
+            assert tests >= 0, (step, tests, L.emu_last_error())
+            assert n_possible.value == valid
+            for allele in range(2):
+                if not uvid[allele]:
+                    assert (log[allele] == 99999).all()                                  # the allele is skipped at this start
+                    continue
+                assert log[allele, :, 0].tolist() == uvid[allele], (start, allele)
+                assert log[allele, :, 1].tolist() == ubases[allele], (start, allele)
+                assert log[allele, :, 2].tolist() == gcmod[allele], (start, allele)
+                assert log[allele, :, 3].tolist() == eshift[allele], (start, allele)
+            assert tests == valid * 2 * max(len(uvid[0]), len(uvid[1]))                  # SimulatorTest.cpp:193
+            assert L.emu_var_check_inserted(h, start) == 0
+            fv, sp = C.c_int32(), C.c_uint32()
+            L.emu_var_get_start(h, C.byref(fv), C.byref(sp))
+            assert [fv.value, sp.value] == step["after"], step
+    finally:
+        L.emu_var_free(h)
