@@ -52,6 +52,10 @@ int rsq_profile_remove_indel_errors(rsq_profile *p);
 /* small getters the callers need to size buffers */
 int rsq_profile_max_read_length(const rsq_profile *p, uint32_t *out);
 int rsq_profile_num_tiles(const rsq_profile *p, uint32_t *out);
+/* `reseq queryProfile` (reseq/main.cpp:481-610): ErrorStats::MaxLenDeletion, the stored reference sequence biases (n = their number;
+ * out may be NULL to ask for n) */
+int rsq_profile_max_len_deletion(const rsq_profile *p, uint32_t *out);
+int rsq_profile_ref_seq_bias(const rsq_profile *p, double *out, size_t cap, size_t *n);
 
 /* ---- reference: Reference::ReadFasta (reseq/Reference.cpp:758) and Reference::ReplaceN (:813) */
 int rsq_ref_load_fasta(const char *path, rsq_ref **out);
@@ -59,6 +63,8 @@ int rsq_ref_replace_n(rsq_ref *r, uint64_t seed);
 void rsq_ref_free(rsq_ref *r);
 int rsq_ref_num_sequences(const rsq_ref *r, uint32_t *out);
 int rsq_ref_sequence_length(const rsq_ref *r, uint32_t seq, uint32_t *out);
+/* ReferenceIdFirstPart (reseq/Reference.cpp:476-480): the id up to the first blank, NUL-terminated */
+int rsq_ref_sequence_name(const rsq_ref *r, uint32_t seq, char *out, size_t cap);
 /* Reference::WriteFasta (reseq/Reference.cpp:896-916; `reseq replaceN` writes the reference after ReplaceN): FASTA, gzip when the
  * name ends in .gz */
 int rsq_ref_write_fasta(const rsq_ref *r, const char *path);

@@ -46,6 +46,9 @@ SYMBOLS = {
     "rsq_profile_remove_indel_errors": (C.c_int, [_vp]),
     "rsq_profile_max_read_length": (C.c_int, [_vp, C.POINTER(_u32)]),
     "rsq_profile_num_tiles": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_profile_max_len_deletion": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rsq_profile_ref_seq_bias": (C.c_int, [_vp, _vp, _sz, _psz]),
+    "rsq_ref_sequence_name": (C.c_int, [_vp, _u32, C.c_char_p, _sz]),
     "rsq_ref_load_fasta": (C.c_int, [C.c_char_p, _pp]),
     "rsq_ref_replace_n": (C.c_int, [_vp, _u64]),
     "rsq_ref_free": (None, [_vp]),

@@ -17,6 +17,7 @@
 #include <map>
 #include <random>
 #include <set>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -47,7 +48,7 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"-j", "threads"}, {"-h", "help"}, {"-b", "bamIn"}, {"-r", "refIn"}, {"-s", "statsIn"}, {"-S", "statsOut"},
                                                    {"-v", "vcfIn"},   {"-p", "probabilitiesIn"}, {"-P", "probabilitiesOut"}, {"-1", "firstReadsOut"},
                                                    {"-2", "secondReadsOut"}, {"-c", "coverage"}, {"-R", "refSim"}, {"-V", "vcfSim"}, {"-i", "input"}, {"-o", "output"}};
-const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors"};
+const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors", "maxLenDeletion", "maxReadLength"};
 
 bool parse(int argc, char **argv, int first, Args &a) {
     for (int i = first; i < argc; ++i) {
@@ -525,6 +526,80 @@ const char *kUsage =
 
 }  // namespace
 
+// reseq queryProfile -s <profile> [-r <ref.fa>] [--maxLenDeletion] [--maxReadLength] [--refSeqBias <file|->] (main.cpp:481-610)
+int query_profile(const Args &a) {
+    // -r / -s carry the long names of the illuminaPE mode in this parser; queryProfile calls them ref and stats
+    const std::string stats = a.get("stats", a.get("statsIn")), ref_path = a.get("ref", a.get("refIn"));
+    if (stats.empty()) {
+        ERR("stats option is mandatory.");
+        return 1;
+    }
+    if (a.has("refSeqBias") && ref_path.empty()) {
+        ERR("ref option is mandatory if refSeqBias is specified.");
+        return 1;
+    }
+    rsq_profile *prof = nullptr;
+    rsq_ref *ref = nullptr;
+    INFO("Reading reference sequence biases from " << stats);
+    bool ok = check(rsq_profile_load(stats.c_str(), &prof), "Could not load profile");
+    if (ok && !ref_path.empty()) {
+        INFO("Reading reference from " << ref_path);
+        ok = check(rsq_ref_load_fasta(ref_path.c_str(), &ref), "Could not load reference");
+    }
+    bool no_output = true;
+    if (ok && a.has("maxLenDeletion")) {
+        uint32_t v = 0;
+        rsq_profile_max_len_deletion(prof, &v);
+        std::cout << "maxLenDeletion: " << v << std::endl;
+        no_output = false;
+    }
+    if (ok && a.has("maxReadLength")) {
+        uint32_t v = 0;
+        rsq_profile_max_read_length(prof, &v);
+        std::cout << "maxReadLength: " << v << std::endl;
+        no_output = false;
+    }
+    if (ok && a.has("refSeqBias")) {                              // FragmentDistributionStats::WriteRefSeqBias (FragmentDistributionStats.cpp:3643-3670)
+        size_t n = 0;
+        uint32_t n_seqs = 0;
+        rsq_profile_ref_seq_bias(prof, nullptr, 0, &n);
+        rsq_ref_num_sequences(ref, &n_seqs);
+        if (n != n_seqs) {
+            ERR("Reference and reseq file do not match. The reference has " << n_seqs << " sequences and the reseq file has biases for " << n << " sequences");
+            ok = false;
+        } else {
+            std::vector<double> bias(n ? n : 1);
+            rsq_profile_ref_seq_bias(prof, bias.data(), bias.size(), &n);
+            std::ostringstream text;
+            for (uint32_t i = 0; i < n_seqs; ++i) {
+                char name[4096];
+                rsq_ref_sequence_name(ref, i, name, sizeof name);
+                text << name << '\t' << bias[i] << '\n';
+            }
+            const std::string file = a.get("refSeqBias") == "-" ? "" : a.get("refSeqBias");
+            if (file.empty()) {
+                INFO("Writing reference sequence biases to stdout");
+                std::cout << text.str();
+            } else {
+                INFO("Writing reference sequence biases to " << file);
+                std::ofstream f(file);
+                if (!f) {
+                    ERR("Unable to open reference bias file " << file);
+                    ok = false;
+                } else f << text.str();
+            }
+        }
+        no_output = false;
+    }
+    rsq_ref_free(ref);
+    rsq_profile_free(prof);
+    if (ok && no_output) {
+        ERR("No output option was selected.");
+        return 1;
+    }
+    return ok ? 0 : 1;
+}
+
 // reseq replaceN -r <refIn.fa> -R <refSim.fa> [--seed] (main.cpp:611-692)
 int replace_n(const Args &a) {
     if (!a.has("refIn")) {
@@ -572,7 +647,8 @@ int main(int argc, char **argv) {
     if (command == "illuminaPE") return illumina_pe(a);
     if (command == "seqToIllumina" || command == "replaceQuals") return seq_to_illumina(a);
     if (command == "replaceN") return replace_n(a);
-    if (command == "queryProfile" || command == "test") {
+    if (command == "queryProfile") return query_profile(a);
+    if (command == "test") {
         ERR("command '" << command << "' is not part of this build (simulation stage only)");
         return 1;
     }

@@ -523,6 +523,27 @@ int rsq_profile_num_tiles(const rsq_profile *p, uint32_t *out) {
     return RSQ_OK;
 }
 
+int rsq_profile_max_len_deletion(const rsq_profile *p, uint32_t *out) {
+    REQUIRE(p && out, "null argument");
+    *out = p->p.max_len_deletion;
+    return RSQ_OK;
+}
+int rsq_profile_ref_seq_bias(const rsq_profile *p, double *out, size_t cap, size_t *n) {
+    REQUIRE(p && n, "null argument");
+    *n = p->p.ref_seq_bias.size();
+    if (!out) return RSQ_OK;
+    if (cap < *n) return RSQ_ENOSPC;
+    memcpy(out, p->p.ref_seq_bias.data(), *n * sizeof(double));
+    return RSQ_OK;
+}
+int rsq_ref_sequence_name(const rsq_ref *r, uint32_t seq, char *out, size_t cap) {
+    REQUIRE(r && out && seq < r->r.codes.size(), "bad sequence id");
+    const std::string name = r->r.first_part(seq);
+    if (name.size() + 1 > cap) return RSQ_ENOSPC;
+    memcpy(out, name.c_str(), name.size() + 1);
+    return RSQ_OK;
+}
+
 int rsq_ref_load_fasta(const char *path, rsq_ref **out) {
     REQUIRE(path && out, "null argument");
     try {
