@@ -202,9 +202,8 @@ RSQ_HD uint32_t clamp_row(const DevTable &t, int n, uint32_t v) {      // Adjust
 }
 
 // generic draw with every margin in HBM; returns the outcome VALUE
-template <int NM>
-RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, const uint8_t *__restrict__ par0, const uint32_t (&idx)[NM], double u,
-                     double &prob_sum) {
+template <int NM, class Par0>
+RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, Par0 par0, const uint32_t (&idx)[NM], double u, double &prob_sum) {
     prob_sum = 0.0;
     if (!t.k) return 0;
     const uint32_t kp = row_stride(t.k);

@@ -938,6 +938,8 @@ struct LdsTables {
     const RSQ_LDS double *img;         // image of the workgroup
     uint32_t seg;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
+    // the outcome values: behind the descriptors in the image (the plan stages them whenever the pool is small); an image without them is not built
+    RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_doubles - S.lds.par0_doubles)); }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
     RSQ_HD DevTable base_call(uint32_t i) const { return desc(4u * S.n_tiles + i - seg * 20u * S.n_tiles); }
     RSQ_HD DevTable indel(uint32_t i) const { return desc(24u * S.n_tiles + i); }
@@ -945,7 +947,7 @@ struct LdsTables {
 
     template <class R0, class R1, class R2, class R3>
     RSQ_HD uint32_t rows4(const DevTable &t, double u, double &ps, const R0 &r0, const R1 &r1, const R2 &r2, const R3 &r3) const {
-        return S.par0[t.par0_off + draw_rows_k(t.k, u, ps, r0, r1, r2, r3)];
+        return par0()[t.par0_off + draw_rows_k(t.k, u, ps, r0, r1, r2, r3)];
     }
     // margins 2 (position) and 3 (error rate) of a quality draw
     template <class R0, class R1>
@@ -989,9 +991,9 @@ struct LdsTables {
         if constexpr (BL) return base_call_tail(t, local, idx, u, ps, LdsRow{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp});
         else return base_call_tail(t, local, idx, u, ps, GlobalRow{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp});
     }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(indel(i), S.pool, S.par0, idx, u, ps); }
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(indel(i), S.pool, par0(), idx, u, ps); }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
-        return draw<3>(seq_quality(i), S.pool, S.par0, idx, u, ps);
+        return draw<3>(seq_quality(i), S.pool, par0(), idx, u, ps);
     }
 };
 
@@ -1007,6 +1009,8 @@ RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t
     for (uint32_t i = tid; i < wb; i += nthreads) dst[wq + i] = b[i];
     for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
     for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i];
+    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(S.par0);      // the pool is padded to whole words by pack_tables
+    for (uint32_t i = tid; i < 2u * S.lds.par0_doubles; i += nthreads) dst[wq + wb + wi + ws + i] = p0[i];
 }
 // rows 0..n_rows-1 of margin 3 of `n_tables` tables starting at descriptor `first`, one slot per row
 RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS double *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,

@@ -95,7 +95,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
     // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): as much as fits 160 KiB, most valuable first.
     const uint32_t T = p.n_tiles();
     LdsPlan plan{};
-    plan.desc_doubles = lds_desc_count(T) * (uint32_t)(sizeof(DevTable) / sizeof(double));
+    plan.par0_doubles = par0.size() <= 8192 ? (uint32_t)((par0.size() + 1 + 15) / 16) * 2u : 0u;       // the outcome values of every table, when small; whole 16 bytes: rows stay aligned
+    plan.desc_doubles = lds_desc_count(T) * (uint32_t)(sizeof(DevTable) / sizeof(double)) + plan.par0_doubles;
     auto rows_q = [&](const DevTable &d) { return d.k ? (d.rows[0] + d.rows[1]) * row_stride(d.k) : 0u; };
     auto rows_b = [&](const DevTable &d) { return d.k ? d.rows[0] * row_stride(d.k) : 0u; };
     uint64_t need_q = 0, need_b = 0;
@@ -121,6 +122,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     };
     uint32_t allow = ~0u, rate_rows = kLdsRateRows;
     if (const char *e = getenv("RSQ_FILL_MODE")) allow = (uint32_t)atoi(e);                       // tuning overrides: never stage these,
+    if (!plan.par0_doubles) allow = 0;                                                            // an image always carries the outcome values
     if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
     uint64_t used = plan.desc_doubles;
     if (used <= budget / 4 && (allow & kLdsDesc)) plan.mask |= kLdsDesc;
@@ -163,6 +165,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
         plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
         plan.total_doubles = (plan.mask & kLdsRate) ? plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b : end;
     } else plan.total_doubles = (plan.mask & kLdsDesc) ? plan.desc_doubles : 0u;
+    if ((plan.desc_doubles | plan.q3_off | plan.b3_off) & 1u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);
@@ -171,6 +174,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     s.dev.error_rate = up.put(error_rate);
     s.dev.indels = up.put(indels);
     par0.push_back(0);
+    par0.resize(std::max<size_t>(par0.size(), (size_t)plan.par0_doubles * 8), 0);      // whole words for the copy into the LDS image
     pool.push_back(0.0);
     pool.push_back(0.0);
     s.dev.pool = up.put(pool);

@@ -61,7 +61,8 @@ RSQ_HD uint32_t row_stride(uint32_t k) {
 enum : uint32_t { kLdsDesc = 1, kLdsQuality = 2, kLdsBaseCall = 4, kLdsRate = 16 };
 struct LdsPlan {
     uint32_t mask;               // kLds* bits of what the plan stages
-    uint32_t desc_doubles;       // size of the descriptor area (in doubles)
+    uint32_t desc_doubles;       // size of the descriptor area (in doubles): the descriptors, then the outcome-value pool (par0)
+    uint32_t par0_doubles;       // size of the outcome-value pool in the image, 0 if it stays in HBM
     uint32_t slot_q, slot_b;     // row slot (doubles) per quality / base-call table = max row stride of the family
     uint32_t rate_rows_q, rate_rows_b;   // kLdsRate: rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
     uint32_t q3_off, b3_off;     // [4T][rate_rows_q] quality slots, [20T][rate_rows_b] base-call slots
