@@ -523,6 +523,15 @@ RSQ_HD uint32_t draw_read_length(const DevSim &S, uint32_t seg, uint32_t fragmen
     return read_len;
 }
 
+// the plain loop of Simulator.cpp:482-489 for any template source
+template <class Src>
+RSQ_HD void template_totals_loop(const Src &src, uint32_t n, uint32_t &gc, uint32_t &rate_sum) {
+    for (uint32_t k = 0; k < n; ++k) {
+        if (is_gc(src.base(k))) ++gc;
+        rate_sum += src.sys(k) >> 8;
+    }
+}
+
 struct AdapterSrc {                    // the adapter as template of FillReadPart(..., 'S', NULL, ...)
     const uint8_t *seq;
     const uint16_t *sys_;
@@ -571,10 +580,7 @@ struct ReadMachine {
         const uint32_t seq_length = par.read_length < org_len ? par.read_length : org_len;
         uint32_t mean_error_rate = 0;
         if (seq_length) {                                              // Simulator.cpp:480-504
-            for (uint32_t k = 0; k < seq_length; ++k) {
-                if (is_gc(src.base(k))) ++par.gc_seq;
-                mean_error_rate += src.sys(k) >> 8;
-            }
+            src.totals(seq_length, par.gc_seq, mean_error_rate);       // G/C bases and the sum of the error rates of the first seq_length template bases
             par.gc_seq = percent_u16(par.gc_seq, seq_length);
             mean_error_rate = divide_u32(mean_error_rate, seq_length);
         } else {                                                       // adapter-only read :505-522

@@ -815,10 +815,24 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
     bool reverse;
     const uint16_t *sys_;               // systematic errors at the first template base
     const uint64_t *converted;          // --methylation: the template after CTConversion, 2 bits per base in read orientation; else nullptr
+    const uint32_t *gc_prefix;          // DevSim::gc_prefix
     RSQ_HD uint32_t org_len() const { return len; }
     RSQ_HD uint32_t ref(uint32_t k) const { return reverse ? 3u - ref_base(words, word_off, first - 1u - k) : ref_base(words, word_off, first + k); }
     RSQ_HD uint32_t base(uint32_t k) const { return converted ? (uint32_t)(converted[k >> 5] >> ((k & 31u) * 2u)) & 3u : ref(k); }
     RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+    // Simulator.cpp:482-489 without a load per base: the G/C count of the template's reference range from the per-word prefix sums
+    // (the complement strand has the same count), the error rates four per 8-byte load
+    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
+        if (converted || !gc_prefix) return template_totals_loop(*this, n, gc, rate_sum);
+        gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
+        uint32_t k = 0;
+        for (; k < n && ((uintptr_t)(sys_ + k) & 7u); ++k) rate_sum += sys_[k] >> 8;
+        for (; k + 4u <= n; k += 4u) {
+            const uint64_t four = *reinterpret_cast<const uint64_t *>(sys_ + k);
+            rate_sum += (uint32_t)((four >> 8) & 0xFFu) + (uint32_t)((four >> 24) & 0xFFu) + (uint32_t)((four >> 40) & 0xFFu) + (uint32_t)(four >> 56);
+        }
+        for (; k < n; ++k) rate_sum += sys_[k] >> 8;
+    }
 };
 
 // ------------------------------------------------------------------------------------- bisulfite conversion (a16)
@@ -907,6 +921,7 @@ RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, ui
 }
 
 struct EmptySrc {                       // adapter-only pair: org_seq_ = "" (Simulator.cpp:2369-2371)
+    RSQ_HD void totals(uint32_t, uint32_t &, uint32_t &) const {}
     RSQ_HD uint32_t org_len() const { return 0; }
     RSQ_HD uint32_t base(uint32_t) const { return 0; }
     RSQ_HD uint32_t sys(uint32_t) const { return 0; }
@@ -1057,6 +1072,7 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
     src.first = src.reverse ? end : f.start;
     src.sys_ = src.reverse ? S.sys_rev + S.seq_base_off[f.seq] + (L - end) : S.sys_fwd + S.seq_base_off[f.seq] + f.start;
     src.converted = nullptr;
+    src.gc_prefix = S.gc_prefix;
     return src;
 }
 // The converted template of mate `seg` of fragment f (CTConversion's dispatcher, Simulator.cpp:2219-2247): the forward mate is
@@ -1093,6 +1109,7 @@ struct RecordSrc {
     RSQ_HD uint32_t org_len() const { return len; }
     RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
     RSQ_HD uint32_t sys(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
+    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const { template_totals_loop(*this, n, gc, rate_sum); }
 };
 #ifndef RSQ_FILL_BLOCK
 #define RSQ_FILL_BLOCK 768
@@ -1166,7 +1183,7 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
                        c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
         const uint32_t strand = from_fragment ? f.strand : 0u;
         const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg)};
-        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr};      // len 0 = empty template
+        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
         if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
         ReadMeta meta;
         fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
