@@ -9,6 +9,6 @@ for f in glob.glob("gpurun_out/q/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
-    if "k_fill_reads" in k: print(k, {c: round(sum(v)/len(v)/3.9e6,1) for c,v in sorted(acc[k].items())})
+    if "k_fill_reads" in k: print(k, {c: round(sum(v)/len(v)/(3.9e6*3),1) for c,v in sorted(acc[k].items())})
     if "k_sieve" in k or "k_format" in k: print(k, {c: round(sum(v)/len(v)/1e6,2) for c,v in sorted(acc[k].items())})
 PY
