@@ -255,6 +255,9 @@ typedef struct orc_sim {
     uint32_t *meth_n;
     uint32_t **meth_first, **meth_second;
     double **meth_rate;
+    /* variants (oracle_variants.cpp): NumAlleles() and the per-sequence variants with their systematic errors */
+    uint16_t num_alleles;
+    void *var_state;
 } orc_sim;
 
 /* Simulator.cpp:2655-2898 up to "Starting read generation": pairs, thresholds, sys errors */
@@ -302,6 +305,16 @@ typedef struct { uint64_t seed; uint32_t c0, c1, c2, c3base; } orc_stream;
 int orc_fill_read(const orc_sim *s, orc_read *out, uint8_t template_segment, uint16_t tile_id, uint32_t fragment_length,
                   const uint8_t *org_seq, uint32_t org_len, const uint8_t *sys_dom, const uint8_t *sys_rate,
                   const orc_stream *st);
+/* the same with the systematic errors behind a cursor: next = GetSysErrorFromBlock (Simulator.cpp:240-292), deleted = the deletion
+ * branch of FillReadPart (:380-392), reset = back to the read's first template base (FillRead walks the errors twice, :487-502) */
+typedef struct {
+    void *ctx;
+    void (*reset)(void *ctx);
+    void (*next)(void *ctx, uint8_t *dom_error, uint8_t *error_rate);
+    void (*deleted)(void *ctx, uint8_t *error_rate);
+} orc_sys_cursor;
+int orc_fill_read_cursor(const orc_sim *s, orc_read *out, uint8_t template_segment, uint16_t tile_id, uint32_t fragment_length,
+                         const uint8_t *org_seq, uint32_t org_len, const orc_sys_cursor *sys, const orc_stream *st);
 
 /* Simulator.cpp:634-721 CreateReads + :596-632 CreateReadId: FASTQ text of both mates of the fragments. */
 typedef struct { char *data; size_t len, cap; } orc_text;
@@ -309,6 +322,7 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
 /* Simulator.cpp:2359-2382 */
 int orc_simulate_adapter_only_pairs(const orc_sim *s, orc_text *r1, orc_text *r2);
 void orc_text_free(orc_text *t);
+void orc_text_append_record(orc_text *t, const char *id, const orc_read *rd);
 /* Reference::Variant, InsertVariant, ReadFirstVariants / ReadVariants (Reference.h:24-62,115-139; Reference.cpp:126-420,1046-1077).
  * Loading only. */
 typedef struct {
@@ -328,6 +342,42 @@ void orc_insert_variant(orc_variants *vs, uint32_t seq, uint32_t position, const
 orc_variants *orc_variants_new(uint32_t n_seqs);
 orc_variants *orc_read_variants(const char *path, const orc_reference *r, char *err, size_t err_cap);
 void orc_variants_free(orc_variants *vs);
+
+/* ---- the simulation with variants (oracle_variants.cpp, C++; the bookkeeping in oracle_variants.hpp) */
+typedef struct {
+    uint32_t seq, start, len;     /* cur_start_position, fragment_length */
+    uint16_t dup;
+    uint8_t strand, allele;
+    uint32_t block, number;
+    uint32_t end;                 /* cur_end_position = start + len + end_pos_shift_[allele] */
+    uint32_t sub;                 /* pass of the do-while loop at this start position (> 0: the fragment starts inside inserted bases) */
+    int32_t start_var;            /* bias_mod.StartVariant() */
+    uint32_t start_var_pos;
+    int32_t end_var;              /* bias_mod.EndVariant(variants, cur_end_position, allele) */
+    uint32_t end_var_pos;
+} orc_fragment_var;
+orc_sim *orc_sim_new_variants(const orc_profile *p, const orc_reference *r, const orc_variants *vs, uint64_t seed, uint64_t num_read_pairs, double coverage,
+                              const char *record_base_identifier, int ref_bias_mode, const char *ref_bias_file, char *err, size_t err_cap);
+int orc_var_attach(orc_sim *s, const orc_variants *vs);
+void orc_var_detach(orc_sim *s);
+const char *orc_var_last_error(void);
+/* var_errors_ of the err_variants_ entry of one variant on one strand (SetSystematicErrorVariantsForward / Reverse); returns its size */
+uint32_t orc_var_sys_errors(const orc_sim *s, int strand, uint32_t seq, uint32_t var_id, uint8_t *dom, uint8_t *rate, uint32_t cap);
+/* Simulator.cpp:2249-2357 with variants; UINT64_MAX on an error (orc_var_last_error) */
+uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment_var **out);
+int orc_create_reads_var(const orc_sim *s, const orc_fragment_var *frags, uint64_t n, orc_text *r1, orc_text *r2);
+/* utilitiesTest.cpp:61-137 DominantBaseWithMemory script: op 0 Clear, 1 Set(seq, arg), 2 Update(seq[arg]), 3 copy from the other object */
+void orc_dombase_memory_script(const uint8_t *seq, uint32_t len, uint32_t n_ops, const uint8_t *which, const uint8_t *op, const uint32_t *arg, uint8_t *out);
+/* SimulatorTest::TestVariationInSimulateFromGivenBlock driver */
+void *orc_var_new(const uint8_t *codes, uint32_t n, const uint8_t *comp_codes, uint32_t n_comp, uint32_t n_var, const uint32_t *positions, const char *const *var_seqs,
+                  const uint64_t *allele0);
+void orc_var_free(void *h);
+void orc_var_set_first_variant(void *h, int32_t id);
+void orc_var_get_start(void *h, int32_t *first_variant_id, uint32_t *start_variant_pos);
+int orc_var_prepare_start(void *h, uint32_t cur_start, uint32_t first_fragment_length, uint32_t comp_pos, uint32_t *sur_out, uint32_t *ref_sur_out, uint32_t *comp_sur_out);
+int orc_var_inner_loop(void *h, uint32_t cur_start, uint32_t from, uint32_t to, const uint32_t *modified_start_pos, const int32_t *use_comp, int32_t *log,
+                       uint32_t *n_possible);
+int orc_var_check_inserted(void *h, uint32_t cur_start);
 
 /* --methylation without variants: Reference::PrepareMethylationFile/ReadMethylation (Reference.cpp:1132-1310) and
  * Simulator::CTConversion (Simulator.cpp:1925-2002,2219-2247).  0, or -1 with the reference's message. */

@@ -406,8 +406,8 @@ static double calculate_bias_normalization(orc_sim *s) {
             t[0] = 1.0;
             t[1] = 1.0;
         } else {
-            t[0] = orc_calculate_non_zero_threshold(p->dispersion, full_normalization, t[0], 1);
-            t[1] = pow(t[0], 2 * 1);
+            t[0] = orc_calculate_non_zero_threshold(p->dispersion, full_normalization, t[0], s->num_alleles);   /* FDS.cpp:3575-3576 */
+            t[1] = pow(t[0], 2 * s->num_alleles);
         }
     }
     s->norm_by_len = norm;
@@ -442,7 +442,13 @@ orc_sim *orc_sim_new(const orc_profile *p, const orc_reference *r, uint64_t seed
 
 orc_sim *orc_sim_new_bias(const orc_profile *p, const orc_reference *r, uint64_t seed, uint64_t num_read_pairs, double coverage,
                           const char *record_base_identifier, int ref_bias_mode, const char *ref_bias_file, char *err, size_t err_cap) {
+    return orc_sim_new_variants(p, r, NULL, seed, num_read_pairs, coverage, record_base_identifier, ref_bias_mode, ref_bias_file, err, err_cap);
+}
+
+orc_sim *orc_sim_new_variants(const orc_profile *p, const orc_reference *r, const orc_variants *vs, uint64_t seed, uint64_t num_read_pairs, double coverage,
+                              const char *record_base_identifier, int ref_bias_mode, const char *ref_bias_file, char *err, size_t err_cap) {
     orc_sim *s = calloc(1, sizeof *s);
+    s->num_alleles = vs ? (uint16_t)vs->num_alleles : 1;
     s->p = p;
     s->r = r;
     s->seed = seed;
@@ -522,6 +528,11 @@ orc_sim *orc_sim_new_bias(const orc_profile *p, const orc_reference *r, uint64_t
         }
     }
     s->total_blocks = next_block - 1;
+    if (vs && orc_var_attach(s, vs)) {
+        if (err) snprintf(err, err_cap, "%s", orc_var_last_error());
+        orc_sim_free(s);
+        return NULL;
+    }
     return s;
 }
 
@@ -531,6 +542,7 @@ void orc_sim_set_normalization(orc_sim *s, double bias_normalization, const doub
 }
 
 void orc_sim_free(orc_sim *s) {
+    if (s && s->var_state) orc_var_detach(s);
     if (!s) return;
     if (s->meth_n) {
         for (uint32_t i = 0; i < s->r->n_seqs; ++i) {
@@ -662,14 +674,31 @@ static orc_philox_out stream_words(const draw_ctx *d, uint32_t step) {
     return orc_philox4x32_10(d->st->seed, d->st->c0, d->st->c1, d->st->c2, d->st->c3base | step);
 }
 
-/* Simulator.cpp:294-452.  sys_dom/sys_rate == NULL selects the adapter's systematic errors. */
+/* the systematic errors of consecutive template bases without variants: GetSysErrorFromBlock's last branch (:286-291) */
+typedef struct {
+    const uint8_t *dom, *rate;
+    uint32_t pos;
+} flat_cursor;
+static void flat_reset(void *ctx) { ((flat_cursor *)ctx)->pos = 0; }
+static void flat_next(void *ctx, uint8_t *dom, uint8_t *rate) {
+    flat_cursor *c = ctx;
+    *dom = c->dom[c->pos];
+    *rate = c->rate[c->pos];
+    ++c->pos;
+}
+static void flat_deleted(void *ctx, uint8_t *rate) {
+    flat_cursor *c = ctx;
+    *rate = c->rate[c->pos];
+    ++c->pos;
+}
+
+/* Simulator.cpp:294-452.  sys == NULL selects the adapter's systematic errors. */
 static void fill_read_part(draw_ctx *d, orc_read *rd, cigar_buf *cg, uint8_t seg, uint16_t tile_id, const uint8_t *org, uint32_t org_len, uint32_t org_pos,
-                           char base_cigar_element, const uint8_t *sys_dom, const uint8_t *sys_rate, uint32_t adapter_id, fill_par *par) {
+                           char base_cigar_element, const orc_sys_cursor *sys, uint32_t adapter_id, fill_par *par) {
     const orc_profile *p = d->s->p;
     uint32_t nt = p->n_tiles;
     uint16_t cigar_element_length = 0;
     char cigar_element = base_cigar_element;
-    uint32_t block_pos = 0;
     uint8_t dom_error = 0;
     while (par->read_pos < par->read_length && org_pos < org_len) {
         orc_philox_out w = stream_words(d, 2u + d->iteration++);
@@ -679,11 +708,8 @@ static void fill_read_part(draw_ctx *d, orc_read *rd, cigar_buf *cg, uint8_t seg
         if (0.0 == prob_sum) indel = 0;
         const orc_table *qt = &p->quality[((size_t)seg * nt + tile_id) * 4 + org[org_pos]];
         if (0 == indel) {
-            if (sys_dom) {                                           /* GetSysErrorFromBlock without variants (:286-291) */
-                dom_error = sys_dom[block_pos];
-                par->error_rate = sys_rate[block_pos];
-                ++block_pos;
-            } else {
+            if (sys) sys->next(sys->ctx, &dom_error, &par->error_rate);   /* GetSysErrorFromBlock */
+            else {
                 dom_error = d->s->adapter_dom[seg][adapter_id][org_pos];
                 par->error_rate = d->s->adapter_rate[seg][adapter_id][org_pos];
             }
@@ -710,10 +736,8 @@ static void fill_read_part(draw_ctx *d, orc_read *rd, cigar_buf *cg, uint8_t seg
             ++par->read_pos;
             ++org_pos;
         } else if (1 == indel) {                                     /* kDeletion */
-            if (sys_dom) {
-                par->error_rate = sys_rate[block_pos];
-                ++block_pos;
-            } else par->error_rate = d->s->adapter_rate[seg][adapter_id][org_pos];
+            if (sys) sys->deleted(sys->ctx, &par->error_rate);
+            else par->error_rate = d->s->adapter_rate[seg][adapter_id][org_pos];
             if ('D' == cigar_element) {
                 ++cigar_element_length;
                 ++par->indel_pos;
@@ -764,6 +788,13 @@ static uint16_t draw_read_length(const orc_profile *p, uint8_t seg, uint32_t fra
 /* Simulator.cpp:454-594 */
 int orc_fill_read(const orc_sim *s, orc_read *rd, uint8_t seg, uint16_t tile_id, uint32_t fragment_length, const uint8_t *org, uint32_t org_len,
                   const uint8_t *sys_dom, const uint8_t *sys_rate, const orc_stream *st) {
+    flat_cursor fc = {sys_dom, sys_rate, 0};
+    orc_sys_cursor cur = {&fc, flat_reset, flat_next, flat_deleted};
+    return orc_fill_read_cursor(s, rd, seg, tile_id, fragment_length, org, org_len, sys_dom ? &cur : NULL, st);
+}
+
+int orc_fill_read_cursor(const orc_sim *s, orc_read *rd, uint8_t seg, uint16_t tile_id, uint32_t fragment_length, const uint8_t *org, uint32_t org_len,
+                         const orc_sys_cursor *sys, const orc_stream *st) {
     const orc_profile *p = s->p;
     uint32_t nt = p->n_tiles;
     draw_ctx d = {s, st, 0};
@@ -780,10 +811,13 @@ int orc_fill_read(const orc_sim *s, orc_read *rd, uint8_t seg, uint16_t tile_id,
     uint16_t seq_length = (uint16_t)(par.read_length < org_len ? par.read_length : org_len);
     uint32_t mean_error_rate = 0;
     if (seq_length) {
-        for (uint16_t read_pos = seq_length, i = 0; read_pos--; ++i) {
+        for (uint16_t read_pos = seq_length; read_pos--;) {
+            uint8_t dom_error, error_rate;
             if (is_gc(org[read_pos])) ++par.gc_seq;
-            mean_error_rate += sys_rate[i];
+            sys->next(sys->ctx, &dom_error, &error_rate);           /* GetSysErrorFromBlock on copies of the start state (:487-502) */
+            mean_error_rate += error_rate;
         }
+        sys->reset(sys->ctx);
         par.gc_seq = orc_percent_u16(par.gc_seq, seq_length);
         mean_error_rate = orc_divide_u32(mean_error_rate, seq_length);
     } else {
@@ -802,14 +836,14 @@ int orc_fill_read(const orc_sim *s, orc_read *rd, uint8_t seg, uint16_t tile_id,
     par.seq_qual = (uint8_t)orc_draw(sqt, idx_sq, orc_u32(h0.w[2]), &prob_sum);
     if (0.0 == prob_sum) par.seq_qual = (uint8_t)orc_most_likely(sqt);
 
-    fill_read_part(&d, rd, &cg, seg, tile_id, org, org_len, 0, 'M', sys_dom, sys_rate, 0, &par);
+    fill_read_part(&d, rd, &cg, seg, tile_id, org, org_len, 0, 'M', sys, 0, &par);
 
     if (par.read_pos < par.read_length) {
         if (0 == adapter_id) adapter_id = discrete_draw(ad->adapter_cp, ad->n, orc_u32(h1.w[1]));
         uint32_t adapter_pos = 0;
         if (0 == par.read_pos)
             adapter_pos = discrete_draw(ad->cut_cp[adapter_id], ad->cut_ptr[adapter_id + 1] - ad->cut_ptr[adapter_id], orc_u32(h0.w[3])) + ad->cut_from[adapter_id];
-        fill_read_part(&d, rd, &cg, seg, tile_id, ad->seqs + ad->seq_ptr[adapter_id], ad->seq_ptr[adapter_id + 1] - ad->seq_ptr[adapter_id], adapter_pos, 'S', NULL, NULL,
+        fill_read_part(&d, rd, &cg, seg, tile_id, ad->seqs + ad->seq_ptr[adapter_id], ad->seq_ptr[adapter_id + 1] - ad->seq_ptr[adapter_id], adapter_pos, 'S', NULL,
                        adapter_id, &par);
         if (par.read_pos < par.read_length) {
             cigar_append(&cg, 'H', (uint32_t)(par.read_length - par.read_pos));
@@ -842,7 +876,7 @@ void orc_text_free(orc_text *t) {
     t->data = NULL;
     t->len = t->cap = 0;
 }
-static void append_record(orc_text *t, const char *id, const orc_read *rd) {
+void orc_text_append_record(orc_text *t, const char *id, const orc_read *rd) {
     static const char kBases[] = "ACGTN";
     size_t idl = strlen(id);
     text_reserve(t, idl + 2u * rd->read_len + 8);
@@ -973,7 +1007,7 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
             char id[8192];
             snprintf(id, sizeof id, "%s%u_%u:%u:%s:%u:%u:1337:1337 %s E%u", s->base_identifier, f->block, f->number, print_start, r->first_name[f->seq], print_end,
                      (unsigned)p->tiles[tile_id], rd[seg].cigar, (unsigned)rd[seg].num_errors);
-            append_record(dst[seg], id, &rd[seg]);
+            orc_text_append_record(dst[seg], id, &rd[seg]);
         }
     }
     free(tmpl[0]);
@@ -997,7 +1031,7 @@ int orc_simulate_adapter_only_pairs(const orc_sim *s, orc_text *r1, orc_text *r2
             char id[8192];
             snprintf(id, sizeof id, "%s0_%llu:0:Adapter:0:%u:1337:1337 %s E%u", s->base_identifier, (unsigned long long)(i + 1), (unsigned)p->tiles[tile_id], rd[seg].cigar,
                      (unsigned)rd[seg].num_errors);
-            append_record(dst[seg], id, &rd[seg]);
+            orc_text_append_record(dst[seg], id, &rd[seg]);
         }
     }
     free(rd);

@@ -1,22 +1,43 @@
-// rsq_variants.h -- the per-allele bookkeeping of the coverage sieve when variants are loaded:
-// Simulator::VariantBiasVarModifiers and the functions that keep it up to date while SimulateFromGivenBlock walks start positions
-// and fragment lengths (Simulator.h:29-89,401-412; Simulator.cpp:1330-1340,1399-1896), plus Reference::ReferenceSequence with variants
-// (Reference.cpp:498-567).  Host code for now: restated with the reference's variable widths and statement order, pinned to
-// SimulatorTest::TestVariationInSimulateFromGivenBlock through tests/hostemu; not yet wired into the kernels.
+// oracle_variants.hpp -- TEST INFRASTRUCTURE (part of the CPU oracle, see oracle.h): the per-allele bookkeeping of the coverage sieve when
+// variants are loaded: Simulator::VariantBiasVarModifiers and the functions that keep it up to date while
+// SimulateFromGivenBlock walks start positions and fragment lengths (Simulator.h:29-89,401-412; Simulator.cpp:1330-1340,1399-1896), plus
+// Reference::ReferenceSequence with variants (Reference.cpp:498-567).  Restated with the reference's variable widths and statement order
+// (incremental over fragment lengths, as there); pinned to SimulatorTest::TestVariationInSimulateFromGivenBlock (orc_var_* driver in
+// oracle_variants.cpp).  C++ because the bookkeeping is vectors of vectors; everything it computes with comes from oracle.h.
 #pragma once
 #include <stdint.h>
 
 #include <algorithm>
+#include <stdexcept>
 #include <utility>
 #include <vector>
 
-#include "rsq_core.h"
-#include "rsq_host.h"
+#include "oracle.h"
 
-namespace rsq {
+namespace orcv {
+
+constexpr uint32_t kSurStart = 10, kSurRange = 10, kSurBlocks = 3, kSurLength = 30;     // Surrounding.h:17
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+inline bool is_gc(uint8_t b) { return b == 1 || b == 2; }
+inline uint32_t percent_u32(uint32_t nom, uint32_t den) { return orc_percent_u32(nom, den); }
+
+struct Variant {                                                             // Reference.h:24-62
+    uint32_t position = 0;
+    std::vector<uint8_t> var_seq;
+    uint64_t allele[2] = {0, 0};
+    bool in_allele(uint32_t a) const { return (allele[a / 64] >> (a % 64)) & 1u; }
+    uint32_t first_allele() const {                                          // Reference.h:42-58
+        orc_variant v;
+        v.allele[0] = allele[0];
+        v.allele[1] = allele[1];
+        return orc_variant_first_allele(&v);
+    }
+};
 
 struct Sur3 {
-    uint32_t b[3] = {0, 0, 0};
+    int32_t b[3] = {0, 0, 0};
 };
 
 // one reference sequence with its variants (what the functions below read of reseq::Reference)
@@ -38,18 +59,12 @@ struct VarRef {
     // ForwardSurrounding / ReverseSurrounding (SurroundingBase.hpp:64-81,196-202) on the base codes, with wrap-around
     Sur3 forward_surrounding(uint32_t pos) const {
         Sur3 s;
-        const uint64_t L = length();
-        uint64_t p = (uint64_t)pos + L - kSurStart;
-        for (uint32_t blk = 0; blk < kSurBlocks; ++blk)
-            for (uint32_t i = 0; i < kSurRange; ++i, ++p) s.b[blk] = (s.b[blk] << 2) + (*codes)[p % L];
+        orc_surrounding_forward(codes->data(), length(), pos, s.b);
         return s;
     }
     Sur3 reverse_surrounding(uint32_t pos) const {
         Sur3 s;
-        const uint64_t L = length();
-        uint64_t q = (uint64_t)(L - pos - 1) + L - kSurStart;                // position on the reverse complement
-        for (uint32_t blk = 0; blk < kSurBlocks; ++blk)
-            for (uint32_t i = 0; i < kSurRange; ++i, ++q) s.b[blk] = (s.b[blk] << 2) + (3u - (*codes)[L - 1 - (q % L)]);
+        orc_surrounding_reverse(codes->data(), length(), pos, s.b);
         return s;
     }
 };
@@ -85,11 +100,11 @@ inline std::vector<uint8_t> complemented_reverse(const uint8_t *b, size_t n) {  
     for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)(3u - b[n - 1 - i]);
     return out;
 }
-inline void change(Sur3 &s, int32_t pos, uint32_t base) { sur_change_base(s.b, (uint32_t)(uint16_t)pos, base); }
-inline void del_right(Sur3 &s, int32_t pos, uint32_t base) { sur_delete_shift_right(s.b, (uint32_t)(uint16_t)pos, base); }
-inline void del_left(Sur3 &s, int32_t pos, uint32_t base) { sur_delete_shift_left(s.b, (uint32_t)(uint16_t)pos, base); }
-inline void ins_right(Sur3 &s, int32_t pos, const std::vector<uint8_t> &bases) { sur_insert_shift_right(s.b, (uint32_t)(uint16_t)pos, bases.data(), (uint32_t)bases.size()); }
-inline void ins_left(Sur3 &s, int32_t pos, const std::vector<uint8_t> &bases) { sur_insert_shift_left(s.b, (uint32_t)(uint16_t)pos, bases.data(), (uint32_t)bases.size()); }
+inline void change(Sur3 &s, int32_t pos, uint32_t base) { orc_sur_change_base(s.b, (uint32_t)(uint16_t)pos, (uint8_t)base); }
+inline void del_right(Sur3 &s, int32_t pos, uint32_t base) { orc_sur_delete_shift_right(s.b, (uint32_t)(uint16_t)pos, (uint8_t)base); }
+inline void del_left(Sur3 &s, int32_t pos, uint32_t base) { orc_sur_delete_shift_left(s.b, (uint32_t)(uint16_t)pos, (uint8_t)base); }
+inline void ins_right(Sur3 &s, int32_t pos, const std::vector<uint8_t> &bases) { orc_sur_insert_shift_right(s.b, (uint32_t)(uint16_t)pos, bases.data(), (uint32_t)bases.size()); }
+inline void ins_left(Sur3 &s, int32_t pos, const std::vector<uint8_t> &bases) { orc_sur_insert_shift_left(s.b, (uint32_t)(uint16_t)pos, bases.data(), (uint32_t)bases.size()); }
 inline std::vector<uint8_t> sub(const std::vector<uint8_t> &v, size_t from, size_t to) { return std::vector<uint8_t>(v.begin() + (ptrdiff_t)from, v.begin() + (ptrdiff_t)std::min(to, v.size())); }
 }  // namespace variants_detail
 
@@ -462,4 +477,4 @@ inline std::vector<uint8_t> reference_sequence_with_variants(const VarRef &ref, 
     return out;
 }
 
-}  // namespace rsq
+}  // namespace orcv

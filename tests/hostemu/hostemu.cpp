@@ -12,7 +12,6 @@
 #include <utility>
 
 #include "../../reseq_amd/csrc/rsq_pack.h"
-#include "../../reseq_amd/csrc/rsq_variants.h"
 
 using namespace rsq;
 
@@ -349,121 +348,6 @@ void emu_sur_edit(uint32_t *sur, int op, uint32_t pos, const uint8_t *bases, uin
         default: sur_insert_shift_left(s, pos, bases, n); break;
     }
 }
-// ---- rsq_variants.h against SimulatorTest::TestVariationInSimulateFromGivenBlock: a small driver object the Python test steers
-struct VarScenario {
-    std::vector<uint8_t> codes, comp_codes;            // the reference and the sequence with allele 1's variants applied
-    std::vector<Variant> variants, none;
-    VariantBiasMod bm{0, 2};
-    VarRef ref() const {
-        VarRef r;
-        r.codes = &codes;
-        r.variants = &variants;
-        r.num_alleles = 2;
-        return r;
-    }
-    VarRef comp() const {
-        VarRef r;
-        r.codes = &comp_codes;
-        r.variants = &none;
-        return r;
-    }
-};
-void *emu_var_new(const uint8_t *codes, uint32_t n, const uint8_t *comp_codes, uint32_t n_comp, uint32_t n_var, const uint32_t *positions, const char *const *var_seqs,
-                  const uint64_t *allele0) {
-    VarScenario *v = new VarScenario();
-    v->codes.assign(codes, codes + n);
-    v->comp_codes.assign(comp_codes, comp_codes + n_comp);
-    for (uint32_t i = 0; i < n_var; ++i) {
-        Variant x;
-        x.position = positions[i];
-        for (const char *c = var_seqs[i]; *c; ++c) x.var_seq.push_back((uint8_t)(strchr("ACGT", *c) - "ACGT"));
-        x.allele[0] = allele0[i];
-        v->variants.push_back(x);
-    }
-    v->bm = VariantBiasMod(1, 2);                       // Simulator::VariantBiasVarModifiers bias_mod(1, 2)
-    return v;
-}
-void emu_var_free(void *h) { delete static_cast<VarScenario *>(h); }
-void emu_var_set_first_variant(void *h, int32_t id) { static_cast<VarScenario *>(h)->bm.first_variant_id = id; }
-void emu_var_get_start(void *h, int32_t *first_variant_id, uint32_t *start_variant_pos) {
-    const VarScenario &v = *static_cast<VarScenario *>(h);
-    *first_variant_id = v.bm.first_variant_id;
-    *start_variant_pos = v.bm.start_variant_pos;
-}
-// PrepareBiasModForCurrentStartPos with the reference surrounding of cur_start; sur_out: [2 alleles][3]; ref_sur_out / comp_sur_out[3]
-int emu_var_prepare_start(void *h, uint32_t cur_start, uint32_t first_fragment_length, uint32_t comp_pos, uint32_t *sur_out, uint32_t *ref_sur_out, uint32_t *comp_sur_out) {
-    return guard([&] {
-        VarScenario &v = *static_cast<VarScenario *>(h);
-        const Sur3 start = v.ref().forward_surrounding(cur_start);
-        prepare_bias_mod_for_current_start_pos(v.bm, v.ref(), cur_start, first_fragment_length, start);
-        const Sur3 comp = v.comp().forward_surrounding(comp_pos);
-        for (int k = 0; k < 3; ++k) {
-            sur_out[k] = v.bm.surrounding_start[0].b[k];
-            sur_out[3 + k] = v.bm.surrounding_start[1].b[k];
-            ref_sur_out[k] = start.b[k];
-            comp_sur_out[k] = comp.b[k];
-        }
-        return 0;
-    });
-}
-// TestVariationInInnerLoopOfSimulateFromGivenBlock: log[allele][fragment length - from] = {unhandled_variant_id, unhandled_bases, gc_mod, end_pos_shift};
-// returns the number of (allele, strand, length) cases whose end position lies inside the sequence, or -1 - (number of property mismatches)
-int emu_var_inner_loop(void *h, uint32_t cur_start, uint32_t from, uint32_t to, const uint32_t *modified_start_pos /*[2]*/, const int32_t *use_comp /*[2]: 0 ref, 1 comp, -1 none*/,
-                       int32_t *log /*[2][to-from][4]*/, uint32_t *n_possible) {
-    int32_t result = 0;
-    const int rc = guard([&] {
-        VarScenario &v = *static_cast<VarScenario *>(h);
-        const VarRef ref = v.ref();
-        const std::vector<uint32_t> possible = possible_alleles(ref, v.bm, cur_start);
-        *n_possible = (uint32_t)possible.size();
-        int mismatches = 0, tests = 0;
-        for (uint32_t fl = from; fl < to; ++fl)
-            for (uint32_t chosen = 0; chosen < 2 * possible.size(); ++chosen) {          // every strand of every possible allele, in id order
-                const uint32_t allele = possible[chosen / 2];
-                const bool strand = chosen % 2;
-                prepare_bias_mod_for_current_fragment_length(v.bm, ref, cur_start, fl, allele);
-                const VarRef comp = use_comp[allele] == 1 ? v.comp() : ref;
-                const VarRef comp_plain = [&] {
-                    VarRef r = comp;
-                    r.variants = &v.none;
-                    return r;
-                }();
-                const Sur3 want = comp_plain.reverse_surrounding(modified_start_pos[allele] + fl - 1u);
-                for (int k = 0; k < 3; ++k) mismatches += want.b[k] != v.bm.surrounding_end[allele].b[k];
-                int32_t *row = log + ((size_t)allele * (to - from) + (fl - from)) * 4;
-                row[0] = v.bm.unhandled_variant_id[allele];
-                row[1] = (int32_t)v.bm.unhandled_bases_in_variant[allele];
-                row[2] = v.bm.gc_mod[allele];
-                row[3] = v.bm.end_pos_shift[allele];
-                const uint32_t cur_end = cur_start + fl + (uint32_t)v.bm.end_pos_shift[allele];
-                if (cur_end < ref.length()) {
-                    const uint32_t gc_perc = gc_percent_with_variants(v.bm, ref, cur_end, fl, allele);
-                    mismatches += gc_perc != percent_u32(comp_plain.gc_content_absolut(modified_start_pos[allele], modified_start_pos[allele] + fl), fl);
-                    const uint32_t tlen = std::min(fl, 100u + 0u);                      // ReadLengths().to() + MaxLenDeletion of the reference test's DataStats
-                    const std::vector<uint8_t> fwd = reference_sequence_with_variants(ref, cur_start, std::min(fl, tlen), false, v.bm.start_variant(), allele);
-                    const std::vector<uint8_t> rev = reference_sequence_with_variants(ref, cur_end, std::min(fl, tlen), true, v.bm.end_variant(v.variants, cur_end, allele), allele);
-                    const std::vector<uint8_t> &cc = *comp_plain.codes;
-                    for (uint32_t k = 0; k < fl; ++k) {
-                        mismatches += k >= fwd.size() || fwd[k] != cc[modified_start_pos[allele] + k];
-                        mismatches += k >= rev.size() || rev[k] != 3u - cc[modified_start_pos[allele] + fl - 1u - k];
-                    }
-                    (void)strand;
-                    ++tests;
-                }
-            }
-        result = mismatches ? -1 - mismatches : tests;
-        return 0;
-    });
-    return rc ? -1000000 : result;
-}
-int emu_var_check_inserted(void *h, uint32_t cur_start) {
-    return guard([&] {
-        VarScenario &v = *static_cast<VarScenario *>(h);
-        check_for_inserted_bases_to_start_from(v.bm, v.ref(), cur_start);
-        return 0;
-    });
-}
-
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;

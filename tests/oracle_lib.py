@@ -25,6 +25,11 @@ FRAGMENT_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("d
                            ("pad", "u1"), ("block", "<u4"), ("number", "<u4")])
 
 
+FRAGMENT_VAR_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("dup", "<u2"), ("strand", "u1"), ("allele", "u1"), ("block", "<u4"),
+                               ("number", "<u4"), ("end", "<u4"), ("sub", "<u4"), ("start_var", "<i4"), ("start_var_pos", "<u4"), ("end_var", "<i4"),
+                               ("end_var_pos", "<u4")])
+
+
 class OrcVariant(C.Structure):
     _fields_ = [("position", C.c_uint32), ("len", C.c_uint32), ("var_seq", u8p), ("allele", C.c_uint64 * 2)]
 
@@ -162,6 +167,12 @@ def lib():
         "orc_sim_sys_rate": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
         "orc_sim_adapter_dom": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
         "orc_sim_adapter_rate": (u8p, [C.c_void_p, C.c_int, C.c_uint32]),
+        "orc_sim_new_variants": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
+                                              C.c_size_t]),
+        "orc_var_last_error": (C.c_char_p, []),
+        "orc_var_sys_errors": (C.c_uint32, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]),
+        "orc_sieve_blocks_var": (C.c_uint64, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+        "orc_create_reads_var": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
         "free": (None, [C.c_void_p]),
     }
     for name, (res, args) in sig.items():
@@ -227,11 +238,12 @@ def create_sys_error_profile(profile, reference, seed):
 
 
 class Sim:
-    def __init__(self, profile, reference, seed, num_pairs=0, coverage=0.0, base_identifier=b"", ref_bias_mode=0, ref_bias_file=None):
-        self.profile, self.reference = profile, reference
+    def __init__(self, profile, reference, seed, num_pairs=0, coverage=0.0, base_identifier=b"", ref_bias_mode=0, ref_bias_file=None, variants=None):
+        """variants: an OrcVariants pointer (orc_read_variants); it has to outlive the Sim"""
+        self.profile, self.reference, self.variants = profile, reference, variants
         err = C.create_string_buffer(1024)
-        self.h = lib().orc_sim_new_bias(profile.h, reference.h if reference else None, seed, num_pairs, coverage, base_identifier, ref_bias_mode,
-                                        str(ref_bias_file).encode() if ref_bias_file else None, err, len(err))
+        self.h = lib().orc_sim_new_variants(profile.h, reference.h if reference else None, C.cast(variants, C.c_void_p) if variants else None, seed, num_pairs, coverage,
+                                            base_identifier, ref_bias_mode, str(ref_bias_file).encode() if ref_bias_file else None, err, len(err))
         if not self.h:
             raise RuntimeError(err.value.decode())
 
@@ -303,6 +315,30 @@ class Sim:
         r1, r2 = Text(), Text()
         L.orc_create_reads(self.h, frags.ctypes.data_as(C.POINTER(Fragment)), len(frags), C.byref(r1), C.byref(r2))
         return _take_text(r1), _take_text(r2)
+
+    # with variants
+    def sieve_var(self, block_lo, block_hi):
+        L = lib()
+        out = C.c_void_p()
+        n = L.orc_sieve_blocks_var(self.h, block_lo, block_hi, C.byref(out))
+        if n == 2**64 - 1:
+            raise RuntimeError(L.orc_var_last_error().decode())
+        arr = np.frombuffer(C.string_at(out, n * FRAGMENT_VAR_DTYPE.itemsize), dtype=FRAGMENT_VAR_DTYPE).copy() if n else np.zeros(0, FRAGMENT_VAR_DTYPE)
+        L.free(out)
+        return arr
+
+    def create_reads_var(self, frags):
+        L = lib()
+        frags = np.ascontiguousarray(frags, dtype=FRAGMENT_VAR_DTYPE)
+        r1, r2 = Text(), Text()
+        if L.orc_create_reads_var(self.h, frags.ctypes.data, len(frags), C.byref(r1), C.byref(r2)):
+            raise RuntimeError(L.orc_var_last_error().decode())
+        return _take_text(r1), _take_text(r2)
+
+    def var_sys_errors(self, strand, seq, var_id):
+        dom, rate = np.zeros(4096, np.uint8), np.zeros(4096, np.uint8)
+        n = lib().orc_var_sys_errors(self.h, strand, seq, var_id, dom.ctypes.data, rate.ctypes.data, 4096)
+        return dom[:n].copy(), rate[:n].copy()
 
     def adapter_only(self):
         r1, r2 = Text(), Text()

@@ -223,6 +223,30 @@ def test_dominant_base():
             assert rolling.dom_base == expected[pos], pos
 
 
+def test_dominant_base_with_memory():
+    """utilitiesTest.cpp:61-83,123-149: DominantBaseWithMemory (the per-allele dominant base of the variants' systematic errors) gives the
+    values the reference test lists for Set at every position and for Update base by base, on the sequence and on its reverse complement."""
+    L = O.lib()
+    db = KA["dominant_base"]
+    seq = _codes(db["seq"])
+    rc = np.where(seq[::-1] < 4, 3 - seq[::-1], 4).astype(np.uint8)
+    L.orc_dombase_memory_script.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for codes, first, rest in ((seq, db["set_0_1_2"], db["set_from_3"]), (rc, db["revcomp_set_0_1_2"], db["revcomp_set_from_3"])):
+        expected = first + rest
+        which, op, arg, want = [], [], [], []
+        for pos in range(len(codes)):                       # object 0: Clear + Set(seq, pos); object 1: Update(seq[pos]) base by base
+            which += [0, 0, 1]
+            op += [0, 1, 2]
+            arg += [0, pos, pos]
+            want += [None, expected[pos], expected[pos]]
+        which, op, arg = np.array(which, np.uint8), np.array(op, np.uint8), np.array(arg, np.uint32)
+        out = np.zeros(len(op), np.uint8)
+        L.orc_dombase_memory_script(codes.ctypes.data, len(codes), len(op), which.ctypes.data, op.ctypes.data, arg.ctypes.data, out.ctypes.data)
+        for i, w in enumerate(want):
+            if w is not None:
+                assert out[i] == w, (i, arg[i], op[i])
+
+
 def test_divide_and_percent():
     L = O.lib()
     for nom, den, exp in KA["divide"]:
@@ -364,7 +388,7 @@ def test_methylation_loading_known_answers_of_the_reference_test(workdir):
     L.emu_parse_methylation.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
     nr2, f2, s3, r2 = np.zeros(n, np.uint32), np.zeros(16, np.uint32), np.zeros(16, np.uint32), np.zeros(16 * A)
     rc = L.emu_parse_methylation(bed.encode(), ("\n".join(names) + "\n").encode(), lens.ctypes.data, n, A, nr2.ctypes.data, f2.ctypes.data, s3.ctypes.data, r2.ctypes.data, 16)
-    assert rc == 0, L.emu_last_error()
+    assert rc == 0, L.orc_var_last_error()
     check(nr2, f2, s3, r2)
 
 
@@ -562,14 +586,13 @@ def test_surrounding_modifiers_extreme_cases(product):
 
 
 def test_variant_bias_modifiers_like_the_reference_test():
-    """SimulatorTest::TestVariationInSimulateFromGivenBlock (SimulatorTest.cpp:116-364) for rsq_variants.h (host code of the product,
-    driven through the test-only host library): per start position and fragment length the per-allele unhandled variant, unhandled bases,
+    """SimulatorTest::TestVariationInSimulateFromGivenBlock (SimulatorTest.cpp:116-364) for oracle/oracle_variants.hpp (the sieve-side
+    bookkeeping of the oracle's simulation with variants): per start position and fragment length the per-allele unhandled variant, unhandled bases,
     GC modification and end-position shift the reference test lists, and its comparisons of start / end surroundings, GC percent and both
     templates with the sequence that has the variants applied.  The E. coli genome is replaced by 2000 seeded bases that carry the 20
     bases the test quotes at 1000..1019 (everything the expected numbers depend on lies there)."""
-    from backends import emu_lib
     g = KA["variation_in_simulate_from_given_block"]
-    L = emu_lib()
+    L = O.lib()
     ref = np.random.default_rng(11).integers(0, 4, 2000).astype(np.uint8)
     ref[1000:1020] = ["ACGT".index(c) for c in g["bases_1000_1019"]]
     enc = lambda s: np.array(["ACGT".index(c) for c in s], np.uint8)
@@ -580,23 +603,24 @@ def test_variant_bias_modifiers_like_the_reference_test():
     pos = np.array([v[0] for v in g["variants"]], np.uint32)
     bits = np.array([v[2] for v in g["variants"]], np.uint64)
     seqs = (C.c_char_p * n)(*[v[1].encode() for v in g["variants"]])
-    L.emu_var_new.restype = C.c_void_p
-    L.emu_var_new.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p]
-    L.emu_var_free.argtypes = [C.c_void_p]
-    L.emu_var_set_first_variant.argtypes = [C.c_void_p, C.c_int32]
-    L.emu_var_get_start.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
-    L.emu_var_prepare_start.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.emu_var_inner_loop.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
-    L.emu_var_check_inserted.argtypes = [C.c_void_p, C.c_uint32]
-    h = L.emu_var_new(ref.ctypes.data, len(ref), alt.ctypes.data, len(alt), n, pos.ctypes.data, seqs, bits.ctypes.data)
+    L.orc_var_last_error.restype = C.c_char_p
+    L.orc_var_new.restype = C.c_void_p
+    L.orc_var_new.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p]
+    L.orc_var_free.argtypes = [C.c_void_p]
+    L.orc_var_set_first_variant.argtypes = [C.c_void_p, C.c_int32]
+    L.orc_var_get_start.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    L.orc_var_prepare_start.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_var_inner_loop.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.orc_var_check_inserted.argtypes = [C.c_void_p, C.c_uint32]
+    h = L.orc_var_new(ref.ctypes.data, len(ref), alt.ctypes.data, len(alt), n, pos.ctypes.data, seqs, bits.ctypes.data)
     try:
         for step in g["steps"]:
             start = step["start"]
             if "set_first_variant" in step:
-                L.emu_var_set_first_variant(h, step["set_first_variant"])
+                L.orc_var_set_first_variant(h, step["set_first_variant"])
             sur, ref_sur, comp_sur = np.zeros(6, np.uint32), np.zeros(3, np.uint32), np.zeros(3, np.uint32)
             comp_at = step["alt_start_surrounding_at"]
-            assert L.emu_var_prepare_start(h, start, 1, comp_at if comp_at is not None else start, sur.ctypes.data, ref_sur.ctypes.data, comp_sur.ctypes.data) == 0, L.emu_last_error()
+            assert L.orc_var_prepare_start(h, start, 1, comp_at if comp_at is not None else start, sur.ctypes.data, ref_sur.ctypes.data, comp_sur.ctypes.data) == 0, L.orc_var_last_error()
             if step["forward_surrounding_start"]:
                 assert sur[:3].tolist() == ref_sur.tolist(), step                        # allele 0 keeps the reference surrounding
             if comp_at is not None:
@@ -606,8 +630,8 @@ def test_variant_bias_modifiers_like_the_reference_test():
             ms = np.array(mod_start, np.uint32)
             use = np.array([{"ref": 0, "alt": 1, None: -1}[c] for c in comp], np.int32)
             n_possible = C.c_uint32()
-            tests = L.emu_var_inner_loop(h, start, fr, to, ms.ctypes.data, use.ctypes.data, log.ctypes.data, C.byref(n_possible))
-            assert tests >= 0, (step, tests, L.emu_last_error())
+            tests = L.orc_var_inner_loop(h, start, fr, to, ms.ctypes.data, use.ctypes.data, log.ctypes.data, C.byref(n_possible))
+            assert tests >= 0, (step, tests, L.orc_var_last_error())
             assert n_possible.value == valid
             for allele in range(2):
                 if not uvid[allele]:
@@ -618,9 +642,9 @@ def test_variant_bias_modifiers_like_the_reference_test():
                 assert log[allele, :, 2].tolist() == gcmod[allele], (start, allele)
                 assert log[allele, :, 3].tolist() == eshift[allele], (start, allele)
             assert tests == valid * 2 * max(len(uvid[0]), len(uvid[1]))                  # SimulatorTest.cpp:193
-            assert L.emu_var_check_inserted(h, start) == 0
+            assert L.orc_var_check_inserted(h, start) == 0
             fv, sp = C.c_int32(), C.c_uint32()
-            L.emu_var_get_start(h, C.byref(fv), C.byref(sp))
+            L.orc_var_get_start(h, C.byref(fv), C.byref(sp))
             assert [fv.value, sp.value] == step["after"], step
     finally:
-        L.emu_var_free(h)
+        L.orc_var_free(h)
