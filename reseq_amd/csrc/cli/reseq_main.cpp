@@ -197,10 +197,7 @@ bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<
 }
 
 int illumina_pe(const Args &a) {
-    if (a.has("vcfSim") && !a.get("vcfSim").empty()) {
-        ERR("--vcfSim is not supported yet in this build (variants; methylation is supported for a reference without variants)");
-        return 1;
-    }
+    const std::string vcf_path = a.get("vcfSim", "");               // -V: per-allele simulation (substitutions; the library refuses what it cannot simulate yet)
     // main.cpp:862-908: --refBias keep|no|draw|file, --refBiasFile implies file; keep is the default
     int ref_bias_mode = 0;
     const std::string ref_bias_file = a.get("refBiasFile", "");
@@ -243,6 +240,10 @@ int illumina_pe(const Args &a) {
     if (ok) {
         INFO("Reading reference from " << ref_path);
         ok = check(rsq_ref_load_fasta(ref_path.c_str(), &ref), "Could not load reference") && check(rsq_ref_replace_n(ref, seed), "ReplaceN");
+    }
+    if (ok && !vcf_path.empty()) {
+        INFO("Reading variants from " << vcf_path);
+        ok = check(rsq_ref_read_variants(ref, vcf_path.c_str()), "Could not read the variant file");
     }
     ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
     if (ok && !sys_write.empty()) {

@@ -51,7 +51,7 @@ struct Stream {
     uint32_t c0, c1, c2, c3base;
     RSQ_HD Words step(uint32_t s) const { return philox(seed, c0, c1, c2, c3base | s); }
 };
-RSQ_HD uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel) { return (dom << 28) | (strand << 27) | (segsel << 25); }
+RSQ_HD uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel, uint32_t allele = 0) { return (dom << 28) | (strand << 27) | (segsel << 25) | (allele << 17); }
 
 // ------------------------------------------------------------------------- integer helpers (utilities.hpp)
 RSQ_HD bool is_gc(uint32_t b) { return b == 1 || b == 2; }
@@ -288,9 +288,14 @@ RSQ_HD uint32_t reverse_ten_bases(uint32_t g) {
 #endif
     return ((r & 0x55555u) << 1) | ((r >> 1) & 0x55555u);         // the two bits of every base back in order
 }
-RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
+// `wrap_words`: with variants `words` is an allele's copy of the reference; the bases a window takes from beyond a sequence end
+// (wrap-around) are the reference's own, because the variant edits of the surroundings stop at the ends
+// (HandleSurroundingVariantsBeforeCenter / AfterCenter, Simulator.cpp:1459-1589)
+RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3],
+                                const uint64_t *__restrict__ wrap_words = nullptr) {
     uint64_t p = (uint64_t)pos + L - kSurStart;                    // < 2L: one conditional subtraction replaces the reference's % length
     if (p >= L) p -= L;
+    bool wrapped = pos < kSurStart;                                // the window begins before base 0
     if (p + kSurBlocks * kSurRange <= L) {                         // no wrap-around: two loads instead of thirty
         const uint64_t x = ref_bits60(words, word_off, (uint32_t)p);
 #pragma unroll
@@ -301,17 +306,22 @@ RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t wor
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
         for (uint32_t i = 0; i < kSurRange; ++i) {
-            v = (v << 2) + ref_base(words, word_off, (uint32_t)p);
-            if (++p == L) p = 0;
+            v = (v << 2) + ref_base(wrapped && wrap_words ? wrap_words : words, word_off, (uint32_t)p);
+            if (++p == L) {
+                p = 0;
+                wrapped = !wrapped;
+            }
         }
         sur[b] = v;
     }
 }
-RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3]) {
+RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t L, uint32_t pos, uint32_t (&sur)[3],
+                                const uint64_t *__restrict__ wrap_words = nullptr) {
     // position q of the reverse complement is the complement of forward position L-1-q; q starts at (L-pos-1) + L - 10 (mod L)
     uint64_t q = (uint64_t)(L - pos - 1) + L - kSurStart;
     if (q >= L) q -= L;
     uint32_t f = L - 1u - (uint32_t)q;                             // forward position, walks downwards with wrap-around
+    bool wrapped = pos + kSurStart >= L;                           // the window begins behind the last base
     if (f + 1u >= kSurBlocks * kSurRange) {                        // no wrap-around: block b is the complement of forward bases f-10b-9 .. f-10b
         const uint64_t x = ref_bits60(words, word_off, f + 1u - kSurBlocks * kSurRange);
 #pragma unroll
@@ -322,8 +332,12 @@ RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t wor
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
         for (uint32_t i = 0; i < kSurRange; ++i) {
-            v = (v << 2) + (3u - ref_base(words, word_off, f));
-            f = f ? f - 1u : L - 1u;
+            v = (v << 2) + (3u - ref_base(wrapped && wrap_words ? wrap_words : words, word_off, f));
+            if (f) --f;
+            else {
+                f = L - 1u;
+                wrapped = !wrapped;
+            }
         }
         sur[b] = v;
     }
@@ -473,8 +487,8 @@ RSQ_HD uint32_t fragment_counts(const DevSim &S, uint32_t seq, uint32_t fragment
     double bias = general * S.gc_bias[gc] * surrounding_bias(S.sur_bias, sur_start) * surrounding_bias(S.sur_bias, sur_end);
     if (0.0 < bias) {
         double mean = bias * S.bias_normalization;
-        double dispersion = get_dispersion(mean, S.dispersion[0], S.dispersion[1]) / 1;
-        mean /= 1;
+        double dispersion = get_dispersion(mean, S.dispersion[0], S.dispersion[1]) / S.num_alleles;
+        mean /= S.num_alleles;
         return negative_binomial(mean / (mean + dispersion), dispersion, probability_chosen);
     }
     return 0;
@@ -528,7 +542,7 @@ template <class Src>
 RSQ_HD void template_totals_loop(const Src &src, uint32_t n, uint32_t &gc, uint32_t &rate_sum) {
     for (uint32_t k = 0; k < n; ++k) {
         if (is_gc(src.base(k))) ++gc;
-        rate_sum += src.sys(k) >> 8;
+        rate_sum += src.sys_base(k) >> 8;
     }
 }
 
@@ -536,7 +550,8 @@ struct AdapterSrc {                    // the adapter as template of FillReadPar
     const uint8_t *seq;
     const uint16_t *sys_;
     RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
-    RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+    RSQ_HD uint32_t sys_base(uint32_t k) const { return sys_[k]; }
+    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_[k]; }
 };
 
 // FillRead as an explicit state machine: init() does everything before the first per-base iteration (Simulator.cpp:468-531),
@@ -617,8 +632,8 @@ struct ReadMachine {
         const uint32_t org_base = src.base(org_pos);
         const uint32_t qi = tbase + org_base;
         if (0 == indel) {
-            // without variants the block walk of GetSysErrorFromBlock advances in step with org_pos (:286-291)
-            const uint32_t se = src.sys(org_pos);
+            // GetSysErrorFromBlock: without variants its block walk advances in step with org_pos (:286-291)
+            const uint32_t se = src.sys_base(org_pos);
             const uint32_t dom_error = se & 0xFFu;
             par.error_rate = se >> 8;
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
@@ -644,7 +659,7 @@ struct ReadMachine {
             ++par.read_pos;
             ++org_pos;
         } else if (1 == indel) {                                   // ErrorStats::kDeletion
-            par.error_rate = src.sys(org_pos) >> 8;
+            par.error_rate = src.sys_deleted(org_pos) >> 8;          // :380-392
             out.op(it, 1u);
             ++n_indels;
             if ('D' == cg.element) {

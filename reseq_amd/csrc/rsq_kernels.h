@@ -250,22 +250,94 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, doubl
     return n_here;
 }
 
-// a cell with fragments, recorded by the sieve pass and expanded into Fragment records after the scan
+// ---- the cell with variants (substitutions only): every allele is a copy of the packed reference with its substitutions applied, so
+// the per-allele GC modification and the surrounding edits of Simulator.cpp:1404-1896 are plain reads of that copy -- what the
+// reference's own test demands of them (SimulatorTest.cpp:116-195 compares with the sequence that has the variants applied).
+constexpr uint32_t kMaxDevAlleles = 8;             // 2 * alleles chosen (allele, strand) slots per cell live in registers
+RSQ_HD const uint64_t *hap_words(const DevSim &S, uint32_t allele) { return S.variants_loaded ? S.ref_words + (1u + allele) * S.hap_stride : S.ref_words; }
+RSQ_HD const uint32_t *hap_gc_prefix(const DevSim &S, uint32_t allele) { return S.variants_loaded ? S.gc_prefix + (1u + allele) * S.hap_stride : S.gc_prefix; }
+struct VarCell {
+    uint32_t n;                                    // chosen (allele, strand) slots with pairs, in draw order
+    uint16_t cnt[2 * kMaxDevAlleles];
+    uint8_t id[2 * kMaxDevAlleles];                // allele * 2 + strand
+};
+// SelectAllele (Simulator.cpp:1341-1361); reverse_selection as a bit mask
+RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, uint32_t &selectable, uint32_t possible_strands, double random_value) {
+    uint32_t chosen_id = (uint32_t)(uint16_t)(random_value * (possible_strands - n_chosen));
+    uint32_t replacement_correction = 0;
+    for (uint32_t i = 0; i < n_chosen; ++i)
+        if (chosen[i] <= chosen_id) ++replacement_correction;
+    while (replacement_correction)
+        if ((selectable >> (++chosen_id)) & 1u) --replacement_correction;
+    chosen[n_chosen++] = (uint8_t)chosen_id;
+    selectable &= ~(1u << chosen_id);
+}
+RSQ_HD uint32_t word_of(const Words &w, uint32_t k) { return k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)); }
+// Streams (DESIGN.md "Random streams", rows "with variants"): SelectAllele's j-th value = word j&3 of block (start, seq, length,
+// 1<<28 | 2 + (j>>2)); the count uniform of the j-th chosen slot = u53 of words 2(j&1), 2(j&1)+1 of block (.., 1<<28 | 128 + (j>>1)).
+RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCell &cell) {
+    cell.n = 0;
+    const double thr0 = site.thr[2u * len], thr1 = site.thr[2u * len + 1u];
+    if (!(probability_chosen >= thr1)) return 0;                                    // Simulator.h:418-420
+    const uint32_t possible_strands = 2u * S.num_alleles;                           // no deletions: every allele is possible (:1330-1340)
+    const uint32_t non_zero_strands = binomial(possible_strands, 1 - thr0, probability_chosen);
+    const uint32_t end = site.start + len;                                          // end_pos_shift_ is 0 without insertions and deletions
+    if (!non_zero_strands || !(end < site.L)) return 0;
+    uint8_t chosen[2 * kMaxDevAlleles];
+    uint32_t n_chosen = 0, selectable = (1u << possible_strands) - 1u, n_draws = 0;
+    const bool direct = non_zero_strands <= possible_strands / 2u;                  // ChooseAlleles :1387-1397
+    const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
+    Words ws{0, 0, 0, 0};
+    while (n_chosen < to_draw) {
+        if (0u == (n_draws & 3u)) ws = philox(S.seed, site.start, site.seq, len, (kDomSieve << 28) | (2u + (n_draws >> 2)));
+        select_allele(chosen, n_chosen, selectable, possible_strands, u32_to_unit(word_of(ws, n_draws & 3u)));
+        ++n_draws;
+    }
+    if (!direct) {                                                                  // ReverseSelection :1373-1385
+        n_chosen = 0;
+        for (uint32_t id = 0; id < possible_strands; ++id)
+            if ((selectable >> id) & 1u) chosen[n_chosen++] = (uint8_t)id;
+    }
+    uint32_t n_here = 0;
+    Words wc{0, 0, 0, 0};
+    for (uint32_t j = 0; j < n_chosen; ++j) {
+        const uint32_t allele = chosen[j] >> 1;
+        const uint64_t *words = hap_words(S, allele);
+        uint32_t sur_start[3], sur_end[3];
+        surrounding_forward(words, site.word_off, site.L, site.start, sur_start, S.ref_words);       // bias_mod.surrounding_start_.at(allele)
+        surrounding_reverse(words, site.word_off, site.L, end - 1u, sur_end, S.ref_words);           // bias_mod.surrounding_end_.at(allele)
+        const uint32_t gc = percent_u32(ref_gc_count_prefix(words, hap_gc_prefix(S, allele), site.word_off, site.start, end), len);   // GetGCPercent with gc_mod_
+        if (0u == (j & 1u)) wc = philox(S.seed, site.start, site.seq, len, (kDomSieve << 28) | (128u + (j >> 1)));
+        const double u = (j & 1u) ? u53_to_unit(wc.w2, wc.w3) : u53_to_unit(wc.w0, wc.w1);
+        const double adjusted_random = thr0 + u * (1 - thr0);                       // :2322
+        const uint32_t c = fragment_counts(S, site.seq, len, gc, sur_start, sur_end, adjusted_random);
+        if (c) {
+            cell.id[cell.n] = chosen[j];
+            cell.cnt[cell.n] = (uint16_t)c;
+            ++cell.n;
+            n_here += c;
+        }
+    }
+    return n_here;
+}
+
+// a cell with fragments, recorded by the sieve pass and expanded into Fragment records after the scan (with variants: one record per
+// two chosen (allele, strand) slots of the cell)
 struct SieveHit {
     uint32_t slot;         // start position slot of the batch
-    uint32_t intra;        // pairs of the same start position that come before this cell
+    uint32_t intra;        // pairs of the same start position that come before this record's
     uint16_t len, cnt0, cnt1;
-    uint8_t strand0, strand1;
+    uint8_t strand0, strand1, allele0, allele1;
 };
 
-RSQ_HD Fragment make_fragment(const SieveSite &site, uint32_t len, uint32_t dup, uint32_t strand, uint32_t block_id, uint32_t number) {
+RSQ_HD Fragment make_fragment(const SieveSite &site, uint32_t len, uint32_t dup, uint32_t strand, uint32_t block_id, uint32_t number, uint32_t allele = 0) {
     Fragment f;
     f.seq = site.seq;
     f.start = site.start;
     f.len = len;
     f.dup = (uint16_t)dup;
     f.strand = (uint8_t)strand;
-    f.pad = 0;
+    f.allele = (uint8_t)allele;
     f.block = block_id;
     f.number = number;
     return f;
@@ -342,6 +414,7 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     bitmap[t] = bits;
 }
 
+template <bool VAR>
 __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
                                                                   const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
     __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
@@ -358,6 +431,8 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
         for (uint32_t base = 0; base < n_queued; base += 64u) {
             const bool active = base + lane < n_queued;
             uint32_t key = 0xFFFFu, len = 0, n_here = 0, cnt[2] = {0, 0}, strand_of[2] = {0, 0};
+            VarCell cell;
+            cell.n = 0;
             if (active) {
                 const uint32_t e = queue[base + lane];
                 key = e >> 16;
@@ -365,7 +440,9 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
                 SieveSite site;
                 const uint32_t slot = slot0 + key;
                 init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
-                n_here = sieve_cell(S, site, len, sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len), cnt, strand_of);
+                const double u = sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len);
+                if constexpr (VAR) n_here = sieve_cell_var(S, site, len, u, cell);
+                else n_here = sieve_cell(S, site, len, u, cnt, strand_of);
             }
             // exclusive prefix of n_here among the earlier queued cells of the same position (keys are non-decreasing)
             uint32_t incl = n_here;
@@ -381,17 +458,38 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
             const uint32_t next_key = __shfl_down(key, 1, 64);
             const uint32_t old_total = active ? totals[key] : 0u;
             if (n_here) {
-                const uint32_t at = atomicAdd(hit_count, 1u);
-                if (at < hit_cap) {
-                    SieveHit h;
-                    h.slot = slot0 + key;
-                    h.intra = old_total + before_in_batch;
-                    h.len = (uint16_t)len;
-                    h.cnt0 = (uint16_t)cnt[0];
-                    h.cnt1 = (uint16_t)cnt[1];
-                    h.strand0 = (uint8_t)strand_of[0];
-                    h.strand1 = (uint8_t)strand_of[1];
-                    hits[at] = h;
+                if constexpr (VAR) {
+                    uint32_t intra = old_total + before_in_batch;
+                    for (uint32_t e = 0; e < cell.n; e += 2u) {
+                        const bool two = e + 1u < cell.n;
+                        const uint32_t at = atomicAdd(hit_count, 1u);
+                        SieveHit h;
+                        h.slot = slot0 + key;
+                        h.intra = intra;
+                        h.len = (uint16_t)len;
+                        h.cnt0 = cell.cnt[e];
+                        h.cnt1 = two ? cell.cnt[e + 1u] : (uint16_t)0;
+                        h.strand0 = cell.id[e] & 1u;
+                        h.allele0 = cell.id[e] >> 1;
+                        h.strand1 = two ? cell.id[e + 1u] & 1u : 0;
+                        h.allele1 = two ? cell.id[e + 1u] >> 1 : 0;
+                        if (at < hit_cap) hits[at] = h;
+                        intra += (uint32_t)h.cnt0 + h.cnt1;
+                    }
+                } else {
+                    const uint32_t at = atomicAdd(hit_count, 1u);
+                    if (at < hit_cap) {
+                        SieveHit h;
+                        h.slot = slot0 + key;
+                        h.intra = old_total + before_in_batch;
+                        h.len = (uint16_t)len;
+                        h.cnt0 = (uint16_t)cnt[0];
+                        h.cnt1 = (uint16_t)cnt[1];
+                        h.strand0 = (uint8_t)strand_of[0];
+                        h.strand1 = (uint8_t)strand_of[1];
+                        h.allele0 = h.allele1 = 0;
+                        hits[at] = h;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -450,8 +548,8 @@ __global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo,
     const uint64_t base = offsets[h.slot];
     const uint32_t number_base = (uint32_t)(base - offsets[h.slot - h.slot % kBlockSize]);
     uint32_t k = h.intra;
-    for (uint32_t dup = 0; dup < h.cnt0; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand0, block_id, number_base + k + 1u);
-    for (uint32_t dup = 0; dup < h.cnt1; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand1, block_id, number_base + k + 1u);
+    for (uint32_t dup = 0; dup < h.cnt0; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand0, block_id, number_base + k + 1u, h.allele0);
+    for (uint32_t dup = 0; dup < h.cnt1; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand1, block_id, number_base + k + 1u, h.allele1);
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -675,6 +773,10 @@ RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragmen
         t.num(f->block);
         t.ch('_');
         t.num(f->number);
+        if (1u < S.num_alleles) {                                    // Simulator.cpp:612-614
+            t.str("_allele", 7);
+            t.num((uint32_t)f->allele);
+        }
         t.ch(':');
         t.num(f->strand ? end : f->start + 1u);
         t.ch(':');
@@ -752,6 +854,7 @@ RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragm
     uint32_t n = 1u + names.base_len;
     if (f) {
         const uint32_t end = f->start + f->len;
+        if (1u < S.num_alleles) n += 7u + digits_u64(f->allele);
         n += digits_u64(f->block) + 1u + digits_u64(f->number) + 1u + digits_u64(f->strand ? end : f->start + 1u) + 1u +
              (names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]) + 1u + digits_u64(f->strand ? f->start + 1u : end);
     } else n += 2u + digits_u64(adapter_only_number) + 12u;
@@ -819,7 +922,8 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
     RSQ_HD uint32_t org_len() const { return len; }
     RSQ_HD uint32_t ref(uint32_t k) const { return reverse ? 3u - ref_base(words, word_off, first - 1u - k) : ref_base(words, word_off, first + k); }
     RSQ_HD uint32_t base(uint32_t k) const { return converted ? (uint32_t)(converted[k >> 5] >> ((k & 31u) * 2u)) & 3u : ref(k); }
-    RSQ_HD uint32_t sys(uint32_t k) const { return sys_[k]; }
+    RSQ_HD uint32_t sys_base(uint32_t k) const { return sys_[k]; }
+    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_[k]; }
     // Simulator.cpp:482-489 without a load per base: the G/C count of the template's reference range from the per-word prefix sums
     // (the complement strand has the same count), the error rates four per 8-byte load
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
@@ -924,7 +1028,8 @@ struct EmptySrc {                       // adapter-only pair: org_seq_ = "" (Sim
     RSQ_HD void totals(uint32_t, uint32_t &, uint32_t &) const {}
     RSQ_HD uint32_t org_len() const { return 0; }
     RSQ_HD uint32_t base(uint32_t) const { return 0; }
-    RSQ_HD uint32_t sys(uint32_t) const { return 0; }
+    RSQ_HD uint32_t sys_base(uint32_t) const { return 0; }
+    RSQ_HD uint32_t sys_deleted(uint32_t) const { return 0; }
 };
 
 RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3base) {      // Simulator.h:176-181
@@ -1065,14 +1170,91 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
     const uint32_t L = S.seq_len[f.seq], end = f.start + f.len;
     const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion;           // Simulator.cpp:1918-1921
     FragmentSrc src;
-    src.words = S.ref_words;
+    src.words = hap_words(S, f.allele);                                        // with variants: the allele's copy (substitutions applied)
     src.word_off = S.seq_word_off[f.seq];
     src.len = f.len < want ? f.len : want;
     src.reverse = seg != f.strand;                                              // block.at(strand) = start_block
     src.first = src.reverse ? end : f.start;
     src.sys_ = src.reverse ? S.sys_rev + S.seq_base_off[f.seq] + (L - end) : S.sys_fwd + S.seq_base_off[f.seq] + f.start;
     src.converted = nullptr;
-    src.gc_prefix = S.gc_prefix;
+    src.gc_prefix = hap_gc_prefix(S, f.allele);
+    return src;
+}
+
+// The template of a mate with variants (substitutions): FragmentSrc on the allele's copy of the reference, and the systematic
+// errors through the walk of GetSysErrorFromBlock / IncrementBlockPos (Simulator.cpp:232-292) and of FillReadPart's deletion
+// branch (:380-392), stated in strand coordinates (position on the strand the mate reads; variants in that strand's order):
+// the reverse blocks' lists are the mirror image of the forward ones.  cur walks the variants of ALL alleles; a block's
+// err_variants_ list ends where the block ends, and cur_var = 0 after a block change is the first variant of the new block.
+// As written in the reference: after a substitution is used cur is incremented twice (the next variant is skipped unless a block
+// starts in between), and the deletion branch does not look at variants at all (a passed variant is applied late).
+struct VariantSrc : FragmentSrc {
+    const DevVariant *var;              // the sequence's variants in forward order
+    uint32_t n_var, L, allele;
+    uint32_t spos0, cur0;               // start of the walk: strand position of the first template base, first variant at or after it
+    mutable uint32_t spos, cur;
+    RSQ_HD const DevVariant &var_at(uint32_t i) const { return reverse ? var[n_var - 1u - i] : var[i]; }
+    RSQ_HD uint32_t var_spos(uint32_t i) const { return reverse ? L - 1u - var_at(i).pos : var_at(i).pos; }
+    RSQ_HD uint32_t lower_bound(uint32_t sp) const {
+        uint32_t lo = 0, hi = n_var;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (var_spos(mid) < sp) lo = mid + 1u;
+            else hi = mid;
+        }
+        return lo;
+    }
+    // blocks are cut on the forward strand (Simulator.h:254): first strand position of the block after the one holding sp
+    RSQ_HD uint32_t block_end(uint32_t sp) const { return reverse ? L - ((L - sp - 1u) / kBlockSize) * kBlockSize : (sp / kBlockSize + 1u) * kBlockSize; }
+    RSQ_HD void start_walk() {
+        spos = spos0 = reverse ? L - first : first;
+        cur = cur0 = lower_bound(spos0);
+    }
+    RSQ_HD void increment_block_pos() const {                                   // :232-238
+        const uint32_t bend = block_end(spos);
+        if (++spos == bend) cur = lower_bound(spos);
+    }
+    RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292 with substitutions only (var_pos stays 0)
+        const uint32_t bend = block_end(spos);
+        while (cur < n_var) {
+            const uint32_t vs = var_spos(cur);
+            if (!(vs < bend && vs <= spos)) break;                              // cur_var < err_variants_.size() && position_ <= block_pos
+            const DevVariant &v = var_at(cur);
+            if ((v.allele[allele >> 6] >> (allele & 63u)) & 1u) {
+                const uint32_t se = reverse ? v.err_rev : v.err_fwd;
+                ++cur;
+                increment_block_pos();
+                ++cur;
+                return se;
+            }
+            ++cur;
+        }
+        const uint32_t se = sys_[spos - spos0];
+        increment_block_pos();
+        return se;
+    }
+    RSQ_HD uint32_t sys_deleted(uint32_t) const {                               // :380-392
+        const uint32_t se = sys_[spos - spos0];
+        increment_block_pos();
+        return se;
+    }
+    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {    // :480-504: the error rates through a copy of the walk
+        if (converted) {
+            for (uint32_t k = 0; k < n; ++k) gc += is_gc(base(k));
+        } else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
+        for (uint32_t k = 0; k < n; ++k) rate_sum += sys_base(k) >> 8;
+        spos = spos0;
+        cur = cur0;
+    }
+};
+RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, uint32_t seg) {
+    VariantSrc src;
+    static_cast<FragmentSrc &>(src) = fragment_src(S, f, seg);
+    src.var = S.variants + S.var_ptr[f.seq];
+    src.n_var = S.var_ptr[f.seq + 1] - S.var_ptr[f.seq];
+    src.L = S.seq_len[f.seq];
+    src.allele = f.allele;
+    src.start_walk();
     return src;
 }
 // The converted template of mate `seg` of fragment f (CTConversion's dispatcher, Simulator.cpp:2219-2247): the forward mate is
@@ -1089,9 +1271,10 @@ RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, u
 template <class Tab>
 RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
-    const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2));
-    const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)};
-    fill_read(S, tab, st, seg, tile, f.len, fragment_src(S, f, seg), out, meta);
+    const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2, f.allele));
+    const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg, f.allele)};
+    if (S.variants_loaded) fill_read(S, tab, st, seg, tile, f.len, variant_src(S, f, seg), out, meta);
+    else fill_read(S, tab, st, seg, tile, f.len, fragment_src(S, f, seg), out, meta);
 }
 // one mate of adapter-only pair i (Simulator.cpp:2359-2382)
 template <class Tab>
@@ -1108,7 +1291,8 @@ struct RecordSrc {
     uint32_t len;
     RSQ_HD uint32_t org_len() const { return len; }
     RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
-    RSQ_HD uint32_t sys(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
+    RSQ_HD uint32_t sys_base(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
+    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_base(k); }
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const { template_totals_loop(*this, n, gc, rate_sum); }
 };
 #ifndef RSQ_FILL_BLOCK
@@ -1157,7 +1341,7 @@ __device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint
     }
 }
 
-template <uint32_t MASK>
+template <uint32_t MASK, bool VAR = false>
 __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
     extern __shared__ __attribute__((aligned(16))) double lds_image[];
@@ -1182,11 +1366,17 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         const uint32_t c0 = from_fragment ? f.start : (uint32_t)ao, c1 = from_fragment ? f.seq : 0xFFFFFFFFu,
                        c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
         const uint32_t strand = from_fragment ? f.strand : 0u;
-        const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg)};
-        FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
-        if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
+        const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg, f.allele)};
         ReadMeta meta;
-        fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
+        if constexpr (VAR) {                                            // launched for fragments only
+            VariantSrc src = variant_src(S, f, seg);
+            if (raw.templates) src.converted = raw.templates + r * raw.template_words;
+            fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2, f.allele), f.len, src, out, meta);
+        } else {
+            FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
+            if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
+            fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
+        }
         if (active) {
             raw.meta[r] = meta;
             sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta);       // bytes of its FASTQ record

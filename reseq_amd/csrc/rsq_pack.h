@@ -20,6 +20,7 @@ namespace rsq {
 struct Uploader {                                   // copies a host array to wherever the kernels will read it
     virtual void *put_bytes(const void *data, size_t bytes) = 0;
     virtual void write_bytes(void *dst, const void *src, size_t bytes) = 0;      // overwrite part of an array put earlier
+    virtual void read_bytes(void *dst_host, const void *src, size_t bytes) = 0;   // read back what the pre-pass kernels wrote
     virtual ~Uploader() {}
     template <class T>
     T *put(const std::vector<T> &v) {
@@ -36,6 +37,15 @@ struct SimState {
     std::vector<uint64_t> seq_word_off, seq_base_off;
     uint64_t total_ref_size = 0;
     std::vector<std::vector<uint8_t>> ref_codes;     // host copy: DominantBase carry-over between chains
+    // variants (-V): host copies of what the device holds, and of the two table families their systematic errors are drawn from
+    bool has_variants = false;
+    uint32_t num_alleles = 1;
+    std::vector<DevVariant> variants;
+    std::vector<uint32_t> var_ptr;
+    DevVariant *dev_variants = nullptr;
+    std::vector<double> host_pool;
+    std::vector<uint8_t> host_par0;
+    std::vector<DevTable> host_dom_error, host_error_rate;
     DevSim dev{};
     NameTable names{};
     uint16_t *sys_fwd = nullptr, *sys_rev = nullptr, *adapter_sys[2] = {nullptr, nullptr};   // written by the chain pre-pass
@@ -179,6 +189,10 @@ inline void pack_tables(SimState &s, Uploader &up) {
     pool.push_back(0.0);
     s.dev.pool = up.put(pool);
     s.dev.par0 = up.put(par0);
+    s.host_pool = pool;                                              // for the systematic errors of variants (drawn on the host)
+    s.host_par0 = par0;
+    s.host_dom_error = dom_error;
+    s.host_error_rate = error_rate;
 }
 
 // the staging combinations k_fill_reads is instantiated for: a forced mode (RSQ_FILL_MODE, tests) is cut down to the nearest one
@@ -267,7 +281,18 @@ inline void pack_profile(SimState &s, Uploader &up) {
     s.ops_stride = (max_iter + 15u) / 16u;
 }
 
-inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
+// Which variant sets the kernels can simulate today: substitutions only, and no two of them at one position of one allele
+inline void check_variants_supported(const Variants &v) {
+    if (v.num_alleles > kMaxDevAlleles) throw Error("variants: more than " + std::to_string(kMaxDevAlleles) + " alleles are not supported yet");
+    for (const std::vector<Variant> &seq : v.by_seq)
+        for (size_t i = 0; i < seq.size(); ++i) {
+            if (seq[i].var_seq.size() != 1) throw Error("variants: insertions and deletions are not supported yet (only substitutions are simulated)");
+            for (size_t k = i + 1; k < seq.size() && seq[k].position == seq[i].position; ++k)
+                if ((seq[k].allele[0] & seq[i].allele[0]) | (seq[k].allele[1] & seq[i].allele[1])) throw Error("variants: two substitutions at one position of one allele");
+        }
+}
+
+inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const Variants *variants = nullptr) {
     DevSim &d = s.dev;
     d.n_seqs = (uint32_t)r.codes.size();
     s.has_ref = true;
@@ -309,6 +334,58 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r) {
         }
     }
     s.ref_codes = r.codes;
+    s.has_variants = variants != nullptr;
+    s.num_alleles = variants ? variants->num_alleles : 1u;
+    d.num_alleles = s.num_alleles;
+    d.variants_loaded = variants ? 1u : 0u;
+    d.hap_stride = 0;
+    s.variants.clear();
+    s.var_ptr.assign(1, 0);
+    if (variants) {
+        // copy 0 = the reference, copy 1 + a = allele a with its substitutions; G/C prefix sums per copy
+        check_variants_supported(*variants);
+        const size_t stride = words + 1;
+        d.hap_stride = stride;
+        packed.resize(stride * (1u + s.num_alleles));
+        gc_prefix.resize(stride * (1u + s.num_alleles));
+        for (uint32_t a = 0; a < s.num_alleles; ++a) {
+            uint64_t *hp = &packed[stride * (1u + a)];
+            std::copy(packed.begin(), packed.begin() + (ptrdiff_t)stride, hp);
+            for (size_t i = 0; i < r.codes.size(); ++i)
+                for (const Variant &v : variants->by_seq[i])
+                    if (v.in_allele(a)) {
+                        uint64_t &w = hp[s.seq_word_off[i] + (v.position >> 5)];
+                        const uint32_t sh = (v.position & 31u) * 2u;
+                        w = (w & ~((uint64_t)3u << sh)) | ((uint64_t)v.var_seq[0] << sh);
+                    }
+            uint32_t *gp = &gc_prefix[stride * (1u + a)];
+            for (size_t i = 0; i < r.codes.size(); ++i) {
+                const size_t n_words = (r.codes[i].size() + 31) / 32;
+                uint32_t total = 0;
+                for (size_t w = 0; w <= n_words; ++w) {
+                    gp[s.seq_word_off[i] + w] = total;
+                    if (w < n_words) {
+                        const uint64_t x = hp[s.seq_word_off[i] + w];
+                        total += (uint32_t)__builtin_popcountll((x ^ (x >> 1)) & 0x5555555555555555ull);
+                    }
+                }
+            }
+        }
+        for (size_t i = 0; i < r.codes.size(); ++i) {
+            for (const Variant &v : variants->by_seq[i]) {
+                DevVariant dv{};
+                dv.pos = v.position;
+                dv.allele[0] = v.allele[0];
+                dv.allele[1] = v.allele[1];
+                dv.base = v.var_seq[0];
+                s.variants.push_back(dv);
+            }
+            s.var_ptr.push_back((uint32_t)s.variants.size());
+        }
+    } else s.var_ptr.assign(r.codes.size() + 1, 0);
+    s.dev_variants = up.put(s.variants);
+    d.variants = s.dev_variants;
+    d.var_ptr = up.put(s.var_ptr);
     d.ref_words = up.put(packed);
     d.gc_prefix = up.put(gc_prefix);
     d.seq_word_off = up.put(s.seq_word_off);
@@ -427,10 +504,10 @@ inline void interpolate_normalization(const Vect<double> &len_bias, const std::v
     for (uint32_t len = x[k] + 1; len < norm.size(); ++len) norm[len] = len_bias[len] * exp(pars[k + 1] + (len - x[k]) * slope);
 }
 
-inline double threshold0(const double disp[2], double norm, double max_bias) {      // FragmentDistributionStats.cpp:2969-2976, one allele
+inline double threshold0(const double disp[2], double norm, double max_bias, uint32_t num_alleles) {      // FragmentDistributionStats.cpp:2969-2976
     double max_mean = norm * max_bias;
-    double max_dispersion = get_dispersion(max_mean, disp[0], disp[1]) / 1;
-    max_mean /= 1;
+    double max_dispersion = get_dispersion(max_mean, disp[0], disp[1]) / num_alleles;
+    max_mean /= num_alleles;
     return pow(max_dispersion / (max_dispersion + max_mean), max_dispersion);
 }
 
@@ -530,6 +607,140 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
     s.dev.block_seq = up.put(s.block_seq);
     s.dev.first_block = up.put(s.first_block);
     s.dev.total_blocks = s.total_blocks;
+}
+
+// ------------------------------------------------------- systematic errors of the variants' bases (a13 with variants)
+// SetSystematicErrorVariantsForward / Reverse (Simulator.cpp:771-909,1011-1147) after the chains: one sequential pass per strand on
+// the host.  The reverse function is the mirror image of the forward one, so both are one routine in strand coordinates: position
+// sp on the strand (forward position L-1-sp on the reverse strand), bases complemented, variants visited in the strand's order.
+// Per variant: last base (the previous variant's last base when that variant sits directly before, else the strand's base before),
+// the dominant base from a DominantBaseWithMemory per allele (utilities.hpp:302-351) that lives through variants at most
+// kLastX bases apart, the G/C percent of the sys_gc_range_ strand bases before the variant (reference bases only; the reference
+// updates or recounts, both give the window count), and the error-region state (distance, start rate) of the strand's chain at
+// the variant's position -- folded from the start of the strand over the chain's rates, variants never touch it.  The uniforms:
+// words 0, 1 of Philox block (variant index, sequence, 4 + strand, 3<<28 | k) for the k-th base drawn.
+struct HostDomMemory {                                                // DominantBaseWithMemory
+    uint32_t dom = 0, cnt[5] = {0, 0, 0, 0, 0};
+    uint8_t mem[8];
+    uint32_t n = 0;
+    void find(uint32_t cur_pos) {                                     // DominantBase::FindDominant on memory_
+        uint32_t mx = 0;
+        for (int b = 4; b--;) mx = std::max(mx, cnt[b]);
+        if (0 == mx) dom = (n <= cur_pos || 4 == mem[cur_pos]) ? 0u : mem[cur_pos];
+        else {
+            uint32_t pos = cur_pos;
+            while (mx != cnt[mem[--pos]]) {}
+            dom = mem[pos];
+        }
+    }
+    void clear() {
+        for (uint32_t &c : cnt) c = 0;
+        n = 0;
+    }
+    template <class At>
+    void set(const At &at, uint32_t cur_pos) {
+        n = std::min(5u, cur_pos) + 1u;
+        for (uint32_t k = n; k--;) mem[k] = (uint8_t)at(cur_pos + k + 1u - n);
+        for (uint32_t pos = 0; pos + 1u < n; ++pos) ++cnt[mem[pos]];  // DominantBase::Set(memory_, n - 1): at most kLastX bases before
+        find(n - 1u);
+    }
+    void update(uint32_t base) {
+        if (n > 5u + 1u) {
+            for (uint32_t k = 1; k < n; ++k) mem[k - 1] = mem[k];
+            --n;
+        }
+        mem[n++] = (uint8_t)base;
+        if (1 < n) {                                                  // DominantBase::Update(memory_[n-2], memory_, n-2)
+            const uint32_t last_pos = n - 2u;
+            ++cnt[mem[last_pos]];
+            if (5u <= last_pos) --cnt[mem[last_pos - 5u]];
+            find(last_pos + 1u);
+        } else find(0);                                               // DominantBase::Set(memory_, 0)
+    }
+};
+
+// rates: the strand's chain output (dom | rate << 8 per strand position).  Fills err_fwd / err_rev of the sequence's variants.
+inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track) {
+    const std::vector<uint8_t> &codes = s.ref_codes[seq];
+    const uint32_t L = (uint32_t)codes.size(), A = s.num_alleles, range = s.dev.sys_gc_range;
+    DevVariant *vars = s.variants.data() + s.var_ptr[seq];
+    const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
+    if (!n) return;
+    auto at = [&](uint32_t sp) -> uint32_t { return reverse ? 3u - codes[L - 1u - sp] : codes[sp]; };
+    DevSim host = s.dev;                                             // the draws read host copies of the two table families
+    host.pool = s.host_pool.data();
+    host.par0 = s.host_par0.data();
+    std::vector<uint32_t> last_sp(A, 0);
+    std::vector<uint8_t> seen(A, 0), last_base_of(A, 4);
+    std::vector<HostDomMemory> dom(A);
+    uint32_t dist = 0, start_rate = 0, folded = 0;                  // chain state before strand position `folded`
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t var_id = reverse ? n - 1u - k : k;
+        DevVariant &v = vars[var_id];
+        const uint32_t sp = reverse ? L - 1u - v.pos : v.pos, base = reverse ? 3u - v.base : v.base, len = 1;
+        uint32_t chosen = 0;                                        // Variant::FirstAllele
+        while (chosen < A && !((v.allele[chosen >> 6] >> (chosen & 63u)) & 1u)) ++chosen;
+        if (chosen == A) throw Error("variant without an allele");
+        uint32_t last_base;
+        if (seen[chosen] && last_sp[chosen] + 1u == sp) last_base = last_base_of[chosen];
+        else last_base = sp ? at(sp - 1u) : 4u;
+        if (seen[chosen] && last_sp[chosen] + 5u >= sp) {
+            for (uint32_t q = last_sp[chosen] + 1u; q < sp; ++q) dom[chosen].update(at(q));
+        } else {
+            dom[chosen].clear();
+            if (sp) dom[chosen].set(at, sp - 1u);
+        }
+        for (; folded < sp; ++folded) update_distances(s.dev.reset_distance, dist, start_rate, track[folded] >> 8);
+        const uint32_t gc_bases = std::min(sp, range);
+        uint32_t gc = 0;
+        for (uint32_t q = sp - gc_bases; q < sp; ++q) gc += is_gc(at(q));
+        dom[chosen].update(base);
+        const Words w = philox(s.seed, var_id, seq, 4u + (reverse ? 1u : 0u), (kDomSysErr << 28) | 0u);
+        const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};
+        double ps;
+        uint32_t dom_error = draw<3>(s.host_dom_error[(base * 5u + last_base) * 5u + dom[chosen].dom], host.pool, host.par0, idx, u32_to_unit(w.w0), ps);
+        if (0.0 == ps) dom_error = 4;
+        uint32_t rate = draw<3>(s.host_error_rate[base * 5u + dom_error], host.pool, host.par0, idx, u32_to_unit(w.w1), ps);
+        if (0.0 == ps) rate = 0;
+        (reverse ? v.err_rev : v.err_fwd) = (uint16_t)(dom_error | (rate << 8));
+        last_base = base;
+        // the other alleles of the variant: their dominant-base memories (Simulator.cpp:1088-1126 / 849-887)
+        uint32_t ref_allele = A;
+        if (!seen[chosen] || last_sp[chosen] + 5u < sp + len) ref_allele = chosen;
+        for (uint32_t allele = 0; allele < A; ++allele) {
+            if (!((v.allele[allele >> 6] >> (allele & 63u)) & 1u)) continue;
+            if (allele != chosen) {
+                if (seen[allele] && last_sp[allele] + 5u >= sp + len) {
+                    for (uint32_t q = last_sp[allele] + 1u; q < sp; ++q) dom[allele].update(at(q));
+                    dom[allele].update(base);
+                } else if (ref_allele < A) dom[allele] = dom[ref_allele];
+                else {
+                    ref_allele = allele;
+                    dom[allele].clear();
+                    if (sp) dom[allele].set(at, sp - 1u);
+                    dom[allele].update(base);
+                }
+            }
+            seen[allele] = 1;
+            last_sp[allele] = sp;
+            last_base_of[allele] = (uint8_t)last_base;
+        }
+    }
+}
+
+// both strands of every simulated sequence (CreateUnit: the reverse strand first); the tracks come back from the device
+inline void build_variant_sys_errors(SimState &s, Uploader &up) {
+    if (!s.has_variants || s.variants.empty()) return;
+    std::vector<uint16_t> track;
+    for (uint32_t seq = 0; seq < s.dev.n_seqs; ++seq) {
+        if (!s.n_blocks[seq] || s.var_ptr[seq] == s.var_ptr[seq + 1]) continue;
+        track.resize(s.seq_len[seq]);
+        for (int strand = 2; strand--;) {
+            up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq], track.size() * sizeof(uint16_t));
+            variant_sys_errors_strand(s, seq, strand != 0, track.data());
+        }
+    }
+    up.write_bytes(s.dev_variants, s.variants.data(), s.variants.size() * sizeof(DevVariant));
 }
 
 // ------------------------------------------------------------------------------- chains of the a13 pre-pass
@@ -673,8 +884,8 @@ inline void finish_bias_normalization(SimState &s, const BiasPlan &plan, const s
     s.thresholds.assign((size_t)s.n_groups * to * 2, 1.0);
     for (size_t i = 0; i < (size_t)s.n_groups * to; ++i)
         if (0.0 != max_bias[i]) {
-            s.thresholds[2 * i] = threshold0(p.dispersion, s.bias_normalization, max_bias[i]);
-            s.thresholds[2 * i + 1] = pow(s.thresholds[2 * i], 2 * 1);
+            s.thresholds[2 * i] = threshold0(p.dispersion, s.bias_normalization, max_bias[i], s.num_alleles);
+            s.thresholds[2 * i + 1] = pow(s.thresholds[2 * i], 2 * s.num_alleles);               // FragmentDistributionStats.cpp:3575-3576
         }
     s.norm_by_len = norm;
     if (0.0 == s.bias_normalization) throw Error("bias normalisation is zero");

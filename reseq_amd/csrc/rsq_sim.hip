@@ -102,6 +102,7 @@ struct DeviceUploader : Uploader {
         return owned.back()->as<void>();
     }
     void write_bytes(void *dst, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
+    void read_bytes(void *dst_host, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost)); }
 };
 
 // ------------------------------------------------------------------------------------------------ rsq_sim
@@ -195,6 +196,8 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
         upload_normalization(s, s.up);
     }
     s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);
+    HIP_CHECK(hipStreamSynchronize(st));
+    build_variant_sys_errors(s, s.up);                              // -V: the variants' bases, from the finished chains
     s.prepared = true;
 }
 
@@ -247,11 +250,12 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
 }
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
-template <uint32_t MASK>
+template <uint32_t MASK, bool VAR = false>
 static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
     const LdsPlan &pl = s.dev.lds;
     const size_t lds_bytes = MASK ? (size_t)pl.total_doubles * sizeof(double) : 0;
-    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (lds_bytes > 64 * 1024)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MASK, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
     const uint64_t chunks = (n_pairs + 63) / 64;
     uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(chunks, kFillBlock / 64)));
@@ -259,7 +263,7 @@ static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs
     s.fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL(k_fill_reads<MASK>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
+    hipLaunchKernelGGL((k_fill_reads<MASK, VAR>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
                        s.fill_counters.as<uint32_t>());
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
@@ -292,6 +296,13 @@ static void launch_fill_dispatch(uint32_t mask, rsq_sim &s, const Fragment *frag
     if (!done) throw Error("no k_fill_reads instantiation for staging mask " + std::to_string(mask));
 }
 static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+    if (frags && s.has_variants) {
+        // with variants the error walk is per lane state: two instantiations only, every table staged or every table from HBM
+        constexpr uint32_t kAll = kLdsDesc | kLdsQuality | kLdsRate | kLdsBaseCall;
+        if (effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) == kAll) launch_fill_mask<kAll, true>(s, frags, n_pairs, adapter_first, raw, st);
+        else launch_fill_mask<0u, true>(s, frags, n_pairs, adapter_first, raw, st);
+        return;
+    }
     launch_fill_dispatch(effective_fill_mask(s.dev.lds.mask, s.force_fill_mode), s, frags, n_pairs, adapter_first, raw, st,
                          std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
 }
@@ -380,9 +391,12 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
                                s.dev, block_lo, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
             s.timers["sieve_screen"].stop(st);
         }
-        hipLaunchKernelGGL(k_sieve_finish, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot, slots_per_wave,
-                           s.sieve_bitmap.as<uint32_t>(),
-                           s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
+        if (s.has_variants)
+            hipLaunchKernelGGL(k_sieve_finish<true>, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot,
+                               slots_per_wave, s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(k_sieve_finish<false>, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot,
+                               slots_per_wave, s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
         exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
@@ -638,7 +652,6 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     int n = rsq_device_count();
     if (n < 0) return n;
     REQUIRE(device >= 0 && device < n, "device index out of range");
-    REQUIRE(!(ref && ref->has_variants), "the reference carries variants: the per-allele simulation (--vcfSim) is not built yet");
     std::unique_ptr<rsq_sim> s(new rsq_sim());
     int rc = guard([&] {
         HIP_CHECK(hipSetDevice(device));
@@ -651,7 +664,7 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         s->prof = p->p;
         pack_tables(*s, s->up);
         pack_profile(*s, s->up);
-        if (ref) pack_reference(*s, s->up, ref->r);
+        if (ref) pack_reference(*s, s->up, ref->r, ref->has_variants ? &ref->variants : nullptr);
         return RSQ_OK;
     });
     if (rc == RSQ_OK) *out = s.release();
@@ -733,6 +746,7 @@ int rsq_sim_read_sys_errors(rsq_sim *s, const char *path) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         apply_sys_error_records(*s, s->up, parse_sys_error_fastq(read_text_file(path)));
+        build_variant_sys_errors(*s, s->up);                        // their error-region state follows the loaded rates
         return RSQ_OK;
     });
 }
@@ -740,6 +754,7 @@ int rsq_sim_read_methylation(rsq_sim *s, const char *path) {
     REQUIRE(s && path && s->has_ref, "a simulator with a reference is needed");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
+        if (s->has_variants) throw Error("--methylation together with variants is not supported yet");
         pack_methylation(*s, s->up, read_methylation_file(path, s->ref_first_names, s->seq_len));
         return RSQ_OK;
     });

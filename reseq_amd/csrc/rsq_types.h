@@ -76,7 +76,7 @@ struct Fragment {
     uint32_t len;          // fragment length (0 = adapter-only pair)
     uint16_t dup;          // duplicate index at this (start,len,strand) site
     uint8_t strand;
-    uint8_t pad;
+    uint8_t allele;        // 0 without variants
     uint32_t block;        // block number printed in the read id
     uint32_t number;       // read_number within the block (1-based)
 };
@@ -91,6 +91,17 @@ struct ReadMeta {
     uint16_t tile_id;
     uint16_t cigar_chars;  // length of the CIGAR string
     uint16_t plain;        // 1: no insertion or deletion anywhere, the CIGAR follows from the counts above without the stored ops
+};
+
+// One variant of the reference (Reference.h:24-62) as the kernels see it.  Only substitutions reach the device for now: `base` is the
+// single base of var_seq_.  err_fwd / err_rev: the systematic error drawn for that base on the forward / reverse strand
+// (SysErrorVariant::var_errors_, Simulator.h:91-106), dom | rate << 8 like the tracks.
+struct DevVariant {
+    uint32_t pos;
+    uint16_t err_fwd, err_rev;
+    uint64_t allele[2];    // bit a: the variant is in allele a
+    uint8_t base;
+    uint8_t pad[7];
 };
 
 struct DevAdapters {
@@ -149,6 +160,13 @@ struct DevSim {
     const uint64_t *seq_base_off;    // [n_seqs] offset of the sequence in the systematic-error tracks
     const uint16_t *sys_fwd;         // dom | rate<<8 per forward position
     const uint16_t *sys_rev;         // same for the reverse-complement strand, index = L-1-forward position
+    // ---- variants (-V): copy 1 + a of the packed reference and of gc_prefix (hap_stride entries apart) is allele a with its
+    // substitutions applied; copy 0 stays the reference itself (systematic-error chains, bias sums, wrapped surroundings)
+    uint32_t num_alleles;            // Reference::NumAlleles(), 1 without variants
+    uint32_t variants_loaded;        // Reference::VariantsLoaded()
+    uint64_t hap_stride;
+    const DevVariant *variants;      // sorted by position within each sequence
+    const uint32_t *var_ptr;         // [n_seqs + 1]
     // ---- coverage model
     uint32_t insert_from;            // max(1, InsertLengths().from())
     uint32_t insert_to;              // InsertLengths().to()

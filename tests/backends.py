@@ -31,7 +31,9 @@ def emu_lib():
         subprocess.run(["make", "-C", EMU_DIR, "-s"], check=True)
         L = C.CDLL(os.path.join(EMU_DIR, "libhostemu.so"))
         L.emu_last_error.restype = C.c_char_p
-        L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.emu_get_variant_sys.restype = C.c_uint32
+        L.emu_get_variant_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
@@ -70,10 +72,11 @@ class EmuBackend:
 
     fill_mode = -1          # class attribute: tests subclass to cap the LDS staging mode
 
-    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None):
+    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None, vcf_path=None):
         self.L = emu_lib()
         self.h = C.c_void_p()
-        _ok(self.L.emu_create(str(profile_path).encode(), (str(fasta_path) if fasta_path else "").encode(), replace_n_seed, C.byref(self.h)))
+        _ok(self.L.emu_create(str(profile_path).encode(), (str(fasta_path) if fasta_path else "").encode(), replace_n_seed,
+                              (str(vcf_path) if vcf_path else "").encode(), C.byref(self.h)))
         if edits:
             _ok(self.L.emu_edit_profile(self.h, edits.get("error_multiplier", 1.0), int(edits.get("no_substitutions", False)), int(edits.get("no_indels", False))))
         self.L.emu_set_fill_mode(self.h, self.fill_mode)
@@ -112,6 +115,12 @@ class EmuBackend:
         dom, rate = np.zeros(length, np.uint8), np.zeros(length, np.uint8)
         self.L.emu_get_adapter_sys(self.h, seg, adapter, dom.ctypes.data, rate.ctypes.data)
         return dom, rate
+
+    def variant_sys_errors(self, seq, n):
+        """(forward, reverse) dom | rate << 8 of the sequence's n variants"""
+        fwd, rev = np.zeros(max(n, 1), np.uint16), np.zeros(max(n, 1), np.uint16)
+        assert self.L.emu_get_variant_sys(self.h, seq, fwd.ctypes.data, rev.ctypes.data, n) == n
+        return fwd[:n], rev[:n]
 
     def codes(self, seq, length):
         out = np.zeros(length, np.uint8)
@@ -179,7 +188,7 @@ class EmuBackend:
 class GpuBackend:
     name = "gpu"
 
-    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None, device=0):
+    def __init__(self, profile_path, fasta_path=None, replace_n_seed=0, edits=None, device=0, vcf_path=None):
         self.prof = api.Profile(profile_path)
         if edits:
             if edits.get("error_multiplier", 1.0) != 1.0:
@@ -189,6 +198,8 @@ class GpuBackend:
             if edits.get("no_indels"):
                 self.prof.remove_indel_errors()
         self.ref = api.Reference(fasta_path, replace_n_seed) if fasta_path else None
+        if vcf_path:
+            self.ref.read_variants(vcf_path)
         self.sim = api.Simulator(self.prof, self.ref, device)
 
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):

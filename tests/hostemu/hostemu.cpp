@@ -26,6 +26,7 @@ struct HostUploader : Uploader {
         return p;
     }
     void write_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
+    void read_bytes(void *dst_host, const void *src, size_t bytes) override { memcpy(dst_host, src, bytes); }
     ~HostUploader() override {
         for (void *p : owned) free(p);
     }
@@ -177,7 +178,7 @@ extern "C" {
 
 const char *emu_last_error() { return g_err.c_str(); }
 
-int emu_create(const char *profile_path, const char *fasta_path, uint64_t replace_n_seed, void **out) {
+int emu_create(const char *profile_path, const char *fasta_path, uint64_t replace_n_seed, const char *vcf_path, void **out) {
     return guard([&] {
         std::unique_ptr<Emu> s(new Emu());
         s->prof = Profile::load(profile_path);
@@ -186,7 +187,12 @@ int emu_create(const char *profile_path, const char *fasta_path, uint64_t replac
         if (fasta_path && fasta_path[0]) {
             Reference r = Reference::read_fasta(fasta_path);
             r.replace_n(replace_n_seed);
-            pack_reference(*s, s->up, r);
+            if (vcf_path && vcf_path[0]) {                          // what rsq_ref_read_variants + rsq_sim_create do
+                std::vector<std::string> first;
+                for (size_t i = 0; i < r.names.size(); ++i) first.push_back(r.first_part(i));
+                const Variants v = read_variants(vcf_path, first, r.codes);
+                pack_reference(*s, s->up, r, &v);
+            } else pack_reference(*s, s->up, r);
         }
         *out = s.release();
     });
@@ -217,6 +223,7 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
             upload_normalization(s, s.up);
         }
         s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters);
+        build_variant_sys_errors(s, s.up);
         s.build_lds();
         s.prepared = true;
     });
@@ -279,12 +286,14 @@ int emu_read_sys_errors(void *h, const char *path) {
         Emu &s = *static_cast<Emu *>(h);
         if (!s.prepared || !s.has_ref) throw Error("prepare first");
         apply_sys_error_records(s, s.up, parse_sys_error_fastq(read_text_file(path)));
+        build_variant_sys_errors(s, s.up);
         return 0;
     });
 }
 int emu_read_methylation(void *h, const char *path) {
     return guard([&] {
         Emu &s = *static_cast<Emu *>(h);
+        if (s.has_variants) throw Error("--methylation together with variants is not supported yet");
         pack_methylation(s, s.up, read_methylation_file(path, s.ref_first_names, s.seq_len));
         return 0;
     });
@@ -365,6 +374,16 @@ void emu_get_sys(void *h, int reverse, uint32_t seq, uint8_t *dom, uint8_t *rate
         rate[i] = (uint8_t)(src[i] >> 8);
     }
 }
+// err_fwd / err_rev of the sequence's variants after the pre-pass (dom | rate << 8)
+uint32_t emu_get_variant_sys(void *h, uint32_t seq, uint16_t *fwd, uint16_t *rev, uint32_t cap) {
+    Emu &s = *static_cast<Emu *>(h);
+    const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
+    for (uint32_t i = 0; i < n && i < cap; ++i) {
+        fwd[i] = s.dev.variants[s.var_ptr[seq] + i].err_fwd;
+        rev[i] = s.dev.variants[s.var_ptr[seq] + i].err_rev;
+    }
+    return n;
+}
 void emu_get_adapter_sys(void *h, int seg, uint32_t id, uint8_t *dom, uint8_t *rate) {
     Emu &s = *static_cast<Emu *>(h);
     const HostAdapters &a = s.prof.adapters[seg];
@@ -392,6 +411,17 @@ int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, 
             for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
                 uint32_t cnt[2], strand_of[2];
                 const Words w = sieve_quad_words(S, site, len >> 2);
+                if (s.has_variants) {                               // k_sieve_finish<true> + k_sieve_emit
+                    VarCell cell;
+                    if (!sieve_cell_var(S, site, len, sieve_cell_uniform(w, len), cell)) continue;
+                    for (uint32_t e = 0; e < cell.n; ++e)
+                        for (uint32_t dup = 0; dup < cell.cnt[e]; ++dup) {
+                            if (n < cap) out[n] = make_fragment(site, len, dup, cell.id[e] & 1u, block_id, number + 1, cell.id[e] >> 1);
+                            ++number;
+                            ++n;
+                        }
+                    continue;
+                }
                 if (!sieve_cell(S, site, len, sieve_cell_uniform(w, len), cnt, strand_of)) continue;
                 for (uint32_t j = 0; j < 2; ++j)
                     for (uint32_t dup = 0; dup < cnt[j]; ++dup) {
@@ -420,14 +450,19 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 if (frags) {
                     const Fragment &f = frags[pair];
                     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
-                    FragmentSrc src = fragment_src(s.dev, f, seg);
-                    uint64_t tmpl[kTemplateWordsMax];
-                    if (s.dev.meth_ptr) {                       // what k_methylation_templates does for this read
-                        convert_template(s.dev, f, seg, tmpl, s.template_words);
-                        src.converted = tmpl;
+                    const Stream st{s.dev.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg, f.allele)};
+                    const uint32_t tile = draw_tile(s.dev, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2, f.allele));
+                    if (s.has_variants) {                       // k_fill_reads<MASK, true>
+                        run_read(s, seg, st, tile, f.len, variant_src(s.dev, f, seg), out, meta);
+                    } else {
+                        FragmentSrc src = fragment_src(s.dev, f, seg);
+                        uint64_t tmpl[kTemplateWordsMax];
+                        if (s.dev.meth_ptr) {                   // what k_methylation_templates does for this read
+                            convert_template(s.dev, f, seg, tmpl, s.template_words);
+                            src.converted = tmpl;
+                        }
+                        run_read(s, seg, st, tile, f.len, src, out, meta);
                     }
-                    run_read(s, seg, Stream{s.dev.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg)}, draw_tile(s.dev, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2)),
-                             f.len, src, out, meta);
                 } else {
                     const uint64_t i = adapter_first + pair;
                     run_read(s, seg, Stream{s.dev.seed, (uint32_t)i, 0xFFFFFFFFu, (uint32_t)(i >> 32), pair_c3(kDomPair, 0, seg)},

@@ -28,7 +28,7 @@ class Pair:
     """oracle + backend on the same inputs"""
 
     def __init__(self, backend_cls, workdir, tag, cfg, ref_lengths, seed, num_pairs=0, coverage=0.0, base_identifier="", edits=None, ref_bias_mode=0,
-                 ref_bias_file=None, **kw):
+                 ref_bias_file=None, vcf=None, **kw):
         self.ppath, self.fpath, self.seqs = make_inputs(workdir, tag, cfg, ref_lengths, **kw)
         self.oprof = O.Profile(self.ppath)
         if edits:
@@ -40,8 +40,15 @@ class Pair:
             if edits.get("no_indels"):
                 L.orc_profile_remove_indel_errors(self.oprof.h)
         self.oref = O.Reference(self.seqs)
-        self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode(), ref_bias_mode, ref_bias_file)
-        self.b = backend_cls(self.ppath, self.fpath, 0, edits)
+        self.ovars = None
+        if vcf:
+            import ctypes as C
+            err = C.create_string_buffer(2048)
+            self.ovars = O.lib().orc_read_variants(str(vcf).encode(), self.oref.h, err, len(err))
+            if not self.ovars:
+                raise RuntimeError(err.value.decode())
+        self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode(), ref_bias_mode, ref_bias_file, variants=self.ovars)
+        self.b = backend_cls(self.ppath, self.fpath, 0, edits, vcf_path=vcf) if vcf else backend_cls(self.ppath, self.fpath, 0, edits)
         if ref_bias_file:
             self.b.set_ref_bias_file(ref_bias_file)
         self.info = self.b.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
@@ -53,6 +60,8 @@ class Pair:
     def close(self):
         self.b.close()
         self.osim.close()
+        if self.ovars:
+            O.lib().orc_variants_free(self.ovars)
         self.oref.close()
         self.oprof.close()
 
@@ -345,3 +354,105 @@ def case_methylation(backend_cls, workdir):
                 q.osim.read_methylation(bed)
         finally:
             q.close()
+
+
+# ------------------------------------------------------------------------------------------------ variants
+def write_vcf(path, seqs, variants, samples=1):
+    """variants: [(sequence index, 0-based position, alt letters, genotype string like "0|1")]; REF is read from seqs"""
+    lines = ["##fileformat=VCFv4.2"] + [f"##contig=<ID={n.split(' ')[0]},length={len(c)}>" for n, c in seqs]
+    lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i + 1}" for i in range(samples)))
+    for si, pos, ref_len, alt, gt in variants:
+        name = seqs[si][0].split(" ")[0]
+        ref = "".join("ACGT"[b] for b in seqs[si][1][pos:pos + ref_len])
+        lines.append(f"{name}\t{pos + 1}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT\t{gt}")
+    path.write_text("\n".join(lines) + "\n")
+
+
+def _substitution_set(seqs, rng, density, special):
+    """random substitutions plus hand-placed ones: neighbours, block borders, sequence ends, two alts at one position"""
+    out = []
+    for si, (_, codes) in enumerate(seqs):
+        L = len(codes)
+        if L < 200:
+            continue
+        pos = set(int(x) for x in rng.choice(L, size=L // density, replace=False))
+        pos |= {x for x in special if x < L} | {L - 1 - x for x in (0, 1, 2, 9, 10, 19, 20, 29)}
+        for p0 in sorted(pos):
+            alt = "ACGT"[(int(codes[p0]) + 1 + int(rng.integers(0, 3))) % 4]
+            out.append((si, p0, 1, alt, ["0|1", "1|0", "1|1"][int(rng.integers(0, 3))]))
+    return out
+
+
+def _compare_blocks_var(p, lo, hi):
+    ofr = p.osim.sieve_var(lo, hi)
+    o1, o2 = p.osim.create_reads_var(ofr)
+    bfr, b1, b2 = p.b.pairs(lo, hi)
+    assert len(ofr) == len(bfr)
+    for name in ("seq", "start", "len", "dup", "strand", "block", "number"):
+        assert np.array_equal(ofr[name], bfr[name]), name
+    assert np.array_equal(ofr["allele"], bfr["pad"])       # the product keeps the allele in the byte that is padding without variants
+    assert o1 == b1
+    assert o2 == b2
+    return ofr, o1
+
+
+def case_variants_substitutions(backend_cls, workdir):
+    """-V with substitutions (Simulator.cpp:2249-2357 with VariantsLoaded): per-allele sieve (possible alleles, ChooseAlleles, GC and
+    surroundings of the allele, counts with NumAlleles), templates of the allele, the variants' own systematic errors
+    (SetSystematicErrorVariantsForward / Reverse) spliced by GetSysErrorFromBlock, `_allele<a>` read ids.  The oracle runs the
+    reference's general bookkeeping (oracle_variants.hpp); the product reads per-allele copies of the reference."""
+    lengths = [6200, 80, 3100]
+    rng = np.random.default_rng(17)
+    seqs = make_inputs(workdir, "vars", synth.TINY, lengths)[2]
+    special = [0, 1, 2, 5, 9, 10, 11, 19, 20, 21, 29, 30, 31, 995, 996, 997, 998, 999, 1000, 1001, 1002, 1003, 1999, 2000, 2001, 2002, 2004, 2999, 3000]
+    subs = _substitution_set(seqs, rng, 40, special)
+    # a second alternative at positions that already carry one, on the other allele ("1|2")
+    subs_two = []
+    for si, p0, rl, alt, gt in subs:
+        if p0 % 7 == 3:
+            other = next(c for c in "ACGT" if c != alt and c != "ACGT"[seqs[si][1][p0]])
+            subs_two.append((si, p0, rl, f"{alt},{other}", "1|2"))
+        else:
+            subs_two.append((si, p0, rl, alt, gt))
+    vcf = workdir / "subs.vcf"
+    write_vcf(vcf, seqs, subs_two)
+    p = Pair(backend_cls, workdir, "vars", synth.TINY, lengths, seed=23, num_pairs=9000, vcf=vcf)
+    try:
+        assert p.info["total_blocks"] == p.osim.total_blocks()
+        np.testing.assert_allclose(p.b.thresholds(), p.osim.thresholds(), rtol=NORM_RTOL, atol=0)      # thresholds for two alleles
+        if hasattr(p.b, "variant_sys_errors"):
+            for seq in (0, 2):
+                n = p.ovars.contents.n[seq]
+                fwd, rev = p.b.variant_sys_errors(seq, n)
+                for i in range(n):
+                    for strand, got in ((0, fwd), (1, rev)):
+                        d, r = p.osim.var_sys_errors(strand, seq, i)
+                        assert len(d) == 1 and int(d[0]) | (int(r[0]) << 8) == int(got[i]), (seq, i, strand)
+        p.align_normalization()
+        tb = p.info["total_blocks"]
+        ofr, text = _compare_blocks_var(p, 1, tb + 1)
+        assert len(ofr) > 7000 and set(np.unique(ofr["allele"])) == {0, 1}
+        assert b"_allele0:" in text and b"_allele1:" in text
+        part, _ = _compare_blocks_var(p, 2, 4)                 # batching by block range
+        assert len(part) and np.array_equal(part["start"], ofr["start"][(ofr["block"] >= 2) & (ofr["block"] < 4)])
+        # the variants change the output: the same run without them differs
+        plain = Pair(backend_cls, workdir, "vars", synth.TINY, lengths, seed=23, num_pairs=9000)
+        try:
+            plain.align_normalization()
+            assert len(plain.osim.sieve(1, tb + 1)) != len(ofr) or plain.osim.create_reads(plain.osim.sieve(1, tb + 1))[0] != text
+        finally:
+            plain.close()
+    finally:
+        p.close()
+
+
+def case_variants_rejected(backend_cls, workdir):
+    """what the kernels do not simulate yet is refused, not approximated: insertions / deletions, more than eight alleles"""
+    import pytest
+    lengths = [3000]
+    seqs = make_inputs(workdir, "vars_rej", synth.TINY, lengths)[2]
+    vcf = workdir / "indel.vcf"
+    write_vcf(vcf, seqs, [(0, 100, 1, "A", "0|1") if seqs[0][1][100] != 0 else (0, 100, 1, "C", "0|1"), (0, 500, 3, "ACGT"[seqs[0][1][500]], "1|0")])
+    ppath, fpath, _ = make_inputs(workdir, "vars_rej", synth.TINY, lengths)
+    with pytest.raises(Exception, match="insertions and deletions are not supported yet"):
+        backend_cls(ppath, fpath, 0, None, vcf_path=vcf)

@@ -146,3 +146,51 @@ def test_simulate_module_equals_cli(workdir):
     subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", b1, "-2", b2, "--batchBlocks", "3"], check=True, capture_output=True, env=env, cwd=root)
     assert open(a1, "rb").read() == open(b1, "rb").read() and open(a2, "rb").read() == open(b2, "rb").read()
     assert b":0:Adapter:0:" in open(a1, "rb").read()
+
+
+def test_variants_substitutions(workdir):
+    P.case_variants_substitutions(GpuBackend, workdir)
+
+
+def test_variants_not_simulated_yet_are_refused(workdir):
+    P.case_variants_rejected(GpuBackend, workdir)
+
+
+def test_variants_every_staging_mode(workdir, monkeypatch):
+    """the two instantiations of the read kernel with variants: every table from HBM (mode 0) and every table staged"""
+    for mode in ("0", "23"):
+        monkeypatch.setenv("RSQ_FILL_MODE", mode)
+        P.case_variants_substitutions(GpuBackend, workdir)
+
+
+def test_cli_with_variants_equals_the_oracle(workdir):
+    """reseq illuminaPE -V: the files of the command line are the oracle's text for the same seed (own pre-pass: thresholds from the
+    device's tree reduction are given to the oracle), and python -m reseq_amd.simulate -V writes the same files"""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    import oracle_lib as O
+    from reseq_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reseq_amd", "reseq")
+    lengths = [5000, 80, 3210]
+    ppath, fpath, seqs = P.make_inputs(workdir, "cli_var", synth.TINY, lengths)
+    vcf = workdir / "cli_var.vcf"
+    P.write_vcf(vcf, seqs, P._substitution_set(seqs, np.random.default_rng(3), 50, [0, 999, 1000, 1001]))
+    a1, a2, b1, b2 = (str(workdir / n) for n in ("v1.fq", "v2.fq", "w1.fq", "w2.fq"))
+    args = ["-R", fpath, "-s", ppath, "-V", str(vcf), "--numReads", "20000", "--seed", "13", "--refBias", "no"]
+    subprocess.run([exe, "illuminaPE"] + args + ["-1", a1, "-2", a2], check=True, capture_output=True)
+    env = dict(os.environ, PYTHONPATH=root)
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", b1, "-2", b2], check=True, capture_output=True, env=env)
+    assert open(a1, "rb").read() == open(b1, "rb").read() and open(a2, "rb").read() == open(b2, "rb").read()
+    p = P.Pair(GpuBackend, workdir, "cli_var", synth.TINY, lengths, seed=13, num_pairs=20000, ref_bias_mode=1, vcf=vcf)
+    try:
+        p.osim.set_normalization(p.info["bias_normalization"], p.b.thresholds())
+        ofr = p.osim.sieve_var(1, p.info["total_blocks"] + 1)
+        o1, o2 = p.osim.create_reads_var(ofr)
+        ao1, ao2 = p.osim.adapter_only()
+        assert open(a1, "rb").read() == o1 + ao1 and open(a2, "rb").read() == o2 + ao2
+    finally:
+        p.close()

@@ -126,3 +126,11 @@ def test_ref_bias_modes(workdir):
 
 def test_methylation(workdir):
     P.case_methylation(EmuBackend, workdir)
+
+
+def test_variants_substitutions(workdir):
+    P.case_variants_substitutions(EmuBackend, workdir)
+
+
+def test_variants_not_simulated_yet_are_refused(workdir):
+    P.case_variants_rejected(EmuBackend, workdir)
