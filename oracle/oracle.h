@@ -366,6 +366,9 @@ uint32_t orc_var_sys_errors(const orc_sim *s, int strand, uint32_t seq, uint32_t
 /* Simulator.cpp:2249-2357 with variants; UINT64_MAX on an error (orc_var_last_error) */
 uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment_var **out);
 int orc_create_reads_var(const orc_sim *s, const orc_fragment_var *frags, uint64_t n, orc_text *r1, orc_text *r2);
+/* every evaluated (start, pass, length, allele) of the sieve calls since the last query: how many were re-derived from a fresh
+ * VariantBiasVarModifiers, and how many of those differed from the incrementally updated one */
+void orc_var_scratch_counters(uint64_t *checks, uint64_t *mismatches);
 /* utilitiesTest.cpp:61-137 DominantBaseWithMemory script: op 0 Clear, 1 Set(seq, arg), 2 Update(seq[arg]), 3 copy from the other object */
 void orc_dombase_memory_script(const uint8_t *seq, uint32_t len, uint32_t n_ops, const uint8_t *which, const uint8_t *op, const uint32_t *arg, uint8_t *out);
 /* SimulatorTest::TestVariationInSimulateFromGivenBlock driver */

@@ -554,6 +554,15 @@ uint32_t orc_var_sys_errors(const orc_sim *s, int strand, uint32_t seq, uint32_t
 // do-while loop at one start position (starts inside inserted bases); the cell uniform as without variants; SelectAllele's j-th
 // random value: word j&3 of block (start, c1, length, 1<<28 | 2 + (j>>2)); the count uniform of the j-th chosen strand: u53 of words
 // 2(j&1), 2(j&1)+1 of block (start, c1, length, 1<<28 | 128 + (j>>1)).
+static uint64_t g_scratch_checks = 0, g_scratch_mismatches = 0;
+// property check behind the device's design: the bookkeeping the reference updates incrementally over fragment lengths is a pure
+// function of (start, pass, length, allele) -- a fresh VariantBiasVarModifiers taken straight to the length gives the same values
+void orc_var_scratch_counters(uint64_t *checks, uint64_t *mismatches) {
+    *checks = g_scratch_checks;
+    *mismatches = g_scratch_mismatches;
+    g_scratch_checks = g_scratch_mismatches = 0;
+}
+
 uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment_var **out) {
     std::vector<orc_fragment_var> frags;
     const int rc = guard([&] {
@@ -618,6 +627,21 @@ uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t bloc
                                 const uint32_t cur_end = start + len + (uint32_t)bm.end_pos_shift.at(allele);
                                 if (!(cur_end < L)) continue;
                                 const uint8_t gc_perc = (uint8_t)gc_percent_with_variants(bm, ref, cur_end, len, allele);
+                                {
+                                    VariantBiasMod fresh(bm.first_variant_id, A);
+                                    fresh.start_variant_pos = bm.start_variant_pos;
+                                    prepare_bias_mod_for_current_start_pos(fresh, ref, start, frag_len_start, sur_start);
+                                    prepare_bias_mod_for_current_fragment_length(fresh, ref, start, len, allele);
+                                    bool same = fresh.end_pos_shift[allele] == bm.end_pos_shift[allele] && fresh.gc_mod[allele] == bm.gc_mod[allele] &&
+                                                fresh.unhandled_variant_id[allele] == bm.unhandled_variant_id[allele] &&
+                                                fresh.unhandled_bases_in_variant[allele] == bm.unhandled_bases_in_variant[allele];
+                                    for (int k = 0; k < 3; ++k)
+                                        same = same && fresh.surrounding_start[allele].b[k] == bm.surrounding_start[allele].b[k] &&
+                                               fresh.surrounding_end[allele].b[k] == bm.surrounding_end[allele].b[k];
+                                    same = same && gc_percent_with_variants(fresh, ref, cur_end, len, allele) == gc_perc && fresh.end_variant(sv.variants, cur_end, allele) == bm.end_variant(sv.variants, cur_end, allele);
+                                    ++g_scratch_checks;
+                                    g_scratch_mismatches += same ? 0 : 1;
+                                }
                                 const orc_philox_out wc = orc_philox4x32_10(s->seed, start, c1, len, ((uint32_t)ORC_DOM_SIEVE << 28) | (128u + (j >> 1)));
                                 const double adjusted_random = thr[2 * len] + orc_u53(wc.w[2 * (j & 1u)], wc.w[2 * (j & 1u) + 1]) * (1 - thr[2 * len]);
                                 const uint16_t counts = orc_get_fragment_counts(p, s->bias_normalization, s->ref_seq_bias[seq], len, gc_perc, bm.surrounding_start.at(allele).b,

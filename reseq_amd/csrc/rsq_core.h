@@ -376,7 +376,9 @@ RSQ_HD void sur_delete_shift_left(uint32_t (&sur)[3], uint32_t pos, uint32_t new
     sur[del_block] += carry * kSurSize;
     sur[del_block] = (sur[del_block] >> (bit + 2u) << bit) + sur[del_block] % (1u << bit);
 }
-RSQ_HD void sur_insert_shift_right(uint32_t (&sur)[3], uint32_t pos, const uint8_t *new_bases, uint32_t n_new) {      // :62-125
+// new_bases: anything indexable that yields base codes (a pointer, or a view of a variant's bases)
+template <class Bases>
+RSQ_HD void sur_insert_shift_right(uint32_t (&sur)[3], uint32_t pos, const Bases &new_bases, uint32_t n_new) {      // :62-125
     uint32_t block = pos / kSurRange;
     uint32_t to_insert = n_new < kSurLength - pos ? n_new : kSurLength - pos;
     const uint32_t shift_blocks = to_insert / kSurRange, shift_bases = to_insert % kSurRange;
@@ -410,7 +412,8 @@ RSQ_HD void sur_insert_shift_right(uint32_t (&sur)[3], uint32_t pos, const uint8
         }
     }
 }
-RSQ_HD void sur_insert_shift_left(uint32_t (&sur)[3], uint32_t pos, const uint8_t *new_bases, uint32_t n_new) {       // :127-192
+template <class Bases>
+RSQ_HD void sur_insert_shift_left(uint32_t (&sur)[3], uint32_t pos, const Bases &new_bases, uint32_t n_new) {       // :127-192
     uint32_t block = pos / kSurRange;
     uint32_t to_insert = n_new < pos + 1u ? n_new : pos + 1u;
     const uint32_t shift_blocks = to_insert / kSurRange, shift_bases = to_insert % kSurRange;

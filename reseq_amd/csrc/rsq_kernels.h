@@ -7,6 +7,7 @@
 // All arithmetic lives in rsq_core.h; this file only maps work to lanes and moves bytes.
 #pragma once
 #include "rsq_core.h"
+#include "rsq_variants.h"
 
 namespace rsq {
 
@@ -206,10 +207,13 @@ struct SieveSite {
     const double *thr;                 // thresholds of the sequence's coverage group: [insert_to][2]
     uint32_t sur_start[3];
     bool have_start;
+    uint32_t sub;                      // variants of any kind: pass at this start position and what the pass starts from
+    VarStart st;
 };
 
 // Philox block shared by the four cells (start, 4q .. 4q+3): one 32-bit uniform each
-RSQ_HD Words sieve_quad_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site.seq, q, kDomSieve << 28); }
+RSQ_HD uint32_t site_c1(const SieveSite &site) { return site.seq | (site.sub << 22); }
+RSQ_HD Words sieve_quad_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site_c1(site), q, kDomSieve << 28); }
 RSQ_HD double sieve_cell_uniform(const Words &w, uint32_t len) {
     const uint32_t k = len & 3u;
     return u32_to_unit(k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)));
@@ -254,8 +258,8 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, doubl
 // the per-allele GC modification and the surrounding edits of Simulator.cpp:1404-1896 are plain reads of that copy -- what the
 // reference's own test demands of them (SimulatorTest.cpp:116-195 compares with the sequence that has the variants applied).
 constexpr uint32_t kMaxDevAlleles = 8;             // 2 * alleles chosen (allele, strand) slots per cell live in registers
-RSQ_HD const uint64_t *hap_words(const DevSim &S, uint32_t allele) { return S.variants_loaded ? S.ref_words + (1u + allele) * S.hap_stride : S.ref_words; }
-RSQ_HD const uint32_t *hap_gc_prefix(const DevSim &S, uint32_t allele) { return S.variants_loaded ? S.gc_prefix + (1u + allele) * S.hap_stride : S.gc_prefix; }
+RSQ_HD const uint64_t *hap_words(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.ref_words + (1u + allele) * S.hap_stride : S.ref_words; }
+RSQ_HD const uint32_t *hap_gc_prefix(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.gc_prefix + (1u + allele) * S.hap_stride : S.gc_prefix; }
 struct VarCell {
     uint32_t n;                                    // chosen (allele, strand) slots with pairs, in draw order
     uint16_t cnt[2 * kMaxDevAlleles];
@@ -321,6 +325,57 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     return n_here;
 }
 
+// the cell with variants of any kind: possible alleles, ChooseAlleles, and per chosen (allele, strand) the modifiers from scratch
+RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCell &cell) {
+    cell.n = 0;
+    const double thr0 = site.thr[2u * len], thr1 = site.thr[2u * len + 1u];
+    if (!(probability_chosen >= thr1)) return 0;
+    const VarView r = var_view(S, site.seq);
+    uint8_t possible[kMaxDevAlleles];
+    uint32_t n_possible = 0;
+    for (uint32_t allele = 0; allele < S.num_alleles; ++allele)                     // GetPossibleAlleles :1330-1340
+        if (!allele_skipped(r, site.st, allele, site.start)) possible[n_possible++] = (uint8_t)allele;
+    const uint32_t possible_strands = 2u * n_possible;
+    const uint32_t non_zero_strands = binomial(possible_strands, 1 - thr0, probability_chosen);
+    if (!non_zero_strands) return 0;
+    const uint32_t c1 = site_c1(site);
+    uint8_t chosen[2 * kMaxDevAlleles];
+    uint32_t n_chosen = 0, selectable = (1u << possible_strands) - 1u, n_draws = 0;
+    const bool direct = non_zero_strands <= possible_strands / 2u;
+    const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
+    Words ws{0, 0, 0, 0};
+    while (n_chosen < to_draw) {
+        if (0u == (n_draws & 3u)) ws = philox(S.seed, site.start, c1, len, (kDomSieve << 28) | (2u + (n_draws >> 2)));
+        select_allele(chosen, n_chosen, selectable, possible_strands, u32_to_unit(word_of(ws, n_draws & 3u)));
+        ++n_draws;
+    }
+    if (!direct) {
+        n_chosen = 0;
+        for (uint32_t id = 0; id < possible_strands; ++id)
+            if ((selectable >> id) & 1u) chosen[n_chosen++] = (uint8_t)id;
+    }
+    uint32_t n_here = 0;
+    Words wc{0, 0, 0, 0};
+    for (uint32_t j = 0; j < n_chosen; ++j) {
+        const uint32_t allele = possible[chosen[j] >> 1], strand = chosen[j] & 1u;
+        if (0u == (j & 1u)) wc = philox(S.seed, site.start, c1, len, (kDomSieve << 28) | (128u + (j >> 1)));
+        AlleleMod m;
+        VarCellSite vs;
+        evaluate_allele(r, site.st, allele, site.start, S.insert_from, len, m, vs);
+        if (!(vs.cur_end_position < site.L)) continue;                              // :2318
+        const double u = (j & 1u) ? u53_to_unit(wc.w2, wc.w3) : u53_to_unit(wc.w0, wc.w1);
+        const double adjusted_random = thr0 + u * (1 - thr0);
+        const uint32_t c = fragment_counts(S, site.seq, len, vs.gc_percent, m.surrounding_start, m.surrounding_end, adjusted_random);
+        if (c) {
+            cell.id[cell.n] = (uint8_t)(allele * 2u + strand);
+            cell.cnt[cell.n] = (uint16_t)c;
+            ++cell.n;
+            n_here += c;
+        }
+    }
+    return n_here;
+}
+
 // a cell with fragments, recorded by the sieve pass and expanded into Fragment records after the scan (with variants: one record per
 // two chosen (allele, strand) slots of the cell)
 struct SieveHit {
@@ -350,6 +405,51 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
     site.word_off = S.seq_word_off[site.seq];
     site.thr = S.thresholds + (size_t)S.coverage_group[site.seq] * S.insert_to * 2u;
     site.have_start = false;
+    site.sub = 0;
+    site.st = VarStart{0, 0};
+}
+
+// Slots of a batch.  VM 0 / 1 (no variants / substitutions): slot = block * 1000 + offset.  VM 2 (variants of any kind): a block has
+// its 1000 start positions plus the extra passes inside inserted bases (DevSim::extra), merged in loop order -- the extra pass j of a
+// block (0-based, extras sorted) sits at local index (pos - block start) + j + 1.  Returns the block id; first_slot_of_block = the
+// batch slot of the block's first position.
+template <int VM>
+RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t block_hi, uint32_t slot, SieveSite &site, uint32_t *first_slot_of_block = nullptr) {
+    if constexpr (VM != 2) {
+        const uint32_t block_id = block_lo + slot / kBlockSize;
+        init_site(S, block_id, slot % kBlockSize, site);
+        if (first_slot_of_block) *first_slot_of_block = slot - slot % kBlockSize;
+        return block_id;
+    } else {
+        const uint32_t base_lo = S.block_extra_ptr[block_lo];
+        uint32_t lo = block_lo, hi = block_hi;                      // the last block b with (b - block_lo) * 1000 + extras before b <= slot
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((mid - block_lo) * kBlockSize + (S.block_extra_ptr[mid] - base_lo) <= slot) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t block_id = lo, first = (block_id - block_lo) * kBlockSize + (S.block_extra_ptr[block_id] - base_lo), local = slot - first;
+        if (first_slot_of_block) *first_slot_of_block = first;
+        const ExtraStart *e = S.extra + S.block_extra_ptr[block_id];
+        const uint32_t m = S.block_extra_ptr[block_id + 1] - S.block_extra_ptr[block_id];
+        const uint32_t seq = S.block_seq[block_id], bs = (block_id - S.first_block[seq]) * kBlockSize;
+        uint32_t a = 0, b = m;                                       // c = extras whose local index is below `local`
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if ((e[mid].pos - bs) + mid + 1u < local) a = mid + 1u;
+            else b = mid;
+        }
+        const uint32_t c = a;
+        if (c < m && (e[c].pos - bs) + c + 1u == local) {
+            init_site(S, block_id, e[c].pos - bs, site);
+            site.sub = e[c].sub;
+            site.st = VarStart{e[c].first_variant_id, e[c].start_variant_pos};
+        } else {
+            init_site(S, block_id, local - c, site);
+            if (site.start < site.L) site.st = VarStart{(int32_t)var_view(S, seq).lower_bound(site.start), 0u};      // bias_mod.first_variant_id_ at a plain position
+        }
+        return block_id;
+    }
 }
 
 #if defined(__HIPCC__)
@@ -377,12 +477,23 @@ RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 3
 RSQ_HD uint32_t thr_lds_index(uint32_t len) { return len + 2u * (len >> 5); }
 RSQ_HD uint32_t thr_lds_doubles(uint32_t insert_to) { return thr_lds_index(insert_to) + 4u; }
 
-__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
+template <int VM>
+__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
     extern __shared__ __attribute__((aligned(16))) double s_thr1[];
     const uint64_t t0 = (uint64_t)blockIdx.x * kScreenBlock, t = t0 + threadIdx.x, n_tasks = (uint64_t)n_slots * words_per_slot;
     // the block's positions lie in one sequence almost always: then its thresholds come from LDS
     const uint32_t slot_first = (uint32_t)(t0 / words_per_slot), slot_last = (uint32_t)((t0 + kScreenBlock - 1 < n_tasks ? t0 + kScreenBlock - 1 : n_tasks - 1) / words_per_slot);
-    const uint32_t seq_first = S.block_seq[block_lo + slot_first / kBlockSize], seq_last = S.block_seq[block_lo + slot_last / kBlockSize];
+    uint32_t seq_first, seq_last;
+    if constexpr (VM == 2) {                                       // slots are not 1000 per block here
+        SieveSite a, b;
+        init_site_slot<VM>(S, block_lo, block_hi, slot_first, a);
+        init_site_slot<VM>(S, block_lo, block_hi, slot_last, b);
+        seq_first = a.seq;
+        seq_last = b.seq;
+    } else {
+        seq_first = S.block_seq[block_lo + slot_first / kBlockSize];
+        seq_last = S.block_seq[block_lo + slot_last / kBlockSize];
+    }
     const bool staged = seq_first == seq_last;                     // block-uniform
     if (staged) {
         const double *thr = S.thresholds + (size_t)S.coverage_group[seq_first] * S.insert_to * 2u;
@@ -392,7 +503,7 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     if (t >= n_tasks) return;
     const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
     SieveSite site;
-    init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
+    init_site_slot<VM>(S, block_lo, block_hi, slot, site);
     uint32_t bits = 0;
     if (site.start < site.L) {
 #pragma unroll 2
@@ -414,8 +525,8 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     bitmap[t] = bits;
 }
 
-template <bool VAR>
-__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
+template <int VM>
+__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
                                                                   const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
     __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
     extern __shared__ uint32_t s_total[];                          // [kSieveWaves][slots_per_wave] pairs found so far per position
@@ -439,9 +550,10 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
                 len = e & 0xFFFFu;
                 SieveSite site;
                 const uint32_t slot = slot0 + key;
-                init_site(S, block_lo + slot / kBlockSize, slot % kBlockSize, site);
+                init_site_slot<VM>(S, block_lo, block_hi, slot, site);
                 const double u = sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len);
-                if constexpr (VAR) n_here = sieve_cell_var(S, site, len, u, cell);
+                if constexpr (VM == 2) n_here = sieve_cell_general(S, site, len, u, cell);
+                else if constexpr (VM == 1) n_here = sieve_cell_var(S, site, len, u, cell);
                 else n_here = sieve_cell(S, site, len, u, cnt, strand_of);
             }
             // exclusive prefix of n_here among the earlier queued cells of the same position (keys are non-decreasing)
@@ -458,7 +570,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
             const uint32_t next_key = __shfl_down(key, 1, 64);
             const uint32_t old_total = active ? totals[key] : 0u;
             if (n_here) {
-                if constexpr (VAR) {
+                if constexpr (VM != 0) {
                     uint32_t intra = old_total + before_in_batch;
                     for (uint32_t e = 0; e < cell.n; e += 2u) {
                         const bool two = e + 1u < cell.n;
@@ -538,18 +650,39 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
 }
 
 // one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at offsets[slot] + intra
-__global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, const SieveHit *hits, uint32_t n_hits, const uint64_t *offsets, Fragment *frags) {
+template <int VM>
+__global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, uint32_t block_hi, const SieveHit *hits, uint32_t n_hits, const uint64_t *offsets, Fragment *frags,
+                                                   FragmentVar *fvars) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const SieveHit h = hits[i];
-    const uint32_t block_id = block_lo + h.slot / kBlockSize;
     SieveSite site;
-    init_site(S, block_id, h.slot % kBlockSize, site);
+    uint32_t first_slot;
+    const uint32_t block_id = init_site_slot<VM>(S, block_lo, block_hi, h.slot, site, &first_slot);
     const uint64_t base = offsets[h.slot];
-    const uint32_t number_base = (uint32_t)(base - offsets[h.slot - h.slot % kBlockSize]);
+    const uint32_t number_base = (uint32_t)(base - offsets[first_slot]);
     uint32_t k = h.intra;
-    for (uint32_t dup = 0; dup < h.cnt0; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand0, block_id, number_base + k + 1u, h.allele0);
-    for (uint32_t dup = 0; dup < h.cnt1; ++dup, ++k) frags[base + k] = make_fragment(site, h.len, dup, h.strand1, block_id, number_base + k + 1u, h.allele1);
+    for (uint32_t e = 0; e < 2u; ++e) {
+        const uint32_t cnt = e ? h.cnt1 : h.cnt0, strand = e ? h.strand1 : h.strand0, allele = e ? h.allele1 : h.allele0;
+        if (!cnt) continue;
+        FragmentVar fv{};
+        if constexpr (VM == 2) {                                    // what SimulateFromGivenBlock hands to CreateReads (:2334-2337), derived again
+            const VarView r = var_view(S, site.seq);
+            AlleleMod m;
+            VarCellSite vs;
+            evaluate_allele(r, site.st, allele, site.start, S.insert_from, h.len, m, vs);
+            fv.end = vs.cur_end_position;
+            fv.sub = site.sub;
+            fv.start_var = site.st.first_variant_id;
+            fv.start_var_pos = site.st.start_variant_pos;
+            fv.end_var = vs.end_var.first_variant_id;
+            fv.end_var_pos = vs.end_var.start_variant_pos;
+        }
+        for (uint32_t dup = 0; dup < cnt; ++dup, ++k) {
+            frags[base + k] = make_fragment(site, h.len, dup, strand, block_id, number_base + k + 1u, allele);
+            if constexpr (VM == 2) fvars[base + k] = fv;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -765,11 +898,12 @@ RSQ_HD uint32_t digits_u64(uint64_t v) {
 
 // One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632: the id line ...
 template <class Sink>
-RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t) {
+RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t,
+                          const FragmentVar *fv = nullptr) {
     t.ch('@');
     t.str(names.base_identifier, names.base_len);
     if (f) {
-        const uint32_t end = f->start + f->len;
+        const uint32_t end = fv ? fv->end : f->start + f->len;                  // end_position_forward of CreateReads
         t.num(f->block);
         t.ch('_');
         t.num(f->number);
@@ -840,9 +974,9 @@ RSQ_HD void format_line(const WordColumn &row, uint32_t read_len, bool is_qual, 
 }
 template <class P>
 RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &seq,
-                              const WordColumn &qual, const WordColumn &ops, P dst) {
+                              const WordColumn &qual, const WordColumn &ops, P dst, const FragmentVar *fv = nullptr) {
     WordSinkT<P> t(dst);
-    format_header(S, names, f, adapter_only_number, m, ops, t);
+    format_header(S, names, f, adapter_only_number, m, ops, t, fv);
     format_line(seq, m.read_len, false, t);
     format_line(qual, m.read_len, true, t);
     t.finish();
@@ -850,10 +984,10 @@ RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fra
 }
 
 // length of that record without producing it (the read kernel writes it next to the read)
-RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m) {
+RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const FragmentVar *fv = nullptr) {
     uint32_t n = 1u + names.base_len;
     if (f) {
-        const uint32_t end = f->start + f->len;
+        const uint32_t end = fv ? fv->end : f->start + f->len;
         if (1u < S.num_alleles) n += 7u + digits_u64(f->allele);
         n += digits_u64(f->block) + 1u + digits_u64(f->number) + 1u + digits_u64(f->strand ? end : f->start + 1u) + 1u +
              (names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]) + 1u + digits_u64(f->strand ? f->start + 1u : end);
@@ -1166,8 +1300,8 @@ RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS double *img, uint32_t mask, 
 }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
-RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg) {
-    const uint32_t L = S.seq_len[f.seq], end = f.start + f.len;
+RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg, uint32_t end) {
+    const uint32_t L = S.seq_len[f.seq];
     const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion;           // Simulator.cpp:1918-1921
     FragmentSrc src;
     src.words = hap_words(S, f.allele);                                        // with variants: the allele's copy (substitutions applied)
@@ -1180,21 +1314,26 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
     src.gc_prefix = hap_gc_prefix(S, f.allele);
     return src;
 }
+RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg) { return fragment_src(S, f, seg, f.start + f.len); }
 
-// The template of a mate with variants (substitutions): FragmentSrc on the allele's copy of the reference, and the systematic
-// errors through the walk of GetSysErrorFromBlock / IncrementBlockPos (Simulator.cpp:232-292) and of FillReadPart's deletion
-// branch (:380-392), stated in strand coordinates (position on the strand the mate reads; variants in that strand's order):
-// the reverse blocks' lists are the mirror image of the forward ones.  cur walks the variants of ALL alleles; a block's
-// err_variants_ list ends where the block ends, and cur_var = 0 after a block change is the first variant of the new block.
-// As written in the reference: after a substitution is used cur is incremented twice (the next variant is skipped unless a block
-// starts in between), and the deletion branch does not look at variants at all (a passed variant is applied late).
+// The template of a mate with variants: FragmentSrc (on the allele's copy of the reference when all variants are substitutions,
+// else with the template written beforehand by k_variant_templates), and the systematic errors through the walk of
+// GetSysErrorFromBlock / IncrementBlockPos (Simulator.cpp:232-292) and of FillReadPart's deletion branch (:380-392), stated in strand
+// coordinates (position on the strand the mate reads; variants in that strand's order): the reverse blocks' lists are the mirror
+// image of the forward ones.  cur walks the variants of ALL alleles; a block's err_variants_ list ends where the block ends, and
+// cur_var = 0 after a block change is the first variant of the new block.  As written in the reference: after a substitution is
+// used cur is incremented twice (the next variant is skipped unless a block starts in between); inside an insertion the error of the
+// reference position is returned, not the inserted base's; the deletion branch does not look at variants (a passed variant is
+// applied late).
 struct VariantSrc : FragmentSrc {
     const DevVariant *var;              // the sequence's variants in forward order
+    const uint16_t *err_fwd, *err_rev;
     uint32_t n_var, L, allele;
-    uint32_t spos0, cur0;               // start of the walk: strand position of the first template base, first variant at or after it
-    mutable uint32_t spos, cur;
+    uint32_t spos0, cur0, var_pos0;     // start of the walk: strand position of the first template base, variant index, position in an insertion
+    mutable uint32_t spos, cur, var_pos;
     RSQ_HD const DevVariant &var_at(uint32_t i) const { return reverse ? var[n_var - 1u - i] : var[i]; }
     RSQ_HD uint32_t var_spos(uint32_t i) const { return reverse ? L - 1u - var_at(i).pos : var_at(i).pos; }
+    RSQ_HD uint32_t var_err(uint32_t i, uint32_t k) const { return (reverse ? err_rev : err_fwd)[var_at(i).off + k]; }
     RSQ_HD uint32_t lower_bound(uint32_t sp) const {
         uint32_t lo = 0, hi = n_var;
         while (lo < hi) {
@@ -1206,28 +1345,45 @@ struct VariantSrc : FragmentSrc {
     }
     // blocks are cut on the forward strand (Simulator.h:254): first strand position of the block after the one holding sp
     RSQ_HD uint32_t block_end(uint32_t sp) const { return reverse ? L - ((L - sp - 1u) / kBlockSize) * kBlockSize : (sp / kBlockSize + 1u) * kBlockSize; }
-    RSQ_HD void start_walk() {
-        spos = spos0 = reverse ? L - first : first;
-        cur = cur0 = lower_bound(spos0);
+    RSQ_HD void rewind() const {
+        spos = spos0;
+        cur = cur0;
+        var_pos = var_pos0;
     }
     RSQ_HD void increment_block_pos() const {                                   // :232-238
         const uint32_t bend = block_end(spos);
         if (++spos == bend) cur = lower_bound(spos);
     }
-    RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292 with substitutions only (var_pos stays 0)
-        const uint32_t bend = block_end(spos);
+    RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
+        if (var_pos) {
+            const uint32_t se = sys_[spos - spos0];
+            if (++var_pos >= var_at(cur).len) {
+                var_pos = 0;
+                ++cur;
+                increment_block_pos();
+            }
+            return se;
+        }
+        uint32_t bend = block_end(spos);
         while (cur < n_var) {
             const uint32_t vs = var_spos(cur);
             if (!(vs < bend && vs <= spos)) break;                              // cur_var < err_variants_.size() && position_ <= block_pos
             const DevVariant &v = var_at(cur);
             if ((v.allele[allele >> 6] >> (allele & 63u)) & 1u) {
-                const uint32_t se = reverse ? v.err_rev : v.err_fwd;
-                ++cur;
-                increment_block_pos();
-                ++cur;
-                return se;
-            }
-            ++cur;
+                if (0u == v.len) {                                              // deletion
+                    ++cur;
+                    increment_block_pos();
+                    bend = block_end(spos);
+                } else {
+                    const uint32_t se = var_err(cur, 0);
+                    if (1u == v.len) {                                          // substitution
+                        ++cur;
+                        increment_block_pos();
+                        ++cur;
+                    } else var_pos = 1;                                         // insertion
+                    return se;
+                }
+            } else ++cur;
         }
         const uint32_t se = sys_[spos - spos0];
         increment_block_pos();
@@ -1235,7 +1391,11 @@ struct VariantSrc : FragmentSrc {
     }
     RSQ_HD uint32_t sys_deleted(uint32_t) const {                               // :380-392
         const uint32_t se = sys_[spos - spos0];
-        increment_block_pos();
+        if (var_pos && ++var_pos >= var_at(cur).len) var_pos = 0;
+        if (0u == var_pos) {
+            const uint32_t bend = block_end(spos);
+            if (++spos == bend) cur = lower_bound(spos);
+        }
         return se;
     }
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {    // :480-504: the error rates through a copy of the walk
@@ -1243,18 +1403,31 @@ struct VariantSrc : FragmentSrc {
             for (uint32_t k = 0; k < n; ++k) gc += is_gc(base(k));
         } else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
         for (uint32_t k = 0; k < n; ++k) rate_sum += sys_base(k) >> 8;
-        spos = spos0;
-        cur = cur0;
+        rewind();
     }
 };
-RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, uint32_t seg) {
+// fv == nullptr: substitutions only (the walk starts at the first variant at or after the first template base)
+RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, const FragmentVar *fv, uint32_t seg) {
     VariantSrc src;
-    static_cast<FragmentSrc &>(src) = fragment_src(S, f, seg);
+    static_cast<FragmentSrc &>(src) = fragment_src(S, f, seg, fv ? fv->end : f.start + f.len);
     src.var = S.variants + S.var_ptr[f.seq];
+    src.err_fwd = S.var_err_fwd;
+    src.err_rev = S.var_err_rev;
     src.n_var = S.var_ptr[f.seq + 1] - S.var_ptr[f.seq];
     src.L = S.seq_len[f.seq];
     src.allele = f.allele;
-    src.start_walk();
+    src.spos0 = src.reverse ? src.L - src.first : src.first;
+    if (!fv) {
+        src.cur0 = src.lower_bound(src.spos0);
+        src.var_pos0 = 0;
+    } else if (!src.reverse) {                                                  // CreateReads :686-688: variant.at(strand) = start variant
+        src.cur0 = (uint32_t)fv->start_var;
+        src.var_pos0 = fv->start_var_pos;
+    } else {                                                                    // the end variant, seen from the reverse block's list
+        src.cur0 = src.n_var - 1u - (uint32_t)fv->end_var;                      // end_var -1: one past the last
+        src.var_pos0 = fv->end_var_pos ? src.var[fv->end_var].len - fv->end_var_pos : 0u;
+    }
+    src.rewind();
     return src;
 }
 // The converted template of mate `seg` of fragment f (CTConversion's dispatcher, Simulator.cpp:2219-2247): the forward mate is
@@ -1268,12 +1441,20 @@ RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, u
     ct_conversion(tmpl, src.len, m, src.first, meth_start_index(m, f.start), src.reverse, d);
 }
 
+// the template of mate `seg` with variants of any kind: the forward mate from the start variant, the reverse mate from the end variant
+RSQ_HD void variant_template(const DevSim &S, const Fragment &f, const FragmentVar &fv, uint32_t seg, uint64_t *tmpl, uint32_t template_words) {
+    const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion, tl = f.len < want ? f.len : want;
+    const VarView r = var_view(S, f.seq);
+    if (seg == f.strand) reference_sequence_with_variants(r, f.start, tl, false, VarStart{fv.start_var, fv.start_var_pos}, f.allele, tmpl, template_words);
+    else reference_sequence_with_variants(r, fv.end, tl, true, VarStart{fv.end_var, fv.end_var_pos}, f.allele, tmpl, template_words);
+}
+
 template <class Tab>
 RSQ_HD void fill_fragment_read(const DevSim &S, const Tab &tab, const Fragment &f, uint32_t seg, ReadOut &out, ReadMeta &meta) {
     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
     const uint32_t tile = draw_tile(S, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2, f.allele));
     const Stream st{S.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg, f.allele)};
-    if (S.variants_loaded) fill_read(S, tab, st, seg, tile, f.len, variant_src(S, f, seg), out, meta);
+    if (S.variants_loaded) fill_read(S, tab, st, seg, tile, f.len, variant_src(S, f, nullptr, seg), out, meta);
     else fill_read(S, tab, st, seg, tile, f.len, fragment_src(S, f, seg), out, meta);
 }
 // one mate of adapter-only pair i (Simulator.cpp:2359-2382)
@@ -1343,7 +1524,7 @@ __device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint
 
 template <uint32_t MASK, bool VAR = false>
 __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
-                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters) {
+                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
     const RSQ_LDS double *img = fill_stage_image<MASK>(S, lds_image, seg);
@@ -1363,13 +1544,15 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
         const bool from_fragment = frags != nullptr;
         const uint64_t ao = adapter_only_first + pair;
-        const uint32_t c0 = from_fragment ? f.start : (uint32_t)ao, c1 = from_fragment ? f.seq : 0xFFFFFFFFu,
+        FragmentVar fv{};
+        if (VAR && active && fvars) fv = fvars[pair];
+        const uint32_t c0 = from_fragment ? f.start : (uint32_t)ao, c1 = from_fragment ? (f.seq | (fv.sub << 22)) : 0xFFFFFFFFu,
                        c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
         const uint32_t strand = from_fragment ? f.strand : 0u;
         const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg, f.allele)};
         ReadMeta meta;
         if constexpr (VAR) {                                            // launched for fragments only
-            VariantSrc src = variant_src(S, f, seg);
+            VariantSrc src = variant_src(S, f, fvars ? &fv : nullptr, seg);
             if (raw.templates) src.converted = raw.templates + r * raw.template_words;
             fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2, f.allele), f.len, src, out, meta);
         } else {
@@ -1379,7 +1562,7 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         }
         if (active) {
             raw.meta[r] = meta;
-            sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta);       // bytes of its FASTQ record
+            sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
         }
     }
 }
@@ -1445,6 +1628,15 @@ __global__ void __launch_bounds__(256) k_methylation_templates(DevSim S, const F
     convert_template(S, frags[r - seg * n_pairs], seg, raw.templates + r * raw.template_words, raw.template_words);
 }
 
+// variants of any kind: Reference::ReferenceSequence with variants (GetOrgSeq, Simulator.cpp:1909-1914) for both mates of every pair
+__global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragment *frags, const FragmentVar *fvars, uint64_t n_pairs, RawLayout raw) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2u * n_pairs) return;
+    const uint32_t seg = r >= n_pairs ? 1u : 0u;
+    const uint64_t pair = r - seg * n_pairs;
+    variant_template(S, frags[pair], fvars[pair], seg, raw.templates + r * raw.template_words, raw.template_words);
+}
+
 #endif  // __HIPCC__
 
 #if defined(__HIPCC__)
@@ -1456,7 +1648,8 @@ __global__ void __launch_bounds__(256) k_methylation_templates(DevSim S, const F
 // short per-lane work and 8 KiB of LDS per wave (twenty waves per CU) matter more than instruction count.
 constexpr uint32_t kFormatRecords = 16u, kFormatLdsBytes = 8u * 1024u;
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
-                                                    const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1) {
+                                                    const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1,
+                                                    const FragmentVar *fvars = nullptr) {
     __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
     const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords;
     const bool is_qual = part >= 2u, second_half = (part & 1u) != 0u;
@@ -1474,17 +1667,20 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
     const bool through_lds = skew + bytes <= kFormatLdsBytes;                      // wave-uniform
     ReadMeta m;
     Fragment f;
+    FragmentVar fv;
     uint64_t r = 0;
     if (active) {
         r = (uint64_t)seg * n_pairs + pair;
         m = raw.meta[r];
         if (frags) f = frags[pair];
+        if (frags && fvars) fv = fvars[pair];
     }
     const WordColumn seq = raw.seq_of(r), qual = raw.qual_of(r), ops = raw.ops_of(r);
     const Fragment *fp = frags ? &f : nullptr;
+    const FragmentVar *fvp = frags && fvars ? &fv : nullptr;
     const uint64_t ao_number = adapter_only_first + pair + 1u;
     if (!through_lds) {                                                            // oversized ids: write straight to HBM
-        if (active && part == 0u) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair]);
+        if (active && part == 0u) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair], fvp);
         return;
     }
     if (active) {
@@ -1494,7 +1690,7 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         const uint32_t first_word = second_half ? half : 0u, line_at = header + (is_qual ? m.read_len + 3u : 0u);
         const uint32_t part_at = part == 0u ? 0u : line_at + (4u * first_word < m.read_len ? 4u * first_word : m.read_len);
         WordSinkT<RSQ_LDS char *> t(rec_text + part_at);
-        if (part == 0u) format_header(S, names, fp, ao_number, m, ops, t);
+        if (part == 0u) format_header(S, names, fp, ao_number, m, ops, t, fvp);
         format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, second_half ? all_words - half : half, second_half, t);
         t.finish();
     }

@@ -40,9 +40,14 @@ struct SimState {
     // variants (-V): host copies of what the device holds, and of the two table families their systematic errors are drawn from
     bool has_variants = false;
     uint32_t num_alleles = 1;
+    int variants_mode = 0;                           // DevSim::variants_loaded
     std::vector<DevVariant> variants;
     std::vector<uint32_t> var_ptr;
-    DevVariant *dev_variants = nullptr;
+    std::vector<uint8_t> var_bases;
+    std::vector<uint16_t> var_err_fwd, var_err_rev;  // filled by build_variant_sys_errors
+    uint16_t *dev_var_err_fwd = nullptr, *dev_var_err_rev = nullptr;
+    std::vector<ExtraStart> extra;                   // starts inside inserted bases, per sequence in loop order
+    std::vector<uint32_t> extra_seq_ptr;             // [n_seqs + 1]
     std::vector<double> host_pool;
     std::vector<uint8_t> host_par0;
     std::vector<DevTable> host_dom_error, host_error_rate;
@@ -281,15 +286,44 @@ inline void pack_profile(SimState &s, Uploader &up) {
     s.ops_stride = (max_iter + 15u) / 16u;
 }
 
-// Which variant sets the kernels can simulate today: substitutions only, and no two of them at one position of one allele
-inline void check_variants_supported(const Variants &v) {
+// How the kernels simulate a variant set: 1 = substitutions only, at most one per position and allele: every allele gets its own copy
+// of the packed reference; 2 = anything else: the reference's per-allele bookkeeping per sieve cell (rsq_variants.h)
+inline int variants_mode_for(const Variants &v) {
     if (v.num_alleles > kMaxDevAlleles) throw Error("variants: more than " + std::to_string(kMaxDevAlleles) + " alleles are not supported yet");
     for (const std::vector<Variant> &seq : v.by_seq)
         for (size_t i = 0; i < seq.size(); ++i) {
-            if (seq[i].var_seq.size() != 1) throw Error("variants: insertions and deletions are not supported yet (only substitutions are simulated)");
+            if (seq[i].var_seq.size() != 1) return 2;
             for (size_t k = i + 1; k < seq.size() && seq[k].position == seq[i].position; ++k)
-                if ((seq[k].allele[0] & seq[i].allele[0]) | (seq[k].allele[1] & seq[i].allele[1])) throw Error("variants: two substitutions at one position of one allele");
+                if ((seq[k].allele[0] & seq[i].allele[0]) | (seq[k].allele[1] & seq[i].allele[1])) return 2;
         }
+    return 1;
+}
+
+// The extra passes of SimulateFromGivenBlock's do-while loop (Simulator.cpp:2299-2352) at the start positions of one sequence:
+// CheckForInsertedBasesToStartFrom (:1870-1896) run over the variants, in loop order
+inline void extra_starts_of_sequence(const std::vector<Variant> &vars, std::vector<ExtraStart> &out) {
+    int32_t first_variant_id = 0;
+    const size_t n = vars.size();
+    while ((size_t)first_variant_id < n) {
+        const uint32_t cur_start_position = vars[(size_t)first_variant_id].position;       // plain positions leave first_variant_id_ alone
+        uint32_t start_variant_pos = 0, sub = 0;
+        do {
+            if (sub) out.push_back(ExtraStart{cur_start_position, sub, first_variant_id, start_variant_pos});
+            if ((size_t)first_variant_id < n && vars[(size_t)first_variant_id].position == cur_start_position) {
+                if (start_variant_pos) {
+                    if (++start_variant_pos >= vars[(size_t)first_variant_id].var_seq.size()) {
+                        start_variant_pos = 0;
+                        ++first_variant_id;
+                    }
+                } else {
+                    while ((size_t)first_variant_id < n && vars[(size_t)first_variant_id].position == cur_start_position && 2 > vars[(size_t)first_variant_id].var_seq.size())
+                        ++first_variant_id;
+                }
+                if (0 == start_variant_pos && (size_t)first_variant_id < n && vars[(size_t)first_variant_id].position == cur_start_position) start_variant_pos = 1;
+            }
+            ++sub;
+        } while (start_variant_pos);
+    }
 }
 
 inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const Variants *variants = nullptr) {
@@ -337,13 +371,16 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     s.has_variants = variants != nullptr;
     s.num_alleles = variants ? variants->num_alleles : 1u;
     d.num_alleles = s.num_alleles;
-    d.variants_loaded = variants ? 1u : 0u;
     d.hap_stride = 0;
     s.variants.clear();
     s.var_ptr.assign(1, 0);
-    if (variants) {
+    s.variants_mode = variants ? variants_mode_for(*variants) : 0;
+    d.variants_loaded = (uint32_t)s.variants_mode;
+    s.var_bases.clear();
+    s.extra.clear();
+    s.extra_seq_ptr.assign(1, 0);
+    if (1 == s.variants_mode) {
         // copy 0 = the reference, copy 1 + a = allele a with its substitutions; G/C prefix sums per copy
-        check_variants_supported(*variants);
         const size_t stride = words + 1;
         d.hap_stride = stride;
         packed.resize(stride * (1u + s.num_alleles));
@@ -371,20 +408,42 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
                 }
             }
         }
+    }
+    if (variants) {
         for (size_t i = 0; i < r.codes.size(); ++i) {
             for (const Variant &v : variants->by_seq[i]) {
                 DevVariant dv{};
                 dv.pos = v.position;
+                dv.len = (uint32_t)v.var_seq.size();
+                dv.off = (uint32_t)s.var_bases.size();
                 dv.allele[0] = v.allele[0];
                 dv.allele[1] = v.allele[1];
-                dv.base = v.var_seq[0];
+                s.var_bases.insert(s.var_bases.end(), v.var_seq.begin(), v.var_seq.end());
                 s.variants.push_back(dv);
             }
             s.var_ptr.push_back((uint32_t)s.variants.size());
+            if (2 == s.variants_mode && r.codes[i].size() >= d.insert_to) extra_starts_of_sequence(variants->by_seq[i], s.extra);   // sequences that get blocks (:1159)
+            s.extra_seq_ptr.push_back((uint32_t)s.extra.size());
         }
-    } else s.var_ptr.assign(r.codes.size() + 1, 0);
-    s.dev_variants = up.put(s.variants);
-    d.variants = s.dev_variants;
+        if (s.var_bases.size() > 0xFFFFFFF0ull) throw Error("variants: more than 2^32 variant bases");
+    } else {
+        s.var_ptr.assign(r.codes.size() + 1, 0);
+        s.extra_seq_ptr.assign(r.codes.size() + 1, 0);
+    }
+    s.var_err_fwd.assign(s.var_bases.size() + 1, 0);
+    s.var_err_rev.assign(s.var_bases.size() + 1, 0);
+    d.var_bases = up.put(s.var_bases);
+    s.dev_var_err_fwd = up.put(s.var_err_fwd);
+    s.dev_var_err_rev = up.put(s.var_err_rev);
+    d.var_err_fwd = s.dev_var_err_fwd;
+    d.var_err_rev = s.dev_var_err_rev;
+    d.extra = up.put(s.extra);
+    d.block_extra_ptr = nullptr;                                  // set by plan_simulation once the blocks are numbered
+    if (2 == s.variants_mode) {                                   // templates are written out per mate (k_variant_templates)
+        s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;
+        if (s.template_words > kTemplateWordsMax) throw Error("templates longer than 2048 bases are not supported with insertion / deletion variants");
+    }
+    d.variants = up.put(s.variants);
     d.var_ptr = up.put(s.var_ptr);
     d.ref_words = up.put(packed);
     d.gc_prefix = up.put(gc_prefix);
@@ -607,6 +666,19 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
     s.dev.block_seq = up.put(s.block_seq);
     s.dev.first_block = up.put(s.first_block);
     s.dev.total_blocks = s.total_blocks;
+    // variants of any kind: where the extra starts of every block begin (index b = block id; [total_blocks + 1] = all of them)
+    std::vector<uint32_t> block_extra_ptr(s.total_blocks + 2, 0);
+    if (2 == s.variants_mode) {
+        for (uint32_t i = 0; i < n_seqs; ++i)
+            for (uint32_t b = 0; b < s.n_blocks[i]; ++b) {
+                uint32_t k = s.extra_seq_ptr[i];
+                while (k < s.extra_seq_ptr[i + 1] && s.extra[k].pos < b * kBlockSize) ++k;
+                block_extra_ptr[s.first_block[i] + b] = k;
+            }
+        block_extra_ptr[s.total_blocks + 1] = (uint32_t)s.extra.size();
+        block_extra_ptr[0] = 0;
+    }
+    s.dev.block_extra_ptr = up.put(block_extra_ptr);
 }
 
 // ------------------------------------------------------- systematic errors of the variants' bases (a13 with variants)
@@ -659,25 +731,24 @@ struct HostDomMemory {                                                // Dominan
     }
 };
 
-// rates: the strand's chain output (dom | rate << 8 per strand position).  Fills err_fwd / err_rev of the sequence's variants.
+// track: the strand's chain output (dom | rate << 8 per strand position).  Fills var_err_fwd / var_err_rev of the sequence's variants.
 inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track) {
     const std::vector<uint8_t> &codes = s.ref_codes[seq];
     const uint32_t L = (uint32_t)codes.size(), A = s.num_alleles, range = s.dev.sys_gc_range;
-    DevVariant *vars = s.variants.data() + s.var_ptr[seq];
+    const DevVariant *vars = s.variants.data() + s.var_ptr[seq];
     const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
     if (!n) return;
     auto at = [&](uint32_t sp) -> uint32_t { return reverse ? 3u - codes[L - 1u - sp] : codes[sp]; };
-    DevSim host = s.dev;                                             // the draws read host copies of the two table families
-    host.pool = s.host_pool.data();
-    host.par0 = s.host_par0.data();
+    std::vector<uint16_t> &err = reverse ? s.var_err_rev : s.var_err_fwd;
     std::vector<uint32_t> last_sp(A, 0);
     std::vector<uint8_t> seen(A, 0), last_base_of(A, 4);
     std::vector<HostDomMemory> dom(A);
     uint32_t dist = 0, start_rate = 0, folded = 0;                  // chain state before strand position `folded`
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t var_id = reverse ? n - 1u - k : k;
-        DevVariant &v = vars[var_id];
-        const uint32_t sp = reverse ? L - 1u - v.pos : v.pos, base = reverse ? 3u - v.base : v.base, len = 1;
+        const DevVariant &v = vars[var_id];
+        const uint32_t sp = reverse ? L - 1u - v.pos : v.pos, len = v.len;
+        auto var_base = [&](uint32_t j) -> uint32_t { return reverse ? 3u - s.var_bases[v.off + len - 1u - j] : s.var_bases[v.off + j]; };   // j-th base in the strand's order
         uint32_t chosen = 0;                                        // Variant::FirstAllele
         while (chosen < A && !((v.allele[chosen >> 6] >> (chosen & 63u)) & 1u)) ++chosen;
         if (chosen == A) throw Error("variant without an allele");
@@ -694,16 +765,19 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
         const uint32_t gc_bases = std::min(sp, range);
         uint32_t gc = 0;
         for (uint32_t q = sp - gc_bases; q < sp; ++q) gc += is_gc(at(q));
-        dom[chosen].update(base);
-        const Words w = philox(s.seed, var_id, seq, 4u + (reverse ? 1u : 0u), (kDomSysErr << 28) | 0u);
-        const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};
-        double ps;
-        uint32_t dom_error = draw<3>(s.host_dom_error[(base * 5u + last_base) * 5u + dom[chosen].dom], host.pool, host.par0, idx, u32_to_unit(w.w0), ps);
-        if (0.0 == ps) dom_error = 4;
-        uint32_t rate = draw<3>(s.host_error_rate[base * 5u + dom_error], host.pool, host.par0, idx, u32_to_unit(w.w1), ps);
-        if (0.0 == ps) rate = 0;
-        (reverse ? v.err_rev : v.err_fwd) = (uint16_t)(dom_error | (rate << 8));
-        last_base = base;
+        const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};      // variants cannot start an error region: the same for all their bases
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint32_t base = var_base(j);
+            dom[chosen].update(base);
+            const Words w = philox(s.seed, var_id, seq, 4u + (reverse ? 1u : 0u), (kDomSysErr << 28) | j);
+            double ps;
+            uint32_t dom_error = draw<3>(s.host_dom_error[(base * 5u + last_base) * 5u + dom[chosen].dom], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(w.w0), ps);
+            if (0.0 == ps) dom_error = 4;
+            uint32_t rate = draw<3>(s.host_error_rate[base * 5u + dom_error], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(w.w1), ps);
+            if (0.0 == ps) rate = 0;
+            err[v.off + j] = (uint16_t)(dom_error | (rate << 8));
+            last_base = base;
+        }
         // the other alleles of the variant: their dominant-base memories (Simulator.cpp:1088-1126 / 849-887)
         uint32_t ref_allele = A;
         if (!seen[chosen] || last_sp[chosen] + 5u < sp + len) ref_allele = chosen;
@@ -712,13 +786,13 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
             if (allele != chosen) {
                 if (seen[allele] && last_sp[allele] + 5u >= sp + len) {
                     for (uint32_t q = last_sp[allele] + 1u; q < sp; ++q) dom[allele].update(at(q));
-                    dom[allele].update(base);
+                    for (uint32_t j = 0; j < len; ++j) dom[allele].update(var_base(j));
                 } else if (ref_allele < A) dom[allele] = dom[ref_allele];
                 else {
                     ref_allele = allele;
                     dom[allele].clear();
                     if (sp) dom[allele].set(at, sp - 1u);
-                    dom[allele].update(base);
+                    for (uint32_t j = 0; j < len; ++j) dom[allele].update(var_base(j));
                 }
             }
             seen[allele] = 1;
@@ -740,7 +814,8 @@ inline void build_variant_sys_errors(SimState &s, Uploader &up) {
             variant_sys_errors_strand(s, seq, strand != 0, track.data());
         }
     }
-    up.write_bytes(s.dev_variants, s.variants.data(), s.variants.size() * sizeof(DevVariant));
+    up.write_bytes(s.dev_var_err_fwd, s.var_err_fwd.data(), s.var_err_fwd.size() * sizeof(uint16_t));
+    up.write_bytes(s.dev_var_err_rev, s.var_err_rev.data(), s.var_err_rev.size() * sizeof(uint16_t));
 }
 
 // ------------------------------------------------------------------------------- chains of the a13 pre-pass

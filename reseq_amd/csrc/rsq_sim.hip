@@ -110,6 +110,7 @@ struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
     // workspace of the hot path (grow-only)
+    DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
     DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates, rec_flags, rec_index, rec_count;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
@@ -251,7 +252,7 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
 template <uint32_t MASK, bool VAR = false>
-static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
     const LdsPlan &pl = s.dev.lds;
     const size_t lds_bytes = MASK ? (size_t)pl.total_doubles * sizeof(double) : 0;
     if (lds_bytes > 64 * 1024)
@@ -264,7 +265,7 @@ static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs
     HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
     hipLaunchKernelGGL((k_fill_reads<MASK, VAR>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
-                       s.fill_counters.as<uint32_t>());
+                       s.fill_counters.as<uint32_t>(), fvars);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
@@ -295,12 +296,13 @@ static void launch_fill_dispatch(uint32_t mask, rsq_sim &s, const Fragment *frag
     ((mask == kFillMasks[I] ? (launch_fill_mask<kFillMasks[I]>(s, frags, n_pairs, adapter_first, raw, st), done = true) : false), ...);
     if (!done) throw Error("no k_fill_reads instantiation for staging mask " + std::to_string(mask));
 }
-static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st) {
+static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
+                              const FragmentVar *fvars = nullptr) {
     if (frags && s.has_variants) {
         // with variants the error walk is per lane state: two instantiations only, every table staged or every table from HBM
         constexpr uint32_t kAll = kLdsDesc | kLdsQuality | kLdsRate | kLdsBaseCall;
-        if (effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) == kAll) launch_fill_mask<kAll, true>(s, frags, n_pairs, adapter_first, raw, st);
-        else launch_fill_mask<0u, true>(s, frags, n_pairs, adapter_first, raw, st);
+        if (effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) == kAll) launch_fill_mask<kAll, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
+        else launch_fill_mask<0u, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
         return;
     }
     launch_fill_dispatch(effective_fill_mask(s.dev.lds.mask, s.force_fill_mode), s, frags, n_pairs, adapter_first, raw, st,
@@ -309,7 +311,7 @@ static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pair
 
 // reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
 static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap,
-                          size_t *r2_len, hipStream_t st) {
+                          size_t *r2_len, hipStream_t st, const FragmentVar *fvars = nullptr) {
     *r1_len = *r2_len = 0;
     if (!n_pairs) return RSQ_OK;
     RawLayout raw = raw_layout(s, 2 * n_pairs);
@@ -324,7 +326,14 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
         hipLaunchKernelGGL(k_methylation_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, n_pairs, raw);
         HIP_CHECK(hipGetLastError());
     }
-    launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st);
+    if (frags && fvars) {                                            // variants of any kind: both mates' templates with the allele's variants
+        s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
+        raw.templates = s.templates.as<uint64_t>();
+        raw.template_words = s.template_words;
+        hipLaunchKernelGGL(k_variant_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, fvars, n_pairs, raw);
+        HIP_CHECK(hipGetLastError());
+    }
+    launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st, fvars);
     s.timers["scan"].start(st);
     exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
     exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
@@ -332,7 +341,7 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     // the kernel itself refuses to write past the caller's capacity; the host learns the sizes with the final synchronisation
     s.timers["format_write"].start(st);
     hipLaunchKernelGGL(k_format_write, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
-                       (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0));
+                       (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
@@ -360,7 +369,14 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     HIP_CHECK(hipSetDevice(s.device));
     *n_pairs = 0;
     *r1_len = *r2_len = 0;
-    const uint64_t n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
+    const int vm = s.variants_mode;
+    uint64_t n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
+    if (2 == vm && block_hi > block_lo) {                            // plus the starts inside inserted bases of these blocks
+        uint32_t ptr[2];
+        HIP_CHECK(hipMemcpy(&ptr[0], s.dev.block_extra_ptr + block_lo, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&ptr[1], s.dev.block_extra_ptr + block_hi, 4, hipMemcpyDeviceToHost));
+        n_slots += ptr[1] - ptr[0];
+    }
     if (!n_slots) return RSQ_OK;
     if (n_slots * sieve_words_per_slot(s.dev.insert_to) >= (1ull << 32)) {       // slot and bitmap indices are 32 bits wide inside one call
         g_last_error = "block range too large for one call: at most " + std::to_string(((1ull << 32) / sieve_words_per_slot(s.dev.insert_to)) / kBlockSize - 1) + " blocks";
@@ -387,16 +403,20 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         s.timers["sieve"].start(st);
         if (!attempt) {
             s.timers["sieve_screen"].start(st);
-            hipLaunchKernelGGL(k_sieve_screen, dim3(cdiv(n_slots * words_per_slot, kScreenBlock)), dim3(kScreenBlock), thr_lds_doubles(s.dev.insert_to) * sizeof(double), st,
-                               s.dev, block_lo, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
+            const dim3 cgrid(cdiv(n_slots * words_per_slot, kScreenBlock)), cblock(kScreenBlock);
+            const size_t clds = thr_lds_doubles(s.dev.insert_to) * sizeof(double);
+            if (2 == vm) hipLaunchKernelGGL(k_sieve_screen<2>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
+            else hipLaunchKernelGGL(k_sieve_screen<0>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
             s.timers["sieve_screen"].stop(st);
         }
-        if (s.has_variants)
-            hipLaunchKernelGGL(k_sieve_finish<true>, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot,
-                               slots_per_wave, s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
-        else
-            hipLaunchKernelGGL(k_sieve_finish<false>, sgrid, sblock, kSieveWaves * slots_per_wave * sizeof(uint32_t), st, s.dev, block_lo, (uint32_t)n_slots, words_per_slot,
-                               slots_per_wave, s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>());
+        const size_t flds = kSieveWaves * slots_per_wave * sizeof(uint32_t);
+#define RSQ_FINISH(VM)                                                                                                                                        \
+    hipLaunchKernelGGL(k_sieve_finish<VM>, sgrid, sblock, flds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, slots_per_wave,            \
+                       s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>())
+        if (2 == vm) RSQ_FINISH(2);
+        else if (1 == vm) RSQ_FINISH(1);
+        else RSQ_FINISH(0);
+#undef RSQ_FINISH
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
         exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
@@ -414,7 +434,13 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     if (!total) return RSQ_OK;
     s.frags.reserve(total * sizeof(Fragment) + 16);
     s.timers["sieve_emit"].start(st);
-    hipLaunchKernelGGL(k_sieve_emit, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(), s.frags.as<Fragment>());
+    if (2 == vm) {
+        s.fvars.reserve(total * sizeof(FragmentVar) + 16);
+        hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
+                           s.frags.as<Fragment>(), s.fvars.as<FragmentVar>());
+    } else
+        hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
+                           s.frags.as<Fragment>(), (FragmentVar *)nullptr);
     s.timers["sieve_emit"].stop(st);
     HIP_CHECK(hipGetLastError());
     if (frags_out) {
@@ -425,7 +451,7 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         static_assert(sizeof(rsq_fragment) == sizeof(Fragment), "ABI fragment layout");
         HIP_CHECK(hipMemcpyAsync(frags_out, s.frags.as<Fragment>(), total * sizeof(Fragment), hipMemcpyDeviceToDevice, st));
     }
-    return reads_and_text(s, s.frags.as<Fragment>(), total, 0, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st);
+    return reads_and_text(s, s.frags.as<Fragment>(), total, 0, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st, 2 == vm ? s.fvars.as<FragmentVar>() : nullptr);
 }
 
 // CIGAR strings and per-read scalars of the error-model-only mode

@@ -93,15 +93,32 @@ struct ReadMeta {
     uint16_t plain;        // 1: no insertion or deletion anywhere, the CIGAR follows from the counts above without the stored ops
 };
 
-// One variant of the reference (Reference.h:24-62) as the kernels see it.  Only substitutions reach the device for now: `base` is the
-// single base of var_seq_.  err_fwd / err_rev: the systematic error drawn for that base on the forward / reverse strand
-// (SysErrorVariant::var_errors_, Simulator.h:91-106), dom | rate << 8 like the tracks.
+// One variant of the reference (Reference.h:24-62) as the kernels see it: var_seq_ is var_bases[off, off + len) (len 0: deletion,
+// 1: substitution, more: the substituted base followed by inserted bases).  The systematic errors drawn for those bases
+// (SysErrorVariant::var_errors_, Simulator.h:91-106) are var_err_fwd / var_err_rev[off + k] for the k-th base in the strand's
+// drawing order (the reverse strand draws the complemented bases last to first), dom | rate << 8 like the tracks.
 struct DevVariant {
     uint32_t pos;
-    uint16_t err_fwd, err_rev;
+    uint32_t len;
+    uint32_t off;
+    uint32_t pad;
     uint64_t allele[2];    // bit a: the variant is in allele a
-    uint8_t base;
-    uint8_t pad[7];
+};
+// what CreateReads gets of SimulateFromGivenBlock beyond the Fragment when variants are loaded (Simulator.cpp:2334-2337)
+struct FragmentVar {
+    uint32_t end;          // cur_end_position = start + length + end_pos_shift_[allele]
+    uint32_t sub;          // pass at the start position (> 0: the fragment starts inside inserted bases)
+    int32_t start_var;     // bias_mod.StartVariant()
+    uint32_t start_var_pos;
+    int32_t end_var;       // bias_mod.EndVariant(variants, cur_end_position, allele)
+    uint32_t end_var_pos;
+};
+// an extra pass of SimulateFromGivenBlock's do-while loop at a start position (CheckForInsertedBasesToStartFrom, :1870-1896)
+struct ExtraStart {
+    uint32_t pos;          // start position in the sequence
+    uint32_t sub;          // 1, 2, ... in loop order at this position
+    int32_t first_variant_id;
+    uint32_t start_variant_pos;
 };
 
 struct DevAdapters {
@@ -163,10 +180,15 @@ struct DevSim {
     // ---- variants (-V): copy 1 + a of the packed reference and of gc_prefix (hap_stride entries apart) is allele a with its
     // substitutions applied; copy 0 stays the reference itself (systematic-error chains, bias sums, wrapped surroundings)
     uint32_t num_alleles;            // Reference::NumAlleles(), 1 without variants
-    uint32_t variants_loaded;        // Reference::VariantsLoaded()
-    uint64_t hap_stride;
+    uint32_t variants_loaded;        // Reference::VariantsLoaded(): 0 no, 1 substitutions only (allele copies), 2 any kind (rsq_variants.h)
+    uint64_t hap_stride;             // 0 unless variants_loaded == 1
     const DevVariant *variants;      // sorted by position within each sequence
     const uint32_t *var_ptr;         // [n_seqs + 1]
+    const uint8_t *var_bases;
+    const uint16_t *var_err_fwd, *var_err_rev;
+    // variants_loaded == 2: slots of the sieve = start positions plus the extra passes inside inserted bases, in loop order
+    const ExtraStart *extra;         // sorted by (sequence, pos, sub)
+    const uint32_t *block_extra_ptr; // [total_blocks + 2] extras before block b (index b, 1-based)
     // ---- coverage model
     uint32_t insert_from;            // max(1, InsertLengths().from())
     uint32_t insert_to;              // InsertLengths().to()

@@ -33,7 +33,7 @@ def emu_lib():
         L.emu_last_error.restype = C.c_char_p
         L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]
         L.emu_get_variant_sys.restype = C.c_uint32
-        L.emu_get_variant_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.emu_get_variant_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
@@ -116,11 +116,11 @@ class EmuBackend:
         self.L.emu_get_adapter_sys(self.h, seg, adapter, dom.ctypes.data, rate.ctypes.data)
         return dom, rate
 
-    def variant_sys_errors(self, seq, n):
-        """(forward, reverse) dom | rate << 8 of the sequence's n variants"""
-        fwd, rev = np.zeros(max(n, 1), np.uint16), np.zeros(max(n, 1), np.uint16)
-        assert self.L.emu_get_variant_sys(self.h, seq, fwd.ctypes.data, rev.ctypes.data, n) == n
-        return fwd[:n], rev[:n]
+    def variant_sys_errors(self, seq, var_id, reverse):
+        """dom | rate << 8 per base of one variant on one strand, in the strand's drawing order"""
+        out = np.zeros(4096, np.uint16)
+        n = self.L.emu_get_variant_sys(self.h, seq, var_id, int(reverse), out.ctypes.data, len(out))
+        return out[:n].copy()
 
     def codes(self, seq, length):
         out = np.zeros(length, np.uint8)

@@ -34,6 +34,7 @@ struct HostUploader : Uploader {
 
 struct Emu : SimState {
     HostUploader up;
+    std::vector<FragmentVar> fvars;             // of the last emu_sieve call (variants of any kind), parallel to its fragments
     int fill_mode = -1;                         // -1: everything the LDS plan allows (as the product does); else a mask of kLds* bits
     std::vector<double> lds[2];                 // host stand-in for the LDS image of each template segment (+ one wave area)
     uint32_t mask() const { return effective_fill_mask(dev.lds.mask, fill_mode); }
@@ -374,15 +375,13 @@ void emu_get_sys(void *h, int reverse, uint32_t seq, uint8_t *dom, uint8_t *rate
         rate[i] = (uint8_t)(src[i] >> 8);
     }
 }
-// err_fwd / err_rev of the sequence's variants after the pre-pass (dom | rate << 8)
-uint32_t emu_get_variant_sys(void *h, uint32_t seq, uint16_t *fwd, uint16_t *rev, uint32_t cap) {
+// var_errors_ of one variant on one strand after the pre-pass (dom | rate << 8 per base in the strand's drawing order); returns its length
+uint32_t emu_get_variant_sys(void *h, uint32_t seq, uint32_t var_id, int reverse, uint16_t *out, uint32_t cap) {
     Emu &s = *static_cast<Emu *>(h);
-    const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
-    for (uint32_t i = 0; i < n && i < cap; ++i) {
-        fwd[i] = s.dev.variants[s.var_ptr[seq] + i].err_fwd;
-        rev[i] = s.dev.variants[s.var_ptr[seq] + i].err_rev;
-    }
-    return n;
+    const DevVariant &v = s.variants[s.var_ptr[seq] + var_id];
+    const uint16_t *err = reverse ? s.dev.var_err_rev : s.dev.var_err_fwd;
+    for (uint32_t k = 0; k < v.len && k < cap; ++k) out[k] = err[v.off + k];
+    return v.len;
 }
 void emu_get_adapter_sys(void *h, int seg, uint32_t id, uint8_t *dom, uint8_t *rate) {
     Emu &s = *static_cast<Emu *>(h);
@@ -397,10 +396,48 @@ void emu_get_codes(void *h, uint32_t seq, uint8_t *out) {            // unpacks 
     for (uint32_t i = 0; i < s.seq_len[seq]; ++i) out[i] = (uint8_t)ref_base(s.dev.ref_words, s.seq_word_off[seq], i);
 }
 
+// variants of any kind: k_sieve_screen<2> / k_sieve_finish<2> / k_sieve_emit<2> as a loop over the batch's slots
+static int64_t emu_sieve_general(Emu &s, uint32_t block_lo, uint32_t block_hi, Fragment *out, uint64_t cap) {
+    const DevSim &S = s.dev;
+    const uint32_t n_slots = (block_hi - block_lo) * kBlockSize + (S.block_extra_ptr[block_hi] - S.block_extra_ptr[block_lo]);
+    uint64_t n = 0;
+    uint32_t number = 0, last_block = 0;
+    s.fvars.clear();
+    for (uint32_t slot = 0; slot < n_slots; ++slot) {
+        SieveSite site;
+        const uint32_t block_id = init_site_slot<2>(S, block_lo, block_hi, slot, site);
+        if (block_id != last_block) number = 0;
+        last_block = block_id;
+        if (site.start >= site.L) continue;
+        for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
+            VarCell cell;
+            if (!sieve_cell_general(S, site, len, sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len), cell)) continue;
+            for (uint32_t e = 0; e < cell.n; ++e) {
+                const uint32_t allele = cell.id[e] >> 1;
+                const VarView r = var_view(S, site.seq);             // what k_sieve_emit<2> derives again
+                AlleleMod m;
+                VarCellSite vs;
+                evaluate_allele(r, site.st, allele, site.start, S.insert_from, len, m, vs);
+                const FragmentVar fv{vs.cur_end_position, site.sub, site.st.first_variant_id, site.st.start_variant_pos, vs.end_var.first_variant_id, vs.end_var.start_variant_pos};
+                for (uint32_t dup = 0; dup < cell.cnt[e]; ++dup) {
+                    if (n < cap) {
+                        out[n] = make_fragment(site, len, dup, cell.id[e] & 1u, block_id, number + 1, allele);
+                        s.fvars.push_back(fv);
+                    }
+                    ++number;
+                    ++n;
+                }
+            }
+        }
+    }
+    return (int64_t)n;
+}
+
 // the walk of k_sieve<COUNT> + scan + k_sieve<EMIT> with a plain loop over slots and lengths
 int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, uint64_t cap) {
     Emu &s = *static_cast<Emu *>(h);
     const DevSim &S = s.dev;
+    if (2 == s.variants_mode) return emu_sieve_general(s, block_lo, block_hi, out, cap);
     uint64_t n = 0;
     for (uint32_t block_id = block_lo; block_id < block_hi; ++block_id) {
         uint32_t number = 0;
@@ -411,7 +448,7 @@ int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, 
             for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
                 uint32_t cnt[2], strand_of[2];
                 const Words w = sieve_quad_words(S, site, len >> 2);
-                if (s.has_variants) {                               // k_sieve_finish<true> + k_sieve_emit
+                if (s.has_variants) {                               // k_sieve_finish<1> + k_sieve_emit
                     VarCell cell;
                     if (!sieve_cell_var(S, site, len, sieve_cell_uniform(w, len), cell)) continue;
                     for (uint32_t e = 0; e < cell.n; ++e)
@@ -450,10 +487,18 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 if (frags) {
                     const Fragment &f = frags[pair];
                     const uint32_t c2 = f.len | ((uint32_t)f.dup << 16);
-                    const Stream st{s.dev.seed, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, seg, f.allele)};
-                    const uint32_t tile = draw_tile(s.dev, f.start, f.seq, c2, pair_c3(kDomPair, f.strand, 2, f.allele));
-                    if (s.has_variants) {                       // k_fill_reads<MASK, true>
-                        run_read(s, seg, st, tile, f.len, variant_src(s.dev, f, seg), out, meta);
+                    const FragmentVar *fv = 2 == s.variants_mode ? &s.fvars.at(pair) : nullptr;
+                    const uint32_t c1 = f.seq | ((fv ? fv->sub : 0u) << 22);
+                    const Stream st{s.dev.seed, f.start, c1, c2, pair_c3(kDomPair, f.strand, seg, f.allele)};
+                    const uint32_t tile = draw_tile(s.dev, f.start, c1, c2, pair_c3(kDomPair, f.strand, 2, f.allele));
+                    if (s.has_variants) {                       // k_fill_reads<MASK, true>, after k_variant_templates when variants of any kind are loaded
+                        VariantSrc src = variant_src(s.dev, f, fv, seg);
+                        uint64_t tmpl[kTemplateWordsMax];
+                        if (fv) {
+                            variant_template(s.dev, f, *fv, seg, tmpl, s.template_words);
+                            src.converted = tmpl;
+                        }
+                        run_read(s, seg, st, tile, f.len, src, out, meta);
                     } else {
                         FragmentSrc src = fragment_src(s.dev, f, seg);
                         uint64_t tmpl[kTemplateWordsMax];
@@ -470,9 +515,10 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 }
                 out.finish();
                 const Fragment *fp = frags ? &frags[pair] : nullptr;
-                const uint32_t need = record_size(s.dev, s.names, fp, adapter_first + pair + 1, meta);      // what k_fill_reads stores in sizes[]
+                const FragmentVar *fvp = frags && 2 == s.variants_mode ? &s.fvars.at(pair) : nullptr;
+                const uint32_t need = record_size(s.dev, s.names, fp, adapter_first + pair + 1, meta, fvp);      // what k_fill_reads stores in sizes[]
                 if (pos[seg] + need > cap[seg]) throw Error("text buffer too small");
-                const uint32_t wrote = format_record(s.dev, s.names, fp, adapter_first + pair + 1, meta, raw.seq_col(), raw.qual_col(), raw.ops_col(), dst[seg] + pos[seg]);
+                const uint32_t wrote = format_record(s.dev, s.names, fp, adapter_first + pair + 1, meta, raw.seq_col(), raw.qual_col(), raw.ops_col(), dst[seg] + pos[seg], fvp);
                 if (wrote != need) throw Error("record_size disagrees with format_record");
                 pos[seg] += need;
             }

@@ -383,6 +383,15 @@ def _substitution_set(seqs, rng, density, special):
     return out
 
 
+def _compare_variant_sys_errors(p, seqs):
+    for seq in seqs:
+        for i in range(p.ovars.contents.n[seq]):
+            for strand in (0, 1):
+                d, r = p.osim.var_sys_errors(strand, seq, i)
+                got = p.b.variant_sys_errors(seq, i, strand)
+                assert len(got) == len(d) and np.array_equal(got, d.astype(np.uint16) | (r.astype(np.uint16) << 8)), (seq, i, strand)
+
+
 def _compare_blocks_var(p, lo, hi):
     ofr = p.osim.sieve_var(lo, hi)
     o1, o2 = p.osim.create_reads_var(ofr)
@@ -421,13 +430,7 @@ def case_variants_substitutions(backend_cls, workdir):
         assert p.info["total_blocks"] == p.osim.total_blocks()
         np.testing.assert_allclose(p.b.thresholds(), p.osim.thresholds(), rtol=NORM_RTOL, atol=0)      # thresholds for two alleles
         if hasattr(p.b, "variant_sys_errors"):
-            for seq in (0, 2):
-                n = p.ovars.contents.n[seq]
-                fwd, rev = p.b.variant_sys_errors(seq, n)
-                for i in range(n):
-                    for strand, got in ((0, fwd), (1, rev)):
-                        d, r = p.osim.var_sys_errors(strand, seq, i)
-                        assert len(d) == 1 and int(d[0]) | (int(r[0]) << 8) == int(got[i]), (seq, i, strand)
+            _compare_variant_sys_errors(p, (0, 2))
         p.align_normalization()
         tb = p.info["total_blocks"]
         ofr, text = _compare_blocks_var(p, 1, tb + 1)
@@ -446,13 +449,78 @@ def case_variants_substitutions(backend_cls, workdir):
         p.close()
 
 
+def _mixed_variant_set(seqs, rng, density, special=()):
+    """substitutions, insertions (1..6 bases, with or without a substituted first base) and deletions (1..4 bases), non-overlapping"""
+    out = []
+    for si, (_, codes) in enumerate(seqs):
+        L = len(codes)
+        if L < 200:
+            continue
+        last = -1
+        cand = set(int(x) for x in rng.choice(np.arange(0, L - 8), size=L // density, replace=False)) | {x for x in special if x < L - 8}
+        for p0 in sorted(cand):
+            if p0 <= last:
+                continue
+            kind = int(rng.integers(0, 4))
+            gt = ["0|1", "1|0", "1|1"][int(rng.integers(0, 3))]
+            ref = "ACGT"[codes[p0]]
+            other = "ACGT"[(int(codes[p0]) + 1 + int(rng.integers(0, 3))) % 4]
+            ins = "".join("ACGT"[b] for b in rng.integers(0, 4, int(rng.integers(1, 7))))
+            if kind == 0:
+                out.append((si, p0, 1, other, gt))
+                last = p0
+            elif kind == 1:
+                out.append((si, p0, 1, ref + ins, gt))
+                last = p0
+            elif kind == 2:
+                out.append((si, p0, 1, other + ins, gt))          # substitution and insertion in one variant
+                last = p0
+            else:
+                dl = int(rng.integers(1, 5))
+                out.append((si, p0, dl + 1, ref, gt))
+                last = p0 + dl
+    return out
+
+
+def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels", lengths=(6200, 80, 3100), samples=1):
+    """-V with insertions and deletions: starts inside inserted bases as extra slots of the sieve, the reference's per-allele modifiers
+    derived per cell from scratch (rsq_variants.h) against the oracle's incremental bookkeeping, templates with the allele's variants,
+    the error walk through insertions and deletions, end positions shifted by the allele's length changes in the read ids"""
+    lengths = list(lengths)
+    rng = np.random.default_rng(seed)
+    seqs = make_inputs(workdir, tag, synth.TINY, lengths)[2]
+    special = [0, 3, 9, 10, 11, 20, 29, 30, 990, 995, 998, 999, 1000, 1001, 1990, 1999, 2000, 2995, 2999, 3000]
+    vs = _mixed_variant_set(seqs, rng, density, special)
+    if samples > 1:
+        vs = [(si, p0, rl, alt, "\t".join(["0|1", "1|0", "1|1", "0|0"][int(rng.integers(0, 4))] for _ in range(samples - 1)) + "\t" + gt) for si, p0, rl, alt, gt in vs]
+    vcf = workdir / f"{tag}.vcf"
+    write_vcf(vcf, seqs, vs, samples=samples)
+    p = Pair(backend_cls, workdir, tag, synth.TINY, lengths, seed=seed, num_pairs=9000, vcf=vcf)
+    try:
+        np.testing.assert_allclose(p.b.thresholds(), p.osim.thresholds(), rtol=NORM_RTOL, atol=0)
+        if hasattr(p.b, "variant_sys_errors"):
+            _compare_variant_sys_errors(p, [i for i, n in enumerate(lengths) if n >= 200])
+        p.align_normalization()
+        tb = p.info["total_blocks"]
+        ofr, text = _compare_blocks_var(p, 1, tb + 1)
+        assert len(ofr) > 7000
+        assert (ofr["sub"] > 0).sum() > 20                    # fragments that start inside inserted bases
+        shift = ofr["end"].astype(np.int64) - ofr["start"] - ofr["len"]
+        assert shift.min() < 0 < shift.max()                  # insertions shorten, deletions lengthen the reference span
+        part, _ = _compare_blocks_var(p, 2, 5)                # batching by block range
+        assert len(part) == int(((ofr["block"] >= 2) & (ofr["block"] < 5)).sum())
+    finally:
+        p.close()
+
+
 def case_variants_rejected(backend_cls, workdir):
-    """what the kernels do not simulate yet is refused, not approximated: insertions / deletions, more than eight alleles"""
+    """what the kernels do not simulate is refused, not approximated: more than eight alleles"""
     import pytest
     lengths = [3000]
     seqs = make_inputs(workdir, "vars_rej", synth.TINY, lengths)[2]
-    vcf = workdir / "indel.vcf"
-    write_vcf(vcf, seqs, [(0, 100, 1, "A", "0|1") if seqs[0][1][100] != 0 else (0, 100, 1, "C", "0|1"), (0, 500, 3, "ACGT"[seqs[0][1][500]], "1|0")])
+    vcf = workdir / "many.vcf"
+    alt = "A" if seqs[0][1][100] != 0 else "C"
+    write_vcf(vcf, seqs, [(0, 100, 1, alt, "\t".join(["0|1"] * 5))], samples=5)
     ppath, fpath, _ = make_inputs(workdir, "vars_rej", synth.TINY, lengths)
-    with pytest.raises(Exception, match="insertions and deletions are not supported yet"):
+    with pytest.raises(Exception, match="more than 8 alleles"):
         backend_cls(ppath, fpath, 0, None, vcf_path=vcf)

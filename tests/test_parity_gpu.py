@@ -152,6 +152,14 @@ def test_variants_substitutions(workdir):
     P.case_variants_substitutions(GpuBackend, workdir)
 
 
+def test_variants_insertions_and_deletions(workdir):
+    P.case_variants_indels(GpuBackend, workdir)
+
+
+def test_variants_insertions_and_deletions_dense_four_alleles(workdir):
+    P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="indels4", lengths=(5300, 2600), samples=2)
+
+
 def test_variants_not_simulated_yet_are_refused(workdir):
     P.case_variants_rejected(GpuBackend, workdir)
 
@@ -161,6 +169,7 @@ def test_variants_every_staging_mode(workdir, monkeypatch):
     for mode in ("0", "23"):
         monkeypatch.setenv("RSQ_FILL_MODE", mode)
         P.case_variants_substitutions(GpuBackend, workdir)
+        P.case_variants_indels(GpuBackend, workdir)
 
 
 def test_cli_with_variants_equals_the_oracle(workdir):
@@ -178,7 +187,7 @@ def test_cli_with_variants_equals_the_oracle(workdir):
     lengths = [5000, 80, 3210]
     ppath, fpath, seqs = P.make_inputs(workdir, "cli_var", synth.TINY, lengths)
     vcf = workdir / "cli_var.vcf"
-    P.write_vcf(vcf, seqs, P._substitution_set(seqs, np.random.default_rng(3), 50, [0, 999, 1000, 1001]))
+    P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, np.random.default_rng(3), 50, [0, 999, 1000, 1001]))      # substitutions, insertions, deletions
     a1, a2, b1, b2 = (str(workdir / n) for n in ("v1.fq", "v2.fq", "w1.fq", "w2.fq"))
     args = ["-R", fpath, "-s", ppath, "-V", str(vcf), "--numReads", "20000", "--seed", "13", "--refBias", "no"]
     subprocess.run([exe, "illuminaPE"] + args + ["-1", a1, "-2", a2], check=True, capture_output=True)

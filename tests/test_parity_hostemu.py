@@ -132,5 +132,13 @@ def test_variants_substitutions(workdir):
     P.case_variants_substitutions(EmuBackend, workdir)
 
 
+def test_variants_insertions_and_deletions(workdir):
+    P.case_variants_indels(EmuBackend, workdir)
+
+
+def test_variants_insertions_and_deletions_four_alleles(workdir):
+    P.case_variants_indels(EmuBackend, workdir, density=30, seed=47, tag="indels4", lengths=(4300, 2600), samples=2)
+
+
 def test_variants_not_simulated_yet_are_refused(workdir):
     P.case_variants_rejected(EmuBackend, workdir)
