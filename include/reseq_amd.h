@@ -71,8 +71,8 @@ int rsq_ref_write_fasta(const rsq_ref *r, const char *path);
 /* Reference::PrepareVariantFile + ReadFirstVariants / ReadVariants (reseq/Reference.cpp:126-420,1003-1077): loads a VCF, split into
  * single-position variants per sequence (Reference::Variant, Reference.h:24-62).  A simulator created from such a reference simulates
  * per allele (Simulator::SimulateFromGivenBlock with VariantsLoaded, Simulator.cpp:2249-2357; read ids carry "_allele<a>").  What the
- * kernels simulate today: substitutions, insertions and deletions, up to 8 alleles.  rsq_sim_create returns RSQ_EINVAL with a message
- * for more alleles; rsq_sim_read_methylation refuses a simulator with variants. */
+ * kernels simulate: substitutions, insertions and deletions, up to 128 alleles (Reference::Variant::kMaxAlleles), also together with
+ * rsq_sim_read_methylation (one conversion rate per allele). */
 int rsq_ref_read_variants(rsq_ref *r, const char *path);
 int rsq_ref_num_alleles(const rsq_ref *r, uint32_t *out);
 int rsq_ref_num_variants(const rsq_ref *r, uint32_t seq, uint32_t *out);

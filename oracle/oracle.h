@@ -254,7 +254,9 @@ typedef struct orc_sim {
     /* unmethylated regions per sequence (NULL without --methylation): [first, second) and the C->T probability */
     uint32_t *meth_n;
     uint32_t **meth_first, **meth_second;
-    double **meth_rate;
+    double **meth_rate;               /* the first (or only) allele column */
+    uint32_t *meth_n_cols;            /* columns per sequence: 1 or NumAlleles() */
+    double ***meth_rate_cols;         /* [seq][column][region]; Reference::Unmethylation(seq, allele) = column allele, or 0 if there is one */
     /* variants (oracle_variants.cpp): NumAlleles() and the per-sequence variants with their systematic errors */
     uint16_t num_alleles;
     void *var_state;
@@ -385,6 +387,7 @@ int orc_var_check_inserted(void *h, uint32_t cur_start);
 /* --methylation without variants: Reference::PrepareMethylationFile/ReadMethylation (Reference.cpp:1132-1310) and
  * Simulator::CTConversion (Simulator.cpp:1925-2002,2219-2247).  0, or -1 with the reference's message. */
 int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap);
+uint32_t orc_methylation_start(const orc_sim *s, uint32_t seq, uint32_t pos);      /* cur_methylation_start of SimulateFromGivenBlock at a start position */
 int orc_parse_methylation(const char *path, const orc_reference *r, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out, uint32_t *second_out,
                           double *rate_out, uint32_t cap, char *err, size_t err_cap);
 int orc_create_sys_error_profile(const orc_profile *p, const orc_reference *r, uint64_t seed, orc_text *out);

@@ -548,12 +548,17 @@ void orc_sim_free(orc_sim *s) {
         for (uint32_t i = 0; i < s->r->n_seqs; ++i) {
             free(s->meth_first[i]);
             free(s->meth_second[i]);
-            free(s->meth_rate[i]);
+            if (s->meth_rate_cols[i]) {
+                for (uint32_t a = 0; a < s->meth_n_cols[i]; ++a) free(s->meth_rate_cols[i][a]);
+                free(s->meth_rate_cols[i]);
+            }
         }
         free(s->meth_n);
+        free(s->meth_n_cols);
         free(s->meth_first);
         free(s->meth_second);
         free(s->meth_rate);
+        free(s->meth_rate_cols);
     }
     for (int seg = 0; seg < 2; ++seg) {
         if (s->adapter_dom[seg])
@@ -903,7 +908,7 @@ static uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel) { return
 
 /* cur_methylation_start of SimulateFromGivenBlock for a start position (Simulator.cpp:2273,2293-2297; CreateBlock :1214-1219 and the
  * per-position increment keep it at the first region that ends after the position) */
-static uint32_t methylation_start(const orc_sim *s, uint32_t seq, uint32_t pos) {
+uint32_t orc_methylation_start(const orc_sim *s, uint32_t seq, uint32_t pos) {
     uint32_t i = 0;
     while (i < s->meth_n[seq] && s->meth_second[seq][i] <= pos) ++i;
     return i;
@@ -984,7 +989,7 @@ int orc_create_reads(const orc_sim *s, const orc_fragment *frags, uint64_t n, or
                 for (uint32_t k = 0; k < tl; ++k) tmpl[sg][k] = (uint8_t)(3 - codes[end - 1 - k]);
         }
         if (s->meth_n) {                                            /* CTConversion (Simulator.cpp:2219-2247): forward template, then reverse */
-            uint32_t cur_methylation_start = methylation_start(s, f->seq, start);
+            uint32_t cur_methylation_start = orc_methylation_start(s, f->seq, start);
             ct_conversion(s, tmpl[strand], tlen[strand], f->seq, start, cur_methylation_start, 0, start, f->len);
             ct_conversion(s, tmpl[!strand], tlen[!strand], f->seq, end, cur_methylation_start, 1, start, f->len);
         }
@@ -1380,18 +1385,15 @@ static int parse_methylation(const char *path, const orc_reference *r, uint32_t 
 
 int orc_sim_read_methylation(orc_sim *s, const char *path, char *err, size_t err_cap) {
     orc_methylation m;
-    if (parse_methylation(path, s->r, 1, &m, err, err_cap)) return -1;
+    if (parse_methylation(path, s->r, s->num_alleles ? s->num_alleles : 1, &m, err, err_cap)) return -1;
     const uint32_t n_seqs = s->r->n_seqs;
     s->meth_n = m.n;
     s->meth_first = m.first;
     s->meth_second = m.second;
     s->meth_rate = calloc(n_seqs, sizeof(double *));
-    for (uint32_t i = 0; i < n_seqs; ++i) {
-        s->meth_rate[i] = m.rate[i] ? m.rate[i][0] : NULL;                /* the only allele */
-        free(m.rate[i]);
-    }
-    free(m.rate);
-    free(m.n_cols);
+    for (uint32_t i = 0; i < n_seqs; ++i) s->meth_rate[i] = m.rate[i] ? m.rate[i][0] : NULL;
+    s->meth_rate_cols = m.rate;
+    s->meth_n_cols = m.n_cols;
     return 0;
 }
 

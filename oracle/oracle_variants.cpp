@@ -385,6 +385,138 @@ uint32_t discrete_draw(const double *cp, size_t n, double u) {               // 
     return (uint32_t)i;
 }
 
+// Simulator::CTConversion with variants (Simulator.cpp:2004-2217), variable widths as there (read_pos is a uintReadLen, cur_meth an
+// intVariantId).  `deletion` is read before it is ever written in the reference; it starts as false here.  The uniform of template
+// position read_pos: word read_pos&3 of Philox block (start, sequence | sub<<22, length, 7<<28 | reversed<<27 | allele<<17 | read_pos>>2).
+struct MethDraw {
+    const orc_sim *s;
+    uint32_t c0, c1, c2, c3base;
+    double operator()(uint16_t read_pos) const { return orc_u32(orc_philox4x32_10(s->seed, c0, c1, c2, c3base | (read_pos >> 2)).w[read_pos & 3]); }
+};
+void ct_conversion_variants(const orc_sim *s, std::vector<uint8_t> &read, uint32_t seq_id, uint32_t start_pos, uint32_t allele, int32_t cur_methylation_start, bool reversed,
+                            const std::vector<Variant> &variants, std::pair<int32_t, uint32_t> first_variant, const MethDraw &draw) {
+    int32_t cur_meth = cur_methylation_start;
+    uint16_t read_pos = 0;
+    uint32_t ref_pos = start_pos;
+    const double *conversion_rate = s->meth_rate_cols[seq_id][1 < s->meth_n_cols[seq_id] ? allele : 0];      // Reference::Unmethylation (Reference.h:390-397)
+    const uint32_t *first = s->meth_first[seq_id], *second = s->meth_second[seq_id];
+    const int64_t n_regions = s->meth_n[seq_id], n_var = (int64_t)variants.size();
+    int32_t cur_var = first_variant.first;
+    uint32_t var_bases_left = 0;
+    bool deletion = false;
+    auto convert = [&]() {
+        if (1 == read.at(read_pos))
+            if (draw(read_pos) < conversion_rate[cur_meth]) read[read_pos] = 3;
+    };
+    if (reversed) {
+        if (0 <= cur_var && variants.at((size_t)cur_var).position == ref_pos && 1 < variants[(size_t)cur_var].var_seq.size() && variants[(size_t)cur_var].in_allele(allele))
+            var_bases_left = (uint32_t)variants[(size_t)cur_var].var_seq.size() - first_variant.second;
+        while (cur_meth < n_regions && first[cur_meth] <= ref_pos) ++cur_meth;
+        --cur_meth;
+        if (0 <= cur_meth && second[cur_meth] <= ref_pos) {
+            if (var_bases_left) {
+                read_pos = (uint16_t)(read_pos + var_bases_left);
+                var_bases_left = 0;
+                --ref_pos;
+                --cur_var;
+            }
+            while (0 <= cur_var && second[cur_meth] <= variants.at((size_t)cur_var).position && read_pos < read.size()) {
+                if (variants[(size_t)cur_var].in_allele(allele)) {
+                    read_pos = (uint16_t)(read_pos + (ref_pos - variants[(size_t)cur_var].position));
+                    read_pos = (uint16_t)(read_pos + variants[(size_t)cur_var].var_seq.size());
+                    ref_pos = variants[(size_t)cur_var].position - 1u;
+                }
+                --cur_var;
+            }
+            read_pos = (uint16_t)(read_pos + (ref_pos - (second[cur_meth] - 1u)));
+            ref_pos = second[cur_meth] - 1u;
+        }
+        while (0 <= cur_meth && read_pos < read.size()) {
+            while (ref_pos >= first[cur_meth] && read_pos < read.size()) {
+                if (0 == var_bases_left) {
+                    while (0 <= cur_var && variants.at((size_t)cur_var).position == ref_pos && !variants[(size_t)cur_var].in_allele(allele)) --cur_var;
+                    if (0 <= cur_var && variants.at((size_t)cur_var).position == ref_pos) {
+                        if (variants[(size_t)cur_var].var_seq.empty()) {
+                            deletion = true;
+                            --cur_var;
+                        } else var_bases_left = (uint32_t)variants[(size_t)cur_var].var_seq.size();
+                    }
+                }
+                if (deletion) deletion = false;
+                else convert();
+                if (var_bases_left)
+                    if (0 == --var_bases_left) --cur_var;
+                if (0 == var_bases_left) --ref_pos;
+                ++read_pos;
+            }
+            if (0 <= --cur_meth && second[cur_meth] <= ref_pos) {
+                while (0 <= cur_var && second[cur_meth] <= variants.at((size_t)cur_var).position && read_pos < read.size()) {
+                    if (variants[(size_t)cur_var].in_allele(allele)) {
+                        read_pos = (uint16_t)(read_pos + (ref_pos - variants[(size_t)cur_var].position));
+                        read_pos = (uint16_t)(read_pos + variants[(size_t)cur_var].var_seq.size());
+                        ref_pos = variants[(size_t)cur_var].position - 1u;
+                    }
+                    --cur_var;
+                }
+                read_pos = (uint16_t)(read_pos + (ref_pos - (second[cur_meth] - 1u)));
+                ref_pos = second[cur_meth] - 1u;
+            }
+        }
+    } else {
+        if (cur_var < n_var && variants.at((size_t)cur_var).position == ref_pos && 1 < variants[(size_t)cur_var].var_seq.size() && variants[(size_t)cur_var].in_allele(allele))
+            var_bases_left = (uint32_t)variants[(size_t)cur_var].var_seq.size() - first_variant.second;
+        if (cur_meth < n_regions && first[cur_meth] > ref_pos) {
+            if (var_bases_left) {
+                read_pos = (uint16_t)(read_pos + var_bases_left);
+                var_bases_left = 0;
+                ++ref_pos;
+                ++cur_var;
+            }
+            while (cur_var < n_var && first[cur_meth] > variants.at((size_t)cur_var).position && read_pos < read.size()) {
+                if (variants[(size_t)cur_var].in_allele(allele)) {
+                    read_pos = (uint16_t)(read_pos + (variants[(size_t)cur_var].position - ref_pos));
+                    read_pos = (uint16_t)(read_pos + variants[(size_t)cur_var].var_seq.size());
+                    ref_pos = variants[(size_t)cur_var].position + 1u;
+                }
+                ++cur_var;
+            }
+            read_pos = (uint16_t)(read_pos + (first[cur_meth] - ref_pos));
+            ref_pos = first[cur_meth];
+        }
+        while (cur_meth < n_regions && read_pos < read.size()) {
+            while (ref_pos < second[cur_meth] && read_pos < read.size()) {
+                if (0 == var_bases_left) {
+                    while (cur_var < n_var && variants.at((size_t)cur_var).position == ref_pos && !variants[(size_t)cur_var].in_allele(allele)) ++cur_var;
+                    if (cur_var < n_var && variants.at((size_t)cur_var).position == ref_pos) {
+                        if (variants[(size_t)cur_var].var_seq.empty()) {
+                            deletion = true;
+                            ++cur_var;
+                        } else var_bases_left = (uint32_t)variants[(size_t)cur_var].var_seq.size();
+                    }
+                }
+                if (deletion) deletion = false;
+                else convert();
+                if (var_bases_left)
+                    if (0 == --var_bases_left) ++cur_var;
+                if (0 == var_bases_left) ++ref_pos;
+                ++read_pos;
+            }
+            if (++cur_meth < n_regions && first[cur_meth] > ref_pos) {
+                while (cur_var < n_var && first[cur_meth] > variants.at((size_t)cur_var).position && read_pos < read.size()) {
+                    if (variants[(size_t)cur_var].in_allele(allele)) {
+                        read_pos = (uint16_t)(read_pos + (variants[(size_t)cur_var].position - ref_pos));
+                        read_pos = (uint16_t)(read_pos + variants[(size_t)cur_var].var_seq.size());
+                        ref_pos = variants[(size_t)cur_var].position + 1u;
+                    }
+                    ++cur_var;
+                }
+                read_pos = (uint16_t)(read_pos + (first[cur_meth] - ref_pos));
+                ref_pos = first[cur_meth];
+            }
+        }
+    }
+}
+
 // ---- the scenario driver of SimulatorTest::TestVariationInSimulateFromGivenBlock (SimulatorTest.cpp:116-364)
 struct VarScenario {
     std::vector<uint8_t> codes, comp_codes;            // the reference and the sequence with allele 1's variants applied
@@ -693,7 +825,6 @@ int orc_create_reads_var(const orc_sim *s, const orc_fragment_var *frags, uint64
         const orc_profile *p = s->p;
         const orc_reference *r = s->r;
         const VarState &st = state_of(s);
-        if (s->meth_n) throw Error("the oracle has no CTConversion with variants yet");
         std::unique_ptr<orc_read[]> rd(new orc_read[2]);
         orc_text *dst[2] = {r1, r2};
         for (uint64_t i = 0; i < n; ++i) {
@@ -713,6 +844,14 @@ int orc_create_reads_var(const orc_sim *s, const orc_fragment_var *frags, uint64
                                  : reference_sequence_with_variants(ref, f.start, tl, false, {f.start_var, f.start_var_pos}, f.allele);
             }
             const uint32_t c1 = f.seq | (f.sub << 22), c2 = f.len | ((uint32_t)f.dup << 16);
+            if (s->meth_n) {                                             // CTConversion's dispatcher :2219-2247: the forward template, then the reverse one
+                const int32_t cur_methylation_start = (int32_t)orc_methylation_start(s, f.seq, f.start);
+                for (uint32_t reversed = 0; reversed < 2; ++reversed) {
+                    const MethDraw draw{s, f.start, c1, f.len, (7u << 28) | (reversed << 27) | ((uint32_t)f.allele << 17)};
+                    if (!reversed) ct_conversion_variants(s, tmpl[strand], f.seq, f.start, f.allele, cur_methylation_start, false, sv.variants, {f.start_var, f.start_var_pos}, draw);
+                    else ct_conversion_variants(s, tmpl[!strand], f.seq, f.end, f.allele, cur_methylation_start, true, sv.variants, {f.end_var, f.end_var_pos}, draw);
+                }
+            }
             uint16_t tile_id = 0;
             if (1 < p->n_tiles)
                 tile_id = (uint16_t)discrete_draw(p->tile_cp, p->n_tiles, orc_u32(orc_philox4x32_10(s->seed, f.start, c1, c2, pair_c3(ORC_DOM_PAIR, strand, 2, f.allele)).w[0]));

@@ -257,7 +257,7 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, doubl
 // ---- the cell with variants (substitutions only): every allele is a copy of the packed reference with its substitutions applied, so
 // the per-allele GC modification and the surrounding edits of Simulator.cpp:1404-1896 are plain reads of that copy -- what the
 // reference's own test demands of them (SimulatorTest.cpp:116-195 compares with the sequence that has the variants applied).
-constexpr uint32_t kMaxDevAlleles = 8;             // 2 * alleles chosen (allele, strand) slots per cell live in registers
+constexpr uint32_t kMaxDevAlleles = 128;           // Reference::Variant::kMaxAlleles: 2 * alleles (allele, strand) slots per cell, in scratch memory
 RSQ_HD const uint64_t *hap_words(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.ref_words + (1u + allele) * S.hap_stride : S.ref_words; }
 RSQ_HD const uint32_t *hap_gc_prefix(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.gc_prefix + (1u + allele) * S.hap_stride : S.gc_prefix; }
 struct VarCell {
@@ -265,16 +265,24 @@ struct VarCell {
     uint16_t cnt[2 * kMaxDevAlleles];
     uint8_t id[2 * kMaxDevAlleles];                // allele * 2 + strand
 };
-// SelectAllele (Simulator.cpp:1341-1361); reverse_selection as a bit mask
-RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, uint32_t &selectable, uint32_t possible_strands, double random_value) {
+// SelectAllele (Simulator.cpp:1341-1361); reverse_selection as a bit mask over the 2 * alleles slots
+struct SlotMask {
+    uint32_t w[2 * kMaxDevAlleles / 32];
+    RSQ_HD void set_first(uint32_t n) {
+        for (uint32_t i = 0; i < 2 * kMaxDevAlleles / 32; ++i) w[i] = n >= 32u * (i + 1u) ? 0xFFFFFFFFu : (n > 32u * i ? (1u << (n - 32u * i)) - 1u : 0u);
+    }
+    RSQ_HD bool test(uint32_t id) const { return (w[id >> 5] >> (id & 31u)) & 1u; }
+    RSQ_HD void clear(uint32_t id) { w[id >> 5] &= ~(1u << (id & 31u)); }
+};
+RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, SlotMask &selectable, uint32_t possible_strands, double random_value) {
     uint32_t chosen_id = (uint32_t)(uint16_t)(random_value * (possible_strands - n_chosen));
     uint32_t replacement_correction = 0;
     for (uint32_t i = 0; i < n_chosen; ++i)
         if (chosen[i] <= chosen_id) ++replacement_correction;
     while (replacement_correction)
-        if ((selectable >> (++chosen_id)) & 1u) --replacement_correction;
+        if (selectable.test(++chosen_id)) --replacement_correction;
     chosen[n_chosen++] = (uint8_t)chosen_id;
-    selectable &= ~(1u << chosen_id);
+    selectable.clear(chosen_id);
 }
 RSQ_HD uint32_t word_of(const Words &w, uint32_t k) { return k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)); }
 // Streams (DESIGN.md "Random streams", rows "with variants"): SelectAllele's j-th value = word j&3 of block (start, seq, length,
@@ -288,7 +296,9 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     const uint32_t end = site.start + len;                                          // end_pos_shift_ is 0 without insertions and deletions
     if (!non_zero_strands || !(end < site.L)) return 0;
     uint8_t chosen[2 * kMaxDevAlleles];
-    uint32_t n_chosen = 0, selectable = (1u << possible_strands) - 1u, n_draws = 0;
+    uint32_t n_chosen = 0, n_draws = 0;
+    SlotMask selectable;
+    selectable.set_first(possible_strands);
     const bool direct = non_zero_strands <= possible_strands / 2u;                  // ChooseAlleles :1387-1397
     const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
     Words ws{0, 0, 0, 0};
@@ -300,7 +310,7 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     if (!direct) {                                                                  // ReverseSelection :1373-1385
         n_chosen = 0;
         for (uint32_t id = 0; id < possible_strands; ++id)
-            if ((selectable >> id) & 1u) chosen[n_chosen++] = (uint8_t)id;
+            if (selectable.test(id)) chosen[n_chosen++] = (uint8_t)id;
     }
     uint32_t n_here = 0;
     Words wc{0, 0, 0, 0};
@@ -340,7 +350,9 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     if (!non_zero_strands) return 0;
     const uint32_t c1 = site_c1(site);
     uint8_t chosen[2 * kMaxDevAlleles];
-    uint32_t n_chosen = 0, selectable = (1u << possible_strands) - 1u, n_draws = 0;
+    uint32_t n_chosen = 0, n_draws = 0;
+    SlotMask selectable;
+    selectable.set_first(possible_strands);
     const bool direct = non_zero_strands <= possible_strands / 2u;
     const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
     Words ws{0, 0, 0, 0};
@@ -352,7 +364,7 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     if (!direct) {
         n_chosen = 0;
         for (uint32_t id = 0; id < possible_strands; ++id)
-            if ((selectable >> id) & 1u) chosen[n_chosen++] = (uint8_t)id;
+            if (selectable.test(id)) chosen[n_chosen++] = (uint8_t)id;
     }
     uint32_t n_here = 0;
     Words wc{0, 0, 0, 0};
@@ -1081,12 +1093,14 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
 // Philox block (start, sequence, length, 7<<28 | reversed<<27 | k>>2).
 struct MethView {
     const uint32_t *first, *second;
-    const double *rate;
-    uint32_t n;
+    const double *rate;                 // of the allele asked for: rate[region * stride]
+    uint32_t n, stride;
+    RSQ_HD double rate_of(int32_t region) const { return rate[(size_t)region * stride]; }
 };
-RSQ_HD MethView meth_view(const DevSim &S, uint32_t seq) {
+// Reference::Unmethylation(seq, allele): meth_rate holds num_alleles values per region (a file with one column repeats it)
+RSQ_HD MethView meth_view(const DevSim &S, uint32_t seq, uint32_t allele = 0) {
     const uint32_t off = S.meth_ptr[seq];
-    return MethView{S.meth_first + off, S.meth_second + off, S.meth_rate + off, S.meth_ptr[seq + 1] - off};
+    return MethView{S.meth_first + off, S.meth_second + off, S.meth_rate + (size_t)off * S.num_alleles + allele, S.meth_ptr[seq + 1] - off, S.num_alleles};
 }
 // cur_methylation_start of SimulateFromGivenBlock (:2273,:2293-2297, CreateBlock :1214-1219): the first region that ends after pos
 RSQ_HD uint32_t meth_start_index(const MethView &m, uint32_t pos) {
@@ -1130,7 +1144,7 @@ RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, ui
         }
         while (cur_meth > 0 && read_pos < length) {
             while (ref_pos >= m.first[cur_meth] && read_pos < length) {
-                ct_convert_base(tmpl, read_pos, m.rate[cur_meth], d);
+                ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
                 --ref_pos;
                 ++read_pos;
             }
@@ -1146,11 +1160,129 @@ RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, ui
         }
         while (cur_meth < n && read_pos < length) {
             while (ref_pos < m.second[cur_meth] && read_pos < length) {
-                ct_convert_base(tmpl, read_pos, m.rate[cur_meth], d);
+                ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
                 ++ref_pos;
                 ++read_pos;
             }
             if (++cur_meth < n) {
+                read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
+                ref_pos = m.first[cur_meth];
+            }
+        }
+    }
+}
+
+// Simulator::CTConversion with variants (Simulator.cpp:2004-2217), restated like the plain one: read_pos is 16 bits wide, cur_meth
+// signed; `deletion` (read before it is written in the reference) starts as false.
+RSQ_HD void ct_conversion_variants(uint64_t *tmpl, uint32_t length, const MethView &m, const VarView &r, uint32_t start_pos, uint32_t allele, uint32_t cur_methylation_start,
+                                   bool reversed, VarStart first_variant, MethDraws &d) {
+    int32_t cur_meth = (int32_t)cur_methylation_start;
+    uint16_t read_pos = 0;
+    uint32_t ref_pos = start_pos;
+    const int32_t n = (int32_t)m.n, n_var = (int32_t)r.n;
+    int32_t cur_var = first_variant.first_variant_id;
+    uint32_t var_bases_left = 0;
+    bool deletion = false;
+    if (reversed) {
+        if (0 <= cur_var && r.v[cur_var].pos == ref_pos && 1u < r.v[cur_var].len && r.in_allele(r.v[cur_var], allele)) var_bases_left = r.v[cur_var].len - first_variant.start_variant_pos;
+        while (cur_meth < n && m.first[cur_meth] <= ref_pos) ++cur_meth;
+        --cur_meth;
+        if (0 <= cur_meth && m.second[cur_meth] <= ref_pos) {
+            if (var_bases_left) {
+                read_pos = (uint16_t)(read_pos + var_bases_left);
+                var_bases_left = 0;
+                --ref_pos;
+                --cur_var;
+            }
+            while (0 <= cur_var && m.second[cur_meth] <= r.v[cur_var].pos && read_pos < length) {
+                if (r.in_allele(r.v[cur_var], allele)) {
+                    read_pos = (uint16_t)(read_pos + (ref_pos - r.v[cur_var].pos));
+                    read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
+                    ref_pos = r.v[cur_var].pos - 1u;
+                }
+                --cur_var;
+            }
+            read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
+            ref_pos = m.second[cur_meth] - 1u;
+        }
+        while (0 <= cur_meth && read_pos < length) {
+            while (ref_pos >= m.first[cur_meth] && read_pos < length) {
+                if (0u == var_bases_left) {
+                    while (0 <= cur_var && r.v[cur_var].pos == ref_pos && !r.in_allele(r.v[cur_var], allele)) --cur_var;
+                    if (0 <= cur_var && r.v[cur_var].pos == ref_pos) {
+                        if (0u == r.v[cur_var].len) {
+                            deletion = true;
+                            --cur_var;
+                        } else var_bases_left = r.v[cur_var].len;
+                    }
+                }
+                if (deletion) deletion = false;
+                else ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
+                if (var_bases_left)
+                    if (0u == --var_bases_left) --cur_var;
+                if (0u == var_bases_left) --ref_pos;
+                ++read_pos;
+            }
+            if (0 <= --cur_meth && m.second[cur_meth] <= ref_pos) {
+                while (0 <= cur_var && m.second[cur_meth] <= r.v[cur_var].pos && read_pos < length) {
+                    if (r.in_allele(r.v[cur_var], allele)) {
+                        read_pos = (uint16_t)(read_pos + (ref_pos - r.v[cur_var].pos));
+                        read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
+                        ref_pos = r.v[cur_var].pos - 1u;
+                    }
+                    --cur_var;
+                }
+                read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
+                ref_pos = m.second[cur_meth] - 1u;
+            }
+        }
+    } else {
+        if (cur_var < n_var && r.v[cur_var].pos == ref_pos && 1u < r.v[cur_var].len && r.in_allele(r.v[cur_var], allele)) var_bases_left = r.v[cur_var].len - first_variant.start_variant_pos;
+        if (cur_meth < n && m.first[cur_meth] > ref_pos) {
+            if (var_bases_left) {
+                read_pos = (uint16_t)(read_pos + var_bases_left);
+                var_bases_left = 0;
+                ++ref_pos;
+                ++cur_var;
+            }
+            while (cur_var < n_var && m.first[cur_meth] > r.v[cur_var].pos && read_pos < length) {
+                if (r.in_allele(r.v[cur_var], allele)) {
+                    read_pos = (uint16_t)(read_pos + (r.v[cur_var].pos - ref_pos));
+                    read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
+                    ref_pos = r.v[cur_var].pos + 1u;
+                }
+                ++cur_var;
+            }
+            read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
+            ref_pos = m.first[cur_meth];
+        }
+        while (cur_meth < n && read_pos < length) {
+            while (ref_pos < m.second[cur_meth] && read_pos < length) {
+                if (0u == var_bases_left) {
+                    while (cur_var < n_var && r.v[cur_var].pos == ref_pos && !r.in_allele(r.v[cur_var], allele)) ++cur_var;
+                    if (cur_var < n_var && r.v[cur_var].pos == ref_pos) {
+                        if (0u == r.v[cur_var].len) {
+                            deletion = true;
+                            ++cur_var;
+                        } else var_bases_left = r.v[cur_var].len;
+                    }
+                }
+                if (deletion) deletion = false;
+                else ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
+                if (var_bases_left)
+                    if (0u == --var_bases_left) ++cur_var;
+                if (0u == var_bases_left) ++ref_pos;
+                ++read_pos;
+            }
+            if (++cur_meth < n && m.first[cur_meth] > ref_pos) {
+                while (cur_var < n_var && m.first[cur_meth] > r.v[cur_var].pos && read_pos < length) {
+                    if (r.in_allele(r.v[cur_var], allele)) {
+                        read_pos = (uint16_t)(read_pos + (r.v[cur_var].pos - ref_pos));
+                        read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
+                        ref_pos = r.v[cur_var].pos + 1u;
+                    }
+                    ++cur_var;
+                }
                 read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
                 ref_pos = m.first[cur_meth];
             }
@@ -1445,8 +1577,16 @@ RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, u
 RSQ_HD void variant_template(const DevSim &S, const Fragment &f, const FragmentVar &fv, uint32_t seg, uint64_t *tmpl, uint32_t template_words) {
     const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion, tl = f.len < want ? f.len : want;
     const VarView r = var_view(S, f.seq);
-    if (seg == f.strand) reference_sequence_with_variants(r, f.start, tl, false, VarStart{fv.start_var, fv.start_var_pos}, f.allele, tmpl, template_words);
-    else reference_sequence_with_variants(r, fv.end, tl, true, VarStart{fv.end_var, fv.end_var_pos}, f.allele, tmpl, template_words);
+    const bool reversed = seg != f.strand;
+    const VarStart from = reversed ? VarStart{fv.end_var, fv.end_var_pos} : VarStart{fv.start_var, fv.start_var_pos};
+    const uint32_t at = reversed ? fv.end : f.start;
+    reference_sequence_with_variants(r, at, tl, reversed, from, f.allele, tmpl, template_words);
+    if (S.meth_ptr) {                                                           // CTConversion with variants (:2232-2237)
+        const MethView m = meth_view(S, f.seq, f.allele);
+        MethDraws d{S.seed, f.start, f.seq | (fv.sub << 22), f.len, (kDomMethylation << 28) | ((reversed ? 1u : 0u) << 27) | ((uint32_t)f.allele << 17), 0xFFFFFFFFu,
+                    Words{0, 0, 0, 0}};
+        ct_conversion_variants(tmpl, tl, m, r, at, f.allele, meth_start_index(meth_view(S, f.seq), f.start), reversed, from, d);
+    }
 }
 
 template <class Tab>

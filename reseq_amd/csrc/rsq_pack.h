@@ -289,7 +289,8 @@ inline void pack_profile(SimState &s, Uploader &up) {
 // How the kernels simulate a variant set: 1 = substitutions only, at most one per position and allele: every allele gets its own copy
 // of the packed reference; 2 = anything else: the reference's per-allele bookkeeping per sieve cell (rsq_variants.h)
 inline int variants_mode_for(const Variants &v) {
-    if (v.num_alleles > kMaxDevAlleles) throw Error("variants: more than " + std::to_string(kMaxDevAlleles) + " alleles are not supported yet");
+    if (v.num_alleles > kMaxDevAlleles) throw Error("variants: more than " + std::to_string(kMaxDevAlleles) + " alleles");
+    if (v.num_alleles > 8) return 2;                               // a copy of the reference per allele only for a few alleles
     for (const std::vector<Variant> &seq : v.by_seq)
         for (size_t i = 0; i < seq.size(); ++i) {
             if (seq[i].var_seq.size() != 1) return 2;
@@ -862,8 +863,15 @@ inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
     for (size_t i = 0; i < m.first.size(); ++i) {
         first.insert(first.end(), m.first[i].begin(), m.first[i].end());
         second.insert(second.end(), m.second[i].begin(), m.second[i].end());
-        if (!m.rate[i].empty()) rate.insert(rate.end(), m.rate[i][0].begin(), m.rate[i][0].end());      // one allele without variants
+        for (size_t k = 0; k < m.first[i].size(); ++k)                                                   // num_alleles values per region: Reference::Unmethylation
+            for (uint32_t a = 0; a < s.num_alleles; ++a) rate.push_back(m.rate[i][1 < m.rate[i].size() ? a : 0][k]);
         ptr.push_back((uint32_t)first.size());
+    }
+    if (s.has_variants && 2 != s.variants_mode) {
+        // with methylation the templates are written out and converted per mate (k_variant_templates): the path for variants of any
+        // kind.  A substitution-only set has no starts inside inserted bases, so nothing else changes.
+        s.variants_mode = 2;
+        s.dev.variants_loaded = 2;
     }
     s.dev.meth_ptr = up.put(ptr);
     s.dev.meth_first = up.put(first);

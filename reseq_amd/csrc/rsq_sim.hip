@@ -319,7 +319,7 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     s.sizes.reserve(2 * n_pairs * 4 + 16);
     s.off_r1.reserve((n_pairs + 1) * 8);
     s.off_r2.reserve((n_pairs + 1) * 8);
-    if (frags && s.dev.meth_ptr) {                                   // --methylation: CTConversion of both mates' templates first
+    if (frags && s.dev.meth_ptr && !fvars) {                         // --methylation: CTConversion of both mates' templates first
         s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
         raw.templates = s.templates.as<uint64_t>();
         raw.template_words = s.template_words;
@@ -780,8 +780,7 @@ int rsq_sim_read_methylation(rsq_sim *s, const char *path) {
     REQUIRE(s && path && s->has_ref, "a simulator with a reference is needed");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
-        if (s->has_variants) throw Error("--methylation together with variants is not supported yet");
-        pack_methylation(*s, s->up, read_methylation_file(path, s->ref_first_names, s->seq_len));
+        pack_methylation(*s, s->up, read_methylation_file(path, s->ref_first_names, s->seq_len, s->num_alleles));
         return RSQ_OK;
     });
 }

@@ -294,8 +294,7 @@ int emu_read_sys_errors(void *h, const char *path) {
 int emu_read_methylation(void *h, const char *path) {
     return guard([&] {
         Emu &s = *static_cast<Emu *>(h);
-        if (s.has_variants) throw Error("--methylation together with variants is not supported yet");
-        pack_methylation(s, s.up, read_methylation_file(path, s.ref_first_names, s.seq_len));
+        pack_methylation(s, s.up, read_methylation_file(path, s.ref_first_names, s.seq_len, s.num_alleles));
         return 0;
     });
 }

@@ -513,14 +513,48 @@ def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels"
         p.close()
 
 
+def case_variants_with_methylation(backend_cls, workdir):
+    """--methylation together with -V: CTConversion with variants (Simulator.cpp:2004-2217) on the templates of the allele, with one
+    conversion rate per allele (two columns) or one for all (one column); substitutions, insertions and deletions inside and between
+    the regions; and a substitution-only set, which takes the same path once methylation is loaded"""
+    lengths = [6200, 80, 3100]
+    for tag, maker, seed in (("vmeth", _mixed_variant_set, 61), ("vmeth_subs", None, 67)):
+        rng = np.random.default_rng(seed)
+        seqs = make_inputs(workdir, tag, synth.TINY, lengths)[2]
+        vs = maker(seqs, rng, 20, [0, 5, 399, 400, 401, 419, 420, 421, 899, 900, 1499, 1500]) if maker else _substitution_set(seqs, rng, 25, [0, 399, 400, 420, 899, 1500])
+        vcf = workdir / f"{tag}.vcf"
+        write_vcf(vcf, seqs, vs)
+        names = [n.split(" ")[0] for n, _ in seqs]
+        bed = workdir / f"{tag}.bed"
+        bed.write_text(f"{names[0]}\t0\t400\t0.0\t0.5\n{names[0]}\t420\t421\t0.5\t0.0\n{names[0]}\t900\t1500\t0.25\t0.75\n{names[0]}\t2000\t6100\t0.1\t0.9\n"
+                       f"{names[2]}\t100\t3000\t0.3\n")
+        p = Pair(backend_cls, workdir, tag, synth.TINY, lengths, seed=seed, num_pairs=9000, vcf=vcf)
+        try:
+            p.b.read_methylation(bed)
+            p.osim.read_methylation(bed)
+            p.align_normalization()
+            tb = p.info["total_blocks"]
+            ofr, text = _compare_blocks_var(p, 1, tb + 1)
+            assert len(ofr) > 7000
+            plain = Pair(backend_cls, workdir, tag, synth.TINY, lengths, seed=seed, num_pairs=9000, vcf=vcf)
+            try:
+                plain.align_normalization()
+                _, text_plain = _compare_blocks_var(plain, 1, tb + 1)
+                assert text != text_plain and text.count(b"C") < text_plain.count(b"C")
+            finally:
+                plain.close()
+        finally:
+            p.close()
+
+
 def case_variants_rejected(backend_cls, workdir):
-    """what the kernels do not simulate is refused, not approximated: more than eight alleles"""
+    """more alleles than Reference::Variant::kMaxAlleles (128) are refused with the reference's message (Reference.cpp:1016-1019)"""
     import pytest
     lengths = [3000]
     seqs = make_inputs(workdir, "vars_rej", synth.TINY, lengths)[2]
     vcf = workdir / "many.vcf"
     alt = "A" if seqs[0][1][100] != 0 else "C"
-    write_vcf(vcf, seqs, [(0, 100, 1, alt, "\t".join(["0|1"] * 5))], samples=5)
+    write_vcf(vcf, seqs, [(0, 100, 1, alt, "\t".join(["0|1"] * 65))], samples=65)
     ppath, fpath, _ = make_inputs(workdir, "vars_rej", synth.TINY, lengths)
-    with pytest.raises(Exception, match="more than 8 alleles"):
+    with pytest.raises(Exception, match="only 128 alleles are supported"):
         backend_cls(ppath, fpath, 0, None, vcf_path=vcf)

@@ -160,7 +160,17 @@ def test_variants_insertions_and_deletions_dense_four_alleles(workdir):
     P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="indels4", lengths=(5300, 2600), samples=2)
 
 
-def test_variants_not_simulated_yet_are_refused(workdir):
+def test_variants_with_methylation(workdir):
+    P.case_variants_with_methylation(GpuBackend, workdir)
+
+
+def test_variants_many_alleles(workdir):
+    """ten alleles (five samples) and the maximum of 128 (64 samples): ChooseAlleles over up to 256 (allele, strand) slots"""
+    P.case_variants_indels(GpuBackend, workdir, density=25, seed=53, tag="alleles10", lengths=(3300, 2100), samples=5)
+    P.case_variants_indels(GpuBackend, workdir, density=40, seed=59, tag="alleles128", lengths=(3100,), samples=64)
+
+
+def test_variants_more_alleles_than_the_reference_supports_are_refused(workdir):
     P.case_variants_rejected(GpuBackend, workdir)
 
 
