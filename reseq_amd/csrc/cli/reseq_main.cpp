@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../../include/reseq_amd.h"
+#include "../rsq_textio.h"
 
 namespace {
 
@@ -120,54 +121,60 @@ bool load_profile(const Args &a, rsq_profile **p) {
     return true;
 }
 
-// FASTQ / FASTA text files: gzip when the name ends in .gz (SeqAn's SeqFileOut / SeqFileIn pick the format the same way)
+// FASTQ / FASTA text files: gzip / bzip2 when the name ends in .gz / .bz2, inputs by content (SeqAn's SeqFileOut / SeqFileIn pick the
+// format the same way); no file = stdout / stdin
 struct TextOut {
-    FILE *plain = nullptr;
-    gzFile gz = nullptr;
+    rsq::textio::Writer w;
     bool failed = false;
     bool open(const std::string &path) {
-        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) gz = gzopen(path.c_str(), "wb");
-        else plain = fopen(path.c_str(), "wb");
-        return plain || gz;
+        try {
+            return w.open(path);
+        } catch (const std::exception &e) {
+            ERR(e.what());
+            return false;
+        }
     }
     void write(const char *data, size_t n) {
-        if (gz) {
-            for (size_t done = 0; done < n && !failed;) {
-                const unsigned chunk = (unsigned)std::min<size_t>(n - done, 1u << 30);
-                failed = gzwrite(gz, data + done, chunk) != (int)chunk;
-                done += chunk;
-            }
-        } else if (plain) failed = failed || fwrite(data, 1, n, plain) != n;
-        else fwrite(data, 1, n, stdout);
+        if (w.is_open()) w.write(data, n);
+        else failed = failed || fwrite(data, 1, n, stdout) != n;
     }
-    bool good() const { return !failed; }
-    void close() {
-        if (gz) failed = (gzclose(gz) != Z_OK) || failed;
-        if (plain) failed = (fclose(plain) != 0) || failed;
-        gz = nullptr;
-        plain = nullptr;
-    }
+    bool good() const { return !failed && !w.failed; }
+    void close() { failed = !w.close() || failed; }
 };
-struct TextIn {                       // lines of a plain or gzip file, or of stdin
-    gzFile gz = nullptr;
+struct TextIn {                       // lines of a plain, gzip or bzip2 file, or of stdin
+    rsq::textio::Reader r;
+    bool is_file = false;
     std::vector<char> buf = std::vector<char>(1 << 16);
-    bool open(const std::string &path) { return (gz = gzopen(path.c_str(), "rb")) != nullptr; }
+    size_t at = 0, have = 0;
+    bool open(const std::string &path) {
+        try {
+            return is_file = r.open(path);
+        } catch (const std::exception &e) {
+            ERR(e.what());
+            return false;
+        }
+    }
     bool getline(std::string &line) {
-        if (!gz) return (bool)std::getline(std::cin, line);
+        if (!is_file) return (bool)std::getline(std::cin, line);
         line.clear();
-        while (gzgets(gz, buf.data(), (int)buf.size())) {
-            line += buf.data();
-            if (!line.empty() && line.back() == '\n') {
-                line.pop_back();
+        for (;;) {
+            if (at == have) {
+                const int n = r.read(buf.data(), (unsigned)buf.size());
+                if (n <= 0) return !line.empty();
+                at = 0;
+                have = (size_t)n;
+            }
+            const char *p = buf.data() + at, *e = (const char *)memchr(p, '\n', have - at);
+            if (e) {
+                line.append(p, (size_t)(e - p));
+                at += (size_t)(e - p) + 1;
                 return true;
             }
+            line.append(p, have - at);
+            at = have;
         }
-        return !line.empty();
     }
-    void close() {
-        if (gz) gzclose(gz);
-        gz = nullptr;
-    }
+    void close() { r.close(); }
 };
 
 struct DevBuffer {

@@ -1,6 +1,7 @@
 // rsq_host.cpp -- RSQP container reader, profile loading and post-load edits, FASTA reader.
 #include <stdio.h>
 #include "rsq_host.h"
+#include "rsq_textio.h"
 
 #include <string.h>
 #include <zlib.h>
@@ -201,21 +202,19 @@ void Profile::remove_indel_errors() {
 
 // ---------------------------------------------------------------------------------------------- reference
 namespace {
-// plain or gzip-compressed text (zlib reads both through the same calls; SeqAn picks the format the same way)
+// plain, gzip- or bzip2-compressed text (rsq_textio.h; SeqAn picks the format the same way)
 struct GzLines {
-    gzFile f;
+    textio::Reader f;
     std::vector<char> buf;
     size_t at = 0, have = 0;
-    explicit GzLines(const std::string &path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) {
-        if (!f) throw Error("Could not open " + path + " for reading.");
-        gzbuffer(f, 1 << 20);
+    explicit GzLines(const std::string &path) : buf(1 << 20) {
+        if (!f.open(path)) throw Error("Could not open " + path + " for reading.");
     }
-    ~GzLines() { gzclose(f); }
     bool getline(std::string &line) {
         line.clear();
         for (;;) {
             if (at == have) {
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                const int n = f.read(buf.data(), (unsigned)buf.size());
                 if (n < 0) throw Error("read error in a compressed input file");
                 if (n == 0) return !line.empty();
                 at = 0;
@@ -390,38 +389,21 @@ std::vector<SysErrorRecord> parse_sys_error_fastq(const std::string &text) {
     }
     return recs;
 }
-static bool ends_with_gz(const std::string &path) { return path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
-std::string read_text_file(const std::string &path) {                       // plain or gzip
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw Error("Could not open '" + path + "' for reading.");
+std::string read_text_file(const std::string &path) {                       // plain, gzip or bzip2
+    textio::Reader f;
+    if (!f.open(path)) throw Error("Could not open '" + path + "' for reading.");
     std::string text;
     std::vector<char> buf(1 << 20);
     int n;
-    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) text.append(buf.data(), (size_t)n);
-    gzclose(f);
+    while ((n = f.read(buf.data(), (unsigned)buf.size())) > 0) text.append(buf.data(), (size_t)n);
     if (n < 0) throw Error("Could not read '" + path + "'.");
     return text;
 }
-void write_text_file(const std::string &path, const std::string &text) {   // gzip when the name ends in .gz, like SeqAn's SeqFileOut
-    if (ends_with_gz(path)) {
-        gzFile f = gzopen(path.c_str(), "wb");
-        if (!f) throw Error("Could not open '" + path + "' for writing.");
-        size_t done = 0;
-        while (done < text.size()) {
-            const unsigned chunk = (unsigned)std::min<size_t>(text.size() - done, 1u << 30);
-            if (gzwrite(f, text.data() + done, chunk) != (int)chunk) {
-                gzclose(f);
-                throw Error("Could not write '" + path + "'.");
-            }
-            done += chunk;
-        }
-        if (gzclose(f) != Z_OK) throw Error("Could not write '" + path + "'.");
-        return;
-    }
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) throw Error("Could not open '" + path + "' for writing.");
-    const size_t n = fwrite(text.data(), 1, text.size(), f);
-    if (fclose(f) != 0 || n != text.size()) throw Error("Could not write '" + path + "'.");
+void write_text_file(const std::string &path, const std::string &text) {   // gzip / bzip2 when the name ends in .gz / .bz2, like SeqAn's SeqFileOut
+    textio::Writer f;
+    if (!f.open(path)) throw Error("Could not open '" + path + "' for writing.");
+    f.write(text.data(), text.size());
+    if (!f.close()) throw Error("Could not write '" + path + "'.");
 }
 
 std::vector<double> read_ref_bias_file(const std::string &path, const std::vector<std::string> &first_names) {

@@ -104,6 +104,26 @@ def test_gzip_fasta_loads_like_plain(workdir):
     b.close()
 
 
+def test_bzip2_fasta_in_and_out(workdir):
+    """the reference also reads and writes .bz2 (SeqAn with BZip2, ReferenceTest.BZip2); libbz2 is bound at run time (rsq_textio.h)"""
+    import bz2
+    plain = os.path.join(GOLDEN, "reference-test.fa")
+    packed = workdir / "reference-test.fa.bz2"
+    packed.write_bytes(bz2.compress(open(plain, "rb").read()))
+    a, b = api.Reference(plain), api.Reference(str(packed))
+    assert a.num_sequences() == b.num_sequences() == 2
+    for i in range(2):
+        assert np.array_equal(a.codes(i), b.codes(i))
+    out = workdir / "again.fa.bz2"
+    b.write_fasta(out)
+    assert out.read_bytes()[:3] == b"BZh"
+    c = api.Reference(str(out))
+    for i in range(2):
+        assert np.array_equal(a.codes(i), c.codes(i))
+    for r in (a, b, c):
+        r.close()
+
+
 def test_replace_n_cli_mode_and_write_fasta(workdir):
     """`reseq replaceN -r in -R out --seed s` (main.cpp:611-692): ReadFasta, ReplaceN, WriteFasta -- host code only, no GPU needed"""
     import subprocess

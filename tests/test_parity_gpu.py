@@ -127,6 +127,14 @@ def test_cli_gzip_output_and_input(workdir):
     subprocess.run([exe, "illuminaPE", "-R", fgz, "-s", ppath, "--numReads", "1200", "--seed", "9", "-1", b1, "-2", b2, "--readSysError", prof], check=True, capture_output=True)
     assert gzip.open(b1, "rb").read() == open(a1, "rb").read() and gzip.open(b2, "rb").read() == open(a2, "rb").read()
     assert open(b1, "rb").read()[:2] == b"\x1f\x8b" and gzip.open(prof, "rb").read().count(b"\n") == 16
+    # the same with bzip2: reference and systematic-error profile in, FASTQ out
+    import bz2
+    fbz, pbz = str(workdir / "cli_gz.fa.bz2"), str(workdir / "cli_gz_sys.fq.bz2")
+    open(fbz, "wb").write(bz2.compress(open(fpath, "rb").read()))
+    open(pbz, "wb").write(bz2.compress(gzip.open(prof, "rb").read()))
+    c1, c2 = str(workdir / "g1.fq.bz2"), str(workdir / "g2.fq.bz2")
+    subprocess.run([exe, "illuminaPE", "-R", fbz, "-s", ppath, "--numReads", "1200", "--seed", "9", "-1", c1, "-2", c2, "--readSysError", pbz], check=True, capture_output=True)
+    assert bz2.decompress(open(c1, "rb").read()) == open(a1, "rb").read() and bz2.decompress(open(c2, "rb").read()) == open(a2, "rb").read()
 
 
 def test_simulate_module_equals_cli(workdir):
