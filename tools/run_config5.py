@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] (human-sized reference, phased VCF with substitutions and short
+insertions / deletions, methylation BED, coverage 30) on ONE GPU at a chosen scale (default 1/10: 310 Mb in 24 sequences, 0.4 M
+substitutions + 40 k insertions / deletions of at most 20 bases on two alleles, 2 M unmethylated regions with Beta(0.5, 0.5)
+methylation, about 31 M pairs).  Prints one JSON line: sizes, pre-pass and generation times per stage, a checksum, and that a
+second batching writes the same bytes (pairs, total bytes, SHA-256 of the first 6000 blocks).  Not a bench line."""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from reseq_amd import api, synth  # noqa: E402
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+HUMAN = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
+         101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+lengths = [max(5000, int(n * scale)) for n in HUMAN]
+rng = np.random.default_rng(11)
+tmp = tempfile.mkdtemp(prefix="rsq_c5_")
+ppath, fpath, vpath, bpath = (os.path.join(tmp, n) for n in ("p0.rsqp", "ref.fa", "var.vcf", "meth.bed"))
+synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
+t0 = time.perf_counter()
+seqs = synth.make_reference(9, lengths, gc=0.41)
+synth.write_fasta(fpath, seqs)
+total = int(sum(lengths))
+n_sub, n_indel, n_regions = int(4.0e6 * scale), int(0.4e6 * scale), int(20e6 * scale)
+names = [n.split(" ")[0] for n, _ in seqs]
+letters = np.frombuffer(b"ACGT", np.uint8)
+with open(vpath, "w") as f:
+    f.write("##fileformat=VCFv4.2\n" + "".join(f"##contig=<ID={n},length={len(c)}>\n" for n, (_, c) in zip(names, seqs)))
+    f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n")
+    for si, (_, codes) in enumerate(seqs):
+        L = len(codes)
+        k = int((n_sub + n_indel) * L / total)
+        pos = np.unique(rng.integers(1, L - 50, k))
+        pos = pos[np.concatenate(([True], np.diff(pos) > 25))]                 # non-overlapping, as a normalised VCF would have them
+        kinds = rng.random(len(pos)) < n_indel / (n_sub + n_indel)
+        gts = rng.integers(0, 3, len(pos))
+        lines = []
+        for p0, is_indel, g in zip(pos.tolist(), kinds.tolist(), gts.tolist()):
+            gt = ("0|1", "1|0", "1|1")[g]
+            ref = chr(letters[codes[p0]])
+            if not is_indel:
+                alt = chr(letters[(codes[p0] + 1 + p0 % 3) % 4])
+                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT\t{gt}")
+            elif p0 & 1:
+                ins = letters[rng.integers(0, 4, 1 + p0 % 20)].tobytes().decode()
+                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{ref}\t{ref + ins}\t.\tPASS\t.\tGT\t{gt}")
+            else:
+                dl = 1 + p0 % 20
+                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{letters[codes[p0:p0 + dl + 1]].tobytes().decode()}\t{ref}\t.\tPASS\t.\tGT\t{gt}")
+        f.write("\n".join(lines) + "\n")
+with open(bpath, "w") as f:
+    for si, (_, codes) in enumerate(seqs):
+        L = len(codes)
+        k = int(n_regions * L / total)
+        starts = np.unique(rng.integers(0, L - 200, k))
+        starts = starts[np.concatenate(([True], np.diff(starts) > 120))]
+        lens = rng.integers(1, 100, len(starts))
+        meth = rng.beta(0.5, 0.5, (len(starts), 2))
+        f.write("".join(f"{names[si]}\t{a}\t{a + b}\t{m0:.4f}\t{m1:.4f}\n" for a, b, (m0, m1) in zip(starts.tolist(), lens.tolist(), meth.tolist())))
+t_make = time.perf_counter() - t0
+
+t0 = time.perf_counter()
+prof, ref = api.Profile(ppath), api.Reference(fpath, 7)
+alleles = ref.read_variants(vpath)
+sim = api.Simulator(prof, ref, 0)
+sim.read_methylation(bpath)
+t_load = time.perf_counter() - t0
+t0 = time.perf_counter()
+info = sim.prepare(7, 0, 30.0)
+t_prep = time.perf_counter() - t0
+nb = info.total_blocks
+out = {}
+r1 = r2 = None
+for name, batch in (("batch_3000", 3000), ("batch_1500", 1500)):
+    h1, h2 = hashlib.sha256(), hashlib.sha256()
+    n = nbytes = 0
+    t_gpu = 0.0
+    kernel_ms = {}
+    for lo in range(1, nb + 1, batch):
+        hi = min(nb + 1, lo + batch)
+        if r1 is None:
+            _, l1, l2, _ = sim.pairs_device(lo, hi, None, None)
+            r1, r2 = api.DeviceArray(0, int(l1 * 1.5) + 4096), api.DeviceArray(0, int(l2 * 1.5) + 4096)
+        t1 = time.perf_counter()
+        k, l1, l2, rc = sim.pairs_device(lo, hi, r1, r2)
+        t_gpu += time.perf_counter() - t1
+        if rc != api.RSQ_OK:
+            raise SystemExit(f"rc {rc}: {api.lib().rsq_last_error().decode()}")
+        for key in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"):
+            kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
+        n += k
+        nbytes += l1 + l2
+        if hi <= 6001:                                           # checksum of the first 6000 blocks only: the text is hundreds of GB at full scale
+            h1.update(r1.to_numpy(np.uint8, l1).tobytes())
+            h2.update(r2.to_numpy(np.uint8, l2).tobytes())
+    out[name] = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
+    out[name]["sha256_first_6000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
+print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
+                  "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
+                  "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "prepare_s": round(t_prep, 2),
+                  "runs": out, "pairs_per_s_gpu": out["batch_3000"]["pairs"] / out["batch_3000"]["gpu_s"],
+                  "batching_invariant": out["batch_3000"]["pairs"] == out["batch_1500"]["pairs"] and out["batch_3000"]["fastq_bytes"] == out["batch_1500"]["fastq_bytes"] and
+                  out["batch_3000"]["sha256_first_6000_blocks"] == out["batch_1500"]["sha256_first_6000_blocks"]}))
