@@ -12,6 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <mutex>
+#include <thread>
+
 #include "rsq_host.h"
 #include "rsq_kernels.h"
 
@@ -21,6 +25,7 @@ struct Uploader {                                   // copies a host array to wh
     virtual void *put_bytes(const void *data, size_t bytes) = 0;
     virtual void write_bytes(void *dst, const void *src, size_t bytes) = 0;      // overwrite part of an array put earlier
     virtual void read_bytes(void *dst_host, const void *src, size_t bytes) = 0;   // read back what the pre-pass kernels wrote
+    virtual void bind_thread() {}                                                 // called once by every helper thread that will call read_bytes
     virtual ~Uploader() {}
     template <class T>
     T *put(const std::vector<T> &v) {
@@ -670,12 +675,13 @@ inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t n
     // variants of any kind: where the extra starts of every block begin (index b = block id; [total_blocks + 1] = all of them)
     std::vector<uint32_t> block_extra_ptr(s.total_blocks + 2, 0);
     if (2 == s.variants_mode) {
-        for (uint32_t i = 0; i < n_seqs; ++i)
+        for (uint32_t i = 0; i < n_seqs; ++i) {
+            uint32_t k = s.extra_seq_ptr[i];                         // the extras of a sequence are sorted by position
             for (uint32_t b = 0; b < s.n_blocks[i]; ++b) {
-                uint32_t k = s.extra_seq_ptr[i];
                 while (k < s.extra_seq_ptr[i + 1] && s.extra[k].pos < b * kBlockSize) ++k;
                 block_extra_ptr[s.first_block[i] + b] = k;
             }
+        }
         block_extra_ptr[s.total_blocks + 1] = (uint32_t)s.extra.size();
         block_extra_ptr[0] = 0;
     }
@@ -806,15 +812,38 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
 // both strands of every simulated sequence (CreateUnit: the reverse strand first); the tracks come back from the device
 inline void build_variant_sys_errors(SimState &s, Uploader &up) {
     if (!s.has_variants || s.variants.empty()) return;
-    std::vector<uint16_t> track;
-    for (uint32_t seq = 0; seq < s.dev.n_seqs; ++seq) {
-        if (!s.n_blocks[seq] || s.var_ptr[seq] == s.var_ptr[seq + 1]) continue;
-        track.resize(s.seq_len[seq]);
-        for (int strand = 2; strand--;) {
-            up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq], track.size() * sizeof(uint16_t));
-            variant_sys_errors_strand(s, seq, strand != 0, track.data());
+    // (sequence, strand) tasks are independent (own variants, own error arrays): a few host threads share them, longest first
+    std::vector<std::pair<uint32_t, int>> tasks;
+    for (uint32_t seq = 0; seq < s.dev.n_seqs; ++seq)
+        if (s.n_blocks[seq] && s.var_ptr[seq] != s.var_ptr[seq + 1])
+            for (int strand = 2; strand--;) tasks.emplace_back(seq, strand);
+    std::stable_sort(tasks.begin(), tasks.end(), [&](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) { return s.seq_len[a.first] > s.seq_len[b.first]; });
+    std::atomic<size_t> next{0};
+    std::mutex err_mutex;
+    std::string error;
+    auto work = [&](bool helper) {
+        try {
+            if (helper) up.bind_thread();
+            std::vector<uint16_t> track;
+            for (size_t t; (t = next.fetch_add(1)) < tasks.size();) {
+                const uint32_t seq = tasks[t].first;
+                const int strand = tasks[t].second;
+                track.resize(s.seq_len[seq]);
+                up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq], track.size() * sizeof(uint16_t));
+                variant_sys_errors_strand(s, seq, strand != 0, track.data());
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            error = e.what();
         }
-    }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    std::vector<std::thread> helpers;
+    for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(work, true);
+    work(false);
+    for (std::thread &t : helpers) t.join();
+    if (!error.empty()) throw Error(error);
     up.write_bytes(s.dev_var_err_fwd, s.var_err_fwd.data(), s.var_err_fwd.size() * sizeof(uint16_t));
     up.write_bytes(s.dev_var_err_rev, s.var_err_rev.data(), s.var_err_rev.size() * sizeof(uint16_t));
 }

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -95,6 +96,8 @@ struct rsq_ref {
 // arrays packed by rsq_pack.h go to HBM; they live as long as the simulator
 struct DeviceUploader : Uploader {
     std::vector<std::unique_ptr<DevBuf>> owned;
+    int device = 0;
+    void bind_thread() override { HIP_CHECK(hipSetDevice(device)); }
     void *put_bytes(const void *data, size_t bytes) override {
         owned.emplace_back(new DevBuf());
         owned.back()->reserve(bytes + 8);
@@ -191,14 +194,25 @@ static void bias_normalization(rsq_sim &s, hipStream_t st) {
 
 static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
     HIP_CHECK(hipSetDevice(s.device));
+    const bool trace = getenv("RSQ_TRACE_PREPARE") != nullptr;      // stage times of the pre-pass on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+        if (trace) fprintf(stderr, "prepare: %-28s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
+        t0 = now();
+    };
+    auto t0 = now();
     plan_simulation(s, s.up, seed, num_read_pairs, coverage, ref_bias_mode, base_identifier);
+    lap("plan", t0);
     if (s.has_ref) {
         bias_normalization(s, st);
         upload_normalization(s, s.up);
+        lap("bias normalisation", t0);
     }
     s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);
     HIP_CHECK(hipStreamSynchronize(st));
+    lap("systematic-error chains", t0);
     build_variant_sys_errors(s, s.up);                              // -V: the variants' bases, from the finished chains
+    lap("variants' systematic errors", t0);
     s.prepared = true;
 }
 
@@ -682,6 +696,7 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     int rc = guard([&] {
         HIP_CHECK(hipSetDevice(device));
         s->device = device;
+        s->up.device = device;
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
