@@ -136,7 +136,7 @@ typedef struct {
     uint16_t dup;
     uint8_t strand, pad;
     uint32_t block, number;
-} rsq_fragment;
+} rsq_fragment;   /* with insertion / deletion variants the reference span of a fragment is not [start, start + len): the read ids carry the real end */
 
 /* The hot path: Simulator::SimulationThread over blocks [block_lo, block_hi) (reseq/Simulator.cpp:2384-2401):
  * coverage sieve, CreateReads, FASTQ text of both mates.  r1_dev / r2_dev receive the two FASTQ streams in

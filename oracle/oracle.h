@@ -260,6 +260,7 @@ typedef struct orc_sim {
     /* variants (oracle_variants.cpp): NumAlleles() and the per-sequence variants with their systematic errors */
     uint16_t num_alleles;
     void *var_state;
+    const void *variants_source;      /* the orc_variants the state was built from (kept to rebuild it after --readSysError) */
 } orc_sim;
 
 /* Simulator.cpp:2655-2898 up to "Starting read generation": pairs, thresholds, sys errors */

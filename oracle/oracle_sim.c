@@ -1246,6 +1246,14 @@ int orc_sim_load_sys_errors(orc_sim *s, const char *text, size_t len, char *err,
             }
         }
     }
+    if (s->var_state) {                                                  /* the variants' errors are drawn after the records are read (CreateUnit / CreateBlock) */
+        const orc_variants *vs = s->variants_source;
+        orc_var_detach(s);
+        if (orc_var_attach(s, vs)) {
+            if (err) snprintf(err, err_cap, "%s", orc_var_last_error());
+            return -1;
+        }
+    }
     return 0;
 }
 

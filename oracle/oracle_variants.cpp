@@ -666,6 +666,7 @@ int orc_var_attach(orc_sim *s, const orc_variants *vs) {
             sys_error_variants_forward(s, i, sv, st->num_alleles);
         }
         s->var_state = st.release();
+        s->variants_source = vs;
         return 0;
     });
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RSQ_LIB", os.path.join(_HERE, "libreseq_amd.so"))    
 RSQ_OK, RSQ_EINVAL, RSQ_EIO, RSQ_ENODEV, RSQ_EHIP, RSQ_ENOSPC, RSQ_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
 FRAGMENT_DTYPE = np.dtype([("seq", "<u4"), ("start", "<u4"), ("len", "<u4"), ("dup", "<u2"), ("strand", "u1"),
-                           ("pad", "u1"), ("block", "<u4"), ("number", "<u4")])
+                           ("allele", "u1"), ("block", "<u4"), ("number", "<u4")])
 
 
 class SimInfo(C.Structure):

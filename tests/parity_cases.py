@@ -399,7 +399,7 @@ def _compare_blocks_var(p, lo, hi):
     assert len(ofr) == len(bfr)
     for name in ("seq", "start", "len", "dup", "strand", "block", "number"):
         assert np.array_equal(ofr[name], bfr[name]), name
-    assert np.array_equal(ofr["allele"], bfr["pad"])       # the product keeps the allele in the byte that is padding without variants
+    assert np.array_equal(ofr["allele"], bfr["allele"])
     assert o1 == b1
     assert o2 == b2
     return ofr, o1
@@ -509,6 +509,36 @@ def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels"
         assert shift.min() < 0 < shift.max()                  # insertions shorten, deletions lengthen the reference span
         part, _ = _compare_blocks_var(p, 2, 5)                # batching by block range
         assert len(part) == int(((ofr["block"] >= 2) & (ofr["block"] < 5)).sum())
+    finally:
+        p.close()
+
+
+def case_variants_with_loaded_sys_errors(backend_cls, workdir):
+    """--readSysError together with -V: the variants' own errors are drawn against the LOADED tracks (their error-region state follows
+    the file's rates: SetSystematicErrorVariants* run after ReadSystematicErrors, Simulator.cpp:983-986,1232-1234)"""
+    lengths = [5200, 3100]
+    rng = np.random.default_rng(71)
+    seqs = make_inputs(workdir, "vsys", synth.TINY, lengths)[2]
+    vcf = workdir / "vsys.vcf"
+    write_vcf(vcf, seqs, _mixed_variant_set(seqs, rng, 20, [0, 999, 1000]))
+    donor = Pair(backend_cls, workdir, "vsys", synth.TINY, lengths, seed=5, num_pairs=100)      # a profile drawn with another seed
+    prof = workdir / "vsys_profile.fq"
+    try:
+        donor.b.create_sys_error_profile(99, prof)
+    finally:
+        donor.close()
+    p = Pair(backend_cls, workdir, "vsys", synth.TINY, lengths, seed=73, num_pairs=6000, vcf=vcf)
+    try:
+        before = [p.osim.var_sys_errors(0, 0, i) for i in range(p.ovars.contents.n[0])]
+        p.b.read_sys_errors(prof)
+        p.osim.load_sys_errors(prof.read_bytes())
+        after = [p.osim.var_sys_errors(0, 0, i) for i in range(p.ovars.contents.n[0])]
+        assert any(not np.array_equal(a[1], b[1]) or not np.array_equal(a[0], b[0]) for a, b in zip(before, after))
+        if hasattr(p.b, "variant_sys_errors"):
+            _compare_variant_sys_errors(p, [0, 1])
+        p.align_normalization()
+        ofr, _ = _compare_blocks_var(p, 1, p.info["total_blocks"] + 1)
+        assert len(ofr) > 4000
     finally:
         p.close()
 
