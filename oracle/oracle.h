@@ -372,6 +372,11 @@ int orc_create_reads_var(const orc_sim *s, const orc_fragment_var *frags, uint64
 /* every evaluated (start, pass, length, allele) of the sieve calls since the last query: how many were re-derived from a fresh
  * VariantBiasVarModifiers, and how many of those differed from the incrementally updated one */
 void orc_var_scratch_counters(uint64_t *checks, uint64_t *mismatches);
+/* with the check enabled, every cell the sieve evaluates is also compared with the sequence that has the allele's variants applied (the
+ * comparison SimulatorTest.cpp:116-195 makes): out[0] = cells compared, out[1..5] = mismatches of GC percent, start surrounding, end
+ * surrounding, forward template, reverse template */
+void orc_var_haplotype_check(int enable);
+void orc_var_haplotype_counters(uint64_t *out);
 /* utilitiesTest.cpp:61-137 DominantBaseWithMemory script: op 0 Clear, 1 Set(seq, arg), 2 Update(seq[arg]), 3 copy from the other object */
 void orc_dombase_memory_script(const uint8_t *seq, uint32_t len, uint32_t n_ops, const uint8_t *which, const uint8_t *op, const uint32_t *arg, uint8_t *out);
 /* SimulatorTest::TestVariationInSimulateFromGivenBlock driver */

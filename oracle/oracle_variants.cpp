@@ -687,6 +687,41 @@ uint32_t orc_var_sys_errors(const orc_sim *s, int strand, uint32_t seq, uint32_t
 // do-while loop at one start position (starts inside inserted bases); the cell uniform as without variants; SelectAllele's j-th
 // random value: word j&3 of block (start, c1, length, 1<<28 | 2 + (j>>2)); the count uniform of the j-th chosen strand: u53 of words
 // 2(j&1), 2(j&1)+1 of block (start, c1, length, 1<<28 | 128 + (j>>1)).
+// property check in the spirit of SimulatorTest::TestVariationInInnerLoopOfSimulateFromGivenBlock (SimulatorTest.cpp:116-195), for every
+// cell the sieve evaluates: GC percent, start / end surrounding and both templates of the allele equal what the sequence WITH the
+// allele's variants applied gives at the corresponding position.  Cells whose 30-base windows would wrap around a sequence end are
+// left out (the variant edits stop at the ends).  g_hap[0] = cells compared, [1..5] = mismatches of gc, start surrounding, end
+// surrounding, forward template, reverse template.
+static uint64_t g_hap[6] = {0, 0, 0, 0, 0, 0};
+static bool g_hap_check = false;
+struct Haplotype {
+    std::vector<uint8_t> seq;
+    std::vector<uint32_t> at;              // at[p]: index in seq of reference position p (of the variant's first base; of the next kept base if p is deleted)
+};
+static Haplotype make_haplotype(const SeqVars &sv, uint32_t allele) {
+    Haplotype h;
+    const uint32_t L = (uint32_t)sv.codes.size();
+    h.at.resize(L + 1);
+    size_t vi = 0;
+    for (uint32_t p = 0; p < L; ++p) {
+        h.at[p] = (uint32_t)h.seq.size();
+        const Variant *use = nullptr;
+        for (; vi < sv.variants.size() && sv.variants[vi].position == p; ++vi)
+            if (sv.variants[vi].in_allele(allele) && !use) use = &sv.variants[vi];
+        if (!use) h.seq.push_back(sv.codes[p]);
+        else h.seq.insert(h.seq.end(), use->var_seq.begin(), use->var_seq.end());
+    }
+    h.at[L] = (uint32_t)h.seq.size();
+    return h;
+}
+void orc_var_haplotype_check(int enable) { g_hap_check = enable != 0; }
+void orc_var_haplotype_counters(uint64_t *out /*[6]*/) {
+    for (int k = 0; k < 6; ++k) {
+        out[k] = g_hap[k];
+        g_hap[k] = 0;
+    }
+}
+
 static uint64_t g_scratch_checks = 0, g_scratch_mismatches = 0;
 // property check behind the device's design: the bookkeeping the reference updates incrementally over fragment lengths is a pure
 // function of (start, pass, length, allele) -- a fresh VariantBiasVarModifiers taken straight to the length gives the same values
@@ -714,6 +749,9 @@ uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t bloc
             ref.num_alleles = A;
             const uint32_t L = r->len[seq];
             const double *thr = &s->thresholds[(size_t)s->coverage_groups[seq] * to * 2];
+            std::vector<Haplotype> haps;
+            if (g_hap_check)
+                for (uint32_t a = 0; a < A; ++a) haps.push_back(make_haplotype(sv, a));
             for (uint32_t b = 0; b < s->n_blocks[seq]; ++b) {
                 const uint32_t block_id = s->first_block[seq] + b;
                 if (block_id < block_lo || block_id >= block_hi) continue;
@@ -774,6 +812,29 @@ uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t bloc
                                     same = same && gc_percent_with_variants(fresh, ref, cur_end, len, allele) == gc_perc && fresh.end_variant(sv.variants, cur_end, allele) == bm.end_variant(sv.variants, cur_end, allele);
                                     ++g_scratch_checks;
                                     g_scratch_mismatches += same ? 0 : 1;
+                                }
+                                if (g_hap_check) {
+                                    const Haplotype &h = haps[allele];
+                                    const uint32_t hs = h.at[start] + bm.start_variant_pos, Lh = (uint32_t)h.seq.size();
+                                    if (hs >= kSurStart && hs + len + kSurLength < Lh && hs + len >= kSurLength) {
+                                        ++g_hap[0];
+                                        uint32_t gc = 0;
+                                        for (uint32_t k = 0; k < len; ++k) gc += is_gc(h.seq[hs + k]) ? 1 : 0;
+                                        g_hap[1] += orc_percent_u32(gc, len) != gc_perc;
+                                        int32_t ss[3], se[3];
+                                        orc_surrounding_forward(h.seq.data(), Lh, hs, ss);
+                                        orc_surrounding_reverse(h.seq.data(), Lh, hs + len - 1u, se);
+                                        g_hap[2] += memcmp(ss, bm.surrounding_start.at(allele).b, sizeof ss) != 0;
+                                        g_hap[3] += memcmp(se, bm.surrounding_end.at(allele).b, sizeof se) != 0;
+                                        const uint32_t tl = std::min<uint32_t>(len, 40u);
+                                        const std::vector<uint8_t> fwd = reference_sequence_with_variants(ref, start, tl, false, bm.start_variant(), allele);
+                                        const std::vector<uint8_t> rev = reference_sequence_with_variants(ref, cur_end, tl, true, bm.end_variant(sv.variants, cur_end, allele), allele);
+                                        bool f_ok = fwd.size() == tl, r_ok = rev.size() == tl;
+                                        for (uint32_t k = 0; k < tl && f_ok; ++k) f_ok = fwd[k] == h.seq[hs + k];
+                                        for (uint32_t k = 0; k < tl && r_ok; ++k) r_ok = rev[k] == 3u - h.seq[hs + len - 1u - k];
+                                        g_hap[4] += f_ok ? 0 : 1;
+                                        g_hap[5] += r_ok ? 0 : 1;
+                                    }
                                 }
                                 const orc_philox_out wc = orc_philox4x32_10(s->seed, start, c1, len, ((uint32_t)ORC_DOM_SIEVE << 28) | (128u + (j >> 1)));
                                 const double adjusted_random = thr[2 * len] + orc_u53(wc.w[2 * (j & 1u)], wc.w[2 * (j & 1u) + 1]) * (1 - thr[2 * len]);

@@ -648,3 +648,40 @@ def test_variant_bias_modifiers_like_the_reference_test():
             assert [fv.value, sp.value] == step["after"], step
     finally:
         L.orc_var_free(h)
+
+
+def test_variant_bookkeeping_equals_the_edited_sequence_everywhere(workdir):
+    """The statement SimulatorTest::TestVariationInInnerLoopOfSimulateFromGivenBlock makes for its hand-made scenarios (SimulatorTest.cpp
+    :163-192: end surrounding, GC percent and both templates of an allele equal those of the sequence with the variants applied), asked
+    of EVERY cell the oracle's sieve evaluates on random substitution / insertion / deletion sets, start surroundings included -- and that
+    the incrementally updated modifiers equal the ones derived from scratch for the cell (what the device does)."""
+    import parity_cases as P
+    from reseq_amd import synth
+    L = O.lib()
+    L.orc_var_haplotype_check(1)
+    try:
+        for trial, (density, seed) in enumerate([(9, 1), (22, 2)]):
+            lengths = [5200, 3100]
+            rng = np.random.default_rng(300 + trial)
+            ppath, fpath, seqs = P.make_inputs(workdir, f"hap{trial}", synth.TINY, lengths, ref_seed=80 + trial)
+            vcf = workdir / f"hap{trial}.vcf"
+            P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, rng, density))
+            oprof, oref = O.Profile(ppath), O.Reference(seqs)
+            err = C.create_string_buffer(1024)
+            ov = L.orc_read_variants(str(vcf).encode(), oref.h, err, len(err))
+            assert ov, err.value
+            sim = O.Sim(oprof, oref, seed, num_pairs=8000, variants=ov)
+            fr = sim.sieve_var(1, sim.total_blocks() + 1)
+            hap = (C.c_uint64 * 6)()
+            L.orc_var_haplotype_counters(hap)
+            checks, mism = C.c_uint64(), C.c_uint64()
+            L.orc_var_scratch_counters(C.byref(checks), C.byref(mism))
+            assert len(fr) > 7000 and (fr["sub"] > 0).sum() > 50
+            assert hap[0] > 15000 and list(hap)[1:] == [0, 0, 0, 0, 0], list(hap)
+            assert checks.value > 15000 and mism.value == 0
+            sim.close()
+            L.orc_variants_free(ov)
+            oref.close()
+            oprof.close()
+    finally:
+        L.orc_var_haplotype_check(0)
