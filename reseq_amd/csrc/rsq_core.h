@@ -615,6 +615,9 @@ struct ReadMachine {
         const uint32_t sqi = seg * S.n_tiles + tile_id;
         const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
         par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, u32_to_unit(h0.w2), prob_sum);
+#ifdef RSQ_EXP_UNIFORM_SQ
+        par.seq_qual = RSQ_EXP_UNIFORM_SQ;                            // experiment only: what a wave-uniform sequence quality would buy
+#endif
         if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
             const DevTable sqt = tab.seq_quality(sqi);
             par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
