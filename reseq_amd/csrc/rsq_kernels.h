@@ -484,16 +484,17 @@ constexpr uint32_t kSieveLoads = 8;                   // bitmap words a lane of 
 
 RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 31u) >> 5; }
 
-// thr1 of one coverage group in LDS, skewed by two doubles per 32 lengths: the lanes of a wave read lengths 32 apart, and the
-// skew spreads their 16-byte reads over all banks (from HBM each of those reads would touch its own cache line)
-RSQ_HD uint32_t thr_lds_index(uint32_t len) { return len + 2u * (len >> 5); }
-RSQ_HD uint32_t thr_lds_doubles(uint32_t insert_to) { return thr_lds_index(insert_to) + 4u; }
+// The zero thresholds of one coverage group in LDS as 32-bit gates: a cell passes iff its 32-bit word is GREATER than the gate
+// (gate = ceil(thr1 * 2^32) - 1; 0xFFFFFFFF = never: thresholds above 1 - 2^-32 and the lengths outside [insert_from, insert_to)).
+// Four gates per 16-byte read; rows of 32 lengths are skewed by four entries because the lanes of a wave read lengths 32 apart.
+RSQ_HD uint32_t gate_lds_index(uint32_t len) { return len + 4u * (len >> 5); }
+RSQ_HD uint32_t gate_lds_bytes(uint32_t insert_to) { return (gate_lds_index(32u * sieve_words_per_slot(insert_to)) + 8u) * 4u; }
 
 template <int VM>
 __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
-    extern __shared__ __attribute__((aligned(16))) double s_thr1[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_gate[];
     const uint64_t t0 = (uint64_t)blockIdx.x * kScreenBlock, t = t0 + threadIdx.x, n_tasks = (uint64_t)n_slots * words_per_slot;
-    // the block's positions lie in one sequence almost always: then its thresholds come from LDS
+    // the block's positions lie in one sequence almost always: then its gates come from LDS
     const uint32_t slot_first = (uint32_t)(t0 / words_per_slot), slot_last = (uint32_t)((t0 + kScreenBlock - 1 < n_tasks ? t0 + kScreenBlock - 1 : n_tasks - 1) / words_per_slot);
     uint32_t seq_first, seq_last;
     if constexpr (VM == 2) {                                       // slots are not 1000 per block here
@@ -506,10 +507,11 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
         seq_first = S.block_seq[block_lo + slot_first / kBlockSize];
         seq_last = S.block_seq[block_lo + slot_last / kBlockSize];
     }
-    const bool staged = seq_first == seq_last;                     // block-uniform
+    const bool staged = seq_first == seq_last && !S.thr1_has_zero;  // block-uniform
     if (staged) {
-        const double *thr = S.thresholds + (size_t)S.coverage_group[seq_first] * S.insert_to * 2u;
-        for (uint32_t len = threadIdx.x; len < S.insert_to; len += kScreenBlock) s_thr1[thr_lds_index(len)] = thr[2u * len + 1u];
+        const uint64_t *thr = S.thr1_bits + (size_t)S.coverage_group[seq_first] * S.insert_to;
+        for (uint32_t len = threadIdx.x; len < 32u * words_per_slot; len += kScreenBlock)
+            s_gate[gate_lds_index(len)] = len >= S.insert_from && len < S.insert_to ? (uint32_t)(thr[len] - 1ull) : 0xFFFFFFFFu;      // thr1_bits in [1, 2^32]
         __syncthreads();
     }
     if (t >= n_tasks) return;
@@ -518,18 +520,27 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     init_site_slot<VM>(S, block_lo, block_hi, slot, site);
     uint32_t bits = 0;
     if (site.start < site.L) {
+        if (staged) {
 #pragma unroll 2
-        for (uint32_t j = 0; j < 8u; ++j) {
-            const uint32_t len0 = 32u * wi + 4u * j;
-            if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
-            const Words w = sieve_quad_words(S, site, len0 >> 2);
-            const uint32_t word[4] = {w.w0, w.w1, w.w2, w.w3};
-#pragma unroll
-            for (uint32_t e = 0; e < 4u; ++e) {
-                const uint32_t len = len0 + e;
-                if (len >= S.insert_from && len < S.insert_to) {
-                    const double thr1 = staged ? s_thr1[thr_lds_index(len)] : site.thr[2u * len + 1u];
-                    if (u32_to_unit(word[e]) >= thr1) bits |= 1u << (4u * j + e);                     // Simulator.h:418-420
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t len0 = 32u * wi + 4u * j;
+                if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
+                const Words w = sieve_quad_words(S, site, len0 >> 2);
+                const uint4 g = *reinterpret_cast<const uint4 *>(&s_gate[gate_lds_index(len0)]);
+                // Simulator.h:418-420 `probability_chosen >= threshold`, on the 32-bit words themselves (exact, see upload_normalization)
+                const uint32_t four = (w.w0 > g.x ? 1u : 0u) | (w.w1 > g.y ? 2u : 0u) | (w.w2 > g.z ? 4u : 0u) | (w.w3 > g.w ? 8u : 0u);
+                bits |= four << (4u * j);
+            }
+        } else {                                                    // a block across two sequences, or a threshold of exactly zero
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t len0 = 32u * wi + 4u * j;
+                if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
+                const Words w = sieve_quad_words(S, site, len0 >> 2);
+                const uint32_t word[4] = {w.w0, w.w1, w.w2, w.w3};
+                for (uint32_t e = 0; e < 4u; ++e) {
+                    const uint32_t len = len0 + e;
+                    if (len >= S.insert_from && len < S.insert_to && (uint64_t)word[e] >= S.thr1_bits[(size_t)S.coverage_group[site.seq] * S.insert_to + len])
+                        bits |= 1u << (4u * j + e);
                 }
             }
         }

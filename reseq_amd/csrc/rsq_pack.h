@@ -1006,6 +1006,16 @@ inline void finish_bias_normalization(SimState &s, const BiasPlan &plan, const s
 inline void upload_normalization(SimState &s, Uploader &up) {
     s.dev.thresholds = up.put(s.thresholds);
     s.dev.bias_normalization = s.bias_normalization;
+    // the screen of the sieve compares in the integer domain: u = w * 2^-32 >= thr1  <=>  w >= ceil(thr1 * 2^32), w integer; both
+    // scalings are exact in double precision.  A threshold above 1 - 2^-32 gives 2^32: no 32-bit word passes.
+    std::vector<uint64_t> bits(s.thresholds.size() / 2);
+    s.dev.thr1_has_zero = 0;
+    for (size_t i = 0; i < bits.size(); ++i) {
+        const double t = ceil(s.thresholds[2 * i + 1] * 4294967296.0);
+        bits[i] = t <= 0.0 ? 0ull : (t >= 4294967296.0 ? 4294967296ull : (uint64_t)t);
+        if (!bits[i]) s.dev.thr1_has_zero = 1;
+    }
+    s.dev.thr1_bits = up.put(bits);
 }
 
 }  // namespace rsq

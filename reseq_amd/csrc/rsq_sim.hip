@@ -418,7 +418,7 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         if (!attempt) {
             s.timers["sieve_screen"].start(st);
             const dim3 cgrid(cdiv(n_slots * words_per_slot, kScreenBlock)), cblock(kScreenBlock);
-            const size_t clds = thr_lds_doubles(s.dev.insert_to) * sizeof(double);
+            const size_t clds = gate_lds_bytes(s.dev.insert_to);
             if (2 == vm) hipLaunchKernelGGL(k_sieve_screen<2>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
             else hipLaunchKernelGGL(k_sieve_screen<0>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
             s.timers["sieve_screen"].stop(st);
