@@ -3,7 +3,7 @@
 insertions / deletions, methylation BED, coverage 30) on ONE GPU at a chosen scale (default 1/10: 310 Mb in 24 sequences, 0.4 M
 substitutions + 40 k insertions / deletions of at most 20 bases on two alleles, 2 M unmethylated regions with Beta(0.5, 0.5)
 methylation, about 31 M pairs).  Prints one JSON line: sizes, pre-pass and generation times per stage, a checksum, and that a
-second batching writes the same bytes (pairs, total bytes, SHA-256 of the first 6000 blocks).  Not a bench line."""
+second batching writes the same bytes (pairs, total bytes, SHA-256 of the first 48000 blocks).  Not a bench line."""
 import hashlib
 import json
 import os
@@ -79,7 +79,7 @@ t_prep = time.perf_counter() - t0
 nb = info.total_blocks
 out = {}
 r1 = r2 = None
-for name, batch in (("batch_3000", 3000), ("batch_1500", 1500)):
+for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
     h1, h2 = hashlib.sha256(), hashlib.sha256()
     n = nbytes = 0
     t_gpu = 0.0
@@ -98,14 +98,14 @@ for name, batch in (("batch_3000", 3000), ("batch_1500", 1500)):
             kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
         n += k
         nbytes += l1 + l2
-        if hi <= 6001:                                           # checksum of the first 6000 blocks only: the text is hundreds of GB at full scale
+        if hi <= 48001:                                           # checksum of the first 48000 blocks only: the text is hundreds of GB at full scale
             h1.update(r1.to_numpy(np.uint8, l1).tobytes())
             h2.update(r2.to_numpy(np.uint8, l2).tobytes())
     out[name] = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
-    out[name]["sha256_first_6000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
+    out[name]["sha256_first_48000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
 print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "prepare_s": round(t_prep, 2),
-                  "runs": out, "pairs_per_s_gpu": out["batch_3000"]["pairs"] / out["batch_3000"]["gpu_s"],
-                  "batching_invariant": out["batch_3000"]["pairs"] == out["batch_1500"]["pairs"] and out["batch_3000"]["fastq_bytes"] == out["batch_1500"]["fastq_bytes"] and
-                  out["batch_3000"]["sha256_first_6000_blocks"] == out["batch_1500"]["sha256_first_6000_blocks"]}))
+                  "runs": out, "pairs_per_s_gpu": out["batch_24000"]["pairs"] / out["batch_24000"]["gpu_s"],
+                  "batching_invariant": out["batch_24000"]["pairs"] == out["batch_12000"]["pairs"] and out["batch_24000"]["fastq_bytes"] == out["batch_12000"]["fastq_bytes"] and
+                  out["batch_24000"]["sha256_first_48000_blocks"] == out["batch_12000"]["sha256_first_48000_blocks"]}))
