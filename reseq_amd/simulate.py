@@ -22,7 +22,7 @@ from . import sharding
 class GpuBackend:
     """reseq_amd.api.Simulator with reusable device buffers (the product path)."""
 
-    def __init__(self, profile_path, fasta_path, device, replace_n_seed, vcf_path=None):
+    def __init__(self, profile_path, fasta_path, device, replace_n_seed, vcf_path=None, methylation_path=None, sys_error_path=None):
         from . import api
         self.api = api
         self.prof = api.Profile(profile_path)
@@ -30,12 +30,17 @@ class GpuBackend:
         if vcf_path:
             self.ref.read_variants(vcf_path)
         self.sim = api.Simulator(self.prof, self.ref, device)
+        if methylation_path:
+            self.sim.read_methylation(methylation_path)
+        self.sys_error_path = sys_error_path
         self.device = device
         self.r1 = self.r2 = None
         self.seq_len = [self.ref.sequence_length(i) for i in range(self.ref.num_sequences())]
 
     def prepare(self, seed, num_pairs, coverage, ref_bias_mode, base_identifier):
         i = self.sim.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        if self.sys_error_path:                                      # every rank loads the same tracks (Simulator.cpp:2800-2811)
+            self.sim.read_sys_errors(self.sys_error_path)
         return dict(total_blocks=i.total_blocks, total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, insert_to=i.insert_to)
 
     def ref_seq_bias(self):
@@ -123,6 +128,8 @@ def main(argv=None):
     ap.add_argument("-1", "--firstReadsOut", dest="out1", default="reseq-R1.fq")
     ap.add_argument("-2", "--secondReadsOut", dest="out2", default="reseq-R2.fq")
     ap.add_argument("-V", "--vcfSim", dest="vcf", default=None, help="variants to simulate per allele (substitutions)")
+    ap.add_argument("--methylation", default=None, help="extended bed graph with methylation values per region (and allele)")
+    ap.add_argument("--readSysError", default=None, help="systematic-error profile written by reseq illuminaPE --writeSysError")
     ap.add_argument("--numReads", type=int, default=0)
     ap.add_argument("-c", "--coverage", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=None)
@@ -142,7 +149,7 @@ def main(argv=None):
         t = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.broadcast(t, 0)
         seed = int(t.item())
-    backend = GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf)
+    backend = GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError)
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
                                   a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}")
