@@ -513,6 +513,64 @@ def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels"
         p.close()
 
 
+def _complex_variant_set(seqs, rng, density):
+    """long insertions (20..60 bases) and deletions (10..40), records with two alternatives (insertion | substitution, deletion |
+    insertion), neighbouring variants, variants at the first positions"""
+    out = []
+    ins = lambda n: "".join("ACGT"[b] for b in rng.integers(0, 4, n))
+    for si, (_, codes) in enumerate(seqs):
+        L = len(codes)
+        if L < 200:
+            continue
+        last = -1
+        for p0 in sorted(set(int(x) for x in rng.choice(np.arange(0, L - 60), size=L // density, replace=False)) | {0, 1, L - 61}):
+            if p0 <= last:
+                continue
+            ref = "ACGT"[codes[p0]]
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                out.append((si, p0, 1, ref + ins(int(rng.integers(20, 61))), "0|1"))
+                last = p0
+            elif kind == 1:
+                dl = int(rng.integers(10, 41))
+                out.append((si, p0, dl + 1, ref, "1|0"))
+                last = p0 + dl
+            elif kind == 2:
+                out.append((si, p0, 1, f"{ref + ins(3)},{'ACGT'[(codes[p0] + 1) % 4]}", "1|2"))
+                last = p0
+            elif kind == 3:
+                dl = int(rng.integers(1, 4))
+                refs = "".join("ACGT"[codes[p0 + k]] for k in range(dl + 1))
+                out.append((si, p0, dl + 1, f"{ref},{refs + ins(2)}", "1|2"))
+                last = p0 + dl
+            elif kind == 4:
+                out.append((si, p0, 1, "ACGT"[(codes[p0] + 2) % 4], "1|1"))
+                out.append((si, p0 + 1, 1, "ACGT"[codes[p0 + 1]] + ins(2), "0|1"))
+                last = p0 + 1
+            else:
+                out.append((si, p0, 2, ref, "1|1"))
+                last = p0 + 1
+    return out
+
+
+def case_variants_complex(backend_cls, workdir):
+    """insertions longer than a surrounding and than a read, long deletions, two alternatives in one record, neighbouring variants"""
+    lengths = [5300, 2400]
+    rng = np.random.default_rng(401)
+    seqs = make_inputs(workdir, "vcomplex", synth.TINY, lengths, ref_seed=91)[2]
+    vcf = workdir / "vcomplex.vcf"
+    write_vcf(vcf, seqs, _complex_variant_set(seqs, rng, 25))
+    p = Pair(backend_cls, workdir, "vcomplex", synth.TINY, lengths, seed=2, num_pairs=7000, vcf=vcf, ref_seed=91)
+    try:
+        if hasattr(p.b, "variant_sys_errors"):
+            _compare_variant_sys_errors(p, [0, 1])
+        p.align_normalization()
+        ofr, _ = _compare_blocks_var(p, 1, p.info["total_blocks"] + 1)
+        assert len(ofr) > 6000 and ofr["sub"].max() >= 40
+    finally:
+        p.close()
+
+
 def case_variants_with_loaded_sys_errors(backend_cls, workdir):
     """--readSysError together with -V: the variants' own errors are drawn against the LOADED tracks (their error-region state follows
     the file's rates: SetSystematicErrorVariants* run after ReadSystematicErrors, Simulator.cpp:983-986,1232-1234)"""

@@ -168,6 +168,10 @@ def test_variants_insertions_and_deletions_dense_four_alleles(workdir):
     P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="indels4", lengths=(5300, 2600), samples=2)
 
 
+def test_variants_complex(workdir):
+    P.case_variants_complex(GpuBackend, workdir)
+
+
 def test_variants_with_loaded_sys_errors(workdir):
     P.case_variants_with_loaded_sys_errors(GpuBackend, workdir)
 

@@ -140,6 +140,10 @@ def test_variants_insertions_and_deletions_four_alleles(workdir):
     P.case_variants_indels(EmuBackend, workdir, density=30, seed=47, tag="indels4", lengths=(4300, 2600), samples=2)
 
 
+def test_variants_complex(workdir):
+    P.case_variants_complex(EmuBackend, workdir)
+
+
 def test_variants_with_loaded_sys_errors(workdir):
     P.case_variants_with_loaded_sys_errors(EmuBackend, workdir)
 
