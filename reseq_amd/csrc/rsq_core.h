@@ -618,6 +618,9 @@ struct ReadMachine {
 #ifdef RSQ_EXP_UNIFORM_SQ
         par.seq_qual = RSQ_EXP_UNIFORM_SQ;                            // experiment only: what a wave-uniform sequence quality would buy
 #endif
+#ifdef RSQ_EXP_UNIFORM_GC
+        par.gc_seq = RSQ_EXP_UNIFORM_GC;                              // experiment only: what reads sorted by their G/C percent would buy (indel margin 2)
+#endif
         if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
             const DevTable sqt = tab.seq_quality(sqi);
             par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
