@@ -32,8 +32,8 @@ from backends import EmuBackend
 from reseq_amd import simulate, synth
 
 class Emu:                      # the host emulation behind the interface simulate.run_rank drives (the GPU run uses simulate.GpuBackend)
-    def __init__(self, ppath, fpath, seqs):
-        self.b = EmuBackend(ppath, fpath, 0)
+    def __init__(self, ppath, fpath, seqs, vcf=None):
+        self.b = EmuBackend(ppath, fpath, 0, None, vcf_path=vcf) if vcf else EmuBackend(ppath, fpath, 0)
         self.seq_len = [len(c) for _, c in seqs]
     def prepare(self, *a):
         i = self.b.prepare(*a)
@@ -54,7 +54,12 @@ work = pathlib.Path(os.environ["RSQ_WORK"])
 (work / f"sim{rank}").mkdir(parents=True, exist_ok=True)
 ppath, fpath, seqs = P.make_inputs(work / f"sim{rank}", "simjob", synth.TINY, [5000, 80, 3210])
 tag = os.environ["RSQ_TAG"]
-pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3)
+vcf = None
+if os.environ.get("RSQ_VARIANTS"):           # substitutions, insertions, deletions on two alleles: extra start slots cross the shard borders too
+    import numpy as np
+    vcf = work / f"sim{rank}" / "simjob.vcf"
+    P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, np.random.default_rng(5), 30, [999, 1000, 1999, 2000, 2999, 3000]))
+pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs, vcf), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3)
 if rank == 0:
     print("PAIRS", pairs)
 if world > 1:
@@ -63,13 +68,15 @@ if world > 1:
 
 
 @pytest.mark.timeout(900)
-def test_simulate_module_two_ranks_equal_one_rank(workdir):
-    """reseq_amd.simulate.run_rank over gloo with two ranks writes the same two FASTQ files (adapter-only pairs included) as one rank"""
+@pytest.mark.parametrize("variants", ["", "1"])
+def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
+    """reseq_amd.simulate.run_rank over gloo with two ranks writes the same two FASTQ files (adapter-only pairs included) as one rank,
+    without and with variants"""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    base = dict(os.environ, RSQ_TESTS=str(HERE), RSQ_ROOT=str(HERE.parent), RSQ_WORK=str(workdir), RSQ_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    base = dict(os.environ, RSQ_TESTS=str(HERE), RSQ_ROOT=str(HERE.parent), RSQ_WORK=str(workdir), RSQ_PORT=str(port), MASTER_ADDR="127.0.0.1", RSQ_VARIANTS=variants)
     one = subprocess.run([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK="0", WORLD_SIZE="1", RSQ_TAG="one"), capture_output=True, timeout=800)
     assert one.returncode == 0, one.stderr.decode()[-3000:]
     procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="two"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
