@@ -425,7 +425,7 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
 // its 1000 start positions plus the extra passes inside inserted bases (DevSim::extra), merged in loop order -- the extra pass j of a
 // block (0-based, extras sorted) sits at local index (pos - block start) + j + 1.  Returns the block id; first_slot_of_block = the
 // batch slot of the block's first position.
-template <int VM>
+template <int VM, bool NEED_START = true>                             // NEED_START false: only the position and the pass (what the cell's random stream needs)
 RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t block_hi, uint32_t slot, SieveSite &site, uint32_t *first_slot_of_block = nullptr) {
     if constexpr (VM != 2) {
         const uint32_t block_id = block_lo + slot / kBlockSize;
@@ -458,7 +458,7 @@ RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t bloc
             site.st = VarStart{e[c].first_variant_id, e[c].start_variant_pos};
         } else {
             init_site(S, block_id, local - c, site);
-            if (site.start < site.L) site.st = VarStart{(int32_t)var_view(S, seq).lower_bound(site.start), 0u};      // bias_mod.first_variant_id_ at a plain position
+            if (NEED_START && site.start < site.L) site.st = VarStart{(int32_t)var_view(S, seq).lower_bound(site.start), 0u};      // bias_mod.first_variant_id_ at a plain position
         }
         return block_id;
     }
@@ -499,8 +499,8 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     uint32_t seq_first, seq_last;
     if constexpr (VM == 2) {                                       // slots are not 1000 per block here
         SieveSite a, b;
-        init_site_slot<VM>(S, block_lo, block_hi, slot_first, a);
-        init_site_slot<VM>(S, block_lo, block_hi, slot_last, b);
+        init_site_slot<VM, false>(S, block_lo, block_hi, slot_first, a);
+        init_site_slot<VM, false>(S, block_lo, block_hi, slot_last, b);
         seq_first = a.seq;
         seq_last = b.seq;
     } else {
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     if (t >= n_tasks) return;
     const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
     SieveSite site;
-    init_site_slot<VM>(S, block_lo, block_hi, slot, site);
+    init_site_slot<VM, false>(S, block_lo, block_hi, slot, site);
     uint32_t bits = 0;
     if (site.start < site.L) {
         if (staged) {
