@@ -425,8 +425,22 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
 // its 1000 start positions plus the extra passes inside inserted bases (DevSim::extra), merged in loop order -- the extra pass j of a
 // block (0-based, extras sorted) sits at local index (pos - block start) + j + 1.  Returns the block id; first_slot_of_block = the
 // batch slot of the block's first position.
+struct SlotInfo {                      // VM 2: what init_site_slot finds for a slot, written once per batch by k_slot_table
+    uint32_t block_id, offset_in_block, sub, first_slot;
+    int32_t first_variant_id;
+    uint32_t start_variant_pos;
+};
 template <int VM, bool NEED_START = true>                             // NEED_START false: only the position and the pass (what the cell's random stream needs)
-RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t block_hi, uint32_t slot, SieveSite &site, uint32_t *first_slot_of_block = nullptr) {
+RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t block_hi, uint32_t slot, SieveSite &site, uint32_t *first_slot_of_block = nullptr,
+                               const SlotInfo *table = nullptr) {
+    if (VM == 2 && table) {
+        const SlotInfo t = table[slot];
+        init_site(S, t.block_id, t.offset_in_block, site);
+        site.sub = t.sub;
+        site.st = VarStart{t.first_variant_id, t.start_variant_pos};
+        if (first_slot_of_block) *first_slot_of_block = t.first_slot;
+        return t.block_id;
+    }
     if constexpr (VM != 2) {
         const uint32_t block_id = block_lo + slot / kBlockSize;
         init_site(S, block_id, slot % kBlockSize, site);
@@ -484,6 +498,51 @@ constexpr uint32_t kSieveLoads = 8;                   // bitmap words a lane of 
 
 RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 31u) >> 5; }
 
+// variants of any kind: what init_site_slot<2> finds, once per slot and batch.  One workgroup per block of 1000 start positions: the
+// searches over all blocks / all variants happen once per block, the per-slot ones only over the block's own few extra starts and variants.
+__global__ void __launch_bounds__(256) k_slot_table(DevSim S, uint32_t block_lo, SlotInfo *out) {
+    const uint32_t block_id = block_lo + blockIdx.x, base_lo = S.block_extra_ptr[block_lo];
+    const uint32_t first_slot = (block_id - block_lo) * kBlockSize + (S.block_extra_ptr[block_id] - base_lo);
+    const ExtraStart *e = S.extra + S.block_extra_ptr[block_id];
+    const uint32_t m = S.block_extra_ptr[block_id + 1] - S.block_extra_ptr[block_id];
+    const uint32_t seq = S.block_seq[block_id], bs = (block_id - S.first_block[seq]) * kBlockSize, L = S.seq_len[seq];
+    const VarView r = var_view(S, seq);
+    __shared__ uint32_t s_v[2];
+    if (threadIdx.x < 2) s_v[threadIdx.x] = r.lower_bound(bs + threadIdx.x * kBlockSize);
+    __syncthreads();
+    const uint32_t v0 = s_v[0], v1 = s_v[1];                       // the block's variants
+    for (uint32_t local = threadIdx.x; local < kBlockSize + m; local += blockDim.x) {
+        uint32_t a = 0, b = m;                                      // extras whose local index is below `local`
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if ((e[mid].pos - bs) + mid + 1u < local) a = mid + 1u;
+            else b = mid;
+        }
+        SlotInfo t;
+        t.block_id = block_id;
+        t.first_slot = first_slot;
+        if (a < m && (e[a].pos - bs) + a + 1u == local) {
+            t.offset_in_block = e[a].pos - bs;
+            t.sub = e[a].sub;
+            t.first_variant_id = e[a].first_variant_id;
+            t.start_variant_pos = e[a].start_variant_pos;
+        } else {
+            t.offset_in_block = local - a;
+            t.sub = 0;
+            const uint32_t pos = bs + t.offset_in_block;
+            uint32_t lo = v0, hi = v1;                              // first variant at or after the position (none of it is used beyond the sequence)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (r.v[mid].pos < pos) lo = mid + 1u;
+                else hi = mid;
+            }
+            t.first_variant_id = pos < L ? (int32_t)lo : 0;
+            t.start_variant_pos = 0;
+        }
+        out[first_slot + local] = t;
+    }
+}
+
 // The zero thresholds of one coverage group in LDS as 32-bit gates: a cell passes iff its 32-bit word is GREATER than the gate
 // (gate = ceil(thr1 * 2^32) - 1; 0xFFFFFFFF = never: thresholds above 1 - 2^-32 and the lengths outside [insert_from, insert_to)).
 // Four gates per 16-byte read; rows of 32 lengths are skewed by four entries because the lanes of a wave read lengths 32 apart.
@@ -491,7 +550,8 @@ RSQ_HD uint32_t gate_lds_index(uint32_t len) { return len + 4u * (len >> 5); }
 RSQ_HD uint32_t gate_lds_bytes(uint32_t insert_to) { return (gate_lds_index(32u * sieve_words_per_slot(insert_to)) + 8u) * 4u; }
 
 template <int VM>
-__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap) {
+__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap,
+                                                               const SlotInfo *slots) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_gate[];
     const uint64_t t0 = (uint64_t)blockIdx.x * kScreenBlock, t = t0 + threadIdx.x, n_tasks = (uint64_t)n_slots * words_per_slot;
     // the block's positions lie in one sequence almost always: then its gates come from LDS
@@ -499,8 +559,8 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     uint32_t seq_first, seq_last;
     if constexpr (VM == 2) {                                       // slots are not 1000 per block here
         SieveSite a, b;
-        init_site_slot<VM, false>(S, block_lo, block_hi, slot_first, a);
-        init_site_slot<VM, false>(S, block_lo, block_hi, slot_last, b);
+        init_site_slot<VM, false>(S, block_lo, block_hi, slot_first, a, nullptr, slots);
+        init_site_slot<VM, false>(S, block_lo, block_hi, slot_last, b, nullptr, slots);
         seq_first = a.seq;
         seq_last = b.seq;
     } else {
@@ -517,7 +577,7 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     if (t >= n_tasks) return;
     const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
     SieveSite site;
-    init_site_slot<VM, false>(S, block_lo, block_hi, slot, site);
+    init_site_slot<VM, false>(S, block_lo, block_hi, slot, site, nullptr, slots);
     uint32_t bits = 0;
     if (site.start < site.L) {
         if (staged) {
@@ -550,7 +610,8 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
 
 template <int VM>
 __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
-                                                                  const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count) {
+                                                                  const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count,
+                                                                  const SlotInfo *slots) {
     __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
     extern __shared__ uint32_t s_total[];                          // [kSieveWaves][slots_per_wave] pairs found so far per position
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -573,7 +634,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
                 len = e & 0xFFFFu;
                 SieveSite site;
                 const uint32_t slot = slot0 + key;
-                init_site_slot<VM>(S, block_lo, block_hi, slot, site);
+                init_site_slot<VM>(S, block_lo, block_hi, slot, site, nullptr, slots);
                 const double u = sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len);
                 if constexpr (VM == 2) n_here = sieve_cell_general(S, site, len, u, cell);
                 else if constexpr (VM == 1) n_here = sieve_cell_var(S, site, len, u, cell);
@@ -675,13 +736,13 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
 // one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at offsets[slot] + intra
 template <int VM>
 __global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, uint32_t block_hi, const SieveHit *hits, uint32_t n_hits, const uint64_t *offsets, Fragment *frags,
-                                                   FragmentVar *fvars) {
+                                                   FragmentVar *fvars, const SlotInfo *slots) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const SieveHit h = hits[i];
     SieveSite site;
     uint32_t first_slot;
-    const uint32_t block_id = init_site_slot<VM>(S, block_lo, block_hi, h.slot, site, &first_slot);
+    const uint32_t block_id = init_site_slot<VM>(S, block_lo, block_hi, h.slot, site, &first_slot, slots);
     const uint64_t base = offsets[h.slot];
     const uint32_t number_base = (uint32_t)(base - offsets[first_slot]);
     uint32_t k = h.intra;

@@ -114,6 +114,7 @@ struct rsq_sim : SimState {
     DeviceUploader up;
     // workspace of the hot path (grow-only)
     DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
+    DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
     DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates, rec_flags, rec_index, rec_count;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
@@ -419,14 +420,23 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
             s.timers["sieve_screen"].start(st);
             const dim3 cgrid(cdiv(n_slots * words_per_slot, kScreenBlock)), cblock(kScreenBlock);
             const size_t clds = gate_lds_bytes(s.dev.insert_to);
-            if (2 == vm) hipLaunchKernelGGL(k_sieve_screen<2>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
-            else hipLaunchKernelGGL(k_sieve_screen<0>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>());
+            if (2 == vm) {
+                s.slot_table.reserve(n_slots * sizeof(SlotInfo) + 16);
+                s.timers["slot_table"].start(st);
+                hipLaunchKernelGGL(k_slot_table, dim3(block_hi - block_lo), dim3(256), 0, st, s.dev, block_lo, s.slot_table.as<SlotInfo>());
+                s.timers["slot_table"].stop(st);
+                hipLaunchKernelGGL(k_sieve_screen<2>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
+                                   s.slot_table.as<SlotInfo>());
+            } else
+                hipLaunchKernelGGL(k_sieve_screen<0>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
+                                   (const SlotInfo *)nullptr);
             s.timers["sieve_screen"].stop(st);
         }
         const size_t flds = kSieveWaves * slots_per_wave * sizeof(uint32_t);
 #define RSQ_FINISH(VM)                                                                                                                                        \
     hipLaunchKernelGGL(k_sieve_finish<VM>, sgrid, sblock, flds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, slots_per_wave,            \
-                       s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>())
+                       s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>(),                 \
+                       2 == VM ? s.slot_table.as<SlotInfo>() : (const SlotInfo *)nullptr)
         if (2 == vm) RSQ_FINISH(2);
         else if (1 == vm) RSQ_FINISH(1);
         else RSQ_FINISH(0);
@@ -451,10 +461,10 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     if (2 == vm) {
         s.fvars.reserve(total * sizeof(FragmentVar) + 16);
         hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.frags.as<Fragment>(), s.fvars.as<FragmentVar>());
+                           s.frags.as<Fragment>(), s.fvars.as<FragmentVar>(), s.slot_table.as<SlotInfo>());
     } else
         hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.frags.as<Fragment>(), (FragmentVar *)nullptr);
+                           s.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
     s.timers["sieve_emit"].stop(st);
     HIP_CHECK(hipGetLastError());
     if (frags_out) {
