@@ -260,21 +260,26 @@ RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, doubl
 constexpr uint32_t kMaxDevAlleles = 128;           // Reference::Variant::kMaxAlleles: 2 * alleles (allele, strand) slots per cell, in scratch memory
 RSQ_HD const uint64_t *hap_words(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.ref_words + (1u + allele) * S.hap_stride : S.ref_words; }
 RSQ_HD const uint32_t *hap_gc_prefix(const DevSim &S, uint32_t allele) { return S.hap_stride ? S.gc_prefix + (1u + allele) * S.hap_stride : S.gc_prefix; }
-struct VarCell {
+template <uint32_t CAP>                            // CAP alleles at most: small sets keep the cell in registers (k_sieve_finish<VM, 8>)
+struct VarCellT {
     uint32_t n;                                    // chosen (allele, strand) slots with pairs, in draw order
-    uint16_t cnt[2 * kMaxDevAlleles];
-    uint8_t id[2 * kMaxDevAlleles];                // allele * 2 + strand
+    uint16_t cnt[2 * CAP];
+    uint8_t id[2 * CAP];                           // allele * 2 + strand
 };
+using VarCell = VarCellT<kMaxDevAlleles>;
 // SelectAllele (Simulator.cpp:1341-1361); reverse_selection as a bit mask over the 2 * alleles slots
-struct SlotMask {
-    uint32_t w[2 * kMaxDevAlleles / 32];
+template <uint32_t CAP>
+struct SlotMaskT {
+    static constexpr uint32_t kWords = (2 * CAP + 31) / 32;
+    uint32_t w[kWords];
     RSQ_HD void set_first(uint32_t n) {
-        for (uint32_t i = 0; i < 2 * kMaxDevAlleles / 32; ++i) w[i] = n >= 32u * (i + 1u) ? 0xFFFFFFFFu : (n > 32u * i ? (1u << (n - 32u * i)) - 1u : 0u);
+        for (uint32_t i = 0; i < kWords; ++i) w[i] = n >= 32u * (i + 1u) ? 0xFFFFFFFFu : (n > 32u * i ? (1u << (n - 32u * i)) - 1u : 0u);
     }
     RSQ_HD bool test(uint32_t id) const { return (w[id >> 5] >> (id & 31u)) & 1u; }
     RSQ_HD void clear(uint32_t id) { w[id >> 5] &= ~(1u << (id & 31u)); }
 };
-RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, SlotMask &selectable, uint32_t possible_strands, double random_value) {
+template <class Mask>
+RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, Mask &selectable, uint32_t possible_strands, double random_value) {
     uint32_t chosen_id = (uint32_t)(uint16_t)(random_value * (possible_strands - n_chosen));
     uint32_t replacement_correction = 0;
     for (uint32_t i = 0; i < n_chosen; ++i)
@@ -287,7 +292,8 @@ RSQ_HD void select_allele(uint8_t *chosen, uint32_t &n_chosen, SlotMask &selecta
 RSQ_HD uint32_t word_of(const Words &w, uint32_t k) { return k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)); }
 // Streams (DESIGN.md "Random streams", rows "with variants"): SelectAllele's j-th value = word j&3 of block (start, seq, length,
 // 1<<28 | 2 + (j>>2)); the count uniform of the j-th chosen slot = u53 of words 2(j&1), 2(j&1)+1 of block (.., 1<<28 | 128 + (j>>1)).
-RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCell &cell) {
+template <uint32_t CAP>
+RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCellT<CAP> &cell) {
     cell.n = 0;
     const double thr0 = site.thr[2u * len], thr1 = site.thr[2u * len + 1u];
     if (!(probability_chosen >= thr1)) return 0;                                    // Simulator.h:418-420
@@ -295,9 +301,9 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     const uint32_t non_zero_strands = binomial(possible_strands, 1 - thr0, probability_chosen);
     const uint32_t end = site.start + len;                                          // end_pos_shift_ is 0 without insertions and deletions
     if (!non_zero_strands || !(end < site.L)) return 0;
-    uint8_t chosen[2 * kMaxDevAlleles];
+    uint8_t chosen[2 * CAP];
     uint32_t n_chosen = 0, n_draws = 0;
-    SlotMask selectable;
+    SlotMaskT<CAP> selectable;
     selectable.set_first(possible_strands);
     const bool direct = non_zero_strands <= possible_strands / 2u;                  // ChooseAlleles :1387-1397
     const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
@@ -336,12 +342,13 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
 }
 
 // the cell with variants of any kind: possible alleles, ChooseAlleles, and per chosen (allele, strand) the modifiers from scratch
-RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCell &cell) {
+template <uint32_t CAP>
+RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCellT<CAP> &cell) {
     cell.n = 0;
     const double thr0 = site.thr[2u * len], thr1 = site.thr[2u * len + 1u];
     if (!(probability_chosen >= thr1)) return 0;
     const VarView r = var_view(S, site.seq);
-    uint8_t possible[kMaxDevAlleles];
+    uint8_t possible[CAP];
     uint32_t n_possible = 0;
     for (uint32_t allele = 0; allele < S.num_alleles; ++allele)                     // GetPossibleAlleles :1330-1340
         if (!allele_skipped(r, site.st, allele, site.start)) possible[n_possible++] = (uint8_t)allele;
@@ -349,9 +356,9 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     const uint32_t non_zero_strands = binomial(possible_strands, 1 - thr0, probability_chosen);
     if (!non_zero_strands) return 0;
     const uint32_t c1 = site_c1(site);
-    uint8_t chosen[2 * kMaxDevAlleles];
+    uint8_t chosen[2 * CAP];
     uint32_t n_chosen = 0, n_draws = 0;
-    SlotMask selectable;
+    SlotMaskT<CAP> selectable;
     selectable.set_first(possible_strands);
     const bool direct = non_zero_strands <= possible_strands / 2u;
     const uint32_t to_draw = direct ? non_zero_strands : possible_strands - non_zero_strands;
@@ -608,7 +615,7 @@ __global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_
     bitmap[t] = bits;
 }
 
-template <int VM>
+template <int VM, uint32_t CAP = kMaxDevAlleles>
 __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
                                                                   const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count,
                                                                   const SlotInfo *slots) {
@@ -626,7 +633,7 @@ __global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uin
         for (uint32_t base = 0; base < n_queued; base += 64u) {
             const bool active = base + lane < n_queued;
             uint32_t key = 0xFFFFu, len = 0, n_here = 0, cnt[2] = {0, 0}, strand_of[2] = {0, 0};
-            VarCell cell;
+            VarCellT<VM ? CAP : 1u> cell;
             cell.n = 0;
             if (active) {
                 const uint32_t e = queue[base + lane];

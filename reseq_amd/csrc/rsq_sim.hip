@@ -433,13 +433,14 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
             s.timers["sieve_screen"].stop(st);
         }
         const size_t flds = kSieveWaves * slots_per_wave * sizeof(uint32_t);
-#define RSQ_FINISH(VM)                                                                                                                                        \
-    hipLaunchKernelGGL(k_sieve_finish<VM>, sgrid, sblock, flds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, slots_per_wave,            \
+#define RSQ_FINISH(VM, CAP)                                                                                                                                   \
+    hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), sgrid, sblock, flds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, slots_per_wave,            \
                        s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>(),                 \
                        2 == VM ? s.slot_table.as<SlotInfo>() : (const SlotInfo *)nullptr)
-        if (2 == vm) RSQ_FINISH(2);
-        else if (1 == vm) RSQ_FINISH(1);
-        else RSQ_FINISH(0);
+        if (2 == vm && s.num_alleles <= 8) RSQ_FINISH(2, 8);        // few alleles: the cell's (allele, strand) slots stay in registers
+        else if (2 == vm) RSQ_FINISH(2, kMaxDevAlleles);
+        else if (1 == vm) RSQ_FINISH(1, 8);                         // allele copies exist for at most eight alleles
+        else RSQ_FINISH(0, 1);
 #undef RSQ_FINISH
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
