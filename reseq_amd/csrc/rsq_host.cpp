@@ -254,8 +254,13 @@ Reference Reference::read_fasta(const std::string &path) {
         } else {
             if (r.codes.empty()) throw Error(path + " does not start with a FASTA header");
             std::vector<uint8_t> &c = r.codes.back();
+            const size_t old = c.size();
+            if (c.capacity() < old + line.size()) c.reserve(std::max(c.capacity() * 2, old + line.size()));
+            c.resize(old + line.size());
+            uint8_t *d = c.data() + old;
             for (char ch : line)
-                if (ch != ' ' && ch != '\t') c.push_back(lut[(uint8_t)ch]);
+                if (ch != ' ' && ch != '\t') *d++ = lut[(uint8_t)ch];
+            c.resize((size_t)(d - c.data()));
         }
     }
     if (r.codes.empty()) throw Error(path + " does not contain any reference sequences.");
