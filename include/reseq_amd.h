@@ -169,6 +169,9 @@ int rsq_dev_alloc(int device, size_t bytes, void **out_dev);
 int rsq_dev_free(int device, void *dev);
 int rsq_dev_upload(int device, void *dst_dev, const void *src, size_t bytes);
 int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes);
+/* page-locked host memory: rsq_dev_download into it runs at the full PCIe rate (the CLI's output buffers) */
+int rsq_host_alloc(size_t bytes, void **out_host);
+int rsq_host_free(void *host);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,8 @@ SYMBOLS = {
     "rsq_dev_free": (C.c_int, [C.c_int, _vp]),
     "rsq_dev_upload": (C.c_int, [C.c_int, _vp, _vp, _sz]),
     "rsq_dev_download": (C.c_int, [C.c_int, _vp, _vp, _sz]),
+    "rsq_host_alloc": (C.c_int, [_sz, _pp]),
+    "rsq_host_free": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -14,7 +14,10 @@
 
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <random>
 #include <set>
 #include <sstream>
@@ -194,14 +197,83 @@ struct DevBuffer {
     }
 };
 
-bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, std::vector<char> &h, TextOut &f1, TextOut &f2) {
-    h.resize(std::max(l1, l2) + 1);
-    if (!check(rsq_dev_download(0, h.data(), d1.p, l1), "download")) return false;
-    f1.write(h.data(), l1);
-    if (!check(rsq_dev_download(0, h.data(), d2.p, l2), "download")) return false;
-    f2.write(h.data(), l2);
-    return f1.good() && f2.good();
-}
+// One output file with its own writer thread and two page-locked staging buffers: while the thread writes (and compresses) batch i,
+// the simulator produces batch i+1 and its text is copied into the other buffer.
+struct AsyncOut {
+    TextOut out;
+    void *buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0}, len[2] = {0, 0};
+    bool full[2] = {false, false};
+    int next_fill = 0, next_write = 0;
+    bool stop = false, started = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread worker;
+    bool open(const std::string &path) {
+        if (!out.open(path)) return false;
+        worker = std::thread([this] {
+            std::unique_lock<std::mutex> lock(m);
+            for (;;) {
+                cv.wait(lock, [this] { return full[next_write] || stop; });
+                if (!full[next_write]) return;
+                const int k = next_write;
+                lock.unlock();
+                out.write(static_cast<const char *>(buf[k]), len[k]);
+                lock.lock();
+                full[k] = false;
+                next_write ^= 1;
+                cv.notify_all();
+            }
+        });
+        started = true;
+        return true;
+    }
+    // copies `bytes` of device text through the staging buffers, a chunk at a time, and queues the chunks
+    static constexpr size_t kChunk = 64u << 20;
+    bool push(const DevBuffer &d, size_t bytes) {
+        for (size_t done = 0; done < bytes; done += kChunk) {
+            const size_t n = std::min(kChunk, bytes - done);
+            int k;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                k = next_fill;
+                cv.wait(lock, [&] { return !full[k]; });
+            }
+            if (!buf[k]) {
+                if (!check(rsq_host_alloc(kChunk, &buf[k]), "host buffer")) return false;
+                cap[k] = kChunk;
+            }
+            if (!check(rsq_dev_download(0, buf[k], static_cast<const char *>(d.p) + done, n), "download")) return false;
+            {
+                std::lock_guard<std::mutex> lock(m);
+                len[k] = n;
+                full[k] = true;
+                next_fill ^= 1;
+            }
+            cv.notify_all();
+        }
+        return out.good();
+    }
+    void close() {
+        if (started) {
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [this] { return !full[0] && !full[1]; });
+                stop = true;
+            }
+            cv.notify_all();
+            worker.join();
+            started = false;
+        }
+        out.close();
+        for (int k = 0; k < 2; ++k)
+            if (buf[k]) rsq_host_free(buf[k]);
+        buf[0] = buf[1] = nullptr;
+    }
+    bool good() const { return out.good(); }
+};
+
+bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, AsyncOut &f1, AsyncOut &f2) { return f1.push(d1, l1) && f2.push(d2, l2); }
 
 int illumina_pe(const Args &a) {
     const std::string vcf_path = a.get("vcfSim", "");               // -V: per-allele simulation (substitutions; the library refuses what it cannot simulate yet)
@@ -277,7 +349,7 @@ int illumina_pe(const Args &a) {
                    "Preparation failed");
     }
     if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
-    TextOut f1, f2;
+    AsyncOut f1, f2;
     if (ok) {
         const bool o1 = f1.open(out1), o2 = f2.open(out2);
         if (!o1 || !o2) {
@@ -291,7 +363,6 @@ int illumina_pe(const Args &a) {
         INFO("Aiming for " << info.total_pairs + info.adapter_only_pairs << " read pairs");
         INFO("Starting read generation");
         DevBuffer d1, d2;
-        std::vector<char> host;
         uint64_t written = 0;
         // about 4 M pairs per call: large launches keep the persistent read kernel's tail short, and sparse coverage needs long block ranges
         const double pairs_per_block = (double)info.total_pairs / std::max<uint32_t>(1u, info.total_blocks);
@@ -305,7 +376,7 @@ int illumina_pe(const Args &a) {
                 ok = d1.ensure(l1 + l1 / 8 + 4096) && d2.ensure(l2 + l2 / 8 + 4096);
                 if (ok) rc = rsq_sim_pairs(sim, lo, hi, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, &n, nullptr, 0, nullptr);
             }
-            ok = ok && check(rc, "Simulation failed") && (n == 0 || flush_pair(d1, l1, d2, l2, host, f1, f2));
+            ok = ok && check(rc, "Simulation failed") && (n == 0 || flush_pair(d1, l1, d2, l2, f1, f2));
             written += n;
             if (ok && n) INFO("Generated " << written << " read pairs (" << (info.total_pairs ? (written * 100 + info.total_pairs / 2) / info.total_pairs : 0) << "%).");
         }
@@ -317,7 +388,7 @@ int illumina_pe(const Args &a) {
                 ok = d1.ensure(l1 + 4096) && d2.ensure(l2 + 4096);
                 if (ok) rc = rsq_sim_adapter_only_pairs(sim, first, n, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, nullptr);
             }
-            ok = ok && check(rc, "Simulation of adapter-only pairs failed") && flush_pair(d1, l1, d2, l2, host, f1, f2);
+            ok = ok && check(rc, "Simulation of adapter-only pairs failed") && flush_pair(d1, l1, d2, l2, f1, f2);
         }
     }
     f1.close();

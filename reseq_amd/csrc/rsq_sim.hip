@@ -916,6 +916,19 @@ int rsq_dev_upload(int device, void *dst_dev, const void *src, size_t bytes) {
         return RSQ_OK;
     });
 }
+int rsq_host_alloc(size_t bytes, void **out_host) {
+    REQUIRE(out_host, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipHostMalloc(out_host, bytes ? bytes : 8, hipHostMallocDefault));
+        return RSQ_OK;
+    });
+}
+int rsq_host_free(void *host) {
+    return guard([&] {
+        if (host) HIP_CHECK(hipHostFree(host));
+        return RSQ_OK;
+    });
+}
 int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(device));
