@@ -1540,6 +1540,7 @@ struct VariantSrc : FragmentSrc {
     const DevVariant *var;              // the sequence's variants in forward order
     const uint16_t *err_fwd, *err_rev;
     uint32_t n_var, L, allele;
+    uint32_t *walk_error;               // DevSim::walk_error
     uint32_t spos0, cur0, var_pos0;     // start of the walk: strand position of the first template base, variant index, position in an insertion
     mutable uint32_t spos, cur, var_pos;
     RSQ_HD const DevVariant &var_at(uint32_t i) const { return reverse ? var[n_var - 1u - i] : var[i]; }
@@ -1565,7 +1566,15 @@ struct VariantSrc : FragmentSrc {
         const uint32_t bend = block_end(spos);
         if (++spos == bend) cur = lower_bound(spos);
     }
+    // With variants a few bases apart the walk (its skipped variants, its late ones) can use up more reference positions than the
+    // template has and run off the end of the strand: the reference follows a NULL next_block_ there.  Reported, not simulated.
+    RSQ_HD bool off_strand() const {
+        if (spos < L) return false;
+        *walk_error = 1u;
+        return true;
+    }
     RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
+        if (off_strand()) return 0;
         if (var_pos) {
             const uint32_t se = sys_[spos - spos0];
             if (++var_pos >= var_at(cur).len) {
@@ -1584,6 +1593,7 @@ struct VariantSrc : FragmentSrc {
                 if (0u == v.len) {                                              // deletion
                     ++cur;
                     increment_block_pos();
+                    if (off_strand()) return 0;
                     bend = block_end(spos);
                 } else {
                     const uint32_t se = var_err(cur, 0);
@@ -1601,6 +1611,7 @@ struct VariantSrc : FragmentSrc {
         return se;
     }
     RSQ_HD uint32_t sys_deleted(uint32_t) const {                               // :380-392
+        if (off_strand()) return 0;
         const uint32_t se = sys_[spos - spos0];
         if (var_pos && ++var_pos >= var_at(cur).len) var_pos = 0;
         if (0u == var_pos) {
@@ -1627,6 +1638,7 @@ RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, const Fragment
     src.n_var = S.var_ptr[f.seq + 1] - S.var_ptr[f.seq];
     src.L = S.seq_len[f.seq];
     src.allele = f.allele;
+    src.walk_error = S.walk_error;
     src.spos0 = src.reverse ? src.L - src.first : src.first;
     if (!fv) {
         src.cur0 = src.lower_bound(src.spos0);

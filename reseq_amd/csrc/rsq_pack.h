@@ -444,6 +444,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     d.var_err_fwd = s.dev_var_err_fwd;
     d.var_err_rev = s.dev_var_err_rev;
     d.extra = up.put(s.extra);
+    d.walk_error = up.put(std::vector<uint32_t>(2, 0));
     d.block_extra_ptr = nullptr;                                  // set by plan_simulation once the blocks are numbered
     if (2 == s.variants_mode) {                                   // templates are written out per mate (k_variant_templates)
         s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;
@@ -847,6 +848,10 @@ inline void build_variant_sys_errors(SimState &s, Uploader &up) {
     up.write_bytes(s.dev_var_err_fwd, s.var_err_fwd.data(), s.var_err_fwd.size() * sizeof(uint16_t));
     up.write_bytes(s.dev_var_err_rev, s.var_err_rev.data(), s.var_err_rev.size() * sizeof(uint16_t));
 }
+
+constexpr const char *kWalkErrorMessage =
+    "systematic-error walk left the sequence: with variants this close together at a sequence end the reference follows a NULL block "
+    "(GetSysErrorFromBlock, Simulator.cpp:232-292); such a variant set cannot be simulated";
 
 // ------------------------------------------------------------------------------- chains of the a13 pre-pass
 constexpr uint32_t kChainChunk = 256;

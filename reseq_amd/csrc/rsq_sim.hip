@@ -359,11 +359,18 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
                        (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
+    s.mailbox[4] = 0;
+    if (frags && s.has_variants) HIP_CHECK(hipMemcpyAsync(&s.mailbox[4], s.dev.walk_error, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(&s.mailbox[3], s.off_r2.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     *r1_len = s.mailbox[2];
     *r2_len = s.mailbox[3];
+    if ((uint32_t)s.mailbox[4]) {
+        HIP_CHECK(hipMemsetAsync(s.dev.walk_error, 0, 4, st));
+        g_last_error = kWalkErrorMessage;
+        return RSQ_EINVAL;
+    }
     if (*r1_len > r1_cap || *r2_len > r2_cap || !r1 || !r2) {
         g_last_error = "output buffers too small: need " + std::to_string(*r1_len) + " and " + std::to_string(*r2_len) + " bytes";
         return RSQ_ENOSPC;

@@ -186,6 +186,7 @@ struct DevSim {
     const uint32_t *var_ptr;         // [n_seqs + 1]
     const uint8_t *var_bases;
     const uint16_t *var_err_fwd, *var_err_rev;
+    uint32_t *walk_error;            // set by a read whose systematic-error walk leaves its sequence (the reference dereferences a NULL block there)
     // variants_loaded == 2: slots of the sieve = start positions plus the extra passes inside inserted bases, in loop order
     const ExtraStart *extra;         // sorted by (sequence, pos, sub)
     const uint32_t *block_extra_ptr; // [total_blocks + 2] extras before block b (index b, 1-based)

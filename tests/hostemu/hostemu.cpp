@@ -521,6 +521,10 @@ int emu_pairs_text(void *h, const Fragment *frags, uint64_t n_pairs, uint64_t ad
                 if (wrote != need) throw Error("record_size disagrees with format_record");
                 pos[seg] += need;
             }
+        if (frags && s.has_variants && *s.dev.walk_error) {
+            *s.dev.walk_error = 0;
+            throw Error(kWalkErrorMessage);
+        }
         *len1 = pos[0];
         *len2 = pos[1];
     });

@@ -571,6 +571,33 @@ def case_variants_complex(backend_cls, workdir):
         p.close()
 
 
+def case_variants_walk_off_sequence(backend_cls, workdir):
+    """Variants every few bases right at a sequence end: the walk of GetSysErrorFromBlock (skipped and late variants included) uses up more
+    reference positions than the template has and leaves the sequence -- the reference follows a NULL next_block_ there.  The oracle raises,
+    and so does the product, instead of reading whatever lies behind the track."""
+    import pytest
+    lengths = [2705, 4757]
+    rng = np.random.default_rng(1011)
+    # the draws tools/stress_variants.py makes before this variant set (its trial 11)
+    n_seq = int(rng.integers(1, 5))
+    [int(rng.integers(1001, 7000)) if rng.random() < 0.8 else int(rng.integers(40, 90)) for _ in range(n_seq)]
+    int(rng.choice([6, 12, 25, 60])), int(rng.choice([1, 1, 2, 3])), int(rng.integers(0, 3))
+    seqs = make_inputs(workdir, "walkoff", synth.TINY, lengths, ref_seed=511)[2]
+    vcf = workdir / "walkoff.vcf"
+    write_vcf(vcf, seqs, _mixed_variant_set(seqs, rng, 6))
+    p = Pair(backend_cls, workdir, "walkoff", synth.TINY, lengths, seed=int(rng.integers(1, 1 << 30)), num_pairs=int(rng.integers(2000, 9000)), vcf=vcf, ref_seed=511)
+    try:
+        p.align_normalization()
+        ofr = p.osim.sieve_var(1, 2)
+        with pytest.raises(RuntimeError, match="systematic-error walk left the sequence"):
+            p.osim.create_reads_var(ofr)
+        with pytest.raises(Exception, match="systematic-error walk left the sequence"):
+            p.b.pairs(1, 2)
+        _compare_blocks_var(p, 2, 3)                           # away from the sequence end the same set simulates fine
+    finally:
+        p.close()
+
+
 def case_variants_with_loaded_sys_errors(backend_cls, workdir):
     """--readSysError together with -V: the variants' own errors are drawn against the LOADED tracks (their error-region state follows
     the file's rates: SetSystematicErrorVariants* run after ReadSystematicErrors, Simulator.cpp:983-986,1232-1234)"""

@@ -172,6 +172,10 @@ def test_variants_complex(workdir):
     P.case_variants_complex(GpuBackend, workdir)
 
 
+def test_variants_walk_off_sequence_is_reported(workdir):
+    P.case_variants_walk_off_sequence(GpuBackend, workdir)
+
+
 def test_variants_with_loaded_sys_errors(workdir):
     P.case_variants_with_loaded_sys_errors(GpuBackend, workdir)
 
