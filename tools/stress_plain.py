@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress without variants: random references (G/C content, several sequences, some without blocks), synthetic profiles
 from different seeds, random pair counts and seeds, profile edits, optional methylation; fragments and FASTQ text of the device must equal
-the oracle's.  Usage: python tools/stress_plain.py [n_trials] [gpu|emu]"""
+the oracle's.  Usage: python tools/stress_plain.py [n_trials] [gpu|emu] [tiny|p0]"""
 import os
 import pathlib
 import sys
@@ -17,6 +17,7 @@ from reseq_amd import synth  # noqa: E402
 
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 which = sys.argv[2] if len(sys.argv) > 2 else "gpu"
+CFG = synth.P0 if len(sys.argv) > 3 and sys.argv[3] == "p0" else synth.TINY      # p0: the bench profile (2 x 150, inserts up to 1000)
 if which == "gpu":
     from backends import GpuBackend as Backend
 else:
@@ -41,7 +42,7 @@ with tempfile.TemporaryDirectory() as d:
             edits = {"error_multiplier": float(rng.choice([0.5, 2.0, 10.0]))}
         tag = f"pl{t}"
         kw = dict(prof_seed=int(rng.integers(1, 1000)), ref_seed=int(rng.integers(1, 1000)), gc=float(rng.choice([0.25, 0.5, 0.7])))
-        p = P.Pair(Backend, wd, tag, synth.TINY, lengths, seed=int(rng.integers(1, 1 << 40)), num_pairs=int(rng.integers(500, 12000)), edits=edits or None,
+        p = P.Pair(Backend, wd, tag, CFG, lengths, seed=int(rng.integers(1, 1 << 40)), num_pairs=int(rng.integers(500, 12000)), edits=edits or None,
                    ref_bias_mode=int(rng.choice([0, 1, 2])), **kw)
         try:
             if rng.random() < 0.3:

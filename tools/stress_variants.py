@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress for the simulation with variants: random references (several sequences, some too short to get blocks), random
 substitution / insertion / deletion sets of different densities, allele counts and seeds, with and without methylation; the device's
-fragments and FASTQ text must equal the oracle's.  Usage: python tools/stress_variants.py [n_trials] [gpu|emu]"""
+fragments and FASTQ text must equal the oracle's.  Usage: python tools/stress_variants.py [n_trials] [gpu|emu] [tiny|p0]"""
 import os
 import pathlib
 import sys
@@ -17,6 +17,7 @@ from reseq_amd import synth  # noqa: E402
 
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 which = sys.argv[2] if len(sys.argv) > 2 else "gpu"
+CFG = synth.P0 if len(sys.argv) > 3 and sys.argv[3] == "p0" else synth.TINY      # p0: the bench profile (2 x 150, inserts up to 1000)
 if which == "gpu":
     from backends import GpuBackend as Backend
 else:
@@ -35,7 +36,7 @@ with tempfile.TemporaryDirectory() as d:
         samples = int(rng.choice([1, 1, 2, 3]))
         kind = int(rng.integers(0, 3))
         tag = f"st{t}"
-        seqs = P.make_inputs(wd, tag, synth.TINY, lengths, ref_seed=500 + t)[2]
+        seqs = P.make_inputs(wd, tag, CFG, lengths, ref_seed=500 + t)[2]
         maker = (P._mixed_variant_set, P._complex_variant_set, lambda s, r, dd: P._substitution_set(s, r, dd, [0, 1, 999, 1000]))[kind]
         vs = maker(seqs, rng, max(density, 25) if kind == 1 else density)
         if samples > 1:
@@ -43,7 +44,7 @@ with tempfile.TemporaryDirectory() as d:
                   if "," not in alt]
         vcf = wd / f"{tag}.vcf"
         P.write_vcf(vcf, seqs, vs, samples=samples)
-        p = P.Pair(Backend, wd, tag, synth.TINY, lengths, seed=int(rng.integers(1, 1 << 30)), num_pairs=int(rng.integers(2000, 9000)), vcf=vcf, ref_seed=500 + t)
+        p = P.Pair(Backend, wd, tag, CFG, lengths, seed=int(rng.integers(1, 1 << 30)), num_pairs=int(rng.integers(2000, 9000)), vcf=vcf, ref_seed=500 + t)
         try:
             if rng.random() < 0.4:
                 names = [n.split(" ")[0] for n, _ in seqs]
