@@ -161,7 +161,8 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
                         uint32_t cigar_stride, void *stream);
 
 /* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded on the call's stream
- * around each kernel.  names: "sieve" (screen + finish), "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan". */
+ * around each kernel.  names: "sieve" (screen + finish), "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"; with variants of any kind also
+ * "slot_table" and "variant_templates". */
 int rsq_sim_last_kernel_ms(const rsq_sim *s, const char *kernel, double *ms);
 
 /* ---- device memory helpers so that callers without a HIP binding (ctypes tests, the CLI) can stage buffers */

@@ -345,7 +345,9 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
         s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
         raw.templates = s.templates.as<uint64_t>();
         raw.template_words = s.template_words;
+        s.timers["variant_templates"].start(st);
         hipLaunchKernelGGL(k_variant_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, fvars, n_pairs, raw);
+        s.timers["variant_templates"].stop(st);
         HIP_CHECK(hipGetLastError());
     }
     launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st, fvars);

@@ -353,36 +353,61 @@ RSQ_HD void evaluate_allele(const VarView &r, const VarStart &st, uint32_t allel
 }
 
 // Reference::ReferenceSequence with variants (Reference.cpp:498-567): the template of one mate, 2 bits per base in read orientation
-struct TemplateWriter {
+struct TemplateWriter {                 // 32 bases are collected in a register and stored as one word
     uint64_t *words;
     uint32_t n, cap;
+    uint64_t acc;
     RSQ_HD void put(uint32_t base) {
-        if (n < cap) words[n >> 5] |= (uint64_t)base << ((n & 31u) * 2u);
+        if (n < cap) {
+            acc |= (uint64_t)base << ((n & 31u) * 2u);
+            if ((n & 31u) == 31u) {
+                words[n >> 5] = acc;
+                acc = 0;
+            }
+        }
         ++n;
     }
+    RSQ_HD void finish(uint32_t template_words) {                               // the last partial word, zeros behind it
+        const uint32_t have = n < cap ? n : cap;
+        uint32_t w = have >> 5;
+        if (have & 31u) words[w++] = acc;
+        for (; w < template_words; ++w) words[w] = 0;
+    }
 };
-RSQ_HD uint32_t reference_sequence_with_variants(const VarView &r, uint32_t start_pos, uint32_t frag_length, bool reversed, VarStart first_variant, uint32_t allele,
+struct RefReader {                      // consecutive reference bases: one load per 32 of them
+    const VarView &r;
+    uint32_t index = 0xFFFFFFFFu;
+    uint64_t word = 0;
+    RSQ_HD uint32_t at(uint32_t pos) {
+        if ((pos >> 5) != index) {
+            index = pos >> 5;
+            word = r.words[r.word_off + index];
+        }
+        return (uint32_t)(word >> ((pos & 31u) * 2u)) & 3u;
+    }
+};
+RSQ_HD uint32_t reference_sequence_with_variants(const VarView &view, uint32_t start_pos, uint32_t frag_length, bool reversed, VarStart first_variant, uint32_t allele,
                                                  uint64_t *tmpl, uint32_t template_words) {
-    for (uint32_t w = 0; w < template_words; ++w) tmpl[w] = 0;
-    TemplateWriter out{tmpl, 0, frag_length};                                   // resize(out, frag_length) at the end
+    RefReader r{view};
+    TemplateWriter out{tmpl, 0, frag_length, 0};                                // resize(out, frag_length) at the end
     uint32_t cur_start = start_pos;
     int32_t cur_var = first_variant.first_variant_id;
     if (reversed) {
         if (first_variant.start_variant_pos) {
-            const DevVariant &var = r.v[cur_var];
-            for (uint32_t k = first_variant.start_variant_pos; k--;) out.put(3u - r.base(var, k));       // prefix(var_seq_, pos), reverse complemented
+            const DevVariant &var = view.v[cur_var];
+            for (uint32_t k = first_variant.start_variant_pos; k--;) out.put(3u - view.base(var, k));       // prefix(var_seq_, pos), reverse complemented
             --cur_var;
             --cur_start;
         }
         for (; cur_var >= 0 && out.n < frag_length; --cur_var) {
-            const DevVariant &var = r.v[cur_var];
-            if (!r.in_allele(var, allele)) continue;
+            const DevVariant &var = view.v[cur_var];
+            if (!view.in_allele(var, allele)) continue;
             if (cur_start - var.pos > frag_length - out.n) {
                 const uint32_t from = cur_start + out.n - frag_length;
                 for (uint32_t p = cur_start; p-- > from;) out.put(3u - r.at(p));
             } else {
                 for (uint32_t p = cur_start; p-- > var.pos + 1u;) out.put(3u - r.at(p));
-                for (uint32_t k = var.len; k--;) out.put(3u - r.base(var, k));
+                for (uint32_t k = var.len; k--;) out.put(3u - view.base(var, k));
                 cur_start = var.pos;
             }
         }
@@ -392,28 +417,29 @@ RSQ_HD uint32_t reference_sequence_with_variants(const VarView &r, uint32_t star
         }
     } else {
         if (first_variant.start_variant_pos) {
-            const DevVariant &var = r.v[cur_var];
-            for (uint32_t k = first_variant.start_variant_pos; k < var.len; ++k) out.put(r.base(var, k));
+            const DevVariant &var = view.v[cur_var];
+            for (uint32_t k = first_variant.start_variant_pos; k < var.len; ++k) out.put(view.base(var, k));
             ++cur_var;
             ++cur_start;
         }
-        for (; (uint32_t)cur_var < r.n && out.n < frag_length; ++cur_var) {
-            const DevVariant &var = r.v[cur_var];
-            if (!r.in_allele(var, allele)) continue;
+        for (; (uint32_t)cur_var < view.n && out.n < frag_length; ++cur_var) {
+            const DevVariant &var = view.v[cur_var];
+            if (!view.in_allele(var, allele)) continue;
             if (var.pos - cur_start >= frag_length - out.n) {
                 const uint32_t to = cur_start + frag_length - out.n;
                 for (uint32_t p = cur_start; p < to; ++p) out.put(r.at(p));
             } else {
                 for (uint32_t p = cur_start; p < var.pos; ++p) out.put(r.at(p));
-                for (uint32_t k = 0; k < var.len; ++k) out.put(r.base(var, k));
+                for (uint32_t k = 0; k < var.len; ++k) out.put(view.base(var, k));
                 cur_start = var.pos + 1u;
             }
         }
-        if ((uint32_t)cur_var == r.n && out.n < frag_length) {
+        if ((uint32_t)cur_var == view.n && out.n < frag_length) {
             const uint32_t to = cur_start + frag_length - out.n;
             for (uint32_t p = cur_start; p < to; ++p) out.put(r.at(p));
         }
     }
+    out.finish(template_words);
     return out.n < frag_length ? out.n : frag_length;
 }
 

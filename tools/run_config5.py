@@ -94,7 +94,7 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
         t_gpu += time.perf_counter() - t1
         if rc != api.RSQ_OK:
             raise SystemExit(f"rc {rc}: {api.lib().rsq_last_error().decode()}")
-        for key in ("slot_table", "sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"):
+        for key in ("slot_table", "variant_templates", "sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"):
             kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
         n += k
         nbytes += l1 + l2
