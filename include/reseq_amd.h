@@ -35,14 +35,25 @@ enum {
 };
 
 const char *rsq_last_error(void);
+const char *rsq_last_warning(void);          /* non-fatal remarks of the last rsq_profile_load* call ("" if none) */
 const char *rsq_version(void);
 /* number of visible HIP devices, or RSQ_ENODEV */
 int rsq_device_count(void);
 
 /* ---- profile: stands in for DataStats::Load + PrepareProcessing (reseq/DataStats.cpp:1280-1340) and
  *      ProbabilityEstimates::Load + PrepareResult (reseq/ProbabilityEstimates.cpp:961-1065).
- *      `path` is an RSQP container (reseq_amd/container.py documents the layout). */
+ *      `path` is an RSQP container (reseq_amd/container.py documents the layout) or a `.reseq` archive (see rsq_profile_load_reseq). */
 int rsq_profile_load(const char *path, rsq_profile **out);
+/* ReSeq's own profile files: `stats_path` = the `.reseq` Boost text archive DataStats::Save writes (reseq/DataStats.cpp:1302-1320, member
+ * list DataStats.h:180-212), `ipf_path` = the `.reseq.ipf` archive of ProbabilityEstimates::Save (reseq/ProbabilityEstimates.cpp:1047-1065,
+ * member list ProbabilityEstimates.h:1475-1483; NULL = "<stats_path>.ipf", main.cpp:837).  Does what `main` does between loading and
+ * Simulator::Simulate with --ipfIterations 0: DataStats::PrepareProcessing (total reads, AdapterStats::SumCounts / PrepareSimulation,
+ * ErrorStats::PrepareSimulation) and ProbabilityEstimates::PrepareResult (FullExpansion, GetResults, ImputeMissingValues).  Fitting is not
+ * part of this build: tables whose stored precision is above `ipf_precision_percent` (--ipfPrecision, default 5) are used as stored and
+ * reported through rsq_last_warning().  rsq_profile_load recognises such a file by its first bytes and forwards here. */
+int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out);
+/* writes the prepared profile (result tables, not the fit) as an RSQP container */
+int rsq_profile_save(const rsq_profile *p, const char *path);
 void rsq_profile_free(rsq_profile *p);
 /* ProbabilityEstimates::ChangeErrorRate / RemoveSubstitutionErrors / RemoveInDelErrors
  * (reseq/ProbabilityEstimates.h:1516-1549; CLI --errorMutliplier, --noSubstitutionErrors, --noInDelErrors) */

@@ -40,6 +40,9 @@ SYMBOLS = {
     "rsq_version": (C.c_char_p, []),
     "rsq_device_count": (C.c_int, []),
     "rsq_profile_load": (C.c_int, [C.c_char_p, _pp]),
+    "rsq_profile_load_reseq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, _pp]),
+    "rsq_profile_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rsq_last_warning": (C.c_char_p, []),
     "rsq_profile_free": (None, [_vp]),
     "rsq_profile_change_error_rate": (C.c_int, [_vp, C.c_double]),
     "rsq_profile_remove_substitution_errors": (C.c_int, [_vp]),
@@ -118,11 +121,20 @@ def device_count():
 
 
 class Profile:
-    """DataStats::Load + ProbabilityEstimates::Load/PrepareResult on an RSQP container."""
+    """DataStats::Load + ProbabilityEstimates::Load/PrepareResult: an RSQP container, or ReSeq's own `.reseq` archive
+    (then `ipf_path` names the `.reseq.ipf` archive, default `<path>.ipf`)."""
 
-    def __init__(self, path):
+    def __init__(self, path, ipf_path=None, ipf_precision=5.0):
         self.h = C.c_void_p()
-        _check(lib().rsq_profile_load(os.fsencode(path), C.byref(self.h)))
+        if ipf_path is None and ipf_precision == 5.0:
+            _check(lib().rsq_profile_load(os.fsencode(path), C.byref(self.h)))
+        else:
+            _check(lib().rsq_profile_load_reseq(os.fsencode(path), os.fsencode(ipf_path) if ipf_path else None, ipf_precision, C.byref(self.h)))
+        self.warning = lib().rsq_last_warning().decode()
+
+    def save(self, path):
+        """the prepared profile as an RSQP container"""
+        _check(lib().rsq_profile_save(self.h, os.fsencode(path)))
 
     def change_error_rate(self, multiplier):
         _check(lib().rsq_profile_change_error_rate(self.h, multiplier))

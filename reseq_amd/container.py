@@ -1,9 +1,10 @@
-"""RSQP named-array container: the native on-disk form of a ReSeq profile.
+"""RSQP named-array container: the flat on-disk form of a PREPARED ReSeq profile.
 
 The reference keeps a fitted profile in two Boost text archives (`.reseq`:
 DataStats.h:180-212, `.reseq.ipf`: ProbabilityEstimates.h:1475-1483).  This
 build's primary format is a flat, little-endian sequence of named arrays that
-C (oracle/), C++ (reseq_amd/csrc/profile_io.cpp) and numpy read with the same
+C (oracle/oracle_base.c), C++ (reseq_amd/csrc/rsq_host.cpp, written by
+rsq_profile_archive.cpp) and numpy read with the same
 20-line loop.  Field names follow the reference's member names.
 
 Layout

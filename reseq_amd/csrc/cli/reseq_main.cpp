@@ -34,6 +34,10 @@ int g_verbosity = 4;
     do {                                                         \
         if (g_verbosity >= 3) std::cerr << "[INFO] " << msg << std::endl; \
     } while (0)
+#define WARN(msg)                                                \
+    do {                                                         \
+        if (g_verbosity >= 2) std::cerr << "[WARN] " << msg << std::endl; \
+    } while (0)
 #define ERR(msg)                                                 \
     do {                                                         \
         if (g_verbosity >= 1) std::cerr << "[ERROR] " << msg << std::endl; \
@@ -102,16 +106,29 @@ uint64_t get_seed(const Args &a) {                      // main.cpp:340: random 
 bool load_profile(const Args &a, rsq_profile **p) {
     for (const char *k : {"bamIn", "adapterFile", "adapterMatrix", "statsOut", "vcfIn", "statsOnly", "noBias", "tiles", "probabilitiesOut", "stopAfterEstimation"})
         if (a.has(k) && !(std::string(k) == "stopAfterEstimation" && a.has("writeSysError"))) {       // main.cpp:845: the profile alone may be asked for
-            ERR("--" << k << ": profile creation (statistics, bias fit, IPF) is not supported in this build; create the profile with the reference tool and pass it with -s");
+            ERR("--" << k << ": profile creation (statistics, bias fit, IPF) is not supported in this build; create the profile with ReSeq (`reseq illuminaPE -b ... --statsOnly` / `--stopAfterEstimation`) and pass its .reseq file with -s");
             return false;
         }
     if (!a.has("statsIn")) {
         ERR("statsIn option mandatory.");
         return false;
     }
-    if (a.has("ipfIterations") && a.get("ipfIterations") != "0") INFO("--ipfIterations is ignored: the profile holds the prepared result tables");
+    // main.cpp:729-730,776-779: the fit itself is not part of this build, a `.reseq.ipf` file is taken as stored (--ipfIterations 0)
+    if (a.has("ipfIterations") && a.get("ipfIterations") != "0") INFO("--ipfIterations is ignored: fitted tables are used as stored (as with --ipfIterations 0)");
+    char *end = nullptr;
+    const double ipf_precision = a.has("ipfPrecision") ? strtod(a.get("ipfPrecision").c_str(), &end) : 5.0;
+    if (a.has("ipfPrecision") && (end == a.get("ipfPrecision").c_str() || *end || !(ipf_precision > 0.0))) {
+        ERR("ipfPrecision must be positive.");
+        return false;
+    }
+    // a `.reseq` statistics file (with its `.reseq.ipf`, main.cpp:837: "<statsIn>.ipf" unless -p names another) or an RSQP container
     INFO("Reading profile from " << a.get("statsIn"));
-    if (!check(rsq_profile_load(a.get("statsIn").c_str(), p), "Could not load profile")) return false;
+    const bool archives = a.has("probabilitiesIn") || a.has("ipfPrecision");
+    if (!check(archives ? rsq_profile_load_reseq(a.get("statsIn").c_str(), a.has("probabilitiesIn") ? a.get("probabilitiesIn").c_str() : nullptr, ipf_precision, p)
+                        : rsq_profile_load(a.get("statsIn").c_str(), p),
+               "Could not load profile"))
+        return false;
+    if (*rsq_last_warning()) WARN(rsq_last_warning());
     const double mult = a.has("errorMutliplier") ? atof(a.get("errorMutliplier").c_str()) : 1.0;
     if (a.has("noInDelErrors") && !check(rsq_profile_remove_indel_errors(*p), "noInDelErrors")) return false;          // main.cpp:964-982
     if (a.has("noSubstitutionErrors")) {

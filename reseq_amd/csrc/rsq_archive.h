@@ -1,0 +1,301 @@
+// rsq_archive.h -- reader for the Boost.Serialization *text* archives ReSeq keeps its profiles in
+// (`.reseq`: DataStats::Save, reseq/DataStats.cpp:1302-1320; `.reseq.ipf`: ProbabilityEstimates::Save,
+// reseq/ProbabilityEstimates.cpp:1047-1065).  No Boost is involved: the archive is a stream of blank-separated tokens and
+// which tokens appear is decided by the static C++ type of every serialized member, so the reader is driven by a description
+// of those types (built with the helpers below, see rsq_profile_archive.cpp).
+//
+// Token rules of boost::archive::text_oarchive that matter here (the rules are recalled from Boost 1.6x/1.7x, there is no
+// Boost and no sample profile in this image: compatibility with a Boost-written file is UNVERIFIED):
+//   header            "22 serialization::archive <library version>"
+//   arithmetic types  printed as numbers (char-sized integers too), bool as 0/1, double with 17 significant digits
+//   std::string       "<length> <bytes>"
+//   class types       the FIRST time an object of a given C++ type is saved: "<tracking> <version>" (both 0 here: nothing is
+//                     saved through a pointer, no BOOST_CLASS_VERSION is used); afterwards nothing.  Class types are: every
+//                     user class, std::pair, std::array, and std::vector of anything that is not a built-in arithmetic type
+//                     (boost/serialization/collection_traits.hpp makes vectors of arithmetic types "object_serializable")
+//   std::vector<T>    "<count> <item_version>" + items (item_version only when the library version is above 3)
+//   std::vector<bool> "<count>" + items
+//   std::array<T,N>   its class info, then the C array inside: "<N>" + items
+//   std::pair         its class info, first, second
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <charconv>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "rsq_host.h"
+
+namespace rsq {
+namespace archive {
+
+struct Type;
+using TypeP = const Type *;
+
+struct Member {
+    std::string name;
+    TypeP type;
+    bool keep;        // parsed into the Node tree (true) or only walked over (false)
+};
+
+struct Type {
+    enum Kind { UINT, INT, F64, BOOL, STR, VEC, ARR, PAIR, CLS };
+    Kind kind = UINT;
+    std::string name;             // canonical C++ spelling: the identity that decides "first time this type is saved"
+    TypeP elem = nullptr;         // VEC, ARR
+    size_t n = 0;                 // ARR
+    TypeP first = nullptr, second = nullptr;   // PAIR
+    std::vector<Member> members;  // CLS
+    bool class_info = false;
+    int id = 0;
+    bool numeric() const { return kind == UINT || kind == INT || kind == F64 || kind == BOOL; }
+};
+
+// Interns types by name, so that `Vect<uint64_t>` reached through two different members is ONE type (one class-info record).
+class Schema {
+   public:
+    TypeP prim(Type::Kind k, const std::string &name) {
+        Type t;
+        t.kind = k;
+        t.name = name;
+        return intern(std::move(t));
+    }
+    TypeP u8() { return prim(Type::UINT, "unsigned char"); }
+    TypeP u16() { return prim(Type::UINT, "unsigned short"); }
+    TypeP u32() { return prim(Type::UINT, "unsigned int"); }
+    TypeP u64() { return prim(Type::UINT, "unsigned long"); }
+    TypeP i8() { return prim(Type::INT, "signed char"); }
+    TypeP f64() { return prim(Type::F64, "double"); }
+    TypeP boolean() { return prim(Type::BOOL, "bool"); }
+    TypeP str() { return prim(Type::STR, "std::string"); }
+    TypeP vec(TypeP e) {
+        Type t;
+        t.kind = Type::VEC;
+        t.name = "std::vector<" + e->name + ">";
+        t.elem = e;
+        t.class_info = !e->numeric();
+        return intern(std::move(t));
+    }
+    TypeP arr(TypeP e, size_t n) {
+        Type t;
+        t.kind = Type::ARR;
+        t.name = "std::array<" + e->name + "," + std::to_string(n) + ">";
+        t.elem = e;
+        t.n = n;
+        t.class_info = true;
+        return intern(std::move(t));
+    }
+    TypeP pair(TypeP a, TypeP b) {
+        Type t;
+        t.kind = Type::PAIR;
+        t.name = "std::pair<" + a->name + "," + b->name + ">";
+        t.first = a;
+        t.second = b;
+        t.class_info = true;
+        return intern(std::move(t));
+    }
+    TypeP cls(const std::string &name, std::vector<Member> members) {
+        Type t;
+        t.kind = Type::CLS;
+        t.name = name;
+        t.members = std::move(members);
+        t.class_info = true;
+        return intern(std::move(t));
+    }
+    size_t size() const { return types_.size(); }
+
+   private:
+    TypeP intern(Type &&t) {
+        auto it = by_name_.find(t.name);
+        if (it != by_name_.end()) return it->second;
+        t.id = (int)types_.size();
+        types_.push_back(std::make_unique<Type>(std::move(t)));
+        by_name_[types_.back()->name] = types_.back().get();
+        return types_.back().get();
+    }
+    std::vector<std::unique_ptr<Type>> types_;
+    std::unordered_map<std::string, TypeP> by_name_;
+};
+
+// What was read.  Numbers of a vector / array of arithmetic type lie flat in `u` (integers, two's complement for signed) or
+// `f`; everything else has one kid per item / member (members that were not kept stay empty).
+struct Node {
+    TypeP type = nullptr;
+    std::vector<Node> kids;
+    std::vector<uint64_t> u;
+    std::vector<double> f;
+    std::string s;
+    const Node &operator[](const char *member) const {
+        if (!type || type->kind != Type::CLS) throw Error("archive: member access on a value that is not a class");
+        for (size_t i = 0; i < type->members.size(); ++i)
+            if (type->members[i].name == member) {
+                if (!type->members[i].keep) throw Error(std::string("archive: member ") + member + " was not kept");
+                return kids[i];
+            }
+        throw Error(std::string("archive: no member ") + member + " in " + type->name);
+    }
+    const Node &operator[](size_t i) const { return kids.at(i); }
+    const Node &operator[](int i) const { return kids.at((size_t)i); }
+    const Node &operator[](uint32_t i) const { return kids.at(i); }
+    size_t size() const { return type && type->elem && type->elem->numeric() ? (type->elem->kind == Type::F64 ? f.size() : u.size()) : kids.size(); }
+    uint64_t uint() const { return u.at(0); }
+    double real() const { return f.at(0); }
+    const Node &first() const { return kids.at(0); }
+    const Node &second() const { return kids.at(1); }
+};
+
+class Reader {
+   public:
+    Reader(const char *begin, const char *end, size_t n_types, const std::string &what) : p_(begin), end_(end), seen_(n_types, 0), what_(what) {
+        const std::string sig = str();
+        if (sig != "serialization::archive") fail("not a Boost text archive");
+        library_version_ = (uint32_t)unsigned_int();
+    }
+    static bool looks_like_archive(const char *begin, size_t n) {
+        static const char head[] = "22 serialization::archive";
+        return n >= sizeof head - 1 && !memcmp(begin, head, sizeof head - 1);
+    }
+    uint32_t library_version() const { return library_version_; }
+    void read(TypeP t, Node *out) {
+        if (t->class_info && !seen_[t->id]) {
+            seen_[t->id] = 1;
+            const uint64_t tracking = unsigned_int();
+            unsigned_int();   // class version (0 everywhere in ReSeq)
+            if (tracking) fail("class " + t->name + " is saved with object tracking, which ReSeq's profiles do not use");
+        }
+        if (out) out->type = t;
+        switch (t->kind) {
+            case Type::UINT:
+            case Type::BOOL: {
+                const uint64_t v = unsigned_int();
+                if (out) out->u.assign(1, v);
+                break;
+            }
+            case Type::INT: {
+                const int64_t v = signed_int();
+                if (out) out->u.assign(1, (uint64_t)v);
+                break;
+            }
+            case Type::F64: {
+                const double v = real();
+                if (out) out->f.assign(1, v);
+                break;
+            }
+            case Type::STR: {
+                std::string v = str();
+                if (out) out->s = std::move(v);
+                break;
+            }
+            case Type::VEC: {
+                const uint64_t count = unsigned_int();
+                if (t->elem->kind != Type::BOOL && library_version_ > 3) unsigned_int();   // item_version
+                items(t->elem, count, out);
+                break;
+            }
+            case Type::ARR: {
+                const uint64_t count = unsigned_int();
+                if (count != t->n) fail("array " + t->name + " holds " + std::to_string(count) + " items");
+                items(t->elem, count, out);
+                break;
+            }
+            case Type::PAIR:
+                if (out) out->kids.resize(2);
+                read(t->first, out ? &out->kids[0] : nullptr);
+                read(t->second, out ? &out->kids[1] : nullptr);
+                break;
+            case Type::CLS:
+                if (out) out->kids.resize(t->members.size());
+                for (size_t i = 0; i < t->members.size(); ++i) read(t->members[i].type, out && t->members[i].keep ? &out->kids[i] : nullptr);
+                break;
+        }
+    }
+    void expect_end() {
+        skip_blank();
+        if (p_ != end_) fail("tokens left after the last member");
+    }
+
+   private:
+    void items(TypeP e, uint64_t count, Node *out) {
+        if (count > (uint64_t)(end_ - p_)) fail("item count larger than the file");
+        if (e->numeric()) {
+            if (e->kind == Type::F64) {
+                if (out) out->f.resize(count);
+                for (uint64_t i = 0; i < count; ++i) {
+                    const double v = real();
+                    if (out) out->f[i] = v;
+                }
+            } else {
+                if (out) out->u.resize(count);
+                for (uint64_t i = 0; i < count; ++i) {
+                    const uint64_t v = e->kind == Type::INT ? (uint64_t)signed_int() : unsigned_int();
+                    if (out) out->u[i] = v;
+                }
+            }
+            return;
+        }
+        if (out) out->kids.resize(count);
+        for (uint64_t i = 0; i < count; ++i) read(e, out ? &out->kids[i] : nullptr);
+    }
+    [[noreturn]] void fail(const std::string &msg) const { throw Error(what_ + ": " + msg + " (near byte " + std::to_string(p_ - begin()) + ")"); }
+    const char *begin() const { return end_ - size_; }
+    void skip_blank() {
+        while (p_ != end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\r' || *p_ == '\t')) ++p_;
+    }
+    uint64_t unsigned_int() {
+        skip_blank();
+        uint64_t v = 0;
+        auto r = std::from_chars(p_, end_, v);
+        if (r.ec != std::errc()) fail("expected an unsigned integer");
+        p_ = r.ptr;
+        return v;
+    }
+    int64_t signed_int() {
+        skip_blank();
+        int64_t v = 0;
+        auto r = std::from_chars(p_, end_, v);
+        if (r.ec != std::errc()) fail("expected an integer");
+        p_ = r.ptr;
+        return v;
+    }
+    double real() {
+        skip_blank();
+        double v = 0;
+        auto r = std::from_chars(p_, end_, v);
+        if (r.ec == std::errc()) {
+            p_ = r.ptr;
+            return v;
+        }
+        // "nan", "-nan", "inf" as printed by iostreams, or a value from_chars rejects (out of range): strtod decides
+        char buf[64];
+        size_t n = 0;
+        while (p_ + n != end_ && n < sizeof buf - 1 && !(p_[n] == ' ' || p_[n] == '\n' || p_[n] == '\r' || p_[n] == '\t')) {
+            buf[n] = p_[n];
+            ++n;
+        }
+        buf[n] = 0;
+        char *e = nullptr;
+        v = strtod(buf, &e);
+        if (e == buf || *e) fail("expected a floating point number");
+        p_ += n;
+        return v;
+    }
+    std::string str() {
+        const uint64_t n = unsigned_int();
+        if (p_ == end_ || n > (uint64_t)(end_ - p_ - 1)) fail("string longer than the file");
+        ++p_;   // the one blank behind the length
+        std::string v(p_, p_ + n);
+        p_ += n;
+        return v;
+    }
+    const char *p_, *end_;
+    size_t size_ = (size_t)(end_ - p_);
+    std::vector<char> seen_;
+    std::string what_;
+    uint32_t library_version_ = 0;
+};
+
+}  // namespace archive
+}  // namespace rsq

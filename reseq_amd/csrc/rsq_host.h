@@ -98,7 +98,11 @@ struct Profile {
     std::vector<HostTable> quality, seq_quality, base_call, dom_error, error_rate, indels;
     uint32_t n_tiles() const { return (uint32_t)tiles.size(); }
 
-    static Profile load(const std::string &path);
+    static Profile load(const std::string &path);                 // RSQP container
+    // ReSeq's own files (rsq_profile_archive.cpp): DataStats::Load + PrepareProcessing, ProbabilityEstimates::Load + PrepareResult
+    static bool is_archive(const std::string &path);
+    static Profile load_archives(const std::string &stats_path, const std::string &ipf_path, double precision_aim = 0.05, std::string *warnings = nullptr);
+    void save(const std::string &path) const;                     // as an RSQP container
     void change_error_rate(double multiplier);          // ProbabilityEstimates.h:1516-1527
     void remove_substitution_errors();                  // :1529-1540
     void remove_indel_errors();                         // :1542-1549

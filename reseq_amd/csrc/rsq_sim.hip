@@ -17,7 +17,7 @@
 
 namespace rsq {
 
-static thread_local std::string g_last_error;
+static thread_local std::string g_last_error, g_last_warning;
 
 struct HipError : Error {
     using Error::Error;
@@ -549,6 +549,7 @@ static int guard(F &&f) {
 extern "C" {
 
 const char *rsq_last_error(void) { return g_last_error.c_str(); }
+const char *rsq_last_warning(void) { return g_last_warning.c_str(); }
 const char *rsq_version(void) { return "reseq_amd 0.1 (gfx950)"; }
 
 int rsq_device_count(void) {
@@ -560,10 +561,33 @@ int rsq_device_count(void) {
     return n;
 }
 
+int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out) {
+    REQUIRE(stats_path && out, "null argument");
+    REQUIRE(ipf_precision_percent > 0.0, "ipfPrecision must be positive.");      // main.cpp:776-779
+    try {
+        g_last_warning.clear();
+        *out = new rsq_profile{Profile::load_archives(stats_path, ipf_path ? ipf_path : "", ipf_precision_percent / 100.0, &g_last_warning)};
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
 int rsq_profile_load(const char *path, rsq_profile **out) {
     REQUIRE(path && out, "null argument");
     try {
+        if (Profile::is_archive(path)) return rsq_profile_load_reseq(path, nullptr, 5.0, out);
         *out = new rsq_profile{Profile::load(path)};
+        return RSQ_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
+int rsq_profile_save(const rsq_profile *p, const char *path) {
+    REQUIRE(p && path, "null argument");
+    try {
+        p->p.save(path);
         return RSQ_OK;
     } catch (const std::exception &e) {
         g_last_error = e.what();

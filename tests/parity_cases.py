@@ -28,7 +28,7 @@ class Pair:
     """oracle + backend on the same inputs"""
 
     def __init__(self, backend_cls, workdir, tag, cfg, ref_lengths, seed, num_pairs=0, coverage=0.0, base_identifier="", edits=None, ref_bias_mode=0,
-                 ref_bias_file=None, vcf=None, **kw):
+                 ref_bias_file=None, vcf=None, backend_profile=None, **kw):
         self.ppath, self.fpath, self.seqs = make_inputs(workdir, tag, cfg, ref_lengths, **kw)
         self.oprof = O.Profile(self.ppath)
         if edits:
@@ -48,7 +48,8 @@ class Pair:
             if not self.ovars:
                 raise RuntimeError(err.value.decode())
         self.osim = O.Sim(self.oprof, self.oref, seed, num_pairs, coverage, base_identifier.encode(), ref_bias_mode, ref_bias_file, variants=self.ovars)
-        self.b = backend_cls(self.ppath, self.fpath, 0, edits, vcf_path=vcf) if vcf else backend_cls(self.ppath, self.fpath, 0, edits)
+        bprof = backend_profile or self.ppath             # the backend may read the same profile from ReSeq's own files
+        self.b = backend_cls(bprof, self.fpath, 0, edits, vcf_path=vcf) if vcf else backend_cls(bprof, self.fpath, 0, edits)
         if ref_bias_file:
             self.b.set_ref_bias_file(ref_bias_file)
         self.info = self.b.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
@@ -131,6 +132,31 @@ def case_sieve_and_reads_tiny(backend_cls, workdir):
         assert b":1102:" in text and b":2308:" in text
         lens = {len(l) for l in text.split(b"\n")[1::4]}
         assert len(lens) > 1
+    finally:
+        p.close()
+
+
+def case_profile_from_reseq_archive(backend_cls, workdir):
+    """the product reads the profile from `.reseq` + `.reseq.ipf` Boost text archives (rsq_profile_archive.cpp), the oracle from the
+    RSQP container those were made from: pre-pass results, fragments and FASTQ text must not differ"""
+    import archive_fixtures as af
+    from reseq_amd import api
+    lengths = [5000, 80, 3210]
+    arrays = synth.make_profile(synth.TINY, seed=5, n_ref_seqs=len(lengths))
+    stats = workdir / "tiny_e2e_archive.reseq"
+    if not stats.exists():
+        af.write_profile_archives(str(stats), arrays)
+    bprof = str(stats)
+    if backend_cls.name != "gpu":                  # the host emulation takes containers only: convert with the product's reader
+        bprof = str(workdir / "tiny_e2e_archive.rsqp")
+        prof = api.Profile(str(stats))
+        prof.save(bprof)
+        prof.close()
+    p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, lengths, seed=7, num_pairs=3000, backend_profile=bprof, edits=dict(error_multiplier=1.7))
+    try:
+        p.align_normalization()
+        n_all, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert 2000 < n_all < 4000 and b"I" in text and b"D" in text
     finally:
         p.close()
 

@@ -29,6 +29,10 @@ def test_sieve_own_thresholds(workdir):
     P.case_sieve_own_thresholds(GpuBackend, workdir)
 
 
+def test_profile_from_reseq_archive(workdir):
+    P.case_profile_from_reseq_archive(GpuBackend, workdir)
+
+
 def test_dense_coverage(workdir):
     P.case_dense_coverage(GpuBackend, workdir)
 
