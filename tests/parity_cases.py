@@ -624,6 +624,62 @@ def case_variants_walk_off_sequence(backend_cls, workdir):
         p.close()
 
 
+def case_coverage_driven(backend_cls, workdir):
+    """the number of pairs from --coverage (configs 3-4 are coverage driven) and from the profile's corrected coverage
+    (Simulator.cpp:2713-2743, CoveragePropLostFromAdapters :90-104, CoverageToNumberPairs :106-108)"""
+    lengths = [5000, 80, 3210]
+    for coverage in (12.5, 0.0):                          # 0 = keep the coverage of the original data (TINY: 8x)
+        p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, lengths, seed=41, num_pairs=0, coverage=coverage)
+        try:
+            assert p.info["total_pairs"] == p.osim.total_pairs() and p.info["adapter_only_pairs"] == p.osim.adapter_only_pairs()
+            want = (coverage or synth.TINY["corrected_coverage"]) * sum(lengths) / 2 / 29.0
+            assert 0.9 * want < p.info["total_pairs"] + p.info["adapter_only_pairs"] < 1.25 * want
+            p.align_normalization()
+            n, _ = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+            assert 0.85 * p.info["total_pairs"] < n < 1.15 * p.info["total_pairs"]
+        finally:
+            p.close()
+
+
+def case_p0_variants(backend_cls, workdir, kind):
+    """configs[4] in small: the HiSeq-shaped profile (K = 40 qualities, 2x150, inserts up to 1000) on a 30 kb reference with variants on
+    two alleles -- `subs`: substitutions (allele copies of the reference), `indels`: insertions and deletions (per-cell bookkeeping,
+    templates with variants), `meth`: indels together with --methylation (one conversion rate per allele)"""
+    lengths = [30000]
+    tag = f"p0_var_{kind}"
+    rng = np.random.default_rng({"subs": 211, "indels": 223, "meth": 227}[kind])
+    kw = dict(prof_seed=103741084, ref_seed=2)
+    seqs = make_inputs(workdir, tag, synth.P0, lengths, **kw)[2]
+    special = [0, 9, 10, 29, 30, 149, 150, 999, 1000, 1001, 14999, 15000]
+    vs = _substitution_set(seqs, rng, 70, special) if kind == "subs" else _mixed_variant_set(seqs, rng, 70, special)
+    vcf = workdir / f"{tag}.vcf"
+    write_vcf(vcf, seqs, vs)
+    p = Pair(backend_cls, workdir, tag, synth.P0, lengths, seed=53, num_pairs=1500, vcf=vcf, **kw)
+    try:
+        np.testing.assert_allclose(p.b.thresholds(), p.osim.thresholds(), rtol=NORM_RTOL, atol=0)
+        if hasattr(p.b, "variant_sys_errors"):
+            _compare_variant_sys_errors(p, [0])
+        if kind == "meth":
+            name = seqs[0][0].split(" ")[0]
+            bed = workdir / f"{tag}.bed"
+            bed.write_text(f"{name}\t0\t400\t0.0\t0.5\n{name}\t420\t421\t0.5\t0.0\n{name}\t900\t14000\t0.25\t0.75\n{name}\t15000\t29900\t0.1\t0.9\n")
+            p.b.read_methylation(bed)
+            p.osim.read_methylation(bed)
+        p.align_normalization()
+        tb = p.info["total_blocks"]
+        ofr, text = _compare_blocks_var(p, 1, tb + 1)
+        assert 1000 < len(ofr) < 2000 and set(np.unique(ofr["allele"])) == {0, 1}
+        lens = {len(l) for l in text.split(b"\n")[1::4] if l}
+        assert lens == {150}
+        if kind != "subs":
+            shift = ofr["end"].astype(np.int64) - ofr["start"] - ofr["len"]
+            assert shift.min() < 0 < shift.max()
+        part, _ = _compare_blocks_var(p, 7, 19)               # batching by block range
+        assert len(part) == int(((ofr["block"] >= 7) & (ofr["block"] < 19)).sum())
+    finally:
+        p.close()
+
+
 def case_variants_with_loaded_sys_errors(backend_cls, workdir):
     """--readSysError together with -V: the variants' own errors are drawn against the LOADED tracks (their error-region state follows
     the file's rates: SetSystematicErrorVariants* run after ReadSystematicErrors, Simulator.cpp:983-986,1232-1234)"""

@@ -33,6 +33,15 @@ def test_profile_from_reseq_archive(workdir):
     P.case_profile_from_reseq_archive(GpuBackend, workdir)
 
 
+def test_coverage_driven(workdir):
+    P.case_coverage_driven(GpuBackend, workdir)
+
+
+@pytest.mark.parametrize("kind", ["subs", "indels", "meth"])
+def test_p0_variants(workdir, kind):
+    P.case_p0_variants(GpuBackend, workdir, kind)
+
+
 def test_dense_coverage(workdir):
     P.case_dense_coverage(GpuBackend, workdir)
 
@@ -108,6 +117,60 @@ def test_cli_write_then_read_sys_error_profile(workdir):
     assert prof.read_bytes().count(b"\n") == 16
     r = subprocess.run(common + ["-1", a1, "-2", a2, "--writeSysError", str(prof), "--readSysError", str(prof)], capture_output=True)
     assert r.returncode != 0 and b"mutually exclusive" in r.stderr
+
+
+def test_cli_seq_to_illumina_equals_the_oracle(workdir):
+    """reseq seqToIllumina (Simulator::ApplyErrorsAndQualityToFastaInput, Simulator.cpp:2403-2512): FASTA records
+    "{id} {1|2};{fragment length};{dominant errors};{error rates}" -> FASTQ "@{id} {CIGAR} E{errors}"; ids with blanks, error rates above
+    86 % (stored halved, Simulator.cpp:2439-2442), wrapped sequence lines, two template lengths in one file, input order kept"""
+    import os
+    import subprocess
+    import numpy as np
+    import oracle_lib as O
+    from reseq_amd import synth
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reseq_amd", "reseq")
+    ppath, _, _ = P.make_inputs(workdir, "cli_s2i", synth.TINY, [100])
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    parts = [synth.make_error_model_input(21, 700, 30, arrays, zero_frac=0.6), synth.make_error_model_input(22, 60, 75, arrays, zero_frac=0.5),
+             synth.make_error_model_input(23, 300, 30, arrays, zero_frac=0.9)]
+    parts[0]["rate"][3, 5] = 94                     # stored as 90 + 33: decompressed to 94 again
+    parts[0]["rate"][4, 0] = 100                    # the largest: stored as 93 + 33 = '~'
+    parts[0]["rate"][5, 7] = 87                     # odd rates above 86 lose their last bit in the file
+    fasta, ids = [], []
+    for rec in parts:
+        for i in range(len(rec["seg"])):
+            rid = f"read {len(ids)}/x" if len(ids) % 7 == 0 else f"r{len(ids)}"
+            ids.append(rid)
+            seq = "".join("ACGT"[b] for b in rec["seqs"][i])
+            dom = "".join("ACGTN"[b] for b in rec["dom"][i])
+            rate = synth.encode_sys_rate(rec["rate"][i]).tobytes().decode()
+            fasta.append(f">{rid} {int(rec['seg'][i]) + 1};{int(rec['frag_len'][i])};{dom};{rate}")
+            fasta += [seq[k:k + 20] for k in range(0, len(seq), 20)] if len(ids) % 3 == 0 else [seq]
+    inp, out = workdir / "s2i.fa", workdir / "s2i.fq"
+    inp.write_text("\n".join(fasta) + "\n")
+    subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], check=True, capture_output=True)
+    oprof = O.Profile(ppath)
+    want, first = [], 0
+    for rec in parts:
+        rec = dict(rec)
+        r = rec["rate"].astype(np.int64)            # what survives the file: odd percents above 86 become the even one below
+        rec["rate"] = np.where(r > 86, r - (r - 85) % 2, r).astype(np.uint8)
+        for seq, qual, cigar, nerr, _tile in O.error_model_only(oprof, 77, rec, first_index=first):
+            want.append(f"@{ids[len(want)]} {cigar} E{nerr}\n" + "".join("ACGTN"[b] for b in seq) + "\n+\n" + qual.decode() + "\n")
+        first += len(rec["seg"])
+    oprof.close()
+    got = out.read_text()
+    assert got == "".join(want)
+    # replaceQuals is the same mode (BASELINE.json's name for it); stdin / stdout without -i / -o
+    r = subprocess.run([exe, "replaceQuals", "-s", ppath, "--seed", "77"], input=inp.read_bytes(), check=True, capture_output=True)
+    assert r.stdout.decode() == got
+    # the reference's complaints about malformed headers
+    for bad, msg in ((">r 3;40;NNNN;!!!!\nACGT\n", "Template segment is 3"), (">r1;40;NNNN;!!!!\nACGT\n", "No sequence id found"), (">r 1;4x;NNNN;!!!!\nACGT\n", "not a pure integer"),
+                     (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short")):
+        inp.write_text(bad)
+        r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
+        assert r.returncode != 0 and msg.encode() in r.stderr, (bad, r.stderr)
+        assert not out.exists()
 
 
 def test_methylation(workdir):

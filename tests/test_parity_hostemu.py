@@ -71,6 +71,15 @@ def test_profile_from_reseq_archive(workdir):
     P.case_profile_from_reseq_archive(EmuBackend, workdir)
 
 
+def test_coverage_driven(workdir):
+    P.case_coverage_driven(EmuBackend, workdir)
+
+
+@pytest.mark.parametrize("kind", ["subs", "indels", "meth"])
+def test_p0_variants(workdir, kind):
+    P.case_p0_variants(EmuBackend, workdir, kind)
+
+
 def test_dense_coverage(workdir):
     P.case_dense_coverage(EmuBackend, workdir)
 
