@@ -154,7 +154,7 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
     for rec in parts:
         rec = dict(rec)
         r = rec["rate"].astype(np.int64)            # what survives the file: odd percents above 86 become the even one below
-        rec["rate"] = np.where(r > 86, r - (r - 85) % 2, r).astype(np.uint8)
+        rec["rate"] = np.where(r > 86, r - r % 2, r).astype(np.uint8)
         for seq, qual, cigar, nerr, _tile in O.error_model_only(oprof, 77, rec, first_index=first):
             want.append(f"@{ids[len(want)]} {cigar} E{nerr}\n" + "".join("ACGTN"[b] for b in seq) + "\n+\n" + qual.decode() + "\n")
         first += len(rec["seg"])
