@@ -92,23 +92,11 @@ struct GlobalRow {                     // a margin row in HBM (read through L1/L
     const double *p;
     RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const Pair *>(p + 2u * j); }
 };
-struct LdsRow {                        // a margin row staged in the workgroup's LDS image
-    const RSQ_LDS double *p;
-    RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const RSQ_LDS Pair *>(p + 2u * j); }
-};
-// A row that most lanes of the wave find in LDS while the others read it from HBM.  `any_global` is wave-uniform: a wave
-// whose lanes all use LDS issues no vector-memory instruction (a load with few active lanes costs as much as a full one).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RSQ_ANY(x) (__any(x) != 0)
 #else
 #define RSQ_ANY(x) (x)
 #endif
-struct HybridRow {
-    LdsRow l;
-    GlobalRow g;
-    bool use_lds, any_global;
-};
-RSQ_HD HybridRow hybrid_row(const RSQ_LDS double *l, const double *g, bool use_lds) { return HybridRow{LdsRow{l}, GlobalRow{g}, use_lds, RSQ_ANY(!use_lds)}; }
 
 // Both passes work on CHUNKS of U column pairs: all row loads of a chunk are issued before the first product is formed
 // (the loops are latency-bound otherwise).  Rows are zero-padded to whole chunks (row_stride), so no chunk needs a
@@ -118,13 +106,6 @@ template <int U, class R>
 RSQ_HD void load_chunk(Pair (&v)[U], const R &r, uint32_t base) {
 #pragma unroll
     for (int i = 0; i < U; ++i) v[i] = r.pair(base + (uint32_t)i);
-}
-template <int U>
-RSQ_HD void load_chunk(Pair (&v)[U], const HybridRow &r, uint32_t base) {
-    if (r.use_lds) load_chunk<U>(v, r.l, base);
-    if (r.any_global) {
-        if (!r.use_lds) load_chunk<U>(v, r.g, base);
-    }
 }
 template <int U>
 RSQ_HD void mul_chunk(Pair (&a)[U], const Pair (&b)[U]) {
@@ -195,6 +176,109 @@ RSQ_HD uint32_t draw_rows(uint32_t K, double u, double &prob_sum, const Rs &...r
 template <class... Rs>
 RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &...rs) {
     return K <= 2u * kChunkSmall ? draw_rows<(int)kChunkSmall>(K, u, prob_sum, rs...) : draw_rows<(int)kChunkLarge>(K, u, prob_sum, rs...);
+}
+
+// ------------------------------------------------------------------------------------------ screened draw
+// The read kernel's draws in SINGLE precision with a proof obligation: the outcome is taken only when it provably equals the
+// outcome of the double-precision recipe above, otherwise the lane repeats the draw in double precision (draw<NM>, from HBM).
+// Rows are float copies of the tables (DevTable::off32), four columns per 16-byte load, pad columns zero.
+//
+// Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns and keeps one partial sum per quad of columns; S = their total.
+// Pass 2 finds the quad in which the sum from the top first exceeds r = u*S on those partial sums (no loads), reloads that quad
+// and finds the column.  Let T(j) be the exact sum of the columns above and including j (over the double-precision values) and
+// T the exact total: the reference returns the highest j >= 1 with T(j) > u*T up to its own rounding (relative 1e-14), else 0.
+// Error of the single-precision quantities, w = 2^-24, all terms non-negative: a product carries (1+w)^7 (four roundings to
+// float, three multiplications), a term passes at most 2 + Q additions in S (Q quads) and Q + 5 in a sum from the top, r takes
+// two more roundings: |S32 - T| <= (Q+9) w T, |top32(j) - T(j)| <= (Q+12) w T, |r32 - u T| <= (Q+11) w T.  So with
+//     delta = kScreenSafety * (2Q + 24) * w * S32
+// top32(j) - r32 > delta and r32 - top32(j+1) >= delta imply T(j) > u T > T(j+1) with room for the reference's own rounding:
+// column j is the reference's answer.  Everything else (about 2 K delta / S of all draws, 2e-4 for K = 40) is "undecided".
+// Preconditions, checked when the tables are packed (DevTable::f32_ok) and here: values are 0 or in [2^-60, 2^29] (no overflow;
+// an underflowing intermediate product loses at most 2^-97 absolutely) and S32 >= 2^-30.
+struct alignas(16) Quad {
+    float x, y, z, w;
+};
+struct GlobalRow32 {
+    const float *p;
+    RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const Quad *>(p + 4u * c); }
+};
+struct LdsRow32 {
+    const RSQ_LDS float *p;
+    RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const RSQ_LDS Quad *>(p + 4u * c); }
+};
+// A row that some lanes of the wave find in LDS while the others read it from HBM (used only when not every lane finds its row in
+// LDS: the callers branch wave-uniformly between LdsRow32 and this)
+struct MixedRow32 {
+    LdsRow32 l;
+    GlobalRow32 g;
+    bool use_lds;
+    RSQ_HD Quad quad(uint32_t c) const { return use_lds ? l.quad(c) : g.quad(c); }
+};
+
+RSQ_HD Quad mul_quad(const Quad &a, const Quad &b) { return Quad{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+template <class R0, class R1, class R2>
+RSQ_HD Quad prod_quad(uint32_t c, const R0 &r0, const R1 &r1, const R2 &r2) {
+    const Quad a = r0.quad(c), b = r1.quad(c), d = r2.quad(c);
+    return mul_quad(mul_quad(a, b), d);
+}
+template <class R0, class R1, class R2, class R3>
+RSQ_HD Quad prod_quad(uint32_t c, const R0 &r0, const R1 &r1, const R2 &r2, const R3 &r3) {
+    const Quad a = r0.quad(c), b = r1.quad(c), d = r2.quad(c), e = r3.quad(c);
+    return mul_quad(mul_quad(mul_quad(a, b), d), e);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RSQ_SCHED_BARRIER() ((void)0)
+#endif
+#ifndef RSQ_SCREEN_BATCH
+#define RSQ_SCREEN_BATCH 2
+#endif
+constexpr float kScreenSafety = 1.5f;
+constexpr float kScreenMinSum = 9.313225746154785e-10f;      // 2^-30
+
+// Q quads per row (compile-time: the loops unroll, the loads of a batch of quads are issued before their products are formed).
+// Returns true and the outcome COLUMN if the draw is decided.
+template <int Q, class... Rs>
+RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
+    constexpr int G = Q % RSQ_SCREEN_BATCH == 0 ? RSQ_SCREEN_BATCH : (Q % 2 == 0 ? 2 : 1);      // quads per batch
+    float part[Q];
+    float S = 0.f;
+#pragma unroll
+    for (int g = 0; g < Q; g += G) {
+        Quad p[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) p[i] = prod_quad((uint32_t)(g + i), rs...);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            part[g + i] = (p[i].x + p[i].y) + (p[i].z + p[i].w);
+            S += part[g + i];
+        }
+        RSQ_SCHED_BARRIER();                                 // keeps the scheduler from hoisting the loads of every batch to the top (registers)
+    }
+    const float r = (float)u * S;
+    const float delta = kScreenSafety * (float)(2 * Q + 24) * 5.9604644775390625e-08f * S;
+    // the sums from the top never decrease: the quads whose sum exceeds r are the lowest ones; count them, keep the last sum that does not
+    float top = 0.f, above = 0.f;
+    uint32_t below = 0;
+#pragma unroll
+    for (int c = Q; c--;) {
+        top += part[c];
+        const bool hit = top > r;
+        above = hit ? above : top;
+        below += hit ? 1u : 0u;
+    }
+    const uint32_t fc = below ? below - 1u : 0u;             // below == 0: u rounded to 1, or S is 0 (left undecided)
+    const Quad p = prod_quad(fc, rs...);
+    const float t3 = above + p.w, t2 = t3 + p.z, t1 = t2 + p.y, t0 = t1 + p.x;
+    uint32_t j;
+    float hi, lo;
+    if (t3 > r) j = 3u, hi = t3, lo = above;
+    else if (t2 > r) j = 2u, hi = t2, lo = t3;
+    else if (t1 > r) j = 1u, hi = t1, lo = t2;
+    else j = 0u, hi = t0, lo = t1;
+    col = 4u * fc + j;
+    return S >= kScreenMinSum && below != 0u && hi - r > delta && r - lo >= delta;      // S >= 2^-30 also rejects NaN
 }
 
 RSQ_HD uint32_t clamp_row(const DevTable &t, int n, uint32_t v) {      // AdjustIndeces (:368-380)
@@ -629,92 +713,12 @@ struct ReadMachine {
         phase = kTemplate;
     }
 
-    // one iteration of FillReadPart's loop body (Simulator.cpp:322-444) on template `src`
-    template <class Tab, class Src, class Out>
-    RSQ_HD void iterate(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, char base_element, Out &out) {
-        const uint32_t it = par.iteration++;
-        const Words w = st.step(2u + it);
-        double prob_sum;
-        const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
-        uint32_t indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, u32_to_unit(w.w0), prob_sum);
-        if (0.0 == prob_sum) indel = 0;
-        const uint32_t org_base = src.base(org_pos);
-        const uint32_t qi = tbase + org_base;
-        if (0 == indel) {
-            // GetSysErrorFromBlock: without variants its block walk advances in step with org_pos (:286-291)
-            const uint32_t se = src.sys_base(org_pos);
-            const uint32_t dom_error = se & 0xFFu;
-            par.error_rate = se >> 8;
-            const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-            uint32_t q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
-            if (0.0 == prob_sum) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;
-            par.qual = q;
-            const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
-            uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, u32_to_unit(w.w2), prob_sum);
-            if (0.0 == prob_sum) call = org_base;
-            par.base_call = call;
-            out.put(par.read_pos, call, q + S.phred_offset);
-            par.last_written_qual = q;
-            out.op(it, 0u);
-            if (base_element == cg.element) ++cg.length;
-            else {
-                cg.flush();
-                cg.element = base_element;
-                cg.length = 1;
-                par.indel_pos = 0;
-                par.previous_indel_type = 0;
-            }
-            if (call != org_base) ++par.num_errors;
-            ++par.read_pos;
-            ++org_pos;
-        } else if (1 == indel) {                                   // ErrorStats::kDeletion
-            par.error_rate = src.sys_deleted(org_pos) >> 8;          // :380-392
-            out.op(it, 1u);
-            ++n_indels;
-            if ('D' == cg.element) {
-                ++cg.length;
-                ++par.indel_pos;
-            } else {
-                cg.flush();
-                cg.element = 'D';
-                cg.length = 1;
-                par.indel_pos = 1;
-                par.previous_indel_type = 1;
-            }
-            ++par.num_errors;
-            ++org_pos;
-        } else {                                                   // insertion of base indel-2
-            const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-            uint32_t q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
-            if (0.0 == prob_sum) q = par.qual;
-            out.put(par.read_pos, indel - 2u, q + S.phred_offset);
-            par.last_written_qual = q;
-            out.op(it, 2u);
-            ++n_indels;
-            if ('I' == cg.element) {
-                ++cg.length;
-                ++par.indel_pos;
-            } else {
-                cg.flush();
-                cg.element = 'I';
-                cg.length = 1;
-                par.indel_pos = 1;
-                par.previous_indel_type = 0;
-            }
-            ++par.num_errors;
-            ++par.read_pos;
-        }
-    }
-
-    // returns false once the read is complete
-    template <class Tab, class Src, class Out>
-    RSQ_HD bool step(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
+    // Decides what the next iteration is: performs the transitions between the template part, the adapter part and the tail
+    // (Simulator.cpp:447-449, 537-558) until one of them has an iteration to run.  Returns false once the read is complete.
+    RSQ_HD bool advance(const DevSim &S, const Stream &st) {
         for (;;) {
             if (phase == kTemplate) {
-                if (par.read_pos < par.read_length && org_pos < org_len) {
-                    iterate(S, tab, st, src, 'M', out);
-                    return true;
-                }
+                if (par.read_pos < par.read_length && org_pos < org_len) return true;
                 if (cg.length) cg.flush();                          // Simulator.cpp:447-449
                 iter_m = par.iteration;
                 if (!(par.read_pos < par.read_length)) {
@@ -736,11 +740,7 @@ struct ReadMachine {
                 cg.length = 0;
                 phase = kAdapter;
             } else if (phase == kAdapter) {
-                if (par.read_pos < par.read_length && org_pos < org_len) {
-                    const DevAdapters &ad = S.adapters[seg];
-                    iterate(S, tab, st, AdapterSrc{ad.seqs + adapter_a0, ad.sys + adapter_a0}, 'S', out);
-                    return true;
-                }
+                if (par.read_pos < par.read_length && org_pos < org_len) return true;
                 if (cg.length) cg.flush();
                 if (!(par.read_pos < par.read_length)) {
                     phase = kDone;
@@ -751,24 +751,114 @@ struct ReadMachine {
                 pos_tail = 0;
                 phase = kTail;
             } else if (phase == kTail) {
-                if (!(par.read_pos < par.read_length)) {
-                    phase = kDone;
-                    return false;
-                }
-                const Words w = st.step(2u + par.iteration++);       // :564-587 poly-A tail, then random overrun bases
-                double prob_sum;
-                const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-                uint32_t q = tab.draw_quality((seg * S.n_tiles + tile_id) * 4u, idx_q, u32_to_unit(w.w1), prob_sum);
-                if (0.0 == prob_sum && par.read_pos) q = par.last_written_qual;   // at(qual_, read_pos-1) - offset
-                par.qual = q;
-                const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
-                ++pos_tail;
-                out.put(par.read_pos, b, q + S.phred_offset);
-                par.last_written_qual = q;
-                ++par.read_pos;
-                return true;
+                if (par.read_pos < par.read_length) return true;
+                phase = kDone;
+                return false;
             } else return false;
         }
+    }
+
+    // ONE iteration of FillReadPart's loop body (Simulator.cpp:322-444; template part 'M' or adapter part 'S') or of the poly-A /
+    // overrun tail (:564-587).  The three kinds share one instance of every draw: the lanes of a wave may be in different parts
+    // of their reads and still execute the same instructions.  Returns false once the read is complete.
+    template <class Tab, class Src, class Out>
+    RSQ_HD bool step(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
+        if (!advance(S, st)) return false;
+        const bool tail = phase == kTail, from_template = phase == kTemplate;
+        const DevAdapters &ad = S.adapters[seg];
+        const uint32_t it = par.iteration++;
+        const Words w = st.step(2u + it);
+        double prob_sum;
+        uint32_t indel = 0, org_base = 0;
+        if (!tail) {
+            const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
+            indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, u32_to_unit(w.w0), prob_sum);
+            if (0.0 == prob_sum) indel = 0;
+            org_base = from_template ? src.base(org_pos) : (uint32_t)ad.seqs[adapter_a0 + org_pos];
+        }
+        const uint32_t qi = tbase + org_base;                        // the tail draws from the tables of base A (:566)
+        const bool regular = !tail && 0 == indel, deletion = !tail && 1 == indel;
+        uint32_t dom_error = 0;
+        if (regular) {
+            // GetSysErrorFromBlock: without variants its block walk advances in step with org_pos (:286-291)
+            const uint32_t se = from_template ? src.sys_base(org_pos) : (uint32_t)ad.sys[adapter_a0 + org_pos];
+            dom_error = se & 0xFFu;
+            par.error_rate = se >> 8;
+        } else if (deletion) {
+            par.error_rate = (from_template ? src.sys_deleted(org_pos) : (uint32_t)ad.sys[adapter_a0 + org_pos]) >> 8;      // :380-392
+        }
+        uint32_t q = 0;
+        if (!deletion) {
+            const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+            q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
+            if (0.0 == prob_sum) {
+                if (regular) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;      // :341-349
+                else if (tail) q = par.read_pos ? par.last_written_qual : q;                             // at(qual_, read_pos-1) - offset
+                else q = par.qual;                                                                       // insertion :417-420
+            }
+        }
+        if (regular) {
+            par.qual = q;
+            const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
+            uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, u32_to_unit(w.w2), prob_sum);
+            if (0.0 == prob_sum) call = org_base;
+            par.base_call = call;
+            out.put(par.read_pos, call, q + S.phred_offset);
+            par.last_written_qual = q;
+            out.op(it, 0u);
+            const char base_element = from_template ? 'M' : 'S';
+            if (base_element == cg.element) ++cg.length;
+            else {
+                cg.flush();
+                cg.element = base_element;
+                cg.length = 1;
+                par.indel_pos = 0;
+                par.previous_indel_type = 0;
+            }
+            if (call != org_base) ++par.num_errors;
+            ++par.read_pos;
+            ++org_pos;
+        } else if (deletion) {                                     // ErrorStats::kDeletion
+            out.op(it, 1u);
+            ++n_indels;
+            if ('D' == cg.element) {
+                ++cg.length;
+                ++par.indel_pos;
+            } else {
+                cg.flush();
+                cg.element = 'D';
+                cg.length = 1;
+                par.indel_pos = 1;
+                par.previous_indel_type = 1;
+            }
+            ++par.num_errors;
+            ++org_pos;
+        } else if (tail) {                                         // :564-587 poly-A tail, then random overrun bases
+            par.qual = q;
+            const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
+            ++pos_tail;
+            out.put(par.read_pos, b, q + S.phred_offset);
+            par.last_written_qual = q;
+            ++par.read_pos;
+        } else {                                                   // insertion of base indel-2
+            out.put(par.read_pos, indel - 2u, q + S.phred_offset);
+            par.last_written_qual = q;
+            out.op(it, 2u);
+            ++n_indels;
+            if ('I' == cg.element) {
+                ++cg.length;
+                ++par.indel_pos;
+            } else {
+                cg.flush();
+                cg.element = 'I';
+                cg.length = 1;
+                par.indel_pos = 1;
+                par.previous_indel_type = 0;
+            }
+            ++par.num_errors;
+            ++par.read_pos;
+        }
+        return true;
     }
 
     RSQ_HD void finalize(ReadMeta &meta) const {

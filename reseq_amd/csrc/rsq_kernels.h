@@ -1383,91 +1383,128 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
 }
 
 // ------------------------------------------------------------------------------------------- LDS staging
-// A lane reads about 2 KB of table rows per base.  Measured on gfx950 (exp/ta_bench.hip): a wave-level global_load_dwordx4
-// costs the CU's vector-memory path >= 23 cycles (64 lanes x 16 B returned at 64 B/clk) however few lanes are active, and
-// about 2.3 cycles per distinct cache line touched; a ds_read_b128 costs 8.  The read kernel is bound by that path and by
-// the chain of dependent round trips, so the rows whose lines scatter most live in LDS (LdsPlan in rsq_types.h):
-//  * rows that differ from lane to lane because the conditioning value is per-read state -- quality margins over sequence
-//    quality (0) and previous quality (1), base-call margin over the quality (0);
-//  * the first rows of the error-rate margins (88 % of all positions have rate 0).  A lane whose rate is not staged reads
-//    its own row from HBM (HybridRow, rsq_core.h).
-// The rows over the read position stay in HBM: the lanes of a wave share them (4 cache lines per load), and staging them
-// per wave and step was measured slower (performance log).
-// Image layout (doubles): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (8 doubles each), staged
-// margins at DevTable::lds_off, error-rate rows at q3_off / b3_off.
+// A lane evaluates about 250 table entries per base (quality K = 40 over four margins, base call and indel over four and three).
+// Measured on gfx950 (exp/ta_bench.hip): a wave-level global_load_dwordx4 costs the CU's vector-memory path >= 23 cycles (64 lanes
+// x 16 B returned at 64 B/clk) however few lanes are active, and about 2.3 cycles per distinct cache line touched; a ds_read_b128
+// costs 8.  So the read kernel draws SCREENED (rsq_core.h): single-precision copies of the tables, four columns per 16-byte load,
+// and the rows whose addresses scatter most across the lanes of a wave live in the workgroup's LDS image (LdsPlan, rsq_types.h):
+//  * rows chosen by per-read state -- quality margins over sequence quality (0) and previous quality (1), base-call margins over
+//    the quality (0) and the number of errors (2), indel margin over the indel position (0);
+//  * the first rows of the error-rate margins (88 % of all positions have rate 0).  A lane whose rate is not staged reads its
+//    own row from HBM (HybridRow32).
+// The rows over the read position and the read's G/C percent stay in HBM (L2): the lanes of a wave share the position rows (4
+// cache lines per load).  A draw the screen cannot decide is repeated in double precision from HBM (GlobalTables).
+// Image layout (32-bit words): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (20 words each), the outcome
+// values, staged margins at DevTable::lds_off / lds_extra, error-rate rows at q3_off / b3_off.
 RSQ_HD uint32_t lds_desc_count(uint32_t n_tiles) { return 25u * n_tiles + 12u; }
+constexpr uint32_t kDescWords = sizeof(DevTable) / 4u;
 
-template <bool QL, bool BL, bool RT>
-struct LdsTables {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSQ_NOINLINE __device__ __noinline__
+#else
+#define RSQ_NOINLINE inline
+#endif
+// the host emulation counts what the screen decided (tests/hostemu): [family][0 = draws, 1 = left to double precision]
+#if defined(RSQ_SCREEN_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+#define RSQ_SCREEN_COUNT(family, decided) (++RSQ_SCREEN_STATS[family][0], RSQ_SCREEN_STATS[family][1] += !(decided))
+#else
+#define RSQ_SCREEN_COUNT(family, decided) ((void)0)
+#endif
+
+// MASK = quads per row of the quality family (LdsPlan::quads_q) | kScreenRateAll when every row of the quality tables' error-rate
+// margin is staged (else that margin is read from HBM by all lanes: a per-lane mix of the two costs more registers than it saves)
+template <uint32_t MASK>
+struct ScreenTables {
+    static constexpr int QQ = (int)(MASK & 0xFFu);
+    static constexpr bool kRateAll = (MASK & kScreenRateAll) != 0;
     const DevSim &S;
-    const RSQ_LDS double *img;         // image of the workgroup
+    const RSQ_LDS float *img;          // image of the workgroup
     uint32_t seg;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
-    // the outcome values: behind the descriptors in the image (the plan stages them whenever the pool is small); an image without them is not built
-    RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_doubles - S.lds.par0_doubles)); }
+    RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_words - S.lds.par0_words)); }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
-    RSQ_HD DevTable base_call(uint32_t i) const { return desc(4u * S.n_tiles + i - seg * 20u * S.n_tiles); }
-    RSQ_HD DevTable indel(uint32_t i) const { return desc(24u * S.n_tiles + i); }
     RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.n_tiles + 12u + i - seg * S.n_tiles); }
+    RSQ_HD static uint32_t row32(const DevTable &t, int n, uint32_t v, uint32_t slot) {      // offset of the row of margin n in the table's float copy
+        uint32_t before = 0;
+        for (int m = 0; m < n; ++m) before += t.rows[m];
+        return (before + clamp_row(t, n, v)) * slot;
+    }
+    // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
+    template <int NM>
+    RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], double u, double &ps) const {
+        return draw<NM>(t, S.pool, par0(), idx, u, ps);
+    }
+    template <int NM>
+    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, const uint32_t (&idx)[NM], double u, double &ps) const {
+        uint32_t value = par0()[t.par0_off + col];
+        ps = 1.0;
+#ifndef RSQ_EXP_NO_FALLBACK
+        if (RSQ_ANY(!decided)) {
+            if (!decided) value = exact<NM>(t, idx, u, ps);
+        }
+#endif
+        return value;
+    }
 
-    template <class R0, class R1, class R2, class R3>
-    RSQ_HD uint32_t rows4(const DevTable &t, double u, double &ps, const R0 &r0, const R1 &r1, const R2 &r2, const R3 &r3) const {
-        return par0()[t.par0_off + draw_rows_k(t.k, u, ps, r0, r1, r2, r3)];
-    }
-    // margins 2 (position) and 3 (error rate) of a quality draw
-    template <class R0, class R1>
-    RSQ_HD uint32_t quality_tail(const DevTable &t, uint32_t local, const uint32_t (&idx)[4], double u, double &ps, const R0 &m0, const R1 &m1) const {
-        const uint32_t kp = row_stride(t.k), r3 = clamp_row(t, 3, idx[3]);
-        const double *g2 = S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp, *g3 = S.pool + t.off[3] + r3 * kp;
-        const uint32_t nr = S.lds.rate_rows_q;
-        const RSQ_LDS double *l3 = img + S.lds.q3_off + (local * nr + (r3 < nr ? r3 : 0u)) * S.lds.slot_q;
-        if constexpr (RT) return rows4(t, u, ps, m0, m1, GlobalRow{g2}, hybrid_row(l3, g3, r3 < nr));
-        else return rows4(t, u, ps, m0, m1, GlobalRow{g2}, GlobalRow{g3});
-    }
     RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
         const uint32_t local = i - seg * 4u * S.n_tiles;
         const DevTable t = desc(local);
         ps = 0.0;
         if (!t.k) return 0;
-        const uint32_t kp = row_stride(t.k);
-        if constexpr (QL)
-            return quality_tail(t, local, idx, u, ps, LdsRow{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp},
-                                LdsRow{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * kp});
-        else
-            return quality_tail(t, local, idx, u, ps, GlobalRow{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp},
-                                GlobalRow{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp});
-    }
-    template <class R0>
-    RSQ_HD uint32_t base_call_tail(const DevTable &t, uint32_t local, const uint32_t (&idx)[4], double u, double &ps, const R0 &m0) const {
-        const uint32_t kp = row_stride(t.k), r3 = clamp_row(t, 3, idx[3]);
-        const GlobalRow m1{S.pool + t.off[1] + clamp_row(t, 1, idx[1]) * kp}, m2{S.pool + t.off[2] + clamp_row(t, 2, idx[2]) * kp};
-        const double *g3 = S.pool + t.off[3] + r3 * kp;
-        if constexpr (RT) {
-            const uint32_t nr = S.lds.rate_rows_b;
-            return rows4(t, u, ps, m0, m1, m2, hybrid_row(img + S.lds.b3_off + (local * nr + (r3 < nr ? r3 : 0u)) * S.lds.slot_b, g3, r3 < nr));
-        } else return rows4(t, u, ps, m0, m1, m2, GlobalRow{g3});
+        const uint32_t slot = S.lds.slot_q, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_q;
+        const float *g = S.pool32 + t.off32;
+        const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * slot};
+        const GlobalRow32 m2{g + row32(t, 2, idx[2], slot)};
+        uint32_t col = 0;
+        bool decided;
+        if constexpr (kRateAll) decided = draw_screened<QQ>(u, col, m0, m1, m2, LdsRow32{img + S.lds.q3_off + (local * nr + r3) * slot});
+        else decided = draw_screened<QQ>(u, col, m0, m1, m2, GlobalRow32{g + row32(t, 3, idx[3], slot)});
+        decided = decided && t.f32_ok;
+        RSQ_SCREEN_COUNT(0, decided);
+        return settle<4>(decided, col, t, idx, u, ps);
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
         const uint32_t local = i - seg * 20u * S.n_tiles;
         const DevTable t = desc(4u * S.n_tiles + local);
         ps = 0.0;
         if (!t.k) return 0;
-        const uint32_t kp = row_stride(t.k);
-        if constexpr (BL) return base_call_tail(t, local, idx, u, ps, LdsRow{img + t.lds_off + clamp_row(t, 0, idx[0]) * kp});
-        else return base_call_tail(t, local, idx, u, ps, GlobalRow{S.pool + t.off[0] + clamp_row(t, 0, idx[0]) * kp});
+        const uint32_t slot = S.lds.slot_b, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_b;
+        const float *g = S.pool32 + t.off32;
+        const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot};
+        const GlobalRow32 m1{g + row32(t, 1, idx[1], slot)};
+        const bool m2_staged = t.lds_extra != kNoLds, staged = r3 < nr;                         // m2_staged: the same for every table
+        const MixedRow32 m2{LdsRow32{img + (m2_staged ? t.lds_extra + clamp_row(t, 2, idx[2]) * slot : 0u)}, GlobalRow32{g + row32(t, 2, idx[2], slot)}, m2_staged};
+        const MixedRow32 m3{LdsRow32{img + S.lds.b3_off + (local * nr + (staged ? r3 : 0u)) * slot}, GlobalRow32{g + row32(t, 3, idx[3], slot)}, staged};
+        uint32_t col = 0;
+        bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3) && t.f32_ok;
+        RSQ_SCREEN_COUNT(1, decided);
+        return settle<4>(decided, col, t, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(indel(i), S.pool, par0(), idx, u, ps); }
-    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
+        const DevTable t = desc(24u * S.n_tiles + i);
+        ps = 0.0;
+        if (!t.k) return 0;
+        const uint32_t slot = S.lds.slot_i;
+        const float *g = S.pool32 + t.off32;
+        const bool m0_staged = t.lds_off != kNoLds;
+        const MixedRow32 m0{LdsRow32{img + (m0_staged ? t.lds_off + clamp_row(t, 0, idx[0]) * slot : 0u)}, GlobalRow32{g + row32(t, 0, idx[0], slot)}, m0_staged};
+        const GlobalRow32 m1{g + row32(t, 1, idx[1], slot)}, m2{g + row32(t, 2, idx[2], slot)};
+        uint32_t col = 0;
+        bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2) && t.f32_ok;
+        RSQ_SCREEN_COUNT(2, decided);
+        return settle<3>(decided, col, t, idx, u, ps);
+    }
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {     // once per read: double precision
         return draw<3>(seq_quality(i), S.pool, par0(), idx, u, ps);
     }
 };
 
 // Builds the static LDS image of segment `seg`; tid/nthreads describe the calling thread (the host emulation calls it with
 // 0/1).  The caller synchronises the workgroup between the two phases and after the second.
-RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
+RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS float *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
     const uint32_t T = S.n_tiles;
     RSQ_LDS uint32_t *dst = reinterpret_cast<RSQ_LDS uint32_t *>(img);
-    const uint32_t wq = 4u * T * 16u, wb = 20u * T * 16u, wi = 12u * 16u, ws = T * 16u;      // 16 words per descriptor
+    const uint32_t wq = 4u * T * kDescWords, wb = 20u * T * kDescWords, wi = 12u * kDescWords, ws = T * kDescWords;
     const uint32_t *q = reinterpret_cast<const uint32_t *>(S.quality + seg * 4u * T), *b = reinterpret_cast<const uint32_t *>(S.base_call + seg * 20u * T),
                    *in = reinterpret_cast<const uint32_t *>(S.indels), *sq = reinterpret_cast<const uint32_t *>(S.seq_quality + seg * T);
     for (uint32_t i = tid; i < wq; i += nthreads) dst[i] = q[i];
@@ -1475,39 +1512,44 @@ RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS double *img, uint32_t
     for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
     for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i];
     const uint32_t *p0 = reinterpret_cast<const uint32_t *>(S.par0);      // the pool is padded to whole words by pack_tables
-    for (uint32_t i = tid; i < 2u * S.lds.par0_doubles; i += nthreads) dst[wq + wb + wi + ws + i] = p0[i];
+    for (uint32_t i = tid; i < S.lds.par0_words; i += nthreads) dst[wq + wb + wi + ws + i] = p0[i];
 }
 // rows 0..n_rows-1 of margin 3 of `n_tables` tables starting at descriptor `first`, one slot per row
-RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS double *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,
+RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS float *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,
                                 uint32_t nthreads) {
     const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
     for (uint32_t i = tid; i < n_tables * n_rows * slot; i += nthreads) {
         const DevTable tb = d[first + i / (n_rows * slot)];
-        const uint32_t row = (i / slot) % n_rows, c = i % slot, kp = tb.k ? row_stride(tb.k) : 0u;
-        img[dst_off + i] = (row < tb.rows[3] && c < kp) ? S.pool[tb.off[3] + row * kp + c] : 0.0;
+        const uint32_t row = (i / slot) % n_rows, c = i % slot;
+        img[dst_off + i] = (tb.k && row < tb.rows[3]) ? S.pool32[tb.off32 + (tb.rows[0] + tb.rows[1] + tb.rows[2] + row) * slot + c] : 0.f;
     }
 }
-RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS double *img, uint32_t mask, uint32_t tid, uint32_t nthreads) {
+RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, uint32_t nthreads) {
     const uint32_t T = S.n_tiles;
     const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
-    if (mask & kLdsQuality)
-        for (uint32_t t = 0; t < 4u * T; ++t) {
-            const DevTable tb = d[t];
-            if (!tb.k || tb.lds_off == kNoLds) continue;
-            const uint32_t n = (tb.rows[0] + tb.rows[1]) * row_stride(tb.k);
-            for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
-        }
-    if (mask & kLdsBaseCall)
-        for (uint32_t t = 0; t < 20u * T; ++t) {
-            const DevTable tb = d[4u * T + t];
-            if (!tb.k || tb.lds_off == kNoLds) continue;
-            const uint32_t n = tb.rows[0] * row_stride(tb.k);
-            for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool[tb.off[0] + i];
-        }
-    if (mask & kLdsRate) {
-        lds_stage_rate_rows(S, img, 0u, 4u * T, S.lds.rate_rows_q, S.lds.slot_q, S.lds.q3_off, tid, nthreads);
-        lds_stage_rate_rows(S, img, 4u * T, 20u * T, S.lds.rate_rows_b, S.lds.slot_b, S.lds.b3_off, tid, nthreads);
+    for (uint32_t t = 0; t < 4u * T; ++t) {                                     // quality: margins 0 and 1, contiguous in the copy
+        const DevTable tb = d[t];
+        if (!tb.k || tb.lds_off == kNoLds) continue;
+        const uint32_t n = (tb.rows[0] + tb.rows[1]) * S.lds.slot_q;
+        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
     }
+    for (uint32_t t = 0; t < 20u * T; ++t) {                                    // base call: margin 0, margin 2
+        const DevTable tb = d[4u * T + t];
+        if (!tb.k || tb.lds_off == kNoLds) continue;
+        const uint32_t n = tb.rows[0] * S.lds.slot_b;
+        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
+        if (tb.lds_extra == kNoLds) continue;
+        const uint32_t n2 = tb.rows[2] * S.lds.slot_b, from = (tb.rows[0] + tb.rows[1]) * S.lds.slot_b;
+        for (uint32_t i = tid; i < n2; i += nthreads) img[tb.lds_extra + i] = S.pool32[tb.off32 + from + i];
+    }
+    for (uint32_t t = 0; t < 12u; ++t) {                                        // indel: margin 0
+        const DevTable tb = d[24u * T + t];
+        if (!tb.k || tb.lds_off == kNoLds) continue;
+        const uint32_t n = tb.rows[0] * S.lds.slot_i;
+        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
+    }
+    lds_stage_rate_rows(S, img, 0u, 4u * T, S.lds.rate_rows_q, S.lds.slot_q, S.lds.q3_off, tid, nthreads);
+    lds_stage_rate_rows(S, img, 4u * T, 20u * T, S.lds.rate_rows_b, S.lds.slot_b, S.lds.b3_off, tid, nthreads);
 }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
@@ -1719,19 +1761,19 @@ constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
 // goes to HBM).
 // the LDS image of the workgroup's template segment (all waves call it; returns after the final barrier)
 template <uint32_t MASK>
-__device__ RSQ_LDS double *fill_stage_image(const DevSim &S, double *lds_image, uint32_t seg) {
-    RSQ_LDS double *img = (RSQ_LDS double *)lds_image;
+__device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, uint32_t seg) {
+    RSQ_LDS float *img = (RSQ_LDS float *)lds_image;
     if (MASK) {
         lds_stage_descriptors(S, img, seg, threadIdx.x, blockDim.x);
         __syncthreads();
-        lds_stage_rows(S, img, MASK, threadIdx.x, blockDim.x);
+        lds_stage_rows(S, img, threadIdx.x, blockDim.x);
         __syncthreads();
     }
     return img;
 }
 // 64 reads of one wave through the state machine: one uniform step loop
 template <uint32_t MASK, class Src>
-__device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
+__device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS float *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
                                 const Src &src, ReadOut &out, ReadMeta &meta) {
     ReadMachine m;
     if constexpr (MASK == 0) {
@@ -1741,7 +1783,7 @@ __device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint
             while (m.step(S, tab, st, src, out)) {}
         }
     } else {
-        LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{S, img, seg};
+        const ScreenTables<MASK> tab{S, img, seg};
         bool running = active;
         if (active) m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
         while (__any(running))
@@ -1756,9 +1798,9 @@ __device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS double *img, uint
 template <uint32_t MASK, bool VAR = false>
 __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) double lds_image[];
+    extern __shared__ __attribute__((aligned(16))) float lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
-    const RSQ_LDS double *img = fill_stage_image<MASK>(S, lds_image, seg);
+    const RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
         uint32_t chunk = 0;
@@ -1810,9 +1852,9 @@ struct RecordJob {
 };
 template <uint32_t MASK>
 __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters) {
-    extern __shared__ __attribute__((aligned(16))) double lds_image[];
+    extern __shared__ __attribute__((aligned(16))) float lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
-    const RSQ_LDS double *img = fill_stage_image<MASK>(S, lds_image, seg);
+    const RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_mine = job.rec_count[seg];
     const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);

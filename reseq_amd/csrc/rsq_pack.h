@@ -88,7 +88,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
             DevTable d{};
             d.k = (uint32_t)t.par0.size();
             d.par0_off = (uint32_t)par0.size();
-            d.lds_off = kNoLds;
+            d.lds_off = d.lds_extra = kNoLds;
             for (uint32_t v : t.par0) {
                 par0.push_back((uint8_t)v);
                 d.max_value = std::max(d.max_value, v);
@@ -112,80 +112,129 @@ inline void pack_tables(SimState &s, Uploader &up) {
     std::vector<DevTable> quality = pack(p.quality), seq_quality = pack(p.seq_quality), base_call = pack(p.base_call), dom_error = pack(p.dom_error),
                           error_rate = pack(p.error_rate), indels = pack(p.indels);
 
-    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): as much as fits 160 KiB, most valuable first.
+    // Single-precision copies of the families the read kernel draws from per base, for its screened draws (rsq_core.h): every margin,
+    // rows of one slot per family, pad columns zero.
     const uint32_t T = p.n_tiles();
     LdsPlan plan{};
-    plan.par0_doubles = par0.size() <= 8192 ? (uint32_t)((par0.size() + 1 + 15) / 16) * 2u : 0u;       // the outcome values of every table, when small; whole 16 bytes: rows stay aligned
-    plan.desc_doubles = lds_desc_count(T) * (uint32_t)(sizeof(DevTable) / sizeof(double)) + plan.par0_doubles;
-    auto rows_q = [&](const DevTable &d) { return d.k ? (d.rows[0] + d.rows[1]) * row_stride(d.k) : 0u; };
-    auto rows_b = [&](const DevTable &d) { return d.k ? d.rows[0] * row_stride(d.k) : 0u; };
-    uint64_t need_q = 0, need_b = 0;
-    for (uint32_t seg = 0; seg < 2; ++seg) {
-        uint64_t q = 0, b = 0;
-        for (uint32_t i = 0; i < 4 * T; ++i) q += rows_q(quality[seg * 4 * T + i]);
-        for (uint32_t i = 0; i < 20 * T; ++i) b += rows_b(base_call[seg * 20 * T + i]);
-        need_q = std::max(need_q, q);
-        need_b = std::max(need_b, b);
-    }
-    uint32_t max_rate_q = 0, max_rate_b = 0;
-    for (const DevTable &d : quality) {
-        plan.slot_q = std::max(plan.slot_q, d.k ? row_stride(d.k) : 0u);
-        if (d.k) max_rate_q = std::max(max_rate_q, d.rows[3]);
-    }
-    for (const DevTable &d : base_call) {
-        plan.slot_b = std::max(plan.slot_b, d.k ? row_stride(d.k) : 0u);
-        if (d.k) max_rate_b = std::max(max_rate_b, d.rows[3]);
-    }
-    const uint64_t budget = kLdsBudgetBytes / sizeof(double);
-    auto need_rate = [&](uint32_t rows) {
-        return (uint64_t)4 * T * std::max(1u, std::min(rows, max_rate_q)) * plan.slot_q + (uint64_t)20 * T * std::max(1u, std::min(rows, max_rate_b)) * plan.slot_b;
+    std::vector<float> pool32;
+    auto kmax_of = [](const std::vector<DevTable> &tabs) {
+        uint32_t kmax = 0;
+        for (const DevTable &d : tabs) kmax = std::max(kmax, d.k);
+        return kmax;
     };
-    uint32_t allow = ~0u, rate_rows = kLdsRateRows;
-    if (const char *e = getenv("RSQ_FILL_MODE")) allow = (uint32_t)atoi(e);                       // tuning overrides: never stage these,
-    if (!plan.par0_doubles) allow = 0;                                                            // an image always carries the outcome values
-    if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
-    uint64_t used = plan.desc_doubles;
-    if (used <= budget / 4 && (allow & kLdsDesc)) plan.mask |= kLdsDesc;
-    if ((plan.mask & kLdsDesc) && (allow & kLdsQuality) && used + need_q <= budget) {
-        plan.mask |= kLdsQuality;
-        used += need_q;
-        const bool want_rate = (allow & kLdsRate) && used + need_rate(1) <= budget;
-        if ((allow & kLdsBaseCall) && used + need_b + (want_rate ? need_rate(1) : 0) <= budget) {
-            plan.mask |= kLdsBaseCall;
-            used += need_b;
+    auto copy32 = [&](std::vector<DevTable> &tabs, uint32_t slot) {
+        for (DevTable &d : tabs) {
+            d.off32 = (uint32_t)pool32.size();
+            d.f32_ok = 1;
+            if (!d.k) continue;
+            const uint32_t kp = row_stride(d.k);
+            for (uint32_t n = 0; n < 4; ++n)
+                for (uint32_t r = 0; r < d.rows[n]; ++r) {
+                    const double *row = pool.data() + d.off[n] + (size_t)r * kp;
+                    for (uint32_t c = 0; c < slot; ++c) {
+                        const double v = c < d.k ? row[c] : 0.0;
+                        if (!(v == 0.0 || (v >= 0x1p-60 && v <= 0x1p29))) d.f32_ok = 0;          // also NaN, negative
+                        pool32.push_back((float)v);
+                    }
+                }
+            if (pool32.size() > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
         }
-        if (want_rate) {
-            while (rate_rows > 1 && used + need_rate(rate_rows) > budget) --rate_rows;
-            plan.mask |= kLdsRate;
-            plan.rate_rows_q = std::max(1u, std::min(rate_rows, max_rate_q));
-            plan.rate_rows_b = std::max(1u, std::min(rate_rows, max_rate_b));
-            used += need_rate(rate_rows);
-        }
+    };
+    for (uint32_t q : kQualityQuads)
+        if (!plan.quads_q && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
+    const bool screenable = plan.quads_q && quads_of(kmax_of(base_call)) <= kQuadsSmall && quads_of(kmax_of(indels)) <= kQuadsSmall;
+    plan.slot_q = row_slot32(plan.quads_q);
+    plan.slot_b = plan.slot_i = kSlotSmall;
+    if (screenable) {
+        copy32(quality, plan.slot_q);
+        copy32(base_call, plan.slot_b);
+        copy32(indels, plan.slot_i);
     }
-    if (plan.mask & kLdsQuality) {
-        uint32_t end = plan.desc_doubles;
+
+    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): the image of one template segment, the most valuable rows first,
+    // as much as fits 160 KiB.
+    plan.par0_words = par0.size() <= 8192 ? (uint32_t)((par0.size() + 1 + 15) / 16) * 4u : 0u;       // the outcome values of every table; whole 16 bytes: rows stay aligned
+    plan.desc_words = lds_desc_count(T) * kDescWords + plan.par0_words;
+    uint32_t rate_rows_q = ~0u, rate_rows_b = kLdsRateRows;
+    int allow = 1;
+    if (const char *e = getenv("RSQ_FILL_MODE")) allow = atoi(e);                                  // 0: double precision from HBM only (tests run both)
+    if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows_q = rate_rows_b = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
+    uint32_t max_rate_q = 1, max_rate_b = 1;
+    for (const DevTable &d : quality)
+        if (d.k) max_rate_q = std::max(max_rate_q, d.rows[3]);
+    for (const DevTable &d : base_call)
+        if (d.k) max_rate_b = std::max(max_rate_b, d.rows[3]);
+    rate_rows_q = std::min(rate_rows_q, max_rate_q);
+    rate_rows_b = std::min(rate_rows_b, max_rate_b);
+    const uint64_t budget = kLdsBudgetBytes / 4u;
+    if (screenable && plan.par0_words && allow) {
+        uint64_t need = plan.desc_words, need_b2 = 0, need_i0 = 0;                                  // the larger segment decides
         for (uint32_t seg = 0; seg < 2; ++seg) {
-            uint32_t at = plan.desc_doubles;
+            uint64_t q = 0, b = 0, b2 = 0;
             for (uint32_t i = 0; i < 4 * T; ++i) {
-                DevTable &d = quality[seg * 4 * T + i];
-                if (!d.k) continue;
-                d.lds_off = at;
-                at += rows_q(d);
+                const DevTable &d = quality[seg * 4 * T + i];
+                if (d.k) q += (uint64_t)(d.rows[0] + d.rows[1]) * plan.slot_q;
             }
-            if (plan.mask & kLdsBaseCall)
+            for (uint32_t i = 0; i < 20 * T; ++i) {
+                const DevTable &d = base_call[seg * 20 * T + i];
+                if (d.k) b += (uint64_t)d.rows[0] * plan.slot_b, b2 += (uint64_t)d.rows[2] * plan.slot_b;
+            }
+            need = std::max(need, plan.desc_words + q + b);
+            need_b2 = std::max(need_b2, b2);
+        }
+        for (const DevTable &d : indels)
+            if (d.k) need_i0 += (uint64_t)d.rows[0] * plan.slot_i;
+        auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * T * rows_q * plan.slot_q + (uint64_t)20 * T * rows_b * plan.slot_b; };
+        if (need + need_rate(1, 1) <= budget) {
+            // what is left goes to: the error-rate rows of the quality tables (a wave whose lanes all find theirs staged issues no load
+            // for that margin), the indel margin over the indel position, error-rate rows of the base-call tables, its margin over the
+            // number of errors
+            uint32_t rq = 1, rb = 1;
+            while (rq < rate_rows_q && need + need_rate(rq + 1, 1) <= budget) ++rq;
+            const bool stage_i0 = need + need_i0 + need_rate(rq, 1) <= budget;
+            if (stage_i0) need += need_i0;
+            while (rb < rate_rows_b && need + need_rate(rq, rb + 1) <= budget) ++rb;
+            const bool stage_b2 = need + need_b2 + need_rate(rq, rb) <= budget;
+            plan.rate_rows_q = rq;
+            plan.rate_rows_b = rb;
+            uint32_t end = plan.desc_words;
+            for (uint32_t seg = 0; seg < 2; ++seg) {
+                uint32_t at = plan.desc_words;
+                for (uint32_t i = 0; i < 4 * T; ++i) {
+                    DevTable &d = quality[seg * 4 * T + i];
+                    if (!d.k) continue;
+                    d.lds_off = at;
+                    at += (d.rows[0] + d.rows[1]) * plan.slot_q;
+                }
                 for (uint32_t i = 0; i < 20 * T; ++i) {
                     DevTable &d = base_call[seg * 20 * T + i];
                     if (!d.k) continue;
                     d.lds_off = at;
-                    at += rows_b(d);
+                    at += d.rows[0] * plan.slot_b;
+                    if (stage_b2) {
+                        d.lds_extra = at;
+                        at += d.rows[2] * plan.slot_b;
+                    }
                 }
-            end = std::max(end, at);
+                end = std::max(end, at);
+            }
+            if (stage_i0)
+                for (DevTable &d : indels) {
+                    if (!d.k) continue;
+                    d.lds_off = end;
+                    end += d.rows[0] * plan.slot_i;
+                }
+            plan.q3_off = end;
+            plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
+            plan.total_words = plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b;
+            plan.mask = plan.quads_q | (rq == max_rate_q ? kScreenRateAll : 0u);
         }
-        plan.q3_off = end;
-        plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
-        plan.total_doubles = (plan.mask & kLdsRate) ? plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b : end;
-    } else plan.total_doubles = (plan.mask & kLdsDesc) ? plan.desc_doubles : 0u;
-    if ((plan.desc_doubles | plan.q3_off | plan.b3_off) & 1u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
+    }
+    if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.slot_q | plan.slot_b | plan.slot_i) & 3u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
+    if (const char *e = getenv("RSQ_TRACE_PLAN"))
+        if (atoi(e))
+            fprintf(stderr, "[rsq] LDS image: mask %u, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u\n", plan.mask, plan.total_words,
+                    plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off);
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);
@@ -194,10 +243,12 @@ inline void pack_tables(SimState &s, Uploader &up) {
     s.dev.error_rate = up.put(error_rate);
     s.dev.indels = up.put(indels);
     par0.push_back(0);
-    par0.resize(std::max<size_t>(par0.size(), (size_t)plan.par0_doubles * 8), 0);      // whole words for the copy into the LDS image
+    par0.resize(std::max<size_t>(par0.size(), (size_t)plan.par0_words * 4), 0);      // whole words for the copy into the LDS image
     pool.push_back(0.0);
     pool.push_back(0.0);
+    pool32.resize(pool32.size() + 8, 0.f);
     s.dev.pool = up.put(pool);
+    s.dev.pool32 = up.put(pool32);
     s.dev.par0 = up.put(par0);
     s.host_pool = pool;                                              // for the systematic errors of variants (drawn on the host)
     s.host_par0 = par0;
@@ -205,20 +256,9 @@ inline void pack_tables(SimState &s, Uploader &up) {
     s.host_error_rate = error_rate;
 }
 
-// the staging combinations k_fill_reads is instantiated for: a forced mode (RSQ_FILL_MODE, tests) is cut down to the nearest one
-constexpr uint32_t kFillMasks[] = {0u,
-                                   kLdsDesc,
-                                   kLdsDesc | kLdsQuality,
-                                   kLdsDesc | kLdsQuality | kLdsBaseCall,
-                                   kLdsDesc | kLdsQuality | kLdsRate,
-                                   kLdsDesc | kLdsQuality | kLdsRate | kLdsBaseCall};
-inline uint32_t effective_fill_mask(uint32_t plan_mask, int forced) {
-    uint32_t m = plan_mask;
-    if (forced >= 0) m &= (uint32_t)forced;
-    if (!(m & kLdsDesc)) return 0;
-    if (!(m & kLdsQuality)) return kLdsDesc;
-    return m & (kLdsDesc | kLdsQuality | kLdsBaseCall | kLdsRate);
-}
+// the read kernel is instantiated for: 0 = every draw in double precision from HBM, kQualityQuads = screened draws with the LDS image;
+// a forced mode (RSQ_FILL_MODE, tests) can only take the image away
+inline uint32_t effective_fill_mask(uint32_t plan_mask, int forced) { return forced == 0 ? 0u : plan_mask; }
 
 inline void pack_profile(SimState &s, Uploader &up) {
     const Profile &p = s.prof;

@@ -119,7 +119,7 @@ struct rsq_sim : SimState {
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
-    int force_fill_mode = -1;      // RSQ_FILL_MODE=<mask of kLds* bits> restricts the LDS staging (tests run every variant)
+    int force_fill_mode = -1;      // RSQ_FILL_MODE=0: every draw in double precision from HBM (tests run both paths)
 };
 
 namespace rsq {
@@ -265,11 +265,12 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0};
 }
 
-// k_fill_reads: persistent waves, one workgroup per CU slot; MASK (kLds* bits) chosen by the LDS plan of pack_tables
+// k_fill_reads: persistent waves, one workgroup per CU slot; MASK = quads per quality row (screened draws on the LDS image planned by
+// pack_tables) or 0 (double precision from HBM: the reference path the tests compare with)
 template <uint32_t MASK, bool VAR = false>
 static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
     const LdsPlan &pl = s.dev.lds;
-    const size_t lds_bytes = MASK ? (size_t)pl.total_doubles * sizeof(double) : 0;
+    const size_t lds_bytes = MASK ? (size_t)pl.total_words * 4u : 0;
     if (lds_bytes > 64 * 1024)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MASK, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
@@ -286,7 +287,7 @@ static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs
 }
 template <uint32_t MASK>
 static void launch_records_mask(rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st) {
-    const size_t lds_bytes = MASK ? (size_t)s.dev.lds.total_doubles * sizeof(double) : 0;
+    const size_t lds_bytes = MASK ? (size_t)s.dev.lds.total_words * 4u : 0;
     if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_records<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;
     uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(cdiv(n, 64), kFillBlock / 64)));
@@ -298,30 +299,42 @@ static void launch_records_mask(rsq_sim &s, const RecordJob &job, uint64_t n, co
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
-template <size_t... I>
-static void launch_records_dispatch(uint32_t mask, rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st, std::index_sequence<I...>) {
-    bool done = false;
-    ((mask == kFillMasks[I] ? (launch_records_mask<kFillMasks[I]>(s, job, n, raw, st), done = true) : false), ...);
-    if (!done) throw Error("no k_fill_records instantiation for staging mask " + std::to_string(mask));
-}
-template <size_t... I>
-static void launch_fill_dispatch(uint32_t mask, rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
-                                 std::index_sequence<I...>) {
-    bool done = false;
-    ((mask == kFillMasks[I] ? (launch_fill_mask<kFillMasks[I]>(s, frags, n_pairs, adapter_first, raw, st), done = true) : false), ...);
-    if (!done) throw Error("no k_fill_reads instantiation for staging mask " + std::to_string(mask));
-}
 static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
                               const FragmentVar *fvars = nullptr) {
-    if (frags && s.has_variants) {
-        // with variants the error walk is per lane state: two instantiations only, every table staged or every table from HBM
-        constexpr uint32_t kAll = kLdsDesc | kLdsQuality | kLdsRate | kLdsBaseCall;
-        if (effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) == kAll) launch_fill_mask<kAll, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
-        else launch_fill_mask<0u, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
-        return;
+    const uint32_t mask = effective_fill_mask(s.dev.lds.mask, s.force_fill_mode);
+    const bool var = frags && s.has_variants;            // with variants the error walk is per lane state
+#define RSQ_FILL_CASE(Q)                                                                       \
+    if (mask == Q) {                                                                           \
+        if (var) launch_fill_mask<Q, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);  \
+        else launch_fill_mask<Q>(s, frags, n_pairs, adapter_first, raw, st);                   \
+        return;                                                                                \
     }
-    launch_fill_dispatch(effective_fill_mask(s.dev.lds.mask, s.force_fill_mode), s, frags, n_pairs, adapter_first, raw, st,
-                         std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
+    RSQ_FILL_CASE(0u)
+    RSQ_FILL_CASE(kQualityQuads[0])
+    RSQ_FILL_CASE(kQualityQuads[1])
+    RSQ_FILL_CASE(kQualityQuads[2])
+    RSQ_FILL_CASE(kQualityQuads[0] | kScreenRateAll)
+    RSQ_FILL_CASE(kQualityQuads[1] | kScreenRateAll)
+    RSQ_FILL_CASE(kQualityQuads[2] | kScreenRateAll)
+#undef RSQ_FILL_CASE
+    throw Error("no k_fill_reads instantiation for " + std::to_string(mask) + " quads");
+}
+static void launch_fill_records(rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st) {
+    const uint32_t mask = effective_fill_mask(s.dev.lds.mask, s.force_fill_mode);
+#define RSQ_REC_CASE(Q)                                 \
+    if (mask == Q) {                                    \
+        launch_records_mask<Q>(s, job, n, raw, st);     \
+        return;                                         \
+    }
+    RSQ_REC_CASE(0u)
+    RSQ_REC_CASE(kQualityQuads[0])
+    RSQ_REC_CASE(kQualityQuads[1])
+    RSQ_REC_CASE(kQualityQuads[2])
+    RSQ_REC_CASE(kQualityQuads[0] | kScreenRateAll)
+    RSQ_REC_CASE(kQualityQuads[1] | kScreenRateAll)
+    RSQ_REC_CASE(kQualityQuads[2] | kScreenRateAll)
+#undef RSQ_REC_CASE
+    throw Error("no k_fill_records instantiation for " + std::to_string(mask) + " quads");
 }
 
 // reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
@@ -901,8 +914,7 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
         hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
         const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>()};
-        launch_records_dispatch(effective_fill_mask(s->dev.lds.mask, s->force_fill_mode), *s, job, n, raw, st,
-                                std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
+        launch_fill_records(*s, job, n, raw, st);
         s->scan_total.reserve(8);
         HIP_CHECK(hipMemsetAsync(s->scan_total.as<uint32_t>(), 0, 4, st));
         hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,

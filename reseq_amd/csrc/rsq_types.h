@@ -37,36 +37,56 @@ struct DevTable {
     uint32_t rows[4];      // limits_[n].second - limits_[n].first
     uint32_t off[4];       // into the double pool (even: 16-byte aligned)
     uint32_t max_value;    // MaxValue()  (ProbabilityEstimates.h:510-517)
-    uint32_t lds_off;      // offset (doubles) of margin 0 in the workgroup's LDS image, kNoLds if the table is not staged
+    uint32_t lds_off;      // offset (32-bit words) of margin 0 in the workgroup's LDS image, kNoLds if the table is not staged
+    // single-precision copy for the screened draws of the read kernel (rsq_core.h "screened draw"): margins one after the other at
+    // pool32[off32], rows of the table family's slot (LdsPlan::slot_*) floats
+    uint32_t off32;
+    uint32_t f32_ok;       // every value is 0 or in [2^-60, 2^29]: the error bound of the screened draw holds
+    uint32_t lds_extra;    // base call: offset of margin 2 (number of errors) in the LDS image, kNoLds if not staged
+    uint32_t pad;
 };
+static_assert(sizeof(DevTable) == 80, "descriptor layout");
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
-// A draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
+// A double-precision draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
 #ifndef RSQ_CHUNK_LARGE
 #define RSQ_CHUNK_LARGE 4
 #endif
 constexpr uint32_t kChunkSmall = 3, kChunkLarge = RSQ_CHUNK_LARGE;
 RSQ_HD uint32_t chunk_pairs(uint32_t k) { return k <= 2u * kChunkSmall ? kChunkSmall : kChunkLarge; }
 RSQ_HD uint32_t chunks_of(uint32_t k, uint32_t u) { return (k + 2u * u - 1u) / (2u * u); }
-// Row stride in doubles: whole chunks (zero pad columns, so that the draw needs no masks), even (16-byte rows) and
-// == 2 (mod 4): 2*stride dwords == 4 (mod 8), so that the rows different lanes read in one ds_read_b128 spread over all
-// LDS bank groups.
+// Row stride in doubles: whole chunks (zero pad columns, so that the draw needs no masks), even (16-byte rows).
 RSQ_HD uint32_t row_stride(uint32_t k) {
     const uint32_t u = chunk_pairs(k), kp = chunks_of(k, u) * 2u * u;
     return (kp & 2u) ? kp : kp + 2u;
 }
+// Single-precision rows: whole quads of columns (16-byte loads) and a stride == 4 (mod 8) words, so that the rows different lanes
+// read in one ds_read_b128 spread over all LDS bank groups.
+RSQ_HD uint32_t quads_of(uint32_t k) { return (k + 3u) / 4u; }
+RSQ_HD uint32_t row_slot32(uint32_t quads) {
+    const uint32_t w = quads * 4u;
+    return (w & 4u) ? w : w + 4u;
+}
+// what the screened draws are compiled for: the quality family with 10 or 12 quads per row (K <= 40, K <= 48), the base-call and
+// indel families with 2 (K <= 8, rows of 32 bytes)
+constexpr uint32_t kQuadsSmall = 2, kSlotSmall = 8;
+constexpr uint32_t kQualityQuads[] = {10, 11, 12};
+constexpr uint32_t kScreenRateAll = 0x100;
 
-// LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup: the table
-// descriptors of the segment, margins 0+1 of its quality tables, margin 0 of its base-call tables, the first rows of the
-// error-rate margins (quality margin 3, base-call margin 3).
-enum : uint32_t { kLdsDesc = 1, kLdsQuality = 2, kLdsBaseCall = 4, kLdsRate = 16 };
+// LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup, in single precision:
+// the table descriptors of the segment and of the indel tables, the outcome values, margins 0+1 of the segment's quality tables
+// (sequence quality, previous quality), margin 0 of its base-call tables (quality), the first rows of the error-rate margins
+// (quality margin 3, base-call margin 3), and as far as the 160 KiB reach margin 0 of the indel tables and margin 2 of the base-call
+// tables (number of errors).  Offsets and sizes in 32-bit words.
 struct LdsPlan {
-    uint32_t mask;               // kLds* bits of what the plan stages
-    uint32_t desc_doubles;       // size of the descriptor area (in doubles): the descriptors, then the outcome-value pool (par0)
-    uint32_t par0_doubles;       // size of the outcome-value pool in the image, 0 if it stays in HBM
-    uint32_t slot_q, slot_b;     // row slot (doubles) per quality / base-call table = max row stride of the family
-    uint32_t rate_rows_q, rate_rows_b;   // kLdsRate: rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
+    uint32_t mask;               // the read kernel's template argument: quads_q | kScreenRateAll (every row of the quality tables' error-rate margin
+                                 // is staged) when the image exists and the kernel draws screened; 0: double precision from HBM only
+    uint32_t desc_words;         // size of the descriptor area: the descriptors, then the outcome-value pool (par0)
+    uint32_t par0_words;         // size of the outcome-value pool in the image
+    uint32_t slot_q, slot_b, slot_i;        // row slot (floats) of the quality / base-call / indel family
+    uint32_t quads_q;            // 16-byte groups of a quality row that hold columns: one of kQualityQuads
+    uint32_t rate_rows_q, rate_rows_b;      // rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
     uint32_t q3_off, b3_off;     // [4T][rate_rows_q] quality slots, [20T][rate_rows_b] base-call slots
-    uint32_t total_doubles;      // size of the image
+    uint32_t total_words;        // size of the image
 };
 
 // Fragment produced by the coverage sieve: one simulated read pair (Simulator.cpp:2249-2357 -> CreateReads).
@@ -146,6 +166,7 @@ struct DevSim {
     uint64_t seed;
     // ---- tables
     const double *pool;
+    const float *pool32;           // single-precision copy of the quality, base-call and indel tables (DevTable::off32)
     const uint8_t *par0;
     const DevTable *quality;       // [2][n_tiles][4]
     const DevTable *seq_quality;   // [2][n_tiles]

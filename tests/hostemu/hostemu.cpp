@@ -6,6 +6,9 @@
 // memory, and walks them with plain loops in place of the grid.  `pytest -m "not gpu"` compares it with the
 // oracle so that state-machine, packing and counter-layout mistakes are caught in a container without a GPU.
 // Nothing in reseq_amd/ links to or loads this file.
+#include <stdint.h>
+static uint64_t g_screen_stats[3][2];          // quality, base call, indel: draws, draws the screen left to double precision
+#define RSQ_SCREEN_STATS g_screen_stats
 #include <stdlib.h>
 
 #include <memory>
@@ -35,38 +38,41 @@ struct HostUploader : Uploader {
 struct Emu : SimState {
     HostUploader up;
     std::vector<FragmentVar> fvars;             // of the last emu_sieve call (variants of any kind), parallel to its fragments
-    int fill_mode = -1;                         // -1: everything the LDS plan allows (as the product does); else a mask of kLds* bits
-    std::vector<double> lds[2];                 // host stand-in for the LDS image of each template segment (+ one wave area)
+    int fill_mode = -1;                         // -1: screened draws on the LDS image when the plan has one (as the product does); 0: double precision only
+    std::vector<float> lds[2];                  // host stand-in for the LDS image of each template segment
     uint32_t mask() const { return effective_fill_mask(dev.lds.mask, fill_mode); }
     void build_lds() {                          // what a workgroup of k_fill_reads does before its first read
         for (uint32_t seg = 0; seg < 2; ++seg) {
-            lds[seg].assign(dev.lds.total_doubles + 16, 0.0);
+            lds[seg].assign(dev.lds.total_words + 16, 0.f);
             if (mask()) {
                 lds_stage_descriptors(dev, lds[seg].data(), seg, 0, 1);
-                lds_stage_rows(dev, lds[seg].data(), mask(), 0, 1);
+                lds_stage_rows(dev, lds[seg].data(), 0, 1);
             }
         }
     }
 };
 
 // one read through the state machine the way a lane of k_fill_reads<MASK> runs it
-template <uint32_t MASK, class Src>
-void run_lds(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta) {
-    LdsTables<(MASK & kLdsQuality) != 0, (MASK & kLdsBaseCall) != 0, (MASK & kLdsRate) != 0> tab{s.dev, s.lds[seg].data(), seg};
-    fill_read(s.dev, tab, st, seg, tile, frag_len, src, out, meta);
-}
-template <class Src, size_t... I>
-void run_read_dispatch(uint32_t mask, Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta,
-                       std::index_sequence<I...>) {
-    bool done = false;
-    ((mask == kFillMasks[I] ? (run_lds<kFillMasks[I]>(s, seg, st, tile, frag_len, src, out, meta), done = true) : false), ...);
-    if (!done) throw Error("no staging combination " + std::to_string(mask));
-}
 template <class Src>
 void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t frag_len, const Src &src, ReadOut &out, ReadMeta &meta) {
-    const uint32_t mask = s.mask();
-    if (!mask) fill_read(s.dev, GlobalTables{s.dev}, st, seg, tile, frag_len, src, out, meta);
-    else run_read_dispatch(mask, s, seg, st, tile, frag_len, src, out, meta, std::make_index_sequence<sizeof(kFillMasks) / sizeof(kFillMasks[0])>{});
+    if (!s.mask()) fill_read(s.dev, GlobalTables{s.dev}, st, seg, tile, frag_len, src, out, meta);
+    else {
+        bool done = false;
+        auto run = [&](auto tag) {
+            constexpr uint32_t M = decltype(tag)::value;
+            if (s.mask() == M) {
+                fill_read(s.dev, ScreenTables<M>{s.dev, s.lds[seg].data(), seg}, st, seg, tile, frag_len, src, out, meta);
+                done = true;
+            }
+        };
+        run(std::integral_constant<uint32_t, kQualityQuads[0]>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[1]>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[2]>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[0] | kScreenRateAll>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[1] | kScreenRateAll>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[2] | kScreenRateAll>{});
+        if (!done) throw Error("no screened instantiation for mask " + std::to_string(s.mask()));
+    }
 }
 
 thread_local std::string g_err;
@@ -210,6 +216,11 @@ int emu_edit_profile(void *h, double error_multiplier, int no_substitutions, int
     });
 }
 
+// out[6]: the counters above; reset afterwards
+void emu_screen_stats(uint64_t *out) {
+    memcpy(out, g_screen_stats, sizeof g_screen_stats);
+    memset(g_screen_stats, 0, sizeof g_screen_stats);
+}
 void emu_set_fill_mode(void *h, int mode) { static_cast<Emu *>(h)->fill_mode = mode; }
 
 int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {

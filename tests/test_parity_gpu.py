@@ -70,10 +70,10 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(GpuBackend, workdir)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3, 7, 19])
-def test_every_lds_staging_mode(workdir, mode, monkeypatch):
-    """k_fill_reads<MASK>: tables from HBM only (0), descriptors in LDS (1), + quality margins (3), + base-call margin (7),
-    quality margins + error-rate rows (19); everything the plan allows (23) is the default of the tests above"""
+@pytest.mark.parametrize("mode", [0])
+def test_double_precision_path(workdir, mode, monkeypatch):
+    """k_fill_reads<0>: every draw in double precision from HBM, the reference's recipe itself; the default of the other tests is the
+    screened path (single-precision draws on the LDS image, double precision only where the screen cannot decide)"""
     monkeypatch.setenv("RSQ_FILL_MODE", str(mode))
     P.case_sieve_and_reads_tiny(GpuBackend, workdir)
     P.case_p0_reads(GpuBackend, workdir)

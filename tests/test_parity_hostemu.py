@@ -108,10 +108,10 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(EmuBackend, workdir)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 3, 7, 19])
-def test_every_lds_staging_mode(workdir, mode):
-    """k_fill_reads<MASK>: tables from HBM only (0), descriptors in LDS (1), + quality margins (3), + base-call margin (7),
-    quality margins + error-rate rows (19); everything the plan allows (23) is the default of the tests above"""
+@pytest.mark.parametrize("mode", [0])
+def test_double_precision_path(workdir, mode):
+    """k_fill_reads<0>: every draw in double precision from HBM, the reference's recipe itself; the default of the other tests is the
+    screened path (single-precision draws on the LDS image, double precision only where the screen cannot decide)"""
     class Capped(EmuBackend):
         fill_mode = mode
     P.case_sieve_and_reads_tiny(Capped, workdir)
@@ -177,3 +177,20 @@ def test_variants_many_alleles(workdir):
 
 def test_variants_more_alleles_than_the_reference_supports_are_refused(workdir):
     P.case_variants_rejected(EmuBackend, workdir)
+
+
+def test_the_screen_decides_almost_every_draw(workdir):
+    """screened draws (rsq_core.h): single precision decides unless u*S lies within the error bound of a cumulative boundary -- a few
+    draws in ten thousand; everything else is repeated in double precision.  The outputs equal the oracle's either way (the cases
+    above); this checks that the fast path is the one that runs."""
+    import ctypes as C
+    import numpy as np
+    from backends import emu_lib
+    stats = np.zeros(6, np.uint64)
+    emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))             # reset
+    P.case_p0_reads(EmuBackend, workdir)
+    emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))
+    (q, q_left), (b, b_left), (i, i_left) = stats.reshape(3, 2).tolist()
+    assert q > 400_000 and b > 400_000 and i > 400_000
+    assert 0 < q_left < 1e-3 * q, (q, q_left)                               # K = 40: about 2e-4
+    assert b_left < 2e-4 * b and i_left < 2e-4 * i, (b, b_left, i, i_left)
