@@ -242,7 +242,9 @@ constexpr float kScreenMinSum = 9.313225746154785e-10f;      // 2^-30
 template <int Q, class... Rs>
 RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
     constexpr int G = Q % RSQ_SCREEN_BATCH == 0 ? RSQ_SCREEN_BATCH : (Q % 2 == 0 ? 2 : 1);      // quads per batch
+    constexpr bool kKeep = Q <= 2;                           // short rows: the products stay in registers, pass 2 loads nothing
     float part[Q];
+    Quad kept[kKeep ? Q : 1];
     float S = 0.f;
 #pragma unroll
     for (int g = 0; g < Q; g += G) {
@@ -253,6 +255,7 @@ RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
         for (int i = 0; i < G; ++i) {
             part[g + i] = (p[i].x + p[i].y) + (p[i].z + p[i].w);
             S += part[g + i];
+            if constexpr (kKeep) kept[g + i] = p[i];
         }
         RSQ_SCHED_BARRIER();                                 // keeps the scheduler from hoisting the loads of every batch to the top (registers)
     }
@@ -269,7 +272,13 @@ RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
         below += hit ? 1u : 0u;
     }
     const uint32_t fc = below ? below - 1u : 0u;             // below == 0: u rounded to 1, or S is 0 (left undecided)
-    const Quad p = prod_quad(fc, rs...);
+    Quad p;
+    if constexpr (kKeep) {
+        p = kept[0];
+#pragma unroll
+        for (int c = 1; c < Q; ++c)
+            if (fc == (uint32_t)c) p = kept[c];
+    } else p = prod_quad(fc, rs...);
     const float t3 = above + p.w, t2 = t3 + p.z, t1 = t2 + p.y, t0 = t1 + p.x;
     uint32_t j;
     float hi, lo;

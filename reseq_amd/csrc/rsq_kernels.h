@@ -1411,15 +1411,16 @@ constexpr uint32_t kDescWords = sizeof(DevTable) / 4u;
 #define RSQ_SCREEN_COUNT(family, decided) ((void)0)
 #endif
 
-// MASK = quads per row of the quality family (LdsPlan::quads_q) | kScreenRateAll when every row of the quality tables' error-rate
-// margin is staged (else that margin is read from HBM by all lanes: a per-lane mix of the two costs more registers than it saves)
+// QQ = quads per row of the quality family (LdsPlan::quads_q).  `t` is the step the wave is in: the quality rows over the read
+// positions t, ... t-kRingLag are in the wave's ring (lds_ring_load / lds_ring_store).
 template <uint32_t MASK>
 struct ScreenTables {
-    static constexpr int QQ = (int)(MASK & 0xFFu);
-    static constexpr bool kRateAll = (MASK & kScreenRateAll) != 0;
+    static constexpr int QQ = (int)MASK;
     const DevSim &S;
     const RSQ_LDS float *img;          // image of the workgroup
     uint32_t seg;
+    const RSQ_LDS float *ring_;        // the wave's ring
+    uint32_t t;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
     RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_words - S.lds.par0_words)); }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
@@ -1429,6 +1430,9 @@ struct ScreenTables {
         for (int m = 0; m < n; ++m) before += t.rows[m];
         return (before + clamp_row(t, n, v)) * slot;
     }
+    // the ring's rows of read position p; in_ring: p is one of the last steps' positions (a read lags by its deletions)
+    RSQ_HD const RSQ_LDS float *ring(uint32_t p) const { return ring_ + (p % kRingSlots) * S.lds.ring_stride; }
+    RSQ_HD bool in_ring(uint32_t p) const { return t - p <= kRingLag; }
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
     RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], double u, double &ps) const {
@@ -1452,13 +1456,11 @@ struct ScreenTables {
         ps = 0.0;
         if (!t.k) return 0;
         const uint32_t slot = S.lds.slot_q, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_q;
-        const float *g = S.pool32 + t.off32;
         const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * slot};
-        const GlobalRow32 m2{g + row32(t, 2, idx[2], slot)};
+        const LdsRow32 m2{ring(idx[2]) + local * slot};
+        const LdsRow32 m3{img + S.lds.q3_off + (local * nr + (r3 < nr ? r3 : 0u)) * slot};
         uint32_t col = 0;
-        bool decided;
-        if constexpr (kRateAll) decided = draw_screened<QQ>(u, col, m0, m1, m2, LdsRow32{img + S.lds.q3_off + (local * nr + r3) * slot});
-        else decided = draw_screened<QQ>(u, col, m0, m1, m2, GlobalRow32{g + row32(t, 3, idx[3], slot)});
+        bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
         decided = decided && t.f32_ok;
         RSQ_SCREEN_COUNT(0, decided);
         return settle<4>(decided, col, t, idx, u, ps);
@@ -1550,6 +1552,17 @@ RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, ui
     }
     lds_stage_rate_rows(S, img, 0u, 4u * T, S.lds.rate_rows_q, S.lds.slot_q, S.lds.q3_off, tid, nthreads);
     lds_stage_rate_rows(S, img, 4u * T, 20u * T, S.lds.rate_rows_b, S.lds.slot_b, S.lds.b3_off, tid, nthreads);
+}
+// The ring: the quality rows (margin 2) over read position p of the segment's tables, copied by the wave itself at the beginning of
+// step p into slot p % kRingSlots of its ring: one load of 16 bytes per lane instead of one per lane and quad of the row.  Item i is
+// one 16-byte group of one table's row.
+RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.n_tiles * S.lds.quads_q; }
+RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) {
+    const uint32_t table = item / S.lds.quads_q, c = item % S.lds.quads_q, slot = S.lds.slot_q;
+    const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
+    Quad q{0.f, 0.f, 0.f, 0.f};
+    if (d.k) q = *reinterpret_cast<const Quad *>(S.pool32 + d.off32 + (d.rows[0] + d.rows[1] + clamp_row(d, 2, p)) * slot + 4u * c);
+    *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + table * slot + 4u * c) = q;
 }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
@@ -1771,28 +1784,40 @@ __device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, ui
     }
     return img;
 }
-// 64 reads of one wave through the state machine: one uniform step loop
+// 64 reads of one wave through the state machine: one uniform step loop.  Screened (MASK != 0): at the beginning of a step the wave
+// copies the quality rows over the step's read position into its ring.  Returns whether the wave had work.
 template <uint32_t MASK, class Src>
-__device__ void fill_wave_reads(const DevSim &S, const RSQ_LDS float *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
+__device__ bool fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
                                 const Src &src, ReadOut &out, ReadMeta &meta) {
     ReadMachine m;
+    bool any_work;
     if constexpr (MASK == 0) {
         const GlobalTables tab{S};
         if (active) {
             m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
             while (m.step(S, tab, st, src, out)) {}
         }
+        any_work = __any(active) != 0;
     } else {
-        const ScreenTables<MASK> tab{S, img, seg};
+        const uint32_t lane = threadIdx.x & 63u, n_items = lds_ring_items(S);
+        RSQ_LDS float *ring = img + S.lds.ring_off + (threadIdx.x >> 6) * kRingSlots * S.lds.ring_stride;
+        ScreenTables<MASK> tab{S, img, seg, ring, 0u};
         bool running = active;
         if (active) m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
-        while (__any(running))
+        for (uint32_t t = 0; __any(running); ++t) {
+            for (uint32_t item = lane; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
+            __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
+            tab.t = t;
             if (running) running = m.step(S, tab, st, src, out);
+            __builtin_amdgcn_wave_barrier();
+        }
+        any_work = __any(active) != 0;
     }
     if (active) {
         m.finalize(meta);
         out.finish();
     }
+    return any_work;
 }
 
 template <uint32_t MASK, bool VAR = false>
@@ -1800,17 +1825,16 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
-    const RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
+    RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
         chunk = __shfl(chunk, 0, 64);
-        const uint64_t first = (uint64_t)chunk * 64u;
-        if (first >= n_pairs) break;
+        const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave idles through this round of its workgroup
         const uint64_t pair = first + lane;
         const bool active = pair < n_pairs;
-        const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : first);
+        const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : 0u);
         ReadOut out = raw.out_of(r);
         Fragment f{};
         if (active && frags) f = frags[pair];
@@ -1824,19 +1848,21 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
         const uint32_t strand = from_fragment ? f.strand : 0u;
         const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg, f.allele)};
         ReadMeta meta;
+        bool work;
         if constexpr (VAR) {                                            // launched for fragments only
             VariantSrc src = variant_src(S, f, fvars ? &fv : nullptr, seg);
             if (raw.templates) src.converted = raw.templates + r * raw.template_words;
-            fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2, f.allele), f.len, src, out, meta);
+            work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2, f.allele), f.len, src, out, meta);
         } else {
-            FragmentSrc src = from_fragment ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
+            FragmentSrc src = from_fragment && active ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
             if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
-            fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
+            work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
         }
         if (active) {
             raw.meta[r] = meta;
             sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
         }
+        if (!work) break;
     }
 }
 
@@ -1854,7 +1880,7 @@ template <uint32_t MASK>
 __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     const uint32_t seg = blockIdx.x & 1u;
-    const RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
+    RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_mine = job.rec_count[seg];
     const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);
@@ -1862,17 +1888,17 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
         chunk = __shfl(chunk, 0, 64);
-        const uint32_t first = chunk * 64u;
-        if (first >= n_mine) break;
+        const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave idles through this round of its workgroup
         const bool active = first + lane < n_mine;
-        const uint64_t i = index[active ? first + lane : first];
+        const uint64_t i = active ? index[first + lane] : 0u;
         const uint64_t idx = job.first_index + i;
         const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
         const RecordSrc src{job.seqs + i * job.read_len, job.dom + i * job.read_len, job.rate + i * job.read_len, job.read_len};
         ReadOut out = raw.out_of(i);
         ReadMeta meta;
-        fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomErrModel, 0, 2), job.frag_len[i], src, out, meta);
+        const bool work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomErrModel, 0, 2), job.frag_len[i], src, out, meta);
         if (active) raw.meta[i] = meta;
+        if (!work) break;
     }
 }
 // the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known

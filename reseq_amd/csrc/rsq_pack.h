@@ -75,7 +75,7 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 // --------------------------------------------------------------------------------------- packing (create)
 // LDS budget of one k_fill_reads workgroup (MI355X: 160 KiB per CU, one workgroup per CU)
 constexpr uint32_t kLdsBudgetBytes = 160u * 1024u;
-constexpr uint32_t kLdsRateRows = 8;          // rows of the error-rate margins staged in LDS (97 % of all positions have rate 0)
+constexpr uint32_t kLdsRateRowsFirst = 64;    // rows of the error-rate margins staged in LDS before anything optional (97 % of all positions have rate 0)
 
 inline void pack_tables(SimState &s, Uploader &up) {
     const Profile &p = s.prof;
@@ -155,7 +155,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     // as much as fits 160 KiB.
     plan.par0_words = par0.size() <= 8192 ? (uint32_t)((par0.size() + 1 + 15) / 16) * 4u : 0u;       // the outcome values of every table; whole 16 bytes: rows stay aligned
     plan.desc_words = lds_desc_count(T) * kDescWords + plan.par0_words;
-    uint32_t rate_rows_q = ~0u, rate_rows_b = kLdsRateRows;
+    uint32_t rate_rows_q = ~0u, rate_rows_b = ~0u;
     int allow = 1;
     if (const char *e = getenv("RSQ_FILL_MODE")) allow = atoi(e);                                  // 0: double precision from HBM only (tests run both)
     if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows_q = rate_rows_b = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
@@ -185,16 +185,21 @@ inline void pack_tables(SimState &s, Uploader &up) {
         for (const DevTable &d : indels)
             if (d.k) need_i0 += (uint64_t)d.rows[0] * plan.slot_i;
         auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * T * rows_q * plan.slot_q + (uint64_t)20 * T * rows_b * plan.slot_b; };
+        plan.ring_stride = 4 * T * plan.slot_q;
+        need += (uint64_t)(kFillBlock / 64) * kRingSlots * plan.ring_stride;                         // the waves' rings
         if (need + need_rate(1, 1) <= budget) {
-            // what is left goes to: the error-rate rows of the quality tables (a wave whose lanes all find theirs staged issues no load
-            // for that margin), the indel margin over the indel position, error-rate rows of the base-call tables, its margin over the
-            // number of errors
+            // what is left goes to: error-rate rows of the quality tables up to kLdsRateRowsFirst (a lane whose rate has no staged row
+            // repeats its draw in double precision), the base-call margin over the number of errors, the indel margin over the indel
+            // position, then more error-rate rows of both families
             uint32_t rq = 1, rb = 1;
-            while (rq < rate_rows_q && need + need_rate(rq + 1, 1) <= budget) ++rq;
+            while (rq < std::min(rate_rows_q, kLdsRateRowsFirst) && need + need_rate(rq + 1, 1) <= budget) ++rq;
+            const bool stage_b2 = need + need_b2 + need_rate(rq, 1) <= budget;
+            if (stage_b2) need += need_b2;
             const bool stage_i0 = need + need_i0 + need_rate(rq, 1) <= budget;
             if (stage_i0) need += need_i0;
+            while (rb < std::min(rate_rows_b, kLdsRateRowsFirst) && need + need_rate(rq, rb + 1) <= budget) ++rb;
+            while (rq < rate_rows_q && need + need_rate(rq + 1, rb) <= budget) ++rq;
             while (rb < rate_rows_b && need + need_rate(rq, rb + 1) <= budget) ++rb;
-            const bool stage_b2 = need + need_b2 + need_rate(rq, rb) <= budget;
             plan.rate_rows_q = rq;
             plan.rate_rows_b = rb;
             uint32_t end = plan.desc_words;
@@ -224,17 +229,19 @@ inline void pack_tables(SimState &s, Uploader &up) {
                     d.lds_off = end;
                     end += d.rows[0] * plan.slot_i;
                 }
-            plan.q3_off = end;
+            plan.ring_off = end;
+            plan.q3_off = plan.ring_off + (kFillBlock / 64) * kRingSlots * plan.ring_stride;
             plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
             plan.total_words = plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b;
-            plan.mask = plan.quads_q | (rq == max_rate_q ? kScreenRateAll : 0u);
+            plan.mask = plan.quads_q;
         }
     }
-    if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.slot_q | plan.slot_b | plan.slot_i) & 3u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
+    if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.ring_off | plan.ring_stride | plan.slot_q | plan.slot_b | plan.slot_i) & 3u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
     if (const char *e = getenv("RSQ_TRACE_PLAN"))
         if (atoi(e))
-            fprintf(stderr, "[rsq] LDS image: mask %u, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u\n", plan.mask, plan.total_words,
-                    plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off);
+            fprintf(stderr, "[rsq] LDS image: mask %u, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u, ring %u x %u, b2 %d i0 %d\n", plan.mask,
+                    plan.total_words, plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off, plan.ring_off,
+                    plan.ring_stride, (int)(!base_call.empty() && base_call[0].lds_extra != kNoLds), (int)(!indels.empty() && indels[0].lds_off != kNoLds));
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);

@@ -313,9 +313,6 @@ static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pair
     RSQ_FILL_CASE(kQualityQuads[0])
     RSQ_FILL_CASE(kQualityQuads[1])
     RSQ_FILL_CASE(kQualityQuads[2])
-    RSQ_FILL_CASE(kQualityQuads[0] | kScreenRateAll)
-    RSQ_FILL_CASE(kQualityQuads[1] | kScreenRateAll)
-    RSQ_FILL_CASE(kQualityQuads[2] | kScreenRateAll)
 #undef RSQ_FILL_CASE
     throw Error("no k_fill_reads instantiation for " + std::to_string(mask) + " quads");
 }
@@ -330,9 +327,6 @@ static void launch_fill_records(rsq_sim &s, const RecordJob &job, uint64_t n, co
     RSQ_REC_CASE(kQualityQuads[0])
     RSQ_REC_CASE(kQualityQuads[1])
     RSQ_REC_CASE(kQualityQuads[2])
-    RSQ_REC_CASE(kQualityQuads[0] | kScreenRateAll)
-    RSQ_REC_CASE(kQualityQuads[1] | kScreenRateAll)
-    RSQ_REC_CASE(kQualityQuads[2] | kScreenRateAll)
 #undef RSQ_REC_CASE
     throw Error("no k_fill_records instantiation for " + std::to_string(mask) + " quads");
 }

@@ -70,7 +70,7 @@ RSQ_HD uint32_t row_slot32(uint32_t quads) {
 // indel families with 2 (K <= 8, rows of 32 bytes)
 constexpr uint32_t kQuadsSmall = 2, kSlotSmall = 8;
 constexpr uint32_t kQualityQuads[] = {10, 11, 12};
-constexpr uint32_t kScreenRateAll = 0x100;
+constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)
 
 // LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup, in single precision:
 // the table descriptors of the segment and of the indel tables, the outcome values, margins 0+1 of the segment's quality tables
@@ -78,14 +78,15 @@ constexpr uint32_t kScreenRateAll = 0x100;
 // (quality margin 3, base-call margin 3), and as far as the 160 KiB reach margin 0 of the indel tables and margin 2 of the base-call
 // tables (number of errors).  Offsets and sizes in 32-bit words.
 struct LdsPlan {
-    uint32_t mask;               // the read kernel's template argument: quads_q | kScreenRateAll (every row of the quality tables' error-rate margin
-                                 // is staged) when the image exists and the kernel draws screened; 0: double precision from HBM only
+    uint32_t mask;               // the read kernel's template argument: quads_q when the image exists and the kernel draws screened; 0: double
+                                 // precision from HBM only
     uint32_t desc_words;         // size of the descriptor area: the descriptors, then the outcome-value pool (par0)
     uint32_t par0_words;         // size of the outcome-value pool in the image
     uint32_t slot_q, slot_b, slot_i;        // row slot (floats) of the quality / base-call / indel family
     uint32_t quads_q;            // 16-byte groups of a quality row that hold columns: one of kQualityQuads
     uint32_t rate_rows_q, rate_rows_b;      // rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
     uint32_t q3_off, b3_off;     // [4T][rate_rows_q] quality slots, [20T][rate_rows_b] base-call slots
+    uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4T quality slots], the quality rows over the read position of the wave's current steps
     uint32_t total_words;        // size of the image
 };
 

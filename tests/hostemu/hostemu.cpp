@@ -58,19 +58,24 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
     if (!s.mask()) fill_read(s.dev, GlobalTables{s.dev}, st, seg, tile, frag_len, src, out, meta);
     else {
         bool done = false;
-        auto run = [&](auto tag) {
+        auto run = [&](auto tag) {                            // what a lane of k_fill_reads<M> does; the position ring holds the step's rows
             constexpr uint32_t M = decltype(tag)::value;
-            if (s.mask() == M) {
-                fill_read(s.dev, ScreenTables<M>{s.dev, s.lds[seg].data(), seg}, st, seg, tile, frag_len, src, out, meta);
-                done = true;
+            if (s.mask() != M) return;
+            float *img = s.lds[seg].data(), *ring = img + s.dev.lds.ring_off;      // the ring of wave 0
+            ScreenTables<M> tab{s.dev, img, seg, ring, 0u};
+            ReadMachine m;
+            m.init(s.dev, tab, st, seg, tile, frag_len, src);
+            for (;;) {
+                for (uint32_t item = 0; item < lds_ring_items(s.dev); ++item) lds_ring_stage(s.dev, img, ring, m.par.read_pos, item);
+                tab.t = m.par.read_pos;
+                if (!m.step(s.dev, tab, st, src, out)) break;
             }
+            m.finalize(meta);
+            done = true;
         };
         run(std::integral_constant<uint32_t, kQualityQuads[0]>{});
         run(std::integral_constant<uint32_t, kQualityQuads[1]>{});
         run(std::integral_constant<uint32_t, kQualityQuads[2]>{});
-        run(std::integral_constant<uint32_t, kQualityQuads[0] | kScreenRateAll>{});
-        run(std::integral_constant<uint32_t, kQualityQuads[1] | kScreenRateAll>{});
-        run(std::integral_constant<uint32_t, kQualityQuads[2] | kScreenRateAll>{});
         if (!done) throw Error("no screened instantiation for mask " + std::to_string(s.mask()));
     }
 }
