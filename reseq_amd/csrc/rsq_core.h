@@ -195,9 +195,23 @@ RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &..
 // column j is the reference's answer.  Everything else (about 2 K delta / S of all draws, 2e-4 for K = 40) is "undecided".
 // Preconditions, checked when the tables are packed (DevTable::f32_ok) and here: values are 0 or in [2^-60, 2^29] (no overflow;
 // an underflowing intermediate product loses at most 2^-97 absolutely) and S32 >= 2^-30.
-struct alignas(16) Quad {
-    float x, y, z, w;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float Float2 __attribute__((ext_vector_type(2)));      // v_pk_mul_f32 / v_pk_add_f32
+#else
+struct Float2 {
+    float x, y;
 };
+inline Float2 operator*(const Float2 &a, const Float2 &b) { return Float2{a.x * b.x, a.y * b.y}; }
+inline Float2 operator+(const Float2 &a, const Float2 &b) { return Float2{a.x + b.x, a.y + b.y}; }
+#endif
+struct alignas(16) Quad {              // columns 4c .. 4c+3 of a row: lo = (4c, 4c+1), hi = (4c+2, 4c+3)
+    Float2 lo, hi;
+};
+RSQ_HD Quad zero_quad() {
+    Quad q;
+    q.lo.x = q.lo.y = q.hi.x = q.hi.y = 0.f;
+    return q;
+}
 struct GlobalRow32 {
     const float *p;
     RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const Quad *>(p + 4u * c); }
@@ -215,7 +229,7 @@ struct MixedRow32 {
     RSQ_HD Quad quad(uint32_t c) const { return use_lds ? l.quad(c) : g.quad(c); }
 };
 
-RSQ_HD Quad mul_quad(const Quad &a, const Quad &b) { return Quad{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+RSQ_HD Quad mul_quad(const Quad &a, const Quad &b) { return Quad{a.lo * b.lo, a.hi * b.hi}; }
 template <class R0, class R1, class R2>
 RSQ_HD Quad prod_quad(uint32_t c, const R0 &r0, const R1 &r1, const R2 &r2) {
     const Quad a = r0.quad(c), b = r1.quad(c), d = r2.quad(c);
@@ -240,7 +254,7 @@ constexpr float kScreenMinSum = 9.313225746154785e-10f;      // 2^-30
 // Q quads per row (compile-time: the loops unroll, the loads of a batch of quads are issued before their products are formed).
 // Returns true and the outcome COLUMN if the draw is decided.
 template <int Q, class... Rs>
-RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
+RSQ_HD bool draw_screened(uint32_t word, uint32_t &col, const Rs &...rs) {
     constexpr int G = Q % RSQ_SCREEN_BATCH == 0 ? RSQ_SCREEN_BATCH : (Q % 2 == 0 ? 2 : 1);      // quads per batch
     constexpr bool kKeep = Q <= 2;                           // short rows: the products stay in registers, pass 2 loads nothing
     float part[Q];
@@ -253,13 +267,14 @@ RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
         for (int i = 0; i < G; ++i) p[i] = prod_quad((uint32_t)(g + i), rs...);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            part[g + i] = (p[i].x + p[i].y) + (p[i].z + p[i].w);
+            const Float2 half = p[i].lo + p[i].hi;
+            part[g + i] = half.x + half.y;
             S += part[g + i];
             if constexpr (kKeep) kept[g + i] = p[i];
         }
         RSQ_SCHED_BARRIER();                                 // keeps the scheduler from hoisting the loads of every batch to the top (registers)
     }
-    const float r = (float)u * S;
+    const float r = ((float)word * 2.3283064365386963e-10f) * S;      // u = word * 2^-32, rounded to single precision
     const float delta = kScreenSafety * (float)(2 * Q + 24) * 5.9604644775390625e-08f * S;
     // the sums from the top never decrease: the quads whose sum exceeds r are the lowest ones; count them, keep the last sum that does not
     float top = 0.f, above = 0.f;
@@ -279,7 +294,7 @@ RSQ_HD bool draw_screened(double u, uint32_t &col, const Rs &...rs) {
         for (int c = 1; c < Q; ++c)
             if (fc == (uint32_t)c) p = kept[c];
     } else p = prod_quad(fc, rs...);
-    const float t3 = above + p.w, t2 = t3 + p.z, t1 = t2 + p.y, t0 = t1 + p.x;
+    const float t3 = above + p.hi.y, t2 = t3 + p.hi.x, t1 = t2 + p.lo.y, t0 = t1 + p.lo.x;
     uint32_t j;
     float hi, lo;
     if (t3 > r) j = 3u, hi = t3, lo = above;
@@ -315,10 +330,11 @@ struct GlobalTables {
     const DevSim &S;
     RSQ_HD const DevTable &quality(uint32_t i) const { return S.quality[i]; }
     RSQ_HD const DevTable &seq_quality(uint32_t i) const { return S.seq_quality[i]; }
-    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const { return draw<4>(S.quality[i], S.pool, S.par0, idx, u, ps); }
-    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const { return draw<4>(S.base_call[i], S.pool, S.par0, idx, u, ps); }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(S.indels[i], S.pool, S.par0, idx, u, ps); }
-    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const { return draw<3>(S.seq_quality[i], S.pool, S.par0, idx, u, ps); }
+    // `word`: the draw's 32 random bits, u = word * 2^-32
+    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t word, double &ps) const { return draw<4>(S.quality[i], S.pool, S.par0, idx, u32_to_unit(word), ps); }
+    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t word, double &ps) const { return draw<4>(S.base_call[i], S.pool, S.par0, idx, u32_to_unit(word), ps); }
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t word, double &ps) const { return draw<3>(S.indels[i], S.pool, S.par0, idx, u32_to_unit(word), ps); }
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t word, double &ps) const { return draw<3>(S.seq_quality[i], S.pool, S.par0, idx, u32_to_unit(word), ps); }
 };
 
 // ------------------------------------------------------------------------------- 2-bit reference access
@@ -707,7 +723,7 @@ struct ReadMachine {
         double prob_sum;
         const uint32_t sqi = seg * S.n_tiles + tile_id;
         const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
-        par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, u32_to_unit(h0.w2), prob_sum);
+        par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, h0.w2, prob_sum);
 #ifdef RSQ_EXP_UNIFORM_SQ
         par.seq_qual = RSQ_EXP_UNIFORM_SQ;                            // experiment only: what a wave-uniform sequence quality would buy
 #endif
@@ -781,7 +797,7 @@ struct ReadMachine {
         uint32_t indel = 0, org_base = 0;
         if (!tail) {
             const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
-            indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, u32_to_unit(w.w0), prob_sum);
+            indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, w.w0, prob_sum);
             if (0.0 == prob_sum) indel = 0;
             org_base = from_template ? src.base(org_pos) : (uint32_t)ad.seqs[adapter_a0 + org_pos];
         }
@@ -799,7 +815,7 @@ struct ReadMachine {
         uint32_t q = 0;
         if (!deletion) {
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-            q = tab.draw_quality(qi, idx_q, u32_to_unit(w.w1), prob_sum);
+            q = tab.draw_quality(qi, idx_q, w.w1, prob_sum);
             if (0.0 == prob_sum) {
                 if (regular) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;      // :341-349
                 else if (tail) q = par.read_pos ? par.last_written_qual : q;                             // at(qual_, read_pos-1) - offset
@@ -809,7 +825,7 @@ struct ReadMachine {
         if (regular) {
             par.qual = q;
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
-            uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, u32_to_unit(w.w2), prob_sum);
+            uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
             if (0.0 == prob_sum) call = org_base;
             par.base_call = call;
             out.put(par.read_pos, call, q + S.phred_offset);

@@ -1435,11 +1435,11 @@ struct ScreenTables {
     RSQ_HD bool in_ring(uint32_t p) const { return t - p <= kRingLag; }
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
-    RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], double u, double &ps) const {
-        return draw<NM>(t, S.pool, par0(), idx, u, ps);
+    RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], uint32_t word, double &ps) const {
+        return draw<NM>(t, S.pool, par0(), idx, u32_to_unit(word), ps);
     }
     template <int NM>
-    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, const uint32_t (&idx)[NM], double u, double &ps) const {
+    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, const uint32_t (&idx)[NM], uint32_t u, double &ps) const {
         uint32_t value = par0()[t.par0_off + col];
         ps = 1.0;
 #ifndef RSQ_EXP_NO_FALLBACK
@@ -1450,7 +1450,7 @@ struct ScreenTables {
         return value;
     }
 
-    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
+    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, double &ps) const {
         const uint32_t local = i - seg * 4u * S.n_tiles;
         const DevTable t = desc(local);
         ps = 0.0;
@@ -1465,7 +1465,7 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(0, decided);
         return settle<4>(decided, col, t, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], double u, double &ps) const {
+    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, double &ps) const {
         const uint32_t local = i - seg * 20u * S.n_tiles;
         const DevTable t = desc(4u * S.n_tiles + local);
         ps = 0.0;
@@ -1482,7 +1482,7 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(1, decided);
         return settle<4>(decided, col, t, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {
         const DevTable t = desc(24u * S.n_tiles + i);
         ps = 0.0;
         if (!t.k) return 0;
@@ -1496,8 +1496,8 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(2, decided);
         return settle<3>(decided, col, t, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], double u, double &ps) const {     // once per read: double precision
-        return draw<3>(seq_quality(i), S.pool, par0(), idx, u, ps);
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {     // once per read: double precision
+        return draw<3>(seq_quality(i), S.pool, par0(), idx, u32_to_unit(u), ps);
     }
 };
 
@@ -1560,7 +1560,7 @@ RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.n_tiles * S.lds.
 RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) {
     const uint32_t table = item / S.lds.quads_q, c = item % S.lds.quads_q, slot = S.lds.slot_q;
     const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
-    Quad q{0.f, 0.f, 0.f, 0.f};
+    Quad q = zero_quad();
     if (d.k) q = *reinterpret_cast<const Quad *>(S.pool32 + d.off32 + (d.rows[0] + d.rows[1] + clamp_row(d, 2, p)) * slot + 4u * c);
     *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + table * slot + 4u * c) = q;
 }
