@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- simulated 2x150 bp read pairs per second of the illuminaPE hot path on N MI355X.
 
-Workload (BASELINE.json configs[1], restated on synthetic data as SURVEY.md section 8(d) prescribes): a
-4 641 652 bp E. coli-sized reference (i.i.d. bases, GC 50.8 %), the pre-fitted synthetic profile P0
-(2x150, qualities 2..41, insert lengths ~ LogNormal(350, 0.25) in [50,1000), one tile), 10 M read pairs.
-One step = one pass of the hot path over the whole reference: coverage sieve -> fragments -> reads -> FASTQ
-text of both mates, all resident in HBM (rsq_sim_pairs over every block, batched by block range).
-Pre-passes (table packing, bias normalisation, systematic-error tracks) happen once before the timed region.
+Workload (BASELINE.json configs[1], restated on synthetic data as SURVEY.md section 8(d) prescribes): per GPU a
+4 641 652 bp E. coli-sized reference sequence (i.i.d. bases, GC 50.8 %) and 10 M read pairs, the pre-fitted synthetic
+profile P0 (2x150, qualities 2..41, insert lengths ~ LogNormal(350, 0.25) in [50,1000), one tile).
+One step = one pass of the hot path over the job: coverage sieve -> fragments -> reads -> FASTQ text of both mates, all
+resident in HBM (rsq_sim_pairs over every block of the rank's share, batched by block range).  Pre-passes (table packing,
+bias normalisation, systematic-error tracks) happen once before the timed region.
 
-With --gpus N each rank simulates its own reference shard of the same size (weak scaling; blocks are independent,
-so there is no data-path collective); `value` is the whole-job aggregate.
-Prints ONE JSON line on rank 0.
+--gpus N is ONE job: a reference of N such sequences, N x 10 M pairs, one seed; the job's blocks of 1000 start positions
+are split into contiguous ranges by reseq_amd.sharding.partition_blocks and every rank simulates its range ("fragments
+sharded by reference block").  Per-GPU work is fixed as N grows (weak scaling); blocks are independent, so there is no
+data-path collective -- torch.distributed (RCCL) carries the timing barrier and the job totals.  `value` is the whole-job
+aggregate.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -30,45 +33,169 @@ GENOME = 4_641_652
 PAIRS = 10_000_000
 A_PAIR = 1436                 # algorithmic HBM bytes per 2x150 pair (DESIGN.md "Roofline")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+TA_CYCLES_PER_LOAD = 23.0     # a wave-level 16-byte load occupies the CU's vector-memory path that long (exp/ta_bench.hip)
+N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
-def cpu_baseline(profile_path, seqs, seed, sample_bp=150_000):
-    """The CPU oracle (a port, 1 thread) on a bounded sample of the same workload: the first `sample_bp` bases of the
-    reference at the same pair density.  Times sieve + CreateReads only (pre-passes excluded, like the GPU figure)."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (the oracle)
+def _oracle_worker(args):
+    """one process: the oracle on a block range of the sample (set-up excluded from the timing through the barrier)"""
+    profile_path, name, codes, seed, n_pairs, part, parts, barrier, queue = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    name, codes = seqs[0]
-    sub = [(name, codes[:sample_bp])]
-    n_pairs = int(round(PAIRS * sample_bp / GENOME))
     prof = O.Profile(profile_path)
-    ref = O.Reference(sub)
+    ref = O.Reference([(name, codes)])
     sim = O.Sim(prof, ref, seed, n_pairs)
+    lo, hi = sharding.partition_blocks(sim.total_blocks(), parts)[part]
+    barrier.wait()
     t0 = time.perf_counter()
-    fr = sim.sieve(1, sim.total_blocks() + 1)
+    fr = sim.sieve(lo, hi)
     r1, r2 = sim.create_reads(fr)
     dt = time.perf_counter() - t0
-    out = {"value": len(fr) / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port",
-           "sample": f"oracle/liboracle.so, first {sample_bp} bp of the reference at the workload's pair density: {len(fr)} pairs, "
-                     f"{len(r1) + len(r2)} FASTQ bytes in {dt:.1f} s (sieve + CreateReads, pre-passes excluded)"}
+    keep = part == 0 and parts == 1             # the one-process run also hands its text and pre-pass results to the parity check
+    queue.put((len(fr), len(r1) + len(r2), dt, (r1, r2, sim.bias_normalization(), sim.thresholds()) if keep else None))
+
+
+def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    name, codes = seqs[0]
+    codes = codes[:sample_bp]
+    n_pairs = int(round(PAIRS * sample_bp / GENOME))
+    barrier, queue = ctx.Barrier(procs), ctx.Queue()
+    ps = [ctx.Process(target=_oracle_worker, args=((profile_path, name, codes, seed, n_pairs, i, procs, barrier, queue),)) for i in range(procs)]
+    for p in ps:
+        p.start()
+    res = [queue.get() for _ in ps]
+    for p in ps:
+        p.join()
+    pairs, nbytes, wall = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
+    text = next((r[3] for r in res if r[3] is not None), None)
+    return pairs, nbytes, wall, n_pairs, text
+
+
+def cpu_baseline(profile_path, seqs, seed):
+    """The CPU oracle (a port of the reference's algorithm, oracle/liboracle.so) on bounded samples of the same workload -- the first
+    bases of the reference at the workload's pair density; sieve + CreateReads timed, pre-passes excluded like the GPU figure: one
+    process on 300 kb, then one process per host core on a block range each of a sample scaled to the core count."""
+    cores = len(os.sched_getaffinity(0))
+    p1, b1, t1, _, text = _oracle_run(profile_path, seqs, seed, 300_000, 1)
+    many_bp = min(GENOME, max(1_000_000, 100_000 * cores))
+    pn, bn, tn, _, _ = _oracle_run(profile_path, seqs, seed, many_bp, cores)
+    out = {"value": pn / tn, "unit": "read-pairs/s", "cores": cores, "kind": "port",
+           "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1},
+           "sample": f"oracle/liboracle.so; 1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per host core, a block range "
+                     f"each): first {many_bp} bp, {pn} pairs in {tn:.1f} s; sieve + CreateReads, pre-passes excluded"}
+    return out, text
+
+
+# ------------------------------------------------------------------------------ statistical parity on the baseline's sample
+def _kmer_counts(seq_lines, k=8):
+    lut = np.full(256, 4, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    counts = np.zeros(4 ** k, np.int64)
+    for whole in seq_lines:                              # reads of one length at a time, 50 000 reads per pass
+        for at in range(0, len(whole), 50_000):
+            group = whole[at:at + 50_000]
+            a = lut[np.frombuffer(b"".join(group), np.uint8).reshape(len(group), -1)]
+            ok = np.ones((a.shape[0], a.shape[1] - k + 1), bool)
+            code = np.zeros(ok.shape, np.int32)
+            for j in range(k):
+                col = a[:, j:a.shape[1] - k + 1 + j]
+                ok &= col < 4
+                code = code * 4 + np.minimum(col, 3)
+            counts += np.bincount(code[ok], minlength=4 ** k)
+    return counts
+
+
+def _by_length(lines):
+    groups = {}
+    for line in lines:
+        groups.setdefault(len(line), []).append(line)
+    return [g for n, g in groups.items() if n >= 8]
+
+
+def fastq_statistics(text):
+    """8-mer spectrum, per-position quality histogram and substitution rate by (read position, quality) of FASTQ text"""
+    lines = text.split(b"\n")
+    seqs, quals = lines[1::4], lines[3::4]
+    kmers = _kmer_counts(_by_length([s for s in seqs if s]))
+    n = max((len(q) for q in quals), default=0)
+    qhist = np.zeros((n, 64), np.int64)
+    for group in _by_length([q for q in quals if q]):
+        a = np.frombuffer(b"".join(group), np.uint8).reshape(len(group), -1) - 33
+        for p in range(a.shape[1]):
+            qhist[p] += np.bincount(np.minimum(a[:, p], 63), minlength=64)
+    errors = sum(int(l.rsplit(b" E", 1)[1]) for l in lines[0::4] if l)
+    return kmers, qhist, errors
+
+
+def kl_divergence(p_counts, q_counts):
+    p, q = p_counts / max(p_counts.sum(), 1), q_counts / max(q_counts.sum(), 1)
+    m = (p > 0) & (q > 0)
+    missing = float(p[(p > 0) & (q == 0)].sum())         # mass the other spectrum does not have at all
+    return float((p[m] * np.log(p[m] / q[m])).sum()) + (np.inf if missing > 0 else 0.0)
+
+
+def parity_on_sample(profile_path, seqs, seed, device, oracle_text):
+    """The metrics BASELINE.json names beside the throughput, GPU output against the CPU oracle's on the baseline's one-thread sample
+    (same seed: the two are bit-identical by construction, so every distance must be exactly 0)."""
+    sample_bp = 300_000
+    name, codes = seqs[0]
+    tmp = tempfile.mkdtemp(prefix="rsq_parity_")
+    fpath = os.path.join(tmp, "sample.fa")
+    synth.write_fasta(fpath, [(name, codes[:sample_bp])])
+    prof, ref = api.Profile(profile_path), api.Reference(fpath, seed)
+    sim = api.Simulator(prof, ref, device)
+    info = sim.prepare(seed, int(round(PAIRS * sample_bp / GENOME)))
+    # the device sums the bias normalisation as a tree, the oracle sequentially (relative 1e-11): both continue from the oracle's thresholds
+    bn, thr = oracle_text[2], oracle_text[3]
+    out_norm = abs(info.bias_normalization / bn - 1.0)
+    sim.set_normalization(bn, thr)
+    _, g1, g2 = sim.pairs(1, info.total_blocks + 1)
     sim.close()
-    ref.close()
-    prof.close()
+    out = {"sample": f"first {sample_bp} bp, seed {seed}", "bias_normalization_rel_diff": out_norm, "fastq_identical": bool(g1 == oracle_text[0] and g2 == oracle_text[1])}
+    kg, qg, eg = fastq_statistics(g1 + g2)
+    ko, qo, eo = fastq_statistics(oracle_text[0] + oracle_text[1])
+    out["kmer_kl"] = kl_divergence(kg, ko)
+    out["quality_histogram_max_abs_diff"] = int(np.abs(qg - qo).max())
+    out["error_count_diff"] = int(eg - eo)
+    out["pairs"] = int(g1.count(b"\n") // 4)
     return out
 
 
-def measured_traffic():
-    """HBM bytes per k_fill_reads launch from the PMC passes of profiles/collect.sh (FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md, plus WRITE_SIZE): counters cannot be read from inside an un-profiled run, so the
-    figure of the newest committed collection is reported together with its file name."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+# ------------------------------------------------------------------------------------------------------- roofline evidence
+def committed_counters():
+    """Counters cannot be read from inside an un-profiled run: the newest committed collection of profiles/collect.sh is reported with
+    its file name and the kernel it was taken from (bench.py's own launch time of that kernel is next to it, so a stale file shows)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
     if not files:
-        return None, None
+        return None
+    tag = os.path.basename(files[-1])[:-len("_pmc.json")]
     try:
-        with open(files[-1]) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except (OSError, ValueError, KeyError):
-        return None, None
+        pmc = json.load(open(files[-1]))
+        kernel = [k for k in pmc if "k_fill_reads" in k][0]
+        c = {n: v["mean"] for n, v in pmc[kernel].items()}
+        cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
+        out = {"source": f"profiles/{tag}_pmc.json", "kernel": kernel, "kernel_cycles": cycles, "kernel_ms_at_2.4GHz": cycles / 2.4e6,
+               "vmem_loads_per_launch": c["SQ_INSTS_VMEM_RD"], "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+               "vmem_issue_frac": c["SQ_INSTS_VMEM_RD"] / N_CU * TA_CYCLES_PER_LOAD / cycles, "ta_busy_frac": c["TA_BUSY_avr"] / cycles,
+               "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * cycles), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / 4 / (N_CU * cycles),
+               "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]}
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+        out["hbm_bytes_per_launch"] = float(json.load(open(tfile))["hbm_bytes_per_launch"]) if os.path.exists(tfile) else None
+        return out
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+class TorchBuffer:
+    """device memory from torch (uint8) with the two attributes api.Simulator.pairs_device reads"""
+
+    def __init__(self, torch, nbytes, device):
+        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.ptr, self.nbytes = self.t.data_ptr(), int(nbytes)
 
 
 def main():
@@ -76,39 +203,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=PAIRS)
-    ap.add_argument("--genome", type=int, default=GENOME)
+    ap.add_argument("--pairs", type=int, default=PAIRS, help="read pairs per GPU")
+    ap.add_argument("--genome", type=int, default=GENOME, help="reference bases per GPU")
     ap.add_argument("--batch-blocks", type=int, default=1200)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--gc", type=float, default=0.508, help="G+C fraction of the synthetic reference (E. coli: 0.508)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-delivery", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # the job: `world` sequences, world x pairs; every rank holds the (small) reference and the tables, and simulates its block range
     tmp = tempfile.mkdtemp(prefix=f"rsq_bench_{rank}_")
     ppath = os.path.join(tmp, "p0.rsqp")
     fpath = os.path.join(tmp, "ref.fa")
-    synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
-    seqs = synth.make_reference(2 + rank, [args.genome], gc=args.gc, names=[f"synthEcoli{rank} len={args.genome}"])
+    synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084, n_ref_seqs=world))
+    seqs = []
+    for i in range(world):
+        seqs += synth.make_reference(2 + i, [args.genome], gc=args.gc, names=[f"synthEcoli{i} len={args.genome}"])
     synth.write_fasta(fpath, seqs)
+
+    # the CPU oracle first (rank 0 of a single-GPU run only): its worker processes are forked before any device context exists
+    baseline = oracle_text = None
+    if not args.no_cpu_baseline and world == 1:
+        baseline, oracle_text = cpu_baseline(ppath, seqs, args.seed)
+
+    import torch
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
 
     prof = api.Profile(ppath)
     ref = api.Reference(fpath, args.seed)
     sim = api.Simulator(prof, ref, local_rank)
     t0 = time.perf_counter()
-    info = sim.prepare(args.seed, args.pairs)
+    info = sim.prepare(args.seed, args.pairs * world)
     prep_s = time.perf_counter() - t0
-    nb = info.total_blocks
-    batches = [(lo, min(nb + 1, lo + args.batch_blocks)) for lo in range(1, nb + 1, args.batch_blocks)]
+    my_lo, my_hi = sharding.partition_blocks(info.total_blocks, world)[rank]
+    batches = sharding.batches(my_lo, my_hi, args.batch_blocks)
 
     # size the FASTQ buffers once from the largest batch (first pass measures), then reuse them
     need1 = need2 = 0
@@ -117,14 +255,13 @@ def main():
         if rc not in (api.RSQ_OK, api.RSQ_ENOSPC):
             raise api.RsqError(rc, api.lib().rsq_last_error().decode())
         need1, need2 = max(need1, l1), max(need2, l2)
-    r1 = api.DeviceArray(local_rank, need1 + 4096)
-    r2 = api.DeviceArray(local_rank, need2 + 4096)
+    bufs = [(TorchBuffer(torch, need1 + 4096, dev), TorchBuffer(torch, need2 + 4096, dev)) for _ in range(2)]
 
     def step():
         pairs = nbytes = 0
         fill_ms = 0.0
         for lo, hi in batches:
-            n, l1, l2, rc = sim.pairs_device(lo, hi, r1, r2)
+            n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0][0], bufs[0][1])
             if rc != api.RSQ_OK:
                 raise api.RsqError(rc, api.lib().rsq_last_error().decode())
             pairs += n
@@ -152,30 +289,77 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
-
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
+
+    # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1
+    # overlaps the copy of batch k into page-locked host memory on a second stream
+    to_host = None
+    if not args.no_host_delivery:
+        host = [(torch.empty(need1 + 4096, dtype=torch.uint8, pin_memory=True), torch.empty(need2 + 4096, dtype=torch.uint8, pin_memory=True)) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def host_step():
+            moved = 0
+            for i, (lo, hi) in enumerate(batches):
+                k = i & 1
+                done[k].synchronize()                                   # the copy that last used this pair of buffers
+                n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[k][0], bufs[k][1])      # returns when the text is complete
+                if rc != api.RSQ_OK:
+                    raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+                with torch.cuda.stream(copy_stream):
+                    host[k][0][:l1].copy_(bufs[k][0].t[:l1], non_blocking=True)
+                    host[k][1][:l2].copy_(bufs[k][1].t[:l2], non_blocking=True)
+                    done[k].record(copy_stream)
+                moved += l1 + l2
+            copy_stream.synchronize()
+            return moved
+
+        host_step()
+        sync()
+        t0 = time.perf_counter()
+        moved = sum(host_step() for _ in range(args.steps))
+        sync()
+        host_elapsed = time.perf_counter() - t0
+        _, moved_all, host_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", 0, moved, host_elapsed)
+        to_host = {"value": total_pairs / host_elapsed, "unit": "read-pairs/s", "ms_per_step": host_elapsed / args.steps * 1e3,
+                   "host_gbytes_per_s": moved_all / host_elapsed / 1e9, "note": "FASTQ text of both mates copied to page-locked host buffers, copy of batch k "
+                   "overlapping the generation of batch k+1 (the link binds: 7.5 GB per step and GPU)"}
 
     if rank == 0:
         launches = args.steps * len(batches)
         avg_fill_s = fill_ms / 1e3 / launches
         achieved = A_PAIR * (pairs / launches) / avg_fill_s / 1e9          # GB/s of algorithmic traffic in the dominant kernel
-        traffic, traffic_source = measured_traffic()
+        counters = committed_counters()
         out = {
             "metric": "simulated read-pairs/sec (2x150 bp)", "value": total_pairs / elapsed, "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference, pre-fitted synthetic profile P0 (2x150), 10 M pairs, illuminaPE hot path "
-                                   "(sieve + CreateReads + FASTQ text) resident in HBM", "reference_bp": args.genome, "pairs_requested": args.pairs,
-                       "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps, "batch_blocks": args.batch_blocks,
-                       "sharding": "one reference shard per GPU, no collective"},
+            "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference sequence and 10 M pairs per GPU, pre-fitted synthetic profile P0 (2x150), "
+                                   "illuminaPE hot path (sieve + CreateReads + FASTQ text) resident in HBM", "reference_bp": args.genome * world,
+                       "pairs_requested": args.pairs * world, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
+                       "batch_blocks": args.batch_blocks, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
+                       "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": A_PAIR * (pairs / launches), "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches, "avg_launch_ms": avg_fill_s * 1e3,
-                         "note": "table-lookup + RNG bound, not HBM bound: 1.4 KB of algorithmic HBM traffic per pair (DESIGN.md)"},
+                         "traffic": counters["hbm_bytes_per_launch"] if counters else None, "traffic_source": counters["source"].replace("_pmc", "_traffic") if counters else None,
+                         "algorithmic_bytes_per_launch": A_PAIR * (pairs / launches), "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches,
+                         "avg_launch_ms": avg_fill_s * 1e3,
+                         "note": "table-lookup + RNG bound, not HBM bound: 1.4 KB of algorithmic HBM traffic per pair (DESIGN.md); what binds is in `secondary`",
+                         "secondary": None if not counters else {
+                             "resource": "VALU issue", "frac": counters["valu_busy_frac"], "vmem_issue_frac": counters["vmem_issue_frac"], "ta_busy_frac": counters["ta_busy_frac"],
+                             "lds_busy_frac": counters["lds_busy_frac"], "lds_bank_conflict_frac": counters["lds_bank_conflict_frac"],
+                             "kernel": counters["kernel"], "kernel_ms_when_profiled": counters["kernel_ms_at_2.4GHz"], "source": counters["source"],
+                             "note": "fractions of the kernel's cycles from the committed PMC collection: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles); "
+                                     "SQ_INSTS_VMEM_RD / 256 CUs x 23 cycles / cycles; TA_BUSY_avr / cycles"}},
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,
         }
-        if not args.no_cpu_baseline and world == 1:                    # the oracle, on rank 0 of a single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(ppath, seqs, args.seed)
+        if to_host:
+            out["value_to_host"] = to_host
+        if baseline:
+            out["cpu_baseline"] = baseline
+            out["parity_sample"] = parity_on_sample(ppath, seqs, args.seed, local_rank, oracle_text)
+            out["kmer_kl"] = out["parity_sample"]["kmer_kl"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
