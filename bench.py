@@ -38,14 +38,12 @@ N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (the oracle)
-def _oracle_worker(args):
-    """one process: the oracle on a block range of the sample (set-up excluded from the timing through the barrier)"""
-    profile_path, name, codes, seed, n_pairs, part, parts, barrier, queue = args
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    prof = O.Profile(profile_path)
-    ref = O.Reference([(name, codes)])
-    sim = O.Sim(prof, ref, seed, n_pairs)
+_ORACLE = {}                 # the prepared oracle simulation of the current sample, inherited by the forked workers
+
+
+def _oracle_worker(part, parts, barrier, queue):
+    """one process: the oracle on a block range of the sample"""
+    sim = _ORACLE["sim"]
     lo, hi = sharding.partition_blocks(sim.total_blocks(), parts)[part]
     barrier.wait()
     t0 = time.perf_counter()
@@ -57,18 +55,26 @@ def _oracle_worker(args):
 
 
 def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
+    """pre-passes once in this process, then `procs` forked workers on a block range each (they share the prepared state)"""
     import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
     ctx = mp.get_context("fork")
     name, codes = seqs[0]
-    codes = codes[:sample_bp]
     n_pairs = int(round(PAIRS * sample_bp / GENOME))
+    prof = O.Profile(profile_path)
+    ref = O.Reference([(name, codes[:sample_bp])])
+    _ORACLE["sim"] = O.Sim(prof, ref, seed, n_pairs)
     barrier, queue = ctx.Barrier(procs), ctx.Queue()
-    ps = [ctx.Process(target=_oracle_worker, args=((profile_path, name, codes, seed, n_pairs, i, procs, barrier, queue),)) for i in range(procs)]
+    ps = [ctx.Process(target=_oracle_worker, args=(i, procs, barrier, queue)) for i in range(procs)]
     for p in ps:
         p.start()
     res = [queue.get() for _ in ps]
     for p in ps:
         p.join()
+    _ORACLE.pop("sim").close()
+    ref.close()
+    prof.close()
     pairs, nbytes, wall = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
     text = next((r[3] for r in res if r[3] is not None), None)
     return pairs, nbytes, wall, n_pairs, text
@@ -77,10 +83,10 @@ def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
 def cpu_baseline(profile_path, seqs, seed):
     """The CPU oracle (a port of the reference's algorithm, oracle/liboracle.so) on bounded samples of the same workload -- the first
     bases of the reference at the workload's pair density; sieve + CreateReads timed, pre-passes excluded like the GPU figure: one
-    process on 300 kb, then one process per host core on a block range each of a sample scaled to the core count."""
+    process on 300 kb, then one process per host core on a block range each of 1.5 Mb."""
     cores = len(os.sched_getaffinity(0))
     p1, b1, t1, _, text = _oracle_run(profile_path, seqs, seed, 300_000, 1)
-    many_bp = min(GENOME, max(1_000_000, 100_000 * cores))
+    many_bp = 1_500_000
     pn, bn, tn, _, _ = _oracle_run(profile_path, seqs, seed, many_bp, cores)
     out = {"value": pn / tn, "unit": "read-pairs/s", "cores": cores, "kind": "port",
            "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1},

@@ -1,0 +1,167 @@
+"""Empirical frequencies against the conditionals the tables imply -- a check that does NOT go through the oracle's reading of
+LogArrayResult::Draw / FillReadPart (ProbabilityEstimates.h:359-380,481-508, Simulator.cpp:294-452).
+
+seqToIllumina records are simulated with a profile whose sequence-quality tables have a single outcome and whose indel tables are
+reduced to "no indel" (ProbabilityEstimates::RemoveInDelErrors), so that every conditioning value of every quality and base-call draw
+can be read off the output: table = (segment, tile, reference base[, dominant error]); rows = (sequence quality, previous quality,
+read position, systematic error rate) resp. (quality, read position, errors so far, systematic error rate).  For each draw the
+conditional P(outcome) = prod_n T_n[row_n][outcome] / sum is evaluated in numpy from the profile's arrays, and observed counts are
+compared with expected ones per (table, outcome), per (table, position, outcome) and per (table, previous quality / quality, outcome):
+z = (O - E) / sqrt(sum p (1 - p)) must look standard normal.  A wrong row index, a wrong clamp, a transposed margin or a biased
+inverse-CDF scan shows up as |z| of tens to hundreds.
+
+The CPU oracle runs without a GPU, the product on the device (`-m gpu`).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from reseq_amd import synth
+from reseq_amd.container import write_container
+
+N_READS, READ_LEN, SEED = 60_000, 30, 4711
+
+
+def _profile(workdir):
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    sq_value = synth.TINY["qual_from"] + 3
+    for seg in range(2):
+        for tile in range(len(arrays["tiles.tiles"])):
+            lim = arrays[f"tab.seq_quality.{seg}.{tile}.limits"].reshape(-1, 2)
+            rows = int((lim[:, 1] - lim[:, 0]).sum())
+            arrays[f"tab.seq_quality.{seg}.{tile}.par0"] = np.asarray([sq_value], np.uint32)
+            arrays[f"tab.seq_quality.{seg}.{tile}.dim2"] = np.ones(rows)
+    path = workdir / "stat_profile.rsqp"
+    write_container(path, arrays)
+    return arrays, str(path), sq_value
+
+
+def _table(arrays, prefix):
+    par0 = arrays[f"tab.{prefix}.par0"].astype(np.int64)
+    lim = arrays[f"tab.{prefix}.limits"].reshape(-1, 2).astype(np.int64)
+    flat, k, pos, margins = arrays[f"tab.{prefix}.dim2"], len(par0), 0, []
+    for lo, hi in lim:
+        margins.append(flat[pos:pos + (hi - lo) * k].reshape(hi - lo, k))
+        pos += (hi - lo) * k
+    return par0, lim, margins
+
+
+def _conditionals(table, states):
+    """P(column | state) for every draw: states is an (N, NM) integer array of conditioning VALUES"""
+    par0, lim, margins = table
+    p = np.ones((len(states), len(par0)))
+    for n, m in enumerate(margins):
+        row = np.clip(states[:, n] - lim[n, 0], 0, lim[n, 1] - lim[n, 0] - 1)      # AdjustIndeces: below -> first row, at/above -> last
+        p *= m[row]
+    s = p.sum(axis=1, keepdims=True)
+    ok = s[:, 0] > 0
+    return p[ok] / s[ok], ok
+
+
+def _z_scores(p, outcome_col, groups):
+    """z per (group, outcome): groups is an integer label per draw"""
+    n_groups, k = int(groups.max()) + 1, p.shape[1]
+    expected, var = np.zeros((n_groups, k)), np.zeros((n_groups, k))
+    np.add.at(expected, groups, p)
+    np.add.at(var, groups, p * (1 - p))
+    observed = np.zeros((n_groups, k))
+    np.add.at(observed, (groups, outcome_col), 1.0)
+    usable = var > 25.0                                  # normal approximation
+    return (observed[usable] - expected[usable]) / np.sqrt(var[usable])
+
+
+def _check(results, rec, arrays, sq_value, enforce=True):
+    tiles = {int(t): i for i, t in enumerate(arrays["tiles.tiles"])}
+    quality_draws, base_draws = {}, {}
+    for i, (seq, qual, cigar, nerr, tile) in enumerate(results):
+        n_m = int(cigar.split("M")[0]) if "M" in cigar and cigar.split("M")[0].isdigit() else 0
+        if n_m == 0:
+            continue
+        seg, tile_id = int(rec["seg"][i]), tiles[int(tile)] if int(tile) in tiles else int(tile)
+        ref, dom, rate = rec["seqs"][i, :n_m].astype(np.int64), rec["dom"][i, :n_m].astype(np.int64), rec["rate"][i, :n_m].astype(np.int64)
+        q = np.frombuffer(qual[:n_m], np.uint8).astype(np.int64) - 33
+        call = np.frombuffer(seq[:n_m], np.uint8).astype(np.int64)
+        prev = np.concatenate([[1], q[:-1]])                           # ReadFillParameter::qual_ starts at 1 (Simulator.h:232)
+        errors_before = np.concatenate([[0], np.cumsum(call != ref)[:-1]])
+        pos = np.arange(n_m)
+        for b in range(4):
+            sel = ref == b
+            if sel.any():
+                quality_draws.setdefault((seg, tile_id, b), []).append(np.stack([np.full(sel.sum(), sq_value), prev[sel], pos[sel], rate[sel], q[sel]], axis=1))
+                for d in range(5):
+                    sd = sel & (dom == d)
+                    if sd.any():
+                        base_draws.setdefault((seg, tile_id, b, d), []).append(np.stack([q[sd], pos[sd], errors_before[sd], rate[sd], call[sd]], axis=1))
+        assert int((call != ref).sum()) <= nerr                          # E<n> counts the whole read, the template part is a subset
+
+    worst, n_tests, n_draws = 0.0, 0, 0
+    for family, draws, group_cols in (("quality", quality_draws, (2, 1, 3)), ("base_call", base_draws, (0, 1, 2))):
+        for key, parts in draws.items():
+            a = np.concatenate(parts)
+            table = _table(arrays, family + "." + ".".join(map(str, key)))
+            if not len(table[0]):
+                continue
+            p, ok = _conditionals(table, a[:, :4])
+            a = a[ok]
+            col_of = {int(v): c for c, v in enumerate(table[0])}
+            assert all(int(v) in col_of for v in np.unique(a[:, 4])), (family, key, "an outcome the table does not have")
+            col = np.asarray([col_of[int(v)] for v in a[:, 4]])
+            assert (p[np.arange(len(col)), col] > 0).all(), (family, key, "an outcome of probability 0 was drawn")
+            n_draws += len(a)
+            for z in [_z_scores(p, col, np.zeros(len(a), np.int64))] + [_z_scores(p, col, a[:, c] - a[:, c].min()) for c in group_cols]:
+                if len(z):
+                    worst = max(worst, float(np.abs(z).max()))
+                    n_tests += len(z)
+    if enforce:
+        assert n_draws > 1_500_000 and n_tests > 2_000, (n_draws, n_tests)
+        assert worst < 5.5, worst                          # the largest of n_tests standard normal values: beyond 5.5 with probability 4e-8 each
+    return worst, n_tests, n_draws
+
+
+def _records():
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    rec = synth.make_error_model_input(77, N_READS, READ_LEN, arrays, zero_frac=0.7)
+    rec["frag_len"][:] = np.maximum(rec["frag_len"], READ_LEN + 5)          # whole reads are template ('M'): no adapter part
+    return rec
+
+
+def test_conditionals_of_the_oracle(workdir):
+    arrays, path, sq_value = _profile(workdir)
+    rec = _records()
+    prof = O.Profile(path)
+    O.lib().orc_profile_remove_indel_errors(prof.h)
+    results = O.error_model_only(prof, SEED, rec)
+    prof.close()
+    _check(results, rec, arrays, sq_value)
+
+
+def test_the_check_notices_a_shifted_margin(workdir):
+    """the test of the test: the same data evaluated against tables whose position margin is shifted by one row must fail loudly"""
+    arrays, path, sq_value = _profile(workdir)
+    rec = _records()
+    prof = O.Profile(path)
+    O.lib().orc_profile_remove_indel_errors(prof.h)
+    results = O.error_model_only(prof, SEED, rec)[:20_000]
+    prof.close()
+    wrong = dict(arrays)
+    for name in list(arrays):
+        if name.startswith("tab.quality.") and name.endswith(".dim2"):
+            par0, lim, margins = _table(arrays, name[4:-5])
+            margins[2] = np.roll(margins[2], 1, axis=0)
+            wrong[name] = np.concatenate([m.ravel() for m in margins])
+    sub = {k: v[:20_000] for k, v in rec.items()}
+    worst, n_tests, _ = _check(results, sub, wrong, sq_value, enforce=False)
+    assert worst > 20 and n_tests > 500, (worst, n_tests)
+    assert _check(results, sub, arrays, sq_value, enforce=False)[0] < 5.5
+
+
+@pytest.mark.gpu
+def test_conditionals_of_the_product(workdir):
+    from backends import GpuBackend
+    arrays, path, sq_value = _profile(workdir)
+    rec = _records()
+    b = GpuBackend(path, None, 0, {"no_indels": True})
+    b.prepare(SEED)
+    results = b.error_model(rec)
+    b.close()
+    _check(results, rec, arrays, sq_value)
