@@ -175,7 +175,7 @@ def parity_on_sample(profile_path, seqs, seed, device, oracle_text):
 def committed_counters():
     """Counters cannot be read from inside an un-profiled run: the newest committed collection of profiles/collect.sh is reported with
     its file name and the kernel it was taken from (bench.py's own launch time of that kernel is next to it, so a stale file shows)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_pmc.json")))      # by name: round, then letter (mtimes do not survive a checkout)
     if not files:
         return None
     tag = os.path.basename(files[-1])[:-len("_pmc.json")]
