@@ -451,114 +451,6 @@ RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t wor
         sur[b] = v;
     }
 }
-// ------------------------------------------------------------------------------- Surrounding edits for variants
-// Surrounding.cpp:22-192: the 30-base context as three 20-bit blocks, first base most significant.  A variant inside the window
-// changes a base, deletes one (the window refills from its right or its left end) or inserts bases (pushing the rest out on the
-// right or on the left).  `pos` is the position inside the window (0..29); bases are codes 0..3.  Building blocks of the
-// per-allele simulation; pinned to SurroundingTest::TestModifiers / TestModifiersExtremCases.
-constexpr uint32_t kSurLength = kSurBlocks * kSurRange;
-RSQ_HD void sur_change_base(uint32_t (&sur)[3], uint32_t pos, uint32_t new_base) {                        // :22-26
-    const uint32_t bit = 2u * (kSurRange - (pos % kSurRange) - 1u);
-    sur[pos / kSurRange] = (sur[pos / kSurRange] & ~(3u << bit)) + (new_base << bit);
-}
-RSQ_HD void sur_delete_shift_right(uint32_t (&sur)[3], uint32_t pos, uint32_t new_end_base) {             // :28-43 the window refills from the right
-    uint32_t carry = new_end_base;
-    const uint32_t del_block = pos / kSurRange;
-    for (uint32_t block = kSurBlocks; --block > del_block;) {
-        sur[block] = (sur[block] << 2) + carry;
-        carry = sur[block] / kSurSize;
-        sur[block] %= kSurSize;
-    }
-    const uint32_t bit = 2u * (kSurRange - (pos % kSurRange) - 1u);
-    carry += (sur[del_block] % (1u << bit)) << 2;
-    sur[del_block] = (sur[del_block] >> (bit + 2u) << (bit + 2u)) + carry;
-}
-RSQ_HD void sur_delete_shift_left(uint32_t (&sur)[3], uint32_t pos, uint32_t new_end_base) {              // :45-60 the window refills from the left
-    uint32_t carry = new_end_base;
-    const uint32_t del_block = pos / kSurRange;
-    for (uint32_t block = 0; block < del_block; ++block) {
-        sur[block] += carry * kSurSize;
-        carry = sur[block] % 4u;
-        sur[block] >>= 2;
-    }
-    const uint32_t bit = 2u * (kSurRange - (pos % kSurRange) - 1u);
-    sur[del_block] += carry * kSurSize;
-    sur[del_block] = (sur[del_block] >> (bit + 2u) << bit) + sur[del_block] % (1u << bit);
-}
-// new_bases: anything indexable that yields base codes (a pointer, or a view of a variant's bases)
-template <class Bases>
-RSQ_HD void sur_insert_shift_right(uint32_t (&sur)[3], uint32_t pos, const Bases &new_bases, uint32_t n_new) {      // :62-125
-    uint32_t block = pos / kSurRange;
-    uint32_t to_insert = n_new < kSurLength - pos ? n_new : kSurLength - pos;
-    const uint32_t shift_blocks = to_insert / kSurRange, shift_bases = to_insert % kSurRange;
-    for (uint32_t cur = kSurBlocks - shift_blocks; cur-- > block + 1u;) {                                   // shift bases, whole blocks later
-        sur[cur] >>= 2u * shift_bases;
-        sur[cur] += sur[cur - 1u] % (1u << 2u * shift_bases) * (1u << 2u * (kSurRange - shift_bases));
-    }
-    const uint32_t inv_pos = kSurRange - (pos % kSurRange);
-    uint32_t tmp = sur[block] % (1u << 2u * inv_pos);                                                      // what leaves the start block
-    sur[block] >>= 2u * inv_pos;
-    tmp >>= 2u * shift_bases;
-    if (0u < shift_blocks && kSurBlocks > block + shift_blocks) {
-        for (uint32_t cur = kSurBlocks; cur-- > block + shift_blocks + 1u;) sur[cur] = sur[cur - shift_blocks];
-        sur[block + shift_blocks] = tmp;
-    }
-    uint32_t ins = 0, here = to_insert < inv_pos ? to_insert : inv_pos;
-    to_insert -= here;
-    for (; here--;) sur[block] = (sur[block] << 2) + new_bases[ins++];
-    if (0u == shift_blocks && inv_pos > shift_bases) {                                                     // everything happened in the start block
-        sur[block] <<= 2u * (inv_pos - shift_bases);
-        sur[block] += tmp;
-    } else {
-        while (0u < to_insert) {
-            here = to_insert < kSurRange ? to_insert : kSurRange;
-            to_insert -= here;
-            tmp = sur[++block] % (1u << 2u * (kSurRange - here));
-            sur[block] = 0;
-            for (uint32_t i = here; i--;) sur[block] = (sur[block] << 2) + new_bases[ins++];
-            sur[block] <<= 2u * (kSurRange - here);
-            sur[block] += tmp;
-        }
-    }
-}
-template <class Bases>
-RSQ_HD void sur_insert_shift_left(uint32_t (&sur)[3], uint32_t pos, const Bases &new_bases, uint32_t n_new) {       // :127-192
-    uint32_t block = pos / kSurRange;
-    uint32_t to_insert = n_new < pos + 1u ? n_new : pos + 1u;
-    const uint32_t shift_blocks = to_insert / kSurRange, shift_bases = to_insert % kSurRange;
-    for (uint32_t cur = shift_blocks; cur < block; ++cur) {
-        sur[cur] %= 1u << 2u * (kSurRange - shift_bases);
-        sur[cur] <<= 2u * shift_bases;
-        sur[cur] += sur[cur + 1u] >> 2u * (kSurRange - shift_bases);
-    }
-    const uint32_t pos_in_block = pos % kSurRange + 1u;
-    const uint32_t keep = sur[block] % (1u << 2u * (kSurRange - pos_in_block));                           // stays right of the insertion
-    if (pos_in_block > shift_bases) {
-        sur[block] >>= 2u * (kSurRange - pos_in_block);
-        sur[block] %= 1u << 2u * (pos_in_block - shift_bases);
-    } else sur[block] = 0;
-    if (0u < shift_blocks) {
-        if (block >= shift_blocks) {
-            for (uint32_t cur = 0; cur + shift_blocks < block; ++cur) sur[cur] = sur[cur + shift_blocks];
-            sur[block - shift_blocks] = sur[block] << 2u * (kSurRange - (pos_in_block - shift_bases));
-        }
-        sur[block] = 0;
-    }
-    uint32_t here = to_insert < pos_in_block ? to_insert : pos_in_block, ins_to = n_new;
-    for (uint32_t i = ins_to - here; i < ins_to; ++i) sur[block] = (sur[block] << 2) + new_bases[i];
-    to_insert -= here;
-    ins_to -= here;
-    sur[block] <<= 2u * (kSurRange - pos_in_block);
-    sur[block] += keep;
-    while (0u < to_insert) {
-        here = to_insert < kSurRange ? to_insert : kSurRange;
-        sur[--block] >>= 2u * here;
-        for (uint32_t i = ins_to - here; i < ins_to; ++i) sur[block] = (sur[block] << 2) + new_bases[i];
-        to_insert -= here;
-        ins_to -= here;
-    }
-}
-
 // Surrounding.h:114-120 (blocks summed last to first) and utilities.hpp:505 InvLogit2
 RSQ_HD double surrounding_bias(const double *__restrict__ sur_bias, const uint32_t (&sur)[3]) {
     double bias = 0.0;

@@ -341,7 +341,7 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     return n_here;
 }
 
-// the cell with variants of any kind: possible alleles, ChooseAlleles, and per chosen (allele, strand) the modifiers from scratch
+// the cell with variants of any kind: possible alleles, ChooseAlleles, and per chosen (allele, strand) the allele's own stretch (rsq_variants.h)
 template <uint32_t CAP>
 RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint32_t len, double probability_chosen, VarCellT<CAP> &cell) {
     cell.n = 0;
@@ -351,7 +351,7 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     uint8_t possible[CAP];
     uint32_t n_possible = 0;
     for (uint32_t allele = 0; allele < S.num_alleles; ++allele)                     // GetPossibleAlleles :1330-1340
-        if (!allele_skipped(r, site.st, allele, site.start)) possible[n_possible++] = (uint8_t)allele;
+        if (allele_starts_here(r, site.st, allele, site.start)) possible[n_possible++] = (uint8_t)allele;
     const uint32_t possible_strands = 2u * n_possible;
     const uint32_t non_zero_strands = binomial(possible_strands, 1 - thr0, probability_chosen);
     if (!non_zero_strands) return 0;
@@ -378,13 +378,15 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     for (uint32_t j = 0; j < n_chosen; ++j) {
         const uint32_t allele = possible[chosen[j] >> 1], strand = chosen[j] & 1u;
         if (0u == (j & 1u)) wc = philox(S.seed, site.start, c1, len, (kDomSieve << 28) | (128u + (j >> 1)));
-        AlleleMod m;
-        VarCellSite vs;
-        evaluate_allele(r, site.st, allele, site.start, S.insert_from, len, m, vs);
-        if (!(vs.cur_end_position < site.L)) continue;                              // :2318
+        const AlleleView a = allele_view(S, site.seq, allele);
+        const AlleleCell ac = allele_cell(a, site.st, site.start, len);
+        if (!ac.inside) continue;                                                   // :2318
+        uint32_t sur_start[3], sur_end[3];
+        allele_surrounding_forward(a, ac.hs, sur_start);                            // bias_mod.surrounding_start_.at(allele)
+        allele_surrounding_reverse(a, ac.he - 1, sur_end);                          // bias_mod.surrounding_end_.at(allele)
         const double u = (j & 1u) ? u53_to_unit(wc.w2, wc.w3) : u53_to_unit(wc.w0, wc.w1);
         const double adjusted_random = thr0 + u * (1 - thr0);
-        const uint32_t c = fragment_counts(S, site.seq, len, vs.gc_percent, m.surrounding_start, m.surrounding_end, adjusted_random);
+        const uint32_t c = fragment_counts(S, site.seq, len, ac.gc_percent, sur_start, sur_end, adjusted_random);
         if (c) {
             cell.id[cell.n] = (uint8_t)(allele * 2u + strand);
             cell.cnt[cell.n] = (uint16_t)c;
@@ -758,16 +760,13 @@ __global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo,
         if (!cnt) continue;
         FragmentVar fv{};
         if constexpr (VM == 2) {                                    // what SimulateFromGivenBlock hands to CreateReads (:2334-2337), derived again
-            const VarView r = var_view(S, site.seq);
-            AlleleMod m;
-            VarCellSite vs;
-            evaluate_allele(r, site.st, allele, site.start, S.insert_from, h.len, m, vs);
-            fv.end = vs.cur_end_position;
+            const AlleleCell ac = allele_cell(allele_view(S, site.seq, allele), site.st, site.start, h.len);
+            fv.end = ac.end;
             fv.sub = site.sub;
             fv.start_var = site.st.first_variant_id;
             fv.start_var_pos = site.st.start_variant_pos;
-            fv.end_var = vs.end_var.first_variant_id;
-            fv.end_var_pos = vs.end_var.start_variant_pos;
+            fv.end_var = ac.end_var.first_variant_id;
+            fv.end_var_pos = ac.end_var.start_variant_pos;
         }
         for (uint32_t dup = 0; dup < cnt; ++dup, ++k) {
             frags[base + k] = make_fragment(site, h.len, dup, strand, block_id, number_base + k + 1u, allele);

@@ -51,6 +51,8 @@ struct SimState {
     std::vector<uint8_t> var_bases;
     std::vector<uint16_t> var_err_fwd, var_err_rev;  // filled by build_variant_sys_errors
     uint16_t *dev_var_err_fwd = nullptr, *dev_var_err_rev = nullptr;
+    std::vector<AlleleVar> allele_map;               // coordinate maps of the alleles (rsq_variants.h)
+    std::vector<uint32_t> allele_map_ptr;            // [n_seqs * num_alleles + 1]
     std::vector<ExtraStart> extra;                   // starts inside inserted bases, per sequence in loop order
     std::vector<uint32_t> extra_seq_ptr;             // [n_seqs + 1]
     std::vector<double> host_pool;
@@ -338,18 +340,42 @@ inline void pack_profile(SimState &s, Uploader &up) {
     s.ops_stride = (max_iter + 15u) / 16u;
 }
 
-// How the kernels simulate a variant set: 1 = substitutions only, at most one per position and allele: every allele gets its own copy
-// of the packed reference; 2 = anything else: the reference's per-allele bookkeeping per sieve cell (rsq_variants.h)
+// How the kernels simulate a variant set: 1 = substitutions only: every allele gets its own copy of the packed reference;
+// 2 = anything else (and more than eight alleles): alleles as coordinate maps (rsq_variants.h)
 inline int variants_mode_for(const Variants &v) {
     if (v.num_alleles > kMaxDevAlleles) throw Error("variants: more than " + std::to_string(kMaxDevAlleles) + " alleles");
     if (v.num_alleles > 8) return 2;                               // a copy of the reference per allele only for a few alleles
     for (const std::vector<Variant> &seq : v.by_seq)
-        for (size_t i = 0; i < seq.size(); ++i) {
-            if (seq[i].var_seq.size() != 1) return 2;
-            for (size_t k = i + 1; k < seq.size() && seq[k].position == seq[i].position; ++k)
-                if ((seq[k].allele[0] & seq[i].allele[0]) | (seq[k].allele[1] & seq[i].allele[1])) return 2;
-        }
+        for (const Variant &x : seq)
+            if (x.var_seq.size() != 1) return 2;
     return 1;
+}
+
+// The coordinate maps of a sequence's alleles (rsq_variants.h): per allele the variants it has, in position order, with the running
+// difference between allele and reference coordinates and the running G/C difference, and a sentinel behind them.  An allele with
+// two different variants at one position cannot come out of ReadVariants (overlapping records are refused, Reference.cpp:166-168, and one
+// record gives an allele one alternative); the map relies on it, so it is checked.
+inline void allele_maps_of_sequence(const std::vector<Variant> &vars, const std::vector<uint8_t> &codes, uint32_t num_alleles, const std::string &name,
+                                    std::vector<AlleleVar> &out, std::vector<uint32_t> &ptr) {
+    auto is_gc_code = [](uint8_t c) { return c == 1 || c == 2; };
+    for (uint32_t a = 0; a < num_alleles; ++a) {
+        int32_t shift = 0, gc = 0;
+        int64_t last_pos = -1;
+        for (size_t i = 0; i < vars.size(); ++i) {
+            const Variant &v = vars[i];
+            if (!v.in_allele(a)) continue;
+            if ((int64_t)v.position == last_pos)
+                throw Error("variants: allele " + std::to_string(a) + " has two different variants at position " + std::to_string(v.position + 1) + " of " + name +
+                            " (overlapping records on one haplotype)");
+            last_pos = v.position;
+            out.push_back(AlleleVar{v.position, (uint32_t)i, shift, gc});
+            shift += (int32_t)v.var_seq.size() - 1;
+            for (uint8_t b : v.var_seq) gc += is_gc_code(b) ? 1 : 0;
+            gc -= is_gc_code(codes[v.position]) ? 1 : 0;
+        }
+        out.push_back(AlleleVar{(uint32_t)codes.size(), (uint32_t)vars.size(), shift, gc});
+        ptr.push_back((uint32_t)out.size());
+    }
 }
 
 // The extra passes of SimulateFromGivenBlock's do-while loop (Simulator.cpp:2299-2352) at the start positions of one sequence:
@@ -432,6 +458,8 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     s.var_bases.clear();
     s.extra.clear();
     s.extra_seq_ptr.assign(1, 0);
+    s.allele_map.clear();
+    s.allele_map_ptr.assign(1, 0);
     if (1 == s.variants_mode) {
         // copy 0 = the reference, copy 1 + a = allele a with its substitutions; G/C prefix sums per copy
         const size_t stride = words + 1;
@@ -475,6 +503,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
                 s.variants.push_back(dv);
             }
             s.var_ptr.push_back((uint32_t)s.variants.size());
+            allele_maps_of_sequence(variants->by_seq[i], r.codes[i], s.num_alleles, r.first_part(i), s.allele_map, s.allele_map_ptr);
             if (2 == s.variants_mode && r.codes[i].size() >= d.insert_to) extra_starts_of_sequence(variants->by_seq[i], s.extra);   // sequences that get blocks (:1159)
             s.extra_seq_ptr.push_back((uint32_t)s.extra.size());
         }
@@ -486,6 +515,13 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     s.var_err_fwd.assign(s.var_bases.size() + 1, 0);
     s.var_err_rev.assign(s.var_bases.size() + 1, 0);
     d.var_bases = up.put(s.var_bases);
+    {
+        std::vector<uint32_t> bases_gc(s.var_bases.size() + 1, 0);
+        for (size_t k = 0; k < s.var_bases.size(); ++k) bases_gc[k + 1] = bases_gc[k] + ((s.var_bases[k] == 1 || s.var_bases[k] == 2) ? 1u : 0u);
+        d.var_bases_gc = up.put(bases_gc);
+    }
+    d.allele_map = up.put(s.allele_map);
+    d.allele_map_ptr = up.put(s.allele_map_ptr);
     s.dev_var_err_fwd = up.put(s.var_err_fwd);
     s.dev_var_err_rev = up.put(s.var_err_rev);
     d.var_err_fwd = s.dev_var_err_fwd;

@@ -125,6 +125,14 @@ struct DevVariant {
     uint32_t pad;
     uint64_t allele[2];    // bit a: the variant is in allele a
 };
+// One replacement of ONE allele (a variant the allele has), an entry of the allele's coordinate map (rsq_variants.h).  The entries of a
+// (sequence, allele) are sorted by position and end with a sentinel {sequence length, number of the sequence's variants, totals}.
+struct AlleleVar {
+    uint32_t pos;          // reference position
+    uint32_t vid;          // the variant, index among the sequence's variants
+    int32_t shift;         // allele coordinate of `pos` minus pos = sum of (len - 1) over the allele's earlier entries
+    int32_t gc;            // G/C of the allele in front of this entry minus G/C of the reference in front of pos
+};
 // what CreateReads gets of SimulateFromGivenBlock beyond the Fragment when variants are loaded (Simulator.cpp:2334-2337)
 struct FragmentVar {
     uint32_t end;          // cur_end_position = start + length + end_pos_shift_[allele]
@@ -202,11 +210,14 @@ struct DevSim {
     // ---- variants (-V): copy 1 + a of the packed reference and of gc_prefix (hap_stride entries apart) is allele a with its
     // substitutions applied; copy 0 stays the reference itself (systematic-error chains, bias sums, wrapped surroundings)
     uint32_t num_alleles;            // Reference::NumAlleles(), 1 without variants
-    uint32_t variants_loaded;        // Reference::VariantsLoaded(): 0 no, 1 substitutions only (allele copies), 2 any kind (rsq_variants.h)
+    uint32_t variants_loaded;        // Reference::VariantsLoaded(): 0 no, 1 substitutions only (allele copies), 2 any kind (allele coordinate maps, rsq_variants.h)
     uint64_t hap_stride;             // 0 unless variants_loaded == 1
     const DevVariant *variants;      // sorted by position within each sequence
     const uint32_t *var_ptr;         // [n_seqs + 1]
     const uint8_t *var_bases;
+    const uint32_t *var_bases_gc;    // variants_loaded == 2: [bases + 1] G/C among var_bases[0, i)
+    const AlleleVar *allele_map;     // variants_loaded == 2: the coordinate maps, (sequence, allele) after (sequence, allele)
+    const uint32_t *allele_map_ptr;  // [n_seqs * num_alleles + 1]
     const uint16_t *var_err_fwd, *var_err_rev;
     uint32_t *walk_error;            // set by a read whose systematic-error walk leaves its sequence (the reference dereferences a NULL block there)
     // variants_loaded == 2: slots of the sieve = start positions plus the extra passes inside inserted bases, in loop order

@@ -1,14 +1,20 @@
-// rsq_variants.h -- variants of any kind (substitutions, insertions, deletions) on the device: the per-allele modifiers of one sieve
-// cell, derived from scratch.
+// rsq_variants.h -- variants of any kind (substitutions, insertions, deletions) on the device: alleles as coordinate maps.
 //
-// The reference keeps VariantBiasVarModifiers (Simulator.h:29-89) up to date while SimulateFromGivenBlock walks start positions and
-// fragment lengths (Simulator.cpp:1399-1896).  What it holds for (start position, pass at that position, fragment length, allele) does
-// not depend on the lengths visited before (the oracle checks this for every cell it evaluates: orc_var_scratch_counters), so a lane
-// that owns one cell derives it directly: PrepareBiasModForCurrentStartPos for its allele, then one
-// PrepareBiasModForCurrentFragmentLength from the first fragment length to its own.  Same statements, same variable widths as the
-// reference; per-allele vectors become the scalars of one allele.  Also here: Reference::ReferenceSequence with variants
-// (Reference.cpp:498-567) writing a 2-bit template, and the extra passes at a start position (starts inside inserted bases,
-// CheckForInsertedBasesToStartFrom :1870-1896) as slots of the sieve.
+// A variant replaces ONE reference base by var_seq_ (Reference.h:24-62: empty = the base is deleted, one base = substitution, more =
+// the base followed by inserted bases).  An allele of a sequence is therefore the reference with a position-sorted list of such
+// replacements, and everything SimulateFromGivenBlock asks of an allele for one cell (Simulator.cpp:2311-2337: end position, G/C percent,
+// start and end surrounding, EndVariant) is a property of the stretch [hs, hs + fragment length) of the ALLELE's own sequence -- the
+// statement the reference's test makes of its bookkeeping (SimulatorTest.cpp:163-192) and the oracle checks for every cell it evaluates
+// (orc_var_haplotype_check).  The reference reaches these values incrementally while it walks start positions and fragment lengths
+// (VariantBiasVarModifiers, Simulator.cpp:1399-1851, kept as the checker in oracle/oracle_variants.hpp).  Here the host builds once per
+// (sequence, allele) the map between reference and allele coordinates (AlleleVar: per replacement the running length difference and the
+// running G/C difference), and a lane that owns a cell gets
+//   - the allele coordinate of its start:           one search by reference position,
+//   - the end position and EndVariant:              one search by allele coordinate,
+//   - the G/C count of the fragment:                the difference of two prefix values (reference prefix sums + the map's running G/C),
+//   - both surroundings:                            30 allele bases gathered piecewise (runs of the 2-bit reference, bases of replacements)
+// -- O(log variants) per cell instead of a replay over the fragment's length.
+// Also here: Reference::ReferenceSequence with variants (Reference.cpp:498-567) writing a 2-bit template.
 #pragma once
 #include "rsq_core.h"
 
@@ -24,7 +30,6 @@ struct VarView {
     uint32_t n;
     const uint8_t *bases;               // var_seq_ of all variants (DevVariant::off)
     RSQ_HD uint32_t at(uint32_t pos) const { return ref_base(words, word_off, pos); }
-    RSQ_HD bool gc(uint32_t pos) const { return is_gc(at(pos)); }
     RSQ_HD uint32_t base(const DevVariant &var, uint32_t k) const { return bases[var.off + k]; }
     RSQ_HD bool in_allele(const DevVariant &var, uint32_t allele) const { return (var.allele[allele >> 6] >> (allele & 63u)) & 1u; }
     RSQ_HD uint32_t lower_bound(uint32_t pos) const {
@@ -41,315 +46,168 @@ RSQ_HD VarView var_view(const DevSim &S, uint32_t seq) {
     return VarView{S.ref_words, S.gc_prefix, S.seq_word_off[seq], S.seq_len[seq], S.variants + S.var_ptr[seq], S.var_ptr[seq + 1] - S.var_ptr[seq], S.var_bases};
 }
 
-// views of a variant's bases for the surrounding edits
-struct VarBases {                       // var_seq_[from ...)
-    const uint8_t *p;
-    RSQ_HD uint32_t operator[](uint32_t i) const { return p[i]; }
-};
-struct VarBasesRC {                     // ReverseComplementorDna of var_seq_[from, from + n)
-    const uint8_t *p;
-    uint32_t n;
-    RSQ_HD uint32_t operator[](uint32_t i) const { return 3u - p[n - 1u - i]; }
-};
-
-// the start of a pass at a start position: bias_mod.first_variant_id_, start_variant_pos_
+// the start of a pass at a start position: bias_mod.first_variant_id_, start_variant_pos_ (a pass with start_variant_pos > 0 starts
+// inside the inserted bases of variant first_variant_id, CheckForInsertedBasesToStartFrom :1870-1896)
 struct VarStart {
     int32_t first_variant_id;
     uint32_t start_variant_pos;
 };
-// one allele's share of VariantBiasVarModifiers
-struct AlleleMod {
-    int32_t unhandled_variant_id;
-    uint32_t unhandled_bases_in_variant;
-    int32_t gc_mod, end_pos_shift;
-    uint32_t last_end_position;
-    uint32_t surrounding_start[3], surrounding_end[3];
+
+// GetPossibleAlleles (:1330-1340, Simulator.h:401-412): at a start position whose first variant deletes the base the alleles with
+// that deletion have nothing to start from; a pass inside inserted bases exists only for the alleles that have the insertion
+RSQ_HD bool allele_starts_here(const VarView &r, const VarStart &st, uint32_t allele, uint32_t start) {
+    if ((uint32_t)st.first_variant_id >= r.n) return true;
+    const DevVariant &var = r.v[st.first_variant_id];
+    if (var.pos != start) return true;
+    const bool has = r.in_allele(var, allele);
+    if (0u == var.len) return !has;
+    return 0u == st.start_variant_pos || has;
+}
+
+// ---- one allele of one sequence
+struct AlleleView {
+    const AlleleVar *e;                 // its replacements in position order, e[n] = sentinel {L, number of variants, total shift, total G/C}
+    uint32_t n;
+    VarView r;
+    const uint32_t *bases_gc;           // bases_gc[i] = G/C among var_bases[0, i)
+    RSQ_HD const DevVariant &var(uint32_t i) const { return r.v[e[i].vid]; }
+    RSQ_HD int64_t begin_of(uint32_t i) const { return (int64_t)e[i].pos + e[i].shift; }       // allele coordinate of entry i's first base
+    RSQ_HD int64_t length() const { return (int64_t)r.L + e[n].shift; }
+    RSQ_HD uint32_t entries_before(uint32_t pos) const {                  // entries in front of reference position pos
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (e[mid].pos < pos) lo = mid + 1u;
+            else hi = mid;
+        }
+        return lo;
+    }
+    RSQ_HD uint32_t entries_upto(int64_t h) const {                       // entries that begin at or before allele coordinate h
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (begin_of(mid) <= h) lo = mid + 1u;
+            else hi = mid;
+        }
+        return lo;
+    }
+    // allele coordinate of reference position pos (of the first base that replaces it; of the next kept base if pos is deleted)
+    RSQ_HD int64_t to_allele(uint32_t pos) const { return (int64_t)pos + e[entries_before(pos)].shift; }
+    RSQ_HD uint32_t ref_gc_before(uint32_t pos) const {                   // G/C among reference bases [0, pos), pos <= L
+        return r.gc_prefix[r.word_off + (pos >> 5)] - r.gc_prefix[r.word_off] + gc_low(r.words[r.word_off + (pos >> 5)], pos & 31u);
+    }
 };
-
-// Simulator.h:401-412
-RSQ_HD bool allele_skipped(const VarView &r, const VarStart &st, uint32_t allele, uint32_t cur_start_position) {
-    if ((uint32_t)st.first_variant_id < r.n && r.v[st.first_variant_id].pos == cur_start_position) {
-        const DevVariant &var = r.v[st.first_variant_id];
-        if (0u == var.len) return r.in_allele(var, allele);
-        if (st.start_variant_pos) return !r.in_allele(var, allele);
-    }
-    return false;
-}
-// :1399-1402
-RSQ_HD bool variant_inside_current_fragment(const VarView &r, int32_t cur_var_id, uint32_t cur_end_position, int32_t end_pos_shift) {
-    return r.n > (uint32_t)cur_var_id && r.v[cur_var_id].pos < cur_end_position + (uint32_t)end_pos_shift;
-}
-// :1404-1455
-RSQ_HD void handle_gc_mod_and_end_pos_shift_for_new_variants(AlleleMod &m, uint32_t allele, const VarView &r, uint32_t cur_end_position) {
-    while (variant_inside_current_fragment(r, m.unhandled_variant_id, cur_end_position, m.end_pos_shift) && 0u == m.unhandled_bases_in_variant) {
-        const DevVariant &var = r.v[m.unhandled_variant_id];
-        if (!r.in_allele(var, allele)) {
-            ++m.unhandled_variant_id;
-            continue;
-        }
-        for (uint32_t pos = 0; pos < var.len && var.pos + pos < cur_end_position + (uint32_t)m.end_pos_shift; ++pos)
-            if (is_gc(r.base(var, pos))) ++m.gc_mod;
-        if (r.gc(var.pos)) --m.gc_mod;
-        if (0u == var.len) {
-            ++m.end_pos_shift;
-            ++m.unhandled_variant_id;
-        } else if (1u == var.len) {
-            ++m.unhandled_variant_id;
-        } else if (var.pos + var.len <= cur_end_position + (uint32_t)m.end_pos_shift) {
-            m.end_pos_shift -= (int32_t)(var.len - 1u);
-            ++m.unhandled_variant_id;
-        } else {
-            m.unhandled_bases_in_variant = var.pos + var.len - (cur_end_position + (uint32_t)m.end_pos_shift);
-            m.end_pos_shift -= (int32_t)(var.len - m.unhandled_bases_in_variant - 1u);
-        }
-    }
+RSQ_HD AlleleView allele_view(const DevSim &S, uint32_t seq, uint32_t allele) {
+    const uint32_t m = seq * S.num_alleles + allele, lo = S.allele_map_ptr[m], hi = S.allele_map_ptr[m + 1];
+    return AlleleView{S.allele_map + lo, hi - lo - 1u, var_view(S, seq), S.var_bases_gc};
 }
 
-RSQ_HD void sur_change(uint32_t (&s)[3], int32_t pos, uint32_t base) { sur_change_base(s, (uint32_t)(uint16_t)pos, base); }
-// :1459-1527
-RSQ_HD void handle_surrounding_variants_before_center(uint32_t (&sur)[3], uint32_t center_position, int32_t initial_pos_shift, int32_t center_var, uint32_t allele,
-                                                      const VarView &r, bool reverse) {
-    int32_t cur_var = center_var, pos_shift = initial_pos_shift;
-    while (0 <= --cur_var) {
-        const DevVariant &var = r.v[cur_var];
-        const int32_t sur_pos = reverse ? (int32_t)(center_position - var.pos + (uint32_t)pos_shift) : (int32_t)(var.pos - center_position + (uint32_t)pos_shift);
-        if (0 > sur_pos || (int32_t)kSurLength <= sur_pos) break;
-        if (!r.in_allele(var, allele)) continue;
-        if (0u == var.len) {
-            if (reverse) {
-                const int32_t new_base_pos = (int32_t)center_position + pos_shift - (int32_t)kSurLength;
-                sur_delete_shift_right(sur, (uint32_t)(uint16_t)sur_pos, 3u - r.at(0 > new_base_pos ? (uint32_t)((int32_t)r.L + new_base_pos) : (uint32_t)new_base_pos));
-                --pos_shift;
-            } else {
-                if ((uint32_t)++pos_shift > center_position) sur_delete_shift_left(sur, (uint32_t)(uint16_t)sur_pos, r.at(r.L + center_position - (uint32_t)pos_shift));
-                else sur_delete_shift_left(sur, (uint32_t)(uint16_t)sur_pos, r.at(center_position - (uint32_t)pos_shift));
-            }
-        } else {
-            sur_change(sur, sur_pos, reverse ? 3u - r.base(var, 0) : r.base(var, 0));
-            if (1u < var.len) {
-                if (reverse) {
-                    sur_insert_shift_right(sur, (uint32_t)(uint16_t)sur_pos, VarBasesRC{r.bases + var.off + 1u, var.len - 1u}, var.len - 1u);
-                    pos_shift += (int32_t)var.len - 1;
-                } else {
-                    sur_insert_shift_left(sur, (uint32_t)(uint16_t)sur_pos, VarBases{r.bases + var.off + 1u}, var.len - 1u);
-                    pos_shift -= (int32_t)var.len - 1;
-                }
-            }
-        }
-    }
-}
-// :1529-1589
-RSQ_HD void handle_surrounding_variants_after_center(uint32_t (&sur)[3], uint32_t center_position, int32_t initial_pos_shift, int32_t center_var, uint32_t allele,
-                                                     const VarView &r, bool reverse) {
-    int32_t pos_shift = initial_pos_shift;
-    for (int32_t cur_var = center_var; (uint32_t)cur_var < r.n; ++cur_var) {
-        const DevVariant &var = r.v[cur_var];
-        const int32_t sur_pos = reverse ? (int32_t)(center_position - var.pos + (uint32_t)pos_shift) : (int32_t)(var.pos - center_position + (uint32_t)pos_shift);
-        if (0 > sur_pos || (int32_t)kSurLength <= sur_pos) break;
-        if (!r.in_allele(var, allele)) continue;
-        if (0u == var.len) {
-            if (reverse) {
-                ++pos_shift;
-                sur_delete_shift_left(sur, (uint32_t)(uint16_t)sur_pos, 3u - r.at((center_position + (uint32_t)pos_shift) % r.L));
-            } else {
-                sur_delete_shift_right(sur, (uint32_t)(uint16_t)sur_pos, r.at((center_position - (uint32_t)pos_shift + kSurLength) % r.L));
-                --pos_shift;
-            }
-        } else {
-            sur_change(sur, sur_pos, reverse ? 3u - r.base(var, 0) : r.base(var, 0));
-            if (1u < var.len) {
-                if (reverse) {
-                    if (sur_pos) {
-                        sur_insert_shift_left(sur, (uint32_t)(uint16_t)(sur_pos - 1), VarBasesRC{r.bases + var.off + 1u, var.len - 1u}, var.len - 1u);
-                        pos_shift -= (int32_t)var.len - 1;
-                    }
-                } else if (sur_pos + 1 < (int32_t)kSurLength) {
-                    sur_insert_shift_right(sur, (uint32_t)(uint16_t)(sur_pos + 1), VarBases{r.bases + var.off + 1u}, var.len - 1u);
-                    pos_shift += (int32_t)var.len - 1;
-                }
-            }
-        }
-    }
-}
-// :1591-1636; sur starts as the reference's forward surrounding of the position
-RSQ_HD void variant_mod_start_surrounding(uint32_t (&sur)[3], const VarStart &st, uint32_t allele, const VarView &r, uint32_t cur_start_position) {
-    if (!r.n) return;
-    int32_t pos_shift = (int32_t)kSurStart;
-    int32_t cur_var = st.first_variant_id;
-    if (st.start_variant_pos) {
-        const DevVariant &var = r.v[cur_var];
-        sur_change(sur, pos_shift, r.base(var, 0));
-        const uint32_t upto = st.start_variant_pos + 1u < var.len ? st.start_variant_pos + 1u : var.len;      // infix(var_seq_, 1, start_variant_pos_ + 1)
-        sur_insert_shift_left(sur, (uint32_t)pos_shift, VarBases{r.bases + var.off + 1u}, upto - 1u);
-        pos_shift -= (int32_t)st.start_variant_pos;
-    }
-    handle_surrounding_variants_before_center(sur, cur_start_position, pos_shift, cur_var, allele, r, false);
-    pos_shift = (int32_t)kSurStart;
-    cur_var = st.first_variant_id;
-    if (st.start_variant_pos) {
-        const DevVariant &var = r.v[cur_var];
-        if (var.len > st.start_variant_pos + 1u) {
-            if (pos_shift + 1 < (int32_t)kSurLength) {
-                sur_insert_shift_right(sur, (uint32_t)(pos_shift + 1), VarBases{r.bases + var.off + st.start_variant_pos + 1u}, var.len - st.start_variant_pos - 1u);
-                pos_shift += (int32_t)var.len - (int32_t)st.start_variant_pos - 1;
-            }
-        }
-        ++cur_var;
-    }
-    handle_surrounding_variants_after_center(sur, cur_start_position, pos_shift, cur_var, allele, r, false);
-}
-// :1638-1698 for one allele (the skipped-allele test is the caller's); surrounding_start: the reference's forward surrounding of the position
-RSQ_HD void prepare_bias_mod_for_current_start_pos(AlleleMod &m, const VarStart &st, uint32_t allele, const VarView &r, uint32_t cur_start_position,
-                                                   uint32_t first_fragment_length, const uint32_t (&surrounding_start)[3]) {
-    const uint32_t cur_end_position = cur_start_position + first_fragment_length - 1u;
-    m.unhandled_variant_id = st.first_variant_id;
-    m.unhandled_bases_in_variant = 0;
-    m.gc_mod = 0;
-    m.end_pos_shift = 0;
-    if (st.start_variant_pos) {
-        const DevVariant &var = r.v[st.first_variant_id];
-        for (uint32_t pos = st.start_variant_pos; pos < var.len && var.pos + pos - st.start_variant_pos < cur_end_position; ++pos)
-            if (is_gc(r.base(var, pos))) ++m.gc_mod;
-        if (r.gc(cur_start_position)) --m.gc_mod;
-        const uint32_t a = cur_end_position - cur_start_position, b = var.len - st.start_variant_pos;
-        m.end_pos_shift = 1 - (int32_t)(a < b ? a : b);
-        ++m.unhandled_variant_id;
-    }
-    for (int k = 0; k < 3; ++k) m.surrounding_start[k] = surrounding_start[k];
-    variant_mod_start_surrounding(m.surrounding_start, st, allele, r, cur_start_position);
-    handle_gc_mod_and_end_pos_shift_for_new_variants(m, allele, r, cur_end_position);
-    m.last_end_position = cur_end_position;
-}
-// :1700-1752; sur starts as the reference's reverse surrounding of last_position
-RSQ_HD void variant_mod_end_surrounding(uint32_t (&sur)[3], const AlleleMod &m, const VarStart &st, uint32_t allele, const VarView &r, uint32_t last_position) {
-    if (!r.n) return;
-    int32_t pos_shift = (int32_t)kSurStart;
-    int32_t cur_var = m.unhandled_variant_id;
-    if (m.unhandled_bases_in_variant) {
-        const DevVariant &var = r.v[cur_var];
-        sur_insert_shift_left(sur, (uint32_t)pos_shift, VarBasesRC{r.bases + var.off + (var.len - m.unhandled_bases_in_variant), m.unhandled_bases_in_variant},
-                              m.unhandled_bases_in_variant);
-        pos_shift -= (int32_t)m.unhandled_bases_in_variant;
-        ++cur_var;
-    } else if (st.start_variant_pos && r.v[st.first_variant_id].pos == last_position &&
-               r.v[st.first_variant_id].len > st.start_variant_pos - (uint32_t)m.end_pos_shift + 1u) {
-        if (pos_shift) {
-            const DevVariant &var = r.v[st.first_variant_id];
-            const uint32_t from = st.start_variant_pos - (uint32_t)m.end_pos_shift + 1u;
-            sur_insert_shift_left(sur, (uint32_t)(pos_shift - 1), VarBasesRC{r.bases + var.off + from, var.len - from}, var.len - from);
-            pos_shift -= (int32_t)(var.len - from);
-        }
-    }
-    handle_surrounding_variants_after_center(sur, last_position, pos_shift, cur_var, allele, r, true);
-    pos_shift = (int32_t)kSurStart;
-    cur_var = m.unhandled_variant_id;
-    if (m.unhandled_bases_in_variant) {
-        if (pos_shift + 1 < (int32_t)kSurLength) {
-            const DevVariant &var = r.v[cur_var];
-            sur_change(sur, pos_shift + 1, 3u - r.base(var, 0));
-            const uint32_t n_part = var.len - m.unhandled_bases_in_variant - 1u;              // infix(var_seq_, 1, length - unhandled)
-            sur_insert_shift_right(sur, (uint32_t)(pos_shift + 1), VarBasesRC{r.bases + var.off + 1u, n_part}, n_part);
-            pos_shift += (int32_t)var.len - (int32_t)m.unhandled_bases_in_variant - 1;
-        }
-    } else if (st.start_variant_pos && r.v[st.first_variant_id].pos == last_position) {
-        cur_var = st.first_variant_id;
-        const DevVariant &var = r.v[cur_var];
-        sur_change(sur, pos_shift, 3u - r.base(var, 0));
-        uint32_t to = st.start_variant_pos - (uint32_t)m.end_pos_shift + 1u;                   // infix(var_seq_, 1, start_variant_pos_ - end_pos_shift_ + 1)
-        if (to > var.len) to = var.len;
-        sur_insert_shift_right(sur, (uint32_t)pos_shift, VarBasesRC{r.bases + var.off + 1u, to - 1u}, to - 1u);
-        pos_shift += (int32_t)st.start_variant_pos - m.end_pos_shift;
-    }
-    handle_surrounding_variants_before_center(sur, last_position, pos_shift, cur_var, allele, r, true);
-}
-// :1754-1812
-RSQ_HD void update_bias_mod_for_current_fragment_length(AlleleMod &m, const VarStart &st, uint32_t allele, const VarView &r, uint32_t cur_start_position,
-                                                        uint32_t cur_end_position, uint32_t last_end_position) {
-    if (!(cur_end_position > m.last_end_position)) return;
-    bool need_new_variants = false;
-    if (st.start_variant_pos && last_end_position + 1u - cur_start_position <= r.v[st.first_variant_id].len - st.start_variant_pos) {
-        const DevVariant &var = r.v[st.first_variant_id];
-        uint32_t stop_pos = st.start_variant_pos + cur_end_position - cur_start_position;
-        if (stop_pos > var.len) {
-            stop_pos = var.len;
-            need_new_variants = true;
-        }
-        const uint32_t start_pos = st.start_variant_pos + last_end_position + 1u - cur_start_position - 1u;
-        m.end_pos_shift -= (int32_t)(stop_pos - start_pos);
-        for (uint32_t pos = start_pos; pos < stop_pos; ++pos)
-            if (is_gc(r.base(var, pos))) ++m.gc_mod;
-    } else if (m.unhandled_bases_in_variant) {
-        const DevVariant &var = r.v[m.unhandled_variant_id];
-        const uint32_t start_pos = var.len - m.unhandled_bases_in_variant;
-        uint32_t stop_pos = start_pos + cur_end_position - last_end_position;
-        if (stop_pos > var.len) {
-            stop_pos = var.len;
-            need_new_variants = true;
-        }
-        m.end_pos_shift -= (int32_t)(stop_pos - start_pos);
-        m.unhandled_bases_in_variant -= stop_pos - start_pos;
-        for (uint32_t pos = start_pos; pos < stop_pos; ++pos)
-            if (is_gc(r.base(var, pos))) ++m.gc_mod;
-        if (0u == m.unhandled_bases_in_variant) ++m.unhandled_variant_id;
-    } else need_new_variants = true;
-    if (need_new_variants) handle_gc_mod_and_end_pos_shift_for_new_variants(m, allele, r, cur_end_position);
-}
-// :1814-1827
-RSQ_HD void prepare_end_surroundings_for_current_fragment_length(AlleleMod &m, const VarStart &st, uint32_t allele, const VarView &r, uint32_t cur_end_position) {
-    const uint32_t corrected_pos = cur_end_position + (uint32_t)m.end_pos_shift;
-    if (corrected_pos < r.L) {
-        surrounding_reverse(r.words, r.word_off, r.L, corrected_pos, m.surrounding_end);
-        variant_mod_end_surrounding(m.surrounding_end, m, st, allele, r, corrected_pos);
-    }
-}
-// :1829-1851
-RSQ_HD void prepare_bias_mod_for_current_fragment_length(AlleleMod &m, const VarStart &st, uint32_t allele, const VarView &r, uint32_t cur_start_position,
-                                                         uint32_t fragment_length) {
-    const uint32_t cur_end_position = cur_start_position + fragment_length - 1u;
-    if (!(m.last_end_position <= cur_end_position)) return;
-    update_bias_mod_for_current_fragment_length(m, st, allele, r, cur_start_position, cur_end_position, m.last_end_position);
-    if (st.start_variant_pos && fragment_length <= r.v[st.first_variant_id].len - st.start_variant_pos) {
-        update_bias_mod_for_current_fragment_length(m, st, allele, r, cur_start_position, cur_end_position + 1u, cur_end_position);
-        prepare_end_surroundings_for_current_fragment_length(m, st, allele, r, cur_end_position);
-    } else {
-        prepare_end_surroundings_for_current_fragment_length(m, st, allele, r, cur_end_position);
-        update_bias_mod_for_current_fragment_length(m, st, allele, r, cur_start_position, cur_end_position + 1u, cur_end_position);
-    }
-    m.last_end_position = cur_end_position + 1u;
-}
-// Simulator.h:73-89 EndVariant
-RSQ_HD VarStart end_variant(const AlleleMod &m, const VarStart &st, const VarView &r, uint32_t cur_end_position) {
-    if (m.unhandled_bases_in_variant) return VarStart{m.unhandled_variant_id, r.v[m.unhandled_variant_id].len - m.unhandled_bases_in_variant};
-    if (st.start_variant_pos && r.v[st.first_variant_id].pos == cur_end_position - (uint32_t)m.end_pos_shift - 1u)
-        return VarStart{st.first_variant_id, st.start_variant_pos - (uint32_t)m.end_pos_shift + 1u};
-    int32_t first_rev = m.unhandled_variant_id;
-    if ((uint32_t)first_rev == r.n) --first_rev;
-    while (0 <= first_rev && r.v[first_rev].pos >= cur_end_position) --first_rev;
-    return VarStart{first_rev, 0u};
-}
-
-// everything SimulateFromGivenBlock needs of one (start, pass, fragment length, allele): :2311-2330
-struct VarCellSite {
-    uint32_t cur_end_position;
-    uint32_t gc_percent;
-    VarStart end_var;
+// what sits at allele coordinate h (0 <= h <= allele length)
+struct AllelePoint {
+    uint32_t j;                         // entries that begin at or before h
+    uint32_t k;                         // inside: h is base k of entry j-1's bases
+    uint32_t ref;                       // the reference position behind it: the entry's position, or the plain base's own
+    bool inside;
 };
-RSQ_HD void evaluate_allele(const VarView &r, const VarStart &st, uint32_t allele, uint32_t cur_start_position, uint32_t first_fragment_length, uint32_t fragment_length,
-                            AlleleMod &m, VarCellSite &site) {
-    uint32_t sur_start[3];
-    surrounding_forward(r.words, r.word_off, r.L, cur_start_position, sur_start);
-    prepare_bias_mod_for_current_start_pos(m, st, allele, r, cur_start_position, first_fragment_length, sur_start);
-    prepare_bias_mod_for_current_fragment_length(m, st, allele, r, cur_start_position, fragment_length);
-    site.cur_end_position = cur_start_position + fragment_length + (uint32_t)m.end_pos_shift;
-    site.gc_percent = 0;
-    site.end_var = VarStart{0, 0};
-    if (site.cur_end_position < r.L) {
-        // GetGCPercent :1853-1868: the reference's count over [start, end) plus the allele's modification
-        const uint32_t gc_ref = cur_start_position < site.cur_end_position ? ref_gc_count_prefix(r.words, r.gc_prefix, r.word_off, cur_start_position, site.cur_end_position)
-                                                                           : 0u - ref_gc_count_prefix(r.words, r.gc_prefix, r.word_off, site.cur_end_position, cur_start_position);
-        site.gc_percent = percent_u32((uint32_t)((int32_t)gc_ref + m.gc_mod), fragment_length);
-        site.end_var = end_variant(m, st, r, site.cur_end_position);
+RSQ_HD AllelePoint allele_point(const AlleleView &a, int64_t h) {
+    const uint32_t j = a.entries_upto(h);
+    if (j) {
+        const int64_t k = h - a.begin_of(j - 1u);
+        if (k < (int64_t)a.var(j - 1u).len) return AllelePoint{j, (uint32_t)k, a.e[j - 1u].pos, true};
     }
+    return AllelePoint{j, 0u, (uint32_t)(h - a.e[j].shift), false};
+}
+// G/C among the allele's bases [0, h)
+RSQ_HD uint32_t allele_gc_before(const AlleleView &a, const AllelePoint &p) {
+    if (p.inside) {
+        const AlleleVar &en = a.e[p.j - 1u];
+        const uint32_t off = a.r.v[en.vid].off;
+        return (uint32_t)((int32_t)a.ref_gc_before(en.pos) + en.gc) + a.bases_gc[off + p.k] - a.bases_gc[off];
+    }
+    return (uint32_t)((int32_t)a.ref_gc_before(p.ref) + a.e[p.j].gc);
+}
+
+// 30 consecutive allele bases from coordinate h0, first base in the lowest bits.  Coordinates in front of the allele and behind it
+// continue in the REFERENCE around the sequence's ends, without variants: the reference's surroundings wrap around
+// (SurroundingBase.hpp:64-81) and its variant edits stop at the ends (HandleSurroundingVariantsBeforeCenter / AfterCenter, :1459-1589).
+RSQ_HD uint64_t allele_window(const AlleleView &a, int64_t h0) {
+    constexpr uint32_t kN = kSurBlocks * kSurRange;
+    uint64_t x = 0;
+    uint32_t got = 0;
+    int64_t h = h0;
+    const uint32_t L = a.r.L;
+    for (; got < kN && h < 0; ++got, ++h) x |= (uint64_t)a.r.at((uint32_t)((int64_t)L + h)) << (2u * got);
+    if (got < kN && h < a.length()) {
+        const AllelePoint p = allele_point(a, h);
+        uint32_t j = p.j, q = p.ref;                                      // next entry, next reference position
+        if (p.inside) {
+            const DevVariant &var = a.var(j - 1u);
+            for (uint32_t k = p.k; k < var.len && got < kN; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
+            ++q;
+        }
+        while (got < kN && q < L) {
+            const uint32_t stop = a.e[j].pos;                             // the sentinel stops at L
+            uint32_t run = stop - q;
+            if (run > kN - got) run = kN - got;
+            if (run) {
+                x |= (ref_bits60(a.r.words, a.r.word_off, q) & ((1ull << (2u * run)) - 1ull)) << (2u * got);
+                got += run;
+                q += run;
+            }
+            if (got == kN || q == L) break;
+            const DevVariant &var = a.var(j);                             // the entry at q
+            for (uint32_t k = 0; k < var.len && got < kN; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
+            ++j;
+            ++q;
+        }
+    }
+    for (uint32_t q = 0; got < kN; ++got) {
+        x |= (uint64_t)a.r.at(q) << (2u * got);
+        if (++q == L) q = 0;
+    }
+    return x;
+}
+// the allele's forward surrounding of coordinate h (as surrounding_forward does for the reference) and its reverse surrounding
+RSQ_HD void allele_surrounding_forward(const AlleleView &a, int64_t h, uint32_t (&sur)[3]) {
+    const uint64_t x = allele_window(a, h - (int64_t)kSurStart);
+    for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = reverse_ten_bases((uint32_t)(x >> (20u * b)) & 0xFFFFFu);
+}
+RSQ_HD void allele_surrounding_reverse(const AlleleView &a, int64_t h, uint32_t (&sur)[3]) {
+    const uint64_t x = allele_window(a, h + (int64_t)kSurStart + 1 - (int64_t)(kSurBlocks * kSurRange));
+    for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = ~(uint32_t)(x >> (20u * (kSurBlocks - 1u - b))) & 0xFFFFFu;
+}
+
+// one cell (start position, pass, fragment length) of one allele
+struct AlleleCell {
+    int64_t hs, he;                     // the fragment in allele coordinates
+    uint32_t end;                       // cur_end_position = start + length + end_pos_shift_[allele] (:2316)
+    uint32_t gc_percent;                // GetGCPercent (:1853-1868)
+    VarStart end_var;                   // EndVariant (Simulator.h:73-89)
+    bool inside;                        // the end position lies inside the sequence (:2318)
+};
+RSQ_HD AlleleCell allele_cell(const AlleleView &a, const VarStart &st, uint32_t start, uint32_t length) {
+    AlleleCell c;
+    c.hs = a.to_allele(start) + st.start_variant_pos;
+    c.he = c.hs + length;
+    c.end = 0;
+    c.gc_percent = 0;
+    c.end_var = VarStart{0, 0u};
+    c.inside = false;
+    if (c.he > a.length()) return c;                                     // the allele ends before the fragment does
+    const AllelePoint last = allele_point(a, c.he - 1);
+    c.end = last.ref + 1u;                                               // the reference position behind the fragment's last base
+    if (!(c.end < a.r.L)) return c;
+    c.inside = true;
+    const AllelePoint first = allele_point(a, c.hs), behind = allele_point(a, c.he);
+    c.gc_percent = percent_u32(allele_gc_before(a, behind) - allele_gc_before(a, first), length);
+    // EndVariant: a fragment that ends inside inserted bases hands the variant and the number of its bases it uses to the reverse
+    // read; otherwise the last variant in front of the end position.  The reference has a third case for a fragment that ends inside
+    // the inserted bases it started in (Simulator.h:78-80) whose test can only hold for a fragment of one base, so such a fragment
+    // gets the second answer there -- and here.
+    const bool started_in_it = st.start_variant_pos && last.inside && a.e[last.j - 1u].vid == (uint32_t)st.first_variant_id;
+    if (last.inside && last.k + 1u < a.var(last.j - 1u).len && !started_in_it) c.end_var = VarStart{(int32_t)a.e[last.j - 1u].vid, last.k + 1u};
+    else c.end_var = VarStart{(int32_t)a.r.lower_bound(c.end) - 1, 0u};
+    return c;
 }
 
 // Reference::ReferenceSequence with variants (Reference.cpp:498-567): the template of one mate, 2 bits per base in read orientation

@@ -362,17 +362,6 @@ int emu_insert_variants_test(uint32_t n_calls, const uint32_t *positions, const 
         return 0;
     });
 }
-// the product's Surrounding edits (rsq_core.h): op 0 change, 1 delete/shift right, 2 delete/shift left, 3 insert/shift right, 4 insert/shift left
-void emu_sur_edit(uint32_t *sur, int op, uint32_t pos, const uint8_t *bases, uint32_t n) {
-    uint32_t (&s)[3] = *reinterpret_cast<uint32_t (*)[3]>(sur);
-    switch (op) {
-        case 0: sur_change_base(s, pos, bases[0]); break;
-        case 1: sur_delete_shift_right(s, pos, bases[0]); break;
-        case 2: sur_delete_shift_left(s, pos, bases[0]); break;
-        case 3: sur_insert_shift_right(s, pos, bases, n); break;
-        default: sur_insert_shift_left(s, pos, bases, n); break;
-    }
-}
 int emu_set_ref_bias_file(void *h, const char *path) {
     static_cast<Emu *>(h)->ref_bias_file = path;
     return 0;
@@ -429,11 +418,8 @@ static int64_t emu_sieve_general(Emu &s, uint32_t block_lo, uint32_t block_hi, F
             if (!sieve_cell_general(S, site, len, sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len), cell)) continue;
             for (uint32_t e = 0; e < cell.n; ++e) {
                 const uint32_t allele = cell.id[e] >> 1;
-                const VarView r = var_view(S, site.seq);             // what k_sieve_emit<2> derives again
-                AlleleMod m;
-                VarCellSite vs;
-                evaluate_allele(r, site.st, allele, site.start, S.insert_from, len, m, vs);
-                const FragmentVar fv{vs.cur_end_position, site.sub, site.st.first_variant_id, site.st.start_variant_pos, vs.end_var.first_variant_id, vs.end_var.start_variant_pos};
+                const AlleleCell ac = allele_cell(allele_view(S, site.seq, allele), site.st, site.start, len);      // what k_sieve_emit<2> derives again
+                const FragmentVar fv{ac.end, site.sub, site.st.first_variant_id, site.st.start_variant_pos, ac.end_var.first_variant_id, ac.end_var.start_variant_pos};
                 for (uint32_t dup = 0; dup < cell.cnt[e]; ++dup) {
                     if (n < cap) {
                         out[n] = make_fragment(site, len, dup, cell.id[e] & 1u, block_id, number + 1, allele);

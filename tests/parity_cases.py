@@ -475,8 +475,9 @@ def case_variants_substitutions(backend_cls, workdir):
         p.close()
 
 
-def _mixed_variant_set(seqs, rng, density, special=()):
-    """substitutions, insertions (1..6 bases, with or without a substituted first base) and deletions (1..4 bases), non-overlapping"""
+def _mixed_variant_set(seqs, rng, density, special=(), ends=0):
+    """substitutions, insertions (1..6 bases, with or without a substituted first base) and deletions (1..4 bases), non-overlapping;
+    ends > 0: every third position of the first and the last `ends` positions gets one as well (surroundings that wrap around)"""
     out = []
     for si, (_, codes) in enumerate(seqs):
         L = len(codes)
@@ -484,6 +485,8 @@ def _mixed_variant_set(seqs, rng, density, special=()):
             continue
         last = -1
         cand = set(int(x) for x in rng.choice(np.arange(0, L - 8), size=L // density, replace=False)) | {x for x in special if x < L - 8}
+        if ends:
+            cand |= {int(x) for x in list(range(0, ends)) + list(range(L - 8 - ends, L - 8)) if rng.random() < 0.34}
         for p0 in sorted(cand):
             if p0 <= last:
                 continue
@@ -508,15 +511,16 @@ def _mixed_variant_set(seqs, rng, density, special=()):
     return out
 
 
-def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels", lengths=(6200, 80, 3100), samples=1):
-    """-V with insertions and deletions: starts inside inserted bases as extra slots of the sieve, the reference's per-allele modifiers
-    derived per cell from scratch (rsq_variants.h) against the oracle's incremental bookkeeping, templates with the allele's variants,
-    the error walk through insertions and deletions, end positions shifted by the allele's length changes in the read ids"""
+def case_variants_indels(backend_cls, workdir, density=18, seed=31, tag="indels", lengths=(6200, 80, 3100), samples=1, ends=0):
+    """-V with insertions and deletions: starts inside inserted bases as extra slots of the sieve, every cell read off the allele's
+    coordinate map (rsq_variants.h) against the oracle's incremental restatement of the reference's bookkeeping, templates with the
+    allele's variants, the error walk through insertions and deletions, end positions shifted by the allele's length changes in the
+    read ids.  ends > 0: variants crowd the first and the last positions of every sequence (surroundings that wrap around the ends)"""
     lengths = list(lengths)
     rng = np.random.default_rng(seed)
     seqs = make_inputs(workdir, tag, synth.TINY, lengths)[2]
     special = [0, 3, 9, 10, 11, 20, 29, 30, 990, 995, 998, 999, 1000, 1001, 1990, 1999, 2000, 2995, 2999, 3000]
-    vs = _mixed_variant_set(seqs, rng, density, special)
+    vs = _mixed_variant_set(seqs, rng, density, special, ends=ends)
     if samples > 1:
         vs = [(si, p0, rl, alt, "\t".join(["0|1", "1|0", "1|1", "0|0"][int(rng.integers(0, 4))] for _ in range(samples - 1)) + "\t" + gt) for si, p0, rl, alt, gt in vs]
     vcf = workdir / f"{tag}.vcf"

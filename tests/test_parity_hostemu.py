@@ -153,6 +153,12 @@ def test_variants_insertions_and_deletions_four_alleles(workdir):
     P.case_variants_indels(EmuBackend, workdir, density=30, seed=47, tag="indels4", lengths=(4300, 2600), samples=2)
 
 
+def test_variants_crowding_the_sequence_ends(workdir):
+    """start and end surroundings that wrap around a sequence end while variants sit in them: the wrapped part is the plain reference"""
+    P.case_variants_indels(EmuBackend, workdir, density=30, seed=71, tag="ends71", lengths=(3300, 2100), ends=45)
+    P.case_variants_indels(EmuBackend, workdir, density=30, seed=74, tag="ends74", lengths=(3300, 2100), ends=45)
+
+
 def test_variants_complex(workdir):
     P.case_variants_complex(EmuBackend, workdir)
 

@@ -34,10 +34,11 @@ with tempfile.TemporaryDirectory() as d:
             lengths[0] = 3456
         density = int(rng.choice([6, 12, 25, 60]))
         samples = int(rng.choice([1, 1, 2, 3]))
-        kind = int(rng.integers(0, 3))
+        kind = int(rng.integers(0, 4))
         tag = f"st{t}"
         seqs = P.make_inputs(wd, tag, CFG, lengths, ref_seed=500 + t)[2]
-        maker = (P._mixed_variant_set, P._complex_variant_set, lambda s, r, dd: P._substitution_set(s, r, dd, [0, 1, 999, 1000]))[kind]
+        maker = (P._mixed_variant_set, P._complex_variant_set, lambda s, r, dd: P._substitution_set(s, r, dd, [0, 1, 999, 1000]),
+                 lambda s, r, dd: P._mixed_variant_set(s, r, dd, ends=45))[kind]
         vs = maker(seqs, rng, max(density, 25) if kind == 1 else density)
         if samples > 1:
             vs = [(si, p0, rl, alt, "\t".join(["0|1", "1|0", "1|1", "0|0"][int(rng.integers(0, 4))] for _ in range(samples - 1)) + "\t" + gt) for si, p0, rl, alt, gt in vs
