@@ -278,6 +278,13 @@ void orc_sim_free(orc_sim *s);
 uint8_t orc_compress_sys_error_rate(uint8_t percent);              /* Simulator.cpp:2569-2574 */
 uint8_t orc_expand_sys_error_rate(uint8_t stored);                 /* Simulator.h:329-332 */
 /* replace the pre-pass results by externally supplied ones (stage-wise parity tests) */
+/* the sieve's zero-threshold test drawn as gaps between passing lengths (oracle_sim.c): table of one coverage group, passing lengths of one start */
+typedef struct {
+    uint32_t len;
+    double probability_chosen;
+} orc_gap_hit;
+void orc_gap_table(const orc_sim *s, uint32_t group, double *q /*[insert_to]*/, uint32_t *seg_end /*[insert_to]*/);
+uint32_t orc_gap_hits(const orc_sim *s, const double *q, const uint32_t *seg_end, const double *thr, uint32_t start, uint32_t c1, orc_gap_hit *out /*[insert_to]*/);
 void orc_sim_set_normalization(orc_sim *s, double bias_normalization, const double *thresholds /*[n_groups][insert_to][2]*/);
 
 /* Simulator.cpp:61-114 */

@@ -587,18 +587,71 @@ void orc_sim_free(orc_sim *s) {
 
 /* ----------------------------------------------------------------------- sieve */
 /* Simulator.cpp:2249-2357 for one allele, no variants: the duplicates of every (start, length, strand) site. */
+/* The zero-threshold test of SimulateFromGivenBlock without one uniform per cell (hard part 3).  The reference
+   draws probability_chosen ~ U[0,1) for every (start, fragment length) and goes on iff it is >= NonZeroThreshold (Simulator.cpp:2304-2306,
+   Simulator.h:415-420); the cells of a start position are independent, a cell passes with probability 1 - thr1[len], and given that it
+   passes probability_chosen ~ U[thr1[len], 1).  The same process drawn directly: with q[len] = product of thr1 over the lengths up to
+   len (the probability that none of them passes), the first passing length behind cur-1 is the first len with q[len] <= u * q[cur-1]
+   for one uniform u, and its probability_chosen = thr1 + v * (1 - thr1) for a second one: 1 + passes draws per start position
+   instead of one per cell.  The running product restarts (a new segment, a fresh draw) where it falls below 2^-500, so a threshold of
+   exactly zero -- a length that always passes -- ends its segment.  Draw k of a start position: Philox block (start, c1, k, 1<<28),
+   u = u53(w0, w1), v = u53(w2, w3) (DESIGN.md "Random streams"). */
+void orc_gap_table(const orc_sim *s, uint32_t group, double *q, uint32_t *seg_end) {
+    const uint32_t to = s->insert_to;
+    const uint32_t from = (uint32_t)(s->p->insert_lengths.from > 1 ? s->p->insert_lengths.from : 1);
+    const double *thr = &s->thresholds[(size_t)group * to * 2];
+    uint32_t seg_begin = from;
+    double run = 1.0;
+    for (uint32_t len = 0; len < to; ++len) {
+        q[len] = 1.0;
+        seg_end[len] = from;                                  /* lengths in front of the first one: unused */
+    }
+    for (uint32_t len = from; len < to; ++len) {
+        run *= thr[2 * len + 1];
+        q[len] = run;
+        if (run < 0x1p-500 || len + 1 == to) {
+            for (uint32_t l = seg_begin; l <= len; ++l) seg_end[l] = len + 1;
+            seg_begin = len + 1;
+            run = 1.0;
+        }
+    }
+}
+uint32_t orc_gap_hits(const orc_sim *s, const double *q, const uint32_t *seg_end, const double *thr, uint32_t start, uint32_t c1, orc_gap_hit *out) {
+    const uint32_t to = s->insert_to;
+    const uint32_t from = (uint32_t)(s->p->insert_lengths.from > 1 ? s->p->insert_lengths.from : 1);
+    uint32_t cur = from, k = 0, n = 0;
+    while (cur < to) {
+        const orc_philox_out w = orc_philox4x32_10(s->seed, start, c1, k++, (uint32_t)ORC_DOM_SIEVE << 28);
+        const uint32_t e = seg_end[cur];
+        const double base = (cur == from || seg_end[cur - 1] == cur) ? 1.0 : q[cur - 1];
+        const double target = orc_u53(w.w[0], w.w[1]) * base;
+        uint32_t len = cur;
+        while (len < e && !(q[len] <= target)) ++len;         /* the first length of the segment that the product has reached the target at */
+        if (len < e) {
+            out[n].len = len;
+            out[n].probability_chosen = thr[2 * len + 1] + orc_u53(w.w[2], w.w[3]) * (1 - thr[2 * len + 1]);
+            ++n;
+            cur = len + 1;
+        } else cur = e;
+    }
+    return n;
+}
+
 uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out) {
     const orc_profile *p = s->p;
     const orc_reference *r = s->r;
     size_t cap = 1024, n = 0;
     orc_fragment *f = malloc(cap * sizeof *f);
     uint32_t to = s->insert_to;
-    uint32_t frag_len_start = (uint32_t)(p->insert_lengths.from > 1 ? p->insert_lengths.from : 1);     /* :2300 */
+    double *gap_q = malloc(sizeof(double) * to);
+    uint32_t *gap_seg_end = malloc(sizeof(uint32_t) * to);
+    orc_gap_hit *passing = malloc(sizeof(orc_gap_hit) * to);
     for (uint32_t seq = 0; seq < r->n_seqs; ++seq) {
         if (!s->n_blocks[seq]) continue;
         const uint8_t *codes = r->codes[seq];
         uint32_t L = r->len[seq];
         const double *thr = &s->thresholds[(size_t)s->coverage_groups[seq] * to * 2];
+        orc_gap_table(s, s->coverage_groups[seq], gap_q, gap_seg_end);
         for (uint32_t b = 0; b < s->n_blocks[seq]; ++b) {
             uint32_t block_id = s->first_block[seq] + b;
             if (block_id < block_lo || block_id >= block_hi) continue;
@@ -608,11 +661,10 @@ uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi
             for (uint32_t start = block_start; start < block_start + BLOCK_SIZE && start < L; ++start) {
                 orc_surrounding_update_forward(codes, L, start, sur_start);
                 uint32_t last_gc = 0, last_gc_end = start;                                                  /* :1696-1697 */
-                for (uint32_t len = frag_len_start; len < to; ++len) {
-                    /* one Philox block serves the four cells (start, 4q .. 4q+3), one 32-bit uniform each: DESIGN.md "Random streams" */
-                    orc_philox_out w = orc_philox4x32_10(s->seed, start, seq, len >> 2, (uint32_t)ORC_DOM_SIEVE << 28);
-                    double probability_chosen = orc_u32(w.w[len & 3u]);
-                    if (!(probability_chosen >= thr[2 * len + 1])) continue;                               /* Simulator.h:418-420 */
+                const uint32_t n_passing = orc_gap_hits(s, gap_q, gap_seg_end, thr, start, seq, passing);   /* the lengths whose cell passes :2304-2306 */
+                for (uint32_t h = 0; h < n_passing; ++h) {
+                    const uint32_t len = passing[h].len;
+                    const double probability_chosen = passing[h].probability_chosen;
                     uint16_t non_zero_strands = orc_binomial(2, 1 - thr[2 * len], probability_chosen);     /* :2307, FDS.cpp:3598 */
                     if (!non_zero_strands) continue;
                     orc_philox_out w2 = orc_philox4x32_10(s->seed, start, seq, len, ((uint32_t)ORC_DOM_SIEVE << 28) | 1u);
@@ -651,6 +703,9 @@ uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi
             }
         }
     }
+    free(gap_q);
+    free(gap_seg_end);
+    free(passing);
     *out = f;
     return n;
 }

@@ -749,6 +749,10 @@ uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t bloc
             ref.num_alleles = A;
             const uint32_t L = r->len[seq];
             const double *thr = &s->thresholds[(size_t)s->coverage_groups[seq] * to * 2];
+            std::vector<double> gap_q(to);
+            std::vector<uint32_t> gap_seg_end(to);
+            std::vector<orc_gap_hit> passing(to);
+            orc_gap_table(s, s->coverage_groups[seq], gap_q.data(), gap_seg_end.data());
             std::vector<Haplotype> haps;
             if (g_hap_check)
                 for (uint32_t a = 0; a < A; ++a) haps.push_back(make_haplotype(sv, a));
@@ -767,10 +771,10 @@ uint64_t orc_sieve_blocks_var(const orc_sim *s, uint32_t block_lo, uint32_t bloc
                         const uint32_t c1 = seq | (sub << 22);
                         prepare_bias_mod_for_current_start_pos(bm, ref, start, frag_len_start, sur_start);
                         const std::vector<uint32_t> possible = possible_alleles(ref, bm, start);
-                        for (uint32_t len = frag_len_start; len < to; ++len) {
-                            const orc_philox_out w = orc_philox4x32_10(s->seed, start, c1, len >> 2, (uint32_t)ORC_DOM_SIEVE << 28);
-                            const double probability_chosen = orc_u32(w.w[len & 3u]);
-                            if (!(probability_chosen >= thr[2 * len + 1])) continue;
+                        const uint32_t n_passing = orc_gap_hits(s, gap_q.data(), gap_seg_end.data(), thr, start, c1, passing.data());   // the cells that pass :2304-2306
+                        for (uint32_t hit = 0; hit < n_passing; ++hit) {
+                            const uint32_t len = passing[hit].len;
+                            const double probability_chosen = passing[hit].probability_chosen;
                             const uint16_t non_zero_strands = orc_binomial((uint16_t)(2 * possible.size()), 1 - thr[2 * len], probability_chosen);
                             if (!non_zero_strands) continue;
                             // ChooseAlleles (:1387-1397)

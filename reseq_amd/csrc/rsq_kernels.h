@@ -205,18 +205,47 @@ struct SieveSite {
     uint32_t seq, start, L;
     uint64_t word_off;
     const double *thr;                 // thresholds of the sequence's coverage group: [insert_to][2]
+    uint32_t group;                    // the coverage group
     uint32_t sur_start[3];
     bool have_start;
     uint32_t sub;                      // variants of any kind: pass at this start position and what the pass starts from
     VarStart st;
 };
 
-// Philox block shared by the four cells (start, 4q .. 4q+3): one 32-bit uniform each
 RSQ_HD uint32_t site_c1(const SieveSite &site) { return site.seq | (site.sub << 22); }
-RSQ_HD Words sieve_quad_words(const DevSim &S, const SieveSite &site, uint32_t q) { return philox(S.seed, site.start, site_c1(site), q, kDomSieve << 28); }
-RSQ_HD double sieve_cell_uniform(const Words &w, uint32_t len) {
-    const uint32_t k = len & 3u;
-    return u32_to_unit(k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3)));
+
+// Which cells of a start position pass the zero threshold (Simulator.cpp:2304-2306, Simulator.h:415-420).  The reference draws
+// probability_chosen ~ U[0,1) for every (start, fragment length) and goes on iff it is >= thr1[length]: the cells are independent, one
+// passes with probability 1 - thr1, and given that it passes probability_chosen ~ U[thr1, 1).  The same process drawn directly
+// (hard part 3): with q[len] = product of thr1 over the lengths up to len (DevSim::gap_q), the first passing length
+// behind cur-1 is the first one with q[len] <= u * q[cur-1] for one uniform u, found by bisection, and its probability_chosen is
+// thr1 + v * (1 - thr1) for a second one -- 1 + passes Philox blocks per start position instead of one per four cells.
+// Draw k of a start position: block (start, c1, k, 1<<28), u = u53(w0, w1), v = u53(w2, w3).  on_pass(length, probability_chosen).
+template <class F>
+RSQ_HD uint32_t sieve_gaps(const DevSim &S, const SieveSite &site, F &&on_pass) {
+    const double *q = S.gap_q + (size_t)site.group * S.insert_to;
+    const uint32_t *seg_end = S.gap_seg_end + (size_t)site.group * S.insert_to;
+    const uint32_t c1 = site_c1(site);
+    uint32_t cur = S.insert_from, k = 0, n = 0;
+    while (cur < S.insert_to) {
+        const Words w = philox(S.seed, site.start, c1, k++, kDomSieve << 28);
+        const uint32_t e = seg_end[cur];
+        const double base = (cur == S.insert_from || seg_end[cur - 1u] == cur) ? 1.0 : q[cur - 1u];      // a segment starts from 1
+        const double target = u53_to_unit(w.w0, w.w1) * base;
+        uint32_t lo = cur, hi = e;                                  // q does not increase inside a segment
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (q[mid] <= target) hi = mid;
+            else lo = mid + 1u;
+        }
+        if (lo < e) {
+            const double thr1 = site.thr[2u * lo + 1u];
+            on_pass(lo, thr1 + u53_to_unit(w.w2, w.w3) * (1 - thr1));
+            ++n;
+            cur = lo + 1u;
+        } else cur = e;                                             // nothing passes in this segment: the next one gets a fresh draw
+    }
+    return n;
 }
 
 RSQ_HD uint32_t sieve_cell(const DevSim &S, SieveSite &site, uint32_t len, double probability_chosen, uint32_t (&cnt)[2], uint32_t (&strand_of)[2]) {
@@ -397,11 +426,17 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
     return n_here;
 }
 
+// a cell that passed the zero threshold: (start position slot, fragment length) and its probability_chosen, in loop order
+struct SieveCand {
+    uint32_t slot, len;
+    double probability_chosen;
+};
 // a cell with fragments, recorded by the sieve pass and expanded into Fragment records after the scan (with variants: one record per
 // two chosen (allele, strand) slots of the cell)
 struct SieveHit {
     uint32_t slot;         // start position slot of the batch
-    uint32_t intra;        // pairs of the same start position that come before this record's
+    uint32_t cand;         // the cell: index in the batch's candidate list
+    uint32_t intra;        // pairs of the same cell that come before this record's
     uint16_t len, cnt0, cnt1;
     uint8_t strand0, strand1, allele0, allele1;
 };
@@ -424,7 +459,8 @@ RSQ_HD void init_site(const DevSim &S, uint32_t block_id, uint32_t offset_in_blo
     site.L = S.seq_len[site.seq];
     site.start = (block_id - S.first_block[site.seq]) * kBlockSize + offset_in_block;
     site.word_off = S.seq_word_off[site.seq];
-    site.thr = S.thresholds + (size_t)S.coverage_group[site.seq] * S.insert_to * 2u;
+    site.group = S.coverage_group[site.seq];
+    site.thr = S.thresholds + (size_t)site.group * S.insert_to * 2u;
     site.have_start = false;
     site.sub = 0;
     site.st = VarStart{0, 0};
@@ -488,24 +524,16 @@ RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t bloc
 }
 
 #if defined(__HIPCC__)
-// The sieve in two kernels.
-//   k_sieve_screen: one lane per (start position, 32 fragment lengths): eight Philox blocks, 32 comparisons against the zero
-//            threshold, one bitmap word.  About 0.2 % of the cells pass.  Few registers, full occupancy: the kernel is a
-//            chain of dependent 32-bit multiplies and needs many waves per SIMD to keep the multiplier busy.
-//   k_sieve_finish: a wave owns slots_per_wave consecutive start positions (enough for about 64 candidates), turns their bitmap rows into a candidate
-//            queue in LDS, in (position, length) order, and runs the expensive part (strand choice, GC percent, surroundings,
-//            negative binomial count) one lane per queued cell -- full lanes instead of the one or two that a fused loop
-//            would keep busy.
-// counts[slot] = pairs starting at the position.  Every cell with fragments is appended to `hits` together with the number
-// of pairs that precede it at the same start, so that k_sieve_emit can place its fragments in (length, chosen strand order,
-// duplicate) order -- the order of the reference's loops -- once the exclusive scan of counts is known.
-constexpr uint32_t kSieveSlotsMin = 32, kSieveSlotsMax = 1024;  // start positions per wave of k_sieve_finish, chosen from the pair density
-constexpr uint32_t kSieveWaves = 4;
-constexpr uint32_t kSieveQueue = 2048;                 // candidate capacity per wave = the most one pass over 64 bitmap words can add
-constexpr uint32_t kScreenBlock = 256;
-constexpr uint32_t kSieveLoads = 8;                   // bitmap words a lane of k_sieve_finish has in flight
-
-RSQ_HD uint32_t sieve_words_per_slot(uint32_t insert_to) { return (insert_to + 31u) >> 5; }
+// The sieve.
+//   k_sieve_gaps<VM, false>: one lane per start position slot counts the cells that pass the zero threshold (sieve_gaps);
+//   exclusive scan of the counts;
+//   k_sieve_gaps<VM, true>: the same walk again writes the batch's candidate list, (slot, length, probability_chosen) in loop order;
+//   k_sieve_finish: one lane per candidate -- full lanes -- runs the expensive part (strand / allele choice, G/C percent, surroundings,
+//            negative binomial counts), records the cells with fragments in `hits` and the pairs of every candidate in pairs_of;
+//   exclusive scan of pairs_of: the candidates are in the order of the reference's loops (block, start, pass, length), so the scan is
+//            the position of a cell's first Fragment; k_sieve_emit writes the records (chosen strand order, duplicate).  No atomic
+//            decides an order, hence deterministic read ids.
+constexpr uint32_t kSieveBlock = 256;
 
 // variants of any kind: what init_site_slot<2> finds, once per slot and batch.  One workgroup per block of 1000 start positions: the
 // searches over all blocks / all variants happen once per block, the per-slot ones only over the block's own few extra starts and variants.
@@ -552,208 +580,95 @@ __global__ void __launch_bounds__(256) k_slot_table(DevSim S, uint32_t block_lo,
     }
 }
 
-// The zero thresholds of one coverage group in LDS as 32-bit gates: a cell passes iff its 32-bit word is GREATER than the gate
-// (gate = ceil(thr1 * 2^32) - 1; 0xFFFFFFFF = never: thresholds above 1 - 2^-32 and the lengths outside [insert_from, insert_to)).
-// Four gates per 16-byte read; rows of 32 lengths are skewed by four entries because the lanes of a wave read lengths 32 apart.
-RSQ_HD uint32_t gate_lds_index(uint32_t len) { return len + 4u * (len >> 5); }
-RSQ_HD uint32_t gate_lds_bytes(uint32_t insert_to) { return (gate_lds_index(32u * sieve_words_per_slot(insert_to)) + 8u) * 4u; }
-
-template <int VM>
-__global__ void __launch_bounds__(kScreenBlock) k_sieve_screen(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t *bitmap,
-                                                               const SlotInfo *slots) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_gate[];
-    const uint64_t t0 = (uint64_t)blockIdx.x * kScreenBlock, t = t0 + threadIdx.x, n_tasks = (uint64_t)n_slots * words_per_slot;
-    // the block's positions lie in one sequence almost always: then its gates come from LDS
-    const uint32_t slot_first = (uint32_t)(t0 / words_per_slot), slot_last = (uint32_t)((t0 + kScreenBlock - 1 < n_tasks ? t0 + kScreenBlock - 1 : n_tasks - 1) / words_per_slot);
-    uint32_t seq_first, seq_last;
-    if constexpr (VM == 2) {                                       // slots are not 1000 per block here
-        SieveSite a, b;
-        init_site_slot<VM, false>(S, block_lo, block_hi, slot_first, a, nullptr, slots);
-        init_site_slot<VM, false>(S, block_lo, block_hi, slot_last, b, nullptr, slots);
-        seq_first = a.seq;
-        seq_last = b.seq;
-    } else {
-        seq_first = S.block_seq[block_lo + slot_first / kBlockSize];
-        seq_last = S.block_seq[block_lo + slot_last / kBlockSize];
-    }
-    const bool staged = seq_first == seq_last && !S.thr1_has_zero;  // block-uniform
-    if (staged) {
-        const uint64_t *thr = S.thr1_bits + (size_t)S.coverage_group[seq_first] * S.insert_to;
-        for (uint32_t len = threadIdx.x; len < 32u * words_per_slot; len += kScreenBlock)
-            s_gate[gate_lds_index(len)] = len >= S.insert_from && len < S.insert_to ? (uint32_t)(thr[len] - 1ull) : 0xFFFFFFFFu;      // thr1_bits in [1, 2^32]
-        __syncthreads();
-    }
-    if (t >= n_tasks) return;
-    const uint32_t slot = (uint32_t)(t / words_per_slot), wi = (uint32_t)(t % words_per_slot);
+template <int VM, bool FILL>
+__global__ void __launch_bounds__(kSieveBlock) k_sieve_gaps(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t *counts, const uint64_t *cand_off,
+                                                            SieveCand *cands, uint64_t cand_cap, const SlotInfo *slots) {
+    const uint32_t slot = blockIdx.x * kSieveBlock + threadIdx.x;
+    if (slot >= n_slots) return;
     SieveSite site;
     init_site_slot<VM, false>(S, block_lo, block_hi, slot, site, nullptr, slots);
-    uint32_t bits = 0;
-    if (site.start < site.L) {
-        if (staged) {
-#pragma unroll 2
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t len0 = 32u * wi + 4u * j;
-                if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
-                const Words w = sieve_quad_words(S, site, len0 >> 2);
-                const uint4 g = *reinterpret_cast<const uint4 *>(&s_gate[gate_lds_index(len0)]);
-                // Simulator.h:418-420 `probability_chosen >= threshold`, on the 32-bit words themselves (exact, see upload_normalization)
-                const uint32_t four = (w.w0 > g.x ? 1u : 0u) | (w.w1 > g.y ? 2u : 0u) | (w.w2 > g.z ? 4u : 0u) | (w.w3 > g.w ? 8u : 0u);
-                bits |= four << (4u * j);
-            }
-        } else {                                                    // a block across two sequences, or a threshold of exactly zero
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t len0 = 32u * wi + 4u * j;
-                if (len0 + 3u < S.insert_from || len0 >= S.insert_to) continue;
-                const Words w = sieve_quad_words(S, site, len0 >> 2);
-                const uint32_t word[4] = {w.w0, w.w1, w.w2, w.w3};
-                for (uint32_t e = 0; e < 4u; ++e) {
-                    const uint32_t len = len0 + e;
-                    if (len >= S.insert_from && len < S.insert_to && (uint64_t)word[e] >= S.thr1_bits[(size_t)S.coverage_group[site.seq] * S.insert_to + len])
-                        bits |= 1u << (4u * j + e);
-                }
-            }
-        }
+    if (!(site.start < site.L)) {                                   // the last block of a sequence is shorter
+        if constexpr (!FILL) counts[slot] = 0;
+        return;
     }
-    bitmap[t] = bits;
+    if constexpr (FILL) {
+        uint64_t at = cand_off[slot];
+        sieve_gaps(S, site, [&](uint32_t len, double probability_chosen) {
+            if (at < cand_cap) cands[at] = SieveCand{slot, len, probability_chosen};
+            ++at;
+        });
+    } else counts[slot] = sieve_gaps(S, site, [](uint32_t, double) {});
 }
 
 template <int VM, uint32_t CAP = kMaxDevAlleles>
-__global__ void __launch_bounds__(64 * kSieveWaves) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, uint32_t words_per_slot, uint32_t slots_per_wave,
-                                                                  const uint32_t *bitmap, uint32_t *counts, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count,
-                                                                  const SlotInfo *slots) {
-    __shared__ uint32_t s_queue[kSieveWaves][kSieveQueue];         // (slot_local << 16) | length
-    extern __shared__ uint32_t s_total[];                          // [kSieveWaves][slots_per_wave] pairs found so far per position
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t slot0 = (blockIdx.x * kSieveWaves + wave) * slots_per_wave;
-    if (slot0 >= n_slots) return;
-    uint32_t *queue = s_queue[wave], *totals = s_total + wave * slots_per_wave;
-    for (uint32_t k = lane; k < slots_per_wave; k += 64u) totals[k] = 0;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_queued = 0;
-
-    auto finish = [&]() {                                           // wave-uniform: all lanes call it together
-        for (uint32_t base = 0; base < n_queued; base += 64u) {
-            const bool active = base + lane < n_queued;
-            uint32_t key = 0xFFFFu, len = 0, n_here = 0, cnt[2] = {0, 0}, strand_of[2] = {0, 0};
-            VarCellT<VM ? CAP : 1u> cell;
-            cell.n = 0;
-            if (active) {
-                const uint32_t e = queue[base + lane];
-                key = e >> 16;
-                len = e & 0xFFFFu;
-                SieveSite site;
-                const uint32_t slot = slot0 + key;
-                init_site_slot<VM>(S, block_lo, block_hi, slot, site, nullptr, slots);
-                const double u = sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len);
-                if constexpr (VM == 2) n_here = sieve_cell_general(S, site, len, u, cell);
-                else if constexpr (VM == 1) n_here = sieve_cell_var(S, site, len, u, cell);
-                else n_here = sieve_cell(S, site, len, u, cnt, strand_of);
+__global__ void __launch_bounds__(kSieveBlock) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, const uint64_t *cand_off, const SieveCand *cands,
+                                                              uint64_t cand_cap, uint32_t *pairs_of, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count, const SlotInfo *slots) {
+    const uint64_t c = (uint64_t)blockIdx.x * kSieveBlock + threadIdx.x;
+    if (c >= cand_cap) return;
+    uint32_t n_here = 0;
+    if (c < cand_off[n_slots]) {
+        const SieveCand cand = cands[c];
+        SieveSite site;
+        init_site_slot<VM>(S, block_lo, block_hi, cand.slot, site, nullptr, slots);
+        if constexpr (VM != 0) {
+            VarCellT<CAP> cell;
+            if constexpr (VM == 2) n_here = sieve_cell_general(S, site, cand.len, cand.probability_chosen, cell);
+            else n_here = sieve_cell_var(S, site, cand.len, cand.probability_chosen, cell);
+            uint32_t intra = 0;
+            for (uint32_t e = 0; e < cell.n; e += 2u) {
+                const bool two = e + 1u < cell.n;
+                const uint32_t at = atomicAdd(hit_count, 1u);
+                SieveHit h;
+                h.slot = cand.slot;
+                h.cand = (uint32_t)c;
+                h.intra = intra;
+                h.len = (uint16_t)cand.len;
+                h.cnt0 = cell.cnt[e];
+                h.cnt1 = two ? cell.cnt[e + 1u] : (uint16_t)0;
+                h.strand0 = cell.id[e] & 1u;
+                h.allele0 = cell.id[e] >> 1;
+                h.strand1 = two ? cell.id[e + 1u] & 1u : 0;
+                h.allele1 = two ? cell.id[e + 1u] >> 1 : 0;
+                if (at < hit_cap) hits[at] = h;
+                intra += (uint32_t)h.cnt0 + h.cnt1;
             }
-            // exclusive prefix of n_here among the earlier queued cells of the same position (keys are non-decreasing)
-            uint32_t incl = n_here;
-            for (uint32_t d = 1; d < 64u; d <<= 1) {
-                const uint32_t v = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += v;
-            }
-            const uint32_t prev_key = __shfl_up(key, 1, 64);
-            const uint64_t heads = __ballot(lane == 0 || key != prev_key);
-            const uint32_t first = 63u - (uint32_t)__clzll(heads & (lt_mask | (1ull << lane)));
-            const uint32_t first_incl = __shfl(incl, first, 64), first_n = __shfl(n_here, first, 64);
-            const uint32_t before_in_batch = (incl - n_here) - (first_incl - first_n);
-            const uint32_t next_key = __shfl_down(key, 1, 64);
-            const uint32_t old_total = active ? totals[key] : 0u;
+        } else {
+            uint32_t cnt[2], strand_of[2];
+            n_here = sieve_cell(S, site, cand.len, cand.probability_chosen, cnt, strand_of);
             if (n_here) {
-                if constexpr (VM != 0) {
-                    uint32_t intra = old_total + before_in_batch;
-                    for (uint32_t e = 0; e < cell.n; e += 2u) {
-                        const bool two = e + 1u < cell.n;
-                        const uint32_t at = atomicAdd(hit_count, 1u);
-                        SieveHit h;
-                        h.slot = slot0 + key;
-                        h.intra = intra;
-                        h.len = (uint16_t)len;
-                        h.cnt0 = cell.cnt[e];
-                        h.cnt1 = two ? cell.cnt[e + 1u] : (uint16_t)0;
-                        h.strand0 = cell.id[e] & 1u;
-                        h.allele0 = cell.id[e] >> 1;
-                        h.strand1 = two ? cell.id[e + 1u] & 1u : 0;
-                        h.allele1 = two ? cell.id[e + 1u] >> 1 : 0;
-                        if (at < hit_cap) hits[at] = h;
-                        intra += (uint32_t)h.cnt0 + h.cnt1;
-                    }
-                } else {
-                    const uint32_t at = atomicAdd(hit_count, 1u);
-                    if (at < hit_cap) {
-                        SieveHit h;
-                        h.slot = slot0 + key;
-                        h.intra = old_total + before_in_batch;
-                        h.len = (uint16_t)len;
-                        h.cnt0 = (uint16_t)cnt[0];
-                        h.cnt1 = (uint16_t)cnt[1];
-                        h.strand0 = (uint8_t)strand_of[0];
-                        h.strand1 = (uint8_t)strand_of[1];
-                        h.allele0 = h.allele1 = 0;
-                        hits[at] = h;
-                    }
+                const uint32_t at = atomicAdd(hit_count, 1u);
+                if (at < hit_cap) {
+                    SieveHit h;
+                    h.slot = cand.slot;
+                    h.cand = (uint32_t)c;
+                    h.intra = 0;
+                    h.len = (uint16_t)cand.len;
+                    h.cnt0 = (uint16_t)cnt[0];
+                    h.cnt1 = (uint16_t)cnt[1];
+                    h.strand0 = (uint8_t)strand_of[0];
+                    h.strand1 = (uint8_t)strand_of[1];
+                    h.allele0 = h.allele1 = 0;
+                    hits[at] = h;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (active && (lane == 63u || next_key != key)) totals[key] = old_total + before_in_batch + n_here;      // last cell of the position in this batch
-            __builtin_amdgcn_wave_barrier();
-        }
-        n_queued = 0;
-    };
-
-    // the wave's bitmap rows are one contiguous run of words in (position, length) order; kSieveLoads independent loads per lane
-    // are in flight at a time (the kernel runs one wave per SIMD: a dependent load per pass would cost a round trip each)
-    const uint32_t my_slots = n_slots - slot0 < slots_per_wave ? n_slots - slot0 : slots_per_wave;
-    const uint32_t n_words = my_slots * words_per_slot;
-    const uint32_t *row = bitmap + (uint64_t)slot0 * words_per_slot;
-    for (uint32_t i0 = 0; i0 < n_words; i0 += 64u * kSieveLoads) {
-        uint32_t bits_of[kSieveLoads];
-#pragma unroll
-        for (uint32_t u = 0; u < kSieveLoads; ++u) {
-            const uint32_t idx = i0 + 64u * u + lane;
-            bits_of[u] = idx < n_words ? row[idx] : 0u;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kSieveLoads; ++u) {
-            uint32_t bits = bits_of[u];
-            if (!__any(bits != 0u)) continue;
-            const uint32_t idx = i0 + 64u * u + lane, k = idx / words_per_slot, wi = idx - k * words_per_slot;
-            const uint32_t mine = (uint32_t)__popc(bits);
-            uint32_t incl = mine;                                   // candidates of the lanes up to and including this one
-            for (uint32_t d = 1; d < 64u; d <<= 1) {
-                const uint32_t v = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += v;
-            }
-            const uint32_t added = __shfl(incl, 63, 64);
-            if (n_queued + added > kSieveQueue) finish();           // one pass adds at most 64*32 = kSieveQueue cells
-            uint32_t at = n_queued + incl - mine;
-            while (bits) {
-                const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
-                queue[at++] = (k << 16) | (32u * wi + b);
-                bits &= bits - 1u;
-            }
-            n_queued += added;
         }
     }
-    finish();
-    for (uint32_t k = lane; k < my_slots; k += 64u) counts[slot0 + k] = totals[k];
+    pairs_of[c] = n_here;
 }
 
-// one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at offsets[slot] + intra
+// one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at pair_off[cell] + intra; a read's number counts the pairs of
+// its block (CreateReadId, Simulator.cpp:596-632): the block's first cell is the first candidate of its first slot
 template <int VM>
-__global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, uint32_t block_hi, const SieveHit *hits, uint32_t n_hits, const uint64_t *offsets, Fragment *frags,
-                                                   FragmentVar *fvars, const SlotInfo *slots) {
+__global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, uint32_t block_hi, const SieveHit *hits, uint32_t n_hits, const uint64_t *cand_off,
+                                                   const uint64_t *pair_off, Fragment *frags, FragmentVar *fvars, const SlotInfo *slots) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const SieveHit h = hits[i];
     SieveSite site;
     uint32_t first_slot;
     const uint32_t block_id = init_site_slot<VM>(S, block_lo, block_hi, h.slot, site, &first_slot, slots);
-    const uint64_t base = offsets[h.slot];
-    const uint32_t number_base = (uint32_t)(base - offsets[first_slot]);
+    const uint64_t base = pair_off[h.cand];
+    const uint32_t number_base = (uint32_t)(base - pair_off[cand_off[first_slot]]);
     uint32_t k = h.intra;
     for (uint32_t e = 0; e < 2u; ++e) {
         const uint32_t cnt = e ? h.cnt1 : h.cnt0, strand = e ? h.strand1 : h.strand0, allele = e ? h.allele1 : h.allele0;

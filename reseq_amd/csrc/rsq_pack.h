@@ -51,6 +51,7 @@ struct SimState {
     std::vector<uint8_t> var_bases;
     std::vector<uint16_t> var_err_fwd, var_err_rev;  // filled by build_variant_sys_errors
     uint16_t *dev_var_err_fwd = nullptr, *dev_var_err_rev = nullptr;
+    double expected_passing = 0.0;                   // cells of one start position expected to pass the zero threshold (largest coverage group)
     std::vector<AlleleVar> allele_map;               // coordinate maps of the alleles (rsq_variants.h)
     std::vector<uint32_t> allele_map_ptr;            // [n_seqs * num_alleles + 1]
     std::vector<ExtraStart> extra;                   // starts inside inserted bases, per sequence in loop order
@@ -1094,16 +1095,32 @@ inline void finish_bias_normalization(SimState &s, const BiasPlan &plan, const s
 inline void upload_normalization(SimState &s, Uploader &up) {
     s.dev.thresholds = up.put(s.thresholds);
     s.dev.bias_normalization = s.bias_normalization;
-    // the screen of the sieve compares in the integer domain: u = w * 2^-32 >= thr1  <=>  w >= ceil(thr1 * 2^32), w integer; both
-    // scalings are exact in double precision.  A threshold above 1 - 2^-32 gives 2^32: no 32-bit word passes.
-    std::vector<uint64_t> bits(s.thresholds.size() / 2);
-    s.dev.thr1_has_zero = 0;
-    for (size_t i = 0; i < bits.size(); ++i) {
-        const double t = ceil(s.thresholds[2 * i + 1] * 4294967296.0);
-        bits[i] = t <= 0.0 ? 0ull : (t >= 4294967296.0 ? 4294967296ull : (uint64_t)t);
-        if (!bits[i]) s.dev.thr1_has_zero = 1;
+    // The sieve draws the gaps between the lengths whose cell passes the zero threshold instead of one uniform per cell (k_sieve_gaps,
+    // rsq_kernels.h): q[len] = product of thr1 over the lengths of len's segment up to len = the probability that none of them passes.
+    // A segment ends where the product falls below 2^-500 (a threshold of exactly zero ends its segment at once), so no product
+    // underflows; the next segment starts from 1 with a fresh draw.
+    const uint32_t to = s.dev.insert_to, from = s.dev.insert_from;
+    std::vector<double> q((size_t)s.n_groups * to, 1.0);
+    std::vector<uint32_t> seg_end((size_t)s.n_groups * to, from);
+    s.expected_passing = 0.0;
+    for (uint32_t g = 0; g < s.n_groups; ++g) {
+        uint32_t seg_begin = from;
+        double run = 1.0, expected = 0.0;
+        for (uint32_t len = from; len < to; ++len) {
+            const double thr1 = s.thresholds[2 * ((size_t)g * to + len) + 1];
+            expected += 1 - thr1;
+            run *= thr1;
+            q[(size_t)g * to + len] = run;
+            if (run < 0x1p-500 || len + 1 == to) {
+                for (uint32_t l = seg_begin; l <= len; ++l) seg_end[(size_t)g * to + l] = len + 1;
+                seg_begin = len + 1;
+                run = 1.0;
+            }
+        }
+        s.expected_passing = std::max(s.expected_passing, expected);
     }
-    s.dev.thr1_bits = up.put(bits);
+    s.dev.gap_q = up.put(q);
+    s.dev.gap_seg_end = up.put(seg_end);
 }
 
 }  // namespace rsq

@@ -115,7 +115,7 @@ struct rsq_sim : SimState {
     // workspace of the hot path (grow-only)
     DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
     DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, sieve_bitmap, templates, rec_flags, rec_index, rec_count;
+    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -409,50 +409,58 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         n_slots += ptr[1] - ptr[0];
     }
     if (!n_slots) return RSQ_OK;
-    if (n_slots * sieve_words_per_slot(s.dev.insert_to) >= (1ull << 32)) {       // slot and bitmap indices are 32 bits wide inside one call
-        g_last_error = "block range too large for one call: at most " + std::to_string(((1ull << 32) / sieve_words_per_slot(s.dev.insert_to)) / kBlockSize - 1) + " blocks";
+    if (n_slots >= (1ull << 32) - kSieveBlock) {                     // slot indices are 32 bits wide inside one call
+        g_last_error = "block range too large for one call: at most " + std::to_string(((1ull << 32) - kSieveBlock) / kBlockSize - 1) + " blocks";
         return RSQ_EINVAL;
     }
     s.counts.reserve(n_slots * 4 + 16);
     s.offsets.reserve((n_slots + 1) * 8);
     s.hit_count.reserve(8);
-    const uint32_t words_per_slot = sieve_words_per_slot(s.dev.insert_to);
-    s.sieve_bitmap.reserve(n_slots * words_per_slot * 4 + 16);
-    // capacity of the hit list: cells with fragments <= pairs; start from the expected share of this block range
-    uint64_t hit_cap = std::max<uint64_t>(s.hits.bytes() / sizeof(SieveHit),
-                                          (uint64_t)((double)s.total_pairs * (double)(block_hi - block_lo) / (double)s.total_blocks * 1.25) + 65536);
-    uint64_t total = 0;
+    // capacity of the candidate list: the cells expected to pass the zero threshold plus six standard deviations; of the hit list:
+    // cells with fragments <= candidates (with variants a cell has one record per two chosen (allele, strand) slots)
+    const double expected_cands = s.expected_passing * (double)n_slots;
+    uint64_t cand_cap = std::max<uint64_t>(s.cands.bytes() / sizeof(SieveCand), (uint64_t)(expected_cands + 6.0 * sqrt(expected_cands + 1.0)) + 65536);
+    uint64_t hit_cap = std::max<uint64_t>(s.hits.bytes() / sizeof(SieveHit), 0 == vm ? cand_cap : cand_cap + cand_cap / 4);
+    uint64_t total = 0, n_cands = 0;
     uint32_t n_hits = 0;
-    // positions per wave of the finish kernel: about 64 cells with fragments, so that one pass fills the lanes
-    const double pairs_per_position = (double)s.total_pairs / std::max<double>(1.0, (double)s.total_blocks * kBlockSize);
-    uint32_t slots_per_wave = kSieveSlotsMin;
-    while (slots_per_wave < kSieveSlotsMax && slots_per_wave * pairs_per_position < 48.0) slots_per_wave *= 2;
-    const dim3 sgrid(cdiv(n_slots, kSieveWaves * slots_per_wave)), sblock(64 * kSieveWaves);
+    const SlotInfo *slot_table = nullptr;
     for (int attempt = 0;; ++attempt) {
+        if (cand_cap >= (1ull << 32)) throw Error("more than 2^32 sieve candidates in one call: use smaller block ranges");
+        s.cands.reserve(cand_cap * sizeof(SieveCand));
+        s.pairs_of.reserve(cand_cap * 4 + 16);
+        s.pair_off.reserve((cand_cap + 1) * 8);
         s.hits.reserve(hit_cap * sizeof(SieveHit));
         HIP_CHECK(hipMemsetAsync(s.hit_count.as<uint32_t>(), 0, 4, st));
         s.timers["sieve"].start(st);
+        const dim3 ggrid(cdiv(n_slots, kSieveBlock)), gblock(kSieveBlock);
         if (!attempt) {
-            s.timers["sieve_screen"].start(st);
-            const dim3 cgrid(cdiv(n_slots * words_per_slot, kScreenBlock)), cblock(kScreenBlock);
-            const size_t clds = gate_lds_bytes(s.dev.insert_to);
             if (2 == vm) {
                 s.slot_table.reserve(n_slots * sizeof(SlotInfo) + 16);
                 s.timers["slot_table"].start(st);
                 hipLaunchKernelGGL(k_slot_table, dim3(block_hi - block_lo), dim3(256), 0, st, s.dev, block_lo, s.slot_table.as<SlotInfo>());
                 s.timers["slot_table"].stop(st);
-                hipLaunchKernelGGL(k_sieve_screen<2>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
-                                   s.slot_table.as<SlotInfo>());
-            } else
-                hipLaunchKernelGGL(k_sieve_screen<0>, cgrid, cblock, clds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, s.sieve_bitmap.as<uint32_t>(),
-                                   (const SlotInfo *)nullptr);
+                slot_table = s.slot_table.as<SlotInfo>();
+            }
+            s.timers["sieve_screen"].start(st);
+            if (2 == vm)
+                hipLaunchKernelGGL((k_sieve_gaps<2, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr,
+                                   (SieveCand *)nullptr, cand_cap, slot_table);
+            else
+                hipLaunchKernelGGL((k_sieve_gaps<0, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr,
+                                   (SieveCand *)nullptr, cand_cap, slot_table);
             s.timers["sieve_screen"].stop(st);
+            exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
         }
-        const size_t flds = kSieveWaves * slots_per_wave * sizeof(uint32_t);
+        if (2 == vm)
+            hipLaunchKernelGGL((k_sieve_gaps<2, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(),
+                               s.cands.as<SieveCand>(), cand_cap, slot_table);
+        else
+            hipLaunchKernelGGL((k_sieve_gaps<0, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(),
+                               s.cands.as<SieveCand>(), cand_cap, slot_table);
+        const dim3 fgrid(cdiv(cand_cap, kSieveBlock)), fblock(kSieveBlock);
 #define RSQ_FINISH(VM, CAP)                                                                                                                                   \
-    hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), sgrid, sblock, flds, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, words_per_slot, slots_per_wave,            \
-                       s.sieve_bitmap.as<uint32_t>(), s.counts.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)hit_cap, s.hit_count.as<uint32_t>(),                 \
-                       2 == VM ? s.slot_table.as<SlotInfo>() : (const SlotInfo *)nullptr)
+    hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), fgrid, fblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.offsets.as<uint64_t>(), s.cands.as<SieveCand>(),  \
+                       cand_cap, s.pairs_of.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)std::min<uint64_t>(hit_cap, 0xFFFFFFFFull), s.hit_count.as<uint32_t>(), slot_table)
         if (2 == vm && s.num_alleles <= 8) RSQ_FINISH(2, 8);        // few alleles: the cell's (allele, strand) slots stay in registers
         else if (2 == vm) RSQ_FINISH(2, kMaxDevAlleles);
         else if (1 == vm) RSQ_FINISH(1, 8);                         // allele copies exist for at most eight alleles
@@ -460,16 +468,21 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
 #undef RSQ_FINISH
         s.timers["sieve"].stop(st);
         HIP_CHECK(hipGetLastError());
-        exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
+        exclusive_scan(s, s.pairs_of.as<uint32_t>(), cand_cap, s.pair_off.as<uint64_t>(), st);
         s.mailbox[1] = 0;
-        HIP_CHECK(hipMemcpyAsync(&s.mailbox[0], s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&s.mailbox[0], s.pair_off.as<uint64_t>() + cand_cap, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(&s.mailbox[1], s.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&s.mailbox[5], s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         total = s.mailbox[0];
         n_hits = (uint32_t)s.mailbox[1];
-        if (n_hits <= hit_cap) break;
-        if (attempt) throw Error("sieve hit list overflowed twice");
-        hit_cap = (uint64_t)n_hits + 65536;                         // every cell was counted: the exact size is known now
+        n_cands = s.mailbox[5];
+        if (n_cands <= cand_cap && n_hits <= hit_cap) break;
+        if (attempt >= 2) throw Error("sieve lists overflowed three times");
+        // the candidate count is exact; the hit count is exact once the candidates fit, before that it is scaled up with them
+        const double grow = n_cands > cand_cap ? (double)n_cands / (double)cand_cap : 1.0;
+        if (n_hits > hit_cap || grow > 1.0) hit_cap = std::max<uint64_t>(hit_cap, (uint64_t)((double)n_hits * grow * 1.25) + 65536);
+        cand_cap = std::max(cand_cap, n_cands + 65536);
     }
     *n_pairs = total;
     if (!total) return RSQ_OK;
@@ -478,10 +491,10 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     if (2 == vm) {
         s.fvars.reserve(total * sizeof(FragmentVar) + 16);
         hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.frags.as<Fragment>(), s.fvars.as<FragmentVar>(), s.slot_table.as<SlotInfo>());
+                           s.pair_off.as<uint64_t>(), s.frags.as<Fragment>(), s.fvars.as<FragmentVar>(), s.slot_table.as<SlotInfo>());
     } else
         hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
+                           s.pair_off.as<uint64_t>(), s.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
     s.timers["sieve_emit"].stop(st);
     HIP_CHECK(hipGetLastError());
     if (frags_out) {

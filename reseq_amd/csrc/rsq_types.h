@@ -227,8 +227,8 @@ struct DevSim {
     uint32_t insert_from;            // max(1, InsertLengths().from())
     uint32_t insert_to;              // InsertLengths().to()
     const double *thresholds;        // [n_groups][insert_to][2]
-    const uint64_t *thr1_bits;       // [n_groups][insert_to] ceil(thresholds[..][1] * 2^32): the zero threshold for 32-bit uniforms
-    uint32_t thr1_has_zero;          // some entry is 0 (a threshold that underflowed: every word passes); the 32-bit gates cannot say that
+    const double *gap_q;             // [n_groups][insert_to] running product of the zero thresholds inside a segment (the sieve's gap draws)
+    const uint32_t *gap_seg_end;     // [n_groups][insert_to] one past the last length of the length's segment
     const uint32_t *coverage_group;  // [n_seqs]
     const double *ref_seq_bias;      // [n_seqs]
     const double *insert_lengths_bias; // dense [insert_to]

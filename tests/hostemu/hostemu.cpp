@@ -413,9 +413,9 @@ static int64_t emu_sieve_general(Emu &s, uint32_t block_lo, uint32_t block_hi, F
         if (block_id != last_block) number = 0;
         last_block = block_id;
         if (site.start >= site.L) continue;
-        for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
+        sieve_gaps(S, site, [&](uint32_t len, double probability_chosen) {
             VarCell cell;
-            if (!sieve_cell_general(S, site, len, sieve_cell_uniform(sieve_quad_words(S, site, len >> 2), len), cell)) continue;
+            if (!sieve_cell_general(S, site, len, probability_chosen, cell)) return;
             for (uint32_t e = 0; e < cell.n; ++e) {
                 const uint32_t allele = cell.id[e] >> 1;
                 const AlleleCell ac = allele_cell(allele_view(S, site.seq, allele), site.st, site.start, len);      // what k_sieve_emit<2> derives again
@@ -429,12 +429,12 @@ static int64_t emu_sieve_general(Emu &s, uint32_t block_lo, uint32_t block_hi, F
                     ++n;
                 }
             }
-        }
+        });
     }
     return (int64_t)n;
 }
 
-// the walk of k_sieve<COUNT> + scan + k_sieve<EMIT> with a plain loop over slots and lengths
+// k_sieve_gaps + k_sieve_finish + k_sieve_emit with a plain loop over slots and their passing lengths
 int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, uint64_t cap) {
     Emu &s = *static_cast<Emu *>(h);
     const DevSim &S = s.dev;
@@ -446,28 +446,27 @@ int64_t emu_sieve(void *h, uint32_t block_lo, uint32_t block_hi, Fragment *out, 
             SieveSite site;
             init_site(S, block_id, off, site);
             if (site.start >= site.L) break;
-            for (uint32_t len = S.insert_from; len < S.insert_to; ++len) {
+            sieve_gaps(S, site, [&](uint32_t len, double probability_chosen) {
                 uint32_t cnt[2], strand_of[2];
-                const Words w = sieve_quad_words(S, site, len >> 2);
                 if (s.has_variants) {                               // k_sieve_finish<1> + k_sieve_emit
                     VarCell cell;
-                    if (!sieve_cell_var(S, site, len, sieve_cell_uniform(w, len), cell)) continue;
+                    if (!sieve_cell_var(S, site, len, probability_chosen, cell)) return;
                     for (uint32_t e = 0; e < cell.n; ++e)
                         for (uint32_t dup = 0; dup < cell.cnt[e]; ++dup) {
                             if (n < cap) out[n] = make_fragment(site, len, dup, cell.id[e] & 1u, block_id, number + 1, cell.id[e] >> 1);
                             ++number;
                             ++n;
                         }
-                    continue;
+                    return;
                 }
-                if (!sieve_cell(S, site, len, sieve_cell_uniform(w, len), cnt, strand_of)) continue;
+                if (!sieve_cell(S, site, len, probability_chosen, cnt, strand_of)) return;
                 for (uint32_t j = 0; j < 2; ++j)
                     for (uint32_t dup = 0; dup < cnt[j]; ++dup) {
                         if (n < cap) out[n] = make_fragment(site, len, dup, strand_of[j], block_id, number + 1);
                         ++number;
                         ++n;
                     }
-            }
+            });
         }
     }
     return (int64_t)n;

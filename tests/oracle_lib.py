@@ -154,6 +154,8 @@ def lib():
         "orc_systematic_errors": (None, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_int,
                                          C.c_uint16, u8p, u8p, u8p]),
         "orc_sim_bias_normalization": (C.c_double, [C.c_void_p]),
+        "orc_gap_table": (None, [C.c_void_p, C.c_uint32, f64p, u32p]),
+        "orc_gap_hits": (C.c_uint32, [C.c_void_p, f64p, u32p, f64p, C.c_uint32, C.c_uint32, C.c_void_p]),
         "orc_sim_n_groups": (C.c_uint32, [C.c_void_p]),
         "orc_sim_insert_to": (C.c_uint32, [C.c_void_p]),
         "orc_sim_total_pairs": (C.c_uint64, [C.c_void_p]),
@@ -269,6 +271,23 @@ class Sim:
     def norm_by_len(self):
         L = lib()
         return np.ctypeslib.as_array(L.orc_sim_norm_by_len(self.h), shape=(L.orc_sim_insert_to(self.h),)).copy()
+
+    def gap_passes(self, group, starts, c1=0):
+        """the sieve's gap draws of coverage group `group` at the given start positions: (start index, length, probability_chosen) of
+        every cell that passes the zero threshold, plus the table (q, seg_end)"""
+        L = lib()
+        to = L.orc_sim_insert_to(self.h)
+        q, seg_end = np.zeros(to), np.zeros(to, np.uint32)
+        L.orc_gap_table(self.h, group, _ptr(q, f64p), _ptr(seg_end, u32p))
+        thr = np.ascontiguousarray(self.thresholds()[group].reshape(-1))
+        hit = np.dtype([("len", np.uint32), ("pad", np.uint32), ("probability_chosen", np.float64)])
+        buf = np.zeros(to, hit)
+        out = []
+        for i, start in enumerate(starts):
+            n = L.orc_gap_hits(self.h, _ptr(q, f64p), _ptr(seg_end, u32p), _ptr(thr, f64p), int(start), c1, buf.ctypes.data)
+            for k in range(n):
+                out.append((i, int(buf["len"][k]), float(buf["probability_chosen"][k])))
+        return out, q, seg_end
 
     def bias_normalization(self):
         return lib().orc_sim_bias_normalization(self.h)

@@ -223,6 +223,10 @@ def test_simulate_module_equals_cli(workdir):
     assert b":0:Adapter:0:" in open(a1, "rb").read()
 
 
+def test_sieve_with_dense_thresholds(workdir):
+    P.case_sieve_dense_thresholds(GpuBackend, workdir)
+
+
 def test_variants_substitutions(workdir):
     P.case_variants_substitutions(GpuBackend, workdir)
 
@@ -238,7 +242,7 @@ def test_variants_insertions_and_deletions_dense_four_alleles(workdir):
 def test_variants_crowding_the_sequence_ends(workdir):
     """start and end surroundings that wrap around a sequence end while variants sit in them: the wrapped part is the plain reference"""
     P.case_variants_indels(GpuBackend, workdir, density=30, seed=71, tag="ends71", lengths=(3300, 2100), ends=45)
-    P.case_variants_indels(GpuBackend, workdir, density=30, seed=74, tag="ends74", lengths=(3300, 2100), ends=45)
+    P.case_variants_indels(GpuBackend, workdir, density=30, seed=78, tag="ends78", lengths=(3300, 2100), ends=45)
 
 
 def test_variants_complex(workdir):

@@ -165,3 +165,66 @@ def test_conditionals_of_the_product(workdir):
     results = b.error_model(rec)
     b.close()
     _check(results, rec, arrays, sq_value)
+
+
+def test_gap_draws_pass_every_cell_with_its_own_probability(workdir):
+    """The sieve draws the gaps between the cells that pass the zero threshold instead of a uniform per cell (oracle_sim.c orc_gap_hits,
+    rsq_kernels.h sieve_gaps; Simulator.cpp:2304-2306).  Per fragment length the passes over many start positions must be binomial with
+    p = 1 - thr1[length], passes of neighbouring lengths must be uncorrelated, and probability_chosen of a passing cell must be uniform
+    on [thr1, 1).  Also with thresholds small enough that the running product is restarted (segments), and with a threshold of zero."""
+    import parity_cases as P
+    ppath, fpath, seqs = P.make_inputs(workdir, "gaps", synth.TINY, [6000])
+    oprof, oref = O.Profile(ppath), O.Reference(seqs)
+    sim = O.Sim(oprof, oref, 77, num_pairs=9000)
+    try:
+        n_starts = 40_000
+        base = sim.thresholds()
+        to = base.shape[1]
+        lo = int(sim.gap_passes(0, [])[2][0])                   # the first fragment length, max(1, InsertLengths().from())
+        for variant in ("profile", "small", "with_zero"):
+            thr = base.copy()
+            if variant == "small":                              # cells pass with probability 0.7 .. 1 - 1e-9: the running product would underflow without segments
+                thr[0, :, 1] = np.geomspace(3e-1, 1e-9, to)
+                thr[0, :, 0] = np.sqrt(thr[0, :, 1])
+            if variant == "with_zero":
+                thr[0, lo + 7, 1] = 0.0
+                thr[0, lo + 7, 0] = 0.0
+            sim.set_normalization(sim.bias_normalization(), thr)
+            n = 4000 if variant == "small" else n_starts
+            passes, q, seg_end = sim.gap_passes(0, np.arange(n))
+            if variant == "small":
+                assert len(set(seg_end[lo:].tolist())) > 1      # several segments
+            start = np.array([p[0] for p in passes])
+            length = np.array([p[1] for p in passes])
+            pc = np.array([p[2] for p in passes])
+            assert length.min() >= lo and length.max() < to
+            assert len(set(zip(start.tolist(), length.tolist()))) == len(passes)          # a cell passes once
+            p_pass = 1 - thr[0, :, 1]
+            counts = np.bincount(length, minlength=to).astype(float)
+            sel = np.arange(lo, to)
+            var = n * p_pass[sel] * (1 - p_pass[sel])
+            ok = var > 25                                       # the normal approximation holds
+            z = (counts[sel][ok] - n * p_pass[sel][ok]) / np.sqrt(var[ok])
+            assert np.abs(z).max() < 4.8 and abs(z.mean()) < 4.0 / np.sqrt(len(z)) and 0.75 < z.std() < 1.25, (variant, np.abs(z).max(), z.mean(), z.std())
+            rare = (var > 0) & ~ok                              # cells that (nearly) always or (nearly) never pass
+            assert (np.abs(counts[sel][rare] - n * p_pass[sel][rare]) <= 5 * np.sqrt(var[rare]) + 3).all()
+            assert np.array_equal(counts[sel][var == 0], n * p_pass[sel][var == 0])       # certain cells pass always, impossible ones never
+            # independence of neighbouring lengths: joint passes of (len, len + 1) against the product of their probabilities
+            grid = np.zeros((n, to), bool)
+            grid[start, length] = True
+            both = (grid[:, lo:-1] & grid[:, lo + 1:]).sum(0).astype(float)
+            pj = p_pass[lo:-1] * p_pass[lo + 1:]
+            vj = n * pj * (1 - pj)
+            zj = (both[vj > 0] - n * pj[vj > 0]) / np.sqrt(vj[vj > 0])
+            assert np.abs(zj).max() < 4.8 and abs(zj.mean()) < 4.0 / np.sqrt(len(zj)), (variant, np.abs(zj).max(), zj.mean())
+            # probability_chosen | pass ~ U[thr1, 1)
+            t1 = thr[0, length, 1]
+            u = (pc - t1) / (1 - t1)
+            assert u.min() >= 0 and u.max() < 1
+            hist = np.bincount((u * 10).astype(int), minlength=10).astype(float)
+            chi2 = ((hist - len(u) / 10) ** 2 / (len(u) / 10)).sum()
+            assert chi2 < 35, (variant, chi2)                                             # 9 degrees of freedom
+    finally:
+        sim.close()
+        oref.close()
+        oprof.close()
