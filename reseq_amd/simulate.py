@@ -5,14 +5,14 @@
 
 Every rank packs the replicated tables and runs the pre-passes itself (they are a second of work; no collective), takes a
 contiguous range of 1000-position blocks balanced by expected pairs (`sharding.partition_blocks`), writes its FASTQ shard, and
-rank 0 concatenates the shards in rank order and appends the adapter-only pairs.  The result is byte for byte the output of a
+after one all-gather of the shard sizes every rank copies its shard to its own offset of the output files, all ranks at once
+(`sharding.place_shard`); rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
 (seed, sequence, start, length), not by rank (Simulator.cpp:2384-2401 distributes blocks over threads the same way).
-torch.distributed (RCCL) carries two barriers and the job totals.
+torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and three barriers.
 """
 import argparse
 import os
-import shutil
 import sys
 import time
 
@@ -103,15 +103,21 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
             f1.write(a)
             f2.write(b)
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, n_bytes, time.perf_counter() - t0)
-    if dist is not None:
-        dist.barrier()                                               # every shard is on disk
+    # every rank places its shard itself: offsets from the exclusive scan of the shard sizes (one all-gather of two lengths per rank)
+    sizes = sharding.gather_sizes(dist, device, [os.path.getsize(shard1), os.path.getsize(shard2)], world)
     if rank == 0:
-        with open(out1, "wb") as f1, open(out2, "wb") as f2:
-            for r in range(world):
-                for dst, shard in ((f1, f"{out1}.rank{r}"), (f2, f"{out2}.rank{r}")):
-                    with open(shard, "rb") as src:
-                        shutil.copyfileobj(src, dst, 1 << 24)
-                    os.remove(shard)
+        for out, col in ((out1, 0), (out2, 1)):
+            with open(out, "wb") as f:
+                f.truncate(sum(row[col] for row in sizes))
+    if dist is not None:
+        dist.barrier()                                               # the output files exist at their final size
+    for out, shard, col in ((out1, shard1, 0), (out2, shard2, 1)):
+        sharding.place_shard(shard, out, sum(row[col] for row in sizes[:rank]))
+        os.remove(shard)
+    if dist is not None:
+        dist.barrier()                                               # every shard is in place
+    if rank == 0:
+        with open(out1, "ab") as f1, open(out2, "ab") as f2:
             for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does
                 a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
                 f1.write(a)
@@ -144,11 +150,14 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")
-    if dist is not None:                                             # one seed for the whole job
-        t = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=f"cuda:{local_rank}")
+    for out in (a.out1, a.out2):                                     # the single-GPU command line compresses these; shards placed by offset cannot be
+        if out.endswith((".gz", ".bz2")):
+            ap.error(f"{out}: compressed output is not supported by the multi-GPU launcher (write plain FASTQ and compress afterwards)")
+    seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
+    if dist is not None:                                             # one seed for the whole job, all 64 bits of it
+        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.broadcast(t, 0)
-        seed = int(t.item())
+        seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
     backend = GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError)
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
