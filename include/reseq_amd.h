@@ -171,6 +171,13 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
                         uint32_t out_stride, uint16_t *read_len_out_dev, uint16_t *num_errors_out_dev, uint16_t *tile_out_dev, char *cigar_out_dev,
                         uint32_t cigar_stride, void *stream);
 
+/* The same with the FASTQ text written on the device (reseq/Simulator.cpp:2497-2504 and the ordered output of :184-213): record i is
+ * "@{id_i} {CIGAR} E{errors}\n{bases}\n+\n{qualities}\n" with id_i = ids[id_off[i], id_off[i+1]) (device pointers, id_off has
+ * n + 1 entries), records in input order in text_dev.  *text_len = bytes needed; RSQ_ENOSPC if text_cap is smaller (nothing written). */
+int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev,
+                              const uint32_t *frag_len_dev, const uint8_t *dom_dev, const uint8_t *rate_dev, const char *ids_dev, const uint64_t *id_off_dev,
+                              char *text_dev, size_t text_cap, size_t *text_len, void *stream);
+
 /* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded on the call's stream
  * around each kernel.  names: "sieve" (screen + finish), "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"; with variants of any kind also
  * "slot_table" and "variant_templates". */

@@ -80,6 +80,7 @@ SYMBOLS = {
     "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "rsq_sim_error_model_fastq": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "rsq_dev_alloc": (C.c_int, [C.c_int, _sz, _pp]),
     "rsq_dev_free": (C.c_int, [C.c_int, _vp]),
@@ -360,6 +361,32 @@ class Simulator:
                     for i in range(n)]
         finally:
             for d in ins + outs:
+                d.free()
+
+    def error_model_fastq(self, rec, ids, first_index=0, stream=None):
+        """the same records as FASTQ text formatted on the device: "@{id} {CIGAR} E{errors}" (Simulator.cpp:2497-2504); ids: list of bytes"""
+        n, rl = rec["seqs"].shape
+        dev = self.device
+        ins = [DeviceArray.from_numpy(dev, np.ascontiguousarray(rec[k], dt)) for k, dt in
+               (("seqs", np.uint8), ("seg", np.uint8), ("frag_len", np.uint32), ("dom", np.uint8), ("rate", np.uint8))]
+        blob = b"".join(ids)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in ids])
+        ins.append(DeviceArray.from_numpy(dev, np.frombuffer(blob + b"\0", np.uint8)))
+        ins.append(DeviceArray.from_numpy(dev, off))
+        need = C.c_size_t(0)
+        text = None
+        try:
+            rc = lib().rsq_sim_error_model_fastq(self.h, first_index, n, rl, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, ins[5].ptr, ins[6].ptr,
+                                                 None, 0, C.byref(need), stream)
+            if rc != RSQ_ENOSPC:
+                _check(rc)
+            text = DeviceArray(dev, need.value + 16)
+            _check(lib().rsq_sim_error_model_fastq(self.h, first_index, n, rl, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, ins[5].ptr, ins[6].ptr,
+                                                   text.ptr, need.value + 16, C.byref(need), stream))
+            return text.to_numpy(np.uint8, need.value).tobytes()
+        finally:
+            for d in ins + ([text] if text else []):
                 d.free()
 
     def last_kernel_ms(self, name):

@@ -226,8 +226,8 @@ struct AsyncOut {
     std::mutex m;
     std::condition_variable cv;
     std::thread worker;
-    bool open(const std::string &path) {
-        if (!out.open(path)) return false;
+    bool open(const std::string &path) {                  // an empty path: stdout
+        if (!path.empty() && !out.open(path)) return false;
         worker = std::thread([this] {
             std::unique_lock<std::mutex> lock(m);
             for (;;) {
@@ -424,15 +424,18 @@ int illumina_pe(const Args &a) {
     return 0;
 }
 
-// one FASTA record of seqToIllumina's input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
-struct Record {
-    std::string id, seq, dom, rate;
+// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: reader, ErrorModelOnlyThread :2514-2560,
+// ordered output :184-213): a reader thread parses the FASTA text into packed batches in page-locked memory, the main thread uploads a
+// batch, runs the error model and the FASTQ formatter on the device (rsq_sim_error_model_fastq) and hands the text to the writer
+// thread of AsyncOut -- parsing batch k+1, simulating batch k and writing batch k-1 overlap.  Device and host buffers are reused.
+//
+// One FASTA record of the input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
+struct RecordFields {
+    size_t id_len = 0, dom_at = 0, rate_at = 0;
     uint8_t seg = 0;
     uint32_t frag_len = 0;
 };
-
-bool parse_record(const std::string &header, const std::string &seq, Record &r) {
-    const size_t L = seq.size();
+bool parse_record(const std::string &header, size_t L, RecordFields &r) {
     if (header.size() <= 2 * L + 2) {
         ERR("Read description is too short to contain systematic error information and a sequence id: " << header);
         return false;
@@ -442,14 +445,14 @@ bool parse_record(const std::string &header, const std::string &seq, Record &r) 
         ERR("The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " << header);
         return false;
     }
-    r.dom = header.substr(end + 2, L);
-    r.rate = header.substr(header.size() - L);
+    r.dom_at = end + 2;
+    r.rate_at = header.size() - L;
     while (end && header[end] != ' ') --end;
     if (!end) {
         ERR("No sequence id found that is separated by a space from the ReSeq information: " << header);
         return false;
     }
-    r.id = header.substr(0, end);
+    r.id_len = end;
     if (header[end + 1] == '1') r.seg = 0;
     else if (header[end + 1] == '2') r.seg = 1;
     else {
@@ -460,84 +463,182 @@ bool parse_record(const std::string &header, const std::string &seq, Record &r) 
         ERR("The template segment and fragment length are not separated by a semicolon: " << header);
         return false;
     }
-    const std::string fl = header.substr(end + 3, header.size() - 2 * L - 2 - (end + 3));
-    char *stop = nullptr;
-    r.frag_len = (uint32_t)strtoul(fl.c_str(), &stop, 10);
-    if (fl.empty() || *stop) {
-        ERR("Fragment length '" << fl << "' is not a pure integer: " << header);
+    const size_t fl_at = end + 3, fl_end = header.size() - 2 * L - 2;
+    uint64_t v = 0;
+    bool digits = fl_end > fl_at;
+    for (size_t k = fl_at; k < fl_end && digits; ++k) {
+        digits = header[k] >= '0' && header[k] <= '9';
+        v = v * 10 + (uint64_t)(header[k] - '0');
+    }
+    if (!digits) {
+        ERR("Fragment length '" << header.substr(fl_at, fl_end > fl_at ? fl_end - fl_at : 0) << "' is not a pure integer: " << header);
         return false;
     }
-    r.seq = seq;
+    r.frag_len = (uint32_t)v;
     return true;
 }
 
-int code_of(char c) {
-    switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
+struct CodeTable {
+    uint8_t code[256];
+    CodeTable() {
+        memset(code, 4, sizeof code);
+        code[(uint8_t)'A'] = code[(uint8_t)'a'] = 0;
+        code[(uint8_t)'C'] = code[(uint8_t)'c'] = 1;
+        code[(uint8_t)'G'] = code[(uint8_t)'g'] = 2;
+        code[(uint8_t)'T'] = code[(uint8_t)'t'] = 3;
     }
-}
+};
 
-bool run_batch(rsq_sim *sim, uint64_t first_index, const std::vector<Record> &recs, uint32_t max_read, uint8_t phred_unused, TextOut &out) {
-    (void)phred_unused;
-    const size_t n = recs.size(), L = recs[0].seq.size();
-    std::vector<uint8_t> seqs(n * L), seg(n), dom(n * L), rate(n * L);
-    std::vector<uint32_t> fl(n);
-    for (size_t i = 0; i < n; ++i) {
-        seg[i] = recs[i].seg;
-        fl[i] = recs[i].frag_len;
+struct HostArray {                    // page-locked, grow-only
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n, size_t keep = 0) {
+        if (n <= cap) return true;
+        void *q = nullptr;
+        const size_t want = std::max(n, cap + cap / 2);
+        if (!check(rsq_host_alloc(want, &q), "host buffer")) return false;
+        if (keep) memcpy(q, p, keep);
+        if (p) rsq_host_free(p);
+        p = q;
+        cap = want;
+        return true;
+    }
+    template <class T>
+    T *as() { return static_cast<T *>(p); }
+    ~HostArray() {
+        if (p) rsq_host_free(p);
+    }
+};
+
+// records of one template length, packed for rsq_sim_error_model_fastq
+struct PackedBatch {
+    static constexpr size_t kRecords = 1u << 19;
+    size_t n = 0, L = 0, id_bytes = 0;
+    uint64_t first_index = 0;
+    HostArray seqs, dom, rate, seg, fl, ids, id_off;
+    bool start(size_t length, uint64_t first) {
+        n = 0;
+        id_bytes = 0;
+        L = length;
+        first_index = first;
+        return seqs.ensure(kRecords * L) && dom.ensure(kRecords * L) && rate.ensure(kRecords * L) && seg.ensure(kRecords) && fl.ensure(kRecords * 4) &&
+               id_off.ensure((kRecords + 1) * 8) && ids.ensure(kRecords * 48);
+    }
+    bool full() const { return n == kRecords; }
+    bool add(const std::string &header, const std::string &seq, const RecordFields &r) {
+        static const CodeTable t;
+        uint8_t *s = seqs.as<uint8_t>() + n * L, *d = dom.as<uint8_t>() + n * L, *q = rate.as<uint8_t>() + n * L;
+        uint8_t any_n = 0;
         for (size_t k = 0; k < L; ++k) {
-            const int b = code_of(recs[i].seq[k]);
-            if (b > 3) {
-                ERR("input sequences must not contain N: " << recs[i].id);
-                return false;
-            }
-            seqs[i * L + k] = (uint8_t)b;
-            dom[i * L + k] = (uint8_t)code_of(recs[i].dom[k]);
-            int r = (uint8_t)recs[i].rate[k] - 33;                     // Simulator.cpp:2439-2442
-            if (r > 86) r += r - 86;
-            rate[i * L + k] = (uint8_t)r;
+            s[k] = t.code[(uint8_t)seq[k]];
+            any_n |= s[k];
+            d[k] = t.code[(uint8_t)header[r.dom_at + k]];
+            int v = (uint8_t)header[r.rate_at + k] - 33;                 // Simulator.cpp:2439-2442
+            if (v > 86) v += v - 86;
+            q[k] = (uint8_t)v;
         }
+        if (any_n & 4u) {
+            ERR("input sequences must not contain N: " << header.substr(0, r.id_len));
+            return false;
+        }
+        seg.as<uint8_t>()[n] = r.seg;
+        fl.as<uint32_t>()[n] = r.frag_len;
+        if (!ids.ensure(id_bytes + r.id_len + 8, id_bytes)) return false;
+        memcpy(ids.as<char>() + id_bytes, header.data(), r.id_len);
+        id_off.as<uint64_t>()[n] = id_bytes;
+        id_bytes += r.id_len;
+        id_off.as<uint64_t>()[++n] = id_bytes;
+        return true;
     }
-    const uint32_t stride = (max_read + 7u) & ~7u, cstride = 64 + 8 * max_read;
-    void *d[11] = {nullptr};
-    const size_t bytes[11] = {n * L, n, n * 4, n * L, n * L, n * stride, n * stride, n * 2, n * 2, n * 2, n * cstride};
-    bool ok = true;
-    for (int i = 0; ok && i < 11; ++i) ok = check(rsq_dev_alloc(0, bytes[i], &d[i]), "device allocation");
-    const void *src[5] = {seqs.data(), seg.data(), fl.data(), dom.data(), rate.data()};
-    for (int i = 0; ok && i < 5; ++i) ok = check(rsq_dev_upload(0, d[i], src[i], bytes[i]), "upload");
-    ok = ok && check(rsq_sim_error_model(sim, first_index, n, (uint32_t)L, (uint8_t *)d[0], (uint8_t *)d[1], (uint32_t *)d[2], (uint8_t *)d[3], (uint8_t *)d[4],
-                                         (uint8_t *)d[5], (uint8_t *)d[6], stride, (uint16_t *)d[7], (uint16_t *)d[8], (uint16_t *)d[9], (char *)d[10], cstride, nullptr),
-                     "Simulation failed");
-    std::vector<uint8_t> oseq(n * stride), oqual(n * stride);
-    std::vector<uint16_t> rlen(n), nerr(n);
-    std::vector<char> cig(n * cstride);
-    ok = ok && check(rsq_dev_download(0, oseq.data(), d[5], oseq.size()), "download") && check(rsq_dev_download(0, oqual.data(), d[6], oqual.size()), "download") &&
-         check(rsq_dev_download(0, rlen.data(), d[7], n * 2), "download") && check(rsq_dev_download(0, nerr.data(), d[8], n * 2), "download") &&
-         check(rsq_dev_download(0, cig.data(), d[10], cig.size()), "download");
-    for (int i = 0; i < 11; ++i)
-        if (d[i]) rsq_dev_free(0, d[i]);
-    if (!ok) return false;
-    std::string buf;
-    for (size_t i = 0; i < n; ++i) {                                   // Simulator.cpp:2497-2504: id + " {CIGAR} E{n}"
-        buf += '@';
-        buf += recs[i].id;
-        buf += ' ';
-        buf += &cig[i * cstride];
-        buf += " E";
-        buf += std::to_string(nerr[i]);
-        buf += '\n';
-        for (uint16_t k = 0; k < rlen[i]; ++k) buf += "ACGTN"[oseq[i * stride + k]];
-        buf += "\n+\n";
-        buf.append((const char *)&oqual[i * stride], rlen[i]);
-        buf += '\n';
+};
+
+// the reader thread: FASTA text -> packed batches, two in rotation
+struct BatchReader {
+    TextIn &in;
+    PackedBatch batch[2];
+    bool ready[2] = {false, false}, failed = false, done = false, any = false, abort = false;
+    int next_fill = 0, next_take = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread worker;
+    explicit BatchReader(TextIn &input) : in(input) {}
+    void start() {
+        worker = std::thread([this] {
+            const bool ok = run();
+            std::lock_guard<std::mutex> lock(m);
+            failed = !ok;
+            done = true;
+            cv.notify_all();
+        });
     }
-    out.write(buf.data(), buf.size());
-    return out.good();
-}
+    PackedBatch *acquire() {                          // a free slot for the reader
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return !ready[next_fill] || abort; });
+        return abort ? nullptr : &batch[next_fill];
+    }
+    void publish() {
+        std::lock_guard<std::mutex> lock(m);
+        ready[next_fill] = true;
+        next_fill ^= 1;
+        cv.notify_all();
+    }
+    bool run() {
+        std::string line, header, seq;
+        bool have_header = false;
+        uint64_t index = 0;
+        PackedBatch *cur = nullptr;
+        auto finish_record = [&]() {
+            if (!have_header) return true;
+            RecordFields r;
+            if (!parse_record(header, seq.size(), r)) return false;
+            if (cur && (cur->L != seq.size() || cur->full())) {       // one template length per launch
+                publish();
+                cur = nullptr;
+            }
+            if (!cur) {
+                cur = acquire();
+                if (!cur || !cur->start(seq.size(), index)) return false;
+            }
+            if (!cur->add(header, seq, r)) return false;
+            ++index;
+            any = true;
+            return true;
+        };
+        while (in.getline(line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty() && line[0] == '>') {
+                if (!finish_record()) return false;
+                header.assign(line, 1, std::string::npos);
+                have_header = true;
+                seq.clear();
+            } else seq += line;
+        }
+        if (!finish_record()) return false;
+        if (cur && cur->n) publish();
+        return true;
+    }
+    // the next batch for the device; nullptr at the end of the input (or after an error: `failed`)
+    PackedBatch *take() {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return ready[next_take] || done; });
+        if (!ready[next_take]) return nullptr;
+        return &batch[next_take];
+    }
+    void release() {
+        std::lock_guard<std::mutex> lock(m);
+        ready[next_take] = false;
+        next_take ^= 1;
+        cv.notify_all();
+    }
+    void join() {
+        {
+            std::lock_guard<std::mutex> lock(m);             // a reader blocked on a free slot after the consumer gave up
+            abort = true;
+            cv.notify_all();
+        }
+        if (worker.joinable()) worker.join();
+    }
+};
 
 int seq_to_illumina(const Args &a) {
     rsq_profile *prof = nullptr;
@@ -546,54 +647,52 @@ int seq_to_illumina(const Args &a) {
     const uint64_t seed = ok ? get_seed(a) : 0;
     ok = ok && check(rsq_sim_create(prof, nullptr, 0, &sim), "Could not set up the simulator") &&
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
-    uint32_t max_read = 0;
-    if (ok) rsq_profile_max_read_length(prof, &max_read);
     TextIn fin;                                              // stdin / stdout without -i / -o (main.cpp:1009-1021)
-    TextOut fout;
+    AsyncOut fout;
     if (ok && a.has("input") && !fin.open(a.get("input"))) {
         ERR("Could not open '" << a.get("input") << "' for reading.");
         ok = false;
     }
-    if (ok && a.has("output") && !fout.open(a.get("output"))) {
+    if (ok && !fout.open(a.get("output", ""))) {
         ERR("Could not open '" << a.get("output") << "' for writing.");
         ok = false;
     }
     if (ok) {
         INFO("Starting read generation");
-        std::vector<Record> batch;
-        std::string line, header, seq;
-        uint64_t index = 0, first_index = 0, written = 0;
-        bool any = false;
-        auto flush = [&]() {
-            if (batch.empty()) return true;
-            const bool r = run_batch(sim, first_index, batch, max_read, 0, fout);
-            written += batch.size();
-            first_index += batch.size();
-            batch.clear();
-            if (r) INFO("Generated " << written << " reads.");
-            return r;
-        };
-        auto finish_record = [&]() {
-            if (header.empty()) return true;
-            Record r;
-            if (!parse_record(header, seq, r)) return false;
-            if (!batch.empty() && (batch[0].seq.size() != r.seq.size() || batch.size() >= 100000))       // one template length per launch
-                if (!flush()) return false;
-            batch.push_back(r);
-            ++index;
-            any = true;
-            return true;
-        };
-        while (ok && fin.getline(line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            if (!line.empty() && line[0] == '>') {
-                ok = finish_record();
-                header = line.substr(1);
-                seq.clear();
-            } else seq += line;
+        BatchReader reader(fin);
+        reader.start();
+        DevBuffer d_seqs, d_dom, d_rate, d_seg, d_fl, d_ids, d_off, d_text;
+        uint64_t written = 0;
+        while (ok) {
+            PackedBatch *b = reader.take();
+            if (!b) break;
+            const size_t n = b->n, L = b->L;
+            ok = d_seqs.ensure(n * L) && d_dom.ensure(n * L) && d_rate.ensure(n * L) && d_seg.ensure(n) && d_fl.ensure(n * 4) && d_ids.ensure(b->id_bytes + 8) &&
+                 d_off.ensure((n + 1) * 8) && check(rsq_dev_upload(0, d_seqs.p, b->seqs.p, n * L), "upload") && check(rsq_dev_upload(0, d_dom.p, b->dom.p, n * L), "upload") &&
+                 check(rsq_dev_upload(0, d_rate.p, b->rate.p, n * L), "upload") && check(rsq_dev_upload(0, d_seg.p, b->seg.p, n), "upload") &&
+                 check(rsq_dev_upload(0, d_fl.p, b->fl.p, n * 4), "upload") && check(rsq_dev_upload(0, d_ids.p, b->ids.p, b->id_bytes + 1), "upload") &&
+                 check(rsq_dev_upload(0, d_off.p, b->id_off.p, (n + 1) * 8), "upload");
+            size_t len = 0;
+            for (int attempt = 0; ok && attempt < 2; ++attempt) {
+                ok = d_text.ensure(std::max(len + len / 8, n * (2 * L + 96) + b->id_bytes) + 64);
+                if (!ok) break;
+                const int rc = rsq_sim_error_model_fastq(sim, b->first_index, n, (uint32_t)L, (const uint8_t *)d_seqs.p, (const uint8_t *)d_seg.p, (const uint32_t *)d_fl.p,
+                                                         (const uint8_t *)d_dom.p, (const uint8_t *)d_rate.p, (const char *)d_ids.p, (const uint64_t *)d_off.p,
+                                                         (char *)d_text.p, d_text.cap, &len, nullptr);
+                if (rc == RSQ_ENOSPC && !attempt) continue;
+                ok = check(rc, "Simulation failed");
+                break;
+            }
+            reader.release();                                 // the inputs are on the device: the reader may refill the slot
+            ok = ok && fout.push(d_text, len);
+            if (ok) {
+                written += n;
+                INFO("Generated " << written << " reads.");
+            }
         }
-        ok = ok && finish_record() && flush();
-        if (ok && !any) {
+        reader.join();
+        ok = ok && !reader.failed;
+        if (ok && !reader.any) {
             ERR(a.get("input", "stdin") << " does not contain any sequences.");
             ok = false;
         }

@@ -508,6 +508,30 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     return reads_and_text(s, s.frags.as<Fragment>(), total, 0, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st, 2 == vm ? s.fvars.as<FragmentVar>() : nullptr);
 }
 
+// seqToIllumina's FASTQ text on the device (Simulator.cpp:2497-2504: "@{id} {CIGAR} E{errors}", bases, "+", qualities): sizes, then the
+// records at the offsets of their exclusive scan; one lane per record, word-granular stores
+RSQ_HD uint32_t error_model_record_size(const ReadMeta &m, uint32_t id_len) { return 1u + id_len + 1u + m.cigar_chars + 2u + digits_u32(m.num_errors) + 1u + 2u * m.read_len + 4u; }
+__global__ void __launch_bounds__(256) k_record_text_sizes(RawLayout raw, uint64_t n, const uint64_t *id_off, uint32_t *sizes) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sizes[i] = error_model_record_size(raw.meta[i], (uint32_t)(id_off[i + 1] - id_off[i]));
+}
+__global__ void __launch_bounds__(256) k_record_text(RawLayout raw, uint64_t n, const char *ids, const uint64_t *id_off, const uint64_t *offsets, char *dst, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || offsets[n] > cap) return;                          // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
+    const ReadMeta m = raw.meta[i];
+    WordSinkT<char *> t(dst + offsets[i]);
+    t.ch('@');
+    t.str(ids + id_off[i], (uint32_t)(id_off[i + 1] - id_off[i]));
+    t.ch(' ');
+    cigar_replay(raw.ops_of(i), m, t);
+    t.str(" E", 2);
+    t.num((uint32_t)m.num_errors);
+    t.ch('\n');
+    format_line(raw.seq_of(i), m.read_len, false, t);
+    format_line(raw.qual_of(i), m.read_len, true, t);
+    t.finish();
+}
+
 // CIGAR strings and per-read scalars of the error-model-only mode
 __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *num_errors_out,
                                   uint16_t *tile_out, char *cigar_out, uint32_t cigar_stride, uint32_t *overflow) {
@@ -895,6 +919,29 @@ int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_
     });
 }
 
+// the records' reads into the raw arrays: partition by template segment, k_fill_records
+static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
+                                  const uint8_t *dom_dev, const uint8_t *rate_dev, hipStream_t st) {
+    // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
+    const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
+    if (need_ops > s->ops_stride) s->ops_stride = need_ops;
+    if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
+    RawLayout raw = raw_layout(*s, n);
+    // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS
+    s->rec_flags.reserve(n * 4 + 16);
+    s->rec_index.reserve(n * 4 + 16);
+    s->rec_count.reserve(8);
+    s->offsets.reserve((n + 1) * 8);
+    const dim3 rgrid(cdiv(n, 256)), rblock(256);
+    hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
+    exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
+    hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
+    HIP_CHECK(hipGetLastError());
+    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>()};
+    launch_fill_records(*s, job, n, raw, st);
+    return raw;
+}
+
 int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
                         const uint8_t *dom_dev, const uint8_t *rate_dev, uint8_t *seq_out_dev, uint8_t *qual_out_dev, uint32_t out_stride, uint16_t *read_len_out_dev,
                         uint16_t *num_errors_out_dev, uint16_t *tile_out_dev, char *cigar_out_dev, uint32_t cigar_stride, void *stream) {
@@ -905,23 +952,7 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
     return guard([&] {
         hipStream_t st = (hipStream_t)stream;
         HIP_CHECK(hipSetDevice(s->device));
-        // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
-        const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
-        if (need_ops > s->ops_stride) s->ops_stride = need_ops;
-        if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
-        RawLayout raw = raw_layout(*s, n);
-        // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS
-        s->rec_flags.reserve(n * 4 + 16);
-        s->rec_index.reserve(n * 4 + 16);
-        s->rec_count.reserve(8);
-        s->offsets.reserve((n + 1) * 8);
-        const dim3 rgrid(cdiv(n, 256)), rblock(256);
-        hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
-        exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
-        hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
-        HIP_CHECK(hipGetLastError());
-        const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>()};
-        launch_fill_records(*s, job, n, raw, st);
+        const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
         s->scan_total.reserve(8);
         HIP_CHECK(hipMemsetAsync(s->scan_total.as<uint32_t>(), 0, 4, st));
         hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,
@@ -932,6 +963,36 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
         HIP_CHECK(hipStreamSynchronize(st));
         if (overflow) {
             g_last_error = "out_stride or cigar_stride too small for at least one record";
+            return (int)RSQ_ENOSPC;
+        }
+        return (int)RSQ_OK;
+    });
+}
+
+int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
+                              const uint8_t *dom_dev, const uint8_t *rate_dev, const char *ids_dev, const uint64_t *id_off_dev, char *text_dev, size_t text_cap,
+                              size_t *text_len, void *stream) {
+    REQUIRE(s && s->prepared, "simulator not prepared");
+    REQUIRE(seqs_dev && seg_dev && frag_len_dev && dom_dev && rate_dev && ids_dev && id_off_dev && text_len && (text_dev || !text_cap), "null pointer");
+    *text_len = 0;
+    if (!n) return RSQ_OK;
+    return guard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        HIP_CHECK(hipSetDevice(s->device));
+        const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
+        s->sizes.reserve(n * 4 + 16);
+        s->off_r1.reserve((n + 1) * 8);
+        s->timers["format_write"].start(st);
+        hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, id_off_dev, s->sizes.as<uint32_t>());
+        exclusive_scan(*s, s->sizes.as<uint32_t>(), n, s->off_r1.as<uint64_t>(), st);
+        hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids_dev, id_off_dev, s->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
+        s->timers["format_write"].stop(st);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        *text_len = s->mailbox[2];
+        if (*text_len > text_cap) {
+            g_last_error = "text buffer too small: need " + std::to_string(*text_len) + " bytes";
             return (int)RSQ_ENOSPC;
         }
         return (int)RSQ_OK;

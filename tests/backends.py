@@ -253,6 +253,9 @@ class GpuBackend:
     def error_model(self, rec, first_index=0, out_stride=1024, cigar_stride=256):
         return self.sim.error_model(rec, first_index, out_stride, cigar_stride)
 
+    def error_model_fastq(self, rec, ids, first_index=0):
+        return self.sim.error_model_fastq(rec, ids, first_index)
+
     def close(self):
         self.sim.close()
         if self.ref:

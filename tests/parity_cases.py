@@ -258,6 +258,11 @@ def _error_model(backend_cls, workdir, tag, cfg, n, read_len, seed, prof_seed, z
     assert len(got) == len(exp) == n
     for i, (e, g) in enumerate(zip(exp, got)):
         assert e == g, i
+    if hasattr(b, "error_model_fastq"):                       # the text of the same records formatted on the device (rsq_sim_error_model_fastq)
+        ids = [(b"read%d/" % i) + b"x" * (i % 41) + (b" extra words" if i % 5 == 0 else b"") for i in range(n)]
+        want = b"".join(b"@" + ids[i] + b" " + e[2].encode() + b" E%d\n" % e[3] + bytes(b"ACGTN"[c] for c in e[0]) + b"\n+\n" + e[1] + b"\n"
+                        for i, e in enumerate(exp))
+        assert b.error_model_fastq(rec, ids, first_index=17) == want
     b.close()
     oprof.close()
     return exp
