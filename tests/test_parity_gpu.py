@@ -166,7 +166,7 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
     assert r.stdout.decode() == got
     # the reference's complaints about malformed headers
     for bad, msg in ((">r 3;40;NNNN;!!!!\nACGT\n", "Template segment is 3"), (">r1;40;NNNN;!!!!\nACGT\n", "No sequence id found"), (">r 1;4x;NNNN;!!!!\nACGT\n", "not a pure integer"),
-                     (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short")):
+                     (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short"), (">r 1;40;NNNN;!!!!\nACNT\n", "must not contain N")):
         inp.write_text(bad)
         r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
         assert r.returncode != 0 and msg.encode() in r.stderr, (bad, r.stderr)

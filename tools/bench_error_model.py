@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] restated, scaled to N records: seqToIllumina's hot path
-(rsq_sim_error_model: ApplyErrorsAndQualityToFastaInput with the header fields already parsed) on templates resident in HBM.
+(rsq_sim_error_model: ApplyErrorsAndQualityToFastaInput with the header fields already parsed) on templates resident in HBM, in calls
+of at most 10 M records (the same templates with other record indices, i.e. other random streams, until N records are done); the
+second figure is rsq_sim_error_model_fastq, which also formats the FASTQ text on the device.
 Prints one JSON line with reads/s.  Not the bench line (bench.py measures the illuminaPE metric)."""
 import json
 import os
@@ -15,7 +17,9 @@ import numpy as np  # noqa: E402
 
 from reseq_amd import api, synth  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+n = min(total, 10_000_000)
+calls = (total + n - 1) // n
 tmp = tempfile.mkdtemp(prefix="rsq_em_")
 ppath = os.path.join(tmp, "p0.rsqp")
 arrays = synth.make_profile(synth.P0, seed=103741084)
@@ -32,15 +36,40 @@ outs = [api.DeviceArray(dev, n * out_stride), api.DeviceArray(dev, n * out_strid
         api.DeviceArray(dev, n * cigar_stride)]
 
 
+ids = np.char.add("read", np.arange(n).astype(str)).astype("S")
+id_len = np.char.str_len(ids).astype(np.uint64)
+id_off = np.zeros(n + 1, np.uint64)
+id_off[1:] = np.cumsum(id_len)
+blob = b"".join(ids.tolist()) + b"\0"
+d_ids, d_off = api.DeviceArray.from_numpy(dev, np.frombuffer(blob, np.uint8)), api.DeviceArray.from_numpy(dev, id_off)
+text = api.DeviceArray(dev, n * (2 * 150 + 64) + int(id_off[-1]))
+
+
 def once():
     t0 = time.perf_counter()
-    api._check(api.lib().rsq_sim_error_model(sim.h, 0, n, 150, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, outs[0].ptr, outs[1].ptr, out_stride, outs[2].ptr,
-                                             outs[3].ptr, outs[4].ptr, outs[5].ptr, cigar_stride, None))
+    for c in range(calls):
+        api._check(api.lib().rsq_sim_error_model(sim.h, c * n, n, 150, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, outs[0].ptr, outs[1].ptr, out_stride,
+                                                 outs[2].ptr, outs[3].ptr, outs[4].ptr, outs[5].ptr, cigar_stride, None))
     return time.perf_counter() - t0
+
+
+def once_text():
+    need = C.c_size_t(0)
+    t0 = time.perf_counter()
+    for c in range(calls):
+        api._check(api.lib().rsq_sim_error_model_fastq(sim.h, c * n, n, 150, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, ins[4].ptr, d_ids.ptr, d_off.ptr, text.ptr,
+                                                       text.nbytes, C.byref(need), None))
+    return time.perf_counter() - t0, need.value
 
 
 once()
 ts = [once() for _ in range(3)]
 best = min(ts)
-print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "records": n, "read_len": 150, "seconds": ts, "reads_per_s": n / best,
-                  "fill_kernel_ms": sim.last_kernel_ms("fill_reads")}))
+fill_ms = sim.last_kernel_ms("fill_reads")
+once_text()
+tt = [once_text() for _ in range(3)]
+best_text = min(t for t, _ in tt)
+print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
+                  "reads_per_s": n * calls / best, "fill_kernel_ms_last_call": fill_ms, "with_fastq_text_on_device": {"seconds": [t for t, _ in tt], "reads_per_s": n * calls / best_text,
+                                                                                                                  "text_bytes_per_call": tt[0][1],
+                                                                                                                  "format_ms_last_call": sim.last_kernel_ms("format_write")}}))
