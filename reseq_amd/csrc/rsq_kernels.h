@@ -21,6 +21,9 @@ struct Chain {
     uint32_t first_chunk;
     uint32_t initial_dom;  // DominantBase::dom_base_ left behind by the previous chain (Clear() keeps it)
     uint16_t *out;
+    // a rank of a sharded job runs only the chunks its reads can touch: chunks [chunk_lo, chunk_lo + its number of chunks) of the chain,
+    // entered with in_state (dist | start_rate << 24), the outgoing state of chunk chunk_lo - 1 on the neighbouring rank (0 at a chain's start)
+    uint32_t chunk_lo = 0, in_state = 0;
 };
 
 struct ChainAcc {
@@ -120,13 +123,9 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
     if (c >= n_chunks) return;
     const Chain ch = chains[chunk_chain[c]];
     const uint32_t local = c - ch.first_chunk;
-    uint32_t want = 0;
+    uint32_t want = local == 0 ? ch.in_state : 0u;                  // pass 0: every other chunk starts from the guess (0, 0)
     if (pass > 0) {
-        if (local == 0) {
-            out_new[c] = out_prev[c];
-            return;
-        }
-        want = out_prev[c - 1];
+        if (local) want = out_prev[c - 1];
         if (want == used_state[c]) {
             out_new[c] = out_prev[c];
             return;
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
     used_state[c] = want;
     ChainAcc acc{S.ref_words, ch.kind, ch.len, ch.kind < 2 ? S.seq_word_off[ch.id] : 0, ch.kind == 2 ? S.adapters[ch.seg].seqs + S.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
     uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
-    const uint32_t lo = local * chunk_len, hi = lo + chunk_len < ch.len ? lo + chunk_len : ch.len;
+    const uint32_t lo = (ch.chunk_lo + local) * chunk_len, hi = lo + chunk_len < ch.len ? lo + chunk_len : ch.len;
     sys_chain_chunk(S, acc, ch.c1, ch.c2, lo, hi, ch.initial_dom, dist, start_rate, ch.out);
     out_new[c] = dist | (start_rate << 24);
 }
@@ -146,11 +145,13 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
 // The surrounding factors of Reference::Bias depend on one position each (the start, or the end, of the fragment) and are shared by
 // every sampled fragment length: computed once per position (3 table lookups in the 24 MB sur_bias table and an exp each), they turn
 // k_sum_bias from a random-access kernel into a streaming one.  Same function, same values, same product order.
-__global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, double *start_bias, double *end_bias) {
+// [w_lo, w_hi): the part of the concatenated sequences that is needed (a sharded job computes its share)
+__global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, double *start_bias, double *end_bias, uint64_t w_lo, uint64_t w_hi) {
     const uint32_t seq = blockIdx.y, L = S.seq_len[seq];
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= L) return;
     const uint64_t wo = S.seq_word_off[seq], at = S.seq_base_off[seq] + pos;
+    if (at < w_lo || at >= w_hi) return;
     uint32_t sur[3];
     surrounding_forward(S.ref_words, wo, L, pos, sur);
     start_bias[at] = surrounding_bias(S.sur_bias, sur);
@@ -158,8 +159,11 @@ __global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, doubl
     end_bias[at] = surrounding_bias(S.sur_bias, sur);
 }
 
+// One workgroup = one chunk of kBiasBlock * kBiasRun start positions of one (sequence, sampled length).  A chunk belongs to the share
+// [g_lo, g_hi) of the concatenated sequences its first start position lies in; the other chunks' partial results stay zero (the
+// ranks of a sharded job add their arrays up: every entry is non-zero on one rank, so the sum is exact whatever the order).
 __global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *params, const double *start_bias, const double *end_bias, double *partial_sum,
-                                                 double *partial_max) {
+                                                 double *partial_max, uint64_t g_lo, uint64_t g_hi) {
     __shared__ double s_sum[kBiasBlock];
     __shared__ double s_max[kBiasBlock];
     const BiasParam p = params[blockIdx.y];
@@ -167,6 +171,8 @@ __global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *par
     const uint64_t wo = S.seq_word_off[p.seq];
     const uint32_t n_starts = L - p.len + 1;                       // start positions 0 .. L-len (Reference.cpp:645)
     const uint64_t bo = S.seq_base_off[p.seq];
+    const uint64_t chunk_at = bo + (uint64_t)blockIdx.x * kBiasBlock * kBiasRun;
+    if (chunk_at < g_lo || chunk_at >= g_hi) return;
     const uint32_t first = (blockIdx.x * kBiasBlock + threadIdx.x) * kBiasRun;
     double sum = 0.0, mx = 0.0;
     if (first < n_starts) {

@@ -942,12 +942,55 @@ constexpr uint32_t kChainChunk = 256;
 // kChainsAdapters: SimulateErrorModelOnly (Simulator.cpp:2951-2977); kChainsSimulation: Simulate (adapters, then every sequence that
 // gets a unit); kChainsProfile: CreateSystematicErrorProfile (:2597-2653), every sequence and no adapters, from a fresh Simulator.
 enum ChainSet : int { kChainsAdapters = 0, kChainsSimulation = 1, kChainsProfile = 2 };
-inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &chains, std::vector<uint32_t> &chunk_chain) {
+
+// ---- a sharded job: what the rank that simulates blocks [block_lo, block_hi) has to compute of the pre-passes.
+// Per sequence the rank's start positions [p_lo, p_hi) and the positions its reads can touch [p_lo, t_hi): a fragment ends before
+// start + insert_to (Simulator.cpp:2303,2316).  [g_lo, g_hi): the rank's share of the concatenated sequences, for the bias sums.
+struct ShardRange {
+    std::vector<uint32_t> p_lo, p_hi, t_hi;
+    uint64_t g_lo = 0, g_hi = UINT64_MAX;
+    int first_seq = -1, last_seq = -1;      // the sequences of the rank's first and last start position (-1: no blocks)
+};
+inline ShardRange shard_range(const SimState &s, uint32_t block_lo, uint32_t block_hi) {
+    if (block_lo < 1 || block_hi > s.total_blocks + 1 || block_lo > block_hi) throw Error("block range outside [1, total_blocks]");
+    const uint32_t n_seqs = s.dev.n_seqs, halo = s.dev.insert_to + 16u;
+    ShardRange r;
+    r.p_lo.assign(n_seqs, 0);
+    r.p_hi.assign(n_seqs, 0);
+    r.t_hi.assign(n_seqs, 0);
+    auto global_of_block = [&](uint32_t b) { return s.seq_base_off[s.block_seq[b]] + (uint64_t)(b - s.first_block[s.block_seq[b]]) * kBlockSize; };
+    r.g_lo = block_lo <= 1 ? 0 : global_of_block(block_lo);
+    r.g_hi = block_hi > s.total_blocks ? UINT64_MAX : global_of_block(block_hi);
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        if (!s.n_blocks[i]) continue;
+        const uint32_t fb = s.first_block[i], lo = std::max(fb, block_lo), hi = std::min(fb + s.n_blocks[i], block_hi);
+        if (lo >= hi) continue;
+        const uint32_t L = s.seq_len[i];
+        r.p_lo[i] = (lo - fb) * kBlockSize;
+        r.p_hi[i] = (uint32_t)std::min<uint64_t>(L, (uint64_t)(hi - fb) * kBlockSize);
+        r.t_hi[i] = (uint32_t)std::min<uint64_t>(L, (uint64_t)r.p_hi[i] + halo);
+        if (r.first_seq < 0) r.first_seq = (int)i;
+        r.last_seq = (int)i;
+    }
+    return r;
+}
+// where a rank's chains meet its neighbours': the chains that are entered with a state of the neighbouring rank, and the chunks
+// (flat indices) whose outgoing state the neighbours need.  -1: none
+struct ShardEdges {
+    int fwd_in_chain = -1, rev_in_chain = -1;       // forward chain of the rank's first sequence (state from the left neighbour), reverse chain of its last (from the right)
+    int64_t fwd_out_chunk = -1, rev_out_chunk = -1; // for the right neighbour's forward chain / the left neighbour's reverse chain
+};
+
+// `range`: only the chunks of the rank's share (every chunk when null); `edges` is filled with them
+inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &chains, std::vector<uint32_t> &chunk_chain, const ShardRange *range = nullptr,
+                         ShardEdges *edges = nullptr) {
     uint32_t dom_state = 0;                                       // DominantBase(): dom_base_(0)
-    auto add = [&](Chain c) {
+    auto add = [&](Chain c, uint32_t pos_lo, uint32_t pos_hi) {  // chain positions [pos_lo, pos_hi) are needed
         c.first_chunk = (uint32_t)chunk_chain.size();
         c.initial_dom = dom_state;
-        for (uint32_t k = 0; k < cdiv(c.len, kChainChunk); ++k) chunk_chain.push_back((uint32_t)chains.size());
+        c.chunk_lo = pos_lo / kChainChunk;
+        c.in_state = 0;
+        for (uint32_t k = c.chunk_lo; k < cdiv(pos_hi, kChainChunk); ++k) chunk_chain.push_back((uint32_t)chains.size());
         chains.push_back(c);
     };
     const Profile &p = s.prof;
@@ -956,7 +999,7 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
         for (uint32_t i = a.n(); i--;) {
             if (!a.counts[i]) continue;
             const uint32_t len = a.seq_ptr[i + 1] - a.seq_ptr[i];
-            add(Chain{2u, i, (uint32_t)seg, len, i, 2u + (uint32_t)seg, 0, 0, s.adapter_sys[seg] + a.seq_ptr[i]});
+            add(Chain{2u, i, (uint32_t)seg, len, i, 2u + (uint32_t)seg, 0, 0, s.adapter_sys[seg] + a.seq_ptr[i]}, 0, len);
             const uint8_t *codes = a.seqs.data() + a.seq_ptr[i];
             dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, len, dom_state);
         }
@@ -966,8 +1009,26 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
             if (set == kChainsSimulation && !s.n_blocks[i]) continue;      // no unit for sequences shorter than the longest insert
             const uint32_t L = s.seq_len[i];
             const std::vector<uint8_t> &codes = s.ref_codes[i];
+            const bool mine = !range || range->p_lo[i] < range->p_hi[i];
+            const uint32_t f_lo = range ? range->p_lo[i] : 0u, f_hi = range ? range->t_hi[i] : L;       // forward positions the rank needs
             for (uint32_t strand = 2; strand--;) {                  // CreateUnit: whole reverse strand first, then the forward blocks
-                add(Chain{strand, i, 0u, L, i, strand, 0, 0, (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[i]});
+                if (mine) {
+                    const int index = (int)chains.size();
+                    if (strand) add(Chain{strand, i, 0u, L, i, strand, 0, 0, s.sys_rev + s.seq_base_off[i]}, L - f_hi, L - f_lo);       // chain position = L-1-forward position
+                    else add(Chain{strand, i, 0u, L, i, strand, 0, 0, s.sys_fwd + s.seq_base_off[i]}, f_lo, f_hi);
+                    if (range && edges) {
+                        const Chain &c = chains.back();
+                        const uint32_t halo = s.dev.insert_to + 16u;
+                        if (!strand && (int)i == range->first_seq && c.chunk_lo) edges->fwd_in_chain = index;
+                        if (strand && (int)i == range->last_seq && c.chunk_lo) edges->rev_in_chain = index;
+                        if (!strand && (int)i == range->last_seq && range->p_hi[i] < L && range->p_hi[i] / kChainChunk)      // the right neighbour starts at p_hi
+                            edges->fwd_out_chunk = (int64_t)c.first_chunk + (range->p_hi[i] / kChainChunk - 1u - c.chunk_lo);
+                        if (strand && (int)i == range->first_seq && range->p_lo[i]) {                                           // the left neighbour ends at p_lo
+                            const uint32_t t_hi = (uint32_t)std::min<uint64_t>(L, (uint64_t)range->p_lo[i] + halo), lo_chunk = (L - t_hi) / kChainChunk;
+                            if (lo_chunk) edges->rev_out_chunk = (int64_t)c.first_chunk + (lo_chunk - 1u - c.chunk_lo);
+                        }
+                    }
+                }
                 if (strand) dom_state = dom_base_after_chain([&](uint32_t pos) { return 3u - codes[L - 1 - pos]; }, L, dom_state);
                 else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
             }

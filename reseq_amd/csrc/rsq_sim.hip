@@ -120,77 +120,114 @@ struct rsq_sim : SimState {
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
     int force_fill_mode = -1;      // RSQ_FILL_MODE=0: every draw in double precision from HBM (tests run both paths)
+    // the sharded pre-pass (rsq_sim_prepare_plan ... rsq_sim_prepare_finish): what lives between its calls
+    BiasPlan bias_plan;
+    bool planned = false;
+    struct ChainRun {
+        std::vector<Chain> chains;
+        ShardEdges edges;
+        uint32_t n_chunks = 0, passes = 0, block_lo = 0, block_hi = 0;
+        DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
+        bool valid = false;
+    } chain_run;
 };
 
 namespace rsq {
 
 // --------------------------------------------------------------------------------- systematic errors (a13)
-static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set) {
-    std::vector<Chain> chains;
-    std::vector<uint32_t> chunk_chain;
-    build_chains(s, set, chains, chunk_chain);
-    const uint32_t n_chunks = (uint32_t)chunk_chain.size();
-    if (!n_chunks) return 0;
-    DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
-    d_chains.upload(chains);
-    d_chunk_chain.upload(chunk_chain);
-    d_used.reserve(n_chunks * 4);
-    d_out[0].reserve(n_chunks * 4);
-    d_out[1].reserve(n_chunks * 4);
-    d_changed.reserve(8);
-    uint32_t pass = 0;
+// passes of k_sys_chain over the run's chunks until no chunk's incoming state changed; `first_pass`: 0 for a new run, the run's pass
+// count to resume one whose entering states (Chain::in_state) were replaced
+static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t st, uint32_t first_pass) {
+    uint32_t pass = first_pass;
     for (;; ++pass) {
-        HIP_CHECK(hipMemsetAsync(d_changed.as<uint32_t>(), 0, 4, st));
-        hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_chunks, 64)), dim3(64), 0, st, s.dev, d_chains.as<Chain>(), d_chunk_chain.as<uint32_t>(), n_chunks, kChainChunk,
-                           d_used.as<uint32_t>(), d_out[(pass + 1) & 1].as<uint32_t>(), d_out[pass & 1].as<uint32_t>(), d_changed.as<uint32_t>(), (int)pass);
+        HIP_CHECK(hipMemsetAsync(run.d_changed.as<uint32_t>(), 0, 4, st));
+        hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(run.n_chunks, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), run.n_chunks, kChainChunk,
+                           run.d_used.as<uint32_t>(), run.d_out[(pass + 1) & 1].as<uint32_t>(), run.d_out[pass & 1].as<uint32_t>(), run.d_changed.as<uint32_t>(), (int)pass);
         HIP_CHECK(hipGetLastError());
         uint32_t changed = 0;
-        HIP_CHECK(hipMemcpyAsync(&changed, d_changed.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&changed, run.d_changed.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (pass > 0 && !changed) break;
-        if (pass > n_chunks + 2) throw Error("systematic-error chains did not converge");
+        if (pass > first_pass + run.n_chunks + 2) throw Error("systematic-error chains did not converge");
     }
-    return pass + 1;
+    run.passes = pass + 1;                                          // the final states are in d_out[(run.passes - 1) & 1]
+}
+static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const ShardRange *range = nullptr) {
+    rsq_sim::ChainRun &run = s.chain_run;
+    run.valid = false;
+    run.chains.clear();
+    run.edges = ShardEdges{};
+    std::vector<uint32_t> chunk_chain;
+    build_chains(s, set, run.chains, chunk_chain, range, &run.edges);
+    run.n_chunks = (uint32_t)chunk_chain.size();
+    run.passes = 0;
+    if (!run.n_chunks) return 0;
+    run.d_chains.upload(run.chains);
+    run.d_chunk_chain.upload(chunk_chain);
+    run.d_used.reserve(run.n_chunks * 4);
+    run.d_out[0].reserve(run.n_chunks * 4);
+    run.d_out[1].reserve(run.n_chunks * 4);
+    run.d_changed.reserve(8);
+    iterate_sys_chains(s, run, st, 0);
+    run.valid = true;
+    return run.passes;
 }
 
 // ------------------------------------------------------------------------------- bias normalisation (a14)
 // FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization; the SumBias scans (Reference.cpp:622-659) run on
 // the GPU, one launch for all (sequence, sampled length) pairs; partial sums are combined in a fixed order.
 constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
+// partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each) whose first start position lies in the share
+// [g_lo, g_hi) of the concatenated sequences; zero elsewhere.  Layout [parameter][chunk], gx chunks per parameter.
+static uint32_t bias_chunks(const BiasPlan &plan) { return cdiv(plan.max_starts, kBiasBlock * kBiasRun); }
+static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
+    const uint32_t gx = bias_chunks(plan);
+    h_sum.assign((size_t)gx * plan.params.size(), 0.0);
+    h_max.assign(h_sum.size(), 0.0);
+    if (plan.params.empty()) return;
+    DevBuf d_params, d_sum, d_max, d_start_bias, d_end_bias;
+    d_params.upload(plan.params);
+    double *start_bias = nullptr, *end_bias = nullptr;
+    if (s.total_ref_size * 16 <= kSurroundingTrackBytesMax) {      // 16 bytes per base: 50 GB for a human genome, of 288 GB
+        d_start_bias.reserve(s.total_ref_size * 8 + 16);
+        d_end_bias.reserve(s.total_ref_size * 8 + 16);
+        start_bias = d_start_bias.as<double>();
+        end_bias = d_end_bias.as<double>();
+        uint32_t longest = 0;
+        for (uint32_t L : s.seq_len) longest = std::max(longest, L);
+        // the share's chunks read start positions up to a chunk behind g_hi and end positions a fragment length further
+        const uint64_t w_hi = g_hi == UINT64_MAX ? UINT64_MAX : g_hi + (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to;
+        hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias, g_lo, w_hi);
+        HIP_CHECK(hipGetLastError());
+    }
+    d_sum.reserve(h_sum.size() * 8);
+    d_max.reserve(h_sum.size() * 8);
+    HIP_CHECK(hipMemsetAsync(d_sum.as<double>(), 0, h_sum.size() * 8, st));
+    HIP_CHECK(hipMemsetAsync(d_max.as<double>(), 0, h_sum.size() * 8, st));
+    hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), start_bias, end_bias, d_sum.as<double>(),
+                       d_max.as<double>(), g_lo, g_hi);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+// the chunks' partial sums combined in chunk order -- the same additions whoever computed the chunks -- and the arithmetic after SumBias
+static void normalization_from_partials(rsq_sim &s, const BiasPlan &plan, const double *h_sum, const double *h_max) {
+    const uint32_t gx = bias_chunks(plan);
+    std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
+    for (size_t i = 0; i < plan.params.size(); ++i)
+        for (uint32_t b = 0; b < gx; ++b) {
+            sums[i] += h_sum[i * gx + b];
+            maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
+        }
+    finish_bias_normalization(s, plan, sums, maxes);
+    upload_normalization(s, s.up);
+}
 static void bias_normalization(rsq_sim &s, hipStream_t st) {
     const BiasPlan plan = plan_bias_normalization(s, s.up);
-    std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
-    if (!plan.params.empty()) {
-        const uint32_t gx = cdiv(plan.max_starts, kBiasBlock * kBiasRun);
-        DevBuf d_params, d_sum, d_max, d_start_bias, d_end_bias;
-        d_params.upload(plan.params);
-        double *start_bias = nullptr, *end_bias = nullptr;
-        if (s.total_ref_size * 16 <= kSurroundingTrackBytesMax) {      // 16 bytes per base: 50 GB for a human genome, of 288 GB
-            d_start_bias.reserve(s.total_ref_size * 8 + 16);
-            d_end_bias.reserve(s.total_ref_size * 8 + 16);
-            start_bias = d_start_bias.as<double>();
-            end_bias = d_end_bias.as<double>();
-            uint32_t longest = 0;
-            for (uint32_t L : s.seq_len) longest = std::max(longest, L);
-            hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias);
-            HIP_CHECK(hipGetLastError());
-        }
-        d_sum.reserve((size_t)gx * plan.params.size() * 8);
-        d_max.reserve((size_t)gx * plan.params.size() * 8);
-        hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), start_bias, end_bias, d_sum.as<double>(),
-                           d_max.as<double>());
-        HIP_CHECK(hipGetLastError());
-        std::vector<double> h_sum((size_t)gx * plan.params.size()), h_max(h_sum.size());
-        HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        for (size_t i = 0; i < plan.params.size(); ++i)
-            for (uint32_t b = 0; b < gx; ++b) {
-                sums[i] += h_sum[i * gx + b];
-                maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
-            }
-    }
-    finish_bias_normalization(s, plan, sums, maxes);
+    std::vector<double> h_sum, h_max;
+    bias_partials(s, st, plan, 0, UINT64_MAX, h_sum, h_max);
+    normalization_from_partials(s, plan, h_sum.data(), h_max.data());
 }
 
 static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
@@ -204,9 +241,9 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
     auto t0 = now();
     plan_simulation(s, s.up, seed, num_read_pairs, coverage, ref_bias_mode, base_identifier);
     lap("plan", t0);
+    s.planned = false;
     if (s.has_ref) {
         bias_normalization(s, st);
-        upload_normalization(s, s.up);
         lap("bias normalisation", t0);
     }
     s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);

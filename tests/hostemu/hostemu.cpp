@@ -145,13 +145,9 @@ uint32_t run_chains(Emu &s, ChainSet set) {
         for (uint32_t c = 0; c < n; ++c) {
             const Chain &ch = chains[chunk_chain[c]];
             const uint32_t local = c - ch.first_chunk;
-            uint32_t want = 0;
+            uint32_t want = local == 0 ? ch.in_state : 0u;
             if (pass > 0) {
-                if (local == 0) {
-                    cur[c] = prev[c];
-                    continue;
-                }
-                want = prev[c - 1];
+                if (local) want = prev[c - 1];
                 if (want == used[c]) {
                     cur[c] = prev[c];
                     continue;
@@ -162,7 +158,7 @@ uint32_t run_chains(Emu &s, ChainSet set) {
             ChainAcc acc{s.dev.ref_words, ch.kind, ch.len, ch.kind < 2 ? s.seq_word_off[ch.id] : 0,
                          ch.kind == 2 ? s.dev.adapters[ch.seg].seqs + s.dev.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
             uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
-            const uint32_t lo = local * kChainChunk, hi = std::min(lo + kChainChunk, ch.len);
+            const uint32_t lo = (ch.chunk_lo + local) * kChainChunk, hi = std::min(lo + kChainChunk, ch.len);
             sys_chain_chunk(s.dev, acc, ch.c1, ch.c2, lo, hi, ch.initial_dom, dist, start_rate, ch.out);
             cur[c] = dist | (start_rate << 24);
         }
