@@ -105,6 +105,28 @@ void rsq_sim_free(rsq_sim *s);
  * 1 no bias, 2 draw with replacement from the stored biases, 3 read the file given to rsq_sim_set_ref_bias_file. */
 int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier, void *stream);
 
+/* The same pre-pass for ONE rank of a sharded job (one process per GPU, the rank simulates blocks [block_lo, block_hi)): the rank computes
+ * its own share of both pre-passes and exchanges only small arrays with the other ranks; the results equal rsq_sim_prepare's bit for bit.
+ *   rsq_sim_prepare_plan            pair counts, block numbering, coverage groups (host work; reseq/Simulator.cpp:2687-2745)
+ *   rsq_sim_bias_partials           CalculateBiasNormalization / SumBias (reseq/FragmentDistributionStats.cpp:3504-3582, reseq/Reference.cpp:622-659):
+ *                                   partial sums and maxima of the rank's chunks of start positions, zero elsewhere; *n entries each
+ *                                   (rsq_sim_bias_partials(s, 0, 0, NULL, NULL, 0, &n, NULL) asks for n).  The ranks add their arrays up
+ *                                   (all-reduce SUM: every entry is non-zero on exactly one rank, so the sum is exact) ...
+ *   rsq_sim_prepare_normalization   ... and combine them in chunk order: normalisation, spline, thresholds
+ *   rsq_sim_prepare_sys_errors      SetSystematicErrors (reseq/Simulator.h:337-382) for the positions the rank's reads can touch.  The chains are
+ *                                   entered with in_state[0] (forward chain, from the rank on the left) and in_state[1] (reverse chain, from the
+ *                                   rank on the right); out_state[0] is what the rank on the right needs, out_state[1] what the rank on the left
+ *                                   needs.  Called again with other in_state it redoes only what depends on them.  Ranks repeat: all-gather of
+ *                                   out_state, take the neighbours' values, call again -- until no rank's in_state changed (at most world-1 rounds;
+ *                                   states of unaffected chains are final after the first call).  A rank with an empty range passes in_state on.
+ *   rsq_sim_prepare_finish          marks the simulator prepared.
+ * Not available with variants loaded (their systematic errors fold over whole strands): use rsq_sim_prepare there. */
+int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier);
+int rsq_sim_bias_partials(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes, size_t cap, size_t *n, void *stream);
+int rsq_sim_prepare_normalization(rsq_sim *s, const double *sums, const double *maxes, size_t n);
+int rsq_sim_prepare_sys_errors(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, const uint32_t in_state[2], uint32_t out_state[2], void *stream);
+int rsq_sim_prepare_finish(rsq_sim *s);
+
 /* --methylation: Reference::PrepareMethylationFile + ReadMethylation (reseq/Reference.cpp:1132-1310) for a reference without variants:
  * extended BED "sequence start end methylation" in reference order.  Afterwards rsq_sim_pairs applies Simulator::CTConversion
  * (reseq/Simulator.cpp:1925-2002,2219-2247) to the templates of every fragment: inside the listed regions each C becomes T with

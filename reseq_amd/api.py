@@ -66,6 +66,11 @@ SYMBOLS = {
     "rsq_sim_create": (C.c_int, [_vp, _vp, C.c_int, _pp]),
     "rsq_sim_free": (None, [_vp]),
     "rsq_sim_prepare": (C.c_int, [_vp, _u64, _u64, C.c_double, C.c_int, C.c_char_p, _vp]),
+    "rsq_sim_prepare_plan": (C.c_int, [_vp, _u64, _u64, C.c_double, C.c_int, C.c_char_p]),
+    "rsq_sim_bias_partials": (C.c_int, [_vp, _u32, _u32, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "rsq_sim_prepare_normalization": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rsq_sim_prepare_sys_errors": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp]),
+    "rsq_sim_prepare_finish": (C.c_int, [_vp]),
     "rsq_sim_get_info": (C.c_int, [_vp, C.POINTER(SimInfo)]),
     "rsq_sim_get_thresholds": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_get_norm_by_len": (C.c_int, [_vp, _vp, _sz]),
@@ -245,6 +250,31 @@ class Simulator:
 
     def prepare(self, seed, num_read_pairs=0, coverage=0.0, ref_bias_mode=0, record_base_identifier="", stream=None):
         _check(lib().rsq_sim_prepare(self.h, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier.encode(), stream))
+        return self.info()
+
+    # the pre-pass of one rank of a sharded job (include/reseq_amd.h "The same pre-pass for ONE rank"); reseq_amd/sharding.py drives these
+    def prepare_plan(self, seed, num_read_pairs=0, coverage=0.0, ref_bias_mode=0, record_base_identifier=""):
+        _check(lib().rsq_sim_prepare_plan(self.h, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier.encode()))
+        return self.info()
+
+    def bias_partials(self, block_lo, block_hi, stream=None):
+        n = C.c_size_t(0)
+        _check(lib().rsq_sim_bias_partials(self.h, 0, 0, None, None, 0, C.byref(n), None))
+        sums, maxes = np.zeros(n.value), np.zeros(n.value)
+        _check(lib().rsq_sim_bias_partials(self.h, block_lo, block_hi, sums.ctypes.data, maxes.ctypes.data, n.value, C.byref(n), stream))
+        return sums, maxes
+
+    def prepare_normalization(self, sums, maxes):
+        sums, maxes = np.ascontiguousarray(sums, np.float64), np.ascontiguousarray(maxes, np.float64)
+        _check(lib().rsq_sim_prepare_normalization(self.h, sums.ctypes.data, maxes.ctypes.data, sums.size))
+
+    def prepare_sys_errors(self, block_lo, block_hi, in_state, stream=None):
+        i, o = np.asarray(in_state, np.uint32), np.zeros(2, np.uint32)
+        _check(lib().rsq_sim_prepare_sys_errors(self.h, block_lo, block_hi, i.ctypes.data, o.ctypes.data, stream))
+        return [int(o[0]), int(o[1])]
+
+    def prepare_finish(self):
+        _check(lib().rsq_sim_prepare_finish(self.h))
         return self.info()
 
     def info(self):

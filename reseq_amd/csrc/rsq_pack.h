@@ -1184,4 +1184,20 @@ inline void upload_normalization(SimState &s, Uploader &up) {
     s.dev.gap_seg_end = up.put(seg_end);
 }
 
+// ---- the bias sums in chunks (k_sum_bias): kBiasBlock * kBiasRun start positions per chunk, bias_chunks chunks per parameter, layout
+// [parameter][chunk].  The chunks' partial sums are combined in chunk order -- the same additions whoever computed the chunks, one GPU or
+// the ranks of a sharded job -- and the arithmetic after SumBias follows.
+inline uint32_t bias_chunks(const BiasPlan &plan) { return cdiv(plan.max_starts, kBiasBlock * kBiasRun); }
+inline void normalization_from_partials(SimState &s, Uploader &up, const BiasPlan &plan, const double *h_sum, const double *h_max) {
+    const uint32_t gx = bias_chunks(plan);
+    std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
+    for (size_t i = 0; i < plan.params.size(); ++i)
+        for (uint32_t b = 0; b < gx; ++b) {
+            sums[i] += h_sum[i * gx + b];
+            maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
+        }
+    finish_bias_normalization(s, plan, sums, maxes);
+    upload_normalization(s, up);
+}
+
 }  // namespace rsq

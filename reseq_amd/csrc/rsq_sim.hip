@@ -127,6 +127,7 @@ struct rsq_sim : SimState {
         std::vector<Chain> chains;
         ShardEdges edges;
         uint32_t n_chunks = 0, passes = 0, block_lo = 0, block_hi = 0;
+        bool pass_through = false;     // the rank has no blocks: its neighbours' states go straight through
         DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
         bool valid = false;
     } chain_run;
@@ -179,7 +180,6 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const S
 constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
 // partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each) whose first start position lies in the share
 // [g_lo, g_hi) of the concatenated sequences; zero elsewhere.  Layout [parameter][chunk], gx chunks per parameter.
-static uint32_t bias_chunks(const BiasPlan &plan) { return cdiv(plan.max_starts, kBiasBlock * kBiasRun); }
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
     const uint32_t gx = bias_chunks(plan);
     h_sum.assign((size_t)gx * plan.params.size(), 0.0);
@@ -211,23 +211,11 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
 }
-// the chunks' partial sums combined in chunk order -- the same additions whoever computed the chunks -- and the arithmetic after SumBias
-static void normalization_from_partials(rsq_sim &s, const BiasPlan &plan, const double *h_sum, const double *h_max) {
-    const uint32_t gx = bias_chunks(plan);
-    std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
-    for (size_t i = 0; i < plan.params.size(); ++i)
-        for (uint32_t b = 0; b < gx; ++b) {
-            sums[i] += h_sum[i * gx + b];
-            maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
-        }
-    finish_bias_normalization(s, plan, sums, maxes);
-    upload_normalization(s, s.up);
-}
 static void bias_normalization(rsq_sim &s, hipStream_t st) {
     const BiasPlan plan = plan_bias_normalization(s, s.up);
     std::vector<double> h_sum, h_max;
     bias_partials(s, st, plan, 0, UINT64_MAX, h_sum, h_max);
-    normalization_from_partials(s, plan, h_sum.data(), h_max.data());
+    normalization_from_partials(s, s.up, plan, h_sum.data(), h_max.data());
 }
 
 static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
@@ -850,6 +838,96 @@ int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double c
         prepare(*s, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier, (hipStream_t)stream);
         return RSQ_OK;
     });
+}
+
+int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier) {
+    REQUIRE(s, "null argument");
+    REQUIRE(s->has_ref, "the sharded pre-pass needs a reference");
+    REQUIRE(!s->has_variants, "the sharded pre-pass is not available with variants: use rsq_sim_prepare");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        s->prepared = false;
+        s->chain_run.valid = false;
+        plan_simulation(*s, s->up, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier);
+        s->bias_plan = plan_bias_normalization(*s, s->up);
+        s->planned = true;
+        return RSQ_OK;
+    });
+}
+int rsq_sim_bias_partials(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes, size_t cap, size_t *n, void *stream) {
+    REQUIRE(s && n, "null argument");
+    REQUIRE(s->planned, "rsq_sim_prepare_plan must run first");
+    *n = (size_t)bias_chunks(s->bias_plan) * s->bias_plan.params.size();
+    if (!sums && !maxes && !cap) return RSQ_OK;                     // the size query
+    REQUIRE(sums && maxes && cap >= *n, "arrays too small");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        const ShardRange r = shard_range(*s, block_lo, block_hi);
+        std::vector<double> h_sum, h_max;
+        if (r.g_lo < r.g_hi) bias_partials(*s, (hipStream_t)stream, s->bias_plan, r.g_lo, r.g_hi, h_sum, h_max);
+        else {
+            h_sum.assign(*n, 0.0);
+            h_max.assign(*n, 0.0);
+        }
+        memcpy(sums, h_sum.data(), *n * 8);
+        memcpy(maxes, h_max.data(), *n * 8);
+        return RSQ_OK;
+    });
+}
+int rsq_sim_prepare_normalization(rsq_sim *s, const double *sums, const double *maxes, size_t n) {
+    REQUIRE(s && sums && maxes, "null argument");
+    REQUIRE(s->planned, "rsq_sim_prepare_plan must run first");
+    REQUIRE(n == (size_t)bias_chunks(s->bias_plan) * s->bias_plan.params.size(), "wrong number of partial sums");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        normalization_from_partials(*s, s->up, s->bias_plan, sums, maxes);
+        return RSQ_OK;
+    });
+}
+int rsq_sim_prepare_sys_errors(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, const uint32_t in_state[2], uint32_t out_state[2], void *stream) {
+    REQUIRE(s && in_state && out_state, "null argument");
+    REQUIRE(s->planned, "rsq_sim_prepare_plan must run first");
+    return guard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        HIP_CHECK(hipSetDevice(s->device));
+        out_state[0] = in_state[0];                                 // a rank without blocks passes the states on
+        out_state[1] = in_state[1];
+        rsq_sim::ChainRun &run = s->chain_run;
+        if (!(run.valid && run.block_lo == block_lo && run.block_hi == block_hi)) {
+            const ShardRange r = shard_range(*s, block_lo, block_hi);
+            s->passes = run_sys_chains(*s, st, kChainsSimulation, &r);
+            run.block_lo = block_lo;
+            run.block_hi = block_hi;
+            run.pass_through = r.first_seq < 0;
+            run.valid = true;
+        }
+        if (run.pass_through || !run.n_chunks) return RSQ_OK;
+        bool replaced = false;
+        const int in_chain[2] = {run.edges.fwd_in_chain, run.edges.rev_in_chain};
+        for (int k = 0; k < 2; ++k)
+            if (in_chain[k] >= 0 && run.chains[(size_t)in_chain[k]].in_state != in_state[k]) {
+                run.chains[(size_t)in_chain[k]].in_state = in_state[k];
+                replaced = true;
+            }
+        if (replaced) {
+            run.d_chains.upload(run.chains);
+            iterate_sys_chains(*s, run, st, run.passes);            // only the chunks behind a changed state run again
+            s->passes = run.passes;
+        }
+        const int64_t out_chunk[2] = {run.edges.fwd_out_chunk, run.edges.rev_out_chunk};
+        for (int k = 0; k < 2; ++k) {
+            out_state[k] = 0;
+            if (out_chunk[k] >= 0)
+                HIP_CHECK(hipMemcpy(&out_state[k], run.d_out[(run.passes - 1) & 1].as<uint32_t>() + out_chunk[k], 4, hipMemcpyDeviceToHost));
+        }
+        return RSQ_OK;
+    });
+}
+int rsq_sim_prepare_finish(rsq_sim *s) {
+    REQUIRE(s, "null argument");
+    REQUIRE(s->planned && s->chain_run.valid, "the sharded pre-pass has not run");
+    s->prepared = true;
+    return RSQ_OK;
 }
 
 int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out) {

@@ -95,3 +95,85 @@ def place_shard(shard_path: str, out_path: str, offset: int, chunk: int = 1 << 2
     finally:
         os.close(src)
         os.close(dst)
+
+
+def block_weights(seq_len, insert_to, ref_seq_bias):
+    """Expected pairs per block up to a constant: the sequence's reference bias (blocks of a sequence share it); sequences
+    shorter than the longest insert have no blocks (Simulator.cpp:1159)."""
+    w = []
+    for length, bias in zip(seq_len, ref_seq_bias):
+        if length >= insert_to:
+            w += [float(bias)] * ((length + 999) // 1000)
+    return w
+
+
+def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+    """The pre-passes of a sharded job (SURVEY.md section 8(e)): every rank computes its share and the ranks exchange small arrays;
+    every rank ends with the thresholds and, for the positions its reads can touch, the systematic-error tracks of a single-GPU
+    rsq_sim_prepare, bit for bit.  `backend`: prepare_plan / ref_seq_bias / seq_len / bias_partials / prepare_normalization /
+    prepare_sys_errors / prepare_finish (api.Simulator's methods).  Returns (info, the rank's block range, rounds of the chain exchange).
+
+    a14 CalculateBiasNormalization: partial sums and maxima per chunk of 8192 start positions; a chunk is computed by the rank whose
+    share holds its first position, all other entries are zero, so the all-reduce (SUM) is exact in any order, and every rank then adds
+    the chunks up in chunk order -- the additions of the single-GPU run.
+    a13 SetSystematicErrors: a chain's state (distance to the start of the error region, its rate) is all that crosses a shard
+    border.  Every rank first runs its chunks speculatively to a fixed point; the states at the borders then travel rank to rank (forward
+    chains to the right, reverse chains to the left) by all-gathers of two words per rank until no rank's entering state changed; a rank
+    whose state changed redoes only the chunks that depend on it."""
+    import torch
+    info = backend.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+    total_blocks = info["total_blocks"] if isinstance(info, dict) else info.total_blocks
+    insert_to = info["insert_to"] if isinstance(info, dict) else info.insert_to
+    weights = block_weights(backend.seq_len, insert_to, backend.ref_seq_bias())
+    assert len(weights) == total_blocks
+    lo, hi = partition_blocks(total_blocks, world, weights)[rank]
+    sums, maxes = backend.bias_partials(lo, hi)
+    if dist is not None:
+        t = torch.from_numpy(__import__("numpy").stack([sums, maxes])).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                     # every entry is non-zero on one rank
+        sums, maxes = t[0].cpu().numpy(), t[1].cpu().numpy()
+    backend.prepare_normalization(sums, maxes)
+    in_state, rounds = [0, 0], 0
+    while True:
+        out = backend.prepare_sys_errors(lo, hi, in_state)
+        rounds += 1
+        if dist is None:
+            break
+        mine = torch.tensor(out, dtype=torch.int64, device=device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        new_in = [int(everyone[rank - 1][0]) if rank > 0 else 0, int(everyone[rank + 1][1]) if rank + 1 < world else 0]
+        changed = torch.tensor([int(new_in != in_state)], dtype=torch.int64, device=device)
+        dist.all_reduce(changed, op=dist.ReduceOp.MAX)
+        in_state = new_in
+        if not int(changed.item()):
+            break
+        if rounds > world + 2:
+            raise RuntimeError("the chain states at the shard borders did not settle")
+    return backend.prepare_finish(), (lo, hi), rounds
+
+
+def sharded_prepare_in_process(backends, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+    """sharded_prepare for `len(backends)` ranks that live in ONE process (one simulator per device, or a test): the same calls in lock
+    step, the collectives replaced by sums and list lookups.  Returns (infos, block ranges, rounds)."""
+    import numpy as np
+    world = len(backends)
+    infos = [b.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier) for b in backends]
+    get = lambda i, k: i[k] if isinstance(i, dict) else getattr(i, k)
+    weights = block_weights(backends[0].seq_len, get(infos[0], "insert_to"), backends[0].ref_seq_bias())
+    ranges = partition_blocks(get(infos[0], "total_blocks"), world, weights)
+    parts = [b.bias_partials(lo, hi) for b, (lo, hi) in zip(backends, ranges)]
+    sums, maxes = np.sum([p[0] for p in parts], axis=0), np.sum([p[1] for p in parts], axis=0)
+    for b in backends:
+        b.prepare_normalization(sums, maxes)
+    in_states, rounds = [[0, 0] for _ in range(world)], 0
+    while True:
+        outs = [b.prepare_sys_errors(lo, hi, st) for b, (lo, hi), st in zip(backends, ranges, in_states)]
+        rounds += 1
+        new_in = [[outs[r - 1][0] if r > 0 else 0, outs[r + 1][1] if r + 1 < world else 0] for r in range(world)]
+        if new_in == in_states:
+            break
+        in_states = new_in
+        if rounds > world + 2:
+            raise RuntimeError("the chain states at the shard borders did not settle")
+    return [b.prepare_finish() for b in backends], ranges, rounds

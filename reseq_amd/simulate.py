@@ -3,8 +3,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m reseq_amd.simulate \\
         -R ref.fa -s profile.rsqp -1 r1.fq -2 r2.fq --numReads 100000000 --seed 11
 
-Every rank packs the replicated tables and runs the pre-passes itself (they are a second of work; no collective), takes a
-contiguous range of 1000-position blocks balanced by expected pairs (`sharding.partition_blocks`), writes its FASTQ shard, and
+Every rank packs the replicated tables, takes a contiguous range of 1000-position blocks balanced by expected pairs
+(`sharding.partition_blocks`) and computes ITS share of the pre-passes (`sharding.sharded_prepare`: bias sums per chunk + one exact
+all-reduce, systematic-error chains over its own positions + the chain states at the shard borders; with variants loaded every rank
+still runs the whole pre-pass), writes its FASTQ shard, and
 after one all-gather of the shard sizes every rank copies its shard to its own offset of the output files, all ranks at once
 (`sharding.place_shard`); rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
@@ -27,6 +29,7 @@ class GpuBackend:
         self.api = api
         self.prof = api.Profile(profile_path)
         self.ref = api.Reference(fasta_path, replace_n_seed)
+        self.has_variants = bool(vcf_path)
         if vcf_path:
             self.ref.read_variants(vcf_path)
         self.sim = api.Simulator(self.prof, self.ref, device)
@@ -45,6 +48,29 @@ class GpuBackend:
 
     def ref_seq_bias(self):
         return self.sim.ref_seq_bias(len(self.seq_len))
+
+    # the sharded pre-pass (not with variants, and not with a systematic-error profile that replaces the chains anyway)
+    @property
+    def can_shard_prepare(self):
+        return not self.has_variants and not self.sys_error_path
+
+    def _info(self, i):
+        return dict(total_blocks=i.total_blocks, total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, insert_to=i.insert_to)
+
+    def prepare_plan(self, *a):
+        return self._info(self.sim.prepare_plan(*a))
+
+    def bias_partials(self, lo, hi):
+        return self.sim.bias_partials(lo, hi)
+
+    def prepare_normalization(self, sums, maxes):
+        self.sim.prepare_normalization(sums, maxes)
+
+    def prepare_sys_errors(self, lo, hi, in_state):
+        return self.sim.prepare_sys_errors(lo, hi, in_state)
+
+    def prepare_finish(self):
+        return self._info(self.sim.prepare_finish())
 
     def pairs(self, lo, hi):
         import numpy as np
@@ -73,23 +99,19 @@ class GpuBackend:
         self.prof.close()
 
 
-def block_weights(seq_len, insert_to, ref_seq_bias):
-    """Expected pairs per block up to a constant: the sequence's reference bias (blocks of a sequence share it); sequences
-    shorter than the longest insert have no blocks (Simulator.cpp:1159)."""
-    w = []
-    for length, bias in zip(seq_len, ref_seq_bias):
-        if length >= insert_to:
-            w += [float(bias)] * ((length + 999) // 1000)
-    return w
+block_weights = sharding.block_weights
 
 
 def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu"):
     """One rank's share.  `backend` offers prepare / ref_seq_bias / seq_len / pairs / adapter_only_pairs.  Returns (pairs of the whole
     job, seconds of the slowest rank)."""
-    info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
-    weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
-    assert len(weights) == info["total_blocks"]
-    mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
+    if world > 1 and getattr(backend, "can_shard_prepare", False):   # every rank its share of the pre-passes
+        info, mine, _ = sharding.sharded_prepare(backend, dist, device, rank, world, seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+    else:
+        info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
+        assert len(weights) == info["total_blocks"]
+        mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
     if not batch_blocks:                                             # about 4 M pairs per call (large launches), at least 2000 blocks
         batch_blocks = int(min(100000, max(2000, 4e6 * info["total_blocks"] / max(1, info["total_pairs"]))))
     t0 = time.perf_counter()

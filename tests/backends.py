@@ -38,6 +38,13 @@ def emu_lib():
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
         L.emu_prepare.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
+        L.emu_prepare_plan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
+        L.emu_bias_partials_size.restype = C.c_uint64
+        L.emu_bias_partials_size.argtypes = [C.c_void_p]
+        L.emu_bias_partials.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.emu_prepare_normalization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_prepare_sys_errors.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.emu_prepare_finish.argtypes = [C.c_void_p]
         L.emu_get_info.argtypes = [C.c_void_p, C.POINTER(EmuInfo)]
         L.emu_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_get_norm_by_len.argtypes = [C.c_void_p, C.c_void_p]
@@ -83,6 +90,30 @@ class EmuBackend:
 
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
         _ok(self.L.emu_prepare(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))
+        return self.info()
+
+    # the pre-pass of one rank of a sharded job, as api.Simulator offers it
+    def prepare_plan(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+        _ok(self.L.emu_prepare_plan(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))
+        return self.info()
+
+    def bias_partials(self, block_lo, block_hi):
+        n = self.L.emu_bias_partials_size(self.h)
+        sums, maxes = np.zeros(n), np.zeros(n)
+        _ok(self.L.emu_bias_partials(self.h, block_lo, block_hi, sums.ctypes.data, maxes.ctypes.data))
+        return sums, maxes
+
+    def prepare_normalization(self, sums, maxes):
+        sums, maxes = np.ascontiguousarray(sums, np.float64), np.ascontiguousarray(maxes, np.float64)
+        _ok(self.L.emu_prepare_normalization(self.h, sums.ctypes.data, maxes.ctypes.data))
+
+    def prepare_sys_errors(self, block_lo, block_hi, in_state):
+        i, o = np.asarray(in_state, np.uint32), np.zeros(2, np.uint32)
+        _ok(self.L.emu_prepare_sys_errors(self.h, block_lo, block_hi, i.ctypes.data, o.ctypes.data))
+        return [int(o[0]), int(o[1])]
+
+    def prepare_finish(self):
+        _ok(self.L.emu_prepare_finish(self.h))
         return self.info()
 
     def info(self):
@@ -255,6 +286,24 @@ class GpuBackend:
 
     def error_model_fastq(self, rec, ids, first_index=0):
         return self.sim.error_model_fastq(rec, ids, first_index)
+
+    # the pre-pass of one rank of a sharded job
+    def prepare_plan(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+        self.sim.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        return self.info()
+
+    def bias_partials(self, lo, hi):
+        return self.sim.bias_partials(lo, hi)
+
+    def prepare_normalization(self, sums, maxes):
+        self.sim.prepare_normalization(sums, maxes)
+
+    def prepare_sys_errors(self, lo, hi, in_state):
+        return self.sim.prepare_sys_errors(lo, hi, in_state)
+
+    def prepare_finish(self):
+        self.sim.prepare_finish()
+        return self.info()
 
     def close(self):
         self.sim.close()

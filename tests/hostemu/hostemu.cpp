@@ -35,8 +35,18 @@ struct HostUploader : Uploader {
     }
 };
 
+// the chunks of a chain run and what lives between the calls of the sharded pre-pass (rsq_sim::ChainRun)
+struct ChainRun {
+    std::vector<Chain> chains;
+    std::vector<uint32_t> chunk_chain, used, out[2];
+    ShardEdges edges;
+    uint32_t passes = 0, block_lo = 0, block_hi = 0;
+    bool valid = false, pass_through = false;
+};
 struct Emu : SimState {
     HostUploader up;
+    BiasPlan bias_plan;                         // the sharded pre-pass: what lives between its calls
+    ChainRun chain_run;
     std::vector<FragmentVar> fvars;             // of the last emu_sieve call (variants of any kind), parallel to its fragments
     int fill_mode = -1;                         // -1: screened draws on the LDS image when the plan has one (as the product does); 0: double precision only
     std::vector<float> lds[2];                  // host stand-in for the LDS image of each template segment
@@ -95,14 +105,15 @@ int guard(F &&f) {
 
 // the reduction order of k_sum_bias: lanes own runs of kBiasRun starts, a block tree-reduces kBiasBlock lanes,
 // the host adds the block partials in order
-void sum_bias_like_kernel(const Emu &s, const BiasParam &p, double &sum_out, double &max_out) {
+// k_sum_bias: the chunks of one parameter whose first start position lies in the share [g_lo, g_hi); sums / maxes: the parameter's row of bias_chunks entries
+void sum_bias_like_kernel(const Emu &s, const BiasParam &p, uint32_t gx, uint64_t g_lo, uint64_t g_hi, double *sums, double *maxes) {
     const uint32_t L = s.seq_len[p.seq];
-    const uint64_t wo = s.seq_word_off[p.seq];
+    const uint64_t wo = s.seq_word_off[p.seq], bo = s.seq_base_off[p.seq];
     const uint32_t n_starts = L - p.len + 1;
-    const uint32_t blocks = cdiv(n_starts, kBiasBlock * kBiasRun);
-    sum_out = 0.0;
-    max_out = 0.0;
-    for (uint32_t b = 0; b < blocks; ++b) {
+    for (uint32_t b = 0; b < gx; ++b) {
+        sums[b] = maxes[b] = 0.0;
+        const uint64_t chunk_at = bo + (uint64_t)b * kBiasBlock * kBiasRun;
+        if (chunk_at < g_lo || chunk_at >= g_hi) continue;
         double ls[kBiasBlock], lm[kBiasBlock];
         for (uint32_t t = 0; t < kBiasBlock; ++t) {
             const uint32_t first = (b * kBiasBlock + t) * kBiasRun;
@@ -125,36 +136,37 @@ void sum_bias_like_kernel(const Emu &s, const BiasParam &p, double &sum_out, dou
                 ls[t] += ls[t + d];
                 lm[t] = lm[t + d] > lm[t] ? lm[t + d] : lm[t];
             }
-        sum_out += ls[0];
-        max_out = std::max(max_out, lm[0]);
+        sums[b] = ls[0];
+        maxes[b] = lm[0];
     }
 }
+void bias_partials(const Emu &s, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
+    const uint32_t gx = bias_chunks(plan);
+    h_sum.assign((size_t)gx * plan.params.size(), 0.0);
+    h_max.assign(h_sum.size(), 0.0);
+    for (size_t i = 0; i < plan.params.size(); ++i) sum_bias_like_kernel(s, plan.params[i], gx, g_lo, g_hi, &h_sum[i * gx], &h_max[i * gx]);
+}
 
-uint32_t run_chains(Emu &s, ChainSet set) {
-    std::vector<Chain> chains;
-    std::vector<uint32_t> chunk_chain;
-    build_chains(s, set, chains, chunk_chain);
-    const uint32_t n = (uint32_t)chunk_chain.size();
-    if (!n) return 0;
-    std::vector<uint32_t> used(n, 0), out[2] = {std::vector<uint32_t>(n, 0), std::vector<uint32_t>(n, 0)};
-    uint32_t pass = 0;
-    for (;; ++pass) {                                      // same pass structure as k_sys_chain + run_sys_chains
+void iterate_chains(Emu &s, ChainRun &run, uint32_t first_pass) {
+    const uint32_t n = (uint32_t)run.chunk_chain.size();
+    uint32_t pass = first_pass;
+    for (;; ++pass) {                                      // same pass structure as k_sys_chain + iterate_sys_chains
         bool changed = false;
-        const std::vector<uint32_t> &prev = out[(pass + 1) & 1];
-        std::vector<uint32_t> &cur = out[pass & 1];
+        const std::vector<uint32_t> &prev = run.out[(pass + 1) & 1];
+        std::vector<uint32_t> &cur = run.out[pass & 1];
         for (uint32_t c = 0; c < n; ++c) {
-            const Chain &ch = chains[chunk_chain[c]];
+            const Chain &ch = run.chains[run.chunk_chain[c]];
             const uint32_t local = c - ch.first_chunk;
             uint32_t want = local == 0 ? ch.in_state : 0u;
             if (pass > 0) {
                 if (local) want = prev[c - 1];
-                if (want == used[c]) {
+                if (want == run.used[c]) {
                     cur[c] = prev[c];
                     continue;
                 }
                 changed = true;
             }
-            used[c] = want;
+            run.used[c] = want;
             ChainAcc acc{s.dev.ref_words, ch.kind, ch.len, ch.kind < 2 ? s.seq_word_off[ch.id] : 0,
                          ch.kind == 2 ? s.dev.adapters[ch.seg].seqs + s.dev.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
             uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
@@ -164,7 +176,22 @@ uint32_t run_chains(Emu &s, ChainSet set) {
         }
         if (pass > 0 && !changed) break;
     }
-    return pass + 1;
+    run.passes = pass + 1;
+}
+uint32_t run_chains(Emu &s, ChainSet set, ChainRun &run, const ShardRange *range = nullptr) {
+    run = ChainRun{};
+    build_chains(s, set, run.chains, run.chunk_chain, range, &run.edges);
+    const uint32_t n = (uint32_t)run.chunk_chain.size();
+    if (!n) return 0;
+    run.used.assign(n, 0);
+    run.out[0].assign(n, 0);
+    run.out[1].assign(n, 0);
+    iterate_chains(s, run, 0);
+    return run.passes;
+}
+uint32_t run_chains(Emu &s, ChainSet set) {
+    ChainRun run;
+    return run_chains(s, set, run);
 }
 
 struct Raw {                              // one read alone: word columns of pitch 1
@@ -230,13 +257,81 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
         plan_simulation(s, s.up, seed, num_pairs, coverage, ref_bias_mode, base_identifier);
         if (s.has_ref) {
             const BiasPlan plan = plan_bias_normalization(s, s.up);
-            std::vector<double> sums(plan.params.size()), maxes(plan.params.size());
-            for (size_t i = 0; i < plan.params.size(); ++i) sum_bias_like_kernel(s, plan.params[i], sums[i], maxes[i]);
-            finish_bias_normalization(s, plan, sums, maxes);
-            upload_normalization(s, s.up);
+            std::vector<double> h_sum, h_max;
+            bias_partials(s, plan, 0, UINT64_MAX, h_sum, h_max);
+            normalization_from_partials(s, s.up, plan, h_sum.data(), h_max.data());
         }
         s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters);
         build_variant_sys_errors(s, s.up);
+        s.build_lds();
+        s.prepared = true;
+    });
+}
+
+// the sharded pre-pass: host mirror of rsq_sim_prepare_plan / rsq_sim_bias_partials / rsq_sim_prepare_normalization / rsq_sim_prepare_sys_errors /
+// rsq_sim_prepare_finish (rsq_sim.hip), same shared host code (shard_range, build_chains with a range, normalization_from_partials)
+int emu_prepare_plan(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        if (!s.has_ref || s.has_variants) throw Error("the sharded pre-pass needs a reference without variants");
+        s.prepared = false;
+        plan_simulation(s, s.up, seed, num_pairs, coverage, ref_bias_mode, base_identifier);
+        s.bias_plan = plan_bias_normalization(s, s.up);
+        s.chain_run = ChainRun{};
+    });
+}
+uint64_t emu_bias_partials_size(void *h) {
+    Emu &s = *static_cast<Emu *>(h);
+    return (uint64_t)bias_chunks(s.bias_plan) * s.bias_plan.params.size();
+}
+int emu_bias_partials(void *h, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        const ShardRange r = shard_range(s, block_lo, block_hi);
+        std::vector<double> h_sum, h_max;
+        bias_partials(s, s.bias_plan, r.g_lo, r.g_lo < r.g_hi ? r.g_hi : r.g_lo, h_sum, h_max);
+        memcpy(sums, h_sum.data(), h_sum.size() * 8);
+        memcpy(maxes, h_max.data(), h_max.size() * 8);
+    });
+}
+int emu_prepare_normalization(void *h, const double *sums, const double *maxes) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] { normalization_from_partials(s, s.up, s.bias_plan, sums, maxes); });
+}
+int emu_prepare_sys_errors(void *h, uint32_t block_lo, uint32_t block_hi, const uint32_t *in_state, uint32_t *out_state) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        out_state[0] = in_state[0];
+        out_state[1] = in_state[1];
+        ChainRun &run = s.chain_run;
+        if (!(run.valid && run.block_lo == block_lo && run.block_hi == block_hi)) {
+            const ShardRange r = shard_range(s, block_lo, block_hi);
+            s.passes = run_chains(s, kChainsSimulation, run, &r);
+            run.block_lo = block_lo;
+            run.block_hi = block_hi;
+            run.pass_through = r.first_seq < 0;
+            run.valid = true;
+        }
+        if (run.pass_through || run.chunk_chain.empty()) return;
+        bool replaced = false;
+        const int in_chain[2] = {run.edges.fwd_in_chain, run.edges.rev_in_chain};
+        for (int k = 0; k < 2; ++k)
+            if (in_chain[k] >= 0 && run.chains[(size_t)in_chain[k]].in_state != in_state[k]) {
+                run.chains[(size_t)in_chain[k]].in_state = in_state[k];
+                replaced = true;
+            }
+        if (replaced) {
+            iterate_chains(s, run, run.passes);
+            s.passes = run.passes;
+        }
+        const int64_t out_chunk[2] = {run.edges.fwd_out_chunk, run.edges.rev_out_chunk};
+        for (int k = 0; k < 2; ++k) out_state[k] = out_chunk[k] >= 0 ? run.out[(run.passes - 1) & 1][(size_t)out_chunk[k]] : 0u;
+    });
+}
+int emu_prepare_finish(void *h) {
+    Emu &s = *static_cast<Emu *>(h);
+    return guard([&] {
+        if (!s.chain_run.valid) throw Error("the sharded pre-pass has not run");
         s.build_lds();
         s.prepared = true;
     });

@@ -154,6 +154,33 @@ def case_sieve_dense_thresholds(backend_cls, workdir):
         p.close()
 
 
+def case_sharded_prepare(backend_cls, workdir, world=3):
+    """the pre-passes of a sharded job (rsq_sim_prepare_plan .. rsq_sim_prepare_finish, sharding.sharded_prepare_in_process): `world` simulators
+    each compute their share; thresholds equal a whole pre-pass exactly, and every rank's block range simulates to the whole simulator's text"""
+    from reseq_amd import sharding
+    lengths = [9400, 80, 3210, 1000]
+    ppath, fpath, seqs = make_inputs(workdir, "shardprep", synth.TINY, lengths)
+    whole = backend_cls(ppath, fpath)
+    ranks = [backend_cls(ppath, fpath) for _ in range(world)]
+    try:
+        winfo = whole.prepare(23, 20000, 0.0, 1, "Pre")
+        for b in ranks:
+            b.seq_len = lengths
+            b.ref_seq_bias_ = b.ref_seq_bias
+            b.ref_seq_bias = lambda b=b: b.ref_seq_bias_(len(lengths))
+        infos, ranges, rounds = sharding.sharded_prepare_in_process(ranks, 23, 20000, 0.0, 1, "Pre")
+        assert rounds >= 2 and all(lo < hi for lo, hi in ranges)
+        for b, info, (lo, hi) in zip(ranks, infos, ranges):
+            assert info["total_pairs"] == winfo["total_pairs"]
+            assert np.array_equal(b.thresholds(), whole.thresholds())
+            got, want = b.pairs(lo, hi), whole.pairs(lo, hi)
+            assert len(got[0]) == len(want[0]) > 0 and got[1] == want[1] and got[2] == want[2]
+    finally:
+        whole.close()
+        for b in ranks:
+            b.close()
+
+
 def case_profile_from_reseq_archive(backend_cls, workdir):
     """the product reads the profile from `.reseq` + `.reseq.ipf` Boost text archives (rsq_profile_archive.cpp), the oracle from the
     RSQP container those were made from: pre-pass results, fragments and FASTQ text must not differ"""

@@ -223,6 +223,10 @@ def test_simulate_module_equals_cli(workdir):
     assert b":0:Adapter:0:" in open(a1, "rb").read()
 
 
+def test_sharded_pre_passes(workdir):
+    P.case_sharded_prepare(GpuBackend, workdir)
+
+
 def test_sieve_with_dense_thresholds(workdir):
     P.case_sieve_dense_thresholds(GpuBackend, workdir)
 

@@ -141,6 +141,10 @@ def test_methylation(workdir):
     P.case_methylation(EmuBackend, workdir)
 
 
+def test_sharded_pre_passes(workdir):
+    P.case_sharded_prepare(EmuBackend, workdir)
+
+
 def test_sieve_with_dense_thresholds(workdir):
     P.case_sieve_dense_thresholds(EmuBackend, workdir)
 

@@ -35,10 +35,20 @@ class Emu:                      # the host emulation behind the interface simula
     def __init__(self, ppath, fpath, seqs, vcf=None):
         self.b = EmuBackend(ppath, fpath, 0, None, vcf_path=vcf) if vcf else EmuBackend(ppath, fpath, 0)
         self.seq_len = [len(c) for _, c in seqs]
-    def prepare(self, *a):
-        i = self.b.prepare(*a)
         self.n_seqs = len(self.seq_len)
-        return i
+        self.can_shard_prepare = vcf is None
+    def prepare(self, *a):
+        return self.b.prepare(*a)
+    def prepare_plan(self, *a):
+        return self.b.prepare_plan(*a)
+    def bias_partials(self, lo, hi):
+        return self.b.bias_partials(lo, hi)
+    def prepare_normalization(self, sums, maxes):
+        self.b.prepare_normalization(sums, maxes)
+    def prepare_sys_errors(self, lo, hi, in_state):
+        return self.b.prepare_sys_errors(lo, hi, in_state)
+    def prepare_finish(self):
+        return self.b.prepare_finish()
     def ref_seq_bias(self):
         return self.b.ref_seq_bias(self.n_seqs)
     def pairs(self, lo, hi):
@@ -144,3 +154,84 @@ def test_two_ranks_over_gloo_reproduce_the_single_rank_output(workdir):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se.decode()[-3000:]
     assert b"SHARDING_OK" in outs[0][0]
+
+
+PREPASS_WORKER = r"""
+import os, sys, pathlib
+sys.path.insert(0, os.environ["RSQ_TESTS"]); sys.path.insert(0, os.environ["RSQ_ROOT"])
+import numpy as np
+import torch.distributed as dist
+import parity_cases as P
+from backends import EmuBackend
+from reseq_amd import sharding, synth
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["RSQ_PORT"], rank=rank, world_size=world)
+work = pathlib.Path(os.environ["RSQ_WORK"]) / f"pre{rank}"
+work.mkdir(parents=True, exist_ok=True)
+lengths = [9400, 80, 3210, 1000]                 # one sequence spans several ranks, one is too short for blocks, one is a single block
+ppath, fpath, seqs = P.make_inputs(work, "prepass", synth.TINY, lengths)
+
+class B:                                          # the interface sharding.sharded_prepare drives
+    def __init__(self):
+        self.b = EmuBackend(ppath, fpath, 0)
+        self.seq_len = lengths
+        self.states = []
+    def ref_seq_bias(self):
+        return self.b.ref_seq_bias(len(lengths))
+    def prepare_sys_errors(self, lo, hi, in_state):
+        out = self.b.prepare_sys_errors(lo, hi, in_state)
+        self.states.append((list(in_state), out))
+        return out
+    def __getattr__(self, name):
+        return getattr(self.b, name)
+
+b = B()
+info, (lo, hi), rounds = sharding.sharded_prepare(b, dist, "cpu", rank, world, 23, 20000, 0.0, 1, "Pre")
+whole = EmuBackend(ppath, fpath, 0)
+winfo = whole.prepare(23, 20000, 0.0, 1, "Pre")
+assert info["total_pairs"] == winfo["total_pairs"] and info["bias_normalization"] == winfo["bias_normalization"]
+assert np.array_equal(b.b.thresholds(), whole.thresholds()) and np.array_equal(b.b.norm_by_len(), whole.norm_by_len())
+# the tracks over the positions the rank's reads can touch
+first_block, covered = 1, 0
+for seq, L in enumerate(lengths):
+    if L < info["insert_to"]:
+        continue
+    nb = (L + 999) // 1000
+    blo, bhi = max(first_block, lo), min(first_block + nb, hi)
+    if blo < bhi:
+        p_lo, t_hi = (blo - first_block) * 1000, min(L, min(L, (bhi - first_block) * 1000) + info["insert_to"])
+        for strand in (0, 1):
+            mine, ref = b.b.sys_errors(strand, seq, L), whole.sys_errors(strand, seq, L)
+            sl = slice(p_lo, t_hi) if strand == 0 else slice(L - t_hi, L - p_lo)      # the reverse track is indexed L-1-position
+            assert np.array_equal(mine[0][sl], ref[0][sl]) and np.array_equal(mine[1][sl], ref[1][sl]), (rank, seq, strand)
+            covered += t_hi - p_lo
+    first_block += nb
+entered = [s[0] for s in b.states]
+summary = [None] * world
+dist.all_gather_object(summary, dict(rank=rank, range=(lo, hi), rounds=rounds, covered=covered, nonzero_in=any(any(e) for e in entered), calls=len(b.states)))
+if rank == 0:
+    assert all(s["covered"] > 0 for s in summary) and any(s["nonzero_in"] for s in summary), summary
+    assert max(s["rounds"] for s in summary) >= 2, summary
+    print("PREPASS_OK", summary)
+whole.close(); b.b.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+def test_sharded_pre_passes_equal_the_whole_pre_pass(workdir):
+    """four ranks over gloo: every rank computes its share of the bias sums and of the systematic-error chains (sharding.sharded_prepare);
+    thresholds and normalisation equal a whole-genome pre-pass exactly, the tracks equal it over every position the rank's reads can touch,
+    and chain states did cross shard borders"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RSQ_TESTS=str(HERE), RSQ_ROOT=str(HERE.parent), RSQ_WORK=str(workdir), RSQ_PORT=str(port), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, "-c", PREPASS_WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(4)]
+    outs = [p.communicate(timeout=800) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-3000:]
+    assert b"PREPASS_OK" in outs[0][0], outs[0][0][-2000:]
