@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
 // The surrounding factors of Reference::Bias depend on one position each (the start, or the end, of the fragment) and are shared by
 // every sampled fragment length: computed once per position (3 table lookups in the 24 MB sur_bias table and an exp each), they turn
 // k_sum_bias from a random-access kernel into a streaming one.  Same function, same values, same product order.
-// [w_lo, w_hi): the part of the concatenated sequences that is needed (a sharded job computes its share)
+// [w_lo, w_hi): the part of the concatenated sequences that is needed (a sharded job computes its share); the tracks begin at w_lo
 __global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, double *start_bias, double *end_bias, uint64_t w_lo, uint64_t w_hi) {
     const uint32_t seq = blockIdx.y, L = S.seq_len[seq];
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,26 +154,27 @@ __global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, doubl
     if (at < w_lo || at >= w_hi) return;
     uint32_t sur[3];
     surrounding_forward(S.ref_words, wo, L, pos, sur);
-    start_bias[at] = surrounding_bias(S.sur_bias, sur);
+    start_bias[at - w_lo] = surrounding_bias(S.sur_bias, sur);
     surrounding_reverse(S.ref_words, wo, L, pos, sur);
-    end_bias[at] = surrounding_bias(S.sur_bias, sur);
+    end_bias[at - w_lo] = surrounding_bias(S.sur_bias, sur);
 }
 
 // One workgroup = one chunk of kBiasBlock * kBiasRun start positions of one (sequence, sampled length).  A chunk belongs to the share
 // [g_lo, g_hi) of the concatenated sequences its first start position lies in; the other chunks' partial results stay zero (the
 // ranks of a sharded job add their arrays up: every entry is non-zero on one rank, so the sum is exact whatever the order).
-__global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *params, const double *start_bias, const double *end_bias, double *partial_sum,
-                                                 double *partial_max, uint64_t g_lo, uint64_t g_hi) {
+__global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *params, const uint32_t *chunk_param, const uint32_t *chunk_ptr, const double *start_bias,
+                                                 const double *end_bias, uint64_t track_base, double *partial_sum, double *partial_max, uint64_t g_lo, uint64_t g_hi) {
     __shared__ double s_sum[kBiasBlock];
     __shared__ double s_max[kBiasBlock];
-    const BiasParam p = params[blockIdx.y];
+    const uint32_t param = chunk_param[blockIdx.x], chunk = blockIdx.x - chunk_ptr[param];
+    const BiasParam p = params[param];
     const uint32_t L = S.seq_len[p.seq];
     const uint64_t wo = S.seq_word_off[p.seq];
     const uint32_t n_starts = L - p.len + 1;                       // start positions 0 .. L-len (Reference.cpp:645)
-    const uint64_t bo = S.seq_base_off[p.seq];
-    const uint64_t chunk_at = bo + (uint64_t)blockIdx.x * kBiasBlock * kBiasRun;
+    const uint64_t chunk_at = S.seq_base_off[p.seq] + (uint64_t)chunk * kBiasBlock * kBiasRun;
     if (chunk_at < g_lo || chunk_at >= g_hi) return;
-    const uint32_t first = (blockIdx.x * kBiasBlock + threadIdx.x) * kBiasRun;
+    const uint64_t bo = S.seq_base_off[p.seq] - track_base;        // the tracks begin at track_base of the concatenated sequences
+    const uint32_t first = (chunk * kBiasBlock + threadIdx.x) * kBiasRun;
     double sum = 0.0, mx = 0.0;
     if (first < n_starts) {
         const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
@@ -197,8 +198,8 @@ __global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *par
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partial_sum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s_sum[0];
-        partial_max[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s_max[0];
+        partial_sum[blockIdx.x] = s_sum[0];
+        partial_max[blockIdx.x] = s_max[0];
     }
 }
 

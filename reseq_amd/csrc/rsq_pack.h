@@ -1086,6 +1086,8 @@ struct BiasPlan {
     std::vector<uint32_t> sample;           // insert_length_spline.sample_positions_
     std::vector<BiasParam> params;          // FillParamsSimulation order (:2185-2200)
     uint32_t max_starts = 0;
+    // the bias sums run in chunks of kBiasBlock * kBiasRun start positions: chunks [chunk_ptr[i], chunk_ptr[i + 1]) belong to params[i]
+    std::vector<uint32_t> chunk_ptr, chunk_param;
 };
 
 inline BiasPlan plan_bias_normalization(SimState &s, Uploader &up) {
@@ -1116,6 +1118,13 @@ inline BiasPlan plan_bias_normalization(SimState &s, Uploader &up) {
                 plan.params.push_back(BiasParam{ref_id, fl, s.ref_seq_bias[ref_id] * p.insert_lengths_bias[fl]});
                 plan.max_starts = std::max(plan.max_starts, s.seq_len[ref_id] - fl + 1);
             }
+    }
+    plan.chunk_ptr.assign(1, 0);
+    for (size_t i = 0; i < plan.params.size(); ++i) {
+        const uint32_t chunks = cdiv(s.seq_len[plan.params[i].seq] - plan.params[i].len + 1, kBiasBlock * kBiasRun);
+        if ((uint64_t)plan.chunk_ptr.back() + chunks > 0xFFFFFFF0ull) throw Error("too many chunks of start positions for the bias normalisation");
+        plan.chunk_param.insert(plan.chunk_param.end(), chunks, (uint32_t)i);
+        plan.chunk_ptr.push_back(plan.chunk_ptr.back() + chunks);
     }
     return plan;
 }
@@ -1184,17 +1193,16 @@ inline void upload_normalization(SimState &s, Uploader &up) {
     s.dev.gap_seg_end = up.put(seg_end);
 }
 
-// ---- the bias sums in chunks (k_sum_bias): kBiasBlock * kBiasRun start positions per chunk, bias_chunks chunks per parameter, layout
-// [parameter][chunk].  The chunks' partial sums are combined in chunk order -- the same additions whoever computed the chunks, one GPU or
-// the ranks of a sharded job -- and the arithmetic after SumBias follows.
-inline uint32_t bias_chunks(const BiasPlan &plan) { return cdiv(plan.max_starts, kBiasBlock * kBiasRun); }
+// ---- the bias sums in chunks (k_sum_bias): kBiasBlock * kBiasRun start positions per chunk, the chunks of a parameter next to each
+// other (BiasPlan::chunk_ptr).  The chunks' partial sums are combined in chunk order -- the same additions whoever computed the chunks,
+// one GPU or the ranks of a sharded job -- and the arithmetic after SumBias follows.
+inline uint32_t bias_chunks(const BiasPlan &plan) { return plan.chunk_ptr.empty() ? 0u : plan.chunk_ptr.back(); }
 inline void normalization_from_partials(SimState &s, Uploader &up, const BiasPlan &plan, const double *h_sum, const double *h_max) {
-    const uint32_t gx = bias_chunks(plan);
     std::vector<double> sums(plan.params.size(), 0.0), maxes(plan.params.size(), 0.0);
     for (size_t i = 0; i < plan.params.size(); ++i)
-        for (uint32_t b = 0; b < gx; ++b) {
-            sums[i] += h_sum[i * gx + b];
-            maxes[i] = std::max(maxes[i], h_max[i * gx + b]);
+        for (uint32_t b = plan.chunk_ptr[i]; b < plan.chunk_ptr[i + 1]; ++b) {
+            sums[i] += h_sum[b];
+            maxes[i] = std::max(maxes[i], h_max[b]);
         }
     finish_bias_normalization(s, plan, sums, maxes);
     upload_normalization(s, up);

@@ -178,34 +178,37 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const S
 // FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization; the SumBias scans (Reference.cpp:622-659) run on
 // the GPU, one launch for all (sequence, sampled length) pairs; partial sums are combined in a fixed order.
 constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
-// partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each) whose first start position lies in the share
-// [g_lo, g_hi) of the concatenated sequences; zero elsewhere.  Layout [parameter][chunk], gx chunks per parameter.
+// partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each, BiasPlan::chunk_ptr) whose first start position lies in
+// the share [g_lo, g_hi) of the concatenated sequences; zero elsewhere
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
-    const uint32_t gx = bias_chunks(plan);
-    h_sum.assign((size_t)gx * plan.params.size(), 0.0);
-    h_max.assign(h_sum.size(), 0.0);
-    if (plan.params.empty()) return;
-    DevBuf d_params, d_sum, d_max, d_start_bias, d_end_bias;
+    const uint32_t n_chunks = bias_chunks(plan);
+    h_sum.assign(n_chunks, 0.0);
+    h_max.assign(n_chunks, 0.0);
+    if (!n_chunks) return;
+    DevBuf d_params, d_chunk_param, d_chunk_ptr, d_sum, d_max, d_start_bias, d_end_bias;
     d_params.upload(plan.params);
+    d_chunk_param.upload(plan.chunk_param);
+    d_chunk_ptr.upload(plan.chunk_ptr);
+    // the share's chunks read start positions up to a chunk behind g_hi and end positions a fragment length further
+    const uint64_t w_lo = std::min<uint64_t>(g_lo, s.total_ref_size);
+    const uint64_t w_hi = g_hi == UINT64_MAX ? s.total_ref_size : std::min<uint64_t>(s.total_ref_size, g_hi + (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to);
     double *start_bias = nullptr, *end_bias = nullptr;
-    if (s.total_ref_size * 16 <= kSurroundingTrackBytesMax) {      // 16 bytes per base: 50 GB for a human genome, of 288 GB
-        d_start_bias.reserve(s.total_ref_size * 8 + 16);
-        d_end_bias.reserve(s.total_ref_size * 8 + 16);
+    if ((w_hi - w_lo) * 16 <= kSurroundingTrackBytesMax) {         // 16 bytes per base of the share: 50 GB for a whole human genome, of 288 GB
+        d_start_bias.reserve((w_hi - w_lo) * 8 + 16);
+        d_end_bias.reserve((w_hi - w_lo) * 8 + 16);
         start_bias = d_start_bias.as<double>();
         end_bias = d_end_bias.as<double>();
         uint32_t longest = 0;
         for (uint32_t L : s.seq_len) longest = std::max(longest, L);
-        // the share's chunks read start positions up to a chunk behind g_hi and end positions a fragment length further
-        const uint64_t w_hi = g_hi == UINT64_MAX ? UINT64_MAX : g_hi + (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to;
-        hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias, g_lo, w_hi);
+        hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias, w_lo, w_hi);
         HIP_CHECK(hipGetLastError());
     }
-    d_sum.reserve(h_sum.size() * 8);
-    d_max.reserve(h_sum.size() * 8);
-    HIP_CHECK(hipMemsetAsync(d_sum.as<double>(), 0, h_sum.size() * 8, st));
-    HIP_CHECK(hipMemsetAsync(d_max.as<double>(), 0, h_sum.size() * 8, st));
-    hipLaunchKernelGGL(k_sum_bias, dim3(gx, (uint32_t)plan.params.size()), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), start_bias, end_bias, d_sum.as<double>(),
-                       d_max.as<double>(), g_lo, g_hi);
+    d_sum.reserve((size_t)n_chunks * 8);
+    d_max.reserve((size_t)n_chunks * 8);
+    HIP_CHECK(hipMemsetAsync(d_sum.as<double>(), 0, (size_t)n_chunks * 8, st));
+    HIP_CHECK(hipMemsetAsync(d_max.as<double>(), 0, (size_t)n_chunks * 8, st));
+    hipLaunchKernelGGL(k_sum_bias, dim3(n_chunks), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_chunk_param.as<uint32_t>(), d_chunk_ptr.as<uint32_t>(), start_bias,
+                       end_bias, w_lo, d_sum.as<double>(), d_max.as<double>(), g_lo, g_hi);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
@@ -857,7 +860,7 @@ int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, dou
 int rsq_sim_bias_partials(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes, size_t cap, size_t *n, void *stream) {
     REQUIRE(s && n, "null argument");
     REQUIRE(s->planned, "rsq_sim_prepare_plan must run first");
-    *n = (size_t)bias_chunks(s->bias_plan) * s->bias_plan.params.size();
+    *n = (size_t)bias_chunks(s->bias_plan);
     if (!sums && !maxes && !cap) return RSQ_OK;                     // the size query
     REQUIRE(sums && maxes && cap >= *n, "arrays too small");
     return guard([&] {
@@ -877,7 +880,7 @@ int rsq_sim_bias_partials(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, doub
 int rsq_sim_prepare_normalization(rsq_sim *s, const double *sums, const double *maxes, size_t n) {
     REQUIRE(s && sums && maxes, "null argument");
     REQUIRE(s->planned, "rsq_sim_prepare_plan must run first");
-    REQUIRE(n == (size_t)bias_chunks(s->bias_plan) * s->bias_plan.params.size(), "wrong number of partial sums");
+    REQUIRE(n == (size_t)bias_chunks(s->bias_plan), "wrong number of partial sums");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         normalization_from_partials(*s, s->up, s->bias_plan, sums, maxes);
@@ -931,7 +934,7 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
 }
 
 int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out) {
-    REQUIRE(s && out && s->prepared, "simulator not prepared");
+    REQUIRE(s && out && (s->prepared || s->planned), "simulator not prepared");      // the counts are known from rsq_sim_prepare_plan on
     out->total_pairs = s->total_pairs;
     out->adapter_only_pairs = s->adapter_only_pairs;
     out->total_blocks = s->total_blocks;
@@ -1008,7 +1011,7 @@ int rsq_sim_set_ref_bias_file(rsq_sim *s, const char *path) {
     return RSQ_OK;
 }
 int rsq_sim_get_ref_seq_bias(const rsq_sim *s, double *out, size_t n) {
-    REQUIRE(s && out && s->prepared && n == s->ref_seq_bias.size(), "bad arguments");
+    REQUIRE(s && out && (s->prepared || s->planned) && n == s->ref_seq_bias.size(), "bad arguments");
     memcpy(out, s->ref_seq_bias.data(), n * sizeof(double));
     return RSQ_OK;
 }

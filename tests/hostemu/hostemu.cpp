@@ -105,7 +105,7 @@ int guard(F &&f) {
 
 // the reduction order of k_sum_bias: lanes own runs of kBiasRun starts, a block tree-reduces kBiasBlock lanes,
 // the host adds the block partials in order
-// k_sum_bias: the chunks of one parameter whose first start position lies in the share [g_lo, g_hi); sums / maxes: the parameter's row of bias_chunks entries
+// k_sum_bias: the chunks of one parameter whose first start position lies in the share [g_lo, g_hi); sums / maxes: the parameter's gx chunks
 void sum_bias_like_kernel(const Emu &s, const BiasParam &p, uint32_t gx, uint64_t g_lo, uint64_t g_hi, double *sums, double *maxes) {
     const uint32_t L = s.seq_len[p.seq];
     const uint64_t wo = s.seq_word_off[p.seq], bo = s.seq_base_off[p.seq];
@@ -141,10 +141,11 @@ void sum_bias_like_kernel(const Emu &s, const BiasParam &p, uint32_t gx, uint64_
     }
 }
 void bias_partials(const Emu &s, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
-    const uint32_t gx = bias_chunks(plan);
-    h_sum.assign((size_t)gx * plan.params.size(), 0.0);
+    h_sum.assign(bias_chunks(plan), 0.0);
     h_max.assign(h_sum.size(), 0.0);
-    for (size_t i = 0; i < plan.params.size(); ++i) sum_bias_like_kernel(s, plan.params[i], gx, g_lo, g_hi, &h_sum[i * gx], &h_max[i * gx]);
+    for (size_t i = 0; i < plan.params.size(); ++i)
+        if (plan.chunk_ptr[i + 1] > plan.chunk_ptr[i])
+            sum_bias_like_kernel(s, plan.params[i], plan.chunk_ptr[i + 1] - plan.chunk_ptr[i], g_lo, g_hi, &h_sum[plan.chunk_ptr[i]], &h_max[plan.chunk_ptr[i]]);
 }
 
 void iterate_chains(Emu &s, ChainRun &run, uint32_t first_pass) {
@@ -282,7 +283,7 @@ int emu_prepare_plan(void *h, uint64_t seed, uint64_t num_pairs, double coverage
 }
 uint64_t emu_bias_partials_size(void *h) {
     Emu &s = *static_cast<Emu *>(h);
-    return (uint64_t)bias_chunks(s.bias_plan) * s.bias_plan.params.size();
+    return (uint64_t)bias_chunks(s.bias_plan);
 }
 int emu_bias_partials(void *h, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes) {
     Emu &s = *static_cast<Emu *>(h);
