@@ -5,6 +5,7 @@
 // (alias `replaceQuals`) applies the error and quality model to given sequences.  Profile creation (BAM statistics,
 // bias fit, IPF) is not part of this build: the flags are recognised and rejected with a clear message.
 #include <stdint.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,6 +96,30 @@ bool check(int rc, const char *what) {
     return false;
 }
 
+// numeric options: the whole value has to be a number (boost::program_options rejects anything else, main.cpp:1043-1060)
+bool parse_u64(const Args &a, const std::string &key, uint64_t &out) {
+    const std::string v = a.get(key, "");
+    char *end = nullptr;
+    errno = 0;
+    out = strtoull(v.c_str(), &end, 10);
+    if (v.empty() || *end || errno || v[0] == '-') {
+        ERR("the argument ('" << v << "') for option '--" << key << "' is invalid");
+        return false;
+    }
+    return true;
+}
+bool parse_double(const Args &a, const std::string &key, double &out) {
+    const std::string v = a.get(key, "");
+    char *end = nullptr;
+    errno = 0;
+    out = strtod(v.c_str(), &end);
+    if (v.empty() || *end || errno) {
+        ERR("the argument ('" << v << "') for option '--" << key << "' is invalid");
+        return false;
+    }
+    return true;
+}
+
 uint64_t get_seed(const Args &a) {                      // main.cpp:340: random seed if none is given
     if (a.has("seed")) return strtoull(a.get("seed").c_str(), nullptr, 10);
     std::random_device rd;
@@ -163,7 +188,7 @@ struct TextOut {
 };
 struct TextIn {                       // lines of a plain, gzip or bzip2 file, or of stdin
     rsq::textio::Reader r;
-    bool is_file = false;
+    bool is_file = false, failed = false;
     std::vector<char> buf = std::vector<char>(1 << 16);
     size_t at = 0, have = 0;
     bool open(const std::string &path) {
@@ -179,7 +204,14 @@ struct TextIn {                       // lines of a plain, gzip or bzip2 file, o
         line.clear();
         for (;;) {
             if (at == have) {
-                const int n = r.read(buf.data(), (unsigned)buf.size());
+                int n = 0;
+                try {
+                    n = r.read(buf.data(), (unsigned)buf.size());
+                } catch (const std::exception &e) {
+                    ERR(e.what());
+                    failed = true;
+                    return false;
+                }
                 if (n <= 0) return !line.empty();
                 at = 0;
                 have = (size_t)n;
@@ -359,11 +391,17 @@ int illumina_pe(const Args &a) {
         INFO("Reading methylation from file: " << a.get("methylation"));
         ok = check(rsq_sim_read_methylation(sim, a.get("methylation").c_str()), "Could not read methylation file");
     }
+    uint64_t num_reads = 0;
+    double coverage = 0.0;
+    if (ok && a.has("numReads") && a.has("coverage")) {          // main.cpp:783-786
+        ERR("numReads and coverage option are mutually exclusive. Specify the one or the other.");
+        ok = false;
+    }
+    if (ok && a.has("numReads")) ok = parse_u64(a, "numReads", num_reads);
+    if (ok && a.has("coverage")) ok = parse_double(a, "coverage", coverage);
     if (ok) {
         INFO("Preparing for simulation");
-        ok = check(rsq_sim_prepare(sim, seed, strtoull(a.get("numReads", "0").c_str(), nullptr, 10), atof(a.get("coverage", "0").c_str()), ref_bias_mode,
-                                   a.get("recordBaseIdentifier", "ReseqRead").c_str(), nullptr),
-                   "Preparation failed");
+        ok = check(rsq_sim_prepare(sim, seed, num_reads, coverage, ref_bias_mode, a.get("recordBaseIdentifier", "ReseqRead").c_str(), nullptr), "Preparation failed");
     }
     if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
     AsyncOut f1, f2;
@@ -691,7 +729,7 @@ int seq_to_illumina(const Args &a) {
             }
         }
         reader.join();
-        ok = ok && !reader.failed;
+        ok = ok && !reader.failed && !fin.failed;
         if (ok && !reader.any) {
             ERR(a.get("input", "stdin") << " does not contain any sequences.");
             ok = false;
@@ -838,6 +876,13 @@ int main(int argc, char **argv) {
     if (command.empty() || a.has("help")) {
         std::cerr << kUsage << std::endl;
         return command.empty() && !a.has("help") ? 1 : 0;
+    }
+    {                                                         // numeric options that several commands share
+        uint64_t u = 0;
+        double d = 0;
+        if ((a.has("seed") && !parse_u64(a, "seed", u)) || (a.has("errorMutliplier") && !parse_double(a, "errorMutliplier", d)) ||
+            (a.has("ipfPrecision") && !parse_double(a, "ipfPrecision", d)))
+            return 1;
     }
     if (command == "illuminaPE") return illumina_pe(a);
     if (command == "seqToIllumina" || command == "replaceQuals") return seq_to_illumina(a);

@@ -21,7 +21,13 @@
 
 namespace rsq {
 
+// Arrays are owned by the uploader in scopes: what is put at create time lives as long as the simulator; what a pre-pass puts
+// (block numbering, thresholds) is released when that pre-pass runs again, so that repeated rsq_sim_prepare / rsq_sim_set_normalization
+// calls on one simulator do not pile arrays up.
+enum UploadScope : int { kScopeCreate = 0, kScopePlan = 1, kScopeNormalization = 2, kUploadScopes = 3 };
 struct Uploader {                                   // copies a host array to wherever the kernels will read it
+    int current_scope = kScopeCreate;
+    virtual void release_scope(int scope) { (void)scope; }                        // frees what was put in the scope
     virtual void *put_bytes(const void *data, size_t bytes) = 0;
     virtual void write_bytes(void *dst, const void *src, size_t bytes) = 0;      // overwrite part of an array put earlier
     virtual void read_bytes(void *dst_host, const void *src, size_t bytes) = 0;   // read back what the pre-pass kernels wrote
@@ -32,6 +38,16 @@ struct Uploader {                                   // copies a host array to wh
         static const T kZero{};
         return static_cast<T *>(put_bytes(v.empty() ? &kZero : v.data(), (v.empty() ? 1 : v.size()) * sizeof(T)));
     }
+};
+
+struct ScopedUpload {                               // puts inside the block belong to `scope`; `fresh`: what the scope held before is released first
+    Uploader &up;
+    int before;
+    ScopedUpload(Uploader &u, int scope, bool fresh) : up(u), before(u.current_scope) {
+        if (fresh) up.release_scope(scope);
+        up.current_scope = scope;
+    }
+    ~ScopedUpload() { up.current_scope = before; }
 };
 
 struct SimState {
@@ -320,6 +336,7 @@ inline void pack_profile(SimState &s, Uploader &up) {
     std::vector<double> ocp = discrete_cp(p.overrun_bases, 4);           // Simulator.h:168: the N is dropped
     for (int i = 0; i < 4; ++i) d.overrun_cp[i] = ocp[i];
     d.insert_from = (uint32_t)std::max<uint64_t>(1, p.insert_lengths.from);       // Simulator.cpp:2300
+    if (p.insert_lengths.to() > 65536) throw Error("insert lengths above 65535 are not supported (fragment lengths are 16-bit fields of the sieve's records)");
     d.insert_to = (uint32_t)p.insert_lengths.to();
     std::vector<uint64_t> il(d.insert_to + 1, 0);
     std::vector<double> ilb(d.insert_to + 1, 0.0), gcb(101, 0.0);
@@ -702,6 +719,7 @@ inline double set_sys_gc_range(SimState &s) {
 }
 
 inline void plan_simulation(SimState &s, Uploader &up, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
+    const ScopedUpload scope(up, kScopePlan, true);
     const Profile &p = s.prof;
     s.seed = seed;
     s.dev.seed = seed;
@@ -1091,6 +1109,7 @@ struct BiasPlan {
 };
 
 inline BiasPlan plan_bias_normalization(SimState &s, Uploader &up) {
+    const ScopedUpload scope(up, kScopePlan, false);
     const Profile &p = s.prof;
     const uint32_t n_seqs = s.dev.n_seqs;
     BiasPlan plan;
@@ -1163,6 +1182,7 @@ inline void finish_bias_normalization(SimState &s, const BiasPlan &plan, const s
 }
 
 inline void upload_normalization(SimState &s, Uploader &up) {
+    const ScopedUpload scope(up, kScopeNormalization, true);
     s.dev.thresholds = up.put(s.thresholds);
     s.dev.bias_normalization = s.bias_normalization;
     // The sieve draws the gaps between the lengths whose cell passes the zero threshold instead of one uniform per cell (k_sieve_gaps,

@@ -61,6 +61,13 @@ class DevBuf {
 struct Timer {                                     // HIP events on the stream the kernels are launched on
     hipEvent_t a = nullptr, b = nullptr;
     bool used = false;
+    Timer() = default;
+    Timer(const Timer &) = delete;
+    Timer &operator=(const Timer &) = delete;
+    ~Timer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
     void start(hipStream_t st) {
         if (!a) {
             HIP_CHECK(hipEventCreate(&a));
@@ -95,14 +102,19 @@ struct rsq_ref {
 
 // arrays packed by rsq_pack.h go to HBM; they live as long as the simulator
 struct DeviceUploader : Uploader {
-    std::vector<std::unique_ptr<DevBuf>> owned;
+    std::vector<std::unique_ptr<DevBuf>> owned[kUploadScopes];
     int device = 0;
     void bind_thread() override { HIP_CHECK(hipSetDevice(device)); }
+    void release_scope(int scope) override {
+        HIP_CHECK(hipDeviceSynchronize());                         // nothing may still read what goes away
+        owned[scope].clear();
+    }
     void *put_bytes(const void *data, size_t bytes) override {
-        owned.emplace_back(new DevBuf());
-        owned.back()->reserve(bytes + 8);
-        HIP_CHECK(hipMemcpy(owned.back()->as<void>(), data, bytes, hipMemcpyHostToDevice));
-        return owned.back()->as<void>();
+        std::vector<std::unique_ptr<DevBuf>> &own = owned[current_scope];
+        own.emplace_back(new DevBuf());
+        own.back()->reserve(bytes + 8);
+        HIP_CHECK(hipMemcpy(own.back()->as<void>(), data, bytes, hipMemcpyHostToDevice));
+        return own.back()->as<void>();
     }
     void write_bytes(void *dst, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
     void read_bytes(void *dst_host, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost)); }

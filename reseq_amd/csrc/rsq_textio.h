@@ -60,8 +60,15 @@ struct Reader {                          // plain and gzip through zlib (it pass
         }
         return gz || bz;
     }
-    int read(void *buf, unsigned n) {    // bytes read, 0 at the end, < 0 on an error
-        return bz ? Bz2::get().read(bz, buf, (int)n) : gzread(gz, buf, n);
+    int read(void *buf, unsigned n) {    // bytes read, 0 at the end; a read error or a compressed stream that ends early throws
+        const int got = bz ? Bz2::get().read(bz, buf, (int)n) : gzread(gz, buf, n);
+        if (got < 0) throw std::runtime_error("read error in a compressed or plain text input");
+        if (!got && gz) {
+            int err = Z_OK;
+            gzerror(gz, &err);
+            if (err != Z_OK && err != Z_STREAM_END) throw std::runtime_error("gzip input ends in the middle of the stream (truncated file)");
+        }
+        return got;
     }
     void close() {
         if (gz) gzclose(gz);

@@ -21,17 +21,21 @@ using namespace rsq;
 namespace {
 
 struct HostUploader : Uploader {
-    std::vector<void *> owned;
+    std::vector<void *> owned[kUploadScopes];
+    void release_scope(int scope) override {
+        for (void *p : owned[scope]) free(p);
+        owned[scope].clear();
+    }
     void *put_bytes(const void *data, size_t bytes) override {
         void *p = malloc(bytes + 8);
         memcpy(p, data, bytes);
-        owned.push_back(p);
+        owned[current_scope].push_back(p);
         return p;
     }
     void write_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
     void read_bytes(void *dst_host, const void *src, size_t bytes) override { memcpy(dst_host, src, bytes); }
     ~HostUploader() override {
-        for (void *p : owned) free(p);
+        for (int scope = 0; scope < kUploadScopes; ++scope) release_scope(scope);
     }
 };
 

@@ -173,6 +173,26 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
         assert not out.exists()
 
 
+def test_cli_rejects_bad_numbers_and_contradicting_options(workdir):
+    """main.cpp:783-786 (numReads and coverage exclude each other) and values that are not numbers; a gzip reference that ends early"""
+    import gzip
+    import os
+    import subprocess
+    from reseq_amd import synth
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reseq_amd", "reseq")
+    ppath, fpath, _ = P.make_inputs(workdir, "cli_bad", synth.TINY, [4100])
+    base = [exe, "illuminaPE", "-R", fpath, "-s", ppath, "-1", str(workdir / "b1.fq"), "-2", str(workdir / "b2.fq")]
+    for extra, msg in ((["--numReads", "100", "--coverage", "3"], "mutually exclusive"), (["--numReads", "12x"], "is invalid"), (["--coverage", "abc"], "is invalid"),
+                       (["--numReads", "100", "--seed", "1e3"], "is invalid")):
+        r = subprocess.run(base + extra, capture_output=True)
+        assert r.returncode != 0 and msg.encode() in r.stderr, (extra, r.stderr)
+    whole = gzip.compress(open(fpath, "rb").read())
+    cut = str(workdir / "cut.fa.gz")
+    open(cut, "wb").write(whole[:len(whole) // 2])
+    r = subprocess.run([exe, "illuminaPE", "-R", cut, "-s", ppath, "-1", str(workdir / "b1.fq"), "-2", str(workdir / "b2.fq"), "--numReads", "100"], capture_output=True)
+    assert r.returncode != 0 and b"truncated" in r.stderr, r.stderr
+
+
 def test_methylation(workdir):
     P.case_methylation(GpuBackend, workdir)
 

@@ -10,8 +10,9 @@ from reseq_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-GENOME = 2_000_000
-PAIRS = 2_000_000
+GENOME = 4_641_652                             # BASELINE.json configs[1] at full size: E. coli-sized, 10 M pairs
+PAIRS = 10_000_000
+LENGTHS = [2_800_000, 500, GENOME - 2_800_000 - 500]
 
 
 @pytest.fixture(scope="module")
@@ -19,7 +20,7 @@ def world(tmp_path_factory):
     d = tmp_path_factory.mktemp("props")
     ppath, fpath = d / "p0.rsqp", d / "ref.fa"
     synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
-    seqs = synth.make_reference(4, [1_200_000, 500, 800_000 - 500], gc=0.45)       # a scaffold shorter than the longest insert in the middle
+    seqs = synth.make_reference(4, LENGTHS, gc=0.45)       # a scaffold shorter than the longest insert in the middle
     synth.write_fasta(fpath, seqs)
     prof = api.Profile(str(ppath))
     ref = api.Reference(str(fpath), 1)
@@ -46,12 +47,12 @@ def run(prof, ref, seed, batch_blocks):
 def test_batching_invariance_determinism_and_counts(world):
     prof, ref, seqs = world
     info, n_a, a1, a2, first = run(prof, ref, 11, 500)
-    _, n_b, b1, b2, _ = run(prof, ref, 11, 73)                 # other batch boundaries, same bytes
+    _, n_b, b1, b2, _ = run(prof, ref, 11, 173)                # other batch boundaries, same bytes
     assert (n_a, a1, a2) == (n_b, b1, b2)
     _, n_c, c1, _, _ = run(prof, ref, 12, 500)                 # another seed, other bytes, about the same count
     assert c1 != a1 and abs(n_c - n_a) < 0.01 * n_a
-    # 1200 + 800 blocks: the 500-base scaffold has no unit (Simulator.cpp:1159)
-    assert info.total_blocks == 1200 + 800
+    # the 500-base scaffold has no unit (Simulator.cpp:1159)
+    assert info.total_blocks == 2800 + (LENGTHS[2] + 999) // 1000
     assert abs(n_a - info.total_pairs) < 0.005 * info.total_pairs          # NB counts around the requested number
     fr, r1, r2 = first
     l1, l2 = r1.split(b"\n"), r2.split(b"\n")
@@ -67,4 +68,4 @@ def test_batching_invariance_determinism_and_counts(world):
     # fragments are sorted the way the reference's loops emit them: block, start, length
     key = fr["block"].astype(np.int64) * (1 << 40) + fr["start"].astype(np.int64) * (1 << 12) + fr["len"]
     assert np.all(np.diff(key) >= 0)
-    assert np.all(fr["start"] + fr["len"] < np.where(fr["seq"] == 0, 1_200_000, 800_000 - 500))
+    assert np.all(fr["start"] + fr["len"] < np.where(fr["seq"] == 0, LENGTHS[0], LENGTHS[2]))
