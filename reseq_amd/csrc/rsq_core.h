@@ -324,6 +324,22 @@ RSQ_HD uint32_t draw(const DevTable &t, const double *__restrict__ pool, Par0 pa
     return par0[t.par0_off + col];
 }
 
+// The same draw one column pair at a time: identical additions in identical order (the chunk size only groups the loads), a fraction of
+// the registers.  For the rare draws the read kernel's screen leaves open, where speed does not matter and registers do.
+template <int NM, class Par0>
+RSQ_HD uint32_t draw_slim(const DevTable &t, const double *__restrict__ pool, Par0 par0, const uint32_t (&idx)[NM], double u, double &prob_sum) {
+    prob_sum = 0.0;
+    if (!t.k) return 0;
+    const uint32_t kp = row_stride(t.k);
+    GlobalRow m[NM];
+#pragma unroll
+    for (int n = 0; n < NM; ++n) m[n].p = pool + t.off[n] + (size_t)clamp_row(t, n, idx[n]) * kp;
+    uint32_t col;
+    if constexpr (NM == 3) col = draw_rows<1>(t.k, u, prob_sum, m[0], m[1], m[2]);
+    else col = draw_rows<1>(t.k, u, prob_sum, m[0], m[1], m[2], m[3]);
+    return par0[t.par0_off + col];
+}
+
 // How FillRead reaches its tables.  GlobalTables reads descriptors and rows from HBM; the read kernel uses LdsTables
 // (rsq_kernels.h) which serves descriptors and the per-lane-varying margins from LDS.
 struct GlobalTables {

@@ -1357,7 +1357,7 @@ struct ScreenTables {
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
     RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], uint32_t word, double &ps) const {
-        return draw<NM>(t, S.pool, par0(), idx, u32_to_unit(word), ps);
+        return draw_slim<NM>(t, S.pool, par0(), idx, u32_to_unit(word), ps);
     }
     template <int NM>
     RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, const uint32_t (&idx)[NM], uint32_t u, double &ps) const {
@@ -1418,7 +1418,7 @@ struct ScreenTables {
         return settle<3>(decided, col, t, idx, u, ps);
     }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {     // once per read: double precision
-        return draw<3>(seq_quality(i), S.pool, par0(), idx, u32_to_unit(u), ps);
+        return draw_slim<3>(seq_quality(i), S.pool, par0(), idx, u32_to_unit(u), ps);
     }
 };
 
