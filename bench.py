@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=PAIRS, help="read pairs per GPU")
     ap.add_argument("--genome", type=int, default=GENOME, help="reference bases per GPU")
-    ap.add_argument("--batch-blocks", type=int, default=1200)
+    ap.add_argument("--batch-blocks", type=int, default=4800, help="blocks of 1000 start positions per rsq_sim_pairs call (4800: the whole E. coli-sized job in one call)")
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--gc", type=float, default=0.508, help="G+C fraction of the synthetic reference (E. coli: 0.508)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -305,10 +305,13 @@ def main():
         copy_stream = torch.cuda.Stream(device=dev)
         done = [torch.cuda.Event(), torch.cuda.Event()]
 
+        turn = [0]
+
         def host_step():
             moved = 0
-            for i, (lo, hi) in enumerate(batches):
-                k = i & 1
+            for lo, hi in batches:
+                k = turn[0] & 1                                         # the two buffer pairs alternate across batches and steps
+                turn[0] += 1
                 done[k].synchronize()                                   # the copy that last used this pair of buffers
                 n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[k][0], bufs[k][1])      # returns when the text is complete
                 if rc != api.RSQ_OK:

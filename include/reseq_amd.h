@@ -119,8 +119,8 @@ int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double c
  *                                   needs.  Called again with other in_state it redoes only what depends on them.  Ranks repeat: all-gather of
  *                                   out_state, take the neighbours' values, call again -- until no rank's in_state changed (at most world-1 rounds;
  *                                   states of unaffected chains are final after the first call).  A rank with an empty range passes in_state on.
- *   rsq_sim_prepare_finish          marks the simulator prepared.
- * Not available with variants loaded (their systematic errors fold over whole strands): use rsq_sim_prepare there. */
+ *   rsq_sim_prepare_finish          with variants: the systematic errors of the variants' bases inside the rank's share (their error-region state is
+ *                                   folded from the state the rank's chains were entered with); marks the simulator prepared. */
 int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier);
 int rsq_sim_bias_partials(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, double *sums, double *maxes, size_t cap, size_t *n, void *stream);
 int rsq_sim_prepare_normalization(rsq_sim *s, const double *sums, const double *maxes, size_t n);

@@ -144,7 +144,7 @@ RSQ_HD void prod_chunk(Pair (&p)[U], uint32_t base, const R0 &r0, const R1 &r1, 
 template <int U, class... Rs>
 RSQ_HD uint32_t draw_rows(uint32_t K, double u, double &prob_sum, const Rs &...rs) {
     const uint32_t nc = chunks_of(K, U);
-    Pair p[U];
+    Pair p[U] = {};
     double s = 0.0;
     for (uint32_t c = 0; c < nc; ++c) {            // pass 1: prob_sum, ascending columns
         prod_chunk<U>(p, c * U, rs...);

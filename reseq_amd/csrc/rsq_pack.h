@@ -841,8 +841,16 @@ struct HostDomMemory {                                                // Dominan
     }
 };
 
-// track: the strand's chain output (dom | rate << 8 per strand position).  Fills var_err_fwd / var_err_rev of the sequence's variants.
-inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track) {
+// The strand positions [lo, hi) a chain was run over and the chain state it was entered with (a rank of a sharded job runs a part of a
+// strand; the whole strand: {0, L, 0}).
+struct StrandWindow {
+    uint32_t lo, hi, in_state;
+};
+// track: the strand's chain output (dom | rate << 8 per strand position) from position w.lo on.  Fills var_err_fwd / var_err_rev of the
+// sequence's variants inside the window.  What a variant inherits from earlier variants (last base, dominant-base memories) reaches at
+// most five positions back, so the pass may begin at any variant that lies more than five positions behind its predecessor: the variants
+// between that one and the window only feed the memories.
+inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track, StrandWindow w) {
     const std::vector<uint8_t> &codes = s.ref_codes[seq];
     const uint32_t L = (uint32_t)codes.size(), A = s.num_alleles, range = s.dev.sys_gc_range;
     const DevVariant *vars = s.variants.data() + s.var_ptr[seq];
@@ -853,11 +861,26 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
     std::vector<uint32_t> last_sp(A, 0);
     std::vector<uint8_t> seen(A, 0), last_base_of(A, 4);
     std::vector<HostDomMemory> dom(A);
-    uint32_t dist = 0, start_rate = 0, folded = 0;                  // chain state before strand position `folded`
-    for (uint32_t k = 0; k < n; ++k) {
+    uint32_t dist = w.in_state & 0xFFFFFFu, start_rate = w.in_state >> 24, folded = w.lo;      // chain state before strand position `folded`
+    auto sp_of = [&](uint32_t k) { return reverse ? L - 1u - vars[n - 1u - k].pos : vars[k].pos; };
+    uint32_t k0 = 0;
+    {                                                               // the first variant inside the window, then back to a gap of more than five positions
+        uint32_t a = 0, b = n;
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (sp_of(mid) < w.lo) a = mid + 1u;
+            else b = mid;
+        }
+        k0 = a;
+        while (k0 > 0 && k0 < n && sp_of(k0 - 1u) + 5u >= sp_of(k0)) --k0;
+        if (k0 == n) return;
+    }
+    for (uint32_t k = k0; k < n; ++k) {
         const uint32_t var_id = reverse ? n - 1u - k : k;
         const DevVariant &v = vars[var_id];
         const uint32_t sp = reverse ? L - 1u - v.pos : v.pos, len = v.len;
+        if (sp >= w.hi) break;
+        const bool inside = sp >= w.lo;                            // in front of the window: the memories only
         auto var_base = [&](uint32_t j) -> uint32_t { return reverse ? 3u - s.var_bases[v.off + len - 1u - j] : s.var_bases[v.off + j]; };   // j-th base in the strand's order
         uint32_t chosen = 0;                                        // Variant::FirstAllele
         while (chosen < A && !((v.allele[chosen >> 6] >> (chosen & 63u)) & 1u)) ++chosen;
@@ -871,21 +894,23 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
             dom[chosen].clear();
             if (sp) dom[chosen].set(at, sp - 1u);
         }
-        for (; folded < sp; ++folded) update_distances(s.dev.reset_distance, dist, start_rate, track[folded] >> 8);
+        for (; inside && folded < sp; ++folded) update_distances(s.dev.reset_distance, dist, start_rate, track[folded - w.lo] >> 8);
         const uint32_t gc_bases = std::min(sp, range);
         uint32_t gc = 0;
-        for (uint32_t q = sp - gc_bases; q < sp; ++q) gc += is_gc(at(q));
+        for (uint32_t q = sp - gc_bases; inside && q < sp; ++q) gc += is_gc(at(q));
         const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};      // variants cannot start an error region: the same for all their bases
         for (uint32_t j = 0; j < len; ++j) {
             const uint32_t base = var_base(j);
             dom[chosen].update(base);
-            const Words w = philox(s.seed, var_id, seq, 4u + (reverse ? 1u : 0u), (kDomSysErr << 28) | j);
-            double ps;
-            uint32_t dom_error = draw<3>(s.host_dom_error[(base * 5u + last_base) * 5u + dom[chosen].dom], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(w.w0), ps);
-            if (0.0 == ps) dom_error = 4;
-            uint32_t rate = draw<3>(s.host_error_rate[base * 5u + dom_error], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(w.w1), ps);
-            if (0.0 == ps) rate = 0;
-            err[v.off + j] = (uint16_t)(dom_error | (rate << 8));
+            if (inside) {
+                const Words rw = philox(s.seed, var_id, seq, 4u + (reverse ? 1u : 0u), (kDomSysErr << 28) | j);
+                double ps;
+                uint32_t dom_error = draw<3>(s.host_dom_error[(base * 5u + last_base) * 5u + dom[chosen].dom], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(rw.w0), ps);
+                if (0.0 == ps) dom_error = 4;
+                uint32_t rate = draw<3>(s.host_error_rate[base * 5u + dom_error], s.host_pool.data(), s.host_par0.data(), idx, u32_to_unit(rw.w1), ps);
+                if (0.0 == ps) rate = 0;
+                err[v.off + j] = (uint16_t)(dom_error | (rate << 8));
+            }
             last_base = base;
         }
         // the other alleles of the variant: their dominant-base memories (Simulator.cpp:1088-1126 / 849-887)
@@ -912,15 +937,25 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
     }
 }
 
-// both strands of every simulated sequence (CreateUnit: the reverse strand first); the tracks come back from the device
-inline void build_variant_sys_errors(SimState &s, Uploader &up) {
+// both strands of every simulated sequence (CreateUnit: the reverse strand first); the tracks come back from the device.
+// `windows` (a sharded job): the parts of the strands the rank's chains were run over, instead of whole strands.
+struct StrandTask {
+    uint32_t seq;
+    int strand;
+    StrandWindow w;
+};
+inline void build_variant_sys_errors(SimState &s, Uploader &up, const std::vector<StrandTask> *windows = nullptr) {
     if (!s.has_variants || s.variants.empty()) return;
     // (sequence, strand) tasks are independent (own variants, own error arrays): a few host threads share them, longest first
-    std::vector<std::pair<uint32_t, int>> tasks;
-    for (uint32_t seq = 0; seq < s.dev.n_seqs; ++seq)
-        if (s.n_blocks[seq] && s.var_ptr[seq] != s.var_ptr[seq + 1])
-            for (int strand = 2; strand--;) tasks.emplace_back(seq, strand);
-    std::stable_sort(tasks.begin(), tasks.end(), [&](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) { return s.seq_len[a.first] > s.seq_len[b.first]; });
+    std::vector<StrandTask> tasks;
+    if (windows) {
+        for (const StrandTask &t : *windows)
+            if (s.var_ptr[t.seq] != s.var_ptr[t.seq + 1]) tasks.push_back(t);
+    } else
+        for (uint32_t seq = 0; seq < s.dev.n_seqs; ++seq)
+            if (s.n_blocks[seq] && s.var_ptr[seq] != s.var_ptr[seq + 1])
+                for (int strand = 2; strand--;) tasks.push_back(StrandTask{seq, strand, StrandWindow{0u, s.seq_len[seq], 0u}});
+    std::stable_sort(tasks.begin(), tasks.end(), [&](const StrandTask &a, const StrandTask &b) { return a.w.hi - a.w.lo > b.w.hi - b.w.lo; });
     std::atomic<size_t> next{0};
     std::mutex err_mutex;
     std::string error;
@@ -929,11 +964,12 @@ inline void build_variant_sys_errors(SimState &s, Uploader &up) {
             if (helper) up.bind_thread();
             std::vector<uint16_t> track;
             for (size_t t; (t = next.fetch_add(1)) < tasks.size();) {
-                const uint32_t seq = tasks[t].first;
-                const int strand = tasks[t].second;
-                track.resize(s.seq_len[seq]);
-                up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq], track.size() * sizeof(uint16_t));
-                variant_sys_errors_strand(s, seq, strand != 0, track.data());
+                const uint32_t seq = tasks[t].seq;
+                const int strand = tasks[t].strand;
+                const StrandWindow w = tasks[t].w;
+                track.resize(w.hi - w.lo);
+                up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq] + w.lo, track.size() * sizeof(uint16_t));
+                variant_sys_errors_strand(s, seq, strand != 0, track.data(), w);
             }
         } catch (const std::exception &e) {
             std::lock_guard<std::mutex> lock(err_mutex);
@@ -964,15 +1000,44 @@ enum ChainSet : int { kChainsAdapters = 0, kChainsSimulation = 1, kChainsProfile
 // ---- a sharded job: what the rank that simulates blocks [block_lo, block_hi) has to compute of the pre-passes.
 // Per sequence the rank's start positions [p_lo, p_hi) and the positions its reads can touch [p_lo, t_hi): a fragment ends before
 // start + insert_to (Simulator.cpp:2303,2316).  [g_lo, g_hi): the rank's share of the concatenated sequences, for the bias sums.
+// How far behind its start position a fragment's reads can touch the sequence: a fragment ends before start + insert_to
+// (Simulator.cpp:2303,2316); with variants its span on the reference grows by the bases its allele deletes, and the systematic-error walk
+// of a read may run a few positions past its template (GetSysErrorFromBlock with variants), hence the read length on top.
+inline uint32_t shard_halo(const SimState &s) {
+    uint32_t halo = s.dev.insert_to + 16u;
+    if (!s.has_variants) return halo;
+    // the most bases one allele deletes inside any stretch of `span` reference positions, with span = insert_to + that number (iterated)
+    uint32_t deleted = 0;
+    for (int round = 0; round < 4; ++round) {
+        const uint64_t span = (uint64_t)s.dev.insert_to + deleted;
+        uint32_t most = 0;
+        for (size_t m = 0; m + 1 < s.allele_map_ptr.size(); ++m) {
+            const uint32_t seq = (uint32_t)(m / s.num_alleles);
+            const DevVariant *vars = s.variants.data() + s.var_ptr[seq];
+            std::vector<uint32_t> dels;
+            for (uint32_t i = s.allele_map_ptr[m]; i + 1 < s.allele_map_ptr[m + 1]; ++i)
+                if (0 == vars[s.allele_map[i].vid].len) dels.push_back(s.allele_map[i].pos);
+            for (size_t a = 0, b = 0; b < dels.size(); ++b) {
+                while (dels[b] - dels[a] >= span) ++a;
+                most = std::max(most, (uint32_t)(b - a + 1));
+            }
+        }
+        if (most <= deleted) break;
+        deleted = most;
+    }
+    return halo + deleted + s.rmax + 64u;
+}
 struct ShardRange {
+    uint32_t halo = 0;
     std::vector<uint32_t> p_lo, p_hi, t_hi;
     uint64_t g_lo = 0, g_hi = UINT64_MAX;
     int first_seq = -1, last_seq = -1;      // the sequences of the rank's first and last start position (-1: no blocks)
 };
 inline ShardRange shard_range(const SimState &s, uint32_t block_lo, uint32_t block_hi) {
     if (block_lo < 1 || block_hi > s.total_blocks + 1 || block_lo > block_hi) throw Error("block range outside [1, total_blocks]");
-    const uint32_t n_seqs = s.dev.n_seqs, halo = s.dev.insert_to + 16u;
+    const uint32_t n_seqs = s.dev.n_seqs, halo = shard_halo(s);
     ShardRange r;
+    r.halo = halo;
     r.p_lo.assign(n_seqs, 0);
     r.p_hi.assign(n_seqs, 0);
     r.t_hi.assign(n_seqs, 0);
@@ -1036,7 +1101,7 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
                     else add(Chain{strand, i, 0u, L, i, strand, 0, 0, s.sys_fwd + s.seq_base_off[i]}, f_lo, f_hi);
                     if (range && edges) {
                         const Chain &c = chains.back();
-                        const uint32_t halo = s.dev.insert_to + 16u;
+                        const uint32_t halo = range->halo;
                         if (!strand && (int)i == range->first_seq && c.chunk_lo) edges->fwd_in_chain = index;
                         if (strand && (int)i == range->last_seq && c.chunk_lo) edges->rev_in_chain = index;
                         if (!strand && (int)i == range->last_seq && range->p_hi[i] < L && range->p_hi[i] / kChainChunk)      // the right neighbour starts at p_hi
@@ -1051,6 +1116,20 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
                 else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
             }
         }
+}
+
+// the strand windows of a finished chain run (the reference chains among `chains`; n_chunks = all chunks of the run), each with the
+// state its chain was entered with -- what build_variant_sys_errors needs of a rank's share
+inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks) {
+    std::vector<StrandTask> out;
+    for (size_t c = 0; c < chains.size(); ++c) {
+        const Chain &ch = chains[c];
+        if (ch.kind > 1u) continue;
+        const uint32_t chunks = (c + 1 < chains.size() ? chains[c + 1].first_chunk : n_chunks) - ch.first_chunk;
+        const uint32_t lo = ch.chunk_lo * kChainChunk, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + chunks) * kChainChunk);
+        out.push_back(StrandTask{ch.id, (int)ch.kind, StrandWindow{lo, hi, ch.in_state}});
+    }
+    return out;
 }
 
 // --methylation (Reference::PrepareMethylationFile / ReadMethylation, Simulator.cpp:2770-2780): regions as CSR on the device

@@ -858,7 +858,6 @@ int rsq_sim_prepare(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double c
 int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *record_base_identifier) {
     REQUIRE(s, "null argument");
     REQUIRE(s->has_ref, "the sharded pre-pass needs a reference");
-    REQUIRE(!s->has_variants, "the sharded pre-pass is not available with variants: use rsq_sim_prepare");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         s->prepared = false;
@@ -941,8 +940,15 @@ int rsq_sim_prepare_sys_errors(rsq_sim *s, uint32_t block_lo, uint32_t block_hi,
 int rsq_sim_prepare_finish(rsq_sim *s) {
     REQUIRE(s, "null argument");
     REQUIRE(s->planned && s->chain_run.valid, "the sharded pre-pass has not run");
-    s->prepared = true;
-    return RSQ_OK;
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        if (s->has_variants) {                                      // -V: the variants' bases inside the rank's strand windows, from the finished chains
+            const std::vector<StrandTask> windows = strand_tasks(s->chain_run.chains, s->chain_run.n_chunks);
+            build_variant_sys_errors(*s, s->up, &windows);
+        }
+        s->prepared = true;
+        return RSQ_OK;
+    });
 }
 
 int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out) {

@@ -5,8 +5,7 @@
 
 Every rank packs the replicated tables, takes a contiguous range of 1000-position blocks balanced by expected pairs
 (`sharding.partition_blocks`) and computes ITS share of the pre-passes (`sharding.sharded_prepare`: bias sums per chunk + one exact
-all-reduce, systematic-error chains over its own positions + the chain states at the shard borders; with variants loaded every rank
-still runs the whole pre-pass), writes its FASTQ shard, and
+all-reduce, systematic-error chains over its own positions + the chain states at the shard borders), writes its FASTQ shard, and
 after one all-gather of the shard sizes every rank copies its shard to its own offset of the output files, all ranks at once
 (`sharding.place_shard`); rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
@@ -49,10 +48,10 @@ class GpuBackend:
     def ref_seq_bias(self):
         return self.sim.ref_seq_bias(len(self.seq_len))
 
-    # the sharded pre-pass (not with variants, and not with a systematic-error profile that replaces the chains anyway)
+    # the sharded pre-pass (not with a systematic-error profile, which replaces the chains anyway)
     @property
     def can_shard_prepare(self):
-        return not self.has_variants and not self.sys_error_path
+        return not self.sys_error_path
 
     def _info(self, i):
         return dict(total_blocks=i.total_blocks, total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, insert_to=i.insert_to)

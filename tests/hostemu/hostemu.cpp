@@ -278,7 +278,7 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
 int emu_prepare_plan(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
     Emu &s = *static_cast<Emu *>(h);
     return guard([&] {
-        if (!s.has_ref || s.has_variants) throw Error("the sharded pre-pass needs a reference without variants");
+        if (!s.has_ref) throw Error("the sharded pre-pass needs a reference");
         s.prepared = false;
         plan_simulation(s, s.up, seed, num_pairs, coverage, ref_bias_mode, base_identifier);
         s.bias_plan = plan_bias_normalization(s, s.up);
@@ -337,6 +337,10 @@ int emu_prepare_finish(void *h) {
     Emu &s = *static_cast<Emu *>(h);
     return guard([&] {
         if (!s.chain_run.valid) throw Error("the sharded pre-pass has not run");
+        if (s.has_variants) {
+            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size());
+            build_variant_sys_errors(s, s.up, &windows);
+        }
         s.build_lds();
         s.prepared = true;
     });

@@ -154,21 +154,30 @@ def case_sieve_dense_thresholds(backend_cls, workdir):
         p.close()
 
 
-def case_sharded_prepare(backend_cls, workdir, world=3):
+def case_sharded_prepare(backend_cls, workdir, world=3, variants=False, seed=23):
     """the pre-passes of a sharded job (rsq_sim_prepare_plan .. rsq_sim_prepare_finish, sharding.sharded_prepare_in_process): `world` simulators
-    each compute their share; thresholds equal a whole pre-pass exactly, and every rank's block range simulates to the whole simulator's text"""
+    each compute their share; thresholds equal a whole pre-pass exactly, and every rank's block range simulates to the whole simulator's text.
+    variants: with insertions / deletions on two alleles, dense enough that variants sit within five bases of each other across the shard
+    borders (the variants' own systematic errors are then computed per share too)"""
     from reseq_amd import sharding
     lengths = [9400, 80, 3210, 1000]
-    ppath, fpath, seqs = make_inputs(workdir, "shardprep", synth.TINY, lengths)
-    whole = backend_cls(ppath, fpath)
-    ranks = [backend_cls(ppath, fpath) for _ in range(world)]
+    tag = "shardprepv" if variants else "shardprep"
+    ppath, fpath, seqs = make_inputs(workdir, tag, synth.TINY, lengths)
+    kw = {}
+    if variants:
+        vcf = workdir / f"{tag}.vcf"
+        borders = [x + d for x in range(1000, 9000, 1000) for d in (-6, -3, 0, 2, 5)]
+        write_vcf(vcf, seqs, _mixed_variant_set(seqs, np.random.default_rng(seed), 14, borders))
+        kw = dict(vcf_path=vcf)
+    whole = backend_cls(ppath, fpath, **kw)
+    ranks = [backend_cls(ppath, fpath, **kw) for _ in range(world)]
     try:
-        winfo = whole.prepare(23, 20000, 0.0, 1, "Pre")
+        winfo = whole.prepare(seed, 20000, 0.0, 1, "Pre")
         for b in ranks:
             b.seq_len = lengths
             b.ref_seq_bias_ = b.ref_seq_bias
             b.ref_seq_bias = lambda b=b: b.ref_seq_bias_(len(lengths))
-        infos, ranges, rounds = sharding.sharded_prepare_in_process(ranks, 23, 20000, 0.0, 1, "Pre")
+        infos, ranges, rounds = sharding.sharded_prepare_in_process(ranks, seed, 20000, 0.0, 1, "Pre")
         assert rounds >= 2 and all(lo < hi for lo, hi in ranges)
         for b, info, (lo, hi) in zip(ranks, infos, ranges):
             assert info["total_pairs"] == winfo["total_pairs"]

@@ -247,6 +247,10 @@ def test_sharded_pre_passes(workdir):
     P.case_sharded_prepare(GpuBackend, workdir)
 
 
+def test_sharded_pre_passes_with_variants(workdir):
+    P.case_sharded_prepare(GpuBackend, workdir, world=4, variants=True)
+
+
 def test_sieve_with_dense_thresholds(workdir):
     P.case_sieve_dense_thresholds(GpuBackend, workdir)
 

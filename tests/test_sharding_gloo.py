@@ -36,7 +36,7 @@ class Emu:                      # the host emulation behind the interface simula
         self.b = EmuBackend(ppath, fpath, 0, None, vcf_path=vcf) if vcf else EmuBackend(ppath, fpath, 0)
         self.seq_len = [len(c) for _, c in seqs]
         self.n_seqs = len(self.seq_len)
-        self.can_shard_prepare = vcf is None
+        self.can_shard_prepare = True
     def prepare(self, *a):
         return self.b.prepare(*a)
     def prepare_plan(self, *a):
