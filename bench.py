@@ -306,10 +306,13 @@ def main():
         done = [torch.cuda.Event(), torch.cuda.Event()]
 
         turn = [0]
+        # smaller batches than the device-resident leg: on this stack the copy to the host is a blit kernel (__amd_rocclr_copyBuffer in the
+        # kernel trace), which gets compute units only between the launches of the persistent read kernel
+        host_batches = sharding.batches(my_lo, my_hi, min(args.batch_blocks, 1200))
 
         def host_step():
             moved = 0
-            for lo, hi in batches:
+            for lo, hi in host_batches:
                 k = turn[0] & 1                                         # the two buffer pairs alternate across batches and steps
                 turn[0] += 1
                 done[k].synchronize()                                   # the copy that last used this pair of buffers
@@ -332,7 +335,8 @@ def main():
         host_elapsed = time.perf_counter() - t0
         _, moved_all, host_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", 0, moved, host_elapsed)
         to_host = {"value": total_pairs / host_elapsed, "unit": "read-pairs/s", "ms_per_step": host_elapsed / args.steps * 1e3,
-                   "host_gbytes_per_s": moved_all / host_elapsed / 1e9, "note": "FASTQ text of both mates copied to page-locked host buffers, copy of batch k "
+                   "host_gbytes_per_s": moved_all / host_elapsed / 1e9, "batch_blocks": min(args.batch_blocks, 1200),
+                   "note": "FASTQ text of both mates copied to page-locked host buffers, copy of batch k "
                    "overlapping the generation of batch k+1 (the link binds: 7.5 GB per step and GPU)"}
 
     if rank == 0:
