@@ -1647,7 +1647,7 @@ RSQ_HD void variant_template(const DevSim &S, const Fragment &f, const FragmentV
     const bool reversed = seg != f.strand;
     const VarStart from = reversed ? VarStart{fv.end_var, fv.end_var_pos} : VarStart{fv.start_var, fv.start_var_pos};
     const uint32_t at = reversed ? fv.end : f.start;
-    reference_sequence_with_variants(r, at, tl, reversed, from, f.allele, tmpl, template_words);
+    allele_template(allele_view(S, f.seq, f.allele), at, from, tl, reversed, tmpl, template_words);
     if (S.meth_ptr) {                                                           // CTConversion with variants (:2232-2237)
         const MethView m = meth_view(S, f.seq, f.allele);
         MethDraws d{S.seed, f.start, f.seq | (fv.sub << 22), f.len, (kDomMethylation << 28) | ((reversed ? 1u : 0u) << 27) | ((uint32_t)f.allele << 17), 0xFFFFFFFFu,

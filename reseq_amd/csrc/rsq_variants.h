@@ -14,7 +14,7 @@
 //   - the G/C count of the fragment:                the difference of two prefix values (reference prefix sums + the map's running G/C),
 //   - both surroundings:                            30 allele bases gathered piecewise (runs of the 2-bit reference, bases of replacements)
 // -- O(log variants) per cell instead of a replay over the fragment's length.
-// Also here: Reference::ReferenceSequence with variants (Reference.cpp:498-567) writing a 2-bit template.
+// Also here: the templates of a fragment's mates (Reference::ReferenceSequence with variants, Reference.cpp:498-567) as stretches of the allele.
 #pragma once
 #include "rsq_core.h"
 
@@ -127,46 +127,53 @@ RSQ_HD uint32_t allele_gc_before(const AlleleView &a, const AllelePoint &p) {
     return (uint32_t)((int32_t)a.ref_gc_before(p.ref) + a.e[p.j].gc);
 }
 
-// 30 consecutive allele bases from coordinate h0, first base in the lowest bits.  Coordinates in front of the allele and behind it
-// continue in the REFERENCE around the sequence's ends, without variants: the reference's surroundings wrap around
+// up to 32 reference bases from position p of the sequence, first base in the lowest bits (the sequence's spare word makes w[1] readable)
+RSQ_HD uint64_t ref_bits64(const uint64_t *__restrict__ words, uint64_t word_off, uint32_t p) {
+    const uint64_t *w = words + word_off + (p >> 5);
+    const uint32_t off = (p & 31u) * 2u;
+    return off ? (w[0] >> off) | (w[1] << (64u - off)) : w[0];
+}
+// n <= 32 consecutive allele bases from coordinate h0, first base in the lowest bits, zeros above them.  Coordinates in front of the allele
+// and behind it continue in the REFERENCE around the sequence's ends, without variants: the reference's surroundings wrap around
 // (SurroundingBase.hpp:64-81) and its variant edits stop at the ends (HandleSurroundingVariantsBeforeCenter / AfterCenter, :1459-1589).
-RSQ_HD uint64_t allele_window(const AlleleView &a, int64_t h0) {
-    constexpr uint32_t kN = kSurBlocks * kSurRange;
+RSQ_HD uint64_t allele_bits(const AlleleView &a, int64_t h0, uint32_t n) {
     uint64_t x = 0;
     uint32_t got = 0;
     int64_t h = h0;
     const uint32_t L = a.r.L;
-    for (; got < kN && h < 0; ++got, ++h) x |= (uint64_t)a.r.at((uint32_t)((int64_t)L + h)) << (2u * got);
-    if (got < kN && h < a.length()) {
+    for (; got < n && h < 0; ++got, ++h) x |= (uint64_t)a.r.at((uint32_t)((int64_t)L + h)) << (2u * got);
+    if (got < n && h < a.length()) {
         const AllelePoint p = allele_point(a, h);
         uint32_t j = p.j, q = p.ref;                                      // next entry, next reference position
         if (p.inside) {
             const DevVariant &var = a.var(j - 1u);
-            for (uint32_t k = p.k; k < var.len && got < kN; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
+            for (uint32_t k = p.k; k < var.len && got < n; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
             ++q;
         }
-        while (got < kN && q < L) {
+        while (got < n && q < L) {
             const uint32_t stop = a.e[j].pos;                             // the sentinel stops at L
             uint32_t run = stop - q;
-            if (run > kN - got) run = kN - got;
+            if (run > n - got) run = n - got;
             if (run) {
-                x |= (ref_bits60(a.r.words, a.r.word_off, q) & ((1ull << (2u * run)) - 1ull)) << (2u * got);
+                const uint64_t bits = ref_bits64(a.r.words, a.r.word_off, q);
+                x |= (run < 32u ? bits & ((1ull << (2u * run)) - 1ull) : bits) << (2u * got);
                 got += run;
                 q += run;
             }
-            if (got == kN || q == L) break;
+            if (got == n || q == L) break;
             const DevVariant &var = a.var(j);                             // the entry at q
-            for (uint32_t k = 0; k < var.len && got < kN; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
+            for (uint32_t k = 0; k < var.len && got < n; ++k, ++got) x |= (uint64_t)a.r.base(var, k) << (2u * got);
             ++j;
             ++q;
         }
     }
-    for (uint32_t q = 0; got < kN; ++got) {
+    for (uint32_t q = 0; got < n; ++got) {
         x |= (uint64_t)a.r.at(q) << (2u * got);
         if (++q == L) q = 0;
     }
     return x;
 }
+RSQ_HD uint64_t allele_window(const AlleleView &a, int64_t h0) { return allele_bits(a, h0, kSurBlocks * kSurRange); }
 // the allele's forward surrounding of coordinate h (as surrounding_forward does for the reference) and its reverse surrounding
 RSQ_HD void allele_surrounding_forward(const AlleleView &a, int64_t h, uint32_t (&sur)[3]) {
     const uint64_t x = allele_window(a, h - (int64_t)kSurStart);
@@ -210,95 +217,30 @@ RSQ_HD AlleleCell allele_cell(const AlleleView &a, const VarStart &st, uint32_t 
     return c;
 }
 
-// Reference::ReferenceSequence with variants (Reference.cpp:498-567): the template of one mate, 2 bits per base in read orientation
-struct TemplateWriter {                 // 32 bases are collected in a register and stored as one word
-    uint64_t *words;
-    uint32_t n, cap;
-    uint64_t acc;
-    RSQ_HD void put(uint32_t base) {
-        if (n < cap) {
-            acc |= (uint64_t)base << ((n & 31u) * 2u);
-            if ((n & 31u) == 31u) {
-                words[n >> 5] = acc;
-                acc = 0;
-            }
-        }
-        ++n;
+// Reference::ReferenceSequence with variants (Reference.cpp:498-567): the template of one mate, 2 bits per base in read orientation.
+// A template is a stretch of the allele's own sequence: the forward mate's begins at the allele coordinate of (start position, start
+// variant), the reverse mate's is the reverse complement of the stretch that ends where (end position, EndVariant) points -- inside inserted
+// bases after `end_var_pos` of them, else in front of everything that replaces the end position.  32 bases per word, gathered piecewise.
+RSQ_HD uint64_t reverse_complement_bits(uint64_t x, uint32_t n) {        // of the lowest n <= 32 bases
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r = __brevll(~x);
+#else
+    uint64_t r = 0, c = ~x;
+    for (uint32_t i = 0; i < 64u; ++i) r |= ((c >> i) & 1ull) << (63u - i);
+#endif
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);      // the two bits of every base back in order
+    return n < 32u ? r >> (64u - 2u * n) : r;
+}
+RSQ_HD void allele_template(const AlleleView &a, uint32_t pos, VarStart from, uint32_t n, bool reversed, uint64_t *tmpl, uint32_t template_words) {
+    int64_t h;
+    if (from.start_variant_pos) h = a.begin_of(a.entries_before(a.r.v[from.first_variant_id].pos)) + from.start_variant_pos;
+    else h = a.to_allele(pos);
+    uint32_t w = 0;
+    for (uint32_t done = 0; done < n; done += 32u, ++w) {
+        const uint32_t c = n - done < 32u ? n - done : 32u;
+        tmpl[w] = reversed ? reverse_complement_bits(allele_bits(a, h - done - c, c), c) : allele_bits(a, h + done, c);
     }
-    RSQ_HD void finish(uint32_t template_words) {                               // the last partial word, zeros behind it
-        const uint32_t have = n < cap ? n : cap;
-        uint32_t w = have >> 5;
-        if (have & 31u) words[w++] = acc;
-        for (; w < template_words; ++w) words[w] = 0;
-    }
-};
-struct RefReader {                      // consecutive reference bases: one load per 32 of them
-    const VarView &r;
-    uint32_t index = 0xFFFFFFFFu;
-    uint64_t word = 0;
-    RSQ_HD uint32_t at(uint32_t pos) {
-        if ((pos >> 5) != index) {
-            index = pos >> 5;
-            word = r.words[r.word_off + index];
-        }
-        return (uint32_t)(word >> ((pos & 31u) * 2u)) & 3u;
-    }
-};
-RSQ_HD uint32_t reference_sequence_with_variants(const VarView &view, uint32_t start_pos, uint32_t frag_length, bool reversed, VarStart first_variant, uint32_t allele,
-                                                 uint64_t *tmpl, uint32_t template_words) {
-    RefReader r{view};
-    TemplateWriter out{tmpl, 0, frag_length, 0};                                // resize(out, frag_length) at the end
-    uint32_t cur_start = start_pos;
-    int32_t cur_var = first_variant.first_variant_id;
-    if (reversed) {
-        if (first_variant.start_variant_pos) {
-            const DevVariant &var = view.v[cur_var];
-            for (uint32_t k = first_variant.start_variant_pos; k--;) out.put(3u - view.base(var, k));       // prefix(var_seq_, pos), reverse complemented
-            --cur_var;
-            --cur_start;
-        }
-        for (; cur_var >= 0 && out.n < frag_length; --cur_var) {
-            const DevVariant &var = view.v[cur_var];
-            if (!view.in_allele(var, allele)) continue;
-            if (cur_start - var.pos > frag_length - out.n) {
-                const uint32_t from = cur_start + out.n - frag_length;
-                for (uint32_t p = cur_start; p-- > from;) out.put(3u - r.at(p));
-            } else {
-                for (uint32_t p = cur_start; p-- > var.pos + 1u;) out.put(3u - r.at(p));
-                for (uint32_t k = var.len; k--;) out.put(3u - view.base(var, k));
-                cur_start = var.pos;
-            }
-        }
-        if (cur_var == -1 && out.n < frag_length) {
-            const uint32_t from = cur_start + out.n - frag_length;
-            for (uint32_t p = cur_start; p-- > from;) out.put(3u - r.at(p));
-        }
-    } else {
-        if (first_variant.start_variant_pos) {
-            const DevVariant &var = view.v[cur_var];
-            for (uint32_t k = first_variant.start_variant_pos; k < var.len; ++k) out.put(view.base(var, k));
-            ++cur_var;
-            ++cur_start;
-        }
-        for (; (uint32_t)cur_var < view.n && out.n < frag_length; ++cur_var) {
-            const DevVariant &var = view.v[cur_var];
-            if (!view.in_allele(var, allele)) continue;
-            if (var.pos - cur_start >= frag_length - out.n) {
-                const uint32_t to = cur_start + frag_length - out.n;
-                for (uint32_t p = cur_start; p < to; ++p) out.put(r.at(p));
-            } else {
-                for (uint32_t p = cur_start; p < var.pos; ++p) out.put(r.at(p));
-                for (uint32_t k = 0; k < var.len; ++k) out.put(view.base(var, k));
-                cur_start = var.pos + 1u;
-            }
-        }
-        if ((uint32_t)cur_var == view.n && out.n < frag_length) {
-            const uint32_t to = cur_start + frag_length - out.n;
-            for (uint32_t p = cur_start; p < to; ++p) out.put(r.at(p));
-        }
-    }
-    out.finish(template_words);
-    return out.n < frag_length ? out.n : frag_length;
+    for (; w < template_words; ++w) tmpl[w] = 0;
 }
 
 }  // namespace rsq
