@@ -64,6 +64,31 @@ RSQ_HD void update_distances(uint32_t reset_distance, uint32_t &dist, uint32_t &
     }
 }
 
+// One of the chain's two draws, screened (rsq_core.h draw_screened: single precision with a proof that the column is the double-precision
+// one); undecided draws and tables outside the screen's preconditions are repeated in double precision.  Q quads per row of the table's
+// float copy.  Returns the outcome value; `none`: what an all-zero row gives (prob_sum == 0 in the reference's recipe).
+template <int Q>
+RSQ_HD uint32_t chain_draw(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word, uint32_t none) {
+    if (S.chain_quads && t.k && t.f32_ok) {
+        const float *g = S.pool32 + t.off32;
+        const uint32_t slot = 4u * (uint32_t)Q;
+        const GlobalRow32 m0{g + clamp_row(t, 0, idx[0]) * slot}, m1{g + (t.rows[0] + clamp_row(t, 1, idx[1])) * slot},
+            m2{g + (t.rows[0] + t.rows[1] + clamp_row(t, 2, idx[2])) * slot};
+        uint32_t col = 0;
+        if (draw_screened<Q>(word, col, m0, m1, m2)) return S.par0[t.par0_off + col];
+    }
+    double ps;
+    const uint32_t value = draw<3>(t, S.pool, S.par0, idx, u32_to_unit(word), ps);
+    return 0.0 == ps ? none : value;
+}
+RSQ_HD uint32_t chain_draw_rate(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
+    switch (S.chain_quads) {
+        case 8: return chain_draw<8>(S, t, idx, word, 0u);
+        case 16: return chain_draw<16>(S, t, idx, word, 0u);
+        default: return chain_draw<26>(S, t, idx, word, 0u);           // also 0: chain_draw goes straight to double precision
+    }
+}
+
 // Positions [lo,hi) of one chain.  Everything except (dist,start_rate) is a pure function of the sequence and is
 // rebuilt at `lo`, so a chunk can start anywhere given the incoming (dist,start_rate).
 template <class Acc>
@@ -80,11 +105,8 @@ RSQ_HD void sys_chain_chunk(const DevSim &S, const Acc &acc, uint32_t c1, uint32
         const uint32_t b = acc(pos);
         const Words w = philox(S.seed, pos, c1, c2, kDomSysErr << 28);
         const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};
-        double ps;
-        uint32_t dom_error = draw<3>(S.dom_error[(b * 5u + last_base) * 5u + dom], S.pool, S.par0, idx, u32_to_unit(w.w0), ps);
-        if (0.0 == ps) dom_error = 4;
-        uint32_t rate = draw<3>(S.error_rate[b * 5u + dom_error], S.pool, S.par0, idx, u32_to_unit(w.w1), ps);
-        if (0.0 == ps) rate = 0;
+        const uint32_t dom_error = chain_draw<(int)kQuadsSmall>(S, S.dom_error[(b * 5u + last_base) * 5u + dom], idx, w.w0, 4u);
+        const uint32_t rate = chain_draw_rate(S, S.error_rate[b * 5u + dom_error], idx, w.w1);
         out[pos] = (uint16_t)(dom_error | (rate << 8));
         last_base = b;
         ++cnt[b];

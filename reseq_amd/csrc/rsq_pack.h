@@ -169,6 +169,14 @@ inline void pack_tables(SimState &s, Uploader &up) {
         copy32(base_call, plan.slot_b);
         copy32(indels, plan.slot_i);
     }
+    // the two families of the systematic-error chains: rows of whole quads, read from HBM
+    s.dev.chain_quads = 0;
+    for (uint32_t q : kChainQuads)
+        if (!s.dev.chain_quads && quads_of(kmax_of(error_rate)) <= q && quads_of(kmax_of(dom_error)) <= kQuadsSmall) s.dev.chain_quads = q;
+    if (s.dev.chain_quads) {
+        copy32(dom_error, 4u * kQuadsSmall);
+        copy32(error_rate, 4u * s.dev.chain_quads);
+    }
 
     // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): the image of one template segment, the most valuable rows first,
     // as much as fits 160 KiB.

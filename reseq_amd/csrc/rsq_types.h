@@ -70,6 +70,8 @@ RSQ_HD uint32_t row_slot32(uint32_t quads) {
 // indel families with 2 (K <= 8, rows of 32 bytes)
 constexpr uint32_t kQuadsSmall = 2, kSlotSmall = 8;
 constexpr uint32_t kQualityQuads[] = {10, 11, 12};
+// the systematic-error chains (k_sys_chain) screen their two draws as well: dominant error with kQuadsSmall quads, error rate with one of these
+constexpr uint32_t kChainQuads[] = {8, 16, 26};
 constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)
 
 // LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup, in single precision:
@@ -184,6 +186,7 @@ struct DevSim {
     const DevTable *error_rate;    // [4][5]
     const DevTable *indels;        // [2][6]
     LdsPlan lds;
+    uint32_t chain_quads;            // quads per row of the error-rate tables' single-precision copy (one of kChainQuads); 0: the chains draw in double precision only
     uint32_t n_tiles;
     uint8_t phred_offset;
     uint16_t max_len_deletion;
