@@ -196,18 +196,18 @@ __global__ void __launch_bounds__(256) k_sum_bias(DevSim S, const BiasParam *par
     const uint64_t chunk_at = S.seq_base_off[p.seq] + (uint64_t)chunk * kBiasBlock * kBiasRun;
     if (chunk_at < g_lo || chunk_at >= g_hi) return;
     const uint64_t bo = S.seq_base_off[p.seq] - track_base;        // the tracks begin at track_base of the concatenated sequences
-    const uint32_t first = (chunk * kBiasBlock + threadIdx.x) * kBiasRun;
+    // lane t takes the chunk's start positions t, t + kBiasBlock, ...: neighbouring lanes read neighbouring track entries (coalesced), the
+    // G/C count of a fragment comes from the prefix sums.  A lane adds its kBiasRun terms in this order, the tree below adds the lanes.
+    const uint32_t chunk_first = chunk * kBiasBlock * kBiasRun;
     double sum = 0.0, mx = 0.0;
-    if (first < n_starts) {
-        const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
-        uint32_t gc = ref_gc_count_prefix(S.ref_words, S.gc_prefix, wo, first, first + p.len);
-        for (uint32_t start = first; start < last; ++start) {
-            const double bias = start_bias ? p.general_bias * S.gc_bias[percent_u32(gc, p.len)] * start_bias[bo + start] * end_bias[bo + start + p.len - 1u]
-                                           : site_bias(S, wo, L, start, p.len, gc, p.general_bias);
-            sum += bias;
-            mx = bias > mx ? bias : mx;
-            if (start + 1 < last) gc = gc + is_gc(ref_base(S.ref_words, wo, start + p.len)) - is_gc(ref_base(S.ref_words, wo, start));
-        }
+    for (uint32_t j = 0; j < kBiasRun; ++j) {
+        const uint32_t start = chunk_first + j * kBiasBlock + threadIdx.x;
+        if (start >= n_starts) break;
+        const uint32_t gc = ref_gc_count_prefix(S.ref_words, S.gc_prefix, wo, start, start + p.len);
+        const double bias = start_bias ? p.general_bias * S.gc_bias[percent_u32(gc, p.len)] * start_bias[bo + start] * end_bias[bo + start + p.len - 1u]
+                                       : site_bias(S, wo, L, start, p.len, gc, p.general_bias);
+        sum += bias;
+        mx = bias > mx ? bias : mx;
     }
     s_sum[threadIdx.x] = sum;
     s_max[threadIdx.x] = mx;

@@ -119,18 +119,15 @@ void sum_bias_like_kernel(const Emu &s, const BiasParam &p, uint32_t gx, uint64_
         const uint64_t chunk_at = bo + (uint64_t)b * kBiasBlock * kBiasRun;
         if (chunk_at < g_lo || chunk_at >= g_hi) continue;
         double ls[kBiasBlock], lm[kBiasBlock];
-        for (uint32_t t = 0; t < kBiasBlock; ++t) {
-            const uint32_t first = (b * kBiasBlock + t) * kBiasRun;
+        for (uint32_t t = 0; t < kBiasBlock; ++t) {               // lane t: start positions t, t + kBiasBlock, ... of the chunk
             double sum = 0.0, mx = 0.0;
-            if (first < n_starts) {
-                const uint32_t last = first + kBiasRun < n_starts ? first + kBiasRun : n_starts;
-                uint32_t gc = ref_gc_count(s.dev.ref_words, wo, first, first + p.len);
-                for (uint32_t start = first; start < last; ++start) {
-                    const double bias = site_bias(s.dev, wo, L, start, p.len, gc, p.general_bias);
-                    sum += bias;
-                    mx = bias > mx ? bias : mx;
-                    if (start + 1 < last) gc = gc + is_gc(ref_base(s.dev.ref_words, wo, start + p.len)) - is_gc(ref_base(s.dev.ref_words, wo, start));
-                }
+            for (uint32_t j = 0; j < kBiasRun; ++j) {
+                const uint32_t start = b * kBiasBlock * kBiasRun + j * kBiasBlock + t;
+                if (start >= n_starts) break;
+                const uint32_t gc = ref_gc_count(s.dev.ref_words, wo, start, start + p.len);
+                const double bias = site_bias(s.dev, wo, L, start, p.len, gc, p.general_bias);
+                sum += bias;
+                mx = bias > mx ? bias : mx;
             }
             ls[t] = sum;
             lm[t] = mx;
