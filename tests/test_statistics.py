@@ -228,3 +228,123 @@ def test_gap_draws_pass_every_cell_with_its_own_probability(workdir):
         sim.close()
         oref.close()
         oprof.close()
+
+
+# ------------------------------------------------------------------------------------------------------ indel draws
+# The same idea for the third draw of FillReadPart (Simulator.cpp:322-326): indel ~ InDels(previous_indel_type, base_call) given
+# {indel_pos, read_pos, gc_seq}.  Every conditioning value follows from the CIGAR and the bases of the read by the reference's own
+# bookkeeping (:357-372 after a template base, :394-408 after a deletion, :421-439 after an insertion; initial values Simulator.h:232-234;
+# gc_seq :479-500), restated below in numpy straight from those lines -- not from the oracle or the product.
+def _indel_draws(results, rec):
+    """per draw: table index, indel_pos, read_pos, gc_seq, outcome (0 none, 1 deletion, 2 + base insertion); template part only"""
+    import re
+    n = len(results)
+    ops, seqs, read_len = [], [], np.zeros(n, np.int64)
+    for i, (seq, _qual, cigar, _nerr, _tile) in enumerate(results):
+        template_part = re.split("[SH]", cigar)[0]                    # the adapter part ('S') has its own bookkeeping; its count's digits are left over and ignored
+        expanded = "".join(op * int(cnt) for cnt, op in re.findall(r"(\d+)([MID])", template_part))
+        ops.append(expanded)
+        seqs.append(np.frombuffer(seq, np.uint8))
+        read_len[i] = len(seq)
+    width = max(len(o) for o in ops)
+    op = np.full((n, width), ord(" "), np.uint8)
+    for i, o in enumerate(ops):
+        op[i, :len(o)] = np.frombuffer(o.encode(), np.uint8)
+    base = np.full((n, int(read_len.max()) + 1), 4, np.int64)
+    for i, sq in enumerate(seqs):
+        base[i, :len(sq)] = sq
+    tmpl_len = rec["seqs"].shape[1]
+    seq_length = np.minimum(read_len, tmpl_len)
+    gc_count = np.array([int(np.isin(rec["seqs"][i, :seq_length[i]], (1, 2)).sum()) for i in range(n)])
+    gc_seq = np.where(seq_length > 0, (gc_count * 100 + seq_length // 2) // np.maximum(seq_length, 1), 0)      # utilities::Percent
+    read_pos, indel_pos, prev_type = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)
+    base_call = np.full(n, 5, np.int64)
+    element = np.full(n, ord("M"), np.uint8)
+    rows = []
+    for t in range(width):
+        cur = op[:, t]
+        act = cur != ord(" ")
+        if not act.any():
+            break
+        is_m, is_d, is_i = act & (cur == ord("M")), act & (cur == ord("D")), act & (cur == ord("I"))
+        outcome = np.where(is_d, 1, np.where(is_i, 2 + base[np.arange(n), np.minimum(read_pos, base.shape[1] - 1)], 0))
+        rows.append(np.stack([prev_type * 6 + base_call, indel_pos, read_pos, gc_seq, outcome], axis=1)[act])
+        # :357-372
+        changed = is_m & (element != ord("M"))
+        base_call = np.where(is_m, base[np.arange(n), np.minimum(read_pos, base.shape[1] - 1)], base_call)
+        indel_pos = np.where(changed, 0, indel_pos)
+        prev_type = np.where(changed, 0, prev_type)
+        # :394-408
+        cont_d, new_d = is_d & (element == ord("D")), is_d & (element != ord("D"))
+        indel_pos = np.where(cont_d, indel_pos + 1, np.where(new_d, 1, indel_pos))
+        prev_type = np.where(new_d, 1, prev_type)
+        # :421-439
+        cont_i, new_i = is_i & (element == ord("I")), is_i & (element != ord("I"))
+        indel_pos = np.where(cont_i, indel_pos + 1, np.where(new_i, 1, indel_pos))
+        prev_type = np.where(new_i, 0, prev_type)
+        element = np.where(act, cur, element)
+        read_pos = read_pos + (is_m | is_i)
+    return np.concatenate(rows)
+
+
+def _check_indels(results, rec, arrays, enforce=True):
+    draws = _indel_draws(results, rec)
+    worst, n_tests, n_rare = 0.0, 0, 0
+    for table_id in np.unique(draws[:, 0]):
+        a = draws[draws[:, 0] == table_id]
+        table = _table(arrays, f"indels.{table_id // 6}.{table_id % 6}")
+        if not len(table[0]):
+            continue
+        p, ok = _conditionals(table, a[:, 1:4])
+        a = a[ok]
+        col_of = {int(v): c for c, v in enumerate(table[0])}
+        assert all(int(v) in col_of for v in np.unique(a[:, 4])), (table_id, "an outcome the table does not have")
+        col = np.asarray([col_of[int(v)] for v in a[:, 4]])
+        assert (p[np.arange(len(col)), col] > 0).all(), (table_id, "an outcome of probability 0 was drawn")
+        n_rare += int((col > 0).sum())
+        groups = [np.zeros(len(a), np.int64), np.minimum(a[:, 1], 3), a[:, 2] // 6, a[:, 3] // 10]      # all, indel position, read position, G/C
+        for g in groups:
+            z = _z_scores(p, col, g - g.min())
+            if len(z):
+                worst = max(worst, float(np.abs(z).max()))
+                n_tests += len(z)
+    if enforce:
+        assert len(draws) > 1_500_000 and n_rare > 30_000 and n_tests > 300, (len(draws), n_rare, n_tests)
+        assert worst < 5.5, worst
+    return worst, n_tests, len(draws)
+
+
+def _indel_profile(workdir):
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    path = workdir / "stat_indel_profile.rsqp"
+    write_container(path, arrays)
+    return arrays, str(path)
+
+
+def test_indel_conditionals_of_the_oracle(workdir):
+    arrays, path = _indel_profile(workdir)
+    rec = _records()
+    prof = O.Profile(path)
+    results = O.error_model_only(prof, SEED, rec)
+    prof.close()
+    assert _check_indels(results, rec, arrays)[0] < 5.5
+    # the test of the test: indel-position rows shifted by one (the row of a running indel taken for the row of none) must fail loudly
+    wrong = dict(arrays)
+    for name in list(arrays):
+        if name.startswith("tab.indels.") and name.endswith(".dim2"):
+            par0, lim, margins = _table(arrays, name[4:-5])
+            margins[0] = np.roll(margins[0], 1, axis=0)
+            wrong[name] = np.concatenate([m.ravel() for m in margins])
+    assert _check_indels(results, rec, wrong, enforce=False)[0] > 8
+
+
+@pytest.mark.gpu
+def test_indel_conditionals_of_the_product(workdir):
+    from backends import GpuBackend
+    arrays, path = _indel_profile(workdir)
+    rec = _records()
+    b = GpuBackend(path, None, 0)
+    b.prepare(SEED)
+    results = b.error_model(rec)
+    b.close()
+    assert _check_indels(results, rec, arrays)[0] < 5.5
