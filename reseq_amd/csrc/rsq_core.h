@@ -700,12 +700,21 @@ struct ReadMachine {
         const bool tail = phase == kTail, from_template = phase == kTemplate;
         const DevAdapters &ad = S.adapters[seg];
         const uint32_t it = par.iteration++;
+#ifdef RSQ_EXP_NO_PHILOX
+        const Words w{(it + st.c0) * 0x9E3779B9u, (it ^ st.c1) * 0x85EBCA6Bu + 0x1234567u, (it + st.c2) * 0xC2B2AE35u, it * 0x27D4EB2Fu};      // experiment only: what the Philox rounds cost
+#else
         const Words w = st.step(2u + it);
+#endif
         double prob_sum;
         uint32_t indel = 0, org_base = 0;
         if (!tail) {
             const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
+#ifdef RSQ_EXP_NO_INDEL
+            (void)idx_i;
+            prob_sum = 1.0;                                            // experiment only: what the indel draw costs
+#else
             indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, w.w0, prob_sum);
+#endif
             if (0.0 == prob_sum) indel = 0;
             org_base = from_template ? src.base(org_pos) : (uint32_t)ad.seqs[adapter_a0 + org_pos];
         }
@@ -723,7 +732,12 @@ struct ReadMachine {
         uint32_t q = 0;
         if (!deletion) {
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
+#ifdef RSQ_EXP_NO_QUAL
+            q = 2u + (w.w1 >> 28) + (idx_q[1] & 1u);                   // experiment only: what the quality draw costs
+            prob_sum = 1.0;
+#else
             q = tab.draw_quality(qi, idx_q, w.w1, prob_sum);
+#endif
             if (0.0 == prob_sum) {
                 if (regular) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;      // :341-349
                 else if (tail) q = par.read_pos ? par.last_written_qual : q;                             // at(qual_, read_pos-1) - offset
@@ -733,7 +747,12 @@ struct ReadMachine {
         if (regular) {
             par.qual = q;
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
+#ifdef RSQ_EXP_NO_CALL
+            uint32_t call = (w.w2 >> 30) == 3u && idx_b[0] < 3u ? (org_base + 1u) & 3u : org_base;      // experiment only: what the base-call draw costs
+            prob_sum = 1.0;
+#else
             uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
+#endif
             if (0.0 == prob_sum) call = org_base;
             par.base_call = call;
             out.put(par.read_pos, call, q + S.phred_offset);
