@@ -120,6 +120,7 @@ def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pair
     border.  Every rank first runs its chunks speculatively to a fixed point; the states at the borders then travel rank to rank (forward
     chains to the right, reverse chains to the left) by all-gathers of two words per rank until no rank's entering state changed; a rank
     whose state changed redoes only the chunks that depend on it."""
+    import numpy as np
     import torch
     info = backend.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
     total_blocks = info["total_blocks"] if isinstance(info, dict) else info.total_blocks
@@ -129,7 +130,7 @@ def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pair
     lo, hi = partition_blocks(total_blocks, world, weights)[rank]
     sums, maxes = backend.bias_partials(lo, hi)
     if dist is not None:
-        t = torch.from_numpy(__import__("numpy").stack([sums, maxes])).to(device)
+        t = torch.from_numpy(np.stack([sums, maxes])).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)                     # every entry is non-zero on one rank
         sums, maxes = t[0].cpu().numpy(), t[1].cpu().numpy()
     backend.prepare_normalization(sums, maxes)
