@@ -29,6 +29,7 @@ struct Uploader {                                   // copies a host array to wh
     int current_scope = kScopeCreate;
     virtual void release_scope(int scope) { (void)scope; }                        // frees what was put in the scope
     virtual void *put_bytes(const void *data, size_t bytes) = 0;
+    virtual void *put_zeros(size_t bytes) = 0;                                     // an array of zero bytes (no host copy of it)
     virtual void write_bytes(void *dst, const void *src, size_t bytes) = 0;      // overwrite part of an array put earlier
     virtual void read_bytes(void *dst_host, const void *src, size_t bytes) = 0;   // read back what the pre-pass kernels wrote
     virtual void bind_thread() {}                                                 // called once by every helper thread that will call read_bytes
@@ -452,13 +453,41 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     }
     s.total_ref_size = bases;
     std::vector<uint64_t> packed(words + 1, 0);
-    for (size_t i = 0; i < r.codes.size(); ++i) {
-        const std::vector<uint8_t> &c = r.codes[i];
-        uint64_t *w = &packed[s.seq_word_off[i]];
-        for (size_t pos = 0; pos < c.size(); ++pos) {
-            if (c[pos] > 3) throw Error("reference still contains N: call rsq_ref_replace_n first");
-            w[pos >> 5] |= (uint64_t)c[pos] << ((pos & 31) * 2);
-        }
+    {   // 32 bases per word; stretches of 4 M bases are independent (whole words each): a few host threads share them
+        struct Stretch {
+            size_t seq, lo, hi;
+        };
+        std::vector<Stretch> stretches;
+        constexpr size_t kStretch = (size_t)1 << 22;
+        for (size_t i = 0; i < r.codes.size(); ++i)
+            for (size_t lo = 0; lo < r.codes[i].size(); lo += kStretch) stretches.push_back(Stretch{i, lo, std::min(r.codes[i].size(), lo + kStretch)});
+        std::atomic<size_t> next{0};
+        std::atomic<bool> has_n{false};
+        auto work = [&]() {
+            for (size_t t; (t = next.fetch_add(1)) < stretches.size();) {
+                const Stretch &st = stretches[t];
+                const uint8_t *c = r.codes[st.seq].data();
+                uint64_t *w = &packed[s.seq_word_off[st.seq]];
+                for (size_t pos = st.lo; pos < st.hi; pos += 32) {
+                    const size_t n = std::min<size_t>(32, st.hi - pos);
+                    uint64_t x = 0;
+                    uint8_t seen = 0;
+                    for (size_t k = 0; k < n; ++k) {
+                        x |= (uint64_t)(c[pos + k] & 3u) << (2 * k);
+                        seen |= c[pos + k];
+                    }
+                    if (seen > 3) has_n = true;
+                    w[pos >> 5] = x;
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = std::min<size_t>(std::max<size_t>(1, stretches.size()), std::max(1u, std::min(hw ? hw : 1u, 16u)));
+        std::vector<std::thread> helpers;
+        for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(work);
+        work();
+        for (std::thread &t : helpers) t.join();
+        if (has_n) throw Error("reference still contains N: call rsq_ref_replace_n first");
     }
     std::vector<uint32_t> gc_prefix(words + 1, 0);                 // running G/C totals per word, restarting with every sequence
     for (size_t i = 0; i < r.codes.size(); ++i) {
@@ -566,8 +595,8 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     d.seq_word_off = up.put(s.seq_word_off);
     d.seq_len = up.put(s.seq_len);
     d.seq_base_off = up.put(s.seq_base_off);
-    s.sys_fwd = up.put(std::vector<uint16_t>(bases + 8, 0));
-    s.sys_rev = up.put(std::vector<uint16_t>(bases + 8, 0));
+    s.sys_fwd = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
+    s.sys_rev = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
     d.sys_fwd = s.sys_fwd;
     d.sys_rev = s.sys_rev;
     std::string names;

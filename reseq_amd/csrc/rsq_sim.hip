@@ -116,6 +116,13 @@ struct DeviceUploader : Uploader {
         HIP_CHECK(hipMemcpy(own.back()->as<void>(), data, bytes, hipMemcpyHostToDevice));
         return own.back()->as<void>();
     }
+    void *put_zeros(size_t bytes) override {
+        std::vector<std::unique_ptr<DevBuf>> &own = owned[current_scope];
+        own.emplace_back(new DevBuf());
+        own.back()->reserve(bytes + 8);
+        HIP_CHECK(hipMemset(own.back()->as<void>(), 0, bytes + 8));
+        return own.back()->as<void>();
+    }
     void write_bytes(void *dst, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
     void read_bytes(void *dst_host, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost)); }
 };

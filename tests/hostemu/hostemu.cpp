@@ -32,6 +32,11 @@ struct HostUploader : Uploader {
         owned[current_scope].push_back(p);
         return p;
     }
+    void *put_zeros(size_t bytes) override {
+        void *p = calloc(bytes + 8, 1);
+        owned[current_scope].push_back(p);
+        return p;
+    }
     void write_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
     void read_bytes(void *dst_host, const void *src, size_t bytes) override { memcpy(dst_host, src, bytes); }
     ~HostUploader() override {

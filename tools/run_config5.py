@@ -68,10 +68,19 @@ with open(bpath, "w") as f:
 t_make = time.perf_counter() - t0
 
 t0 = time.perf_counter()
+load_stages = {}
+t1 = time.perf_counter()
 prof, ref = api.Profile(ppath), api.Reference(fpath, 7)
+load_stages["fasta_and_replace_n"] = round(time.perf_counter() - t1, 2)
+t1 = time.perf_counter()
 alleles = ref.read_variants(vpath)
+load_stages["vcf"] = round(time.perf_counter() - t1, 2)
+t1 = time.perf_counter()
 sim = api.Simulator(prof, ref, 0)
+load_stages["create_simulator_pack_upload"] = round(time.perf_counter() - t1, 2)
+t1 = time.perf_counter()
 sim.read_methylation(bpath)
+load_stages["methylation_bed"] = round(time.perf_counter() - t1, 2)
 t_load = time.perf_counter() - t0
 t0 = time.perf_counter()
 info = sim.prepare(7, 0, 30.0)
@@ -105,7 +114,7 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
     out[name]["sha256_first_48000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
 print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
-                  "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "prepare_s": round(t_prep, 2),
+                  "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": out["batch_24000"]["pairs"] / out["batch_24000"]["gpu_s"],
                   "batching_invariant": out["batch_24000"]["pairs"] == out["batch_12000"]["pairs"] and out["batch_24000"]["fastq_bytes"] == out["batch_12000"]["fastq_bytes"] and
                   out["batch_24000"]["sha256_first_48000_blocks"] == out["batch_12000"]["sha256_first_48000_blocks"]}))
