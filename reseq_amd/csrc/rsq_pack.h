@@ -1014,7 +1014,7 @@ inline void build_variant_sys_errors(SimState &s, Uploader &up, const std::vecto
         }
     };
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, std::min(hw ? hw : 1u, 64u)));
     std::vector<std::thread> helpers;
     for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(work, true);
     work(false);
@@ -1156,15 +1156,28 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
 }
 
 // the strand windows of a finished chain run (the reference chains among `chains`; n_chunks = all chunks of the run), each with the
-// state its chain was entered with -- what build_variant_sys_errors needs of a rank's share
-inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks) {
+// state its chain was entered with -- what build_variant_sys_errors needs of a rank's share.  Long strands are cut into windows of
+// kWindowChunks chunks, each entered with the state the fixed point left in front of its first chunk (entering_state(flat chunk index)),
+// so that the host pass over the variants has many independent tasks.
+constexpr uint32_t kWindowChunks = 32768;                          // 8.4 M positions
+inline uint32_t window_chunks() {                                  // RSQ_WINDOW_CHUNKS: smaller windows, so that tests on short sequences cut strands too
+    const char *e = getenv("RSQ_WINDOW_CHUNKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (uint32_t)v : kWindowChunks;
+}
+template <class EnteringState>
+inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks, EnteringState &&entering_state) {
     std::vector<StrandTask> out;
     for (size_t c = 0; c < chains.size(); ++c) {
         const Chain &ch = chains[c];
         if (ch.kind > 1u) continue;
         const uint32_t chunks = (c + 1 < chains.size() ? chains[c + 1].first_chunk : n_chunks) - ch.first_chunk;
-        const uint32_t lo = ch.chunk_lo * kChainChunk, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + chunks) * kChainChunk);
-        out.push_back(StrandTask{ch.id, (int)ch.kind, StrandWindow{lo, hi, ch.in_state}});
+        const uint32_t per_window = window_chunks();
+        for (uint32_t first = 0; first < chunks; first += per_window) {
+            const uint32_t count = std::min(per_window, chunks - first);
+            const uint32_t lo = (ch.chunk_lo + first) * kChainChunk, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + first + count) * kChainChunk);
+            out.push_back(StrandTask{ch.id, (int)ch.kind, StrandWindow{lo, hi, first ? entering_state(ch.first_chunk + first) : ch.in_state}});
+        }
     }
     return out;
 }

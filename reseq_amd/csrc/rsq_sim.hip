@@ -172,6 +172,15 @@ static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t s
     }
     run.passes = pass + 1;                                          // the final states are in d_out[(run.passes - 1) & 1]
 }
+// the windows of the finished run's strands; the state in front of a chunk is what the chunk was last run with (d_used)
+static std::vector<StrandTask> chain_windows(rsq_sim &s) {
+    rsq_sim::ChainRun &run = s.chain_run;
+    return strand_tasks(run.chains, run.n_chunks, [&](uint32_t flat_chunk) {
+        uint32_t state = 0;
+        HIP_CHECK(hipMemcpy(&state, run.d_used.as<uint32_t>() + flat_chunk, 4, hipMemcpyDeviceToHost));
+        return state;
+    });
+}
 static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const ShardRange *range = nullptr) {
     rsq_sim::ChainRun &run = s.chain_run;
     run.valid = false;
@@ -259,7 +268,10 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
     s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);
     HIP_CHECK(hipStreamSynchronize(st));
     lap("systematic-error chains", t0);
-    build_variant_sys_errors(s, s.up);                              // -V: the variants' bases, from the finished chains
+    if (s.has_variants && s.chain_run.valid) {                      // -V: the variants' bases, from the finished chains, in windows of the strands
+        const std::vector<StrandTask> windows = chain_windows(s);
+        build_variant_sys_errors(s, s.up, &windows);
+    }
     lap("variants' systematic errors", t0);
     s.prepared = true;
 }
@@ -950,7 +962,7 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         if (s->has_variants) {                                      // -V: the variants' bases inside the rank's strand windows, from the finished chains
-            const std::vector<StrandTask> windows = strand_tasks(s->chain_run.chains, s->chain_run.n_chunks);
+            const std::vector<StrandTask> windows = chain_windows(*s);
             build_variant_sys_errors(*s, s->up, &windows);
         }
         s->prepared = true;

@@ -268,8 +268,12 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
             bias_partials(s, plan, 0, UINT64_MAX, h_sum, h_max);
             normalization_from_partials(s, s.up, plan, h_sum.data(), h_max.data());
         }
-        s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters);
-        build_variant_sys_errors(s, s.up);
+        s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters, s.chain_run);
+        if (s.has_variants) {                                  // as rsq_sim.hip's prepare: the variants' bases in windows of the strands
+            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), [&](uint32_t c) { return s.chain_run.used[c]; });
+            build_variant_sys_errors(s, s.up, &windows);
+        }
+        s.chain_run.valid = false;
         s.build_lds();
         s.prepared = true;
     });
@@ -340,7 +344,7 @@ int emu_prepare_finish(void *h) {
     return guard([&] {
         if (!s.chain_run.valid) throw Error("the sharded pre-pass has not run");
         if (s.has_variants) {
-            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size());
+            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), [&](uint32_t c) { return s.chain_run.used[c]; });
             build_variant_sys_errors(s, s.up, &windows);
         }
         s.build_lds();

@@ -171,6 +171,13 @@ def test_variants_crowding_the_sequence_ends(workdir):
     P.case_variants_indels(EmuBackend, workdir, density=30, seed=78, tag="ends78", lengths=(3300, 2100), ends=45)
 
 
+def test_variants_systematic_errors_in_strand_windows(workdir, monkeypatch):
+    """the host pass over the variants' systematic errors cuts long strands into windows that start from the chain's state in front of them
+    (8.4 M positions each; here two chunks of 256, so that these short sequences are cut as well)"""
+    monkeypatch.setenv("RSQ_WINDOW_CHUNKS", "2")
+    P.case_variants_indels(EmuBackend, workdir, density=9, seed=47, tag="windows", lengths=(5300, 2600), samples=2)
+
+
 def test_variants_complex(workdir):
     P.case_variants_complex(EmuBackend, workdir)
 
