@@ -209,6 +209,15 @@ constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
 // partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each, BiasPlan::chunk_ptr) whose first start position lies in
 // the share [g_lo, g_hi) of the concatenated sequences; zero elsewhere
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
+    const bool trace = getenv("RSQ_TRACE_PREPARE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        HIP_CHECK(hipStreamSynchronize(st));
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "prepare:   bias sums: %-18s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
     const uint32_t n_chunks = bias_chunks(plan);
     h_sum.assign(n_chunks, 0.0);
     h_max.assign(n_chunks, 0.0);
@@ -220,16 +229,19 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     // the share's chunks read start positions up to a chunk behind g_hi and end positions a fragment length further
     const uint64_t w_lo = std::min<uint64_t>(g_lo, s.total_ref_size);
     const uint64_t w_hi = g_hi == UINT64_MAX ? s.total_ref_size : std::min<uint64_t>(s.total_ref_size, g_hi + (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to);
+    lap("chunk tables");
     double *start_bias = nullptr, *end_bias = nullptr;
     if ((w_hi - w_lo) * 16 <= kSurroundingTrackBytesMax) {         // 16 bytes per base of the share: 50 GB for a whole human genome, of 288 GB
         d_start_bias.reserve((w_hi - w_lo) * 8 + 16);
         d_end_bias.reserve((w_hi - w_lo) * 8 + 16);
         start_bias = d_start_bias.as<double>();
         end_bias = d_end_bias.as<double>();
+        lap("track buffers");
         uint32_t longest = 0;
         for (uint32_t L : s.seq_len) longest = std::max(longest, L);
         hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias, w_lo, w_hi);
         HIP_CHECK(hipGetLastError());
+        lap("track kernel");
     }
     d_sum.reserve((size_t)n_chunks * 8);
     d_max.reserve((size_t)n_chunks * 8);
@@ -238,9 +250,11 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     hipLaunchKernelGGL(k_sum_bias, dim3(n_chunks), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_chunk_param.as<uint32_t>(), d_chunk_ptr.as<uint32_t>(), start_bias,
                        end_bias, w_lo, d_sum.as<double>(), d_max.as<double>(), g_lo, g_hi);
     HIP_CHECK(hipGetLastError());
+    lap("sum kernel");
     HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    lap("download");
 }
 static void bias_normalization(rsq_sim &s, hipStream_t st) {
     const BiasPlan plan = plan_bias_normalization(s, s.up);
