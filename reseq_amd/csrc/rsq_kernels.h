@@ -139,25 +139,34 @@ RSQ_HD double site_bias(const DevSim &S, uint64_t word_off, uint32_t L, uint32_t
 // Speculative chunking: pass 0 runs every chunk from (dist,start_rate) = (0,0); later passes re-run exactly the
 // chunks whose true incoming state (the outgoing state of their left neighbour) differs from the one they used.
 // The fixed point is the sequential chain, bit for bit, for any seed.
-__global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains, const uint32_t *chunk_chain, uint32_t n_chunks, uint32_t chunk_len, uint32_t *used_state,
-                            const uint32_t *out_prev, uint32_t *out_new, uint32_t *changed, int pass) {
+//   k_sys_chain_select (passes > 0): one lane per chunk compares; chunks to run again are appended to `list` (their order does not
+//       matter: chunks of one pass are independent), the others keep their outgoing state.  A wave of the run kernel then holds 64 chunks
+//       that all have work, whatever share of the chunks changed.
+//   k_sys_chain: one lane per listed chunk (pass 0: every chunk, list == nullptr).
+RSQ_HD uint32_t chain_incoming(const Chain &ch, uint32_t c, const uint32_t *out_prev, int pass) {
+    const uint32_t local = c - ch.first_chunk;
+    if (local == 0) return ch.in_state;
+    return pass > 0 ? out_prev[c - 1] : 0u;                          // pass 0: the guess (0, 0)
+}
+__global__ void __launch_bounds__(256) k_sys_chain_select(const Chain *chains, const uint32_t *chunk_chain, uint32_t n_chunks, const uint32_t *used_state, const uint32_t *out_prev,
+                                                         uint32_t *out_new, uint32_t *list, uint32_t *n_listed, int pass) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
+    if (chain_incoming(chains[chunk_chain[c]], c, out_prev, pass) == used_state[c]) out_new[c] = out_prev[c];
+    else list[atomicAdd(n_listed, 1u)] = c;
+}
+__global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains, const uint32_t *chunk_chain, const uint32_t *list, uint32_t n_run, uint32_t chunk_len,
+                                                 uint32_t *used_state, const uint32_t *out_prev, uint32_t *out_new, int pass) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_run) return;
+    const uint32_t c = list ? list[i] : i;
     const Chain ch = chains[chunk_chain[c]];
     const uint32_t local = c - ch.first_chunk;
-    uint32_t want = local == 0 ? ch.in_state : 0u;                  // pass 0: every other chunk starts from the guess (0, 0)
-    if (pass > 0) {
-        if (local) want = out_prev[c - 1];
-        if (want == used_state[c]) {
-            out_new[c] = out_prev[c];
-            return;
-        }
-        *changed = 1;
-    }
-    used_state[c] = want;
+    const uint32_t want = chain_incoming(ch, c, out_prev, pass);
     ChainAcc acc{S.ref_words, ch.kind, ch.len, ch.kind < 2 ? S.seq_word_off[ch.id] : 0, ch.kind == 2 ? S.adapters[ch.seg].seqs + S.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
     uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
     const uint32_t lo = (ch.chunk_lo + local) * chunk_len, hi = lo + chunk_len < ch.len ? lo + chunk_len : ch.len;
+    used_state[c] = want;
     sys_chain_chunk(S, acc, ch.c1, ch.c2, lo, hi, ch.initial_dom, dist, start_rate, ch.out);
     out_new[c] = dist | (start_rate << 24);
 }

@@ -147,7 +147,7 @@ struct rsq_sim : SimState {
         ShardEdges edges;
         uint32_t n_chunks = 0, passes = 0, block_lo = 0, block_hi = 0;
         bool pass_through = false;     // the rank has no blocks: its neighbours' states go straight through
-        DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed;
+        DevBuf d_chains, d_chunk_chain, d_used, d_out[2], d_changed, d_list;
         bool valid = false;
     } chain_run;
 };
@@ -158,18 +158,30 @@ namespace rsq {
 // passes of k_sys_chain over the run's chunks until no chunk's incoming state changed; `first_pass`: 0 for a new run, the run's pass
 // count to resume one whose entering states (Chain::in_state) were replaced
 static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t st, uint32_t first_pass) {
+    run.d_list.reserve((size_t)run.n_chunks * 4 + 16);
     uint32_t pass = first_pass;
     for (;; ++pass) {
-        HIP_CHECK(hipMemsetAsync(run.d_changed.as<uint32_t>(), 0, 4, st));
-        hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(run.n_chunks, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), run.n_chunks, kChainChunk,
-                           run.d_used.as<uint32_t>(), run.d_out[(pass + 1) & 1].as<uint32_t>(), run.d_out[pass & 1].as<uint32_t>(), run.d_changed.as<uint32_t>(), (int)pass);
-        HIP_CHECK(hipGetLastError());
-        uint32_t changed = 0;
-        HIP_CHECK(hipMemcpyAsync(&changed, run.d_changed.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (pass > 0 && !changed) break;
+        uint32_t *out_prev = run.d_out[(pass + 1) & 1].as<uint32_t>(), *out_new = run.d_out[pass & 1].as<uint32_t>();
+        uint32_t n_run = run.n_chunks;
+        const uint32_t *list = nullptr;
+        if (pass > 0) {                                             // which chunks were entered with a state that has changed since
+            HIP_CHECK(hipMemsetAsync(run.d_changed.as<uint32_t>(), 0, 4, st));
+            hipLaunchKernelGGL(k_sys_chain_select, dim3(cdiv(run.n_chunks, 256)), dim3(256), 0, st, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), run.n_chunks,
+                               run.d_used.as<uint32_t>(), out_prev, out_new, run.d_list.as<uint32_t>(), run.d_changed.as<uint32_t>(), (int)pass);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(&n_run, run.d_changed.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            list = run.d_list.as<uint32_t>();
+        }
+        if (n_run) {
+            hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_run, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), list, n_run, kChainChunk,
+                               run.d_used.as<uint32_t>(), out_prev, out_new, (int)pass);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (pass > 0 && !n_run) break;
         if (pass > first_pass + run.n_chunks + 2) throw Error("systematic-error chains did not converge");
     }
+    HIP_CHECK(hipStreamSynchronize(st));
     run.passes = pass + 1;                                          // the final states are in d_out[(run.passes - 1) & 1]
 }
 // the windows of the finished run's strands; the state in front of a chunk is what the chunk was last run with (d_used)
