@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--gc", type=float, default=0.508, help="G+C fraction of the synthetic reference (E. coli: 0.508)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-delivery", action="store_true")
+    ap.add_argument("--no-host-delivery", action="store_true", help="skip the value_to_host leg (it is skipped anyway with more than one GPU: every rank would pin 15 GB of host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -300,7 +300,7 @@ def main():
     # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1
     # overlaps the copy of batch k into page-locked host memory on a second stream
     to_host = None
-    if not args.no_host_delivery:
+    if not args.no_host_delivery and world == 1:
         host = [(torch.empty(need1 + 4096, dtype=torch.uint8, pin_memory=True), torch.empty(need2 + 4096, dtype=torch.uint8, pin_memory=True)) for _ in range(2)]
         copy_stream = torch.cuda.Stream(device=dev)
         done = [torch.cuda.Event(), torch.cuda.Event()]
