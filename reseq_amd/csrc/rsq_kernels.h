@@ -836,14 +836,27 @@ struct TextOps {                        // what a record is made of, on top of D
     RSQ_HD void str(const char *s, uint32_t len) {
         for (uint32_t i = 0; i < len; ++i) self().ch(s[i]);
     }
+    // decimal digits without a buffer: peeled from the least significant end into a register, most significant digit lowest, then handed to the
+    // sink four at a time
     RSQ_HD void num(uint32_t v) {              // 32-bit: division by 10 is a multiply and a shift
-        char tmp[10];
-        int k = 0;
+        uint64_t acc = 0;
+        uint32_t n = 0;
         do {
-            tmp[k++] = (char)('0' + v % 10u);
+            acc = (acc << 8) | (uint64_t)('0' + v % 10u);
             v /= 10u;
-        } while (v);
-        while (k) self().ch(tmp[--k]);
+            ++n;
+        } while (v && n < 8u);
+        if (v) {                               // nine or ten digits: the leading ones first
+            uint32_t hi = 0, nh = 0;
+            do {
+                hi = (hi << 8) | ('0' + v % 10u);
+                v /= 10u;
+                ++nh;
+            } while (v);
+            self().bytes(hi, nh);
+        }
+        self().bytes((uint32_t)acc, n < 4u ? n : 4u);
+        if (n > 4u) self().bytes((uint32_t)(acc >> 32), n - 4u);
     }
     RSQ_HD void num(uint64_t v) {
         if (v <= 0xFFFFFFFFull) return num((uint32_t)v);
@@ -868,6 +881,9 @@ struct TextSinkT : TextOps<TextSinkT<P>> {      // appends characters at p (no n
     RSQ_HD void ch(char c) {
         p[n] = c;
         ++n;
+    }
+    RSQ_HD void bytes(uint32_t word, uint32_t count) {        // count <= 4 characters, the first in the low byte
+        for (uint32_t i = 0; i < count; ++i) ch((char)(word >> (8u * i)));
     }
 };
 using TextSink = TextSinkT<char *>;
@@ -910,6 +926,7 @@ struct WordSinkT : TextOps<WordSinkT<P>> {
         }
     }
     RSQ_HD void ch(char c) { push((uint8_t)c, 1u); }
+    RSQ_HD void bytes(uint32_t word, uint32_t count) { push(count < 4u ? word & ((1u << (8u * count)) - 1u) : word, count); }
     RSQ_HD void finish() {
         while (pending) {
             *p = (char)(acc & 0xFFu);
