@@ -22,7 +22,7 @@ if fill and "FETCH_SIZE" in pmc[fill[0]] and "WRITE_SIZE" in pmc[fill[0]]:
     fetch_kib, write_kib = pmc[k]["FETCH_SIZE"]["mean"], pmc[k]["WRITE_SIZE"]["mean"]
     json.dump({"kernel": k, "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib,
                "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024,
-               "note": "mean over the launches of bench.py --steps 1 (4 batches of 1200 blocks, the last one smaller); FETCH_SIZE doubled per the guide's gfx950 correction"},
+               "note": "mean over the k_fill_reads launches of bench.py --steps 1 --warmup 0 --no-host-delivery (the sizing pass and the step: the whole job per launch); FETCH_SIZE doubled per the guide's gfx950 correction"},
               open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 for f in (root + "/bench.json", root + "/bench_under_rocprof.json"):
     try:
