@@ -226,6 +226,20 @@ struct TextIn {                       // lines of a plain, gzip or bzip2 file, o
             at = have;
         }
     }
+    // raw bytes (the block reader of seqToIllumina): bytes read, 0 at the end, < 0 on an error
+    int read_raw(void *dst, unsigned n) {
+        if (!is_file) {
+            const size_t got = fread(dst, 1, n, stdin);
+            return got ? (int)got : (ferror(stdin) ? -1 : 0);
+        }
+        try {
+            return r.read(dst, n);
+        } catch (const std::exception &e) {
+            ERR(e.what());
+            failed = true;
+            return -1;
+        }
+    }
     void close() { r.close(); }
 };
 
@@ -462,46 +476,42 @@ int illumina_pe(const Args &a) {
     return 0;
 }
 
-// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: reader, ErrorModelOnlyThread :2514-2560,
-// ordered output :184-213): a reader thread parses the FASTA text into packed batches in page-locked memory, the main thread uploads a
-// batch, runs the error model and the FASTQ formatter on the device (rsq_sim_error_model_fastq) and hands the text to the writer
-// thread of AsyncOut -- parsing batch k+1, simulating batch k and writing batch k-1 overlap.  Device and host buffers are reused.
-//
-// One FASTA record of the input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
+// One FASTA record of seqToIllumina's input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
 struct RecordFields {
     size_t id_len = 0, dom_at = 0, rate_at = 0;
     uint8_t seg = 0;
     uint32_t frag_len = 0;
 };
-bool parse_record(const std::string &header, size_t L, RecordFields &r) {
-    if (header.size() <= 2 * L + 2) {
-        ERR("Read description is too short to contain systematic error information and a sequence id: " << header);
+bool parse_record(const char *header, size_t header_len, size_t L, RecordFields &r) {
+    auto text = [&]() { return std::string(header, header_len); };
+    if (header_len <= 2 * L + 2) {
+        ERR("Read description is too short to contain systematic error information and a sequence id: " << text());
         return false;
     }
-    size_t end = header.size() - 2 * L - 3;
+    size_t end = header_len - 2 * L - 3;
     if (header[end + 1] != ';' || header[end + 2 + L] != ';') {
-        ERR("The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " << header);
+        ERR("The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " << text());
         return false;
     }
     r.dom_at = end + 2;
-    r.rate_at = header.size() - L;
+    r.rate_at = header_len - L;
     while (end && header[end] != ' ') --end;
     if (!end) {
-        ERR("No sequence id found that is separated by a space from the ReSeq information: " << header);
+        ERR("No sequence id found that is separated by a space from the ReSeq information: " << text());
         return false;
     }
     r.id_len = end;
     if (header[end + 1] == '1') r.seg = 0;
     else if (header[end + 1] == '2') r.seg = 1;
     else {
-        ERR("Template segment is " << header[end + 1] << " not 1 or 2: " << header);
+        ERR("Template segment is " << header[end + 1] << " not 1 or 2: " << text());
         return false;
     }
     if (header[end + 2] != ';') {
-        ERR("The template segment and fragment length are not separated by a semicolon: " << header);
+        ERR("The template segment and fragment length are not separated by a semicolon: " << text());
         return false;
     }
-    const size_t fl_at = end + 3, fl_end = header.size() - 2 * L - 2;
+    const size_t fl_at = end + 3, fl_end = header_len - 2 * L - 2;
     uint64_t v = 0;
     bool digits = fl_end > fl_at;
     for (size_t k = fl_at; k < fl_end && digits; ++k) {
@@ -509,7 +519,7 @@ bool parse_record(const std::string &header, size_t L, RecordFields &r) {
         v = v * 10 + (uint64_t)(header[k] - '0');
     }
     if (!digits) {
-        ERR("Fragment length '" << header.substr(fl_at, fl_end > fl_at ? fl_end - fl_at : 0) << "' is not a pure integer: " << header);
+        ERR("Fragment length '" << std::string(header + fl_at, fl_end > fl_at ? fl_end - fl_at : 0) << "' is not a pure integer: " << text());
         return false;
     }
     r.frag_len = (uint32_t)v;
@@ -535,7 +545,7 @@ struct HostArray {                    // page-locked, grow-only
         void *q = nullptr;
         const size_t want = std::max(n, cap + cap / 2);
         if (!check(rsq_host_alloc(want, &q), "host buffer")) return false;
-        if (keep) memcpy(q, p, keep);
+        if (p && keep) memcpy(q, p, std::min(keep, cap));
         if (p) rsq_host_free(p);
         p = q;
         cap = want;
@@ -548,136 +558,227 @@ struct HostArray {                    // page-locked, grow-only
     }
 };
 
-// records of one template length, packed for rsq_sim_error_model_fastq
-struct PackedBatch {
-    static constexpr size_t kRecords = 1u << 19;
-    size_t n = 0, L = 0, id_bytes = 0;
-    uint64_t first_index = 0;
-    HostArray seqs, dom, rate, seg, fl, ids, id_off;
-    bool start(size_t length, uint64_t first) {
-        n = 0;
-        id_bytes = 0;
-        L = length;
-        first_index = first;
-        return seqs.ensure(kRecords * L) && dom.ensure(kRecords * L) && rate.ensure(kRecords * L) && seg.ensure(kRecords) && fl.ensure(kRecords * 4) &&
-               id_off.ensure((kRecords + 1) * 8) && ids.ensure(kRecords * 48);
+// One block of the input text and what a parser thread makes of it: the records packed for rsq_sim_error_model_fastq, in runs of one
+// template length each (a launch serves one length).  Slots go round: FREE -> TEXT (reader) -> PARSING -> PARSED (a parser) -> FREE (consumer).
+struct ParseSlot {
+    enum State { FREE, TEXT, PARSING, PARSED } state = FREE;
+    std::vector<char> text;           // whole records: ends behind the last line of a record
+    size_t text_len = 0;
+    bool failed = false;
+    struct Run {
+        size_t first, n, L, base_at, id_first;      // records [first, first + n) of the slot, their bases from base_at on
+    };
+    std::vector<Run> runs;
+    size_t n = 0, bases = 0, id_bytes = 0;
+    HostArray seqs, dom, rate, seg, fl, ids, id_off;   // id_off: per run n + 1 offsets relative to the run's first id, stored at first + run index
+    bool reserve(size_t records, size_t n_bases, size_t n_id_bytes) {
+        return seqs.ensure(n_bases, bases) && dom.ensure(n_bases, bases) && rate.ensure(n_bases, bases) && seg.ensure(records, n) && fl.ensure(records * 4, n * 4) &&
+               id_off.ensure((records + runs.size() + 2) * 8, (n + runs.size() + 1) * 8) && ids.ensure(n_id_bytes, id_bytes);
     }
-    bool full() const { return n == kRecords; }
-    bool add(const std::string &header, const std::string &seq, const RecordFields &r) {
+    // parses text[0, text_len) -- complete records -- into the arrays
+    bool parse() {
         static const CodeTable t;
-        uint8_t *s = seqs.as<uint8_t>() + n * L, *d = dom.as<uint8_t>() + n * L, *q = rate.as<uint8_t>() + n * L;
-        uint8_t any_n = 0;
-        for (size_t k = 0; k < L; ++k) {
-            s[k] = t.code[(uint8_t)seq[k]];
-            any_n |= s[k];
-            d[k] = t.code[(uint8_t)header[r.dom_at + k]];
-            int v = (uint8_t)header[r.rate_at + k] - 33;                 // Simulator.cpp:2439-2442
-            if (v > 86) v += v - 86;
-            q[k] = (uint8_t)v;
+        runs.clear();
+        n = bases = id_bytes = 0;
+        const char *p = text.data(), *end = p + text_len;
+        std::string joined;                                   // a sequence that is wrapped over several lines
+        while (p < end) {
+            while (p < end && (*p == '\n' || *p == '\r')) ++p;
+            if (p == end) break;
+            if (*p != '>') {                                   // text in front of the first header: SeqAn skips nothing here, but such a file is not FASTA
+                ERR("sequence data without a header line in the input");
+                return false;
+            }
+            const char *h0 = p + 1, *h1 = (const char *)memchr(h0, '\n', (size_t)(end - h0));
+            if (!h1) h1 = end;
+            const char *line = h1 < end ? h1 + 1 : end;
+            size_t header_len = (size_t)(h1 - h0);
+            if (header_len && h0[header_len - 1] == '\r') --header_len;
+            const char *seq = line;
+            size_t L = 0;
+            joined.clear();
+            bool single = true;
+            while (line < end && *line != '>') {
+                const char *le = (const char *)memchr(line, '\n', (size_t)(end - line));
+                if (!le) le = end;
+                size_t len = (size_t)(le - line);
+                if (len && line[len - 1] == '\r') --len;
+                if (L == 0 && joined.empty()) {
+                    seq = line;
+                    L = len;
+                } else if (len) {
+                    if (single) {
+                        joined.assign(seq, L);
+                        single = false;
+                    }
+                    joined.append(line, len);
+                }
+                line = le < end ? le + 1 : end;
+            }
+            if (!single) {
+                seq = joined.data();
+                L = joined.size();
+            }
+            RecordFields r;
+            if (!parse_record(h0, header_len, L, r)) return false;
+            if (runs.empty() || runs.back().L != L) runs.push_back(Run{n, 0, L, bases, id_bytes});
+            if (!reserve(n + 1, bases + L, id_bytes + r.id_len + 8)) return false;
+            uint8_t *sq = seqs.as<uint8_t>() + bases, *dm = dom.as<uint8_t>() + bases, *rt = rate.as<uint8_t>() + bases;
+            uint8_t any = 0;
+            for (size_t k = 0; k < L; ++k) {
+                sq[k] = t.code[(uint8_t)seq[k]];
+                any |= sq[k];
+                dm[k] = t.code[(uint8_t)h0[r.dom_at + k]];
+                int v = (uint8_t)h0[r.rate_at + k] - 33;                 // Simulator.cpp:2439-2442
+                if (v > 86) v += v - 86;
+                rt[k] = (uint8_t)v;
+            }
+            if (any & 4u) {
+                ERR("input sequences must not contain N: " << std::string(h0, r.id_len));
+                return false;
+            }
+            seg.as<uint8_t>()[n] = r.seg;
+            fl.as<uint32_t>()[n] = r.frag_len;
+            memcpy(ids.as<char>() + id_bytes, h0, r.id_len);
+            Run &run = runs.back();
+            uint64_t *off = id_off.as<uint64_t>() + run.first + (runs.size() - 1);      // n + 1 offsets per run
+            if (!run.n) off[0] = 0;
+            id_bytes += r.id_len;
+            off[run.n + 1] = id_bytes - run.id_first;
+            ++run.n;
+            ++n;
+            bases += L;
+            p = line;
         }
-        if (any_n & 4u) {
-            ERR("input sequences must not contain N: " << header.substr(0, r.id_len));
-            return false;
-        }
-        seg.as<uint8_t>()[n] = r.seg;
-        fl.as<uint32_t>()[n] = r.frag_len;
-        if (!ids.ensure(id_bytes + r.id_len + 8, id_bytes)) return false;
-        memcpy(ids.as<char>() + id_bytes, header.data(), r.id_len);
-        id_off.as<uint64_t>()[n] = id_bytes;
-        id_bytes += r.id_len;
-        id_off.as<uint64_t>()[++n] = id_bytes;
         return true;
     }
 };
 
-// the reader thread: FASTA text -> packed batches, two in rotation
-struct BatchReader {
+// reader thread (cuts the text into blocks of whole records), parser threads, and the consumer's view of the slots in input order
+struct ParsePipeline {
+    static constexpr size_t kBlockBytes = 24u << 20;
     TextIn &in;
-    PackedBatch batch[2];
-    bool ready[2] = {false, false}, failed = false, done = false, any = false, abort = false;
-    int next_fill = 0, next_take = 0;
+    std::vector<ParseSlot> slots;
     std::mutex m;
     std::condition_variable cv;
-    std::thread worker;
-    explicit BatchReader(TextIn &input) : in(input) {}
-    void start() {
-        worker = std::thread([this] {
-            const bool ok = run();
-            std::lock_guard<std::mutex> lock(m);
-            failed = !ok;
-            done = true;
-            cv.notify_all();
-        });
+    std::vector<std::thread> workers;
+    uint64_t blocks_read = 0, next_take = 0;
+    bool eof = false, failed = false, abort = false, any = false;
+    ParsePipeline(TextIn &input, size_t parsers) : in(input), slots(parsers + 2) {
+        workers.emplace_back([this] { read_blocks(); });
+        for (size_t k = 0; k < parsers; ++k) workers.emplace_back([this] { parse_blocks(); });
     }
-    PackedBatch *acquire() {                          // a free slot for the reader
-        std::unique_lock<std::mutex> lock(m);
-        cv.wait(lock, [&] { return !ready[next_fill] || abort; });
-        return abort ? nullptr : &batch[next_fill];
-    }
-    void publish() {
+    void fail() {
         std::lock_guard<std::mutex> lock(m);
-        ready[next_fill] = true;
-        next_fill ^= 1;
+        failed = true;
         cv.notify_all();
     }
-    bool run() {
-        std::string line, header, seq;
-        bool have_header = false;
-        uint64_t index = 0;
-        PackedBatch *cur = nullptr;
-        auto finish_record = [&]() {
-            if (!have_header) return true;
-            RecordFields r;
-            if (!parse_record(header, seq.size(), r)) return false;
-            if (cur && (cur->L != seq.size() || cur->full())) {       // one template length per launch
-                publish();
-                cur = nullptr;
+    void read_blocks() {
+        std::vector<char> carry;
+        for (uint64_t b = 0;; ++b) {
+            ParseSlot *slot = &slots[b % slots.size()];
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return slot->state == ParseSlot::FREE || abort || failed; });
+                if (abort || failed) break;
             }
-            if (!cur) {
-                cur = acquire();
-                if (!cur || !cur->start(seq.size(), index)) return false;
+            std::vector<char> &text = slot->text;
+            text.resize(std::max(text.size(), carry.size() + kBlockBytes + 1));
+            memcpy(text.data(), carry.data(), carry.size());
+            size_t have = carry.size();
+            carry.clear();
+            bool end_of_input = false;
+            for (;;) {                                        // until the block holds the start of another record behind its first one, or the input ends
+                if (have + (1u << 20) > text.size()) text.resize(text.size() * 2);
+                const int got = in.read_raw(text.data() + have, (unsigned)std::min<size_t>(text.size() - have, 1u << 30));
+                if (got < 0) return fail();
+                if (!got) {
+                    end_of_input = true;
+                    break;
+                }
+                have += (size_t)got;
+                if (have >= kBlockBytes) {
+                    size_t cut = have;                        // the last "\n>" of the block
+                    while (cut > 1 && !(text[cut - 1] == '>' && text[cut - 2] == '\n')) --cut;
+                    if (cut > 1) {
+                        carry.assign(text.begin() + (ptrdiff_t)(cut - 1), text.begin() + (ptrdiff_t)have);
+                        have = cut - 1;
+                        break;
+                    }
+                }
             }
-            if (!cur->add(header, seq, r)) return false;
-            ++index;
-            any = true;
-            return true;
-        };
-        while (in.getline(line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            if (!line.empty() && line[0] == '>') {
-                if (!finish_record()) return false;
-                header.assign(line, 1, std::string::npos);
-                have_header = true;
-                seq.clear();
-            } else seq += line;
+            std::lock_guard<std::mutex> lock(m);
+            slot->text_len = have;
+            slot->state = ParseSlot::TEXT;
+            ++blocks_read;
+            if (end_of_input) eof = true;
+            cv.notify_all();
+            if (end_of_input) break;
         }
-        if (!finish_record()) return false;
-        if (cur && cur->n) publish();
-        return true;
+        std::lock_guard<std::mutex> lock(m);
+        eof = true;
+        cv.notify_all();
     }
-    // the next batch for the device; nullptr at the end of the input (or after an error: `failed`)
-    PackedBatch *take() {
+    void parse_blocks() {
+        for (;;) {
+            ParseSlot *slot = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] {
+                    for (ParseSlot &s : slots)
+                        if (s.state == ParseSlot::TEXT) {
+                            slot = &s;
+                            return true;
+                        }
+                    return abort || failed || (eof && true);
+                });
+                if (!slot) {
+                    if (abort || failed) return;
+                    bool pending = false;                     // the reader is done: anything left to parse?
+                    for (ParseSlot &s : slots) pending = pending || s.state == ParseSlot::TEXT;
+                    if (!pending) return;
+                    continue;
+                }
+                slot->state = ParseSlot::PARSING;
+            }
+            const bool ok = slot->parse();
+            std::lock_guard<std::mutex> lock(m);
+            slot->failed = !ok;
+            slot->state = ParseSlot::PARSED;
+            if (!ok) failed = true;
+            cv.notify_all();
+        }
+    }
+    // the next block in input order; nullptr at the end of the input or after an error (`failed`)
+    ParseSlot *take() {
         std::unique_lock<std::mutex> lock(m);
-        cv.wait(lock, [&] { return ready[next_take] || done; });
-        if (!ready[next_take]) return nullptr;
-        return &batch[next_take];
+        ParseSlot *slot = &slots[next_take % slots.size()];
+        cv.wait(lock, [&] { return failed || (slot->state == ParseSlot::PARSED && true) || (eof && next_take >= blocks_read); });
+        if (failed || slot->state != ParseSlot::PARSED) return nullptr;
+        if (slot->n) any = true;
+        return slot;
     }
     void release() {
         std::lock_guard<std::mutex> lock(m);
-        ready[next_take] = false;
-        next_take ^= 1;
+        slots[next_take % slots.size()].state = ParseSlot::FREE;
+        ++next_take;
         cv.notify_all();
     }
     void join() {
         {
-            std::lock_guard<std::mutex> lock(m);             // a reader blocked on a free slot after the consumer gave up
+            std::lock_guard<std::mutex> lock(m);
             abort = true;
             cv.notify_all();
         }
-        if (worker.joinable()) worker.join();
+        for (std::thread &t : workers)
+            if (t.joinable()) t.join();
     }
 };
 
+// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: reader, ErrorModelOnlyThread :2514-2560,
+// ordered output :184-213): a reader thread cuts the FASTA text into blocks of whole records, parser threads pack the blocks into page-locked
+// arrays, the main thread takes the blocks in input order, uploads their records, runs the error model and the FASTQ formatter on the
+// device (rsq_sim_error_model_fastq) and hands the text to the writer thread of AsyncOut.  Device and host buffers are reused.
 int seq_to_illumina(const Args &a) {
     rsq_profile *prof = nullptr;
     rsq_sim *sim = nullptr;
@@ -697,40 +798,48 @@ int seq_to_illumina(const Args &a) {
     }
     if (ok) {
         INFO("Starting read generation");
-        BatchReader reader(fin);
-        reader.start();
+        const unsigned hw = std::thread::hardware_concurrency();
+        ParsePipeline pipe(fin, std::max(1u, std::min(hw > 2 ? hw - 2 : 1u, 6u)));
         DevBuffer d_seqs, d_dom, d_rate, d_seg, d_fl, d_ids, d_off, d_text;
-        uint64_t written = 0;
+        uint64_t written = 0, next_report = 0;
         while (ok) {
-            PackedBatch *b = reader.take();
+            ParseSlot *b = pipe.take();
             if (!b) break;
-            const size_t n = b->n, L = b->L;
-            ok = d_seqs.ensure(n * L) && d_dom.ensure(n * L) && d_rate.ensure(n * L) && d_seg.ensure(n) && d_fl.ensure(n * 4) && d_ids.ensure(b->id_bytes + 8) &&
-                 d_off.ensure((n + 1) * 8) && check(rsq_dev_upload(0, d_seqs.p, b->seqs.p, n * L), "upload") && check(rsq_dev_upload(0, d_dom.p, b->dom.p, n * L), "upload") &&
-                 check(rsq_dev_upload(0, d_rate.p, b->rate.p, n * L), "upload") && check(rsq_dev_upload(0, d_seg.p, b->seg.p, n), "upload") &&
-                 check(rsq_dev_upload(0, d_fl.p, b->fl.p, n * 4), "upload") && check(rsq_dev_upload(0, d_ids.p, b->ids.p, b->id_bytes + 1), "upload") &&
-                 check(rsq_dev_upload(0, d_off.p, b->id_off.p, (n + 1) * 8), "upload");
-            size_t len = 0;
-            for (int attempt = 0; ok && attempt < 2; ++attempt) {
-                ok = d_text.ensure(std::max(len + len / 8, n * (2 * L + 96) + b->id_bytes) + 64);
-                if (!ok) break;
-                const int rc = rsq_sim_error_model_fastq(sim, b->first_index, n, (uint32_t)L, (const uint8_t *)d_seqs.p, (const uint8_t *)d_seg.p, (const uint32_t *)d_fl.p,
-                                                         (const uint8_t *)d_dom.p, (const uint8_t *)d_rate.p, (const char *)d_ids.p, (const uint64_t *)d_off.p,
-                                                         (char *)d_text.p, d_text.cap, &len, nullptr);
-                if (rc == RSQ_ENOSPC && !attempt) continue;
-                ok = check(rc, "Simulation failed");
-                break;
+            for (size_t r = 0; ok && r < b->runs.size(); ++r) {
+                const ParseSlot::Run &run = b->runs[r];
+                const size_t n = run.n, L = run.L;
+                const size_t run_id_bytes = (size_t)b->id_off.as<uint64_t>()[run.first + r + n];
+                ok = d_seqs.ensure(n * L + 8) && d_dom.ensure(n * L + 8) && d_rate.ensure(n * L + 8) && d_seg.ensure(n) && d_fl.ensure(n * 4) && d_ids.ensure(run_id_bytes + 8) &&
+                     d_off.ensure((n + 1) * 8) && check(rsq_dev_upload(0, d_seqs.p, b->seqs.as<uint8_t>() + run.base_at, n * L), "upload") &&
+                     check(rsq_dev_upload(0, d_dom.p, b->dom.as<uint8_t>() + run.base_at, n * L), "upload") &&
+                     check(rsq_dev_upload(0, d_rate.p, b->rate.as<uint8_t>() + run.base_at, n * L), "upload") &&
+                     check(rsq_dev_upload(0, d_seg.p, b->seg.as<uint8_t>() + run.first, n), "upload") &&
+                     check(rsq_dev_upload(0, d_fl.p, b->fl.as<uint32_t>() + run.first, n * 4), "upload") &&
+                     check(rsq_dev_upload(0, d_ids.p, b->ids.as<char>() + run.id_first, run_id_bytes + 1), "upload") &&
+                     check(rsq_dev_upload(0, d_off.p, b->id_off.as<uint64_t>() + run.first + r, (n + 1) * 8), "upload");
+                size_t len = 0;
+                for (int attempt = 0; ok && attempt < 2; ++attempt) {
+                    ok = d_text.ensure(std::max(len + len / 8, n * (2 * L + 96) + run_id_bytes) + 64);
+                    if (!ok) break;
+                    const int rc = rsq_sim_error_model_fastq(sim, written, n, (uint32_t)L, (const uint8_t *)d_seqs.p, (const uint8_t *)d_seg.p, (const uint32_t *)d_fl.p,
+                                                             (const uint8_t *)d_dom.p, (const uint8_t *)d_rate.p, (const char *)d_ids.p, (const uint64_t *)d_off.p,
+                                                             (char *)d_text.p, d_text.cap, &len, nullptr);
+                    if (rc == RSQ_ENOSPC && !attempt) continue;
+                    ok = check(rc, "Simulation failed");
+                    break;
+                }
+                ok = ok && fout.push(d_text, len);
+                written += n;                                     // = the index of the next record in the input (it selects the records' random streams)
             }
-            reader.release();                                 // the inputs are on the device: the reader may refill the slot
-            ok = ok && fout.push(d_text, len);
-            if (ok) {
-                written += n;
+            pipe.release();                                       // the records are on the device: the slot may take the next block
+            if (ok && written >= next_report) {
                 INFO("Generated " << written << " reads.");
+                next_report = written + 1000000;
             }
         }
-        reader.join();
-        ok = ok && !reader.failed && !fin.failed;
-        if (ok && !reader.any) {
+        pipe.join();
+        ok = ok && !pipe.failed && !fin.failed;
+        if (ok && !pipe.any) {
             ERR(a.get("input", "stdin") << " does not contain any sequences.");
             ok = false;
         }
