@@ -112,7 +112,70 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
             h2.update(r2.to_numpy(np.uint8, l2).tobytes())
     out[name] = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
     out[name]["sha256_first_48000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
-print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
+# `python tools/run_config5.py <scale> shard`: the pre-pass of the same job sharded over 2, 4, 8 ranks (the ranks' simulators in this process,
+# sharding.sharded_prepare_in_process): seconds per rank, and that a rank's blocks then simulate to the same text as after the whole pre-pass
+sharded = None
+if len(sys.argv) > 2 and sys.argv[2] == "shard":
+    from reseq_amd import sharding
+
+
+    class Rank:
+        def __init__(self):
+            self.sim = api.Simulator(prof, ref, 0)
+            self.sim.read_methylation(bpath)
+            self.seq_len = lengths
+            self.seconds = 0.0
+
+        def _timed(self, f, *a):
+            t = time.perf_counter()
+            r = f(*a)
+            self.seconds += time.perf_counter() - t
+            return r
+
+        def ref_seq_bias(self):
+            return self.sim.ref_seq_bias(len(lengths))
+
+        def prepare_plan(self, *a):
+            return self._timed(self.sim.prepare_plan, *a)
+
+        def bias_partials(self, lo, hi):
+            return self._timed(self.sim.bias_partials, lo, hi)
+
+        def prepare_normalization(self, a, b):
+            return self._timed(self.sim.prepare_normalization, a, b)
+
+        def prepare_sys_errors(self, lo, hi, st):
+            return self._timed(self.sim.prepare_sys_errors, lo, hi, st)
+
+        def prepare_finish(self):
+            return self._timed(self.sim.prepare_finish)
+
+
+    def text_hash(s, lo, hi):
+        _, l1, l2, _ = s.pairs_device(lo, hi, None, None)
+        a, b = api.DeviceArray(0, l1 + 4096), api.DeviceArray(0, l2 + 4096)
+        k, l1, l2, rc = s.pairs_device(lo, hi, a, b)
+        assert rc == api.RSQ_OK
+        h = hashlib.sha256(a.to_numpy(np.uint8, l1).tobytes() + b.to_numpy(np.uint8, l2).tobytes()).hexdigest()
+        a.free()
+        b.free()
+        return k, h
+
+
+    sharded = {}
+    for world in (2, 4, 8):
+        ranks = [Rank() for _ in range(world)]
+        _, ranges, rounds = sharding.sharded_prepare_in_process(ranks, 7, 0, 30.0)
+        lo, hi = ranges[world // 2]
+        mid = lo + (hi - lo) // 2
+        same = text_hash(ranks[world // 2].sim, mid, min(hi, mid + 200)) == text_hash(sim, mid, min(hi, mid + 200))
+        lo, hi = ranges[-1]
+        same = same and text_hash(ranks[-1].sim, lo, min(hi, lo + 200)) == text_hash(sim, lo, min(hi, lo + 200))      # the first blocks behind a shard border
+        sharded[str(world)] = {"per_rank_s": [round(r.seconds, 3) for r in ranks], "chain_exchange_rounds": rounds, "equal_to_whole_pre_pass": bool(same)}
+        for r in ranks:
+            r.sim.close()
+
+print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "sharded_prepare": sharded, "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": out["batch_24000"]["pairs"] / out["batch_24000"]["gpu_s"],
