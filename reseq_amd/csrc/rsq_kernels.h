@@ -747,16 +747,29 @@ __global__ void k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *tile_
     }
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = s[0];
 }
-__global__ void k_scan_tiles(uint64_t *tile_sums, uint32_t n_tiles, uint64_t *total) {      // one block, serial over tiles (few thousand)
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t acc = 0;
-        for (uint32_t i = 0; i < n_tiles; ++i) {
-            uint64_t v = tile_sums[i];
-            tile_sums[i] = acc;
-            acc += v;
-        }
-        *total = acc;
+// one workgroup: every thread adds up a stretch of tiles, the stretches' sums are scanned in LDS, then every thread turns its stretch into
+// exclusive prefixes (tens of thousands of tiles for a batch of 10 M pairs: a single serial thread took a millisecond)
+constexpr uint32_t kScanTilesBlock = 1024;
+__global__ void __launch_bounds__(kScanTilesBlock) k_scan_tiles(uint64_t *tile_sums, uint32_t n_tiles, uint64_t *total) {
+    __shared__ uint64_t s[kScanTilesBlock];
+    const uint32_t per = (n_tiles + kScanTilesBlock - 1u) / kScanTilesBlock, lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    uint64_t acc = 0;
+    for (uint32_t i = lo; i < hi; ++i) acc += tile_sums[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanTilesBlock; d <<= 1) {              // inclusive scan of the stretches' sums
+        const uint64_t v = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
     }
+    uint64_t run = s[threadIdx.x] - acc;                              // what lies in front of this thread's stretch
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t v = tile_sums[i];
+        tile_sums[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == kScanTilesBlock - 1u) *total = s[threadIdx.x];
 }
 __global__ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *tile_sums, const uint64_t *total, uint64_t *out) {
     __shared__ uint64_t s[kScanBlock];

@@ -336,7 +336,7 @@ static void exclusive_scan(rsq_sim &s, const uint32_t *in, uint64_t n, uint64_t 
     s.tile_sums.reserve((size_t)(tiles + 1) * 8);
     s.scan_total.reserve(8);
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(64), 0, st, s.tile_sums.as<uint64_t>(), tiles, s.scan_total.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanTilesBlock), 0, st, s.tile_sums.as<uint64_t>(), tiles, s.scan_total.as<uint64_t>());
     hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>(), s.scan_total.as<uint64_t>(), out);
     HIP_CHECK(hipGetLastError());
 }
