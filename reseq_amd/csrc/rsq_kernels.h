@@ -1134,15 +1134,20 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
     // Simulator.cpp:482-489 without a load per base: the G/C count of the template's reference range from the per-word prefix sums
     // (the complement strand has the same count), the error rates four per 8-byte load
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
-        if (converted || !gc_prefix) return template_totals_loop(*this, n, gc, rate_sum);
-        gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
-        uint32_t k = 0;
-        for (; k < n && ((uintptr_t)(sys_ + k) & 7u); ++k) rate_sum += sys_[k] >> 8;
+        if (!converted && !gc_prefix) return template_totals_loop(*this, n, gc, rate_sum);
+        if (converted) gc += ref_gc_count(converted, 0, 0, n);                  // the converted template is packed like the reference, from base 0
+        else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
+        rate_sum += rate_total(n);
+    }
+    RSQ_HD uint32_t rate_total(uint32_t n) const {
+        uint32_t k = 0, sum = 0;
+        for (; k < n && ((uintptr_t)(sys_ + k) & 7u); ++k) sum += sys_[k] >> 8;
         for (; k + 4u <= n; k += 4u) {
             const uint64_t four = *reinterpret_cast<const uint64_t *>(sys_ + k);
-            rate_sum += (uint32_t)((four >> 8) & 0xFFu) + (uint32_t)((four >> 24) & 0xFFu) + (uint32_t)((four >> 40) & 0xFFu) + (uint32_t)(four >> 56);
+            sum += (uint32_t)((four >> 8) & 0xFFu) + (uint32_t)((four >> 24) & 0xFFu) + (uint32_t)((four >> 40) & 0xFFu) + (uint32_t)(four >> 56);
         }
-        for (; k < n; ++k) rate_sum += sys_[k] >> 8;
+        for (; k < n; ++k) sum += sys_[k] >> 8;
+        return sum;
     }
 };
 
@@ -1594,14 +1599,22 @@ struct VariantSrc : FragmentSrc {
     }
     // blocks are cut on the forward strand (Simulator.h:254): first strand position of the block after the one holding sp
     RSQ_HD uint32_t block_end(uint32_t sp) const { return reverse ? L - ((L - sp - 1u) / kBlockSize) * kBlockSize : (sp / kBlockSize + 1u) * kBlockSize; }
+    // what the common step -- a plain reference base, no variant in reach -- needs, kept between steps: the strand position of variant `cur`
+    // (none: 0xFFFFFFFF) and the end of the block holding spos; refreshed whenever cur or the block changes
+    mutable uint32_t vs_cur, bend_cur;
+    RSQ_HD void refresh() const {
+        vs_cur = cur < n_var ? var_spos(cur) : 0xFFFFFFFFu;
+        bend_cur = block_end(spos);
+    }
     RSQ_HD void rewind() const {
         spos = spos0;
         cur = cur0;
         var_pos = var_pos0;
+        refresh();
     }
     RSQ_HD void increment_block_pos() const {                                   // :232-238
-        const uint32_t bend = block_end(spos);
-        if (++spos == bend) cur = lower_bound(spos);
+        if (++spos == bend_cur) cur = lower_bound(spos);
+        refresh();
     }
     // With variants a few bases apart the walk (its skipped variants, its late ones) can use up more reference positions than the
     // template has and run off the end of the strand: the reference follows a NULL next_block_ there.  Reported, not simulated.
@@ -1612,6 +1625,14 @@ struct VariantSrc : FragmentSrc {
     }
     RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
         if (off_strand()) return 0;
+        if (!var_pos && !(vs_cur < bend_cur && vs_cur <= spos)) {               // the common step: no variant of the block at or before this position
+            const uint32_t se = sys_[spos - spos0];
+            if (++spos == bend_cur) {
+                cur = lower_bound(spos);
+                refresh();
+            }
+            return se;
+        }
         if (var_pos) {
             const uint32_t se = sys_[spos - spos0];
             if (++var_pos >= var_at(cur).len) {
@@ -1621,7 +1642,7 @@ struct VariantSrc : FragmentSrc {
             }
             return se;
         }
-        uint32_t bend = block_end(spos);
+        uint32_t bend = bend_cur;
         while (cur < n_var) {
             const uint32_t vs = var_spos(cur);
             if (!(vs < bend && vs <= spos)) break;                              // cur_var < err_variants_.size() && position_ <= block_pos
@@ -1631,14 +1652,18 @@ struct VariantSrc : FragmentSrc {
                     ++cur;
                     increment_block_pos();
                     if (off_strand()) return 0;
-                    bend = block_end(spos);
+                    bend = bend_cur;
                 } else {
                     const uint32_t se = var_err(cur, 0);
                     if (1u == v.len) {                                          // substitution
                         ++cur;
                         increment_block_pos();
                         ++cur;
-                    } else var_pos = 1;                                         // insertion
+                        refresh();
+                    } else {
+                        var_pos = 1;                                            // insertion
+                        refresh();
+                    }
                     return se;
                 }
             } else ++cur;
@@ -1652,15 +1677,20 @@ struct VariantSrc : FragmentSrc {
         const uint32_t se = sys_[spos - spos0];
         if (var_pos && ++var_pos >= var_at(cur).len) var_pos = 0;
         if (0u == var_pos) {
-            const uint32_t bend = block_end(spos);
-            if (++spos == bend) cur = lower_bound(spos);
+            if (++spos == bend_cur) cur = lower_bound(spos);
         }
+        refresh();
         return se;
     }
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {    // :480-504: the error rates through a copy of the walk
-        if (converted) {
-            for (uint32_t k = 0; k < n; ++k) gc += is_gc(base(k));
-        } else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
+        if (converted) gc += ref_gc_count(converted, 0, 0, n);
+        else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
+        // no variant in reach of these n steps (the walk starts at the first variant at or behind the first base, and that one lies behind the
+        // last): the walk returns the strand's own errors, a block change finds the same variant again
+        if (!var_pos0 && vs_cur >= spos0 + n && (0u == cur0 || var_spos(cur0 - 1u) < spos0)) {
+            rate_sum += rate_total(n);
+            return;
+        }
         for (uint32_t k = 0; k < n; ++k) rate_sum += sys_base(k) >> 8;
         rewind();
     }
