@@ -1580,14 +1580,15 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
 // applied late).
 struct VariantSrc : FragmentSrc {
     const DevVariant *var;              // the sequence's variants in forward order
-    const uint16_t *err_fwd, *err_rev;
+    const uint16_t *err;                // the variants' systematic errors on the strand the mate reads
+    const uint16_t *sys_at;             // sys_ - spos0: indexed by strand position
     uint32_t n_var, L, allele;
     uint32_t *walk_error;               // DevSim::walk_error
     uint32_t spos0, cur0, var_pos0;     // start of the walk: strand position of the first template base, variant index, position in an insertion
     mutable uint32_t spos, cur, var_pos;
     RSQ_HD const DevVariant &var_at(uint32_t i) const { return reverse ? var[n_var - 1u - i] : var[i]; }
     RSQ_HD uint32_t var_spos(uint32_t i) const { return reverse ? L - 1u - var_at(i).pos : var_at(i).pos; }
-    RSQ_HD uint32_t var_err(uint32_t i, uint32_t k) const { return (reverse ? err_rev : err_fwd)[var_at(i).off + k]; }
+    RSQ_HD uint32_t var_err(uint32_t i, uint32_t k) const { return err[var_at(i).off + k]; }
     RSQ_HD uint32_t lower_bound(uint32_t sp) const {
         uint32_t lo = 0, hi = n_var;
         while (lo < hi) {
@@ -1626,7 +1627,7 @@ struct VariantSrc : FragmentSrc {
     RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
         if (off_strand()) return 0;
         if (!var_pos && !(vs_cur < bend_cur && vs_cur <= spos)) {               // the common step: no variant of the block at or before this position
-            const uint32_t se = sys_[spos - spos0];
+            const uint32_t se = sys_at[spos];
             if (++spos == bend_cur) {
                 cur = lower_bound(spos);
                 refresh();
@@ -1634,7 +1635,7 @@ struct VariantSrc : FragmentSrc {
             return se;
         }
         if (var_pos) {
-            const uint32_t se = sys_[spos - spos0];
+            const uint32_t se = sys_at[spos];
             if (++var_pos >= var_at(cur).len) {
                 var_pos = 0;
                 ++cur;
@@ -1668,13 +1669,13 @@ struct VariantSrc : FragmentSrc {
                 }
             } else ++cur;
         }
-        const uint32_t se = sys_[spos - spos0];
+        const uint32_t se = sys_at[spos];
         increment_block_pos();
         return se;
     }
     RSQ_HD uint32_t sys_deleted(uint32_t) const {                               // :380-392
         if (off_strand()) return 0;
-        const uint32_t se = sys_[spos - spos0];
+        const uint32_t se = sys_at[spos];
         if (var_pos && ++var_pos >= var_at(cur).len) var_pos = 0;
         if (0u == var_pos) {
             if (++spos == bend_cur) cur = lower_bound(spos);
@@ -1700,13 +1701,13 @@ RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, const Fragment
     VariantSrc src;
     static_cast<FragmentSrc &>(src) = fragment_src(S, f, seg, fv ? fv->end : f.start + f.len);
     src.var = S.variants + S.var_ptr[f.seq];
-    src.err_fwd = S.var_err_fwd;
-    src.err_rev = S.var_err_rev;
+    src.err = src.reverse ? S.var_err_rev : S.var_err_fwd;
     src.n_var = S.var_ptr[f.seq + 1] - S.var_ptr[f.seq];
     src.L = S.seq_len[f.seq];
     src.allele = f.allele;
     src.walk_error = S.walk_error;
     src.spos0 = src.reverse ? src.L - src.first : src.first;
+    src.sys_at = src.sys_ - src.spos0;
     if (!fv) {
         src.cur0 = src.lower_bound(src.spos0);
         src.var_pos0 = 0;
