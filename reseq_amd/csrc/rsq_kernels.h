@@ -1473,6 +1473,13 @@ struct ScreenTables {
         const DevTable t = desc(24u * S.n_tiles + i);
         ps = 0.0;
         if (!t.k) return 0;
+        // nearly every draw: the random word alone says "no indel" (DevTable::sure_below); the wave skips the rows when all its lanes are that sure
+        const bool sure = u < t.sure_below && 0u == clamp_row(t, 0, idx[0]);
+        RSQ_SCREEN_COUNT(3, sure);
+        if (!RSQ_ANY(!sure)) {
+            ps = 1.0;
+            return 0;
+        }
         const uint32_t slot = S.lds.slot_i;
         const float *g = S.pool32 + t.off32;
         const bool m0_staged = t.lds_off != kNoLds;

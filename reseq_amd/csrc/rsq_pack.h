@@ -160,6 +160,38 @@ inline void pack_tables(SimState &s, Uploader &up) {
             if (pool32.size() > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
         }
     };
+    // The indel draw almost always returns "no indel".  The outcome columns are ordered by frequency, the likeliest on top (K-1), and LogArrayResult::Draw
+    // (rsq_core.h draw_rows) scans from the top: it returns column K-1 iff p_top > u * S.  For every choice of rows p_c <= f_c * p_top with f_c = the
+    // product over the margins of the largest ratio row[c] / row[top] (margin 0: its row 0 only -- the indel position, 0 outside an indel), so
+    // p_top / S >= 1 / (1 + B), B = sum of the f_c: for u below that (the reference's own roundings are 1e-14 of it; 1e-9 is allowed for) the top column
+    // is certain without reading a row.  A row with row[top] = 0 < row[c] leaves the table without a bound; rows that are 0 in both give
+    // p_c = 0 = p_top (prob_sum 0 also means "no indel", Simulator.cpp:349).
+    auto certain_top_column = [&](DevTable &d) {
+        d.sure_below = 0;
+        if (!d.k || !d.f32_ok || !d.rows[0] || par0[d.par0_off + d.k - 1u] != 0) return;
+        const uint32_t kp = row_stride(d.k), top = d.k - 1u;
+        double bound = 0.0;
+        for (uint32_t c = 0; c < top; ++c) {
+            const double *row0 = pool.data() + d.off[0];
+            if (row0[c] == 0.0) continue;
+            if (row0[top] == 0.0) return;
+            double f = row0[c] / row0[top];
+            for (uint32_t n = 1; n < 4; ++n) {
+                if (!d.rows[n]) continue;
+                double worst = 0.0;
+                for (uint32_t r = 0; r < d.rows[n]; ++r) {
+                    const double *row = pool.data() + d.off[n] + (size_t)r * kp;
+                    if (row[c] == 0.0) continue;
+                    if (row[top] == 0.0) return;
+                    worst = std::max(worst, row[c] / row[top]);
+                }
+                f *= worst;
+            }
+            bound += f;
+        }
+        const double words = std::floor(1.0 / (1.0 + bound) * (1.0 - 1e-9) * 4294967296.0);
+        if (words >= 1.0) d.sure_below = (uint32_t)std::min(words, 4294967295.0);
+    };
     for (uint32_t q : kQualityQuads)
         if (!plan.quads_q && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
     const bool screenable = plan.quads_q && quads_of(kmax_of(base_call)) <= kQuadsSmall && quads_of(kmax_of(indels)) <= kQuadsSmall;
@@ -169,6 +201,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
         copy32(quality, plan.slot_q);
         copy32(base_call, plan.slot_b);
         copy32(indels, plan.slot_i);
+        if (!getenv("RSQ_NO_INDEL_SKIP"))
+            for (DevTable &d : indels) certain_top_column(d);
     }
     // the two families of the systematic-error chains: rows of whole quads, read from HBM
     s.dev.chain_quads = 0;

@@ -7,7 +7,7 @@
 // oracle so that state-machine, packing and counter-layout mistakes are caught in a container without a GPU.
 // Nothing in reseq_amd/ links to or loads this file.
 #include <stdint.h>
-static uint64_t g_screen_stats[3][2];          // quality, base call, indel: draws, draws the screen left to double precision
+static uint64_t g_screen_stats[4][2];          // quality, base call, indel: draws, draws the screen left to double precision; indel draws, those the random word alone does not decide
 #define RSQ_SCREEN_STATS g_screen_stats
 #include <stdlib.h>
 
@@ -251,7 +251,7 @@ int emu_edit_profile(void *h, double error_multiplier, int no_substitutions, int
     });
 }
 
-// out[6]: the counters above; reset afterwards
+// out[8]: the counters above; reset afterwards
 void emu_screen_stats(uint64_t *out) {
     memcpy(out, g_screen_stats, sizeof g_screen_stats);
     memset(g_screen_stats, 0, sizeof g_screen_stats);

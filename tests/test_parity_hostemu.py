@@ -211,11 +211,13 @@ def test_the_screen_decides_almost_every_draw(workdir):
     import ctypes as C
     import numpy as np
     from backends import emu_lib
-    stats = np.zeros(6, np.uint64)
+    stats = np.zeros(8, np.uint64)
     emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))             # reset
     P.case_p0_reads(EmuBackend, workdir)
     emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))
-    (q, q_left), (b, b_left), (i, i_left) = stats.reshape(3, 2).tolist()
-    assert q > 400_000 and b > 400_000 and i > 400_000
+    (q, q_left), (b, b_left), (i, i_left), (w, w_left) = stats.reshape(4, 2).tolist()
+    assert q > 400_000 and b > 400_000 and w > 400_000
     assert 0 < q_left < 1e-3 * q, (q, q_left)                               # K = 40: about 2e-4
-    assert b_left < 2e-4 * b and i_left < 2e-4 * i, (b, b_left, i, i_left)
+    assert b_left < 2e-4 * b and i_left <= 2e-4 * w, (b, b_left, i, i_left)
+    # the indel draw: the random word alone says "no indel" (DevTable::sure_below) except for a few draws in a thousand; only those read rows
+    assert i == w_left and 0 < w_left < 5e-3 * w, (w, w_left)
