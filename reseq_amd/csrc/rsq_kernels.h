@@ -1473,8 +1473,9 @@ struct ScreenTables {
         const DevTable t = desc(24u * S.n_tiles + i);
         ps = 0.0;
         if (!t.k) return 0;
-        // nearly every draw: the random word alone says "no indel" (DevTable::sure_below); the wave skips the rows when all its lanes are that sure
-        const bool sure = u < t.sure_below && 0u == clamp_row(t, 0, idx[0]);
+        // nearly every draw: the random word alone says "no indel" (DevTable::sure_range); the wave skips the rows when all its lanes are that sure
+        const uint32_t lo16 = t.sure_range & 0xFFFFu;
+        const bool sure = (u >> 16) - lo16 < (t.sure_range >> 16) - lo16 && 0u == clamp_row(t, 0, idx[0]);
         RSQ_SCREEN_COUNT(3, sure);
         if (!RSQ_ANY(!sure)) {
             ps = 1.0;

@@ -160,37 +160,67 @@ inline void pack_tables(SimState &s, Uploader &up) {
             if (pool32.size() > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
         }
     };
-    // The indel draw almost always returns "no indel".  The outcome columns are ordered by frequency, the likeliest on top (K-1), and LogArrayResult::Draw
-    // (rsq_core.h draw_rows) scans from the top: it returns column K-1 iff p_top > u * S.  For every choice of rows p_c <= f_c * p_top with f_c = the
-    // product over the margins of the largest ratio row[c] / row[top] (margin 0: its row 0 only -- the indel position, 0 outside an indel), so
-    // p_top / S >= 1 / (1 + B), B = sum of the f_c: for u below that (the reference's own roundings are 1e-14 of it; 1e-9 is allowed for) the top column
-    // is certain without reading a row.  A row with row[top] = 0 < row[c] leaves the table without a bound; rows that are 0 in both give
-    // p_c = 0 = p_top (prob_sum 0 also means "no indel", Simulator.cpp:349).
-    auto certain_top_column = [&](DevTable &d) {
-        d.sure_below = 0;
-        if (!d.k || !d.f32_ok || !d.rows[0] || par0[d.par0_off + d.k - 1u] != 0) return;
-        const uint32_t kp = row_stride(d.k), top = d.k - 1u;
-        double bound = 0.0;
-        for (uint32_t c = 0; c < top; ++c) {
-            const double *row0 = pool.data() + d.off[0];
-            if (row0[c] == 0.0) continue;
-            if (row0[top] == 0.0) return;
-            double f = row0[c] / row0[top];
-            for (uint32_t n = 1; n < 4; ++n) {
-                if (!d.rows[n]) continue;
-                double worst = 0.0;
-                for (uint32_t r = 0; r < d.rows[n]; ++r) {
-                    const double *row = pool.data() + d.off[n] + (size_t)r * kp;
-                    if (row[c] == 0.0) continue;
-                    if (row[top] == 0.0) return;
-                    worst = std::max(worst, row[c] / row[top]);
+    // Draws decided by the random word alone: the indel draw almost always returns "no indel".
+    // LogArrayResult::Draw (rsq_core.h draw_rows) sums the products p_c from the top column down and returns the highest column z >= 1 whose sum T(z)
+    // exceeds u * S, else 0: column z iff T(z+1) <= u * S < T(z).  For every choice of rows p_c <= f_c * p_z with f_c = the product over the margins of
+    // the largest ratio row[c] / row[z] over the rows that may be combined, so with B_lo = sum of the f_c below z and B_hi = the sum above it:
+    // T(z+1) / S <= B_hi / (1 + B_hi) and T(z) / S >= 1 / (1 + B_lo); for u between the two (the reference's own roundings are 1e-14 of them; 1e-9 is
+    // allowed for) column z is certain without reading a row.  Margin 0 enters with ONE row (the lane knows it).  A row with row[z] = 0 < row[c]
+    // leaves no bound.  The bounds are kept as 16-bit fractions lo16 <= hi16:
+    // the draw is certain when lo16 <= (word >> 16) < hi16.
+    struct Certain {
+        uint32_t lo16 = 0, hi16 = 0;
+    };
+    // worst[z * 8 + c]: margins 1 .. 3 over all their rows, < 0: no bound
+    auto worst_ratios = [&](const DevTable &d, double (&worst)[64]) {
+        const uint32_t kp = row_stride(d.k);
+        for (uint32_t z = 0; z < d.k; ++z)
+            for (uint32_t c = 0; c < d.k; ++c) {
+                double f = 1.0;
+                for (uint32_t n = 1; n < 4 && f >= 0.0; ++n) {
+                    if (!d.rows[n]) continue;
+                    double w = 0.0;
+                    for (uint32_t r = 0; r < d.rows[n]; ++r) {
+                        const double *row = pool.data() + d.off[n] + (size_t)r * kp;
+                        if (row[z] > 0.0) w = std::max(w, row[c] / row[z]);
+                        else if (row[c] > 0.0) w = -1.0;
+                        if (w < 0.0) break;
+                    }
+                    f = w < 0.0 ? -1.0 : f * w;
                 }
-                f *= worst;
+                worst[z * 8u + c] = f;
             }
-            bound += f;
+    };
+    auto certain_column = [&](const DevTable &d, const double (&worst)[64], uint32_t row0, uint32_t z) {
+        const double *m0 = pool.data() + d.off[0] + (size_t)row0 * row_stride(d.k);
+        Certain none, r;
+        double below = 0.0, above = 0.0;
+        for (uint32_t c = 0; c < d.k; ++c) {
+            if (c == z) continue;
+            double f;
+            if (m0[z] > 0.0) f = m0[c] / m0[z];
+            else if (m0[c] > 0.0) return none;
+            else f = 0.0;
+            if (worst[z * 8u + c] < 0.0) return none;
+            (c < z ? below : above) += f * worst[z * 8u + c];
         }
-        const double words = std::floor(1.0 / (1.0 + bound) * (1.0 - 1e-9) * 4294967296.0);
-        if (words >= 1.0) d.sure_below = (uint32_t)std::min(words, 4294967295.0);
+        const double lo = above / (1.0 + above) * (1.0 + 1e-9), hi = 1.0 / (1.0 + below) * (1.0 - 1e-9);
+        r.lo16 = (uint32_t)std::ceil(lo * 65536.0);
+        r.hi16 = (uint32_t)std::floor(hi * 65536.0);
+        return r.lo16 < r.hi16 ? r : none;
+    };
+    // indel tables: one bound per table, for margin 0 (the indel position) at its row 0 and the column of value 0 = "no indel" (prob_sum 0 means the
+    // same, Simulator.cpp:349, so all-zero rows do no harm)
+    auto certain_no_indel = [&](DevTable &d) {
+        d.sure_range = 0;
+        if (!d.k || d.k > 8u || !d.f32_ok || !d.rows[0]) return;
+        double worst[64];
+        worst_ratios(d, worst);
+        for (uint32_t z = 0; z < d.k; ++z)
+            if (0 == par0[d.par0_off + z]) {
+                const Certain c = certain_column(d, worst, 0, z);
+                d.sure_range = c.lo16 | (c.hi16 << 16);
+            }
     };
     for (uint32_t q : kQualityQuads)
         if (!plan.quads_q && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
@@ -202,7 +232,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
         copy32(base_call, plan.slot_b);
         copy32(indels, plan.slot_i);
         if (!getenv("RSQ_NO_INDEL_SKIP"))
-            for (DevTable &d : indels) certain_top_column(d);
+            for (DevTable &d : indels) certain_no_indel(d);
     }
     // the two families of the systematic-error chains: rows of whole quads, read from HBM
     s.dev.chain_quads = 0;

@@ -43,9 +43,9 @@ struct DevTable {
     uint32_t off32;
     uint32_t f32_ok;       // every value is 0 or in [2^-60, 2^29]: the error bound of the screened draw holds
     uint32_t lds_extra;    // base call: offset of margin 2 (number of errors) in the LDS image, kNoLds if not staged
-    // indel tables: a draw whose 32 random bits are below sure_below, with margin 0 at its row 0, returns the top column, value 0 = no indel,
-    // whatever the rows of the other margins are (rsq_pack.h certain_top_column); 0: no such bound
-    uint32_t sure_below;
+    // indel tables: lo16 | hi16 << 16; a draw with lo16 <= (random word >> 16) < hi16 and margin 0 at its row 0 returns value 0 = no indel whatever the
+    // rows of the other margins are (rsq_pack.h certain_no_indel); 0: no such bound
+    uint32_t sure_range;
 };
 static_assert(sizeof(DevTable) == 80, "descriptor layout");
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;

@@ -155,6 +155,12 @@ def _indel_table(rng, cfg, prev_type, last_call):
     t2[:, 1:] = 1.0 + 0.004 * np.abs(gc - 50.0)
     for t in (t0, t1, t2):
         t *= _noise(rng, t.shape, 0.02)
+    # the scale of a margin's column is arbitrary (only the products matter) but decides the column order of result_table: with
+    # cfg["indel_columns_shuffled"] two insertion columns sort above "no indel", one with a sizeable rate
+    if cfg.get("indel_columns_shuffled"):
+        t0[:, 2] *= 300.0
+        t0[:, 2:4] /= 4.0
+        t1[:, 2:4] *= 4.0
     lim = [(0, cfg["indel_pos_to"]), (0, rl), (0, 101)]
     return result_table([t0, t1, t2], vals, lim)
 

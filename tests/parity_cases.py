@@ -267,6 +267,24 @@ def case_p0_reads(backend_cls, workdir):
         p.close()
 
 
+def case_indel_columns_shuffled(backend_cls, workdir):
+    """the indel draw decided by the random word alone (DevTable::sure_range) when "no indel" is a middle column of its tables and one
+    insertion is frequent: the range has a lower and an upper end"""
+    cfg = dict(synth.P0, name="P0s", indel_columns_shuffled=True)
+    p = Pair(backend_cls, workdir, "p0_shuffled", cfg, [20000], seed=13, num_pairs=1000, prof_seed=7, ref_seed=3)
+    try:
+        arrays = synth.make_profile(cfg, seed=7)
+        par0 = arrays["tab.indels.0.0.par0"].tolist()
+        assert 0 < par0.index(0) < len(par0) - 1, par0
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert 600 < n < 1400
+        cigars = [l.split(b" ")[1] for l in text.split(b"\n")[0::4] if l]
+        assert sum(b"I" in c for c in cigars) > 20
+    finally:
+        p.close()
+
+
 def case_profile_edits(backend_cls, workdir):
     for edits in ({"error_multiplier": 3.0}, {"no_substitutions": True}, {"no_indels": True}, {"no_substitutions": True, "no_indels": True}):
         p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=5, num_pairs=800, edits=edits)

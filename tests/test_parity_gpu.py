@@ -54,6 +54,10 @@ def test_p0_reads(workdir):
     P.case_p0_reads(GpuBackend, workdir)
 
 
+def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(workdir):
+    P.case_indel_columns_shuffled(GpuBackend, workdir)
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(GpuBackend, workdir)
 

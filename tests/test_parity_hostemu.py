@@ -92,6 +92,18 @@ def test_p0_reads(workdir):
     P.case_p0_reads(EmuBackend, workdir)
 
 
+def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(workdir):
+    import ctypes as C
+    import numpy as np
+    from backends import emu_lib
+    stats = np.zeros(8, np.uint64)
+    emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))             # reset
+    P.case_indel_columns_shuffled(EmuBackend, workdir)
+    emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))
+    w, w_left = stats.reshape(4, 2)[3].tolist()
+    assert w > 200_000 and 1e-3 * w < w_left < 0.05 * w, (w, w_left)        # the frequent insertion and the bound's slack: about 1 %
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(EmuBackend, workdir)
 
@@ -219,5 +231,5 @@ def test_the_screen_decides_almost_every_draw(workdir):
     assert q > 400_000 and b > 400_000 and w > 400_000
     assert 0 < q_left < 1e-3 * q, (q, q_left)                               # K = 40: about 2e-4
     assert b_left < 2e-4 * b and i_left <= 2e-4 * w, (b, b_left, i, i_left)
-    # the indel draw: the random word alone says "no indel" (DevTable::sure_below) except for a few draws in a thousand; only those read rows
+    # the indel draw: the random word alone says "no indel" (DevTable::sure_range) except for a few draws in a thousand; only those read rows
     assert i == w_left and 0 < w_left < 5e-3 * w, (w, w_left)
