@@ -41,8 +41,14 @@ with tempfile.TemporaryDirectory() as d:
         elif r < 0.45:
             edits = {"error_multiplier": float(rng.choice([0.5, 2.0, 10.0]))}
         tag = f"pl{t}"
+        cfg = dict(CFG)                                            # the indel draw's word-alone bound: other column orders, indel rates up to a few percent
+        if rng.random() < 0.3:
+            cfg["indel_columns_shuffled"] = True
+        if rng.random() < 0.3:
+            cfg["del_rate"] = cfg["del_rate"] * float(rng.choice([10.0, 300.0]))
+            cfg["ins_rate"] = cfg["ins_rate"] * float(rng.choice([1.0, 100.0]))
         kw = dict(prof_seed=int(rng.integers(1, 1000)), ref_seed=int(rng.integers(1, 1000)), gc=float(rng.choice([0.25, 0.5, 0.7])))
-        p = P.Pair(Backend, wd, tag, CFG, lengths, seed=int(rng.integers(1, 1 << 40)), num_pairs=int(rng.integers(500, 12000)), edits=edits or None,
+        p = P.Pair(Backend, wd, tag, cfg, lengths, seed=int(rng.integers(1, 1 << 40)), num_pairs=int(rng.integers(500, 12000)), edits=edits or None,
                    ref_bias_mode=int(rng.choice([0, 1, 2])), **kw)
         try:
             if rng.random() < 0.3:
