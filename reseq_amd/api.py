@@ -181,6 +181,11 @@ class Reference:
         _check(lib().rsq_ref_sequence_length(self.h, i, C.byref(v)))
         return v.value
 
+    def sequence_name(self, i):
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().rsq_ref_sequence_name(self.h, i, buf, len(buf)))
+        return buf.value.decode()
+
     def read_variants(self, path):
         """Reference::PrepareVariantFile + ReadFirstVariants: returns the number of alleles"""
         _check(lib().rsq_ref_read_variants(self.h, str(path).encode()))

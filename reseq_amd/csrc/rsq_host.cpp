@@ -3,13 +3,22 @@
 #include "rsq_host.h"
 #include "rsq_textio.h"
 
+#include <errno.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <exception>
+#include <mutex>
 
 #include <fstream>
+#include <thread>
 
 #include "rsq_core.h"
 
@@ -233,17 +242,140 @@ struct GzLines {
 };
 }  // namespace
 
-Reference Reference::read_fasta(const std::string &path) {
-    GzLines f(path);
+namespace {
+struct BaseCodes {
     uint8_t lut[256];
-    memset(lut, 4, sizeof lut);                // every IUPAC code that is not ACGT becomes N (IupacString -> Dna5String)
-    const char *acgt = "ACGT";
-    for (int i = 0; i < 4; ++i) {
-        lut[(uint8_t)acgt[i]] = (uint8_t)i;
-        lut[(uint8_t)(acgt[i] + 32)] = (uint8_t)i;
+    BaseCodes() {
+        memset(lut, 4, sizeof lut);            // every IUPAC code that is not ACGT becomes N (IupacString -> Dna5String)
+        const char *acgt = "ACGT";
+        for (int i = 0; i < 4; ++i) {
+            lut[(uint8_t)acgt[i]] = (uint8_t)i;
+            lut[(uint8_t)(acgt[i] + 32)] = (uint8_t)i;
+        }
+        lut[(uint8_t)'U'] = lut[(uint8_t)'u'] = 3;
     }
-    lut[(uint8_t)'U'] = lut[(uint8_t)'u'] = 3;
+};
+
+template <class F>
+void on_threads(size_t n_items, unsigned n_threads, F f) {      // f(item) for every item, items handed out in order
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    std::exception_ptr failed;
+    std::mutex m;
+    auto work = [&] {
+        try {
+            for (size_t i; (i = next.fetch_add(1)) < n_items;) f(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m);
+            failed = std::current_exception();
+        }
+    };
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    if (failed) std::rethrow_exception(failed);
+}
+
+// A plain-text FASTA file in memory, read by several threads: the header lines are found first, then the text between them is cut into
+// stretches that are counted and converted independently (a base's code does not depend on the line it stands in).  The same rules as the
+// line reader below: a line starts a record iff its first character is '>', one '\r' before the line end is dropped, blanks and tabs are
+// skipped, empty lines ignored.  Returns false (nothing read) for anything that is not a regular uncompressed file.
+bool read_fasta_mapped(const std::string &path, Reference &r) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    // small files: the line reader.  RSQ_FASTA_STRETCH (tests): the stretch length in bytes, also the size from which a file is mapped
+    const char *env = getenv("RSQ_FASTA_STRETCH");
+    const size_t kStretch = env ? std::max<size_t>(1, strtoull(env, nullptr, 10)) : (size_t)8u << 20, min_size = env ? 4 : (size_t)1 << 20;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < min_size) {
+        close(fd);
+        return false;
+    }
+    const size_t n = (size_t)st.st_size;
+    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return false;
+    struct Unmap {
+        void *p;
+        size_t n;
+        ~Unmap() { munmap(p, n); }
+    } unmap{map, n};
+    const char *d = static_cast<const char *>(map);
+    if (((uint8_t)d[0] == 0x1f && (uint8_t)d[1] == 0x8b) || !memcmp(d, "BZh", 3)) return false;      // gzip, bzip2
+    madvise(map, n, MADV_SEQUENTIAL);
+    const unsigned hw = std::thread::hardware_concurrency(), n_threads = std::max(1u, std::min(hw ? hw : 4u, 32u));
+    const size_t n_scan = (n + kStretch - 1) / kStretch;
+    std::vector<std::vector<size_t>> found(n_scan);
+    on_threads(n_scan, n_threads, [&](size_t i) {
+        const size_t lo = i * kStretch, hi = std::min(n, lo + kStretch);
+        for (const char *p = d + lo; p < d + hi && (p = (const char *)memchr(p, '>', (size_t)(d + hi - p))); ++p)
+            if (p == d || p[-1] == '\n') found[i].push_back((size_t)(p - d));
+    });
+    std::vector<size_t> header;
+    for (const auto &f : found) header.insert(header.end(), f.begin(), f.end());
+    if (header.empty()) return false;                                  // the line reader words the error
+    for (size_t p = 0; p < header[0]; ++p)
+        if (d[p] != '\n' && d[p] != '\r') return false;
+
+    struct Stretch {
+        size_t record, lo, hi, kept;
+    };
+    std::vector<Stretch> stretches;
+    std::vector<size_t> first_stretch(header.size() + 1);
+    r.names.resize(header.size());
+    r.codes.resize(header.size());
+    for (size_t i = 0; i < header.size(); ++i) {
+        const size_t end = i + 1 < header.size() ? header[i + 1] : n;
+        const char *eol = (const char *)memchr(d + header[i], '\n', end - header[i]);
+        size_t name_end = eol ? (size_t)(eol - d) : end;
+        const size_t body = eol ? name_end + 1 : end;
+        if (name_end > header[i] + 1 && d[name_end - 1] == '\r') --name_end;
+        r.names[i].assign(d + header[i] + 1, name_end - header[i] - 1);
+        first_stretch[i] = stretches.size();
+        for (size_t lo = body; lo < end; lo += kStretch) stretches.push_back(Stretch{i, lo, std::min(end, lo + kStretch), 0});
+    }
+    first_stretch[header.size()] = stretches.size();
+    auto dropped = [&](size_t p) {                                     // not a base: line ends, blanks, the '\r' of a "\r\n" (or before the end of the file)
+        const char c = d[p];
+        return c == '\n' || c == ' ' || c == '\t' || (c == '\r' && (p + 1 == n || d[p + 1] == '\n'));
+    };
+    on_threads(stretches.size(), n_threads, [&](size_t i) {
+        Stretch &s = stretches[i];
+        size_t kept = 0;
+        for (size_t p = s.lo; p < s.hi; ++p) kept += !dropped(p);
+        s.kept = kept;
+    });
+    std::vector<size_t> offset(stretches.size());
+    for (size_t i = 0; i < header.size(); ++i) {
+        size_t total = 0;
+        for (size_t k = first_stretch[i]; k < first_stretch[i + 1]; ++k) {
+            offset[k] = total;
+            total += stretches[k].kept;
+        }
+        if (total > 0xFFFFFFFFull) throw Error("reference sequence longer than 2^32-1 bases");
+    }
+    on_threads(header.size(), n_threads, [&](size_t i) {                // the allocation (and its zero fill) of one sequence per thread
+        const size_t k = first_stretch[i + 1];
+        r.codes[i].resize(k > first_stretch[i] ? offset[k - 1] + stretches[k - 1].kept : 0);
+    });
+    static const BaseCodes codes;
+    on_threads(stretches.size(), n_threads, [&](size_t i) {
+        const Stretch &s = stretches[i];
+        uint8_t *out = r.codes[s.record].data() + offset[i];
+        for (size_t p = s.lo; p < s.hi; ++p)
+            if (!dropped(p)) *out++ = codes.lut[(uint8_t)d[p]];
+    });
+    return true;
+}
+}  // namespace
+
+Reference Reference::read_fasta(const std::string &path) {
     Reference r;
+    if (!getenv("RSQ_SERIAL_FASTA") && read_fasta_mapped(path, r)) return r;
+    r = Reference();
+    GzLines f(path);
+    static const BaseCodes codes;
+    const uint8_t *lut = codes.lut;
     std::string line;
     while (f.getline(line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -270,9 +402,15 @@ Reference Reference::read_fasta(const std::string &path) {
 }
 
 bool Reference::has_n() const {
-    for (const auto &c : codes)
-        for (uint8_t b : c)
-            if (b > 3) return true;
+    for (const auto &c : codes) {
+        size_t i = 0;
+        for (uint64_t w; i + 8 <= c.size(); i += 8) {
+            memcpy(&w, c.data() + i, 8);
+            if (w & 0x0404040404040404ull) return true;
+        }
+        for (; i < c.size(); ++i)
+            if (c[i] > 3) return true;
+    }
     return false;
 }
 
@@ -301,6 +439,10 @@ void Reference::replace_n(uint64_t seed) {
         for (size_t start = 0; start < c.size();) {
             if (c[start] <= 3) {
                 ++start;
+                for (uint64_t w; start + 8 <= c.size(); start += 8) {              // eight bases at a time while none of them is N (code 4)
+                    memcpy(&w, c.data() + start, 8);
+                    if (w & 0x0404040404040404ull) break;
+                }
                 continue;
             }
             size_t end = start;
@@ -482,6 +624,21 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
     m.second.resize(n);
     m.rate.resize(n);
     bool file_done = false;
+    // std::stoll / std::stod of the text from `at` on, without the copies: false where they would throw (nothing to convert, out of range)
+    auto to_int = [](const std::string &text, size_t at, long long &v) {
+        if (at >= text.size()) return false;
+        char *end;
+        errno = 0;
+        v = strtoll(text.c_str() + at, &end, 10);
+        return end != text.c_str() + at && errno != ERANGE;
+    };
+    auto to_double = [](const std::string &text, size_t at, double &v) {
+        if (at >= text.size()) return false;
+        char *end;
+        errno = 0;
+        v = strtod(text.c_str() + at, &end);
+        return end != text.c_str() + at && errno != ERANGE;
+    };
     for (size_t i = 0; i < n && !file_done; ++i) {
         if (first_names[i] != cur_seq) continue;                                              // no entries for this sequence
         m.rate[i].resize(num_alleles_ref);
@@ -489,11 +646,7 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
         while (!f.fail()) {
             size_t a = line.find_first_not_of(" \t", cur_seq.size() + 1), b = line.find_first_of(" \t", a);
             long long v;
-            try {
-                v = std::stoll(line.substr(a, b));
-            } catch (const std::exception &) {
-                throw Error("Could not convert second field to int for line:\n" + line);
-            }
+            if (!to_int(line, a, v)) throw Error("Could not convert second field to int for line:\n" + line);
             if (m.first[i].empty()) {
                 if (v < 0) throw Error("Second field is negative in line:\n" + line);
             } else if (v < (long long)m.second[i].back()) {
@@ -503,11 +656,7 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
             const uint32_t region_start = (uint32_t)v;
             a = line.find_first_not_of(" \t", b);
             b = line.find_first_of(" \t", a);
-            try {
-                v = std::stoll(line.substr(a, b));
-            } catch (const std::exception &) {
-                throw Error("Could not convert third field to int for line:\n" + line);
-            }
+            if (!to_int(line, a, v)) throw Error("Could not convert third field to int for line:\n" + line);
             if (v <= (long long)region_start) throw Error("Third field is smaller than second field in line:\n" + line);
             if (v > (long long)seq_len[i]) throw Error("Third field is larger than sequence length:\n" + line);
             m.first[i].push_back(region_start);
@@ -520,11 +669,7 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
                                                           : "More alleles specified than in last line [" + std::to_string(num_alleles) + "] in line:\n" + line);
                 b = line.find_first_of(" \t", a);
                 double d;
-                try {
-                    d = std::stod(line.substr(a, b));
-                } catch (const std::exception &) {
-                    throw Error("Could not convert field " + std::to_string(4 + allele) + " to double for line:\n" + line);
-                }
+                if (!to_double(line, a, d)) throw Error("Could not convert field " + std::to_string(4 + allele) + " to double for line:\n" + line);
                 if (0.0 > d || d > 1.0) throw Error("Field " + std::to_string(4 + allele) + " is not between 0 and 1:\n" + line);
                 m.rate[i][allele++].push_back(1.0 - d);                                        // the probability of a C->T conversion
                 a = line.find_first_not_of(" \t", b);

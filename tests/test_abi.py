@@ -104,6 +104,58 @@ def test_gzip_fasta_loads_like_plain(workdir):
     b.close()
 
 
+def test_mapped_fasta_reader_reads_what_the_line_reader_reads(workdir, monkeypatch):
+    """large plain FASTA files are memory-mapped and converted by several threads in stretches (rsq_host.cpp read_fasta_mapped); here the
+    stretches are a few bytes, so that headers, line ends, "\\r\\n", blanks and '>' inside a line fall on stretch borders"""
+    rng = np.random.default_rng(3)
+    letters = "ACGTacgtNnRYKMUu"
+    texts = []
+    for trial in range(12):
+        parts = ["\n\r\n"] if trial % 3 == 0 else []
+        for s in range(int(rng.integers(1, 5))):
+            parts.append(f">seq{s} trial {trial} with > inside" + ("\r\n" if trial & 1 else "\n"))
+            for _ in range(int(rng.integers(0, 9))):
+                line = "".join(letters[k] for k in rng.integers(0, len(letters), int(rng.integers(0, 70))))
+                if rng.random() < 0.2:
+                    line = line[:5] + " \t" + line[5:] + ">"
+                if rng.random() < 0.1:
+                    line += "\rA"                                       # a carriage return inside a line is a character (N), not a line end
+                parts.append(line + ("\r\n" if trial & 1 else "\n"))
+        text = "".join(parts)
+        if trial % 4 == 2:
+            text = text.rstrip("\n")                                    # no newline at the end of the file
+        if trial % 4 == 3 and text.endswith("\r\n"):
+            text = text[:-1]                                            # ends with a lone carriage return
+        texts.append(text)
+    for i, text in enumerate(texts):
+        path = workdir / f"tricky{i}.fa"
+        path.write_bytes(text.encode())
+        monkeypatch.setenv("RSQ_SERIAL_FASTA", "1")
+        a = api.Reference(str(path))
+        monkeypatch.delenv("RSQ_SERIAL_FASTA")
+        for stretch in (1, 7, 64, 1 << 20):
+            monkeypatch.setenv("RSQ_FASTA_STRETCH", str(stretch))
+            b = api.Reference(str(path))
+            assert a.num_sequences() == b.num_sequences(), (i, stretch)
+            for k in range(a.num_sequences()):
+                assert a.sequence_name(k) == b.sequence_name(k), (i, stretch, k)
+                assert np.array_equal(a.codes(k), b.codes(k)), (i, stretch, k)
+            b.close()
+        monkeypatch.delenv("RSQ_FASTA_STRETCH")
+        a.close()
+    # text before the first header: refused by both readers
+    bad = workdir / "bad.fa"
+    bad.write_bytes(b"ACGT\n>s\nACGT\n")
+    for env in ({"RSQ_SERIAL_FASTA": "1"}, {"RSQ_FASTA_STRETCH": "5"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pytest.raises(api.RsqError) as e:
+            api.Reference(str(bad))
+        assert "FASTA header" in str(e.value)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_bzip2_fasta_in_and_out(workdir):
     """the reference also reads and writes .bz2 (SeqAn with BZip2, ReferenceTest.BZip2); libbz2 is bound at run time (rsq_textio.h)"""
     import bz2
