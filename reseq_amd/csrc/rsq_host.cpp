@@ -735,18 +735,16 @@ void insert_variant(std::vector<Variant> &variants, uint32_t position, const std
 }
 
 namespace {
-std::vector<std::string> split_tabs(const std::string &line) {
-    std::vector<std::string> f;
-    size_t at = 0;
-    for (;;) {
-        const size_t e = line.find('\t', at);
-        if (e == std::string::npos) {
-            f.push_back(line.substr(at));
-            return f;
-        }
-        f.push_back(line.substr(at, e - at));
+void split_tabs(const std::string &line, std::vector<std::string> &f) {      // f is reused from record to record: its strings keep their storage
+    size_t at = 0, n = 0;
+    for (;; ++n) {
+        const size_t e = line.find('\t', at), len = (e == std::string::npos ? line.size() : e) - at;
+        if (n == f.size()) f.emplace_back();
+        f[n].assign(line, at, len);
+        if (e == std::string::npos) break;
         at = e + 1;
     }
+    f.resize(n + 1);
 }
 uint8_t dna5_code(char c) {
     switch (c) {
@@ -793,7 +791,8 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
 
     Variants out;
     out.by_seq.resize(first_names.size());
-    std::vector<std::string> rec = split_tabs(line);
+    std::vector<std::string> rec;
+    split_tabs(line, rec);
     if (rec.size() < 10) throw Error("Could not read first vcf record: fewer than 10 columns");
     out.num_alleles = 0;                                              // ReadFirstVariants (:1046-1058)
     for (size_t g = 9; g < rec.size(); ++g) {
@@ -806,9 +805,13 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
     // ReadVariants (:126-420) over the whole file
     const uint32_t A = out.num_alleles;
     std::vector<uint32_t> allele(A);
-    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0;
+    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0, last_rid = 0xFFFFFFFFu;
+    std::vector<uint8_t> vcf_ref, inserted;                           // per record, kept for their storage
+    std::vector<size_t> alt_start;
+    std::vector<std::array<uint64_t, 2>> gt_has_var;
     for (;;) {
-        uint32_t rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());      // unknown names get a new id
+        if (last_rid >= contigs.size() || contigs[last_rid] != rec[0]) last_rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());
+        const uint32_t rid = last_rid;                                // unknown names get a new id
         const long long pos1 = atoll(rec[1].c_str());
         const uint32_t begin_pos = (uint32_t)(pos1 - 1);
         bool skip_rest = false;
@@ -832,7 +835,7 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
                 } else old_ref_id = rid;
                 const std::string &ref = rec[3], &alt = rec[4];
                 end_pos = start_pos + (uint32_t)ref.size();
-                std::vector<uint8_t> vcf_ref(ref.size());
+                vcf_ref.resize(ref.size());
                 bool ref_n = false;
                 for (size_t k = 0; k < ref.size(); ++k) ref_n |= (vcf_ref[k] = dna5_code(ref[k])) > 3;
                 if (ref_n)
@@ -876,8 +879,8 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
                     ok = false;
                 }
                 if (ok) {                                             // :270-370 alternatives, one bit per allele that carries them
-                    std::vector<size_t> alt_start{0};
-                    std::vector<std::array<uint64_t, 2>> gt_has_var;
+                    alt_start.assign(1, 0);
+                    gt_has_var.clear();
                     uint32_t chosen_var = 1;
                     auto carriers = [&](bool last) {
                         std::array<uint64_t, 2> bits{0, 0};
@@ -901,7 +904,7 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
                         for (size_t n_alt = 0; n_alt < gt_has_var.size(); ++n_alt) {
                             if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
                             const size_t alt_len = alt_start[n_alt + 1] - 1 - alt_start[n_alt];
-                            std::vector<uint8_t> inserted;
+                            inserted.clear();
                             if (pos + 1 == vcf_ref.size() && pos + 1 < alt_len) {                         // insertion
                                 for (size_t k = alt_start[n_alt] + pos; k < alt_start[n_alt + 1] - 1; ++k) inserted.push_back(dna5_code(alt[k]));
                             } else if (pos < alt_len) {                                                    // base mutation
@@ -931,7 +934,7 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
             }
         }
         if (!got) break;
-        rec = split_tabs(line);
+        split_tabs(line, rec);
         if (rec.size() < 10) {
             error("Could not read vcf record: fewer than 10 columns");
             break;
