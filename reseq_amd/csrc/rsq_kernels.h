@@ -178,11 +178,17 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
 // k_sum_bias from a random-access kernel into a streaming one.  Same function, same values, same product order.
 // [w_lo, w_hi): the part of the concatenated sequences that is needed (a sharded job computes its share); the tracks begin at w_lo
 __global__ void __launch_bounds__(256) k_surrounding_bias_tracks(DevSim S, double *start_bias, double *end_bias, uint64_t w_lo, uint64_t w_hi) {
-    const uint32_t seq = blockIdx.y, L = S.seq_len[seq];
-    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t at = w_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (at >= w_hi) return;
+    uint32_t seq = 0;                                               // the last sequence that begins at or before `at` (empty sequences share their begin)
+    for (uint32_t lo = 0, hi = S.n_seqs; lo < hi;) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.seq_base_off[mid] <= at) seq = mid, lo = mid + 1u;
+        else hi = mid;
+    }
+    const uint32_t L = S.seq_len[seq], pos = (uint32_t)(at - S.seq_base_off[seq]);
     if (pos >= L) return;
-    const uint64_t wo = S.seq_word_off[seq], at = S.seq_base_off[seq] + pos;
-    if (at < w_lo || at >= w_hi) return;
+    const uint64_t wo = S.seq_word_off[seq];
     uint32_t sur[3];
     surrounding_forward(S.ref_words, wo, L, pos, sur);
     start_bias[at - w_lo] = surrounding_bias(S.sur_bias, sur);

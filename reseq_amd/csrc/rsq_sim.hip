@@ -217,7 +217,7 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const S
 // ------------------------------------------------------------------------------- bias normalisation (a14)
 // FragmentDistributionStats.cpp:3504-3582 CalculateBiasNormalization; the SumBias scans (Reference.cpp:622-659) run on
 // the GPU, one launch for all (sequence, sampled length) pairs; partial sums are combined in a fixed order.
-constexpr uint64_t kSurroundingTrackBytesMax = 96ull << 30;
+constexpr uint64_t kBiasWindow = 512ull << 20;       // start positions per pass of the bias sums: 2 x 4 GB of tracks
 // partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each, BiasPlan::chunk_ptr) whose first start position lies in
 // the share [g_lo, g_hi) of the concatenated sequences; zero elsewhere
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
@@ -238,31 +238,30 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     d_params.upload(plan.params);
     d_chunk_param.upload(plan.chunk_param);
     d_chunk_ptr.upload(plan.chunk_ptr);
-    // the share's chunks read start positions up to a chunk behind g_hi and end positions a fragment length further
-    const uint64_t w_lo = std::min<uint64_t>(g_lo, s.total_ref_size);
-    const uint64_t w_hi = g_hi == UINT64_MAX ? s.total_ref_size : std::min<uint64_t>(s.total_ref_size, g_hi + (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to);
-    lap("chunk tables");
-    double *start_bias = nullptr, *end_bias = nullptr;
-    if ((w_hi - w_lo) * 16 <= kSurroundingTrackBytesMax) {         // 16 bytes per base of the share: 50 GB for a whole human genome, of 288 GB
-        d_start_bias.reserve((w_hi - w_lo) * 8 + 16);
-        d_end_bias.reserve((w_hi - w_lo) * 8 + 16);
-        start_bias = d_start_bias.as<double>();
-        end_bias = d_end_bias.as<double>();
-        lap("track buffers");
-        uint32_t longest = 0;
-        for (uint32_t L : s.seq_len) longest = std::max(longest, L);
-        hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3(cdiv(longest, 256), s.dev.n_seqs), dim3(256), 0, st, s.dev, start_bias, end_bias, w_lo, w_hi);
-        HIP_CHECK(hipGetLastError());
-        lap("track kernel");
-    }
     d_sum.reserve((size_t)n_chunks * 8);
     d_max.reserve((size_t)n_chunks * 8);
     HIP_CHECK(hipMemsetAsync(d_sum.as<double>(), 0, (size_t)n_chunks * 8, st));
     HIP_CHECK(hipMemsetAsync(d_max.as<double>(), 0, (size_t)n_chunks * 8, st));
-    hipLaunchKernelGGL(k_sum_bias, dim3(n_chunks), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_chunk_param.as<uint32_t>(), d_chunk_ptr.as<uint32_t>(), start_bias,
-                       end_bias, w_lo, d_sum.as<double>(), d_max.as<double>(), g_lo, g_hi);
-    HIP_CHECK(hipGetLastError());
-    lap("sum kernel");
+    lap("chunk tables");
+    // The share in windows of kBiasWindow positions: the tracks of one window (16 bytes per position; allocating them for a whole human-sized
+    // reference takes a second) are computed, its chunks summed, the buffers used again.  A window's chunks read start positions up to a chunk
+    // behind its end and end positions a fragment length further.
+    const uint64_t lo = std::min<uint64_t>(g_lo, s.total_ref_size), hi = std::min<uint64_t>(g_hi, s.total_ref_size);
+    uint64_t window = kBiasWindow;
+    if (const char *e = getenv("RSQ_BIAS_WINDOW")) window = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    const uint64_t reach = (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to, track_len = std::min(hi - lo, window) + reach;
+    d_start_bias.reserve(track_len * 8 + 16);
+    d_end_bias.reserve(track_len * 8 + 16);
+    lap("track buffers");
+    for (uint64_t a = lo; a < hi; a += window) {
+        const uint64_t b = std::min(hi, a + window), w_hi = std::min<uint64_t>(s.total_ref_size, b + reach);
+        hipLaunchKernelGGL(k_surrounding_bias_tracks, dim3((uint32_t)cdiv(w_hi - a, 256)), dim3(256), 0, st, s.dev, d_start_bias.as<double>(), d_end_bias.as<double>(), a, w_hi);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_sum_bias, dim3(n_chunks), dim3(kBiasBlock), 0, st, s.dev, d_params.as<BiasParam>(), d_chunk_param.as<uint32_t>(), d_chunk_ptr.as<uint32_t>(),
+                           d_start_bias.as<double>(), d_end_bias.as<double>(), a, d_sum.as<double>(), d_max.as<double>(), a, b);
+        HIP_CHECK(hipGetLastError());
+    }
+    lap("track and sum kernels");
     HIP_CHECK(hipMemcpyAsync(h_sum.data(), d_sum.as<double>(), h_sum.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(h_max.data(), d_max.as<double>(), h_max.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

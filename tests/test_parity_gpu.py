@@ -103,6 +103,37 @@ def test_ref_bias_modes(workdir):
     P.case_ref_bias_modes(GpuBackend, workdir)
 
 
+def test_bias_sums_in_windows_are_the_sums_at_once(workdir, monkeypatch):
+    """the bias sums run over the reference in windows whose surrounding tracks reuse two buffers (rsq_sim.hip bias_partials); a chunk's sum does
+    not depend on the window it is computed in: windows of 700 positions (several per sequence, borders inside chunks' reach) give the same
+    doubles as one window, also for a share of a sharded pre-pass"""
+    import numpy as np
+    from parity_cases import make_inputs
+    from reseq_amd import synth
+    lengths = [5200, 90, 3100, 2048]
+    ppath, fpath, _ = make_inputs(workdir, "biaswin", synth.TINY, lengths)
+    got = []
+    for window in (None, "700", "64"):
+        if window:
+            monkeypatch.setenv("RSQ_BIAS_WINDOW", window)
+        b = GpuBackend(ppath, fpath)
+        info = b.prepare(5, num_pairs=3000)
+        thr = np.array(b.thresholds())
+        b.close()
+        b = GpuBackend(ppath, fpath)
+        b.prepare_plan(5, num_pairs=3000)
+        sums, maxes = b.bias_partials(5, b.info()["total_blocks"] + 1)        # from block 5 of the first sequence on: the chunks of the later sequences
+        b.close()
+        got.append((info["bias_normalization"], thr, np.array(sums), np.array(maxes)))
+        if window:
+            monkeypatch.delenv("RSQ_BIAS_WINDOW")
+    for norm, thr, sums, maxes in got[1:]:
+        assert norm == got[0][0]
+        assert np.array_equal(thr, got[0][1])
+        assert np.array_equal(sums, got[0][2]) and np.array_equal(maxes, got[0][3])
+    assert 0 < np.count_nonzero(got[0][2]) < len(got[0][2])
+
+
 def test_cli_write_then_read_sys_error_profile(workdir):
     """reseq illuminaPE --writeSysError f simulates from the profile it just wrote (main.cpp:389), so a second run with
     --readSysError f and the same seed must produce the same FASTQ files; --refBias no is accepted"""
