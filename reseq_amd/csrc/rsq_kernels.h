@@ -1404,6 +1404,26 @@ constexpr uint32_t kDescWords = sizeof(DevTable) / 4u;
 #define RSQ_SCREEN_COUNT(family, decided) ((void)0)
 #endif
 
+// A draw the screen left open, as a call: the double-precision recipe (draw_slim) is rare and large, and inlined at every draw site it costs the read
+// kernel's loop registers and a tenth of its time.  The callee reads the descriptor from the image again; the result carries prob_sum == 0 in bit 31.
+template <int NM>
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+    uint32_t exact_draw_call(const double *pool, const RSQ_LDS float *img, uint32_t par0_words, uint32_t desc, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t word) {
+    const DevTable t = reinterpret_cast<const RSQ_LDS DevTable *>(img)[desc];
+    uint32_t idx[NM];
+    idx[0] = i0;
+    idx[1] = i1;
+    idx[2] = i2;
+    if constexpr (NM == 4) idx[3] = i3;
+    double ps;
+    const uint32_t value = draw_slim<NM>(t, pool, reinterpret_cast<const RSQ_LDS uint8_t *>(img + par0_words), idx, u32_to_unit(word), ps);
+    return value | (0.0 == ps ? 0x80000000u : 0u);
+}
+
 // QQ = quads per row of the quality family (LdsPlan::quads_q).  `t` is the step the wave is in: the quality rows over the read
 // positions t, ... t-kRingLag are in the wave's ring (lds_ring_load / lds_ring_store).
 template <uint32_t MASK>
@@ -1428,16 +1448,19 @@ struct ScreenTables {
     RSQ_HD bool in_ring(uint32_t p) const { return t - p <= kRingLag; }
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
-    RSQ_HD uint32_t exact(const DevTable &t, const uint32_t (&idx)[NM], uint32_t word, double &ps) const {
-        return draw_slim<NM>(t, S.pool, par0(), idx, u32_to_unit(word), ps);
+    RSQ_HD uint32_t exact(uint32_t desc, const uint32_t (&idx)[NM], uint32_t word, double &ps) const {
+        const uint32_t r = exact_draw_call<NM>(S.pool, img, S.lds.desc_words - S.lds.par0_words, desc, idx[0], idx[1], idx[2], NM == 4 ? idx[NM - 1] : 0u, word);
+        ps = (r >> 31) ? 0.0 : 1.0;                                  // the callers only ask whether prob_sum is 0
+        return r & 0x7FFFFFFFu;
     }
     template <int NM>
-    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, const uint32_t (&idx)[NM], uint32_t u, double &ps) const {
+    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, uint32_t desc, const uint32_t (&idx)[NM], uint32_t u, double &ps) const {
         uint32_t value = par0()[t.par0_off + col];
         ps = 1.0;
+        decided = decided && !S.force_exact;
 #ifndef RSQ_EXP_NO_FALLBACK
         if (RSQ_ANY(!decided)) {
-            if (!decided) value = exact<NM>(t, idx, u, ps);
+            if (!decided) value = exact<NM>(desc, idx, u, ps);
         }
 #endif
         return value;
@@ -1456,7 +1479,7 @@ struct ScreenTables {
         bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
         decided = decided && t.f32_ok;
         RSQ_SCREEN_COUNT(0, decided);
-        return settle<4>(decided, col, t, idx, u, ps);
+        return settle<4>(decided, col, t, local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, double &ps) const {
         const uint32_t local = i - seg * 20u * S.n_tiles;
@@ -1473,7 +1496,7 @@ struct ScreenTables {
         uint32_t col = 0;
         bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3) && t.f32_ok;
         RSQ_SCREEN_COUNT(1, decided);
-        return settle<4>(decided, col, t, idx, u, ps);
+        return settle<4>(decided, col, t, 4u * S.n_tiles + local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {
         const DevTable t = desc(24u * S.n_tiles + i);
@@ -1495,10 +1518,12 @@ struct ScreenTables {
         uint32_t col = 0;
         bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2) && t.f32_ok;
         RSQ_SCREEN_COUNT(2, decided);
-        return settle<3>(decided, col, t, idx, u, ps);
+        return settle<3>(decided, col, t, 24u * S.n_tiles + i, idx, u, ps);
     }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {     // once per read: double precision
-        return draw_slim<3>(seq_quality(i), S.pool, par0(), idx, u32_to_unit(u), ps);
+        const uint32_t r = exact_draw_call<3>(S.pool, img, S.lds.desc_words - S.lds.par0_words, 24u * S.n_tiles + 12u + i - seg * S.n_tiles, idx[0], idx[1], idx[2], 0u, u);
+        ps = (r >> 31) ? 0.0 : 1.0;
+        return r & 0x7FFFFFFFu;
     }
 };
 

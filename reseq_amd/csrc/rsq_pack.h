@@ -236,6 +236,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     }
     // the two families of the systematic-error chains: rows of whole quads, read from HBM
     s.dev.chain_quads = 0;
+    s.dev.force_exact = getenv("RSQ_FORCE_EXACT") ? 1u : 0u;
     for (uint32_t q : kChainQuads)
         if (!s.dev.chain_quads && quads_of(kmax_of(error_rate)) <= q && quads_of(kmax_of(dom_error)) <= kQuadsSmall) s.dev.chain_quads = q;
     if (s.dev.chain_quads) {

@@ -188,6 +188,7 @@ struct DevSim {
     const DevTable *error_rate;    // [4][5]
     const DevTable *indels;        // [2][6]
     LdsPlan lds;
+    uint32_t force_exact;            // tests (RSQ_FORCE_EXACT): the read kernel's screen decides nothing, every draw takes the double-precision route behind it
     uint32_t chain_quads;            // quads per row of the error-rate tables' single-precision copy (one of kChainQuads); 0: the chains draw in double precision only
     uint32_t n_tiles;
     uint8_t phred_offset;

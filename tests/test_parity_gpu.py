@@ -84,6 +84,18 @@ def test_double_precision_path(workdir, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_every_draw_through_the_route_behind_the_screen(workdir, monkeypatch):
+    """RSQ_FORCE_EXACT: the screen decides nothing, so every draw of the read kernel (and of seqToIllumina's) takes the route of an undecided one,
+    the call of the double-precision recipe (exact_draw_call)"""
+    monkeypatch.setenv("RSQ_FORCE_EXACT", "1")
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+    P.case_p0_reads(GpuBackend, workdir)
+    P.case_indel_columns_shuffled(GpuBackend, workdir)
+    P.case_error_model_p0(GpuBackend, workdir)
+    P.case_adapter_only(GpuBackend, workdir)
+
+
+@pytest.mark.gpu
 def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
     """only row 0 of the error-rate margins staged: every position with a systematic error rate takes the HBM branch"""
     monkeypatch.setenv("RSQ_RATE_ROWS", "1")

@@ -92,6 +92,11 @@ def test_p0_reads(workdir):
     P.case_p0_reads(EmuBackend, workdir)
 
 
+def test_every_draw_through_the_route_behind_the_screen(workdir, monkeypatch):
+    monkeypatch.setenv("RSQ_FORCE_EXACT", "1")
+    P.case_p0_reads(EmuBackend, workdir)
+
+
 def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(workdir):
     import ctypes as C
     import numpy as np
