@@ -343,6 +343,7 @@ RSQ_HD uint32_t draw_slim(const DevTable &t, const double *__restrict__ pool, Pa
 // How FillRead reaches its tables.  GlobalTables reads descriptors and rows from HBM; the read kernel uses LdsTables
 // (rsq_kernels.h) which serves descriptors and the per-lane-varying margins from LDS.
 struct GlobalTables {
+    using Sum = double;            // what a draw reports of prob_sum; the callers only ask whether it is 0
     const DevSim &S;
     RSQ_HD const DevTable &quality(uint32_t i) const { return S.quality[i]; }
     RSQ_HD const DevTable &seq_quality(uint32_t i) const { return S.seq_quality[i]; }
@@ -628,7 +629,7 @@ struct ReadMachine {
             par.gc_seq = percent_u16(par.gc_seq, alen & 0xFFFFu);
             mean_error_rate = divide_u32(mean_error_rate, alen);
         }
-        double prob_sum;
+        typename Tab::Sum prob_sum;
         const uint32_t sqi = seg * S.n_tiles + tile_id;
         const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
         par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, h0.w2, prob_sum);
@@ -638,7 +639,7 @@ struct ReadMachine {
 #ifdef RSQ_EXP_UNIFORM_GC
         par.gc_seq = RSQ_EXP_UNIFORM_GC;                              // experiment only: what reads sorted by their G/C percent would buy (indel margin 2)
 #endif
-        if (0.0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
+        if (0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
             const DevTable sqt = tab.seq_quality(sqi);
             par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
         }
@@ -705,17 +706,17 @@ struct ReadMachine {
 #else
         const Words w = st.step(2u + it);
 #endif
-        double prob_sum;
+        typename Tab::Sum prob_sum;
         uint32_t indel = 0, org_base = 0;
         if (!tail) {
             const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
 #ifdef RSQ_EXP_NO_INDEL
             (void)idx_i;
-            prob_sum = 1.0;                                            // experiment only: what the indel draw costs
+            prob_sum = 1;                                              // experiment only: what the indel draw costs
 #else
             indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, w.w0, prob_sum);
 #endif
-            if (0.0 == prob_sum) indel = 0;
+            if (0 == prob_sum) indel = 0;
             org_base = from_template ? src.base(org_pos) : (uint32_t)ad.seqs[adapter_a0 + org_pos];
         }
         const uint32_t qi = tbase + org_base;                        // the tail draws from the tables of base A (:566)
@@ -734,11 +735,11 @@ struct ReadMachine {
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
 #ifdef RSQ_EXP_NO_QUAL
             q = 2u + (w.w1 >> 28) + (idx_q[1] & 1u);                   // experiment only: what the quality draw costs
-            prob_sum = 1.0;
+            prob_sum = 1;
 #else
             q = tab.draw_quality(qi, idx_q, w.w1, prob_sum);
 #endif
-            if (0.0 == prob_sum) {
+            if (0 == prob_sum) {
                 if (regular) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;      // :341-349
                 else if (tail) q = par.read_pos ? par.last_written_qual : q;                             // at(qual_, read_pos-1) - offset
                 else q = par.qual;                                                                       // insertion :417-420
@@ -749,11 +750,11 @@ struct ReadMachine {
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
 #ifdef RSQ_EXP_NO_CALL
             uint32_t call = (w.w2 >> 30) == 3u && idx_b[0] < 3u ? (org_base + 1u) & 3u : org_base;      // experiment only: what the base-call draw costs
-            prob_sum = 1.0;
+            prob_sum = 1;
 #else
             uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
 #endif
-            if (0.0 == prob_sum) call = org_base;
+            if (0 == prob_sum) call = org_base;
             par.base_call = call;
             out.put(par.read_pos, call, q + S.phred_offset);
             par.last_written_qual = q;

@@ -1428,6 +1428,7 @@ inline
 // positions t, ... t-kRingLag are in the wave's ring (lds_ring_load / lds_ring_store).
 template <uint32_t MASK>
 struct ScreenTables {
+    using Sum = uint32_t;              // 0: prob_sum is 0, else 1 (all the callers ask; a double here costs the loop moves and 64-bit compares)
     static constexpr int QQ = (int)MASK;
     const DevSim &S;
     const RSQ_LDS float *img;          // image of the workgroup
@@ -1448,15 +1449,15 @@ struct ScreenTables {
     RSQ_HD bool in_ring(uint32_t p) const { return t - p <= kRingLag; }
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
-    RSQ_HD uint32_t exact(uint32_t desc, const uint32_t (&idx)[NM], uint32_t word, double &ps) const {
+    RSQ_HD uint32_t exact(uint32_t desc, const uint32_t (&idx)[NM], uint32_t word, uint32_t &ps) const {
         const uint32_t r = exact_draw_call<NM>(S.pool, img, S.lds.desc_words - S.lds.par0_words, desc, idx[0], idx[1], idx[2], NM == 4 ? idx[NM - 1] : 0u, word);
-        ps = (r >> 31) ? 0.0 : 1.0;                                  // the callers only ask whether prob_sum is 0
+        ps = (r >> 31) ^ 1u;                                  // the callers only ask whether prob_sum is 0
         return r & 0x7FFFFFFFu;
     }
     template <int NM>
-    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, uint32_t desc, const uint32_t (&idx)[NM], uint32_t u, double &ps) const {
+    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, uint32_t desc, const uint32_t (&idx)[NM], uint32_t u, uint32_t &ps) const {
         uint32_t value = par0()[t.par0_off + col];
-        ps = 1.0;
+        ps = 1u;
         decided = decided && !S.force_exact;
 #ifndef RSQ_EXP_NO_FALLBACK
         if (RSQ_ANY(!decided)) {
@@ -1466,10 +1467,10 @@ struct ScreenTables {
         return value;
     }
 
-    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, double &ps) const {
+    RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
         const uint32_t local = i - seg * 4u * S.n_tiles;
         const DevTable t = desc(local);
-        ps = 0.0;
+        ps = 0u;
         if (!t.k) return 0;
         const uint32_t slot = S.lds.slot_q, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_q;
         const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * slot};
@@ -1481,10 +1482,10 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(0, decided);
         return settle<4>(decided, col, t, local, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, double &ps) const {
+    RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
         const uint32_t local = i - seg * 20u * S.n_tiles;
         const DevTable t = desc(4u * S.n_tiles + local);
-        ps = 0.0;
+        ps = 0u;
         if (!t.k) return 0;
         const uint32_t slot = S.lds.slot_b, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_b;
         const float *g = S.pool32 + t.off32;
@@ -1498,16 +1499,16 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(1, decided);
         return settle<4>(decided, col, t, 4u * S.n_tiles + local, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {
+    RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {
         const DevTable t = desc(24u * S.n_tiles + i);
-        ps = 0.0;
+        ps = 0u;
         if (!t.k) return 0;
         // nearly every draw: the random word alone says "no indel" (DevTable::sure_range); the wave skips the rows when all its lanes are that sure
         const uint32_t lo16 = t.sure_range & 0xFFFFu;
         const bool sure = (u >> 16) - lo16 < (t.sure_range >> 16) - lo16 && 0u == clamp_row(t, 0, idx[0]);
         RSQ_SCREEN_COUNT(3, sure);
         if (!RSQ_ANY(!sure)) {
-            ps = 1.0;
+            ps = 1u;
             return 0;
         }
         const uint32_t slot = S.lds.slot_i;
@@ -1520,9 +1521,9 @@ struct ScreenTables {
         RSQ_SCREEN_COUNT(2, decided);
         return settle<3>(decided, col, t, 24u * S.n_tiles + i, idx, u, ps);
     }
-    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, double &ps) const {     // once per read: double precision
+    RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {     // once per read: double precision
         const uint32_t r = exact_draw_call<3>(S.pool, img, S.lds.desc_words - S.lds.par0_words, 24u * S.n_tiles + 12u + i - seg * S.n_tiles, idx[0], idx[1], idx[2], 0u, u);
-        ps = (r >> 31) ? 0.0 : 1.0;
+        ps = (r >> 31) ^ 1u;
         return r & 0x7FFFFFFFu;
     }
 };
