@@ -1804,17 +1804,70 @@ RSQ_HD void fill_adapter_only_read(const DevSim &S, const Tab &tab, uint64_t i, 
     fill_read(S, tab, st, seg, tile, 0u, EmptySrc{}, out, meta);
 }
 
-// seqToIllumina records (Simulator.cpp:2403-2512): templates and systematic errors come from arrays
+// seqToIllumina records (Simulator.cpp:2403-2512): templates and systematic errors come from byte arrays, a record per lane -- 64 cache lines per
+// load instruction.  The source therefore holds the 8-byte group (k >> 3) of the three arrays it last read: three loads per eight bases instead of per
+// base, and the totals of FillRead's start (G/C count, rate sum) come from the same groups.  `safe`: bytes from the record's first byte to the end of
+// the arrays; a group reaching beyond it is read byte by byte.
 struct RecordSrc {
     const uint8_t *seq;
     const uint8_t *dom, *rate;
     uint32_t len;
+    uint32_t safe;
+    mutable uint32_t group;
+    mutable uint64_t w_seq, w_dom, w_rate;
+    RSQ_HD static uint64_t load8(const uint8_t *p, uint32_t off, uint32_t safe) {
+        uint64_t w = 0;
+        if (off + 8u <= safe) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            w = *reinterpret_cast<const uint64_t __attribute__((aligned(1))) *>(p + off);      // unaligned 8-byte loads are what the hardware does (amdhsa)
+#else
+            memcpy(&w, p + off, 8);
+#endif
+        } else {
+            for (uint32_t j = 0; j < 8u && off + j < safe; ++j) w |= (uint64_t)p[off + j] << (8u * j);
+        }
+        return w;
+    }
+    RSQ_HD void hold(uint32_t k) const {
+        const uint32_t g = k >> 3;
+        if (g == group) return;
+        group = g;
+        w_seq = load8(seq, g * 8u, safe);
+        w_dom = load8(dom, g * 8u, safe);
+        w_rate = load8(rate, g * 8u, safe);
+    }
     RSQ_HD uint32_t org_len() const { return len; }
-    RSQ_HD uint32_t base(uint32_t k) const { return seq[k]; }
-    RSQ_HD uint32_t sys_base(uint32_t k) const { return (uint32_t)dom[k] | ((uint32_t)rate[k] << 8); }
+    RSQ_HD uint32_t base(uint32_t k) const {
+        hold(k);
+        return (uint32_t)(w_seq >> ((k & 7u) * 8u)) & 0xFFu;
+    }
+    RSQ_HD uint32_t sys_base(uint32_t k) const {
+        hold(k);
+        const uint32_t sh = (k & 7u) * 8u;
+        return ((uint32_t)(w_dom >> sh) & 0xFFu) | (((uint32_t)(w_rate >> sh) & 0xFFu) << 8);
+    }
     RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_base(k); }
-    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const { template_totals_loop(*this, n, gc, rate_sum); }
+    // Simulator.cpp:482-489 over the groups, from the last one down (the first stays held): a base is G/C iff it is 1 or 2, the rates add up bytewise
+    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
+        const uint64_t kOnes = 0x0101010101010101ull, kEven = 0x00FF00FF00FF00FFull;
+        for (uint32_t g = (n + 7u) >> 3; g--;) {
+            hold(g * 8u);
+            const uint32_t left = n - g * 8u;                                 // bases of this group that count
+            const uint64_t keep = left >= 8u ? ~0ull : (1ull << (8u * left)) - 1ull;
+            const uint64_t w = w_seq & keep, r = w_rate & keep;
+            const uint64_t high = (w >> 2) | (w >> 3) | (w >> 4) | (w >> 5) | (w >> 6) | (w >> 7);
+            const uint64_t is = (w ^ (w >> 1)) & ~high & kOnes;
+            gc += (uint32_t)((is * kOnes) >> 56);
+            const uint64_t pairs = (r & kEven) + ((r >> 8) & kEven);
+            rate_sum += (uint32_t)((pairs * 0x0001000100010001ull) >> 48);
+        }
+    }
 };
+// record i of n: the arrays hold read_len bytes per record
+RSQ_HD RecordSrc record_src(const uint8_t *seqs, const uint8_t *dom, const uint8_t *rate, uint32_t read_len, uint64_t i, uint64_t n) {
+    const uint64_t rest = (n - i) * read_len;
+    return RecordSrc{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len, rest > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rest, 0xFFFFFFFFu, 0, 0, 0};
+}
 #ifndef RSQ_FILL_BLOCK
 #define RSQ_FILL_BLOCK 768
 #endif
@@ -1928,6 +1981,7 @@ struct RecordJob {
     const uint8_t *seqs, *dom, *rate;
     const uint32_t *frag_len;
     const uint32_t *rec_index, *rec_count;
+    uint64_t n_records;
 };
 template <uint32_t MASK>
 __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters) {
@@ -1946,7 +2000,7 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob
         const uint64_t i = active ? index[first + lane] : 0u;
         const uint64_t idx = job.first_index + i;
         const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-        const RecordSrc src{job.seqs + i * job.read_len, job.dom + i * job.read_len, job.rate + i * job.read_len, job.read_len};
+        const RecordSrc src = record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
         ReadOut out = raw.out_of(i);
         ReadMeta meta;
         const bool work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomErrModel, 0, 2), job.frag_len[i], src, out, meta);

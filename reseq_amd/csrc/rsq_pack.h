@@ -222,8 +222,10 @@ inline void pack_tables(SimState &s, Uploader &up) {
                 d.sure_range = c.lo16 | (c.hi16 << 16);
             }
     };
+    uint32_t min_quads = 0;
+    if (const char *e = getenv("RSQ_MIN_QUALITY_QUADS")) min_quads = (uint32_t)atoi(e);          // measurements: a wider instantiation than the profile needs
     for (uint32_t q : kQualityQuads)
-        if (!plan.quads_q && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
+        if (!plan.quads_q && q >= min_quads && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
     const bool screenable = plan.quads_q && quads_of(kmax_of(base_call)) <= kQuadsSmall && quads_of(kmax_of(indels)) <= kQuadsSmall;
     plan.slot_q = row_slot32(plan.quads_q);
     plan.slot_b = plan.slot_i = kSlotSmall;

@@ -397,6 +397,9 @@ static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pair
     RSQ_FILL_CASE(kQualityQuads[0])
     RSQ_FILL_CASE(kQualityQuads[1])
     RSQ_FILL_CASE(kQualityQuads[2])
+    RSQ_FILL_CASE(kQualityQuads[3])
+    RSQ_FILL_CASE(kQualityQuads[4])
+    static_assert(sizeof(kQualityQuads) == 5 * sizeof(uint32_t), "one case per entry");
 #undef RSQ_FILL_CASE
     throw Error("no k_fill_reads instantiation for " + std::to_string(mask) + " quads");
 }
@@ -411,6 +414,8 @@ static void launch_fill_records(rsq_sim &s, const RecordJob &job, uint64_t n, co
     RSQ_REC_CASE(kQualityQuads[0])
     RSQ_REC_CASE(kQualityQuads[1])
     RSQ_REC_CASE(kQualityQuads[2])
+    RSQ_REC_CASE(kQualityQuads[3])
+    RSQ_REC_CASE(kQualityQuads[4])
 #undef RSQ_REC_CASE
     throw Error("no k_fill_records instantiation for " + std::to_string(mask) + " quads");
 }
@@ -1117,7 +1122,7 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
     exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
     hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
     HIP_CHECK(hipGetLastError());
-    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>()};
+    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>(), n};
     launch_fill_records(*s, job, n, raw, st);
     return raw;
 }

@@ -68,10 +68,10 @@ RSQ_HD uint32_t row_slot32(uint32_t quads) {
     const uint32_t w = quads * 4u;
     return (w & 4u) ? w : w + 4u;
 }
-// what the screened draws are compiled for: the quality family with 10 or 12 quads per row (K <= 40, K <= 48), the base-call and
+// what the screened draws are compiled for: the quality family with 3, 6 (binned qualities: K <= 12, K <= 24) or 10 to 12 quads per row (K <= 40 .. 48), the base-call and
 // indel families with 2 (K <= 8, rows of 32 bytes)
 constexpr uint32_t kQuadsSmall = 2, kSlotSmall = 8;
-constexpr uint32_t kQualityQuads[] = {10, 11, 12};
+constexpr uint32_t kQualityQuads[] = {3, 6, 10, 11, 12};
 // the systematic-error chains (k_sys_chain) screen their two draws as well: dominant error with kQuadsSmall quads, error rate with one of these
 constexpr uint32_t kChainQuads[] = {8, 16, 26};
 constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)

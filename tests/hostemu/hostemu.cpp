@@ -95,6 +95,8 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
         run(std::integral_constant<uint32_t, kQualityQuads[0]>{});
         run(std::integral_constant<uint32_t, kQualityQuads[1]>{});
         run(std::integral_constant<uint32_t, kQualityQuads[2]>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[3]>{});
+        run(std::integral_constant<uint32_t, kQualityQuads[4]>{});
         if (!done) throw Error("no screened instantiation for mask " + std::to_string(s.mask()));
     }
 }
@@ -648,7 +650,7 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
         for (uint64_t i = 0; i < n; ++i) {
             ReadOut out = raw.out(s);
             ReadMeta m;
-            RecordSrc src{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len};
+            RecordSrc src = record_src(seqs, dom, rate, read_len, i, n);
             const uint64_t idx = first_index + i;              // as a lane of k_fill_records<MASK> runs it
             const uint32_t seg = segs[i];
             run_read(s, seg, Stream{s.dev.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)},

@@ -22,7 +22,10 @@ n = min(total, 10_000_000)
 calls = (total + n - 1) // n
 tmp = tempfile.mkdtemp(prefix="rsq_em_")
 ppath = os.path.join(tmp, "p0.rsqp")
-arrays = synth.make_profile(synth.P0, seed=103741084)
+# `python tools/bench_error_model.py N binned`: the same profile with 12 quality values (30 .. 41; K <= 12 takes the 3-quad instantiation of the
+# read kernels; RSQ_MIN_QUALITY_QUADS=10 in the environment forces the 10-quad one for comparison)
+CFG = dict(synth.P0, name="P0b", qual_from=30, qual_to=42) if len(sys.argv) > 2 and sys.argv[2] == "binned" else synth.P0
+arrays = synth.make_profile(CFG, seed=103741084)
 synth.write_profile(ppath, arrays)
 rec = synth.make_error_model_input(3, n, 150, arrays, zero_frac=0.97)
 prof = api.Profile(ppath)
@@ -69,7 +72,7 @@ fill_ms = sim.last_kernel_ms("fill_reads")
 once_text()
 tt = [once_text() for _ in range(3)]
 best_text = min(t for t, _ in tt)
-print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
+print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "profile": CFG["name"], "quality_values": CFG["qual_to"] - CFG["qual_from"], "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
                   "reads_per_s": n * calls / best, "fill_kernel_ms_last_call": fill_ms, "with_fastq_text_on_device": {"seconds": [t for t, _ in tt], "reads_per_s": n * calls / best_text,
                                                                                                                   "text_bytes_per_call": tt[0][1],
                                                                                                                   "format_ms_last_call": sim.last_kernel_ms("format_write")}}))
