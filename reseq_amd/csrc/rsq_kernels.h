@@ -1132,11 +1132,36 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
     const uint16_t *sys_;               // systematic errors at the first template base
     const uint64_t *converted;          // --methylation: the template after CTConversion, 2 bits per base in read orientation; else nullptr
     const uint32_t *gc_prefix;          // DevSim::gc_prefix
+    // Per-lane streams: a load instruction of the wave touches 64 cache lines here, so the source holds what it last read -- the 64-bit word of the
+    // template (32 bases; of the reference or of the converted template, a source reads only one of them) and a group of four systematic errors
+    // (the tracks end in 8 spare entries, pack_reference).
+    mutable uint32_t held_word = 0xFFFFFFFFu, held_sys = 0xFFFFFFFFu;
+    mutable uint64_t word = 0, sys4 = 0;
+    RSQ_HD uint64_t template_word(const uint64_t *from, uint32_t index) const {
+        if (index != held_word) {
+            held_word = index;
+            word = from[index];
+        }
+        return word;
+    }
     RSQ_HD uint32_t org_len() const { return len; }
-    RSQ_HD uint32_t ref(uint32_t k) const { return reverse ? 3u - ref_base(words, word_off, first - 1u - k) : ref_base(words, word_off, first + k); }
-    RSQ_HD uint32_t base(uint32_t k) const { return converted ? (uint32_t)(converted[k >> 5] >> ((k & 31u) * 2u)) & 3u : ref(k); }
-    RSQ_HD uint32_t sys_base(uint32_t k) const { return sys_[k]; }
-    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_[k]; }
+    RSQ_HD uint32_t ref(uint32_t k) const {
+        const uint32_t pos = reverse ? first - 1u - k : first + k, b = (uint32_t)(template_word(words + word_off, pos >> 5) >> ((pos & 31u) * 2u)) & 3u;
+        return reverse ? 3u - b : b;
+    }
+    RSQ_HD uint32_t base(uint32_t k) const { return converted ? (uint32_t)(template_word(converted, k >> 5) >> ((k & 31u) * 2u)) & 3u : ref(k); }
+    RSQ_HD uint32_t sys_base(uint32_t k) const {
+        if ((k >> 2) != held_sys) {
+            held_sys = k >> 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+            sys4 = *reinterpret_cast<const uint64_t __attribute__((aligned(2))) *>(sys_ + (k & ~3u));
+#else
+            memcpy(&sys4, sys_ + (k & ~3u), 8);
+#endif
+        }
+        return (uint32_t)(sys4 >> ((k & 3u) * 16u)) & 0xFFFFu;
+    }
+    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_base(k); }
     // Simulator.cpp:482-489 without a load per base: the G/C count of the template's reference range from the per-word prefix sums
     // (the complement strand has the same count), the error rates four per 8-byte load
     RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
