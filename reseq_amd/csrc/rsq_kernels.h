@@ -1646,7 +1646,6 @@ RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg
 struct VariantSrc : FragmentSrc {
     const DevVariant *var;              // the sequence's variants in forward order
     const uint16_t *err;                // the variants' systematic errors on the strand the mate reads
-    const uint16_t *sys_at;             // sys_ - spos0: indexed by strand position
     uint32_t n_var, L, allele;
     uint32_t *walk_error;               // DevSim::walk_error
     uint32_t spos0, cur0, var_pos0;     // start of the walk: strand position of the first template base, variant index, position in an insertion
@@ -1692,7 +1691,7 @@ struct VariantSrc : FragmentSrc {
     RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
         if (off_strand()) return 0;
         if (!var_pos && !(vs_cur < bend_cur && vs_cur <= spos)) {               // the common step: no variant of the block at or before this position
-            const uint32_t se = sys_at[spos];
+            const uint32_t se = FragmentSrc::sys_base(spos - spos0);
             if (++spos == bend_cur) {
                 cur = lower_bound(spos);
                 refresh();
@@ -1700,7 +1699,7 @@ struct VariantSrc : FragmentSrc {
             return se;
         }
         if (var_pos) {
-            const uint32_t se = sys_at[spos];
+            const uint32_t se = FragmentSrc::sys_base(spos - spos0);
             if (++var_pos >= var_at(cur).len) {
                 var_pos = 0;
                 ++cur;
@@ -1734,13 +1733,13 @@ struct VariantSrc : FragmentSrc {
                 }
             } else ++cur;
         }
-        const uint32_t se = sys_at[spos];
+        const uint32_t se = FragmentSrc::sys_base(spos - spos0);
         increment_block_pos();
         return se;
     }
     RSQ_HD uint32_t sys_deleted(uint32_t) const {                               // :380-392
         if (off_strand()) return 0;
-        const uint32_t se = sys_at[spos];
+        const uint32_t se = FragmentSrc::sys_base(spos - spos0);
         if (var_pos && ++var_pos >= var_at(cur).len) var_pos = 0;
         if (0u == var_pos) {
             if (++spos == bend_cur) cur = lower_bound(spos);
@@ -1772,7 +1771,6 @@ RSQ_HD VariantSrc variant_src(const DevSim &S, const Fragment &f, const Fragment
     src.allele = f.allele;
     src.walk_error = S.walk_error;
     src.spos0 = src.reverse ? src.L - src.first : src.first;
-    src.sys_at = src.sys_ - src.spos0;
     if (!fv) {
         src.cur0 = src.lower_bound(src.spos0);
         src.var_pos0 = 0;
