@@ -1170,14 +1170,29 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
         else gc += reverse ? ref_gc_count_prefix(words, gc_prefix, word_off, first - n, first) : ref_gc_count_prefix(words, gc_prefix, word_off, first, first + n);
         rate_sum += rate_total(n);
     }
+    // eight entries per 16-byte load (the tracks end in 8 spare entries); the rate is an entry's high byte
     RSQ_HD uint32_t rate_total(uint32_t n) const {
-        uint32_t k = 0, sum = 0;
-        for (; k < n && ((uintptr_t)(sys_ + k) & 7u); ++k) sum += sys_[k] >> 8;
-        for (; k + 4u <= n; k += 4u) {
-            const uint64_t four = *reinterpret_cast<const uint64_t *>(sys_ + k);
-            sum += (uint32_t)((four >> 8) & 0xFFu) + (uint32_t)((four >> 24) & 0xFFu) + (uint32_t)((four >> 40) & 0xFFu) + (uint32_t)(four >> 56);
+        struct __attribute__((packed, aligned(2))) Eight {
+            uint64_t a, b;
+        };
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < n; k += 8u) {
+            Eight e;
+#if defined(__HIP_DEVICE_COMPILE__)
+            e = *reinterpret_cast<const Eight *>(sys_ + k);
+#else
+            memcpy(&e, sys_ + k, 16);
+#endif
+            const uint32_t left = n - k;                               // entries of this group that count
+            if (left < 8u) {
+                if (left <= 4u) {
+                    e.b = 0;
+                    if (left < 4u) e.a &= (1ull << (16u * left)) - 1ull;
+                } else e.b &= (1ull << (16u * (left - 4u))) - 1ull;
+            }
+            const uint64_t kHigh = 0x00FF00FF00FF00FFull, kAdd = 0x0001000100010001ull;
+            sum += (uint32_t)((((e.a >> 8) & kHigh) * kAdd) >> 48) + (uint32_t)((((e.b >> 8) & kHigh) * kAdd) >> 48);
         }
-        for (; k < n; ++k) sum += sys_[k] >> 8;
         return sum;
     }
 };
