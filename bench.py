@@ -214,10 +214,18 @@ def main():
     ap.add_argument("--batch-blocks", type=int, default=4800, help="blocks of 1000 start positions per rsq_sim_pairs call (4800: the whole E. coli-sized job in one call)")
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--gc", type=float, default=0.508, help="G+C fraction of the synthetic reference (E. coli: 0.508)")
+    ap.add_argument("--tiles", type=int, default=1, help="NOT the headline: P0 with so many tiles (per-tile tables; above one tile the read kernel serves one tile per workgroup)")
+    ap.add_argument("--lib", default=None, help="another build of libreseq_amd.so (experiment builds, exp/)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="rsq_set_option before the simulator is created (measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the value_to_host leg (it is skipped anyway with more than one GPU: every rank would pin 15 GB of host memory)")
     args = ap.parse_args()
 
+    if args.lib:
+        api.use_library(args.lib)
+    for item in args.option:
+        name, value = item.split("=", 1)
+        api.set_option(name, int(value))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,7 +234,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"rsq_bench_{rank}_")
     ppath = os.path.join(tmp, "p0.rsqp")
     fpath = os.path.join(tmp, "ref.fa")
-    synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084, n_ref_seqs=world))
+    cfg = synth.P0 if args.tiles <= 1 else synth.p0_with_tiles(args.tiles)
+    synth.write_profile(ppath, synth.make_profile(cfg, seed=103741084, n_ref_seqs=world))
     seqs = []
     for i in range(world):
         seqs += synth.make_reference(2 + i, [args.genome], gc=args.gc, names=[f"synthEcoli{i} len={args.genome}"])
@@ -295,6 +304,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
+    plan = sim.fill_plan()
+    if plan["image_tiles"] and plan["image_tiles"] < args.tiles:
+        kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
 
     # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1
@@ -349,7 +361,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference sequence and 10 M pairs per GPU, pre-fitted synthetic profile P0 (2x150), "
-                                   "illuminaPE hot path (sieve + CreateReads + FASTQ text) resident in HBM", "reference_bp": args.genome * world,
+                                   "illuminaPE hot path (sieve + CreateReads + FASTQ text) resident in HBM" +
+                                   (f" -- NOT the headline: P0 with {args.tiles} tiles (per-tile tables)" if args.tiles > 1 else ""),
+                       "tiles": args.tiles, "fill_plan": plan, "options": args.option, "reference_bp": args.genome * world,
                        "pairs_requested": args.pairs * world, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
                        "batch_blocks": args.batch_blocks, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
                        "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective"},

@@ -35,8 +35,14 @@ enum {
 };
 
 const char *rsq_last_error(void);
-const char *rsq_last_warning(void);          /* non-fatal remarks of the last rsq_profile_load* call ("" if none) */
+const char *rsq_last_warning(void);          /* non-fatal remarks of the last rsq_profile_load* or rsq_sim_create call ("" if none) */
 const char *rsq_version(void);
+/* Testing and measurement switches (reseq_amd/csrc/rsq_host.h `Options`; README "Options").  The library reads nothing from the environment: an
+ * embedding program sets a switch explicitly, and a simulator takes the values current when it is created (pre-pass switches: when the pre-pass
+ * runs).  Reads and FASTQ bytes never depend on them -- they choose between equivalent routes (e.g. fill_mode 0: every per-base draw in double
+ * precision from device memory, the reference's own recipe, ProbabilityEstimates.h:481-508).  RSQ_EINVAL for an unknown name. */
+int rsq_set_option(const char *name, int64_t value);
+int rsq_get_option(const char *name, int64_t *value);
 /* number of visible HIP devices, or RSQ_ENODEV */
 int rsq_device_count(void);
 
@@ -147,6 +153,11 @@ typedef struct {
     double bias_normalization;
 } rsq_sim_info;
 int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out);
+/* How the read kernels (FillRead, Simulator.cpp:454-594) reach the profile's tables on this simulator: quality_quads = 16-byte groups per quality row of
+ * the screened single-precision draws, 0 = every per-base draw in double precision from device memory (rsq_last_warning() after rsq_sim_create says
+ * why); image_tiles = tiles whose tables one workgroup's local-memory image holds: all of the profile's (reads of any tile served by any workgroup) or 1
+ * (reads binned by the tile they draw, Simulator.h:176-181, one tile per workgroup at a time); image_bytes = size of that image. */
+int rsq_sim_get_fill_plan(const rsq_sim *s, uint32_t *quality_quads, uint32_t *image_tiles, uint32_t *image_bytes);
 
 /* pre-pass results, for inspection and stage-wise parity tests */
 int rsq_sim_get_thresholds(const rsq_sim *s, double *out, size_t n);           /* [groups][insert_to][2] */

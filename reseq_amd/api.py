@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RSQ_LIB", os.path.join(_HERE, "libreseq_amd.so"))      # RSQ_LIB: experiment builds of the same library
+LIB_PATH = os.path.join(_HERE, "libreseq_amd.so")
 
 RSQ_OK, RSQ_EINVAL, RSQ_EIO, RSQ_ENODEV, RSQ_EHIP, RSQ_ENOSPC, RSQ_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
@@ -38,6 +38,8 @@ _psz = C.POINTER(C.c_size_t)
 SYMBOLS = {
     "rsq_last_error": (C.c_char_p, []),
     "rsq_version": (C.c_char_p, []),
+    "rsq_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "rsq_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "rsq_device_count": (C.c_int, []),
     "rsq_profile_load": (C.c_int, [C.c_char_p, _pp]),
     "rsq_profile_load_reseq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, _pp]),
@@ -72,6 +74,7 @@ SYMBOLS = {
     "rsq_sim_prepare_sys_errors": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "rsq_sim_prepare_finish": (C.c_int, [_vp]),
     "rsq_sim_get_info": (C.c_int, [_vp, C.POINTER(SimInfo)]),
+    "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rsq_sim_get_thresholds": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_get_norm_by_len": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_set_normalization": (C.c_int, [_vp, C.c_double, _vp, _sz]),
@@ -112,6 +115,29 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def use_library(path):
+    """Bind another build of the same library (experiment builds under exp/); must be called before anything else."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.abspath(path)
+
+
+def set_option(name, value):
+    """Testing / measurement switches of the library (include/reseq_amd.h rsq_set_option); results never depend on them."""
+    _check(lib().rsq_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int64(0)
+    _check(lib().rsq_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def last_warning():
+    return lib().rsq_last_warning().decode(errors="replace")
 
 
 def _check(rc):
@@ -286,6 +312,12 @@ class Simulator:
         i = SimInfo()
         _check(lib().rsq_sim_get_info(self.h, C.byref(i)))
         return i
+
+    def fill_plan(self):
+        """{'mask': quads per quality row of the screened draws (0: double precision only), 'image_tiles', 'image_bytes'}"""
+        q, t, b = _u32(0), _u32(0), _u32(0)
+        _check(lib().rsq_sim_get_fill_plan(self.h, C.byref(q), C.byref(t), C.byref(b)))
+        return {"mask": q.value, "image_tiles": t.value, "image_bytes": b.value}
 
     def thresholds(self):
         i = self.info()

@@ -24,6 +24,49 @@
 
 namespace rsq {
 
+// ------------------------------------------------------------------------------------------------ options
+Options &options() {
+    static Options o;
+    return o;
+}
+namespace {
+struct OptionEntry {
+    const char *name;
+    int64_t Options::*field;
+};
+const OptionEntry kOptionTable[] = {
+    {"fill_mode", &Options::fill_mode},         {"image_tiles", &Options::image_tiles},     {"rate_rows", &Options::rate_rows},
+    {"no_indel_skip", &Options::no_indel_skip}, {"force_exact", &Options::force_exact},     {"min_quality_quads", &Options::min_quality_quads},
+    {"unit_chunks", &Options::unit_chunks},     {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
+    {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},
+    {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap},
+};
+}  // namespace
+bool set_option(const char *name, int64_t value) {
+    for (const OptionEntry &e : kOptionTable)
+        if (0 == strcmp(name, e.name)) {
+            options().*(e.field) = value;
+            return true;
+        }
+    return false;
+}
+bool get_option(const char *name, int64_t *value) {
+    for (const OptionEntry &e : kOptionTable)
+        if (0 == strcmp(name, e.name)) {
+            *value = options().*(e.field);
+            return true;
+        }
+    return false;
+}
+const char *option_names() {
+    static const std::string names = [] {
+        std::string s;
+        for (const OptionEntry &e : kOptionTable) s += (s.empty() ? "" : " ") + std::string(e.name);
+        return s;
+    }();
+    return names.c_str();
+}
+
 // ---------------------------------------------------------------------------------------------- container
 static size_t pad8(size_t n) { return (8 - (n & 7)) & 7; }
 
@@ -284,9 +327,9 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
-    // small files: the line reader.  RSQ_FASTA_STRETCH (tests): the stretch length in bytes, also the size from which a file is mapped
-    const char *env = getenv("RSQ_FASTA_STRETCH");
-    const size_t kStretch = env ? std::max<size_t>(1, strtoull(env, nullptr, 10)) : (size_t)8u << 20, min_size = env ? 4 : (size_t)1 << 20;
+    // small files: the line reader.  Option fasta_stretch (tests): the stretch length in bytes, also the size from which a file is mapped
+    const int64_t stretch_opt = options().fasta_stretch;
+    const size_t kStretch = stretch_opt > 0 ? (size_t)stretch_opt : (size_t)8u << 20, min_size = stretch_opt > 0 ? 4 : (size_t)1 << 20;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < min_size) {
         close(fd);
         return false;
@@ -371,7 +414,7 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
 
 Reference Reference::read_fasta(const std::string &path) {
     Reference r;
-    if (!getenv("RSQ_SERIAL_FASTA") && read_fasta_mapped(path, r)) return r;
+    if (!options().serial_fasta && read_fasta_mapped(path, r)) return r;
     r = Reference();
     GzLines f(path);
     static const BaseCodes codes;

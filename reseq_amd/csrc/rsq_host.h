@@ -14,6 +14,31 @@ struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// ------------------------------------------------------------------------------------------------ options
+// Testing and measurement switches of the library (C ABI rsq_set_option / rsq_get_option): explicit calls of the embedding program, never
+// read from the environment.  Results (reads, FASTQ bytes) do not depend on any of them; they choose between equivalent routes.  A simulator
+// takes the values current when it is created (rsq_sim_create) or, for the pre-pass switches, when the pre-pass runs.
+struct Options {
+    int64_t fill_mode = -1;            // -1: screened draws on the LDS image when the plan has one; 0: every draw of the read kernels in double precision from HBM
+    int64_t image_tiles = 0;           // 0: the image holds all tiles when they fit, else one tile per workgroup; 1: one tile per workgroup even when all fit
+    int64_t rate_rows = 0;             // > 0: at most so many error-rate rows in the LDS image
+    int64_t no_indel_skip = 0;         // 1: no indel draw decided by the random word alone
+    int64_t force_exact = 0;           // 1: the screen decides nothing, every draw takes the double-precision route behind it
+    int64_t min_quality_quads = 0;     // a wider instantiation of the read kernels than the profile's quality values need
+    int64_t unit_chunks = 0;           // > 0: chunks of 64 reads per work unit of the per-tile read kernel
+    int64_t trace_plan = 0;            // 1: the LDS plan on stderr
+    int64_t trace_prepare = 0;         // 1: stage times of the pre-pass on stderr
+    int64_t bias_window = 0;           // > 0: start positions per pass of the bias sums
+    int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
+    int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
+    int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
+    int64_t overlap = -1;              // -1: rsq_sim_pairs pipelines sieve / reads / text over sub-ranges when the batch is large; 0: one pass; n > 0: n sub-ranges
+};
+Options &options();                                               // the process-wide values
+bool set_option(const char *name, int64_t value);                 // false: no such option
+bool get_option(const char *name, int64_t *value);
+const char *option_names();                                       // space-separated, for error messages
+
 // ---------------------------------------------------------------------------------------------- container
 struct Array {
     int dtype = 0;   // 0 u8, 1 u16, 2 u32, 3 u64, 4 i32, 5 i64, 6 f64

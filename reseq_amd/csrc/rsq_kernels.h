@@ -1427,9 +1427,13 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
 //    own row from HBM (HybridRow32).
 // The rows over the read position and the read's G/C percent stay in HBM (L2): the lanes of a wave share the position rows (4
 // cache lines per load).  A draw the screen cannot decide is repeated in double precision from HBM (GlobalTables).
-// Image layout (32-bit words): descriptors [quality 4T][base_call 20T][indels 12][seq_quality T] (20 words each), the outcome
-// values, staged margins at DevTable::lds_off / lds_extra, error-rate rows at q3_off / b3_off.
+// Image layout (32-bit words), Ti = LdsPlan::img_tiles: descriptors [quality 4 Ti][base_call 20 Ti][indels 12][seq_quality Ti] (20 words
+// each), the outcome values of these tables, staged margins at DevTable::lds_off / lds_extra, error-rate rows at q3_off / b3_off.
+// An image serves the reads of one template segment and of tiles first_tile .. first_tile + Ti - 1 (Ti = n_tiles: all tiles; Ti = 1: the reads
+// are binned by tile and a workgroup stages the image of the bin it serves, fill_binned_loop); it is identified by the index of its first
+// quality table, qbase = (segment * n_tiles + first_tile) * 4.  Descriptors in the image have par0_off relative to the image's outcome values.
 RSQ_HD uint32_t lds_desc_count(uint32_t n_tiles) { return 25u * n_tiles + 12u; }
+RSQ_HD uint32_t image_qbase(const DevSim &S, uint32_t seg, uint32_t first_tile) { return (seg * S.n_tiles + first_tile) * 4u; }
 constexpr uint32_t kDescWords = sizeof(DevTable) / 4u;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1472,13 +1476,13 @@ struct ScreenTables {
     static constexpr int QQ = (int)MASK;
     const DevSim &S;
     const RSQ_LDS float *img;          // image of the workgroup
-    uint32_t seg;
+    uint32_t qbase;                    // index of the image's first quality table (image_qbase)
     const RSQ_LDS float *ring_;        // the wave's ring
     uint32_t t;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
     RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_words - S.lds.par0_words)); }
-    RSQ_HD DevTable quality(uint32_t i) const { return desc(i - seg * 4u * S.n_tiles); }
-    RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.n_tiles + 12u + i - seg * S.n_tiles); }
+    RSQ_HD DevTable quality(uint32_t i) const { return desc(i - qbase); }
+    RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.lds.img_tiles + 12u + i - qbase / 4u); }
     RSQ_HD static uint32_t row32(const DevTable &t, int n, uint32_t v, uint32_t slot) {      // offset of the row of margin n in the table's float copy
         uint32_t before = 0;
         for (int m = 0; m < n; ++m) before += t.rows[m];
@@ -1508,7 +1512,7 @@ struct ScreenTables {
     }
 
     RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
-        const uint32_t local = i - seg * 4u * S.n_tiles;
+        const uint32_t local = i - qbase;
         const DevTable t = desc(local);
         ps = 0u;
         if (!t.k) return 0;
@@ -1523,8 +1527,8 @@ struct ScreenTables {
         return settle<4>(decided, col, t, local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
-        const uint32_t local = i - seg * 20u * S.n_tiles;
-        const DevTable t = desc(4u * S.n_tiles + local);
+        const uint32_t local = i - qbase * 5u;
+        const DevTable t = desc(4u * S.lds.img_tiles + local);
         ps = 0u;
         if (!t.k) return 0;
         const uint32_t slot = S.lds.slot_b, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_b;
@@ -1537,10 +1541,10 @@ struct ScreenTables {
         uint32_t col = 0;
         bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3) && t.f32_ok;
         RSQ_SCREEN_COUNT(1, decided);
-        return settle<4>(decided, col, t, 4u * S.n_tiles + local, idx, u, ps);
+        return settle<4>(decided, col, t, 4u * S.lds.img_tiles + local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {
-        const DevTable t = desc(24u * S.n_tiles + i);
+        const DevTable t = desc(24u * S.lds.img_tiles + i);
         ps = 0u;
         if (!t.k) return 0;
         // nearly every draw: the random word alone says "no indel" (DevTable::sure_range); the wave skips the rows when all its lanes are that sure
@@ -1559,29 +1563,33 @@ struct ScreenTables {
         uint32_t col = 0;
         bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2) && t.f32_ok;
         RSQ_SCREEN_COUNT(2, decided);
-        return settle<3>(decided, col, t, 24u * S.n_tiles + i, idx, u, ps);
+        return settle<3>(decided, col, t, 24u * S.lds.img_tiles + i, idx, u, ps);
     }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {     // once per read: double precision
-        const uint32_t r = exact_draw_call<3>(S.pool, img, S.lds.desc_words - S.lds.par0_words, 24u * S.n_tiles + 12u + i - seg * S.n_tiles, idx[0], idx[1], idx[2], 0u, u);
+        const uint32_t r = exact_draw_call<3>(S.pool, img, S.lds.desc_words - S.lds.par0_words, 24u * S.lds.img_tiles + 12u + i - qbase / 4u, idx[0], idx[1], idx[2], 0u, u);
         ps = (r >> 31) ^ 1u;
         return r & 0x7FFFFFFFu;
     }
 };
 
-// Builds the static LDS image of segment `seg`; tid/nthreads describe the calling thread (the host emulation calls it with
+// Builds the LDS image `qbase` (image_qbase); tid/nthreads describe the calling thread (the host emulation calls it with
 // 0/1).  The caller synchronises the workgroup between the two phases and after the second.
-RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS float *img, uint32_t seg, uint32_t tid, uint32_t nthreads) {
-    const uint32_t T = S.n_tiles;
+RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS float *img, uint32_t qbase, uint32_t tid, uint32_t nthreads) {
+    const uint32_t T = S.lds.img_tiles;
     RSQ_LDS uint32_t *dst = reinterpret_cast<RSQ_LDS uint32_t *>(img);
     const uint32_t wq = 4u * T * kDescWords, wb = 20u * T * kDescWords, wi = 12u * kDescWords, ws = T * kDescWords;
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(S.quality + seg * 4u * T), *b = reinterpret_cast<const uint32_t *>(S.base_call + seg * 20u * T),
-                   *in = reinterpret_cast<const uint32_t *>(S.indels), *sq = reinterpret_cast<const uint32_t *>(S.seq_quality + seg * T);
-    for (uint32_t i = tid; i < wq; i += nthreads) dst[i] = q[i];
-    for (uint32_t i = tid; i < wb; i += nthreads) dst[wq + i] = b[i];
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(S.quality + qbase), *b = reinterpret_cast<const uint32_t *>(S.base_call + qbase * 5u),
+                   *in = reinterpret_cast<const uint32_t *>(S.indels), *sq = reinterpret_cast<const uint32_t *>(S.seq_quality + qbase / 4u);
+    // outcome values: the indel tables' are the first bytes of the pool, the image's tiles' a contiguous range from its first quality table's on;
+    // par0_off (word 1 of a descriptor) becomes relative to the image's copy
+    const uint32_t tiles_at = S.quality[qbase].par0_off, shift = tiles_at - S.lds.par0_indel_bytes;
+    for (uint32_t i = tid; i < wq; i += nthreads) dst[i] = q[i] - (i % kDescWords == 1u ? shift : 0u);
+    for (uint32_t i = tid; i < wb; i += nthreads) dst[wq + i] = b[i] - (i % kDescWords == 1u ? shift : 0u);
     for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
-    for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i];
-    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(S.par0);      // the pool is padded to whole words by pack_tables
-    for (uint32_t i = tid; i < S.lds.par0_words; i += nthreads) dst[wq + wb + wi + ws + i] = p0[i];
+    for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i] - (i % kDescWords == 1u ? shift : 0u);
+    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(S.par0), *p1 = reinterpret_cast<const uint32_t *>(S.par0 + tiles_at);      // ranges start on words; the pool has spare bytes at its end
+    const uint32_t indel_words = S.lds.par0_indel_bytes / 4u;
+    for (uint32_t i = tid; i < S.lds.par0_words; i += nthreads) dst[wq + wb + wi + ws + i] = i < indel_words ? p0[i] : p1[i - indel_words];
 }
 // rows 0..n_rows-1 of margin 3 of `n_tables` tables starting at descriptor `first`, one slot per row
 RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS float *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,
@@ -1594,7 +1602,7 @@ RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS float *img, uint32_t fi
     }
 }
 RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, uint32_t nthreads) {
-    const uint32_t T = S.n_tiles;
+    const uint32_t T = S.lds.img_tiles;
     const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
     for (uint32_t t = 0; t < 4u * T; ++t) {                                     // quality: margins 0 and 1, contiguous in the copy
         const DevTable tb = d[t];
@@ -1623,7 +1631,7 @@ RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, ui
 // The ring: the quality rows (margin 2) over read position p of the segment's tables, copied by the wave itself at the beginning of
 // step p into slot p % kRingSlots of its ring: one load of 16 bytes per lane instead of one per lane and quad of the row.  Item i is
 // one 16-byte group of one table's row.
-RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.n_tiles * S.lds.quads_q; }
+RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.lds.img_tiles * S.lds.quads_q; }
 RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) {
     const uint32_t table = item / S.lds.quads_q, c = item % S.lds.quads_q, slot = S.lds.slot_q;
     const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
@@ -1911,17 +1919,145 @@ RSQ_HD RecordSrc record_src(const uint8_t *seqs, const uint8_t *dom, const uint8
 #endif
 constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
 
+// Reads binned by tile (LdsPlan::img_tiles == 1 < n_tiles): bin = segment * n_tiles + tile.  `perm` lists the items (pairs of a batch: both segments
+// share the list of a tile; seqToIllumina records: a record has one segment) bin after bin; a bin's chunks of 64 items are handed out in UNITS of
+// unit_chunks chunks: a workgroup takes a unit, stages the bin's image if it is not the one it holds, and its waves pull the unit's chunks.
+struct FillBins {
+    const uint32_t *perm;           // items sorted by bin
+    const uint32_t *bin_first;      // [n_bins] first entry of the bin in perm
+    const uint32_t *bin_count;      // [n_bins]
+    const uint32_t *unit_ptr;       // [n_bins + 1] units in front of the bin
+    uint32_t *unit_counter;
+    uint32_t n_bins, unit_chunks;
+};
+constexpr uint32_t kSchedWords = 4;              // LDS words behind the image that fill_binned_loop keeps its unit and chunk counter in
+constexpr uint32_t kBinKeysLds = 4096;          // up to so many bin keys the counting kernels aggregate in LDS
+constexpr uint32_t kBinItemsPerThread = 16, kBinBlock = 256;
+
+// the stream of one mate of a pair (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382): what k_fill_reads and the tile binning agree on
+struct PairStream {
+    uint32_t c0, c1, c2, strand;
+};
+RSQ_HD PairStream pair_stream(const Fragment *f, uint32_t sub, uint64_t adapter_only_number) {
+    if (f) return PairStream{f->start, f->seq | (sub << 22), f->len | ((uint32_t)f->dup << 16), f->strand};
+    return PairStream{(uint32_t)adapter_only_number, 0xFFFFFFFFu, (uint32_t)(adapter_only_number >> 32), 0u};
+}
+
 #if defined(__HIPCC__)
-// One lane per read, persistent waves.  A workgroup serves one template segment (blockIdx.x & 1), builds its static LDS
-// image once, then every wave pulls chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail).
-// All lanes of a wave walk their reads' state machines in one uniform loop.  MASK = kLds* bits (0: every table access
-// goes to HBM).
-// the LDS image of the workgroup's template segment (all waves call it; returns after the final barrier)
+// bin keys of the items + their histogram.  Pairs: key = tile (TileId() once per pair, Simulator.cpp:701-704); records: key = segment * n_tiles + tile.
+__device__ inline void bin_count_key(uint32_t key, bool valid, uint32_t n_keys, uint32_t *hist, uint32_t *s_hist) {
+    if (n_keys <= kBinKeysLds) {
+        for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) s_hist[k] = 0;
+        __syncthreads();
+        if (valid) atomicAdd(&s_hist[key], 1u);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x)
+            if (s_hist[k]) atomicAdd(&hist[k], s_hist[k]);
+    } else if (valid) atomicAdd(&hist[key], 1u);
+}
+__global__ void __launch_bounds__(kBinBlock) k_pair_tiles(DevSim S, const Fragment *frags, const FragmentVar *fvars, uint64_t n_pairs, uint64_t adapter_only_first, uint16_t *key_of,
+                                                         uint32_t *hist) {
+    __shared__ uint32_t s_hist[kBinKeysLds];
+    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pair < n_pairs;
+    uint32_t key = 0;
+    if (valid) {
+        Fragment f{};
+        if (frags) f = frags[pair];
+        const PairStream ps = pair_stream(frags ? &f : nullptr, fvars ? fvars[pair].sub : 0u, adapter_only_first + pair);
+        key = draw_tile(S, ps.c0, ps.c1, ps.c2, pair_c3(kDomPair, ps.strand, 2, f.allele));
+        key_of[pair] = (uint16_t)key;
+    }
+    bin_count_key(key, valid, S.n_tiles, hist, s_hist);
+}
+__global__ void __launch_bounds__(kBinBlock) k_record_tiles(DevSim S, const uint8_t *segs, uint64_t first_index, uint64_t n, uint16_t *key_of, uint32_t *hist) {
+    __shared__ uint32_t s_hist[kBinKeysLds];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t key = 0;
+    if (valid) {
+        const uint64_t idx = first_index + i;
+        key = (segs[i] ? S.n_tiles : 0u) + draw_tile(S, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, 2));
+        key_of[i] = (uint16_t)key;
+    }
+    bin_count_key(key, valid, 2u * S.n_tiles, hist, s_hist);
+}
+// one workgroup: the bins' places in perm (exclusive scan of the histogram), their units, the scatter's cursors.  pairs: n_keys = n_tiles, bins
+// (segment, tile) of both segments share tile's entries; records: n_keys = 2 n_tiles = the bins.
+__global__ void __launch_bounds__(1024) k_bins_plan(const uint32_t *hist, uint32_t n_keys, uint32_t n_bins, uint32_t unit_chunks, uint32_t *bin_first, uint32_t *bin_count,
+                                                    uint32_t *unit_ptr, uint32_t *cursor, uint32_t *unit_counter) {
+    __shared__ uint32_t s_part[1024], s_units[1024];
+    const uint32_t t = threadIdx.x, per = (n_bins + 1023u) / 1024u, lo = t * per, hi = lo + per < n_bins ? lo + per : n_bins;
+    // bins lo .. hi-1 of this thread; bin b has the items of key b % n_keys
+    uint32_t items = 0, units = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = hist[b % n_keys];
+        if (b < n_keys) items += c;
+        units += ((c + 63u) / 64u + unit_chunks - 1u) / unit_chunks;
+    }
+    s_part[t] = items;
+    s_units[t] = units;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                       // inclusive scans over the threads
+        const uint32_t a = t >= d ? s_part[t - d] : 0u, u = t >= d ? s_units[t - d] : 0u;
+        __syncthreads();
+        s_part[t] += a;
+        s_units[t] += u;
+        __syncthreads();
+    }
+    uint32_t at = s_part[t] - items, unit_at = s_units[t] - units;
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = hist[b % n_keys];
+        if (b < n_keys) {
+            cursor[b] = at;
+            for (uint32_t r = b; r < n_bins; r += n_keys) bin_first[r] = at, bin_count[r] = c;
+            at += c;
+        }
+        unit_ptr[b] = unit_at;
+        unit_at += ((c + 63u) / 64u + unit_chunks - 1u) / unit_chunks;
+    }
+    if (t == 1023u) unit_ptr[n_bins] = s_units[1023];
+    if (t == 0) *unit_counter = 0;
+}
+// items to their bins' places: ranks inside the workgroup from LDS counters, one global reservation per workgroup and key
+__global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const uint16_t *key_of, uint64_t n, uint32_t n_keys, uint32_t *cursor, uint32_t *perm) {
+    __shared__ uint32_t s_count[kBinKeysLds], s_base[kBinKeysLds];
+    const uint64_t first = (uint64_t)blockIdx.x * (kBinBlock * kBinItemsPerThread);
+    if (n_keys > kBinKeysLds) {
+        for (uint32_t j = 0; j < kBinItemsPerThread; ++j) {
+            const uint64_t i = first + (uint64_t)j * kBinBlock + threadIdx.x;
+            if (i < n) perm[atomicAdd(&cursor[key_of[i]], 1u)] = (uint32_t)i;
+        }
+        return;
+    }
+    for (uint32_t k = threadIdx.x; k < n_keys; k += kBinBlock) s_count[k] = 0;
+    __syncthreads();
+    uint32_t rank[kBinItemsPerThread], key[kBinItemsPerThread];
+#pragma unroll
+    for (uint32_t j = 0; j < kBinItemsPerThread; ++j) {
+        const uint64_t i = first + (uint64_t)j * kBinBlock + threadIdx.x;
+        key[j] = i < n ? key_of[i] : 0xFFFFFFFFu;
+        rank[j] = i < n ? atomicAdd(&s_count[key[j]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_keys; k += kBinBlock)
+        if (s_count[k]) s_base[k] = atomicAdd(&cursor[k], s_count[k]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kBinItemsPerThread; ++j)
+        if (key[j] != 0xFFFFFFFFu) perm[s_base[key[j]] + rank[j]] = (uint32_t)(first + (uint64_t)j * kBinBlock + threadIdx.x);
+}
+
+// One lane per read, persistent waves.  A workgroup serves one LDS image at a time -- a template segment (blockIdx.x & 1) with all tiles, built once, every
+// wave pulling chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail); or, BINNED, the (segment, tile) of the work unit
+// it took (fill_binned_loop).  All lanes of a wave walk their reads' state machines in one uniform loop.  MASK = quads per quality row of the
+// screened draws (0: every table access goes to HBM in double precision).
+// the LDS image `qbase` of the workgroup (all waves call it; returns after the final barrier)
 template <uint32_t MASK>
-__device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, uint32_t seg) {
+__device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, uint32_t qbase) {
     RSQ_LDS float *img = (RSQ_LDS float *)lds_image;
     if (MASK) {
-        lds_stage_descriptors(S, img, seg, threadIdx.x, blockDim.x);
+        lds_stage_descriptors(S, img, qbase, threadIdx.x, blockDim.x);
         __syncthreads();
         lds_stage_rows(S, img, threadIdx.x, blockDim.x);
         __syncthreads();
@@ -1929,25 +2065,23 @@ __device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, ui
     return img;
 }
 // 64 reads of one wave through the state machine: one uniform step loop.  Screened (MASK != 0): at the beginning of a step the wave
-// copies the quality rows over the step's read position into its ring.  Returns whether the wave had work.
+// copies the quality rows over the step's read position into its ring.  `tile` (index among the profile's tiles) is the lane's own.
 template <uint32_t MASK, class Src>
-__device__ bool fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t seg, bool active, const Stream &st, uint32_t tile_c3, uint32_t fragment_length,
+__device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, bool active, const Stream &st, uint32_t tile, uint32_t fragment_length,
                                 const Src &src, ReadOut &out, ReadMeta &meta) {
     ReadMachine m;
-    bool any_work;
     if constexpr (MASK == 0) {
         const GlobalTables tab{S};
         if (active) {
-            m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
+            m.init(S, tab, st, seg, tile, fragment_length, src);
             while (m.step(S, tab, st, src, out)) {}
         }
-        any_work = __any(active) != 0;
     } else {
         const uint32_t lane = threadIdx.x & 63u, n_items = lds_ring_items(S);
         RSQ_LDS float *ring = img + S.lds.ring_off + (threadIdx.x >> 6) * kRingSlots * S.lds.ring_stride;
-        ScreenTables<MASK> tab{S, img, seg, ring, 0u};
+        ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
         bool running = active;
-        if (active) m.init(S, tab, st, seg, draw_tile(S, st.c0, st.c1, st.c2, tile_c3), fragment_length, src);
+        if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
         for (uint32_t t = 0; __any(running); ++t) {
             for (uint32_t item = lane; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
@@ -1955,64 +2089,113 @@ __device__ bool fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t se
             if (running) running = m.step(S, tab, st, src, out);
             __builtin_amdgcn_wave_barrier();
         }
-        any_work = __any(active) != 0;
     }
     if (active) {
         m.finalize(meta);
         out.finish();
     }
-    return any_work;
 }
 
-template <uint32_t MASK, bool VAR = false>
-__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
-                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) float lds_image[];
-    const uint32_t seg = blockIdx.x & 1u;
-    RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
-    const uint32_t lane = threadIdx.x & 63u;
+// The scheduler of the binned kernels.  Units are taken from one global counter; the workgroup's waves pull the chunks of its unit from a counter in LDS
+// (the two words behind the image).  chunk(img, qbase, seg, tile, item, active) runs 64 items.
+template <uint32_t MASK, class Chunk>
+__device__ void fill_binned_loop(const DevSim &S, float *lds_image, const FillBins &bins, Chunk &&chunk) {
+    RSQ_LDS float *img = (RSQ_LDS float *)lds_image;
+    RSQ_LDS uint32_t *sched = reinterpret_cast<RSQ_LDS uint32_t *>(img + (MASK ? S.lds.total_words : 0u));      // [0] the unit, [1] its next chunk
+    const uint32_t lane = threadIdx.x & 63u, n_units = bins.unit_ptr[bins.n_bins];
+    uint32_t staged = 0xFFFFFFFFu;
     for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
-        chunk = __shfl(chunk, 0, 64);
-        const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave idles through this round of its workgroup
-        const uint64_t pair = first + lane;
-        const bool active = pair < n_pairs;
-        const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : 0u);
-        ReadOut out = raw.out_of(r);
-        Fragment f{};
-        if (active && frags) f = frags[pair];
-        // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
-        const bool from_fragment = frags != nullptr;
-        const uint64_t ao = adapter_only_first + pair;
-        FragmentVar fv{};
-        if (VAR && active && fvars) fv = fvars[pair];
-        const uint32_t c0 = from_fragment ? f.start : (uint32_t)ao, c1 = from_fragment ? (f.seq | (fv.sub << 22)) : 0xFFFFFFFFu,
-                       c2 = from_fragment ? (f.len | ((uint32_t)f.dup << 16)) : (uint32_t)(ao >> 32);
-        const uint32_t strand = from_fragment ? f.strand : 0u;
-        const Stream st{S.seed, c0, c1, c2, pair_c3(kDomPair, strand, seg, f.allele)};
-        ReadMeta meta;
-        bool work;
-        if constexpr (VAR) {                                            // launched for fragments only
-            VariantSrc src = variant_src(S, f, fvars ? &fv : nullptr, seg);
-            if (raw.templates) src.converted = raw.templates + r * raw.template_words;
-            work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2, f.allele), f.len, src, out, meta);
-        } else {
-            FragmentSrc src = from_fragment && active ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
-            if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
-            work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomPair, strand, 2), f.len, src, out, meta);
+        __syncthreads();                                               // every wave is done with the last unit
+        if (threadIdx.x == 0) {
+            sched[0] = atomicAdd(bins.unit_counter, 1u);
+            sched[1] = 0;
         }
-        if (active) {
-            raw.meta[r] = meta;
-            sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
+        __syncthreads();
+        const uint32_t unit = sched[0];
+        if (unit >= n_units) break;
+        uint32_t lo = 0, hi = bins.n_bins;                             // the unit's bin: the last one with unit_ptr[bin] <= unit
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (bins.unit_ptr[mid] <= unit) lo = mid;
+            else hi = mid;
         }
-        if (!work) break;
+        const uint32_t bin = lo, seg = bin / S.n_tiles, tile = bin - seg * S.n_tiles, qbase = image_qbase(S, seg, tile);
+        if (bin != staged) {
+            fill_stage_image<MASK>(S, lds_image, qbase);
+            staged = bin;
+        }
+        const uint32_t n_items = bins.bin_count[bin], first = bins.bin_first[bin], first_chunk = (unit - bins.unit_ptr[bin]) * bins.unit_chunks;
+        const uint32_t left = (n_items + 63u) / 64u - first_chunk, n_chunks = left < bins.unit_chunks ? left : bins.unit_chunks;
+        for (;;) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&sched[1], 1u);
+            c = __shfl(c, 0, 64);
+            if (c >= n_chunks) break;
+            const uint32_t k = (first_chunk + c) * 64u + lane;
+            const bool active = k < n_items;
+            chunk(img, qbase, seg, tile, active ? bins.perm[first + k] : 0u, active);
+        }
+    }
+}
+
+// one chunk of 64 pairs (lane = pair `pair` of the batch if active), mate `seg`
+template <uint32_t MASK, bool VAR, bool BINNED>
+__device__ void fill_pair_chunk(const DevSim &S, const NameTable &names, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t pair, bool active,
+                                const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, const RawLayout &raw, uint32_t *sizes, const FragmentVar *fvars) {
+    const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : 0u);
+    ReadOut out = raw.out_of(r);
+    Fragment f{};
+    if (active && frags) f = frags[pair];
+    // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
+    const bool from_fragment = frags != nullptr;
+    const uint64_t ao = adapter_only_first + pair;
+    FragmentVar fv{};
+    if (VAR && active && fvars) fv = fvars[pair];
+    const PairStream ps = pair_stream(from_fragment ? &f : nullptr, fv.sub, ao);
+    const Stream st{S.seed, ps.c0, ps.c1, ps.c2, pair_c3(kDomPair, ps.strand, seg, f.allele)};
+    const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, ps.c0, ps.c1, ps.c2, pair_c3(kDomPair, ps.strand, 2, f.allele)) : 0u);
+    ReadMeta meta;
+    if constexpr (VAR) {                                            // launched for fragments only
+        VariantSrc src = variant_src(S, f, fvars ? &fv : nullptr, seg);
+        if (raw.templates) src.converted = raw.templates + r * raw.template_words;
+        fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, f.len, src, out, meta);
+    } else {
+        FragmentSrc src = from_fragment && active ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
+        if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
+        fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, f.len, src, out, meta);
+    }
+    if (active) {
+        raw.meta[r] = meta;
+        sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
+    }
+}
+
+template <uint32_t MASK, bool VAR = false, bool BINNED = false>
+__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
+                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {
+    extern __shared__ __attribute__((aligned(16))) float lds_image[];
+    if constexpr (BINNED) {
+        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t pair, bool active) {
+            fill_pair_chunk<MASK, VAR, true>(S, names, img, qbase, seg, tile, pair, active, frags, n_pairs, adapter_only_first, raw, sizes, fvars);
+        });
+    } else {
+        const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
+        RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, qbase);
+        const uint32_t lane = threadIdx.x & 63u;
+        for (;;) {
+            uint32_t chunk = 0;
+            if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
+            chunk = __shfl(chunk, 0, 64);
+            const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave is done
+            if (first >= n_pairs) break;
+            fill_pair_chunk<MASK, VAR, false>(S, names, img, qbase, seg, 0u, first + lane, first + lane < n_pairs, frags, n_pairs, adapter_only_first, raw, sizes, fvars);
+        }
     }
 }
 
 // seqToIllumina (ApplyErrorsAndQualityToFastaInput, Simulator.cpp:2403-2512) through the same workgroups: the records were
 // partitioned by template segment (rec_index: segment-0 records first; rec_count[2] on the device), a workgroup serves one
-// segment and its waves pull chunks of 64 records.
+// segment and its waves pull chunks of 64 records; or, BINNED, by (segment, tile) like the pairs.
 struct RecordJob {
     uint64_t first_index;
     uint32_t read_len;
@@ -2021,29 +2204,40 @@ struct RecordJob {
     const uint32_t *rec_index, *rec_count;
     uint64_t n_records;
 };
-template <uint32_t MASK>
-__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters) {
+template <uint32_t MASK, bool BINNED>
+__device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t i, bool active,
+                                  const RawLayout &raw) {
+    const uint64_t idx = job.first_index + i;
+    const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
+    const RecordSrc src = record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
+    ReadOut out = raw.out_of(i);
+    ReadMeta meta;
+    const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, st.c0, st.c1, st.c2, pair_c3(kDomErrModel, 0, 2)) : 0u);
+    fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
+    if (active) raw.meta[i] = meta;
+}
+template <uint32_t MASK, bool BINNED = false>
+__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
-    const uint32_t seg = blockIdx.x & 1u;
-    RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, seg);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_mine = job.rec_count[seg];
-    const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);
-    for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
-        chunk = __shfl(chunk, 0, 64);
-        const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave idles through this round of its workgroup
-        const bool active = first + lane < n_mine;
-        const uint64_t i = active ? index[first + lane] : 0u;
-        const uint64_t idx = job.first_index + i;
-        const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-        const RecordSrc src = record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
-        ReadOut out = raw.out_of(i);
-        ReadMeta meta;
-        const bool work = fill_wave_reads<MASK>(S, img, seg, active, st, pair_c3(kDomErrModel, 0, 2), job.frag_len[i], src, out, meta);
-        if (active) raw.meta[i] = meta;
-        if (!work) break;
+    if constexpr (BINNED) {
+        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t i, bool active) {
+            fill_record_chunk<MASK, true>(S, job, img, qbase, seg, tile, i, active, raw);
+        });
+    } else {
+        const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
+        RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, qbase);
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t n_mine = job.rec_count[seg];
+        const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);
+        for (;;) {
+            uint32_t chunk = 0;
+            if (lane == 0) chunk = atomicAdd(&chunk_counters[seg], 1u);
+            chunk = __shfl(chunk, 0, 64);
+            const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave is done
+            if (first >= n_mine) break;
+            const bool active = first + lane < n_mine;
+            fill_record_chunk<MASK, false>(S, job, img, qbase, seg, 0u, active ? index[first + lane] : 0u, active, raw);
+        }
     }
 }
 // the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known

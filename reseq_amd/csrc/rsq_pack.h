@@ -88,6 +88,7 @@ struct SimState {
     std::vector<double> thresholds, norm_by_len, ref_seq_bias;
     std::string ref_bias_file;                       // --refBiasFile, consumed by plan_simulation when ref_bias_mode is kRefBiasFile
     double bias_normalization = 0;
+    std::string plan_note;                           // what pack_tables has to say about the read kernels' route (rsq_last_warning after rsq_sim_create)
 };
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -107,12 +108,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
             const HostTable &t = tabs[i];
             DevTable d{};
             d.k = (uint32_t)t.par0.size();
-            d.par0_off = (uint32_t)par0.size();
             d.lds_off = d.lds_extra = kNoLds;
-            for (uint32_t v : t.par0) {
-                par0.push_back((uint8_t)v);
-                d.max_value = std::max(d.max_value, v);
-            }
+            for (uint32_t v : t.par0) d.max_value = std::max(d.max_value, v);          // par0_off: assigned below, in the order the LDS images copy the values
             const uint32_t kp = row_stride(d.k);                       // even stride: zero pad column when K is odd
             for (uint32_t n = 0; n < t.nm; ++n) {
                 d.from[n] = t.from[n];
@@ -136,6 +133,29 @@ inline void pack_tables(SimState &s, Uploader &up) {
     // rows of one slot per family, pad columns zero.
     const uint32_t T = p.n_tiles();
     LdsPlan plan{};
+    // The outcome values (par0) in the order the LDS images want them: the indel tables', then per (segment, tile) those of its quality, sequence-quality
+    // and base-call tables -- an image copies the indel range and the range of its tiles --, then the two families of the systematic-error chains.  Every
+    // range starts on a word.
+    auto put_par0 = [&](DevTable &d, const HostTable &t) {
+        d.par0_off = (uint32_t)par0.size();
+        for (uint32_t v : t.par0) par0.push_back((uint8_t)v);
+    };
+    auto pad_par0 = [&] { par0.resize((par0.size() + 3u) & ~(size_t)3u, 0); };
+    for (size_t i = 0; i < indels.size(); ++i) put_par0(indels[i], p.indels[i]);
+    pad_par0();
+    const uint32_t par0_indel_bytes = (uint32_t)par0.size();
+    std::vector<uint32_t> par0_tile_first(2 * T + 1, 0);                                            // byte range of the tables of (segment, tile)
+    for (uint32_t g = 0; g < 2 * T; ++g) {
+        par0_tile_first[g] = (uint32_t)par0.size();
+        for (uint32_t i = 0; i < 4; ++i) put_par0(quality[g * 4 + i], p.quality[g * 4 + i]);
+        put_par0(seq_quality[g], p.seq_quality[g]);
+        for (uint32_t i = 0; i < 20; ++i) put_par0(base_call[g * 20 + i], p.base_call[g * 20 + i]);
+        pad_par0();
+    }
+    par0_tile_first[2 * T] = (uint32_t)par0.size();
+    for (size_t i = 0; i < dom_error.size(); ++i) put_par0(dom_error[i], p.dom_error[i]);
+    for (size_t i = 0; i < error_rate.size(); ++i) put_par0(error_rate[i], p.error_rate[i]);
+
     std::vector<float> pool32;
     auto kmax_of = [](const std::vector<DevTable> &tabs) {
         uint32_t kmax = 0;
@@ -222,8 +242,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
                 d.sure_range = c.lo16 | (c.hi16 << 16);
             }
     };
-    uint32_t min_quads = 0;
-    if (const char *e = getenv("RSQ_MIN_QUALITY_QUADS")) min_quads = (uint32_t)atoi(e);          // measurements: a wider instantiation than the profile needs
+    const Options &opt = options();
+    const uint32_t min_quads = opt.min_quality_quads > 0 ? (uint32_t)opt.min_quality_quads : 0u;     // measurements: a wider instantiation than the profile needs
     for (uint32_t q : kQualityQuads)
         if (!plan.quads_q && q >= min_quads && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
     const bool screenable = plan.quads_q && quads_of(kmax_of(base_call)) <= kQuadsSmall && quads_of(kmax_of(indels)) <= kQuadsSmall;
@@ -233,12 +253,12 @@ inline void pack_tables(SimState &s, Uploader &up) {
         copy32(quality, plan.slot_q);
         copy32(base_call, plan.slot_b);
         copy32(indels, plan.slot_i);
-        if (!getenv("RSQ_NO_INDEL_SKIP"))
+        if (!opt.no_indel_skip)
             for (DevTable &d : indels) certain_no_indel(d);
     }
     // the two families of the systematic-error chains: rows of whole quads, read from HBM
     s.dev.chain_quads = 0;
-    s.dev.force_exact = getenv("RSQ_FORCE_EXACT") ? 1u : 0u;
+    s.dev.force_exact = opt.force_exact ? 1u : 0u;
     for (uint32_t q : kChainQuads)
         if (!s.dev.chain_quads && quads_of(kmax_of(error_rate)) <= q && quads_of(kmax_of(dom_error)) <= kQuadsSmall) s.dev.chain_quads = q;
     if (s.dev.chain_quads) {
@@ -246,14 +266,12 @@ inline void pack_tables(SimState &s, Uploader &up) {
         copy32(error_rate, 4u * s.dev.chain_quads);
     }
 
-    // LDS plan of the read kernel (rsq_kernels.h "LDS staging"): the image of one template segment, the most valuable rows first,
-    // as much as fits 160 KiB.
-    plan.par0_words = par0.size() <= 8192 ? (uint32_t)((par0.size() + 1 + 15) / 16) * 4u : 0u;       // the outcome values of every table; whole 16 bytes: rows stay aligned
-    plan.desc_words = lds_desc_count(T) * kDescWords + plan.par0_words;
+    // LDS plan of the read kernels (rsq_kernels.h "LDS staging"): one image per template segment with the tables of ALL tiles when they fit the 160 KiB,
+    // else one image per (segment, tile) -- the read kernel then serves one tile per workgroup (k_fill_reads<MASK, VAR, true>: reads binned by tile).  The
+    // most valuable rows first: descriptors and outcome values, quality margins 0 + 1, base-call margin 0, the waves' rings and one error-rate row are
+    // required; more error-rate rows, base-call margin 2 and indel margin 0 take what is left.
     uint32_t rate_rows_q = ~0u, rate_rows_b = ~0u;
-    int allow = 1;
-    if (const char *e = getenv("RSQ_FILL_MODE")) allow = atoi(e);                                  // 0: double precision from HBM only (tests run both)
-    if (const char *e = getenv("RSQ_RATE_ROWS")) rate_rows_q = rate_rows_b = (uint32_t)std::max(1, atoi(e));       // at most so many error-rate rows
+    if (opt.rate_rows > 0) rate_rows_q = rate_rows_b = (uint32_t)std::min<int64_t>(opt.rate_rows, 1 << 20);       // at most so many error-rate rows
     uint32_t max_rate_q = 1, max_rate_b = 1;
     for (const DevTable &d : quality)
         if (d.k) max_rate_q = std::max(max_rate_q, d.rows[3]);
@@ -261,82 +279,101 @@ inline void pack_tables(SimState &s, Uploader &up) {
         if (d.k) max_rate_b = std::max(max_rate_b, d.rows[3]);
     rate_rows_q = std::min(rate_rows_q, max_rate_q);
     rate_rows_b = std::min(rate_rows_b, max_rate_b);
-    const uint64_t budget = kLdsBudgetBytes / 4u;
-    if (screenable && plan.par0_words && allow) {
-        uint64_t need = plan.desc_words, need_b2 = 0, need_i0 = 0;                                  // the larger segment decides
-        for (uint32_t seg = 0; seg < 2; ++seg) {
+    const uint64_t budget = kLdsBudgetBytes / 4u - kSchedWords;
+    // tries an image of Ti tiles; fills `plan` and the tables' offsets when the required parts fit
+    auto plan_image = [&](uint32_t Ti) {
+        const uint32_t n_img = 2 * T / Ti;                                                         // images: (segment, group of Ti tiles)
+        uint32_t par0_bytes = 0;
+        for (uint32_t g = 0; g < n_img; ++g) par0_bytes = std::max(par0_bytes, par0_indel_bytes + par0_tile_first[(g + 1) * Ti] - par0_tile_first[g * Ti]);
+        const uint32_t par0_words = (par0_bytes + 15u) / 16u * 4u;                                 // whole 16 bytes: rows stay aligned
+        const uint32_t desc_words = lds_desc_count(Ti) * kDescWords + par0_words;
+        uint64_t need = desc_words, need_b2 = 0, need_i0 = 0;                                       // the largest image decides
+        for (uint32_t g = 0; g < n_img; ++g) {
             uint64_t q = 0, b = 0, b2 = 0;
-            for (uint32_t i = 0; i < 4 * T; ++i) {
-                const DevTable &d = quality[seg * 4 * T + i];
+            for (uint32_t i = 0; i < 4 * Ti; ++i) {
+                const DevTable &d = quality[g * 4 * Ti + i];
                 if (d.k) q += (uint64_t)(d.rows[0] + d.rows[1]) * plan.slot_q;
             }
-            for (uint32_t i = 0; i < 20 * T; ++i) {
-                const DevTable &d = base_call[seg * 20 * T + i];
+            for (uint32_t i = 0; i < 20 * Ti; ++i) {
+                const DevTable &d = base_call[g * 20 * Ti + i];
                 if (d.k) b += (uint64_t)d.rows[0] * plan.slot_b, b2 += (uint64_t)d.rows[2] * plan.slot_b;
             }
-            need = std::max(need, plan.desc_words + q + b);
+            need = std::max(need, desc_words + q + b);
             need_b2 = std::max(need_b2, b2);
         }
         for (const DevTable &d : indels)
             if (d.k) need_i0 += (uint64_t)d.rows[0] * plan.slot_i;
-        auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * T * rows_q * plan.slot_q + (uint64_t)20 * T * rows_b * plan.slot_b; };
-        plan.ring_stride = 4 * T * plan.slot_q;
-        need += (uint64_t)(kFillBlock / 64) * kRingSlots * plan.ring_stride;                         // the waves' rings
-        if (need + need_rate(1, 1) <= budget) {
-            // what is left goes to: error-rate rows of the quality tables up to kLdsRateRowsFirst (a lane whose rate has no staged row
-            // repeats its draw in double precision), the base-call margin over the number of errors, the indel margin over the indel
-            // position, then more error-rate rows of both families
-            uint32_t rq = 1, rb = 1;
-            while (rq < std::min(rate_rows_q, kLdsRateRowsFirst) && need + need_rate(rq + 1, 1) <= budget) ++rq;
-            const bool stage_b2 = need + need_b2 + need_rate(rq, 1) <= budget;
-            if (stage_b2) need += need_b2;
-            const bool stage_i0 = need + need_i0 + need_rate(rq, 1) <= budget;
-            if (stage_i0) need += need_i0;
-            while (rb < std::min(rate_rows_b, kLdsRateRowsFirst) && need + need_rate(rq, rb + 1) <= budget) ++rb;
-            while (rq < rate_rows_q && need + need_rate(rq + 1, rb) <= budget) ++rq;
-            while (rb < rate_rows_b && need + need_rate(rq, rb + 1) <= budget) ++rb;
-            plan.rate_rows_q = rq;
-            plan.rate_rows_b = rb;
-            uint32_t end = plan.desc_words;
-            for (uint32_t seg = 0; seg < 2; ++seg) {
-                uint32_t at = plan.desc_words;
-                for (uint32_t i = 0; i < 4 * T; ++i) {
-                    DevTable &d = quality[seg * 4 * T + i];
-                    if (!d.k) continue;
-                    d.lds_off = at;
-                    at += (d.rows[0] + d.rows[1]) * plan.slot_q;
-                }
-                for (uint32_t i = 0; i < 20 * T; ++i) {
-                    DevTable &d = base_call[seg * 20 * T + i];
-                    if (!d.k) continue;
-                    d.lds_off = at;
-                    at += d.rows[0] * plan.slot_b;
-                    if (stage_b2) {
-                        d.lds_extra = at;
-                        at += d.rows[2] * plan.slot_b;
-                    }
-                }
-                end = std::max(end, at);
+        auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * Ti * rows_q * plan.slot_q + (uint64_t)20 * Ti * rows_b * plan.slot_b; };
+        const uint32_t ring_stride = 4 * Ti * plan.slot_q;
+        need += (uint64_t)(kFillBlock / 64) * kRingSlots * ring_stride;                              // the waves' rings
+        if (need + need_rate(1, 1) > budget) return false;
+        // what is left goes to: error-rate rows of the quality tables up to kLdsRateRowsFirst (a lane whose rate has no staged row
+        // repeats its draw in double precision), the base-call margin over the number of errors, the indel margin over the indel
+        // position, then more error-rate rows of both families
+        uint32_t rq = 1, rb = 1;
+        while (rq < std::min(rate_rows_q, kLdsRateRowsFirst) && need + need_rate(rq + 1, 1) <= budget) ++rq;
+        const bool stage_b2 = need + need_b2 + need_rate(rq, 1) <= budget;
+        if (stage_b2) need += need_b2;
+        const bool stage_i0 = need + need_i0 + need_rate(rq, 1) <= budget;
+        if (stage_i0) need += need_i0;
+        while (rb < std::min(rate_rows_b, kLdsRateRowsFirst) && need + need_rate(rq, rb + 1) <= budget) ++rb;
+        while (rq < rate_rows_q && need + need_rate(rq + 1, rb) <= budget) ++rq;
+        while (rb < rate_rows_b && need + need_rate(rq, rb + 1) <= budget) ++rb;
+        plan.img_tiles = Ti;
+        plan.par0_words = par0_words;
+        plan.par0_indel_bytes = par0_indel_bytes;
+        plan.desc_words = desc_words;
+        plan.ring_stride = ring_stride;
+        plan.rate_rows_q = rq;
+        plan.rate_rows_b = rb;
+        uint32_t end = desc_words;
+        for (uint32_t g = 0; g < n_img; ++g) {
+            uint32_t at = desc_words;
+            for (uint32_t i = 0; i < 4 * Ti; ++i) {
+                DevTable &d = quality[g * 4 * Ti + i];
+                if (!d.k) continue;
+                d.lds_off = at;
+                at += (d.rows[0] + d.rows[1]) * plan.slot_q;
             }
-            if (stage_i0)
-                for (DevTable &d : indels) {
-                    if (!d.k) continue;
-                    d.lds_off = end;
-                    end += d.rows[0] * plan.slot_i;
+            for (uint32_t i = 0; i < 20 * Ti; ++i) {
+                DevTable &d = base_call[g * 20 * Ti + i];
+                if (!d.k) continue;
+                d.lds_off = at;
+                at += d.rows[0] * plan.slot_b;
+                if (stage_b2) {
+                    d.lds_extra = at;
+                    at += d.rows[2] * plan.slot_b;
                 }
-            plan.ring_off = end;
-            plan.q3_off = plan.ring_off + (kFillBlock / 64) * kRingSlots * plan.ring_stride;
-            plan.b3_off = plan.q3_off + 4 * T * plan.rate_rows_q * plan.slot_q;
-            plan.total_words = plan.b3_off + 20 * T * plan.rate_rows_b * plan.slot_b;
-            plan.mask = plan.quads_q;
+            }
+            end = std::max(end, at);
         }
-    }
+        if (stage_i0)
+            for (DevTable &d : indels) {
+                if (!d.k) continue;
+                d.lds_off = end;
+                end += d.rows[0] * plan.slot_i;
+            }
+        plan.ring_off = end;
+        plan.q3_off = plan.ring_off + (kFillBlock / 64) * kRingSlots * plan.ring_stride;
+        plan.b3_off = plan.q3_off + 4 * Ti * plan.rate_rows_q * plan.slot_q;
+        plan.total_words = plan.b3_off + 20 * Ti * plan.rate_rows_b * plan.slot_b;
+        plan.mask = plan.quads_q;
+        return true;
+    };
+    plan.img_tiles = T;
+    if (screenable && opt.fill_mode != 0) {
+        const bool per_tile_first = opt.image_tiles == 1 && T > 1;
+        if (!(per_tile_first && plan_image(1)) && !plan_image(T) && !(T > 1 && plan_image(1)))
+            s.plan_note = "the read kernels' table image does not fit the " + std::to_string(kLdsBudgetBytes / 1024u) +
+                          " KiB of local memory even for one tile: every per-base draw runs in double precision from device memory (several times slower)";
+    } else if (!screenable && opt.fill_mode != 0)
+        s.plan_note = "the profile's tables are outside what the screened single-precision draws are built for (more than " + std::to_string(4u * kQualityQuads[4]) +
+                      " quality values, or more than 8 base-call / indel outcomes): every per-base draw runs in double precision from device memory (several times slower)";
     if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.ring_off | plan.ring_stride | plan.slot_q | plan.slot_b | plan.slot_i) & 3u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
-    if (const char *e = getenv("RSQ_TRACE_PLAN"))
-        if (atoi(e))
-            fprintf(stderr, "[rsq] LDS image: mask %u, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u, ring %u x %u, b2 %d i0 %d\n", plan.mask,
-                    plan.total_words, plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off, plan.ring_off,
-                    plan.ring_stride, (int)(!base_call.empty() && base_call[0].lds_extra != kNoLds), (int)(!indels.empty() && indels[0].lds_off != kNoLds));
+    if (opt.trace_plan)
+        fprintf(stderr, "[rsq] LDS image: mask %u, %u of %u tiles per image, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u, ring %u x %u, b2 %d i0 %d\n", plan.mask,
+                plan.img_tiles, T, plan.total_words, plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off, plan.ring_off,
+                plan.ring_stride, (int)(!base_call.empty() && base_call[0].lds_extra != kNoLds), (int)(!indels.empty() && indels[0].lds_off != kNoLds));
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);
@@ -344,8 +381,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
     s.dev.dom_error = up.put(dom_error);
     s.dev.error_rate = up.put(error_rate);
     s.dev.indels = up.put(indels);
-    par0.push_back(0);
-    par0.resize(std::max<size_t>(par0.size(), (size_t)plan.par0_words * 4), 0);      // whole words for the copy into the LDS image
+    par0.resize(((par0.size() + 3u) & ~(size_t)3u) + (size_t)plan.par0_words * 4u + 16u, 0);      // an image copies whole words, up to par0_words of them from a range's start
     pool.push_back(0.0);
     pool.push_back(0.0);
     pool32.resize(pool32.size() + 8, 0.f);
@@ -1227,9 +1263,8 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
 // kWindowChunks chunks, each entered with the state the fixed point left in front of its first chunk (entering_state(flat chunk index)),
 // so that the host pass over the variants has many independent tasks.
 constexpr uint32_t kWindowChunks = 32768;                          // 8.4 M positions
-inline uint32_t window_chunks() {                                  // RSQ_WINDOW_CHUNKS: smaller windows, so that tests on short sequences cut strands too
-    const char *e = getenv("RSQ_WINDOW_CHUNKS");
-    const int v = e ? atoi(e) : 0;
+inline uint32_t window_chunks() {                                  // option window_chunks: smaller windows, so that tests on short sequences cut strands too
+    const int64_t v = options().window_chunks;
     return v > 0 ? (uint32_t)v : kWindowChunks;
 }
 template <class EnteringState>

@@ -135,6 +135,7 @@ struct rsq_sim : SimState {
     DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
     DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
     DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
+    DevBuf bin_keys, bin_small, bin_perm;      // reads binned by tile: key per item; histogram, bins, units, cursors (one small buffer); the sorted items
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -221,7 +222,7 @@ constexpr uint64_t kBiasWindow = 512ull << 20;       // start positions per pass
 // partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each, BiasPlan::chunk_ptr) whose first start position lies in
 // the share [g_lo, g_hi) of the concatenated sequences; zero elsewhere
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
-    const bool trace = getenv("RSQ_TRACE_PREPARE") != nullptr;
+    const bool trace = options().trace_prepare != 0;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -248,7 +249,7 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     // behind its end and end positions a fragment length further.
     const uint64_t lo = std::min<uint64_t>(g_lo, s.total_ref_size), hi = std::min<uint64_t>(g_hi, s.total_ref_size);
     uint64_t window = kBiasWindow;
-    if (const char *e = getenv("RSQ_BIAS_WINDOW")) window = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    if (options().bias_window > 0) window = (uint64_t)options().bias_window;
     const uint64_t reach = (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to, track_len = std::min(hi - lo, window) + reach;
     d_start_bias.reserve(track_len * 8 + 16);
     d_end_bias.reserve(track_len * 8 + 16);
@@ -276,7 +277,7 @@ static void bias_normalization(rsq_sim &s, hipStream_t st) {
 
 static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
     HIP_CHECK(hipSetDevice(s.device));
-    const bool trace = getenv("RSQ_TRACE_PREPARE") != nullptr;      // stage times of the pre-pass on stderr
+    const bool trace = options().trace_prepare != 0;                // stage times of the pre-pass on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
         if (trace) fprintf(stderr, "prepare: %-28s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
@@ -349,39 +350,92 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0};
 }
 
+// Reads binned by tile (the LDS plan holds one tile per image): keys, histogram, the bins' places and units, the scatter.  n_keys = n_tiles (pairs:
+// both mates of a pair have the pair's tile) or 2 n_tiles (records); bins = (segment, tile).
+static bool fill_is_binned(const rsq_sim &s) { return effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) != 0 && s.dev.lds.img_tiles < s.dev.n_tiles; }
+template <class CountKernel>
+static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, hipStream_t st, CountKernel &&count_keys) {
+    if (n_items >= 0xFFFFFFFFull) throw Error("more than 2^32 reads in one call of a profile with tiles: use smaller block ranges");
+    const uint32_t n_bins = 2 * s.dev.n_tiles;
+    const int64_t unit_opt = options().unit_chunks;
+    const uint32_t unit_chunks = unit_opt > 0 ? (uint32_t)std::min<int64_t>(unit_opt, 1 << 20) : 4u * (kFillBlock / 64u);
+    s.bin_keys.reserve(n_items * 2 + 16);
+    s.bin_perm.reserve(n_items * 4 + 16);
+    // [hist n_keys][cursor n_keys][bin_first n_bins][bin_count n_bins][unit_ptr n_bins + 1][unit_counter 1]
+    const size_t words = 2 * (size_t)n_keys + 3 * (size_t)n_bins + 2;
+    s.bin_small.reserve(words * 4 + 16);
+    uint32_t *hist = s.bin_small.as<uint32_t>(), *cursor = hist + n_keys, *bin_first = cursor + n_keys, *bin_count = bin_first + n_bins, *unit_ptr = bin_count + n_bins,
+             *unit_counter = unit_ptr + n_bins + 1;
+    HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)n_keys * 4, st));
+    s.timers["bin_tiles"].start(st);
+    count_keys(s.bin_keys.as<uint16_t>(), hist);
+    hipLaunchKernelGGL(k_bins_plan, dim3(1), dim3(1024), 0, st, hist, n_keys, n_bins, unit_chunks, bin_first, bin_count, unit_ptr, cursor, unit_counter);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n_items, kBinBlock * kBinItemsPerThread)), dim3(kBinBlock), 0, st, s.bin_keys.as<uint16_t>(), n_items, n_keys, cursor,
+                       s.bin_perm.as<uint32_t>());
+    s.timers["bin_tiles"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    return FillBins{s.bin_perm.as<uint32_t>(), bin_first, bin_count, unit_ptr, unit_counter, n_bins, unit_chunks};
+}
+template <class Kernel>
+static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kernel kernel) {
+    const size_t lds_bytes = (screened ? (size_t)s.dev.lds.total_words * 4u : 0) + (binned ? kSchedWords * 4u : 0);
+    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    return lds_bytes;
+}
+// workgroups of a read kernel: persistent, one (or two, when two images fit) per CU, not more than there are rounds of chunks
+static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item) {
+    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
+    const uint64_t chunks = (n_items + 63) / 64;
+    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, segments_per_item * cdiv(chunks, kFillBlock / 64)));
+    return (blocks + 1u) & ~1u;                                     // segments alternate over blockIdx.x
+}
+
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK = quads per quality row (screened draws on the LDS image planned by
 // pack_tables) or 0 (double precision from HBM: the reference path the tests compare with)
-template <uint32_t MASK, bool VAR = false>
-static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
-    const LdsPlan &pl = s.dev.lds;
-    const size_t lds_bytes = MASK ? (size_t)pl.total_words * 4u : 0;
-    if (lds_bytes > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_reads<MASK, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
-    const uint64_t chunks = (n_pairs + 63) / 64;
-    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(chunks, kFillBlock / 64)));
-    blocks = (blocks + 1u) & ~1u;                                   // segments alternate over blockIdx.x
+template <uint32_t MASK, bool VAR, bool BINNED>
+static void launch_fill_kernel(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars) {
+    FillBins bins{};
+    if (BINNED)
+        bins = build_fill_bins(s, n_pairs, s.dev.n_tiles, st, [&](uint16_t *keys, uint32_t *hist) {
+            hipLaunchKernelGGL(k_pair_tiles, dim3(cdiv(n_pairs, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, frags, fvars, n_pairs, adapter_first, keys, hist);
+        });
+    const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_reads<MASK, VAR, BINNED>);
+    const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2);
     s.fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL((k_fill_reads<MASK, VAR>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
-                       s.fill_counters.as<uint32_t>(), fvars);
+    hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
+                       s.fill_counters.as<uint32_t>(), fvars, bins);
+    s.timers["fill_reads"].stop(st);
+    HIP_CHECK(hipGetLastError());
+}
+template <uint32_t MASK, bool VAR = false>
+static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
+    if constexpr (MASK != 0)
+        if (fill_is_binned(s)) return launch_fill_kernel<MASK, VAR, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
+    launch_fill_kernel<MASK, VAR, false>(s, frags, n_pairs, adapter_first, raw, st, fvars);
+}
+template <uint32_t MASK, bool BINNED>
+static void launch_records_kernel(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
+    FillBins bins{};
+    if (BINNED)
+        bins = build_fill_bins(s, n, 2 * s.dev.n_tiles, st, [&](uint16_t *keys, uint32_t *hist) {
+            hipLaunchKernelGGL(k_record_tiles, dim3(cdiv(n, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, seg_dev, job.first_index, n, keys, hist);
+        });
+    const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED>);
+    const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1);
+    s.fill_counters.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
+    s.timers["fill_reads"].start(st);
+    hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
 template <uint32_t MASK>
-static void launch_records_mask(rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st) {
-    const size_t lds_bytes = MASK ? (size_t)s.dev.lds.total_words * 4u : 0;
-    if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_records<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;
-    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, 2 * cdiv(cdiv(n, 64), kFillBlock / 64)));
-    blocks = (blocks + 1u) & ~1u;
-    s.fill_counters.reserve(8);
-    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
-    s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL(k_fill_records<MASK>, dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.fill_counters.as<uint32_t>());
-    s.timers["fill_reads"].stop(st);
-    HIP_CHECK(hipGetLastError());
+static void launch_records_mask(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
+    if constexpr (MASK != 0)
+        if (fill_is_binned(s)) return launch_records_kernel<MASK, true>(s, job, seg_dev, n, raw, st);
+    launch_records_kernel<MASK, false>(s, job, seg_dev, n, raw, st);
 }
 static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
                               const FragmentVar *fvars = nullptr) {
@@ -403,12 +457,12 @@ static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pair
 #undef RSQ_FILL_CASE
     throw Error("no k_fill_reads instantiation for " + std::to_string(mask) + " quads");
 }
-static void launch_fill_records(rsq_sim &s, const RecordJob &job, uint64_t n, const RawLayout &raw, hipStream_t st) {
+static void launch_fill_records(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     const uint32_t mask = effective_fill_mask(s.dev.lds.mask, s.force_fill_mode);
-#define RSQ_REC_CASE(Q)                                 \
-    if (mask == Q) {                                    \
-        launch_records_mask<Q>(s, job, n, raw, st);     \
-        return;                                         \
+#define RSQ_REC_CASE(Q)                                          \
+    if (mask == Q) {                                             \
+        launch_records_mask<Q>(s, job, seg_dev, n, raw, st);     \
+        return;                                                  \
     }
     RSQ_REC_CASE(0u)
     RSQ_REC_CASE(kQualityQuads[0])
@@ -684,6 +738,18 @@ extern "C" {
 const char *rsq_last_error(void) { return g_last_error.c_str(); }
 const char *rsq_last_warning(void) { return g_last_warning.c_str(); }
 const char *rsq_version(void) { return "reseq_amd 0.1 (gfx950)"; }
+int rsq_set_option(const char *name, int64_t value) {
+    REQUIRE(name, "null argument");
+    if (set_option(name, value)) return RSQ_OK;
+    g_last_error = std::string("unknown option '") + name + "' (options: " + option_names() + ")";
+    return RSQ_EINVAL;
+}
+int rsq_get_option(const char *name, int64_t *value) {
+    REQUIRE(name && value, "null argument");
+    if (get_option(name, value)) return RSQ_OK;
+    g_last_error = std::string("unknown option '") + name + "' (options: " + option_names() + ")";
+    return RSQ_EINVAL;
+}
 
 int rsq_device_count(void) {
     int n = 0;
@@ -878,9 +944,10 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 8 * sizeof(uint64_t), hipHostMallocDefault));
-        if (const char *m = getenv("RSQ_FILL_MODE")) s->force_fill_mode = atoi(m);
+        s->force_fill_mode = (int)options().fill_mode;
         s->prof = p->p;
         pack_tables(*s, s->up);
+        g_last_warning = s->plan_note;
         pack_profile(*s, s->up);
         if (ref) pack_reference(*s, s->up, ref->r, ref->has_variants ? &ref->variants : nullptr);
         return RSQ_OK;
@@ -1000,6 +1067,13 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
     });
 }
 
+int rsq_sim_get_fill_plan(const rsq_sim *s, uint32_t *quality_quads, uint32_t *image_tiles, uint32_t *image_bytes) {
+    REQUIRE(s && quality_quads && image_tiles && image_bytes, "null argument");
+    *quality_quads = effective_fill_mask(s->dev.lds.mask, s->force_fill_mode);
+    *image_tiles = *quality_quads ? s->dev.lds.img_tiles : 0u;
+    *image_bytes = *quality_quads ? s->dev.lds.total_words * 4u : 0u;
+    return RSQ_OK;
+}
 int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out) {
     REQUIRE(s && out && (s->prepared || s->planned), "simulator not prepared");      // the counts are known from rsq_sim_prepare_plan on
     out->total_pairs = s->total_pairs;
@@ -1112,18 +1186,20 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
     if (need_ops > s->ops_stride) s->ops_stride = need_ops;
     if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
     RawLayout raw = raw_layout(*s, n);
-    // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS
-    s->rec_flags.reserve(n * 4 + 16);
-    s->rec_index.reserve(n * 4 + 16);
-    s->rec_count.reserve(8);
-    s->offsets.reserve((n + 1) * 8);
-    const dim3 rgrid(cdiv(n, 256)), rblock(256);
-    hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
-    exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
-    hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
-    HIP_CHECK(hipGetLastError());
+    // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS (binned by tile: build_fill_bins)
+    if (!fill_is_binned(*s)) {
+        s->rec_flags.reserve(n * 4 + 16);
+        s->rec_index.reserve(n * 4 + 16);
+        s->rec_count.reserve(8);
+        s->offsets.reserve((n + 1) * 8);
+        const dim3 rgrid(cdiv(n, 256)), rblock(256);
+        hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
+        exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
+        hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
+        HIP_CHECK(hipGetLastError());
+    }
     const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>(), n};
-    launch_fill_records(*s, job, n, raw, st);
+    launch_fill_records(*s, job, seg_dev, n, raw, st);
     return raw;
 }
 

@@ -48,6 +48,7 @@ struct DevTable {
     uint32_t sure_range;
 };
 static_assert(sizeof(DevTable) == 80, "descriptor layout");
+static_assert(__builtin_offsetof(DevTable, par0_off) == 4, "lds_stage_descriptors rewrites word 1 of a descriptor");
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 // A double-precision draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
 #ifndef RSQ_CHUNK_LARGE
@@ -76,21 +77,25 @@ constexpr uint32_t kQualityQuads[] = {3, 6, 10, 11, 12};
 constexpr uint32_t kChainQuads[] = {8, 16, 26};
 constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)
 
-// LDS image of k_fill_reads, one per template segment (rsq_kernels.h "LDS staging"), built once per workgroup, in single precision:
-// the table descriptors of the segment and of the indel tables, the outcome values, margins 0+1 of the segment's quality tables
+// LDS image of k_fill_reads (rsq_kernels.h "LDS staging"), in single precision: one per template segment holding the tables of all tiles
+// (img_tiles == n_tiles; built once per workgroup) or, when those do not fit, one per (segment, tile) (img_tiles == 1; a workgroup builds the
+// image of the tile whose reads it is about to serve).  Contents:
+// the table descriptors of the image's tiles and of the indel tables, their outcome values, margins 0+1 of the quality tables
 // (sequence quality, previous quality), margin 0 of its base-call tables (quality), the first rows of the error-rate margins
 // (quality margin 3, base-call margin 3), and as far as the 160 KiB reach margin 0 of the indel tables and margin 2 of the base-call
 // tables (number of errors).  Offsets and sizes in 32-bit words.
 struct LdsPlan {
     uint32_t mask;               // the read kernel's template argument: quads_q when the image exists and the kernel draws screened; 0: double
                                  // precision from HBM only
-    uint32_t desc_words;         // size of the descriptor area: the descriptors, then the outcome-value pool (par0)
-    uint32_t par0_words;         // size of the outcome-value pool in the image
+    uint32_t img_tiles;          // tiles per image: n_tiles, or 1 (reads binned by tile, one tile per workgroup)
+    uint32_t desc_words;         // size of the descriptor area: the descriptors, then the outcome values (par0) of the image's tables
+    uint32_t par0_words;         // size of the outcome-value area in the image: the indel tables' values (par0_indel_bytes, from byte 0 of the pool), then
+    uint32_t par0_indel_bytes;   // those of the image's tiles (contiguous in the pool from the first quality table's par0_off on)
     uint32_t slot_q, slot_b, slot_i;        // row slot (floats) of the quality / base-call / indel family
     uint32_t quads_q;            // 16-byte groups of a quality row that hold columns: one of kQualityQuads
     uint32_t rate_rows_q, rate_rows_b;      // rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
-    uint32_t q3_off, b3_off;     // [4T][rate_rows_q] quality slots, [20T][rate_rows_b] base-call slots
-    uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4T quality slots], the quality rows over the read position of the wave's current steps
+    uint32_t q3_off, b3_off;     // [4 img_tiles][rate_rows_q] quality slots, [20 img_tiles][rate_rows_b] base-call slots
+    uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4 img_tiles quality slots], the quality rows over the read position of the wave's current steps
     uint32_t total_words;        // size of the image
 };
 

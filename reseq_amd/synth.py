@@ -244,6 +244,13 @@ P0 = dict(
     dispersion=(0.04, 0.3), sur_sigma=0.12, corrected_coverage=30.0,
 )
 
+def p0_with_tiles(n_tiles):
+    """P0 with `n_tiles` tiles of unequal abundance (reseq illuminaPE --tiles, main.cpp:277-283: per-tile tables,
+    ProbabilityEstimates.h:1497-1514); HiSeq numbering: surface, swath, tile"""
+    tiles = [1101 + (i % 16) + 100 * ((i // 16) % 3) + 1000 * (i // 48) for i in range(n_tiles)]
+    return dict(P0, name=f"P0t{n_tiles}", tiles=tiles, tile_abundance=[1 + (i * 5) % 7 for i in range(n_tiles)])
+
+
 TINY = dict(
     name="TINY", read_len_max=30, read_len_var=True,
     qual_from=2, qual_to=12, phred_offset=33,

@@ -37,6 +37,9 @@ def emu_lib():
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
+        L.emu_set_option.argtypes = [C.c_char_p, C.c_longlong]
+        L.emu_image_tiles.argtypes = [C.c_void_p]
+        L.emu_plan_mask.argtypes = [C.c_void_p]
         L.emu_prepare.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
         L.emu_prepare_plan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]
         L.emu_bias_partials_size.restype = C.c_uint64
@@ -74,6 +77,13 @@ def _ok(rc):
         raise RuntimeError(emu_lib().emu_last_error().decode())
 
 
+def set_option_everywhere(name, value):
+    """rsq_set_option of the product library (host-side call: works without a GPU) and its twin in the host emulation"""
+    api.set_option(name, value)
+    if emu_lib().emu_set_option(name.encode(), int(value)) != 0:
+        raise KeyError(name)
+
+
 class EmuBackend:
     name = "hostemu"
 
@@ -86,7 +96,11 @@ class EmuBackend:
                               (str(vcf_path) if vcf_path else "").encode(), C.byref(self.h)))
         if edits:
             _ok(self.L.emu_edit_profile(self.h, edits.get("error_multiplier", 1.0), int(edits.get("no_substitutions", False)), int(edits.get("no_indels", False))))
-        self.L.emu_set_fill_mode(self.h, self.fill_mode)
+        if self.fill_mode != -1:
+            self.L.emu_set_fill_mode(self.h, self.fill_mode)
+
+    def fill_plan(self):
+        return {"mask": self.L.emu_plan_mask(self.h), "image_tiles": self.L.emu_image_tiles(self.h)}
 
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
         _ok(self.L.emu_prepare(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))
@@ -236,6 +250,9 @@ class GpuBackend:
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
         self.sim.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
         return self.info()
+
+    def fill_plan(self):
+        return self.sim.fill_plan()
 
     def info(self):
         i = self.sim.info()

@@ -62,3 +62,22 @@ def p0_profile_path(workdir):
     path = workdir / "p0.rsqp"
     synth.write_profile(path, synth.make_profile(synth.P0, seed=103741084))
     return str(path)
+
+
+OPTION_DEFAULTS = {"fill_mode": -1, "overlap": -1}          # every other option: 0
+
+
+@pytest.fixture
+def rsq_options():
+    """set(name, value): an option of the product library and of the host emulation (rsq_set_option; reseq_amd/csrc/rsq_host.h Options),
+    back to its default when the test ends"""
+    from backends import set_option_everywhere
+    changed = []
+
+    def set_(name, value):
+        set_option_everywhere(name, value)
+        changed.append(name)
+
+    yield set_
+    for name in changed:
+        set_option_everywhere(name, OPTION_DEFAULTS.get(name, 0))

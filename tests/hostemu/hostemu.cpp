@@ -11,6 +11,7 @@ static uint64_t g_screen_stats[4][2];          // quality, base call, indel: dra
 #define RSQ_SCREEN_STATS g_screen_stats
 #include <stdlib.h>
 
+#include <map>
 #include <memory>
 #include <utility>
 
@@ -58,16 +59,18 @@ struct Emu : SimState {
     ChainRun chain_run;
     std::vector<FragmentVar> fvars;             // of the last emu_sieve call (variants of any kind), parallel to its fragments
     int fill_mode = -1;                         // -1: screened draws on the LDS image when the plan has one (as the product does); 0: double precision only
-    std::vector<float> lds[2];                  // host stand-in for the LDS image of each template segment
+    std::map<uint32_t, std::vector<float>> lds; // host stand-in for the LDS images, by image_qbase: one per template segment, or per (segment, tile)
     uint32_t mask() const { return effective_fill_mask(dev.lds.mask, fill_mode); }
-    void build_lds() {                          // what a workgroup of k_fill_reads does before its first read
-        for (uint32_t seg = 0; seg < 2; ++seg) {
-            lds[seg].assign(dev.lds.total_words + 16, 0.f);
-            if (mask()) {
-                lds_stage_descriptors(dev, lds[seg].data(), seg, 0, 1);
-                lds_stage_rows(dev, lds[seg].data(), 0, 1);
-            }
+    void build_lds() { lds.clear(); }           // images are built when a read first asks for them
+    float *image(uint32_t seg, uint32_t tile) { // what a workgroup of k_fill_reads does before it serves reads of (seg, tile)
+        const uint32_t qbase = image_qbase(dev, seg, dev.lds.img_tiles < dev.n_tiles ? tile : 0u);
+        std::vector<float> &img = lds[qbase];
+        if (img.empty()) {
+            img.assign(dev.lds.total_words + 16, 0.f);
+            lds_stage_descriptors(dev, img.data(), qbase, 0, 1);
+            lds_stage_rows(dev, img.data(), 0, 1);
         }
+        return img.data();
     }
 };
 
@@ -80,8 +83,8 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
         auto run = [&](auto tag) {                            // what a lane of k_fill_reads<M> does; the position ring holds the step's rows
             constexpr uint32_t M = decltype(tag)::value;
             if (s.mask() != M) return;
-            float *img = s.lds[seg].data(), *ring = img + s.dev.lds.ring_off;      // the ring of wave 0
-            ScreenTables<M> tab{s.dev, img, seg, ring, 0u};
+            float *img = s.image(seg, tile), *ring = img + s.dev.lds.ring_off;      // the ring of wave 0
+            ScreenTables<M> tab{s.dev, img, image_qbase(s.dev, seg, s.dev.lds.img_tiles < s.dev.n_tiles ? tile : 0u), ring, 0u};
             ReadMachine m;
             m.init(s.dev, tab, st, seg, tile, frag_len, src);
             for (;;) {
@@ -225,6 +228,7 @@ const char *emu_last_error() { return g_err.c_str(); }
 int emu_create(const char *profile_path, const char *fasta_path, uint64_t replace_n_seed, const char *vcf_path, void **out) {
     return guard([&] {
         std::unique_ptr<Emu> s(new Emu());
+        s->fill_mode = (int)options().fill_mode;                    // as rsq_sim_create
         s->prof = Profile::load(profile_path);
         pack_tables(*s, s->up);
         pack_profile(*s, s->up);
@@ -259,6 +263,9 @@ void emu_screen_stats(uint64_t *out) {
     memset(g_screen_stats, 0, sizeof g_screen_stats);
 }
 void emu_set_fill_mode(void *h, int mode) { static_cast<Emu *>(h)->fill_mode = mode; }
+int emu_set_option(const char *name, long long value) { return set_option(name, value) ? 0 : -1; }       // rsq_set_option
+int emu_image_tiles(void *h) { return (int)static_cast<Emu *>(h)->dev.lds.img_tiles; }
+int emu_plan_mask(void *h) { return (int)static_cast<Emu *>(h)->dev.lds.mask; }
 
 int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int ref_bias_mode, const char *base_identifier) {
     Emu &s = *static_cast<Emu *>(h);

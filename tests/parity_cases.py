@@ -267,6 +267,34 @@ def case_p0_reads(backend_cls, workdir):
         p.close()
 
 
+def case_p0_tiles(backend_cls, workdir, n_tiles, num_pairs=1500, expect_image_tiles=1):
+    """P0 with several tiles: their tables do not fit one 160 KiB image, so the read kernels serve one tile per workgroup (reads binned by the
+    tile they draw); fragments, read ids (the tile is part of them) and FASTQ text equal the oracle's, for pairs, adapter-only pairs and
+    seqToIllumina records"""
+    cfg = synth.p0_with_tiles(n_tiles)
+    tag = f"p0_tiles{n_tiles}"
+    p = Pair(backend_cls, workdir, tag, cfg, [30000], seed=11, num_pairs=num_pairs, prof_seed=21, ref_seed=2)
+    try:
+        plan = p.b.fill_plan()
+        assert plan["mask"] != 0, plan                          # screened draws, not the double-precision route
+        if expect_image_tiles is not None:
+            assert plan["image_tiles"] == expect_image_tiles, plan
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert 0.6 * num_pairs < n < 1.4 * num_pairs
+        tiles_seen = {l.split(b":")[4] for l in text.split(b"\n")[0::4] if l}
+        assert len(tiles_seen) >= min(n_tiles, 3) and tiles_seen <= {b"%d" % t for t in cfg["tiles"]}
+        # the same in two calls: the bins of a call depend on the call's pairs only
+        half = 1 + p.info["total_blocks"] // 2
+        f1, a1, a2 = p.b.pairs(1, half)
+        f2, b1, b2 = p.b.pairs(half, p.info["total_blocks"] + 1)
+        assert a1 + b1 == text
+    finally:
+        p.close()
+    exp = _error_model(backend_cls, workdir, tag, cfg, 600, 150, seed=99, prof_seed=21, zero_frac=0.9)
+    assert len({e[4] for e in exp}) >= min(n_tiles, 3)
+
+
 def case_indel_columns_shuffled(backend_cls, workdir):
     """the indel draw decided by the random word alone (DevTable::sure_range) when "no indel" is a middle column of its tables and one
     insertion is frequent: the range has a lower and an upper end"""

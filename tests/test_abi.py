@@ -104,7 +104,7 @@ def test_gzip_fasta_loads_like_plain(workdir):
     b.close()
 
 
-def test_mapped_fasta_reader_reads_what_the_line_reader_reads(workdir, monkeypatch):
+def test_mapped_fasta_reader_reads_what_the_line_reader_reads(workdir, rsq_options):
     """large plain FASTA files are memory-mapped and converted by several threads in stretches (rsq_host.cpp read_fasta_mapped); here the
     stretches are a few bytes, so that headers, line ends, "\\r\\n", blanks and '>' inside a line fall on stretch borders"""
     rng = np.random.default_rng(3)
@@ -130,30 +130,30 @@ def test_mapped_fasta_reader_reads_what_the_line_reader_reads(workdir, monkeypat
     for i, text in enumerate(texts):
         path = workdir / f"tricky{i}.fa"
         path.write_bytes(text.encode())
-        monkeypatch.setenv("RSQ_SERIAL_FASTA", "1")
+        rsq_options("serial_fasta", 1)
         a = api.Reference(str(path))
-        monkeypatch.delenv("RSQ_SERIAL_FASTA")
+        rsq_options("serial_fasta", 0)
         for stretch in (1, 7, 64, 1 << 20):
-            monkeypatch.setenv("RSQ_FASTA_STRETCH", str(stretch))
+            rsq_options("fasta_stretch", stretch)
             b = api.Reference(str(path))
             assert a.num_sequences() == b.num_sequences(), (i, stretch)
             for k in range(a.num_sequences()):
                 assert a.sequence_name(k) == b.sequence_name(k), (i, stretch, k)
                 assert np.array_equal(a.codes(k), b.codes(k)), (i, stretch, k)
             b.close()
-        monkeypatch.delenv("RSQ_FASTA_STRETCH")
+        rsq_options("fasta_stretch", 0)
         a.close()
     # text before the first header: refused by both readers
     bad = workdir / "bad.fa"
     bad.write_bytes(b"ACGT\n>s\nACGT\n")
-    for env in ({"RSQ_SERIAL_FASTA": "1"}, {"RSQ_FASTA_STRETCH": "5"}):
+    for env in ({"serial_fasta": 1}, {"fasta_stretch": 5}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            rsq_options(k, v)
         with pytest.raises(api.RsqError) as e:
             api.Reference(str(bad))
         assert "FASTA header" in str(e.value)
         for k in env:
-            monkeypatch.delenv(k)
+            rsq_options(k, 0)
 
 
 def test_bzip2_fasta_in_and_out(workdir):

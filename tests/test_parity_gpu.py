@@ -74,20 +74,40 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(GpuBackend, workdir)
 
 
+@pytest.mark.parametrize("n_tiles", [3, 96])
+def test_p0_with_tiles(workdir, n_tiles):
+    """--tiles profiles: one tile's tables per workgroup image, reads binned by tile (k_fill_reads<MASK, VAR, true>, k_fill_records<MASK, true>)"""
+    P.case_p0_tiles(GpuBackend, workdir, n_tiles, num_pairs=1500 if n_tiles == 3 else 6000)
+
+
+def test_tiles_binned_although_they_fit(workdir, rsq_options):
+    """TINY's three tiles fit one image; option image_tiles = 1 bins them all the same: the scheduler (work units, re-staged images, short
+    last units) on profiles with adapters, variable read lengths and indels; unit_chunks = 1: a unit per chunk of 64 reads"""
+    rsq_options("image_tiles", 1)
+    for unit in (0, 1):
+        rsq_options("unit_chunks", unit)
+        P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+        P.case_dense_coverage(GpuBackend, workdir)
+        P.case_adapter_only(GpuBackend, workdir)
+        P.case_error_model_tiny(GpuBackend, workdir)
+        P.case_variants_indels(GpuBackend, workdir)
+        P.case_methylation(GpuBackend, workdir)
+
+
 @pytest.mark.parametrize("mode", [0])
-def test_double_precision_path(workdir, mode, monkeypatch):
+def test_double_precision_path(workdir, mode, rsq_options):
     """k_fill_reads<0>: every draw in double precision from HBM, the reference's recipe itself; the default of the other tests is the
     screened path (single-precision draws on the LDS image, double precision only where the screen cannot decide)"""
-    monkeypatch.setenv("RSQ_FILL_MODE", str(mode))
+    rsq_options("fill_mode", mode)
     P.case_sieve_and_reads_tiny(GpuBackend, workdir)
     P.case_p0_reads(GpuBackend, workdir)
 
 
 @pytest.mark.gpu
-def test_every_draw_through_the_route_behind_the_screen(workdir, monkeypatch):
-    """RSQ_FORCE_EXACT: the screen decides nothing, so every draw of the read kernel (and of seqToIllumina's) takes the route of an undecided one,
+def test_every_draw_through_the_route_behind_the_screen(workdir, rsq_options):
+    """option force_exact: the screen decides nothing, so every draw of the read kernel (and of seqToIllumina's) takes the route of an undecided one,
     the call of the double-precision recipe (exact_draw_call)"""
-    monkeypatch.setenv("RSQ_FORCE_EXACT", "1")
+    rsq_options("force_exact", 1)
     P.case_sieve_and_reads_tiny(GpuBackend, workdir)
     P.case_p0_reads(GpuBackend, workdir)
     P.case_indel_columns_shuffled(GpuBackend, workdir)
@@ -96,9 +116,9 @@ def test_every_draw_through_the_route_behind_the_screen(workdir, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
+def test_error_rate_rows_fall_back_to_hbm(workdir, rsq_options):
     """only row 0 of the error-rate margins staged: every position with a systematic error rate takes the HBM branch"""
-    monkeypatch.setenv("RSQ_RATE_ROWS", "1")
+    rsq_options("rate_rows", 1)
     P.case_sieve_and_reads_tiny(GpuBackend, workdir)
     P.case_p0_reads(GpuBackend, workdir)
 
@@ -115,7 +135,7 @@ def test_ref_bias_modes(workdir):
     P.case_ref_bias_modes(GpuBackend, workdir)
 
 
-def test_bias_sums_in_windows_are_the_sums_at_once(workdir, monkeypatch):
+def test_bias_sums_in_windows_are_the_sums_at_once(workdir, rsq_options):
     """the bias sums run over the reference in windows whose surrounding tracks reuse two buffers (rsq_sim.hip bias_partials); a chunk's sum does
     not depend on the window it is computed in: windows of 700 positions (several per sequence, borders inside chunks' reach) give the same
     doubles as one window, also for a share of a sharded pre-pass"""
@@ -125,9 +145,8 @@ def test_bias_sums_in_windows_are_the_sums_at_once(workdir, monkeypatch):
     lengths = [5200, 90, 3100, 2048]
     ppath, fpath, _ = make_inputs(workdir, "biaswin", synth.TINY, lengths)
     got = []
-    for window in (None, "700", "64"):
-        if window:
-            monkeypatch.setenv("RSQ_BIAS_WINDOW", window)
+    for window in (0, 700, 64):
+        rsq_options("bias_window", window)
         b = GpuBackend(ppath, fpath)
         info = b.prepare(5, num_pairs=3000)
         thr = np.array(b.thresholds())
@@ -137,8 +156,6 @@ def test_bias_sums_in_windows_are_the_sums_at_once(workdir, monkeypatch):
         sums, maxes = b.bias_partials(5, b.info()["total_blocks"] + 1)        # from block 5 of the first sequence on: the chunks of the later sequences
         b.close()
         got.append((info["bias_normalization"], thr, np.array(sums), np.array(maxes)))
-        if window:
-            monkeypatch.delenv("RSQ_BIAS_WINDOW")
     for norm, thr, sums, maxes in got[1:]:
         assert norm == got[0][0]
         assert np.array_equal(thr, got[0][1])
@@ -320,10 +337,10 @@ def test_variants_crowding_the_sequence_ends(workdir):
     P.case_variants_indels(GpuBackend, workdir, density=30, seed=78, tag="ends78", lengths=(3300, 2100), ends=45)
 
 
-def test_variants_systematic_errors_in_strand_windows(workdir, monkeypatch):
+def test_variants_systematic_errors_in_strand_windows(workdir, rsq_options):
     """the host pass over the variants' systematic errors cuts long strands into windows that start from the chain's state in front of them
     (8.4 M positions each; here two chunks of 256, so that these short sequences are cut as well)"""
-    monkeypatch.setenv("RSQ_WINDOW_CHUNKS", "2")
+    rsq_options("window_chunks", 2)
     P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="windows", lengths=(5300, 2600), samples=2)
 
 
@@ -353,10 +370,10 @@ def test_variants_more_alleles_than_the_reference_supports_are_refused(workdir):
     P.case_variants_rejected(GpuBackend, workdir)
 
 
-def test_variants_every_staging_mode(workdir, monkeypatch):
+def test_variants_every_staging_mode(workdir, rsq_options):
     """the two instantiations of the read kernel with variants: every table from HBM (mode 0) and every table staged"""
-    for mode in ("0", "23"):
-        monkeypatch.setenv("RSQ_FILL_MODE", mode)
+    for mode in (0, -1):
+        rsq_options("fill_mode", mode)
         P.case_variants_substitutions(GpuBackend, workdir)
         P.case_variants_indels(GpuBackend, workdir)
 

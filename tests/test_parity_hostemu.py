@@ -92,8 +92,8 @@ def test_p0_reads(workdir):
     P.case_p0_reads(EmuBackend, workdir)
 
 
-def test_every_draw_through_the_route_behind_the_screen(workdir, monkeypatch):
-    monkeypatch.setenv("RSQ_FORCE_EXACT", "1")
+def test_every_draw_through_the_route_behind_the_screen(workdir, rsq_options):
+    rsq_options("force_exact", 1)
     P.case_p0_reads(EmuBackend, workdir)
 
 
@@ -125,6 +125,20 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(EmuBackend, workdir)
 
 
+def test_p0_with_tiles(workdir):
+    """--tiles profiles: the LDS plan holds one tile per image (lds_stage_descriptors / ScreenTables with a tile's image_qbase)"""
+    P.case_p0_tiles(EmuBackend, workdir, 3, num_pairs=700)
+
+
+def test_tiles_binned_although_they_fit(workdir, rsq_options):
+    rsq_options("image_tiles", 1)
+    b = EmuBackend(str(P.make_inputs(workdir, "tiny_e2e", P.synth.TINY, [5000, 80, 3210])[0]))
+    assert b.fill_plan() == {"mask": 3, "image_tiles": 1}
+    b.close()
+    P.case_sieve_and_reads_tiny(EmuBackend, workdir)
+    P.case_error_model_tiny(EmuBackend, workdir)
+
+
 @pytest.mark.parametrize("mode", [0])
 def test_double_precision_path(workdir, mode):
     """k_fill_reads<0>: every draw in double precision from HBM, the reference's recipe itself; the default of the other tests is the
@@ -135,9 +149,9 @@ def test_double_precision_path(workdir, mode):
     P.case_p0_reads(Capped, workdir)
 
 
-def test_error_rate_rows_fall_back_to_hbm(workdir, monkeypatch):
+def test_error_rate_rows_fall_back_to_hbm(workdir, rsq_options):
     """only row 0 of the error-rate margins staged: every position with a systematic error rate takes the HBM branch"""
-    monkeypatch.setenv("RSQ_RATE_ROWS", "1")
+    rsq_options("rate_rows", 1)
     P.case_sieve_and_reads_tiny(EmuBackend, workdir)
     P.case_p0_reads(EmuBackend, workdir)
 
@@ -188,10 +202,10 @@ def test_variants_crowding_the_sequence_ends(workdir):
     P.case_variants_indels(EmuBackend, workdir, density=30, seed=78, tag="ends78", lengths=(3300, 2100), ends=45)
 
 
-def test_variants_systematic_errors_in_strand_windows(workdir, monkeypatch):
+def test_variants_systematic_errors_in_strand_windows(workdir, rsq_options):
     """the host pass over the variants' systematic errors cuts long strands into windows that start from the chain's state in front of them
     (8.4 M positions each; here two chunks of 256, so that these short sequences are cut as well)"""
-    monkeypatch.setenv("RSQ_WINDOW_CHUNKS", "2")
+    rsq_options("window_chunks", 2)
     P.case_variants_indels(EmuBackend, workdir, density=9, seed=47, tag="windows", lengths=(5300, 2600), samples=2)
 
 
