@@ -223,9 +223,6 @@ def main():
 
     if args.lib:
         api.use_library(args.lib)
-    for item in args.option:
-        name, value = item.split("=", 1)
-        api.set_option(name, int(value))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,6 +251,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    for item in args.option:                      # after torch: the library binds to the HIP runtime torch has loaded
+        name, value = item.split("=", 1)
+        api.set_option(name, int(value))
     prof = api.Profile(ppath)
     ref = api.Reference(fpath, args.seed)
     sim = api.Simulator(prof, ref, local_rank)
@@ -305,8 +305,10 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
     plan = sim.fill_plan()
-    if plan["image_tiles"] and plan["image_tiles"] < args.tiles:
-        kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")
+    try:
+        kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")          # only when the read kernel runs binned by tile
+    except api.RsqError:
+        pass
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
 
     # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1

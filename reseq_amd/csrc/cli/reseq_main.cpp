@@ -864,7 +864,8 @@ const char *kUsage =
     "Commands:\n"
     "  illuminaPE\t\tsimulates illumina paired-end data from a fitted profile (-s) and a reference (-R)\n"
     "  seqToIllumina\t\tapplies illumina quality and error model to input sequences (alias: replaceQuals)\n"
-    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h\n";
+    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h,\n"
+    "         --rsqOption name:value[,...] (measurement switches of libreseq_amd, include/reseq_amd.h rsq_set_option; results never depend on them)\n";
 
 }  // namespace
 
@@ -978,6 +979,16 @@ int main(int argc, char **argv) {
     Args a;
     if (!parse((int)rest.size(), rest.data(), 1, a)) return 1;
     if (a.has("verbosity")) g_verbosity = atoi(a.get("verbosity").c_str());
+    if (a.has("rsqOption")) {                                 // measurement switches of the library (rsq_set_option): name:value[,name:value...]
+        std::stringstream list(a.get("rsqOption"));
+        std::string item;
+        while (std::getline(list, item, ',')) {
+            const size_t colon = item.find(':');
+            char *end = nullptr;
+            const long long v = colon == std::string::npos ? 1 : strtoll(item.c_str() + colon + 1, &end, 10);
+            if ((end && *end) || !check(rsq_set_option(item.substr(0, colon).c_str(), v), "--rsqOption")) return 1;
+        }
+    }
     if (a.has("version")) {
         std::cerr << rsq_version() << " (stands in for ReSeq version 1.1 simulation stage)" << std::endl;
         return 0;

@@ -37,7 +37,7 @@ struct OptionEntry {
 const OptionEntry kOptionTable[] = {
     {"fill_mode", &Options::fill_mode},         {"image_tiles", &Options::image_tiles},     {"rate_rows", &Options::rate_rows},
     {"no_indel_skip", &Options::no_indel_skip}, {"force_exact", &Options::force_exact},     {"min_quality_quads", &Options::min_quality_quads},
-    {"unit_chunks", &Options::unit_chunks},     {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
+    {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
     {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},
     {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap},
 };

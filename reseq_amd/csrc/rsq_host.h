@@ -25,7 +25,6 @@ struct Options {
     int64_t no_indel_skip = 0;         // 1: no indel draw decided by the random word alone
     int64_t force_exact = 0;           // 1: the screen decides nothing, every draw takes the double-precision route behind it
     int64_t min_quality_quads = 0;     // a wider instantiation of the read kernels than the profile's quality values need
-    int64_t unit_chunks = 0;           // > 0: chunks of 64 reads per work unit of the per-tile read kernel
     int64_t trace_plan = 0;            // 1: the LDS plan on stderr
     int64_t trace_prepare = 0;         // 1: stage times of the pre-pass on stderr
     int64_t bias_window = 0;           // > 0: start positions per pass of the bias sums

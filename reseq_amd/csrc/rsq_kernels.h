@@ -1117,6 +1117,8 @@ struct RawLayout {                      // word-major arrays of the read kernel,
     uint64_t pitch;                     // reads per word row (>= number of reads)
     uint64_t *templates;                // --methylation: [reads][template_words] converted templates, else nullptr
     uint32_t template_words;
+    const uint32_t *order;              // seqToIllumina, after a read kernel that ran binned by tile: row r holds record order[r]; nullptr: record r
+    RSQ_HD uint64_t item_of(uint64_t row) const { return order ? order[row] : row; }
     RSQ_HD WordColumn seq_of(uint64_t r) const { return WordColumn{seq + r, pitch}; }
     RSQ_HD WordColumn qual_of(uint64_t r) const { return WordColumn{qual + r, pitch}; }
     RSQ_HD WordColumn ops_of(uint64_t r) const { return WordColumn{ops + r, pitch}; }
@@ -1919,18 +1921,22 @@ RSQ_HD RecordSrc record_src(const uint8_t *seqs, const uint8_t *dom, const uint8
 #endif
 constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
 
-// Reads binned by tile (LdsPlan::img_tiles == 1 < n_tiles): bin = segment * n_tiles + tile.  `perm` lists the items (pairs of a batch: both segments
-// share the list of a tile; seqToIllumina records: a record has one segment) bin after bin; a bin's chunks of 64 items are handed out in UNITS of
-// unit_chunks chunks: a workgroup takes a unit, stages the bin's image if it is not the one it holds, and its waves pull the unit's chunks.
+// Reads binned by tile (LdsPlan::binned): bin = segment * n_tiles + tile.  `perm` lists the items (pairs of a batch: both segments share the list of a
+// tile; seqToIllumina records: a record has one segment) bin after bin.  A workgroup joins a bin, stages its image and its waves pull the bin's chunks
+// of 64 items from the bin's counter -- like the plain kernel's waves, without meeting each other -- until the bin is used up; only then does the
+// workgroup synchronise, choose the bin with the most chunks left per workgroup already on it, and stage again.
 struct FillBins {
     const uint32_t *perm;           // items sorted by bin
     const uint32_t *bin_first;      // [n_bins] first entry of the bin in perm
     const uint32_t *bin_count;      // [n_bins]
-    const uint32_t *unit_ptr;       // [n_bins + 1] units in front of the bin
-    uint32_t *unit_counter;
-    uint32_t n_bins, unit_chunks;
+    const uint32_t *chunk_ptr;      // [n_bins + 1] chunks of the bins in front
+    uint32_t *next_chunk;           // [n_bins] the bin's chunks handed out so far
+    uint32_t *workers;              // [n_bins] workgroups on the bin
+    uint32_t n_bins;
+    const Fragment *frags;          // pairs: the fragments (and what the sieve found of their variants) in perm's order, so that a wave reads them in one piece and
+    const FragmentVar *fvars;       // the pair index is needed only before and after a chunk's reads
 };
-constexpr uint32_t kSchedWords = 4;              // LDS words behind the image that fill_binned_loop keeps its unit and chunk counter in
+constexpr uint32_t kSchedWords = 8;              // LDS words behind the image in which fill_binned_loop keeps the bin its workgroup is on
 constexpr uint32_t kBinKeysLds = 4096;          // up to so many bin keys the counting kernels aggregate in LDS
 constexpr uint32_t kBinItemsPerThread = 16, kBinBlock = 256;
 
@@ -1982,30 +1988,30 @@ __global__ void __launch_bounds__(kBinBlock) k_record_tiles(DevSim S, const uint
     }
     bin_count_key(key, valid, 2u * S.n_tiles, hist, s_hist);
 }
-// one workgroup: the bins' places in perm (exclusive scan of the histogram), their units, the scatter's cursors.  pairs: n_keys = n_tiles, bins
+// one workgroup: the bins' places in perm (exclusive scan of the histogram), the scatter's cursors, the scheduler's counters.  pairs: n_keys = n_tiles, bins
 // (segment, tile) of both segments share tile's entries; records: n_keys = 2 n_tiles = the bins.
-__global__ void __launch_bounds__(1024) k_bins_plan(const uint32_t *hist, uint32_t n_keys, uint32_t n_bins, uint32_t unit_chunks, uint32_t *bin_first, uint32_t *bin_count,
-                                                    uint32_t *unit_ptr, uint32_t *cursor, uint32_t *unit_counter) {
-    __shared__ uint32_t s_part[1024], s_units[1024];
-    const uint32_t t = threadIdx.x, per = (n_bins + 1023u) / 1024u, lo = t * per, hi = lo + per < n_bins ? lo + per : n_bins;
-    // bins lo .. hi-1 of this thread; bin b has the items of key b % n_keys
-    uint32_t items = 0, units = 0;
+__global__ void __launch_bounds__(1024) k_bins_plan(const uint32_t *hist, uint32_t n_keys, uint32_t n_bins, uint32_t *bin_first, uint32_t *bin_count, uint32_t *cursor,
+                                                    uint32_t *chunk_ptr, uint32_t *next_chunk, uint32_t *workers) {
+    __shared__ uint32_t s_part[1024], s_chunks[1024];
+    const uint32_t t = threadIdx.x, per = (n_bins + 1023u) / 1024u, lo = t * per < n_bins ? t * per : n_bins, hi = lo + per < n_bins ? lo + per : n_bins;
+    // bins lo .. hi-1 of this thread; bin b has the items of key b % n_keys (the first n_keys bins place them)
+    uint32_t items = 0, chunks = 0;
     for (uint32_t b = lo; b < hi; ++b) {
         const uint32_t c = hist[b % n_keys];
         if (b < n_keys) items += c;
-        units += ((c + 63u) / 64u + unit_chunks - 1u) / unit_chunks;
+        chunks += (c + 63u) / 64u;
     }
     s_part[t] = items;
-    s_units[t] = units;
+    s_chunks[t] = chunks;
     __syncthreads();
     for (uint32_t d = 1; d < 1024u; d <<= 1) {                       // inclusive scans over the threads
-        const uint32_t a = t >= d ? s_part[t - d] : 0u, u = t >= d ? s_units[t - d] : 0u;
+        const uint32_t a = t >= d ? s_part[t - d] : 0u, c = t >= d ? s_chunks[t - d] : 0u;
         __syncthreads();
         s_part[t] += a;
-        s_units[t] += u;
+        s_chunks[t] += c;
         __syncthreads();
     }
-    uint32_t at = s_part[t] - items, unit_at = s_units[t] - units;
+    uint32_t at = s_part[t] - items, chunk_at = s_chunks[t] - chunks;
     for (uint32_t b = lo; b < hi; ++b) {
         const uint32_t c = hist[b % n_keys];
         if (b < n_keys) {
@@ -2013,20 +2019,26 @@ __global__ void __launch_bounds__(1024) k_bins_plan(const uint32_t *hist, uint32
             for (uint32_t r = b; r < n_bins; r += n_keys) bin_first[r] = at, bin_count[r] = c;
             at += c;
         }
-        unit_ptr[b] = unit_at;
-        unit_at += ((c + 63u) / 64u + unit_chunks - 1u) / unit_chunks;
+        chunk_ptr[b] = chunk_at;
+        chunk_at += (c + 63u) / 64u;
+        next_chunk[b] = workers[b] = 0;
     }
-    if (t == 1023u) unit_ptr[n_bins] = s_units[1023];
-    if (t == 0) *unit_counter = 0;
+    if (t == 1023u) chunk_ptr[n_bins] = s_chunks[1023];
 }
 // items to their bins' places: ranks inside the workgroup from LDS counters, one global reservation per workgroup and key
-__global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const uint16_t *key_of, uint64_t n, uint32_t n_keys, uint32_t *cursor, uint32_t *perm) {
+__global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const uint16_t *key_of, uint64_t n, uint32_t n_keys, uint32_t *cursor, uint32_t *perm, const Fragment *frags,
+                                                          const FragmentVar *fvars, Fragment *frags_sorted, FragmentVar *fvars_sorted) {
     __shared__ uint32_t s_count[kBinKeysLds], s_base[kBinKeysLds];
     const uint64_t first = (uint64_t)blockIdx.x * (kBinBlock * kBinItemsPerThread);
+    auto place = [&](uint32_t at, uint64_t i) {
+        perm[at] = (uint32_t)i;
+        if (frags) frags_sorted[at] = frags[i];
+        if (fvars) fvars_sorted[at] = fvars[i];
+    };
     if (n_keys > kBinKeysLds) {
         for (uint32_t j = 0; j < kBinItemsPerThread; ++j) {
             const uint64_t i = first + (uint64_t)j * kBinBlock + threadIdx.x;
-            if (i < n) perm[atomicAdd(&cursor[key_of[i]], 1u)] = (uint32_t)i;
+            if (i < n) place(atomicAdd(&cursor[key_of[i]], 1u), i);
         }
         return;
     }
@@ -2045,7 +2057,7 @@ __global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const uint16_t *key_o
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < kBinItemsPerThread; ++j)
-        if (key[j] != 0xFFFFFFFFu) perm[s_base[key[j]] + rank[j]] = (uint32_t)(first + (uint64_t)j * kBinBlock + threadIdx.x);
+        if (key[j] != 0xFFFFFFFFu) place(s_base[key[j]] + rank[j], first + (uint64_t)j * kBinBlock + threadIdx.x);
 }
 
 // One lane per read, persistent waves.  A workgroup serves one LDS image at a time -- a template segment (blockIdx.x & 1) with all tiles, built once, every
@@ -2096,77 +2108,104 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
     }
 }
 
-// The scheduler of the binned kernels.  Units are taken from one global counter; the workgroup's waves pull the chunks of its unit from a counter in LDS
-// (the two words behind the image).  chunk(img, qbase, seg, tile, item, active) runs 64 items.
+// The scheduler of the binned kernels.  The workgroup's first wave chooses the bin: the one with the most chunks left per workgroup on it (counting the
+// newcomer), found by a strided scan of the bins' counters (the first choice: by the workgroup's number); the choice is left in the LDS words behind the image ([0] the bin or 0xFFFFFFFF: nothing
+// left anywhere, [1] the bin whose image is staged).  chunk(img, qbase, seg, tile, place, active) runs the 64 items perm[place + lane] (place is wave-uniform).
 template <uint32_t MASK, class Chunk>
 __device__ void fill_binned_loop(const DevSim &S, float *lds_image, const FillBins &bins, Chunk &&chunk) {
     RSQ_LDS float *img = (RSQ_LDS float *)lds_image;
-    RSQ_LDS uint32_t *sched = reinterpret_cast<RSQ_LDS uint32_t *>(img + (MASK ? S.lds.total_words : 0u));      // [0] the unit, [1] its next chunk
-    const uint32_t lane = threadIdx.x & 63u, n_units = bins.unit_ptr[bins.n_bins];
-    uint32_t staged = 0xFFFFFFFFu;
-    for (;;) {
-        __syncthreads();                                               // every wave is done with the last unit
-        if (threadIdx.x == 0) {
-            sched[0] = atomicAdd(bins.unit_counter, 1u);
-            sched[1] = 0;
+    RSQ_LDS uint32_t *sched = reinterpret_cast<RSQ_LDS uint32_t *>(img + (MASK ? S.lds.total_words : 0u));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) sched[1] = 0xFFFFFFFFu;
+    for (bool first_choice = true;; first_choice = false) {
+        if (threadIdx.x < 64u) {
+            uint64_t best = 0;
+            if (first_choice) {
+                // all workgroups choose at once and cannot see each other yet: workgroup g of G begins with the bin that holds chunk (g + 1/2) / G of all chunks,
+                // so that the bins start with workgroups in proportion to their sizes
+                const uint64_t total = bins.chunk_ptr[bins.n_bins], target = ((2u * (uint64_t)blockIdx.x + 1u) * total) / (2u * gridDim.x);
+                uint32_t lo = 0, hi = bins.n_bins;                     // the last bin with chunk_ptr[bin] <= target
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (bins.chunk_ptr[mid] <= target) lo = mid;
+                    else hi = mid;
+                }
+                best = total ? ((uint64_t)1 << 32) | (0xFFFFFFFFu - lo) : 0u;
+            } else {
+                // score = chunks left * 4096 / (workgroups on the bin + 1); ties go to the lower bin
+                for (uint32_t b = lane; b < bins.n_bins; b += 64u) {
+                    const uint32_t n = (bins.bin_count[b] + 63u) / 64u, done = bins.next_chunk[b], left = done < n ? n - done : 0u;
+                    const uint64_t score = (uint64_t)left * 4096u / (bins.workers[b] + 1u), packed = (score << 32) | (0xFFFFFFFFu - b);
+                    if (left && packed > best) best = packed;
+                }
+            }
+            for (uint32_t d = 32; d; d >>= 1) {
+                const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(best >> 32), (int)d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, (int)d, 64);
+                best = other > best ? other : best;
+            }
+            if (lane == 0) {
+                const uint32_t bin = best ? 0xFFFFFFFFu - (uint32_t)best : 0xFFFFFFFFu;
+                sched[0] = bin;
+                if (best) atomicAdd(&bins.workers[bin], 1u);
+            }
         }
         __syncthreads();
-        const uint32_t unit = sched[0];
-        if (unit >= n_units) break;
-        uint32_t lo = 0, hi = bins.n_bins;                             // the unit's bin: the last one with unit_ptr[bin] <= unit
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (bins.unit_ptr[mid] <= unit) lo = mid;
-            else hi = mid;
-        }
-        const uint32_t bin = lo, seg = bin / S.n_tiles, tile = bin - seg * S.n_tiles, qbase = image_qbase(S, seg, tile);
-        if (bin != staged) {
+        // what comes out of LDS is wave-uniform, but a vector register to the compiler: readfirstlane makes it scalar again (else every index derived
+        // from the segment and the image becomes per-lane arithmetic)
+        const uint32_t bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[0]);
+        if (bin == 0xFFFFFFFFu) break;
+        const uint32_t seg = bin / S.n_tiles, tile = bin - seg * S.n_tiles, qbase = image_qbase(S, seg, tile);
+        if (bin != (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[1])) {      // all read before anyone writes (barriers inside the staging)
             fill_stage_image<MASK>(S, lds_image, qbase);
-            staged = bin;
+            if (threadIdx.x == 0) sched[1] = bin;
         }
-        const uint32_t n_items = bins.bin_count[bin], first = bins.bin_first[bin], first_chunk = (unit - bins.unit_ptr[bin]) * bins.unit_chunks;
-        const uint32_t left = (n_items + 63u) / 64u - first_chunk, n_chunks = left < bins.unit_chunks ? left : bins.unit_chunks;
+        const uint32_t first = bins.bin_first[bin], n_items = bins.bin_count[bin];
         for (;;) {
             uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(&sched[1], 1u);
-            c = __shfl(c, 0, 64);
-            if (c >= n_chunks) break;
-            const uint32_t k = (first_chunk + c) * 64u + lane;
-            const bool active = k < n_items;
-            chunk(img, qbase, seg, tile, active ? bins.perm[first + k] : 0u, active);
+            if (lane == 0) c = atomicAdd(&bins.next_chunk[bin], 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if ((uint64_t)c * 64u >= n_items) break;
+            chunk(img, qbase, seg, tile, first + c * 64u, c * 64u + lane < n_items);
         }
+        __syncthreads();                                               // every wave is done with the bin
+        if (threadIdx.x == 0) atomicSub(&bins.workers[bin], 1u);
     }
 }
 
-// one chunk of 64 pairs (lane = pair `pair` of the batch if active), mate `seg`
+// one chunk of 64 pairs, mate `seg`: lane = row `row` of the segment's raw arrays if active.  Not binned: row = pair of the batch.  Binned: row = place in
+// perm, the pair is perm[row] and its fragment record sorted[row] (a wave's rows are consecutive either way: 256-byte stores; k_format_write goes
+// through perm as well); the pair index itself is read where it is needed, before and after the reads, and does not live through them.
 template <uint32_t MASK, bool VAR, bool BINNED>
-__device__ void fill_pair_chunk(const DevSim &S, const NameTable &names, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t pair, bool active,
-                                const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, const RawLayout &raw, uint32_t *sizes, const FragmentVar *fvars) {
-    const uint64_t r = (uint64_t)seg * n_pairs + (active ? pair : 0u);
-    ReadOut out = raw.out_of(r);
+__device__ void fill_pair_chunk(const DevSim &S, const NameTable &names, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t row, bool active,
+                                const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, const RawLayout &raw, uint32_t *sizes, const FragmentVar *fvars,
+                                const uint32_t *perm) {
+    const uint64_t at = active ? row : 0u, r_out = (uint64_t)seg * n_pairs + at;
+    ReadOut out = raw.out_of(r_out);
     Fragment f{};
-    if (active && frags) f = frags[pair];
+    if (active && frags) f = frags[at];
     // the read's stream and template (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382)
     const bool from_fragment = frags != nullptr;
-    const uint64_t ao = adapter_only_first + pair;
     FragmentVar fv{};
-    if (VAR && active && fvars) fv = fvars[pair];
-    const PairStream ps = pair_stream(from_fragment ? &f : nullptr, fv.sub, ao);
+    if (VAR && active && fvars) fv = fvars[at];
+    const bool need_pair = !from_fragment || raw.templates != nullptr;              // wave-uniform
+    const uint64_t pair0 = BINNED ? (need_pair && active ? perm[at] : 0u) : at;
+    const PairStream ps = pair_stream(from_fragment ? &f : nullptr, fv.sub, adapter_only_first + pair0);
     const Stream st{S.seed, ps.c0, ps.c1, ps.c2, pair_c3(kDomPair, ps.strand, seg, f.allele)};
     const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, ps.c0, ps.c1, ps.c2, pair_c3(kDomPair, ps.strand, 2, f.allele)) : 0u);
     ReadMeta meta;
     if constexpr (VAR) {                                            // launched for fragments only
         VariantSrc src = variant_src(S, f, fvars ? &fv : nullptr, seg);
-        if (raw.templates) src.converted = raw.templates + r * raw.template_words;
+        if (raw.templates) src.converted = raw.templates + ((uint64_t)seg * n_pairs + pair0) * raw.template_words;
         fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, f.len, src, out, meta);
     } else {
         FragmentSrc src = from_fragment && active ? fragment_src(S, f, seg) : FragmentSrc{S.ref_words, 0, 0, 0, false, S.sys_fwd, nullptr, nullptr};      // len 0 = empty template
-        if (from_fragment && raw.templates) src.converted = raw.templates + r * raw.template_words;
+        if (from_fragment && raw.templates) src.converted = raw.templates + ((uint64_t)seg * n_pairs + pair0) * raw.template_words;
         fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, f.len, src, out, meta);
     }
     if (active) {
-        raw.meta[r] = meta;
-        sizes[r] = record_size(S, names, from_fragment ? &f : nullptr, ao + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
+        raw.meta[r_out] = meta;
+        const uint64_t pair = BINNED ? perm[at] : at;
+        sizes[(uint64_t)seg * n_pairs + pair] = record_size(S, names, from_fragment ? &f : nullptr, adapter_only_first + pair + 1u, meta, VAR && fvars ? &fv : nullptr);       // bytes of its FASTQ record
     }
 }
 
@@ -2175,8 +2214,9 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     if constexpr (BINNED) {
-        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t pair, bool active) {
-            fill_pair_chunk<MASK, VAR, true>(S, names, img, qbase, seg, tile, pair, active, frags, n_pairs, adapter_only_first, raw, sizes, fvars);
+        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t place, bool active) {
+            fill_pair_chunk<MASK, VAR, true>(S, names, img, qbase, seg, tile, place + (threadIdx.x & 63u), active, frags ? bins.frags : nullptr, n_pairs, adapter_only_first, raw,
+                                             sizes, fvars ? bins.fvars : nullptr, bins.perm);
         });
     } else {
         const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
@@ -2188,7 +2228,7 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
             chunk = __shfl(chunk, 0, 64);
             const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave is done
             if (first >= n_pairs) break;
-            fill_pair_chunk<MASK, VAR, false>(S, names, img, qbase, seg, 0u, first + lane, first + lane < n_pairs, frags, n_pairs, adapter_only_first, raw, sizes, fvars);
+            fill_pair_chunk<MASK, VAR, false>(S, names, img, qbase, seg, 0u, first + lane, first + lane < n_pairs, frags, n_pairs, adapter_only_first, raw, sizes, fvars, nullptr);
         }
     }
 }
@@ -2204,24 +2244,26 @@ struct RecordJob {
     const uint32_t *rec_index, *rec_count;
     uint64_t n_records;
 };
+// lane = record i if active; `row`: its row of the raw arrays (i, or binned its place in perm: the text / array kernels go through perm as well)
 template <uint32_t MASK, bool BINNED>
-__device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t i, bool active,
+__device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t i, uint64_t row, bool active,
                                   const RawLayout &raw) {
     const uint64_t idx = job.first_index + i;
     const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
     const RecordSrc src = record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
-    ReadOut out = raw.out_of(i);
+    ReadOut out = raw.out_of(active ? row : 0u);
     ReadMeta meta;
     const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, st.c0, st.c1, st.c2, pair_c3(kDomErrModel, 0, 2)) : 0u);
     fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
-    if (active) raw.meta[i] = meta;
+    if (active) raw.meta[row] = meta;
 }
 template <uint32_t MASK, bool BINNED = false>
 __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     if constexpr (BINNED) {
-        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t i, bool active) {
-            fill_record_chunk<MASK, true>(S, job, img, qbase, seg, tile, i, active, raw);
+        fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t place, bool active) {
+            const uint32_t row = place + (threadIdx.x & 63u);
+            fill_record_chunk<MASK, true>(S, job, img, qbase, seg, tile, active ? bins.perm[row] : 0u, row, active, raw);
         });
     } else {
         const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
@@ -2236,7 +2278,8 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob
             const uint64_t first = (uint64_t)chunk * 64u;                   // past the end: the wave is done
             if (first >= n_mine) break;
             const bool active = first + lane < n_mine;
-            fill_record_chunk<MASK, false>(S, job, img, qbase, seg, 0u, active ? index[first + lane] : 0u, active, raw);
+            const uint32_t i = active ? index[first + lane] : 0u;
+            fill_record_chunk<MASK, false>(S, job, img, qbase, seg, 0u, i, i, active, raw);
         }
     }
 }
@@ -2285,9 +2328,13 @@ __global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragm
 // 48-63 the two halves of the qualities.  The kernel is latency-bound (dependent byte pushes, four load round trips), so
 // short per-lane work and 8 KiB of LDS per wave (twenty waves per CU) matter more than instruction count.
 constexpr uint32_t kFormatRecords = 16u, kFormatLdsBytes = 8u * 1024u;
+// PERM (the read kernel ran binned by tile): the wave's 16 records are those whose raw rows are consecutive -- pairs perm[first .. first + 15] --, their
+// texts lie anywhere in the output, so every record has a 512-byte slot of the image (same alignment modulo 16 as its destination) and its four lanes
+// copy it out.
+template <bool PERM>
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
                                                     const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1,
-                                                    const FragmentVar *fvars = nullptr) {
+                                                    const FragmentVar *fvars, const uint32_t *perm) {
     __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
     const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords;
     const bool is_qual = part >= 2u, second_half = (part & 1u) != 0u;
@@ -2297,18 +2344,20 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
     char *dst = seg ? dst1 : dst0;
     if (offsets[n_pairs] > (seg ? cap1 : cap0)) return;                            // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
     const uint64_t last = first + kFormatRecords < n_pairs ? first + kFormatRecords : n_pairs;
-    const uint64_t g_begin = offsets[first], g_end = offsets[last];
-    const uint64_t a_begin = (uint64_t)(uintptr_t)(dst + g_begin);                 // absolute byte address of the range
-    const uint32_t skew = (uint32_t)(a_begin & 15u), bytes = (uint32_t)(g_end - g_begin);
-    const uint64_t pair = first + rec;
-    const bool active = pair < last;
-    const bool through_lds = skew + bytes <= kFormatLdsBytes;                      // wave-uniform
+    const uint64_t row = first + rec;                                              // of the raw arrays, within the segment
+    const bool active = row < last;
+    const uint64_t pair = PERM ? (active ? perm[row] : 0u) : row;
+    // the byte range of the wave's text (PERM: of the lane's record) and where it starts modulo 16
+    const uint64_t g_begin = PERM ? (active ? offsets[pair] : 0u) : offsets[first], g_end = PERM ? (active ? offsets[pair + 1u] : 0u) : offsets[last];
+    const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)(dst + g_begin) & 15u), bytes = (uint32_t)(g_end - g_begin);
+    constexpr uint32_t kSlot = kFormatLdsBytes / kFormatRecords;
+    const bool through_lds = PERM ? __all(skew + bytes <= kSlot) != 0 : skew + bytes <= kFormatLdsBytes;      // wave-uniform
     ReadMeta m;
     Fragment f;
     FragmentVar fv;
     uint64_t r = 0;
     if (active) {
-        r = (uint64_t)seg * n_pairs + pair;
+        r = (uint64_t)seg * n_pairs + row;
         m = raw.meta[r];
         if (frags) f = frags[pair];
         if (frags && fvars) fv = fvars[pair];
@@ -2321,8 +2370,9 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         if (active && part == 0u) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair], fvp);
         return;
     }
+    const uint32_t slot_at = PERM ? rec * kSlot : 0u;
     if (active) {
-        RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + skew + (uint32_t)(offsets[pair] - g_begin);
+        RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + slot_at + skew + (PERM ? 0u : (uint32_t)(offsets[pair] - g_begin));
         const uint32_t header = (uint32_t)(offsets[pair + 1u] - offsets[pair]) - 2u * m.read_len - 4u;
         const uint32_t all_words = (m.read_len + 3u) >> 2, half = (all_words + 1u) >> 1;      // the first half ends on a word boundary
         const uint32_t first_word = second_half ? half : 0u, line_at = header + (is_qual ? m.read_len + 3u : 0u);
@@ -2333,13 +2383,15 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         t.finish();
     }
     __syncthreads();
-    const uint32_t lo = skew, hi = skew + bytes;                                   // LDS byte range holding text
+    const uint32_t lo = skew, hi = skew + bytes;                                   // LDS byte range (within the slot) holding text
     char *g_chunk0 = dst + g_begin - skew;                                         // 16-byte aligned
-    for (uint32_t c = lane * 16u; c < hi; c += 64u * 16u) {
+    const char *s_from = s_text + slot_at;
+    // the image goes out in aligned 16-byte stores: all lanes over the wave's range, or (PERM) a record's four lanes over its slot
+    for (uint32_t c = (PERM ? part : lane) * 16u; c < hi; c += (PERM ? 4u : 64u) * 16u) {
         if (c >= lo && c + 16u <= hi) {
-            *reinterpret_cast<uint4 *>(g_chunk0 + c) = *reinterpret_cast<const uint4 *>(s_text + c);
+            *reinterpret_cast<uint4 *>(g_chunk0 + c) = *reinterpret_cast<const uint4 *>(s_from + c);
         } else {
-            for (uint32_t b = c < lo ? lo : c; b < c + 16u && b < hi; ++b) g_chunk0[b] = s_text[b];
+            for (uint32_t b = c < lo ? lo : c; b < c + 16u && b < hi; ++b) g_chunk0[b] = s_from[b];
         }
     }
 }

@@ -320,6 +320,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
         while (rq < rate_rows_q && need + need_rate(rq + 1, rb) <= budget) ++rq;
         while (rb < rate_rows_b && need + need_rate(rq, rb + 1) <= budget) ++rb;
         plan.img_tiles = Ti;
+        plan.binned = (Ti < T || opt.image_tiles == 1) ? 1u : 0u;
         plan.par0_words = par0_words;
         plan.par0_indel_bytes = par0_indel_bytes;
         plan.desc_words = desc_words;

@@ -135,7 +135,7 @@ struct rsq_sim : SimState {
     DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
     DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
     DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
-    DevBuf bin_keys, bin_small, bin_perm;      // reads binned by tile: key per item; histogram, bins, units, cursors (one small buffer); the sorted items
+    DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, units, cursors (one small buffer); the sorted items
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -347,34 +347,35 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     s.raw_qual.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
     s.raw_ops.reserve((uint64_t)s.ops_stride * pitch * 4 + 16);
     s.raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
-    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0};
+    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0, nullptr};
 }
 
 // Reads binned by tile (the LDS plan holds one tile per image): keys, histogram, the bins' places and units, the scatter.  n_keys = n_tiles (pairs:
 // both mates of a pair have the pair's tile) or 2 n_tiles (records); bins = (segment, tile).
-static bool fill_is_binned(const rsq_sim &s) { return effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) != 0 && s.dev.lds.img_tiles < s.dev.n_tiles; }
+static bool fill_is_binned(const rsq_sim &s) { return effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) != 0 && s.dev.lds.binned; }
 template <class CountKernel>
-static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, hipStream_t st, CountKernel &&count_keys) {
+static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, hipStream_t st, CountKernel &&count_keys, const Fragment *frags = nullptr,
+                                const FragmentVar *fvars = nullptr) {
     if (n_items >= 0xFFFFFFFFull) throw Error("more than 2^32 reads in one call of a profile with tiles: use smaller block ranges");
     const uint32_t n_bins = 2 * s.dev.n_tiles;
-    const int64_t unit_opt = options().unit_chunks;
-    const uint32_t unit_chunks = unit_opt > 0 ? (uint32_t)std::min<int64_t>(unit_opt, 1 << 20) : 4u * (kFillBlock / 64u);
     s.bin_keys.reserve(n_items * 2 + 16);
     s.bin_perm.reserve(n_items * 4 + 16);
-    // [hist n_keys][cursor n_keys][bin_first n_bins][bin_count n_bins][unit_ptr n_bins + 1][unit_counter 1]
-    const size_t words = 2 * (size_t)n_keys + 3 * (size_t)n_bins + 2;
+    // [hist n_keys][cursor n_keys][bin_first n_bins][bin_count n_bins][next_chunk n_bins][workers n_bins][chunk_ptr n_bins + 1]
+    const size_t words = 2 * (size_t)n_keys + 5 * (size_t)n_bins + 1;
     s.bin_small.reserve(words * 4 + 16);
-    uint32_t *hist = s.bin_small.as<uint32_t>(), *cursor = hist + n_keys, *bin_first = cursor + n_keys, *bin_count = bin_first + n_bins, *unit_ptr = bin_count + n_bins,
-             *unit_counter = unit_ptr + n_bins + 1;
+    uint32_t *hist = s.bin_small.as<uint32_t>(), *cursor = hist + n_keys, *bin_first = cursor + n_keys, *bin_count = bin_first + n_bins, *next_chunk = bin_count + n_bins,
+             *workers = next_chunk + n_bins, *chunk_ptr = workers + n_bins;
     HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)n_keys * 4, st));
     s.timers["bin_tiles"].start(st);
     count_keys(s.bin_keys.as<uint16_t>(), hist);
-    hipLaunchKernelGGL(k_bins_plan, dim3(1), dim3(1024), 0, st, hist, n_keys, n_bins, unit_chunks, bin_first, bin_count, unit_ptr, cursor, unit_counter);
+    hipLaunchKernelGGL(k_bins_plan, dim3(1), dim3(1024), 0, st, hist, n_keys, n_bins, bin_first, bin_count, cursor, chunk_ptr, next_chunk, workers);
+    if (frags) s.bin_frags.reserve(n_items * sizeof(Fragment) + 16);
+    if (fvars) s.bin_fvars.reserve(n_items * sizeof(FragmentVar) + 16);
     hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n_items, kBinBlock * kBinItemsPerThread)), dim3(kBinBlock), 0, st, s.bin_keys.as<uint16_t>(), n_items, n_keys, cursor,
-                       s.bin_perm.as<uint32_t>());
+                       s.bin_perm.as<uint32_t>(), frags, fvars, s.bin_frags.as<Fragment>(), s.bin_fvars.as<FragmentVar>());
     s.timers["bin_tiles"].stop(st);
     HIP_CHECK(hipGetLastError());
-    return FillBins{s.bin_perm.as<uint32_t>(), bin_first, bin_count, unit_ptr, unit_counter, n_bins, unit_chunks};
+    return FillBins{s.bin_perm.as<uint32_t>(), bin_first, bin_count, chunk_ptr, next_chunk, workers, n_bins, s.bin_frags.as<Fragment>(), s.bin_fvars.as<FragmentVar>()};
 }
 template <class Kernel>
 static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kernel kernel) {
@@ -392,13 +393,14 @@ static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK = quads per quality row (screened draws on the LDS image planned by
 // pack_tables) or 0 (double precision from HBM: the reference path the tests compare with)
+// they return the order of the raw arrays' rows: nullptr = row i is item i, else row i is item perm[i] (binned by tile)
 template <uint32_t MASK, bool VAR, bool BINNED>
-static void launch_fill_kernel(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars) {
+static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars) {
     FillBins bins{};
     if (BINNED)
         bins = build_fill_bins(s, n_pairs, s.dev.n_tiles, st, [&](uint16_t *keys, uint32_t *hist) {
             hipLaunchKernelGGL(k_pair_tiles, dim3(cdiv(n_pairs, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, frags, fvars, n_pairs, adapter_first, keys, hist);
-        });
+        }, frags, fvars);
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_reads<MASK, VAR, BINNED>);
     const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2);
     s.fill_counters.reserve(8);
@@ -408,15 +410,16 @@ static void launch_fill_kernel(rsq_sim &s, const Fragment *frags, uint64_t n_pai
                        s.fill_counters.as<uint32_t>(), fvars, bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
+    return bins.perm;
 }
 template <uint32_t MASK, bool VAR = false>
-static void launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
+static const uint32_t *launch_fill_mask(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st, const FragmentVar *fvars = nullptr) {
     if constexpr (MASK != 0)
         if (fill_is_binned(s)) return launch_fill_kernel<MASK, VAR, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
-    launch_fill_kernel<MASK, VAR, false>(s, frags, n_pairs, adapter_first, raw, st, fvars);
+    return launch_fill_kernel<MASK, VAR, false>(s, frags, n_pairs, adapter_first, raw, st, fvars);
 }
 template <uint32_t MASK, bool BINNED>
-static void launch_records_kernel(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
+static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     FillBins bins{};
     if (BINNED)
         bins = build_fill_bins(s, n, 2 * s.dev.n_tiles, st, [&](uint16_t *keys, uint32_t *hist) {
@@ -430,22 +433,22 @@ static void launch_records_kernel(rsq_sim &s, const RecordJob &job, const uint8_
     hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
+    return bins.perm;
 }
 template <uint32_t MASK>
-static void launch_records_mask(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
+static const uint32_t *launch_records_mask(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     if constexpr (MASK != 0)
         if (fill_is_binned(s)) return launch_records_kernel<MASK, true>(s, job, seg_dev, n, raw, st);
-    launch_records_kernel<MASK, false>(s, job, seg_dev, n, raw, st);
+    return launch_records_kernel<MASK, false>(s, job, seg_dev, n, raw, st);
 }
-static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
+static const uint32_t *launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
                               const FragmentVar *fvars = nullptr) {
     const uint32_t mask = effective_fill_mask(s.dev.lds.mask, s.force_fill_mode);
     const bool var = frags && s.has_variants;            // with variants the error walk is per lane state
 #define RSQ_FILL_CASE(Q)                                                                       \
-    if (mask == Q) {                                                                           \
-        if (var) launch_fill_mask<Q, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);  \
-        else launch_fill_mask<Q>(s, frags, n_pairs, adapter_first, raw, st);                   \
-        return;                                                                                \
+    if (mask == Q) {                                                                                  \
+        if (var) return launch_fill_mask<Q, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);  \
+        return launch_fill_mask<Q>(s, frags, n_pairs, adapter_first, raw, st);                        \
     }
     RSQ_FILL_CASE(0u)
     RSQ_FILL_CASE(kQualityQuads[0])
@@ -457,13 +460,10 @@ static void launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pair
 #undef RSQ_FILL_CASE
     throw Error("no k_fill_reads instantiation for " + std::to_string(mask) + " quads");
 }
-static void launch_fill_records(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
+static const uint32_t *launch_fill_records(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     const uint32_t mask = effective_fill_mask(s.dev.lds.mask, s.force_fill_mode);
-#define RSQ_REC_CASE(Q)                                          \
-    if (mask == Q) {                                             \
-        launch_records_mask<Q>(s, job, seg_dev, n, raw, st);     \
-        return;                                                  \
-    }
+#define RSQ_REC_CASE(Q) \
+    if (mask == Q) return launch_records_mask<Q>(s, job, seg_dev, n, raw, st);
     RSQ_REC_CASE(0u)
     RSQ_REC_CASE(kQualityQuads[0])
     RSQ_REC_CASE(kQualityQuads[1])
@@ -500,15 +500,19 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
         s.timers["variant_templates"].stop(st);
         HIP_CHECK(hipGetLastError());
     }
-    launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st, fvars);
+    const uint32_t *row_order = launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st, fvars);
     s.timers["scan"].start(st);
     exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
     exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
     s.timers["scan"].stop(st);
     // the kernel itself refuses to write past the caller's capacity; the host learns the sizes with the final synchronisation
     s.timers["format_write"].start(st);
-    hipLaunchKernelGGL(k_format_write, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
-                       (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars);
+    if (row_order)
+        hipLaunchKernelGGL(k_format_write<true>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
+                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, row_order);
+    else
+        hipLaunchKernelGGL(k_format_write<false>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
+                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, (const uint32_t *)nullptr);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
     s.mailbox[4] = 0;
@@ -655,37 +659,41 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
 // records at the offsets of their exclusive scan; one lane per record, word-granular stores
 RSQ_HD uint32_t error_model_record_size(const ReadMeta &m, uint32_t id_len) { return 1u + id_len + 1u + m.cigar_chars + 2u + digits_u32(m.num_errors) + 1u + 2u * m.read_len + 4u; }
 __global__ void __launch_bounds__(256) k_record_text_sizes(RawLayout raw, uint64_t n, const uint64_t *id_off, uint32_t *sizes) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sizes[i] = error_model_record_size(raw.meta[i], (uint32_t)(id_off[i + 1] - id_off[i]));
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint64_t i = raw.item_of(row);
+    sizes[i] = error_model_record_size(raw.meta[row], (uint32_t)(id_off[i + 1] - id_off[i]));
 }
 __global__ void __launch_bounds__(256) k_record_text(RawLayout raw, uint64_t n, const char *ids, const uint64_t *id_off, const uint64_t *offsets, char *dst, uint64_t cap) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || offsets[n] > cap) return;                          // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
-    const ReadMeta m = raw.meta[i];
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n || offsets[n] > cap) return;                        // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
+    const uint64_t i = raw.item_of(row);
+    const ReadMeta m = raw.meta[row];
     WordSinkT<char *> t(dst + offsets[i]);
     t.ch('@');
     t.str(ids + id_off[i], (uint32_t)(id_off[i + 1] - id_off[i]));
     t.ch(' ');
-    cigar_replay(raw.ops_of(i), m, t);
+    cigar_replay(raw.ops_of(row), m, t);
     t.str(" E", 2);
     t.num((uint32_t)m.num_errors);
     t.ch('\n');
-    format_line(raw.seq_of(i), m.read_len, false, t);
-    format_line(raw.qual_of(i), m.read_len, true, t);
+    format_line(raw.seq_of(row), m.read_len, false, t);
+    format_line(raw.qual_of(row), m.read_len, true, t);
     t.finish();
 }
 
 // CIGAR strings and per-read scalars of the error-model-only mode
 __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *num_errors_out,
                                   uint16_t *tile_out, char *cigar_out, uint32_t cigar_stride, uint32_t *overflow) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const ReadMeta m = raw.meta[i];
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint64_t i = raw.item_of(row);
+    const ReadMeta m = raw.meta[row];
     read_len_out[i] = m.read_len;
     num_errors_out[i] = m.num_errors;
     tile_out[i] = m.tile_id;
     const uint32_t nb = m.read_len < out_stride ? m.read_len : out_stride;
-    const WordColumn seq = raw.seq_of(i), qual = raw.qual_of(i);
+    const WordColumn seq = raw.seq_of(row), qual = raw.qual_of(row);
     if (!((out_stride | (uint32_t)(uintptr_t)seq_out | (uint32_t)(uintptr_t)qual_out) & 3u)) {      // word-aligned rows: copy words
         uint32_t *so = reinterpret_cast<uint32_t *>(seq_out + i * out_stride), *qo = reinterpret_cast<uint32_t *>(qual_out + i * out_stride);
         for (uint32_t w = 0; 4u * w < nb; ++w) {                   // bytes past read_len inside the last word are zero in the raw arrays
@@ -703,7 +711,7 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
         return;
     }
     TextSink t{cigar_out + i * cigar_stride, 0};
-    cigar_replay(raw.ops_of(i), m, t);
+    cigar_replay(raw.ops_of(row), m, t);
     t.ch(0);
 }
 
@@ -1199,7 +1207,7 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
         HIP_CHECK(hipGetLastError());
     }
     const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>(), n};
-    launch_fill_records(*s, job, seg_dev, n, raw, st);
+    raw.order = launch_fill_records(*s, job, seg_dev, n, raw, st);
     return raw;
 }
 

@@ -88,6 +88,7 @@ struct LdsPlan {
     uint32_t mask;               // the read kernel's template argument: quads_q when the image exists and the kernel draws screened; 0: double
                                  // precision from HBM only
     uint32_t img_tiles;          // tiles per image: n_tiles, or 1 (reads binned by tile, one tile per workgroup)
+    uint32_t binned;             // the read kernels run binned by tile (img_tiles < n_tiles, or asked for by option image_tiles = 1)
     uint32_t desc_words;         // size of the descriptor area: the descriptors, then the outcome values (par0) of the image's tables
     uint32_t par0_words;         // size of the outcome-value area in the image: the indel tables' values (par0_indel_bytes, from byte 0 of the pool), then
     uint32_t par0_indel_bytes;   // those of the image's tiles (contiguous in the pool from the first quality table's par0_off on)

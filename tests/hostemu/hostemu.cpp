@@ -63,7 +63,7 @@ struct Emu : SimState {
     uint32_t mask() const { return effective_fill_mask(dev.lds.mask, fill_mode); }
     void build_lds() { lds.clear(); }           // images are built when a read first asks for them
     float *image(uint32_t seg, uint32_t tile) { // what a workgroup of k_fill_reads does before it serves reads of (seg, tile)
-        const uint32_t qbase = image_qbase(dev, seg, dev.lds.img_tiles < dev.n_tiles ? tile : 0u);
+        const uint32_t qbase = image_qbase(dev, seg, dev.lds.binned ? tile : 0u);
         std::vector<float> &img = lds[qbase];
         if (img.empty()) {
             img.assign(dev.lds.total_words + 16, 0.f);
@@ -84,7 +84,7 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
             constexpr uint32_t M = decltype(tag)::value;
             if (s.mask() != M) return;
             float *img = s.image(seg, tile), *ring = img + s.dev.lds.ring_off;      // the ring of wave 0
-            ScreenTables<M> tab{s.dev, img, image_qbase(s.dev, seg, s.dev.lds.img_tiles < s.dev.n_tiles ? tile : 0u), ring, 0u};
+            ScreenTables<M> tab{s.dev, img, image_qbase(s.dev, seg, s.dev.lds.binned ? tile : 0u), ring, 0u};
             ReadMachine m;
             m.init(s.dev, tab, st, seg, tile, frag_len, src);
             for (;;) {

@@ -81,17 +81,15 @@ def test_p0_with_tiles(workdir, n_tiles):
 
 
 def test_tiles_binned_although_they_fit(workdir, rsq_options):
-    """TINY's three tiles fit one image; option image_tiles = 1 bins them all the same: the scheduler (work units, re-staged images, short
-    last units) on profiles with adapters, variable read lengths and indels; unit_chunks = 1: a unit per chunk of 64 reads"""
+    """TINY's three tiles fit one image; option image_tiles = 1 bins them all the same: the scheduler (bins chosen by the workgroups, re-staged
+    images, bins shorter than a chunk) on profiles with adapters, variable read lengths and indels"""
     rsq_options("image_tiles", 1)
-    for unit in (0, 1):
-        rsq_options("unit_chunks", unit)
-        P.case_sieve_and_reads_tiny(GpuBackend, workdir)
-        P.case_dense_coverage(GpuBackend, workdir)
-        P.case_adapter_only(GpuBackend, workdir)
-        P.case_error_model_tiny(GpuBackend, workdir)
-        P.case_variants_indels(GpuBackend, workdir)
-        P.case_methylation(GpuBackend, workdir)
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+    P.case_dense_coverage(GpuBackend, workdir)
+    P.case_adapter_only(GpuBackend, workdir)
+    P.case_error_model_tiny(GpuBackend, workdir)
+    P.case_variants_indels(GpuBackend, workdir)
+    P.case_methylation(GpuBackend, workdir)
 
 
 @pytest.mark.parametrize("mode", [0])

@@ -23,7 +23,7 @@ calls = (total + n - 1) // n
 tmp = tempfile.mkdtemp(prefix="rsq_em_")
 ppath = os.path.join(tmp, "p0.rsqp")
 # `python tools/bench_error_model.py N binned`: the same profile with 12 quality values (30 .. 41; K <= 12 takes the 3-quad instantiation of the
-# read kernels; RSQ_MIN_QUALITY_QUADS=10 in the environment forces the 10-quad one for comparison)
+# read kernels; api.set_option("min_quality_quads", 10) forces the 10-quad one for comparison)
 CFG = dict(synth.P0, name="P0b", qual_from=30, qual_to=42) if len(sys.argv) > 2 and sys.argv[2] == "binned" else synth.P0
 arrays = synth.make_profile(CFG, seed=103741084)
 synth.write_profile(ppath, arrays)
