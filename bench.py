@@ -273,7 +273,7 @@ def main():
     bufs = [(TorchBuffer(torch, need1 + 4096, dev), TorchBuffer(torch, need2 + 4096, dev)) for _ in range(2)]
 
     def step():
-        pairs = nbytes = 0
+        pairs = nbytes = launches = 0
         fill_ms = 0.0
         for lo, hi in batches:
             n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0][0], bufs[0][1])
@@ -282,8 +282,9 @@ def main():
             pairs += n
             nbytes += l1 + l2
             if n:
-                fill_ms += sim.last_kernel_ms("fill_reads")
-        return pairs, nbytes, fill_ms
+                fill_ms += sim.last_kernel_ms("fill_reads")              # summed over the call's launches (pipelined sub-ranges)
+                launches += sim.last_kernel_launches("fill_reads")
+        return pairs, nbytes, fill_ms, launches
 
     def sync():
         torch.cuda.synchronize()
@@ -294,13 +295,14 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    pairs = nbytes = 0
+    pairs = nbytes = fill_launches = 0
     fill_ms = 0.0
     for _ in range(args.steps):
-        p, b, f = step()
+        p, b, f, n_launch = step()
         pairs += p
         nbytes += b
         fill_ms += f
+        fill_launches += n_launch
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
@@ -354,7 +356,7 @@ def main():
                    "overlapping the generation of batch k+1 (the link binds: 7.5 GB per step and GPU)"}
 
     if rank == 0:
-        launches = args.steps * len(batches)
+        launches = max(fill_launches, 1)                                   # k_fill_reads launches in the timed region
         avg_fill_s = fill_ms / 1e3 / launches
         achieved = A_PAIR * (pairs / launches) / avg_fill_s / 1e9          # GB/s of algorithmic traffic in the dominant kernel
         counters = committed_counters()
@@ -367,7 +369,7 @@ def main():
                                    (f" -- NOT the headline: P0 with {args.tiles} tiles (per-tile tables)" if args.tiles > 1 else ""),
                        "tiles": args.tiles, "fill_plan": plan, "options": args.option, "reference_bp": args.genome * world,
                        "pairs_requested": args.pairs * world, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
-                       "batch_blocks": args.batch_blocks, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
+                       "batch_blocks": args.batch_blocks, "read_kernel_launches_per_step": launches / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
                        "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": counters["hbm_bytes_per_launch"] if counters else None, "traffic_source": counters["source"].replace("_pmc", "_traffic") if counters else None,

@@ -211,10 +211,13 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
                               const uint32_t *frag_len_dev, const uint8_t *dom_dev, const uint8_t *rate_dev, const char *ids_dev, const uint64_t *id_off_dev,
                               char *text_dev, size_t text_cap, size_t *text_len, void *stream);
 
-/* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded on the call's stream
- * around each kernel.  names: "sieve" (screen + finish), "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"; with variants of any kind also
- * "slot_table" and "variant_templates". */
+/* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded around each kernel on the stream it was launched on.  A call
+ * over a large block range runs as several sub-ranges (blocks are independent, Simulator.cpp:2384-2401) whose sieve / reads / text stages are pipelined on
+ * three streams: the time is the SUM over the call's launches of that kernel, rsq_sim_last_kernel_launches says how many there were.
+ * names: "sieve" (screen + finish), "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"; with variants of any kind also
+ * "slot_table" and "variant_templates"; for a profile with tiles "bin_tiles". */
 int rsq_sim_last_kernel_ms(const rsq_sim *s, const char *kernel, double *ms);
+int rsq_sim_last_kernel_launches(const rsq_sim *s, const char *kernel, uint32_t *launches);
 
 /* ---- device memory helpers so that callers without a HIP binding (ctypes tests, the CLI) can stage buffers */
 int rsq_dev_alloc(int device, size_t bytes, void **out_dev);

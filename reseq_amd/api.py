@@ -90,6 +90,7 @@ SYMBOLS = {
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "rsq_sim_error_model_fastq": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
+    "rsq_sim_last_kernel_launches": (C.c_int, [_vp, C.c_char_p, C.POINTER(_u32)]),
     "rsq_dev_alloc": (C.c_int, [C.c_int, _sz, _pp]),
     "rsq_dev_free": (C.c_int, [C.c_int, _vp]),
     "rsq_dev_upload": (C.c_int, [C.c_int, _vp, _vp, _sz]),
@@ -457,8 +458,14 @@ class Simulator:
                 d.free()
 
     def last_kernel_ms(self, name):
+        """sum over the last call's launches of the kernel (a large call runs in pipelined sub-ranges)"""
         v = C.c_double()
         _check(lib().rsq_sim_last_kernel_ms(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def last_kernel_launches(self, name):
+        v = _u32(0)
+        _check(lib().rsq_sim_last_kernel_launches(self.h, name.encode(), C.byref(v)))
         return v.value
 
     def close(self):

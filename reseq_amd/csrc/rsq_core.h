@@ -428,9 +428,11 @@ RSQ_HD void surrounding_forward(const uint64_t *__restrict__ words, uint64_t wor
         for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = reverse_ten_bases((uint32_t)(x >> (20u * b)) & 0xFFFFFu);
         return;
     }
-#pragma unroll
+    // windows over a sequence end (rare): rolled loops -- unrolled, their thirty loads cost the sieve's candidate kernel hundreds of vector registers
+#pragma unroll 1
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
+#pragma unroll 1
         for (uint32_t i = 0; i < kSurRange; ++i) {
             v = (v << 2) + ref_base(wrapped && wrap_words ? wrap_words : words, word_off, (uint32_t)p);
             if (++p == L) {
@@ -454,9 +456,10 @@ RSQ_HD void surrounding_reverse(const uint64_t *__restrict__ words, uint64_t wor
         for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = ~(uint32_t)(x >> (20u * (kSurBlocks - 1u - b))) & 0xFFFFFu;
         return;
     }
-#pragma unroll
+#pragma unroll 1
     for (uint32_t b = 0; b < kSurBlocks; ++b) {
         uint32_t v = 0;
+#pragma unroll 1
         for (uint32_t i = 0; i < kSurRange; ++i) {
             v = (v << 2) + (3u - ref_base(wrapped && wrap_words ? wrap_words : words, word_off, f));
             if (f) --f;

@@ -31,7 +31,7 @@ struct Options {
     int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
     int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
     int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
-    int64_t overlap = -1;              // -1: rsq_sim_pairs pipelines sieve / reads / text over sub-ranges when the batch is large; 0: one pass; n > 0: n sub-ranges
+    int64_t overlap = 0;               // n > 1: rsq_sim_pairs cuts its block range into n sub-ranges whose sieve / reads / text stages are pipelined on three streams
 };
 Options &options();                                               // the process-wide values
 bool set_option(const char *name, int64_t value);                 // false: no such option

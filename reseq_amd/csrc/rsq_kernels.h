@@ -393,6 +393,7 @@ RSQ_HD uint32_t sieve_cell_var(const DevSim &S, const SieveSite &site, uint32_t 
     }
     uint32_t n_here = 0;
     Words wc{0, 0, 0, 0};
+#pragma unroll 1                                                                   // unrolled over the 16 slots the loop body's gathers and the count draw took 361 vector registers
     for (uint32_t j = 0; j < n_chosen; ++j) {
         const uint32_t allele = chosen[j] >> 1;
         const uint64_t *words = hap_words(S, allele);
@@ -756,8 +757,10 @@ __global__ void k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *tile_
 // one workgroup: every thread adds up a stretch of tiles, the stretches' sums are scanned in LDS, then every thread turns its stretch into
 // exclusive prefixes (tens of thousands of tiles for a batch of 10 M pairs: a single serial thread took a millisecond)
 constexpr uint32_t kScanTilesBlock = 1024;
-__global__ void __launch_bounds__(kScanTilesBlock) k_scan_tiles(uint64_t *tile_sums, uint32_t n_tiles, uint64_t *total) {
+// `init`: what lies in front of the whole array (nullptr: 0) -- the offsets of a sub-range continue where the sub-range in front of it ended
+__global__ void __launch_bounds__(kScanTilesBlock) k_scan_tiles(uint64_t *tile_sums, uint32_t n_tiles, uint64_t *total, const uint64_t *init) {
     __shared__ uint64_t s[kScanTilesBlock];
+    const uint64_t first = init ? *init : 0u;
     const uint32_t per = (n_tiles + kScanTilesBlock - 1u) / kScanTilesBlock, lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
     uint64_t acc = 0;
     for (uint32_t i = lo; i < hi; ++i) acc += tile_sums[i];
@@ -769,13 +772,13 @@ __global__ void __launch_bounds__(kScanTilesBlock) k_scan_tiles(uint64_t *tile_s
         s[threadIdx.x] += v;
         __syncthreads();
     }
-    uint64_t run = s[threadIdx.x] - acc;                              // what lies in front of this thread's stretch
+    uint64_t run = first + s[threadIdx.x] - acc;                      // what lies in front of this thread's stretch
     for (uint32_t i = lo; i < hi; ++i) {
         const uint64_t v = tile_sums[i];
         tile_sums[i] = run;
         run += v;
     }
-    if (threadIdx.x == kScanTilesBlock - 1u) *total = s[threadIdx.x];
+    if (threadIdx.x == kScanTilesBlock - 1u) *total = first + s[threadIdx.x];
 }
 __global__ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *tile_sums, const uint64_t *total, uint64_t *out) {
     __shared__ uint64_t s[kScanBlock];

@@ -38,7 +38,10 @@ class DevBuf {
     ~DevBuf() { if (p_) (void)hipFree(p_); }
     void reserve(size_t bytes) {                   // grow-only
         if (bytes <= bytes_) return;
-        if (p_) HIP_CHECK(hipFree(p_));
+        if (p_) {
+            HIP_CHECK(hipDeviceSynchronize());     // a pipelined call may still read the old array on another stream
+            HIP_CHECK(hipFree(p_));
+        }
         p_ = nullptr;
         bytes_ = 0;
         HIP_CHECK(hipMalloc(&p_, bytes ? bytes : 8));
@@ -58,33 +61,41 @@ class DevBuf {
     size_t bytes_ = 0;
 };
 
-struct Timer {                                     // HIP events on the stream the kernels are launched on
-    hipEvent_t a = nullptr, b = nullptr;
-    bool used = false;
+struct Timer {                                     // HIP events on the stream the kernels are launched on; a call may time several launches (sub-ranges)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t used = 0;
     Timer() = default;
     Timer(const Timer &) = delete;
     Timer &operator=(const Timer &) = delete;
     ~Timer() {
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
+        for (auto &e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     }
+    void reset() { used = 0; }
     void start(hipStream_t st) {
-        if (!a) {
+        if (used == events.size()) {
+            hipEvent_t a, b;
             HIP_CHECK(hipEventCreate(&a));
             HIP_CHECK(hipEventCreate(&b));
+            events.emplace_back(a, b);
         }
-        HIP_CHECK(hipEventRecord(a, st));
+        HIP_CHECK(hipEventRecord(events[used].first, st));
     }
     void stop(hipStream_t st) {
-        HIP_CHECK(hipEventRecord(b, st));
-        used = true;
+        HIP_CHECK(hipEventRecord(events[used].second, st));
+        ++used;
     }
-    double ms() const {
-        if (!used) return 0.0;
-        float t = 0;
-        if (hipEventElapsedTime(&t, a, b) != hipSuccess) return 0.0;
-        return t;
+    double ms() const {                            // sum over the launches since reset()
+        double sum = 0.0;
+        for (size_t i = 0; i < used; ++i) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, events[i].first, events[i].second) == hipSuccess) sum += t;
+        }
+        return sum;
     }
+    size_t launches() const { return used; }
 };
 
 }  // namespace rsq
@@ -131,11 +142,18 @@ struct DeviceUploader : Uploader {
 struct rsq_sim : SimState {
     int device = 0;
     DeviceUploader up;
-    // workspace of the hot path (grow-only)
-    DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
-    DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
-    DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
-    DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, units, cursors (one small buffer); the sorted items
+    // workspace of the hot path (grow-only): two sets, so that the sieve of one sub-range of a call can run beside the FASTQ text of the one before it
+    struct Workspace {
+        DevBuf fvars;                  // FragmentVar per fragment (variants of any kind)
+        DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
+        DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
+        DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, counters (one small buffer); the sorted items
+        hipEvent_t text_done = nullptr;      // the text stage that last read this set's arrays
+    } ws[2];
+    DevBuf totals;                 // [sub-ranges + 1][2] bytes of FASTQ text in front of a sub-range, per file
+    Workspace *cur = &ws[0];       // the set the stage being enqueued works on
+    hipStream_t side[2] = {nullptr, nullptr};      // the sieve's and the text's stream of a pipelined call
+    hipEvent_t ev_call = nullptr, ev_fill = nullptr, ev_emit = nullptr;
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
@@ -331,23 +349,25 @@ static void create_sys_error_profile(rsq_sim &s, uint64_t seed, const char *path
 }
 
 // --------------------------------------------------------------------------------------------- hot path
-static void exclusive_scan(rsq_sim &s, const uint32_t *in, uint64_t n, uint64_t *out, hipStream_t st) {
+// out[i] = *init + in[0] + ... + in[i-1] for i = 0 .. n (init nullptr: 0); the total also goes to *total_out if given
+static void exclusive_scan(rsq_sim &s, const uint32_t *in, uint64_t n, uint64_t *out, hipStream_t st, const uint64_t *init = nullptr, uint64_t *total_out = nullptr) {
     const uint32_t tiles = cdiv(n, kScanTile);
-    s.tile_sums.reserve((size_t)(tiles + 1) * 8);
-    s.scan_total.reserve(8);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanTilesBlock), 0, st, s.tile_sums.as<uint64_t>(), tiles, s.scan_total.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.tile_sums.as<uint64_t>(), s.scan_total.as<uint64_t>(), out);
+    s.cur->tile_sums.reserve((size_t)(tiles + 1) * 8);
+    s.cur->scan_total.reserve(8);
+    uint64_t *total = total_out ? total_out : s.cur->scan_total.as<uint64_t>();
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.cur->tile_sums.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanTilesBlock), 0, st, s.cur->tile_sums.as<uint64_t>(), tiles, total, init);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, st, in, n, s.cur->tile_sums.as<uint64_t>(), total, out);
     HIP_CHECK(hipGetLastError());
 }
 
 static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
     const uint64_t pitch = (n_reads + 63u) & ~(uint64_t)63u;            // word rows start on 256-byte boundaries
-    s.raw_seq.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
-    s.raw_qual.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
-    s.raw_ops.reserve((uint64_t)s.ops_stride * pitch * 4 + 16);
-    s.raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
-    return RawLayout{s.raw_seq.as<uint32_t>(), s.raw_qual.as<uint32_t>(), s.raw_ops.as<uint32_t>(), s.raw_meta.as<ReadMeta>(), pitch, nullptr, 0, nullptr};
+    s.cur->raw_seq.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
+    s.cur->raw_qual.reserve((uint64_t)(s.read_stride / 4u) * pitch * 4 + 16);
+    s.cur->raw_ops.reserve((uint64_t)s.ops_stride * pitch * 4 + 16);
+    s.cur->raw_meta.reserve(n_reads * sizeof(ReadMeta) + 16);
+    return RawLayout{s.cur->raw_seq.as<uint32_t>(), s.cur->raw_qual.as<uint32_t>(), s.cur->raw_ops.as<uint32_t>(), s.cur->raw_meta.as<ReadMeta>(), pitch, nullptr, 0, nullptr};
 }
 
 // Reads binned by tile (the LDS plan holds one tile per image): keys, histogram, the bins' places and units, the scatter.  n_keys = n_tiles (pairs:
@@ -358,24 +378,24 @@ static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, h
                                 const FragmentVar *fvars = nullptr) {
     if (n_items >= 0xFFFFFFFFull) throw Error("more than 2^32 reads in one call of a profile with tiles: use smaller block ranges");
     const uint32_t n_bins = 2 * s.dev.n_tiles;
-    s.bin_keys.reserve(n_items * 2 + 16);
-    s.bin_perm.reserve(n_items * 4 + 16);
+    s.cur->bin_keys.reserve(n_items * 2 + 16);
+    s.cur->bin_perm.reserve(n_items * 4 + 16);
     // [hist n_keys][cursor n_keys][bin_first n_bins][bin_count n_bins][next_chunk n_bins][workers n_bins][chunk_ptr n_bins + 1]
     const size_t words = 2 * (size_t)n_keys + 5 * (size_t)n_bins + 1;
-    s.bin_small.reserve(words * 4 + 16);
-    uint32_t *hist = s.bin_small.as<uint32_t>(), *cursor = hist + n_keys, *bin_first = cursor + n_keys, *bin_count = bin_first + n_bins, *next_chunk = bin_count + n_bins,
+    s.cur->bin_small.reserve(words * 4 + 16);
+    uint32_t *hist = s.cur->bin_small.as<uint32_t>(), *cursor = hist + n_keys, *bin_first = cursor + n_keys, *bin_count = bin_first + n_bins, *next_chunk = bin_count + n_bins,
              *workers = next_chunk + n_bins, *chunk_ptr = workers + n_bins;
     HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)n_keys * 4, st));
     s.timers["bin_tiles"].start(st);
-    count_keys(s.bin_keys.as<uint16_t>(), hist);
+    count_keys(s.cur->bin_keys.as<uint16_t>(), hist);
     hipLaunchKernelGGL(k_bins_plan, dim3(1), dim3(1024), 0, st, hist, n_keys, n_bins, bin_first, bin_count, cursor, chunk_ptr, next_chunk, workers);
-    if (frags) s.bin_frags.reserve(n_items * sizeof(Fragment) + 16);
-    if (fvars) s.bin_fvars.reserve(n_items * sizeof(FragmentVar) + 16);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n_items, kBinBlock * kBinItemsPerThread)), dim3(kBinBlock), 0, st, s.bin_keys.as<uint16_t>(), n_items, n_keys, cursor,
-                       s.bin_perm.as<uint32_t>(), frags, fvars, s.bin_frags.as<Fragment>(), s.bin_fvars.as<FragmentVar>());
+    if (frags) s.cur->bin_frags.reserve(n_items * sizeof(Fragment) + 16);
+    if (fvars) s.cur->bin_fvars.reserve(n_items * sizeof(FragmentVar) + 16);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(cdiv(n_items, kBinBlock * kBinItemsPerThread)), dim3(kBinBlock), 0, st, s.cur->bin_keys.as<uint16_t>(), n_items, n_keys, cursor,
+                       s.cur->bin_perm.as<uint32_t>(), frags, fvars, s.cur->bin_frags.as<Fragment>(), s.cur->bin_fvars.as<FragmentVar>());
     s.timers["bin_tiles"].stop(st);
     HIP_CHECK(hipGetLastError());
-    return FillBins{s.bin_perm.as<uint32_t>(), bin_first, bin_count, chunk_ptr, next_chunk, workers, n_bins, s.bin_frags.as<Fragment>(), s.bin_fvars.as<FragmentVar>()};
+    return FillBins{s.cur->bin_perm.as<uint32_t>(), bin_first, bin_count, chunk_ptr, next_chunk, workers, n_bins, s.cur->bin_frags.as<Fragment>(), s.cur->bin_fvars.as<FragmentVar>()};
 }
 template <class Kernel>
 static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kernel kernel) {
@@ -403,11 +423,11 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
         }, frags, fvars);
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_reads<MASK, VAR, BINNED>);
     const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2);
-    s.fill_counters.reserve(8);
-    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
+    s.cur->fill_counters.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.sizes.as<uint32_t>(),
-                       s.fill_counters.as<uint32_t>(), fvars, bins);
+    hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
+                       s.cur->fill_counters.as<uint32_t>(), fvars, bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;
@@ -427,10 +447,10 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
         });
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED>);
     const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1);
-    s.fill_counters.reserve(8);
-    HIP_CHECK(hipMemsetAsync(s.fill_counters.as<uint32_t>(), 0, 8, st));
+    s.cur->fill_counters.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.fill_counters.as<uint32_t>(), bins);
+    hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;
@@ -474,26 +494,25 @@ static const uint32_t *launch_fill_records(rsq_sim &s, const RecordJob &job, con
     throw Error("no k_fill_records instantiation for " + std::to_string(mask) + " quads");
 }
 
-// reads + FASTQ text of n_pairs pairs (fragments on the device, or adapter-only pairs when frags == nullptr)
-static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap,
-                          size_t *r2_len, hipStream_t st, const FragmentVar *fvars = nullptr) {
-    *r1_len = *r2_len = 0;
-    if (!n_pairs) return RSQ_OK;
+// ---- the stages of one (sub-)range; they work on the simulator's current workspace (s.cur)
+// reads of n_pairs pairs into the raw arrays (fragments on the device, or adapter-only pairs when frags == nullptr) and their record sizes
+struct ReadsDone {
+    RawLayout raw;
+    const uint32_t *row_order;
+};
+static ReadsDone reads_stage(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, hipStream_t st, const FragmentVar *fvars) {
     RawLayout raw = raw_layout(s, 2 * n_pairs);
-    const dim3 grid(cdiv(n_pairs, kFormatRecords), 2), block(64);
-    s.sizes.reserve(2 * n_pairs * 4 + 16);
-    s.off_r1.reserve((n_pairs + 1) * 8);
-    s.off_r2.reserve((n_pairs + 1) * 8);
+    s.cur->sizes.reserve(2 * n_pairs * 4 + 16);
     if (frags && s.dev.meth_ptr && !fvars) {                         // --methylation: CTConversion of both mates' templates first
-        s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
-        raw.templates = s.templates.as<uint64_t>();
+        s.cur->templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
+        raw.templates = s.cur->templates.as<uint64_t>();
         raw.template_words = s.template_words;
         hipLaunchKernelGGL(k_methylation_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, n_pairs, raw);
         HIP_CHECK(hipGetLastError());
     }
     if (frags && fvars) {                                            // variants of any kind: both mates' templates with the allele's variants
-        s.templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
-        raw.templates = s.templates.as<uint64_t>();
+        s.cur->templates.reserve(2 * n_pairs * s.template_words * 8 + 16);
+        raw.templates = s.cur->templates.as<uint64_t>();
         raw.template_words = s.template_words;
         s.timers["variant_templates"].start(st);
         hipLaunchKernelGGL(k_variant_templates, dim3(cdiv(2 * n_pairs, 256)), dim3(256), 0, st, s.dev, frags, fvars, n_pairs, raw);
@@ -501,29 +520,45 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
         HIP_CHECK(hipGetLastError());
     }
     const uint32_t *row_order = launch_fill_reads(s, frags, n_pairs, adapter_first, raw, st, fvars);
+    return ReadsDone{raw, row_order};
+}
+// FASTQ text of the pairs of reads_stage: their offsets continue at totals[2 * part] / [2 * part + 1] (bytes of text in front of this part, per
+// file), where the part ends goes to totals[2 * (part + 1)] / [.. + 1].  The kernel refuses to write past the caller's capacity.
+static void text_stage(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const ReadsDone &rd, char *r1, size_t r1_cap, char *r2, size_t r2_cap,
+                       uint32_t part, hipStream_t st, const FragmentVar *fvars) {
+    rsq_sim::Workspace &w = *s.cur;
+    w.off_r1.reserve((n_pairs + 1) * 8);
+    w.off_r2.reserve((n_pairs + 1) * 8);
+    uint64_t *totals = s.totals.as<uint64_t>();
     s.timers["scan"].start(st);
-    exclusive_scan(s, s.sizes.as<uint32_t>(), n_pairs, s.off_r1.as<uint64_t>(), st);
-    exclusive_scan(s, s.sizes.as<uint32_t>() + n_pairs, n_pairs, s.off_r2.as<uint64_t>(), st);
+    exclusive_scan(s, w.sizes.as<uint32_t>(), n_pairs, w.off_r1.as<uint64_t>(), st, totals + 2 * part, totals + 2 * (part + 1));
+    exclusive_scan(s, w.sizes.as<uint32_t>() + n_pairs, n_pairs, w.off_r2.as<uint64_t>(), st, totals + 2 * part + 1, totals + 2 * (part + 1) + 1);
     s.timers["scan"].stop(st);
-    // the kernel itself refuses to write past the caller's capacity; the host learns the sizes with the final synchronisation
+    const dim3 grid(cdiv(n_pairs, kFormatRecords), 2), block(64);
     s.timers["format_write"].start(st);
-    if (row_order)
-        hipLaunchKernelGGL(k_format_write<true>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
-                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, row_order);
+    if (rd.row_order)
+        hipLaunchKernelGGL(k_format_write<true>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
+                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, rd.row_order);
     else
-        hipLaunchKernelGGL(k_format_write<false>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.off_r1.as<uint64_t>(), s.off_r2.as<uint64_t>(), r1, r2,
+        hipLaunchKernelGGL(k_format_write<false>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
                            (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, (const uint32_t *)nullptr);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
+}
+static void reset_call_timers(rsq_sim &s) {
+    for (auto &t : s.timers) t.second.reset();
+}
+// what a call ends with: the bytes of text of `parts` parts, the variant walk's error flag; the call's streams are idle afterwards
+static int finish_call(rsq_sim &s, uint32_t parts, bool with_variants, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, hipStream_t text_stream) {
     s.mailbox[4] = 0;
-    if (frags && s.has_variants) HIP_CHECK(hipMemcpyAsync(&s.mailbox[4], s.dev.walk_error, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.off_r1.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&s.mailbox[3], s.off_r2.as<uint64_t>() + n_pairs, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    if (with_variants) HIP_CHECK(hipMemcpyAsync(&s.mailbox[4], s.dev.walk_error, 4, hipMemcpyDeviceToHost, text_stream));
+    HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.totals.as<uint64_t>() + 2 * parts, 16, hipMemcpyDeviceToHost, text_stream));
+    HIP_CHECK(hipStreamSynchronize(text_stream));
     *r1_len = s.mailbox[2];
     *r2_len = s.mailbox[3];
     if ((uint32_t)s.mailbox[4]) {
-        HIP_CHECK(hipMemsetAsync(s.dev.walk_error, 0, 4, st));
+        HIP_CHECK(hipMemsetAsync(s.dev.walk_error, 0, 4, text_stream));
+        HIP_CHECK(hipStreamSynchronize(text_stream));
         g_last_error = kWalkErrorMessage;
         return RSQ_EINVAL;
     }
@@ -533,7 +568,159 @@ static int reads_and_text(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, u
     }
     return RSQ_OK;
 }
+static void begin_totals(rsq_sim &s, uint32_t parts, hipStream_t st) {
+    s.totals.reserve((size_t)(parts + 1) * 16 + 16);
+    HIP_CHECK(hipMemsetAsync(s.totals.as<uint64_t>(), 0, 16, st));
+}
 
+// reads + FASTQ text of adapter-only pairs (Simulator::SimulateAdapterOnlyPairs, Simulator.cpp:2359-2382): one part on the caller's stream
+static int adapter_only_pairs(rsq_sim &s, uint64_t n_pairs, uint64_t adapter_first, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, hipStream_t st) {
+    *r1_len = *r2_len = 0;
+    if (!n_pairs) return RSQ_OK;
+    reset_call_timers(s);
+    s.cur = &s.ws[0];
+    begin_totals(s, 1, st);
+    const ReadsDone rd = reads_stage(s, nullptr, n_pairs, adapter_first, st, nullptr);
+    text_stage(s, nullptr, n_pairs, adapter_first, rd, r1, r1_cap, r2, r2_cap, 0, st, nullptr);
+    return finish_call(s, 1, false, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st);
+}
+
+// The sieve of one block range on the current workspace: attempt 0 is launched without waiting; collect() waits for it, and if a list overflowed
+// repeats the pass with the exact sizes (capacities come from the expected number of passing cells + 6 sigma, so that is rare).
+struct SieveRun {
+    uint32_t block_lo = 0, block_hi = 0;
+    uint64_t n_slots = 0, cand_cap = 0, hit_cap = 0, total = 0, n_cands = 0;
+    uint32_t n_hits = 0;
+    const SlotInfo *slot_table = nullptr;
+};
+static void sieve_attempt(rsq_sim &s, SieveRun &r, int attempt, uint64_t *mail, hipStream_t st) {
+    rsq_sim::Workspace &w = *s.cur;
+    const int vm = s.variants_mode;
+    if (r.cand_cap >= (1ull << 32)) throw Error("more than 2^32 sieve candidates in one call: use smaller block ranges");
+    w.cands.reserve(r.cand_cap * sizeof(SieveCand));
+    w.pairs_of.reserve(r.cand_cap * 4 + 16);
+    w.pair_off.reserve((r.cand_cap + 1) * 8);
+    w.hits.reserve(r.hit_cap * sizeof(SieveHit));
+    HIP_CHECK(hipMemsetAsync(w.hit_count.as<uint32_t>(), 0, 4, st));
+    s.timers["sieve"].start(st);
+    const uint32_t block_lo = r.block_lo, block_hi = r.block_hi;
+    const uint64_t n_slots = r.n_slots, cand_cap = r.cand_cap;
+    const dim3 ggrid(cdiv(n_slots, kSieveBlock)), gblock(kSieveBlock);
+    if (!attempt) {
+        if (2 == vm) {
+            w.slot_table.reserve(n_slots * sizeof(SlotInfo) + 16);
+            s.timers["slot_table"].start(st);
+            hipLaunchKernelGGL(k_slot_table, dim3(block_hi - block_lo), dim3(256), 0, st, s.dev, block_lo, w.slot_table.as<SlotInfo>());
+            s.timers["slot_table"].stop(st);
+            r.slot_table = w.slot_table.as<SlotInfo>();
+        }
+        s.timers["sieve_screen"].start(st);
+        if (2 == vm)
+            hipLaunchKernelGGL((k_sieve_gaps<2, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, w.counts.as<uint32_t>(), (const uint64_t *)nullptr,
+                               (SieveCand *)nullptr, cand_cap, r.slot_table);
+        else
+            hipLaunchKernelGGL((k_sieve_gaps<0, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, w.counts.as<uint32_t>(), (const uint64_t *)nullptr,
+                               (SieveCand *)nullptr, cand_cap, r.slot_table);
+        s.timers["sieve_screen"].stop(st);
+        exclusive_scan(s, w.counts.as<uint32_t>(), n_slots, w.offsets.as<uint64_t>(), st);
+    }
+    const SlotInfo *slot_table = r.slot_table;
+    if (2 == vm)
+        hipLaunchKernelGGL((k_sieve_gaps<2, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, w.offsets.as<uint64_t>(),
+                           w.cands.as<SieveCand>(), cand_cap, slot_table);
+    else
+        hipLaunchKernelGGL((k_sieve_gaps<0, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, w.offsets.as<uint64_t>(),
+                           w.cands.as<SieveCand>(), cand_cap, slot_table);
+    const dim3 fgrid(cdiv(cand_cap, kSieveBlock)), fblock(kSieveBlock);
+#define RSQ_FINISH(VM, CAP)                                                                                                                                   \
+    hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), fgrid, fblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, w.offsets.as<uint64_t>(), w.cands.as<SieveCand>(),  \
+                       cand_cap, w.pairs_of.as<uint32_t>(), w.hits.as<SieveHit>(), (uint32_t)std::min<uint64_t>(r.hit_cap, 0xFFFFFFFFull), w.hit_count.as<uint32_t>(), slot_table)
+    if (2 == vm && s.num_alleles <= 8) RSQ_FINISH(2, 8);        // few alleles: the cell's (allele, strand) slots stay in registers
+    else if (2 == vm) RSQ_FINISH(2, kMaxDevAlleles);
+    else if (1 == vm) RSQ_FINISH(1, 8);                         // allele copies exist for at most eight alleles
+    else RSQ_FINISH(0, 1);
+#undef RSQ_FINISH
+    s.timers["sieve"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    exclusive_scan(s, w.pairs_of.as<uint32_t>(), cand_cap, w.pair_off.as<uint64_t>(), st);
+    mail[1] = 0;
+    HIP_CHECK(hipMemcpyAsync(&mail[0], w.pair_off.as<uint64_t>() + cand_cap, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&mail[1], w.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&mail[5], w.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
+}
+// false: the range has no start position slots at all
+static bool sieve_launch(rsq_sim &s, SieveRun &r, uint32_t block_lo, uint32_t block_hi, uint64_t *mail, hipStream_t st) {
+    rsq_sim::Workspace &w = *s.cur;
+    const int vm = s.variants_mode;
+    r = SieveRun{};
+    r.block_lo = block_lo;
+    r.block_hi = block_hi;
+    r.n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
+    if (2 == vm && block_hi > block_lo) {                            // plus the starts inside inserted bases of these blocks
+        uint32_t ptr[2];
+        HIP_CHECK(hipMemcpy(&ptr[0], s.dev.block_extra_ptr + block_lo, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&ptr[1], s.dev.block_extra_ptr + block_hi, 4, hipMemcpyDeviceToHost));
+        r.n_slots += ptr[1] - ptr[0];
+    }
+    if (!r.n_slots) return false;
+    if (r.n_slots >= (1ull << 32) - kSieveBlock)                     // slot indices are 32 bits wide inside one call
+        throw Error("block range too large for one call: at most " + std::to_string(((1ull << 32) - kSieveBlock) / kBlockSize - 1) + " blocks");
+    w.counts.reserve(r.n_slots * 4 + 16);
+    w.offsets.reserve((r.n_slots + 1) * 8);
+    w.hit_count.reserve(8);
+    // capacity of the candidate list: the cells expected to pass the zero threshold plus six standard deviations; of the hit list:
+    // cells with fragments <= candidates (with variants a cell has one record per two chosen (allele, strand) slots)
+    const double expected_cands = s.expected_passing * (double)r.n_slots;
+    r.cand_cap = std::max<uint64_t>(w.cands.bytes() / sizeof(SieveCand), (uint64_t)(expected_cands + 6.0 * sqrt(expected_cands + 1.0)) + 65536);
+    r.hit_cap = std::max<uint64_t>(w.hits.bytes() / sizeof(SieveHit), 0 == vm ? r.cand_cap : r.cand_cap + r.cand_cap / 4);
+    sieve_attempt(s, r, 0, mail, st);
+    return true;
+}
+static void sieve_collect(rsq_sim &s, SieveRun &r, uint64_t *mail, hipStream_t st) {
+    for (int attempt = 0;; ++attempt) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        r.total = mail[0];
+        r.n_hits = (uint32_t)mail[1];
+        r.n_cands = mail[5];
+        if (r.n_cands <= r.cand_cap && r.n_hits <= r.hit_cap) return;
+        if (attempt >= 2) throw Error("sieve lists overflowed three times");
+        // the candidate count is exact; the hit count is exact once the candidates fit, before that it is scaled up with them
+        const double grow = r.n_cands > r.cand_cap ? (double)r.n_cands / (double)r.cand_cap : 1.0;
+        if (r.n_hits > r.hit_cap || grow > 1.0) r.hit_cap = std::max<uint64_t>(r.hit_cap, (uint64_t)((double)r.n_hits * grow * 1.25) + 65536);
+        r.cand_cap = std::max(r.cand_cap, r.n_cands + 65536);
+        sieve_attempt(s, r, attempt + 1, mail, st);
+    }
+}
+static void sieve_emit(rsq_sim &s, const SieveRun &r, hipStream_t st) {
+    rsq_sim::Workspace &w = *s.cur;
+    w.frags.reserve(r.total * sizeof(Fragment) + 16);
+    s.timers["sieve_emit"].start(st);
+    if (2 == s.variants_mode) {
+        w.fvars.reserve(r.total * sizeof(FragmentVar) + 16);
+        hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(r.n_hits, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, w.hits.as<SieveHit>(), r.n_hits, w.offsets.as<uint64_t>(),
+                           w.pair_off.as<uint64_t>(), w.frags.as<Fragment>(), w.fvars.as<FragmentVar>(), w.slot_table.as<SlotInfo>());
+    } else
+        hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(r.n_hits, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, w.hits.as<SieveHit>(), r.n_hits, w.offsets.as<uint64_t>(),
+                           w.pair_off.as<uint64_t>(), w.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
+    s.timers["sieve_emit"].stop(st);
+    HIP_CHECK(hipGetLastError());
+}
+
+// SimulateFromGivenBlock + CreateReads + Output for the blocks [block_lo, block_hi) (Simulator.cpp:2249-2357, 634-721, 215-230).  Blocks are independent
+// (:2384-2401), so a range can be cut into `parts` sub-ranges that move through three stages -- sieve, reads, FASTQ text -- on three streams: the read
+// kernel owns every CU while it runs (160 KB of LDS, all vector registers), so nothing overlaps IT; the sieve of part k + 1 and the text of part k run side
+// by side behind it.  That does not pay (pairs_parts), so a call is one part unless option overlap asks for more; what stays is the stage structure.
+//   reads(k) waits for: fragments of part k (sieve stream), the text of part k - 2 (same workspace);
+//   sieve(k + 1) waits for: reads(k) launched and done (else it would only take CUs from it), the text of part k - 1 (same workspace);
+//   text(k) waits for reads(k).
+// The host meets the sieve once per part (list sizes decide the next launches), everything else is ordered by events.
+static uint32_t pairs_parts(uint32_t n_blocks) {
+    // Measured (bench workload, 10 M pairs): 1 part 81.6 ms per step, 2 parts 83.0, 4 parts 84.3, 8 parts 87.7 -- the sieve's candidate kernel and the
+    // formatter both live on the memory system (gathers in the 24 MB surrounding table; 15 GB of raw arrays and text), so side by side each takes nearly as long
+    // as the two in a row, and every part adds a read-kernel tail.  One part unless asked (option overlap = n, tests).
+    const int64_t opt = options().overlap;
+    return opt > 0 ? (uint32_t)std::min<int64_t>(opt, std::max<uint32_t>(n_blocks, 1u)) : 1u;
+}
 static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, uint64_t *n_pairs,
                      rsq_fragment *frags_out, size_t frags_cap, hipStream_t st) {
     if (!s.prepared || !s.has_ref) {
@@ -547,112 +734,87 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     HIP_CHECK(hipSetDevice(s.device));
     *n_pairs = 0;
     *r1_len = *r2_len = 0;
+    if (block_lo == block_hi) return RSQ_OK;
+    reset_call_timers(s);
     const int vm = s.variants_mode;
-    uint64_t n_slots = (uint64_t)(block_hi - block_lo) * kBlockSize;
-    if (2 == vm && block_hi > block_lo) {                            // plus the starts inside inserted bases of these blocks
-        uint32_t ptr[2];
-        HIP_CHECK(hipMemcpy(&ptr[0], s.dev.block_extra_ptr + block_lo, 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&ptr[1], s.dev.block_extra_ptr + block_hi, 4, hipMemcpyDeviceToHost));
-        n_slots += ptr[1] - ptr[0];
+    const uint32_t parts = pairs_parts(block_hi - block_lo);
+    // one part: everything on the caller's stream; more: the reads stay there, sieve and text get their own
+    hipStream_t s_reads = st, s_sieve = parts > 1 ? s.side[0] : st, s_text = parts > 1 ? s.side[1] : st;
+    if (parts > 1) {                                                 // the side streams begin where the caller's stream is
+        HIP_CHECK(hipEventRecord(s.ev_call, st));
+        HIP_CHECK(hipStreamWaitEvent(s_sieve, s.ev_call, 0));
+        HIP_CHECK(hipStreamWaitEvent(s_text, s.ev_call, 0));
     }
-    if (!n_slots) return RSQ_OK;
-    if (n_slots >= (1ull << 32) - kSieveBlock) {                     // slot indices are 32 bits wide inside one call
-        g_last_error = "block range too large for one call: at most " + std::to_string(((1ull << 32) - kSieveBlock) / kBlockSize - 1) + " blocks";
-        return RSQ_EINVAL;
-    }
-    s.counts.reserve(n_slots * 4 + 16);
-    s.offsets.reserve((n_slots + 1) * 8);
-    s.hit_count.reserve(8);
-    // capacity of the candidate list: the cells expected to pass the zero threshold plus six standard deviations; of the hit list:
-    // cells with fragments <= candidates (with variants a cell has one record per two chosen (allele, strand) slots)
-    const double expected_cands = s.expected_passing * (double)n_slots;
-    uint64_t cand_cap = std::max<uint64_t>(s.cands.bytes() / sizeof(SieveCand), (uint64_t)(expected_cands + 6.0 * sqrt(expected_cands + 1.0)) + 65536);
-    uint64_t hit_cap = std::max<uint64_t>(s.hits.bytes() / sizeof(SieveHit), 0 == vm ? cand_cap : cand_cap + cand_cap / 4);
-    uint64_t total = 0, n_cands = 0;
-    uint32_t n_hits = 0;
-    const SlotInfo *slot_table = nullptr;
-    for (int attempt = 0;; ++attempt) {
-        if (cand_cap >= (1ull << 32)) throw Error("more than 2^32 sieve candidates in one call: use smaller block ranges");
-        s.cands.reserve(cand_cap * sizeof(SieveCand));
-        s.pairs_of.reserve(cand_cap * 4 + 16);
-        s.pair_off.reserve((cand_cap + 1) * 8);
-        s.hits.reserve(hit_cap * sizeof(SieveHit));
-        HIP_CHECK(hipMemsetAsync(s.hit_count.as<uint32_t>(), 0, 4, st));
-        s.timers["sieve"].start(st);
-        const dim3 ggrid(cdiv(n_slots, kSieveBlock)), gblock(kSieveBlock);
-        if (!attempt) {
-            if (2 == vm) {
-                s.slot_table.reserve(n_slots * sizeof(SlotInfo) + 16);
-                s.timers["slot_table"].start(st);
-                hipLaunchKernelGGL(k_slot_table, dim3(block_hi - block_lo), dim3(256), 0, st, s.dev, block_lo, s.slot_table.as<SlotInfo>());
-                s.timers["slot_table"].stop(st);
-                slot_table = s.slot_table.as<SlotInfo>();
+    begin_totals(s, parts, s_text);
+    struct Abort {                                                   // an error in the middle: nothing of the call may still run when it returns
+        rsq_sim &s;
+        bool armed = true;
+        ~Abort() {
+            if (armed) (void)hipDeviceSynchronize();
+        }
+    } abort_guard{s};
+    auto part_range = [&](uint32_t k) {
+        const uint64_t n = block_hi - block_lo;
+        return std::pair<uint32_t, uint32_t>(block_lo + (uint32_t)(n * k / parts), block_lo + (uint32_t)(n * (k + 1) / parts));
+    };
+    SieveRun run[2];
+    bool has_slots[2] = {false, false};
+    s.cur = &s.ws[0];
+    has_slots[0] = sieve_launch(s, run[0], part_range(0).first, part_range(0).second, s.mailbox + 0, s_sieve);
+    uint64_t total_pairs = 0;
+    static_assert(sizeof(rsq_fragment) == sizeof(Fragment), "ABI fragment layout");
+    for (uint32_t k = 0; k < parts; ++k) {
+        const uint32_t p = k & 1u;
+        s.cur = &s.ws[p];
+        SieveRun &r = run[p];
+        uint64_t *mail = s.mailbox + 8 * p;
+        if (has_slots[p]) sieve_collect(s, r, mail, s_sieve);
+        const uint64_t n = has_slots[p] ? r.total : 0;
+        const Fragment *frags = s.cur->frags.as<Fragment>();
+        const FragmentVar *fvars = nullptr;
+        if (n) {
+            sieve_emit(s, r, s_sieve);
+            frags = s.cur->frags.as<Fragment>();
+            fvars = 2 == vm ? s.cur->fvars.as<FragmentVar>() : nullptr;
+            if (frags_out) {
+                if (frags_cap < total_pairs + n) {
+                    g_last_error = "fragment buffer too small: need at least " + std::to_string(total_pairs + n) + " records";
+                    return RSQ_ENOSPC;
+                }
+                HIP_CHECK(hipMemcpyAsync(frags_out + total_pairs, frags, n * sizeof(Fragment), hipMemcpyDeviceToDevice, s_sieve));
             }
-            s.timers["sieve_screen"].start(st);
-            if (2 == vm)
-                hipLaunchKernelGGL((k_sieve_gaps<2, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr,
-                                   (SieveCand *)nullptr, cand_cap, slot_table);
-            else
-                hipLaunchKernelGGL((k_sieve_gaps<0, false>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.counts.as<uint32_t>(), (const uint64_t *)nullptr,
-                                   (SieveCand *)nullptr, cand_cap, slot_table);
-            s.timers["sieve_screen"].stop(st);
-            exclusive_scan(s, s.counts.as<uint32_t>(), n_slots, s.offsets.as<uint64_t>(), st);
+            if (parts > 1) {
+                HIP_CHECK(hipEventRecord(s.ev_emit, s_sieve));
+                HIP_CHECK(hipStreamWaitEvent(s_reads, s.ev_emit, 0));
+                if (k >= 2) HIP_CHECK(hipStreamWaitEvent(s_reads, s.cur->text_done, 0));       // the raw arrays of this workspace were last read by text(k - 2)
+            }
+            const ReadsDone rd = reads_stage(s, frags, n, 0, s_reads, fvars);
+            if (parts > 1) {
+                HIP_CHECK(hipEventRecord(s.ev_fill, s_reads));
+                HIP_CHECK(hipStreamWaitEvent(s_text, s.ev_fill, 0));
+            }
+            text_stage(s, frags, n, 0, rd, r1, r1_cap, r2, r2_cap, k, s_text, fvars);
+        } else {                                                     // no pairs in this part: its text ends where it begins
+            HIP_CHECK(hipMemcpyAsync(s.totals.as<uint64_t>() + 2 * (k + 1), s.totals.as<uint64_t>() + 2 * k, 16, hipMemcpyDeviceToDevice, s_text));
         }
-        if (2 == vm)
-            hipLaunchKernelGGL((k_sieve_gaps<2, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(),
-                               s.cands.as<SieveCand>(), cand_cap, slot_table);
-        else
-            hipLaunchKernelGGL((k_sieve_gaps<0, true>), ggrid, gblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, (uint32_t *)nullptr, s.offsets.as<uint64_t>(),
-                               s.cands.as<SieveCand>(), cand_cap, slot_table);
-        const dim3 fgrid(cdiv(cand_cap, kSieveBlock)), fblock(kSieveBlock);
-#define RSQ_FINISH(VM, CAP)                                                                                                                                   \
-    hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), fgrid, fblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, s.offsets.as<uint64_t>(), s.cands.as<SieveCand>(),  \
-                       cand_cap, s.pairs_of.as<uint32_t>(), s.hits.as<SieveHit>(), (uint32_t)std::min<uint64_t>(hit_cap, 0xFFFFFFFFull), s.hit_count.as<uint32_t>(), slot_table)
-        if (2 == vm && s.num_alleles <= 8) RSQ_FINISH(2, 8);        // few alleles: the cell's (allele, strand) slots stay in registers
-        else if (2 == vm) RSQ_FINISH(2, kMaxDevAlleles);
-        else if (1 == vm) RSQ_FINISH(1, 8);                         // allele copies exist for at most eight alleles
-        else RSQ_FINISH(0, 1);
-#undef RSQ_FINISH
-        s.timers["sieve"].stop(st);
-        HIP_CHECK(hipGetLastError());
-        exclusive_scan(s, s.pairs_of.as<uint32_t>(), cand_cap, s.pair_off.as<uint64_t>(), st);
-        s.mailbox[1] = 0;
-        HIP_CHECK(hipMemcpyAsync(&s.mailbox[0], s.pair_off.as<uint64_t>() + cand_cap, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(&s.mailbox[1], s.hit_count.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(&s.mailbox[5], s.offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        total = s.mailbox[0];
-        n_hits = (uint32_t)s.mailbox[1];
-        n_cands = s.mailbox[5];
-        if (n_cands <= cand_cap && n_hits <= hit_cap) break;
-        if (attempt >= 2) throw Error("sieve lists overflowed three times");
-        // the candidate count is exact; the hit count is exact once the candidates fit, before that it is scaled up with them
-        const double grow = n_cands > cand_cap ? (double)n_cands / (double)cand_cap : 1.0;
-        if (n_hits > hit_cap || grow > 1.0) hit_cap = std::max<uint64_t>(hit_cap, (uint64_t)((double)n_hits * grow * 1.25) + 65536);
-        cand_cap = std::max(cand_cap, n_cands + 65536);
-    }
-    *n_pairs = total;
-    if (!total) return RSQ_OK;
-    s.frags.reserve(total * sizeof(Fragment) + 16);
-    s.timers["sieve_emit"].start(st);
-    if (2 == vm) {
-        s.fvars.reserve(total * sizeof(FragmentVar) + 16);
-        hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.pair_off.as<uint64_t>(), s.frags.as<Fragment>(), s.fvars.as<FragmentVar>(), s.slot_table.as<SlotInfo>());
-    } else
-        hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(n_hits, 256)), dim3(256), 0, st, s.dev, block_lo, block_hi, s.hits.as<SieveHit>(), n_hits, s.offsets.as<uint64_t>(),
-                           s.pair_off.as<uint64_t>(), s.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
-    s.timers["sieve_emit"].stop(st);
-    HIP_CHECK(hipGetLastError());
-    if (frags_out) {
-        if (frags_cap < total) {
-            g_last_error = "fragment buffer too small: need " + std::to_string(total) + " records";
-            return RSQ_ENOSPC;
+        if (parts > 1) HIP_CHECK(hipEventRecord(s.cur->text_done, s_text));
+        total_pairs += n;
+        if (k + 1 < parts) {                                         // the next part's sieve, on the other workspace
+            s.cur = &s.ws[p ^ 1u];
+            if (n) HIP_CHECK(hipStreamWaitEvent(s_sieve, s.ev_fill, 0));
+            if (k >= 1) HIP_CHECK(hipStreamWaitEvent(s_sieve, s.cur->text_done, 0));
+            has_slots[p ^ 1u] = sieve_launch(s, run[p ^ 1u], part_range(k + 1).first, part_range(k + 1).second, s.mailbox + 8 * (p ^ 1u), s_sieve);
         }
-        static_assert(sizeof(rsq_fragment) == sizeof(Fragment), "ABI fragment layout");
-        HIP_CHECK(hipMemcpyAsync(frags_out, s.frags.as<Fragment>(), total * sizeof(Fragment), hipMemcpyDeviceToDevice, st));
     }
-    return reads_and_text(s, s.frags.as<Fragment>(), total, 0, r1, r1_cap, r1_len, r2, r2_cap, r2_len, st, 2 == vm ? s.fvars.as<FragmentVar>() : nullptr);
+    *n_pairs = total_pairs;
+    const int rc = total_pairs ? finish_call(s, parts, s.has_variants, r1, r1_cap, r1_len, r2, r2_cap, r2_len, s_text) : (int)RSQ_OK;
+    if (parts > 1) {                                                 // the caller's stream continues behind the whole call
+        HIP_CHECK(hipStreamSynchronize(s_sieve));
+        HIP_CHECK(hipStreamSynchronize(s_text));
+        HIP_CHECK(hipStreamSynchronize(s_reads));
+    } else HIP_CHECK(hipStreamSynchronize(st));
+    abort_guard.armed = false;
+    return rc;
 }
 
 // seqToIllumina's FASTQ text on the device (Simulator.cpp:2497-2504: "@{id} {CIGAR} E{errors}", bases, "+", qualities): sizes, then the
@@ -951,7 +1113,12 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 8 * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 16 * sizeof(uint64_t), hipHostMallocDefault));
+        for (hipStream_t &st : s->side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (rsq_sim::Workspace &w : s->ws) HIP_CHECK(hipEventCreateWithFlags(&w.text_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_call, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_fill, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_emit, hipEventDisableTiming));
         s->force_fill_mode = (int)options().fill_mode;
         s->prof = p->p;
         pack_tables(*s, s->up);
@@ -967,6 +1134,12 @@ void rsq_sim_free(rsq_sim *s) {
     if (s) {
         (void)hipSetDevice(s->device);
         if (s->mailbox) (void)hipHostFree(s->mailbox);
+        for (hipStream_t st : s->side)
+            if (st) (void)hipStreamDestroy(st);
+        for (rsq_sim::Workspace &w : s->ws)
+            if (w.text_done) (void)hipEventDestroy(w.text_done);
+        for (hipEvent_t e : {s->ev_call, s->ev_fill, s->ev_emit})
+            if (e) (void)hipEventDestroy(e);
     }
     delete s;
 }
@@ -1182,7 +1355,7 @@ int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_
     REQUIRE(s && r1_len && r2_len && s->prepared, "simulator not prepared");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
-        return reads_and_text(*s, nullptr, n, first, r1_dev, r1_cap, r1_len, r2_dev, r2_cap, r2_len, (hipStream_t)stream);
+        return adapter_only_pairs(*s, n, first, r1_dev, r1_cap, r1_len, r2_dev, r2_cap, r2_len, (hipStream_t)stream);
     });
 }
 
@@ -1193,20 +1366,22 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
     const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
     if (need_ops > s->ops_stride) s->ops_stride = need_ops;
     if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
+    s->cur = &s->ws[0];
+    reset_call_timers(*s);
     RawLayout raw = raw_layout(*s, n);
     // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS (binned by tile: build_fill_bins)
     if (!fill_is_binned(*s)) {
-        s->rec_flags.reserve(n * 4 + 16);
-        s->rec_index.reserve(n * 4 + 16);
-        s->rec_count.reserve(8);
-        s->offsets.reserve((n + 1) * 8);
+        s->cur->rec_flags.reserve(n * 4 + 16);
+        s->cur->rec_index.reserve(n * 4 + 16);
+        s->cur->rec_count.reserve(8);
+        s->cur->offsets.reserve((n + 1) * 8);
         const dim3 rgrid(cdiv(n, 256)), rblock(256);
-        hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->rec_flags.as<uint32_t>());
-        exclusive_scan(*s, s->rec_flags.as<uint32_t>(), n, s->offsets.as<uint64_t>(), st);
-        hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->offsets.as<uint64_t>(), s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>());
+        hipLaunchKernelGGL(k_record_flags, rgrid, rblock, 0, st, seg_dev, n, s->cur->rec_flags.as<uint32_t>());
+        exclusive_scan(*s, s->cur->rec_flags.as<uint32_t>(), n, s->cur->offsets.as<uint64_t>(), st);
+        hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->cur->offsets.as<uint64_t>(), s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
     }
-    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->rec_index.as<uint32_t>(), s->rec_count.as<uint32_t>(), n};
+    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>(), n};
     raw.order = launch_fill_records(*s, job, seg_dev, n, raw, st);
     return raw;
 }
@@ -1222,13 +1397,13 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
         hipStream_t st = (hipStream_t)stream;
         HIP_CHECK(hipSetDevice(s->device));
         const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
-        s->scan_total.reserve(8);
-        HIP_CHECK(hipMemsetAsync(s->scan_total.as<uint32_t>(), 0, 4, st));
+        s->cur->scan_total.reserve(8);
+        HIP_CHECK(hipMemsetAsync(s->cur->scan_total.as<uint32_t>(), 0, 4, st));
         hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,
-                           tile_out_dev, cigar_out_dev, cigar_stride, s->scan_total.as<uint32_t>());
+                           tile_out_dev, cigar_out_dev, cigar_stride, s->cur->scan_total.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
         uint32_t overflow = 0;
-        HIP_CHECK(hipMemcpyAsync(&overflow, s->scan_total.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&overflow, s->cur->scan_total.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (overflow) {
             g_last_error = "out_stride or cigar_stride too small for at least one record";
@@ -1249,15 +1424,15 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
         hipStream_t st = (hipStream_t)stream;
         HIP_CHECK(hipSetDevice(s->device));
         const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
-        s->sizes.reserve(n * 4 + 16);
-        s->off_r1.reserve((n + 1) * 8);
+        s->cur->sizes.reserve(n * 4 + 16);
+        s->cur->off_r1.reserve((n + 1) * 8);
         s->timers["format_write"].start(st);
-        hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, id_off_dev, s->sizes.as<uint32_t>());
-        exclusive_scan(*s, s->sizes.as<uint32_t>(), n, s->off_r1.as<uint64_t>(), st);
-        hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids_dev, id_off_dev, s->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
+        hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, id_off_dev, s->cur->sizes.as<uint32_t>());
+        exclusive_scan(*s, s->cur->sizes.as<uint32_t>(), n, s->cur->off_r1.as<uint64_t>(), st);
+        hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids_dev, id_off_dev, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
         s->timers["format_write"].stop(st);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->cur->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         *text_len = s->mailbox[2];
         if (*text_len > text_cap) {
@@ -1271,8 +1446,14 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
 int rsq_sim_last_kernel_ms(const rsq_sim *s, const char *kernel, double *ms) {
     REQUIRE(s && kernel && ms, "null argument");
     auto it = s->timers.find(kernel);
-    REQUIRE(it != s->timers.end(), "unknown kernel name or kernel not launched yet");
+    REQUIRE(it != s->timers.end() && it->second.launches(), "unknown kernel name or kernel not launched in the last call");
     *ms = it->second.ms();
+    return RSQ_OK;
+}
+int rsq_sim_last_kernel_launches(const rsq_sim *s, const char *kernel, uint32_t *launches) {
+    REQUIRE(s && kernel && launches, "null argument");
+    auto it = s->timers.find(kernel);
+    *launches = it == s->timers.end() ? 0u : (uint32_t)it->second.launches();
     return RSQ_OK;
 }
 

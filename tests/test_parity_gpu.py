@@ -92,6 +92,21 @@ def test_tiles_binned_although_they_fit(workdir, rsq_options):
     P.case_methylation(GpuBackend, workdir)
 
 
+@pytest.mark.parametrize("parts", [2, 3, 7])
+def test_pipelined_sub_ranges(workdir, parts, rsq_options):
+    """rsq_sim_pairs over a large block range runs as sub-ranges whose sieve / reads / text stages overlap on three streams (two workspaces, offsets
+    of a part continuing where the part before ended); option overlap = n forces n parts on these small cases: same fragments, same bytes,
+    also with parts that hold no pair at all (the 80-base sequence has no block with fragments), with variants, methylation and tiles"""
+    rsq_options("overlap", parts)
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+    P.case_p0_reads(GpuBackend, workdir)
+    P.case_dense_coverage(GpuBackend, workdir)
+    P.case_variants_indels(GpuBackend, workdir)
+    P.case_variants_substitutions(GpuBackend, workdir)
+    P.case_methylation(GpuBackend, workdir)
+    P.case_p0_tiles(GpuBackend, workdir, 3)
+
+
 @pytest.mark.parametrize("mode", [0])
 def test_double_precision_path(workdir, mode, rsq_options):
     """k_fill_reads<0>: every draw in double precision from HBM, the reference's recipe itself; the default of the other tests is the

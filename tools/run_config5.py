@@ -18,6 +18,10 @@ import numpy as np  # noqa: E402
 from reseq_amd import api, synth  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+# `snv`: substitutions only (the commonest kind of call set: the sieve takes the allele-copy route, k_sieve_finish<1, 8>), no methylation file; `--lib path`: another build
+snv_only = "snv" in sys.argv[2:]
+if "--lib" in sys.argv:
+    api.use_library(sys.argv[sys.argv.index("--lib") + 1])
 HUMAN = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
          101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 lengths = [max(5000, int(n * scale)) for n in HUMAN]
@@ -29,7 +33,7 @@ t0 = time.perf_counter()
 seqs = synth.make_reference(9, lengths, gc=0.41)
 synth.write_fasta(fpath, seqs)
 total = int(sum(lengths))
-n_sub, n_indel, n_regions = int(4.0e6 * scale), int(0.4e6 * scale), int(20e6 * scale)
+n_sub, n_indel, n_regions = int(4.0e6 * scale), 0 if snv_only else int(0.4e6 * scale), 0 if snv_only else int(20e6 * scale)
 names = [n.split(" ")[0] for n, _ in seqs]
 letters = np.frombuffer(b"ACGT", np.uint8)
 with open(vpath, "w") as f:
@@ -61,6 +65,8 @@ with open(bpath, "w") as f:
         L = len(codes)
         k = int(n_regions * L / total)
         starts = np.unique(rng.integers(0, L - 200, k))
+        if not len(starts):
+            continue
         starts = starts[np.concatenate(([True], np.diff(starts) > 120))]
         lens = rng.integers(1, 100, len(starts))
         meth = rng.beta(0.5, 0.5, (len(starts), 2))
@@ -79,7 +85,8 @@ t1 = time.perf_counter()
 sim = api.Simulator(prof, ref, 0)
 load_stages["create_simulator_pack_upload"] = round(time.perf_counter() - t1, 2)
 t1 = time.perf_counter()
-sim.read_methylation(bpath)
+if not snv_only:
+    sim.read_methylation(bpath)
 load_stages["methylation_bed"] = round(time.perf_counter() - t1, 2)
 t_load = time.perf_counter() - t0
 t0 = time.perf_counter()
@@ -104,7 +111,8 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
         if rc != api.RSQ_OK:
             raise SystemExit(f"rc {rc}: {api.lib().rsq_last_error().decode()}")
         for key in ("slot_table", "variant_templates", "sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"):
-            kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
+            if sim.last_kernel_launches(key):
+                kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
         n += k
         nbytes += l1 + l2
         if hi <= 48001:                                           # checksum of the first 48000 blocks only: the text is hundreds of GB at full scale
@@ -115,14 +123,15 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
 # `python tools/run_config5.py <scale> shard`: the pre-pass of the same job sharded over 2, 4, 8 ranks (the ranks' simulators in this process,
 # sharding.sharded_prepare_in_process): seconds per rank, and that a rank's blocks then simulate to the same text as after the whole pre-pass
 sharded = None
-if len(sys.argv) > 2 and sys.argv[2] == "shard":
+if "shard" in sys.argv[2:]:
     from reseq_amd import sharding
 
 
     class Rank:
         def __init__(self):
             self.sim = api.Simulator(prof, ref, 0)
-            self.sim.read_methylation(bpath)
+            if not snv_only:
+                self.sim.read_methylation(bpath)
             self.seq_len = lengths
             self.seconds = 0.0
 
@@ -175,7 +184,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "shard":
         for r in ranks:
             r.sim.close()
 
-print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU", "sharded_prepare": sharded, "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
+print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU" + (", substitutions only, no methylation" if snv_only else ""), "sharded_prepare": sharded, "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": out["batch_24000"]["pairs"] / out["batch_24000"]["gpu_s"],
