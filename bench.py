@@ -122,8 +122,43 @@ def _by_length(lines):
     return [g for n, g in groups.items() if n >= 8]
 
 
-def fastq_statistics(text):
-    """8-mer spectrum, per-position quality histogram and substitution rate by (read position, quality) of FASTQ text"""
+def error_rate_by_context(lines, codes, read_len=150, pos_bin=10):
+    """Substitution rate by (read position bin, quality) -- BASELINE.json's "error-rate-by-context" -- of the reads whose CIGAR is one run of
+    matches: the read id carries the fragment's start and end on the reference (Simulator.cpp:609-631), a mate reads the forward strand from the
+    start or the reverse strand from the end, whichever fits better.  Returns (mismatches, bases) as [position bin][quality] arrays."""
+    lut = np.full(256, 4, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    plain = b" %dM " % read_len
+    ids = [i for i in range(0, len(lines) - 3, 4) if plain in lines[i] and len(lines[i + 1]) == read_len]
+    mism, total = np.zeros((read_len // pos_bin, 64), np.int64), np.zeros((read_len // pos_bin, 64), np.int64)
+    if not ids:
+        return mism, total
+    codes = np.concatenate([codes.astype(np.uint8), np.full(read_len, 4, np.uint8)])       # fragments shorter than a read run into the adapter: not compared
+    L = len(codes) - read_len
+    for at in range(0, len(ids), 100_000):
+        part = ids[at:at + 100_000]
+        fields = [lines[i].split(b":") for i in part]
+        a, b = np.array([int(f[1]) for f in fields]), np.array([int(f[3]) for f in fields])
+        start, end = np.minimum(a, b) - 1, np.maximum(a, b)              # the id gives first and last base (1-based), swapped for fragments of the reverse strand
+        bases = lut[np.frombuffer(b"".join(lines[i + 1] for i in part), np.uint8).reshape(len(part), read_len)]
+        qual = np.frombuffer(b"".join(lines[i + 3] for i in part), np.uint8).reshape(len(part), read_len) - 33
+        k = np.arange(read_len)[None, :]
+        fwd = codes[np.minimum(start[:, None] + k, L + read_len - 1)]
+        rev = 3 - codes[np.clip(end[:, None] - 1 - k, 0, L - 1)].astype(np.int16)
+        whole = (end - start >= read_len)[:, None]                                          # the template covers the read
+        m_f, m_r = (bases != fwd) & whole, (bases != rev) & whole
+        use_f = (m_f.sum(1) <= m_r.sum(1))[:, None]
+        m = np.where(use_f, m_f, m_r)
+        cell = (k // pos_bin) * 64 + np.minimum(qual, 63)
+        total += np.bincount(cell[np.broadcast_to(whole, cell.shape)], minlength=total.size).reshape(total.shape)
+        mism += np.bincount(cell[m], minlength=total.size).reshape(total.shape)
+    return mism, total
+
+
+def fastq_statistics(text, codes=None):
+    """8-mer spectrum, per-position quality histogram and the sum of the ids' error counts (E<n>) of FASTQ text; with the reference's bases
+    also the substitution rate by (read position bin, quality)"""
     lines = text.split(b"\n")
     seqs, quals = lines[1::4], lines[3::4]
     kmers = _kmer_counts(_by_length([s for s in seqs if s]))
@@ -134,7 +169,8 @@ def fastq_statistics(text):
         for p in range(a.shape[1]):
             qhist[p] += np.bincount(np.minimum(a[:, p], 63), minlength=64)
     errors = sum(int(l.rsplit(b" E", 1)[1]) for l in lines[0::4] if l)
-    return kmers, qhist, errors
+    context = error_rate_by_context(lines, codes) if codes is not None else None
+    return kmers, qhist, errors, context
 
 
 def kl_divergence(p_counts, q_counts):
@@ -162,11 +198,18 @@ def parity_on_sample(profile_path, seqs, seed, device, oracle_text):
     _, g1, g2 = sim.pairs(1, info.total_blocks + 1)
     sim.close()
     out = {"sample": f"first {sample_bp} bp, seed {seed}", "bias_normalization_rel_diff": out_norm, "fastq_identical": bool(g1 == oracle_text[0] and g2 == oracle_text[1])}
-    kg, qg, eg = fastq_statistics(g1 + g2)
-    ko, qo, eo = fastq_statistics(oracle_text[0] + oracle_text[1])
+    kg, qg, eg, cg = fastq_statistics(g1 + g2, codes[:sample_bp])
+    ko, qo, eo, co = fastq_statistics(oracle_text[0] + oracle_text[1], codes[:sample_bp])
     out["kmer_kl"] = kl_divergence(kg, ko)
     out["quality_histogram_max_abs_diff"] = int(np.abs(qg - qo).max())
     out["error_count_diff"] = int(eg - eo)
+    # error rate by context: substitutions per base by (read position bin of 10, quality), device against oracle, over the cells with at least 1000 bases
+    (mg, tg), (mo, to) = cg, co
+    busy = (tg >= 1000) & (to >= 1000)
+    rate_g, rate_o = mg[busy] / np.maximum(tg[busy], 1), mo[busy] / np.maximum(to[busy], 1)
+    out["error_rate_by_context"] = {"cells": int(busy.sum()), "bases": int(tg.sum()), "substitutions": int(mg.sum()), "max_abs_rate_diff": float(np.abs(rate_g - rate_o).max()) if busy.any() else None,
+                                    "counts_identical": bool(np.array_equal(mg, mo) and np.array_equal(tg, to)),
+                                    "rate_by_quality_decile": [round(float(mg[:, q:q + 10].sum() / max(tg[:, q:q + 10].sum(), 1)), 6) for q in range(0, 50, 10)]}
     out["pairs"] = int(g1.count(b"\n") // 4)
     return out
 

@@ -366,6 +366,16 @@ def case_error_model_p0(backend_cls, workdir):
     assert all(len(e[0]) == 150 for e in exp)
 
 
+def case_error_model_p0_groups(backend_cls, workdir, n=7000):
+    """k_fill_records reads a record's template, dominant errors and rates in 8-byte groups held between steps: templates of 149, 150 and 151 bases (the
+    last group partly filled; the template one base short of / beyond the profile's read length) with a systematic error rate at 40 % of the positions,
+    group borders included; 3 x n records"""
+    for read_len in (149, 150, 151):
+        exp = _error_model(backend_cls, workdir, "em_p0", synth.P0, n, read_len, seed=100 + read_len, prof_seed=103741084, zero_frac=0.6)
+        assert sum(e[3] > 0 for e in exp) > n // 20                 # reads with errors
+        assert all(len(e[0]) == 150 for e in exp)
+
+
 def case_sys_error_profile_round_trip(backend_cls, workdir):
     """--writeSysError / --readSysError (Simulator.cpp:2562-2653, Simulator.h:326-335): the profile text equals the oracle's, and a
     simulation that reads it back produces the oracle's reads from the same file"""

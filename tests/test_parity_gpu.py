@@ -74,6 +74,10 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(GpuBackend, workdir)
 
 
+def test_error_model_p0_at_the_borders_of_the_eight_byte_groups(workdir):
+    P.case_error_model_p0_groups(GpuBackend, workdir)
+
+
 @pytest.mark.parametrize("n_tiles", [3, 96])
 def test_p0_with_tiles(workdir, n_tiles):
     """--tiles profiles: one tile's tables per workgroup image, reads binned by tile (k_fill_reads<MASK, VAR, true>, k_fill_records<MASK, true>)"""

@@ -125,6 +125,10 @@ def test_error_model_p0(workdir):
     P.case_error_model_p0(EmuBackend, workdir)
 
 
+def test_error_model_p0_at_the_borders_of_the_eight_byte_groups(workdir):
+    P.case_error_model_p0_groups(EmuBackend, workdir, n=600)
+
+
 def test_p0_with_tiles(workdir):
     """--tiles profiles: the LDS plan holds one tile per image (lds_stage_descriptors / ScreenTables with a tile's image_qbase)"""
     P.case_p0_tiles(EmuBackend, workdir, 3, num_pairs=700)

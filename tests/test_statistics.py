@@ -348,3 +348,229 @@ def test_indel_conditionals_of_the_product(workdir):
     results = b.error_model(rec)
     b.close()
     assert _check_indels(results, rec, arrays)[0] < 5.5
+
+
+# --------------------------------------------------------------------------------- sequence quality and read length draws
+# FillRead's first two draws (Simulator.cpp:468-531): read_len ~ ReadLength(segment, fragment length) (Simulator.h:185-198: the counts of
+# ReadLengthsByFragmentLength scanned from the longest read down) and seq_qual ~ SequenceQuality(segment, tile) given {G/C percent, mean
+# systematic error rate, fragment length / 10} of the first min(read_len, template) template bases (:480-504, rounding utilities.hpp:450,552).
+# The read length is an output.  The sequence quality is not, so the profile's quality tables are replaced by ones whose margin over the
+# sequence quality is the identity and whose other margins are flat: every base of a read then carries seq_qual as its quality.
+def _revealing_profile(workdir):
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    values = np.arange(synth.TINY["qual_from"], synth.TINY["qual_to"], dtype=np.uint32)
+    k = len(values)
+    for seg in range(2):
+        for tile in range(len(arrays["tiles.tiles"])):
+            assert np.array_equal(np.sort(arrays[f"tab.seq_quality.{seg}.{tile}.par0"]), values)
+            for base in range(4):
+                prefix = f"tab.quality.{seg}.{tile}.{base}"
+                arrays[prefix + ".par0"] = values
+                arrays[prefix + ".limits"] = np.asarray([values[0], values[-1] + 1, 0, 1, 0, 1, 0, 1], arrays[prefix + ".limits"].dtype)
+                arrays[prefix + ".dim2"] = np.concatenate([np.eye(k).ravel(), np.ones(3 * k)])
+    path = workdir / "stat_revealing_profile.rsqp"
+    write_container(path, arrays)
+    return arrays, str(path)
+
+
+def _percent(nom, den):
+    return (nom * 100 + den // 2) // den                      # utilities::Percent / Divide: round half up
+
+
+def _check_first_draws(results, rec, arrays, enforce=True):
+    tiles = {int(t): i for i, t in enumerate(arrays["tiles.tiles"])}
+    n = len(results)
+    read_len = np.array([len(r[0]) for r in results])
+    seq_qual = np.array([r[1][0] - 33 for r in results])
+    assert all(len(set(r[1])) == 1 for r in results[:2000])                # every base carries the sequence quality
+    seg, frag = rec["seg"].astype(np.int64), rec["frag_len"].astype(np.int64)
+    tile = np.array([tiles[int(r[4])] if int(r[4]) in tiles else int(r[4]) for r in results])
+    tmpl_len = rec["seqs"].shape[1]
+    seq_length = np.minimum(read_len, tmpl_len)
+    ar = np.arange(tmpl_len)[None, :] < seq_length[:, None]
+    gc = _percent((np.isin(rec["seqs"], (1, 2)) & ar).sum(1), seq_length)
+    mean_err = _percent_free_divide((rec["rate"].astype(np.int64) * ar).sum(1), seq_length)
+    worst, n_tests = 0.0, 0
+    # sequence quality: one table per (segment, tile)
+    for s in range(2):
+        for t in range(len(tiles)):
+            sel = (seg == s) & (tile == t)
+            table = _table(arrays, f"seq_quality.{s}.{t}")
+            states = np.stack([gc[sel], mean_err[sel], frag[sel] // 10], axis=1)
+            p, ok = _conditionals(table, states)
+            assert ok.all()
+            col_of = {int(v): c for c, v in enumerate(table[0])}
+            col = np.asarray([col_of[int(v)] for v in seq_qual[sel]])
+            assert (p[np.arange(len(col)), col] > 0).all()
+            for g in (np.zeros(len(col), np.int64), states[:, 0] // 10, states[:, 1], states[:, 2] // 2):
+                z = _z_scores(p, col, g - g.min())
+                if len(z):
+                    worst = max(worst, float(np.abs(z).max()))
+                    n_tests += len(z)
+    # read length: P(read_len | segment, fragment length) = count / sum of the fragment length's row
+    for s in range(2):
+        ptr, rfrom, vals = arrays[f"rl_by_fl.{s}.row_ptr"].astype(np.int64), arrays[f"rl_by_fl.{s}.row_from"].astype(np.int64), arrays[f"rl_by_fl.{s}.values"].astype(np.float64)
+        first = int(arrays[f"rl_by_fl.{s}.from"][0])
+        sel = np.flatnonzero(seg == s)
+        rows = frag[sel] - first
+        width = int((ptr[1:] - ptr[:-1]).max())
+        lo = int(rfrom.min())
+        p = np.zeros((len(sel), width + int(rfrom.max()) - lo))
+        for i, r in enumerate(rows):
+            v = vals[ptr[r]:ptr[r + 1]]
+            p[i, rfrom[r] - lo:rfrom[r] - lo + len(v)] = v / v.sum()
+        col = read_len[sel] - lo
+        assert (col >= 0).all() and (p[np.arange(len(col)), col] > 0).all()
+        for g in (np.zeros(len(col), np.int64), rows // 8):
+            z = _z_scores(p, col, g - g.min())
+            if len(z):
+                worst = max(worst, float(np.abs(z).max()))
+                n_tests += len(z)
+    if enforce:
+        assert n > 50_000 and n_tests > 150, (n, n_tests)
+        assert worst < 5.5, worst
+    return worst, n_tests
+
+
+def _percent_free_divide(nom, den):
+    return (nom + den // 2) // den                           # utilities::Divide
+
+
+def _first_draw_records():
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    rec = synth.make_error_model_input(78, N_READS, READ_LEN, arrays, zero_frac=0.5)
+    return rec                                               # fragment lengths as drawn: short fragments end in adapter, the template totals cover min(read_len, fragment) bases
+
+
+def test_sequence_quality_and_read_length_of_the_oracle(workdir):
+    arrays, path = _revealing_profile(workdir)
+    rec = _first_draw_records()
+    rec["frag_len"][:] = np.maximum(rec["frag_len"], READ_LEN + 5)
+    prof = O.Profile(path)
+    O.lib().orc_profile_remove_indel_errors(prof.h)
+    results = O.error_model_only(prof, SEED, rec)
+    prof.close()
+    assert _check_first_draws(results, rec, arrays)[0] < 5.5
+    # the test of the test: G/C rows shifted by one
+    wrong = dict(arrays)
+    for name in list(arrays):
+        if name.startswith("tab.seq_quality.") and name.endswith(".dim2"):
+            par0, lim, margins = _table(arrays, name[4:-5])
+            margins[1] = np.roll(margins[1], 2, axis=0)
+            wrong[name] = np.concatenate([m.ravel() for m in margins])
+    assert _check_first_draws(results, rec, wrong, enforce=False)[0] > 8
+
+
+@pytest.mark.gpu
+def test_sequence_quality_and_read_length_of_the_product(workdir):
+    from backends import GpuBackend
+    arrays, path = _revealing_profile(workdir)
+    rec = _first_draw_records()
+    rec["frag_len"][:] = np.maximum(rec["frag_len"], READ_LEN + 5)
+    b = GpuBackend(path, None, 0, {"no_indels": True})
+    b.prepare(SEED)
+    results = b.error_model(rec)
+    b.close()
+    assert _check_first_draws(results, rec, arrays)[0] < 5.5
+
+
+# -------------------------------------------------------------------------------------------------- fragment counts
+# GetFragmentCounts (FragmentDistributionStats.cpp:3615-3627): the number of fragments of a chosen (start, length, strand) site is the negative-binomial
+# quantile of a uniform on [thr0, 1), thr0 = the probability of no fragment at the LARGEST bias -- so for any site P(count = j | count >= 1) is the
+# zero-truncated negative binomial with mean = bias * normalisation and r = Dispersion(mean) (:900-907, :3602-3613), bias = reference bias x length
+# bias x G/C bias x surrounding(start) x surrounding(end) (Reference.h:167,283; Surrounding.h:114-120; SurroundingBase.hpp:64-81).  Evaluated here
+# in numpy from the profile's arrays and the reference's bases for every site the sieve reports, and compared with the duplicates it reports.
+def _site_counts(frags):
+    key = np.stack([frags["seq"].astype(np.int64), frags["start"].astype(np.int64), frags["len"].astype(np.int64), frags["strand"].astype(np.int64)], axis=1)
+    sites, inverse = np.unique(key, axis=0, return_inverse=True)
+    counts = np.zeros(len(sites), np.int64)
+    np.maximum.at(counts, inverse.ravel(), frags["dup"].astype(np.int64) + 1)
+    assert np.array_equal(np.bincount(inverse.ravel(), minlength=len(sites)), counts)          # duplicates 0 .. count - 1, each once
+    return sites, counts
+
+
+def _kmer_bias(sur_bias, bases):
+    """bases: (N, 30) codes, first base most significant within each block of ten (SurroundingBase.hpp:64-73)"""
+    weights = 4 ** np.arange(9, -1, -1)
+    total = np.zeros(len(bases))
+    for b in (2, 1, 0):                                       # Surrounding.h:114-120 sums the blocks last to first
+        total = total + sur_bias[b][(bases[:, 10 * b:10 * b + 10] * weights).sum(1)]
+    return 2.0 / (1.0 + np.exp(-total))
+
+
+def _check_fragment_counts(frags, arrays, seqs, bias_normalization, enforce=True, shift_gc=0, dispersion_scale=1.0):
+    sites, counts = _site_counts(frags)
+    sur_bias = arrays["frag.sur_bias"].reshape(3, -1)
+    gc_bias, disp = arrays["frag.gc_bias"], arrays["frag.dispersion_parameters"] * dispersion_scale
+    ilb, ilb_from = arrays["frag.insert_lengths_bias"], int(arrays["frag.insert_lengths_bias.from"][0])
+    means, conds, cols = [], [], []
+    for s, (_, codes) in enumerate(seqs):
+        sel = sites[:, 0] == s
+        if not sel.any():
+            continue
+        codes = codes.astype(np.int64)
+        L = len(codes)
+        start, length = sites[sel, 1], sites[sel, 2]
+        end = start + length
+        fwd = codes[(start[:, None] - 10 + np.arange(30)[None, :]) % L]
+        rev = 3 - codes[(end[:, None] - 1 + 10 - np.arange(30)[None, :]) % L]          # reverse complement, walking down from end - 1 + 10
+        prefix = np.concatenate([[0], np.cumsum(np.isin(codes, (1, 2)))])
+        gc = np.minimum(_percent(prefix[end] - prefix[start], length) + shift_gc, 100)
+        bias = arrays["frag.ref_seq_bias"][s] * ilb[length - ilb_from] * gc_bias[gc] * _kmer_bias(sur_bias, fwd) * _kmer_bias(sur_bias, rev)
+        mean = bias * bias_normalization
+        r = np.minimum(mean / (disp[0] + disp[1] * mean), mean * 1e10)
+        p = mean / (mean + r)
+        pmf0 = (1 - p) ** r
+        pmf1 = pmf0 * p * r                                  # pc *= p * ((r - 1) / k + 1), k = 1
+        pmf2 = pmf1 * p * ((r - 1) / 2 + 1)
+        conds.append(np.stack([pmf1, pmf2, 1 - pmf0 - pmf1 - pmf2], axis=1) / (1 - pmf0)[:, None])      # counts 1, 2, 3 and more
+        means.append(mean)
+        cols.append(np.minimum(counts[sel], 3) - 1)
+    mean, cond, col = np.concatenate(means), np.concatenate(conds), np.concatenate(cols)
+    group = np.searchsorted(np.quantile(mean, np.linspace(0, 1, 9)[1:-1]), mean)         # eight groups of sites by their mean
+    expected, observed, var = np.zeros((8, 3)), np.zeros((8, 3)), np.zeros((8, 3))
+    np.add.at(expected, group, cond)
+    np.add.at(var, group, cond * (1 - cond))
+    np.add.at(observed, (group, col), 1.0)
+    usable = var > 25
+    z = (observed[usable] - expected[usable]) / np.sqrt(var[usable])
+    if enforce:
+        assert len(sites) > 40_000 and usable.sum() >= 16 and (counts > 1).sum() > 2_000, (len(sites), int(usable.sum()), int((counts > 1).sum()))
+        assert np.abs(z).max() < 5.0, z
+    return float(np.abs(z).max())
+
+
+def _count_case(workdir):
+    import parity_cases as P
+    cfg = dict(synth.TINY, name="TINYd", dispersion=(0.5, 0.8))                   # sizeable over-dispersion: duplicates are common
+    return cfg, P.make_inputs(workdir, "stat_counts", cfg, [40000, 25000], prof_seed=6, ref_seed=4)
+
+
+def test_fragment_counts_of_the_oracle(workdir):
+    cfg, (ppath, fpath, seqs) = _count_case(workdir)
+    arrays = synth.make_profile(cfg, seed=6, n_ref_seqs=2)
+    oprof, oref = O.Profile(ppath), O.Reference(seqs)
+    sim = O.Sim(oprof, oref, 91, num_pairs=160_000)
+    try:
+        frags = sim.sieve(1, sim.total_blocks() + 1)
+        assert _check_fragment_counts(frags, arrays, seqs, sim.bias_normalization()) < 5.0
+        # the test of the test: with r proportional to the mean (small means) the truncated law hardly depends on the mean itself, but it does on the
+        # dispersion parameters -- a fifth more must fail loudly; and a normalisation off by a factor of three shows as well
+        assert _check_fragment_counts(frags, arrays, seqs, sim.bias_normalization(), enforce=False, dispersion_scale=1.2) > 8
+        assert _check_fragment_counts(frags, arrays, seqs, sim.bias_normalization() * 3.0, enforce=False) > 8
+    finally:
+        sim.close()
+        oref.close()
+        oprof.close()
+
+
+@pytest.mark.gpu
+def test_fragment_counts_of_the_product(workdir):
+    from backends import GpuBackend
+    cfg, (ppath, fpath, seqs) = _count_case(workdir)
+    arrays = synth.make_profile(cfg, seed=6, n_ref_seqs=2)
+    b = GpuBackend(ppath, fpath)
+    info = b.prepare(91, num_pairs=160_000)
+    frags, _, _ = b.pairs(1, info["total_blocks"] + 1)
+    b.close()
+    assert _check_fragment_counts(frags, arrays, seqs, info["bias_normalization"]) < 5.0
