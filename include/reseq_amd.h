@@ -59,6 +59,12 @@ int rsq_profile_load(const char *path, rsq_profile **out);
  * reported through rsq_last_warning().  rsq_profile_load recognises such a file by its first bytes and forwards here. */
 int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out);
 /* writes the prepared profile (result tables, not the fit) as an RSQP container */
+/* Diagnosis of ReSeq's own profile files (DataStats::Save / ProbabilityEstimates::Save, reseq/DataStats.cpp:1302-1320, ProbabilityEstimates.cpp:1047-1065): a text
+ * table of where every serialized C++ type's class information sits in the two archives (byte, tracking, version, type, member path of the first object) and,
+ * if a file does not parse, the message naming the member path and type at which it stops.  The reader's token rules cannot be validated against a
+ * Boost-written file in the build image (INTEGRATION.md "Profile files"); this is what to send back when a real profile fails.  `ipf_path` NULL: stats_path + ".ipf".
+ * Writes at most cap bytes (NUL-terminated) and the full length to *need. */
+int rsq_profile_archive_layout(const char *stats_path, const char *ipf_path, char *out, size_t cap, size_t *need);
 int rsq_profile_save(const rsq_profile *p, const char *path);
 void rsq_profile_free(rsq_profile *p);
 /* ProbabilityEstimates::ChangeErrorRate / RemoveSubstitutionErrors / RemoveInDelErrors

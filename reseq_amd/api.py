@@ -44,6 +44,7 @@ SYMBOLS = {
     "rsq_profile_load": (C.c_int, [C.c_char_p, _pp]),
     "rsq_profile_load_reseq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, _pp]),
     "rsq_profile_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rsq_profile_archive_layout": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsq_last_warning": (C.c_char_p, []),
     "rsq_profile_free": (None, [_vp]),
     "rsq_profile_change_error_rate": (C.c_int, [_vp, C.c_double]),
@@ -135,6 +136,16 @@ def get_option(name):
     v = C.c_int64(0)
     _check(lib().rsq_get_option(name.encode(), C.byref(v)))
     return v.value
+
+
+def archive_layout(stats_path, ipf_path=None):
+    """where the class information of every serialized type sits in a .reseq / .reseq.ipf pair, and the parse error if there is one"""
+    need = C.c_size_t(0)
+    ipf = ipf_path.encode() if ipf_path else None
+    _check(lib().rsq_profile_archive_layout(str(stats_path).encode(), ipf, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(lib().rsq_profile_archive_layout(str(stats_path).encode(), ipf, buf, need.value, C.byref(need)))
+    return buf.value.decode(errors="replace")
 
 
 def last_warning():

@@ -57,7 +57,8 @@ struct Args {
 const std::map<std::string, std::string> kShort = {{"-j", "threads"}, {"-h", "help"}, {"-b", "bamIn"}, {"-r", "refIn"}, {"-s", "statsIn"}, {"-S", "statsOut"},
                                                    {"-v", "vcfIn"},   {"-p", "probabilitiesIn"}, {"-P", "probabilitiesOut"}, {"-1", "firstReadsOut"},
                                                    {"-2", "secondReadsOut"}, {"-c", "coverage"}, {"-R", "refSim"}, {"-V", "vcfSim"}, {"-i", "input"}, {"-o", "output"}};
-const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors", "maxLenDeletion", "maxReadLength"};
+const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors", "maxLenDeletion", "maxReadLength",
+                                      "dumpArchiveLayout"};
 
 bool parse(int argc, char **argv, int first, Args &a) {
     for (int i = first; i < argc; ++i) {
@@ -880,6 +881,15 @@ int query_profile(const Args &a) {
     if (a.has("refSeqBias") && ref_path.empty()) {
         ERR("ref option is mandatory if refSeqBias is specified.");
         return 1;
+    }
+    if (a.has("dumpArchiveLayout")) {                             // not in the reference: diagnosis of a .reseq / .reseq.ipf pair this build cannot read
+        size_t need = 0;
+        const std::string ipf = a.get("probabilitiesIn");
+        if (!check(rsq_profile_archive_layout(stats.c_str(), ipf.empty() ? nullptr : ipf.c_str(), nullptr, 0, &need), "Could not lay out the profile archives")) return 1;
+        std::vector<char> text(need);
+        rsq_profile_archive_layout(stats.c_str(), ipf.empty() ? nullptr : ipf.c_str(), text.data(), text.size(), &need);
+        std::cout << text.data();
+        return 0;
     }
     rsq_profile *prof = nullptr;
     rsq_ref *ref = nullptr;

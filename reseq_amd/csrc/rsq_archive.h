@@ -147,6 +147,15 @@ struct Node {
     const Node &second() const { return kids.at(1); }
 };
 
+// Where the class information of a type was found: the first object of the type in the stream.  The reader cannot be checked against a file written by
+// Boost in this image, so when a real profile does not parse, this list (`reseq queryProfile --dumpArchiveLayout`) and the member path in the error
+// message are what tells which of the token rules above is wrong.
+struct ClassInfoSite {
+    std::string type, path;
+    size_t byte = 0;
+    uint64_t tracking = 0, version = 0;
+};
+
 class Reader {
    public:
     Reader(const char *begin, const char *end, size_t n_types, const std::string &what) : p_(begin), end_(end), seen_(n_types, 0), what_(what) {
@@ -154,16 +163,26 @@ class Reader {
         if (sig != "serialization::archive") fail("not a Boost text archive");
         library_version_ = (uint32_t)unsigned_int();
     }
+    const std::vector<ClassInfoSite> &class_info_sites() const { return sites_; }
     static bool looks_like_archive(const char *begin, size_t n) {
         static const char head[] = "22 serialization::archive";
         return n >= sizeof head - 1 && !memcmp(begin, head, sizeof head - 1);
     }
     uint32_t library_version() const { return library_version_; }
     void read(TypeP t, Node *out) {
+        current_ = t;
         if (t->class_info && !seen_[t->id]) {
-            seen_[t->id] = 1;
+            seen_[t->id] = (uint32_t)sites_.size() + 1u;
+            ClassInfoSite site;
+            site.type = t->name;
+            site.path = path_string();
+            skip_blank();
+            site.byte = (size_t)(p_ - begin());
+            sites_.push_back(site);
             const uint64_t tracking = unsigned_int();
-            unsigned_int();   // class version (0 everywhere in ReSeq)
+            const uint64_t version = unsigned_int();   // class version (0 everywhere in ReSeq)
+            sites_.back().tracking = tracking;
+            sites_.back().version = version;
             if (tracking) fail("class " + t->name + " is saved with object tracking, which ReSeq's profiles do not use");
         }
         if (out) out->type = t;
@@ -201,14 +220,24 @@ class Reader {
                 items(t->elem, count, out);
                 break;
             }
-            case Type::PAIR:
+            case Type::PAIR: {
+                static const std::string kFirst = "first", kSecond = "second";
                 if (out) out->kids.resize(2);
+                path_.push_back(Seg{t, &kFirst, 0});
                 read(t->first, out ? &out->kids[0] : nullptr);
+                path_.back().name = &kSecond;
                 read(t->second, out ? &out->kids[1] : nullptr);
+                path_.pop_back();
                 break;
+            }
             case Type::CLS:
                 if (out) out->kids.resize(t->members.size());
-                for (size_t i = 0; i < t->members.size(); ++i) read(t->members[i].type, out && t->members[i].keep ? &out->kids[i] : nullptr);
+                path_.push_back(Seg{t, nullptr, 0});
+                for (size_t i = 0; i < t->members.size(); ++i) {
+                    path_.back().name = &t->members[i].name;
+                    read(t->members[i].type, out && t->members[i].keep ? &out->kids[i] : nullptr);
+                }
+                path_.pop_back();
                 break;
         }
     }
@@ -219,27 +248,59 @@ class Reader {
 
    private:
     void items(TypeP e, uint64_t count, Node *out) {
-        if (count > (uint64_t)(end_ - p_)) fail("item count larger than the file");
+        if (count > (uint64_t)(end_ - p_)) fail("item count " + std::to_string(count) + " larger than the file");
+        const TypeP holder = current_;
+        path_.push_back(Seg{holder, nullptr, 0});
+        uint64_t &i = path_.back().index;
         if (e->numeric()) {
+            current_ = e;
             if (e->kind == Type::F64) {
                 if (out) out->f.resize(count);
-                for (uint64_t i = 0; i < count; ++i) {
+                for (i = 0; i < count; ++i) {
                     const double v = real();
                     if (out) out->f[i] = v;
                 }
             } else {
                 if (out) out->u.resize(count);
-                for (uint64_t i = 0; i < count; ++i) {
+                for (i = 0; i < count; ++i) {
                     const uint64_t v = e->kind == Type::INT ? (uint64_t)signed_int() : unsigned_int();
                     if (out) out->u[i] = v;
                 }
             }
-            return;
+        } else {
+            if (out) out->kids.resize(count);
+            for (uint64_t k = 0; k < count; ++k) {                   // the path's back may move when deeper levels push
+                path_.back().index = k;
+                read(e, out ? &out->kids[k] : nullptr);
+            }
         }
-        if (out) out->kids.resize(count);
-        for (uint64_t i = 0; i < count; ++i) read(e, out ? &out->kids[i] : nullptr);
+        path_.pop_back();
     }
-    [[noreturn]] void fail(const std::string &msg) const { throw Error(what_ + ": " + msg + " (near byte " + std::to_string(p_ - begin()) + ")"); }
+    // "DataStats.errors_.indel_by_indel_pos_[1][3].second[17]"
+    std::string path_string() const {
+        std::string s = root_;
+        for (const Seg &g : path_) {
+            if (g.name) s += "." + *g.name;
+            else s += "[" + std::to_string(g.index) + "]";
+        }
+        return s;
+    }
+    // the message names the member being read, its type, and for the class types around it where their class information was taken from the stream:
+    // a missing or surplus "tracking version" pair shifts every later token, so the last sites in front of the failure are the suspects
+    [[noreturn]] void fail(const std::string &msg) const {
+        std::string m = what_ + ": " + msg + " at " + path_string() + (current_ ? " (" + current_->name + ")" : "") + ", near byte " + std::to_string(p_ - begin());
+        if (library_version_) m += "; archive library version " + std::to_string(library_version_);
+        std::string chain;
+        for (size_t k = path_.size(); k-- && chain.size() < 600;) {
+            const TypeP t = path_[k].holder;
+            if (!t || !t->class_info) continue;
+            const uint32_t site = seen_[t->id];
+            chain += (chain.empty() ? "" : "; ") + t->name + (site ? ": class info read at byte " + std::to_string(sites_[site - 1].byte) + " (" + sites_[site - 1].path + ")" : ": no class info read");
+        }
+        if (!chain.empty()) m += "; enclosing types: " + chain;
+        if (!sites_.empty()) m += "; last class info read: " + sites_.back().type + " at byte " + std::to_string(sites_.back().byte);
+        throw Error(m);
+    }
     const char *begin() const { return end_ - size_; }
     void skip_blank() {
         while (p_ != end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\r' || *p_ == '\t')) ++p_;
@@ -290,11 +351,22 @@ class Reader {
         p_ += n;
         return v;
     }
+    struct Seg {
+        TypeP holder;                  // the class / pair / container the segment is a part of
+        const std::string *name;       // member name, or nullptr: item `index`
+        uint64_t index;
+    };
     const char *p_, *end_;
     size_t size_ = (size_t)(end_ - p_);
-    std::vector<char> seen_;
-    std::string what_;
+    std::vector<uint32_t> seen_;       // per type: 0, or 1 + index of its class-info site
+    std::vector<ClassInfoSite> sites_;
+    std::vector<Seg> path_;
+    TypeP current_ = nullptr;
+    std::string what_, root_;
     uint32_t library_version_ = 0;
+
+   public:
+    void set_root(const std::string &name) { root_ = name; }
 };
 
 }  // namespace archive

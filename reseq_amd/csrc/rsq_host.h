@@ -126,6 +126,7 @@ struct Profile {
     // ReSeq's own files (rsq_profile_archive.cpp): DataStats::Load + PrepareProcessing, ProbabilityEstimates::Load + PrepareResult
     static bool is_archive(const std::string &path);
     static Profile load_archives(const std::string &stats_path, const std::string &ipf_path, double precision_aim = 0.05, std::string *warnings = nullptr);
+    static std::string archive_layout(const std::string &stats_path, const std::string &ipf_path);      // the class-info sites of both files, the parse error if any
     void save(const std::string &path) const;                     // as an RSQP container
     void change_error_rate(double multiplier);          // ProbabilityEstimates.h:1516-1527
     void remove_substitution_errors();                  // :1529-1540

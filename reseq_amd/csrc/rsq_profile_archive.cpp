@@ -546,9 +546,12 @@ Profile Profile::load_archives(const std::string &stats_path, const std::string 
     const std::string ipf_path = ipf_path_in.empty() ? stats_path + ".ipf" : ipf_path_in;
     Profile p;
     uint64_t creation_time = 0;
+    uint32_t versions[2] = {0, 0};
     {
         const std::vector<char> buf = slurp(stats_path);
         archive::Reader r(buf.data(), buf.data() + buf.size(), types.s.size(), stats_path);
+        r.set_root("DataStats");
+        versions[0] = r.library_version();
         Node st;
         r.read(types.data_stats, &st);
         r.expect_end();
@@ -560,6 +563,8 @@ Profile Profile::load_archives(const std::string &stats_path, const std::string 
     {
         const std::vector<char> buf = slurp(ipf_path);
         archive::Reader r(buf.data(), buf.data() + buf.size(), types.s.size(), ipf_path);
+        r.set_root("ProbabilityEstimates");
+        versions[1] = r.library_version();
         Node pe;
         r.read(types.probability_estimates, &pe);
         r.expect_end();
@@ -567,8 +572,49 @@ Profile Profile::load_archives(const std::string &stats_path, const std::string 
             throw Error(ipf_path + " was fitted to another statistics file than " + stats_path + " (creation times differ); fitting is not part of this build");
         fill_from_estimates(p, pe, precision_aim, warn);
     }
+    // said every time: the token rules of the reader could not be checked against a file written by Boost itself (INTEGRATION.md "Profile files")
+    warn += "read as Boost text archives of library version " + std::to_string(versions[0]) + " (" + stats_path + ") and " + std::to_string(versions[1]) + " (" + ipf_path +
+            "); if tables look wrong, send the output of `reseq queryProfile --dumpArchiveLayout -s " + stats_path + "`. ";
     if (warnings) *warnings = warn;
     return p;
+}
+
+// Where every class type's information sits in the two files (archive::ClassInfoSite), and if a file does not parse, the reader's message with the member
+// path: what a maintainer needs to tell which token rule of rsq_archive.h a real ReSeq profile contradicts.
+std::string Profile::archive_layout(const std::string &stats_path, const std::string &ipf_path_in) {
+    static ReseqTypes types;
+    const std::string ipf_path = ipf_path_in.empty() ? stats_path + ".ipf" : ipf_path_in;
+    std::string out;
+    auto one = [&](const std::string &path, const char *root, archive::TypeP type) {
+        out += "# " + path + " (" + root + ")\n";
+        std::vector<char> buf;
+        try {
+            buf = slurp(path);
+        } catch (const std::exception &e) {
+            out += std::string("error\t") + e.what() + "\n";
+            return;
+        }
+        out += "bytes\t" + std::to_string(buf.size()) + "\n";
+        std::unique_ptr<archive::Reader> r;
+        std::string error;
+        try {
+            r.reset(new archive::Reader(buf.data(), buf.data() + buf.size(), types.s.size(), path));
+            r->set_root(root);
+            out += "library_version\t" + std::to_string(r->library_version()) + "\n";
+            r->read(type, nullptr);
+            r->expect_end();
+        } catch (const std::exception &e) {
+            error = e.what();
+        }
+        out += "byte\ttracking\tversion\ttype\tfirst object\n";
+        if (r)
+            for (const archive::ClassInfoSite &c : r->class_info_sites())
+                out += std::to_string(c.byte) + "\t" + std::to_string(c.tracking) + "\t" + std::to_string(c.version) + "\t" + c.type + "\t" + c.path + "\n";
+        out += error.empty() ? "parsed\tto the end\n" : "error\t" + error + "\n";
+    };
+    one(stats_path, "DataStats", types.data_stats);
+    one(ipf_path, "ProbabilityEstimates", types.probability_estimates);
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------- RSQP writer

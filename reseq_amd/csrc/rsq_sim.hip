@@ -953,6 +953,19 @@ int rsq_profile_load(const char *path, rsq_profile **out) {
         return RSQ_EIO;
     }
 }
+int rsq_profile_archive_layout(const char *stats_path, const char *ipf_path, char *out, size_t cap, size_t *need) {
+    REQUIRE(stats_path && need && (out || !cap), "null argument");
+    return guard([&] {
+        const std::string text = Profile::archive_layout(stats_path, ipf_path ? ipf_path : "");
+        *need = text.size() + 1;
+        if (cap) {
+            const size_t n = std::min(cap - 1, text.size());
+            memcpy(out, text.data(), n);
+            out[n] = 0;
+        }
+        return (int)RSQ_OK;
+    });
+}
 int rsq_profile_save(const rsq_profile *p, const char *path) {
     REQUIRE(p && path, "null argument");
     try {
