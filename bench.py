@@ -224,10 +224,12 @@ def committed_counters():
     tag = os.path.basename(files[-1])[:-len("_pmc.json")]
     try:
         pmc = json.load(open(files[-1]))
+        recorded = pmc.pop("_kernel_source_hash", None)
         kernel = [k for k in pmc if "k_fill_reads" in k][0]
         c = {n: v["mean"] for n, v in pmc[kernel].items()}
         cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
-        out = {"source": f"profiles/{tag}_pmc.json", "kernel": kernel, "kernel_cycles": cycles, "kernel_ms_at_2.4GHz": cycles / 2.4e6,
+        from reseq_amd.provenance import kernel_source_hash
+        out = {"source": f"profiles/{tag}_pmc.json", "kernel_source_hash_when_collected": recorded, "counters_stale": recorded != kernel_source_hash(), "kernel": kernel, "kernel_cycles": cycles, "kernel_ms_at_2.4GHz": cycles / 2.4e6,
                "vmem_loads_per_launch": c["SQ_INSTS_VMEM_RD"], "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
                "vmem_issue_frac": c["SQ_INSTS_VMEM_RD"] / N_CU * TA_CYCLES_PER_LOAD / cycles, "ta_busy_frac": c["TA_BUSY_avr"] / cycles,
                "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * cycles), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / 4 / (N_CU * cycles),
@@ -423,6 +425,7 @@ def main():
                              "resource": "VALU issue", "frac": counters["valu_busy_frac"], "vmem_issue_frac": counters["vmem_issue_frac"], "ta_busy_frac": counters["ta_busy_frac"],
                              "lds_busy_frac": counters["lds_busy_frac"], "lds_bank_conflict_frac": counters["lds_bank_conflict_frac"],
                              "kernel": counters["kernel"], "kernel_ms_when_profiled": counters["kernel_ms_at_2.4GHz"], "source": counters["source"],
+                             "counters_stale": counters["counters_stale"],
                              "note": "fractions of the kernel's cycles from the committed PMC collection: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles); "
                                      "SQ_INSTS_VMEM_RD / 256 CUs x 23 cycles / cycles; TA_BUSY_avr / cycles"}},
             "kernel_ms_last_batch": kernel_ms,

@@ -57,6 +57,8 @@ int rsq_profile_load(const char *path, rsq_profile **out);
  * ErrorStats::PrepareSimulation) and ProbabilityEstimates::PrepareResult (FullExpansion, GetResults, ImputeMissingValues).  Fitting is not
  * part of this build: tables whose stored precision is above `ipf_precision_percent` (--ipfPrecision, default 5) are used as stored and
  * reported through rsq_last_warning().  rsq_profile_load recognises such a file by its first bytes and forwards here. */
+/* *yes = 1 if the file begins like a Boost text archive (ReSeq's own .reseq), 0 otherwise (an RSQP container, or unreadable) */
+int rsq_profile_is_reseq_archive(const char *path, int *yes);
 int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out);
 /* writes the prepared profile (result tables, not the fit) as an RSQP container */
 /* Diagnosis of ReSeq's own profile files (DataStats::Save / ProbabilityEstimates::Save, reseq/DataStats.cpp:1302-1320, ProbabilityEstimates.cpp:1047-1065): a text

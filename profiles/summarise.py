@@ -4,7 +4,9 @@
    <tag>_pmc.json           mean counter value per launch and kernel
    <tag>_traffic.json       HBM bytes per k_fill_reads launch: 2 x FETCH_SIZE + WRITE_SIZE, both in KiB as rocprofv3 reports them
                             (the factor 2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md "HBM"; WRITE_SIZE uncalibrated)"""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reseq_amd.provenance import kernel_source_hash
 root, tag = sys.argv[1], sys.argv[2]
 for f in glob.glob(root + "/stats/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
@@ -15,8 +17,9 @@ for f in sorted(glob.glob(root + "/pmc_*/*_counter_collection.csv")):
         if k.startswith("rsq::"):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 pmc = {k: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
+pmc["_kernel_source_hash"] = kernel_source_hash()           # bench.py: counters_stale when the sources it runs from hash differently
 json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-fill = [k for k in pmc if "k_fill_reads" in k]
+fill = [k for k in pmc if "k_fill_reads" in k and not k.startswith("_")]
 if fill and "FETCH_SIZE" in pmc[fill[0]] and "WRITE_SIZE" in pmc[fill[0]]:
     k = fill[0]
     fetch_kib, write_kib = pmc[k]["FETCH_SIZE"]["mean"], pmc[k]["WRITE_SIZE"]["mean"]

@@ -43,6 +43,7 @@ SYMBOLS = {
     "rsq_device_count": (C.c_int, []),
     "rsq_profile_load": (C.c_int, [C.c_char_p, _pp]),
     "rsq_profile_load_reseq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, _pp]),
+    "rsq_profile_is_reseq_archive": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "rsq_profile_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rsq_profile_archive_layout": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsq_last_warning": (C.c_char_p, []),

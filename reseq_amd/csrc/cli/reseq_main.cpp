@@ -149,7 +149,10 @@ bool load_profile(const Args &a, rsq_profile **p) {
     }
     // a `.reseq` statistics file (with its `.reseq.ipf`, main.cpp:837: "<statsIn>.ipf" unless -p names another) or an RSQP container
     INFO("Reading profile from " << a.get("statsIn"));
-    const bool archives = a.has("probabilitiesIn") || a.has("ipfPrecision");
+    int archives = 0;                                             // by the file's content, not by the options given
+    rsq_profile_is_reseq_archive(a.get("statsIn").c_str(), &archives);
+    if (!archives && (a.has("probabilitiesIn") || a.has("ipfPrecision")))
+        WARN("--probabilitiesIn / --ipfPrecision are ignored: " << a.get("statsIn") << " is an RSQP container, which holds the prepared tables");
     if (!check(archives ? rsq_profile_load_reseq(a.get("statsIn").c_str(), a.has("probabilitiesIn") ? a.get("probabilitiesIn").c_str() : nullptr, ipf_precision, p)
                         : rsq_profile_load(a.get("statsIn").c_str(), p),
                "Could not load profile"))

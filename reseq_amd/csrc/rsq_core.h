@@ -194,7 +194,8 @@ RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &..
 // top32(j) - r32 > delta and r32 - top32(j+1) >= delta imply T(j) > u T > T(j+1) with room for the reference's own rounding:
 // column j is the reference's answer.  Everything else (about 2 K delta / S of all draws, 2e-4 for K = 40) is "undecided".
 // Preconditions, checked when the tables are packed (DevTable::f32_ok) and here: values are 0 or in [2^-60, 2^29] (no overflow;
-// an underflowing intermediate product loses at most 2^-97 absolutely) and S32 >= 2^-30.
+// an intermediate product that underflows -- (r0*r1) itself below 2^-126, i.e. two factors near 2^-60 and below -- is lost entirely: at most 2^-68 absolutely after the
+// largest factors 2^29 * 2^29, far below delta >= 2^-30 * 2^-19; this assumes gradual or flushed underflow alike, no other denormal mode) and S32 >= 2^-30.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float Float2 __attribute__((ext_vector_type(2)));      // v_pk_mul_f32 / v_pk_add_f32
 #else
@@ -636,12 +637,6 @@ struct ReadMachine {
         const uint32_t sqi = seg * S.n_tiles + tile_id;
         const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
         par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, h0.w2, prob_sum);
-#ifdef RSQ_EXP_UNIFORM_SQ
-        par.seq_qual = RSQ_EXP_UNIFORM_SQ;                            // experiment only: what a wave-uniform sequence quality would buy
-#endif
-#ifdef RSQ_EXP_UNIFORM_GC
-        par.gc_seq = RSQ_EXP_UNIFORM_GC;                              // experiment only: what reads sorted by their G/C percent would buy (indel margin 2)
-#endif
         if (0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
             const DevTable sqt = tab.seq_quality(sqi);
             par.seq_qual = sqt.k ? S.par0[sqt.par0_off + sqt.k - 1u] : 0u;
@@ -704,21 +699,12 @@ struct ReadMachine {
         const bool tail = phase == kTail, from_template = phase == kTemplate;
         const DevAdapters &ad = S.adapters[seg];
         const uint32_t it = par.iteration++;
-#ifdef RSQ_EXP_NO_PHILOX
-        const Words w{(it + st.c0) * 0x9E3779B9u, (it ^ st.c1) * 0x85EBCA6Bu + 0x1234567u, (it + st.c2) * 0xC2B2AE35u, it * 0x27D4EB2Fu};      // experiment only: what the Philox rounds cost
-#else
         const Words w = st.step(2u + it);
-#endif
         typename Tab::Sum prob_sum;
         uint32_t indel = 0, org_base = 0;
         if (!tail) {
             const uint32_t idx_i[3] = {par.indel_pos, par.read_pos, par.gc_seq};
-#ifdef RSQ_EXP_NO_INDEL
-            (void)idx_i;
-            prob_sum = 1;                                              // experiment only: what the indel draw costs
-#else
             indel = tab.draw_indel(par.previous_indel_type * 6u + par.base_call, idx_i, w.w0, prob_sum);
-#endif
             if (0 == prob_sum) indel = 0;
             org_base = from_template ? src.base(org_pos) : (uint32_t)ad.seqs[adapter_a0 + org_pos];
         }
@@ -736,12 +722,7 @@ struct ReadMachine {
         uint32_t q = 0;
         if (!deletion) {
             const uint32_t idx_q[4] = {par.seq_qual, par.qual, par.read_pos, par.error_rate};
-#ifdef RSQ_EXP_NO_QUAL
-            q = 2u + (w.w1 >> 28) + (idx_q[1] & 1u);                   // experiment only: what the quality draw costs
-            prob_sum = 1;
-#else
             q = tab.draw_quality(qi, idx_q, w.w1, prob_sum);
-#endif
             if (0 == prob_sum) {
                 if (regular) q = par.read_pos ? par.last_written_qual : tab.quality(qi).max_value;      // :341-349
                 else if (tail) q = par.read_pos ? par.last_written_qual : q;                             // at(qual_, read_pos-1) - offset
@@ -751,12 +732,7 @@ struct ReadMachine {
         if (regular) {
             par.qual = q;
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
-#ifdef RSQ_EXP_NO_CALL
-            uint32_t call = (w.w2 >> 30) == 3u && idx_b[0] < 3u ? (org_base + 1u) & 3u : org_base;      // experiment only: what the base-call draw costs
-            prob_sum = 1;
-#else
             uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
-#endif
             if (0 == prob_sum) call = org_base;
             par.base_call = call;
             out.put(par.read_pos, call, q + S.phred_offset);

@@ -1508,11 +1508,9 @@ struct ScreenTables {
         uint32_t value = par0()[t.par0_off + col];
         ps = 1u;
         decided = decided && !S.force_exact;
-#ifndef RSQ_EXP_NO_FALLBACK
         if (RSQ_ANY(!decided)) {
             if (!decided) value = exact<NM>(desc, idx, u, ps);
         }
-#endif
         return value;
     }
 

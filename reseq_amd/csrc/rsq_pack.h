@@ -82,6 +82,8 @@ struct SimState {
     uint32_t rmax = 0, read_stride = 0, ops_stride = 0, max_adapter = 0, template_words = 0;
     // prepare() results
     bool prepared = false;
+    bool normalized = false;                         // the sharded pre-pass: rsq_sim_prepare_normalization has run since the plan
+    uint32_t prepared_lo = 0, prepared_hi = 0;       // blocks whose systematic-error tracks are finished: all of them after rsq_sim_prepare, the rank's range after the sharded pre-pass
     uint64_t seed = 0, total_pairs = 0, adapter_only_pairs = 0;
     uint32_t n_groups = 0, passes = 0, total_blocks = 0;
     std::vector<uint32_t> coverage_groups, first_block, n_blocks, block_seq;

@@ -318,6 +318,8 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
     }
     lap("variants' systematic errors", t0);
     s.prepared = true;
+    s.prepared_lo = 1;
+    s.prepared_hi = s.total_blocks + 1;
 }
 
 // Simulator::CreateSystematicErrorProfile (Simulator.cpp:2597-2653): both strands of every sequence, reverse first, as FASTQ.
@@ -731,6 +733,11 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
         g_last_error = "block range outside [1, total_blocks]";
         return RSQ_EINVAL;
     }
+    if (block_lo < block_hi && (block_lo < s.prepared_lo || block_hi > s.prepared_hi)) {       // a sharded pre-pass finished the tracks of the rank's own blocks only
+        g_last_error = "blocks [" + std::to_string(block_lo) + ", " + std::to_string(block_hi) + ") lie outside the range the sharded pre-pass prepared on this simulator, [" +
+                       std::to_string(s.prepared_lo) + ", " + std::to_string(s.prepared_hi) + ")";
+        return RSQ_ESTATE;
+    }
     HIP_CHECK(hipSetDevice(s.device));
     *n_pairs = 0;
     *r1_len = *r2_len = 0;
@@ -941,6 +948,11 @@ int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double 
         g_last_error = e.what();
         return RSQ_EIO;
     }
+}
+int rsq_profile_is_reseq_archive(const char *path, int *yes) {
+    REQUIRE(path && yes, "null argument");
+    *yes = Profile::is_archive(path) ? 1 : 0;
+    return RSQ_OK;
 }
 int rsq_profile_load(const char *path, rsq_profile **out) {
     REQUIRE(path && out, "null argument");
@@ -1171,6 +1183,7 @@ int rsq_sim_prepare_plan(rsq_sim *s, uint64_t seed, uint64_t num_read_pairs, dou
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         s->prepared = false;
+        s->normalized = false;
         s->chain_run.valid = false;
         plan_simulation(*s, s->up, seed, num_read_pairs, coverage, ref_bias_mode, record_base_identifier);
         s->bias_plan = plan_bias_normalization(*s, s->up);
@@ -1205,6 +1218,7 @@ int rsq_sim_prepare_normalization(rsq_sim *s, const double *sums, const double *
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
         normalization_from_partials(*s, s->up, s->bias_plan, sums, maxes);
+        s->normalized = true;
         return RSQ_OK;
     });
 }
@@ -1250,8 +1264,11 @@ int rsq_sim_prepare_sys_errors(rsq_sim *s, uint32_t block_lo, uint32_t block_hi,
 int rsq_sim_prepare_finish(rsq_sim *s) {
     REQUIRE(s, "null argument");
     REQUIRE(s->planned && s->chain_run.valid, "the sharded pre-pass has not run");
+    REQUIRE(s->normalized, "rsq_sim_prepare_normalization must run before rsq_sim_prepare_finish (the thresholds of the sieve come from it)");
     return guard([&] {
         HIP_CHECK(hipSetDevice(s->device));
+        s->prepared_lo = s->chain_run.block_lo;                     // only these blocks' tracks are finished
+        s->prepared_hi = s->chain_run.block_hi;
         if (s->has_variants) {                                      // -V: the variants' bases inside the rank's strand windows, from the finished chains
             const std::vector<StrandTask> windows = chain_windows(*s);
             build_variant_sys_errors(*s, s->up, &windows);
@@ -1314,6 +1331,8 @@ static int download_sys(const rsq_sim *s, const uint16_t *src, uint8_t *dom_out,
 int rsq_sim_get_sys_errors(const rsq_sim *s, int reverse_strand, uint32_t seq, uint8_t *dom_out, uint8_t *rate_out, uint32_t len) {
     REQUIRE(s && s->prepared && s->has_ref && seq < s->dev.n_seqs && len == s->seq_len[seq] && dom_out && rate_out, "bad arguments");
     REQUIRE(s->n_blocks[seq], "sequence is shorter than the longest insert length and is not simulated");
+    REQUIRE(s->first_block[seq] >= s->prepared_lo && s->first_block[seq] + s->n_blocks[seq] <= s->prepared_hi,
+            "the sequence's systematic errors were not (all) drawn on this simulator: the sharded pre-pass finishes the tracks of the rank's own blocks only");
     return download_sys(s, (reverse_strand ? s->sys_rev : s->sys_fwd) + s->seq_base_off[seq], dom_out, rate_out, len);
 }
 int rsq_sim_create_sys_error_profile(rsq_sim *s, uint64_t seed, const char *path, void *stream) {
@@ -1329,6 +1348,8 @@ int rsq_sim_read_sys_errors(rsq_sim *s, const char *path) {
         HIP_CHECK(hipSetDevice(s->device));
         apply_sys_error_records(*s, s->up, parse_sys_error_fastq(read_text_file(path)));
         build_variant_sys_errors(*s, s->up);                        // their error-region state follows the loaded rates
+        s->prepared_lo = 1;                                         // the file holds the tracks of every sequence
+        s->prepared_hi = s->total_blocks + 1;
         return RSQ_OK;
     });
 }

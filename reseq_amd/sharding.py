@@ -90,6 +90,8 @@ def place_shard(shard_path: str, out_path: str, offset: int, chunk: int = 1 << 2
             if n <= 0 and in_kernel:
                 in_kernel = False
                 continue
+            if n <= 0:
+                raise IOError(f"{shard_path}: no bytes copied at offset {done} of {size} (shard truncated while it was placed?)")
             done += n
         return done
     finally:
