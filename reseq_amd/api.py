@@ -88,6 +88,9 @@ SYMBOLS = {
     "rsq_sim_read_methylation": (C.c_int, [_vp, C.c_char_p]),
     "rsq_sim_get_ref_seq_bias": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
+    "rsq_sim_job_generate": (C.c_int, [_vp, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp]),
+    "rsq_sim_job_write": (C.c_int, [_vp, C.c_char_p, _u64, C.c_char_p, _u64, _u32]),
+    "rsq_sim_job_free": (C.c_int, [_vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "rsq_sim_error_model_fastq": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
@@ -402,6 +405,19 @@ class Simulator:
         finally:
             for d in (r1, r2, fr):
                 d.free()
+
+    def job_generate(self, block_lo, block_hi, batch_blocks=0, stream=None):
+        """the rank's share of a job: simulated once, its FASTQ text kept in device memory; returns (pairs, bytes of file 1, bytes of file 2)"""
+        n, b1, b2 = _u64(0), _u64(0), _u64(0)
+        _check(lib().rsq_sim_job_generate(self.h, block_lo, block_hi, batch_blocks, C.byref(n), C.byref(b1), C.byref(b2), stream))
+        return n.value, b1.value, b2.value
+
+    def job_write(self, r1_path, r1_offset, r2_path, r2_offset, threads_per_file=0):
+        """the kept text to its place in the two final files (parallel pwrite from page-locked buffers)"""
+        _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode(), r2_offset, threads_per_file))
+
+    def job_free(self):
+        _check(lib().rsq_sim_job_free(self.h))
 
     def adapter_only_pairs(self, first, n, stream=None):
         l1, l2 = C.c_size_t(), C.c_size_t()

@@ -31,6 +31,7 @@ struct Options {
     int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
     int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
     int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
+    int64_t job_chunk_bytes = 0;       // > 0: size of the device arrays rsq_sim_job_generate keeps a rank's FASTQ text in (default 2 GiB; tests: small, so that the text spans several)
     int64_t overlap = 0;               // n > 1: rsq_sim_pairs cuts its block range into n sub-ranges whose sieve / reads / text stages are pipelined on three streams
 };
 Options &options();                                               // the process-wide values

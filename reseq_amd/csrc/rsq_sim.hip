@@ -1,12 +1,16 @@
 // rsq_sim.hip -- the simulator object behind the C ABI (include/reseq_amd.h): packs profile + reference into
 // HBM, runs the pre-passes and drives the kernels of rsq_kernels.h.  Compiled for gfx950 only.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <math.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
+#include <thread>
 #include <memory>
 #include <string>
 #include <utility>
@@ -150,6 +154,19 @@ struct rsq_sim : SimState {
         DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, counters (one small buffer); the sorted items
         hipEvent_t text_done = nullptr;      // the text stage that last read this set's arrays
     } ws[2];
+    // rsq_sim_job_generate: the FASTQ text of a rank's block range, kept until rsq_sim_job_write / rsq_sim_job_free: per file a list of device arrays, filled in order
+    struct JobText {
+        std::vector<std::unique_ptr<DevBuf>> chunks[2];
+        std::vector<size_t> used[2];
+        uint64_t bytes[2] = {0, 0};
+        void clear() {
+            for (int f = 0; f < 2; ++f) {
+                chunks[f].clear();
+                used[f].clear();
+                bytes[f] = 0;
+            }
+        }
+    } job;
     DevBuf totals;                 // [sub-ranges + 1][2] bytes of FASTQ text in front of a sub-range, per file
     Workspace *cur = &ws[0];       // the set the stage being enqueued works on
     hipStream_t side[2] = {nullptr, nullptr};      // the sieve's and the text's stream of a pipelined call
@@ -1382,6 +1399,140 @@ int rsq_sim_pairs(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, char *r1_dev
                   uint64_t *n_pairs, rsq_fragment *frags_dev, size_t frags_cap, void *stream) {
     REQUIRE(s && r1_len && r2_len && n_pairs, "null argument");
     return guard([&] { return sim_pairs(*s, block_lo, block_hi, r1_dev, r1_cap, r1_len, r2_dev, r2_cap, r2_len, n_pairs, frags_dev, frags_cap, (hipStream_t)stream); });
+}
+
+// ---- a rank's share, generated once and kept (include/reseq_amd.h rsq_sim_job_*)
+constexpr size_t kJobChunkBytes = (size_t)2 << 30, kJobSliceBytes = (size_t)32 << 20;
+int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint32_t batch_blocks, uint64_t *n_pairs, uint64_t *r1_bytes, uint64_t *r2_bytes, void *stream) {
+    REQUIRE(s && n_pairs && r1_bytes && r2_bytes, "null argument");
+    *n_pairs = *r1_bytes = *r2_bytes = 0;
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        rsq_sim::JobText &job = s->job;
+        job.clear();
+        const size_t chunk_bytes = options().job_chunk_bytes > 0 ? (size_t)options().job_chunk_bytes : kJobChunkBytes;
+        if (!batch_blocks)                                          // about 4 M pairs per call (large launches), at least 2000 blocks
+            batch_blocks = (uint32_t)std::min(100000.0, std::max(2000.0, 4e6 * (double)s->total_blocks / (double)std::max<uint64_t>(1, s->total_pairs)));
+        double per_block[2] = {0.0, 0.0};                           // the largest bytes per block seen so far: what the next call is given room for
+        auto room = [&](int f) { return job.chunks[f].empty() ? (size_t)0 : job.chunks[f].back()->bytes() - job.used[f].back(); };
+        auto new_chunk = [&](int f, size_t at_least) {
+            job.chunks[f].emplace_back(new DevBuf());
+            job.chunks[f].back()->reserve(std::max(chunk_bytes, at_least));
+            job.used[f].push_back(0);
+        };
+        for (uint32_t lo = block_lo; lo < block_hi; lo += batch_blocks) {
+            const uint32_t hi = (uint32_t)std::min<uint64_t>(block_hi, (uint64_t)lo + batch_blocks);
+            for (int f = 0; f < 2; ++f) {
+                const size_t expect = (size_t)(per_block[f] * (hi - lo) * 1.15) + 65536;
+                if (room(f) < expect) new_chunk(f, expect);
+            }
+            for (int attempt = 0;; ++attempt) {
+                size_t len[2] = {0, 0};
+                uint64_t n = 0;
+                char *dst[2];
+                for (int f = 0; f < 2; ++f) dst[f] = job.chunks[f].back()->as<char>() + job.used[f].back();
+                const int rc = sim_pairs(*s, lo, hi, dst[0], room(0), &len[0], dst[1], room(1), &len[1], &n, nullptr, 0, (hipStream_t)stream);
+                if (rc == RSQ_ENOSPC && attempt < 2) {              // the estimate was too small (the first call has none): arrays for what the call asked
+                    for (int f = 0; f < 2; ++f)
+                        if (len[f] > room(f)) new_chunk(f, len[f] + len[f] / 16 + 65536);
+                    continue;
+                }
+                if (rc != RSQ_OK) return rc;
+                for (int f = 0; f < 2; ++f) {
+                    job.used[f].back() += len[f];
+                    job.bytes[f] += len[f];
+                    per_block[f] = std::max(per_block[f], (double)len[f] / (double)(hi - lo));
+                }
+                *n_pairs += n;
+                break;
+            }
+        }
+        *r1_bytes = job.bytes[0];
+        *r2_bytes = job.bytes[1];
+        return (int)RSQ_OK;
+    });
+}
+int rsq_sim_job_free(rsq_sim *s) {
+    REQUIRE(s, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        s->job.clear();
+        return (int)RSQ_OK;
+    });
+}
+int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file) {
+    REQUIRE(s && r1_path && r2_path, "null argument");
+    return guard([&] {
+        const rsq_sim::JobText &job = s->job;
+        const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 4u;
+        const char *paths[2] = {r1_path, r2_path};
+        const uint64_t offsets[2] = {r1_offset, r2_offset};
+        int fds[2] = {-1, -1};
+        for (int f = 0; f < 2; ++f) {
+            fds[f] = open(paths[f], O_WRONLY | O_CREAT, 0644);
+            if (fds[f] < 0) {
+                if (f) close(fds[0]);
+                throw Error(std::string("cannot open '") + paths[f] + "' for writing: " + strerror(errno));
+            }
+        }
+        std::atomic<bool> failed{false};
+        std::mutex message_mutex;
+        std::string message;
+        auto fail = [&](const std::string &m) {
+            std::lock_guard<std::mutex> lock(message_mutex);
+            if (!failed.exchange(true)) message = m;
+        };
+        // thread t of file f writes bytes [bytes * t / T, bytes * (t + 1) / T) of the file's text: slices of 32 MB, the copy of one overlapping the write of the one before
+        auto work = [&](int f, uint32_t t) {
+            try {
+                HIP_CHECK(hipSetDevice(s->device));
+                const uint64_t begin = job.bytes[f] * t / T, end = job.bytes[f] * (t + 1) / T;
+                if (begin == end) return;
+                hipStream_t st;
+                HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                char *host[2] = {nullptr, nullptr};
+                for (char *&h : host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), kJobSliceBytes, hipHostMallocDefault));
+                struct Slice {
+                    const char *src;
+                    size_t n;
+                    uint64_t at;                                    // place in the file's text
+                };
+                std::vector<Slice> slices;
+                uint64_t chunk_at = 0;
+                for (size_t c = 0; c < job.chunks[f].size(); ++c) {
+                    const uint64_t c_end = chunk_at + job.used[f][c], from = std::max(begin, chunk_at), to = std::min(end, c_end);
+                    for (uint64_t a = from; a < to; a += kJobSliceBytes) slices.push_back(Slice{job.chunks[f][c]->as<char>() + (a - chunk_at), (size_t)std::min<uint64_t>(kJobSliceBytes, to - a), a});
+                    chunk_at = c_end;
+                }
+                auto copy = [&](size_t i) { HIP_CHECK(hipMemcpyAsync(host[i & 1], slices[i].src, slices[i].n, hipMemcpyDeviceToHost, st)); };
+                if (!slices.empty()) copy(0);
+                for (size_t i = 0; i < slices.size() && !failed; ++i) {
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    if (i + 1 < slices.size()) copy(i + 1);
+                    size_t done = 0;
+                    while (done < slices[i].n) {
+                        const ssize_t w = pwrite(fds[f], host[i & 1] + done, slices[i].n - done, (off_t)(offsets[f] + slices[i].at + done));
+                        if (w < 0 && errno == EINTR) continue;
+                        if (w <= 0) throw Error(std::string("writing '") + paths[f] + "' failed: " + (w < 0 ? strerror(errno) : "no space"));
+                        done += (size_t)w;
+                    }
+                }
+                HIP_CHECK(hipStreamSynchronize(st));
+                for (char *h : host) (void)hipHostFree(h);
+                (void)hipStreamDestroy(st);
+            } catch (const std::exception &e) {
+                fail(e.what());
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int f = 0; f < 2; ++f)
+            for (uint32_t t = 0; t < T; ++t) pool.emplace_back(work, f, t);
+        for (std::thread &t : pool) t.join();
+        for (int f = 0; f < 2; ++f)
+            if (close(fds[f]) != 0) fail(std::string("closing '") + paths[f] + "' failed: " + strerror(errno));
+        if (failed) throw Error(message);
+        return (int)RSQ_OK;
+    });
 }
 
 int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,

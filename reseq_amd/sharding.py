@@ -3,11 +3,11 @@
 Blocks of 1000 start positions are independent given the replicated tables, the reference and the systematic-error
 tracks: a block's fragments, read ids and Philox counters depend on (seed, sequence, start, length) only.  Ranks therefore
 take disjoint contiguous block ranges and there is no data-path collective; the ranks' FASTQ shards in rank order are byte
-for byte the single-GPU output (Simulator.cpp:2384-2401 hands blocks to threads the same way).  Every rank copies its shard to
-its offset of the output file itself (place_shard), so the merge is N parallel copies, not one serial one.
-torch.distributed (RCCL on the GPU box, gloo in the CPU tests) carries only the job totals and the shard sizes.
+for byte the single-GPU output (Simulator.cpp:2384-2401 hands blocks to threads the same way).  Every rank keeps the text of its
+range in device memory until one all-gather of the sizes has told it its offset, then writes it there itself (rsq_sim_job_generate /
+rsq_sim_job_write): N parallel writers, no shard files.
+torch.distributed (RCCL on the GPU box, gloo in the CPU tests) carries only the job totals and the text sizes.
 """
-import os
 from typing import Callable, List, Sequence, Tuple
 
 
@@ -68,35 +68,6 @@ def gather_sizes(dist, device, mine: Sequence[int], world: int) -> List[List[int
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     return [[int(v) for v in row.tolist()] for row in out]
-
-
-def place_shard(shard_path: str, out_path: str, offset: int, chunk: int = 1 << 26) -> int:
-    """copies the whole shard file to `offset` of the (existing, already sized) output file; in-kernel copy where the
-    file system offers it (copy_file_range), pread / pwrite otherwise.  Returns the bytes copied."""
-    size = os.path.getsize(shard_path)
-    src, dst = os.open(shard_path, os.O_RDONLY), os.open(out_path, os.O_WRONLY)
-    try:
-        done, in_kernel = 0, hasattr(os, "copy_file_range")
-        while done < size:
-            n = 0
-            if in_kernel:
-                try:
-                    n = os.copy_file_range(src, dst, min(chunk, size - done), done, offset + done)
-                except OSError:
-                    in_kernel = False
-            if not in_kernel:
-                buf = os.pread(src, min(chunk, size - done), done)
-                n = os.pwrite(dst, buf, offset + done)
-            if n <= 0 and in_kernel:
-                in_kernel = False
-                continue
-            if n <= 0:
-                raise IOError(f"{shard_path}: no bytes copied at offset {done} of {size} (shard truncated while it was placed?)")
-            done += n
-        return done
-    finally:
-        os.close(src)
-        os.close(dst)
 
 
 def block_weights(seq_len, insert_to, ref_seq_bias):

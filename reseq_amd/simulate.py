@@ -5,9 +5,10 @@
 
 Every rank packs the replicated tables, takes a contiguous range of 1000-position blocks balanced by expected pairs
 (`sharding.partition_blocks`) and computes ITS share of the pre-passes (`sharding.sharded_prepare`: bias sums per chunk + one exact
-all-reduce, systematic-error chains over its own positions + the chain states at the shard borders), writes its FASTQ shard, and
-after one all-gather of the shard sizes every rank copies its shard to its own offset of the output files, all ranks at once
-(`sharding.place_shard`); rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
+all-reduce, systematic-error chains over its own positions + the chain states at the shard borders), simulates its blocks ONCE with the
+FASTQ text kept in device memory (`rsq_sim_job_generate`), and after one all-gather of the text sizes writes it straight to its own
+byte range of the two output files (`rsq_sim_job_write`: page-locked double buffers, several pwrite threads per file), all ranks at once --
+no shard files, no second copy, nothing through Python; rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
 (seed, sequence, start, length), not by rank (Simulator.cpp:2384-2401 distributes blocks over threads the same way).
 torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and three barriers.
@@ -36,7 +37,6 @@ class GpuBackend:
             self.sim.read_methylation(methylation_path)
         self.sys_error_path = sys_error_path
         self.device = device
-        self.r1 = self.r2 = None
         self.seq_len = [self.ref.sequence_length(i) for i in range(self.ref.num_sequences())]
 
     def prepare(self, seed, num_pairs, coverage, ref_bias_mode, base_identifier):
@@ -71,28 +71,18 @@ class GpuBackend:
     def prepare_finish(self):
         return self._info(self.sim.prepare_finish())
 
-    def pairs(self, lo, hi):
-        import numpy as np
-        api = self.api
-        for _ in range(2):
-            n, l1, l2, rc = self.sim.pairs_device(lo, hi, self.r1, self.r2)
-            if rc == api.RSQ_OK:
-                return n, self.r1.to_numpy(np.uint8, l1).tobytes() if n else b"", self.r2.to_numpy(np.uint8, l2).tobytes() if n else b""
-            if rc != api.RSQ_ENOSPC:
-                raise api.RsqError(rc, api.lib().rsq_last_error().decode())
-            for d in (self.r1, self.r2):
-                if d is not None:
-                    d.free()
-            self.r1, self.r2 = api.DeviceArray(self.device, l1 + l1 // 8 + 4096), api.DeviceArray(self.device, l2 + l2 // 8 + 4096)
-        raise RuntimeError("rsq_sim_pairs kept asking for larger buffers")
+    # the rank's share: simulated once, the text kept in device memory, then written to its place in the final files by the library's writer threads
+    def job_generate(self, lo, hi, batch_blocks):
+        return self.sim.job_generate(lo, hi, batch_blocks or 0)
+
+    def job_write(self, path1, offset1, path2, offset2):
+        self.sim.job_write(path1, offset1, path2, offset2)
+        self.sim.job_free()
 
     def adapter_only_pairs(self, first, n):
         return self.sim.adapter_only_pairs(first, n)
 
     def close(self):
-        for d in (self.r1, self.r2):
-            if d is not None:
-                d.free()
         self.sim.close()
         self.ref.close()
         self.prof.close()
@@ -102,8 +92,9 @@ block_weights = sharding.block_weights
 
 
 def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu"):
-    """One rank's share.  `backend` offers prepare / ref_seq_bias / seq_len / pairs / adapter_only_pairs.  Returns (pairs of the whole
-    job, seconds of the slowest rank)."""
+    """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
+    Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
+    small exchanges; the data never passes through Python."""
     if world > 1 and getattr(backend, "can_shard_prepare", False):   # every rank its share of the pre-passes
         info, mine, _ = sharding.sharded_prepare(backend, dist, device, rank, world, seed, num_pairs, coverage, ref_bias_mode, base_identifier)
     else:
@@ -111,32 +102,21 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
         weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
         assert len(weights) == info["total_blocks"]
         mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
-    if not batch_blocks:                                             # about 4 M pairs per call (large launches), at least 2000 blocks
-        batch_blocks = int(min(100000, max(2000, 4e6 * info["total_blocks"] / max(1, info["total_pairs"]))))
     t0 = time.perf_counter()
-    n_mine = n_bytes = 0
-    shard1, shard2 = f"{out1}.rank{rank}", f"{out2}.rank{rank}"
-    with open(shard1, "wb") as f1, open(shard2, "wb") as f2:
-        for lo, hi in sharding.batches(mine[0], mine[1], batch_blocks):
-            n, a, b = backend.pairs(lo, hi)
-            n_mine += n
-            n_bytes += len(a) + len(b)
-            f1.write(a)
-            f2.write(b)
-    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, n_bytes, time.perf_counter() - t0)
-    # every rank places its shard itself: offsets from the exclusive scan of the shard sizes (one all-gather of two lengths per rank)
-    sizes = sharding.gather_sizes(dist, device, [os.path.getsize(shard1), os.path.getsize(shard2)], world)
-    if rank == 0:
-        for out, col in ((out1, 0), (out2, 1)):
+    n_mine, bytes1, bytes2 = backend.job_generate(mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
+    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, bytes1 + bytes2, time.perf_counter() - t0)
+    # one all-gather of two lengths per rank: the exclusive scan over the ranks is every rank's offset in the final files
+    sizes = sharding.gather_sizes(dist, device, [bytes1, bytes2], world)
+    end1, end2 = (sum(row[col] for row in sizes) for col in (0, 1))
+    if rank == 0:                                                    # the files exist at the size of the ranks' text before anybody writes into them
+        for out, size in ((out1, end1), (out2, end2)):
             with open(out, "wb") as f:
-                f.truncate(sum(row[col] for row in sizes))
+                f.truncate(size)
     if dist is not None:
-        dist.barrier()                                               # the output files exist at their final size
-    for out, shard, col in ((out1, shard1, 0), (out2, shard2, 1)):
-        sharding.place_shard(shard, out, sum(row[col] for row in sizes[:rank]))
-        os.remove(shard)
+        dist.barrier()
+    backend.job_write(out1, sum(row[0] for row in sizes[:rank]), out2, sum(row[1] for row in sizes[:rank]))      # all ranks at once, each its own byte range
     if dist is not None:
-        dist.barrier()                                               # every shard is in place
+        dist.barrier()                                               # every rank's text is in place
     if rank == 0:
         with open(out1, "ab") as f1, open(out2, "ab") as f2:
             for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does

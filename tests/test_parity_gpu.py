@@ -96,6 +96,31 @@ def test_tiles_binned_although_they_fit(workdir, rsq_options):
     P.case_methylation(GpuBackend, workdir)
 
 
+def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
+    """rsq_sim_job_generate / rsq_sim_job_write (a rank's share of a multi-GPU job): the text of a block range generated in several calls, kept in device arrays
+    (here small ones, so that it spans many and calls outgrow their array), written by several threads per file at an offset of files that hold other bytes"""
+    import numpy as np
+    from parity_cases import make_inputs
+    from reseq_amd import synth
+    ppath, fpath, _ = make_inputs(workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210])
+    b = GpuBackend(ppath, fpath)
+    info = b.prepare(7, num_pairs=3000)
+    lo, hi = 2, info["total_blocks"] + 1
+    frags, t1, t2 = b.pairs(lo, hi)
+    for chunk_bytes, batch, threads in ((0, 0, 0), (30_000, 2, 3), (5_000, 1, 5)):
+        rsq_options("job_chunk_bytes", chunk_bytes)
+        n, n1, n2 = b.sim.job_generate(lo, hi, batch)
+        assert (n, n1, n2) == (len(frags), len(t1), len(t2))
+        f1, f2 = workdir / "job_1.fq", workdir / "job_2.fq"
+        f1.write_bytes(b"x" * (len(t1) + 300))
+        f2.write_bytes(b"y" * 50)                                     # shorter than offset + text: pwrite extends it
+        b.sim.job_write(f1, 100, f2, 70, threads)
+        assert f1.read_bytes() == b"x" * 100 + t1 + b"x" * 200
+        assert f2.read_bytes() == b"y" * 50 + bytes(20) + t2
+        b.sim.job_free()
+    b.close()
+
+
 @pytest.mark.parametrize("parts", [2, 3, 7])
 def test_pipelined_sub_ranges(workdir, parts, rsq_options):
     """rsq_sim_pairs over a large block range runs as sub-ranges whose sieve / reads / text stages overlap on three streams (two workspaces, offsets

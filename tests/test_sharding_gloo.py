@@ -51,9 +51,20 @@ class Emu:                      # the host emulation behind the interface simula
         return self.b.prepare_finish()
     def ref_seq_bias(self):
         return self.b.ref_seq_bias(self.n_seqs)
-    def pairs(self, lo, hi):
-        fr, a, b = self.b.pairs(lo, hi)
-        return len(fr), a, b
+    def job_generate(self, lo, hi, batch_blocks):          # what rsq_sim_job_generate / rsq_sim_job_write do, for the host emulation: the text kept, then put in place
+        from reseq_amd import sharding
+        self.text, n = [bytearray(), bytearray()], 0
+        for a, b in sharding.batches(lo, hi, batch_blocks or 2000):
+            fr, t1, t2 = self.b.pairs(a, b)
+            n += len(fr)
+            self.text[0] += t1
+            self.text[1] += t2
+        return n, len(self.text[0]), len(self.text[1])
+    def job_write(self, path1, offset1, path2, offset2):
+        for path, offset, text in ((path1, offset1, self.text[0]), (path2, offset2, self.text[1])):
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+            os.pwrite(fd, bytes(text), offset)
+            os.close(fd)
     def adapter_only_pairs(self, first, n):
         return self.b.adapter_only_pairs(first, n)
 
