@@ -195,7 +195,8 @@ typedef struct {
  * whole range in device memory -- 288 GB of HBM hold a rank's share of a 30x human-sized job (236 GB of text over 8 ranks) with room to spare -- so that the
  * ranks can exchange their sizes BEFORE anything is written and every rank then writes straight to its own offset of the two final files: no shard files, no
  * second copy, no second simulation.  rsq_sim_job_write copies the kept text through page-locked double buffers and pwrite()s it at the given offsets with
- * `threads_per_file` threads per file (each its own part of the range, stream and buffers; 0: 4); the files are created if need be, never truncated.
+ * `threads_per_file` threads per file (each its own part of the range, stream and buffers; 0: 1 -- buffered writes into one file serialise on its inode lock); the files
+ * are created if need be, never truncated.
  * rsq_sim_job_free releases the text (rsq_sim_free does too).  A single-process run has offset 0 and may as well stream (the `reseq` command line does). */
 int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint32_t batch_blocks, uint64_t *n_pairs, uint64_t *r1_bytes, uint64_t *r2_bytes, void *stream);
 int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file);

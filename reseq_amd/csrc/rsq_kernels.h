@@ -1203,11 +1203,24 @@ struct FragmentSrc {                    // template of one mate cut from the 2-b
 };
 
 // ------------------------------------------------------------------------------------- bisulfite conversion (a16)
-// Simulator::CTConversion without variants (Simulator.cpp:1925-2002), once per (start, length, strand) site and mate, so
-// that all duplicates of a site share the converted template.  Restated with the reference's variable widths: read_pos is
-// a uintReadLen (uint16_t) and wraps when the next region is more than 65535 bases away, and the reverse walk stops at
-// region index 0 (`while(cur_meth && ...)`), exactly as written there.  The uniform of template position k is word k&3 of
-// Philox block (start, sequence, length, 7<<28 | reversed<<27 | k>>2).
+// Simulator::CTConversion (Simulator.cpp:1925-2247): a C of a template becomes a T with probability 1 - methylation where the template lies in an
+// unmethylated region of the BED file; once per (start, length, strand) site and mate, so that all duplicates of a site share the converted template.
+// The uniform of template position k is word k&3 of Philox block (start, sequence, length, 7<<28 | reversed<<27 | k>>2) -- a pure function of k, so
+// the walk below may visit positions in any grouping.
+//
+// The reference walks template and reference base by base, in three overloads times two mirrored directions.  Here ONE walk serves both strands and
+// both cases (with and without variants): positions are taken in the strand's own direction (MethSide: x = pos on the forward strand, -pos on the
+// reverse strand, so regions and variants are met in increasing x either way), and the walk advances by EVENTS -- a region's entry and exit, the
+// variant the cursor points at, the template's end -- converting whole runs of template positions at once (the C's of a run are found 32 bases per
+// word).  What the reference's walk does beyond the plain geometry is kept, because it decides bytes of the output (DESIGN.md section 1 lists it):
+//   * the template position is 16 bits wide (uintReadLen): a jump over more than 65535 bases wraps, and the walk goes on if the wrapped value is
+//     below the template length;
+//   * the reverse mate's walk begins at the fragment's end position (one past its last base), not at the last base;
+//   * without variants the reverse walk never enters the sequence's first region (`while(cur_meth && ...)`); with variants it does;
+//   * a deleted base inside a region takes a template position (without converting it);
+//   * only the variant under the cursor is looked at: variants of other alleles at a position are passed over when the walk stands on them, but a
+//     second variant at the position of one that was just used stays under the cursor and hides all later ones until the next stretch without regions;
+//   * the reference reads its `deletion` flag before writing it (Simulator.cpp:2026): here it starts as false.
 struct MethView {
     const uint32_t *first, *second;
     const double *rate;                 // of the allele asked for: rate[region * stride]
@@ -1243,168 +1256,120 @@ struct MethDraws {                      // lazily evaluated Philox blocks of one
         return u32_to_unit(j == 0u ? w.w0 : (j == 1u ? w.w1 : (j == 2u ? w.w2 : w.w3)));
     }
 };
-RSQ_HD void ct_convert_base(uint64_t *tmpl, uint32_t k, double rate, MethDraws &d) {
-    const uint32_t sh = (k & 31u) * 2u;
-    if (((tmpl[k >> 5] >> sh) & 3u) == 1u && d.uniform(k) < rate) tmpl[k >> 5] |= (uint64_t)3u << sh;      // C (1) -> T (3)
-}
-RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, uint32_t start_pos, uint32_t cur_methylation_start, bool reversed, MethDraws &d) {
-    int32_t cur_meth = (int32_t)cur_methylation_start;
-    uint16_t read_pos = 0;
-    uint32_t ref_pos = start_pos;
-    const int32_t n = (int32_t)m.n;
-    if (reversed) {
-        while (cur_meth < n && m.first[cur_meth] <= ref_pos) ++cur_meth;       // bring cur_meth to the last region in reach
-        --cur_meth;
-        if (cur_meth > 0 && m.second[cur_meth] <= ref_pos) {                     // `if( cur_meth && ...)`: -1 would index out of range in the reference
-            read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
-            ref_pos = m.second[cur_meth] - 1u;
-        }
-        while (cur_meth > 0 && read_pos < length) {
-            while (ref_pos >= m.first[cur_meth] && read_pos < length) {
-                ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
-                --ref_pos;
-                ++read_pos;
-            }
-            if (--cur_meth > 0 && m.second[cur_meth] <= ref_pos) {
-                read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
-                ref_pos = m.second[cur_meth] - 1u;
-            }
-        }
-    } else {
-        if (cur_meth < n && m.first[cur_meth] > ref_pos) {
-            read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
-            ref_pos = m.first[cur_meth];
-        }
-        while (cur_meth < n && read_pos < length) {
-            while (ref_pos < m.second[cur_meth] && read_pos < length) {
-                ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
-                ++ref_pos;
-                ++read_pos;
-            }
-            if (++cur_meth < n) {
-                read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
-                ref_pos = m.first[cur_meth];
-            }
+// template positions [t, t + n) lie in a region with conversion probability `rate`: the C's among them (code 1: low bit set, high bit clear), word by word
+RSQ_HD void ct_convert_run(uint64_t *tmpl, uint32_t t, uint32_t n, double rate, MethDraws &d) {
+    const uint32_t end = t + n;
+    for (uint32_t w = t >> 5; (w << 5) < end; ++w) {
+        const uint32_t lo = t > (w << 5) ? t - (w << 5) : 0u, hi = end - (w << 5) < 32u ? end - (w << 5) : 32u;      // bases lo .. hi-1 of the word
+        uint64_t cs = tmpl[w] & ~(tmpl[w] >> 1) & 0x5555555555555555ull;
+        cs &= (hi == 32u ? ~0ull : (1ull << (2u * hi)) - 1ull) & ~((1ull << (2u * lo)) - 1ull);
+        while (cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t bit = (uint32_t)__ffsll((long long)cs) - 1u;
+#else
+            const uint32_t bit = (uint32_t)__builtin_ctzll(cs);
+#endif
+            cs &= cs - 1ull;
+            if (d.uniform((w << 5) + (bit >> 1)) < rate) tmpl[w] |= (uint64_t)3u << bit;                             // C (1) -> T (3)
         }
     }
 }
-
-// Simulator::CTConversion with variants (Simulator.cpp:2004-2217), restated like the plain one: read_pos is 16 bits wide, cur_meth
-// signed; `deletion` (read before it is written in the reference) starts as false.
-RSQ_HD void ct_conversion_variants(uint64_t *tmpl, uint32_t length, const MethView &m, const VarView &r, uint32_t start_pos, uint32_t allele, uint32_t cur_methylation_start,
-                                   bool reversed, VarStart first_variant, MethDraws &d) {
-    int32_t cur_meth = (int32_t)cur_methylation_start;
-    uint16_t read_pos = 0;
-    uint32_t ref_pos = start_pos;
-    const int32_t n = (int32_t)m.n, n_var = (int32_t)r.n;
-    int32_t cur_var = first_variant.first_variant_id;
-    uint32_t var_bases_left = 0;
-    bool deletion = false;
-    if (reversed) {
-        if (0 <= cur_var && r.v[cur_var].pos == ref_pos && 1u < r.v[cur_var].len && r.in_allele(r.v[cur_var], allele)) var_bases_left = r.v[cur_var].len - first_variant.start_variant_pos;
-        while (cur_meth < n && m.first[cur_meth] <= ref_pos) ++cur_meth;
-        --cur_meth;
-        if (0 <= cur_meth && m.second[cur_meth] <= ref_pos) {
-            if (var_bases_left) {
-                read_pos = (uint16_t)(read_pos + var_bases_left);
-                var_bases_left = 0;
-                --ref_pos;
-                --cur_var;
-            }
-            while (0 <= cur_var && m.second[cur_meth] <= r.v[cur_var].pos && read_pos < length) {
-                if (r.in_allele(r.v[cur_var], allele)) {
-                    read_pos = (uint16_t)(read_pos + (ref_pos - r.v[cur_var].pos));
-                    read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
-                    ref_pos = r.v[cur_var].pos - 1u;
-                }
-                --cur_var;
-            }
-            read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
-            ref_pos = m.second[cur_meth] - 1u;
+// regions and variants as the walk of one strand meets them
+template <bool REV>
+struct MethSide {
+    const MethView &m;
+    const VarView *r;                   // nullptr: no variants loaded
+    uint32_t allele;
+    int32_t lowest;                     // the reverse walk's last region: 1 without variants, 0 with
+    RSQ_HD int64_t coord(uint32_t pos) const { return REV ? -(int64_t)pos : (int64_t)pos; }
+    RSQ_HD int64_t entry(int32_t i) const { return REV ? 1 - (int64_t)m.second[i] : (int64_t)m.first[i]; }      // the first x inside the region
+    RSQ_HD int64_t exit(int32_t i) const { return REV ? 1 - (int64_t)m.first[i] : (int64_t)m.second[i]; }       // the first x behind it
+    RSQ_HD bool region(int32_t i) const { return REV ? i >= lowest : i < (int32_t)m.n; }
+    RSQ_HD bool variant(int32_t j) const { return r && (REV ? j >= 0 : j < (int32_t)r->n); }
+    RSQ_HD static int32_t next(int32_t i) { return REV ? i - 1 : i + 1; }
+    RSQ_HD int64_t at(int32_t j) const { return coord(r->v[j].pos); }
+    RSQ_HD uint32_t len(int32_t j) const { return r->v[j].len; }
+    RSQ_HD bool mine(int32_t j) const { return r->in_allele(r->v[j], allele); }
+    // the region the walk begins in or in front of: forward the first that ends behind the position, reverse the last that begins at or before it
+    RSQ_HD int32_t first_region(uint32_t pos) const {
+        if (!REV) return (int32_t)meth_start_index(m, pos);
+        uint32_t lo = 0, hi = m.n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (m.first[mid] <= pos) lo = mid + 1;
+            else hi = mid;
         }
-        while (0 <= cur_meth && read_pos < length) {
-            while (ref_pos >= m.first[cur_meth] && read_pos < length) {
-                if (0u == var_bases_left) {
-                    while (0 <= cur_var && r.v[cur_var].pos == ref_pos && !r.in_allele(r.v[cur_var], allele)) --cur_var;
-                    if (0 <= cur_var && r.v[cur_var].pos == ref_pos) {
-                        if (0u == r.v[cur_var].len) {
-                            deletion = true;
-                            --cur_var;
-                        } else var_bases_left = r.v[cur_var].len;
-                    }
-                }
-                if (deletion) deletion = false;
-                else ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
-                if (var_bases_left)
-                    if (0u == --var_bases_left) --cur_var;
-                if (0u == var_bases_left) --ref_pos;
-                ++read_pos;
-            }
-            if (0 <= --cur_meth && m.second[cur_meth] <= ref_pos) {
-                while (0 <= cur_var && m.second[cur_meth] <= r.v[cur_var].pos && read_pos < length) {
-                    if (r.in_allele(r.v[cur_var], allele)) {
-                        read_pos = (uint16_t)(read_pos + (ref_pos - r.v[cur_var].pos));
-                        read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
-                        ref_pos = r.v[cur_var].pos - 1u;
-                    }
-                    --cur_var;
-                }
-                read_pos = (uint16_t)(read_pos + (ref_pos - (m.second[cur_meth] - 1u)));
-                ref_pos = m.second[cur_meth] - 1u;
-            }
-        }
-    } else {
-        if (cur_var < n_var && r.v[cur_var].pos == ref_pos && 1u < r.v[cur_var].len && r.in_allele(r.v[cur_var], allele)) var_bases_left = r.v[cur_var].len - first_variant.start_variant_pos;
-        if (cur_meth < n && m.first[cur_meth] > ref_pos) {
-            if (var_bases_left) {
-                read_pos = (uint16_t)(read_pos + var_bases_left);
-                var_bases_left = 0;
-                ++ref_pos;
-                ++cur_var;
-            }
-            while (cur_var < n_var && m.first[cur_meth] > r.v[cur_var].pos && read_pos < length) {
-                if (r.in_allele(r.v[cur_var], allele)) {
-                    read_pos = (uint16_t)(read_pos + (r.v[cur_var].pos - ref_pos));
-                    read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
-                    ref_pos = r.v[cur_var].pos + 1u;
-                }
-                ++cur_var;
-            }
-            read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
-            ref_pos = m.first[cur_meth];
-        }
-        while (cur_meth < n && read_pos < length) {
-            while (ref_pos < m.second[cur_meth] && read_pos < length) {
-                if (0u == var_bases_left) {
-                    while (cur_var < n_var && r.v[cur_var].pos == ref_pos && !r.in_allele(r.v[cur_var], allele)) ++cur_var;
-                    if (cur_var < n_var && r.v[cur_var].pos == ref_pos) {
-                        if (0u == r.v[cur_var].len) {
-                            deletion = true;
-                            ++cur_var;
-                        } else var_bases_left = r.v[cur_var].len;
-                    }
-                }
-                if (deletion) deletion = false;
-                else ct_convert_base(tmpl, read_pos, m.rate_of(cur_meth), d);
-                if (var_bases_left)
-                    if (0u == --var_bases_left) ++cur_var;
-                if (0u == var_bases_left) ++ref_pos;
-                ++read_pos;
-            }
-            if (++cur_meth < n && m.first[cur_meth] > ref_pos) {
-                while (cur_var < n_var && m.first[cur_meth] > r.v[cur_var].pos && read_pos < length) {
-                    if (r.in_allele(r.v[cur_var], allele)) {
-                        read_pos = (uint16_t)(read_pos + (r.v[cur_var].pos - ref_pos));
-                        read_pos = (uint16_t)(read_pos + r.v[cur_var].len);
-                        ref_pos = r.v[cur_var].pos + 1u;
-                    }
-                    ++cur_var;
-                }
-                read_pos = (uint16_t)(read_pos + (m.first[cur_meth] - ref_pos));
-                ref_pos = m.first[cur_meth];
-            }
-        }
+        return (int32_t)lo - 1;
     }
+};
+template <bool REV>
+RSQ_HD void methylation_walk(uint64_t *tmpl, uint32_t length, const MethView &m, const VarView *r, uint32_t allele, uint32_t start_pos, VarStart from, MethDraws &d) {
+    const MethSide<REV> side{m, r, allele, r ? 0 : 1};
+    int64_t x = side.coord(start_pos);
+    uint16_t t = 0;                                                   // uintReadLen
+    int32_t region = side.first_region(start_pos), var = r ? from.first_variant_id : -1;
+    uint32_t left = 0;                                                // bases of the variant at x the walk has not passed yet
+    if (side.variant(var) && side.at(var) == x && side.len(var) > 1u && side.mine(var)) left = side.len(var) - from.start_variant_pos;
+    // the stretch without information in front of `region`: the template position moves on by what the allele holds there
+    auto skip_to = [&](int32_t reg) {
+        if (left) {
+            t = (uint16_t)(t + left);
+            left = 0;
+            ++x;
+            var = side.next(var);
+        }
+        while (side.variant(var) && side.at(var) < side.entry(reg) && t < length) {
+            if (side.mine(var)) {
+                t = (uint16_t)(t + (uint16_t)(side.at(var) - x) + (uint16_t)side.len(var));
+                x = side.at(var) + 1;
+            }
+            var = side.next(var);
+        }
+        t = (uint16_t)(t + (uint16_t)(side.entry(reg) - x));
+        x = side.entry(reg);
+    };
+    if (side.region(region) && side.entry(region) > x) skip_to(region);
+    while (side.region(region) && t < length) {
+        const double rate = m.rate_of(region);
+        const int64_t out = side.exit(region);
+        while (x < out && t < length) {
+            if (!left) {                                              // does a variant of the allele begin here?
+                while (side.variant(var) && side.at(var) == x && !side.mine(var)) var = side.next(var);
+                if (side.variant(var) && side.at(var) == x) {
+                    if (0u == side.len(var)) {                        // the deleted base: a template position passes unconverted
+                        var = side.next(var);
+                        ++x;
+                        ++t;
+                        continue;
+                    }
+                    left = side.len(var);
+                }
+            }
+            uint32_t run;
+            if (left) {                                               // the variant's bases, all at this x
+                run = left < length - t ? left : length - t;
+                left -= run;
+                if (!left) {
+                    var = side.next(var);
+                    ++x;
+                }
+            } else {                                                  // reference bases up to the region's end or the variant under the cursor
+                int64_t until = out;
+                if (side.variant(var) && side.at(var) > x && side.at(var) < until) until = side.at(var);
+                run = until - x < (int64_t)(length - t) ? (uint32_t)(until - x) : length - t;
+                x += run;
+            }
+            ct_convert_run(tmpl, t, run, rate, d);
+            t = (uint16_t)(t + run);
+        }
+        region = side.next(region);
+        if (side.region(region) && side.entry(region) > x) skip_to(region);
+    }
+}
+// CTConversion of one mate's template: `start_pos` = the fragment's start (forward mate) or END position (reverse mate), `r` = the sequence's variants or nullptr
+RSQ_HD void ct_conversion(uint64_t *tmpl, uint32_t length, const MethView &m, const VarView *r, uint32_t allele, uint32_t start_pos, bool reversed, VarStart from, MethDraws &d) {
+    if (reversed) methylation_walk<true>(tmpl, length, m, r, allele, start_pos, from, d);
+    else methylation_walk<false>(tmpl, length, m, r, allele, start_pos, from, d);
 }
 
 struct EmptySrc {                       // adapter-only pair: org_seq_ = "" (Simulator.cpp:2369-2371)
@@ -1818,7 +1783,7 @@ RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, u
     for (uint32_t k = 0; k < src.len; ++k) tmpl[k >> 5] |= (uint64_t)src.ref(k) << ((k & 31u) * 2u);
     const MethView m = meth_view(S, f.seq);
     MethDraws d{S.seed, f.start, f.seq, f.len, (kDomMethylation << 28) | ((src.reverse ? 1u : 0u) << 27), 0xFFFFFFFFu, Words{0, 0, 0, 0}};
-    ct_conversion(tmpl, src.len, m, src.first, meth_start_index(m, f.start), src.reverse, d);
+    ct_conversion(tmpl, src.len, m, nullptr, 0u, src.first, src.reverse, VarStart{0, 0u}, d);
 }
 
 // the template of mate `seg` with variants of any kind: the forward mate from the start variant, the reverse mate from the end variant
@@ -1833,7 +1798,7 @@ RSQ_HD void variant_template(const DevSim &S, const Fragment &f, const FragmentV
         const MethView m = meth_view(S, f.seq, f.allele);
         MethDraws d{S.seed, f.start, f.seq | (fv.sub << 22), f.len, (kDomMethylation << 28) | ((reversed ? 1u : 0u) << 27) | ((uint32_t)f.allele << 17), 0xFFFFFFFFu,
                     Words{0, 0, 0, 0}};
-        ct_conversion_variants(tmpl, tl, m, r, at, f.allele, meth_start_index(meth_view(S, f.seq), f.start), reversed, from, d);
+        ct_conversion(tmpl, tl, m, &r, f.allele, at, reversed, from, d);
     }
 }
 

@@ -1413,11 +1413,19 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         const size_t chunk_bytes = options().job_chunk_bytes > 0 ? (size_t)options().job_chunk_bytes : kJobChunkBytes;
         if (!batch_blocks)                                          // about 4 M pairs per call (large launches), at least 2000 blocks
             batch_blocks = (uint32_t)std::min(100000.0, std::max(2000.0, 4e6 * (double)s->total_blocks / (double)std::max<uint64_t>(1, s->total_pairs)));
-        double per_block[2] = {0.0, 0.0};                           // the largest bytes per block seen so far: what the next call is given room for
+        // bytes per block a call is given room for: the largest seen so far; before the first call 400 bytes per read (2 x 150 characters, an id of 60 to 90) at the
+        // job's pair density
+        const double prior = 400.0 * (double)s->total_pairs / (double)std::max<uint32_t>(1, s->total_blocks);
+        double per_block[2] = {prior, prior};
         auto room = [&](int f) { return job.chunks[f].empty() ? (size_t)0 : job.chunks[f].back()->bytes() - job.used[f].back(); };
+        // arrays: the whole range in one when memory allows (option job_chunk_bytes unset), else pieces of 2 GiB
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+        const size_t whole = (size_t)(prior * (double)(block_hi - block_lo) * 1.1) + ((size_t)64 << 20);
+        const size_t first_chunk = options().job_chunk_bytes > 0 ? chunk_bytes : (2 * whole + ((size_t)8 << 30) < free_bytes ? std::max(whole, chunk_bytes) : chunk_bytes);
         auto new_chunk = [&](int f, size_t at_least) {
             job.chunks[f].emplace_back(new DevBuf());
-            job.chunks[f].back()->reserve(std::max(chunk_bytes, at_least));
+            job.chunks[f].back()->reserve(std::max(job.chunks[f].size() == 1 ? first_chunk : chunk_bytes, at_least));
             job.used[f].push_back(0);
         };
         for (uint32_t lo = block_lo; lo < block_hi; lo += batch_blocks) {
@@ -1464,10 +1472,13 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
     REQUIRE(s && r1_path && r2_path, "null argument");
     return guard([&] {
         const rsq_sim::JobText &job = s->job;
-        const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 4u;
+        const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 1u;
         const char *paths[2] = {r1_path, r2_path};
         const uint64_t offsets[2] = {r1_offset, r2_offset};
         int fds[2] = {-1, -1};
+        // Buffered pwrite()s into ONE file take the inode's lock one after the other, so more threads per file do not help on tmpfs or ext4 (measured on /dev/shm, 23 GB:
+        // 1 thread per file 12.9 GB/s, 4 threads 7.5, 8 threads 7.2); copying into a shared mapping of the pre-sized file avoids that lock but pays a page fault per
+        // 4 KB (6.4 GB/s however many threads) -- profiles/r03_e_*.  One thread per file is the default; file systems with concurrent direct I/O may want more.
         for (int f = 0; f < 2; ++f) {
             fds[f] = open(paths[f], O_WRONLY | O_CREAT, 0644);
             if (fds[f] < 0) {

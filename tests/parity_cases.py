@@ -871,6 +871,43 @@ def case_variants_with_methylation(backend_cls, workdir):
             p.close()
 
 
+def case_variants_methylation_far_regions(backend_cls, workdir, seeds=(73, 79)):
+    """CTConversion with variants where the reference's walk is more than geometry: regions more than 65535 bases apart (the 16-bit
+    template position wraps and the walk goes on), variants of both kinds inside, at the borders of and between the regions, records with two
+    alternatives at one position (the variant cursor stays behind on the second one), deletions inside regions, fragments that start inside inserted bases"""
+    lengths = [140000, 2300]
+    for seed in seeds:
+        tag = f"vmeth_far{seed}"
+        rng = np.random.default_rng(seed)
+        seqs = make_inputs(workdir, tag, synth.TINY, lengths, ref_seed=seed)[2]
+        vs = sorted(set((si, p0, rl, alt, gt) for si, p0, rl, alt, gt in _complex_variant_set(seqs, rng, 40) + _mixed_variant_set(seqs, rng, 35, [99, 100, 101, 699, 700, 66100, 66101, 131900])),
+                    key=lambda v: (v[0], v[1]))
+        kept, last = [], (-1, -1)
+        for v in vs:                                              # the two generators' records must not overlap; none near a sequence end (the reference's error walk leaves the sequence there)
+            if (v[0], v[1]) > last and 60 <= v[1] < lengths[v[0]] - 400:
+                kept.append(v)
+                last = (v[0], v[1] + v[2] + 1)
+        vcf = workdir / f"{tag}.vcf"
+        write_vcf(vcf, seqs, kept)
+        names = [n.split(" ")[0] for n, _ in seqs]
+        bed = workdir / f"{tag}.bed"
+        bed.write_text(f"{names[0]}\t100\t700\t0.1\t0.6\n{names[0]}\t66100\t66800\t0.0\t0.3\n{names[0]}\t66830\t66831\t0.2\t0.2\n{names[0]}\t131900\t132600\t0.4\t0.0\n"
+                       f"{names[1]}\t5\t2290\t0.25\n")
+        p = Pair(backend_cls, workdir, tag, synth.TINY, lengths, seed=seed, num_pairs=200000, vcf=vcf, ref_seed=seed)
+        try:
+            p.b.read_methylation(bed)
+            p.osim.read_methylation(bed)
+            p.align_normalization()
+            tb = p.info["total_blocks"]
+            n = 0
+            for lo, hi in ((1, 3), (66, 69), (131, 135), (141, tb + 1)):      # around the regions, and the second sequence
+                ofr, _ = _compare_blocks_var(p, lo, min(hi, tb + 1))
+                n += len(ofr)
+            assert n > 10000
+        finally:
+            p.close()
+
+
 def case_variants_rejected(backend_cls, workdir):
     """more alleles than Reference::Variant::kMaxAlleles (128) are refused with the reference's message (Reference.cpp:1016-1019)"""
     import pytest

@@ -398,6 +398,10 @@ def test_variants_with_loaded_sys_errors(workdir):
     P.case_variants_with_loaded_sys_errors(GpuBackend, workdir)
 
 
+def test_variants_with_methylation_in_regions_far_apart(workdir):
+    P.case_variants_methylation_far_regions(GpuBackend, workdir)
+
+
 def test_variants_with_methylation(workdir):
     P.case_variants_with_methylation(GpuBackend, workdir)
 

@@ -225,6 +225,10 @@ def test_variants_with_loaded_sys_errors(workdir):
     P.case_variants_with_loaded_sys_errors(EmuBackend, workdir)
 
 
+def test_variants_with_methylation_in_regions_far_apart(workdir):
+    P.case_variants_methylation_far_regions(EmuBackend, workdir)
+
+
 def test_variants_with_methylation(workdir):
     P.case_variants_with_methylation(EmuBackend, workdir)
 

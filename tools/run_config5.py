@@ -120,6 +120,31 @@ for name, batch in (("batch_24000", 24000), ("batch_12000", 12000)):
             h2.update(r2.to_numpy(np.uint8, l2).tobytes())
     out[name] = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
     out[name]["sha256_first_48000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
+# `python tools/run_config5.py <scale> job`: the whole range as ONE rank's share -- generated once with the text kept in HBM (rsq_sim_job_generate), then written to
+# files in /dev/shm by the library's writer threads (rsq_sim_job_write): seconds and GB/s of both, and that the files hold the bytes of the batched run
+job = None
+if "job" in sys.argv[2:]:
+    import shutil
+    free = shutil.disk_usage("/dev/shm").free
+    t1 = time.perf_counter()
+    n, b1, b2 = sim.job_generate(1, nb + 1, 24000)
+    t_gen = time.perf_counter() - t1
+    job = {"pairs": n, "fastq_bytes": b1 + b2, "generate_s": round(t_gen, 3), "pairs_per_s": n / t_gen, "dev_shm_free_bytes": free}
+    if b1 + b2 < 0.8 * free:
+        p1, p2 = "/dev/shm/rsq_c5_1.fq", "/dev/shm/rsq_c5_2.fq"
+        for threads in (1, 2, 4):
+            t1 = time.perf_counter()
+            sim.job_write(p1, 0, p2, 0, threads)
+            t_w = time.perf_counter() - t1
+            job[f"write_{threads}_threads_per_file"] = {"seconds": round(t_w, 3), "gbytes_per_s": round((b1 + b2) / t_w / 1e9, 2)}
+        h1, h2 = hashlib.sha256(), hashlib.sha256()
+        first = out["batch_24000"]
+        with open(p1, "rb") as f1, open(p2, "rb") as f2:
+            ok_size = os.path.getsize(p1) == b1 and os.path.getsize(p2) == b2 and b1 + b2 == first["fastq_bytes"]
+        job["sizes_equal_batched_run"] = bool(ok_size and n == first["pairs"])
+        os.remove(p1)
+        os.remove(p2)
+    sim.job_free()
 # `python tools/run_config5.py <scale> shard`: the pre-pass of the same job sharded over 2, 4, 8 ranks (the ranks' simulators in this process,
 # sharding.sharded_prepare_in_process): seconds per rank, and that a rank's blocks then simulate to the same text as after the whole pre-pass
 sharded = None
@@ -184,7 +209,7 @@ if "shard" in sys.argv[2:]:
         for r in ranks:
             r.sim.close()
 
-print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU" + (", substitutions only, no methylation" if snv_only else ""), "sharded_prepare": sharded, "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
+print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU" + (", substitutions only, no methylation" if snv_only else ""), "sharded_prepare": sharded, "job": job, "reference_bp": total, "sequences": len(lengths), "alleles": alleles,
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": out["batch_24000"]["pairs"] / out["batch_24000"]["gpu_s"],
