@@ -855,8 +855,16 @@ RSQ_HD void cigar_replay(const WordColumn &ops, const ReadMeta &m, Sink &sink) {
 template <class Derived>
 struct TextOps {                        // what a record is made of, on top of Derived::ch
     RSQ_HD Derived &self() { return *static_cast<Derived *>(this); }
+    // four characters per push (the sinks take up to four bytes at once): the id line is mostly fixed text
     RSQ_HD void str(const char *s, uint32_t len) {
-        for (uint32_t i = 0; i < len; ++i) self().ch(s[i]);
+        uint32_t i = 0;
+        for (; i + 4u <= len; i += 4u)
+            self().bytes((uint32_t)(uint8_t)s[i] | ((uint32_t)(uint8_t)s[i + 1u] << 8) | ((uint32_t)(uint8_t)s[i + 2u] << 16) | ((uint32_t)(uint8_t)s[i + 3u] << 24), 4u);
+        if (i < len) {
+            uint32_t w = 0;
+            for (uint32_t k = 0; i + k < len; ++k) w |= (uint32_t)(uint8_t)s[i + k] << (8u * k);
+            self().bytes(w, len - i);
+        }
     }
     // decimal digits without a buffer: peeled from the least significant end into a register, most significant digit lowest, then handed to the
     // sink four at a time

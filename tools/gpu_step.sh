@@ -1,6 +1,6 @@
 # GPU check of the working tree: the -m gpu suite, then the headline bench (no CPU baseline), the kernel times of its last batch
 mkdir -p gpurun_out/step
-python -m pytest tests -m gpu -x -q > gpurun_out/step/tests.log 2>&1; echo "tests rc $?"; tail -4 gpurun_out/step/tests.log
+if [ -z "$NO_TESTS" ]; then python -m pytest tests -m gpu -x -q > gpurun_out/step/tests.log 2>&1; echo "tests rc $?"; tail -4 gpurun_out/step/tests.log; fi
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery"
 run() { tag=$1; shift; $B "$@" > gpurun_out/step/bench_$tag.json 2> gpurun_out/step/bench_$tag.err || tail -3 gpurun_out/step/bench_$tag.err
 python -c "
