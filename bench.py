@@ -215,10 +215,12 @@ def parity_on_sample(profile_path, seqs, seed, device, oracle_text):
 
 
 # ------------------------------------------------------------------------------------------------------- roofline evidence
-def committed_counters():
-    """Counters cannot be read from inside an un-profiled run: the newest committed collection of profiles/collect.sh is reported with
-    its file name and the kernel it was taken from (bench.py's own launch time of that kernel is next to it, so a stale file shows)."""
+def committed_counters(tiles=1):
+    """Counters cannot be read from inside an un-profiled run: the newest committed collection of profiles/collect.sh for this workload is reported
+    with its file name and the kernel it was taken from (bench.py's own launch time of that kernel is next to it, and `counters_stale` says whether
+    the kernel sources have changed since)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_pmc.json")))      # by name: round, then letter (mtimes do not survive a checkout)
+    files = [f for f in files if (f"_tiles{tiles}_" in os.path.basename(f)) == (tiles > 1) and ("_tiles" in os.path.basename(f)) == (tiles > 1)]
     if not files:
         return None
     tag = os.path.basename(files[-1])[:-len("_pmc.json")]
@@ -404,7 +406,7 @@ def main():
         launches = max(fill_launches, 1)                                   # k_fill_reads launches in the timed region
         avg_fill_s = fill_ms / 1e3 / launches
         achieved = A_PAIR * (pairs / launches) / avg_fill_s / 1e9          # GB/s of algorithmic traffic in the dominant kernel
-        counters = committed_counters()
+        counters = committed_counters(args.tiles)
         out = {
             "metric": "simulated read-pairs/sec (2x150 bp)", "value": total_pairs / elapsed, "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
