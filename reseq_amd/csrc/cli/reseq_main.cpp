@@ -803,7 +803,12 @@ int seq_to_illumina(const Args &a) {
     if (ok) {
         INFO("Starting read generation");
         const unsigned hw = std::thread::hardware_concurrency();
-        ParsePipeline pipe(fin, std::max(1u, std::min(hw > 2 ? hw - 2 : 1u, 6u)));
+        // parser threads: six keep the single writer of the output file busy (buffered writes into one file serialise on its inode: 6 GB/s); more were
+        // measured slower -- every parser slot owns page-locked arrays, whose allocation is what a run of 20 M records waits for (6 threads 2.5 s, 16: 3.2 s,
+        // 32: 5.0 s; the marginal rate beyond the start-up is 25 M reads/s either way).  --parseThreads overrides.
+        uint32_t parsers = std::max(1u, std::min(hw > 2 ? hw - 2 : 1u, 6u));
+        if (a.has("parseThreads")) parsers = (uint32_t)std::max(1, atoi(a.get("parseThreads").c_str()));
+        ParsePipeline pipe(fin, parsers);
         DevBuffer d_seqs, d_dom, d_rate, d_seg, d_fl, d_ids, d_off, d_text;
         uint64_t written = 0, next_report = 0;
         while (ok) {
