@@ -91,7 +91,12 @@ class GpuBackend:
 block_weights = sharding.block_weights
 
 
-def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu"):
+def part_name(path, rank, world):
+    """--splitOutput: the file of rank `rank`; the parts in rank order, one after the other, are the single file"""
+    return f"{path}.part{rank + 1:0{len(str(world))}d}of{world}"
+
+
+def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False):
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
     small exchanges; the data never passes through Python."""
@@ -105,6 +110,23 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     t0 = time.perf_counter()
     n_mine, bytes1, bytes2 = backend.job_generate(mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, bytes1 + bytes2, time.perf_counter() - t0)
+    if split_output:
+        # One pair of files per rank: buffered writes into ONE file take its inode lock one after the other, whoever writes (8 GB/s for the whole job however
+        # many ranks, profiles/r03_g_*), separate files do not (49 GB/s with 8 writers behind one GPU's link).  No exchange of sizes, no barrier: a rank is done
+        # when its text is out.  The last rank appends the adapter-only pairs, so that the parts in rank order concatenate to the single-file output.
+        p1, p2 = part_name(out1, rank, world), part_name(out2, rank, world)
+        for p in (p1, p2):
+            open(p, "wb").close()
+        backend.job_write(p1, 0, p2, 0)
+        if rank == world - 1:
+            with open(p1, "ab") as f1, open(p2, "ab") as f2:
+                for first in range(0, info["adapter_only_pairs"], 100000):
+                    a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
+                    f1.write(a)
+                    f2.write(b)
+        if dist is not None:
+            dist.barrier()
+        return int(total_pairs) + info["adapter_only_pairs"], elapsed
     # one all-gather of two lengths per rank: the exclusive scan over the ranks is every rank's offset in the final files
     sizes = sharding.gather_sizes(dist, device, [bytes1, bytes2], world)
     end1, end2 = (sum(row[col] for row in sizes) for col in (0, 1))
@@ -143,6 +165,8 @@ def main(argv=None):
     ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
     ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 4 M pairs)")
+    ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own pair of files <out>.part<k>of<N> (their concatenation in order is the single file): "
+                    "writes into one file serialise on its inode lock, 8 GB/s for the whole job; separate files scale with the ranks")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch
@@ -162,7 +186,7 @@ def main(argv=None):
     backend = GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError)
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
-                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}")
+                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput)
         if rank == 0:
             print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
     finally:

@@ -80,7 +80,8 @@ if os.environ.get("RSQ_VARIANTS"):           # substitutions, insertions, deleti
     import numpy as np
     vcf = work / f"sim{rank}" / "simjob.vcf"
     P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, np.random.default_rng(5), 30, [999, 1000, 1999, 2000, 2999, 3000]))
-pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs, vcf), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3)
+pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs, vcf), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3,
+                             split_output=bool(os.environ.get("RSQ_SPLIT")))
 if rank == 0:
     print("PAIRS", pairs)
 if world > 1:
@@ -107,6 +108,14 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
         assert p.returncode == 0, se.decode()[-3000:]
     pairs_line = lambda out: [l for l in out.split(b"\n") if l.startswith(b"PAIRS")]          # gloo prints connection notes on stdout
     assert pairs_line(one.stdout) == pairs_line(outs[0][0]) and len(pairs_line(one.stdout)) == 1
+    # --splitOutput: one pair of files per rank, whose concatenation in rank order is the single output
+    procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="split", RSQ_SPLIT="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=800)
+        assert p.returncode == 0, se.decode()[-3000:]
+    for k in (1, 2):
+        assert (workdir / f"split_{k}.fq.part1of2").read_bytes() + (workdir / f"split_{k}.fq.part2of2").read_bytes() == (workdir / f"one_{k}.fq").read_bytes()
     for k in (1, 2):
         a, b = (workdir / f"one_{k}.fq").read_bytes(), (workdir / f"two_{k}.fq").read_bytes()
         assert a == b and a.count(b"\n") % 4 == 0 and b":0:Adapter:0:" in a
