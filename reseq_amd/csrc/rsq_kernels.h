@@ -645,60 +645,62 @@ __global__ void __launch_bounds__(kSieveBlock) k_sieve_gaps(DevSim S, uint32_t b
     } else counts[slot] = sieve_gaps(S, site, [](uint32_t, double) {});
 }
 
+// The cells with fragments go into the hit list.  Their order in the list is free (k_sieve_emit places fragments by the scan of pairs_of), so places are taken with an
+// atomic counter -- ONE reservation per workgroup: a counter bumped once per wave (557 k times per 10 M pairs) is a queue at one L2 channel, about 10 ns per
+// atomic, and was what the kernel's 6.5 ms consisted of for two rounds (VALU 13 % busy, TA 54 %: "latency-bound"); with the workgroup's records ranked in LDS
+// first the kernel takes 1.7 ms.
 template <int VM, uint32_t CAP = kMaxDevAlleles>
 __global__ void __launch_bounds__(kSieveBlock) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, const uint64_t *cand_off, const SieveCand *cands,
                                                               uint64_t cand_cap, uint32_t *pairs_of, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count, const SlotInfo *slots) {
+    __shared__ uint32_t s_records, s_base;
+    if (threadIdx.x == 0) s_records = 0;
+    __syncthreads();
     const uint64_t c = (uint64_t)blockIdx.x * kSieveBlock + threadIdx.x;
-    if (c >= cand_cap) return;
-    uint32_t n_here = 0;
-    if (c < cand_off[n_slots]) {
-        const SieveCand cand = cands[c];
+    const bool has_cell = c < cand_cap && c < cand_off[n_slots];
+    uint32_t n_here = 0, n_records = 0;                             // pairs of the cell; its records: one per two chosen (allele, strand) slots
+    SieveCand cand{};
+    VarCellT<VM != 0 ? CAP : 1u> cell;                              // VM 0: the two strands' counts in cnt[0..1], their strands in id[0..1]
+    cell.n = 0;
+    if (has_cell) {
+        cand = cands[c];
         SieveSite site;
         init_site_slot<VM>(S, block_lo, block_hi, cand.slot, site, nullptr, slots);
-        if constexpr (VM != 0) {
-            VarCellT<CAP> cell;
-            if constexpr (VM == 2) n_here = sieve_cell_general(S, site, cand.len, cand.probability_chosen, cell);
-            else n_here = sieve_cell_var(S, site, cand.len, cand.probability_chosen, cell);
-            uint32_t intra = 0;
-            for (uint32_t e = 0; e < cell.n; e += 2u) {
-                const bool two = e + 1u < cell.n;
-                const uint32_t at = atomicAdd(hit_count, 1u);
-                SieveHit h;
-                h.slot = cand.slot;
-                h.cand = (uint32_t)c;
-                h.intra = intra;
-                h.len = (uint16_t)cand.len;
-                h.cnt0 = cell.cnt[e];
-                h.cnt1 = two ? cell.cnt[e + 1u] : (uint16_t)0;
-                h.strand0 = cell.id[e] & 1u;
-                h.allele0 = cell.id[e] >> 1;
-                h.strand1 = two ? cell.id[e + 1u] & 1u : 0;
-                h.allele1 = two ? cell.id[e + 1u] >> 1 : 0;
-                if (at < hit_cap) hits[at] = h;
-                intra += (uint32_t)h.cnt0 + h.cnt1;
-            }
-        } else {
+        if constexpr (VM == 2) n_here = sieve_cell_general(S, site, cand.len, cand.probability_chosen, cell);
+        else if constexpr (VM == 1) n_here = sieve_cell_var(S, site, cand.len, cand.probability_chosen, cell);
+        else {
             uint32_t cnt[2], strand_of[2];
             n_here = sieve_cell(S, site, cand.len, cand.probability_chosen, cnt, strand_of);
-            if (n_here) {
-                const uint32_t at = atomicAdd(hit_count, 1u);
-                if (at < hit_cap) {
-                    SieveHit h;
-                    h.slot = cand.slot;
-                    h.cand = (uint32_t)c;
-                    h.intra = 0;
-                    h.len = (uint16_t)cand.len;
-                    h.cnt0 = (uint16_t)cnt[0];
-                    h.cnt1 = (uint16_t)cnt[1];
-                    h.strand0 = (uint8_t)strand_of[0];
-                    h.strand1 = (uint8_t)strand_of[1];
-                    h.allele0 = h.allele1 = 0;
-                    hits[at] = h;
-                }
+            cell.n = n_here ? 2u : 0u;
+            for (uint32_t e = 0; e < 2u; ++e) {
+                cell.cnt[e] = (uint16_t)cnt[e];
+                cell.id[e] = (uint8_t)strand_of[e];                 // allele 0
             }
         }
+        n_records = (cell.n + 1u) / 2u;
     }
-    pairs_of[c] = n_here;
+    const uint32_t rank = n_records ? atomicAdd(&s_records, n_records) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_records) s_base = atomicAdd(hit_count, s_records);
+    __syncthreads();
+    uint32_t intra = 0;
+    for (uint32_t e = 0; e < cell.n; e += 2u) {
+        const bool two = e + 1u < cell.n;
+        const uint32_t at = s_base + rank + e / 2u;
+        SieveHit h;
+        h.slot = cand.slot;
+        h.cand = (uint32_t)c;
+        h.intra = intra;
+        h.len = (uint16_t)cand.len;
+        h.cnt0 = cell.cnt[e];
+        h.cnt1 = two ? cell.cnt[e + 1u] : (uint16_t)0;
+        h.strand0 = cell.id[e] & 1u;
+        h.allele0 = cell.id[e] >> 1;
+        h.strand1 = two ? cell.id[e + 1u] & 1u : 0;
+        h.allele1 = two ? cell.id[e + 1u] >> 1 : 0;
+        if (at < hit_cap) hits[at] = h;
+        intra += (uint32_t)h.cnt0 + h.cnt1;
+    }
+    if (c < cand_cap) pairs_of[c] = n_here;
 }
 
 // one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at pair_off[cell] + intra; a read's number counts the pairs of
