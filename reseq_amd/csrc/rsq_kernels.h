@@ -647,11 +647,12 @@ __global__ void __launch_bounds__(kSieveBlock) k_sieve_gaps(DevSim S, uint32_t b
 
 // The cells with fragments go into the hit list.  Their order in the list is free (k_sieve_emit places fragments by the scan of pairs_of), so places are taken with an
 // atomic counter -- ONE reservation per workgroup: a counter bumped once per wave (557 k times per 10 M pairs) is a queue at one L2 channel, about 10 ns per
-// atomic, and was what the kernel's 6.5 ms consisted of for two rounds (VALU 13 % busy, TA 54 %: "latency-bound"); with the workgroup's records ranked in LDS
-// first the kernel takes 1.7 ms.
+// atomic, and was what the kernel's 6.5 ms consisted of for two rounds (VALU 13 % busy, TA 54 %: "latency-bound").  Without variants there is no list at all
+// (a cell has one record at most: a word per candidate, k_sieve_emit runs over the candidates).
 template <int VM, uint32_t CAP = kMaxDevAlleles>
 __global__ void __launch_bounds__(kSieveBlock) k_sieve_finish(DevSim S, uint32_t block_lo, uint32_t block_hi, uint32_t n_slots, const uint64_t *cand_off, const SieveCand *cands,
-                                                              uint64_t cand_cap, uint32_t *pairs_of, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count, const SlotInfo *slots) {
+                                                              uint64_t cand_cap, uint32_t *pairs_of, SieveHit *hits, uint32_t hit_cap, uint32_t *hit_count, const SlotInfo *slots,
+                                                              uint32_t *cell_info) {
     __shared__ uint32_t s_records, s_base;
     if (threadIdx.x == 0) s_records = 0;
     __syncthreads();
@@ -677,6 +678,15 @@ __global__ void __launch_bounds__(kSieveBlock) k_sieve_finish(DevSim S, uint32_t
             }
         }
         n_records = (cell.n + 1u) / 2u;
+    }
+    if constexpr (VM == 0) {
+        // without variants a cell has one record at most: no list -- what k_sieve_emit needs beyond pairs_of goes into a word per candidate (coalesced), and the
+        // emit kernel runs over the candidates
+        if (c < cand_cap) {
+            pairs_of[c] = n_here;
+            cell_info[c] = (uint32_t)cell.cnt[0] | ((uint32_t)(cell.id[0] & 1u) << 16) | ((uint32_t)(cell.id[1] & 1u) << 17);
+        }
+        return;
     }
     const uint32_t rank = n_records ? atomicAdd(&s_records, n_records) : 0u;
     __syncthreads();
@@ -705,12 +715,29 @@ __global__ void __launch_bounds__(kSieveBlock) k_sieve_finish(DevSim S, uint32_t
 
 // one lane per recorded cell: writes its cnt0 + cnt1 Fragment records at pair_off[cell] + intra; a read's number counts the pairs of
 // its block (CreateReadId, Simulator.cpp:596-632): the block's first cell is the first candidate of its first slot
+// VM 0: one lane per CANDIDATE (n_hits = their number): the cell's record is put together from pairs_of, cell_info and the candidate itself
 template <int VM>
 __global__ void __launch_bounds__(256) k_sieve_emit(DevSim S, uint32_t block_lo, uint32_t block_hi, const SieveHit *hits, uint32_t n_hits, const uint64_t *cand_off,
-                                                   const uint64_t *pair_off, Fragment *frags, FragmentVar *fvars, const SlotInfo *slots) {
+                                                   const uint64_t *pair_off, Fragment *frags, FragmentVar *fvars, const SlotInfo *slots, const SieveCand *cands = nullptr,
+                                                   const uint32_t *pairs_of = nullptr, const uint32_t *cell_info = nullptr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
-    const SieveHit h = hits[i];
+    SieveHit h;
+    if constexpr (VM == 0) {
+        const uint32_t pairs = pairs_of[i];
+        if (!pairs) return;
+        const SieveCand cand = cands[i];
+        const uint32_t info = cell_info[i];
+        h.slot = cand.slot;
+        h.cand = i;
+        h.intra = 0;
+        h.len = (uint16_t)cand.len;
+        h.cnt0 = (uint16_t)(info & 0xFFFFu);
+        h.cnt1 = (uint16_t)(pairs - (info & 0xFFFFu));
+        h.strand0 = (uint8_t)((info >> 16) & 1u);
+        h.strand1 = (uint8_t)((info >> 17) & 1u);
+        h.allele0 = h.allele1 = 0;
+    } else h = hits[i];
     SieveSite site;
     uint32_t first_slot;
     const uint32_t block_id = init_site_slot<VM>(S, block_lo, block_hi, h.slot, site, &first_slot, slots);

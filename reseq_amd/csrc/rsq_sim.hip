@@ -152,6 +152,7 @@ struct rsq_sim : SimState {
         DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
         DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
         DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, counters (one small buffer); the sorted items
+        DevBuf cell_info;              // the sieve without variants: per candidate the first strand's count and the two strands (k_sieve_finish<0> -> k_sieve_emit<0>)
         hipEvent_t text_done = nullptr;      // the text stage that last read this set's arrays
     } ws[2];
     // rsq_sim_job_generate: the FASTQ text of a rank's block range, kept until rsq_sim_job_write / rsq_sim_job_free: per file a list of device arrays, filled in order
@@ -619,7 +620,8 @@ static void sieve_attempt(rsq_sim &s, SieveRun &r, int attempt, uint64_t *mail, 
     w.cands.reserve(r.cand_cap * sizeof(SieveCand));
     w.pairs_of.reserve(r.cand_cap * 4 + 16);
     w.pair_off.reserve((r.cand_cap + 1) * 8);
-    w.hits.reserve(r.hit_cap * sizeof(SieveHit));
+    if (vm) w.hits.reserve(r.hit_cap * sizeof(SieveHit));
+    else w.cell_info.reserve(r.cand_cap * 4 + 16);
     HIP_CHECK(hipMemsetAsync(w.hit_count.as<uint32_t>(), 0, 4, st));
     s.timers["sieve"].start(st);
     const uint32_t block_lo = r.block_lo, block_hi = r.block_hi;
@@ -653,7 +655,8 @@ static void sieve_attempt(rsq_sim &s, SieveRun &r, int attempt, uint64_t *mail, 
     const dim3 fgrid(cdiv(cand_cap, kSieveBlock)), fblock(kSieveBlock);
 #define RSQ_FINISH(VM, CAP)                                                                                                                                   \
     hipLaunchKernelGGL((k_sieve_finish<VM, CAP>), fgrid, fblock, 0, st, s.dev, block_lo, block_hi, (uint32_t)n_slots, w.offsets.as<uint64_t>(), w.cands.as<SieveCand>(),  \
-                       cand_cap, w.pairs_of.as<uint32_t>(), w.hits.as<SieveHit>(), (uint32_t)std::min<uint64_t>(r.hit_cap, 0xFFFFFFFFull), w.hit_count.as<uint32_t>(), slot_table)
+                       cand_cap, w.pairs_of.as<uint32_t>(), w.hits.as<SieveHit>(), (uint32_t)std::min<uint64_t>(r.hit_cap, 0xFFFFFFFFull), w.hit_count.as<uint32_t>(), slot_table, \
+                       w.cell_info.as<uint32_t>())
     if (2 == vm && s.num_alleles <= 8) RSQ_FINISH(2, 8);        // few alleles: the cell's (allele, strand) slots stay in registers
     else if (2 == vm) RSQ_FINISH(2, kMaxDevAlleles);
     else if (1 == vm) RSQ_FINISH(1, 8);                         // allele copies exist for at most eight alleles
@@ -718,9 +721,13 @@ static void sieve_emit(rsq_sim &s, const SieveRun &r, hipStream_t st) {
         w.fvars.reserve(r.total * sizeof(FragmentVar) + 16);
         hipLaunchKernelGGL(k_sieve_emit<2>, dim3(cdiv(r.n_hits, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, w.hits.as<SieveHit>(), r.n_hits, w.offsets.as<uint64_t>(),
                            w.pair_off.as<uint64_t>(), w.frags.as<Fragment>(), w.fvars.as<FragmentVar>(), w.slot_table.as<SlotInfo>());
-    } else
-        hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(r.n_hits, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, w.hits.as<SieveHit>(), r.n_hits, w.offsets.as<uint64_t>(),
+    } else if (1 == s.variants_mode)                                // allele copies: the hit list (a cell may have several records), slots as without variants
+        hipLaunchKernelGGL(k_sieve_emit<1>, dim3(cdiv(r.n_hits, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, w.hits.as<SieveHit>(), r.n_hits, w.offsets.as<uint64_t>(),
                            w.pair_off.as<uint64_t>(), w.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr);
+    else
+        hipLaunchKernelGGL(k_sieve_emit<0>, dim3(cdiv(r.n_cands, 256)), dim3(256), 0, st, s.dev, r.block_lo, r.block_hi, (const SieveHit *)nullptr, (uint32_t)r.n_cands,
+                           w.offsets.as<uint64_t>(), w.pair_off.as<uint64_t>(), w.frags.as<Fragment>(), (FragmentVar *)nullptr, (const SlotInfo *)nullptr, w.cands.as<SieveCand>(),
+                           w.pairs_of.as<uint32_t>(), w.cell_info.as<uint32_t>());
     s.timers["sieve_emit"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
