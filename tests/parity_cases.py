@@ -295,6 +295,24 @@ def case_p0_tiles(backend_cls, workdir, n_tiles, num_pairs=1500, expect_image_ti
     assert len({e[4] for e in exp}) >= min(n_tiles, 3)
 
 
+def case_more_quality_values_than_the_screen_is_built_for(backend_cls, workdir):
+    """60 quality values: above the 48 the screened single-precision draws are instantiated for, so the read kernels take the double-precision route
+    (LogArrayResult::Draw as written, every row from device memory); the plan says so (rsq_last_warning after rsq_sim_create), the output is the oracle's"""
+    cfg = dict(synth.TINY, name="TINYq60", qual_from=2, qual_to=62)
+    p = Pair(backend_cls, workdir, "tiny_q60", cfg, [4000, 2500], seed=17, num_pairs=2500, prof_seed=9)
+    try:
+        plan = p.b.fill_plan()
+        assert plan["mask"] == 0, plan
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert n > 1500
+        assert max(max(l) for l in text.split(b"\n")[3::4] if l) > 33 + 48          # qualities above the 48th value occur
+    finally:
+        p.close()
+    exp = _error_model(backend_cls, workdir, "tiny_q60", cfg, 300, 30, seed=5, prof_seed=9, zero_frac=0.7)
+    assert len(exp) == 300
+
+
 def case_indel_columns_shuffled(backend_cls, workdir):
     """the indel draw decided by the random word alone (DevTable::sure_range) when "no indel" is a middle column of its tables and one
     insertion is frequent: the range has a lower and an upper end"""

@@ -50,6 +50,12 @@ def test_adapter_only(workdir):
     P.case_adapter_only(GpuBackend, workdir)
 
 
+def test_more_quality_values_than_the_screen_is_built_for(workdir):
+    P.case_more_quality_values_than_the_screen_is_built_for(GpuBackend, workdir)
+    from reseq_amd import api
+    assert "double precision" in api.last_warning()                      # rsq_sim_create said why this profile takes the slow route
+
+
 def test_p0_reads(workdir):
     P.case_p0_reads(GpuBackend, workdir)
 

@@ -88,6 +88,10 @@ def test_adapter_only(workdir):
     P.case_adapter_only(EmuBackend, workdir)
 
 
+def test_more_quality_values_than_the_screen_is_built_for(workdir):
+    P.case_more_quality_values_than_the_screen_is_built_for(EmuBackend, workdir)
+
+
 def test_p0_reads(workdir):
     P.case_p0_reads(EmuBackend, workdir)
 
