@@ -150,10 +150,21 @@ RSQ_HD uint32_t chain_incoming(const Chain &ch, uint32_t c, const uint32_t *out_
 }
 __global__ void __launch_bounds__(256) k_sys_chain_select(const Chain *chains, const uint32_t *chunk_chain, uint32_t n_chunks, const uint32_t *used_state, const uint32_t *out_prev,
                                                          uint32_t *out_new, uint32_t *list, uint32_t *n_listed, int pass) {
+    // places in the list are reserved once per workgroup (ranks in LDS): one global atomic per wave queues at one L2 channel (see k_sieve_finish)
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    if (chain_incoming(chains[chunk_chain[c]], c, out_prev, pass) == used_state[c]) out_new[c] = out_prev[c];
-    else list[atomicAdd(n_listed, 1u)] = c;
+    bool again = false;
+    if (c < n_chunks) {
+        again = chain_incoming(chains[chunk_chain[c]], c, out_prev, pass) != used_state[c];
+        if (!again) out_new[c] = out_prev[c];
+    }
+    const uint32_t rank = again ? atomicAdd(&s_n, 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_listed, s_n);
+    __syncthreads();
+    if (again) list[s_base + rank] = c;
 }
 __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains, const uint32_t *chunk_chain, const uint32_t *list, uint32_t n_run, uint32_t chunk_len,
                                                  uint32_t *used_state, const uint32_t *out_prev, uint32_t *out_new, int pass) {
@@ -1940,7 +1951,10 @@ struct FillBins {
     const FragmentVar *fvars;       // the pair index is needed only before and after a chunk's reads
 };
 constexpr uint32_t kSchedWords = 8;              // LDS words behind the image in which fill_binned_loop keeps the bin its workgroup is on
-constexpr uint32_t kBinKeysLds = 4096;          // up to so many bin keys the counting kernels aggregate in LDS
+#ifndef RSQ_BIN_KEYS_LDS
+#define RSQ_BIN_KEYS_LDS 4096
+#endif
+constexpr uint32_t kBinKeysLds = RSQ_BIN_KEYS_LDS;      // up to so many bin keys the counting kernels aggregate in LDS (a build with 2 runs the tile tests through the other branch)
 constexpr uint32_t kBinItemsPerThread = 16, kBinBlock = 256;
 
 // the stream of one mate of a pair (CreateReads :634-721 / SimulateAdapterOnlyPairs :2359-2382): what k_fill_reads and the tile binning agree on
