@@ -15,6 +15,7 @@
 #include <array>
 #include <atomic>
 #include <exception>
+#include <memory>
 #include <mutex>
 
 #include <fstream>
@@ -39,6 +40,7 @@ const OptionEntry kOptionTable[] = {
     {"no_indel_skip", &Options::no_indel_skip}, {"force_exact", &Options::force_exact},     {"min_quality_quads", &Options::min_quality_quads},
     {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
     {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},
+    {"serial_parse", &Options::serial_parse},   {"parse_stretch", &Options::parse_stretch}, {"mapped_parses", &Options::mapped_parses},
     {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap},             {"job_chunk_bytes", &Options::job_chunk_bytes},
 };
 }  // namespace
@@ -653,7 +655,210 @@ std::vector<double> read_ref_bias_file(const std::string &path, const std::vecto
 }
 
 // -------------------------------------------------------------------------------------------- methylation (BED)
+namespace {
+// A regular uncompressed file of at least `min_size` bytes that ends with a line end, mapped for several readers.
+struct MappedText {
+    const char *d = nullptr;
+    size_t n = 0;
+    bool open(const std::string &path, size_t min_size) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < std::max<size_t>(min_size, 4)) {
+            close(fd);
+            return false;
+        }
+        void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (map == MAP_FAILED) return false;
+        d = static_cast<const char *>(map);
+        n = (size_t)st.st_size;
+        madvise(map, n, MADV_SEQUENTIAL);
+        return '\n' == d[n - 1] && !((uint8_t)d[0] == 0x1f && (uint8_t)d[1] == 0x8b) && 0 != memcmp(d, "BZh", 3);
+    }
+    ~MappedText() {
+        if (d) munmap(const_cast<char *>(d), n);
+    }
+    // [lo, hi) of piece i of about `stretch` bytes, cut at line starts
+    std::vector<size_t> cut(size_t stretch) const {
+        std::vector<size_t> at{0};
+        for (size_t p = stretch; p < n; p += stretch) {
+            const char *e = (const char *)memchr(d + p, '\n', n - p);
+            const size_t start = e ? (size_t)(e - d) + 1 : n;
+            if (start > at.back() && start < n) at.push_back(start);
+        }
+        at.push_back(n);
+        return at;
+    }
+};
+inline bool blank(char c) { return ' ' == c || '\t' == c; }
+
+// strtod for the text at p (a digit or '.'), which some line end follows: plain decimals of at most 15 digits are an integer over a power of ten, both exact
+// in binary64, and one IEEE division rounds their quotient correctly -- the value strtod returns; everything else goes to strtod.  False where std::stod would throw.
+inline bool decimal_at(const char *p, const char *&end, double &v) {
+    static const double pow10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const char *q = p;
+    uint64_t mant = 0;
+    unsigned digits = 0, after = 0;
+    for (; *q >= '0' && *q <= '9'; ++q, ++digits) mant = mant * 10 + (uint64_t)(*q - '0');
+    if ('.' == *q)
+        for (++q; *q >= '0' && *q <= '9'; ++q, ++digits, ++after) mant = mant * 10 + (uint64_t)(*q - '0');
+    if (digits && digits <= 15 && (blank(*q) || '\n' == *q)) {
+        end = q;
+        v = (double)mant / pow10[after];
+        return true;
+    }
+    char *e;
+    errno = 0;
+    v = strtod(p, &e);
+    end = e;
+    return e != p && errno != ERANGE;
+}
+
+// The methylation file read by several threads, for the file every tool writes: lines `name start end rate [rate ...]` separated by blanks or tabs, plain
+// decimal numbers, sequences in the order of the reference, regions in order.  Pieces of the file are parsed independently into (start, end, rates) and
+// runs of one name; the runs are then matched to the reference's sequences and the pieces checked against the sequence lengths and copied to their place.
+// Anything else -- a '\r', a number in another notation, a region out of order or out of range, an unknown or repeated name, a change in the number of
+// alleles -- returns false with nothing kept, and the line reader below reads the file from its start: the messages, and what is silently ignored, are its.
+bool read_methylation_mapped(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len, uint32_t num_alleles_ref, Methylation &m) {
+    const int64_t stretch_opt = options().parse_stretch;
+    const size_t stretch = stretch_opt > 0 ? (size_t)stretch_opt : (size_t)4u << 20;
+    MappedText text;
+    if (!text.open(path, stretch_opt > 0 ? 4 : (size_t)1 << 20)) return false;
+    const char *d = text.d;
+    size_t begin = 0;                                                    // empty and track lines before the first record (Reference.cpp:1150)
+    while (begin < text.n) {
+        const size_t len = (size_t)((const char *)memchr(d + begin, '\n', text.n - begin) - (d + begin));
+        if (len && !(len >= 5 && 0 == memcmp(d + begin, "track", 5))) break;
+        begin += len + 1;
+    }
+    if (begin >= text.n) return false;
+    std::vector<size_t> at = text.cut(stretch);
+    at.erase(at.begin(), std::upper_bound(at.begin(), at.end(), begin));
+    at.insert(at.begin(), begin);
+    struct Run {
+        const char *name;
+        size_t name_len, first_region, n_regions;
+        uint32_t alleles, seq;
+    };
+    struct Piece {
+        std::vector<uint32_t> first, second;
+        std::vector<double> rate;                                        // the rates of a region side by side
+        std::vector<Run> runs;
+        bool plain = true;
+        size_t out = 0;                                                  // where its first run continues in the sequence's arrays
+    };
+    std::vector<Piece> pieces(at.size() - 1);
+    const unsigned hw = std::thread::hardware_concurrency(), n_threads = std::max(1u, std::min(hw ? hw : 4u, 32u));
+    on_threads(pieces.size(), n_threads, [&](size_t i) {
+        Piece &pc = pieces[i];
+        const size_t guess = (at[i + 1] - at[i]) / 24;
+        pc.first.reserve(guess);
+        pc.second.reserve(guess);
+        pc.rate.reserve(guess * num_alleles_ref);
+        auto number = [](const char *&p, uint64_t &v) {                  // digits followed by a blank
+            const char *q = p;
+            for (v = 0; *q >= '0' && *q <= '9' && q - p < 11; ++q) v = v * 10 + (uint64_t)(*q - '0');
+            const bool fine = q != p && blank(*q) && v <= 0xFFFFFFFFull;
+            for (p = q; blank(*p); ++p) {}
+            return fine;
+        };
+        for (const char *p = d + at[i], *const stop = d + at[i + 1]; p < stop;) {
+            const char *e = (const char *)memchr(p, '\n', (size_t)(stop - p));
+            if (e == p) {                                                // empty lines are ignored
+                ++p;
+                continue;
+            }
+            const char *name = p;
+            while (!blank(*p) && p < e) ++p;
+            const size_t name_len = (size_t)(p - name);
+            uint64_t first, second;
+            if ('\r' == e[-1] || !name_len || p == e) return void(pc.plain = false);
+            while (blank(*p)) ++p;
+            if (!number(p, first) || !number(p, second) || second <= first) return void(pc.plain = false);
+            uint32_t alleles = 0;
+            while (p < e) {
+                double v;
+                const char *q;
+                if (!((*p >= '0' && *p <= '9') || '.' == *p) || !decimal_at(p, q, v) || q > e || !(blank(*q) || q == e) || !(0.0 <= v && v <= 1.0)) return void(pc.plain = false);
+                pc.rate.push_back(1.0 - v);                              // the probability of a C->T conversion
+                ++alleles;
+                for (p = q; blank(*p); ++p) {}
+            }
+            if (pc.runs.empty() || pc.runs.back().name_len != name_len || 0 != memcmp(pc.runs.back().name, name, name_len))
+                pc.runs.push_back(Run{name, name_len, pc.first.size(), 0, alleles, 0});
+            else if (first < pc.second.back())
+                return void(pc.plain = false);
+            if (alleles != pc.runs.back().alleles || !alleles) return void(pc.plain = false);
+            ++pc.runs.back().n_regions;
+            pc.first.push_back((uint32_t)first);
+            pc.second.push_back((uint32_t)second);
+            p = e + 1;
+        }
+    });
+    // runs -> sequences, as the line reader walks them: each new name is looked for among the sequences after the last one
+    const size_t n = first_names.size();
+    std::vector<size_t> regions(n, 0);
+    std::vector<uint32_t> alleles(n, 0);
+    size_t seq = 0;
+    const Run *last = nullptr;
+    uint32_t last_end = 0;
+    for (Piece &pc : pieces) {
+        if (!pc.plain) return false;
+        for (Run &r : pc.runs) {
+            if (last && last->name_len == r.name_len && 0 == memcmp(last->name, r.name, r.name_len)) {      // the run goes on in the next piece
+                if (r.alleles != last->alleles || pc.first[r.first_region] < last_end) return false;
+                if (&r == &pc.runs[0]) pc.out = regions[seq];
+            } else {
+                if (last) ++seq;
+                while (seq < n && (first_names[seq].size() != r.name_len || 0 != memcmp(first_names[seq].data(), r.name, r.name_len))) ++seq;
+                if (seq == n || (1 != r.alleles && num_alleles_ref != r.alleles)) return false;
+                alleles[seq] = r.alleles;
+            }
+            r.seq = (uint32_t)seq;
+            regions[seq] += r.n_regions;
+            last = &r;
+            last_end = pc.second[r.first_region + r.n_regions - 1];
+        }
+    }
+    if (!last) return false;
+    m.first.assign(n, {});
+    m.second.assign(n, {});
+    m.rate.assign(n, {});
+    on_threads(n, n_threads, [&](size_t i) {
+        if (!alleles[i]) return;
+        m.first[i].resize(regions[i]);
+        m.second[i].resize(regions[i]);
+        m.rate[i].assign(alleles[i], std::vector<double>(regions[i]));
+    });
+    std::atomic<bool> in_range{true};
+    on_threads(pieces.size(), n_threads, [&](size_t i) {
+        const Piece &pc = pieces[i];
+        size_t out = pc.out, rates = 0;                                  // the piece's rates lie run after run, a region's alleles side by side
+        for (const Run &r : pc.runs) {
+            if (&r != &pc.runs[0]) out = 0;                              // only a piece's first run can continue one of the piece before
+            for (size_t k = 0; k < r.n_regions; ++k) {
+                const size_t src = r.first_region + k;
+                if (pc.first[src] >= seq_len[r.seq] || pc.second[src] > seq_len[r.seq]) return void(in_range = false);
+                m.first[r.seq][out + k] = pc.first[src];
+                m.second[r.seq][out + k] = pc.second[src];
+                for (uint32_t a = 0; a < r.alleles; ++a) m.rate[r.seq][a][out + k] = pc.rate[rates + k * r.alleles + a];
+            }
+            rates += r.n_regions * r.alleles;
+        }
+    });
+    return in_range;
+}
+}      // namespace
+
 Methylation read_methylation_file(const std::string &path, const std::vector<std::string> &first_names, const std::vector<uint32_t> &seq_len, uint32_t num_alleles_ref) {
+    if (!options().serial_parse) {
+        Methylation mapped;
+        if (read_methylation_mapped(path, first_names, seq_len, num_alleles_ref, mapped)) {
+            ++options().mapped_parses;
+            return mapped;
+        }
+    }
     std::ifstream f(path);
     if (!f.is_open()) throw Error("Unable to open methylation file " + path);
     std::string line;
@@ -798,9 +1003,249 @@ uint8_t dna5_code(char c) {
         default: return 4;
     }
 }
+// ReadVariants (Reference.cpp:126-420): the records of a file, or of a piece of it, one after the other
+struct VcfRecords {
+    const std::vector<std::string> &first_names, &contigs;
+    const std::vector<std::vector<uint8_t>> &codes;
+    const uint32_t A;
+    std::vector<std::vector<Variant>> *by_seq;                        // the whole file: the lists per sequence
+    std::vector<std::pair<uint32_t, std::vector<Variant>>> runs;      // a piece (by_seq null): its sequences in the order met, which a sorted file meets once each
+    std::string errors;
+    uint32_t n_errors = 0, records = 0;
+    size_t reserve_hint = 0;
+    uint32_t first_rid = 0, first_begin = 0;                          // of the first record
+    std::vector<uint32_t> allele;
+    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0, last_rid = 0xFFFFFFFFu;
+    std::vector<uint8_t> vcf_ref, inserted;                           // per record, kept for their storage
+    std::vector<size_t> alt_start;
+    std::vector<std::array<uint64_t, 2>> gt_has_var;
+
+    VcfRecords(const std::vector<std::string> &names, const std::vector<std::string> &contig_names, const std::vector<std::vector<uint8_t>> &seqs, uint32_t num_alleles,
+               std::vector<std::vector<Variant>> *lists)
+        : first_names(names), contigs(contig_names), codes(seqs), A(num_alleles), by_seq(lists), allele(num_alleles) {}
+    void error(const std::string &msg) {
+        if (n_errors++ < 20) errors += msg + " ";                     // kMaxErrorsShownPerFile
+    }
+    std::vector<Variant> &list_of(uint32_t rid) {
+        if (by_seq) return (*by_seq)[rid];
+        if (runs.empty() || runs.back().first != rid) {
+            runs.emplace_back(rid, std::vector<Variant>());
+            runs.back().second.reserve(reserve_hint);
+        }
+        return runs.back().second;
+    }
+    void record(const std::vector<std::string> &rec) {
+    if (last_rid >= contigs.size() || contigs[last_rid] != rec[0]) last_rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());
+    const uint32_t rid = last_rid;                                // unknown names get a new id
+    const long long pos1 = atoll(rec[1].c_str());
+    const uint32_t begin_pos = (uint32_t)(pos1 - 1);
+    bool skip_rest = false;
+    if (rid < read_for) {                                         // :393-401 (checked when the record is read)
+        error("Variant file is not properly position sorted. Found sequence id " + std::to_string(rid) + " after id " + std::to_string(read_for));
+        skip_rest = true;
+    } else if (rid == read_for && old_ref_id != 0xFFFFFFFFu && begin_pos < start_pos) {
+        error("Variant file is not properly position sorted. Found in sequence id " + std::to_string(rid) + " position " + std::to_string(begin_pos) + " after position " +
+              std::to_string(start_pos));
+        skip_rest = true;
+    } else read_for = rid;
+    if (!skip_rest) {
+        if (rid >= first_names.size()) {
+            error("Variant starting in reference sequence " + std::to_string(rid) + " does not belong to an existing reference sequence.");
+        } else if (begin_pos >= codes[rid].size()) {
+            error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(begin_pos) + " starts after the end of the reference sequence.");
+        } else {
+            start_pos = begin_pos;
+            if (old_ref_id == rid) {
+                if (start_pos < end_pos) error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " overlaps with a previous variant.");
+            } else old_ref_id = rid;
+            const std::string &ref = rec[3], &alt = rec[4];
+            end_pos = start_pos + (uint32_t)ref.size();
+            vcf_ref.resize(ref.size());
+            bool ref_n = false;
+            for (size_t k = 0; k < ref.size(); ++k) ref_n |= (vcf_ref[k] = dna5_code(ref[k])) > 3;
+            if (ref_n)
+                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an reference column containing ambiguous bases (e.g. N).");
+            else if (end_pos > codes[rid].size() || !std::equal(vcf_ref.begin(), vcf_ref.end(), codes[rid].begin() + start_pos))
+                error("The specified reference in vcf file '" + ref + "' is not identical with the specified reference sequence " + std::to_string(rid) + " at position " +
+                      std::to_string(start_pos) + ".");
+            // genotypes (:196-262)
+            bool ok = true;
+            uint32_t cur_allele = 0;
+            for (size_t g = 9; g < rec.size() && ok; ++g) {
+                if (cur_allele >= A) {
+                    error("Found to many alleles in genotype definition");
+                    ok = false;
+                    break;
+                }
+                uint32_t chosen = 0;
+                bool column_ok = true;
+                for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos) {
+                    const char c = rec[g][pos];
+                    if ('|' == c || '/' == c) {
+                        if (cur_allele < A) allele[cur_allele] = chosen;
+                        ++cur_allele;
+                        chosen = 0;
+                    } else if ('0' <= c && '9' >= c) chosen = chosen * 10 + (uint32_t)(c - '0');
+                    else {
+                        error(std::string("Unallowed character '") + c + "' in genotype definition '" + rec[g] + "'");
+                        column_ok = false;
+                    }
+                }
+                if (cur_allele >= A) {                               // the reference would index past `allele` here
+                    error("Found to many alleles in genotype definition");
+                    ok = false;
+                    break;
+                }
+                allele[cur_allele++] = column_ok ? chosen : 0;
+                ok = ok && column_ok;
+            }
+            if (ok && cur_allele < A) {
+                error("Could not find enough alleles in genotype definition");
+                ok = false;
+            }
+            if (ok) {                                             // :270-370 alternatives, one bit per allele that carries them
+                alt_start.assign(1, 0);
+                gt_has_var.clear();
+                uint32_t chosen_var = 1;
+                auto carriers = [&](bool last) {
+                    std::array<uint64_t, 2> bits{0, 0};
+                    for (uint32_t a = A; a--;) {
+                        bits[a / 64] <<= 1;
+                        if (allele[a] == chosen_var) ++bits[a / 64];
+                        else if (last && allele[a] > chosen_var)
+                            error("Variant number " + std::to_string(allele[a]) + " does not exist for sequence id " + std::to_string(rid) + " and position " + std::to_string(begin_pos));
+                    }
+                    gt_has_var.push_back(bits);
+                    ++chosen_var;
+                };
+                for (size_t pos = 0; pos < alt.size(); ++pos)
+                    if (',' == alt[pos]) {
+                        alt_start.push_back(pos + 1);
+                        carriers(false);
+                    }
+                alt_start.push_back(alt.size() + 1);
+                carriers(true);
+                for (size_t pos = 0; pos < vcf_ref.size(); ++pos)
+                    for (size_t n_alt = 0; n_alt < gt_has_var.size(); ++n_alt) {
+                        if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
+                        const size_t alt_len = alt_start[n_alt + 1] - 1 - alt_start[n_alt];
+                        inserted.clear();
+                        if (pos + 1 == vcf_ref.size() && pos + 1 < alt_len) {                         // insertion
+                            for (size_t k = alt_start[n_alt] + pos; k < alt_start[n_alt + 1] - 1; ++k) inserted.push_back(dna5_code(alt[k]));
+                        } else if (pos < alt_len) {                                                    // base mutation
+                            const uint8_t b = dna5_code(alt[alt_start[n_alt] + pos]);
+                            if (vcf_ref[pos] == b) continue;
+                            inserted.push_back(b);
+                        }                                                                              // else: deletion, ""
+                        bool has_n = false;
+                        for (uint8_t b : inserted) has_n |= b > 3;
+                        if (has_n) {
+                            error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an alternative column containing ambiguous bases (e.g. N).");
+                        } else {
+                            const uint64_t bits[2] = {gt_has_var[n_alt][0], gt_has_var[n_alt][1]};
+                            insert_variant(list_of(rid), start_pos + (uint32_t)pos, inserted, bits);
+                        }
+                    }
+            }
+        }
+    }
+        if (!records++) {
+            first_rid = rid;
+            first_begin = begin_pos;
+        }
+    }
+};
+
+// The variant file read by several threads, for a sorted, plain-text file without a single complaint: the header and the first record are read as below, the
+// rest is cut into pieces at line starts and every piece's records go through VcfRecords on their own -- a record's variants depend on the records before it
+// only through the checks of the order (sequence ids not decreasing, positions not decreasing and not inside the record before), which are made again where
+// the pieces meet.  A piece's lists are appended to the sequences' in file order: records of a sorted file share no position, so InsertVariant never reaches
+// into the record before.  Any message anywhere returns false with nothing kept, and the line reader reads the file from its start and words the complaint.
+bool read_variants_mapped(const std::string &path, const std::vector<std::string> &first_names, const std::vector<std::vector<uint8_t>> &codes, Variants &out) {
+    const int64_t stretch_opt = options().parse_stretch;
+    const size_t stretch = stretch_opt > 0 ? (size_t)stretch_opt : (size_t)4u << 20;
+    MappedText text;
+    if (!text.open(path, stretch_opt > 0 ? 4 : (size_t)1 << 20)) return false;
+    const char *d = text.d;
+    auto line_at = [&](size_t at, std::string &line) {                  // the line without its end; returns the start of the next
+        const char *e = (const char *)memchr(d + at, '\n', text.n - at);
+        line.assign(d + at, (size_t)(e - (d + at)));
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return (size_t)(e - d) + 1;
+    };
+    std::vector<std::string> contigs, rec;
+    std::string line;
+    size_t begin = 0;
+    bool have_record = false;
+    while (begin < text.n && !have_record) {
+        const size_t next = line_at(begin, line);
+        if (line.compare(0, 13, "##contig=<ID=") == 0) {
+            const size_t e = line.find_first_of(",>", 13);
+            contigs.push_back(line.substr(13, e == std::string::npos ? std::string::npos : e - 13));
+        }
+        if (line.empty() || '#' == line[0]) begin = next;
+        else have_record = true;
+    }
+    if (!have_record || contigs != first_names) return false;
+    split_tabs(line, rec);
+    if (rec.size() < 10) return false;
+    uint32_t A = 0;
+    for (size_t g = 9; g < rec.size(); ++g) {
+        for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos)
+            if ('|' == rec[g][pos] || '/' == rec[g][pos]) ++A;
+        ++A;
+    }
+    if (A > Variant::kMaxAlleles) return false;
+    std::vector<size_t> at = text.cut(stretch);
+    at.erase(at.begin(), std::upper_bound(at.begin(), at.end(), begin));
+    at.insert(at.begin(), begin);
+    std::vector<std::unique_ptr<VcfRecords>> pieces(at.size() - 1);
+    const unsigned hw = std::thread::hardware_concurrency(), n_threads = std::max(1u, std::min(hw ? hw : 4u, 32u));
+    std::atomic<bool> plain{true};
+    on_threads(pieces.size(), n_threads, [&](size_t i) {
+        pieces[i].reset(new VcfRecords(first_names, contigs, codes, A, nullptr));
+        VcfRecords &r = *pieces[i];
+        r.reserve_hint = (at[i + 1] - at[i]) / 24;
+        std::string text_line;
+        std::vector<std::string> fields;
+        for (size_t p = at[i]; p < at[i + 1] && plain;) {
+            p = line_at(p, text_line);
+            if (text_line.empty()) continue;
+            split_tabs(text_line, fields);
+            if (fields.size() < 10) return void(plain = false);
+            r.record(fields);
+            if (r.n_errors) return void(plain = false);
+        }
+    });
+    if (!plain) return false;
+    const VcfRecords *last = nullptr;
+    std::vector<size_t> total(first_names.size(), 0);
+    for (const auto &pc : pieces) {
+        if (!pc->records) continue;
+        if (last && (pc->first_rid < last->read_for || (pc->first_rid == last->read_for && (pc->first_begin < last->start_pos || pc->first_begin < last->end_pos)))) return false;
+        last = pc.get();
+        for (const auto &run : pc->runs) total[run.first] += run.second.size();
+    }
+    out.num_alleles = A;
+    out.by_seq.assign(first_names.size(), {});
+    for (size_t i = 0; i < total.size(); ++i) out.by_seq[i].reserve(total[i]);
+    for (auto &pc : pieces)
+        for (auto &run : pc->runs) {
+            std::vector<Variant> &to = out.by_seq[run.first];
+            to.insert(to.end(), std::make_move_iterator(run.second.begin()), std::make_move_iterator(run.second.end()));
+        }
+    return true;
+}
 }  // namespace
 
 Variants read_variants(const std::string &path, const std::vector<std::string> &first_names, const std::vector<std::vector<uint8_t>> &codes) {
+    if (!options().serial_parse) {
+        Variants mapped;
+        if (read_variants_mapped(path, first_names, codes, mapped)) {
+            ++options().mapped_parses;
+            return mapped;
+        }
+    }
     GzLines f(path);
     std::string line;
     std::vector<std::string> contigs;
@@ -845,129 +1290,10 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
     }
     if (out.num_alleles > Variant::kMaxAlleles) throw Error("Currently only 128 alleles are supported, but file has " + std::to_string(out.num_alleles) + ".");
 
-    // ReadVariants (:126-420) over the whole file
-    const uint32_t A = out.num_alleles;
-    std::vector<uint32_t> allele(A);
-    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0, last_rid = 0xFFFFFFFFu;
-    std::vector<uint8_t> vcf_ref, inserted;                           // per record, kept for their storage
-    std::vector<size_t> alt_start;
-    std::vector<std::array<uint64_t, 2>> gt_has_var;
+    VcfRecords r(first_names, contigs, codes, out.num_alleles, &out.by_seq);
     for (;;) {
-        if (last_rid >= contigs.size() || contigs[last_rid] != rec[0]) last_rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());
-        const uint32_t rid = last_rid;                                // unknown names get a new id
-        const long long pos1 = atoll(rec[1].c_str());
-        const uint32_t begin_pos = (uint32_t)(pos1 - 1);
-        bool skip_rest = false;
-        if (rid < read_for) {                                         // :393-401 (checked when the record is read)
-            error("Variant file is not properly position sorted. Found sequence id " + std::to_string(rid) + " after id " + std::to_string(read_for));
-            skip_rest = true;
-        } else if (rid == read_for && old_ref_id != 0xFFFFFFFFu && begin_pos < start_pos) {
-            error("Variant file is not properly position sorted. Found in sequence id " + std::to_string(rid) + " position " + std::to_string(begin_pos) + " after position " +
-                  std::to_string(start_pos));
-            skip_rest = true;
-        } else read_for = rid;
-        if (!skip_rest) {
-            if (rid >= first_names.size()) {
-                error("Variant starting in reference sequence " + std::to_string(rid) + " does not belong to an existing reference sequence.");
-            } else if (begin_pos >= codes[rid].size()) {
-                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(begin_pos) + " starts after the end of the reference sequence.");
-            } else {
-                start_pos = begin_pos;
-                if (old_ref_id == rid) {
-                    if (start_pos < end_pos) error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " overlaps with a previous variant.");
-                } else old_ref_id = rid;
-                const std::string &ref = rec[3], &alt = rec[4];
-                end_pos = start_pos + (uint32_t)ref.size();
-                vcf_ref.resize(ref.size());
-                bool ref_n = false;
-                for (size_t k = 0; k < ref.size(); ++k) ref_n |= (vcf_ref[k] = dna5_code(ref[k])) > 3;
-                if (ref_n)
-                    error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an reference column containing ambiguous bases (e.g. N).");
-                else if (end_pos > codes[rid].size() || !std::equal(vcf_ref.begin(), vcf_ref.end(), codes[rid].begin() + start_pos))
-                    error("The specified reference in vcf file '" + ref + "' is not identical with the specified reference sequence " + std::to_string(rid) + " at position " +
-                          std::to_string(start_pos) + ".");
-                // genotypes (:196-262)
-                bool ok = true;
-                uint32_t cur_allele = 0;
-                for (size_t g = 9; g < rec.size() && ok; ++g) {
-                    if (cur_allele >= A) {
-                        error("Found to many alleles in genotype definition");
-                        ok = false;
-                        break;
-                    }
-                    uint32_t chosen = 0;
-                    bool column_ok = true;
-                    for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos) {
-                        const char c = rec[g][pos];
-                        if ('|' == c || '/' == c) {
-                            if (cur_allele < A) allele[cur_allele] = chosen;
-                            ++cur_allele;
-                            chosen = 0;
-                        } else if ('0' <= c && '9' >= c) chosen = chosen * 10 + (uint32_t)(c - '0');
-                        else {
-                            error(std::string("Unallowed character '") + c + "' in genotype definition '" + rec[g] + "'");
-                            column_ok = false;
-                        }
-                    }
-                    if (cur_allele >= A) {                               // the reference would index past `allele` here
-                        error("Found to many alleles in genotype definition");
-                        ok = false;
-                        break;
-                    }
-                    allele[cur_allele++] = column_ok ? chosen : 0;
-                    ok = ok && column_ok;
-                }
-                if (ok && cur_allele < A) {
-                    error("Could not find enough alleles in genotype definition");
-                    ok = false;
-                }
-                if (ok) {                                             // :270-370 alternatives, one bit per allele that carries them
-                    alt_start.assign(1, 0);
-                    gt_has_var.clear();
-                    uint32_t chosen_var = 1;
-                    auto carriers = [&](bool last) {
-                        std::array<uint64_t, 2> bits{0, 0};
-                        for (uint32_t a = A; a--;) {
-                            bits[a / 64] <<= 1;
-                            if (allele[a] == chosen_var) ++bits[a / 64];
-                            else if (last && allele[a] > chosen_var)
-                                error("Variant number " + std::to_string(allele[a]) + " does not exist for sequence id " + std::to_string(rid) + " and position " + std::to_string(begin_pos));
-                        }
-                        gt_has_var.push_back(bits);
-                        ++chosen_var;
-                    };
-                    for (size_t pos = 0; pos < alt.size(); ++pos)
-                        if (',' == alt[pos]) {
-                            alt_start.push_back(pos + 1);
-                            carriers(false);
-                        }
-                    alt_start.push_back(alt.size() + 1);
-                    carriers(true);
-                    for (size_t pos = 0; pos < vcf_ref.size(); ++pos)
-                        for (size_t n_alt = 0; n_alt < gt_has_var.size(); ++n_alt) {
-                            if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
-                            const size_t alt_len = alt_start[n_alt + 1] - 1 - alt_start[n_alt];
-                            inserted.clear();
-                            if (pos + 1 == vcf_ref.size() && pos + 1 < alt_len) {                         // insertion
-                                for (size_t k = alt_start[n_alt] + pos; k < alt_start[n_alt + 1] - 1; ++k) inserted.push_back(dna5_code(alt[k]));
-                            } else if (pos < alt_len) {                                                    // base mutation
-                                const uint8_t b = dna5_code(alt[alt_start[n_alt] + pos]);
-                                if (vcf_ref[pos] == b) continue;
-                                inserted.push_back(b);
-                            }                                                                              // else: deletion, ""
-                            bool has_n = false;
-                            for (uint8_t b : inserted) has_n |= b > 3;
-                            if (has_n) {
-                                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an alternative column containing ambiguous bases (e.g. N).");
-                            } else {
-                                const uint64_t bits[2] = {gt_has_var[n_alt][0], gt_has_var[n_alt][1]};
-                                insert_variant(out.by_seq[rid], start_pos + (uint32_t)pos, inserted, bits);
-                            }
-                        }
-                }
-            }
-        }
-        if (n_errors >= 20) break;                                    // kMaxErrorsShownPerFile
+        r.record(rec);
+        if (r.n_errors >= 20) break;                                  // kMaxErrorsShownPerFile
         bool got = false;
         while (f.getline(line)) {
             if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -979,11 +1305,11 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
         if (!got) break;
         split_tabs(line, rec);
         if (rec.size() < 10) {
-            error("Could not read vcf record: fewer than 10 columns");
+            r.error("Could not read vcf record: fewer than 10 columns");
             break;
         }
     }
-    if (n_errors) throw Error(errors);
+    if (r.n_errors) throw Error(r.errors);
     return out;
 }
 

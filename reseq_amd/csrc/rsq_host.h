@@ -6,6 +6,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <string.h>
 #include <vector>
 
 namespace rsq {
@@ -31,6 +32,9 @@ struct Options {
     int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
     int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
     int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
+    int64_t serial_parse = 0;          // 1: the line readers for every methylation and variant file
+    int64_t mapped_parses = 0;         // a count, not a switch: files the memory-mapped methylation / variant readers have read (the others went to the line readers)
+    int64_t parse_stretch = 0;         // > 0: piece length of the memory-mapped methylation / variant readers (and no minimum file size)
     int64_t job_chunk_bytes = 0;       // > 0: size of the device arrays rsq_sim_job_generate keeps a rank's FASTQ text in (default 2 GiB; tests: small, so that the text spans several)
     int64_t overlap = 0;               // n > 1: rsq_sim_pairs cuts its block range into n sub-ranges whose sieve / reads / text stages are pipelined on three streams
 };
@@ -183,10 +187,51 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
 // insertion = the base at the position followed by the inserted bases), kept per sequence sorted by position and, at one position,
 // by length; one bit per allele (up to 128) says which alleles carry it.  Loading only: the simulation with variants (SURVEY.md
 // section 8 row a17) is not built yet.
+// var_seq_ of a variant: base codes 0..3, none for a deletion, one for a substitution, a few for an insertion -- kept inside the variant up to 16 of them (a
+// call set's millions of substitutions then cost no allocation each), on the heap beyond
+class BaseSeq {
+    static constexpr uint32_t kInPlace = 16;
+    union {
+        uint8_t here_[kInPlace];
+        uint8_t *far_;
+    };
+    uint32_t n_ = 0;
+    void take(const uint8_t *from, size_t n) {
+        n_ = (uint32_t)n;
+        uint8_t *to = here_;
+        if (n > kInPlace) to = far_ = new uint8_t[n];
+        if (n) memcpy(to, from, n);
+    }
+
+  public:
+    BaseSeq() {}
+    BaseSeq(const std::vector<uint8_t> &v) { take(v.data(), v.size()); }
+    BaseSeq(const BaseSeq &o) { take(o.data(), o.n_); }
+    BaseSeq(BaseSeq &&o) noexcept {
+        memcpy(static_cast<void *>(this), &o, sizeof *this);
+        o.n_ = 0;
+    }
+    BaseSeq &operator=(BaseSeq o) noexcept {
+        if (n_ > kInPlace) delete[] far_;
+        memcpy(static_cast<void *>(this), &o, sizeof *this);
+        o.n_ = 0;
+        return *this;
+    }
+    ~BaseSeq() {
+        if (n_ > kInPlace) delete[] far_;
+    }
+    const uint8_t *data() const { return n_ > kInPlace ? far_ : here_; }
+    size_t size() const { return n_; }
+    uint8_t operator[](size_t i) const { return data()[i]; }
+    const uint8_t *begin() const { return data(); }
+    const uint8_t *end() const { return data() + n_; }
+    bool operator==(const std::vector<uint8_t> &v) const { return v.size() == n_ && (!n_ || 0 == memcmp(v.data(), data(), n_)); }
+    bool operator==(const BaseSeq &o) const { return o.n_ == n_ && (!n_ || 0 == memcmp(o.data(), data(), n_)); }
+};
 struct Variant {
     static constexpr uint32_t kMaxAlleles = 128;
     uint32_t position = 0;
-    std::vector<uint8_t> var_seq;          // base codes 0..3
+    BaseSeq var_seq;
     uint64_t allele[2] = {0, 0};
     bool in_allele(uint32_t a) const { return (allele[a / 64] >> (a % 64)) & 1; }
     uint32_t first_allele() const;         // Reference.h:42-58

@@ -38,6 +38,8 @@ def emu_lib():
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_option.argtypes = [C.c_char_p, C.c_longlong]
+        L.emu_get_option.argtypes = [C.c_char_p]
+        L.emu_get_option.restype = C.c_longlong
         L.emu_image_tiles.argtypes = [C.c_void_p]
         L.emu_plan_mask.argtypes = [C.c_void_p]
         L.emu_prepare.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p]

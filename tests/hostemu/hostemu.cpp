@@ -264,6 +264,10 @@ void emu_screen_stats(uint64_t *out) {
 }
 void emu_set_fill_mode(void *h, int mode) { static_cast<Emu *>(h)->fill_mode = mode; }
 int emu_set_option(const char *name, long long value) { return set_option(name, value) ? 0 : -1; }       // rsq_set_option
+long long emu_get_option(const char *name) {                                                             // rsq_get_option; -1 for an unknown name
+    int64_t v = -1;
+    return get_option(name, &v) ? (long long)v : -1;
+}
 int emu_image_tiles(void *h) { return (int)static_cast<Emu *>(h)->dev.lds.img_tiles; }
 int emu_plan_mask(void *h) { return (int)static_cast<Emu *>(h)->dev.lds.mask; }
 
@@ -431,8 +435,8 @@ int emu_read_methylation(void *h, const char *path) {
 }
 // the product's BED parser alone (rsq_host.cpp read_methylation_file), for pinning against the reference's own loading test:
 // rate_out is [sum of regions][num_alleles]; a sequence with one column repeats it for every allele (Reference.h:390-397)
-int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t *lens, uint32_t n_seqs, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out,
-                          uint32_t *second_out, double *rate_out, uint32_t cap) {
+int emu_parse_methylation_columns(const char *path, const char *names_nl, const uint32_t *lens, uint32_t n_seqs, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out,
+                                  uint32_t *second_out, double *rate_out, uint32_t cap, uint32_t *columns_out /* rate columns per sequence, may be null */) {
     return guard([&] {
         std::vector<std::string> names;
         std::string cur;
@@ -447,6 +451,7 @@ int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t
         uint32_t at = 0;
         for (uint32_t i = 0; i < n_seqs; ++i) {
             n_regions[i] = (uint32_t)m.first[i].size();
+            if (columns_out) columns_out[i] = (uint32_t)m.rate[i].size();
             for (size_t k = 0; k < m.first[i].size() && at < cap; ++k, ++at) {
                 first_out[at] = m.first[i][k];
                 second_out[at] = m.second[i][k];
@@ -455,6 +460,10 @@ int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t
         }
         return 0;
     });
+}
+int emu_parse_methylation(const char *path, const char *names_nl, const uint32_t *lens, uint32_t n_seqs, uint32_t num_alleles, uint32_t *n_regions, uint32_t *first_out,
+                          uint32_t *second_out, double *rate_out, uint32_t cap) {
+    return emu_parse_methylation_columns(path, names_nl, lens, n_seqs, num_alleles, n_regions, first_out, second_out, rate_out, cap, nullptr);
 }
 // the product's InsertVariant alone (rsq_host.cpp), for ReferenceTest::TestInsertVariant: calls in, list out (positions, lengths, letters, bits)
 int emu_insert_variants_test(uint32_t n_calls, const uint32_t *positions, const char *const *var_seqs, const uint64_t *allele0, uint32_t *n_out, uint32_t *pos_out,
