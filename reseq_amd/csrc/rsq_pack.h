@@ -13,6 +13,7 @@
 #include <vector>
 
 #include <atomic>
+#include <exception>
 #include <mutex>
 #include <thread>
 
@@ -58,7 +59,8 @@ struct SimState {
     std::vector<uint32_t> seq_len;
     std::vector<uint64_t> seq_word_off, seq_base_off;
     uint64_t total_ref_size = 0;
-    std::vector<std::vector<uint8_t>> ref_codes;     // host copy: DominantBase carry-over between chains
+    std::vector<uint64_t> ref_words_host;            // host copy of the packed reference (32 bases per word, seq_word_off): DominantBase carry-over between chains
+    uint32_t ref_code(uint32_t seq, uint32_t pos) const { return (uint32_t)(ref_words_host[seq_word_off[seq] + (pos >> 5)] >> ((pos & 31u) * 2u)) & 3u; }
     // variants (-V): host copies of what the device holds, and of the two table families their systematic errors are drawn from
     bool has_variants = false;
     uint32_t num_alleles = 1;
@@ -538,6 +540,29 @@ inline void extra_starts_of_sequence(const std::vector<Variant> &vars, std::vect
     }
 }
 
+// f(item) for every item on a few host threads (items handed out in order)
+template <class F>
+inline void pack_on_threads(size_t n_items, F f) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::min<size_t>(std::max<size_t>(1, n_items), std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    std::atomic<size_t> next{0};
+    std::exception_ptr failed;
+    std::mutex m;
+    auto work = [&]() {
+        try {
+            for (size_t t; (t = next.fetch_add(1)) < n_items;) f(t);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m);
+            failed = std::current_exception();
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(work);
+    work();
+    for (std::thread &t : helpers) t.join();
+    if (failed) std::rethrow_exception(failed);
+}
+
 inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const Variants *variants = nullptr) {
     DevSim &d = s.dev;
     d.n_seqs = (uint32_t)r.codes.size();
@@ -567,47 +592,55 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
         constexpr size_t kStretch = (size_t)1 << 22;
         for (size_t i = 0; i < r.codes.size(); ++i)
             for (size_t lo = 0; lo < r.codes[i].size(); lo += kStretch) stretches.push_back(Stretch{i, lo, std::min(r.codes[i].size(), lo + kStretch)});
-        std::atomic<size_t> next{0};
         std::atomic<bool> has_n{false};
-        auto work = [&]() {
-            for (size_t t; (t = next.fetch_add(1)) < stretches.size();) {
+        pack_on_threads(stretches.size(), [&](size_t t) {
+            {                                                       // whole words: 32 bases each
                 const Stretch &st = stretches[t];
                 const uint8_t *c = r.codes[st.seq].data();
                 uint64_t *w = &packed[s.seq_word_off[st.seq]];
+                uint64_t seen = 0;
                 for (size_t pos = st.lo; pos < st.hi; pos += 32) {
                     const size_t n = std::min<size_t>(32, st.hi - pos);
                     uint64_t x = 0;
-                    uint8_t seen = 0;
-                    for (size_t k = 0; k < n; ++k) {
-                        x |= (uint64_t)(c[pos + k] & 3u) << (2 * k);
-                        seen |= c[pos + k];
+                    if (32 == n) {                                  // eight codes per load: their 2-bit fields, a byte apart, are pushed together in three steps
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            uint64_t y;
+                            memcpy(&y, c + pos + 8 * q, 8);
+                            seen |= y;
+                            y &= 0x0303030303030303ull;
+                            y = (y | y >> 6) & 0x000F000F000F000Full;
+                            y = (y | y >> 12) & 0x000000FF000000FFull;
+                            y = (y | y >> 24) & 0xFFFFull;
+                            x |= y << (16 * q);
+                        }
+                    } else {
+                        for (size_t k = 0; k < n; ++k) {
+                            x |= (uint64_t)(c[pos + k] & 3u) << (2 * k);
+                            seen |= c[pos + k];
+                        }
                     }
-                    if (seen > 3) has_n = true;
                     w[pos >> 5] = x;
                 }
+                if (seen & 0xFCFCFCFCFCFCFCFCull) has_n = true;
             }
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_threads = std::min<size_t>(std::max<size_t>(1, stretches.size()), std::max(1u, std::min(hw ? hw : 1u, 16u)));
-        std::vector<std::thread> helpers;
-        for (size_t t = 1; t < n_threads; ++t) helpers.emplace_back(work);
-        work();
-        for (std::thread &t : helpers) t.join();
+        });
         if (has_n) throw Error("reference still contains N: call rsq_ref_replace_n first");
     }
     std::vector<uint32_t> gc_prefix(words + 1, 0);                 // running G/C totals per word, restarting with every sequence
-    for (size_t i = 0; i < r.codes.size(); ++i) {
-        const size_t n_words = (r.codes[i].size() + 31) / 32;
-        uint32_t total = 0;
-        for (size_t w = 0; w <= n_words; ++w) {                    // the spare word holds the sequence total
-            gc_prefix[s.seq_word_off[i] + w] = total;
-            if (w < n_words) {
-                const uint64_t x = packed[s.seq_word_off[i] + w];
-                total += (uint32_t)__builtin_popcountll((x ^ (x >> 1)) & 0x5555555555555555ull);
+    auto gc_totals = [&](const uint64_t *copy, uint32_t *out) {     // of one copy of the reference, a sequence per thread
+        pack_on_threads(r.codes.size(), [&](size_t i) {
+            const size_t n_words = (r.codes[i].size() + 31) / 32;
+            uint32_t total = 0;
+            for (size_t w = 0; w <= n_words; ++w) {                // the spare word holds the sequence total
+                out[s.seq_word_off[i] + w] = total;
+                if (w < n_words) {
+                    const uint64_t x = copy[s.seq_word_off[i] + w];
+                    total += (uint32_t)__builtin_popcountll((x ^ (x >> 1)) & 0x5555555555555555ull);
+                }
             }
-        }
-    }
-    s.ref_codes = r.codes;
+        });
+    };
+    gc_totals(packed.data(), gc_prefix.data());
     s.has_variants = variants != nullptr;
     s.num_alleles = variants ? variants->num_alleles : 1u;
     d.num_alleles = s.num_alleles;
@@ -637,38 +670,59 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
                         const uint32_t sh = (v.position & 31u) * 2u;
                         w = (w & ~((uint64_t)3u << sh)) | ((uint64_t)v.var_seq[0] << sh);
                     }
-            uint32_t *gp = &gc_prefix[stride * (1u + a)];
-            for (size_t i = 0; i < r.codes.size(); ++i) {
-                const size_t n_words = (r.codes[i].size() + 31) / 32;
-                uint32_t total = 0;
-                for (size_t w = 0; w <= n_words; ++w) {
-                    gp[s.seq_word_off[i] + w] = total;
-                    if (w < n_words) {
-                        const uint64_t x = hp[s.seq_word_off[i] + w];
-                        total += (uint32_t)__builtin_popcountll((x ^ (x >> 1)) & 0x5555555555555555ull);
-                    }
-                }
-            }
+            gc_totals(hp, &gc_prefix[stride * (1u + a)]);
         }
     }
     if (variants) {
-        for (size_t i = 0; i < r.codes.size(); ++i) {
+        // a sequence's variants, allele maps and extra starts depend on nothing outside it: a sequence per thread, then one after the other into the arrays
+        struct PerSequence {
+            std::vector<DevVariant> variants;                      // off counts from the sequence's first base
+            std::vector<uint8_t> bases;
+            std::vector<AlleleVar> allele_map;
+            std::vector<uint32_t> allele_map_ptr;                  // ends, counted from the sequence's first entry
+            std::vector<ExtraStart> extra;
+        };
+        std::vector<PerSequence> per(r.codes.size());
+        pack_on_threads(r.codes.size(), [&](size_t i) {
+            PerSequence &q = per[i];
+            q.variants.reserve(variants->by_seq[i].size());
             for (const Variant &v : variants->by_seq[i]) {
                 DevVariant dv{};
                 dv.pos = v.position;
                 dv.len = (uint32_t)v.var_seq.size();
-                dv.off = (uint32_t)s.var_bases.size();
+                dv.off = (uint32_t)q.bases.size();
                 dv.allele[0] = v.allele[0];
                 dv.allele[1] = v.allele[1];
-                s.var_bases.insert(s.var_bases.end(), v.var_seq.begin(), v.var_seq.end());
-                s.variants.push_back(dv);
+                q.bases.insert(q.bases.end(), v.var_seq.begin(), v.var_seq.end());
+                q.variants.push_back(dv);
             }
-            s.var_ptr.push_back((uint32_t)s.variants.size());
-            allele_maps_of_sequence(variants->by_seq[i], r.codes[i], s.num_alleles, r.first_part(i), s.allele_map, s.allele_map_ptr);
-            if (2 == s.variants_mode && r.codes[i].size() >= d.insert_to) extra_starts_of_sequence(variants->by_seq[i], s.extra);   // sequences that get blocks (:1159)
-            s.extra_seq_ptr.push_back((uint32_t)s.extra.size());
+            allele_maps_of_sequence(variants->by_seq[i], r.codes[i], s.num_alleles, r.first_part(i), q.allele_map, q.allele_map_ptr);
+            if (2 == s.variants_mode && r.codes[i].size() >= d.insert_to) extra_starts_of_sequence(variants->by_seq[i], q.extra);   // sequences that get blocks (:1159)
+        });
+        size_t n_variants = 0, n_bases = 0, n_map = 0, n_extra = 0;
+        for (const PerSequence &q : per) {
+            n_variants += q.variants.size();
+            n_bases += q.bases.size();
+            n_map += q.allele_map.size();
+            n_extra += q.extra.size();
         }
-        if (s.var_bases.size() > 0xFFFFFFF0ull) throw Error("variants: more than 2^32 variant bases");
+        if (n_bases > 0xFFFFFFF0ull) throw Error("variants: more than 2^32 variant bases");
+        s.variants.reserve(n_variants);
+        s.var_bases.reserve(n_bases);
+        s.allele_map.reserve(n_map);
+        s.extra.reserve(n_extra);
+        for (PerSequence &q : per) {
+            const uint32_t base0 = (uint32_t)s.var_bases.size(), map0 = (uint32_t)s.allele_map.size();
+            for (DevVariant &dv : q.variants) dv.off += base0;
+            s.variants.insert(s.variants.end(), q.variants.begin(), q.variants.end());
+            s.var_bases.insert(s.var_bases.end(), q.bases.begin(), q.bases.end());
+            s.allele_map.insert(s.allele_map.end(), q.allele_map.begin(), q.allele_map.end());
+            for (uint32_t end : q.allele_map_ptr) s.allele_map_ptr.push_back(map0 + end);
+            s.extra.insert(s.extra.end(), q.extra.begin(), q.extra.end());
+            s.var_ptr.push_back((uint32_t)s.variants.size());
+            s.extra_seq_ptr.push_back((uint32_t)s.extra.size());
+            q = PerSequence();
+        }
     } else {
         s.var_ptr.assign(r.codes.size() + 1, 0);
         s.extra_seq_ptr.assign(r.codes.size() + 1, 0);
@@ -697,6 +751,9 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     d.variants = up.put(s.variants);
     d.var_ptr = up.put(s.var_ptr);
     d.ref_words = up.put(packed);
+    packed.resize(words + 1);                                     // the allele copies are the device's
+    packed.shrink_to_fit();
+    s.ref_words_host = std::move(packed);
     d.gc_prefix = up.put(gc_prefix);
     d.seq_word_off = up.put(s.seq_word_off);
     d.seq_len = up.put(s.seq_len);
@@ -994,12 +1051,11 @@ struct StrandWindow {
 // most five positions back, so the pass may begin at any variant that lies more than five positions behind its predecessor: the variants
 // between that one and the window only feed the memories.
 inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track, StrandWindow w) {
-    const std::vector<uint8_t> &codes = s.ref_codes[seq];
-    const uint32_t L = (uint32_t)codes.size(), A = s.num_alleles, range = s.dev.sys_gc_range;
+    const uint32_t L = s.seq_len[seq], A = s.num_alleles, range = s.dev.sys_gc_range;
     const DevVariant *vars = s.variants.data() + s.var_ptr[seq];
     const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
     if (!n) return;
-    auto at = [&](uint32_t sp) -> uint32_t { return reverse ? 3u - codes[L - 1u - sp] : codes[sp]; };
+    auto at = [&](uint32_t sp) -> uint32_t { return reverse ? 3u - s.ref_code(seq, L - 1u - sp) : s.ref_code(seq, sp); };
     std::vector<uint16_t> &err = reverse ? s.var_err_rev : s.var_err_fwd;
     std::vector<uint32_t> last_sp(A, 0);
     std::vector<uint8_t> seen(A, 0), last_base_of(A, 4);
@@ -1234,7 +1290,6 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
         for (uint32_t i = 0; i < s.dev.n_seqs; ++i) {
             if (set == kChainsSimulation && !s.n_blocks[i]) continue;      // no unit for sequences shorter than the longest insert
             const uint32_t L = s.seq_len[i];
-            const std::vector<uint8_t> &codes = s.ref_codes[i];
             const bool mine = !range || range->p_lo[i] < range->p_hi[i];
             const uint32_t f_lo = range ? range->p_lo[i] : 0u, f_hi = range ? range->t_hi[i] : L;       // forward positions the rank needs
             for (uint32_t strand = 2; strand--;) {                  // CreateUnit: whole reverse strand first, then the forward blocks
@@ -1255,8 +1310,8 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
                         }
                     }
                 }
-                if (strand) dom_state = dom_base_after_chain([&](uint32_t pos) { return 3u - codes[L - 1 - pos]; }, L, dom_state);
-                else dom_state = dom_base_after_chain([&](uint32_t pos) { return (uint32_t)codes[pos]; }, L, dom_state);
+                if (strand) dom_state = dom_base_after_chain([&](uint32_t pos) { return 3u - s.ref_code(i, L - 1 - pos); }, L, dom_state);
+                else dom_state = dom_base_after_chain([&](uint32_t pos) { return s.ref_code(i, pos); }, L, dom_state);
             }
         }
 }
