@@ -40,6 +40,7 @@ const OptionEntry kOptionTable[] = {
     {"no_indel_skip", &Options::no_indel_skip}, {"force_exact", &Options::force_exact},     {"min_quality_quads", &Options::min_quality_quads},
     {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
     {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},
+    {"chain_chunk", &Options::chain_chunk},     {"chain_warmup", &Options::chain_warmup},
     {"serial_parse", &Options::serial_parse},   {"parse_stretch", &Options::parse_stretch}, {"mapped_parses", &Options::mapped_parses},
     {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap},             {"job_chunk_bytes", &Options::job_chunk_bytes},
 };

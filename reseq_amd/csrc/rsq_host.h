@@ -32,6 +32,8 @@ struct Options {
     int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
     int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
     int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
+    int64_t chain_chunk = 0;           // > 0: positions per chunk of the systematic-error chains (default: 256 to 4096 by the size of the reference)
+    int64_t chain_warmup = -1;         // >= 0: positions of the run-up in front of a chunk in the chains' first pass (default: half a chunk, at most 384)
     int64_t serial_parse = 0;          // 1: the line readers for every methylation and variant file
     int64_t mapped_parses = 0;         // a count, not a switch: files the memory-mapped methylation / variant readers have read (the others went to the line readers)
     int64_t parse_stretch = 0;         // > 0: piece length of the memory-mapped methylation / variant readers (and no minimum file size)

@@ -90,10 +90,11 @@ RSQ_HD uint32_t chain_draw_rate(const DevSim &S, const DevTable &t, const uint32
 }
 
 // Positions [lo,hi) of one chain.  Everything except (dist,start_rate) is a pure function of the sequence and is
-// rebuilt at `lo`, so a chunk can start anywhere given the incoming (dist,start_rate).
+// rebuilt at `lo`, so a chunk can start anywhere given the incoming (dist,start_rate).  keep_from > lo: the positions in front of keep_from are a run-up
+// (nothing is written for them) and *kept_state receives the state in front of keep_from.
 template <class Acc>
 RSQ_HD void sys_chain_chunk(const DevSim &S, const Acc &acc, uint32_t c1, uint32_t c2, uint32_t lo, uint32_t hi, uint32_t initial_dom, uint32_t &dist,
-                            uint32_t &start_rate, uint16_t *out) {
+                            uint32_t &start_rate, uint16_t *out, uint32_t keep_from = 0, uint32_t *kept_state = nullptr) {
     uint32_t cnt[4] = {0, 0, 0, 0};
     for (uint32_t p = lo > 5 ? lo - 5 : 0; p < lo; ++p) ++cnt[acc(p)];
     uint32_t last_base = lo ? acc(lo - 1) : 4u;
@@ -102,12 +103,13 @@ RSQ_HD void sys_chain_chunk(const DevSim &S, const Acc &acc, uint32_t c1, uint32
     uint32_t gc_bases = lo < range ? lo : range, gc = 0;
     for (uint32_t p = lo - gc_bases; p < lo; ++p) gc += is_gc(acc(p));
     for (uint32_t pos = lo; pos < hi; ++pos) {
+        if (pos == keep_from && kept_state) *kept_state = dist | (start_rate << 24);
         const uint32_t b = acc(pos);
         const Words w = philox(S.seed, pos, c1, c2, kDomSysErr << 28);
         const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};
         const uint32_t dom_error = chain_draw<(int)kQuadsSmall>(S, S.dom_error[(b * 5u + last_base) * 5u + dom], idx, w.w0, 4u);
         const uint32_t rate = chain_draw_rate(S, S.error_rate[b * 5u + dom_error], idx, w.w1);
-        out[pos] = (uint16_t)(dom_error | (rate << 8));
+        if (pos >= keep_from) out[pos] = (uint16_t)(dom_error | (rate << 8));
         last_base = b;
         ++cnt[b];
         if (pos >= 5) --cnt[acc(pos - 5)];
@@ -136,9 +138,13 @@ RSQ_HD double site_bias(const DevSim &S, uint64_t word_off, uint32_t L, uint32_t
 
 #if defined(__HIPCC__)
 
-// Speculative chunking: pass 0 runs every chunk from (dist,start_rate) = (0,0); later passes re-run exactly the
+// Speculative chunking: pass 0 runs every chunk from a guess of its incoming (dist,start_rate); later passes re-run exactly the
 // chunks whose true incoming state (the outgoing state of their left neighbour) differs from the one they used.
-// The fixed point is the sequential chain, bit for bit, for any seed.
+// The fixed point is the sequential chain, bit for bit, for any seed and any guess.
+// The guess: the chain run from (0,0) over the `warmup` positions in front of the chunk.  Two runs of the chain over the same positions draw from the same
+// random numbers whatever their states, and meet for good as soon as both have left their error regions (measured on a human-sized reference with (0,0) as
+// the guess at the chunk's own first position: 97 % of the chunks were run a second time, 12 % a third time after 256 more positions, 1.3 % a fourth: the states
+// of two runs meet within about 120 positions).  Long chunks with a short run-up keep the second pass small: see chain_chunk_len.
 //   k_sys_chain_select (passes > 0): one lane per chunk compares; chunks to run again are appended to `list` (their order does not
 //       matter: chunks of one pass are independent), the others keep their outgoing state.  A wave of the run kernel then holds 64 chunks
 //       that all have work, whatever share of the chunks changed.
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(256) k_sys_chain_select(const Chain *chains, c
     if (again) list[s_base + rank] = c;
 }
 __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains, const uint32_t *chunk_chain, const uint32_t *list, uint32_t n_run, uint32_t chunk_len,
-                                                 uint32_t *used_state, const uint32_t *out_prev, uint32_t *out_new, int pass) {
+                                                 uint32_t warmup, uint32_t *used_state, const uint32_t *out_prev, uint32_t *out_new, int pass) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_run) return;
     const uint32_t c = list ? list[i] : i;
@@ -177,9 +183,44 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
     ChainAcc acc{S.ref_words, ch.kind, ch.len, ch.kind < 2 ? S.seq_word_off[ch.id] : 0, ch.kind == 2 ? S.adapters[ch.seg].seqs + S.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
     uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
     const uint32_t lo = (ch.chunk_lo + local) * chunk_len, hi = lo + chunk_len < ch.len ? lo + chunk_len : ch.len;
-    used_state[c] = want;
-    sys_chain_chunk(S, acc, ch.c1, ch.c2, lo, hi, ch.initial_dom, dist, start_rate, ch.out);
+    const uint32_t from = pass == 0 && local ? lo - (warmup < lo ? warmup : lo) : lo;      // pass 0: the guess is the end of a run-up from (0,0)
+    uint32_t used = want;
+    sys_chain_chunk(S, acc, ch.c1, ch.c2, from, hi, ch.initial_dom, dist, start_rate, ch.out, lo, &used);
+    used_state[c] = used;
     out_new[c] = dist | (start_rate << 24);
+}
+
+// -V: the chain state in front of every variant's position, per strand (blockIdx.y): the entering state of the position's chunk at the fixed point (used_state),
+// folded over the chunk's track up to the position (at most chunk_len - 1 steps).  The host pass over the variants' own bases (variant_sys_errors_strand) needs
+// nothing else of the tracks, which therefore stay on the device (12 GB for a human-sized reference).  span: per (sequence, strand) the chain and how many of its
+// chunks were run (a rank of a sharded job runs a part); variants outside get state 0, which nobody reads.
+struct ChainSpan {
+    int32_t chain;
+    uint32_t chunks;
+};
+__global__ void __launch_bounds__(256) k_variant_chain_states(DevSim S, const Chain *chains, const ChainSpan *span, const uint32_t *used_state, uint32_t chunk_len,
+                                                             uint32_t n_variants, uint32_t *states /* [2][n_variants] */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, strand = blockIdx.y;
+    if (i >= n_variants) return;
+    uint32_t seq = 0;                                               // the last sequence whose variants begin at or before i
+    for (uint32_t lo = 0, hi = S.n_seqs; lo < hi;) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.var_ptr[mid] <= i) seq = mid, lo = mid + 1u;
+        else hi = mid;
+    }
+    const ChainSpan sp = span[seq * 2u + strand];
+    uint32_t state = 0;
+    if (sp.chain >= 0) {
+        const Chain ch = chains[sp.chain];
+        const uint32_t L = S.seq_len[seq], pos = strand ? L - 1u - S.variants[i].pos : S.variants[i].pos, chunk = pos / chunk_len;
+        if (chunk >= ch.chunk_lo && chunk - ch.chunk_lo < sp.chunks) {
+            state = used_state[ch.first_chunk + (chunk - ch.chunk_lo)];
+            uint32_t dist = state & 0xFFFFFFu, start_rate = state >> 24;
+            for (uint32_t p = chunk * chunk_len; p < pos; ++p) update_distances(S.reset_distance, dist, start_rate, (uint32_t)ch.out[p] >> 8);
+            state = dist | (start_rate << 24);
+        }
+    }
+    states[(size_t)strand * n_variants + i] = state;
 }
 
 // ------------------------------------------------------------------------------------ bias normalisation

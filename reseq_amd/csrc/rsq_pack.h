@@ -59,6 +59,7 @@ struct SimState {
     std::vector<uint32_t> seq_len;
     std::vector<uint64_t> seq_word_off, seq_base_off;
     uint64_t total_ref_size = 0;
+    uint32_t chain_chunk = 256;                      // positions per chunk of the systematic-error chains: chain_chunk_len(total_ref_size), set when a run of the chains begins
     std::vector<uint64_t> ref_words_host;            // host copy of the packed reference (32 bases per word, seq_word_off): DominantBase carry-over between chains
     uint32_t ref_code(uint32_t seq, uint32_t pos) const { return (uint32_t)(ref_words_host[seq_word_off[seq] + (pos >> 5)] >> ((pos & 31u) * 2u)) & 3u; }
     // variants (-V): host copies of what the device holds, and of the two table families their systematic errors are drawn from
@@ -1050,7 +1051,9 @@ struct StrandWindow {
 // sequence's variants inside the window.  What a variant inherits from earlier variants (last base, dominant-base memories) reaches at
 // most five positions back, so the pass may begin at any variant that lies more than five positions behind its predecessor: the variants
 // between that one and the window only feed the memories.
-inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track, StrandWindow w) {
+// `states` (instead of the track): the chain state in front of every variant of the sequence on this strand, in the variants' order (dist | start_rate << 24;
+// k_variant_chain_states folds the track on the device from the chunk's entering state, so the track need not come back).
+inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, const uint16_t *track, StrandWindow w, const uint32_t *states = nullptr) {
     const uint32_t L = s.seq_len[seq], A = s.num_alleles, range = s.dev.sys_gc_range;
     const DevVariant *vars = s.variants.data() + s.var_ptr[seq];
     const uint32_t n = s.var_ptr[seq + 1] - s.var_ptr[seq];
@@ -1093,7 +1096,11 @@ inline void variant_sys_errors_strand(SimState &s, uint32_t seq, bool reverse, c
             dom[chosen].clear();
             if (sp) dom[chosen].set(at, sp - 1u);
         }
-        for (; inside && folded < sp; ++folded) update_distances(s.dev.reset_distance, dist, start_rate, track[folded - w.lo] >> 8);
+        if (inside && states) {
+            dist = states[var_id] & 0xFFFFFFu;
+            start_rate = states[var_id] >> 24;
+        } else
+            for (; inside && folded < sp; ++folded) update_distances(s.dev.reset_distance, dist, start_rate, track[folded - w.lo] >> 8);
         const uint32_t gc_bases = std::min(sp, range);
         uint32_t gc = 0;
         for (uint32_t q = sp - gc_bases; inside && q < sp; ++q) gc += is_gc(at(q));
@@ -1143,7 +1150,9 @@ struct StrandTask {
     int strand;
     StrandWindow w;
 };
-inline void build_variant_sys_errors(SimState &s, Uploader &up, const std::vector<StrandTask> *windows = nullptr) {
+// states_fwd / states_rev: per variant (s.variants' order) the chain state in front of it on either strand, when the caller has them; otherwise the tracks are read
+inline void build_variant_sys_errors(SimState &s, Uploader &up, const std::vector<StrandTask> *windows = nullptr, const uint32_t *states_fwd = nullptr,
+                                     const uint32_t *states_rev = nullptr) {
     if (!s.has_variants || s.variants.empty()) return;
     // (sequence, strand) tasks are independent (own variants, own error arrays): a few host threads share them, longest first
     std::vector<StrandTask> tasks;
@@ -1166,9 +1175,12 @@ inline void build_variant_sys_errors(SimState &s, Uploader &up, const std::vecto
                 const uint32_t seq = tasks[t].seq;
                 const int strand = tasks[t].strand;
                 const StrandWindow w = tasks[t].w;
-                track.resize(w.hi - w.lo);
-                up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq] + w.lo, track.size() * sizeof(uint16_t));
-                variant_sys_errors_strand(s, seq, strand != 0, track.data(), w);
+                const uint32_t *states = strand ? states_rev : states_fwd;
+                if (!states) {
+                    track.resize(w.hi - w.lo);
+                    up.read_bytes(track.data(), (strand ? s.sys_rev : s.sys_fwd) + s.seq_base_off[seq] + w.lo, track.size() * sizeof(uint16_t));
+                }
+                variant_sys_errors_strand(s, seq, strand != 0, track.data(), w, states ? states + s.var_ptr[seq] : nullptr);
             }
         } catch (const std::exception &e) {
             std::lock_guard<std::mutex> lock(err_mutex);
@@ -1191,7 +1203,22 @@ constexpr const char *kWalkErrorMessage =
     "(GetSysErrorFromBlock, Simulator.cpp:232-292); such a variant set cannot be simulated";
 
 // ------------------------------------------------------------------------------- chains of the a13 pre-pass
-constexpr uint32_t kChainChunk = 256;
+// Positions per chunk of a chain (one lane each) and the run-up in front of a chunk in pass 0 (rsq_kernels.h, "Speculative chunking").  The chunks of a pass are
+// independent, so they only have to be many enough to fill the device (2 M: eight waves on each of its 1024 SIMDs twice over); beyond that longer chunks make
+// the run-up -- work that is thrown away -- a smaller share: 256 positions up to 0.5 Gb of strands, 4096 for a human-sized reference (6.2 Gb, 1.5 M chunks).  The
+// run-up is half a chunk, at most 384 positions (three times the distance within which two runs were measured to meet; on the human-sized reference, chunk
+// length : run-up -> seconds of the chains: 1024:384 1.38, 2048:384 1.19, 2048:768 1.34, 4096:384 1.10, 4096:768 1.17, 4096:1536 1.33, 8192:768 1.14, 16384:1024 1.16; 256:0 was
+// 1.86).  Ranks of a sharded job derive the same values from the same reference.  Options chain_chunk / chain_warmup override them (tests, measurements).
+inline uint32_t chain_chunk_len(uint64_t total_ref_size) {
+    if (options().chain_chunk > 0) return (uint32_t)options().chain_chunk;
+    uint32_t len = 256;
+    while (len < 4096 && 2 * total_ref_size / len > (2u << 20)) len *= 2;
+    return len;
+}
+inline uint32_t chain_warmup_len(uint32_t chunk_len) {
+    if (options().chain_warmup >= 0) return (uint32_t)options().chain_warmup;
+    return std::min(chunk_len / 2, 384u);
+}
 // kChainsAdapters: SimulateErrorModelOnly (Simulator.cpp:2951-2977); kChainsSimulation: Simulate (adapters, then every sequence that
 // gets a unit); kChainsProfile: CreateSystematicErrorProfile (:2597-2653), every sequence and no adapters, from a fresh Simulator.
 enum ChainSet : int { kChainsAdapters = 0, kChainsSimulation = 1, kChainsProfile = 2 };
@@ -1270,9 +1297,9 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
     auto add = [&](Chain c, uint32_t pos_lo, uint32_t pos_hi) {  // chain positions [pos_lo, pos_hi) are needed
         c.first_chunk = (uint32_t)chunk_chain.size();
         c.initial_dom = dom_state;
-        c.chunk_lo = pos_lo / kChainChunk;
+        c.chunk_lo = pos_lo / s.chain_chunk;
         c.in_state = 0;
-        for (uint32_t k = c.chunk_lo; k < cdiv(pos_hi, kChainChunk); ++k) chunk_chain.push_back((uint32_t)chains.size());
+        for (uint32_t k = c.chunk_lo; k < cdiv(pos_hi, s.chain_chunk); ++k) chunk_chain.push_back((uint32_t)chains.size());
         chains.push_back(c);
     };
     const Profile &p = s.prof;
@@ -1302,10 +1329,10 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
                         const uint32_t halo = range->halo;
                         if (!strand && (int)i == range->first_seq && c.chunk_lo) edges->fwd_in_chain = index;
                         if (strand && (int)i == range->last_seq && c.chunk_lo) edges->rev_in_chain = index;
-                        if (!strand && (int)i == range->last_seq && range->p_hi[i] < L && range->p_hi[i] / kChainChunk)      // the right neighbour starts at p_hi
-                            edges->fwd_out_chunk = (int64_t)c.first_chunk + (range->p_hi[i] / kChainChunk - 1u - c.chunk_lo);
+                        if (!strand && (int)i == range->last_seq && range->p_hi[i] < L && range->p_hi[i] / s.chain_chunk)      // the right neighbour starts at p_hi
+                            edges->fwd_out_chunk = (int64_t)c.first_chunk + (range->p_hi[i] / s.chain_chunk - 1u - c.chunk_lo);
                         if (strand && (int)i == range->first_seq && range->p_lo[i]) {                                           // the left neighbour ends at p_lo
-                            const uint32_t t_hi = (uint32_t)std::min<uint64_t>(L, (uint64_t)range->p_lo[i] + halo), lo_chunk = (L - t_hi) / kChainChunk;
+                            const uint32_t t_hi = (uint32_t)std::min<uint64_t>(L, (uint64_t)range->p_lo[i] + halo), lo_chunk = (L - t_hi) / s.chain_chunk;
                             if (lo_chunk) edges->rev_out_chunk = (int64_t)c.first_chunk + (lo_chunk - 1u - c.chunk_lo);
                         }
                     }
@@ -1326,7 +1353,7 @@ inline uint32_t window_chunks() {                                  // option win
     return v > 0 ? (uint32_t)v : kWindowChunks;
 }
 template <class EnteringState>
-inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks, EnteringState &&entering_state) {
+inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks, uint32_t chunk_len, EnteringState &&entering_state) {
     std::vector<StrandTask> out;
     for (size_t c = 0; c < chains.size(); ++c) {
         const Chain &ch = chains[c];
@@ -1335,7 +1362,7 @@ inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, ui
         const uint32_t per_window = window_chunks();
         for (uint32_t first = 0; first < chunks; first += per_window) {
             const uint32_t count = std::min(per_window, chunks - first);
-            const uint32_t lo = (ch.chunk_lo + first) * kChainChunk, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + first + count) * kChainChunk);
+            const uint32_t lo = (ch.chunk_lo + first) * chunk_len, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + first + count) * chunk_len);
             out.push_back(StrandTask{ch.id, (int)ch.kind, StrandWindow{lo, hi, first ? entering_state(ch.first_chunk + first) : ch.in_state}});
         }
     }

@@ -211,8 +211,8 @@ static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t s
             list = run.d_list.as<uint32_t>();
         }
         if (n_run) {
-            hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_run, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), list, n_run, kChainChunk,
-                               run.d_used.as<uint32_t>(), out_prev, out_new, (int)pass);
+            hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_run, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), list, n_run, s.chain_chunk,
+                               chain_warmup_len(s.chain_chunk), run.d_used.as<uint32_t>(), out_prev, out_new, (int)pass);
             HIP_CHECK(hipGetLastError());
         }
         if (pass > 0 && !n_run) break;
@@ -221,14 +221,29 @@ static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t s
     HIP_CHECK(hipStreamSynchronize(st));
     run.passes = pass + 1;                                          // the final states are in d_out[(run.passes - 1) & 1]
 }
-// the windows of the finished run's strands; the state in front of a chunk is what the chunk was last run with (d_used)
-static std::vector<StrandTask> chain_windows(rsq_sim &s) {
+// -V after a finished run: the variants' own systematic errors.  The chain state in front of every variant comes from the device (k_variant_chain_states: 8 bytes per
+// variant come back instead of the tracks' 4 bytes per reference position), the pass over the variants' bases runs on the host's threads.
+static void variant_sys_errors_from_run(rsq_sim &s, hipStream_t st) {
     rsq_sim::ChainRun &run = s.chain_run;
-    return strand_tasks(run.chains, run.n_chunks, [&](uint32_t flat_chunk) {
-        uint32_t state = 0;
-        HIP_CHECK(hipMemcpy(&state, run.d_used.as<uint32_t>() + flat_chunk, 4, hipMemcpyDeviceToHost));
-        return state;
-    });
+    const uint32_t n_variants = (uint32_t)s.variants.size();
+    if (!s.has_variants || !n_variants) return;
+    std::vector<ChainSpan> span((size_t)s.dev.n_seqs * 2, ChainSpan{-1, 0});
+    for (size_t c = 0; c < run.chains.size(); ++c) {
+        const Chain &ch = run.chains[c];
+        if (ch.kind > 1u) continue;
+        span[(size_t)ch.id * 2 + ch.kind] = ChainSpan{(int32_t)c, (c + 1 < run.chains.size() ? run.chains[c + 1].first_chunk : run.n_chunks) - ch.first_chunk};
+    }
+    DevBuf d_span, d_states;
+    d_span.upload(span);
+    d_states.reserve((size_t)n_variants * 8);
+    hipLaunchKernelGGL(k_variant_chain_states, dim3(cdiv(n_variants, 256), 2), dim3(256), 0, st, s.dev, run.d_chains.as<Chain>(), d_span.as<ChainSpan>(), run.d_used.as<uint32_t>(),
+                       s.chain_chunk, n_variants, d_states.as<uint32_t>());
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> states((size_t)n_variants * 2);
+    HIP_CHECK(hipMemcpyAsync(states.data(), d_states.as<uint32_t>(), states.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const std::vector<StrandTask> windows = strand_tasks(run.chains, run.n_chunks, s.chain_chunk, [](uint32_t) { return 0u; });      // the windows' entering states are not needed
+    build_variant_sys_errors(s, s.up, &windows, states.data(), states.data() + n_variants);
 }
 static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const ShardRange *range = nullptr) {
     rsq_sim::ChainRun &run = s.chain_run;
@@ -236,6 +251,7 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const S
     run.chains.clear();
     run.edges = ShardEdges{};
     std::vector<uint32_t> chunk_chain;
+    s.chain_chunk = chain_chunk_len(s.total_ref_size);
     build_chains(s, set, run.chains, chunk_chain, range, &run.edges);
     run.n_chunks = (uint32_t)chunk_chain.size();
     run.passes = 0;
@@ -330,10 +346,7 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
     s.passes = run_sys_chains(s, st, s.has_ref ? kChainsSimulation : kChainsAdapters);
     HIP_CHECK(hipStreamSynchronize(st));
     lap("systematic-error chains", t0);
-    if (s.has_variants && s.chain_run.valid) {                      // -V: the variants' bases, from the finished chains, in windows of the strands
-        const std::vector<StrandTask> windows = chain_windows(s);
-        build_variant_sys_errors(s, s.up, &windows);
-    }
+    if (s.has_variants && s.chain_run.valid) variant_sys_errors_from_run(s, st);      // -V: the variants' bases, from the finished chains
     lap("variants' systematic errors", t0);
     s.prepared = true;
     s.prepared_lo = 1;
@@ -1293,10 +1306,7 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
         HIP_CHECK(hipSetDevice(s->device));
         s->prepared_lo = s->chain_run.block_lo;                     // only these blocks' tracks are finished
         s->prepared_hi = s->chain_run.block_hi;
-        if (s->has_variants) {                                      // -V: the variants' bases inside the rank's strand windows, from the finished chains
-            const std::vector<StrandTask> windows = chain_windows(*s);
-            build_variant_sys_errors(*s, s->up, &windows);
-        }
+        if (s->has_variants) variant_sys_errors_from_run(*s, nullptr);      // -V: the variants' bases inside the rank's strand windows, from the finished chains
         s->prepared = true;
         return RSQ_OK;
     });

@@ -188,6 +188,14 @@ def test_sharded_pre_passes_with_variants(workdir):
     P.case_sharded_prepare(EmuBackend, workdir, world=4, variants=True)
 
 
+@pytest.mark.parametrize("chunk,warmup", [(1024, 300), (64, 0)])
+def test_sharded_pre_passes_with_other_chunks(workdir, rsq_options, chunk, warmup):
+    """shard borders fall inside chunks of any length; the ranks exchange the states at the chunk borders next to them"""
+    rsq_options("chain_chunk", chunk)
+    rsq_options("chain_warmup", warmup)
+    P.case_sharded_prepare(EmuBackend, workdir, world=4, variants=True)
+
+
 def test_sieve_with_dense_thresholds(workdir):
     P.case_sieve_dense_thresholds(EmuBackend, workdir)
 
@@ -215,6 +223,16 @@ def test_variants_systematic_errors_in_strand_windows(workdir, rsq_options):
     (8.4 M positions each; here two chunks of 256, so that these short sequences are cut as well)"""
     rsq_options("window_chunks", 2)
     P.case_variants_indels(EmuBackend, workdir, density=9, seed=47, tag="windows", lengths=(5300, 2600), samples=2)
+
+
+@pytest.mark.parametrize("chunk,warmup", [(64, 0), (64, 17), (1024, 100), (4096, -1), (256, 0)])
+def test_chains_in_chunks_of_any_length_with_any_run_up(workdir, rsq_options, chunk, warmup):
+    """the systematic-error chains are a fixed point of passes over chunks: the tracks (and the variants' own errors, which start from the chain state in
+    front of them) do not depend on the chunk length or on the run-up the first pass guesses a chunk's entering state from"""
+    rsq_options("chain_chunk", chunk)
+    rsq_options("chain_warmup", warmup)
+    P.case_prepass(EmuBackend, workdir)
+    P.case_variants_indels(EmuBackend, workdir, density=9, seed=47, tag=f"chunk{chunk}_{warmup}", lengths=(5300, 2600), samples=2)
 
 
 def test_variants_complex(workdir):

@@ -22,6 +22,9 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 snv_only = "snv" in sys.argv[2:]
 if "--lib" in sys.argv:
     api.use_library(sys.argv[sys.argv.index("--lib") + 1])
+for k, a in enumerate(sys.argv):                                     # --option name=value: rsq_set_option (e.g. trace_prepare=1: stage times of the pre-pass on stderr)
+    if a == "--option":
+        api.set_option(*[(n, int(v)) for n, v in [sys.argv[k + 1].split("=")]][0])
 HUMAN = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
          101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 lengths = [max(5000, int(n * scale)) for n in HUMAN]
@@ -89,6 +92,16 @@ if not snv_only:
     sim.read_methylation(bpath)
 load_stages["methylation_bed"] = round(time.perf_counter() - t1, 2)
 t_load = time.perf_counter() - t0
+# `prepare_sweep chunk:warmup,chunk:warmup,...`: the pre-pass timed under several chunk lengths / run-ups of the systematic-error chains, nothing else
+if "prepare_sweep" in sys.argv[2:]:
+    for combo in sys.argv[sys.argv.index("prepare_sweep") + 1].split(","):
+        chunk, warmup = (int(v) for v in combo.split(":"))
+        api.set_option("chain_chunk", chunk)
+        api.set_option("chain_warmup", warmup)
+        t0 = time.perf_counter()
+        sim.prepare(7, 0, 30.0)
+        print(json.dumps({"chain_chunk": chunk, "chain_warmup": warmup, "prepare_s": round(time.perf_counter() - t0, 3)}), flush=True)
+    sys.exit(0)
 t0 = time.perf_counter()
 info = sim.prepare(7, 0, 30.0)
 t_prep = time.perf_counter() - t0
