@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -39,7 +40,7 @@ const OptionEntry kOptionTable[] = {
     {"fill_mode", &Options::fill_mode},         {"image_tiles", &Options::image_tiles},     {"rate_rows", &Options::rate_rows},
     {"no_indel_skip", &Options::no_indel_skip}, {"force_exact", &Options::force_exact},     {"min_quality_quads", &Options::min_quality_quads},
     {"trace_plan", &Options::trace_plan},       {"trace_prepare", &Options::trace_prepare},
-    {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},
+    {"bias_window", &Options::bias_window},     {"window_chunks", &Options::window_chunks}, {"serial_fasta", &Options::serial_fasta},   {"trace_load", &Options::trace_load},
     {"chain_chunk", &Options::chain_chunk},     {"chain_warmup", &Options::chain_warmup},
     {"serial_parse", &Options::serial_parse},   {"parse_stretch", &Options::parse_stretch}, {"mapped_parses", &Options::mapped_parses},
     {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap},             {"job_chunk_bytes", &Options::job_chunk_bytes},
@@ -326,7 +327,19 @@ void on_threads(size_t n_items, unsigned n_threads, F f) {      // f(item) for e
 // stretches that are counted and converted independently (a base's code does not depend on the line it stands in).  The same rules as the
 // line reader below: a line starts a record iff its first character is '>', one '\r' before the line end is dropped, blanks and tabs are
 // skipped, empty lines ignored.  Returns false (nothing read) for anything that is not a regular uncompressed file.
+// option trace_load: stage times of the readers on stderr
+struct LoadLap {
+    const char *who;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!options().trace_load) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "load: %-10s %-22s %8.3f s\n", who, what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 bool read_fasta_mapped(const std::string &path, Reference &r) {
+    LoadLap lap{"fasta"};
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -357,6 +370,7 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
         for (const char *p = d + lo; p < d + hi && (p = (const char *)memchr(p, '>', (size_t)(d + hi - p))); ++p)
             if (p == d || p[-1] == '\n') found[i].push_back((size_t)(p - d));
     });
+    lap("map + find headers");
     std::vector<size_t> header;
     for (const auto &f : found) header.insert(header.end(), f.begin(), f.end());
     if (header.empty()) return false;                                  // the line reader words the error
@@ -391,6 +405,7 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
         for (size_t p = s.lo; p < s.hi; ++p) kept += !dropped(p);
         s.kept = kept;
     });
+    lap("count bases");
     std::vector<size_t> offset(stretches.size());
     for (size_t i = 0; i < header.size(); ++i) {
         size_t total = 0;
@@ -404,6 +419,7 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
         const size_t k = first_stretch[i + 1];
         r.codes[i].resize(k > first_stretch[i] ? offset[k - 1] + stretches[k - 1].kept : 0);
     });
+    lap("allocate");
     static const BaseCodes codes;
     on_threads(stretches.size(), n_threads, [&](size_t i) {
         const Stretch &s = stretches[i];
@@ -411,6 +427,7 @@ bool read_fasta_mapped(const std::string &path, Reference &r) {
         for (size_t p = s.lo; p < s.hi; ++p)
             if (!dropped(p)) *out++ = codes.lut[(uint8_t)d[p]];
     });
+    lap("convert");
     return true;
 }
 }  // namespace
@@ -479,7 +496,10 @@ std::string Reference::first_part(size_t i) const {
 // four before it at the end; drawn when the stretch is the whole sequence).  The draw of position p is Philox word w0 & 3 of
 // counter (p, sequence, 0, 5<<28), also when p lies in a flank that is itself N.
 void Reference::replace_n(uint64_t seed) {
-    for (size_t s = 0; s < codes.size(); ++s) {
+    LoadLap lap{"replace_n"};
+    // the draws are keyed by (seed, sequence, position): sequences are independent, one per thread
+    const unsigned hw = std::thread::hardware_concurrency();
+    on_threads(codes.size(), std::max(1u, std::min(hw ? hw : 4u, 32u)), [&](size_t s) {
         std::vector<uint8_t> &c = codes[s];
         auto draw = [&](size_t pos) { return (uint8_t)(philox(seed, (uint32_t)pos, (uint32_t)s, 0, kDomReplaceN << 28).w0 & 3u); };
         for (size_t start = 0; start < c.size();) {
@@ -522,7 +542,8 @@ void Reference::replace_n(uint64_t seed) {
             }
             start = end;
         }
-    }
+    });
+    lap("all sequences");
 }
 
 // ------------------------------------------------------------------- systematic-error profile (FASTQ) and ref-bias file

@@ -30,6 +30,7 @@ struct Options {
     int64_t trace_prepare = 0;         // 1: stage times of the pre-pass on stderr
     int64_t bias_window = 0;           // > 0: start positions per pass of the bias sums
     int64_t window_chunks = 0;         // > 0: window length (chunks) of the host pass over the variants' systematic errors
+    int64_t trace_load = 0;            // 1: stage times of the FASTA reader and of replace_n on stderr
     int64_t serial_fasta = 0;          // 1: the line reader for every FASTA file
     int64_t fasta_stretch = 0;         // > 0: stretch length of the memory-mapped FASTA reader
     int64_t chain_chunk = 0;           // > 0: positions per chunk of the systematic-error chains (default: 256 to 4096 by the size of the reference)

@@ -76,6 +76,23 @@ with open(bpath, "w") as f:
         f.write("".join(f"{names[si]}\t{a}\t{a + b}\t{m0:.4f}\t{m1:.4f}\n" for a, b, (m0, m1) in zip(starts.tolist(), lens.tolist(), meth.tolist())))
 t_make = time.perf_counter() - t0
 
+# `loads N`: N processes load the job's inputs at the same time, as the ranks of an N-GPU job on one host do (here all of them onto this one GPU): seconds per process and stage
+if "loads" in sys.argv[2:]:
+    import subprocess
+    n_proc = int(sys.argv[sys.argv.index("loads") + 1])
+    code = ("import sys, time, json; sys.path.insert(0, %r); from reseq_amd import api; api.set_option('trace_load', %d); t0 = time.perf_counter(); st = {}; t = time.perf_counter()\n"
+            "prof, ref = api.Profile(%r), api.Reference(%r, 7); st['fasta_and_replace_n'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+            "ref.read_variants(%r); st['vcf'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+            "sim = api.Simulator(prof, ref, 0); st['create_simulator_pack_upload'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+            "sim.read_methylation(%r); st['methylation_bed'] = round(time.perf_counter() - t, 2)\n"
+            "print(json.dumps({'load_s': round(time.perf_counter() - t0, 2), 'stages': st}))\n") % (ROOT, int("trace" in sys.argv), ppath, fpath, vpath, bpath)
+    result = {}
+    for n in sorted({1, n_proc}):
+        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(n)]
+        result[str(n)] = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    print(json.dumps({"config": f"configs[4] human-sized at scale {scale}: the load of N ranks at once on one host", "host_threads": os.cpu_count(), "loads": result}))
+    sys.exit(0)
+
 t0 = time.perf_counter()
 load_stages = {}
 t1 = time.perf_counter()
