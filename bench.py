@@ -80,17 +80,35 @@ def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
     return pairs, nbytes, wall, n_pairs, text
 
 
+def usable_cpus():
+    """hardware threads this process may run on at once: its affinity mask, capped by the container's CPU quota (cgroup cpu.max / cfs_quota_us) --
+    a box of this pool shows 256 threads and grants 16 CPUs; processes beyond the quota only take turns"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota, period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(profile_path, seqs, seed):
     """The CPU oracle (a port of the reference's algorithm, oracle/liboracle.so) on bounded samples of the same workload -- the first
     bases of the reference at the workload's pair density; sieve + CreateReads timed, pre-passes excluded like the GPU figure: one
-    process on 300 kb, then one process per host core on a block range each of 1.5 Mb."""
-    cores = len(os.sched_getaffinity(0))
+    process on 300 kb, then one process per CPU the container may use (usable_cpus) on a block range each of 1.5 Mb."""
+    cores, host_threads = usable_cpus(), len(os.sched_getaffinity(0))
     p1, b1, t1, _, text = _oracle_run(profile_path, seqs, seed, 300_000, 1)
     many_bp = 1_500_000
     pn, bn, tn, _, _ = _oracle_run(profile_path, seqs, seed, many_bp, cores)
     out = {"value": pn / tn, "unit": "read-pairs/s", "cores": cores, "kind": "port",
            "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1},
-           "sample": f"oracle/liboracle.so; 1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per host core, a block range "
+           "sample": f"oracle/liboracle.so; 1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per CPU of the container's quota; the host shows {host_threads} hardware threads; a block range "
                      f"each): first {many_bp} bp, {pn} pairs in {tn:.1f} s; sieve + CreateReads, pre-passes excluded"}
     return out, text
 
