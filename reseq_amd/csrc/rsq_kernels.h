@@ -82,6 +82,10 @@ RSQ_HD uint32_t chain_draw(const DevSim &S, const DevTable &t, const uint32_t (&
     return 0.0 == ps ? none : value;
 }
 RSQ_HD uint32_t chain_draw_rate(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
+    if (t.sure_range) {                                              // the word alone says "rate 0" for the lane's rows of margins 0 and 2 (rsq_pack.h): no row is read
+        const uint32_t range = S.chain_sure[t.sure_range + clamp_row(t, 0, idx[0]) * t.rows[2] + clamp_row(t, 2, idx[2])], lo16 = range & 0xFFFFu;
+        if ((word >> 16) - lo16 < (range >> 16) - lo16) return 0u;
+    }
     switch (S.chain_quads) {
         case 8: return chain_draw<8>(S, t, idx, word, 0u);
         case 16: return chain_draw<16>(S, t, idx, word, 0u);

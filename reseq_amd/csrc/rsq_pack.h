@@ -266,10 +266,52 @@ inline void pack_tables(SimState &s, Uploader &up) {
     s.dev.force_exact = opt.force_exact ? 1u : 0u;
     for (uint32_t q : kChainQuads)
         if (!s.dev.chain_quads && quads_of(kmax_of(error_rate)) <= q && quads_of(kmax_of(dom_error)) <= kQuadsSmall) s.dev.chain_quads = q;
+    std::vector<uint32_t> chain_sure(1, 0u);
     if (s.dev.chain_quads) {
         copy32(dom_error, 4u * kQuadsSmall);
         copy32(error_rate, 4u * s.dev.chain_quads);
+        // Error-rate draws decided by the random word alone: at most positions the table is one of "rate 0 almost surely" (no dominant error there), and a lane
+        // that knows its rows of margin 0 (distance) and margin 2 (start rate) can tell from the bound above -- the worst ratios taken over the rows of margin 1
+        // (G/C percent) only -- whether its word gives value 0 whatever the G/C row is.  One range per (table, row of margin 0, row of margin 2), read instead of
+        // three rows of up to 104 values: the chains are bound by that traffic (the rows come from L2; without this draw a pass takes 40 % of its time).
+        if (!opt.no_indel_skip)
+            for (DevTable &d : error_rate) {
+                d.sure_range = 0;
+                if (!d.k || !d.f32_ok || !d.rows[0] || !d.rows[1] || !d.rows[2]) continue;
+                uint32_t z = d.k;
+                for (uint32_t c = 0; c < d.k; ++c)
+                    if (0 == par0[d.par0_off + c]) z = c;
+                if (z == d.k) continue;
+                const uint32_t kp = row_stride(d.k);
+                std::vector<double> worst1(d.k, 0.0);                // over the rows of margin 1: the largest row[c] / row[z]; < 0: no bound
+                for (uint32_t c = 0; c < d.k; ++c)
+                    for (uint32_t r = 0; r < d.rows[1] && worst1[c] >= 0.0; ++r) {
+                        const double *row = pool.data() + d.off[1] + (size_t)r * kp;
+                        if (row[z] > 0.0) worst1[c] = std::max(worst1[c], row[c] / row[z]);
+                        else if (row[c] > 0.0) worst1[c] = -1.0;
+                    }
+                d.sure_range = (uint32_t)chain_sure.size();
+                for (uint32_t r0 = 0; r0 < d.rows[0]; ++r0)
+                    for (uint32_t r2 = 0; r2 < d.rows[2]; ++r2) {
+                        const double *m0 = pool.data() + d.off[0] + (size_t)r0 * kp, *m2 = pool.data() + d.off[2] + (size_t)r2 * kp;
+                        double below = 0.0, above = 0.0;
+                        bool bound = m0[z] > 0.0 && m2[z] > 0.0;
+                        for (uint32_t c = 0; c < d.k && bound; ++c) {
+                            if (c == z) continue;
+                            if (worst1[c] < 0.0) bound = false;
+                            else (c < z ? below : above) += (m0[c] / m0[z]) * worst1[c] * (m2[c] / m2[z]);
+                        }
+                        uint32_t range = 0;
+                        if (bound) {
+                            const double lo = above / (1.0 + above) * (1.0 + 1e-9), hi = 1.0 / (1.0 + below) * (1.0 - 1e-9);
+                            const uint32_t lo16 = (uint32_t)std::ceil(lo * 65536.0), hi16 = (uint32_t)std::floor(hi * 65536.0);
+                            if (lo16 < hi16) range = lo16 | (hi16 << 16);
+                        }
+                        chain_sure.push_back(range);
+                    }
+            }
     }
+    s.dev.chain_sure = up.put(chain_sure);
 
     // LDS plan of the read kernels (rsq_kernels.h "LDS staging"): one image per template segment with the tables of ALL tiles when they fit the 160 KiB,
     // else one image per (segment, tile) -- the read kernel then serves one tile per workgroup (k_fill_reads<MASK, VAR, true>: reads binned by tile).  The

@@ -44,7 +44,8 @@ struct DevTable {
     uint32_t f32_ok;       // every value is 0 or in [2^-60, 2^29]: the error bound of the screened draw holds
     uint32_t lds_extra;    // base call: offset of margin 2 (number of errors) in the LDS image, kNoLds if not staged
     // indel tables: lo16 | hi16 << 16; a draw with lo16 <= (random word >> 16) < hi16 and margin 0 at its row 0 returns value 0 = no indel whatever the
-    // rows of the other margins are (rsq_pack.h certain_no_indel); 0: no such bound
+    // rows of the other margins are (rsq_pack.h certain_no_indel); 0: no such bound.  Error-rate tables (the chains): index into DevSim::chain_sure of the table's
+    // ranges [row of margin 0][row of margin 2] for value 0 = rate 0; 0: none
     uint32_t sure_range;
 };
 static_assert(sizeof(DevTable) == 80, "descriptor layout");
@@ -185,6 +186,7 @@ struct DevSim {
     uint64_t seed;
     // ---- tables
     const double *pool;
+    const uint32_t *chain_sure;    // error-rate tables: lo16 | hi16 << 16 per (table, row of margin 0, row of margin 2), DevTable::sure_range (rsq_pack.h)
     const float *pool32;           // single-precision copy of the quality, base-call and indel tables (DevTable::off32)
     const uint8_t *par0;
     const DevTable *quality;       // [2][n_tiles][4]
