@@ -1693,13 +1693,27 @@ RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, ui
 // step p into slot p % kRingSlots of its ring: one load of 16 bytes per lane instead of one per lane and quad of the row.  Item i is
 // one 16-byte group of one table's row.
 RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.lds.img_tiles * S.lds.quads_q; }
-RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) {
+// What does not change from step to step is worked out once per chunk of reads (RingItem): where the table's rows over the read position begin, the first
+// position and the last row of that margin, the item's place in a ring slot.
+struct RingItem {
+    const float *rows;                 // row 0 of margin 2, at the item's group of four columns; nullptr: an empty table (zeros)
+    uint32_t from, last;               // DevTable::from[2], rows[2] - 1
+    uint32_t at;                       // floats from the slot's start
+};
+RSQ_HD RingItem lds_ring_item(const DevSim &S, const RSQ_LDS float *img, uint32_t item) {
     const uint32_t table = item / S.lds.quads_q, c = item % S.lds.quads_q, slot = S.lds.slot_q;
     const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
-    Quad q = zero_quad();
-    if (d.k) q = *reinterpret_cast<const Quad *>(S.pool32 + d.off32 + (d.rows[0] + d.rows[1] + clamp_row(d, 2, p)) * slot + 4u * c);
-    *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + table * slot + 4u * c) = q;
+    return RingItem{d.k ? S.pool32 + d.off32 + (d.rows[0] + d.rows[1]) * slot + 4u * c : nullptr, d.from[2], d.rows[2] - 1u, table * slot + 4u * c};
 }
+RSQ_HD void lds_ring_stage(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) {
+    Quad q = zero_quad();
+    if (it.rows) {
+        const int32_t d = (int32_t)p - (int32_t)it.from, row = d < 0 ? 0 : (d > (int32_t)it.last ? (int32_t)it.last : d);      // clamp_row
+        q = *reinterpret_cast<const Quad *>(it.rows + (uint32_t)row * S.lds.slot_q);
+    }
+    *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + it.at) = q;
+}
+RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) { lds_ring_stage(S, lds_ring_item(S, img, item), ring, p); }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
 RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg, uint32_t end) {
@@ -2156,8 +2170,10 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
         bool running = active;
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
+        const RingItem mine = lane < n_items ? lds_ring_item(S, img, lane) : RingItem{nullptr, 0u, 0u, 0u};      // the lane's first item (with one tile per image: its only one)
         for (uint32_t t = 0; __any(running); ++t) {
-            for (uint32_t item = lane; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
+            if (lane < n_items) lds_ring_stage(S, mine, ring, t);
+            for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
             if (running) running = m.step(S, tab, st, src, out);
