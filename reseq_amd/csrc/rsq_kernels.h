@@ -1605,17 +1605,19 @@ struct ScreenTables {
         return settle<4>(decided, col, t, 4u * S.lds.img_tiles + local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {
-        const DevTable t = desc(24u * S.lds.img_tiles + i);
-        ps = 0u;
-        if (!t.k) return 0;
-        // nearly every draw: the random word alone says "no indel" (DevTable::sure_range); the wave skips the rows when all its lanes are that sure
-        const uint32_t lo16 = t.sure_range & 0xFFFFu;
-        const bool sure = (u >> 16) - lo16 < (t.sure_range >> 16) - lo16 && 0u == clamp_row(t, 0, idx[0]);
+        // nearly every draw: the random word alone says "no indel" (DevTable::sure_range, 0 for an empty table; margin 0 at its row 0: the index is not above the
+        // margin's first); the wave skips the rows when all its lanes are that sure, and has read two words of the descriptor
+        const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img) + (24u * S.lds.img_tiles + i);
+        const uint32_t range = d->sure_range, lo16 = range & 0xFFFFu;
+        const bool sure = (u >> 16) - lo16 < (range >> 16) - lo16 && idx[0] <= d->from[0];
         RSQ_SCREEN_COUNT(3, sure);
         if (!RSQ_ANY(!sure)) {
             ps = 1u;
             return 0;
         }
+        const DevTable t = *d;
+        ps = 0u;
+        if (!t.k) return 0;
         const uint32_t slot = S.lds.slot_i;
         const float *g = S.pool32 + t.off32;
         const bool m0_staged = t.lds_off != kNoLds;
