@@ -56,11 +56,25 @@ RSQ_HD uint32_t pair_c3(uint32_t dom, uint32_t strand, uint32_t segsel, uint32_t
 // ------------------------------------------------------------------------- integer helpers (utilities.hpp)
 RSQ_HD bool is_gc(uint32_t b) { return b == 1 || b == 2; }
 RSQ_HD uint32_t divide_u32(uint32_t nom, uint32_t den) { return (nom + den / 2u) / den; }          // :450-452
+// x / d for x < 2^24, 1 <= d and a quotient below 2^17 (the percentages: at most 65535 + d / 2 over d).  The device has no integer division: the compiler's
+// sequence for a 32-bit one is about 28 instructions.  Here: both operands are exact in single precision, the product with the reciprocal (1 ulp) is off by less than
+// 2^17 * 2^-22 of the true quotient, so its integer part is the quotient or one beside it, and the remainder says which.
+RSQ_HD uint32_t div_small(uint32_t x, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)d));
+    const int32_t r = (int32_t)(x - q * d);
+    if (r < 0) --q;
+    else if ((uint32_t)r >= d) ++q;
+    return q;
+#else
+    return x / d;
+#endif
+}
 RSQ_HD uint32_t percent_u16(uint32_t nom, uint32_t den) {                                            // :552-554, T = uint16_t
     uint32_t n100 = (nom * 100u) & 0xFFFFu;
-    return (((n100 + den / 2u) / den) & 0xFFFFu) & 0xFFu;
+    return (div_small(n100 + den / 2u, den) & 0xFFFFu) & 0xFFu;
 }
-RSQ_HD uint32_t percent_u32(uint32_t nom, uint32_t den) { return ((nom * 100u + den / 2u) / den) & 0xFFu; }
+RSQ_HD uint32_t percent_u32(uint32_t nom, uint32_t den) { return div_small(nom * 100u + den / 2u, den) & 0xFFu; }      // nom <= den < 2^16 (G/C counts of fragments, of reads)
 RSQ_HD uint32_t safe_percent_u16(uint32_t nom, uint32_t den) { return den ? percent_u16(nom, den) : 50u; }  // :566-573
 RSQ_HD uint32_t transform_distance(uint32_t d) { return (d + 9u) / 10u; }                           // :593-595
 
