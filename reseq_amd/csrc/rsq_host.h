@@ -23,7 +23,7 @@ struct Options {
     int64_t fill_mode = -1;            // -1: screened draws on the LDS image when the plan has one; 0: every draw of the read kernels in double precision from HBM
     int64_t image_tiles = 0;           // 0: the image holds all tiles when they fit, else one tile per workgroup; 1: one tile per workgroup even when all fit
     int64_t rate_rows = 0;             // > 0: at most so many error-rate rows in the LDS image
-    int64_t no_indel_skip = 0;         // 1: no indel draw decided by the random word alone
+    int64_t no_indel_skip = 0;         // 1: no draw decided by the random word alone (the reads' indel draw, the chains' error-rate draw)
     int64_t force_exact = 0;           // 1: the screen decides nothing, every draw takes the double-precision route behind it
     int64_t min_quality_quads = 0;     // a wider instantiation of the read kernels than the profile's quality values need
     int64_t trace_plan = 0;            // 1: the LDS plan on stderr

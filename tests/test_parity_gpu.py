@@ -363,6 +363,14 @@ def test_sharded_pre_passes_with_variants(workdir):
     P.case_sharded_prepare(GpuBackend, workdir, world=4, variants=True)
 
 
+def test_draws_without_the_bounds_on_the_random_word(workdir, rsq_options):
+    """option no_indel_skip: every indel draw of the reads and every error-rate draw of the chains reads its rows (normally the random word alone decides most of
+    them, rsq_pack.h certain_column / chain_sure); the results are the same"""
+    rsq_options("no_indel_skip", 1)
+    P.case_prepass(GpuBackend, workdir)
+    P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="nobounds", lengths=(5300, 2600), samples=2)
+
+
 @pytest.mark.parametrize("chunk,warmup", [(1024, 300), (64, 0)])
 def test_sharded_pre_passes_with_other_chunks(workdir, rsq_options, chunk, warmup):
     """shard borders fall inside chunks of any length; the ranks exchange the states at the chunk borders next to them"""
