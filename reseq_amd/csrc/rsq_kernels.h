@@ -1707,14 +1707,18 @@ RSQ_HD RingItem lds_ring_item(const DevSim &S, const RSQ_LDS float *img, uint32_
     const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
     return RingItem{d.k ? S.pool32 + d.off32 + (d.rows[0] + d.rows[1]) * slot + 4u * c : nullptr, d.from[2], d.rows[2] - 1u, table * slot + 4u * c};
 }
-RSQ_HD void lds_ring_stage(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) {
+RSQ_HD Quad lds_ring_load(const DevSim &S, const RingItem &it, uint32_t p) {
     Quad q = zero_quad();
     if (it.rows) {
         const int32_t d = (int32_t)p - (int32_t)it.from, row = d < 0 ? 0 : (d > (int32_t)it.last ? (int32_t)it.last : d);      // clamp_row
         q = *reinterpret_cast<const Quad *>(it.rows + (uint32_t)row * S.lds.slot_q);
     }
+    return q;
+}
+RSQ_HD void lds_ring_store(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p, const Quad &q) {
     *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + it.at) = q;
 }
+RSQ_HD void lds_ring_stage(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) { lds_ring_store(S, it, ring, p, lds_ring_load(S, it, p)); }
 RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) { lds_ring_stage(S, lds_ring_item(S, img, item), ring, p); }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
@@ -2173,8 +2177,13 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         bool running = active;
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
         const RingItem mine = lane < n_items ? lds_ring_item(S, img, lane) : RingItem{nullptr, 0u, 0u, 0u};      // the lane's first item (with one tile per image: its only one)
+        // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
+        Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
         for (uint32_t t = 0; __any(running); ++t) {
-            if (lane < n_items) lds_ring_stage(S, mine, ring, t);
+            if (lane < n_items) {
+                lds_ring_store(S, mine, ring, t, ahead);
+                ahead = lds_ring_load(S, mine, t + 1u);
+            }
             for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
