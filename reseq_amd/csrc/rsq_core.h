@@ -669,6 +669,10 @@ struct ReadMachine {
     // Decides what the next iteration is: performs the transitions between the template part, the adapter part and the tail
     // (Simulator.cpp:447-449, 537-558) until one of them has an iteration to run.  Returns false once the read is complete.
     RSQ_HD bool advance(const DevSim &S, const Stream &st) {
+        if (phase == kTemplate && par.read_pos < par.read_length && org_pos < org_len) return true;      // nearly every iteration
+        return advance_parts(S, st);
+    }
+    RSQ_HD bool advance_parts(const DevSim &S, const Stream &st) {
         for (;;) {
             if (phase == kTemplate) {
                 if (par.read_pos < par.read_length && org_pos < org_len) return true;
