@@ -81,16 +81,22 @@ RSQ_HD uint32_t chain_draw(const DevSim &S, const DevTable &t, const uint32_t (&
     const uint32_t value = draw<3>(t, S.pool, S.par0, idx, u32_to_unit(word), ps);
     return 0.0 == ps ? none : value;
 }
-RSQ_HD uint32_t chain_draw_rate(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
-    if (t.sure_range) {                                              // the word alone says "rate 0" for the lane's rows of margins 0 and 2 (rsq_pack.h): no row is read
-        const uint32_t range = S.chain_sure[t.sure_range + clamp_row(t, 0, idx[0]) * t.rows[2] + clamp_row(t, 2, idx[2])], lo16 = range & 0xFFFFu;
-        if ((word >> 16) - lo16 < (range >> 16) - lo16) return 0u;
-    }
+RSQ_HD uint32_t chain_draw_rate_rows(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
     switch (S.chain_quads) {
         case 8: return chain_draw<8>(S, t, idx, word, 0u);
         case 16: return chain_draw<16>(S, t, idx, word, 0u);
         default: return chain_draw<26>(S, t, idx, word, 0u);           // also 0: chain_draw goes straight to double precision
     }
+}
+// the word alone says "rate 0" for the lane's rows of margins 0 and 2 (rsq_pack.h): no row is read
+RSQ_HD bool chain_rate_is_zero(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
+    if (!t.sure_range) return false;
+    const uint32_t range = S.chain_sure[t.sure_range + clamp_row(t, 0, idx[0]) * t.rows[2] + clamp_row(t, 2, idx[2])], lo16 = range & 0xFFFFu;
+    return (word >> 16) - lo16 < (range >> 16) - lo16;
+}
+RSQ_HD uint32_t chain_draw_rate(const DevSim &S, const DevTable &t, const uint32_t (&idx)[3], uint32_t word) {
+    if (chain_rate_is_zero(S, t, idx, word)) return 0u;
+    return chain_draw_rate_rows(S, t, idx, word);
 }
 
 // Positions [lo,hi) of one chain.  Everything except (dist,start_rate) is a pure function of the sequence and is
@@ -124,6 +130,64 @@ RSQ_HD void sys_chain_chunk(const DevSim &S, const Acc &acc, uint32_t c1, uint32
         else if (is_gc(acc(pos - gc_bases))) --gc;
     }
 }
+
+#if defined(__HIPCC__)
+// The same positions for the 64 chunks of a wave, with the expensive part of a position -- an error-rate draw that has to read its rows, about one position in
+// thirty -- done for several lanes at once: a lane whose draw the random word does not decide waits (its chunk is its own: nothing orders the lanes of a wave)
+// until kChainBatch lanes wait or no lane can go on, and the rows are read and multiplied by a wave most of whose lanes take part instead of two of them.
+// Position by position a lane does what sys_chain_chunk does; only when it does it differs.
+constexpr uint32_t kChainBatch = 16;        // human-sized chains: 8 -> 0.159 s, 16 -> 0.150, 32 -> 0.178, 48 -> 0.20 at a quarter of the size (0.185 one lane at a time)
+template <class Acc>
+__device__ void sys_chain_chunk_batched(const DevSim &S, const Acc &acc, uint32_t c1, uint32_t c2, uint32_t lo, uint32_t hi, uint32_t initial_dom, uint32_t &dist,
+                                        uint32_t &start_rate, uint16_t *out, uint32_t keep_from, uint32_t *kept_state) {
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    for (uint32_t p = lo > 5 ? lo - 5 : 0; p < lo; ++p) ++cnt[acc(p)];
+    uint32_t last_base = lo ? acc(lo - 1) : 4u;
+    uint32_t dom = lo ? find_dominant(acc, cnt, lo) : initial_dom;
+    const uint32_t range = S.sys_gc_range;
+    uint32_t gc_bases = lo < range ? lo : range, gc = 0;
+    for (uint32_t p = lo - gc_bases; p < lo; ++p) gc += is_gc(acc(p));
+    uint32_t pos = lo, b = 0, dom_error = 0, word1 = 0;
+    bool waiting = false;
+    for (;;) {
+        const bool left = pos < hi;
+        if (!__any(left)) break;
+        uint32_t rate = 0;
+        bool have_rate = false;
+        if (left && !waiting) {
+            if (pos == keep_from && kept_state) *kept_state = dist | (start_rate << 24);
+            b = acc(pos);
+            const Words w = philox(S.seed, pos, c1, c2, kDomSysErr << 28);
+            const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};
+            dom_error = chain_draw<(int)kQuadsSmall>(S, S.dom_error[(b * 5u + last_base) * 5u + dom], idx, w.w0, 4u);
+            word1 = w.w1;
+            have_rate = chain_rate_is_zero(S, S.error_rate[b * 5u + dom_error], idx, word1);
+            waiting = !have_rate;
+        }
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot(waiting)), n_go = (uint32_t)__popcll(__ballot(left && !waiting));
+        if (n_wait >= kChainBatch || (n_wait && !n_go)) {
+            if (waiting) {
+                const uint32_t idx[3] = {transform_distance(dist), safe_percent_u16(gc, gc_bases), start_rate};      // the lane's state has not moved while it waited
+                rate = chain_draw_rate_rows(S, S.error_rate[b * 5u + dom_error], idx, word1);
+                have_rate = true;
+                waiting = false;
+            }
+        }
+        if (have_rate) {
+            if (pos >= keep_from) out[pos] = (uint16_t)(dom_error | (rate << 8));
+            last_base = b;
+            ++cnt[b];
+            if (pos >= 5) --cnt[acc(pos - 5)];
+            dom = find_dominant(acc, cnt, pos + 1);
+            update_distances(S.reset_distance, dist, start_rate, rate);
+            if (is_gc(b)) ++gc;                                     // Simulator.h:354-366 UpdateGC
+            if (gc_bases < range) ++gc_bases;
+            else if (is_gc(acc(pos - gc_bases))) --gc;
+            ++pos;
+        }
+    }
+}
+#endif
 
 struct BiasParam {
     uint32_t seq, len;
@@ -189,7 +253,7 @@ __global__ void __launch_bounds__(64) k_sys_chain(DevSim S, const Chain *chains,
     const uint32_t lo = (ch.chunk_lo + local) * chunk_len, hi = lo + chunk_len < ch.len ? lo + chunk_len : ch.len;
     const uint32_t from = pass == 0 && local ? lo - (warmup < lo ? warmup : lo) : lo;      // pass 0: the guess is the end of a run-up from (0,0)
     uint32_t used = want;
-    sys_chain_chunk(S, acc, ch.c1, ch.c2, from, hi, ch.initial_dom, dist, start_rate, ch.out, lo, &used);
+    sys_chain_chunk_batched(S, acc, ch.c1, ch.c2, from, hi, ch.initial_dom, dist, start_rate, ch.out, lo, &used);
     used_state[c] = used;
     out_new[c] = dist | (start_rate << 24);
 }
