@@ -96,6 +96,28 @@ def part_name(path, rank, world):
     return f"{path}.part{rank + 1:0{len(str(world))}d}of{world}"
 
 
+def _agree(dist, device, error, what):
+    """Every rank learns whether any rank failed in the step just done (one all-reduce, which also takes the place of a barrier): the failing rank raises its own
+    exception, the others a RuntimeError -- nobody is left waiting in a collective for a rank that has gone"""
+    failed = error is not None
+    if dist is not None:
+        import torch
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = bool(int(flag.item()))
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError(f"another rank failed while {what}")
+
+
+def _attempt(f, *a):
+    try:
+        return f(*a), None
+    except Exception as e:       # noqa: BLE001 -- handed to _agree, which raises it after the ranks have agreed
+        return None, e
+
+
 def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False):
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
@@ -108,45 +130,51 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
         assert len(weights) == info["total_blocks"]
         mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
     t0 = time.perf_counter()
-    n_mine, bytes1, bytes2 = backend.job_generate(mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
+    generated, error = _attempt(backend.job_generate, mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
+    _agree(dist, device, error, "generating its share")
+    n_mine, bytes1, bytes2 = generated
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, bytes1 + bytes2, time.perf_counter() - t0)
     if split_output:
         # One pair of files per rank: buffered writes into ONE file take its inode lock one after the other, whoever writes (8 GB/s for the whole job however
         # many ranks, profiles/r03_g_*), separate files do not (49 GB/s with 8 writers behind one GPU's link).  No exchange of sizes, no barrier: a rank is done
         # when its text is out.  The last rank appends the adapter-only pairs, so that the parts in rank order concatenate to the single-file output.
         p1, p2 = part_name(out1, rank, world), part_name(out2, rank, world)
-        for p in (p1, p2):
-            open(p, "wb").close()
-        backend.job_write(p1, 0, p2, 0)
-        if rank == world - 1:
-            with open(p1, "ab") as f1, open(p2, "ab") as f2:
-                for first in range(0, info["adapter_only_pairs"], 100000):
-                    a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
-                    f1.write(a)
-                    f2.write(b)
-        if dist is not None:
-            dist.barrier()
+
+        def write_parts():
+            for p in (p1, p2):
+                open(p, "wb").close()
+            backend.job_write(p1, 0, p2, 0)
+            if rank == world - 1:
+                with open(p1, "ab") as f1, open(p2, "ab") as f2:
+                    for first in range(0, info["adapter_only_pairs"], 100000):
+                        a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
+                        f1.write(a)
+                        f2.write(b)
+
+        _agree(dist, device, _attempt(write_parts)[1], "writing its part")
         return int(total_pairs) + info["adapter_only_pairs"], elapsed
     # one all-gather of two lengths per rank: the exclusive scan over the ranks is every rank's offset in the final files
     sizes = sharding.gather_sizes(dist, device, [bytes1, bytes2], world)
     end1, end2 = (sum(row[col] for row in sizes) for col in (0, 1))
-    if rank == 0:                                                    # the files exist at the size of the ranks' text before anybody writes into them
-        for out, size in ((out1, end1), (out2, end2)):
-            with open(out, "wb") as f:
-                f.truncate(size)
-    if dist is not None:
-        dist.barrier()
-    backend.job_write(out1, sum(row[0] for row in sizes[:rank]), out2, sum(row[1] for row in sizes[:rank]))      # all ranks at once, each its own byte range
-    if dist is not None:
-        dist.barrier()                                               # every rank's text is in place
-    if rank == 0:
-        with open(out1, "ab") as f1, open(out2, "ab") as f2:
-            for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does
-                a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
-                f1.write(a)
-                f2.write(b)
-    if dist is not None:
-        dist.barrier()
+    def create_files():                                              # the files exist at the size of the ranks' text before anybody writes into them
+        if rank == 0:
+            for out, size in ((out1, end1), (out2, end2)):
+                with open(out, "wb") as f:
+                    f.truncate(size)
+
+    def append_adapter_only_pairs():
+        if rank == 0:
+            with open(out1, "ab") as f1, open(out2, "ab") as f2:
+                for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does
+                    a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
+                    f1.write(a)
+                    f2.write(b)
+
+    # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
+    _agree(dist, device, _attempt(create_files)[1], "creating the output files")
+    _agree(dist, device, _attempt(backend.job_write, out1, sum(row[0] for row in sizes[:rank]), out2, sum(row[1] for row in sizes[:rank]))[1],
+           "writing its byte range")                                 # all ranks at once, each its own byte range
+    _agree(dist, device, _attempt(append_adapter_only_pairs)[1], "appending the adapter-only pairs")
     return int(total_pairs) + info["adapter_only_pairs"], elapsed
 
 

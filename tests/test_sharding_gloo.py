@@ -61,6 +61,8 @@ class Emu:                      # the host emulation behind the interface simula
             self.text[1] += t2
         return n, len(self.text[0]), len(self.text[1])
     def job_write(self, path1, offset1, path2, offset2):
+        if os.environ.get("RSQ_FAIL_WRITE") == os.environ["RANK"]:
+            raise IOError("no space left on the device (the test's)")
         for path, offset, text in ((path1, offset1, self.text[0]), (path2, offset2, self.text[1])):
             fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
             os.pwrite(fd, bytes(text), offset)
@@ -120,6 +122,14 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
         a, b = (workdir / f"one_{k}.fq").read_bytes(), (workdir / f"two_{k}.fq").read_bytes()
         assert a == b and a.count(b"\n") % 4 == 0 and b":0:Adapter:0:" in a
     assert not list(workdir.glob("*.rank*"))
+    # a rank that fails leaves nobody waiting: it raises its own error, the other one says that another rank failed (simulate._agree)
+    if not variants:
+        for split in ("", "1"):
+            procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="fail" + split, RSQ_SPLIT=split, RSQ_FAIL_WRITE="1"),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+            errs = [p.communicate(timeout=300)[1].decode() for p in procs]
+            assert all(p.returncode != 0 for p in procs)
+            assert "another rank failed while writing" in errs[0] and "no space left on the device" in errs[1], errs
 
 
 WORKER = r"""
