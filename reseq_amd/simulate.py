@@ -11,7 +11,7 @@ byte range of the two output files (`rsq_sim_job_write`: page-locked double buff
 no shard files, no second copy, nothing through Python; rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
 (seed, sequence, start, length), not by rank (Simulator.cpp:2384-2401 distributes blocks over threads the same way).
-torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and three barriers.
+torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and, after every step, whether any rank failed in it (in a barrier's place).
 """
 import argparse
 import os
