@@ -189,11 +189,14 @@ if "shard" in sys.argv[2:]:
                 self.sim.read_methylation(bpath)
             self.seq_len = lengths
             self.seconds = 0.0
+            self.by_call = {}
 
         def _timed(self, f, *a):
             t = time.perf_counter()
             r = f(*a)
-            self.seconds += time.perf_counter() - t
+            dt = time.perf_counter() - t
+            self.seconds += dt
+            self.by_call[f.__name__] = round(self.by_call.get(f.__name__, 0.0) + dt, 3)
             return r
 
         def ref_seq_bias(self):
@@ -235,7 +238,7 @@ if "shard" in sys.argv[2:]:
         same = text_hash(ranks[world // 2].sim, mid, min(hi, mid + 200)) == text_hash(sim, mid, min(hi, mid + 200))
         lo, hi = ranges[-1]
         same = same and text_hash(ranks[-1].sim, lo, min(hi, lo + 200)) == text_hash(sim, lo, min(hi, lo + 200))      # the first blocks behind a shard border
-        sharded[str(world)] = {"per_rank_s": [round(r.seconds, 3) for r in ranks], "chain_exchange_rounds": rounds, "equal_to_whole_pre_pass": bool(same)}
+        sharded[str(world)] = {"per_rank_s": [round(r.seconds, 3) for r in ranks], "last_rank_by_call_s": ranks[-1].by_call, "chain_exchange_rounds": rounds, "equal_to_whole_pre_pass": bool(same)}
         for r in ranks:
             r.sim.close()
 
