@@ -278,3 +278,56 @@ def test_variant_readers_other_files(tmp_path, both_vcf_readers):
     other.write_text(vcf.read_text().replace("##contig=<ID=seq1,", "##contig=<ID=seq9,"))
     res = both_vcf_readers(fa, other, len(seqs))
     assert res[0] == "error" and "Contigs at position 1" in res[1]
+
+
+# ------------------------------------------------------------------------------------------------ random damage
+def _damage(rng, text):
+    """one to three random edits of a text file: a character changed, removed or inserted, a line removed, doubled or moved"""
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 6))
+        if kind < 3 and text:
+            at = int(rng.integers(0, len(text)))
+            alphabet = "0123456789.\t \n-+eE\rxNACGT|/:chrseq"
+            c = alphabet[int(rng.integers(0, len(alphabet)))]
+            text = text[:at] + (c + text[at + 1:] if kind == 0 else text[at + 1:] if kind == 1 else c + text[at:])
+        else:
+            lines = text.split("\n")
+            if len(lines) < 3:
+                continue
+            a, b = int(rng.integers(0, len(lines) - 1)), int(rng.integers(0, len(lines) - 1))
+            if kind == 3:
+                del lines[a]
+            elif kind == 4:
+                lines.insert(b, lines[a])
+            else:
+                lines.insert(b, lines.pop(a))
+            text = "\n".join(lines)
+    return text
+
+
+def test_methylation_readers_agree_on_randomly_damaged_files(tmp_path, both_readers):
+    rng = np.random.default_rng(77)
+    good = bed_text(rng, 2, per_sequence=25)
+    outcomes = {"ok": 0, "error": 0, "mapped": 0}
+    for k in range(250 * int(os.environ.get("RSQ_FUZZ", "1"))):          # RSQ_FUZZ=20: a longer run by hand
+        p = tmp_path / "d.bed"
+        p.write_bytes(_damage(rng, good).encode())
+        res = both_readers(p, 2)                                    # asserts that the mapped reader (three piece lengths) gives what the line reader gives
+        outcomes[res[0]] += 1
+        outcomes["mapped"] += res[-1] > 0
+    assert outcomes["ok"] > 30 and outcomes["error"] > 30 and outcomes["mapped"] > 10, outcomes
+
+
+def test_variant_readers_agree_on_randomly_damaged_files(tmp_path, both_vcf_readers):
+    P, seqs, fa, rng = _vcf_inputs(tmp_path, lengths=(1500, 150, 2200))
+    vcf = tmp_path / "v.vcf"
+    P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, rng, 25))
+    good = vcf.read_text()
+    outcomes = {"ok": 0, "error": 0, "mapped": 0}
+    for k in range(120 * int(os.environ.get("RSQ_FUZZ", "1"))):
+        p = tmp_path / "d.vcf"
+        p.write_bytes(_damage(rng, good).encode())
+        res = both_vcf_readers(fa, p, len(seqs))
+        outcomes[res[0]] += 1
+        outcomes["mapped"] += res[-1] > 0
+    assert outcomes["ok"] > 5 and outcomes["error"] > 30, outcomes
