@@ -1037,15 +1037,30 @@ struct TextOps {                        // what a record is made of, on top of D
         self().bytes((uint32_t)acc, n < 4u ? n : 4u);
         if (n > 4u) self().bytes((uint32_t)(acc >> 32), n - 4u);
     }
-    RSQ_HD void num(uint64_t v) {
+    RSQ_HD void nine_digits(uint32_t v) {      // v < 10^9 with its leading zeros
+        uint32_t low = 0, mid = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            low = (low << 8) | ('0' + v % 10u);
+            v /= 10u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mid = (mid << 8) | ('0' + v % 10u);
+            v /= 10u;
+        }
+        self().ch((char)('0' + v));
+        self().bytes(mid, 4u);
+        self().bytes(low, 4u);
+    }
+    RSQ_HD void num(uint64_t v) {              // beyond 32 bits (read numbers of a job of more than 4 G pairs): groups of nine digits, no buffer
         if (v <= 0xFFFFFFFFull) return num((uint32_t)v);
-        char tmp[20];
-        int k = 0;
-        do {
-            tmp[k++] = (char)('0' + v % 10);
-            v /= 10;
-        } while (v);
-        while (k) self().ch(tmp[--k]);
+        const uint64_t kE9 = 1000000000ull, upper = v / kE9;
+        if (upper >= kE9) {
+            num((uint32_t)(upper / kE9));
+            nine_digits((uint32_t)(upper % kE9));
+        } else num((uint32_t)upper);
+        nine_digits((uint32_t)(v % kE9));
     }
     RSQ_HD void element(char op, uint32_t count) {
         num(count);
@@ -1137,25 +1152,26 @@ RSQ_HD uint32_t digits_u64(uint64_t v) {
 
 // One FASTQ record "@id\nSEQ\n+\nQUAL\n" with the id of Simulator.cpp:596-632: the id line ...
 template <class Sink>
-RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t,
-                          const FragmentVar *fv = nullptr) {
+// (the fragment and its variant part by reference and two flags, not by pointers that may be null: a pointer chosen at run time puts the structure into scratch memory)
+RSQ_HD void format_header(const DevSim &S, const NameTable &names, bool has_f, const Fragment &f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t,
+                          bool has_fv, const FragmentVar &fv) {
     t.ch('@');
     t.str(names.base_identifier, names.base_len);
-    if (f) {
-        const uint32_t end = fv ? fv->end : f->start + f->len;                  // end_position_forward of CreateReads
-        t.num(f->block);
+    if (has_f) {
+        const uint32_t end = has_fv ? fv.end : f.start + f.len;                  // end_position_forward of CreateReads
+        t.num(f.block);
         t.ch('_');
-        t.num(f->number);
+        t.num(f.number);
         if (1u < S.num_alleles) {                                    // Simulator.cpp:612-614
             t.str("_allele", 7);
-            t.num((uint32_t)f->allele);
+            t.num((uint32_t)f.allele);
         }
         t.ch(':');
-        t.num(f->strand ? end : f->start + 1u);
+        t.num(f.strand ? end : f.start + 1u);
         t.ch(':');
-        t.str(names.names + names.name_ptr[f->seq], names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]);
+        t.str(names.names + names.name_ptr[f.seq], names.name_ptr[f.seq + 1] - names.name_ptr[f.seq]);
         t.ch(':');
-        t.num(f->strand ? f->start + 1u : end);
+        t.num(f.strand ? f.start + 1u : end);
     } else {
         t.ch('0');
         t.ch('_');
@@ -1169,6 +1185,11 @@ RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragmen
     t.str(" E", 2);
     t.num((uint32_t)m.num_errors);
     t.ch('\n');
+}
+template <class Sink>
+RSQ_HD void format_header(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &ops, Sink &t,
+                          const FragmentVar *fv = nullptr) {
+    format_header(S, names, f != nullptr, f ? *f : Fragment{}, adapter_only_number, m, ops, t, fv != nullptr, fv ? *fv : FragmentVar{});
 }
 // ... and one of its two data lines: the bases ("SEQ\n+\n", is_qual false) or the qualities ("QUAL\n").  The read kernel
 // leaves both as bytes in 16-byte aligned rows; four base codes become four letters with one byte permute.
@@ -1212,27 +1233,35 @@ RSQ_HD void format_line(const WordColumn &row, uint32_t read_len, bool is_qual, 
     format_line_part(row, read_len, is_qual, 0u, (read_len + 3u) >> 2, true, t);
 }
 template <class P>
-RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &seq,
-                              const WordColumn &qual, const WordColumn &ops, P dst, const FragmentVar *fv = nullptr) {
+RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, bool has_f, const Fragment &f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &seq,
+                              const WordColumn &qual, const WordColumn &ops, P dst, bool has_fv, const FragmentVar &fv) {
     WordSinkT<P> t(dst);
-    format_header(S, names, f, adapter_only_number, m, ops, t, fv);
+    format_header(S, names, has_f, f, adapter_only_number, m, ops, t, has_fv, fv);
     format_line(seq, m.read_len, false, t);
     format_line(qual, m.read_len, true, t);
     t.finish();
     return t.n;
 }
+template <class P>
+RSQ_HD uint32_t format_record(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const WordColumn &seq,
+                              const WordColumn &qual, const WordColumn &ops, P dst, const FragmentVar *fv = nullptr) {
+    return format_record(S, names, f != nullptr, f ? *f : Fragment{}, adapter_only_number, m, seq, qual, ops, dst, fv != nullptr, fv ? *fv : FragmentVar{});
+}
 
 // length of that record without producing it (the read kernel writes it next to the read)
-RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const FragmentVar *fv = nullptr) {
+RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, bool has_f, const Fragment &f, uint64_t adapter_only_number, const ReadMeta &m, bool has_fv, const FragmentVar &fv) {
     uint32_t n = 1u + names.base_len;
-    if (f) {
-        const uint32_t end = fv ? fv->end : f->start + f->len;
-        if (1u < S.num_alleles) n += 7u + digits_u64(f->allele);
-        n += digits_u64(f->block) + 1u + digits_u64(f->number) + 1u + digits_u64(f->strand ? end : f->start + 1u) + 1u +
-             (names.name_ptr[f->seq + 1] - names.name_ptr[f->seq]) + 1u + digits_u64(f->strand ? f->start + 1u : end);
+    if (has_f) {
+        const uint32_t end = has_fv ? fv.end : f.start + f.len;
+        if (1u < S.num_alleles) n += 7u + digits_u64(f.allele);
+        n += digits_u64(f.block) + 1u + digits_u64(f.number) + 1u + digits_u64(f.strand ? end : f.start + 1u) + 1u +
+             (names.name_ptr[f.seq + 1] - names.name_ptr[f.seq]) + 1u + digits_u64(f.strand ? f.start + 1u : end);
     } else n += 2u + digits_u64(adapter_only_number) + 12u;
     n += 1u + digits_u64(S.tiles[m.tile_id]) + 11u + m.cigar_chars + 2u + digits_u64(m.num_errors) + 1u;
     return n + 2u * m.read_len + 4u;
+}
+RSQ_HD uint32_t record_size(const DevSim &S, const NameTable &names, const Fragment *f, uint64_t adapter_only_number, const ReadMeta &m, const FragmentVar *fv = nullptr) {
+    return record_size(S, names, f != nullptr, f ? *f : Fragment{}, adapter_only_number, m, fv != nullptr, fv ? *fv : FragmentVar{});
 }
 
 // ------------------------------------------------------------------------------------------------- reads
@@ -2516,11 +2545,9 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         if (frags && fvars) fv = fvars[pair];
     }
     const WordColumn seq = raw.seq_of(r), qual = raw.qual_of(r), ops = raw.ops_of(r);
-    const Fragment *fp = frags ? &f : nullptr;
-    const FragmentVar *fvp = frags && fvars ? &fv : nullptr;
     const uint64_t ao_number = adapter_only_first + pair + 1u;
     if (!through_lds) {                                                            // oversized ids: write straight to HBM
-        if (active && part == 0u) format_record(S, names, fp, ao_number, m, seq, qual, ops, dst + offsets[pair], fvp);
+        if (active && part == 0u) format_record(S, names, frags != nullptr, f, ao_number, m, seq, qual, ops, dst + offsets[pair], frags && fvars, fv);
         return;
     }
     const uint32_t slot_at = PERM ? rec * kSlot : 0u;
@@ -2531,7 +2558,7 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
         const uint32_t first_word = second_half ? half : 0u, line_at = header + (is_qual ? m.read_len + 3u : 0u);
         const uint32_t part_at = part == 0u ? 0u : line_at + (4u * first_word < m.read_len ? 4u * first_word : m.read_len);
         WordSinkT<RSQ_LDS char *> t(rec_text + part_at);
-        if (part == 0u) format_header(S, names, fp, ao_number, m, ops, t, fvp);
+        if (part == 0u) format_header(S, names, frags != nullptr, f, ao_number, m, ops, t, frags && fvars, fv);
         format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, second_half ? all_words - half : half, second_half, t);
         t.finish();
     }
