@@ -269,6 +269,108 @@ class TorchBuffer:
         self.ptr, self.nbytes = self.t.data_ptr(), int(nbytes)
 
 
+def ranks_or_relaunch(args):
+    """(rank, local rank, world size) of this process.  Started bare with --gpus N > 1 -- no launcher's environment -- the script starts its N ranks itself, one process
+    per GPU through torch.distributed.run, as Simulator::Simulate starts its own workers (Simulator.cpp:2830-2836); a launcher's world size that is not --gpus is refused."""
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): start it as `python bench.py --gpus N` or with --nproc-per-node equal to --gpus")
+    if args.backend == "gloo" and not args.emulate:
+        raise SystemExit("bench.py: --backend gloo is for --emulate only; ranks on GPUs talk through RCCL (nccl)")
+    return rank, local_rank, world
+
+
+def single_rank_rendezvous():
+    """--dist-single started bare: the rendezvous a launcher would have put into the environment (no effect under a launcher)"""
+    import socket
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+
+
+def rank_times(dist, device, elapsed, steps, world):
+    """ms per step of every rank, in rank order (all-gather of one double)"""
+    if dist is None:
+        return [elapsed / steps * 1e3]
+    import torch
+    t = torch.tensor([elapsed / steps * 1e3], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def main_emulated(args, rank, world):
+    """--emulate: this script's launch, sharding, timing brackets and totals with tests/hostemu's CPU loop over the kernels' per-lane functions where the device would be.
+    The line it prints is marked as such and is no measurement of anything; the CPU suite runs it with two ranks over gloo (tests/test_bench_launch.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from backends import EmuBackend
+    dist = None
+    if world > 1 or args.dist_single:
+        import torch.distributed as dist
+        single_rank_rendezvous()
+        dist.init_process_group("gloo")
+    genome, pairs_per_rank = min(args.genome, 6000), min(args.pairs, 1500)
+    tmp = tempfile.mkdtemp(prefix=f"rsq_bench_emu_{rank}_")
+    ppath, fpath = os.path.join(tmp, "tiny.rsqp"), os.path.join(tmp, "ref.fa")
+    synth.write_profile(ppath, synth.make_profile(synth.TINY, seed=103741084, n_ref_seqs=world))
+    seqs = []
+    for i in range(world):
+        seqs += synth.make_reference(2 + i, [genome], gc=args.gc, names=[f"synthTiny{i} len={genome}"])
+    synth.write_fasta(fpath, seqs)
+    sim = EmuBackend(ppath, fpath, args.seed)
+    info = sim.prepare(args.seed, pairs_per_rank * world)
+    my_lo, my_hi = sharding.partition_blocks(info["total_blocks"], world)[rank]
+    batches = sharding.batches(my_lo, my_hi, args.batch_blocks)
+
+    def step():
+        pairs = nbytes = 0
+        for lo, hi in batches:
+            fr, r1, r2 = sim.pairs(lo, hi)
+            pairs += len(fr)
+            nbytes += len(r1) + len(r2)
+        return pairs, nbytes
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    pairs = nbytes = 0
+    for _ in range(args.steps):
+        p, b = step()
+        pairs += p
+        nbytes += b
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_rank = rank_times(dist, "cpu", elapsed, args.steps, world)
+    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, "cpu", pairs, nbytes, elapsed)
+    sim.close()
+    if rank == 0:
+        print(json.dumps({"metric": "EMULATED on the CPU (tests/hostemu), not a measurement: simulated read-pairs/sec", "emulated": True, "value": total_pairs / elapsed, "unit": "read-pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_per_rank": per_rank,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "TINY profile, host emulation -- the launcher's test", "backend": args.backend, "reference_bp": genome * world, "pairs_per_step": total_pairs / args.steps,
+                                     "fastq_bytes_per_step": total_bytes / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info["total_blocks"]}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,15 +384,19 @@ def main():
     ap.add_argument("--tiles", type=int, default=1, help="NOT the headline: P0 with so many tiles (per-tile tables; above one tile the read kernel serves one tile per workgroup)")
     ap.add_argument("--lib", default=None, help="another build of libreseq_amd.so (experiment builds, exp/)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="rsq_set_option before the simulator is created (measurements)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of a run with more than one rank (and of --dist-single); gloo only with --emulate")
+    ap.add_argument("--emulate", action="store_true", help="TEST SWITCH, not a measurement: the launch / sharding / totals path of this script with the host emulation of the kernels "
+                    "(tests/hostemu, the TINY profile, a few thousand pairs) in the device's place -- what the CPU suite runs with --gpus 2 --backend gloo")
+    ap.add_argument("--dist-single", action="store_true", help="initialise torch.distributed although there is one rank (the RCCL calls of the N-rank path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the value_to_host leg (it is skipped anyway with more than one GPU: every rank would pin 15 GB of host memory)")
     args = ap.parse_args()
 
     if args.lib:
         api.use_library(args.lib)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = ranks_or_relaunch(args)
+    if args.emulate:
+        return main_emulated(args, rank, world)
 
     # the job: `world` sequences, world x pairs; every rank holds the (small) reference and the tables, and simulates its block range
     tmp = tempfile.mkdtemp(prefix=f"rsq_bench_{rank}_")
@@ -305,15 +411,16 @@ def main():
 
     # the CPU oracle first (rank 0 of a single-GPU run only): its worker processes are forked before any device context exists
     baseline = oracle_text = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not args.dist_single:
         baseline, oracle_text = cpu_baseline(ppath, seqs, args.seed)
 
     import torch
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.dist_single:
         import torch.distributed as dist
+        single_rank_rendezvous()
         dist.init_process_group("nccl", device_id=dev)
 
     for item in args.option:                      # after torch: the library binds to the HIP runtime torch has loaded
@@ -376,6 +483,7 @@ def main():
         kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")          # only when the read kernel runs binned by tile
     except api.RsqError:
         pass
+    per_rank = rank_times(dist, f"cuda:{local_rank}", elapsed, args.steps, world)
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
 
     # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1
@@ -427,7 +535,7 @@ def main():
         counters = committed_counters(args.tiles)
         out = {
             "metric": "simulated read-pairs/sec (2x150 bp)", "value": total_pairs / elapsed, "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_per_rank": per_rank, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference sequence and 10 M pairs per GPU, pre-fitted synthetic profile P0 (2x150), "
                                    "illuminaPE hot path (sieve + CreateReads + FASTQ text) resident in HBM" +
@@ -435,7 +543,8 @@ def main():
                        "tiles": args.tiles, "fill_plan": plan, "options": args.option, "reference_bp": args.genome * world,
                        "pairs_requested": args.pairs * world, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
                        "batch_blocks": args.batch_blocks, "read_kernel_launches_per_step": launches / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
-                       "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective"},
+                       "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective",
+                       "collectives": None if dist is None else "torch.distributed nccl (RCCL): barrier, all_reduce of the totals, all_gather of the ranks' times"},
             "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": counters["hbm_bytes_per_launch"] if counters else None, "traffic_source": counters["source"].replace("_pmc", "_traffic") if counters else None,
                          "algorithmic_bytes_per_launch": A_PAIR * (pairs / launches), "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches,

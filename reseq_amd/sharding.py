@@ -80,7 +80,7 @@ def block_weights(seq_len, insert_to, ref_seq_bias):
     return w
 
 
-def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
+def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", agree=None):
     """The pre-passes of a sharded job (SURVEY.md section 8(e)): every rank computes its share and the ranks exchange small arrays;
     every rank ends with the thresholds and, for the positions its reads can touch, the systematic-error tracks of a single-GPU
     rsq_sim_prepare, bit for bit.  `backend`: prepare_plan / ref_seq_bias / seq_len / bias_partials / prepare_normalization /
@@ -92,24 +92,42 @@ def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pair
     a13 SetSystematicErrors: a chain's state (distance to the start of the error region, its rate) is all that crosses a shard
     border.  Every rank first runs its chunks speculatively to a fixed point; the states at the borders then travel rank to rank (forward
     chains to the right, reverse chains to the left) by all-gathers of two words per rank until no rank's entering state changed; a rank
-    whose state changed redoes only the chunks that depend on it."""
+    whose state changed redoes only the chunks that depend on it.
+
+    `agree(error_or_None, what)`: called after every phase that runs the rank's own work (planning, bias sums, each round of the chains, finishing) and BEFORE the
+    collective that follows it -- the launcher's exchange of a "failed" flag (simulate._agree), so that a rank whose phase raised (no memory for the bias sums, a bad
+    input file on one node) does not leave the others waiting in the collective; without it a phase's exception simply propagates."""
     import numpy as np
     import torch
-    info = backend.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
-    total_blocks = info["total_blocks"] if isinstance(info, dict) else info.total_blocks
-    insert_to = info["insert_to"] if isinstance(info, dict) else info.insert_to
-    weights = block_weights(backend.seq_len, insert_to, backend.ref_seq_bias())
-    assert len(weights) == total_blocks
-    lo, hi = partition_blocks(total_blocks, world, weights)[rank]
-    sums, maxes = backend.bias_partials(lo, hi)
+
+    def phase(what, f, *a):
+        if agree is None:
+            return f(*a)
+        try:
+            out, error = f(*a), None
+        except Exception as e:      # noqa: BLE001 -- raised by agree() once every rank knows
+            out, error = None, e
+        agree(error, what)
+        return out
+
+    def plan():
+        info = backend.prepare_plan(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+        total_blocks = info["total_blocks"] if isinstance(info, dict) else info.total_blocks
+        insert_to = info["insert_to"] if isinstance(info, dict) else info.insert_to
+        weights = block_weights(backend.seq_len, insert_to, backend.ref_seq_bias())
+        assert len(weights) == total_blocks
+        return partition_blocks(total_blocks, world, weights)[rank]
+
+    lo, hi = phase("planning the pre-pass", plan)
+    sums, maxes = phase("summing the coverage bias of its share", backend.bias_partials, lo, hi)
     if dist is not None:
         t = torch.from_numpy(np.stack([sums, maxes])).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)                     # every entry is non-zero on one rank
         sums, maxes = t[0].cpu().numpy(), t[1].cpu().numpy()
-    backend.prepare_normalization(sums, maxes)
+    phase("normalising the coverage bias", backend.prepare_normalization, sums, maxes)
     in_state, rounds = [0, 0], 0
     while True:
-        out = backend.prepare_sys_errors(lo, hi, in_state)
+        out = phase("running the systematic-error chains of its share", backend.prepare_sys_errors, lo, hi, in_state)
         rounds += 1
         if dist is None:
             break
@@ -124,7 +142,7 @@ def sharded_prepare(backend, dist, device, rank: int, world: int, seed, num_pair
             break
         if rounds > world + 2:
             raise RuntimeError("the chain states at the shard borders did not settle")
-    return backend.prepare_finish(), (lo, hi), rounds
+    return phase("finishing the pre-pass", backend.prepare_finish), (lo, hi), rounds
 
 
 def sharded_prepare_in_process(backends, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):

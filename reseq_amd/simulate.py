@@ -11,7 +11,8 @@ byte range of the two output files (`rsq_sim_job_write`: page-locked double buff
 no shard files, no second copy, nothing through Python; rank 0 appends the adapter-only pairs.  The result is byte for byte the output of a
 single-GPU run (`reseq_amd/reseq illuminaPE` with the same arguments): blocks are independent and every random stream is keyed by
 (seed, sequence, start, length), not by rank (Simulator.cpp:2384-2401 distributes blocks over threads the same way).
-torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and, after every step, whether any rank failed in it (in a barrier's place).
+torch.distributed (RCCL) carries the seed, the job totals, the shard sizes and, after every step -- each phase of the pre-pass, generating, creating the files,
+writing, appending -- whether any rank failed in it (in a barrier's place): no rank enters a collective that another rank will not reach.
 """
 import argparse
 import os
@@ -122,13 +123,18 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
     small exchanges; the data never passes through Python."""
-    if world > 1 and getattr(backend, "can_shard_prepare", False):   # every rank its share of the pre-passes
-        info, mine, _ = sharding.sharded_prepare(backend, dist, device, rank, world, seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+    if dist is not None and getattr(backend, "can_shard_prepare", False):   # every rank its share of the pre-passes (its phases agree among the ranks themselves)
+        info, mine, _ = sharding.sharded_prepare(backend, dist, device, rank, world, seed, num_pairs, coverage, ref_bias_mode, base_identifier,
+                                                 agree=lambda error, what: _agree(dist, device, error, what))
     else:
-        info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
-        weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
-        assert len(weights) == info["total_blocks"]
-        mine = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
+        def whole_prepare():
+            info = backend.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
+            weights = block_weights(backend.seq_len, info["insert_to"], backend.ref_seq_bias())
+            assert len(weights) == info["total_blocks"]
+            return info, sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
+        prepared, error = _attempt(whole_prepare)
+        _agree(dist, device, error, "preparing the simulation")
+        info, mine = prepared
     t0 = time.perf_counter()
     generated, error = _attempt(backend.job_generate, mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
     _agree(dist, device, error, "generating its share")
@@ -199,7 +205,7 @@ def main(argv=None):
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:                                   # under a launcher, also one that started a single rank: the same exchanges, over RCCL
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

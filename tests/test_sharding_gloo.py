@@ -42,10 +42,14 @@ class Emu:                      # the host emulation behind the interface simula
     def prepare_plan(self, *a):
         return self.b.prepare_plan(*a)
     def bias_partials(self, lo, hi):
+        if os.environ.get("RSQ_FAIL_BIAS") == os.environ["RANK"]:
+            raise MemoryError("no memory for the bias sums (the test's)")
         return self.b.bias_partials(lo, hi)
     def prepare_normalization(self, sums, maxes):
         self.b.prepare_normalization(sums, maxes)
     def prepare_sys_errors(self, lo, hi, in_state):
+        if os.environ.get("RSQ_FAIL_CHAINS") == os.environ["RANK"]:
+            raise RuntimeError("the chains failed (the test's)")
         return self.b.prepare_sys_errors(lo, hi, in_state)
     def prepare_finish(self):
         return self.b.prepare_finish()
@@ -130,6 +134,14 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
             errs = [p.communicate(timeout=300)[1].decode() for p in procs]
             assert all(p.returncode != 0 for p in procs)
             assert "another rank failed while writing" in errs[0] and "no space left on the device" in errs[1], errs
+        # ... also in the pre-pass, whose phases stand in front of collectives (the bias sums' all-reduce, the chain states' all-gather)
+        for switch, failing, said, own in (("RSQ_FAIL_BIAS", 0, "another rank failed while summing the coverage bias", "no memory for the bias sums"),
+                                           ("RSQ_FAIL_CHAINS", 1, "another rank failed while running the systematic-error chains", "the chains failed")):
+            procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="failpre", **{switch: str(failing)}),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+            errs = [p.communicate(timeout=300)[1].decode() for p in procs]
+            assert all(p.returncode != 0 for p in procs)
+            assert said in errs[1 - failing] and own in errs[failing], errs
 
 
 WORKER = r"""
