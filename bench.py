@@ -411,14 +411,14 @@ def main():
 
     # the CPU oracle first (rank 0 of a single-GPU run only): its worker processes are forked before any device context exists
     baseline = oracle_text = None
-    if not args.no_cpu_baseline and world == 1 and not args.dist_single:
+    if not args.no_cpu_baseline and world == 1 and not args.dist_single and "TORCHELASTIC_RUN_ID" not in os.environ:
         baseline, oracle_text = cpu_baseline(ppath, seqs, args.seed)
 
     import torch
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.dist_single:
+    if world > 1 or args.dist_single or "TORCHELASTIC_RUN_ID" in os.environ:      # more than one rank, or one rank under a launcher: the same calls over RCCL
         import torch.distributed as dist
         single_rank_rendezvous()
         dist.init_process_group("nccl", device_id=dev)
