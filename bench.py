@@ -479,6 +479,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
     plan = sim.fill_plan()
+    specialized, spec_note = sim.specialize(0)                         # already done by prepare(): this asks what runs
+    plan["read_kernel"] = "compiled for the profile at run time (hiprtc)" if specialized else "the library's own instantiation"
+    plan["read_kernel_note"] = spec_note
     try:
         kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")          # only when the read kernel runs binned by tile
     except api.RsqError:

@@ -166,6 +166,24 @@ int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out);
  * why); image_tiles = tiles whose tables one workgroup's local-memory image holds: all of the profile's (reads of any tile served by any workgroup) or 1
  * (reads binned by the tile they draw, Simulator.h:176-181, one tile per workgroup at a time); image_bytes = size of that image. */
 int rsq_sim_get_fill_plan(const rsq_sim *s, uint32_t *quality_quads, uint32_t *image_tiles, uint32_t *image_bytes);
+/* The read kernel COMPILED FOR THIS SIMULATOR'S PROFILE.  What a loaded profile fixes -- the local-memory plan, the value ranges and row counts of its quality /
+ * base-call / indel tables, tiles, phred offset -- are loop bounds and address factors of LogArrayResult::Draw (reseq/ProbabilityEstimates.h:481-508, members of
+ * the loaded tables there).  The library carries the kernels' source; with libhiprtc present it compiles them with those values as literals -- per kernel variant
+ * when the variant is first launched, kept for the simulator's life and, as a code object, in the kernel cache directory.  This call does it NOW, so that no
+ * compilation falls into a timed region (rsq_sim_prepare does it for `kind` 0 by itself): kind 0 = read pairs (rsq_sim_pairs ...), 1 = seqToIllumina records
+ * (rsq_sim_error_model ...).  *specialized = 1: the profile's own kernel is in place; 0: the library's own instantiation (any profile) runs -- option
+ * `specialize` 0, no libhiprtc, no table image, or a failed compilation; rsq_last_warning() says which, and how long compiling took.  The reads are the same bytes
+ * either way. */
+int rsq_sim_specialize(rsq_sim *s, int kind, int *specialized);
+/* Directory of the compiled kernels' code objects (files rsq_spec_*_<hash>.hsaco; the hash covers sources, literals, variant, device architecture and compiler
+ * version).  Default: $XDG_CACHE_HOME/reseq_amd, else ~/.cache/reseq_amd -- the one thing the library takes from the environment; "" or NULL: keep nothing on disk. */
+int rsq_set_kernel_cache_dir(const char *path);
+/* Host only, no device needed: compiles the read kernel for `p` as rsq_sim_specialize would for a device of architecture `arch` ("gfx950"), from a plan packed
+ * into host memory; the code object goes to `out_path` (NULL: nowhere; the kernel cache is used and filled as usual).  kind as above; with_variants: the variant
+ * of the read-pair kernel for a reference with variants; binned: the variant that serves one tile per workgroup (forced when the profile's tiles do not fit one
+ * image).  *code_bytes = size of the code object, *seconds (may be NULL) = compilation time, 0 from the cache.  For build checks (hiprtc cross-compiles) and for
+ * reading the generated code (tools/kernel_resources.py --code-object).  RSQ_EINVAL with the compiler's log when it fails. */
+int rsq_profile_compile_read_kernel(const rsq_profile *p, int kind, int with_variants, int binned, const char *arch, const char *out_path, size_t *code_bytes, double *seconds);
 
 /* pre-pass results, for inspection and stage-wise parity tests */
 int rsq_sim_get_thresholds(const rsq_sim *s, double *out, size_t n);           /* [groups][insert_to][2] */

@@ -77,6 +77,9 @@ SYMBOLS = {
     "rsq_sim_prepare_finish": (C.c_int, [_vp]),
     "rsq_sim_get_info": (C.c_int, [_vp, C.POINTER(SimInfo)]),
     "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "rsq_sim_specialize": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "rsq_set_kernel_cache_dir": (C.c_int, [C.c_char_p]),
+    "rsq_profile_compile_read_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "rsq_sim_get_thresholds": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_get_norm_by_len": (C.c_int, [_vp, _vp, _sz]),
     "rsq_sim_set_normalization": (C.c_int, [_vp, C.c_double, _vp, _sz]),
@@ -152,6 +155,11 @@ def archive_layout(stats_path, ipf_path=None):
     return buf.value.decode(errors="replace")
 
 
+def set_kernel_cache_dir(path):
+    """where the read kernels compiled for a profile are kept between processes (None / "": nowhere); default ~/.cache/reseq_amd"""
+    _check(lib().rsq_set_kernel_cache_dir((path or "").encode()))
+
+
 def last_warning():
     return lib().rsq_last_warning().decode(errors="replace")
 
@@ -183,6 +191,12 @@ class Profile:
     def save(self, path):
         """the prepared profile as an RSQP container"""
         _check(lib().rsq_profile_save(self.h, os.fsencode(path)))
+
+    def compile_read_kernel(self, kind=0, with_variants=False, binned=False, arch="gfx950", out_path=None):
+        """host only: the read kernel compiled for this profile (what Simulator.specialize does on the device); returns (bytes of the code object, seconds)"""
+        n, t = C.c_size_t(0), C.c_double(0.0)
+        _check(lib().rsq_profile_compile_read_kernel(self.h, kind, int(with_variants), int(binned), arch.encode(), os.fsencode(out_path) if out_path else None, C.byref(n), C.byref(t)))
+        return n.value, t.value
 
     def change_error_rate(self, multiplier):
         _check(lib().rsq_profile_change_error_rate(self.h, multiplier))
@@ -334,6 +348,13 @@ class Simulator:
         q, t, b = _u32(0), _u32(0), _u32(0)
         _check(lib().rsq_sim_get_fill_plan(self.h, C.byref(q), C.byref(t), C.byref(b)))
         return {"mask": q.value, "image_tiles": t.value, "image_bytes": b.value}
+
+    def specialize(self, kind=0):
+        """Compiles the read kernel (kind 0: read pairs, 1: seqToIllumina records) for this simulator's profile now.  Returns (specialized, what the library says):
+        False when its own instantiation runs instead (option specialize 0, no libhiprtc, no table image, a failed compilation)."""
+        done = C.c_int(0)
+        _check(lib().rsq_sim_specialize(self.h, kind, C.byref(done)))
+        return bool(done.value), last_warning()
 
     def thresholds(self):
         i = self.info()

@@ -10,9 +10,10 @@
 // The functions are __host__ __device__ so that tests/hostemu can run the very same state machine on the
 // CPU against the oracle without a GPU.  The shipped library only ever calls them from kernels.
 #pragma once
-#include <math.h>
-
 #include "rsq_types.h"
+#if !defined(__HIPCC_RTC__)
+#include <math.h>
+#endif
 
 namespace rsq {
 
@@ -618,7 +619,7 @@ struct ReadMachine {
     RSQ_HD void init(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg_, uint32_t tile, uint32_t fragment_length, const Src &src) {
         seg = seg_;
         tile_id = tile;
-        tbase = (seg * S.n_tiles + tile_id) * 4u;
+        tbase = (seg * RSQ_SIM(S, n_tiles) + tile_id) * 4u;
         par.read_pos = 0;
         par.previous_indel_type = 0;
         par.indel_pos = 0;
@@ -655,7 +656,7 @@ struct ReadMachine {
             mean_error_rate = divide_u32(mean_error_rate, alen);
         }
         typename Tab::Sum prob_sum;
-        const uint32_t sqi = seg * S.n_tiles + tile_id;
+        const uint32_t sqi = seg * RSQ_SIM(S, n_tiles) + tile_id;
         const uint32_t idx_sq[3] = {par.gc_seq, mean_error_rate, fragment_length / kSqFragmentLengthBinSize};
         par.seq_qual = tab.draw_seq_quality(sqi, idx_sq, h0.w2, prob_sum);
         if (0 == prob_sum) {                                         // MostLikely(), ProbabilityEstimates.h:519-526
@@ -760,7 +761,7 @@ struct ReadMachine {
             uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
             if (0 == prob_sum) call = org_base;
             par.base_call = call;
-            out.put(par.read_pos, call, q + S.phred_offset);
+            out.put(par.read_pos, call, q + RSQ_SIM(S, phred_offset));
             par.last_written_qual = q;
             out.op(it, 0u);
             const char base_element = from_template ? 'M' : 'S';
@@ -794,11 +795,11 @@ struct ReadMachine {
             par.qual = q;
             const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
             ++pos_tail;
-            out.put(par.read_pos, b, q + S.phred_offset);
+            out.put(par.read_pos, b, q + RSQ_SIM(S, phred_offset));
             par.last_written_qual = q;
             ++par.read_pos;
         } else {                                                   // insertion of base indel-2
-            out.put(par.read_pos, indel - 2u, q + S.phred_offset);
+            out.put(par.read_pos, indel - 2u, q + RSQ_SIM(S, phred_offset));
             par.last_written_qual = q;
             out.op(it, 2u);
             ++n_indels;

@@ -131,7 +131,7 @@ RSQ_HD void sys_chain_chunk(const DevSim &S, const Acc &acc, uint32_t c1, uint32
     }
 }
 
-#if defined(__HIPCC__)
+#if RSQ_DEVICE_BUILD
 // The same positions for the 64 chunks of a wave, with the expensive part of a position -- an error-rate draw that has to read its rows, about one position in
 // thirty -- done for several lanes at once: a lane whose draw the random word does not decide waits (its chunk is its own: nothing orders the lanes of a wave)
 // until kChainBatch lanes wait or no lane can go on, and the rows are read and multiplied by a wave most of whose lanes take part instead of two of them.
@@ -204,7 +204,7 @@ RSQ_HD double site_bias(const DevSim &S, uint64_t word_off, uint32_t L, uint32_t
     return general_bias * S.gc_bias[percent_u32(gc_count, len)] * surrounding_bias(S.sur_bias, ss) * surrounding_bias(S.sur_bias, se);
 }
 
-#if defined(__HIPCC__)
+#if RSQ_DEVICE_BUILD
 
 // Speculative chunking: pass 0 runs every chunk from a guess of its incoming (dist,start_rate); later passes re-run exactly the
 // chunks whose true incoming state (the outgoing state of their left neighbour) differs from the one they used.
@@ -688,7 +688,7 @@ RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t bloc
     }
 }
 
-#if defined(__HIPCC__)
+#if RSQ_DEVICE_BUILD
 // The sieve.
 //   k_sieve_gaps<VM, false>: one lane per start position slot counts the cells that pass the zero threshold (sieve_gaps);
 //   exclusive scan of the counts;
@@ -1567,7 +1567,7 @@ struct EmptySrc {                       // adapter-only pair: org_seq_ = "" (Sim
 };
 
 RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3base) {      // Simulator.h:176-181
-    if (S.n_tiles > 1) return discrete_draw(S.tile_cp, S.n_tiles, u32_to_unit(philox(S.seed, c0, c1, c2, c3base).w0));
+    if (RSQ_SIM(S, n_tiles) > 1) return discrete_draw(S.tile_cp, RSQ_SIM(S, n_tiles), u32_to_unit(philox(S.seed, c0, c1, c2, c3base).w0));
     return 0;
 }
 
@@ -1583,13 +1583,13 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
 //    own row from HBM (HybridRow32).
 // The rows over the read position and the read's G/C percent stay in HBM (L2): the lanes of a wave share the position rows (4
 // cache lines per load).  A draw the screen cannot decide is repeated in double precision from HBM (GlobalTables).
-// Image layout (32-bit words), Ti = LdsPlan::img_tiles: descriptors [quality 4 Ti][base_call 20 Ti][indels 12][seq_quality Ti] (20 words
-// each), the outcome values of these tables, staged margins at DevTable::lds_off / lds_extra, error-rate rows at q3_off / b3_off.
+// Image layout (32-bit words), Ti = LdsPlan::img_tiles: descriptors [quality 4 Ti][base_call 20 Ti][indels 12][seq_quality Ti] (18 words
+// each), the outcome values of these tables, the outcome values by column and the staged margins of the three families (FamilyGeo), error-rate rows at q3_off / b3_off.
 // An image serves the reads of one template segment and of tiles first_tile .. first_tile + Ti - 1 (Ti = n_tiles: all tiles; Ti = 1: the reads
 // are binned by tile and a workgroup stages the image of the bin it serves, fill_binned_loop); it is identified by the index of its first
 // quality table, qbase = (segment * n_tiles + first_tile) * 4.  Descriptors in the image have par0_off relative to the image's outcome values.
 RSQ_HD uint32_t lds_desc_count(uint32_t n_tiles) { return 25u * n_tiles + 12u; }
-RSQ_HD uint32_t image_qbase(const DevSim &S, uint32_t seg, uint32_t first_tile) { return (seg * S.n_tiles + first_tile) * 4u; }
+RSQ_HD uint32_t image_qbase(const DevSim &S, uint32_t seg, uint32_t first_tile) { return (seg * RSQ_SIM(S, n_tiles) + first_tile) * 4u; }
 constexpr uint32_t kDescWords = sizeof(DevTable) / 4u;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1624,8 +1624,19 @@ inline
     return value | (0.0 == ps ? 0x80000000u : 0u);
 }
 
+// row of margin n for value v: AdjustIndeces over the family's common range
+#define RSQ_GEO_ROW(S, fam, n, v) ((uint32_t)geo_clamp((int32_t)(v) - (int32_t)RSQ_PLAN(S, fam.from[n]), (int32_t)RSQ_PLAN(S, fam.last[n])))
+RSQ_HD int32_t geo_clamp(int32_t d, int32_t last) {
+#if defined(__clang__)
+    return __builtin_elementwise_min(__builtin_elementwise_max(d, 0), last);
+#else
+    return d < 0 ? 0 : (d > last ? last : d);
+#endif
+}
+
 // QQ = quads per row of the quality family (LdsPlan::quads_q).  `t` is the step the wave is in: the quality rows over the read
-// positions t, ... t-kRingLag are in the wave's ring (lds_ring_load / lds_ring_store).
+// positions t, ... t-kRingLag are in the wave's ring (lds_ring_load / lds_ring_store).  Rows are found from (table, value) by the families' common
+// geometry; a table's descriptor is read only on the double-precision route and for the rare fallbacks of FillReadPart.
 template <uint32_t MASK>
 struct ScreenTables {
     using Sum = uint32_t;              // 0: prob_sum is 0, else 1 (all the callers ask; a double here costs the loop moves and 64-bit compares)
@@ -1636,29 +1647,25 @@ struct ScreenTables {
     const RSQ_LDS float *ring_;        // the wave's ring
     uint32_t t;
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
-    RSQ_HD const RSQ_LDS uint8_t *par0() const { return reinterpret_cast<const RSQ_LDS uint8_t *>(img + (S.lds.desc_words - S.lds.par0_words)); }
+    RSQ_HD uint32_t par0_at() const { return RSQ_PLAN(S, desc_words) - RSQ_PLAN(S, par0_words); }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - qbase); }
-    RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * S.lds.img_tiles + 12u + i - qbase / 4u); }
-    RSQ_HD static uint32_t row32(const DevTable &t, int n, uint32_t v, uint32_t slot) {      // offset of the row of margin n in the table's float copy
-        uint32_t before = 0;
-        for (int m = 0; m < n; ++m) before += t.rows[m];
-        return (before + clamp_row(t, n, v)) * slot;
-    }
+    RSQ_HD DevTable seq_quality(uint32_t i) const { return desc(24u * RSQ_PLAN(S, img_tiles) + 12u + i - qbase / 4u); }
     // the ring's rows of read position p; in_ring: p is one of the last steps' positions (a read lags by its deletions)
-    RSQ_HD const RSQ_LDS float *ring(uint32_t p) const { return ring_ + (p % kRingSlots) * S.lds.ring_stride; }
+    RSQ_HD const RSQ_LDS float *ring(uint32_t p) const { return ring_ + (p % kRingSlots) * RSQ_PLAN(S, ring_stride); }
     RSQ_HD bool in_ring(uint32_t p) const { return t - p <= kRingLag; }
     // a draw the screen left open (or a table outside its preconditions): the reference's recipe in double precision
     template <int NM>
     RSQ_HD uint32_t exact(uint32_t desc, const uint32_t (&idx)[NM], uint32_t word, uint32_t &ps) const {
-        const uint32_t r = exact_draw_call<NM>(S.pool, img, S.lds.desc_words - S.lds.par0_words, desc, idx[0], idx[1], idx[2], NM == 4 ? idx[NM - 1] : 0u, word);
+        const uint32_t r = exact_draw_call<NM>(S.pool, img, par0_at(), desc, idx[0], idx[1], idx[2], NM == 4 ? idx[NM - 1] : 0u, word);
         ps = (r >> 31) ^ 1u;                                  // the callers only ask whether prob_sum is 0
         return r & 0x7FFFFFFFu;
     }
+    // `values`: FamilyGeo::values of the family, `column` = table of the image * slot + column
     template <int NM>
-    RSQ_HD uint32_t settle(bool decided, uint32_t col, const DevTable &t, uint32_t desc, const uint32_t (&idx)[NM], uint32_t u, uint32_t &ps) const {
-        uint32_t value = par0()[t.par0_off + col];
+    RSQ_HD uint32_t settle(bool decided, uint32_t values, uint32_t column, uint32_t desc, const uint32_t (&idx)[NM], uint32_t u, uint32_t &ps) const {
+        uint32_t value = reinterpret_cast<const RSQ_LDS uint8_t *>(img)[values + column];
         ps = 1u;
-        decided = decided && !S.force_exact;
+        decided = decided && !RSQ_SIM(S, force_exact);
         if (RSQ_ANY(!decided)) {
             if (!decided) value = exact<NM>(desc, idx, u, ps);
         }
@@ -1666,41 +1673,35 @@ struct ScreenTables {
     }
 
     RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
-        const uint32_t local = i - qbase;
-        const DevTable t = desc(local);
-        ps = 0u;
-        if (!t.k) return 0;
-        const uint32_t slot = S.lds.slot_q, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_q;
-        const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot}, m1{img + t.lds_off + (t.rows[0] + clamp_row(t, 1, idx[1])) * slot};
+        const uint32_t local = i - qbase, slot = RSQ_PLAN(S, slot_q), nr = RSQ_PLAN(S, rate_rows_q), r3 = RSQ_GEO_ROW(S, q, 3, idx[3]);
+        const RSQ_LDS float *mine = img + RSQ_PLAN(S, q.lds) + local * (RSQ_PLAN(S, q.lds_rows) * slot);      // margins 0 and 1 of the table
+        const LdsRow32 m0{mine + RSQ_GEO_ROW(S, q, 0, idx[0]) * slot}, m1{mine + (RSQ_PLAN(S, q.before[1]) + RSQ_GEO_ROW(S, q, 1, idx[1])) * slot};
         const LdsRow32 m2{ring(idx[2]) + local * slot};
-        const LdsRow32 m3{img + S.lds.q3_off + (local * nr + (r3 < nr ? r3 : 0u)) * slot};
+        const LdsRow32 m3{img + RSQ_PLAN(S, q3_off) + (local * nr + (r3 < nr ? r3 : 0u)) * slot};
         uint32_t col = 0;
-        bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
-        decided = decided && t.f32_ok;
+        const bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
         RSQ_SCREEN_COUNT(0, decided);
-        return settle<4>(decided, col, t, local, idx, u, ps);
+        return settle<4>(decided, RSQ_PLAN(S, q.values), local * slot + col, local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
-        const uint32_t local = i - qbase * 5u;
-        const DevTable t = desc(4u * S.lds.img_tiles + local);
-        ps = 0u;
-        if (!t.k) return 0;
-        const uint32_t slot = S.lds.slot_b, r3 = clamp_row(t, 3, idx[3]), nr = S.lds.rate_rows_b;
-        const float *g = S.pool32 + t.off32;
-        const LdsRow32 m0{img + t.lds_off + clamp_row(t, 0, idx[0]) * slot};
-        const GlobalRow32 m1{g + row32(t, 1, idx[1], slot)};
-        const bool m2_staged = t.lds_extra != kNoLds, staged = r3 < nr;                         // m2_staged: the same for every table
-        const MixedRow32 m2{LdsRow32{img + (m2_staged ? t.lds_extra + clamp_row(t, 2, idx[2]) * slot : 0u)}, GlobalRow32{g + row32(t, 2, idx[2], slot)}, m2_staged};
-        const MixedRow32 m3{LdsRow32{img + S.lds.b3_off + (local * nr + (staged ? r3 : 0u)) * slot}, GlobalRow32{g + row32(t, 3, idx[3], slot)}, staged};
+        const uint32_t local = i - qbase * 5u, slot = RSQ_PLAN(S, slot_b), nr = RSQ_PLAN(S, rate_rows_b), r3 = RSQ_GEO_ROW(S, b, 3, idx[3]);
+        const float *g = S.pool32 + RSQ_PLAN(S, b.off32) + i * (RSQ_PLAN(S, b.table_rows) * slot);             // the table's rows in device memory
+        const LdsRow32 m0{img + RSQ_PLAN(S, b.lds) + (local * RSQ_PLAN(S, b.lds_rows) + RSQ_GEO_ROW(S, b, 0, idx[0])) * slot};
+        const GlobalRow32 m1{g + (RSQ_PLAN(S, b.before[1]) + RSQ_GEO_ROW(S, b, 1, idx[1])) * slot};
+        const uint32_t r2 = RSQ_GEO_ROW(S, b, 2, idx[2]);
+        const bool m2_staged = RSQ_PLAN(S, b.lds2) != kNoLds, staged = r3 < nr;
+        const MixedRow32 m2{LdsRow32{img + (m2_staged ? RSQ_PLAN(S, b.lds2) + (local * (RSQ_PLAN(S, b.last[2]) + 1u) + r2) * slot : 0u)},
+                            GlobalRow32{g + (RSQ_PLAN(S, b.before[2]) + r2) * slot}, m2_staged};
+        const MixedRow32 m3{LdsRow32{img + RSQ_PLAN(S, b3_off) + (local * nr + (staged ? r3 : 0u)) * slot}, GlobalRow32{g + (RSQ_PLAN(S, b.before[3]) + r3) * slot}, staged};
         uint32_t col = 0;
-        bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3) && t.f32_ok;
+        const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3);
         RSQ_SCREEN_COUNT(1, decided);
-        return settle<4>(decided, col, t, 4u * S.lds.img_tiles + local, idx, u, ps);
+        return settle<4>(decided, RSQ_PLAN(S, b.values), local * slot + col, 4u * RSQ_PLAN(S, img_tiles) + local, idx, u, ps);
     }
     RSQ_HD uint32_t draw_indel(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {
         // nearly every draw: the random word alone says "no indel" (DevTable::sure_range, 0 for an empty table; margin 0 at its row 0: the index is not above the
         // margin's first); the wave skips the rows when all its lanes are that sure, and has read two words of the descriptor
-        const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img) + (24u * S.lds.img_tiles + i);
+        const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img) + (24u * RSQ_PLAN(S, img_tiles) + i);
         const uint32_t range = d->sure_range, lo16 = range & 0xFFFFu;
         const bool sure = (u >> 16) - lo16 < (range >> 16) - lo16 && idx[0] <= d->from[0];
         RSQ_SCREEN_COUNT(3, sure);
@@ -1708,21 +1709,18 @@ struct ScreenTables {
             ps = 1u;
             return 0;
         }
-        const DevTable t = *d;
-        ps = 0u;
-        if (!t.k) return 0;
-        const uint32_t slot = S.lds.slot_i;
-        const float *g = S.pool32 + t.off32;
-        const bool m0_staged = t.lds_off != kNoLds;
-        const MixedRow32 m0{LdsRow32{img + (m0_staged ? t.lds_off + clamp_row(t, 0, idx[0]) * slot : 0u)}, GlobalRow32{g + row32(t, 0, idx[0], slot)}, m0_staged};
-        const GlobalRow32 m1{g + row32(t, 1, idx[1], slot)}, m2{g + row32(t, 2, idx[2], slot)};
+        const uint32_t slot = RSQ_PLAN(S, slot_i), r0 = RSQ_GEO_ROW(S, i, 0, idx[0]);
+        const float *g = S.pool32 + RSQ_PLAN(S, i.off32) + i * (RSQ_PLAN(S, i.table_rows) * slot);
+        const bool m0_staged = RSQ_PLAN(S, i.lds) != kNoLds;
+        const MixedRow32 m0{LdsRow32{img + (m0_staged ? RSQ_PLAN(S, i.lds) + (i * RSQ_PLAN(S, i.lds_rows) + r0) * slot : 0u)}, GlobalRow32{g + r0 * slot}, m0_staged};
+        const GlobalRow32 m1{g + (RSQ_PLAN(S, i.before[1]) + RSQ_GEO_ROW(S, i, 1, idx[1])) * slot}, m2{g + (RSQ_PLAN(S, i.before[2]) + RSQ_GEO_ROW(S, i, 2, idx[2])) * slot};
         uint32_t col = 0;
-        bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2) && t.f32_ok;
+        const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2);
         RSQ_SCREEN_COUNT(2, decided);
-        return settle<3>(decided, col, t, 24u * S.lds.img_tiles + i, idx, u, ps);
+        return settle<3>(decided, RSQ_PLAN(S, i.values), i * slot + col, 24u * RSQ_PLAN(S, img_tiles) + i, idx, u, ps);
     }
     RSQ_HD uint32_t draw_seq_quality(uint32_t i, const uint32_t (&idx)[3], uint32_t u, uint32_t &ps) const {     // once per read: double precision
-        const uint32_t r = exact_draw_call<3>(S.pool, img, S.lds.desc_words - S.lds.par0_words, 24u * S.lds.img_tiles + 12u + i - qbase / 4u, idx[0], idx[1], idx[2], 0u, u);
+        const uint32_t r = exact_draw_call<3>(S.pool, img, par0_at(), 24u * RSQ_PLAN(S, img_tiles) + 12u + i - qbase / 4u, idx[0], idx[1], idx[2], 0u, u);
         ps = (r >> 31) ^ 1u;
         return r & 0x7FFFFFFFu;
     }
@@ -1731,93 +1729,77 @@ struct ScreenTables {
 // Builds the LDS image `qbase` (image_qbase); tid/nthreads describe the calling thread (the host emulation calls it with
 // 0/1).  The caller synchronises the workgroup between the two phases and after the second.
 RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS float *img, uint32_t qbase, uint32_t tid, uint32_t nthreads) {
-    const uint32_t T = S.lds.img_tiles;
+    const uint32_t T = RSQ_PLAN(S, img_tiles);
     RSQ_LDS uint32_t *dst = reinterpret_cast<RSQ_LDS uint32_t *>(img);
     const uint32_t wq = 4u * T * kDescWords, wb = 20u * T * kDescWords, wi = 12u * kDescWords, ws = T * kDescWords;
     const uint32_t *q = reinterpret_cast<const uint32_t *>(S.quality + qbase), *b = reinterpret_cast<const uint32_t *>(S.base_call + qbase * 5u),
                    *in = reinterpret_cast<const uint32_t *>(S.indels), *sq = reinterpret_cast<const uint32_t *>(S.seq_quality + qbase / 4u);
     // outcome values: the indel tables' are the first bytes of the pool, the image's tiles' a contiguous range from its first quality table's on;
     // par0_off (word 1 of a descriptor) becomes relative to the image's copy
-    const uint32_t tiles_at = S.quality[qbase].par0_off, shift = tiles_at - S.lds.par0_indel_bytes;
+    const uint32_t tiles_at = S.quality[qbase].par0_off, shift = tiles_at - RSQ_PLAN(S, par0_indel_bytes);
     for (uint32_t i = tid; i < wq; i += nthreads) dst[i] = q[i] - (i % kDescWords == 1u ? shift : 0u);
     for (uint32_t i = tid; i < wb; i += nthreads) dst[wq + i] = b[i] - (i % kDescWords == 1u ? shift : 0u);
     for (uint32_t i = tid; i < wi; i += nthreads) dst[wq + wb + i] = in[i];
     for (uint32_t i = tid; i < ws; i += nthreads) dst[wq + wb + wi + i] = sq[i] - (i % kDescWords == 1u ? shift : 0u);
     const uint32_t *p0 = reinterpret_cast<const uint32_t *>(S.par0), *p1 = reinterpret_cast<const uint32_t *>(S.par0 + tiles_at);      // ranges start on words; the pool has spare bytes at its end
-    const uint32_t indel_words = S.lds.par0_indel_bytes / 4u;
-    for (uint32_t i = tid; i < S.lds.par0_words; i += nthreads) dst[wq + wb + wi + ws + i] = i < indel_words ? p0[i] : p1[i - indel_words];
+    const uint32_t indel_words = RSQ_PLAN(S, par0_indel_bytes) / 4u, par0_at = RSQ_PLAN(S, desc_words) - RSQ_PLAN(S, par0_words);
+    for (uint32_t i = tid; i < RSQ_PLAN(S, par0_words); i += nthreads) dst[par0_at + i] = i < indel_words ? p0[i] : p1[i - indel_words];
+    // the outcome values by column of the image's tables (FamilyGeo::values; whole words: slots are multiples of four columns)
+    const uint32_t nq = T * RSQ_PLAN(S, slot_q), nb = 5u * T * RSQ_PLAN(S, slot_b), ni = 3u * RSQ_PLAN(S, slot_i);
+    const uint32_t *vq = reinterpret_cast<const uint32_t *>(S.par0 + RSQ_PLAN(S, q.values_src)) + qbase / 4u * RSQ_PLAN(S, slot_q),
+                   *vb = reinterpret_cast<const uint32_t *>(S.par0 + RSQ_PLAN(S, b.values_src)) + qbase / 4u * 5u * RSQ_PLAN(S, slot_b),
+                   *vi = reinterpret_cast<const uint32_t *>(S.par0 + RSQ_PLAN(S, i.values_src));
+    for (uint32_t i = tid; i < nq; i += nthreads) dst[RSQ_PLAN(S, q.values) / 4u + i] = vq[i];
+    for (uint32_t i = tid; i < nb; i += nthreads) dst[RSQ_PLAN(S, b.values) / 4u + i] = vb[i];
+    for (uint32_t i = tid; i < ni; i += nthreads) dst[RSQ_PLAN(S, i.values) / 4u + i] = vi[i];
 }
-// rows 0..n_rows-1 of margin 3 of `n_tables` tables starting at descriptor `first`, one slot per row
-RSQ_HD void lds_stage_rate_rows(const DevSim &S, RSQ_LDS float *img, uint32_t first, uint32_t n_tables, uint32_t n_rows, uint32_t slot, uint32_t dst_off, uint32_t tid,
-                                uint32_t nthreads) {
-    const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
-    for (uint32_t i = tid; i < n_tables * n_rows * slot; i += nthreads) {
-        const DevTable tb = d[first + i / (n_rows * slot)];
-        const uint32_t row = (i / slot) % n_rows, c = i % slot;
-        img[dst_off + i] = (tb.k && row < tb.rows[3]) ? S.pool32[tb.off32 + (tb.rows[0] + tb.rows[1] + tb.rows[2] + row) * slot + c] : 0.f;
+// rows [first_row, first_row + n_rows) of `n_tables` tables of a family, from table `first` of the profile on, to [table][n_rows][slot] at dst_off: whole 16-byte groups
+RSQ_HD void lds_stage_family_rows(const DevSim &S, RSQ_LDS float *img, uint32_t off32, uint32_t table_rows, uint32_t first, uint32_t n_tables, uint32_t first_row, uint32_t n_rows,
+                                  uint32_t slot, uint32_t dst_off, uint32_t tid, uint32_t nthreads) {
+    const uint32_t per_table = n_rows * (slot / 4u);
+    for (uint32_t i = tid; i < n_tables * per_table; i += nthreads) {
+        const uint32_t table = i / per_table, g = i - table * per_table;
+        reinterpret_cast<RSQ_LDS Quad *>(img + dst_off)[i] = reinterpret_cast<const Quad *>(S.pool32 + off32 + ((size_t)(first + table) * table_rows + first_row) * slot)[g];
     }
 }
-RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t tid, uint32_t nthreads) {
-    const uint32_t T = S.lds.img_tiles;
-    const RSQ_LDS DevTable *d = reinterpret_cast<const RSQ_LDS DevTable *>(img);
-    for (uint32_t t = 0; t < 4u * T; ++t) {                                     // quality: margins 0 and 1, contiguous in the copy
-        const DevTable tb = d[t];
-        if (!tb.k || tb.lds_off == kNoLds) continue;
-        const uint32_t n = (tb.rows[0] + tb.rows[1]) * S.lds.slot_q;
-        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
-    }
-    for (uint32_t t = 0; t < 20u * T; ++t) {                                    // base call: margin 0, margin 2
-        const DevTable tb = d[4u * T + t];
-        if (!tb.k || tb.lds_off == kNoLds) continue;
-        const uint32_t n = tb.rows[0] * S.lds.slot_b;
-        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
-        if (tb.lds_extra == kNoLds) continue;
-        const uint32_t n2 = tb.rows[2] * S.lds.slot_b, from = (tb.rows[0] + tb.rows[1]) * S.lds.slot_b;
-        for (uint32_t i = tid; i < n2; i += nthreads) img[tb.lds_extra + i] = S.pool32[tb.off32 + from + i];
-    }
-    for (uint32_t t = 0; t < 12u; ++t) {                                        // indel: margin 0
-        const DevTable tb = d[24u * T + t];
-        if (!tb.k || tb.lds_off == kNoLds) continue;
-        const uint32_t n = tb.rows[0] * S.lds.slot_i;
-        for (uint32_t i = tid; i < n; i += nthreads) img[tb.lds_off + i] = S.pool32[tb.off32 + i];
-    }
-    lds_stage_rate_rows(S, img, 0u, 4u * T, S.lds.rate_rows_q, S.lds.slot_q, S.lds.q3_off, tid, nthreads);
-    lds_stage_rate_rows(S, img, 4u * T, 20u * T, S.lds.rate_rows_b, S.lds.slot_b, S.lds.b3_off, tid, nthreads);
+RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t qbase, uint32_t tid, uint32_t nthreads) {
+    const uint32_t T = RSQ_PLAN(S, img_tiles), sq = RSQ_PLAN(S, slot_q), sb = RSQ_PLAN(S, slot_b), si = RSQ_PLAN(S, slot_i);
+    // quality: margins 0 and 1; base call: margin 0, margin 2; indel: margin 0; then the first rows of the two error-rate margins
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, 0u, RSQ_PLAN(S, q.lds_rows), sq, RSQ_PLAN(S, q.lds), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, 0u, RSQ_PLAN(S, b.lds_rows), sb, RSQ_PLAN(S, b.lds), tid, nthreads);
+    if (RSQ_PLAN(S, b.lds2) != kNoLds)
+        lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[2]), RSQ_PLAN(S, b.last[2]) + 1u, sb, RSQ_PLAN(S, b.lds2), tid,
+                              nthreads);
+    if (RSQ_PLAN(S, i.lds) != kNoLds)
+        lds_stage_family_rows(S, img, RSQ_PLAN(S, i.off32), RSQ_PLAN(S, i.table_rows), 0u, 12u, 0u, RSQ_PLAN(S, i.lds_rows), si, RSQ_PLAN(S, i.lds), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, RSQ_PLAN(S, q.before[3]), RSQ_PLAN(S, rate_rows_q), sq, RSQ_PLAN(S, q3_off), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[3]), RSQ_PLAN(S, rate_rows_b), sb, RSQ_PLAN(S, b3_off), tid, nthreads);
 }
 // The ring: the quality rows (margin 2) over read position p of the segment's tables, copied by the wave itself at the beginning of
 // step p into slot p % kRingSlots of its ring: one load of 16 bytes per lane instead of one per lane and quad of the row.  Item i is
 // one 16-byte group of one table's row.
-RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * S.lds.img_tiles * S.lds.quads_q; }
-// What does not change from step to step is worked out once per chunk of reads (RingItem): where the table's rows over the read position begin, the first
-// position and the last row of that margin, the item's place in a ring slot.
+RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * RSQ_PLAN(S, img_tiles) * RSQ_PLAN(S, quads_q); }
+// What does not change from step to step is worked out once per chunk of reads (RingItem): where the table's rows over the read position begin and the
+// item's place in a ring slot (first position and last row of the margin are the family's).
 struct RingItem {
-    const float *rows;                 // row 0 of margin 2, at the item's group of four columns; nullptr: an empty table (zeros)
-    uint32_t from, last;               // DevTable::from[2], rows[2] - 1
+    const float *rows;                 // row 0 of margin 2, at the item's group of four columns
     uint32_t at;                       // floats from the slot's start
 };
-RSQ_HD RingItem lds_ring_item(const DevSim &S, const RSQ_LDS float *img, uint32_t item) {
-    const uint32_t table = item / S.lds.quads_q, c = item % S.lds.quads_q, slot = S.lds.slot_q;
-    const DevTable d = reinterpret_cast<const RSQ_LDS DevTable *>(img)[table];
-    return RingItem{d.k ? S.pool32 + d.off32 + (d.rows[0] + d.rows[1]) * slot + 4u * c : nullptr, d.from[2], d.rows[2] - 1u, table * slot + 4u * c};
+RSQ_HD RingItem lds_ring_item(const DevSim &S, uint32_t qbase, uint32_t item) {
+    const uint32_t table = item / RSQ_PLAN(S, quads_q), c = item % RSQ_PLAN(S, quads_q), slot = RSQ_PLAN(S, slot_q);
+    return RingItem{S.pool32 + RSQ_PLAN(S, q.off32) + ((size_t)(qbase + table) * RSQ_PLAN(S, q.table_rows) + RSQ_PLAN(S, q.before[2])) * slot + 4u * c, table * slot + 4u * c};
 }
-RSQ_HD Quad lds_ring_load(const DevSim &S, const RingItem &it, uint32_t p) {
-    Quad q = zero_quad();
-    if (it.rows) {
-        const int32_t d = (int32_t)p - (int32_t)it.from, row = d < 0 ? 0 : (d > (int32_t)it.last ? (int32_t)it.last : d);      // clamp_row
-        q = *reinterpret_cast<const Quad *>(it.rows + (uint32_t)row * S.lds.slot_q);
-    }
-    return q;
-}
+RSQ_HD Quad lds_ring_load(const DevSim &S, const RingItem &it, uint32_t p) { return *reinterpret_cast<const Quad *>(it.rows + RSQ_GEO_ROW(S, q, 2, p) * RSQ_PLAN(S, slot_q)); }
 RSQ_HD void lds_ring_store(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p, const Quad &q) {
-    *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * S.lds.ring_stride + it.at) = q;
+    *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * RSQ_PLAN(S, ring_stride) + it.at) = q;
 }
 RSQ_HD void lds_ring_stage(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) { lds_ring_store(S, it, ring, p, lds_ring_load(S, it, p)); }
-RSQ_HD void lds_ring_stage(const DevSim &S, const RSQ_LDS float *img, RSQ_LDS float *ring, uint32_t p, uint32_t item) { lds_ring_stage(S, lds_ring_item(S, img, item), ring, p); }
+RSQ_HD void lds_ring_stage(const DevSim &S, uint32_t qbase, RSQ_LDS float *ring, uint32_t p, uint32_t item) { lds_ring_stage(S, lds_ring_item(S, qbase, item), ring, p); }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
 RSQ_HD FragmentSrc fragment_src(const DevSim &S, const Fragment &f, uint32_t seg, uint32_t end) {
     const uint32_t L = S.seq_len[f.seq];
-    const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion;           // Simulator.cpp:1918-1921
+    const uint32_t want = S.read_lengths[seg].to + RSQ_SIM(S, max_len_deletion);           // Simulator.cpp:1918-1921
     FragmentSrc src;
     src.words = hap_words(S, f.allele);                                        // with variants: the allele's copy (substitutions applied)
     src.word_off = S.seq_word_off[f.seq];
@@ -1994,7 +1976,7 @@ RSQ_HD void convert_template(const DevSim &S, const Fragment &f, uint32_t seg, u
 
 // the template of mate `seg` with variants of any kind: the forward mate from the start variant, the reverse mate from the end variant
 RSQ_HD void variant_template(const DevSim &S, const Fragment &f, const FragmentVar &fv, uint32_t seg, uint64_t *tmpl, uint32_t template_words) {
-    const uint32_t want = S.read_lengths[seg].to + S.max_len_deletion, tl = f.len < want ? f.len : want;
+    const uint32_t want = S.read_lengths[seg].to + RSQ_SIM(S, max_len_deletion), tl = f.len < want ? f.len : want;
     const VarView r = var_view(S, f.seq);
     const bool reversed = seg != f.strand;
     const VarStart from = reversed ? VarStart{fv.end_var, fv.end_var_pos} : VarStart{fv.start_var, fv.start_var_pos};
@@ -2124,7 +2106,7 @@ RSQ_HD PairStream pair_stream(const Fragment *f, uint32_t sub, uint64_t adapter_
     return PairStream{(uint32_t)adapter_only_number, 0xFFFFFFFFu, (uint32_t)(adapter_only_number >> 32), 0u};
 }
 
-#if defined(__HIPCC__)
+#if RSQ_DEVICE_BUILD
 // bin keys of the items + their histogram.  Pairs: key = tile (TileId() once per pair, Simulator.cpp:701-704); records: key = segment * n_tiles + tile.
 __device__ inline void bin_count_key(uint32_t key, bool valid, uint32_t n_keys, uint32_t *hist, uint32_t *s_hist) {
     if (n_keys <= kBinKeysLds) {
@@ -2246,7 +2228,7 @@ __device__ RSQ_LDS float *fill_stage_image(const DevSim &S, float *lds_image, ui
     if (MASK) {
         lds_stage_descriptors(S, img, qbase, threadIdx.x, blockDim.x);
         __syncthreads();
-        lds_stage_rows(S, img, threadIdx.x, blockDim.x);
+        lds_stage_rows(S, img, qbase, threadIdx.x, blockDim.x);
         __syncthreads();
     }
     return img;
@@ -2265,11 +2247,11 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         }
     } else {
         const uint32_t lane = threadIdx.x & 63u, n_items = lds_ring_items(S);
-        RSQ_LDS float *ring = img + S.lds.ring_off + (threadIdx.x >> 6) * kRingSlots * S.lds.ring_stride;
+        RSQ_LDS float *ring = img + RSQ_PLAN(S, ring_off) + (threadIdx.x >> 6) * kRingSlots * RSQ_PLAN(S, ring_stride);
         ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
         bool running = active;
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
-        const RingItem mine = lane < n_items ? lds_ring_item(S, img, lane) : RingItem{nullptr, 0u, 0u, 0u};      // the lane's first item (with one tile per image: its only one)
+        const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
         Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
         for (uint32_t t = 0; __any(running); ++t) {
@@ -2277,7 +2259,7 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
                 lds_ring_store(S, mine, ring, t, ahead);
                 ahead = lds_ring_load(S, mine, t + 1u);
             }
-            for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, img, ring, t, item);
+            for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, qbase, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
             if (running) running = m.step(S, tab, st, src, out);
@@ -2296,7 +2278,7 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
 template <uint32_t MASK, class Chunk>
 __device__ void fill_binned_loop(const DevSim &S, float *lds_image, const FillBins &bins, Chunk &&chunk) {
     RSQ_LDS float *img = (RSQ_LDS float *)lds_image;
-    RSQ_LDS uint32_t *sched = reinterpret_cast<RSQ_LDS uint32_t *>(img + (MASK ? S.lds.total_words : 0u));
+    RSQ_LDS uint32_t *sched = reinterpret_cast<RSQ_LDS uint32_t *>(img + (MASK ? RSQ_PLAN(S, total_words) : 0u));
     const uint32_t lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) sched[1] = 0xFFFFFFFFu;
     for (bool first_choice = true;; first_choice = false) {
@@ -2336,7 +2318,7 @@ __device__ void fill_binned_loop(const DevSim &S, float *lds_image, const FillBi
         // from the segment and the image becomes per-lane arithmetic)
         const uint32_t bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[0]);
         if (bin == 0xFFFFFFFFu) break;
-        const uint32_t seg = bin / S.n_tiles, tile = bin - seg * S.n_tiles, qbase = image_qbase(S, seg, tile);
+        const uint32_t seg = bin / RSQ_SIM(S, n_tiles), tile = bin - seg * RSQ_SIM(S, n_tiles), qbase = image_qbase(S, seg, tile);
         if (bin != (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[1])) {      // all read before anyone writes (barriers inside the staging)
             fill_stage_image<MASK>(S, lds_image, qbase);
             if (threadIdx.x == 0) sched[1] = bin;
@@ -2391,9 +2373,9 @@ __device__ void fill_pair_chunk(const DevSim &S, const NameTable &names, RSQ_LDS
     }
 }
 
-template <uint32_t MASK, bool VAR = false, bool BINNED = false>
-__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
-                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {
+template <uint32_t MASK, bool VAR, bool BINNED>
+__device__ __forceinline__ void fill_reads_body(const DevSim &S, const NameTable &names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, const RawLayout &raw,
+                                                uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, const FillBins &bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     if constexpr (BINNED) {
         fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t place, bool active) {
@@ -2413,6 +2395,12 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable n
             fill_pair_chunk<MASK, VAR, false>(S, names, img, qbase, seg, 0u, first + lane, first + lane < n_pairs, frags, n_pairs, adapter_only_first, raw, sizes, fvars, nullptr);
         }
     }
+}
+// the library's own instantiations (every shape of profile); a kernel compiled for one profile wraps the same body (rsq_spec.h)
+template <uint32_t MASK, bool VAR = false, bool BINNED = false>
+__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
+                                                          RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {
+    fill_reads_body<MASK, VAR, BINNED>(S, names, frags, n_pairs, adapter_only_first, raw, sizes, chunk_counters, fvars, bins);
 }
 
 // seqToIllumina (ApplyErrorsAndQualityToFastaInput, Simulator.cpp:2403-2512) through the same workgroups: the records were
@@ -2439,8 +2427,8 @@ __device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS
     fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
     if (active) raw.meta[row] = meta;
 }
-template <uint32_t MASK, bool BINNED = false>
-__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
+template <uint32_t MASK, bool BINNED>
+__device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJob &job, const RawLayout &raw, uint32_t *chunk_counters, const FillBins &bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     if constexpr (BINNED) {
         fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t place, bool active) {
@@ -2464,6 +2452,10 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob
             fill_record_chunk<MASK, false>(S, job, img, qbase, seg, 0u, i, i, active, raw);
         }
     }
+}
+template <uint32_t MASK, bool BINNED = false>
+__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
+    fill_records_body<MASK, BINNED>(S, job, raw, chunk_counters, bins);
 }
 // the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known
 __global__ void k_record_flags(const uint8_t *segs, uint64_t n, uint32_t *flags) {
@@ -2502,7 +2494,7 @@ __global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragm
 
 #endif  // __HIPCC__
 
-#if defined(__HIPCC__)
+#if RSQ_DEVICE_BUILD
 // FASTQ text: one wave per 16 consecutive records of one file (grid.y = template segment = output file).  The records
 // occupy one contiguous byte range of the output, so the wave formats them into an LDS image of that range (laid out with
 // the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Four lanes

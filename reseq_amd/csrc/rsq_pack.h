@@ -113,7 +113,6 @@ inline void pack_tables(SimState &s, Uploader &up) {
             const HostTable &t = tabs[i];
             DevTable d{};
             d.k = (uint32_t)t.par0.size();
-            d.lds_off = d.lds_extra = kNoLds;
             for (uint32_t v : t.par0) d.max_value = std::max(d.max_value, v);          // par0_off: assigned below, in the order the LDS images copy the values
             const uint32_t kp = row_stride(d.k);                       // even stride: zero pad column when K is odd
             for (uint32_t n = 0; n < t.nm; ++n) {
@@ -247,6 +246,55 @@ inline void pack_tables(SimState &s, Uploader &up) {
                 d.sure_range = c.lo16 | (c.hi16 << 16);
             }
     };
+    // The read kernel's three families over their common ranges (FamilyGeo, rsq_types.h): table i of the family at [i][table_rows][slot], row r of margin n = the
+    // table's own row of value from[n] + r (its edge rows outside its own range: AdjustIndeces); empty tables and tables outside the screen's preconditions are zeros.
+    // Then the outcome value of every column, [i][slot] bytes behind the pool of outcome values.
+    auto family = [&](std::vector<DevTable> &tabs, uint32_t nm, uint32_t slot) {
+        FamilyGeo g{};
+        uint32_t to[4] = {0, 0, 0, 0};
+        bool any = false;
+        for (const DevTable &d : tabs) {
+            if (!d.k) continue;
+            for (uint32_t n = 0; n < nm; ++n) {
+                g.from[n] = any ? std::min(g.from[n], d.from[n]) : d.from[n];
+                to[n] = any ? std::max(to[n], d.from[n] + d.rows[n]) : d.from[n] + d.rows[n];
+            }
+            any = true;
+        }
+        for (uint32_t n = 0; n < 4; ++n) {
+            const uint32_t rows = n < nm ? std::max(1u, to[n] - g.from[n]) : 0u;
+            g.before[n] = g.table_rows;
+            g.last[n] = rows ? rows - 1u : 0u;
+            g.table_rows += rows;
+        }
+        g.off32 = (uint32_t)pool32.size();
+        g.lds = g.lds2 = kNoLds;
+        if (pool32.size() + (uint64_t)tabs.size() * g.table_rows * slot > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
+        for (DevTable &d : tabs) {
+            d.off32 = 0;
+            d.f32_ok = 1;
+            const uint32_t kp = row_stride(d.k);
+            for (uint32_t n = 0; n < nm && d.k; ++n)
+                for (uint32_t r = 0; r < d.rows[n]; ++r)
+                    for (uint32_t c = 0; c < d.k; ++c) {
+                        const double v = pool[d.off[n] + (size_t)r * kp + c];
+                        if (!(v == 0.0 || (v >= 0x1p-60 && v <= 0x1p29))) d.f32_ok = 0;              // also NaN, negative
+                    }
+            const bool zeros = !d.k || !d.f32_ok;
+            for (uint32_t n = 0; n < nm; ++n)
+                for (uint32_t r = 0; r <= g.last[n]; ++r) {
+                    const int64_t own = (int64_t)g.from[n] + r - (int64_t)d.from[n];
+                    const double *row = zeros ? nullptr : pool.data() + d.off[n] + (size_t)std::min<int64_t>(std::max<int64_t>(own, 0), (int64_t)d.rows[n] - 1) * kp;
+                    for (uint32_t c = 0; c < slot; ++c) pool32.push_back(row && c < d.k ? (float)row[c] : 0.f);
+                }
+        }
+        return g;
+    };
+    auto family_values = [&](FamilyGeo &g, const std::vector<DevTable> &tabs, uint32_t slot) {
+        g.values_src = (uint32_t)par0.size();
+        for (const DevTable &d : tabs)
+            for (uint32_t c = 0; c < slot; ++c) par0.push_back(c < d.k ? par0[d.par0_off + c] : (uint8_t)0);
+    };
     const Options &opt = options();
     const uint32_t min_quads = opt.min_quality_quads > 0 ? (uint32_t)opt.min_quality_quads : 0u;     // measurements: a wider instantiation than the profile needs
     for (uint32_t q : kQualityQuads)
@@ -255,9 +303,9 @@ inline void pack_tables(SimState &s, Uploader &up) {
     plan.slot_q = row_slot32(plan.quads_q);
     plan.slot_b = plan.slot_i = kSlotSmall;
     if (screenable) {
-        copy32(quality, plan.slot_q);
-        copy32(base_call, plan.slot_b);
-        copy32(indels, plan.slot_i);
+        plan.q = family(quality, 4, plan.slot_q);
+        plan.b = family(base_call, 4, plan.slot_b);
+        plan.i = family(indels, 3, plan.slot_i);
         if (!opt.no_indel_skip)
             for (DevTable &d : indels) certain_no_indel(d);
     }
@@ -312,6 +360,12 @@ inline void pack_tables(SimState &s, Uploader &up) {
             }
     }
     s.dev.chain_sure = up.put(chain_sure);
+    if (screenable) {
+        pad_par0();
+        family_values(plan.q, quality, plan.slot_q);
+        family_values(plan.b, base_call, plan.slot_b);
+        family_values(plan.i, indels, plan.slot_i);
+    }
 
     // LDS plan of the read kernels (rsq_kernels.h "LDS staging"): one image per template segment with the tables of ALL tiles when they fit the 160 KiB,
     // else one image per (segment, tile) -- the read kernel then serves one tile per workgroup (k_fill_reads<MASK, VAR, true>: reads binned by tile).  The
@@ -319,13 +373,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
     // required; more error-rate rows, base-call margin 2 and indel margin 0 take what is left.
     uint32_t rate_rows_q = ~0u, rate_rows_b = ~0u;
     if (opt.rate_rows > 0) rate_rows_q = rate_rows_b = (uint32_t)std::min<int64_t>(opt.rate_rows, 1 << 20);       // at most so many error-rate rows
-    uint32_t max_rate_q = 1, max_rate_b = 1;
-    for (const DevTable &d : quality)
-        if (d.k) max_rate_q = std::max(max_rate_q, d.rows[3]);
-    for (const DevTable &d : base_call)
-        if (d.k) max_rate_b = std::max(max_rate_b, d.rows[3]);
-    rate_rows_q = std::min(rate_rows_q, max_rate_q);
-    rate_rows_b = std::min(rate_rows_b, max_rate_b);
+    rate_rows_q = std::min(rate_rows_q, plan.q.last[3] + 1u);         // rows of the common range (FamilyGeo)
+    rate_rows_b = std::min(rate_rows_b, plan.b.last[3] + 1u);
     const uint64_t budget = kLdsBudgetBytes / 4u - kSchedWords;
     // tries an image of Ti tiles; fills `plan` and the tables' offsets when the required parts fit
     auto plan_image = [&](uint32_t Ti) {
@@ -333,23 +382,12 @@ inline void pack_tables(SimState &s, Uploader &up) {
         uint32_t par0_bytes = 0;
         for (uint32_t g = 0; g < n_img; ++g) par0_bytes = std::max(par0_bytes, par0_indel_bytes + par0_tile_first[(g + 1) * Ti] - par0_tile_first[g * Ti]);
         const uint32_t par0_words = (par0_bytes + 15u) / 16u * 4u;                                 // whole 16 bytes: rows stay aligned
-        const uint32_t desc_words = lds_desc_count(Ti) * kDescWords + par0_words;
-        uint64_t need = desc_words, need_b2 = 0, need_i0 = 0;                                       // the largest image decides
-        for (uint32_t g = 0; g < n_img; ++g) {
-            uint64_t q = 0, b = 0, b2 = 0;
-            for (uint32_t i = 0; i < 4 * Ti; ++i) {
-                const DevTable &d = quality[g * 4 * Ti + i];
-                if (d.k) q += (uint64_t)(d.rows[0] + d.rows[1]) * plan.slot_q;
-            }
-            for (uint32_t i = 0; i < 20 * Ti; ++i) {
-                const DevTable &d = base_call[g * 20 * Ti + i];
-                if (d.k) b += (uint64_t)d.rows[0] * plan.slot_b, b2 += (uint64_t)d.rows[2] * plan.slot_b;
-            }
-            need = std::max(need, desc_words + q + b);
-            need_b2 = std::max(need_b2, b2);
-        }
-        for (const DevTable &d : indels)
-            if (d.k) need_i0 += (uint64_t)d.rows[0] * plan.slot_i;
+        const uint32_t desc_words = (lds_desc_count(Ti) * kDescWords + 3u) / 4u * 4u + par0_words;
+        const uint32_t values_words = (4 * Ti * plan.slot_q + 20 * Ti * plan.slot_b + 12 * plan.slot_i + 15u) / 16u * 4u;      // a byte per column
+        const uint32_t rows_q = plan.q.last[0] + 1 + plan.q.last[1] + 1, rows_b = plan.b.last[0] + 1, rows_b2 = plan.b.last[2] + 1, rows_i = plan.i.last[0] + 1;
+        const uint64_t need_q = (uint64_t)4 * Ti * rows_q * plan.slot_q, need_b = (uint64_t)20 * Ti * rows_b * plan.slot_b, need_b2 = (uint64_t)20 * Ti * rows_b2 * plan.slot_b,
+                       need_i0 = (uint64_t)12 * rows_i * plan.slot_i;
+        uint64_t need = (uint64_t)desc_words + values_words + need_q + need_b;
         auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * Ti * rows_q * plan.slot_q + (uint64_t)20 * Ti * rows_b * plan.slot_b; };
         const uint32_t ring_stride = 4 * Ti * plan.slot_q;
         need += (uint64_t)(kFillBlock / 64) * kRingSlots * ring_stride;                              // the waves' rings
@@ -374,34 +412,18 @@ inline void pack_tables(SimState &s, Uploader &up) {
         plan.ring_stride = ring_stride;
         plan.rate_rows_q = rq;
         plan.rate_rows_b = rb;
-        uint32_t end = desc_words;
-        for (uint32_t g = 0; g < n_img; ++g) {
-            uint32_t at = desc_words;
-            for (uint32_t i = 0; i < 4 * Ti; ++i) {
-                DevTable &d = quality[g * 4 * Ti + i];
-                if (!d.k) continue;
-                d.lds_off = at;
-                at += (d.rows[0] + d.rows[1]) * plan.slot_q;
-            }
-            for (uint32_t i = 0; i < 20 * Ti; ++i) {
-                DevTable &d = base_call[g * 20 * Ti + i];
-                if (!d.k) continue;
-                d.lds_off = at;
-                at += d.rows[0] * plan.slot_b;
-                if (stage_b2) {
-                    d.lds_extra = at;
-                    at += d.rows[2] * plan.slot_b;
-                }
-            }
-            end = std::max(end, at);
-        }
-        if (stage_i0)
-            for (DevTable &d : indels) {
-                if (!d.k) continue;
-                d.lds_off = end;
-                end += d.rows[0] * plan.slot_i;
-            }
-        plan.ring_off = end;
+        plan.q.values = desc_words * 4u;
+        plan.b.values = plan.q.values + 4 * Ti * plan.slot_q;
+        plan.i.values = plan.b.values + 20 * Ti * plan.slot_b;
+        uint32_t at = desc_words + values_words;
+        plan.q.lds = at, plan.q.lds_rows = rows_q, at += (uint32_t)need_q;
+        plan.b.lds = at, plan.b.lds_rows = rows_b, at += (uint32_t)need_b;
+        plan.b.lds2 = stage_b2 ? at : kNoLds;
+        if (stage_b2) at += (uint32_t)need_b2;
+        plan.i.lds = stage_i0 ? at : kNoLds;
+        plan.i.lds_rows = rows_i;
+        if (stage_i0) at += (uint32_t)need_i0;
+        plan.ring_off = at;
         plan.q3_off = plan.ring_off + (kFillBlock / 64) * kRingSlots * plan.ring_stride;
         plan.b3_off = plan.q3_off + 4 * Ti * plan.rate_rows_q * plan.slot_q;
         plan.total_words = plan.b3_off + 20 * Ti * plan.rate_rows_b * plan.slot_b;
@@ -417,11 +439,13 @@ inline void pack_tables(SimState &s, Uploader &up) {
     } else if (!screenable && opt.fill_mode != 0)
         s.plan_note = "the profile's tables are outside what the screened single-precision draws are built for (more than " + std::to_string(4u * kQualityQuads[4]) +
                       " quality values, or more than 8 base-call / indel outcomes): every per-base draw runs in double precision from device memory (several times slower)";
-    if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.ring_off | plan.ring_stride | plan.slot_q | plan.slot_b | plan.slot_i) & 3u) throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
+    if ((plan.desc_words | plan.q3_off | plan.b3_off | plan.ring_off | plan.ring_stride | plan.slot_q | plan.slot_b | plan.slot_i | plan.q.off32 | plan.b.off32 | plan.i.off32 |
+         (plan.mask ? plan.q.lds | plan.b.lds | (plan.b.lds2 != kNoLds ? plan.b.lds2 : 0u) | (plan.i.lds != kNoLds ? plan.i.lds : 0u) : 0u)) & 3u)
+        throw Error("internal: LDS rows must start on 16-byte boundaries");      // a misaligned ds_read_b128 is 2.4x slower
     if (opt.trace_plan)
         fprintf(stderr, "[rsq] LDS image: mask %u, %u of %u tiles per image, %u words (%u KiB), desc %u, quality slot %u, rate rows %u / %u, q3 %u b3 %u, ring %u x %u, b2 %d i0 %d\n", plan.mask,
                 plan.img_tiles, T, plan.total_words, plan.total_words / 256, plan.desc_words, plan.slot_q, plan.rate_rows_q, plan.rate_rows_b, plan.q3_off, plan.b3_off, plan.ring_off,
-                plan.ring_stride, (int)(!base_call.empty() && base_call[0].lds_extra != kNoLds), (int)(!indels.empty() && indels[0].lds_off != kNoLds));
+                plan.ring_stride, (int)(plan.b.lds2 != kNoLds), (int)(plan.i.lds != kNoLds));
     s.dev.lds = plan;
     s.dev.quality = up.put(quality);
     s.dev.seq_quality = up.put(seq_quality);

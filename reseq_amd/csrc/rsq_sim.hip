@@ -18,6 +18,7 @@
 
 #include "../../include/reseq_amd.h"
 #include "rsq_pack.h"
+#include "rsq_spec.h"
 
 namespace rsq {
 
@@ -176,6 +177,10 @@ struct rsq_sim : SimState {
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
     int force_fill_mode = -1;      // RSQ_FILL_MODE=0: every draw in double precision from HBM (tests run both paths)
+    // read kernels compiled for this simulator's profile (rsq_spec.h); `specialize`: option specialize when the simulator was created
+    SpecKernels spec;
+    std::string arch;              // hipDeviceProp_t::gcnArchName
+    bool specialize = true;
     // the sharded pre-pass (rsq_sim_prepare_plan ... rsq_sim_prepare_finish): what lives between its calls
     BiasPlan bias_plan;
     bool planned = false;
@@ -188,6 +193,19 @@ struct rsq_sim : SimState {
         bool valid = false;
     } chain_run;
 };
+
+static bool fill_is_binned(const rsq_sim &s) { return effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) != 0 && s.dev.lds.binned; }
+// The read kernel compiled for this simulator's profile (rsq_spec.h), or nullptr: the library's own instantiation runs.  Compiles at the first request of a variant;
+// what happened is kept for rsq_sim_specialize / rsq_last_warning.
+static thread_local std::string g_spec_note;
+static hipFunction_t spec_kernel(rsq_sim &s, SpecKind kind, uint32_t mask, bool var, bool binned) {
+    if (!s.specialize || mask == 0) return nullptr;                    // mask 0: no image, no plan to compile in
+    std::string note;
+    hipFunction_t fn = s.spec.get(s.dev, SpecVariant{kind, mask, var, binned}, s.arch, note);
+    if (options().trace_plan && note != g_spec_note) fprintf(stderr, "[rsq] %s\n", note.c_str());
+    g_spec_note = note;
+    return fn;
+}
 
 namespace rsq {
 
@@ -351,6 +369,9 @@ static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double c
     s.prepared = true;
     s.prepared_lo = 1;
     s.prepared_hi = s.total_blocks + 1;
+    // the read kernel for this profile (rsq_spec.h), so that no compilation falls into the first rsq_sim_pairs
+    if (s.has_ref) (void)spec_kernel(s, SpecKind::kReads, effective_fill_mask(s.dev.lds.mask, s.force_fill_mode), s.has_variants, fill_is_binned(s));
+    lap("read kernel for the profile", t0);
 }
 
 // Simulator::CreateSystematicErrorProfile (Simulator.cpp:2597-2653): both strands of every sequence, reverse first, as FASTQ.
@@ -405,7 +426,6 @@ static RawLayout raw_layout(rsq_sim &s, uint64_t n_reads) {
 
 // Reads binned by tile (the LDS plan holds one tile per image): keys, histogram, the bins' places and units, the scatter.  n_keys = n_tiles (pairs:
 // both mates of a pair have the pair's tile) or 2 n_tiles (records); bins = (segment, tile).
-static bool fill_is_binned(const rsq_sim &s) { return effective_fill_mask(s.dev.lds.mask, s.force_fill_mode) != 0 && s.dev.lds.binned; }
 template <class CountKernel>
 static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, hipStream_t st, CountKernel &&count_keys, const Fragment *frags = nullptr,
                                 const FragmentVar *fvars = nullptr) {
@@ -458,9 +478,16 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
     const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2);
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
+    hipFunction_t spec = spec_kernel(s, SpecKind::kReads, MASK, VAR, BINNED);
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
-                       s.cur->fill_counters.as<uint32_t>(), fvars, bins);
+    if (spec) {
+        uint32_t *sizes = s.cur->sizes.as<uint32_t>(), *counters = s.cur->fill_counters.as<uint32_t>();
+        RawLayout raw_arg = raw;
+        void *args[] = {&s.dev, &s.names, &frags, &n_pairs, &adapter_first, &raw_arg, &sizes, &counters, &fvars, &bins};
+        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
+    } else
+        hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
+                           s.cur->fill_counters.as<uint32_t>(), fvars, bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;
@@ -482,8 +509,16 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
     const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1);
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
+    hipFunction_t spec = spec_kernel(s, SpecKind::kRecords, MASK, false, BINNED);
     s.timers["fill_reads"].start(st);
-    hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
+    if (spec) {
+        uint32_t *counters = s.cur->fill_counters.as<uint32_t>();
+        RecordJob job_arg = job;
+        RawLayout raw_arg = raw;
+        void *args[] = {&s.dev, &job_arg, &raw_arg, &counters, &bins};
+        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
+    } else
+        hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;
@@ -1175,6 +1210,8 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
+        s->arch = prop.gcnArchName;
+        s->specialize = options().specialize != 0;
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 16 * sizeof(uint64_t), hipHostMallocDefault));
         for (hipStream_t &st : s->side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (rsq_sim::Workspace &w : s->ws) HIP_CHECK(hipEventCreateWithFlags(&w.text_done, hipEventDisableTiming));
@@ -1308,10 +1345,69 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
         s->prepared_hi = s->chain_run.block_hi;
         if (s->has_variants) variant_sys_errors_from_run(*s, nullptr);      // -V: the variants' bases inside the rank's strand windows, from the finished chains
         s->prepared = true;
+        (void)spec_kernel(*s, SpecKind::kReads, effective_fill_mask(s->dev.lds.mask, s->force_fill_mode), s->has_variants, fill_is_binned(*s));
         return RSQ_OK;
     });
 }
 
+int rsq_sim_specialize(rsq_sim *s, int kind, int *specialized) {
+    REQUIRE(s && specialized && (kind == 0 || kind == 1), "null argument, or a kind that is neither 0 (read pairs) nor 1 (seqToIllumina records)");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        const uint32_t mask = effective_fill_mask(s->dev.lds.mask, s->force_fill_mode);
+        g_spec_note.clear();
+        hipFunction_t fn = spec_kernel(*s, kind == 0 ? SpecKind::kReads : SpecKind::kRecords, mask, kind == 0 && s->has_variants, fill_is_binned(*s));
+        *specialized = fn != nullptr;
+        if (!s->specialize) g_spec_note = "option specialize is 0: the library's own instantiation of the read kernel runs";
+        else if (!mask) g_spec_note = "the read kernel draws in double precision from device memory (no table image): nothing to compile for the profile";
+        g_last_warning = g_spec_note;
+        return RSQ_OK;
+    });
+}
+// host only: the plan of the profile packed into host memory (nothing is uploaded), then the compilation rsq_sim_specialize would do
+int rsq_profile_compile_read_kernel(const rsq_profile *p, int kind, int with_variants, int binned, const char *arch, const char *out_path, size_t *code_bytes, double *seconds) {
+    REQUIRE(p && arch && code_bytes && (kind == 0 || kind == 1), "null argument, or a kind that is neither 0 nor 1");
+    struct HostArrays : Uploader {
+        std::vector<std::unique_ptr<char[]>> owned;
+        void *put_bytes(const void *data, size_t bytes) override {
+            owned.emplace_back(new char[bytes + 8]);
+            memcpy(owned.back().get(), data, bytes);
+            return owned.back().get();
+        }
+        void *put_zeros(size_t bytes) override {
+            owned.emplace_back(new char[bytes + 8]());
+            return owned.back().get();
+        }
+        void write_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
+        void read_bytes(void *dst, const void *src, size_t bytes) override { memcpy(dst, src, bytes); }
+    };
+    int rc = guard([&] {
+        HostArrays up;
+        SimState s;
+        s.prof = p->p;
+        pack_tables(s, up);
+        pack_profile(s, up);
+        if (!s.dev.lds.mask) throw Error("the profile has no table image (" + s.plan_note + "): there is nothing to compile for it");
+        SpecCode c;
+        std::string note;
+        if (!spec_compile(s.dev, SpecVariant{kind == 0 ? SpecKind::kReads : SpecKind::kRecords, s.dev.lds.mask, kind == 0 && with_variants != 0, binned != 0 || s.dev.lds.binned != 0}, arch, c, note))
+            throw Error(note);
+        *code_bytes = c.code.size();
+        if (seconds) *seconds = c.seconds;
+        if (out_path && *out_path) {
+            FILE *f = fopen(out_path, "wb");
+            if (!f || fwrite(c.code.data(), 1, c.code.size(), f) != c.code.size()) throw Error(std::string("cannot write ") + out_path);
+            fclose(f);
+        }
+        return RSQ_OK;
+    });
+    return rc;
+}
+int rsq_set_kernel_cache_dir(const char *path) {
+    spec_cache_dir_override() = path ? path : "";
+    spec_cache_dir_set() = true;
+    return RSQ_OK;
+}
 int rsq_sim_get_fill_plan(const rsq_sim *s, uint32_t *quality_quads, uint32_t *image_tiles, uint32_t *image_bytes) {
     REQUIRE(s && quality_quads && image_tiles && image_bytes, "null argument");
     *quality_quads = effective_fill_mask(s->dev.lds.mask, s->force_fill_mode);

@@ -5,12 +5,26 @@
 // (schmeing/ReSeq): tables are LogArrayResult<N> (ProbabilityEstimates.h:351-557), "sys errors" are
 // SimBlock::sys_errors_ (Simulator.h:115), thresholds are non_zero_thresholds_ (Simulator.h:298).
 #pragma once
+// compiled by hipcc (the library) or at run time by hiprtc (a read kernel for one profile, rsq_spec.h; its built-in header has the fixed-width types and the
+// device's math), or by a host compiler (the test-only host emulation)
+#if defined(__HIPCC_RTC__)
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint16_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+using __hip_internal::uint8_t;
+typedef unsigned long uintptr_t;
+#define RSQ_DEVICE_BUILD 1
+#define RSQ_HD __host__ __device__ __forceinline__
+#elif defined(__HIPCC__)
 #include <stdint.h>
-
-#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define RSQ_DEVICE_BUILD 1
 #define RSQ_HD __host__ __device__ __forceinline__
 #else
+#include <stdint.h>
+#define RSQ_DEVICE_BUILD 0
 #define RSQ_HD inline
 #endif
 
@@ -37,18 +51,16 @@ struct DevTable {
     uint32_t rows[4];      // limits_[n].second - limits_[n].first
     uint32_t off[4];       // into the double pool (even: 16-byte aligned)
     uint32_t max_value;    // MaxValue()  (ProbabilityEstimates.h:510-517)
-    uint32_t lds_off;      // offset (32-bit words) of margin 0 in the workgroup's LDS image, kNoLds if the table is not staged
-    // single-precision copy for the screened draws of the read kernel (rsq_core.h "screened draw"): margins one after the other at
-    // pool32[off32], rows of the table family's slot (LdsPlan::slot_*) floats
+    // the two families of the systematic-error chains: single-precision copy for their screened draws (rsq_core.h "screened draw"), margins one after the
+    // other at pool32[off32], rows of whole quads.  (The read kernel's families are laid out per family, FamilyGeo below.)
     uint32_t off32;
     uint32_t f32_ok;       // every value is 0 or in [2^-60, 2^29]: the error bound of the screened draw holds
-    uint32_t lds_extra;    // base call: offset of margin 2 (number of errors) in the LDS image, kNoLds if not staged
     // indel tables: lo16 | hi16 << 16; a draw with lo16 <= (random word >> 16) < hi16 and margin 0 at its row 0 returns value 0 = no indel whatever the
     // rows of the other margins are (rsq_pack.h certain_no_indel); 0: no such bound.  Error-rate tables (the chains): index into DevSim::chain_sure of the table's
     // ranges [row of margin 0][row of margin 2] for value 0 = rate 0; 0: none
     uint32_t sure_range;
 };
-static_assert(sizeof(DevTable) == 80, "descriptor layout");
+static_assert(sizeof(DevTable) == 72, "descriptor layout");
 static_assert(__builtin_offsetof(DevTable, par0_off) == 4, "lds_stage_descriptors rewrites word 1 of a descriptor");
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 // A double-precision draw walks a row in chunks of U column pairs: U = 3 for the small tables (K <= 6: base call, indel), 4 otherwise.
@@ -78,10 +90,30 @@ constexpr uint32_t kQualityQuads[] = {3, 6, 10, 11, 12};
 constexpr uint32_t kChainQuads[] = {8, 16, 26};
 constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)
 
+// One table family of the read kernel (quality, base call, indel) in the screened layout.  LogArrayResult::Draw clamps every conditioning value to the table's own
+// range (AdjustIndeces, ProbabilityEstimates.h:368-380): a value outside it IS the edge row.  So every table of a family can be written over the family's COMMON
+// ranges -- from = the smallest first value, rows up to the largest last one, a table's edge rows repeated where its own range is shorter -- without changing a
+// single draw, and a lane finds its four rows by arithmetic on (table number, value) alone: no descriptor is read, and all of this is a constant of the profile
+// (literals in a kernel compiled for the profile, rsq_spec.h).  An empty table, or one outside the screen's preconditions, is all zeros: its draws come out
+// undecided (prob_sum below 2^-30) and take the double-precision route, which reads the table's own descriptor.
+struct FamilyGeo {
+    uint32_t from[4];            // common first value of margin n
+    uint32_t last[4];            // common last row of margin n (rows - 1)
+    uint32_t before[4];          // rows of the margins in front of margin n within a table
+    uint32_t table_rows;         // rows of one table (all margins)
+    uint32_t off32;              // DevSim::pool32: [table of the profile][table_rows][slot]
+    uint32_t lds;                // image: the staged leading margins, [table of the image][lds_rows][slot]; kNoLds: not staged (the indel family's margin 0 when it does not fit)
+    uint32_t lds_rows;           // quality: rows of margins 0 and 1; base call, indel: rows of margin 0
+    uint32_t lds2;               // base call: margin 2 over the number of errors, [table of the image][last[2] + 1][slot]; kNoLds: read from device memory
+    uint32_t values;             // image, in BYTES from its start: the outcome value of every column, [table of the image][slot] (0 in the pad columns)
+    uint32_t values_src;         // DevSim::par0, bytes: the same for all tables of the profile (what an image copies)
+};
+
 // LDS image of k_fill_reads (rsq_kernels.h "LDS staging"), in single precision: one per template segment holding the tables of all tiles
 // (img_tiles == n_tiles; built once per workgroup) or, when those do not fit, one per (segment, tile) (img_tiles == 1; a workgroup builds the
 // image of the tile whose reads it is about to serve).  Contents:
-// the table descriptors of the image's tiles and of the indel tables, their outcome values, margins 0+1 of the quality tables
+// the table descriptors of the image's tiles and of the indel tables, their outcome values (both for the double-precision route), the outcome values by column
+// of the three families (FamilyGeo::values), margins 0+1 of the quality tables
 // (sequence quality, previous quality), margin 0 of its base-call tables (quality), the first rows of the error-rate margins
 // (quality margin 3, base-call margin 3), and as far as the 160 KiB reach margin 0 of the indel tables and margin 2 of the base-call
 // tables (number of errors).  Offsets and sizes in 32-bit words.
@@ -99,6 +131,7 @@ struct LdsPlan {
     uint32_t q3_off, b3_off;     // [4 img_tiles][rate_rows_q] quality slots, [20 img_tiles][rate_rows_b] base-call slots
     uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4 img_tiles quality slots], the quality rows over the read position of the wave's current steps
     uint32_t total_words;        // size of the image
+    FamilyGeo q, b, i;           // the three families' common geometry
 };
 
 // Fragment produced by the coverage sieve: one simulated read pair (Simulator.cpp:2249-2357 -> CreateReads).
@@ -259,6 +292,17 @@ struct DevSim {
     const uint32_t *meth_first, *meth_second;
     const double *meth_rate;
 };
+
+// What the read kernel knows of the profile's layout -- the LDS plan and the families' common geometry (LdsPlan, FamilyGeo) and a few scalars of DevSim -- is read
+// through these two macros: from the kernel argument in the library's own build; as LITERALS in a kernel compiled for one profile (rsq_spec.h: RSQ_SPEC defines
+// namespace rsq::spec with the same names), where row addresses fold into multiply-adds with constants and the values no longer occupy scalar registers.
+#if defined(RSQ_SPEC)
+#define RSQ_PLAN(S, field) (::rsq::spec::lds.field)
+#define RSQ_SIM(S, field) (::rsq::spec::field)
+#else
+#define RSQ_PLAN(S, field) ((S).lds.field)
+#define RSQ_SIM(S, field) ((S).field)
+#endif
 
 struct NameTable {                       // first parts of the reference ids + the record base identifier
     const char *names;

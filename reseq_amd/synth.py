@@ -56,6 +56,25 @@ def result_table(margins, values, limits):
     return dict(par0=par0, limits=lim, dim2=np.concatenate(parts))
 
 
+def ragged_table(tab, j):
+    """The table with rows cut off the ends of its conditioning ranges (by how many depends on the table's number j), as the tables of a real profile
+    differ in the value ranges they were fitted on (ProbabilityEstimates.h:386-396: limits_ are per table); draws outside a table's own range take its edge rows."""
+    k = len(tab["par0"])
+    if k == 0:
+        return tab
+    lim, parts, at = tab["limits"].copy(), [], 0
+    cut = np.random.default_rng(4000 + j).integers(0, 4, size=(len(lim), 2))
+    for n, (lo, hi) in enumerate(tab["limits"].tolist()):
+        rows = hi - lo
+        m = tab["dim2"][at:at + rows * k].reshape(rows, k)
+        at += rows * k
+        front = int(cut[n, 0]) if rows > 6 else 0
+        back = int(cut[n, 1]) if rows - front > 6 else 0
+        parts.append(m[front:rows - back].ravel())
+        lim[n] = (lo + front, hi - back)
+    return dict(par0=tab["par0"], limits=lim, dim2=np.concatenate(parts))
+
+
 def _noise(rng, shape, sigma=0.05):
     return np.exp(rng.normal(0.0, sigma, size=shape))
 
@@ -365,13 +384,18 @@ def make_profile(cfg=None, seed=103741084, n_ref_seqs=1):
         for k, v in tab.items():
             out[f"tab.{prefix}.{k}"] = v
 
+    # ragged_tables: every table of the read kernel's three families over its own value ranges, and an empty table in each of two families
+    ragged = (lambda tab, j: ragged_table(tab, j)) if cfg.get("ragged_tables") else (lambda tab, j: tab)
+    empty = (lambda tab: result_table([], [], tab["limits"].tolist())) if cfg.get("ragged_tables") else (lambda tab: tab)
+    j = 0
     for seg in range(2):
         for tile in range(nt):
             put(f"seq_quality.{seg}.{tile}", _seq_quality_table(rng, cfg, seg))
             for base in range(4):
-                put(f"quality.{seg}.{tile}.{base}", _quality_table(rng, cfg, seg, base))
+                put(f"quality.{seg}.{tile}.{base}", ragged(_quality_table(rng, cfg, seg, base), j := j + 1))
                 for dom in range(5):
-                    put(f"base_call.{seg}.{tile}.{base}.{dom}", _base_call_table(rng, cfg, seg, base, dom))
+                    tab = ragged(_base_call_table(rng, cfg, seg, base, dom), j := j + 1)
+                    put(f"base_call.{seg}.{tile}.{base}.{dom}", empty(tab) if (seg, tile, base, dom) == (1, nt - 1, 2, 4) else tab)
     for base in range(4):
         for prev in range(5):
             for dom5 in range(4):
@@ -383,7 +407,8 @@ def make_profile(cfg=None, seed=103741084, n_ref_seqs=1):
             put(f"error_rate.{base}.{dom_err}", _error_rate_table(rng, cfg, base, dom_err))
     for prev_type in range(2):
         for last_call in range(6):
-            put(f"indels.{prev_type}.{last_call}", _indel_table(rng, cfg, prev_type, last_call))
+            tab = ragged(_indel_table(rng, cfg, prev_type, last_call), j := j + 1)
+            put(f"indels.{prev_type}.{last_call}", empty(tab) if (prev_type, last_call) == (1, 4) else tab)
     return out
 
 

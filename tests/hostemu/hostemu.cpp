@@ -68,7 +68,7 @@ struct Emu : SimState {
         if (img.empty()) {
             img.assign(dev.lds.total_words + 16, 0.f);
             lds_stage_descriptors(dev, img.data(), qbase, 0, 1);
-            lds_stage_rows(dev, img.data(), 0, 1);
+            lds_stage_rows(dev, img.data(), qbase, 0, 1);
         }
         return img.data();
     }
@@ -84,11 +84,12 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
             constexpr uint32_t M = decltype(tag)::value;
             if (s.mask() != M) return;
             float *img = s.image(seg, tile), *ring = img + s.dev.lds.ring_off;      // the ring of wave 0
-            ScreenTables<M> tab{s.dev, img, image_qbase(s.dev, seg, s.dev.lds.binned ? tile : 0u), ring, 0u};
+            const uint32_t qbase = image_qbase(s.dev, seg, s.dev.lds.binned ? tile : 0u);
+            ScreenTables<M> tab{s.dev, img, qbase, ring, 0u};
             ReadMachine m;
             m.init(s.dev, tab, st, seg, tile, frag_len, src);
             for (;;) {
-                for (uint32_t item = 0; item < lds_ring_items(s.dev); ++item) lds_ring_stage(s.dev, img, ring, m.par.read_pos, item);
+                for (uint32_t item = 0; item < lds_ring_items(s.dev); ++item) lds_ring_stage(s.dev, qbase, ring, m.par.read_pos, item);
                 tab.t = m.par.read_pos;
                 if (!m.step(s.dev, tab, st, src, out)) break;
             }

@@ -331,6 +331,27 @@ def case_indel_columns_shuffled(backend_cls, workdir):
         p.close()
 
 
+def case_ragged_tables(backend_cls, workdir, cfg_base=None, lengths=(5000, 3210), num_pairs=3000):
+    """Every quality, base-call and indel table over its own value ranges (rows cut off both ends, differently per table) and an empty table in two families: the read
+    kernel's layout writes all tables of a family over the family's common ranges with edge rows repeated (FamilyGeo) -- the output must stay the oracle's, whose Draw
+    clamps per table (AdjustIndeces)"""
+    cfg = dict(cfg_base or synth.TINY, ragged_tables=True)
+    cfg["name"] = cfg["name"] + "rag"
+    arrays = synth.make_profile(cfg, seed=19)
+    lims = {tuple(map(tuple, arrays[k].tolist())) for k in arrays if k.startswith("tab.quality.") and k.endswith(".limits")}
+    assert len(lims) > 3, "the quality tables must differ in their ranges"
+    p = Pair(backend_cls, workdir, cfg["name"].lower(), cfg, list(lengths), seed=29, num_pairs=num_pairs, prof_seed=19)
+    try:
+        assert p.b.fill_plan()["mask"] != 0
+        p.align_normalization()
+        n, text = _compare_blocks(p, 1, p.info["total_blocks"] + 1)
+        assert n > num_pairs // 2
+    finally:
+        p.close()
+    exp = _error_model(backend_cls, workdir, cfg["name"].lower(), cfg, 400, cfg["read_len_max"], seed=5, prof_seed=19, zero_frac=0.7)
+    assert len(exp) == 400
+
+
 def case_profile_edits(backend_cls, workdir):
     for edits in ({"error_multiplier": 3.0}, {"no_substitutions": True}, {"no_indels": True}, {"no_substitutions": True, "no_indels": True}):
         p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=5, num_pairs=800, edits=edits)

@@ -64,6 +64,12 @@ def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(w
     P.case_indel_columns_shuffled(GpuBackend, workdir)
 
 
+def test_tables_over_their_own_value_ranges(workdir):
+    from reseq_amd import synth
+    P.case_ragged_tables(GpuBackend, workdir)
+    P.case_ragged_tables(GpuBackend, workdir, cfg_base=synth.P0, lengths=(20000,), num_pairs=1000)
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(GpuBackend, workdir)
 

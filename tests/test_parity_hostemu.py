@@ -113,6 +113,10 @@ def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(w
     assert w > 200_000 and 1e-3 * w < w_left < 0.05 * w, (w, w_left)        # the frequent insertion and the bound's slack: about 1 %
 
 
+def test_tables_over_their_own_value_ranges(workdir):
+    P.case_ragged_tables(EmuBackend, workdir)
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(EmuBackend, workdir)
 

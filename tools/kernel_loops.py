@@ -18,7 +18,9 @@ CLASSES = ("scratch_load", "scratch_store", "v_readlane", "v_writelane", "s_load
            "v_mul_f64", "v_add_f64", "s_waitcnt", "s_cbranch", "v_", "s_")
 
 
-def disassemble(lib):
+def disassemble(lib, code_object=None):
+    if code_object:
+        return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", code_object], check=True, capture_output=True, text=True).stdout
     with tempfile.TemporaryDirectory() as d:
         tmp = os.path.join(d, "lib.so")
         os.symlink(os.path.abspath(lib), tmp)
@@ -32,9 +34,10 @@ def main():
     ap.add_argument("pattern")
     ap.add_argument("--lib", default=os.path.join(ROOT, "reseq_amd", "libreseq_amd.so"))
     ap.add_argument("--loops", type=int, default=4)
+    ap.add_argument("--code-object", default=None, help="a bare code object instead of the library (Profile.compile_read_kernel(out_path=...))")
     a = ap.parse_args()
     funcs, cur = collections.OrderedDict(), None
-    for line in disassemble(a.lib).splitlines():
+    for line in disassemble(a.lib, a.code_object).splitlines():
         m = re.match(r"^([0-9a-f]+) <(.+)>:", line)
         if m:
             cur = (m.group(2), int(m.group(1), 16))

@@ -16,7 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELDS = ["vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"]
 
 
-def kernels(lib):
+def kernels(lib, code_object=None):
+    if code_object:                                   # a bare gfx code object (what rsq_profile_compile_read_kernel writes), not a library with a bundle
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", code_object], check=True, capture_output=True, text=True).stdout
+        return parse_notes(notes)
     with tempfile.TemporaryDirectory() as d:
         tmp = os.path.join(d, "lib.so")
         os.symlink(os.path.abspath(lib), tmp)
@@ -25,6 +28,10 @@ def kernels(lib):
         if not cos:
             raise SystemExit("no gfx code object found in " + lib)
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", os.path.join(d, cos[0])], check=True, capture_output=True, text=True).stdout
+    return parse_notes(notes)
+
+
+def parse_notes(notes):
     out, cur = [], None
     for line in notes.splitlines():
         m = re.match(r"\s+(?:- )?\.(\w+):\s+(.*)", line)
@@ -48,8 +55,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("pattern", nargs="?", default="")
     ap.add_argument("--lib", default=os.path.join(ROOT, "reseq_amd", "libreseq_amd.so"))
+    ap.add_argument("--code-object", default=None, help="a bare code object instead of the library (Profile.compile_read_kernel(out_path=...))")
     a = ap.parse_args()
-    ks = kernels(a.lib)
+    ks = kernels(a.lib, a.code_object)
     names = demangle([k["name"] for k in ks])
     print(f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'vspill':>6} {'sspill':>6} {'scratch':>7} {'lds':>6}  kernel")
     for k, n in sorted(zip(ks, names), key=lambda x: x[1]):
