@@ -245,7 +245,7 @@ def committed_counters(tiles=1):
     try:
         pmc = json.load(open(files[-1]))
         recorded = pmc.pop("_kernel_source_hash", None)
-        kernel = [k for k in pmc if "k_fill_reads" in k][0]
+        kernel = sorted((k for k in pmc if "fill_reads" in k), key=lambda k: not k.startswith("rsq_spec_"))[0]      # the profile's own kernel (rsq_spec_fill_reads) when it ran
         c = {n: v["mean"] for n, v in pmc[kernel].items()}
         cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
         from reseq_amd.provenance import kernel_source_hash

@@ -37,9 +37,12 @@ enum {
 const char *rsq_last_error(void);
 const char *rsq_last_warning(void);          /* non-fatal remarks of the last rsq_profile_load* or rsq_sim_create call ("" if none) */
 const char *rsq_version(void);
-/* Testing and measurement switches (reseq_amd/csrc/rsq_host.h `Options`; README "Options").  The library reads nothing from the environment: an
- * embedding program sets a switch explicitly, and a simulator takes the values current when it is created (pre-pass switches: when the pre-pass
- * runs).  Reads and FASTQ bytes never depend on them -- they choose between equivalent routes (e.g. fill_mode 0: every per-base draw in double
+/* Testing and measurement switches (reseq_amd/csrc/rsq_host.h `Options`; README "Options").  The library takes no switch from the environment (only the default place of the
+ * kernel cache, rsq_set_kernel_cache_dir): an embedding program sets a switch explicitly.  A simulator takes the values current when it is created -- fill_mode,
+ * image_tiles, rate_rows, no_indel_skip, force_exact, min_quality_quads, specialize --; the others are read by the call they shape, from the process-wide values:
+ * the pre-pass switches (bias_window, window_chunks, chain_chunk, chain_warmup, trace_prepare) when the pre-pass runs, overlap by rsq_sim_pairs, job_chunk_bytes
+ * by rsq_sim_job_generate, the loaders' (serial_fasta, fasta_stretch, serial_parse, parse_stretch, trace_load) by the load; mapped_parses is a counter the
+ * loaders add to.  Reads and FASTQ bytes never depend on them -- they choose between equivalent routes (e.g. fill_mode 0: every per-base draw in double
  * precision from device memory, the reference's own recipe, ProbabilityEstimates.h:481-508).  RSQ_EINVAL for an unknown name. */
 int rsq_set_option(const char *name, int64_t value);
 int rsq_get_option(const char *name, int64_t *value);
@@ -50,6 +53,8 @@ int rsq_device_count(void);
  *      ProbabilityEstimates::Load + PrepareResult (reseq/ProbabilityEstimates.cpp:961-1065).
  *      `path` is an RSQP container (reseq_amd/container.py documents the layout) or a `.reseq` archive (see rsq_profile_load_reseq). */
 int rsq_profile_load(const char *path, rsq_profile **out);
+/* *yes = 1 if the file begins like a Boost text archive (ReSeq's own .reseq), 0 otherwise (an RSQP container, or unreadable) */
+int rsq_profile_is_reseq_archive(const char *path, int *yes);
 /* ReSeq's own profile files: `stats_path` = the `.reseq` Boost text archive DataStats::Save writes (reseq/DataStats.cpp:1302-1320, member
  * list DataStats.h:180-212), `ipf_path` = the `.reseq.ipf` archive of ProbabilityEstimates::Save (reseq/ProbabilityEstimates.cpp:1047-1065,
  * member list ProbabilityEstimates.h:1475-1483; NULL = "<stats_path>.ipf", main.cpp:837).  Does what `main` does between loading and
@@ -57,16 +62,14 @@ int rsq_profile_load(const char *path, rsq_profile **out);
  * ErrorStats::PrepareSimulation) and ProbabilityEstimates::PrepareResult (FullExpansion, GetResults, ImputeMissingValues).  Fitting is not
  * part of this build: tables whose stored precision is above `ipf_precision_percent` (--ipfPrecision, default 5) are used as stored and
  * reported through rsq_last_warning().  rsq_profile_load recognises such a file by its first bytes and forwards here. */
-/* *yes = 1 if the file begins like a Boost text archive (ReSeq's own .reseq), 0 otherwise (an RSQP container, or unreadable) */
-int rsq_profile_is_reseq_archive(const char *path, int *yes);
 int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out);
-/* writes the prepared profile (result tables, not the fit) as an RSQP container */
 /* Diagnosis of ReSeq's own profile files (DataStats::Save / ProbabilityEstimates::Save, reseq/DataStats.cpp:1302-1320, ProbabilityEstimates.cpp:1047-1065): a text
  * table of where every serialized C++ type's class information sits in the two archives (byte, tracking, version, type, member path of the first object) and,
  * if a file does not parse, the message naming the member path and type at which it stops.  The reader's token rules cannot be validated against a
  * Boost-written file in the build image (INTEGRATION.md "Profile files"); this is what to send back when a real profile fails.  `ipf_path` NULL: stats_path + ".ipf".
  * Writes at most cap bytes (NUL-terminated) and the full length to *need. */
 int rsq_profile_archive_layout(const char *stats_path, const char *ipf_path, char *out, size_t cap, size_t *need);
+/* writes the prepared profile (result tables, not the fit) as an RSQP container */
 int rsq_profile_save(const rsq_profile *p, const char *path);
 void rsq_profile_free(rsq_profile *p);
 /* ProbabilityEstimates::ChangeErrorRate / RemoveSubstitutionErrors / RemoveInDelErrors
@@ -179,7 +182,8 @@ int rsq_sim_specialize(rsq_sim *s, int kind, int *specialized);
  * version).  Default: $XDG_CACHE_HOME/reseq_amd, else ~/.cache/reseq_amd -- the one thing the library takes from the environment; "" or NULL: keep nothing on disk. */
 int rsq_set_kernel_cache_dir(const char *path);
 /* Host only, no device needed: compiles the read kernel for `p` as rsq_sim_specialize would for a device of architecture `arch` ("gfx950"), from a plan packed
- * into host memory; the code object goes to `out_path` (NULL: nowhere; the kernel cache is used and filled as usual).  kind as above; with_variants: the variant
+ * into host memory; the code object goes to `out_path` (NULL: nowhere; the kernel cache is used and filled as usual; a name ending in ".hip": the program text itself
+ * is written instead, nothing is compiled -- `hipcc -I reseq_amd/csrc` builds it outside).  kind as above; with_variants: the variant
  * of the read-pair kernel for a reference with variants; binned: the variant that serves one tile per workgroup (forced when the profile's tiles do not fit one
  * image).  *code_bytes = size of the code object, *seconds (may be NULL) = compilation time, 0 from the cache.  For build checks (hiprtc cross-compiles) and for
  * reading the generated code (tools/kernel_resources.py --code-object).  RSQ_EINVAL with the compiler's log when it fails. */

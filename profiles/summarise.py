@@ -14,12 +14,12 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(root + "/pmc_*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if k.startswith("rsq::"):
+        if k.startswith("rsq::") or k.startswith("rsq_spec_"):        # the library's kernels and the read kernels compiled for the profile (rsq_spec.h)
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 pmc = {k: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
 pmc["_kernel_source_hash"] = kernel_source_hash()           # bench.py: counters_stale when the sources it runs from hash differently
 json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-fill = [k for k in pmc if "k_fill_reads" in k and not k.startswith("_")]
+fill = sorted((k for k in pmc if "fill_reads" in k and not k.startswith("_")), key=lambda k: not k.startswith("rsq_spec_"))       # the profile's own kernel first
 if fill and "FETCH_SIZE" in pmc[fill[0]] and "WRITE_SIZE" in pmc[fill[0]]:
     k = fill[0]
     fetch_kib, write_kib = pmc[k]["FETCH_SIZE"]["mean"], pmc[k]["WRITE_SIZE"]["mean"]

@@ -877,7 +877,7 @@ Methylation read_methylation_file(const std::string &path, const std::vector<std
     if (!options().serial_parse) {
         Methylation mapped;
         if (read_methylation_mapped(path, first_names, seq_len, num_alleles_ref, mapped)) {
-            ++options().mapped_parses;
+            __atomic_add_fetch(&options().mapped_parses, 1, __ATOMIC_RELAXED);      // files may be loaded from several threads
             return mapped;
         }
     }
@@ -1264,7 +1264,7 @@ Variants read_variants(const std::string &path, const std::vector<std::string> &
     if (!options().serial_parse) {
         Variants mapped;
         if (read_variants_mapped(path, first_names, codes, mapped)) {
-            ++options().mapped_parses;
+            __atomic_add_fetch(&options().mapped_parses, 1, __ATOMIC_RELAXED);      // files may be loaded from several threads
             return mapped;
         }
     }

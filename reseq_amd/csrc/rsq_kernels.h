@@ -1674,10 +1674,10 @@ struct ScreenTables {
 
     RSQ_HD uint32_t draw_quality(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
         const uint32_t local = i - qbase, slot = RSQ_PLAN(S, slot_q), nr = RSQ_PLAN(S, rate_rows_q), r3 = RSQ_GEO_ROW(S, q, 3, idx[3]);
-        const RSQ_LDS float *mine = img + RSQ_PLAN(S, q.lds) + local * (RSQ_PLAN(S, q.lds_rows) * slot);      // margins 0 and 1 of the table
+        const RSQ_LDS float *mine = img + RSQ_PLAN(S, q.lds) + local * RSQ_PLAN(S, q.lds_stride);      // margins 0 and 1 of the table
         const LdsRow32 m0{mine + RSQ_GEO_ROW(S, q, 0, idx[0]) * slot}, m1{mine + (RSQ_PLAN(S, q.before[1]) + RSQ_GEO_ROW(S, q, 1, idx[1])) * slot};
         const LdsRow32 m2{ring(idx[2]) + local * slot};
-        const LdsRow32 m3{img + RSQ_PLAN(S, q3_off) + (local * nr + (r3 < nr ? r3 : 0u)) * slot};
+        const LdsRow32 m3{img + RSQ_PLAN(S, q3_off) + local * RSQ_PLAN(S, q3_stride) + (r3 < nr ? r3 : 0u) * slot};
         uint32_t col = 0;
         const bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
         RSQ_SCREEN_COUNT(0, decided);
@@ -1686,13 +1686,13 @@ struct ScreenTables {
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
         const uint32_t local = i - qbase * 5u, slot = RSQ_PLAN(S, slot_b), nr = RSQ_PLAN(S, rate_rows_b), r3 = RSQ_GEO_ROW(S, b, 3, idx[3]);
         const float *g = S.pool32 + RSQ_PLAN(S, b.off32) + i * (RSQ_PLAN(S, b.table_rows) * slot);             // the table's rows in device memory
-        const LdsRow32 m0{img + RSQ_PLAN(S, b.lds) + (local * RSQ_PLAN(S, b.lds_rows) + RSQ_GEO_ROW(S, b, 0, idx[0])) * slot};
+        const LdsRow32 m0{img + RSQ_PLAN(S, b.lds) + local * RSQ_PLAN(S, b.lds_stride) + RSQ_GEO_ROW(S, b, 0, idx[0]) * slot};
         const GlobalRow32 m1{g + (RSQ_PLAN(S, b.before[1]) + RSQ_GEO_ROW(S, b, 1, idx[1])) * slot};
         const uint32_t r2 = RSQ_GEO_ROW(S, b, 2, idx[2]);
         const bool m2_staged = RSQ_PLAN(S, b.lds2) != kNoLds, staged = r3 < nr;
-        const MixedRow32 m2{LdsRow32{img + (m2_staged ? RSQ_PLAN(S, b.lds2) + (local * (RSQ_PLAN(S, b.last[2]) + 1u) + r2) * slot : 0u)},
+        const MixedRow32 m2{LdsRow32{img + (m2_staged ? RSQ_PLAN(S, b.lds2) + local * RSQ_PLAN(S, b.lds2_stride) + r2 * slot : 0u)},
                             GlobalRow32{g + (RSQ_PLAN(S, b.before[2]) + r2) * slot}, m2_staged};
-        const MixedRow32 m3{LdsRow32{img + RSQ_PLAN(S, b3_off) + (local * nr + (staged ? r3 : 0u)) * slot}, GlobalRow32{g + (RSQ_PLAN(S, b.before[3]) + r3) * slot}, staged};
+        const MixedRow32 m3{LdsRow32{img + RSQ_PLAN(S, b3_off) + local * RSQ_PLAN(S, b3_stride) + (staged ? r3 : 0u) * slot}, GlobalRow32{g + (RSQ_PLAN(S, b.before[3]) + r3) * slot}, staged};
         uint32_t col = 0;
         const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3);
         RSQ_SCREEN_COUNT(1, decided);
@@ -1712,7 +1712,7 @@ struct ScreenTables {
         const uint32_t slot = RSQ_PLAN(S, slot_i), r0 = RSQ_GEO_ROW(S, i, 0, idx[0]);
         const float *g = S.pool32 + RSQ_PLAN(S, i.off32) + i * (RSQ_PLAN(S, i.table_rows) * slot);
         const bool m0_staged = RSQ_PLAN(S, i.lds) != kNoLds;
-        const MixedRow32 m0{LdsRow32{img + (m0_staged ? RSQ_PLAN(S, i.lds) + (i * RSQ_PLAN(S, i.lds_rows) + r0) * slot : 0u)}, GlobalRow32{g + r0 * slot}, m0_staged};
+        const MixedRow32 m0{LdsRow32{img + (m0_staged ? RSQ_PLAN(S, i.lds) + i * RSQ_PLAN(S, i.lds_stride) + r0 * slot : 0u)}, GlobalRow32{g + r0 * slot}, m0_staged};
         const GlobalRow32 m1{g + (RSQ_PLAN(S, i.before[1]) + RSQ_GEO_ROW(S, i, 1, idx[1])) * slot}, m2{g + (RSQ_PLAN(S, i.before[2]) + RSQ_GEO_ROW(S, i, 2, idx[2])) * slot};
         uint32_t col = 0;
         const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2);
@@ -1755,25 +1755,27 @@ RSQ_HD void lds_stage_descriptors(const DevSim &S, RSQ_LDS float *img, uint32_t 
 }
 // rows [first_row, first_row + n_rows) of `n_tables` tables of a family, from table `first` of the profile on, to [table][n_rows][slot] at dst_off: whole 16-byte groups
 RSQ_HD void lds_stage_family_rows(const DevSim &S, RSQ_LDS float *img, uint32_t off32, uint32_t table_rows, uint32_t first, uint32_t n_tables, uint32_t first_row, uint32_t n_rows,
-                                  uint32_t slot, uint32_t dst_off, uint32_t tid, uint32_t nthreads) {
+                                  uint32_t slot, uint32_t dst_off, uint32_t dst_stride, uint32_t tid, uint32_t nthreads) {
     const uint32_t per_table = n_rows * (slot / 4u);
     for (uint32_t i = tid; i < n_tables * per_table; i += nthreads) {
         const uint32_t table = i / per_table, g = i - table * per_table;
-        reinterpret_cast<RSQ_LDS Quad *>(img + dst_off)[i] = reinterpret_cast<const Quad *>(S.pool32 + off32 + ((size_t)(first + table) * table_rows + first_row) * slot)[g];
+        reinterpret_cast<RSQ_LDS Quad *>(img + dst_off + table * dst_stride)[g] = reinterpret_cast<const Quad *>(S.pool32 + off32 + ((size_t)(first + table) * table_rows + first_row) * slot)[g];
     }
 }
 RSQ_HD void lds_stage_rows(const DevSim &S, RSQ_LDS float *img, uint32_t qbase, uint32_t tid, uint32_t nthreads) {
     const uint32_t T = RSQ_PLAN(S, img_tiles), sq = RSQ_PLAN(S, slot_q), sb = RSQ_PLAN(S, slot_b), si = RSQ_PLAN(S, slot_i);
     // quality: margins 0 and 1; base call: margin 0, margin 2; indel: margin 0; then the first rows of the two error-rate margins
-    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, 0u, RSQ_PLAN(S, q.lds_rows), sq, RSQ_PLAN(S, q.lds), tid, nthreads);
-    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, 0u, RSQ_PLAN(S, b.lds_rows), sb, RSQ_PLAN(S, b.lds), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, 0u, RSQ_PLAN(S, q.lds_rows), sq, RSQ_PLAN(S, q.lds), RSQ_PLAN(S, q.lds_stride), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, 0u, RSQ_PLAN(S, b.lds_rows), sb, RSQ_PLAN(S, b.lds), RSQ_PLAN(S, b.lds_stride), tid, nthreads);
     if (RSQ_PLAN(S, b.lds2) != kNoLds)
-        lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[2]), RSQ_PLAN(S, b.last[2]) + 1u, sb, RSQ_PLAN(S, b.lds2), tid,
-                              nthreads);
+        lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[2]), RSQ_PLAN(S, b.last[2]) + 1u, sb, RSQ_PLAN(S, b.lds2),
+                              RSQ_PLAN(S, b.lds2_stride), tid, nthreads);
     if (RSQ_PLAN(S, i.lds) != kNoLds)
-        lds_stage_family_rows(S, img, RSQ_PLAN(S, i.off32), RSQ_PLAN(S, i.table_rows), 0u, 12u, 0u, RSQ_PLAN(S, i.lds_rows), si, RSQ_PLAN(S, i.lds), tid, nthreads);
-    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, RSQ_PLAN(S, q.before[3]), RSQ_PLAN(S, rate_rows_q), sq, RSQ_PLAN(S, q3_off), tid, nthreads);
-    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[3]), RSQ_PLAN(S, rate_rows_b), sb, RSQ_PLAN(S, b3_off), tid, nthreads);
+        lds_stage_family_rows(S, img, RSQ_PLAN(S, i.off32), RSQ_PLAN(S, i.table_rows), 0u, 12u, 0u, RSQ_PLAN(S, i.lds_rows), si, RSQ_PLAN(S, i.lds), RSQ_PLAN(S, i.lds_stride), tid, nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, q.off32), RSQ_PLAN(S, q.table_rows), qbase, 4u * T, RSQ_PLAN(S, q.before[3]), RSQ_PLAN(S, rate_rows_q), sq, RSQ_PLAN(S, q3_off), RSQ_PLAN(S, q3_stride), tid,
+                          nthreads);
+    lds_stage_family_rows(S, img, RSQ_PLAN(S, b.off32), RSQ_PLAN(S, b.table_rows), qbase * 5u, 20u * T, RSQ_PLAN(S, b.before[3]), RSQ_PLAN(S, rate_rows_b), sb, RSQ_PLAN(S, b3_off), RSQ_PLAN(S, b3_stride), tid,
+                          nthreads);
 }
 // The ring: the quality rows (margin 2) over read position p of the segment's tables, copied by the wave itself at the beginning of
 // step p into slot p % kRingSlots of its ring: one load of 16 bytes per lane instead of one per lane and quad of the row.  Item i is
@@ -2298,8 +2300,11 @@ __device__ void fill_binned_loop(const DevSim &S, float *lds_image, const FillBi
             } else {
                 // score = chunks left * 4096 / (workgroups on the bin + 1); ties go to the lower bin
                 for (uint32_t b = lane; b < bins.n_bins; b += 64u) {
-                    const uint32_t n = (bins.bin_count[b] + 63u) / 64u, done = bins.next_chunk[b], left = done < n ? n - done : 0u;
-                    const uint64_t score = (uint64_t)left * 4096u / (bins.workers[b] + 1u), packed = (score << 32) | (0xFFFFFFFFu - b);
+                    // other workgroups change these two with atomics while this one scans them: loads that go to the device-coherent level, not to this CU's vector cache
+                    // (a stale "chunks left" would send the workgroup back to a used-up bin, from which it returns here)
+                    const uint32_t n = (bins.bin_count[b] + 63u) / 64u, done = __hip_atomic_load(&bins.next_chunk[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                   on_it = __hip_atomic_load(&bins.workers[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), left = done < n ? n - done : 0u;
+                    const uint64_t score = (uint64_t)left * 4096u / (on_it + 1u), packed = (score << 32) | (0xFFFFFFFFu - b);
                     if (left && packed > best) best = packed;
                 }
             }

@@ -385,10 +385,15 @@ inline void pack_tables(SimState &s, Uploader &up) {
         const uint32_t desc_words = (lds_desc_count(Ti) * kDescWords + 3u) / 4u * 4u + par0_words;
         const uint32_t values_words = (4 * Ti * plan.slot_q + 20 * Ti * plan.slot_b + 12 * plan.slot_i + 15u) / 16u * 4u;      // a byte per column
         const uint32_t rows_q = plan.q.last[0] + 1 + plan.q.last[1] + 1, rows_b = plan.b.last[0] + 1, rows_b2 = plan.b.last[2] + 1, rows_i = plan.i.last[0] + 1;
-        const uint64_t need_q = (uint64_t)4 * Ti * rows_q * plan.slot_q, need_b = (uint64_t)20 * Ti * rows_b * plan.slot_b, need_b2 = (uint64_t)20 * Ti * rows_b2 * plan.slot_b,
-                       need_i0 = (uint64_t)12 * rows_i * plan.slot_i;
+        // floats from one table's block to the next: an odd number of 16-byte groups (LdsPlan: the tables' copies of a row in different bank groups)
+        auto odd_stride = [](uint64_t floats) { return (uint32_t)(((floats / 4u) | 1u) * 4u); };      // floats is a multiple of 4: an even number of groups gets one more
+        const uint32_t stride_q = odd_stride((uint64_t)rows_q * plan.slot_q), stride_b = odd_stride((uint64_t)rows_b * plan.slot_b), stride_b2 = odd_stride((uint64_t)rows_b2 * plan.slot_b),
+                       stride_i = odd_stride((uint64_t)rows_i * plan.slot_i);
+        const uint64_t need_q = (uint64_t)4 * Ti * stride_q, need_b = (uint64_t)20 * Ti * stride_b, need_b2 = (uint64_t)20 * Ti * stride_b2, need_i0 = (uint64_t)12 * stride_i;
         uint64_t need = (uint64_t)desc_words + values_words + need_q + need_b;
-        auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) { return (uint64_t)4 * Ti * rows_q * plan.slot_q + (uint64_t)20 * Ti * rows_b * plan.slot_b; };
+        auto need_rate = [&](uint32_t rows_q, uint32_t rows_b) {
+            return (uint64_t)4 * Ti * odd_stride((uint64_t)rows_q * plan.slot_q) + (uint64_t)20 * Ti * odd_stride((uint64_t)rows_b * plan.slot_b);
+        };
         const uint32_t ring_stride = 4 * Ti * plan.slot_q;
         need += (uint64_t)(kFillBlock / 64) * kRingSlots * ring_stride;                              // the waves' rings
         if (need + need_rate(1, 1) > budget) return false;
@@ -416,17 +421,21 @@ inline void pack_tables(SimState &s, Uploader &up) {
         plan.b.values = plan.q.values + 4 * Ti * plan.slot_q;
         plan.i.values = plan.b.values + 20 * Ti * plan.slot_b;
         uint32_t at = desc_words + values_words;
-        plan.q.lds = at, plan.q.lds_rows = rows_q, at += (uint32_t)need_q;
-        plan.b.lds = at, plan.b.lds_rows = rows_b, at += (uint32_t)need_b;
+        plan.q.lds = at, plan.q.lds_rows = rows_q, plan.q.lds_stride = stride_q, at += (uint32_t)need_q;
+        plan.b.lds = at, plan.b.lds_rows = rows_b, plan.b.lds_stride = stride_b, at += (uint32_t)need_b;
         plan.b.lds2 = stage_b2 ? at : kNoLds;
+        plan.b.lds2_stride = stride_b2;
         if (stage_b2) at += (uint32_t)need_b2;
         plan.i.lds = stage_i0 ? at : kNoLds;
         plan.i.lds_rows = rows_i;
+        plan.i.lds_stride = stride_i;
         if (stage_i0) at += (uint32_t)need_i0;
         plan.ring_off = at;
         plan.q3_off = plan.ring_off + (kFillBlock / 64) * kRingSlots * plan.ring_stride;
-        plan.b3_off = plan.q3_off + 4 * Ti * plan.rate_rows_q * plan.slot_q;
-        plan.total_words = plan.b3_off + 20 * Ti * plan.rate_rows_b * plan.slot_b;
+        plan.q3_stride = odd_stride((uint64_t)plan.rate_rows_q * plan.slot_q);
+        plan.b3_stride = odd_stride((uint64_t)plan.rate_rows_b * plan.slot_b);
+        plan.b3_off = plan.q3_off + 4 * Ti * plan.q3_stride;
+        plan.total_words = plan.b3_off + 20 * Ti * plan.b3_stride;
         plan.mask = plan.quads_q;
         return true;
     };

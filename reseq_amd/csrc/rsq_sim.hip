@@ -161,7 +161,9 @@ struct rsq_sim : SimState {
         std::vector<std::unique_ptr<DevBuf>> chunks[2];
         std::vector<size_t> used[2];
         uint64_t bytes[2] = {0, 0};
+        bool complete = false;         // rsq_sim_job_generate ran to its end: the text is whole (not: never generated, freed, or left half-made by a failed call)
         void clear() {
+            complete = false;
             for (int f = 0; f < 2; ++f) {
                 chunks[f].clear();
                 used[f].clear();
@@ -795,8 +797,8 @@ static uint32_t pairs_parts(uint32_t n_blocks) {
     const int64_t opt = options().overlap;
     return opt > 0 ? (uint32_t)std::min<int64_t>(opt, std::max<uint32_t>(n_blocks, 1u)) : 1u;
 }
-static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, uint64_t *n_pairs,
-                     rsq_fragment *frags_out, size_t frags_cap, hipStream_t st) {
+// what rsq_sim_pairs and rsq_sim_job_generate ask of a block range before anything is sized from it
+static int check_block_range(const rsq_sim &s, uint32_t block_lo, uint32_t block_hi) {
     if (!s.prepared || !s.has_ref) {
         g_last_error = "rsq_sim_prepare with a reference must run before rsq_sim_pairs";
         return RSQ_ESTATE;
@@ -810,6 +812,11 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
                        std::to_string(s.prepared_lo) + ", " + std::to_string(s.prepared_hi) + ")";
         return RSQ_ESTATE;
     }
+    return RSQ_OK;
+}
+static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1, size_t r1_cap, size_t *r1_len, char *r2, size_t r2_cap, size_t *r2_len, uint64_t *n_pairs,
+                     rsq_fragment *frags_out, size_t frags_cap, hipStream_t st) {
+    if (const int rc = check_block_range(s, block_lo, block_hi)) return rc;
     HIP_CHECK(hipSetDevice(s.device));
     *n_pairs = 0;
     *r1_len = *r2_len = 0;
@@ -1388,10 +1395,20 @@ int rsq_profile_compile_read_kernel(const rsq_profile *p, int kind, int with_var
         pack_tables(s, up);
         pack_profile(s, up);
         if (!s.dev.lds.mask) throw Error("the profile has no table image (" + s.plan_note + "): there is nothing to compile for it");
+        const SpecVariant variant{kind == 0 ? SpecKind::kReads : SpecKind::kRecords, s.dev.lds.mask, kind == 0 && with_variants != 0, binned != 0 || s.dev.lds.binned != 0};
+        const std::string path = out_path ? out_path : "";
+        if (path.size() > 4 && path.compare(path.size() - 4, 4, ".hip") == 0) {        // the program itself (for `hipcc -I reseq_amd/csrc -g ...`: listings with source lines)
+            const std::string program = spec_program(spec_literals(s.dev), variant);
+            FILE *f = fopen(out_path, "wb");
+            if (!f || fwrite(program.data(), 1, program.size(), f) != program.size()) throw Error(std::string("cannot write ") + out_path);
+            fclose(f);
+            *code_bytes = program.size();
+            if (seconds) *seconds = 0.0;
+            return RSQ_OK;
+        }
         SpecCode c;
         std::string note;
-        if (!spec_compile(s.dev, SpecVariant{kind == 0 ? SpecKind::kReads : SpecKind::kRecords, s.dev.lds.mask, kind == 0 && with_variants != 0, binned != 0 || s.dev.lds.binned != 0}, arch, c, note))
-            throw Error(note);
+        if (!spec_compile(s.dev, variant, arch, c, note)) throw Error(note);
         *code_bytes = c.code.size();
         if (seconds) *seconds = c.seconds;
         if (out_path && *out_path) {
@@ -1523,6 +1540,7 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         HIP_CHECK(hipSetDevice(s->device));
         rsq_sim::JobText &job = s->job;
         job.clear();
+        if (const int rc = check_block_range(*s, block_lo, block_hi)) return rc;      // before anything is sized from the range (block_hi - block_lo is unsigned)
         const size_t chunk_bytes = options().job_chunk_bytes > 0 ? (size_t)options().job_chunk_bytes : kJobChunkBytes;
         if (!batch_blocks)                                          // about 4 M pairs per call (large launches), at least 2000 blocks
             batch_blocks = (uint32_t)std::min(100000.0, std::max(2000.0, 4e6 * (double)s->total_blocks / (double)std::max<uint64_t>(1, s->total_pairs)));
@@ -1570,6 +1588,7 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         }
         *r1_bytes = job.bytes[0];
         *r2_bytes = job.bytes[1];
+        job.complete = true;
         return (int)RSQ_OK;
     });
 }
@@ -1585,6 +1604,10 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
     REQUIRE(s && r1_path && r2_path, "null argument");
     return guard([&] {
         const rsq_sim::JobText &job = s->job;
+        if (!job.complete) {
+            g_last_error = "rsq_sim_job_write: there is no generated text (rsq_sim_job_generate has not run to its end on this simulator, or rsq_sim_job_free has released it)";
+            return (int)RSQ_ESTATE;
+        }
         const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 1u;
         const char *paths[2] = {r1_path, r2_path};
         const uint64_t offsets[2] = {r1_offset, r2_offset};
@@ -1612,10 +1635,20 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
                 HIP_CHECK(hipSetDevice(s->device));
                 const uint64_t begin = job.bytes[f] * t / T, end = job.bytes[f] * (t + 1) / T;
                 if (begin == end) return;
-                hipStream_t st;
-                HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                char *host[2] = {nullptr, nullptr};
-                for (char *&h : host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), kJobSliceBytes, hipHostMallocDefault));
+                struct Staging {                                    // released however the thread leaves (a failed pwrite or HIP call throws)
+                    hipStream_t st = nullptr;
+                    char *host[2] = {nullptr, nullptr};
+                    ~Staging() {
+                        if (st) (void)hipStreamSynchronize(st);     // a copy still in flight must not land in freed memory
+                        for (char *h : host)
+                            if (h) (void)hipHostFree(h);
+                        if (st) (void)hipStreamDestroy(st);
+                    }
+                } staging;
+                HIP_CHECK(hipStreamCreateWithFlags(&staging.st, hipStreamNonBlocking));
+                for (char *&h : staging.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), kJobSliceBytes, hipHostMallocDefault));
+                hipStream_t st = staging.st;
+                char *const *host = staging.host;
                 struct Slice {
                     const char *src;
                     size_t n;
@@ -1642,8 +1675,6 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
                     }
                 }
                 HIP_CHECK(hipStreamSynchronize(st));
-                for (char *h : host) (void)hipHostFree(h);
-                (void)hipStreamDestroy(st);
             } catch (const std::exception &e) {
                 fail(e.what());
             }

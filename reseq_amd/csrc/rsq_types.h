@@ -104,7 +104,9 @@ struct FamilyGeo {
     uint32_t off32;              // DevSim::pool32: [table of the profile][table_rows][slot]
     uint32_t lds;                // image: the staged leading margins, [table of the image][lds_rows][slot]; kNoLds: not staged (the indel family's margin 0 when it does not fit)
     uint32_t lds_rows;           // quality: rows of margins 0 and 1; base call, indel: rows of margin 0
+    uint32_t lds_stride;         // floats from one table's staged rows to the next table's: lds_rows * slot, padded to an ODD number of 16-byte groups (below)
     uint32_t lds2;               // base call: margin 2 over the number of errors, [table of the image][last[2] + 1][slot]; kNoLds: read from device memory
+    uint32_t lds2_stride;        // its table stride, padded likewise
     uint32_t values;             // image, in BYTES from its start: the outcome value of every column, [table of the image][slot] (0 in the pad columns)
     uint32_t values_src;         // DevSim::par0, bytes: the same for all tables of the profile (what an image copies)
 };
@@ -129,6 +131,12 @@ struct LdsPlan {
     uint32_t quads_q;            // 16-byte groups of a quality row that hold columns: one of kQualityQuads
     uint32_t rate_rows_q, rate_rows_b;      // rows 0..n-1 of quality margin 3 / base-call margin 3 are staged
     uint32_t q3_off, b3_off;     // [4 img_tiles][rate_rows_q] quality slots, [20 img_tiles][rate_rows_b] base-call slots
+    // Table strides of the staged blocks are ODD numbers of 16-byte groups.  A ds_read_b128 serves 16 lanes per LDS cycle, a lane's 16 bytes from one of 16 bank groups
+    // (address / 16 mod 16), and lanes that read DIFFERENT addresses in one bank group take turns.  The lanes of a wave sit at (nearly) one read position and mostly
+    // at error rate 0, so what differs between them is the TABLE (the template base) and the quality rows: with a table stride that is a multiple of 16 groups -- 80
+    // quality rows of 11 groups, 64 error-rate rows of 11 groups -- the same row of the four tables fell into ONE bank group, a four-way conflict on every read of
+    // the error-rate margin.  With an odd stride the tables' copies of a row lie in four different groups.
+    uint32_t q3_stride, b3_stride;
     uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4 img_tiles quality slots], the quality rows over the read position of the wave's current steps
     uint32_t total_words;        // size of the image
     FamilyGeo q, b, i;           // the three families' common geometry

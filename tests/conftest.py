@@ -64,7 +64,7 @@ def p0_profile_path(workdir):
     return str(path)
 
 
-OPTION_DEFAULTS = {"fill_mode": -1, "chain_warmup": -1}          # every other option: 0
+OPTION_DEFAULTS = {"fill_mode": -1, "chain_warmup": -1, "specialize": 1}          # every other option: 0
 
 
 @pytest.fixture

@@ -89,6 +89,30 @@ def test_no_cpu_fallback_without_a_gpu(tiny_profile_path):
     p.close()
 
 
+def test_read_kernel_compiles_for_a_profile_without_a_gpu(tiny_profile_path, workdir):
+    """rsq_profile_compile_read_kernel: the library carries the read kernels' source and hiprtc compiles it with the profile's plan as literals -- host only (the
+    compiler cross-compiles), so the build of the run-time route is checked here; the code object holds the kernel, and a second request comes from the kernel cache"""
+    import subprocess
+    api.set_kernel_cache_dir(str(workdir / "kernel_cache"))
+    try:
+        p = api.Profile(tiny_profile_path)
+        for kind, var, name in ((0, False, "rsq_spec_fill_reads"), (0, True, "rsq_spec_fill_reads"), (1, False, "rsq_spec_fill_records")):
+            out = workdir / f"spec_{kind}_{int(var)}.hsaco"
+            size, seconds = p.compile_read_kernel(kind, with_variants=var, out_path=str(out))
+            assert size == out.stat().st_size > 10000 and seconds > 0
+            syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--symbols", str(out)], capture_output=True, text=True, check=True).stdout
+            assert any(l.split()[-1] == name and " FUNC " in l for l in syms.splitlines() if l.strip()), syms[-2000:]
+            size2, seconds2 = p.compile_read_kernel(kind, with_variants=var)
+            assert size2 == size and seconds2 == 0.0                       # from the cache directory
+        assert len(list((workdir / "kernel_cache").glob("rsq_spec_*.hsaco"))) == 3
+        with pytest.raises(api.RsqError) as e:                            # the compiler's complaint reaches the caller
+            p.compile_read_kernel(0, arch="gfx000")
+        assert "failed" in str(e.value)
+        p.close()
+    finally:
+        api.set_kernel_cache_dir(None)
+
+
 def test_gzip_fasta_loads_like_plain(workdir):
     """SeqAn opens .gz references transparently (SURVEY.md section 8(b) inputs); so does rsq_ref_load_fasta"""
     import gzip

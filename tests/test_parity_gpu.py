@@ -170,6 +170,45 @@ def test_every_draw_through_the_route_behind_the_screen(workdir, rsq_options):
 
 
 @pytest.mark.gpu
+def test_read_kernel_compiled_for_the_profile_and_the_library_instantiation(workdir, rsq_options):
+    """Every other test runs the read kernels compiled for the loaded profile at run time (hiprtc: rsq_sim_specialize says so).  Here: that this IS what runs, that a
+    second simulator of the same profile takes the code object from the kernel cache, and -- option specialize 0 -- the same cases through the library's own
+    instantiations (any profile's shapes as run-time values)"""
+    from reseq_amd import api, synth
+    api.set_kernel_cache_dir(str(workdir / "kernel_cache"))
+    try:
+        ppath, fpath, _ = P.make_inputs(workdir, "spec", synth.TINY, [5000, 3210])
+        notes = []
+        for _ in range(2):
+            prof, ref = api.Profile(ppath), api.Reference(fpath, 0)
+            sim = api.Simulator(prof, ref, 0)
+            sim.prepare(7, 3000)
+            done, note = sim.specialize(0)
+            assert done and "rsq_spec_fill_reads compiled for this profile" in note, note
+            done, note1 = sim.specialize(1)
+            assert done and "rsq_spec_fill_records" in note1, note1
+            notes.append(note)
+            sim.close(), ref.close(), prof.close()
+        assert " ms)" in notes[0] and "kernel cache" in notes[1], notes
+    finally:
+        api.set_kernel_cache_dir(None)
+    rsq_options("specialize", 0)
+    prof, ref = api.Profile(ppath), api.Reference(fpath, 0)
+    sim = api.Simulator(prof, ref, 0)
+    sim.prepare(7, 3000)
+    done, note = sim.specialize(0)
+    assert not done and "specialize is 0" in note
+    sim.close(), ref.close(), prof.close()
+    P.case_sieve_and_reads_tiny(GpuBackend, workdir)
+    P.case_p0_reads(GpuBackend, workdir)
+    P.case_ragged_tables(GpuBackend, workdir)
+    P.case_p0_tiles(GpuBackend, workdir, 3)
+    P.case_error_model_p0(GpuBackend, workdir)
+    P.case_variants_indels(GpuBackend, workdir)
+    P.case_adapter_only(GpuBackend, workdir)
+
+
+@pytest.mark.gpu
 def test_error_rate_rows_fall_back_to_hbm(workdir, rsq_options):
     """only row 0 of the error-rate margins staged: every position with a systematic error rate takes the HBM branch"""
     rsq_options("rate_rows", 1)

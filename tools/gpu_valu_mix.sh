@@ -10,7 +10,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/valu_mix/p*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_fill_reads" in r["Kernel_Name"]:
+        if "fill_reads" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 steps = 47.5e6
 for k, v in sorted(acc.items()):
