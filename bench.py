@@ -33,6 +33,8 @@ GENOME = 4_641_652
 PAIRS = 10_000_000
 A_PAIR = 1436                 # algorithmic HBM bytes per 2x150 pair (DESIGN.md "Roofline")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+LDS_BYTES_PER_PAIR = 2 * 150 * 808   # algorithmic LDS bytes per 2x150 pair (808 B of single-precision table rows per base)
+LDS_PEAK_TBS = 256 * 256 * 2.4e9 / 1e12   # MI355X_MICROARCH.md "LDS": 256 B/clk/CU for ds_read_b64/b128, 256 CUs, 2.4 GHz = 157 TB/s
 TA_CYCLES_PER_LOAD = 23.0     # a wave-level 16-byte load occupies the CU's vector-memory path that long (exp/ta_bench.hip)
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
@@ -252,7 +254,7 @@ def committed_counters(tiles=1):
         out = {"source": f"profiles/{tag}_pmc.json", "kernel_source_hash_when_collected": recorded, "counters_stale": recorded != kernel_source_hash(), "kernel": kernel, "kernel_cycles": cycles, "kernel_ms_at_2.4GHz": cycles / 2.4e6,
                "vmem_loads_per_launch": c["SQ_INSTS_VMEM_RD"], "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
                "vmem_issue_frac": c["SQ_INSTS_VMEM_RD"] / N_CU * TA_CYCLES_PER_LOAD / cycles, "ta_busy_frac": c["TA_BUSY_avr"] / cycles,
-               "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * cycles), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / 4 / (N_CU * cycles),
+               "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * cycles), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (N_CU * cycles),
                "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]}
         tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
         out["hbm_bytes_per_launch"] = float(json.load(open(tfile))["hbm_bytes_per_launch"]) if os.path.exists(tfile) else None
@@ -556,10 +558,14 @@ def main():
                          "secondary": None if not counters else {
                              "resource": "VALU issue", "frac": counters["valu_busy_frac"], "vmem_issue_frac": counters["vmem_issue_frac"], "ta_busy_frac": counters["ta_busy_frac"],
                              "lds_busy_frac": counters["lds_busy_frac"], "lds_bank_conflict_frac": counters["lds_bank_conflict_frac"],
+                             "lds_roofline": {"achieved": LDS_BYTES_PER_PAIR * (pairs / launches) / avg_fill_s / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                                              "frac": LDS_BYTES_PER_PAIR * (pairs / launches) / avg_fill_s / 1e12 / LDS_PEAK_TBS, "bytes_per_pair": LDS_BYTES_PER_PAIR,
+                                              "note": "algorithmic LDS bytes (SURVEY.md 8(d)) over this run's launch time; the array's measured busy share is lds_busy_frac, "
+                                                      "of which lds_bank_conflict_frac are conflict cycles"},
                              "kernel": counters["kernel"], "kernel_ms_when_profiled": counters["kernel_ms_at_2.4GHz"], "source": counters["source"],
                              "counters_stale": counters["counters_stale"],
                              "note": "fractions of the kernel's cycles from the committed PMC collection: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles); "
-                                     "SQ_INSTS_VMEM_RD / 256 CUs x 23 cycles / cycles; TA_BUSY_avr / cycles"}},
+                                     "SQ_INSTS_VMEM_RD / 256 CUs x 23 cycles / cycles; TA_BUSY_avr / cycles; SQ_LDS_IDX_ACTIVE (LDS-array cycles, all CUs) / (256 CUs x cycles)"}},
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,
         }

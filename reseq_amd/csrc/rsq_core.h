@@ -198,8 +198,8 @@ RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &..
 // outcome of the double-precision recipe above, otherwise the lane repeats the draw in double precision (draw<NM>, from HBM).
 // Rows are float copies of the tables (DevTable::off32), four columns per 16-byte load, pad columns zero.
 //
-// Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns and keeps one partial sum per quad of columns; S = their total.
-// Pass 2 finds the quad in which the sum from the top first exceeds r = u*S on those partial sums (no loads), reloads that quad
+// Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns from the top quad down and keeps, per quad, the sum of the columns from the top down to it; S = the
+// last of them.  Pass 2 finds the quad in which the sum from the top first exceeds r = u*S among those sums (no loads), reloads that quad
 // and finds the column.  Let T(j) be the exact sum of the columns above and including j (over the double-precision values) and
 // T the exact total: the reference returns the highest j >= 1 with T(j) > u*T up to its own rounding (relative 1e-14), else 0.
 // Error of the single-precision quantities, w = 2^-24, all terms non-negative: a product carries (1+w)^7 (four roundings to
@@ -273,33 +273,37 @@ template <int Q, class... Rs>
 RSQ_HD bool draw_screened(uint32_t word, uint32_t &col, const Rs &...rs) {
     constexpr int G = Q % RSQ_SCREEN_BATCH == 0 ? RSQ_SCREEN_BATCH : (Q % 2 == 0 ? 2 : 1);      // quads per batch
     constexpr bool kKeep = Q <= 2;                           // short rows: the products stay in registers, pass 2 loads nothing
-    float part[Q];
+    // pass 1 runs from the top quad down with ONE running sum, kept as a pair (the columns 0, 1 and 2, 3 of the quads so far): top[c] = the sum of the quads c and
+    // above, S = top[0].  A term passes one addition inside its quad, at most Q in the running pair and one across the pair: the bounds above hold (Q + 2 additions
+    // in S and in a sum from the top, four more inside the chosen quad).  [One sum instead of a sum per quad, a total and a second pass over the per-quad sums: 20
+    // additions and the compiler's shuffles to pair them up less per draw of 40 columns.]
+    float top[Q];
     Quad kept[kKeep ? Q : 1];
-    float S = 0.f;
+    Float2 run;
+    run.x = run.y = 0.f;
 #pragma unroll
-    for (int g = 0; g < Q; g += G) {
+    for (int g = Q - G; g >= 0; g -= G) {
         Quad p[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) p[i] = prod_quad((uint32_t)(g + i), rs...);
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const Float2 half = p[i].lo + p[i].hi;
-            part[g + i] = half.x + half.y;
-            S += part[g + i];
+        for (int i = G; i--;) {
+            run = run + (p[i].lo + p[i].hi);
+            top[g + i] = run.x + run.y;
             if constexpr (kKeep) kept[g + i] = p[i];
         }
         RSQ_SCHED_BARRIER();                                 // keeps the scheduler from hoisting the loads of every batch to the top (registers)
     }
+    const float S = top[0];
     const float r = ((float)word * 2.3283064365386963e-10f) * S;      // u = word * 2^-32, rounded to single precision
     const float delta = kScreenSafety * (float)(2 * Q + 24) * 5.9604644775390625e-08f * S;
     // the sums from the top never decrease: the quads whose sum exceeds r are the lowest ones; count them, keep the last sum that does not
-    float top = 0.f, above = 0.f;
+    float above = 0.f;
     uint32_t below = 0;
 #pragma unroll
     for (int c = Q; c--;) {
-        top += part[c];
-        const bool hit = top > r;
-        above = hit ? above : top;
+        const bool hit = top[c] > r;
+        above = hit ? above : top[c];
         below += hit ? 1u : 0u;
     }
     const uint32_t fc = below ? below - 1u : 0u;             // below == 0: u rounded to 1, or S is 0 (left undecided)
@@ -615,6 +619,13 @@ struct ReadMachine {
     uint32_t iter_m, hard_clip, tail_length, pos_tail, n_indels;
     uint32_t start_cut_word;           // h0.w3, needed only if the read starts inside the adapter
 
+    // a machine without a read: every step() returns false at once (the lanes of a wave beyond the end of the batch)
+    RSQ_HD void idle() {
+        par = FillState{};
+        cg = CigarRun{'M', 0, 0};
+        phase = kDone;
+        seg = tile_id = tbase = org_pos = org_len = adapter_id = adapter_a0 = iter_m = hard_clip = tail_length = pos_tail = n_indels = start_cut_word = 0;
+    }
     template <class Tab, class Src>
     RSQ_HD void init(const DevSim &S, const Tab &tab, const Stream &st, uint32_t seg_, uint32_t tile, uint32_t fragment_length, const Src &src) {
         seg = seg_;

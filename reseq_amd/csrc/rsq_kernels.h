@@ -2252,6 +2252,7 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         RSQ_LDS float *ring = img + RSQ_PLAN(S, ring_off) + (threadIdx.x >> 6) * kRingSlots * RSQ_PLAN(S, ring_stride);
         ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
         bool running = active;
+        m.idle();
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
         const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
@@ -2264,7 +2265,7 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, qbase, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
-            if (running) running = m.step(S, tab, st, src, out);
+            running = m.step(S, tab, st, src, out);          // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
             __builtin_amdgcn_wave_barrier();
         }
     }
