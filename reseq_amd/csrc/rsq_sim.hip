@@ -1629,7 +1629,15 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
             std::lock_guard<std::mutex> lock(message_mutex);
             if (!failed.exchange(true)) message = m;
         };
-        // thread t of file f writes bytes [bytes * t / T, bytes * (t + 1) / T) of the file's text: slices of 32 MB, the copy of one overlapping the write of the one before
+        // Option job_write_direct: the file is also opened with O_DIRECT, and what lies on whole blocks of the file (kDirectAlign) bypasses the page cache: writers of
+        // ONE file then do not take turns on its inode (buffered writes into one file serialise there however many ranks write, profiles/r03_g_*).  A rank's byte
+        // range begins and ends anywhere, so its head and tail up to the next block boundary go through the buffered descriptor.  Falls back to buffered writes
+        // when the file system refuses O_DIRECT (tmpfs does).
+        constexpr uint64_t kDirectAlign = 4096;
+        int direct_fds[2] = {-1, -1};
+        if (options().job_write_direct)
+            for (int f = 0; f < 2; ++f) direct_fds[f] = open(paths[f], O_WRONLY | O_DIRECT);
+        // thread t of file f writes bytes [bytes * t / T, bytes * (t + 1) / T) of the file's text: pieces of at most 32 MB, the copy of one overlapping the write of the one before
         auto work = [&](int f, uint32_t t) {
             try {
                 HIP_CHECK(hipSetDevice(s->device));
@@ -1646,32 +1654,55 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
                     }
                 } staging;
                 HIP_CHECK(hipStreamCreateWithFlags(&staging.st, hipStreamNonBlocking));
-                for (char *&h : staging.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), kJobSliceBytes, hipHostMallocDefault));
+                for (char *&h : staging.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), kJobSliceBytes, hipHostMallocDefault));      // page-aligned: fit for O_DIRECT
                 hipStream_t st = staging.st;
                 char *const *host = staging.host;
-                struct Slice {
-                    const char *src;
-                    size_t n;
+                struct Piece {
                     uint64_t at;                                    // place in the file's text
+                    size_t n;
+                    bool direct;
                 };
-                std::vector<Slice> slices;
-                uint64_t chunk_at = 0;
-                for (size_t c = 0; c < job.chunks[f].size(); ++c) {
-                    const uint64_t c_end = chunk_at + job.used[f][c], from = std::max(begin, chunk_at), to = std::min(end, c_end);
-                    for (uint64_t a = from; a < to; a += kJobSliceBytes) slices.push_back(Slice{job.chunks[f][c]->as<char>() + (a - chunk_at), (size_t)std::min<uint64_t>(kJobSliceBytes, to - a), a});
-                    chunk_at = c_end;
+                std::vector<Piece> pieces;
+                {
+                    const uint64_t file_begin = offsets[f] + begin, file_end = offsets[f] + end;      // in the file
+                    uint64_t a = file_begin;
+                    const bool direct = direct_fds[f] >= 0;
+                    if (direct && a % kDirectAlign) {               // the head up to the first block boundary
+                        const uint64_t to = std::min(file_end, (a / kDirectAlign + 1) * kDirectAlign);
+                        pieces.push_back(Piece{a - offsets[f], (size_t)(to - a), false});
+                        a = to;
+                    }
+                    const uint64_t whole_end = direct ? std::max(a, file_end / kDirectAlign * kDirectAlign) : file_end;
+                    for (; a < whole_end; a += std::min<uint64_t>(kJobSliceBytes, whole_end - a)) pieces.push_back(Piece{a - offsets[f], (size_t)std::min<uint64_t>(kJobSliceBytes, whole_end - a), direct});
+                    if (a < file_end) pieces.push_back(Piece{a - offsets[f], (size_t)(file_end - a), false});      // the tail behind the last whole block
                 }
-                auto copy = [&](size_t i) { HIP_CHECK(hipMemcpyAsync(host[i & 1], slices[i].src, slices[i].n, hipMemcpyDeviceToHost, st)); };
-                if (!slices.empty()) copy(0);
-                for (size_t i = 0; i < slices.size() && !failed; ++i) {
+                // the text lies in a list of device arrays: a piece may reach over the end of one
+                auto copy = [&](size_t i) {
+                    uint64_t chunk_at = 0, at = pieces[i].at;
+                    size_t left = pieces[i].n, put = 0;
+                    for (size_t c = 0; c < job.chunks[f].size() && left; ++c) {
+                        const uint64_t c_end = chunk_at + job.used[f][c];
+                        if (at < c_end) {
+                            const size_t n = (size_t)std::min<uint64_t>(left, c_end - at);
+                            HIP_CHECK(hipMemcpyAsync(host[i & 1] + put, job.chunks[f][c]->as<char>() + (at - chunk_at), n, hipMemcpyDeviceToHost, st));
+                            at += n, put += n, left -= n;
+                        }
+                        chunk_at = c_end;
+                    }
+                    if (left) throw Error("internal: a piece of the job's text lies outside its arrays");
+                };
+                if (!pieces.empty()) copy(0);
+                for (size_t i = 0; i < pieces.size() && !failed; ++i) {
                     HIP_CHECK(hipStreamSynchronize(st));
-                    if (i + 1 < slices.size()) copy(i + 1);
+                    if (i + 1 < pieces.size()) copy(i + 1);
                     size_t done = 0;
-                    while (done < slices[i].n) {
-                        const ssize_t w = pwrite(fds[f], host[i & 1] + done, slices[i].n - done, (off_t)(offsets[f] + slices[i].at + done));
+                    const int fd = pieces[i].direct ? direct_fds[f] : fds[f];
+                    while (done < pieces[i].n) {
+                        const ssize_t w = pwrite(fd, host[i & 1] + done, pieces[i].n - done, (off_t)(offsets[f] + pieces[i].at + done));
                         if (w < 0 && errno == EINTR) continue;
                         if (w <= 0) throw Error(std::string("writing '") + paths[f] + "' failed: " + (w < 0 ? strerror(errno) : "no space"));
                         done += (size_t)w;
+                        if (pieces[i].direct && done < pieces[i].n && done % kDirectAlign) throw Error(std::string("writing '") + paths[f] + "': a direct write stopped inside a block");
                     }
                 }
                 HIP_CHECK(hipStreamSynchronize(st));
@@ -1683,8 +1714,10 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
         for (int f = 0; f < 2; ++f)
             for (uint32_t t = 0; t < T; ++t) pool.emplace_back(work, f, t);
         for (std::thread &t : pool) t.join();
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f) {
+            if (direct_fds[f] >= 0) close(direct_fds[f]);
             if (close(fds[f]) != 0) fail(std::string("closing '") + paths[f] + "' failed: " + strerror(errno));
+        }
         if (failed) throw Error(message);
         return (int)RSQ_OK;
     });
