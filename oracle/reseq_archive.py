@@ -258,14 +258,48 @@ def _fmt_double(x):
     return "%.17e" % x
 
 
+# The token rules that could not be checked against a Boost-written file, as switches (reseq_amd/csrc/rsq_archive.h Grammar): the default is the recalled rule set.
+DEFAULT_GRAMMAR = dict(item_version=1, array_class_info=True, array_count=True, pair_class_info=True, arithmetic_vector_class_info=False)
+
+
+def all_grammars():
+    """every combination of the doubtful rules, the recalled one first"""
+    out = [dict(DEFAULT_GRAMMAR)]
+    for iv in (1, 2, 3, 0):
+        for aci in (True, False):
+            for ac in (True, False):
+                for pci in (True, False):
+                    for avci in (False, True):
+                        g = dict(item_version=iv, array_class_info=aci, array_count=ac, pair_class_info=pci, arithmetic_vector_class_info=avci)
+                        if g != DEFAULT_GRAMMAR:
+                            out.append(g)
+    return out
+
+
+def _has_class_info(t, g):
+    if t.kind == "arr":
+        return g["array_class_info"]
+    if t.kind == "pair":
+        return g["pair_class_info"]
+    if t.kind == "vec":
+        return t.elem.kind not in "uifb" or g["arithmetic_vector_class_info"]
+    return t.class_info
+
+
+def _has_item_version(t, g):
+    iv = g["item_version"]
+    return iv == 3 or (iv == 1 and t.elem.kind != "b") or (iv == 2 and t.elem.kind not in "uifb")
+
+
 class _Writer:
-    def __init__(self, library_version):
+    def __init__(self, library_version, grammar=None):
         self.tok = ["22 serialization::archive", str(library_version)]
         self.seen = set()
         self.library_version = library_version
+        self.g = dict(DEFAULT_GRAMMAR, **(grammar or {}))
 
     def put(self, t, v):
-        if t.class_info and t.name not in self.seen:
+        if _has_class_info(t, self.g) and t.name not in self.seen:
             self.seen.add(t.name)
             self.tok.append("0 0")
         k = t.kind
@@ -279,13 +313,14 @@ class _Writer:
             self.tok.append("%d %s" % (len(v.encode()), v))
         elif k == "vec":
             self.tok.append(str(len(v)))
-            if t.elem.kind != "b" and self.library_version > 3:
+            if _has_item_version(t, self.g) and self.library_version > 3:
                 self.tok.append("0")
             self.items(t.elem, v)
         elif k == "arr":
             if len(v) != t.n:
                 raise ValueError("%s given %d items" % (t.name, len(v)))
-            self.tok.append(str(t.n))
+            if self.g["array_count"]:
+                self.tok.append(str(t.n))
             self.items(t.elem, v)
         elif k == "pair":
             self.put(t.members[0][1], v[0])
@@ -308,15 +343,15 @@ class _Writer:
                 self.put(e, x)
 
 
-def dumps(type_expr, value, library_version=17):
-    w = _Writer(library_version)
+def dumps(type_expr, value, library_version=17, grammar=None):
+    w = _Writer(library_version, grammar)
     w.put(get_type(type_expr), value)
     return " ".join(w.tok) + "\n"
 
 
-def write_archive(path, type_expr, value, library_version=17):
+def write_archive(path, type_expr, value, library_version=17, grammar=None):
     with open(path, "w") as f:
-        f.write(dumps(type_expr, value, library_version))
+        f.write(dumps(type_expr, value, library_version, grammar))
 
 
 # ------------------------------------------------------------------------------------------------------------ reader

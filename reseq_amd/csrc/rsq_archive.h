@@ -17,6 +17,7 @@
 //   std::vector<bool> "<count>" + items
 //   std::array<T,N>   its class info, then the C array inside: "<N>" + items
 //   std::pair         its class info, first, second
+// The rules marked doubtful in SURVEY.md appendix A are switches (Grammar below): a file is read under the recalled set first and, if that fails, under the others.
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -34,6 +35,40 @@ namespace archive {
 
 struct Type;
 using TypeP = const Type *;
+
+// The token rules above that cannot be checked against a Boost-written file in this image, as switches.  The default-constructed Grammar is the recalled rule set;
+// Grammar::alternatives() lists every combination, the recalled one first.  A file that does not parse under one grammar is tried under the next: the schema's fixed
+// sizes (std::array<T, N> counts, the 3 x 4^10 surroundings, the margin counts of LogIPF<N>), "tracking must be 0" and "no token left after the last member" are
+// the self-check that tells the right one -- a surplus or missing token shifts everything behind it.
+struct Grammar {
+    enum ItemVersion : uint8_t { kNever = 0, kAllButBool = 1, kClassItemsOnly = 2, kEveryVector = 3 };
+    uint8_t item_version = kAllButBool;           // which std::vector counts are followed by "<item_version>" (library version > 3)
+    bool array_class_info = true;                 // std::array<T, N> is a class type: "<tracking> <version>" the first time
+    bool array_count = true;                      // the C array inside a std::array is preceded by its count
+    bool pair_class_info = true;                  // std::pair is a class type
+    bool arithmetic_vector_class_info = false;    // std::vector of an arithmetic type is a class type too
+    bool is_default() const { return item_version == kAllButBool && array_class_info && array_count && pair_class_info && !arithmetic_vector_class_info; }
+    std::string name() const {
+        static const char *iv[] = {"no item_version", "item_version behind every vector count but vector<bool>'s", "item_version behind the counts of vectors of class-type items only",
+                                   "item_version behind every vector count"};
+        return std::string(iv[item_version]) + "; std::array " + (array_class_info ? "with" : "without") + " class information, " + (array_count ? "with" : "without") +
+               " a count; std::pair " + (pair_class_info ? "with" : "without") + " class information; vectors of arithmetic types " +
+               (arithmetic_vector_class_info ? "with" : "without") + " class information";
+    }
+    static std::vector<Grammar> alternatives() {
+        std::vector<Grammar> out(1);                                    // the recalled rules first
+        for (uint8_t iv : {kAllButBool, kClassItemsOnly, kEveryVector, kNever})
+            for (bool aci : {true, false})
+                for (bool ac : {true, false})
+                    for (bool pci : {true, false})
+                        for (bool avci : {false, true}) {
+                            Grammar g;
+                            g.item_version = iv, g.array_class_info = aci, g.array_count = ac, g.pair_class_info = pci, g.arithmetic_vector_class_info = avci;
+                            if (!g.is_default()) out.push_back(g);
+                        }
+        return out;
+    }
+};
 
 struct Member {
     std::string name;
@@ -158,7 +193,8 @@ struct ClassInfoSite {
 
 class Reader {
    public:
-    Reader(const char *begin, const char *end, size_t n_types, const std::string &what) : p_(begin), end_(end), seen_(n_types, 0), what_(what) {
+    Reader(const char *begin, const char *end, size_t n_types, const std::string &what, const Grammar &grammar = Grammar())
+        : p_(begin), end_(end), seen_(n_types, 0), what_(what), g_(grammar) {
         const std::string sig = str();
         if (sig != "serialization::archive") fail("not a Boost text archive");
         library_version_ = (uint32_t)unsigned_int();
@@ -171,7 +207,7 @@ class Reader {
     uint32_t library_version() const { return library_version_; }
     void read(TypeP t, Node *out) {
         current_ = t;
-        if (t->class_info && !seen_[t->id]) {
+        if (has_class_info(t) && !seen_[t->id]) {
             seen_[t->id] = (uint32_t)sites_.size() + 1u;
             ClassInfoSite site;
             site.type = t->name;
@@ -210,12 +246,14 @@ class Reader {
             }
             case Type::VEC: {
                 const uint64_t count = unsigned_int();
-                if (t->elem->kind != Type::BOOL && library_version_ > 3) unsigned_int();   // item_version
+                const bool item_version = g_.item_version == Grammar::kEveryVector || (g_.item_version == Grammar::kAllButBool && t->elem->kind != Type::BOOL) ||
+                                          (g_.item_version == Grammar::kClassItemsOnly && !t->elem->numeric());
+                if (item_version && library_version_ > 3) unsigned_int();
                 items(t->elem, count, out);
                 break;
             }
             case Type::ARR: {
-                const uint64_t count = unsigned_int();
+                const uint64_t count = g_.array_count ? unsigned_int() : t->n;
                 if (count != t->n) fail("array " + t->name + " holds " + std::to_string(count) + " items");
                 items(t->elem, count, out);
                 break;
@@ -247,6 +285,15 @@ class Reader {
     }
 
    private:
+    bool has_class_info(TypeP t) const {
+        switch (t->kind) {
+            case Type::CLS: return true;
+            case Type::ARR: return g_.array_class_info;
+            case Type::PAIR: return g_.pair_class_info;
+            case Type::VEC: return !t->elem->numeric() || g_.arithmetic_vector_class_info;
+            default: return false;
+        }
+    }
     void items(TypeP e, uint64_t count, Node *out) {
         if (count > (uint64_t)(end_ - p_)) fail("item count " + std::to_string(count) + " larger than the file");
         const TypeP holder = current_;
@@ -293,7 +340,7 @@ class Reader {
         std::string chain;
         for (size_t k = path_.size(); k-- && chain.size() < 600;) {
             const TypeP t = path_[k].holder;
-            if (!t || !t->class_info) continue;
+            if (!t || !has_class_info(t)) continue;
             const uint32_t site = seen_[t->id];
             chain += (chain.empty() ? "" : "; ") + t->name + (site ? ": class info read at byte " + std::to_string(sites_[site - 1].byte) + " (" + sites_[site - 1].path + ")" : ": no class info read");
         }
@@ -364,6 +411,7 @@ class Reader {
     TypeP current_ = nullptr;
     std::string what_, root_;
     uint32_t library_version_ = 0;
+    Grammar g_;
 
    public:
     void set_root(const std::string &name) { root_ = name; }

@@ -547,31 +547,45 @@ Profile Profile::load_archives(const std::string &stats_path, const std::string 
     Profile p;
     uint64_t creation_time = 0;
     uint32_t versions[2] = {0, 0};
+    std::string grammar_note;
+    // one file under the recalled token rules, then under the alternatives (archive::Grammar): the first that reads the file to its end with every fixed size in
+    // place is taken; if none does, the recalled rules' message (member path, type, class-info sites) is the error
+    auto parse = [&](const std::string &path, const char *root, archive::TypeP type, uint32_t &version, Node &out) {
+        const std::vector<char> buf = slurp(path);
+        std::string first_error;
+        for (const archive::Grammar &g : archive::Grammar::alternatives()) {
+            try {
+                archive::Reader r(buf.data(), buf.data() + buf.size(), types.s.size(), path, g);
+                r.set_root(root);
+                version = r.library_version();
+                Node n;
+                r.read(type, &n);
+                r.expect_end();
+                out = std::move(n);
+                if (!g.is_default()) grammar_note += path + " does not follow the recalled token rules but parses as: " + g.name() + ". ";
+                return;
+            } catch (const std::exception &e) {
+                if (first_error.empty()) first_error = e.what();
+            }
+        }
+        throw Error(first_error + "; no alternative of the doubtful token rules (" + std::to_string(archive::Grammar::alternatives().size()) + " combinations, rsq_archive.h Grammar) reads the file either");
+    };
     {
-        const std::vector<char> buf = slurp(stats_path);
-        archive::Reader r(buf.data(), buf.data() + buf.size(), types.s.size(), stats_path);
-        r.set_root("DataStats");
-        versions[0] = r.library_version();
         Node st;
-        r.read(types.data_stats, &st);
-        r.expect_end();
+        parse(stats_path, "DataStats", types.data_stats, versions[0], st);
         creation_time = st["creation_time_"].uint();
         fill_from_stats(p, st);
     }
     if (p.total_number_reads == 0) throw Error("the statistics in " + stats_path + " hold no reads");   // main.cpp:830-832
     std::string warn;
     {
-        const std::vector<char> buf = slurp(ipf_path);
-        archive::Reader r(buf.data(), buf.data() + buf.size(), types.s.size(), ipf_path);
-        r.set_root("ProbabilityEstimates");
-        versions[1] = r.library_version();
         Node pe;
-        r.read(types.probability_estimates, &pe);
-        r.expect_end();
+        parse(ipf_path, "ProbabilityEstimates", types.probability_estimates, versions[1], pe);
         if (pe["stats_creation_time_"].uint() != creation_time)   // ProbabilityEstimates.cpp:1079-1083: ReSeq would refit from scratch
             throw Error(ipf_path + " was fitted to another statistics file than " + stats_path + " (creation times differ); fitting is not part of this build");
         fill_from_estimates(p, pe, precision_aim, warn);
     }
+    warn += grammar_note;
     // said every time: the token rules of the reader could not be checked against a file written by Boost itself (INTEGRATION.md "Profile files")
     warn += "read as Boost text archives of library version " + std::to_string(versions[0]) + " (" + stats_path + ") and " + std::to_string(versions[1]) + " (" + ipf_path +
             "); if tables look wrong, send the output of `reseq queryProfile --dumpArchiveLayout -s " + stats_path + "`. ";
@@ -595,16 +609,33 @@ std::string Profile::archive_layout(const std::string &stats_path, const std::st
             return;
         }
         out += "bytes\t" + std::to_string(buf.size()) + "\n";
-        std::unique_ptr<archive::Reader> r;
+        std::unique_ptr<archive::Reader> r, first;
         std::string error;
-        try {
-            r.reset(new archive::Reader(buf.data(), buf.data() + buf.size(), types.s.size(), path));
-            r->set_root(root);
-            out += "library_version\t" + std::to_string(r->library_version()) + "\n";
-            r->read(type, nullptr);
-            r->expect_end();
-        } catch (const std::exception &e) {
-            error = e.what();
+        for (const archive::Grammar &g : archive::Grammar::alternatives()) {          // the recalled token rules, then the alternatives; the first that fits is shown
+            std::string e_this;
+            try {
+                r.reset(new archive::Reader(buf.data(), buf.data() + buf.size(), types.s.size(), path, g));
+                r->set_root(root);
+                r->read(type, nullptr);
+                r->expect_end();
+            } catch (const std::exception &e) {
+                e_this = e.what();
+            }
+            if (e_this.empty()) {
+                error.clear();
+                out += "library_version\t" + std::to_string(r->library_version()) + "\n";
+                out += std::string("token_rules\t") + (g.is_default() ? "as recalled: " : "NOT as recalled: ") + g.name() + "\n";
+                break;
+            }
+            if (!first) {                                                              // no grammar fits: the recalled rules' sites and message are what is shown
+                first = std::move(r);
+                error = e_this;
+            }
+            r.reset();
+        }
+        if (!r) {
+            r = std::move(first);
+            if (r) out += "library_version\t" + std::to_string(r->library_version()) + "\n";
         }
         out += "byte\ttracking\tversion\ttype\tfirst object\n";
         if (r)

@@ -212,8 +212,9 @@ def from_rsqp(arrays, creation_time=1600000000, rng=None):
     return st, pe
 
 
-def write_profile_archives(stats_path, arrays, creation_time=1600000000, rng=None, ipf_path=None):
-    st, pe = from_rsqp(arrays, creation_time, rng)
-    ra.write_archive(stats_path, "DataStats", st)
-    ra.write_archive(ipf_path or str(stats_path) + ".ipf", "ProbabilityEstimates", pe)
+def write_profile_archives(stats_path, arrays, creation_time=1600000000, rng=None, ipf_path=None, grammar=None, trees=None):
+    """`grammar`: an alternative of the doubtful token rules (oracle/reseq_archive.py all_grammars); `trees`: (DataStats, ProbabilityEstimates) made earlier"""
+    st, pe = trees or from_rsqp(arrays, creation_time, rng)
+    ra.write_archive(stats_path, "DataStats", st, grammar=grammar)
+    ra.write_archive(ipf_path or str(stats_path) + ".ipf", "ProbabilityEstimates", pe, grammar=grammar)
     return st, pe

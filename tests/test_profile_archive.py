@@ -270,6 +270,44 @@ def test_error_paths(tiny_archives, tiny_profile_arrays, tmp_path):
         api.Profile(junk)
 
 
+# ------------------------------------------------------------------------------------------------------ the doubtful token rules
+def test_every_alternative_of_the_doubtful_token_rules_loads_to_the_same_tables(tiny_profile_arrays, tmp_path):
+    """The reader's token rules are recalled, not checked against a Boost-written file.  The doubtful ones are switches (rsq_archive.h
+    Grammar: item_version behind which vector counts, class information for std::array / std::pair / vectors of arithmetic types, the count inside a std::array); a
+    file that does not parse under the recalled set is read under the others, and the fixed sizes in the schema tell which fits.  The TINY profile written under
+    EVERY combination must load to bit-identical tables, and the warning must name the rules that fitted."""
+    import os
+    grammars = ra.all_grammars()
+    assert len(grammars) == 64 and grammars[0] == ra.DEFAULT_GRAMMAR
+    if not os.environ.get("RSQ_ALL_GRAMMARS"):              # every switch on its own, and every item_version rule with all the others flipped (all 64: RSQ_ALL_GRAMMARS=1, five minutes)
+        flips = lambda g: sum(g[k] != ra.DEFAULT_GRAMMAR[k] for k in g)
+        all_flipped = lambda g: all(g[k] != ra.DEFAULT_GRAMMAR[k] for k in g if k != "item_version")
+        grammars = [g for g in grammars if flips(g) <= 1 or all_flipped(g)]
+        assert len(grammars) == 12
+    trees = af.from_rsqp(tiny_profile_arrays, 1600000000, np.random.default_rng(7))        # binned tables with missing rows: every container type is in use
+    want = None
+    for k, g in enumerate(grammars):
+        path = str(tmp_path / f"g{k}.reseq")
+        af.write_profile_archives(path, tiny_profile_arrays, grammar=g, trees=trees)
+        got, warning = _product_arrays(path, None, str(tmp_path / f"g{k}.rsqp"))
+        if want is None:
+            want = got
+            assert "does not follow the recalled token rules" not in warning
+        else:
+            _assert_same(got, want, f"grammar {g}")
+            assert warning.count("does not follow the recalled token rules") in (1, 2), warning           # both files, unless one holds nothing the rule is about (no std::pair in the .ipf)
+            assert ("no item_version" in warning) == (g["item_version"] == 0) and ("std::pair without class information" in warning) == (not g["pair_class_info"])
+            assert ("std::array without class information, " in warning) == (not g["array_class_info"])
+            if k in (1, len(grammars) - 1):
+                layout = api.archive_layout(path)
+                assert layout.count("token_rules\tNOT as recalled") in (1, 2) and layout.count("parsed\tto the end") == 2
+    # two files of one profile need not share the rules (each is tried on its own)
+    mixed = str(tmp_path / "mixed.reseq")
+    ra.write_archive(mixed, "DataStats", trees[0], grammar=grammars[5])
+    ra.write_archive(mixed + ".ipf", "ProbabilityEstimates", trees[1], grammar=grammars[-1])
+    _assert_same(_product_arrays(mixed, None, str(tmp_path / "mixed.rsqp"))[0], want, "mixed grammars")
+
+
 # ------------------------------------------------------------------------------------------------------ diagnosis
 def test_archive_layout_and_the_member_path_of_a_parse_error(tiny_archives, tmp_path):
     """The reader cannot be validated against a Boost-written file here, so a file it cannot read must say WHERE: the layout lists the class-info site of
@@ -299,6 +337,7 @@ def test_archive_layout_and_the_member_path_of_a_parse_error(tiny_archives, tmp_
         api.Profile(broken, ipf_path=plain + ".ipf")
     msg = str(e.value)
     assert " at DataStats." in msg and "near byte" in msg and "enclosing types:" in msg and "class info read at byte" in msg and "archive library version 17" in msg
+    assert "no alternative of the doubtful token rules (64 combinations" in msg                # every grammar was tried; the recalled rules' message is the one shown
     shifted = api.archive_layout(broken, plain + ".ipf")
     assert "\nerror\t" in shifted.split("# ")[1] and "parsed\tto the end" in shifted.split("# ")[2]
     got = [l.split("\t") for l in shifted.split("# ")[1].splitlines() if l[:1].isdigit()]
