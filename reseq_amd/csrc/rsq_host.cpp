@@ -1025,7 +1025,13 @@ uint8_t dna5_code(char c) {
         default: return 4;
     }
 }
-// ReadVariants (Reference.cpp:126-420): the records of a file, or of a piece of it, one after the other
+// The records of a variant file, or of a piece of it, one after the other (what Reference::ReadVariants does with a record, Reference.cpp:126-420; the messages
+// are the reference's, in its order -- they are part of the command line's behaviour).  A record goes through four stages, each with its own small state:
+//   place        sequence id and position, and the file's sort order against the record before
+//   reference    the REF column against the sequence
+//   genotypes    the sample columns -> for every allele the number of the alternative it carries (0: the reference)
+//   alternatives the ALT column cut at its commas; per alternative the set of alleles that carry it, and per reference base of the record what the
+//                alternative puts in its place (a substitution, the last base plus inserted ones, or nothing: a deletion) -> insert_variant
 struct VcfRecords {
     const std::vector<std::string> &first_names, &contigs;
     const std::vector<std::vector<uint8_t>> &codes;
@@ -1036,15 +1042,18 @@ struct VcfRecords {
     uint32_t n_errors = 0, records = 0;
     size_t reserve_hint = 0;
     uint32_t first_rid = 0, first_begin = 0;                          // of the first record
-    std::vector<uint32_t> allele;
-    uint32_t old_ref_id = 0xFFFFFFFFu, start_pos = 0, end_pos = 0, read_for = 0, last_rid = 0xFFFFFFFFu;
-    std::vector<uint8_t> vcf_ref, inserted;                           // per record, kept for their storage
-    std::vector<size_t> alt_start;
-    std::vector<std::array<uint64_t, 2>> gt_has_var;
+    // the order of the file so far: the sequence the records have reached, the sequence and span of the last record that was placed
+    uint32_t reached_seq = 0, placed_seq = 0xFFFFFFFFu, placed_begin = 0, placed_end = 0, name_cache = 0xFFFFFFFFu;
+    std::vector<uint32_t> carried;                                    // per allele: number of the alternative it carries in this record
+    std::vector<uint8_t> ref_codes, put;                              // per record, kept for their storage
+    struct Span {
+        size_t at, len;
+    };
+    std::vector<Span> alternatives;
 
     VcfRecords(const std::vector<std::string> &names, const std::vector<std::string> &contig_names, const std::vector<std::vector<uint8_t>> &seqs, uint32_t num_alleles,
                std::vector<std::vector<Variant>> *lists)
-        : first_names(names), contigs(contig_names), codes(seqs), A(num_alleles), by_seq(lists), allele(num_alleles) {}
+        : first_names(names), contigs(contig_names), codes(seqs), A(num_alleles), by_seq(lists), carried(num_alleles) {}
     void error(const std::string &msg) {
         if (n_errors++ < 20) errors += msg + " ";                     // kMaxErrorsShownPerFile
     }
@@ -1056,124 +1065,130 @@ struct VcfRecords {
         }
         return runs.back().second;
     }
-    void record(const std::vector<std::string> &rec) {
-    if (last_rid >= contigs.size() || contigs[last_rid] != rec[0]) last_rid = (uint32_t)(std::find(contigs.begin(), contigs.end(), rec[0]) - contigs.begin());
-    const uint32_t rid = last_rid;                                // unknown names get a new id
-    const long long pos1 = atoll(rec[1].c_str());
-    const uint32_t begin_pos = (uint32_t)(pos1 - 1);
-    bool skip_rest = false;
-    if (rid < read_for) {                                         // :393-401 (checked when the record is read)
-        error("Variant file is not properly position sorted. Found sequence id " + std::to_string(rid) + " after id " + std::to_string(read_for));
-        skip_rest = true;
-    } else if (rid == read_for && old_ref_id != 0xFFFFFFFFu && begin_pos < start_pos) {
-        error("Variant file is not properly position sorted. Found in sequence id " + std::to_string(rid) + " position " + std::to_string(begin_pos) + " after position " +
-              std::to_string(start_pos));
-        skip_rest = true;
-    } else read_for = rid;
-    if (!skip_rest) {
+    static std::string at(uint32_t rid, uint32_t pos) { return "Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(pos); }
+
+    // the record's sequence (names the header did not list get an id behind the known ones) and whether the file is still sorted (:393-401)
+    bool place(const std::string &name, uint32_t begin, uint32_t &rid) {
+        if (name_cache >= contigs.size() || contigs[name_cache] != name) name_cache = (uint32_t)(std::find(contigs.begin(), contigs.end(), name) - contigs.begin());
+        rid = name_cache;
+        if (rid < reached_seq) {
+            error("Variant file is not properly position sorted. Found sequence id " + std::to_string(rid) + " after id " + std::to_string(reached_seq));
+            return false;
+        }
+        if (rid == reached_seq && placed_seq != 0xFFFFFFFFu && begin < placed_begin) {
+            error("Variant file is not properly position sorted. Found in sequence id " + std::to_string(rid) + " position " + std::to_string(begin) + " after position " +
+                  std::to_string(placed_begin));
+            return false;
+        }
+        reached_seq = rid;
+        return true;
+    }
+    // the REF column: inside the sequence, free of N, equal to the sequence (:176-194); the record counts as placed whatever the column says
+    bool reference_column(uint32_t rid, uint32_t begin, const std::string &ref) {
         if (rid >= first_names.size()) {
             error("Variant starting in reference sequence " + std::to_string(rid) + " does not belong to an existing reference sequence.");
-        } else if (begin_pos >= codes[rid].size()) {
-            error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(begin_pos) + " starts after the end of the reference sequence.");
-        } else {
-            start_pos = begin_pos;
-            if (old_ref_id == rid) {
-                if (start_pos < end_pos) error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " overlaps with a previous variant.");
-            } else old_ref_id = rid;
-            const std::string &ref = rec[3], &alt = rec[4];
-            end_pos = start_pos + (uint32_t)ref.size();
-            vcf_ref.resize(ref.size());
-            bool ref_n = false;
-            for (size_t k = 0; k < ref.size(); ++k) ref_n |= (vcf_ref[k] = dna5_code(ref[k])) > 3;
-            if (ref_n)
-                error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an reference column containing ambiguous bases (e.g. N).");
-            else if (end_pos > codes[rid].size() || !std::equal(vcf_ref.begin(), vcf_ref.end(), codes[rid].begin() + start_pos))
-                error("The specified reference in vcf file '" + ref + "' is not identical with the specified reference sequence " + std::to_string(rid) + " at position " +
-                      std::to_string(start_pos) + ".");
-            // genotypes (:196-262)
-            bool ok = true;
-            uint32_t cur_allele = 0;
-            for (size_t g = 9; g < rec.size() && ok; ++g) {
-                if (cur_allele >= A) {
-                    error("Found to many alleles in genotype definition");
-                    ok = false;
-                    break;
-                }
-                uint32_t chosen = 0;
-                bool column_ok = true;
-                for (size_t pos = 0; pos < rec[g].size() && ':' != rec[g][pos]; ++pos) {
-                    const char c = rec[g][pos];
-                    if ('|' == c || '/' == c) {
-                        if (cur_allele < A) allele[cur_allele] = chosen;
-                        ++cur_allele;
-                        chosen = 0;
-                    } else if ('0' <= c && '9' >= c) chosen = chosen * 10 + (uint32_t)(c - '0');
-                    else {
-                        error(std::string("Unallowed character '") + c + "' in genotype definition '" + rec[g] + "'");
-                        column_ok = false;
-                    }
-                }
-                if (cur_allele >= A) {                               // the reference would index past `allele` here
-                    error("Found to many alleles in genotype definition");
-                    ok = false;
-                    break;
-                }
-                allele[cur_allele++] = column_ok ? chosen : 0;
-                ok = ok && column_ok;
-            }
-            if (ok && cur_allele < A) {
-                error("Could not find enough alleles in genotype definition");
-                ok = false;
-            }
-            if (ok) {                                             // :270-370 alternatives, one bit per allele that carries them
-                alt_start.assign(1, 0);
-                gt_has_var.clear();
-                uint32_t chosen_var = 1;
-                auto carriers = [&](bool last) {
-                    std::array<uint64_t, 2> bits{0, 0};
-                    for (uint32_t a = A; a--;) {
-                        bits[a / 64] <<= 1;
-                        if (allele[a] == chosen_var) ++bits[a / 64];
-                        else if (last && allele[a] > chosen_var)
-                            error("Variant number " + std::to_string(allele[a]) + " does not exist for sequence id " + std::to_string(rid) + " and position " + std::to_string(begin_pos));
-                    }
-                    gt_has_var.push_back(bits);
-                    ++chosen_var;
-                };
-                for (size_t pos = 0; pos < alt.size(); ++pos)
-                    if (',' == alt[pos]) {
-                        alt_start.push_back(pos + 1);
-                        carriers(false);
-                    }
-                alt_start.push_back(alt.size() + 1);
-                carriers(true);
-                for (size_t pos = 0; pos < vcf_ref.size(); ++pos)
-                    for (size_t n_alt = 0; n_alt < gt_has_var.size(); ++n_alt) {
-                        if (!(gt_has_var[n_alt][0] | gt_has_var[n_alt][1])) continue;
-                        const size_t alt_len = alt_start[n_alt + 1] - 1 - alt_start[n_alt];
-                        inserted.clear();
-                        if (pos + 1 == vcf_ref.size() && pos + 1 < alt_len) {                         // insertion
-                            for (size_t k = alt_start[n_alt] + pos; k < alt_start[n_alt + 1] - 1; ++k) inserted.push_back(dna5_code(alt[k]));
-                        } else if (pos < alt_len) {                                                    // base mutation
-                            const uint8_t b = dna5_code(alt[alt_start[n_alt] + pos]);
-                            if (vcf_ref[pos] == b) continue;
-                            inserted.push_back(b);
-                        }                                                                              // else: deletion, ""
-                        bool has_n = false;
-                        for (uint8_t b : inserted) has_n |= b > 3;
-                        if (has_n) {
-                            error("Variant starting in reference sequence " + std::to_string(rid) + " at position " + std::to_string(start_pos) + " has an alternative column containing ambiguous bases (e.g. N).");
-                        } else {
-                            const uint64_t bits[2] = {gt_has_var[n_alt][0], gt_has_var[n_alt][1]};
-                            insert_variant(list_of(rid), start_pos + (uint32_t)pos, inserted, bits);
-                        }
-                    }
-            }
+            return false;
         }
+        if (begin >= codes[rid].size()) {
+            error(at(rid, begin) + " starts after the end of the reference sequence.");
+            return false;
+        }
+        if (placed_seq == rid && begin < placed_end) error(at(rid, begin) + " overlaps with a previous variant.");
+        placed_seq = rid;
+        placed_begin = begin;
+        placed_end = begin + (uint32_t)ref.size();
+        ref_codes.resize(ref.size());
+        bool ambiguous = false;
+        for (size_t k = 0; k < ref.size(); ++k) ambiguous |= (ref_codes[k] = dna5_code(ref[k])) > 3;
+        if (ambiguous) error(at(rid, begin) + " has an reference column containing ambiguous bases (e.g. N).");
+        else if (placed_end > codes[rid].size() || !std::equal(ref_codes.begin(), ref_codes.end(), codes[rid].begin() + begin))
+            error("The specified reference in vcf file '" + ref + "' is not identical with the specified reference sequence " + std::to_string(rid) + " at position " + std::to_string(begin) + ".");
+        return true;
     }
+    // the sample columns "1|0:..." (:196-262): numbers separated by | or /, up to the first colon; one allele per number, A of them over all columns
+    bool genotypes(const std::vector<std::string> &rec) {
+        uint32_t filled = 0;
+        for (size_t g = 9; g < rec.size(); ++g) {
+            const std::string &column = rec[g];
+            if (filled >= A) {
+                error("Found to many alleles in genotype definition");
+                return false;
+            }
+            uint32_t number = 0;
+            bool clean = true;
+            for (size_t k = 0; k < column.size() && ':' != column[k]; ++k) {
+                const char c = column[k];
+                if ('|' == c || '/' == c) {
+                    if (filled < A) carried[filled] = number;
+                    ++filled;
+                    number = 0;
+                } else if ('0' <= c && '9' >= c) number = number * 10 + (uint32_t)(c - '0');
+                else {
+                    error(std::string("Unallowed character '") + c + "' in genotype definition '" + column + "'");
+                    clean = false;
+                }
+            }
+            if (filled >= A) {                                       // the reference would write behind its array here
+                error("Found to many alleles in genotype definition");
+                return false;
+            }
+            carried[filled++] = clean ? number : 0;
+            if (!clean) return false;
+        }
+        if (filled < A) {
+            error("Could not find enough alleles in genotype definition");
+            return false;
+        }
+        return true;
+    }
+    // the alleles that carry alternative `number` (1-based), one bit each
+    std::array<uint64_t, 2> carriers(uint32_t number) const {
+        std::array<uint64_t, 2> bits{0, 0};
+        for (uint32_t a = 0; a < A; ++a)
+            if (carried[a] == number) bits[a / 64] |= (uint64_t)1 << (a % 64);
+        return bits;
+    }
+    // the ALT column (:270-370)
+    void alternatives_column(uint32_t rid, uint32_t begin, const std::string &alt) {
+        alternatives.clear();
+        for (size_t from = 0;;) {
+            const size_t comma = alt.find(',', from);
+            alternatives.push_back(Span{from, (comma == std::string::npos ? alt.size() : comma) - from});
+            if (comma == std::string::npos) break;
+            from = comma + 1;
+        }
+        for (uint32_t a = A; a--;)                                   // numbers beyond the last alternative
+            if (carried[a] > alternatives.size())
+                error("Variant number " + std::to_string(carried[a]) + " does not exist for sequence id " + std::to_string(rid) + " and position " + std::to_string(begin));
+        const size_t ref_len = ref_codes.size();
+        for (size_t k = 0; k < ref_len; ++k)
+            for (size_t n = 0; n < alternatives.size(); ++n) {
+                const std::array<uint64_t, 2> who = carriers((uint32_t)n + 1u);
+                if (!(who[0] | who[1])) continue;
+                const Span &s = alternatives[n];
+                put.clear();
+                if (k + 1 == ref_len && k + 1 < s.len) {              // the record's last reference base and what the alternative has beyond it: an insertion
+                    for (size_t j = k; j < s.len; ++j) put.push_back(dna5_code(alt[s.at + j]));
+                } else if (k < s.len) {                               // base for base
+                    const uint8_t b = dna5_code(alt[s.at + k]);
+                    if (ref_codes[k] == b) continue;
+                    put.push_back(b);
+                }                                                     // else the alternative is shorter: the base is deleted
+                if (std::any_of(put.begin(), put.end(), [](uint8_t b) { return b > 3; })) {
+                    error(at(rid, begin) + " has an alternative column containing ambiguous bases (e.g. N).");
+                    continue;
+                }
+                const uint64_t bits[2] = {who[0], who[1]};
+                insert_variant(list_of(rid), begin + (uint32_t)k, put, bits);
+            }
+    }
+    void record(const std::vector<std::string> &rec) {
+        const uint32_t begin = (uint32_t)(atoll(rec[1].c_str()) - 1);
+        uint32_t rid = 0;
+        if (place(rec[0], begin, rid) && reference_column(rid, begin, rec[3]) && genotypes(rec)) alternatives_column(rid, begin, rec[4]);
         if (!records++) {
             first_rid = rid;
-            first_begin = begin_pos;
+            first_begin = begin;
         }
     }
 };
@@ -1244,7 +1259,7 @@ bool read_variants_mapped(const std::string &path, const std::vector<std::string
     std::vector<size_t> total(first_names.size(), 0);
     for (const auto &pc : pieces) {
         if (!pc->records) continue;
-        if (last && (pc->first_rid < last->read_for || (pc->first_rid == last->read_for && (pc->first_begin < last->start_pos || pc->first_begin < last->end_pos)))) return false;
+        if (last && (pc->first_rid < last->reached_seq || (pc->first_rid == last->reached_seq && (pc->first_begin < last->placed_begin || pc->first_begin < last->placed_end)))) return false;
         last = pc.get();
         for (const auto &run : pc->runs) total[run.first] += run.second.size();
     }
