@@ -169,6 +169,17 @@ int rsq_sim_get_info(const rsq_sim *s, rsq_sim_info *out);
  * why); image_tiles = tiles whose tables one workgroup's local-memory image holds: all of the profile's (reads of any tile served by any workgroup) or 1
  * (reads binned by the tile they draw, Simulator.h:176-181, one tile per workgroup at a time); image_bytes = size of that image. */
 int rsq_sim_get_fill_plan(const rsq_sim *s, uint32_t *quality_quads, uint32_t *image_tiles, uint32_t *image_bytes);
+/* One load per host.  Simulator::Simulate has one process and one copy of the reference (reseq/Simulator.cpp:2687-2700); a job of one process per GPU would read
+ * and pack the same FASTA, variant and methylation files once per rank, on the cores the ranks of a host share.  rsq_sim_export_reference writes what THIS simulator
+ * keeps of those files -- sequence names and lengths, the packed bases and G/C prefix sums (of every allele's copy), variants, allele maps, methylation regions; the
+ * result of rsq_sim_create with a reference and of rsq_sim_read_methylation -- to `path` (a file in /dev/shm, say), complete before it appears under its name;
+ * rsq_sim_import_reference gives a simulator created WITHOUT a reference (rsq_sim_create(profile, NULL, ...)) exactly that state: both end in the same device arrays
+ * through the same code, so the reads do not depend on which of the two a rank did.  The file records the profile values the packing used; another profile's
+ * simulator is refused (RSQ_EINVAL).  reseq_amd/simulate.py: the first rank of every host loads and exports, the others import. */
+int rsq_sim_export_reference(rsq_sim *s, const char *path);
+/* lengths of the simulator's reference sequences (what a launcher that imported the reference balances the ranks' block ranges with); out NULL: only the count */
+int rsq_sim_get_sequence_lengths(const rsq_sim *s, uint32_t *out, size_t cap, uint32_t *n_sequences);
+int rsq_sim_import_reference(rsq_sim *s, const char *path);
 /* The read kernel COMPILED FOR THIS SIMULATOR'S PROFILE.  What a loaded profile fixes -- the local-memory plan, the value ranges and row counts of its quality /
  * base-call / indel tables, tiles, phred offset -- are loop bounds and address factors of LogArrayResult::Draw (reseq/ProbabilityEstimates.h:481-508, members of
  * the loaded tables there).  The library carries the kernels' source; with libhiprtc present it compiles them with those values as literals -- per kernel variant

@@ -78,6 +78,9 @@ SYMBOLS = {
     "rsq_sim_get_info": (C.c_int, [_vp, C.POINTER(SimInfo)]),
     "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rsq_sim_specialize": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "rsq_sim_export_reference": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_get_sequence_lengths": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32)]),
+    "rsq_sim_import_reference": (C.c_int, [_vp, C.c_char_p]),
     "rsq_set_kernel_cache_dir": (C.c_int, [C.c_char_p]),
     "rsq_profile_compile_read_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "rsq_sim_get_thresholds": (C.c_int, [_vp, _vp, _sz]),
@@ -348,6 +351,21 @@ class Simulator:
         q, t, b = _u32(0), _u32(0), _u32(0)
         _check(lib().rsq_sim_get_fill_plan(self.h, C.byref(q), C.byref(t), C.byref(b)))
         return {"mask": q.value, "image_tiles": t.value, "image_bytes": b.value}
+
+    def sequence_lengths(self):
+        n = _u32(0)
+        _check(lib().rsq_sim_get_sequence_lengths(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint32)
+        _check(lib().rsq_sim_get_sequence_lengths(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return [int(x) for x in out]
+
+    def export_reference(self, path):
+        """what the simulator keeps of its reference, variant and methylation files, for the other ranks of the host (import_reference)"""
+        _check(lib().rsq_sim_export_reference(self.h, os.fsencode(path)))
+
+    def import_reference(self, path):
+        """the state another process exported; this simulator was created with reference None"""
+        _check(lib().rsq_sim_import_reference(self.h, os.fsencode(path)))
 
     def specialize(self, kind=0):
         """Compiles the read kernel (kind 0: read pairs, 1: seqToIllumina records) for this simulator's profile now.  Returns (specialized, what the library says):

@@ -5,6 +5,7 @@
 // that the per-lane functions of rsq_core.h / rsq_kernels.h can be checked against the oracle without a GPU.
 #pragma once
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -94,6 +95,11 @@ struct SimState {
     std::string ref_bias_file;                       // --refBiasFile, consumed by plan_simulation when ref_bias_mode is kRefBiasFile
     double bias_normalization = 0;
     std::string plan_note;                           // what pack_tables has to say about the read kernels' route (rsq_last_warning after rsq_sim_create)
+    // kept for export_reference: the variants' mode as pack_reference chose it (pack_methylation may raise it), the methylation regions as uploaded
+    int variants_mode_packed = 0;
+    bool has_methylation = false;
+    std::vector<uint32_t> meth_ptr_host, meth_first_host, meth_second_host;
+    std::vector<double> meth_rate_host;
 };
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -639,6 +645,62 @@ inline void pack_on_threads(size_t n_items, F f) {
     if (failed) std::rethrow_exception(failed);
 }
 
+// The second half of pack_reference: the simulator's state is complete on the host (sequence tables, variants, allele maps, extra starts in SimState; `packed` =
+// the 2-bit words of the reference and, with a substitution-only variant set, of every allele's copy; `gc_prefix` likewise), now everything goes to where the
+// kernels read it.  Also the route of a reference another process packed (import_reference below): both end in the same arrays.
+inline void upload_reference(SimState &s, Uploader &up, std::vector<uint64_t> packed, const std::vector<uint32_t> &gc_prefix) {
+    DevSim &d = s.dev;
+    uint64_t words = 0, bases = 0;
+    for (uint32_t len : s.seq_len) {
+        words += (len + 31) / 32 + 1;
+        bases += len;
+    }
+    s.var_err_fwd.assign(s.var_bases.size() + 1, 0);
+    s.var_err_rev.assign(s.var_bases.size() + 1, 0);
+    d.var_bases = up.put(s.var_bases);
+    {
+        std::vector<uint32_t> bases_gc(s.var_bases.size() + 1, 0);
+        for (size_t k = 0; k < s.var_bases.size(); ++k) bases_gc[k + 1] = bases_gc[k] + ((s.var_bases[k] == 1 || s.var_bases[k] == 2) ? 1u : 0u);
+        d.var_bases_gc = up.put(bases_gc);
+    }
+    d.allele_map = up.put(s.allele_map);
+    d.allele_map_ptr = up.put(s.allele_map_ptr);
+    s.dev_var_err_fwd = up.put(s.var_err_fwd);
+    s.dev_var_err_rev = up.put(s.var_err_rev);
+    d.var_err_fwd = s.dev_var_err_fwd;
+    d.var_err_rev = s.dev_var_err_rev;
+    d.extra = up.put(s.extra);
+    d.walk_error = up.put(std::vector<uint32_t>(2, 0));
+    d.block_extra_ptr = nullptr;                                  // set by plan_simulation once the blocks are numbered
+    if (2 == s.variants_mode) {                                   // templates are written out per mate (k_variant_templates)
+        s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;
+        if (s.template_words > kTemplateWordsMax) throw Error("templates longer than 2048 bases are not supported with insertion / deletion variants");
+    }
+    d.variants = up.put(s.variants);
+    d.var_ptr = up.put(s.var_ptr);
+    d.ref_words = up.put(packed);
+    packed.resize(words + 1);                                     // the allele copies are the device's
+    packed.shrink_to_fit();
+    s.ref_words_host = std::move(packed);
+    d.gc_prefix = up.put(gc_prefix);
+    d.seq_word_off = up.put(s.seq_word_off);
+    d.seq_len = up.put(s.seq_len);
+    d.seq_base_off = up.put(s.seq_base_off);
+    s.sys_fwd = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
+    s.sys_rev = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
+    d.sys_fwd = s.sys_fwd;
+    d.sys_rev = s.sys_rev;
+    std::string names;
+    std::vector<uint32_t> ptr{0};
+    for (const std::string &n : s.ref_first_names) {
+        names += n;
+        ptr.push_back((uint32_t)names.size());
+    }
+    names.push_back(' ');
+    s.names.names = up.put(std::vector<char>(names.begin(), names.end()));
+    s.names.name_ptr = up.put(ptr);
+}
+
 inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const Variants *variants = nullptr) {
     DevSim &d = s.dev;
     d.n_seqs = (uint32_t)r.codes.size();
@@ -724,6 +786,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
     s.variants.clear();
     s.var_ptr.assign(1, 0);
     s.variants_mode = variants ? variants_mode_for(*variants) : 0;
+    s.variants_mode_packed = s.variants_mode;
     d.variants_loaded = (uint32_t)s.variants_mode;
     s.var_bases.clear();
     s.extra.clear();
@@ -803,50 +866,7 @@ inline void pack_reference(SimState &s, Uploader &up, const Reference &r, const 
         s.var_ptr.assign(r.codes.size() + 1, 0);
         s.extra_seq_ptr.assign(r.codes.size() + 1, 0);
     }
-    s.var_err_fwd.assign(s.var_bases.size() + 1, 0);
-    s.var_err_rev.assign(s.var_bases.size() + 1, 0);
-    d.var_bases = up.put(s.var_bases);
-    {
-        std::vector<uint32_t> bases_gc(s.var_bases.size() + 1, 0);
-        for (size_t k = 0; k < s.var_bases.size(); ++k) bases_gc[k + 1] = bases_gc[k] + ((s.var_bases[k] == 1 || s.var_bases[k] == 2) ? 1u : 0u);
-        d.var_bases_gc = up.put(bases_gc);
-    }
-    d.allele_map = up.put(s.allele_map);
-    d.allele_map_ptr = up.put(s.allele_map_ptr);
-    s.dev_var_err_fwd = up.put(s.var_err_fwd);
-    s.dev_var_err_rev = up.put(s.var_err_rev);
-    d.var_err_fwd = s.dev_var_err_fwd;
-    d.var_err_rev = s.dev_var_err_rev;
-    d.extra = up.put(s.extra);
-    d.walk_error = up.put(std::vector<uint32_t>(2, 0));
-    d.block_extra_ptr = nullptr;                                  // set by plan_simulation once the blocks are numbered
-    if (2 == s.variants_mode) {                                   // templates are written out per mate (k_variant_templates)
-        s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;
-        if (s.template_words > kTemplateWordsMax) throw Error("templates longer than 2048 bases are not supported with insertion / deletion variants");
-    }
-    d.variants = up.put(s.variants);
-    d.var_ptr = up.put(s.var_ptr);
-    d.ref_words = up.put(packed);
-    packed.resize(words + 1);                                     // the allele copies are the device's
-    packed.shrink_to_fit();
-    s.ref_words_host = std::move(packed);
-    d.gc_prefix = up.put(gc_prefix);
-    d.seq_word_off = up.put(s.seq_word_off);
-    d.seq_len = up.put(s.seq_len);
-    d.seq_base_off = up.put(s.seq_base_off);
-    s.sys_fwd = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
-    s.sys_rev = static_cast<uint16_t *>(up.put_zeros((bases + 8) * sizeof(uint16_t)));
-    d.sys_fwd = s.sys_fwd;
-    d.sys_rev = s.sys_rev;
-    std::string names;
-    std::vector<uint32_t> ptr{0};
-    for (const std::string &n : s.ref_first_names) {
-        names += n;
-        ptr.push_back((uint32_t)names.size());
-    }
-    names.push_back(' ');
-    s.names.names = up.put(std::vector<char>(names.begin(), names.end()));
-    s.names.name_ptr = up.put(ptr);
+    upload_reference(s, up, std::move(packed), gc_prefix);
 }
 
 // utilities.hpp:238-262 on the host, only to carry DominantBase::dom_base_ from the end of one chain to the start of
@@ -1445,16 +1465,8 @@ inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, ui
 }
 
 // --methylation (Reference::PrepareMethylationFile / ReadMethylation, Simulator.cpp:2770-2780): regions as CSR on the device
-inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
-    std::vector<uint32_t> ptr{0}, first, second;
-    std::vector<double> rate;
-    for (size_t i = 0; i < m.first.size(); ++i) {
-        first.insert(first.end(), m.first[i].begin(), m.first[i].end());
-        second.insert(second.end(), m.second[i].begin(), m.second[i].end());
-        for (size_t k = 0; k < m.first[i].size(); ++k)                                                   // num_alleles values per region: Reference::Unmethylation
-            for (uint32_t a = 0; a < s.num_alleles; ++a) rate.push_back(m.rate[i][1 < m.rate[i].size() ? a : 0][k]);
-        ptr.push_back((uint32_t)first.size());
-    }
+// the regions as the kernels read them (CSR over the sequences; num_alleles rates per region) -> device; also the route of regions another process parsed
+inline void install_methylation(SimState &s, Uploader &up, std::vector<uint32_t> ptr, std::vector<uint32_t> first, std::vector<uint32_t> second, std::vector<double> rate) {
     if (s.has_variants && 2 != s.variants_mode) {
         // with methylation the templates are written out and converted per mate (k_variant_templates): the path for variants of any
         // kind.  A substitution-only set has no starts inside inserted bases, so nothing else changes.
@@ -1467,6 +1479,213 @@ inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
     s.dev.meth_rate = up.put(rate);
     s.template_words = (s.rmax + s.prof.max_len_deletion + 31u) / 32u + 1u;          // GetOrgSeq: at most Rmax + MaxLenDeletion bases
     if (s.template_words > kTemplateWordsMax) throw Error("templates longer than 2048 bases are not supported with --methylation");
+    s.has_methylation = true;
+    s.meth_ptr_host = std::move(ptr);
+    s.meth_first_host = std::move(first);
+    s.meth_second_host = std::move(second);
+    s.meth_rate_host = std::move(rate);
+}
+inline void pack_methylation(SimState &s, Uploader &up, const Methylation &m) {
+    std::vector<uint32_t> ptr{0}, first, second;
+    std::vector<double> rate;
+    for (size_t i = 0; i < m.first.size(); ++i) {
+        first.insert(first.end(), m.first[i].begin(), m.first[i].end());
+        second.insert(second.end(), m.second[i].begin(), m.second[i].end());
+        for (size_t k = 0; k < m.first[i].size(); ++k)                                                   // num_alleles values per region: Reference::Unmethylation
+            for (uint32_t a = 0; a < s.num_alleles; ++a) rate.push_back(m.rate[i][1 < m.rate[i].size() ? a : 0][k]);
+        ptr.push_back((uint32_t)first.size());
+    }
+    install_methylation(s, up, std::move(ptr), std::move(first), std::move(second), std::move(rate));
+}
+
+// ------------------------------------------------------------------------------------------ one load per host
+// Eight ranks on one host used to read and pack the same FASTA, VCF and BED eight times, sharing the host's cores (the job's longest stage at human scale).  What a
+// simulator keeps of those files is the result of pack_reference / pack_methylation; export_reference writes exactly that -- sequence tables, the 2-bit words and
+// G/C prefix sums (of every allele's copy too), variants, allele maps, extra starts, methylation regions -- into one file (the launcher puts it into /dev/shm), and
+// import_reference gives another process's simulator the same state through the same upload_reference / install_methylation: ONE rank of a host parses and packs,
+// the others map its result.  The file names what the packing depended on (longest insert, longest read, longest deletion of the profile): an importer with another
+// profile is refused.  Layout: "RSQREF1\0", then records {u32 tag, u32 element size, u64 count, bytes padded to 8}.
+namespace refio {
+enum Tag : uint32_t {
+    kScalars = 1, kNames, kNamePtr, kIds, kIdPtr, kSeqLen, kWords, kGcPrefix, kVariants, kVarPtr, kVarBases, kAlleleMap, kAlleleMapPtr, kExtra, kExtraSeqPtr, kMethPtr, kMethFirst,
+    kMethSecond, kMethRate, kEnd
+};
+struct Scalars {
+    uint64_t hap_stride, total_ref_size;
+    uint32_t n_seqs, has_variants, num_alleles, variants_mode_packed, has_methylation, insert_to, rmax, max_len_deletion;
+};
+struct Writer {
+    FILE *f;
+    template <class T>
+    void put(uint32_t tag, const T *data, uint64_t count) {
+        const uint32_t head[2] = {tag, (uint32_t)sizeof(T)};
+        static const char zeros[8] = {0};
+        const size_t bytes = (size_t)count * sizeof(T);
+        if (fwrite(head, 1, 8, f) != 8 || fwrite(&count, 1, 8, f) != 8 || (bytes && fwrite(data, 1, bytes, f) != bytes) || fwrite(zeros, 1, (8 - bytes % 8) % 8, f) != (8 - bytes % 8) % 8)
+            throw Error("writing the packed reference failed");
+    }
+    template <class T>
+    void put(uint32_t tag, const std::vector<T> &v) { put(tag, v.data(), v.size()); }
+};
+struct Record {
+    const char *data = nullptr;
+    uint64_t count = 0;
+    uint32_t size = 0;
+};
+}  // namespace refio
+
+inline void export_reference(const SimState &s, Uploader &up, const std::string &path) {
+    if (!s.has_ref) throw Error("the simulator has no reference to export");
+    using namespace refio;
+    const std::string tmp = path + ".writing";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) throw Error("cannot write " + tmp);
+    try {
+        if (fwrite("RSQREF1", 1, 8, f) != 8) throw Error("writing the packed reference failed");
+        Writer w{f};
+        const Scalars sc{s.dev.hap_stride, s.total_ref_size, s.dev.n_seqs, s.has_variants ? 1u : 0u, s.num_alleles, (uint32_t)s.variants_mode_packed, s.has_methylation ? 1u : 0u,
+                         s.dev.insert_to, s.rmax, (uint32_t)s.prof.max_len_deletion};
+        w.put(kScalars, &sc, 1);
+        std::string names, ids;
+        std::vector<uint64_t> name_ptr{0}, id_ptr{0};
+        for (size_t i = 0; i < s.ref_first_names.size(); ++i) {
+            names += s.ref_first_names[i];
+            ids += s.ref_ids[i];
+            name_ptr.push_back(names.size());
+            id_ptr.push_back(ids.size());
+        }
+        w.put(kNames, names.data(), names.size());
+        w.put(kNamePtr, name_ptr);
+        w.put(kIds, ids.data(), ids.size());
+        w.put(kIdPtr, id_ptr);
+        w.put(kSeqLen, s.seq_len);
+        uint64_t words = 0;
+        for (uint32_t len : s.seq_len) words += (len + 31) / 32 + 1;
+        const uint64_t copies = s.dev.hap_stride ? 1u + s.num_alleles : 1u, n_words = s.dev.hap_stride ? s.dev.hap_stride * copies : words + 1;
+        {   // the packed words and the G/C prefix sums live where the kernels read them (the host keeps the reference's own words only)
+            std::vector<uint64_t> packed(n_words);
+            up.read_bytes(packed.data(), s.dev.ref_words, n_words * 8);
+            w.put(kWords, packed);
+        }
+        {
+            std::vector<uint32_t> gc(n_words);
+            up.read_bytes(gc.data(), s.dev.gc_prefix, n_words * 4);
+            w.put(kGcPrefix, gc);
+        }
+        w.put(kVariants, s.variants);
+        w.put(kVarPtr, s.var_ptr);
+        w.put(kVarBases, s.var_bases);
+        w.put(kAlleleMap, s.allele_map);
+        w.put(kAlleleMapPtr, s.allele_map_ptr);
+        w.put(kExtra, s.extra);
+        w.put(kExtraSeqPtr, s.extra_seq_ptr);
+        if (s.has_methylation) {
+            w.put(kMethPtr, s.meth_ptr_host);
+            w.put(kMethFirst, s.meth_first_host);
+            w.put(kMethSecond, s.meth_second_host);
+            w.put(kMethRate, s.meth_rate_host);
+        }
+        w.put(kEnd, (const char *)nullptr, 0);
+    } catch (...) {
+        fclose(f);
+        remove(tmp.c_str());
+        throw;
+    }
+    if (fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0) {      // complete, then visible under its name
+        remove(tmp.c_str());
+        throw Error("writing " + path + " failed");
+    }
+}
+
+// `data`, `size`: the file (mapped by the caller, alive during the call).  The simulator must have been created without a reference, for the same profile.
+inline void import_reference(SimState &s, Uploader &up, const char *data, size_t size, const std::string &what) {
+    using namespace refio;
+    if (s.has_ref) throw Error("the simulator has a reference already");
+    if (size < 8 || memcmp(data, "RSQREF1", 8)) throw Error(what + " is not a packed reference of this library");
+    Record rec[kEnd + 1];
+    bool complete = false;
+    for (size_t at = 8; at + 16 <= size;) {
+        uint32_t head[2];
+        uint64_t count;
+        memcpy(head, data + at, 8);
+        memcpy(&count, data + at + 8, 8);
+        at += 16;
+        if (head[0] == kEnd) {
+            complete = true;
+            break;
+        }
+        const uint64_t bytes = count * head[1];
+        if (head[0] == 0 || head[0] > kEnd || bytes > size - at) throw Error(what + ": damaged record");
+        rec[head[0]] = Record{data + at, count, head[1]};
+        at += (bytes + 7) / 8 * 8;
+    }
+    if (!complete) throw Error(what + " is incomplete");
+    auto take = [&](uint32_t tag, auto &vec) {
+        using T = typename std::remove_reference_t<decltype(vec)>::value_type;
+        if (rec[tag].size != sizeof(T) && rec[tag].count) throw Error(what + ": record " + std::to_string(tag) + " has another element size");
+        vec.resize(rec[tag].count);
+        if (rec[tag].count) memcpy(vec.data(), rec[tag].data, rec[tag].count * sizeof(T));
+    };
+    if (rec[kScalars].count != 1 || rec[kScalars].size != sizeof(Scalars)) throw Error(what + ": no header record");
+    Scalars sc;
+    memcpy(&sc, rec[kScalars].data, sizeof sc);
+    if (sc.insert_to != s.dev.insert_to || sc.rmax != s.rmax || sc.max_len_deletion != (uint32_t)s.prof.max_len_deletion)
+        throw Error(what + " was packed for another profile (longest insert / read / deletion " + std::to_string(sc.insert_to) + " / " + std::to_string(sc.rmax) + " / " +
+                    std::to_string(sc.max_len_deletion) + ", this simulator's " + std::to_string(s.dev.insert_to) + " / " + std::to_string(s.rmax) + " / " + std::to_string(s.prof.max_len_deletion) + ")");
+    DevSim &d = s.dev;
+    std::vector<uint64_t> name_ptr, id_ptr;
+    take(kNamePtr, name_ptr);
+    take(kIdPtr, id_ptr);
+    take(kSeqLen, s.seq_len);
+    if (s.seq_len.size() != sc.n_seqs || name_ptr.size() != (size_t)sc.n_seqs + 1 || id_ptr.size() != (size_t)sc.n_seqs + 1 || name_ptr.back() != rec[kNames].count || id_ptr.back() != rec[kIds].count)
+        throw Error(what + ": sequence tables do not fit together");
+    s.ref_first_names.clear();
+    s.ref_ids.clear();
+    s.seq_word_off.clear();
+    s.seq_base_off.clear();
+    uint64_t words = 0, bases = 0;
+    for (uint32_t i = 0; i < sc.n_seqs; ++i) {
+        s.ref_first_names.emplace_back(rec[kNames].data + name_ptr[i], name_ptr[i + 1] - name_ptr[i]);
+        s.ref_ids.emplace_back(rec[kIds].data + id_ptr[i], id_ptr[i + 1] - id_ptr[i]);
+        s.seq_word_off.push_back(words);
+        s.seq_base_off.push_back(bases);
+        words += (s.seq_len[i] + 31) / 32 + 1;
+        bases += s.seq_len[i];
+    }
+    if (bases != sc.total_ref_size) throw Error(what + ": sequence lengths do not add up");
+    d.n_seqs = sc.n_seqs;
+    s.has_ref = true;
+    s.total_ref_size = bases;
+    s.has_variants = sc.has_variants != 0;
+    s.num_alleles = sc.num_alleles;
+    d.num_alleles = sc.num_alleles;
+    d.hap_stride = sc.hap_stride;
+    s.variants_mode = s.variants_mode_packed = (int)sc.variants_mode_packed;
+    d.variants_loaded = sc.variants_mode_packed;
+    take(kVariants, s.variants);
+    take(kVarPtr, s.var_ptr);
+    take(kVarBases, s.var_bases);
+    take(kAlleleMap, s.allele_map);
+    take(kAlleleMapPtr, s.allele_map_ptr);
+    take(kExtra, s.extra);
+    take(kExtraSeqPtr, s.extra_seq_ptr);
+    std::vector<uint64_t> packed;
+    std::vector<uint32_t> gc_prefix;
+    take(kWords, packed);
+    take(kGcPrefix, gc_prefix);
+    const uint64_t n_words = sc.hap_stride ? sc.hap_stride * (1u + sc.num_alleles) : words + 1;
+    if (packed.size() != n_words || gc_prefix.size() != n_words || s.var_ptr.size() != (size_t)sc.n_seqs + 1 || s.extra_seq_ptr.size() != (size_t)sc.n_seqs + 1)
+        throw Error(what + ": arrays of unexpected sizes");
+    upload_reference(s, up, std::move(packed), gc_prefix);
+    if (sc.has_methylation) {
+        std::vector<uint32_t> ptr, first, second;
+        std::vector<double> rate;
+        take(kMethPtr, ptr);
+        take(kMethFirst, first);
+        take(kMethSecond, second);
+        take(kMethRate, rate);
+        install_methylation(s, up, std::move(ptr), std::move(first), std::move(second), std::move(rate));
+    }
 }
 
 // --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335).  Units consume the

@@ -2,6 +2,8 @@
 // HBM, runs the pre-passes and drives the kernels of rsq_kernels.h.  Compiled for gfx950 only.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <math.h>
 #include <string.h>
 #include <unistd.h>
@@ -141,6 +143,30 @@ struct DeviceUploader : Uploader {
     }
     void write_bytes(void *dst, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
     void read_bytes(void *dst_host, const void *src, size_t bytes) override { HIP_CHECK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost)); }
+};
+
+struct MappedFile {                                                   // a whole file, read-only
+    const char *data = nullptr;
+    size_t size = 0;
+    explicit MappedFile(const char *path) {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) throw Error(std::string("cannot open ") + path + ": " + strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+            close(fd);
+            throw Error(std::string(path) + " is empty or cannot be examined");
+        }
+        size = (size_t)st.st_size;
+        void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) throw Error(std::string("cannot map ") + path);
+        data = static_cast<const char *>(p);
+    }
+    ~MappedFile() {
+        if (data) munmap(const_cast<char *>(data), size);
+    }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
 };
 
 // ------------------------------------------------------------------------------------------------ rsq_sim
@@ -1357,6 +1383,34 @@ int rsq_sim_prepare_finish(rsq_sim *s) {
     });
 }
 
+int rsq_sim_get_sequence_lengths(const rsq_sim *s, uint32_t *out, size_t cap, uint32_t *n_sequences) {
+    REQUIRE(s && n_sequences && s->has_ref, "null argument, or a simulator without a reference");
+    *n_sequences = (uint32_t)s->seq_len.size();
+    if (out && cap >= s->seq_len.size()) memcpy(out, s->seq_len.data(), s->seq_len.size() * sizeof(uint32_t));
+    else if (out) {
+        g_last_error = "room for " + std::to_string(cap) + " lengths, the reference has " + std::to_string(s->seq_len.size()) + " sequences";
+        return RSQ_ENOSPC;
+    }
+    return RSQ_OK;
+}
+int rsq_sim_export_reference(rsq_sim *s, const char *path) {
+    REQUIRE(s && path, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        HIP_CHECK(hipDeviceSynchronize());
+        export_reference(*s, s->up, path);
+        return RSQ_OK;
+    });
+}
+int rsq_sim_import_reference(rsq_sim *s, const char *path) {
+    REQUIRE(s && path, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        MappedFile m(path);
+        import_reference(*s, s->up, m.data, m.size, path);
+        return RSQ_OK;
+    });
+}
 int rsq_sim_specialize(rsq_sim *s, int kind, int *specialized) {
     REQUIRE(s && specialized && (kind == 0 || kind == 1), "null argument, or a kind that is neither 0 (read pairs) nor 1 (seqToIllumina records)");
     return guard([&] {

@@ -3,7 +3,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m reseq_amd.simulate \\
         -R ref.fa -s profile.rsqp -1 r1.fq -2 r2.fq --numReads 100000000 --seed 11
 
-Every rank packs the replicated tables, takes a contiguous range of 1000-position blocks balanced by expected pairs
+The first rank of a host reads and packs the reference, variant and methylation files and the host's other ranks take the packed result from shared memory
+(`load_once_per_host`).  Every rank packs the (small) profile tables, takes a contiguous range of 1000-position blocks balanced by expected pairs
 (`sharding.partition_blocks`) and computes ITS share of the pre-passes (`sharding.sharded_prepare`: bias sums per chunk + one exact
 all-reduce, systematic-error chains over its own positions + the chain states at the shard borders), simulates its blocks ONCE with the
 FASTQ text kept in device memory (`rsq_sim_job_generate`), and after one all-gather of the text sizes writes it straight to its own
@@ -25,20 +26,29 @@ from . import sharding
 class GpuBackend:
     """reseq_amd.api.Simulator with reusable device buffers (the product path)."""
 
-    def __init__(self, profile_path, fasta_path, device, replace_n_seed, vcf_path=None, methylation_path=None, sys_error_path=None):
+    def __init__(self, profile_path, fasta_path, device, replace_n_seed, vcf_path=None, methylation_path=None, sys_error_path=None, packed_from=None):
+        """`packed_from`: a file another rank of this host wrote with export_reference -- the reference, variant and methylation files are not read again"""
         from . import api
         self.api = api
         self.prof = api.Profile(profile_path)
-        self.ref = api.Reference(fasta_path, replace_n_seed)
         self.has_variants = bool(vcf_path)
-        if vcf_path:
-            self.ref.read_variants(vcf_path)
-        self.sim = api.Simulator(self.prof, self.ref, device)
-        if methylation_path:
-            self.sim.read_methylation(methylation_path)
+        if packed_from:
+            self.ref = None
+            self.sim = api.Simulator(self.prof, None, device)
+            self.sim.import_reference(packed_from)
+        else:
+            self.ref = api.Reference(fasta_path, replace_n_seed)
+            if vcf_path:
+                self.ref.read_variants(vcf_path)
+            self.sim = api.Simulator(self.prof, self.ref, device)
+            if methylation_path:
+                self.sim.read_methylation(methylation_path)
         self.sys_error_path = sys_error_path
         self.device = device
-        self.seq_len = [self.ref.sequence_length(i) for i in range(self.ref.num_sequences())]
+        self.seq_len = self.sim.sequence_lengths()
+
+    def export_reference(self, path):
+        self.sim.export_reference(path)
 
     def prepare(self, seed, num_pairs, coverage, ref_bias_mode, base_identifier):
         i = self.sim.prepare(seed, num_pairs, coverage, ref_bias_mode, base_identifier)
@@ -85,7 +95,8 @@ class GpuBackend:
 
     def close(self):
         self.sim.close()
-        self.ref.close()
+        if self.ref:
+            self.ref.close()
         self.prof.close()
 
 
@@ -110,6 +121,43 @@ def _agree(dist, device, error, what):
         raise error
     if failed:
         raise RuntimeError(f"another rank failed while {what}")
+
+
+def load_once_per_host(make_backend, dist, device, local_rank, local_world, node, shm_dir="/dev/shm"):
+    """One load per host: the host's first rank reads and packs the reference, variant and methylation files (`make_backend(None)`) and exports the result to shared
+    memory; the host's other ranks take it from there (`make_backend(path)`) -- rsq_sim_export_reference / rsq_sim_import_reference.  Without a process group, or
+    with one rank per host, every rank loads for itself.  The ranks agree after each half, so that a loader that fails (a missing file, a malformed record) takes
+    the others with it instead of leaving them waiting for a file that never appears."""
+    if dist is None or local_world <= 1:
+        return make_backend(None)
+    import torch
+    token = torch.tensor([int.from_bytes(os.urandom(7), "little")], dtype=torch.int64, device=device)       # one name for the job's files, from rank 0
+    dist.broadcast(token, 0)
+    path = os.path.join(shm_dir, f"rsq_packed_reference_{int(token.item()):014x}_host{node}")
+    loader = local_rank == 0
+    backend, error = None, None
+    if loader:
+        def load_and_export():
+            b = make_backend(None)
+            try:
+                b.export_reference(path)
+            except Exception:
+                b.close()
+                raise
+            return b
+        backend, error = _attempt(load_and_export)
+    _agree(dist, device, error, "loading and packing the reference for its host")
+    if not loader:
+        backend, error = _attempt(make_backend, path)
+    try:
+        _agree(dist, device, error, "taking the packed reference of its host")
+    finally:
+        if loader:
+            try:
+                os.unlink(path)                                      # every rank of the host has it in its own memory by now (or the job is over)
+            except OSError:
+                pass
+    return backend
 
 
 def _attempt(f, *a):
@@ -199,6 +247,8 @@ def main(argv=None):
     ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
     ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 4 M pairs)")
+    ap.add_argument("--everyRankLoads", action="store_true", help="every rank reads and packs the reference, variant and methylation files itself (default: the first rank of a host "
+                    "does and the host's other ranks take the packed result from shared memory)")
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own pair of files <out>.part<k>of<N> (their concatenation in order is the single file): "
                     "writes into one file serialise on its inode lock, 8 GB/s for the whole job; separate files scale with the ranks")
     a = ap.parse_args(argv)
@@ -217,7 +267,11 @@ def main(argv=None):
         t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.broadcast(t, 0)
         seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
-    backend = GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError)
+    make = lambda packed_from: GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
+    if a.everyRankLoads:
+        backend = make(None)
+    else:
+        backend = load_once_per_host(make, dist, f"cuda:{local_rank}", local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)))
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
                                   a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput)

@@ -35,6 +35,8 @@ def emu_lib():
         L.emu_get_variant_sys.restype = C.c_uint32
         L.emu_get_variant_sys.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]
         L.emu_free.argtypes = [C.c_void_p]
+        L.emu_export_reference.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_import_reference.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_option.argtypes = [C.c_char_p, C.c_longlong]
@@ -103,6 +105,12 @@ class EmuBackend:
 
     def fill_plan(self):
         return {"mask": self.L.emu_plan_mask(self.h), "image_tiles": self.L.emu_image_tiles(self.h)}
+
+    def export_reference(self, path):
+        _ok(self.L.emu_export_reference(self.h, str(path).encode()))
+
+    def import_reference(self, path):
+        _ok(self.L.emu_import_reference(self.h, str(path).encode()))
 
     def prepare(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):
         _ok(self.L.emu_prepare(self.h, seed, num_pairs, coverage, ref_bias_mode, base_identifier.encode()))
@@ -255,6 +263,12 @@ class GpuBackend:
 
     def fill_plan(self):
         return self.sim.fill_plan()
+
+    def export_reference(self, path):
+        self.sim.export_reference(str(path))
+
+    def import_reference(self, path):
+        self.sim.import_reference(str(path))
 
     def info(self):
         i = self.sim.info()

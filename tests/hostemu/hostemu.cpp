@@ -249,6 +249,20 @@ int emu_create(const char *profile_path, const char *fasta_path, uint64_t replac
     });
 }
 void emu_free(void *h) { delete static_cast<Emu *>(h); }
+// rsq_sim_export_reference / rsq_sim_import_reference: the same two functions of rsq_pack.h behind them
+int emu_export_reference(void *h, const char *path) {
+    return guard([&] {
+        Emu &s = *static_cast<Emu *>(h);
+        export_reference(s, s.up, path);
+    });
+}
+int emu_import_reference(void *h, const char *path) {
+    return guard([&] {
+        Emu &s = *static_cast<Emu *>(h);
+        const std::string text = read_text_file(path);               // plain bytes
+        import_reference(s, s.up, text.data(), text.size(), path);
+    });
+}
 
 int emu_edit_profile(void *h, double error_multiplier, int no_substitutions, int no_indels) {
     Emu &s = *static_cast<Emu *>(h);

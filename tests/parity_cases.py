@@ -352,6 +352,56 @@ def case_ragged_tables(backend_cls, workdir, cfg_base=None, lengths=(5000, 3210)
     assert len(exp) == 400
 
 
+def case_packed_reference(backend_cls, workdir):
+    """One load per host (rsq_sim_export_reference / rsq_sim_import_reference): a simulator that was given another simulator's packed reference -- variants of every
+    kind on two alleles and methylation regions included -- instead of the files writes the same fragments and FASTQ bytes; a file packed for another profile,
+    a damaged file and a second import are refused"""
+    import pytest
+    ppath, fpath, seqs = make_inputs(workdir, "packed", synth.TINY, [6200, 80, 3100])
+    vcf = workdir / "packed.vcf"
+    write_vcf(vcf, seqs, _mixed_variant_set(seqs, np.random.default_rng(5), 30, [999, 1000, 1999, 2000]))
+    names = [n.split(" ")[0] for n, _ in seqs]
+    for with_variants in (True, False):
+        bed = workdir / f"packed_{int(with_variants)}.bed"                  # a rate per allele: two with the phased sample, one without variants
+        second = (lambda r: f"\t{r}") if with_variants else (lambda r: "")
+        bed.write_text(f"{names[0]}\t100\t900\t0.3{second(0.6)}\n{names[0]}\t2000\t5000\t0.0{second(0.5)}\n{names[2]}\t50\t2000\t0.0{second(1.0)}\n")
+        a = backend_cls(ppath, fpath, 0, None, vcf_path=str(vcf)) if with_variants else backend_cls(ppath, fpath, 0)
+        b = backend_cls(ppath, None, 0)
+        try:
+            a.read_methylation(bed)
+            packed = workdir / f"packed_{int(with_variants)}.ref"
+            a.export_reference(packed)
+            b.import_reference(packed)
+            ia, ib = a.prepare(7, 3000), b.prepare(7, 3000)
+            assert ia == ib
+            fa, a1, a2 = a.pairs(1, ia["total_blocks"] + 1)
+            fb, b1, b2 = b.pairs(1, ib["total_blocks"] + 1)
+            assert len(fa) > 2000 and fa.tobytes() == fb.tobytes() and a1 == b1 and a2 == b2
+            if with_variants:
+                assert b"_allele1" in a1
+            with pytest.raises(Exception, match="has a reference already"):
+                b.import_reference(packed)
+        finally:
+            a.close()
+            b.close()
+    other = workdir / "packed_other.rsqp"
+    synth.write_profile(other, synth.make_profile(dict(synth.TINY, name="TINYr32", read_len_max=32), seed=5, n_ref_seqs=3))
+    c = backend_cls(str(other), None, 0)
+    try:
+        with pytest.raises(Exception, match="packed for another profile"):
+            c.import_reference(workdir / "packed_1.ref")
+    finally:
+        c.close()
+    data = (workdir / "packed_1.ref").read_bytes()
+    (workdir / "cut.ref").write_bytes(data[:len(data) // 2])
+    d = backend_cls(ppath, None, 0)
+    try:
+        with pytest.raises(Exception, match="incomplete|damaged"):
+            d.import_reference(workdir / "cut.ref")
+    finally:
+        d.close()
+
+
 def case_profile_edits(backend_cls, workdir):
     for edits in ({"error_multiplier": 3.0}, {"no_substitutions": True}, {"no_indels": True}, {"no_substitutions": True, "no_indels": True}):
         p = Pair(backend_cls, workdir, "tiny_e2e", synth.TINY, [5000, 80, 3210], seed=5, num_pairs=800, edits=edits)

@@ -70,6 +70,10 @@ def test_tables_over_their_own_value_ranges(workdir):
     P.case_ragged_tables(GpuBackend, workdir, cfg_base=synth.P0, lengths=(20000,), num_pairs=1000)
 
 
+def test_packed_reference_of_another_simulator(workdir):
+    P.case_packed_reference(GpuBackend, workdir)
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(GpuBackend, workdir)
 

@@ -117,6 +117,10 @@ def test_tables_over_their_own_value_ranges(workdir):
     P.case_ragged_tables(EmuBackend, workdir)
 
 
+def test_packed_reference_of_another_simulator(workdir):
+    P.case_packed_reference(EmuBackend, workdir)
+
+
 def test_profile_edits(workdir):
     P.case_profile_edits(EmuBackend, workdir)
 

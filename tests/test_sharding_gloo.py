@@ -32,11 +32,23 @@ from backends import EmuBackend
 from reseq_amd import simulate, synth
 
 class Emu:                      # the host emulation behind the interface simulate.run_rank drives (the GPU run uses simulate.GpuBackend)
-    def __init__(self, ppath, fpath, seqs, vcf=None):
-        self.b = EmuBackend(ppath, fpath, 0, None, vcf_path=vcf) if vcf else EmuBackend(ppath, fpath, 0)
+    def __init__(self, ppath, fpath, seqs, vcf=None, packed_from=None):
+        if packed_from:             # the reference another rank of the "host" packed (simulate.load_once_per_host)
+            if os.environ.get("RSQ_FAIL_IMPORT") == os.environ["RANK"]:
+                raise IOError("cannot map the packed reference (the test's)")
+            self.b = EmuBackend(ppath, None, 0)
+            self.b.import_reference(packed_from)
+        else:
+            if os.environ.get("RSQ_FAIL_LOAD") == os.environ["RANK"]:
+                raise IOError("reference file not found (the test's)")
+            self.b = EmuBackend(ppath, fpath, 0, None, vcf_path=vcf) if vcf else EmuBackend(ppath, fpath, 0)
         self.seq_len = [len(c) for _, c in seqs]
         self.n_seqs = len(self.seq_len)
         self.can_shard_prepare = True
+    def export_reference(self, path):
+        self.b.export_reference(path)
+    def close(self):
+        self.b.close()
     def prepare(self, *a):
         return self.b.prepare(*a)
     def prepare_plan(self, *a):
@@ -86,7 +98,13 @@ if os.environ.get("RSQ_VARIANTS"):           # substitutions, insertions, deleti
     import numpy as np
     vcf = work / f"sim{rank}" / "simjob.vcf"
     P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, np.random.default_rng(5), 30, [999, 1000, 1999, 2000, 2999, 3000]))
-pairs, _ = simulate.run_rank(Emu(ppath, fpath, seqs, vcf), dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3,
+if os.environ.get("RSQ_SHARED_LOAD"):          # the two ranks as the ranks of one host: rank 0 loads and exports, rank 1 imports (its FASTA path does not even exist)
+    make = lambda packed_from: Emu(ppath, fpath if rank == 0 else str(work / "no_such.fa"), seqs, vcf if rank == 0 else None, packed_from=packed_from)
+    backend = simulate.load_once_per_host(make, dist if world > 1 else None, "cpu", rank, world, 0, shm_dir=str(work))
+    assert not list(work.glob("rsq_packed_reference_*")), "the exported file is gone once every rank has it"
+else:
+    backend = Emu(ppath, fpath, seqs, vcf)
+pairs, _ = simulate.run_rank(backend, dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3,
                              split_output=bool(os.environ.get("RSQ_SPLIT")))
 if rank == 0:
     print("PAIRS", pairs)
@@ -126,6 +144,14 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
         a, b = (workdir / f"one_{k}.fq").read_bytes(), (workdir / f"two_{k}.fq").read_bytes()
         assert a == b and a.count(b"\n") % 4 == 0 and b":0:Adapter:0:" in a
     assert not list(workdir.glob("*.rank*"))
+    # one load per host: rank 0 reads and packs, rank 1 takes the packed reference (variants included) from the shared directory -- the same two files
+    procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="shared", RSQ_SHARED_LOAD="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=800)
+        assert p.returncode == 0, se.decode()[-3000:]
+    for k in (1, 2):
+        assert (workdir / f"shared_{k}.fq").read_bytes() == (workdir / f"one_{k}.fq").read_bytes()
     # a rank that fails leaves nobody waiting: it raises its own error, the other one says that another rank failed (simulate._agree)
     if not variants:
         for split in ("", "1"):
@@ -142,6 +168,15 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
             errs = [p.communicate(timeout=300)[1].decode() for p in procs]
             assert all(p.returncode != 0 for p in procs)
             assert said in errs[1 - failing] and own in errs[failing], errs
+        # ... and in the shared load: the loader's failure reaches the rank that waits for its file, an importer's failure the loader
+        for switch, failing, said, own in (("RSQ_FAIL_LOAD", 0, "another rank failed while loading and packing the reference", "reference file not found"),
+                                           ("RSQ_FAIL_IMPORT", 1, "another rank failed while taking the packed reference", "cannot map the packed reference")):
+            procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="failload", RSQ_SHARED_LOAD="1", **{switch: str(failing)}),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+            errs = [p.communicate(timeout=300)[1].decode() for p in procs]
+            assert all(p.returncode != 0 for p in procs)
+            assert said in errs[1 - failing] and own in errs[failing], errs
+            assert not list(workdir.glob("rsq_packed_reference_*"))
 
 
 WORKER = r"""

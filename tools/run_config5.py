@@ -90,7 +90,25 @@ if "loads" in sys.argv[2:]:
     for n in sorted({1, n_proc}):
         procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(n)]
         result[str(n)] = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
-    print(json.dumps({"config": f"configs[4] human-sized at scale {scale}: the load of N ranks at once on one host", "host_threads": os.cpu_count(), "loads": result}))
+    # one load per host (rsq_sim_export_reference / rsq_sim_import_reference): process 0 loads as above and exports to /dev/shm, the others wait for the file and
+    # import it -- seconds from the common start until every process holds its simulator
+    shared = os.path.join("/dev/shm", f"rsq_c5_packed_{os.getpid()}")
+    code_shared = ("import sys, os, time, json; sys.path.insert(0, %r); from reseq_amd import api; rank = int(sys.argv[1]); t0 = time.perf_counter(); st = {}; t = t0\n"
+                   "prof = api.Profile(%r)\n"
+                   "if rank == 0:\n"
+                   "    ref = api.Reference(%r, 7); ref.read_variants(%r); sim = api.Simulator(prof, ref, 0); sim.read_methylation(%r); st['load'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+                   "    sim.export_reference(%r); st['export'] = round(time.perf_counter() - t, 2)\n"
+                   "else:\n"
+                   "    sim = api.Simulator(prof, None, 0); st['create'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+                   "    while not os.path.exists(%r): time.sleep(0.002)\n"
+                   "    st['wait_for_the_loader'] = round(time.perf_counter() - t, 2); t = time.perf_counter()\n"
+                   "    sim.import_reference(%r); st['import'] = round(time.perf_counter() - t, 2)\n"
+                   "print(json.dumps({'ready_s': round(time.perf_counter() - t0, 2), 'stages': st, 'file_bytes': os.path.getsize(%r)}))\n") % (ROOT, ppath, fpath, vpath, bpath, shared, shared, shared, shared)
+    procs = [subprocess.Popen([sys.executable, "-c", code_shared, str(r)], stdout=subprocess.PIPE, text=True) for r in range(n_proc)]
+    one_load = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    os.unlink(shared)
+    print(json.dumps({"config": f"configs[4] human-sized at scale {scale}: the load of N ranks at once on one host", "host_threads": os.cpu_count(), "loads": result,
+                      "one_load_per_host": {str(n_proc): one_load}}))
     sys.exit(0)
 
 t0 = time.perf_counter()
