@@ -123,8 +123,17 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
     info = b.prepare(7, num_pairs=3000)
     lo, hi = 2, info["total_blocks"] + 1
     frags, t1, t2 = b.pairs(lo, hi)
-    for chunk_bytes, batch, threads in ((0, 0, 0), (30_000, 2, 3), (5_000, 1, 5)):
+    import pytest
+    from reseq_amd import api
+    with pytest.raises(api.RsqError) as e:                                # nothing generated yet: refused, not two files of zeros
+        b.sim.job_write(workdir / "none_1.fq", 0, workdir / "none_2.fq", 0, 0)
+    assert e.value.code == api.RSQ_ESTATE and "no generated text" in str(e.value)
+    with pytest.raises(api.RsqError) as e:                                # an inverted range is refused before anything is sized from it
+        b.sim.job_generate(hi, lo, 0)
+    assert e.value.code == api.RSQ_EINVAL
+    for chunk_bytes, batch, threads, direct in ((0, 0, 0, 0), (30_000, 2, 3, 0), (5_000, 1, 5, 0), (30_000, 2, 2, 1), (0, 0, 1, 1)):
         rsq_options("job_chunk_bytes", chunk_bytes)
+        rsq_options("job_write_direct", direct)                               # whole 4 KB blocks around the page cache where the file system allows it, head and tail buffered
         n, n1, n2 = b.sim.job_generate(lo, hi, batch)
         assert (n, n1, n2) == (len(frags), len(t1), len(t2))
         f1, f2 = workdir / "job_1.fq", workdir / "job_2.fq"
@@ -134,6 +143,8 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
         assert f1.read_bytes() == b"x" * 100 + t1 + b"x" * 200
         assert f2.read_bytes() == b"y" * 50 + bytes(20) + t2
         b.sim.job_free()
+        with pytest.raises(api.RsqError):                                 # freed: nothing to write
+            b.sim.job_write(f1, 100, f2, 70, threads)
     b.close()
 
 
