@@ -766,67 +766,55 @@ struct ReadMachine {
                 else q = par.qual;                                                                       // insertion :417-420
             }
         }
+        // what the iteration emits is decided in the branches and written in ONE place behind them (a base and its quality for every kind but a deletion, an edit
+        // operation for every kind but the tail): one store site instead of three, and the output cursors change in one place
+        uint32_t put_base = 0, op_code = 0;
+        char element = 0;                                          // the CIGAR run the iteration belongs to; the tail has none
+        const bool insertion = !tail && indel > 1u;
         if (regular) {
             par.qual = q;
             const uint32_t idx_b[4] = {par.qual, par.read_pos, par.num_errors, par.error_rate};
             uint32_t call = tab.draw_base_call(qi * 5u + dom_error, idx_b, w.w2, prob_sum);
             if (0 == prob_sum) call = org_base;
             par.base_call = call;
-            out.put(par.read_pos, call, q + RSQ_SIM(S, phred_offset));
-            par.last_written_qual = q;
-            out.op(it, 0u);
-            const char base_element = from_template ? 'M' : 'S';
-            if (base_element == cg.element) ++cg.length;
-            else {
-                cg.flush();
-                cg.element = base_element;
-                cg.length = 1;
-                par.indel_pos = 0;
-                par.previous_indel_type = 0;
-            }
+            put_base = call;
+            element = from_template ? 'M' : 'S';
             if (call != org_base) ++par.num_errors;
-            ++par.read_pos;
-            ++org_pos;
         } else if (deletion) {                                     // ErrorStats::kDeletion
-            out.op(it, 1u);
-            ++n_indels;
-            if ('D' == cg.element) {
-                ++cg.length;
-                ++par.indel_pos;
-            } else {
-                cg.flush();
-                cg.element = 'D';
-                cg.length = 1;
-                par.indel_pos = 1;
-                par.previous_indel_type = 1;
-            }
-            ++par.num_errors;
-            ++org_pos;
+            op_code = 1u;
+            element = 'D';
         } else if (tail) {                                         // :564-587 poly-A tail, then random overrun bases
             par.qual = q;
-            const uint32_t b = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
+            put_base = pos_tail < tail_length ? 0u : discrete_draw(S.overrun_cp, 4, u32_to_unit(w.w3));
             ++pos_tail;
-            out.put(par.read_pos, b, q + RSQ_SIM(S, phred_offset));
-            par.last_written_qual = q;
-            ++par.read_pos;
         } else {                                                   // insertion of base indel-2
-            out.put(par.read_pos, indel - 2u, q + RSQ_SIM(S, phred_offset));
-            par.last_written_qual = q;
-            out.op(it, 2u);
-            ++n_indels;
-            if ('I' == cg.element) {
+            put_base = indel - 2u;
+            op_code = 2u;
+            element = 'I';
+        }
+        // the run-length bookkeeping of the three kinds with a CIGAR element, once (:358-368, 398-408, 428-438): the run goes on, or the one before is closed
+        if (element) {
+            const uint32_t is_indel = deletion || insertion ? 1u : 0u;
+            n_indels += is_indel;
+            par.num_errors += is_indel;
+            if (element == cg.element) {
                 ++cg.length;
-                ++par.indel_pos;
+                par.indel_pos += is_indel;
             } else {
                 cg.flush();
-                cg.element = 'I';
+                cg.element = element;
                 cg.length = 1;
-                par.indel_pos = 1;
-                par.previous_indel_type = 0;
+                par.indel_pos = is_indel;
+                par.previous_indel_type = deletion ? 1u : 0u;
             }
-            ++par.num_errors;
+            if (!insertion) ++org_pos;                             // a template base was used (or deleted)
+        }
+        if (!deletion) {
+            out.put(par.read_pos, put_base, q + RSQ_SIM(S, phred_offset));
+            par.last_written_qual = q;
             ++par.read_pos;
         }
+        if (!tail) out.op(it, op_code);
         return true;
     }
 

@@ -42,6 +42,16 @@ def workdir(tmp_path_factory):
     return tmp_path_factory.mktemp("rsq")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def kernel_cache_in_the_session_directory(tmp_path_factory):
+    """read kernels compiled for a profile (rsq_spec.h) keep their code objects in this session's directory, not under the user's ~/.cache: every profile of the
+    suite is compiled once per session, and a test run leaves nothing behind"""
+    from reseq_amd import api
+    api.set_kernel_cache_dir(str(tmp_path_factory.mktemp("kernel_cache")))
+    yield
+    api.set_kernel_cache_dir(None)
+
+
 @pytest.fixture(scope="session")
 def tiny_profile_path(workdir):
     from reseq_amd import synth

@@ -110,7 +110,7 @@ def test_read_kernel_compiles_for_a_profile_without_a_gpu(tiny_profile_path, wor
         assert "failed" in str(e.value)
         p.close()
     finally:
-        api.set_kernel_cache_dir(None)
+        api.set_kernel_cache_dir(str(workdir / "kernel_cache_session"))     # what the session's fixture had set up is gone; any directory of this run does
 
 
 def test_gzip_fasta_loads_like_plain(workdir):

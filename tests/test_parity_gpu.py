@@ -206,7 +206,7 @@ def test_read_kernel_compiled_for_the_profile_and_the_library_instantiation(work
             sim.close(), ref.close(), prof.close()
         assert " ms)" in notes[0] and "kernel cache" in notes[1], notes
     finally:
-        api.set_kernel_cache_dir(None)
+        api.set_kernel_cache_dir(str(workdir / "kernel_cache_session"))
     rsq_options("specialize", 0)
     prof, ref = api.Profile(ppath), api.Reference(fpath, 0)
     sim = api.Simulator(prof, ref, 0)

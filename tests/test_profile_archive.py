@@ -279,11 +279,10 @@ def test_every_alternative_of_the_doubtful_token_rules_loads_to_the_same_tables(
     import os
     grammars = ra.all_grammars()
     assert len(grammars) == 64 and grammars[0] == ra.DEFAULT_GRAMMAR
-    if not os.environ.get("RSQ_ALL_GRAMMARS"):              # every switch on its own, and every item_version rule with all the others flipped (all 64: RSQ_ALL_GRAMMARS=1, five minutes)
+    if not os.environ.get("RSQ_ALL_GRAMMARS"):              # every switch on its own, and everything flipped at once (all 64: RSQ_ALL_GRAMMARS=1, five minutes)
         flips = lambda g: sum(g[k] != ra.DEFAULT_GRAMMAR[k] for k in g)
-        all_flipped = lambda g: all(g[k] != ra.DEFAULT_GRAMMAR[k] for k in g if k != "item_version")
-        grammars = [g for g in grammars if flips(g) <= 1 or all_flipped(g)]
-        assert len(grammars) == 12
+        grammars = [g for g in grammars if flips(g) <= 1 or (flips(g) == 5 and g["item_version"] == 0)]
+        assert len(grammars) == 9
     trees = af.from_rsqp(tiny_profile_arrays, 1600000000, np.random.default_rng(7))        # binned tables with missing rows: every container type is in use
     want = None
     for k, g in enumerate(grammars):
