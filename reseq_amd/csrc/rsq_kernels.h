@@ -576,8 +576,8 @@ RSQ_HD uint32_t sieve_cell_general(const DevSim &S, const SieveSite &site, uint3
         const AlleleCell ac = allele_cell(a, site.st, site.start, len);
         if (!ac.inside) continue;                                                   // :2318
         uint32_t sur_start[3], sur_end[3];
-        allele_surrounding_forward(a, ac.hs, sur_start);                            // bias_mod.surrounding_start_.at(allele)
-        allele_surrounding_reverse(a, ac.he - 1, sur_end);                          // bias_mod.surrounding_end_.at(allele)
+        allele_surrounding_forward(a, ac.hs, sur_start, ac.first_entries);          // bias_mod.surrounding_start_.at(allele)
+        allele_surrounding_reverse(a, ac.he - 1, sur_end, ac.last_entries);         // bias_mod.surrounding_end_.at(allele)
         const double u = (j & 1u) ? u53_to_unit(wc.w2, wc.w3) : u53_to_unit(wc.w0, wc.w1);
         const double adjusted_random = thr0 + u * (1 - thr0);
         const uint32_t c = fragment_counts(S, site.seq, len, ac.gc_percent, sur_start, sur_end, adjusted_random);

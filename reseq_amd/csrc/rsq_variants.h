@@ -41,6 +41,18 @@ struct VarView {
         }
         return lo;
     }
+    // the same index, found by a short walk from `hint` (an index near the answer) where that suffices: what one cell of the sieve asks lies within a fragment's
+    // length of what it asked before, a handful of variants at most, while a bisection of a chromosome's variants is twenty dependent loads
+    RSQ_HD uint32_t lower_bound(uint32_t pos, uint32_t hint) const {
+        uint32_t k = hint < n ? hint : n;
+        for (uint32_t step = 0; step < kHintWalk; ++step) {
+            if (k < n && v[k].pos < pos) ++k;
+            else if (k > 0u && !(v[k - 1u].pos < pos)) --k;
+            else return k;
+        }
+        return lower_bound(pos);
+    }
+    static constexpr uint32_t kHintWalk = 8;
 };
 RSQ_HD VarView var_view(const DevSim &S, uint32_t seq) {
     return VarView{S.ref_words, S.gc_prefix, S.seq_word_off[seq], S.seq_len[seq], S.variants + S.var_ptr[seq], S.var_ptr[seq + 1] - S.var_ptr[seq], S.var_bases};
@@ -91,6 +103,18 @@ struct AlleleView {
         }
         return lo;
     }
+    // the same count by a short walk from `hint` (VarView::lower_bound with a hint); kNoHint: the bisection
+    static constexpr uint32_t kNoHint = 0xFFFFFFFFu;
+    RSQ_HD uint32_t entries_upto(int64_t h, uint32_t hint) const {
+        if (hint == kNoHint) return entries_upto(h);
+        uint32_t j = hint < n ? hint : n;
+        for (uint32_t step = 0; step < VarView::kHintWalk; ++step) {
+            if (j < n && begin_of(j) <= h) ++j;
+            else if (j > 0u && begin_of(j - 1u) > h) --j;
+            else return j;
+        }
+        return entries_upto(h);
+    }
     // allele coordinate of reference position pos (of the first base that replaces it; of the next kept base if pos is deleted)
     RSQ_HD int64_t to_allele(uint32_t pos) const { return (int64_t)pos + e[entries_before(pos)].shift; }
     RSQ_HD uint32_t ref_gc_before(uint32_t pos) const {                   // G/C among reference bases [0, pos), pos <= L
@@ -109,8 +133,8 @@ struct AllelePoint {
     uint32_t ref;                       // the reference position behind it: the entry's position, or the plain base's own
     bool inside;
 };
-RSQ_HD AllelePoint allele_point(const AlleleView &a, int64_t h) {
-    const uint32_t j = a.entries_upto(h);
+RSQ_HD AllelePoint allele_point(const AlleleView &a, int64_t h, uint32_t hint = AlleleView::kNoHint) {
+    const uint32_t j = a.entries_upto(h, hint);
     if (j) {
         const int64_t k = h - a.begin_of(j - 1u);
         if (k < (int64_t)a.var(j - 1u).len) return AllelePoint{j, (uint32_t)k, a.e[j - 1u].pos, true};
@@ -136,14 +160,14 @@ RSQ_HD uint64_t ref_bits64(const uint64_t *__restrict__ words, uint64_t word_off
 // n <= 32 consecutive allele bases from coordinate h0, first base in the lowest bits, zeros above them.  Coordinates in front of the allele
 // and behind it continue in the REFERENCE around the sequence's ends, without variants: the reference's surroundings wrap around
 // (SurroundingBase.hpp:64-81) and its variant edits stop at the ends (HandleSurroundingVariantsBeforeCenter / AfterCenter, :1459-1589).
-RSQ_HD uint64_t allele_bits(const AlleleView &a, int64_t h0, uint32_t n) {
+RSQ_HD uint64_t allele_bits(const AlleleView &a, int64_t h0, uint32_t n, uint32_t hint = AlleleView::kNoHint) {
     uint64_t x = 0;
     uint32_t got = 0;
     int64_t h = h0;
     const uint32_t L = a.r.L;
     for (; got < n && h < 0; ++got, ++h) x |= (uint64_t)a.r.at((uint32_t)((int64_t)L + h)) << (2u * got);
     if (got < n && h < a.length()) {
-        const AllelePoint p = allele_point(a, h);
+        const AllelePoint p = allele_point(a, h, hint);
         uint32_t j = p.j, q = p.ref;                                      // next entry, next reference position
         if (p.inside) {
             const DevVariant &var = a.var(j - 1u);
@@ -173,14 +197,14 @@ RSQ_HD uint64_t allele_bits(const AlleleView &a, int64_t h0, uint32_t n) {
     }
     return x;
 }
-RSQ_HD uint64_t allele_window(const AlleleView &a, int64_t h0) { return allele_bits(a, h0, kSurBlocks * kSurRange); }
+RSQ_HD uint64_t allele_window(const AlleleView &a, int64_t h0, uint32_t hint = AlleleView::kNoHint) { return allele_bits(a, h0, kSurBlocks * kSurRange, hint); }
 // the allele's forward surrounding of coordinate h (as surrounding_forward does for the reference) and its reverse surrounding
-RSQ_HD void allele_surrounding_forward(const AlleleView &a, int64_t h, uint32_t (&sur)[3]) {
-    const uint64_t x = allele_window(a, h - (int64_t)kSurStart);
+RSQ_HD void allele_surrounding_forward(const AlleleView &a, int64_t h, uint32_t (&sur)[3], uint32_t hint = AlleleView::kNoHint) {
+    const uint64_t x = allele_window(a, h - (int64_t)kSurStart, hint);
     for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = reverse_ten_bases((uint32_t)(x >> (20u * b)) & 0xFFFFFu);
 }
-RSQ_HD void allele_surrounding_reverse(const AlleleView &a, int64_t h, uint32_t (&sur)[3]) {
-    const uint64_t x = allele_window(a, h + (int64_t)kSurStart + 1 - (int64_t)(kSurBlocks * kSurRange));
+RSQ_HD void allele_surrounding_reverse(const AlleleView &a, int64_t h, uint32_t (&sur)[3], uint32_t hint = AlleleView::kNoHint) {
+    const uint64_t x = allele_window(a, h + (int64_t)kSurStart + 1 - (int64_t)(kSurBlocks * kSurRange), hint);
     for (uint32_t b = 0; b < kSurBlocks; ++b) sur[b] = ~(uint32_t)(x >> (20u * (kSurBlocks - 1u - b))) & 0xFFFFFu;
 }
 
@@ -191,21 +215,26 @@ struct AlleleCell {
     uint32_t gc_percent;                // GetGCPercent (:1853-1868)
     VarStart end_var;                   // EndVariant (Simulator.h:73-89)
     bool inside;                        // the end position lies inside the sequence (:2318)
+    uint32_t first_entries, last_entries;      // entries of the allele's map that begin at or before hs / he - 1: hints for what is asked next (the surroundings)
 };
 RSQ_HD AlleleCell allele_cell(const AlleleView &a, const VarStart &st, uint32_t start, uint32_t length) {
     AlleleCell c;
-    c.hs = a.to_allele(start) + st.start_variant_pos;
+    const uint32_t before = a.entries_before(start);                     // the cell's one bisection; everything else it asks lies a fragment's length from here
+    c.hs = (int64_t)start + a.e[before].shift + st.start_variant_pos;      // to_allele(start) + ...
     c.he = c.hs + length;
     c.end = 0;
     c.gc_percent = 0;
     c.end_var = VarStart{0, 0u};
     c.inside = false;
+    c.first_entries = c.last_entries = before;
     if (c.he > a.length()) return c;                                     // the allele ends before the fragment does
-    const AllelePoint last = allele_point(a, c.he - 1);
+    const AllelePoint last = allele_point(a, c.he - 1, before);
+    c.last_entries = last.j;
     c.end = last.ref + 1u;                                               // the reference position behind the fragment's last base
     if (!(c.end < a.r.L)) return c;
     c.inside = true;
-    const AllelePoint first = allele_point(a, c.hs), behind = allele_point(a, c.he);
+    const AllelePoint first = allele_point(a, c.hs, before), behind = allele_point(a, c.he, last.j);
+    c.first_entries = first.j;
     c.gc_percent = percent_u32(allele_gc_before(a, behind) - allele_gc_before(a, first), length);
     // EndVariant: a fragment that ends inside inserted bases hands the variant and the number of its bases it uses to the reverse
     // read; otherwise the last variant in front of the end position.  The reference has a third case for a fragment that ends inside
@@ -213,7 +242,7 @@ RSQ_HD AlleleCell allele_cell(const AlleleView &a, const VarStart &st, uint32_t 
     // gets the second answer there -- and here.
     const bool started_in_it = st.start_variant_pos && last.inside && a.e[last.j - 1u].vid == (uint32_t)st.first_variant_id;
     if (last.inside && last.k + 1u < a.var(last.j - 1u).len && !started_in_it) c.end_var = VarStart{(int32_t)a.e[last.j - 1u].vid, last.k + 1u};
-    else c.end_var = VarStart{(int32_t)a.r.lower_bound(c.end) - 1, 0u};
+    else c.end_var = VarStart{(int32_t)a.r.lower_bound(c.end, a.e[last.j].vid) - 1, 0u};      // near the allele's next entry (the sentinel: the number of variants)
     return c;
 }
 
@@ -233,12 +262,18 @@ RSQ_HD uint64_t reverse_complement_bits(uint64_t x, uint32_t n) {        // of t
 }
 RSQ_HD void allele_template(const AlleleView &a, uint32_t pos, VarStart from, uint32_t n, bool reversed, uint64_t *tmpl, uint32_t template_words) {
     int64_t h;
-    if (from.start_variant_pos) h = a.begin_of(a.entries_before(a.r.v[from.first_variant_id].pos)) + from.start_variant_pos;
-    else h = a.to_allele(pos);
+    uint32_t near;                                                       // entries of the map around the template's first base: the one bisection, a hint for every word
+    if (from.start_variant_pos) {
+        near = a.entries_before(a.r.v[from.first_variant_id].pos);
+        h = a.begin_of(near) + from.start_variant_pos;
+    } else {
+        near = a.entries_before(pos);
+        h = (int64_t)pos + a.e[near].shift;                             // to_allele(pos)
+    }
     uint32_t w = 0;
     for (uint32_t done = 0; done < n; done += 32u, ++w) {
         const uint32_t c = n - done < 32u ? n - done : 32u;
-        tmpl[w] = reversed ? reverse_complement_bits(allele_bits(a, h - done - c, c), c) : allele_bits(a, h + done, c);
+        tmpl[w] = reversed ? reverse_complement_bits(allele_bits(a, h - done - c, c, near), c) : allele_bits(a, h + done, c, near);
     }
     for (; w < template_words; ++w) tmpl[w] = 0;
 }
