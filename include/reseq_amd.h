@@ -233,6 +233,9 @@ typedef struct {
  * rsq_sim_job_free releases the text (rsq_sim_free does too).  A single-process run has offset 0 and may as well stream (the `reseq` command line does). */
 int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint32_t batch_blocks, uint64_t *n_pairs, uint64_t *r1_bytes, uint64_t *r2_bytes, void *stream);
 int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file);
+/* `bytes` of the kept text of file `file` (0 / 1) from byte `at` on, copied into the caller's device memory: a rank's contribution to one round of a gather of
+ * the output (simulate.py --gatherOutput: fixed-size slices gathered on the first rank over RCCL, which writes them with rsq_dev_pwrite).  RSQ_ESTATE without text. */
+int rsq_sim_job_read(rsq_sim *s, int file, uint64_t at, size_t bytes, char *dst_dev, void *stream);
 int rsq_sim_job_free(rsq_sim *s);
 
 /* The hot path: Simulator::SimulationThread over blocks [block_lo, block_hi) (reseq/Simulator.cpp:2384-2401):
@@ -277,6 +280,9 @@ int rsq_dev_alloc(int device, size_t bytes, void **out_dev);
 int rsq_dev_free(int device, void *dev);
 int rsq_dev_upload(int device, void *dst_dev, const void *src, size_t bytes);
 int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes);
+/* `bytes` of device memory to byte `offset` of the file `path` (created if missing), through page-locked buffers with the copy of one slice under the write of
+ * the one before: what the ONE writer of a gathered output does with the slices it received (reseq_amd/simulate.py --gatherOutput) */
+int rsq_dev_pwrite(int device, const void *src_dev, size_t bytes, const char *path, uint64_t offset);
 /* page-locked host memory: rsq_dev_download into it runs at the full PCIe rate (the CLI's output buffers) */
 int rsq_host_alloc(size_t bytes, void **out_host);
 int rsq_host_free(void *host);

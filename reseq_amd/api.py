@@ -79,6 +79,8 @@ SYMBOLS = {
     "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rsq_sim_specialize": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "rsq_sim_export_reference": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_job_read": (C.c_int, [_vp, C.c_int, _u64, _sz, _vp, _vp]),
+    "rsq_dev_pwrite": (C.c_int, [C.c_int, _vp, _sz, C.c_char_p, _u64]),
     "rsq_sim_get_sequence_lengths": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32)]),
     "rsq_sim_import_reference": (C.c_int, [_vp, C.c_char_p]),
     "rsq_set_kernel_cache_dir": (C.c_int, [C.c_char_p]),
@@ -156,6 +158,11 @@ def archive_layout(stats_path, ipf_path=None):
     buf = C.create_string_buffer(need.value)
     _check(lib().rsq_profile_archive_layout(str(stats_path).encode(), ipf, buf, need.value, C.byref(need)))
     return buf.value.decode(errors="replace")
+
+
+def dev_pwrite(device, src_ptr, nbytes, path, offset):
+    """device memory at `src_ptr` to byte `offset` of a file (page-locked double buffers)"""
+    _check(lib().rsq_dev_pwrite(device, C.c_void_p(src_ptr), nbytes, os.fsencode(path), offset))
 
 
 def set_kernel_cache_dir(path):
@@ -454,6 +461,10 @@ class Simulator:
     def job_write(self, r1_path, r1_offset, r2_path, r2_offset, threads_per_file=0):
         """the kept text to its place in the two final files (parallel pwrite from page-locked buffers)"""
         _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode(), r2_offset, threads_per_file))
+
+    def job_read(self, file, at, nbytes, dst_ptr, stream=None):
+        """bytes [at, at + nbytes) of the kept text of file 0 / 1 into device memory at `dst_ptr` (an integer address, e.g. a torch tensor's data_ptr())"""
+        _check(lib().rsq_sim_job_read(self.h, file, at, nbytes, C.c_void_p(dst_ptr), stream))
 
     def job_free(self):
         _check(lib().rsq_sim_job_free(self.h))

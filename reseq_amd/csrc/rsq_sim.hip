@@ -1777,6 +1777,36 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
     });
 }
 
+// a stretch of the kept text into device memory of the caller (what a rank contributes to one round of a gather of the output)
+int rsq_sim_job_read(rsq_sim *s, int file, uint64_t at, size_t bytes, char *dst_dev, void *stream) {
+    REQUIRE(s && (file == 0 || file == 1) && (dst_dev || !bytes), "null argument, or a file that is neither 0 nor 1");
+    return guard([&] {
+        const rsq_sim::JobText &job = s->job;
+        if (!job.complete) {
+            g_last_error = "rsq_sim_job_read: there is no generated text (rsq_sim_job_generate has not run to its end on this simulator, or rsq_sim_job_free has released it)";
+            return (int)RSQ_ESTATE;
+        }
+        if (at > job.bytes[file] || bytes > job.bytes[file] - at) {
+            g_last_error = "rsq_sim_job_read: bytes [" + std::to_string(at) + ", " + std::to_string(at + bytes) + ") lie outside the file's " + std::to_string(job.bytes[file]) + " bytes of text";
+            return (int)RSQ_EINVAL;
+        }
+        HIP_CHECK(hipSetDevice(s->device));
+        uint64_t chunk_at = 0;
+        size_t left = bytes, put = 0;
+        for (size_t c = 0; c < job.chunks[file].size() && left; ++c) {            // the text lies in a list of device arrays
+            const uint64_t c_end = chunk_at + job.used[file][c];
+            if (at < c_end) {
+                const size_t n = (size_t)std::min<uint64_t>(left, c_end - at);
+                HIP_CHECK(hipMemcpyAsync(dst_dev + put, job.chunks[file][c]->as<char>() + (at - chunk_at), n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                at += n, put += n, left -= n;
+            }
+            chunk_at = c_end;
+        }
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        return (int)RSQ_OK;
+    });
+}
+
 int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_dev, size_t r1_cap, size_t *r1_len, char *r2_dev, size_t r2_cap, size_t *r2_len,
                                void *stream) {
     REQUIRE(s && r1_len && r2_len && s->prepared, "simulator not prepared");
@@ -1916,6 +1946,49 @@ int rsq_host_alloc(size_t bytes, void **out_host) {
 int rsq_host_free(void *host) {
     return guard([&] {
         if (host) HIP_CHECK(hipHostFree(host));
+        return RSQ_OK;
+    });
+}
+// device memory to its place in a file: slices through two page-locked buffers, the copy of one under the write of the one before (the writer of a gathered output)
+int rsq_dev_pwrite(int device, const void *src_dev, size_t bytes, const char *path, uint64_t offset) {
+    REQUIRE(path && (src_dev || !bytes), "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        struct Staging {
+            hipStream_t st = nullptr;
+            char *host[2] = {nullptr, nullptr};
+            int fd = -1;
+            ~Staging() {
+                if (st) (void)hipStreamSynchronize(st);
+                for (char *h : host)
+                    if (h) (void)hipHostFree(h);
+                if (st) (void)hipStreamDestroy(st);
+                if (fd >= 0) close(fd);
+            }
+        } g;
+        g.fd = open(path, O_WRONLY | O_CREAT, 0644);
+        if (g.fd < 0) throw Error(std::string("cannot open '") + path + "' for writing: " + strerror(errno));
+        constexpr size_t kSlice = (size_t)16 << 20;
+        HIP_CHECK(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
+        for (char *&h : g.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h), std::min(kSlice, std::max<size_t>(bytes, 1)), hipHostMallocDefault));
+        const char *src = static_cast<const char *>(src_dev);
+        const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+        auto copy = [&](size_t i) { HIP_CHECK(hipMemcpyAsync(g.host[i & 1], src + i * kSlice, std::min(kSlice, bytes - i * kSlice), hipMemcpyDeviceToHost, g.st)); };
+        if (n_slices) copy(0);
+        for (size_t i = 0; i < n_slices; ++i) {
+            HIP_CHECK(hipStreamSynchronize(g.st));
+            if (i + 1 < n_slices) copy(i + 1);
+            const size_t n = std::min(kSlice, bytes - i * kSlice);
+            for (size_t done = 0; done < n;) {
+                const ssize_t w = pwrite(g.fd, g.host[i & 1] + done, n - done, (off_t)(offset + i * kSlice + done));
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) throw Error(std::string("writing '") + path + "' failed: " + (w < 0 ? strerror(errno) : "no space"));
+                done += (size_t)w;
+            }
+        }
+        const int fd = g.fd;
+        g.fd = -1;
+        if (close(fd) != 0) throw Error(std::string("closing '") + path + "' failed: " + strerror(errno));
         return RSQ_OK;
     });
 }

@@ -93,6 +93,20 @@ class GpuBackend:
     def adapter_only_pairs(self, first, n):
         return self.sim.adapter_only_pairs(first, n)
 
+    # --gatherOutput: a slice of the kept text as a device tensor of `size` bytes (the first `n` of them text), and a received slice to its place in a file
+    def job_slice(self, file, at, n, size):
+        import torch
+        t = torch.zeros(size, dtype=torch.uint8, device=f"cuda:{self.device}")
+        if n:
+            self.sim.job_read(file, at, n, t.data_ptr())
+        return t
+
+    def write_slice(self, tensor, n, path, offset):
+        self.api.dev_pwrite(self.device, tensor.data_ptr(), n, path, offset)
+
+    def job_free(self):
+        self.sim.job_free()
+
     def close(self):
         self.sim.close()
         if self.ref:
@@ -167,7 +181,32 @@ def _attempt(f, *a):
         return None, e
 
 
-def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False):
+def gather_to_first_rank(backend, dist, rank, world, sizes, outs, slice_bytes):
+    """The ranks' kept text merged by a collective (BASELINE.json's "RCCL all-gather over xGMI only to merge the emitted FASTQ buffers", as a gather: only one rank
+    writes): per file and round every rank contributes one fixed-size slice of its text (rsq_sim_job_read), the first rank receives the N slices (dist.gather: RCCL
+    over xGMI on a GPU host) and writes each to its rank's place in the file (rsq_dev_pwrite).  An option, not the default: N ranks writing their own byte ranges
+    reach what one writer reaches, and this route moves every byte once more."""
+    for f in (0, 1):
+        start = [sum(row[f] for row in sizes[:r]) for r in range(world)]
+        rounds = -(-max(row[f] for row in sizes) // slice_bytes)
+        for k in range(rounds):
+            at = k * slice_bytes
+            mine = max(0, min(slice_bytes, sizes[rank][f] - at))
+            send = backend.job_slice(f, at, mine, slice_bytes)
+            recv = [send.new_empty(slice_bytes) for _ in range(world)] if rank == 0 else None
+            if dist is not None:
+                dist.gather(send, recv, dst=0)
+            else:
+                recv = [send]
+            if rank == 0:
+                for r in range(world):
+                    n = max(0, min(slice_bytes, sizes[r][f] - at))
+                    if n:
+                        backend.write_slice(recv[r], n, outs[f], start[r] + at)
+
+
+def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False,
+             gather_output=False, gather_slice_bytes=256 << 20):
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
     small exchanges; the data never passes through Python."""
@@ -226,8 +265,14 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
 
     # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
     _agree(dist, device, _attempt(create_files)[1], "creating the output files")
-    _agree(dist, device, _attempt(backend.job_write, out1, sum(row[0] for row in sizes[:rank]), out2, sum(row[1] for row in sizes[:rank]))[1],
-           "writing its byte range")                                 # all ranks at once, each its own byte range
+    if gather_output:                                                # one writer, fed by a collective
+        def gathered():
+            gather_to_first_rank(backend, dist, rank, world, sizes, (out1, out2), gather_slice_bytes)
+            backend.job_free()
+        _agree(dist, device, _attempt(gathered)[1], "gathering the text on the first rank")
+    else:
+        _agree(dist, device, _attempt(backend.job_write, out1, sum(row[0] for row in sizes[:rank]), out2, sum(row[1] for row in sizes[:rank]))[1],
+               "writing its byte range")                             # all ranks at once, each its own byte range
     _agree(dist, device, _attempt(append_adapter_only_pairs)[1], "appending the adapter-only pairs")
     return int(total_pairs) + info["adapter_only_pairs"], elapsed
 
@@ -247,6 +292,9 @@ def main(argv=None):
     ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
     ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 4 M pairs)")
+    ap.add_argument("--gatherOutput", action="store_true", help="the ranks' text is gathered on the first rank by a collective (RCCL) in slices and written by that rank alone, "
+                    "instead of every rank writing its own byte range of the files")
+    ap.add_argument("--gatherSliceMB", type=int, default=256, help="--gatherOutput: bytes (MiB) per rank and round of the gather")
     ap.add_argument("--everyRankLoads", action="store_true", help="every rank reads and packs the reference, variant and methylation files itself (default: the first rank of a host "
                     "does and the host's other ranks take the packed result from shared memory)")
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own pair of files <out>.part<k>of<N> (their concatenation in order is the single file): "
@@ -274,7 +322,7 @@ def main(argv=None):
         backend = load_once_per_host(make, dist, f"cuda:{local_rank}", local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)))
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
-                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput)
+                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput, a.gatherOutput, a.gatherSliceMB << 20)
         if rank == 0:
             print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
     finally:

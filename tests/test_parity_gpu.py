@@ -413,6 +413,11 @@ def test_simulate_module_equals_cli(workdir):
     subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", b1, "-2", b2, "--batchBlocks", "3"], check=True, capture_output=True, env=env, cwd=root)
     assert open(a1, "rb").read() == open(b1, "rb").read() and open(a2, "rb").read() == open(b2, "rb").read()
     assert b":0:Adapter:0:" in open(a1, "rb").read()
+    # --gatherOutput (one rank here: the slices go from the kept text through rsq_sim_job_read into tensors and through rsq_dev_pwrite into the files)
+    c1, c2 = str(workdir / "u1.fq"), str(workdir / "u2.fq")
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", c1, "-2", c2, "--batchBlocks", "3", "--gatherOutput", "--gatherSliceMB", "1"], check=True, capture_output=True,
+                   env=env, cwd=root)
+    assert open(a1, "rb").read() == open(c1, "rb").read() and open(a2, "rb").read() == open(c2, "rb").read()
 
 
 def test_sharded_pre_passes(workdir):

@@ -85,6 +85,18 @@ class Emu:                      # the host emulation behind the interface simula
             os.close(fd)
     def adapter_only_pairs(self, first, n):
         return self.b.adapter_only_pairs(first, n)
+    def job_slice(self, file, at, n, size):                # --gatherOutput: a fixed-size slice of the kept text as a tensor, a received one to its place
+        import torch
+        t = torch.zeros(size, dtype=torch.uint8)
+        if n:
+            t[:n] = torch.frombuffer(bytearray(self.text[file][at:at + n]), dtype=torch.uint8)
+        return t
+    def write_slice(self, tensor, n, path, offset):
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+        os.pwrite(fd, tensor[:n].numpy().tobytes(), offset)
+        os.close(fd)
+    def job_free(self):
+        self.text = None
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:
@@ -105,7 +117,7 @@ if os.environ.get("RSQ_SHARED_LOAD"):          # the two ranks as the ranks of o
 else:
     backend = Emu(ppath, fpath, seqs, vcf)
 pairs, _ = simulate.run_rank(backend, dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3,
-                             split_output=bool(os.environ.get("RSQ_SPLIT")))
+                             split_output=bool(os.environ.get("RSQ_SPLIT")), gather_output=bool(os.environ.get("RSQ_GATHER")), gather_slice_bytes=200_000)
 if rank == 0:
     print("PAIRS", pairs)
 if world > 1:
@@ -144,6 +156,14 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
         a, b = (workdir / f"one_{k}.fq").read_bytes(), (workdir / f"two_{k}.fq").read_bytes()
         assert a == b and a.count(b"\n") % 4 == 0 and b":0:Adapter:0:" in a
     assert not list(workdir.glob("*.rank*"))
+    # --gatherOutput: the ranks' text gathered on rank 0 in slices of 200 kB (several rounds, the ranks' last slices of different lengths) and written by rank 0 alone
+    procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="gathered", RSQ_GATHER="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=800)
+        assert p.returncode == 0, se.decode()[-3000:]
+    for k in (1, 2):
+        assert (workdir / f"gathered_{k}.fq").read_bytes() == (workdir / f"one_{k}.fq").read_bytes()
     # one load per host: rank 0 reads and packs, rank 1 takes the packed reference (variants included) from the shared directory -- the same two files
     procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="shared", RSQ_SHARED_LOAD="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(2)]
