@@ -58,7 +58,7 @@ const std::map<std::string, std::string> kShort = {{"-j", "threads"}, {"-h", "he
                                                    {"-v", "vcfIn"},   {"-p", "probabilitiesIn"}, {"-P", "probabilitiesOut"}, {"-1", "firstReadsOut"},
                                                    {"-2", "secondReadsOut"}, {"-c", "coverage"}, {"-R", "refSim"}, {"-V", "vcfSim"}, {"-i", "input"}, {"-o", "output"}};
 const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors", "maxLenDeletion", "maxReadLength",
-                                      "dumpArchiveLayout"};
+                                      "dumpArchiveLayout", "traceStages"};
 
 bool parse(int argc, char **argv, int first, Args &a) {
     for (int i = first; i < argc; ++i) {
@@ -811,13 +811,22 @@ int seq_to_illumina(const Args &a) {
         ParsePipeline pipe(fin, parsers);
         DevBuffer d_seqs, d_dom, d_rate, d_seg, d_fl, d_ids, d_off, d_text;
         uint64_t written = 0, next_report = 0;
+        // --traceStages: where the consuming thread's time goes (waiting for a parsed block, uploads, the device call, handing the text to the writer)
+        const bool trace = a.has("traceStages");
+        double t_wait = 0, t_up = 0, t_dev = 0, t_push = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
+        const auto t_all = now();
         while (ok) {
+            auto t0 = now();
             ParseSlot *b = pipe.take();
+            t_wait += since(t0);
             if (!b) break;
             for (size_t r = 0; ok && r < b->runs.size(); ++r) {
                 const ParseSlot::Run &run = b->runs[r];
                 const size_t n = run.n, L = run.L;
                 const size_t run_id_bytes = (size_t)b->id_off.as<uint64_t>()[run.first + r + n];
+                t0 = now();
                 ok = d_seqs.ensure(n * L + 8) && d_dom.ensure(n * L + 8) && d_rate.ensure(n * L + 8) && d_seg.ensure(n) && d_fl.ensure(n * 4) && d_ids.ensure(run_id_bytes + 8) &&
                      d_off.ensure((n + 1) * 8) && check(rsq_dev_upload(0, d_seqs.p, b->seqs.as<uint8_t>() + run.base_at, n * L), "upload") &&
                      check(rsq_dev_upload(0, d_dom.p, b->dom.as<uint8_t>() + run.base_at, n * L), "upload") &&
@@ -826,6 +835,8 @@ int seq_to_illumina(const Args &a) {
                      check(rsq_dev_upload(0, d_fl.p, b->fl.as<uint32_t>() + run.first, n * 4), "upload") &&
                      check(rsq_dev_upload(0, d_ids.p, b->ids.as<char>() + run.id_first, run_id_bytes + 1), "upload") &&
                      check(rsq_dev_upload(0, d_off.p, b->id_off.as<uint64_t>() + run.first + r, (n + 1) * 8), "upload");
+                t_up += since(t0);
+                t0 = now();
                 size_t len = 0;
                 for (int attempt = 0; ok && attempt < 2; ++attempt) {
                     ok = d_text.ensure(std::max(len + len / 8, n * (2 * L + 96) + run_id_bytes) + 64);
@@ -837,7 +848,10 @@ int seq_to_illumina(const Args &a) {
                     ok = check(rc, "Simulation failed");
                     break;
                 }
+                t_dev += since(t0);
+                t0 = now();
                 ok = ok && fout.push(d_text, len);
+                t_push += since(t0);
                 written += n;                                     // = the index of the next record in the input (it selects the records' random streams)
             }
             pipe.release();                                       // the records are on the device: the slot may take the next block
@@ -846,6 +860,9 @@ int seq_to_illumina(const Args &a) {
                 next_report = written + 1000000;
             }
         }
+        if (trace)
+            fprintf(stderr, "stages of the consuming thread: %.3f s in all for %llu records; waiting for parsed blocks %.3f, uploads %.3f, device (error model + text) %.3f, text to the writer %.3f\n",
+                    since(t_all), (unsigned long long)written, t_wait, t_up, t_dev, t_push);
         pipe.join();
         ok = ok && !pipe.failed && !fin.failed;
         if (ok && !pipe.any) {

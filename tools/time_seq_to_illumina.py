@@ -54,8 +54,9 @@ exe = os.path.join(ROOT, "reseq_amd", "reseq")
 times = []
 for _ in range(2):
     t0 = time.perf_counter()
-    subprocess.run([exe, "seqToIllumina", "-i", inp, "-o", out, "-s", ppath, "--seed", "5"], check=True, capture_output=True)
+    r = subprocess.run([exe, "seqToIllumina", "-i", inp, "-o", out, "-s", ppath, "--seed", "5", "--traceStages"] + sys.argv[2:], check=True, capture_output=True, text=True)
     times.append(time.perf_counter() - t0)
+    stages = [l for l in r.stderr.splitlines() if l.startswith("stages of")]
 # the first records against the oracle
 import oracle_lib as O  # noqa: E402
 K = 3000
@@ -86,7 +87,7 @@ if N <= 10_000_000 and N > 2 * BASE:
             lines_seen += 1
     mid_ok = b"".join(got_mid).decode() == want_mid
 in_bytes, out_bytes = os.path.getsize(inp), os.path.getsize(out)
-print(json.dumps({"config": "configs[2] through `reseq seqToIllumina` (files in /dev/shm)", "records": N, "read_len": L, "wall_s": times, "reads_per_s_wall": N / min(times),
+print(json.dumps({"config": "configs[2] through `reseq seqToIllumina` (files in /dev/shm)", "records": N, "read_len": L, "wall_s": times, "stages": stages[-1] if stages else None, "reads_per_s_wall": N / min(times),
                   "input_bytes": in_bytes, "output_bytes": out_bytes, "first_records_equal_oracle": got == want, "checked_records": K, "records_in_the_middle_equal_oracle": mid_ok}))
 for p in (inp, out, ppath):
     os.remove(p)
