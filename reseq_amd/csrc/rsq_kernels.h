@@ -204,7 +204,7 @@ RSQ_HD double site_bias(const DevSim &S, uint64_t word_off, uint32_t L, uint32_t
     return general_bias * S.gc_bias[percent_u32(gc_count, len)] * surrounding_bias(S.sur_bias, ss) * surrounding_bias(S.sur_bias, se);
 }
 
-#if RSQ_DEVICE_BUILD
+#if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)      // the library's kernels: not part of a read kernel compiled for one profile (rsq_spec.h)
 
 // Speculative chunking: pass 0 runs every chunk from a guess of its incoming (dist,start_rate); later passes re-run exactly the
 // chunks whose true incoming state (the outgoing state of their left neighbour) differs from the one they used.
@@ -688,7 +688,7 @@ RSQ_HD uint32_t init_site_slot(const DevSim &S, uint32_t block_lo, uint32_t bloc
     }
 }
 
-#if RSQ_DEVICE_BUILD
+#if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)      // the library's kernels: not part of a read kernel compiled for one profile (rsq_spec.h)
 // The sieve.
 //   k_sieve_gaps<VM, false>: one lane per start position slot counts the cells that pass the zero threshold (sieve_gaps);
 //   exclusive scan of the counts;
@@ -2109,6 +2109,7 @@ RSQ_HD PairStream pair_stream(const Fragment *f, uint32_t sub, uint64_t adapter_
 }
 
 #if RSQ_DEVICE_BUILD
+#if !defined(RSQ_SPEC)
 // bin keys of the items + their histogram.  Pairs: key = tile (TileId() once per pair, Simulator.cpp:701-704); records: key = segment * n_tiles + tile.
 __device__ inline void bin_count_key(uint32_t key, bool valid, uint32_t n_keys, uint32_t *hist, uint32_t *s_hist) {
     if (n_keys <= kBinKeysLds) {
@@ -2219,6 +2220,7 @@ __global__ void __launch_bounds__(kBinBlock) k_bin_scatter(const uint16_t *key_o
         if (key[j] != 0xFFFFFFFFu) place(s_base[key[j]] + rank[j], first + (uint64_t)j * kBinBlock + threadIdx.x);
 }
 
+#endif
 // One lane per read, persistent waves.  A workgroup serves one LDS image at a time -- a template segment (blockIdx.x & 1) with all tiles, built once, every
 // wave pulling chunks of 64 pairs from the segment's counter until the batch is exhausted (no tail); or, BINNED, the (segment, tile) of the work unit
 // it took (fill_binned_loop).  All lanes of a wave walk their reads' state machines in one uniform loop.  MASK = quads per quality row of the
@@ -2463,6 +2465,7 @@ template <uint32_t MASK, bool BINNED = false>
 __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
     fill_records_body<MASK, BINNED>(S, job, raw, chunk_counters, bins);
 }
+#if !defined(RSQ_SPEC)
 // the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known
 __global__ void k_record_flags(const uint8_t *segs, uint64_t n, uint32_t *flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2498,9 +2501,10 @@ __global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragm
     variant_template(S, frags[pair], fvars[pair], seg, raw.templates + r * raw.template_words, raw.template_words);
 }
 
+#endif
 #endif  // __HIPCC__
 
-#if RSQ_DEVICE_BUILD
+#if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)      // the library's kernels: not part of a read kernel compiled for one profile (rsq_spec.h)
 // FASTQ text: one wave per 16 consecutive records of one file (grid.y = template segment = output file).  The records
 // occupy one contiguous byte range of the output, so the wave formats them into an LDS image of that range (laid out with
 // the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Four lanes
