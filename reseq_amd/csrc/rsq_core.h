@@ -196,7 +196,7 @@ RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &..
 // ------------------------------------------------------------------------------------------ screened draw
 // The read kernel's draws in SINGLE precision with a proof obligation: the outcome is taken only when it provably equals the
 // outcome of the double-precision recipe above, otherwise the lane repeats the draw in double precision (draw<NM>, from HBM).
-// Rows are float copies of the tables (DevTable::off32), four columns per 16-byte load, pad columns zero.
+// Rows are float copies of the tables (the read kernel's families: FamilyGeo, rsq_types.h; the chains': DevTable::off32), four columns per 16-byte load, pad columns zero.
 //
 // Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns from the top quad down and keeps, per quad, the sum of the columns from the top down to it; S = the
 // last of them.  Pass 2 finds the quad in which the sum from the top first exceeds r = u*S among those sums (no loads), reloads that quad

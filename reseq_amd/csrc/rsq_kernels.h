@@ -1580,7 +1580,7 @@ RSQ_HD uint32_t draw_tile(const DevSim &S, uint32_t c0, uint32_t c1, uint32_t c2
 //  * rows chosen by per-read state -- quality margins over sequence quality (0) and previous quality (1), base-call margins over
 //    the quality (0) and the number of errors (2), indel margin over the indel position (0);
 //  * the first rows of the error-rate margins (88 % of all positions have rate 0).  A lane whose rate is not staged reads its
-//    own row from HBM (HybridRow32).
+//    own row from HBM (MixedRow32, rsq_core.h).
 // The rows over the read position and the read's G/C percent stay in HBM (L2): the lanes of a wave share the position rows (4
 // cache lines per load).  A draw the screen cannot decide is repeated in double precision from HBM (GlobalTables).
 // Image layout (32-bit words), Ti = LdsPlan::img_tiles: descriptors [quality 4 Ti][base_call 20 Ti][indels 12][seq_quality Ti] (18 words

@@ -228,7 +228,7 @@ struct DevSim {
     // ---- tables
     const double *pool;
     const uint32_t *chain_sure;    // error-rate tables: lo16 | hi16 << 16 per (table, row of margin 0, row of margin 2), DevTable::sure_range (rsq_pack.h)
-    const float *pool32;           // single-precision copy of the quality, base-call and indel tables (DevTable::off32)
+    const float *pool32;           // single-precision copies: the read kernel's three families (FamilyGeo::off32), the chains' two (DevTable::off32)
     const uint8_t *par0;
     const DevTable *quality;       // [2][n_tiles][4]
     const DevTable *seq_quality;   // [2][n_tiles]
