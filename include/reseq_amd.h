@@ -267,6 +267,18 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
                               const uint32_t *frag_len_dev, const uint8_t *dom_dev, const uint8_t *rate_dev, const char *ids_dev, const uint64_t *id_off_dev,
                               char *text_dev, size_t text_cap, size_t *text_len, void *stream);
 
+/* The same from the FASTA text itself, parsed on the device (reseq/Simulator.cpp:2423-2485 are the header's checks, :2900-3014 the reader this replaces):
+ * text_dev[0, text_len) is a stretch of the input file as it stands there, beginning at a record's '>' (line ends may precede it); records are
+ * ">{id} {1|2};{fragment length};{dominant errors};{error rates}" and the template on one line or wrapped over several, line ends \n or \r\n.
+ * final = 0: more text follows, so the block's last record may be cut off -- it is left out, *consumed = its offset, and the caller hands the bytes from there on
+ * again in front of the text that follows (no record starts in the block: *consumed = 0, *n_records = 0 -- hand in more).  final = 1: the block ends the input,
+ * *consumed = text_len.  The records' FASTQ text goes to out_dev in input order exactly as rsq_sim_error_model_fastq writes it (*out_len bytes; RSQ_ENOSPC and
+ * nothing written if out_cap is smaller), *n_records = their number; first_index = the index in the input of the block's first record.
+ * A malformed record -- the first in input order -- ends the call with RSQ_EIO and the reference's message about it in rsq_last_error().
+ * Kernel time: "parse_records" beside the names below.  text_len < 4 GB. */
+int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text_dev, size_t text_len, int final, char *out_dev, size_t out_cap, size_t *out_len,
+                              uint64_t *n_records, size_t *consumed, void *stream);
+
 /* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded around each kernel on the stream it was launched on.  A call
  * over a large block range runs as several sub-ranges (blocks are independent, Simulator.cpp:2384-2401) whose sieve / reads / text stages are pipelined on
  * three streams: the time is the SUM over the call's launches of that kernel, rsq_sim_last_kernel_launches says how many there were.
@@ -286,6 +298,13 @@ int rsq_dev_pwrite(int device, const void *src_dev, size_t bytes, const char *pa
 /* page-locked host memory: rsq_dev_download into it runs at the full PCIe rate (the CLI's output buffers) */
 int rsq_host_alloc(size_t bytes, void **out_host);
 int rsq_host_free(void *host);
+/* Streams of the caller's own, for a pipeline whose sides run in threads (the seqToIllumina command: readers upload blocks of text, one thread runs
+ * rsq_sim_error_model_fasta, one downloads the FASTQ text; the reference's shape is one reader, worker threads and ordered output, Simulator.cpp:2900-3014):
+ * the plain copies above use the null stream, which waits for all others.  rsq_dev_copy_on returns when its copy is done; kind 0 = host to device,
+ * 1 = device to host, 2 = device to device; host memory from rsq_host_alloc for the full rate. */
+int rsq_stream_create(int device, void **out_stream);
+int rsq_stream_destroy(int device, void *stream);
+int rsq_dev_copy_on(int device, void *dst, const void *src, size_t bytes, int kind, void *stream);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ SYMBOLS = {
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "rsq_sim_error_model_fastq": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "rsq_sim_error_model_fasta": (C.c_int, [_vp, _u64, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_u64), C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "rsq_sim_last_kernel_launches": (C.c_int, [_vp, C.c_char_p, C.POINTER(_u32)]),
     "rsq_dev_alloc": (C.c_int, [C.c_int, _sz, _pp]),
@@ -110,6 +111,9 @@ SYMBOLS = {
     "rsq_dev_download": (C.c_int, [C.c_int, _vp, _vp, _sz]),
     "rsq_host_alloc": (C.c_int, [_sz, _pp]),
     "rsq_host_free": (C.c_int, [_vp]),
+    "rsq_stream_create": (C.c_int, [C.c_int, _pp]),
+    "rsq_stream_destroy": (C.c_int, [C.c_int, _vp]),
+    "rsq_dev_copy_on": (C.c_int, [C.c_int, _vp, _vp, _sz, C.c_int, _vp]),
 }
 
 _lib = None
@@ -533,6 +537,27 @@ class Simulator:
             return text.to_numpy(np.uint8, need.value).tobytes()
         finally:
             for d in ins + ([text] if text else []):
+                d.free()
+
+    def error_model_fasta(self, text, first_index=0, final=True, stream=None):
+        """seqToIllumina's FASTA text parsed on the device (rsq_sim_error_model_fasta; Simulator.cpp:2403-2512): text = bytes of the input file from a record's
+        '>' on.  Returns (FASTQ text, records written, bytes consumed); final=False leaves the block's last record to the caller (hand text[consumed:] in
+        again in front of what follows).  A malformed record raises with the reference's message."""
+        dev = self.device
+        src = DeviceArray.from_numpy(dev, np.frombuffer(bytes(text) + b"\0" * 8, np.uint8))
+        need, n, used = C.c_size_t(0), _u64(0), C.c_size_t(0)
+        out = None
+        try:
+            rc = lib().rsq_sim_error_model_fasta(self.h, first_index, src.ptr, len(text), 1 if final else 0, None, 0, C.byref(need), C.byref(n), C.byref(used), stream)
+            if rc != RSQ_ENOSPC:
+                _check(rc)
+                return b"", n.value, used.value
+            out = DeviceArray(dev, need.value + 16)
+            _check(lib().rsq_sim_error_model_fasta(self.h, first_index, src.ptr, len(text), 1 if final else 0, out.ptr, need.value + 16, C.byref(need), C.byref(n),
+                                                   C.byref(used), stream))
+            return out.to_numpy(np.uint8, need.value).tobytes(), n.value, used.value
+        finally:
+            for d in [src] + ([out] if out else []):
                 d.free()
 
     def last_kernel_ms(self, name):

@@ -9,9 +9,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 #include <fstream>
 #include <iostream>
@@ -480,79 +485,16 @@ int illumina_pe(const Args &a) {
     return 0;
 }
 
-// One FASTA record of seqToIllumina's input: "{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485)
-struct RecordFields {
-    size_t id_len = 0, dom_at = 0, rate_at = 0;
-    uint8_t seg = 0;
-    uint32_t frag_len = 0;
-};
-bool parse_record(const char *header, size_t header_len, size_t L, RecordFields &r) {
-    auto text = [&]() { return std::string(header, header_len); };
-    if (header_len <= 2 * L + 2) {
-        ERR("Read description is too short to contain systematic error information and a sequence id: " << text());
-        return false;
-    }
-    size_t end = header_len - 2 * L - 3;
-    if (header[end + 1] != ';' || header[end + 2 + L] != ';') {
-        ERR("The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " << text());
-        return false;
-    }
-    r.dom_at = end + 2;
-    r.rate_at = header_len - L;
-    while (end && header[end] != ' ') --end;
-    if (!end) {
-        ERR("No sequence id found that is separated by a space from the ReSeq information: " << text());
-        return false;
-    }
-    r.id_len = end;
-    if (header[end + 1] == '1') r.seg = 0;
-    else if (header[end + 1] == '2') r.seg = 1;
-    else {
-        ERR("Template segment is " << header[end + 1] << " not 1 or 2: " << text());
-        return false;
-    }
-    if (header[end + 2] != ';') {
-        ERR("The template segment and fragment length are not separated by a semicolon: " << text());
-        return false;
-    }
-    const size_t fl_at = end + 3, fl_end = header_len - 2 * L - 2;
-    uint64_t v = 0;
-    bool digits = fl_end > fl_at;
-    for (size_t k = fl_at; k < fl_end && digits; ++k) {
-        digits = header[k] >= '0' && header[k] <= '9';
-        v = v * 10 + (uint64_t)(header[k] - '0');
-    }
-    if (!digits) {
-        ERR("Fragment length '" << std::string(header + fl_at, fl_end > fl_at ? fl_end - fl_at : 0) << "' is not a pure integer: " << text());
-        return false;
-    }
-    r.frag_len = (uint32_t)v;
-    return true;
-}
-
-struct CodeTable {
-    uint8_t code[256];
-    CodeTable() {
-        memset(code, 4, sizeof code);
-        code[(uint8_t)'A'] = code[(uint8_t)'a'] = 0;
-        code[(uint8_t)'C'] = code[(uint8_t)'c'] = 1;
-        code[(uint8_t)'G'] = code[(uint8_t)'g'] = 2;
-        code[(uint8_t)'T'] = code[(uint8_t)'t'] = 3;
-    }
-};
-
 struct HostArray {                    // page-locked, grow-only
     void *p = nullptr;
     size_t cap = 0;
-    bool ensure(size_t n, size_t keep = 0) {
+    bool ensure(size_t n) {
         if (n <= cap) return true;
-        void *q = nullptr;
-        const size_t want = std::max(n, cap + cap / 2);
-        if (!check(rsq_host_alloc(want, &q), "host buffer")) return false;
-        if (p && keep) memcpy(q, p, std::min(keep, cap));
         if (p) rsq_host_free(p);
-        p = q;
-        cap = want;
+        p = nullptr;
+        cap = 0;
+        if (!check(rsq_host_alloc(n, &p), "host buffer")) return false;
+        cap = n;
         return true;
     }
     template <class T>
@@ -562,210 +504,143 @@ struct HostArray {                    // page-locked, grow-only
     }
 };
 
-// One block of the input text and what a parser thread makes of it: the records packed for rsq_sim_error_model_fastq, in runs of one
-// template length each (a launch serves one length).  Slots go round: FREE -> TEXT (reader) -> PARSING -> PARSED (a parser) -> FREE (consumer).
-struct ParseSlot {
-    enum State { FREE, TEXT, PARSING, PARSED } state = FREE;
-    std::vector<char> text;           // whole records: ends behind the last line of a record
-    size_t text_len = 0;
-    bool failed = false;
-    struct Run {
-        size_t first, n, L, base_at, id_first;      // records [first, first + n) of the slot, their bases from base_at on
-    };
-    std::vector<Run> runs;
-    size_t n = 0, bases = 0, id_bytes = 0;
-    HostArray seqs, dom, rate, seg, fl, ids, id_off;   // id_off: per run n + 1 offsets relative to the run's first id, stored at first + run index
-    bool reserve(size_t records, size_t n_bases, size_t n_id_bytes) {
-        return seqs.ensure(n_bases, bases) && dom.ensure(n_bases, bases) && rate.ensure(n_bases, bases) && seg.ensure(records, n) && fl.ensure(records * 4, n * 4) &&
-               id_off.ensure((records + runs.size() + 2) * 8, (n + runs.size() + 1) * 8) && ids.ensure(n_id_bytes, id_bytes);
-    }
-    // parses text[0, text_len) -- complete records -- into the arrays
-    bool parse() {
-        static const CodeTable t;
-        runs.clear();
-        n = bases = id_bytes = 0;
-        const char *p = text.data(), *end = p + text_len;
-        std::string joined;                                   // a sequence that is wrapped over several lines
-        while (p < end) {
-            while (p < end && (*p == '\n' || *p == '\r')) ++p;
-            if (p == end) break;
-            if (*p != '>') {                                   // text in front of the first header: SeqAn skips nothing here, but such a file is not FASTA
-                ERR("sequence data without a header line in the input");
-                return false;
-            }
-            const char *h0 = p + 1, *h1 = (const char *)memchr(h0, '\n', (size_t)(end - h0));
-            if (!h1) h1 = end;
-            const char *line = h1 < end ? h1 + 1 : end;
-            size_t header_len = (size_t)(h1 - h0);
-            if (header_len && h0[header_len - 1] == '\r') --header_len;
-            const char *seq = line;
-            size_t L = 0;
-            joined.clear();
-            bool single = true;
-            while (line < end && *line != '>') {
-                const char *le = (const char *)memchr(line, '\n', (size_t)(end - line));
-                if (!le) le = end;
-                size_t len = (size_t)(le - line);
-                if (len && line[len - 1] == '\r') --len;
-                if (L == 0 && joined.empty()) {
-                    seq = line;
-                    L = len;
-                } else if (len) {
-                    if (single) {
-                        joined.assign(seq, L);
-                        single = false;
-                    }
-                    joined.append(line, len);
-                }
-                line = le < end ? le + 1 : end;
-            }
-            if (!single) {
-                seq = joined.data();
-                L = joined.size();
-            }
-            RecordFields r;
-            if (!parse_record(h0, header_len, L, r)) return false;
-            if (runs.empty() || runs.back().L != L) runs.push_back(Run{n, 0, L, bases, id_bytes});
-            if (!reserve(n + 1, bases + L, id_bytes + r.id_len + 8)) return false;
-            uint8_t *sq = seqs.as<uint8_t>() + bases, *dm = dom.as<uint8_t>() + bases, *rt = rate.as<uint8_t>() + bases;
-            uint8_t any = 0;
-            for (size_t k = 0; k < L; ++k) {
-                sq[k] = t.code[(uint8_t)seq[k]];
-                any |= sq[k];
-                dm[k] = t.code[(uint8_t)h0[r.dom_at + k]];
-                int v = (uint8_t)h0[r.rate_at + k] - 33;                 // Simulator.cpp:2439-2442
-                if (v > 86) v += v - 86;
-                rt[k] = (uint8_t)v;
-            }
-            if (any & 4u) {
-                ERR("input sequences must not contain N: " << std::string(h0, r.id_len));
-                return false;
-            }
-            seg.as<uint8_t>()[n] = r.seg;
-            fl.as<uint32_t>()[n] = r.frag_len;
-            memcpy(ids.as<char>() + id_bytes, h0, r.id_len);
-            Run &run = runs.back();
-            uint64_t *off = id_off.as<uint64_t>() + run.first + (runs.size() - 1);      // n + 1 offsets per run
-            if (!run.n) off[0] = 0;
-            id_bytes += r.id_len;
-            off[run.n + 1] = id_bytes - run.id_first;
-            ++run.n;
-            ++n;
-            bases += L;
-            p = line;
-        }
-        return true;
-    }
+using Clock = std::chrono::steady_clock;
+const Clock::time_point g_process_start = Clock::now();
+double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+struct StageTime {                    // seconds a side of the pipeline spent in one of its stages, summed over its threads
+    std::atomic<uint64_t> ns{0};
+    void add(Clock::time_point t0) { ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
+    double s() const { return (double)ns.load() * 1e-9; }
 };
 
-// reader thread (cuts the text into blocks of whole records), parser threads, and the consumer's view of the slots in input order
-struct ParsePipeline {
-    static constexpr size_t kBlockBytes = 24u << 20;
-    TextIn &in;
-    std::vector<ParseSlot> slots;
+// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: a reader, ErrorModelOnlyThread :2514-2560, ordered output
+// :184-213).  Here the FASTA text goes to the device as it stands in the file and is parsed there (rsq_sim_error_model_fasta), so the host only moves bytes:
+//   input side    blocks of the file in page-locked slots, uploaded by the thread that read them -- a plain file is read by several threads at fixed offsets
+//                 (records that cross a block's end are the simulator side's business), a compressed file or stdin by one;
+//   simulator     the main thread takes the blocks in input order -- all that are there, up to eight -- and puts them behind what the call before left over
+//                 (device to device: a call on 100 000 records takes 1.1 ms, on 800 000 four: the read kernel of a small call is a chain of 150 steps on waves
+//                 that have a SIMD to themselves), runs the device call;
+//   output side   a thread downloads the FASTQ text into page-locked buffers, another writes (and compresses) them: OutPipe.
+// Every side has its own stream and its own buffers: they overlap.
+struct InPipe {
+    struct Slot {
+        HostArray host;
+        DevBuffer dev;
+        size_t len = 0;
+        bool last = false, ready = false;
+        uint64_t turn = 0;                           // the block this slot serves next
+    };
+    const size_t block_bytes;
+    std::vector<Slot> slots;
+    TextIn *stream_in = nullptr;                     // sequential input (stdin, gzip, bzip2) ...
+    int fd = -1;                                     // ... or a plain file read at offsets
+    uint64_t file_size = 0, n_blocks = 0;
+    std::atomic<uint64_t> next{0};
     std::mutex m;
     std::condition_variable cv;
-    std::vector<std::thread> workers;
-    uint64_t blocks_read = 0, next_take = 0;
-    bool eof = false, failed = false, abort = false, any = false;
-    ParsePipeline(TextIn &input, size_t parsers) : in(input), slots(parsers + 2) {
-        workers.emplace_back([this] { read_blocks(); });
-        for (size_t k = 0; k < parsers; ++k) workers.emplace_back([this] { parse_blocks(); });
+    std::vector<std::thread> readers;
+    bool failed = false, abort = false;
+    StageTime t_read, t_upload, t_slot;
+    InPipe(size_t block, size_t n_readers) : block_bytes(block), slots(n_readers + 2) {
+        for (size_t k = 0; k < slots.size(); ++k) slots[k].turn = k;
+    }
+    void start_file(int file, uint64_t size, size_t n_readers) {
+        fd = file;
+        file_size = size;
+        n_blocks = std::max<uint64_t>(1, (size + block_bytes - 1) / block_bytes);
+        for (size_t k = 0; k < n_readers; ++k) readers.emplace_back([this] { read_at_offsets(); });
+    }
+    void start_stream(TextIn &in) {
+        stream_in = &in;
+        readers.emplace_back([this] { read_in_sequence(); });
     }
     void fail() {
         std::lock_guard<std::mutex> lock(m);
         failed = true;
         cv.notify_all();
     }
-    void read_blocks() {
-        std::vector<char> carry;
-        for (uint64_t b = 0;; ++b) {
-            ParseSlot *slot = &slots[b % slots.size()];
-            {
-                std::unique_lock<std::mutex> lock(m);
-                cv.wait(lock, [&] { return slot->state == ParseSlot::FREE || abort || failed; });
-                if (abort || failed) break;
+    Slot *wait_for_slot(uint64_t b) {                // the slot of block b once the block that used it before is done with; nullptr: the run ends
+        const auto t0 = Clock::now();
+        Slot *s = &slots[b % slots.size()];
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return (s->turn == b && !s->ready) || abort || failed; });
+        t_slot.add(t0);
+        return abort || failed ? nullptr : s;
+    }
+    bool upload_and_publish(Slot *s, size_t len, bool last, void *stream) {
+        const auto t0 = Clock::now();
+        if (!check(rsq_dev_copy_on(0, s->dev.p, s->host.p, len, 0, stream), "upload")) return false;
+        t_upload.add(t0);
+        std::lock_guard<std::mutex> lock(m);
+        s->len = len;
+        s->last = last;
+        s->ready = true;
+        cv.notify_all();
+        return true;
+    }
+    void read_at_offsets() {
+        void *stream = nullptr;
+        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
+        for (;;) {
+            const uint64_t b = next++;
+            if (b >= n_blocks) break;
+            Slot *s = wait_for_slot(b);
+            if (!s) break;
+            const uint64_t off = b * block_bytes;
+            const size_t len = (size_t)std::min<uint64_t>(block_bytes, file_size - off);
+            if (!s->host.ensure(block_bytes) || !s->dev.ensure(block_bytes + 16)) return fail();
+            const auto t0 = Clock::now();
+            for (size_t have = 0; have < len;) {
+                const ssize_t got = pread(fd, s->host.as<char>() + have, len - have, (off_t)(off + have));
+                if (got <= 0) {
+                    if (got < 0 && errno == EINTR) continue;
+                    ERR("reading the input failed" << (got ? std::string(": ") + strerror(errno) : std::string(": the file has become shorter")));
+                    return fail();
+                }
+                have += (size_t)got;
             }
-            std::vector<char> &text = slot->text;
-            text.resize(std::max(text.size(), carry.size() + kBlockBytes + 1));
-            memcpy(text.data(), carry.data(), carry.size());
-            size_t have = carry.size();
-            carry.clear();
+            t_read.add(t0);
+            if (!upload_and_publish(s, len, b + 1 == n_blocks, stream)) return fail();
+        }
+        rsq_stream_destroy(0, stream);
+    }
+    void read_in_sequence() {
+        void *stream = nullptr;
+        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
+        for (uint64_t b = 0;; ++b) {
+            Slot *s = wait_for_slot(b);
+            if (!s) break;
+            if (!s->host.ensure(block_bytes) || !s->dev.ensure(block_bytes + 16)) return fail();
+            const auto t0 = Clock::now();
+            size_t have = 0;
             bool end_of_input = false;
-            for (;;) {                                        // until the block holds the start of another record behind its first one, or the input ends
-                if (have + (1u << 20) > text.size()) text.resize(text.size() * 2);
-                const int got = in.read_raw(text.data() + have, (unsigned)std::min<size_t>(text.size() - have, 1u << 30));
+            while (have < block_bytes) {
+                const int got = stream_in->read_raw(s->host.as<char>() + have, (unsigned)std::min<size_t>(block_bytes - have, 1u << 30));
                 if (got < 0) return fail();
                 if (!got) {
                     end_of_input = true;
                     break;
                 }
                 have += (size_t)got;
-                if (have >= kBlockBytes) {
-                    size_t cut = have;                        // the last "\n>" of the block
-                    while (cut > 1 && !(text[cut - 1] == '>' && text[cut - 2] == '\n')) --cut;
-                    if (cut > 1) {
-                        carry.assign(text.begin() + (ptrdiff_t)(cut - 1), text.begin() + (ptrdiff_t)have);
-                        have = cut - 1;
-                        break;
-                    }
-                }
             }
-            std::lock_guard<std::mutex> lock(m);
-            slot->text_len = have;
-            slot->state = ParseSlot::TEXT;
-            ++blocks_read;
-            if (end_of_input) eof = true;
-            cv.notify_all();
+            t_read.add(t0);
+            if (!upload_and_publish(s, have, end_of_input, stream)) return fail();
             if (end_of_input) break;
         }
-        std::lock_guard<std::mutex> lock(m);
-        eof = true;
-        cv.notify_all();
+        rsq_stream_destroy(0, stream);
     }
-    void parse_blocks() {
-        for (;;) {
-            ParseSlot *slot = nullptr;
-            {
-                std::unique_lock<std::mutex> lock(m);
-                cv.wait(lock, [&] {
-                    for (ParseSlot &s : slots)
-                        if (s.state == ParseSlot::TEXT) {
-                            slot = &s;
-                            return true;
-                        }
-                    return abort || failed || (eof && true);
-                });
-                if (!slot) {
-                    if (abort || failed) return;
-                    bool pending = false;                     // the reader is done: anything left to parse?
-                    for (ParseSlot &s : slots) pending = pending || s.state == ParseSlot::TEXT;
-                    if (!pending) return;
-                    continue;
-                }
-                slot->state = ParseSlot::PARSING;
-            }
-            const bool ok = slot->parse();
-            std::lock_guard<std::mutex> lock(m);
-            slot->failed = !ok;
-            slot->state = ParseSlot::PARSED;
-            if (!ok) failed = true;
-            cv.notify_all();
-        }
-    }
-    // the next block in input order; nullptr at the end of the input or after an error (`failed`)
-    ParseSlot *take() {
+    // block b, in input order; nullptr after an error -- or, if the caller does not want to wait, while the block is not there yet
+    Slot *take(uint64_t b, bool wait = true) {
+        Slot *s = &slots[b % slots.size()];
         std::unique_lock<std::mutex> lock(m);
-        ParseSlot *slot = &slots[next_take % slots.size()];
-        cv.wait(lock, [&] { return failed || (slot->state == ParseSlot::PARSED && true) || (eof && next_take >= blocks_read); });
-        if (failed || slot->state != ParseSlot::PARSED) return nullptr;
-        if (slot->n) any = true;
-        return slot;
+        if (wait) cv.wait(lock, [&] { return (s->turn == b && s->ready) || failed; });
+        return failed || !(s->turn == b && s->ready) ? nullptr : s;
     }
-    void release() {
+    void release(uint64_t b) {
+        Slot &s = slots[b % slots.size()];
         std::lock_guard<std::mutex> lock(m);
-        slots[next_take % slots.size()].state = ParseSlot::FREE;
-        ++next_take;
+        s.ready = false;
+        s.turn += slots.size();
         cv.notify_all();
     }
     void join() {
@@ -774,27 +649,165 @@ struct ParsePipeline {
             abort = true;
             cv.notify_all();
         }
-        for (std::thread &t : workers)
+        for (std::thread &t : readers)
             if (t.joinable()) t.join();
+        if (fd >= 0) ::close(fd);
+        fd = -1;
     }
 };
 
-// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: reader, ErrorModelOnlyThread :2514-2560,
-// ordered output :184-213): a reader thread cuts the FASTA text into blocks of whole records, parser threads pack the blocks into page-locked
-// arrays, the main thread takes the blocks in input order, uploads their records, runs the error model and the FASTQ formatter on the
-// device (rsq_sim_error_model_fastq) and hands the text to the writer thread of AsyncOut.  Device and host buffers are reused.
+// The output side: device buffers the simulator fills in turn, a thread that copies them into page-locked buffers, a thread that writes those.
+struct OutPipe {
+    static constexpr uint64_t kDev = 3, kStage = 3;
+    static constexpr size_t kChunk = 64u << 20;
+    TextOut out;
+    DevBuffer dev[kDev];
+    size_t dev_len[kDev] = {0, 0, 0};
+    HostArray stage[kStage];
+    size_t stage_len[kStage] = {0, 0, 0};
+    uint64_t filled = 0, drained = 0, staged = 0, written = 0;       // texts handed in / downloaded; chunks downloaded / written
+    bool closing = false, downloader_done = false, failed = false, started = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread downloader, writer;
+    StageTime t_download, t_stage, t_write, t_dev;
+    bool open(const std::string &path) {                  // an empty path: stdout
+        if (!path.empty() && !out.open(path)) return false;
+        downloader = std::thread([this] { download(); });
+        writer = std::thread([this] { write(); });
+        started = true;
+        return true;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lock(m);
+        failed = true;
+        cv.notify_all();
+    }
+    // the device buffer the next text goes to (the caller may enlarge it), once its last text has been downloaded; nullptr after an error
+    DevBuffer *begin() {
+        const auto t0 = Clock::now();
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return filled - drained < kDev || failed; });
+        t_dev.add(t0);
+        return failed ? nullptr : &dev[filled % kDev];
+    }
+    void submit(size_t bytes) {
+        std::lock_guard<std::mutex> lock(m);
+        dev_len[filled % kDev] = bytes;
+        ++filled;
+        cv.notify_all();
+    }
+    void download() {
+        void *stream = nullptr;
+        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
+        for (;;) {
+            uint64_t k;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return drained < filled || closing || failed; });
+                if (failed || drained == filled) break;
+                k = drained % kDev;
+            }
+            for (size_t done = 0; done < dev_len[k]; done += kChunk) {
+                const size_t n = std::min(kChunk, dev_len[k] - done);
+                uint64_t j;
+                {
+                    const auto t0 = Clock::now();
+                    std::unique_lock<std::mutex> lock(m);
+                    cv.wait(lock, [&] { return staged - written < kStage || failed; });
+                    t_stage.add(t0);
+                    if (failed) break;
+                    j = staged % kStage;
+                }
+                const auto t0 = Clock::now();
+                if (!stage[j].ensure(kChunk) || !check(rsq_dev_copy_on(0, stage[j].p, static_cast<const char *>(dev[k].p) + done, n, 1, stream), "download")) return finish_download(true);
+                t_download.add(t0);
+                std::lock_guard<std::mutex> lock(m);
+                stage_len[j] = n;
+                ++staged;
+                cv.notify_all();
+            }
+            std::lock_guard<std::mutex> lock(m);
+            ++drained;
+            cv.notify_all();
+        }
+        rsq_stream_destroy(0, stream);
+        finish_download(false);
+    }
+    void finish_download(bool error) {
+        std::lock_guard<std::mutex> lock(m);
+        failed = failed || error;
+        downloader_done = true;
+        cv.notify_all();
+    }
+    void write() {
+        for (;;) {
+            uint64_t j;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return written < staged || downloader_done || failed; });
+                if (failed || written == staged) break;
+                j = written % kStage;
+            }
+            const auto t0 = Clock::now();
+            out.write(stage[j].as<char>(), stage_len[j]);
+            t_write.add(t0);
+            std::lock_guard<std::mutex> lock(m);
+            ++written;
+            if (!out.good()) failed = true;
+            cv.notify_all();
+        }
+    }
+    void close() {
+        if (started) {
+            {
+                std::lock_guard<std::mutex> lock(m);
+                closing = true;
+                cv.notify_all();
+            }
+            downloader.join();
+            writer.join();
+            started = false;
+        }
+        out.close();
+    }
+    bool good() const { return !failed && out.good(); }
+};
+
+// a file that can be read at offsets by several threads: regular, and neither gzip nor bzip2 by its first bytes
+int open_plain_file(const std::string &path, uint64_t &size) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    unsigned char magic[3] = {0, 0, 0};
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || pread(fd, magic, 3, 0) < 0 || (magic[0] == 0x1f && magic[1] == 0x8b) || (magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')) {
+        ::close(fd);
+        return -1;
+    }
+    size = (uint64_t)st.st_size;
+    return fd;
+}
+
 int seq_to_illumina(const Args &a) {
     rsq_profile *prof = nullptr;
     rsq_sim *sim = nullptr;
+    const bool trace = a.has("traceStages");
     bool ok = load_profile(a, &prof);
+    const double at_profile = seconds_since(g_process_start);
     const uint64_t seed = ok ? get_seed(a) : 0;
     ok = ok && check(rsq_sim_create(prof, nullptr, 0, &sim), "Could not set up the simulator") &&
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
+    const double at_prepared = seconds_since(g_process_start);
     TextIn fin;                                              // stdin / stdout without -i / -o (main.cpp:1009-1021)
-    AsyncOut fout;
-    if (ok && a.has("input") && !fin.open(a.get("input"))) {
-        ERR("Could not open '" << a.get("input") << "' for reading.");
-        ok = false;
+    OutPipe fout;
+    uint64_t plain_size = 0;
+    int plain_fd = -1;
+    if (ok && a.has("input")) {
+        plain_fd = open_plain_file(a.get("input"), plain_size);
+        if (plain_fd < 0 && !fin.open(a.get("input"))) {
+            ERR("Could not open '" << a.get("input") << "' for reading.");
+            ok = false;
+        }
     }
     if (ok && !fout.open(a.get("output", ""))) {
         ERR("Could not open '" << a.get("output") << "' for writing.");
@@ -803,72 +816,94 @@ int seq_to_illumina(const Args &a) {
     if (ok) {
         INFO("Starting read generation");
         const unsigned hw = std::thread::hardware_concurrency();
-        // parser threads: six keep the single writer of the output file busy (buffered writes into one file serialise on its inode: 6 GB/s); more were
-        // measured slower -- every parser slot owns page-locked arrays, whose allocation is what a run of 20 M records waits for (6 threads 2.5 s, 16: 3.2 s,
-        // 32: 5.0 s; the marginal rate beyond the start-up is 25 M reads/s either way).  --parseThreads overrides.
-        uint32_t parsers = std::max(1u, std::min(hw > 2 ? hw - 2 : 1u, 6u));
-        if (a.has("parseThreads")) parsers = (uint32_t)std::max(1, atoi(a.get("parseThreads").c_str()));
-        ParsePipeline pipe(fin, parsers);
-        DevBuffer d_seqs, d_dom, d_rate, d_seg, d_fl, d_ids, d_off, d_text;
-        uint64_t written = 0, next_report = 0;
-        // --traceStages: where the consuming thread's time goes (waiting for a parsed block, uploads, the device call, handing the text to the writer)
-        const bool trace = a.has("traceStages");
-        double t_wait = 0, t_up = 0, t_dev = 0, t_push = 0;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
-        const auto t_all = now();
-        while (ok) {
-            auto t0 = now();
-            ParseSlot *b = pipe.take();
-            t_wait += since(t0);
-            if (!b) break;
-            for (size_t r = 0; ok && r < b->runs.size(); ++r) {
-                const ParseSlot::Run &run = b->runs[r];
-                const size_t n = run.n, L = run.L;
-                const size_t run_id_bytes = (size_t)b->id_off.as<uint64_t>()[run.first + r + n];
-                t0 = now();
-                ok = d_seqs.ensure(n * L + 8) && d_dom.ensure(n * L + 8) && d_rate.ensure(n * L + 8) && d_seg.ensure(n) && d_fl.ensure(n * 4) && d_ids.ensure(run_id_bytes + 8) &&
-                     d_off.ensure((n + 1) * 8) && check(rsq_dev_upload(0, d_seqs.p, b->seqs.as<uint8_t>() + run.base_at, n * L), "upload") &&
-                     check(rsq_dev_upload(0, d_dom.p, b->dom.as<uint8_t>() + run.base_at, n * L), "upload") &&
-                     check(rsq_dev_upload(0, d_rate.p, b->rate.as<uint8_t>() + run.base_at, n * L), "upload") &&
-                     check(rsq_dev_upload(0, d_seg.p, b->seg.as<uint8_t>() + run.first, n), "upload") &&
-                     check(rsq_dev_upload(0, d_fl.p, b->fl.as<uint32_t>() + run.first, n * 4), "upload") &&
-                     check(rsq_dev_upload(0, d_ids.p, b->ids.as<char>() + run.id_first, run_id_bytes + 1), "upload") &&
-                     check(rsq_dev_upload(0, d_off.p, b->id_off.as<uint64_t>() + run.first + r, (n + 1) * 8), "upload");
-                t_up += since(t0);
-                t0 = now();
-                size_t len = 0;
-                for (int attempt = 0; ok && attempt < 2; ++attempt) {
-                    ok = d_text.ensure(std::max(len + len / 8, n * (2 * L + 96) + run_id_bytes) + 64);
-                    if (!ok) break;
-                    const int rc = rsq_sim_error_model_fastq(sim, written, n, (uint32_t)L, (const uint8_t *)d_seqs.p, (const uint8_t *)d_seg.p, (const uint32_t *)d_fl.p,
-                                                             (const uint8_t *)d_dom.p, (const uint8_t *)d_rate.p, (const char *)d_ids.p, (const uint64_t *)d_off.p,
-                                                             (char *)d_text.p, d_text.cap, &len, nullptr);
-                    if (rc == RSQ_ENOSPC && !attempt) continue;
-                    ok = check(rc, "Simulation failed");
-                    break;
-                }
-                t_dev += since(t0);
-                t0 = now();
-                ok = ok && fout.push(d_text, len);
-                t_push += since(t0);
-                written += n;                                     // = the index of the next record in the input (it selects the records' random streams)
+        // reader threads of a plain file: one copies about 6 GB/s out of the page cache (--readThreads overrides; a stream has one reader whatever it says)
+        uint32_t n_readers = std::max(1u, std::min(hw > 3 ? hw - 3 : 1u, 6u));
+        for (const char *name : {"readThreads", "parseThreads"})
+            if (a.has(name)) n_readers = (uint32_t)std::max(1, atoi(a.get(name).c_str()));
+        // blocks of 48 MB, up to eight of them in a call (--blockKB / --batchBlocks: the tests make them small)
+        const size_t block_bytes = (size_t)std::min(1 << 20, std::max(1, a.has("blockKB") ? atoi(a.get("blockKB").c_str()) : 48 << 10)) << 10;
+        uint32_t batch_blocks = (uint32_t)std::max(1, a.has("batchBlocks") ? atoi(a.get("batchBlocks").c_str()) : 8);
+        while (batch_blocks > 1 && batch_blocks * block_bytes > ((size_t)3 << 30)) --batch_blocks;      // a call takes less than 4 GB of text
+        InPipe in(block_bytes, plain_fd >= 0 ? n_readers : 1);
+        if (plain_fd >= 0) in.start_file(plain_fd, plain_size, n_readers);
+        else in.start_stream(fin);
+        void *stream = nullptr;
+        ok = check(rsq_stream_create(0, &stream), "stream");
+        DevBuffer joined[2];                                  // the text of a call: what the call before left over (it lies in the other one), then the blocks
+        int next_joined = 0;
+        const char *rest = nullptr;                           // the start of a record whose end the next block holds
+        size_t rest_len = 0;
+        uint64_t records = 0, next_report = 0, calls = 0;
+        StageTime t_wait, t_join, t_call;
+        double at_first_block = 0;
+        const auto t_all = Clock::now();
+        bool last = false;
+        for (uint64_t b = 0; ok && !last;) {
+            auto t0 = Clock::now();
+            InPipe::Slot *slot = in.take(b);
+            t_wait.add(t0);
+            if (!slot) {
+                ok = false;
+                break;
             }
-            pipe.release();                                       // the records are on the device: the slot may take the next block
-            if (ok && written >= next_report) {
-                INFO("Generated " << written << " reads.");
-                next_report = written + 1000000;
+            if (!b) at_first_block = seconds_since(g_process_start);
+            t0 = Clock::now();
+            DevBuffer &j = joined[next_joined];
+            next_joined ^= 1;
+            ok = j.ensure(rest_len + batch_blocks * block_bytes + 16) && (!rest_len || check(rsq_dev_copy_on(0, j.p, rest, rest_len, 2, stream), "copy"));
+            char *text = static_cast<char *>(j.p);
+            size_t len = rest_len;
+            for (uint32_t k = 0; ok && slot; ++k) {
+                ok = check(rsq_dev_copy_on(0, text + len, slot->dev.p, slot->len, 2, stream), "copy");
+                len += slot->len;
+                last = slot->last;
+                in.release(b++);
+                slot = last || k + 1 == batch_blocks ? nullptr : in.take(b, false);
+            }
+            t_join.add(t0);
+            t0 = Clock::now();
+            DevBuffer *o = ok ? fout.begin() : nullptr;
+            ok = ok && o;
+            size_t out_len = 0, used = 0;
+            uint64_t n = 0;
+            for (int attempt = 0; ok && attempt < 2; ++attempt) {
+                ok = o->ensure(std::max(out_len + out_len / 8, len + len / 8) + 4096);
+                if (!ok) break;
+                const int rc = rsq_sim_error_model_fasta(sim, records, text, len, last ? 1 : 0, static_cast<char *>(o->p), o->cap, &out_len, &n, &used, stream);
+                if (rc == RSQ_ENOSPC && !attempt) continue;
+                if (rc == RSQ_EIO) {                              // the reference's complaint about a record (Simulator.cpp:2423-2485)
+                    ERR(rsq_last_error());
+                    ok = false;
+                } else ok = check(rc, "Simulation failed");
+                break;
+            }
+            t_call.add(t0);
+            if (!ok) break;
+            ++calls;
+            if (out_len) fout.submit(out_len);
+            records += n;                                         // = the index of the next record in the input (it selects the records' random streams)
+            rest = text + used;
+            rest_len = len - used;
+            if (records >= next_report) {
+                INFO("Generated " << records << " reads.");
+                next_report = records + 1000000;
             }
         }
         if (trace)
-            fprintf(stderr, "stages of the consuming thread: %.3f s in all for %llu records; waiting for parsed blocks %.3f, uploads %.3f, device (error model + text) %.3f, text to the writer %.3f\n",
-                    since(t_all), (unsigned long long)written, t_wait, t_up, t_dev, t_push);
-        pipe.join();
-        ok = ok && !pipe.failed && !fin.failed;
-        if (ok && !pipe.any) {
+            fprintf(stderr,
+                    "stages: profile loaded at %.3f s of the process, simulator prepared at %.3f, first block on the device at %.3f; the simulator side took %.3f s for %llu records in %llu calls: "
+                    "waiting for blocks %.3f, putting blocks together %.3f, device calls %.3f (of these waiting for a free output buffer %.3f); readers (summed over %u threads): reading %.3f, "
+                    "uploads %.3f, waiting for a slot %.3f; downloads %.3f (+ %.3f waiting for a free buffer); writing %.3f\n",
+                    at_profile, at_prepared, at_first_block, seconds_since(t_all), (unsigned long long)records, (unsigned long long)calls, t_wait.s(), t_join.s(), t_call.s(), fout.t_dev.s(),
+                    (unsigned)in.readers.size(), in.t_read.s(), in.t_upload.s(), in.t_slot.s(), fout.t_download.s(), fout.t_stage.s(), fout.t_write.s());
+        in.join();
+        ok = ok && !in.failed && !fin.failed;
+        if (ok && !records) {
             ERR(a.get("input", "stdin") << " does not contain any sequences.");
             ok = false;
         }
+        if (!ok) fout.fail();
+        rsq_stream_destroy(0, stream);
     }
     fin.close();
     fout.close();

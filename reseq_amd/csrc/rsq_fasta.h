@@ -1,0 +1,254 @@
+// rsq_fasta.h -- seqToIllumina's input parsed on the device (Simulator::ApplyErrorsAndQualityToFastaInput, reseq/Simulator.cpp:2403-2512).
+//
+// The caller uploads FASTA text as it stands in the file.  A record is ">{id} {1|2};{fragment length};{dominant errors};{error rates}", a line end, and the
+// template bases on one line or wrapped over several; it reaches from a '>' at the start of a line to the next one.
+//   k_fasta_count / k_fasta_starts   a wave per 4 KB of text finds the record starts (ballots; a scan over the tiles' counts in between keeps the input order)
+//   k_fasta_records                  a lane per record: the reference's checks of the header in the reference's order (Simulator.cpp:2423-2485), template
+//                                    bases -> codes 0..3, dominant errors -> codes 0..4, error rates -> percent (:2439-2442), written in 8-byte groups at
+//                                    the record's own offset of three arrays as large as the text -- what k_fill_records reads (RecordSrc) needs no scan
+//                                    and no second copy, a record of any length fits, and the id stays where it is in the text (the formatter reads it there).
+//                                    A workgroup's 256 records are one stretch of the text: it is staged into LDS with whole-line loads and the lanes read
+//                                    their records there (a lane walking its record in HBM touches a cache line of its own with every load: measured 3.0 ms
+//                                    per million records against 1.4 with the stretch in LDS); a stretch that does not fit is read where it is.
+// A malformed record sets the smallest index of a bad record; the host fetches that record's text and words the reference's message (record_message).
+// parse_record is plain code of one record: the host emulation of the tests runs it as it is.
+#pragma once
+#include "rsq_types.h"
+#include "rsq_core.h"
+
+namespace rsq {
+namespace fasta {
+
+enum RecordError : uint32_t {
+    kRecordOk = 0,
+    kTooShort,              // Simulator.cpp:2424-2427
+    kErrorSeparators,       // :2431-2434
+    kNoId,                  // :2447-2450
+    kSegment,               // :2454-2463
+    kSegmentSeparator,      // :2465-2468
+    kFragmentLength,        // :2470-2477
+    kContainsN              // the reference's tables have no row for N: the CLI of this repository has refused such records since round 1
+};
+struct RecordFields {
+    uint32_t len, id_len, frag_len, seg;
+};
+
+constexpr uint64_t kOnes = 0x0101010101010101ull, kHighs = 0x8080808080808080ull;
+// bytes [off, off + 8) of a record of `size` bytes, zeros beyond it
+// (P: pointer to the text's bytes -- const uint8_t * or, on the device, the same in LDS)
+template <class P>
+struct WordOf;
+template <>
+struct WordOf<const uint8_t *> {
+    typedef const uint64_t __attribute__((aligned(1))) *type;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+struct WordOf<const RSQ_LDS uint8_t *> {
+    typedef const RSQ_LDS uint64_t __attribute__((aligned(1))) *type;
+};
+#endif
+template <class P>
+RSQ_HD uint64_t word_at(P rec, uint64_t off, uint64_t size) {
+    uint64_t w = 0;
+    if (off + 8u <= size) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        w = *reinterpret_cast<typename WordOf<P>::type>(rec + off);          // unaligned 8-byte loads are what the hardware does (amdhsa)
+#else
+        for (uint32_t j = 0; j < 8u; ++j) w |= (uint64_t)rec[off + j] << (8u * j);
+#endif
+    } else
+        for (uint32_t j = 0; off + j < size; ++j) w |= (uint64_t)rec[off + j] << (8u * j);
+    return w;
+}
+RSQ_HD void store_word(uint8_t *dst, uint64_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint64_t __attribute__((aligned(1))) *>(dst) = w;
+#else
+    for (uint32_t j = 0; j < 8u; ++j) dst[j] = (uint8_t)(w >> (8u * j));
+#endif
+}
+// the first position >= from of byte c in the record, or size
+template <class P>
+RSQ_HD uint64_t find_byte(P rec, uint64_t from, uint64_t size, uint8_t c) {
+    for (uint64_t off = from; off < size; off += 8u) {
+        const uint64_t w = word_at(rec, off, size) ^ (kOnes * c);        // a zero byte where the text has c (bytes past the end are c itself: not zero for c != 0)
+        const uint64_t t = (w - kOnes) & ~w & kHighs;                       // exact in its lowest set bit
+        if (t) {
+            const uint64_t at = off + ((uint64_t)__builtin_ctzll(t) >> 3);
+            return at < size ? at : size;
+        }
+    }
+    return size;
+}
+RSQ_HD uint32_t base_code(uint32_t c) {          // A C G T in either case -> 0..3, everything else 4
+    const uint32_t u = c & 0xDFu;
+    return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+}
+RSQ_HD uint32_t rate_percent(uint32_t c) {       // Simulator.cpp:2439-2442: percents above 86 are stored halved
+    uint32_t v = (c - 33u) & 0xFFu;
+    if (v > 86u) v += v - 86u;
+    return v & 0xFFu;
+}
+// the 8 codes of a word of text
+template <class F>
+RSQ_HD uint64_t map_bytes(uint64_t w, F &&f) {
+    uint64_t out = 0;
+    for (uint32_t j = 0; j < 8u; ++j) out |= (uint64_t)f((uint32_t)(w >> (8u * j)) & 0xFFu) << (8u * j);
+    return out;
+}
+
+// record_start: a '>' that begins a line (or the text)
+RSQ_HD bool record_start(const uint8_t *text, uint64_t p) { return text[p] == '>' && (p == 0 || text[p - 1] == '\n'); }
+
+// One record rec[0, size): rec[0] is its '>'.  Codes go to seqs / dom / rate[0, len) (the caller passes the arrays at the record's offset; size > len always).
+// The checks follow the reference's order; the bases are counted first because every check needs their number.
+template <class P>
+RSQ_HD RecordError parse_record(P rec, uint64_t size, uint8_t *seqs, uint8_t *dom, uint8_t *rate, RecordFields &f) {
+    const uint64_t line_end = find_byte(rec, 1, size, '\n');
+    uint64_t header_len = line_end - 1u;
+    if (header_len && rec[line_end - 1u] == '\r') --header_len;
+    // the template: every line behind the header, line ends ('\n', or '\r' in front of one or of the record's end) dropped
+    uint64_t L = 0, group = 0;
+    uint32_t any = 0;
+    for (uint64_t off = line_end + 1u; off < size; off += 8u) {
+        const uint64_t w = word_at(rec, off, size);
+        const uint32_t behind = off + 8u < size ? rec[off + 8u] : (uint32_t)'\n';      // the byte behind the word; the record's end counts as a line end
+        for (uint32_t j = 0; j < 8u && off + j < size; ++j) {
+            const uint32_t c = (uint32_t)(w >> (8u * j)) & 0xFFu;
+            if (c == '\n') continue;
+            if (c == '\r') {
+                const uint32_t next = off + j + 1u >= size ? (uint32_t)'\n' : j < 7u ? (uint32_t)(w >> (8u * (j + 1u))) & 0xFFu : behind;
+                if (next == '\n') continue;
+            }
+            const uint32_t code = base_code(c);
+            any |= code;
+            group |= (uint64_t)code << (8u * (L & 7u));
+            if ((++L & 7u) == 0) {
+                store_word(seqs + L - 8u, group);
+                group = 0;
+            }
+        }
+    }
+    for (uint64_t k = L & ~(uint64_t)7u; k < L; ++k) seqs[k] = (uint8_t)(group >> (8u * (k & 7u)));
+    if (header_len <= 2u * L + 2u) return kTooShort;
+    const P h = rec + 1;
+    uint64_t end = header_len - 2u * L - 3u;
+    if (h[end + 1u] != ';' || h[end + 2u + L] != ';') return kErrorSeparators;
+    const uint64_t dom_at = end + 2u, rate_at = header_len - L;
+    while (end && h[end] != ' ') --end;
+    if (!end) return kNoId;
+    if (h[end + 1u] == '1') f.seg = 0;
+    else if (h[end + 1u] == '2') f.seg = 1;
+    else return kSegment;
+    if (h[end + 2u] != ';') return kSegmentSeparator;
+    const uint64_t fl_at = end + 3u, fl_end = header_len - 2u * L - 2u;
+    if (fl_end <= fl_at) return kFragmentLength;
+    uint32_t v = 0;                                   // (the reference's stoi ends the run for a number beyond 32 bits; here it wraps as in this repository's CLI since round 1)
+    for (uint64_t k = fl_at; k < fl_end; ++k) {
+        const uint32_t d = (uint32_t)h[k] - (uint32_t)'0';
+        if (d > 9u) return kFragmentLength;
+        v = v * 10u + d;
+    }
+    if (any & 4u) return kContainsN;
+    f.len = (uint32_t)L;
+    f.id_len = (uint32_t)end;
+    f.frag_len = v;
+    // the systematic errors: whole 8-byte groups, the rest by bytes (the arrays' bytes behind [0, L) belong to the record as well, but stay untouched)
+    const uint64_t hs = header_len;
+    uint64_t k = 0;
+    for (; k + 8u <= L; k += 8u) {
+        store_word(dom + k, map_bytes(word_at(h, dom_at + k, hs), base_code));
+        store_word(rate + k, map_bytes(word_at(h, rate_at + k, hs), rate_percent));
+    }
+    for (; k < L; ++k) {
+        dom[k] = (uint8_t)base_code(h[dom_at + k]);
+        rate[k] = (uint8_t)rate_percent(h[rate_at + k]);
+    }
+    return kRecordOk;
+}
+
+#if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)
+constexpr uint32_t kTileBytes = 4096, kStartsBlock = 256;        // a wave per tile, four tiles per workgroup
+// record starts in tile `tile`, 64 bytes per step: f(position, rank within the tile) for each, returns their number
+template <class F>
+__device__ uint32_t tile_starts(const uint8_t *text, uint64_t text_len, uint64_t tile, F &&f) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t count = 0;
+    for (uint32_t step = 0; step < kTileBytes / 64u; ++step) {
+        const uint64_t p = tile * kTileBytes + step * 64u + lane;
+        const bool is = p < text_len && record_start(text, p);
+        const uint64_t mask = __ballot(is);
+        if (is) f(p, count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)));
+        count += (uint32_t)__popcll(mask);
+    }
+    return count;
+}
+__global__ void __launch_bounds__(kStartsBlock) k_fasta_count(const uint8_t *text, uint64_t text_len, uint32_t n_tiles, uint32_t *counts) {
+    const uint64_t tile = (uint64_t)blockIdx.x * (kStartsBlock / 64u) + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint32_t n = tile_starts(text, text_len, tile, [](uint64_t, uint32_t) {});
+    if ((threadIdx.x & 63u) == 0) counts[tile] = n;
+}
+// at[0 .. n): the starts in input order; at[n] = text_len
+__global__ void __launch_bounds__(kStartsBlock) k_fasta_starts(const uint8_t *text, uint64_t text_len, uint32_t n_tiles, const uint64_t *first_of_tile, uint32_t *at) {
+    const uint64_t tile = (uint64_t)blockIdx.x * (kStartsBlock / 64u) + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint64_t first = first_of_tile[tile];
+    tile_starts(text, text_len, tile, [&](uint64_t p, uint32_t rank) { at[first + rank] = (uint32_t)p; });
+    if (tile == 0 && (threadIdx.x & 63u) == 0) at[first_of_tile[n_tiles]] = (uint32_t)text_len;
+}
+// summary[0] = the longest template, [1] = the first malformed record (0xFFFFFFFF: none), [2] = text other than line ends in front of the first record
+struct Records {
+    const uint32_t *at;
+    uint32_t *len, *id_len, *frag_len;
+    uint8_t *seg;
+};
+// text[0, lead_end) lies in front of the first record: anything but line ends there is sequence data without a header
+__global__ void __launch_bounds__(256) k_fasta_lead(const uint8_t *text, uint32_t lead_end, uint32_t *summary) {
+    bool other = false;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < lead_end; p += (uint64_t)gridDim.x * blockDim.x) other = other || (text[p] != '\n' && text[p] != '\r');
+    if (other) summary[2] = 1u;
+}
+// A workgroup takes kRecordsBlock consecutive records.  Their text is one stretch [at[first], at[last]): up to kStageBytes of it go to LDS in 16-byte loads
+// that follow each other through the lanes (from the 16-byte boundary below the stretch: device allocations begin and end on one, so the loads stay inside).
+constexpr uint32_t kRecordsBlock = 256, kStageBytes = 144u << 10;
+template <class P>
+__device__ uint32_t record_of_lane(P rec, uint64_t size, uint32_t i, uint32_t at, const Records &r, uint8_t *seqs, uint8_t *dom, uint8_t *rate, uint32_t *summary) {
+    RecordFields f{0, 0, 0, 0};
+    const RecordError e = parse_record(rec, size, seqs + at, dom + at, rate + at, f);
+    r.len[i] = f.len;
+    r.id_len[i] = f.id_len;
+    r.frag_len[i] = f.frag_len;
+    r.seg[i] = (uint8_t)f.seg;
+    if (e != kRecordOk) atomicMin(&summary[1], i);
+    return e == kRecordOk ? f.len : 0u;
+}
+__global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *text, uint32_t n, Records r, uint8_t *seqs, uint8_t *dom, uint8_t *rate, uint32_t *summary) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    const uint32_t first = blockIdx.x * kRecordsBlock, last = min(first + kRecordsBlock, n), i = first + threadIdx.x;
+    const uint32_t begin = r.at[first], end = r.at[last];
+    const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(text + begin) & 15u), span = skew + (end - begin);
+    const bool staged = span <= kStageBytes;
+    if (staged) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(text + begin - skew);
+        uint4 *dst = reinterpret_cast<uint4 *>(stage);
+        const uint32_t words = (span + 15u) >> 4;
+#pragma unroll 8
+        for (uint32_t w = threadIdx.x; w < words; w += kRecordsBlock) dst[w] = src[w];
+        __syncthreads();
+    }
+    uint32_t longest = 0;
+    if (i < n) {
+        const uint32_t at = r.at[i];
+        const uint64_t size = (uint64_t)r.at[i + 1] - at;
+        longest = staged ? record_of_lane((const RSQ_LDS uint8_t *)stage + skew + (at - begin), size, i, at, r, seqs, dom, rate, summary)
+                         : record_of_lane(text + at, size, i, at, r, seqs, dom, rate, summary);
+    }
+    for (uint32_t d = 32; d; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)d, 64));      // one atomic per wave, not per record
+    if ((threadIdx.x & 63u) == 0 && longest) atomicMax(&summary[0], longest);
+}
+#endif
+
+}  // namespace fasta
+}  // namespace rsq

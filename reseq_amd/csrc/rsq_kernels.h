@@ -2072,6 +2072,10 @@ RSQ_HD RecordSrc record_src(const uint8_t *seqs, const uint8_t *dom, const uint8
     const uint64_t rest = (n - i) * read_len;
     return RecordSrc{seqs + i * read_len, dom + i * read_len, rate + i * read_len, read_len, rest > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rest, 0xFFFFFFFFu, 0, 0, 0};
 }
+// a record of `len` bytes at offset `at` of arrays of `bytes` bytes (records parsed on the device lie where their text lay, rsq_fasta.h)
+RSQ_HD RecordSrc record_src_at(const uint8_t *seqs, const uint8_t *dom, const uint8_t *rate, uint32_t at, uint32_t len, uint32_t bytes) {
+    return RecordSrc{seqs + at, dom + at, rate + at, len, bytes - at, 0xFFFFFFFFu, 0, 0, 0};
+}
 #ifndef RSQ_FILL_BLOCK
 #define RSQ_FILL_BLOCK 768
 #endif
@@ -2421,6 +2425,9 @@ struct RecordJob {
     const uint32_t *frag_len;
     const uint32_t *rec_index, *rec_count;
     uint64_t n_records;
+    // nullptr: record i is bytes [i * read_len, (i + 1) * read_len) of the arrays; else bytes [rec_at[i], rec_at[i] + rec_len[i]) of arrays of array_bytes bytes
+    const uint32_t *rec_at, *rec_len;
+    uint32_t array_bytes;
 };
 // lane = record i if active; `row`: its row of the raw arrays (i, or binned its place in perm: the text / array kernels go through perm as well)
 template <uint32_t MASK, bool BINNED>
@@ -2428,7 +2435,8 @@ __device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS
                                   const RawLayout &raw) {
     const uint64_t idx = job.first_index + i;
     const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-    const RecordSrc src = record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
+    const RecordSrc src = job.rec_at ? record_src_at(job.seqs, job.dom, job.rate, job.rec_at[i], job.rec_len[i], job.array_bytes)
+                                     : record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
     ReadOut out = raw.out_of(active ? row : 0u);
     ReadMeta meta;
     const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, st.c0, st.c1, st.c2, pair_c3(kDomErrModel, 0, 2)) : 0u);

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/reseq_amd.h"
+#include "rsq_fasta.h"
 #include "rsq_pack.h"
 #include "rsq_spec.h"
 
@@ -179,6 +180,7 @@ struct rsq_sim : SimState {
         DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
         DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
         DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, counters (one small buffer); the sorted items
+        DevBuf fa_counts, fa_first, fa_at, fa_len, fa_id_len, fa_frag_len, fa_seg, fa_seqs, fa_dom, fa_rate, fa_summary;      // rsq_sim_error_model_fasta (rsq_fasta.h)
         DevBuf cell_info;              // the sieve without variants: per candidate the first strand's count and the two strands (k_sieve_finish<0> -> k_sieve_emit<0>)
         hipEvent_t text_done = nullptr;      // the text stage that last read this set's arrays
     } ws[2];
@@ -484,7 +486,9 @@ static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kerne
     if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return lds_bytes;
 }
-// workgroups of a read kernel: persistent, one (or two, when two images fit) per CU, not more than there are rounds of chunks
+// workgroups of a read kernel: persistent, one (or two, when two images fit) per CU, not more than there are rounds of chunks.  (Spreading a small call over
+// more workgroups -- one per four chunks -- does not shorten it: a seqToIllumina call on 107 000 records takes 1.1 ms either way, the chain of 150 steps of a
+// wave that has its SIMD to itself; the command line therefore hands over several blocks in one call.)
 static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item) {
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
     const uint64_t chunks = (n_items + 63) / 64;
@@ -932,20 +936,28 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
 // seqToIllumina's FASTQ text on the device (Simulator.cpp:2497-2504: "@{id} {CIGAR} E{errors}", bases, "+", qualities): sizes, then the
 // records at the offsets of their exclusive scan; one lane per record, word-granular stores
 RSQ_HD uint32_t error_model_record_size(const ReadMeta &m, uint32_t id_len) { return 1u + id_len + 1u + m.cigar_chars + 2u + digits_u32(m.num_errors) + 1u + 2u * m.read_len + 4u; }
-__global__ void __launch_bounds__(256) k_record_text_sizes(RawLayout raw, uint64_t n, const uint64_t *id_off, uint32_t *sizes) {
+// the records' ids: packed one after the other (off: n + 1 offsets) or where they stand in the FASTA text (at: offset of the record's '>', len: the id's length)
+struct RecordIds {
+    const char *chars;
+    const uint64_t *off;
+    const uint32_t *at, *len;
+    RSQ_HD const char *begin(uint64_t i) const { return chars + (off ? off[i] : (uint64_t)at[i] + 1u); }
+    RSQ_HD uint32_t length(uint64_t i) const { return off ? (uint32_t)(off[i + 1] - off[i]) : len[i]; }
+};
+__global__ void __launch_bounds__(256) k_record_text_sizes(RawLayout raw, uint64_t n, RecordIds ids, uint32_t *sizes) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     const uint64_t i = raw.item_of(row);
-    sizes[i] = error_model_record_size(raw.meta[row], (uint32_t)(id_off[i + 1] - id_off[i]));
+    sizes[i] = error_model_record_size(raw.meta[row], ids.length(i));
 }
-__global__ void __launch_bounds__(256) k_record_text(RawLayout raw, uint64_t n, const char *ids, const uint64_t *id_off, const uint64_t *offsets, char *dst, uint64_t cap) {
+__global__ void __launch_bounds__(256) k_record_text(RawLayout raw, uint64_t n, RecordIds ids, const uint64_t *offsets, char *dst, uint64_t cap) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n || offsets[n] > cap) return;                        // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
     const uint64_t i = raw.item_of(row);
     const ReadMeta m = raw.meta[row];
     WordSinkT<char *> t(dst + offsets[i]);
     t.ch('@');
-    t.str(ids + id_off[i], (uint32_t)(id_off[i + 1] - id_off[i]));
+    t.str(ids.begin(i), ids.length(i));
     t.ch(' ');
     cigar_replay(raw.ops_of(row), m, t);
     t.str(" E", 2);
@@ -1817,14 +1829,16 @@ int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_
 }
 
 // the records' reads into the raw arrays: partition by template segment, k_fill_records
+// (rec_at / rec_len: records of their own lengths at their own offsets of arrays of array_bytes bytes, read_len = the longest; nullptr: n x read_len bytes)
 static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
-                                  const uint8_t *dom_dev, const uint8_t *rate_dev, hipStream_t st) {
+                                  const uint8_t *dom_dev, const uint8_t *rate_dev, hipStream_t st, const uint32_t *rec_at = nullptr, const uint32_t *rec_len = nullptr,
+                                  uint32_t array_bytes = 0, bool fresh_timers = true) {
     // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
     const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
     if (need_ops > s->ops_stride) s->ops_stride = need_ops;
     if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
     s->cur = &s->ws[0];
-    reset_call_timers(*s);
+    if (fresh_timers) reset_call_timers(*s);
     RawLayout raw = raw_layout(*s, n);
     // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS (binned by tile: build_fill_bins)
     if (!fill_is_binned(*s)) {
@@ -1838,7 +1852,7 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
         hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->cur->offsets.as<uint64_t>(), s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
     }
-    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>(), n};
+    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>(), n, rec_at, rec_len, array_bytes};
     raw.order = launch_fill_records(*s, job, seg_dev, n, raw, st);
     return raw;
 }
@@ -1870,6 +1884,26 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
     });
 }
 
+// the FASTQ text of the records in the raw arrays: sizes, scan, text; *text_len = the bytes needed (RSQ_ENOSPC, nothing written, if text_cap is smaller)
+static int error_model_text(rsq_sim *s, const RawLayout &raw, uint64_t n, const RecordIds &ids, char *text_dev, size_t text_cap, size_t *text_len, hipStream_t st) {
+    s->cur->sizes.reserve(n * 4 + 16);
+    s->cur->off_r1.reserve((n + 1) * 8);
+    s->timers["format_write"].start(st);
+    hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids, s->cur->sizes.as<uint32_t>());
+    exclusive_scan(*s, s->cur->sizes.as<uint32_t>(), n, s->cur->off_r1.as<uint64_t>(), st);
+    hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
+    s->timers["format_write"].stop(st);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->cur->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    *text_len = s->mailbox[2];
+    if (*text_len > text_cap) {
+        g_last_error = "text buffer too small: need " + std::to_string(*text_len) + " bytes";
+        return (int)RSQ_ENOSPC;
+    }
+    return (int)RSQ_OK;
+}
+
 int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
                               const uint8_t *dom_dev, const uint8_t *rate_dev, const char *ids_dev, const uint64_t *id_off_dev, char *text_dev, size_t text_cap,
                               size_t *text_len, void *stream) {
@@ -1881,22 +1915,125 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
         hipStream_t st = (hipStream_t)stream;
         HIP_CHECK(hipSetDevice(s->device));
         const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
-        s->cur->sizes.reserve(n * 4 + 16);
-        s->cur->off_r1.reserve((n + 1) * 8);
-        s->timers["format_write"].start(st);
-        hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, id_off_dev, s->cur->sizes.as<uint32_t>());
-        exclusive_scan(*s, s->cur->sizes.as<uint32_t>(), n, s->cur->off_r1.as<uint64_t>(), st);
-        hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids_dev, id_off_dev, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
-        s->timers["format_write"].stop(st);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->cur->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        *text_len = s->mailbox[2];
-        if (*text_len > text_cap) {
-            g_last_error = "text buffer too small: need " + std::to_string(*text_len) + " bytes";
-            return (int)RSQ_ENOSPC;
+        return error_model_text(s, raw, n, RecordIds{ids_dev, id_off_dev, nullptr, nullptr}, text_dev, text_cap, text_len, st);
+    });
+}
+
+// the reference's complaint about a malformed record (Simulator.cpp:2423-2485; rec = the record's text from its '>' on)
+static std::string record_message(const std::vector<uint8_t> &rec) {
+    std::vector<uint8_t> scratch[3];
+    for (auto &v : scratch) v.resize(rec.size() + 8);
+    fasta::RecordFields f{0, 0, 0, 0};
+    const fasta::RecordError e = fasta::parse_record(rec.data(), rec.size(), scratch[0].data(), scratch[1].data(), scratch[2].data(), f);
+    const size_t line_end = (size_t)fasta::find_byte(rec.data(), 1, rec.size(), '\n');
+    size_t header_len = line_end - 1;
+    if (header_len && rec[line_end - 1] == '\r') --header_len;
+    const std::string header(reinterpret_cast<const char *>(rec.data()) + 1, header_len);
+    size_t L = 0;                                            // the template's length: as parse_record counts it
+    for (size_t p = line_end + 1; p < rec.size(); ++p)
+        if (rec[p] != '\n' && !(rec[p] == '\r' && (p + 1 == rec.size() || rec[p + 1] == '\n'))) ++L;
+    size_t end = header_len > 2 * L + 2 ? header_len - 2 * L - 3 : 0;
+    while (end && header[end] != ' ') --end;
+    switch (e) {
+        case fasta::kTooShort: return "Read description is too short to contain systematic error information and a sequence id: " + header;
+        case fasta::kErrorSeparators: return "The two systematic error entries are not separated by a semicolon from themselves or the rest of the ReSeq information: " + header;
+        case fasta::kNoId: return "No sequence id found that is separated by a space from the ReSeq information: " + header;
+        case fasta::kSegment: return std::string("Template segment is ") + header[end + 1] + " not 1 or 2: " + header;
+        case fasta::kSegmentSeparator: return "The template segment and fragment length are not separated by a semicolon: " + header;
+        case fasta::kFragmentLength: {
+            const size_t fl_at = end + 3, fl_end = header_len - 2 * L - 2;
+            return "Fragment length '" + (fl_end > fl_at ? header.substr(fl_at, fl_end - fl_at) : std::string()) + "' is not a pure integer: " + header;
         }
-        return (int)RSQ_OK;
+        case fasta::kContainsN: return "input sequences must not contain N: " + header.substr(0, end);
+        default: return "malformed record: " + header;
+    }
+}
+
+int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text_dev, size_t text_len, int final, char *out_dev, size_t out_cap, size_t *out_len,
+                              uint64_t *n_records, size_t *consumed, void *stream) {
+    REQUIRE(s && s->prepared, "simulator not prepared");
+    REQUIRE(out_len && n_records && consumed && (text_dev || !text_len) && (out_dev || !out_cap), "null pointer");
+    REQUIRE(text_len < 0xFFFFFFF0ull, "a block of FASTA text has to be shorter than 4 GB");
+    *out_len = 0;
+    *n_records = 0;
+    *consumed = 0;
+    if (!text_len) return RSQ_OK;
+    return guard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        HIP_CHECK(hipSetDevice(s->device));
+        s->cur = &s->ws[0];
+        rsq_sim::Workspace &w = *s->cur;
+        const uint8_t *text = reinterpret_cast<const uint8_t *>(text_dev);
+        // the record starts: counts per tile, their scan, the starts in input order
+        const uint32_t n_tiles = cdiv(text_len, fasta::kTileBytes);
+        auto roomy = [](size_t bytes) { return bytes + bytes / 8 + 64; };          // blocks differ by a few percent: grow once
+        w.fa_counts.reserve(roomy((size_t)n_tiles * 4));
+        w.fa_first.reserve(roomy(((size_t)n_tiles + 1) * 8));
+        w.fa_summary.reserve(64);
+        const dim3 tgrid(cdiv(n_tiles, fasta::kStartsBlock / 64u)), tblock(fasta::kStartsBlock);
+        hipLaunchKernelGGL(fasta::k_fasta_count, tgrid, tblock, 0, st, text, (uint64_t)text_len, n_tiles, w.fa_counts.as<uint32_t>());
+        exclusive_scan(*s, w.fa_counts.as<uint32_t>(), n_tiles, w.fa_first.as<uint64_t>(), st);
+        HIP_CHECK(hipMemcpyAsync(&s->mailbox[0], w.fa_first.as<uint64_t>() + n_tiles, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint64_t starts = s->mailbox[0];
+        if (starts >= 0xFFFFFFFFull) throw Error("more than 2^32 records in one block of text");
+        w.fa_at.reserve(roomy((starts + 1) * 4));
+        hipLaunchKernelGGL(fasta::k_fasta_starts, tgrid, tblock, 0, st, text, (uint64_t)text_len, n_tiles, w.fa_first.as<uint64_t>(), w.fa_at.as<uint32_t>());
+        // a block that is not the input's last leaves its last record to the caller: its end is not known yet
+        const uint32_t n = (uint32_t)(final || !starts ? starts : starts - 1);
+        w.fa_len.reserve(roomy((size_t)n * 4));
+        w.fa_id_len.reserve(roomy((size_t)n * 4));
+        w.fa_frag_len.reserve(roomy((size_t)n * 4));
+        w.fa_seg.reserve(roomy(n));
+        w.fa_seqs.reserve(roomy(text_len + 8));
+        w.fa_dom.reserve(roomy(text_len + 8));
+        w.fa_rate.reserve(roomy(text_len + 8));
+        uint32_t *summary = w.fa_summary.as<uint32_t>();
+        const uint32_t init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+        uint32_t *mail = reinterpret_cast<uint32_t *>(&s->mailbox[0]);              // [0..3] summary, [4] the first start, [5] the last start
+        memcpy(mail, init, sizeof init);
+        HIP_CHECK(hipMemcpyAsync(summary, mail, sizeof init, hipMemcpyHostToDevice, st));
+        // text in front of the first record: [0, at[0]) -- at[0] = text_len without any record
+        HIP_CHECK(hipMemcpyAsync(&mail[4], w.fa_at.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&mail[5], w.fa_at.as<uint32_t>() + (starts ? starts - 1 : 0), 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t lead_end = mail[4], last_start = mail[5];
+        reset_call_timers(*s);
+        s->timers["parse_records"].start(st);
+        const fasta::Records rec{w.fa_at.as<uint32_t>(), w.fa_len.as<uint32_t>(), w.fa_id_len.as<uint32_t>(), w.fa_frag_len.as<uint32_t>(), w.fa_seg.as<uint8_t>()};
+        if (lead_end) hipLaunchKernelGGL(fasta::k_fasta_lead, dim3(std::min(1024u, cdiv(lead_end, 256))), dim3(256), 0, st, text, lead_end, summary);
+        if (n) {
+            static const bool lds_set = [] {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fasta::k_fasta_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fasta::kStageBytes));
+                return true;
+            }();
+            (void)lds_set;
+            hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_seqs.as<uint8_t>(),
+                               w.fa_dom.as<uint8_t>(), w.fa_rate.as<uint8_t>(), summary);
+        }
+        s->timers["parse_records"].stop(st);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(mail, summary, 16, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t longest = mail[0], first_bad = mail[1];
+        if (mail[2]) {
+            g_last_error = "sequence data without a header line in the input";
+            return (int)RSQ_EIO;
+        }
+        if (first_bad != 0xFFFFFFFFu) {
+            uint32_t span[2];
+            HIP_CHECK(hipMemcpy(span, w.fa_at.as<uint32_t>() + first_bad, 8, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> record(span[1] - span[0]);
+            HIP_CHECK(hipMemcpy(record.data(), text + span[0], record.size(), hipMemcpyDeviceToHost));
+            g_last_error = record_message(record);
+            return (int)RSQ_EIO;
+        }
+        *consumed = final || !starts ? text_len : last_start;
+        *n_records = n;
+        if (!n) return (int)RSQ_OK;
+        const RawLayout raw = error_model_fill(s, first_index, n, longest, w.fa_seqs.as<uint8_t>(), w.fa_seg.as<uint8_t>(), w.fa_frag_len.as<uint32_t>(), w.fa_dom.as<uint8_t>(),
+                                               w.fa_rate.as<uint8_t>(), st, w.fa_at.as<uint32_t>(), w.fa_len.as<uint32_t>(), (uint32_t)text_len + 8u, false);
+        return error_model_text(s, raw, n, RecordIds{text_dev, nullptr, w.fa_at.as<uint32_t>(), w.fa_id_len.as<uint32_t>()}, out_dev, out_cap, out_len, st);
     });
 }
 
@@ -1996,6 +2133,35 @@ int rsq_dev_download(int device, void *dst, const void *src_dev, size_t bytes) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
+        return RSQ_OK;
+    });
+}
+// streams of the caller's own (the CLI's reader, simulator and writer sides each work on one): copies on them return when they are done and leave
+// the other streams alone -- the plain calls above go through the null stream, which waits for every other one
+int rsq_stream_create(int device, void **out_stream) {
+    REQUIRE(out_stream, "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        hipStream_t st = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        *out_stream = st;
+        return RSQ_OK;
+    });
+}
+int rsq_stream_destroy(int device, void *stream) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        if (stream) HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+        return RSQ_OK;
+    });
+}
+int rsq_dev_copy_on(int device, void *dst, const void *src, size_t bytes, int kind, void *stream) {
+    REQUIRE(kind >= 0 && kind <= 2 && (dst || !bytes) && (src || !bytes), "kind is 0 (host to device), 1 (device to host) or 2 (device to device)");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        static const hipMemcpyKind kinds[3] = {hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice};
+        if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kinds[kind], (hipStream_t)stream));
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         return RSQ_OK;
     });
 }

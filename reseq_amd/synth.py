@@ -447,6 +447,36 @@ def encode_sys_rate(rate):
     return (q + 33).astype(np.uint8)
 
 
+def fixed_width_fasta(rec):
+    """seqToIllumina's input for the records as a byte matrix, one row per record: ">r" 9 digits " " segment ";" 3 digits ";" dominant errors ";" rates,
+    a line end, the bases, a line end (fragment lengths 100..999; number_rows writes the ids).  The measuring tools write files of any size from it."""
+    n, L = rec["seqs"].shape
+    fl = np.asarray(rec["frag_len"], np.int64)
+    assert fl.min() >= 100 and fl.max() <= 999
+    block = np.zeros((n, 21 + 3 * L), np.uint8)
+    block[:, 0:2] = np.frombuffer(b">r", np.uint8)
+    block[:, 11] = ord(" ")
+    block[:, 12] = np.asarray(rec["seg"], np.uint8) + ord("1")
+    block[:, 13] = ord(";")
+    for k in range(3):
+        block[:, 14 + k] = (fl // 10 ** (2 - k)) % 10 + ord("0")
+    block[:, 17] = ord(";")
+    block[:, 18:18 + L] = np.frombuffer(b"ACGTN", np.uint8)[rec["dom"]]
+    block[:, 18 + L] = ord(";")
+    block[:, 19 + L:19 + 2 * L] = encode_sys_rate(rec["rate"])
+    block[:, 19 + 2 * L] = ord("\n")
+    block[:, 20 + 2 * L:20 + 3 * L] = np.frombuffer(b"ACGT", np.uint8)[rec["seqs"]]
+    block[:, 20 + 3 * L] = ord("\n")
+    return block
+
+
+def number_rows(block, first):
+    """ids "r{first + row:09d}" into the rows of fixed_width_fasta"""
+    idx = np.arange(first, first + len(block))
+    for k in range(9):
+        block[:, 2 + k] = (idx // 10 ** (8 - k)) % 10 + ord("0")
+
+
 def make_error_model_input(seed, n, read_len, profile, zero_frac=0.97):
     """Records for seqToIllumina (Simulator.cpp:2403-2512): per record a
     template, the segment, fragment length, dominant-error bases and rates."""

@@ -69,6 +69,7 @@ def emu_lib():
         L.emu_pairs_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
         L.emu_error_model.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
+        L.emu_parse_fasta.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32] + [C.c_void_p] * 8 + [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint32)] * 3
         L.emu_draw.restype = C.c_uint32
         L.emu_draw.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_double, C.POINTER(C.c_double)]
         L.emu_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -86,6 +87,30 @@ def set_option_everywhere(name, value):
     api.set_option(name, value)
     if emu_lib().emu_set_option(name.encode(), int(value)) != 0:
         raise KeyError(name)
+
+
+def emu_parse_fasta(text, final=True):
+    """rsq_fasta.h's record_start / parse_record run on the CPU over a block of seqToIllumina input.  Returns a dict: n, consumed, bad (index of the first
+    malformed record or None), bad_kind, lead (text in front of the first record), and per record at, len, id_len, frag_len, seg, seqs, dom, rate"""
+    import numpy as np
+    L = emu_lib()
+    buf = np.frombuffer(bytes(text) + b"\0" * 8, np.uint8)
+    cap = text.count(b">") + 1
+    at = np.zeros(cap + 1, np.uint32)
+    ln, idl, fl = (np.zeros(cap, np.uint32) for _ in range(3))
+    seg = np.zeros(cap, np.uint8)
+    seqs, dom, rate = (np.full(len(text) + 8, 0xEE, np.uint8) for _ in range(3))
+    n, used, bad, kind, lead = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    rc = L.emu_parse_fasta(buf.ctypes.data, len(text), 1 if final else 0, cap, at.ctypes.data, ln.ctypes.data, idl.ctypes.data, fl.ctypes.data, seg.ctypes.data,
+                           seqs.ctypes.data, dom.ctypes.data, rate.ctypes.data, C.byref(n), C.byref(used), C.byref(bad), C.byref(kind), C.byref(lead))
+    assert rc == 0
+    k = n.value
+    out = {"n": k, "consumed": used.value, "bad": None if bad.value == 0xFFFFFFFF else bad.value, "bad_kind": kind.value, "lead": bool(lead.value), "at": at[:k + 1].copy(),
+           "len": ln[:k].copy(), "id_len": idl[:k].copy(), "frag_len": fl[:k].copy(), "seg": seg[:k].copy()}
+    for name, arr in (("seqs", seqs), ("dom", dom), ("rate", rate)):
+        out[name] = [arr[at[i]:at[i] + ln[i]].copy() for i in range(k)]
+    out["arrays"] = (seqs, dom, rate)
+    return out
 
 
 class EmuBackend:
@@ -319,6 +344,9 @@ class GpuBackend:
 
     def error_model_fastq(self, rec, ids, first_index=0):
         return self.sim.error_model_fastq(rec, ids, first_index)
+
+    def error_model_fasta(self, text, first_index=0, final=True):
+        return self.sim.error_model_fasta(text, first_index, final)
 
     # the pre-pass of one rank of a sharded job
     def prepare_plan(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):

@@ -434,9 +434,53 @@ def _error_model(backend_cls, workdir, tag, cfg, n, read_len, seed, prof_seed, z
         want = b"".join(b"@" + ids[i] + b" " + e[2].encode() + b" E%d\n" % e[3] + bytes(b"ACGTN"[c] for c in e[0]) + b"\n+\n" + e[1] + b"\n"
                         for i, e in enumerate(exp))
         assert b.error_model_fastq(rec, ids, first_index=17) == want
+    if hasattr(b, "error_model_fasta"):                       # the same through the FASTA text, parsed on the device (rsq_sim_error_model_fasta)
+        _error_model_fasta(b, oprof, seed, rec)
     b.close()
     oprof.close()
     return exp
+
+
+def fasta_of_records(rec, ids, wrap_every=0, line_end="\n"):
+    """seqToIllumina's input for the records: ">{id} {1|2};{fragment length};{dominant errors};{error rates}" (Simulator.cpp:2423-2485), every
+    wrap_every-th sequence wrapped over lines of 20"""
+    lines = []
+    for i, rid in enumerate(ids):
+        seq = "".join("ACGT"[c] for c in rec["seqs"][i])
+        dom = "".join("ACGTN"[c] for c in rec["dom"][i])
+        rate = synth.encode_sys_rate(rec["rate"][i]).tobytes().decode()
+        lines.append(f">{rid} {int(rec['seg'][i]) + 1};{int(rec['frag_len'][i])};{dom};{rate}")
+        lines += [seq[k:k + 20] for k in range(0, len(seq), 20)] if wrap_every and i % wrap_every == 0 else [seq]
+    return (line_end.join(lines) + line_end).encode()
+
+
+def _error_model_fasta(b, oprof, seed, rec):
+    rec = dict(rec)
+    r = rec["rate"].astype(np.int64)                          # what survives the file: odd percents above 86 become the even one below (Simulator.cpp:2439-2442)
+    rec["rate"] = np.where(r > 86, r - r % 2, r).astype(np.uint8)
+    n = len(rec["seg"])
+    ids = [f"read {i}/x" if i % 7 == 0 else f"r{i}" for i in range(n)]
+    exp = O.error_model_only(oprof, seed, rec, first_index=17)
+    want = b"".join(b"@" + ids[i].encode() + b" " + e[2].encode() + b" E%d\n" % e[3] + bytes(b"ACGTN"[c] for c in e[0]) + b"\n+\n" + e[1] + b"\n" for i, e in enumerate(exp))
+    text = fasta_of_records(rec, ids, wrap_every=3)
+    got, k, used = b.error_model_fasta(text, first_index=17)
+    assert (k, used) == (n, len(text))
+    assert got == want
+    assert b.error_model_fasta(fasta_of_records(rec, ids, wrap_every=2, line_end="\r\n"), first_index=17)[0] == want
+    # in blocks that end anywhere: what the call leaves over goes in front of the next block
+    for block in (len(text) // 3 + 1, 4096):
+        out, first, rest, pos = [], 17, b"", 0
+        while True:
+            piece = rest + text[pos:pos + block]
+            pos += block
+            final = pos >= len(text)
+            got, k, used = b.error_model_fasta(piece, first_index=first, final=final)
+            out.append(got)
+            first += k
+            rest = piece[used:]
+            if final:
+                break
+        assert first == 17 + n and not rest and b"".join(out) == want, block
 
 
 def case_error_model_tiny(backend_cls, workdir):

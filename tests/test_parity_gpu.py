@@ -336,6 +336,22 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
     # replaceQuals is the same mode (BASELINE.json's name for it); stdin / stdout without -i / -o
     r = subprocess.run([exe, "replaceQuals", "-s", ppath, "--seed", "77"], input=inp.read_bytes(), check=True, capture_output=True)
     assert r.stdout.decode() == got
+    # blocks far smaller than the file (the pipeline's default is 48 MB): several readers at offsets, records across block ends put together on the device, one
+    # block or several in a call (records longer than a block among them); a gzip file, which one reader reads in sequence
+    for extra in (["--blockKB", "4", "--readThreads", "3"], ["--blockKB", "1", "--batchBlocks", "1", "--readThreads", "5"], ["--blockKB", "7", "--batchBlocks", "3"]):
+        subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"] + extra, check=True, capture_output=True)
+        assert out.read_text() == got, extra
+    r = subprocess.run([exe, "replaceQuals", "-s", ppath, "--seed", "77", "--blockKB", "3"], input=inp.read_bytes(), check=True, capture_output=True)
+    assert r.stdout.decode() == got
+    import gzip
+    gz = workdir / "s2i.fa.gz"
+    gz.write_bytes(gzip.compress(inp.read_bytes()))
+    subprocess.run([exe, "seqToIllumina", "-i", str(gz), "-o", str(workdir / "s2i.fq.gz"), "-s", ppath, "--seed", "77", "--blockKB", "16"], check=True, capture_output=True)
+    assert gzip.decompress((workdir / "s2i.fq.gz").read_bytes()).decode() == got
+    crlf = workdir / "s2i_crlf.fa"
+    crlf.write_bytes(inp.read_bytes().replace(b"\n", b"\r\n"))
+    subprocess.run([exe, "seqToIllumina", "-i", str(crlf), "-o", str(out), "-s", ppath, "--seed", "77", "--blockKB", "5"], check=True, capture_output=True)
+    assert out.read_text() == got
     # the reference's complaints about malformed headers
     for bad, msg in ((">r 3;40;NNNN;!!!!\nACGT\n", "Template segment is 3"), (">r1;40;NNNN;!!!!\nACGT\n", "No sequence id found"), (">r 1;4x;NNNN;!!!!\nACGT\n", "not a pure integer"),
                      (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short"), (">r 1;40;NNNN;!!!!\nACNT\n", "must not contain N")):
@@ -343,6 +359,16 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
         r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
         assert r.returncode != 0 and msg.encode() in r.stderr, (bad, r.stderr)
         assert not out.exists()
+    # a malformed record far into the file, and text in front of the first record
+    inp.write_text("\n".join(fasta) + "\n>r 3;40;NNNN;!!!!\nACGT\n" + "\n".join(fasta[:40]) + "\n")
+    r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77", "--blockKB", "4"], capture_output=True)
+    assert r.returncode != 0 and b"Template segment is 3 not 1 or 2: r 3;40;NNNN;!!!!" in r.stderr and not out.exists()
+    inp.write_text("ACGT\n" + "\n".join(fasta) + "\n")
+    r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
+    assert r.returncode != 0 and b"without a header" in r.stderr and not out.exists()
+    inp.write_text("\n")
+    r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
+    assert r.returncode != 0 and b"does not contain any sequences" in r.stderr and not out.exists()
 
 
 def test_cli_rejects_bad_numbers_and_contradicting_options(workdir):

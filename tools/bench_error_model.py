@@ -72,7 +72,38 @@ fill_ms = sim.last_kernel_ms("fill_reads")
 once_text()
 tt = [once_text() for _ in range(3)]
 best_text = min(t for t, _ in tt)
-print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "profile": CFG["name"], "quality_values": CFG["qual_to"] - CFG["qual_from"], "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
+# the same records as FASTA text resident in HBM, parsed on the device (rsq_sim_error_model_fasta): in one call (below 4 GB of text) and in blocks of 48 MB as the
+# command line hands them over
+rec["frag_len"] = np.clip(rec["frag_len"], 100, 999).astype(np.uint32)
+n_text = min(n, 8_000_000)
+rows = synth.fixed_width_fasta({k: v[:n_text] for k, v in rec.items()})
+synth.number_rows(rows, 0)
+W = rows.shape[1]
+d_fasta = api.DeviceArray.from_numpy(dev, np.concatenate([rows.reshape(-1), np.zeros(8, np.uint8)]))
+del rows
+
+
+def once_fasta(block_records):
+    need, k, used = C.c_size_t(0), C.c_uint64(0), C.c_size_t(0)
+    ms = {"parse_records": 0.0, "fill_reads": 0.0, "format_write": 0.0}
+    t0 = time.perf_counter()
+    for first in range(0, n_text, block_records):
+        m = min(block_records, n_text - first)
+        api._check(api.lib().rsq_sim_error_model_fasta(sim.h, first, C.c_void_p(d_fasta.ptr.value + first * W), m * W, 1, text.ptr, text.nbytes, C.byref(need), C.byref(k), C.byref(used), None))
+        assert k.value == m and used.value == m * W
+        for name in ms:
+            ms[name] += sim.last_kernel_ms(name)
+    return time.perf_counter() - t0, ms
+
+
+fasta = {}
+for label, block_records in (("one_call", n_text), ("blocks_of_48_MB", (48 << 20) // W), ("blocks_of_192_MB", (192 << 20) // W)):
+    once_fasta(block_records)
+    runs = [once_fasta(block_records) for _ in range(3)]
+    t, ms = min(runs, key=lambda r: r[0])
+    fasta[label] = {"records_per_call": block_records, "calls": -(-n_text // block_records), "seconds": [r[0] for r in runs], "reads_per_s": n_text / t, "kernel_ms_summed": ms}
+print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "from_fasta_text_parsed_on_device": dict(fasta, records=n_text, text_bytes=n_text * W), "profile": CFG["name"], "quality_values": CFG["qual_to"] - CFG["qual_from"], "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
                   "reads_per_s": n * calls / best, "fill_kernel_ms_last_call": fill_ms, "with_fastq_text_on_device": {"seconds": [t for t, _ in tt], "reads_per_s": n * calls / best_text,
                                                                                                                   "text_bytes_per_call": tt[0][1],
                                                                                                                   "format_ms_last_call": sim.last_kernel_ms("format_write")}}))
+

@@ -1,15 +1,19 @@
-# wall time of reseq seqToIllumina on N records with several parser-thread counts (tools/time_seq_to_illumina.py builds the input once per call)
-N=${1:-20000000}
-for t in 6 16 32; do
-python - "$N" "$t" <<'PY'
-import sys, re, subprocess, json
-n, t = sys.argv[1], sys.argv[2]
-src = open("tools/time_seq_to_illumina.py").read().replace('"--seed", "5"]', '"--seed", "5", "--parseThreads", "%s"]' % t)
-open("/tmp/ts2i.py", "w").write(src.replace('os.path.dirname(os.path.dirname(os.path.abspath(__file__)))', 'os.getcwd()'))
-r = subprocess.run([sys.executable, "/tmp/ts2i.py", n], capture_output=True, text=True)
-line = r.stdout.strip().split("\n")[-1] if r.stdout.strip() else r.stderr[-500:]
-try:
-    d = json.loads(line); print("threads", t, "wall", d["wall_s"], "M reads/s", round(d["reads_per_s_wall"]/1e6, 2), d["first_records_equal_oracle"], d["records_in_the_middle_equal_oracle"])
-except Exception: print(line)
+#!/bin/bash
+# `reseq seqToIllumina` on 20 M records in /dev/shm under a few settings: bash tools/gpu_s2i.sh <tag>
+tag=${1:-s2i}; out=gpurun_out/$tag; mkdir -p $out
+run() { name=$1; shift; python tools/time_seq_to_illumina.py 20000000 "$@" > $out/s2i_$name.json 2> $out/s2i_$name.err; python - $out/s2i_$name.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); print(sys.argv[1].split("/")[-1], [round(t, 2) for t in d["wall_s"]], d["stages"])
 PY
-done
+}
+run default
+run readers2 --readThreads 2
+run readers12 --readThreads 12
+run batch1 --batchBlocks 1
+run block16 --blockKB 16384
+RSQ_S2I_OUT=/dev/null run devnull
+lscpu | grep -i "numa\|socket\|model name" > $out/lscpu.txt
+RSQ_S2I_OUT=/tmp/rsq_s2i_out.fq run overlay
+rm -f /tmp/rsq_s2i_out.fq
+python tools/bench_error_model.py 8000000 > $out/config3_8M.json 2> $out/config3_8M.err; python -c "
+import json,sys; d=json.load(open('$out/config3_8M.json')); print(json.dumps(d['from_fasta_text_parsed_on_device'], indent=1)); print(d['reads_per_s'], d['with_fastq_text_on_device']['reads_per_s'])"; tail -3 $out/config3_8M.err
