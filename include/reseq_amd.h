@@ -229,7 +229,7 @@ typedef struct {
  * ranks can exchange their sizes BEFORE anything is written and every rank then writes straight to its own offset of the two final files: no shard files, no
  * second copy, no second simulation.  rsq_sim_job_write copies the kept text through page-locked double buffers and pwrite()s it at the given offsets with
  * `threads_per_file` threads per file (each its own part of the range, stream and buffers; 0: 1 -- buffered writes into one file serialise on its inode lock); the files
- * are created if need be, never truncated.
+ * are created if need be, never truncated.  r2_path NULL: a job with one file (the records' text kept by rsq_sim_error_model_file with keep_text).
  * rsq_sim_job_free releases the text (rsq_sim_free does too).  A single-process run has offset 0 and may as well stream (the `reseq` command line does). */
 int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint32_t batch_blocks, uint64_t *n_pairs, uint64_t *r1_bytes, uint64_t *r2_bytes, void *stream);
 int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file);
@@ -278,6 +278,34 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
  * Kernel time: "parse_records" beside the names below.  text_len < 4 GB. */
 int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text_dev, size_t text_len, int final, char *out_dev, size_t out_cap, size_t *out_len,
                               uint64_t *n_records, size_t *consumed, void *stream);
+
+/* Simulator::SimulateErrorModelOnly (reseq/Simulator.h:457, Simulator.cpp:2900-3014): seqToIllumina from file to file.  input_path NULL = stdin, output_path NULL =
+ * stdout; gzip / bzip2 input by content, output by name (.gz, .bz2) as SeqAn does.  A pipeline around rsq_sim_error_model_fasta: a plain file is read at offsets by
+ * several threads that upload their blocks themselves, the calling thread runs the device calls on the blocks that are there, two more threads download and write the
+ * text; a compressed file or a pipe has one reader.  *n_records records written as *out_bytes bytes of FASTQ.  An input without any record gives *n_records = 0 (the
+ * reference calls that an error: the caller's to report).  A malformed record: RSQ_EIO and the reference's words in rsq_last_error(); what has been written of the
+ * output by then is the caller's to remove (Simulator.cpp:2888-2892 does).
+ * options (NULL or zero fields: the defaults): read_threads (6), block_kb (48 MB blocks), batch_blocks (up to 8 blocks in one device call); from / to: bytes
+ * [from, to) of a plain input file, `from` a record's first byte (to = 0: the file's end), first_record: the index in the whole input of the range's first record --
+ * a rank's share of a job over several GPUs (rsq_fasta_count_records finds the ranges); progress: called with the records done so far, about every million;
+ * trace / trace_cap: receives one line saying where each side of the pipeline spent its time; keep_text = 1 (with output_path NULL): nothing is written, the text
+ * stays in device memory like the pairs' text of rsq_sim_job_generate -- rsq_sim_job_write(sim, path, offset, NULL, 0, threads) puts it at a rank's offset of the
+ * one output file once the ranks know each other's *out_bytes, rsq_sim_job_read serves a gather, rsq_sim_job_free releases it. */
+typedef struct {
+    uint32_t read_threads, block_kb, batch_blocks;
+    uint32_t keep_text;
+    uint64_t from, to, first_record;
+    void (*progress)(uint64_t records, void *user);
+    void *user;
+    char *trace;
+    size_t trace_cap;
+} rsq_error_model_file_options;
+int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *output_path, const rsq_error_model_file_options *options, uint64_t *n_records,
+                             uint64_t *out_bytes);
+/* Record starts ('>' at the start of a line or of the file) in bytes [from, to) of a plain file (to = 0: its end): their number, and the first one's offset (`to` if
+ * there is none).  Host code, no device.  Ranks of a sharded seqToIllumina run count their stretch of the file, exchange the two numbers, and know the index of
+ * their first record and where the next rank's share begins (reseq_amd/simulate.py; SURVEY section 8(e): "seqToIllumina shards by input record ranges"). */
+int rsq_fasta_count_records(const char *path, uint64_t from, uint64_t to, uint32_t threads, uint64_t *n_starts, uint64_t *first_start);
 
 /* kernel timing of the last rsq_sim_pairs / rsq_sim_error_model call: HIP events recorded around each kernel on the stream it was launched on.  A call
  * over a large block range runs as several sub-ranges (blocks are independent, Simulator.cpp:2384-2401) whose sieve / reads / text stages are pipelined on

@@ -102,6 +102,8 @@ SYMBOLS = {
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "rsq_sim_error_model_fastq": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
+    "rsq_sim_error_model_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rsq_fasta_count_records": (C.c_int, [C.c_char_p, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "rsq_sim_error_model_fasta": (C.c_int, [_vp, _u64, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_u64), C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "rsq_sim_last_kernel_launches": (C.c_int, [_vp, C.c_char_p, C.POINTER(_u32)]),
@@ -232,6 +234,19 @@ class Profile:
             self.h = C.c_void_p()
 
 
+def load_profile(path, ipf_path=None):
+    """a profile by the file's content: ReSeq's `.reseq` archive (with its `.reseq.ipf`: ipf_path, default `<path>.ipf`) or an RSQP container -- what the command line does"""
+    archive = C.c_int(0)
+    lib().rsq_profile_is_reseq_archive(os.fsencode(path), C.byref(archive))
+    if not archive.value:
+        return Profile(path)
+    p = Profile.__new__(Profile)
+    p.h = C.c_void_p()
+    _check(lib().rsq_profile_load_reseq(os.fsencode(path), os.fsencode(ipf_path) if ipf_path else None, 5.0, C.byref(p.h)))
+    p.warning = lib().rsq_last_warning().decode()
+    return p
+
+
 class Reference:
     """Reference::ReadFasta (+ ReplaceN)."""
 
@@ -286,6 +301,19 @@ class Reference:
         if self.h:
             lib().rsq_ref_free(self.h)
             self.h = C.c_void_p()
+
+
+class ErrorModelFileOptions(C.Structure):
+    """rsq_error_model_file_options (include/reseq_amd.h)"""
+    _fields_ = [("read_threads", C.c_uint32), ("block_kb", C.c_uint32), ("batch_blocks", C.c_uint32), ("keep_text", C.c_uint32), ("from_", C.c_uint64), ("to", C.c_uint64), ("first_record", C.c_uint64),
+                ("progress", C.c_void_p), ("user", C.c_void_p), ("trace", C.c_char_p), ("trace_cap", C.c_size_t)]
+
+
+def count_fasta_records(path, from_=0, to=0, threads=0):
+    """record starts in bytes [from_, to) of a plain FASTA file (to = 0: its end): (their number, the first one's offset -- `to` if none).  Host code, no device."""
+    n, first = _u64(0), _u64(0)
+    _check(lib().rsq_fasta_count_records(os.fsencode(path), from_, to, threads, C.byref(n), C.byref(first)))
+    return n.value, first.value
 
 
 class DeviceArray:
@@ -463,8 +491,8 @@ class Simulator:
         return n.value, b1.value, b2.value
 
     def job_write(self, r1_path, r1_offset, r2_path, r2_offset, threads_per_file=0):
-        """the kept text to its place in the two final files (parallel pwrite from page-locked buffers)"""
-        _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode(), r2_offset, threads_per_file))
+        """the kept text to its place in the two final files (parallel pwrite from page-locked buffers); r2_path None: a job with one file"""
+        _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode() if r2_path is not None else None, r2_offset, threads_per_file))
 
     def job_read(self, file, at, nbytes, dst_ptr, stream=None):
         """bytes [at, at + nbytes) of the kept text of file 0 / 1 into device memory at `dst_ptr` (an integer address, e.g. a torch tensor's data_ptr())"""
@@ -559,6 +587,20 @@ class Simulator:
         finally:
             for d in [src] + ([out] if out else []):
                 d.free()
+
+    def error_model_file(self, input_path, output_path, from_=0, to=0, first_record=0, read_threads=0, block_kb=0, batch_blocks=0, trace=False, keep_text=False):
+        """Simulator::SimulateErrorModelOnly (Simulator.cpp:2900-3014) from file to file (rsq_sim_error_model_file); from_ / to / first_record: a rank's share of a
+        plain input file; keep_text (output_path None): the text stays in device memory for job_write / job_read.  Returns (records, bytes of FASTQ) and, with
+        trace, the line about the pipeline's stages."""
+        opt = ErrorModelFileOptions(read_threads=read_threads, block_kb=block_kb, batch_blocks=batch_blocks, keep_text=1 if keep_text else 0, from_=from_, to=to,
+                                    first_record=first_record)
+        buf = C.create_string_buffer(2048) if trace else None
+        if trace:
+            opt.trace, opt.trace_cap = C.cast(buf, C.c_char_p), 2048
+        n, nbytes = _u64(0), _u64(0)
+        _check(lib().rsq_sim_error_model_file(self.h, os.fsencode(input_path) if input_path else None, os.fsencode(output_path) if output_path else None, C.byref(opt),
+                                              C.byref(n), C.byref(nbytes)))
+        return (n.value, nbytes.value, buf.value.decode()) if trace else (n.value, nbytes.value)
 
     def last_kernel_ms(self, name):
         """sum over the last call's launches of the kernel (a large call runs in pipelined sub-ranges)"""

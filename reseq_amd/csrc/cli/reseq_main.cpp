@@ -175,8 +175,7 @@ bool load_profile(const Args &a, rsq_profile **p) {
     return true;
 }
 
-// FASTQ / FASTA text files: gzip / bzip2 when the name ends in .gz / .bz2, inputs by content (SeqAn's SeqFileOut / SeqFileIn pick the
-// format the same way); no file = stdout / stdin
+// FASTQ text files: gzip / bzip2 when the name ends in .gz / .bz2 (SeqAn's SeqFileOut picks the format the same way); no file = stdout
 struct TextOut {
     rsq::textio::Writer w;
     bool failed = false;
@@ -195,63 +194,6 @@ struct TextOut {
     bool good() const { return !failed && !w.failed; }
     void close() { failed = !w.close() || failed; }
 };
-struct TextIn {                       // lines of a plain, gzip or bzip2 file, or of stdin
-    rsq::textio::Reader r;
-    bool is_file = false, failed = false;
-    std::vector<char> buf = std::vector<char>(1 << 16);
-    size_t at = 0, have = 0;
-    bool open(const std::string &path) {
-        try {
-            return is_file = r.open(path);
-        } catch (const std::exception &e) {
-            ERR(e.what());
-            return false;
-        }
-    }
-    bool getline(std::string &line) {
-        if (!is_file) return (bool)std::getline(std::cin, line);
-        line.clear();
-        for (;;) {
-            if (at == have) {
-                int n = 0;
-                try {
-                    n = r.read(buf.data(), (unsigned)buf.size());
-                } catch (const std::exception &e) {
-                    ERR(e.what());
-                    failed = true;
-                    return false;
-                }
-                if (n <= 0) return !line.empty();
-                at = 0;
-                have = (size_t)n;
-            }
-            const char *p = buf.data() + at, *e = (const char *)memchr(p, '\n', have - at);
-            if (e) {
-                line.append(p, (size_t)(e - p));
-                at += (size_t)(e - p) + 1;
-                return true;
-            }
-            line.append(p, have - at);
-            at = have;
-        }
-    }
-    // raw bytes (the block reader of seqToIllumina): bytes read, 0 at the end, < 0 on an error
-    int read_raw(void *dst, unsigned n) {
-        if (!is_file) {
-            const size_t got = fread(dst, 1, n, stdin);
-            return got ? (int)got : (ferror(stdin) ? -1 : 0);
-        }
-        try {
-            return r.read(dst, n);
-        } catch (const std::exception &e) {
-            ERR(e.what());
-            failed = true;
-            return -1;
-        }
-    }
-    void close() { r.close(); }
-};
-
 struct DevBuffer {
     void *p = nullptr;
     size_t cap = 0;
@@ -485,429 +427,53 @@ int illumina_pe(const Args &a) {
     return 0;
 }
 
-struct HostArray {                    // page-locked, grow-only
-    void *p = nullptr;
-    size_t cap = 0;
-    bool ensure(size_t n) {
-        if (n <= cap) return true;
-        if (p) rsq_host_free(p);
-        p = nullptr;
-        cap = 0;
-        if (!check(rsq_host_alloc(n, &p), "host buffer")) return false;
-        cap = n;
-        return true;
-    }
-    template <class T>
-    T *as() { return static_cast<T *>(p); }
-    ~HostArray() {
-        if (p) rsq_host_free(p);
-    }
-};
-
 using Clock = std::chrono::steady_clock;
 const Clock::time_point g_process_start = Clock::now();
 double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
-struct StageTime {                    // seconds a side of the pipeline spent in one of its stages, summed over its threads
-    std::atomic<uint64_t> ns{0};
-    void add(Clock::time_point t0) { ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
-    double s() const { return (double)ns.load() * 1e-9; }
-};
 
-// ---- seqToIllumina as a pipeline (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014: a reader, ErrorModelOnlyThread :2514-2560, ordered output
-// :184-213).  Here the FASTA text goes to the device as it stands in the file and is parsed there (rsq_sim_error_model_fasta), so the host only moves bytes:
-//   input side    blocks of the file in page-locked slots, uploaded by the thread that read them -- a plain file is read by several threads at fixed offsets
-//                 (records that cross a block's end are the simulator side's business), a compressed file or stdin by one;
-//   simulator     the main thread takes the blocks in input order -- all that are there, up to eight -- and puts them behind what the call before left over
-//                 (device to device: a call on 100 000 records takes 1.1 ms, on 800 000 four: the read kernel of a small call is a chain of 150 steps on waves
-//                 that have a SIMD to themselves), runs the device call;
-//   output side   a thread downloads the FASTQ text into page-locked buffers, another writes (and compresses) them: OutPipe.
-// Every side has its own stream and its own buffers: they overlap.
-struct InPipe {
-    struct Slot {
-        HostArray host;
-        DevBuffer dev;
-        size_t len = 0;
-        bool last = false, ready = false;
-        uint64_t turn = 0;                           // the block this slot serves next
-    };
-    const size_t block_bytes;
-    std::vector<Slot> slots;
-    TextIn *stream_in = nullptr;                     // sequential input (stdin, gzip, bzip2) ...
-    int fd = -1;                                     // ... or a plain file read at offsets
-    uint64_t file_size = 0, n_blocks = 0;
-    std::atomic<uint64_t> next{0};
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<std::thread> readers;
-    bool failed = false, abort = false;
-    StageTime t_read, t_upload, t_slot;
-    InPipe(size_t block, size_t n_readers) : block_bytes(block), slots(n_readers + 2) {
-        for (size_t k = 0; k < slots.size(); ++k) slots[k].turn = k;
-    }
-    void start_file(int file, uint64_t size, size_t n_readers) {
-        fd = file;
-        file_size = size;
-        n_blocks = std::max<uint64_t>(1, (size + block_bytes - 1) / block_bytes);
-        for (size_t k = 0; k < n_readers; ++k) readers.emplace_back([this] { read_at_offsets(); });
-    }
-    void start_stream(TextIn &in) {
-        stream_in = &in;
-        readers.emplace_back([this] { read_in_sequence(); });
-    }
-    void fail() {
-        std::lock_guard<std::mutex> lock(m);
-        failed = true;
-        cv.notify_all();
-    }
-    Slot *wait_for_slot(uint64_t b) {                // the slot of block b once the block that used it before is done with; nullptr: the run ends
-        const auto t0 = Clock::now();
-        Slot *s = &slots[b % slots.size()];
-        std::unique_lock<std::mutex> lock(m);
-        cv.wait(lock, [&] { return (s->turn == b && !s->ready) || abort || failed; });
-        t_slot.add(t0);
-        return abort || failed ? nullptr : s;
-    }
-    bool upload_and_publish(Slot *s, size_t len, bool last, void *stream) {
-        const auto t0 = Clock::now();
-        if (!check(rsq_dev_copy_on(0, s->dev.p, s->host.p, len, 0, stream), "upload")) return false;
-        t_upload.add(t0);
-        std::lock_guard<std::mutex> lock(m);
-        s->len = len;
-        s->last = last;
-        s->ready = true;
-        cv.notify_all();
-        return true;
-    }
-    void read_at_offsets() {
-        void *stream = nullptr;
-        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
-        for (;;) {
-            const uint64_t b = next++;
-            if (b >= n_blocks) break;
-            Slot *s = wait_for_slot(b);
-            if (!s) break;
-            const uint64_t off = b * block_bytes;
-            const size_t len = (size_t)std::min<uint64_t>(block_bytes, file_size - off);
-            if (!s->host.ensure(block_bytes) || !s->dev.ensure(block_bytes + 16)) return fail();
-            const auto t0 = Clock::now();
-            for (size_t have = 0; have < len;) {
-                const ssize_t got = pread(fd, s->host.as<char>() + have, len - have, (off_t)(off + have));
-                if (got <= 0) {
-                    if (got < 0 && errno == EINTR) continue;
-                    ERR("reading the input failed" << (got ? std::string(": ") + strerror(errno) : std::string(": the file has become shorter")));
-                    return fail();
-                }
-                have += (size_t)got;
-            }
-            t_read.add(t0);
-            if (!upload_and_publish(s, len, b + 1 == n_blocks, stream)) return fail();
-        }
-        rsq_stream_destroy(0, stream);
-    }
-    void read_in_sequence() {
-        void *stream = nullptr;
-        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
-        for (uint64_t b = 0;; ++b) {
-            Slot *s = wait_for_slot(b);
-            if (!s) break;
-            if (!s->host.ensure(block_bytes) || !s->dev.ensure(block_bytes + 16)) return fail();
-            const auto t0 = Clock::now();
-            size_t have = 0;
-            bool end_of_input = false;
-            while (have < block_bytes) {
-                const int got = stream_in->read_raw(s->host.as<char>() + have, (unsigned)std::min<size_t>(block_bytes - have, 1u << 30));
-                if (got < 0) return fail();
-                if (!got) {
-                    end_of_input = true;
-                    break;
-                }
-                have += (size_t)got;
-            }
-            t_read.add(t0);
-            if (!upload_and_publish(s, have, end_of_input, stream)) return fail();
-            if (end_of_input) break;
-        }
-        rsq_stream_destroy(0, stream);
-    }
-    // block b, in input order; nullptr after an error -- or, if the caller does not want to wait, while the block is not there yet
-    Slot *take(uint64_t b, bool wait = true) {
-        Slot *s = &slots[b % slots.size()];
-        std::unique_lock<std::mutex> lock(m);
-        if (wait) cv.wait(lock, [&] { return (s->turn == b && s->ready) || failed; });
-        return failed || !(s->turn == b && s->ready) ? nullptr : s;
-    }
-    void release(uint64_t b) {
-        Slot &s = slots[b % slots.size()];
-        std::lock_guard<std::mutex> lock(m);
-        s.ready = false;
-        s.turn += slots.size();
-        cv.notify_all();
-    }
-    void join() {
-        {
-            std::lock_guard<std::mutex> lock(m);
-            abort = true;
-            cv.notify_all();
-        }
-        for (std::thread &t : readers)
-            if (t.joinable()) t.join();
-        if (fd >= 0) ::close(fd);
-        fd = -1;
-    }
-};
-
-// The output side: device buffers the simulator fills in turn, a thread that copies them into page-locked buffers, a thread that writes those.
-struct OutPipe {
-    static constexpr uint64_t kDev = 3, kStage = 3;
-    static constexpr size_t kChunk = 64u << 20;
-    TextOut out;
-    DevBuffer dev[kDev];
-    size_t dev_len[kDev] = {0, 0, 0};
-    HostArray stage[kStage];
-    size_t stage_len[kStage] = {0, 0, 0};
-    uint64_t filled = 0, drained = 0, staged = 0, written = 0;       // texts handed in / downloaded; chunks downloaded / written
-    bool closing = false, downloader_done = false, failed = false, started = false;
-    std::mutex m;
-    std::condition_variable cv;
-    std::thread downloader, writer;
-    StageTime t_download, t_stage, t_write, t_dev;
-    bool open(const std::string &path) {                  // an empty path: stdout
-        if (!path.empty() && !out.open(path)) return false;
-        downloader = std::thread([this] { download(); });
-        writer = std::thread([this] { write(); });
-        started = true;
-        return true;
-    }
-    void fail() {
-        std::lock_guard<std::mutex> lock(m);
-        failed = true;
-        cv.notify_all();
-    }
-    // the device buffer the next text goes to (the caller may enlarge it), once its last text has been downloaded; nullptr after an error
-    DevBuffer *begin() {
-        const auto t0 = Clock::now();
-        std::unique_lock<std::mutex> lock(m);
-        cv.wait(lock, [&] { return filled - drained < kDev || failed; });
-        t_dev.add(t0);
-        return failed ? nullptr : &dev[filled % kDev];
-    }
-    void submit(size_t bytes) {
-        std::lock_guard<std::mutex> lock(m);
-        dev_len[filled % kDev] = bytes;
-        ++filled;
-        cv.notify_all();
-    }
-    void download() {
-        void *stream = nullptr;
-        if (!check(rsq_stream_create(0, &stream), "stream")) return fail();
-        for (;;) {
-            uint64_t k;
-            {
-                std::unique_lock<std::mutex> lock(m);
-                cv.wait(lock, [&] { return drained < filled || closing || failed; });
-                if (failed || drained == filled) break;
-                k = drained % kDev;
-            }
-            for (size_t done = 0; done < dev_len[k]; done += kChunk) {
-                const size_t n = std::min(kChunk, dev_len[k] - done);
-                uint64_t j;
-                {
-                    const auto t0 = Clock::now();
-                    std::unique_lock<std::mutex> lock(m);
-                    cv.wait(lock, [&] { return staged - written < kStage || failed; });
-                    t_stage.add(t0);
-                    if (failed) break;
-                    j = staged % kStage;
-                }
-                const auto t0 = Clock::now();
-                if (!stage[j].ensure(kChunk) || !check(rsq_dev_copy_on(0, stage[j].p, static_cast<const char *>(dev[k].p) + done, n, 1, stream), "download")) return finish_download(true);
-                t_download.add(t0);
-                std::lock_guard<std::mutex> lock(m);
-                stage_len[j] = n;
-                ++staged;
-                cv.notify_all();
-            }
-            std::lock_guard<std::mutex> lock(m);
-            ++drained;
-            cv.notify_all();
-        }
-        rsq_stream_destroy(0, stream);
-        finish_download(false);
-    }
-    void finish_download(bool error) {
-        std::lock_guard<std::mutex> lock(m);
-        failed = failed || error;
-        downloader_done = true;
-        cv.notify_all();
-    }
-    void write() {
-        for (;;) {
-            uint64_t j;
-            {
-                std::unique_lock<std::mutex> lock(m);
-                cv.wait(lock, [&] { return written < staged || downloader_done || failed; });
-                if (failed || written == staged) break;
-                j = written % kStage;
-            }
-            const auto t0 = Clock::now();
-            out.write(stage[j].as<char>(), stage_len[j]);
-            t_write.add(t0);
-            std::lock_guard<std::mutex> lock(m);
-            ++written;
-            if (!out.good()) failed = true;
-            cv.notify_all();
-        }
-    }
-    void close() {
-        if (started) {
-            {
-                std::lock_guard<std::mutex> lock(m);
-                closing = true;
-                cv.notify_all();
-            }
-            downloader.join();
-            writer.join();
-            started = false;
-        }
-        out.close();
-    }
-    bool good() const { return !failed && out.good(); }
-};
-
-// a file that can be read at offsets by several threads: regular, and neither gzip nor bzip2 by its first bytes
-int open_plain_file(const std::string &path, uint64_t &size) {
-    const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return -1;
-    struct stat st;
-    unsigned char magic[3] = {0, 0, 0};
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || pread(fd, magic, 3, 0) < 0 || (magic[0] == 0x1f && magic[1] == 0x8b) || (magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')) {
-        ::close(fd);
-        return -1;
-    }
-    size = (uint64_t)st.st_size;
-    return fd;
-}
-
+// ---- seqToIllumina (main.cpp:1009-1021, 1131; Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014): the library's file-to-file pipeline
+// (rsq_sim_error_model_file: readers at file offsets, the FASTA text parsed on the device, ordered output) with the reference's options and messages
 int seq_to_illumina(const Args &a) {
     rsq_profile *prof = nullptr;
     rsq_sim *sim = nullptr;
-    const bool trace = a.has("traceStages");
     bool ok = load_profile(a, &prof);
     const double at_profile = seconds_since(g_process_start);
     const uint64_t seed = ok ? get_seed(a) : 0;
     ok = ok && check(rsq_sim_create(prof, nullptr, 0, &sim), "Could not set up the simulator") &&
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
     const double at_prepared = seconds_since(g_process_start);
-    TextIn fin;                                              // stdin / stdout without -i / -o (main.cpp:1009-1021)
-    OutPipe fout;
-    uint64_t plain_size = 0;
-    int plain_fd = -1;
-    if (ok && a.has("input")) {
-        plain_fd = open_plain_file(a.get("input"), plain_size);
-        if (plain_fd < 0 && !fin.open(a.get("input"))) {
-            ERR("Could not open '" << a.get("input") << "' for reading.");
-            ok = false;
-        }
-    }
-    if (ok && !fout.open(a.get("output", ""))) {
-        ERR("Could not open '" << a.get("output") << "' for writing.");
-        ok = false;
-    }
     if (ok) {
         INFO("Starting read generation");
-        const unsigned hw = std::thread::hardware_concurrency();
-        // reader threads of a plain file: one copies about 6 GB/s out of the page cache (--readThreads overrides; a stream has one reader whatever it says)
-        uint32_t n_readers = std::max(1u, std::min(hw > 3 ? hw - 3 : 1u, 6u));
+        rsq_error_model_file_options opt;
+        memset(&opt, 0, sizeof opt);
+        // --readThreads, --blockKB, --batchBlocks: the pipeline's sizes (the tests make them small); --inputFrom / --inputTo / --firstRecord: a rank's share of
+        // the input in a job over several GPUs (reseq_amd/simulate.py works them out)
         for (const char *name : {"readThreads", "parseThreads"})
-            if (a.has(name)) n_readers = (uint32_t)std::max(1, atoi(a.get(name).c_str()));
-        // blocks of 48 MB, up to eight of them in a call (--blockKB / --batchBlocks: the tests make them small)
-        const size_t block_bytes = (size_t)std::min(1 << 20, std::max(1, a.has("blockKB") ? atoi(a.get("blockKB").c_str()) : 48 << 10)) << 10;
-        uint32_t batch_blocks = (uint32_t)std::max(1, a.has("batchBlocks") ? atoi(a.get("batchBlocks").c_str()) : 8);
-        while (batch_blocks > 1 && batch_blocks * block_bytes > ((size_t)3 << 30)) --batch_blocks;      // a call takes less than 4 GB of text
-        InPipe in(block_bytes, plain_fd >= 0 ? n_readers : 1);
-        if (plain_fd >= 0) in.start_file(plain_fd, plain_size, n_readers);
-        else in.start_stream(fin);
-        void *stream = nullptr;
-        ok = check(rsq_stream_create(0, &stream), "stream");
-        DevBuffer joined[2];                                  // the text of a call: what the call before left over (it lies in the other one), then the blocks
-        int next_joined = 0;
-        const char *rest = nullptr;                           // the start of a record whose end the next block holds
-        size_t rest_len = 0;
-        uint64_t records = 0, next_report = 0, calls = 0;
-        StageTime t_wait, t_join, t_call;
-        double at_first_block = 0;
-        const auto t_all = Clock::now();
-        bool last = false;
-        for (uint64_t b = 0; ok && !last;) {
-            auto t0 = Clock::now();
-            InPipe::Slot *slot = in.take(b);
-            t_wait.add(t0);
-            if (!slot) {
+            if (a.has(name)) opt.read_threads = (uint32_t)std::max(1, atoi(a.get(name).c_str()));
+        if (a.has("blockKB")) opt.block_kb = (uint32_t)std::max(1, atoi(a.get("blockKB").c_str()));
+        if (a.has("batchBlocks")) opt.batch_blocks = (uint32_t)std::max(1, atoi(a.get("batchBlocks").c_str()));
+        ok = (!a.has("inputFrom") || parse_u64(a, "inputFrom", opt.from)) && (!a.has("inputTo") || parse_u64(a, "inputTo", opt.to)) &&
+             (!a.has("firstRecord") || parse_u64(a, "firstRecord", opt.first_record));
+        opt.progress = [](uint64_t records, void *) { INFO("Generated " << records << " reads."); };
+        char trace[1024] = "";
+        if (a.has("traceStages")) {
+            opt.trace = trace;
+            opt.trace_cap = sizeof trace;
+        }
+        uint64_t records = 0, bytes = 0;
+        if (ok) {
+            const int rc = rsq_sim_error_model_file(sim, a.has("input") ? a.get("input").c_str() : nullptr, a.has("output") ? a.get("output").c_str() : nullptr, &opt, &records, &bytes);
+            if (rc != RSQ_OK) {
+                ERR(rsq_last_error());                           // the reference's complaint about a record (Simulator.cpp:2423-2485), or what went wrong with a file
                 ok = false;
-                break;
-            }
-            if (!b) at_first_block = seconds_since(g_process_start);
-            t0 = Clock::now();
-            DevBuffer &j = joined[next_joined];
-            next_joined ^= 1;
-            ok = j.ensure(rest_len + batch_blocks * block_bytes + 16) && (!rest_len || check(rsq_dev_copy_on(0, j.p, rest, rest_len, 2, stream), "copy"));
-            char *text = static_cast<char *>(j.p);
-            size_t len = rest_len;
-            for (uint32_t k = 0; ok && slot; ++k) {
-                ok = check(rsq_dev_copy_on(0, text + len, slot->dev.p, slot->len, 2, stream), "copy");
-                len += slot->len;
-                last = slot->last;
-                in.release(b++);
-                slot = last || k + 1 == batch_blocks ? nullptr : in.take(b, false);
-            }
-            t_join.add(t0);
-            t0 = Clock::now();
-            DevBuffer *o = ok ? fout.begin() : nullptr;
-            ok = ok && o;
-            size_t out_len = 0, used = 0;
-            uint64_t n = 0;
-            for (int attempt = 0; ok && attempt < 2; ++attempt) {
-                ok = o->ensure(std::max(out_len + out_len / 8, len + len / 8) + 4096);
-                if (!ok) break;
-                const int rc = rsq_sim_error_model_fasta(sim, records, text, len, last ? 1 : 0, static_cast<char *>(o->p), o->cap, &out_len, &n, &used, stream);
-                if (rc == RSQ_ENOSPC && !attempt) continue;
-                if (rc == RSQ_EIO) {                              // the reference's complaint about a record (Simulator.cpp:2423-2485)
-                    ERR(rsq_last_error());
-                    ok = false;
-                } else ok = check(rc, "Simulation failed");
-                break;
-            }
-            t_call.add(t0);
-            if (!ok) break;
-            ++calls;
-            if (out_len) fout.submit(out_len);
-            records += n;                                         // = the index of the next record in the input (it selects the records' random streams)
-            rest = text + used;
-            rest_len = len - used;
-            if (records >= next_report) {
-                INFO("Generated " << records << " reads.");
-                next_report = records + 1000000;
             }
         }
-        if (trace)
-            fprintf(stderr,
-                    "stages: profile loaded at %.3f s of the process, simulator prepared at %.3f, first block on the device at %.3f; the simulator side took %.3f s for %llu records in %llu calls: "
-                    "waiting for blocks %.3f, putting blocks together %.3f, device calls %.3f (of these waiting for a free output buffer %.3f); readers (summed over %u threads): reading %.3f, "
-                    "uploads %.3f, waiting for a slot %.3f; downloads %.3f (+ %.3f waiting for a free buffer); writing %.3f\n",
-                    at_profile, at_prepared, at_first_block, seconds_since(t_all), (unsigned long long)records, (unsigned long long)calls, t_wait.s(), t_join.s(), t_call.s(), fout.t_dev.s(),
-                    (unsigned)in.readers.size(), in.t_read.s(), in.t_upload.s(), in.t_slot.s(), fout.t_download.s(), fout.t_stage.s(), fout.t_write.s());
-        in.join();
-        ok = ok && !in.failed && !fin.failed;
-        if (ok && !records) {
+        if (*trace) fprintf(stderr, "stages: profile loaded at %.3f s of the process, simulator prepared at %.3f; %s\n", at_profile, at_prepared, trace);
+        if (ok && !records && !a.has("inputFrom")) {
             ERR(a.get("input", "stdin") << " does not contain any sequences.");
             ok = false;
         }
-        if (!ok) fout.fail();
-        rsq_stream_destroy(0, stream);
     }
-    fin.close();
-    fout.close();
-    ok = ok && fout.good();
     rsq_sim_free(sim);
     rsq_profile_free(prof);
     if (!ok) {

@@ -22,6 +22,7 @@
 #include "rsq_fasta.h"
 #include "rsq_pack.h"
 #include "rsq_spec.h"
+#include "rsq_textio.h"
 
 namespace rsq {
 
@@ -68,6 +69,10 @@ class DevBuf {
     void *p_ = nullptr;
     size_t bytes_ = 0;
 };
+
+}  // namespace rsq
+#include "rsq_s2i.h"
+namespace rsq {
 
 struct Timer {                                     // HIP events on the stream the kernels are launched on; a call may time several launches (sub-ranges)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1667,13 +1672,15 @@ int rsq_sim_job_free(rsq_sim *s) {
     });
 }
 int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file) {
-    REQUIRE(s && r1_path && r2_path, "null argument");
+    REQUIRE(s && r1_path, "null argument");
     return guard([&] {
         const rsq_sim::JobText &job = s->job;
         if (!job.complete) {
             g_last_error = "rsq_sim_job_write: there is no generated text (rsq_sim_job_generate has not run to its end on this simulator, or rsq_sim_job_free has released it)";
             return (int)RSQ_ESTATE;
         }
+        if (!r2_path && job.bytes[1]) throw Error("rsq_sim_job_write: the job has text for a second file, but no second path was given");
+        const int n_files = r2_path ? 2 : 1;                  // one file: the text of seqToIllumina records kept by rsq_sim_error_model_file
         const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 1u;
         const char *paths[2] = {r1_path, r2_path};
         const uint64_t offsets[2] = {r1_offset, r2_offset};
@@ -1681,7 +1688,7 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
         // Buffered pwrite()s into ONE file take the inode's lock one after the other, so more threads per file do not help on tmpfs or ext4 (measured on /dev/shm, 23 GB:
         // 1 thread per file 12.9 GB/s, 4 threads 7.5, 8 threads 7.2); copying into a shared mapping of the pre-sized file avoids that lock but pays a page fault per
         // 4 KB (6.4 GB/s however many threads) -- profiles/r03_e_*.  One thread per file is the default; file systems with concurrent direct I/O may want more.
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < n_files; ++f) {
             fds[f] = open(paths[f], O_WRONLY | O_CREAT, 0644);
             if (fds[f] < 0) {
                 if (f) close(fds[0]);
@@ -1702,7 +1709,7 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
         constexpr uint64_t kDirectAlign = 4096;
         int direct_fds[2] = {-1, -1};
         if (options().job_write_direct)
-            for (int f = 0; f < 2; ++f) direct_fds[f] = open(paths[f], O_WRONLY | O_DIRECT);
+            for (int f = 0; f < n_files; ++f) direct_fds[f] = open(paths[f], O_WRONLY | O_DIRECT);
         // thread t of file f writes bytes [bytes * t / T, bytes * (t + 1) / T) of the file's text: pieces of at most 32 MB, the copy of one overlapping the write of the one before
         auto work = [&](int f, uint32_t t) {
             try {
@@ -1777,10 +1784,10 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
             }
         };
         std::vector<std::thread> pool;
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < n_files; ++f)
             for (uint32_t t = 0; t < T; ++t) pool.emplace_back(work, f, t);
         for (std::thread &t : pool) t.join();
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < n_files; ++f) {
             if (direct_fds[f] >= 0) close(direct_fds[f]);
             if (close(fds[f]) != 0) fail(std::string("closing '") + paths[f] + "' failed: " + strerror(errno));
         }
@@ -2034,6 +2041,153 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
         const RawLayout raw = error_model_fill(s, first_index, n, longest, w.fa_seqs.as<uint8_t>(), w.fa_seg.as<uint8_t>(), w.fa_frag_len.as<uint32_t>(), w.fa_dom.as<uint8_t>(),
                                                w.fa_rate.as<uint8_t>(), st, w.fa_at.as<uint32_t>(), w.fa_len.as<uint32_t>(), (uint32_t)text_len + 8u, false);
         return error_model_text(s, raw, n, RecordIds{text_dev, nullptr, w.fa_at.as<uint32_t>(), w.fa_id_len.as<uint32_t>()}, out_dev, out_cap, out_len, st);
+    });
+}
+
+int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *output_path, const rsq_error_model_file_options *options, uint64_t *n_records,
+                             uint64_t *out_bytes) {
+    REQUIRE(s && s->prepared, "simulator not prepared");
+    REQUIRE(n_records && out_bytes, "null argument");
+    *n_records = 0;
+    *out_bytes = 0;
+    return guard([&] {
+        using namespace s2i;
+        const auto t_start = Clock::now();
+        rsq_error_model_file_options opt{};
+        if (options) opt = *options;
+        HIP_CHECK(hipSetDevice(s->device));
+        const unsigned hw = std::thread::hardware_concurrency();
+        // reader threads of a plain file: one copies 6-9 GB/s out of the page cache
+        const uint32_t n_readers = opt.read_threads ? opt.read_threads : std::max(1u, std::min(hw > 3 ? hw - 3 : 1u, 6u));
+        const size_t block_bytes = (size_t)std::min<uint32_t>(1u << 20, opt.block_kb ? opt.block_kb : 48u << 10) << 10;
+        uint32_t batch_blocks = opt.batch_blocks ? opt.batch_blocks : 8u;
+        while (batch_blocks > 1 && batch_blocks * block_bytes > ((size_t)3 << 30)) --batch_blocks;      // a call takes less than 4 GB of text
+        uint64_t plain_size = 0;
+        FileDescriptor plain;
+        SequentialIn seq_in;
+        if (input_path) plain.fd = open_plain_file(input_path, plain_size);
+        if (plain.fd < 0) {
+            if (opt.from || opt.to) throw Error("a byte range needs an input file that can be read at offsets (not compressed, not a pipe)");
+            if (!seq_in.open(input_path)) {
+                g_last_error = std::string("Could not open '") + input_path + "' for reading.";
+                return (int)RSQ_EIO;
+            }
+        }
+        const uint64_t to = std::min(opt.to ? opt.to : plain_size, plain_size), from = std::min(opt.from, to);
+        Fault fault;
+        OutPipe out(s->device, fault);
+        rsq_sim::JobText &job = s->job;
+        if (opt.keep_text) {                                  // the text stays in device memory, as rsq_sim_job_generate keeps a rank's share of the pairs' text
+            if (output_path) throw Error("keep_text and an output path exclude each other");
+            job.clear();
+        } else if (!out.open(output_path)) {
+            g_last_error = std::string("Could not open '") + output_path + "' for writing.";
+            return (int)RSQ_EIO;
+        }
+        auto room = [&] { return job.chunks[0].empty() ? (size_t)0 : job.chunks[0].back()->bytes() - job.used[0].back(); };
+        auto new_chunk = [&](size_t bytes) {
+            job.chunks[0].push_back(std::make_unique<DevBuf>());
+            job.chunks[0].back()->reserve(std::max<size_t>(bytes, (size_t)256 << 20));
+            job.used[0].push_back(0);
+        };
+        InPipe in(s->device, block_bytes, plain.fd >= 0 ? n_readers : 1, fault);
+        if (plain.fd >= 0) in.start_file(plain.fd, from, to, n_readers);
+        else in.start_stream(seq_in);
+        CopyStream st;
+        DevBuf joined[2];                                     // the text of a call: what the call before left over (it lies in the other one), then the blocks
+        int next_joined = 0;
+        const char *rest = nullptr;                           // the start of a record whose end the next block holds
+        size_t rest_len = 0;
+        uint64_t records = 0, next_report = 0, calls = 0;
+        StageTime t_wait, t_join, t_call;
+        double at_first_block = 0;
+        int rc = RSQ_OK;
+        bool last = false;
+        for (uint64_t b = 0; rc == RSQ_OK && !last;) {
+            auto t0 = Clock::now();
+            InPipe::Slot *slot = in.take(b);
+            t_wait.add(t0);
+            if (!slot) break;                                 // a side has failed: `fault` says why
+            if (!b) at_first_block = seconds_since(t_start);
+            t0 = Clock::now();
+            DevBuf &j = joined[next_joined];
+            next_joined ^= 1;
+            j.reserve(rest_len + batch_blocks * block_bytes + 16);
+            char *text = j.as<char>();
+            st.copy(text, rest, rest_len, hipMemcpyDeviceToDevice);
+            size_t len = rest_len;
+            for (uint32_t k = 0; slot; ++k) {
+                st.copy(text + len, slot->dev.as<char>(), slot->len, hipMemcpyDeviceToDevice);
+                len += slot->len;
+                last = slot->last;
+                in.release(b++);
+                slot = last || k + 1 == batch_blocks ? nullptr : in.take(b, false);
+            }
+            t_join.add(t0);
+            t0 = Clock::now();
+            DevBuf *o = opt.keep_text ? nullptr : out.begin();
+            if (!o && !opt.keep_text) break;
+            size_t out_len = 0, used = 0;
+            uint64_t n = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const size_t want = std::max(out_len + out_len / 8, len + len / 8) + 4096;
+                char *dst;
+                size_t cap;
+                if (opt.keep_text) {
+                    if (room() < (attempt ? out_len : want)) new_chunk(want);
+                    dst = job.chunks[0].back()->as<char>() + job.used[0].back();
+                    cap = room();
+                } else {
+                    o->reserve(want);
+                    dst = o->as<char>();
+                    cap = o->bytes();
+                }
+                rc = rsq_sim_error_model_fasta(s, opt.first_record + records, text, len, last ? 1 : 0, dst, cap, &out_len, &n, &used, st.st);
+                if (rc != RSQ_ENOSPC) break;
+            }
+            t_call.add(t0);
+            if (rc != RSQ_OK) break;                          // g_last_error holds the reason (the reference's complaint about a record: RSQ_EIO)
+            ++calls;
+            if (opt.keep_text) {
+                job.used[0].back() += out_len;
+                job.bytes[0] += out_len;
+            } else if (out_len) out.submit(out_len);
+            records += n;                                     // first_record + records = the index of the next record in the input (it selects the records' random streams)
+            rest = text + used;
+            rest_len = len - used;
+            if (opt.progress && records >= next_report) {
+                opt.progress(records, opt.user);
+                next_report = records + 1000000;
+            }
+        }
+        const double t_loop = seconds_since(t_start);
+        if (rc != RSQ_OK) fault.raise(g_last_error);
+        in.join();
+        out.close();
+        if (opt.trace && opt.trace_cap)
+            snprintf(opt.trace, opt.trace_cap,
+                     "first block on the device %.3f s into the call; the simulator side took %.3f s for %llu records in %llu calls: waiting for blocks %.3f, putting blocks together "
+                     "%.3f, device calls %.3f (of these waiting for a free output buffer %.3f); readers (summed over %u threads): reading %.3f, uploads %.3f, waiting for a slot %.3f; "
+                     "downloads %.3f (+ %.3f waiting for a free buffer); writing %.3f",
+                     at_first_block, t_loop, (unsigned long long)records, (unsigned long long)calls, t_wait.s(), t_join.s(), t_call.s(), out.t_dev.s(), (unsigned)in.readers.size(),
+                     in.t_read.s(), in.t_upload.s(), in.t_slot.s(), out.t_download.s(), out.t_stage.s(), out.t_write.s());
+        if (fault.set) {
+            if (opt.keep_text) job.clear();
+            g_last_error = fault.what;
+            return rc != RSQ_OK ? rc : (int)RSQ_EIO;
+        }
+        *n_records = records;
+        *out_bytes = opt.keep_text ? job.bytes[0] : out.bytes;
+        job.complete = opt.keep_text != 0;
+        return (int)RSQ_OK;
+    });
+}
+
+int rsq_fasta_count_records(const char *path, uint64_t from, uint64_t to, uint32_t threads, uint64_t *n_starts, uint64_t *first_start) {
+    REQUIRE(path && n_starts && first_start, "null argument");
+    return guard([&] {
+        s2i::count_records(path, from, to, threads, n_starts, first_start);
+        return (int)RSQ_OK;
     });
 }
 

@@ -70,6 +70,29 @@ def gather_sizes(dist, device, mine: Sequence[int], world: int) -> List[List[int
     return [[int(v) for v in row.tolist()] for row in out]
 
 
+def record_stretch(size: int, rank: int, world: int) -> Tuple[int, int]:
+    """seqToIllumina over several ranks ("shards by input record ranges"): the bytes of the input file in which rank `rank` counts record starts"""
+    return size * rank // world, size * (rank + 1) // world
+
+
+def record_share(counts: Sequence[Sequence[int]], size: int, rank: int) -> Tuple[int, int, int]:
+    """counts[r] = (record starts in rank r's stretch, offset of the first of them).  A record belongs to the rank in whose stretch it starts, wherever it ends:
+    returns the rank's bytes [begin, end) of the file -- from its first record's start to the first record start of the next rank that has one (the file's end if
+    none) -- and the index in the whole input of its first record (it selects the records' random streams, so the ranks' output is the single run's).  The first
+    rank begins at byte 0: what stands in front of the first record is its to complain about.  A rank without a record start has an empty share."""
+    first_record = sum(int(row[0]) for row in counts[:rank])
+    end = size
+    for n, first in counts[rank + 1:]:
+        if n:
+            end = int(first)
+            break
+    if rank == 0:
+        return 0, end, 0
+    if not counts[rank][0]:
+        return end, end, first_record
+    return int(counts[rank][1]), end, first_record
+
+
 def block_weights(seq_len, insert_to, ref_seq_bias):
     """Expected pairs per block up to a constant: the sequence's reference bias (blocks of a sequence share it); sequences
     shorter than the longest insert have no blocks (Simulator.cpp:1159)."""

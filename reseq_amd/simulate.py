@@ -277,7 +277,114 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     return int(total_pairs) + info["adapter_only_pairs"], elapsed
 
 
+def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cpu", split_output=False, count=None, **pipeline):
+    """`seqToIllumina` over several ranks (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014; SURVEY section 8(e): shards by input record ranges).
+    Every rank counts the record starts in its stretch of the (plain) input file (`count`: api.count_fasta_records, host code), one all-gather of the two numbers
+    tells it which bytes are its records and what the index of its first record is; it runs them through the library's pipeline with the text kept in device
+    memory (`sim.error_model_file(..., keep_text=True)`), and after one all-gather of the text sizes writes it at its offset of the one output file
+    (`sim.job_write`) -- or, split_output, into its own part file.  The output is byte for byte the single run's: a record's random stream is selected by its
+    index in the input.  Returns (records of the whole job, seconds on the slowest rank)."""
+    def counted():
+        size = os.path.getsize(input_path)
+        lo, hi = sharding.record_stretch(size, rank, world)
+        return size, count(input_path, lo, hi) if hi > lo else (0, hi)
+    got, error = _attempt(counted)
+    _agree(dist, device, error, "counting the records of its stretch of the input")
+    size, (n_starts, first_start) = got
+    counts = sharding.gather_sizes(dist, device, [n_starts, first_start], world)
+    begin, end, first_record = sharding.record_share(counts, size, rank)
+    t0 = time.perf_counter()
+
+    def simulated():
+        if end <= begin and rank:                                    # no record starts in this rank's stretch
+            return 0, 0
+        return sim.error_model_file(input_path, None, from_=begin, to=end, first_record=first_record, keep_text=True, **pipeline)[:2]
+    got, error = _attempt(simulated)
+    _agree(dist, device, error, "simulating its records")
+    records, nbytes = got
+    total_records, _, elapsed = sharding.job_totals(dist, device, records, nbytes, time.perf_counter() - t0)
+    if not nbytes:                                                   # nothing kept (an empty share): nothing to write either
+        write = lambda path, offset: None
+    else:
+        write = lambda path, offset: sim.job_write(path, offset, None, 0)
+    if split_output:
+        part = part_name(output_path, rank, world)
+
+        def write_part():
+            open(part, "wb").close()
+            write(part, 0)
+        _agree(dist, device, _attempt(write_part)[1], "writing its part")
+        return int(total_records), elapsed
+    sizes = sharding.gather_sizes(dist, device, [nbytes], world)
+
+    def create_file():
+        if rank == 0:
+            with open(output_path, "wb") as f:
+                f.truncate(sum(row[0] for row in sizes))
+    _agree(dist, device, _attempt(create_file)[1], "creating the output file")
+    _agree(dist, device, _attempt(write, output_path, sum(row[0] for row in sizes[:rank]))[1], "writing its byte range")
+    if nbytes:
+        sim.job_free()
+    return int(total_records), elapsed
+
+
+def main_records(argv):
+    """python -m reseq_amd.simulate seqToIllumina -i in.fa -o out.fq -s profile [--seed N] [--splitOutput]: `reseq seqToIllumina` over the GPUs of a host"""
+    ap = argparse.ArgumentParser(prog="reseq_amd.simulate seqToIllumina", description=main_records.__doc__)
+    ap.add_argument("-i", "--input", required=True, help="FASTA records with the systematic errors in their id lines; a plain file (ranks read it at offsets)")
+    ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("-s", "--statsIn", dest="profile", required=True)
+    ap.add_argument("-p", "--probabilitiesIn", dest="ipf", default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own file <out>.part<k>of<N> (their concatenation in order is the single file)")
+    a = ap.parse_args(argv)
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if a.output.endswith((".gz", ".bz2")):
+        ap.error(f"{a.output}: compressed output is not supported by the multi-GPU launcher (write plain FASTQ and compress afterwards)")
+    import torch
+    from . import api
+    dist = None
+    if "WORLD_SIZE" in os.environ:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = f"cuda:{local_rank}"
+    seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
+    if dist is not None:                                             # one seed for the whole job, all 64 bits of it
+        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
+        dist.broadcast(t, 0)
+        seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
+    prof = sim = None
+    try:
+        def set_up():
+            p = api.load_profile(a.profile, a.ipf)
+            s = api.Simulator(p, None, local_rank)
+            s.prepare(seed)
+            return p, s
+        got, error = _attempt(set_up)
+        _agree(dist, device, error, "setting up its simulator")
+        prof, sim = got
+        records, seconds = run_records_rank(sim, dist, rank, world, a.input, a.output, device, a.splitOutput, count=api.count_fasta_records)
+        if rank == 0:
+            if not records:
+                print(f"!!! Error: {a.input} does not contain any sequences.", file=sys.stderr)
+                if not a.splitOutput:
+                    os.remove(a.output)
+                sys.exit(1)
+            print(f">>> Info: Generated {records} reads on {world} GPU(s), {seconds:.2f} s on the slowest rank", file=sys.stderr)
+    finally:
+        if sim is not None:
+            sim.close()
+        if prof is not None:
+            prof.close()
+        if dist is not None:
+            dist.destroy_process_group()
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if argv and argv[0] in ("seqToIllumina", "replaceQuals"):
+        return main_records(argv[1:])
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("-R", "--refSim", "-r", "--refIn", dest="ref", required=True)
     ap.add_argument("-s", "--statsIn", dest="profile", required=True)

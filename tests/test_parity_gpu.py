@@ -446,6 +446,70 @@ def test_simulate_module_equals_cli(workdir):
     assert open(a1, "rb").read() == open(c1, "rb").read() and open(a2, "rb").read() == open(c2, "rb").read()
 
 
+def test_seq_to_illumina_in_shares_equals_the_single_run(workdir):
+    """seqToIllumina over several GPUs (shards by input record ranges), the ranks one after the other on this GPU: rsq_fasta_count_records per
+    stretch of the file, sharding.record_share, rsq_sim_error_model_file with keep_text on the share, rsq_sim_job_write at the offset -- the bytes of
+    `reseq seqToIllumina`; the launcher itself (python -m reseq_amd.simulate seqToIllumina) with one rank, over RCCL; a malformed record in a share"""
+    import os
+    import subprocess
+    import sys
+    from reseq_amd import api, sharding, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "reseq_amd", "reseq")
+    ppath, _, _ = P.make_inputs(workdir, "s2i_shares", synth.TINY, [100])
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    parts = [synth.make_error_model_input(31, 900, 30, arrays, zero_frac=0.6), synth.make_error_model_input(32, 80, 75, arrays, zero_frac=0.5)]
+    text = b"".join(P.fasta_of_records(rec, [f"read {k}/{i} x" if i % 5 == 0 else f"r{k}_{i}" for i in range(len(rec["seg"]))], wrap_every=4) for k, rec in enumerate(parts))
+    inp, single = workdir / "shares.fa", workdir / "single.fq"
+    inp.write_bytes(text)
+    subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(single), "-s", ppath, "--seed", "21"], check=True, capture_output=True)
+    want = single.read_bytes()
+    assert want.count(b"\n") == 4 * 980
+    prof = api.Profile(ppath)
+    sim = api.Simulator(prof, None, 0)
+    sim.prepare(21)
+    try:
+        # the whole file through the library call, to a file and kept
+        whole = workdir / "whole.fq"
+        n, nbytes, trace = sim.error_model_file(inp, whole, block_kb=8, batch_blocks=2, read_threads=3, trace=True)
+        assert (n, nbytes) == (980, len(want)) and whole.read_bytes() == want and "device calls" in trace
+        for world in (2, 3, 7):
+            counts = []
+            for r in range(world):
+                lo, hi = sharding.record_stretch(len(text), r, world)
+                counts.append(api.count_fasta_records(inp, lo, hi))
+            out = workdir / f"shares{world}.fq"
+            out.write_bytes(b"")
+            offset, records = 0, 0
+            for r in range(world):
+                begin, end, first = sharding.record_share(counts, len(text), r)
+                assert first == records
+                if end <= begin:
+                    continue
+                n, nbytes = sim.error_model_file(inp, None, from_=begin, to=end, first_record=first, keep_text=True, block_kb=16)
+                sim.job_write(out, offset, None, 0)
+                sim.job_free()
+                offset += nbytes
+                records += n
+            assert records == 980 and out.read_bytes() == want, world
+        with pytest.raises(Exception, match="no generated text"):
+            sim.job_write(workdir / "nothing.fq", 0, None, 0)
+        bad = workdir / "bad.fa"
+        bad.write_bytes(text + b">r 3;40;NNNN;!!!!\nACGT\n")
+        with pytest.raises(Exception, match="Template segment is 3 not 1 or 2"):
+            sim.error_model_file(bad, None, keep_text=True)
+        with pytest.raises(Exception, match="no generated text"):         # a failed run keeps nothing
+            sim.job_write(workdir / "nothing.fq", 0, None, 0)
+    finally:
+        sim.close()
+        prof.close()
+    env = dict(os.environ, PYTHONPATH=root, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    launched = workdir / "launched.fq"
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate", "seqToIllumina", "-i", str(inp), "-o", str(launched), "-s", ppath, "--seed", "21"], check=True, capture_output=True,
+                   env=env, cwd=root)
+    assert launched.read_bytes() == want
+
+
 def test_sharded_pre_passes(workdir):
     P.case_sharded_prepare(GpuBackend, workdir)
 
