@@ -194,6 +194,24 @@ struct TextOut {
     bool good() const { return !failed && !w.failed; }
     void close() { failed = !w.close() || failed; }
 };
+using Clock = std::chrono::steady_clock;
+const Clock::time_point g_process_start = Clock::now();
+double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+// --traceStages: seconds of the process at which a stage was reached
+struct StageTrace {
+    bool on = false;
+    std::string line;
+    void at(const char *what) {
+        if (!on) return;
+        char b[96];
+        snprintf(b, sizeof b, "%s%s %.3f", line.empty() ? "" : ", ", what, seconds_since(g_process_start));
+        line += b;
+    }
+    ~StageTrace() {
+        if (on) fprintf(stderr, "stages (seconds of the process): %s\n", line.c_str());
+    }
+};
+
 struct DevBuffer {
     void *p = nullptr;
     size_t cap = 0;
@@ -245,8 +263,12 @@ struct AsyncOut {
     // copies `bytes` of device text through the staging buffers, a chunk at a time, and queues the chunks
     static constexpr size_t kChunk = 64u << 20;
     bool push(const DevBuffer &d, size_t bytes) {
-        for (size_t done = 0; done < bytes; done += kChunk) {
-            const size_t n = std::min(kChunk, bytes - done);
+        for (size_t done = 0; done < bytes; done += kChunk)
+            if (!push_chunk(d, done, std::min(kChunk, bytes - done))) return false;
+        return out.good();
+    }
+    bool push_chunk(const DevBuffer &d, size_t done, size_t n) {
+        {
             int k;
             {
                 std::unique_lock<std::mutex> lock(m);
@@ -287,7 +309,15 @@ struct AsyncOut {
     bool good() const { return out.good(); }
 };
 
-bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, AsyncOut &f1, AsyncOut &f2) { return f1.push(d1, l1) && f2.push(d2, l2); }
+// the two files chunk by chunk in turn: while this thread waits for a free buffer of one file, the other file's writer has work (a file in /dev/shm takes 6 GB/s,
+// whoever writes it: one file after the other would halve the rate)
+bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, AsyncOut &f1, AsyncOut &f2) {
+    for (size_t done = 0; done < std::max(l1, l2); done += AsyncOut::kChunk) {
+        if (done < l1 && !f1.push_chunk(d1, done, std::min(AsyncOut::kChunk, l1 - done))) return false;
+        if (done < l2 && !f2.push_chunk(d2, done, std::min(AsyncOut::kChunk, l2 - done))) return false;
+    }
+    return f1.good() && f2.good();
+}
 
 int illumina_pe(const Args &a) {
     const std::string vcf_path = a.get("vcfSim", "");               // -V: per-allele simulation (substitutions; the library refuses what it cannot simulate yet)
@@ -328,17 +358,22 @@ int illumina_pe(const Args &a) {
     rsq_profile *prof = nullptr;
     rsq_ref *ref = nullptr;
     rsq_sim *sim = nullptr;
+    StageTrace trace;
+    trace.on = a.has("traceStages");
     bool ok = load_profile(a, &prof);
+    trace.at("profile loaded");
     const uint64_t seed = ok ? get_seed(a) : 0;
     if (ok) {
         INFO("Reading reference from " << ref_path);
         ok = check(rsq_ref_load_fasta(ref_path.c_str(), &ref), "Could not load reference") && check(rsq_ref_replace_n(ref, seed), "ReplaceN");
+        trace.at("reference read");
     }
     if (ok && !vcf_path.empty()) {
         INFO("Reading variants from " << vcf_path);
         ok = check(rsq_ref_read_variants(ref, vcf_path.c_str()), "Could not read the variant file");
     }
     ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
+    trace.at("simulator created");
     if (ok && !sys_write.empty()) {
         INFO("Writing systematic error profile to " << sys_write);
         ok = check(rsq_sim_create_sys_error_profile(sim, seed, sys_write.c_str(), nullptr), "Could not write systematic error profile");
@@ -369,6 +404,7 @@ int illumina_pe(const Args &a) {
         ok = check(rsq_sim_prepare(sim, seed, num_reads, coverage, ref_bias_mode, a.get("recordBaseIdentifier", "ReseqRead").c_str(), nullptr), "Preparation failed");
     }
     if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
+    trace.at("prepared");
     AsyncOut f1, f2;
     if (ok) {
         const bool o1 = f1.open(out1), o2 = f2.open(out2);
@@ -411,12 +447,15 @@ int illumina_pe(const Args &a) {
             ok = ok && check(rc, "Simulation of adapter-only pairs failed") && flush_pair(d1, l1, d2, l2, f1, f2);
         }
     }
+    trace.at("last text handed to the writers");
     f1.close();
     f2.close();
+    trace.at("files closed");
     ok = ok && f1.good() && f2.good();
     rsq_sim_free(sim);
     rsq_ref_free(ref);
     rsq_profile_free(prof);
+    trace.at("simulator released");
     if (!ok) {                                               // Simulator.cpp:2888-2892: do not leave partial output behind
         ERR("An error occurred in the process: Terminating simulation");
         remove(out1.c_str());
@@ -426,10 +465,6 @@ int illumina_pe(const Args &a) {
     INFO("Simulation finished succesfully");
     return 0;
 }
-
-using Clock = std::chrono::steady_clock;
-const Clock::time_point g_process_start = Clock::now();
-double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
 // ---- seqToIllumina (main.cpp:1009-1021, 1131; Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014): the library's file-to-file pipeline
 // (rsq_sim_error_model_file: readers at file offsets, the FASTA text parsed on the device, ordered output) with the reference's options and messages

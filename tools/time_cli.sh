@@ -9,6 +9,6 @@ synth.write_profile('/dev/shm/p0.rsqp', synth.make_profile(synth.P0, seed=103741
 synth.write_fasta('/dev/shm/ecoli.fa', synth.make_reference(2, [4641652], gc=0.508))
 PY
 for i in 1 2; do
-  s=$(date +%s%N); reseq_amd/reseq illuminaPE -R /dev/shm/ecoli.fa -s /dev/shm/p0.rsqp -1 /dev/shm/r1.fq -2 /dev/shm/r2.fq --numReads 10000000 --seed 11 2>&1 | tail -2; echo "wall $(( ($(date +%s%N) - s) / 1000000 )) ms"
+  s=$(date +%s%N); reseq_amd/reseq illuminaPE -R /dev/shm/ecoli.fa -s /dev/shm/p0.rsqp -1 /dev/shm/r1.fq -2 /dev/shm/r2.fq --numReads 10000000 --seed 11 --traceStages 2>&1 | tail -3; echo "wall $(( ($(date +%s%N) - s) / 1000000 )) ms"
 done
 ls -la /dev/shm/r1.fq /dev/shm/r2.fq; rm -f /dev/shm/r1.fq /dev/shm/r2.fq /dev/shm/ecoli.fa /dev/shm/p0.rsqp
