@@ -567,21 +567,22 @@ class Simulator:
             for d in ins + ([text] if text else []):
                 d.free()
 
-    def error_model_fasta(self, text, first_index=0, final=True, stream=None):
+    def error_model_fasta(self, text, first_index=0, final=True, stream=None, skew=0):
         """seqToIllumina's FASTA text parsed on the device (rsq_sim_error_model_fasta; Simulator.cpp:2403-2512): text = bytes of the input file from a record's
         '>' on.  Returns (FASTQ text, records written, bytes consumed); final=False leaves the block's last record to the caller (hand text[consumed:] in
         again in front of what follows).  A malformed record raises with the reference's message."""
         dev = self.device
-        src = DeviceArray.from_numpy(dev, np.frombuffer(bytes(text) + b"\0" * 8, np.uint8))
+        src = DeviceArray.from_numpy(dev, np.frombuffer(b"\n" * skew + bytes(text) + b"\0" * 8, np.uint8))      # skew: the text begins that many bytes into the allocation
+        text_ptr = C.c_void_p(src.ptr.value + skew)
         need, n, used = C.c_size_t(0), _u64(0), C.c_size_t(0)
         out = None
         try:
-            rc = lib().rsq_sim_error_model_fasta(self.h, first_index, src.ptr, len(text), 1 if final else 0, None, 0, C.byref(need), C.byref(n), C.byref(used), stream)
+            rc = lib().rsq_sim_error_model_fasta(self.h, first_index, text_ptr, len(text), 1 if final else 0, None, 0, C.byref(need), C.byref(n), C.byref(used), stream)
             if rc != RSQ_ENOSPC:
                 _check(rc)
                 return b"", n.value, used.value
             out = DeviceArray(dev, need.value + 16)
-            _check(lib().rsq_sim_error_model_fasta(self.h, first_index, src.ptr, len(text), 1 if final else 0, out.ptr, need.value + 16, C.byref(need), C.byref(n),
+            _check(lib().rsq_sim_error_model_fasta(self.h, first_index, text_ptr, len(text), 1 if final else 0, out.ptr, need.value + 16, C.byref(need), C.byref(n),
                                                    C.byref(used), stream))
             return out.to_numpy(np.uint8, need.value).tobytes(), n.value, used.value
         finally:

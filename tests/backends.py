@@ -345,8 +345,8 @@ class GpuBackend:
     def error_model_fastq(self, rec, ids, first_index=0):
         return self.sim.error_model_fastq(rec, ids, first_index)
 
-    def error_model_fasta(self, text, first_index=0, final=True):
-        return self.sim.error_model_fasta(text, first_index, final)
+    def error_model_fasta(self, text, first_index=0, final=True, skew=0):
+        return self.sim.error_model_fasta(text, first_index, final, skew=skew)
 
     # the pre-pass of one rank of a sharded job
     def prepare_plan(self, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier=""):

@@ -467,6 +467,8 @@ def _error_model_fasta(b, oprof, seed, rec):
     assert (k, used) == (n, len(text))
     assert got == want
     assert b.error_model_fasta(fasta_of_records(rec, ids, wrap_every=2, line_end="\r\n"), first_index=17)[0] == want
+    for skew in (1, 7, 9):                                   # text that does not begin on a 16-byte boundary of device memory (the record kernel stages whole 16-byte words)
+        assert b.error_model_fasta(text, first_index=17, skew=skew)[0] == want, skew
     # in blocks that end anywhere: what the call leaves over goes in front of the next block
     for block in (len(text) // 3 + 1, 4096):
         out, first, rest, pos = [], 17, b"", 0
@@ -487,6 +489,12 @@ def case_error_model_tiny(backend_cls, workdir):
     exp = _error_model(backend_cls, workdir, "em_tiny", synth.TINY, 400, 30, seed=13, prof_seed=5, zero_frac=0.7)
     assert len({e[4] for e in exp}) == 3                      # all three tiles drawn
     assert any("D" in e[2] for e in exp) and any("I" in e[2] for e in exp)
+
+
+def case_error_model_templates_beyond_the_staging(backend_cls, workdir):
+    """records of 1.2 KB and 3 KB: the 256 records of a workgroup of k_fasta_records no longer fit the 144 KB of LDS their text is staged in, the lanes read HBM"""
+    _error_model(backend_cls, workdir, "em_tiny", synth.TINY, 700, 400, seed=3, prof_seed=5, zero_frac=0.5)
+    _error_model(backend_cls, workdir, "em_tiny", synth.TINY, 300, 1000, seed=4, prof_seed=5, zero_frac=0.8)
 
 
 def case_error_model_long_templates(backend_cls, workdir):

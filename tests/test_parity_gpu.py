@@ -86,6 +86,73 @@ def test_error_model_long_templates(workdir):
     P.case_error_model_long_templates(GpuBackend, workdir)
 
 
+def test_error_model_templates_beyond_the_staging(workdir):
+    P.case_error_model_templates_beyond_the_staging(GpuBackend, workdir)
+
+
+def test_error_model_fasta_on_damaged_files(workdir):
+    """rsq_sim_error_model_fasta on files damaged at random (bytes replaced, dropped, inserted): the reference's complaint about the first malformed record as the
+    restatement in tests/test_fasta_records.py expects it -- or, if the file is still well-formed, the text of rsq_sim_error_model_fastq on the fields that
+    restatement reads (runs of equal template length; that entry point is pinned to the oracle by the cases above)"""
+    import os
+    import random
+    import numpy as np
+    import test_fasta_records as F
+    from reseq_amd import synth
+    ppath, _, _ = P.make_inputs(workdir, "em_tiny", synth.TINY, [100], prof_seed=5)
+    b = GpuBackend(ppath, None)
+    b.prepare(19)
+    words = {1: "too short to contain", 2: "not separated by a semicolon from themselves", 3: "No sequence id found", 4: "not 1 or 2", 5: "template segment and fragment length are not separated",
+             6: "is not a pure integer", 7: "must not contain N"}
+    rng = random.Random(77)
+    base = [F.fasta_text(11, 300, 20, wrap=6), F.fasta_text(12, 90, 33, crlf=True), F.fasta_text(13, 600, 8), F.fasta_text(14, 40, 330)]
+    seen, well_formed = set(), 0
+    try:
+        for r in range(int(os.environ.get("RSQ_FUZZ", "1")) * 120):
+            text = bytearray(base[r % 4])
+            for _ in range(rng.randint(0, 2)):
+                at = rng.randrange(len(text))
+                what, c = rng.random(), rng.choice(b";; >>\n\r12ACGTN!x0")
+                if what < 0.5:
+                    text[at] = c
+                elif what < 0.75:
+                    del text[at]
+                else:
+                    text.insert(at, c)
+            text = bytes(text)
+            n, _consumed, lead, bad, fields = F.expect(text)
+            if lead or bad:
+                with pytest.raises(Exception) as e:
+                    b.error_model_fasta(text, first_index=5)
+                assert ("without a header" if lead else words[bad[1]]) in str(e.value), (r, bad, str(e.value))
+                seen.add("lead" if lead else bad[1])
+                continue
+            recs, _ = F.records_of(text)
+            got, k, used = b.error_model_fasta(text, first_index=5)
+            assert (k, used) == (n, len(text))
+            want, i = [], 0
+            while i < n:                                      # runs of one template length
+                j = i
+                while j < n and len(fields[j]["seqs"]) == len(fields[i]["seqs"]):
+                    j += 1
+                L = len(fields[i]["seqs"])
+                if L:
+                    rec = {key: np.stack([fields[q][key] for q in range(i, j)]) for key in ("seqs", "dom", "rate")}
+                    rec["seg"] = np.array([fields[q]["seg"] for q in range(i, j)], np.uint8)
+                    rec["frag_len"] = np.array([fields[q]["frag_len"] for q in range(i, j)], np.uint32)
+                    want.append(b.error_model_fastq(rec, [recs[q][1][:fields[q]["id_len"]] for q in range(i, j)], first_index=5 + i))
+                else:
+                    want = None                               # a record without bases: the array entry point has no shape for it
+                    break
+                i = j
+            if want is not None:
+                assert got == b"".join(want), r
+                well_formed += 1
+    finally:
+        b.close()
+    assert len(seen) >= 5 and well_formed >= 20, (seen, well_formed)
+
+
 def test_error_model_p0(workdir):
     P.case_error_model_p0(GpuBackend, workdir)
 
