@@ -274,7 +274,9 @@ int rsq_sim_error_model_fastq(rsq_sim *s, uint64_t first_index, uint64_t n, uint
  * again in front of the text that follows (no record starts in the block: *consumed = 0, *n_records = 0 -- hand in more).  final = 1: the block ends the input,
  * *consumed = text_len.  The records' FASTQ text goes to out_dev in input order exactly as rsq_sim_error_model_fastq writes it (*out_len bytes; RSQ_ENOSPC and
  * nothing written if out_cap is smaller), *n_records = their number; first_index = the index in the input of the block's first record.
- * A malformed record -- the first in input order -- ends the call with RSQ_EIO and the reference's message about it in rsq_last_error().
+ * A malformed record -- the first in input order -- ends the call with RSQ_EIO and the reference's message about it in rsq_last_error().  So does, in this call and
+ * in the two above, a fragment length that the profile's insert lengths / read lengths by fragment length do not hold (profiles with more than one read length look
+ * it up there, Simulator.h:185-198; the reference's Vect::at prints "Called index ... range is from ... to ..." and throws): checked on the device before anything is simulated.
  * Kernel time: "parse_records" beside the names below.  text_len < 4 GB. */
 int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text_dev, size_t text_len, int final, char *out_dev, size_t out_cap, size_t *out_len,
                               uint64_t *n_records, size_t *consumed, void *stream);

@@ -2474,6 +2474,18 @@ __global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob
     fill_records_body<MASK, BINNED>(S, job, raw, chunk_counters, bins);
 }
 #if !defined(RSQ_SPEC)
+// ReadLength (Simulator.h:185-198) looks a record's fragment length up in InsertLengths() and ReadLengthsByFragmentLength(segment) with Vect::at, which ends the
+// reference's run for a length outside ("Called index ... range is from ... to ..."): the first such record, so that the caller can say the same instead of
+// reading beyond the tables.  lo / hi per segment: the lengths that have rows in both (all of them for a profile with one read length).
+struct FragmentRange {
+    uint32_t lo[2], hi[2];
+};
+__global__ void k_fragment_range(const uint8_t *segs, const uint32_t *frag_len, uint64_t n, FragmentRange range, uint32_t *first_bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seg = segs[i] ? 1u : 0u, fl = frag_len[i];
+    if (fl < range.lo[seg] || fl >= range.hi[seg]) atomicMin(first_bad, (uint32_t)i);
+}
 // the partition: flags for the scan, then the scatter once the number of segment-1 records before every record is known
 __global__ void k_record_flags(const uint8_t *segs, uint64_t n, uint32_t *flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

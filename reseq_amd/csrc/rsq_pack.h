@@ -84,6 +84,7 @@ struct SimState {
     NameTable names{};
     uint16_t *sys_fwd = nullptr, *sys_rev = nullptr, *adapter_sys[2] = {nullptr, nullptr};   // written by the chain pre-pass
     uint32_t rmax = 0, read_stride = 0, ops_stride = 0, max_adapter = 0, template_words = 0;
+    uint64_t insert_lengths_from = 0;      // InsertLengths().from(): what Vect::at names when a seqToIllumina record's fragment length lies outside
     // prepare() results
     bool prepared = false;
     bool normalized = false;                         // the sharded pre-pass: rsq_sim_prepare_normalization has run since the plan
@@ -535,6 +536,7 @@ inline void pack_profile(SimState &s, Uploader &up) {
     std::vector<double> ocp = discrete_cp(p.overrun_bases, 4);           // Simulator.h:168: the N is dropped
     for (int i = 0; i < 4; ++i) d.overrun_cp[i] = ocp[i];
     d.insert_from = (uint32_t)std::max<uint64_t>(1, p.insert_lengths.from);       // Simulator.cpp:2300
+    s.insert_lengths_from = p.insert_lengths.from;
     if (p.insert_lengths.to() > 65536) throw Error("insert lengths above 65535 are not supported (fragment lengths are 16-bit fields of the sieve's records)");
     d.insert_to = (uint32_t)p.insert_lengths.to();
     std::vector<uint64_t> il(d.insert_to + 1, 0);

@@ -1009,6 +1009,10 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
 }  // namespace rsq
 
 // ================================================================================================= C ABI
+// (a seqToIllumina record whose fragment length the profile's tables do not hold: check_fragment_lengths)
+struct FragmentLengthOutside : rsq::Error {
+    using rsq::Error::Error;
+};
 template <class F>
 static int guard(F &&f) {
     try {
@@ -1016,6 +1020,9 @@ static int guard(F &&f) {
     } catch (const HipError &e) {
         g_last_error = e.what();
         return RSQ_EHIP;
+    } catch (const FragmentLengthOutside &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
     } catch (const Error &e) {
         g_last_error = e.what();
         return RSQ_EINVAL;
@@ -1835,6 +1842,41 @@ int rsq_sim_adapter_only_pairs(rsq_sim *s, uint64_t first, uint64_t n, char *r1_
     });
 }
 
+// A profile with several read lengths draws a record's read length from tables over the fragment length (draw_read_length): a length outside them ends the call
+// with the words of the reference's Vect::at (Vect.hpp:196-221 prints them before it throws) -- RSQ_EIO, nothing simulated
+static void check_fragment_lengths(rsq_sim *s, uint64_t n, const uint8_t *seg_dev, const uint32_t *frag_len_dev, hipStream_t st) {
+    FragmentRange range{{0u, 0u}, {0xFFFFFFFFu, 0xFFFFFFFFu}};
+    bool any = false;
+    for (int seg = 0; seg < 2; ++seg) {
+        const DevReadLengths &rl = s->dev.read_lengths[seg];
+        if (rl.fixed) continue;
+        any = true;
+        range.lo[seg] = std::max((uint32_t)s->insert_lengths_from, rl.row_first);
+        range.hi[seg] = std::min(s->dev.insert_to, rl.row_first + rl.rows);
+    }
+    if (!any) return;
+    s->cur->rec_count.reserve(16);
+    uint32_t *flag = s->cur->rec_count.as<uint32_t>() + 2;            // (words 0 and 1 are the partition's counts)
+    uint32_t *mail = reinterpret_cast<uint32_t *>(&s->mailbox[6]);
+    mail[0] = 0xFFFFFFFFu;
+    HIP_CHECK(hipMemcpyAsync(flag, mail, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fragment_range, dim3(cdiv(n, 256)), dim3(256), 0, st, seg_dev, frag_len_dev, n, range, flag);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(mail, flag, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t bad = mail[0];
+    if (bad == 0xFFFFFFFFu) return;
+    uint32_t fl = 0;
+    uint8_t seg = 0;
+    HIP_CHECK(hipMemcpy(&fl, frag_len_dev + bad, 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&seg, seg_dev + bad, 1, hipMemcpyDeviceToHost));
+    const DevReadLengths &rl = s->dev.read_lengths[seg ? 1 : 0];
+    const bool in_insert_lengths = fl >= s->insert_lengths_from && fl < s->dev.insert_to;
+    const uint64_t from = in_insert_lengths ? rl.row_first : s->insert_lengths_from, to = in_insert_lengths ? (uint64_t)rl.row_first + rl.rows : s->dev.insert_to;
+    throw FragmentLengthOutside("record " + std::to_string(bad) + " of the call: Called index " + std::to_string(fl) + " range is from " + std::to_string(from) + " to " + std::to_string(to) +
+                                " (the fragment length has no entry in the profile's " + (in_insert_lengths ? "read lengths by fragment length" : "insert lengths") + ")");
+}
+
 // the records' reads into the raw arrays: partition by template segment, k_fill_records
 // (rec_at / rec_len: records of their own lengths at their own offsets of arrays of array_bytes bytes, read_len = the longest; nullptr: n x read_len bytes)
 static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
@@ -1846,6 +1888,7 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
     if (n >= 0xFFFFFFFFull) throw Error("at most 2^32-1 records per call");
     s->cur = &s->ws[0];
     if (fresh_timers) reset_call_timers(*s);
+    check_fragment_lengths(s, n, seg_dev, frag_len_dev, st);
     RawLayout raw = raw_layout(*s, n);
     // partition the records by template segment: the read kernel's workgroups hold one segment's tables in LDS (binned by tile: build_fill_bins)
     if (!fill_is_binned(*s)) {

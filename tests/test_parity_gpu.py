@@ -96,6 +96,7 @@ def test_error_model_fasta_on_damaged_files(workdir):
     restatement reads (runs of equal template length; that entry point is pinned to the oracle by the cases above)"""
     import os
     import random
+    import re
     import numpy as np
     import test_fasta_records as F
     from reseq_amd import synth
@@ -128,7 +129,15 @@ def test_error_model_fasta_on_damaged_files(workdir):
                 seen.add("lead" if lead else bad[1])
                 continue
             recs, _ = F.records_of(text)
-            got, k, used = b.error_model_fasta(text, first_index=5)
+            try:
+                got, k, used = b.error_model_fasta(text, first_index=5)
+            except Exception as e:                        # a damaged fragment length outside the profile's tables: the words of the reference's Vect::at (Vect.hpp:196-221)
+                m = re.search(r"record (\d+) of the call: Called index (\d+) range is from (\d+) to (\d+)", str(e))
+                assert m, str(e)
+                i, fl, lo, hi = (int(v) for v in m.groups())
+                assert fields[i]["frag_len"] == fl and not lo <= fl < hi and all(lo <= f["frag_len"] < hi for f in fields[:i]), str(e)
+                seen.add("fragment length outside the profile")
+                continue
             assert (k, used) == (n, len(text))
             want, i = [], 0
             while i < n:                                      # runs of one template length
@@ -421,7 +430,9 @@ def test_cli_seq_to_illumina_equals_the_oracle(workdir):
     assert out.read_text() == got
     # the reference's complaints about malformed headers
     for bad, msg in ((">r 3;40;NNNN;!!!!\nACGT\n", "Template segment is 3"), (">r1;40;NNNN;!!!!\nACGT\n", "No sequence id found"), (">r 1;4x;NNNN;!!!!\nACGT\n", "not a pure integer"),
-                     (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short"), (">r 1;40;NNNN;!!!!\nACNT\n", "must not contain N")):
+                     (">r 1;40;NNN;!!!!\nACGT\n", "not separated by a semicolon"), (">r\nACGT\n", "too short"), (">r 1;40;NNNN;!!!!\nACNT\n", "must not contain N"),
+                     # a fragment length the profile's tables do not hold: the reference's Vect::at prints this and throws (Vect.hpp:196-221, from ReadLength, Simulator.h:185-198)
+                     (">r 1;70000;NNNN;!!!!\nACGT\n", "Called index 70000 range is from")):
         inp.write_text(bad)
         r = subprocess.run([exe, "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", ppath, "--seed", "77"], capture_output=True)
         assert r.returncode != 0 and msg.encode() in r.stderr, (bad, r.stderr)
