@@ -739,6 +739,11 @@ int emu_parse_fasta(const uint8_t *text, uint64_t text_len, int final, uint32_t 
     return 0;
 }
 
+// the library's text writer (gzip / bzip2 by the name's ending), for the tests of its compressed output
+int emu_write_text_file(const char *path, const char *data, size_t n) {
+    return guard([&] { write_text_file(path, std::string(data, n)); });
+}
+
 // single draws, for direct comparison with the oracle's Draw
 uint32_t emu_draw(void *h, int family, uint32_t index, const uint32_t *idx, double u, double *prob_sum) {
     Emu &s = *static_cast<Emu *>(h);
