@@ -233,6 +233,11 @@ typedef struct {
  * rsq_sim_job_free releases the text (rsq_sim_free does too).  A single-process run has offset 0 and may as well stream (the `reseq` command line does). */
 int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint32_t batch_blocks, uint64_t *n_pairs, uint64_t *r1_bytes, uint64_t *r2_bytes, void *stream);
 int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const char *r2_path, uint64_t r2_offset, uint32_t threads_per_file);
+/* Compressed output of a job over several processes: the kept text becomes gzip members of 1 MB of text each in host memory (a pool of threads sized by the
+ * processors the process may use; zlib's default level), the device arrays are released, *r1_bytes / *r2_bytes = the COMPRESSED sizes.  A file of concatenated
+ * members is a gzip file (RFC 1952; SeqAn, zlib's gzread and gzip -d read it as one stream), so the ranks exchange these sizes and rsq_sim_job_write puts each
+ * rank's members at its offset exactly as it does plain text.  The decompressed file is the single run's; where the members end depends on the ranks' shares. */
+int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes);
 /* `bytes` of the kept text of file `file` (0 / 1) from byte `at` on, copied into the caller's device memory: a rank's contribution to one round of a gather of
  * the output (simulate.py --gatherOutput: fixed-size slices gathered on the first rank over RCCL, which writes them with rsq_dev_pwrite).  RSQ_ESTATE without text. */
 int rsq_sim_job_read(rsq_sim *s, int file, uint64_t at, size_t bytes, char *dst_dev, void *stream);

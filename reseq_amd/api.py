@@ -98,6 +98,7 @@ SYMBOLS = {
     "rsq_sim_pairs": (C.c_int, [_vp, _u32, _u32, _vp, _sz, _psz, _vp, _sz, _psz, C.POINTER(_u64), _vp, _sz, _vp]),
     "rsq_sim_job_generate": (C.c_int, [_vp, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp]),
     "rsq_sim_job_write": (C.c_int, [_vp, C.c_char_p, _u64, C.c_char_p, _u64, _u32]),
+    "rsq_sim_job_compress": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rsq_sim_job_free": (C.c_int, [_vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
@@ -493,6 +494,12 @@ class Simulator:
     def job_write(self, r1_path, r1_offset, r2_path, r2_offset, threads_per_file=0):
         """the kept text to its place in the two final files (parallel pwrite from page-locked buffers); r2_path None: a job with one file"""
         _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode() if r2_path is not None else None, r2_offset, threads_per_file))
+
+    def job_compress(self):
+        """the kept text as gzip members in host memory (rsq_sim_job_compress); returns the compressed sizes of the two files, which job_write then writes"""
+        b1, b2 = _u64(0), _u64(0)
+        _check(lib().rsq_sim_job_compress(self.h, C.byref(b1), C.byref(b2)))
+        return b1.value, b2.value
 
     def job_read(self, file, at, nbytes, dst_ptr, stream=None):
         """bytes [at, at + nbytes) of the kept text of file 0 / 1 into device memory at `dst_ptr` (an integer address, e.g. a torch tensor's data_ptr())"""

@@ -195,8 +195,12 @@ struct rsq_sim : SimState {
         std::vector<size_t> used[2];
         uint64_t bytes[2] = {0, 0};
         bool complete = false;         // rsq_sim_job_generate ran to its end: the text is whole (not: never generated, freed, or left half-made by a failed call)
+        std::vector<unsigned char> packed[2];      // rsq_sim_job_compress: the text as gzip members in host memory (the device arrays are released, bytes[] = these sizes)
+        bool is_packed = false;
         void clear() {
             complete = false;
+            is_packed = false;
+            for (auto &p : packed) std::vector<unsigned char>().swap(p);
             for (int f = 0; f < 2; ++f) {
                 chunks[f].clear();
                 used[f].clear();
@@ -1688,6 +1692,25 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
         }
         if (!r2_path && job.bytes[1]) throw Error("rsq_sim_job_write: the job has text for a second file, but no second path was given");
         const int n_files = r2_path ? 2 : 1;                  // one file: the text of seqToIllumina records kept by rsq_sim_error_model_file
+        if (job.is_packed) {                                  // compressed in host memory already (rsq_sim_job_compress): plain writes at the offsets
+            const char *names[2] = {r1_path, r2_path};
+            const uint64_t at[2] = {r1_offset, r2_offset};
+            for (int f = 0; f < n_files; ++f) {
+                const int fd = open(names[f], O_WRONLY | O_CREAT, 0644);
+                if (fd < 0) throw Error(std::string("cannot open '") + names[f] + "' for writing: " + strerror(errno));
+                for (size_t done = 0; done < job.packed[f].size();) {
+                    const ssize_t w = pwrite(fd, job.packed[f].data() + done, std::min<size_t>(job.packed[f].size() - done, (size_t)1 << 30), (off_t)(at[f] + done));
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w <= 0) {
+                        close(fd);
+                        throw Error(std::string("writing '") + names[f] + "' failed: " + (w < 0 ? strerror(errno) : "no space"));
+                    }
+                    done += (size_t)w;
+                }
+                if (close(fd) != 0) throw Error(std::string("closing '") + names[f] + "' failed: " + strerror(errno));
+            }
+            return (int)RSQ_OK;
+        }
         const uint32_t T = threads_per_file ? std::min(threads_per_file, 64u) : 1u;
         const char *paths[2] = {r1_path, r2_path};
         const uint64_t offsets[2] = {r1_offset, r2_offset};
@@ -1803,11 +1826,58 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
     });
 }
 
+// The kept text as gzip members (rsq_textio.h ParallelGzip: 1 MB of text each, compressed by a pool of threads) in host memory; the device arrays are released.
+// A file of concatenated members is a gzip file: ranks exchange their COMPRESSED sizes and write their members at the offsets like plain text.
+int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes) {
+    REQUIRE(s && r1_bytes && r2_bytes, "null argument");
+    return guard([&] {
+        rsq_sim::JobText &job = s->job;
+        if (!job.complete || job.is_packed) {
+            g_last_error = "rsq_sim_job_compress: there is no generated text, or it has been compressed already";
+            return (int)RSQ_ESTATE;
+        }
+        HIP_CHECK(hipSetDevice(s->device));
+        s2i::CopyStream st;
+        s2i::Pinned host[2];
+        for (auto &h : host) h.ensure(kJobSliceBytes);
+        for (int f = 0; f < 2; ++f) {
+            textio::ParallelGzip gz;
+            gz.open_memory(job.packed[f]);
+            // the text lies in a list of device arrays; slices of kJobSliceBytes, the copy of one under the compression of the one before
+            struct Slice {
+                size_t chunk, at, n;
+            };
+            std::vector<Slice> slices;
+            for (size_t c = 0; c < job.chunks[f].size(); ++c)
+                for (size_t at = 0; at < job.used[f][c]; at += kJobSliceBytes) slices.push_back(Slice{c, at, std::min<size_t>(kJobSliceBytes, job.used[f][c] - at)});
+            auto copy = [&](size_t i) { HIP_CHECK(hipMemcpyAsync(host[i & 1].p, job.chunks[f][slices[i].chunk]->as<char>() + slices[i].at, slices[i].n, hipMemcpyDeviceToHost, st.st)); };
+            if (!slices.empty()) copy(0);
+            for (size_t i = 0; i < slices.size(); ++i) {
+                HIP_CHECK(hipStreamSynchronize(st.st));
+                if (i + 1 < slices.size()) copy(i + 1);
+                gz.write(host[i & 1].chars(), slices[i].n);
+            }
+            if (!gz.close()) throw Error("compressing the job's text failed");
+            job.chunks[f].clear();
+            job.used[f].clear();
+            job.bytes[f] = job.packed[f].size();
+        }
+        job.is_packed = true;
+        *r1_bytes = job.bytes[0];
+        *r2_bytes = job.bytes[1];
+        return (int)RSQ_OK;
+    });
+}
+
 // a stretch of the kept text into device memory of the caller (what a rank contributes to one round of a gather of the output)
 int rsq_sim_job_read(rsq_sim *s, int file, uint64_t at, size_t bytes, char *dst_dev, void *stream) {
     REQUIRE(s && (file == 0 || file == 1) && (dst_dev || !bytes), "null argument, or a file that is neither 0 nor 1");
     return guard([&] {
         const rsq_sim::JobText &job = s->job;
+        if (job.is_packed) {
+            g_last_error = "rsq_sim_job_read: the text has been compressed into host memory (rsq_sim_job_compress); a gather works on the plain text";
+            return (int)RSQ_ESTATE;
+        }
         if (!job.complete) {
             g_last_error = "rsq_sim_job_read: there is no generated text (rsq_sim_job_generate has not run to its end on this simulator, or rsq_sim_job_free has released it)";
             return (int)RSQ_ESTATE;

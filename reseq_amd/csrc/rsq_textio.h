@@ -120,14 +120,29 @@ struct ParallelGzip {
     size_t job_pieces = 0, next_piece = 0, pieces_done = 0;
     uint64_t generation = 0;
     bool stop = false, bad = false;
+    std::vector<unsigned char> *memory = nullptr;         // members are appended here instead of written to a file (a rank's compressed share of a job's output)
     bool open(const std::string &path) {
         f = fopen(path.c_str(), "wb");
         if (!f) return false;
+        start();
+        return true;
+    }
+    void open_memory(std::vector<unsigned char> &into) {
+        memory = &into;
+        start();
+    }
+    bool put(const std::vector<unsigned char> &bytes) {
+        if (memory) {
+            memory->insert(memory->end(), bytes.begin(), bytes.end());
+            return true;
+        }
+        return fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    }
+    void start() {
         // two threads per usable processor: a chunk of 64 pieces then divides evenly enough, and under a quota the scheduler's throttling falls on many short
         // runs instead of stalling few long ones (a container with 16 processors: 14 threads 197 MB/s, 32 threads 223-256, 64 threads 262; one thread 19.4)
         const unsigned threads = std::max(2u, std::min(2u * usable_cpus(), 64u));
         for (unsigned t = 0; t < threads; ++t) pool.emplace_back([this] { worker(); });
-        return true;
     }
     static bool begin_member(z_stream &z) {
         memset(&z, 0, sizeof z);
@@ -182,7 +197,7 @@ struct ParallelGzip {
             job_pieces = 0;
             failed = failed || bad;
         }
-        for (size_t p = 0; p < count && !failed; ++p) failed = fwrite(out[p].data(), 1, out[p].size(), f) != out[p].size();
+        for (size_t p = 0; p < count && !failed; ++p) failed = !put(out[p]);
         any = true;
     }
     void write(const char *text, size_t n) {
@@ -199,8 +214,9 @@ struct ParallelGzip {
         pieces(data, n);
         carry.assign(data + n / kPiece * kPiece, data + n);
     }
+    // (a file without text is one empty member, as gzclose leaves it; a rank's share in memory may be empty)
     bool close() {
-        if (!f) return !failed;
+        if (!f && !memory) return !failed;
         {
             std::lock_guard<std::mutex> lock(m);
             stop = true;
@@ -208,15 +224,17 @@ struct ParallelGzip {
         }
         for (std::thread &t : pool) t.join();
         pool.clear();
-        if (!carry.empty() || !any) {                      // the rest; a file without text is one empty member, as gzclose leaves it
+        if (!carry.empty() || (!any && f)) {               // the rest
             z_stream z;
             std::vector<unsigned char> last;
             const bool ok = begin_member(z) && member(z, carry.data(), carry.size(), last);
             if (ok) deflateEnd(&z);
-            failed = !ok || fwrite(last.data(), 1, last.size(), f) != last.size() || failed;
+            failed = !ok || !put(last) || failed;
+            carry.clear();
         }
-        failed = (fclose(f) != 0) || failed;
+        if (f) failed = (fclose(f) != 0) || failed;
         f = nullptr;
+        memory = nullptr;
         return !failed;
     }
     ~ParallelGzip() { close(); }

@@ -86,6 +86,9 @@ class GpuBackend:
     def job_generate(self, lo, hi, batch_blocks):
         return self.sim.job_generate(lo, hi, batch_blocks or 0)
 
+    def job_compress(self):
+        return self.sim.job_compress()
+
     def job_write(self, path1, offset1, path2, offset2):
         self.sim.job_write(path1, offset1, path2, offset2)
         self.sim.job_free()
@@ -205,8 +208,14 @@ def gather_to_first_rank(backend, dist, rank, world, sizes, outs, slice_bytes):
                         backend.write_slice(recv[r], n, outs[f], start[r] + at)
 
 
+def _gzip_member(text):
+    """text as one gzip member to append to a compressed output (nothing for no text)"""
+    import gzip
+    return gzip.compress(text, 6) if text else b""
+
+
 def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False,
-             gather_output=False, gather_slice_bytes=256 << 20):
+             gather_output=False, gather_slice_bytes=256 << 20, compress=False):
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
     small exchanges; the data never passes through Python."""
@@ -227,6 +236,13 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     _agree(dist, device, error, "generating its share")
     n_mine, bytes1, bytes2 = generated
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, bytes1 + bytes2, time.perf_counter() - t0)
+    wrap = _gzip_member if compress else (lambda text: text)
+    if compress:
+        # .gz outputs: the rank's text becomes gzip members in host memory (rsq_sim_job_compress: a pool of threads per rank); a file of concatenated members is a
+        # gzip file, so from here on the COMPRESSED sizes are the shard sizes and everything else stays as it is.  The decompressed files are the single run's.
+        packed, error = _attempt(backend.job_compress)
+        _agree(dist, device, error, "compressing its share")
+        bytes1, bytes2 = packed
     if split_output:
         # One pair of files per rank: buffered writes into ONE file take its inode lock one after the other, whoever writes (8 GB/s for the whole job however
         # many ranks, profiles/r03_g_*), separate files do not (49 GB/s with 8 writers behind one GPU's link).  No exchange of sizes, no barrier: a rank is done
@@ -241,8 +257,8 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
                 with open(p1, "ab") as f1, open(p2, "ab") as f2:
                     for first in range(0, info["adapter_only_pairs"], 100000):
                         a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
-                        f1.write(a)
-                        f2.write(b)
+                        f1.write(wrap(a))
+                        f2.write(wrap(b))
 
         _agree(dist, device, _attempt(write_parts)[1], "writing its part")
         return int(total_pairs) + info["adapter_only_pairs"], elapsed
@@ -260,8 +276,8 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
             with open(out1, "ab") as f1, open(out2, "ab") as f2:
                 for first in range(0, info["adapter_only_pairs"], 100000):   # Simulator.cpp:2359-2382, as the single-GPU CLI does
                     a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
-                    f1.write(a)
-                    f2.write(b)
+                    f1.write(wrap(a))
+                    f2.write(wrap(b))
 
     # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
     _agree(dist, device, _attempt(create_files)[1], "creating the output files")
@@ -277,7 +293,7 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     return int(total_pairs) + info["adapter_only_pairs"], elapsed
 
 
-def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cpu", split_output=False, count=None, **pipeline):
+def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cpu", split_output=False, count=None, compress=False, **pipeline):
     """`seqToIllumina` over several ranks (Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014; SURVEY section 8(e): shards by input record ranges).
     Every rank counts the record starts in its stretch of the (plain) input file (`count`: api.count_fasta_records, host code), one all-gather of the two numbers
     tells it which bytes are its records and what the index of its first record is; it runs them through the library's pipeline with the text kept in device
@@ -303,6 +319,10 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
     _agree(dist, device, error, "simulating its records")
     records, nbytes = got
     total_records, _, elapsed = sharding.job_totals(dist, device, records, nbytes, time.perf_counter() - t0)
+    if compress:                                                     # a .gz output: the share as gzip members, their size is the shard size (run_rank says why)
+        packed, error = _attempt(lambda: sim.job_compress()[0] if nbytes else 0)
+        _agree(dist, device, error, "compressing its share")
+        nbytes = packed
     if not nbytes:                                                   # nothing kept (an empty share): nothing to write either
         write = lambda path, offset: None
     else:
@@ -339,8 +359,8 @@ def main_records(argv):
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own file <out>.part<k>of<N> (their concatenation in order is the single file)")
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    if a.output.endswith((".gz", ".bz2")):
-        ap.error(f"{a.output}: compressed output is not supported by the multi-GPU launcher (write plain FASTQ and compress afterwards)")
+    if a.output.endswith(".bz2"):
+        ap.error(f"{a.output}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
     import torch
     from . import api
     dist = None
@@ -364,7 +384,7 @@ def main_records(argv):
         got, error = _attempt(set_up)
         _agree(dist, device, error, "setting up its simulator")
         prof, sim = got
-        records, seconds = run_records_rank(sim, dist, rank, world, a.input, a.output, device, a.splitOutput, count=api.count_fasta_records)
+        records, seconds = run_records_rank(sim, dist, rank, world, a.input, a.output, device, a.splitOutput, count=api.count_fasta_records, compress=a.output.endswith(".gz"))
         if rank == 0:
             if not records:
                 print(f"!!! Error: {a.input} does not contain any sequences.", file=sys.stderr)
@@ -414,9 +434,14 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    for out in (a.out1, a.out2):                                     # the single-GPU command line compresses these; shards placed by offset cannot be
-        if out.endswith((".gz", ".bz2")):
-            ap.error(f"{out}: compressed output is not supported by the multi-GPU launcher (write plain FASTQ and compress afterwards)")
+    compress = a.out1.endswith(".gz")                                # gzip members concatenate, so a rank's compressed share has a place in the file like plain text
+    if a.out2.endswith(".gz") != compress:
+        ap.error("the two output files are either both plain or both .gz")
+    if compress and a.gatherOutput:
+        ap.error("--gatherOutput moves plain text; with .gz outputs every rank writes its own compressed share")
+    for out in (a.out1, a.out2):
+        if out.endswith(".bz2"):
+            ap.error(f"{out}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
     seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
     if dist is not None:                                             # one seed for the whole job, all 64 bits of it
         t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=f"cuda:{local_rank}")
@@ -429,7 +454,7 @@ def main(argv=None):
         backend = load_once_per_host(make, dist, f"cuda:{local_rank}", local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)))
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
-                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput, a.gatherOutput, a.gatherSliceMB << 20)
+                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput, a.gatherOutput, a.gatherSliceMB << 20, compress)
         if rank == 0:
             print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
     finally:

@@ -221,6 +221,28 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
         b.sim.job_free()
         with pytest.raises(api.RsqError):                                 # freed: nothing to write
             b.sim.job_write(f1, 100, f2, 70, threads)
+    # rsq_sim_job_compress: the kept text as gzip members in host memory, written at offsets like the plain text (a rank's share of .gz outputs)
+    import gzip
+    rsq_options("job_chunk_bytes", 30_000)
+    rsq_options("job_write_direct", 0)
+    b.sim.job_generate(lo, hi, 2)
+    c1, c2 = b.sim.job_compress()
+    assert 0 < c1 < len(t1) // 2 and 0 < c2 < len(t2) // 2
+    with pytest.raises(api.RsqError) as e:                                # once only; and a gather works on plain text
+        b.sim.job_compress()
+    assert e.value.code == api.RSQ_ESTATE
+    scratch = api.DeviceArray(0, 16)
+    with pytest.raises(api.RsqError) as e:
+        b.sim.job_read(0, 0, 16, scratch.ptr.value)
+    assert e.value.code == api.RSQ_ESTATE and "compressed" in str(e.value)
+    scratch.free()
+    g1, g2 = workdir / "job_1.fq.gz", workdir / "job_2.fq.gz"
+    g1.write_bytes(gzip.compress(b"in front\n"))
+    front = len(g1.read_bytes())
+    b.sim.job_write(g1, front, g2, 0, 0)
+    assert gzip.decompress(g1.read_bytes()) == b"in front\n" + t1 and len(g1.read_bytes()) == front + c1
+    assert gzip.decompress(g2.read_bytes()) == t2 and len(g2.read_bytes()) == c2
+    b.sim.job_free()
     b.close()
 
 
@@ -522,6 +544,11 @@ def test_simulate_module_equals_cli(workdir):
     subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", c1, "-2", c2, "--batchBlocks", "3", "--gatherOutput", "--gatherSliceMB", "1"], check=True, capture_output=True,
                    env=env, cwd=root)
     assert open(a1, "rb").read() == open(c1, "rb").read() and open(a2, "rb").read() == open(c2, "rb").read()
+    # .gz outputs: the rank's share compressed by the library's threads (rsq_sim_job_compress), the adapter-only pairs as a member behind it
+    import gzip
+    g1, g2 = str(workdir / "v1.fq.gz"), str(workdir / "v2.fq.gz")
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate"] + args + ["-1", g1, "-2", g2, "--batchBlocks", "3"], check=True, capture_output=True, env=env, cwd=root)
+    assert gzip.decompress(open(g1, "rb").read()) == open(a1, "rb").read() and gzip.decompress(open(g2, "rb").read()) == open(a2, "rb").read()
 
 
 def test_seq_to_illumina_in_shares_equals_the_single_run(workdir):
@@ -586,6 +613,11 @@ def test_seq_to_illumina_in_shares_equals_the_single_run(workdir):
     subprocess.run([sys.executable, "-m", "reseq_amd.simulate", "seqToIllumina", "-i", str(inp), "-o", str(launched), "-s", ppath, "--seed", "21"], check=True, capture_output=True,
                    env=env, cwd=root)
     assert launched.read_bytes() == want
+    import gzip
+    packed = workdir / "launched.fq.gz"
+    subprocess.run([sys.executable, "-m", "reseq_amd.simulate", "seqToIllumina", "-i", str(inp), "-o", str(packed), "-s", ppath, "--seed", "21"], check=True, capture_output=True,
+                   env=env, cwd=root)
+    assert gzip.decompress(packed.read_bytes()) == want
 
 
 def test_sharded_pre_passes(workdir):

@@ -76,6 +76,10 @@ class Emu:                      # the host emulation behind the interface simula
             self.text[0] += t1
             self.text[1] += t2
         return n, len(self.text[0]), len(self.text[1])
+    def job_compress(self):                                # rsq_sim_job_compress: gzip members of 1 MB of text
+        import gzip
+        self.text = [bytearray(b"".join(gzip.compress(bytes(t[k:k + (1 << 20)]), 6) for k in range(0, len(t), 1 << 20))) for t in self.text]
+        return len(self.text[0]), len(self.text[1])
     def job_write(self, path1, offset1, path2, offset2):
         if os.environ.get("RSQ_FAIL_WRITE") == os.environ["RANK"]:
             raise IOError("no space left on the device (the test's)")
@@ -117,7 +121,8 @@ if os.environ.get("RSQ_SHARED_LOAD"):          # the two ranks as the ranks of o
 else:
     backend = Emu(ppath, fpath, seqs, vcf)
 pairs, _ = simulate.run_rank(backend, dist if world > 1 else None, rank, world, str(work / f"{tag}_1.fq"), str(work / f"{tag}_2.fq"), 7, 30000, 0.0, 1, "Job", 3,
-                             split_output=bool(os.environ.get("RSQ_SPLIT")), gather_output=bool(os.environ.get("RSQ_GATHER")), gather_slice_bytes=200_000)
+                             split_output=bool(os.environ.get("RSQ_SPLIT")), gather_output=bool(os.environ.get("RSQ_GATHER")), gather_slice_bytes=200_000,
+                             compress=tag.endswith("gz"))
 if rank == 0:
     print("PAIRS", pairs)
 if world > 1:
@@ -164,6 +169,19 @@ def test_simulate_module_two_ranks_equal_one_rank(workdir, variants):
         assert p.returncode == 0, se.decode()[-3000:]
     for k in (1, 2):
         assert (workdir / f"gathered_{k}.fq").read_bytes() == (workdir / f"one_{k}.fq").read_bytes()
+    # compressed outputs: every rank's share as gzip members at its offset of the file (the sizes exchanged are the compressed ones), the adapter-only pairs as a
+    # member behind them; the decompressed files are the single run's -- also rank by rank with --splitOutput
+    import gzip
+    for tag, extra in (("twogz", {}), ("splitgz", {"RSQ_SPLIT": "1"})):
+        procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG=tag, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                 for r in range(2)]
+        for p in procs:
+            so, se = p.communicate(timeout=800)
+            assert p.returncode == 0, se.decode()[-3000:]
+    for k in (1, 2):
+        assert gzip.decompress((workdir / f"twogz_{k}.fq").read_bytes()) == (workdir / f"one_{k}.fq").read_bytes()
+        parts = [(workdir / f"splitgz_{k}.fq.part{r}of2").read_bytes() for r in (1, 2)]
+        assert gzip.decompress(parts[0]) + gzip.decompress(parts[1]) == (workdir / f"one_{k}.fq").read_bytes() == gzip.decompress(parts[0] + parts[1])
     # one load per host: rank 0 reads and packs, rank 1 takes the packed reference (variants included) from the shared directory -- the same two files
     procs = [subprocess.Popen([sys.executable, "-c", SIMULATE_WORKER], env=dict(base, RANK=str(r), WORLD_SIZE="2", RSQ_TAG="shared", RSQ_SHARED_LOAD="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(2)]
