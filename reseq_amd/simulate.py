@@ -333,6 +333,8 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
         def write_part():
             open(part, "wb").close()
             write(part, 0)
+            if nbytes:
+                sim.job_free()
         _agree(dist, device, _attempt(write_part)[1], "writing its part")
         return int(total_records), elapsed
     sizes = sharding.gather_sizes(dist, device, [nbytes], world)
