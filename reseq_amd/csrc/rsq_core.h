@@ -262,7 +262,7 @@ RSQ_HD Quad prod_quad(uint32_t c, const R0 &r0, const R1 &r1, const R2 &r2, cons
 #define RSQ_SCHED_BARRIER() ((void)0)
 #endif
 #ifndef RSQ_SCREEN_BATCH
-#define RSQ_SCREEN_BATCH 2
+#define RSQ_SCREEN_BATCH 1
 #endif
 constexpr float kScreenSafety = 1.5f;
 constexpr float kScreenMinSum = 9.313225746154785e-10f;      // 2^-30

@@ -2076,10 +2076,21 @@ RSQ_HD RecordSrc record_src(const uint8_t *seqs, const uint8_t *dom, const uint8
 RSQ_HD RecordSrc record_src_at(const uint8_t *seqs, const uint8_t *dom, const uint8_t *rate, uint32_t at, uint32_t len, uint32_t bytes) {
     return RecordSrc{seqs + at, dom + at, rate + at, len, bytes - at, 0xFFFFFFFFu, 0, 0, 0};
 }
+// Workgroup sizes of the read kernels: 1024 threads -- four waves per SIMD at 128 VGPRs.  The step is a chain of dependent draws that leaves VALU and LDS idle a
+// fifth of the time at three waves per SIMD; a fourth wave fills more of it than the spills cost that 128 registers bring (the profile's own kernel for read pairs:
+// 11 spilled VGPRs, 80 B of scratch; with variants 67 and 208 B).  Measured against 768 threads, 157-168 VGPRs and no spill (profiles/r04_zz_block_*): read pairs
+// 47.2 -> 42.5 ms per 10 M pairs, seqToIllumina records 22.9 -> 22.1 ms per 8 M, configs[4] at 1/10 scale 107.5 -> 112.8 M pairs/s -- with the screen's loads
+// issued a quad at a time (RSQ_SCREEN_BATCH 1; two at a time the walking kernels lose 3-7 % at 1024 threads).  RSQ_FILL_BLOCK_WALK: the kernels whose source walks
+// per-lane state (variants, records), should a build want them smaller.
 #ifndef RSQ_FILL_BLOCK
-#define RSQ_FILL_BLOCK 768
+#define RSQ_FILL_BLOCK 1024
 #endif
-constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK;
+#ifndef RSQ_FILL_BLOCK_WALK
+#define RSQ_FILL_BLOCK_WALK 1024
+#endif
+constexpr uint32_t kFillBlock = RSQ_FILL_BLOCK, kFillBlockWalk = RSQ_FILL_BLOCK_WALK;
+constexpr uint32_t kFillWavesMax = (kFillBlock > kFillBlockWalk ? kFillBlock : kFillBlockWalk) / 64u;      // the LDS image has a ring for every wave of the larger one
+RSQ_HD constexpr uint32_t fill_block(bool walk) { return walk ? kFillBlockWalk : kFillBlock; }
 
 // Reads binned by tile (LdsPlan::binned): bin = segment * n_tiles + tile.  `perm` lists the items (pairs of a batch: both segments share the list of a
 // tile; seqToIllumina records: a record has one segment) bin after bin.  A workgroup joins a bin, stages its image and its waves pull the bin's chunks
@@ -2410,7 +2421,7 @@ __device__ __forceinline__ void fill_reads_body(const DevSim &S, const NameTable
 }
 // the library's own instantiations (every shape of profile); a kernel compiled for one profile wraps the same body (rsq_spec.h)
 template <uint32_t MASK, bool VAR = false, bool BINNED = false>
-__global__ void __launch_bounds__(kFillBlock) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
+__global__ void __launch_bounds__(fill_block(VAR)) k_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first,
                                                           RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {
     fill_reads_body<MASK, VAR, BINNED>(S, names, frags, n_pairs, adapter_only_first, raw, sizes, chunk_counters, fvars, bins);
 }
@@ -2470,7 +2481,7 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
     }
 }
 template <uint32_t MASK, bool BINNED = false>
-__global__ void __launch_bounds__(kFillBlock) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
+__global__ void __launch_bounds__(kFillBlockWalk) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
     fill_records_body<MASK, BINNED>(S, job, raw, chunk_counters, bins);
 }
 #if !defined(RSQ_SPEC)

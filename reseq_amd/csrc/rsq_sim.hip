@@ -498,10 +498,10 @@ static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kerne
 // workgroups of a read kernel: persistent, one (or two, when two images fit) per CU, not more than there are rounds of chunks.  (Spreading a small call over
 // more workgroups -- one per four chunks -- does not shorten it: a seqToIllumina call on 107 000 records takes 1.1 ms either way, the chain of 150 steps of a
 // wave that has its SIMD to itself; the command line therefore hands over several blocks in one call.)
-static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item) {
+static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item, uint32_t block) {
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
     const uint64_t chunks = (n_items + 63) / 64;
-    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, segments_per_item * cdiv(chunks, kFillBlock / 64)));
+    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, segments_per_item * cdiv(chunks, block / 64)));
     return (blocks + 1u) & ~1u;                                     // segments alternate over blockIdx.x
 }
 
@@ -516,7 +516,8 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
             hipLaunchKernelGGL(k_pair_tiles, dim3(cdiv(n_pairs, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, frags, fvars, n_pairs, adapter_first, keys, hist);
         }, frags, fvars);
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_reads<MASK, VAR, BINNED>);
-    const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2);
+    constexpr uint32_t kBlock = fill_block(VAR);
+    const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2, kBlock);
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
     hipFunction_t spec = spec_kernel(s, SpecKind::kReads, MASK, VAR, BINNED);
@@ -525,9 +526,9 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
         uint32_t *sizes = s.cur->sizes.as<uint32_t>(), *counters = s.cur->fill_counters.as<uint32_t>();
         RawLayout raw_arg = raw;
         void *args[] = {&s.dev, &s.names, &frags, &n_pairs, &adapter_first, &raw_arg, &sizes, &counters, &fvars, &bins};
-        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
-        hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
+        hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
                            s.cur->fill_counters.as<uint32_t>(), fvars, bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
@@ -547,7 +548,7 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
             hipLaunchKernelGGL(k_record_tiles, dim3(cdiv(n, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, seg_dev, job.first_index, n, keys, hist);
         });
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED>);
-    const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1);
+    const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1, kFillBlockWalk);
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
     hipFunction_t spec = spec_kernel(s, SpecKind::kRecords, MASK, false, BINNED);
@@ -557,9 +558,9 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
         RecordJob job_arg = job;
         RawLayout raw_arg = raw;
         void *args[] = {&s.dev, &job_arg, &raw_arg, &counters, &bins};
-        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlockWalk, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
-        hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlock), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
+        hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlockWalk), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;

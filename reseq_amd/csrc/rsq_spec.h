@@ -97,11 +97,11 @@ inline std::string spec_program(const std::string &literals, const SpecVariant &
     std::string t = "#define RSQ_SPEC 1\n#include \"rsq_types.h\"\n" + literals + "#include \"rsq_kernels.h\"\nusing namespace rsq;\n";
     const std::string m = std::to_string(v.mask) + "u, ";
     if (v.kind == SpecKind::kReads)
-        t += "extern \"C\" __global__ void __launch_bounds__(kFillBlock) rsq_spec_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, "
+        t += std::string("extern \"C\" __global__ void __launch_bounds__(fill_block(") + (v.var ? "true" : "false") + ")) rsq_spec_fill_reads(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, "
              "RawLayout raw, uint32_t *sizes, uint32_t *chunk_counters, const FragmentVar *fvars, FillBins bins) {\n    fill_reads_body<" + m + (v.var ? "true, " : "false, ") +
              (v.binned ? "true" : "false") + ">(S, names, frags, n_pairs, adapter_only_first, raw, sizes, chunk_counters, fvars, bins);\n}\n";
     else
-        t += "extern \"C\" __global__ void __launch_bounds__(kFillBlock) rsq_spec_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {\n"
+        t += "extern \"C\" __global__ void __launch_bounds__(kFillBlockWalk) rsq_spec_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {\n"
              "    fill_records_body<" + m + (v.binned ? "true" : "false") + ">(S, job, raw, chunk_counters, bins);\n}\n";
     return t;
 }
@@ -147,7 +147,7 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     rtc.version(&out.rtc_major, &out.rtc_minor);
     const char *headers[] = {kSrc_rsq_types_h, kSrc_rsq_core_h, kSrc_rsq_variants_h, kSrc_rsq_kernels_h};
     const char *names[] = {"rsq_types.h", "rsq_core.h", "rsq_variants.h", "rsq_kernels.h"};
-    uint64_t h = fnv1a(program + " " + std::to_string(RSQ_FILL_BLOCK) + " " + std::to_string(RSQ_SCREEN_BATCH) + " " + std::to_string(RSQ_CHUNK_LARGE), fnv1a(arch, 0xcbf29ce484222325ull));
+    uint64_t h = fnv1a(program + " " + std::to_string(RSQ_FILL_BLOCK) + " " + std::to_string(RSQ_FILL_BLOCK_WALK) + " " + std::to_string(RSQ_SCREEN_BATCH) + " " + std::to_string(RSQ_CHUNK_LARGE), fnv1a(arch, 0xcbf29ce484222325ull));
     for (const char *src : headers) h = fnv1a(src, strlen(src), h);
     h = fnv1a(&out.rtc_major, sizeof(int), fnv1a(&out.rtc_minor, sizeof(int), h));
     char name[64];
@@ -176,10 +176,10 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     const std::string arch_opt = "--offload-arch=" + arch;
     // the library's own flags (Makefile): the double-precision route must round like the reference's separate multiply / add; and the build's geometry macros as
     // this library was compiled with them (workgroup size, batch of the screen, chunk of the double-precision draws): the launch and the LDS plan are the library's
-    const std::string block = "-DRSQ_FILL_BLOCK=" + std::to_string(RSQ_FILL_BLOCK), batch = "-DRSQ_SCREEN_BATCH=" + std::to_string(RSQ_SCREEN_BATCH),
-                      chunk = "-DRSQ_CHUNK_LARGE=" + std::to_string(RSQ_CHUNK_LARGE);
-    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), batch.c_str(), chunk.c_str()};
-    if (rtc.compile(prog, 8, opts) != 0) {
+    const std::string block = "-DRSQ_FILL_BLOCK=" + std::to_string(RSQ_FILL_BLOCK), walk = "-DRSQ_FILL_BLOCK_WALK=" + std::to_string(RSQ_FILL_BLOCK_WALK),
+                      batch = "-DRSQ_SCREEN_BATCH=" + std::to_string(RSQ_SCREEN_BATCH), chunk = "-DRSQ_CHUNK_LARGE=" + std::to_string(RSQ_CHUNK_LARGE);
+    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str()};
+    if (rtc.compile(prog, 9, opts) != 0) {
         size_t n = 0;
         rtc.log_size(prog, &n);
         std::string log(n, '\0');
