@@ -2541,16 +2541,30 @@ __global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragm
 // the same alignment modulo 16 as the destination) and then copies the image out with aligned 16-byte stores.  Four lanes
 // share a record: lanes 0-15 write the id line and the first half of the bases, lanes 16-31 the second half, lanes 32-47 and
 // 48-63 the two halves of the qualities.  The kernel is latency-bound (dependent byte pushes, four load round trips), so
-// short per-lane work and 8 KiB of LDS per wave (twenty waves per CU) matter more than instruction count.
-constexpr uint32_t kFormatRecords = 16u, kFormatLdsBytes = 8u * 1024u;
+// short per-lane work and many waves per CU matter more than instruction count: the image is as large as the records need (lds_bytes, dynamic: the host sizes
+// it from the longest record of the call before -- 8 KiB a wave were twenty waves per CU and 5.6 ms per 10 M pairs, 6 KiB are 26 and 4.7 ms); a wave whose records do
+// not fit writes them straight to HBM.
+constexpr uint32_t kFormatRecords = 16u, kFormatLdsMax = 16u * 1024u, kFormatLdsMin = 2u * 1024u;
+// the image for records of at most `record_bytes` (the longest record of the call before and a few bytes for a digit more in its numbers), whole 128 bytes
+RSQ_HD uint32_t format_lds_bytes(uint64_t record_bytes) {
+    const uint64_t want = (kFormatRecords * record_bytes + 16u + 127u) & ~(uint64_t)127u;
+    return (uint32_t)(want < kFormatLdsMin ? kFormatLdsMin : want > kFormatLdsMax ? kFormatLdsMax : want);
+}
+// the longest of n record sizes (one atomic per wave)
+__global__ void __launch_bounds__(256) k_max_size(const uint32_t *sizes, uint64_t n, uint32_t *longest) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = max(m, sizes[i]);
+    for (uint32_t d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, (int)d, 64));
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax(longest, m);
+}
 // PERM (the read kernel ran binned by tile): the wave's 16 records are those whose raw rows are consecutive -- pairs perm[first .. first + 15] --, their
 // texts lie anywhere in the output, so every record has a 512-byte slot of the image (same alignment modulo 16 as its destination) and its four lanes
 // copy it out.
 template <bool PERM>
 __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_only_first, RawLayout raw,
                                                     const uint64_t *offsets0, const uint64_t *offsets1, char *dst0, char *dst1, uint64_t cap0, uint64_t cap1,
-                                                    const FragmentVar *fvars, const uint32_t *perm) {
-    __shared__ __attribute__((aligned(16))) char s_text[kFormatLdsBytes];
+                                                    const FragmentVar *fvars, const uint32_t *perm, uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char s_text[];
     const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords;
     const bool is_qual = part >= 2u, second_half = (part & 1u) != 0u;
     const uint64_t first = (uint64_t)blockIdx.x * kFormatRecords;
@@ -2565,8 +2579,8 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
     // the byte range of the wave's text (PERM: of the lane's record) and where it starts modulo 16
     const uint64_t g_begin = PERM ? (active ? offsets[pair] : 0u) : offsets[first], g_end = PERM ? (active ? offsets[pair + 1u] : 0u) : offsets[last];
     const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)(dst + g_begin) & 15u), bytes = (uint32_t)(g_end - g_begin);
-    constexpr uint32_t kSlot = kFormatLdsBytes / kFormatRecords;
-    const bool through_lds = PERM ? __all(skew + bytes <= kSlot) != 0 : skew + bytes <= kFormatLdsBytes;      // wave-uniform
+    const uint32_t kSlot = (lds_bytes / kFormatRecords) & ~15u;
+    const bool through_lds = PERM ? __all(skew + bytes <= kSlot) != 0 : skew + bytes <= lds_bytes;      // wave-uniform
     ReadMeta m;
     Fragment f;
     FragmentVar fv;

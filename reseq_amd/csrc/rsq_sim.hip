@@ -215,6 +215,8 @@ struct rsq_sim : SimState {
     std::map<std::string, Timer> timers;
     uint32_t n_cu = 256;
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
+    uint64_t format_record_bytes = 480;      // the longest FASTQ record of the last rsq_sim_pairs call and a few bytes (text_stage sizes the formatter's LDS image with it)
+    DevBuf longest_record;                   // where a call's text stages leave it
     int force_fill_mode = -1;      // RSQ_FILL_MODE=0: every draw in double precision from HBM (tests run both paths)
     // read kernels compiled for this simulator's profile (rsq_spec.h); `specialize`: option specialize when the simulator was created
     SpecKernels spec;
@@ -645,13 +647,17 @@ static void text_stage(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint
     exclusive_scan(s, w.sizes.as<uint32_t>() + n_pairs, n_pairs, w.off_r2.as<uint64_t>(), st, totals + 2 * part + 1, totals + 2 * (part + 1) + 1);
     s.timers["scan"].stop(st);
     const dim3 grid(cdiv(n_pairs, kFormatRecords), 2), block(64);
+    // the wave's LDS image: sized by the longest record of the call before (the first call takes room for records of 480 bytes); binned rows have a slot per
+    // record, each with its own alignment.  This call's longest record goes to totals' last word for the next one.
+    const uint32_t lds = rd.row_order ? std::min(kFormatLdsMax, format_lds_bytes(s.format_record_bytes) + 16u * kFormatRecords) : format_lds_bytes(s.format_record_bytes);
+    hipLaunchKernelGGL(k_max_size, dim3(std::min<uint64_t>(1024, cdiv(2 * n_pairs, 256))), dim3(256), 0, st, w.sizes.as<uint32_t>(), 2 * n_pairs, s.longest_record.as<uint32_t>());
     s.timers["format_write"].start(st);
     if (rd.row_order)
-        hipLaunchKernelGGL(k_format_write<true>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
-                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, rd.row_order);
+        hipLaunchKernelGGL(k_format_write<true>, grid, block, lds, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
+                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, rd.row_order, lds);
     else
-        hipLaunchKernelGGL(k_format_write<false>, grid, block, 0, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
-                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_format_write<false>, grid, block, lds, st, s.dev, s.names, frags, n_pairs, adapter_first, rd.raw, w.off_r1.as<uint64_t>(), w.off_r2.as<uint64_t>(), r1, r2,
+                           (uint64_t)(r1 ? r1_cap : 0), (uint64_t)(r2 ? r2_cap : 0), fvars, (const uint32_t *)nullptr, lds);
     s.timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
 }
@@ -663,6 +669,7 @@ static int finish_call(rsq_sim &s, uint32_t parts, bool with_variants, char *r1,
     s.mailbox[4] = 0;
     if (with_variants) HIP_CHECK(hipMemcpyAsync(&s.mailbox[4], s.dev.walk_error, 4, hipMemcpyDeviceToHost, text_stream));
     HIP_CHECK(hipMemcpyAsync(&s.mailbox[2], s.totals.as<uint64_t>() + 2 * parts, 16, hipMemcpyDeviceToHost, text_stream));
+    HIP_CHECK(hipMemcpyAsync(&s.mailbox[5], s.longest_record.as<uint32_t>(), 4, hipMemcpyDeviceToHost, text_stream));
     HIP_CHECK(hipStreamSynchronize(text_stream));
     *r1_len = s.mailbox[2];
     *r2_len = s.mailbox[3];
@@ -680,7 +687,9 @@ static int finish_call(rsq_sim &s, uint32_t parts, bool with_variants, char *r1,
 }
 static void begin_totals(rsq_sim &s, uint32_t parts, hipStream_t st) {
     s.totals.reserve((size_t)(parts + 1) * 16 + 16);
+    s.longest_record.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.totals.as<uint64_t>(), 0, 16, st));
+    HIP_CHECK(hipMemsetAsync(s.longest_record.as<uint32_t>(), 0, 4, st));
 }
 
 // reads + FASTQ text of adapter-only pairs (Simulator::SimulateAdapterOnlyPairs, Simulator.cpp:2359-2382): one part on the caller's stream
@@ -934,6 +943,7 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     }
     *n_pairs = total_pairs;
     const int rc = total_pairs ? finish_call(s, parts, s.has_variants, r1, r1_cap, r1_len, r2, r2_cap, r2_len, s_text) : (int)RSQ_OK;
+    if (total_pairs && (rc == RSQ_OK || rc == RSQ_ENOSPC) && (uint32_t)s.mailbox[5]) s.format_record_bytes = (uint32_t)s.mailbox[5] + 8u;      // for the next call's text stage
     if (parts > 1) {                                                 // the caller's stream continues behind the whole call
         HIP_CHECK(hipStreamSynchronize(s_sieve));
         HIP_CHECK(hipStreamSynchronize(s_text));
