@@ -2544,7 +2544,12 @@ __global__ void __launch_bounds__(256) k_variant_templates(DevSim S, const Fragm
 // short per-lane work and many waves per CU matter more than instruction count: the image is as large as the records need (lds_bytes, dynamic: the host sizes
 // it from the longest record of the call before -- 8 KiB a wave were twenty waves per CU and 5.6 ms per 10 M pairs, 6 KiB are 26 and 4.7 ms); a wave whose records do
 // not fit writes them straight to HBM.
-constexpr uint32_t kFormatRecords = 16u, kFormatLdsMax = 16u * 1024u, kFormatLdsMin = 2u * 1024u;
+// (records per wave: 16, four lanes each.  Eight records with eight lanes each need half the LDS and half the work per lane, but their loads of the raw
+// rows cover 32 bytes instead of 64: 2.3 ms slower per 10 M pairs)
+#ifndef RSQ_FORMAT_RECORDS
+#define RSQ_FORMAT_RECORDS 16
+#endif
+constexpr uint32_t kFormatRecords = RSQ_FORMAT_RECORDS, kFormatLdsMax = 16u * 1024u, kFormatLdsMin = 1024u;
 // the image for records of at most `record_bytes` (the longest record of the call before and a few bytes for a digit more in its numbers), whole 128 bytes
 RSQ_HD uint32_t format_lds_bytes(uint64_t record_bytes) {
     const uint64_t want = (kFormatRecords * record_bytes + 16u + 127u) & ~(uint64_t)127u;
@@ -2566,7 +2571,9 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
                                                     const FragmentVar *fvars, const uint32_t *perm, uint32_t lds_bytes) {
     extern __shared__ __attribute__((aligned(16))) char s_text[];
     const uint32_t lane = threadIdx.x, seg = blockIdx.y, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords;
-    const bool is_qual = part >= 2u, second_half = (part & 1u) != 0u;
+    constexpr uint32_t kLineParts = 32u / kFormatRecords;                          // lanes that share a line of a record
+    const bool is_qual = part >= kLineParts;
+    const uint32_t sub = part % kLineParts;
     const uint64_t first = (uint64_t)blockIdx.x * kFormatRecords;
     if (first >= n_pairs) return;
     const uint64_t *offsets = seg ? offsets1 : offsets0;
@@ -2601,12 +2608,12 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
     if (active) {
         RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + slot_at + skew + (PERM ? 0u : (uint32_t)(offsets[pair] - g_begin));
         const uint32_t header = (uint32_t)(offsets[pair + 1u] - offsets[pair]) - 2u * m.read_len - 4u;
-        const uint32_t all_words = (m.read_len + 3u) >> 2, half = (all_words + 1u) >> 1;      // the first half ends on a word boundary
-        const uint32_t first_word = second_half ? half : 0u, line_at = header + (is_qual ? m.read_len + 3u : 0u);
+        const uint32_t all_words = (m.read_len + 3u) >> 2, per = (all_words + kLineParts - 1u) / kLineParts;      // the parts end on word boundaries
+        const uint32_t first_word = sub * per, line_at = header + (is_qual ? m.read_len + 3u : 0u);
         const uint32_t part_at = part == 0u ? 0u : line_at + (4u * first_word < m.read_len ? 4u * first_word : m.read_len);
         WordSinkT<RSQ_LDS char *> t(rec_text + part_at);
         if (part == 0u) format_header(S, names, frags != nullptr, f, ao_number, m, ops, t, frags && fvars, fv);
-        format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, second_half ? all_words - half : half, second_half, t);
+        format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, per, sub == kLineParts - 1u, t);
         t.finish();
     }
     __syncthreads();
@@ -2614,7 +2621,7 @@ __global__ void __launch_bounds__(64) k_format_write(DevSim S, NameTable names, 
     char *g_chunk0 = dst + g_begin - skew;                                         // 16-byte aligned
     const char *s_from = s_text + slot_at;
     // the image goes out in aligned 16-byte stores: all lanes over the wave's range, or (PERM) a record's four lanes over its slot
-    for (uint32_t c = (PERM ? part : lane) * 16u; c < hi; c += (PERM ? 4u : 64u) * 16u) {
+    for (uint32_t c = (PERM ? part : lane) * 16u; c < hi; c += (PERM ? 64u / kFormatRecords : 64u) * 16u) {
         if (c >= lo && c + 16u <= hi) {
             *reinterpret_cast<uint4 *>(g_chunk0 + c) = *reinterpret_cast<const uint4 *>(s_from + c);
         } else {
