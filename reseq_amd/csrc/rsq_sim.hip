@@ -217,6 +217,7 @@ struct rsq_sim : SimState {
     uint64_t *mailbox = nullptr;   // pinned host words the hot path's few device-to-host scalars land in
     uint64_t format_record_bytes = 480;      // the longest FASTQ record of the last rsq_sim_pairs call and a few bytes (text_stage sizes the formatter's LDS image with it)
     DevBuf longest_record;                   // where a call's text stages leave it
+    uint64_t record_text_bytes = 480;        // the same for the seqToIllumina records' text (error_model_text)
     int force_fill_mode = -1;      // RSQ_FILL_MODE=0: every draw in double precision from HBM (tests run both paths)
     // read kernels compiled for this simulator's profile (rsq_spec.h); `specialize`: option specialize when the simulator was created
     SpecKernels spec;
@@ -970,22 +971,67 @@ __global__ void __launch_bounds__(256) k_record_text_sizes(RawLayout raw, uint64
     const uint64_t i = raw.item_of(row);
     sizes[i] = error_model_record_size(raw.meta[row], ids.length(i));
 }
-__global__ void __launch_bounds__(256) k_record_text(RawLayout raw, uint64_t n, RecordIds ids, const uint64_t *offsets, char *dst, uint64_t cap) {
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n || offsets[n] > cap) return;                        // the caller's buffer is too small: write nothing (RSQ_ENOSPC)
-    const uint64_t i = raw.item_of(row);
-    const ReadMeta m = raw.meta[row];
-    WordSinkT<char *> t(dst + offsets[i]);
-    t.ch('@');
-    t.str(ids.begin(i), ids.length(i));
-    t.ch(' ');
-    cigar_replay(raw.ops_of(row), m, t);
-    t.str(" E", 2);
-    t.num((uint32_t)m.num_errors);
-    t.ch('\n');
-    format_line(raw.seq_of(row), m.read_len, false, t);
-    format_line(raw.qual_of(row), m.read_len, true, t);
-    t.finish();
+// The text by waves, as k_format_write writes the pairs' (rsq_kernels.h): a wave takes 16 consecutive raw rows, four lanes per record (the header and the first
+// half of the bases, the second half, the two halves of the qualities), formats them into an LDS image of their contiguous stretch of the output and copies
+// the image out in aligned 16-byte stores; PERM (rows binned by tile): a slot of the image per record.  (One lane per record with word-granular stores, the
+// kernel of rounds 2-4, wrote 0.3 TB/s: 8.3 ms per 8 M records.)  A wave whose records do not fit the image writes them lane by lane.
+template <bool PERM>
+__global__ void __launch_bounds__(64) k_record_text_waves(RawLayout raw, uint64_t n, RecordIds ids, const uint64_t *offsets, char *dst, uint64_t cap, uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char s_text[];
+    constexpr uint32_t kLineParts = 32u / kFormatRecords;
+    const uint32_t lane = threadIdx.x, rec = lane & (kFormatRecords - 1u), part = lane / kFormatRecords, sub = part % kLineParts;
+    const bool is_qual = part >= kLineParts;
+    const uint64_t first = (uint64_t)blockIdx.x * kFormatRecords;
+    if (first >= n || offsets[n] > cap) return;                                      // (the caller's buffer is too small: write nothing, RSQ_ENOSPC)
+    const uint64_t last = first + kFormatRecords < n ? first + kFormatRecords : n, row = first + rec;
+    const bool active = row < last;
+    const uint64_t item = PERM ? (active ? raw.order[row] : 0u) : row;
+    const uint64_t g_begin = PERM ? (active ? offsets[item] : 0u) : offsets[first], g_end = PERM ? (active ? offsets[item + 1u] : 0u) : offsets[last];
+    const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)(dst + g_begin) & 15u), bytes = (uint32_t)(g_end - g_begin);
+    const uint32_t slot = (lds_bytes / kFormatRecords) & ~15u;
+    const bool through_lds = PERM ? __all(skew + bytes <= slot) != 0 : skew + bytes <= lds_bytes;      // wave-uniform
+    ReadMeta m{};
+    if (active) m = raw.meta[row];
+    const WordColumn seq = raw.seq_of(active ? row : 0u), qual = raw.qual_of(active ? row : 0u), ops = raw.ops_of(active ? row : 0u);
+    auto header = [&](auto &t) {
+        t.ch('@');
+        t.str(ids.begin(item), ids.length(item));
+        t.ch(' ');
+        cigar_replay(ops, m, t);
+        t.str(" E", 2);
+        t.num((uint32_t)m.num_errors);
+        t.ch('\n');
+    };
+    if (!through_lds) {
+        if (active && part == 0u) {
+            WordSinkT<char *> t(dst + offsets[item]);
+            header(t);
+            format_line(seq, m.read_len, false, t);
+            format_line(qual, m.read_len, true, t);
+            t.finish();
+        }
+        return;
+    }
+    const uint32_t slot_at = PERM ? rec * slot : 0u;
+    if (active) {
+        RSQ_LDS char *rec_text = (RSQ_LDS char *)s_text + slot_at + skew + (PERM ? 0u : (uint32_t)(offsets[item] - g_begin));
+        const uint32_t head = (uint32_t)(offsets[item + 1u] - offsets[item]) - 2u * m.read_len - 4u;
+        const uint32_t all_words = (m.read_len + 3u) >> 2, per = (all_words + kLineParts - 1u) / kLineParts, first_word = sub * per;
+        const uint32_t line_at = head + (is_qual ? m.read_len + 3u : 0u), part_at = part == 0u ? 0u : line_at + (4u * first_word < m.read_len ? 4u * first_word : m.read_len);
+        WordSinkT<RSQ_LDS char *> t(rec_text + part_at);
+        if (part == 0u) header(t);
+        format_line_part(is_qual ? qual : seq, m.read_len, is_qual, first_word, per, sub == kLineParts - 1u, t);
+        t.finish();
+    }
+    __syncthreads();
+    const uint32_t lo = skew, hi = skew + bytes;
+    char *g_chunk0 = dst + g_begin - skew;                                           // 16-byte aligned
+    const char *s_from = s_text + slot_at;
+    for (uint32_t c = (PERM ? part : lane) * 16u; c < hi; c += (PERM ? 64u / kFormatRecords : 64u) * 16u) {
+        if (c >= lo && c + 16u <= hi) *reinterpret_cast<uint4 *>(g_chunk0 + c) = *reinterpret_cast<const uint4 *>(s_from + c);
+        else
+            for (uint32_t b = c < lo ? lo : c; b < c + 16u && b < hi; ++b) g_chunk0[b] = s_from[b];
+    }
 }
 
 // CIGAR strings and per-read scalars of the error-model-only mode
@@ -2022,12 +2068,22 @@ static int error_model_text(rsq_sim *s, const RawLayout &raw, uint64_t n, const 
     s->timers["format_write"].start(st);
     hipLaunchKernelGGL(k_record_text_sizes, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids, s->cur->sizes.as<uint32_t>());
     exclusive_scan(*s, s->cur->sizes.as<uint32_t>(), n, s->cur->off_r1.as<uint64_t>(), st);
-    hipLaunchKernelGGL(k_record_text, dim3(cdiv(n, 256)), dim3(256), 0, st, raw, n, ids, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap);
+    // the waves' LDS image is sized by the longest record of the call before (this call's goes to longest_record for the next one)
+    s->longest_record.reserve(8);
+    HIP_CHECK(hipMemsetAsync(s->longest_record.as<uint32_t>(), 0, 4, st));
+    hipLaunchKernelGGL(k_max_size, dim3(std::min<uint64_t>(1024, cdiv(n, 256))), dim3(256), 0, st, s->cur->sizes.as<uint32_t>(), n, s->longest_record.as<uint32_t>());
+    const uint32_t lds = raw.order ? std::min(kFormatLdsMax, format_lds_bytes(s->record_text_bytes) + 16u * kFormatRecords) : format_lds_bytes(s->record_text_bytes);
+    if (raw.order)
+        hipLaunchKernelGGL(k_record_text_waves<true>, dim3(cdiv(n, kFormatRecords)), dim3(64), lds, st, raw, n, ids, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap, lds);
+    else
+        hipLaunchKernelGGL(k_record_text_waves<false>, dim3(cdiv(n, kFormatRecords)), dim3(64), lds, st, raw, n, ids, s->cur->off_r1.as<uint64_t>(), text_dev, (uint64_t)text_cap, lds);
     s->timers["format_write"].stop(st);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(&s->mailbox[2], s->cur->off_r1.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&s->mailbox[5], s->longest_record.as<uint32_t>(), 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     *text_len = s->mailbox[2];
+    if ((uint32_t)s->mailbox[5]) s->record_text_bytes = (uint32_t)s->mailbox[5] + 8u;
     if (*text_len > text_cap) {
         g_last_error = "text buffer too small: need " + std::to_string(*text_len) + " bytes";
         return (int)RSQ_ENOSPC;
