@@ -739,6 +739,25 @@ int emu_parse_fasta(const uint8_t *text, uint64_t text_len, int final, uint32_t 
     return 0;
 }
 
+// rsq_fasta.h converts eight bytes at a time: every byte value in every place of a word against the conversions of one byte; returns the number of disagreements
+int emu_fasta_words_check() {
+    int bad = 0;
+    for (uint32_t place = 0; place < 8; ++place)
+        for (uint32_t c = 0; c < 256; ++c)
+            for (uint32_t other : {0u, 0xFFu, 0x41u, 0x7Fu, 0x80u, 0x0Au}) {
+                uint64_t w = 0;
+                for (uint32_t j = 0; j < 8; ++j) w |= (uint64_t)(j == place ? c : other) << (8 * j);
+                const uint64_t codes = fasta::base_codes(w), rates = fasta::rate_percents(w), zeros = fasta::zero_bytes(w);
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const uint32_t b = (uint32_t)(w >> (8 * j)) & 0xFFu;
+                    bad += ((codes >> (8 * j)) & 0xFFu) != fasta::base_code(b);
+                    bad += ((rates >> (8 * j)) & 0xFFu) != fasta::rate_percent(b);
+                    bad += ((zeros >> (8 * j)) & 0xFFu) != (b ? 0u : 0x80u);
+                }
+            }
+    return bad;
+}
+
 // the library's text writer (gzip / bzip2 by the name's ending), for the tests of its compressed output
 int emu_write_text_file(const char *path, const char *data, size_t n) {
     return guard([&] { write_text_file(path, std::string(data, n)); });

@@ -118,6 +118,12 @@ def fasta_text(seed, n, read_len, wrap=0, crlf=False, ids_with_blanks=True, lowe
     return (nl.join(lines) + (nl if last_newline else "")).encode()
 
 
+def test_eight_bytes_at_a_time_equal_one_at_a_time():
+    """base_codes / rate_percents / zero_bytes of rsq_fasta.h on every byte value in every place of a word"""
+    from backends import emu_lib
+    assert emu_lib().emu_fasta_words_check() == 0
+
+
 @pytest.mark.parametrize("read_len", [1, 7, 8, 9, 30, 75, 151])
 def test_well_formed_records(read_len):
     """lengths around the 8-byte groups the codes are written in; ids with blanks, rates above 86 percent (stored halved, Simulator.cpp:2439-2442)"""
