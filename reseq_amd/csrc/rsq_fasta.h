@@ -187,17 +187,34 @@ RSQ_HD RecordError parse_record(P rec, uint64_t size, uint8_t *seqs, uint8_t *do
 
 #if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)
 constexpr uint32_t kTileBytes = 4096, kStartsBlock = 256;        // a wave per tile, four tiles per workgroup
-// record starts in tile `tile`, 64 bytes per step: f(position, rank within the tile) for each, returns their number
+// record starts in tile `tile`: f(position, rank within the tile) for each, returns their number.  A lane takes 16 bytes of a step's 1024 as two words: the '>'
+// bytes whose byte in front is a line end (zero_bytes of the words; the byte in front of the lane's first one is the lane before's last), counted with popcounts
+// and ranked by a prefix sum over the lanes.  [A byte per lane and a ballot per 64 bytes read the text at 0.4 TB/s.]
 template <class F>
 __device__ uint32_t tile_starts(const uint8_t *text, uint64_t text_len, uint64_t tile, F &&f) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t count = 0;
-    for (uint32_t step = 0; step < kTileBytes / 64u; ++step) {
-        const uint64_t p = tile * kTileBytes + step * 64u + lane;
-        const bool is = p < text_len && record_start(text, p);
-        const uint64_t mask = __ballot(is);
-        if (is) f(p, count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)));
-        count += (uint32_t)__popcll(mask);
+    for (uint32_t step = 0; step < kTileBytes / 1024u; ++step) {
+        const uint64_t p = tile * kTileBytes + step * 1024u + lane * 16u;
+        uint64_t m0 = 0, m1 = 0;
+        if (p < text_len) {
+            const uint64_t left = text_len - p;
+            const uint64_t w0 = word_at(text + p, 0, left), w1 = left > 8u ? word_at(text + p, 8, left) : 0u;      // (bytes behind the text's end are zeros: no '>')
+            const uint64_t front = p == 0 || text[p - 1] == '\n' ? 0x80u : 0u;                     // a line's (or the text's) first byte
+            const uint64_t nl0 = zero_bytes(w0 ^ (kOnes * '\n')), nl1 = zero_bytes(w1 ^ (kOnes * '\n'));
+            m0 = zero_bytes(w0 ^ (kOnes * '>')) & ((nl0 << 8) | front);
+            m1 = zero_bytes(w1 ^ (kOnes * '>')) & ((nl1 << 8) | (nl0 >> 56));
+        }
+        const uint32_t mine = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+        uint32_t upto = mine;                                                                     // inclusive prefix sum over the lanes
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t below = (uint32_t)__shfl_up((int)upto, (int)d, 64);
+            if (lane >= d) upto += below;
+        }
+        uint32_t rank = count + upto - mine;
+        for (uint64_t m = m0; m; m &= m - 1u) f(p + ((uint64_t)__builtin_ctzll(m) >> 3), rank++);
+        for (uint64_t m = m1; m; m &= m - 1u) f(p + 8u + ((uint64_t)__builtin_ctzll(m) >> 3), rank++);
+        count += (uint32_t)__shfl((int)upto, 63, 64);
     }
     return count;
 }
