@@ -526,7 +526,9 @@ const char *kUsage =
     "Commands:\n"
     "  illuminaPE\t\tsimulates illumina paired-end data from a fitted profile (-s) and a reference (-R)\n"
     "  seqToIllumina\t\tapplies illumina quality and error model to input sequences (alias: replaceQuals)\n"
-    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h,\n"
+    "                 \t-i in.fa[.gz|.bz2] (stdin) -o out.fq[.gz|.bz2] (stdout) -s profile; --readThreads N, --traceStages;\n"
+    "                 \t--inputFrom / --inputTo BYTE, --firstRecord K: a share of a plain input (python -m reseq_amd.simulate seqToIllumina works them out)\n"
+    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h, --traceStages,\n"
     "         --rsqOption name:value[,...] (measurement switches of libreseq_amd, include/reseq_amd.h rsq_set_option; results never depend on them)\n";
 
 }  // namespace
