@@ -1034,7 +1034,23 @@ __global__ void __launch_bounds__(64) k_record_text_waves(RawLayout raw, uint64_
     }
 }
 
-// CIGAR strings and per-read scalars of the error-model-only mode
+// The reads' bases and qualities as rows of out_stride bytes (word-aligned): sixteen lanes copy a row, a word each per step -- 64 bytes of a row in one store
+// instruction, where a lane per row wrote four bytes into each of 64 rows (10 ms per 8 M records of 150 bases).  Bytes past read_len inside the last word
+// are zero in the raw arrays.
+__global__ void __launch_bounds__(256) k_error_model_rows(RawLayout raw, uint64_t n, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride) {
+    const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (row >= n) return;
+    const uint64_t i = raw.item_of(row);
+    const uint32_t read_len = raw.meta[row].read_len, nb = read_len < out_stride ? read_len : out_stride;
+    const WordColumn seq = raw.seq_of(row), qual = raw.qual_of(row);
+    uint32_t *so = reinterpret_cast<uint32_t *>(seq_out + i * out_stride), *qo = reinterpret_cast<uint32_t *>(qual_out + i * out_stride);
+    for (uint32_t w = threadIdx.x & 15u; 4u * w < nb; w += 16u) {
+        so[w] = seq.at(w);
+        qo[w] = qual.at(w);
+    }
+}
+
+// CIGAR strings and per-read scalars of the error-model-only mode (and the rows when they are not word-aligned)
 __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, uint8_t *qual_out, uint32_t out_stride, uint16_t *read_len_out, uint16_t *num_errors_out,
                                   uint16_t *tile_out, char *cigar_out, uint32_t cigar_stride, uint32_t *overflow) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1046,13 +1062,7 @@ __global__ void k_error_model_out(RawLayout raw, uint64_t n, uint8_t *seq_out, u
     tile_out[i] = m.tile_id;
     const uint32_t nb = m.read_len < out_stride ? m.read_len : out_stride;
     const WordColumn seq = raw.seq_of(row), qual = raw.qual_of(row);
-    if (!((out_stride | (uint32_t)(uintptr_t)seq_out | (uint32_t)(uintptr_t)qual_out) & 3u)) {      // word-aligned rows: copy words
-        uint32_t *so = reinterpret_cast<uint32_t *>(seq_out + i * out_stride), *qo = reinterpret_cast<uint32_t *>(qual_out + i * out_stride);
-        for (uint32_t w = 0; 4u * w < nb; ++w) {                   // bytes past read_len inside the last word are zero in the raw arrays
-            so[w] = seq.at(w);
-            qo[w] = qual.at(w);
-        }
-    } else
+    if ((out_stride | (uint32_t)(uintptr_t)seq_out | (uint32_t)(uintptr_t)qual_out) & 3u)        // (word-aligned rows are copied by k_error_model_rows)
         for (uint32_t k = 0; k < nb; ++k) {
             seq_out[i * out_stride + k] = (uint8_t)(seq.at(k >> 2) >> (8u * (k & 3u)));
             qual_out[i * out_stride + k] = (uint8_t)(qual.at(k >> 2) >> (8u * (k & 3u)));
@@ -2047,6 +2057,8 @@ int rsq_sim_error_model(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t r
         const RawLayout raw = error_model_fill(s, first_index, n, read_len, seqs_dev, seg_dev, frag_len_dev, dom_dev, rate_dev, st);
         s->cur->scan_total.reserve(8);
         HIP_CHECK(hipMemsetAsync(s->cur->scan_total.as<uint32_t>(), 0, 4, st));
+        if (!((out_stride | (uint32_t)(uintptr_t)seq_out_dev | (uint32_t)(uintptr_t)qual_out_dev) & 3u))
+            hipLaunchKernelGGL(k_error_model_rows, dim3(cdiv(n * 16, 256)), dim3(256), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride);
         hipLaunchKernelGGL(k_error_model_out, dim3(cdiv(n, 64)), dim3(64), 0, st, raw, n, seq_out_dev, qual_out_dev, out_stride, read_len_out_dev, num_errors_out_dev,
                            tile_out_dev, cigar_out_dev, cigar_stride, s->cur->scan_total.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
