@@ -2,14 +2,16 @@
 //
 // The caller uploads FASTA text as it stands in the file.  A record is ">{id} {1|2};{fragment length};{dominant errors};{error rates}", a line end, and the
 // template bases on one line or wrapped over several; it reaches from a '>' at the start of a line to the next one.
-//   k_fasta_count / k_fasta_starts   a wave per 4 KB of text finds the record starts (ballots; a scan over the tiles' counts in between keeps the input order)
+//   k_fasta_count / k_fasta_starts   a wave per 4 KB of text finds the record starts (16 bytes per lane, word tests; a scan over the tiles' counts in between
+//                                    keeps the input order)
 //   k_fasta_records                  a lane per record: the reference's checks of the header in the reference's order (Simulator.cpp:2423-2485), template
 //                                    bases -> codes 0..3, dominant errors -> codes 0..4, error rates -> percent (:2439-2442), written in 8-byte groups at
 //                                    the record's own offset of three arrays as large as the text -- what k_fill_records reads (RecordSrc) needs no scan
 //                                    and no second copy, a record of any length fits, and the id stays where it is in the text (the formatter reads it there).
 //                                    A workgroup's 256 records are one stretch of the text: it is staged into LDS with whole-line loads and the lanes read
 //                                    their records there (a lane walking its record in HBM touches a cache line of its own with every load: measured 3.0 ms
-//                                    per million records against 1.4 with the stretch in LDS); a stretch that does not fit is read where it is.
+//                                    per million records against 1.4 with the stretch in LDS, 0.6 since the bytes are converted eight at a time); a stretch
+//                                    that does not fit is read where it is.
 // A malformed record sets the smallest index of a bad record; the host fetches that record's text and words the reference's message (record_message).
 // parse_record is plain code of one record: the host emulation of the tests runs it as it is.
 #pragma once
