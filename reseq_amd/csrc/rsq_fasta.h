@@ -5,9 +5,9 @@
 //   k_fasta_count / k_fasta_starts   a wave per 4 KB of text finds the record starts (16 bytes per lane, word tests; a scan over the tiles' counts in between
 //                                    keeps the input order)
 //   k_fasta_records                  a lane per record: the reference's checks of the header in the reference's order (Simulator.cpp:2423-2485), template
-//                                    bases -> codes 0..3, dominant errors -> codes 0..4, error rates -> percent (:2439-2442), written in 8-byte groups at
-//                                    the record's own offset of three arrays as large as the text -- what k_fill_records reads (RecordSrc) needs no scan
-//                                    and no second copy, a record of any length fits, and the id stays where it is in the text (the formatter reads it there).
+//                                    bases -> codes 0..3, dominant errors -> codes 0..4, error rates -> percent (:2439-2442), packed into a half-word per base
+//                                    at the record's own offset of an array as long as the text -- what k_fill_records reads (PackedRecordSrc) needs no
+//                                    scan and no second copy, a record of any length fits, and the id stays where it is in the text (the formatter reads it there).
 //                                    A workgroup's 256 records are one stretch of the text: it is staged into LDS with whole-line loads and the lanes read
 //                                    their records there (a lane walking its record in HBM touches a cache line of its own with every load: measured 3.0 ms
 //                                    per million records against 1.4 with the stretch in LDS, 0.6 since the bytes are converted eight at a time); a stretch
@@ -114,42 +114,63 @@ RSQ_HD uint64_t rate_percents(uint64_t w) {      // rate_percent of every byte
 // record_start: a '>' that begins a line (or the text)
 RSQ_HD bool record_start(const uint8_t *text, uint64_t p) { return text[p] == '>' && (p == 0 || text[p - 1] == '\n'); }
 
-// One record rec[0, size): rec[0] is its '>'.  Codes go to seqs / dom / rate[0, len) (the caller passes the arrays at the record's offset; size > len always).
-// The checks follow the reference's order; the bases are counted first because every check needs their number.
+// Where a record's codes go.  ByteArrays: three arrays of bytes (what rsq_sim_error_model takes from its callers, and what the tests read).  Packed: a half-word
+// per base -- base code in bits 0-1, dominant error in bits 2-4, error percent in bits 8-15 -- so that the read kernel's lane gets eight bases of all three
+// with ONE 16-byte load instead of three 8-byte ones (PackedRecordSrc, rsq_kernels.h: a lane's record is 450 bytes of its own, every load touches 64 lines).
+struct ByteArrays {
+    uint8_t *seqs, *dom, *rate;
+    RSQ_HD void eight(uint64_t k, uint64_t s, uint64_t d, uint64_t r) const {
+        store_word(seqs + k, s);
+        store_word(dom + k, d);
+        store_word(rate + k, r);
+    }
+    RSQ_HD void one(uint64_t k, uint32_t s, uint32_t d, uint32_t r) const {
+        seqs[k] = (uint8_t)s;
+        dom[k] = (uint8_t)d;
+        rate[k] = (uint8_t)r;
+    }
+};
+RSQ_HD uint64_t spread_bytes(uint32_t x) {       // bytes 0..3 of x into the low bytes of four half-words
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    return (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+}
+struct Packed {
+    uint16_t *codes;
+    RSQ_HD void eight(uint64_t k, uint64_t s, uint64_t d, uint64_t r) const {
+        const uint64_t low = s | (d << 2);
+        store_word(reinterpret_cast<uint8_t *>(codes + k), spread_bytes((uint32_t)low) | (spread_bytes((uint32_t)r) << 8));
+        store_word(reinterpret_cast<uint8_t *>(codes + k + 4u), spread_bytes((uint32_t)(low >> 32)) | (spread_bytes((uint32_t)(r >> 32)) << 8));
+    }
+    RSQ_HD void one(uint64_t k, uint32_t s, uint32_t d, uint32_t r) const { codes[k] = (uint16_t)(s | (d << 2) | (r << 8)); }
+};
+
+// is byte j of the word (at offset off of the record) the end of a line: '\n', or '\r' in front of one or of the record's end
 template <class P>
-RSQ_HD RecordError parse_record(P rec, uint64_t size, uint8_t *seqs, uint8_t *dom, uint8_t *rate, RecordFields &f) {
+RSQ_HD bool line_end_byte(P rec, uint64_t size, uint64_t off, uint64_t w, uint32_t j) {
+    const uint32_t c = (uint32_t)(w >> (8u * j)) & 0xFFu;
+    if (c == '\n') return true;
+    if (c != '\r') return false;
+    const uint32_t next = off + j + 1u >= size ? (uint32_t)'\n' : j < 7u ? (uint32_t)(w >> (8u * (j + 1u))) & 0xFFu : (uint32_t)rec[off + 8u];
+    return next == '\n';
+}
+
+// One record rec[0, size): rec[0] is its '>'.  The codes of base k go to out (k < len; a record of n bytes has fewer than n / 3 bases).
+// The checks follow the reference's order; the bases are counted first because every check needs their number, and converted last, together with the systematic
+// errors the header holds for them.
+template <class P, class Out>
+RSQ_HD RecordError parse_record(P rec, uint64_t size, const Out &out, RecordFields &f) {
     const uint64_t line_end = find_byte(rec, 1, size, '\n');
     uint64_t header_len = line_end - 1u;
     if (header_len && rec[line_end - 1u] == '\r') --header_len;
-    // the template: every line behind the header, line ends ('\n', or '\r' in front of one or of the record's end) dropped
-    uint64_t L = 0, group = 0, any = 0;
+    // the template: every line behind the header, line ends dropped
+    uint64_t L = 0;
     for (uint64_t off = line_end + 1u; off < size; off += 8u) {
         const uint64_t w = word_at(rec, off, size);
-        if (off + 8u <= size && (L & 7u) == 0 && !(zero_bytes(w ^ (kOnes * '\n')) | zero_bytes(w ^ (kOnes * '\r')))) {      // eight bases, no line end among them
-            const uint64_t codes = base_codes(w);
-            any |= codes;
-            store_word(seqs + L, codes);
-            L += 8u;
-            continue;
-        }
-        const uint32_t behind = off + 8u < size ? rec[off + 8u] : (uint32_t)'\n';      // the byte behind the word; the record's end counts as a line end
-        for (uint32_t j = 0; j < 8u && off + j < size; ++j) {
-            const uint32_t c = (uint32_t)(w >> (8u * j)) & 0xFFu;
-            if (c == '\n') continue;
-            if (c == '\r') {
-                const uint32_t next = off + j + 1u >= size ? (uint32_t)'\n' : j < 7u ? (uint32_t)(w >> (8u * (j + 1u))) & 0xFFu : behind;
-                if (next == '\n') continue;
-            }
-            const uint32_t code = base_code(c);
-            any |= code;
-            group |= (uint64_t)code << (8u * (L & 7u));
-            if ((++L & 7u) == 0) {
-                store_word(seqs + L - 8u, group);
-                group = 0;
-            }
-        }
+        if (off + 8u <= size && !(zero_bytes(w ^ (kOnes * '\n')) | zero_bytes(w ^ (kOnes * '\r')))) L += 8u;
+        else
+            for (uint32_t j = 0; j < 8u && off + j < size; ++j) L += line_end_byte(rec, size, off, w, j) ? 0u : 1u;
     }
-    for (uint64_t k = L & ~(uint64_t)7u; k < L; ++k) seqs[k] = (uint8_t)(group >> (8u * (k & 7u)));
     if (header_len <= 2u * L + 2u) return kTooShort;
     const P h = rec + 1;
     uint64_t end = header_len - 2u * L - 3u;
@@ -169,22 +190,30 @@ RSQ_HD RecordError parse_record(P rec, uint64_t size, uint8_t *seqs, uint8_t *do
         if (d > 9u) return kFragmentLength;
         v = v * 10u + d;
     }
-    if (any & (kOnes * 4u)) return kContainsN;
     f.len = (uint32_t)L;
     f.id_len = (uint32_t)end;
     f.frag_len = v;
-    // the systematic errors: whole 8-byte groups, the rest by bytes (the arrays' bytes behind [0, L) belong to the record as well, but stay untouched)
+    // bases, dominant errors and rates: eight at a time where eight bases stand in one word of the text, one by one around the line ends
     const uint64_t hs = header_len;
-    uint64_t k = 0;
-    for (; k + 8u <= L; k += 8u) {
-        store_word(dom + k, base_codes(word_at(h, dom_at + k, hs)));
-        store_word(rate + k, rate_percents(word_at(h, rate_at + k, hs)));
+    uint64_t k = 0, any = 0;
+    for (uint64_t off = line_end + 1u; off < size; off += 8u) {
+        const uint64_t w = word_at(rec, off, size);
+        if (off + 8u <= size && !(zero_bytes(w ^ (kOnes * '\n')) | zero_bytes(w ^ (kOnes * '\r')))) {
+            const uint64_t codes = base_codes(w);
+            any |= codes;
+            out.eight(k, codes, base_codes(word_at(h, dom_at + k, hs)), rate_percents(word_at(h, rate_at + k, hs)));
+            k += 8u;
+            continue;
+        }
+        for (uint32_t j = 0; j < 8u && off + j < size; ++j) {
+            if (line_end_byte(rec, size, off, w, j)) continue;
+            const uint32_t code = base_code((uint32_t)(w >> (8u * j)) & 0xFFu);
+            any |= code;
+            out.one(k, code, base_code(h[dom_at + k]), rate_percent(h[rate_at + k]));
+            ++k;
+        }
     }
-    for (; k < L; ++k) {
-        dom[k] = (uint8_t)base_code(h[dom_at + k]);
-        rate[k] = (uint8_t)rate_percent(h[rate_at + k]);
-    }
-    return kRecordOk;
+    return any & (kOnes * 4u) ? kContainsN : kRecordOk;
 }
 
 #if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)
@@ -250,9 +279,9 @@ __global__ void __launch_bounds__(256) k_fasta_lead(const uint8_t *text, uint32_
 // that follow each other through the lanes (from the 16-byte boundary below the stretch: device allocations begin and end on one, so the loads stay inside).
 constexpr uint32_t kRecordsBlock = 256, kStageBytes = 144u << 10;
 template <class P>
-__device__ uint32_t record_of_lane(P rec, uint64_t size, uint32_t i, uint32_t at, const Records &r, uint8_t *seqs, uint8_t *dom, uint8_t *rate, uint32_t *summary) {
+__device__ uint32_t record_of_lane(P rec, uint64_t size, uint32_t i, uint32_t at, const Records &r, uint16_t *codes, uint32_t *summary) {
     RecordFields f{0, 0, 0, 0};
-    const RecordError e = parse_record(rec, size, seqs + at, dom + at, rate + at, f);
+    const RecordError e = parse_record(rec, size, Packed{codes + at}, f);
     r.len[i] = f.len;
     r.id_len[i] = f.id_len;
     r.frag_len[i] = f.frag_len;
@@ -260,7 +289,7 @@ __device__ uint32_t record_of_lane(P rec, uint64_t size, uint32_t i, uint32_t at
     if (e != kRecordOk) atomicMin(&summary[1], i);
     return e == kRecordOk ? f.len : 0u;
 }
-__global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *text, uint32_t n, Records r, uint8_t *seqs, uint8_t *dom, uint8_t *rate, uint32_t *summary) {
+__global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *text, uint32_t n, Records r, uint16_t *codes, uint32_t *summary) {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     const uint32_t first = blockIdx.x * kRecordsBlock, last = min(first + kRecordsBlock, n), i = first + threadIdx.x;
     const uint32_t begin = r.at[first], end = r.at[last];
@@ -278,8 +307,8 @@ __global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *
     if (i < n) {
         const uint32_t at = r.at[i];
         const uint64_t size = (uint64_t)r.at[i + 1] - at;
-        longest = staged ? record_of_lane((const RSQ_LDS uint8_t *)stage + skew + (at - begin), size, i, at, r, seqs, dom, rate, summary)
-                         : record_of_lane(text + at, size, i, at, r, seqs, dom, rate, summary);
+        longest = staged ? record_of_lane((const RSQ_LDS uint8_t *)stage + skew + (at - begin), size, i, at, r, codes, summary)
+                         : record_of_lane(text + at, size, i, at, r, codes, summary);
     }
     for (uint32_t d = 32; d; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)d, 64));      // one atomic per wave, not per record
     if ((threadIdx.x & 63u) == 0 && longest) atomicMax(&summary[0], longest);

@@ -2082,6 +2082,66 @@ RSQ_HD RecordSrc record_src_at(const uint8_t *seqs, const uint8_t *dom, const ui
 // 47.2 -> 42.5 ms per 10 M pairs, seqToIllumina records 22.9 -> 22.1 ms per 8 M, configs[4] at 1/10 scale 107.5 -> 112.8 M pairs/s -- with the screen's loads
 // issued a quad at a time (RSQ_SCREEN_BATCH 1; two at a time the walking kernels lose 3-7 % at 1024 threads).  RSQ_FILL_BLOCK_WALK: the kernels whose source walks
 // per-lane state (variants, records), should a build want them smaller.
+// The same for records parsed on the device (rsq_fasta.h Packed): a half-word per base -- base code in bits 0-1, dominant error in bits 2-4, error percent in
+// bits 8-15 -- so the lane's eight bases of all three come with ONE 16-byte load (RecordSrc: three 8-byte loads, each touching a cache line of the lane's own).
+struct PackedRecordSrc {
+    const uint16_t *codes;
+    uint32_t len;
+    uint32_t safe;                   // half-words from the record's first one to the end of the array
+    mutable uint32_t group;
+    mutable uint64_t lo, hi;         // bases 0-3 and 4-7 of the held group
+    RSQ_HD void hold(uint32_t k) const {
+        const uint32_t g = k >> 3;
+        if (g == group) return;
+        group = g;
+        const uint16_t *p = codes + 8u * g;
+        if (8u * g + 8u <= safe) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            lo = *reinterpret_cast<const uint64_t __attribute__((aligned(2))) *>(p);
+            hi = *reinterpret_cast<const uint64_t __attribute__((aligned(2))) *>(p + 4);
+#else
+            memcpy(&lo, p, 8);
+            memcpy(&hi, p + 4, 8);
+#endif
+        } else {
+            lo = hi = 0;
+            for (uint32_t j = 0; j < 8u && 8u * g + j < safe; ++j) (j < 4u ? lo : hi) |= (uint64_t)p[j] << (16u * (j & 3u));
+        }
+    }
+    RSQ_HD uint32_t half(uint32_t k) const {
+        hold(k);
+        return (uint32_t)(((k & 4u) ? hi : lo) >> (16u * (k & 3u))) & 0xFFFFu;
+    }
+    RSQ_HD uint32_t org_len() const { return len; }
+    RSQ_HD uint32_t base(uint32_t k) const { return half(k) & 3u; }
+    RSQ_HD uint32_t sys_base(uint32_t k) const {
+        const uint32_t h = half(k);
+        return ((h >> 2) & 7u) | (h & 0xFF00u);
+    }
+    RSQ_HD uint32_t sys_deleted(uint32_t k) const { return sys_base(k); }
+    // Simulator.cpp:482-489 over the groups, from the last one down (the first stays held): a base is G/C iff its two bits differ, the rates are the high bytes
+    RSQ_HD void totals(uint32_t n, uint32_t &gc, uint32_t &rate_sum) const {
+        const uint64_t kHalfOnes = 0x0001000100010001ull;
+        for (uint32_t g = (n + 7u) >> 3; g--;) {
+            hold(g * 8u);
+            const uint32_t left = n - g * 8u;                                 // bases of this group that count
+            for (uint32_t part = 0; part < 2u; ++part) {
+                const uint32_t mine = left > 4u * part ? (left - 4u * part < 4u ? left - 4u * part : 4u) : 0u;
+                if (!mine) continue;
+                const uint64_t keep = mine >= 4u ? ~0ull : (1ull << (16u * mine)) - 1ull, w = (part ? hi : lo) & keep;
+#if defined(__HIP_DEVICE_COMPILE__)
+                gc += (uint32_t)__popcll((w ^ (w >> 1)) & kHalfOnes);
+#else
+                gc += (uint32_t)__builtin_popcountll((w ^ (w >> 1)) & kHalfOnes);
+#endif
+                rate_sum += (uint32_t)((((w >> 8) & 0x00FF00FF00FF00FFull) * kHalfOnes) >> 48);
+            }
+        }
+    }
+};
+RSQ_HD PackedRecordSrc packed_record_src(const uint16_t *codes, uint32_t at, uint32_t len, uint32_t halfwords) {
+    return PackedRecordSrc{codes + at, len, halfwords - at, 0xFFFFFFFFu, 0, 0};
+}
 #ifndef RSQ_FILL_BLOCK
 #define RSQ_FILL_BLOCK 1024
 #endif
@@ -2439,28 +2499,35 @@ struct RecordJob {
     // nullptr: record i is bytes [i * read_len, (i + 1) * read_len) of the arrays; else bytes [rec_at[i], rec_at[i] + rec_len[i]) of arrays of array_bytes bytes
     const uint32_t *rec_at, *rec_len;
     uint32_t array_bytes;
+    // records parsed on the device (the PACKED kernels): a half-word per base at rec_at[i] of `codes` (array_bytes half-words), seqs / dom / rate unused
+    const uint16_t *codes;
 };
 // lane = record i if active; `row`: its row of the raw arrays (i, or binned its place in perm: the text / array kernels go through perm as well)
-template <uint32_t MASK, bool BINNED>
+template <uint32_t MASK, bool BINNED, bool PACKED>
 __device__ void fill_record_chunk(const DevSim &S, const RecordJob &job, RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t bin_tile, uint64_t i, uint64_t row, bool active,
                                   const RawLayout &raw) {
     const uint64_t idx = job.first_index + i;
     const Stream st{S.seed, (uint32_t)idx, (uint32_t)(idx >> 32), 0u, pair_c3(kDomErrModel, 0, seg)};
-    const RecordSrc src = job.rec_at ? record_src_at(job.seqs, job.dom, job.rate, job.rec_at[i], job.rec_len[i], job.array_bytes)
-                                     : record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
     ReadOut out = raw.out_of(active ? row : 0u);
     ReadMeta meta;
     const uint32_t tile = BINNED ? bin_tile : (active ? draw_tile(S, st.c0, st.c1, st.c2, pair_c3(kDomErrModel, 0, 2)) : 0u);
-    fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
+    if constexpr (PACKED) {
+        const PackedRecordSrc src = packed_record_src(job.codes, job.rec_at[i], job.rec_len[i], job.array_bytes);
+        fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
+    } else {
+        const RecordSrc src = job.rec_at ? record_src_at(job.seqs, job.dom, job.rate, job.rec_at[i], job.rec_len[i], job.array_bytes)
+                                         : record_src(job.seqs, job.dom, job.rate, job.read_len, i, job.n_records);
+        fill_wave_reads<MASK>(S, img, qbase, seg, active, st, tile, job.frag_len[i], src, out, meta);
+    }
     if (active) raw.meta[row] = meta;
 }
-template <uint32_t MASK, bool BINNED>
+template <uint32_t MASK, bool BINNED, bool PACKED>
 __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJob &job, const RawLayout &raw, uint32_t *chunk_counters, const FillBins &bins) {
     extern __shared__ __attribute__((aligned(16))) float lds_image[];
     if constexpr (BINNED) {
         fill_binned_loop<MASK>(S, lds_image, bins, [&](RSQ_LDS float *img, uint32_t qbase, uint32_t seg, uint32_t tile, uint32_t place, bool active) {
             const uint32_t row = place + (threadIdx.x & 63u);
-            fill_record_chunk<MASK, true>(S, job, img, qbase, seg, tile, active ? bins.perm[row] : 0u, row, active, raw);
+            fill_record_chunk<MASK, true, PACKED>(S, job, img, qbase, seg, tile, active ? bins.perm[row] : 0u, row, active, raw);
         });
     } else {
         const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
@@ -2476,13 +2543,13 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
             if (first >= n_mine) break;
             const bool active = first + lane < n_mine;
             const uint32_t i = active ? index[first + lane] : 0u;
-            fill_record_chunk<MASK, false>(S, job, img, qbase, seg, 0u, i, i, active, raw);
+            fill_record_chunk<MASK, false, PACKED>(S, job, img, qbase, seg, 0u, i, i, active, raw);
         }
     }
 }
-template <uint32_t MASK, bool BINNED = false>
+template <uint32_t MASK, bool BINNED = false, bool PACKED = false>
 __global__ void __launch_bounds__(kFillBlockWalk) k_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {
-    fill_records_body<MASK, BINNED>(S, job, raw, chunk_counters, bins);
+    fill_records_body<MASK, BINNED, PACKED>(S, job, raw, chunk_counters, bins);
 }
 #if !defined(RSQ_SPEC)
 // ReadLength (Simulator.h:185-198) looks a record's fragment length up in InsertLengths() and ReadLengthsByFragmentLength(segment) with Vect::at, which ends the

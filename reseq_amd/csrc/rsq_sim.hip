@@ -185,7 +185,7 @@ struct rsq_sim : SimState {
         DevBuf slot_table;             // SlotInfo per slot of the batch (variants of any kind)
         DevBuf counts, offsets, tile_sums, scan_total, frags, raw_seq, raw_qual, raw_ops, raw_meta, sizes, off_r1, off_r2, fill_counters, hits, hit_count, cands, pairs_of, pair_off, templates, rec_flags, rec_index, rec_count;
         DevBuf bin_keys, bin_small, bin_perm, bin_frags, bin_fvars;      // reads binned by tile: key per item; histogram, bins, counters (one small buffer); the sorted items
-        DevBuf fa_counts, fa_first, fa_at, fa_len, fa_id_len, fa_frag_len, fa_seg, fa_seqs, fa_dom, fa_rate, fa_summary;      // rsq_sim_error_model_fasta (rsq_fasta.h)
+        DevBuf fa_counts, fa_first, fa_at, fa_len, fa_id_len, fa_frag_len, fa_seg, fa_codes, fa_summary;      // rsq_sim_error_model_fasta (rsq_fasta.h)
         DevBuf cell_info;              // the sieve without variants: per candidate the first strand's count and the two strands (k_sieve_finish<0> -> k_sieve_emit<0>)
         hipEvent_t text_done = nullptr;      // the text stage that last read this set's arrays
     } ws[2];
@@ -543,18 +543,18 @@ static const uint32_t *launch_fill_mask(rsq_sim &s, const Fragment *frags, uint6
         if (fill_is_binned(s)) return launch_fill_kernel<MASK, VAR, true>(s, frags, n_pairs, adapter_first, raw, st, fvars);
     return launch_fill_kernel<MASK, VAR, false>(s, frags, n_pairs, adapter_first, raw, st, fvars);
 }
-template <uint32_t MASK, bool BINNED>
+template <uint32_t MASK, bool BINNED, bool PACKED>
 static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     FillBins bins{};
     if (BINNED)
         bins = build_fill_bins(s, n, 2 * s.dev.n_tiles, st, [&](uint16_t *keys, uint32_t *hist) {
             hipLaunchKernelGGL(k_record_tiles, dim3(cdiv(n, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, seg_dev, job.first_index, n, keys, hist);
         });
-    const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED>);
+    const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED, PACKED>);
     const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1, kFillBlockWalk);
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
-    hipFunction_t spec = spec_kernel(s, SpecKind::kRecords, MASK, false, BINNED);
+    hipFunction_t spec = spec_kernel(s, SpecKind::kRecords, MASK, PACKED, BINNED);      // (the variant's `var` flag names the packed records here)
     s.timers["fill_reads"].start(st);
     if (spec) {
         uint32_t *counters = s.cur->fill_counters.as<uint32_t>();
@@ -563,7 +563,7 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
         void *args[] = {&s.dev, &job_arg, &raw_arg, &counters, &bins};
         HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlockWalk, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
-        hipLaunchKernelGGL((k_fill_records<MASK, BINNED>), dim3(blocks), dim3(kFillBlockWalk), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
+        hipLaunchKernelGGL((k_fill_records<MASK, BINNED, PACKED>), dim3(blocks), dim3(kFillBlockWalk), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
     HIP_CHECK(hipGetLastError());
     return bins.perm;
@@ -571,8 +571,8 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
 template <uint32_t MASK>
 static const uint32_t *launch_records_mask(rsq_sim &s, const RecordJob &job, const uint8_t *seg_dev, uint64_t n, const RawLayout &raw, hipStream_t st) {
     if constexpr (MASK != 0)
-        if (fill_is_binned(s)) return launch_records_kernel<MASK, true>(s, job, seg_dev, n, raw, st);
-    return launch_records_kernel<MASK, false>(s, job, seg_dev, n, raw, st);
+        if (fill_is_binned(s)) return job.codes ? launch_records_kernel<MASK, true, true>(s, job, seg_dev, n, raw, st) : launch_records_kernel<MASK, true, false>(s, job, seg_dev, n, raw, st);
+    return job.codes ? launch_records_kernel<MASK, false, true>(s, job, seg_dev, n, raw, st) : launch_records_kernel<MASK, false, false>(s, job, seg_dev, n, raw, st);
 }
 static const uint32_t *launch_fill_reads(rsq_sim &s, const Fragment *frags, uint64_t n_pairs, uint64_t adapter_first, const RawLayout &raw, hipStream_t st,
                               const FragmentVar *fvars = nullptr) {
@@ -1513,6 +1513,7 @@ int rsq_sim_specialize(rsq_sim *s, int kind, int *specialized) {
         const uint32_t mask = effective_fill_mask(s->dev.lds.mask, s->force_fill_mode);
         g_spec_note.clear();
         hipFunction_t fn = spec_kernel(*s, kind == 0 ? SpecKind::kReads : SpecKind::kRecords, mask, kind == 0 && s->has_variants, fill_is_binned(*s));
+        if (kind == 1 && fn) fn = spec_kernel(*s, SpecKind::kRecords, mask, true, fill_is_binned(*s));      // and the kernel for records parsed on the device (packed codes)
         *specialized = fn != nullptr;
         if (!s->specialize) g_spec_note = "option specialize is 0: the library's own instantiation of the read kernel runs";
         else if (!mask) g_spec_note = "the read kernel draws in double precision from device memory (no table image): nothing to compile for the profile";
@@ -2018,7 +2019,7 @@ static void check_fragment_lengths(rsq_sim *s, uint64_t n, const uint8_t *seg_de
 // (rec_at / rec_len: records of their own lengths at their own offsets of arrays of array_bytes bytes, read_len = the longest; nullptr: n x read_len bytes)
 static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, uint32_t read_len, const uint8_t *seqs_dev, const uint8_t *seg_dev, const uint32_t *frag_len_dev,
                                   const uint8_t *dom_dev, const uint8_t *rate_dev, hipStream_t st, const uint32_t *rec_at = nullptr, const uint32_t *rec_len = nullptr,
-                                  uint32_t array_bytes = 0, bool fresh_timers = true) {
+                                  uint32_t array_bytes = 0, bool fresh_timers = true, const uint16_t *codes = nullptr) {
     // a template longer than the profile's reads needs a wider op buffer than the one sized at create time
     const uint32_t need_ops = (s->rmax + read_len + s->max_adapter + 4u + 15u) / 16u;
     if (need_ops > s->ops_stride) s->ops_stride = need_ops;
@@ -2039,7 +2040,7 @@ static RawLayout error_model_fill(rsq_sim *s, uint64_t first_index, uint64_t n, 
         hipLaunchKernelGGL(k_record_partition, rgrid, rblock, 0, st, seg_dev, n, s->cur->offsets.as<uint64_t>(), s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>());
         HIP_CHECK(hipGetLastError());
     }
-    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>(), n, rec_at, rec_len, array_bytes};
+    const RecordJob job{first_index, read_len, seqs_dev, dom_dev, rate_dev, frag_len_dev, s->cur->rec_index.as<uint32_t>(), s->cur->rec_count.as<uint32_t>(), n, rec_at, rec_len, array_bytes, codes};
     raw.order = launch_fill_records(*s, job, seg_dev, n, raw, st);
     return raw;
 }
@@ -2123,7 +2124,7 @@ static std::string record_message(const std::vector<uint8_t> &rec) {
     std::vector<uint8_t> scratch[3];
     for (auto &v : scratch) v.resize(rec.size() + 8);
     fasta::RecordFields f{0, 0, 0, 0};
-    const fasta::RecordError e = fasta::parse_record(rec.data(), rec.size(), scratch[0].data(), scratch[1].data(), scratch[2].data(), f);
+    const fasta::RecordError e = fasta::parse_record(rec.data(), rec.size(), fasta::ByteArrays{scratch[0].data(), scratch[1].data(), scratch[2].data()}, f);
     const size_t line_end = (size_t)fasta::find_byte(rec.data(), 1, rec.size(), '\n');
     size_t header_len = line_end - 1;
     if (header_len && rec[line_end - 1] == '\r') --header_len;
@@ -2184,9 +2185,7 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
         w.fa_id_len.reserve(roomy((size_t)n * 4));
         w.fa_frag_len.reserve(roomy((size_t)n * 4));
         w.fa_seg.reserve(roomy(n));
-        w.fa_seqs.reserve(roomy(text_len + 8));
-        w.fa_dom.reserve(roomy(text_len + 8));
-        w.fa_rate.reserve(roomy(text_len + 8));
+        w.fa_codes.reserve(roomy(2 * (text_len + 8)));                // a half-word per byte of text: a record's codes lie at its own offset
         uint32_t *summary = w.fa_summary.as<uint32_t>();
         const uint32_t init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
         uint32_t *mail = reinterpret_cast<uint32_t *>(&s->mailbox[0]);              // [0..3] summary, [4] the first start, [5] the last start
@@ -2207,8 +2206,7 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
                 return true;
             }();
             (void)lds_set;
-            hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_seqs.as<uint8_t>(),
-                               w.fa_dom.as<uint8_t>(), w.fa_rate.as<uint8_t>(), summary);
+            hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_codes.as<uint16_t>(), summary);
         }
         s->timers["parse_records"].stop(st);
         HIP_CHECK(hipGetLastError());
@@ -2230,8 +2228,8 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
         *consumed = final || !starts ? text_len : last_start;
         *n_records = n;
         if (!n) return (int)RSQ_OK;
-        const RawLayout raw = error_model_fill(s, first_index, n, longest, w.fa_seqs.as<uint8_t>(), w.fa_seg.as<uint8_t>(), w.fa_frag_len.as<uint32_t>(), w.fa_dom.as<uint8_t>(),
-                                               w.fa_rate.as<uint8_t>(), st, w.fa_at.as<uint32_t>(), w.fa_len.as<uint32_t>(), (uint32_t)text_len + 8u, false);
+        const RawLayout raw = error_model_fill(s, first_index, n, longest, nullptr, w.fa_seg.as<uint8_t>(), w.fa_frag_len.as<uint32_t>(), nullptr, nullptr, st, w.fa_at.as<uint32_t>(),
+                                               w.fa_len.as<uint32_t>(), (uint32_t)text_len + 8u, false, w.fa_codes.as<uint16_t>());
         return error_model_text(s, raw, n, RecordIds{text_dev, nullptr, w.fa_at.as<uint32_t>(), w.fa_id_len.as<uint32_t>()}, out_dev, out_cap, out_len, st);
     });
 }
@@ -2285,6 +2283,8 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
         InPipe in(s->device, block_bytes, plain.fd >= 0 ? n_readers : 1, fault);
         if (plain.fd >= 0) in.start_file(plain.fd, from, to, n_readers);
         else in.start_stream(seq_in);
+        // the records' read kernel for this profile, while the readers fetch the first blocks (a second of compilation the first time a profile is used)
+        (void)spec_kernel(*s, SpecKind::kRecords, effective_fill_mask(s->dev.lds.mask, s->force_fill_mode), true, fill_is_binned(*s));
         CopyStream st;
         DevBuf joined[2];                                     // the text of a call: what the call before left over (it lies in the other one), then the blocks
         int next_joined = 0;

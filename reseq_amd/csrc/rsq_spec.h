@@ -102,7 +102,7 @@ inline std::string spec_program(const std::string &literals, const SpecVariant &
              (v.binned ? "true" : "false") + ">(S, names, frags, n_pairs, adapter_only_first, raw, sizes, chunk_counters, fvars, bins);\n}\n";
     else
         t += "extern \"C\" __global__ void __launch_bounds__(kFillBlockWalk) rsq_spec_fill_records(DevSim S, RecordJob job, RawLayout raw, uint32_t *chunk_counters, FillBins bins) {\n"
-             "    fill_records_body<" + m + (v.binned ? "true" : "false") + ">(S, job, raw, chunk_counters, bins);\n}\n";
+             "    fill_records_body<" + m + (v.binned ? "true, " : "false, ") + (v.var ? "true" : "false") + ">(S, job, raw, chunk_counters, bins);\n}\n";      // (var: the records are packed)
     return t;
 }
 

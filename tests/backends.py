@@ -69,7 +69,7 @@ def emu_lib():
         L.emu_pairs_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
         L.emu_error_model.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
-        L.emu_parse_fasta.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32] + [C.c_void_p] * 8 + [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint32)] * 3
+        L.emu_parse_fasta.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32] + [C.c_void_p] * 8 + [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint32)] * 3 + [C.c_void_p]
         L.emu_draw.restype = C.c_uint32
         L.emu_draw.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_double, C.POINTER(C.c_double)]
         L.emu_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -100,9 +100,10 @@ def emu_parse_fasta(text, final=True):
     ln, idl, fl = (np.zeros(cap, np.uint32) for _ in range(3))
     seg = np.zeros(cap, np.uint8)
     seqs, dom, rate = (np.full(len(text) + 8, 0xEE, np.uint8) for _ in range(3))
+    packed = np.full(len(text) + 8, 0xEEEE, np.uint16)
     n, used, bad, kind, lead = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
     rc = L.emu_parse_fasta(buf.ctypes.data, len(text), 1 if final else 0, cap, at.ctypes.data, ln.ctypes.data, idl.ctypes.data, fl.ctypes.data, seg.ctypes.data,
-                           seqs.ctypes.data, dom.ctypes.data, rate.ctypes.data, C.byref(n), C.byref(used), C.byref(bad), C.byref(kind), C.byref(lead))
+                           seqs.ctypes.data, dom.ctypes.data, rate.ctypes.data, C.byref(n), C.byref(used), C.byref(bad), C.byref(kind), C.byref(lead), packed.ctypes.data)
     assert rc == 0
     k = n.value
     out = {"n": k, "consumed": used.value, "bad": None if bad.value == 0xFFFFFFFF else bad.value, "bad_kind": kind.value, "lead": bool(lead.value), "at": at[:k + 1].copy(),
@@ -110,6 +111,7 @@ def emu_parse_fasta(text, final=True):
     for name, arr in (("seqs", seqs), ("dom", dom), ("rate", rate)):
         out[name] = [arr[at[i]:at[i] + ln[i]].copy() for i in range(k)]
     out["arrays"] = (seqs, dom, rate)
+    out["packed"] = packed               # the device's layout: base | dominant error << 2 | percent << 8 per base, at the record's offset
     return out
 
 

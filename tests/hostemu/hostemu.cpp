@@ -705,10 +705,10 @@ int emu_error_model(void *h, uint64_t first_index, uint64_t n, uint32_t read_len
 }
 
 // rsq_sim_error_model_fasta's parsing stage (rsq_fasta.h: record_start as k_fasta_starts applies it, parse_record as a lane of k_fasta_records runs it).
-// at[cap + 1]; len / id_len / frag_len / seg[cap]; seqs / dom / rate[text_len + 8].  *bad = the first malformed record (its kind in *bad_kind) or 0xFFFFFFFF;
+// at[cap + 1]; len / id_len / frag_len / seg[cap]; seqs / dom / rate[text_len + 8]; packed[text_len + 8] (or null): the device's half-word per base.  *bad = the first malformed record (its kind in *bad_kind) or 0xFFFFFFFF;
 // *lead = 1: text other than line ends in front of the first record.  Returns -1 if cap is too small.
 int emu_parse_fasta(const uint8_t *text, uint64_t text_len, int final, uint32_t cap, uint32_t *at, uint32_t *len, uint32_t *id_len, uint32_t *frag_len, uint8_t *seg, uint8_t *seqs,
-                    uint8_t *dom, uint8_t *rate, uint32_t *n_records, uint64_t *consumed, uint32_t *bad, uint32_t *bad_kind, uint32_t *lead) {
+                    uint8_t *dom, uint8_t *rate, uint32_t *n_records, uint64_t *consumed, uint32_t *bad, uint32_t *bad_kind, uint32_t *lead, uint16_t *packed) {
     uint32_t starts = 0;
     for (uint64_t p = 0; p < text_len; ++p)
         if (fasta::record_start(text, p)) {
@@ -724,7 +724,11 @@ int emu_parse_fasta(const uint8_t *text, uint64_t text_len, int final, uint32_t 
     *bad_kind = 0;
     for (uint32_t i = 0; i < n; ++i) {
         fasta::RecordFields f{0, 0, 0, 0};
-        const fasta::RecordError e = fasta::parse_record(text + at[i], (uint64_t)at[i + 1] - at[i], seqs + at[i], dom + at[i], rate + at[i], f);
+        const fasta::RecordError e = fasta::parse_record(text + at[i], (uint64_t)at[i + 1] - at[i], fasta::ByteArrays{seqs + at[i], dom + at[i], rate + at[i]}, f);
+        if (packed) {                                                      // the device's layout of the same record: a half-word per base
+            fasta::RecordFields g{0, 0, 0, 0};
+            if (fasta::parse_record(text + at[i], (uint64_t)at[i + 1] - at[i], fasta::Packed{packed + at[i]}, g) != e) return -2;
+        }
         len[i] = f.len;
         id_len[i] = f.id_len;
         frag_len[i] = f.frag_len;

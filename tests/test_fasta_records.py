@@ -85,11 +85,15 @@ def check(text, final=True):
         for k in ("seqs", "dom", "rate"):
             assert np.array_equal(got[k][i], f[k]), (i, k)
     # nothing is written outside the records' own stretches [at, at + len) of the three arrays
+    mask = np.ones(len(got["packed"]), bool)
+    for i in range(n):
+        mask[got["at"][i]:got["at"][i] + got["len"][i]] = False
     for arr in got["arrays"]:
-        mask = np.ones(len(arr), bool)
-        for i in range(n):
-            mask[got["at"][i]:got["at"][i] + got["len"][i]] = False
         assert np.all(arr[mask] == 0xEE)
+    # the device's layout (a half-word per base at the same offsets) holds the same codes
+    seqs, dom, rate = got["arrays"]
+    want = seqs.astype(np.uint16) | (dom.astype(np.uint16) << 2) | (rate.astype(np.uint16) << 8)
+    assert np.array_equal(got["packed"][~mask], want[~mask]) and np.all(got["packed"][mask] == 0xEEEE)
     return got
 
 
