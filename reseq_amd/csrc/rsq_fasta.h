@@ -190,6 +190,9 @@ RSQ_HD RecordError parse_record(P rec, uint64_t size, const Out &out, RecordFiel
         if (d > 9u) return kFragmentLength;
         v = v * 10u + d;
     }
+    // (the fields are set HERE, not behind the conversion below: with the assignments at the function's end, hipcc 7.2 / gfx950 stored id_len = 0 in the
+    // instantiation that reads the record from HBM -- its code zeroes the register behind the loop and never sets it on the path of a good record; the
+    // instantiation on LDS was right.  tests: test_error_model_templates_beyond_the_staging)
     f.len = (uint32_t)L;
     f.id_len = (uint32_t)end;
     f.frag_len = v;
