@@ -8,6 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -1540,8 +1543,13 @@ inline void export_reference(const SimState &s, Uploader &up, const std::string 
     if (!s.has_ref) throw Error("the simulator has no reference to export");
     using namespace refio;
     const std::string tmp = path + ".writing";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) throw Error("cannot write " + tmp);
+    // the launcher puts the file into /dev/shm, which anyone may write: never through a link someone else left there, never over an existing file, and readable by the owner only
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    FILE *f = fd < 0 ? nullptr : fdopen(fd, "wb");
+    if (!f) {
+        if (fd >= 0) close(fd);
+        throw Error("cannot write " + tmp + ": " + strerror(errno));
+    }
     try {
         if (fwrite("RSQREF1", 1, 8, f) != 8) throw Error("writing the packed reference failed");
         Writer w{f};
@@ -1616,8 +1624,8 @@ inline void import_reference(SimState &s, Uploader &up, const char *data, size_t
             complete = true;
             break;
         }
+        if (head[0] == 0 || head[0] > kEnd || head[1] == 0 || count > (size - at) / head[1]) throw Error(what + ": damaged record");      // no product that could wrap
         const uint64_t bytes = count * head[1];
-        if (head[0] == 0 || head[0] > kEnd || bytes > size - at) throw Error(what + ": damaged record");
         rec[head[0]] = Record{data + at, count, head[1]};
         at += (bytes + 7) / 8 * 8;
     }
@@ -1639,7 +1647,14 @@ inline void import_reference(SimState &s, Uploader &up, const char *data, size_t
     take(kNamePtr, name_ptr);
     take(kIdPtr, id_ptr);
     take(kSeqLen, s.seq_len);
-    if (s.seq_len.size() != sc.n_seqs || name_ptr.size() != (size_t)sc.n_seqs + 1 || id_ptr.size() != (size_t)sc.n_seqs + 1 || name_ptr.back() != rec[kNames].count || id_ptr.back() != rec[kIds].count)
+    // an offset array of n + 1 entries over `total` items: from 0, non-decreasing, ending at total
+    auto offsets_fit = [](const auto &ptr, size_t n, uint64_t total) {
+        if (ptr.size() != n + 1 || ptr.front() != 0 || ptr.back() != total) return false;
+        for (size_t i = 0; i < n; ++i)
+            if (ptr[i] > ptr[i + 1]) return false;
+        return true;
+    };
+    if (s.seq_len.size() != sc.n_seqs || rec[kNames].size > 1 || rec[kIds].size > 1 || !offsets_fit(name_ptr, sc.n_seqs, rec[kNames].count) || !offsets_fit(id_ptr, sc.n_seqs, rec[kIds].count))
         throw Error(what + ": sequence tables do not fit together");
     s.ref_first_names.clear();
     s.ref_ids.clear();
@@ -1676,18 +1691,41 @@ inline void import_reference(SimState &s, Uploader &up, const char *data, size_t
     take(kWords, packed);
     take(kGcPrefix, gc_prefix);
     const uint64_t n_words = sc.hap_stride ? sc.hap_stride * (1u + sc.num_alleles) : words + 1;
-    if (packed.size() != n_words || gc_prefix.size() != n_words || s.var_ptr.size() != (size_t)sc.n_seqs + 1 || s.extra_seq_ptr.size() != (size_t)sc.n_seqs + 1)
-        throw Error(what + ": arrays of unexpected sizes");
-    upload_reference(s, up, std::move(packed), gc_prefix);
-    if (sc.has_methylation) {
-        std::vector<uint32_t> ptr, first, second;
-        std::vector<double> rate;
-        take(kMethPtr, ptr);
-        take(kMethFirst, first);
-        take(kMethSecond, second);
-        take(kMethRate, rate);
-        install_methylation(s, up, std::move(ptr), std::move(first), std::move(second), std::move(rate));
+    if (packed.size() != n_words || gc_prefix.size() != n_words || (sc.hap_stride && sc.hap_stride < words + 1)) throw Error(what + ": arrays of unexpected sizes");
+    // what the kernels index with: every offset array over its payload, every variant inside its sequence and the pool of its bases, every map entry a variant of its sequence
+    if (sc.num_alleles == 0 || sc.num_alleles > 128u || sc.variants_mode_packed > 2u || !offsets_fit(s.var_ptr, sc.n_seqs, s.variants.size()) ||
+        !offsets_fit(s.extra_seq_ptr, sc.n_seqs, s.extra.size()) || !offsets_fit(s.allele_map_ptr, sc.has_variants ? (size_t)sc.n_seqs * sc.num_alleles : 0, s.allele_map.size()))
+        throw Error(what + ": variant tables do not fit together");
+    for (uint32_t i = 0; i < sc.n_seqs; ++i) {
+        const uint32_t n_var = s.var_ptr[i + 1] - s.var_ptr[i];
+        for (uint64_t v = s.var_ptr[i]; v < s.var_ptr[i + 1]; ++v) {
+            const DevVariant &var = s.variants[v];
+            if (var.pos >= s.seq_len[i] || var.off > s.var_bases.size() || var.len > s.var_bases.size() - var.off || (v > s.var_ptr[i] && s.variants[v - 1].pos > var.pos))
+                throw Error(what + ": a variant outside its sequence or the pool of variant bases");
+        }
+        for (uint64_t e = s.extra_seq_ptr[i]; e < s.extra_seq_ptr[i + 1]; ++e)
+            if (s.extra[e].pos >= s.seq_len[i] || (s.extra[e].first_variant_id >= 0 && (uint32_t)s.extra[e].first_variant_id >= n_var)) throw Error(what + ": an extra start outside its sequence");
+        if (sc.has_variants)
+            for (uint64_t m = s.allele_map_ptr[(size_t)i * sc.num_alleles]; m < s.allele_map_ptr[(size_t)(i + 1) * sc.num_alleles]; ++m)
+                if (s.allele_map[m].pos > s.seq_len[i] || s.allele_map[m].vid > n_var) throw Error(what + ": an allele map entry outside its sequence");
     }
+    for (uint8_t b : s.var_bases)
+        if (b > 4u) throw Error(what + ": a variant base that is no base");
+    std::vector<uint32_t> meth_ptr, meth_first, meth_second;
+    std::vector<double> meth_rate;
+    if (sc.has_methylation) {
+        take(kMethPtr, meth_ptr);
+        take(kMethFirst, meth_first);
+        take(kMethSecond, meth_second);
+        take(kMethRate, meth_rate);
+        if (!offsets_fit(meth_ptr, sc.n_seqs, meth_first.size()) || meth_second.size() != meth_first.size() || meth_rate.size() != meth_first.size() * (size_t)sc.num_alleles)
+            throw Error(what + ": methylation tables do not fit together");
+        for (uint32_t i = 0; i < sc.n_seqs; ++i)
+            for (uint32_t k = meth_ptr[i]; k < meth_ptr[i + 1]; ++k)
+                if (meth_first[k] > meth_second[k] || meth_second[k] > s.seq_len[i]) throw Error(what + ": a methylation region outside its sequence");
+    }
+    upload_reference(s, up, std::move(packed), gc_prefix);
+    if (sc.has_methylation) install_methylation(s, up, std::move(meth_ptr), std::move(meth_first), std::move(meth_second), std::move(meth_rate));
 }
 
 // --readSysError: LoadSysErrorRecord (Simulator.cpp:750-769) + ReadSystematicErrors (Simulator.h:326-335).  Units consume the

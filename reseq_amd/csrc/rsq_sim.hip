@@ -492,6 +492,11 @@ static FillBins build_fill_bins(rsq_sim &s, uint64_t n_items, uint32_t n_keys, h
     HIP_CHECK(hipGetLastError());
     return FillBins{s.cur->bin_perm.as<uint32_t>(), bin_first, bin_count, chunk_ptr, next_chunk, workers, n_bins, s.cur->bin_frags.as<Fragment>(), s.cur->bin_fvars.as<FragmentVar>()};
 }
+// the same opt-in for a kernel compiled for the profile (a module function).  The runtime of this image launches module functions with up to the device's 160 KB
+// without it and knows the attribute for host-registered functions only, so an error here is not one of the launch -- the launch itself is checked.
+static void spec_allow_lds(hipFunction_t fn, size_t lds_bytes) {
+    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) (void)hipGetLastError();
+}
 template <class Kernel>
 static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kernel kernel) {
     const size_t lds_bytes = (screened ? (size_t)s.dev.lds.total_words * 4u : 0) + (binned ? kSchedWords * 4u : 0);
@@ -529,6 +534,7 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
         uint32_t *sizes = s.cur->sizes.as<uint32_t>(), *counters = s.cur->fill_counters.as<uint32_t>();
         RawLayout raw_arg = raw;
         void *args[] = {&s.dev, &s.names, &frags, &n_pairs, &adapter_first, &raw_arg, &sizes, &counters, &fvars, &bins};
+        spec_allow_lds(spec, lds_bytes);
         HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kBlock, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
         hipLaunchKernelGGL((k_fill_reads<MASK, VAR, BINNED>), dim3(blocks), dim3(kBlock), lds_bytes, st, s.dev, s.names, frags, n_pairs, adapter_first, raw, s.cur->sizes.as<uint32_t>(),
@@ -561,6 +567,7 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
         RecordJob job_arg = job;
         RawLayout raw_arg = raw;
         void *args[] = {&s.dev, &job_arg, &raw_arg, &counters, &bins};
+        spec_allow_lds(spec, lds_bytes);
         HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlockWalk, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
         hipLaunchKernelGGL((k_fill_records<MASK, BINNED, PACKED>), dim3(blocks), dim3(kFillBlockWalk), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
@@ -2201,11 +2208,8 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
         const fasta::Records rec{w.fa_at.as<uint32_t>(), w.fa_len.as<uint32_t>(), w.fa_id_len.as<uint32_t>(), w.fa_frag_len.as<uint32_t>(), w.fa_seg.as<uint8_t>()};
         if (lead_end) hipLaunchKernelGGL(fasta::k_fasta_lead, dim3(std::min(1024u, cdiv(lead_end, 256))), dim3(256), 0, st, text, lead_end, summary);
         if (n) {
-            static const bool lds_set = [] {
-                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fasta::k_fasta_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fasta::kStageBytes));
-                return true;
-            }();
-            (void)lds_set;
+            // per launch like fill_lds_bytes: function attributes belong to the device the call runs on, and a process may hold simulators on several
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fasta::k_fasta_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fasta::kStageBytes));
             hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_codes.as<uint16_t>(), summary);
         }
         s->timers["parse_records"].stop(st);
@@ -2225,7 +2229,7 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
             g_last_error = record_message(record);
             return (int)RSQ_EIO;
         }
-        *consumed = final || !starts ? text_len : last_start;
+        *consumed = final ? text_len : (starts ? last_start : 0);      // no record starts in a block that is not the last: nothing consumed, the caller hands in more
         *n_records = n;
         if (!n) return (int)RSQ_OK;
         const RawLayout raw = error_model_fill(s, first_index, n, longest, nullptr, w.fa_seg.as<uint8_t>(), w.fa_frag_len.as<uint32_t>(), nullptr, nullptr, st, w.fa_at.as<uint32_t>(),

@@ -153,27 +153,32 @@ def load_once_per_host(make_backend, dist, device, local_rank, local_world, node
     path = os.path.join(shm_dir, f"rsq_packed_reference_{int(token.item()):014x}_host{node}")
     loader = local_rank == 0
     backend, error = None, None
-    if loader:
-        def load_and_export():
-            b = make_backend(None)
-            try:
-                b.export_reference(path)
-            except Exception:
-                b.close()
-                raise
-            return b
-        backend, error = _attempt(load_and_export)
-    _agree(dist, device, error, "loading and packing the reference for its host")
-    if not loader:
-        backend, error = _attempt(make_backend, path)
     try:
+        if loader:
+            def load_and_export():
+                b = make_backend(None)
+                try:
+                    b.export_reference(path)
+                except Exception:
+                    b.close()
+                    raise
+                return b
+            backend, error = _attempt(load_and_export)
+        _agree(dist, device, error, "loading and packing the reference for its host")
+        if not loader:
+            backend, error = _attempt(make_backend, path)
         _agree(dist, device, error, "taking the packed reference of its host")
+    except BaseException:
+        if backend is not None:                                      # some rank failed: this one gives its device memory back before the job ends
+            backend.close()
+        raise
     finally:
         if loader:
-            try:
-                os.unlink(path)                                      # every rank of the host has it in its own memory by now (or the job is over)
-            except OSError:
-                pass
+            for name in (path, path + ".writing"):                   # every rank of the host has it in its own memory by now -- or the job is over either way
+                try:
+                    os.unlink(name)
+                except OSError:
+                    pass
     return backend
 
 

@@ -400,6 +400,66 @@ def case_packed_reference(backend_cls, workdir):
             d.import_reference(workdir / "cut.ref")
     finally:
         d.close()
+    # a file someone else may have written (the launcher's /dev/shm): every crafted record below is refused by name, none reaches an array index.
+    # Layout: "RSQREF1\0", then {u32 tag, u32 element size, u64 count, bytes padded to 8} (rsq_pack.h refio)
+    import struct
+    records, at = [], 8
+    while True:
+        tag, size, count = struct.unpack_from("<IIQ", data, at)
+        records.append((tag, size, count, at + 16))
+        if tag == 20:                                                      # kEnd
+            break
+        at += 16 + (count * size + 7) // 8 * 8
+    place = {tag: (size, count, body) for tag, size, count, body in records}
+
+    def crafted(tag, index, value, fmt):
+        size, count, body = place[tag]
+        out = bytearray(data)
+        struct.pack_into(fmt, out, body + (index % count) * size, value)
+        return bytes(out)
+
+    def header(tag, size=None, count=None):
+        out = bytearray(data)
+        old_size, old_count, body = place[tag]
+        struct.pack_into("<IQ", out, body - 12, old_size if size is None else size, old_count if count is None else count)
+        return bytes(out)
+    tampered = {
+        "count times size wraps": (header(7, size=1 << 31, count=(1 << 33) + 1), "damaged record"),              # kWords
+        "element size 0": (header(7, size=0), "damaged record"),
+        "name offsets decrease": (crafted(3, 1, 1 << 40, "<Q"), "sequence tables"),                                # kNamePtr
+        "id offsets past the ids": (crafted(5, -1, 1 << 40, "<Q"), "sequence tables"),                             # kIdPtr
+        "variant offsets past the variants": (crafted(10, -1, 1 << 30, "<I"), "variant tables"),                   # kVarPtr
+        "variant offsets decrease": (crafted(10, 1, 0xFFFFFFF0, "<I"), "variant tables"),
+        "allele map offsets past the map": (crafted(13, -1, 1 << 30, "<I"), "variant tables"),                     # kAlleleMapPtr
+        "extra start offsets past the list": (crafted(15, -1, 1 << 30, "<I"), "variant tables"),                   # kExtraSeqPtr
+        "a variant behind its sequence": (crafted(9, 0, 0x7FFFFFFF, "<I"), "a variant outside"),                   # kVariants[0].pos
+        "a map entry of no variant": (crafted(12, 0, 0x7FFFFFFF, "<I"), "allele map entry"),                       # kAlleleMap[0].pos
+        "methylation offsets past the regions": (crafted(16, -1, 1 << 30, "<I"), "methylation tables"),            # kMethPtr
+        "a region behind its sequence": (crafted(18, 0, 0x7FFFFFFF, "<I"), "methylation region"),                  # kMethSecond
+        "fewer conversion rates than regions": (header(19, count=place[19][1] - 1), "methylation tables|damaged|incomplete"),
+    }
+    for what, (blob, message) in tampered.items():
+        (workdir / "tampered.ref").write_bytes(blob)
+        d = backend_cls(ppath, None, 0)
+        try:
+            with pytest.raises(Exception, match=message):
+                d.import_reference(workdir / "tampered.ref")
+        finally:
+            d.close()
+    # the export neither follows a link left at its temporary name nor writes over a file there
+    a = backend_cls(ppath, fpath, 0)
+    try:
+        victim = workdir / "victim.txt"
+        victim.write_text("untouched")
+        (workdir / "linked.ref.writing").symlink_to(victim)
+        with pytest.raises(Exception, match="cannot write"):
+            a.export_reference(workdir / "linked.ref")
+        assert victim.read_text() == "untouched" and not (workdir / "linked.ref").exists()
+        (workdir / "linked.ref.writing").unlink()
+        a.export_reference(workdir / "linked.ref")
+        assert ((workdir / "linked.ref").stat().st_mode & 0o777) == 0o600
+    finally:
+        a.close()
 
 
 def case_profile_edits(backend_cls, workdir):
