@@ -13,6 +13,10 @@ are split into contiguous ranges by reseq_amd.sharding.partition_blocks and ever
 sharded by reference block").  Per-GPU work is fixed as N grows (weak scaling); blocks are independent, so there is no
 data-path collective -- torch.distributed (RCCL) carries the timing barrier and the job totals.  `value` is the whole-job
 aggregate.  Prints ONE JSON line on rank 0.
+
+--scaling strong: the fixed-size job instead -- ONE such sequence and 10 M pairs whatever N is, its blocks split over the N ranks
+by expected pairs (sharding.block_weights); the line says "scaling": "strong".  Under --gpus N > 1 the default (weak) line also
+carries a `strong_scaling` leg measured after the headline's timed region, so that one driver run records both kinds.
 """
 import argparse
 import glob
@@ -271,6 +275,72 @@ class TorchBuffer:
         self.ptr, self.nbytes = self.t.data_ptr(), int(nbytes)
 
 
+class PairsJob:
+    """One illuminaPE job on this rank's device: profile + reference loaded, pre-passes done, the rank's block range (balanced by expected pairs) cut into
+    batches, FASTQ buffers sized from the largest batch.  measure() = `warmup` untimed steps, then `steps` timed ones bracketed by synchronize + barrier."""
+
+    def __init__(self, torch, dist, dev, rank, world, profile_path, fasta_path, seed, total_pairs, seq_lens, batch_blocks):
+        self.torch, self.dist = torch, dist
+        self.prof = api.Profile(profile_path)
+        self.ref = api.Reference(fasta_path, seed)
+        self.sim = api.Simulator(self.prof, self.ref, dev.index)
+        t0 = time.perf_counter()
+        self.info = self.sim.prepare(seed, total_pairs)
+        self.prep_s = time.perf_counter() - t0
+        weights = sharding.block_weights(seq_lens, self.info.insert_to, self.sim.ref_seq_bias(len(seq_lens)))
+        self.my_lo, self.my_hi = sharding.partition_blocks(self.info.total_blocks, world, weights)[rank]
+        self.batches = sharding.batches(self.my_lo, self.my_hi, batch_blocks)
+        # size the FASTQ buffers once from the largest batch (first pass measures), then reuse them
+        self.need1 = self.need2 = 0
+        for lo, hi in self.batches:
+            n, l1, l2, rc = self.sim.pairs_device(lo, hi, None, None)
+            if rc not in (api.RSQ_OK, api.RSQ_ENOSPC):
+                raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+            self.need1, self.need2 = max(self.need1, l1), max(self.need2, l2)
+        self.bufs = [(TorchBuffer(torch, self.need1 + 4096, dev), TorchBuffer(torch, self.need2 + 4096, dev)) for _ in range(2)]
+
+    def step(self):
+        pairs = nbytes = launches = 0
+        fill_ms = 0.0
+        for lo, hi in self.batches:
+            n, l1, l2, rc = self.sim.pairs_device(lo, hi, self.bufs[0][0], self.bufs[0][1])
+            if rc != api.RSQ_OK:
+                raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+            pairs += n
+            nbytes += l1 + l2
+            if n:
+                fill_ms += self.sim.last_kernel_ms("fill_reads")              # summed over the call's launches (pipelined sub-ranges)
+                launches += self.sim.last_kernel_launches("fill_reads")
+        return pairs, nbytes, fill_ms, launches
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def measure(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        pairs = nbytes = launches = 0
+        fill_ms = 0.0
+        for _ in range(steps):
+            p, b, f, n_launch = self.step()
+            pairs += p
+            nbytes += b
+            fill_ms += f
+            launches += n_launch
+        self.sync()
+        return {"pairs": pairs, "nbytes": nbytes, "fill_ms": fill_ms, "launches": launches, "elapsed": time.perf_counter() - t0}
+
+    def close(self):
+        self.bufs = None
+        self.sim.close()
+        self.ref.close()
+        self.prof.close()
+
+
 def ranks_or_relaunch(args):
     """(rank, local rank, world size) of this process.  Started bare with --gpus N > 1 -- no launcher's environment -- the script starts its N ranks itself, one process
     per GPU through torch.distributed.run, as Simulator::Simulate starts its own workers (Simulator.cpp:2830-2836); a launcher's world size that is not --gpus is refused."""
@@ -326,14 +396,16 @@ def main_emulated(args, rank, world):
     genome, pairs_per_rank = min(args.genome, 6000), min(args.pairs, 1500)
     tmp = tempfile.mkdtemp(prefix=f"rsq_bench_emu_{rank}_")
     ppath, fpath = os.path.join(tmp, "tiny.rsqp"), os.path.join(tmp, "ref.fa")
-    synth.write_profile(ppath, synth.make_profile(synth.TINY, seed=103741084, n_ref_seqs=world))
+    n_seqs = world if args.scaling == "weak" else 1
+    synth.write_profile(ppath, synth.make_profile(synth.TINY, seed=103741084, n_ref_seqs=n_seqs))
     seqs = []
-    for i in range(world):
+    for i in range(n_seqs):
         seqs += synth.make_reference(2 + i, [genome], gc=args.gc, names=[f"synthTiny{i} len={genome}"])
     synth.write_fasta(fpath, seqs)
     sim = EmuBackend(ppath, fpath, args.seed)
-    info = sim.prepare(args.seed, pairs_per_rank * world)
-    my_lo, my_hi = sharding.partition_blocks(info["total_blocks"], world)[rank]
+    info = sim.prepare(args.seed, pairs_per_rank * n_seqs)
+    weights = sharding.block_weights([genome] * n_seqs, info["insert_to"], sim.ref_seq_bias(n_seqs))
+    my_lo, my_hi = sharding.partition_blocks(info["total_blocks"], world, weights)[rank]
     batches = sharding.batches(my_lo, my_hi, args.batch_blocks)
 
     def step():
@@ -365,8 +437,9 @@ def main_emulated(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "EMULATED on the CPU (tests/hostemu), not a measurement: simulated read-pairs/sec", "emulated": True, "value": total_pairs / elapsed, "unit": "read-pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_per_rank": per_rank,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": "TINY profile, host emulation -- the launcher's test", "backend": args.backend, "reference_bp": genome * world, "pairs_per_step": total_pairs / args.steps,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "TINY profile, host emulation -- the launcher's test", "backend": args.backend, "reference_bp": genome * n_seqs, "pairs_per_step": total_pairs / args.steps,
+                                     "collectives": None if dist is None else "torch.distributed gloo (the emulation's stand-in for RCCL): barrier, all_reduce of the totals, all_gather of the ranks' times",
                                      "fastq_bytes_per_step": total_bytes / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info["total_blocks"]}}))
     if dist is not None:
         dist.barrier()
@@ -390,6 +463,8 @@ def main():
     ap.add_argument("--emulate", action="store_true", help="TEST SWITCH, not a measurement: the launch / sharding / totals path of this script with the host emulation of the kernels "
                     "(tests/hostemu, the TINY profile, a few thousand pairs) in the device's place -- what the CPU suite runs with --gpus 2 --backend gloo")
     ap.add_argument("--dist-single", action="store_true", help="initialise torch.distributed although there is one rank (the RCCL calls of the N-rank path on one GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): N sequences and N x --pairs on N GPUs; strong: ONE sequence and --pairs pairs split over the N GPUs")
+    ap.add_argument("--no-strong-leg", action="store_true", help="with --gpus N > 1 and weak scaling: skip the extra fixed-size measurement (`strong_scaling` in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the value_to_host leg (it is skipped anyway with more than one GPU: every rank would pin 15 GB of host memory)")
     args = ap.parse_args()
@@ -405,11 +480,17 @@ def main():
     ppath = os.path.join(tmp, "p0.rsqp")
     fpath = os.path.join(tmp, "ref.fa")
     cfg = synth.P0 if args.tiles <= 1 else synth.p0_with_tiles(args.tiles)
-    synth.write_profile(ppath, synth.make_profile(cfg, seed=103741084, n_ref_seqs=world))
+    n_seqs = world if args.scaling == "weak" else 1
+    synth.write_profile(ppath, synth.make_profile(cfg, seed=103741084, n_ref_seqs=n_seqs))
     seqs = []
-    for i in range(world):
+    for i in range(n_seqs):
         seqs += synth.make_reference(2 + i, [args.genome], gc=args.gc, names=[f"synthEcoli{i} len={args.genome}"])
     synth.write_fasta(fpath, seqs)
+    ppath1, fpath1 = ppath, fpath
+    if n_seqs > 1 and not args.no_strong_leg:        # the fixed-size job of the strong-scaling leg: the first sequence alone
+        ppath1, fpath1 = os.path.join(tmp, "p0_one.rsqp"), os.path.join(tmp, "ref_one.fa")
+        synth.write_profile(ppath1, synth.make_profile(cfg, seed=103741084, n_ref_seqs=1))
+        synth.write_fasta(fpath1, seqs[:1])
 
     # the CPU oracle first (rank 0 of a single-GPU run only): its worker processes are forked before any device context exists
     baseline = oracle_text = None
@@ -428,57 +509,11 @@ def main():
     for item in args.option:                      # after torch: the library binds to the HIP runtime torch has loaded
         name, value = item.split("=", 1)
         api.set_option(name, int(value))
-    prof = api.Profile(ppath)
-    ref = api.Reference(fpath, args.seed)
-    sim = api.Simulator(prof, ref, local_rank)
-    t0 = time.perf_counter()
-    info = sim.prepare(args.seed, args.pairs * world)
-    prep_s = time.perf_counter() - t0
-    my_lo, my_hi = sharding.partition_blocks(info.total_blocks, world)[rank]
-    batches = sharding.batches(my_lo, my_hi, args.batch_blocks)
-
-    # size the FASTQ buffers once from the largest batch (first pass measures), then reuse them
-    need1 = need2 = 0
-    for lo, hi in batches:
-        n, l1, l2, rc = sim.pairs_device(lo, hi, None, None)
-        if rc not in (api.RSQ_OK, api.RSQ_ENOSPC):
-            raise api.RsqError(rc, api.lib().rsq_last_error().decode())
-        need1, need2 = max(need1, l1), max(need2, l2)
-    bufs = [(TorchBuffer(torch, need1 + 4096, dev), TorchBuffer(torch, need2 + 4096, dev)) for _ in range(2)]
-
-    def step():
-        pairs = nbytes = launches = 0
-        fill_ms = 0.0
-        for lo, hi in batches:
-            n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0][0], bufs[0][1])
-            if rc != api.RSQ_OK:
-                raise api.RsqError(rc, api.lib().rsq_last_error().decode())
-            pairs += n
-            nbytes += l1 + l2
-            if n:
-                fill_ms += sim.last_kernel_ms("fill_reads")              # summed over the call's launches (pipelined sub-ranges)
-                launches += sim.last_kernel_launches("fill_reads")
-        return pairs, nbytes, fill_ms, launches
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    pairs = nbytes = fill_launches = 0
-    fill_ms = 0.0
-    for _ in range(args.steps):
-        p, b, f, n_launch = step()
-        pairs += p
-        nbytes += b
-        fill_ms += f
-        fill_launches += n_launch
-    sync()
-    elapsed = time.perf_counter() - t0
+    job = PairsJob(torch, dist, dev, rank, world, ppath, fpath, args.seed, args.pairs * n_seqs, [args.genome] * n_seqs, args.batch_blocks)
+    sim, info, prep_s, my_lo, my_hi, bufs, need1, need2 = job.sim, job.info, job.prep_s, job.my_lo, job.my_hi, job.bufs, job.need1, job.need2
+    sync = job.sync
+    m = job.measure(args.steps, args.warmup)
+    pairs, nbytes, fill_ms, fill_launches, elapsed = m["pairs"], m["nbytes"], m["fill_ms"], m["launches"], m["elapsed"]
     kernel_ms = {k: sim.last_kernel_ms(k) for k in ("sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan")}
     plan = sim.fill_plan()
     specialized, spec_note = sim.specialize(0)                         # already done by prepare(): this asks what runs
@@ -490,6 +525,19 @@ def main():
         pass
     per_rank = rank_times(dist, f"cuda:{local_rank}", elapsed, args.steps, world)
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
+
+    # the fixed-size job beside the weak one (N > 1): ONE sequence and --pairs pairs, its blocks split over the ranks by expected pairs -- BASELINE's configs[3] / [4]
+    # are of this kind (one genome sharded over 8).  After the headline's timed region, with its own barriers and the same max-over-ranks timing.
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong_leg:
+        fixed = PairsJob(torch, dist, dev, rank, world, ppath1, fpath1, args.seed, args.pairs, [args.genome], args.batch_blocks)
+        ms = fixed.measure(args.steps, 1)
+        s_rank = rank_times(dist, f"cuda:{local_rank}", ms["elapsed"], args.steps, world)
+        s_pairs, _, s_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", ms["pairs"], ms["nbytes"], ms["elapsed"])
+        strong = {"scaling": "strong", "value": s_pairs / s_elapsed, "unit": "read-pairs/s", "ms_per_step": s_elapsed / args.steps * 1e3, "ms_per_step_per_rank": s_rank,
+                  "pairs_per_step": s_pairs / args.steps, "reference_bp": args.genome, "blocks_of_rank_0": [fixed.my_lo, fixed.my_hi], "total_blocks": fixed.info.total_blocks,
+                  "note": "ONE E. coli-sized sequence and --pairs pairs split over the ranks by sharding.block_weights; compare with the N = 1 headline of the same workload"}
+        fixed.close()
 
     # the same steps delivered to the host (what Simulator::Flush hands to the writer, Simulator.cpp:150-182): generation of batch k+1
     # overlaps the copy of batch k into page-locked host memory on a second stream
@@ -540,15 +588,15 @@ def main():
         counters = committed_counters(args.tiles)
         out = {
             "metric": "simulated read-pairs/sec (2x150 bp)", "value": total_pairs / elapsed, "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_per_rank": per_rank, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_per_rank": per_rank, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference sequence and 10 M pairs per GPU, pre-fitted synthetic profile P0 (2x150), "
+            "config": {"workload": "configs[1]: E. coli-sized 4.64 Mb synthetic reference sequence and 10 M pairs " + ("per GPU" if args.scaling == "weak" else "in all, split over the GPUs") + ", pre-fitted synthetic profile P0 (2x150), "
                                    "illuminaPE hot path (sieve + CreateReads + FASTQ text) resident in HBM" +
                                    (f" -- NOT the headline: P0 with {args.tiles} tiles (per-tile tables)" if args.tiles > 1 else ""),
-                       "tiles": args.tiles, "fill_plan": plan, "options": args.option, "reference_bp": args.genome * world,
-                       "pairs_requested": args.pairs * world, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
+                       "tiles": args.tiles, "fill_plan": plan, "options": args.option, "reference_bp": args.genome * n_seqs,
+                       "pairs_requested": args.pairs * n_seqs, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
                        "batch_blocks": args.batch_blocks, "read_kernel_launches_per_step": launches / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
-                       "sharding": "one job; contiguous block ranges per GPU (partition_blocks); no data-path collective",
+                       "sharding": "one job; contiguous block ranges per GPU balanced by expected pairs (partition_blocks with block_weights); no data-path collective",
                        "collectives": None if dist is None else "torch.distributed nccl (RCCL): barrier, all_reduce of the totals, all_gather of the ranks' times"},
             "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": counters["hbm_bytes_per_launch"] if counters else None, "traffic_source": counters["source"].replace("_pmc", "_traffic") if counters else None,
@@ -569,6 +617,8 @@ def main():
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,
         }
+        if strong:
+            out["strong_scaling"] = strong
         if to_host:
             out["value_to_host"] = to_host
         if baseline:

@@ -23,6 +23,51 @@ import time
 from . import sharding
 
 
+def _launcher_flags(ap):
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend; ranks on GPUs talk through RCCL (nccl) -- gloo only with --emulate")
+    ap.add_argument("--emulate", action="store_true", help="TEST SWITCH, not a product path: tests/hostemu's CPU loop over the kernels' per-lane functions stands where the device would be "
+                    "(the module tests/emu_ranks.py of the directory RSQ_TESTS names), so that the launcher's N-rank path runs in a container without a GPU; says so on stderr")
+    ap.add_argument("--distTimeout", type=int, default=600, help="seconds a rank waits in a collective for the others before it gives up (a rank that died takes the job with it)")
+
+
+def _emulation(a, ap):
+    """--emulate: the test-side stand-ins, or an error -- never a silent route around the device"""
+    if a.backend == "gloo" and not a.emulate:
+        ap.error("--backend gloo is for --emulate only; ranks on GPUs talk through RCCL (nccl)")
+    if not a.emulate:
+        return None
+    tests = os.environ.get("RSQ_TESTS")
+    if not tests or not os.path.exists(os.path.join(tests, "emu_ranks.py")):
+        ap.error("--emulate needs RSQ_TESTS=<the repository's tests directory> (the host emulation is test infrastructure, not part of the package)")
+    sys.path.insert(0, tests)
+    import emu_ranks
+    print(">>> EMULATED on the CPU (tests/hostemu): the launcher's test, not the product path and not a measurement", file=sys.stderr)
+    return emu_ranks
+
+
+def _start_ranks(a, local_rank):
+    """(dist or None, the device the small exchanges live on).  Under a launcher -- also one that started a single rank -- the same exchanges over RCCL (gloo: --emulate)."""
+    if "WORLD_SIZE" not in os.environ:
+        return None, "cpu" if a.emulate else f"cuda:{local_rank}"
+    import datetime
+    import torch
+    import torch.distributed as dist
+    if a.emulate:
+        dist.init_process_group(a.backend if a.backend == "gloo" else "gloo", timeout=datetime.timedelta(seconds=a.distTimeout))
+        return dist, "cpu"
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=a.distTimeout))
+    return dist, f"cuda:{local_rank}"
+
+
+def _fault(step, rank):
+    """RSQ_FAULT_INJECT=<step>:<rank> -- the named rank dies on the spot (SIGKILL: no exception, no goodbye) when it reaches the named step; the failure tests' way of
+    losing a rank in the middle of a job (tests/test_multi_gpu.py).  Steps: generate, write."""
+    if os.environ.get("RSQ_FAULT_INJECT") == f"{step}:{rank}":
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
+
+
 class GpuBackend:
     """reseq_amd.api.Simulator with reusable device buffers (the product path)."""
 
@@ -237,6 +282,7 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
         _agree(dist, device, error, "preparing the simulation")
         info, mine = prepared
     t0 = time.perf_counter()
+    _fault("generate", rank)
     generated, error = _attempt(backend.job_generate, mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
     _agree(dist, device, error, "generating its share")
     n_mine, bytes1, bytes2 = generated
@@ -286,6 +332,7 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
 
     # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
     _agree(dist, device, _attempt(create_files)[1], "creating the output files")
+    _fault("write", rank)
     if gather_output:                                                # one writer, fed by a collective
         def gathered():
             gather_to_first_rank(backend, dist, rank, world, sizes, (out1, out2), gather_slice_bytes)
@@ -364,18 +411,15 @@ def main_records(argv):
     ap.add_argument("-p", "--probabilitiesIn", dest="ipf", default=None)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own file <out>.part<k>of<N> (their concatenation in order is the single file)")
+    _launcher_flags(ap)
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if a.output.endswith(".bz2"):
         ap.error(f"{a.output}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
+    emu = _emulation(a, ap)
     import torch
     from . import api
-    dist = None
-    if "WORLD_SIZE" in os.environ:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = f"cuda:{local_rank}"
+    dist, device = _start_ranks(a, local_rank)
     seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
     if dist is not None:                                             # one seed for the whole job, all 64 bits of it
         t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
@@ -384,6 +428,8 @@ def main_records(argv):
     prof = sim = None
     try:
         def set_up():
+            if emu:
+                return None, emu.EmuRecordsSim(a.profile, seed)
             p = api.load_profile(a.profile, a.ipf)
             s = api.Simulator(p, None, local_rank)
             s.prepare(seed)
@@ -429,18 +475,17 @@ def main(argv=None):
     ap.add_argument("--gatherOutput", action="store_true", help="the ranks' text is gathered on the first rank by a collective (RCCL) in slices and written by that rank alone, "
                     "instead of every rank writing its own byte range of the files")
     ap.add_argument("--gatherSliceMB", type=int, default=256, help="--gatherOutput: bytes (MiB) per rank and round of the gather")
+    ap.add_argument("--gatherSliceBytes", type=int, default=0, help="--gatherOutput: the same in bytes (small jobs, tests); overrides --gatherSliceMB")
     ap.add_argument("--everyRankLoads", action="store_true", help="every rank reads and packs the reference, variant and methylation files itself (default: the first rank of a host "
                     "does and the host's other ranks take the packed result from shared memory)")
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own pair of files <out>.part<k>of<N> (their concatenation in order is the single file): "
                     "writes into one file serialise on its inode lock, 8 GB/s for the whole job; separate files scale with the ranks")
+    _launcher_flags(ap)
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    emu = _emulation(a, ap)
     import torch
-    dist = None
-    if "WORLD_SIZE" in os.environ:                                   # under a launcher, also one that started a single rank: the same exchanges, over RCCL
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist, device = _start_ranks(a, local_rank)
     compress = a.out1.endswith(".gz")                                # gzip members concatenate, so a rank's compressed share has a place in the file like plain text
     if a.out2.endswith(".gz") != compress:
         ap.error("the two output files are either both plain or both .gz")
@@ -451,17 +496,21 @@ def main(argv=None):
             ap.error(f"{out}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
     seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
     if dist is not None:                                             # one seed for the whole job, all 64 bits of it
-        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=f"cuda:{local_rank}")
+        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
         dist.broadcast(t, 0)
         seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
-    make = lambda packed_from: GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
+    if emu:
+        make = lambda packed_from: emu.EmuRankBackend(a.profile, a.ref, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
+    else:
+        make = lambda packed_from: GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
     if a.everyRankLoads:
         backend = make(None)
     else:
-        backend = load_once_per_host(make, dist, f"cuda:{local_rank}", local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)))
+        backend = load_once_per_host(make, dist, device, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)),
+                                     shm_dir=os.environ.get("RSQ_SHM_DIR", "/dev/shm"))
     try:
         pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
-                                  a.recordBaseIdentifier, a.batchBlocks, f"cuda:{local_rank}", a.splitOutput, a.gatherOutput, a.gatherSliceMB << 20, compress)
+                                  a.recordBaseIdentifier, a.batchBlocks, device, a.splitOutput, a.gatherOutput, a.gatherSliceBytes or a.gatherSliceMB << 20, compress)
         if rank == 0:
             print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
     finally:

@@ -54,6 +54,7 @@ def emu_lib():
         L.emu_prepare_finish.argtypes = [C.c_void_p]
         L.emu_get_info.argtypes = [C.c_void_p, C.POINTER(EmuInfo)]
         L.emu_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_get_sequence_lengths.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_get_norm_by_len.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_set_normalization.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
         L.emu_get_sys.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -172,6 +173,13 @@ class EmuBackend:
         self.L.emu_get_info(self.h, C.byref(i))
         return dict(total_pairs=i.total_pairs, adapter_only_pairs=i.adapter_only_pairs, total_blocks=i.total_blocks, n_groups=i.n_groups, insert_to=i.insert_to,
                     passes=i.passes, bias_normalization=i.bias_normalization)
+
+    def sequence_lengths(self):
+        i = EmuInfo()
+        self.L.emu_get_info(self.h, C.byref(i))
+        out = np.zeros(i.n_seqs, np.uint32)
+        self.L.emu_get_sequence_lengths(self.h, out.ctypes.data)
+        return [int(x) for x in out]
 
     def thresholds(self):
         i = self.info()

@@ -392,6 +392,11 @@ void emu_get_info(void *h, emu_info *o) {
     Emu &s = *static_cast<Emu *>(h);
     *o = emu_info{s.total_pairs, s.adapter_only_pairs, s.total_blocks, s.n_groups, s.dev.insert_to, s.passes, s.dev.n_seqs, s.rmax, s.bias_normalization};
 }
+// rsq_sim_get_sequence_lengths: n_seqs values (emu_get_info tells how many)
+void emu_get_sequence_lengths(void *h, uint32_t *out) {
+    const Emu &s = *static_cast<Emu *>(h);
+    memcpy(out, s.seq_len.data(), s.seq_len.size() * sizeof(uint32_t));
+}
 void emu_get_thresholds(void *h, double *out) {
     Emu &s = *static_cast<Emu *>(h);
     memcpy(out, s.thresholds.data(), s.thresholds.size() * 8);

@@ -1,0 +1,317 @@
+"""The N-rank path, one process per rank under torch.distributed.run, in two modes of the SAME test bodies:
+
+  rccl  (-m gpu; skipped with a reason when fewer than two devices are visible): the product -- `python -m reseq_amd.simulate` on N GPUs over RCCL, compared byte for
+        byte with the single-device command line (`reseq illuminaPE` / `reseq seqToIllumina`, Simulator.cpp:2830-2836 starts its own workers the same way and
+        :2384-2401 hands them blocks), run with 2 ranks and with min(8, devices) ranks;
+  gloo  (CPU suite): the same launcher with `--backend gloo --emulate` -- tests/hostemu where the device would be (tests/emu_ranks.py) -- compared with the same
+        module run as one rank without a launcher.
+
+What is covered: (i) illuminaPE plain, with variants + methylation, --splitOutput, --gatherOutput, .gz; (ii) seqToIllumina; (iii) the sharded pre-pass against the
+whole one; (iv) one load per host: only one rank ever opens the FASTA; (v) bench.py --gpus 2; (vi) a rank killed in the middle of the job takes the job with it."""
+import gzip
+import json
+import os
+import pathlib
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import parity_cases as P
+from reseq_amd import api, synth
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parent
+RESEQ = ROOT / "reseq_amd" / "reseq"
+
+
+def _devices():
+    try:
+        return api.device_count()
+    except Exception:      # noqa: BLE001 -- no library, no device: the gloo mode does not need one
+        return 0
+
+
+def _worlds(mode):
+    if mode == "gloo":
+        return [2]
+    n = _devices()
+    return sorted({2, min(8, n)})
+
+
+@pytest.fixture(params=["gloo", pytest.param("rccl", marks=pytest.mark.gpu)])
+def mode(request):
+    if request.param == "rccl" and _devices() < 2:
+        pytest.skip(f"the N-rank path over RCCL needs at least two visible devices ({_devices()} here); its bodies run over gloo with the host emulation in the CPU suite")
+    return request.param
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(workdir, **extra):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    e.update(PYTHONPATH=str(ROOT) + os.pathsep + e.get("PYTHONPATH", ""), RSQ_TESTS=str(HERE), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update({k: str(v) for k, v in extra.items()})
+    return e
+
+
+def launch(mode, world, args, workdir, target=("-m", "reseq_amd.simulate"), timeout=900, check=True, **env):
+    """the target under torch.distributed.run with `world` ranks on this host"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_port()), *target, *map(str, args)]
+    if mode == "gloo":
+        cmd += ["--backend", "gloo", "--emulate"]
+        env.setdefault("RSQ_SHM_DIR", workdir)                      # the packed reference of the "host" goes where the test can see that it is gone
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=_env(workdir, **env), cwd=str(ROOT))
+    if check:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    return r
+
+
+def single(mode, sub, args, workdir, **env):
+    """the single-device run the ranks' output is compared with: the command line on one GPU, or the launcher's module as one rank on the emulation"""
+    if mode == "gloo":
+        cmd = [sys.executable, "-m", "reseq_amd.simulate", *([sub] if sub == "seqToIllumina" else []), *map(str, args), "--emulate"]
+    else:
+        cmd = [str(RESEQ), sub, *map(str, args)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(workdir, **env), cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    return r
+
+
+@pytest.fixture(scope="module")
+def job(tmp_path_factory):
+    """TINY profile (three tiles, adapters, variable read lengths, indels), three sequences of which one is too short for blocks; variants of every kind on two
+    alleles with extra starts across block borders, and methylation regions with a rate per allele"""
+    work = tmp_path_factory.mktemp("multi_gpu")
+    ppath, fpath, seqs = P.make_inputs(work, "job", synth.TINY, [7000, 80, 4210])
+    vcf = work / "job.vcf"
+    P.write_vcf(vcf, seqs, P._mixed_variant_set(seqs, np.random.default_rng(5), 30, [999, 1000, 1999, 2000, 2999, 3000]))
+    names = [n.split(" ")[0] for n, _ in seqs]
+    bed = work / "job.bed"
+    bed.write_text(f"{names[0]}\t100\t900\t0.3\t0.6\n{names[0]}\t2000\t5000\t0.0\t0.5\n{names[2]}\t50\t2000\t0.0\t1.0\n")
+    return dict(work=work, profile=ppath, fasta=fpath, vcf=str(vcf), bed=str(bed))
+
+
+def _pe_args(job, tag, extra=(), gz=False):
+    ext = ".fq.gz" if gz else ".fq"
+    out = [str(job["work"] / f"{tag}_{k}{ext}") for k in (1, 2)]
+    return ["-R", job["fasta"], "-s", job["profile"], "-1", out[0], "-2", out[1], "--numReads", 40000, "--seed", 7, "--refBias", "no", "--recordBaseIdentifier", "Job", *extra], out
+
+
+def _single_pe(mode, job, tag, extra=()):
+    args, out = _pe_args(job, f"{mode}_{tag}_one", extra)
+    if not all(os.path.exists(o) for o in out):
+        single(mode, "illuminaPE", args, job["work"])
+    texts = [open(o, "rb").read() for o in out]
+    assert texts[0].count(b"\n") % 4 == 0 and texts[0].count(b"\n") == texts[1].count(b"\n") > 4 * 5000 and b":0:Adapter:0:" in texts[0]
+    return texts
+
+
+# ------------------------------------------------------------------------------------------------------------------------ (i)
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("inputs", ["plain", "variants_methylation"])
+def test_illumina_pe_on_n_ranks_writes_the_single_device_files(mode, job, inputs):
+    extra = ["-V", job["vcf"], "--methylation", job["bed"]] if inputs != "plain" else []
+    want = _single_pe(mode, job, inputs, extra)
+    if inputs != "plain":
+        assert b"_allele1" in want[0]
+    for world in _worlds(mode):
+        tag = f"{mode}_{inputs}_w{world}"
+        # every rank writes its own byte range of the two files (batches of three blocks: several device calls per rank)
+        args, out = _pe_args(job, tag, [*extra, "--batchBlocks", 3])
+        r = launch(mode, world, args, job["work"])
+        assert f"on {world} GPU(s)" in r.stderr
+        assert [open(o, "rb").read() for o in out] == want, (world, "byte ranges")
+        # --splitOutput: a pair of files per rank whose concatenation in rank order is the single output
+        args, out = _pe_args(job, tag + "_split", [*extra, "--splitOutput"])
+        launch(mode, world, args, job["work"])
+        for o, w in zip(out, want):
+            digits = len(str(world))
+            assert b"".join(open(f"{o}.part{k + 1:0{digits}d}of{world}", "rb").read() for k in range(world)) == w, (world, "split")
+        # --gatherOutput: the ranks' text gathered on the first rank by a collective in slices (several rounds, last slices of different lengths), one writer
+        args, out = _pe_args(job, tag + "_gather", [*extra, "--gatherOutput", "--gatherSliceBytes", 300_000])
+        launch(mode, world, args, job["work"])
+        assert [open(o, "rb").read() for o in out] == want, (world, "gathered")
+        # .gz: every rank's share as gzip members at its offset (the sizes exchanged are the compressed ones), the adapter-only pairs as a member behind them
+        args, out = _pe_args(job, tag, extra, gz=True)
+        launch(mode, world, args, job["work"])
+        assert [gzip.decompress(open(o, "rb").read()) for o in out] == want, (world, "gz")
+    assert not list(pathlib.Path(job["work"]).glob("rsq_packed_reference_*")) and not list(pathlib.Path("/dev/shm").glob("rsq_packed_reference_*"))
+
+
+# ----------------------------------------------------------------------------------------------------------------------- (ii)
+@pytest.mark.timeout(1800)
+def test_seq_to_illumina_on_n_ranks_writes_the_single_device_file(mode, job):
+    n = 600 if mode == "gloo" else 40000
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    rec = synth.make_error_model_input(9, n, 30, arrays, zero_frac=0.7)
+    r = rec["rate"].astype(np.int64)                          # what survives the file: odd percents above 86 become the even one below (Simulator.cpp:2439-2442)
+    rec["rate"] = np.where(r > 86, r - r % 2, r).astype(np.uint8)
+    ids = [f"read {i}/x" if i % 7 == 0 else f"r{i}" for i in range(n)]
+    fa = job["work"] / f"{mode}_records.fa"
+    fa.write_bytes(P.fasta_of_records(rec, ids, wrap_every=3))
+    one = job["work"] / f"{mode}_records_one.fq"
+    single(mode, "seqToIllumina", ["-i", fa, "-o", one, "-s", job["profile"], "--seed", 13], job["work"])
+    want = one.read_bytes()
+    assert want.count(b"\n") == 4 * n and want.startswith(b"@read 0/x ")
+    for world in _worlds(mode):
+        out = job["work"] / f"{mode}_records_w{world}.fq"
+        r = launch(mode, world, ["seqToIllumina", "-i", fa, "-o", out, "-s", job["profile"], "--seed", 13], job["work"])
+        assert f"Generated {n} reads on {world} GPU(s)" in r.stderr
+        assert out.read_bytes() == want, world
+        launch(mode, world, ["seqToIllumina", "-i", fa, "-o", out, "-s", job["profile"], "--seed", 13, "--splitOutput"], job["work"])
+        digits = len(str(world))
+        assert b"".join(open(f"{out}.part{k + 1:0{digits}d}of{world}", "rb").read() for k in range(world)) == want, world
+        gz = job["work"] / f"{mode}_records_w{world}.fq.gz"
+        launch(mode, world, ["seqToIllumina", "-i", fa, "-o", gz, "-s", job["profile"], "--seed", 13], job["work"])
+        assert gzip.decompress(gz.read_bytes()) == want, world
+    # a malformed record on one rank: that rank says what the reference's reader says, the job ends, nobody waits
+    text = fa.read_bytes()
+    cut = text.index(b">", len(text) * 3 // 4)
+    end = text.index(b"\n", cut)
+    fields = text[cut:end].rsplit(b" ", 1)
+    bad = job["work"] / f"{mode}_records_bad.fa"
+    bad.write_bytes(text[:cut] + fields[0] + b" 3" + fields[1][1:] + text[end:])
+    r = launch(mode, 2, ["seqToIllumina", "-i", bad, "-o", job["work"] / f"{mode}_bad.fq", "-s", job["profile"], "--seed", 13], job["work"], check=False, timeout=600)
+    assert r.returncode != 0 and ("Template segment" in r.stderr or "malformed record" in r.stderr) and "another rank failed while simulating its records" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------- (iii)
+@pytest.mark.timeout(1800)
+def test_sharded_pre_pass_equals_the_whole_pre_pass(mode, job):
+    for world in sorted({*_worlds(mode), 4} if mode == "gloo" else set(_worlds(mode))):
+        r = launch(mode, world, ["prepass", job["work"] / f"{mode}_prepass_w{world}"], job["work"], target=(str(HERE / "multi_gpu_worker.py"),))
+        assert "PREPASS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+# ----------------------------------------------------------------------------------------------------------------------- (iv)
+OPEN_LOG_C = r"""
+// LD_PRELOAD shim of the test: every open of the file RSQ_OPEN_WATCH names appends "<pid>\n" to the file RSQ_OPEN_LOG names (inotify would do, but it merges the
+// identical events of two ranks that open the file at the same moment).  open / open64 / openat / fopen and their 64-bit names: whatever the readers use.
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+static void note(const char *path) {
+    const char *watch = getenv("RSQ_OPEN_WATCH"), *log = getenv("RSQ_OPEN_LOG");
+    if (!path || !watch || !log || strcmp(path, watch)) return;
+    static int (*real_open)(const char *, int, ...);
+    if (!real_open) real_open = (int (*)(const char *, int, ...))dlsym(RTLD_NEXT, "open");
+    const int fd = real_open(log, O_WRONLY | O_APPEND | O_CREAT, 0644);
+    if (fd < 0) return;
+    char line[32];
+    const int n = snprintf(line, sizeof line, "%d\n", (int)getpid());
+    if (write(fd, line, n) != n) {}
+    close(fd);
+}
+#define OPEN_LIKE(name)                                                                   \
+    int name(const char *path, int flags, ...) {                                          \
+        static int (*real)(const char *, int, ...);                                       \
+        if (!real) real = (int (*)(const char *, int, ...))dlsym(RTLD_NEXT, #name);       \
+        va_list ap;                                                                       \
+        va_start(ap, flags);                                                              \
+        const int mode = va_arg(ap, int);                                                 \
+        va_end(ap);                                                                       \
+        note(path);                                                                       \
+        return real(path, flags, mode);                                                   \
+    }
+OPEN_LIKE(open)
+OPEN_LIKE(open64)
+#define OPENAT_LIKE(name)                                                                 \
+    int name(int dir, const char *path, int flags, ...) {                                 \
+        static int (*real)(int, const char *, int, ...);                                  \
+        if (!real) real = (int (*)(int, const char *, int, ...))dlsym(RTLD_NEXT, #name);  \
+        va_list ap;                                                                       \
+        va_start(ap, flags);                                                              \
+        const int mode = va_arg(ap, int);                                                 \
+        va_end(ap);                                                                       \
+        note(path);                                                                       \
+        return real(dir, path, flags, mode);                                              \
+    }
+OPENAT_LIKE(openat)
+OPENAT_LIKE(openat64)
+#define FOPEN_LIKE(name)                                                                  \
+    FILE *name(const char *path, const char *mode) {                                      \
+        static FILE *(*real)(const char *, const char *);                                 \
+        if (!real) real = (FILE * (*)(const char *, const char *)) dlsym(RTLD_NEXT, #name); \
+        note(path);                                                                       \
+        return real(path, mode);                                                          \
+    }
+FOPEN_LIKE(fopen)
+FOPEN_LIKE(fopen64)
+"""
+
+
+def _open_log_shim(work):
+    so = pathlib.Path(work) / "openlog.so"
+    if not so.exists():
+        (pathlib.Path(work) / "openlog.c").write_text(OPEN_LOG_C)
+        subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", str(so), str(pathlib.Path(work) / "openlog.c"), "-ldl"], check=True)
+    return str(so)
+
+
+@pytest.mark.timeout(1800)
+def test_only_one_rank_of_a_host_opens_the_reference(mode, job):
+    """one load per host (simulate.load_once_per_host): with N ranks on the host ONE process opens the FASTA (and the VCF), the others take the packed reference
+    from shared memory; with --everyRankLoads all N do.  Who opened what is logged by an LD_PRELOAD shim of the test."""
+    world = _worlds(mode)[-1]
+    shim = _open_log_shim(job["work"])
+    want = _single_pe(mode, job, "variants_methylation", ["-V", job["vcf"], "--methylation", job["bed"]])
+    openers = {}
+    for how, extra in (("shared", []), ("each", ["--everyRankLoads"])):
+        for watched in ("fasta", "vcf"):
+            log = pathlib.Path(job["work"]) / f"{mode}_opens_{how}_{watched}.log"
+            log.unlink(missing_ok=True)
+            args, out = _pe_args(job, f"{mode}_opens_{how}", ["-V", job["vcf"], "--methylation", job["bed"], *extra])
+            launch(mode, world, args, job["work"], LD_PRELOAD=shim, RSQ_OPEN_WATCH=job[watched], RSQ_OPEN_LOG=log)
+            assert [open(o, "rb").read() for o in out] == want
+            openers[how, watched] = {int(x) for x in log.read_text().split()} if log.exists() else set()
+    for watched in ("fasta", "vcf"):
+        assert len(openers["shared", watched]) == 1, f"{world} ranks of one host: the {watched} file was opened by the processes {openers['shared', watched]}, one must load for all"
+        assert len(openers["each", watched]) == world, (watched, openers["each", watched])
+
+
+# ------------------------------------------------------------------------------------------------------------------------ (v)
+@pytest.mark.timeout(1800)
+def test_bench_on_two_ranks(mode, job):
+    flags = ["--gpus", "2", "--steps", "2", "--warmup", "1"] + (["--backend", "gloo", "--emulate"] if mode == "gloo" else ["--pairs", "1000000", "--no-cpu-baseline"])
+    for scaling in ("weak", "strong"):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags, "--scaling", scaling], capture_output=True, text=True, timeout=1500, env=_env(job["work"]), cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-5000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == scaling and len(line["ms_per_step_per_rank"]) == 2
+        assert line["ms_per_step"] >= max(line["ms_per_step_per_rank"]) * 0.999 and line["value"] > 0
+        assert "barrier" in line["config"]["collectives"] and ("nccl" if mode == "rccl" else "gloo") in line["config"]["collectives"]
+        if mode == "rccl":
+            assert "roofline" in line and line["roofline"]["frac"] > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------- (vi)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("step", ["generate", "write"])
+def test_a_rank_that_dies_takes_the_job_with_it(mode, job, step):
+    """SIGKILL of one rank at the named step (simulate._fault): the launcher ends the others, the command returns non-zero well inside the collective timeout, no rank
+    stays behind and the packed reference is gone from shared memory"""
+    args, out = _pe_args(job, f"{mode}_killed_{step}")
+    t0 = time.time()
+    r = launch(mode, 2, [*args, "--distTimeout", 120], job["work"], check=False, timeout=600, RSQ_FAULT_INJECT=f"{step}:1")
+    took = time.time() - t0
+    assert r.returncode != 0, r.stderr[-3000:]
+    assert took < 240, took
+    assert "Generated" not in r.stderr
+    leftover = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert not [l for l in leftover.splitlines() if f"{mode}_killed_{step}" in l and "ps -eo" not in l], leftover
+    assert not list(pathlib.Path(job["work"]).glob("rsq_packed_reference_*")) and not list(pathlib.Path("/dev/shm").glob("rsq_packed_reference_*"))
