@@ -275,6 +275,155 @@ class TorchBuffer:
         self.ptr, self.nbytes = self.t.data_ptr(), int(nbytes)
 
 
+# ------------------------------------------------------------------------------------------- BASELINE.json configs[2]-[4]
+def _parity_case(name, *args):
+    """one of the suite's parity cases (tests/parity_cases.py: the C ABI on this device against the CPU oracle, byte for byte) as a yes/no in the bench line"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pathlib import Path
+    import parity_cases as P
+    from backends import GpuBackend
+    t0 = time.perf_counter()
+    try:
+        with tempfile.TemporaryDirectory(prefix="rsq_parity_") as d:
+            getattr(P, name)(GpuBackend, Path(d), *args)
+        return {"case": f"tests/parity_cases.py::{name}{args if args else ''}", "equal_to_oracle": True, "seconds": round(time.perf_counter() - t0, 1)}
+    except AssertionError as e:
+        return {"case": f"tests/parity_cases.py::{name}{args if args else ''}", "equal_to_oracle": False, "what": str(e)[:300]}
+
+
+def _timed_pairs_job(sim, nb, batch, device, bufs, hash_blocks=48000):
+    """every block of the job once, in calls of `batch` blocks: pairs, bytes, seconds on the device, summed kernel times, SHA-256 of the two files' text of the first
+    `hash_blocks` blocks (downloaded after the call's time is taken)"""
+    import hashlib
+    h1, h2 = hashlib.sha256(), hashlib.sha256()
+    n = nbytes = 0
+    t_gpu = 0.0
+    kernel_ms = {}
+    for lo in range(1, nb + 1, batch):
+        hi = min(nb + 1, lo + batch)
+        if not bufs:                                                       # sized for the largest call of the leg: `bufs` arrives with the block count to size for
+            raise ValueError("size the buffers first (_pairs_buffers)")
+        t1 = time.perf_counter()
+        k, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0], bufs[1])
+        t_gpu += time.perf_counter() - t1
+        if rc != api.RSQ_OK:
+            raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+        for key in ("slot_table", "variant_templates", "sieve", "sieve_screen", "sieve_emit", "fill_reads", "format_write", "scan"):
+            if sim.last_kernel_launches(key):
+                kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
+        n += k
+        nbytes += l1 + l2
+        if hi <= hash_blocks + 1:
+            h1.update(bufs[0].to_numpy(np.uint8, l1).tobytes())
+            h2.update(bufs[1].to_numpy(np.uint8, l2).tobytes())
+    return {"pairs": n, "fastq_bytes": nbytes, "gpu_s": round(t_gpu, 4), "pairs_per_s": n / t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()},
+            f"sha256_first_{hash_blocks}_blocks": h1.hexdigest() + ":" + h2.hexdigest()}
+
+
+def _pairs_buffers(sim, nb, batch, device):
+    """two FASTQ buffers for calls of up to `batch` blocks: the need of every such call is asked first (a call without buffers returns the sizes)"""
+    need1 = need2 = 0
+    for lo in range(1, nb + 1, batch):
+        _, l1, l2, _ = sim.pairs_device(lo, min(nb + 1, lo + batch), None, None)
+        need1, need2 = max(need1, l1), max(need2, l2)
+    return [api.DeviceArray(device, need1 + 4096), api.DeviceArray(device, need2 + 4096)]
+
+
+def other_configs(device, seed, which=("2", "3", "4")):
+    """BASELINE.json's configs[2], [3] and [4] on ONE GPU, each measured once after the headline's timed region: rates with the inputs resident in
+    HBM, per-kernel times, checksums, invariance under another batching, and a small oracle parity case of the same kind of input.  Not the headline metric."""
+    import ctypes as C
+    import hashlib
+    from reseq_amd import workloads
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rsq_other_")
+    ppath = os.path.join(tmp, "p0.rsqp")
+    arrays = workloads.p0_profile(ppath)
+    if "2" in which:
+        # configs[2] seqToIllumina (replaceQuals): 8 M records of 150 bases as FASTA text resident in HBM, found, parsed, simulated and formatted on the device
+        t0 = time.perf_counter()
+        n = 8_000_000
+        rows, _ = workloads.seq_to_illumina_rows(n, arrays)
+        width = rows.shape[1]
+        d_text = api.DeviceArray.from_numpy(device, np.concatenate([rows.reshape(-1), np.zeros(8, np.uint8)]))
+        del rows
+        make_s = time.perf_counter() - t0
+        prof = api.Profile(ppath)
+        sim = api.Simulator(prof, None, device)
+        sim.prepare(seed)
+        d_out = api.DeviceArray(device, n * (2 * 150 + 64 + 16))
+        need, k, used = C.c_size_t(0), C.c_uint64(0), C.c_size_t(0)
+
+        def call():
+            t = time.perf_counter()
+            api._check(api.lib().rsq_sim_error_model_fasta(sim.h, 0, d_text.ptr, n * width, 1, d_out.ptr, d_out.nbytes, C.byref(need), C.byref(k), C.byref(used), None))
+            return time.perf_counter() - t
+        call()
+        seconds = [call() for _ in range(3)]
+        assert k.value == n and used.value == n * width
+        ms = {name: round(sim.last_kernel_ms(name), 2) for name in ("parse_records", "fill_reads", "format_write")}
+        text = d_out.to_numpy(np.uint8, need.value)
+        out["configs[2]"] = {"workload": f"seqToIllumina: {n} records of 150 bases as FASTA text ({n * width} bytes) resident in HBM, one rsq_sim_error_model_fasta call", "reads_per_s": n / min(seconds),
+                             "seconds": [round(t, 4) for t in seconds], "kernel_ms": ms, "fastq_bytes": int(need.value), "sha256": hashlib.sha256(text.tobytes()).hexdigest(),
+                             "make_inputs_s": round(make_s, 1), "parity_sample": _parity_case("case_error_model_p0")}
+        del text
+        for d in (d_text, d_out):
+            d.free()
+        sim.close()
+        prof.close()
+    if "3" in which:
+        # configs[3] Drosophila-sized at full size: 143.7 Mb in 7 sequences + 1000 scaffolds, coverage 30
+        t0 = time.perf_counter()
+        fpath, lengths = workloads.drosophila_sized(tmp)
+        make_s = time.perf_counter() - t0
+        prof, ref = api.Profile(ppath), api.Reference(fpath, 7)
+        sim = api.Simulator(prof, ref, device)
+        t0 = time.perf_counter()
+        info = sim.prepare(7, 0, 30.0)
+        prep_s = time.perf_counter() - t0
+        bufs = _pairs_buffers(sim, info.total_blocks, 24000, device)                     # also the warm-up (kernels compiled for the profile)
+        runs = {f"batch_{b}": _timed_pairs_job(sim, info.total_blocks, b, device, bufs) for b in (24000, 8000)}      # both have a call that ends with block 48000
+        same = len({(r["pairs"], r["fastq_bytes"], r["sha256_first_48000_blocks"]) for r in runs.values()}) == 1
+        out["configs[3]"] = {"workload": f"illuminaPE: Drosophila-sized reference ({sum(lengths)} bp in {len(lengths)} sequences, 1000 of them scaffolds shorter than the longest insert), P0, coverage 30, ONE GPU",
+                             "pairs_per_s": max(r["pairs_per_s"] for r in runs.values()), "pairs": runs["batch_24000"]["pairs"], "runs": runs, "batching_invariant": same, "prepare_s": round(prep_s, 2),
+                             "make_inputs_s": round(make_s, 1), "parity_sample": _parity_case("case_coverage_driven")}
+        for d in bufs:
+            d.free()
+        sim.close()
+        ref.close()
+        prof.close()
+        os.remove(fpath)
+    if "4" in which:
+        # configs[4] human-sized at 1/10 scale with variants of every kind on two alleles and methylation
+        t0 = time.perf_counter()
+        job = workloads.human_sized(tmp, 0.1)
+        make_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        prof, ref = api.Profile(ppath), api.Reference(job["fasta"], 7)
+        alleles = ref.read_variants(job["vcf"])
+        sim = api.Simulator(prof, ref, device)
+        sim.read_methylation(job["bed"])
+        load_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        info = sim.prepare(7, 0, 30.0)
+        prep_s = time.perf_counter() - t0
+        bufs = _pairs_buffers(sim, info.total_blocks, 24000, device)
+        runs = {f"batch_{b}": _timed_pairs_job(sim, info.total_blocks, b, device, bufs) for b in (24000, 12000)}
+        same = len({(r["pairs"], r["fastq_bytes"], r["sha256_first_48000_blocks"]) for r in runs.values()}) == 1
+        out["configs[4]"] = {"workload": f"illuminaPE at 1/10 of the human-sized job: {sum(job['lengths'])} bp in 24 sequences, {alleles} alleles, {job['substitutions']} substitutions + {job['indels']} "
+                                         f"insertions / deletions, {job['regions']} methylation regions, P0, coverage 30, ONE GPU",
+                             "pairs_per_s": max(r["pairs_per_s"] for r in runs.values()), "pairs": runs["batch_24000"]["pairs"], "runs": runs, "batching_invariant": same,
+                             "load_s": round(load_s, 2), "prepare_s": round(prep_s, 2), "make_inputs_s": round(make_s, 1), "parity_sample": _parity_case("case_p0_variants", "meth")}
+        for d in bufs:
+            d.free()
+        sim.close()
+        ref.close()
+        prof.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 class PairsJob:
     """One illuminaPE job on this rank's device: profile + reference loaded, pre-passes done, the rank's block range (balanced by expected pairs) cut into
     batches, FASTQ buffers sized from the largest batch.  measure() = `warmup` untimed steps, then `steps` timed ones bracketed by synchronize + barrier."""
@@ -465,6 +614,8 @@ def main():
     ap.add_argument("--dist-single", action="store_true", help="initialise torch.distributed although there is one rank (the RCCL calls of the N-rank path on one GPU)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): N sequences and N x --pairs on N GPUs; strong: ONE sequence and --pairs pairs split over the N GPUs")
     ap.add_argument("--no-strong-leg", action="store_true", help="with --gpus N > 1 and weak scaling: skip the extra fixed-size measurement (`strong_scaling` in the line)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` leg (BASELINE.json's configs[2]-[4] on one GPU after the headline; about two minutes)")
+    ap.add_argument("--other-configs", default="2,3,4", help="which of configs[2], [3], [4] the leg runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the value_to_host leg (it is skipped anyway with more than one GPU: every rank would pin 15 GB of host memory)")
     args = ap.parse_args()
@@ -581,6 +732,11 @@ def main():
                    "note": "FASTQ text of both mates copied to page-locked host buffers, copy of batch k "
                    "overlapping the generation of batch k+1 (the link binds: 7.5 GB per step and GPU)"}
 
+    others = None
+    if world == 1 and not args.no_other_configs and args.tiles <= 1:
+        job.close()                                                        # the headline's buffers go back first
+        sim = None
+        others = other_configs(local_rank, args.seed, tuple(args.other_configs.split(",")))
     if rank == 0:
         launches = max(fill_launches, 1)                                   # k_fill_reads launches in the timed region
         avg_fill_s = fill_ms / 1e3 / launches
@@ -617,6 +773,8 @@ def main():
             "kernel_ms_last_batch": kernel_ms,
             "prepare_s": prep_s, "sys_chain_passes": info.sys_chain_passes,
         }
+        if others:
+            out["other_configs"] = others
         if strong:
             out["strong_scaling"] = strong
         if to_host:

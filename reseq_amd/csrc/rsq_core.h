@@ -108,7 +108,9 @@ struct GlobalRow {                     // a margin row in HBM (read through L1/L
     RSQ_HD Pair pair(uint32_t j) const { return *reinterpret_cast<const Pair *>(p + 2u * j); }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
-#define RSQ_ANY(x) (__any(x) != 0)
+// the wave's ballot of a predicate is the compare's own result (s_and with exec); __any() takes an int, so the predicate went to a register, was compared again,
+// and the mask took a trip through vcc: three vector instructions per use, four uses in a step
+#define RSQ_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
 #else
 #define RSQ_ANY(x) (x)
 #endif
@@ -681,7 +683,7 @@ struct ReadMachine {
     // Decides what the next iteration is: performs the transitions between the template part, the adapter part and the tail
     // (Simulator.cpp:447-449, 537-558) until one of them has an iteration to run.  Returns false once the read is complete.
     RSQ_HD bool advance(const DevSim &S, const Stream &st) {
-        if (phase == kTemplate && par.read_pos < par.read_length && org_pos < org_len) return true;      // nearly every iteration
+        if (__builtin_expect(phase == kTemplate && par.read_pos < par.read_length && org_pos < org_len, 1)) return true;      // nearly every iteration
         return advance_parts(S, st);
     }
     RSQ_HD bool advance_parts(const DevSim &S, const Stream &st) {
@@ -735,7 +737,7 @@ struct ReadMachine {
         if (!advance(S, st)) return false;
         const bool tail = phase == kTail, from_template = phase == kTemplate;
         const DevAdapters &ad = S.adapters[seg];
-        const uint32_t it = par.iteration++;
+        const uint32_t it = par.iteration;                           // counted at the end of the step: old and new value never live side by side
         const Words w = st.step(2u + it);
         typename Tab::Sum prob_sum;
         uint32_t indel = 0, org_base = 0;
@@ -815,6 +817,7 @@ struct ReadMachine {
             ++par.read_pos;
         }
         if (!tail) out.op(it, op_code);
+        par.iteration = it + 1u;
         return true;
     }
 

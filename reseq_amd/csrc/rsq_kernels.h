@@ -1666,9 +1666,9 @@ struct ScreenTables {
         uint32_t value = reinterpret_cast<const RSQ_LDS uint8_t *>(img)[values + column];
         ps = 1u;
         decided = decided && !RSQ_SIM(S, force_exact);
-        if (RSQ_ANY(!decided)) {
-            if (!decided) value = exact<NM>(desc, idx, u, ps);
-        }
+        // a divergent branch around a call is skipped by the wave when no lane takes it (s_cbranch_execz): no ballot needed in front of it -- the ballot of a
+        // predicate that is a conjunction of compares costs a select, a compare and three scalar instructions per draw
+        if (!decided) value = exact<NM>(desc, idx, u, ps);
         return value;
     }
 
@@ -1705,10 +1705,8 @@ struct ScreenTables {
         const uint32_t range = d->sure_range, lo16 = range & 0xFFFFu;
         const bool sure = (u >> 16) - lo16 < (range >> 16) - lo16 && idx[0] <= d->from[0];
         RSQ_SCREEN_COUNT(3, sure);
-        if (!RSQ_ANY(!sure)) {
-            ps = 1u;
-            return 0;
-        }
+        ps = 1u;
+        if (sure) return 0;                                 // the lanes that are not sure draw among themselves; a wave without one skips the branch (s_cbranch_execz)
         const uint32_t slot = RSQ_PLAN(S, slot_i), r0 = RSQ_GEO_ROW(S, i, 0, idx[0]);
         const float *g = S.pool32 + RSQ_PLAN(S, i.off32) + i * (RSQ_PLAN(S, i.table_rows) * slot);
         const bool m0_staged = RSQ_PLAN(S, i.lds) != kNoLds;
@@ -2328,13 +2326,12 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         const uint32_t lane = threadIdx.x & 63u, n_items = lds_ring_items(S);
         RSQ_LDS float *ring = img + RSQ_PLAN(S, ring_off) + (threadIdx.x >> 6) * kRingSlots * RSQ_PLAN(S, ring_stride);
         ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
-        bool running = active;
         m.idle();
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
         const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
         Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
-        for (uint32_t t = 0; __any(running); ++t) {
+        for (uint32_t t = 0; RSQ_ANY(m.phase != ReadMachine::kDone); ++t) {      // a read is complete (or a lane has none) exactly when its machine is in kDone: a plain compare for the ballot
             if (lane < n_items) {
                 lds_ring_store(S, mine, ring, t, ahead);
                 ahead = lds_ring_load(S, mine, t + 1u);
@@ -2342,7 +2339,15 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, qbase, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
-            running = m.step(S, tab, st, src, out);          // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
+#if defined(RSQ_PIN_STATE)
+            // the read's loop-carried state through one register each: a tied asm operand is read and written in the same register, which leads the allocator to keep a
+            // value and its successor there instead of in two registers with a move between them at the loop head (12 moves per step in the kernel compiled for P0)
+#define RSQ_PIN(x) asm volatile("" : "+v"(x))
+            RSQ_PIN(m.par.iteration); RSQ_PIN(m.par.read_pos); RSQ_PIN(m.par.num_errors); RSQ_PIN(m.par.qual); RSQ_PIN(m.par.last_written_qual); RSQ_PIN(m.par.base_call);
+            RSQ_PIN(m.par.indel_pos); RSQ_PIN(m.par.previous_indel_type); RSQ_PIN(m.org_pos); RSQ_PIN(m.cg.length); RSQ_PIN(m.cg.chars); RSQ_PIN(m.n_indels);
+            RSQ_PIN(out.seq_word); RSQ_PIN(out.qual_word); RSQ_PIN(out.cur_word); RSQ_PIN(out.cur_index);
+#endif
+            m.step(S, tab, st, src, out);                    // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
             __builtin_amdgcn_wave_barrier();
         }
     }

@@ -118,11 +118,26 @@ def _single_pe(mode, job, tag, extra=()):
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("inputs", ["plain", "variants_methylation"])
 def test_illumina_pe_on_n_ranks_writes_the_single_device_files(mode, job, inputs):
+    _illumina_pe(mode, job, inputs, _worlds(mode))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_one_rank_under_the_launcher_writes_the_command_line_files(job):
+    """What a box with ONE device can run of the RCCL mode: the launcher with a single rank -- process group over nccl, every exchange of the N-rank path with a
+    world of one, GpuBackend, the job kept in device memory and written at its offset -- against the command line, for both commands."""
+    if _devices() < 1:
+        pytest.skip("no device")
+    _illumina_pe("rccl", job, "variants_methylation", [1])
+    _seq_to_illumina("rccl", job, [1])
+
+
+def _illumina_pe(mode, job, inputs, worlds):
     extra = ["-V", job["vcf"], "--methylation", job["bed"]] if inputs != "plain" else []
     want = _single_pe(mode, job, inputs, extra)
     if inputs != "plain":
         assert b"_allele1" in want[0]
-    for world in _worlds(mode):
+    for world in worlds:
         tag = f"{mode}_{inputs}_w{world}"
         # every rank writes its own byte range of the two files (batches of three blocks: several device calls per rank)
         args, out = _pe_args(job, tag, [*extra, "--batchBlocks", 3])
@@ -149,6 +164,10 @@ def test_illumina_pe_on_n_ranks_writes_the_single_device_files(mode, job, inputs
 # ----------------------------------------------------------------------------------------------------------------------- (ii)
 @pytest.mark.timeout(1800)
 def test_seq_to_illumina_on_n_ranks_writes_the_single_device_file(mode, job):
+    _seq_to_illumina(mode, job, _worlds(mode))
+
+
+def _seq_to_illumina(mode, job, worlds):
     n = 600 if mode == "gloo" else 40000
     arrays = synth.make_profile(synth.TINY, seed=5)
     rec = synth.make_error_model_input(9, n, 30, arrays, zero_frac=0.7)
@@ -161,7 +180,7 @@ def test_seq_to_illumina_on_n_ranks_writes_the_single_device_file(mode, job):
     single(mode, "seqToIllumina", ["-i", fa, "-o", one, "-s", job["profile"], "--seed", 13], job["work"])
     want = one.read_bytes()
     assert want.count(b"\n") == 4 * n and want.startswith(b"@read 0/x ")
-    for world in _worlds(mode):
+    for world in worlds:
         out = job["work"] / f"{mode}_records_w{world}.fq"
         r = launch(mode, world, ["seqToIllumina", "-i", fa, "-o", out, "-s", job["profile"], "--seed", 13], job["work"])
         assert f"Generated {n} reads on {world} GPU(s)" in r.stderr
@@ -179,8 +198,9 @@ def test_seq_to_illumina_on_n_ranks_writes_the_single_device_file(mode, job):
     fields = text[cut:end].rsplit(b" ", 1)
     bad = job["work"] / f"{mode}_records_bad.fa"
     bad.write_bytes(text[:cut] + fields[0] + b" 3" + fields[1][1:] + text[end:])
-    r = launch(mode, 2, ["seqToIllumina", "-i", bad, "-o", job["work"] / f"{mode}_bad.fq", "-s", job["profile"], "--seed", 13], job["work"], check=False, timeout=600)
-    assert r.returncode != 0 and ("Template segment" in r.stderr or "malformed record" in r.stderr) and "another rank failed while simulating its records" in r.stderr
+    r = launch(mode, max(worlds), ["seqToIllumina", "-i", bad, "-o", job["work"] / f"{mode}_bad.fq", "-s", job["profile"], "--seed", 13], job["work"], check=False, timeout=600)
+    assert r.returncode != 0 and ("Template segment" in r.stderr or "malformed record" in r.stderr), r.stderr[-3000:]
+    assert max(worlds) == 1 or "another rank failed while simulating its records" in r.stderr
 
 
 # ---------------------------------------------------------------------------------------------------------------------- (iii)

@@ -16,13 +16,13 @@ import numpy as np  # noqa: E402
 
 from reseq_amd import api, synth  # noqa: E402
 
-BIG = [32_079_331, 28_110_227, 25_286_936, 23_542_271, 23_513_712, 7_350_000 + 3_667_352 - 1_000 * 600, 1_348_131]     # 143.7 Mb with the scaffolds
+from reseq_amd import workloads  # noqa: E402
+
 tmp = tempfile.mkdtemp(prefix="rsq_c4_")
-ppath, fpath = os.path.join(tmp, "p0.rsqp"), os.path.join(tmp, "ref.fa")
-synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
-lengths = BIG + [600] * 1000
+ppath = os.path.join(tmp, "p0.rsqp")
+workloads.p0_profile(ppath)
 t0 = time.perf_counter()
-synth.write_fasta(fpath, synth.make_reference(5, lengths, gc=0.42))
+fpath, lengths = workloads.drosophila_sized(tmp)                    # the inputs' one definition (bench.py's other_configs leg runs the same)
 t_make = time.perf_counter() - t0
 prof, ref = api.Profile(ppath), api.Reference(fpath, 7)
 sim = api.Simulator(prof, ref, 0)

@@ -25,55 +25,15 @@ if "--lib" in sys.argv:
 for k, a in enumerate(sys.argv):                                     # --option name=value: rsq_set_option (e.g. trace_prepare=1: stage times of the pre-pass on stderr)
     if a == "--option":
         api.set_option(*[(n, int(v)) for n, v in [sys.argv[k + 1].split("=")]][0])
-HUMAN = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
-         101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
-lengths = [max(5000, int(n * scale)) for n in HUMAN]
-rng = np.random.default_rng(11)
+from reseq_amd import workloads  # noqa: E402
+
 tmp = tempfile.mkdtemp(prefix="rsq_c5_")
-ppath, fpath, vpath, bpath = (os.path.join(tmp, n) for n in ("p0.rsqp", "ref.fa", "var.vcf", "meth.bed"))
-synth.write_profile(ppath, synth.make_profile(synth.P0, seed=103741084))
+ppath = os.path.join(tmp, "p0.rsqp")
+workloads.p0_profile(ppath)
 t0 = time.perf_counter()
-seqs = synth.make_reference(9, lengths, gc=0.41)
-synth.write_fasta(fpath, seqs)
-total = int(sum(lengths))
-n_sub, n_indel, n_regions = int(4.0e6 * scale), 0 if snv_only else int(0.4e6 * scale), 0 if snv_only else int(20e6 * scale)
-names = [n.split(" ")[0] for n, _ in seqs]
-letters = np.frombuffer(b"ACGT", np.uint8)
-with open(vpath, "w") as f:
-    f.write("##fileformat=VCFv4.2\n" + "".join(f"##contig=<ID={n},length={len(c)}>\n" for n, (_, c) in zip(names, seqs)))
-    f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n")
-    for si, (_, codes) in enumerate(seqs):
-        L = len(codes)
-        k = int((n_sub + n_indel) * L / total)
-        pos = np.unique(rng.integers(1, L - 50, k))
-        pos = pos[np.concatenate(([True], np.diff(pos) > 25))]                 # non-overlapping, as a normalised VCF would have them
-        kinds = rng.random(len(pos)) < n_indel / (n_sub + n_indel)
-        gts = rng.integers(0, 3, len(pos))
-        lines = []
-        for p0, is_indel, g in zip(pos.tolist(), kinds.tolist(), gts.tolist()):
-            gt = ("0|1", "1|0", "1|1")[g]
-            ref = chr(letters[codes[p0]])
-            if not is_indel:
-                alt = chr(letters[(codes[p0] + 1 + p0 % 3) % 4])
-                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT\t{gt}")
-            elif p0 & 1:
-                ins = letters[rng.integers(0, 4, 1 + p0 % 20)].tobytes().decode()
-                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{ref}\t{ref + ins}\t.\tPASS\t.\tGT\t{gt}")
-            else:
-                dl = 1 + p0 % 20
-                lines.append(f"{names[si]}\t{p0 + 1}\t.\t{letters[codes[p0:p0 + dl + 1]].tobytes().decode()}\t{ref}\t.\tPASS\t.\tGT\t{gt}")
-        f.write("\n".join(lines) + "\n")
-with open(bpath, "w") as f:
-    for si, (_, codes) in enumerate(seqs):
-        L = len(codes)
-        k = int(n_regions * L / total)
-        starts = np.unique(rng.integers(0, L - 200, k))
-        if not len(starts):
-            continue
-        starts = starts[np.concatenate(([True], np.diff(starts) > 120))]
-        lens = rng.integers(1, 100, len(starts))
-        meth = rng.beta(0.5, 0.5, (len(starts), 2))
-        f.write("".join(f"{names[si]}\t{a}\t{a + b}\t{m0:.4f}\t{m1:.4f}\n" for a, b, (m0, m1) in zip(starts.tolist(), lens.tolist(), meth.tolist())))
+job_in = workloads.human_sized(tmp, scale, snv_only)                 # the inputs' one definition (bench.py's other_configs leg runs the same at scale 0.1)
+fpath, vpath, bpath, lengths = job_in["fasta"], job_in["vcf"], job_in["bed"], job_in["lengths"]
+total, n_sub, n_indel, n_regions = int(sum(lengths)), job_in["substitutions"], job_in["indels"], job_in["regions"]
 t_make = time.perf_counter() - t0
 
 # `loads N`: N processes load the job's inputs at the same time, as the ranks of an N-GPU job on one host do (here all of them onto this one GPU): seconds per process and stage
