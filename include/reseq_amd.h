@@ -238,6 +238,14 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
  * members is a gzip file (RFC 1952; SeqAn, zlib's gzread and gzip -d read it as one stream), so the ranks exchange these sizes and rsq_sim_job_write puts each
  * rank's members at its offset exactly as it does plain text.  The decompressed file is the single run's; where the members end depends on the ranks' shares. */
 int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes);
+
+/* gzip on the device (reseq_amd/csrc/rsq_deflate.h; the reference compresses in SeqAn's stream behind Simulator::Flush, reseq/Simulator.cpp:150-182, for the output
+ * names of main.cpp:404,412): text_dev[0, text_len) -- device memory -- as gzip members (RFC 1952) one behind the other in out_dev, every member the deflate
+ * (RFC 1951, one block with a dynamic Huffman code taken from a sample of the call's text) of at most 65280 bytes of text, framed like a BGZF block (extra field
+ * "BC"); concatenated members are a gzip file for zlib's gzread, gzip -d, SeqAn and bgzip alike.  *out_len = their bytes; RSQ_ENOSPC (and the size needed) if
+ * out_cap is smaller -- rsq_gzip_bound(text_len) always suffices.  Kernel time: "gzip".  rsq_sim_job_compress uses it unless option host_gzip is 1. */
+size_t rsq_gzip_bound(size_t text_len);
+int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char *out_dev, size_t out_cap, size_t *out_len, void *stream);
 /* `bytes` of the kept text of file `file` (0 / 1) from byte `at` on, copied into the caller's device memory: a rank's contribution to one round of a gather of
  * the output (simulate.py --gatherOutput: fixed-size slices gathered on the first rank over RCCL, which writes them with rsq_dev_pwrite).  RSQ_ESTATE without text. */
 int rsq_sim_job_read(rsq_sim *s, int file, uint64_t at, size_t bytes, char *dst_dev, void *stream);

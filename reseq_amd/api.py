@@ -99,6 +99,8 @@ SYMBOLS = {
     "rsq_sim_job_generate": (C.c_int, [_vp, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp]),
     "rsq_sim_job_write": (C.c_int, [_vp, C.c_char_p, _u64, C.c_char_p, _u64, _u32]),
     "rsq_sim_job_compress": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rsq_gzip_bound": (C.c_size_t, [C.c_size_t]),
+    "rsq_sim_gzip_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_job_free": (C.c_int, [_vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
     "rsq_sim_error_model": (C.c_int, [_vp, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
@@ -495,8 +497,33 @@ class Simulator:
         """the kept text to its place in the two final files (parallel pwrite from page-locked buffers); r2_path None: a job with one file"""
         _check(lib().rsq_sim_job_write(self.h, str(r1_path).encode(), r1_offset, str(r2_path).encode() if r2_path is not None else None, r2_offset, threads_per_file))
 
+    def gzip_device(self, text_dev, text_len, out_dev=None, out_cap=0, stream=None):
+        """text_dev[0, text_len) -- a DeviceArray or an address in device memory -- as gzip members in out_dev (rsq_sim_gzip_device); returns (bytes of the members, rc):
+        rc RSQ_ENOSPC when out_cap is smaller than that"""
+        ptr = lambda d: d.ptr if isinstance(d, DeviceArray) else C.c_void_p(d) if d else None
+        n = C.c_size_t(0)
+        rc = lib().rsq_sim_gzip_device(self.h, ptr(text_dev), text_len, ptr(out_dev), out_cap, C.byref(n), stream)
+        if rc not in (RSQ_OK, RSQ_ENOSPC):
+            _check(rc)
+        return n.value, rc
+
+    def gzip(self, text):
+        """bytes -> the gzip members the device makes of them (a test's and a tool's convenience: upload, rsq_sim_gzip_device, download)"""
+        if not text:
+            return b""
+        src = DeviceArray.from_numpy(self.device, np.frombuffer(text, np.uint8))
+        out = DeviceArray(self.device, lib().rsq_gzip_bound(len(text)))
+        try:
+            n, rc = self.gzip_device(src, len(text), out, out.nbytes)
+            _check(rc)
+            return out.to_numpy(np.uint8, n).tobytes()
+        finally:
+            src.free()
+            out.free()
+
     def job_compress(self):
-        """the kept text as gzip members in host memory (rsq_sim_job_compress); returns the compressed sizes of the two files, which job_write then writes"""
+        """the kept text as gzip members (rsq_sim_job_compress: made on the device and kept there; in host memory with option host_gzip); returns the compressed
+        sizes of the two files, which job_write then writes"""
         b1, b2 = _u64(0), _u64(0)
         _check(lib().rsq_sim_job_compress(self.h, C.byref(b1), C.byref(b2)))
         return b1.value, b2.value

@@ -179,9 +179,9 @@ bool load_profile(const Args &a, rsq_profile **p) {
 struct TextOut {
     rsq::textio::Writer w;
     bool failed = false;
-    bool open(const std::string &path) {
+    bool open(const std::string &path, bool as_it_comes = false) {      // as_it_comes: the bytes are .gz members already (made on the device), whatever the name says
         try {
-            return w.open(path);
+            return as_it_comes ? w.open_plain(path) : w.open(path);
         } catch (const std::exception &e) {
             ERR(e.what());
             return false;
@@ -241,8 +241,8 @@ struct AsyncOut {
     std::mutex m;
     std::condition_variable cv;
     std::thread worker;
-    bool open(const std::string &path) {                  // an empty path: stdout
-        if (!path.empty() && !out.open(path)) return false;
+    bool open(const std::string &path, bool as_it_comes = false) {      // an empty path: stdout
+        if (!path.empty() && !out.open(path, as_it_comes)) return false;
         worker = std::thread([this] {
             std::unique_lock<std::mutex> lock(m);
             for (;;) {
@@ -406,8 +406,13 @@ int illumina_pe(const Args &a) {
     if (ok && !sys_read.empty()) ok = check(rsq_sim_read_sys_errors(sim, sys_read.c_str()), "Could not read systematic error profile");
     trace.at("prepared");
     AsyncOut f1, f2;
+    // .gz outputs: the text of every call becomes gzip members on the device (rsq_sim_gzip_device) -- a third of the bytes cross the link and the writer threads
+    // only write (--rsqOption host_gzip:1: zlib on host threads behind the writers, as before)
+    int64_t host_gzip = 0;
+    rsq_get_option("host_gzip", &host_gzip);
+    const bool gz1 = !host_gzip && rsq::textio::has_suffix(out1, ".gz"), gz2 = !host_gzip && rsq::textio::has_suffix(out2, ".gz");
     if (ok) {
-        const bool o1 = f1.open(out1), o2 = f2.open(out2);
+        const bool o1 = f1.open(out1, gz1), o2 = f2.open(out2, gz2);
         if (!o1 || !o2) {
             ERR("Could not open '" << (o1 ? out2 : out1) << "' for writing.");
             ok = false;
@@ -418,8 +423,18 @@ int illumina_pe(const Args &a) {
         rsq_sim_get_info(sim, &info);
         INFO("Aiming for " << info.total_pairs + info.adapter_only_pairs << " read pairs");
         INFO("Starting read generation");
-        DevBuffer d1, d2;
+        DevBuffer d1, d2, g1, g2;
         uint64_t written = 0;
+        // a call's text of one file as members in `g`: true and the members' size, or false
+        auto members = [&](bool gz, DevBuffer &d, size_t &len, DevBuffer &g) {
+            if (!gz || !len) return true;
+            size_t packed = 0;
+            if (!g.ensure(len / 2 + (1u << 20))) return false;
+            int rc = rsq_sim_gzip_device(sim, (const char *)d.p, len, (char *)g.p, g.cap, &packed, nullptr);
+            if (rc == RSQ_ENOSPC && g.ensure(rsq_gzip_bound(len))) rc = rsq_sim_gzip_device(sim, (const char *)d.p, len, (char *)g.p, g.cap, &packed, nullptr);
+            len = packed;
+            return check(rc, "Compressing the output failed");
+        };
         // about 4 M pairs per call: large launches keep the persistent read kernel's tail short, and sparse coverage needs long block ranges
         const double pairs_per_block = (double)info.total_pairs / std::max<uint32_t>(1u, info.total_blocks);
         const uint32_t step = (uint32_t)std::min(100000.0, std::max(2000.0, 4e6 / std::max(1e-9, pairs_per_block)));
@@ -432,7 +447,7 @@ int illumina_pe(const Args &a) {
                 ok = d1.ensure(l1 + l1 / 8 + 4096) && d2.ensure(l2 + l2 / 8 + 4096);
                 if (ok) rc = rsq_sim_pairs(sim, lo, hi, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, &n, nullptr, 0, nullptr);
             }
-            ok = ok && check(rc, "Simulation failed") && (n == 0 || flush_pair(d1, l1, d2, l2, f1, f2));
+            ok = ok && check(rc, "Simulation failed") && (n == 0 || (members(gz1, d1, l1, g1) && members(gz2, d2, l2, g2) && flush_pair(gz1 ? g1 : d1, l1, gz2 ? g2 : d2, l2, f1, f2)));
             written += n;
             if (ok && n) INFO("Generated " << written << " read pairs (" << (info.total_pairs ? (written * 100 + info.total_pairs / 2) / info.total_pairs : 0) << "%).");
         }
@@ -444,7 +459,7 @@ int illumina_pe(const Args &a) {
                 ok = d1.ensure(l1 + 4096) && d2.ensure(l2 + 4096);
                 if (ok) rc = rsq_sim_adapter_only_pairs(sim, first, n, (char *)d1.p, d1.cap, &l1, (char *)d2.p, d2.cap, &l2, nullptr);
             }
-            ok = ok && check(rc, "Simulation of adapter-only pairs failed") && flush_pair(d1, l1, d2, l2, f1, f2);
+            ok = ok && check(rc, "Simulation of adapter-only pairs failed") && members(gz1, d1, l1, g1) && members(gz2, d2, l2, g2) && flush_pair(gz1 ? g1 : d1, l1, gz2 ? g2 : d2, l2, f1, f2);
         }
     }
     trace.at("last text handed to the writers");

@@ -82,7 +82,7 @@ struct SequentialIn {
 struct SequentialOut {
     textio::Writer w;
     bool failed = false;
-    bool open(const char *path) { return !path || w.open(path); }
+    bool open(const char *path, bool as_it_comes = false) { return !path || (as_it_comes ? w.open_plain(path) : w.open(path)); }
     void write(const char *data, size_t n) {
         if (w.is_open()) w.write(data, n);
         else failed = failed || fwrite(data, 1, n, stdout) != n;
@@ -246,8 +246,8 @@ struct OutPipe {
     Fault &fault;
     StageTime t_download, t_stage, t_write, t_dev;
     OutPipe(int dev_id, Fault &f) : device(dev_id), fault(f) {}
-    bool open(const char *path) {                         // nullptr: stdout
-        if (!out.open(path)) return false;
+    bool open(const char *path, bool as_it_comes = false) {      // nullptr: stdout; as_it_comes: no compression by the name (the bytes are .gz members already)
+        if (!out.open(path, as_it_comes)) return false;
         downloader = std::thread([this] { guarded([this] { download(); }); finish_download(); });
         writer = std::thread([this] { guarded([this] { write(); }); });
         started = true;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/reseq_amd.h"
+#include "rsq_deflate.h"
 #include "rsq_fasta.h"
 #include "rsq_pack.h"
 #include "rsq_spec.h"
@@ -60,6 +61,14 @@ class DevBuf {
     void upload(const std::vector<T> &v) {
         reserve(v.size() * sizeof(T) + 8);
         if (!v.empty()) HIP_CHECK(hipMemcpy(p_, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void release() {
+        if (p_) {
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipFree(p_));
+        }
+        p_ = nullptr;
+        bytes_ = 0;
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p_); }
@@ -197,9 +206,11 @@ struct rsq_sim : SimState {
         bool complete = false;         // rsq_sim_job_generate ran to its end: the text is whole (not: never generated, freed, or left half-made by a failed call)
         std::vector<unsigned char> packed[2];      // rsq_sim_job_compress: the text as gzip members in host memory (the device arrays are released, bytes[] = these sizes)
         bool is_packed = false;
+        bool device_packed = false;                // rsq_sim_job_compress on the device: chunks[] hold gzip members instead of text (used[] and bytes[] their sizes)
         void clear() {
             complete = false;
             is_packed = false;
+            device_packed = false;
             for (auto &p : packed) std::vector<unsigned char>().swap(p);
             for (int f = 0; f < 2; ++f) {
                 chunks[f].clear();
@@ -209,6 +220,7 @@ struct rsq_sim : SimState {
         }
     } job;
     DevBuf totals;                 // [sub-ranges + 1][2] bytes of FASTQ text in front of a sub-range, per file
+    DevBuf gz_slots, gz_sizes, gz_at, gz_hist, gz_codes, gz_total;      // gzip on the device (rsq_deflate.h): the members' slots, their sizes and places, the sample's counts, the call's code
     Workspace *cur = &ws[0];       // the set the stage being enqueued works on
     hipStream_t side[2] = {nullptr, nullptr};      // the sieve's and the text's stream of a pipelined call
     hipEvent_t ev_call = nullptr, ev_fill = nullptr, ev_emit = nullptr;
@@ -1901,17 +1913,126 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
     });
 }
 
+// ------------------------------------------------------------------------------------------------ gzip on the device (rsq_deflate.h)
+// The code of a call: the symbol counts of a sample of its pieces (k_gzip_pieces<true>), the code built on the host (gz::build_codes), uploaded.
+static void gzip_code_of(rsq_sim &s, const uint8_t *text, size_t n, hipStream_t st) {
+    const uint64_t n_pieces = cdiv(n, gz::kPiece);
+    const uint32_t stride = gz::sample_stride(n_pieces);
+    s.gz_hist.reserve((gz::kLitLen + gz::kDist) * 4);
+    s.gz_codes.reserve(sizeof(gz::Codes));
+    HIP_CHECK(hipMemsetAsync(s.gz_hist.as<uint32_t>(), 0, (gz::kLitLen + gz::kDist) * 4, st));
+    hipLaunchKernelGGL(gz::k_gzip_pieces<true>, dim3((uint32_t)cdiv(n_pieces, stride)), dim3(gz::kThreads), 0, st, text, (uint64_t)n, stride, (const gz::Codes *)nullptr, (uint8_t *)nullptr,
+                       (uint32_t *)nullptr, s.gz_hist.as<uint32_t>());
+    HIP_CHECK(hipGetLastError());
+    uint32_t hist[gz::kLitLen + gz::kDist];
+    HIP_CHECK(hipMemcpyAsync(hist, s.gz_hist.as<uint32_t>(), sizeof hist, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const gz::Codes codes = gz::build_codes(hist);
+    HIP_CHECK(hipMemcpyAsync(s.gz_codes.as<char>(), &codes, sizeof codes, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));                             // `codes` leaves scope
+}
+// text[0, n) of device memory as gzip members behind each other in out (device memory, room for out_cap bytes): stretches of at most kGzipStretch pieces go through
+// the slots (compress, store what did not fit, scan the sizes, move the members into place).  *out_len = the bytes of all members; more than out_cap: nothing
+// useful is in out, RSQ_ENOSPC.  with_code: the call's code is taken from this text first (else the caller has set it: several arrays of one job share a code).
+constexpr uint64_t kGzipStretch = 8192;                              // pieces per pass: 535 MB of text, as much again in slots
+static int gzip_device(rsq_sim &s, const uint8_t *text, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, bool with_code, hipStream_t st) {
+    *out_len = 0;
+    if (!n) return RSQ_OK;
+    if (with_code) gzip_code_of(s, text, n, st);
+    const uint64_t n_pieces = cdiv(n, gz::kPiece);
+    const uint64_t stretch = std::min<uint64_t>(n_pieces, kGzipStretch);
+    s.gz_slots.reserve(stretch * gz::kSlot);
+    s.gz_sizes.reserve(stretch * 4);
+    s.gz_at.reserve((stretch + 1) * 8);
+    s.gz_total.reserve(8);
+    size_t total = 0;
+    for (uint64_t first = 0; first < n_pieces; first += stretch) {
+        const uint32_t pieces = (uint32_t)std::min<uint64_t>(stretch, n_pieces - first);
+        const uint8_t *t = text + first * gz::kPiece;
+        const uint64_t bytes = std::min<uint64_t>((uint64_t)pieces * gz::kPiece, n - first * gz::kPiece);
+        s.timers["gzip"].start(st);
+        hipLaunchKernelGGL(gz::k_gzip_pieces<false>, dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, 1u, s.gz_codes.as<gz::Codes>(), s.gz_slots.as<uint8_t>(), s.gz_sizes.as<uint32_t>(), (uint32_t *)nullptr);
+        hipLaunchKernelGGL(gz::k_gzip_stored, dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, s.gz_slots.as<uint8_t>(), s.gz_sizes.as<uint32_t>());
+        exclusive_scan(s, s.gz_sizes.as<uint32_t>(), pieces, s.gz_at.as<uint64_t>(), st, nullptr, s.gz_total.as<uint64_t>());
+        uint64_t stretch_bytes = 0;
+        HIP_CHECK(hipMemcpyAsync(&stretch_bytes, s.gz_total.as<uint64_t>(), 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (total + stretch_bytes <= out_cap)
+            hipLaunchKernelGGL(gz::k_gzip_compact, dim3(pieces), dim3(256), 0, st, s.gz_slots.as<uint8_t>(), s.gz_sizes.as<uint32_t>(), s.gz_at.as<uint64_t>(), out + total);
+        s.timers["gzip"].stop(st);
+        HIP_CHECK(hipGetLastError());
+        total += stretch_bytes;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    *out_len = total;
+    if (total > out_cap) {
+        g_last_error = "output buffer too small: the members need " + std::to_string(total) + " bytes";
+        return RSQ_ENOSPC;
+    }
+    return RSQ_OK;
+}
+size_t rsq_gzip_bound(size_t text_len) { return (size_t)cdiv(text_len, gz::kPiece) * (gz::kHeaderBytes + 5u + gz::kTrailerBytes) + text_len; }
+int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char *out_dev, size_t out_cap, size_t *out_len, void *stream) {
+    REQUIRE(s && out_len && (text_dev || !text_len) && (out_dev || !out_cap), "null argument");
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        reset_call_timers(*s);
+        return gzip_device(*s, reinterpret_cast<const uint8_t *>(text_dev), text_len, reinterpret_cast<uint8_t *>(out_dev), out_cap, out_len, true, (hipStream_t)stream);
+    });
+}
+// the kept text of a job on the device: every array of text becomes an array of members (the first array's sample gives the code of the file); the text is released
+static void job_compress_on_device(rsq_sim &s, hipStream_t st) {
+    rsq_sim::JobText &job = s.job;
+    reset_call_timers(s);
+    for (int f = 0; f < 2; ++f) {
+        uint64_t packed_bytes = 0;
+        for (size_t c = 0; c < job.chunks[f].size(); ++c) {
+            const size_t n = job.used[f][c];
+            if (!n) continue;
+            const uint8_t *text = job.chunks[f][c]->as<uint8_t>();
+            // members need a third of the text or less; an array of that size first, the bound if the text is of another kind (the call then runs again)
+            std::unique_ptr<DevBuf> packed(new DevBuf());
+            size_t len = 0;
+            packed->reserve(n / 2 + ((size_t)1 << 20));
+            int rc = gzip_device(s, text, n, packed->as<uint8_t>(), packed->bytes(), &len, c == 0, st);
+            if (rc == RSQ_ENOSPC) {
+                packed.reset(new DevBuf());
+                packed->reserve(rsq_gzip_bound(n));
+                rc = gzip_device(s, text, n, packed->as<uint8_t>(), packed->bytes(), &len, false, st);
+            }
+            if (rc != RSQ_OK) throw Error("compressing the job's text on the device failed: " + g_last_error);
+            std::unique_ptr<DevBuf> fitted(new DevBuf());             // an array of the members' size (the first was sized by guess)
+            fitted->reserve(len);
+            HIP_CHECK(hipMemcpyAsync(fitted->as<char>(), packed->as<char>(), len, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            packed = std::move(fitted);
+            job.chunks[f][c] = std::move(packed);                     // the text's array is released
+            job.used[f][c] = len;
+            packed_bytes += len;
+        }
+        job.bytes[f] = packed_bytes;
+    }
+    s.gz_slots.release();                                             // the slots are as large as the text was: not kept beyond the call
+}
+
 // The kept text as gzip members (rsq_textio.h ParallelGzip: 1 MB of text each, compressed by a pool of threads) in host memory; the device arrays are released.
 // A file of concatenated members is a gzip file: ranks exchange their COMPRESSED sizes and write their members at the offsets like plain text.
 int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes) {
     REQUIRE(s && r1_bytes && r2_bytes, "null argument");
     return guard([&] {
         rsq_sim::JobText &job = s->job;
-        if (!job.complete || job.is_packed) {
+        if (!job.complete || job.is_packed || job.device_packed) {
             g_last_error = "rsq_sim_job_compress: there is no generated text, or it has been compressed already";
             return (int)RSQ_ESTATE;
         }
         HIP_CHECK(hipSetDevice(s->device));
+        if (!options().host_gzip) {                                   // on the device: the members stay in device memory, rsq_sim_job_write / _job_read serve them like text
+            job_compress_on_device(*s, nullptr);
+            job.device_packed = true;
+            *r1_bytes = job.bytes[0];
+            *r2_bytes = job.bytes[1];
+            return (int)RSQ_OK;
+        }
         s2i::CopyStream st;
         s2i::Pinned host[2];
         for (auto &h : host) h.ensure(kJobSliceBytes);
@@ -2271,10 +2392,14 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
         Fault fault;
         OutPipe out(s->device, fault);
         rsq_sim::JobText &job = s->job;
+        // a .gz output: every call's text becomes gzip members on the device (rsq_deflate.h) and the members go down the link and into the file as they are -- a third
+        // of the bytes, and no host thread compresses (option host_gzip: zlib behind the writer, as before round 5)
+        const bool gz_on_device = output_path && textio::has_suffix(output_path, ".gz") && !rsq::options().host_gzip;
+        DevBuf call_text;
         if (opt.keep_text) {                                  // the text stays in device memory, as rsq_sim_job_generate keeps a rank's share of the pairs' text
             if (output_path) throw Error("keep_text and an output path exclude each other");
             job.clear();
-        } else if (!out.open(output_path)) {
+        } else if (!out.open(output_path, gz_on_device)) {
             g_last_error = std::string("Could not open '") + output_path + "' for writing.";
             return (int)RSQ_EIO;
         }
@@ -2334,12 +2459,23 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
                     dst = job.chunks[0].back()->as<char>() + job.used[0].back();
                     cap = room();
                 } else {
-                    o->reserve(want);
-                    dst = o->as<char>();
-                    cap = o->bytes();
+                    DevBuf &to = gz_on_device ? call_text : *o;
+                    to.reserve(want);
+                    dst = to.as<char>();
+                    cap = to.bytes();
                 }
                 rc = rsq_sim_error_model_fasta(s, opt.first_record + records, text, len, last ? 1 : 0, dst, cap, &out_len, &n, &used, st.st);
                 if (rc != RSQ_ENOSPC) break;
+            }
+            if (rc == RSQ_OK && gz_on_device && out_len) {
+                size_t packed = 0;
+                o->reserve(out_len / 2 + ((size_t)1 << 20));
+                rc = gzip_device(*s, call_text.as<uint8_t>(), out_len, o->as<uint8_t>(), o->bytes(), &packed, true, st.st);
+                if (rc == RSQ_ENOSPC) {
+                    o->reserve(rsq_gzip_bound(out_len));
+                    rc = gzip_device(*s, call_text.as<uint8_t>(), out_len, o->as<uint8_t>(), o->bytes(), &packed, false, st.st);
+                }
+                out_len = packed;
             }
             t_call.add(t0);
             if (rc != RSQ_OK) break;                          // g_last_error holds the reason (the reference's complaint about a record: RSQ_EIO)

@@ -251,6 +251,10 @@ struct Writer {
         else plain = fopen(path.c_str(), "wb");
         return plain || bz;
     }
+    bool open_plain(const std::string &path) {       // the bytes as they come, whatever the name says: .gz members made on the device (rsq_deflate.h)
+        plain = fopen(path.c_str(), "wb");
+        return plain != nullptr;
+    }
     bool is_open() const { return plain || gz.f || bz; }
     void write(const char *data, size_t n) {
         if (gz.f) {

@@ -15,6 +15,7 @@ static uint64_t g_screen_stats[4][2];          // quality, base call, indel: dra
 #include <memory>
 #include <utility>
 
+#include "../../reseq_amd/csrc/rsq_deflate.h"
 #include "../../reseq_amd/csrc/rsq_fasta.h"
 #include "../../reseq_amd/csrc/rsq_pack.h"
 
@@ -770,6 +771,32 @@ int emu_fasta_words_check() {
 // the library's text writer (gzip / bzip2 by the name's ending), for the tests of its compressed output
 int emu_write_text_file(const char *path, const char *data, size_t n) {
     return guard([&] { write_text_file(path, std::string(data, n)); });
+}
+
+// rsq_deflate.h's per-thread walk of a piece with the workgroup's threads taken in turn: text -> gzip members (what k_gzip_pieces / k_gzip_stored / k_gzip_compact write).
+// *len = bytes needed; written only if cap is enough.  force_stored: every piece through the stored route (the fallback for text the sample's code does not suit).
+int emu_gzip(const uint8_t *text, uint64_t n, int force_stored, uint8_t *out, uint64_t cap, uint64_t *len) {
+    return guard([&] {
+        std::vector<uint8_t> members;
+        if (force_stored) {
+            std::vector<uint8_t> slot(rsq::gz::kSlot);
+            for (uint64_t at = 0; at < n; at += rsq::gz::kPiece) {
+                const uint32_t m = rsq::gz::stored_piece_on_the_host(text + at, (uint32_t)std::min<uint64_t>(rsq::gz::kPiece, n - at), slot.data());
+                members.insert(members.end(), slot.begin() + rsq::gz::kSlotPad, slot.begin() + rsq::gz::kSlotPad + m);
+            }
+        } else rsq::gz::gzip_on_the_host(text, n, members);
+        *len = members.size();
+        if (members.size() <= cap && !members.empty()) memcpy(out, members.data(), members.size());
+    });
+}
+// the code a sample's counts lead to: lengths of the 286 + 30 symbols and the header's size, for the tests of the code builder
+int emu_gzip_code(const uint32_t *sample, uint8_t *lengths, uint32_t *header_bits) {
+    return guard([&] {
+        const rsq::gz::Codes c = rsq::gz::build_codes(sample);
+        for (uint32_t i = 0; i < 286; ++i) lengths[i] = (uint8_t)(c.litlen[i] & 15u);
+        for (uint32_t i = 0; i < 30; ++i) lengths[286 + i] = (uint8_t)(c.dist[i] & 15u);
+        *header_bits = c.header_bits;
+    });
 }
 
 // single draws, for direct comparison with the oracle's Draw

@@ -221,27 +221,34 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
         b.sim.job_free()
         with pytest.raises(api.RsqError):                                 # freed: nothing to write
             b.sim.job_write(f1, 100, f2, 70, threads)
-    # rsq_sim_job_compress: the kept text as gzip members in host memory, written at offsets like the plain text (a rank's share of .gz outputs)
+    # rsq_sim_job_compress: the kept text as gzip members, written at offsets like the plain text (a rank's share of .gz outputs) -- made on the device and kept there
+    # (the arrays of text become arrays of members, which rsq_sim_job_read serves as well), or with option host_gzip by zlib on host threads into host memory
     import gzip
     rsq_options("job_chunk_bytes", 30_000)
     rsq_options("job_write_direct", 0)
-    b.sim.job_generate(lo, hi, 2)
-    c1, c2 = b.sim.job_compress()
-    assert 0 < c1 < len(t1) // 2 and 0 < c2 < len(t2) // 2
-    with pytest.raises(api.RsqError) as e:                                # once only; and a gather works on plain text
-        b.sim.job_compress()
-    assert e.value.code == api.RSQ_ESTATE
-    scratch = api.DeviceArray(0, 16)
-    with pytest.raises(api.RsqError) as e:
-        b.sim.job_read(0, 0, 16, scratch.ptr.value)
-    assert e.value.code == api.RSQ_ESTATE and "compressed" in str(e.value)
-    scratch.free()
-    g1, g2 = workdir / "job_1.fq.gz", workdir / "job_2.fq.gz"
-    g1.write_bytes(gzip.compress(b"in front\n"))
-    front = len(g1.read_bytes())
-    b.sim.job_write(g1, front, g2, 0, 0)
-    assert gzip.decompress(g1.read_bytes()) == b"in front\n" + t1 and len(g1.read_bytes()) == front + c1
-    assert gzip.decompress(g2.read_bytes()) == t2 and len(g2.read_bytes()) == c2
+    for host_gzip in (0, 1):
+        rsq_options("host_gzip", host_gzip)
+        b.sim.job_generate(lo, hi, 2)
+        c1, c2 = b.sim.job_compress()
+        assert 0 < c1 < len(t1) // 2 and 0 < c2 < len(t2) // 2
+        with pytest.raises(api.RsqError) as e:                                # once only
+            b.sim.job_compress()
+        assert e.value.code == api.RSQ_ESTATE
+        scratch = api.DeviceArray(0, c1)
+        if host_gzip:                                                         # in host memory: nothing on the device to read
+            with pytest.raises(api.RsqError) as e:
+                b.sim.job_read(0, 0, 16, scratch.ptr.value)
+            assert e.value.code == api.RSQ_ESTATE and "compressed" in str(e.value)
+        else:
+            b.sim.job_read(0, 0, c1, scratch.ptr.value)
+            assert gzip.decompress(scratch.to_numpy(np.uint8, c1).tobytes()) == t1
+        scratch.free()
+        g1, g2 = workdir / f"job{host_gzip}_1.fq.gz", workdir / f"job{host_gzip}_2.fq.gz"
+        g1.write_bytes(gzip.compress(b"in front\n"))
+        front = len(g1.read_bytes())
+        b.sim.job_write(g1, front, g2, 0, 0)
+        assert gzip.decompress(g1.read_bytes()) == b"in front\n" + t1 and len(g1.read_bytes()) == front + c1
+        assert gzip.decompress(g2.read_bytes()) == t2 and len(g2.read_bytes()) == c2
     b.sim.job_free()
     b.close()
 
