@@ -727,7 +727,51 @@ def main():
         sync()
         host_elapsed = time.perf_counter() - t0
         _, moved_all, host_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", 0, moved, host_elapsed)
-        to_host = {"value": total_pairs / host_elapsed, "unit": "read-pairs/s", "ms_per_step": host_elapsed / args.steps * 1e3,
+        # the same delivered as .gz: every batch's text becomes gzip members on the device (rsq_sim_gzip_device), and the members -- a third of the bytes -- cross the link
+        gz_bufs = [(TorchBuffer(torch, need1 // 2 + (1 << 20), dev), TorchBuffer(torch, need2 // 2 + (1 << 20), dev)) for _ in range(2)]
+        gz_ms = [0.0]
+
+        def host_step_gz():
+            moved = text = 0
+            for lo, hi in host_batches:
+                k = turn[0] & 1
+                turn[0] += 1
+                n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0][0], bufs[0][1])
+                if rc != api.RSQ_OK:
+                    raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+                done[k].synchronize()                                   # the copy that last used this pair of member buffers
+                sizes = []
+                for f, length in ((0, l1), (1, l2)):
+                    size, rc = sim.gzip_device(bufs[0][f].ptr, length, gz_bufs[k][f].ptr, gz_bufs[k][f].nbytes)
+                    if rc != api.RSQ_OK:
+                        raise api.RsqError(rc, api.lib().rsq_last_error().decode())
+                    gz_ms[0] += sim.last_kernel_ms("gzip")
+                    sizes.append(size)
+                with torch.cuda.stream(copy_stream):
+                    host[k][0][:sizes[0]].copy_(gz_bufs[k][0].t[:sizes[0]], non_blocking=True)
+                    host[k][1][:sizes[1]].copy_(gz_bufs[k][1].t[:sizes[1]], non_blocking=True)
+                    done[k].record(copy_stream)
+                moved += sum(sizes)
+                text += l1 + l2
+            copy_stream.synchronize()
+            return moved, text
+
+        host_step_gz()
+        sync()
+        gz_ms[0] = 0.0
+        t0 = time.perf_counter()
+        gz_moved = gz_text = 0
+        for _ in range(args.steps):
+            m_, t_ = host_step_gz()
+            gz_moved += m_
+            gz_text += t_
+        sync()
+        gz_elapsed = time.perf_counter() - t0
+        compressed = {"value": total_pairs / gz_elapsed, "unit": "read-pairs/s", "ms_per_step": gz_elapsed / args.steps * 1e3, "host_gbytes_per_s": gz_moved / gz_elapsed / 1e9,
+                      "text_over_members": gz_text / max(gz_moved, 1), "gzip_kernels_ms_per_step": gz_ms[0] / args.steps, "gzip_gbytes_of_text_per_s": gz_text / max(gz_ms[0], 1e-9) / 1e6,
+                      "note": "FASTQ text of both mates as gzip members made on the device (rsq_deflate.h: BGZF-framed, one dynamic Huffman code per call) copied to page-locked host "
+                              "buffers; the copy of batch k overlaps generation and compression of batch k+1"}
+        to_host = {"value": total_pairs / host_elapsed, "unit": "read-pairs/s", "ms_per_step": host_elapsed / args.steps * 1e3, "compressed": compressed,
                    "host_gbytes_per_s": moved_all / host_elapsed / 1e9, "batch_blocks": min(args.batch_blocks, 1200),
                    "note": "FASTQ text of both mates copied to page-locked host buffers, copy of batch k "
                    "overlapping the generation of batch k+1 (the link binds: 7.5 GB per step and GPU)"}

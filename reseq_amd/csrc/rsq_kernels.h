@@ -2536,7 +2536,14 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
         });
     } else {
         const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
+#if defined(RSQ_TRACE_FILL)      // measurements (exp/): when a workgroup began, had its image, and ended -- device clock, three words per workgroup behind the counters
+        uint64_t *trace = reinterpret_cast<uint64_t *>(chunk_counters) + 2 + 3 * blockIdx.x;
+        if (threadIdx.x == 0) trace[0] = wall_clock64();
+#endif
         RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, qbase);
+#if defined(RSQ_TRACE_FILL)
+        if (threadIdx.x == 0) trace[1] = wall_clock64();
+#endif
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t n_mine = job.rec_count[seg];
         const uint32_t *index = job.rec_index + (seg ? job.rec_count[0] : 0u);
@@ -2550,6 +2557,9 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
             const uint32_t i = active ? index[first + lane] : 0u;
             fill_record_chunk<MASK, false, PACKED>(S, job, img, qbase, seg, 0u, i, i, active, raw);
         }
+#if defined(RSQ_TRACE_FILL)
+        if (threadIdx.x == 0) trace[2] = wall_clock64();
+#endif
     }
 }
 template <uint32_t MASK, bool BINNED = false, bool PACKED = false>

@@ -515,14 +515,23 @@ static size_t fill_lds_bytes(const rsq_sim &s, bool screened, bool binned, Kerne
     if (lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return lds_bytes;
 }
-// workgroups of a read kernel: persistent, one (or two, when two images fit) per CU, not more than there are rounds of chunks.  (Spreading a small call over
-// more workgroups -- one per four chunks -- does not shorten it: a seqToIllumina call on 107 000 records takes 1.1 ms either way, the chain of 150 steps of a
-// wave that has its SIMD to itself; the command line therefore hands over several blocks in one call.)
-static uint32_t fill_blocks(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item, uint32_t block) {
+// Shape of a read kernel's launch: persistent workgroups, one (or two, when two images fit) per CU, not more than there are rounds of chunks -- and for a call
+// that does not fill the device, FEWER WAVES PER WORKGROUP ON MORE CUs: a wave that has its SIMD to itself walks a chunk's 150 steps in 0.40 ms, four waves that
+// start on one SIMD at the same instant take 1.0 ms for theirs (they run in phase: all in the Philox rounds, then all waiting for LDS; the waves of a long launch
+// drift apart and fill each other's stalls -- DESIGN.md 4.5).  A seqToIllumina call on 107 000 records took 1.08 ms on 106 workgroups of 16 waves and takes half of
+// that on 256 workgroups of 8 (tools/time_small_calls.py, profiles/r05_e_small_calls_*).  The kernels take any workgroup size up to their launch bound: the image
+// is staged by blockDim.x threads, a wave's ring lies at its number in the workgroup.
+struct FillShape {
+    uint32_t blocks, threads;
+};
+static FillShape fill_shape(const rsq_sim &s, size_t lds_bytes, uint64_t n_items, uint32_t segments_per_item, uint32_t max_threads) {
     const uint32_t per_cu = lds_bytes * 2 <= kLdsBudgetBytes ? 2u : 1u;         // workgroups resident per CU (LDS image, 2048 threads)
-    const uint64_t chunks = (n_items + 63) / 64;
-    uint32_t blocks = std::min<uint64_t>((uint64_t)s.n_cu * per_cu, std::max<uint64_t>(2, segments_per_item * cdiv(chunks, block / 64)));
-    return (blocks + 1u) & ~1u;                                     // segments alternate over blockIdx.x
+    const uint64_t chunks = segments_per_item * ((n_items + 63) / 64), slots = (uint64_t)s.n_cu * per_cu;
+    uint32_t waves = (uint32_t)std::min<uint64_t>(max_threads / 64u, std::max<uint64_t>(4u, cdiv(chunks, slots)));
+    waves = std::min(max_threads / 64u, (waves + 3u) & ~3u);                 // whole waves per SIMD
+    if (options().fill_waves > 0) waves = (uint32_t)std::min<int64_t>(max_threads / 64u, options().fill_waves);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(2, cdiv(chunks, waves)));
+    return FillShape{(blocks + 1u) & ~1u, waves * 64u};                     // segments alternate over blockIdx.x
 }
 
 // k_fill_reads: persistent waves, one workgroup per CU slot; MASK = quads per quality row (screened draws on the LDS image planned by
@@ -536,8 +545,8 @@ static const uint32_t *launch_fill_kernel(rsq_sim &s, const Fragment *frags, uin
             hipLaunchKernelGGL(k_pair_tiles, dim3(cdiv(n_pairs, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, frags, fvars, n_pairs, adapter_first, keys, hist);
         }, frags, fvars);
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_reads<MASK, VAR, BINNED>);
-    constexpr uint32_t kBlock = fill_block(VAR);
-    const uint32_t blocks = fill_blocks(s, lds_bytes, n_pairs, 2, kBlock);
+    const FillShape shape = fill_shape(s, lds_bytes, n_pairs, 2, fill_block(VAR));
+    const uint32_t blocks = shape.blocks, kBlock = shape.threads;
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
     hipFunction_t spec = spec_kernel(s, SpecKind::kReads, MASK, VAR, BINNED);
@@ -569,9 +578,15 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
             hipLaunchKernelGGL(k_record_tiles, dim3(cdiv(n, kBinBlock)), dim3(kBinBlock), 0, st, s.dev, seg_dev, job.first_index, n, keys, hist);
         });
     const size_t lds_bytes = fill_lds_bytes(s, MASK != 0, BINNED, &k_fill_records<MASK, BINNED, PACKED>);
-    const uint32_t blocks = fill_blocks(s, lds_bytes, n, 1, kFillBlockWalk);
+    const FillShape shape = fill_shape(s, lds_bytes, n, 1, kFillBlockWalk);
+    const uint32_t blocks = shape.blocks;
+#if defined(RSQ_TRACE_FILL)
+    s.cur->fill_counters.reserve(16 + 24 * (size_t)blocks);
+    HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 16 + 24 * (size_t)blocks, st));
+#else
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
+#endif
     hipFunction_t spec = spec_kernel(s, SpecKind::kRecords, MASK, PACKED, BINNED);      // (the variant's `var` flag names the packed records here)
     s.timers["fill_reads"].start(st);
     if (spec) {
@@ -580,10 +595,32 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
         RawLayout raw_arg = raw;
         void *args[] = {&s.dev, &job_arg, &raw_arg, &counters, &bins};
         spec_allow_lds(spec, lds_bytes);
-        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, kFillBlockWalk, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(spec, blocks, 1, 1, shape.threads, 1, 1, (unsigned)lds_bytes, st, args, nullptr));
     } else
-        hipLaunchKernelGGL((k_fill_records<MASK, BINNED, PACKED>), dim3(blocks), dim3(kFillBlockWalk), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
+        hipLaunchKernelGGL((k_fill_records<MASK, BINNED, PACKED>), dim3(blocks), dim3(shape.threads), lds_bytes, st, s.dev, job, raw, s.cur->fill_counters.as<uint32_t>(), bins);
     s.timers["fill_reads"].stop(st);
+#if defined(RSQ_TRACE_FILL)
+    {
+        std::vector<uint64_t> t(2 + 3 * (size_t)blocks);
+        HIP_CHECK(hipMemcpyAsync(t.data(), s.cur->fill_counters.as<uint64_t>(), t.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        uint64_t first = ~0ull, last_start = 0, last_end = 0, stage = 0, run = 0;
+        for (uint32_t b = 0; b < blocks; ++b) {
+            first = std::min(first, t[2 + 3 * b]);
+            last_start = std::max(last_start, t[2 + 3 * b]);
+            last_end = std::max(last_end, t[4 + 3 * b]);
+            stage += t[3 + 3 * b] - t[2 + 3 * b];
+            run += t[4 + 3 * b] - t[3 + 3 * b];
+        }
+        if (blocks == 64) {
+            std::string line;
+            for (uint32_t b = 0; b < blocks; ++b) line += " " + std::to_string(b) + ":" + std::to_string((t[2 + 3 * b] - first) / 100) + "+" + std::to_string((t[4 + 3 * b] - t[2 + 3 * b]) / 100);
+            fprintf(stderr, "trace_fill workgroup:start+duration (us):%s\n", line.c_str());
+        }
+        fprintf(stderr, "trace_fill: %u workgroups of %u threads, %llu items: last start %.1f us after the first, last end %.1f us; image staged in %.1f us, chunks %.1f us (means; 100 MHz clock)\n", blocks,
+                shape.threads, (unsigned long long)n, (last_start - first) / 100.0, (last_end - first) / 100.0, stage / 100.0 / blocks, run / 100.0 / blocks);
+    }
+#endif
     HIP_CHECK(hipGetLastError());
     return bins.perm;
 }

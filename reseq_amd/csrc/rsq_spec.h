@@ -147,7 +147,11 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     rtc.version(&out.rtc_major, &out.rtc_minor);
     const char *headers[] = {kSrc_rsq_types_h, kSrc_rsq_core_h, kSrc_rsq_variants_h, kSrc_rsq_kernels_h};
     const char *names[] = {"rsq_types.h", "rsq_core.h", "rsq_variants.h", "rsq_kernels.h"};
-    uint64_t h = fnv1a(program + " " + std::to_string(RSQ_FILL_BLOCK) + " " + std::to_string(RSQ_FILL_BLOCK_WALK) + " " + std::to_string(RSQ_SCREEN_BATCH) + " " + std::to_string(RSQ_CHUNK_LARGE), fnv1a(arch, 0xcbf29ce484222325ull));
+    uint64_t h = fnv1a(program + " " + std::to_string(RSQ_FILL_BLOCK) + " " + std::to_string(RSQ_FILL_BLOCK_WALK) + " " + std::to_string(RSQ_SCREEN_BATCH) + " " + std::to_string(RSQ_CHUNK_LARGE)
+#if defined(RSQ_TRACE_FILL)
+                                + " trace"
+#endif
+                            , fnv1a(arch, 0xcbf29ce484222325ull));
     for (const char *src : headers) h = fnv1a(src, strlen(src), h);
     h = fnv1a(&out.rtc_major, sizeof(int), fnv1a(&out.rtc_minor, sizeof(int), h));
     char name[64];
@@ -178,8 +182,12 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     // this library was compiled with them (workgroup size, batch of the screen, chunk of the double-precision draws): the launch and the LDS plan are the library's
     const std::string block = "-DRSQ_FILL_BLOCK=" + std::to_string(RSQ_FILL_BLOCK), walk = "-DRSQ_FILL_BLOCK_WALK=" + std::to_string(RSQ_FILL_BLOCK_WALK),
                       batch = "-DRSQ_SCREEN_BATCH=" + std::to_string(RSQ_SCREEN_BATCH), chunk = "-DRSQ_CHUNK_LARGE=" + std::to_string(RSQ_CHUNK_LARGE);
+#if defined(RSQ_TRACE_FILL)
+    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str(), "-DRSQ_TRACE_FILL=1"};
+#else
     const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str()};
-    if (rtc.compile(prog, 9, opts) != 0) {
+#endif
+    if (rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
         size_t n = 0;
         rtc.log_size(prog, &n);
         std::string log(n, '\0');
