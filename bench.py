@@ -731,9 +731,12 @@ def main():
         gz_bufs = [(TorchBuffer(torch, need1 // 2 + (1 << 20), dev), TorchBuffer(torch, need2 // 2 + (1 << 20), dev)) for _ in range(2)]
         gz_ms = [0.0]
 
+        sim.gzip_keep_code(True)                                      # one Huffman code for the run, as the command line keeps it
+        gz_batches = sharding.batches(my_lo, my_hi, args.batch_blocks)      # whole calls: a third of the bytes cross the link, the copies no longer crowd the read kernel out
+
         def host_step_gz():
             moved = text = 0
-            for lo, hi in host_batches:
+            for lo, hi in gz_batches:
                 k = turn[0] & 1
                 turn[0] += 1
                 n, l1, l2, rc = sim.pairs_device(lo, hi, bufs[0][0], bufs[0][1])
@@ -753,22 +756,24 @@ def main():
                     done[k].record(copy_stream)
                 moved += sum(sizes)
                 text += l1 + l2
-            copy_stream.synchronize()
-            return moved, text
+            return moved, text                                          # the copies run on: the next batch -- of this step or the next -- is generated under them
 
         host_step_gz()
+        copy_stream.synchronize()
         sync()
         gz_ms[0] = 0.0
         t0 = time.perf_counter()
         gz_moved = gz_text = 0
-        for _ in range(args.steps):
+        gz_steps = max(args.steps, 6)                                   # the last step's copy has nothing to hide under: a few more steps than the headline's three
+        for _ in range(gz_steps):
             m_, t_ = host_step_gz()
             gz_moved += m_
             gz_text += t_
+        copy_stream.synchronize()                                       # every member of every step is in host memory
         sync()
         gz_elapsed = time.perf_counter() - t0
-        compressed = {"value": total_pairs / gz_elapsed, "unit": "read-pairs/s", "ms_per_step": gz_elapsed / args.steps * 1e3, "host_gbytes_per_s": gz_moved / gz_elapsed / 1e9,
-                      "text_over_members": gz_text / max(gz_moved, 1), "gzip_kernels_ms_per_step": gz_ms[0] / args.steps, "gzip_gbytes_of_text_per_s": gz_text / max(gz_ms[0], 1e-9) / 1e6,
+        compressed = {"value": total_pairs / args.steps * gz_steps / gz_elapsed, "unit": "read-pairs/s", "steps": gz_steps, "ms_per_step": gz_elapsed / gz_steps * 1e3, "host_gbytes_per_s": gz_moved / gz_elapsed / 1e9,
+                      "text_over_members": gz_text / max(gz_moved, 1), "gzip_kernels_ms_per_step": gz_ms[0] / gz_steps, "gzip_gbytes_of_text_per_s": gz_text / max(gz_ms[0], 1e-9) / 1e6, "batch_blocks": args.batch_blocks,
                       "note": "FASTQ text of both mates as gzip members made on the device (rsq_deflate.h: BGZF-framed, one dynamic Huffman code per call) copied to page-locked host "
                               "buffers; the copy of batch k overlaps generation and compression of batch k+1"}
         to_host = {"value": total_pairs / host_elapsed, "unit": "read-pairs/s", "ms_per_step": host_elapsed / args.steps * 1e3, "compressed": compressed,

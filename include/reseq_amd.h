@@ -245,6 +245,9 @@ int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes);
  * "BC"); concatenated members are a gzip file for zlib's gzread, gzip -d, SeqAn and bgzip alike.  *out_len = their bytes; RSQ_ENOSPC (and the size needed) if
  * out_cap is smaller -- rsq_gzip_bound(text_len) always suffices.  Kernel time: "gzip".  rsq_sim_job_compress uses it unless option host_gzip is 1. */
 size_t rsq_gzip_bound(size_t text_len);
+/* keep = 1: the Huffman code of the NEXT rsq_sim_gzip_device call serves the calls after it as well (text of one kind, call after call: a file written in batches --
+ * no sample, no code and no wait for them per call); keep = 0 (the default): every call its own code.  Either way every member is a complete gzip member. */
+int rsq_sim_gzip_keep_code(rsq_sim *s, int keep);
 int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char *out_dev, size_t out_cap, size_t *out_len, void *stream);
 /* `bytes` of the kept text of file `file` (0 / 1) from byte `at` on, copied into the caller's device memory: a rank's contribution to one round of a gather of
  * the output (simulate.py --gatherOutput: fixed-size slices gathered on the first rank over RCCL, which writes them with rsq_dev_pwrite).  RSQ_ESTATE without text. */

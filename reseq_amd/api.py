@@ -100,6 +100,7 @@ SYMBOLS = {
     "rsq_sim_job_write": (C.c_int, [_vp, C.c_char_p, _u64, C.c_char_p, _u64, _u32]),
     "rsq_sim_job_compress": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rsq_gzip_bound": (C.c_size_t, [C.c_size_t]),
+    "rsq_sim_gzip_keep_code": (C.c_int, [_vp, C.c_int]),
     "rsq_sim_gzip_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_job_free": (C.c_int, [_vp]),
     "rsq_sim_adapter_only_pairs": (C.c_int, [_vp, _u64, _u64, _vp, _sz, _psz, _vp, _sz, _psz, _vp]),
@@ -506,6 +507,10 @@ class Simulator:
         if rc not in (RSQ_OK, RSQ_ENOSPC):
             _check(rc)
         return n.value, rc
+
+    def gzip_keep_code(self, keep=True):
+        """the next gzip_device call's Huffman code serves the calls after it (rsq_sim_gzip_keep_code)"""
+        _check(lib().rsq_sim_gzip_keep_code(self.h, 1 if keep else 0))
 
     def gzip(self, text):
         """bytes -> the gzip members the device makes of them (a test's and a tool's convenience: upload, rsq_sim_gzip_device, download)"""

@@ -411,6 +411,7 @@ int illumina_pe(const Args &a) {
     int64_t host_gzip = 0;
     rsq_get_option("host_gzip", &host_gzip);
     const bool gz1 = !host_gzip && rsq::textio::has_suffix(out1, ".gz"), gz2 = !host_gzip && rsq::textio::has_suffix(out2, ".gz");
+    if (ok && (gz1 || gz2)) rsq_sim_gzip_keep_code(sim, 1);      // one Huffman code for the run: the first batch's sample
     if (ok) {
         const bool o1 = f1.open(out1, gz1), o2 = f2.open(out2, gz2);
         if (!o1 || !o2) {

@@ -7,16 +7,20 @@
 // code that is NOT the piece's own: the code is built on the host once per call from the symbol counts of a sample of the call's pieces (FASTQ text is stationary:
 // the same ids, four bases, forty qualities everywhere) -- so the device never builds a code, and a piece's encoding needs nothing of another piece.
 //
-// A piece on the device, 128 threads (k_gzip_pieces):
-//   rounds of 8 KB; per round
-//   A  every position finds its candidate -- the nearest earlier position with the same four bytes, through a hash table of positions in LDS, filled 128 positions
-//      at a time (read all, barrier, atomicMax all: deterministic), plus the position one byte back (runs) -- and measures the match (len <= 257, distance <= 32768);
-//   B  thread t owns the 64-byte segment t of the round and walks it greedily (longest match at the current position, as zlib's level 1 does; a match may not
-//      leave the segment: the walks are independent), once to count its bits, then -- after a scan of the counts -- to write them: codes LSB-first into 32-bit
-//      words of the member's slot in HBM, the two words a thread may share with its neighbours by atomicOr;
-//   the end-of-block code, the CRC-32 of the text (slices per thread, folded with x^(8 len) mod P like zlib's crc32_combine) and the trailer.
-// A piece whose bits come to no less than the piece itself (text that looks nothing like the sample, or a few bytes behind the block header) is stored instead
-// (BTYPE 00) by a second kernel: text + 31 bytes bound every member, and the slot holds that.
+// A piece on the device, 256 threads (k_gzip_pieces), three workgroups per CU (51 KB of LDS each):
+//   rounds of 8 KB; the round's text -- with 272 bytes beyond it and what came before -- stands in a 16 KB ring in LDS (global loads of 16 bytes, once); per round
+//   A  every position finds its candidate -- the nearest earlier position with the same four bytes, through a hash table of positions in LDS, filled 256 positions
+//      at a time (read all, barrier, atomicMax all: deterministic), plus the position one byte back (runs) -- and probes it for eight bytes, without a loop: most
+//      positions lie inside a match that B passes over, so nothing more is measured here; a match is kept in 16 bits (length, distance up to 2048);
+//   B  thread t owns the 32-byte segment t of the round: its 32 matches and 32 bytes go into registers (six 16-byte LDS reads) and an unrolled walk takes them
+//      greedily (longest match at the current position, as zlib's level 1 does; a match that reaches the probe's end is measured to its end now; a match may not
+//      leave the segment: the walks are independent) -- once to count the bits, then, after a scan of the counts over the workgroup, to OR the codes LSB-first
+//      into the round's bit buffer in LDS (ds_or: neighbours share a word where their bits meet); the buffer's complete words go to the member in HBM in coalesced
+//      stores, its last, incomplete word to the front of the next round's buffer;
+//   the end-of-block code, the CRC-32 of the text (slices per thread, four bytes per step, folded with x^(8 len) mod P like zlib's crc32_combine) and the trailer.
+// A piece whose bits come to no less than the piece itself (text that looks nothing like the sample, or a few bytes behind the block header), or a round of which
+// needs more than 8 bits per byte, is stored instead (BTYPE 00) by a second kernel: text + 31 bytes bound every member, and the slot holds that.
+// Measured on the simulator's own FASTQ text (P0, 742 MB): 86 GB/s by kernel time, 2.78 x smaller (zlib level 1: 3.19 x, level 6: 3.71 x) -- profiles/r05_*.
 //
 // The per-thread functions are host/device code: tests/hostemu runs the same walk on the CPU against zlib's inflate.
 #pragma once
@@ -40,7 +44,9 @@ constexpr uint32_t kPiece = 65280;                 // bytes of text per member: 
 constexpr uint32_t kThreads = 256, kSeg = 32, kRound = kThreads * kSeg;
 constexpr uint32_t kHashBits = 11, kMinMatch = 3, kMaxMatch = 257;
 constexpr uint32_t kRing = 16384, kAhead = 272;      // the device keeps the last kRing bytes of the piece in LDS: a round, kAhead bytes beyond it (the longest match + a word), and the history
-constexpr uint32_t kMaxDist = kRing - kRound - kAhead - 16u;      // how far back a match may reach: what is certainly still in the ring (24 288; deflate allows 32 768)
+constexpr uint32_t kMaxDist = 2048;               // how far back a match may reach: a match is kept as (length - 2) << 11 | (distance - 1) in 16 bits, and the ring holds far more
+constexpr uint32_t kOutWords = 2048;              // words of the round's bit buffer in LDS: 8 bits per byte of the round -- a round that needs more is not worth coding
+static_assert(kSeg == 32 && kMaxDist <= kRing - kRound - kAhead - 16u, "the packed match and the ring");
 constexpr uint32_t kHeaderBytes = 18, kTrailerBytes = 8;
 constexpr uint32_t kSlot = 65536 + 64;             // bytes of a member's slot: a stored piece needs kPiece + 5 + header + trailer
 constexpr uint32_t kSlotPad = 2;                   // the member begins here in its slot: its deflate data, 18 bytes on, then lies on a 4-byte boundary (atomicOr on words)
@@ -101,27 +107,18 @@ struct RingText {
 #endif
     }
 };
-// length of the common prefix of the text at p and at q (q < p), at most `limit` bytes; nothing at or behind n is read as text
-template <class Text>
-RSQ_HD uint32_t match_length(const Text &text, uint32_t n, uint32_t p, uint32_t q, uint32_t limit) {
-    uint32_t len = 0;
-    while (len + 4u <= limit && p + len + 4u <= n) {
-        const uint32_t x = text.word(p + len) ^ text.word(q + len);
-        if (x) return len + low_zero_bytes(x);
-        len += 4u;
-    }
-    while (len < limit && p + len < n && text.byte(p + len) == text.byte(q + len)) ++len;
-    return len;
-}
-// what phase A leaves per position of a round: 0 = no match, else length - 2 (3 .. 257 -> 1 .. 255) and distance - 1
+// what phase A leaves per position of a round: a match's length (0: none) and distance
 struct Found {
     uint32_t len, dist;
 };
-// cand_plus1: the hash table's entry for the position's four bytes as it stood before this group of positions was entered (position + 1, 0 = none)
-// A match is never used beyond the end of the 64-byte segment its position lies in (phase B cuts it there): the comparison stops there as well -- inside a run of
-// one character every position would otherwise compare hundreds of bytes that no token takes.
+// Phase A looks eight bytes far (seven for a run): enough to tell a match from none and to compare two candidates, and without a loop -- most positions lie INSIDE
+// a match that the walk of phase B passes over, so what is measured here beyond that would be thrown away.  A match that reaches this far is measured to its end by
+// the walk when it takes it (extend_match).
+constexpr uint32_t kProbe = 7;
+// A match is never used beyond the end of the 32-byte segment its position lies in (phase B cuts it there): `limit` stops there as well.
+// v = text.word(p); cand_plus1: the hash table's entry for these four bytes as it stood before this group of positions was entered (position + 1, 0 = none)
 template <class Text>
-RSQ_HD Found find_match(const Text &text, uint32_t n, uint32_t round_lo, uint32_t p, uint32_t v, uint32_t cand_plus1) {      // v = text.word(p)
+RSQ_HD Found find_match(const Text &text, uint32_t n, uint32_t round_lo, uint32_t p, uint32_t v, uint32_t cand_plus1) {
     Found f{0u, 0u};
     if (p + kMinMatch > n) return f;
     const uint32_t segment_end = round_lo + ((p - round_lo) / kSeg + 1u) * kSeg;
@@ -130,13 +127,29 @@ RSQ_HD Found find_match(const Text &text, uint32_t n, uint32_t round_lo, uint32_
     if (limit < kMinMatch) return f;
     if (cand_plus1 && limit >= 4u) {                                 // the table's candidate: all four hashed bytes, or nothing (a collision)
         const uint32_t q = cand_plus1 - 1u;
-        if (p - q <= kMaxDist && text.word(q) == v) f = Found{4u + match_length(text, n, p + 4u, q + 4u, limit - 4u), p - q};
+        if (p - q <= kMaxDist && text.word(q) == v) {
+            const uint32_t x = text.word(p + 4u) ^ text.word(q + 4u), len = 4u + (x ? low_zero_bytes(x) : 4u);
+            f = Found{len < limit ? len : limit, p - q};
+        }
     }
     if (p && f.len < limit && ((text.word(p - 1u) ^ v) & 0xFFFFFFu) == 0u) {      // a run: the position one byte back (the table knows nothing nearer than a group)
-        const uint32_t len = 3u + match_length(text, n, p + 3u, p + 2u, limit - 3u);
+        const uint32_t x = text.word(p + 3u) ^ text.word(p + 2u);
+        uint32_t len = 3u + (x ? low_zero_bytes(x) : 4u);
+        if (len > limit) len = limit;
         if (len > f.len) f = Found{len, 1u};
     }
     return f;
+}
+// the match of `len` bytes (so far) at p, `dist` back, to its end: at most `most` bytes in all
+template <class Text>
+RSQ_HD uint32_t extend_match(const Text &text, uint32_t p, uint32_t dist, uint32_t len, uint32_t most) {
+    while (len < most) {
+        uint32_t x = text.word(p + len) ^ text.word(p + len - dist);
+        if (most - len < 4u) x &= (1u << (8u * (most - len))) - 1u;   // only the bytes that count
+        if (x) return len + low_zero_bytes(x);
+        len += 4u;
+    }
+    return most;
 }
 
 // RFC 1951 3.2.5: symbol, number of extra bits and their value for a length (3..257) and a distance (1..32768), by arithmetic instead of tables
@@ -157,24 +170,32 @@ RSQ_HD Sym distance_symbol(uint32_t dist) {
     return Sym{2u * k + ((d >> (k - 1u)) & 1u), k - 1u, d & ((1u << (k - 1u)) - 1u)};
 }
 
-// Phase B: the greedy walk over one segment [lo, hi) of a round whose matches lie in found_len / found_dist (indexed from the round's first position).
-// A match that would leave the segment is cut (a cut below three bytes becomes literals).
-template <class Text, class Sink, class Lens, class Dists>     // Lens / Dists: pointers into LDS on the device, plain ones in the host's walk
-RSQ_HD void walk_segment(const Text &text, uint32_t round_lo, uint32_t lo, uint32_t hi, Lens found_len, Dists found_dist, Sink &sink) {
-    uint32_t p = lo;
-    while (p < hi) {
-        uint32_t len = found_len[p - round_lo];
-        if (len) {
-            len += 2u;
-            if (p + len > hi) len = hi - p;
+// Phase B: the greedy walk over one 32-byte segment, from registers: `found` = the segment's 32 packed matches (0 = none, else (length - 2) << 11 | (distance - 1)),
+// `text` = its 32 bytes, n = how many of them exist (the piece's last segment).  A match that would leave the segment is cut (a cut below three bytes becomes
+// literals).  The loop is unrolled: every position reads its match and byte out of a register by constant shifts; what a position does depends on `skip`, the bytes
+// a match before it still covers.
+struct Segment {
+    uint32_t found[kSeg / 2u], text[kSeg / 4u];
+};
+template <class Sink, class Extend>      // Extend: (position in the segment, distance, length so far, most) -> the match's full length (extend_match on the segment's text)
+RSQ_HD void walk_segment(const Segment &g, uint32_t n, Sink &sink, const Extend &extend) {
+    uint32_t skip = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < kSeg; ++i) {
+        const uint32_t e = (g.found[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu, c = (g.text[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
+        uint32_t len = e >> 11;
+        len = len ? len + 2u : 0u;
+        if (i + len > n) len = n > i ? n - i : 0u;
+        const bool here = skip == 0u && i < n, is_match = len >= kMinMatch;
+        if (here) {
+            if (is_match) {
+                if (len >= kProbe && i + len < n) len = extend(i, (e & 2047u) + 1u, len, n - i);      // phase A looked no further
+                sink.match(len, (e & 2047u) + 1u);
+            } else sink.literal(c);
         }
-        if (len >= kMinMatch) {
-            sink.match(len, (uint32_t)found_dist[p - round_lo] + 1u);
-            p += len;
-        } else {
-            sink.literal(text.byte(p));
-            ++p;
-        }
+        skip = here ? (is_match ? len - 1u : 0u) : (skip ? skip - 1u : 0u);
     }
 }
 template <class Tab>
@@ -196,43 +217,26 @@ struct HistogramSink {                   // symbol counts of a segment (the samp
         add(kLitLen + distance_symbol(d).code);
     }
 };
-// Bits into 32-bit words of the member's slot, LSB first.  `Out`: put(word index, value, shared) -- shared words (a thread's first and last) are OR-ed atomically
-// into zeroed memory, the words in between are the thread's own.
-template <class Tab, class Out>
+// Bits into the round's buffer, LSB first, at bit `at` of it: every push ORs its bits into the one or two words they fall into (`Or`: or_word(index, value) --
+// an LDS atomic on the device: neighbouring threads share a word where their bits meet).  The buffer is zero where nothing was pushed.
+template <class Tab, class Or>
 struct BitSink {
     Tab litlen, dist;
-    Out out;
-    uint64_t acc = 0;
-    uint32_t filled = 0, word = 0;        // bits in acc, index of the word they begin
-    bool first = true;
-    RSQ_HD void begin(uint64_t bit_offset) {
-        word = (uint32_t)(bit_offset >> 5);
-        filled = (uint32_t)(bit_offset & 31u);
-        acc = 0;
-        first = true;
-    }
+    Or out;
+    uint32_t at = 0;
     RSQ_HD void push(uint32_t value, uint32_t bits) {
-        acc |= (uint64_t)value << filled;
-        filled += bits;
-        if (filled >= 32u) {
-            out.put(word, (uint32_t)acc, first);
-            first = false;
-            acc >>= 32;
-            filled -= 32u;
-            ++word;
-        }
+        const uint64_t x = (uint64_t)value << (at & 31u);
+        out.or_word(at >> 5, (uint32_t)x);
+        if ((uint32_t)(x >> 32)) out.or_word((at >> 5) + 1u, (uint32_t)(x >> 32));
+        at += bits;
     }
     RSQ_HD void code(uint32_t entry) { push(entry >> 4, entry & 15u); }
     RSQ_HD void literal(uint32_t b) { code(litlen[b]); }
     RSQ_HD void match(uint32_t len, uint32_t d) {
         const Sym l = length_symbol(len), s = distance_symbol(d);
-        code(litlen[l.code]);
-        if (l.extra_bits) push(l.extra, l.extra_bits);
-        code(dist[s.code]);
-        if (s.extra_bits) push(s.extra, s.extra_bits);
-    }
-    RSQ_HD void finish() {
-        if (filled) out.put(word, (uint32_t)acc, true);
+        const uint32_t a = litlen[l.code], b = dist[s.code];
+        push((a >> 4) | (l.extra << (a & 15u)), (a & 15u) + l.extra_bits);              // at most 15 + 3 bits (lengths up to 32)
+        push((b >> 4) | (s.extra << (b & 15u)), (b & 15u) + s.extra_bits);              // at most 15 + 10 bits (distances up to 2048)
     }
 };
 
@@ -283,15 +287,9 @@ RSQ_HD void member_header(uint8_t *h, uint32_t member_bytes) {
 
 #if RSQ_DEVICE_BUILD && !defined(RSQ_SPEC)
 // ------------------------------------------------------------------------------------------------------------------------- device
-struct SlotOut {
-    uint32_t *words;
-    RSQ_LDS uint32_t *overflow;
-    __device__ void put(uint32_t w, uint32_t v, bool shared) {
-        if (w < kSlotWords) {
-            if (shared) atomicOr(words + w, v);
-            else words[w] = v;
-        } else *overflow = 1u;
-    }
+struct LdsOr {
+    RSQ_LDS uint32_t *words;
+    __device__ void or_word(uint32_t w, uint32_t v) { atomicOr(words + w, v); }
 };
 // the CRC-32 of a piece by the workgroup: a slice per thread (the first takes the remainder), folded pairwise; every thread returns it.  `table`: 4 x 256 words --
 // four bytes per step (slicing by four), the slice read 16 bytes per load where it lies on a 16-byte boundary of memory
@@ -352,13 +350,44 @@ __device__ inline void ring_load(RSQ_LDS uint8_t *ring, const uint8_t *t, uint32
     } else
         for (uint32_t p = lo + tid; p < hi; p += kThreads) ring[p & (kRing - 1u)] = t[p];
 }
+// the thread's segment of the round out of LDS into registers: 32 packed matches, 32 bytes of text (both on 16-byte boundaries)
+__device__ inline Segment load_segment(const RSQ_LDS uint16_t *found, const RSQ_LDS uint8_t *ring, uint32_t round_lo, uint32_t lo) {
+    Segment g;
+    const RSQ_LDS uint4 *f = reinterpret_cast<const RSQ_LDS uint4 *>(found + (lo - round_lo));
+    const RSQ_LDS uint4 *t = reinterpret_cast<const RSQ_LDS uint4 *>(ring + (lo & (kRing - 1u)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 v = f[k];
+        g.found[4 * k] = v.x, g.found[4 * k + 1] = v.y, g.found[4 * k + 2] = v.z, g.found[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint4 v = t[k];
+        g.text[4 * k] = v.x, g.text[4 * k + 1] = v.y, g.text[4 * k + 2] = v.z, g.text[4 * k + 3] = v.w;
+    }
+    return g;
+}
+// The bits of `total` more bits stand in the round's buffer from bit `frac` (< 32) on: its complete words go to the member's data (coalesced), the buffer is zeroed
+// and the last, incomplete word moves to its front.  Returns the number of words written.  All threads; barriers inside.
+__device__ inline uint32_t flush_round(RSQ_LDS uint32_t *out, uint32_t *words, uint32_t word_base, uint32_t frac, uint32_t total, bool all) {
+    const uint32_t tid = threadIdx.x, have = frac + total, complete = all ? (have + 31u) >> 5 : have >> 5;
+    __syncthreads();                                                  // every thread's bits are in the buffer
+    for (uint32_t w = tid; w < complete; w += kThreads)
+        if (word_base + w < kSlotWords) words[word_base + w] = out[w];
+    const uint32_t carry = out[complete];
+    __syncthreads();
+    for (uint32_t w = tid; w <= complete + 1u && w < kOutWords + 2u; w += kThreads) out[w] = 0u;
+    __syncthreads();
+    if (tid == 0 && !all) out[0] = carry;
+    return complete;
+}
 template <bool SAMPLE>
 __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, uint64_t n, uint32_t piece_step, const Codes *codes, uint8_t *slots, uint32_t *sizes, uint32_t *hist) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing + 16u];
+    __shared__ __attribute__((aligned(16))) uint16_t s_found[kRound];
     __shared__ uint32_t head[1u << kHashBits];
-    __shared__ uint8_t found_len[kRound];
-    __shared__ uint16_t found_dist[kRound];
-    __shared__ uint32_t s_litlen[kLitLen], s_dist[kDist], s_hist[kLitLen + kDist], s_part[kThreads], s_wave[kThreads / 64u], s_overflow;
+    __shared__ uint32_t s_out[SAMPLE ? 1u : kOutWords + 2u], s_litlen[SAMPLE ? 1u : kLitLen], s_dist[SAMPLE ? 1u : kDist], s_hist[SAMPLE ? kLitLen + kDist : 1u];
+    __shared__ uint32_t s_part[kThreads], s_wave[kThreads / 64u];
     const uint32_t tid = threadIdx.x;
     const uint64_t piece = (uint64_t)blockIdx.x * piece_step;
     const uint8_t *t = text + piece * kPiece;
@@ -366,25 +395,29 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
     uint8_t *slot = SAMPLE ? nullptr : slots + piece * kSlot;
     uint32_t *words = SAMPLE ? nullptr : reinterpret_cast<uint32_t *>(slot + kSlotPad + kHeaderBytes);
     RSQ_LDS uint8_t *ring = (RSQ_LDS uint8_t *)s_ring;
+    RSQ_LDS uint16_t *found = (RSQ_LDS uint16_t *)s_found;
+    RSQ_LDS uint32_t *out = (RSQ_LDS uint32_t *)s_out;
+    const RSQ_LDS uint32_t *litlen = (const RSQ_LDS uint32_t *)s_litlen, *dist = (const RSQ_LDS uint32_t *)s_dist;
     const RingText rt{ring};
     for (uint32_t i = tid; i < (1u << kHashBits); i += kThreads) head[i] = 0u;
+    uint32_t word_base = 0, frac = 0;                                 // words of deflate data written, bits waiting in front of the buffer: the same in every thread
+    bool overflow = false;                                            // a round needed more than its buffer: the piece is stored (the same in every thread)
     if (SAMPLE) {
         for (uint32_t i = tid; i < kLitLen + kDist; i += kThreads) s_hist[i] = 0u;
     } else {
         for (uint32_t i = tid; i < kLitLen; i += kThreads) s_litlen[i] = codes->litlen[i];
         if (tid < kDist) s_dist[tid] = codes->dist[tid];
-        if (tid == 0) s_overflow = 0u;
-        uint4 *z = reinterpret_cast<uint4 *>(slot);                     // the slot zeroed: bits are OR-ed into it (slots are 16-byte multiples apart)
-        for (uint32_t i = tid; i < kSlot / 16u; i += kThreads) z[i] = uint4{0u, 0u, 0u, 0u};
-        __syncthreads();
-        for (uint32_t w = tid; w * 32u < codes->header_bits; w += kThreads) words[w] = codes->header[w];
+        for (uint32_t w = tid; w < kOutWords + 2u; w += kThreads) out[w] = w * 32u < codes->header_bits ? codes->header[w] : 0u;      // the block header: the first bits of the data
+        const uint32_t header_bits = codes->header_bits;
+        word_base += flush_round(out, words, word_base, 0u, header_bits, false);
+        frac = header_bits & 31u;
     }
-    uint64_t bit = SAMPLE ? 0u : codes->header_bits;                  // the same in every thread
     for (uint32_t round_lo = 0; round_lo < len; round_lo += kRound) {
         const uint32_t round_hi = round_lo + kRound < len ? round_lo + kRound : len;
         // the ring: this round and kAhead bytes behind it are new (the first round brings its own bytes as well), everything older stays
         {
             const uint32_t from = round_lo ? round_lo + kAhead : 0u, to = round_lo + kRound + kAhead < len ? round_lo + kRound + kAhead : len;
+            __syncthreads();
             if (from < to) ring_load(ring, t, from, to);
             __syncthreads();
             if (tid < 16u) ring[kRing + tid] = ring[tid];
@@ -396,23 +429,22 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
             const uint32_t v = rt.word(p), h = hashed ? hash4(v) : 0u, cand = hashed ? head[h] : 0u;      // (bytes behind the piece's end may be anything: they are never counted)
             __syncthreads();
             if (hashed) atomicMax(&head[h], p + 1u);
-            if (p < round_hi) {
-                const Found f = find_match(rt, len, round_lo, p, v, cand);
-                found_len[p - round_lo] = (uint8_t)(f.len ? f.len - 2u : 0u);
-                found_dist[p - round_lo] = (uint16_t)(f.len ? f.dist - 1u : 0u);
+            if (p < round_lo + kRound) {
+                const Found f = p < round_hi ? find_match(rt, len, round_lo, p, v, cand) : Found{0u, 0u};
+                found[p - round_lo] = (uint16_t)(f.len ? ((f.len - 2u) << 11) | (f.dist - 1u) : 0u);
             }
             __syncthreads();
         }
-        const uint32_t lo = round_lo + tid * kSeg, hi = lo + kSeg < round_hi ? lo + kSeg : round_hi;
+        const uint32_t lo = round_lo + tid * kSeg, n_seg = lo >= round_hi ? 0u : (round_hi - lo < kSeg ? round_hi - lo : kSeg);
+        const Segment g = load_segment(found, ring, round_lo, lo);
+        const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(rt, lo + i, d, so_far, most); };
         if (SAMPLE) {
-            if (lo < hi) {
-                auto add = [&](uint32_t sym) { atomicAdd(&s_hist[sym], 1u); };
-                HistogramSink<decltype(add)> sink{add};
-                walk_segment(rt, round_lo, lo, hi, (const RSQ_LDS uint8_t *)found_len, (const RSQ_LDS uint16_t *)found_dist, sink);
-            }
+            auto add = [&](uint32_t sym) { atomicAdd(&s_hist[sym], 1u); };
+            HistogramSink<decltype(add)> sink{add};
+            walk_segment(g, n_seg, sink, extend);
         } else {
-            CountSink<const RSQ_LDS uint32_t *> count{(const RSQ_LDS uint32_t *)s_litlen, (const RSQ_LDS uint32_t *)s_dist};
-            if (lo < hi) walk_segment(rt, round_lo, lo, hi, (const RSQ_LDS uint8_t *)found_len, (const RSQ_LDS uint16_t *)found_dist, count);
+            CountSink<const RSQ_LDS uint32_t *> count{litlen, dist};
+            walk_segment(g, n_seg, count, extend);
             // exclusive scan of the segments' bits over the workgroup: within the wave by shuffles, the waves' totals through LDS
             uint32_t incl = count.bits;
             for (uint32_t d = 1; d < 64u; d *= 2) {
@@ -426,15 +458,14 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
                 if (w < (tid >> 6)) before += s_wave[w];
                 total += s_wave[w];
             }
-            if (lo < hi) {
-                BitSink<const RSQ_LDS uint32_t *, SlotOut> sink{(const RSQ_LDS uint32_t *)s_litlen, (const RSQ_LDS uint32_t *)s_dist, SlotOut{words, (RSQ_LDS uint32_t *)&s_overflow}};
-                sink.begin(bit + before + incl - count.bits);
-                walk_segment(rt, round_lo, lo, hi, (const RSQ_LDS uint8_t *)found_len, (const RSQ_LDS uint16_t *)found_dist, sink);
-                sink.finish();
+            if (frac + total > kOutWords * 32u) overflow = true;
+            if (!overflow) {
+                BitSink<const RSQ_LDS uint32_t *, LdsOr> sink{litlen, dist, LdsOr{out}, frac + before + incl - count.bits};
+                walk_segment(g, n_seg, sink, extend);
+                word_base += flush_round(out, words, word_base, frac, total, false);
+                frac = (frac + total) & 31u;
             }
-            bit += total;
         }
-        __syncthreads();                                                  // the round's matches and the waves' totals are done with
     }
     if (SAMPLE) {
         if (tid == 0) atomicAdd(&s_hist[256], 1u);
@@ -443,18 +474,19 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
             if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
         return;
     }
-    if (tid == 0) {
-        BitSink<const RSQ_LDS uint32_t *, SlotOut> sink{(const RSQ_LDS uint32_t *)s_litlen, (const RSQ_LDS uint32_t *)s_dist, SlotOut{words, (RSQ_LDS uint32_t *)&s_overflow}};
-        sink.begin(bit);
+    const uint32_t eob_bits = s_litlen[256] & 15u;
+    if (tid == 0 && !overflow) {
+        BitSink<const RSQ_LDS uint32_t *, LdsOr> sink{litlen, dist, LdsOr{out}, frac};
         sink.code(s_litlen[256]);
-        sink.finish();
     }
-    bit += s_litlen[256] & 15u;
+    const uint64_t bits = (uint64_t)word_base * 32u + frac + eob_bits;
+    if (!overflow) flush_round(out, words, word_base, frac, eob_bits, true);
+    __syncthreads();
     // the ring is done with: its memory holds the CRC's tables
-    const uint32_t crc = piece_crc(t, len, reinterpret_cast<RSQ_LDS uint32_t *>(ring), (RSQ_LDS uint32_t *)s_part);      // its barriers also publish s_overflow
+    const uint32_t crc = piece_crc(t, len, reinterpret_cast<RSQ_LDS uint32_t *>(ring), (RSQ_LDS uint32_t *)s_part);
     if (tid == 0) {
-        const uint32_t data_bytes = (uint32_t)((bit + 7u) / 8u);
-        if (s_overflow || data_bytes > 5u + len) sizes[piece] = 0u;      // no smaller than stored (a piece the code does not suit, or a few bytes behind a header of forty): stored
+        const uint32_t data_bytes = (uint32_t)((bits + 7u) / 8u);
+        if (overflow || data_bytes > 5u + len) sizes[piece] = 0u;      // no smaller than stored (a piece the code does not suit, or a few bytes behind a header of forty): stored
         else {
             member_frame(slot, data_bytes, crc, len);
             sizes[piece] = kHeaderBytes + data_bytes + kTrailerBytes;
@@ -653,32 +685,26 @@ inline Codes build_codes(const uint32_t *sample) {
 
 // ---------------------------------------------------------------------------------------- host: a piece, thread by thread (tests/hostemu)
 // The device's walk with the workgroup's threads taken one after the other: `hist` != nullptr counts the piece's symbols (the sample), else the member is written
-// to out (kSlot bytes, zeroed here); returns the member's size, 0 if its bits do not fit the slot (the caller stores the piece).
+// to out (kSlot bytes, zeroed here); returns the member's size, 0 where the device gives the piece up (a round's bits beyond its buffer, or no smaller than stored).
 inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *codes, uint8_t *out, uint32_t *hist) {
     std::vector<uint32_t> head((size_t)1 << kHashBits, 0);
-    std::vector<uint8_t> found_len(kRound);
-    std::vector<uint16_t> found_dist(kRound);
-    uint32_t *words = reinterpret_cast<uint32_t *>(out + kSlotPad + kHeaderBytes);
-    const uint32_t slot_words = kSlotWords;
-    bool overflow = false;
-    struct Out {
+    std::vector<uint16_t> found(kRound);
+    std::vector<uint32_t> data((size_t)kSlotWords + kOutWords + 4, 0);      // the deflate data, all of it in one buffer of bits
+    struct Or {
         uint32_t *words;
-        uint32_t cap;
-        bool *overflow;
-        void put(uint32_t w, uint32_t v, bool) {
-            if (w < cap) words[w] |= v;
-            else *overflow = true;
-        }
+        void or_word(uint32_t w, uint32_t v) { words[w] |= v; }
     };
     uint64_t bit = 0;
+    bool overflow = false;
     if (!hist) {
-        memset(out, 0, kSlot);
-        for (uint32_t w = 0; w * 32u < codes->header_bits; ++w) words[w] = codes->header[w];
+        for (uint32_t w = 0; w * 32u < codes->header_bits; ++w) data[w] = codes->header[w];
         bit = codes->header_bits;
     }
+    const PlainText pt{text, n};
     for (uint32_t round_lo = 0; round_lo < n; round_lo += kRound) {
         const uint32_t round_hi = std::min(n, round_lo + kRound);
-        for (uint32_t group = round_lo; group < round_hi; group += kThreads) {              // phase A, 128 positions at a time
+        std::fill(found.begin(), found.end(), 0);
+        for (uint32_t group = round_lo; group < round_hi; group += kThreads) {              // phase A, kThreads positions at a time
             uint32_t cand[kThreads];
             for (uint32_t t = 0; t < kThreads; ++t) {
                 const uint32_t p = group + t;
@@ -694,40 +720,58 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
             for (uint32_t t = 0; t < kThreads; ++t) {
                 const uint32_t p = group + t;
                 if (p >= round_hi) break;
-                const Found f = find_match(PlainText{text, n}, n, round_lo, p, PlainText{text, n}.word(p), cand[t]);
-                found_len[p - round_lo] = (uint8_t)(f.len ? f.len - 2u : 0u);
-                found_dist[p - round_lo] = (uint16_t)(f.len ? f.dist - 1u : 0u);
+                const Found f = find_match(pt, n, round_lo, p, pt.word(p), cand[t]);
+                found[p - round_lo] = (uint16_t)(f.len ? ((f.len - 2u) << 11) | (f.dist - 1u) : 0u);
             }
         }
-        for (uint32_t t = 0; t < kThreads; ++t) {                                            // phase B
-            const uint32_t lo = round_lo + t * kSeg, hi = std::min(round_hi, lo + kSeg);
-            if (lo >= hi) break;
+        uint32_t round_bits = 0;
+        std::vector<Segment> segs(kThreads);
+        std::vector<uint32_t> seg_n(kThreads, 0), seg_bits(kThreads, 0);
+        for (uint32_t t = 0; t < kThreads; ++t) {                                            // phase B: the segments into "registers", the counts
+            const uint32_t lo = round_lo + t * kSeg;
+            seg_n[t] = lo >= round_hi ? 0u : std::min(kSeg, round_hi - lo);
+            Segment &g = segs[t];
+            memset(&g, 0, sizeof g);
+            const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(pt, lo + i, d, so_far, most); };
+            for (uint32_t i = 0; i < kSeg; ++i) {
+                g.found[i >> 1] |= (uint32_t)found[lo - round_lo + i] << ((i & 1u) * 16u);
+                if (lo + i < n) g.text[i >> 2] |= (uint32_t)text[lo + i] << ((i & 3u) * 8u);
+            }
             if (hist) {
                 auto add = [hist](uint32_t s) { ++hist[s]; };
                 HistogramSink<decltype(add)> sink{add};
-                walk_segment(PlainText{text, n}, round_lo, lo, hi, found_len.data(), found_dist.data(), sink);
+                walk_segment(g, seg_n[t], sink, extend);
             } else {
                 CountSink<const uint32_t *> count{codes->litlen, codes->dist};
-                walk_segment(PlainText{text, n}, round_lo, lo, hi, found_len.data(), found_dist.data(), count);
-                BitSink<const uint32_t *, Out> sink{codes->litlen, codes->dist, Out{words, slot_words, &overflow}};
-                sink.begin(bit);
-                walk_segment(PlainText{text, n}, round_lo, lo, hi, found_len.data(), found_dist.data(), sink);
-                sink.finish();
-                bit += count.bits;
+                walk_segment(g, seg_n[t], count, extend);
+                seg_bits[t] = count.bits;
+                round_bits += count.bits;
             }
+        }
+        if (hist) continue;
+        if ((bit & 31u) + round_bits > kOutWords * 32u) overflow = true;                     // the device's buffer for a round's bits
+        if (overflow) continue;
+        for (uint32_t t = 0; t < kThreads; ++t) {
+            BitSink<const uint32_t *, Or> sink{codes->litlen, codes->dist, Or{data.data() + (bit >> 5)}, (uint32_t)(bit & 31u)};
+            const uint32_t lo = round_lo + t * kSeg;
+            const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(pt, lo + i, d, so_far, most); };
+            walk_segment(segs[t], seg_n[t], sink, extend);
+            bit += seg_bits[t];
         }
     }
     if (hist) {
         ++hist[256];
         return 0;
     }
-    BitSink<const uint32_t *, Out> sink{codes->litlen, codes->dist, Out{words, slot_words, &overflow}};
-    sink.begin(bit);
-    sink.code(codes->litlen[256]);
-    sink.finish();
+    if (!overflow) {
+        BitSink<const uint32_t *, Or> sink{codes->litlen, codes->dist, Or{data.data() + (bit >> 5)}, (uint32_t)(bit & 31u)};
+        sink.code(codes->litlen[256]);
+    }
     bit += codes->litlen[256] & 15u;
     const uint32_t data_bytes = (uint32_t)((bit + 7u) / 8u), member = kHeaderBytes + data_bytes + kTrailerBytes;
     if (overflow || data_bytes > 5u + n) return 0;                   // as the device decides: no smaller than stored
+    memset(out, 0, kSlot);
+    memcpy(out + kSlotPad + kHeaderBytes, data.data(), data_bytes);
     uint32_t table[256];
     for (uint32_t i = 0; i < 256; ++i) table[i] = crc_table_entry(i);
     // the CRC as the device folds it: a slice per thread (the first takes the remainder), pairs folded level by level with x^(8 L 2^k)

@@ -220,6 +220,7 @@ struct rsq_sim : SimState {
         }
     } job;
     DevBuf totals;                 // [sub-ranges + 1][2] bytes of FASTQ text in front of a sub-range, per file
+    bool gz_keep_code = false, gz_have_code = false;      // rsq_sim_gzip_keep_code: the code of the first call serves the calls after it
     DevBuf gz_slots, gz_sizes, gz_at, gz_hist, gz_codes, gz_total;      // gzip on the device (rsq_deflate.h): the members' slots, their sizes and places, the sample's counts, the call's code
     Workspace *cur = &ws[0];       // the set the stage being enqueued works on
     hipStream_t side[2] = {nullptr, nullptr};      // the sieve's and the text's stream of a pipelined call
@@ -1975,7 +1976,10 @@ constexpr uint64_t kGzipStretch = 8192;                              // pieces p
 static int gzip_device(rsq_sim &s, const uint8_t *text, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, bool with_code, hipStream_t st) {
     *out_len = 0;
     if (!n) return RSQ_OK;
-    if (with_code) gzip_code_of(s, text, n, st);
+    if (with_code && !(s.gz_keep_code && s.gz_have_code)) {
+        gzip_code_of(s, text, n, st);
+        s.gz_have_code = true;
+    }
     const uint64_t n_pieces = cdiv(n, gz::kPiece);
     const uint64_t stretch = std::min<uint64_t>(n_pieces, kGzipStretch);
     s.gz_slots.reserve(stretch * gz::kSlot);
@@ -2008,6 +2012,12 @@ static int gzip_device(rsq_sim &s, const uint8_t *text, size_t n, uint8_t *out, 
     }
     return RSQ_OK;
 }
+int rsq_sim_gzip_keep_code(rsq_sim *s, int keep) {
+    REQUIRE(s, "null argument");
+    s->gz_keep_code = keep != 0;
+    s->gz_have_code = false;
+    return RSQ_OK;
+}
 size_t rsq_gzip_bound(size_t text_len) { return (size_t)cdiv(text_len, gz::kPiece) * (gz::kHeaderBytes + 5u + gz::kTrailerBytes) + text_len; }
 int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char *out_dev, size_t out_cap, size_t *out_len, void *stream) {
     REQUIRE(s && out_len && (text_dev || !text_len) && (out_dev || !out_cap), "null argument");
@@ -2021,6 +2031,15 @@ int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char 
 static void job_compress_on_device(rsq_sim &s, hipStream_t st) {
     rsq_sim::JobText &job = s.job;
     reset_call_timers(s);
+    const bool kept = s.gz_keep_code;                                 // a job's text is of one kind: the first array's sample gives the code of all of them
+    if (!kept) (void)rsq_sim_gzip_keep_code(&s, 1);
+    struct Restore {
+        rsq_sim &s;
+        bool kept;
+        ~Restore() {
+            if (!kept) (void)rsq_sim_gzip_keep_code(&s, 0);
+        }
+    } restore{s, kept};
     for (int f = 0; f < 2; ++f) {
         uint64_t packed_bytes = 0;
         for (size_t c = 0; c < job.chunks[f].size(); ++c) {
@@ -2031,7 +2050,7 @@ static void job_compress_on_device(rsq_sim &s, hipStream_t st) {
             std::unique_ptr<DevBuf> packed(new DevBuf());
             size_t len = 0;
             packed->reserve(n / 2 + ((size_t)1 << 20));
-            int rc = gzip_device(s, text, n, packed->as<uint8_t>(), packed->bytes(), &len, c == 0, st);
+            int rc = gzip_device(s, text, n, packed->as<uint8_t>(), packed->bytes(), &len, true, st);
             if (rc == RSQ_ENOSPC) {
                 packed.reset(new DevBuf());
                 packed->reserve(rsq_gzip_bound(n));
@@ -2433,6 +2452,7 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
         // of the bytes, and no host thread compresses (option host_gzip: zlib behind the writer, as before round 5)
         const bool gz_on_device = output_path && textio::has_suffix(output_path, ".gz") && !rsq::options().host_gzip;
         DevBuf call_text;
+        if (gz_on_device) (void)rsq_sim_gzip_keep_code(s, 1);        // the first call's sample gives the code of the whole file
         if (opt.keep_text) {                                  // the text stays in device memory, as rsq_sim_job_generate keeps a rank's share of the pairs' text
             if (output_path) throw Error("keep_text and an output path exclude each other");
             job.clear();
