@@ -1846,9 +1846,18 @@ struct VariantSrc : FragmentSrc {
     // what the common step -- a plain reference base, no variant in reach -- needs, kept between steps: the strand position of variant `cur`
     // (none: 0xFFFFFFFF) and the end of the block holding spos; refreshed whenever cur or the block changes
     mutable uint32_t vs_cur, bend_cur;
+    // ... and, for the step itself, ONE number: the strand position before which nothing of the walk can happen -- no variant of the block at or before the
+    // position, not the block's last position (the step behind it changes the block), not inside an insertion, not beyond the strand.  A step in front of it
+    // is the plain track's (one compare); everything else goes the long way below, which keeps its own state (cur, var_pos, the block's end) wherever the
+    // compiler finds room for it -- these are read once in a few hundred steps.
+    mutable uint32_t quiet_until;
     RSQ_HD void refresh() const {
         vs_cur = cur < n_var ? var_spos(cur) : 0xFFFFFFFFu;
         bend_cur = block_end(spos);
+        uint32_t q = bend_cur - 1u;
+        if (vs_cur < q) q = vs_cur;
+        if (L < q) q = L;
+        quiet_until = var_pos ? 0u : q;
     }
     RSQ_HD void rewind() const {
         spos = spos0;
@@ -1868,8 +1877,20 @@ struct VariantSrc : FragmentSrc {
         return true;
     }
     RSQ_HD uint32_t sys_base(uint32_t) const {                                  // :240-292
+#if defined(RSQ_NO_QUIET)                                                        // measurements: the walk without its short cut
+        if (false) {
+#else
+        if (__builtin_expect(spos < quiet_until, 1)) {                          // nearly every step
+#endif
+            const uint32_t se = FragmentSrc::sys_base(spos - spos0);
+            ++spos;
+            return se;
+        }
+        return sys_base_event();
+    }
+    RSQ_HD uint32_t sys_base_event() const {
         if (off_strand()) return 0;
-        if (!var_pos && !(vs_cur < bend_cur && vs_cur <= spos)) {               // the common step: no variant of the block at or before this position
+        if (!var_pos && !(vs_cur < bend_cur && vs_cur <= spos)) {               // no variant of the block at or before this position: the block's last position
             const uint32_t se = FragmentSrc::sys_base(spos - spos0);
             if (++spos == bend_cur) {
                 cur = lower_bound(spos);
