@@ -234,6 +234,13 @@ struct GlobalRow32 {
     const float *p;
     RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const Quad *>(p + 4u * c); }
 };
+// a row of the single-precision pool by its BYTE offset from the pool's (wave-uniform) address: the load then takes the pool's address from scalar registers and a
+// 32-bit offset per lane (global_load ... v_off, s[base:base+1] offset:16c) -- one 32-bit multiply-add per row instead of a 64-bit address built per access
+struct PoolRow32 {
+    const float *pool;
+    uint32_t at;
+    RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const Quad *>(reinterpret_cast<const char *>(pool) + (at + 16u * c)); }
+};
 struct LdsRow32 {
     const RSQ_LDS float *p;
     RSQ_HD Quad quad(uint32_t c) const { return *reinterpret_cast<const RSQ_LDS Quad *>(p + 4u * c); }
@@ -242,7 +249,7 @@ struct LdsRow32 {
 // LDS: the callers branch wave-uniformly between LdsRow32 and this)
 struct MixedRow32 {
     LdsRow32 l;
-    GlobalRow32 g;
+    PoolRow32 g;
     bool use_lds;
     RSQ_HD Quad quad(uint32_t c) const { return use_lds ? l.quad(c) : g.quad(c); }
 };

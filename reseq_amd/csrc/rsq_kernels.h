@@ -1685,14 +1685,14 @@ struct ScreenTables {
     }
     RSQ_HD uint32_t draw_base_call(uint32_t i, const uint32_t (&idx)[4], uint32_t u, uint32_t &ps) const {
         const uint32_t local = i - qbase * 5u, slot = RSQ_PLAN(S, slot_b), nr = RSQ_PLAN(S, rate_rows_b), r3 = RSQ_GEO_ROW(S, b, 3, idx[3]);
-        const float *g = S.pool32 + RSQ_PLAN(S, b.off32) + i * (RSQ_PLAN(S, b.table_rows) * slot);             // the table's rows in device memory
+        const uint32_t g = 4u * (RSQ_PLAN(S, b.off32) + i * (RSQ_PLAN(S, b.table_rows) * slot));               // the table's rows in device memory: bytes from the pool's address (below 4 GB: pack_tables)
         const LdsRow32 m0{img + RSQ_PLAN(S, b.lds) + local * RSQ_PLAN(S, b.lds_stride) + RSQ_GEO_ROW(S, b, 0, idx[0]) * slot};
-        const GlobalRow32 m1{g + (RSQ_PLAN(S, b.before[1]) + RSQ_GEO_ROW(S, b, 1, idx[1])) * slot};
+        const PoolRow32 m1{S.pool32, g + 4u * (RSQ_PLAN(S, b.before[1]) + RSQ_GEO_ROW(S, b, 1, idx[1])) * slot};
         const uint32_t r2 = RSQ_GEO_ROW(S, b, 2, idx[2]);
         const bool m2_staged = RSQ_PLAN(S, b.lds2) != kNoLds, staged = r3 < nr;
         const MixedRow32 m2{LdsRow32{img + (m2_staged ? RSQ_PLAN(S, b.lds2) + local * RSQ_PLAN(S, b.lds2_stride) + r2 * slot : 0u)},
-                            GlobalRow32{g + (RSQ_PLAN(S, b.before[2]) + r2) * slot}, m2_staged};
-        const MixedRow32 m3{LdsRow32{img + RSQ_PLAN(S, b3_off) + local * RSQ_PLAN(S, b3_stride) + (staged ? r3 : 0u) * slot}, GlobalRow32{g + (RSQ_PLAN(S, b.before[3]) + r3) * slot}, staged};
+                            PoolRow32{S.pool32, g + 4u * (RSQ_PLAN(S, b.before[2]) + r2) * slot}, m2_staged};
+        const MixedRow32 m3{LdsRow32{img + RSQ_PLAN(S, b3_off) + local * RSQ_PLAN(S, b3_stride) + (staged ? r3 : 0u) * slot}, PoolRow32{S.pool32, g + 4u * (RSQ_PLAN(S, b.before[3]) + r3) * slot}, staged};
         uint32_t col = 0;
         const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2, m3);
         RSQ_SCREEN_COUNT(1, decided);
@@ -1708,10 +1708,10 @@ struct ScreenTables {
         ps = 1u;
         if (sure) return 0;                                 // the lanes that are not sure draw among themselves; a wave without one skips the branch (s_cbranch_execz)
         const uint32_t slot = RSQ_PLAN(S, slot_i), r0 = RSQ_GEO_ROW(S, i, 0, idx[0]);
-        const float *g = S.pool32 + RSQ_PLAN(S, i.off32) + i * (RSQ_PLAN(S, i.table_rows) * slot);
+        const uint32_t g = 4u * (RSQ_PLAN(S, i.off32) + i * (RSQ_PLAN(S, i.table_rows) * slot));
         const bool m0_staged = RSQ_PLAN(S, i.lds) != kNoLds;
-        const MixedRow32 m0{LdsRow32{img + (m0_staged ? RSQ_PLAN(S, i.lds) + i * RSQ_PLAN(S, i.lds_stride) + r0 * slot : 0u)}, GlobalRow32{g + r0 * slot}, m0_staged};
-        const GlobalRow32 m1{g + (RSQ_PLAN(S, i.before[1]) + RSQ_GEO_ROW(S, i, 1, idx[1])) * slot}, m2{g + (RSQ_PLAN(S, i.before[2]) + RSQ_GEO_ROW(S, i, 2, idx[2])) * slot};
+        const MixedRow32 m0{LdsRow32{img + (m0_staged ? RSQ_PLAN(S, i.lds) + i * RSQ_PLAN(S, i.lds_stride) + r0 * slot : 0u)}, PoolRow32{S.pool32, g + 4u * r0 * slot}, m0_staged};
+        const PoolRow32 m1{S.pool32, g + 4u * (RSQ_PLAN(S, i.before[1]) + RSQ_GEO_ROW(S, i, 1, idx[1])) * slot}, m2{S.pool32, g + 4u * (RSQ_PLAN(S, i.before[2]) + RSQ_GEO_ROW(S, i, 2, idx[2])) * slot};
         uint32_t col = 0;
         const bool decided = draw_screened<(int)kQuadsSmall>(u, col, m0, m1, m2);
         RSQ_SCREEN_COUNT(2, decided);
@@ -1782,14 +1782,14 @@ RSQ_HD uint32_t lds_ring_items(const DevSim &S) { return 4u * RSQ_PLAN(S, img_ti
 // What does not change from step to step is worked out once per chunk of reads (RingItem): where the table's rows over the read position begin and the
 // item's place in a ring slot (first position and last row of the margin are the family's).
 struct RingItem {
-    const float *rows;                 // row 0 of margin 2, at the item's group of four columns
+    uint32_t rows;                     // row 0 of margin 2, at the item's group of four columns: bytes from the pool's address
     uint32_t at;                       // floats from the slot's start
 };
 RSQ_HD RingItem lds_ring_item(const DevSim &S, uint32_t qbase, uint32_t item) {
     const uint32_t table = item / RSQ_PLAN(S, quads_q), c = item % RSQ_PLAN(S, quads_q), slot = RSQ_PLAN(S, slot_q);
-    return RingItem{S.pool32 + RSQ_PLAN(S, q.off32) + ((size_t)(qbase + table) * RSQ_PLAN(S, q.table_rows) + RSQ_PLAN(S, q.before[2])) * slot + 4u * c, table * slot + 4u * c};
+    return RingItem{4u * (RSQ_PLAN(S, q.off32) + ((qbase + table) * RSQ_PLAN(S, q.table_rows) + RSQ_PLAN(S, q.before[2])) * slot + 4u * c), table * slot + 4u * c};
 }
-RSQ_HD Quad lds_ring_load(const DevSim &S, const RingItem &it, uint32_t p) { return *reinterpret_cast<const Quad *>(it.rows + RSQ_GEO_ROW(S, q, 2, p) * RSQ_PLAN(S, slot_q)); }
+RSQ_HD Quad lds_ring_load(const DevSim &S, const RingItem &it, uint32_t p) { return PoolRow32{S.pool32, it.rows + 4u * RSQ_GEO_ROW(S, q, 2, p) * RSQ_PLAN(S, slot_q)}.quad(0u); }
 RSQ_HD void lds_ring_store(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p, const Quad &q) {
     *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * RSQ_PLAN(S, ring_stride) + it.at) = q;
 }
