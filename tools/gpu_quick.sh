@@ -3,9 +3,9 @@
 tag=${1:-quick}; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery $*"
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery --no-other-configs $*"
 timeout 600 $B > $out/bench.json 2> $out/bench.err
-P="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-delivery $*"
+P="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-delivery --no-other-configs $*"
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $out/pmc -o p --output-format csv -- $P > /dev/null 2> $out/pmc.err
 python - "$out" <<'PY'
 import csv, glob, collections, json, sys
