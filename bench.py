@@ -115,7 +115,10 @@ def cpu_baseline(profile_path, seqs, seed):
     out = {"value": pn / tn, "unit": "read-pairs/s", "cores": cores, "kind": "port",
            "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1},
            "sample": f"oracle/liboracle.so; 1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per CPU of the container's quota; the host shows {host_threads} hardware threads; a block range "
-                     f"each): first {many_bp} bp, {pn} pairs in {tn:.1f} s; sieve + CreateReads, pre-passes excluded"}
+                     f"each): first {many_bp} bp, {pn} pairs in {tn:.1f} s; sieve + CreateReads, pre-passes excluded.  The bridge to the reference itself (SURVEY.md 8(d) item 4, cannot be "
+                     f"re-measured here: the reference does not build in this image): BASELINE.md's survey ran Simulator::Simulate under a header shim on an 8-vCPU 2.1 GHz Xeon with a degenerate "
+                     f"(hand-filled) profile -- 17.7 k pairs/s on one thread, 95 k on eight; from the three per-base draws alone with realistic K, 9.3 k pairs/s per core",
+           "reference_survey": {"pairs_per_s_one_thread": 17700, "pairs_per_s_eight_threads": 95000, "source": "BASELINE.md (survey-time measurement, degenerate profile, another host)"}}
     return out, text
 
 
