@@ -292,12 +292,12 @@ __device__ uint32_t record_of_lane(P rec, uint64_t size, uint32_t i, uint32_t at
     if (e != kRecordOk) atomicMin(&summary[1], i);
     return e == kRecordOk ? f.len : 0u;
 }
-__global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *text, uint32_t n, Records r, uint16_t *codes, uint32_t *summary) {
+__global__ void __launch_bounds__(kRecordsBlock) k_fasta_records(const uint8_t *text, uint32_t n, Records r, uint16_t *codes, uint32_t *summary, uint32_t stage_limit) {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     const uint32_t first = blockIdx.x * kRecordsBlock, last = min(first + kRecordsBlock, n), i = first + threadIdx.x;
     const uint32_t begin = r.at[first], end = r.at[last];
     const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(text + begin) & 15u), span = skew + (end - begin);
-    const bool staged = span <= kStageBytes;
+    const bool staged = span <= stage_limit;                          // kStageBytes; 0 (option fasta_no_stage): every workgroup reads its records where they lie in HBM
     if (staged) {
         const uint4 *src = reinterpret_cast<const uint4 *>(text + begin - skew);
         uint4 *dst = reinterpret_cast<uint4 *>(stage);

@@ -41,6 +41,7 @@ struct Options {
     int64_t job_chunk_bytes = 0;       // > 0: size of the device arrays rsq_sim_job_generate keeps a rank's FASTQ text in (default 2 GiB; tests: small, so that the text spans several)
     int64_t job_write_direct = 0;      // 1: rsq_sim_job_write passes the whole 4 KB blocks of a rank's byte range around the page cache (O_DIRECT) where the file system allows it
     int64_t specialize = 1;            // 1: the read kernels are compiled for the loaded profile at run time (hiprtc, rsq_spec.h) where that is possible; 0: always the library's own instantiations
+    int64_t fasta_no_stage = 0;        // 1: k_fasta_records parses every record where it lies in HBM (the instantiation that otherwise only serves records too long for the LDS staging)
     int64_t fill_waves = 0;            // > 0: waves per workgroup of the read kernels (default: by the size of the call, fill_shape in rsq_sim.hip; measurements)
     int64_t host_gzip = 0;             // 1: .gz output is compressed by zlib on host threads (the route before round 5; the checker of the device's gzip); 0: on the device (rsq_deflate.h)
     int64_t overlap = 0;               // n > 1: rsq_sim_pairs cuts its block range into n sub-ranges whose sieve / reads / text stages are pipelined on three streams

@@ -2387,7 +2387,8 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
         if (n) {
             // per launch like fill_lds_bytes: function attributes belong to the device the call runs on, and a process may hold simulators on several
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fasta::k_fasta_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fasta::kStageBytes));
-            hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_codes.as<uint16_t>(), summary);
+            hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_codes.as<uint16_t>(), summary,
+                               rsq::options().fasta_no_stage ? 0u : fasta::kStageBytes);
         }
         s->timers["parse_records"].stop(st);
         HIP_CHECK(hipGetLastError());

@@ -90,6 +90,31 @@ def test_error_model_templates_beyond_the_staging(workdir):
     P.case_error_model_templates_beyond_the_staging(GpuBackend, workdir)
 
 
+def test_fasta_records_parsed_where_they_lie_in_hbm(workdir, rsq_options):
+    """k_fasta_records has two instantiations of parse_record: on the workgroup's stretch of text staged in LDS, and on the text where it lies in HBM (records too
+    long for the staging).  hipcc 7.2 once lost a field of one of them (rsq_fasta.h, the note above parse_record's fields): every FASTA case through BOTH, the second
+    forced with option fasta_no_stage"""
+    rsq_options("fasta_no_stage", 1)
+    P.case_error_model_tiny(GpuBackend, workdir)
+    P.case_error_model_p0(GpuBackend, workdir)
+    P.case_error_model_long_templates(GpuBackend, workdir)
+
+
+def test_a_block_of_fasta_text_without_a_record_start(workdir, tiny_profile_path):
+    """include/reseq_amd.h: a block that is not the last and holds no record start consumes nothing and yields no record (the caller hands in more); as the last block
+    it is consumed whole"""
+    from reseq_amd import api
+    prof = api.Profile(tiny_profile_path)
+    s = api.Simulator(prof, None, 0)
+    s.prepare(5)
+    try:
+        assert s.error_model_fasta(b"\n\n\n", final=False) == (b"", 0, 0)
+        assert s.error_model_fasta(b"\n\n\n", final=True) == (b"", 0, 3)
+    finally:
+        s.close()
+        prof.close()
+
+
 def test_error_model_fasta_on_damaged_files(workdir):
     """rsq_sim_error_model_fasta on files damaged at random (bytes replaced, dropped, inserted): the reference's complaint about the first malformed record as the
     restatement in tests/test_fasta_records.py expects it -- or, if the file is still well-formed, the text of rsq_sim_error_model_fastq on the fields that
