@@ -742,6 +742,12 @@ struct ReadMachine {
     template <class Tab, class Src, class Out>
     RSQ_HD bool step(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
         if (!advance(S, st)) return false;
+        iterate(S, tab, st, src, out);
+        return true;
+    }
+    // the iteration itself, for a machine that advance() found an iteration for
+    template <class Tab, class Src, class Out>
+    RSQ_HD void iterate(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
         const bool tail = phase == kTail, from_template = phase == kTemplate;
         const DevAdapters &ad = S.adapters[seg];
         const uint32_t it = par.iteration;                           // counted at the end of the step: old and new value never live side by side
@@ -825,7 +831,6 @@ struct ReadMachine {
         }
         if (!tail) out.op(it, op_code);
         par.iteration = it + 1u;
-        return true;
     }
 
     RSQ_HD void finalize(ReadMeta &meta) const {

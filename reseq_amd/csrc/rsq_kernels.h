@@ -9,6 +9,9 @@
 #include "rsq_core.h"
 #include "rsq_variants.h"
 
+#ifndef RSQ_UNIFORM_STEP
+#define RSQ_UNIFORM_STEP 0      // 1: measured slower (VALU 443 -> 492 per wave-step: the second copy of the iteration costs registers, the first keeps its moves) -- DESIGN_LOG.md section 11
+#endif
 namespace rsq {
 
 // ------------------------------------------------------------------------------------ systematic errors
@@ -2368,7 +2371,16 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             RSQ_PIN(m.par.indel_pos); RSQ_PIN(m.par.previous_indel_type); RSQ_PIN(m.org_pos); RSQ_PIN(m.cg.length); RSQ_PIN(m.cg.chars); RSQ_PIN(m.n_indels);
             RSQ_PIN(out.seq_word); RSQ_PIN(out.qual_word); RSQ_PIN(out.cur_word); RSQ_PIN(out.cur_index);
 #endif
+#if RSQ_UNIFORM_STEP
+            // Nearly every step finds an iteration in ALL lanes of the wave (reads end within a few steps of each other).  That step runs behind a wave-uniform branch:
+            // no lane sits it out, so the state it writes needs no copy of the old state kept beside it for such lanes -- the copies (two register sets around the
+            // "lane not running" join, some 35 moves per step) stay on the other path, which the wave takes in a chunk's last steps.
+            const bool run = m.advance(S, st);
+            if (!RSQ_ANY(!run)) m.iterate(S, tab, st, src, out);
+            else if (run) m.iterate(S, tab, st, src, out);
+#else
             m.step(S, tab, st, src, out);                    // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
+#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
