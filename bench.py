@@ -316,11 +316,13 @@ def _timed_pairs_job(sim, nb, batch, device, bufs, hash_blocks=48000):
                 kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
         n += k
         nbytes += l1 + l2
-        if hi <= hash_blocks + 1:
+        if hash_blocks and hi <= hash_blocks + 1:
             h1.update(bufs[0].to_numpy(np.uint8, l1).tobytes())
             h2.update(bufs[1].to_numpy(np.uint8, l2).tobytes())
-    return {"pairs": n, "fastq_bytes": nbytes, "gpu_s": round(t_gpu, 4), "pairs_per_s": n / t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()},
-            f"sha256_first_{hash_blocks}_blocks": h1.hexdigest() + ":" + h2.hexdigest()}
+    out = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": round(t_gpu, 4), "pairs_per_s": n / t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
+    if hash_blocks:
+        out[f"sha256_first_{hash_blocks}_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
+    return out
 
 
 def _pairs_buffers(sim, nb, batch, device):
@@ -384,9 +386,12 @@ def other_configs(device, seed, which=("2", "3", "4")):
         t0 = time.perf_counter()
         info = sim.prepare(7, 0, 30.0)
         prep_s = time.perf_counter() - t0
-        bufs = _pairs_buffers(sim, info.total_blocks, 24000, device)                     # also the warm-up (kernels compiled for the profile)
-        runs = {f"batch_{b}": _timed_pairs_job(sim, info.total_blocks, b, device, bufs) for b in (24000, 8000)}      # both have a call that ends with block 48000
-        same = len({(r["pairs"], r["fastq_bytes"], r["sha256_first_48000_blocks"]) for r in runs.values()}) == 1
+        bufs = _pairs_buffers(sim, info.total_blocks, info.total_blocks, device)         # also the warm-up (kernels compiled for the profile)
+        # the whole job in one call (as the headline runs its job), and in calls of 24000 and 8000 blocks (the command line takes about 4 M pairs per call);
+        # the checksum covers the first 48000 blocks: the batched runs have a call that ends there, the whole job is cut there for it
+        runs = {f"batch_{b}": _timed_pairs_job(sim, info.total_blocks, b, device, bufs) for b in (24000, 8000)}
+        runs["one_call"] = _timed_pairs_job(sim, info.total_blocks, info.total_blocks, device, bufs, hash_blocks=0)
+        same = len({(r["pairs"], r["fastq_bytes"]) for r in runs.values()}) == 1 and runs["batch_24000"]["sha256_first_48000_blocks"] == runs["batch_8000"]["sha256_first_48000_blocks"]
         out["configs[3]"] = {"workload": f"illuminaPE: Drosophila-sized reference ({sum(lengths)} bp in {len(lengths)} sequences, 1000 of them scaffolds shorter than the longest insert), P0, coverage 30, ONE GPU",
                              "pairs_per_s": max(r["pairs_per_s"] for r in runs.values()), "pairs": runs["batch_24000"]["pairs"], "runs": runs, "batching_invariant": same, "prepare_s": round(prep_s, 2),
                              "make_inputs_s": round(make_s, 1), "parity_sample": _parity_case("case_coverage_driven")}
@@ -410,9 +415,10 @@ def other_configs(device, seed, which=("2", "3", "4")):
         t0 = time.perf_counter()
         info = sim.prepare(7, 0, 30.0)
         prep_s = time.perf_counter() - t0
-        bufs = _pairs_buffers(sim, info.total_blocks, 24000, device)
+        bufs = _pairs_buffers(sim, info.total_blocks, info.total_blocks, device)
         runs = {f"batch_{b}": _timed_pairs_job(sim, info.total_blocks, b, device, bufs) for b in (24000, 12000)}
-        same = len({(r["pairs"], r["fastq_bytes"], r["sha256_first_48000_blocks"]) for r in runs.values()}) == 1
+        runs["one_call"] = _timed_pairs_job(sim, info.total_blocks, info.total_blocks, device, bufs, hash_blocks=0)
+        same = len({(r["pairs"], r["fastq_bytes"]) for r in runs.values()}) == 1 and runs["batch_24000"]["sha256_first_48000_blocks"] == runs["batch_12000"]["sha256_first_48000_blocks"]
         out["configs[4]"] = {"workload": f"illuminaPE at 1/10 of the human-sized job: {sum(job['lengths'])} bp in 24 sequences, {alleles} alleles, {job['substitutions']} substitutions + {job['indels']} "
                                          f"insertions / deletions, {job['regions']} methylation regions, P0, coverage 30, ONE GPU",
                              "pairs_per_s": max(r["pairs_per_s"] for r in runs.values()), "pairs": runs["batch_24000"]["pairs"], "runs": runs, "batching_invariant": same,

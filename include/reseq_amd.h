@@ -224,7 +224,7 @@ typedef struct {
 } rsq_fragment;   /* with insertion / deletion variants the reference span of a fragment is not [start, start + len): the read ids carry the real end */
 
 /* A rank's share of a job, generated once and kept (Simulator::Simulate's worker loop + Output/Flush, Simulator.cpp:2384-2401, 150-230, for one of N processes).
- * rsq_sim_job_generate simulates the blocks [block_lo, block_hi) in calls of `batch_blocks` blocks (0: about 4 M pairs per call) and keeps the FASTQ text of the
+ * rsq_sim_job_generate simulates the blocks [block_lo, block_hi) in calls of `batch_blocks` blocks (0: about 12 M pairs per call) and keeps the FASTQ text of the
  * whole range in device memory -- 288 GB of HBM hold a rank's share of a 30x human-sized job (236 GB of text over 8 ranks) with room to spare -- so that the
  * ranks can exchange their sizes BEFORE anything is written and every rank then writes straight to its own offset of the two final files: no shard files, no
  * second copy, no second simulation.  rsq_sim_job_write copies the kept text through page-locked double buffers and pwrite()s it at the given offsets with

@@ -1749,8 +1749,11 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         job.clear();
         if (const int rc = check_block_range(*s, block_lo, block_hi)) return rc;      // before anything is sized from the range (block_hi - block_lo is unsigned)
         const size_t chunk_bytes = options().job_chunk_bytes > 0 ? (size_t)options().job_chunk_bytes : kJobChunkBytes;
-        if (!batch_blocks)                                          // about 4 M pairs per call (large launches), at least 2000 blocks
-            batch_blocks = (uint32_t)std::min(100000.0, std::max(2000.0, 4e6 * (double)s->total_blocks / (double)std::max<uint64_t>(1, s->total_pairs)));
+        // about 12 M pairs per call, at least 2000 blocks: a call is a round of launches with a tail behind each, and a longer call shares it among more pairs --
+        // the Drosophila-sized job runs at 154 M pairs/s in calls of 2.4 M pairs and at 179 M in one call of 14.5 M, the human-sized one at a tenth of its size
+        // at 119 and 139 M (profiles/r05_i_other_configs.json); 12 M pairs take about 20 GB of the 288 for workspace and text
+        if (!batch_blocks)
+            batch_blocks = (uint32_t)std::min(400000.0, std::max(2000.0, 12e6 * (double)s->total_blocks / (double)std::max<uint64_t>(1, s->total_pairs)));
         // bytes per block a call is given room for: the largest seen so far; before the first call 400 bytes per read (2 x 150 characters, an id of 60 to 90) at the
         // job's pair density
         const double prior = 400.0 * (double)s->total_pairs / (double)std::max<uint32_t>(1, s->total_blocks);

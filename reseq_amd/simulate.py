@@ -471,7 +471,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
-    ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 4 M pairs)")
+    ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 12 M pairs)")
     ap.add_argument("--gatherOutput", action="store_true", help="the ranks' text is gathered on the first rank by a collective (RCCL) in slices and written by that rank alone, "
                     "instead of every rank writing its own byte range of the files")
     ap.add_argument("--gatherSliceMB", type=int, default=256, help="--gatherOutput: bytes (MiB) per rank and round of the gather")

@@ -103,7 +103,7 @@ t_prep = time.perf_counter() - t0
 nb = info.total_blocks
 out = {}
 r1 = r2 = None
-# `batches a,b`: blocks of 1000 start positions per rsq_sim_pairs call of the two runs (default 24000 and 12000; rsq_sim_job_generate takes about 4 M pairs per call: 40000 at coverage 30)
+# `batches a,b`: blocks of 1000 start positions per rsq_sim_pairs call of the two runs (default 24000 and 12000; rsq_sim_job_generate takes about 12 M pairs per call: 120000 at coverage 30)
 batches = [int(x) for x in sys.argv[sys.argv.index("batches") + 1].split(",")] if "batches" in sys.argv[2:] else [24000, 12000]
 for name, batch in [(f"batch_{b}", b) for b in batches]:
     h1, h2 = hashlib.sha256(), hashlib.sha256()
@@ -226,4 +226,6 @@ print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU" + 
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": max(r["pairs"] / r["gpu_s"] for r in out.values()),
-                  "batching_invariant": len({(r["pairs"], r["fastq_bytes"], r["sha256_first_48000_blocks"]) for r in out.values()}) == 1}))
+                  # pairs and bytes of every run; the checksum of the first 48000 blocks among the runs that have a call ending there
+                  "batching_invariant": len({(r["pairs"], r["fastq_bytes"]) for r in out.values()}) == 1 and
+                  len({r["sha256_first_48000_blocks"] for name, r in out.items() if 48000 % int(name.split("_")[1]) == 0} or {""}) == 1}))
