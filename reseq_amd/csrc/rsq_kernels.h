@@ -1649,6 +1649,7 @@ struct ScreenTables {
     uint32_t qbase;                    // index of the image's first quality table (image_qbase)
     const RSQ_LDS float *ring_;        // the wave's ring
     uint32_t t;
+    uint32_t demand = 0xFFFFFFFFu;     // the read position whose rows the wave staged in the slot behind the ring at this step (a read that lags by more than kRingLag), or none
     RSQ_HD DevTable desc(uint32_t local) const { return reinterpret_cast<const RSQ_LDS DevTable *>(img)[local]; }
     RSQ_HD uint32_t par0_at() const { return RSQ_PLAN(S, desc_words) - RSQ_PLAN(S, par0_words); }
     RSQ_HD DevTable quality(uint32_t i) const { return desc(i - qbase); }
@@ -1679,10 +1680,12 @@ struct ScreenTables {
         const uint32_t local = i - qbase, slot = RSQ_PLAN(S, slot_q), nr = RSQ_PLAN(S, rate_rows_q), r3 = RSQ_GEO_ROW(S, q, 3, idx[3]);
         const RSQ_LDS float *mine = img + RSQ_PLAN(S, q.lds) + local * RSQ_PLAN(S, q.lds_stride);      // margins 0 and 1 of the table
         const LdsRow32 m0{mine + RSQ_GEO_ROW(S, q, 0, idx[0]) * slot}, m1{mine + (RSQ_PLAN(S, q.before[1]) + RSQ_GEO_ROW(S, q, 1, idx[1])) * slot};
-        const LdsRow32 m2{ring(idx[2]) + local * slot};
+        // the rows over the read position: in the ring, or for a read that lags further in the slot behind it when the wave staged this position there
+        const bool near = in_ring(idx[2]);
+        const LdsRow32 m2{ring_ + (near ? idx[2] % kRingSlots : kRingSlots) * RSQ_PLAN(S, ring_stride) + local * slot};
         const LdsRow32 m3{img + RSQ_PLAN(S, q3_off) + local * RSQ_PLAN(S, q3_stride) + (r3 < nr ? r3 : 0u) * slot};
         uint32_t col = 0;
-        const bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && in_ring(idx[2]) && r3 < nr;      // a rate whose row is not staged: double precision
+        const bool decided = draw_screened<QQ>(u, col, m0, m1, m2, m3) && (near || idx[2] == demand) && r3 < nr;      // a rate or a position whose row is not staged: double precision
         RSQ_SCREEN_COUNT(0, decided);
         return settle<4>(decided, RSQ_PLAN(S, q.values), local * slot + col, local, idx, u, ps);
     }
@@ -1797,6 +1800,10 @@ RSQ_HD void lds_ring_store(const DevSim &S, const RingItem &it, RSQ_LDS float *r
     *reinterpret_cast<RSQ_LDS Quad *>(ring + (p % kRingSlots) * RSQ_PLAN(S, ring_stride) + it.at) = q;
 }
 RSQ_HD void lds_ring_stage(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) { lds_ring_store(S, it, ring, p, lds_ring_load(S, it, p)); }
+// the rows over position p into the slot behind the ring (ScreenTables::demand)
+RSQ_HD void lds_ring_stage_demand(const DevSim &S, const RingItem &it, RSQ_LDS float *ring, uint32_t p) {
+    *reinterpret_cast<RSQ_LDS Quad *>(ring + kRingSlots * RSQ_PLAN(S, ring_stride) + it.at) = lds_ring_load(S, it, p);
+}
 RSQ_HD void lds_ring_stage(const DevSim &S, uint32_t qbase, RSQ_LDS float *ring, uint32_t p, uint32_t item) { lds_ring_stage(S, lds_ring_item(S, qbase, item), ring, p); }
 // CreateReads for one mate of a fragment (Simulator.cpp:634-721, GetOrgSeq :1916-1922)
 // template and systematic errors of mate `seg` of fragment f (GetOrgSeq :1916-1922, CreateReads :680-684)
@@ -2348,14 +2355,19 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         }
     } else {
         const uint32_t lane = threadIdx.x & 63u, n_items = lds_ring_items(S);
-        RSQ_LDS float *ring = img + RSQ_PLAN(S, ring_off) + (threadIdx.x >> 6) * kRingSlots * RSQ_PLAN(S, ring_stride);
+        RSQ_LDS float *ring = img + RSQ_PLAN(S, ring_off) + (threadIdx.x >> 6) * kRingRows * RSQ_PLAN(S, ring_stride);
         ScreenTables<MASK> tab{S, img, qbase, ring, 0u};
         m.idle();
         if (active) m.init(S, tab, st, seg, tile, fragment_length, src);
         const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
         Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
+#if defined(RSQ_EXP_ROTATE)
+        uint32_t t = 0;
+        if (RSQ_ANY(m.phase != ReadMachine::kDone)) do {
+#else
         for (uint32_t t = 0; RSQ_ANY(m.phase != ReadMachine::kDone); ++t) {      // a read is complete (or a lane has none) exactly when its machine is in kDone: a plain compare for the ballot
+#endif
             if (lane < n_items) {
                 lds_ring_store(S, mine, ring, t, ahead);
                 ahead = lds_ring_load(S, mine, t + 1u);
@@ -2363,6 +2375,18 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, qbase, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
+            // A read that has lost more than kRingLag steps to deletions no longer finds the rows over its position in the ring; left to the double-precision call at
+            // every step it would double the time of its wave's remaining steps (one read in 1600 with profile P0 -- and the whole launch waits for such a wave when
+            // the call is small).  The wave stages the rows over the first such read's position in the slot behind the ring; another one at another position is rarer still.
+            const uint64_t lagging = __builtin_amdgcn_ballot_w64(m.phase != ReadMachine::kDone && t - m.par.read_pos > kRingLag);
+            tab.demand = 0xFFFFFFFFu;
+            if (lagging) {
+                const uint32_t p = __builtin_amdgcn_readlane(m.par.read_pos, __builtin_ctzll(lagging));
+                if (lane < n_items) lds_ring_stage_demand(S, mine, ring, p);
+                for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage_demand(S, lds_ring_item(S, qbase, item), ring, p);
+                __builtin_amdgcn_wave_barrier();
+                tab.demand = p;
+            }
 #if defined(RSQ_PIN_STATE)
             // the read's loop-carried state through one register each: a tied asm operand is read and written in the same register, which leads the allocator to keep a
             // value and its successor there instead of in two registers with a move between them at the loop head (12 moves per step in the kernel compiled for P0)
@@ -2378,11 +2402,19 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             const bool run = m.advance(S, st);
             if (!RSQ_ANY(!run)) m.iterate(S, tab, st, src, out);
             else if (run) m.iterate(S, tab, st, src, out);
+#elif defined(RSQ_EXP_ALWAYS)
+            (void)m.advance(S, st);
+            m.iterate(S, tab, st, src, out);
 #else
             m.step(S, tab, st, src, out);                    // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
 #endif
             __builtin_amdgcn_wave_barrier();
+#if defined(RSQ_EXP_ROTATE)
+            ++t;
+        } while (RSQ_ANY(m.phase != ReadMachine::kDone));
+#else
         }
+#endif
     }
     if (active) {
         m.finalize(meta);
@@ -2570,7 +2602,7 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
     } else {
         const uint32_t seg = blockIdx.x & 1u, qbase = image_qbase(S, seg, 0u);
 #if defined(RSQ_TRACE_FILL)      // measurements (exp/): when a workgroup began, had its image, and ended -- device clock, three words per workgroup behind the counters
-        uint64_t *trace = reinterpret_cast<uint64_t *>(chunk_counters) + 2 + 3 * blockIdx.x;
+        uint64_t *trace = reinterpret_cast<uint64_t *>(chunk_counters) + 2 + 4 * blockIdx.x;
         if (threadIdx.x == 0) trace[0] = wall_clock64();
 #endif
         RSQ_LDS float *img = fill_stage_image<MASK>(S, lds_image, qbase);
@@ -2589,9 +2621,12 @@ __device__ __forceinline__ void fill_records_body(const DevSim &S, const RecordJ
             const bool active = first + lane < n_mine;
             const uint32_t i = active ? index[first + lane] : 0u;
             fill_record_chunk<MASK, false, PACKED>(S, job, img, qbase, seg, 0u, i, i, active, raw);
+#if defined(RSQ_TRACE_FILL)
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(trace + 3), 1ull);      // chunks this workgroup ran
+#endif
         }
 #if defined(RSQ_TRACE_FILL)
-        if (threadIdx.x == 0) trace[2] = wall_clock64();
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(trace + 2), (unsigned long long)wall_clock64());      // the workgroup's last wave
 #endif
     }
 }

@@ -405,7 +405,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
             return (uint64_t)4 * Ti * odd_stride((uint64_t)rows_q * plan.slot_q) + (uint64_t)20 * Ti * odd_stride((uint64_t)rows_b * plan.slot_b);
         };
         const uint32_t ring_stride = 4 * Ti * plan.slot_q;
-        need += (uint64_t)kFillWavesMax * kRingSlots * ring_stride;                              // the waves' rings
+        need += (uint64_t)kFillWavesMax * kRingRows * ring_stride;                              // the waves' rings
         if (need + need_rate(1, 1) > budget) return false;
         // what is left goes to: error-rate rows of the quality tables up to kLdsRateRowsFirst (a lane whose rate has no staged row
         // repeats its draw in double precision), the base-call margin over the number of errors, the indel margin over the indel
@@ -441,7 +441,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
         plan.i.lds_stride = stride_i;
         if (stage_i0) at += (uint32_t)need_i0;
         plan.ring_off = at;
-        plan.q3_off = plan.ring_off + kFillWavesMax * kRingSlots * plan.ring_stride;
+        plan.q3_off = plan.ring_off + kFillWavesMax * kRingRows * plan.ring_stride;
         plan.q3_stride = odd_stride((uint64_t)plan.rate_rows_q * plan.slot_q);
         plan.b3_stride = odd_stride((uint64_t)plan.rate_rows_b * plan.slot_b);
         plan.b3_off = plan.q3_off + 4 * Ti * plan.q3_stride;

@@ -582,8 +582,8 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
     const FillShape shape = fill_shape(s, lds_bytes, n, 1, kFillBlockWalk);
     const uint32_t blocks = shape.blocks;
 #if defined(RSQ_TRACE_FILL)
-    s.cur->fill_counters.reserve(16 + 24 * (size_t)blocks);
-    HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 16 + 24 * (size_t)blocks, st));
+    s.cur->fill_counters.reserve(16 + 32 * (size_t)blocks);
+    HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 16 + 32 * (size_t)blocks, st));
 #else
     s.cur->fill_counters.reserve(8);
     HIP_CHECK(hipMemsetAsync(s.cur->fill_counters.as<uint32_t>(), 0, 8, st));
@@ -602,21 +602,23 @@ static const uint32_t *launch_records_kernel(rsq_sim &s, const RecordJob &job, c
     s.timers["fill_reads"].stop(st);
 #if defined(RSQ_TRACE_FILL)
     {
-        std::vector<uint64_t> t(2 + 3 * (size_t)blocks);
+        std::vector<uint64_t> t(2 + 4 * (size_t)blocks);
         HIP_CHECK(hipMemcpyAsync(t.data(), s.cur->fill_counters.as<uint64_t>(), t.size() * 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         uint64_t first = ~0ull, last_start = 0, last_end = 0, stage = 0, run = 0;
         for (uint32_t b = 0; b < blocks; ++b) {
-            first = std::min(first, t[2 + 3 * b]);
-            last_start = std::max(last_start, t[2 + 3 * b]);
-            last_end = std::max(last_end, t[4 + 3 * b]);
-            stage += t[3 + 3 * b] - t[2 + 3 * b];
-            run += t[4 + 3 * b] - t[3 + 3 * b];
+            first = std::min(first, t[2 + 4 * b]);
+            last_start = std::max(last_start, t[2 + 4 * b]);
+            last_end = std::max(last_end, t[4 + 4 * b]);
+            stage += t[3 + 4 * b] - t[2 + 4 * b];
+            run += t[4 + 4 * b] - t[3 + 4 * b];
         }
-        if (blocks == 64) {
+        if (getenv("RSQ_TRACE_WORKGROUPS")) {                      // workgroup: start + duration until its last wave ended (us), chunks it ran
             std::string line;
-            for (uint32_t b = 0; b < blocks; ++b) line += " " + std::to_string(b) + ":" + std::to_string((t[2 + 3 * b] - first) / 100) + "+" + std::to_string((t[4 + 3 * b] - t[2 + 3 * b]) / 100);
-            fprintf(stderr, "trace_fill workgroup:start+duration (us):%s\n", line.c_str());
+            for (uint32_t b = 0; b < blocks; ++b) {
+                line += " " + std::to_string(b) + ":" + std::to_string((t[2 + 4 * b] - first) / 100) + "+" + std::to_string((t[4 + 4 * b] - t[2 + 4 * b]) / 100) + "/" + std::to_string(t[5 + 4 * b]);
+            }
+            fprintf(stderr, "trace_fill workgroup:start+duration(us)/chunks:%s\n", line.c_str());
         }
         fprintf(stderr, "trace_fill: %u workgroups of %u threads, %llu items: last start %.1f us after the first, last end %.1f us; image staged in %.1f us, chunks %.1f us (means; 100 MHz clock)\n", blocks,
                 shape.threads, (unsigned long long)n, (last_start - first) / 100.0, (last_end - first) / 100.0, stage / 100.0 / blocks, run / 100.0 / blocks);

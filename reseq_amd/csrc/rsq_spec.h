@@ -129,6 +129,22 @@ inline std::string spec_cache_dir() {
     return base;
 }
 
+// Experiments on the read kernel without a rebuild of the library: RSQ_SPEC_OPTIONS="-DNAME=1 -DOTHER=2" adds compiler options (part of the cache key).
+inline std::vector<std::string> spec_extra_options() {
+    std::vector<std::string> out;
+    const char *e = getenv("RSQ_SPEC_OPTIONS");
+    if (!e) return out;
+    std::string cur;
+    for (const char *p = e;; ++p) {
+        if (*p == ' ' || *p == '\0') {
+            if (!cur.empty()) out.push_back(cur);
+            cur.clear();
+            if (!*p) break;
+        } else cur += *p;
+    }
+    return out;
+}
+
 // The code object of one variant for one profile: from the disk cache, else compiled (and put there).  false: not available, `note` says why.
 struct SpecCode {
     std::vector<char> code;
@@ -152,6 +168,7 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
                                 + " trace"
 #endif
                             , fnv1a(arch, 0xcbf29ce484222325ull));
+    for (const std::string &o : spec_extra_options()) h = fnv1a(o.data(), o.size(), h);
     for (const char *src : headers) h = fnv1a(src, strlen(src), h);
     h = fnv1a(&out.rtc_major, sizeof(int), fnv1a(&out.rtc_minor, sizeof(int), h));
     char name[64];
@@ -182,12 +199,13 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     // this library was compiled with them (workgroup size, batch of the screen, chunk of the double-precision draws): the launch and the LDS plan are the library's
     const std::string block = "-DRSQ_FILL_BLOCK=" + std::to_string(RSQ_FILL_BLOCK), walk = "-DRSQ_FILL_BLOCK_WALK=" + std::to_string(RSQ_FILL_BLOCK_WALK),
                       batch = "-DRSQ_SCREEN_BATCH=" + std::to_string(RSQ_SCREEN_BATCH), chunk = "-DRSQ_CHUNK_LARGE=" + std::to_string(RSQ_CHUNK_LARGE);
+    std::vector<const char *> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str()};
 #if defined(RSQ_TRACE_FILL)
-    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str(), "-DRSQ_TRACE_FILL=1"};
-#else
-    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-missing-braces", block.c_str(), walk.c_str(), batch.c_str(), chunk.c_str()};
+    opts.push_back("-DRSQ_TRACE_FILL=1");
 #endif
-    if (rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
+    const std::vector<std::string> extra = spec_extra_options();
+    for (const std::string &o : extra) opts.push_back(o.c_str());
+    if (rtc.compile(prog, (int)opts.size(), opts.data()) != 0) {
         size_t n = 0;
         rtc.log_size(prog, &n);
         std::string log(n, '\0');

@@ -89,6 +89,7 @@ constexpr uint32_t kQualityQuads[] = {3, 6, 10, 11, 12};
 // the systematic-error chains (k_sys_chain) screen their two draws as well: dominant error with kQuadsSmall quads, error rate with one of these
 constexpr uint32_t kChainQuads[] = {8, 16, 26};
 constexpr uint32_t kRingSlots = 2, kRingLag = 1;      // quality rows over the read position of the wave's last steps; a read may lag so many steps (deletions)
+constexpr uint32_t kRingRows = kRingSlots + 1u;       // and one slot staged on demand: the rows over the position of a read that lags further (ScreenTables::demand)
 
 // One table family of the read kernel (quality, base call, indel) in the screened layout.  LogArrayResult::Draw clamps every conditioning value to the table's own
 // range (AdjustIndeces, ProbabilityEstimates.h:368-380): a value outside it IS the edge row.  So every table of a family can be written over the family's COMMON

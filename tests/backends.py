@@ -39,6 +39,7 @@ def emu_lib():
         L.emu_import_reference.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_edit_profile.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.emu_set_fill_mode.argtypes = [C.c_void_p, C.c_int]
+        L.emu_set_ring_lag.argtypes = [C.c_uint32]
         L.emu_set_option.argtypes = [C.c_char_p, C.c_longlong]
         L.emu_get_option.argtypes = [C.c_char_p]
         L.emu_get_option.restype = C.c_longlong

@@ -9,6 +9,7 @@
 #include <stdint.h>
 static uint64_t g_screen_stats[4][2];          // quality, base call, indel: draws, draws the screen left to double precision; indel draws, those the random word alone does not decide
 #define RSQ_SCREEN_STATS g_screen_stats
+static uint32_t g_ring_lag = 0;                    // emu_set_ring_lag
 #include <stdlib.h>
 
 #include <map>
@@ -91,8 +92,16 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
             ReadMachine m;
             m.init(s.dev, tab, st, seg, tile, frag_len, src);
             for (;;) {
-                for (uint32_t item = 0; item < lds_ring_items(s.dev); ++item) lds_ring_stage(s.dev, qbase, ring, m.par.read_pos, item);
-                tab.t = m.par.read_pos;
+                // g_ring_lag = L: the read as a lane of a wave that is L steps ahead of it (the other lanes lost fewer steps to deletions): the ring holds the rows over the
+                // wave's last positions, and beyond kRingLag the slot behind the ring holds the rows over this read's position (fill_wave_reads)
+                const uint32_t t = m.par.read_pos + g_ring_lag;
+                for (uint32_t item = 0; item < lds_ring_items(s.dev); ++item) {
+                    const RingItem it = lds_ring_item(s.dev, qbase, item);
+                    for (uint32_t back = 0; back <= kRingLag && back <= t; ++back) lds_ring_stage(s.dev, it, ring, t - back);
+                    if (g_ring_lag > kRingLag) lds_ring_stage_demand(s.dev, it, ring, m.par.read_pos);
+                }
+                tab.t = t;
+                tab.demand = g_ring_lag > kRingLag ? m.par.read_pos : 0xFFFFFFFFu;
                 if (!m.step(s.dev, tab, st, src, out)) break;
             }
             m.finalize(meta);
@@ -281,6 +290,7 @@ void emu_screen_stats(uint64_t *out) {
     memcpy(out, g_screen_stats, sizeof g_screen_stats);
     memset(g_screen_stats, 0, sizeof g_screen_stats);
 }
+void emu_set_ring_lag(uint32_t steps) { g_ring_lag = steps; }
 void emu_set_fill_mode(void *h, int mode) { static_cast<Emu *>(h)->fill_mode = mode; }
 int emu_set_option(const char *name, long long value) { return set_option(name, value) ? 0 : -1; }       // rsq_set_option
 long long emu_get_option(const char *name) {                                                             // rsq_get_option; -1 for an unknown name

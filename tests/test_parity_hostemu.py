@@ -101,6 +101,26 @@ def test_every_draw_through_the_route_behind_the_screen(workdir, rsq_options):
     P.case_p0_reads(EmuBackend, workdir)
 
 
+@pytest.mark.parametrize("lag", [1, 2, 5])
+def test_a_read_that_lags_its_wave_finds_its_quality_rows(workdir, lag):
+    """A lane whose read lost steps to deletions is behind its wave's step counter: up to kRingLag steps its position's rows are still in the ring, beyond that the
+    wave stages them in the slot behind the ring (fill_wave_reads).  The emulated lane runs `lag` steps behind: same reads as the oracle's, and the screen still decides
+    nearly every quality draw (without the slot, every draw of such a read went to the double-precision call)."""
+    import ctypes as C
+    import numpy as np
+    from backends import emu_lib
+    stats = np.zeros(8, np.uint64)
+    emu_lib().emu_set_ring_lag(lag)
+    try:
+        emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))             # reset
+        P.case_p0_reads(EmuBackend, workdir)
+        emu_lib().emu_screen_stats(C.c_void_p(stats.ctypes.data))
+    finally:
+        emu_lib().emu_set_ring_lag(0)
+    draws, left = stats.reshape(4, 2)[0].tolist()
+    assert draws > 10_000 and left < 0.01 * draws, (draws, left)
+
+
 def test_indel_draw_decided_by_the_word_alone_with_no_indel_in_a_middle_column(workdir):
     import ctypes as C
     import numpy as np
