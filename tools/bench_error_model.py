@@ -96,12 +96,54 @@ def once_fasta(block_records):
     return time.perf_counter() - t0, ms
 
 
+def callers_side_by_side(block_records, n_callers):
+    """The same blocks handed to `n_callers` simulators of the profile, each on its own thread, stream and output buffer (a call is synchronous: a caller with
+    small blocks keeps the device busy by having more than one in flight).  Caller c takes blocks c, c + n_callers, ..."""
+    import threading
+    sims, streams, outs = [], [], []
+    for _ in range(n_callers):
+        sm = api.Simulator(prof, None, dev)
+        sm.prepare(11)
+        st = C.c_void_p()
+        api._check(api.lib().rsq_stream_create(dev, C.byref(st)))
+        sims.append(sm)
+        streams.append(st)
+        outs.append(api.DeviceArray(dev, block_records * (W + 64)))
+    starts = list(range(0, n_text, block_records))
+
+    def work(c):
+        need, k, used = C.c_size_t(0), C.c_uint64(0), C.c_size_t(0)
+        for first in starts[c::n_callers]:
+            m = min(block_records, n_text - first)
+            api._check(api.lib().rsq_sim_error_model_fasta(sims[c].h, first, C.c_void_p(d_fasta.ptr.value + first * W), m * W, 1, outs[c].ptr, outs[c].nbytes, C.byref(need), C.byref(k),
+                                                           C.byref(used), streams[c]))
+            assert k.value == m and used.value == m * W
+
+    def once():
+        th = [threading.Thread(target=work, args=(c,)) for c in range(n_callers)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    once()
+    secs = [once() for _ in range(3)]
+    for sm, st in zip(sims, streams):
+        sm.close()
+        api.lib().rsq_stream_destroy(dev, st)
+    return {"records_per_call": block_records, "callers": n_callers, "seconds": secs, "reads_per_s": n_text / min(secs)}
+
+
 fasta = {}
 for label, block_records in (("one_call", n_text), ("blocks_of_48_MB", (48 << 20) // W), ("blocks_of_192_MB", (192 << 20) // W)):
     once_fasta(block_records)
     runs = [once_fasta(block_records) for _ in range(3)]
     t, ms = min(runs, key=lambda r: r[0])
     fasta[label] = {"records_per_call": block_records, "calls": -(-n_text // block_records), "seconds": [r[0] for r in runs], "reads_per_s": n_text / t, "kernel_ms_summed": ms}
+for callers in (2, 4):
+    fasta[f"blocks_of_48_MB_{callers}_callers"] = callers_side_by_side((48 << 20) // W, callers)
 print(json.dumps({"config": "configs[2] seqToIllumina, templates and outputs resident in HBM", "from_fasta_text_parsed_on_device": dict(fasta, records=n_text, text_bytes=n_text * W), "profile": CFG["name"], "quality_values": CFG["qual_to"] - CFG["qual_from"], "records": n * calls, "records_per_call": n, "read_len": 150, "seconds": ts,
                   "reads_per_s": n * calls / best, "fill_kernel_ms_last_call": fill_ms, "with_fastq_text_on_device": {"seconds": [t for t, _ in tt], "reads_per_s": n * calls / best_text,
                                                                                                                   "text_bytes_per_call": tt[0][1],
