@@ -200,19 +200,22 @@ RSQ_HD uint32_t draw_rows_k(uint32_t K, double u, double &prob_sum, const Rs &..
 // outcome of the double-precision recipe above, otherwise the lane repeats the draw in double precision (draw<NM>, from HBM).
 // Rows are float copies of the tables (the read kernel's families: FamilyGeo, rsq_types.h; the chains': DevTable::off32), four columns per 16-byte load, pad columns zero.
 //
-// Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns from the top quad down and keeps, per quad, the sum of the columns from the top down to it; S = the
-// last of them.  Pass 2 finds the quad in which the sum from the top first exceeds r = u*S among those sums (no loads), reloads that quad
-// and finds the column.  Let T(j) be the exact sum of the columns above and including j (over the double-precision values) and
-// T the exact total: the reference returns the highest j >= 1 with T(j) > u*T up to its own rounding (relative 1e-14), else 0.
-// Error of the single-precision quantities, w = 2^-24, all terms non-negative: a product carries (1+w)^7 (four roundings to
-// float, three multiplications), a term passes at most 2 + Q additions in S (Q quads) and Q + 5 in a sum from the top, r takes
-// two more roundings: |S32 - T| <= (Q+9) w T, |top32(j) - T(j)| <= (Q+12) w T, |r32 - u T| <= (Q+11) w T.  So with
-//     delta = kScreenSafety * (2Q + 24) * w * S32
-// top32(j) - r32 > delta and r32 - top32(j+1) >= delta imply T(j) > u T > T(j+1) with room for the reference's own rounding:
-// column j is the reference's answer.  Everything else (about 2 K delta / S of all draws, 2e-4 for K = 40) is "undecided".
+// Pass 1 forms the products ((r0*r1)*r2)*r3 of all columns from the bottom quad up and keeps, per quad, the sum of the columns below it; S = the sum of all.
+// Pass 2 finds the last quad whose sum-below is less than r = (1-u)*S among those sums (no loads), reloads that quad and finds the column.  Let B(j) be the exact sum
+// of the columns below j (over the double-precision values), T the exact total and T(j) = T - B(j) the sum of the columns j and above: the reference returns the
+// highest j >= 1 with T(j) > u*T up to its own rounding (relative 1e-14 of T), else 0 -- the highest j with B(j) < (1-u)*T.
+// Error of the single-precision quantities, w = 2^-24, all terms non-negative: a product carries (1+w)^7 (four roundings to float, three multiplications), a term
+// passes at most 2 + Q additions in S (Q quads) and Q + 5 in a sum from the bottom, and r takes two more roundings -- 1-u = (2^32 - word) * 2^-32 is formed from the
+// integer, so its error is relative to ITSELF: |S32 - T| <= (Q+9) w T, |bot32(j) - B(j)| <= (Q+12) w B(j), |r32 - (1-u) T| <= (Q+11) w (1-u) T.
+// Sums of non-negative terms have errors relative to themselves, and near the decision all three are about bot32(j+1) =: hi.  So with
+//     delta = kScreenSafety * (2Q + 24) * w * (hi + 2^-20 S32)
+// r32 - bot32(j) > delta and bot32(j+1) - r32 >= delta imply B(j) < (1-u) T <= B(j+1) with room for the reference's own rounding (the 2^-20 S32 term: 1e-12 T):
+// column j is the reference's answer.  Everything else is "undecided": a band of 2 delta around every column boundary, i.e. 2 (2Q+24) w kScreenSafety * sum over
+// the boundaries of B(j)/T of all draws.  The columns are sorted by ascending likelihood (ProbabilityEstimates.h GetResults), so B(j)/T is tiny for all but the last
+// few: about 5e-5 of the quality draws of profile P0 (K = 40), where the sums from the top down -- errors relative to T at every boundary -- left 2.2e-4 undecided.
 // Preconditions, checked when the tables are packed (DevTable::f32_ok) and here: values are 0 or in [2^-60, 2^29] (no overflow;
 // an intermediate product that underflows -- (r0*r1) itself below 2^-126, i.e. two factors near 2^-60 and below -- is lost entirely: at most 2^-68 absolutely after the
-// largest factors 2^29 * 2^29, far below delta >= 2^-30 * 2^-19; this assumes gradual or flushed underflow alike, no other denormal mode) and S32 >= 2^-30.
+// largest factors 2^29 * 2^29, far below delta >= 2^-30 * 2^-20 * 2^-19; this assumes gradual or flushed underflow alike, no other denormal mode) and S32 >= 2^-30.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float Float2 __attribute__((ext_vector_type(2)));      // v_pk_mul_f32 / v_pk_add_f32
 #else
@@ -282,40 +285,40 @@ template <int Q, class... Rs>
 RSQ_HD bool draw_screened(uint32_t word, uint32_t &col, const Rs &...rs) {
     constexpr int G = Q % RSQ_SCREEN_BATCH == 0 ? RSQ_SCREEN_BATCH : (Q % 2 == 0 ? 2 : 1);      // quads per batch
     constexpr bool kKeep = Q <= 2;                           // short rows: the products stay in registers, pass 2 loads nothing
-    // pass 1 runs from the top quad down with ONE running sum, kept as a pair (the columns 0, 1 and 2, 3 of the quads so far): top[c] = the sum of the quads c and
-    // above, S = top[0].  A term passes one addition inside its quad, at most Q in the running pair and one across the pair: the bounds above hold (Q + 2 additions
-    // in S and in a sum from the top, four more inside the chosen quad).  [One sum instead of a sum per quad, a total and a second pass over the per-quad sums: 20
+    // pass 1 runs from the bottom quad up with ONE running sum, kept as a pair (the columns 0, 1 and 2, 3 of the quads so far): bot[c] = the sum of the quads below
+    // c, S = bot[Q].  A term passes one addition inside its quad, at most Q in the running pair and one across the pair: the bounds above hold (Q + 2 additions
+    // in S and in a sum from the bottom, four more inside the chosen quad).  [One sum instead of a sum per quad, a total and a second pass over the per-quad sums: 20
     // additions and the compiler's shuffles to pair them up less per draw of 40 columns.]
-    float top[Q];
+    float bot[Q + 1];
     Quad kept[kKeep ? Q : 1];
     Float2 run;
     run.x = run.y = 0.f;
+    bot[0] = 0.f;
 #pragma unroll
-    for (int g = Q - G; g >= 0; g -= G) {
+    for (int g = 0; g < Q; g += G) {
         Quad p[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) p[i] = prod_quad((uint32_t)(g + i), rs...);
 #pragma unroll
-        for (int i = G; i--;) {
+        for (int i = 0; i < G; ++i) {
             run = run + (p[i].lo + p[i].hi);
-            top[g + i] = run.x + run.y;
+            bot[g + i + 1] = run.x + run.y;
             if constexpr (kKeep) kept[g + i] = p[i];
         }
         RSQ_SCHED_BARRIER();                                 // keeps the scheduler from hoisting the loads of every batch to the top (registers)
     }
-    const float S = top[0];
-    const float r = ((float)word * 2.3283064365386963e-10f) * S;      // u = word * 2^-32, rounded to single precision
-    const float delta = kScreenSafety * (float)(2 * Q + 24) * 5.9604644775390625e-08f * S;
-    // the sums from the top never decrease: the quads whose sum exceeds r are the lowest ones; count them, keep the last sum that does not
-    float above = 0.f;
+    const float S = bot[Q];
+    const float r = ((float)(0u - word) * 2.3283064365386963e-10f) * S;      // (1 - u) S, 1 - u = (2^32 - word) * 2^-32 rounded to single precision; word 0 gives 0: undecided
+    // the sums from the bottom never decrease: the quads whose sum-below is less than r are the lowest ones; count them, keep the last such sum
+    float base = 0.f;
     uint32_t below = 0;
 #pragma unroll
-    for (int c = Q; c--;) {
-        const bool hit = top[c] > r;
-        above = hit ? above : top[c];
+    for (int c = 0; c < Q; ++c) {
+        const bool hit = bot[c] < r;
+        base = hit ? bot[c] : base;
         below += hit ? 1u : 0u;
     }
-    const uint32_t fc = below ? below - 1u : 0u;             // below == 0: u rounded to 1, or S is 0 (left undecided)
+    const uint32_t fc = below ? below - 1u : 0u;             // below == 0: r is 0 (word 0, or S is 0), left undecided
     Quad p;
     if constexpr (kKeep) {
         p = kept[0];
@@ -323,15 +326,16 @@ RSQ_HD bool draw_screened(uint32_t word, uint32_t &col, const Rs &...rs) {
         for (int c = 1; c < Q; ++c)
             if (fc == (uint32_t)c) p = kept[c];
     } else p = prod_quad(fc, rs...);
-    const float t3 = above + p.hi.y, t2 = t3 + p.hi.x, t1 = t2 + p.lo.y, t0 = t1 + p.lo.x;
+    const float b1 = base + p.lo.x, b2 = b1 + p.lo.y, b3 = b2 + p.hi.x, b4 = b3 + p.hi.y;
     uint32_t j;
     float hi, lo;
-    if (t3 > r) j = 3u, hi = t3, lo = above;
-    else if (t2 > r) j = 2u, hi = t2, lo = t3;
-    else if (t1 > r) j = 1u, hi = t1, lo = t2;
-    else j = 0u, hi = t0, lo = t1;
+    if (b3 < r) j = 3u, lo = b3, hi = b4;
+    else if (b2 < r) j = 2u, lo = b2, hi = b3;
+    else if (b1 < r) j = 1u, lo = b1, hi = b2;
+    else j = 0u, lo = base, hi = b1;
     col = 4u * fc + j;
-    return S >= kScreenMinSum && below != 0u && hi - r > delta && r - lo >= delta;      // S >= 2^-30 also rejects NaN
+    const float delta = (kScreenSafety * (float)(2 * Q + 24) * 5.9604644775390625e-08f) * (hi + 9.5367431640625e-07f * S);
+    return S >= kScreenMinSum && below != 0u && r - lo > delta && hi - r >= delta;      // S >= 2^-30 also rejects NaN
 }
 
 // AdjustIndeces (:368-380): v < from ? 0 : (v - from >= rows ? rows - 1 : v - from), as a signed difference held between 0 and rows - 1 (values, first values
