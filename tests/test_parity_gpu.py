@@ -692,6 +692,12 @@ def test_variants_insertions_and_deletions_dense_four_alleles(workdir):
     P.case_variants_indels(GpuBackend, workdir, density=9, seed=47, tag="indels4", lengths=(5300, 2600), samples=2)
 
 
+def test_variants_sparse_call_set(workdir):
+    """most fragments hold no variant at all (the usual case of a real call set: one variant in several hundred bases); the walk over the variants finds nothing in them"""
+    P.case_variants_indels(GpuBackend, workdir, density=150, seed=31, tag="sparse", lengths=(5300, 2600), samples=1)
+    P.case_variants_indels(GpuBackend, workdir, density=60, seed=53, tag="sparseb", lengths=(5300, 2600), samples=2)
+
+
 def test_variants_crowding_the_sequence_ends(workdir):
     """start and end surroundings that wrap around a sequence end while variants sit in them: the wrapped part is the plain reference"""
     P.case_variants_indels(GpuBackend, workdir, density=30, seed=71, tag="ends71", lengths=(3300, 2100), ends=45)
