@@ -138,7 +138,7 @@ struct LdsPlan {
     // quality rows of 11 groups, 64 error-rate rows of 11 groups -- the same row of the four tables fell into ONE bank group, a four-way conflict on every read of
     // the error-rate margin.  With an odd stride the tables' copies of a row lie in four different groups.
     uint32_t q3_stride, b3_stride;
-    uint32_t ring_off, ring_stride;      // per wave: kRingSlots x [4 img_tiles quality slots], the quality rows over the read position of the wave's current steps
+    uint32_t ring_off, ring_stride;      // per wave: kRingRows x [4 img_tiles quality slots]: the quality rows over the read positions of the wave's current steps, and one slot staged on demand
     uint32_t total_words;        // size of the image
     FamilyGeo q, b, i;           // the three families' common geometry
 };
