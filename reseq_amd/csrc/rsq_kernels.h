@@ -9,9 +9,6 @@
 #include "rsq_core.h"
 #include "rsq_variants.h"
 
-#ifndef RSQ_UNIFORM_STEP
-#define RSQ_UNIFORM_STEP 0      // 1: measured slower (VALU 443 -> 492 per wave-step: the second copy of the iteration costs registers, the first keeps its moves) -- DESIGN_LOG.md section 11
-#endif
 namespace rsq {
 
 // ------------------------------------------------------------------------------------ systematic errors
@@ -2371,12 +2368,9 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
         Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
-#if defined(RSQ_EXP_ROTATE)
-        uint32_t t = 0;
-        if (RSQ_ANY(m.phase != ReadMachine::kDone)) do {
-#else
+        // (What did NOT take the ~35 register copies of the loop-carried state out of this loop, each measured on the device -- DESIGN_LOG.md section 11: tied asm
+        // operands on the state, the iteration behind a wave-uniform branch (a second copy of it: VALU +11 %), the loop tested at its bottom, the phase changes behind a call.)
         for (uint32_t t = 0; RSQ_ANY(m.phase != ReadMachine::kDone); ++t) {      // a read is complete (or a lane has none) exactly when its machine is in kDone: a plain compare for the ballot
-#endif
             if (lane < n_items) {
                 lds_ring_store(S, mine, ring, t, ahead);
                 ahead = lds_ring_load(S, mine, t + 1u);
@@ -2396,34 +2390,9 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
                 __builtin_amdgcn_wave_barrier();
                 tab.demand = p;
             }
-#if defined(RSQ_PIN_STATE)
-            // the read's loop-carried state through one register each: a tied asm operand is read and written in the same register, which leads the allocator to keep a
-            // value and its successor there instead of in two registers with a move between them at the loop head (12 moves per step in the kernel compiled for P0)
-#define RSQ_PIN(x) asm volatile("" : "+v"(x))
-            RSQ_PIN(m.par.iteration); RSQ_PIN(m.par.read_pos); RSQ_PIN(m.par.num_errors); RSQ_PIN(m.par.qual); RSQ_PIN(m.par.last_written_qual); RSQ_PIN(m.par.base_call);
-            RSQ_PIN(m.par.indel_pos); RSQ_PIN(m.par.previous_indel_type); RSQ_PIN(m.org_pos); RSQ_PIN(m.cg.length); RSQ_PIN(m.cg.chars); RSQ_PIN(m.n_indels);
-            RSQ_PIN(out.seq_word); RSQ_PIN(out.qual_word); RSQ_PIN(out.cur_word); RSQ_PIN(out.cur_index);
-#endif
-#if RSQ_UNIFORM_STEP
-            // Nearly every step finds an iteration in ALL lanes of the wave (reads end within a few steps of each other).  That step runs behind a wave-uniform branch:
-            // no lane sits it out, so the state it writes needs no copy of the old state kept beside it for such lanes -- the copies (two register sets around the
-            // "lane not running" join, some 35 moves per step) stay on the other path, which the wave takes in a chunk's last steps.
-            const bool run = m.advance(S, st);
-            if (!RSQ_ANY(!run)) m.iterate(S, tab, st, src, out);
-            else if (run) m.iterate(S, tab, st, src, out);
-#elif defined(RSQ_EXP_ALWAYS)
-            (void)m.advance(S, st);
-            m.iterate(S, tab, st, src, out);
-#else
             m.step(S, tab, st, src, out);                    // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
-#endif
             __builtin_amdgcn_wave_barrier();
-#if defined(RSQ_EXP_ROTATE)
-            ++t;
-        } while (RSQ_ANY(m.phase != ReadMachine::kDone));
-#else
         }
-#endif
     }
     if (active) {
         m.finalize(meta);
