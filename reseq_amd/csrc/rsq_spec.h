@@ -176,6 +176,14 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     const std::string dir = spec_cache_dir();
     out.cache_path = dir.empty() ? "" : dir + name;
     out.code.clear();
+    // A process started by rocprofv3 gets another code object from the same sources (measured, round 5: 768 bytes longer, 6.7 % more vector instructions per launch of the
+    // read kernel, 3 % slower).  The cause seems to be WHICH compiler is loaded: a Python process that has imported PyTorch finds the libhiprtc / libamd_comgr of the
+    // wheel (ROCm 7.0: 9 spilled vector registers in the kernel compiled for P0), rocprofv3 puts the system's /opt/rocm-7.2.0/lib first (12, like the image's hipcc).
+    // Both report version 9.0, so the key cannot tell them apart.  A profiled process may USE what an un-profiled one left in the cache -- then the profiler sees the
+    // kernel the product runs -- but what it compiles itself goes under a name of its own: it must not become every later run's kernel (profiles/collect.sh therefore
+    // begins with an un-profiled run).
+    const bool under_profiler = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY_CTOR");
+    if (under_profiler && !out.cache_path.empty() && access(out.cache_path.c_str(), R_OK) != 0) out.cache_path += ".under_profiler";
     if (!out.cache_path.empty()) {
         if (FILE *f = fopen(out.cache_path.c_str(), "rb")) {
             fseek(f, 0, SEEK_END);
