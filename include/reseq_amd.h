@@ -71,6 +71,12 @@ int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double 
 int rsq_profile_archive_layout(const char *stats_path, const char *ipf_path, char *out, size_t cap, size_t *need);
 /* writes the prepared profile (result tables, not the fit) as an RSQP container */
 int rsq_profile_save(const rsq_profile *p, const char *path);
+/* rsq_profile_save_reseq: the writer that ReSeq's own files lack here -- `stats_path` / "<stats_path>.ipf" (ipf_path NULL) as Boost text archives under the token
+ * rules rsq_archive.h recalls (DataStats::Save, DataStats.cpp:1302-1320; ProbabilityEstimates::Save, ProbabilityEstimates.cpp:1047-1065).  The statistics and fits
+ * written are those whose prepared form -- PrepareProcessing / PrepareResult -- is the loaded profile; what the simulation never reads is default-constructed.
+ * rsq_profile_load_reseq reads the pair back to the same tables bit for bit.  Whether the ORIGINAL binary reads it cannot be checked in this image: a user who can
+ * run `reseq queryProfile -s <path>` on a written pair is asked to tell (INTEGRATION.md "Profile files").  creation_time 0: now. */
+int rsq_profile_save_reseq(const rsq_profile *p, const char *stats_path, const char *ipf_path, uint64_t creation_time);
 void rsq_profile_free(rsq_profile *p);
 /* ProbabilityEstimates::ChangeErrorRate / RemoveSubstitutionErrors / RemoveInDelErrors
  * (reseq/ProbabilityEstimates.h:1516-1549; CLI --errorMutliplier, --noSubstitutionErrors, --noInDelErrors) */

@@ -45,6 +45,7 @@ SYMBOLS = {
     "rsq_profile_load_reseq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, _pp]),
     "rsq_profile_is_reseq_archive": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "rsq_profile_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rsq_profile_save_reseq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64]),
     "rsq_profile_archive_layout": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsq_last_warning": (C.c_char_p, []),
     "rsq_profile_free": (None, [_vp]),
@@ -211,6 +212,10 @@ class Profile:
     def save(self, path):
         """the prepared profile as an RSQP container"""
         _check(lib().rsq_profile_save(self.h, os.fsencode(path)))
+
+    def save_reseq(self, stats_path, ipf_path=None, creation_time=0):
+        """as ReSeq's own pair of files (`stats_path` and `<stats_path>.ipf`): rsq_profile_save_reseq"""
+        _check(lib().rsq_profile_save_reseq(self.h, os.fsencode(stats_path), os.fsencode(ipf_path) if ipf_path else None, int(creation_time)))
 
     def compile_read_kernel(self, kind=0, with_variants=False, binned=False, arch="gfx950", out_path=None):
         """host only: the read kernel compiled for this profile (what Simulator.specialize does on the device); returns (bytes of the code object, seconds)"""

@@ -141,6 +141,8 @@ struct Profile {
     static Profile load_archives(const std::string &stats_path, const std::string &ipf_path, double precision_aim = 0.05, std::string *warnings = nullptr);
     static std::string archive_layout(const std::string &stats_path, const std::string &ipf_path);      // the class-info sites of both files, the parse error if any
     void save(const std::string &path) const;                     // as an RSQP container
+    // as ReSeq's own pair of files (rsq_profile_archive.cpp): statistics and fits whose prepared form is this profile; ipf_path empty: "<stats_path>.ipf"
+    void save_archives(const std::string &stats_path, const std::string &ipf_path, uint64_t creation_time) const;
     void change_error_rate(double multiplier);          // ProbabilityEstimates.h:1516-1527
     void remove_substitution_errors();                  // :1529-1540
     void remove_indel_errors();                         // :1542-1549

@@ -540,6 +540,351 @@ bool Profile::is_archive(const std::string &path) {
     return n > 0 && archive::Reader::looks_like_archive(head, (size_t)n);
 }
 
+// ------------------------------------------------------------------------------------------------ writing
+// The inverse of load_archives for a loaded profile: a DataStats and a ProbabilityEstimates value whose PrepareProcessing / PrepareResult give this profile again,
+// written under the recalled token rules (rsq_archive.h) -- so that a ReSeq user can hand a profile of this library to the original binary (and tell us whether
+// the binary reads it: INTEGRATION.md "Profile files").  What the simulation never reads is written default-constructed, except where the loaders insist on a shape
+// (the 3 x 4^10 surrounding counts).  A result table is already laid out as GetResults leaves it, so it is stored as a converged, un-binned fit whose dimension 0
+// holds the table's columns in their order; the margins between two conditions, which the simulation never reads, are ones.
+namespace {
+
+Node default_node(TypeP t) {
+    Node n;
+    n.type = t;
+    switch (t->kind) {
+        case archive::Type::UINT:
+        case archive::Type::INT:
+        case archive::Type::BOOL: n.u.assign(1, 0); break;
+        case archive::Type::F64: n.f.assign(1, 0.0); break;
+        case archive::Type::STR:
+        case archive::Type::VEC: break;
+        case archive::Type::ARR:
+            if (t->elem->numeric()) (t->elem->kind == archive::Type::F64 ? (void)n.f.assign(t->n, 0.0) : (void)n.u.assign(t->n, 0));
+            else n.kids.assign(t->n, default_node(t->elem));
+            break;
+        case archive::Type::PAIR: n.kids = {default_node(t->first), default_node(t->second)}; break;
+        case archive::Type::CLS:
+            for (const Member &m : t->members) n.kids.push_back(default_node(m.type));
+            break;
+    }
+    return n;
+}
+Node &member(Node &cls, const char *name) {
+    for (size_t i = 0; i < cls.type->members.size(); ++i)
+        if (cls.type->members[i].name == name) return cls.kids[i];
+    throw Error(std::string("archive: no member ") + name + " in " + cls.type->name);
+}
+void set_uint(Node &n, uint64_t v) { n.u.assign(1, v); }
+void set_real(Node &n, double v) { n.f.assign(1, v); }
+// a Vect<T> node (class {vec_: pair(offset, vector)}) from an offset and numbers
+template <class T>
+void set_vect(Node &n, uint64_t from, const T *values, size_t count) {
+    Node &pair = member(n, "vec_");
+    set_uint(pair.kids[0], from);
+    Node &vec = pair.kids[1];
+    if (vec.type->elem->kind == archive::Type::F64) vec.f.assign(values, values + count);
+    else vec.u.assign(values, values + count);
+}
+template <class T>
+void set_vect(Node &n, const Vect<T> &v) { set_vect(n, v.from, v.v.data(), v.v.size()); }
+// a Vect<Vect<u64>> node: offset and rows (each an offset and numbers)
+struct Row {
+    uint64_t from = 0;
+    std::vector<uint64_t> values;
+};
+void set_vect2(Node &n, uint64_t from, const std::vector<Row> &rows) {
+    Node &pair = member(n, "vec_");
+    set_uint(pair.kids[0], from);
+    Node &vec = pair.kids[1];
+    vec.kids.clear();
+    for (const Row &r : rows) {
+        Node row = default_node(vec.type->elem);
+        set_vect(row, r.from, r.values.data(), r.values.size());
+        vec.kids.push_back(std::move(row));
+    }
+}
+
+class ArchiveWriter {
+   public:
+    ArchiveWriter(size_t n_types, uint32_t library_version) : seen_(n_types, 0), version_(library_version) { out_ = "22 serialization::archive " + std::to_string(library_version); }
+    void put(TypeP t, const Node &v) {
+        const bool class_info = t->kind == archive::Type::CLS || t->kind == archive::Type::ARR || t->kind == archive::Type::PAIR || (t->kind == archive::Type::VEC && !t->elem->numeric());
+        if (class_info && !seen_[t->id]) {
+            seen_[t->id] = 1;
+            out_ += " 0 0";
+        }
+        switch (t->kind) {
+            case archive::Type::UINT:
+            case archive::Type::BOOL: uint(v.u.at(0)); break;
+            case archive::Type::INT: out_ += ' ' + std::to_string((int64_t)v.u.at(0)); break;
+            case archive::Type::F64: real(v.f.at(0)); break;
+            case archive::Type::STR: out_ += ' ' + std::to_string(v.s.size()) + ' ' + v.s; break;
+            case archive::Type::VEC: {
+                const size_t count = t->elem->numeric() ? (t->elem->kind == archive::Type::F64 ? v.f.size() : v.u.size()) : v.kids.size();
+                uint(count);
+                if (t->elem->kind != archive::Type::BOOL && version_ > 3) out_ += " 0";      // item_version (the recalled rule: behind every count but vector<bool>'s)
+                items(t->elem, count, v);
+                break;
+            }
+            case archive::Type::ARR: {
+                const size_t count = t->elem->numeric() ? (t->elem->kind == archive::Type::F64 ? v.f.size() : v.u.size()) : v.kids.size();
+                if (count != t->n) throw Error("archive: " + t->name + " given " + std::to_string(count) + " items");
+                uint(t->n);
+                items(t->elem, count, v);
+                break;
+            }
+            case archive::Type::PAIR:
+                put(t->first, v.kids.at(0));
+                put(t->second, v.kids.at(1));
+                break;
+            case archive::Type::CLS:
+                for (size_t i = 0; i < t->members.size(); ++i) put(t->members[i].type, v.kids.at(i));
+                break;
+        }
+    }
+    void write(const std::string &path) {
+        out_ += '\n';
+        write_text_file(path, out_);
+    }
+
+   private:
+    void uint(uint64_t v) { out_ += ' ' + std::to_string(v); }
+    void real(double v) {
+        char buf[40];
+        snprintf(buf, sizeof buf, " %.17e", v);
+        out_ += buf;
+    }
+    void items(TypeP e, size_t count, const Node &v) {
+        if (e->kind == archive::Type::F64)
+            for (size_t i = 0; i < count; ++i) real(v.f[i]);
+        else if (e->kind == archive::Type::INT)
+            for (size_t i = 0; i < count; ++i) out_ += ' ' + std::to_string((int64_t)v.u[i]);
+        else if (e->numeric())
+            for (size_t i = 0; i < count; ++i) uint(v.u[i]);
+        else
+            for (size_t i = 0; i < count; ++i) put(e, v.kids[i]);
+    }
+    std::string out_;
+    std::vector<char> seen_;
+    uint32_t version_;
+};
+
+// a result table as a converged, un-binned LogIPF<N> (N = margins + 1) whose PrepareResult is the table (tests/archive_fixtures.py ipf_from_table states the same)
+void set_ipf(Node &ipf, const HostTable &t) {
+    const uint32_t n_dims = t.nm + 1u, n_margins = n_dims * (n_dims - 1u) / 2u;
+    const size_t k = t.par0.size();
+    Node &estimates = member(ipf, "estimates_");
+    const double kMax = 1.7976931348623157e308;
+    if (!k) {                                                          // a table without data: a default-constructed fit
+        set_uint(member(ipf, "steps_"), 0);
+        set_real(member(ipf, "precision_"), kMax);
+        member(ipf, "margin_precision_").f.assign(n_margins, kMax);
+        member(ipf, "update_dist_").u.assign(n_margins, 2);
+        return;
+    }
+    const uint32_t steps = 37;
+    const double precision = 0.01;
+    set_uint(member(ipf, "steps_"), steps);
+    set_uint(member(ipf, "needed_updates_"), steps);
+    set_real(member(ipf, "precision_"), precision);
+    member(ipf, "margin_precision_").f.assign(n_margins, precision);
+    set_uint(member(ipf, "last_margin_"), 1);
+    member(ipf, "last_update_").u.assign(n_margins, steps);
+    member(ipf, "update_dist_").u.assign(n_margins, 2);
+    std::vector<uint32_t> size(n_dims);
+    size[0] = (uint32_t)k;
+    Node &dims = member(ipf, "dim_indices_"), &initial = member(ipf, "initial_dim_indices_reduced_"), &reduced = member(ipf, "dim_indices_reduced_");
+    dims.kids[0].u.assign(t.par0.begin(), t.par0.end());
+    for (uint32_t n = 1; n < n_dims; ++n) {
+        size[n] = t.to[n - 1] - t.from[n - 1];
+        for (uint32_t v = t.from[n - 1]; v < t.to[n - 1]; ++v) dims.kids[n].u.push_back(v);
+    }
+    for (uint32_t n = 0; n < n_dims; ++n) {
+        for (uint32_t i = 0; i < size[n]; ++i) initial.kids[n].u.push_back(i);
+        reduced.kids[n].u = initial.kids[n].u;
+    }
+    member(estimates, "dim_size_").u.assign(size.begin(), size.end());
+    Node &dim2 = member(estimates, "dim2_");
+    for (uint32_t n = 0; n < t.nm; ++n) dim2.kids[n].f = t.dim2[n];   // margin n: dimension n + 1 against the columns
+    // the margins between two conditions, in the (dim_a, dim_b) walk of LogArrayCalc::SetUp
+    uint32_t a = n_dims, b = n_dims - 1u;
+    std::vector<std::pair<uint32_t, uint32_t>> pair_of(n_margins);
+    for (uint32_t n = n_margins; n--;) {
+        if (--a == b) {
+            --b;
+            a = n_dims - 1u;
+        }
+        pair_of[n] = {a, b};
+    }
+    for (uint32_t n = n_dims - 1u; n < n_margins; ++n) dim2.kids[n].f.assign((size_t)size[pair_of[n].first] * size[pair_of[n].second], 1.0);
+}
+
+}  // namespace
+
+void Profile::save_archives(const std::string &stats_path, const std::string &ipf_path_in, uint64_t creation_time) const {
+    static ReseqTypes types;
+    const std::string ipf_path = ipf_path_in.empty() ? stats_path + ".ipf" : ipf_path_in;
+    const Profile &p = *this;
+    const uint32_t nt = p.n_tiles();
+    {
+        Node st = default_node(types.data_stats);
+        set_uint(member(st, "creation_time_"), creation_time);
+        set_uint(member(st, "phred_quality_offset_"), p.phred_offset);
+        set_real(member(st, "corrected_coverage_"), p.corrected_coverage);
+        Node &coverage = member(st, "coverage_");
+        set_uint(member(coverage, "reset_distance_"), p.reset_distance);
+        set_uint(member(coverage, "coverage_threshold_"), 10);
+        // the longest deletion is all the simulation takes from the indel statistics (ErrorStats::PrepareSimulation): deletions of up to max_len_deletion bases
+        // behind an 'A' call, shorter ones elsewhere; insertions do not count
+        {
+            Node &indel = member(member(st, "errors_"), "indel_by_indel_pos_");
+            const uint32_t d = p.max_len_deletion;
+            set_vect2(indel.kids[1].kids[0], 0, std::vector<Row>(d, Row{0, {5, 1}}));
+            set_vect2(indel.kids[1].kids[2], 0, std::vector<Row>(d ? d - 1u : 0u, Row{0, {9}}));
+            set_vect2(indel.kids[0].kids[1], 0, std::vector<Row>(d + 3u, Row{0, {4, 0, 1}}));
+        }
+        Node &fd = member(st, "fragment_distribution_");
+        set_vect(member(fd, "insert_lengths_"), p.insert_lengths);
+        set_vect(member(fd, "insert_lengths_bias_"), p.insert_lengths_bias);
+        set_vect(member(fd, "gc_fragment_content_bias_"), p.gc_bias);
+        if (p.sur_bias.size() != (size_t)kSurBlocks * kSurSize) throw Error("profile without the 3 x 4^10 surrounding biases");
+        for (uint32_t b = 0; b < kSurBlocks; ++b) {
+            member(member(fd, "fragment_surroundings_bias_"), "bias_").kids[b].f.assign(p.sur_bias.begin() + (size_t)b * kSurSize, p.sur_bias.begin() + (size_t)(b + 1) * kSurSize);
+            member(member(fd, "fragment_surroundings_"), "counts_").kids[b].u.assign(kSurSize, 0);
+        }
+        member(fd, "dispersion_parameters_").f.assign(p.dispersion, p.dispersion + 2);
+        member(fd, "ref_seq_bias_").f = p.ref_seq_bias;
+        member(fd, "abundance_").u.assign(p.ref_seq_bias.size(), 7);
+        for (int seg = 0; seg < 2; ++seg) {
+            set_vect(member(st, "read_lengths_").kids[seg], p.read_lengths[seg]);
+            const HostRlByFl &r = p.rl_by_fl[seg];
+            std::vector<Row> rows, nm_rows;
+            int64_t nm_lo = -1, nm_hi = -1;
+            for (size_t i = 0; i < r.row_from.size(); ++i) {
+                rows.push_back(Row{r.row_from[i], std::vector<uint64_t>(r.values.begin() + r.row_ptr[i], r.values.begin() + r.row_ptr[i + 1])});
+                // the non-mapped counts are stored with another shape than the mapped ones: only the rows that hold something, trimmed to what they hold
+                const uint64_t *nm = r.non_mapped.data() + r.row_ptr[i];
+                const size_t len = r.row_ptr[i + 1] - r.row_ptr[i];
+                size_t lo = 0, hi = len;
+                while (lo < len && !nm[lo]) ++lo;
+                while (hi > lo && !nm[hi - 1]) --hi;
+                if (lo < hi) {
+                    if (nm_lo < 0) nm_lo = (int64_t)i;
+                    nm_hi = (int64_t)i + 1;
+                }
+            }
+            set_vect2(member(st, "read_lengths_by_fragment_length_").kids[seg], r.from, rows);
+            if (nm_lo >= 0) {
+                for (int64_t i = nm_lo; i < nm_hi; ++i) {
+                    const uint64_t *nm = r.non_mapped.data() + r.row_ptr[i];
+                    const size_t len = r.row_ptr[i + 1] - r.row_ptr[i];
+                    size_t lo = 0, hi = len;
+                    while (lo < len && !nm[lo]) ++lo;
+                    while (hi > lo && !nm[hi - 1]) --hi;
+                    nm_rows.push_back(lo < hi ? Row{r.row_from[i] + lo, std::vector<uint64_t>(nm + lo, nm + hi)} : Row{});
+                }
+                set_vect2(member(st, "non_mapped_read_lengths_by_fragment_length_").kids[seg], r.from + (uint64_t)nm_lo, nm_rows);
+            }
+        }
+        Node &tiles = member(st, "tiles_");
+        member(tiles, "tiles_").u.assign(p.tiles.begin(), p.tiles.end());
+        member(tiles, "abundance_").u = p.tile_abundance;
+
+        Node &ad = member(st, "adapters_");
+        std::vector<std::string> seqs[2];
+        for (int seg = 0; seg < 2; ++seg) {
+            const HostAdapters &a = p.adapters[seg];
+            Node &names = member(ad, "names_").kids[seg], &archive_seqs = member(ad, "seqs_archive").kids[seg], &cuts = member(ad, "start_cut_").kids[seg];
+            for (uint32_t i = 0; i < a.n(); ++i) {
+                std::string sq;
+                for (uint32_t k = a.seq_ptr[i]; k < a.seq_ptr[i + 1]; ++k) sq += "ACGT"[a.seqs[k] & 3u];
+                seqs[seg].push_back(sq);
+                Node name = default_node(names.type->elem), text = default_node(archive_seqs.type->elem), cut = default_node(cuts.type->elem);
+                name.s = "adapter " + std::to_string(seg) + "/" + std::to_string(i);
+                text.s = sq;
+                set_vect(cut, a.cut_from[i], a.cut.data() + a.cut_ptr[i], a.cut_ptr[i + 1] - a.cut_ptr[i]);
+                names.kids.push_back(std::move(name));
+                archive_seqs.kids.push_back(std::move(text));
+                cuts.kids.push_back(std::move(cut));
+            }
+        }
+        // the detections of adapter pairs, at the adapters' full lengths (beyond every prefix shared with a neighbour: SumCounts counts them), spread so that the rows'
+        // sums are the first adapters' counts and the columns' sums the second adapters': from the top left corner on
+        {
+            const uint32_t n1 = p.adapters[0].n(), n2 = p.adapters[1].n();
+            std::vector<uint64_t> left1 = p.adapters[0].counts, left2 = p.adapters[1].counts;
+            uint64_t s1 = 0, s2 = 0;
+            for (uint64_t c : left1) s1 += c;
+            for (uint64_t c : left2) s2 += c;
+            if (s1 != s2) throw Error("the adapter counts of the two read segments do not sum to the same number of detections");
+            Node &counts = member(ad, "counts_"), &comb = member(ad, "combinations_");
+            uint32_t a2 = 0;
+            std::vector<std::vector<uint64_t>> cell(n1, std::vector<uint64_t>(n2, 0));
+            for (uint32_t a1 = 0; a1 < n1; ++a1)
+                while (left1[a1] && a2 < n2) {
+                    const uint64_t take = std::min(left1[a1], left2[a2]);
+                    cell[a1][a2] += take;
+                    left1[a1] -= take;
+                    left2[a2] -= take;
+                    if (!left2[a2]) ++a2;
+                }
+            for (uint32_t a1 = 0; a1 < n1; ++a1) {
+                Node row = default_node(counts.type->elem), flags = default_node(comb.type->elem);
+                for (uint32_t b2 = 0; b2 < n2; ++b2) {
+                    Node c = default_node(row.type->elem);
+                    if (cell[a1][b2]) set_vect2(c, seqs[0][a1].size(), {Row{seqs[1][b2].size(), {cell[a1][b2]}}});
+                    row.kids.push_back(std::move(c));
+                    flags.u.push_back(a1 == b2 ? 1 : 0);
+                }
+                counts.kids.push_back(std::move(row));
+                comb.kids.push_back(std::move(flags));
+            }
+        }
+        set_vect(member(ad, "polya_tail_length_"), p.polya);
+        member(ad, "overrun_bases_").u.assign(p.overrun_bases, p.overrun_bases + 5);
+        ArchiveWriter w(types.s.size(), 17);
+        w.put(types.data_stats, st);
+        w.write(stats_path);
+    }
+    {
+        Node pe = default_node(types.probability_estimates);
+        set_uint(member(pe, "stats_creation_time_"), creation_time);
+        auto need = [&](const std::vector<HostTable> &v, size_t n, const char *what) {
+            if (v.size() != n) throw Error(std::string("profile with ") + std::to_string(v.size()) + " " + what + " tables, " + std::to_string(n) + " expected");
+        };
+        need(p.quality, 8u * nt, "quality");
+        need(p.seq_quality, 2u * nt, "sequence quality");
+        need(p.base_call, 40u * nt, "base call");
+        need(p.dom_error, 100, "dominant error");
+        need(p.error_rate, 20, "error rate");
+        need(p.indels, 12, "indel");
+        for (uint32_t seg = 0; seg < 2; ++seg) {
+            Node &q = member(pe, "quality_").kids[seg], &sq = member(pe, "sequence_quality_").kids[seg], &bc = member(pe, "base_call_").kids[seg];
+            for (uint32_t tile = 0; tile < nt; ++tile) {
+                Node qt = default_node(q.type->elem), st = default_node(sq.type->elem), bt = default_node(bc.type->elem);
+                set_ipf(st, p.seq_quality[seg * nt + tile]);
+                for (uint32_t base = 0; base < 4; ++base) {
+                    set_ipf(qt.kids[base], p.quality[(seg * nt + tile) * 4u + base]);
+                    for (uint32_t dom = 0; dom < 5; ++dom) set_ipf(bt.kids[base].kids[dom], p.base_call[((seg * nt + tile) * 4u + base) * 5u + dom]);
+                }
+                q.kids.push_back(std::move(qt));
+                sq.kids.push_back(std::move(st));
+                bc.kids.push_back(std::move(bt));
+            }
+        }
+        for (uint32_t base = 0; base < 4; ++base) {
+            for (uint32_t prev = 0; prev < 5; ++prev)
+                for (uint32_t dom = 0; dom < 5; ++dom) set_ipf(member(pe, "dom_error_").kids[base].kids[prev].kids[dom], p.dom_error[(base * 5u + prev) * 5u + dom]);
+            for (uint32_t dom = 0; dom < 5; ++dom) set_ipf(member(pe, "error_rate_").kids[base].kids[dom], p.error_rate[base * 5u + dom]);
+        }
+        for (uint32_t type = 0; type < 2; ++type)
+            for (uint32_t call = 0; call < 6; ++call) set_ipf(member(pe, "indels_").kids[type].kids[call], p.indels[type * 6u + call]);
+        ArchiveWriter w(types.s.size(), 17);
+        w.put(types.probability_estimates, pe);
+        w.write(ipf_path);
+    }
+}
+
 // `ipf_path` empty: "<stats_path>.ipf" (main.cpp:837).  precision_aim as a fraction (--ipfPrecision is in percent, main.cpp:733).
 Profile Profile::load_archives(const std::string &stats_path, const std::string &ipf_path_in, double precision_aim, std::string *warnings) {
     static ReseqTypes types;   // immutable after construction

@@ -1247,6 +1247,19 @@ int rsq_profile_save(const rsq_profile *p, const char *path) {
         return RSQ_EIO;
     }
 }
+int rsq_profile_save_reseq(const rsq_profile *p, const char *stats_path, const char *ipf_path, uint64_t creation_time) {
+    REQUIRE(p && stats_path, "null argument");
+    try {
+        p->p.save_archives(stats_path, ipf_path ? ipf_path : "", creation_time ? creation_time : (uint64_t)time(nullptr));
+        return RSQ_OK;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        return RSQ_EINVAL;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RSQ_EIO;
+    }
+}
 void rsq_profile_free(rsq_profile *p) { delete p; }
 int rsq_profile_change_error_rate(rsq_profile *p, double m) {
     REQUIRE(p && m > 0.0, "bad error multiplier");

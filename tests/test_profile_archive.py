@@ -91,6 +91,48 @@ def test_archive_profile_equals_the_profile_it_was_made_from(tiny_archives, tiny
     _assert_same(got, ra.load_profile(tiny_archives["plain"]), "product vs oracle")
 
 
+def test_the_product_writes_the_archives_the_fixture_writes(tiny_archives, tiny_profile_arrays, tmp_path):
+    """rsq_profile_save_reseq: a loaded profile goes out as ReSeq's own pair of files.  From the container of the TINY profile the product writes, token for token, what
+    the tests' own writer (oracle/reseq_archive.py through tests/archive_fixtures.py) writes for it; the pair loads to the same tables bit for bit; a profile that came
+    from archives with re-binned fits and imputed rows goes out and comes back unchanged as well (its tables are what PrepareResult left)."""
+    from reseq_amd import synth
+    src = str(tmp_path / "tiny.rsqp")
+    synth.write_profile(src, tiny_profile_arrays)
+    p = api.Profile(src)
+    out = str(tmp_path / "written.reseq")
+    p.save_reseq(out, creation_time=1600000000)
+    p.close()
+    assert open(out, "rb").read() == open(tiny_archives["plain"], "rb").read()
+    assert open(out + ".ipf", "rb").read() == open(tiny_archives["plain"] + ".ipf", "rb").read()
+    got, warning = _product_arrays(out, None, str(tmp_path / "back.rsqp"))
+    assert "does not follow the recalled token rules" not in warning
+    _assert_same(got, tiny_profile_arrays, "written and read back vs source")
+    # a profile from re-binned fits with imputed rows
+    binned = api.Profile(tiny_archives["binned"], ipf_path=tiny_archives["binned_ipf"])
+    binned.save(str(tmp_path / "binned.rsqp"))
+    binned.save_reseq(str(tmp_path / "binned_again.reseq"), ipf_path=str(tmp_path / "binned_again.fit"))
+    binned.close()
+    again, _ = _product_arrays(str(tmp_path / "binned_again.reseq"), str(tmp_path / "binned_again.fit"), str(tmp_path / "binned_back.rsqp"))
+    # Rows that ImputeMissingValues filled change the columns' mean likelihoods, by which GetResults sorts them: such a table comes back with its columns in another
+    # order (the same distribution; the original binary would sort the same way).  Compared with the columns in the order of their outcome values.
+    def by_outcome(arrays):
+        out = dict(arrays)
+        for name in arrays:
+            if name.startswith("tab.") and name.endswith(".par0"):
+                par0 = np.asarray(arrays[name])
+                order = np.argsort(par0, kind="stable")
+                out[name] = par0[order]
+                flat = np.asarray(arrays[name[:-5] + ".dim2"])
+                if len(par0):
+                    out[name[:-5] + ".dim2"] = flat.reshape(-1, len(par0))[:, order].ravel()
+        return out
+    want = read_container(str(tmp_path / "binned.rsqp"))
+    _assert_same(by_outcome(again), by_outcome(want), "re-binned profile written and read back")
+    assert any(not np.array_equal(again[n], want[n]) for n in want if n.endswith(".par0"))      # (the case exists in the fixture)
+    with pytest.raises(api.RsqError):
+        api.Profile(src).save_reseq(str(tmp_path / "no_such_directory" / "x.reseq"))
+
+
 def test_binned_tables_and_missing_rows_product_equals_oracle(tiny_archives, tiny_profile_arrays):
     got, _ = _product_arrays(tiny_archives["binned"], tiny_archives["binned_ipf"], str(tiny_archives["dir"] / "binned.rsqp"))
     want = ra.load_profile(tiny_archives["binned"], tiny_archives["binned_ipf"])
