@@ -592,6 +592,12 @@ int query_profile(const Args &a) {
         std::cout << "maxReadLength: " << v << std::endl;
         no_output = false;
     }
+    if (ok && a.has("statsOut")) {                                // not in the reference: the loaded profile as ReSeq's own pair of files (-S <name>.reseq [-P <fit file>]), INTEGRATION.md
+        const std::string out = a.get("statsOut"), fit = a.get("probabilitiesOut");
+        ok = check(rsq_profile_save_reseq(prof, out.c_str(), fit.empty() ? nullptr : fit.c_str(), 0), "Could not write the profile archives");
+        if (ok) INFO("Wrote " << out << " and " << (fit.empty() ? out + ".ipf" : fit));
+        no_output = false;
+    }
     if (ok && a.has("refSeqBias")) {                              // FragmentDistributionStats::WriteRefSeqBias (FragmentDistributionStats.cpp:3643-3670)
         size_t n = 0;
         uint32_t n_seqs = 0;

@@ -240,3 +240,9 @@ def test_query_profile_cli_mode(workdir, tiny_profile_path):
     assert r.returncode == 0 and [l[0] for l in lines] == ["chrA", "chrB"]
     assert np.allclose([float(l[1]) for l in lines], arrays["frag.ref_seq_bias"], rtol=1e-5)
     assert subprocess.run([exe, "queryProfile", "-s", tiny_profile_path], capture_output=True).returncode == 1      # no output option selected
+    # -S: the loaded profile as ReSeq's own pair of files (rsq_profile_save_reseq), which loads again and answers the same
+    out = workdir / "written.reseq"
+    r = subprocess.run([exe, "queryProfile", "-s", tiny_profile_path, "-S", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and out.exists() and (workdir / "written.reseq.ipf").exists(), r.stderr
+    r = subprocess.run([exe, "queryProfile", "-s", str(out), "--maxReadLength", "--maxLenDeletion"], capture_output=True, text=True)
+    assert r.returncode == 0 and "maxReadLength: 30" in r.stdout and "maxLenDeletion: " in r.stdout
