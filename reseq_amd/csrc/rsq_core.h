@@ -694,7 +694,7 @@ struct ReadMachine {
     // Decides what the next iteration is: performs the transitions between the template part, the adapter part and the tail
     // (Simulator.cpp:447-449, 537-558) until one of them has an iteration to run.  Returns false once the read is complete.
     RSQ_HD bool advance(const DevSim &S, const Stream &st) {
-        if (__builtin_expect(phase == kTemplate && par.read_pos < par.read_length && org_pos < org_len, 1)) return true;      // nearly every iteration
+        if (__builtin_expect(in_template(), 1)) return true;      // nearly every iteration
         return advance_parts(S, st);
     }
     RSQ_HD bool advance_parts(const DevSim &S, const Stream &st) {
@@ -749,10 +749,13 @@ struct ReadMachine {
         iterate(S, tab, st, src, out);
         return true;
     }
-    // the iteration itself, for a machine that advance() found an iteration for
-    template <class Tab, class Src, class Out>
+    // whether the next iteration is one of the template part -- what advance() finds for nearly every iteration
+    RSQ_HD bool in_template() const { return phase == kTemplate && par.read_pos < par.read_length && org_pos < org_len; }
+    // the iteration itself, for a machine that advance() found an iteration for.  TEMPLATE_PART: the caller knows that the machine is in the template part
+    // (in_template()): the adapter's and the tail's branches are not compiled in.
+    template <bool TEMPLATE_PART = false, class Tab, class Src, class Out>
     RSQ_HD void iterate(const DevSim &S, const Tab &tab, const Stream &st, const Src &src, Out &out) {
-        const bool tail = phase == kTail, from_template = phase == kTemplate;
+        const bool tail = !TEMPLATE_PART && phase == kTail, from_template = TEMPLATE_PART || phase == kTemplate;
         const DevAdapters &ad = S.adapters[seg];
         const uint32_t it = par.iteration;                           // counted at the end of the step: old and new value never live side by side
         const Words w = st.step(2u + it);

@@ -2368,9 +2368,11 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
         const RingItem mine = lds_ring_item(S, qbase, lane < n_items ? lane : 0u);      // the lane's first item (with one tile per image: its only one)
         // the lane's item of the NEXT step is loaded while this step runs (the row comes from L2: its latency would stand at the head of every step)
         Quad ahead = lane < n_items ? lds_ring_load(S, mine, 0u) : zero_quad();
-        // (What did NOT take the ~35 register copies of the loop-carried state out of this loop, each measured on the device -- DESIGN_LOG.md section 11: tied asm
-        // operands on the state, the iteration behind a wave-uniform branch (a second copy of it: VALU +11 %), the loop tested at its bottom, the phase changes behind a call.)
-        for (uint32_t t = 0; RSQ_ANY(m.phase != ReadMachine::kDone); ++t) {      // a read is complete (or a lane has none) exactly when its machine is in kDone: a plain compare for the ballot
+        // What the wave does at the beginning of a step: its ring slot of the step (and the prefetch of the next), and the slot behind the ring for a read that has
+        // lost more than kRingLag steps to deletions -- such a read no longer finds the rows over its position in the ring, and left to the double-precision call at
+        // every step it would double the time of its wave's remaining steps (one read in 1600 with profile P0; the whole launch waits for such a wave when the call
+        // is small).  The wave stages the rows over the first such read's position; another one at another position is rarer still.
+        auto begin_step = [&](uint32_t t) {
             if (lane < n_items) {
                 lds_ring_store(S, mine, ring, t, ahead);
                 ahead = lds_ring_load(S, mine, t + 1u);
@@ -2378,9 +2380,6 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
             for (uint32_t item = lane + 64u; item < n_items; item += 64u) lds_ring_stage(S, qbase, ring, t, item);
             __builtin_amdgcn_wave_barrier();                 // the wave's LDS writes precede its reads (in order in hardware; this orders the compiler)
             tab.t = t;
-            // A read that has lost more than kRingLag steps to deletions no longer finds the rows over its position in the ring; left to the double-precision call at
-            // every step it would double the time of its wave's remaining steps (one read in 1600 with profile P0 -- and the whole launch waits for such a wave when
-            // the call is small).  The wave stages the rows over the first such read's position in the slot behind the ring; another one at another position is rarer still.
             const uint64_t lagging = __builtin_amdgcn_ballot_w64(m.phase != ReadMachine::kDone && t - m.par.read_pos > kRingLag);
             tab.demand = 0xFFFFFFFFu;
             if (lagging) {
@@ -2390,6 +2389,21 @@ __device__ void fill_wave_reads(const DevSim &S, RSQ_LDS float *img, uint32_t qb
                 __builtin_amdgcn_wave_barrier();
                 tab.demand = p;
             }
+        };
+        uint32_t t = 0;
+        // TWO loops.  While EVERY lane of the wave has a template base in front of it -- all but a chunk's last steps -- the step has no lane that sits it out, no
+        // adapter and no tail: the iteration runs unmasked and compiled for the template part alone.  The second loop is the general one (lanes whose read is
+        // complete or that have none return at once; phase changes; adapter and tail iterations).  One loop for both kept the read's state in two register sets with
+        // moves between them around the "lane not running" join of EVERY step: 20.36 G -> 19.57 G vector instructions per launch of 10 M pairs, 216 -> 223 M pairs/s
+        // (What did NOT move those copies, each measured on the device -- DESIGN_LOG.md section 11: tied asm operands on the state, both kinds of step behind a
+        // wave-uniform branch inside ONE loop (11 % more instructions), the loop tested at its bottom, the phase changes behind a call.)
+        for (; !RSQ_ANY(!m.in_template()); ++t) {
+            begin_step(t);
+            m.template iterate<true>(S, tab, st, src, out);
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (; RSQ_ANY(m.phase != ReadMachine::kDone); ++t) {      // a read is complete (or a lane has none) exactly when its machine is in kDone: a plain compare for the ballot
+            begin_step(t);
             m.step(S, tab, st, src, out);                    // a lane whose read is complete (or that has none: phase kDone from the start) returns at once
             __builtin_amdgcn_wave_barrier();
         }

@@ -102,7 +102,9 @@ void run_read(Emu &s, uint32_t seg, const Stream &st, uint32_t tile, uint32_t fr
                 }
                 tab.t = t;
                 tab.demand = g_ring_lag > kRingLag ? m.par.read_pos : 0xFFFFFFFFu;
-                if (!m.step(s.dev, tab, st, src, out)) break;
+                // as the wave's two loops run it: an iteration of the template part through the instantiation compiled for it, anything else through the general step
+                if (m.in_template()) m.template iterate<true>(s.dev, tab, st, src, out);
+                else if (!m.step(s.dev, tab, st, src, out)) break;
             }
             m.finalize(meta);
             done = true;
