@@ -59,10 +59,34 @@ def main():
         if op.startswith(("s_cbranch", "s_branch")) and m and labels.get(m.group(1), i + 1) <= i:
             s0 = labels[m.group(1)]
             loops.append((sum(1 for _, o, _ in insts[s0:i] if o.startswith("v_pk_mul")), -(i - s0), s0, i))
-    most = max(l[0] for l in loops)
-    _, _, lo, hi = max(l for l in loops if l[0] == most)
-    loop = (lo, hi)
-    lo, hi = loop
+    # the step loops: since round 5 there are two (every lane in the template part / the general one) -- the smallest loops that hold the three draws' packed
+    # multiplies (at least 60 of them), none containing another
+    # (a loop shows as several backward branches to neighbouring labels: overlapping ranges are one loop, reported over their hull -- but a range that spans two
+    # loops which each hold the draws is the chunk loop around them, not a step loop)
+    cands = sorted((l for l in loops if l[0] >= 60), key=lambda l: l[3] - l[2])
+    picked = []
+    for l in cands:
+        inside = [p for p in picked if p[2] >= l[2] and p[3] <= l[3]]
+        if len({(p[2], p[3]) for p in inside}) >= 2 and not any(p[2] <= l[2] and p[3] >= l[3] for p in picked):
+            lone = [p for p in inside if not any(q is not p and q[2] < p[3] and p[2] < q[3] for q in inside)]
+            if len(lone) >= 2 or sum(1 for p in inside) >= 2 and max(p[3] for p in inside) - min(p[2] for p in inside) > 1.5 * max(p[3] - p[2] for p in inside):
+                continue
+        picked.append(l)
+    hulls = []
+    for l in sorted(picked, key=lambda l: l[2]):
+        if hulls and l[2] <= hulls[-1][3]:
+            hulls[-1] = (hulls[-1][0], hulls[-1][1], hulls[-1][2], max(hulls[-1][3], l[3]))
+        else:
+            hulls.append(l)
+    picked = hulls
+    print(f"{kernel}: vgprs {meta['vgpr_count']} sgprs {meta['sgpr_count']} spilled vgprs {meta['vgpr_spill_count']} sgprs {meta['sgpr_spill_count']} scratch {meta['private_segment_fixed_size']} B; "
+          f"{len(insts)} instructions")
+    for which, (_, _, lo, hi) in enumerate(picked):
+        report(insts, labels, lo, hi, a.dump and which == 0, f"step loop {which + 1} of {len(picked)}")
+    print(f"files in {d}")
+
+
+def report(insts, labels, lo, hi, dump, title):
     body = insts[lo:hi + 1]
     ops = collections.Counter(op for _, op, _ in body)
     valu = sum(v for k, v in ops.items() if k.startswith("v_") and not k.startswith(("v_readlane", "v_writelane", "v_readfirstlane")))
@@ -72,18 +96,15 @@ def main():
                     "buffer_load", "buffer_store", "scratch_", "s_load", "s_nop", "s_waitcnt", "s_cbranch", "s_swappc"):
             if k.startswith(cls):
                 group[cls] += v
-    print(f"{kernel}: vgprs {meta['vgpr_count']} sgprs {meta['sgpr_count']} spilled vgprs {meta['vgpr_spill_count']} sgprs {meta['sgpr_spill_count']} scratch {meta['private_segment_fixed_size']} B; "
-          f"{len(insts)} instructions")
-    print(f"step loop [{lo}, {hi}]: {hi - lo + 1} instructions, VALU {valu}, SALU {sum(v for k, v in ops.items() if k.startswith('s_'))}")
+    print(f"{title} [{lo}, {hi}]: {hi - lo + 1} instructions, VALU {valu}, SALU {sum(v for k, v in ops.items() if k.startswith('s_'))}")
     print("  " + ", ".join(f"{k} {v}" for k, v in group.most_common()))
-    if a.dump:
+    if dump:
         inv = {}
         for k, v in labels.items():
             inv.setdefault(v, []).append(k)
         for i in range(lo, hi + 1):
             ln, op, t = insts[i]
             print(f"{i} {' '.join(inv.get(i, [])):10s} {ln[0][4:7] if ln else ''}:{ln[1] if ln else ''}\t{t}")
-    print(f"files in {d}")
 
 
 if __name__ == "__main__":
