@@ -514,8 +514,10 @@ def ranks_or_relaunch(args):
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): start it as `python bench.py --gpus N` or with --nproc-per-node equal to --gpus")
-    if args.backend == "gloo" and not args.emulate:
-        raise SystemExit("bench.py: --backend gloo is for --emulate only; ranks on GPUs talk through RCCL (nccl)")
+    if args.backend == "gloo" and not (args.emulate or args.shareDevice):
+        raise SystemExit("bench.py: --backend gloo needs --shareDevice (ranks as processes on shared devices) or --emulate; ranks that own a GPU each talk through RCCL (nccl)")
+    if args.shareDevice and args.backend != "gloo":
+        raise SystemExit("bench.py: --shareDevice needs --backend gloo: RCCL cannot put two ranks on one device")
     return rank, local_rank, world
 
 
@@ -617,7 +619,10 @@ def main():
     ap.add_argument("--tiles", type=int, default=1, help="NOT the headline: P0 with so many tiles (per-tile tables; above one tile the read kernel serves one tile per workgroup)")
     ap.add_argument("--lib", default=None, help="another build of libreseq_amd.so (experiment builds, exp/)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="rsq_set_option before the simulator is created (measurements)")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of a run with more than one rank (and of --dist-single); gloo only with --emulate")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of a run with more than one rank (and of --dist-single); gloo only with "
+                    "--shareDevice or --emulate")
+    ap.add_argument("--shareDevice", action="store_true", help="NOT a scaling measurement: rank r runs on device r %% devices and the small exchanges go over gloo on the CPU -- the N-rank "
+                    "path of this script with the real kernels on a host with fewer devices than ranks (the line says so)")
     ap.add_argument("--emulate", action="store_true", help="TEST SWITCH, not a measurement: the launch / sharding / totals path of this script with the host emulation of the kernels "
                     "(tests/hostemu, the TINY profile, a few thousand pairs) in the device's place -- what the CPU suite runs with --gpus 2 --backend gloo")
     ap.add_argument("--dist-single", action="store_true", help="initialise torch.distributed although there is one rank (the RCCL calls of the N-rank path on one GPU)")
@@ -659,12 +664,17 @@ def main():
 
     import torch
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    hip_device = local_rank % torch.cuda.device_count() if args.shareDevice else local_rank
+    torch.cuda.set_device(hip_device)
+    dev = torch.device("cuda", hip_device)
+    xdev = "cpu" if args.shareDevice else f"cuda:{hip_device}"                   # where the ranks' small exchanges live
     if world > 1 or args.dist_single or "TORCHELASTIC_RUN_ID" in os.environ:      # more than one rank, or one rank under a launcher: the same calls over RCCL
         import torch.distributed as dist
         single_rank_rendezvous()
-        dist.init_process_group("nccl", device_id=dev)
+        if args.shareDevice:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     for item in args.option:                      # after torch: the library binds to the HIP runtime torch has loaded
         name, value = item.split("=", 1)
@@ -683,8 +693,8 @@ def main():
         kernel_ms["bin_tiles"] = sim.last_kernel_ms("bin_tiles")          # only when the read kernel runs binned by tile
     except api.RsqError:
         pass
-    per_rank = rank_times(dist, f"cuda:{local_rank}", elapsed, args.steps, world)
-    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", pairs, nbytes, elapsed)      # sum, sum, max over ranks
+    per_rank = rank_times(dist, xdev, elapsed, args.steps, world)
+    total_pairs, total_bytes, elapsed = sharding.job_totals(dist, xdev, pairs, nbytes, elapsed)      # sum, sum, max over ranks
 
     # the fixed-size job beside the weak one (N > 1): ONE sequence and --pairs pairs, its blocks split over the ranks by expected pairs -- BASELINE's configs[3] / [4]
     # are of this kind (one genome sharded over 8).  After the headline's timed region, with its own barriers and the same max-over-ranks timing.
@@ -692,8 +702,8 @@ def main():
     if world > 1 and args.scaling == "weak" and not args.no_strong_leg:
         fixed = PairsJob(torch, dist, dev, rank, world, ppath1, fpath1, args.seed, args.pairs, [args.genome], args.batch_blocks)
         ms = fixed.measure(args.steps, 1)
-        s_rank = rank_times(dist, f"cuda:{local_rank}", ms["elapsed"], args.steps, world)
-        s_pairs, _, s_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", ms["pairs"], ms["nbytes"], ms["elapsed"])
+        s_rank = rank_times(dist, xdev, ms["elapsed"], args.steps, world)
+        s_pairs, _, s_elapsed = sharding.job_totals(dist, xdev, ms["pairs"], ms["nbytes"], ms["elapsed"])
         strong = {"scaling": "strong", "value": s_pairs / s_elapsed, "unit": "read-pairs/s", "ms_per_step": s_elapsed / args.steps * 1e3, "ms_per_step_per_rank": s_rank,
                   "pairs_per_step": s_pairs / args.steps, "reference_bp": args.genome, "blocks_of_rank_0": [fixed.my_lo, fixed.my_hi], "total_blocks": fixed.info.total_blocks,
                   "note": "ONE E. coli-sized sequence and --pairs pairs split over the ranks by sharding.block_weights; compare with the N = 1 headline of the same workload"}
@@ -735,7 +745,7 @@ def main():
         moved = sum(host_step() for _ in range(args.steps))
         sync()
         host_elapsed = time.perf_counter() - t0
-        _, moved_all, host_elapsed = sharding.job_totals(dist, f"cuda:{local_rank}", 0, moved, host_elapsed)
+        _, moved_all, host_elapsed = sharding.job_totals(dist, xdev, 0, moved, host_elapsed)
         # the same delivered as .gz: every batch's text becomes gzip members on the device (rsq_sim_gzip_device), and the members -- a third of the bytes -- cross the link
         gz_bufs = [(TorchBuffer(torch, need1 // 2 + (1 << 20), dev), TorchBuffer(torch, need2 // 2 + (1 << 20), dev)) for _ in range(2)]
         gz_ms = [0.0]
@@ -811,8 +821,11 @@ def main():
                        "pairs_requested": args.pairs * n_seqs, "pairs_per_step_per_gpu": pairs // args.steps, "fastq_bytes_per_step_per_gpu": nbytes // args.steps,
                        "batch_blocks": args.batch_blocks, "read_kernel_launches_per_step": launches / args.steps, "blocks_of_rank_0": [my_lo, my_hi], "total_blocks": info.total_blocks,
                        "sharding": "one job; contiguous block ranges per GPU balanced by expected pairs (partition_blocks with block_weights); no data-path collective",
-                       "collectives": None if dist is None else "torch.distributed nccl (RCCL): barrier, all_reduce of the totals, all_gather of the ranks' times"},
-            "roofline": {"bound": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "collectives": None if dist is None else ("torch.distributed gloo on the CPU (the ranks share devices)" if args.shareDevice else "torch.distributed nccl (RCCL)") +
+                                      ": barrier, all_reduce of the totals, all_gather of the ranks' times",
+                       **({"ranks_share_devices": True, "note": f"--shareDevice: {world} processes on {torch.cuda.device_count()} device(s) -- the N-rank path with the real kernels, "
+                                                                "not a scaling measurement"} if args.shareDevice else {})},
+            "roofline": {"bound": "valu", "bound_of_achieved": "hbm", "kernel": "k_fill_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": counters["hbm_bytes_per_launch"] if counters else None, "traffic_source": counters["source"].replace("_pmc", "_traffic") if counters else None,
                          "algorithmic_bytes_per_launch": A_PAIR * (pairs / launches), "bytes_per_pair": A_PAIR, "pairs_per_launch": pairs / launches,
                          "avg_launch_ms": avg_fill_s * 1e3,

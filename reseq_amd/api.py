@@ -243,7 +243,7 @@ class Profile:
             self.h = C.c_void_p()
 
 
-def load_profile(path, ipf_path=None):
+def load_profile(path, ipf_path=None, ipf_precision=5.0):
     """a profile by the file's content: ReSeq's `.reseq` archive (with its `.reseq.ipf`: ipf_path, default `<path>.ipf`) or an RSQP container -- what the command line does"""
     archive = C.c_int(0)
     lib().rsq_profile_is_reseq_archive(os.fsencode(path), C.byref(archive))
@@ -251,7 +251,7 @@ def load_profile(path, ipf_path=None):
         return Profile(path)
     p = Profile.__new__(Profile)
     p.h = C.c_void_p()
-    _check(lib().rsq_profile_load_reseq(os.fsencode(path), os.fsencode(ipf_path) if ipf_path else None, 5.0, C.byref(p.h)))
+    _check(lib().rsq_profile_load_reseq(os.fsencode(path), os.fsencode(ipf_path) if ipf_path else None, float(ipf_precision), C.byref(p.h)))
     p.warning = lib().rsq_last_warning().decode()
     return p
 

@@ -24,73 +24,132 @@ from . import sharding
 
 
 def _launcher_flags(ap):
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend; ranks on GPUs talk through RCCL (nccl) -- gloo only with --emulate")
-    ap.add_argument("--emulate", action="store_true", help="TEST SWITCH, not a product path: tests/hostemu's CPU loop over the kernels' per-lane functions stands where the device would be "
-                    "(the module tests/emu_ranks.py of the directory RSQ_TESTS names), so that the launcher's N-rank path runs in a container without a GPU; says so on stderr")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend; ranks that own a GPU each talk through RCCL (nccl) -- gloo carries the small "
+                    "exchanges on the CPU when ranks share devices (--shareDevice)")
+    ap.add_argument("--shareDevice", action="store_true", help="more ranks than devices: rank r runs on device r %% devices, the small exchanges go over gloo on the CPU (RCCL needs a "
+                    "device per rank).  Every kernel, buffer and file write is the N-rank path's; several processes share a device's time, so this is not a scaling configuration -- "
+                    "it is how the N-rank path is exercised on a host with one GPU")
     ap.add_argument("--distTimeout", type=int, default=600, help="seconds a rank waits in a collective for the others before it gives up (a rank that died takes the job with it)")
 
 
-def _emulation(a, ap):
-    """--emulate: the test-side stand-ins, or an error -- never a silent route around the device"""
-    if a.backend == "gloo" and not a.emulate:
-        ap.error("--backend gloo is for --emulate only; ranks on GPUs talk through RCCL (nccl)")
-    if not a.emulate:
-        return None
-    tests = os.environ.get("RSQ_TESTS")
-    if not tests or not os.path.exists(os.path.join(tests, "emu_ranks.py")):
-        ap.error("--emulate needs RSQ_TESTS=<the repository's tests directory> (the host emulation is test infrastructure, not part of the package)")
-    sys.path.insert(0, tests)
-    import emu_ranks
-    print(">>> EMULATED on the CPU (tests/hostemu): the launcher's test, not the product path and not a measurement", file=sys.stderr)
-    return emu_ranks
+class Hooks:
+    """What a caller of main() may replace -- nothing in the product does.  tests/simulate_under_test.py puts the host emulation of the kernels where the device would
+    be (`make_backend`, `records_sim`, exchanges on the CPU) and lets a named rank die at a named step (`at_step`); none of that is reachable from this module's own
+    command line or environment."""
+    make_backend = None          # (args, seed, packed_from) -> what run_rank drives
+    records_sim = None           # (args, seed) -> what run_records_rank drives
+    on_cpu = False               # no device behind the ranks: the exchanges live on the CPU (gloo)
+    banner = None                # said on stderr before anything else
+
+    @staticmethod
+    def at_step(step, rank):
+        pass
 
 
-def _start_ranks(a, local_rank):
-    """(dist or None, the device the small exchanges live on).  Under a launcher -- also one that started a single rank -- the same exchanges over RCCL (gloo: --emulate)."""
+def _check_backend(a, ap, hooks):
+    if a.backend == "gloo" and not (a.shareDevice or hooks.on_cpu):
+        ap.error("--backend gloo needs --shareDevice: ranks that own a GPU each talk through RCCL (nccl)")
+    if a.shareDevice and a.backend != "gloo":
+        ap.error("--shareDevice needs --backend gloo: RCCL cannot put two ranks on one device")
+    if hooks.banner:
+        print(hooks.banner, file=sys.stderr)
+
+
+def _device_of(a, local_rank, hooks):
+    """the HIP device of this rank"""
+    if hooks.on_cpu:
+        return 0
+    if not a.shareDevice:
+        return local_rank
+    from . import api
+    return local_rank % api.device_count()
+
+
+def _start_ranks(a, local_rank, hooks):
+    """(dist or None, the device the small exchanges live on).  Under a launcher -- also one that started a single rank -- the same exchanges over RCCL, or over gloo on
+    the CPU when the ranks share devices."""
+    on_cpu = hooks.on_cpu or a.shareDevice
     if "WORLD_SIZE" not in os.environ:
-        return None, "cpu" if a.emulate else f"cuda:{local_rank}"
+        return None, "cpu" if on_cpu else f"cuda:{local_rank}"
     import datetime
     import torch
     import torch.distributed as dist
-    if a.emulate:
-        dist.init_process_group(a.backend if a.backend == "gloo" else "gloo", timeout=datetime.timedelta(seconds=a.distTimeout))
+    if on_cpu:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=a.distTimeout))
         return dist, "cpu"
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=a.distTimeout))
     return dist, f"cuda:{local_rank}"
 
 
-def _fault(step, rank):
-    """RSQ_FAULT_INJECT=<step>:<rank> -- the named rank dies on the spot (SIGKILL: no exception, no goodbye) when it reaches the named step; the failure tests' way of
-    losing a rank in the middle of a job (tests/test_multi_gpu.py).  Steps: generate, write."""
-    if os.environ.get("RSQ_FAULT_INJECT") == f"{step}:{rank}":
-        import signal
-        os.kill(os.getpid(), signal.SIGKILL)
+def _profile_flags(ap):
+    """the options main.cpp applies to a loaded profile (main.cpp:946-982, ProbabilityEstimates.h:1516-1549): the same names, the spelling of --errorMutliplier included"""
+    ap.add_argument("-p", "--probabilitiesIn", dest="ipf", default=None, help="the .reseq.ipf archive that belongs to a .reseq profile (default: <statsIn>.ipf)")
+    ap.add_argument("--ipfPrecision", type=float, default=5.0, help="precision the fitted tables must have reached (percent)")
+    ap.add_argument("--errorMutliplier", type=float, default=1.0, help="the profile's substitution error rates times this factor")
+    ap.add_argument("--noInDelErrors", action="store_true", help="simulate no insertions and deletions")
+    ap.add_argument("--noSubstitutionErrors", action="store_true", help="simulate no substitution errors")
+
+
+def _check_profile_flags(a, ap):
+    if not a.ipfPrecision > 0.0:
+        ap.error("ipfPrecision must be positive.")
+    if a.noSubstitutionErrors and a.errorMutliplier != 1.0:          # main.cpp:946
+        ap.error("noSubstitutionErrors and errorMutliplier cannot be combined.")
+
+
+def load_edited_profile(a):
+    """DataStats / ProbabilityEstimates loaded and edited as the command line does before the simulator sees them (reseq_main.cpp load_profile, main.cpp:964-982);
+    every rank does the same to its own copy"""
+    from . import api
+    prof = api.load_profile(a.profile, a.ipf, a.ipfPrecision)
+    try:
+        if a.noInDelErrors:
+            prof.remove_indel_errors()
+        if a.noSubstitutionErrors:
+            prof.remove_substitution_errors()
+        elif a.errorMutliplier != 1.0:
+            prof.change_error_rate(a.errorMutliplier)
+    except Exception:
+        prof.close()
+        raise
+    return prof
 
 
 class GpuBackend:
     """reseq_amd.api.Simulator with reusable device buffers (the product path)."""
 
-    def __init__(self, profile_path, fasta_path, device, replace_n_seed, vcf_path=None, methylation_path=None, sys_error_path=None, packed_from=None):
-        """`packed_from`: a file another rank of this host wrote with export_reference -- the reference, variant and methylation files are not read again"""
+    def __init__(self, profile, fasta_path, device, replace_n_seed, vcf_path=None, methylation_path=None, sys_error_path=None, packed_from=None, ref_bias_file=None):
+        """`profile`: a loaded api.Profile (owned from here on) or the path of one.  `packed_from`: a file another rank of this host wrote with export_reference -- the
+        reference, variant and methylation files are not read again"""
         from . import api
         self.api = api
-        self.prof = api.Profile(profile_path)
+        self.prof = profile if isinstance(profile, api.Profile) else api.load_profile(profile)
         self.has_variants = bool(vcf_path)
-        if packed_from:
-            self.ref = None
-            self.sim = api.Simulator(self.prof, None, device)
-            self.sim.import_reference(packed_from)
-        else:
-            self.ref = api.Reference(fasta_path, replace_n_seed)
-            if vcf_path:
-                self.ref.read_variants(vcf_path)
-            self.sim = api.Simulator(self.prof, self.ref, device)
-            if methylation_path:
-                self.sim.read_methylation(methylation_path)
+        self.ref = self.sim = None
+        try:
+            if packed_from:
+                self.sim = api.Simulator(self.prof, None, device)
+                self.sim.import_reference(packed_from)
+            else:
+                self.ref = api.Reference(fasta_path, replace_n_seed)
+                if vcf_path:
+                    self.ref.read_variants(vcf_path)
+                self.sim = api.Simulator(self.prof, self.ref, device)
+                if methylation_path:
+                    self.sim.read_methylation(methylation_path)
+            if ref_bias_file:                                            # main.cpp:862-908: read by prepare, on every rank
+                self.sim.set_ref_bias_file(ref_bias_file)
+        except Exception:
+            self.close()
+            raise
         self.sys_error_path = sys_error_path
         self.device = device
         self.seq_len = self.sim.sequence_lengths()
+
+    def create_sys_error_profile(self, seed, path):
+        """--writeSysError (main.cpp:351-397): ONE rank draws the profile and writes it; all ranks then read it like a --readSysError file"""
+        self.sim.create_sys_error_profile(seed, path)
 
     def export_reference(self, path):
         self.sim.export_reference(path)
@@ -156,7 +215,8 @@ class GpuBackend:
         self.sim.job_free()
 
     def close(self):
-        self.sim.close()
+        if self.sim:
+            self.sim.close()
         if self.ref:
             self.ref.close()
         self.prof.close()
@@ -234,7 +294,7 @@ def _attempt(f, *a):
         return None, e
 
 
-def gather_to_first_rank(backend, dist, rank, world, sizes, outs, slice_bytes):
+def gather_to_first_rank(backend, dist, rank, world, sizes, outs, slice_bytes, exchange_on_cpu=False):
     """The ranks' kept text merged by a collective (BASELINE.json's "RCCL all-gather over xGMI only to merge the emitted FASTQ buffers", as a gather: only one rank
     writes): per file and round every rank contributes one fixed-size slice of its text (rsq_sim_job_read), the first rank receives the N slices (dist.gather: RCCL
     over xGMI on a GPU host) and writes each to its rank's place in the file (rsq_dev_pwrite).  An option, not the default: N ranks writing their own byte ranges
@@ -246,16 +306,18 @@ def gather_to_first_rank(backend, dist, rank, world, sizes, outs, slice_bytes):
             at = k * slice_bytes
             mine = max(0, min(slice_bytes, sizes[rank][f] - at))
             send = backend.job_slice(f, at, mine, slice_bytes)
-            recv = [send.new_empty(slice_bytes) for _ in range(world)] if rank == 0 else None
+            # ranks that share devices exchange over gloo on the CPU (--shareDevice): the slice crosses to the host for the collective and back for the writer
+            carried = send.cpu() if exchange_on_cpu and send.device.type != "cpu" else send
+            recv = [carried.new_empty(slice_bytes) for _ in range(world)] if rank == 0 else None
             if dist is not None:
-                dist.gather(send, recv, dst=0)
+                dist.gather(carried, recv, dst=0)
             else:
-                recv = [send]
+                recv = [carried]
             if rank == 0:
                 for r in range(world):
                     n = max(0, min(slice_bytes, sizes[r][f] - at))
                     if n:
-                        backend.write_slice(recv[r], n, outs[f], start[r] + at)
+                        backend.write_slice(recv[r].to(send.device), n, outs[f], start[r] + at)
 
 
 def _gzip_member(text):
@@ -265,7 +327,7 @@ def _gzip_member(text):
 
 
 def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage=0.0, ref_bias_mode=0, base_identifier="", batch_blocks=None, device="cpu", split_output=False,
-             gather_output=False, gather_slice_bytes=256 << 20, compress=False):
+             gather_output=False, gather_slice_bytes=256 << 20, compress=False, at_step=Hooks.at_step):
     """One rank's share.  `backend` offers prepare (or the sharded pre-pass) / ref_seq_bias / seq_len / job_generate / job_write / adapter_only_pairs.
     Returns (pairs of the whole job, seconds of generation on the slowest rank).  This function is the launcher: it decides who does what and carries three
     small exchanges; the data never passes through Python."""
@@ -282,7 +344,7 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
         _agree(dist, device, error, "preparing the simulation")
         info, mine = prepared
     t0 = time.perf_counter()
-    _fault("generate", rank)
+    at_step("generate", rank)
     generated, error = _attempt(backend.job_generate, mine[0], mine[1], batch_blocks)      # the rank's text stays where it was made (HBM) until its place is known
     _agree(dist, device, error, "generating its share")
     n_mine, bytes1, bytes2 = generated
@@ -332,10 +394,10 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
 
     # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
     _agree(dist, device, _attempt(create_files)[1], "creating the output files")
-    _fault("write", rank)
+    at_step("write", rank)
     if gather_output:                                                # one writer, fed by a collective
         def gathered():
-            gather_to_first_rank(backend, dist, rank, world, sizes, (out1, out2), gather_slice_bytes)
+            gather_to_first_rank(backend, dist, rank, world, sizes, (out1, out2), gather_slice_bytes, exchange_on_cpu=str(device) == "cpu")
             backend.job_free()
         _agree(dist, device, _attempt(gathered)[1], "gathering the text on the first rank")
     else:
@@ -402,13 +464,24 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
     return int(total_records), elapsed
 
 
-def main_records(argv):
+def _broadcast_seed(a, dist, device):
+    """one seed for the whole job, all 64 bits of it"""
+    seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
+    if dist is not None:
+        import torch
+        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
+        dist.broadcast(t, 0)
+        seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
+    return seed
+
+
+def main_records(argv, hooks=Hooks):
     """python -m reseq_amd.simulate seqToIllumina -i in.fa -o out.fq -s profile [--seed N] [--splitOutput]: `reseq seqToIllumina` over the GPUs of a host"""
     ap = argparse.ArgumentParser(prog="reseq_amd.simulate seqToIllumina", description=main_records.__doc__)
     ap.add_argument("-i", "--input", required=True, help="FASTA records with the systematic errors in their id lines; a plain file (ranks read it at offsets)")
     ap.add_argument("-o", "--output", required=True)
     ap.add_argument("-s", "--statsIn", dest="profile", required=True)
-    ap.add_argument("-p", "--probabilitiesIn", dest="ipf", default=None)
+    _profile_flags(ap)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--splitOutput", action="store_true", help="every rank writes its own file <out>.part<k>of<N> (their concatenation in order is the single file)")
     _launcher_flags(ap)
@@ -416,23 +489,23 @@ def main_records(argv):
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if a.output.endswith(".bz2"):
         ap.error(f"{a.output}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
-    emu = _emulation(a, ap)
-    import torch
+    _check_profile_flags(a, ap)
+    _check_backend(a, ap, hooks)
     from . import api
-    dist, device = _start_ranks(a, local_rank)
-    seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
-    if dist is not None:                                             # one seed for the whole job, all 64 bits of it
-        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
-        dist.broadcast(t, 0)
-        seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
+    dist, device = _start_ranks(a, local_rank, hooks)
+    seed = _broadcast_seed(a, dist, device)
     prof = sim = None
     try:
         def set_up():
-            if emu:
-                return None, emu.EmuRecordsSim(a.profile, seed)
-            p = api.load_profile(a.profile, a.ipf)
-            s = api.Simulator(p, None, local_rank)
-            s.prepare(seed)
+            if hooks.records_sim:
+                return None, hooks.records_sim(a, seed)
+            p = load_edited_profile(a)
+            try:
+                s = api.Simulator(p, None, _device_of(a, local_rank, hooks))
+                s.prepare(seed)
+            except Exception:
+                p.close()
+                raise
             return p, s
         got, error = _attempt(set_up)
         _agree(dist, device, error, "setting up its simulator")
@@ -454,22 +527,25 @@ def main_records(argv):
             dist.destroy_process_group()
 
 
-def main(argv=None):
+def main(argv=None, hooks=Hooks):
     argv = sys.argv[1:] if argv is None else list(argv)
     if argv and argv[0] in ("seqToIllumina", "replaceQuals"):
-        return main_records(argv[1:])
+        return main_records(argv[1:], hooks)
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("-R", "--refSim", "-r", "--refIn", dest="ref", required=True)
     ap.add_argument("-s", "--statsIn", dest="profile", required=True)
+    _profile_flags(ap)
     ap.add_argument("-1", "--firstReadsOut", dest="out1", default="reseq-R1.fq")
     ap.add_argument("-2", "--secondReadsOut", dest="out2", default="reseq-R2.fq")
     ap.add_argument("-V", "--vcfSim", dest="vcf", default=None, help="variants to simulate per allele (substitutions)")
     ap.add_argument("--methylation", default=None, help="extended bed graph with methylation values per region (and allele)")
     ap.add_argument("--readSysError", default=None, help="systematic-error profile written by reseq illuminaPE --writeSysError")
+    ap.add_argument("--writeSysError", default=None, help="draw the systematic errors once (the first rank), write them to this file and simulate with them")
     ap.add_argument("--numReads", type=int, default=0)
     ap.add_argument("-c", "--coverage", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=None)
-    ap.add_argument("--refBias", choices=["keep", "no", "draw"], default="keep")
+    ap.add_argument("--refBias", choices=["keep", "no", "draw", "file"], default=None)
+    ap.add_argument("--refBiasFile", default=None, help="reference sequence biases, one `<sequence id> <bias>` per line (implies --refBias file)")
     ap.add_argument("--recordBaseIdentifier", default="ReseqRead")
     ap.add_argument("--batchBlocks", type=int, default=0, help="blocks of 1000 start positions per device call (default: about 12 M pairs)")
     ap.add_argument("--gatherOutput", action="store_true", help="the ranks' text is gathered on the first rank by a collective (RCCL) in slices and written by that rank alone, "
@@ -483,9 +559,17 @@ def main(argv=None):
     _launcher_flags(ap)
     a = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    emu = _emulation(a, ap)
-    import torch
-    dist, device = _start_ranks(a, local_rank)
+    _check_profile_flags(a, ap)
+    _check_backend(a, ap, hooks)
+    # main.cpp:862-908: --refBias keep|no|draw|file, --refBiasFile implies file; keep is the default
+    if a.refBias is None:
+        a.refBias = "file" if a.refBiasFile else "keep"
+    elif (a.refBias == "file") != bool(a.refBiasFile):
+        ap.error("refBiasFile option mandatory if refBias is set to 'file'." if a.refBias == "file" else "refBiasFile option only allowed if refBias is set to 'file'.")
+    if a.writeSysError and a.readSysError:                           # main.cpp:351-397
+        ap.error("writeSysError and readSysError option are mutually exclusive. Specify the one or the other.")
+    if a.numReads and a.coverage:                                    # main.cpp:783-786
+        ap.error("numReads and coverage option are mutually exclusive. Specify the one or the other.")
     compress = a.out1.endswith(".gz")                                # gzip members concatenate, so a rank's compressed share has a place in the file like plain text
     if a.out2.endswith(".gz") != compress:
         ap.error("the two output files are either both plain or both .gz")
@@ -494,23 +578,36 @@ def main(argv=None):
     for out in (a.out1, a.out2):
         if out.endswith(".bz2"):
             ap.error(f"{out}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
-    seed = (a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little")) & 0xFFFFFFFFFFFFFFFF
-    if dist is not None:                                             # one seed for the whole job, all 64 bits of it
-        t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=device)
-        dist.broadcast(t, 0)
-        seed = int(t.item()) & 0xFFFFFFFFFFFFFFFF
-    if emu:
-        make = lambda packed_from: emu.EmuRankBackend(a.profile, a.ref, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
+    dist, device = _start_ranks(a, local_rank, hooks)
+    seed = _broadcast_seed(a, dist, device)
+    if hooks.make_backend:
+        make = lambda packed_from: hooks.make_backend(a, seed, packed_from)
     else:
-        make = lambda packed_from: GpuBackend(a.profile, a.ref, local_rank, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from)
+        hip_device = _device_of(a, local_rank, hooks)
+        make = lambda packed_from: GpuBackend(load_edited_profile(a), a.ref, hip_device, seed, a.vcf, a.methylation, a.readSysError, packed_from=packed_from,
+                                              ref_bias_file=a.refBiasFile)
     if a.everyRankLoads:
         backend = make(None)
     else:
         backend = load_once_per_host(make, dist, device, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), int(os.environ.get("GROUP_RANK", 0)),
                                      shm_dir=os.environ.get("RSQ_SHM_DIR", "/dev/shm"))
     try:
-        pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2}[a.refBias],
-                                  a.recordBaseIdentifier, a.batchBlocks, device, a.splitOutput, a.gatherOutput, a.gatherSliceBytes or a.gatherSliceMB << 20, compress)
+        if a.writeSysError:
+            # main.cpp:351-397 WriteSysError: the first rank draws and writes the profile, then every rank reads it as it would a --readSysError file
+            def write_profile():
+                if rank == 0:
+                    print(f">>> Info: Writing systematic error profile to {a.writeSysError}", file=sys.stderr)
+                    try:
+                        backend.create_sys_error_profile(seed, a.writeSysError)
+                    except Exception:
+                        if os.path.exists(a.writeSysError):          # main.cpp:392
+                            os.remove(a.writeSysError)
+                        raise
+            _agree(dist, device, _attempt(write_profile)[1], "writing the systematic error profile")
+            backend.sys_error_path = a.writeSysError
+        pairs, seconds = run_rank(backend, dist, rank, world, a.out1, a.out2, seed, a.numReads, a.coverage, {"keep": 0, "no": 1, "draw": 2, "file": 3}[a.refBias],
+                                  a.recordBaseIdentifier, a.batchBlocks, device, a.splitOutput, a.gatherOutput, a.gatherSliceBytes or a.gatherSliceMB << 20, compress,
+                                  at_step=hooks.at_step)
         if rank == 0:
             print(f">>> Info: Generated {pairs} read pairs on {world} GPU(s), {seconds:.2f} s of generation on the slowest rank", file=sys.stderr)
     finally:

@@ -1,6 +1,6 @@
 """Test infrastructure: the host emulation of the kernels (tests/hostemu) behind the two interfaces reseq_amd.simulate drives -- the GPU run uses
-simulate.GpuBackend and api.Simulator.  `python -m reseq_amd.simulate --emulate --backend gloo` (a labelled test switch) imports this module from the
-directory RSQ_TESTS names, so that the launcher's N-rank path -- one process per rank under torch.distributed.run, the exchanges, the offsets, the failure
+simulate.GpuBackend and api.Simulator.  tests/simulate_under_test.py --emulate hands these classes to reseq_amd.simulate.main as its hooks, so that the launcher's
+N-rank path -- one process per rank under torch.distributed.run, the exchanges, the offsets, the failure
 handling -- runs in the CPU suite exactly as it will run over RCCL (tests/test_multi_gpu.py has both modes of every test)."""
 import os
 
@@ -18,16 +18,18 @@ def _fail(switch, message, error=IOError):
 class EmuRankBackend:
     """what simulate.run_rank / load_once_per_host / sharding.sharded_prepare drive"""
 
-    def __init__(self, profile_path, fasta_path, replace_n_seed=0, vcf_path=None, methylation_path=None, sys_error_path=None, packed_from=None):
+    def __init__(self, profile_path, fasta_path, replace_n_seed=0, vcf_path=None, methylation_path=None, sys_error_path=None, packed_from=None, edits=None, ref_bias_file=None):
         if packed_from:             # the reference another rank of the "host" packed (simulate.load_once_per_host)
             _fail("IMPORT", "cannot map the packed reference")
-            self.b = EmuBackend(profile_path, None, 0)
+            self.b = EmuBackend(profile_path, None, 0, edits)
             self.b.import_reference(packed_from)
         else:
             _fail("LOAD", "reference file not found")
-            self.b = EmuBackend(profile_path, fasta_path, replace_n_seed, None, vcf_path=vcf_path) if vcf_path else EmuBackend(profile_path, fasta_path, replace_n_seed)
+            self.b = EmuBackend(profile_path, fasta_path, replace_n_seed, edits, vcf_path=vcf_path)
             if methylation_path:
                 self.b.read_methylation(methylation_path)
+        if ref_bias_file:
+            self.b.set_ref_bias_file(ref_bias_file)
         self.sys_error_path = sys_error_path
         self.seq_len = self.b.sequence_lengths()
         self.text = None
@@ -38,6 +40,9 @@ class EmuRankBackend:
 
     def export_reference(self, path):
         self.b.export_reference(path)
+
+    def create_sys_error_profile(self, seed, path):
+        self.b.create_sys_error_profile(seed, path)
 
     def close(self):
         self.b.close()
@@ -114,8 +119,8 @@ class EmuRecordsSim:
     """what simulate.run_records_rank drives (api.Simulator on a GPU): seqToIllumina's records of a byte range of the input through rsq_fasta.h's parser and
     the read machine, both run on the CPU by tests/hostemu; the FASTQ text as rsq_sim_error_model_fasta writes it"""
 
-    def __init__(self, profile_path, seed):
-        self.b = EmuBackend(profile_path, None, 0)
+    def __init__(self, profile_path, seed, edits=None):
+        self.b = EmuBackend(profile_path, None, 0, edits)
         self.b.prepare(seed)
         self.text = None
 

@@ -1,13 +1,18 @@
-"""The N-rank path, one process per rank under torch.distributed.run, in two modes of the SAME test bodies:
+"""The N-rank path, one process per rank under torch.distributed.run, in three modes of the SAME test bodies:
 
-  rccl  (-m gpu; skipped with a reason when fewer than two devices are visible): the product -- `python -m reseq_amd.simulate` on N GPUs over RCCL, compared byte for
-        byte with the single-device command line (`reseq illuminaPE` / `reseq seqToIllumina`, Simulator.cpp:2830-2836 starts its own workers the same way and
-        :2384-2401 hands them blocks), run with 2 ranks and with min(8, devices) ranks;
-  gloo  (CPU suite): the same launcher with `--backend gloo --emulate` -- tests/hostemu where the device would be (tests/emu_ranks.py) -- compared with the same
-        module run as one rank without a launcher.
+  rccl    (-m gpu; skipped with a reason when fewer than two devices are visible): the product -- `python -m reseq_amd.simulate` on N GPUs over RCCL, compared byte
+          for byte with the single-device command line (`reseq illuminaPE` / `reseq seqToIllumina`, Simulator.cpp:2830-2836 starts its own workers the same way and
+          :2384-2401 hands them blocks), run with 2 ranks and with min(8, devices) ranks;
+  shared  (-m gpu; needs ONE device): the same launcher and the same kernels with 2 and 4 PROCESSES on device 0 (`--backend gloo --shareDevice`: the ranks' small
+          exchanges go over gloo on the CPU, because RCCL cannot put two ranks on one device).  Everything of the N-rank path except RCCL itself runs on hardware:
+          the packed reference exported to /dev/shm by one process and imported by the others, sharded pre-passes across real shard borders under separate
+          processes, N writers into one file at offsets, N compilations racing on one kernel cache, a rank killed with its device context open;
+  gloo    (CPU suite): the launcher under tests/simulate_under_test.py --emulate -- tests/hostemu where the device would be (tests/emu_ranks.py) -- compared with
+          the same module run as one rank without a launcher.
 
 What is covered: (i) illuminaPE plain, with variants + methylation, --splitOutput, --gatherOutput, .gz; (ii) seqToIllumina; (iii) the sharded pre-pass against the
-whole one; (iv) one load per host: only one rank ever opens the FASTA; (v) bench.py --gpus 2; (vi) a rank killed in the middle of the job takes the job with it."""
+whole one; (iv) one load per host: only one rank ever opens the FASTA; (v) bench.py --gpus 2; (vi) a rank killed in the middle of the job takes the job with it;
+(vii) the options main.cpp applies after loading (error multiplier, no indels / substitutions, --refBiasFile, --writeSysError) on N ranks against the command line."""
 import gzip
 import json
 import os
@@ -21,6 +26,7 @@ import numpy as np
 import pytest
 
 import parity_cases as P
+from conftest import read_fasta as conftest_read_fasta
 from reseq_amd import api, synth
 
 HERE = pathlib.Path(__file__).resolve().parent
@@ -38,14 +44,19 @@ def _devices():
 def _worlds(mode):
     if mode == "gloo":
         return [2]
+    if mode == "shared":
+        return [2, 4]
     n = _devices()
     return sorted({2, min(8, n)})
 
 
-@pytest.fixture(params=["gloo", pytest.param("rccl", marks=pytest.mark.gpu)])
+@pytest.fixture(params=["gloo", pytest.param("shared", marks=pytest.mark.gpu), pytest.param("rccl", marks=pytest.mark.gpu)])
 def mode(request):
     if request.param == "rccl" and _devices() < 2:
-        pytest.skip(f"the N-rank path over RCCL needs at least two visible devices ({_devices()} here); its bodies run over gloo with the host emulation in the CPU suite")
+        pytest.skip(f"the N-rank path over RCCL needs at least two visible devices ({_devices()} here); its bodies run with the real kernels in mode `shared` (N processes on "
+                    "one device, exchanges over gloo) and over gloo with the host emulation in the CPU suite")
+    if request.param == "shared" and _devices() < 1:
+        pytest.skip("no device")
     return request.param
 
 
@@ -62,12 +73,20 @@ def _env(workdir, **extra):
     return e
 
 
-def launch(mode, world, args, workdir, target=("-m", "reseq_amd.simulate"), timeout=900, check=True, **env):
-    """the target under torch.distributed.run with `world` ranks on this host"""
+UNDER_TEST = (str(HERE / "simulate_under_test.py"),)                # reseq_amd.simulate.main with the suite's hooks (emulation, a rank that dies)
+
+
+def launch(mode, world, args, workdir, target=None, timeout=900, check=True, **env):
+    """the target under torch.distributed.run with `world` ranks on this host.  The default target is the product's own entry point, `-m reseq_amd.simulate`, for the
+    modes with a device behind the ranks and tests/simulate_under_test.py for the emulation."""
+    if target is None:
+        target = UNDER_TEST if mode == "gloo" else ("-m", "reseq_amd.simulate")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_port()), *target, *map(str, args)]
     if mode == "gloo":
         cmd += ["--backend", "gloo", "--emulate"]
         env.setdefault("RSQ_SHM_DIR", workdir)                      # the packed reference of the "host" goes where the test can see that it is gone
+    elif mode == "shared":
+        cmd += ["--backend", "gloo", "--shareDevice"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=_env(workdir, **env), cwd=str(ROOT))
     if check:
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
@@ -77,7 +96,7 @@ def launch(mode, world, args, workdir, target=("-m", "reseq_amd.simulate"), time
 def single(mode, sub, args, workdir, **env):
     """the single-device run the ranks' output is compared with: the command line on one GPU, or the launcher's module as one rank on the emulation"""
     if mode == "gloo":
-        cmd = [sys.executable, "-m", "reseq_amd.simulate", *([sub] if sub == "seqToIllumina" else []), *map(str, args), "--emulate"]
+        cmd = [sys.executable, *UNDER_TEST, *([sub] if sub == "seqToIllumina" else []), *map(str, args), "--emulate"]
     else:
         cmd = [str(RESEQ), sub, *map(str, args)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(workdir, **env), cwd=str(ROOT))
@@ -96,7 +115,9 @@ def job(tmp_path_factory):
     names = [n.split(" ")[0] for n, _ in seqs]
     bed = work / "job.bed"
     bed.write_text(f"{names[0]}\t100\t900\t0.3\t0.6\n{names[0]}\t2000\t5000\t0.0\t0.5\n{names[2]}\t50\t2000\t0.0\t1.0\n")
-    return dict(work=work, profile=ppath, fasta=fpath, vcf=str(vcf), bed=str(bed))
+    # without the short sequence: a systematic-error profile is written for every sequence and read for those with blocks only (Simulator.cpp:750-769)
+    ppath2, fpath2, _ = P.make_inputs(work, "long_only", synth.TINY, [7000, 4210])
+    return dict(work=work, profile=ppath, fasta=fpath, vcf=str(vcf), bed=str(bed), long_only=dict(work=work, profile=ppath2, fasta=fpath2))
 
 
 def _pe_args(job, tag, extra=(), gz=False):
@@ -106,7 +127,7 @@ def _pe_args(job, tag, extra=(), gz=False):
 
 
 def _single_pe(mode, job, tag, extra=()):
-    args, out = _pe_args(job, f"{mode}_{tag}_one", extra)
+    args, out = _pe_args(job, f"{'emu' if mode == 'gloo' else 'cli'}_{tag}_one", extra)
     if not all(os.path.exists(o) for o in out):
         single(mode, "illuminaPE", args, job["work"])
     texts = [open(o, "rb").read() for o in out]
@@ -306,6 +327,8 @@ def test_only_one_rank_of_a_host_opens_the_reference(mode, job):
 @pytest.mark.timeout(1800)
 def test_bench_on_two_ranks(mode, job):
     flags = ["--gpus", "2", "--steps", "2", "--warmup", "1"] + (["--backend", "gloo", "--emulate"] if mode == "gloo" else ["--pairs", "1000000", "--no-cpu-baseline"])
+    if mode == "shared":
+        flags += ["--backend", "gloo", "--shareDevice", "--genome", "1000000", "--pairs", "400000"]
     for scaling in ("weak", "strong"):
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags, "--scaling", scaling], capture_output=True, text=True, timeout=1500, env=_env(job["work"]), cwd=str(ROOT))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-5000:]
@@ -315,7 +338,9 @@ def test_bench_on_two_ranks(mode, job):
         assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == scaling and len(line["ms_per_step_per_rank"]) == 2
         assert line["ms_per_step"] >= max(line["ms_per_step_per_rank"]) * 0.999 and line["value"] > 0
         assert "barrier" in line["config"]["collectives"] and ("nccl" if mode == "rccl" else "gloo") in line["config"]["collectives"]
-        if mode == "rccl":
+        if mode == "shared":
+            assert line["config"]["ranks_share_devices"] and "not a scaling" in line["config"]["note"]
+        if mode != "gloo":
             assert "roofline" in line and line["roofline"]["frac"] > 0
 
 
@@ -327,7 +352,7 @@ def test_a_rank_that_dies_takes_the_job_with_it(mode, job, step):
     stays behind and the packed reference is gone from shared memory"""
     args, out = _pe_args(job, f"{mode}_killed_{step}")
     t0 = time.time()
-    r = launch(mode, 2, [*args, "--distTimeout", 120], job["work"], check=False, timeout=600, RSQ_FAULT_INJECT=f"{step}:1")
+    r = launch(mode, 2, [*args, "--distTimeout", 120], job["work"], target=UNDER_TEST, check=False, timeout=600, RSQ_FAULT_INJECT=f"{step}:1")
     took = time.time() - t0
     assert r.returncode != 0, r.stderr[-3000:]
     assert took < 240, took
@@ -335,3 +360,77 @@ def test_a_rank_that_dies_takes_the_job_with_it(mode, job, step):
     leftover = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
     assert not [l for l in leftover.splitlines() if f"{mode}_killed_{step}" in l and "ps -eo" not in l], leftover
     assert not list(pathlib.Path(job["work"]).glob("rsq_packed_reference_*")) and not list(pathlib.Path("/dev/shm").glob("rsq_packed_reference_*"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------- (vii)
+@pytest.mark.timeout(1800)
+def test_post_load_options_on_n_ranks_write_the_single_device_files(mode, job):
+    """main.cpp:964-982 (--errorMutliplier, --noInDelErrors, --noSubstitutionErrors; ProbabilityEstimates.h:1516-1549), :862-908 (--refBiasFile) and :351-397
+    (--writeSysError): what `reseq illuminaPE` does with them on one device, the launcher does on every rank -- the files are the command line's byte for byte, and
+    every option changes them"""
+    plain = _single_pe(mode, job, "plain")
+    names = [n.split(" ")[0] for n, _ in conftest_read_fasta(job["fasta"])]
+    bias = job["work"] / "job_ref_bias.txt"
+    # the forms of test/ref-bias-test.txt: a leading '>', a comment behind the name, a name that is no sequence; every sequence needs a line
+    bias.write_text(f">{names[2]} something   0.25\nnot_a_sequence 0.5\n{names[0]} 2.0\n{names[1]} 1.0\n")
+    world = _worlds(mode)[-1]
+    cases = {
+        "multiplier_no_indels": ["--errorMutliplier", 2.5, "--noInDelErrors"],
+        "no_substitutions": ["--noSubstitutionErrors"],
+        "ref_bias_file": ["--refBiasFile", bias],
+    }
+    for tag, flags in cases.items():
+        extra = flags
+        base = [a for a in _pe_args(job, "unused")[0]]
+        if tag == "ref_bias_file":                                  # --refBias no of the common arguments and --refBiasFile exclude each other
+            k = base.index("--refBias")
+            del base[k:k + 2]
+        one = [str(job["work"] / f"{'emu' if mode == 'gloo' else 'cli'}_{tag}_one_{k}.fq") for k in (1, 2)]
+        many = [str(job["work"] / f"{mode}_{tag}_w{world}_{k}.fq") for k in (1, 2)]
+
+        def with_outputs(args, outs):
+            args = list(args)
+            args[args.index("-1") + 1], args[args.index("-2") + 1] = outs
+            return args
+        if not all(os.path.exists(o) for o in one):
+            single(mode, "illuminaPE", with_outputs([*base, *extra], one), job["work"])
+        want = [open(o, "rb").read() for o in one]
+        assert want != plain and want[0].count(b"\n") > 4 * 5000, tag
+        launch(mode, world, with_outputs([*base, *extra, "--batchBlocks", 3], many), job["work"])
+        assert [open(o, "rb").read() for o in many] == want, tag
+    # --writeSysError: the first rank draws and writes the profile, every rank then simulates with it; file and reads are the command line's
+    long_only = job["long_only"]
+    args, out = _pe_args(long_only, f"{mode}_write_sys_one", ["--writeSysError", job["work"] / f"{mode}_sys_one.prof"])
+    single(mode, "illuminaPE", args, job["work"])
+    want = [open(o, "rb").read() for o in out]
+    args, out = _pe_args(long_only, f"{mode}_write_sys_w{world}", ["--writeSysError", job["work"] / f"{mode}_sys_w{world}.prof"])
+    launch(mode, world, args, job["work"])
+    assert (job["work"] / f"{mode}_sys_w{world}.prof").read_bytes() == (job["work"] / f"{mode}_sys_one.prof").read_bytes()
+    assert [open(o, "rb").read() for o in out] == want and want[0].count(b"\n") > 4 * 5000
+    # and --readSysError of that file gives the same reads again
+    args, out = _pe_args(long_only, f"{mode}_read_sys_w{world}", ["--readSysError", job["work"] / f"{mode}_sys_one.prof"])
+    launch(mode, world, args, job["work"])
+    assert [open(o, "rb").read() for o in out] == want
+
+
+def test_the_launcher_refuses_what_the_command_line_refuses(job, tmp_path):
+    """argument rules of main.cpp:946 (noSubstitutionErrors with errorMutliplier), :862-908 (refBias file / refBiasFile), :351-397 (write / readSysError), :783-786
+    (numReads / coverage) -- before any device or process group is touched"""
+    args = _pe_args(job, "refused")[0]
+    for extra, message in ((["--noSubstitutionErrors", "--errorMutliplier", "2"], "noSubstitutionErrors and errorMutliplier cannot be combined."),
+                           (["--refBias", "file"], "refBiasFile option mandatory if refBias is set to 'file'."),
+                           (["--refBiasFile", "x.txt"], "refBiasFile option only allowed if refBias is set to 'file'."),          # the common arguments say --refBias no
+                           (["--writeSysError", "a", "--readSysError", "b"], "writeSysError and readSysError option are mutually exclusive."),
+                           (["--coverage", "3"], "numReads and coverage option are mutually exclusive."),
+                           (["--ipfPrecision", "0"], "ipfPrecision must be positive."),
+                           (["--backend", "gloo"], "--backend gloo needs --shareDevice"),
+                           (["--shareDevice"], "--shareDevice needs --backend gloo")):
+        argv = [a for a in args]
+        if extra[0] == "--refBias":
+            k = argv.index("--refBias")
+            del argv[k:k + 2]
+        r = subprocess.run([sys.executable, "-m", "reseq_amd.simulate", *map(str, argv), *extra], capture_output=True, text=True, timeout=300, env=_env(tmp_path), cwd=str(ROOT))
+        assert r.returncode == 2 and message in r.stderr, (extra, r.stderr[-1500:])
+    # the product's entry point knows neither the emulation nor the fault switch
+    r = subprocess.run([sys.executable, "-m", "reseq_amd.simulate", *map(str, args), "--emulate"], capture_output=True, text=True, timeout=300, env=_env(tmp_path), cwd=str(ROOT))
+    assert r.returncode == 2 and "unrecognized arguments: --emulate" in r.stderr
