@@ -120,6 +120,14 @@ int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len
 int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim **out);
 void rsq_sim_free(rsq_sim *s);
 
+/* Reference::ReferenceSequence (reseq/Reference.cpp:483-496 plain, :498-567 with variants; reseq/Reference.h) as the kernels compute it on the device: the
+ * `frag_length` bases of `allele` that start at `start_pos` (reversed: the reverse complement of those that END in front of `start_pos`), beginning
+ * `first_variant_pos` bases inside the inserted bases of variant `first_variant_id` of the sequence when that is not 0 -- the arguments GetOrgSeq passes
+ * (reseq/Simulator.cpp:1909-1914).  Base codes (A=0,C=1,G=2,T=3) into out[frag_length].  For checks against the reference's known answers
+ * (reseq/ReferenceTest.cpp:277-326) and for callers that want a template without simulating it; RSQ_EINVAL when the stretch leaves the allele's sequence. */
+int rsq_sim_reference_sequence(rsq_sim *s, uint32_t seq, uint32_t start_pos, uint32_t frag_length, int reversed, int32_t first_variant_id, uint32_t first_variant_pos, uint32_t allele,
+                               uint8_t *out, size_t cap);
+
 /* Everything Simulator::Simulate does before "Starting read generation" (reseq/Simulator.cpp:2687-2826):
  * number of pairs (num_read_pairs, or coverage, or the profile's corrected coverage when both are 0), adapter-only
  * share, CalculateBiasNormalization, systematic errors of adapters and of both strands of every sequence.

@@ -558,6 +558,19 @@ void *orc_var_new(const uint8_t *codes, uint32_t n, const uint8_t *comp_codes, u
     return v;
 }
 void orc_var_free(void *h) { delete static_cast<VarScenario *>(h); }
+// Reference::ReferenceSequence(insert_string, seq_id, start_pos, frag_length, reversed, variants, first_variant, allele) (Reference.cpp:498-567) on the scenario's
+// sequence and variants: base codes into out[frag_length]; the number of bases, -1 for an error.  Pinned to ReferenceTest.cpp:283-326.
+int orc_var_reference_sequence(void *h, uint32_t start_pos, uint32_t frag_length, int reversed, int32_t first_variant_id, uint32_t first_variant_pos, uint32_t allele, uint8_t *out) {
+    const VarScenario &v = *static_cast<VarScenario *>(h);
+    try {
+        const std::vector<uint8_t> seq = reference_sequence_with_variants(v.ref(), start_pos, frag_length, reversed != 0, {first_variant_id, first_variant_pos}, allele);
+        memcpy(out, seq.data(), seq.size());
+        return (int)seq.size();
+    } catch (const std::exception &e) {
+        g_error = e.what();
+        return -1;
+    }
+}
 void orc_var_set_first_variant(void *h, int32_t id) { static_cast<VarScenario *>(h)->bm.first_variant_id = id; }
 void orc_var_get_start(void *h, int32_t *first_variant_id, uint32_t *start_variant_pos) {
     const VarScenario &v = *static_cast<VarScenario *>(h);

@@ -80,6 +80,7 @@ SYMBOLS = {
     "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rsq_sim_specialize": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "rsq_sim_export_reference": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_reference_sequence": (C.c_int, [_vp, _u32, _u32, _u32, C.c_int, C.c_int32, _u32, _u32, _vp, _sz]),
     "rsq_sim_job_read": (C.c_int, [_vp, C.c_int, _u64, _sz, _vp, _vp]),
     "rsq_dev_pwrite": (C.c_int, [C.c_int, _vp, _sz, C.c_char_p, _u64]),
     "rsq_sim_get_sequence_lengths": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32)]),
@@ -406,6 +407,12 @@ class Simulator:
         out = np.zeros(n.value, np.uint32)
         _check(lib().rsq_sim_get_sequence_lengths(self.h, out.ctypes.data, out.size, C.byref(n)))
         return [int(x) for x in out]
+
+    def reference_sequence(self, seq, start_pos, frag_length, reversed=False, first_variant=(0, 0), allele=0):
+        """Reference::ReferenceSequence (with variants: of one allele, from inside inserted bases when first_variant[1] > 0) as letters"""
+        out = np.zeros(max(1, frag_length), np.uint8)
+        _check(lib().rsq_sim_reference_sequence(self.h, seq, start_pos, frag_length, int(bool(reversed)), int(first_variant[0]), int(first_variant[1]), allele, out.ctypes.data, out.size))
+        return "".join("ACGT"[c] for c in out[:frag_length])
 
     def export_reference(self, path):
         """what the simulator keeps of its reference, variant and methylation files, for the other ranks of the host (import_reference)"""

@@ -1560,6 +1560,71 @@ int rsq_sim_get_sequence_lengths(const rsq_sim *s, uint32_t *out, size_t cap, ui
     }
     return RSQ_OK;
 }
+// Reference::ReferenceSequence (Reference.cpp:483-567) for one call, the way the kernels get a template: allele_template on the allele's coordinate map (variants of
+// any kind), else FragmentSrc on the allele's copy of the packed reference.  One thread; flag 1: the stretch leaves the allele's sequence.
+__global__ void k_reference_sequence(DevSim S, uint32_t seq, uint32_t allele, uint32_t pos, VarStart from, uint32_t n, bool reversed, uint64_t *tmpl, uint32_t words, uint32_t *flag) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (2u == S.variants_loaded) {
+        const AlleleView a = allele_view(S, seq, allele);
+        const int64_t h = from.start_variant_pos ? a.begin_of(a.entries_before(a.r.v[from.first_variant_id].pos)) + from.start_variant_pos : a.to_allele(pos);
+        if (reversed ? h < (int64_t)n : h + (int64_t)n > a.length()) {
+            *flag = 1u;
+            return;
+        }
+        allele_template(a, pos, from, n, reversed, tmpl, words);
+        return;
+    }
+    FragmentSrc src;
+    src.words = hap_words(S, allele);
+    src.word_off = S.seq_word_off[seq];
+    src.first = pos;
+    src.len = n;
+    src.reverse = reversed;
+    src.sys_ = nullptr;
+    src.converted = nullptr;
+    src.gc_prefix = nullptr;
+    for (uint32_t w = 0; w < words; ++w) tmpl[w] = 0;
+    for (uint32_t k = 0; k < n; ++k) tmpl[k >> 5] |= (uint64_t)src.ref(k) << ((k & 31u) * 2u);
+}
+int rsq_sim_reference_sequence(rsq_sim *s, uint32_t seq, uint32_t start_pos, uint32_t frag_length, int reversed, int32_t first_variant_id, uint32_t first_variant_pos, uint32_t allele,
+                               uint8_t *out, size_t cap) {
+    REQUIRE(s && out && s->has_ref && seq < s->dev.n_seqs, "null argument, a simulator without a reference, or no such sequence");
+    REQUIRE(allele < (s->has_variants ? s->num_alleles : 1u), "no such allele");
+    REQUIRE(frag_length <= (1u << 20) && cap >= frag_length, "room for fewer bases than asked for (at most 2^20 per call)");
+    const uint32_t L = s->seq_len[seq];
+    REQUIRE(reversed ? start_pos <= L : start_pos < L || 0 == frag_length, "start position outside the sequence");
+    if (2 != s->variants_mode)                                      // alleles as long as the reference (with coordinate maps the kernel checks against the allele's length)
+        REQUIRE(reversed ? frag_length <= start_pos : frag_length <= L - start_pos, "the stretch asked for leaves the sequence");
+    if (first_variant_pos) {
+        REQUIRE(2 == s->variants_mode, "a start inside inserted bases needs variants with insertions");
+        const uint32_t n_var = s->var_ptr[seq + 1] - s->var_ptr[seq];
+        REQUIRE(first_variant_id >= 0 && (uint32_t)first_variant_id < n_var && first_variant_pos <= s->variants[s->var_ptr[seq] + first_variant_id].len,
+                "first_variant does not name bases of a variant of this sequence");
+    }
+    if (!frag_length) return RSQ_OK;
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        const uint32_t words = (frag_length + 31u) / 32u;
+        uint64_t *dev = nullptr;
+        HIP_CHECK(hipMalloc(&dev, (size_t)(words + 1u) * sizeof(uint64_t)));
+        std::vector<uint64_t> host(words + 1u, 0);
+        hipError_t e = hipMemset(dev, 0, (size_t)(words + 1u) * sizeof(uint64_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_reference_sequence, dim3(1), dim3(64), 0, nullptr, s->dev, seq, allele, start_pos, VarStart{first_variant_id, first_variant_pos}, frag_length, reversed != 0,
+                               dev, words, reinterpret_cast<uint32_t *>(dev + words));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(host.data(), dev, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        (void)hipFree(dev);
+        HIP_CHECK(e);
+        if (host[words]) {
+            g_last_error = "the stretch asked for leaves the allele's sequence";
+            return RSQ_EINVAL;
+        }
+        for (uint32_t k = 0; k < frag_length; ++k) out[k] = (uint8_t)((host[k >> 5] >> ((k & 31u) * 2u)) & 3u);
+        return RSQ_OK;
+    });
+}
 int rsq_sim_export_reference(rsq_sim *s, const char *path) {
     REQUIRE(s && path, "null argument");
     return guard([&] {

@@ -251,6 +251,54 @@ ka["variation_in_simulate_from_given_block"] = {
     ],
 }
 
+# reseq/ReferenceTest.cpp:283-326 TestLoadingAndAccess: Reference::ReferenceSequence with variants on sequence 0 of test/reference-test.fa
+# variants: [position, var_seq, allele bits]; calls: [start_pos, frag_length, reversed, first_variant id, position inside it, allele, expected]
+ka["reference_sequence_with_variants"] = {
+    "seq": 0,
+    "plain": [[0, 10, False, "AGCTTTTCAT"], [500, 10, True, "ATGGTTTTTT"]],             # ReferenceTest.cpp:277-282 (no variants)
+    "variants": [[2, "", 2], [4, "TAG", 3], [9, "C", 1]],
+    "calls": [
+        [0, 12, False, 0, 0, 0, "AGCTTAGTTCAC"],
+        [0, 11, False, 0, 0, 1, "AGTTAGTTCAT"],
+        [4, 8, False, 1, 0, 1, "TAGTTCAT"],
+        [4, 7, False, 1, 1, 1, "AGTTCAT"],
+        [4, 6, False, 1, 2, 1, "GTTCAT"],
+        [10, 12, True, 2, 0, 0, "GTGAACTAAGCT"],
+        [10, 11, True, 2, 0, 1, "ATGAACTAACT"],
+        [5, 7, True, 1, 0, 0, "CTAAGCT"],
+        [5, 6, True, 1, 2, 0, "TAAGCT"],
+        [5, 5, True, 1, 1, 0, "AAGCT"],
+    ],
+    "added_variant": [499, "TAG", 3],                                                       # :309
+    "calls_with_added_variant": [
+        [500, 12, True, 3, 0, 0, "CTATGGTTTTTT"],
+        # :313-325 "fragment length is shorter than variant length"
+        [4, 1, False, 1, 0, 1, "T"], [4, 1, False, 1, 1, 1, "A"], [4, 1, False, 1, 2, 1, "G"],
+        [5, 1, True, 1, 0, 0, "C"], [5, 1, True, 1, 2, 0, "T"], [5, 1, True, 1, 1, 0, "A"],
+    ],
+    # the same four variants as a VCF on reference-test.fa (the product reads variants from files only): 1-based POS, the deletion with its anchor base
+    "vcf_records": [["NC_000913.3_1-500", 2, "GC", "G", "0|1"], ["NC_000913.3_1-500", 5, "T", "TAG", "1|1"], ["NC_000913.3_1-500", 10, "T", "C", "1|0"],
+                    ["NC_000913.3_1-500", 500, "T", "TAG", "1|1"]],
+}
+
+# reseq/ReferenceTest.cpp:271-272,328-329: ReferenceId / ReferenceIdFirstPart of test/reference-test.fa (the first part goes into every read id, Simulator.cpp:596-632)
+ka["reference_ids"] = {"full": ["NC_000913.3_1-500 bla", "NC_000913.3_10000-10500 blub"], "first_part": ["NC_000913.3_1-500", "NC_000913.3_10000-10500"],
+                       "lengths": [500, 501]}
+
+# reseq/ReferenceTest.cpp:263-266: every base of test/reference-special-chars.fa (IUPAC codes) loads as N
+ka["reference_special_chars"] = {"file": "reference-special-chars.fa", "n_bases": 11, "all": "N"}
+
+# reseq/FragmentDistributionStatsTest.cpp:1020-1048 UpdateRefSeqBias on test/reference-test.fa (two sequences) and test/ref-bias-test.txt
+ka["update_ref_seq_bias"] = {
+    "file": "ref-bias-test.txt",
+    "cases": [   # [mode, stored bias before the call, expected]
+        ["keep", [0.5], [1.0, 1.0]],             # a stored vector of the wrong size: keep falls back to no bias
+        ["keep", [0.25, 0.5], [0.25, 0.5]],
+        ["no", [0.5], [1.0, 1.0]],
+        ["file", [0.5], [2.0, 1.0]],
+    ],
+}
+
 with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
     json.dump(ka, f, indent=1)
 print("wrote", len(ka), "groups")

@@ -1,6 +1,7 @@
 """The C-ABI library loads, exports every symbol include/reseq_amd.h declares, its host-only entry points work
 without a GPU, and the simulation entry points fail loudly (no CPU fallback) when no device is visible."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -246,3 +247,48 @@ def test_query_profile_cli_mode(workdir, tiny_profile_path):
     assert r.returncode == 0 and out.exists() and (workdir / "written.reseq.ipf").exists(), r.stderr
     r = subprocess.run([exe, "queryProfile", "-s", str(out), "--maxReadLength", "--maxLenDeletion"], capture_output=True, text=True)
     assert r.returncode == 0 and "maxReadLength: 30" in r.stdout and "maxLenDeletion: " in r.stdout
+
+
+def test_the_references_own_fixtures_load(workdir):
+    """The reference's test data as it lies in its test/ directory (byte-identical copies under tests/golden/): reference-test.fa.gz and .bz2 written by the reference's
+    authors load like the plain file (ReferenceTest GZip / BZip2), every IUPAC code of reference-special-chars.fa loads as N (ReferenceTest.cpp:263-266), and
+    rsq_ref_sequence_name returns ReferenceIdFirstPart (ReferenceTest.cpp:328-329) -- the string that goes into every read id."""
+    ka = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))
+    plain = api.Reference(os.path.join(GOLDEN, "reference-test.fa"))
+    assert [plain.sequence_name(i) for i in range(2)] == ka["reference_ids"]["first_part"]
+    assert [plain.sequence_length(i) for i in range(2)] == ka["reference_ids"]["lengths"]
+    import bz2
+    import gzip
+    for packed, opener in (("reference-test.fa.gz", gzip.open), ("reference-test.fa.bz2", bz2.open)):
+        r = api.Reference(os.path.join(GOLDEN, packed))
+        with opener(os.path.join(GOLDEN, packed), "rb") as f:           # the packed fixtures name their sequences "NC_000913.3:1-500 ...", the plain one "NC_000913.3_1-500 ..."
+            names = [line[1:].split()[0].decode() for line in f if line.startswith(b">")]
+        assert r.num_sequences() == 2 and [r.sequence_name(i) for i in range(2)] == names and names[0].startswith("NC_000913.3")
+        for i in range(2):
+            assert np.array_equal(plain.codes(i), r.codes(i)), (packed, i)
+        r.close()
+    plain.close()
+    g = ka["reference_special_chars"]
+    special = api.Reference(os.path.join(GOLDEN, g["file"]))
+    assert special.num_sequences() == 1 and special.sequence_length(0) == g["n_bases"] and (special.codes(0) == 4).all()
+    special.close()
+
+
+def test_variants_of_the_reference_sequence_known_answers(workdir):
+    """the VCF that encodes the variants of ReferenceTest.cpp:283-326 (a deletion with its anchor base, two insertions, a substitution, on two alleles) loads as exactly
+    the Reference::Variant list the test builds by hand; the templates themselves are checked on the device (tests/test_parity_gpu.py)"""
+    ka = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))["reference_sequence_with_variants"]
+    vcf = workdir / "reference_sequence_known_answers.vcf"
+    write_known_answer_vcf(vcf, ka)
+    r = api.Reference(os.path.join(GOLDEN, "reference-test.fa"))
+    assert r.read_variants(vcf) == 2
+    assert r.variants(0) == [tuple(v) for v in ka["variants"] + [ka["added_variant"]]] and r.variants(1) == []
+    r.close()
+
+
+def write_known_answer_vcf(path, ka):
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=NC_000913.3_1-500,length=500>", "##contig=<ID=NC_000913.3_10000-10500,length=501>",
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">', "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample"]
+    lines += [f"{chrom}\t{pos}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT\t{gt}" for chrom, pos, ref, alt, gt in ka["vcf_records"]]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")

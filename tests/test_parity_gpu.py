@@ -790,3 +790,83 @@ def test_cli_with_variants_equals_the_oracle(workdir):
         assert open(a1, "rb").read() == o1 + ao1 and open(a2, "rb").read() == o2 + ao2
     finally:
         p.close()
+
+
+# ------------------------------------------------------------------------------------------------------- the reference's own known answers through the C ABI
+def test_reference_sequence_known_answers_on_the_device(workdir, tiny_profile_path):
+    """ReferenceTest.cpp:277-326 through rsq_sim_reference_sequence: the templates the KERNELS compute (allele_template on the allele's coordinate map, the function
+    k_variant_templates runs per mate) for the 17 calls of the reference's test -- both alleles, forward and reversed, starts inside inserted bases, fragments shorter
+    than the variant they start in -- from a VCF that encodes the test's hand-built variants; and the two calls without variants"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from reseq_amd import api
+    from test_abi import write_known_answer_vcf
+    ka = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))["reference_sequence_with_variants"]
+    prof = api.Profile(tiny_profile_path)
+    fasta = os.path.join(GOLDEN, "reference-test.fa")
+    # without variants
+    ref = api.Reference(fasta, 0)
+    sim = api.Simulator(prof, ref, 0)
+    for start, length, reversed_, want in ka["plain"]:
+        assert sim.reference_sequence(ka["seq"], start, length, reversed_) == want
+    with pytest.raises(api.RsqError):
+        sim.reference_sequence(ka["seq"], 495, 10)                     # leaves the sequence
+    sim.close()
+    ref.close()
+    # with the variants of the test; the fourth variant (position 499) lies behind everything the first ten calls read, so one simulator serves all 17
+    vcf = workdir / "reference_sequence_known_answers.vcf"
+    write_known_answer_vcf(vcf, ka)
+    ref = api.Reference(fasta, 0)
+    assert ref.read_variants(vcf) == 2
+    sim = api.Simulator(prof, ref, 0)
+    n = 0
+    for start, length, reversed_, vid, vpos, allele, want in ka["calls"] + ka["calls_with_added_variant"]:
+        assert sim.reference_sequence(ka["seq"], start, length, reversed_, (vid, vpos), allele) == want, (start, length, reversed_, vid, vpos, allele)
+        n += 1
+    assert n == 17
+    assert sim.reference_sequence(1, 0, 12, False, (0, 0), 1) == "GATTGCGCTGGC"        # the sequence without variants, on an allele
+    with pytest.raises(api.RsqError):
+        sim.reference_sequence(0, 0, 10, False, (0, 0), 2)             # no such allele
+    with pytest.raises(api.RsqError):
+        sim.reference_sequence(0, 4, 3, False, (1, 4), 1)              # variant 1 has three bases
+    sim.close()
+    ref.close()
+    # a substitution-only set is packed as a copy of the reference per allele (rsq_pack.h variants_mode_for): the other route of the same entry point
+    sub = dict(ka, vcf_records=[r for r in ka["vcf_records"] if len(r[2]) == len(r[3]) == 1])
+    write_known_answer_vcf(workdir / "reference_sequence_substitution.vcf", sub)
+    ref = api.Reference(fasta, 0)
+    ref.read_variants(workdir / "reference_sequence_substitution.vcf")
+    sim = api.Simulator(prof, ref, 0)
+    assert sim.reference_sequence(0, 0, 12, False, (0, 0), 0) == "AGCTTTTCACTC" and sim.reference_sequence(0, 0, 12, False, (0, 0), 1) == "AGCTTTTCATTC"
+    assert sim.reference_sequence(0, 12, 12, True, (0, 0), 0) == "GAGTGAAAAGCT"
+    sim.close()
+    ref.close()
+    prof.close()
+
+
+def test_update_ref_seq_bias_known_answers(workdir):
+    """FragmentDistributionStatsTest.cpp:1020-1048 through rsq_sim_set_ref_bias_file / rsq_sim_prepare / rsq_sim_get_ref_seq_bias, on the reference's own
+    reference-test.fa and ref-bias-test.txt (byte-identical copies): keep falls back to ones when the stored vector has another size, keep keeps, no gives ones,
+    the file gives {2.0, 1.0}"""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from reseq_amd import api, synth
+    g = json.load(open(os.path.join(GOLDEN, "reference_known_answers.json")))["update_ref_seq_bias"]
+    ref = api.Reference(os.path.join(GOLDEN, "reference-test.fa"), 0)
+    for k, (mode, stored, want) in enumerate(g["cases"]):
+        arrays = synth.make_profile(synth.TINY, seed=5, n_ref_seqs=len(stored))
+        arrays["frag.ref_seq_bias"] = np.array(stored, np.float64)
+        path = workdir / f"update_ref_seq_bias_{k}.rsqp"
+        synth.write_profile(path, arrays)
+        prof = api.Profile(path)
+        sim = api.Simulator(prof, ref, 0)
+        if mode == "file":
+            sim.set_ref_bias_file(os.path.join(GOLDEN, g["file"]))
+        sim.prepare(3, 100, 0.0, {"keep": 0, "no": 1, "draw": 2, "file": 3}[mode])
+        assert sim.ref_seq_bias(2).tolist() == want, (mode, stored)
+        sim.close()
+        prof.close()
+    ref.close()
