@@ -38,12 +38,12 @@ const char *rsq_last_error(void);
 const char *rsq_last_warning(void);          /* non-fatal remarks of the last rsq_profile_load* or rsq_sim_create call ("" if none) */
 const char *rsq_version(void);
 /* Testing and measurement switches (reseq_amd/csrc/rsq_host.h `Options`; README "Options").  The library takes no switch from the environment (only the default place of the
- * kernel cache, rsq_set_kernel_cache_dir): an embedding program sets a switch explicitly.  A simulator takes the values current when it is created -- fill_mode,
- * image_tiles, rate_rows, no_indel_skip, force_exact, min_quality_quads, specialize --; the others are read by the call they shape, from the process-wide values:
- * the pre-pass switches (bias_window, window_chunks, chain_chunk, chain_warmup, trace_prepare) when the pre-pass runs, overlap by rsq_sim_pairs, job_chunk_bytes
- * by rsq_sim_job_generate, the loaders' (serial_fasta, fasta_stretch, serial_parse, parse_stretch, trace_load) by the load; mapped_parses is a counter the
- * loaders add to.  Reads and FASTQ bytes never depend on them -- they choose between equivalent routes (e.g. fill_mode 0: every per-base draw in double
- * precision from device memory, the reference's own recipe, ProbabilityEstimates.h:481-508).  RSQ_EINVAL for an unknown name. */
+ * kernel cache, rsq_set_kernel_cache_dir): an embedding program sets a switch explicitly.  A simulator takes a copy of ALL values when it is created (rsq_sim_create)
+ * and reads only that copy afterwards -- several simulators of one process (one per GPU and host thread, see rsq_sim_create) never look at a value another thread
+ * is changing; set the switches before the simulators are created.  The loaders, which have no simulator (rsq_ref_load_fasta, rsq_ref_read_variants,
+ * rsq_sim_read_methylation's parser: serial_fasta, fasta_stretch, serial_parse, parse_stretch, trace_load), read the process-wide values when they run;
+ * mapped_parses is a counter they add to.  Reads and FASTQ bytes never depend on any of them -- they choose between equivalent routes (e.g. fill_mode 0: every
+ * per-base draw in double precision from device memory, the reference's own recipe, ProbabilityEstimates.h:481-508).  RSQ_EINVAL for an unknown name. */
 int rsq_set_option(const char *name, int64_t value);
 int rsq_get_option(const char *name, int64_t *value);
 /* number of visible HIP devices, or RSQ_ENODEV */
@@ -236,6 +236,14 @@ typedef struct {
     uint8_t strand, pad;
     uint32_t block, number;
 } rsq_fragment;   /* with insertion / deletion variants the reference span of a fragment is not [start, start + len): the read ids carry the real end */
+
+/* Which blocks a worker simulates.  Simulator::SimulationThread (reseq/Simulator.cpp:2384-2401) takes blocks one by one from a shared counter; here a worker -- a
+ * host thread with its own simulator and device inside `reseq illuminaPE --gpus N`, or a process of the launcher -- owns a contiguous range, so that the workers'
+ * texts in worker order are the single run's.  rsq_sim_block_weights: expected pairs per block up to a constant (the sequence's reference bias), weights[*n_blocks]
+ * in block order (NULL: only the count), after rsq_sim_prepare.  rsq_partition_blocks: bounds[workers + 1], worker r gets blocks [bounds[r], bounds[r + 1]) of
+ * 1 .. total_blocks, balanced by the weights; a worker may get an empty range. */
+int rsq_sim_block_weights(const rsq_sim *s, double *weights, size_t cap, uint32_t *n_blocks);
+int rsq_partition_blocks(uint32_t total_blocks, uint32_t workers, const double *weights, uint32_t *bounds);
 
 /* A rank's share of a job, generated once and kept (Simulator::Simulate's worker loop + Output/Flush, Simulator.cpp:2384-2401, 150-230, for one of N processes).
  * rsq_sim_job_generate simulates the blocks [block_lo, block_hi) in calls of `batch_blocks` blocks (0: about 12 M pairs per call) and keeps the FASTQ text of the

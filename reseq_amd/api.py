@@ -80,6 +80,8 @@ SYMBOLS = {
     "rsq_sim_get_fill_plan": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "rsq_sim_specialize": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "rsq_sim_export_reference": (C.c_int, [_vp, C.c_char_p]),
+    "rsq_sim_block_weights": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32)]),
+    "rsq_partition_blocks": (C.c_int, [_u32, _u32, _vp, _vp]),
     "rsq_sim_reference_sequence": (C.c_int, [_vp, _u32, _u32, _u32, C.c_int, C.c_int32, _u32, _u32, _vp, _sz]),
     "rsq_sim_job_read": (C.c_int, [_vp, C.c_int, _u64, _sz, _vp, _vp]),
     "rsq_dev_pwrite": (C.c_int, [C.c_int, _vp, _sz, C.c_char_p, _u64]),
@@ -170,6 +172,16 @@ def archive_layout(stats_path, ipf_path=None):
     buf = C.create_string_buffer(need.value)
     _check(lib().rsq_profile_archive_layout(str(stats_path).encode(), ipf, buf, need.value, C.byref(need)))
     return buf.value.decode(errors="replace")
+
+
+def partition_blocks(total_blocks, workers, weights=None):
+    """rsq_partition_blocks: [(lo, hi)] per worker -- the library's statement of sharding.partition_blocks (what `reseq illuminaPE --gpus N` uses)"""
+    w = np.ascontiguousarray(np.ones(total_blocks) if weights is None else weights, dtype=np.float64)
+    if w.size != total_blocks:
+        raise ValueError("one weight per block")
+    bounds = np.zeros(workers + 1, np.uint32)
+    _check(lib().rsq_partition_blocks(total_blocks, workers, w.ctypes.data, bounds.ctypes.data))
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(workers)]
 
 
 def dev_pwrite(device, src_ptr, nbytes, path, offset):
@@ -407,6 +419,13 @@ class Simulator:
         out = np.zeros(n.value, np.uint32)
         _check(lib().rsq_sim_get_sequence_lengths(self.h, out.ctypes.data, out.size, C.byref(n)))
         return [int(x) for x in out]
+
+    def block_weights(self):
+        n = _u32(0)
+        _check(lib().rsq_sim_block_weights(self.h, None, 0, C.byref(n)))
+        w = np.zeros(n.value, np.float64)
+        _check(lib().rsq_sim_block_weights(self.h, w.ctypes.data, w.size, C.byref(n)))
+        return w
 
     def reference_sequence(self, seq, start_pos, frag_length, reversed=False, first_variant=(0, 0), allele=0):
         """Reference::ReferenceSequence (with variants: of one allele, from inside inserted bases when first_variant[1] > 0) as letters"""

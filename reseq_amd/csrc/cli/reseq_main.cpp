@@ -215,17 +215,18 @@ struct StageTrace {
 struct DevBuffer {
     void *p = nullptr;
     size_t cap = 0;
+    int device = 0;
     bool ensure(size_t n) {
         if (n <= cap) return true;
-        if (p) rsq_dev_free(0, p);
+        if (p) rsq_dev_free(device, p);
         p = nullptr;
         cap = 0;
-        if (!check(rsq_dev_alloc(0, n, &p), "device allocation")) return false;
+        if (!check(rsq_dev_alloc(device, n, &p), "device allocation")) return false;
         cap = n;
         return true;
     }
     ~DevBuffer() {
-        if (p) rsq_dev_free(0, p);
+        if (p) rsq_dev_free(device, p);
     }
 };
 
@@ -319,6 +320,173 @@ bool flush_pair(DevBuffer &d1, size_t l1, DevBuffer &d2, size_t l2, AsyncOut &f1
     return f1.good() && f2.good();
 }
 
+// illuminaPE on several devices inside one process (Simulator::Simulate starts its own worker threads, Simulator.cpp:2830-2836, and hands them blocks, :2384-2401).
+// N host threads, one simulator each on device (worker % devices): every worker prepares, simulates its contiguous share of the blocks with the text kept in device
+// memory (rsq_sim_job_generate), the exclusive scan of the workers' text sizes gives every worker its place in the two files, and all workers write at once
+// (rsq_sim_job_write).  No process group, no collective, no Python: the workers share nothing but the loaded profile and reference.  The files are byte for byte
+// the single-device run's.
+struct PeJob {
+    const Args &a;
+    rsq_profile *prof;
+    rsq_ref *ref;
+    uint64_t seed, num_reads;
+    double coverage;
+    int ref_bias_mode;
+    std::string ref_bias_file, sys_read, sys_write, methylation, out1, out2, base_identifier;
+};
+struct Worker {
+    int device = 0;
+    rsq_sim *sim = nullptr;
+    uint32_t lo = 1, hi = 1;
+    uint64_t pairs = 0, bytes[2] = {0, 0};
+    std::string error;                                     // rsq_last_error() is the calling thread's own: taken where the call failed
+    bool fail(int rc, const char *what) {
+        if (rc == RSQ_OK) return false;
+        error = std::string(what) + ": " + rsq_last_error();
+        return true;
+    }
+};
+// runs f(worker index) on one thread per worker and waits for all; false if any worker reported an error (the first one is printed)
+template <class F>
+bool on_all_workers(std::vector<Worker> &workers, F &&f) {
+    std::vector<std::thread> threads;
+    for (size_t r = 1; r < workers.size(); ++r) threads.emplace_back([&, r] { f(r); });
+    f(0);
+    for (std::thread &t : threads) t.join();
+    for (size_t r = 0; r < workers.size(); ++r)
+        if (!workers[r].error.empty()) {
+            ERR("worker " << r << " (device " << workers[r].device << "): " << workers[r].error);
+            return false;
+        }
+    return true;
+}
+int illumina_pe_on_workers(const PeJob &job, int n_workers, int n_devices) {
+    std::vector<Worker> workers((size_t)n_workers);
+    for (int r = 0; r < n_workers; ++r) workers[(size_t)r].device = r % n_devices;
+    INFO("Simulating with " << n_workers << " workers on " << std::min(n_workers, n_devices) << " device(s)");
+    const bool gz = rsq::textio::has_suffix(job.out1, ".gz");
+    auto release = [&] {
+        for (Worker &w : workers) rsq_sim_free(w.sim);
+    };
+    // every worker: its simulator on its device
+    bool ok = on_all_workers(workers, [&](size_t r) {
+        Worker &w = workers[r];
+        if (w.fail(rsq_sim_create(job.prof, job.ref, w.device, &w.sim), "Could not set up the simulator")) return;
+        if (!job.ref_bias_file.empty() && w.fail(rsq_sim_set_ref_bias_file(w.sim, job.ref_bias_file.c_str()), "refBiasFile")) return;
+        if (!job.methylation.empty() && w.fail(rsq_sim_read_methylation(w.sim, job.methylation.c_str()), "Could not read methylation file")) return;
+    });
+    std::string sys_read = job.sys_read;
+    if (ok && !job.sys_write.empty()) {                       // main.cpp:351-397: one worker draws and writes the profile, all read it
+        INFO("Writing systematic error profile to " << job.sys_write);
+        ok = check(rsq_sim_create_sys_error_profile(workers[0].sim, job.seed, job.sys_write.c_str(), nullptr), "Could not write systematic error profile");
+        if (!ok) remove(job.sys_write.c_str());
+        sys_read = job.sys_write;
+    }
+    if (ok && job.a.has("stopAfterEstimation")) {
+        release();
+        return 0;
+    }
+    if (ok) {
+        INFO("Preparing for simulation");
+        ok = on_all_workers(workers, [&](size_t r) {
+            Worker &w = workers[r];
+            if (w.fail(rsq_sim_prepare(w.sim, job.seed, job.num_reads, job.coverage, job.ref_bias_mode, job.base_identifier.c_str(), nullptr), "Preparation failed")) return;
+            if (!sys_read.empty()) w.fail(rsq_sim_read_sys_errors(w.sim, sys_read.c_str()), "Could not read systematic error profile");
+        });
+    }
+    rsq_sim_info info;
+    if (ok) {                                                 // the workers' block ranges: the rule of the N-process launcher (rsq_partition_blocks)
+        rsq_sim_get_info(workers[0].sim, &info);
+        INFO("Aiming for " << info.total_pairs + info.adapter_only_pairs << " read pairs");
+        uint32_t n_blocks = 0;
+        ok = check(rsq_sim_block_weights(workers[0].sim, nullptr, 0, &n_blocks), "block weights");
+        std::vector<double> weights(n_blocks);
+        std::vector<uint32_t> bounds((size_t)n_workers + 1);
+        ok = ok && check(rsq_sim_block_weights(workers[0].sim, weights.data(), weights.size(), &n_blocks), "block weights") &&
+             check(rsq_partition_blocks(n_blocks, (uint32_t)n_workers, weights.data(), bounds.data()), "partition");
+        for (int r = 0; ok && r < n_workers; ++r) {
+            workers[(size_t)r].lo = bounds[(size_t)r];
+            workers[(size_t)r].hi = bounds[(size_t)r + 1];
+        }
+    }
+    if (ok) {
+        INFO("Starting read generation");
+        ok = on_all_workers(workers, [&](size_t r) {
+            Worker &w = workers[r];
+            if (w.fail(rsq_sim_job_generate(w.sim, w.lo, w.hi, 0, &w.pairs, &w.bytes[0], &w.bytes[1], nullptr), "Simulation failed")) return;
+            if (gz && w.bytes[0] + w.bytes[1]) w.fail(rsq_sim_job_compress(w.sim, &w.bytes[0], &w.bytes[1]), "Compressing the output failed");
+        });
+    }
+    uint64_t end[2] = {0, 0}, pairs = 0;
+    if (ok) {                                                 // the files at the size of the workers' text, then all workers write their byte ranges at once
+        for (const Worker &w : workers) {
+            end[0] += w.bytes[0];
+            end[1] += w.bytes[1];
+            pairs += w.pairs;
+        }
+        INFO("Generated " << pairs << " read pairs (" << (info.total_pairs ? (pairs * 100 + info.total_pairs / 2) / info.total_pairs : 0) << "%).");
+        for (int f = 0; ok && f < 2; ++f) {
+            const std::string &path = f ? job.out2 : job.out1;
+            const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0 || ftruncate(fd, (off_t)end[f]) != 0) {
+                ERR("Could not open '" << path << "' for writing.");
+                ok = false;
+            }
+            if (fd >= 0) ::close(fd);
+        }
+    }
+    if (ok) {
+        std::vector<uint64_t> at0(workers.size()), at1(workers.size());
+        uint64_t o0 = 0, o1 = 0;
+        for (size_t r = 0; r < workers.size(); ++r) {
+            at0[r] = o0;
+            at1[r] = o1;
+            o0 += workers[r].bytes[0];
+            o1 += workers[r].bytes[1];
+        }
+        ok = on_all_workers(workers, [&](size_t r) {
+            Worker &w = workers[r];
+            if (w.bytes[0] + w.bytes[1] && w.fail(rsq_sim_job_write(w.sim, job.out1.c_str(), at0[r], job.out2.c_str(), at1[r], 0), "Writing the output failed")) return;
+            rsq_sim_job_free(w.sim);
+        });
+    }
+    if (ok && info.adapter_only_pairs) {                      // Simulator.cpp:2359-2382, behind everything else; the first worker's simulator
+        Worker &w = workers[0];
+        DevBuffer d1, d2, g1, g2;
+        d1.device = d2.device = g1.device = g2.device = w.device;
+        for (uint64_t first = 0; ok && first < info.adapter_only_pairs; first += 100000) {
+            const uint64_t n = std::min<uint64_t>(100000, info.adapter_only_pairs - first);
+            size_t len[2] = {0, 0};
+            int rc = rsq_sim_adapter_only_pairs(w.sim, first, n, (char *)d1.p, d1.cap, &len[0], (char *)d2.p, d2.cap, &len[1], nullptr);
+            if (rc == RSQ_ENOSPC) {
+                ok = d1.ensure(len[0] + 4096) && d2.ensure(len[1] + 4096);
+                if (ok) rc = rsq_sim_adapter_only_pairs(w.sim, first, n, (char *)d1.p, d1.cap, &len[0], (char *)d2.p, d2.cap, &len[1], nullptr);
+            }
+            ok = ok && check(rc, "Simulation of adapter-only pairs failed");
+            for (int f = 0; ok && f < 2; ++f) {
+                DevBuffer &text = f ? d2 : d1, &packed = f ? g2 : g1;
+                const void *src = text.p;
+                size_t bytes = len[f];
+                if (gz && bytes) {
+                    ok = packed.ensure(rsq_gzip_bound(bytes)) && check(rsq_sim_gzip_device(w.sim, (const char *)text.p, bytes, (char *)packed.p, packed.cap, &bytes, nullptr), "Compressing the output failed");
+                    src = packed.p;
+                }
+                if (ok && bytes) ok = check(rsq_dev_pwrite(w.device, src, bytes, (f ? job.out2 : job.out1).c_str(), end[f]), "Writing the output failed");
+                end[f] += bytes;
+            }
+        }
+    }
+    release();
+    if (!ok) {                                               // Simulator.cpp:2888-2892: do not leave partial output behind
+        ERR("An error occurred in the process: Terminating simulation");
+        remove(job.out1.c_str());
+        remove(job.out2.c_str());
+        return 1;
+    }
+    INFO("Simulation finished succesfully");
+    return 0;
+}
+
 int illumina_pe(const Args &a) {
     const std::string vcf_path = a.get("vcfSim", "");               // -V: per-allele simulation (substitutions; the library refuses what it cannot simulate yet)
     // main.cpp:862-908: --refBias keep|no|draw|file, --refBiasFile implies file; keep is the default
@@ -371,6 +539,47 @@ int illumina_pe(const Args &a) {
     if (ok && !vcf_path.empty()) {
         INFO("Reading variants from " << vcf_path);
         ok = check(rsq_ref_read_variants(ref, vcf_path.c_str()), "Could not read the variant file");
+    }
+    // --gpus N: N workers inside this process, worker r on device r % devices (more workers than devices share them).  The reference's -j / --threads asks for
+    // worker threads of the simulation (main.cpp:436, Simulator.cpp:2830-2836): without --gpus it asks for as many workers as there are devices to give each its own.
+    int n_workers = 1, n_devices = 1;
+    if (ok && (a.has("gpus") || a.has("threads"))) {
+        uint64_t asked = 0;
+        ok = parse_u64(a, a.has("gpus") ? "gpus" : "threads", asked);
+        n_devices = ok ? rsq_device_count() : 1;
+        if (ok && n_devices < 1) ok = check(n_devices, "No device");
+        if (ok && a.has("gpus") && (asked < 1 || asked > 1024)) {
+            ERR("gpus must be between 1 and 1024.");
+            ok = false;
+        }
+        if (ok) n_workers = a.has("gpus") ? (int)asked : (int)std::min<uint64_t>(std::max<uint64_t>(asked, 1), (uint64_t)n_devices);
+    }
+    if (ok && n_workers > 1) {
+        const bool gz = rsq::textio::has_suffix(out1, ".gz");
+        uint64_t num_reads = 0;
+        double coverage = 0.0;
+        if (a.has("numReads") && a.has("coverage")) {               // main.cpp:783-786
+            ERR("numReads and coverage option are mutually exclusive. Specify the one or the other.");
+            ok = false;
+        }
+        if (ok && gz != rsq::textio::has_suffix(out2, ".gz")) {
+            ERR("with more than one worker the two output files are either both plain or both .gz");
+            ok = false;
+        }
+        if (ok && (rsq::textio::has_suffix(out1, ".bz2") || rsq::textio::has_suffix(out2, ".bz2"))) {
+            ERR("bzip2 output is written by one worker only (write .gz or plain FASTQ with --gpus)");
+            ok = false;
+        }
+        if (ok && a.has("numReads")) ok = parse_u64(a, "numReads", num_reads);
+        if (ok && a.has("coverage")) ok = parse_double(a, "coverage", coverage);
+        int rc = 1;
+        if (ok) {
+            const PeJob job{a, prof, ref, seed, num_reads, coverage, ref_bias_mode, ref_bias_file, sys_read, sys_write, a.get("methylation", ""), out1, out2, a.get("recordBaseIdentifier", "ReseqRead")};
+            rc = illumina_pe_on_workers(job, n_workers, n_devices);
+        }
+        rsq_ref_free(ref);
+        rsq_profile_free(prof);
+        return rc;
     }
     ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
     trace.at("simulator created");
@@ -545,7 +754,9 @@ const char *kUsage =
     "  seqToIllumina\t\tapplies illumina quality and error model to input sequences (alias: replaceQuals)\n"
     "                 \t-i in.fa[.gz|.bz2] (stdin) -o out.fq[.gz|.bz2] (stdout) -s profile; --readThreads N, --traceStages;\n"
     "                 \t--inputFrom / --inputTo BYTE, --firstRecord K: a share of a plain input (python -m reseq_amd.simulate seqToIllumina works them out)\n"
-    "General: -j/--threads N (ignored: the GPU does the work), --verbosity 0-4, --version, -h, --traceStages,\n"
+    "                 \t--gpus N: N workers in this process, worker r on device r % devices, the files byte for byte the single-device run's\n"
+    "General: -j/--threads N (illuminaPE: as many workers as asked for, at most one per device; else ignored: the GPU does the work),\n"
+    "         --verbosity 0-4, --version, -h, --traceStages,\n"
     "         --rsqOption name:value[,...] (measurement switches of libreseq_amd, include/reseq_amd.h rsq_set_option; results never depend on them)\n";
 
 }  // namespace

@@ -18,7 +18,7 @@ struct Error : std::runtime_error {
 // ------------------------------------------------------------------------------------------------ options
 // Testing and measurement switches of the library (C ABI rsq_set_option / rsq_get_option): explicit calls of the embedding program, never
 // read from the environment.  Results (reads, FASTQ bytes) do not depend on any of them; they choose between equivalent routes.  A simulator
-// takes the values current when it is created (rsq_sim_create) or, for the pre-pass switches, when the pre-pass runs.
+// takes a copy of all values when it is created (rsq_sim_create; SimState::opt) and reads only the copy; the loaders read the process-wide values.
 struct Options {
     int64_t fill_mode = -1;            // -1: screened draws on the LDS image when the plan has one; 0: every draw of the read kernels in double precision from HBM
     int64_t image_tiles = 0;           // 0: the image holds all tiles when they fit, else one tile per workgroup; 1: one tile per workgroup even when all fit

@@ -57,6 +57,7 @@ struct ScopedUpload {                               // puts inside the block bel
 };
 
 struct SimState {
+    Options opt = options();                         // the switches as they stood when the simulator was created: later rsq_set_option calls shape later simulators
     Profile prof;
     bool has_ref = false;
     std::vector<std::string> ref_first_names, ref_ids;   // ReferenceIdFirstPart / ReferenceId
@@ -305,7 +306,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
         for (const DevTable &d : tabs)
             for (uint32_t c = 0; c < slot; ++c) par0.push_back(c < d.k ? par0[d.par0_off + c] : (uint8_t)0);
     };
-    const Options &opt = options();
+    const Options &opt = s.opt;
     const uint32_t min_quads = opt.min_quality_quads > 0 ? (uint32_t)opt.min_quality_quads : 0u;     // measurements: a wider instantiation than the profile needs
     for (uint32_t q : kQualityQuads)
         if (!plan.quads_q && q >= min_quads && quads_of(kmax_of(quality)) <= q) plan.quads_q = q;
@@ -1309,14 +1310,14 @@ constexpr const char *kWalkErrorMessage =
 // run-up is half a chunk, at most 384 positions (three times the distance within which two runs were measured to meet; on the human-sized reference, chunk
 // length : run-up -> seconds of the chains: 1024:384 1.38, 2048:384 1.19, 2048:768 1.34, 4096:384 1.10, 4096:768 1.17, 4096:1536 1.33, 8192:768 1.14, 16384:1024 1.16; 256:0 was
 // 1.86).  Ranks of a sharded job derive the same values from the same reference.  Options chain_chunk / chain_warmup override them (tests, measurements).
-inline uint32_t chain_chunk_len(uint64_t total_ref_size) {
-    if (options().chain_chunk > 0) return (uint32_t)options().chain_chunk;
+inline uint32_t chain_chunk_len(uint64_t total_ref_size, const Options &opt) {
+    if (opt.chain_chunk > 0) return (uint32_t)opt.chain_chunk;
     uint32_t len = 256;
     while (len < 4096 && 2 * total_ref_size / len > (2u << 20)) len *= 2;
     return len;
 }
-inline uint32_t chain_warmup_len(uint32_t chunk_len) {
-    if (options().chain_warmup >= 0) return (uint32_t)options().chain_warmup;
+inline uint32_t chain_warmup_len(uint32_t chunk_len, const Options &opt) {
+    if (opt.chain_warmup >= 0) return (uint32_t)opt.chain_warmup;
     return std::min(chunk_len / 2, 384u);
 }
 // kChainsAdapters: SimulateErrorModelOnly (Simulator.cpp:2951-2977); kChainsSimulation: Simulate (adapters, then every sequence that
@@ -1448,18 +1449,18 @@ inline void build_chains(const SimState &s, ChainSet set, std::vector<Chain> &ch
 // kWindowChunks chunks, each entered with the state the fixed point left in front of its first chunk (entering_state(flat chunk index)),
 // so that the host pass over the variants has many independent tasks.
 constexpr uint32_t kWindowChunks = 32768;                          // 8.4 M positions
-inline uint32_t window_chunks() {                                  // option window_chunks: smaller windows, so that tests on short sequences cut strands too
-    const int64_t v = options().window_chunks;
+inline uint32_t window_chunks(const Options &opt) {                // option window_chunks: smaller windows, so that tests on short sequences cut strands too
+    const int64_t v = opt.window_chunks;
     return v > 0 ? (uint32_t)v : kWindowChunks;
 }
 template <class EnteringState>
-inline std::vector<StrandTask> strand_tasks(const std::vector<Chain> &chains, uint32_t n_chunks, uint32_t chunk_len, EnteringState &&entering_state) {
+inline std::vector<StrandTask> strand_tasks(const Options &opt, const std::vector<Chain> &chains, uint32_t n_chunks, uint32_t chunk_len, EnteringState &&entering_state) {
     std::vector<StrandTask> out;
     for (size_t c = 0; c < chains.size(); ++c) {
         const Chain &ch = chains[c];
         if (ch.kind > 1u) continue;
         const uint32_t chunks = (c + 1 < chains.size() ? chains[c + 1].first_chunk : n_chunks) - ch.first_chunk;
-        const uint32_t per_window = window_chunks();
+        const uint32_t per_window = window_chunks(opt);
         for (uint32_t first = 0; first < chunks; first += per_window) {
             const uint32_t count = std::min(per_window, chunks - first);
             const uint32_t lo = (ch.chunk_lo + first) * chunk_len, hi = (uint32_t)std::min<uint64_t>(ch.len, (uint64_t)(ch.chunk_lo + first + count) * chunk_len);

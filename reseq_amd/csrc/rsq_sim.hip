@@ -257,7 +257,7 @@ static hipFunction_t spec_kernel(rsq_sim &s, SpecKind kind, uint32_t mask, bool 
     if (!s.specialize || mask == 0) return nullptr;                    // mask 0: no image, no plan to compile in
     std::string note;
     hipFunction_t fn = s.spec.get(s.dev, SpecVariant{kind, mask, var, binned}, s.arch, note);
-    if (options().trace_plan && note != g_spec_note) fprintf(stderr, "[rsq] %s\n", note.c_str());
+    if (s.opt.trace_plan && note != g_spec_note) fprintf(stderr, "[rsq] %s\n", note.c_str());
     g_spec_note = note;
     return fn;
 }
@@ -285,7 +285,7 @@ static void iterate_sys_chains(rsq_sim &s, rsq_sim::ChainRun &run, hipStream_t s
         }
         if (n_run) {
             hipLaunchKernelGGL(k_sys_chain, dim3(cdiv(n_run, 64)), dim3(64), 0, st, s.dev, run.d_chains.as<Chain>(), run.d_chunk_chain.as<uint32_t>(), list, n_run, s.chain_chunk,
-                               chain_warmup_len(s.chain_chunk), run.d_used.as<uint32_t>(), out_prev, out_new, (int)pass);
+                               chain_warmup_len(s.chain_chunk, s.opt), run.d_used.as<uint32_t>(), out_prev, out_new, (int)pass);
             HIP_CHECK(hipGetLastError());
         }
         if (pass > 0 && !n_run) break;
@@ -315,7 +315,7 @@ static void variant_sys_errors_from_run(rsq_sim &s, hipStream_t st) {
     std::vector<uint32_t> states((size_t)n_variants * 2);
     HIP_CHECK(hipMemcpyAsync(states.data(), d_states.as<uint32_t>(), states.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const std::vector<StrandTask> windows = strand_tasks(run.chains, run.n_chunks, s.chain_chunk, [](uint32_t) { return 0u; });      // the windows' entering states are not needed
+    const std::vector<StrandTask> windows = strand_tasks(s.opt, run.chains, run.n_chunks, s.chain_chunk, [](uint32_t) { return 0u; });      // the windows' entering states are not needed
     build_variant_sys_errors(s, s.up, &windows, states.data(), states.data() + n_variants);
 }
 static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const ShardRange *range = nullptr) {
@@ -324,7 +324,7 @@ static uint32_t run_sys_chains(rsq_sim &s, hipStream_t st, ChainSet set, const S
     run.chains.clear();
     run.edges = ShardEdges{};
     std::vector<uint32_t> chunk_chain;
-    s.chain_chunk = chain_chunk_len(s.total_ref_size);
+    s.chain_chunk = chain_chunk_len(s.total_ref_size, s.opt);
     build_chains(s, set, run.chains, chunk_chain, range, &run.edges);
     run.n_chunks = (uint32_t)chunk_chain.size();
     run.passes = 0;
@@ -347,7 +347,7 @@ constexpr uint64_t kBiasWindow = 512ull << 20;       // start positions per pass
 // partial sums and maxima of the chunks (kBiasBlock * kBiasRun start positions each, BiasPlan::chunk_ptr) whose first start position lies in
 // the share [g_lo, g_hi) of the concatenated sequences; zero elsewhere
 static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint64_t g_lo, uint64_t g_hi, std::vector<double> &h_sum, std::vector<double> &h_max) {
-    const bool trace = options().trace_prepare != 0;
+    const bool trace = s.opt.trace_prepare != 0;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -374,7 +374,7 @@ static void bias_partials(rsq_sim &s, hipStream_t st, const BiasPlan &plan, uint
     // behind its end and end positions a fragment length further.
     const uint64_t lo = std::min<uint64_t>(g_lo, s.total_ref_size), hi = std::min<uint64_t>(g_hi, s.total_ref_size);
     uint64_t window = kBiasWindow;
-    if (options().bias_window > 0) window = (uint64_t)options().bias_window;
+    if (s.opt.bias_window > 0) window = (uint64_t)s.opt.bias_window;
     const uint64_t reach = (uint64_t)kBiasBlock * kBiasRun + s.dev.insert_to, track_len = std::min(hi - lo, window) + reach;
     d_start_bias.reserve(track_len * 8 + 16);
     d_end_bias.reserve(track_len * 8 + 16);
@@ -402,7 +402,7 @@ static void bias_normalization(rsq_sim &s, hipStream_t st) {
 
 static void prepare(rsq_sim &s, uint64_t seed, uint64_t num_read_pairs, double coverage, int ref_bias_mode, const char *base_identifier, hipStream_t st) {
     HIP_CHECK(hipSetDevice(s.device));
-    const bool trace = options().trace_prepare != 0;                // stage times of the pre-pass on stderr
+    const bool trace = s.opt.trace_prepare != 0;                // stage times of the pre-pass on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
         if (trace) fprintf(stderr, "prepare: %-28s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
@@ -530,7 +530,7 @@ static FillShape fill_shape(const rsq_sim &s, size_t lds_bytes, uint64_t n_items
     const uint64_t chunks = segments_per_item * ((n_items + 63) / 64), slots = (uint64_t)s.n_cu * per_cu;
     uint32_t waves = (uint32_t)std::min<uint64_t>(max_threads / 64u, std::max<uint64_t>(4u, cdiv(chunks, slots)));
     waves = std::min(max_threads / 64u, (waves + 3u) & ~3u);                 // whole waves per SIMD
-    if (options().fill_waves > 0) waves = (uint32_t)std::min<int64_t>(max_threads / 64u, options().fill_waves);
+    if (s.opt.fill_waves > 0) waves = (uint32_t)std::min<int64_t>(max_threads / 64u, s.opt.fill_waves);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(2, cdiv(chunks, waves)));
     return FillShape{(blocks + 1u) & ~1u, waves * 64u};                     // segments alternate over blockIdx.x
 }
@@ -899,11 +899,11 @@ static void sieve_emit(rsq_sim &s, const SieveRun &r, hipStream_t st) {
 //   sieve(k + 1) waits for: reads(k) launched and done (else it would only take CUs from it), the text of part k - 1 (same workspace);
 //   text(k) waits for reads(k).
 // The host meets the sieve once per part (list sizes decide the next launches), everything else is ordered by events.
-static uint32_t pairs_parts(uint32_t n_blocks) {
+static uint32_t pairs_parts(const rsq_sim &s, uint32_t n_blocks) {
     // Measured (bench workload, 10 M pairs): 1 part 81.6 ms per step, 2 parts 83.0, 4 parts 84.3, 8 parts 87.7 -- the sieve's candidate kernel and the
     // formatter both live on the memory system (gathers in the 24 MB surrounding table; 15 GB of raw arrays and text), so side by side each takes nearly as long
     // as the two in a row, and every part adds a read-kernel tail.  One part unless asked (option overlap = n, tests).
-    const int64_t opt = options().overlap;
+    const int64_t opt = s.opt.overlap;
     return opt > 0 ? (uint32_t)std::min<int64_t>(opt, std::max<uint32_t>(n_blocks, 1u)) : 1u;
 }
 // what rsq_sim_pairs and rsq_sim_job_generate ask of a block range before anything is sized from it
@@ -932,7 +932,7 @@ static int sim_pairs(rsq_sim &s, uint32_t block_lo, uint32_t block_hi, char *r1,
     if (block_lo == block_hi) return RSQ_OK;
     reset_call_timers(s);
     const int vm = s.variants_mode;
-    const uint32_t parts = pairs_parts(block_hi - block_lo);
+    const uint32_t parts = pairs_parts(s, block_hi - block_lo);
     // one part: everything on the caller's stream; more: the reads stay there, sieve and text get their own
     hipStream_t s_reads = st, s_sieve = parts > 1 ? s.side[0] : st, s_text = parts > 1 ? s.side[1] : st;
     if (parts > 1) {                                                 // the side streams begin where the caller's stream is
@@ -1196,6 +1196,39 @@ int rsq_device_count(void) {
     return n;
 }
 
+// Which blocks a worker simulates (Simulator.cpp:2384-2401 hands blocks to threads one by one from a counter; here every worker owns a contiguous range, so that the
+// workers' texts in worker order are the single run's): ranges balanced by expected pairs per block.  The one rule for the `reseq` command line's device threads and
+// the N-process launcher (reseq_amd/sharding.py partition_blocks states the same arithmetic in the same order; tests/test_abi.py compares them).
+int rsq_partition_blocks(uint32_t total_blocks, uint32_t workers, const double *weights, uint32_t *bounds) {
+    REQUIRE(workers >= 1 && bounds && (weights || !total_blocks), "null argument or no worker");
+    double total = 0.0;
+    for (uint32_t b = 0; b < total_blocks; ++b) total += weights[b];
+    bounds[0] = 1;
+    double acc = 0.0;
+    uint32_t b = 0;
+    for (uint32_t r = 1; r < workers; ++r) {
+        const double target = total * (double)r / (double)workers;
+        while (b < total_blocks && acc + weights[b] / 2 <= target) acc += weights[b++];
+        bounds[r] = b + 1u;
+    }
+    bounds[workers] = total_blocks + 1u;
+    return RSQ_OK;
+}
+int rsq_sim_block_weights(const rsq_sim *s, double *weights, size_t cap, uint32_t *n_blocks) {
+    REQUIRE(s && n_blocks && s->prepared && s->has_ref, "a prepared simulator with a reference");
+    *n_blocks = s->total_blocks;
+    if (!weights) return RSQ_OK;
+    if (cap < s->total_blocks) {
+        g_last_error = "room for " + std::to_string(cap) + " weights, the job has " + std::to_string(s->total_blocks) + " blocks";
+        return RSQ_ENOSPC;
+    }
+    size_t at = 0;
+    for (uint32_t i = 0; i < s->dev.n_seqs; ++i)                   // a sequence's blocks share its reference bias; sequences shorter than the longest insert have none (:1159)
+        for (uint32_t k = 0; k < s->n_blocks[i]; ++k) weights[at++] = s->ref_seq_bias[i];
+    REQUIRE(at == s->total_blocks, "block counts do not add up");
+    return RSQ_OK;
+}
+
 int rsq_profile_load_reseq(const char *stats_path, const char *ipf_path, double ipf_precision_percent, rsq_profile **out) {
     REQUIRE(stats_path && out, "null argument");
     REQUIRE(ipf_precision_percent > 0.0, "ipfPrecision must be positive.");      // main.cpp:776-779
@@ -1411,14 +1444,14 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         s->n_cu = (uint32_t)prop.multiProcessorCount;
         s->arch = prop.gcnArchName;
-        s->specialize = options().specialize != 0;
+        s->specialize = s->opt.specialize != 0;
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->mailbox), 16 * sizeof(uint64_t), hipHostMallocDefault));
         for (hipStream_t &st : s->side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (rsq_sim::Workspace &w : s->ws) HIP_CHECK(hipEventCreateWithFlags(&w.text_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_call, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_fill, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_emit, hipEventDisableTiming));
-        s->force_fill_mode = (int)options().fill_mode;
+        s->force_fill_mode = (int)s->opt.fill_mode;
         s->prof = p->p;
         pack_tables(*s, s->up);
         g_last_warning = s->plan_note;
@@ -1828,7 +1861,7 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         rsq_sim::JobText &job = s->job;
         job.clear();
         if (const int rc = check_block_range(*s, block_lo, block_hi)) return rc;      // before anything is sized from the range (block_hi - block_lo is unsigned)
-        const size_t chunk_bytes = options().job_chunk_bytes > 0 ? (size_t)options().job_chunk_bytes : kJobChunkBytes;
+        const size_t chunk_bytes = s->opt.job_chunk_bytes > 0 ? (size_t)s->opt.job_chunk_bytes : kJobChunkBytes;
         // about 12 M pairs per call, at least 2000 blocks: a call is a round of launches with a tail behind each, and a longer call shares it among more pairs --
         // the Drosophila-sized job runs at 154 M pairs/s in calls of 2.4 M pairs and at 179 M in one call of 14.5 M, the human-sized one at a tenth of its size
         // at 119 and 139 M (profiles/r05_i_other_configs.json); 12 M pairs take about 20 GB of the 288 for workspace and text
@@ -1843,7 +1876,7 @@ int rsq_sim_job_generate(rsq_sim *s, uint32_t block_lo, uint32_t block_hi, uint3
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
         const size_t whole = (size_t)(prior * (double)(block_hi - block_lo) * 1.1) + ((size_t)64 << 20);
-        const size_t first_chunk = options().job_chunk_bytes > 0 ? chunk_bytes : (2 * whole + ((size_t)8 << 30) < free_bytes ? std::max(whole, chunk_bytes) : chunk_bytes);
+        const size_t first_chunk = s->opt.job_chunk_bytes > 0 ? chunk_bytes : (2 * whole + ((size_t)8 << 30) < free_bytes ? std::max(whole, chunk_bytes) : chunk_bytes);
         auto new_chunk = [&](int f, size_t at_least) {
             job.chunks[f].emplace_back(new DevBuf());
             job.chunks[f].back()->reserve(std::max(job.chunks[f].size() == 1 ? first_chunk : chunk_bytes, at_least));
@@ -1946,7 +1979,7 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
         // when the file system refuses O_DIRECT (tmpfs does).
         constexpr uint64_t kDirectAlign = 4096;
         int direct_fds[2] = {-1, -1};
-        if (options().job_write_direct)
+        if (s->opt.job_write_direct)
             for (int f = 0; f < n_files; ++f) direct_fds[f] = open(paths[f], O_WRONLY | O_DIRECT);
         // thread t of file f writes bytes [bytes * t / T, bytes * (t + 1) / T) of the file's text: pieces of at most 32 MB, the copy of one overlapping the write of the one before
         auto work = [&](int f, uint32_t t) {
@@ -2165,7 +2198,7 @@ int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes) {
             return (int)RSQ_ESTATE;
         }
         HIP_CHECK(hipSetDevice(s->device));
-        if (!options().host_gzip) {                                   // on the device: the members stay in device memory, rsq_sim_job_write / _job_read serve them like text
+        if (!s->opt.host_gzip) {                                   // on the device: the members stay in device memory, rsq_sim_job_write / _job_read serve them like text
             job_compress_on_device(*s, nullptr);
             job.device_packed = true;
             *r1_bytes = job.bytes[0];
@@ -2471,7 +2504,7 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
             // per launch like fill_lds_bytes: function attributes belong to the device the call runs on, and a process may hold simulators on several
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fasta::k_fasta_records), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fasta::kStageBytes));
             hipLaunchKernelGGL(fasta::k_fasta_records, dim3(cdiv(n, fasta::kRecordsBlock)), dim3(fasta::kRecordsBlock), fasta::kStageBytes, st, text, n, rec, w.fa_codes.as<uint16_t>(), summary,
-                               rsq::options().fasta_no_stage ? 0u : fasta::kStageBytes);
+                               s->opt.fasta_no_stage ? 0u : fasta::kStageBytes);
         }
         s->timers["parse_records"].stop(st);
         HIP_CHECK(hipGetLastError());
@@ -2534,7 +2567,7 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
         rsq_sim::JobText &job = s->job;
         // a .gz output: every call's text becomes gzip members on the device (rsq_deflate.h) and the members go down the link and into the file as they are -- a third
         // of the bytes, and no host thread compresses (option host_gzip: zlib behind the writer, as before round 5)
-        const bool gz_on_device = output_path && textio::has_suffix(output_path, ".gz") && !rsq::options().host_gzip;
+        const bool gz_on_device = output_path && textio::has_suffix(output_path, ".gz") && !s->opt.host_gzip;
         DevBuf call_text;
         if (gz_on_device) (void)rsq_sim_gzip_keep_code(s, 1);        // the first call's sample gives the code of the whole file
         if (opt.keep_text) {                                  // the text stays in device memory, as rsq_sim_job_generate keeps a rank's share of the pairs' text

@@ -196,7 +196,7 @@ void iterate_chains(Emu &s, ChainRun &run, uint32_t first_pass) {
             ChainAcc acc{s.dev.ref_words, ch.kind, ch.len, ch.kind < 2 ? s.seq_word_off[ch.id] : 0,
                          ch.kind == 2 ? s.dev.adapters[ch.seg].seqs + s.dev.adapters[ch.seg].seq_ptr[ch.id] : nullptr};
             uint32_t dist = want & 0xFFFFFFu, start_rate = want >> 24;
-            const uint32_t lo = (ch.chunk_lo + local) * s.chain_chunk, hi = std::min(lo + s.chain_chunk, ch.len), warmup = chain_warmup_len(s.chain_chunk);
+            const uint32_t lo = (ch.chunk_lo + local) * s.chain_chunk, hi = std::min(lo + s.chain_chunk, ch.len), warmup = chain_warmup_len(s.chain_chunk, s.opt);
             const uint32_t from = pass == 0 && local ? lo - std::min(warmup, lo) : lo;      // k_sys_chain: the guess of pass 0 is the end of a run-up
             sys_chain_chunk(s.dev, acc, ch.c1, ch.c2, from, hi, ch.initial_dom, dist, start_rate, ch.out, lo, &run.used[c]);
             cur[c] = dist | (start_rate << 24);
@@ -207,7 +207,7 @@ void iterate_chains(Emu &s, ChainRun &run, uint32_t first_pass) {
 }
 uint32_t run_chains(Emu &s, ChainSet set, ChainRun &run, const ShardRange *range = nullptr) {
     run = ChainRun{};
-    s.chain_chunk = chain_chunk_len(s.total_ref_size);
+    s.chain_chunk = chain_chunk_len(s.total_ref_size, s.opt);
     build_chains(s, set, run.chains, run.chunk_chain, range, &run.edges);
     const uint32_t n = (uint32_t)run.chunk_chain.size();
     if (!n) return 0;
@@ -244,7 +244,7 @@ const char *emu_last_error() { return g_err.c_str(); }
 int emu_create(const char *profile_path, const char *fasta_path, uint64_t replace_n_seed, const char *vcf_path, void **out) {
     return guard([&] {
         std::unique_ptr<Emu> s(new Emu());
-        s->fill_mode = (int)options().fill_mode;                    // as rsq_sim_create
+        s->fill_mode = (int)s->opt.fill_mode;                    // as rsq_sim_create
         s->prof = Profile::load(profile_path);
         pack_tables(*s, s->up);
         pack_profile(*s, s->up);
@@ -314,7 +314,7 @@ int emu_prepare(void *h, uint64_t seed, uint64_t num_pairs, double coverage, int
         }
         s.passes = run_chains(s, s.has_ref ? kChainsSimulation : kChainsAdapters, s.chain_run);
         if (s.has_variants) {                                  // as rsq_sim.hip's prepare: the variants' bases in windows of the strands
-            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), s.chain_chunk, [&](uint32_t c) { return s.chain_run.used[c]; });
+            const std::vector<StrandTask> windows = strand_tasks(s.opt, s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), s.chain_chunk, [&](uint32_t c) { return s.chain_run.used[c]; });
             build_variant_sys_errors(s, s.up, &windows);
         }
         s.chain_run.valid = false;
@@ -388,7 +388,7 @@ int emu_prepare_finish(void *h) {
     return guard([&] {
         if (!s.chain_run.valid) throw Error("the sharded pre-pass has not run");
         if (s.has_variants) {
-            const std::vector<StrandTask> windows = strand_tasks(s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), s.chain_chunk, [&](uint32_t c) { return s.chain_run.used[c]; });
+            const std::vector<StrandTask> windows = strand_tasks(s.opt, s.chain_run.chains, (uint32_t)s.chain_run.chunk_chain.size(), s.chain_chunk, [&](uint32_t c) { return s.chain_run.used[c]; });
             build_variant_sys_errors(s, s.up, &windows);
         }
         s.build_lds();

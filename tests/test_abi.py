@@ -292,3 +292,29 @@ def write_known_answer_vcf(path, ka):
     lines += [f"{chrom}\t{pos}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT\t{gt}" for chrom, pos, ref, alt, gt in ka["vcf_records"]]
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def test_partition_blocks_is_the_launchers_rule():
+    """rsq_partition_blocks (what `reseq illuminaPE --gpus N` cuts its workers' ranges with) against reseq_amd.sharding.partition_blocks (the N-process launcher's):
+    the same bounds for any weights -- uniform, biased per sequence, zeros, more workers than blocks, no blocks at all"""
+    from reseq_amd import sharding
+    rng = np.random.default_rng(17)
+    cases = [(0, 3, None), (1, 1, None), (5, 8, None), (4800, 8, None)]
+    for _ in range(200):
+        n = int(rng.integers(1, 400))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            w = rng.random(n)
+        elif kind == 1:                                      # a few sequences, each with its bias
+            w = np.repeat(rng.choice([0.25, 1.0, 2.0, 7.5], size=8), rng.integers(1, 80, size=8))[:n]
+            n = len(w)
+        elif kind == 2:
+            w = rng.random(n) * (rng.random(n) < 0.3)        # many blocks without weight
+        else:
+            w = np.full(n, 0.1)                              # sums that are not exact in binary
+        cases.append((n, int(rng.integers(1, 17)), w))
+    for n, world, w in cases:
+        want = sharding.partition_blocks(n, world, None if w is None else [float(x) for x in w])
+        got = api.partition_blocks(n, world, w)
+        assert got == want, (n, world)
+        assert got[0][0] == 1 and got[-1][1] == n + 1 and all(a[1] == b[0] for a, b in zip(got, got[1:]))

@@ -434,3 +434,73 @@ def test_the_launcher_refuses_what_the_command_line_refuses(job, tmp_path):
     # the product's entry point knows neither the emulation nor the fault switch
     r = subprocess.run([sys.executable, "-m", "reseq_amd.simulate", *map(str, args), "--emulate"], capture_output=True, text=True, timeout=300, env=_env(tmp_path), cwd=str(ROOT))
     assert r.returncode == 2 and "unrecognized arguments: --emulate" in r.stderr
+
+
+# --------------------------------------------------------------------------------------------------------------------- (viii)
+def _cli_pe(job, tag, extra=(), gz=False, check=True, source=None):
+    args, out = _pe_args(source or job, f"cli_{tag}", extra, gz)
+    r = subprocess.run([str(RESEQ), "illuminaPE", *map(str, args)], capture_output=True, text=True, timeout=900, env=_env(job["work"]), cwd=str(ROOT))
+    if check:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    return r, out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_reseq_illumina_pe_on_several_workers_in_one_process(job):
+    """`reseq illuminaPE --gpus N`: N host threads in the command line's own process, one simulator each on device worker % devices (Simulator.cpp:2830-2836 starts
+    its workers itself; main.cpp:436 -j) -- no launcher, no Python, no process group.  With 2, 3 and 8 workers (on a one-device box: all on device 0, which is also
+    the test of the header's promise that simulators of one process may be driven from a thread each) the files are the single worker's byte for byte: plain, with
+    variants + methylation, as .gz (decompressed), with --writeSysError, with the post-load options; -j asks for workers but never more than there are devices."""
+    if _devices() < 1:
+        pytest.skip("no device")
+    plain = _single_pe("shared", job, "plain")
+    meth_extra = ["-V", job["vcf"], "--methylation", job["bed"]]
+    meth = _single_pe("shared", job, "variants_methylation", meth_extra)
+    for n in (2, 3, 8):
+        r, out = _cli_pe(job, f"workers{n}_plain", ["--gpus", n])
+        assert f"Simulating with {n} workers on {min(n, _devices())} device(s)" in r.stderr
+        assert [open(o, "rb").read() for o in out] == plain, n
+        r, out = _cli_pe(job, f"workers{n}_meth", [*meth_extra, "--gpus", n])
+        assert [open(o, "rb").read() for o in out] == meth, n
+    r, out = _cli_pe(job, "workers3_gz", [*meth_extra, "--gpus", 3], gz=True)
+    assert [gzip.decompress(open(o, "rb").read()) for o in out] == meth
+    r, out = _cli_pe(job, "workers2_host_gz", ["--gpus", 2, "--rsqOption", "host_gzip:1"], gz=True)
+    assert [gzip.decompress(open(o, "rb").read()) for o in out] == plain
+    # options that change the profile or the pre-pass, on one worker and on four
+    bias = job["work"] / "workers_ref_bias.txt"
+    names = [n.split(" ")[0] for n, _ in conftest_read_fasta(job["fasta"])]
+    bias.write_text(f"{names[0]} 2.0\n{names[1]} 1.0\n{names[2]} 0.25\n")
+    for tag, flags in (("edits", ["--errorMutliplier", 2.5, "--noInDelErrors"]), ("bias", ["--refBiasFile", bias])):
+        base = list(_pe_args(job, "unused")[0])
+        if tag == "bias":
+            k = base.index("--refBias")
+            del base[k:k + 2]
+        outs = {}
+        for n in (1, 4):
+            args = list(base)
+            outs[n] = [str(job["work"] / f"cli_workers{n}_{tag}_{k}.fq") for k in (1, 2)]
+            args[args.index("-1") + 1], args[args.index("-2") + 1] = outs[n]
+            r = subprocess.run([str(RESEQ), "illuminaPE", *map(str, args), *map(str, flags), "--gpus", str(n)], capture_output=True, text=True, timeout=900, env=_env(job["work"]), cwd=str(ROOT))
+            assert r.returncode == 0, r.stderr[-4000:]
+        texts = {n: [open(o, "rb").read() for o in outs[n]] for n in outs}
+        assert texts[1] == texts[4] and texts[1] != plain, tag
+    long_only = job["long_only"]
+    r, one = _cli_pe(job, "workers1_sys", ["--writeSysError", job["work"] / "cli_workers1_sys.prof"], source=long_only)
+    r, four = _cli_pe(job, "workers4_sys", ["--writeSysError", job["work"] / "cli_workers4_sys.prof", "--gpus", 4], source=long_only)
+    assert (job["work"] / "cli_workers1_sys.prof").read_bytes() == (job["work"] / "cli_workers4_sys.prof").read_bytes()
+    assert [open(o, "rb").read() for o in one] == [open(o, "rb").read() for o in four]
+    # -j: the reference's worker count, at most one worker per device here
+    r, out = _cli_pe(job, "threads16_plain", ["-j", 16])
+    want_workers = min(16, _devices())
+    assert (f"Simulating with {want_workers} workers" in r.stderr) == (want_workers > 1)
+    assert [open(o, "rb").read() for o in out] == plain
+    # refused: --gpus 0, a .bz2 output with several workers; a worker's failure ends the command and leaves no output behind
+    r, out = _cli_pe(job, "workers0", ["--gpus", 0], check=False)
+    assert r.returncode != 0 and "gpus must be between 1 and 1024." in r.stderr
+    args, out = _pe_args(job, "cli_workers_bz2", ["--gpus", 2])
+    args[args.index("-1") + 1] += ".bz2"
+    r = subprocess.run([str(RESEQ), "illuminaPE", *map(str, args)], capture_output=True, text=True, timeout=900, env=_env(job["work"]), cwd=str(ROOT))
+    assert r.returncode != 0 and "bzip2 output is written by one worker only" in r.stderr
+    r, out = _cli_pe(job, "workers2_bad_meth", ["--gpus", 2, "--methylation", job["work"] / "no_such_file.bed"], check=False)
+    assert r.returncode != 0 and "worker" in r.stderr and not any(os.path.exists(o) for o in out)
