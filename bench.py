@@ -47,20 +47,21 @@ N_SIMD, N_CU, N_XCD = 1024, 256, 8
 _ORACLE = {}                 # the prepared oracle simulation of the current sample, inherited by the forked workers
 
 
-def _oracle_worker(part, parts, barrier, queue):
+def _oracle_worker(part, parts, barrier, queue, literal):
     """one process: the oracle on a block range of the sample"""
     sim = _ORACLE["sim"]
     lo, hi = sharding.partition_blocks(sim.total_blocks(), parts)[part]
     barrier.wait()
     t0 = time.perf_counter()
-    fr = sim.sieve(lo, hi)
+    fr = sim.sieve_literal(lo, hi) if literal else sim.sieve(lo, hi)
+    sieve_s = time.perf_counter() - t0
     r1, r2 = sim.create_reads(fr)
     dt = time.perf_counter() - t0
-    keep = part == 0 and parts == 1             # the one-process run also hands its text and pre-pass results to the parity check
-    queue.put((len(fr), len(r1) + len(r2), dt, (r1, r2, sim.bias_normalization(), sim.thresholds()) if keep else None))
+    keep = part == 0 and parts == 1 and not literal        # the one-process run also hands its text and pre-pass results to the parity check
+    queue.put((len(fr), len(r1) + len(r2), dt, (r1, r2, sim.bias_normalization(), sim.thresholds()) if keep else None, sieve_s))
 
 
-def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
+def _oracle_run(profile_path, seqs, seed, sample_bp, procs, literal=False):
     """pre-passes once in this process, then `procs` forked workers on a block range each (they share the prepared state)"""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -72,7 +73,7 @@ def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
     ref = O.Reference([(name, codes[:sample_bp])])
     _ORACLE["sim"] = O.Sim(prof, ref, seed, n_pairs)
     barrier, queue = ctx.Barrier(procs), ctx.Queue()
-    ps = [ctx.Process(target=_oracle_worker, args=(i, procs, barrier, queue)) for i in range(procs)]
+    ps = [ctx.Process(target=_oracle_worker, args=(i, procs, barrier, queue, literal)) for i in range(procs)]
     for p in ps:
         p.start()
     res = [queue.get() for _ in ps]
@@ -83,6 +84,8 @@ def _oracle_run(profile_path, seqs, seed, sample_bp, procs):
     prof.close()
     pairs, nbytes, wall = sum(r[0] for r in res), sum(r[1] for r in res), max(r[2] for r in res)
     text = next((r[3] for r in res if r[3] is not None), None)
+    if literal:
+        return pairs, nbytes, wall, n_pairs, max(r[4] for r in res)
     return pairs, nbytes, wall, n_pairs, text
 
 
@@ -112,9 +115,19 @@ def cpu_baseline(profile_path, seqs, seed):
     p1, b1, t1, _, text = _oracle_run(profile_path, seqs, seed, 300_000, 1)
     many_bp = 1_500_000
     pn, bn, tn, _, _ = _oracle_run(profile_path, seqs, seed, many_bp, cores)
+    # the reference's own loop shape: one uniform per (start position, fragment length) (Simulator.cpp:2302-2306, orc_sieve_blocks_literal) -- about a thousand draws per
+    # start position where the gap sieve above makes one or two.  A smaller sample: the cells, not the pairs, are what costs.
+    literal_bp = 100_000
+    pl, _, tl, _, sieve_l = _oracle_run(profile_path, seqs, seed, literal_bp, 1, literal=True)
     out = {"value": pn / tn, "unit": "read-pairs/s", "cores": cores, "kind": "port",
-           "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1},
-           "sample": f"oracle/liboracle.so; 1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per CPU of the container's quota; the host shows {host_threads} hardware threads; a block range "
+           "single_thread": {"value": p1 / t1, "unit": "read-pairs/s", "cores": 1, "sieve": "gaps"},
+           "single_thread_reference_shaped": {"value": pl / tl, "unit": "read-pairs/s", "cores": 1, "sieve": "literal: one uniform per (start, fragment length), Simulator.cpp:2302-2306",
+                                              "sample_bp": literal_bp, "pairs": pl, "seconds": round(tl, 2), "sieve_seconds": round(sieve_l, 2),
+                                              "sieve_ns_per_start_position": round(sieve_l / literal_bp * 1e9, 1)},
+           "sample": f"oracle/liboracle.so with the GAP sieve (the product's substitution for the reference's per-cell loop: the passing cells of a start position drawn by their gaps, "
+                     f"1-2 draws per start position instead of ~1000 -- `value` and `single_thread` are therefore FASTER than the reference's algorithm would be; `single_thread_reference_shaped` "
+                     f"times the reference's loop as written, orc_sieve_blocks_literal, on the first {literal_bp} bp: {pl} pairs in {tl:.1f} s of which {sieve_l:.1f} s sieve).  "
+                     f"1 thread: first 300000 bp, {p1} pairs, {b1} FASTQ bytes in {t1:.1f} s; {cores} processes (one per CPU of the container's quota; the host shows {host_threads} hardware threads; a block range "
                      f"each): first {many_bp} bp, {pn} pairs in {tn:.1f} s; sieve + CreateReads, pre-passes excluded.  The bridge to the reference itself (SURVEY.md 8(d) item 4, cannot be "
                      f"re-measured here: the reference does not build in this image): BASELINE.md's survey ran Simulator::Simulate under a header shim on an 8-vCPU 2.1 GHz Xeon with a degenerate "
                      f"(hand-filled) profile -- 17.7 k pairs/s on one thread, 95 k on eight; from the three per-base draws alone with realistic K, 9.3 k pairs/s per core",

@@ -299,6 +299,9 @@ double orc_sum_bias(const double *gc_bias, uint32_t gc_from, uint32_t gc_size, c
 /* Simulator.cpp:2249-2357 without variants/methylation: the fragments of one block range, in
  * (block, start, length, chosen-strand order, duplicate) order.  Returns the count; *out is malloc'ed. */
 uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out);
+/* Simulator.cpp:2302-2306 as written -- one uniform per (start, fragment length) -- on a random stream of its own (oracle_sim.c) */
+uint32_t orc_literal_hits(const orc_sim *s, const double *thr, uint32_t start, uint32_t c1, orc_gap_hit *out /*[insert_to]*/);
+uint64_t orc_sieve_blocks_literal(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out);
 
 /* One simulated read (Simulator.cpp:454-594 FillRead + :294-452 FillReadPart). */
 typedef struct {

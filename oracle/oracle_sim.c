@@ -637,7 +637,31 @@ uint32_t orc_gap_hits(const orc_sim *s, const double *q, const uint32_t *seg_end
     return n;
 }
 
-uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out) {
+/* Simulator.cpp:2302-2306 AS WRITTEN: one uniform per (start, fragment length), the cell goes on iff ProbabilityAboveThreshold (Simulator.h:418-420).  ~1000 draws per
+   start position of which ~0.2 % pass; the product and orc_gap_hits above draw the same process by its gaps.  Stream: Philox block (start, c1, len, 1<<28 | 2) -- a stream
+   of its own, so the literal and the gap run of one seed are two independent samples of the process (tests/test_statistics.py compares them).  From the second
+   draw on everything is shared with the gap route: strands, alleles and counts are keyed by (start, sequence, length). */
+uint32_t orc_literal_hits(const orc_sim *s, const double *thr, uint32_t start, uint32_t c1, orc_gap_hit *out) {
+    const uint32_t to = s->insert_to;
+    const uint32_t from = (uint32_t)(s->p->insert_lengths.from > 1 ? s->p->insert_lengths.from : 1);   /* :2298 */
+    uint32_t n = 0;
+    for (uint32_t len = from; len < to; ++len) {                                                       /* :2302 */
+        const orc_philox_out w = orc_philox4x32_10(s->seed, start, c1, len, ((uint32_t)ORC_DOM_SIEVE << 28) | 2u);
+        const double probability_chosen = orc_u53(w.w[0], w.w[1]);                                     /* :2303 rdist.ZeroToOne(rgen) */
+        if (probability_chosen >= thr[2 * len + 1]) {                                                  /* :2304, Simulator.h:418-420 */
+            out[n].len = len;
+            out[n].probability_chosen = probability_chosen;
+            ++n;
+        }
+    }
+    return n;
+}
+
+static uint64_t sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out, int literal);
+uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out) { return sieve_blocks(s, block_lo, block_hi, out, 0); }
+/* the reference's own loop shape, cell by cell: what `cpu_baseline` times as the reference-shaped single-thread figure and what the two-sample tests hold the gap route against */
+uint64_t orc_sieve_blocks_literal(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out) { return sieve_blocks(s, block_lo, block_hi, out, 1); }
+static uint64_t sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi, orc_fragment **out, int literal) {
     const orc_profile *p = s->p;
     const orc_reference *r = s->r;
     size_t cap = 1024, n = 0;
@@ -661,7 +685,8 @@ uint64_t orc_sieve_blocks(const orc_sim *s, uint32_t block_lo, uint32_t block_hi
             for (uint32_t start = block_start; start < block_start + BLOCK_SIZE && start < L; ++start) {
                 orc_surrounding_update_forward(codes, L, start, sur_start);
                 uint32_t last_gc = 0, last_gc_end = start;                                                  /* :1696-1697 */
-                const uint32_t n_passing = orc_gap_hits(s, gap_q, gap_seg_end, thr, start, seq, passing);   /* the lengths whose cell passes :2304-2306 */
+                const uint32_t n_passing = literal ? orc_literal_hits(s, thr, start, seq, passing)             /* the lengths whose cell passes :2304-2306 */
+                                                   : orc_gap_hits(s, gap_q, gap_seg_end, thr, start, seq, passing);
                 for (uint32_t h = 0; h < n_passing; ++h) {
                     const uint32_t len = passing[h].len;
                     const double probability_chosen = passing[h].probability_chosen;

@@ -154,6 +154,8 @@ def lib():
         "orc_systematic_errors": (None, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_int,
                                          C.c_uint16, u8p, u8p, u8p]),
         "orc_sim_bias_normalization": (C.c_double, [C.c_void_p]),
+        "orc_sieve_blocks_literal": (C.c_uint64, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(Fragment))]),
+        "orc_literal_hits": (C.c_uint32, [C.c_void_p, f64p, C.c_uint32, C.c_uint32, C.c_void_p]),
         "orc_gap_table": (None, [C.c_void_p, C.c_uint32, f64p, u32p]),
         "orc_gap_hits": (C.c_uint32, [C.c_void_p, f64p, u32p, f64p, C.c_uint32, C.c_uint32, C.c_void_p]),
         "orc_sim_n_groups": (C.c_uint32, [C.c_void_p]),
@@ -289,6 +291,19 @@ class Sim:
                 out.append((i, int(buf["len"][k]), float(buf["probability_chosen"][k])))
         return out, q, seg_end
 
+    def literal_passes(self, group, starts, c1=0):
+        """the same cells by the reference's own loop, one uniform per (start, length) (orc_literal_hits, Simulator.cpp:2302-2306): (start index, length, probability_chosen)"""
+        L = lib()
+        to = L.orc_sim_insert_to(self.h)
+        thr = np.ascontiguousarray(self.thresholds()[group].reshape(-1))
+        hit = np.dtype([("len", np.uint32), ("pad", np.uint32), ("probability_chosen", np.float64)])
+        buf = np.zeros(to, hit)
+        out = []
+        for i, start in enumerate(starts):
+            n = L.orc_literal_hits(self.h, _ptr(thr, f64p), int(start), c1, buf.ctypes.data)
+            out += [(i, int(buf["len"][k]), float(buf["probability_chosen"][k])) for k in range(n)]
+        return out
+
     def bias_normalization(self):
         return lib().orc_sim_bias_normalization(self.h)
 
@@ -324,6 +339,15 @@ class Sim:
         L = lib()
         out = C.POINTER(Fragment)()
         n = L.orc_sieve_blocks(self.h, block_lo, block_hi, C.byref(out))
+        arr = np.frombuffer(C.string_at(out, n * C.sizeof(Fragment)), dtype=FRAGMENT_DTYPE).copy() if n else np.zeros(0, FRAGMENT_DTYPE)
+        L.free(out)
+        return arr
+
+    def sieve_literal(self, block_lo, block_hi):
+        """orc_sieve_blocks_literal: the sieve with the reference's per-cell loop (a random stream of its own)"""
+        L = lib()
+        out = C.POINTER(Fragment)()
+        n = L.orc_sieve_blocks_literal(self.h, block_lo, block_hi, C.byref(out))
         arr = np.frombuffer(C.string_at(out, n * C.sizeof(Fragment)), dtype=FRAGMENT_DTYPE).copy() if n else np.zeros(0, FRAGMENT_DTYPE)
         L.free(out)
         return arr

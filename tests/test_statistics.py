@@ -574,3 +574,105 @@ def test_fragment_counts_of_the_product(workdir):
     frags, _, _ = b.pairs(1, info["total_blocks"] + 1)
     b.close()
     assert _check_fragment_counts(frags, arrays, seqs, info["bias_normalization"]) < 5.0
+
+
+# ------------------------------------------------------------------------------------------------------ the sieve: literal loop against gap draws
+def _chi2_equal_exposure(a, b, min_total=10.0):
+    """two count vectors from the SAME number of trials per bin (the same cells, another random stream): under one process a_i - b_i has mean 0 and variance about
+    a_i + b_i (binomial counts of rare events), so sum (a - b)^2 / (a + b) is chi-square with one degree of freedom per bin -- totals included, unlike a test of
+    homogeneity, which only compares shapes.  Bins with few events pooled into one.  (statistic, degrees of freedom)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    small = (a + b) < min_total
+    if small.any():
+        a, b = np.append(a[~small], a[small].sum()), np.append(b[~small], b[small].sum())
+    keep = (a + b) > 0
+    return float(((a - b)[keep] ** 2 / (a + b)[keep]).sum()), int(keep.sum())
+
+
+def _chi2_two_samples(a, b, min_expected=5.0):
+    """homogeneity of two count vectors over the same bins (bins with small expectations pooled into one): (statistic, degrees of freedom)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    A, B = a.sum(), b.sum()
+    e_a, e_b = (a + b) * A / (A + B), (a + b) * B / (A + B)
+    small = np.minimum(e_a, e_b) < min_expected
+    if small.any():
+        a, b = np.append(a[~small], a[small].sum()), np.append(b[~small], b[small].sum())
+        e_a, e_b = (a + b) * A / (A + B), (a + b) * B / (A + B)
+    keep = (a + b) > 0
+    stat = ((a - e_a)[keep] ** 2 / e_a[keep] + (b - e_b)[keep] ** 2 / e_b[keep]).sum()
+    return float(stat), int(keep.sum() - 1)
+
+
+def test_gap_sieve_and_the_references_loop_are_two_samples_of_one_process(workdir):
+    """Product and oracle draw the sieve's passing cells by their gaps (oracle_sim.c orc_gap_hits, rsq_kernels.h sieve_gaps); the reference draws one uniform per
+    (start, fragment length) cell (Simulator.cpp:2302-2306).  orc_sieve_blocks_literal is that loop as written, on a random stream of its own, so for one seed the
+    two routes are independent samples and bit parity between product and oracle says nothing about them being the same process -- this test does: over 1.4 * 10^7
+    cells (8 seeds x 20 000 start positions x 89 lengths) the two routes must agree in (i) passing cells per fragment length, (ii) simulated sites per fragment length,
+    (iii) sites with one and with two strands, (iv) (site, strand)s with 1, 2, ... pairs -- counts over the same cells, compared bin by bin with their totals
+    (_chi2_equal_exposure) -- and (v) where probability_chosen lies within its range (homogeneity).  Negative controls: a gap run whose pass probabilities are 5 % off
+    must fail (i), one whose strand thresholds are 5 % off must fail (iii) or (iv)."""
+    from scipy.stats import chi2
+    import parity_cases as P
+    ppath, fpath, seqs = P.make_inputs(workdir, "two_samples", synth.TINY, [20000])
+    oprof, oref = O.Profile(ppath), O.Reference(seqs)
+    L = len(seqs[0][1])
+
+    def sample(route, seeds, scale_pass=1.0, scale_strand=1.0):
+        out = dict(passes=None, frags=None, strands=np.zeros(3), pairs=np.zeros(8), pc=np.zeros(10), cells=0)
+        for seed in seeds:
+            sim = O.Sim(oprof, oref, seed, num_pairs=30000)
+            thr = sim.thresholds()
+            to = thr.shape[1]
+            if scale_pass != 1.0 or scale_strand != 1.0:
+                thr = thr.copy()
+                thr[0, :, 1] = 1 - np.minimum(1.0, scale_pass * (1 - thr[0, :, 1]))           # P(the cell passes) scaled
+                thr[0, :, 0] = 1 - np.minimum(1.0, scale_strand * (1 - thr[0, :, 0]))         # P(a strand is non-zero) scaled
+                sim.set_normalization(sim.bias_normalization(), thr)
+            lo = int(sim.gap_passes(0, [])[2][0])
+            if out["passes"] is None:
+                out["passes"], out["frags"] = np.zeros(to), np.zeros(to)
+            passes = sim.literal_passes(0, np.arange(L)) if route == "literal" else sim.gap_passes(0, np.arange(L))[0]
+            length = np.array([p[1] for p in passes])
+            pc = np.array([p[2] for p in passes])
+            out["passes"] += np.bincount(length, minlength=to)
+            t1 = thr[0, length, 1]
+            u = (pc - t1) / np.where(t1 < 1, 1 - t1, 1.0)
+            assert u.min() >= 0 and u.max() < 1
+            out["pc"] += np.bincount((u * 10).astype(int), minlength=10)
+            out["cells"] += L * (to - lo)
+            fr = (sim.sieve_literal if route == "literal" else sim.sieve)(1, sim.total_blocks() + 1)
+            site = fr["start"].astype(np.int64) * to + fr["len"]
+            out["frags"] += np.bincount(np.unique(site) % to, minlength=to)       # simulated sites per length (pairs per site are compound: their own test below)
+            per_strand = {}
+            for s_, st_, d_ in zip(site.tolist(), fr["strand"].tolist(), fr["dup"].tolist()):
+                per_strand[(s_, st_)] = max(per_strand.get((s_, st_), 0), d_ + 1)
+            strands_of_site = {}
+            for (s_, st_), n_ in per_strand.items():
+                strands_of_site[s_] = strands_of_site.get(s_, 0) + 1
+                out["pairs"][min(n_, 7)] += 1
+            for n_ in strands_of_site.values():
+                out["strands"][n_] += 1
+            sim.close()
+        return out
+
+    lit, gap = sample("literal", range(100, 108)), sample("gap", range(100, 108))
+    assert lit["cells"] == gap["cells"] > 1.4e7 and lit["passes"].sum() > 300_000 and lit["frags"].sum() > 100_000
+    verdicts = {}
+    for what in ("passes", "frags", "strands", "pairs", "pc"):
+        stat, df = (_chi2_two_samples if what == "pc" else _chi2_equal_exposure)(lit[what], gap[what])
+        verdicts[what] = (stat, df, chi2.sf(stat, df))
+        assert stat < chi2.ppf(1 - 1e-5, df), (what, stat, df)                  # fixed seeds: the test is deterministic; 1e-5 is the margin against an unlucky choice of them
+    print("two-sample verdicts (statistic, df, p):", {k: (round(v[0], 1), v[1], round(v[2], 4)) for k, v in verdicts.items()})
+    assert all(df >= 1 for _, df, _ in verdicts.values()) and verdicts["passes"][1] > 60
+    # negative controls: the same tests see a 5 % error
+    off_pass = sample("gap", range(100, 108), scale_pass=1.05)
+    stat, df = _chi2_equal_exposure(lit["passes"], off_pass["passes"])
+    print("negative control, passes 5 % off:", round(stat, 1), df)
+    assert stat > chi2.ppf(1 - 1e-9, df), ("passes, 5 % off", stat, df)
+    off_strand = sample("gap", range(100, 108), scale_strand=1.05)
+    stat_s, df_s = _chi2_equal_exposure(lit["strands"], off_strand["strands"])
+    stat_p, df_p = _chi2_equal_exposure(lit["pairs"], off_strand["pairs"])
+    print("negative control, strand thresholds 5 % off:", round(stat_s, 1), df_s, round(stat_p, 1), df_p)
+    assert stat_s > chi2.ppf(1 - 1e-9, df_s) or stat_p > chi2.ppf(1 - 1e-9, df_p), ("strands / pairs, 5 % off", stat_s, df_s, stat_p, df_p)
+    oref.close()
+    oprof.close()
