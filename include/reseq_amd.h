@@ -267,6 +267,10 @@ int rsq_sim_job_compress(rsq_sim *s, uint64_t *r1_bytes, uint64_t *r2_bytes);
  * "BC"); concatenated members are a gzip file for zlib's gzread, gzip -d, SeqAn and bgzip alike.  *out_len = their bytes; RSQ_ENOSPC (and the size needed) if
  * out_cap is smaller -- rsq_gzip_bound(text_len) always suffices.  Kernel time: "gzip".  rsq_sim_job_compress uses it unless option host_gzip is 1. */
 size_t rsq_gzip_bound(size_t text_len);
+/* the 28 bytes that end a BGZF file (an empty member; bgzip / htslib warn when it is missing, gzip / zlib / SeqAn read it as no text): returns 28 and, with room,
+ * writes them to out.  The members of rsq_sim_gzip_device are framed as BGZF blocks; whoever finishes a file of them appends this one (the command line, the
+ * launcher and rsq_sim_error_model_file on a whole file do). */
+size_t rsq_gzip_eof_member(char *out, size_t cap);
 /* keep = 1: the Huffman code of the NEXT rsq_sim_gzip_device call serves the calls after it as well (text of one kind, call after call: a file written in batches --
  * no sample, no code and no wait for them per call); keep = 0 (the default): every call its own code.  Either way every member is a complete gzip member. */
 int rsq_sim_gzip_keep_code(rsq_sim *s, int keep);
@@ -322,7 +326,8 @@ int rsq_sim_error_model_fasta(rsq_sim *s, uint64_t first_index, const char *text
 /* Simulator::SimulateErrorModelOnly (reseq/Simulator.h:457, Simulator.cpp:2900-3014): seqToIllumina from file to file.  input_path NULL = stdin, output_path NULL =
  * stdout; gzip / bzip2 input by content, output by name (.gz, .bz2) as SeqAn does.  A pipeline around rsq_sim_error_model_fasta: a plain file is read at offsets by
  * several threads that upload their blocks themselves, the calling thread runs the device calls on the blocks that are there, two more threads download and write the
- * text; a compressed file or a pipe has one reader.  *n_records records written as *out_bytes bytes of FASTQ.  An input without any record gives *n_records = 0 (the
+ * text; a compressed file or a pipe has one reader.  *n_records records written as *out_bytes bytes -- of FASTQ text, or of gzip members when the output's name ends in
+ * .gz and the device compresses (the bytes that went into the file).  An input without any record gives *n_records = 0 (the
  * reference calls that an error: the caller's to report).  A malformed record: RSQ_EIO and the reference's words in rsq_last_error(); what has been written of the
  * output by then is the caller's to remove (Simulator.cpp:2888-2892 does).
  * options (NULL or zero fields: the defaults): read_threads (6), block_kb (48 MB blocks), batch_blocks (up to 8 blocks in one device call); from / to: bytes

@@ -104,6 +104,7 @@ SYMBOLS = {
     "rsq_sim_job_write": (C.c_int, [_vp, C.c_char_p, _u64, C.c_char_p, _u64, _u32]),
     "rsq_sim_job_compress": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rsq_gzip_bound": (C.c_size_t, [C.c_size_t]),
+    "rsq_gzip_eof_member": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "rsq_sim_gzip_keep_code": (C.c_int, [_vp, C.c_int]),
     "rsq_sim_gzip_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "rsq_sim_job_free": (C.c_int, [_vp]),
@@ -172,6 +173,13 @@ def archive_layout(stats_path, ipf_path=None):
     buf = C.create_string_buffer(need.value)
     _check(lib().rsq_profile_archive_layout(str(stats_path).encode(), ipf, buf, need.value, C.byref(need)))
     return buf.value.decode(errors="replace")
+
+
+def gzip_eof_member():
+    """the 28 bytes that end a BGZF file (rsq_gzip_eof_member)"""
+    buf = C.create_string_buffer(32)
+    n = lib().rsq_gzip_eof_member(buf, 32)
+    return buf.raw[:n]
 
 
 def partition_blocks(total_blocks, workers, weights=None):
@@ -556,6 +564,10 @@ class Simulator:
         finally:
             src.free()
             out.free()
+
+    def gzip_end(self):
+        """what ends a .gz file whose members this simulator made: BGZF's end-of-file member behind device-made members, nothing behind zlib's (option host_gzip)"""
+        return b"" if get_option("host_gzip") else gzip_eof_member()
 
     def job_compress(self):
         """the kept text as gzip members (rsq_sim_job_compress: made on the device and kept there; in host memory with option host_gzip); returns the compressed

@@ -63,7 +63,7 @@ const std::map<std::string, std::string> kShort = {{"-j", "threads"}, {"-h", "he
                                                    {"-v", "vcfIn"},   {"-p", "probabilitiesIn"}, {"-P", "probabilitiesOut"}, {"-1", "firstReadsOut"},
                                                    {"-2", "secondReadsOut"}, {"-c", "coverage"}, {"-R", "refSim"}, {"-V", "vcfSim"}, {"-i", "input"}, {"-o", "output"}};
 const std::set<std::string> kFlags = {"help", "version", "noBias", "noTiles", "statsOnly", "tiles", "stopAfterEstimation", "noInDelErrors", "noSubstitutionErrors", "maxLenDeletion", "maxReadLength",
-                                      "dumpArchiveLayout", "traceStages"};
+                                      "dumpArchiveLayout", "traceStages", "hostGzip"};
 
 bool parse(int argc, char **argv, int first, Args &a) {
     for (int i = first; i < argc; ++i) {
@@ -234,6 +234,7 @@ struct DevBuffer {
 // the simulator produces batch i+1 and its text is copied into the other buffer.
 struct AsyncOut {
     TextOut out;
+    std::string tail;                                   // written behind the last text when the file is closed (the BGZF end-of-file member)
     void *buf[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0}, len[2] = {0, 0};
     bool full[2] = {false, false};
@@ -302,6 +303,7 @@ struct AsyncOut {
             worker.join();
             started = false;
         }
+        if (!tail.empty() && out.good()) out.write(tail.data(), tail.size());
         out.close();
         for (int k = 0; k < 2; ++k)
             if (buf[k]) rsq_host_free(buf[k]);
@@ -476,6 +478,18 @@ int illumina_pe_on_workers(const PeJob &job, int n_workers, int n_devices) {
             }
         }
     }
+    int64_t host_gzip = 0;
+    rsq_get_option("host_gzip", &host_gzip);
+    if (ok && gz && !host_gzip) {                             // files of device-made members (BGZF blocks) end with BGZF's end-of-file member
+        char eof[32];
+        const size_t n = rsq_gzip_eof_member(eof, sizeof eof);
+        for (int f = 0; ok && f < 2; ++f) {
+            const int fd = ::open((f ? job.out2 : job.out1).c_str(), O_WRONLY);
+            ok = fd >= 0 && pwrite(fd, eof, n, (off_t)end[f]) == (ssize_t)n;
+            if (fd >= 0) ::close(fd);
+            if (!ok) ERR("Writing the output failed");
+        }
+    }
     release();
     if (!ok) {                                               // Simulator.cpp:2888-2892: do not leave partial output behind
         ERR("An error occurred in the process: Terminating simulation");
@@ -621,6 +635,12 @@ int illumina_pe(const Args &a) {
     rsq_get_option("host_gzip", &host_gzip);
     const bool gz1 = !host_gzip && rsq::textio::has_suffix(out1, ".gz"), gz2 = !host_gzip && rsq::textio::has_suffix(out2, ".gz");
     if (ok && (gz1 || gz2)) rsq_sim_gzip_keep_code(sim, 1);      // one Huffman code for the run: the first batch's sample
+    {                                                            // files of device-made members (BGZF blocks) end with BGZF's end-of-file member
+        char eof[32];
+        const size_t n = rsq_gzip_eof_member(eof, sizeof eof);
+        if (gz1) f1.tail.assign(eof, n);
+        if (gz2) f2.tail.assign(eof, n);
+    }
     if (ok) {
         const bool o1 = f1.open(out1, gz1), o2 = f2.open(out2, gz2);
         if (!o1 || !o2) {
@@ -755,6 +775,8 @@ const char *kUsage =
     "                 \t-i in.fa[.gz|.bz2] (stdin) -o out.fq[.gz|.bz2] (stdout) -s profile; --readThreads N, --traceStages;\n"
     "                 \t--inputFrom / --inputTo BYTE, --firstRecord K: a share of a plain input (python -m reseq_amd.simulate seqToIllumina works them out)\n"
     "                 \t--gpus N: N workers in this process, worker r on device r % devices, the files byte for byte the single-device run's\n"
+    "Outputs named *.gz are compressed on the GPU (gzip members framed as BGZF blocks; about 15 % larger than zlib level 1, 33 % larger than level 6);\n"
+    "         --hostGzip compresses them with zlib on host threads instead (smaller files, a fraction of the speed).\n"
     "General: -j/--threads N (illuminaPE: as many workers as asked for, at most one per device; else ignored: the GPU does the work),\n"
     "         --verbosity 0-4, --version, -h, --traceStages,\n"
     "         --rsqOption name:value[,...] (measurement switches of libreseq_amd, include/reseq_amd.h rsq_set_option; results never depend on them)\n";
@@ -807,6 +829,9 @@ int query_profile(const Args &a) {
         const std::string out = a.get("statsOut"), fit = a.get("probabilitiesOut");
         ok = check(rsq_profile_save_reseq(prof, out.c_str(), fit.empty() ? nullptr : fit.c_str(), 0), "Could not write the profile archives");
         if (ok) INFO("Wrote " << out << " and " << (fit.empty() ? out + ".ipf" : fit));
+        if (ok)
+            WARN("EXPERIMENTAL: these archives hold the prepared tables and made-up raw statistics around them (what the simulation never reads), under Boost token rules that no "
+                 "Boost-written file could be checked against here; this library reads them back bit for bit, whether the original reseq does is untested (INTEGRATION.md)");
         no_output = false;
     }
     if (ok && a.has("refSeqBias")) {                              // FragmentDistributionStats::WriteRefSeqBias (FragmentDistributionStats.cpp:3643-3670)
@@ -896,6 +921,7 @@ int main(int argc, char **argv) {
             if ((end && *end) || !check(rsq_set_option(item.substr(0, colon).c_str(), v), "--rsqOption")) return 1;
         }
     }
+    if (a.has("hostGzip") && !check(rsq_set_option("host_gzip", 1), "--hostGzip")) return 1;      // .gz outputs by zlib on host threads: smaller files, slower
     if (a.has("version")) {
         std::cerr << rsq_version() << " (stands in for ReSeq version 1.1 simulation stage)" << std::endl;
         return 0;

@@ -192,7 +192,7 @@ inline void pack_tables(SimState &s, Uploader &up) {
                         pool32.push_back((float)v);
                     }
                 }
-            if (pool32.size() > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
+            if (pool32.size() * sizeof(float) > 0xFFFFFFF0ull) throw Error("single-precision probability tables exceed 4 GB (the kernels address them by 32-bit byte offsets)");
         }
     };
     // Draws decided by the random word alone: the indel draw almost always returns "no indel".
@@ -280,7 +280,8 @@ inline void pack_tables(SimState &s, Uploader &up) {
         }
         g.off32 = (uint32_t)pool32.size();
         g.lds = g.lds2 = kNoLds;
-        if (pool32.size() + (uint64_t)tabs.size() * g.table_rows * slot > 0xFFFFFFF0ull) throw Error("probability tables exceed 2^32 entries");
+        if ((pool32.size() + (uint64_t)tabs.size() * g.table_rows * slot) * sizeof(float) > 0xFFFFFFF0ull)      // PoolRow32 / lds_ring_item: 32-bit BYTE offsets into the pool
+            throw Error("single-precision probability tables exceed 4 GB (the kernels address them by 32-bit byte offsets)");
         for (DevTable &d : tabs) {
             d.off32 = 0;
             d.f32_ok = 1;

@@ -10,6 +10,8 @@
 // decide the token stream (rsq_archive.h).  Only what the simulation reads is kept; the rest is walked over.
 // The fitting side (ProbabilityEstimates::Estimate with iterations) is out of scope: tables are taken as stored.
 #include <math.h>
+#include <stdio.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <fstream>
@@ -644,7 +646,20 @@ class ArchiveWriter {
     }
     void write(const std::string &path) {
         out_ += '\n';
-        write_text_file(path, out_);
+        // under another name in the same directory first (with the same suffix: write_text_file picks the compression by it), then renamed into place -- nobody finds half a file
+        const size_t slash = path.rfind('/');
+        const std::string dir = slash == std::string::npos ? "" : path.substr(0, slash + 1), base = slash == std::string::npos ? path : path.substr(slash + 1);
+        const std::string tmp = dir + ".writing." + std::to_string((long)getpid()) + "." + base;
+        try {
+            write_text_file(tmp, out_);
+        } catch (...) {
+            unlink(tmp.c_str());
+            throw;
+        }
+        if (rename(tmp.c_str(), path.c_str()) != 0) {
+            unlink(tmp.c_str());
+            throw Error("Could not write '" + path + "'.");
+        }
     }
 
    private:
@@ -816,7 +831,9 @@ void Profile::save_archives(const std::string &stats_path, const std::string &ip
             uint64_t s1 = 0, s2 = 0;
             for (uint64_t c : left1) s1 += c;
             for (uint64_t c : left2) s2 += c;
-            if (s1 != s2) throw Error("the adapter counts of the two read segments do not sum to the same number of detections");
+            if (s1 != s2)                                         // ReSeq stores detections of adapter PAIRS: row sums and column sums of one matrix have one total
+                throw Error("this profile cannot be written as ReSeq's archives: the adapter counts of its two read segments sum to " + std::to_string(s1) + " and " + std::to_string(s2) +
+                            " detections, and ReSeq's file holds one matrix of adapter pairs whose row and column sums they have to be (an RSQP container, rsq_profile_save, holds any counts)");
             Node &counts = member(ad, "counts_"), &comb = member(ad, "combinations_");
             uint32_t a2 = 0;
             std::vector<std::vector<uint64_t>> cell(n1, std::vector<uint64_t>(n2, 0));

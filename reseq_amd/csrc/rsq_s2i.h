@@ -244,6 +244,7 @@ struct OutPipe {
     std::condition_variable cv;
     std::thread downloader, writer;
     Fault &fault;
+    std::string tail;
     StageTime t_download, t_stage, t_write, t_dev;
     OutPipe(int dev_id, Fault &f) : device(dev_id), fault(f) {}
     bool open(const char *path, bool as_it_comes = false) {      // nullptr: stdout; as_it_comes: no compression by the name (the bytes are .gz members already)
@@ -350,6 +351,7 @@ struct OutPipe {
             downloader.join();
             writer.join();
             started = false;
+            if (!tail.empty() && !fault.set) out.write(tail.data(), tail.size());      // what ends the file behind the last text (the BGZF end-of-file member)
             out.close();
             if (!out.good()) fault.raise("writing the output failed");
         }

@@ -2134,6 +2134,13 @@ int rsq_sim_gzip_keep_code(rsq_sim *s, int keep) {
     s->gz_have_code = false;
     return RSQ_OK;
 }
+// The member that ends a BGZF file (SAM specification 4.1.2: an empty block, 28 bytes): bgzip / htslib warn about a file without it.  It is a complete gzip member of no
+// text, so gzip, zlib and SeqAn read the file as before.  Whoever finishes a file of device-made members appends it.
+size_t rsq_gzip_eof_member(char *out, size_t cap) {
+    static const unsigned char kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (out && cap >= sizeof kEof) memcpy(out, kEof, sizeof kEof);
+    return sizeof kEof;
+}
 size_t rsq_gzip_bound(size_t text_len) { return (size_t)cdiv(text_len, gz::kPiece) * (gz::kHeaderBytes + 5u + gz::kTrailerBytes) + text_len; }
 int rsq_sim_gzip_device(rsq_sim *s, const char *text_dev, size_t text_len, char *out_dev, size_t out_cap, size_t *out_len, void *stream) {
     REQUIRE(s && out_len && (text_dev || !text_len) && (out_dev || !out_cap), "null argument");
@@ -2569,11 +2576,23 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
         // of the bytes, and no host thread compresses (option host_gzip: zlib behind the writer, as before round 5)
         const bool gz_on_device = output_path && textio::has_suffix(output_path, ".gz") && !s->opt.host_gzip;
         DevBuf call_text;
-        if (gz_on_device) (void)rsq_sim_gzip_keep_code(s, 1);        // the first call's sample gives the code of the whole file
+        // the first call's sample gives the code of the whole file -- of THIS file: the caller's setting (and no code of this file's) is what later calls find
+        struct RestoreCode {
+            rsq_sim *s;
+            bool on, kept;
+            ~RestoreCode() {
+                if (on) (void)rsq_sim_gzip_keep_code(s, kept ? 1 : 0);
+            }
+        } restore_code{s, gz_on_device, s->gz_keep_code};
+        if (gz_on_device) (void)rsq_sim_gzip_keep_code(s, 1);
         if (opt.keep_text) {                                  // the text stays in device memory, as rsq_sim_job_generate keeps a rank's share of the pairs' text
             if (output_path) throw Error("keep_text and an output path exclude each other");
             job.clear();
-        } else if (!out.open(output_path, gz_on_device)) {
+        } else if (gz_on_device && !opt.from && !opt.to) {     // a whole file of device-made members ends like a BGZF file (a share of a job: whoever ends the file does it)
+            char eof[32];
+            out.tail.assign(eof, rsq_gzip_eof_member(eof, sizeof eof));
+        }
+        if (!opt.keep_text && !out.open(output_path, gz_on_device)) {
             g_last_error = std::string("Could not open '") + output_path + "' for writing.";
             return (int)RSQ_EIO;
         }
@@ -2683,7 +2702,7 @@ int rsq_sim_error_model_file(rsq_sim *s, const char *input_path, const char *out
             return rc != RSQ_OK ? rc : (int)RSQ_EIO;
         }
         *n_records = records;
-        *out_bytes = opt.keep_text ? job.bytes[0] : out.bytes;
+        *out_bytes = opt.keep_text ? job.bytes[0] : out.bytes + out.tail.size();
         job.complete = opt.keep_text != 0;
         return (int)RSQ_OK;
     });

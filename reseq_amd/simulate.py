@@ -200,6 +200,17 @@ class GpuBackend:
     def adapter_only_pairs(self, first, n):
         return self.sim.adapter_only_pairs(first, n)
 
+    # .gz outputs: text that does not come from the kept job (the adapter-only pairs) as members of the same kind, and what ends a file of such members
+    def gzip_members(self, text):
+        if not text:
+            return b""
+        if self.api.get_option("host_gzip"):
+            return _gzip_member(text)
+        return self.sim.gzip(text)
+
+    def gzip_end(self):
+        return self.sim.gzip_end()
+
     # --gatherOutput: a slice of the kept text as a device tensor of `size` bytes (the first `n` of them text), and a received slice to its place in a file
     def job_slice(self, file, at, n, size):
         import torch
@@ -349,7 +360,9 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
     _agree(dist, device, error, "generating its share")
     n_mine, bytes1, bytes2 = generated
     total_pairs, total_bytes, elapsed = sharding.job_totals(dist, device, n_mine, bytes1 + bytes2, time.perf_counter() - t0)
-    wrap = _gzip_member if compress else (lambda text: text)
+    # text from outside the kept job as members like the job's own (on the device: BGZF-framed; the emulation and host_gzip: zlib's), and the file's last bytes
+    wrap = getattr(backend, "gzip_members", _gzip_member) if compress else (lambda text: text)
+    file_end = getattr(backend, "gzip_end", lambda: b"")() if compress else b""
     if compress:
         # .gz outputs: the rank's text becomes gzip members in host memory (rsq_sim_job_compress: a pool of threads per rank); a file of concatenated members is a
         # gzip file, so from here on the COMPRESSED sizes are the shard sizes and everything else stays as it is.  The decompressed files are the single run's.
@@ -372,6 +385,8 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
                         a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
                         f1.write(wrap(a))
                         f2.write(wrap(b))
+                    f1.write(file_end)
+                    f2.write(file_end)
 
         _agree(dist, device, _attempt(write_parts)[1], "writing its part")
         return int(total_pairs) + info["adapter_only_pairs"], elapsed
@@ -391,6 +406,8 @@ def run_rank(backend, dist, rank, world, out1, out2, seed, num_pairs=0, coverage
                     a, b = backend.adapter_only_pairs(first, min(100000, info["adapter_only_pairs"] - first))
                     f1.write(wrap(a))
                     f2.write(wrap(b))
+                f1.write(file_end)
+                f2.write(file_end)
 
     # three steps, after each of which the ranks agree that all of them got through (what a barrier stood for, and no rank waits for one that failed)
     _agree(dist, device, _attempt(create_files)[1], "creating the output files")
@@ -437,6 +454,7 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
         packed, error = _attempt(lambda: sim.job_compress()[0] if nbytes else 0)
         _agree(dist, device, error, "compressing its share")
         nbytes = packed
+    file_end = getattr(sim, "gzip_end", lambda: b"")() if compress else b""      # behind device-made members: BGZF's end-of-file member
     if not nbytes:                                                   # nothing kept (an empty share): nothing to write either
         write = lambda path, offset: None
     else:
@@ -449,6 +467,9 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
             write(part, 0)
             if nbytes:
                 sim.job_free()
+            if rank == world - 1 and file_end:
+                with open(part, "ab") as f:
+                    f.write(file_end)
         _agree(dist, device, _attempt(write_part)[1], "writing its part")
         return int(total_records), elapsed
     sizes = sharding.gather_sizes(dist, device, [nbytes], world)
@@ -461,6 +482,12 @@ def run_records_rank(sim, dist, rank, world, input_path, output_path, device="cp
     _agree(dist, device, _attempt(write, output_path, sum(row[0] for row in sizes[:rank]))[1], "writing its byte range")
     if nbytes:
         sim.job_free()
+
+    def end_file():
+        if rank == 0 and file_end:
+            with open(output_path, "ab") as f:
+                f.write(file_end)
+    _agree(dist, device, _attempt(end_file)[1], "ending the output file")
     return int(total_records), elapsed
 
 

@@ -318,3 +318,13 @@ def test_partition_blocks_is_the_launchers_rule():
         got = api.partition_blocks(n, world, w)
         assert got == want, (n, world)
         assert got[0][0] == 1 and got[-1][1] == n + 1 and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+
+
+def test_bgzf_end_of_file_member():
+    """rsq_gzip_eof_member: the 28 bytes of the SAM specification's BGZF end-of-file block -- a complete gzip member of no text with the "BC" extra field"""
+    import zlib
+    eof = api.gzip_eof_member()
+    assert len(eof) == 28 and eof[:4] == b"\x1f\x8b\x08\x04" and eof[12:14] == b"BC" and int.from_bytes(eof[16:18], "little") == 27
+    d = zlib.decompressobj(31)
+    assert d.decompress(eof) == b"" and d.eof and d.unused_data == b""
+    assert zlib.decompress(zlib.compress(b"x") , 15) == b"x"

@@ -179,6 +179,8 @@ def _illumina_pe(mode, job, inputs, worlds):
         args, out = _pe_args(job, tag, extra, gz=True)
         launch(mode, world, args, job["work"])
         assert [gzip.decompress(open(o, "rb").read()) for o in out] == want, (world, "gz")
+        if mode != "gloo":                                          # device-made members are BGZF blocks: the file ends with BGZF's end-of-file member
+            assert all(open(o, "rb").read().endswith(api.gzip_eof_member()) for o in out)
     assert not list(pathlib.Path(job["work"]).glob("rsq_packed_reference_*")) and not list(pathlib.Path("/dev/shm").glob("rsq_packed_reference_*"))
 
 
@@ -212,6 +214,7 @@ def _seq_to_illumina(mode, job, worlds):
         gz = job["work"] / f"{mode}_records_w{world}.fq.gz"
         launch(mode, world, ["seqToIllumina", "-i", fa, "-o", gz, "-s", job["profile"], "--seed", 13], job["work"])
         assert gzip.decompress(gz.read_bytes()) == want, world
+        assert mode == "gloo" or gz.read_bytes().endswith(api.gzip_eof_member())
     # a malformed record on one rank: that rank says what the reference's reader says, the job ends, nobody waits
     text = fa.read_bytes()
     cut = text.index(b">", len(text) * 3 // 4)
@@ -465,6 +468,11 @@ def test_reseq_illumina_pe_on_several_workers_in_one_process(job):
         assert [open(o, "rb").read() for o in out] == meth, n
     r, out = _cli_pe(job, "workers3_gz", [*meth_extra, "--gpus", 3], gz=True)
     assert [gzip.decompress(open(o, "rb").read()) for o in out] == meth
+    assert all(open(o, "rb").read().endswith(api.gzip_eof_member()) for o in out)
+    r, out = _cli_pe(job, "workers1_gz", meth_extra, gz=True)
+    assert [gzip.decompress(open(o, "rb").read()) for o in out] == meth and all(open(o, "rb").read().endswith(api.gzip_eof_member()) for o in out)
+    r, out = _cli_pe(job, "workers1_host_gz", [*meth_extra, "--hostGzip"], gz=True)
+    assert [gzip.decompress(open(o, "rb").read()) for o in out] == meth and not any(open(o, "rb").read().endswith(api.gzip_eof_member()) for o in out)
     r, out = _cli_pe(job, "workers2_host_gz", ["--gpus", 2, "--rsqOption", "host_gzip:1"], gz=True)
     assert [gzip.decompress(open(o, "rb").read()) for o in out] == plain
     # options that change the profile or the pre-pass, on one worker and on four
