@@ -7,20 +7,28 @@
 // code that is NOT the piece's own: the code is built on the host once per call from the symbol counts of a sample of the call's pieces (FASTQ text is stationary:
 // the same ids, four bases, forty qualities everywhere) -- so the device never builds a code, and a piece's encoding needs nothing of another piece.
 //
-// A piece on the device, 256 threads (k_gzip_pieces), three workgroups per CU (51 KB of LDS each):
+// A piece on the device, 256 threads (k_gzip_pieces), three or four workgroups per CU (40 KB of LDS each):
 //   rounds of 8 KB; the round's text -- with 272 bytes beyond it and what came before -- stands in a 16 KB ring in LDS (global loads of 16 bytes, once); per round
-//   A  every position finds its candidate -- the nearest earlier position with the same four bytes, through a hash table of positions in LDS, filled 256 positions
-//      at a time (read all, barrier, atomicMax all: deterministic), plus the position one byte back (runs) -- and probes it for eight bytes, without a loop: most
-//      positions lie inside a match that B passes over, so nothing more is measured here; a match is kept in 16 bits (length, distance up to 2048);
-//   B  thread t owns the 32-byte segment t of the round: its 32 matches and 32 bytes go into registers (six 16-byte LDS reads) and an unrolled walk takes them
-//      greedily (longest match at the current position, as zlib's level 1 does; a match that reaches the probe's end is measured to its end now; a match may not
-//      leave the segment: the walks are independent) -- once to count the bits, then, after a scan of the counts over the workgroup, to OR the codes LSB-first
-//      into the round's bit buffer in LDS (ds_or: neighbours share a word where their bits meet); the buffer's complete words go to the member in HBM in coalesced
-//      stores, its last, incomplete word to the front of the next round's buffer;
+//   L  the LINES: FASTQ text is searched for matches only where matches are -- the lines that begin with '@' and the lines behind them (ids and bases); quality lines
+//      are coded as literals and runs (see "FASTQ text by its lines" below).  Which line a position lies in comes out of one scan over the workgroup;
+//   A1 every searched position enters a hash table of positions in LDS, keyed by SIX bytes, 256 positions at a time (read all, barrier, atomicMax all: deterministic);
+//      what the table held before is the position's candidate;
+//   A2 every fourth searched position is PROBED, a thread per probe (all lanes at work): the candidate verified and measured to its end (the end of the 32-byte
+//      segment at most: segments are coded independently), and so a run of the byte before it; 16 bits per probe.  The three positions behind a probed one inherit
+//      what is left of its match;
+//   B  thread t owns the 32-byte segment t of the round: its bytes and its eight probes' matches in registers, an unrolled walk takes them greedily (as zlib's level
+//      1 does) without touching the text again -- once to count the bits, then, after a scan of the counts over the workgroup, to OR the codes LSB-first into the
+//      round's bit buffer in LDS (ds_or: neighbours share a word where their bits meet); the buffer's complete words go to the member in HBM in coalesced stores, its
+//      last, incomplete word to the front of the next round's buffer;
 //   the end-of-block code, the CRC-32 of the text (slices per thread, four bytes per step, folded with x^(8 len) mod P like zlib's crc32_combine) and the trailer.
 // A piece whose bits come to no less than the piece itself (text that looks nothing like the sample, or a few bytes behind the block header), or a round of which
 // needs more than 8 bits per byte, is stored instead (BTYPE 00) by a second kernel: text + 31 bytes bound every member, and the slot holds that.
-// Measured on the simulator's own FASTQ text (P0, 742 MB): 86 GB/s by kernel time, 2.78 x smaller (zlib level 1: 3.19 x, level 6: 3.71 x) -- profiles/r05_*.
+// Measured on the simulator's own FASTQ text (P0, 804 MB): 182 GB/s by kernel time, 2.78 x smaller (zlib level 1: 3.18 x, level 6: 3.71 x) -- profiles/r06_*.
+// Round 5's kernel searched and probed every position of every line with a four-byte key and measured a match in the walk, twice: 90 GB/s, 2.75 x.  What made the
+// difference (tools/micro/gzip_bench.hip, clocks per phase): the walks no longer read LDS text in divergent loops, the found array is an eighth (four workgroups
+// per CU), x^(8 len) is a constant instead of 44 multiplications per thread, a fifth of the probes; the six-byte key found the better candidates.
+// Text with a handful of quality values and short reads (the test profile TINY) is where this costs size: 1.29 x zlib level 1 (round 5's kernel: about 1.05 x) --
+// its short repeats fall between the probes.  zlib on host threads (option host_gzip, `reseq --hostGzip`) remains for whoever wants the smallest file.
 //
 // The per-thread functions are host/device code: tests/hostemu runs the same walk on the CPU against zlib's inflate.
 #pragma once
@@ -47,6 +55,9 @@ constexpr uint32_t kRing = 16384, kAhead = 272;      // the device keeps the las
 constexpr uint32_t kMaxDist = 2048;               // how far back a match may reach: a match is kept as (length - 2) << 11 | (distance - 1) in 16 bits, and the ring holds far more
 constexpr uint32_t kOutWords = 2048;              // words of the round's bit buffer in LDS: 8 bits per byte of the round -- a round that needs more is not worth coding
 static_assert(kSeg == 32 && kMaxDist <= kRing - kRound - kAhead - 16u, "the packed match and the ring");
+constexpr uint32_t kMinRun = 4;                    // shortest run taken as a match one byte back in a line that is not searched ("FASTQ text by its lines" below)
+constexpr uint32_t kProbeStep = 4;                 // every so many positions of a searched line are probed
+static_assert(kSeg % (2u * kProbeStep) == 0, "a segment's entries of the found array fill whole words");
 constexpr uint32_t kHeaderBytes = 18, kTrailerBytes = 8;
 constexpr uint32_t kSlot = 65536 + 64;             // bytes of a member's slot: a stored piece needs kPiece + 5 + header + trailer
 constexpr uint32_t kSlotPad = 2;                   // the member begins here in its slot: its deflate data, 18 bytes on, then lies on a 4-byte boundary (atomicOr on words)
@@ -63,6 +74,10 @@ struct Codes {
 };
 
 RSQ_HD uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32u - kHashBits); }
+// The table is entered with SIX bytes (v = the four a match is verified on first, more = the four behind them): among four letters any four bytes recur within the
+// window by chance, and the chance candidate -- the latest -- hides the read that truly overlaps; six bytes recur by chance once in 4096 positions.  (Measured on P0's
+// text: 2.74 x smaller with four bytes, 2.91 x with six, 2.89 x with eight; the shortest match found this way is six bytes, which is about where a match begins to pay.)
+RSQ_HD uint32_t hash6(uint32_t v, uint32_t more) { return hash4(v ^ ((more & 0xFFFFu) * 0x9E3779B1u)); }
 RSQ_HD uint32_t load4(const uint8_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(p);
@@ -107,39 +122,6 @@ struct RingText {
 #endif
     }
 };
-// what phase A leaves per position of a round: a match's length (0: none) and distance
-struct Found {
-    uint32_t len, dist;
-};
-// Phase A looks eight bytes far (seven for a run): enough to tell a match from none and to compare two candidates, and without a loop -- most positions lie INSIDE
-// a match that the walk of phase B passes over, so what is measured here beyond that would be thrown away.  A match that reaches this far is measured to its end by
-// the walk when it takes it (extend_match).
-constexpr uint32_t kProbe = 7;
-// A match is never used beyond the end of the 32-byte segment its position lies in (phase B cuts it there): `limit` stops there as well.
-// v = text.word(p); cand_plus1: the hash table's entry for these four bytes as it stood before this group of positions was entered (position + 1, 0 = none)
-template <class Text>
-RSQ_HD Found find_match(const Text &text, uint32_t n, uint32_t round_lo, uint32_t p, uint32_t v, uint32_t cand_plus1) {
-    Found f{0u, 0u};
-    if (p + kMinMatch > n) return f;
-    const uint32_t segment_end = round_lo + ((p - round_lo) / kSeg + 1u) * kSeg;
-    uint32_t limit = n - p < kMaxMatch ? n - p : kMaxMatch;
-    if (segment_end - p < limit) limit = segment_end - p;
-    if (limit < kMinMatch) return f;
-    if (cand_plus1 && limit >= 4u) {                                 // the table's candidate: all four hashed bytes, or nothing (a collision)
-        const uint32_t q = cand_plus1 - 1u;
-        if (p - q <= kMaxDist && text.word(q) == v) {
-            const uint32_t x = text.word(p + 4u) ^ text.word(q + 4u), len = 4u + (x ? low_zero_bytes(x) : 4u);
-            f = Found{len < limit ? len : limit, p - q};
-        }
-    }
-    if (p && f.len < limit && ((text.word(p - 1u) ^ v) & 0xFFFFFFu) == 0u) {      // a run: the position one byte back (the table knows nothing nearer than a group)
-        const uint32_t x = text.word(p + 3u) ^ text.word(p + 2u);
-        uint32_t len = 3u + (x ? low_zero_bytes(x) : 4u);
-        if (len > limit) len = limit;
-        if (len > f.len) f = Found{len, 1u};
-    }
-    return f;
-}
 // the match of `len` bytes (so far) at p, `dist` back, to its end: at most `most` bytes in all
 template <class Text>
 RSQ_HD uint32_t extend_match(const Text &text, uint32_t p, uint32_t dist, uint32_t len, uint32_t most) {
@@ -175,25 +157,117 @@ RSQ_HD Sym distance_symbol(uint32_t dist) {
 // literals).  The loop is unrolled: every position reads its match and byte out of a register by constant shifts; what a position does depends on `skip`, the bytes
 // a match before it still covers.
 struct Segment {
-    uint32_t found[kSeg / 2u], text[kSeg / 4u];
+    uint32_t found[kSeg / kProbeStep / 2u], text[kSeg / 4u];      // the probed positions' entries (found_at), the bytes
+    uint32_t kind;                       // bit i: position i lies in a line that is searched for matches (line_kinds); else only runs of its own bytes count
+    uint32_t eq;                         // bit i (i >= 1): byte i equals byte i - 1 of the segment
 };
-template <class Sink, class Extend>      // Extend: (position in the segment, distance, length so far, most) -> the match's full length (extend_match on the segment's text)
-RSQ_HD void walk_segment(const Segment &g, uint32_t n, Sink &sink, const Extend &extend) {
+// ---- FASTQ text by its lines.  A record is an id line, 150 bases, "+", 150 qualities.  Matches worth their price exist between the id lines and between the base
+// lines of neighbouring records (the simulator writes its pairs in the order of their start positions: neighbours overlap); a quality line repeats nothing but, now
+// and then, a byte.  So the lines that begin with '@' and the lines behind them are SEARCHED (hashed, probed: phase A), every other line is coded as literals and as
+// runs of one byte (a match one byte back, found in the segment's own registers).  The rule needs no knowledge of records: a quality line that happens to begin with
+// '@' is searched too, and so is the "+" behind it -- the choice only ever costs size, never correctness.  Of the searched positions every fourth is PROBED (probe); the three behind it inherit its match, a byte shorter each -- the bytes of a match that has been
+// compared are equal wherever one starts among them.  What is lost is a match that begins on a position that is not probed and whose predecessor found nothing: it
+// begins up to three literals later.
+RSQ_HD uint32_t zero_bytes_of(uint32_t x) {        // 4 bits: byte k of x is zero
+    const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 in every zero byte
+    return ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+}
+RSQ_HD uint32_t bytes_equal_to(const uint32_t *text, uint32_t c) {                   // bit i: byte i of the segment's text is c
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < kSeg / 4u; ++k) m |= zero_bytes_of(text[k] ^ (c * 0x01010101u)) << (4u * k);
+    return m;
+}
+RSQ_HD uint32_t bytes_equal_to_previous(const uint32_t *text) {                      // bit i: byte i equals byte i - 1 (bit 0: never)
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < kSeg / 4u; ++k) {
+        const uint32_t before = k ? text[k - 1u] >> 24 : (~text[0]) & 0xFFu;
+        m |= zero_bytes_of(text[k] ^ ((text[k] << 8) | before)) << (4u * k);
+    }
+    return m;
+}
+RSQ_HD uint32_t count_trailing_zeros(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+// The state of the line a position lies in: bit 0 = the line is searched, bit 1 = it began with '@'.  A line that begins with byte c behind a line in state s is in
+// state next_line_state(s, c == '@'): searched iff it or the line before it began with '@'.  kLineStateAtStart: the (partial) line a piece begins in, unknown, is searched
+// and so is the line behind it.
+constexpr uint32_t kLineStateAtStart = 3u;
+RSQ_HD uint32_t next_line_state(uint32_t s, bool at) { return (at ? 3u : 0u) | (s >> 1); }
+// `starts`: bit i = a line begins at position i of the segment (the byte before it is a newline); `at`: bytes_equal_to '@'.  The positions in searched lines, given the
+// state the segment is entered in:
+RSQ_HD uint32_t line_kinds(uint32_t state, uint32_t starts, uint32_t at) {
+    uint32_t kind = state & 1u ? 0xFFFFFFFFu : 0u;
+    for (; starts; starts &= starts - 1u) {
+        const uint32_t i = count_trailing_zeros(starts), upper = 0xFFFFFFFFu << i;
+        state = next_line_state(state, (at >> i) & 1u);
+        kind = state & 1u ? kind | upper : kind & ~upper;
+    }
+    return kind;
+}
+// ... and what the segment does to the state, as a table of four 2-bit entries (entry s at bits 2s): the segments' tables compose (line_compose), so the state in
+// front of every segment of a round comes out of one scan over the workgroup
+constexpr uint32_t kLineIdentity = 0xE4u;
+RSQ_HD uint32_t line_transfer(uint32_t starts, uint32_t at) {
+    uint32_t table = 0;
+    for (uint32_t s = 0; s < 4u; ++s) {
+        uint32_t state = s;
+        for (uint32_t m = starts; m; m &= m - 1u) state = next_line_state(state, (at >> count_trailing_zeros(m)) & 1u);
+        table |= state << (2u * s);
+    }
+    return table;
+}
+RSQ_HD uint32_t line_compose(uint32_t first, uint32_t then) {
+    uint32_t table = 0;
+    for (uint32_t s = 0; s < 4u; ++s) table |= ((then >> (2u * ((first >> (2u * s)) & 3u))) & 3u) << (2u * s);
+    return table;
+}
+RSQ_HD uint32_t line_apply(uint32_t table, uint32_t state) { return (table >> (2u * state)) & 3u; }
+// A probed position's entry of the found array, 16 bits: 0 = no match, else bits 0-10 distance - 1, bits 11-15 length - 2 (the match measured to its end: at most the
+// rest of the segment, 32 bytes).  The kProbeStep - 1 positions behind it have no entry: they inherit (found_at).
+RSQ_HD uint32_t pack_found(uint32_t len, uint32_t dist) { return len >= kMinMatch ? ((len - 2u) << 11) | (dist - 1u) : 0u; }
+// the probe of position p (a multiple of kProbeStep in its segment); cand_dist: how far back the hash table's candidate for p's bytes lies (0: none).  The candidate
+// is verified on its first four bytes and measured to its end; so is a run (the byte before p three times more).  A match ends with the segment of p.
+template <class Text>
+RSQ_HD uint32_t probe(const Text &text, uint32_t n, uint32_t round_lo, uint32_t p, uint32_t cand_dist) {
+    if (p + kMinMatch > n) return 0u;
+    const uint32_t segment_end = round_lo + ((p - round_lo) / kSeg + 1u) * kSeg;
+    const uint32_t limit = n - p < segment_end - p ? n - p : segment_end - p;
+    if (limit < kMinMatch) return 0u;
+    const uint32_t v = text.word(p);
+    uint32_t len = 0, dist = 0;
+    if (cand_dist && limit >= 4u && text.word(p - cand_dist) == v) {
+        len = extend_match(text, p, cand_dist, 4u, limit);
+        dist = cand_dist;
+    }
+    if (p && len < limit && ((text.word(p - 1u) ^ v) & 0xFFFFFFu) == 0u) {
+        const uint32_t run = extend_match(text, p, 1u, 3u, limit);
+        if (run > len) len = run, dist = 1u;
+    }
+    return pack_found(len, dist);
+}
+// what position i of a segment finds: its own entry if it is probed, else what is left of the entry of the probed position before it.  found: the segment's
+// kSeg / kProbeStep entries, two per word.  (length, distance); length 0 = nothing
+RSQ_HD void found_at(const uint32_t *found, uint32_t i, uint32_t &len, uint32_t &dist) {
+    const uint32_t j = i / kProbeStep, k = i % kProbeStep, e = (found[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu, parent = e ? (e >> 11) + 2u : 0u;
+    len = parent >= kMinMatch + k ? parent - k : 0u;
+    dist = (e & 2047u) + 1u;
+}
+template <class Sink>
+RSQ_HD void walk_segment(const Segment &g, uint32_t n, Sink &sink) {
     uint32_t skip = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t i = 0; i < kSeg; ++i) {
-        const uint32_t e = (g.found[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu, c = (g.text[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
-        uint32_t len = e >> 11;
-        len = len ? len + 2u : 0u;
+        const uint32_t c = (g.text[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
+        const bool searched = (g.kind >> i) & 1u;
+        const uint32_t run = i ? count_trailing_zeros(~(g.eq >> i)) : 0u;             // bytes from i on that equal byte i - 1
+        uint32_t len, dist;
+        found_at(g.found, i, len, dist);
+        if (!searched) len = run >= kMinRun ? run : 0u, dist = 1u;
         if (i + len > n) len = n > i ? n - i : 0u;
         const bool here = skip == 0u && i < n, is_match = len >= kMinMatch;
         if (here) {
-            if (is_match) {
-                if (len >= kProbe && i + len < n) len = extend(i, (e & 2047u) + 1u, len, n - i);      // phase A looked no further
-                sink.match(len, (e & 2047u) + 1u);
-            } else sink.literal(c);
+            if (is_match) sink.match(len, dist);
+            else sink.literal(c);
         }
         skip = here ? (is_match ? len - 1u : 0u) : (skip ? skip - 1u : 0u);
     }
@@ -265,6 +339,28 @@ RSQ_HD uint32_t multmodp(uint32_t a, uint32_t b) {
     }
     return p;
 }
+constexpr uint32_t multmodp_c(uint32_t a, uint32_t b) {           // multmodp for constant expressions
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0) break;
+        }
+        m >>= 1;
+        b = b & 1u ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+constexpr uint32_t x_to_8n_modp_c(uint32_t n_bytes) {
+    uint32_t result = 1u << 31, square = 1u << 30;
+    for (uint64_t e = (uint64_t)n_bytes * 8u; e; e >>= 1) {
+        if (e & 1u) result = multmodp_c(square, result);
+        square = multmodp_c(square, square);
+    }
+    return result;
+}
+constexpr uint32_t kFullSlice = kPiece / kThreads;              // bytes of text per thread of a whole piece (the CRC's slices)
+constexpr uint32_t kXFullSlice = x_to_8n_modp_c(kFullSlice);    // x^(8 kFullSlice) mod P: every thread of every whole piece needed it, 44 multiplications mod P each
 RSQ_HD uint32_t x_to_8n_modp(uint32_t n_bytes) {               // x^(8 n) mod P: square-and-multiply over the bits of 8 n (x itself is 1 << 30 in the reflected form)
     uint32_t result = 1u << 31, square = 1u << 30;            // 1 and x
     for (uint64_t e = (uint64_t)n_bytes * 8u; e; e >>= 1) {
@@ -319,7 +415,7 @@ __device__ inline uint32_t piece_crc(const uint8_t *t, uint32_t len, RSQ_LDS uin
         __syncthreads();
     }
     part[tid] = tid == 0 ? crc32_slice(table, t, first) : crc32_slice(table, t + first + (tid - 1u) * L, L);
-    uint32_t x = x_to_8n_modp(L);
+    uint32_t x = L == kFullSlice ? kXFullSlice : x_to_8n_modp(L);
     for (uint32_t width = 1; width < kThreads; width *= 2) {
         __syncthreads();
         if (tid % (2u * width) == 0) part[tid] = crc_combine(part[tid], part[tid + width], x);
@@ -381,13 +477,26 @@ __device__ inline uint32_t flush_round(RSQ_LDS uint32_t *out, uint32_t *words, u
     if (tid == 0 && !all) out[0] = carry;
     return complete;
 }
+// RSQ_GZ_TRACE (tools/micro/gzip_bench.hip): thread 0 of every workgroup adds the shader clocks it spent in each phase to hist[phase] (the sample kernel's argument, unused
+// by the other)
+#if defined(RSQ_GZ_TRACE)
+#define RSQ_GZ_MARK(phase)                                              \
+    do {                                                                \
+        const unsigned long long now_ = clock64();                      \
+        if (!SAMPLE && tid == 0) trace_[phase] += now_ - mark_;         \
+        mark_ = now_;                                                   \
+    } while (0)
+#else
+#define RSQ_GZ_MARK(phase)
+#endif
 template <bool SAMPLE>
 __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, uint64_t n, uint32_t piece_step, const Codes *codes, uint8_t *slots, uint32_t *sizes, uint32_t *hist) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing + 16u];
-    __shared__ __attribute__((aligned(16))) uint16_t s_found[kRound];
+    __shared__ __attribute__((aligned(16))) uint16_t s_found[kRound / kProbeStep];      // an entry per probed position
     __shared__ uint32_t head[1u << kHashBits];
     __shared__ uint32_t s_out[SAMPLE ? 1u : kOutWords + 2u], s_litlen[SAMPLE ? 1u : kLitLen], s_dist[SAMPLE ? 1u : kDist], s_hist[SAMPLE ? kLitLen + kDist : 1u];
-    __shared__ uint32_t s_part[kThreads], s_wave[kThreads / 64u];
+    __shared__ uint32_t s_part[kThreads], s_wave[kThreads / 64u], s_kind[kThreads];
+    __shared__ uint16_t s_list[SAMPLE ? kRound / kProbeStep : 1u];      // the positions to probe: in the sample kernel an array of its own, else inside the round's bit buffer
     const uint32_t tid = threadIdx.x;
     const uint64_t piece = (uint64_t)blockIdx.x * piece_step;
     const uint8_t *t = text + piece * kPiece;
@@ -399,6 +508,12 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
     RSQ_LDS uint32_t *out = (RSQ_LDS uint32_t *)s_out;
     const RSQ_LDS uint32_t *litlen = (const RSQ_LDS uint32_t *)s_litlen, *dist = (const RSQ_LDS uint32_t *)s_dist;
     const RingText rt{ring};
+    static_assert(kRound / kProbeStep <= 2u * kOutWords, "the probe list fits the round's bit buffer behind its first word");
+    RSQ_LDS uint16_t *list = SAMPLE ? (RSQ_LDS uint16_t *)s_list : reinterpret_cast<RSQ_LDS uint16_t *>(out + 1);
+    uint32_t line_state = kLineStateAtStart, n_probes = 0;                 // the same in every thread
+#if defined(RSQ_GZ_TRACE)
+    unsigned long long trace_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mark_ = clock64();
+#endif
     for (uint32_t i = tid; i < (1u << kHashBits); i += kThreads) head[i] = 0u;
     uint32_t word_base = 0, frac = 0;                                 // words of deflate data written, bits waiting in front of the buffer: the same in every thread
     bool overflow = false;                                            // a round needed more than its buffer: the piece is stored (the same in every thread)
@@ -423,28 +538,92 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
             if (tid < 16u) ring[kRing + tid] = ring[tid];
         }
         __syncthreads();
+        RSQ_GZ_MARK(0);
+        // ---- the lines of the round: which positions of the thread's segment are searched (the state in front of it: a scan of the segments' tables over the workgroup),
+        // the bytes that repeat their predecessor, and the list of the positions to probe
+        const uint32_t lo = round_lo + tid * kSeg, n_seg = lo >= round_hi ? 0u : (round_hi - lo < kSeg ? round_hi - lo : kSeg);
+        Segment g;
+        {
+            const RSQ_LDS uint4 *t16 = reinterpret_cast<const RSQ_LDS uint4 *>(ring + (lo & (kRing - 1u)));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint4 v = t16[k];
+                g.text[4 * k] = v.x, g.text[4 * k + 1] = v.y, g.text[4 * k + 2] = v.z, g.text[4 * k + 3] = v.w;
+            }
+        }
+        {
+            const uint32_t valid = n_seg >= kSeg ? 0xFFFFFFFFu : (1u << n_seg) - 1u;
+            const uint32_t starts = ((bytes_equal_to(g.text, '\n') << 1) | (lo && n_seg && rt.byte(lo - 1u) == '\n' ? 1u : 0u)) & valid, at = bytes_equal_to(g.text, '@');
+            uint32_t incl = line_transfer(starts, at);                     // of the segments up to and including this one, within the wave
+            for (uint32_t d = 1; d < 64u; d *= 2) {
+                const uint32_t before = (uint32_t)__shfl_up((int)incl, (int)d, 64);
+                if ((tid & 63u) >= d) incl = line_compose(before, incl);
+            }
+            uint32_t excl = (uint32_t)__shfl_up((int)incl, 1, 64);
+            if ((tid & 63u) == 0u) excl = kLineIdentity;
+            if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t state = line_state;                                   // in front of this thread's wave, then of its segment
+            for (uint32_t w = 0; w < (tid >> 6); ++w) state = line_apply(s_wave[w], state);
+            uint32_t after = line_state;
+            for (uint32_t w = 0; w < kThreads / 64u; ++w) after = line_apply(s_wave[w], after);
+            line_state = after;                                            // in front of the next round: the same in every thread
+            g.kind = line_kinds(line_apply(excl, state), starts, at) & valid;
+            g.eq = bytes_equal_to_previous(g.text);
+            s_kind[tid] = g.kind;
+            const uint32_t mine = g.kind & 0x11111111u;                     // the probed positions of the segment: every kProbeStep-th
+            uint32_t upto = (uint32_t)__builtin_popcount(mine);
+            const uint32_t own = upto;
+            for (uint32_t d = 1; d < 64u; d *= 2) {
+                const uint32_t other = (uint32_t)__shfl_up((int)upto, (int)d, 64);
+                if ((tid & 63u) >= d) upto += other;
+            }
+            __syncthreads();                                               // s_wave has been read
+            if ((tid & 63u) == 63u) s_wave[tid >> 6] = upto;
+            __syncthreads();
+            uint32_t at_list = upto - own;
+            n_probes = 0;
+            for (uint32_t w = 0; w < kThreads / 64u; ++w) {
+                if (w < (tid >> 6)) at_list += s_wave[w];
+                n_probes += s_wave[w];
+            }
+            for (uint32_t m = mine; m; m &= m - 1u) list[at_list++] = (uint16_t)(tid * kSeg + count_trailing_zeros(m));
+        }
+        __syncthreads();
+        RSQ_GZ_MARK(1);
+        // ---- phase A1: the searched positions enter the hash table, kThreads positions at a time; what the table held for a position's six bytes before its group
+        // entered is its candidate, kept as a distance (for the probed positions: the others inherit)
         for (uint32_t group = round_lo; group < round_hi; group += kThreads) {
-            const uint32_t p = group + tid;
-            const bool hashed = p + 4u <= len;
-            const uint32_t v = rt.word(p), h = hashed ? hash4(v) : 0u, cand = hashed ? head[h] : 0u;      // (bytes behind the piece's end may be anything: they are never counted)
+            const uint32_t p = group + tid, rel = p - round_lo;
+            const bool hashed = p + 4u <= len && ((s_kind[rel / kSeg] >> (rel % kSeg)) & 1u);      // (bytes behind the piece's end may be anything: they are never counted)
+            const uint32_t h = hashed ? hash6(rt.word(p), rt.word(p + 4u)) : 0u, cand = hashed ? head[h] : 0u;
             __syncthreads();
             if (hashed) atomicMax(&head[h], p + 1u);
-            if (p < round_lo + kRound) {
-                const Found f = p < round_hi ? find_match(rt, len, round_lo, p, v, cand) : Found{0u, 0u};
-                found[p - round_lo] = (uint16_t)(f.len ? ((f.len - 2u) << 11) | (f.dist - 1u) : 0u);
-            }
+            if (p % kProbeStep == 0u) found[rel / kProbeStep] = (uint16_t)(cand && p + 1u - cand <= kMaxDist ? p + 1u - cand : 0u);
             __syncthreads();
         }
-        const uint32_t lo = round_lo + tid * kSeg, n_seg = lo >= round_hi ? 0u : (round_hi - lo < kSeg ? round_hi - lo : kSeg);
-        const Segment g = load_segment(found, ring, round_lo, lo);
-        const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(rt, lo + i, d, so_far, most); };
+        RSQ_GZ_MARK(2);
+        // ---- phase A2: the probes, a thread each (all lanes at work), and what the positions behind them inherit
+        for (uint32_t k = tid; k < n_probes; k += kThreads) {
+            const uint32_t rel = list[k];
+            found[rel / kProbeStep] = (uint16_t)probe(rt, len, round_lo, round_lo + rel, found[rel / kProbeStep]);
+        }
+        __syncthreads();
+        if (!SAMPLE)                                                       // the list stood in the round's bit buffer (behind its first word): zero again
+            for (uint32_t w = 1u + tid; w < 2u + n_probes / 2u; w += kThreads) out[w] = 0u;
+        {
+            const uint4 v = *reinterpret_cast<const RSQ_LDS uint4 *>(found + (lo - round_lo) / kProbeStep);
+            g.found[0] = v.x, g.found[1] = v.y, g.found[2] = v.z, g.found[3] = v.w;
+        }
+        __syncthreads();                                                   // (the buffer is zero before anybody's bits go in)
+        RSQ_GZ_MARK(3);
         if (SAMPLE) {
             auto add = [&](uint32_t sym) { atomicAdd(&s_hist[sym], 1u); };
             HistogramSink<decltype(add)> sink{add};
-            walk_segment(g, n_seg, sink, extend);
+            walk_segment(g, n_seg, sink);
         } else {
             CountSink<const RSQ_LDS uint32_t *> count{litlen, dist};
-            walk_segment(g, n_seg, count, extend);
+            walk_segment(g, n_seg, count);
             // exclusive scan of the segments' bits over the workgroup: within the wave by shuffles, the waves' totals through LDS
             uint32_t incl = count.bits;
             for (uint32_t d = 1; d < 64u; d *= 2) {
@@ -453,6 +632,7 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
             }
             if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
             __syncthreads();
+            RSQ_GZ_MARK(4);
             uint32_t before = 0, total = 0;
             for (uint32_t w = 0; w < kThreads / 64u; ++w) {
                 if (w < (tid >> 6)) before += s_wave[w];
@@ -461,9 +641,11 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
             if (frac + total > kOutWords * 32u) overflow = true;
             if (!overflow) {
                 BitSink<const RSQ_LDS uint32_t *, LdsOr> sink{litlen, dist, LdsOr{out}, frac + before + incl - count.bits};
-                walk_segment(g, n_seg, sink, extend);
+                walk_segment(g, n_seg, sink);
+                RSQ_GZ_MARK(5);
                 word_base += flush_round(out, words, word_base, frac, total, false);
                 frac = (frac + total) & 31u;
+                RSQ_GZ_MARK(6);
             }
         }
     }
@@ -484,6 +666,11 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
     __syncthreads();
     // the ring is done with: its memory holds the CRC's tables
     const uint32_t crc = piece_crc(t, len, reinterpret_cast<RSQ_LDS uint32_t *>(ring), (RSQ_LDS uint32_t *)s_part);
+    RSQ_GZ_MARK(7);
+#if defined(RSQ_GZ_TRACE)
+    if (!SAMPLE && tid == 0 && hist)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(hist) + i, trace_[i]);
+#endif
     if (tid == 0) {
         const uint32_t data_bytes = (uint32_t)((bits + 7u) / 8u);
         if (overflow || data_bytes > 5u + len) sizes[piece] = 0u;      // no smaller than stored (a piece the code does not suit, or a few bytes behind a header of forty): stored
@@ -688,7 +875,7 @@ inline Codes build_codes(const uint32_t *sample) {
 // to out (kSlot bytes, zeroed here); returns the member's size, 0 where the device gives the piece up (a round's bits beyond its buffer, or no smaller than stored).
 inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *codes, uint8_t *out, uint32_t *hist) {
     std::vector<uint32_t> head((size_t)1 << kHashBits, 0);
-    std::vector<uint16_t> found(kRound);
+    std::vector<uint16_t> found(kRound / kProbeStep);
     std::vector<uint32_t> data((size_t)kSlotWords + kOutWords + 4, 0);      // the deflate data, all of it in one buffer of bits
     struct Or {
         uint32_t *words;
@@ -701,28 +888,43 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
         bit = codes->header_bits;
     }
     const PlainText pt{text, n};
+    uint32_t line_state = kLineStateAtStart;
     for (uint32_t round_lo = 0; round_lo < n; round_lo += kRound) {
         const uint32_t round_hi = std::min(n, round_lo + kRound);
         std::fill(found.begin(), found.end(), 0);
-        for (uint32_t group = round_lo; group < round_hi; group += kThreads) {              // phase A, kThreads positions at a time
+        // the lines of the round: per segment which of its positions are searched, and the bytes that repeat the byte before them
+        std::vector<uint32_t> kinds(kThreads, 0), eqs(kThreads, 0);
+        for (uint32_t t = 0; t < kThreads; ++t) {
+            const uint32_t lo = round_lo + t * kSeg;
+            uint32_t words[kSeg / 4u] = {0};
+            for (uint32_t i = 0; i < kSeg && lo + i < n; ++i) words[i >> 2] |= (uint32_t)text[lo + i] << ((i & 3u) * 8u);
+            const uint32_t valid = lo >= round_hi ? 0u : (round_hi - lo >= kSeg ? 0xFFFFFFFFu : (1u << (round_hi - lo)) - 1u);
+            const uint32_t starts = ((bytes_equal_to(words, '\n') << 1) | (lo && lo < round_hi && text[lo - 1u] == '\n' ? 1u : 0u)) & valid, at = bytes_equal_to(words, '@');
+            kinds[t] = line_kinds(line_state, starts, at) & valid;
+            eqs[t] = bytes_equal_to_previous(words);
+            line_state = line_apply(line_transfer(starts, at), line_state);
+        }
+        // phase A1: the searched positions enter the hash table kThreads positions at a time; what the table held for a position's four bytes before its group entered
+        // is its candidate, kept as a distance
+        for (uint32_t group = round_lo; group < round_hi; group += kThreads) {
             uint32_t cand[kThreads];
-            for (uint32_t t = 0; t < kThreads; ++t) {
-                const uint32_t p = group + t;
-                cand[t] = p + 4u <= n ? head[hash4(load4(text + p))] : 0u;
-            }
-            for (uint32_t t = 0; t < kThreads; ++t) {
-                const uint32_t p = group + t;
-                if (p + 4u <= n) {
-                    uint32_t &h = head[hash4(load4(text + p))];
-                    h = std::max(h, p + 1u);
+            auto searched = [&](uint32_t p) { return p < round_hi && ((kinds[(p - round_lo) / kSeg] >> ((p - round_lo) % kSeg)) & 1u) && p + 4u <= n; };
+            auto hash_at = [&](uint32_t p) { return hash6(load4(text + p), pt.word(p + 4u)); };
+            for (uint32_t t = 0; t < kThreads; ++t) cand[t] = searched(group + t) ? head[hash_at(group + t)] : 0u;
+            for (uint32_t t = 0; t < kThreads; ++t)
+                if (searched(group + t)) {
+                    uint32_t &h = head[hash_at(group + t)];
+                    h = std::max(h, group + t + 1u);
                 }
-            }
             for (uint32_t t = 0; t < kThreads; ++t) {
                 const uint32_t p = group + t;
-                if (p >= round_hi) break;
-                const Found f = find_match(pt, n, round_lo, p, pt.word(p), cand[t]);
-                found[p - round_lo] = (uint16_t)(f.len ? ((f.len - 2u) << 11) | (f.dist - 1u) : 0u);
+                if (p < round_hi && p % kProbeStep == 0u) found[(p - round_lo) / kProbeStep] = (uint16_t)(cand[t] && p + 1u - cand[t] <= kMaxDist ? p + 1u - cand[t] : 0u);
             }
+        }
+        // phase A2: every kProbeStep-th searched position is probed, the positions behind it inherit
+        for (uint32_t p = round_lo; p < round_hi; p += kProbeStep) {
+            if (!((kinds[(p - round_lo) / kSeg] >> ((p - round_lo) % kSeg)) & 1u)) continue;
+            found[(p - round_lo) / kProbeStep] = (uint16_t)probe(pt, n, round_lo, p, found[(p - round_lo) / kProbeStep]);
         }
         uint32_t round_bits = 0;
         std::vector<Segment> segs(kThreads);
@@ -732,18 +934,18 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
             seg_n[t] = lo >= round_hi ? 0u : std::min(kSeg, round_hi - lo);
             Segment &g = segs[t];
             memset(&g, 0, sizeof g);
-            const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(pt, lo + i, d, so_far, most); };
-            for (uint32_t i = 0; i < kSeg; ++i) {
-                g.found[i >> 1] |= (uint32_t)found[lo - round_lo + i] << ((i & 1u) * 16u);
+            g.kind = kinds[t];
+            g.eq = eqs[t];
+            for (uint32_t i = 0; i < kSeg; ++i)
                 if (lo + i < n) g.text[i >> 2] |= (uint32_t)text[lo + i] << ((i & 3u) * 8u);
-            }
+            for (uint32_t j = 0; j < kSeg / kProbeStep; ++j) g.found[j >> 1] |= (uint32_t)found[(lo - round_lo) / kProbeStep + j] << ((j & 1u) * 16u);
             if (hist) {
                 auto add = [hist](uint32_t s) { ++hist[s]; };
                 HistogramSink<decltype(add)> sink{add};
-                walk_segment(g, seg_n[t], sink, extend);
+                walk_segment(g, seg_n[t], sink);
             } else {
                 CountSink<const uint32_t *> count{codes->litlen, codes->dist};
-                walk_segment(g, seg_n[t], count, extend);
+                walk_segment(g, seg_n[t], count);
                 seg_bits[t] = count.bits;
                 round_bits += count.bits;
             }
@@ -754,8 +956,7 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
         for (uint32_t t = 0; t < kThreads; ++t) {
             BitSink<const uint32_t *, Or> sink{codes->litlen, codes->dist, Or{data.data() + (bit >> 5)}, (uint32_t)(bit & 31u)};
             const uint32_t lo = round_lo + t * kSeg;
-            const auto extend = [&](uint32_t i, uint32_t d, uint32_t so_far, uint32_t most) { return extend_match(pt, lo + i, d, so_far, most); };
-            walk_segment(segs[t], seg_n[t], sink, extend);
+            walk_segment(segs[t], seg_n[t], sink);
             bit += seg_bits[t];
         }
     }

@@ -44,6 +44,7 @@ const OptionEntry kOptionTable[] = {
     {"chain_chunk", &Options::chain_chunk},     {"chain_warmup", &Options::chain_warmup},
     {"serial_parse", &Options::serial_parse},   {"parse_stretch", &Options::parse_stretch}, {"mapped_parses", &Options::mapped_parses},
     {"fasta_stretch", &Options::fasta_stretch}, {"overlap", &Options::overlap}, {"specialize", &Options::specialize}, {"job_write_direct", &Options::job_write_direct},             {"job_chunk_bytes", &Options::job_chunk_bytes}, {"host_gzip", &Options::host_gzip}, {"fill_waves", &Options::fill_waves}, {"fasta_no_stage", &Options::fasta_no_stage},
+    {"hiprtc_by_name", &Options::hiprtc_by_name},
 };
 }  // namespace
 bool set_option(const char *name, int64_t value) {

@@ -44,6 +44,7 @@ struct Options {
     int64_t fasta_no_stage = 0;        // 1: k_fasta_records parses every record where it lies in HBM (the instantiation that otherwise only serves records too long for the LDS staging)
     int64_t fill_waves = 0;            // > 0: waves per workgroup of the read kernels (default: by the size of the call, fill_shape in rsq_sim.hip; measurements)
     int64_t host_gzip = 0;             // 1: .gz output is compressed by zlib on host threads (the route before round 5; the checker of the device's gzip); 0: on the device (rsq_deflate.h)
+    int64_t hiprtc_by_name = 0;        // 1: libhiprtc is searched by name (whatever copy the process finds first, e.g. PyTorch's) instead of the system ROCm's by path; read once, at first use
     int64_t overlap = 0;               // n > 1: rsq_sim_pairs cuts its block range into n sub-ranges whose sieve / reads / text stages are pipelined on three streams
 };
 Options &options();                                               // the process-wide values

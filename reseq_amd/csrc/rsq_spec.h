@@ -44,18 +44,32 @@ struct Hiprtc {                                   // the few entry points, bound
     int (*destroy)(Program *) = nullptr;
     int (*version)(int *, int *) = nullptr;
     bool ok = false;
+    std::string path;                             // the file the entry points came from (dladdr), for rsq_sim_specialize's note
+    // ONE compiler whatever the process has loaded before: the system ROCm's libhiprtc by its full path first.  By name alone a Python process that has imported
+    // PyTorch finds the wheel's copy (another ROCm release: another register allocation of the same sources, the read kernel 3 % faster or slower), a process under
+    // rocprofv3 or without PyTorch the system's -- the product's speed then depended on what had been imported first.  Option hiprtc_by_name 1
+    // restores the search by name (measurements of exactly that difference).
     static const Hiprtc &get() {
         static Hiprtc h = [] {
             Hiprtc r;
             void *lib = nullptr;
-            for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"})
+            const bool by_name = options().hiprtc_by_name != 0;
+            for (const char *name : {"/opt/rocm/lib/libhiprtc.so", "libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"}) {
+                if (by_name && name[0] == '/') continue;
                 if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            }
+            if (!lib && by_name) lib = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
             if (!lib) return r;
             auto bind = [&](auto &f, const char *name) { f = reinterpret_cast<std::remove_reference_t<decltype(f)>>(dlsym(lib, name)); return f != nullptr; };
             int bound = 0;
             bound += bind(r.create, "hiprtcCreateProgram") + bind(r.compile, "hiprtcCompileProgram") + bind(r.log_size, "hiprtcGetProgramLogSize") + bind(r.log, "hiprtcGetProgramLog");
             bound += bind(r.code_size, "hiprtcGetCodeSize") + bind(r.code, "hiprtcGetCode") + bind(r.destroy, "hiprtcDestroyProgram") + bind(r.version, "hiprtcVersion");
             r.ok = bound == 8;
+            Dl_info info;
+            if (r.ok && dladdr(reinterpret_cast<void *>(r.create), &info) && info.dli_fname) {
+                char real[4096];
+                r.path = realpath(info.dli_fname, real) ? real : info.dli_fname;
+            }
             return r;
         }();
         return h;
@@ -171,6 +185,7 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     for (const std::string &o : spec_extra_options()) h = fnv1a(o.data(), o.size(), h);
     for (const char *src : headers) h = fnv1a(src, strlen(src), h);
     h = fnv1a(&out.rtc_major, sizeof(int), fnv1a(&out.rtc_minor, sizeof(int), h));
+    h = fnv1a(rtc.path.data(), rtc.path.size(), h);                   // two copies of libhiprtc that report one version are still two compilers
     char name[64];
     snprintf(name, sizeof name, "/%s_%016llx.hsaco", spec_kernel_name(v.kind), (unsigned long long)h);
     const std::string dir = spec_cache_dir();
@@ -280,8 +295,9 @@ class SpecKernels {
             note = "loading the read kernel compiled for this profile failed: the library's own instantiation runs instead";
             return;
         }
-        char buf[256];
-        snprintf(buf, sizeof buf, "%s compiled for this profile (%s, hiprtc %d.%d, %s)", spec_kernel_name(v.kind), arch.c_str(), c.rtc_major, c.rtc_minor,
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s compiled for this profile (%s, hiprtc %d.%d of %s, %s)", spec_kernel_name(v.kind), arch.c_str(), c.rtc_major, c.rtc_minor,
+                 Hiprtc::get().path.empty() ? "an unnamed file" : Hiprtc::get().path.c_str(),
                  c.from_cache ? "code object from the kernel cache" : (std::to_string((int)(c.seconds * 1000)) + " ms").c_str());
         note = buf;
     }
