@@ -5,6 +5,7 @@ substitutions + 40 k insertions / deletions of at most 20 bases on two alleles, 
 methylation, about 31 M pairs).  Prints one JSON line: sizes, pre-pass and generation times per stage, a checksum, and that a
 second batching writes the same bytes (pairs, total bytes, SHA-256 of the first 48000 blocks).  Not a bench line."""
 import hashlib
+import math
 import json
 import os
 import sys
@@ -105,9 +106,14 @@ out = {}
 r1 = r2 = None
 # `batches a,b`: blocks of 1000 start positions per rsq_sim_pairs call of the two runs (default 24000 and 12000; rsq_sim_job_generate takes about 12 M pairs per call: 120000 at coverage 30)
 batches = [int(x) for x in sys.argv[sys.argv.index("batches") + 1].split(",")] if "batches" in sys.argv[2:] else [24000, 12000]
+# the checksum covers the blocks up to a border EVERY batching has a call ending at -- the least common multiple of the batch sizes (the whole job if that lies beyond
+# it): the text is hundreds of GB at full scale, and a run that hashed nothing must not report the hash of nothing (round 5's file did)
+hash_border = math.lcm(*batches)
+if hash_border >= nb:
+    hash_border = nb
 for name, batch in [(f"batch_{b}", b) for b in batches]:
     h1, h2 = hashlib.sha256(), hashlib.sha256()
-    n = nbytes = 0
+    n = nbytes = hashed_to = hashed_bytes = 0
     t_gpu = 0.0
     kernel_ms = {}
     for lo in range(1, nb + 1, batch):
@@ -125,11 +131,14 @@ for name, batch in [(f"batch_{b}", b) for b in batches]:
                 kernel_ms[key] = kernel_ms.get(key, 0.0) + sim.last_kernel_ms(key)
         n += k
         nbytes += l1 + l2
-        if hi <= 48001:                                           # checksum of the first 48000 blocks only: the text is hundreds of GB at full scale
+        if hi <= hash_border + 1:
             h1.update(r1.to_numpy(np.uint8, l1).tobytes())
             h2.update(r2.to_numpy(np.uint8, l2).tobytes())
+            hashed_to = hi - 1
+            hashed_bytes += l1 + l2
     out[name] = {"pairs": n, "fastq_bytes": nbytes, "gpu_s": t_gpu, "kernel_ms": {k: round(v, 1) for k, v in kernel_ms.items()}}
-    out[name]["sha256_first_48000_blocks"] = h1.hexdigest() + ":" + h2.hexdigest()
+    assert hashed_to == hash_border and hashed_bytes > 0, (name, hashed_to, hash_border)
+    out[name]["sha256_first_blocks"] = {"blocks": hash_border, "bytes": hashed_bytes, "r1:r2": h1.hexdigest() + ":" + h2.hexdigest()}
 # `python tools/run_config5.py <scale> job`: the whole range as ONE rank's share -- generated once with the text kept in HBM (rsq_sim_job_generate), then written to
 # files in /dev/shm by the library's writer threads (rsq_sim_job_write): seconds and GB/s of both, and that the files hold the bytes of the batched run
 job = None
@@ -226,6 +235,5 @@ print(json.dumps({"config": f"configs[4] human-sized at scale {scale}, 1 GPU" + 
                   "substitutions_requested": n_sub, "indels_requested": n_indel, "methylation_regions_requested": n_regions, "total_blocks": nb,
                   "pairs_from_coverage_30": info.total_pairs, "make_inputs_s": round(t_make, 1), "load_s": round(t_load, 2), "load_stages_s": load_stages, "prepare_s": round(t_prep, 2),
                   "runs": out, "pairs_per_s_gpu": max(r["pairs"] / r["gpu_s"] for r in out.values()),
-                  # pairs and bytes of every run; the checksum of the first 48000 blocks among the runs that have a call ending there
-                  "batching_invariant": len({(r["pairs"], r["fastq_bytes"]) for r in out.values()}) == 1 and
-                  len({r["sha256_first_48000_blocks"] for name, r in out.items() if 48000 % int(name.split("_")[1]) == 0} or {""}) == 1}))
+                  # pairs and bytes of every run, and the checksum of the text up to the border all batchings share
+                  "batching_invariant": len({(r["pairs"], r["fastq_bytes"], r["sha256_first_blocks"]["r1:r2"]) for r in out.values()}) == 1}))
