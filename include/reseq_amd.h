@@ -119,6 +119,11 @@ int rsq_ref_get_codes(const rsq_ref *r, uint32_t seq, uint8_t *out, uint32_t len
  *      (`ref` may be NULL for the error-model-only mode).  The profile and reference may be freed afterwards. */
 int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim **out);
 void rsq_sim_free(rsq_sim *s);
+/* A simulator reads the option switches (rsq_set_option) from the copy it took when it was created.  rsq_sim_take_options copies them again, by the thread that
+ * drives the simulator: for a caller that changes a call-shaping switch (overlap, job_chunk_bytes, job_write_direct, host_gzip, fill_waves, the pre-pass switches)
+ * between the calls of one simulator.  What was decided at creation -- the packed tables and the compiled kernel: fill_mode, image_tiles, rate_rows,
+ * min_quality_quads, specialize -- stays. */
+int rsq_sim_take_options(rsq_sim *s);
 
 /* Reference::ReferenceSequence (reseq/Reference.cpp:483-496 plain, :498-567 with variants; reseq/Reference.h) as the kernels compute it on the device: the
  * `frag_length` bases of `allele` that start at `start_pos` (reversed: the reverse complement of those that END in front of `start_pos`), beginning

@@ -70,6 +70,7 @@ SYMBOLS = {
     "rsq_ref_get_codes": (C.c_int, [_vp, _u32, _vp, _u32]),
     "rsq_sim_create": (C.c_int, [_vp, _vp, C.c_int, _pp]),
     "rsq_sim_free": (None, [_vp]),
+    "rsq_sim_take_options": (C.c_int, [_vp]),
     "rsq_sim_prepare": (C.c_int, [_vp, _u64, _u64, C.c_double, C.c_int, C.c_char_p, _vp]),
     "rsq_sim_prepare_plan": (C.c_int, [_vp, _u64, _u64, C.c_double, C.c_int, C.c_char_p]),
     "rsq_sim_bias_partials": (C.c_int, [_vp, _u32, _u32, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
@@ -427,6 +428,10 @@ class Simulator:
         out = np.zeros(n.value, np.uint32)
         _check(lib().rsq_sim_get_sequence_lengths(self.h, out.ctypes.data, out.size, C.byref(n)))
         return [int(x) for x in out]
+
+    def take_options(self):
+        """the option switches as they stand now (a simulator otherwise keeps the copy it took when it was created)"""
+        _check(lib().rsq_sim_take_options(self.h))
 
     def block_weights(self):
         n = _u32(0)

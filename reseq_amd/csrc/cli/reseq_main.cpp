@@ -281,7 +281,7 @@ struct AsyncOut {
                 if (!check(rsq_host_alloc(kChunk, &buf[k]), "host buffer")) return false;
                 cap[k] = kChunk;
             }
-            if (!check(rsq_dev_download(0, buf[k], static_cast<const char *>(d.p) + done, n), "download")) return false;
+            if (!check(rsq_dev_download(d.device, buf[k], static_cast<const char *>(d.p) + done, n), "download")) return false;
             {
                 std::lock_guard<std::mutex> lock(m);
                 len[k] = n;
@@ -595,7 +595,9 @@ int illumina_pe(const Args &a) {
         rsq_profile_free(prof);
         return rc;
     }
-    ok = ok && check(rsq_sim_create(prof, ref, 0, &sim), "Could not set up the simulator");
+    uint64_t device = 0;                                         // --device D: the one worker's device (with --gpus N the workers take devices 0 .. N - 1)
+    if (ok && a.has("device")) ok = parse_u64(a, "device", device);
+    ok = ok && check(rsq_sim_create(prof, ref, (int)device, &sim), "Could not set up the simulator");
     trace.at("simulator created");
     if (ok && !sys_write.empty()) {
         INFO("Writing systematic error profile to " << sys_write);
@@ -654,6 +656,7 @@ int illumina_pe(const Args &a) {
         INFO("Aiming for " << info.total_pairs + info.adapter_only_pairs << " read pairs");
         INFO("Starting read generation");
         DevBuffer d1, d2, g1, g2;
+        d1.device = d2.device = g1.device = g2.device = (int)device;
         uint64_t written = 0;
         // a call's text of one file as members in `g`: true and the members' size, or false
         auto members = [&](bool gz, DevBuffer &d, size_t &len, DevBuffer &g) {
@@ -720,7 +723,9 @@ int seq_to_illumina(const Args &a) {
     bool ok = load_profile(a, &prof);
     const double at_profile = seconds_since(g_process_start);
     const uint64_t seed = ok ? get_seed(a) : 0;
-    ok = ok && check(rsq_sim_create(prof, nullptr, 0, &sim), "Could not set up the simulator") &&
+    uint64_t device = 0;                                         // --device D
+    if (ok && a.has("device")) ok = parse_u64(a, "device", device);
+    ok = ok && check(rsq_sim_create(prof, nullptr, (int)device, &sim), "Could not set up the simulator") &&
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
     const double at_prepared = seconds_since(g_process_start);
     if (ok) {
@@ -774,7 +779,7 @@ const char *kUsage =
     "  seqToIllumina\t\tapplies illumina quality and error model to input sequences (alias: replaceQuals)\n"
     "                 \t-i in.fa[.gz|.bz2] (stdin) -o out.fq[.gz|.bz2] (stdout) -s profile; --readThreads N, --traceStages;\n"
     "                 \t--inputFrom / --inputTo BYTE, --firstRecord K: a share of a plain input (python -m reseq_amd.simulate seqToIllumina works them out)\n"
-    "                 \t--gpus N: N workers in this process, worker r on device r % devices, the files byte for byte the single-device run's\n"
+    "                 \t--gpus N: N workers in this process, worker r on device r % devices, the files byte for byte the single-device run's; --device D: the one worker's device\n"
     "Outputs named *.gz are compressed on the GPU (gzip members framed as BGZF blocks; about 15 % larger than zlib level 1, 33 % larger than level 6);\n"
     "         --hostGzip compresses them with zlib on host threads instead (smaller files, a fraction of the speed).\n"
     "General: -j/--threads N (illuminaPE: as many workers as asked for, at most one per device; else ignored: the GPU does the work),\n"

@@ -1462,6 +1462,14 @@ int rsq_sim_create(const rsq_profile *p, const rsq_ref *ref, int device, rsq_sim
     if (rc == RSQ_OK) *out = s.release();
     return rc;
 }
+// the switches again, as they stand now (a simulator otherwise keeps the copy it took when it was created): for a caller that changes a call-shaping switch --
+// overlap, job_chunk_bytes, job_write_direct, host_gzip, fill_waves, the pre-pass switches -- between the calls of ONE simulator.  What was decided when the
+// simulator was created (fill_mode, image_tiles, rate_rows, min_quality_quads, specialize: the packed tables and the compiled kernel) stays.
+int rsq_sim_take_options(rsq_sim *s) {
+    REQUIRE(s, "null argument");
+    s->opt = options();
+    return RSQ_OK;
+}
 void rsq_sim_free(rsq_sim *s) {
     if (s) {
         (void)hipSetDevice(s->device);

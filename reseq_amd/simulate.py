@@ -55,6 +55,13 @@ def _check_backend(a, ap, hooks):
         print(hooks.banner, file=sys.stderr)
 
 
+def _torch_first(hooks):
+    """PyTorch before the library: both bring a HIP runtime, and the process must settle on the one torch.distributed (RCCL) and the tensors of the small exchanges
+    use -- libreseq_amd.so then binds to the runtime that is loaded.  The other order leaves torch without devices ("No HIP GPUs are available")."""
+    if not hooks.on_cpu:
+        import torch  # noqa: F401
+
+
 def _device_of(a, local_rank, hooks):
     """the HIP device of this rank"""
     if hooks.on_cpu:
@@ -518,6 +525,7 @@ def main_records(argv, hooks=Hooks):
         ap.error(f"{a.output}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
     _check_profile_flags(a, ap)
     _check_backend(a, ap, hooks)
+    _torch_first(hooks)
     from . import api
     dist, device = _start_ranks(a, local_rank, hooks)
     seed = _broadcast_seed(a, dist, device)
@@ -605,6 +613,7 @@ def main(argv=None, hooks=Hooks):
     for out in (a.out1, a.out2):
         if out.endswith(".bz2"):
             ap.error(f"{out}: bzip2 output is not supported by the multi-GPU launcher (write .gz or plain FASTQ)")
+    _torch_first(hooks)
     dist, device = _start_ranks(a, local_rank, hooks)
     seed = _broadcast_seed(a, dist, device)
     if hooks.make_backend:

@@ -503,6 +503,11 @@ def test_reseq_illumina_pe_on_several_workers_in_one_process(job):
     want_workers = min(16, _devices())
     assert (f"Simulating with {want_workers} workers" in r.stderr) == (want_workers > 1)
     assert [open(o, "rb").read() for o in out] == plain
+    # --device D: the one worker's device
+    r, out = _cli_pe(job, "device0_plain", ["--device", _devices() - 1])
+    assert [open(o, "rb").read() for o in out] == plain
+    r, out = _cli_pe(job, "device_none", ["--device", 4096], check=False)
+    assert r.returncode != 0 and "device index out of range" in r.stderr
     # refused: --gpus 0, a .bz2 output with several workers; a worker's failure ends the command and leaves no output behind
     r, out = _cli_pe(job, "workers0", ["--gpus", 0], check=False)
     assert r.returncode != 0 and "gpus must be between 1 and 1024." in r.stderr

@@ -235,6 +235,7 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
     for chunk_bytes, batch, threads, direct in ((0, 0, 0, 0), (30_000, 2, 3, 0), (5_000, 1, 5, 0), (30_000, 2, 2, 1), (0, 0, 1, 1)):
         rsq_options("job_chunk_bytes", chunk_bytes)
         rsq_options("job_write_direct", direct)                               # whole 4 KB blocks around the page cache where the file system allows it, head and tail buffered
+        b.sim.take_options()                                                  # (a simulator keeps the switches it was created with until told otherwise)
         n, n1, n2 = b.sim.job_generate(lo, hi, batch)
         assert (n, n1, n2) == (len(frags), len(t1), len(t2))
         f1, f2 = workdir / "job_1.fq", workdir / "job_2.fq"
@@ -253,6 +254,7 @@ def test_job_text_kept_on_the_device_and_written_in_place(workdir, rsq_options):
     rsq_options("job_write_direct", 0)
     for host_gzip in (0, 1):
         rsq_options("host_gzip", host_gzip)
+        b.sim.take_options()
         b.sim.job_generate(lo, hi, 2)
         c1, c2 = b.sim.job_compress()
         assert 0 < c1 < len(t1) // 2 and 0 < c2 < len(t2) // 2

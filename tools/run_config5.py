@@ -94,6 +94,7 @@ if "prepare_sweep" in sys.argv[2:]:
         chunk, warmup = (int(v) for v in combo.split(":"))
         api.set_option("chain_chunk", chunk)
         api.set_option("chain_warmup", warmup)
+        sim.take_options()
         t0 = time.perf_counter()
         sim.prepare(7, 0, 30.0)
         print(json.dumps({"chain_chunk": chunk, "chain_warmup": warmup, "prepare_s": round(time.perf_counter() - t0, 3)}), flush=True)
