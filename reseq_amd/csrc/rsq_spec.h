@@ -45,10 +45,13 @@ struct Hiprtc {                                   // the few entry points, bound
     int (*version)(int *, int *) = nullptr;
     bool ok = false;
     std::string path;                             // the file the entry points came from (dladdr), for rsq_sim_specialize's note
-    // ONE compiler whatever the process has loaded before: the system ROCm's libhiprtc by its full path first.  By name alone a Python process that has imported
-    // PyTorch finds the wheel's copy (another ROCm release: another register allocation of the same sources, the read kernel 3 % faster or slower), a process under
-    // rocprofv3 or without PyTorch the system's -- the product's speed then depended on what had been imported first.  Option hiprtc_by_name 1
-    // restores the search by name (measurements of exactly that difference).
+    std::string comgr;                            // ... and the code generator behind it: the libamd_comgr that libhiprtc's own lookups find
+    // The system ROCm's libhiprtc by its full path first: by name a Python process that has imported PyTorch finds the wheel's copy, a process under rocprofv3 or
+    // without PyTorch the system's (option hiprtc_by_name 1 restores that search).  That pins the front end only.  The code generator is libamd_comgr, which
+    // libhiprtc needs by its soname -- and a process that has imported PyTorch has the wheel's copy loaded under that soname already, so the loader hands it to the
+    // system's libhiprtc as well (measured: 28 spilled registers in the variant kernel from the wheel's ROCm 7.0 code generator, 43 from the system's 7.2; 8 % of the
+    // variant path, nothing of the plain one).  Which copy compiled a kernel is therefore recorded (note, bench line) and part of the cache key, not forced: the
+    // command line and every process without PyTorch get the system's.
     static const Hiprtc &get() {
         static Hiprtc h = [] {
             Hiprtc r;
@@ -70,6 +73,11 @@ struct Hiprtc {                                   // the few entry points, bound
                 char real[4096];
                 r.path = realpath(info.dli_fname, real) ? real : info.dli_fname;
             }
+            if (void *sym = r.ok ? dlsym(lib, "amd_comgr_get_version") : nullptr)       // looked up the way libhiprtc's own references are: through its dependencies
+                if (dladdr(sym, &info) && info.dli_fname) {
+                    char real[4096];
+                    r.comgr = realpath(info.dli_fname, real) ? real : info.dli_fname;
+                }
             return r;
         }();
         return h;
@@ -186,6 +194,7 @@ inline bool spec_compile(const DevSim &dev, const SpecVariant &v, const std::str
     for (const char *src : headers) h = fnv1a(src, strlen(src), h);
     h = fnv1a(&out.rtc_major, sizeof(int), fnv1a(&out.rtc_minor, sizeof(int), h));
     h = fnv1a(rtc.path.data(), rtc.path.size(), h);                   // two copies of libhiprtc that report one version are still two compilers
+    h = fnv1a(rtc.comgr.data(), rtc.comgr.size(), h);                 // ... and so are two code generators behind one libhiprtc
     char name[64];
     snprintf(name, sizeof name, "/%s_%016llx.hsaco", spec_kernel_name(v.kind), (unsigned long long)h);
     const std::string dir = spec_cache_dir();
@@ -295,9 +304,9 @@ class SpecKernels {
             note = "loading the read kernel compiled for this profile failed: the library's own instantiation runs instead";
             return;
         }
-        char buf[512];
-        snprintf(buf, sizeof buf, "%s compiled for this profile (%s, hiprtc %d.%d of %s, %s)", spec_kernel_name(v.kind), arch.c_str(), c.rtc_major, c.rtc_minor,
-                 Hiprtc::get().path.empty() ? "an unnamed file" : Hiprtc::get().path.c_str(),
+        char buf[1024];
+        snprintf(buf, sizeof buf, "%s compiled for this profile (%s, hiprtc %d.%d of %s, code generator %s, %s)", spec_kernel_name(v.kind), arch.c_str(), c.rtc_major, c.rtc_minor,
+                 Hiprtc::get().path.empty() ? "an unnamed file" : Hiprtc::get().path.c_str(), Hiprtc::get().comgr.empty() ? "unknown" : Hiprtc::get().comgr.c_str(),
                  c.from_cache ? "code object from the kernel cache" : (std::to_string((int)(c.seconds * 1000)) + " ms").c_str());
         note = buf;
     }
