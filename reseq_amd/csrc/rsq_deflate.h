@@ -27,8 +27,11 @@
 // Round 5's kernel searched and probed every position of every line with a four-byte key and measured a match in the walk, twice: 90 GB/s, 2.75 x.  What made the
 // difference (tools/micro/gzip_bench.hip, clocks per phase): the walks no longer read LDS text in divergent loops, the found array is an eighth (four workgroups
 // per CU), x^(8 len) is a constant instead of 44 multiplications per thread, a fifth of the probes; the six-byte key found the better candidates.
-// Text with a handful of quality values and short reads (the test profile TINY) is where this costs size: 1.29 x zlib level 1 (round 5's kernel: about 1.05 x) --
-// its short repeats fall between the probes.  zlib on host threads (option host_gzip, `reseq --hostGzip`) remains for whoever wants the smallest file.
+// Text with a handful of quality values and short reads (the test profile TINY) repeats in short stretches everywhere, which fall between the probes of that rule (1.29 x
+// zlib level 1).  The call's sample is therefore walked a second way -- the DENSE route, template parameter STEP = kDenseStep: every position of every line searched
+// and probed, a four-byte key, which is round 5's search in this round's kernel -- and gz::dense_pays prices both samples with their own codes: the dense route is taken
+// where it makes the sample more than 5 % smaller (TINY: 1.07 x zlib level 1 at 94 GB/s; P0's text stays with the lines: forced dense it gives round 5's bytes exactly,
+// 1.156 x, at 93 GB/s).  zlib on host threads (option host_gzip, `reseq --hostGzip`) remains for whoever wants the smallest file.
 //
 // The per-thread functions are host/device code: tests/hostemu runs the same walk on the CPU against zlib's inflate.
 #pragma once
@@ -56,7 +59,8 @@ constexpr uint32_t kMaxDist = 2048;               // how far back a match may re
 constexpr uint32_t kOutWords = 2048;              // words of the round's bit buffer in LDS: 8 bits per byte of the round -- a round that needs more is not worth coding
 static_assert(kSeg == 32 && kMaxDist <= kRing - kRound - kAhead - 16u, "the packed match and the ring");
 constexpr uint32_t kMinRun = 4;                    // shortest run taken as a match one byte back in a line that is not searched ("FASTQ text by its lines" below)
-constexpr uint32_t kProbeStep = 4;                 // every so many positions of a searched line are probed
+constexpr uint32_t kProbeStep = 4;                 // every so many positions of a searched line are probed ...
+constexpr uint32_t kDenseStep = 1;                 // ... or, for text with little to tell its symbols apart (dense_pays), every position of every line, with a four-byte key
 static_assert(kSeg % (2u * kProbeStep) == 0, "a segment's entries of the found array fill whole words");
 constexpr uint32_t kHeaderBytes = 18, kTrailerBytes = 8;
 constexpr uint32_t kSlot = 65536 + 64;             // bytes of a member's slot: a stored piece needs kPiece + 5 + header + trailer
@@ -71,6 +75,7 @@ struct Codes {
     uint32_t dist[kDist];
     uint32_t header_bits;
     uint32_t header[kHeaderWords];     // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, the code length code, the code lengths -- LSB first
+    uint32_t dense;                    // the code was built for (and the pieces are to be walked by) the dense route: kDenseStep
 };
 
 RSQ_HD uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32u - kHashBits); }
@@ -156,8 +161,9 @@ RSQ_HD Sym distance_symbol(uint32_t dist) {
 // `text` = its 32 bytes, n = how many of them exist (the piece's last segment).  A match that would leave the segment is cut (a cut below three bytes becomes
 // literals).  The loop is unrolled: every position reads its match and byte out of a register by constant shifts; what a position does depends on `skip`, the bytes
 // a match before it still covers.
-struct Segment {
-    uint32_t found[kSeg / kProbeStep / 2u], text[kSeg / 4u];      // the probed positions' entries (found_at), the bytes
+template <uint32_t STEP>
+struct SegmentT {
+    uint32_t found[kSeg / STEP / 2u], text[kSeg / 4u];      // the probed positions' entries (found_at), the bytes
     uint32_t kind;                       // bit i: position i lies in a line that is searched for matches (line_kinds); else only runs of its own bytes count
     uint32_t eq;                         // bit i (i >= 1): byte i equals byte i - 1 of the segment
 };
@@ -245,13 +251,14 @@ RSQ_HD uint32_t probe(const Text &text, uint32_t n, uint32_t round_lo, uint32_t 
 }
 // what position i of a segment finds: its own entry if it is probed, else what is left of the entry of the probed position before it.  found: the segment's
 // kSeg / kProbeStep entries, two per word.  (length, distance); length 0 = nothing
+template <uint32_t STEP>
 RSQ_HD void found_at(const uint32_t *found, uint32_t i, uint32_t &len, uint32_t &dist) {
-    const uint32_t j = i / kProbeStep, k = i % kProbeStep, e = (found[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu, parent = e ? (e >> 11) + 2u : 0u;
+    const uint32_t j = i / STEP, k = i % STEP, e = (found[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu, parent = e ? (e >> 11) + 2u : 0u;
     len = parent >= kMinMatch + k ? parent - k : 0u;
     dist = (e & 2047u) + 1u;
 }
-template <class Sink>
-RSQ_HD void walk_segment(const Segment &g, uint32_t n, Sink &sink) {
+template <uint32_t STEP, class Sink>
+RSQ_HD void walk_segment(const SegmentT<STEP> &g, uint32_t n, Sink &sink) {
     uint32_t skip = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -261,7 +268,7 @@ RSQ_HD void walk_segment(const Segment &g, uint32_t n, Sink &sink) {
         const bool searched = (g.kind >> i) & 1u;
         const uint32_t run = i ? count_trailing_zeros(~(g.eq >> i)) : 0u;             // bytes from i on that equal byte i - 1
         uint32_t len, dist;
-        found_at(g.found, i, len, dist);
+        found_at<STEP>(g.found, i, len, dist);
         if (!searched) len = run >= kMinRun ? run : 0u, dist = 1u;
         if (i + len > n) len = n > i ? n - i : 0u;
         const bool here = skip == 0u && i < n, is_match = len >= kMinMatch;
@@ -446,23 +453,6 @@ __device__ inline void ring_load(RSQ_LDS uint8_t *ring, const uint8_t *t, uint32
     } else
         for (uint32_t p = lo + tid; p < hi; p += kThreads) ring[p & (kRing - 1u)] = t[p];
 }
-// the thread's segment of the round out of LDS into registers: 32 packed matches, 32 bytes of text (both on 16-byte boundaries)
-__device__ inline Segment load_segment(const RSQ_LDS uint16_t *found, const RSQ_LDS uint8_t *ring, uint32_t round_lo, uint32_t lo) {
-    Segment g;
-    const RSQ_LDS uint4 *f = reinterpret_cast<const RSQ_LDS uint4 *>(found + (lo - round_lo));
-    const RSQ_LDS uint4 *t = reinterpret_cast<const RSQ_LDS uint4 *>(ring + (lo & (kRing - 1u)));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4 v = f[k];
-        g.found[4 * k] = v.x, g.found[4 * k + 1] = v.y, g.found[4 * k + 2] = v.z, g.found[4 * k + 3] = v.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const uint4 v = t[k];
-        g.text[4 * k] = v.x, g.text[4 * k + 1] = v.y, g.text[4 * k + 2] = v.z, g.text[4 * k + 3] = v.w;
-    }
-    return g;
-}
 // The bits of `total` more bits stand in the round's buffer from bit `frac` (< 32) on: its complete words go to the member's data (coalesced), the buffer is zeroed
 // and the last, incomplete word moves to its front.  Returns the number of words written.  All threads; barriers inside.
 __device__ inline uint32_t flush_round(RSQ_LDS uint32_t *out, uint32_t *words, uint32_t word_base, uint32_t frac, uint32_t total, bool all) {
@@ -489,14 +479,14 @@ __device__ inline uint32_t flush_round(RSQ_LDS uint32_t *out, uint32_t *words, u
 #else
 #define RSQ_GZ_MARK(phase)
 #endif
-template <bool SAMPLE>
+template <bool SAMPLE, uint32_t STEP = kProbeStep>     // STEP = kProbeStep: FASTQ by its lines; kDenseStep: every position of every line searched and probed, a four-byte key
 __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, uint64_t n, uint32_t piece_step, const Codes *codes, uint8_t *slots, uint32_t *sizes, uint32_t *hist) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing + 16u];
-    __shared__ __attribute__((aligned(16))) uint16_t s_found[kRound / kProbeStep];      // an entry per probed position
+    __shared__ __attribute__((aligned(16))) uint16_t s_found[kRound / STEP];      // an entry per probed position
     __shared__ uint32_t head[1u << kHashBits];
     __shared__ uint32_t s_out[SAMPLE ? 1u : kOutWords + 2u], s_litlen[SAMPLE ? 1u : kLitLen], s_dist[SAMPLE ? 1u : kDist], s_hist[SAMPLE ? kLitLen + kDist : 1u];
     __shared__ uint32_t s_part[kThreads], s_wave[kThreads / 64u], s_kind[kThreads];
-    __shared__ uint16_t s_list[SAMPLE ? kRound / kProbeStep : 1u];      // the positions to probe: in the sample kernel an array of its own, else inside the round's bit buffer
+    __shared__ uint16_t s_list[SAMPLE && STEP > 1u ? kRound / STEP : 1u];      // the positions to probe: in the sample kernel an array of its own, else inside the round's bit buffer (dense: every position, no list)
     const uint32_t tid = threadIdx.x;
     const uint64_t piece = (uint64_t)blockIdx.x * piece_step;
     const uint8_t *t = text + piece * kPiece;
@@ -508,7 +498,7 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
     RSQ_LDS uint32_t *out = (RSQ_LDS uint32_t *)s_out;
     const RSQ_LDS uint32_t *litlen = (const RSQ_LDS uint32_t *)s_litlen, *dist = (const RSQ_LDS uint32_t *)s_dist;
     const RingText rt{ring};
-    static_assert(kRound / kProbeStep <= 2u * kOutWords, "the probe list fits the round's bit buffer behind its first word");
+    static_assert(STEP == 1u || kRound / STEP <= 2u * kOutWords, "the probe list fits the round's bit buffer behind its first word");
     RSQ_LDS uint16_t *list = SAMPLE ? (RSQ_LDS uint16_t *)s_list : reinterpret_cast<RSQ_LDS uint16_t *>(out + 1);
     uint32_t line_state = kLineStateAtStart, n_probes = 0;                 // the same in every thread
 #if defined(RSQ_GZ_TRACE)
@@ -542,7 +532,7 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
         // ---- the lines of the round: which positions of the thread's segment are searched (the state in front of it: a scan of the segments' tables over the workgroup),
         // the bytes that repeat their predecessor, and the list of the positions to probe
         const uint32_t lo = round_lo + tid * kSeg, n_seg = lo >= round_hi ? 0u : (round_hi - lo < kSeg ? round_hi - lo : kSeg);
-        Segment g;
+        SegmentT<STEP> g;
         {
             const RSQ_LDS uint4 *t16 = reinterpret_cast<const RSQ_LDS uint4 *>(ring + (lo & (kRing - 1u)));
 #pragma unroll
@@ -551,7 +541,11 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
                 g.text[4 * k] = v.x, g.text[4 * k + 1] = v.y, g.text[4 * k + 2] = v.z, g.text[4 * k + 3] = v.w;
             }
         }
-        {
+        if constexpr (STEP == 1u) {                                          // dense: every position is searched and probed
+            g.kind = n_seg >= kSeg ? 0xFFFFFFFFu : (1u << n_seg) - 1u;
+            g.eq = 0u;
+            n_probes = round_hi - round_lo;
+        } else {
             const uint32_t valid = n_seg >= kSeg ? 0xFFFFFFFFu : (1u << n_seg) - 1u;
             const uint32_t starts = ((bytes_equal_to(g.text, '\n') << 1) | (lo && n_seg && rt.byte(lo - 1u) == '\n' ? 1u : 0u)) & valid, at = bytes_equal_to(g.text, '@');
             uint32_t incl = line_transfer(starts, at);                     // of the segments up to and including this one, within the wave
@@ -595,25 +589,29 @@ __global__ void __launch_bounds__(kThreads) k_gzip_pieces(const uint8_t *text, u
         // entered is its candidate, kept as a distance (for the probed positions: the others inherit)
         for (uint32_t group = round_lo; group < round_hi; group += kThreads) {
             const uint32_t p = group + tid, rel = p - round_lo;
-            const bool hashed = p + 4u <= len && ((s_kind[rel / kSeg] >> (rel % kSeg)) & 1u);      // (bytes behind the piece's end may be anything: they are never counted)
-            const uint32_t h = hashed ? hash6(rt.word(p), rt.word(p + 4u)) : 0u, cand = hashed ? head[h] : 0u;
+            const bool hashed = p + 4u <= len && (STEP == 1u || ((s_kind[rel / kSeg] >> (rel % kSeg)) & 1u));      // (bytes behind the piece's end may be anything: they are never counted)
+            const uint32_t h = hashed ? (STEP == 1u ? hash4(rt.word(p)) : hash6(rt.word(p), rt.word(p + 4u))) : 0u, cand = hashed ? head[h] : 0u;
             __syncthreads();
             if (hashed) atomicMax(&head[h], p + 1u);
-            if (p % kProbeStep == 0u) found[rel / kProbeStep] = (uint16_t)(cand && p + 1u - cand <= kMaxDist ? p + 1u - cand : 0u);
+            if (p % STEP == 0u && rel < kRound) found[rel / STEP] = (uint16_t)(cand && p + 1u - cand <= kMaxDist ? p + 1u - cand : 0u);
             __syncthreads();
         }
         RSQ_GZ_MARK(2);
         // ---- phase A2: the probes, a thread each (all lanes at work), and what the positions behind them inherit
         for (uint32_t k = tid; k < n_probes; k += kThreads) {
-            const uint32_t rel = list[k];
-            found[rel / kProbeStep] = (uint16_t)probe(rt, len, round_lo, round_lo + rel, found[rel / kProbeStep]);
+            const uint32_t rel = STEP == 1u ? k : list[k];
+            found[rel / STEP] = (uint16_t)probe(rt, len, round_lo, round_lo + rel, found[rel / STEP]);
         }
         __syncthreads();
-        if (!SAMPLE)                                                       // the list stood in the round's bit buffer (behind its first word): zero again
+        if (!SAMPLE && STEP > 1u)                                          // the list stood in the round's bit buffer (behind its first word): zero again
             for (uint32_t w = 1u + tid; w < 2u + n_probes / 2u; w += kThreads) out[w] = 0u;
         {
-            const uint4 v = *reinterpret_cast<const RSQ_LDS uint4 *>(found + (lo - round_lo) / kProbeStep);
-            g.found[0] = v.x, g.found[1] = v.y, g.found[2] = v.z, g.found[3] = v.w;
+            const RSQ_LDS uint4 *f16 = reinterpret_cast<const RSQ_LDS uint4 *>(found + (lo - round_lo) / STEP);
+#pragma unroll
+            for (uint32_t k = 0; k < kSeg / STEP / 8u; ++k) {
+                const uint4 v = f16[k];
+                g.found[4 * k] = v.x, g.found[4 * k + 1] = v.y, g.found[4 * k + 2] = v.z, g.found[4 * k + 3] = v.w;
+            }
         }
         __syncthreads();                                                   // (the buffer is zero before anybody's bits go in)
         RSQ_GZ_MARK(3);
@@ -716,6 +714,7 @@ __global__ void __launch_bounds__(256) k_gzip_compact(const uint8_t *slots, cons
 }  // namespace gz
 }  // namespace rsq
 #include <algorithm>
+#include <cmath>
 #include <stdexcept>
 #include <vector>
 namespace rsq {
@@ -873,9 +872,10 @@ inline Codes build_codes(const uint32_t *sample) {
 // ---------------------------------------------------------------------------------------- host: a piece, thread by thread (tests/hostemu)
 // The device's walk with the workgroup's threads taken one after the other: `hist` != nullptr counts the piece's symbols (the sample), else the member is written
 // to out (kSlot bytes, zeroed here); returns the member's size, 0 where the device gives the piece up (a round's bits beyond its buffer, or no smaller than stored).
-inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *codes, uint8_t *out, uint32_t *hist) {
+template <uint32_t STEP>
+inline uint32_t piece_on_the_host_t(const uint8_t *text, uint32_t n, const Codes *codes, uint8_t *out, uint32_t *hist) {
     std::vector<uint32_t> head((size_t)1 << kHashBits, 0);
-    std::vector<uint16_t> found(kRound / kProbeStep);
+    std::vector<uint16_t> found(kRound / STEP);
     std::vector<uint32_t> data((size_t)kSlotWords + kOutWords + 4, 0);      // the deflate data, all of it in one buffer of bits
     struct Or {
         uint32_t *words;
@@ -900,7 +900,7 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
             for (uint32_t i = 0; i < kSeg && lo + i < n; ++i) words[i >> 2] |= (uint32_t)text[lo + i] << ((i & 3u) * 8u);
             const uint32_t valid = lo >= round_hi ? 0u : (round_hi - lo >= kSeg ? 0xFFFFFFFFu : (1u << (round_hi - lo)) - 1u);
             const uint32_t starts = ((bytes_equal_to(words, '\n') << 1) | (lo && lo < round_hi && text[lo - 1u] == '\n' ? 1u : 0u)) & valid, at = bytes_equal_to(words, '@');
-            kinds[t] = line_kinds(line_state, starts, at) & valid;
+            kinds[t] = (STEP == 1u ? 0xFFFFFFFFu : line_kinds(line_state, starts, at)) & valid;
             eqs[t] = bytes_equal_to_previous(words);
             line_state = line_apply(line_transfer(starts, at), line_state);
         }
@@ -909,7 +909,7 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
         for (uint32_t group = round_lo; group < round_hi; group += kThreads) {
             uint32_t cand[kThreads];
             auto searched = [&](uint32_t p) { return p < round_hi && ((kinds[(p - round_lo) / kSeg] >> ((p - round_lo) % kSeg)) & 1u) && p + 4u <= n; };
-            auto hash_at = [&](uint32_t p) { return hash6(load4(text + p), pt.word(p + 4u)); };
+            auto hash_at = [&](uint32_t p) { return STEP == 1u ? hash4(load4(text + p)) : hash6(load4(text + p), pt.word(p + 4u)); };
             for (uint32_t t = 0; t < kThreads; ++t) cand[t] = searched(group + t) ? head[hash_at(group + t)] : 0u;
             for (uint32_t t = 0; t < kThreads; ++t)
                 if (searched(group + t)) {
@@ -918,27 +918,27 @@ inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *
                 }
             for (uint32_t t = 0; t < kThreads; ++t) {
                 const uint32_t p = group + t;
-                if (p < round_hi && p % kProbeStep == 0u) found[(p - round_lo) / kProbeStep] = (uint16_t)(cand[t] && p + 1u - cand[t] <= kMaxDist ? p + 1u - cand[t] : 0u);
+                if (p < round_hi && p % STEP == 0u) found[(p - round_lo) / STEP] = (uint16_t)(cand[t] && p + 1u - cand[t] <= kMaxDist ? p + 1u - cand[t] : 0u);
             }
         }
         // phase A2: every kProbeStep-th searched position is probed, the positions behind it inherit
-        for (uint32_t p = round_lo; p < round_hi; p += kProbeStep) {
+        for (uint32_t p = round_lo; p < round_hi; p += STEP) {
             if (!((kinds[(p - round_lo) / kSeg] >> ((p - round_lo) % kSeg)) & 1u)) continue;
-            found[(p - round_lo) / kProbeStep] = (uint16_t)probe(pt, n, round_lo, p, found[(p - round_lo) / kProbeStep]);
+            found[(p - round_lo) / STEP] = (uint16_t)probe(pt, n, round_lo, p, found[(p - round_lo) / STEP]);
         }
         uint32_t round_bits = 0;
-        std::vector<Segment> segs(kThreads);
+        std::vector<SegmentT<STEP>> segs(kThreads);
         std::vector<uint32_t> seg_n(kThreads, 0), seg_bits(kThreads, 0);
         for (uint32_t t = 0; t < kThreads; ++t) {                                            // phase B: the segments into "registers", the counts
             const uint32_t lo = round_lo + t * kSeg;
             seg_n[t] = lo >= round_hi ? 0u : std::min(kSeg, round_hi - lo);
-            Segment &g = segs[t];
+            SegmentT<STEP> &g = segs[t];
             memset(&g, 0, sizeof g);
             g.kind = kinds[t];
             g.eq = eqs[t];
             for (uint32_t i = 0; i < kSeg; ++i)
                 if (lo + i < n) g.text[i >> 2] |= (uint32_t)text[lo + i] << ((i & 3u) * 8u);
-            for (uint32_t j = 0; j < kSeg / kProbeStep; ++j) g.found[j >> 1] |= (uint32_t)found[(lo - round_lo) / kProbeStep + j] << ((j & 1u) * 16u);
+            for (uint32_t j = 0; j < kSeg / STEP; ++j) g.found[j >> 1] |= (uint32_t)found[(lo - round_lo) / STEP + j] << ((j & 1u) * 16u);
             if (hist) {
                 auto add = [hist](uint32_t s) { ++hist[s]; };
                 HistogramSink<decltype(add)> sink{add};
@@ -1010,19 +1010,51 @@ inline uint32_t stored_piece_on_the_host(const uint8_t *text, uint32_t n, uint8_
     }
     return member;
 }
+inline uint32_t piece_on_the_host(const uint8_t *text, uint32_t n, const Codes *codes, uint8_t *out, uint32_t *hist, bool dense = false) {
+    return dense ? piece_on_the_host_t<kDenseStep>(text, n, codes, out, hist) : piece_on_the_host_t<kProbeStep>(text, n, codes, out, hist);
+}
 // which pieces of a call are the sample: at most 64, spread evenly
 inline uint32_t sample_stride(uint64_t n_pieces) { return (uint32_t)std::max<uint64_t>(1, (n_pieces + 63) / 64); }
+// Which route a call takes: the sample is walked both ways and each way's symbol counts are priced with the code built from them (code lengths plus the extra bits of
+// lengths and distances, RFC 1951 3.2.5); the dense route -- every position of every line searched and probed with a four-byte key, half the speed -- is taken where
+// it makes the sample smaller by more than kDenseMustSave.  That is text whose repeats are short and everywhere (a handful of quality values, reads of thirty bases:
+// the test profile TINY, 17 % smaller dense); on P0's text the rule for FASTQ lines gives the smaller sample outright (its six-byte key finds the overlapping reads).
+constexpr double kDenseMustSave = 0.05;
+inline uint64_t sample_bits(const uint32_t *sample, const Codes &codes) {
+    uint64_t bits = 0;
+    for (uint32_t c = 0; c < 286u; ++c) {
+        const uint32_t extra = c < 265u || c == 285u ? 0u : (c - 261u) / 4u;
+        bits += (uint64_t)sample[c] * ((codes.litlen[c] & 15u) + extra);
+    }
+    for (uint32_t d = 0; d < 30u; ++d) bits += (uint64_t)sample[kLitLen + d] * ((codes.dist[d] & 15u) + (d < 4u ? 0u : d / 2u - 1u));
+    return bits;
+}
+inline bool dense_pays(const uint32_t *sample_lines, const uint32_t *sample_dense) {
+    const uint64_t lines = sample_bits(sample_lines, build_codes(sample_lines)), dense = sample_bits(sample_dense, build_codes(sample_dense));
+    return (double)dense < (1.0 - kDenseMustSave) * (double)lines;
+}
 // the whole call on the host (tests/hostemu): text -> members, appended to out
-inline void gzip_on_the_host(const uint8_t *text, uint64_t n, std::vector<uint8_t> &out) {
+inline void gzip_on_the_host(const uint8_t *text, uint64_t n, std::vector<uint8_t> &out, int force_route = -1 /* 0 / 1: FASTQ lines / dense, whatever the sample says */) {
     const uint64_t n_pieces = (n + kPiece - 1) / kPiece;
-    std::vector<uint32_t> hist(kLitLen + kDist, 0);
     const uint32_t stride = sample_stride(n_pieces);
-    for (uint64_t i = 0; i < n_pieces; i += stride) piece_on_the_host(text + i * kPiece, (uint32_t)std::min<uint64_t>(kPiece, n - i * kPiece), nullptr, nullptr, hist.data());
-    const Codes codes = build_codes(hist.data());
+    auto sample = [&](bool dense) {
+        std::vector<uint32_t> hist(kLitLen + kDist, 0);
+        for (uint64_t i = 0; i < n_pieces; i += stride) piece_on_the_host(text + i * kPiece, (uint32_t)std::min<uint64_t>(kPiece, n - i * kPiece), nullptr, nullptr, hist.data(), dense);
+        return hist;
+    };
+    std::vector<uint32_t> hist = sample(force_route == 1);
+    bool dense = force_route == 1;
+    if (force_route < 0) {
+        const std::vector<uint32_t> other = sample(true);
+        dense = dense_pays(hist.data(), other.data());
+        if (dense) hist = other;
+    }
+    Codes codes = build_codes(hist.data());
+    codes.dense = dense ? 1u : 0u;
     std::vector<uint8_t> slot(kSlot);
     for (uint64_t i = 0; i < n_pieces; ++i) {
         const uint32_t len = (uint32_t)std::min<uint64_t>(kPiece, n - i * kPiece);
-        uint32_t member = piece_on_the_host(text + i * kPiece, len, &codes, slot.data(), nullptr);
+        uint32_t member = piece_on_the_host(text + i * kPiece, len, &codes, slot.data(), nullptr, dense);
         if (!member) member = stored_piece_on_the_host(text + i * kPiece, len, slot.data());
         out.insert(out.end(), slot.begin() + kSlotPad, slot.begin() + kSlotPad + member);
     }

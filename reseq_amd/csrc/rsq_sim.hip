@@ -220,6 +220,7 @@ struct rsq_sim : SimState {
         }
     } job;
     DevBuf totals;                 // [sub-ranges + 1][2] bytes of FASTQ text in front of a sub-range, per file
+    bool gz_dense = false;                                 // the route of the code in gz_codes: every position searched and probed (gz::dense_pays), else FASTQ by its lines
     bool gz_keep_code = false, gz_have_code = false;      // rsq_sim_gzip_keep_code: the code of the first call serves the calls after it
     DevBuf gz_slots, gz_sizes, gz_at, gz_hist, gz_codes, gz_total;      // gzip on the device (rsq_deflate.h): the members' slots, their sizes and places, the sample's counts, the call's code
     Workspace *cur = &ws[0];       // the set the stage being enqueued works on
@@ -2080,16 +2081,20 @@ int rsq_sim_job_write(rsq_sim *s, const char *r1_path, uint64_t r1_offset, const
 static void gzip_code_of(rsq_sim &s, const uint8_t *text, size_t n, hipStream_t st) {
     const uint64_t n_pieces = cdiv(n, gz::kPiece);
     const uint32_t stride = gz::sample_stride(n_pieces);
-    s.gz_hist.reserve((gz::kLitLen + gz::kDist) * 4);
+    s.gz_hist.reserve(2 * (gz::kLitLen + gz::kDist) * 4);           // the sample walked both ways: by FASTQ lines, and densely (gz::dense_pays decides)
     s.gz_codes.reserve(sizeof(gz::Codes));
-    HIP_CHECK(hipMemsetAsync(s.gz_hist.as<uint32_t>(), 0, (gz::kLitLen + gz::kDist) * 4, st));
-    hipLaunchKernelGGL(gz::k_gzip_pieces<true>, dim3((uint32_t)cdiv(n_pieces, stride)), dim3(gz::kThreads), 0, st, text, (uint64_t)n, stride, (const gz::Codes *)nullptr, (uint8_t *)nullptr,
-                       (uint32_t *)nullptr, s.gz_hist.as<uint32_t>());
+    uint32_t *lines = s.gz_hist.as<uint32_t>(), *dense = lines + gz::kLitLen + gz::kDist;
+    HIP_CHECK(hipMemsetAsync(lines, 0, 2 * (gz::kLitLen + gz::kDist) * 4, st));
+    const dim3 grid((uint32_t)cdiv(n_pieces, stride)), block(gz::kThreads);
+    hipLaunchKernelGGL((gz::k_gzip_pieces<true, gz::kProbeStep>), grid, block, 0, st, text, (uint64_t)n, stride, (const gz::Codes *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, lines);
+    hipLaunchKernelGGL((gz::k_gzip_pieces<true, gz::kDenseStep>), grid, block, 0, st, text, (uint64_t)n, stride, (const gz::Codes *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, dense);
     HIP_CHECK(hipGetLastError());
-    uint32_t hist[gz::kLitLen + gz::kDist];
-    HIP_CHECK(hipMemcpyAsync(hist, s.gz_hist.as<uint32_t>(), sizeof hist, hipMemcpyDeviceToHost, st));
+    uint32_t hist[2][gz::kLitLen + gz::kDist];
+    HIP_CHECK(hipMemcpyAsync(hist, lines, sizeof hist, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const gz::Codes codes = gz::build_codes(hist);
+    s.gz_dense = gz::dense_pays(hist[0], hist[1]);
+    gz::Codes codes = gz::build_codes(hist[s.gz_dense ? 1 : 0]);
+    codes.dense = s.gz_dense ? 1u : 0u;
     HIP_CHECK(hipMemcpyAsync(s.gz_codes.as<char>(), &codes, sizeof codes, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));                             // `codes` leaves scope
 }
@@ -2116,7 +2121,12 @@ static int gzip_device(rsq_sim &s, const uint8_t *text, size_t n, uint8_t *out, 
         const uint8_t *t = text + first * gz::kPiece;
         const uint64_t bytes = std::min<uint64_t>((uint64_t)pieces * gz::kPiece, n - first * gz::kPiece);
         s.timers["gzip"].start(st);
-        hipLaunchKernelGGL(gz::k_gzip_pieces<false>, dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, 1u, s.gz_codes.as<gz::Codes>(), s.gz_slots.as<uint8_t>(), s.gz_sizes.as<uint32_t>(), (uint32_t *)nullptr);
+        if (s.gz_dense)
+            hipLaunchKernelGGL((gz::k_gzip_pieces<false, gz::kDenseStep>), dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, 1u, s.gz_codes.as<gz::Codes>(), s.gz_slots.as<uint8_t>(),
+                               s.gz_sizes.as<uint32_t>(), (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((gz::k_gzip_pieces<false, gz::kProbeStep>), dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, 1u, s.gz_codes.as<gz::Codes>(), s.gz_slots.as<uint8_t>(),
+                               s.gz_sizes.as<uint32_t>(), (uint32_t *)nullptr);
         hipLaunchKernelGGL(gz::k_gzip_stored, dim3(pieces), dim3(gz::kThreads), 0, st, t, bytes, s.gz_slots.as<uint8_t>(), s.gz_sizes.as<uint32_t>());
         exclusive_scan(s, s.gz_sizes.as<uint32_t>(), pieces, s.gz_at.as<uint64_t>(), st, nullptr, s.gz_total.as<uint64_t>());
         uint64_t stretch_bytes = 0;

@@ -238,7 +238,7 @@ def test_gz_outputs_of_the_command_line_are_made_on_the_device(workdir):
         assert len(plain) > 5 * PIECE and b":0:Adapter:0:" in plain
         assert b"".join(t for _, t in members_of(device)) == plain == gzip.decompress(host)
         assert host[3] == 0 and device[3] == 4                                    # FLG: zlib writes no extra field, the device's members carry BGZF's
-        assert len(device) < 1.6 * len(host)              # TINY's text (30-base reads, five quality values) is the worst case of the device's rule: 1.29 x zlib level 1, 1.55 x level 6 (rsq_deflate.h)
+        assert len(device) < 1.35 * len(host)             # TINY's text (30-base reads, five quality values) takes the dense route (gz::dense_pays): 1.07 x zlib level 1, 1.29 x level 6; by FASTQ lines it would be 1.55 x
     # seqToIllumina from file to file
     arrays = synth.make_profile(synth.TINY, seed=5)
     rec = synth.make_error_model_input(9, 30000, 30, arrays, zero_frac=0.7)

@@ -1,6 +1,6 @@
 // tools/micro/gzip_bench.hip -- the gzip kernels of rsq_deflate.h alone, on a text file: a few seconds to compile where the library takes minutes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I reseq_amd/csrc [-DNAME=...] -o /tmp/gzip_bench tools/micro/gzip_bench.hip -lz
-//   /tmp/gzip_bench text.fq [copies]
+//   /tmp/gzip_bench text.fq [copies [lines|dense]]
 // The text, repeated `copies` times in device memory (default: up to 768 MB), through k_gzip_pieces<true> (sample) -> build_codes -> k_gzip_pieces<false> + k_gzip_stored:
 // kernel time by HIP events, size against zlib levels 1 and 6, the first members inflated by zlib and compared with the text and with the host walk (piece_on_the_host).
 #include <hip/hip_runtime.h>
@@ -57,11 +57,23 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&codes, sizeof(Codes)));
     CHECK(hipMemset(hist, 0, (kLitLen + kDist) * 4));
     const uint32_t stride = sample_stride(n_pieces);
-    hipLaunchKernelGGL(k_gzip_pieces<true>, dim3((n_pieces + stride - 1) / stride), dim3(kThreads), 0, 0, text, n, stride, (const Codes *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, hist);
-    std::vector<uint32_t> h_hist(kLitLen + kDist);
+    uint32_t *hist2 = nullptr;
+    CHECK(hipMalloc(&hist2, (kLitLen + kDist) * 4));
+    CHECK(hipMemset(hist2, 0, (kLitLen + kDist) * 4));
+    hipLaunchKernelGGL((k_gzip_pieces<true, kProbeStep>), dim3((n_pieces + stride - 1) / stride), dim3(kThreads), 0, 0, text, n, stride, (const Codes *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, hist);
+    hipLaunchKernelGGL((k_gzip_pieces<true, kDenseStep>), dim3((n_pieces + stride - 1) / stride), dim3(kThreads), 0, 0, text, n, stride, (const Codes *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, hist2);
+    std::vector<uint32_t> h_hist(kLitLen + kDist), h_hist2(kLitLen + kDist);
     CHECK(hipMemcpy(h_hist.data(), hist, h_hist.size() * 4, hipMemcpyDeviceToHost));
-    const Codes h_codes = build_codes(h_hist.data());
+    CHECK(hipMemcpy(h_hist2.data(), hist2, h_hist2.size() * 4, hipMemcpyDeviceToHost));
+    // the route: what the sample says (dense_pays), or argv[3] = lines | dense
+    const bool dense = argc > 3 ? !strcmp(argv[3], "dense") : dense_pays(h_hist.data(), h_hist2.data());
+    Codes h_codes = build_codes(dense ? h_hist2.data() : h_hist.data());
+    h_codes.dense = dense ? 1u : 0u;
     CHECK(hipMemcpy(codes, &h_codes, sizeof h_codes, hipMemcpyHostToDevice));
+    auto launch = [&](uint32_t *trace) {
+        if (dense) hipLaunchKernelGGL((k_gzip_pieces<false, kDenseStep>), dim3(n_pieces), dim3(kThreads), 0, 0, text, n, 1u, codes, slots, sizes, trace);
+        else hipLaunchKernelGGL((k_gzip_pieces<false, kProbeStep>), dim3(n_pieces), dim3(kThreads), 0, 0, text, n, 1u, codes, slots, sizes, trace);
+    };
     hipEvent_t e0, e1, e2;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -70,7 +82,7 @@ int main(int argc, char **argv) {
     unsigned long long *trace = nullptr;
     CHECK(hipMalloc(&trace, 64));
     CHECK(hipMemset(trace, 0, 64));
-    hipLaunchKernelGGL(k_gzip_pieces<false>, dim3(n_pieces), dim3(kThreads), 0, 0, text, n, 1u, codes, slots, sizes, reinterpret_cast<uint32_t *>(trace));
+    launch(reinterpret_cast<uint32_t *>(trace));
     unsigned long long h_trace[8];
     CHECK(hipMemcpy(h_trace, trace, 64, hipMemcpyDeviceToHost));
     {
@@ -85,7 +97,7 @@ int main(int argc, char **argv) {
     float best = 1e30f, best_stored = 0;
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_gzip_pieces<false>, dim3(n_pieces), dim3(kThreads), 0, 0, text, n, 1u, codes, slots, sizes, (uint32_t *)nullptr);
+        launch(nullptr);
         CHECK(hipEventRecord(e1, 0));
         hipLaunchKernelGGL(k_gzip_stored, dim3(n_pieces), dim3(kThreads), 0, 0, text, n, slots, sizes);
         CHECK(hipEventRecord(e2, 0));
@@ -124,7 +136,7 @@ int main(int argc, char **argv) {
         const int rc = inflate(&z, Z_FINISH);
         const bool ok = rc == Z_STREAM_END && z.total_out == len && !memcmp(back.data(), want.data(), len);
         inflateEnd(&z);
-        uint32_t host_size = piece_on_the_host(want.data(), len, &h_codes, host_slot.data(), nullptr);
+        uint32_t host_size = piece_on_the_host(want.data(), len, &h_codes, host_slot.data(), nullptr, dense);
         if (!host_size) host_size = stored_piece_on_the_host(want.data(), len, host_slot.data());
         const bool same = host_size == size && !memcmp(host_slot.data() + kSlotPad, slot.data() + kSlotPad, size);
         if (!ok || !same) {
@@ -138,8 +150,8 @@ int main(int argc, char **argv) {
     compress2(zbuf.data(), &z1, one.data(), one.size(), 1);
     compress2(zbuf.data(), &z6, one.data(), one.size(), 6);
     printf("{\"text_bytes\": %llu, \"pieces\": %llu, \"kernel_ms\": %.3f, \"stored_kernel_ms\": %.3f, \"gbytes_per_s\": %.1f, \"ms_per_7p5_GB\": %.1f, \"members_bytes\": %llu, \"ratio\": %.3f, "
-           "\"zlib1_ratio\": %.3f, \"zlib6_ratio\": %.3f, \"size_over_zlib1\": %.3f, \"stored_pieces\": %llu, \"checked_pieces_wrong\": %d}\n",
+           "\"zlib1_ratio\": %.3f, \"zlib6_ratio\": %.3f, \"size_over_zlib1\": %.3f, \"stored_pieces\": %llu, \"checked_pieces_wrong\": %d, \"route\": \"%s\"}\n",
            (unsigned long long)n, (unsigned long long)n_pieces, best, best_stored, n / (best * 1e-3) / 1e9, 7.5e9 / (n / (best * 1e-3)) * 1e3, (unsigned long long)total, (double)n / total,
-           (double)one.size() / z1, (double)one.size() / z6, ((double)total / n) / ((double)z1 / one.size()), (unsigned long long)stored, bad);
+           (double)one.size() / z1, (double)one.size() / z6, ((double)total / n) / ((double)z1 / one.size()), (unsigned long long)stored, bad, dense ? "dense" : "lines");
     return bad ? 1 : 0;
 }
