@@ -73,11 +73,23 @@ struct Hiprtc {                                   // the few entry points, bound
                 char real[4096];
                 r.path = realpath(info.dli_fname, real) ? real : info.dli_fname;
             }
-            if (void *sym = r.ok ? dlsym(lib, "amd_comgr_get_version") : nullptr)       // looked up the way libhiprtc's own references are: through its dependencies
-                if (dladdr(sym, &info) && info.dli_fname) {
+            // libhiprtc loads the code generator itself, by its soname, when it first compiles: the copy the process already holds under that name (PyTorch's), else the
+            // one the loader finds -- asked for here the same way, so that its file is known before the first compilation (it is part of the cache key)
+            if (r.ok) {
+                void *comgr = nullptr;
+                for (const char *name : {"libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"}) {
+                    if ((comgr = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+                }
+                if (!comgr)
+                    for (const char *name : {"libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"}) {
+                        if ((comgr = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+                    }
+                void *sym = comgr ? dlsym(comgr, "amd_comgr_get_version") : nullptr;
+                if (sym && dladdr(sym, &info) && info.dli_fname) {
                     char real[4096];
                     r.comgr = realpath(info.dli_fname, real) ? real : info.dli_fname;
                 }
+            }
             return r;
         }();
         return h;
