@@ -715,6 +715,131 @@ int illumina_pe(const Args &a) {
     return 0;
 }
 
+// seqToIllumina on several devices inside one process (the reference's worker threads, Simulator.cpp:2900-3014 with -j): the input -- a plain file -- is cut into the
+// workers' stretches of bytes, a record belongs to the worker in whose stretch it begins (rsq_fasta_count_records; the rule of reseq_amd/sharding.py record_share), its
+// index in the whole input selects its random stream, and every worker keeps its text in device memory until the sizes are known and then writes its byte range of the
+// one output file.  Byte for byte the single worker's file.
+int seq_to_illumina_on_workers(const Args &a, rsq_profile *prof, uint64_t seed, int n_workers, int n_devices, const std::string &input, const std::string &output,
+                               rsq_error_model_file_options base) {
+    struct Share {
+        int device = 0;
+        rsq_sim *sim = nullptr;
+        uint64_t lo = 0, hi = 0, n_starts = 0, first_start = 0, begin = 0, end = 0, first_record = 0, records = 0, bytes = 0;
+        std::string error;
+    };
+    std::vector<Share> w((size_t)n_workers);
+    struct stat st;
+    if (stat(input.c_str(), &st) != 0) {
+        ERR("Could not open '" << input << "' for reading.");
+        return 1;
+    }
+    const uint64_t size = (uint64_t)st.st_size;
+    INFO("Simulating with " << n_workers << " workers on " << std::min(n_workers, n_devices) << " device(s)");
+    auto on_all = [&](auto &&f) {
+        std::vector<std::thread> threads;
+        for (size_t r = 1; r < w.size(); ++r) threads.emplace_back([&, r] { f(r); });
+        f(0);
+        for (std::thread &t : threads) t.join();
+        for (size_t r = 0; r < w.size(); ++r)
+            if (!w[r].error.empty()) {
+                ERR(w[r].error);                                  // the reference's complaint about a record (Simulator.cpp:2423-2485), or what went wrong
+                return false;
+            }
+        return true;
+    };
+    auto fail = [&](size_t r, int rc, const char *what) {
+        if (rc == RSQ_OK) return false;
+        w[r].error = *what ? std::string(what) + ": " + rsq_last_error() : std::string(rsq_last_error());
+        return true;
+    };
+    bool ok = on_all([&](size_t r) {                              // the record starts of every worker's stretch (host code), its simulator meanwhile
+        w[r].device = (int)r % n_devices;
+        w[r].lo = size * r / w.size();
+        w[r].hi = size * (r + 1) / w.size();
+        w[r].first_start = w[r].hi;
+        if (w[r].hi > w[r].lo && fail(r, rsq_fasta_count_records(input.c_str(), w[r].lo, w[r].hi, 0, &w[r].n_starts, &w[r].first_start), "Counting the records")) return;
+        if (fail(r, rsq_sim_create(prof, nullptr, w[r].device, &w[r].sim), "Could not set up the simulator")) return;
+        fail(r, rsq_sim_prepare(w[r].sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
+    });
+    if (ok) {                                                     // the shares: from a worker's first record to the first record of the next worker that has one
+        uint64_t before = 0;
+        for (size_t r = 0; r < w.size(); ++r) {
+            w[r].first_record = before;
+            before += w[r].n_starts;
+            uint64_t end = size;
+            for (size_t k = r + 1; k < w.size(); ++k)
+                if (w[k].n_starts) {
+                    end = w[k].first_start;
+                    break;
+                }
+            w[r].end = end;
+            w[r].begin = r == 0 ? 0 : (w[r].n_starts ? w[r].first_start : end);      // what stands in front of the first record is the first worker's to complain about
+        }
+        INFO("Starting read generation");
+        ok = on_all([&](size_t r) {
+            if (w[r].end <= w[r].begin && r) return;                 // no record begins in this worker's stretch
+            rsq_error_model_file_options opt = base;
+            opt.keep_text = 1;
+            opt.from = w[r].begin;
+            opt.to = w[r].end;
+            opt.first_record = w[r].first_record;
+            opt.progress = nullptr;
+            opt.trace = nullptr;
+            opt.trace_cap = 0;
+            if (w[r].end <= w[r].begin) return;                      // (an empty file: nothing for the first worker either)
+            fail(r, rsq_sim_error_model_file(w[r].sim, input.c_str(), nullptr, &opt, &w[r].records, &w[r].bytes), "");
+        });
+    }
+    const bool gz = rsq::textio::has_suffix(output, ".gz");
+    if (ok && gz)
+        ok = on_all([&](size_t r) {
+            uint64_t none = 0;
+            if (w[r].bytes) fail(r, rsq_sim_job_compress(w[r].sim, &w[r].bytes, &none), "Compressing the output failed");
+        });
+    uint64_t records = 0, total = 0;
+    for (const Share &x : w) records += x.records, total += x.bytes;
+    if (ok && !records) {
+        ERR(input << " does not contain any sequences.");
+        ok = false;
+    }
+    if (ok) {
+        INFO("Generated " << records << " reads.");
+        const int fd = ::open(output.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0 || ftruncate(fd, (off_t)total) != 0) {
+            ERR("Could not open '" << output << "' for writing.");
+            ok = false;
+        }
+        if (fd >= 0) ::close(fd);
+    }
+    if (ok) {
+        std::vector<uint64_t> at(w.size());
+        uint64_t o = 0;
+        for (size_t r = 0; r < w.size(); ++r) at[r] = o, o += w[r].bytes;
+        ok = on_all([&](size_t r) {
+            if (w[r].bytes && fail(r, rsq_sim_job_write(w[r].sim, output.c_str(), at[r], nullptr, 0, 0), "Writing the output failed")) return;
+            if (w[r].bytes) rsq_sim_job_free(w[r].sim);
+        });
+    }
+    int64_t host_gzip = 0;
+    rsq_get_option("host_gzip", &host_gzip);
+    if (ok && gz && !host_gzip) {                                 // a file of device-made members ends with BGZF's end-of-file member
+        char eof[32];
+        const size_t n = rsq_gzip_eof_member(eof, sizeof eof);
+        const int fd = ::open(output.c_str(), O_WRONLY);
+        ok = fd >= 0 && pwrite(fd, eof, n, (off_t)total) == (ssize_t)n;
+        if (fd >= 0) ::close(fd);
+        if (!ok) ERR("Writing the output failed");
+    }
+    for (Share &x : w) rsq_sim_free(x.sim);
+    if (!ok) {
+        ERR("An error occurred in the process: Terminating simulation");
+        remove(output.c_str());
+        return 1;
+    }
+    INFO("Simulation finished succesfully");
+    return 0;
+}
+
 // ---- seqToIllumina (main.cpp:1009-1021, 1131; Simulator::SimulateErrorModelOnly, Simulator.cpp:2900-3014): the library's file-to-file pipeline
 // (rsq_sim_error_model_file: readers at file offsets, the FASTA text parsed on the device, ordered output) with the reference's options and messages
 int seq_to_illumina(const Args &a) {
@@ -725,6 +850,33 @@ int seq_to_illumina(const Args &a) {
     const uint64_t seed = ok ? get_seed(a) : 0;
     uint64_t device = 0;                                         // --device D
     if (ok && a.has("device")) ok = parse_u64(a, "device", device);
+    // --gpus N / -j N: N workers as for illuminaPE -- for a plain input file and an output file (a stream or a compressed input has one reader: one worker then)
+    if (ok && (a.has("gpus") || a.has("threads"))) {
+        uint64_t asked = 0;
+        ok = parse_u64(a, a.has("gpus") ? "gpus" : "threads", asked);
+        const int n_devices = ok ? rsq_device_count() : 1;
+        if (ok && n_devices < 1) ok = check(n_devices, "No device");
+        if (ok && a.has("gpus") && (asked < 1 || asked > 1024)) {
+            ERR("gpus must be between 1 and 1024.");
+            ok = false;
+        }
+        const int n_workers = !ok ? 1 : a.has("gpus") ? (int)asked : (int)std::min<uint64_t>(std::max<uint64_t>(asked, 1), (uint64_t)n_devices);
+        const std::string input = a.get("input", ""), output = a.get("output", "");
+        const bool plain_files = !input.empty() && !output.empty() && !rsq::textio::has_suffix(input, ".gz") && !rsq::textio::has_suffix(input, ".bz2") &&
+                                 !rsq::textio::has_suffix(output, ".bz2") && !a.has("inputFrom") && !a.has("inputTo");
+        if (ok && n_workers > 1 && !plain_files) WARN("--gpus / -j: several workers need a plain input file and an output file (not .bz2); one worker runs");
+        if (ok && n_workers > 1 && plain_files) {
+            rsq_error_model_file_options base;
+            memset(&base, 0, sizeof base);
+            for (const char *name : {"readThreads", "parseThreads"})
+                if (a.has(name)) base.read_threads = (uint32_t)std::max(1, atoi(a.get(name).c_str()));
+            if (a.has("blockKB")) base.block_kb = (uint32_t)std::max(1, atoi(a.get("blockKB").c_str()));
+            if (a.has("batchBlocks")) base.batch_blocks = (uint32_t)std::max(1, atoi(a.get("batchBlocks").c_str()));
+            const int rc = seq_to_illumina_on_workers(a, prof, seed, n_workers, n_devices, input, output, base);
+            rsq_profile_free(prof);
+            return rc;
+        }
+    }
     ok = ok && check(rsq_sim_create(prof, nullptr, (int)device, &sim), "Could not set up the simulator") &&
          check(rsq_sim_prepare(sim, seed, 0, 0.0, 0, "", nullptr), "Preparation failed");
     const double at_prepared = seconds_since(g_process_start);
@@ -782,7 +934,7 @@ const char *kUsage =
     "                 \t--gpus N: N workers in this process, worker r on device r % devices, the files byte for byte the single-device run's; --device D: the one worker's device\n"
     "Outputs named *.gz are compressed on the GPU (gzip members framed as BGZF blocks; about 15 % larger than zlib level 1, 33 % larger than level 6);\n"
     "         --hostGzip compresses them with zlib on host threads instead (smaller files, a fraction of the speed).\n"
-    "General: -j/--threads N (illuminaPE: as many workers as asked for, at most one per device; else ignored: the GPU does the work),\n"
+    "General: -j/--threads N (illuminaPE, seqToIllumina: as many workers as asked for, at most one per device; --gpus N: exactly N),\n"
     "         --verbosity 0-4, --version, -h, --traceStages,\n"
     "         --rsqOption name:value[,...] (measurement switches of libreseq_amd, include/reseq_amd.h rsq_set_option; results never depend on them)\n";
 

@@ -517,3 +517,67 @@ def test_reseq_illumina_pe_on_several_workers_in_one_process(job):
     assert r.returncode != 0 and "bzip2 output is written by one worker only" in r.stderr
     r, out = _cli_pe(job, "workers2_bad_meth", ["--gpus", 2, "--methylation", job["work"] / "no_such_file.bed"], check=False)
     assert r.returncode != 0 and "worker" in r.stderr and not any(os.path.exists(o) for o in out)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_reseq_seq_to_illumina_on_several_workers_in_one_process(job):
+    """`reseq seqToIllumina --gpus N` (Simulator::SimulateErrorModelOnly's worker threads, Simulator.cpp:2900-3014 with -j): the plain input cut into the workers'
+    stretches, a record belonging to the worker in whose stretch it begins, every worker's text kept on its device and written at its offset -- the single worker's
+    file byte for byte with 2, 3 and 8 workers (records wrapped over lines, so that stretches end inside records), as .gz, with more workers than records; a
+    malformed record ends the command with the reference's words and leaves no output; a stream or a compressed input runs with one worker"""
+    if _devices() < 1:
+        pytest.skip("no device")
+    n = 20000
+    arrays = synth.make_profile(synth.TINY, seed=5)
+    rec = synth.make_error_model_input(9, n, 30, arrays, zero_frac=0.7)
+    r = rec["rate"].astype(np.int64)
+    rec["rate"] = np.where(r > 86, r - r % 2, r).astype(np.uint8)
+    ids = [f"read {i}/x" if i % 7 == 0 else f"r{i}" for i in range(n)]
+    fa = job["work"] / "cli_workers_records.fa"
+    fa.write_bytes(P.fasta_of_records(rec, ids, wrap_every=3))
+
+    def run(out, *extra, inp=fa, check=True):
+        r = subprocess.run([str(RESEQ), "seqToIllumina", "-i", str(inp), "-o", str(out), "-s", job["profile"], "--seed", "13", *map(str, extra)], capture_output=True, text=True,
+                           timeout=900, env=_env(job["work"]), cwd=str(ROOT))
+        if check:
+            assert r.returncode == 0, r.stderr[-4000:]
+        return r
+    one = job["work"] / "cli_workers_records_one.fq"
+    run(one)
+    want = one.read_bytes()
+    assert want.count(b"\n") == 4 * n and want.startswith(b"@read 0/x ")
+    for workers in (2, 3, 8):
+        out = job["work"] / f"cli_workers_records_{workers}.fq"
+        r = run(out, "--gpus", workers)
+        assert f"Simulating with {workers} workers" in r.stderr and f"Generated {n} reads." in r.stderr
+        assert out.read_bytes() == want, workers
+    gz = job["work"] / "cli_workers_records_3.fq.gz"
+    run(gz, "--gpus", 3)
+    assert gzip.decompress(gz.read_bytes()) == want and gz.read_bytes().endswith(api.gzip_eof_member())
+    run(gz, "--gpus", 2, "--hostGzip")
+    assert gzip.decompress(gz.read_bytes()) == want
+    # more workers than records; an input without records
+    few = job["work"] / "cli_workers_few.fa"
+    few.write_bytes(P.fasta_of_records({k: v[:3] for k, v in rec.items()}, ids[:3], wrap_every=3))
+    run(job["work"] / "cli_workers_few_1.fq", inp=few)
+    run(job["work"] / "cli_workers_few_8.fq", "--gpus", 8, inp=few)
+    assert (job["work"] / "cli_workers_few_8.fq").read_bytes() == (job["work"] / "cli_workers_few_1.fq").read_bytes()
+    empty = job["work"] / "cli_workers_empty.fa"
+    empty.write_bytes(b"")
+    r = run(job["work"] / "cli_workers_empty.fq", "--gpus", 2, inp=empty, check=False)
+    assert r.returncode != 0 and "does not contain any sequences." in r.stderr and not (job["work"] / "cli_workers_empty.fq").exists()
+    # a malformed record in one worker's share
+    text = fa.read_bytes()
+    cut = text.index(b">", len(text) * 3 // 4)
+    end = text.index(b"\n", cut)
+    fields = text[cut:end].rsplit(b" ", 1)
+    bad = job["work"] / "cli_workers_bad.fa"
+    bad.write_bytes(text[:cut] + fields[0] + b" 3" + fields[1][1:] + text[end:])
+    r = run(job["work"] / "cli_workers_bad.fq", "--gpus", 4, inp=bad, check=False)
+    assert r.returncode != 0 and "Template segment is 3 not 1 or 2" in r.stderr and not (job["work"] / "cli_workers_bad.fq").exists()
+    # a compressed input has one reader: one worker, said so
+    packed = job["work"] / "cli_workers_records.fa.gz"
+    packed.write_bytes(gzip.compress(text))
+    r = run(job["work"] / "cli_workers_from_gz.fq", "--gpus", 2, inp=packed)
+    assert "one worker runs" in r.stderr and (job["work"] / "cli_workers_from_gz.fq").read_bytes() == want
