@@ -246,7 +246,8 @@ typedef struct {
  * host thread with its own simulator and device inside `reseq illuminaPE --gpus N`, or a process of the launcher -- owns a contiguous range, so that the workers'
  * texts in worker order are the single run's.  rsq_sim_block_weights: expected pairs per block up to a constant (the sequence's reference bias), weights[*n_blocks]
  * in block order (NULL: only the count), after rsq_sim_prepare.  rsq_partition_blocks: bounds[workers + 1], worker r gets blocks [bounds[r], bounds[r + 1]) of
- * 1 .. total_blocks, balanced by the weights; a worker may get an empty range. */
+ * 1 .. total_blocks, balanced by the weights; a worker may get an empty range.  (rsq_sim_block_weights also after rsq_sim_prepare_plan: the sharded pre-pass needs
+ * the ranges before it runs.) */
 int rsq_sim_block_weights(const rsq_sim *s, double *weights, size_t cap, uint32_t *n_blocks);
 int rsq_partition_blocks(uint32_t total_blocks, uint32_t workers, const double *weights, uint32_t *bounds);
 

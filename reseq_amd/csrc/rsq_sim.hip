@@ -1216,7 +1216,7 @@ int rsq_partition_blocks(uint32_t total_blocks, uint32_t workers, const double *
     return RSQ_OK;
 }
 int rsq_sim_block_weights(const rsq_sim *s, double *weights, size_t cap, uint32_t *n_blocks) {
-    REQUIRE(s && n_blocks && s->prepared && s->has_ref, "a prepared simulator with a reference");
+    REQUIRE(s && n_blocks && (s->prepared || s->planned) && s->has_ref, "a simulator with a reference after rsq_sim_prepare or rsq_sim_prepare_plan");
     *n_blocks = s->total_blocks;
     if (!weights) return RSQ_OK;
     if (cap < s->total_blocks) {
