@@ -955,7 +955,6 @@ inline uint32_t piece_on_the_host_t(const uint8_t *text, uint32_t n, const Codes
         if (overflow) continue;
         for (uint32_t t = 0; t < kThreads; ++t) {
             BitSink<const uint32_t *, Or> sink{codes->litlen, codes->dist, Or{data.data() + (bit >> 5)}, (uint32_t)(bit & 31u)};
-            const uint32_t lo = round_lo + t * kSeg;
             walk_segment(segs[t], seg_n[t], sink);
             bit += seg_bits[t];
         }
