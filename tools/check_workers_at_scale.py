@@ -3,7 +3,10 @@
 thousands of bases; here the workers' shares hold hundreds of sequences and a hundred thousand variants, the pre-passes are shared among the workers' threads and the
 text of every worker is gigabytes.  One device serves all workers when there is only one (which checks the path, not the speed).
 
-    python tools/check_workers_at_scale.py [drosophila|human] [scale] [workers] [--gz]
+    python tools/check_workers_at_scale.py [drosophila|human] [scale] [workers] [--gz] [--launcher]
+
+--launcher: the N workers are N PROCESSES under torch.distributed.run (python -m reseq_amd.simulate --backend gloo --shareDevice when the box has fewer devices than
+ranks, RCCL else) instead of threads of the binary: one load per host through /dev/shm, sharded pre-passes over gloo / RCCL, N writers into one file.
 """
 import hashlib
 import json
@@ -21,6 +24,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "drosophila"
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
 workers = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 gz = "--gz" in sys.argv
+launcher = "--launcher" in sys.argv
 tmp = tempfile.mkdtemp(prefix="rsq_workers_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 ppath = os.path.join(tmp, "p0.rsqp")
 extra = []
@@ -49,11 +53,22 @@ def sha(path):
     return h.hexdigest()
 
 
-out = {"config": f"{which}-sized at scale {scale}: {sum(lengths)} bp in {len(lengths)} sequences, P0, coverage 30" + (", variants + methylation" if extra else "") + (", .gz" if gz else ""), "runs": {}}
+out = {"workers_are": "processes under torch.distributed.run (reseq_amd.simulate)" if launcher else "threads of the reseq binary (--gpus N)", "config": f"{which}-sized at scale {scale}: {sum(lengths)} bp in {len(lengths)} sequences, P0, coverage 30" + (", variants + methylation" if extra else "") + (", .gz" if gz else ""), "runs": {}}
 for n in (1, workers):
     r1, r2 = (os.path.join(tmp, f"w{n}_{k}{ext}") for k in (1, 2))
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "illuminaPE", "-R", fasta, "-s", ppath, "-1", r1, "-2", r2, "--coverage", "30", "--seed", "7", *extra, "--gpus", str(n)], capture_output=True, text=True)
+    common = ["-R", fasta, "-s", ppath, "-1", r1, "-2", r2, "--coverage", "30", "--seed", "7", *extra]
+    if launcher and n > 1:
+        import socket
+        from reseq_amd import api
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        share = ["--backend", "gloo", "--shareDevice"] if api.device_count() < n else []
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "reseq_amd.simulate", *common, *share]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    else:
+        r = subprocess.run([exe, "illuminaPE", *common, "--gpus", str(n)], capture_output=True, text=True)
     wall = time.perf_counter() - t0
     if r.returncode:
         raise SystemExit(r.stderr[-3000:])
